@@ -1,0 +1,439 @@
+// gjx_device.hpp — gfx950 device-side building blocks: counter-based RNG, the bit-exact f32 math
+// specification, samplers / log-densities, and 64-wide wavefront reductions/scans.
+//
+// Everything numeric here uses only IEEE-exact primitives (+ - * fma / sqrt rint, integer ops)
+// in a fixed order; the translation unit is compiled with -ffp-contract=off so nothing is
+// re-associated or fused behind our back.  That is what makes ancestor indices and log-weights
+// bit-identical to the CPU oracle on identical counters.
+//
+// Reference call sites this arithmetic replaces (relative to /root/reference/src/genjax/_src):
+//   jax.random.split/fold_in ........ inference/smc.py:299-300, generative_functions/static.py:349-352
+//   tfd.X(...).sample / .log_prob ... generative_functions/distributions/tensorflow_probability/__init__.py:52-62
+//   logsumexp ....................... inference/smc.py:97,107
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GJX_DEV __device__ __forceinline__
+#define GJX_HD __host__ __device__ __forceinline__
+
+namespace gjx {
+
+constexpr int kWave = 64;         // CDNA wavefront
+constexpr int kBlock = 256;       // threads per workgroup (4 waves, one per SIMD)
+constexpr int kTile = 1024;       // particles per workgroup tile (4 per thread)
+constexpr int kCatFrac = 23;      // fixed-point bits of per-row categorical CDFs
+
+GJX_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+GJX_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// ------------------------------------------------------------------------------------------------
+// Ciphers (Salmon et al., SC'11).  Threefry2x32-20 is jax.random's default; Philox4x32-10 is the
+// native scheme named by the north star.
+// ------------------------------------------------------------------------------------------------
+GJX_HD uint32_t rotl32(uint32_t x, uint32_t r) { return (x << r) | (x >> (32u - r)); }
+
+GJX_HD void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0,
+                         uint32_t& o1) {
+  const uint32_t k2 = 0x1BD11BDAu ^ k0 ^ k1;
+  uint32_t x0 = c0 + k0, x1 = c1 + k1;
+#define GJX_TF_R(r) x0 += x1; x1 = rotl32(x1, r); x1 ^= x0;
+  GJX_TF_R(13) GJX_TF_R(15) GJX_TF_R(26) GJX_TF_R(6)
+  x0 += k1; x1 += k2 + 1u;
+  GJX_TF_R(17) GJX_TF_R(29) GJX_TF_R(16) GJX_TF_R(24)
+  x0 += k2; x1 += k0 + 2u;
+  GJX_TF_R(13) GJX_TF_R(15) GJX_TF_R(26) GJX_TF_R(6)
+  x0 += k0; x1 += k1 + 3u;
+  GJX_TF_R(17) GJX_TF_R(29) GJX_TF_R(16) GJX_TF_R(24)
+  x0 += k1; x1 += k2 + 4u;
+  GJX_TF_R(13) GJX_TF_R(15) GJX_TF_R(26) GJX_TF_R(6)
+  x0 += k2; x1 += k0 + 5u;
+#undef GJX_TF_R
+  o0 = x0;
+  o1 = x1;
+}
+
+GJX_HD void philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
+                       uint32_t c3, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;  // v_mad_u64_u32: hi and lo in one op
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
+constexpr uint32_t kTagSplit = 0x53504C54u;  // "SPLT"
+constexpr uint32_t kTagFold = 0x464F4C44u;   // "FOLD"
+constexpr uint32_t kTagBits = 0x42495453u;   // "BITS"
+
+struct Key {
+  uint32_t k0, k1;
+};
+
+// split(parent, *)[i]
+template <int IMPL>
+GJX_HD Key split_at(Key parent, uint64_t i) {
+  Key out;
+  if (IMPL == 0) {
+    threefry2x32(parent.k0, parent.k1, (uint32_t)(i >> 32), (uint32_t)i, out.k0, out.k1);
+  } else {
+    uint32_t o2, o3;
+    philox4x32(parent.k0, parent.k1, (uint32_t)i, (uint32_t)(i >> 32), 0u, kTagSplit, out.k0,
+               out.k1, o2, o3);
+  }
+  return out;
+}
+template <int IMPL>
+GJX_HD Key fold_in(Key k, uint32_t d) {
+  Key out;
+  if (IMPL == 0) {
+    threefry2x32(k.k0, k.k1, 0u, d, out.k0, out.k1);
+  } else {
+    uint32_t o2, o3;
+    philox4x32(k.k0, k.k1, d, 0u, 0u, kTagFold, out.k0, out.k1, o2, o3);
+  }
+  return out;
+}
+
+// A draw stream: key plus optional leaf-site counter.  THREEFRY folds the counter into the key
+// (one block, jax semantics); PHILOX carries it in the 128-bit counter (no extra block).
+template <int IMPL>
+struct Stream {
+  Key k;
+  uint32_t f, hf;
+  GJX_HD Stream(Key key, bool has_fold, uint32_t fold) {
+    if (IMPL == 0) {
+      k = has_fold ? fold_in<0>(key, fold) : key;
+      f = 0u;
+      hf = 0u;
+    } else {
+      k = key;
+      f = has_fold ? fold : 0u;
+      hf = has_fold ? 1u : 0u;
+    }
+  }
+  GJX_HD void words(uint32_t sub, uint32_t& w0, uint32_t& w1) const {
+    if (IMPL == 0) {
+      threefry2x32(k.k0, k.k1, 0u, sub, w0, w1);
+    } else {
+      uint32_t o2, o3;
+      philox4x32(k.k0, k.k1, sub, f, hf, kTagBits, w0, w1, o2, o3);
+    }
+  }
+  GJX_HD uint32_t bits32(uint32_t sub) const {
+    uint32_t w0, w1;
+    words(sub, w0, w1);
+    return IMPL == 0 ? (w0 ^ w1) : w0;
+  }
+  GJX_HD uint64_t bits64(uint32_t sub) const {
+    uint32_t w0, w1;
+    words(sub, w0, w1);
+    return ((uint64_t)w0 << 32) | w1;
+  }
+};
+
+// Host-visible description of a key batch (mirrors gjx_keys).
+struct KeySrc {
+  const uint32_t* keys;  // mode 0
+  Key parent;            // mode 1
+  uint64_t first;
+  int mode;
+  int has_fold;
+  uint32_t fold;
+};
+template <int IMPL>
+GJX_DEV Key key_at(const KeySrc& s, uint64_t i) {
+  if (s.mode == 0) {
+    const uint2 v = reinterpret_cast<const uint2*>(s.keys)[i];
+    return Key{v.x, v.y};
+  }
+  if (s.mode == 2) return s.parent;
+  return split_at<IMPL>(s.parent, s.first + i);
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 math spec.  Cephes logf/expf coefficients; Giles' single-precision erfinv.
+// ------------------------------------------------------------------------------------------------
+GJX_HD float m_log(float x) {
+  uint32_t ix = f2u(x);
+  int32_t e = 0;
+  if (ix == 0u) return -__builtin_inff();
+  if (ix < 0x00800000u) {
+    x = x * 8388608.0f;
+    ix = f2u(x);
+    e = -23;
+  }
+  const uint32_t t = ix - 0x3f3504f3u;
+  e += (int32_t)t >> 23;
+  const float m = u2f((t & 0x007fffffu) + 0x3f3504f3u);
+  const float f = m - 1.0f;
+  const float z = f * f;
+  float p = 7.0376836292E-2f;
+  p = __builtin_fmaf(p, f, -1.1514610310E-1f);
+  p = __builtin_fmaf(p, f, 1.1676998740E-1f);
+  p = __builtin_fmaf(p, f, -1.2420140846E-1f);
+  p = __builtin_fmaf(p, f, 1.4249322787E-1f);
+  p = __builtin_fmaf(p, f, -1.6668057665E-1f);
+  p = __builtin_fmaf(p, f, 2.0000714765E-1f);
+  p = __builtin_fmaf(p, f, -2.4999993993E-1f);
+  p = __builtin_fmaf(p, f, 3.3333331174E-1f);
+  float y = (p * f) * z;
+  const float fe = (float)e;
+  y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+  y = __builtin_fmaf(-0.5f, z, y);
+  float r = f + y;
+  r = __builtin_fmaf(fe, 0.693359375f, r);
+  return r;
+}
+
+GJX_HD float m_exp(float x) {
+  if (!(x >= -86.0f)) return 0.0f;
+  if (x > 88.0f) x = 88.0f;
+  const float fx = __builtin_rintf(x * 1.44269504088896341f);
+  x = __builtin_fmaf(fx, -0.693359375f, x);
+  x = __builtin_fmaf(fx, 2.12194440e-4f, x);
+  const float z = x * x;
+  float p = 1.9875691500E-4f;
+  p = __builtin_fmaf(p, x, 1.3981999507E-3f);
+  p = __builtin_fmaf(p, x, 8.3334519073E-3f);
+  p = __builtin_fmaf(p, x, 4.1665795894E-2f);
+  p = __builtin_fmaf(p, x, 1.6666665459E-1f);
+  p = __builtin_fmaf(p, x, 5.0000001201E-1f);
+  const float y = __builtin_fmaf(p, z, x) + 1.0f;
+  const int32_t n = (int32_t)fx;
+  return u2f(f2u(y) + ((uint32_t)n << 23));
+}
+
+GJX_HD float m_erfinv(float x) {
+  float w = -m_log((1.0f - x) * (1.0f + x));
+  float p;
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f;
+    p = __builtin_fmaf(p, w, 3.43273939e-07f);
+    p = __builtin_fmaf(p, w, -3.5233877e-06f);
+    p = __builtin_fmaf(p, w, -4.39150654e-06f);
+    p = __builtin_fmaf(p, w, 0.00021858087f);
+    p = __builtin_fmaf(p, w, -0.00125372503f);
+    p = __builtin_fmaf(p, w, -0.00417768164f);
+    p = __builtin_fmaf(p, w, 0.246640727f);
+    p = __builtin_fmaf(p, w, 1.50140941f);
+  } else {
+    w = __builtin_sqrtf(w) - 3.0f;
+    p = -0.000200214257f;
+    p = __builtin_fmaf(p, w, 0.000100950558f);
+    p = __builtin_fmaf(p, w, 0.00134934322f);
+    p = __builtin_fmaf(p, w, -0.00367342844f);
+    p = __builtin_fmaf(p, w, 0.00573950773f);
+    p = __builtin_fmaf(p, w, -0.0076224613f);
+    p = __builtin_fmaf(p, w, 0.00943887047f);
+    p = __builtin_fmaf(p, w, 1.00167406f);
+    p = __builtin_fmaf(p, w, 2.83297682f);
+  }
+  return p * x;
+}
+
+GJX_HD float m_lgamma(float x) {
+  float p = 1.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (x < 8.0f) {
+      p = p * x;
+      x = x + 1.0f;
+    }
+  }
+  const float xi = 1.0f / x;
+  const float xi2 = xi * xi;
+  float s = __builtin_fmaf(xi2, 7.9365079365e-4f, -2.7777777778e-3f);
+  s = __builtin_fmaf(s, xi2, 8.3333333333e-2f);
+  s = s * xi;
+  float r = (x - 0.5f) * m_log(x);
+  r = r - x;
+  r = r + 0.91893853320467f;
+  r = r + s;
+  r = r - m_log(p);
+  return r;
+}
+
+GJX_HD float uniform01(uint32_t bits) { return u2f((bits >> 9) | 0x3F800000u) - 1.0f; }
+
+GJX_HD float std_normal(uint32_t bits) {
+  const float lo = -0.99999994f;
+  float u = uniform01(bits) * 2.0f + lo;
+  u = u > lo ? u : lo;
+  return 1.41421356237309505f * m_erfinv(u);
+}
+
+// --- log-densities (TFP formulas).  The *_pre forms take the per-site constants a plan hoists.
+GJX_HD float normal_rs(float scale) { return 1.0f / scale; }
+GJX_HD float normal_lognorm(float scale) { return 0.91893853320467f + m_log(scale); }
+GJX_HD float logpdf_normal_pre(float x, float loc, float rs, float lognorm) {
+  const float d = x * rs - loc * rs;
+  return (-0.5f * d) * d - lognorm;
+}
+GJX_HD float logpdf_normal(float x, float loc, float scale) {
+  return logpdf_normal_pre(x, loc, normal_rs(scale), normal_lognorm(scale));
+}
+GJX_HD float xlogy(float a, float y) { return a == 0.0f ? 0.0f : a * m_log(y); }
+GJX_HD float gamma_lognorm(float conc, float rate) { return m_lgamma(conc) - conc * m_log(rate); }
+GJX_HD float logpdf_gamma_pre(float x, float conc, float rate, float lognorm) {
+  return (xlogy(conc - 1.0f, x) - rate * x) - lognorm;
+}
+GJX_HD float logpdf_gamma(float x, float conc, float rate) {
+  return logpdf_gamma_pre(x, conc, rate, gamma_lognorm(conc, rate));
+}
+GJX_HD float beta_lbeta(float a, float b) { return (m_lgamma(a) + m_lgamma(b)) - m_lgamma(a + b); }
+GJX_HD float logpdf_beta_pre(float x, float a, float b, float lbeta) {
+  return (xlogy(a - 1.0f, x) + xlogy(b - 1.0f, 1.0f - x)) - lbeta;
+}
+GJX_HD float logpdf_beta(float x, float a, float b) {
+  return logpdf_beta_pre(x, a, b, beta_lbeta(a, b));
+}
+GJX_HD float logpdf_bernoulli(bool e, float p) { return e ? m_log(p) : m_log(1.0f - p); }
+
+// --- Marsaglia-Tsang Gamma(conc, 1).  Attempt a of gamma `which` uses sub-stream 1 + 2a + which
+// (w0 -> normal, w1 -> uniform); the conc<1 boost uniform is word `which` of sub-stream 0.
+template <int IMPL>
+GJX_DEV float std_gamma(const Stream<IMPL>& st, int which, float conc) {
+  const bool boost = conc < 1.0f;
+  const float a = boost ? conc + 1.0f : conc;
+  const float d = a - 0.33333334f;
+  const float c = 1.0f / __builtin_sqrtf(9.0f * d);
+  float v = 1.0f;
+  for (int att = 0; att < 64; ++att) {
+    uint32_t w0, w1;
+    st.words((uint32_t)(1 + 2 * att + which), w0, w1);
+    const float x = std_normal(w0);
+    const float t = 1.0f + c * x;
+    if (t <= 0.0f) continue;
+    v = (t * t) * t;
+    const float u = uniform01(w1);
+    float rhs = (0.5f * x) * x + d;
+    rhs = rhs - d * v;
+    rhs = rhs + d * m_log(v);
+    if (m_log(u) < rhs) break;
+  }
+  float g = d * v;
+  if (boost) {
+    uint32_t w0, w1;
+    st.words(0u, w0, w1);
+    const float ub = uniform01(which ? w1 : w0);
+    g = g * m_exp(m_log(ub) / conc);
+  }
+  return g;
+}
+
+// --- fixed-point weights: q = rint(exp(lw - m) * 2^frac) as u64 (exact, order-independent sums).
+GJX_HD uint64_t fixw(float lw, float m, int frac) {
+  if (lw == m) return (uint64_t)1 << frac;
+  const float d = lw - m;
+  if (!(d >= -80.0f)) return 0;
+  const float s = m_exp(d);
+  const float t = s * u2f((uint32_t)(127 + frac) << 23);
+  return (uint64_t)__builtin_rintf(t);
+}
+GJX_HD uint32_t cat_fix(float l, float m) {
+  if (l == m) return 1u << kCatFrac;
+  const float d = l - m;
+  if (!(d >= -80.0f)) return 0u;
+  return (uint32_t)__builtin_rintf(m_exp(d) * 8388608.0f);
+}
+GJX_HD int frac_bits(uint64_t n_total) {
+  int lg = 0;
+  while (lg < 63 && ((uint64_t)1 << lg) < n_total) ++lg;
+  const int f = 62 - lg;
+  return f > 40 ? 40 : (f < 8 ? 8 : f);
+}
+GJX_HD float gumbel_from_bits(uint32_t bits) {
+  const float tiny = 1.17549435e-38f;
+  float u = uniform01(bits) + tiny;
+  u = u > tiny ? u : tiny;
+  return -m_log(-m_log(u));
+}
+
+// Systematic comb: number of teeth (j + u0), j in [0, n_out), strictly below mass C * scale.
+GJX_HD int64_t teeth_below(uint64_t C, double scale, double u0, int64_t n_out) {
+  const double P = (double)C * scale;
+  const double c = __builtin_ceil(P - u0);
+  if (!(c > 0.0)) return 0;
+  if (c >= (double)n_out) return n_out;
+  return (int64_t)c;
+}
+GJX_HD double u0_from_bits(uint64_t U) { return (double)(U >> 11) * 0x1.0p-53; }
+
+// ------------------------------------------------------------------------------------------------
+// 64-wide wavefront / 256-thread workgroup reductions and scans (LDS-staged across the 4 waves).
+// ------------------------------------------------------------------------------------------------
+GJX_DEV float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(v, off, kWave);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+GJX_DEV uint64_t wave_sum(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, off, kWave);
+  return v;
+}
+// Block-wide max; result valid in every thread.  `sh` needs 4 floats.
+GJX_DEV float block_max(float v, float* sh) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float r = sh[0];
+#pragma unroll
+  for (int i = 1; i < kBlock / kWave; ++i) r = sh[i] > r ? sh[i] : r;
+  return r;
+}
+GJX_DEV uint64_t block_sum(uint64_t v, uint64_t* sh) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  uint64_t r = 0;
+#pragma unroll
+  for (int i = 0; i < kBlock / kWave; ++i) r += sh[i];
+  return r;
+}
+// Inclusive wave scan of u64.
+GJX_DEV uint64_t wave_scan_incl(uint64_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const uint64_t o = (uint64_t)__shfl_up((unsigned long long)v, off, kWave);
+    if (lane >= off) v += o;
+  }
+  return v;
+}
+// Exclusive block scan of one u64 per thread; returns the exclusive prefix, total in `total`.
+GJX_DEV uint64_t block_scan_excl(uint64_t v, uint64_t* sh, uint64_t& total) {
+  const uint64_t incl = wave_scan_incl(v);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 63) sh[w] = incl;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kBlock / kWave; ++i) {
+    if (i < w) base += sh[i];
+    tot += sh[i];
+  }
+  total = tot;
+  return base + incl - v;
+}
+
+}  // namespace gjx

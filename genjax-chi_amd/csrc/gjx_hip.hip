@@ -1,0 +1,1470 @@
+// gjx_hip.hip — libgjx_hip.so: hand-written gfx950 kernels behind the C-ABI of include/gjx.h.
+//
+// Layout in HBM: a trace is a flat struct-of-arrays buffer — one 4-byte column per `@` site with
+// the particle axis contiguous, plus score[n] and logw[n].  Workgroups are 256 threads (one wave
+// per SIMD) and own a tile of 1024 consecutive particles, so every global access is a full
+// 256-B-per-wave coalesced row.  Reductions are staged wave -> LDS -> per-tile partials; weight
+// sums are exact u64 fixed-point, so any reduction order (and any number of GPUs) gives the same
+// bits.  No entry point allocates, frees or synchronises (graph-capturable), except plan
+// create/destroy.
+#include "../../include/gjx.h"
+#include "gjx_device.hpp"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <new>
+#include <string.h>
+
+using namespace gjx;
+
+namespace {
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? GJX_OK : GJX_ERR_LAUNCH; }
+inline hipStream_t S(gjx_stream s) { return reinterpret_cast<hipStream_t>(s); }
+inline uint64_t ntiles_of(uint64_t n) { return (n + kTile - 1) / kTile; }
+inline unsigned grid_for(uint64_t n) {
+  uint64_t b = ntiles_of(n);
+  return (unsigned)(b < 1 ? 1 : (b > 0x7fffffffull ? 0x7fffffffull : b));
+}
+
+bool keys_ok(const gjx_keys* k) {
+  if (!k) return false;
+  if (k->impl != 0 && k->impl != 1) return false;
+  if (k->mode == 0) return k->keys != nullptr;
+  return k->mode == 1 || k->mode == 2;
+}
+KeySrc key_src(const gjx_keys* k) {
+  KeySrc s;
+  s.keys = k->keys;
+  s.parent = Key{k->parent[0], k->parent[1]};
+  s.first = k->first;
+  s.mode = k->mode;
+  s.has_fold = k->has_fold;
+  s.fold = k->fold;
+  return s;
+}
+
+struct Opnd {
+  const float* p;
+  float s;
+  GJX_DEV float at(uint64_t i) const { return p ? p[i] : s; }
+};
+inline Opnd opnd(gjx_f32 a) { return Opnd{a.ptr, a.scalar}; }
+
+// Every elementwise kernel walks its tile as 4 rows of 256 lanes: i = tile*1024 + r*256 + tid.
+#define GJX_TILE_LOOP(i, n)                                                              \
+  for (uint64_t tile_ = blockIdx.x; tile_ * kTile < (n); tile_ += gridDim.x)             \
+    for (uint64_t i = tile_ * kTile + threadIdx.x; i < (n) && i < (tile_ + 1) * kTile;  \
+         i += kBlock)
+
+// ------------------------------------------------------------------------------------------------
+// RNG kernels
+// ------------------------------------------------------------------------------------------------
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_rng_keys(KeySrc ks, uint64_t n, uint32_t* out) {
+  GJX_TILE_LOOP(i, n) {
+    Key k = key_at<IMPL>(ks, i);
+    if (ks.has_fold) k = fold_in<IMPL>(k, ks.fold);
+    reinterpret_cast<uint2*>(out)[i] = make_uint2(k.k0, k.k1);
+  }
+}
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_rng_bits(KeySrc ks, uint32_t sub, uint64_t n,
+                                                     uint32_t* out) {
+  GJX_TILE_LOOP(i, n) {
+    const Stream<IMPL> st(key_at<IMPL>(ks, i), ks.has_fold != 0, ks.fold);
+    out[i] = st.bits32(sub);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Categorical rows (small K, evaluated on the fly: sequential in k exactly as the spec states)
+// ------------------------------------------------------------------------------------------------
+GJX_DEV float row_max(const float* l, uint32_t K) {
+  float m = l[0];
+  for (uint32_t c = 1; c < K; ++c) m = l[c] > m ? l[c] : m;
+  return m;
+}
+GJX_DEV float row_lse(const float* l, uint32_t K) {
+  const float m = row_max(l, K);
+  float acc = 0.0f;
+  for (uint32_t c = 0; c < K; ++c) acc = acc + m_exp(l[c] - m);
+  return m + m_log(acc);
+}
+GJX_DEV int32_t cat_invcdf(const float* l, uint32_t K, uint32_t bits) {
+  const float m = row_max(l, K);
+  uint64_t Q = 0;
+  for (uint32_t c = 0; c < K; ++c) Q += cat_fix(l[c], m);
+  const uint64_t thr = ((uint64_t)bits * Q) >> 32;
+  uint64_t C = 0;
+  for (uint32_t c = 0; c < K; ++c) {
+    C += cat_fix(l[c], m);
+    if (C > thr) return (int32_t)c;
+  }
+  return (int32_t)(K - 1);
+}
+template <int IMPL>
+GJX_DEV int32_t cat_gumbel(const float* l, uint32_t K, const Stream<IMPL>& st) {
+  int32_t best = 0;
+  float bv = -__builtin_inff();
+  for (uint32_t c = 0; c < K; ++c) {
+    const float v = l[c] + gumbel_from_bits(st.bits32(c));
+    if (v > bv || c == 0) {
+      bv = v;
+      best = (int32_t)c;
+    }
+  }
+  return best;
+}
+GJX_DEV const float* cat_row(const float* logits, uint64_t n_rows, uint32_t K,
+                             const int32_t* row_index, uint64_t i) {
+  const uint64_t r = row_index ? (uint64_t)row_index[i] : (n_rows == 1 ? 0 : i);
+  return logits + r * K;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Elementwise fused sample + log-density
+// ------------------------------------------------------------------------------------------------
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_sample_normal(KeySrc ks, Opnd loc, Opnd scale,
+                                                          float* val, float* score, uint64_t n) {
+  GJX_TILE_LOOP(i, n) {
+    const Stream<IMPL> st(key_at<IMPL>(ks, i), ks.has_fold != 0, ks.fold);
+    const float mu = loc.at(i), sg = scale.at(i);
+    const float eps = std_normal(st.bits32(0));
+    const float t = sg * eps;
+    const float v = mu + t;
+    val[i] = v;
+    if (score) score[i] = logpdf_normal(v, mu, sg);
+  }
+}
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_sample_gamma(KeySrc ks, Opnd conc, Opnd rate,
+                                                         float* val, float* score, uint64_t n) {
+  GJX_TILE_LOOP(i, n) {
+    const Stream<IMPL> st(key_at<IMPL>(ks, i), ks.has_fold != 0, ks.fold);
+    const float a = conc.at(i), b = rate.at(i);
+    const float v = std_gamma<IMPL>(st, 0, a) / b;
+    val[i] = v;
+    if (score) score[i] = logpdf_gamma(v, a, b);
+  }
+}
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_sample_beta(KeySrc ks, Opnd a_, Opnd b_, float* val,
+                                                        float* score, uint64_t n) {
+  GJX_TILE_LOOP(i, n) {
+    const Stream<IMPL> st(key_at<IMPL>(ks, i), ks.has_fold != 0, ks.fold);
+    const float a = a_.at(i), b = b_.at(i);
+    const float g1 = std_gamma<IMPL>(st, 0, a);
+    const float g2 = std_gamma<IMPL>(st, 1, b);
+    const float v = g1 / (g1 + g2);
+    val[i] = v;
+    if (score) score[i] = logpdf_beta(v, a, b);
+  }
+}
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_sample_bernoulli(KeySrc ks, Opnd probs, uint8_t* val,
+                                                             float* score, uint64_t n) {
+  GJX_TILE_LOOP(i, n) {
+    const Stream<IMPL> st(key_at<IMPL>(ks, i), ks.has_fold != 0, ks.fold);
+    const float p = probs.at(i);
+    const bool e = uniform01(st.bits32(0)) < p;
+    val[i] = e ? 1 : 0;
+    if (score) score[i] = logpdf_bernoulli(e, p);
+  }
+}
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_sample_categorical(KeySrc ks, const float* logits,
+                                                               uint64_t n_rows, uint32_t K,
+                                                               const int32_t* row_index, int mode,
+                                                               int32_t* val, float* score,
+                                                               uint64_t n) {
+  GJX_TILE_LOOP(i, n) {
+    const Stream<IMPL> st(key_at<IMPL>(ks, i), ks.has_fold != 0, ks.fold);
+    const float* l = cat_row(logits, n_rows, K, row_index, i);
+    const int32_t v = mode == 0 ? cat_gumbel<IMPL>(l, K, st) : cat_invcdf(l, K, st.bits32(0));
+    val[i] = v;
+    if (score) score[i] = l[v] - row_lse(l, K);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_logpdf_normal(Opnd v, Opnd loc, Opnd scale,
+                                                          float* score, uint64_t n) {
+  GJX_TILE_LOOP(i, n) score[i] = logpdf_normal(v.at(i), loc.at(i), scale.at(i));
+}
+__global__ __launch_bounds__(kBlock) void k_logpdf_gamma(Opnd v, Opnd conc, Opnd rate,
+                                                         float* score, uint64_t n) {
+  GJX_TILE_LOOP(i, n) score[i] = logpdf_gamma(v.at(i), conc.at(i), rate.at(i));
+}
+__global__ __launch_bounds__(kBlock) void k_logpdf_beta(Opnd v, Opnd a, Opnd b, float* score,
+                                                        uint64_t n) {
+  GJX_TILE_LOOP(i, n) score[i] = logpdf_beta(v.at(i), a.at(i), b.at(i));
+}
+__global__ __launch_bounds__(kBlock) void k_logpdf_bernoulli(const uint8_t* v, int vs, Opnd probs,
+                                                             float* score, uint64_t n) {
+  GJX_TILE_LOOP(i, n) score[i] = logpdf_bernoulli(v ? v[i] != 0 : vs != 0, probs.at(i));
+}
+__global__ __launch_bounds__(kBlock) void k_logpdf_categorical(const int32_t* v, int vs,
+                                                               const float* logits,
+                                                               uint64_t n_rows, uint32_t K,
+                                                               const int32_t* row_index,
+                                                               float* score, uint64_t n) {
+  GJX_TILE_LOOP(i, n) {
+    const float* l = cat_row(logits, n_rows, K, row_index, i);
+    const int32_t c = v ? v[i] : vs;
+    score[i] = (c < 0 || (uint32_t)c >= K) ? -__builtin_inff() : l[c] - row_lse(l, K);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused static-model importance: the whole `@gen` body per particle in one kernel.
+// The site table lives in device memory and is read through wave-uniform (scalar) loads; site
+// values that later sites may reference are kept in LDS as vals[site][lane] (conflict-free).
+// ------------------------------------------------------------------------------------------------
+struct CArg {
+  int32_t kind, ref;
+  float scale, offset;
+  const float* table;
+};
+struct CSite {
+  int32_t dist, observed, out_col, n_cat, n_rows, cat_mode;
+  CArg a0, a1, obs;
+  const float* logits;
+  int32_t pre;       // 1: pre0/pre1 hold the hoisted per-site constants
+  float pre0, pre1;  // normal: rs, lognorm; gamma: -, lognorm; beta: -, lbeta
+};
+struct RunCols {
+  const float* in[16];
+  void* out[GJX_MAX_SITES];
+};
+
+GJX_DEV float site_f32(const uint32_t* vals, int ref, bool is_int) {
+  const uint32_t raw = vals[ref * kBlock + threadIdx.x];
+  return is_int ? (float)(int32_t)raw : u2f(raw);
+}
+
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__ sites,
+                                                       int n_sites, KeySrc ks, RunCols cols,
+                                                       float* score, float* logw, uint64_t n,
+                                                       float* max_partials) {
+  extern __shared__ uint32_t vals[];  // [n_sites][kBlock]
+  __shared__ float sh_red[kBlock / kWave];
+  // is_int bitmask of sites (bernoulli / categorical values are stored as int32)
+  uint64_t int_mask = 0;
+  for (int q = 0; q < n_sites; ++q)
+    if (sites[q].dist >= GJX_DIST_BERNOULLI) int_mask |= (uint64_t)1 << q;
+
+  for (uint64_t tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
+    float tmax = -__builtin_inff();
+    for (int r = 0; r < kTile / kBlock; ++r) {
+      const uint64_t i = tile * kTile + (uint64_t)r * kBlock + threadIdx.x;
+      if (i < n) {
+        const Key pkey = key_at<IMPL>(ks, i);
+        float w = 0.0f, sc = 0.0f;
+        for (int q = 0; q < n_sites; ++q) {
+          const CSite& st = sites[q];
+          const bool is_int = st.dist >= GJX_DIST_BERNOULLI;
+          float a0 = 0.0f, a1 = 0.0f;
+          const float* row = nullptr;
+          auto eval = [&](const CArg& a) -> float {
+            switch (a.kind) {
+              case GJX_ARG_CONST: return a.offset;
+              case GJX_ARG_SITE: {
+                const float t = a.scale * site_f32(vals, a.ref, (int_mask >> a.ref) & 1);
+                return t + a.offset;
+              }
+              case GJX_ARG_INPUT: {
+                const float t = a.scale * cols.in[a.ref][i];
+                return t + a.offset;
+              }
+              default: {
+                const uint32_t raw = vals[a.ref * kBlock + threadIdx.x];
+                const int32_t idx = ((int_mask >> a.ref) & 1) ? (int32_t)raw
+                                                                : (int32_t)__builtin_rintf(u2f(raw));
+                return a.table[idx];
+              }
+            }
+          };
+          if (st.dist == GJX_DIST_CATEGORICAL) {
+            int32_t rr;
+            if (st.a0.kind == GJX_ARG_SITE) {
+              const uint32_t raw = vals[st.a0.ref * kBlock + threadIdx.x];
+              rr = ((int_mask >> st.a0.ref) & 1) ? (int32_t)raw : (int32_t)__builtin_rintf(u2f(raw));
+            } else if (st.a0.kind == GJX_ARG_CONST) {
+              rr = (int32_t)__builtin_rintf(st.a0.offset);
+            } else {
+              rr = (int32_t)__builtin_rintf(eval(st.a0));
+            }
+            rr = rr < 0 ? 0 : (rr >= st.n_rows ? st.n_rows - 1 : rr);
+            row = st.logits + (size_t)rr * (size_t)st.n_cat;
+          } else {
+            a0 = eval(st.a0);
+            if (st.dist != GJX_DIST_BERNOULLI) a1 = eval(st.a1);
+          }
+          float vf = 0.0f;
+          int32_t vi = 0;
+          if (st.observed) {
+            const float ov = st.obs.kind == GJX_ARG_CONST ? st.obs.offset : cols.in[st.obs.ref][i];
+            if (is_int) vi = (int32_t)__builtin_rintf(ov);
+            else vf = ov;
+          } else {
+            const Stream<IMPL> strm(pkey, true, (uint32_t)(q + 1));
+            switch (st.dist) {
+              case GJX_DIST_NORMAL: {
+                const float t = a1 * std_normal(strm.bits32(0));
+                vf = a0 + t;
+                break;
+              }
+              case GJX_DIST_GAMMA: vf = std_gamma<IMPL>(strm, 0, a0) / a1; break;
+              case GJX_DIST_BETA: {
+                const float g1 = std_gamma<IMPL>(strm, 0, a0);
+                const float g2 = std_gamma<IMPL>(strm, 1, a1);
+                vf = g1 / (g1 + g2);
+                break;
+              }
+              case GJX_DIST_BERNOULLI: vi = uniform01(strm.bits32(0)) < a0 ? 1 : 0; break;
+              default:
+                vi = st.cat_mode == 0 ? cat_gumbel<IMPL>(row, (uint32_t)st.n_cat, strm)
+                                      : cat_invcdf(row, (uint32_t)st.n_cat, strm.bits32(0));
+            }
+          }
+          float lp;
+          switch (st.dist) {
+            case GJX_DIST_NORMAL:
+              lp = st.pre ? logpdf_normal_pre(vf, a0, st.pre0, st.pre1) : logpdf_normal(vf, a0, a1);
+              break;
+            case GJX_DIST_GAMMA:
+              lp = st.pre ? logpdf_gamma_pre(vf, a0, a1, st.pre1) : logpdf_gamma(vf, a0, a1);
+              break;
+            case GJX_DIST_BETA:
+              lp = st.pre ? logpdf_beta_pre(vf, a0, a1, st.pre1) : logpdf_beta(vf, a0, a1);
+              break;
+            case GJX_DIST_BERNOULLI: lp = logpdf_bernoulli(vi != 0, a0); break;
+            default:
+              lp = (vi < 0 || vi >= st.n_cat) ? -__builtin_inff()
+                                              : row[vi] - row_lse(row, (uint32_t)st.n_cat);
+          }
+          sc = sc + lp;
+          if (st.observed) w = w + lp;
+          const uint32_t raw = is_int ? (uint32_t)vi : f2u(vf);
+          vals[q * kBlock + threadIdx.x] = raw;
+          if (st.out_col >= 0) reinterpret_cast<uint32_t*>(cols.out[st.out_col])[i] = raw;
+        }
+        logw[i] = w;
+        if (score) score[i] = sc;
+        tmax = w > tmax ? w : tmax;
+      }
+    }
+    if (max_partials) {
+      const float bm = block_max(tmax, sh_red);
+      if (threadIdx.x == 0) max_partials[tile] = bm;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// log-sum-exp: tile partials -> tiny finishing kernels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_max_partials(const float* x, uint64_t n,
+                                                         float* partials) {
+  __shared__ float sh[kBlock / kWave];
+  for (uint64_t tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
+    float m = -__builtin_inff();
+    for (uint64_t i = tile * kTile + threadIdx.x; i < n && i < (tile + 1) * kTile; i += kBlock) {
+      const float v = x[i];
+      m = v > m ? v : m;
+    }
+    m = block_max(m, sh);
+    if (threadIdx.x == 0) partials[tile] = m;
+  }
+}
+// one block: out[0] = max(partials[0..np))
+__global__ __launch_bounds__(kBlock) void k_reduce_max(const float* partials, uint64_t np,
+                                                       float* out) {
+  __shared__ float sh[kBlock / kWave];
+  float m = -__builtin_inff();
+  for (uint64_t i = threadIdx.x; i < np; i += kBlock) {
+    const float v = partials[i];
+    m = v > m ? v : m;
+  }
+  m = block_max(m, sh);
+  if (threadIdx.x == 0) out[0] = m;
+}
+__global__ __launch_bounds__(kBlock) void k_expsum_partials(const float* x, uint64_t n,
+                                                            const float* m_ptr, int frac,
+                                                            uint64_t* partials) {
+  __shared__ uint64_t sh[kBlock / kWave];
+  const float m = m_ptr[0];
+  for (uint64_t tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
+    uint64_t acc = 0;
+    for (uint64_t i = tile * kTile + threadIdx.x; i < n && i < (tile + 1) * kTile; i += kBlock)
+      acc += fixw(x[i], m, frac);
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) partials[tile] = acc;
+  }
+}
+// one block: out_q = sum(partials) (+= if accumulate); optional lse = m + log(q 2^-frac)
+__global__ __launch_bounds__(kBlock) void k_reduce_sum(const uint64_t* partials, uint64_t np,
+                                                       uint64_t* out_q, int accumulate,
+                                                       const float* m_ptr, int frac,
+                                                       float* out_lse, float* out_max) {
+  __shared__ uint64_t sh[kBlock / kWave];
+  uint64_t acc = 0;
+  for (uint64_t i = threadIdx.x; i < np; i += kBlock) acc += partials[i];
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) {
+    if (out_q) out_q[0] = accumulate ? out_q[0] + acc : acc;
+    if (out_lse) {
+      const float qf = (float)acc * u2f((uint32_t)(127 - frac) << 23);
+      out_lse[0] = m_ptr[0] + m_log(qf);
+    }
+    if (out_max) out_max[0] = m_ptr[0];
+  }
+}
+__global__ void k_lse_finish(const float* m_ptr, const uint64_t* q_ptr, int frac, float* out) {
+  const float qf = (float)q_ptr[0] * u2f((uint32_t)(127 - frac) << 23);
+  out[0] = m_ptr[0] + m_log(qf);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Systematic resampling, tile-centric: workgroup b owns SOURCE particles [b*1024, (b+1)*1024).
+// It rebuilds the fixed-point CDF of its tile in LDS (prefix of the preceding tiles comes from the
+// per-tile sums), turns it into "teeth below" counts, and serves the contiguous range of OUTPUT
+// slots whose teeth fall into its mass — so both the source reads (one tile of lw / state) and
+// the output writes are coalesced, and ancestors never round-trip through HBM unless asked for.
+// The per-output work (propagate + weight for the fused SMC models) is the template policy.
+// ------------------------------------------------------------------------------------------------
+struct ResampleArgs {
+  const float* lw;            // [n] source log-weights
+  const float* m_ptr;         // max of lw
+  const uint64_t* tile_sums;  // [ntiles] fixed-point mass of every source tile
+  uint64_t n, ntiles;
+  uint64_t n_out;             // number of comb teeth (global output slots)
+  int64_t out_lo, out_hi;     // slots this launch serves
+  int frac;
+  int lw_vec;                 // lw is 16-byte aligned: tiles may use float4 loads
+  Key rkey;                   // resampling key (its sub-stream 0 gives the comb offset)
+  int rkey_has_fold;
+  uint32_t rkey_fold;
+  uint64_t* q_total_out;      // nullable: block 0 stores the total mass (= sum of tile_sums)
+};
+
+struct AncestorOnly {
+  int32_t* anc;  // [out_hi - out_lo]
+  GJX_DEV void load_source(uint64_t, uint64_t, int) const {}
+  GJX_DEV float emit(int64_t j, int64_t out_lo, uint64_t src, int) const {
+    anc[j - out_lo] = (int32_t)src;
+    return 0.0f;
+  }
+};
+
+template <int IMPL, class Policy>
+__global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P,
+                                                     float* max_partials) {
+  __shared__ uint64_t sh64[kBlock / kWave];
+  __shared__ float shf[kBlock / kWave];
+  __shared__ int32_t nb[kTile];  // teeth below the inclusive CDF of each source in the tile
+  const uint64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+
+  // prefix / total of tile masses (u64, exact)
+  uint64_t pre = 0, tot = 0;
+  for (uint64_t k = tid; k < A.ntiles; k += kBlock) {
+    const uint64_t v = A.tile_sums[k];
+    tot += v;
+    if (k < b) pre += v;
+  }
+  pre = block_sum(pre, sh64);
+  tot = block_sum(tot, sh64);
+  if (A.q_total_out && b == 0 && tid == 0) A.q_total_out[0] = tot;
+
+  const Stream<IMPL> rs(A.rkey, A.rkey_has_fold != 0, A.rkey_fold);
+  const double u0 = u0_from_bits(rs.bits64(0));
+  const double scale = (double)A.n_out / (double)tot;
+  const float m = A.m_ptr[0];
+  const uint64_t base = b * kTile;
+
+  // tile CDF: each thread owns 4 CONSECUTIVE sources (base + 4*tid + r) so the scan is a
+  // thread-local prefix plus one block scan.
+  uint64_t q[4];
+  uint64_t local = 0;
+  float lw4[4];
+  if (A.lw_vec && base + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
+    const float4 v = reinterpret_cast<const float4*>(A.lw + base)[tid];
+    lw4[0] = v.x; lw4[1] = v.y; lw4[2] = v.z; lw4[3] = v.w;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint64_t i = base + 4 * (uint64_t)tid + r;
+      lw4[r] = i < A.n ? A.lw[i] : -__builtin_inff();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t i = base + 4 * (uint64_t)tid + r;
+    q[r] = i < A.n ? fixw(lw4[r], m, A.frac) : 0;
+    local += q[r];
+  }
+  uint64_t tile_total;
+  uint64_t run = pre + block_scan_excl(local, sh64, tile_total);
+  const int64_t n_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t i = base + 4 * (uint64_t)tid + r;
+    run += q[r];
+    // the last real particle (and any padding after it) closes the comb at n_out
+    const int64_t t = (i + 1 >= A.n) ? (int64_t)A.n_out
+                                     : teeth_below(run, scale, u0, (int64_t)A.n_out);
+    nb[4 * tid + r] = (int32_t)t;
+  }
+  P.load_source(base, A.n, tid);
+  __syncthreads();
+  const int64_t n_hi = nb[kTile - 1];
+  const int64_t j0 = n_lo > A.out_lo ? n_lo : A.out_lo;
+  const int64_t j1 = n_hi < A.out_hi ? n_hi : A.out_hi;
+
+  float tmax = -__builtin_inff();
+  for (int64_t j = j0 + tid; j < j1; j += kBlock) {
+    // first source s in the tile with nb[s] > j
+    int lo = 0, hi = kTile - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)nb[mid] > j) hi = mid;
+      else lo = mid + 1;
+    }
+    const float w = P.emit(j, A.out_lo, base + (uint64_t)lo, lo);
+    tmax = w > tmax ? w : tmax;
+  }
+  if (max_partials) {
+    const float bm = block_max(tmax, shf);
+    if (tid == 0) max_partials[b] = bm;
+  }
+}
+
+// Per-tile fixed-point mass of local log-weights, written at the global tile offset.
+// The max is reduced redundantly by every block from the per-tile maxima (L2-resident).
+__global__ __launch_bounds__(kBlock) void k_tile_sums(const float* lw, uint64_t n_local,
+                                                      const float* max_partials, uint64_t n_mp,
+                                                      int frac, uint64_t* tile_sums_at,
+                                                      float* max_out) {
+  __shared__ uint64_t sh64[kBlock / kWave];
+  __shared__ float shf[kBlock / kWave];
+  float m = -__builtin_inff();
+  for (uint64_t k = threadIdx.x; k < n_mp; k += kBlock) {
+    const float v = max_partials[k];
+    m = v > m ? v : m;
+  }
+  m = block_max(m, shf);
+  if (max_out && blockIdx.x == 0 && threadIdx.x == 0) max_out[0] = m;
+  const uint64_t tile = blockIdx.x;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t i = tile * kTile + (uint64_t)r * kBlock + threadIdx.x;
+    if (i < n_local) acc += fixw(lw[i], m, frac);
+  }
+  acc = block_sum(acc, sh64);
+  if (threadIdx.x == 0) tile_sums_at[tile] = acc;
+}
+
+// Inclusive fixed-point CDF materialised in HBM (multinomial / single-draw paths).
+__global__ __launch_bounds__(kBlock) void k_cdf(const float* lw, uint64_t n, const float* m_ptr,
+                                                const uint64_t* tile_sums, uint64_t ntiles,
+                                                int frac, uint64_t* cdf) {
+  __shared__ uint64_t sh64[kBlock / kWave];
+  const uint64_t b = blockIdx.x;
+  uint64_t pre = 0;
+  for (uint64_t k = threadIdx.x; k < b; k += kBlock) pre += tile_sums[k];
+  pre = block_sum(pre, sh64);
+  const float m = m_ptr[0];
+  const uint64_t base = b * kTile;
+  uint64_t q[4], local = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t i = base + 4 * (uint64_t)threadIdx.x + r;
+    q[r] = i < n ? fixw(lw[i], m, frac) : 0;
+    local += q[r];
+  }
+  uint64_t tt;
+  uint64_t run = pre + block_scan_excl(local, sh64, tt);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t i = base + 4 * (uint64_t)threadIdx.x + r;
+    run += q[r];
+    if (i < n) cdf[i] = run;
+  }
+}
+GJX_DEV uint64_t cdf_upper_bound(const uint64_t* cdf, uint64_t n, uint64_t thr) {
+  uint64_t lo = 0, hi = n - 1;  // first i with cdf[i] > thr
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (cdf[mid] > thr) hi = mid;
+    else lo = mid + 1;
+  }
+  return lo;
+}
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_multinomial(Key rkey, int has_fold, uint32_t fold,
+                                                        const uint64_t* cdf, uint64_t n,
+                                                        uint64_t n_out, int32_t* anc,
+                                                        int64_t* idx64) {
+  const Stream<IMPL> st(rkey, has_fold != 0, fold);
+  const uint64_t Q = cdf[n - 1];
+  GJX_TILE_LOOP(j, n_out) {
+    const uint64_t thr = __umul64hi(st.bits64((uint32_t)j), Q);
+    const uint64_t a = cdf_upper_bound(cdf, n, thr);
+    if (anc) anc[j] = (int32_t)a;
+    if (idx64) idx64[j] = (int64_t)a;
+  }
+}
+
+// Gumbel-max single draw over n logits (jax.random.categorical semantics): tile argmax partials.
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_gumbel_partials(Key key, int has_fold, uint32_t fold,
+                                                            const float* logits, uint64_t n,
+                                                            float* pv, int64_t* pi) {
+  __shared__ float shv[kBlock];
+  __shared__ int64_t shi[kBlock];
+  const Stream<IMPL> st(key, has_fold != 0, fold);
+  for (uint64_t tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
+    float bv = -__builtin_inff();
+    int64_t bi = INT64_MAX;
+    for (uint64_t i = tile * kTile + threadIdx.x; i < n && i < (tile + 1) * kTile; i += kBlock) {
+      const float v = logits[i] + gumbel_from_bits(st.bits32((uint32_t)i));
+      if (v > bv || bi == INT64_MAX) { bv = v; bi = (int64_t)i; }
+    }
+    shv[threadIdx.x] = bv;
+    shi[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) {
+        const float ov = shv[threadIdx.x + off];
+        const int64_t oi = shi[threadIdx.x + off];
+        const float mv = shv[threadIdx.x];
+        const int64_t mi = shi[threadIdx.x];
+        // sequential-scan semantics: first index attaining the maximum wins
+        if (oi != INT64_MAX && (mi == INT64_MAX || ov > mv || (ov == mv && oi < mi))) {
+          shv[threadIdx.x] = ov;
+          shi[threadIdx.x] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { pv[tile] = shv[0]; pi[tile] = shi[0]; }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_argmax_final(const float* pv, const int64_t* pi,
+                                                         uint64_t np, int64_t* out) {
+  __shared__ float shv[kBlock];
+  __shared__ int64_t shi[kBlock];
+  float bv = -__builtin_inff();
+  int64_t bi = INT64_MAX;
+  for (uint64_t k = threadIdx.x; k < np; k += kBlock) {
+    const float v = pv[k];
+    const int64_t i = pi[k];
+    if (bi == INT64_MAX || v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+  }
+  shv[threadIdx.x] = bv;
+  shi[threadIdx.x] = bi;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const float ov = shv[threadIdx.x + off];
+      const int64_t oi = shi[threadIdx.x + off];
+      const float mv = shv[threadIdx.x];
+      const int64_t mi = shi[threadIdx.x];
+      if (oi != INT64_MAX && (mi == INT64_MAX || ov > mv || (ov == mv && oi < mi))) {
+        shv[threadIdx.x] = ov;
+        shi[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = shi[0];
+}
+
+struct GatherCols {
+  const uint32_t* src[16];
+  uint32_t* dst[16];
+};
+__global__ __launch_bounds__(kBlock) void k_gather(const int32_t* anc, uint64_t n_out,
+                                                   GatherCols g, int n_cols) {
+  GJX_TILE_LOOP(j, n_out) {
+    const int32_t a = anc[j];
+    for (int c = 0; c < n_cols; ++c) g.dst[c][j] = g.src[c][a];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused bootstrap-SMC policies: propagate + weight one output slot.
+// ------------------------------------------------------------------------------------------------
+template <int IMPL>
+struct LgssmPolicy {
+  const float* prev_state;  // [n] (global) previous-step particles
+  float* state_out;         // [n_local]
+  float* logw_out;          // [n_local]
+  int32_t* anc_out;         // nullable [n_local]
+  Key step_key;
+  float a, q, y, rs, lognorm;
+  float* xs;                // LDS tile of previous states (set in load_source)
+  GJX_DEV void load_source(uint64_t base, uint64_t n, int tid) {
+    __shared__ float xs_tile[kTile];
+    xs = xs_tile;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint64_t i = base + (uint64_t)r * kBlock + tid;
+      xs_tile[r * kBlock + tid] = i < n ? prev_state[i] : 0.0f;
+    }
+  }
+  GJX_DEV float emit(int64_t j, int64_t out_lo, uint64_t src, int src_local) const {
+    const Key pk = split_at<IMPL>(step_key, (uint64_t)j);
+    const Stream<IMPL> st(pk, true, 1u);
+    const float eps = std_normal(st.bits32(0));
+    const float mean = a * xs[src_local];
+    const float t = q * eps;
+    const float x = mean + t;
+    const float lw = logpdf_normal_pre(y, x, rs, lognorm);
+    state_out[j - out_lo] = x;
+    logw_out[j - out_lo] = lw;
+    if (anc_out) anc_out[j - out_lo] = (int32_t)src;
+    return lw;
+  }
+};
+
+template <int IMPL>
+struct HmmPolicy {
+  const int32_t* prev_state;
+  int32_t* state_out;
+  float* logw_out;
+  int32_t* anc_out;
+  Key step_key;
+  const uint32_t* trans_cdf;  // [K,K]
+  const float* obs_logp;      // [K,K]
+  int32_t K, y;
+  int32_t* zs;
+  float* ocol;
+  GJX_DEV void load_source(uint64_t base, uint64_t n, int tid) {
+    __shared__ int32_t zs_tile[kTile];
+    __shared__ float ocol_tile[256];
+    zs = zs_tile;
+    ocol = ocol_tile;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint64_t i = base + (uint64_t)r * kBlock + tid;
+      zs_tile[r * kBlock + tid] = i < n ? prev_state[i] : 0;
+    }
+    if (tid < K) ocol_tile[tid] = obs_logp[(size_t)tid * K + y];
+  }
+  GJX_DEV float emit(int64_t j, int64_t out_lo, uint64_t src, int src_local) const {
+    const Key pk = split_at<IMPL>(step_key, (uint64_t)j);
+    const Stream<IMPL> st(pk, true, 1u);
+    const uint32_t bits = st.bits32(0);
+    const uint32_t* cdf = trans_cdf + (size_t)zs[src_local] * K;
+    const uint64_t thr = ((uint64_t)bits * (uint64_t)cdf[K - 1]) >> 32;
+    uint32_t lo = 0, hi = (uint32_t)K - 1;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if ((uint64_t)cdf[mid] > thr) hi = mid;
+      else lo = mid + 1;
+    }
+    const float lw = ocol[lo];
+    state_out[j - out_lo] = (int32_t)lo;
+    logw_out[j - out_lo] = lw;
+    if (anc_out) anc_out[j - out_lo] = (int32_t)src;
+    return lw;
+  }
+};
+
+// Step 0 (no resampling): one block per GLOBAL tile; tiles outside this rank only clear their
+// max partial so the array can be max-combined across ranks.
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_lgssm_init(Key step_key, uint64_t first_slot,
+                                                       uint64_t n_local, float x0_loc,
+                                                       float x0_scale, float y, float rs,
+                                                       float lognorm, float* state_out,
+                                                       float* logw_out, int32_t* anc_out,
+                                                       float* max_partials) {
+  __shared__ float shf[kBlock / kWave];
+  const uint64_t gbase = (uint64_t)blockIdx.x * kTile;
+  float tmax = -__builtin_inff();
+  if (gbase >= first_slot && gbase < first_slot + n_local) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint64_t j = gbase + (uint64_t)r * kBlock + threadIdx.x;
+      if (j < first_slot + n_local) {
+        const Key pk = split_at<IMPL>(step_key, j);
+        const Stream<IMPL> st(pk, true, 1u);
+        const float eps = std_normal(st.bits32(0));
+        const float t = x0_scale * eps;
+        const float x = x0_loc + t;
+        const float lw = logpdf_normal_pre(y, x, rs, lognorm);
+        state_out[j - first_slot] = x;
+        logw_out[j - first_slot] = lw;
+        if (anc_out) anc_out[j - first_slot] = (int32_t)j;
+        tmax = lw > tmax ? lw : tmax;
+      }
+    }
+  }
+  const float bm = block_max(tmax, shf);
+  if (threadIdx.x == 0) max_partials[blockIdx.x] = bm;
+}
+
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_hmm_init(Key step_key, uint64_t first_slot,
+                                                     uint64_t n_local, const uint32_t* trans_cdf,
+                                                     const float* obs_logp, int32_t K,
+                                                     int32_t init_state, int32_t y,
+                                                     int32_t* state_out, float* logw_out,
+                                                     int32_t* anc_out, float* max_partials) {
+  __shared__ float shf[kBlock / kWave];
+  const uint64_t gbase = (uint64_t)blockIdx.x * kTile;
+  float tmax = -__builtin_inff();
+  if (gbase >= first_slot && gbase < first_slot + n_local) {
+    const uint32_t* cdf = trans_cdf + (size_t)init_state * K;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint64_t j = gbase + (uint64_t)r * kBlock + threadIdx.x;
+      if (j < first_slot + n_local) {
+        const Key pk = split_at<IMPL>(step_key, j);
+        const Stream<IMPL> st(pk, true, 1u);
+        const uint32_t bits = st.bits32(0);
+        const uint64_t thr = ((uint64_t)bits * (uint64_t)cdf[K - 1]) >> 32;
+        uint32_t lo = 0, hi = (uint32_t)K - 1;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if ((uint64_t)cdf[mid] > thr) hi = mid;
+          else lo = mid + 1;
+        }
+        const float lw = obs_logp[(size_t)lo * K + y];
+        state_out[j - first_slot] = (int32_t)lo;
+        logw_out[j - first_slot] = lw;
+        if (anc_out) anc_out[j - first_slot] = (int32_t)j;
+        tmax = lw > tmax ? lw : tmax;
+      }
+    }
+  }
+  const float bm = block_max(tmax, shf);
+  if (threadIdx.x == 0) max_partials[blockIdx.x] = bm;
+}
+
+// HMM tables: one thread per row, sequential in k (exactly the spec's order).
+__global__ void k_hmm_prepare(const float* trans_logits, const float* obs_logits, int32_t K,
+                              uint32_t* trans_cdf, float* obs_logp) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= K) return;
+  const float* l = trans_logits + (size_t)r * K;
+  const float m = row_max(l, (uint32_t)K);
+  uint32_t C = 0;
+  for (int c = 0; c < K; ++c) {
+    C += cat_fix(l[c], m);
+    trans_cdf[(size_t)r * K + c] = C;
+  }
+  const float* o = obs_logits + (size_t)r * K;
+  const float lse = row_lse(o, (uint32_t)K);
+  for (int c = 0; c < K; ++c) obs_logp[(size_t)r * K + c] = o[c] - lse;
+}
+
+// workspace carving
+struct Carver {
+  char* p;
+  size_t left;
+  bool ok = true;
+  template <class T>
+  T* take(size_t count) {
+    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    if (!ok || bytes > left) {
+      ok = false;
+      return nullptr;
+    }
+    T* r = reinterpret_cast<T*>(p);
+    p += bytes;
+    left -= bytes;
+    return r;
+  }
+};
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+extern "C" {
+
+int gjx_version(int* major, int* minor) {
+  if (major) *major = GJX_VERSION_MAJOR;
+  if (minor) *minor = GJX_VERSION_MINOR;
+  return GJX_OK;
+}
+const char* gjx_backend_name(void) { return "hip-gfx950"; }
+int gjx_frac_bits(uint64_t n_total) { return frac_bits(n_total); }
+uint64_t gjx_smc_tile(void) { return kTile; }
+uint64_t gjx_num_tiles(uint64_t n) { return ntiles_of(n); }
+
+size_t gjx_workspace_bytes(int op, uint64_t n) {
+  const uint64_t nt = ntiles_of(n);
+  switch (op) {
+    case GJX_OP_LOGSUMEXP: return pad256(nt * 4) + pad256(nt * 8) + 1024;
+    case GJX_OP_CATEGORICAL_INDEX:
+    case GJX_OP_RESAMPLE:
+      return pad256(nt * 4) + 2 * pad256(nt * 8) + pad256(n * 8) + 1024;
+    case GJX_OP_SMC:
+      return 2 * pad256(n * 4) + pad256(nt * 4) + pad256(nt * 8) + 2 * pad256(256 * 256 * 4) + 1024;
+    default: return 0;
+  }
+}
+
+#define GJX_DISPATCH_IMPL(impl, KERNEL, ...)  \
+  do {                                        \
+    if ((impl) == 0) KERNEL<0> __VA_ARGS__;   \
+    else KERNEL<1> __VA_ARGS__;               \
+  } while (0)
+
+int gjx_rng_keys(const gjx_keys* k, uint64_t n, uint32_t* out, gjx_stream s) {
+  if (!keys_ok(k) || (!out && n)) return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  GJX_DISPATCH_IMPL(k->impl, k_rng_keys, <<<grid_for(n), kBlock, 0, S(s)>>>(key_src(k), n, out));
+  return launch_status();
+}
+int gjx_rng_bits(const gjx_keys* k, uint32_t sub, uint64_t n, uint32_t* out, gjx_stream s) {
+  if (!keys_ok(k) || (!out && n)) return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  GJX_DISPATCH_IMPL(k->impl, k_rng_bits, <<<grid_for(n), kBlock, 0, S(s)>>>(key_src(k), sub, n, out));
+  return launch_status();
+}
+
+int gjx_sample_logpdf_normal(const gjx_keys* k, gjx_f32 loc, gjx_f32 scale, float* value_out,
+                             float* score_out, uint64_t n, gjx_stream s) {
+  if (!keys_ok(k) || !value_out) return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  GJX_DISPATCH_IMPL(k->impl, k_sample_normal,
+                    <<<grid_for(n), kBlock, 0, S(s)>>>(key_src(k), opnd(loc), opnd(scale), value_out, score_out, n));
+  return launch_status();
+}
+int gjx_sample_logpdf_gamma(const gjx_keys* k, gjx_f32 concentration, gjx_f32 rate,
+                            float* value_out, float* score_out, uint64_t n, gjx_stream s) {
+  if (!keys_ok(k) || !value_out) return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  GJX_DISPATCH_IMPL(k->impl, k_sample_gamma,
+                    <<<grid_for(n), kBlock, 0, S(s)>>>(key_src(k), opnd(concentration), opnd(rate), value_out, score_out, n));
+  return launch_status();
+}
+int gjx_sample_logpdf_beta(const gjx_keys* k, gjx_f32 a, gjx_f32 b, float* value_out,
+                           float* score_out, uint64_t n, gjx_stream s) {
+  if (!keys_ok(k) || !value_out) return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  GJX_DISPATCH_IMPL(k->impl, k_sample_beta,
+                    <<<grid_for(n), kBlock, 0, S(s)>>>(key_src(k), opnd(a), opnd(b), value_out, score_out, n));
+  return launch_status();
+}
+int gjx_sample_logpdf_bernoulli(const gjx_keys* k, gjx_f32 probs, uint8_t* value_out,
+                                float* score_out, uint64_t n, gjx_stream s) {
+  if (!keys_ok(k) || !value_out) return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  GJX_DISPATCH_IMPL(k->impl, k_sample_bernoulli,
+                    <<<grid_for(n), kBlock, 0, S(s)>>>(key_src(k), opnd(probs), value_out, score_out, n));
+  return launch_status();
+}
+int gjx_sample_logpdf_categorical(const gjx_keys* k, const float* logits, uint64_t n_rows,
+                                  uint32_t n_cat, const int32_t* row_index, int mode,
+                                  int32_t* value_out, float* score_out, uint64_t n, gjx_stream s) {
+  if (!keys_ok(k) || !value_out || !logits || n_cat == 0 || (mode != 0 && mode != 1))
+    return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  GJX_DISPATCH_IMPL(k->impl, k_sample_categorical,
+                    <<<grid_for(n), kBlock, 0, S(s)>>>(key_src(k), logits, n_rows, n_cat, row_index, mode, value_out, score_out, n));
+  return launch_status();
+}
+
+int gjx_logpdf_normal(gjx_f32 value, gjx_f32 loc, gjx_f32 scale, float* score_out, uint64_t n,
+                      gjx_stream s) {
+  if (!score_out) return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  k_logpdf_normal<<<grid_for(n), kBlock, 0, S(s)>>>(opnd(value), opnd(loc), opnd(scale), score_out, n);
+  return launch_status();
+}
+int gjx_logpdf_gamma(gjx_f32 value, gjx_f32 concentration, gjx_f32 rate, float* score_out,
+                     uint64_t n, gjx_stream s) {
+  if (!score_out) return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  k_logpdf_gamma<<<grid_for(n), kBlock, 0, S(s)>>>(opnd(value), opnd(concentration), opnd(rate), score_out, n);
+  return launch_status();
+}
+int gjx_logpdf_beta(gjx_f32 value, gjx_f32 a, gjx_f32 b, float* score_out, uint64_t n,
+                    gjx_stream s) {
+  if (!score_out) return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  k_logpdf_beta<<<grid_for(n), kBlock, 0, S(s)>>>(opnd(value), opnd(a), opnd(b), score_out, n);
+  return launch_status();
+}
+int gjx_logpdf_bernoulli(const uint8_t* value, int value_scalar, gjx_f32 probs, float* score_out,
+                         uint64_t n, gjx_stream s) {
+  if (!score_out) return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  k_logpdf_bernoulli<<<grid_for(n), kBlock, 0, S(s)>>>(value, value_scalar, opnd(probs), score_out, n);
+  return launch_status();
+}
+int gjx_logpdf_categorical(const int32_t* value, int value_scalar, const float* logits,
+                           uint64_t n_rows, uint32_t n_cat, const int32_t* row_index,
+                           float* score_out, uint64_t n, gjx_stream s) {
+  if (!score_out || !logits || n_cat == 0) return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  k_logpdf_categorical<<<grid_for(n), kBlock, 0, S(s)>>>(value, value_scalar, logits, n_rows, n_cat, row_index, score_out, n);
+  return launch_status();
+}
+
+// ---- plans ---------------------------------------------------------------------------------------
+struct gjx_plan {
+  int n_sites;
+  CSite host[GJX_MAX_SITES];
+  CSite* dev;
+};
+
+static bool arg_ok(const gjx_arg& a, int s) {
+  switch (a.kind) {
+    case GJX_ARG_CONST: return true;
+    case GJX_ARG_SITE: return a.ref >= 0 && a.ref < s;
+    case GJX_ARG_INPUT: return a.ref >= 0 && a.ref < 16;
+    case GJX_ARG_TABLE: return a.ref >= 0 && a.ref < s && a.table != nullptr;
+    default: return false;
+  }
+}
+static CArg carg(const gjx_arg& a) { return CArg{a.kind, a.ref, a.scale, a.offset, a.table}; }
+
+int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
+  if (!sites || !out || n_sites <= 0 || n_sites > GJX_MAX_SITES) return GJX_ERR_INVALID;
+  gjx_plan* p = new (std::nothrow) gjx_plan;
+  if (!p) return GJX_ERR_LAUNCH;
+  p->n_sites = n_sites;
+  p->dev = nullptr;
+  for (int s = 0; s < n_sites; ++s) {
+    const gjx_site& st = sites[s];
+    bool ok = st.dist >= 0 && st.dist <= GJX_DIST_CATEGORICAL && arg_ok(st.arg[0], s);
+    if (ok && st.dist != GJX_DIST_BERNOULLI && st.dist != GJX_DIST_CATEGORICAL) ok = arg_ok(st.arg[1], s);
+    if (ok && st.observed) ok = st.obs.kind == GJX_ARG_CONST || (st.obs.kind == GJX_ARG_INPUT && st.obs.ref >= 0 && st.obs.ref < 16);
+    if (ok && st.dist == GJX_DIST_CATEGORICAL)
+      ok = st.logits && st.n_cat > 0 && st.n_rows > 0 && (st.cat_mode == 0 || st.cat_mode == 1);
+    if (!ok) {
+      delete p;
+      return GJX_ERR_INVALID;
+    }
+    CSite& c = p->host[s];
+    memset(&c, 0, sizeof(c));
+    c.dist = st.dist; c.observed = st.observed; c.out_col = st.out_col;
+    c.n_cat = st.n_cat; c.n_rows = st.n_rows; c.cat_mode = st.cat_mode;
+    c.a0 = carg(st.arg[0]); c.a1 = carg(st.arg[1]); c.obs = carg(st.obs);
+    c.logits = st.logits;
+    // Hoist per-site constants: same spec functions, evaluated once on the host (IEEE-exact ops
+    // give the same bits as evaluating them per particle on the device).
+    const bool c0 = st.arg[0].kind == GJX_ARG_CONST, c1 = st.arg[1].kind == GJX_ARG_CONST;
+    if (st.dist == GJX_DIST_NORMAL && c1) {
+      c.pre = 1; c.pre0 = normal_rs(st.arg[1].offset); c.pre1 = normal_lognorm(st.arg[1].offset);
+    } else if (st.dist == GJX_DIST_GAMMA && c0 && c1) {
+      c.pre = 1; c.pre1 = gamma_lognorm(st.arg[0].offset, st.arg[1].offset);
+    } else if (st.dist == GJX_DIST_BETA && c0 && c1) {
+      c.pre = 1; c.pre1 = beta_lbeta(st.arg[0].offset, st.arg[1].offset);
+    }
+  }
+  if (hipMalloc(&p->dev, sizeof(CSite) * (size_t)n_sites) != hipSuccess) {
+    delete p;
+    return GJX_ERR_NO_DEVICE;
+  }
+  if (hipMemcpy(p->dev, p->host, sizeof(CSite) * (size_t)n_sites, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(p->dev);
+    delete p;
+    return GJX_ERR_LAUNCH;
+  }
+  *out = p;
+  return GJX_OK;
+}
+int gjx_plan_destroy(gjx_plan* p) {
+  if (!p) return GJX_OK;
+  if (p->dev) (void)hipFree(p->dev);
+  delete p;
+  return GJX_OK;
+}
+
+int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const* input_cols,
+                       int n_input_cols, void* const* value_cols, int n_value_cols, float* score,
+                       float* logw, uint64_t n, float* max_partials, gjx_stream s) {
+  if (!p || !keys_ok(pk) || pk->has_fold || !logw || n_input_cols < 0 || n_input_cols > 16 ||
+      n_value_cols < 0 || n_value_cols > GJX_MAX_SITES)
+    return GJX_ERR_INVALID;
+  RunCols cols;
+  memset(&cols, 0, sizeof(cols));
+  for (int c = 0; c < n_input_cols; ++c) cols.in[c] = input_cols[c];
+  for (int c = 0; c < n_value_cols; ++c) cols.out[c] = value_cols[c];
+  for (int q = 0; q < p->n_sites; ++q) {
+    const CSite& st = p->host[q];
+    if (st.out_col >= n_value_cols) return GJX_ERR_INVALID;
+    if (st.out_col >= 0 && !cols.out[st.out_col]) return GJX_ERR_INVALID;
+    if (st.a0.kind == GJX_ARG_INPUT && st.a0.ref >= n_input_cols) return GJX_ERR_INVALID;
+    if (st.a1.kind == GJX_ARG_INPUT && st.a1.ref >= n_input_cols) return GJX_ERR_INVALID;
+    if (st.observed && st.obs.kind == GJX_ARG_INPUT && st.obs.ref >= n_input_cols) return GJX_ERR_INVALID;
+  }
+  if (n == 0) return GJX_OK;
+  const size_t lds = sizeof(uint32_t) * (size_t)p->n_sites * kBlock;
+  GJX_DISPATCH_IMPL(pk->impl, k_importance,
+                    <<<grid_for(n), kBlock, lds, S(s)>>>(p->dev, p->n_sites, key_src(pk), cols, score, logw, n, max_partials));
+  return launch_status();
+}
+
+// ---- weights -------------------------------------------------------------------------------------
+int gjx_max_f32(const float* x, uint64_t n, const float* max_partials_in, float* out_max, void* ws,
+                size_t ws_bytes, gjx_stream s) {
+  if ((!x && !max_partials_in) || !out_max || n == 0) return GJX_ERR_INVALID;
+  const uint64_t nt = ntiles_of(n);
+  const float* partials = max_partials_in;
+  if (!partials) {
+    Carver cv{(char*)ws, ws ? ws_bytes : 0};
+    float* mp = cv.take<float>(nt);
+    if (!cv.ok) return GJX_ERR_WORKSPACE;
+    k_max_partials<<<grid_for(n), kBlock, 0, S(s)>>>(x, n, mp);
+    partials = mp;
+  }
+  k_reduce_max<<<1, kBlock, 0, S(s)>>>(partials, nt, out_max);
+  return launch_status();
+}
+int gjx_expsum_fix(const float* x, uint64_t n, const float* max_dev, int frac_bits_, uint64_t* out_q,
+                   void* ws, size_t ws_bytes, gjx_stream s) {
+  if (!x || !max_dev || !out_q || n == 0 || frac_bits_ < 1 || frac_bits_ > 40) return GJX_ERR_INVALID;
+  const uint64_t nt = ntiles_of(n);
+  Carver cv{(char*)ws, ws ? ws_bytes : 0};
+  (void)cv.take<float>(nt);
+  uint64_t* qp = cv.take<uint64_t>(nt);
+  if (!cv.ok) return GJX_ERR_WORKSPACE;
+  k_expsum_partials<<<grid_for(n), kBlock, 0, S(s)>>>(x, n, max_dev, frac_bits_, qp);
+  k_reduce_sum<<<1, kBlock, 0, S(s)>>>(qp, nt, out_q, 0, max_dev, frac_bits_, nullptr, nullptr);
+  return launch_status();
+}
+int gjx_lse_finish(const float* max_dev, const uint64_t* q_dev, int frac_bits_, float* out_lse,
+                   gjx_stream s) {
+  if (!max_dev || !q_dev || !out_lse) return GJX_ERR_INVALID;
+  k_lse_finish<<<1, 1, 0, S(s)>>>(max_dev, q_dev, frac_bits_, out_lse);
+  return launch_status();
+}
+int gjx_logsumexp_f32(const float* x, uint64_t n, const float* max_partials_in, float* out_lse,
+                      float* out_max, uint64_t* out_q, void* ws, size_t ws_bytes, gjx_stream s) {
+  if (!x || n == 0) return GJX_ERR_INVALID;
+  const uint64_t nt = ntiles_of(n);
+  Carver cv{(char*)ws, ws ? ws_bytes : 0};
+  float* mp = cv.take<float>(nt);
+  uint64_t* qp = cv.take<uint64_t>(nt);
+  float* m = cv.take<float>(1);
+  if (!cv.ok) return GJX_ERR_WORKSPACE;
+  const int frac = frac_bits(n);
+  if (!max_partials_in) {
+    k_max_partials<<<grid_for(n), kBlock, 0, S(s)>>>(x, n, mp);
+    max_partials_in = mp;
+  }
+  k_reduce_max<<<1, kBlock, 0, S(s)>>>(max_partials_in, nt, m);
+  k_expsum_partials<<<grid_for(n), kBlock, 0, S(s)>>>(x, n, m, frac, qp);
+  k_reduce_sum<<<1, kBlock, 0, S(s)>>>(qp, nt, out_q, 0, m, frac, out_lse, out_max);
+  return launch_status();
+}
+
+// shared front half of the resampling entry points: (max, tile sums) of logw
+static int weights_prepare(const float* logw, uint64_t n, Carver& cv, float** m_out,
+                           uint64_t** tiles_out, hipStream_t st) {
+  const uint64_t nt = ntiles_of(n);
+  float* mp = cv.take<float>(nt);
+  uint64_t* tiles = cv.take<uint64_t>(nt);
+  float* m = cv.take<float>(1);
+  if (!cv.ok) return GJX_ERR_WORKSPACE;
+  k_max_partials<<<grid_for(n), kBlock, 0, st>>>(logw, n, mp);
+  k_tile_sums<<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, frac_bits(n), tiles, m);
+  *m_out = m;
+  *tiles_out = tiles;
+  return GJX_OK;
+}
+
+// A scalar key (categorical draw / resampling offset) is resolved on the host side of the call.
+static int scalar_key(const gjx_keys* key, Key* out) {
+  const Key parent{key->parent[0], key->parent[1]};
+  if (key->mode == 2) { *out = parent; return GJX_OK; }
+  if (key->mode != 1) return GJX_ERR_UNSUPPORTED;  // device-resident scalar keys: not needed by the host API
+  *out = key->impl == 0 ? split_at<0>(parent, key->first) : split_at<1>(parent, key->first);
+  return GJX_OK;
+}
+
+int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, int64_t* out_idx,
+                          int mode, void* ws, size_t ws_bytes, gjx_stream s) {
+  if (!keys_ok(key) || !logits || !out_idx || n == 0 || (mode != 0 && mode != 1)) return GJX_ERR_INVALID;
+  Key k;
+  int rc = scalar_key(key, &k);
+  if (rc) return rc;
+  const uint64_t nt = ntiles_of(n);
+  Carver cv{(char*)ws, ws ? ws_bytes : 0};
+  if (mode == 0) {
+    if (n > 0xffffffffull) return GJX_ERR_UNSUPPORTED;
+    float* pv = cv.take<float>(nt);
+    int64_t* pi = cv.take<int64_t>(nt);
+    if (!cv.ok) return GJX_ERR_WORKSPACE;
+    GJX_DISPATCH_IMPL(key->impl, k_gumbel_partials,
+                      <<<grid_for(n), kBlock, 0, S(s)>>>(k, key->has_fold, key->fold, logits, n, pv, pi));
+    k_argmax_final<<<1, kBlock, 0, S(s)>>>(pv, pi, nt, out_idx);
+    return launch_status();
+  }
+  float* m;
+  uint64_t* tiles;
+  rc = weights_prepare(logits, n, cv, &m, &tiles, S(s));
+  if (rc) return rc;
+  uint64_t* cdf = cv.take<uint64_t>(n);
+  if (!cv.ok) return GJX_ERR_WORKSPACE;
+  k_cdf<<<(unsigned)nt, kBlock, 0, S(s)>>>(logits, n, m, tiles, nt, frac_bits(n), cdf);
+  GJX_DISPATCH_IMPL(key->impl, k_multinomial,
+                    <<<1, kBlock, 0, S(s)>>>(k, key->has_fold, key->fold, cdf, n, 1, nullptr, out_idx));
+  return launch_status();
+}
+
+int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, uint64_t n_out,
+                            int32_t* ancestors, float* out_max, uint64_t* out_q, void* ws,
+                            size_t ws_bytes, gjx_stream s) {
+  if (!keys_ok(key) || !logw || !ancestors || n == 0 || n_out == 0 || n > 0x7fffffffull ||
+      n_out > 0x7fffffffull)
+    return GJX_ERR_INVALID;
+  Key k;
+  int rc = scalar_key(key, &k);
+  if (rc) return rc;
+  Carver cv{(char*)ws, ws ? ws_bytes : 0};
+  float* m;
+  uint64_t* tiles;
+  rc = weights_prepare(logw, n, cv, &m, &tiles, S(s));
+  if (rc) return rc;
+  uint64_t* qtot = cv.take<uint64_t>(1);
+  if (!cv.ok) return GJX_ERR_WORKSPACE;
+  ResampleArgs A;
+  A.lw = logw; A.m_ptr = m; A.tile_sums = tiles; A.n = n; A.ntiles = ntiles_of(n);
+  A.n_out = n_out; A.out_lo = 0; A.out_hi = (int64_t)n_out; A.frac = frac_bits(n);
+  A.lw_vec = ((uintptr_t)logw & 15) == 0;
+  A.rkey = k; A.rkey_has_fold = key->has_fold; A.rkey_fold = key->fold;
+  A.q_total_out = out_q ? out_q : qtot;
+  AncestorOnly P{ancestors};
+  if (key->impl == 0) k_resample<0, AncestorOnly><<<(unsigned)A.ntiles, kBlock, 0, S(s)>>>(A, P, nullptr);
+  else k_resample<1, AncestorOnly><<<(unsigned)A.ntiles, kBlock, 0, S(s)>>>(A, P, nullptr);
+  if (out_max) (void)hipMemcpyAsync(out_max, m, sizeof(float), hipMemcpyDeviceToDevice, S(s));
+  return launch_status();
+}
+
+int gjx_resample_multinomial(const gjx_keys* key, const float* logw, uint64_t n, uint64_t n_out,
+                             int32_t* ancestors, float* out_max, uint64_t* out_q, void* ws,
+                             size_t ws_bytes, gjx_stream s) {
+  if (!keys_ok(key) || !logw || !ancestors || n == 0 || n_out == 0 || n > 0x7fffffffull)
+    return GJX_ERR_INVALID;
+  Key k;
+  int rc = scalar_key(key, &k);
+  if (rc) return rc;
+  Carver cv{(char*)ws, ws ? ws_bytes : 0};
+  float* m;
+  uint64_t* tiles;
+  rc = weights_prepare(logw, n, cv, &m, &tiles, S(s));
+  if (rc) return rc;
+  uint64_t* cdf = cv.take<uint64_t>(n);
+  if (!cv.ok) return GJX_ERR_WORKSPACE;
+  const uint64_t nt = ntiles_of(n);
+  k_cdf<<<(unsigned)nt, kBlock, 0, S(s)>>>(logw, n, m, tiles, nt, frac_bits(n), cdf);
+  GJX_DISPATCH_IMPL(key->impl, k_multinomial,
+                    <<<grid_for(n_out), kBlock, 0, S(s)>>>(k, key->has_fold, key->fold, cdf, n, n_out, ancestors, nullptr));
+  if (out_max) (void)hipMemcpyAsync(out_max, m, sizeof(float), hipMemcpyDeviceToDevice, S(s));
+  if (out_q) (void)hipMemcpyAsync(out_q, cdf + (n - 1), sizeof(uint64_t), hipMemcpyDeviceToDevice, S(s));
+  return launch_status();
+}
+
+int gjx_gather_cols(const int32_t* ancestors, uint64_t n_out, const void* const* src_cols,
+                    void* const* dst_cols, int n_cols, gjx_stream s) {
+  if (!ancestors || !src_cols || !dst_cols || n_cols < 0) return GJX_ERR_INVALID;
+  if (n_out == 0) return GJX_OK;
+  for (int c0 = 0; c0 < n_cols; c0 += 16) {
+    GatherCols g;
+    memset(&g, 0, sizeof(g));
+    const int nc = n_cols - c0 < 16 ? n_cols - c0 : 16;
+    for (int c = 0; c < nc; ++c) {
+      g.src[c] = (const uint32_t*)src_cols[c0 + c];
+      g.dst[c] = (uint32_t*)dst_cols[c0 + c];
+      if (!g.src[c] || !g.dst[c]) return GJX_ERR_INVALID;
+    }
+    k_gather<<<grid_for(n_out), kBlock, 0, S(s)>>>(ancestors, n_out, g, nc);
+  }
+  return launch_status();
+}
+
+// ---- fused bootstrap SMC ---------------------------------------------------------------------------
+static bool cfg_ok(const gjx_smc_config* c) {
+  return c && (c->impl == 0 || c->impl == 1) && c->n_total > 0 && c->n_local > 0 &&
+         c->first_slot + c->n_local <= c->n_total && c->n_steps > 0 && c->step_keys &&
+         c->resample_keys && (c->first_slot % kTile) == 0 && c->n_total <= 0x7fffffffull;
+}
+
+int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gjx_stream s) {
+  if (!mdl || !trans_cdf || !obs_logp || mdl->n_states <= 0 || mdl->n_states > 256 ||
+      !mdl->trans_logits || !mdl->obs_logits)
+    return GJX_ERR_INVALID;
+  k_hmm_prepare<<<(mdl->n_states + 63) / 64, 64, 0, S(s)>>>(mdl->trans_logits, mdl->obs_logits,
+                                                             mdl->n_states, trans_cdf, obs_logp);
+  return launch_status();
+}
+
+static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const float* prev_logw,
+                                      const float* prev_max, const uint64_t* prev_tile_sums,
+                                      uint64_t* prev_q_out) {
+  ResampleArgs A;
+  A.lw = prev_logw; A.m_ptr = prev_max; A.tile_sums = prev_tile_sums;
+  A.n = cfg->n_total; A.ntiles = ntiles_of(cfg->n_total); A.n_out = cfg->n_total;
+  A.out_lo = (int64_t)cfg->first_slot; A.out_hi = (int64_t)(cfg->first_slot + cfg->n_local);
+  A.frac = frac_bits(cfg->n_total);
+  A.lw_vec = ((uintptr_t)prev_logw & 15) == 0;
+  A.rkey = Key{cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1]};
+  A.rkey_has_fold = 0; A.rkey_fold = 0;
+  A.q_total_out = prev_q_out;
+  return A;
+}
+
+int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t,
+                         const float* prev_state, const float* prev_logw, const float* prev_max,
+                         const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* state_out,
+                         float* logw_out, float* max_partials_out, int32_t* ancestors_out,
+                         gjx_stream s) {
+  if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !state_out || !logw_out || !max_partials_out)
+    return GJX_ERR_INVALID;
+  const Key sk{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
+  const float rs = normal_rs(mdl->r), lognorm = normal_lognorm(mdl->r);
+  const unsigned nt = (unsigned)ntiles_of(cfg->n_total);
+  if (t == 0) {
+    GJX_DISPATCH_IMPL(cfg->impl, k_lgssm_init,
+                      <<<nt, kBlock, 0, S(s)>>>(sk, cfg->first_slot, cfg->n_local, mdl->x0_loc, mdl->x0_scale, y_t, rs, lognorm, state_out, logw_out, ancestors_out, max_partials_out));
+    return launch_status();
+  }
+  if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
+  ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out);
+  if (cfg->impl == 0) {
+    LgssmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr};
+    k_resample<0, LgssmPolicy<0>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+  } else {
+    LgssmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr};
+    k_resample<1, LgssmPolicy<1>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+  }
+  return launch_status();
+}
+
+int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_t y_t,
+                       const int32_t* prev_state, const float* prev_logw, const float* prev_max,
+                       const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
+                       const uint32_t* trans_cdf, const float* obs_logp, int32_t* state_out,
+                       float* logw_out, float* max_partials_out, int32_t* ancestors_out,
+                       gjx_stream s) {
+  if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !state_out || !logw_out ||
+      !max_partials_out || !trans_cdf || !obs_logp || y_t < 0 || y_t >= mdl->n_states ||
+      mdl->n_states > 256 || mdl->init_state < 0 || mdl->init_state >= mdl->n_states)
+    return GJX_ERR_INVALID;
+  const Key sk{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
+  const unsigned nt = (unsigned)ntiles_of(cfg->n_total);
+  if (t == 0) {
+    GJX_DISPATCH_IMPL(cfg->impl, k_hmm_init,
+                      <<<nt, kBlock, 0, S(s)>>>(sk, cfg->first_slot, cfg->n_local, trans_cdf, obs_logp, mdl->n_states, mdl->init_state, y_t, state_out, logw_out, ancestors_out, max_partials_out));
+    return launch_status();
+  }
+  if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
+  ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out);
+  if (cfg->impl == 0) {
+    HmmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr};
+    k_resample<0, HmmPolicy<0>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+  } else {
+    HmmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr};
+    k_resample<1, HmmPolicy<1>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+  }
+  return launch_status();
+}
+
+int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const float* max_partials,
+                   float* max_out, uint64_t* tile_sums, gjx_stream s) {
+  if (!cfg_ok(cfg) || !logw_local || !max_partials || !max_out || !tile_sums) return GJX_ERR_INVALID;
+  const uint64_t nt_total = ntiles_of(cfg->n_total);
+  const uint64_t nt_local = ntiles_of(cfg->n_local);
+  k_tile_sums<<<(unsigned)nt_local, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total,
+                                                       frac_bits(cfg->n_total),
+                                                       tile_sums + cfg->first_slot / kTile, max_out);
+  return launch_status();
+}
+
+int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
+                   gjx_stream s) {
+  if (!cfg_ok(cfg) || !tile_sums || !q_out) return GJX_ERR_INVALID;
+  k_reduce_sum<<<1, kBlock, 0, S(s)>>>(tile_sums, ntiles_of(cfg->n_total), q_out, 0, nullptr, 0, nullptr, nullptr);
+  return launch_status();
+}
+
+}  // extern "C"
+
+template <class StateT, class StepA>
+static int smc_run(const gjx_smc_config* cfg, const void* model, float* out_max, uint64_t* out_q,
+                   StateT* state_out, float* logw_out, int32_t* ancestors_out, void* ws,
+                   size_t ws_bytes, gjx_stream s, StepA step_a) {
+  if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !model || !out_max ||
+      !out_q || !state_out || !logw_out)
+    return GJX_ERR_INVALID;
+  const uint64_t N = cfg->n_total, nt = ntiles_of(N);
+  Carver cv{(char*)ws, ws ? ws_bytes : 0};
+  StateT* st_ws = cv.take<StateT>(N);
+  float* lw_ws = cv.take<float>(N);
+  float* mp = cv.take<float>(nt);
+  uint64_t* tiles = cv.take<uint64_t>(nt);
+  if (!cv.ok) return GJX_ERR_WORKSPACE;
+  // ping-pong so that the last step lands in the caller's output buffers
+  StateT* stb[2];
+  float* lwb[2];
+  const int last = (cfg->n_steps - 1) & 1;
+  stb[last] = state_out; stb[last ^ 1] = st_ws;
+  lwb[last] = logw_out; lwb[last ^ 1] = lw_ws;
+  for (int t = 0; t < cfg->n_steps; ++t) {
+    const int cur = t & 1, prv = cur ^ 1;
+    int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * N : nullptr;
+    int rc = step_a(t, stb[prv], lwb[prv], t ? out_max + (t - 1) : nullptr, tiles,
+                    t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur], mp, anc_t);
+    if (rc) return rc;
+    rc = gjx_smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s);
+    if (rc) return rc;
+  }
+  return gjx_smc_finish(cfg, tiles, out_q + (cfg->n_steps - 1), s);
+}
+
+extern "C" {
+
+int gjx_smc_run_lgssm(const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y_host,
+                      float* out_max, uint64_t* out_q, float* state_out, float* logw_out,
+                      int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s) {
+  if (!y_host) return GJX_ERR_INVALID;
+  auto step = [&](int t, const float* ps, const float* pl, const float* pm, const uint64_t* tiles,
+                  uint64_t* pq, float* so, float* lo, float* mp, int32_t* anc) {
+    return gjx_smc_lgssm_step_a(cfg, model, t, y_host[t], ps, pl, pm, tiles, pq, so, lo, mp, anc, s);
+  };
+  return smc_run<float>(cfg, model, out_max, out_q, state_out, logw_out, ancestors_out, ws, ws_bytes,
+                        s, step);
+}
+
+int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32_t* y_host,
+                    float* out_max, uint64_t* out_q, int32_t* state_out, float* logw_out,
+                    int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s) {
+  if (!y_host || !model || model->n_states <= 0 || model->n_states > 256) return GJX_ERR_INVALID;
+  // tables live at the tail of the workspace
+  const size_t kk = (size_t)model->n_states * (size_t)model->n_states;
+  const size_t tail = 2 * pad256(kk * 4);
+  if (!ws || ws_bytes < tail) return GJX_ERR_WORKSPACE;
+  char* tail_p = (char*)ws + (ws_bytes - tail);
+  tail_p = (char*)(((uintptr_t)tail_p) & ~(uintptr_t)255);
+  uint32_t* tcdf = (uint32_t*)tail_p;
+  float* ologp = (float*)(tail_p + pad256(kk * 4));
+  if ((char*)ologp + kk * 4 > (char*)ws + ws_bytes) return GJX_ERR_WORKSPACE;
+  int rc = gjx_hmm_prepare(model, tcdf, ologp, s);
+  if (rc) return rc;
+  const size_t head_bytes = (size_t)(tail_p - (char*)ws);
+  auto step = [&](int t, const int32_t* ps, const float* pl, const float* pm, const uint64_t* tiles,
+                  uint64_t* pq, int32_t* so, float* lo, float* mp, int32_t* anc) {
+    return gjx_smc_hmm_step_a(cfg, model, t, y_host[t], ps, pl, pm, tiles, pq, tcdf, ologp, so, lo, mp, anc, s);
+  };
+  return smc_run<int32_t>(cfg, model, out_max, out_q, state_out, logw_out, ancestors_out, ws,
+                          head_bytes, s, step);
+}
+
+}  // extern "C"

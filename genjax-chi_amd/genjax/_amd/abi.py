@@ -1,0 +1,222 @@
+"""ctypes binding of include/gjx.h — the thin C-ABI layer between the Python host API and the
+hand-written HIP kernels (libgjx_hip.so).
+
+This module only declares structs/prototypes and checks status codes.  It never picks a library
+by itself: `runtime.py` loads `lib/libgjx_hip.so` and fails loudly if it is missing.  (The test
+suite loads the CPU oracle through the same class to drive the identical host logic on CPU
+tensors; the product never does.)
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+c_u32p = C.POINTER(C.c_uint32)
+c_u64p = C.POINTER(C.c_uint64)
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u8p = C.POINTER(C.c_uint8)
+
+GJX_OK = 0
+STATUS = {
+    0: "GJX_OK",
+    -1: "GJX_ERR_INVALID",
+    -2: "GJX_ERR_UNSUPPORTED",
+    -3: "GJX_ERR_WORKSPACE",
+    -4: "GJX_ERR_LAUNCH",
+    -5: "GJX_ERR_NO_DEVICE",
+}
+
+RNG_THREEFRY = 0
+RNG_PHILOX = 1
+
+DIST_NORMAL, DIST_GAMMA, DIST_BETA, DIST_BERNOULLI, DIST_CATEGORICAL = range(5)
+ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE = range(4)
+OP_LOGSUMEXP, OP_CATEGORICAL_INDEX, OP_RESAMPLE, OP_SMC = range(4)
+MAX_SITES = 64
+
+
+class GjxError(RuntimeError):
+    def __init__(self, fn: str, code: int):
+        super().__init__(f"{fn} failed: {STATUS.get(code, code)}")
+        self.code = code
+
+
+class Keys(C.Structure):
+    _fields_ = [
+        ("impl", C.c_int32),
+        ("mode", C.c_int32),
+        ("keys", C.c_void_p),
+        ("parent", C.c_uint32 * 2),
+        ("first", C.c_uint64),
+        ("has_fold", C.c_int32),
+        ("fold", C.c_uint32),
+    ]
+
+
+class F32(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("scalar", C.c_float)]
+
+
+class Arg(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("ref", C.c_int32),
+        ("scale", C.c_float),
+        ("offset", C.c_float),
+        ("table", C.c_void_p),
+    ]
+
+
+class Site(C.Structure):
+    _fields_ = [
+        ("dist", C.c_int32),
+        ("observed", C.c_int32),
+        ("out_col", C.c_int32),
+        ("n_cat", C.c_int32),
+        ("n_rows", C.c_int32),
+        ("cat_mode", C.c_int32),
+        ("arg", Arg * 2),
+        ("obs", Arg),
+        ("logits", C.c_void_p),
+    ]
+
+
+class Lgssm(C.Structure):
+    _fields_ = [
+        ("x0_loc", C.c_float),
+        ("x0_scale", C.c_float),
+        ("a", C.c_float),
+        ("q", C.c_float),
+        ("r", C.c_float),
+    ]
+
+
+class Hmm(C.Structure):
+    _fields_ = [
+        ("n_states", C.c_int32),
+        ("init_state", C.c_int32),
+        ("trans_logits", C.c_void_p),
+        ("obs_logits", C.c_void_p),
+    ]
+
+
+class SmcConfig(C.Structure):
+    _fields_ = [
+        ("impl", C.c_int32),
+        ("n_total", C.c_uint64),
+        ("first_slot", C.c_uint64),
+        ("n_local", C.c_uint64),
+        ("n_steps", C.c_int32),
+        ("step_keys", C.c_void_p),
+        ("resample_keys", C.c_void_p),
+    ]
+
+
+_P = C.c_void_p
+_KP = C.POINTER(Keys)
+
+# name -> (restype, argtypes).  Every symbol include/gjx.h declares must be listed here;
+# tests/test_abi_symbols.py cross-checks the header against this table and the built .so.
+PROTOTYPES = {
+    "gjx_version": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gjx_backend_name": (C.c_char_p, []),
+    "gjx_rng_keys": (C.c_int, [_KP, C.c_uint64, _P, _P]),
+    "gjx_rng_bits": (C.c_int, [_KP, C.c_uint32, C.c_uint64, _P, _P]),
+    "gjx_sample_logpdf_normal": (C.c_int, [_KP, F32, F32, _P, _P, C.c_uint64, _P]),
+    "gjx_sample_logpdf_gamma": (C.c_int, [_KP, F32, F32, _P, _P, C.c_uint64, _P]),
+    "gjx_sample_logpdf_beta": (C.c_int, [_KP, F32, F32, _P, _P, C.c_uint64, _P]),
+    "gjx_sample_logpdf_bernoulli": (C.c_int, [_KP, F32, _P, _P, C.c_uint64, _P]),
+    "gjx_sample_logpdf_categorical": (
+        C.c_int,
+        [_KP, _P, C.c_uint64, C.c_uint32, _P, C.c_int, _P, _P, C.c_uint64, _P],
+    ),
+    "gjx_logpdf_normal": (C.c_int, [F32, F32, F32, _P, C.c_uint64, _P]),
+    "gjx_logpdf_gamma": (C.c_int, [F32, F32, F32, _P, C.c_uint64, _P]),
+    "gjx_logpdf_beta": (C.c_int, [F32, F32, F32, _P, C.c_uint64, _P]),
+    "gjx_logpdf_bernoulli": (C.c_int, [_P, C.c_int, F32, _P, C.c_uint64, _P]),
+    "gjx_logpdf_categorical": (
+        C.c_int,
+        [_P, C.c_int, _P, C.c_uint64, C.c_uint32, _P, _P, C.c_uint64, _P],
+    ),
+    "gjx_plan_create": (C.c_int, [C.POINTER(Site), C.c_int, C.POINTER(_P)]),
+    "gjx_plan_destroy": (C.c_int, [_P]),
+    "gjx_importance_run": (
+        C.c_int,
+        [_P, _KP, C.POINTER(_P), C.c_int, C.POINTER(_P), C.c_int, _P, _P, C.c_uint64, _P, _P],
+    ),
+    "gjx_workspace_bytes": (C.c_size_t, [C.c_int, C.c_uint64]),
+    "gjx_frac_bits": (C.c_int, [C.c_uint64]),
+    "gjx_num_tiles": (C.c_uint64, [C.c_uint64]),
+    "gjx_max_f32": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.c_size_t, _P]),
+    "gjx_expsum_fix": (C.c_int, [_P, C.c_uint64, _P, C.c_int, _P, _P, C.c_size_t, _P]),
+    "gjx_lse_finish": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "gjx_logsumexp_f32": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "gjx_categorical_index": (C.c_int, [_KP, _P, C.c_uint64, _P, C.c_int, _P, C.c_size_t, _P]),
+    "gjx_resample_systematic": (
+        C.c_int,
+        [_KP, _P, C.c_uint64, C.c_uint64, _P, _P, _P, _P, C.c_size_t, _P],
+    ),
+    "gjx_resample_multinomial": (
+        C.c_int,
+        [_KP, _P, C.c_uint64, C.c_uint64, _P, _P, _P, _P, C.c_size_t, _P],
+    ),
+    "gjx_gather_cols": (C.c_int, [_P, C.c_uint64, C.POINTER(_P), C.POINTER(_P), C.c_int, _P]),
+    "gjx_smc_tile": (C.c_uint64, []),
+    "gjx_smc_run_lgssm": (
+        C.c_int,
+        [C.POINTER(SmcConfig), C.POINTER(Lgssm), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
+    ),
+    "gjx_smc_run_hmm": (
+        C.c_int,
+        [C.POINTER(SmcConfig), C.POINTER(Hmm), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
+    ),
+    "gjx_smc_lgssm_step_a": (
+        C.c_int,
+        [C.POINTER(SmcConfig), C.POINTER(Lgssm), C.c_int, C.c_float] + [_P] * 10,
+    ),
+    "gjx_smc_hmm_step_a": (
+        C.c_int,
+        [C.POINTER(SmcConfig), C.POINTER(Hmm), C.c_int, C.c_int32] + [_P] * 12,
+    ),
+    "gjx_smc_step_b": (C.c_int, [C.POINTER(SmcConfig), _P, _P, _P, _P, _P]),
+    "gjx_smc_finish": (C.c_int, [C.POINTER(SmcConfig), _P, _P, _P]),
+    "gjx_hmm_prepare": (C.c_int, [C.POINTER(Hmm), _P, _P, _P]),
+}
+
+_NO_STATUS = {
+    "gjx_backend_name",
+    "gjx_workspace_bytes",
+    "gjx_frac_bits",
+    "gjx_smc_tile",
+    "gjx_num_tiles",
+}
+
+
+class GjxLib:
+    """A loaded implementation of include/gjx.h.  `device_type` is the torch device type whose
+    memory the library's "dev" pointers refer to ("cuda" for libgjx_hip.so)."""
+
+    def __init__(self, path: str, device_type: str):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.path = path
+        self.device_type = device_type
+        self._dll = C.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(self._dll, name)  # AttributeError => ABI symbol missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, "_" + name, fn)
+        major, minor = C.c_int(), C.c_int()
+        self.call("gjx_version", C.byref(major), C.byref(minor))
+        self.version = (major.value, minor.value)
+        self.name = self._gjx_backend_name().decode()
+
+    def call(self, name: str, *args):
+        rc = getattr(self, "_" + name)(*args)
+        if name not in _NO_STATUS and rc != GJX_OK:
+            raise GjxError(name, rc)
+        return rc

@@ -1,0 +1,349 @@
+"""Tensor-level wrappers over the C-ABI (include/gjx.h).
+
+`Ops` owns a loaded `GjxLib` and turns torch tensors into raw pointers + sizes.  torch is only the
+device-memory holder and stream provider here; all arithmetic happens inside the library.  Every
+method checks that its tensors live on the library's device type, are contiguous and have the
+dtype the ABI documents — operand shapes are validated on the host before any kernel launches.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import abi
+from .abi import GjxLib, Keys, F32
+
+
+@dataclass(frozen=True)
+class KeyBatch:
+    """Host-side description of `n` per-particle keys (mirrors gjx_keys)."""
+
+    impl: int
+    mode: int  # 0 explicit tensor [n,2] (int32 view of u32), 1 lazy split, 2 literal
+    tensor: torch.Tensor | None = None
+    parent: tuple[int, int] = (0, 0)
+    first: int = 0
+    fold: int | None = None
+
+    def with_fold(self, fold: int) -> "KeyBatch":
+        if self.fold is not None:
+            raise ValueError("key batch already carries a fold")
+        return KeyBatch(self.impl, self.mode, self.tensor, self.parent, self.first, int(fold))
+
+
+class Ops:
+    def __init__(self, lib: GjxLib):
+        self.lib = lib
+        self.device_type = lib.device_type
+        self.tile = int(lib.call("gjx_smc_tile"))
+        self._ws: dict = {}
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def device(self) -> torch.device:
+        if self.device_type == "cuda":
+            return torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")
+
+    def stream(self):
+        if self.device_type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(0)
+
+    def _chk(self, t: torch.Tensor, dtype, n: int | None = None, name: str = "tensor"):
+        if t.device.type != self.device_type:
+            raise ValueError(f"{name}: expected a {self.device_type} tensor, got {t.device}")
+        if t.dtype != dtype:
+            raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+        if not t.is_contiguous():
+            raise ValueError(f"{name}: must be contiguous")
+        if n is not None and t.numel() != n:
+            raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
+        return C.c_void_p(t.data_ptr())
+
+    def empty(self, n, dtype):
+        return torch.empty(n, dtype=dtype, device=self.device())
+
+    def workspace(self, op: int, n: int) -> tuple[torch.Tensor, int]:
+        nbytes = int(self.lib.call("gjx_workspace_bytes", op, n))
+        key = (op, str(self.device()))
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(nbytes, 1024), dtype=torch.uint8, device=self.device())
+            self._ws[key] = ws
+        return ws, nbytes
+
+    def _keys(self, kb: KeyBatch, n: int) -> Keys:
+        k = Keys()
+        k.impl = kb.impl
+        k.mode = kb.mode
+        if kb.mode == 0:
+            assert kb.tensor is not None
+            k.keys = self._chk(kb.tensor, torch.int32, 2 * n, "keys").value
+        else:
+            k.keys = None
+            k.parent[0], k.parent[1] = kb.parent
+            k.first = kb.first
+        k.has_fold = 0 if kb.fold is None else 1
+        k.fold = 0 if kb.fold is None else kb.fold & 0xFFFFFFFF
+        return k
+
+    def _f32(self, v, n: int, name: str) -> F32:
+        if isinstance(v, torch.Tensor):
+            if v.numel() == 1 and v.dim() == 0:
+                return F32(None, float(v))
+            return F32(self._chk(v, torch.float32, n, name).value, 0.0)
+        return F32(None, float(v))
+
+    def num_tiles(self, n: int) -> int:
+        return int(self.lib.call("gjx_num_tiles", n))
+
+    def frac_bits(self, n_total: int) -> int:
+        return int(self.lib.call("gjx_frac_bits", n_total))
+
+    # ---- RNG --------------------------------------------------------------------------------
+    def rng_keys(self, kb: KeyBatch, n: int) -> torch.Tensor:
+        out = self.empty((n, 2), torch.int32)
+        self.lib.call("gjx_rng_keys", C.byref(self._keys(kb, n)), n, C.c_void_p(out.data_ptr()), self.stream())
+        return out
+
+    def rng_bits(self, kb: KeyBatch, n: int, sub: int = 0) -> torch.Tensor:
+        out = self.empty(n, torch.int32)
+        self.lib.call("gjx_rng_bits", C.byref(self._keys(kb, n)), sub, n, C.c_void_p(out.data_ptr()), self.stream())
+        return out
+
+    # ---- distributions ------------------------------------------------------------------------
+    def sample_logpdf(self, dist: str, kb: KeyBatch, n: int, a, b=None, want_score=True):
+        score = self.empty(n, torch.float32) if want_score else None
+        sp = C.c_void_p(score.data_ptr()) if want_score else None
+        k = C.byref(self._keys(kb, n))
+        if dist in ("normal", "gamma", "beta"):
+            val = self.empty(n, torch.float32)
+            self.lib.call(f"gjx_sample_logpdf_{dist}", k, self._f32(a, n, "arg0"), self._f32(b, n, "arg1"),
+                          C.c_void_p(val.data_ptr()), sp, n, self.stream())
+        elif dist == "bernoulli":
+            val = self.empty(n, torch.uint8)
+            self.lib.call("gjx_sample_logpdf_bernoulli", k, self._f32(a, n, "probs"),
+                          C.c_void_p(val.data_ptr()), sp, n, self.stream())
+        else:
+            raise ValueError(dist)
+        return val, score
+
+    def sample_logpdf_categorical(self, kb: KeyBatch, n: int, logits: torch.Tensor, row_index=None,
+                                  mode: int = 1, want_score=True):
+        if logits.dim() != 2:
+            raise ValueError("logits must be [n_rows, n_cat]")
+        n_rows, n_cat = logits.shape
+        if row_index is None and n_rows not in (1, n):
+            raise ValueError("logits rows must be 1 or n when no row_index is given")
+        lp = self._chk(logits, torch.float32, name="logits")
+        rp = None if row_index is None else self._chk(row_index, torch.int32, n, "row_index")
+        val = self.empty(n, torch.int32)
+        score = self.empty(n, torch.float32) if want_score else None
+        self.lib.call("gjx_sample_logpdf_categorical", C.byref(self._keys(kb, n)), lp, n_rows, n_cat, rp, mode,
+                      C.c_void_p(val.data_ptr()), C.c_void_p(score.data_ptr()) if want_score else None, n,
+                      self.stream())
+        return val, score
+
+    def logpdf(self, dist: str, n: int, value, a, b=None) -> torch.Tensor:
+        score = self.empty(n, torch.float32)
+        sp = C.c_void_p(score.data_ptr())
+        if dist in ("normal", "gamma", "beta"):
+            self.lib.call(f"gjx_logpdf_{dist}", self._f32(value, n, "value"), self._f32(a, n, "arg0"),
+                          self._f32(b, n, "arg1"), sp, n, self.stream())
+        elif dist == "bernoulli":
+            if isinstance(value, torch.Tensor) and value.numel() > 1:
+                vp, vs = self._chk(value, torch.uint8, n, "value"), 0
+            else:
+                vp, vs = None, int(bool(value))
+            self.lib.call("gjx_logpdf_bernoulli", vp, vs, self._f32(a, n, "probs"), sp, n, self.stream())
+        else:
+            raise ValueError(dist)
+        return score
+
+    def logpdf_categorical(self, n: int, value, logits: torch.Tensor, row_index=None) -> torch.Tensor:
+        n_rows, n_cat = logits.shape
+        if row_index is None and n_rows not in (1, n):
+            raise ValueError("logits rows must be 1 or n when no row_index is given")
+        score = self.empty(n, torch.float32)
+        if isinstance(value, torch.Tensor) and value.numel() > 1:
+            vp, vs = self._chk(value, torch.int32, n, "value"), 0
+        else:
+            vp, vs = None, int(value)
+        rp = None if row_index is None else self._chk(row_index, torch.int32, n, "row_index")
+        self.lib.call("gjx_logpdf_categorical", vp, vs, self._chk(logits, torch.float32, name="logits"), n_rows,
+                      n_cat, rp, C.c_void_p(score.data_ptr()), n, self.stream())
+        return score
+
+    # ---- plans ----------------------------------------------------------------------------------
+    def plan_create(self, sites: list[abi.Site]) -> "Plan":
+        arr = (abi.Site * len(sites))(*sites)
+        handle = C.c_void_p()
+        self.lib.call("gjx_plan_create", arr, len(sites), C.byref(handle))
+        return Plan(self, handle, len(sites))
+
+    def importance_run(self, plan: "Plan", kb: KeyBatch, n: int, input_cols: list[torch.Tensor],
+                       value_dtypes: list, want_score=True, want_max_partials=True):
+        if kb.fold is not None:
+            raise ValueError("particle keys must not carry a fold")
+        ins = (C.c_void_p * max(1, len(input_cols)))()
+        for i, t in enumerate(input_cols):
+            ins[i] = self._chk(t, torch.float32, n, f"input_cols[{i}]").value
+        vals = [self.empty(n, dt) for dt in value_dtypes]
+        outs = (C.c_void_p * max(1, len(vals)))()
+        for i, t in enumerate(vals):
+            outs[i] = t.data_ptr()
+        score = self.empty(n, torch.float32) if want_score else None
+        logw = self.empty(n, torch.float32)
+        mp = self.empty(self.num_tiles(n), torch.float32) if want_max_partials else None
+        self.lib.call("gjx_importance_run", plan.handle, C.byref(self._keys(kb, n)), ins, len(input_cols), outs,
+                      len(vals), C.c_void_p(score.data_ptr()) if want_score else None,
+                      C.c_void_p(logw.data_ptr()), n, C.c_void_p(mp.data_ptr()) if mp is not None else None,
+                      self.stream())
+        return vals, score, logw, mp
+
+    # ---- weights --------------------------------------------------------------------------------
+    def max_f32(self, x: torch.Tensor | None, n: int, max_partials=None) -> torch.Tensor:
+        out = self.empty(1, torch.float32)
+        ws, nb = self.workspace(abi.OP_LOGSUMEXP, n)
+        self.lib.call("gjx_max_f32", None if x is None else self._chk(x, torch.float32, n, "x"), n,
+                      None if max_partials is None else self._chk(max_partials, torch.float32, self.num_tiles(n)),
+                      C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), nb, self.stream())
+        return out
+
+    def expsum_fix(self, x: torch.Tensor, max_dev: torch.Tensor, frac: int) -> torch.Tensor:
+        n = x.numel()
+        out = self.empty(1, torch.int64)
+        ws, nb = self.workspace(abi.OP_LOGSUMEXP, n)
+        self.lib.call("gjx_expsum_fix", self._chk(x, torch.float32, n, "x"), n,
+                      self._chk(max_dev, torch.float32, 1, "max"), frac, C.c_void_p(out.data_ptr()),
+                      C.c_void_p(ws.data_ptr()), nb, self.stream())
+        return out
+
+    def lse_finish(self, max_dev: torch.Tensor, q_dev: torch.Tensor, frac: int) -> torch.Tensor:
+        out = self.empty(1, torch.float32)
+        self.lib.call("gjx_lse_finish", self._chk(max_dev, torch.float32, 1), self._chk(q_dev, torch.int64, 1),
+                      frac, C.c_void_p(out.data_ptr()), self.stream())
+        return out
+
+    def logsumexp(self, x: torch.Tensor, max_partials=None):
+        """-> (lse f32[1], max f32[1], q i64[1]) on device."""
+        n = x.numel()
+        lse, m, q = self.empty(1, torch.float32), self.empty(1, torch.float32), self.empty(1, torch.int64)
+        ws, nb = self.workspace(abi.OP_LOGSUMEXP, n)
+        self.lib.call("gjx_logsumexp_f32", self._chk(x, torch.float32, n, "x"), n,
+                      None if max_partials is None else self._chk(max_partials, torch.float32, self.num_tiles(n)),
+                      C.c_void_p(lse.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(q.data_ptr()),
+                      C.c_void_p(ws.data_ptr()), nb, self.stream())
+        return lse, m, q
+
+    def categorical_index(self, kb: KeyBatch, logits: torch.Tensor, mode: int = 0) -> torch.Tensor:
+        n = logits.numel()
+        out = self.empty(1, torch.int64)
+        ws, nb = self.workspace(abi.OP_CATEGORICAL_INDEX, n)
+        self.lib.call("gjx_categorical_index", C.byref(self._keys(kb, 1)), self._chk(logits, torch.float32, n), n,
+                      C.c_void_p(out.data_ptr()), mode, C.c_void_p(ws.data_ptr()), nb, self.stream())
+        return out
+
+    def resample(self, kind: str, kb: KeyBatch, logw: torch.Tensor, n_out: int | None = None):
+        """-> (ancestors int32[n_out], max f32[1], q i64[1])."""
+        n = logw.numel()
+        n_out = n if n_out is None else n_out
+        anc = self.empty(n_out, torch.int32)
+        m, q = self.empty(1, torch.float32), self.empty(1, torch.int64)
+        ws, nb = self.workspace(abi.OP_RESAMPLE, max(n, n_out))
+        self.lib.call(f"gjx_resample_{kind}", C.byref(self._keys(kb, 1)), self._chk(logw, torch.float32, n), n,
+                      n_out, C.c_void_p(anc.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(q.data_ptr()),
+                      C.c_void_p(ws.data_ptr()), nb, self.stream())
+        return anc, m, q
+
+    def gather_cols(self, ancestors: torch.Tensor, cols: list[torch.Tensor]) -> list[torch.Tensor]:
+        n_out = ancestors.numel()
+        self._chk(ancestors, torch.int32, name="ancestors")
+        src = (C.c_void_p * max(1, len(cols)))()
+        dst = (C.c_void_p * max(1, len(cols)))()
+        outs = []
+        for i, c in enumerate(cols):
+            if c.element_size() != 4 or c.dim() != 1 or not c.is_contiguous() or c.device.type != self.device_type:
+                raise ValueError("gather_cols: columns must be contiguous 1-D 4-byte tensors on the device")
+            o = torch.empty(n_out, dtype=c.dtype, device=c.device)
+            src[i], dst[i] = c.data_ptr(), o.data_ptr()
+            outs.append(o)
+        self.lib.call("gjx_gather_cols", C.c_void_p(ancestors.data_ptr()), n_out, src, dst, len(cols), self.stream())
+        return outs
+
+    # ---- fused SMC --------------------------------------------------------------------------------
+    def _smc_cfg(self, impl, n_total, first, n_local, step_keys, resample_keys):
+        import numpy as np
+
+        T = len(step_keys)
+        sk = np.ascontiguousarray(np.asarray(step_keys, dtype=np.uint32).reshape(T, 2))
+        rk = np.ascontiguousarray(np.asarray(resample_keys, dtype=np.uint32).reshape(T, 2))
+        cfg = abi.SmcConfig()
+        cfg.impl, cfg.n_total, cfg.first_slot, cfg.n_local, cfg.n_steps = impl, n_total, first, n_local, T
+        cfg.step_keys, cfg.resample_keys = sk.ctypes.data, rk.ctypes.data
+        cfg._keep = (sk, rk)  # keep host arrays alive
+        return cfg
+
+    def smc_run_lgssm(self, impl, n, step_keys, resample_keys, model: abi.Lgssm, y, want_ancestors=False):
+        import numpy as np
+
+        T = len(step_keys)
+        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys)
+        yh = np.ascontiguousarray(np.asarray(y, dtype=np.float32))
+        assert yh.size == T
+        out_max, out_q = self.empty(T, torch.float32), self.empty(T, torch.int64)
+        state, logw = self.empty(n, torch.float32), self.empty(n, torch.float32)
+        anc = self.empty((T, n), torch.int32) if want_ancestors else None
+        ws, nb = self.workspace(abi.OP_SMC, n)
+        self.lib.call("gjx_smc_run_lgssm", C.byref(cfg), C.byref(model), C.c_void_p(yh.ctypes.data),
+                      C.c_void_p(out_max.data_ptr()), C.c_void_p(out_q.data_ptr()), C.c_void_p(state.data_ptr()),
+                      C.c_void_p(logw.data_ptr()), C.c_void_p(anc.data_ptr()) if anc is not None else None,
+                      C.c_void_p(ws.data_ptr()), nb, self.stream())
+        return out_max, out_q, state, logw, anc
+
+    def smc_run_hmm(self, impl, n, step_keys, resample_keys, n_states, init_state, trans_logits, obs_logits, y,
+                    want_ancestors=False):
+        import numpy as np
+
+        T = len(step_keys)
+        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys)
+        yh = np.ascontiguousarray(np.asarray(y, dtype=np.int32))
+        assert yh.size == T
+        mdl = abi.Hmm()
+        mdl.n_states, mdl.init_state = n_states, init_state
+        mdl.trans_logits = self._chk(trans_logits, torch.float32, n_states * n_states).value
+        mdl.obs_logits = self._chk(obs_logits, torch.float32, n_states * n_states).value
+        out_max, out_q = self.empty(T, torch.float32), self.empty(T, torch.int64)
+        state, logw = self.empty(n, torch.int32), self.empty(n, torch.float32)
+        anc = self.empty((T, n), torch.int32) if want_ancestors else None
+        ws, nb = self.workspace(abi.OP_SMC, n)
+        self.lib.call("gjx_smc_run_hmm", C.byref(cfg), C.byref(mdl), C.c_void_p(yh.ctypes.data),
+                      C.c_void_p(out_max.data_ptr()), C.c_void_p(out_q.data_ptr()), C.c_void_p(state.data_ptr()),
+                      C.c_void_p(logw.data_ptr()), C.c_void_p(anc.data_ptr()) if anc is not None else None,
+                      C.c_void_p(ws.data_ptr()), nb, self.stream())
+        return out_max, out_q, state, logw, anc
+
+    def log_z_from_pairs(self, out_max: torch.Tensor, out_q: torch.Tensor, n_total: int) -> float:
+        """log Z = sum_t (max_t + log(q_t 2^-frac) - log N), evaluated in float64 on the host from
+        the exact per-step (max, fixed-point sum) pairs."""
+        frac = self.frac_bits(n_total)
+        m = out_max.detach().cpu().double()
+        q = out_q.detach().cpu().double()
+        return float((m + torch.log(q) - frac * math.log(2.0) - math.log(n_total)).sum())
+
+
+class Plan:
+    def __init__(self, ops: Ops, handle, n_sites: int):
+        self.ops, self.handle, self.n_sites = ops, handle, n_sites
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.ops.lib.call("gjx_plan_destroy", self.handle)
+                self.handle = None
+        except Exception:
+            pass

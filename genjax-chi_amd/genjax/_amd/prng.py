@@ -1,0 +1,114 @@
+"""Host side of the counter-based PRNG: scalar keys are plain Python integers and are derived on
+the host (a few cipher blocks); batches of per-particle keys stay *lazy* — `split(key, n)` with a
+large n returns a `KeyBatch` describing `split(key, *)[first + i]`, and the kernels derive each
+particle's key in registers instead of reading n×8 bytes of keys from HBM.
+
+Derivation semantics:
+  impl="threefry"  jax.random's Threefry2x32 key tree with jax_threefry_partitionable
+                   (reference call sites: inference/smc.py:154,171,299-300; static.py:349-352;
+                   scan.py:267-268).
+  impl="philox"    native Philox4x32-10 counter scheme.
+The scalar ciphers below restate Salmon et al. (SC'11) and are checked against the Random123
+known-answer vectors in tests/test_prng_host.py.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+from .ops import KeyBatch
+
+M32 = 0xFFFFFFFF
+THREEFRY, PHILOX = 0, 1
+_IMPL = {"threefry": THREEFRY, "philox": PHILOX, THREEFRY: THREEFRY, PHILOX: PHILOX}
+TAG_SPLIT, TAG_FOLD, TAG_BITS = 0x53504C54, 0x464F4C44, 0x42495453
+
+_default_impl = THREEFRY
+
+
+def set_default_impl(impl) -> None:
+    global _default_impl
+    _default_impl = _IMPL[impl]
+
+
+def _rotl(x, r):
+    return ((x << r) | (x >> (32 - r))) & M32
+
+
+def threefry2x32(k0, k1, c0, c1):
+    rot = ((13, 15, 26, 6), (17, 29, 16, 24))
+    ks = (k0, k1, 0x1BD11BDA ^ k0 ^ k1)
+    x0, x1 = (c0 + ks[0]) & M32, (c1 + ks[1]) & M32
+    for blk in range(5):
+        for r in rot[blk & 1]:
+            x0 = (x0 + x1) & M32
+            x1 = _rotl(x1, r) ^ x0
+        x0 = (x0 + ks[(blk + 1) % 3]) & M32
+        x1 = (x1 + ks[(blk + 2) % 3] + blk + 1) & M32
+    return x0, x1
+
+
+def philox4x32(k0, k1, c0, c1, c2, c3):
+    for _ in range(10):
+        p0 = 0xD2511F53 * c0
+        p1 = 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = (p1 >> 32) ^ c1 ^ k0, p1 & M32, (p0 >> 32) ^ c3 ^ k1, p0 & M32
+        k0 = (k0 + 0x9E3779B9) & M32
+        k1 = (k1 + 0xBB67AE85) & M32
+    return c0, c1, c2, c3
+
+
+@dataclass(frozen=True)
+class PRNGKey:
+    """A scalar key: two 32-bit words + the derivation scheme."""
+
+    k0: int
+    k1: int
+    impl: int = THREEFRY
+
+    def words(self) -> tuple[int, int]:
+        return (self.k0, self.k1)
+
+    def literal(self) -> KeyBatch:
+        """This key as a 1-element key batch (by value)."""
+        return KeyBatch(self.impl, 2, parent=(self.k0, self.k1))
+
+    def __repr__(self):
+        return f"PRNGKey({self.k0:#010x}, {self.k1:#010x}, {'threefry' if self.impl == 0 else 'philox'})"
+
+
+def key(seed: int, impl=None) -> PRNGKey:
+    """jax.random.key(seed): key words (seed >> 32, seed & 0xffffffff)."""
+    impl = _default_impl if impl is None else _IMPL[impl]
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    return PRNGKey((seed >> 32) & M32, seed & M32, impl)
+
+
+PRNGKeyLike = PRNGKey
+
+
+def split_at(k: PRNGKey, i: int) -> PRNGKey:
+    if k.impl == THREEFRY:
+        o0, o1 = threefry2x32(k.k0, k.k1, (i >> 32) & M32, i & M32)
+    else:
+        o0, o1, _, _ = philox4x32(k.k0, k.k1, i & M32, (i >> 32) & M32, 0, TAG_SPLIT)
+    return PRNGKey(o0, o1, k.impl)
+
+
+def split(k: PRNGKey, num: int = 2):
+    """jax.random.split for a scalar key -> tuple of scalar keys (host-derived)."""
+    return tuple(split_at(k, i) for i in range(num))
+
+
+def split_lazy(k: PRNGKey, n: int, first: int = 0) -> KeyBatch:
+    """split(k, n_total)[first : first + n] as a lazy per-particle key batch."""
+    return KeyBatch(k.impl, 1, parent=(k.k0, k.k1), first=first)
+
+
+def fold_in(k: PRNGKey, data: int) -> PRNGKey:
+    d = int(data) & M32
+    if k.impl == THREEFRY:
+        o0, o1 = threefry2x32(k.k0, k.k1, 0, d)
+    else:
+        o0, o1, _, _ = philox4x32(k.k0, k.k1, d, 0, 0, TAG_FOLD)
+    return PRNGKey(o0, o1, k.impl)

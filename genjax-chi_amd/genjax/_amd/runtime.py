@@ -1,0 +1,54 @@
+"""Backend selection: the product has exactly one compute backend, libgjx_hip.so on a gfx950 GPU.
+
+There is NO CPU fallback: if the HIP library is missing, fails to load, or no GPU is visible, the
+first compute call raises `BackendUnavailable`.  (Tests may install another `Ops` — e.g. one bound
+to the CPU oracle — with `use_ops()`; nothing in the package does.)
+"""
+
+from __future__ import annotations
+
+import contextlib
+import os
+
+from .abi import GjxLib
+from .ops import Ops
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libgjx_hip.so"))
+
+_current: Ops | None = None
+
+
+class BackendUnavailable(RuntimeError):
+    pass
+
+
+def load_hip_ops() -> Ops:
+    import torch
+
+    if not os.path.exists(HIP_LIB_PATH):
+        raise BackendUnavailable(
+            f"{HIP_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    if not torch.cuda.is_available():
+        raise BackendUnavailable("no ROCm GPU visible to torch; the genjax AMD backend needs an MI355X (gfx950)")
+    return Ops(GjxLib(HIP_LIB_PATH, "cuda"))
+
+
+def get_ops() -> Ops:
+    global _current
+    if _current is None:
+        _current = load_hip_ops()
+    return _current
+
+
+@contextlib.contextmanager
+def use_ops(ops: Ops):
+    """Temporarily install `ops` as the backend (test hook)."""
+    global _current
+    prev, _current = _current, ops
+    try:
+        yield ops
+    finally:
+        _current = prev

@@ -1,0 +1,236 @@
+"""The BASELINE.json workloads expressed directly on the C-ABI wrappers (`Ops`): synthetic inputs,
+key schedules, fused-kernel drivers and the closed-form log-Z each one is checked against.
+
+These are the fixed-structure fast paths the host API (`ImportanceK`, `BootstrapSMC`) lowers to;
+bench.py, __graft_entry__.smoke() and the parity tests call them with either backend.
+  C2  gaussian10_importance  ImportanceK on a 10-latent Gaussian model
+  C3  lgssm_smc              bootstrap SMC, linear-Gaussian state space (C3)
+  C5  hmm_smc                bootstrap SMC, 256-state HMM (C5; model shape exact_testbed.py:62-68)
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import abi, prng
+from .ops import Ops
+
+# ---------------------------------------------------------------------------------------------
+# C2: ImportanceK, z_i ~ N(0,1), y_i ~ N(z_i, 0.5), i < 10
+# ---------------------------------------------------------------------------------------------
+G10_LATENTS = 10
+G10_OBS_SCALE = 0.5
+
+
+def gaussian10_data():
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal(G10_LATENTS)
+    y = z + G10_OBS_SCALE * rng.standard_normal(G10_LATENTS)
+    return y.astype(np.float32)
+
+
+def gaussian10_exact_log_z(y=None) -> float:
+    y = gaussian10_data() if y is None else y
+    var = 1.0 + G10_OBS_SCALE**2
+    yd = y.astype(np.float64)
+    return float(np.sum(-0.5 * yd * yd / var - 0.5 * math.log(2 * math.pi * var)))
+
+
+def gaussian10_sites(y) -> list[abi.Site]:
+    """Site table of
+        @gen
+        def model():
+            for i in range(10):
+                z = normal(0.0, 1.0) @ f"z{i}"
+                normal(z, 0.5) @ f"y{i}"          # constrained to y[i]
+    in program order (static.py:349-352 numbers the sites 1..20)."""
+    sites = []
+    for i in range(G10_LATENTS):
+        z = abi.Site()
+        z.dist, z.observed, z.out_col = abi.DIST_NORMAL, 0, i
+        z.arg[0] = abi.Arg(abi.ARG_CONST, 0, 0.0, 0.0, None)
+        z.arg[1] = abi.Arg(abi.ARG_CONST, 0, 0.0, 1.0, None)
+        sites.append(z)
+        o = abi.Site()
+        o.dist, o.observed, o.out_col = abi.DIST_NORMAL, 1, -1
+        o.arg[0] = abi.Arg(abi.ARG_SITE, 2 * i, 1.0, 0.0, None)
+        o.arg[1] = abi.Arg(abi.ARG_CONST, 0, 0.0, G10_OBS_SCALE, None)
+        o.obs = abi.Arg(abi.ARG_CONST, 0, 0.0, float(y[i]), None)
+        sites.append(o)
+    return sites
+
+
+def importance_particle_keys(root: prng.PRNGKey, n_local: int, first: int = 0):
+    """Key tree of ImportanceK(...).log_marginal_likelihood_estimate(key):
+    (_, k1) = split(key) [smc.py:154]; (_, k2) = split(k1) [smc.py:299]; p_i = split(k2, N)[i]."""
+    k1 = prng.split(root)[1]
+    k2 = prng.split(k1)[1]
+    return prng.split_lazy(k2, n_local, first)
+
+
+class Gaussian10:
+    """Reusable state of the C2 workload (plan + key batch), so a bench step is kernels only."""
+
+    def __init__(self, ops: Ops, impl: int, seed: int, n_local: int, first: int = 0, n_total: int | None = None):
+        self.ops, self.n, self.first = ops, n_local, first
+        self.n_total = n_local if n_total is None else n_total
+        self.y = gaussian10_data()
+        self.plan = ops.plan_create(gaussian10_sites(self.y))
+        self.keys = importance_particle_keys(prng.key(seed, impl), n_local, first)
+        self.frac = ops.frac_bits(self.n_total)
+
+    def step(self):
+        """One ImportanceK pass on this rank: trace columns, score, log-weights and the local
+        (max, fixed-point sum) pair — all device tensors, no host sync."""
+        vals, score, logw, mp = self.ops.importance_run(
+            self.plan, self.keys, self.n, [], [torch.float32] * G10_LATENTS, want_score=True, want_max_partials=True
+        )
+        if self.n_total == self.n:
+            lse, m, q = self.ops.logsumexp(logw, max_partials=mp)
+            return dict(values=vals, score=score, logw=logw, lse=lse, max=m, q=q)
+        m = self.ops.max_f32(None, self.n, max_partials=mp)
+        return dict(values=vals, score=score, logw=logw, max=m, max_partials=mp)
+
+    def finish_distributed(self, out, global_max: torch.Tensor):
+        """Second half for the sharded run: local fixed-point sum under the all-reduced max."""
+        out["q"] = self.ops.expsum_fix(out["logw"], global_max, self.frac)
+        return out
+
+
+def gaussian10_importance(ops: Ops, impl: int, seed: int, n: int):
+    w = Gaussian10(ops, impl, seed, n)
+    out = w.step()
+    q, m = int(out["q"].cpu()), float(out["max"].cpu())
+    log_z = m + math.log(q) - w.frac * math.log(2.0) - math.log(n)
+    return dict(logw=out["logw"], score=out["score"], values=out["values"], q=q, max=m, lse=float(out["lse"].cpu()),
+                log_z=log_z, log_z_exact=gaussian10_exact_log_z(w.y))
+
+
+# ---------------------------------------------------------------------------------------------
+# C3: bootstrap SMC on x_0~N(0,1), x_t~N(0.9 x_{t-1}, 1), y_t~N(x_t, 0.5)
+# ---------------------------------------------------------------------------------------------
+LGSSM = dict(x0_loc=0.0, x0_scale=1.0, a=0.9, q=1.0, r=0.5)
+
+
+def lgssm_model() -> abi.Lgssm:
+    return abi.Lgssm(LGSSM["x0_loc"], LGSSM["x0_scale"], LGSSM["a"], LGSSM["q"], LGSSM["r"])
+
+
+def lgssm_data(T: int):
+    rng = np.random.default_rng(1)
+    x = np.empty(T)
+    y = np.empty(T)
+    for t in range(T):
+        x[t] = (LGSSM["x0_loc"] + LGSSM["x0_scale"] * rng.standard_normal()) if t == 0 else (
+            LGSSM["a"] * x[t - 1] + LGSSM["q"] * rng.standard_normal())
+        y[t] = x[t] + LGSSM["r"] * rng.standard_normal()
+    return y.astype(np.float32)
+
+
+def lgssm_exact_log_z(y) -> float:
+    """Scalar Kalman filter in float64."""
+    m, p = LGSSM["x0_loc"], LGSSM["x0_scale"] ** 2
+    ll = 0.0
+    for t, yt in enumerate(np.asarray(y, dtype=np.float64)):
+        if t > 0:
+            m, p = LGSSM["a"] * m, LGSSM["a"] ** 2 * p + LGSSM["q"] ** 2
+        s = p + LGSSM["r"] ** 2
+        ll += -0.5 * (yt - m) ** 2 / s - 0.5 * math.log(2 * math.pi * s)
+        k = p / s
+        m, p = m + k * (yt - m), (1 - k) * p
+    return ll
+
+
+def smc_key_schedule(root: prng.PRNGKey, T: int):
+    """step_keys[t], resample_keys[t] = split(root, 2T)[2t], [2t+1]."""
+    ks = prng.split(root, 2 * T)
+    return [k.words() for k in ks[0::2]], [k.words() for k in ks[1::2]]
+
+
+def lgssm_smc(ops: Ops, impl: int, seed: int, n: int, T: int, want_ancestors: bool = False):
+    y = lgssm_data(T)
+    sk, rk = smc_key_schedule(prng.key(seed, impl), T)
+    out_max, out_q, state, logw, anc = ops.smc_run_lgssm(impl, n, sk, rk, lgssm_model(), y, want_ancestors)
+    return dict(out_max=out_max, out_q=out_q, state=state, logw=logw, ancestors=anc,
+                log_z=ops.log_z_from_pairs(out_max, out_q, n), log_z_exact=lgssm_exact_log_z(y))
+
+
+# ---------------------------------------------------------------------------------------------
+# C5: HMM with circulant logits (construction of distributions/custom/discrete_hmm.py:42-86)
+# ---------------------------------------------------------------------------------------------
+def scaled_circulant(n: int, k: int, epsilon: float, delta: float) -> np.ndarray:
+    """Row-circulant matrix whose first column is eps^|i| within distance k of the diagonal
+    (wrapping) and -delta elsewhere — restated from the reference's description, float32."""
+    src = np.empty(n, dtype=np.float64)
+    for i in range(n):
+        if i <= k:
+            src[i] = epsilon ** abs(i)
+        elif i - n >= -k:
+            src[i] = epsilon ** abs(i - n)
+        else:
+            src[i] = -delta
+    idx = (np.arange(n)[:, None] - np.arange(n)[None, :]) % n  # scipy.linalg.circulant layout
+    return src[idx].astype(np.float32)
+
+
+HMM = dict(n_states=256, adjacency=8, sigma_trans=0.5, sigma_obs=0.5, init_state=128)
+
+
+def hmm_tables(n_states=None):
+    k = HMM["n_states"] if n_states is None else n_states
+    adj = min(HMM["adjacency"], max(1, k // 4))
+    trans = scaled_circulant(k, adj, HMM["sigma_trans"], 1.0 / HMM["sigma_trans"])
+    obs = scaled_circulant(k, adj, HMM["sigma_obs"], 1.0 / HMM["sigma_obs"])
+    return trans, obs
+
+
+def _softmax64(l):
+    l = l.astype(np.float64)
+    l = l - l.max(axis=1, keepdims=True)
+    p = np.exp(l)
+    return p / p.sum(axis=1, keepdims=True)
+
+
+def hmm_data(T: int, n_states=None, init_state=None):
+    trans, obs = hmm_tables(n_states)
+    k = trans.shape[0]
+    z = (HMM["init_state"] if init_state is None else init_state) % k
+    pt, po = _softmax64(trans), _softmax64(obs)
+    rng = np.random.default_rng(2)
+    ys = np.empty(T, dtype=np.int32)
+    for t in range(T):
+        z = rng.choice(k, p=pt[z])
+        ys[t] = rng.choice(k, p=po[z])
+    return ys
+
+
+def hmm_exact_log_z(y, n_states=None, init_state=None) -> float:
+    """Forward algorithm in float64 (the quantity discrete_hmm.py:118-143 computes)."""
+    trans, obs = hmm_tables(n_states)
+    k = trans.shape[0]
+    pt, po = _softmax64(trans), _softmax64(obs)
+    alpha = np.zeros(k)
+    alpha[(HMM["init_state"] if init_state is None else init_state) % k] = 1.0
+    ll = 0.0
+    for yt in y:
+        alpha = (alpha @ pt) * po[:, yt]
+        s = alpha.sum()
+        ll += math.log(s)
+        alpha /= s
+    return ll
+
+
+def hmm_smc(ops: Ops, impl: int, seed: int, n: int, T: int, n_states=None, want_ancestors: bool = False):
+    trans, obs = hmm_tables(n_states)
+    k = trans.shape[0]
+    init = HMM["init_state"] % k
+    y = hmm_data(T, n_states)
+    dev = ops.device()
+    tl, ol = torch.from_numpy(trans).to(dev).contiguous(), torch.from_numpy(obs).to(dev).contiguous()
+    sk, rk = smc_key_schedule(prng.key(seed, impl), T)
+    out_max, out_q, state, logw, anc = ops.smc_run_hmm(impl, n, sk, rk, k, init, tl, ol, y, want_ancestors)
+    return dict(out_max=out_max, out_q=out_q, state=state, logw=logw, ancestors=anc,
+                log_z=ops.log_z_from_pairs(out_max, out_q, n), log_z_exact=hmm_exact_log_z(y, n_states))

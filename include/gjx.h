@@ -1,0 +1,323 @@
+/*
+ * gjx.h — C-ABI of the MI355X-native vectorised-trace inference backend.
+ *
+ * The reference (genjax-dev/genjax-chi) is pure Python on JAX and has NO FFI / plugin boundary
+ * (SURVEY.md F1, §8b): there is no existing native interface to bind.  This header therefore
+ * defines the boundary a maintainer WOULD bind (ctypes stub in INTEGRATION.md); every entry point
+ * names the reference call site(s) it replaces (paths relative to the reference's src/genjax/_src).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types.  All entry points return int:
+ *    GJX_OK (0) or a negative gjx_status.  No C++ exception crosses the boundary.
+ *  - Pointers documented "dev" are device (HBM) pointers for libgjx_hip.so and host pointers for
+ *    the CPU oracle build (oracle/libgjx_oracle.so, test infrastructure only).  Pointers
+ *    documented "host" are always host memory.  All memory is BORROWED: the library never frees
+ *    or retains a caller pointer past the stream-ordered call (plans copy what they keep).
+ *  - Every compute entry point takes a gjx_stream (hipStream_t) and is asynchronous w.r.t. the
+ *    host; no entry point synchronises, allocates or frees device memory (graph-capturable).
+ *    Scratch comes from a caller-provided workspace (gjx_workspace_bytes()).
+ *  - Particle axis is the fastest-varying axis of every column (struct-of-arrays trace buffer).
+ *  - All arithmetic follows the bit-exact f32/u64 specification in DESIGN.md §3 ("math spec");
+ *    HIP and oracle results are bit-identical on identical counters.
+ */
+#ifndef GJX_H
+#define GJX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GJX_VERSION_MAJOR 0
+#define GJX_VERSION_MINOR 1
+
+typedef void* gjx_stream; /* hipStream_t; ignored by the oracle build */
+
+typedef enum {
+  GJX_OK = 0,
+  GJX_ERR_INVALID = -1,      /* bad argument (null pointer, size 0 where not allowed, bad enum) */
+  GJX_ERR_UNSUPPORTED = -2,  /* valid request this build cannot run */
+  GJX_ERR_WORKSPACE = -3,    /* workspace too small */
+  GJX_ERR_LAUNCH = -4,       /* HIP launch / runtime failure */
+  GJX_ERR_NO_DEVICE = -5     /* no usable gfx950 device */
+} gjx_status;
+
+/* ---- PRNG ------------------------------------------------------------------------------- */
+
+/* Cipher / derivation scheme.  THREEFRY reproduces jax.random's key tree (SURVEY App. A:
+ * threefry2x32, partitionable split/fold_in); PHILOX is the native counter scheme
+ * (Philox4x32-10). */
+typedef enum { GJX_RNG_THREEFRY = 0, GJX_RNG_PHILOX = 1 } gjx_rng_impl;
+
+/* A batch of n per-particle keys, either materialised or lazily derived in-register.
+ *   mode 0: keys[i] = (keys[2i], keys[2i+1])                      (dev u32[n,2])
+ *   mode 1: keys[i] = split(parent, *)[first + i]                 (nothing read from HBM)
+ *   mode 2: keys[i] = parent for every i                          (one literal key, by value)
+ * If has_fold, the key actually used is fold_in(keys[i], fold) — the per-`@`-site key of
+ * generative_functions/static.py:349-352 (counter from 1).
+ * Replaces: jax.random.split / fold_in call sites inference/smc.py:299-300, static.py:261,350. */
+typedef struct {
+  int32_t impl;        /* gjx_rng_impl */
+  int32_t mode;        /* 0 explicit, 1 lazy split, 2 literal */
+  const uint32_t* keys;/* dev, mode 0 */
+  uint32_t parent[2];  /* mode 1 / 2 */
+  uint64_t first;      /* mode 1: global index of element 0 (shard offset) */
+  int32_t has_fold;
+  uint32_t fold;
+} gjx_keys;
+
+/* f32 operand: per-particle column (dev, stride 1) or broadcast scalar when ptr == NULL. */
+typedef struct {
+  const float* ptr;
+  float scalar;
+} gjx_f32;
+
+int gjx_version(int* major, int* minor);
+const char* gjx_backend_name(void); /* "hip-gfx950" or "oracle-cpu" */
+
+/* out[i] = the i-th key described by k (after the optional fold).  dev u32[n,2].
+ * Replaces jax.random.split (smc.py:300,386; vmap.py:186,201) and fold_in (static.py:350,
+ * scan.py:213,268) when keys must be materialised. */
+int gjx_rng_keys(const gjx_keys* k, uint64_t n, uint32_t* out, gjx_stream s);
+
+/* out[i] = 32 random bits of key i, sub-stream `sub` (DESIGN.md §3.2 bits32_at).  dev u32[n]. */
+int gjx_rng_bits(const gjx_keys* k, uint32_t sub, uint64_t n, uint32_t* out, gjx_stream s);
+
+/* ---- distributions: fused sample + log-density ------------------------------------------- *
+ * Replaces ExactDensity.random_weighted / estimate_logpdf
+ * (generative_functions/distributions/distribution.py:371-396) over the TFP wrappers
+ * (distributions/tensorflow_probability/__init__.py:35-64; instances normal 259, gamma 164,
+ * beta 82, flip 155, bernoulli 72, categorical 102-104), batched over the particle axis as
+ * ImportanceK's vmap does (inference/smc.py:302-310).
+ * value_out / score_out are dev [n]; score_out may be NULL.  */
+int gjx_sample_logpdf_normal(const gjx_keys* k, gjx_f32 loc, gjx_f32 scale, float* value_out,
+                             float* score_out, uint64_t n, gjx_stream s);
+int gjx_sample_logpdf_gamma(const gjx_keys* k, gjx_f32 concentration, gjx_f32 rate,
+                            float* value_out, float* score_out, uint64_t n, gjx_stream s);
+int gjx_sample_logpdf_beta(const gjx_keys* k, gjx_f32 a, gjx_f32 b, float* value_out,
+                           float* score_out, uint64_t n, gjx_stream s);
+/* probs in [0,1]; value is uint8 (0/1) — tfd.Bernoulli(probs=p, dtype=bool). */
+int gjx_sample_logpdf_bernoulli(const gjx_keys* k, gjx_f32 probs, uint8_t* value_out,
+                                float* score_out, uint64_t n, gjx_stream s);
+/* logits: dev f32 [n_rows, n_cat] row-major; row of particle i = row_index ? row_index[i] : (n_rows==1 ? 0 : i).
+ * mode 0 = Gumbel-max (jax.random.categorical semantics, n_cat uniforms per draw),
+ * mode 1 = inverse-CDF on the fixed-point CDF (one uniform per draw). value int32. */
+int gjx_sample_logpdf_categorical(const gjx_keys* k, const float* logits, uint64_t n_rows,
+                                  uint32_t n_cat, const int32_t* row_index, int mode,
+                                  int32_t* value_out, float* score_out, uint64_t n, gjx_stream s);
+
+/* log-density of given values (constrained sites: distribution.py:144-147, 383-396). */
+int gjx_logpdf_normal(gjx_f32 value, gjx_f32 loc, gjx_f32 scale, float* score_out, uint64_t n,
+                      gjx_stream s);
+int gjx_logpdf_gamma(gjx_f32 value, gjx_f32 concentration, gjx_f32 rate, float* score_out,
+                     uint64_t n, gjx_stream s);
+int gjx_logpdf_beta(gjx_f32 value, gjx_f32 a, gjx_f32 b, float* score_out, uint64_t n,
+                    gjx_stream s);
+/* value: dev uint8[n] or NULL => value_scalar for every particle. */
+int gjx_logpdf_bernoulli(const uint8_t* value, int value_scalar, gjx_f32 probs, float* score_out,
+                         uint64_t n, gjx_stream s);
+int gjx_logpdf_categorical(const int32_t* value, int value_scalar, const float* logits,
+                           uint64_t n_rows, uint32_t n_cat, const int32_t* row_index,
+                           float* score_out, uint64_t n, gjx_stream s);
+
+/* ---- fused static-model importance (the `@gen` body as one kernel) ------------------------ *
+ * Replaces vmap(target.importance) over StaticGenerativeFunction.generate
+ * (inference/smc.py:308-310 -> inference/sp.py:83-87 -> generative_functions/static.py:340-399):
+ * per particle, walk the `@` sites in program order; site s uses key fold_in(particle_key, s+1);
+ * latent sites sample and add their log-density to score; observed sites add their log-density
+ * to score AND weight (static.py:377; StaticTrace.get_score static.py:102-105). */
+typedef enum {
+  GJX_DIST_NORMAL = 0,     /* args: loc, scale */
+  GJX_DIST_GAMMA = 1,      /* args: concentration, rate */
+  GJX_DIST_BETA = 2,       /* args: concentration1, concentration0 */
+  GJX_DIST_BERNOULLI = 3,  /* args: probs (flip) */
+  GJX_DIST_CATEGORICAL = 4 /* arg0 selects the logits row; table = logits [n_rows,n_cat] */
+} gjx_dist;
+
+typedef enum {
+  GJX_ARG_CONST = 0, /* value = offset */
+  GJX_ARG_SITE = 1,  /* value = scale * (value of site `ref`, as f32) + offset */
+  GJX_ARG_INPUT = 2, /* value = scale * input_cols[ref][i] + offset */
+  GJX_ARG_TABLE = 3  /* value = table[(int) value of site `ref`] (dev f32 table) */
+} gjx_arg_kind;
+
+typedef struct {
+  int32_t kind;
+  int32_t ref;
+  float scale;
+  float offset;
+  const float* table; /* dev, GJX_ARG_TABLE only */
+} gjx_arg;
+
+typedef struct {
+  int32_t dist;       /* gjx_dist */
+  int32_t observed;   /* 0 latent (sampled), 1 observed (constrained) */
+  int32_t out_col;    /* index into value_cols, or -1: do not materialise this site's value */
+  int32_t n_cat;      /* categorical: number of categories */
+  int32_t n_rows;     /* categorical: rows in `logits` */
+  int32_t cat_mode;   /* categorical: 0 Gumbel-max, 1 inverse-CDF */
+  gjx_arg arg[2];
+  gjx_arg obs;        /* observed value: CONST or INPUT (int-valued dists: rounded to nearest) */
+  const float* logits;/* dev f32 [n_rows,n_cat], categorical only (borrowed until plan destroy) */
+} gjx_site;
+
+typedef struct gjx_plan gjx_plan;
+
+#define GJX_MAX_SITES 64
+
+int gjx_plan_create(const gjx_site* sites /*host*/, int n_sites, gjx_plan** out);
+int gjx_plan_destroy(gjx_plan* p);
+/* particle_keys: the per-particle keys BEFORE the per-site fold (has_fold must be 0).
+ * input_cols / value_cols: host arrays of dev pointers (each column dev [n], 4-byte elements:
+ * f32, or int32 for Bernoulli/Categorical values; at most 16 input columns).  score, logw: dev
+ * f32[n] (score nullable).  max_partials: nullable dev f32[gjx_num_tiles(n)]; when given, the
+ * kernel also stores the per-tile maxima of logw so the following log-sum-exp skips its max pass. */
+int gjx_importance_run(const gjx_plan* p, const gjx_keys* particle_keys,
+                       const float* const* input_cols, int n_input_cols, void* const* value_cols,
+                       int n_value_cols, float* score, float* logw, uint64_t n,
+                       float* max_partials, gjx_stream s);
+
+/* ---- weights: log-sum-exp, single draw, resampling ---------------------------------------- */
+
+typedef enum {
+  GJX_OP_LOGSUMEXP = 0,
+  GJX_OP_CATEGORICAL_INDEX = 1,
+  GJX_OP_RESAMPLE = 2,
+  GJX_OP_SMC = 3
+} gjx_op;
+size_t gjx_workspace_bytes(int op, uint64_t n);
+
+/* Number of fractional bits of the fixed-point weight q = rint(exp(lw - max) * 2^frac) used by
+ * every weight sum for a population of n_total particles. */
+int gjx_frac_bits(uint64_t n_total);
+
+/* Tiles: every kernel processes particles in tiles of gjx_smc_tile() (1024); per-tile partial
+ * arrays have gjx_num_tiles(n) entries. */
+uint64_t gjx_num_tiles(uint64_t n);
+
+/* out_max[0] = max_i x[i] (dev f32). Pass 1 of logsumexp; multi-GPU callers all-reduce(max) it.
+ * max_partials_in: nullable per-tile maxima already produced by gjx_importance_run (then x may be
+ * NULL and only the final reduction runs). */
+int gjx_max_f32(const float* x, uint64_t n, const float* max_partials_in, float* out_max, void* ws,
+                size_t ws_bytes, gjx_stream s);
+/* out_q[0] = sum_i rint(exp(x[i] - max[0]) * 2^frac_bits) as exact u64 (order-independent);
+ * multi-GPU callers all-reduce(sum) it. */
+int gjx_expsum_fix(const float* x, uint64_t n, const float* max_dev, int frac_bits,
+                   uint64_t* out_q, void* ws, size_t ws_bytes, gjx_stream s);
+/* out_lse[0] = max + log(q * 2^-frac_bits) in f32 (math spec log). */
+int gjx_lse_finish(const float* max_dev, const uint64_t* q_dev, int frac_bits, float* out_lse,
+                   gjx_stream s);
+/* Single-device convenience = the three calls above with frac = gjx_frac_bits(n).  out_lse /
+ * out_max / out_q nullable; max_partials_in as for gjx_max_f32.
+ * Replaces jax.scipy.special.logsumexp at inference/smc.py:97,107,464. */
+int gjx_logsumexp_f32(const float* x, uint64_t n, const float* max_partials_in, float* out_lse,
+                      float* out_max, uint64_t* out_q, void* ws, size_t ws_bytes, gjx_stream s);
+
+/* One index ~ Categorical(softmax(logits)); key: scalar key (mode 0, n=1 keys) on host side of
+ * gjx_keys.  mode 0 Gumbel-max (n uniforms; jax.random.categorical), mode 1 inverse-CDF.
+ * Replaces ParticleCollection.sample_particle's draw (inference/smc.py:102-109). */
+int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, int64_t* out_idx,
+                          int mode, void* ws, size_t ws_bytes, gjx_stream s);
+
+/* ancestors[j], j < n_out: systematic (one 64-bit uniform, monotone ancestors) or multinomial
+ * (n_out iid draws) resampling from softmax(logw).  out_max/out_q receive the (max, fixed-point
+ * sum) pair of logw.  NOT in the reference library (docs idiom
+ * docs/cookbook/inactive/inference/importance_sampling.ipynb cell 16). */
+int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, uint64_t n_out,
+                            int32_t* ancestors, float* out_max, uint64_t* out_q, void* ws,
+                            size_t ws_bytes, gjx_stream s);
+int gjx_resample_multinomial(const gjx_keys* key, const float* logw, uint64_t n, uint64_t n_out,
+                             int32_t* ancestors, float* out_max, uint64_t* out_q, void* ws,
+                             size_t ws_bytes, gjx_stream s);
+
+/* dst_cols[c][j] = src_cols[c][ancestors[j]] for 4-byte columns.  src_cols/dst_cols: host arrays
+ * of dev pointers.  Replaces ParticleCollection.get_particle's tree_map(v[idx])
+ * (inference/smc.py:90-91) for a vector of indices. */
+int gjx_gather_cols(const int32_t* ancestors, uint64_t n_out, const void* const* src_cols,
+                    void* const* dst_cols, int n_cols, gjx_stream s);
+
+/* ---- fused bootstrap SMC for the benchmark state-space models ------------------------------ *
+ * One call enqueues the whole T-step filter (2 kernels per step) on the stream, no host sync.
+ * Particle slot j (global index) of step t uses key split(step_keys[t], *)[j], site counter 1
+ * (the kernel `@gen` body has one latent site; Scan.generate scan.py:237-294 is the reference's
+ * T-loop, resampling itself is not in the reference: SURVEY F3/E3).
+ * Multi-device: each rank owns slots [first_slot, first_slot+n_local) of n_total and passes
+ * n_local < n_total; the exchange hooks below are used by the host between kernels. */
+typedef struct {
+  float x0_loc, x0_scale; /* x_0 ~ N(x0_loc, x0_scale) */
+  float a;                /* x_t ~ N(a * x_{t-1}, q) */
+  float q;
+  float r;                /* y_t ~ N(x_t, r) */
+} gjx_lgssm;
+
+typedef struct {
+  int32_t n_states;
+  int32_t init_state;        /* z_{-1} (discrete_hmm.py:101 uses a fixed initial state) */
+  const float* trans_logits; /* dev f32 [K,K]: row = previous state */
+  const float* obs_logits;   /* dev f32 [K,K]: row = state, column = observation */
+} gjx_hmm;
+
+/* Layout-independent description of one SMC run. */
+typedef struct {
+  int32_t impl;            /* gjx_rng_impl */
+  uint64_t n_total;        /* global particle count (< 2^31) */
+  uint64_t first_slot;     /* this rank's first slot (multiple of the tile size) */
+  uint64_t n_local;        /* this rank's slot count */
+  int32_t n_steps;         /* T */
+  const uint32_t* step_keys;     /* host u32[T,2]: per-step propagate keys */
+  const uint32_t* resample_keys; /* host u32[T,2]: per-step resampling keys (entry 0 unused) */
+} gjx_smc_config;
+
+/* Single-device whole run (first_slot = 0, n_local = n_total).  y: HOST array [T] (f32 for lgssm,
+ * int32 for hmm) — observations are baked into the launches.
+ * Outputs: out_max dev f32[T], out_q dev u64[T] (per-step (max, fixed-point sum) of the
+ * incremental log-weights => log Z = sum_t (max_t + log(q_t 2^-frac) - log N), frac =
+ * gjx_frac_bits(n_total)); state_out dev [n] final-step particles (f32 x / int32 z) and logw_out
+ * dev f32[n] their weights (before the final resampling); ancestors_out dev int32[T,n] or NULL
+ * (row 0 is the identity). */
+int gjx_smc_run_lgssm(const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y_host,
+                      float* out_max, uint64_t* out_q, float* state_out, float* logw_out,
+                      int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s);
+int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32_t* y_host,
+                    float* out_max, uint64_t* out_q, int32_t* state_out, float* logw_out,
+                    int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s);
+
+/* Per-step pieces (the whole-run calls are loops over these; the multi-device driver runs the
+ * RCCL exchange between them).  All "global" arrays are indexed by global slot / global tile.
+ *  step A (t): for every slot j in [first_slot, first_slot+n_local): systematic-resampling
+ *    ancestor from the GLOBAL previous population (prev_state / prev_logw dev [n_total], prev_max
+ *    dev f32[1], prev_tile_sums dev u64[gjx_num_tiles(n_total)]), propagate, weight.  Writes
+ *    state_out / logw_out / ancestors_out (nullable) dev [n_local] and max_partials_out dev
+ *    f32[gjx_num_tiles(n_total)]: max over that array == max of the local new log-weights
+ *    (-inf entries for work this rank did not own, so ranks combine it with all-reduce(max)).
+ *    prev_q_out (nullable dev u64[1]) receives sum(prev_tile_sums).  t == 0 ignores prev_*.
+ *  step B: max_out[0] = max(max_partials) and tile_sums[first_slot/tile + b] = fixed-point mass
+ *    of local tile b under that max (tile_sums is the GLOBAL array; ranks all-gather it).
+ *  finish: q_out[0] = sum(tile_sums) (the last step's total). */
+int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* model, int t, float y_t,
+                         const float* prev_state, const float* prev_logw, const float* prev_max,
+                         const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* state_out,
+                         float* logw_out, float* max_partials_out, int32_t* ancestors_out,
+                         gjx_stream s);
+int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* model, int t, int32_t y_t,
+                       const int32_t* prev_state, const float* prev_logw, const float* prev_max,
+                       const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
+                       const uint32_t* trans_cdf /* dev u32[K,K] from gjx_hmm_prepare */,
+                       const float* obs_logp /* dev f32[K,K] from gjx_hmm_prepare */,
+                       int32_t* state_out, float* logw_out, float* max_partials_out,
+                       int32_t* ancestors_out, gjx_stream s);
+int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const float* max_partials,
+                   float* max_out, uint64_t* tile_sums, gjx_stream s);
+int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
+                   gjx_stream s);
+/* HMM tables: trans_cdf dev u32[K,K] fixed-point inclusive CDF per row,
+ * obs_logp dev f32[K,K] = log_softmax rows of obs_logits.  K <= 256. */
+int gjx_hmm_prepare(const gjx_hmm* model, uint32_t* trans_cdf, float* obs_logp, gjx_stream s);
+uint64_t gjx_smc_tile(void); /* particles per tile */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GJX_H */

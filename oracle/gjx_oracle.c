@@ -1,0 +1,831 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see gjx_oracle_math.h for the pinning statement).
+ *
+ * CPU implementation of include/gjx.h with HOST pointers; `gjx_stream` is ignored and every call
+ * is synchronous.  Each function is a straight-line, sequential-semantics restatement of the
+ * reference path (citations relative to /root/reference/src/genjax/_src):
+ *   importance walk ........ generative_functions/static.py:340-399 (GenerateHandler),
+ *                            distributions/distribution.py:117-147, 371-396
+ *   ImportanceK batching ... inference/smc.py:298-315
+ *   log-marginal / draw .... inference/smc.py:96-109
+ *   Scan T-loop ............ generative_functions/combinators/scan.py:237-294
+ * OpenMP only parallelises loops whose iterations are independent or whose reduction is an
+ * exact integer sum / max, so results do not depend on the thread count.
+ */
+#include "../include/gjx.h"
+#include "gjx_oracle_math.h"
+
+#include <stdlib.h>
+
+#define O_TILE 1024u
+#define O_CAT_FRAC 23
+
+int gjx_version(int* major, int* minor) {
+  if (major) *major = GJX_VERSION_MAJOR;
+  if (minor) *minor = GJX_VERSION_MINOR;
+  return GJX_OK;
+}
+const char* gjx_backend_name(void) { return "oracle-cpu"; }
+int gjx_frac_bits(uint64_t n_total) { return o_frac_bits(n_total); }
+uint64_t gjx_smc_tile(void) { return O_TILE; }
+uint64_t gjx_num_tiles(uint64_t n) { return (n + O_TILE - 1) / O_TILE; }
+size_t gjx_workspace_bytes(int op, uint64_t n) { (void)op; (void)n; return 64; }
+
+/* ---- keys ---------------------------------------------------------------------------------- */
+static inline void key_at(const gjx_keys* k, uint64_t i, uint32_t out[2]) {
+  if (k->mode == 0) { out[0] = k->keys[2 * i]; out[1] = k->keys[2 * i + 1]; }
+  else if (k->mode == 1) o_split_at(k->impl, k->parent, k->first + i, out);
+  else { out[0] = k->parent[0]; out[1] = k->parent[1]; }
+}
+static inline o_stream stream_at(const gjx_keys* k, uint64_t i) {
+  uint32_t key[2];
+  key_at(k, i, key);
+  return o_stream_make(k->impl, key, k->has_fold, k->fold);
+}
+static int keys_ok(const gjx_keys* k) {
+  if (!k) return 0;
+  if (k->impl != 0 && k->impl != 1) return 0;
+  if (k->mode == 0) return k->keys != NULL;
+  return k->mode == 1 || k->mode == 2;
+}
+
+int gjx_rng_keys(const gjx_keys* k, uint64_t n, uint32_t* out, gjx_stream s) {
+  (void)s;
+  if (!keys_ok(k) || (!out && n)) return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    uint32_t key[2];
+    key_at(k, (uint64_t)i, key);
+    if (k->has_fold) { uint32_t f[2]; o_fold_in(k->impl, key, k->fold, f); key[0] = f[0]; key[1] = f[1]; }
+    out[2 * i] = key[0];
+    out[2 * i + 1] = key[1];
+  }
+  return GJX_OK;
+}
+
+int gjx_rng_bits(const gjx_keys* k, uint32_t sub, uint64_t n, uint32_t* out, gjx_stream s) {
+  (void)s;
+  if (!keys_ok(k) || (!out && n)) return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    o_stream st = stream_at(k, (uint64_t)i);
+    out[i] = o_bits32_at(&st, sub);
+  }
+  return GJX_OK;
+}
+
+/* ---- categorical helpers --------------------------------------------------------------------- */
+static float row_max(const float* l, uint32_t K) {
+  float m = l[0];
+  for (uint32_t c = 1; c < K; ++c) m = l[c] > m ? l[c] : m;
+  return m;
+}
+/* lse of a logits row: max + log(sum_k exp(l_k - max)), f32, sequential in k. */
+static float row_lse(const float* l, uint32_t K) {
+  float m = row_max(l, K);
+  float acc = 0.0f;
+  for (uint32_t c = 0; c < K; ++c) acc = acc + o_exp(l[c] - m);
+  return m + o_log(acc);
+}
+static inline uint32_t cat_fix(float l, float m) {
+  if (l == m) return 1u << O_CAT_FRAC;
+  float d = l - m;
+  if (!(d >= -80.0f)) return 0u;
+  return (uint32_t)rintf(o_exp(d) * 8388608.0f);
+}
+/* inverse-CDF draw on the fixed-point CDF of one logits row. */
+static int32_t cat_invcdf(const float* l, uint32_t K, uint32_t bits) {
+  float m = row_max(l, K);
+  uint64_t Q = 0;
+  for (uint32_t c = 0; c < K; ++c) Q += cat_fix(l[c], m);
+  uint64_t thr = ((uint64_t)bits * Q) >> 32;
+  uint64_t C = 0;
+  for (uint32_t c = 0; c < K; ++c) {
+    C += cat_fix(l[c], m);
+    if (C > thr) return (int32_t)c;
+  }
+  return (int32_t)(K - 1);
+}
+static inline float gumbel_from_bits(uint32_t bits) {
+  const float tiny = 1.17549435e-38f;
+  float u = o_uniform01(bits) + tiny; /* f*(1-tiny)+tiny with 1-tiny == 1 in f32 */
+  u = u > tiny ? u : tiny;
+  return -o_log(-o_log(u));
+}
+static int32_t cat_gumbel(const float* l, uint32_t K, const o_stream* st) {
+  int32_t best = 0;
+  float bv = -INFINITY;
+  for (uint32_t c = 0; c < K; ++c) {
+    float v = l[c] + gumbel_from_bits(o_bits32_at(st, c));
+    if (v > bv || c == 0) { bv = v; best = (int32_t)c; }
+  }
+  return best;
+}
+static inline const float* cat_row(const float* logits, uint64_t n_rows, uint32_t K,
+                                   const int32_t* row_index, uint64_t i) {
+  uint64_t r = row_index ? (uint64_t)row_index[i] : (n_rows == 1 ? 0 : i);
+  return logits + r * K;
+}
+
+/* ---- elementwise distributions --------------------------------------------------------------- */
+#define OPND(a, i) ((a).ptr ? (a).ptr[i] : (a).scalar)
+
+int gjx_sample_logpdf_normal(const gjx_keys* k, gjx_f32 loc, gjx_f32 scale, float* value_out,
+                             float* score_out, uint64_t n, gjx_stream s) {
+  (void)s;
+  if (!keys_ok(k) || !value_out) return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    o_stream st = stream_at(k, (uint64_t)i);
+    float mu = OPND(loc, i), sg = OPND(scale, i);
+    float eps = o_std_normal(o_bits32_at(&st, 0));
+    float t = sg * eps;
+    float v = mu + t;
+    value_out[i] = v;
+    if (score_out) score_out[i] = o_logpdf_normal(v, mu, sg);
+  }
+  return GJX_OK;
+}
+
+int gjx_sample_logpdf_gamma(const gjx_keys* k, gjx_f32 concentration, gjx_f32 rate,
+                            float* value_out, float* score_out, uint64_t n, gjx_stream s) {
+  (void)s;
+  if (!keys_ok(k) || !value_out) return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    o_stream st = stream_at(k, (uint64_t)i);
+    float a = OPND(concentration, i), b = OPND(rate, i);
+    float v = o_std_gamma(&st, 0, a) / b;
+    value_out[i] = v;
+    if (score_out) score_out[i] = o_logpdf_gamma(v, a, b);
+  }
+  return GJX_OK;
+}
+
+int gjx_sample_logpdf_beta(const gjx_keys* k, gjx_f32 a_, gjx_f32 b_, float* value_out,
+                           float* score_out, uint64_t n, gjx_stream s) {
+  (void)s;
+  if (!keys_ok(k) || !value_out) return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    o_stream st = stream_at(k, (uint64_t)i);
+    float a = OPND(a_, i), b = OPND(b_, i);
+    float g1 = o_std_gamma(&st, 0, a);
+    float g2 = o_std_gamma(&st, 1, b);
+    float v = g1 / (g1 + g2);
+    value_out[i] = v;
+    if (score_out) score_out[i] = o_logpdf_beta(v, a, b);
+  }
+  return GJX_OK;
+}
+
+int gjx_sample_logpdf_bernoulli(const gjx_keys* k, gjx_f32 probs, uint8_t* value_out,
+                                float* score_out, uint64_t n, gjx_stream s) {
+  (void)s;
+  if (!keys_ok(k) || !value_out) return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    o_stream st = stream_at(k, (uint64_t)i);
+    float p = OPND(probs, i);
+    int e = o_uniform01(o_bits32_at(&st, 0)) < p;
+    value_out[i] = (uint8_t)e;
+    if (score_out) score_out[i] = o_logpdf_bernoulli(e, p);
+  }
+  return GJX_OK;
+}
+
+int gjx_sample_logpdf_categorical(const gjx_keys* k, const float* logits, uint64_t n_rows,
+                                  uint32_t n_cat, const int32_t* row_index, int mode,
+                                  int32_t* value_out, float* score_out, uint64_t n, gjx_stream s) {
+  (void)s;
+  if (!keys_ok(k) || !value_out || !logits || n_cat == 0 || (mode != 0 && mode != 1))
+    return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    o_stream st = stream_at(k, (uint64_t)i);
+    const float* l = cat_row(logits, n_rows, n_cat, row_index, (uint64_t)i);
+    int32_t v = mode == 0 ? cat_gumbel(l, n_cat, &st) : cat_invcdf(l, n_cat, o_bits32_at(&st, 0));
+    value_out[i] = v;
+    if (score_out) score_out[i] = l[v] - row_lse(l, n_cat);
+  }
+  return GJX_OK;
+}
+
+int gjx_logpdf_normal(gjx_f32 value, gjx_f32 loc, gjx_f32 scale, float* score_out, uint64_t n,
+                      gjx_stream s) {
+  (void)s;
+  if (!score_out) return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i)
+    score_out[i] = o_logpdf_normal(OPND(value, i), OPND(loc, i), OPND(scale, i));
+  return GJX_OK;
+}
+int gjx_logpdf_gamma(gjx_f32 value, gjx_f32 concentration, gjx_f32 rate, float* score_out,
+                     uint64_t n, gjx_stream s) {
+  (void)s;
+  if (!score_out) return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i)
+    score_out[i] = o_logpdf_gamma(OPND(value, i), OPND(concentration, i), OPND(rate, i));
+  return GJX_OK;
+}
+int gjx_logpdf_beta(gjx_f32 value, gjx_f32 a, gjx_f32 b, float* score_out, uint64_t n,
+                    gjx_stream s) {
+  (void)s;
+  if (!score_out) return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i)
+    score_out[i] = o_logpdf_beta(OPND(value, i), OPND(a, i), OPND(b, i));
+  return GJX_OK;
+}
+int gjx_logpdf_bernoulli(const uint8_t* value, int value_scalar, gjx_f32 probs, float* score_out,
+                         uint64_t n, gjx_stream s) {
+  (void)s;
+  if (!score_out) return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i)
+    score_out[i] = o_logpdf_bernoulli(value ? value[i] != 0 : value_scalar != 0, OPND(probs, i));
+  return GJX_OK;
+}
+int gjx_logpdf_categorical(const int32_t* value, int value_scalar, const float* logits,
+                           uint64_t n_rows, uint32_t n_cat, const int32_t* row_index,
+                           float* score_out, uint64_t n, gjx_stream s) {
+  (void)s;
+  if (!score_out || !logits || n_cat == 0) return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    const float* l = cat_row(logits, n_rows, n_cat, row_index, (uint64_t)i);
+    int32_t v = value ? value[i] : value_scalar;
+    score_out[i] = (v < 0 || (uint32_t)v >= n_cat) ? -INFINITY : l[v] - row_lse(l, n_cat);
+  }
+  return GJX_OK;
+}
+
+/* ---- fused static-model importance ------------------------------------------------------------ */
+struct gjx_plan {
+  int n_sites;
+  gjx_site sites[GJX_MAX_SITES];
+};
+
+static int arg_ok(const gjx_arg* a, int s, int allow_site) {
+  switch (a->kind) {
+    case GJX_ARG_CONST: return 1;
+    case GJX_ARG_SITE: return allow_site && a->ref >= 0 && a->ref < s;
+    case GJX_ARG_INPUT: return a->ref >= 0;
+    case GJX_ARG_TABLE: return allow_site && a->ref >= 0 && a->ref < s && a->table != NULL;
+    default: return 0;
+  }
+}
+
+int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
+  if (!sites || !out || n_sites <= 0 || n_sites > GJX_MAX_SITES) return GJX_ERR_INVALID;
+  for (int s = 0; s < n_sites; ++s) {
+    const gjx_site* st = &sites[s];
+    if (st->dist < 0 || st->dist > GJX_DIST_CATEGORICAL) return GJX_ERR_INVALID;
+    if (!arg_ok(&st->arg[0], s, 1)) return GJX_ERR_INVALID;
+    if (st->dist != GJX_DIST_BERNOULLI && st->dist != GJX_DIST_CATEGORICAL &&
+        !arg_ok(&st->arg[1], s, 1))
+      return GJX_ERR_INVALID;
+    if (st->observed && !(st->obs.kind == GJX_ARG_CONST || st->obs.kind == GJX_ARG_INPUT))
+      return GJX_ERR_INVALID;
+    if (st->dist == GJX_DIST_CATEGORICAL &&
+        (!st->logits || st->n_cat <= 0 || st->n_rows <= 0 || (st->cat_mode != 0 && st->cat_mode != 1)))
+      return GJX_ERR_INVALID;
+  }
+  gjx_plan* p = (gjx_plan*)malloc(sizeof(gjx_plan));
+  if (!p) return GJX_ERR_LAUNCH;
+  p->n_sites = n_sites;
+  memcpy(p->sites, sites, sizeof(gjx_site) * (size_t)n_sites);
+  *out = p;
+  return GJX_OK;
+}
+int gjx_plan_destroy(gjx_plan* p) { free(p); return GJX_OK; }
+
+typedef struct { float f; int32_t i; int is_int; } site_val;
+
+static inline float sv_as_f32(const site_val* v) { return v->is_int ? (float)v->i : v->f; }
+static inline int32_t sv_as_i32(const site_val* v) { return v->is_int ? v->i : (int32_t)rintf(v->f); }
+
+static inline float eval_arg(const gjx_arg* a, const site_val* vals, const float* const* in,
+                             uint64_t i) {
+  switch (a->kind) {
+    case GJX_ARG_CONST: return a->offset;
+    case GJX_ARG_SITE: { float t = a->scale * sv_as_f32(&vals[a->ref]); return t + a->offset; }
+    case GJX_ARG_INPUT: { float t = a->scale * in[a->ref][i]; return t + a->offset; }
+    default: return a->table[sv_as_i32(&vals[a->ref])];
+  }
+}
+
+int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const* input_cols,
+                       int n_input_cols, void* const* value_cols, int n_value_cols, float* score,
+                       float* logw, uint64_t n, float* max_partials, gjx_stream s) {
+  (void)s;
+  if (!p || !keys_ok(pk) || pk->has_fold || !logw) return GJX_ERR_INVALID;
+  for (int q = 0; q < p->n_sites; ++q) {
+    const gjx_site* st = &p->sites[q];
+    if (st->out_col >= n_value_cols) return GJX_ERR_INVALID;
+    for (int a = 0; a < 2; ++a)
+      if (st->arg[a].kind == GJX_ARG_INPUT && st->arg[a].ref >= n_input_cols) return GJX_ERR_INVALID;
+    if (st->observed && st->obs.kind == GJX_ARG_INPUT && st->obs.ref >= n_input_cols)
+      return GJX_ERR_INVALID;
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    uint32_t key[2];
+    key_at(pk, (uint64_t)i, key);
+    site_val vals[GJX_MAX_SITES];
+    float w = 0.0f, sc = 0.0f;
+    for (int q = 0; q < p->n_sites; ++q) {
+      const gjx_site* st = &p->sites[q];
+      site_val v;
+      v.f = 0.0f; v.i = 0;
+      v.is_int = (st->dist == GJX_DIST_BERNOULLI || st->dist == GJX_DIST_CATEGORICAL);
+      float a0 = 0.0f, a1 = 0.0f;
+      const float* row = NULL;
+      if (st->dist == GJX_DIST_CATEGORICAL) {
+        int32_t r = 0;
+        if (st->arg[0].kind == GJX_ARG_SITE) r = sv_as_i32(&vals[st->arg[0].ref]);
+        else if (st->arg[0].kind == GJX_ARG_CONST) r = (int32_t)rintf(st->arg[0].offset);
+        else r = (int32_t)rintf(eval_arg(&st->arg[0], vals, input_cols, (uint64_t)i));
+        if (r < 0) r = 0;
+        if (r >= st->n_rows) r = st->n_rows - 1;
+        row = st->logits + (size_t)r * (size_t)st->n_cat;
+      } else {
+        a0 = eval_arg(&st->arg[0], vals, input_cols, (uint64_t)i);
+        if (st->dist != GJX_DIST_BERNOULLI) a1 = eval_arg(&st->arg[1], vals, input_cols, (uint64_t)i);
+      }
+      float lp;
+      if (st->observed) {
+        float ov = st->obs.kind == GJX_ARG_CONST ? st->obs.offset : input_cols[st->obs.ref][i];
+        if (v.is_int) v.i = (int32_t)rintf(ov); else v.f = ov;
+      } else {
+        o_stream strm = o_stream_make(pk->impl, key, 1, (uint32_t)(q + 1));
+        switch (st->dist) {
+          case GJX_DIST_NORMAL: { float t = a1 * o_std_normal(o_bits32_at(&strm, 0)); v.f = a0 + t; break; }
+          case GJX_DIST_GAMMA: v.f = o_std_gamma(&strm, 0, a0) / a1; break;
+          case GJX_DIST_BETA: { float g1 = o_std_gamma(&strm, 0, a0), g2 = o_std_gamma(&strm, 1, a1); v.f = g1 / (g1 + g2); break; }
+          case GJX_DIST_BERNOULLI: v.i = o_uniform01(o_bits32_at(&strm, 0)) < a0; break;
+          default: v.i = st->cat_mode == 0 ? cat_gumbel(row, (uint32_t)st->n_cat, &strm)
+                                           : cat_invcdf(row, (uint32_t)st->n_cat, o_bits32_at(&strm, 0));
+        }
+      }
+      switch (st->dist) {
+        case GJX_DIST_NORMAL: lp = o_logpdf_normal(v.f, a0, a1); break;
+        case GJX_DIST_GAMMA: lp = o_logpdf_gamma(v.f, a0, a1); break;
+        case GJX_DIST_BETA: lp = o_logpdf_beta(v.f, a0, a1); break;
+        case GJX_DIST_BERNOULLI: lp = o_logpdf_bernoulli(v.i != 0, a0); break;
+        default: lp = (v.i < 0 || v.i >= st->n_cat) ? -INFINITY : row[v.i] - row_lse(row, (uint32_t)st->n_cat);
+      }
+      sc = sc + lp;
+      if (st->observed) w = w + lp;
+      vals[q] = v;
+      if (st->out_col >= 0) {
+        if (v.is_int) ((int32_t*)value_cols[st->out_col])[i] = v.i;
+        else ((float*)value_cols[st->out_col])[i] = v.f;
+      }
+    }
+    logw[i] = w;
+    if (score) score[i] = sc;
+  }
+  if (max_partials) {
+    for (uint64_t b = 0; b * O_TILE < n; ++b) {
+      float m = -INFINITY;
+      for (uint64_t i = b * O_TILE; i < n && i < (b + 1) * O_TILE; ++i) m = logw[i] > m ? logw[i] : m;
+      max_partials[b] = m;
+    }
+  }
+  return GJX_OK;
+}
+
+/* ---- weights ------------------------------------------------------------------------------------ */
+int gjx_max_f32(const float* x, uint64_t n, const float* max_partials_in, float* out_max, void* ws,
+                size_t ws_bytes, gjx_stream s) {
+  (void)ws; (void)ws_bytes; (void)s;
+  if ((!x && !max_partials_in) || !out_max || n == 0) return GJX_ERR_INVALID;
+  float m = -INFINITY;
+  if (max_partials_in) {
+    for (uint64_t b = 0; b < gjx_num_tiles(n); ++b) m = max_partials_in[b] > m ? max_partials_in[b] : m;
+  } else {
+#pragma omp parallel for reduction(max : m) schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) m = x[i] > m ? x[i] : m;
+  }
+  *out_max = m;
+  return GJX_OK;
+}
+int gjx_expsum_fix(const float* x, uint64_t n, const float* max_dev, int frac_bits, uint64_t* out_q,
+                   void* ws, size_t ws_bytes, gjx_stream s) {
+  (void)ws; (void)ws_bytes; (void)s;
+  if (!x || !max_dev || !out_q || frac_bits < 1 || frac_bits > 40) return GJX_ERR_INVALID;
+  float m = *max_dev;
+  uint64_t Q = 0;
+#pragma omp parallel for reduction(+ : Q) schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) Q += o_fixw(x[i], m, frac_bits);
+  *out_q = Q;
+  return GJX_OK;
+}
+static float lse_from(float m, uint64_t q, int frac) {
+  /* (float)q is a correctly rounded u64->f32 conversion; scaling by 2^-frac is exact. */
+  float qf = (float)q * o_u2f((uint32_t)(127 - frac) << 23);
+  return m + o_log(qf);
+}
+int gjx_lse_finish(const float* max_dev, const uint64_t* q_dev, int frac_bits, float* out_lse,
+                   gjx_stream s) {
+  (void)s;
+  if (!max_dev || !q_dev || !out_lse) return GJX_ERR_INVALID;
+  *out_lse = lse_from(*max_dev, *q_dev, frac_bits);
+  return GJX_OK;
+}
+int gjx_logsumexp_f32(const float* x, uint64_t n, const float* max_partials_in, float* out_lse,
+                      float* out_max, uint64_t* out_q, void* ws, size_t ws_bytes, gjx_stream s) {
+  float m;
+  uint64_t q;
+  int frac = o_frac_bits(n);
+  if (!x) return GJX_ERR_INVALID;
+  int rc = gjx_max_f32(x, n, max_partials_in, &m, ws, ws_bytes, s);
+  if (rc) return rc;
+  rc = gjx_expsum_fix(x, n, &m, frac, &q, ws, ws_bytes, s);
+  if (rc) return rc;
+  if (out_lse) *out_lse = lse_from(m, q, frac);
+  if (out_max) *out_max = m;
+  if (out_q) *out_q = q;
+  return GJX_OK;
+}
+
+static inline uint64_t mulhi64(uint64_t a, uint64_t b) {
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+}
+
+int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, int64_t* out_idx,
+                          int mode, void* ws, size_t ws_bytes, gjx_stream s) {
+  (void)ws; (void)ws_bytes; (void)s;
+  if (!keys_ok(key) || !logits || !out_idx || n == 0 || (mode != 0 && mode != 1)) return GJX_ERR_INVALID;
+  o_stream st = stream_at(key, 0);
+  if (mode == 0) {
+    int64_t best = 0;
+    float bv = -INFINITY;
+    for (uint64_t i = 0; i < n; ++i) {
+      float v = logits[i] + gumbel_from_bits(o_bits32_at(&st, (uint32_t)i));
+      if (v > bv || i == 0) { bv = v; best = (int64_t)i; }
+    }
+    *out_idx = best;
+    return GJX_OK;
+  }
+  float m = -INFINITY;
+  for (uint64_t i = 0; i < n; ++i) m = logits[i] > m ? logits[i] : m;
+  int frac = o_frac_bits(n);
+  uint64_t Q = 0;
+  for (uint64_t i = 0; i < n; ++i) Q += o_fixw(logits[i], m, frac);
+  uint64_t thr = mulhi64(o_bits64_at(&st, 0), Q);
+  uint64_t C = 0;
+  int64_t idx = (int64_t)n - 1;
+  for (uint64_t i = 0; i < n; ++i) {
+    C += o_fixw(logits[i], m, frac);
+    if (C > thr) { idx = (int64_t)i; break; }
+  }
+  *out_idx = idx;
+  return GJX_OK;
+}
+
+/* Number of comb teeth (j + u0), j in [0, n_out), strictly below normalised mass P = C*scale. */
+static inline int64_t teeth_below(uint64_t C, double scale, double u0, int64_t n_out) {
+  double P = (double)C * scale;
+  double c = ceil(P - u0);
+  if (!(c > 0.0)) return 0;
+  if (c >= (double)n_out) return n_out;
+  return (int64_t)c;
+}
+static inline double u0_from_bits(uint64_t U) { return (double)(U >> 11) * 0x1.0p-53; }
+
+int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, uint64_t n_out,
+                            int32_t* ancestors, float* out_max, uint64_t* out_q, void* ws,
+                            size_t ws_bytes, gjx_stream s) {
+  (void)ws; (void)ws_bytes; (void)s;
+  if (!keys_ok(key) || !logw || !ancestors || n == 0 || n_out == 0) return GJX_ERR_INVALID;
+  float m = -INFINITY;
+  for (uint64_t i = 0; i < n; ++i) m = logw[i] > m ? logw[i] : m;
+  int frac = o_frac_bits(n);
+  uint64_t Q = 0;
+  for (uint64_t i = 0; i < n; ++i) Q += o_fixw(logw[i], m, frac);
+  o_stream st = stream_at(key, 0);
+  double u0 = u0_from_bits(o_bits64_at(&st, 0));
+  double scale = (double)n_out / (double)Q;
+  uint64_t C = 0;
+  int64_t prev = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    C += o_fixw(logw[i], m, frac);
+    int64_t ni = (i == n - 1) ? (int64_t)n_out : teeth_below(C, scale, u0, (int64_t)n_out);
+    for (int64_t j = prev; j < ni; ++j) ancestors[j] = (int32_t)i;
+    if (ni > prev) prev = ni;
+  }
+  if (out_max) *out_max = m;
+  if (out_q) *out_q = Q;
+  return GJX_OK;
+}
+
+int gjx_resample_multinomial(const gjx_keys* key, const float* logw, uint64_t n, uint64_t n_out,
+                             int32_t* ancestors, float* out_max, uint64_t* out_q, void* ws,
+                             size_t ws_bytes, gjx_stream s) {
+  (void)ws; (void)ws_bytes; (void)s;
+  if (!keys_ok(key) || !logw || !ancestors || n == 0 || n_out == 0) return GJX_ERR_INVALID;
+  float m = -INFINITY;
+  for (uint64_t i = 0; i < n; ++i) m = logw[i] > m ? logw[i] : m;
+  int frac = o_frac_bits(n);
+  uint64_t* cdf = (uint64_t*)malloc(sizeof(uint64_t) * n);
+  if (!cdf) return GJX_ERR_LAUNCH;
+  uint64_t C = 0;
+  for (uint64_t i = 0; i < n; ++i) { C += o_fixw(logw[i], m, frac); cdf[i] = C; }
+  o_stream st = stream_at(key, 0);
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < (int64_t)n_out; ++j) {
+    uint64_t thr = mulhi64(o_bits64_at(&st, (uint32_t)j), C);
+    uint64_t lo = 0, hi = n - 1; /* first i with cdf[i] > thr */
+    while (lo < hi) {
+      uint64_t mid = (lo + hi) >> 1;
+      if (cdf[mid] > thr) hi = mid; else lo = mid + 1;
+    }
+    ancestors[j] = (int32_t)lo;
+  }
+  free(cdf);
+  if (out_max) *out_max = m;
+  if (out_q) *out_q = C;
+  return GJX_OK;
+}
+
+int gjx_gather_cols(const int32_t* ancestors, uint64_t n_out, const void* const* src_cols,
+                    void* const* dst_cols, int n_cols, gjx_stream s) {
+  (void)s;
+  if (!ancestors || !src_cols || !dst_cols || n_cols < 0) return GJX_ERR_INVALID;
+  for (int c = 0; c < n_cols; ++c) {
+    const uint32_t* src = (const uint32_t*)src_cols[c];
+    uint32_t* dst = (uint32_t*)dst_cols[c];
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < (int64_t)n_out; ++j) dst[j] = src[ancestors[j]];
+  }
+  return GJX_OK;
+}
+
+/* ---- fused bootstrap SMC ------------------------------------------------------------------------ */
+static int cfg_ok(const gjx_smc_config* c) {
+  return c && (c->impl == 0 || c->impl == 1) && c->n_total > 0 && c->n_local > 0 &&
+         c->first_slot + c->n_local <= c->n_total && c->n_steps > 0 && c->step_keys &&
+         c->resample_keys && (c->first_slot % O_TILE) == 0;
+}
+
+/* Ancestors of slots [lo, hi) by systematic resampling of the GLOBAL previous population. */
+static void smc_ancestors(const gjx_smc_config* cfg, int t, const float* prev_logw, float m,
+                          uint64_t Q, int32_t* anc /* [n_local] */) {
+  const uint64_t N = cfg->n_total;
+  const int frac = o_frac_bits(N);
+  const int64_t lo = (int64_t)cfg->first_slot, hi = lo + (int64_t)cfg->n_local;
+  o_stream st = o_stream_make(cfg->impl, &cfg->resample_keys[2 * t], 0, 0);
+  double u0 = u0_from_bits(o_bits64_at(&st, 0));
+  double scale = (double)N / (double)Q;
+  uint64_t C = 0;
+  int64_t prev = 0;
+  for (uint64_t i = 0; i < N && prev < hi; ++i) {
+    C += o_fixw(prev_logw[i], m, frac);
+    int64_t ni = (i == N - 1) ? (int64_t)N : teeth_below(C, scale, u0, (int64_t)N);
+    int64_t a = prev > lo ? prev : lo, b = ni < hi ? ni : hi;
+    for (int64_t j = a; j < b; ++j) anc[j - lo] = (int32_t)i;
+    if (ni > prev) prev = ni;
+  }
+}
+
+int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const float* max_partials,
+                   float* max_out, uint64_t* tile_sums, gjx_stream s) {
+  (void)s;
+  if (!cfg_ok(cfg) || !logw_local || !max_partials || !max_out || !tile_sums) return GJX_ERR_INVALID;
+  const int frac = o_frac_bits(cfg->n_total);
+  float m = -INFINITY;
+  for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) m = max_partials[b] > m ? max_partials[b] : m;
+  *max_out = m;
+  const uint64_t tile0 = cfg->first_slot / O_TILE;
+  const uint64_t ntile = gjx_num_tiles(cfg->n_local);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < (int64_t)ntile; ++b) {
+    uint64_t acc = 0;
+    uint64_t e = ((uint64_t)b + 1) * O_TILE;
+    if (e > cfg->n_local) e = cfg->n_local;
+    for (uint64_t i = (uint64_t)b * O_TILE; i < e; ++i) acc += o_fixw(logw_local[i], m, frac);
+    tile_sums[tile0 + (uint64_t)b] = acc;
+  }
+  return GJX_OK;
+}
+
+int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
+                   gjx_stream s) {
+  (void)s;
+  if (!cfg_ok(cfg) || !tile_sums || !q_out) return GJX_ERR_INVALID;
+  uint64_t Q = 0;
+  for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) Q += tile_sums[b];
+  *q_out = Q;
+  return GJX_OK;
+}
+
+/* max_partials_out: only "max over the array == local max" is specified; the oracle puts the
+ * local max in the rank's first tile entry and -inf elsewhere. */
+static void put_max_partials(const gjx_smc_config* cfg, float mx, float* mp) {
+  for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) mp[b] = -INFINITY;
+  mp[cfg->first_slot / O_TILE] = mx;
+}
+static uint64_t sum_tiles(const gjx_smc_config* cfg, const uint64_t* tiles) {
+  uint64_t Q = 0;
+  for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) Q += tiles[b];
+  return Q;
+}
+
+int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t,
+                         const float* prev_state, const float* prev_logw, const float* prev_max,
+                         const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* state_out,
+                         float* logw_out, float* max_partials_out, int32_t* ancestors_out,
+                         gjx_stream s) {
+  (void)s;
+  if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !state_out || !logw_out || !max_partials_out)
+    return GJX_ERR_INVALID;
+  const uint64_t nl = cfg->n_local;
+  int32_t* anc = NULL;
+  if (t > 0) {
+    if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
+    anc = ancestors_out ? ancestors_out : (int32_t*)malloc(sizeof(int32_t) * nl);
+    if (!anc) return GJX_ERR_LAUNCH;
+    const uint64_t Qprev = sum_tiles(cfg, prev_tile_sums);
+    if (prev_q_out) *prev_q_out = Qprev;
+    smc_ancestors(cfg, t, prev_logw, *prev_max, Qprev, anc);
+  } else if (ancestors_out) {
+    for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
+  }
+  const uint32_t* skey = &cfg->step_keys[2 * t];
+  float mx = -INFINITY;
+#pragma omp parallel for reduction(max : mx) schedule(static)
+  for (int64_t j = 0; j < (int64_t)nl; ++j) {
+    uint32_t pk[2];
+    o_split_at(cfg->impl, skey, cfg->first_slot + (uint64_t)j, pk);
+    o_stream st = o_stream_make(cfg->impl, pk, 1, 1u);
+    float eps = o_std_normal(o_bits32_at(&st, 0));
+    float x;
+    if (t == 0) {
+      float tt = mdl->x0_scale * eps;
+      x = mdl->x0_loc + tt;
+    } else {
+      float mean = mdl->a * prev_state[anc[j]];
+      float tt = mdl->q * eps;
+      x = mean + tt;
+    }
+    float lw = o_logpdf_normal(y_t, x, mdl->r);
+    state_out[j] = x;
+    logw_out[j] = lw;
+    mx = lw > mx ? lw : mx;
+  }
+  put_max_partials(cfg, mx, max_partials_out);
+  if (anc && anc != ancestors_out) free(anc);
+  return GJX_OK;
+}
+
+int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gjx_stream s) {
+  (void)s;
+  if (!mdl || !trans_cdf || !obs_logp || mdl->n_states <= 0 || mdl->n_states > 256 ||
+      !mdl->trans_logits || !mdl->obs_logits)
+    return GJX_ERR_INVALID;
+  const uint32_t K = (uint32_t)mdl->n_states;
+  for (uint32_t r = 0; r < K; ++r) {
+    const float* l = mdl->trans_logits + (size_t)r * K;
+    float m = row_max(l, K);
+    uint32_t C = 0;
+    for (uint32_t c = 0; c < K; ++c) { C += cat_fix(l[c], m); trans_cdf[(size_t)r * K + c] = C; }
+    const float* o = mdl->obs_logits + (size_t)r * K;
+    float lse = row_lse(o, K);
+    for (uint32_t c = 0; c < K; ++c) obs_logp[(size_t)r * K + c] = o[c] - lse;
+  }
+  return GJX_OK;
+}
+
+int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_t y_t,
+                       const int32_t* prev_state, const float* prev_logw, const float* prev_max,
+                       const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
+                       const uint32_t* trans_cdf, const float* obs_logp, int32_t* state_out,
+                       float* logw_out, float* max_partials_out, int32_t* ancestors_out,
+                       gjx_stream s) {
+  (void)s;
+  if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !state_out || !logw_out || !max_partials_out ||
+      !trans_cdf || !obs_logp || y_t < 0 || y_t >= mdl->n_states)
+    return GJX_ERR_INVALID;
+  const uint64_t nl = cfg->n_local;
+  const uint32_t K = (uint32_t)mdl->n_states;
+  int32_t* anc = NULL;
+  if (t > 0) {
+    if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
+    anc = ancestors_out ? ancestors_out : (int32_t*)malloc(sizeof(int32_t) * nl);
+    if (!anc) return GJX_ERR_LAUNCH;
+    const uint64_t Qprev = sum_tiles(cfg, prev_tile_sums);
+    if (prev_q_out) *prev_q_out = Qprev;
+    smc_ancestors(cfg, t, prev_logw, *prev_max, Qprev, anc);
+  } else if (ancestors_out) {
+    for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
+  }
+  const uint32_t* skey = &cfg->step_keys[2 * t];
+  float mx = -INFINITY;
+#pragma omp parallel for reduction(max : mx) schedule(static)
+  for (int64_t j = 0; j < (int64_t)nl; ++j) {
+    uint32_t pk[2];
+    o_split_at(cfg->impl, skey, cfg->first_slot + (uint64_t)j, pk);
+    o_stream st = o_stream_make(cfg->impl, pk, 1, 1u);
+    uint32_t bits = o_bits32_at(&st, 0);
+    int32_t zp = t == 0 ? mdl->init_state : prev_state[anc[j]];
+    const uint32_t* cdf = trans_cdf + (size_t)zp * K;
+    uint64_t thr = ((uint64_t)bits * (uint64_t)cdf[K - 1]) >> 32;
+    uint32_t lo = 0, hi = K - 1; /* first c with cdf[c] > thr */
+    while (lo < hi) {
+      uint32_t mid = (lo + hi) >> 1;
+      if ((uint64_t)cdf[mid] > thr) hi = mid; else lo = mid + 1;
+    }
+    float lw = obs_logp[(size_t)lo * K + (uint32_t)y_t];
+    state_out[j] = (int32_t)lo;
+    logw_out[j] = lw;
+    mx = lw > mx ? lw : mx;
+  }
+  put_max_partials(cfg, mx, max_partials_out);
+  if (anc && anc != ancestors_out) free(anc);
+  return GJX_OK;
+}
+
+/* Whole single-device runs: the straightforward T-loop over the step pieces. */
+static int smc_run_common(const gjx_smc_config* cfg, int is_hmm, const void* model, const void* y,
+                          float* out_max, uint64_t* out_q, void* state_out, float* logw_out,
+                          int32_t* ancestors_out) {
+  if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !model || !y ||
+      !out_max || !out_q || !state_out || !logw_out)
+    return GJX_ERR_INVALID;
+  const uint64_t N = cfg->n_total;
+  const uint64_t ntile = gjx_num_tiles(N);
+  void* st[2] = {malloc(4 * N), malloc(4 * N)};
+  float* lw[2] = {(float*)malloc(4 * N), (float*)malloc(4 * N)};
+  uint64_t* tiles = (uint64_t*)malloc(8 * ntile);
+  float* mp = (float*)malloc(4 * ntile);
+  uint32_t* tcdf = NULL;
+  float* ologp = NULL;
+  int rc = GJX_OK;
+  if (is_hmm) {
+    const gjx_hmm* h = (const gjx_hmm*)model;
+    size_t kk = (size_t)h->n_states * (size_t)h->n_states;
+    tcdf = (uint32_t*)malloc(4 * kk);
+    ologp = (float*)malloc(4 * kk);
+    rc = gjx_hmm_prepare(h, tcdf, ologp, NULL);
+  }
+  for (int t = 0; t < cfg->n_steps && rc == GJX_OK; ++t) {
+    int cur = t & 1, prv = cur ^ 1;
+    int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * N : NULL;
+    if (is_hmm)
+      rc = gjx_smc_hmm_step_a(cfg, (const gjx_hmm*)model, t, ((const int32_t*)y)[t],
+                              (const int32_t*)st[prv], lw[prv], t ? &out_max[t - 1] : NULL, tiles,
+                              t ? &out_q[t - 1] : NULL, tcdf, ologp, (int32_t*)st[cur], lw[cur], mp,
+                              anc_t, NULL);
+    else
+      rc = gjx_smc_lgssm_step_a(cfg, (const gjx_lgssm*)model, t, ((const float*)y)[t],
+                                (const float*)st[prv], lw[prv], t ? &out_max[t - 1] : NULL, tiles,
+                                t ? &out_q[t - 1] : NULL, (float*)st[cur], lw[cur], mp, anc_t, NULL);
+    if (rc == GJX_OK) rc = gjx_smc_step_b(cfg, lw[cur], mp, &out_max[t], tiles, NULL);
+  }
+  if (rc == GJX_OK) rc = gjx_smc_finish(cfg, tiles, &out_q[cfg->n_steps - 1], NULL);
+  if (rc == GJX_OK) {
+    int last = (cfg->n_steps - 1) & 1;
+    memcpy(state_out, st[last], 4 * N);
+    memcpy(logw_out, lw[last], 4 * N);
+  }
+  free(st[0]); free(st[1]); free(lw[0]); free(lw[1]); free(tiles); free(mp); free(tcdf); free(ologp);
+  return rc;
+}
+
+int gjx_smc_run_lgssm(const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y,
+                      float* out_max, uint64_t* out_q, float* state_out, float* logw_out,
+                      int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s) {
+  (void)ws; (void)ws_bytes; (void)s;
+  return smc_run_common(cfg, 0, model, y, out_max, out_q, state_out, logw_out, ancestors_out);
+}
+int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32_t* y,
+                    float* out_max, uint64_t* out_q, int32_t* state_out, float* logw_out,
+                    int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s) {
+  (void)ws; (void)ws_bytes; (void)s;
+  return smc_run_common(cfg, 1, model, y, out_max, out_q, state_out, logw_out, ancestors_out);
+}
+
+/* ---- oracle-only probes (not part of include/gjx.h): raw ciphers and math-spec functions, so the
+ * tests can pin them against Random123 known answers and scipy float64. ------------------------ */
+void gjo_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]) {
+  o_threefry2x32(key[0], key[1], ctr[0], ctr[1], &out[0], &out[1]);
+}
+void gjo_philox4x32(const uint32_t key[2], const uint32_t ctr[4], uint32_t out[4]) {
+  o_philox4x32(key[0], key[1], ctr, out);
+}
+/* fn: 0 log, 1 exp, 2 erfinv, 3 lgamma, 4 std_normal(bits as float bit pattern), 5 uniform01 */
+void gjo_math(int fn, const float* x, float* y, uint64_t n) {
+  for (uint64_t i = 0; i < n; ++i) {
+    switch (fn) {
+      case 0: y[i] = o_log(x[i]); break;
+      case 1: y[i] = o_exp(x[i]); break;
+      case 2: y[i] = o_erfinv(x[i]); break;
+      case 3: y[i] = o_lgamma(x[i]); break;
+      case 4: y[i] = o_std_normal(o_f2u(x[i])); break;
+      default: y[i] = o_uniform01(o_f2u(x[i])); break;
+    }
+  }
+}

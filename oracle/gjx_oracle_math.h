@@ -1,0 +1,314 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product; only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load anything under oracle/.
+ *
+ * Plain-C restatement of the arithmetic the SMC / ImportanceK hot path performs.  In the
+ * reference that arithmetic lives in third-party code that is NOT vendored under /root/reference
+ * (SURVEY F4): jax 0.5.2 / jaxlib 0.5.1 (jax.random threefry2x32, jax.scipy.special.logsumexp)
+ * and tensorflow-probability 0.23.0 (tfd.Normal/Gamma/Beta/Bernoulli/Categorical sample/log_prob),
+ * called from generative_functions/distributions/tensorflow_probability/__init__.py:52-62.
+ * We restate the published algorithms (Salmon et al. SC'11 for Threefry/Philox; Giles 2010 erfinv
+ * as used by XLA; Marsaglia-Tsang 2000 gamma; TFP log_prob formulas) with a fully
+ * specified f32 operation order so that the HIP kernels can be bit-compared.
+ *
+ * PARITY PINNING: the reference cannot be imported here (missing jax/tfp/beartype,
+ * Python 3.10 < 3.11) and its tests hold no random golden vectors.  This oracle is
+ * pinned by: Random123 known-answer vectors (Threefry2x32-20, Philox4x32-10), scipy float64
+ * log-densities, the reference tests' closed-form answers (tests/inference/test_smc.py:32-87,
+ * tests/generative_functions/test_static_gen_fn.py:317-318) and analytic log-Z (Kalman / HMM
+ * forward / conjugate Gaussian).  Bit-level parity with real JAX output is UNPINNED.
+ */
+#ifndef GJX_ORACLE_MATH_H
+#define GJX_ORACLE_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline uint32_t o_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float o_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* ---------------- ciphers (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as
+ * 1, 2, 3", SC'11).  jax.random's default implementation is threefry2x32. -------- */
+
+static inline uint32_t o_rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+static inline void o_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
+                                  uint32_t* o0, uint32_t* o1) {
+  static const int R[8] = {13, 15, 26, 6, 17, 29, 16, 24};
+  uint32_t ks[3] = {k0, k1, 0x1BD11BDAu ^ k0 ^ k1};
+  uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+  for (int blk = 0; blk < 5; ++blk) {
+    for (int r = 0; r < 4; ++r) {
+      x0 += x1;
+      x1 = o_rotl(x1, R[(blk & 1) * 4 + r]);
+      x1 ^= x0;
+    }
+    x0 += ks[(blk + 1) % 3];
+    x1 += ks[(blk + 2) % 3] + (uint32_t)(blk + 1);
+  }
+  *o0 = x0;
+  *o1 = x1;
+}
+
+static inline void o_philox4x32(uint32_t k0, uint32_t k1, const uint32_t c[4], uint32_t out[4]) {
+  uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* ---------------- key derivation ----------------------------------------- *
+ * THREEFRY = jax.random semantics with jax_threefry_partitionable (default from jax 0.5.0,
+ * SURVEY App. A): split(k,n)[i] = TF(k,(0,i)); fold_in(k,d) = TF(k,(0,d)).
+ * PHILOX (native): derive(k, idx, tag) = words 0,1 of PH(ctr=(idx_lo, idx_hi, 0, tag), key=k). */
+#define O_TAG_SPLIT 0x53504C54u /* "SPLT" */
+#define O_TAG_FOLD 0x464F4C44u  /* "FOLD" */
+#define O_TAG_BITS 0x42495453u  /* "BITS" */
+
+static inline void o_split_at(int impl, const uint32_t k[2], uint64_t i, uint32_t out[2]) {
+  if (impl == 0) {
+    o_threefry2x32(k[0], k[1], (uint32_t)(i >> 32), (uint32_t)i, &out[0], &out[1]);
+  } else {
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), 0u, O_TAG_SPLIT}, o[4];
+    o_philox4x32(k[0], k[1], c, o);
+    out[0] = o[0]; out[1] = o[1];
+  }
+}
+static inline void o_fold_in(int impl, const uint32_t k[2], uint32_t d, uint32_t out[2]) {
+  if (impl == 0) {
+    o_threefry2x32(k[0], k[1], 0u, d, &out[0], &out[1]);
+  } else {
+    uint32_t c[4] = {d, 0u, 0u, O_TAG_FOLD}, o[4];
+    o_philox4x32(k[0], k[1], c, o);
+    out[0] = o[0]; out[1] = o[1];
+  }
+}
+/* A draw stream = (key, optional leaf-site counter).  THREEFRY: the stream key is
+ * fold_in(key, fold) (static.py:349-352) and sub-stream `sub` is TF(stream key, (0, sub)).
+ * PHILOX: the leaf fold is carried in the counter instead of costing a block:
+ * words(sub) = PH(ctr = (sub, fold, has_fold, TAG_BITS), key). */
+typedef struct { int impl; uint32_t k[2]; uint32_t f; uint32_t hf; } o_stream;
+
+static inline o_stream o_stream_make(int impl, const uint32_t key[2], int has_fold, uint32_t fold) {
+  o_stream s;
+  s.impl = impl; s.f = 0u; s.hf = 0u;
+  s.k[0] = key[0]; s.k[1] = key[1];
+  if (has_fold) {
+    if (impl == 0) o_fold_in(0, key, fold, s.k);
+    else { s.f = fold; s.hf = 1u; }
+  }
+  return s;
+}
+/* Two raw words of sub-stream `sub`. */
+static inline void o_words(const o_stream* s, uint32_t sub, uint32_t* w0, uint32_t* w1) {
+  if (s->impl == 0) {
+    o_threefry2x32(s->k[0], s->k[1], 0u, sub, w0, w1);
+  } else {
+    uint32_t c[4] = {sub, s->f, s->hf, O_TAG_BITS}, o[4];
+    o_philox4x32(s->k[0], s->k[1], c, o);
+    *w0 = o[0]; *w1 = o[1];
+  }
+}
+/* 32 random bits of element `sub` — jax _threefry_random_bits_partitionable: hi ^ lo. */
+static inline uint32_t o_bits32_at(const o_stream* s, uint32_t sub) {
+  uint32_t w0, w1;
+  o_words(s, sub, &w0, &w1);
+  return s->impl == 0 ? (w0 ^ w1) : w0;
+}
+static inline uint64_t o_bits64_at(const o_stream* s, uint32_t sub) {
+  uint32_t w0, w1;
+  o_words(s, sub, &w0, &w1);
+  return ((uint64_t)w0 << 32) | w1;
+}
+
+/* ---------------- f32 math spec: only IEEE-exact primitives -------------- *
+ * (+, -, *, fmaf, /, sqrtf, rintf, integer ops).  Coefficients: Cephes logf/expf
+ * (Moshier), Giles' single-precision erfinv (the polynomial XLA's ErfInv32 uses). */
+
+static inline float o_log(float x) {
+  uint32_t ix = o_f2u(x);
+  int32_t e = 0;
+  if (ix == 0u) return -INFINITY;
+  if (ix < 0x00800000u) { x = x * 8388608.0f; ix = o_f2u(x); e = -23; }
+  uint32_t t = ix - 0x3f3504f3u;
+  e += (int32_t)t >> 23;
+  float m = o_u2f((t & 0x007fffffu) + 0x3f3504f3u);
+  float f = m - 1.0f;
+  float z = f * f;
+  float p = 7.0376836292E-2f;
+  p = fmaf(p, f, -1.1514610310E-1f);
+  p = fmaf(p, f, 1.1676998740E-1f);
+  p = fmaf(p, f, -1.2420140846E-1f);
+  p = fmaf(p, f, 1.4249322787E-1f);
+  p = fmaf(p, f, -1.6668057665E-1f);
+  p = fmaf(p, f, 2.0000714765E-1f);
+  p = fmaf(p, f, -2.4999993993E-1f);
+  p = fmaf(p, f, 3.3333331174E-1f);
+  float y = (p * f) * z;
+  float fe = (float)e;
+  y = fmaf(fe, -2.12194440e-4f, y);
+  y = fmaf(-0.5f, z, y);
+  float r = f + y;
+  r = fmaf(fe, 0.693359375f, r);
+  return r;
+}
+
+static inline float o_exp(float x) {
+  if (!(x >= -86.0f)) return 0.0f; /* also NaN -> 0 */
+  if (x > 88.0f) x = 88.0f;
+  float fx = rintf(x * 1.44269504088896341f);
+  x = fmaf(fx, -0.693359375f, x);
+  x = fmaf(fx, 2.12194440e-4f, x);
+  float z = x * x;
+  float p = 1.9875691500E-4f;
+  p = fmaf(p, x, 1.3981999507E-3f);
+  p = fmaf(p, x, 8.3334519073E-3f);
+  p = fmaf(p, x, 4.1665795894E-2f);
+  p = fmaf(p, x, 1.6666665459E-1f);
+  p = fmaf(p, x, 5.0000001201E-1f);
+  float y = fmaf(p, z, x) + 1.0f;
+  int32_t n = (int32_t)fx;
+  return o_u2f(o_f2u(y) + ((uint32_t)n << 23));
+}
+
+static inline float o_erfinv(float x) {
+  float w = -o_log((1.0f - x) * (1.0f + x));
+  float p;
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f;
+    p = fmaf(p, w, 3.43273939e-07f);
+    p = fmaf(p, w, -3.5233877e-06f);
+    p = fmaf(p, w, -4.39150654e-06f);
+    p = fmaf(p, w, 0.00021858087f);
+    p = fmaf(p, w, -0.00125372503f);
+    p = fmaf(p, w, -0.00417768164f);
+    p = fmaf(p, w, 0.246640727f);
+    p = fmaf(p, w, 1.50140941f);
+  } else {
+    w = sqrtf(w) - 3.0f;
+    p = -0.000200214257f;
+    p = fmaf(p, w, 0.000100950558f);
+    p = fmaf(p, w, 0.00134934322f);
+    p = fmaf(p, w, -0.00367342844f);
+    p = fmaf(p, w, 0.00573950773f);
+    p = fmaf(p, w, -0.0076224613f);
+    p = fmaf(p, w, 0.00943887047f);
+    p = fmaf(p, w, 1.00167406f);
+    p = fmaf(p, w, 2.83297682f);
+  }
+  return p * x;
+}
+
+/* lgamma for x > 0: recurrence up to x >= 8, then Stirling with three correction terms. */
+static inline float o_lgamma(float x) {
+  float p = 1.0f;
+  for (int i = 0; i < 8; ++i) {
+    if (x < 8.0f) { p = p * x; x = x + 1.0f; }
+  }
+  float xi = 1.0f / x;
+  float xi2 = xi * xi;
+  float s = fmaf(xi2, 7.9365079365e-4f, -2.7777777778e-3f);
+  s = fmaf(s, xi2, 8.3333333333e-2f);
+  s = s * xi;
+  float r = (x - 0.5f) * o_log(x);
+  r = r - x;
+  r = r + 0.91893853320467f;
+  r = r + s;
+  r = r - o_log(p);
+  return r;
+}
+
+/* jax.random.uniform bit trick: 23 mantissa bits -> [0,1). */
+static inline float o_uniform01(uint32_t bits) { return o_u2f((bits >> 9) | 0x3F800000u) - 1.0f; }
+
+/* jax.random.normal: u ~ U(nextafter(-1,0), 1); sqrt(2) * erfinv(u)  (SURVEY App. A). */
+static inline float o_std_normal(uint32_t bits) {
+  const float lo = -0.99999994f;
+  float u = o_uniform01(bits) * 2.0f + lo;
+  u = u > lo ? u : lo;
+  return 1.41421356237309505f * o_erfinv(u);
+}
+
+/* ---------------- log-densities (TFP formulas) ----------------------------- */
+
+static inline float o_logpdf_normal(float x, float loc, float scale) {
+  float rs = 1.0f / scale;
+  float lognorm = 0.91893853320467f + o_log(scale);
+  float d = x * rs - loc * rs;
+  return (-0.5f * d) * d - lognorm;
+}
+static inline float o_xlogy(float a, float y) { return a == 0.0f ? 0.0f : a * o_log(y); }
+static inline float o_logpdf_gamma(float x, float conc, float rate) {
+  float lognorm = o_lgamma(conc) - conc * o_log(rate);
+  return (o_xlogy(conc - 1.0f, x) - rate * x) - lognorm;
+}
+static inline float o_logpdf_beta(float x, float a, float b) {
+  float lbeta = (o_lgamma(a) + o_lgamma(b)) - o_lgamma(a + b);
+  return (o_xlogy(a - 1.0f, x) + o_xlogy(b - 1.0f, 1.0f - x)) - lbeta;
+}
+static inline float o_logpdf_bernoulli(int e, float p) {
+  return e ? o_log(p) : o_log(1.0f - p);
+}
+
+/* ---------------- samplers ------------------------------------------------------------------ */
+
+/* Marsaglia & Tsang (2000) Gamma(conc, 1) on sub-streams of `key`: attempt a of gamma `which`
+ * (0/1; Beta draws two) uses words(sub = 1 + 2a + which): w0 -> normal, w1 -> uniform.  The
+ * conc < 1 boost uniform is word `which` of sub 0.  At most 64 attempts (then accept). */
+static inline float o_std_gamma(const o_stream* st, int which, float conc) {
+  int boost = conc < 1.0f;
+  float a = boost ? conc + 1.0f : conc;
+  float d = a - 0.33333334f;
+  float c = 1.0f / sqrtf(9.0f * d);
+  float v = 1.0f;
+  for (int att = 0; att < 64; ++att) {
+    uint32_t w0, w1;
+    o_words(st, (uint32_t)(1 + 2 * att + which), &w0, &w1);
+    float x = o_std_normal(w0);
+    float t = 1.0f + c * x;
+    if (t <= 0.0f) continue;
+    v = (t * t) * t;
+    float u = o_uniform01(w1);
+    float rhs = (0.5f * x) * x + d;
+    rhs = rhs - d * v;
+    rhs = rhs + d * o_log(v);
+    if (o_log(u) < rhs) break;
+  }
+  float g = d * v;
+  if (boost) {
+    uint32_t w0, w1;
+    o_words(st, 0u, &w0, &w1);
+    float ub = o_uniform01(which ? w1 : w0);
+    g = g * o_exp(o_log(ub) / conc);
+  }
+  return g;
+}
+
+/* ---------------- fixed-point weights ------------------------------------ */
+static inline int o_frac_bits(uint64_t n_total) {
+  int lg = 0;
+  while (lg < 63 && ((uint64_t)1 << lg) < n_total) ++lg;
+  int f = 62 - lg;
+  return f > 40 ? 40 : (f < 8 ? 8 : f);
+}
+static inline uint64_t o_fixw(float lw, float m, int frac) {
+  if (lw == m) return (uint64_t)1 << frac;
+  float d = lw - m;
+  if (!(d >= -80.0f)) return 0;
+  float s = o_exp(d);
+  float t = s * o_u2f((uint32_t)(127 + frac) << 23); /* * 2^frac, exact */
+  return (uint64_t)rintf(t);
+}
+
+#endif
