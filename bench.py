@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path of BASELINE.json on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload importance|smc_lgssm|smc_hmm]
+                  [--rng philox|threefry] [--no-cpu-baseline] [--no-extra]
+
+A "step" is one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
+  importance (default, BASELINE configs[1]): ImportanceK on the 10-latent Gaussian model, 1e6
+      particles per GPU: fused `@gen`-body kernel (RNG -> samplers -> SoA trace columns -> score,
+      log-weights, per-tile max) + fixed-point log-sum-exp.  value = particles/s.
+  smc_lgssm (configs[2]): bootstrap SMC, T=100, 1e6 particles per GPU.  value = particle-steps/s.
+  smc_hmm   (configs[4]): 256-state HMM, T=500.
+For N>1 (launched by torch.distributed.run, one rank per GPU) the particle population is sharded
+(weak scaling); importance needs one all-reduce(max) + one all-reduce(sum) of the log-normaliser.
+Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "genjax-chi_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_PER_GPU = 1_000_000
+# Algorithmic bytes per unit (SURVEY §8d / DESIGN.md §5)
+BYTES_IMPORTANCE_PER_PARTICLE = 52  # 10 latent columns + score + logw written, logw re-read
+BYTES_IMPORTANCE_KERNEL_PER_PARTICLE = 48  # the dominant kernel's share (everything but the re-read)
+BYTES_SMC_PER_PARTICLE_STEP = 44
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--workload", default="importance", choices=["importance", "smc_lgssm", "smc_hmm"])
+    p.add_argument("--rng", default="philox", choices=["philox", "threefry"])
+    p.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra", action="store_true")
+    return p.parse_args()
+
+
+def init_dist(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
+    else:
+        torch.cuda.set_device(0)
+    return rank, world
+
+
+def barrier_sync(world):
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds, world):
+    if world == 1:
+        return seconds
+    import torch.distributed as dist
+
+    t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def bench_importance(args, ops, rank, world):
+    import torch.distributed as dist
+
+    from genjax._amd import workloads as W
+
+    impl = 1 if args.rng == "philox" else 0
+    n = args.particles
+    wl = W.Gaussian10(ops, impl, seed=0, n_local=n, first=rank * n, n_total=world * n)
+    kernel_ms = []
+
+    def step(timed):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        vals, score, logw, mp = ops.importance_run(wl.plan, wl.keys, n, [], [torch.float32] * W.G10_LATENTS)
+        if timed:
+            e1.record()
+            kernel_ms.append((e0, e1))
+        if world == 1:
+            lse, m, q = ops.logsumexp(logw, max_partials=mp)
+        else:
+            m = ops.max_f32(None, n, max_partials=mp)
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)
+            q = ops.expsum_fix(logw, m, wl.frac)
+            dist.all_reduce(q, op=dist.ReduceOp.SUM)
+        return m, q, logw
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m, q, logw = step(True)
+    barrier_sync(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    k_ms = sum(a.elapsed_time(b) for a, b in kernel_ms) / len(kernel_ms)
+    ms_per_step = dt / args.steps * 1e3
+    total_particles = n * world
+    log_z = float(m.cpu()) + math.log(int(q.cpu())) - wl.frac * math.log(2.0) - math.log(total_particles)
+    achieved = BYTES_IMPORTANCE_KERNEL_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9
+    res = {
+        "metric": "particles/sec, ImportanceK log-marginal-likelihood estimate (1e6 particles per GPU)",
+        "value": total_particles / (dt / args.steps),
+        "unit": "particles/s",
+        "ms_per_step": ms_per_step,
+        "config": {"workload": "ImportanceK k_particles=1e6/GPU on a 10-latent Gaussian model (BASELINE configs[1])",
+                   "particles_per_gpu": n, "latent_sites": 10, "observed_sites": 10, "rng": args.rng,
+                   "parallelism": f"particle-sharded x{world}"},
+        "roofline": {"bound": "hbm", "kernel": "k_importance", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": BYTES_IMPORTANCE_KERNEL_PER_PARTICLE * n},
+        "log_z": log_z,
+        "log_z_exact": W.gaussian10_exact_log_z(wl.y),
+    }
+    return res, wl
+
+
+def bench_smc(args, ops, rank, world, kind):
+    from genjax._amd import prng, workloads as W
+
+    impl = 1 if args.rng == "philox" else 0
+    n = args.particles
+    if world > 1:
+        from genjax._amd import dist_smc
+
+        return dist_smc.bench(args, ops, rank, world, kind)
+    T = 100 if kind == "smc_lgssm" else 500
+    run = (lambda: W.lgssm_smc(ops, impl, 1, n, T)) if kind == "smc_lgssm" else (lambda: W.hmm_smc(ops, impl, 2, n, T))
+    for _ in range(max(1, min(args.warmup, 2))):
+        r = run()
+    barrier_sync(world)
+    steps = max(1, min(args.steps, 10))
+    t0 = time.perf_counter()
+    evs = []
+    for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = run()
+        e1.record()
+        evs.append((e0, e1))
+    barrier_sync(world)
+    dt = (time.perf_counter() - t0) / steps
+    dev_ms = sum(a.elapsed_time(b) for a, b in evs) / steps
+    per_step_ms = dev_ms / T
+    achieved = BYTES_SMC_PER_PARTICLE_STEP * n / (per_step_ms * 1e-3) / 1e9
+    return {
+        "metric": "particle-steps/sec, bootstrap SMC (1e6 particles per GPU)",
+        "value": n * T / dt,
+        "unit": "particle-steps/s",
+        "ms_per_step": dt * 1e3,
+        "config": {"workload": f"bootstrap SMC {kind} T={T} N={n}", "rng": args.rng},
+        "roofline": {"bound": "hbm", "kernel": "k_resample+k_tile_sums (one SMC step)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "step_ms": per_step_ms, "algorithmic_bytes_per_launch": BYTES_SMC_PER_PARTICLE_STEP * n},
+        "log_z": r["log_z"], "log_z_exact": r["log_z_exact"],
+    }
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a port: plain C + OpenMP restatement) timed on this box's host cores on a
+    bounded sample of the same workload."""
+    from genjax._amd import workloads as W
+    from genjax._amd.abi import GjxLib
+    from genjax._amd.ops import Ops
+
+    lib = os.path.join(ROOT, "oracle", "libgjx_oracle.so")
+    if not os.path.exists(lib):
+        return None
+    ora = Ops(GjxLib(lib, "cpu"))
+    impl = 1 if args.rng == "philox" else 0
+    cores = os.cpu_count() or 1
+    if args.workload == "importance":
+        n = args.particles
+        wl = W.Gaussian10(ora, impl, seed=0, n_local=n)
+        wl.step()
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0:
+            wl.step()
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": n * reps / dt, "unit": "particles/s", "cores": cores, "kind": "port",
+                "sample": f"{reps} full passes of the same {n}-particle ImportanceK workload (OpenMP, {cores} threads)"}
+    T = 10
+    n = args.particles
+    fn = W.lgssm_smc if args.workload == "smc_lgssm" else W.hmm_smc
+    seed = 1 if args.workload == "smc_lgssm" else 2
+    fn(ora, impl, seed, n, 2)
+    t0 = time.perf_counter()
+    fn(ora, impl, seed, n, T)
+    dt = time.perf_counter() - t0
+    return {"value": n * T / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": f"first {T} steps of the same {n}-particle filter (propagate/weight OpenMP over {cores} threads, "
+                      "resampling scan sequential)"}
+
+
+def main():
+    args = parse()
+    rank, world = init_dist(args.gpus)
+    from genjax._amd.runtime import load_hip_ops
+
+    ops = load_hip_ops()  # raises without libgjx_hip.so / a GPU: there is no CPU fallback
+    if args.workload == "importance":
+        res, _ = bench_importance(args, ops, rank, world)
+    else:
+        res = bench_smc(args, ops, rank, world, args.workload)
+    if rank == 0:
+        out = {
+            "metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": res.pop("config"), "roofline": res.pop("roofline"),
+        }
+        out.update(res)
+        out["log_z_abs_err_vs_exact"] = abs(out["log_z"] - out["log_z_exact"])
+        if world == 1 and not args.no_extra and args.workload == "importance":
+            extra = {}
+            for kind in ("smc_lgssm",):
+                a2 = argparse.Namespace(**vars(args))
+                a2.steps, a2.warmup = 5, 1
+                r = bench_smc(a2, ops, rank, world, kind)
+                extra[kind] = {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "log_z", "log_z_exact")}
+            a2 = argparse.Namespace(**vars(args))
+            a2.rng = "threefry" if args.rng == "philox" else "philox"
+            a2.steps, a2.warmup = 20, 3
+            r, _ = bench_importance(a2, ops, rank, world)
+            extra[f"importance_{a2.rng}"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "log_z")}
+            out["extra"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

