@@ -1,0 +1,514 @@
+"""`Target`, `Algorithm`, `Marginal` and the SMC algorithm family on vectorised traces.
+
+Mirrors inference/sp.py:52-273 and inference/smc.py:56-465 of the reference: same constructors,
+methods, key-derivation order (SURVEY §3.5 including the key-reuse quirks) and error behaviour.
+What differs is the execution model: where the reference `vmap`s a per-particle function, a key
+batch of K keys drives ONE run of the model over K-wide device columns; `logsumexp`, the
+categorical draw of `sample_particle`, resampling and ancestor gathers are C-ABI kernels.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Any
+
+import torch
+
+from . import prng
+from .choicemap import ChoiceMap, Selection
+from .lang import (Distribution, DistributionTrace, GenerativeFunction, ParticleKeys, Trace, _map_any, split,
+                   squeeze_leaf)
+from .ops import KeyBatch
+from .runtime import get_ops
+
+
+# =================================================================================================
+# Target  (inference/sp.py:52-94)
+# =================================================================================================
+class Target:
+    """Unnormalised posterior: a generative function, its arguments and a constraint."""
+
+    def __init__(self, p: GenerativeFunction, args: tuple, constraint: ChoiceMap):
+        if isinstance(p, Marginal):  # sp.py:46-49,79
+            raise TypeError("Target does not support Marginal generative functions.")
+        if not isinstance(p, GenerativeFunction):
+            raise TypeError(f"Target: p must be a GenerativeFunction, got {type(p).__name__}")
+        if not isinstance(args, tuple):
+            raise TypeError("Target: args must be a tuple")
+        if not isinstance(constraint, ChoiceMap):
+            raise TypeError("Target: constraint must be a ChoiceMap")
+        self.p, self.args, self.constraint = p, args, constraint
+
+    def importance(self, key, constraint: ChoiceMap):
+        merged = self.constraint.merge(constraint)
+        return self.p.importance(key, merged, self.args)
+
+    def filter_to_unconstrained(self, choice_map: ChoiceMap) -> ChoiceMap:
+        return choice_map.filter(~self.constraint.get_selection())
+
+    def __getitem__(self, addr):
+        return self.constraint[addr]
+
+
+# =================================================================================================
+# Algorithm / SampleDistribution  (inference/sp.py:101-199)
+# =================================================================================================
+class SampleDistribution(Distribution):
+    """Distributions whose return value is a ChoiceMap."""
+
+    def canonical_args(self, args, kwargs):
+        return tuple(args)
+
+    def simulate(self, key, args):
+        w, v = self.random_weighted(key, *args)
+        return DistributionTrace(self, args, v, w)
+
+    def __call__(self, *args, **kwargs):
+        return super().__call__(*args, **kwargs)
+
+
+class Algorithm(SampleDistribution):
+    def random_weighted(self, key, *args):
+        raise NotImplementedError
+
+    def estimate_logpdf(self, key, v, *args):
+        raise NotImplementedError
+
+    def estimate_normalizing_constant(self, key, target):
+        raise NotImplementedError
+
+    def estimate_reciprocal_normalizing_constant(self, key, target, latent_choices, w):
+        raise NotImplementedError
+
+
+# =================================================================================================
+# ParticleCollection  (inference/smc.py:76-109)
+# =================================================================================================
+class ParticleCollection:
+    """Weighted particles: a trace whose leaves carry the particle axis, log-weights f32[K]."""
+
+    def __init__(self, particles: Trace, log_weights: torch.Tensor, is_valid=True, max_partials=None):
+        self.particles, self.log_weights, self.is_valid = particles, log_weights, is_valid
+        self._max_partials = max_partials
+        self._lse = None
+
+    def get_particles(self) -> Trace:
+        return self.particles
+
+    def get_log_weights(self) -> torch.Tensor:
+        return self.log_weights
+
+    def __len__(self):
+        return int(self.log_weights.shape[0])
+
+    def _lse_triple(self):
+        if self._lse is None:
+            lw = self.log_weights.contiguous()
+            self._lse = get_ops().logsumexp(lw, max_partials=self._max_partials)
+        return self._lse
+
+    def get_log_marginal_likelihood_estimate(self) -> torch.Tensor:
+        """logsumexp(log_weights) - log K  (smc.py:96-97), f32 scalar tensor on the device."""
+        lse, _, _ = self._lse_triple()
+        return lse[0] - math.log(len(self))
+
+    def log_marginal_likelihood_estimate_f64(self) -> float:
+        """The same estimate evaluated in float64 from the exact (max, fixed-point sum) pair."""
+        _, m, q = self._lse_triple()
+        n = len(self)
+        return float(m.cpu()) + math.log(int(q.cpu())) - get_ops().frac_bits(n) * math.log(2.0) - math.log(n)
+
+    def get_particle(self, idx) -> Trace:
+        """tree_map(lambda v: v[idx]) over the trace (smc.py:90-91)."""
+        if isinstance(idx, torch.Tensor):
+            idx = int(idx.reshape(-1)[0].cpu())
+        n = len(self)
+        return self.particles.map_leaves(lambda v: v[idx] if _has_particle_axis(v, n) else v)
+
+    def __getitem__(self, idx):
+        return self.get_particle(idx), self.log_weights[idx]
+
+    def sample_particle(self, key) -> Trace:
+        """One particle with probability proportional to its weight (smc.py:102-109): a
+        categorical draw over log_weights - logsumexp(log_weights) — the normaliser is a constant
+        shift, which neither Gumbel-max nor the inverse-CDF draw depends on."""
+        ops = get_ops()
+        kb = _literal_key(key)
+        idx = ops.categorical_index(kb, self.log_weights.contiguous(), mode=0)
+        return self.get_particle(idx)
+
+    # -- resampling (not in the reference library: SURVEY F3/E2) -----------------------------------
+    def resample(self, key, method: str = "systematic", n_out: int | None = None) -> "ParticleCollection":
+        """New equally weighted collection whose particles are drawn with probability proportional
+        to the weights.  log-weights become logsumexp(lw) - log K, preserving the estimate."""
+        ops = get_ops()
+        n = len(self)
+        anc, _, _ = ops.resample(method, _literal_key(key), self.log_weights.contiguous(), n_out)
+        new = gather_trace(self.particles, anc, n)
+        lz = self.get_log_marginal_likelihood_estimate()
+        k = anc.shape[0]
+        lw = torch.zeros(k, dtype=torch.float32, device=self.log_weights.device) + lz
+        out = ParticleCollection(new, lw, self.is_valid)
+        out.ancestors = anc
+        return out
+
+    def effective_sample_size(self) -> float:
+        lw = self.log_weights.double()
+        lw = lw - lw.max()
+        w = torch.exp(lw)
+        return float((w.sum() ** 2 / (w * w).sum()).cpu())
+
+
+def _has_particle_axis(v, n) -> bool:
+    return isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == n
+
+
+def _literal_key(key) -> KeyBatch:
+    if isinstance(key, prng.PRNGKey):
+        return key.literal()
+    raise TypeError("expected a scalar PRNG key")
+
+
+def gather_trace(trace: Trace, ancestors: torch.Tensor, n: int) -> Trace:
+    """trace[ancestors] for every leaf with the particle axis; 4-byte columns go through the
+    gather kernel in one launch."""
+    ops = get_ops()
+    cols, seen = [], {}
+
+    def collect(v):
+        if _has_particle_axis(v, n) and v.dim() == 1 and v.element_size() == 4 and v.is_contiguous():
+            if id(v) not in seen:
+                seen[id(v)] = len(cols)
+                cols.append(v)
+        return v
+
+    trace.map_leaves(collect)
+    gathered = ops.gather_cols(ancestors, cols) if cols else []
+    idx64 = None
+
+    def apply(v):
+        nonlocal idx64
+        if id(v) in seen:
+            return gathered[seen[id(v)]]
+        if _has_particle_axis(v, n):
+            if idx64 is None:
+                idx64 = ancestors.long()
+            return v[idx64]
+        return v
+
+    return trace.map_leaves(apply)
+
+
+def stack_to_first_dim(a, b):
+    """CSMC stacking helper (smc.py:56-68): concatenate along the first axis, then squeeze."""
+    ops = get_ops()
+    a = torch.as_tensor(a, device=ops.device()) if not isinstance(a, torch.Tensor) else a
+    b = torch.as_tensor(b, device=a.device) if not isinstance(b, torch.Tensor) else b.to(a.device)
+    if a.dim() <= 1:
+        a = a.reshape(-1, 1)
+    if b.dim() <= 1:
+        b = b.reshape(-1, 1)
+    if a.dtype != b.dtype:
+        b = b.to(a.dtype)
+    return torch.cat([a, b], dim=0).squeeze()
+
+
+def _col_of(v, n: int):
+    """Broadcast a per-trace scalar leaf to a [n] column (constrained constants are stored once)."""
+    ops = get_ops()
+    if isinstance(v, torch.Tensor):
+        if v.dim() >= 1 and v.shape[0] == n:
+            return v
+        return v.reshape(1).expand(n).contiguous() if v.dim() == 0 else v
+    if isinstance(v, bool):
+        return torch.full((n,), v, dtype=torch.bool, device=ops.device())
+    if isinstance(v, int):
+        return torch.full((n,), v, dtype=torch.int32, device=ops.device())
+    if isinstance(v, float):
+        return torch.full((n,), v, dtype=torch.float32, device=ops.device())
+    return v
+
+
+def _stack_leaf(a, na: int, b):
+    a = _col_of(a, na)
+    if not isinstance(a, torch.Tensor):
+        return a
+    b = torch.as_tensor(b, device=a.device).to(a.dtype).reshape((1,) + tuple(a.shape[1:]))
+    return torch.cat([a, b], dim=0)
+
+
+def _stack_traces(a: Trace, na: int, b: Trace) -> Trace:
+    """tree_map(stack_to_first_dim, a, b): `a` carries na particles, `b` one; b goes LAST."""
+    from .lang import MaterialTrace
+
+    ca, cb = dict(a.get_choices().leaves()), dict(b.get_choices().leaves())
+    choices = ChoiceMap.from_mapping([(addr, _stack_leaf(v, na, cb[addr])) for addr, v in ca.items()])
+    ra, rb = a.get_retval(), b.get_retval()
+    retval = _stack_leaf(ra, na, rb) if isinstance(ra, (torch.Tensor, bool, int, float)) else ra
+    return MaterialTrace(a.get_gen_fn(), a.get_args(), retval, choices, _stack_leaf(a.get_score(), na, b.get_score()))
+
+
+def _expand0(trace: Trace) -> Trace:
+    return trace.map_leaves(lambda v: v[None] if isinstance(v, torch.Tensor) else v)
+
+
+def _as_col(v, n=1):
+    ops = get_ops()
+    if isinstance(v, torch.Tensor):
+        return v.reshape(-1).to(torch.float32)
+    return torch.full((n,), float(v), dtype=torch.float32, device=ops.device())
+
+
+# =================================================================================================
+# SMC algorithms  (inference/smc.py:117-465)
+# =================================================================================================
+class SMCAlgorithm(Algorithm):
+    """Abstract SMC algorithm: `run_smc`, `run_csmc`, and the derived estimators."""
+
+    def get_num_particles(self) -> int:
+        raise NotImplementedError
+
+    def get_final_target(self) -> Target:
+        raise NotImplementedError
+
+    def run_smc(self, key) -> ParticleCollection:
+        raise NotImplementedError
+
+    def run_csmc(self, key, retained: ChoiceMap) -> ParticleCollection:
+        raise NotImplementedError
+
+    def log_marginal_likelihood_estimate(self, key, target: Target | None = None):
+        algorithm = ChangeTarget(self, target) if target else self
+        key, sub_key = split(key)
+        return algorithm.run_smc(sub_key).get_log_marginal_likelihood_estimate()
+
+    # -- GenSP ---------------------------------------------------------------------------------------
+    def random_weighted(self, key, *args):
+        assert isinstance(args[0], Target)
+        target = args[0]
+        algorithm = ChangeTarget(self, target)
+        key, sub_key = split(key)
+        collection = algorithm.run_smc(key)
+        particle = collection.sample_particle(sub_key)
+        log_density_estimate = particle.get_score() - collection.get_log_marginal_likelihood_estimate()
+        chm = target.filter_to_unconstrained(particle.get_choices())
+        return log_density_estimate, chm
+
+    def estimate_logpdf(self, key, v: ChoiceMap, *args):
+        assert isinstance(args[0], Target)
+        target = args[0]
+        algorithm = ChangeTarget(self, target)
+        key, sub_key = split(key)
+        collection = algorithm.run_csmc(key, v)
+        particle = collection.sample_particle(sub_key)
+        return particle.get_score() - collection.get_log_marginal_likelihood_estimate()
+
+    # -- VI via GRASP ----------------------------------------------------------------------------------
+    def estimate_normalizing_constant(self, key, target: Target):
+        algorithm = ChangeTarget(self, target)
+        key, sub_key = split(key)
+        return algorithm.run_smc(sub_key).get_log_marginal_likelihood_estimate()
+
+    def estimate_reciprocal_normalizing_constant(self, key, target: Target, latent_choices: ChoiceMap, w):
+        algorithm = ChangeTarget(self, target)
+        return algorithm.run_csmc_for_normalizing_constant(key, latent_choices, w)
+
+
+class Importance(SMCAlgorithm):
+    """One-particle importance sampling, optional proposal `q` (smc.py:233-279)."""
+
+    def __init__(self, target: Target, q: SampleDistribution | None = None):
+        self.target, self.q = target, q
+
+    def get_num_particles(self):
+        return 1
+
+    def get_final_target(self):
+        return self.target
+
+    def run_smc(self, key):
+        key, sub_key = split(key)
+        if self.q is not None:
+            log_weight, choice = self.q.random_weighted(sub_key, self.target)
+            tr, target_score = self.target.importance(key, choice)
+        else:
+            log_weight = 0.0
+            tr, target_score = self.target.importance(key, ChoiceMap.empty())
+        return ParticleCollection(_expand0(tr), _as_col(target_score - log_weight), True)
+
+    def run_csmc(self, key, retained: ChoiceMap):
+        key, sub_key = split(key)
+        q_score = self.q.estimate_logpdf(sub_key, retained, self.target) if self.q else 0.0
+        tr, target_score = self.target.importance(key, retained)
+        return ParticleCollection(_expand0(tr), _as_col(target_score - q_score), True)
+
+
+class ImportanceK(SMCAlgorithm):
+    """K-particle importance sampling (smc.py:282-351): `k_particles` keys, ONE batched run."""
+
+    def __init__(self, target: Target, q: SampleDistribution | None = None, k_particles: int = 2):
+        self.target, self.q, self.k_particles = target, q, int(k_particles)
+
+    def get_num_particles(self):
+        return self.k_particles
+
+    def get_final_target(self):
+        return self.target
+
+    def run_smc(self, key):
+        key, sub_key = split(key)
+        sub_keys = split(sub_key, self.get_num_particles())
+        if self.q is not None:
+            # the SAME sub_keys drive the proposal and the target (smc.py:302-305)
+            log_weights, choices = _batched_random_weighted(self.q, sub_keys, self.target)
+            trs, target_scores = self.target.importance(sub_keys, choices)
+            return ParticleCollection(trs, target_scores - log_weights, True)
+        trs, target_scores = self.target.importance(sub_keys, ChoiceMap.empty())
+        return ParticleCollection(trs, target_scores, True, max_partials=getattr(trs, "max_partials", None))
+
+    def run_csmc(self, key, retained: ChoiceMap):
+        k = self.get_num_particles()
+        key, sub_key = split(key)
+        sub_keys = split(sub_key, k - 1)
+        if self.q:
+            log_scores, choices = _batched_random_weighted(self.q, sub_keys, self.target)
+            retained_choice_score = self.q.estimate_logpdf(key, retained, self.target)
+            stacked_choices = _stack_choice_maps(choices, k - 1, retained)
+            stacked_scores = _stack_leaf(log_scores, k - 1, retained_choice_score)
+            sub_keys = split(key, k)
+            target_traces, target_scores = self.target.importance(sub_keys, stacked_choices)
+        else:
+            if k > 1:
+                ignored_traces, ignored_scores = self.target.importance(sub_keys, ChoiceMap.empty())
+            retained_trace, retained_choice_score = self.target.importance(key, retained)
+            if k > 1:
+                target_scores = _stack_leaf(ignored_scores, k - 1, retained_choice_score)
+                target_traces = _stack_traces(ignored_traces, k - 1, retained_trace)  # retained particle LAST
+            else:
+                target_scores = _as_col(retained_choice_score)
+                target_traces = _expand0(retained_trace)
+            stacked_scores = 0.0
+        return ParticleCollection(target_traces, (target_scores - stacked_scores).reshape(-1), True)
+
+
+def _batched_random_weighted(q, sub_keys: ParticleKeys, target: Target):
+    """vmap(q.random_weighted, in_axes=(0, None))(sub_keys, target)."""
+    if hasattr(q, "batched_random_weighted"):
+        return q.batched_random_weighted(sub_keys, target)
+    # generic proposals run once per key (the reference vmaps them); their results are stacked
+    ws, chms = [], []
+    for k in sub_keys:
+        w, chm = q.random_weighted(k, target)
+        ws.append(torch.as_tensor(w, dtype=torch.float32, device=get_ops().device()).reshape(()))
+        chms.append(dict(chm.leaves()))
+    choices = ChoiceMap.from_mapping(
+        [(addr, torch.stack([torch.as_tensor(c[addr], device=get_ops().device()) for c in chms])) for addr in chms[0]])
+    return torch.stack(ws), choices
+
+
+def _stack_choice_maps(batched: ChoiceMap, n: int, single: ChoiceMap) -> ChoiceMap:
+    sdict = dict(single.leaves())
+    return ChoiceMap.from_mapping([(addr, _stack_leaf(v, n, sdict[addr])) for addr, v in batched.leaves()])
+
+
+class ChangeTarget(SMCAlgorithm):
+    """Re-weight a collection for a new target (smc.py:359-465)."""
+
+    def __init__(self, prev: SMCAlgorithm, target: Target):
+        self.prev, self.target = prev, target
+
+    def get_num_particles(self):
+        return self.prev.get_num_particles()
+
+    def get_final_target(self):
+        return self.target
+
+    def _reweight(self, key, collection: ParticleCollection, n_keys: int, upto: int | None = None):
+        """vmap(_reweight)(split(key, n), particles, weights): constrain the new target to the
+        particles' latent choices, w' = new_weight - old_score + w."""
+        particles, weights = collection.get_particles(), collection.get_log_weights()
+        if upto is not None:
+            n_all = len(collection)
+            particles = particles.map_leaves(lambda v: v[:upto] if _has_particle_axis(v, n_all) else v)
+            weights = weights[:upto]
+        if self.target is self.prev.get_final_target() and upto is None:
+            # Identical target object: new_weight is the particle's full score recomputed by the same
+            # kernels, so new_weight - score + w == w bit for bit; skip the second pass.
+            return particles, weights
+        latents = self.prev.get_final_target().filter_to_unconstrained(particles.get_choices())
+        sub_keys = split(key, n_keys)
+        new_trace, new_weight = self.target.importance(sub_keys, latents)
+        return new_trace, new_weight - particles.get_score() + weights
+
+    def run_smc(self, key):
+        collection = self.prev.run_smc(key)
+        new_particles, new_weights = self._reweight(key, collection, self.get_num_particles())
+        return ParticleCollection(new_particles, new_weights, True,
+                                  max_partials=collection._max_partials if new_weights is collection.log_weights else None)
+
+    def run_csmc(self, key, retained: ChoiceMap):
+        collection = self.prev.run_csmc(key, retained)
+        new_particles, new_weights = self._reweight(key, collection, self.get_num_particles())
+        return ParticleCollection(new_particles, new_weights, True)
+
+    def run_csmc_for_normalizing_constant(self, key, latent_choices: ChoiceMap, w):
+        key, sub_key = split(key)
+        collection = self.prev.run_csmc(sub_key, latent_choices)
+        num_particles = self.get_num_particles()
+        retained_score = collection.get_particle(-1).get_score()
+        retained_weight = collection.get_log_weights()[-1]
+        tail = _as_col(w - retained_score + retained_weight)
+        if num_particles > 1:
+            _, rejected = self._reweight_always(key, collection, num_particles - 1, upto=num_particles - 1)
+            all_weights = torch.cat([rejected.reshape(-1), tail])
+        else:
+            all_weights = tail
+        lse, _, _ = get_ops().logsumexp(all_weights.contiguous())
+        return retained_score - (lse[0] - math.log(num_particles))
+
+    def _reweight_always(self, key, collection, n_keys, upto):
+        n_all = len(collection)
+        particles = collection.get_particles().map_leaves(lambda v: v[:upto] if _has_particle_axis(v, n_all) else v)
+        weights = collection.get_log_weights()[:upto]
+        latents = self.prev.get_final_target().filter_to_unconstrained(particles.get_choices())
+        new_trace, new_weight = self.target.importance(split(key, n_keys), latents)
+        return new_trace, new_weight - particles.get_score() + weights
+
+
+# =================================================================================================
+# Marginal  (inference/sp.py:207-273)
+# =================================================================================================
+class Marginal(SampleDistribution):
+    """Marginal of a generative function over a selection, optionally with a custom algorithm."""
+
+    def __init__(self, gen_fn: GenerativeFunction, selection: Selection = Selection.all(), algorithm=None):
+        self.gen_fn, self.selection, self.algorithm = gen_fn, selection, algorithm
+
+    def random_weighted(self, key, *args):
+        key, sub_key = split(key)
+        tr = self.gen_fn.simulate(sub_key, args)
+        choices = tr.get_choices()
+        latent_choices = choices.filter(self.selection)
+        key, sub_key = split(key)
+        weight = tr.project(sub_key, ~self.selection)
+        if self.algorithm is None:
+            return weight, latent_choices
+        target = Target(self.gen_fn, args, latent_choices)
+        other_choices = choices.filter(~self.selection)
+        z = self.algorithm.estimate_reciprocal_normalizing_constant(key, target, other_choices, weight)
+        return z, latent_choices
+
+    def estimate_logpdf(self, key, v: ChoiceMap, *args):
+        if self.algorithm is None:
+            _, weight = self.gen_fn.importance(key, v, args)
+            return weight
+        target = Target(self.gen_fn, args, v)
+        return self.algorithm.estimate_normalizing_constant(key, target)
+
+
+def marginal(selection: Selection = Selection.all(), algorithm=None):
+    def decorator(gen_fn: GenerativeFunction) -> Marginal:
+        return Marginal(gen_fn, selection, algorithm)
+
+    return decorator

@@ -1,0 +1,838 @@
+"""The generative-function interface on vectorised traces.
+
+Mirror of the reference interface for the importance / SMC path (same names, argument meaning and
+error behaviour):
+  GenerativeFunction / Trace ........ core/generative/generative_function.py:72-230, 238-689
+  GenerativeFunctionClosure (`@`) ... core/generative/generative_function.py:1557-1684
+  `@gen`, handlers, StaticTrace ..... generative_functions/static.py:80-119, 209-399, 725-810, 1044-1049
+  Distribution / ExactDensity ....... generative_functions/distributions/distribution.py:59-147, 359-476
+
+MI355X-first design instead of a tracing compiler: a model body runs ONCE over the whole particle
+population.  Keys are per-particle key batches (lazy `split`), every `dist(args) @ addr` is one fused
+sample+log-density kernel over a [n] column, values flow between sites as device columns, and the
+trace is the struct-of-arrays of those columns.  When the body's structure is static and its
+inter-site arithmetic is affine, the whole walk is lowered to ONE kernel (`gjx_importance_run`)
+through `plan.py`; both routes implement the same arithmetic spec and are bit-identical.
+"""
+
+from __future__ import annotations
+
+import threading
+from dataclasses import dataclass
+from typing import Any, Callable
+
+import torch
+
+from . import prng
+from .choicemap import ChoiceMap, Selection
+from .ops import KeyBatch
+from .runtime import get_ops
+
+# =================================================================================================
+# keys
+# =================================================================================================
+
+
+@dataclass(frozen=True)
+class ParticleKeys:
+    """n per-particle keys (the result of `split(key, n)`), possibly lazy."""
+
+    kb: KeyBatch
+    n: int
+
+    @property
+    def impl(self):
+        return self.kb.impl
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            start, stop, step = i.indices(self.n)
+            if step != 1:
+                raise IndexError("ParticleKeys supports contiguous slices only")
+            if self.kb.mode == 1:
+                return ParticleKeys(KeyBatch(self.kb.impl, 1, parent=self.kb.parent, first=self.kb.first + start,
+                                             fold=self.kb.fold), max(0, stop - start))
+            if self.kb.mode == 0:
+                return ParticleKeys(KeyBatch(self.kb.impl, 0, tensor=self.kb.tensor[start:stop].contiguous(),
+                                             fold=self.kb.fold), max(0, stop - start))
+            return ParticleKeys(self.kb, max(0, stop - start))
+        i = int(i)
+        if i < 0:
+            i += self.n
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        if self.kb.fold is not None:
+            raise ValueError("cannot index a folded key batch")
+        if self.kb.mode == 1:
+            return prng.split_at(prng.PRNGKey(*self.kb.parent, self.kb.impl), self.kb.first + i)
+        if self.kb.mode == 2:
+            return prng.PRNGKey(*self.kb.parent, self.kb.impl)
+        w = self.kb.tensor[i].cpu().tolist()
+        return prng.PRNGKey(w[0] & 0xFFFFFFFF, w[1] & 0xFFFFFFFF, self.kb.impl)
+
+    def __iter__(self):
+        return (self[i] for i in range(self.n))
+
+
+def as_particle_keys(key) -> tuple[ParticleKeys, bool]:
+    """-> (keys, batched).  A scalar key runs as a population of one and results are squeezed."""
+    if isinstance(key, ParticleKeys):
+        return key, True
+    if isinstance(key, prng.PRNGKey):
+        return ParticleKeys(key.literal(), 1), False
+    raise TypeError(f"expected a PRNG key, got {type(key).__name__}")
+
+
+def split(key, num: int = 2):
+    """`jax.random.split`: scalar key -> `num` keys (lazy batch; iterable / indexable)."""
+    if isinstance(key, prng.PRNGKey):
+        return ParticleKeys(prng.split_lazy(key, num), num)
+    raise TypeError("split() of a key batch is not supported; split the scalar key instead")
+
+
+def fold_in(key, data: int):
+    if isinstance(key, prng.PRNGKey):
+        return prng.fold_in(key, data)
+    if isinstance(key, ParticleKeys):
+        ops = get_ops()
+        t = ops.rng_keys(key.kb.with_fold(data), key.n)
+        return ParticleKeys(KeyBatch(key.impl, 0, tensor=t), key.n)
+    raise TypeError(type(key))
+
+
+def site_keys(key: ParticleKeys, counter: int, leaf: bool) -> ParticleKeys:
+    """Per-`@`-site key: fold_in(key, counter) (static.py:349-352).  Leaf distributions take the
+    fold lazily (fused into their kernel); nested generative functions get materialised keys."""
+    if leaf:
+        return ParticleKeys(key.kb.with_fold(counter), key.n)
+    return fold_in(key, counter)
+
+
+# =================================================================================================
+# values
+# =================================================================================================
+def squeeze_leaf(v):
+    if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == 1:
+        return v[0]
+    return v
+
+
+def batch_size_of(v) -> int | None:
+    if isinstance(v, torch.Tensor) and v.dim() >= 1:
+        return int(v.shape[0])
+    return None
+
+
+# =================================================================================================
+# traces
+# =================================================================================================
+class Trace:
+    def get_args(self):
+        raise NotImplementedError
+
+    def get_retval(self):
+        raise NotImplementedError
+
+    def get_gen_fn(self):
+        raise NotImplementedError
+
+    def get_score(self):
+        raise NotImplementedError
+
+    def get_choices(self) -> ChoiceMap:
+        raise NotImplementedError
+
+    def get_sample(self) -> ChoiceMap:
+        return self.get_choices()
+
+    def project(self, key, selection: Selection):
+        return self.get_gen_fn().project(key, self, selection)
+
+    def map_leaves(self, fn) -> "Trace":
+        raise NotImplementedError
+
+
+class MaterialTrace(Trace):
+    """A trace reduced to what the inference layer reads: choices, score, retval, args."""
+
+    def __init__(self, gen_fn, args, retval, choices: ChoiceMap, score):
+        self.gen_fn, self.args, self.retval, self.choices, self.score = gen_fn, args, retval, choices, score
+
+    @staticmethod
+    def of(tr: Trace) -> "MaterialTrace":
+        return MaterialTrace(tr.get_gen_fn(), tr.get_args(), tr.get_retval(), tr.get_choices(), tr.get_score())
+
+    def get_args(self):
+        return self.args
+
+    def get_retval(self):
+        return self.retval
+
+    def get_gen_fn(self):
+        return self.gen_fn
+
+    def get_score(self):
+        return self.score
+
+    def get_choices(self):
+        return self.choices
+
+    def map_leaves(self, fn):
+        return MaterialTrace(self.gen_fn, _map_any(fn, self.args), _map_any(fn, self.retval),
+                             self.choices.map_leaves(lambda v: _map_any(fn, v) if not isinstance(v, torch.Tensor) else fn(v)),
+                             _map_any(fn, self.score))
+
+
+class EmptyTrace(Trace):
+    def __init__(self, gen_fn):
+        self.gen_fn = gen_fn
+
+    def get_args(self):
+        return ()
+
+    def get_retval(self):
+        return None
+
+    def get_gen_fn(self):
+        return self.gen_fn
+
+    def get_score(self):
+        return 0.0
+
+    def get_choices(self):
+        return ChoiceMap.empty()
+
+
+class DistributionTrace(Trace):
+    """(gen_fn, args, value, score) — distribution.py:59-82."""
+
+    def __init__(self, gen_fn, args, value, score):
+        self.gen_fn, self.args, self.value, self.score = gen_fn, args, value, score
+
+    def get_args(self):
+        return self.args
+
+    def get_retval(self):
+        return self.value
+
+    def get_gen_fn(self):
+        return self.gen_fn
+
+    def get_score(self):
+        return self.score
+
+    def get_choices(self):
+        return ChoiceMap.choice(self.value)
+
+    def map_leaves(self, fn):
+        return DistributionTrace(self.gen_fn, tuple(_map_any(fn, a) for a in self.args), fn(self.value), fn(self.score))
+
+
+def _map_any(fn, v):
+    if isinstance(v, torch.Tensor):
+        return fn(v)
+    if isinstance(v, (tuple, list)):
+        return type(v)(_map_any(fn, x) for x in v)
+    if isinstance(v, dict):
+        return {k: _map_any(fn, x) for k, x in v.items()}
+    if isinstance(v, Trace):
+        return v.map_leaves(fn)
+    if isinstance(v, ChoiceMap):
+        return v.map_leaves(lambda x: _map_any(fn, x))
+    return v
+
+
+class StaticTrace(Trace):
+    """static.py:80-119: score = sum of sub-trace scores; choices = {address: sub-choices}."""
+
+    def __init__(self, gen_fn, args, retval, subtraces: dict, score=None):
+        self.gen_fn, self.args, self.retval, self.subtraces = gen_fn, args, retval, subtraces
+        self._score = score  # the fused path produces the total directly
+
+    def get_args(self):
+        return self.args
+
+    def get_retval(self):
+        return self.retval
+
+    def get_gen_fn(self):
+        return self.gen_fn
+
+    def get_choices(self):
+        return ChoiceMap.d({addr: tr.get_choices() for addr, tr in self.subtraces.items()})
+
+    def get_score(self):
+        if self._score is not None:
+            return self._score
+        total = None
+        for tr in self.subtraces.values():
+            s = tr.get_score()
+            total = s if total is None else total + s
+        return 0.0 if total is None else total
+
+    def get_inner_trace(self, address):
+        return self.subtraces[address]
+
+    get_subtrace = get_inner_trace
+
+    def map_leaves(self, fn):
+        return StaticTrace(self.gen_fn, _map_any(fn, self.args), _map_any(fn, self.retval),
+                           {a: t.map_leaves(fn) for a, t in self.subtraces.items()},
+                           None if self._score is None else _map_any(fn, self._score))
+
+
+class ValueTrace(DistributionTrace):
+    """Sub-trace of a fused run: the site's column is materialised, its individual score is not
+    (only the particle's total is); asking for it computes it with the log-density kernel."""
+
+    def __init__(self, gen_fn, args_thunk, value):
+        self.gen_fn, self._args_thunk, self.value = gen_fn, args_thunk, value
+        self._score = None
+
+    @property
+    def args(self):
+        return self._args_thunk()
+
+    @property
+    def score(self):
+        if self._score is None:
+            self._score = self.gen_fn.estimate_logpdf(None, self.value, *self.args)
+        return self._score
+
+    def map_leaves(self, fn):
+        t = ValueTrace(self.gen_fn, lambda: _map_any(fn, self._args_thunk()), fn(self.value))
+        return t
+
+
+# =================================================================================================
+# generative functions
+# =================================================================================================
+class AddressReuse(Exception):
+    """Attempt to re-use an address within one generative function call (static.py:139-143)."""
+
+
+class MissingAddress(Exception):
+    """`assess` was not given a value for a visited address (static.py:145-148)."""
+
+
+class GenerativeFunctionClosure:
+    """`gen_fn(*args)`; `closure @ "addr"` traces it at an address (generative_function.py:1568-1583)."""
+
+    def __init__(self, gen_fn, args: tuple, kwargs: dict):
+        self.gen_fn, self.args, self.kwargs = gen_fn, args, kwargs
+
+    def __matmul__(self, addr):
+        return trace(addr, self.gen_fn, self._call_args())
+
+    def _call_args(self):
+        return self.gen_fn.canonical_args(self.args, self.kwargs)
+
+    def __call__(self, key, *more):
+        return self.gen_fn.simulate(key, self._call_args()).get_retval()
+
+    def simulate(self, key, args=()):
+        return self.gen_fn.simulate(key, self._call_args() + tuple(args))
+
+
+class GenerativeFunction:
+    def canonical_args(self, args, kwargs):
+        if kwargs:
+            raise TypeError(f"{type(self).__name__} does not take keyword arguments")
+        return tuple(args)
+
+    def __call__(self, *args, **kwargs) -> GenerativeFunctionClosure:
+        return GenerativeFunctionClosure(self, args, kwargs)
+
+    # -- GFI (generative_function.py:378-675) ------------------------------------------------------
+    def simulate(self, key, args) -> Trace:
+        raise NotImplementedError
+
+    def assess(self, sample: ChoiceMap, args):
+        raise NotImplementedError
+
+    def generate(self, key, constraint: ChoiceMap, args):
+        raise NotImplementedError
+
+    def importance(self, key, constraint: ChoiceMap, args):
+        """Same as `generate` (generative_function.py:629-675)."""
+        return self.generate(key, constraint, args)
+
+    def propose(self, key, args):
+        tr = self.simulate(key, args)
+        return tr.get_choices(), tr.get_score(), tr.get_retval()
+
+    def project(self, key, trace: Trace, selection: Selection):
+        raise NotImplementedError
+
+    # -- combinator sugar ----------------------------------------------------------------------------
+    def marginal(self, /, *, selection: Selection = Selection.all(), algorithm=None):
+        from .inference import Marginal
+
+        return Marginal(self, selection, algorithm)
+
+    def scan(self, /, *, n: int | None = None):
+        from .combinators import Scan
+
+        return Scan(self, length=n)
+
+    def partial_apply(self, *first_args):
+        outer = self
+
+        def body(*rest):
+            return outer(*first_args, *rest) @ "_partial"
+
+        return StaticGenerativeFunction(body)
+
+
+# -------------------------------------------------------------------------------------------------
+# handlers (static.py:209-399)
+# -------------------------------------------------------------------------------------------------
+_tls = threading.local()
+
+
+def _stack() -> list:
+    if not hasattr(_tls, "stack"):
+        _tls.stack = []
+    return _tls.stack
+
+
+def trace(addr, gen_fn: GenerativeFunction, args: tuple):
+    st = _stack()
+    if not st:
+        raise RuntimeError("`@` used outside of a generative function (`@gen`) body")
+    addr = addr if isinstance(addr, tuple) else (addr,)
+    for seg in addr:
+        if not isinstance(seg, (str, int)):
+            raise TypeError(f"static addresses must be strings (or ints), got {seg!r}")
+    return st[-1].handle_trace(addr if len(addr) > 1 else addr[0], gen_fn, args)
+
+
+class _Handler:
+    def __init__(self):
+        self.traces: dict = {}
+
+    def record(self, addr, tr):
+        if addr in self.traces:
+            raise AddressReuse(addr)
+        self.traces[addr] = tr
+
+    def run(self, source, args):
+        st = _stack()
+        st.append(self)
+        try:
+            return source(*args)
+        finally:
+            st.pop()
+
+
+class SimulateHandler(_Handler):
+    def __init__(self, key: ParticleKeys):
+        super().__init__()
+        self.key, self.counter = key, 1
+
+    def handle_trace(self, addr, gen_fn, args):
+        sub_key = site_keys(self.key, self.counter, isinstance(gen_fn, Distribution))
+        self.counter += 1
+        tr = gen_fn.simulate(sub_key, args)
+        self.record(addr, tr)
+        return tr.get_retval()
+
+
+class GenerateHandler(_Handler):
+    def __init__(self, key: ParticleKeys, constraint: ChoiceMap):
+        super().__init__()
+        self.key, self.constraint, self.counter = key, constraint, 1
+        self.weight = 0.0
+
+    def handle_trace(self, addr, gen_fn, args):
+        sub = self.constraint.get_submap(*(addr if isinstance(addr, tuple) else (addr,)))
+        sub_key = site_keys(self.key, self.counter, isinstance(gen_fn, Distribution))
+        self.counter += 1  # constrained sites consume a counter too (static.py:374-375)
+        tr, w = gen_fn.generate(sub_key, sub, args)
+        self.weight = self.weight + w
+        self.record(addr, tr)
+        return tr.get_retval()
+
+
+class AssessHandler(_Handler):
+    def __init__(self, sample: ChoiceMap):
+        super().__init__()
+        self.sample, self.score = sample, 0.0
+
+    def handle_trace(self, addr, gen_fn, args):
+        sub = self.sample.get_submap(*(addr if isinstance(addr, tuple) else (addr,)))
+        if sub.static_is_empty():
+            raise MissingAddress(addr)
+        score, v = gen_fn.assess(sub, args)
+        self.score = self.score + score
+        self.record(addr, None)
+        return v
+
+
+class AddressHandler(_Handler):
+    """Records which addresses a body visits (for `ChoiceMap.invalid_subset`)."""
+
+    def __init__(self, key):
+        super().__init__()
+        self.key, self.shape = key, ChoiceMap.empty()
+
+    def handle_trace(self, addr, gen_fn, args):
+        tr = gen_fn.simulate(site_keys(self.key, 1, isinstance(gen_fn, Distribution)), args)
+        a = addr if isinstance(addr, tuple) else (addr,)
+        self.shape = self.shape | ChoiceMap.entry(tr.get_choices() if not isinstance(gen_fn, Distribution) else True, *a)
+        return tr.get_retval()
+
+
+def visited_addresses(gen_fn, args) -> ChoiceMap:
+    if isinstance(gen_fn, StaticGenerativeFunction):
+        h = AddressHandler(as_particle_keys(prng.key(0))[0])
+        h.run(gen_fn.source, args)
+        return h.shape
+    return gen_fn.simulate(prng.key(0), args).get_choices().map_leaves(lambda v: True)
+
+
+class StaticGenerativeFunction(GenerativeFunction):
+    """A Python function whose body traces other generative functions with `@` (static.py:725-1036)."""
+
+    def __init__(self, source: Callable):
+        self.source = source
+        self.__name__ = getattr(source, "__name__", "gen_fn")
+        self._plan_cache: dict = {}
+
+    def __get__(self, instance, owner=None):  # `@gen` on methods (static.py:757-763)
+        if instance is None:
+            return self
+        return StaticGenerativeFunction(self.source.__get__(instance, owner))
+
+    def simulate(self, key, args):
+        pk, batched = as_particle_keys(key)
+        h = SimulateHandler(pk)
+        retval = h.run(self.source, args)
+        tr = StaticTrace(self, args, retval, h.traces)
+        return tr if batched else tr.map_leaves(squeeze_leaf)
+
+    def generate(self, key, constraint: ChoiceMap, args):
+        pk, batched = as_particle_keys(key)
+        if batched:
+            from .plan import try_fused_generate
+
+            fused = try_fused_generate(self, pk, constraint, args)
+            if fused is not None:
+                return fused
+        h = GenerateHandler(pk, constraint)
+        retval = h.run(self.source, args)
+        tr = StaticTrace(self, args, retval, h.traces)
+        w = h.weight
+        if not batched:
+            return tr.map_leaves(squeeze_leaf), squeeze_leaf(w)
+        if not isinstance(w, torch.Tensor):  # no constrained site: a column of zeros
+            w = torch.zeros(pk.n, dtype=torch.float32, device=get_ops().device()) + w
+        return tr, w
+
+    def assess(self, sample: ChoiceMap, args):
+        h = AssessHandler(sample)
+        retval = h.run(self.source, args)
+        return h.score, retval
+
+    def project(self, key, trace: StaticTrace, selection: Selection):
+        total = 0.0
+        for addr, sub in trace.subtraces.items():
+            a = addr if isinstance(addr, tuple) else (addr,)
+            total = total + sub.get_gen_fn().project(key, sub, selection(*a))
+        return total
+
+
+def gen(f: Callable) -> StaticGenerativeFunction:
+    """`@gen` (static.py:1044-1049)."""
+    if isinstance(f, GenerativeFunction):
+        return f
+    return StaticGenerativeFunction(f)
+
+
+# =================================================================================================
+# distributions
+# =================================================================================================
+def _to_device_col(v, n: int, dtype=torch.float32):
+    """Operand for a kernel: Python scalar / 0-d tensor -> float; [n] tensor -> contiguous column."""
+    ops = get_ops()
+    if isinstance(v, torch.Tensor):
+        if v.dim() == 0:
+            return float(v)
+        if v.dim() == 1 and v.shape[0] == n:
+            return v.to(device=ops.device(), dtype=dtype).contiguous()
+        if v.dim() == 1 and v.shape[0] == 1:
+            return float(v[0])
+        raise NotImplementedError(
+            f"distribution argument of shape {tuple(v.shape)} with {n} particles: only scalar events are supported")
+    if isinstance(v, (bool, int, float)):
+        return float(v)
+    try:
+        import numpy as np
+
+        a = np.asarray(v)
+        if a.ndim == 0:
+            return float(a)
+    except Exception:
+        pass
+    raise TypeError(f"unsupported distribution argument {type(v).__name__}")
+
+
+class Distribution(GenerativeFunction):
+    """Exact-density distribution backed by one fused sample+log-density kernel
+    (mirrors ExactDensity, distribution.py:359-419)."""
+
+    name = "distribution"
+    dist_id: int = -1
+    value_dtype = torch.float32
+
+    # subclasses: _sample(keys: ParticleKeys, args) -> (value, score); _logpdf(n, value, args) -> score
+    def __repr__(self):
+        return f"genjax.{self.name}"
+
+    # -- ExactDensity surface ----------------------------------------------------------------------
+    def sample(self, key, *args, **kwargs):
+        return self.random_weighted(key, *self.canonical_args(args, kwargs))[1]
+
+    def logpdf(self, v, *args, **kwargs):
+        return self.estimate_logpdf(None, v, *self.canonical_args(args, kwargs))
+
+    def random_weighted(self, key, *args):
+        pk, batched = as_particle_keys(key)
+        value, score = self._sample(pk, args)
+        if not batched:
+            value, score = squeeze_leaf(value), squeeze_leaf(score)
+        return score, value
+
+    def estimate_logpdf(self, key, v, *args):
+        n = batch_size_of(v)
+        for a in args:
+            n = n or batch_size_of(a)
+        batched = n is not None
+        score = self._logpdf(n or 1, v, args)
+        return score if batched else squeeze_leaf(score)
+
+    # -- GFI -----------------------------------------------------------------------------------------
+    def simulate(self, key, args):
+        w, v = self.random_weighted(key, *args)
+        return DistributionTrace(self, args, v, w)
+
+    def generate(self, key, constraint: ChoiceMap, args):
+        """distribution.py:117-147: unconstrained -> simulate, weight 0; constrained -> weight =
+        score = logpdf(value)."""
+        v = constraint.get_value()
+        if v is None:
+            if not constraint.static_is_empty():
+                raise ValueError("constraint for a distribution must be a value (ChoiceMap.choice)")
+            return self.simulate(key, args), 0.0
+        pk, batched = as_particle_keys(key)
+        n = pk.n
+        w = self._logpdf(n, v, args)
+        if not batched:
+            w = squeeze_leaf(w)
+        return DistributionTrace(self, args, self._canonical_value(v, n if batched else None), w), w
+
+    def assess(self, sample: ChoiceMap, args):
+        v = sample.get_value()
+        if v is None:
+            raise MissingAddress(())
+        w = self.estimate_logpdf(None, v, *args)
+        return w, v
+
+    def project(self, key, trace: DistributionTrace, selection: Selection):
+        return trace.get_score() if selection.check() else 0.0
+
+    def _canonical_value(self, v, n):
+        return v
+
+
+def _bool_col(t: torch.Tensor) -> torch.Tensor:
+    return t.view(torch.bool) if t.dtype == torch.uint8 else t
+
+
+class _RealDist(Distribution):
+    abi_name = ""
+    arg_names: tuple = ()
+
+    def canonical_args(self, args, kwargs):
+        args = list(args)
+        for nm in self.arg_names[len(args):]:
+            if nm not in kwargs:
+                raise TypeError(f"genjax.{self.name}: missing argument {nm!r}")
+            args.append(kwargs[nm])
+        if len(args) != len(self.arg_names):
+            raise TypeError(f"genjax.{self.name} takes {len(self.arg_names)} arguments")
+        return tuple(args)
+
+    def _sample(self, pk: ParticleKeys, args):
+        ops = get_ops()
+        a, b = (_to_device_col(x, pk.n) for x in args)
+        return ops.sample_logpdf(self.abi_name, pk.kb, pk.n, a, b)
+
+    def _logpdf(self, n, v, args):
+        ops = get_ops()
+        a, b = (_to_device_col(x, n) for x in args)
+        return ops.logpdf(self.abi_name, n, _to_device_col(v, n), a, b)
+
+
+class Normal(_RealDist):
+    """tfd.Normal(loc, scale) — tensorflow_probability/__init__.py:259."""
+    name, abi_name, dist_id, arg_names = "normal", "normal", 0, ("loc", "scale")
+
+
+class Gamma(_RealDist):
+    """tfd.Gamma(concentration, rate) — tensorflow_probability/__init__.py:164."""
+    name, abi_name, dist_id, arg_names = "gamma", "gamma", 1, ("concentration", "rate")
+
+
+class Beta(_RealDist):
+    """tfd.Beta(concentration1, concentration0) — tensorflow_probability/__init__.py:82."""
+    name, abi_name, dist_id, arg_names = "beta", "beta", 2, ("concentration1", "concentration0")
+
+
+class Flip(Distribution):
+    """tfd.Bernoulli(probs=p, dtype=bool) — tensorflow_probability/__init__.py:155."""
+    name, dist_id, value_dtype = "flip", 3, torch.bool
+
+    def canonical_args(self, args, kwargs):
+        if kwargs:
+            if set(kwargs) != {"probs"} or args:
+                raise TypeError("genjax.flip takes a single probability")
+            return (kwargs["probs"],)
+        if len(args) != 1:
+            raise TypeError("genjax.flip takes a single probability")
+        return tuple(args)
+
+    def _probs(self, args, n):
+        return _to_device_col(args[0], n)
+
+    def _sample(self, pk, args):
+        v, s = get_ops().sample_logpdf("bernoulli", pk.kb, pk.n, self._probs(args, pk.n))
+        return _bool_col(v), s
+
+    def _logpdf(self, n, v, args):
+        ops = get_ops()
+        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == n and n > 1:
+            v = v.to(ops.device()).to(torch.uint8).contiguous()
+        else:
+            v = bool(v)
+        return ops.logpdf("bernoulli", n, v, self._probs(args, n))
+
+
+class Bernoulli(Flip):
+    """tfd.Bernoulli(logits=... | probs=...) — tensorflow_probability/__init__.py:72; a bare
+    positional argument means logits and warns (distribution.py:479-500)."""
+    name = "bernoulli"
+
+    def canonical_args(self, args, kwargs):
+        import warnings
+
+        if args and not kwargs:
+            warnings.warn("The use of a bare argument to genjax.bernoulli is deprecated. Please specify "
+                          "`logits=` or `probs=` for the parameters. The default, which will be used in this "
+                          "case, is logits.", DeprecationWarning)
+            return (("logits", args[0]),)
+        if len(kwargs) == 1 and not args and next(iter(kwargs)) in ("logits", "probs"):
+            return (next(iter(kwargs.items())),)
+        raise TypeError("genjax.bernoulli takes logits= or probs=")
+
+    def _probs(self, args, n):
+        kind, v = args[0]
+        if kind == "probs":
+            return _to_device_col(v, n)
+        t = torch.as_tensor(v, dtype=torch.float32)
+        return _to_device_col(torch.sigmoid(t), n)
+
+
+class Categorical(Distribution):
+    """tfd.Categorical(logits=... | probs=...) — tensorflow_probability/__init__.py:102-104.
+    `sampling` selects how a category is drawn: "gumbel" = jax.random.categorical's Gumbel-max
+    (n_cat uniforms per draw, the reference semantics), "inverse_cdf" = one uniform on the
+    fixed-point CDF (the HBM-friendly default for large category counts)."""
+    name, dist_id, value_dtype = "categorical", 4, torch.int32
+    sampling = "gumbel"
+
+    def canonical_args(self, args, kwargs):
+        import warnings
+
+        if args and not kwargs:
+            warnings.warn("The use of a bare argument to genjax.categorical is deprecated. Please specify "
+                          "`logits=` or `probs=` for the parameters. The default, which will be used in this "
+                          "case, is logits.", DeprecationWarning)
+            return (("logits", args[0]),)
+        if len(kwargs) == 1 and not args and next(iter(kwargs)) in ("logits", "probs"):
+            return (next(iter(kwargs.items())),)
+        raise TypeError("genjax.categorical takes logits= or probs=")
+
+    @staticmethod
+    def _logits(arg, n):
+        """-> f32 logits [rows, K] on the device, rows in {1, n}."""
+        ops = get_ops()
+        kind, v = arg if (isinstance(arg, tuple) and len(arg) == 2 and arg[0] in ("logits", "probs")) else ("logits", arg)
+        t = torch.as_tensor(v, dtype=torch.float32).to(ops.device())
+        if kind == "probs":
+            t = torch.log(t)
+        if t.dim() == 1:
+            t = t[None, :]
+        if t.dim() != 2 or t.shape[0] not in (1, n):
+            raise NotImplementedError(f"categorical parameters of shape {tuple(t.shape)} with {n} particles")
+        return t.contiguous()
+
+    def _sample(self, pk, args):
+        mode = 0 if self.sampling == "gumbel" else 1
+        return get_ops().sample_logpdf_categorical(pk.kb, pk.n, self._logits(args[0], pk.n), None, mode)
+
+    def _logpdf(self, n, v, args):
+        ops = get_ops()
+        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == n and n > 1:
+            v = v.to(ops.device()).to(torch.int32).contiguous()
+        else:
+            v = int(v)
+        return ops.logpdf_categorical(n, v, self._logits(args[0], n))
+
+
+normal = Normal()
+gamma = Gamma()
+beta = Beta()
+flip = Flip()
+bernoulli = Bernoulli()
+categorical = Categorical()
+
+
+class ExactDensityFromCallables(Distribution):
+    """`exact_density(sample, logpdf, name)` (distribution.py:436-476): a user-defined distribution
+    from two Python callables operating on columns."""
+
+    def __init__(self, sample, logpdf, name):
+        self._s, self._l, self.name = sample, logpdf, name
+
+    def canonical_args(self, args, kwargs):
+        return tuple(args) + ((kwargs,) if kwargs else ())
+
+    def _split_kwargs(self, args):
+        if args and isinstance(args[-1], dict):
+            return args[:-1], args[-1]
+        return args, {}
+
+    def _sample(self, pk, args):
+        a, kw = self._split_kwargs(args)
+        v = self._s(pk, *a, **kw)
+        return v, self._logpdf(pk.n, v, args)
+
+    def _logpdf(self, n, v, args):
+        a, kw = self._split_kwargs(args)
+        w = self._l(v, *a, **kw)
+        if isinstance(w, torch.Tensor) and w.dim() > 1:
+            w = w.reshape(w.shape[0], -1).sum(1)  # non-scalar logpdf is summed (distribution.py:392-396)
+        return w
+
+
+def exact_density(sample, logpdf, name: str | None = None):
+    import warnings
+
+    if name is None:
+        warnings.warn("You should supply a name argument to exact_density")
+        name = "unknown"
+    return ExactDensityFromCallables(sample, logpdf, name)

@@ -1,0 +1,282 @@
+"""Lowering a `@gen` body to ONE fused kernel (`gjx_importance_run`).
+
+The body is run once with symbolic site values.  If every `@` site is a supported distribution and
+every distribution argument is (a) a constant, (b) `c * v`, `v + d`, `c * v + d`, `v - d` or `-v`
+of ONE earlier site value or constraint column, or (c) `table[v]` of an integer-valued earlier
+site, the walk of static.py:340-399 becomes a site table for the HIP interpreter kernel.  Anything
+else (nested generative functions, non-affine arithmetic, data-dependent Python control flow)
+raises `PlanUnsupported` and the caller falls back to the per-site column kernels — which compute
+the same numbers bit for bit, only with one launch per site.
+
+Restricting the affine forms to at most one multiply and one add is deliberate: that is exactly
+the f32 operation sequence the column path would execute for the same expression, so both routes
+round identically.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import abi
+from .choicemap import ChoiceMap
+from .lang import (Distribution, ParticleKeys, StaticTrace, ValueTrace, _Handler, normal, gamma, beta, flip,
+                   bernoulli, categorical, Categorical)
+from .runtime import get_ops
+
+MAX_INPUT_COLS = 16
+
+
+class PlanUnsupported(Exception):
+    pass
+
+
+class Sym:
+    """Symbolic f32 value: scale * source + offset, source = ("site", idx) | ("input", idx)."""
+
+    __slots__ = ("src", "scale", "offset", "has_mul", "has_add", "is_int", "tracer")
+
+    def __init__(self, tracer, src, scale=1.0, offset=0.0, has_mul=False, has_add=False, is_int=False):
+        self.tracer, self.src, self.scale, self.offset = tracer, src, scale, offset
+        self.has_mul, self.has_add, self.is_int = has_mul, has_add, is_int
+
+    # -- affine algebra (one multiply, then one add — in that order) -------------------------------
+    @staticmethod
+    def _const(c):
+        if isinstance(c, (bool, int, float)):
+            return float(c)
+        if isinstance(c, torch.Tensor) and c.dim() == 0:
+            return float(c)
+        raise PlanUnsupported("non-constant operand")
+
+    def __mul__(self, c):
+        c = self._const(c)
+        if self.has_mul or self.has_add:
+            raise PlanUnsupported("more than one multiply / multiply after add")
+        return Sym(self.tracer, self.src, float(torch.tensor(c, dtype=torch.float32)), 0.0, True, False, False)
+
+    __rmul__ = __mul__
+
+    def __add__(self, c):
+        c = self._const(c)
+        if self.has_add:
+            raise PlanUnsupported("more than one add")
+        return Sym(self.tracer, self.src, self.scale, float(torch.tensor(c, dtype=torch.float32)), self.has_mul,
+                   True, False)
+
+    __radd__ = __add__
+
+    def __sub__(self, c):
+        return self.__add__(-self._const(c))
+
+    def __neg__(self):
+        return self.__mul__(-1.0)
+
+    def _no(self, *a, **k):
+        raise PlanUnsupported("unsupported operation on a traced site value")
+
+    __truediv__ = __rtruediv__ = __rsub__ = __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
+    __lt__ = __le__ = __gt__ = __ge__ = __abs__ = __index__ = __array__ = __len__ = __iter__ = _no
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        raise PlanUnsupported(f"torch.{getattr(func, '__name__', func)} on a traced site value")
+
+
+class _Table:
+    """`table[sym]` with a 1-D constant table and an integer-valued site."""
+
+    def __init__(self, tracer, table: torch.Tensor, idx: Sym):
+        self.tracer, self.table, self.idx = tracer, table, idx
+
+
+_DIST_IDS = {id(normal): abi.DIST_NORMAL, id(gamma): abi.DIST_GAMMA, id(beta): abi.DIST_BETA,
+             id(flip): abi.DIST_BERNOULLI}
+
+
+class PlanTracer(_Handler):
+    def __init__(self, constraint: ChoiceMap, n: int):
+        super().__init__()
+        self.constraint, self.n = constraint, n
+        self.sites: list[abi.Site] = []
+        self.meta: list[dict] = []  # per site: addr, gen_fn, args (symbolic), out_col, observed
+        self.inputs: list[torch.Tensor] = []
+        self.keep: list = []  # device tensors the site table points into
+        self.n_out = 0
+
+    # -- argument encoding ---------------------------------------------------------------------------
+    def _arg(self, v) -> abi.Arg:
+        if isinstance(v, Sym):
+            kind = abi.ARG_SITE if v.src[0] == "site" else abi.ARG_INPUT
+            return abi.Arg(kind, v.src[1], v.scale, v.offset, None)
+        if isinstance(v, _Table):
+            return abi.Arg(abi.ARG_TABLE, v.idx.src[1], 0.0, 0.0, v.table.data_ptr())
+        if isinstance(v, torch.Tensor) and v.dim() == 1 and v.shape[0] == self.n and self.n > 1:
+            return abi.Arg(abi.ARG_INPUT, self._input(v), 1.0, 0.0, None)
+        return abi.Arg(abi.ARG_CONST, 0, 0.0, Sym._const(v), None)
+
+    def _input(self, col: torch.Tensor) -> int:
+        if len(self.inputs) >= MAX_INPUT_COLS:
+            raise PlanUnsupported("too many per-particle input columns")
+        ops = get_ops()
+        self.inputs.append(col.to(device=ops.device(), dtype=torch.float32).contiguous())
+        return len(self.inputs) - 1
+
+    def handle_trace(self, addr, gen_fn, args):
+        if not isinstance(gen_fn, Distribution):
+            raise PlanUnsupported("nested generative function")
+        if len(self.sites) >= abi.MAX_SITES:
+            raise PlanUnsupported("too many sites")
+        a = addr if isinstance(addr, tuple) else (addr,)
+        sub = self.constraint.get_submap(*a)
+        obs = sub.get_value()
+        if obs is None and not sub.static_is_empty():
+            raise PlanUnsupported("structured constraint at a distribution address")
+        site = abi.Site()
+        site.observed = 0 if obs is None else 1
+        site.out_col = -1
+        is_int = False
+        if id(gen_fn) in _DIST_IDS:
+            site.dist = _DIST_IDS[id(gen_fn)]
+            site.arg[0] = self._arg(args[0])
+            if site.dist != abi.DIST_BERNOULLI:
+                site.arg[1] = self._arg(args[1])
+            is_int = site.dist == abi.DIST_BERNOULLI
+        elif gen_fn is bernoulli:
+            kind, v = args[0]
+            if kind != "probs":
+                raise PlanUnsupported("bernoulli(logits=) in a fused plan")
+            site.dist = abi.DIST_BERNOULLI
+            site.arg[0] = self._arg(v)
+            is_int = True
+        elif isinstance(gen_fn, Categorical):
+            kind, v = args[0] if isinstance(args[0], tuple) else ("logits", args[0])
+            if isinstance(v, (Sym, _Table)):
+                raise PlanUnsupported("data-dependent categorical parameters")
+            logits = Categorical._logits((kind, v), self.n)
+            if logits.shape[0] != 1:
+                raise PlanUnsupported("per-particle categorical parameters")
+            self.keep.append(logits)
+            site.dist = abi.DIST_CATEGORICAL
+            site.n_cat, site.n_rows = int(logits.shape[1]), 1
+            site.cat_mode = 0 if gen_fn.sampling == "gumbel" else 1
+            site.arg[0] = abi.Arg(abi.ARG_CONST, 0, 0.0, 0.0, None)
+            site.logits = logits.data_ptr()
+            is_int = True
+        else:
+            raise PlanUnsupported(f"distribution {gen_fn!r} has no fused sampler")
+        idx = len(self.sites)
+        if obs is not None:
+            if isinstance(obs, torch.Tensor) and obs.dim() == 1 and obs.shape[0] == self.n and self.n > 1:
+                site.obs = abi.Arg(abi.ARG_INPUT, self._input(obs.to(torch.float32)), 1.0, 0.0, None)
+            else:
+                site.obs = abi.Arg(abi.ARG_CONST, 0, 0.0, Sym._const(obs) if not isinstance(obs, bool) else float(obs), None)
+        else:
+            site.out_col = self.n_out
+            self.n_out += 1
+        self.sites.append(site)
+        self.meta.append(dict(addr=addr, gen_fn=gen_fn, args=args, obs=obs, out_col=site.out_col, is_int=is_int,
+                              dtype=gen_fn.value_dtype))
+        self.record(addr, None)
+        if obs is not None:
+            # a constrained value may feed later sites: constants stay constants, columns become inputs
+            if isinstance(obs, torch.Tensor) and obs.dim() == 1 and obs.shape[0] == self.n and self.n > 1:
+                return Sym(self, ("input", site.obs.ref), is_int=is_int)
+            return obs
+        return _IntSym(self, ("site", idx)) if is_int else Sym(self, ("site", idx))
+
+
+class _IntSym(Sym):
+    """Integer-valued site (flip / categorical): usable as a table index or as a 0/1 value."""
+
+    def __init__(self, tracer, src):
+        super().__init__(tracer, src, is_int=True)
+
+
+class TableProxy:
+    """Wrap a constant 1-D tensor so that `proxy[int_site]` is traceable (`means[idx]`)."""
+
+    def __init__(self, table):
+        self.table = torch.as_tensor(table, dtype=torch.float32)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, Sym):
+            if not idx.is_int:
+                raise PlanUnsupported("table index must be an integer-valued site")
+            ops = get_ops()
+            t = self.table.to(ops.device()).contiguous()
+            idx.tracer.keep.append(t)
+            return _Table(idx.tracer, t, idx)
+        if isinstance(idx, torch.Tensor):
+            return self.table.to(idx.device)[idx.long()]
+        return self.table[idx]
+
+
+def _contains_sym(v) -> bool:
+    if isinstance(v, (Sym, _Table)):
+        return True
+    if isinstance(v, (tuple, list)):
+        return any(_contains_sym(x) for x in v)
+    if isinstance(v, dict):
+        return any(_contains_sym(x) for x in v.values())
+    return False
+
+
+def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
+    """-> (trace, weight) through the fused kernel, or None when the body is not plan-able."""
+    if pk.kb.fold is not None or any(_needs_eager(a) for a in args):
+        return None
+    tracer = PlanTracer(constraint, pk.n)
+    try:
+        retval = tracer.run(gen_fn.source, args)
+    except Exception:
+        # PlanUnsupported, or any error provoked by feeding symbolic values to code that expects
+        # tensors: the column path re-runs the body and raises genuine model errors itself.
+        return None
+    if not tracer.sites:
+        return None
+    ops = get_ops()
+    plan = ops.plan_create(tracer.sites)
+    dtypes = [torch.float32] * tracer.n_out
+    for m in tracer.meta:
+        if m["out_col"] >= 0 and m["is_int"]:
+            dtypes[m["out_col"]] = torch.int32
+    vals, score, logw, mp = ops.importance_run(plan, pk.kb, pk.n, tracer.inputs, dtypes, want_score=True,
+                                               want_max_partials=True)
+    site_vals = []
+    for m in tracer.meta:
+        if m["out_col"] >= 0:
+            v = vals[m["out_col"]]
+            if m["dtype"] == torch.bool:
+                v = v != 0
+            site_vals.append(v)
+        else:
+            site_vals.append(m["obs"])
+
+    def resolve(x):
+        if isinstance(x, Sym):
+            base = site_vals[x.src[1]] if x.src[0] == "site" else tracer.inputs[x.src[1]]
+            base = base.to(torch.float32) if isinstance(base, torch.Tensor) else float(base)
+            out = base
+            if x.has_mul:
+                out = out * x.scale
+            if x.has_add:
+                out = out + x.offset
+            return out
+        if isinstance(x, _Table):
+            return x.table[site_vals[x.idx.src[1]].long()]
+        if isinstance(x, tuple):
+            return tuple(resolve(y) for y in x)
+        if isinstance(x, list):
+            return [resolve(y) for y in x]
+        return x
+
+    subtraces = {}
+    for m, v in zip(tracer.meta, site_vals):
+        subtraces[m["addr"]] = ValueTrace(m["gen_fn"], (lambda a=m["args"]: tuple(resolve(y) for y in a)), v)
+    tr = StaticTrace(gen_fn, args, resolve(retval), subtraces, score=score)
+    tr.max_partials = mp  # lets the particle collection skip the max pass of its log-sum-exp
+    return tr, logw
+
+
+def _needs_eager(a) -> bool:
+    return isinstance(a, torch.Tensor) and a.dim() >= 1 and a.numel() > 1

@@ -1,0 +1,90 @@
+"""Bootstrap SMC on the fused state-space kernels (`gjx_smc_run_lgssm` / `gjx_smc_run_hmm`).
+
+The reference's SMC module has no resampling step or SMC loop; the north star
+asks for bootstrap SMC with systematic resampling and an ancestor gather.  This is that driver:
+one call enqueues the whole T-step filter — per step one fused resample+gather+propagate+weight
+kernel and one tile-sum kernel — with no host synchronisation.  The model classes are the
+fixed-structure equivalents of the `@scan`/`@gen` kernels
+
+    x' = normal(a * x, q) @ "x";  normal(x', r) @ "y"                  (LinearGaussianSSM)
+    z' = categorical(T[z, :]) @ "z";  categorical(O[z', :]) @ "x"      (DiscreteHMM, exact_testbed.py:62-68)
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import abi, prng
+from .runtime import get_ops
+
+
+@dataclass(frozen=True)
+class LinearGaussianSSM:
+    x0_loc: float = 0.0
+    x0_scale: float = 1.0
+    a: float = 0.9
+    q: float = 1.0
+    r: float = 0.5
+
+
+@dataclass(frozen=True)
+class DiscreteHMM:
+    trans_logits: torch.Tensor  # [K, K], row = previous state
+    obs_logits: torch.Tensor  # [K, K], row = state
+    init_state: int = 0
+
+
+@dataclass
+class SMCResult:
+    log_marginal_likelihood: float  # float64 from the exact per-step (max, fixed-point sum) pairs
+    step_max: torch.Tensor  # f32[T]
+    step_q: torch.Tensor  # i64[T]
+    particles: torch.Tensor  # final-step particles [n]
+    log_weights: torch.Tensor  # their incremental log-weights [n]
+    ancestors: torch.Tensor | None  # int32[T, n] (row 0 = identity)
+
+    def get_log_marginal_likelihood_estimate(self) -> float:
+        return self.log_marginal_likelihood
+
+
+def smc_key_schedule(key: prng.PRNGKey, T: int):
+    """step t propagates with split(key, 2T)[2t] and resamples with split(key, 2T)[2t+1]."""
+    ks = prng.split(key, 2 * T)
+    return [k.words() for k in ks[0::2]], [k.words() for k in ks[1::2]]
+
+
+class BootstrapSMC:
+    """Bootstrap particle filter, systematic resampling at every step."""
+
+    def __init__(self, model, observations, n_particles: int, record_ancestors: bool = False):
+        self.model, self.n, self.record_ancestors = model, int(n_particles), record_ancestors
+        self.observations = np.asarray(observations)
+
+    def get_num_particles(self):
+        return self.n
+
+    def run(self, key: prng.PRNGKey) -> SMCResult:
+        ops = get_ops()
+        T = len(self.observations)
+        sk, rk = smc_key_schedule(key, T)
+        if isinstance(self.model, LinearGaussianSSM):
+            m = self.model
+            out = ops.smc_run_lgssm(key.impl, self.n, sk, rk, abi.Lgssm(m.x0_loc, m.x0_scale, m.a, m.q, m.r),
+                                    self.observations.astype(np.float32), self.record_ancestors)
+        elif isinstance(self.model, DiscreteHMM):
+            m = self.model
+            dev = ops.device()
+            tl = torch.as_tensor(m.trans_logits, dtype=torch.float32).to(dev).contiguous()
+            ol = torch.as_tensor(m.obs_logits, dtype=torch.float32).to(dev).contiguous()
+            out = ops.smc_run_hmm(key.impl, self.n, sk, rk, int(tl.shape[0]), int(m.init_state), tl, ol,
+                                  self.observations.astype(np.int32), self.record_ancestors)
+        else:
+            raise TypeError(f"no fused SMC kernel for {type(self.model).__name__}")
+        step_max, step_q, state, logw, anc = out
+        return SMCResult(ops.log_z_from_pairs(step_max, step_q, self.n), step_max, step_q, state, logw, anc)
+
+    def log_marginal_likelihood_estimate(self, key: prng.PRNGKey) -> float:
+        return self.run(key).log_marginal_likelihood

@@ -1,0 +1,337 @@
+"""Host-API test bodies shared by the CPU suite (oracle backend injected with `use_ops`) and the
+GPU suite (the product's HIP backend).  They read like the reference's own tests for the path:
+tests/inference/test_smc.py, tests/generative_functions/{test_static_gen_fn,test_distributions,
+test_scan_combinator}.py and README.md:89-123."""
+
+import math
+import warnings
+
+import pytest
+import torch
+
+import genjax
+from genjax import ChoiceMap, ChoiceMapBuilder as C, SelectionBuilder as S, Target, beta, categorical, flip, gamma, gen, normal
+from genjax._amd import jaxlike
+from genjax._amd.lang import ParticleKeys, StaticTrace
+from genjax._amd.plan import try_fused_generate
+from genjax.inference.smc import BootstrapSMC, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM
+
+jax = jaxlike
+jnp = jaxlike.jnp
+
+
+def f(x):
+    return float(x.detach().cpu()) if isinstance(x, torch.Tensor) else float(x)
+
+
+# ---- tests/inference/test_smc.py ------------------------------------------------------------------
+def case_exact_flip_flip_trivial(impl):
+    @gen
+    def flip_flip_trivial():
+        _ = flip(0.5) @ "x"
+        _ = flip(0.7) @ "y"
+
+    key = genjax.random.key(314159, impl)
+    problem = Target(flip_flip_trivial, (), C["y"].set(True))
+    z_exact = f(flip.assess(problem.constraint.get_submap("y"), (0.7,))[0])
+    assert z_exact == pytest.approx(math.log(0.7), abs=1e-7)
+    z = Importance(problem).log_marginal_likelihood_estimate(key)
+    assert f(z) == pytest.approx(z_exact, rel=1e-1)
+    z = ImportanceK(problem, k_particles=1000).log_marginal_likelihood_estimate(key)
+    assert f(z) == pytest.approx(z_exact, rel=1e-3)
+
+
+def case_exact_flip_flip(impl):
+    @gen
+    def flip_flip():
+        v1 = flip(0.5) @ "x"
+        p = jax.lax.cond(v1, lambda: 0.9, lambda: 0.3)
+        _ = flip(p) @ "y"
+
+    key = genjax.random.key(314159, impl)
+    problem = Target(flip_flip, (), C["y"].set(True))
+    assert problem["y"] is True
+    z = ImportanceK(problem, k_particles=2000).log_marginal_likelihood_estimate(key)
+    assert f(z) == pytest.approx(math.log(0.6), rel=1e-1)
+    z = ImportanceK(problem, k_particles=200000).log_marginal_likelihood_estimate(key)
+    assert f(z) == pytest.approx(math.log(0.6), abs=1e-2)
+
+
+def case_non_marginal_target(impl):
+    @gen
+    def model():
+        idx = categorical(probs=[0.5, 0.25, 0.25]) @ "idx"
+        means = jnp.array([0.0, 10.0, 11.0])
+        vars_ = jnp.array([1.0, 1.0, 1.0])
+        x = normal(means[idx], vars_[idx]) @ "x"
+        y = normal(means[idx], vars_[idx]) @ "y"
+        return x, y
+
+    marginal_model = model.marginal(selection=S["x"] | S["y"])
+    with pytest.raises(TypeError):
+        Target(marginal_model, (), C["x"].set(1.0))
+    # the model itself is a fine target
+    t = Target(model, (), C["x"].set(10.5))
+    z = ImportanceK(t, k_particles=50000).log_marginal_likelihood_estimate(genjax.random.key(1, impl))
+    exact = math.log(0.5 * _npdf(10.5, 0) + 0.25 * _npdf(10.5, 10) + 0.25 * _npdf(10.5, 11))
+    assert f(z) == pytest.approx(exact, abs=0.05)
+
+
+def _npdf(x, m, s=1.0):
+    return math.exp(-0.5 * ((x - m) / s) ** 2) / (s * math.sqrt(2 * math.pi))
+
+
+# ---- README.md:89-123 -------------------------------------------------------------------------------
+def case_readme_beta_bernoulli(impl):
+    @gen
+    def beta_bernoulli(a, b):
+        p = beta(a, b) @ "p"
+        v = flip(p) @ "v"
+        return v
+
+    def run_inference(obs: bool):
+        posterior_target = Target(beta_bernoulli, (2.0, 2.0), ChoiceMap.d({"v": obs}))
+        alg = ImportanceK(posterior_target, k_particles=50)
+        key = jax.random.key(314159, impl)
+        sub_keys = jax.random.split(key, 50)
+        _, p_chm = jax.vmap(alg.random_weighted, in_axes=(0, None))(sub_keys, posterior_target)
+        assert p_chm["p"].shape == (50,)
+        return f(jnp.mean(p_chm["p"]))
+
+    assert run_inference(True) == pytest.approx(0.6, abs=0.07)  # README prints 0.6039314
+    assert run_inference(False) == pytest.approx(0.4, abs=0.07)  # README prints 0.3679334
+    t = Target(beta_bernoulli, (2.0, 2.0), ChoiceMap.d({"v": True}))
+    z = ImportanceK(t, k_particles=100000).log_marginal_likelihood_estimate(jax.random.key(2, impl))
+    assert f(z) == pytest.approx(math.log(0.5), abs=1e-2)
+
+
+# ---- tests/generative_functions/test_static_gen_fn.py --------------------------------------------
+def case_static_gen_fn(impl):
+    @gen
+    def model():
+        y1 = normal(0.0, 1.0) @ "y1"
+        y2 = normal(0.0, 1.0) @ "y2"
+        return y1 + y2
+
+    key = genjax.random.key(314159, impl)
+    score, retval = model.assess(C.kw(y1=1.0, y2=-1.0), ())  # test_static_gen_fn.py:317-318
+    assert f(score) == pytest.approx(-2.837877, abs=1e-6) and f(retval) == 0.0
+    tr = model.simulate(key, ())
+    ch = tr.get_choices()
+    assert f(tr.get_score()) == pytest.approx(f(model.assess(ch, ())[0]), rel=1e-6)
+    assert f(tr.get_retval()) == pytest.approx(f(ch["y1"]) + f(ch["y2"]), rel=1e-6)
+    # importance: weight = sum of constrained-site log-densities; 0 without constraints (441-489)
+    tr2, w = model.importance(key, C["y2"].set(0.5), ())
+    assert f(w) == pytest.approx(f(normal.logpdf(0.5, 0.0, 1.0)), rel=1e-6)
+    assert f(tr2.get_choices()["y2"]) == 0.5
+    assert f(tr2.get_score()) == pytest.approx(f(w) + f(normal.logpdf(tr2.get_choices()["y1"], 0.0, 1.0)), rel=1e-5)
+    tr3, w0 = model.importance(key, C.n(), ())
+    assert f(w0) == 0.0
+    # address reuse (static.py:213-216)
+    @gen
+    def bad():
+        normal(0.0, 1.0) @ "x"
+        normal(0.0, 1.0) @ "x"
+
+    with pytest.raises(genjax.AddressReuse):
+        bad.simulate(key, ())
+    with pytest.raises(genjax.MissingAddress):
+        model.assess(C.kw(y1=1.0), ())
+    # tuple addresses and nested calls (test_core.py:27-38, test_static_gen_fn.py:253-256)
+    @gen
+    def inner(m):
+        return normal(m, 1.0) @ "z"
+
+    @gen
+    def outer():
+        a = normal(0.0, 1.0) @ ("x", "x0")
+        b = inner(a) @ "sub"
+        return b
+
+    tr = outer.simulate(key, ())
+    ch = tr.get_choices()
+    assert ("x", "x0") in ch and ("sub", "z") in ch and "x" not in ch
+    tr4, w4 = outer.importance(key, C["sub", "z"].set(2.0), ())
+    assert f(w4) == pytest.approx(f(normal.logpdf(2.0, f(tr4.get_choices()["x", "x0"]), 1.0)), rel=1e-5)
+    # kwargs to distributions (test_distributions.py:490-520)
+    @gen
+    def kw():
+        a = normal(loc=0.0, scale=0.1) @ "a"
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            c = categorical([0.0, 1.0]) @ "c"
+            assert any(issubclass(r.category, DeprecationWarning) for r in rec)
+        d = categorical(logits=[0.0, 1.0]) @ "d"
+        return a
+
+    kw.simulate(key, ())
+
+
+# ---- tests/generative_functions/test_distributions.py:25-60 ---------------------------------------
+def case_distributions(impl):
+    key = genjax.random.key(314159, impl)
+    for dist, args, v in ((normal, (0.0, 1.0), 0.5), (gamma, (2.0, 3.0), 1.5), (beta, (2.0, 2.0), 0.3), (flip, (0.3,), True)):
+        tr = dist.simulate(key, args)
+        assert f(tr.get_score()) == pytest.approx(f(dist.assess(tr.get_choices(), args)[0]), rel=1e-6)
+        tr, w = dist.importance(key, C.n(), args)
+        assert f(w) == 0.0
+        tr, w = dist.importance(key, C.v(v), args)
+        assert f(w) == f(tr.get_score()) == pytest.approx(f(dist.logpdf(v, *args)), rel=1e-6)
+    assert f(normal.logpdf(0.5, 0.0, 1.0)) == pytest.approx(-1.0439385332, abs=1e-6)
+    assert f(beta.logpdf(0.3, 2.0, 2.0)) == pytest.approx(0.2311117210, abs=1e-5)
+    assert f(gamma.logpdf(1.5, 2.0, 3.0)) == pytest.approx(-1.8973103146, abs=1e-5)
+    lp = [f(categorical.logpdf(k, logits=[-0.3, -0.5])) for k in (0, 1)]
+    assert lp == pytest.approx([-0.59813887, -0.79813887], abs=1e-6)
+    # the same scalar key gives the same draw; batches give per-particle draws
+    a, b = normal.sample(key, 0.0, 1.0), normal.sample(key, 0.0, 1.0)
+    assert f(a) == f(b)
+    col = normal.sample(genjax.random.split(key, 1000), 0.0, 1.0)
+    assert col.shape == (1000,) and abs(f(col.mean())) < 0.15
+
+
+# ---- batched execution: fused kernel == per-site column kernels, bit for bit -------------------------
+def case_fused_equals_eager(impl):
+    @gen
+    def model(a):
+        p = beta(2.0, a) @ "p"
+        v = flip(p) @ "v"
+        g = gamma(0.7, p * 2.0 + 0.5) @ "g"
+        x = normal(g * 0.5, 1.5) @ "x"
+        y = normal(x - 1.0, 0.5) @ "y"
+        return x
+
+    n = 5000
+    keys = genjax.random.split(genjax.random.key(7, impl), n)
+    ycol = torch.linspace(-1, 1, n)
+    for chm in (C.n(), C["v"].set(True) | C["y"].set(0.25), C["y"].set(ycol.to(_dev())) | C["p"].set(0.4)):
+        fused = try_fused_generate(model, keys, chm, (3.0,))
+        assert fused is not None, "this model must lower to the fused kernel"
+        from genjax._amd.lang import GenerateHandler
+
+        h = GenerateHandler(keys, chm)
+        retval = h.run(model.source, (3.0,))
+        eager = StaticTrace(model, (3.0,), retval, h.traces)
+        ftr, fw = fused
+        ew = h.weight
+        if isinstance(ew, torch.Tensor):
+            assert torch.equal(fw, ew)
+        else:
+            assert float(fw.abs().max()) == 0.0 and ew == 0.0
+        assert torch.equal(ftr.get_score(), eager.get_score())
+        fc, ec = dict(ftr.get_choices().leaves()), dict(eager.get_choices().leaves())
+        assert fc.keys() == ec.keys()
+        for k in fc:
+            a_, b_ = fc[k], ec[k]
+            if isinstance(a_, torch.Tensor) and a_.dim():
+                assert torch.equal(a_, b_.to(a_.dtype) if isinstance(b_, torch.Tensor) else torch.full_like(a_, b_)), k
+        assert torch.equal(ftr.get_retval(), eager.get_retval())
+        # a site score recomputed on demand from the fused trace equals the eager one
+        assert torch.equal(ftr.get_subtrace("x").get_score(), eager.get_subtrace("x").get_score())
+
+
+def _dev():
+    from genjax._amd.runtime import get_ops
+
+    return get_ops().device()
+
+
+# ---- ParticleCollection / ChangeTarget / CSMC ---------------------------------------------------------
+def case_particle_collection(impl):
+    @gen
+    def model():
+        x = normal(0.0, 1.0) @ "x"
+        _ = normal(x, 0.5) @ "y"
+        return x
+
+    key = genjax.random.key(11, impl)
+    t = Target(model, (), C["y"].set(1.0))
+    alg = ImportanceK(t, k_particles=20000)
+    coll = alg.run_smc(key)
+    lw = coll.get_log_weights()
+    assert lw.shape == (20000,) and len(coll) == 20000
+    z = f(coll.get_log_marginal_likelihood_estimate())
+    exact = math.log(_npdf(1.0, 0.0, math.sqrt(1.25)))
+    assert z == pytest.approx(exact, abs=0.03)
+    assert coll.log_marginal_likelihood_estimate_f64() == pytest.approx(z, abs=1e-5)
+    assert z == pytest.approx(f(torch.logsumexp(lw.double(), 0)) - math.log(20000), abs=1e-5)
+    p = coll.sample_particle(genjax.random.key(3, impl))
+    assert p.get_choices()["x"].dim() == 0 and f(p.get_choices()["y"]) == 1.0
+    tr5, w5 = coll[5]
+    assert f(w5) == f(lw[5]) and f(tr5.get_choices()["x"]) == f(coll.get_particles().get_choices()["x"][5])
+    # posterior mean of x | y=1 is 0.8: importance estimate and resampled estimate
+    xs = coll.get_particles().get_choices()["x"]
+    w = torch.softmax(lw.double(), 0)
+    assert f((w * xs.double()).sum()) == pytest.approx(0.8, abs=0.03)
+    for method in ("systematic", "multinomial"):
+        rs = coll.resample(genjax.random.key(4, impl), method)
+        assert f(rs.get_particles().get_choices()["x"].mean()) == pytest.approx(0.8, abs=0.03)
+        assert f(rs.get_log_marginal_likelihood_estimate()) == pytest.approx(z, abs=1e-4)
+        a = rs.ancestors.long()
+        assert torch.equal(rs.get_particles().get_choices()["x"], xs[a])
+    assert 1.0 < coll.effective_sample_size() < 20000
+    # ChangeTarget to a different observation re-weights exactly by the likelihood ratio
+    t2 = Target(model, (), C["y"].set(-0.5))
+    c2 = ChangeTarget(alg, t2).run_smc(key)
+    want = lw + normal.logpdf(-0.5, xs, 0.5) - normal.logpdf(1.0, xs, 0.5)
+    assert torch.allclose(c2.get_log_weights(), want, atol=2e-5)
+    z2 = f(alg.log_marginal_likelihood_estimate(key, t2))
+    assert z2 == pytest.approx(math.log(_npdf(-0.5, 0.0, math.sqrt(1.25))), abs=0.1)
+    # random_weighted: density estimate = score - log Z_hat
+    score, chm = alg.random_weighted(genjax.random.key(5, impl), t)
+    assert "x" in chm and "y" not in chm
+    # conditional SMC keeps the retained particle last
+    retained = C["x"].set(0.123)
+    cs = ImportanceK(t, k_particles=16).run_csmc(genjax.random.key(6, impl), retained)
+    assert len(cs) == 16 and f(cs.get_particles().get_choices()["x"][-1]) == pytest.approx(0.123)
+    # estimate_logpdf mirrors smc.py:181-198 literally: score of a particle drawn from the conditional
+    # collection minus the log-marginal estimate (finite, and a posterior log-density of SOME particle)
+    est = ImportanceK(t, k_particles=64).estimate_logpdf(genjax.random.key(8, impl), retained, t)
+    assert math.isfinite(f(est)) and f(est) < math.log(_npdf(0.8, 0.8, math.sqrt(0.2))) + 0.5
+    one = Importance(t).run_csmc(genjax.random.key(9, impl), retained)
+    assert len(one) == 1
+
+
+# ---- scan (tests/generative_functions/test_scan_combinator.py:54-61) ------------------------------------
+def case_scan(impl):
+    @genjax.scan(n=10)
+    @gen
+    def chain(x, _):
+        z = normal(x, 1.0) @ "z"
+        return z, None
+
+    key = genjax.random.key(314159, impl)
+    tr = chain.simulate(key, (0.0, None))
+    zs = tr.get_choices()["z"]
+    assert zs.shape == (10,)
+    assert f(tr.get_score()) == pytest.approx(f(chain.assess(tr.get_choices(), (0.0, None))[0]), rel=1e-5)
+    for i in (0, 3, 9):
+        tr, w = chain.importance(key, C[i, "z"].set(0.5), (0.0, None))
+        zs = tr.get_choices()["z"]
+        assert f(zs[i]) == 0.5
+        prev = 0.0 if i == 0 else f(zs[i - 1])
+        assert f(w) == pytest.approx(f(normal.assess(C.v(0.5), (prev, 1.0))[0]), rel=1e-5)
+    # batched over particles: [n, T] leaves
+    keys = genjax.random.split(key, 64)
+    trb, wb = chain.importance(keys, C[2, "z"].set(0.5), (0.0, None))
+    assert trb.get_choices()["z"].shape == (64, 10) and wb.shape == (64,)
+    assert trb.get_score().shape == (64,)
+
+
+# ---- fused bootstrap SMC ---------------------------------------------------------------------------------
+def case_bootstrap_smc(impl):
+    from genjax._amd import workloads as W
+
+    y = W.lgssm_data(30)
+    smc = BootstrapSMC(LinearGaussianSSM(), y, n_particles=20000, record_ancestors=True)
+    res = smc.run(genjax.random.key(3, impl))
+    assert res.log_marginal_likelihood == pytest.approx(W.lgssm_exact_log_z(y), abs=0.15)
+    assert res.ancestors.shape == (30, 20000) and res.particles.shape == (20000,)
+    a = res.ancestors[7]
+    assert bool((a[1:] >= a[:-1]).all())
+    res2 = smc.run(genjax.random.key(3, impl))
+    assert torch.equal(res.step_q, res2.step_q)  # counter-based: runs are replayable
+
+
+ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
+             case_static_gen_fn, case_distributions, case_fused_equals_eager, case_particle_collection, case_scan,
+             case_bootstrap_smc]

@@ -1,0 +1,14 @@
+"""Host logic (`@gen`, ChoiceMap, Target, ImportanceK, ...) on CPU: the oracle is injected as the
+backend through the test hook `use_ops` so that the SAME host code the GPU runs is exercised here."""
+
+import pytest
+
+import host_api_cases as H
+from genjax._amd.runtime import use_ops
+
+
+@pytest.mark.parametrize("impl", ["threefry", "philox"])
+@pytest.mark.parametrize("case", H.ALL_CASES, ids=lambda c: c.__name__)
+def test_host_api(oracle_ops, case, impl):
+    with use_ops(oracle_ops):
+        case(impl)

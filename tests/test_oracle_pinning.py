@@ -1,0 +1,226 @@
+"""CPU tests that pin the ORACLE (the checker) before it is trusted: Random123 known answers,
+scipy float64 log-densities, accuracy of the math spec, the reference tests' closed-form answers,
+distributional checks of the samplers, resampling invariants, and the committed regression vectors."""
+
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy import special, stats
+
+from genjax._amd import workloads as W
+from genjax._amd.ops import KeyBatch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def gold(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def raw(oracle_ops):
+    return oracle_ops.lib._dll
+
+
+def test_cipher_known_answers(raw):
+    kat = gold("rng_kat.json")
+    for v in kat["threefry2x32_20"]:
+        k = (C.c_uint32 * 2)(*[int(x, 16) for x in v["key"]])
+        c = (C.c_uint32 * 2)(*[int(x, 16) for x in v["ctr"]])
+        o = (C.c_uint32 * 2)()
+        raw.gjo_threefry2x32(k, c, o)
+        assert [f"{x:08x}" for x in o] == v["out"]
+    for v in kat["philox4x32_10"]:
+        k = (C.c_uint32 * 2)(*[int(x, 16) for x in v["key"]])
+        c = (C.c_uint32 * 4)(*[int(x, 16) for x in v["ctr"]])
+        o = (C.c_uint32 * 4)()
+        raw.gjo_philox4x32(k, c, o)
+        assert [f"{x:08x}" for x in o] == v["out"]
+
+
+def test_jax_key_tree_is_threefry_of_counter(oracle_ops, raw):
+    """split(k, n)[i] == fold_in(k, i) == threefry2x32(k, (0, i)) — jax_threefry_partitionable
+    semantics."""
+    key = (0x13198A2E, 0x03707344)
+    ks = oracle_ops.rng_keys(KeyBatch(0, 1, parent=key, first=0), 5).numpy().view(np.uint32)
+    for i in range(5):
+        k = (C.c_uint32 * 2)(*key)
+        c = (C.c_uint32 * 2)(0, i)
+        o = (C.c_uint32 * 2)()
+        raw.gjo_threefry2x32(k, c, o)
+        assert tuple(ks[i]) == (o[0], o[1])
+        f = oracle_ops.rng_keys(KeyBatch(0, 2, parent=key).with_fold(i), 1).numpy().view(np.uint32)[0]
+        assert tuple(f) == (o[0], o[1])
+    # 32 random bits of a key = hi ^ lo of block (0, 0)
+    b = oracle_ops.rng_bits(KeyBatch(0, 2, parent=key), 1).numpy().view(np.uint32)[0]
+    k = (C.c_uint32 * 2)(*key); c = (C.c_uint32 * 2)(0, 0); o = (C.c_uint32 * 2)()
+    raw.gjo_threefry2x32(k, c, o)
+    assert b == o[0] ^ o[1]
+
+
+def _math(raw, fn, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    raw.gjo_math(fn, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.c_uint64(x.size))
+    return y
+
+
+def test_math_spec_accuracy(raw):
+    rng = np.random.default_rng(0)
+    x = np.exp(rng.uniform(-80, 80, 100000)).astype(np.float32)
+    assert np.max(np.abs(_math(raw, 0, x) - np.log(x.astype(np.float64))) / np.maximum(1, np.abs(np.log(x.astype(np.float64))))) < 2e-7
+    x = rng.uniform(-85, 85, 100000).astype(np.float32)
+    assert np.max(np.abs(_math(raw, 1, x) / np.exp(x.astype(np.float64)) - 1)) < 3e-7
+    x = rng.uniform(-1, 1, 100000).astype(np.float32)
+    ref = special.erfinv(x.astype(np.float64))
+    assert np.max(np.abs(_math(raw, 2, x) - ref) / np.maximum(1e-3, np.abs(ref))) < 1e-6
+    x = np.exp(rng.uniform(-6, 6, 100000)).astype(np.float32)
+    ref = special.gammaln(x.astype(np.float64))
+    assert np.max(np.abs(_math(raw, 3, x) - ref) / np.maximum(1, np.abs(ref))) < 1e-5
+    assert _math(raw, 0, [0.0])[0] == -np.inf and _math(raw, 1, [-200.0])[0] == 0.0
+
+
+def test_logpdfs_against_scipy(oracle_ops):
+    g = gold("logpdf_scipy.json")
+    for r in g["normal"]:
+        got = float(oracle_ops.logpdf("normal", 1, r["x"], r["loc"], r["scale"]))
+        assert got == pytest.approx(r["logpdf"], rel=2e-6, abs=2e-6)
+    for r in g["gamma"]:
+        got = float(oracle_ops.logpdf("gamma", 1, r["x"], r["concentration"], r["rate"]))
+        assert got == pytest.approx(r["logpdf"], rel=1e-5, abs=1e-5)
+    for r in g["beta"]:
+        got = float(oracle_ops.logpdf("beta", 1, r["x"], r["a"], r["b"]))
+        assert got == pytest.approx(r["logpdf"], rel=1e-5, abs=2e-5)
+    for r in g["bernoulli"]:
+        got = float(oracle_ops.logpdf("bernoulli", 1, bool(r["x"]), r["p"]))
+        assert got == pytest.approx(r["logpdf"], rel=1e-6)
+    for r in g["categorical"]:
+        lg = torch.tensor([r["logits"]])
+        for k, want in enumerate(r["logpdf"]):
+            assert float(oracle_ops.logpdf_categorical(1, k, lg)) == pytest.approx(want, rel=1e-6)
+
+
+def test_reference_known_answers(oracle_ops):
+    r = gold("reference_kat.json")
+    # tests/generative_functions/test_static_gen_fn.py:317-318
+    s = float(oracle_ops.logpdf("normal", 1, 1.0, 0.0, 1.0)) + float(oracle_ops.logpdf("normal", 1, -1.0, 0.0, 1.0))
+    assert s == pytest.approx(r["assess_two_std_normals_y1_1_y2_m1"], abs=1e-6)
+    assert float(oracle_ops.logpdf("normal", 1, 0.5, 0.0, 1.0)) == pytest.approx(r["normal_logpdf_0p5_0_1"], abs=1e-6)
+    assert float(oracle_ops.logpdf("bernoulli", 1, True, 0.7)) == pytest.approx(r["flip_flip_trivial_logZ"], abs=1e-7)
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_sampler_distributions(oracle_ops, impl):
+    n = 400000
+    kb = KeyBatch(impl, 1, parent=(123, 456), first=0)
+    v, _ = oracle_ops.sample_logpdf("normal", kb.with_fold(1), n, 1.0, 2.0)
+    assert stats.kstest(v.numpy().astype(np.float64), "norm", args=(1.0, 2.0)).pvalue > 1e-3
+    for a, b in ((2.5, 3.0), (0.3, 1.0), (1.0, 0.5)):
+        v, _ = oracle_ops.sample_logpdf("gamma", kb.with_fold(2), n, a, b)
+        assert stats.kstest(v.numpy().astype(np.float64), "gamma", args=(a, 0, 1 / b)).pvalue > 1e-3
+    for a, b in ((2.0, 2.0), (0.5, 3.0)):
+        v, _ = oracle_ops.sample_logpdf("beta", kb.with_fold(3), n, a, b)
+        assert stats.kstest(v.numpy().astype(np.float64), "beta", args=(a, b)).pvalue > 1e-3
+    v, _ = oracle_ops.sample_logpdf("bernoulli", kb.with_fold(4), n, 0.3)
+    assert abs(float(v.float().mean()) - 0.3) < 4 * math.sqrt(0.21 / n)
+    lg = torch.tensor([[0.1, -1.0, 2.0, 0.5, float("-inf")]])
+    p = torch.softmax(lg[0].double(), 0).numpy()
+    for mode in (0, 1):
+        v, s = oracle_ops.sample_logpdf_categorical(kb.with_fold(5), n, lg, None, mode)
+        cnt = np.bincount(v.numpy(), minlength=5)
+        assert cnt[4] == 0
+        assert stats.chisquare(cnt[:4], p[:4] * n).pvalue > 1e-3
+        assert np.allclose(s.numpy(), np.log(p)[v.numpy()], atol=1e-6)
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_closed_form_log_z(oracle_ops, impl):
+    g = W.gaussian10_importance(oracle_ops, impl, seed=0, n=400000)
+    assert abs(g["log_z"] - g["log_z_exact"]) < 0.35
+    ref = float(torch.logsumexp(g["logw"].double(), 0)) - math.log(400000)
+    assert abs(g["log_z"] - ref) < 1e-6 and abs(g["lse"] - math.log(400000) - ref) < 1e-5
+    s = W.lgssm_smc(oracle_ops, impl, seed=1, n=50000, T=40)
+    assert abs(s["log_z"] - s["log_z_exact"]) < 0.1
+    h = W.hmm_smc(oracle_ops, impl, seed=2, n=20000, T=30, n_states=32)
+    assert abs(h["log_z"] - h["log_z_exact"]) < 0.15
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_resampling_invariants(oracle_ops, impl):
+    g = torch.Generator().manual_seed(7)
+    for n, n_out in ((1, 1), (10, 50), (5000, 5000), (3000, 1000)):
+        lw = torch.randn(n, generator=g) * 3
+        if n > 5:
+            lw[2] = float("-inf")
+        key = KeyBatch(impl, 2, parent=(n, 1))
+        a, m, q = oracle_ops.resample("systematic", key, lw, n_out)
+        assert a.shape[0] == n_out and bool((a[1:] >= a[:-1]).all())
+        cnt = torch.bincount(a.long(), minlength=n).double()
+        w = torch.softmax(lw.double(), 0) * n_out
+        assert float((cnt - w).abs().max()) < 1 + 1e-6  # counts in {floor, ceil}
+        if n > 5:
+            assert cnt[2] == 0
+        assert float(m) == float(lw.max())
+        # the (max, q) pair reproduces logsumexp
+        lse = float(m) + math.log(int(q)) - oracle_ops.frac_bits(n) * math.log(2)
+        assert lse == pytest.approx(float(torch.logsumexp(lw.double(), 0)), abs=1e-6)
+        a2, _, _ = oracle_ops.resample("multinomial", key, lw, n_out)
+        assert int(a2.min()) >= 0 and int(a2.max()) < n
+    # multinomial frequencies
+    lw = torch.tensor([0.0, 1.0, 2.0, -1.0])
+    a, _, _ = oracle_ops.resample("multinomial", KeyBatch(impl, 2, parent=(9, 9)), lw, 200000)
+    cnt = np.bincount(a.numpy(), minlength=4)
+    assert stats.chisquare(cnt, torch.softmax(lw.double(), 0).numpy() * 200000).pvalue > 1e-3
+
+
+def test_logsumexp_edge_cases(oracle_ops):
+    for x in ([0.0], [-1e30, 0.0], [5.0] * 7, [float("-inf"), -3.0]):
+        t = torch.tensor(x)
+        lse, m, q = oracle_ops.logsumexp(t)
+        assert float(lse) == pytest.approx(float(torch.logsumexp(t.double(), 0)), abs=1e-6)
+
+
+def test_regression_vectors(oracle_ops):
+    check_regression(oracle_ops)
+
+
+def check_regression(ops):
+    """Shared with the GPU suite: the committed oracle outputs must be reproduced exactly."""
+    reg = gold("oracle_regression.json")
+    dev = ops.device()
+    for impl, nm in ((0, "threefry"), (1, "philox")):
+        r = reg[nm]
+        kb = KeyBatch(impl, 1, parent=(0, 42), first=0)
+        assert ops.rng_keys(kb, 4).cpu().view(-1).tolist() == r["keys"]
+        assert ops.rng_bits(kb.with_fold(1), 4).cpu().tolist() == r["bits_fold1"]
+        v, s = ops.sample_logpdf("normal", kb.with_fold(1), 4, 0.0, 1.0)
+        assert v.cpu().view(torch.int32).tolist() == r["normal_bits"]
+        assert s.cpu().view(torch.int32).tolist() == r["normal_score_bits"]
+        v, _ = ops.sample_logpdf("gamma", kb.with_fold(2), 4, 0.7, 2.0)
+        assert v.cpu().view(torch.int32).tolist() == r["gamma_bits"]
+        v, _ = ops.sample_logpdf("beta", kb.with_fold(3), 4, 2.0, 2.0)
+        assert v.cpu().view(torch.int32).tolist() == r["beta_bits"]
+        v, _ = ops.sample_logpdf("bernoulli", kb.with_fold(4), 8, 0.3)
+        assert v.cpu().tolist() == r["bernoulli"]
+        lw = torch.linspace(-3, 2, 37).to(dev)
+        a, m, q = ops.resample("systematic", KeyBatch(impl, 2, parent=(5, 6)), lw)
+        assert a.cpu().tolist() == r["systematic_ancestors"] and int(q.cpu()) == r["systematic_q"]
+        a, _, _ = ops.resample("multinomial", KeyBatch(impl, 2, parent=(5, 6)), lw, 12)
+        assert a.cpu().tolist() == r["multinomial_ancestors"]
+        assert int(ops.categorical_index(KeyBatch(impl, 2, parent=(5, 6)), lw, 0).cpu()) == r["categorical_index_gumbel"]
+        assert int(ops.categorical_index(KeyBatch(impl, 2, parent=(5, 6)), lw, 1).cpu()) == r["categorical_index_invcdf"]
+        g = W.gaussian10_importance(ops, impl, seed=3, n=2048)
+        assert g["q"] == r["gaussian10_q"]
+        assert g["logw"][:4].cpu().view(torch.int32).tolist() == r["gaussian10_logw_head_bits"]
+        s_ = W.lgssm_smc(ops, impl, seed=4, n=2048, T=6, want_ancestors=True)
+        assert s_["out_q"].cpu().tolist() == r["lgssm_q"]
+        assert s_["ancestors"][5, :16].cpu().tolist() == r["lgssm_anc_t5_head"]
+        h = W.hmm_smc(ops, impl, seed=5, n=2048, T=6, n_states=16)
+        assert h["out_q"].cpu().tolist() == r["hmm_q"]
