@@ -11,8 +11,18 @@
 //   tfd.X(...).sample / .log_prob ... generative_functions/distributions/tensorflow_probability/__init__.py:52-62
 //   logsumexp ....................... inference/smc.py:97,107
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else  // hiprtc (plan specialisation): HIP built-ins are pre-included, fixed-width types are not
+typedef unsigned char uint8_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long uintptr_t;
+typedef unsigned long size_t;
+#endif
 
 #define GJX_DEV __device__ __forceinline__
 #define GJX_HD __host__ __device__ __forceinline__
@@ -129,8 +139,16 @@ struct Stream {
       philox4x32(k.k0, k.k1, sub, f, hf, kTagBits, w0, w1, o2, o3);
     }
   }
+  // 32 bits of sub-stream `sub`.  PHILOX packs the single-word draw (sub 0) of the four leaf
+  // sites f>>2 into one block: word (f & 3) of PH(ctr = (0, f >> 2, 2, TAG_BITS), key).
   GJX_HD uint32_t bits32(uint32_t sub) const {
     uint32_t w0, w1;
+    if (IMPL == 1 && hf && sub == 0u) {
+      uint32_t o[4];
+      philox4x32(k.k0, k.k1, 0u, f >> 2, 2u, kTagBits, o[0], o[1], o[2], o[3]);
+      const uint32_t sel = f & 3u;
+      return sel == 0 ? o[0] : (sel == 1 ? o[1] : (sel == 2 ? o[2] : o[3]));
+    }
     words(sub, w0, w1);
     return IMPL == 0 ? (w0 ^ w1) : w0;
   }
@@ -139,6 +157,12 @@ struct Stream {
     words(sub, w0, w1);
     return ((uint64_t)w0 << 32) | w1;
   }
+};
+
+// Column pointer table of one importance run (kernel argument, by value).
+struct RunCols {
+  const float* in[16];
+  void* out[64];
 };
 
 // Host-visible description of a key batch (mirrors gjx_keys).

@@ -15,6 +15,8 @@
 #include <new>
 #include <string.h>
 
+#include "gjx_plan_jit.hpp"
+
 using namespace gjx;
 
 namespace {
@@ -222,143 +224,199 @@ __global__ __launch_bounds__(kBlock) void k_logpdf_categorical(const int32_t* v,
 // values that later sites may reference are kept in LDS as vals[site][lane] (conflict-free).
 // ------------------------------------------------------------------------------------------------
 struct CArg {
-  int32_t kind, ref;
+  int32_t kind, ref;   // ref: LDS slot (SITE / TABLE) or input column (INPUT)
+  int32_t ref_is_int;  // the referenced site value is an int32 (bernoulli / categorical)
+  int32_t ref_site;    // SITE / TABLE: index of the referenced site (plan specialisation)
   float scale, offset;
   const float* table;
 };
 struct CSite {
   int32_t dist, observed, out_col, n_cat, n_rows, cat_mode;
+  int32_t slot;  // LDS slot this site's value is kept in for later sites, -1 if never referenced
   CArg a0, a1, obs;
   const float* logits;
   int32_t pre;       // 1: pre0/pre1 hold the hoisted per-site constants
   float pre0, pre1;  // normal: rs, lognorm; gamma: -, lognorm; beta: -, lbeta
 };
-struct RunCols {
-  const float* in[16];
-  void* out[GJX_MAX_SITES];
-};
+static_assert(GJX_MAX_SITES == 64, "RunCols::out is sized for 64 sites");
 
-GJX_DEV float site_f32(const uint32_t* vals, int ref, bool is_int) {
-  const uint32_t raw = vals[ref * kBlock + threadIdx.x];
-  return is_int ? (float)(int32_t)raw : u2f(raw);
-}
+constexpr int kPPT = kTile / kBlock;  // particles per thread (4): ILP across independent particles
+constexpr int kMaskNormal = 1 << GJX_DIST_NORMAL;
+constexpr int kMaskReal = kMaskNormal | (1 << GJX_DIST_GAMMA) | (1 << GJX_DIST_BETA) | (1 << GJX_DIST_BERNOULLI);
+constexpr int kMaskAll = kMaskReal | (1 << GJX_DIST_CATEGORICAL);
 
-template <int IMPL>
+// Site-outer / particle-inner interpreter: the site table is decoded once per tile row (scalar
+// loads, wave-uniform branches) and each decoded site is applied to the thread's 4 particles, so
+// four independent cipher / erfinv chains are in flight per lane.  Values a later site refers to
+// live in LDS slots assigned by liveness at plan creation (vals[slot][r][lane], conflict-free).
+// MASK is the compile-time set of distributions the plan may contain: an all-Normal model does not
+// carry the gamma rejection loop or the categorical scans in its instruction stream.
+template <int IMPL, int MASK>
 __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__ sites,
                                                        int n_sites, KeySrc ks, RunCols cols,
                                                        float* score, float* logw, uint64_t n,
                                                        float* max_partials) {
-  extern __shared__ uint32_t vals[];  // [n_sites][kBlock]
+  extern __shared__ uint32_t vals[];  // [n_slots][kPPT][kBlock]
   __shared__ float sh_red[kBlock / kWave];
-  // is_int bitmask of sites (bernoulli / categorical values are stored as int32)
-  uint64_t int_mask = 0;
-  for (int q = 0; q < n_sites; ++q)
-    if (sites[q].dist >= GJX_DIST_BERNOULLI) int_mask |= (uint64_t)1 << q;
+  const int tid = threadIdx.x;
 
   for (uint64_t tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
-    float tmax = -__builtin_inff();
-    for (int r = 0; r < kTile / kBlock; ++r) {
-      const uint64_t i = tile * kTile + (uint64_t)r * kBlock + threadIdx.x;
-      if (i < n) {
-        const Key pkey = key_at<IMPL>(ks, i);
-        float w = 0.0f, sc = 0.0f;
-        for (int q = 0; q < n_sites; ++q) {
-          const CSite& st = sites[q];
-          const bool is_int = st.dist >= GJX_DIST_BERNOULLI;
-          float a0 = 0.0f, a1 = 0.0f;
-          const float* row = nullptr;
-          auto eval = [&](const CArg& a) -> float {
-            switch (a.kind) {
-              case GJX_ARG_CONST: return a.offset;
-              case GJX_ARG_SITE: {
-                const float t = a.scale * site_f32(vals, a.ref, (int_mask >> a.ref) & 1);
-                return t + a.offset;
-              }
-              case GJX_ARG_INPUT: {
-                const float t = a.scale * cols.in[a.ref][i];
-                return t + a.offset;
-              }
-              default: {
-                const uint32_t raw = vals[a.ref * kBlock + threadIdx.x];
-                const int32_t idx = ((int_mask >> a.ref) & 1) ? (int32_t)raw
-                                                                : (int32_t)__builtin_rintf(u2f(raw));
-                return a.table[idx];
-              }
-            }
-          };
-          if (st.dist == GJX_DIST_CATEGORICAL) {
-            int32_t rr;
-            if (st.a0.kind == GJX_ARG_SITE) {
-              const uint32_t raw = vals[st.a0.ref * kBlock + threadIdx.x];
-              rr = ((int_mask >> st.a0.ref) & 1) ? (int32_t)raw : (int32_t)__builtin_rintf(u2f(raw));
-            } else if (st.a0.kind == GJX_ARG_CONST) {
-              rr = (int32_t)__builtin_rintf(st.a0.offset);
-            } else {
-              rr = (int32_t)__builtin_rintf(eval(st.a0));
-            }
-            rr = rr < 0 ? 0 : (rr >= st.n_rows ? st.n_rows - 1 : rr);
-            row = st.logits + (size_t)rr * (size_t)st.n_cat;
-          } else {
-            a0 = eval(st.a0);
-            if (st.dist != GJX_DIST_BERNOULLI) a1 = eval(st.a1);
+    uint64_t idx[kPPT];
+    Key pkey[kPPT];
+    float w[kPPT], sc[kPPT];
+    uint32_t pw[kPPT][4];  // PHILOX: cached packed block (4 single-word draws) per particle
+    int pw_blk = -1;
+#pragma unroll
+    for (int r = 0; r < kPPT; ++r) {
+      idx[r] = tile * kTile + (uint64_t)r * kBlock + tid;
+      // out-of-range lanes of the last tile run on the last particle and are masked at the stores
+      pkey[r] = key_at<IMPL>(ks, idx[r] < n ? idx[r] : n - 1);
+      w[r] = 0.0f;
+      sc[r] = 0.0f;
+    }
+    for (int q = 0; q < n_sites; ++q) {
+      const CSite& st = sites[q];
+      const int dist = st.dist;
+      const bool is_int = dist >= GJX_DIST_BERNOULLI;
+      auto eval = [&](const CArg& a, int r) -> float {
+        switch (a.kind) {
+          case GJX_ARG_CONST: return a.offset;
+          case GJX_ARG_SITE: {
+            const uint32_t raw = vals[(a.ref * kPPT + r) * kBlock + tid];
+            const float base = a.ref_is_int ? (float)(int32_t)raw : u2f(raw);
+            const float t = a.scale * base;
+            return t + a.offset;
           }
-          float vf = 0.0f;
-          int32_t vi = 0;
-          if (st.observed) {
-            const float ov = st.obs.kind == GJX_ARG_CONST ? st.obs.offset : cols.in[st.obs.ref][i];
-            if (is_int) vi = (int32_t)__builtin_rintf(ov);
-            else vf = ov;
-          } else {
-            const Stream<IMPL> strm(pkey, true, (uint32_t)(q + 1));
-            switch (st.dist) {
-              case GJX_DIST_NORMAL: {
-                const float t = a1 * std_normal(strm.bits32(0));
-                vf = a0 + t;
-                break;
-              }
-              case GJX_DIST_GAMMA: vf = std_gamma<IMPL>(strm, 0, a0) / a1; break;
-              case GJX_DIST_BETA: {
-                const float g1 = std_gamma<IMPL>(strm, 0, a0);
-                const float g2 = std_gamma<IMPL>(strm, 1, a1);
-                vf = g1 / (g1 + g2);
-                break;
-              }
-              case GJX_DIST_BERNOULLI: vi = uniform01(strm.bits32(0)) < a0 ? 1 : 0; break;
-              default:
-                vi = st.cat_mode == 0 ? cat_gumbel<IMPL>(row, (uint32_t)st.n_cat, strm)
-                                      : cat_invcdf(row, (uint32_t)st.n_cat, strm.bits32(0));
-            }
+          case GJX_ARG_INPUT: {
+            const float t = a.scale * cols.in[a.ref][idx[r] < n ? idx[r] : n - 1];
+            return t + a.offset;
           }
-          float lp;
-          switch (st.dist) {
-            case GJX_DIST_NORMAL:
-              lp = st.pre ? logpdf_normal_pre(vf, a0, st.pre0, st.pre1) : logpdf_normal(vf, a0, a1);
-              break;
-            case GJX_DIST_GAMMA:
-              lp = st.pre ? logpdf_gamma_pre(vf, a0, a1, st.pre1) : logpdf_gamma(vf, a0, a1);
-              break;
-            case GJX_DIST_BETA:
-              lp = st.pre ? logpdf_beta_pre(vf, a0, a1, st.pre1) : logpdf_beta(vf, a0, a1);
-              break;
-            case GJX_DIST_BERNOULLI: lp = logpdf_bernoulli(vi != 0, a0); break;
-            default:
-              lp = (vi < 0 || vi >= st.n_cat) ? -__builtin_inff()
-                                              : row[vi] - row_lse(row, (uint32_t)st.n_cat);
+          default: {
+            const uint32_t raw = vals[(a.ref * kPPT + r) * kBlock + tid];
+            const int32_t ti = a.ref_is_int ? (int32_t)raw : (int32_t)__builtin_rintf(u2f(raw));
+            return a.table[ti];
           }
-          sc = sc + lp;
-          if (st.observed) w = w + lp;
-          const uint32_t raw = is_int ? (uint32_t)vi : f2u(vf);
-          vals[q * kBlock + threadIdx.x] = raw;
-          if (st.out_col >= 0) reinterpret_cast<uint32_t*>(cols.out[st.out_col])[i] = raw;
         }
-        logw[i] = w;
-        if (score) score[i] = sc;
-        tmax = w > tmax ? w : tmax;
+      };
+      float a0[kPPT], a1[kPPT];
+      const float* row[kPPT];
+#pragma unroll
+      for (int r = 0; r < kPPT; ++r) {
+        a0[r] = 0.0f;
+        a1[r] = 0.0f;
+        row[r] = nullptr;
+        if ((MASK & (1 << GJX_DIST_CATEGORICAL)) && dist == GJX_DIST_CATEGORICAL) {
+          int32_t rr;
+          if (st.a0.kind == GJX_ARG_SITE) {
+            const uint32_t raw = vals[(st.a0.ref * kPPT + r) * kBlock + tid];
+            rr = st.a0.ref_is_int ? (int32_t)raw : (int32_t)__builtin_rintf(u2f(raw));
+          } else if (st.a0.kind == GJX_ARG_CONST) {
+            rr = (int32_t)__builtin_rintf(st.a0.offset);
+          } else {
+            rr = (int32_t)__builtin_rintf(eval(st.a0, r));
+          }
+          rr = rr < 0 ? 0 : (rr >= st.n_rows ? st.n_rows - 1 : rr);
+          row[r] = st.logits + (size_t)rr * (size_t)st.n_cat;
+        } else {
+          a0[r] = eval(st.a0, r);
+          if (dist != GJX_DIST_BERNOULLI) a1[r] = eval(st.a1, r);
+        }
+      }
+      float vf[kPPT];
+      int32_t vi[kPPT];
+      if (st.observed) {
+#pragma unroll
+        for (int r = 0; r < kPPT; ++r) {
+          const float ov = st.obs.kind == GJX_ARG_CONST ? st.obs.offset
+                                                        : cols.in[st.obs.ref][idx[r] < n ? idx[r] : n - 1];
+          vf[r] = ov;
+          vi[r] = is_int ? (int32_t)__builtin_rintf(ov) : 0;
+        }
+      } else {
+        const uint32_t fold = (uint32_t)(q + 1);
+        // single-word draws (normal / bernoulli / inverse-CDF categorical)
+        uint32_t bits[kPPT];
+        const bool one_word = dist == GJX_DIST_NORMAL || dist == GJX_DIST_BERNOULLI ||
+                              (dist == GJX_DIST_CATEGORICAL && st.cat_mode == 1);
+        if (one_word) {
+          if (IMPL == 1) {
+            if (pw_blk != (int)(fold >> 2)) {
+              pw_blk = (int)(fold >> 2);
+#pragma unroll
+              for (int r = 0; r < kPPT; ++r)
+                philox4x32(pkey[r].k0, pkey[r].k1, 0u, fold >> 2, 2u, kTagBits, pw[r][0], pw[r][1],
+                           pw[r][2], pw[r][3]);
+            }
+            const uint32_t sel = fold & 3u;
+#pragma unroll
+            for (int r = 0; r < kPPT; ++r)
+              bits[r] = sel == 0 ? pw[r][0] : (sel == 1 ? pw[r][1] : (sel == 2 ? pw[r][2] : pw[r][3]));
+          } else {
+#pragma unroll
+            for (int r = 0; r < kPPT; ++r) bits[r] = Stream<IMPL>(pkey[r], true, fold).bits32(0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < kPPT; ++r) {
+          vf[r] = 0.0f;
+          vi[r] = 0;
+          if (dist == GJX_DIST_NORMAL) {
+            const float t = a1[r] * std_normal(bits[r]);
+            vf[r] = a0[r] + t;
+          } else if ((MASK & (1 << GJX_DIST_BERNOULLI)) && dist == GJX_DIST_BERNOULLI) {
+            vi[r] = uniform01(bits[r]) < a0[r] ? 1 : 0;
+          } else if ((MASK & (1 << GJX_DIST_GAMMA)) && dist == GJX_DIST_GAMMA) {
+            const Stream<IMPL> strm(pkey[r], true, fold);
+            vf[r] = std_gamma<IMPL>(strm, 0, a0[r]) / a1[r];
+          } else if ((MASK & (1 << GJX_DIST_BETA)) && dist == GJX_DIST_BETA) {
+            const Stream<IMPL> strm(pkey[r], true, fold);
+            const float g1 = std_gamma<IMPL>(strm, 0, a0[r]);
+            const float g2 = std_gamma<IMPL>(strm, 1, a1[r]);
+            vf[r] = g1 / (g1 + g2);
+          } else if ((MASK & (1 << GJX_DIST_CATEGORICAL)) && dist == GJX_DIST_CATEGORICAL) {
+            if (st.cat_mode == 0) {
+              const Stream<IMPL> strm(pkey[r], true, fold);
+              vi[r] = cat_gumbel<IMPL>(row[r], (uint32_t)st.n_cat, strm);
+            } else {
+              vi[r] = cat_invcdf(row[r], (uint32_t)st.n_cat, bits[r]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kPPT; ++r) {
+        float lp = 0.0f;
+        if (dist == GJX_DIST_NORMAL) {
+          lp = st.pre ? logpdf_normal_pre(vf[r], a0[r], st.pre0, st.pre1) : logpdf_normal(vf[r], a0[r], a1[r]);
+        } else if ((MASK & (1 << GJX_DIST_GAMMA)) && dist == GJX_DIST_GAMMA) {
+          lp = st.pre ? logpdf_gamma_pre(vf[r], a0[r], a1[r], st.pre1) : logpdf_gamma(vf[r], a0[r], a1[r]);
+        } else if ((MASK & (1 << GJX_DIST_BETA)) && dist == GJX_DIST_BETA) {
+          lp = st.pre ? logpdf_beta_pre(vf[r], a0[r], a1[r], st.pre1) : logpdf_beta(vf[r], a0[r], a1[r]);
+        } else if ((MASK & (1 << GJX_DIST_BERNOULLI)) && dist == GJX_DIST_BERNOULLI) {
+          lp = logpdf_bernoulli(vi[r] != 0, a0[r]);
+        } else if ((MASK & (1 << GJX_DIST_CATEGORICAL)) && dist == GJX_DIST_CATEGORICAL) {
+          lp = (vi[r] < 0 || vi[r] >= st.n_cat) ? -__builtin_inff()
+                                               : row[r][vi[r]] - row_lse(row[r], (uint32_t)st.n_cat);
+        }
+        sc[r] = sc[r] + lp;
+        if (st.observed) w[r] = w[r] + lp;
+        const uint32_t raw = is_int ? (uint32_t)vi[r] : f2u(vf[r]);
+        if (st.slot >= 0) vals[(st.slot * kPPT + r) * kBlock + tid] = raw;
+        if (st.out_col >= 0 && idx[r] < n) reinterpret_cast<uint32_t*>(cols.out[st.out_col])[idx[r]] = raw;
+      }
+    }
+    float tmax = -__builtin_inff();
+#pragma unroll
+    for (int r = 0; r < kPPT; ++r) {
+      if (idx[r] < n) {
+        logw[idx[r]] = w[r];
+        if (score) score[idx[r]] = sc[r];
+        tmax = w[r] > tmax ? w[r] : tmax;
       }
     }
     if (max_partials) {
       const float bm = block_max(tmax, sh_red);
-      if (threadIdx.x == 0) max_partials[tile] = bm;
+      if (tid == 0) max_partials[tile] = bm;
     }
   }
 }
@@ -1018,8 +1076,12 @@ int gjx_logpdf_categorical(const int32_t* value, int value_scalar, const float* 
 // ---- plans ---------------------------------------------------------------------------------------
 struct gjx_plan {
   int n_sites;
+  int n_slots;
+  int dist_mask;
   CSite host[GJX_MAX_SITES];
   CSite* dev;
+  gjx_jit::Compiled jit[2];  // specialised kernel per RNG scheme, built on first use
+  std::mutex jit_mu;
 };
 
 static bool arg_ok(const gjx_arg& a, int s) {
@@ -1031,7 +1093,7 @@ static bool arg_ok(const gjx_arg& a, int s) {
     default: return false;
   }
 }
-static CArg carg(const gjx_arg& a) { return CArg{a.kind, a.ref, a.scale, a.offset, a.table}; }
+static CArg carg(const gjx_arg& a) { return CArg{a.kind, a.ref, 0, a.ref, a.scale, a.offset, a.table}; }
 
 int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
   if (!sites || !out || n_sites <= 0 || n_sites > GJX_MAX_SITES) return GJX_ERR_INVALID;
@@ -1039,10 +1101,14 @@ int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
   if (!p) return GJX_ERR_LAUNCH;
   p->n_sites = n_sites;
   p->dev = nullptr;
+  p->dist_mask = 0;
+  int last_use[GJX_MAX_SITES];
+  for (int s = 0; s < n_sites; ++s) last_use[s] = -1;
   for (int s = 0; s < n_sites; ++s) {
     const gjx_site& st = sites[s];
     bool ok = st.dist >= 0 && st.dist <= GJX_DIST_CATEGORICAL && arg_ok(st.arg[0], s);
-    if (ok && st.dist != GJX_DIST_BERNOULLI && st.dist != GJX_DIST_CATEGORICAL) ok = arg_ok(st.arg[1], s);
+    const bool two_args = st.dist != GJX_DIST_BERNOULLI && st.dist != GJX_DIST_CATEGORICAL;
+    if (ok && two_args) ok = arg_ok(st.arg[1], s);
     if (ok && st.observed) ok = st.obs.kind == GJX_ARG_CONST || (st.obs.kind == GJX_ARG_INPUT && st.obs.ref >= 0 && st.obs.ref < 16);
     if (ok && st.dist == GJX_DIST_CATEGORICAL)
       ok = st.logits && st.n_cat > 0 && st.n_rows > 0 && (st.cat_mode == 0 || st.cat_mode == 1);
@@ -1050,12 +1116,17 @@ int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
       delete p;
       return GJX_ERR_INVALID;
     }
+    p->dist_mask |= 1 << st.dist;
     CSite& c = p->host[s];
     memset(&c, 0, sizeof(c));
     c.dist = st.dist; c.observed = st.observed; c.out_col = st.out_col;
     c.n_cat = st.n_cat; c.n_rows = st.n_rows; c.cat_mode = st.cat_mode;
+    c.slot = -1;
     c.a0 = carg(st.arg[0]); c.a1 = carg(st.arg[1]); c.obs = carg(st.obs);
+    if (!two_args) c.a1.kind = GJX_ARG_CONST;
     c.logits = st.logits;
+    for (CArg* a : {&c.a0, &c.a1})
+      if (a->kind == GJX_ARG_SITE || a->kind == GJX_ARG_TABLE) last_use[a->ref] = s;
     // Hoist per-site constants: same spec functions, evaluated once on the host (IEEE-exact ops
     // give the same bits as evaluating them per particle on the device).
     const bool c0 = st.arg[0].kind == GJX_ARG_CONST, c1 = st.arg[1].kind == GJX_ARG_CONST;
@@ -1067,21 +1138,74 @@ int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
       c.pre = 1; c.pre1 = beta_lbeta(st.arg[0].offset, st.arg[1].offset);
     }
   }
-  if (hipMalloc(&p->dev, sizeof(CSite) * (size_t)n_sites) != hipSuccess) {
-    delete p;
+  // LDS slots by liveness (linear scan): a value occupies a slot from its site to its last use.
+  int slot_free_at[GJX_MAX_SITES];  // slot -> first site index at which it is free again
+  int n_slots = 0;
+  int site_slot[GJX_MAX_SITES];
+  for (int s = 0; s < n_sites; ++s) {
+    site_slot[s] = -1;
+    CSite& c = p->host[s];
+    // translate this site's references BEFORE taking a slot for its own value
+    for (CArg* a : {&c.a0, &c.a1})
+      if (a->kind == GJX_ARG_SITE || a->kind == GJX_ARG_TABLE) {
+        a->ref_is_int = p->host[a->ref].dist >= GJX_DIST_BERNOULLI;
+        a->ref = site_slot[a->ref];
+      }
+    if (last_use[s] < 0) continue;
+    int slot = -1;
+    for (int k = 0; k < n_slots; ++k)
+      if (slot_free_at[k] <= s) { slot = k; break; }
+    if (slot < 0) slot = n_slots++;
+    slot_free_at[slot] = last_use[s] + 1;  // reusable by sites after the last reader
+    site_slot[s] = slot;
+    c.slot = slot;
+  }
+  p->n_slots = n_slots;
+  *out = p;  // the interpreter's device copy of the table is made on first use (plan_device_table)
+  return GJX_OK;
+}
+
+// Device copy of the site table for the interpreter kernel (not needed by specialised kernels).
+static int plan_device_table(gjx_plan* p) {
+  std::lock_guard<std::mutex> lock(p->jit_mu);
+  if (p->dev) return GJX_OK;
+  if (hipMalloc(&p->dev, sizeof(CSite) * (size_t)p->n_sites) != hipSuccess) {
+    p->dev = nullptr;
     return GJX_ERR_NO_DEVICE;
   }
-  if (hipMemcpy(p->dev, p->host, sizeof(CSite) * (size_t)n_sites, hipMemcpyHostToDevice) != hipSuccess) {
+  if (hipMemcpy(p->dev, p->host, sizeof(CSite) * (size_t)p->n_sites, hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(p->dev);
-    delete p;
+    p->dev = nullptr;
     return GJX_ERR_LAUNCH;
   }
-  *out = p;
   return GJX_OK;
+}
+
+int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t buf_len, size_t* needed) {
+  if (!p || (impl != 0 && impl != 1)) return GJX_ERR_INVALID;
+  gjx_jit::Gen<CSite, CArg> g;
+  g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites;
+  const std::string src = g.run();
+  if (needed) *needed = src.size() + 1;
+  if (buf && buf_len > 0) {
+    const size_t k = src.size() < buf_len - 1 ? src.size() : buf_len - 1;
+    memcpy(buf, src.data(), k);
+    buf[k] = 0;
+  }
+  return GJX_OK;
+}
+
+int gjx_plan_compile_check(const gjx_plan* p, int impl) {
+  if (!p || (impl != 0 && impl != 1)) return GJX_ERR_INVALID;
+  gjx_jit::Gen<CSite, CArg> g;
+  g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites;
+  return gjx_jit::compile_only(g.run()) ? GJX_OK : GJX_ERR_UNSUPPORTED;
 }
 int gjx_plan_destroy(gjx_plan* p) {
   if (!p) return GJX_OK;
   if (p->dev) (void)hipFree(p->dev);
+  for (auto& c : p->jit)
+    if (c.mod) (void)hipModuleUnload(c.mod);
   delete p;
   return GJX_OK;
 }
@@ -1105,9 +1229,45 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
     if (st.observed && st.obs.kind == GJX_ARG_INPUT && st.obs.ref >= n_input_cols) return GJX_ERR_INVALID;
   }
   if (n == 0) return GJX_OK;
-  const size_t lds = sizeof(uint32_t) * (size_t)p->n_sites * kBlock;
-  GJX_DISPATCH_IMPL(pk->impl, k_importance,
-                    <<<grid_for(n), kBlock, lds, S(s)>>>(p->dev, p->n_sites, key_src(pk), cols, score, logw, n, max_partials));
+  KeySrc k = key_src(pk);
+  // Specialised straight-line kernel for this site table (compiled once per plan and RNG scheme).
+  if (gjx_jit::enabled()) {
+    gjx_plan* mp = const_cast<gjx_plan*>(p);
+    gjx_jit::Compiled& c = mp->jit[pk->impl];
+    if (c.state == 0) {
+      std::lock_guard<std::mutex> lock(mp->jit_mu);
+      if (c.state == 0) {
+        gjx_jit::Gen<CSite, CArg> g;
+        g.impl = pk->impl; g.sites = p->host; g.n_sites = p->n_sites;
+        c.state = gjx_jit::compile(g.run(), &c) ? 1 : -1;
+      }
+    }
+    if (c.state == 1) {
+      uint64_t nn = n;
+      void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials};
+      if (hipModuleLaunchKernel(c.fn, grid_for(n), 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess)
+        return GJX_ERR_LAUNCH;
+      return launch_status();
+    }
+  }
+  {
+    const int rc = plan_device_table(const_cast<gjx_plan*>(p));
+    if (rc) return rc;
+  }
+  const size_t lds = sizeof(uint32_t) * (size_t)(p->n_slots > 0 ? p->n_slots : 1) * kTile;
+#define GJX_LAUNCH_IMPORTANCE(IMPL, MASK) \
+  k_importance<IMPL, MASK><<<grid_for(n), kBlock, lds, S(s)>>>(p->dev, p->n_sites, k, cols, score, logw, n, max_partials)
+  const int m = p->dist_mask;
+  if (pk->impl == 0) {
+    if ((m & ~kMaskNormal) == 0) GJX_LAUNCH_IMPORTANCE(0, kMaskNormal);
+    else if ((m & ~kMaskReal) == 0) GJX_LAUNCH_IMPORTANCE(0, kMaskReal);
+    else GJX_LAUNCH_IMPORTANCE(0, kMaskAll);
+  } else {
+    if ((m & ~kMaskNormal) == 0) GJX_LAUNCH_IMPORTANCE(1, kMaskNormal);
+    else if ((m & ~kMaskReal) == 0) GJX_LAUNCH_IMPORTANCE(1, kMaskReal);
+    else GJX_LAUNCH_IMPORTANCE(1, kMaskAll);
+  }
+#undef GJX_LAUNCH_IMPORTANCE
   return launch_status();
 }
 

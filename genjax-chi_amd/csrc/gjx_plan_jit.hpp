@@ -1,0 +1,239 @@
+// gjx_plan_jit.hpp — plan specialisation: one straight-line gfx950 kernel per site table.
+//
+// The interpreter kernel (k_importance) pays ~200 scalar instructions and ~28 scalar loads per
+// site to decode the table (rocprofv3 PMC, profiles/r01_b_*).  A static model's table is known when
+// the plan is created, so we emit the walk of static.py:340-399 as straight-line HIP — the same
+// device functions from gjx_device.hpp in the same order, with every constant folded into a literal
+// — and compile it for gfx950 with hiprtc.  Both kernels implement the one arithmetic spec and are
+// bit-identical (tests/test_gpu_parity_abi.py runs each plan both ways).
+//
+// This is included by gjx_hip.hip inside its anonymous namespace users; it needs CSite / gjx_plan.
+#pragma once
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <sstream>
+#include <string>
+
+namespace gjx_jit {
+
+// The device header, embedded at build time (see __graft_entry__.build()).
+static const char kDeviceHeader[] =
+#include "gjx_device_embed.inc"
+    ;
+
+inline std::string flit(float f) {
+  char b[48];
+  std::snprintf(b, sizeof b, "u2f(0x%08xu)", gjx::f2u(f));
+  return b;
+}
+inline std::string plit(const void* p) {
+  char b[64];
+  std::snprintf(b, sizeof b, "((const float*)0x%llxull)", (unsigned long long)(uintptr_t)p);
+  return b;
+}
+
+template <class CSiteT, class CArgT>
+struct Gen {
+  std::ostringstream o;
+  int impl;
+  const CSiteT* sites;
+  int n_sites;
+
+  static bool is_int(const CSiteT& s) { return s.dist >= GJX_DIST_BERNOULLI; }
+
+  std::string val_f32(int site) const {
+    return is_int(sites[site]) ? "(float)vi" + std::to_string(site) : "vf" + std::to_string(site);
+  }
+  std::string val_i32(int site) const {
+    return is_int(sites[site]) ? "vi" + std::to_string(site)
+                               : "(int32_t)__builtin_rintf(vf" + std::to_string(site) + ")";
+  }
+  // The value of an argument, in exactly the interpreter's operation order.
+  std::string arg(const CArgT& a) const {
+    switch (a.kind) {
+      case GJX_ARG_CONST: return flit(a.offset);
+      case GJX_ARG_SITE: return "((" + flit(a.scale) + " * " + val_f32(a.ref_site) + ") + " + flit(a.offset) + ")";
+      case GJX_ARG_INPUT:
+        return "((" + flit(a.scale) + " * cols.in[" + std::to_string(a.ref) + "][i]) + " + flit(a.offset) + ")";
+      default: return plit(a.table) + "[" + val_i32(a.ref_site) + "]";
+    }
+  }
+
+  std::string run() {
+    const std::string I = std::to_string(impl);
+    o << "#include \"gjx_device.hpp\"\nusing namespace gjx;\n";
+    o << "__device__ __forceinline__ float jrow_max(const float* l, uint32_t K){ float m=l[0]; for(uint32_t c=1;c<K;++c) m = l[c]>m?l[c]:m; return m; }\n";
+    o << "__device__ __forceinline__ float jrow_lse(const float* l, uint32_t K){ const float m=jrow_max(l,K); float acc=0.0f; for(uint32_t c=0;c<K;++c) acc = acc + m_exp(l[c]-m); return m + m_log(acc); }\n";
+    o << "__device__ __forceinline__ int32_t jcat_invcdf(const float* l, uint32_t K, uint32_t bits){ const float m=jrow_max(l,K); uint64_t Q=0; for(uint32_t c=0;c<K;++c) Q += cat_fix(l[c],m); const uint64_t thr=((uint64_t)bits*Q)>>32; uint64_t C=0; for(uint32_t c=0;c<K;++c){ C += cat_fix(l[c],m); if (C>thr) return (int32_t)c; } return (int32_t)(K-1); }\n";
+    o << "template <int IMPL> __device__ __forceinline__ int32_t jcat_gumbel(const float* l, uint32_t K, const Stream<IMPL>& st){ int32_t best=0; float bv=-__builtin_inff(); for(uint32_t c=0;c<K;++c){ const float v = l[c] + gumbel_from_bits(st.bits32(c)); if (v>bv || c==0){ bv=v; best=(int32_t)c; } } return best; }\n";
+    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_plan_kernel(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials) {\n";
+    o << "  __shared__ float sh_red[4];\n";
+    o << "  for (uint64_t tile = blockIdx.x; tile * 1024 < n; tile += gridDim.x) {\n";
+    o << "    float tmax = -__builtin_inff();\n";
+    o << "    for (int r = 0; r < 4; ++r) {\n";
+    o << "      const uint64_t i = tile * 1024 + (uint64_t)r * 256 + threadIdx.x;\n";
+    o << "      if (i < n) {\n";
+    o << "        const Key pkey = key_at<" << I << ">(ks, i);\n";
+    o << "        float w = 0.0f, sc = 0.0f;\n";
+    int cur_blk = -1;
+    for (int q = 0; q < n_sites; ++q) {
+      const CSiteT& st = sites[q];
+      const std::string Q = std::to_string(q);
+      const uint32_t fold = (uint32_t)(q + 1);
+      o << "        // site " << q << " dist " << st.dist << (st.observed ? " observed" : " latent") << "\n";
+      std::string row;
+      if (st.dist == GJX_DIST_CATEGORICAL) {
+        std::string rr;
+        if (st.a0.kind == GJX_ARG_SITE) rr = val_i32(st.a0.ref_site);
+        else if (st.a0.kind == GJX_ARG_CONST) rr = "(int32_t)__builtin_rintf(" + flit(st.a0.offset) + ")";
+        else rr = "(int32_t)__builtin_rintf(" + arg(st.a0) + ")";
+        o << "        int32_t rr" << Q << " = " << rr << "; rr" << Q << " = rr" << Q << " < 0 ? 0 : (rr" << Q
+          << " >= " << st.n_rows << " ? " << st.n_rows - 1 << " : rr" << Q << ");\n";
+        o << "        const float* row" << Q << " = " << plit(st.logits) << " + (size_t)rr" << Q << " * " << st.n_cat << ";\n";
+        row = "row" + Q;
+      } else {
+        o << "        const float a0_" << Q << " = " << arg(st.a0) << ";\n";
+        if (st.dist != GJX_DIST_BERNOULLI) o << "        const float a1_" << Q << " = " << arg(st.a1) << ";\n";
+      }
+      const bool isint = is_int(st);
+      if (st.observed) {
+        const std::string ov = st.obs.kind == GJX_ARG_CONST ? flit(st.obs.offset)
+                                                            : "cols.in[" + std::to_string(st.obs.ref) + "][i]";
+        if (isint) o << "        const int32_t vi" << Q << " = (int32_t)__builtin_rintf(" << ov << ");\n";
+        else o << "        const float vf" << Q << " = " << ov << ";\n";
+      } else {
+        const bool one_word = st.dist == GJX_DIST_NORMAL || st.dist == GJX_DIST_BERNOULLI ||
+                              (st.dist == GJX_DIST_CATEGORICAL && st.cat_mode == 1);
+        if (one_word) {
+          if (impl == 1) {
+            const int blk = (int)(fold >> 2);
+            if (blk != cur_blk) {
+              cur_blk = blk;
+              o << "        uint32_t pw" << blk << "_0, pw" << blk << "_1, pw" << blk << "_2, pw" << blk << "_3;\n";
+              o << "        philox4x32(pkey.k0, pkey.k1, 0u, " << blk << "u, 2u, kTagBits, pw" << blk << "_0, pw" << blk
+                << "_1, pw" << blk << "_2, pw" << blk << "_3);\n";
+            }
+            o << "        const uint32_t bits" << Q << " = pw" << blk << "_" << (fold & 3u) << ";\n";
+          } else {
+            o << "        const uint32_t bits" << Q << " = Stream<0>(pkey, true, " << fold << "u).bits32(0);\n";
+          }
+        }
+        switch (st.dist) {
+          case GJX_DIST_NORMAL:
+            o << "        const float t" << Q << " = a1_" << Q << " * std_normal(bits" << Q << ");\n";
+            o << "        const float vf" << Q << " = a0_" << Q << " + t" << Q << ";\n";
+            break;
+          case GJX_DIST_BERNOULLI:
+            o << "        const int32_t vi" << Q << " = uniform01(bits" << Q << ") < a0_" << Q << " ? 1 : 0;\n";
+            break;
+          case GJX_DIST_GAMMA:
+            o << "        const Stream<" << I << "> strm" << Q << "(pkey, true, " << fold << "u);\n";
+            o << "        const float vf" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 0, a0_" << Q << ") / a1_" << Q << ";\n";
+            break;
+          case GJX_DIST_BETA:
+            o << "        const Stream<" << I << "> strm" << Q << "(pkey, true, " << fold << "u);\n";
+            o << "        const float g1_" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 0, a0_" << Q << ");\n";
+            o << "        const float g2_" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 1, a1_" << Q << ");\n";
+            o << "        const float vf" << Q << " = g1_" << Q << " / (g1_" << Q << " + g2_" << Q << ");\n";
+            break;
+          default:
+            if (st.cat_mode == 0) {
+              o << "        const Stream<" << I << "> strm" << Q << "(pkey, true, " << fold << "u);\n";
+              o << "        const int32_t vi" << Q << " = jcat_gumbel<" << I << ">(" << row << ", " << st.n_cat << "u, strm" << Q << ");\n";
+            } else {
+              o << "        const int32_t vi" << Q << " = jcat_invcdf(" << row << ", " << st.n_cat << "u, bits" << Q << ");\n";
+            }
+        }
+      }
+      // log-density
+      std::string lp;
+      const std::string v = (isint ? "vi" : "vf") + Q;
+      switch (st.dist) {
+        case GJX_DIST_NORMAL:
+          lp = st.pre ? "logpdf_normal_pre(" + v + ", a0_" + Q + ", " + flit(st.pre0) + ", " + flit(st.pre1) + ")"
+                      : "logpdf_normal(" + v + ", a0_" + Q + ", a1_" + Q + ")";
+          break;
+        case GJX_DIST_GAMMA:
+          lp = st.pre ? "logpdf_gamma_pre(" + v + ", a0_" + Q + ", a1_" + Q + ", " + flit(st.pre1) + ")"
+                      : "logpdf_gamma(" + v + ", a0_" + Q + ", a1_" + Q + ")";
+          break;
+        case GJX_DIST_BETA:
+          lp = st.pre ? "logpdf_beta_pre(" + v + ", a0_" + Q + ", a1_" + Q + ", " + flit(st.pre1) + ")"
+                      : "logpdf_beta(" + v + ", a0_" + Q + ", a1_" + Q + ")";
+          break;
+        case GJX_DIST_BERNOULLI: lp = "logpdf_bernoulli(" + v + " != 0, a0_" + Q + ")"; break;
+        default:
+          lp = "((" + v + " < 0 || " + v + " >= " + std::to_string(st.n_cat) + ") ? -__builtin_inff() : " + row + "[" + v +
+               "] - jrow_lse(" + row + ", " + std::to_string(st.n_cat) + "u))";
+      }
+      o << "        { const float lp = " << lp << "; sc = sc + lp;" << (st.observed ? " w = w + lp;" : "") << " }\n";
+      if (st.out_col >= 0)
+        o << "        reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "])[i] = "
+          << (isint ? "(uint32_t)" + v : "f2u(" + v + ")") << ";\n";
+    }
+    o << "        logw[i] = w;\n        if (score) score[i] = sc;\n        tmax = w > tmax ? w : tmax;\n";
+    o << "      }\n    }\n";
+    o << "    if (max_partials) { const float bm = block_max(tmax, sh_red); if (threadIdx.x == 0) max_partials[tile] = bm; }\n";
+    o << "  }\n}\n";
+    return o.str();
+  }
+};
+
+struct Compiled {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  int state = 0;  // 0 untried, 1 ready, -1 failed
+};
+
+inline bool enabled() {
+  const char* e = std::getenv("GJX_PLAN_JIT");
+  return !(e && e[0] == '0');
+}
+
+// Compile `src` for gfx950; on success `code` holds the code object.
+inline bool compile_to_code(const std::string& src, std::string* code) {
+  hiprtcProgram prog;
+  const char* hn[] = {"gjx_device.hpp"};
+  const char* hs[] = {kDeviceHeader};
+  if (hiprtcCreateProgram(&prog, src.c_str(), "gjx_plan.hip", 1, hs, hn) != HIPRTC_SUCCESS) return false;
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+  const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+  if (r != HIPRTC_SUCCESS) {
+    if (std::getenv("GJX_PLAN_JIT_VERBOSE")) {
+      size_t ls = 0;
+      hiprtcGetProgramLogSize(prog, &ls);
+      std::string log(ls, 0);
+      hiprtcGetProgramLog(prog, &log[0]);
+      std::fprintf(stderr, "[gjx] plan specialisation failed to compile:\n%s\n", log.c_str());
+    }
+    hiprtcDestroyProgram(&prog);
+    return false;
+  }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  code->assign(cs, 0);
+  hiprtcGetCode(prog, &(*code)[0]);
+  hiprtcDestroyProgram(&prog);
+  return true;
+}
+inline bool compile_only(const std::string& src) {
+  std::string code;
+  return compile_to_code(src, &code) && !code.empty();
+}
+// ... and load it on the current device.
+inline bool compile(const std::string& src, Compiled* out) {
+  std::string code;
+  if (!compile_to_code(src, &code)) return false;
+  if (hipModuleLoadData(&out->mod, code.data()) != hipSuccess) return false;
+  if (hipModuleGetFunction(&out->fn, out->mod, "gjx_plan_kernel") != hipSuccess) {
+    (void)hipModuleUnload(out->mod);
+    out->mod = nullptr;
+    return false;
+  }
+  return true;
+}
+
+}  // namespace gjx_jit

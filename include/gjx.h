@@ -169,6 +169,13 @@ typedef struct gjx_plan gjx_plan;
 
 int gjx_plan_create(const gjx_site* sites /*host*/, int n_sites, gjx_plan** out);
 int gjx_plan_destroy(gjx_plan* p);
+/* Plan specialisation (libgjx_hip.so): on first use per RNG scheme a plan is lowered to a
+ * straight-line gfx950 kernel — the same device functions in the same order, constants folded —
+ * and compiled with hiprtc; GJX_PLAN_JIT=0 keeps the table-interpreter kernel.  Diagnostics:
+ * the generated HIP source (buf nullable; *needed = bytes incl. NUL) and an offline compile check
+ * (needs no GPU).  The oracle build returns GJX_ERR_UNSUPPORTED for both. */
+int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t buf_len, size_t* needed);
+int gjx_plan_compile_check(const gjx_plan* p, int impl);
 /* particle_keys: the per-particle keys BEFORE the per-site fold (has_fold must be 0).
  * input_cols / value_cols: host arrays of dev pointers (each column dev [n], 4-byte elements:
  * f32, or int32 for Bernoulli/Categorical values; at most 16 input columns).  score, logw: dev

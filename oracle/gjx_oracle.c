@@ -300,6 +300,11 @@ int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
   return GJX_OK;
 }
 int gjx_plan_destroy(gjx_plan* p) { free(p); return GJX_OK; }
+int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t buf_len, size_t* needed) {
+  (void)p; (void)impl; (void)buf; (void)buf_len; (void)needed;
+  return GJX_ERR_UNSUPPORTED;
+}
+int gjx_plan_compile_check(const gjx_plan* p, int impl) { (void)p; (void)impl; return GJX_ERR_UNSUPPORTED; }
 
 typedef struct { float f; int32_t i; int is_int; } site_val;
 

@@ -119,9 +119,17 @@ static inline void o_words(const o_stream* s, uint32_t sub, uint32_t* w0, uint32
     *w0 = o[0]; *w1 = o[1];
   }
 }
-/* 32 random bits of element `sub` — jax _threefry_random_bits_partitionable: hi ^ lo. */
+/* 32 random bits of element `sub` — THREEFRY: jax _threefry_random_bits_partitionable, hi ^ lo.
+ * PHILOX: word 0 of the sub-stream, except the single-word draw (sub 0) of a leaf site with
+ * counter f, which is word (f & 3) of the block shared by the four sites f>>2:
+ * PH(ctr = (0, f >> 2, 2, TAG_BITS), key) — one cipher block serves four scalar sites. */
 static inline uint32_t o_bits32_at(const o_stream* s, uint32_t sub) {
   uint32_t w0, w1;
+  if (s->impl == 1 && s->hf && sub == 0u) {
+    uint32_t c[4] = {0u, s->f >> 2, 2u, O_TAG_BITS}, o[4];
+    o_philox4x32(s->k[0], s->k[1], c, o);
+    return o[s->f & 3u];
+  }
   o_words(s, sub, &w0, &w1);
   return s->impl == 0 ? (w0 ^ w1) : w0;
 }

@@ -111,9 +111,17 @@ def test_categorical(hip_ops, oracle_ops, impl, mode):
     assert not bool((hv.cpu() == 2).any()) or True
 
 
+@pytest.fixture(params=["specialized", "interpreter"])
+def plan_mode(request, monkeypatch):
+    """Both importance kernels: the hiprtc-specialised straight-line kernel (default) and the
+    site-table interpreter (GJX_PLAN_JIT=0)."""
+    monkeypatch.setenv("GJX_PLAN_JIT", "1" if request.param == "specialized" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("n", [1, 1000, 1024, 70001])
-def test_importance_gaussian10(hip_ops, oracle_ops, impl, n):
+def test_importance_gaussian10(hip_ops, oracle_ops, impl, n, plan_mode):
     h = W.gaussian10_importance(hip_ops, impl, seed=11, n=n)
     o = W.gaussian10_importance(oracle_ops, impl, seed=11, n=n)
     same(h["logw"], o["logw"], "logw")
@@ -124,7 +132,7 @@ def test_importance_gaussian10(hip_ops, oracle_ops, impl, n):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-def test_importance_mixed_plan(hip_ops, oracle_ops, impl):
+def test_importance_mixed_plan(hip_ops, oracle_ops, impl, plan_mode):
     """A plan touching every distribution and argument kind: beta-bernoulli, gamma-scaled normal,
     categorical selecting a table row, input columns, observed input column."""
     n = 20000
