@@ -24,6 +24,7 @@ namespace {
 inline int launch_status() { return hipGetLastError() == hipSuccess ? GJX_OK : GJX_ERR_LAUNCH; }
 inline hipStream_t S(gjx_stream s) { return reinterpret_cast<hipStream_t>(s); }
 inline uint64_t ntiles_of(uint64_t n) { return (n + kTile - 1) / kTile; }
+inline uint64_t nrows_of(uint64_t n) { return (n + kBlock - 1) / kBlock; }  // max-partial granularity
 inline unsigned grid_for(uint64_t n) {
   uint64_t b = ntiles_of(n);
   return (unsigned)(b < 1 ? 1 : (b > 0x7fffffffull ? 0x7fffffffull : b));
@@ -405,18 +406,16 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
         if (st.out_col >= 0 && idx[r] < n) reinterpret_cast<uint32_t*>(cols.out[st.out_col])[idx[r]] = raw;
       }
     }
-    float tmax = -__builtin_inff();
 #pragma unroll
     for (int r = 0; r < kPPT; ++r) {
       if (idx[r] < n) {
         logw[idx[r]] = w[r];
         if (score) score[idx[r]] = sc[r];
-        tmax = w[r] > tmax ? w[r] : tmax;
       }
-    }
-    if (max_partials) {
-      const float bm = block_max(tmax, sh_red);
-      if (tid == 0) max_partials[tile] = bm;
+      if (max_partials && (tile * kTile + (uint64_t)r * kBlock) < n) {  // one partial per 256-particle row
+        const float bm = block_max(idx[r] < n ? w[r] : -__builtin_inff(), sh_red);
+        if (tid == 0) max_partials[tile * kPPT + r] = bm;
+      }
     }
   }
 }
@@ -449,11 +448,27 @@ __global__ __launch_bounds__(kBlock) void k_reduce_max(const float* partials, ui
   m = block_max(m, sh);
   if (threadIdx.x == 0) out[0] = m;
 }
+// m_ptr == nullptr: every block reduces the row maxima itself (L2-resident, 4 B per 256 particles)
+// instead of waiting for a separate one-block reduction kernel; block 0 publishes the max.
 __global__ __launch_bounds__(kBlock) void k_expsum_partials(const float* x, uint64_t n,
-                                                            const float* m_ptr, int frac,
+                                                            const float* m_ptr,
+                                                            const float* max_partials, uint64_t n_mp,
+                                                            float* max_out, int frac,
                                                             uint64_t* partials) {
   __shared__ uint64_t sh[kBlock / kWave];
-  const float m = m_ptr[0];
+  __shared__ float shf[kBlock / kWave];
+  float m;
+  if (m_ptr) {
+    m = m_ptr[0];
+  } else {
+    m = -__builtin_inff();
+    for (uint64_t k = threadIdx.x; k < n_mp; k += kBlock) {
+      const float v = max_partials[k];
+      m = v > m ? v : m;
+    }
+    m = block_max(m, shf);
+    if (max_out && blockIdx.x == 0 && threadIdx.x == 0) max_out[0] = m;
+  }
   for (uint64_t tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
     uint64_t acc = 0;
     for (uint64_t i = tile * kTile + threadIdx.x; i < n && i < (tile + 1) * kTile; i += kBlock)
@@ -960,11 +975,12 @@ const char* gjx_backend_name(void) { return "hip-gfx950"; }
 int gjx_frac_bits(uint64_t n_total) { return frac_bits(n_total); }
 uint64_t gjx_smc_tile(void) { return kTile; }
 uint64_t gjx_num_tiles(uint64_t n) { return ntiles_of(n); }
+uint64_t gjx_num_max_partials(uint64_t n) { return nrows_of(n); }
 
 size_t gjx_workspace_bytes(int op, uint64_t n) {
   const uint64_t nt = ntiles_of(n);
   switch (op) {
-    case GJX_OP_LOGSUMEXP: return pad256(nt * 4) + pad256(nt * 8) + 1024;
+    case GJX_OP_LOGSUMEXP: return pad256(nrows_of(n) * 4) + pad256(nt * 8) + 1024;
     case GJX_OP_CATEGORICAL_INDEX:
     case GJX_OP_RESAMPLE:
       return pad256(nt * 4) + 2 * pad256(nt * 8) + pad256(n * 8) + 1024;
@@ -1239,13 +1255,16 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
       if (c.state == 0) {
         gjx_jit::Gen<CSite, CArg> g;
         g.impl = pk->impl; g.sites = p->host; g.n_sites = p->n_sites;
+        if (const char* e = std::getenv("GJX_JIT_MIN_WAVES")) g.min_waves = atoi(e);
         c.state = gjx_jit::compile(g.run(), &c) ? 1 : -1;
       }
     }
     if (c.state == 1) {
       uint64_t nn = n;
       void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials};
-      if (hipModuleLaunchKernel(c.fn, grid_for(n), 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess)
+      const uint64_t rows = nrows_of(n);
+      if (hipModuleLaunchKernel(c.fn, (unsigned)(rows > 0x7fffffffull ? 0x7fffffffull : rows), 1, 1, kBlock, 1, 1, 0,
+                                S(s), args, nullptr) != hipSuccess)
         return GJX_ERR_LAUNCH;
       return launch_status();
     }
@@ -1277,14 +1296,16 @@ int gjx_max_f32(const float* x, uint64_t n, const float* max_partials_in, float*
   if ((!x && !max_partials_in) || !out_max || n == 0) return GJX_ERR_INVALID;
   const uint64_t nt = ntiles_of(n);
   const float* partials = max_partials_in;
+  uint64_t np = nrows_of(n);  // caller-provided partials are per 256-particle row
   if (!partials) {
     Carver cv{(char*)ws, ws ? ws_bytes : 0};
-    float* mp = cv.take<float>(nt);
+    float* mp = cv.take<float>(nrows_of(n));
     if (!cv.ok) return GJX_ERR_WORKSPACE;
     k_max_partials<<<grid_for(n), kBlock, 0, S(s)>>>(x, n, mp);
     partials = mp;
+    np = nt;
   }
-  k_reduce_max<<<1, kBlock, 0, S(s)>>>(partials, nt, out_max);
+  k_reduce_max<<<1, kBlock, 0, S(s)>>>(partials, np, out_max);
   return launch_status();
 }
 int gjx_expsum_fix(const float* x, uint64_t n, const float* max_dev, int frac_bits_, uint64_t* out_q,
@@ -1292,10 +1313,10 @@ int gjx_expsum_fix(const float* x, uint64_t n, const float* max_dev, int frac_bi
   if (!x || !max_dev || !out_q || n == 0 || frac_bits_ < 1 || frac_bits_ > 40) return GJX_ERR_INVALID;
   const uint64_t nt = ntiles_of(n);
   Carver cv{(char*)ws, ws ? ws_bytes : 0};
-  (void)cv.take<float>(nt);
+  (void)cv.take<float>(nrows_of(n));
   uint64_t* qp = cv.take<uint64_t>(nt);
   if (!cv.ok) return GJX_ERR_WORKSPACE;
-  k_expsum_partials<<<grid_for(n), kBlock, 0, S(s)>>>(x, n, max_dev, frac_bits_, qp);
+  k_expsum_partials<<<grid_for(n), kBlock, 0, S(s)>>>(x, n, max_dev, nullptr, 0, nullptr, frac_bits_, qp);
   k_reduce_sum<<<1, kBlock, 0, S(s)>>>(qp, nt, out_q, 0, max_dev, frac_bits_, nullptr, nullptr);
   return launch_status();
 }
@@ -1310,17 +1331,18 @@ int gjx_logsumexp_f32(const float* x, uint64_t n, const float* max_partials_in, 
   if (!x || n == 0) return GJX_ERR_INVALID;
   const uint64_t nt = ntiles_of(n);
   Carver cv{(char*)ws, ws ? ws_bytes : 0};
-  float* mp = cv.take<float>(nt);
+  float* mp = cv.take<float>(nrows_of(n));
   uint64_t* qp = cv.take<uint64_t>(nt);
   float* m = cv.take<float>(1);
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   const int frac = frac_bits(n);
+  uint64_t np = nrows_of(n);
   if (!max_partials_in) {
     k_max_partials<<<grid_for(n), kBlock, 0, S(s)>>>(x, n, mp);
     max_partials_in = mp;
+    np = nt;
   }
-  k_reduce_max<<<1, kBlock, 0, S(s)>>>(max_partials_in, nt, m);
-  k_expsum_partials<<<grid_for(n), kBlock, 0, S(s)>>>(x, n, m, frac, qp);
+  k_expsum_partials<<<grid_for(n), kBlock, 0, S(s)>>>(x, n, nullptr, max_partials_in, np, m, frac, qp);
   k_reduce_sum<<<1, kBlock, 0, S(s)>>>(qp, nt, out_q, 0, m, frac, out_lse, out_max);
   return launch_status();
 }

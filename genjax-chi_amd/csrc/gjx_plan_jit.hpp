@@ -41,6 +41,7 @@ struct Gen {
   int impl;
   const CSiteT* sites;
   int n_sites;
+  int min_waves = 0;  // __launch_bounds__ waves-per-SIMD hint (0 = none)
 
   static bool is_int(const CSiteT& s) { return s.dist >= GJX_DIST_BERNOULLI; }
 
@@ -69,12 +70,15 @@ struct Gen {
     o << "__device__ __forceinline__ float jrow_lse(const float* l, uint32_t K){ const float m=jrow_max(l,K); float acc=0.0f; for(uint32_t c=0;c<K;++c) acc = acc + m_exp(l[c]-m); return m + m_log(acc); }\n";
     o << "__device__ __forceinline__ int32_t jcat_invcdf(const float* l, uint32_t K, uint32_t bits){ const float m=jrow_max(l,K); uint64_t Q=0; for(uint32_t c=0;c<K;++c) Q += cat_fix(l[c],m); const uint64_t thr=((uint64_t)bits*Q)>>32; uint64_t C=0; for(uint32_t c=0;c<K;++c){ C += cat_fix(l[c],m); if (C>thr) return (int32_t)c; } return (int32_t)(K-1); }\n";
     o << "template <int IMPL> __device__ __forceinline__ int32_t jcat_gumbel(const float* l, uint32_t K, const Stream<IMPL>& st){ int32_t best=0; float bv=-__builtin_inff(); for(uint32_t c=0;c<K;++c){ const float v = l[c] + gumbel_from_bits(st.bits32(c)); if (v>bv || c==0){ bv=v; best=(int32_t)c; } } return best; }\n";
-    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_plan_kernel(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials) {\n";
+    // One workgroup per 256-particle row (grid-stride): short blocks keep every SIMD's wave slots
+    // full even at 1e6 particles (15 rows per lane), where a 4-row block would serialise its rows.
+    o << "extern \"C\" __global__ __launch_bounds__(256" << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
+      << ") void gjx_plan_kernel(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials) {\n";
     o << "  __shared__ float sh_red[4];\n";
-    o << "  for (uint64_t tile = blockIdx.x; tile * 1024 < n; tile += gridDim.x) {\n";
+    o << "  for (uint64_t row = blockIdx.x; row * 256 < n; row += gridDim.x) {\n";
     o << "    float tmax = -__builtin_inff();\n";
-    o << "    for (int r = 0; r < 4; ++r) {\n";
-    o << "      const uint64_t i = tile * 1024 + (uint64_t)r * 256 + threadIdx.x;\n";
+    o << "    {\n";
+    o << "      const uint64_t i = row * 256 + threadIdx.x;\n";
     o << "      if (i < n) {\n";
     o << "        const Key pkey = key_at<" << I << ">(ks, i);\n";
     o << "        float w = 0.0f, sc = 0.0f;\n";
@@ -176,7 +180,7 @@ struct Gen {
     }
     o << "        logw[i] = w;\n        if (score) score[i] = sc;\n        tmax = w > tmax ? w : tmax;\n";
     o << "      }\n    }\n";
-    o << "    if (max_partials) { const float bm = block_max(tmax, sh_red); if (threadIdx.x == 0) max_partials[tile] = bm; }\n";
+    o << "    if (max_partials) { const float bm = block_max(tmax, sh_red); if (threadIdx.x == 0) max_partials[row] = bm; }\n";
     o << "  }\n}\n";
     return o.str();
   }

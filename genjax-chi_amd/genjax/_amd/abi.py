@@ -152,6 +152,7 @@ PROTOTYPES = {
     "gjx_workspace_bytes": (C.c_size_t, [C.c_int, C.c_uint64]),
     "gjx_frac_bits": (C.c_int, [C.c_uint64]),
     "gjx_num_tiles": (C.c_uint64, [C.c_uint64]),
+    "gjx_num_max_partials": (C.c_uint64, [C.c_uint64]),
     "gjx_max_f32": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.c_size_t, _P]),
     "gjx_expsum_fix": (C.c_int, [_P, C.c_uint64, _P, C.c_int, _P, _P, C.c_size_t, _P]),
     "gjx_lse_finish": (C.c_int, [_P, _P, C.c_int, _P, _P]),
@@ -194,6 +195,7 @@ _NO_STATUS = {
     "gjx_frac_bits",
     "gjx_smc_tile",
     "gjx_num_tiles",
+    "gjx_num_max_partials",
 }
 
 

@@ -101,6 +101,9 @@ class Ops:
     def num_tiles(self, n: int) -> int:
         return int(self.lib.call("gjx_num_tiles", n))
 
+    def num_max_partials(self, n: int) -> int:
+        return int(self.lib.call("gjx_num_max_partials", n))
+
     def frac_bits(self, n_total: int) -> int:
         return int(self.lib.call("gjx_frac_bits", n_total))
 
@@ -198,19 +201,26 @@ class Ops:
             outs[i] = t.data_ptr()
         score = self.empty(n, torch.float32) if want_score else None
         logw = self.empty(n, torch.float32)
-        mp = self.empty(self.num_tiles(n), torch.float32) if want_max_partials else None
+        mp = self.empty(self.num_max_partials(n), torch.float32) if want_max_partials else None
         self.lib.call("gjx_importance_run", plan.handle, C.byref(self._keys(kb, n)), ins, len(input_cols), outs,
                       len(vals), C.c_void_p(score.data_ptr()) if want_score else None,
                       C.c_void_p(logw.data_ptr()), n, C.c_void_p(mp.data_ptr()) if mp is not None else None,
                       self.stream())
         return vals, score, logw, mp
 
+    def prepare_importance(self, plan: "Plan", kb: KeyBatch, n: int, input_cols: list[torch.Tensor],
+                           value_dtypes: list, with_lse: bool = True) -> "PreparedImportance":
+        """Pre-bind one importance pass (+ its log-sum-exp) to persistent output buffers: a launch
+        is then two C calls with no allocation or marshalling on the host (what a latency-bound
+        1e6-particle step needs; it is also what a HIP-graph capture of the step would replay)."""
+        return PreparedImportance(self, plan, kb, n, input_cols, value_dtypes, with_lse)
+
     # ---- weights --------------------------------------------------------------------------------
     def max_f32(self, x: torch.Tensor | None, n: int, max_partials=None) -> torch.Tensor:
         out = self.empty(1, torch.float32)
         ws, nb = self.workspace(abi.OP_LOGSUMEXP, n)
         self.lib.call("gjx_max_f32", None if x is None else self._chk(x, torch.float32, n, "x"), n,
-                      None if max_partials is None else self._chk(max_partials, torch.float32, self.num_tiles(n)),
+                      None if max_partials is None else self._chk(max_partials, torch.float32, self.num_max_partials(n)),
                       C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), nb, self.stream())
         return out
 
@@ -235,7 +245,7 @@ class Ops:
         lse, m, q = self.empty(1, torch.float32), self.empty(1, torch.float32), self.empty(1, torch.int64)
         ws, nb = self.workspace(abi.OP_LOGSUMEXP, n)
         self.lib.call("gjx_logsumexp_f32", self._chk(x, torch.float32, n, "x"), n,
-                      None if max_partials is None else self._chk(max_partials, torch.float32, self.num_tiles(n)),
+                      None if max_partials is None else self._chk(max_partials, torch.float32, self.num_max_partials(n)),
                       C.c_void_p(lse.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(q.data_ptr()),
                       C.c_void_p(ws.data_ptr()), nb, self.stream())
         return lse, m, q
@@ -347,3 +357,48 @@ class Plan:
                 self.handle = None
         except Exception:
             pass
+
+
+class PreparedImportance:
+    """A fully marshalled `gjx_importance_run` (+ `gjx_logsumexp_f32`) call on persistent buffers."""
+
+    def __init__(self, ops: Ops, plan: Plan, kb: KeyBatch, n: int, input_cols, value_dtypes, with_lse):
+        if kb.fold is not None:
+            raise ValueError("particle keys must not carry a fold")
+        self.ops, self.plan, self.n = ops, plan, n
+        self.inputs = [t for t in input_cols]
+        self.values = [ops.empty(n, dt) for dt in value_dtypes]
+        self.score, self.logw = ops.empty(n, torch.float32), ops.empty(n, torch.float32)
+        self.max_partials = ops.empty(ops.num_max_partials(n), torch.float32)
+        self.lse, self.max, self.q = ops.empty(1, torch.float32), ops.empty(1, torch.float32), ops.empty(1, torch.int64)
+        self._keys = ops._keys(kb, n)
+        self._ins = (C.c_void_p * max(1, len(self.inputs)))(*[ops._chk(t, torch.float32, n).value for t in self.inputs])
+        self._outs = (C.c_void_p * max(1, len(self.values)))(*[t.data_ptr() for t in self.values])
+        self._ws, self._nb = ops.workspace(abi.OP_LOGSUMEXP, n)
+        self._ws = self._ws.clone()  # private: the shared workspace may be re-grown by other calls
+        lib = ops.lib
+        self._run = lib._gjx_importance_run
+        self._lse = lib._gjx_logsumexp_f32
+        self._args_run = (plan.handle, C.byref(self._keys), self._ins, len(self.inputs), self._outs, len(self.values),
+                          C.c_void_p(self.score.data_ptr()), C.c_void_p(self.logw.data_ptr()), n,
+                          C.c_void_p(self.max_partials.data_ptr()))
+        self._args_lse = (C.c_void_p(self.logw.data_ptr()), n, C.c_void_p(self.max_partials.data_ptr()),
+                          C.c_void_p(self.lse.data_ptr()), C.c_void_p(self.max.data_ptr()), C.c_void_p(self.q.data_ptr()),
+                          C.c_void_p(self._ws.data_ptr()), self._nb)
+        self.with_lse = with_lse
+
+    def launch_importance(self, stream=None):
+        rc = self._run(*self._args_run, stream if stream is not None else self.ops.stream())
+        if rc:
+            raise abi.GjxError("gjx_importance_run", rc)
+
+    def launch_lse(self, stream=None):
+        rc = self._lse(*self._args_lse, stream if stream is not None else self.ops.stream())
+        if rc:
+            raise abi.GjxError("gjx_logsumexp_f32", rc)
+
+    def launch(self, stream=None):
+        st = stream if stream is not None else self.ops.stream()
+        self.launch_importance(st)
+        if self.with_lse:
+            self.launch_lse(st)

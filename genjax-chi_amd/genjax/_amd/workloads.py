@@ -82,6 +82,13 @@ class Gaussian10:
         self.keys = importance_particle_keys(prng.key(seed, impl), n_local, first)
         self.frac = ops.frac_bits(self.n_total)
 
+    def prepare(self):
+        """Persistent-buffer form of `step` (no host allocation per pass)."""
+        if getattr(self, "_prep", None) is None:
+            self._prep = self.ops.prepare_importance(self.plan, self.keys, self.n, [], [torch.float32] * G10_LATENTS,
+                                                     with_lse=(self.n_total == self.n))
+        return self._prep
+
     def step(self):
         """One ImportanceK pass on this rank: trace columns, score, log-weights and the local
         (max, fixed-point sum) pair — all device tensors, no host sync."""

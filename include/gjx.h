@@ -179,8 +179,9 @@ int gjx_plan_compile_check(const gjx_plan* p, int impl);
 /* particle_keys: the per-particle keys BEFORE the per-site fold (has_fold must be 0).
  * input_cols / value_cols: host arrays of dev pointers (each column dev [n], 4-byte elements:
  * f32, or int32 for Bernoulli/Categorical values; at most 16 input columns).  score, logw: dev
- * f32[n] (score nullable).  max_partials: nullable dev f32[gjx_num_tiles(n)]; when given, the
- * kernel also stores the per-tile maxima of logw so the following log-sum-exp skips its max pass. */
+ * f32[n] (score nullable).  max_partials: nullable dev f32[gjx_num_max_partials(n)]; when given, the
+ * kernel also stores the maxima of logw per 256-particle row so the following log-sum-exp skips
+ * its max pass. */
 int gjx_importance_run(const gjx_plan* p, const gjx_keys* particle_keys,
                        const float* const* input_cols, int n_input_cols, void* const* value_cols,
                        int n_value_cols, float* score, float* logw, uint64_t n,
@@ -203,10 +204,11 @@ int gjx_frac_bits(uint64_t n_total);
 /* Tiles: every kernel processes particles in tiles of gjx_smc_tile() (1024); per-tile partial
  * arrays have gjx_num_tiles(n) entries. */
 uint64_t gjx_num_tiles(uint64_t n);
+uint64_t gjx_num_max_partials(uint64_t n); /* entries of the max_partials array of gjx_importance_run */
 
 /* out_max[0] = max_i x[i] (dev f32). Pass 1 of logsumexp; multi-GPU callers all-reduce(max) it.
- * max_partials_in: nullable per-tile maxima already produced by gjx_importance_run (then x may be
- * NULL and only the final reduction runs). */
+ * max_partials_in: nullable row maxima already produced by gjx_importance_run
+ * (gjx_num_max_partials(n) entries; then x may be NULL and only the final reduction runs). */
 int gjx_max_f32(const float* x, uint64_t n, const float* max_partials_in, float* out_max, void* ws,
                 size_t ws_bytes, gjx_stream s);
 /* out_q[0] = sum_i rint(exp(x[i] - max[0]) * 2^frac_bits) as exact u64 (order-independent);

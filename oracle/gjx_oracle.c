@@ -29,6 +29,8 @@ const char* gjx_backend_name(void) { return "oracle-cpu"; }
 int gjx_frac_bits(uint64_t n_total) { return o_frac_bits(n_total); }
 uint64_t gjx_smc_tile(void) { return O_TILE; }
 uint64_t gjx_num_tiles(uint64_t n) { return (n + O_TILE - 1) / O_TILE; }
+#define O_ROW 256u
+uint64_t gjx_num_max_partials(uint64_t n) { return (n + O_ROW - 1) / O_ROW; }
 size_t gjx_workspace_bytes(int op, uint64_t n) { (void)op; (void)n; return 64; }
 
 /* ---- keys ---------------------------------------------------------------------------------- */
@@ -393,9 +395,9 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
     if (score) score[i] = sc;
   }
   if (max_partials) {
-    for (uint64_t b = 0; b * O_TILE < n; ++b) {
+    for (uint64_t b = 0; b * O_ROW < n; ++b) {
       float m = -INFINITY;
-      for (uint64_t i = b * O_TILE; i < n && i < (b + 1) * O_TILE; ++i) m = logw[i] > m ? logw[i] : m;
+      for (uint64_t i = b * O_ROW; i < n && i < (b + 1) * O_ROW; ++i) m = logw[i] > m ? logw[i] : m;
       max_partials[b] = m;
     }
   }
@@ -409,7 +411,7 @@ int gjx_max_f32(const float* x, uint64_t n, const float* max_partials_in, float*
   if ((!x && !max_partials_in) || !out_max || n == 0) return GJX_ERR_INVALID;
   float m = -INFINITY;
   if (max_partials_in) {
-    for (uint64_t b = 0; b < gjx_num_tiles(n); ++b) m = max_partials_in[b] > m ? max_partials_in[b] : m;
+    for (uint64_t b = 0; b < gjx_num_max_partials(n); ++b) m = max_partials_in[b] > m ? max_partials_in[b] : m;
   } else {
 #pragma omp parallel for reduction(max : m) schedule(static)
     for (int64_t i = 0; i < (int64_t)n; ++i) m = x[i] > m ? x[i] : m;
