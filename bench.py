@@ -51,16 +51,21 @@ def parse():
     return p.parse_args()
 
 
+FORCE_DIST = bool(os.environ.get("GJX_BENCH_FORCE_DIST"))  # exercise the N>1 code path with one rank
+
+
 def init_dist(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         import torch.distributed as dist
 
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
     else:
         torch.cuda.set_device(0)
@@ -68,7 +73,7 @@ def init_dist(n_gpus):
 
 
 def barrier_sync(world):
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         import torch.distributed as dist
 
         dist.barrier()
@@ -76,7 +81,7 @@ def barrier_sync(world):
 
 
 def max_over_ranks(seconds, world):
-    if world == 1:
+    if world == 1 and not FORCE_DIST:
         return seconds
     import torch.distributed as dist
 
@@ -109,10 +114,10 @@ def bench_importance(args, ops, rank, world):
         if timed:
             kernel_ms.append((e0, e1))
         logw, mp = prep.logw, prep.max_partials
-        if world == 1:
+        if world == 1 and not FORCE_DIST:
             prep.launch_lse(st)
             m, q = prep.max, prep.q
-        else:
+        else:  # sharded population: exact global log-normaliser = all-reduce(max) + all-reduce(sum of u64)
             m = ops.max_f32(None, n, max_partials=mp)
             dist.all_reduce(m, op=dist.ReduceOp.MAX)
             q = ops.expsum_fix(logw, m, wl.frac)
@@ -161,11 +166,36 @@ def bench_smc(args, ops, rank, world, kind):
 
     impl = 1 if args.rng == "philox" else 0
     n = args.particles
-    if world > 1:
-        from genjax._amd import dist_smc
-
-        return dist_smc.bench(args, ops, rank, world, kind)
     T = 100 if kind == "smc_lgssm" else 500
+    if world > 1 or FORCE_DIST:
+        if kind != "smc_lgssm":
+            raise SystemExit("sharded SMC is implemented for smc_lgssm")
+        from genjax._amd import dist as gdist
+
+        # the sharded filter exchanges whole 1024-particle tiles: round the per-GPU population up
+        n = -(-n // ops.tile) * ops.tile
+        n_total = n * world
+        smc = gdist.ShardedLgssmSMC(ops, impl, 1, n_total, T, rank, world)
+        smc.run()
+        barrier_sync(world)
+        steps = max(1, min(args.steps, 5))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = smc.run()
+        barrier_sync(world)
+        dt = max_over_ranks((time.perf_counter() - t0) / steps, world)
+        per_step_ms = dt * 1e3 / T
+        achieved = BYTES_SMC_PER_PARTICLE_STEP * n / (per_step_ms * 1e-3) / 1e9
+        return {
+            "metric": "particle-steps/sec, bootstrap SMC (1e6 particles per GPU)",
+            "value": n_total * T / dt, "unit": "particle-steps/s", "ms_per_step": dt * 1e3,
+            "config": {"workload": f"bootstrap SMC {kind} T={T} N={n_total} sharded x{world}", "rng": args.rng,
+                       "parallelism": f"particle-sharded x{world}: all-reduce(max) + all-gather per step"},
+            "roofline": {"bound": "hbm", "kernel": "one SMC step incl. exchange", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "step_ms": per_step_ms, "algorithmic_bytes_per_launch": BYTES_SMC_PER_PARTICLE_STEP * n},
+            "log_z": r["log_z"], "log_z_exact": r["log_z_exact"],
+        }
     run = (lambda: W.lgssm_smc(ops, impl, 1, n, T)) if kind == "smc_lgssm" else (lambda: W.hmm_smc(ops, impl, 2, n, T))
     for _ in range(max(1, min(args.warmup, 2))):
         r = run()
@@ -269,7 +299,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         import torch.distributed as dist
 
         dist.barrier()

@@ -337,6 +337,28 @@ class Ops:
                       C.c_void_p(ws.data_ptr()), nb, self.stream())
         return out_max, out_q, state, logw, anc
 
+    # ---- step-level SMC pieces (multi-device driver: dist.py) -----------------------------------
+    def smc_config(self, impl, n_total, first, n_local, step_keys, resample_keys):
+        return self._smc_cfg(impl, n_total, first, n_local, step_keys, resample_keys)
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def smc_lgssm_step_a(self, cfg, model: abi.Lgssm, t: int, y_t: float, prev_state, prev_logw, prev_max,
+                         prev_tile_sums, prev_q_out, state_out, logw_out, max_partials_out, ancestors_out=None):
+        self.lib.call("gjx_smc_lgssm_step_a", C.byref(cfg), C.byref(model), t, float(y_t), self._p(prev_state),
+                      self._p(prev_logw), self._p(prev_max), self._p(prev_tile_sums), self._p(prev_q_out),
+                      self._p(state_out), self._p(logw_out), self._p(max_partials_out), self._p(ancestors_out),
+                      self.stream())
+
+    def smc_step_b(self, cfg, logw_local, max_partials, max_out, tile_sums):
+        self.lib.call("gjx_smc_step_b", C.byref(cfg), self._p(logw_local), self._p(max_partials), self._p(max_out),
+                      self._p(tile_sums), self.stream())
+
+    def smc_finish(self, cfg, tile_sums, q_out):
+        self.lib.call("gjx_smc_finish", C.byref(cfg), self._p(tile_sums), self._p(q_out), self.stream())
+
     def log_z_from_pairs(self, out_max: torch.Tensor, out_q: torch.Tensor, n_total: int) -> float:
         """log Z = sum_t (max_t + log(q_t 2^-frac) - log N), evaluated in float64 on the host from
         the exact per-step (max, fixed-point sum) pairs."""
