@@ -152,7 +152,7 @@ def bench_importance(args, ops, rank, world):
         "config": {"workload": "ImportanceK k_particles=1e6/GPU on a 10-latent Gaussian model (BASELINE configs[1])",
                    "particles_per_gpu": n, "latent_sites": 10, "observed_sites": 10, "rng": args.rng,
                    "parallelism": f"particle-sharded x{world}"},
-        "roofline": {"bound": "hbm", "kernel": "k_importance", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": f"gjx_plan_kernel_{args.rng}", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": BYTES_IMPORTANCE_KERNEL_PER_PARTICLE * n},
         "log_z": log_z,

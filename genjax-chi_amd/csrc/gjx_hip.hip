@@ -1256,7 +1256,7 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
         gjx_jit::Gen<CSite, CArg> g;
         g.impl = pk->impl; g.sites = p->host; g.n_sites = p->n_sites;
         if (const char* e = std::getenv("GJX_JIT_MIN_WAVES")) g.min_waves = atoi(e);
-        c.state = gjx_jit::compile(g.run(), &c) ? 1 : -1;
+        c.state = gjx_jit::compile(g.run(), pk->impl, &c) ? 1 : -1;
       }
     }
     if (c.state == 1) {

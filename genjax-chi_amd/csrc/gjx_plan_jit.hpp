@@ -73,7 +73,7 @@ struct Gen {
     // One workgroup per 256-particle row (grid-stride): short blocks keep every SIMD's wave slots
     // full even at 1e6 particles (15 rows per lane), where a 4-row block would serialise its rows.
     o << "extern \"C\" __global__ __launch_bounds__(256" << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
-      << ") void gjx_plan_kernel(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials) {\n";
+      << ") void gjx_plan_kernel_" << (impl == 0 ? "threefry" : "philox") << "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials) {\n";
     o << "  __shared__ float sh_red[4];\n";
     o << "  for (uint64_t row = blockIdx.x; row * 256 < n; row += gridDim.x) {\n";
     o << "    float tmax = -__builtin_inff();\n";
@@ -228,11 +228,12 @@ inline bool compile_only(const std::string& src) {
   return compile_to_code(src, &code) && !code.empty();
 }
 // ... and load it on the current device.
-inline bool compile(const std::string& src, Compiled* out) {
+inline bool compile(const std::string& src, int impl, Compiled* out) {
   std::string code;
   if (!compile_to_code(src, &code)) return false;
   if (hipModuleLoadData(&out->mod, code.data()) != hipSuccess) return false;
-  if (hipModuleGetFunction(&out->fn, out->mod, "gjx_plan_kernel") != hipSuccess) {
+  if (hipModuleGetFunction(&out->fn, out->mod, impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox") !=
+      hipSuccess) {
     (void)hipModuleUnload(out->mod);
     out->mod = nullptr;
     return false;
