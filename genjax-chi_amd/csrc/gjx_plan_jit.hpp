@@ -16,6 +16,8 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <unordered_map>
+#include <utility>
 
 namespace gjx_jit {
 
@@ -227,17 +229,30 @@ inline bool compile_only(const std::string& src) {
   std::string code;
   return compile_to_code(src, &code) && !code.empty();
 }
-// ... and load it on the current device.
+// ... and load it on the current device.  Identical sources (same model, same constants) share
+// one module process-wide, so re-creating a plan does not recompile.
 inline bool compile(const std::string& src, int impl, Compiled* out) {
+  static std::mutex mu;
+  static std::unordered_map<std::string, std::pair<hipModule_t, hipFunction_t>> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(src);
+  if (it != cache.end()) {
+    out->mod = nullptr;  // owned by the cache
+    out->fn = it->second.second;
+    return true;
+  }
   std::string code;
   if (!compile_to_code(src, &code)) return false;
-  if (hipModuleLoadData(&out->mod, code.data()) != hipSuccess) return false;
-  if (hipModuleGetFunction(&out->fn, out->mod, impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox") !=
-      hipSuccess) {
-    (void)hipModuleUnload(out->mod);
-    out->mod = nullptr;
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return false;
+  if (hipModuleGetFunction(&fn, mod, impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox") != hipSuccess) {
+    (void)hipModuleUnload(mod);
     return false;
   }
+  cache.emplace(src, std::make_pair(mod, fn));
+  out->mod = nullptr;
+  out->fn = fn;
   return true;
 }
 

@@ -50,6 +50,51 @@ def importance_log_z(ops: Ops, wl: "W.Gaussian10", prep=None):
     return log_z, prep.logw, m, q
 
 
+class BatchedImportance:
+    """Sharded ImportanceK passes with *bucketed* collectives: B independent passes are issued back to
+    back, their B local maxima are all-reduced as ONE message, then the B fixed-point sums as one more.
+    A small-message RCCL all-reduce costs tens of microseconds of latency (and as much host time to
+    enqueue), more than the 29 us kernel; bucketing B passes amortises it B-fold — the xGMI analogue
+    of gradient bucketing.  Each pass keeps its own output buffers (B x 48 MB at 1e6 particles)."""
+
+    def __init__(self, ops: Ops, make_workload, batch: int = 8):
+        self.ops, self.batch = ops, batch
+        dev = ops.device()
+        self.m_all = torch.empty(batch, dtype=torch.float32, device=dev)
+        self.q_all = torch.empty(batch, dtype=torch.int64, device=dev)
+        self.preps = []
+        self.wl = None
+        for _ in range(batch):
+            wl = make_workload()
+            self.wl = self.wl or wl
+            self.preps.append((wl, ops.prepare_importance(wl.plan, wl.keys, wl.n, [], [torch.float32] * W.G10_LATENTS,
+                                                          with_lse=False)))
+        self.m_views = [self.m_all[b:b + 1] for b in range(batch)]
+        self.q_views = [self.q_all[b:b + 1] for b in range(batch)]
+
+    def run(self, count: int | None = None, on_kernel=None):
+        """`count` (<= batch) passes; afterwards m_all[:count], q_all[:count] hold the global pairs."""
+        dist, ops = _dist(), self.ops
+        count = self.batch if count is None else count
+        for b in range(count):
+            wl, prep = self.preps[b]
+            if on_kernel:
+                on_kernel(b, 0)
+            prep.launch_importance()
+            if on_kernel:
+                on_kernel(b, 1)
+            ops.max_f32(None, wl.n, max_partials=prep.max_partials, out=self.m_views[b])
+        dist.all_reduce(self.m_all[:count], op=dist.ReduceOp.MAX)
+        for b in range(count):
+            wl, prep = self.preps[b]
+            ops.expsum_fix(prep.logw, self.m_views[b], wl.frac, out=self.q_views[b])
+        dist.all_reduce(self.q_all[:count], op=dist.ReduceOp.SUM)
+
+    def log_z(self, b: int = 0) -> float:
+        return (float(self.m_all[b].cpu()) + math.log(int(self.q_all[b].cpu())) - self.wl.frac * math.log(2.0)
+                - math.log(self.wl.n_total))
+
+
 class ShardedLgssmSMC:
     """Bootstrap SMC on the linear-Gaussian model with the population sharded over ranks."""
 

@@ -216,17 +216,17 @@ class Ops:
         return PreparedImportance(self, plan, kb, n, input_cols, value_dtypes, with_lse)
 
     # ---- weights --------------------------------------------------------------------------------
-    def max_f32(self, x: torch.Tensor | None, n: int, max_partials=None) -> torch.Tensor:
-        out = self.empty(1, torch.float32)
+    def max_f32(self, x: torch.Tensor | None, n: int, max_partials=None, out=None) -> torch.Tensor:
+        out = self.empty(1, torch.float32) if out is None else out
         ws, nb = self.workspace(abi.OP_LOGSUMEXP, n)
         self.lib.call("gjx_max_f32", None if x is None else self._chk(x, torch.float32, n, "x"), n,
                       None if max_partials is None else self._chk(max_partials, torch.float32, self.num_max_partials(n)),
                       C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), nb, self.stream())
         return out
 
-    def expsum_fix(self, x: torch.Tensor, max_dev: torch.Tensor, frac: int) -> torch.Tensor:
+    def expsum_fix(self, x: torch.Tensor, max_dev: torch.Tensor, frac: int, out=None) -> torch.Tensor:
         n = x.numel()
-        out = self.empty(1, torch.int64)
+        out = self.empty(1, torch.int64) if out is None else out
         ws, nb = self.workspace(abi.OP_LOGSUMEXP, n)
         self.lib.call("gjx_expsum_fix", self._chk(x, torch.float32, n, "x"), n,
                       self._chk(max_dev, torch.float32, 1, "max"), frac, C.c_void_p(out.data_ptr()),

@@ -37,6 +37,12 @@ def _worker(rank, world, port, impl, n_total, T, out_dir):
     n_local = n_total // world
     wl = W.Gaussian10(ops, impl, seed=3, n_local=n_local, first=rank * n_local, n_total=n_total)
     log_z, logw, m, q = gdist.importance_log_z(ops, wl)
+    pipe = gdist.BatchedImportance(
+        ops, lambda: W.Gaussian10(ops, impl, seed=3, n_local=n_local, first=rank * n_local, n_total=n_total), batch=3)
+    pipe.run()
+    pipe.run(2)
+    assert all(torch.equal(pipe.m_all[b:b + 1], m) and torch.equal(pipe.q_all[b:b + 1], q) for b in range(3))
+    assert pipe.log_z(1) == log_z
     smc = gdist.ShardedLgssmSMC(ops, impl, seed=5, n_total=n_total, T=T, rank=rank, world=world,
                                 record_ancestors=True).run()
     torch.save(dict(log_z=log_z, logw=logw.clone(), m=m, q=q, smc_max=smc["out_max"], smc_q=smc["out_q"],
