@@ -165,6 +165,21 @@ struct RunCols {
   void* out[64];
 };
 
+// The 32-bit draw of SMC slot j at one step (one latent site per step).  THREEFRY keeps the jax
+// shape: particle key split(step_key)[j], site key fold_in(., 1), bits of block 0 (3 blocks).
+// PHILOX is counter-native: word 0 of PH(ctr = (j_lo, j_hi, 0, "SMCS"), step_key) — one block.
+constexpr uint32_t kTagSmc = 0x534D4353u;  // "SMCS"
+template <int IMPL>
+GJX_HD uint32_t smc_slot_bits(Key step_key, uint64_t j) {
+  if (IMPL == 0) {
+    const Stream<0> st(split_at<0>(step_key, j), true, 1u);
+    return st.bits32(0);
+  }
+  uint32_t o0, o1, o2, o3;
+  philox4x32(step_key.k0, step_key.k1, (uint32_t)j, (uint32_t)(j >> 32), 0u, kTagSmc, o0, o1, o2, o3);
+  return o0;
+}
+
 // Host-visible description of a key batch (mirrors gjx_keys).
 struct KeySrc {
   const uint32_t* keys;  // mode 0

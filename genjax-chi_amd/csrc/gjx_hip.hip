@@ -14,6 +14,7 @@
 #include <math.h>
 #include <new>
 #include <string.h>
+#include <type_traits>
 
 #include "gjx_plan_jit.hpp"
 
@@ -523,13 +524,15 @@ struct ResampleArgs {
   uint64_t* q_total_out;      // nullable: block 0 stores the total mass (= sum of tile_sums)
 };
 
+// A policy turns (output slot j, its ancestor) into the new particle.  `compute` is pure so the
+// kernel can run four slots' cipher / transform chains interleaved; `store` writes the results.
 struct AncestorOnly {
   int32_t* anc;  // [out_hi - out_lo]
-  GJX_DEV void load_source(uint64_t, uint64_t, int) const {}
-  GJX_DEV float emit(int64_t j, int64_t out_lo, uint64_t src, int) const {
-    anc[j - out_lo] = (int32_t)src;
-    return 0.0f;
-  }
+  struct Out {};
+  GJX_DEV void fetch_source(uint64_t, uint64_t, int) const {}
+  GJX_DEV void stage_source(int) const {}
+  GJX_DEV float compute(int64_t, int, Out&) const { return 0.0f; }
+  GJX_DEV void store(int64_t j, int64_t out_lo, uint64_t src, const Out&) const { anc[j - out_lo] = (int32_t)src; }
 };
 
 template <int IMPL, class Policy>
@@ -540,6 +543,21 @@ __global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P,
   __shared__ int32_t nb[kTile];  // teeth below the inclusive CDF of each source in the tile
   const uint64_t b = blockIdx.x;
   const int tid = threadIdx.x;
+  const uint64_t base = b * kTile;
+
+  // Issue this tile's loads first: their HBM latency overlaps the tile-mass prefix reduction.
+  float lw4[4];
+  if (A.lw_vec && base + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
+    const float4 v = reinterpret_cast<const float4*>(A.lw + base)[tid];
+    lw4[0] = v.x; lw4[1] = v.y; lw4[2] = v.z; lw4[3] = v.w;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint64_t i = base + 4 * (uint64_t)tid + r;
+      lw4[r] = i < A.n ? A.lw[i] : -__builtin_inff();
+    }
+  }
+  P.fetch_source(base, A.n, tid);  // registers now, LDS after the scan
 
   // prefix / total of tile masses (u64, exact)
   uint64_t pre = 0, tot = 0;
@@ -556,23 +574,11 @@ __global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P,
   const double u0 = u0_from_bits(rs.bits64(0));
   const double scale = (double)A.n_out / (double)tot;
   const float m = A.m_ptr[0];
-  const uint64_t base = b * kTile;
 
   // tile CDF: each thread owns 4 CONSECUTIVE sources (base + 4*tid + r) so the scan is a
   // thread-local prefix plus one block scan.
   uint64_t q[4];
   uint64_t local = 0;
-  float lw4[4];
-  if (A.lw_vec && base + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
-    const float4 v = reinterpret_cast<const float4*>(A.lw + base)[tid];
-    lw4[0] = v.x; lw4[1] = v.y; lw4[2] = v.z; lw4[3] = v.w;
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint64_t i = base + 4 * (uint64_t)tid + r;
-      lw4[r] = i < A.n ? A.lw[i] : -__builtin_inff();
-    }
-  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint64_t i = base + 4 * (uint64_t)tid + r;
@@ -591,24 +597,60 @@ __global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P,
                                      : teeth_below(run, scale, u0, (int64_t)A.n_out);
     nb[4 * tid + r] = (int32_t)t;
   }
-  P.load_source(base, A.n, tid);
+  P.stage_source(tid);
   __syncthreads();
   const int64_t n_hi = nb[kTile - 1];
   const int64_t j0 = n_lo > A.out_lo ? n_lo : A.out_lo;
   const int64_t j1 = n_hi < A.out_hi ? n_hi : A.out_hi;
 
+  // Output slots in groups of up to 4 rows (256 slots each) per pass: NU independent ancestor
+  // searches and NU independent propagate chains are in flight per lane (ILP); the group size is
+  // wave-uniform, so rows past the block's range cost nothing.  Stores close the group.
   float tmax = -__builtin_inff();
-  for (int64_t j = j0 + tid; j < j1; j += kBlock) {
-    // first source s in the tile with nb[s] > j
-    int lo = 0, hi = kTile - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((int64_t)nb[mid] > j) hi = mid;
-      else lo = mid + 1;
+  auto group = [&](auto nu_tag, int64_t jb) {
+    constexpr int NU = decltype(nu_tag)::value;
+    int64_t jj[NU];
+    bool ok[NU];
+    int lo[NU], hi[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int64_t j = jb + tid + (int64_t)u * kBlock;
+      ok[u] = j < j1;
+      jj[u] = ok[u] ? j : j1 - 1;  // surplus lanes of the last row redo its last slot, stores masked
+      lo[u] = 0;
+      hi[u] = kTile - 1;
     }
-    const float w = P.emit(j, A.out_lo, base + (uint64_t)lo, lo);
-    tmax = w > tmax ? w : tmax;
+    // first source s in the tile with nb[s] > j: exactly log2(kTile) halvings, branch-free
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int mid = (lo[u] + hi[u]) >> 1;
+        const bool gt = (int64_t)nb[mid] > jj[u];
+        hi[u] = gt ? mid : hi[u];
+        lo[u] = gt ? lo[u] : mid + 1;
+      }
+    }
+    typename Policy::Out out[NU];
+    float w[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) w[u] = P.compute(jj[u], lo[u], out[u]);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (ok[u]) {
+        P.store(jj[u], A.out_lo, base + (uint64_t)lo[u], out[u]);
+        tmax = w[u] > tmax ? w[u] : tmax;
+      }
+    }
+  };
+  for (int64_t jb = j0; jb < j1; jb += 4 * (int64_t)kBlock) {
+    const int64_t rows = (j1 - jb + kBlock - 1) / kBlock;  // wave-uniform
+    if (rows >= 4) group(std::integral_constant<int, 4>{}, jb);
+    else if (rows == 3) group(std::integral_constant<int, 3>{}, jb);
+    else if (rows == 2) group(std::integral_constant<int, 2>{}, jb);
+    else group(std::integral_constant<int, 1>{}, jb);
   }
+  static_assert(kTile == 1024, "the ancestor search assumes 10 halvings");
   if (max_partials) {
     const float bm = block_max(tmax, shf);
     if (tid == 0) max_partials[b] = bm;
@@ -623,6 +665,13 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums(const float* lw, uint64_t 
                                                       float* max_out) {
   __shared__ uint64_t sh64[kBlock / kWave];
   __shared__ float shf[kBlock / kWave];
+  const uint64_t tile = blockIdx.x;
+  float lwv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // issued before the max reduction so the latencies overlap
+    const uint64_t i = tile * kTile + (uint64_t)r * kBlock + threadIdx.x;
+    lwv[r] = i < n_local ? lw[i] : -__builtin_inff();
+  }
   float m = -__builtin_inff();
   for (uint64_t k = threadIdx.x; k < n_mp; k += kBlock) {
     const float v = max_partials[k];
@@ -630,12 +679,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums(const float* lw, uint64_t 
   }
   m = block_max(m, shf);
   if (max_out && blockIdx.x == 0 && threadIdx.x == 0) max_out[0] = m;
-  const uint64_t tile = blockIdx.x;
   uint64_t acc = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint64_t i = tile * kTile + (uint64_t)r * kBlock + threadIdx.x;
-    if (i < n_local) acc += fixw(lw[i], m, frac);
+    if (i < n_local) acc += fixw(lwv[r], m, frac);
   }
   acc = block_sum(acc, sh64);
   if (threadIdx.x == 0) tile_sums_at[tile] = acc;
@@ -781,28 +829,36 @@ struct LgssmPolicy {
   int32_t* anc_out;         // nullable [n_local]
   Key step_key;
   float a, q, y, rs, lognorm;
-  float* xs;                // LDS tile of previous states (set in load_source)
-  GJX_DEV void load_source(uint64_t base, uint64_t n, int tid) {
-    __shared__ float xs_tile[kTile];
-    xs = xs_tile;
+  float* xs;                // LDS tile of previous states (set in stage_source)
+  float xr[4];              // the tile row values while in flight
+  GJX_DEV void fetch_source(uint64_t base, uint64_t n, int tid) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const uint64_t i = base + (uint64_t)r * kBlock + tid;
-      xs_tile[r * kBlock + tid] = i < n ? prev_state[i] : 0.0f;
+      xr[r] = i < n ? prev_state[i] : 0.0f;
     }
   }
-  GJX_DEV float emit(int64_t j, int64_t out_lo, uint64_t src, int src_local) const {
-    const Key pk = split_at<IMPL>(step_key, (uint64_t)j);
-    const Stream<IMPL> st(pk, true, 1u);
-    const float eps = std_normal(st.bits32(0));
+  GJX_DEV void stage_source(int tid) {
+    __shared__ float xs_tile[kTile];
+    xs = xs_tile;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xs_tile[r * kBlock + tid] = xr[r];
+  }
+  struct Out {
+    float x, lw;
+  };
+  GJX_DEV float compute(int64_t j, int src_local, Out& o) const {
+    const float eps = std_normal(smc_slot_bits<IMPL>(step_key, (uint64_t)j));
     const float mean = a * xs[src_local];
     const float t = q * eps;
-    const float x = mean + t;
-    const float lw = logpdf_normal_pre(y, x, rs, lognorm);
-    state_out[j - out_lo] = x;
-    logw_out[j - out_lo] = lw;
+    o.x = mean + t;
+    o.lw = logpdf_normal_pre(y, o.x, rs, lognorm);
+    return o.lw;
+  }
+  GJX_DEV void store(int64_t j, int64_t out_lo, uint64_t src, const Out& o) const {
+    state_out[j - out_lo] = o.x;
+    logw_out[j - out_lo] = o.lw;
     if (anc_out) anc_out[j - out_lo] = (int32_t)src;
-    return lw;
   }
 };
 
@@ -818,22 +874,31 @@ struct HmmPolicy {
   int32_t K, y;
   int32_t* zs;
   float* ocol;
-  GJX_DEV void load_source(uint64_t base, uint64_t n, int tid) {
+  int32_t zr[4];
+  float oc;
+  GJX_DEV void fetch_source(uint64_t base, uint64_t n, int tid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint64_t i = base + (uint64_t)r * kBlock + tid;
+      zr[r] = i < n ? prev_state[i] : 0;
+    }
+    oc = tid < K ? obs_logp[(size_t)tid * K + y] : 0.0f;
+  }
+  GJX_DEV void stage_source(int tid) {
     __shared__ int32_t zs_tile[kTile];
     __shared__ float ocol_tile[256];
     zs = zs_tile;
     ocol = ocol_tile;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint64_t i = base + (uint64_t)r * kBlock + tid;
-      zs_tile[r * kBlock + tid] = i < n ? prev_state[i] : 0;
-    }
-    if (tid < K) ocol_tile[tid] = obs_logp[(size_t)tid * K + y];
+    for (int r = 0; r < 4; ++r) zs_tile[r * kBlock + tid] = zr[r];
+    if (tid < K) ocol_tile[tid] = oc;
   }
-  GJX_DEV float emit(int64_t j, int64_t out_lo, uint64_t src, int src_local) const {
-    const Key pk = split_at<IMPL>(step_key, (uint64_t)j);
-    const Stream<IMPL> st(pk, true, 1u);
-    const uint32_t bits = st.bits32(0);
+  struct Out {
+    int32_t z;
+    float lw;
+  };
+  GJX_DEV float compute(int64_t j, int src_local, Out& o) const {
+    const uint32_t bits = smc_slot_bits<IMPL>(step_key, (uint64_t)j);
     const uint32_t* cdf = trans_cdf + (size_t)zs[src_local] * K;
     const uint64_t thr = ((uint64_t)bits * (uint64_t)cdf[K - 1]) >> 32;
     uint32_t lo = 0, hi = (uint32_t)K - 1;
@@ -842,11 +907,14 @@ struct HmmPolicy {
       if ((uint64_t)cdf[mid] > thr) hi = mid;
       else lo = mid + 1;
     }
-    const float lw = ocol[lo];
-    state_out[j - out_lo] = (int32_t)lo;
-    logw_out[j - out_lo] = lw;
+    o.z = (int32_t)lo;
+    o.lw = ocol[lo];
+    return o.lw;
+  }
+  GJX_DEV void store(int64_t j, int64_t out_lo, uint64_t src, const Out& o) const {
+    state_out[j - out_lo] = o.z;
+    logw_out[j - out_lo] = o.lw;
     if (anc_out) anc_out[j - out_lo] = (int32_t)src;
-    return lw;
   }
 };
 
@@ -867,9 +935,7 @@ __global__ __launch_bounds__(kBlock) void k_lgssm_init(Key step_key, uint64_t fi
     for (int r = 0; r < 4; ++r) {
       const uint64_t j = gbase + (uint64_t)r * kBlock + threadIdx.x;
       if (j < first_slot + n_local) {
-        const Key pk = split_at<IMPL>(step_key, j);
-        const Stream<IMPL> st(pk, true, 1u);
-        const float eps = std_normal(st.bits32(0));
+        const float eps = std_normal(smc_slot_bits<IMPL>(step_key, j));
         const float t = x0_scale * eps;
         const float x = x0_loc + t;
         const float lw = logpdf_normal_pre(y, x, rs, lognorm);
@@ -900,9 +966,7 @@ __global__ __launch_bounds__(kBlock) void k_hmm_init(Key step_key, uint64_t firs
     for (int r = 0; r < 4; ++r) {
       const uint64_t j = gbase + (uint64_t)r * kBlock + threadIdx.x;
       if (j < first_slot + n_local) {
-        const Key pk = split_at<IMPL>(step_key, j);
-        const Stream<IMPL> st(pk, true, 1u);
-        const uint32_t bits = st.bits32(0);
+        const uint32_t bits = smc_slot_bits<IMPL>(step_key, j);
         const uint64_t thr = ((uint64_t)bits * (uint64_t)cdf[K - 1]) >> 32;
         uint32_t lo = 0, hi = (uint32_t)K - 1;
         while (lo < hi) {
@@ -1521,10 +1585,10 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
   ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out);
   if (cfg->impl == 0) {
-    LgssmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr};
+    LgssmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {0, 0, 0, 0}};
     k_resample<0, LgssmPolicy<0>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   } else {
-    LgssmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr};
+    LgssmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {0, 0, 0, 0}};
     k_resample<1, LgssmPolicy<1>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   }
   return launch_status();
@@ -1550,10 +1614,10 @@ int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
   ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out);
   if (cfg->impl == 0) {
-    HmmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr};
+    HmmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {0, 0, 0, 0}, 0.0f};
     k_resample<0, HmmPolicy<0>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   } else {
-    HmmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr};
+    HmmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {0, 0, 0, 0}, 0.0f};
     k_resample<1, HmmPolicy<1>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   }
   return launch_status();

@@ -665,10 +665,7 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
   float mx = -INFINITY;
 #pragma omp parallel for reduction(max : mx) schedule(static)
   for (int64_t j = 0; j < (int64_t)nl; ++j) {
-    uint32_t pk[2];
-    o_split_at(cfg->impl, skey, cfg->first_slot + (uint64_t)j, pk);
-    o_stream st = o_stream_make(cfg->impl, pk, 1, 1u);
-    float eps = o_std_normal(o_bits32_at(&st, 0));
+    float eps = o_std_normal(o_smc_slot_bits(cfg->impl, skey, cfg->first_slot + (uint64_t)j));
     float x;
     if (t == 0) {
       float tt = mdl->x0_scale * eps;
@@ -733,10 +730,7 @@ int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int
   float mx = -INFINITY;
 #pragma omp parallel for reduction(max : mx) schedule(static)
   for (int64_t j = 0; j < (int64_t)nl; ++j) {
-    uint32_t pk[2];
-    o_split_at(cfg->impl, skey, cfg->first_slot + (uint64_t)j, pk);
-    o_stream st = o_stream_make(cfg->impl, pk, 1, 1u);
-    uint32_t bits = o_bits32_at(&st, 0);
+    uint32_t bits = o_smc_slot_bits(cfg->impl, skey, cfg->first_slot + (uint64_t)j);
     int32_t zp = t == 0 ? mdl->init_state : prev_state[anc[j]];
     const uint32_t* cdf = trans_cdf + (size_t)zp * K;
     uint64_t thr = ((uint64_t)bits * (uint64_t)cdf[K - 1]) >> 32;

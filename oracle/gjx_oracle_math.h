@@ -139,6 +139,22 @@ static inline uint64_t o_bits64_at(const o_stream* s, uint32_t sub) {
   return ((uint64_t)w0 << 32) | w1;
 }
 
+/* The 32-bit draw of SMC slot j at one step.  THREEFRY: particle key
+ * split(step_key)[j], site key fold_in(., 1), bits of block 0.  PHILOX: word 0 of
+ * PH(ctr = (j_lo, j_hi, 0, "SMCS"), step_key). */
+#define O_TAG_SMC 0x534D4353u
+static inline uint32_t o_smc_slot_bits(int impl, const uint32_t step_key[2], uint64_t j) {
+  if (impl == 0) {
+    uint32_t pk[2];
+    o_split_at(0, step_key, j, pk);
+    o_stream st = o_stream_make(0, pk, 1, 1u);
+    return o_bits32_at(&st, 0);
+  }
+  uint32_t c[4] = {(uint32_t)j, (uint32_t)(j >> 32), 0u, O_TAG_SMC}, o[4];
+  o_philox4x32(step_key[0], step_key[1], c, o);
+  return o[0];
+}
+
 /* ---------------- f32 math spec: only IEEE-exact primitives -------------- *
  * (+, -, *, fmaf, /, sqrtf, rintf, integer ops).  Coefficients: Cephes logf/expf
  * (Moshier), Giles' single-precision erfinv (the polynomial XLA's ErfInv32 uses). */
