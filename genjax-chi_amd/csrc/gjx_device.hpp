@@ -380,6 +380,25 @@ GJX_HD uint64_t fixw(float lw, float m, int frac) {
   const float t = s * u2f((uint32_t)(127 + frac) << 23);
   return (uint64_t)__builtin_rintf(t);
 }
+// --- row-anchored fixed point: a 256-particle row is anchored at the power of two
+// 2^e just above its own maximum, so the producing kernel can emit (e, sum) without knowing the
+// global maximum; rows combine by exact right shifts.
+constexpr int kRowFrac = 30;
+constexpr int32_t kRowEmpty = -(1 << 30);
+GJX_HD int32_t row_anchor(float m) {
+  if (!(m > -__builtin_inff())) return kRowEmpty;  // -inf or NaN: the row carries no mass
+  float t = m * 1.44269504088896341f;
+  t = t > 16777216.0f ? 16777216.0f : (t < -16777216.0f ? -16777216.0f : t);
+  return (int32_t)__builtin_ceilf(t);
+}
+GJX_HD uint64_t rowfix(float lw, int32_t e) {
+  if (e == kRowEmpty || !(lw > -__builtin_inff())) return 0;
+  const float fe = (float)e;
+  float d = __builtin_fmaf(-fe, 0.693359375f, lw);
+  d = __builtin_fmaf(-fe, -2.12194440e-4f, d);
+  return (uint64_t)__builtin_rintf(m_exp(d) * 1073741824.0f);
+}
+
 GJX_HD uint32_t cat_fix(float l, float m) {
   if (l == m) return 1u << kCatFrac;
   const float d = l - m;

@@ -257,9 +257,11 @@ template <int IMPL, int MASK>
 __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__ sites,
                                                        int n_sites, KeySrc ks, RunCols cols,
                                                        float* score, float* logw, uint64_t n,
-                                                       float* max_partials) {
+                                                       float* max_partials, int32_t* row_e,
+                                                       uint64_t* row_s) {
   extern __shared__ uint32_t vals[];  // [n_slots][kPPT][kBlock]
   __shared__ float sh_red[kBlock / kWave];
+  __shared__ uint64_t sh_sum[kBlock / kWave];
   const int tid = threadIdx.x;
 
   for (uint64_t tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
@@ -413,9 +415,17 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
         logw[idx[r]] = w[r];
         if (score) score[idx[r]] = sc[r];
       }
-      if (max_partials && (tile * kTile + (uint64_t)r * kBlock) < n) {  // one partial per 256-particle row
+      if ((max_partials || row_e) && (tile * kTile + (uint64_t)r * kBlock) < n) {  // per 256-particle row
         const float bm = block_max(idx[r] < n ? w[r] : -__builtin_inff(), sh_red);
-        if (tid == 0) max_partials[tile * kPPT + r] = bm;
+        if (max_partials && tid == 0) max_partials[tile * kPPT + r] = bm;
+        if (row_e) {  // row-anchored partial sum: no global maximum needed
+          const int32_t eb = row_anchor(bm);
+          const uint64_t sb = block_sum(idx[r] < n ? rowfix(w[r], eb) : 0, sh_sum);
+          if (tid == 0) {
+            row_e[tile * kPPT + r] = eb;
+            row_s[tile * kPPT + r] = sb;
+          }
+        }
       }
     }
   }
@@ -494,6 +504,87 @@ __global__ __launch_bounds__(kBlock) void k_reduce_sum(const uint64_t* partials,
       out_lse[0] = m_ptr[0] + m_log(qf);
     }
     if (out_max) out_max[0] = m_ptr[0];
+  }
+}
+// Row-anchored partial sums of arbitrary log-weights: one pass, one workgroup per 256-particle row.
+__global__ __launch_bounds__(kBlock) void k_row_stats(const float* x, uint64_t n, int32_t* row_e,
+                                                      uint64_t* row_s) {
+  __shared__ float shf[kBlock / kWave];
+  __shared__ uint64_t sh64[kBlock / kWave];
+  for (uint64_t row = blockIdx.x; row * kBlock < n; row += gridDim.x) {
+    const uint64_t i = row * kBlock + threadIdx.x;
+    const float v = i < n ? x[i] : -__builtin_inff();
+    const int32_t eb = row_anchor(block_max(v, shf));
+    const uint64_t sb = block_sum(i < n ? rowfix(v, eb) : 0, sh64);
+    if (threadIdx.x == 0) {
+      row_e[row] = eb;
+      row_s[row] = sb;
+    }
+  }
+}
+// one block: e = max e_b, Q = sum_b S_b >> (e - e_b), lse = e ln2 + log(Q 2^-30).
+// Up to 16 rows per thread are held in registers (all loads in flight at once: one memory latency),
+// which covers 4096 rows = 1M particles; larger populations take the two-pass loop.
+__global__ __launch_bounds__(kBlock) void k_lse_rows(const int32_t* row_e, const uint64_t* row_s,
+                                                     uint64_t n_rows, int32_t* out_e,
+                                                     uint64_t* out_q, float* out_lse) {
+  __shared__ int32_t she[kBlock / kWave];
+  __shared__ uint64_t sh64[kBlock / kWave];
+  constexpr int kPer = 16;
+  const bool in_regs = n_rows <= (uint64_t)kPer * kBlock;
+  int32_t ev[kPer];
+  uint64_t sv[kPer];
+  int32_t e = kRowEmpty;
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const uint64_t b = threadIdx.x + (uint64_t)k * kBlock;
+      ev[k] = b < n_rows ? row_e[b] : kRowEmpty;
+      sv[k] = b < n_rows ? row_s[b] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) e = ev[k] > e ? ev[k] : e;
+  } else {
+    for (uint64_t b = threadIdx.x; b < n_rows; b += kBlock) e = row_e[b] > e ? row_e[b] : e;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int32_t o = __shfl_xor(e, off, kWave);
+    e = o > e ? o : e;
+  }
+  if ((threadIdx.x & 63) == 0) she[threadIdx.x >> 6] = e;
+  __syncthreads();
+  e = she[0];
+#pragma unroll
+  for (int i = 1; i < kBlock / kWave; ++i) e = she[i] > e ? she[i] : e;
+  uint64_t acc = 0;
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int64_t sh = (int64_t)e - (int64_t)ev[k];
+      acc += (ev[k] == kRowEmpty || sh > 63) ? 0 : (sv[k] >> sh);
+    }
+  } else {
+    for (uint64_t b = threadIdx.x; b < n_rows; b += kBlock) {
+      const int32_t eb = row_e[b];
+      if (eb == kRowEmpty) continue;
+      const int64_t sh = (int64_t)e - (int64_t)eb;
+      acc += sh > 63 ? 0 : (row_s[b] >> sh);
+    }
+  }
+  acc = block_sum(acc, sh64);
+  if (threadIdx.x == 0) {
+    if (out_e) out_e[0] = e;
+    if (out_q) out_q[0] = acc;
+    if (out_lse) {
+      if (e == kRowEmpty || acc == 0) {
+        out_lse[0] = -__builtin_inff();
+      } else {
+        const float t1 = (float)e * 0.69314718055994531f;
+        const float t2 = m_log((float)acc * u2f((uint32_t)(127 - kRowFrac) << 23));
+        out_lse[0] = t1 + t2;
+      }
+    }
   }
 }
 __global__ void k_lse_finish(const float* m_ptr, const uint64_t* q_ptr, int frac, float* out) {
@@ -1292,9 +1383,10 @@ int gjx_plan_destroy(gjx_plan* p) {
 
 int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const* input_cols,
                        int n_input_cols, void* const* value_cols, int n_value_cols, float* score,
-                       float* logw, uint64_t n, float* max_partials, gjx_stream s) {
+                       float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s,
+                       gjx_stream s) {
   if (!p || !keys_ok(pk) || pk->has_fold || !logw || n_input_cols < 0 || n_input_cols > 16 ||
-      n_value_cols < 0 || n_value_cols > GJX_MAX_SITES)
+      n_value_cols < 0 || n_value_cols > GJX_MAX_SITES || ((row_e == nullptr) != (row_s == nullptr)))
     return GJX_ERR_INVALID;
   RunCols cols;
   memset(&cols, 0, sizeof(cols));
@@ -1325,7 +1417,7 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
     }
     if (c.state == 1) {
       uint64_t nn = n;
-      void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials};
+      void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials, &row_e, &row_s};
       const uint64_t rows = nrows_of(n);
       if (hipModuleLaunchKernel(c.fn, (unsigned)(rows > 0x7fffffffull ? 0x7fffffffull : rows), 1, 1, kBlock, 1, 1, 0,
                                 S(s), args, nullptr) != hipSuccess)
@@ -1339,7 +1431,7 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
   }
   const size_t lds = sizeof(uint32_t) * (size_t)(p->n_slots > 0 ? p->n_slots : 1) * kTile;
 #define GJX_LAUNCH_IMPORTANCE(IMPL, MASK) \
-  k_importance<IMPL, MASK><<<grid_for(n), kBlock, lds, S(s)>>>(p->dev, p->n_sites, k, cols, score, logw, n, max_partials)
+  k_importance<IMPL, MASK><<<grid_for(n), kBlock, lds, S(s)>>>(p->dev, p->n_sites, k, cols, score, logw, n, max_partials, row_e, row_s)
   const int m = p->dist_mask;
   if (pk->impl == 0) {
     if ((m & ~kMaskNormal) == 0) GJX_LAUNCH_IMPORTANCE(0, kMaskNormal);
@@ -1382,6 +1474,18 @@ int gjx_expsum_fix(const float* x, uint64_t n, const float* max_dev, int frac_bi
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   k_expsum_partials<<<grid_for(n), kBlock, 0, S(s)>>>(x, n, max_dev, nullptr, 0, nullptr, frac_bits_, qp);
   k_reduce_sum<<<1, kBlock, 0, S(s)>>>(qp, nt, out_q, 0, max_dev, frac_bits_, nullptr, nullptr);
+  return launch_status();
+}
+int gjx_row_stats(const float* x, uint64_t n, int32_t* row_e, uint64_t* row_s, gjx_stream s) {
+  if (!x || !row_e || !row_s || n == 0) return GJX_ERR_INVALID;
+  const uint64_t rows = nrows_of(n);
+  k_row_stats<<<(unsigned)(rows > 0x7fffffffull ? 0x7fffffffull : rows), kBlock, 0, S(s)>>>(x, n, row_e, row_s);
+  return launch_status();
+}
+int gjx_lse_rows(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, int32_t* out_e,
+                 uint64_t* out_q, float* out_lse, gjx_stream s) {
+  if (!row_e || !row_s || n_rows == 0) return GJX_ERR_INVALID;
+  k_lse_rows<<<1, kBlock, 0, S(s)>>>(row_e, row_s, n_rows, out_e, out_q, out_lse);
   return launch_status();
 }
 int gjx_lse_finish(const float* max_dev, const uint64_t* q_dev, int frac_bits_, float* out_lse,

@@ -75,10 +75,10 @@ struct Gen {
     // One workgroup per 256-particle row (grid-stride): short blocks keep every SIMD's wave slots
     // full even at 1e6 particles (15 rows per lane), where a 4-row block would serialise its rows.
     o << "extern \"C\" __global__ __launch_bounds__(256" << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
-      << ") void gjx_plan_kernel_" << (impl == 0 ? "threefry" : "philox") << "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials) {\n";
-    o << "  __shared__ float sh_red[4];\n";
+      << ") void gjx_plan_kernel_" << (impl == 0 ? "threefry" : "philox") << "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s) {\n";
+    o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
     o << "  for (uint64_t row = blockIdx.x; row * 256 < n; row += gridDim.x) {\n";
-    o << "    float tmax = -__builtin_inff();\n";
+    o << "    float tmax = -__builtin_inff();\n    bool live = false;\n";
     o << "    {\n";
     o << "      const uint64_t i = row * 256 + threadIdx.x;\n";
     o << "      if (i < n) {\n";
@@ -180,9 +180,16 @@ struct Gen {
         o << "        reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "])[i] = "
           << (isint ? "(uint32_t)" + v : "f2u(" + v + ")") << ";\n";
     }
-    o << "        logw[i] = w;\n        if (score) score[i] = sc;\n        tmax = w > tmax ? w : tmax;\n";
+    o << "        logw[i] = w;\n        if (score) score[i] = sc;\n        tmax = w;\n        live = true;\n";
     o << "      }\n    }\n";
-    o << "    if (max_partials) { const float bm = block_max(tmax, sh_red); if (threadIdx.x == 0) max_partials[row] = bm; }\n";
+    o << "    if (max_partials || row_e) {\n";
+    o << "      const float bm = block_max(tmax, sh_red);\n";
+    o << "      if (max_partials && threadIdx.x == 0) max_partials[row] = bm;\n";
+    o << "      if (row_e) {\n";
+    o << "        const int32_t eb = row_anchor(bm);\n";
+    o << "        const uint64_t sb = block_sum(live ? rowfix(tmax, eb) : 0, sh_sum);\n";
+    o << "        if (threadIdx.x == 0) { row_e[row] = eb; row_s[row] = sb; }\n";
+    o << "      }\n    }\n";
     o << "  }\n}\n";
     return o.str();
   }

@@ -147,12 +147,14 @@ PROTOTYPES = {
     "gjx_plan_compile_check": (C.c_int, [_P, C.c_int]),
     "gjx_importance_run": (
         C.c_int,
-        [_P, _KP, C.POINTER(_P), C.c_int, C.POINTER(_P), C.c_int, _P, _P, C.c_uint64, _P, _P],
+        [_P, _KP, C.POINTER(_P), C.c_int, C.POINTER(_P), C.c_int, _P, _P, C.c_uint64, _P, _P, _P, _P],
     ),
     "gjx_workspace_bytes": (C.c_size_t, [C.c_int, C.c_uint64]),
     "gjx_frac_bits": (C.c_int, [C.c_uint64]),
     "gjx_num_tiles": (C.c_uint64, [C.c_uint64]),
     "gjx_num_max_partials": (C.c_uint64, [C.c_uint64]),
+    "gjx_row_stats": (C.c_int, [_P, C.c_uint64, _P, _P, _P]),
+    "gjx_lse_rows": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P]),
     "gjx_max_f32": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.c_size_t, _P]),
     "gjx_expsum_fix": (C.c_int, [_P, C.c_uint64, _P, C.c_int, _P, _P, C.c_size_t, _P]),
     "gjx_lse_finish": (C.c_int, [_P, _P, C.c_int, _P, _P]),

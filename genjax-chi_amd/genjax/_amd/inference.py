@@ -88,9 +88,11 @@ class Algorithm(SampleDistribution):
 class ParticleCollection:
     """Weighted particles: a trace whose leaves carry the particle axis, log-weights f32[K]."""
 
-    def __init__(self, particles: Trace, log_weights: torch.Tensor, is_valid=True, max_partials=None):
+    def __init__(self, particles: Trace, log_weights: torch.Tensor, is_valid=True, max_partials=None,
+                 row_stats=None):
         self.particles, self.log_weights, self.is_valid = particles, log_weights, is_valid
         self._max_partials = max_partials
+        self._rows = row_stats  # row-anchored partial sums emitted by the kernel that produced log_weights
         self._lse = None
 
     def get_particles(self) -> Trace:
@@ -103,9 +105,12 @@ class ParticleCollection:
         return int(self.log_weights.shape[0])
 
     def _lse_triple(self):
+        """(lse, e, q): row-anchored log-sum-exp — from the producer kernel's
+        partial sums when it emitted them, else one pass over the weights."""
         if self._lse is None:
-            lw = self.log_weights.contiguous()
-            self._lse = get_ops().logsumexp(lw, max_partials=self._max_partials)
+            ops = get_ops()
+            rows = self._rows if self._rows is not None else ops.row_stats(self.log_weights.contiguous())
+            self._lse = ops.lse_rows(rows)
         return self._lse
 
     def get_log_marginal_likelihood_estimate(self) -> torch.Tensor:
@@ -114,10 +119,9 @@ class ParticleCollection:
         return lse[0] - math.log(len(self))
 
     def log_marginal_likelihood_estimate_f64(self) -> float:
-        """The same estimate evaluated in float64 from the exact (max, fixed-point sum) pair."""
-        _, m, q = self._lse_triple()
-        n = len(self)
-        return float(m.cpu()) + math.log(int(q.cpu())) - get_ops().frac_bits(n) * math.log(2.0) - math.log(n)
+        """The same estimate evaluated in float64 from the exact (anchor, fixed-point sum) pair."""
+        _, e, q = self._lse_triple()
+        return get_ops().log_z_from_rows(e, q, len(self))
 
     def get_particle(self, idx) -> Trace:
         """tree_map(lambda v: v[idx]) over the trace (smc.py:90-91)."""
@@ -365,7 +369,8 @@ class ImportanceK(SMCAlgorithm):
             trs, target_scores = self.target.importance(sub_keys, choices)
             return ParticleCollection(trs, target_scores - log_weights, True)
         trs, target_scores = self.target.importance(sub_keys, ChoiceMap.empty())
-        return ParticleCollection(trs, target_scores, True, max_partials=getattr(trs, "max_partials", None))
+        return ParticleCollection(trs, target_scores, True, max_partials=getattr(trs, "max_partials", None),
+                                  row_stats=getattr(trs, "row_stats", None))
 
     def run_csmc(self, key, retained: ChoiceMap):
         k = self.get_num_particles()
@@ -444,8 +449,10 @@ class ChangeTarget(SMCAlgorithm):
     def run_smc(self, key):
         collection = self.prev.run_smc(key)
         new_particles, new_weights = self._reweight(key, collection, self.get_num_particles())
+        same = new_weights is collection.log_weights
         return ParticleCollection(new_particles, new_weights, True,
-                                  max_partials=collection._max_partials if new_weights is collection.log_weights else None)
+                                  max_partials=collection._max_partials if same else None,
+                                  row_stats=collection._rows if same else None)
 
     def run_csmc(self, key, retained: ChoiceMap):
         collection = self.prev.run_csmc(key, retained)

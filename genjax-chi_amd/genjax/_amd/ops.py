@@ -189,7 +189,7 @@ class Ops:
         return Plan(self, handle, len(sites))
 
     def importance_run(self, plan: "Plan", kb: KeyBatch, n: int, input_cols: list[torch.Tensor],
-                       value_dtypes: list, want_score=True, want_max_partials=True):
+                       value_dtypes: list, want_score=True, want_max_partials=True, want_rows=False):
         if kb.fold is not None:
             raise ValueError("particle keys must not carry a fold")
         ins = (C.c_void_p * max(1, len(input_cols)))()
@@ -202,11 +202,35 @@ class Ops:
         score = self.empty(n, torch.float32) if want_score else None
         logw = self.empty(n, torch.float32)
         mp = self.empty(self.num_max_partials(n), torch.float32) if want_max_partials else None
+        rows = RowStats(self.empty(self.num_max_partials(n), torch.int32),
+                        self.empty(self.num_max_partials(n), torch.int64), n) if want_rows else None
         self.lib.call("gjx_importance_run", plan.handle, C.byref(self._keys(kb, n)), ins, len(input_cols), outs,
                       len(vals), C.c_void_p(score.data_ptr()) if want_score else None,
                       C.c_void_p(logw.data_ptr()), n, C.c_void_p(mp.data_ptr()) if mp is not None else None,
-                      self.stream())
+                      self._p(rows.e) if rows else None, self._p(rows.s) if rows else None, self.stream())
+        if want_rows:
+            return vals, score, logw, mp, rows
         return vals, score, logw, mp
+
+    # ---- row-anchored log-sum-exp ----------------------------------------------
+    def row_stats(self, x: torch.Tensor) -> "RowStats":
+        n = x.numel()
+        rows = RowStats(self.empty(self.num_max_partials(n), torch.int32), self.empty(self.num_max_partials(n), torch.int64), n)
+        self.lib.call("gjx_row_stats", self._chk(x, torch.float32, n, "x"), n, self._p(rows.e), self._p(rows.s),
+                      self.stream())
+        return rows
+
+    def lse_rows(self, rows: "RowStats"):
+        """-> (lse f32[1], e i32[1], q i64[1]) on device."""
+        lse, e, q = self.empty(1, torch.float32), self.empty(1, torch.int32), self.empty(1, torch.int64)
+        self.lib.call("gjx_lse_rows", self._p(rows.e), self._p(rows.s), rows.e.numel(), self._p(e), self._p(q),
+                      self._p(lse), self.stream())
+        return lse, e, q
+
+    @staticmethod
+    def log_z_from_rows(e: torch.Tensor, q: torch.Tensor, n_total: int) -> float:
+        """float64 log Z = e ln2 + log(q) - 30 ln2 - log N from the exact (e, q) pair."""
+        return int(e.cpu()) * math.log(2.0) + math.log(int(q.cpu())) - 30 * math.log(2.0) - math.log(n_total)
 
     def prepare_importance(self, plan: "Plan", kb: KeyBatch, n: int, input_cols: list[torch.Tensor],
                            value_dtypes: list, with_lse: bool = True) -> "PreparedImportance":
@@ -368,6 +392,15 @@ class Ops:
         return float((m + torch.log(q) - frac * math.log(2.0) - math.log(n_total)).sum())
 
 
+@dataclass
+class RowStats:
+    """Row-anchored partial sums of a log-weight column (one (e, S) pair per 256 particles)."""
+
+    e: torch.Tensor  # int32[rows]
+    s: torch.Tensor  # int64[rows]
+    n: int
+
+
 class Plan:
     def __init__(self, ops: Ops, handle, n_sites: int):
         self.ops, self.handle, self.n_sites = ops, handle, n_sites
@@ -392,6 +425,8 @@ class PreparedImportance:
         self.values = [ops.empty(n, dt) for dt in value_dtypes]
         self.score, self.logw = ops.empty(n, torch.float32), ops.empty(n, torch.float32)
         self.max_partials = ops.empty(ops.num_max_partials(n), torch.float32)
+        self.rows = RowStats(ops.empty(ops.num_max_partials(n), torch.int32), ops.empty(ops.num_max_partials(n), torch.int64), n)
+        self.row_e_out, self.row_q_out = ops.empty(1, torch.int32), ops.empty(1, torch.int64)
         self.lse, self.max, self.q = ops.empty(1, torch.float32), ops.empty(1, torch.float32), ops.empty(1, torch.int64)
         self._keys = ops._keys(kb, n)
         self._ins = (C.c_void_p * max(1, len(self.inputs)))(*[ops._chk(t, torch.float32, n).value for t in self.inputs])
@@ -403,7 +438,12 @@ class PreparedImportance:
         self._lse = lib._gjx_logsumexp_f32
         self._args_run = (plan.handle, C.byref(self._keys), self._ins, len(self.inputs), self._outs, len(self.values),
                           C.c_void_p(self.score.data_ptr()), C.c_void_p(self.logw.data_ptr()), n,
-                          C.c_void_p(self.max_partials.data_ptr()))
+                          C.c_void_p(self.max_partials.data_ptr()), C.c_void_p(self.rows.e.data_ptr()),
+                          C.c_void_p(self.rows.s.data_ptr()))
+        self._lse_rows = lib._gjx_lse_rows
+        self._args_lse_rows = (C.c_void_p(self.rows.e.data_ptr()), C.c_void_p(self.rows.s.data_ptr()),
+                               self.rows.e.numel(), C.c_void_p(self.row_e_out.data_ptr()),
+                               C.c_void_p(self.row_q_out.data_ptr()), C.c_void_p(self.lse.data_ptr()))
         self._args_lse = (C.c_void_p(self.logw.data_ptr()), n, C.c_void_p(self.max_partials.data_ptr()),
                           C.c_void_p(self.lse.data_ptr()), C.c_void_p(self.max.data_ptr()), C.c_void_p(self.q.data_ptr()),
                           C.c_void_p(self._ws.data_ptr()), self._nb)
@@ -419,8 +459,107 @@ class PreparedImportance:
         if rc:
             raise abi.GjxError("gjx_logsumexp_f32", rc)
 
+    def launch_lse_rows(self, stream=None):
+        """Row-anchored log-sum-exp from the partial sums the importance kernel emitted: one tiny
+        kernel, no pass over logw.  Results in .lse, .row_e_out, .row_q_out."""
+        rc = self._lse_rows(*self._args_lse_rows, stream if stream is not None else self.ops.stream())
+        if rc:
+            raise abi.GjxError("gjx_lse_rows", rc)
+
     def launch(self, stream=None):
         st = stream if stream is not None else self.ops.stream()
         self.launch_importance(st)
         if self.with_lse:
-            self.launch_lse(st)
+            self.launch_lse_rows(st)
+
+
+class _Hip:
+    """The few HIP runtime calls the pipeline needs, bound through ctypes on the runtime torch has
+    already loaded (torch.cuda.Event costs ~5 us of Python per call; these cost ~1)."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            import os
+
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+            lib = C.CDLL(path)
+            lib.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+            lib.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+            lib.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+            lib.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+            lib.hipEventSynchronize.argtypes = [C.c_void_p]
+            lib.hipEventDestroy.argtypes = [C.c_void_p]
+            cls._lib = lib
+        return cls._lib
+
+
+class HipEvent:
+    """A raw hipEvent_t (timing enabled unless `timing=False`)."""
+
+    def __init__(self, timing: bool = True):
+        self.h = C.c_void_p()
+        rc = _Hip.lib().hipEventCreateWithFlags(C.byref(self.h), 0 if timing else 2)  # 2 = hipEventDisableTiming
+        if rc:
+            raise RuntimeError(f"hipEventCreateWithFlags: {rc}")
+
+    def record(self, stream_handle):
+        _Hip.lib().hipEventRecord(self.h, stream_handle)
+
+    def elapsed_ms(self, end: "HipEvent") -> float:
+        out = C.c_float()
+        _Hip.lib().hipEventSynchronize(end.h)
+        rc = _Hip.lib().hipEventElapsedTime(C.byref(out), self.h, end.h)
+        if rc:
+            raise RuntimeError(f"hipEventElapsedTime: {rc}")
+        return out.value
+
+    def __del__(self):
+        try:
+            _Hip.lib().hipEventDestroy(self.h)
+        except Exception:
+            pass
+
+
+class ImportancePipeline:
+    """Back-to-back importance passes with their log-sum-exp on a second HIP stream.
+
+    The importance kernel of pass i+1 does not depend on the log-normaliser of pass i, and the two
+    small log-sum-exp kernels are latency-bound (a few workgroups), so running them on a side stream
+    hides them under the next pass's kernel: per-pass time falls from kernel + lse to ~kernel.
+    `depth` prepared buffer sets rotate; events order reuse.  (GPU only.)"""
+
+    def __init__(self, ops: Ops, preps: list["PreparedImportance"]):
+        self.ops, self.preps = ops, preps
+        self.main = torch.cuda.current_stream()
+        self.side = torch.cuda.Stream()
+        self.ev_done = [HipEvent(timing=False) for _ in preps]
+        self.ev_free = [HipEvent(timing=False) for _ in preps]
+        self.used = [False] * len(preps)
+        self.i = 0
+        self._main_h = C.c_void_p(self.main.cuda_stream)
+        self._side_h = C.c_void_p(self.side.cuda_stream)
+        self._wait = _Hip.lib().hipStreamWaitEvent
+
+    def step(self, e0: HipEvent | None = None, e1: HipEvent | None = None) -> "PreparedImportance":
+        k = self.i % len(self.preps)
+        self.i += 1
+        prep = self.preps[k]
+        if self.used[k]:
+            self._wait(self._main_h, self.ev_free[k].h, 0)  # its previous log-sum-exp has consumed the buffers
+        if e0 is not None:
+            e0.record(self._main_h)
+        prep.launch_importance(self._main_h)
+        if e1 is not None:
+            e1.record(self._main_h)
+        self.ev_done[k].record(self._main_h)
+        self._wait(self._side_h, self.ev_done[k].h, 0)
+        prep.launch_lse(self._side_h)
+        self.ev_free[k].record(self._side_h)
+        self.used[k] = True
+        return prep
+
+    def drain(self):
+        self.main.wait_stream(self.side)

@@ -240,8 +240,8 @@ def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
     for m in tracer.meta:
         if m["out_col"] >= 0 and m["is_int"]:
             dtypes[m["out_col"]] = torch.int32
-    vals, score, logw, mp = ops.importance_run(plan, pk.kb, pk.n, tracer.inputs, dtypes, want_score=True,
-                                               want_max_partials=True)
+    vals, score, logw, mp, rows = ops.importance_run(plan, pk.kb, pk.n, tracer.inputs, dtypes, want_score=True,
+                                                     want_max_partials=True, want_rows=True)
     site_vals = []
     for m in tracer.meta:
         if m["out_col"] >= 0:
@@ -274,7 +274,8 @@ def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
     for m, v in zip(tracer.meta, site_vals):
         subtraces[m["addr"]] = ValueTrace(m["gen_fn"], (lambda a=m["args"]: tuple(resolve(y) for y in a)), v)
     tr = StaticTrace(gen_fn, args, resolve(retval), subtraces, score=score)
-    tr.max_partials = mp  # lets the particle collection skip the max pass of its log-sum-exp
+    tr.max_partials = mp  # lets a max-anchored log-sum-exp skip its max pass
+    tr.row_stats = rows  # row-anchored partial sums: the log-marginal needs one tiny kernel more
     return tr, logw
 
 

@@ -92,12 +92,14 @@ class Gaussian10:
     def step(self):
         """One ImportanceK pass on this rank: trace columns, score, log-weights and the local
         (max, fixed-point sum) pair — all device tensors, no host sync."""
-        vals, score, logw, mp = self.ops.importance_run(
-            self.plan, self.keys, self.n, [], [torch.float32] * G10_LATENTS, want_score=True, want_max_partials=True
-        )
+        vals, score, logw, mp, rows = self.ops.importance_run(
+            self.plan, self.keys, self.n, [], [torch.float32] * G10_LATENTS, want_score=True, want_max_partials=True,
+            want_rows=True)
         if self.n_total == self.n:
-            lse, m, q = self.ops.logsumexp(logw, max_partials=mp)
-            return dict(values=vals, score=score, logw=logw, lse=lse, max=m, q=q)
+            lse, m, q = self.ops.logsumexp(logw, max_partials=mp)  # max-anchored form (shardable, §3.5)
+            rlse, re, rq = self.ops.lse_rows(rows)  # row-anchored form (fused into the kernel, §3.5b)
+            return dict(values=vals, score=score, logw=logw, lse=lse, max=m, q=q, rows=rows, row_lse=rlse,
+                        row_e=re, row_q=rq)
         m = self.ops.max_f32(None, self.n, max_partials=mp)
         return dict(values=vals, score=score, logw=logw, max=m, max_partials=mp)
 
@@ -113,7 +115,9 @@ def gaussian10_importance(ops: Ops, impl: int, seed: int, n: int):
     q, m = int(out["q"].cpu()), float(out["max"].cpu())
     log_z = m + math.log(q) - w.frac * math.log(2.0) - math.log(n)
     return dict(logw=out["logw"], score=out["score"], values=out["values"], q=q, max=m, lse=float(out["lse"].cpu()),
-                log_z=log_z, log_z_exact=gaussian10_exact_log_z(w.y))
+                log_z=log_z, log_z_exact=gaussian10_exact_log_z(w.y), rows=out["rows"],
+                row_lse=float(out["row_lse"].cpu()), row_e=int(out["row_e"].cpu()), row_q=int(out["row_q"].cpu()),
+                log_z_rows=ops.log_z_from_rows(out["row_e"], out["row_q"], n))
 
 
 # ---------------------------------------------------------------------------------------------

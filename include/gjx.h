@@ -181,11 +181,12 @@ int gjx_plan_compile_check(const gjx_plan* p, int impl);
  * f32, or int32 for Bernoulli/Categorical values; at most 16 input columns).  score, logw: dev
  * f32[n] (score nullable).  max_partials: nullable dev f32[gjx_num_max_partials(n)]; when given, the
  * kernel also stores the maxima of logw per 256-particle row so the following log-sum-exp skips
- * its max pass. */
+ * its max pass.  row_e / row_s: nullable (both or neither) row-anchored partial sums, see
+ * gjx_lse_rows: with them the log-marginal needs one further tiny kernel and no pass over logw. */
 int gjx_importance_run(const gjx_plan* p, const gjx_keys* particle_keys,
                        const float* const* input_cols, int n_input_cols, void* const* value_cols,
                        int n_value_cols, float* score, float* logw, uint64_t n,
-                       float* max_partials, gjx_stream s);
+                       float* max_partials, int32_t* row_e, uint64_t* row_s, gjx_stream s);
 
 /* ---- weights: log-sum-exp, single draw, resampling ---------------------------------------- */
 
@@ -204,7 +205,17 @@ int gjx_frac_bits(uint64_t n_total);
 /* Tiles: every kernel processes particles in tiles of gjx_smc_tile() (1024); per-tile partial
  * arrays have gjx_num_tiles(n) entries. */
 uint64_t gjx_num_tiles(uint64_t n);
-uint64_t gjx_num_max_partials(uint64_t n); /* entries of the max_partials array of gjx_importance_run */
+uint64_t gjx_num_max_partials(uint64_t n); /* rows: entries of max_partials / row_e / row_s */
+
+/* Row-anchored log-sum-exp.  Each 256-particle row b is summarised by
+ * (row_e[b], row_s[b]): anchor exponent e_b = ceil(max_b * log2 e) and S_b = sum of
+ * rint(exp(x_i - e_b ln 2) * 2^30) as exact u64 — computable by the kernel that PRODUCES the
+ * log-weights, before any global maximum exists (gjx_importance_run fills them when row_e/row_s
+ * are given).  Rows combine exactly: e = max e_b, Q = sum_b (S_b >> (e - e_b)),
+ * lse = e ln 2 + log(Q 2^-30).  gjx_row_stats is the one-pass producer for arbitrary x. */
+int gjx_row_stats(const float* x, uint64_t n, int32_t* row_e, uint64_t* row_s, gjx_stream s);
+int gjx_lse_rows(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, int32_t* out_e /*nullable*/,
+                 uint64_t* out_q /*nullable*/, float* out_lse /*nullable*/, gjx_stream s);
 
 /* out_max[0] = max_i x[i] (dev f32). Pass 1 of logsumexp; multi-GPU callers all-reduce(max) it.
  * max_partials_in: nullable row maxima already produced by gjx_importance_run

@@ -325,7 +325,8 @@ static inline float eval_arg(const gjx_arg* a, const site_val* vals, const float
 
 int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const* input_cols,
                        int n_input_cols, void* const* value_cols, int n_value_cols, float* score,
-                       float* logw, uint64_t n, float* max_partials, gjx_stream s) {
+                       float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s,
+                       gjx_stream s) {
   (void)s;
   if (!p || !keys_ok(pk) || pk->has_fold || !logw) return GJX_ERR_INVALID;
   for (int q = 0; q < p->n_sites; ++q) {
@@ -399,6 +400,50 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
       float m = -INFINITY;
       for (uint64_t i = b * O_ROW; i < n && i < (b + 1) * O_ROW; ++i) m = logw[i] > m ? logw[i] : m;
       max_partials[b] = m;
+    }
+  }
+  if (row_e && row_s) return gjx_row_stats(logw, n, row_e, row_s, s);
+  return GJX_OK;
+}
+
+/* ---- row-anchored weights ----------------------------------------------------- */
+int gjx_row_stats(const float* x, uint64_t n, int32_t* row_e, uint64_t* row_s, gjx_stream s) {
+  (void)s;
+  if (!x || !row_e || !row_s || n == 0) return GJX_ERR_INVALID;
+  const uint64_t nr = gjx_num_max_partials(n);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < (int64_t)nr; ++b) {
+    uint64_t lo = (uint64_t)b * O_ROW, hi = lo + O_ROW < n ? lo + O_ROW : n;
+    float m = -INFINITY;
+    for (uint64_t i = lo; i < hi; ++i) m = x[i] > m ? x[i] : m;
+    int32_t e = o_row_anchor(m);
+    uint64_t acc = 0;
+    for (uint64_t i = lo; i < hi; ++i) acc += o_rowfix(x[i], e);
+    row_e[b] = e;
+    row_s[b] = acc;
+  }
+  return GJX_OK;
+}
+int gjx_lse_rows(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, int32_t* out_e,
+                 uint64_t* out_q, float* out_lse, gjx_stream s) {
+  (void)s;
+  if (!row_e || !row_s || n_rows == 0) return GJX_ERR_INVALID;
+  int32_t e = O_ROW_EMPTY;
+  for (uint64_t b = 0; b < n_rows; ++b) e = row_e[b] > e ? row_e[b] : e;
+  uint64_t Q = 0;
+  for (uint64_t b = 0; b < n_rows; ++b) {
+    if (row_e[b] == O_ROW_EMPTY) continue;
+    int64_t sh = (int64_t)e - (int64_t)row_e[b];
+    Q += sh > 63 ? 0 : (row_s[b] >> sh);
+  }
+  if (out_e) *out_e = e;
+  if (out_q) *out_q = Q;
+  if (out_lse) {
+    if (e == O_ROW_EMPTY || Q == 0) *out_lse = -INFINITY;
+    else {
+      float t1 = (float)e * 0.69314718055994531f;
+      float t2 = o_log((float)Q * o_u2f((uint32_t)(127 - O_ROW_FRAC) << 23));
+      *out_lse = t1 + t2;
     }
   }
   return GJX_OK;

@@ -335,4 +335,21 @@ static inline uint64_t o_fixw(float lw, float m, int frac) {
   return (uint64_t)rintf(t);
 }
 
+/* ---------------- row-anchored fixed point ------------------------------- */
+#define O_ROW_FRAC 30
+#define O_ROW_EMPTY (-(1 << 30))
+static inline int32_t o_row_anchor(float m) {
+  if (!(m > -INFINITY)) return O_ROW_EMPTY;
+  float t = m * 1.44269504088896341f;
+  t = t > 16777216.0f ? 16777216.0f : (t < -16777216.0f ? -16777216.0f : t);
+  return (int32_t)ceilf(t);
+}
+static inline uint64_t o_rowfix(float lw, int32_t e) {
+  if (e == O_ROW_EMPTY || !(lw > -INFINITY)) return 0;
+  float fe = (float)e;
+  float d = fmaf(-fe, 0.693359375f, lw);
+  d = fmaf(-fe, -2.12194440e-4f, d);
+  return (uint64_t)rintf(o_exp(d) * 1073741824.0f);
+}
+
 #endif

@@ -129,6 +129,10 @@ def test_importance_gaussian10(hip_ops, oracle_ops, impl, n, plan_mode):
     for a, b in zip(h["values"], o["values"]):
         same(a, b, "latent column")
     assert h["q"] == o["q"] and h["max"] == o["max"] and h["lse"] == o["lse"]
+    # row-anchored partial sums emitted by the importance kernel itself
+    same(h["rows"].e, o["rows"].e, "row anchors"); same(h["rows"].s, o["rows"].s, "row sums")
+    assert (h["row_e"], h["row_q"], h["row_lse"]) == (o["row_e"], o["row_q"], o["row_lse"])
+    assert abs(h["log_z_rows"] - h["log_z"]) < 1e-6, "the two fixed-point forms agree to fixed-point resolution"
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -194,6 +198,12 @@ def test_logsumexp(hip_ops, oracle_ops, n):
     frac = hip_ops.frac_bits(n)
     q = hip_ops.expsum_fix(dev(x, hip_ops), m, frac)
     same(q, oq, "expsum_fix"); same(hip_ops.lse_finish(m, q, frac), ol, "lse_finish")
+    # row-anchored form
+    hr, orr = hip_ops.row_stats(dev(x, hip_ops)), oracle_ops.row_stats(x)
+    same(hr.e, orr.e, "row_stats e"); same(hr.s, orr.s, "row_stats s")
+    for a, b in zip(hip_ops.lse_rows(hr), oracle_ops.lse_rows(orr)):
+        same(a, b, "lse_rows")
+    assert abs(float(hip_ops.lse_rows(hr)[0].cpu()) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
 
 
 @pytest.mark.parametrize("impl", IMPLS)

@@ -182,10 +182,19 @@ def test_resampling_invariants(oracle_ops, impl):
 
 
 def test_logsumexp_edge_cases(oracle_ops):
-    for x in ([0.0], [-1e30, 0.0], [5.0] * 7, [float("-inf"), -3.0]):
+    for x in ([0.0], [-1e30, 0.0], [5.0] * 7, [float("-inf"), -3.0], [-1e4, -1e4 + 1.0], [300.0, 299.0]):
         t = torch.tensor(x)
         lse, m, q = oracle_ops.logsumexp(t)
-        assert float(lse) == pytest.approx(float(torch.logsumexp(t.double(), 0)), abs=1e-6)
+        ref = float(torch.logsumexp(t.double(), 0))
+        assert float(lse) == pytest.approx(ref, abs=1e-6, rel=1e-6)
+        rl, e, rq = oracle_ops.lse_rows(oracle_ops.row_stats(t))  # row-anchored form
+        assert float(rl) == pytest.approx(ref, abs=1e-6, rel=1e-6)
+        assert oracle_ops.log_z_from_rows(e, rq, 1) == pytest.approx(ref, abs=1e-6, rel=1e-7)
+    assert float(oracle_ops.lse_rows(oracle_ops.row_stats(torch.full((700,), float("-inf"))))[0]) == float("-inf")
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(100000, generator=g) * 30  # rows with very different anchors
+    rl, e, rq = oracle_ops.lse_rows(oracle_ops.row_stats(x))
+    assert oracle_ops.log_z_from_rows(e, rq, 1) == pytest.approx(float(torch.logsumexp(x.double(), 0)), abs=1e-7)
 
 
 def test_regression_vectors(oracle_ops):
