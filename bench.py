@@ -324,9 +324,9 @@ def main():
         out["log_z_abs_err_vs_exact"] = abs(out["log_z"] - out["log_z_exact"])
         if world == 1 and not args.no_extra and args.workload == "importance":
             extra = {}
-            for kind in ("smc_lgssm",):
+            for kind in ("smc_lgssm", "smc_hmm"):
                 a2 = argparse.Namespace(**vars(args))
-                a2.steps, a2.warmup = 5, 1
+                a2.steps, a2.warmup = (5, 1) if kind == "smc_lgssm" else (2, 1)
                 r = bench_smc(a2, ops, rank, world, kind)
                 extra[kind] = {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "log_z", "log_z_exact")}
             a2 = argparse.Namespace(**vars(args))

@@ -73,6 +73,18 @@ __global__ __launch_bounds__(kBlock) void k_rng_keys(KeySrc ks, uint64_t n, uint
   }
 }
 template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_rng_split_each(KeySrc ks, uint64_t n, uint32_t m,
+                                                           uint32_t* out) {
+  const uint64_t total = n * m;
+  GJX_TILE_LOOP(e, total) {
+    const uint64_t i = e / m, j = e % m;
+    Key k = key_at<IMPL>(ks, i);
+    if (ks.has_fold) k = fold_in<IMPL>(k, ks.fold);
+    k = split_at<IMPL>(k, j);
+    reinterpret_cast<uint2*>(out)[e] = make_uint2(k.k0, k.k1);
+  }
+}
+template <int IMPL>
 __global__ __launch_bounds__(kBlock) void k_rng_bits(KeySrc ks, uint32_t sub, uint64_t n,
                                                      uint32_t* out) {
   GJX_TILE_LOOP(i, n) {
@@ -1155,6 +1167,12 @@ int gjx_rng_keys(const gjx_keys* k, uint64_t n, uint32_t* out, gjx_stream s) {
   if (!keys_ok(k) || (!out && n)) return GJX_ERR_INVALID;
   if (n == 0) return GJX_OK;
   GJX_DISPATCH_IMPL(k->impl, k_rng_keys, <<<grid_for(n), kBlock, 0, S(s)>>>(key_src(k), n, out));
+  return launch_status();
+}
+int gjx_rng_split_each(const gjx_keys* k, uint64_t n, uint32_t m, uint32_t* out, gjx_stream s) {
+  if (!keys_ok(k) || (!out && n) || m == 0) return GJX_ERR_INVALID;
+  if (n == 0) return GJX_OK;
+  GJX_DISPATCH_IMPL(k->impl, k_rng_split_each, <<<grid_for(n * m), kBlock, 0, S(s)>>>(key_src(k), n, m, out));
   return launch_status();
 }
 int gjx_rng_bits(const gjx_keys* k, uint32_t sub, uint64_t n, uint32_t* out, gjx_stream s) {

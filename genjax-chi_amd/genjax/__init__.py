@@ -11,7 +11,7 @@ from ._amd.choicemap import (ChoiceMap, ChoiceMapBuilder as _CMB, ChoiceMapNoVal
 from ._amd.lang import (AddressReuse, Distribution, GenerativeFunction, GenerativeFunctionClosure, MissingAddress,
                         StaticGenerativeFunction, Trace, bernoulli, beta, categorical, exact_density, flip, gamma,
                         gen, normal)
-from ._amd.combinators import Scan, scan
+from ._amd.combinators import Scan, Vmap, scan, vmap
 from ._amd.inference import Algorithm, Marginal, SampleDistribution, Target, marginal
 from ._amd import prng as _prng
 from ._amd.lang import split as _split, fold_in as _fold_in
@@ -40,6 +40,6 @@ __all__ = [
     "GenerativeFunction", "GenerativeFunctionClosure", "Marginal", "MissingAddress", "SampleDistribution", "Scan",
     "Selection", "SelectionBuilder", "StaticGenerativeFunction", "Target", "Trace", "bernoulli", "beta",
     "categorical", "exact_density", "flip", "gamma", "gen", "inference", "jaxlike", "marginal", "normal", "random",
-    "scan",
+    "scan", "Vmap", "vmap",
 ]
 __version__ = "0.1.0"

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "gjx_version": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gjx_backend_name": (C.c_char_p, []),
     "gjx_rng_keys": (C.c_int, [_KP, C.c_uint64, _P, _P]),
+    "gjx_rng_split_each": (C.c_int, [_KP, C.c_uint64, C.c_uint32, _P, _P]),
     "gjx_rng_bits": (C.c_int, [_KP, C.c_uint32, C.c_uint64, _P, _P]),
     "gjx_sample_logpdf_normal": (C.c_int, [_KP, F32, F32, _P, _P, C.c_uint64, _P]),
     "gjx_sample_logpdf_gamma": (C.c_int, [_KP, F32, F32, _P, _P, C.c_uint64, _P]),

@@ -15,6 +15,8 @@ import torch
 
 from .choicemap import ChoiceMap, Selection
 from .lang import GenerativeFunction, ParticleKeys, Trace, _map_any, as_particle_keys, fold_in, squeeze_leaf
+from .ops import KeyBatch
+from .runtime import get_ops
 
 
 def _index_xs(xs, t):
@@ -131,5 +133,159 @@ def scan(*, n: int | None = None):
         from .lang import gen
 
         return Scan(gen(f), length=n)
+
+    return decorator
+
+
+# =================================================================================================
+# Vmap (reference: generative_functions/combinators/vmap.py:55-94 VmapTrace, 180-218 simulate/generate)
+# =================================================================================================
+class VmapTrace(Trace):
+    """The inner trace runs over n*m "virtual particles" (particle i, element j at i*m + j); leaves
+    are presented as [n, m] ([m] for a scalar key), score = sum over the mapped axis."""
+
+    def __init__(self, gen_fn, inner: Trace, args, n: int, m: int, batched: bool):
+        self.gen_fn, self.inner, self.args, self.n, self.m, self.batched = gen_fn, inner, args, n, m, batched
+
+    def _shape(self, v):
+        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == self.n * self.m:
+            v = v.reshape((self.n, self.m) + tuple(v.shape[1:]))
+            return v if self.batched else v[0]
+        return v
+
+    def get_args(self):
+        return self.args
+
+    def get_gen_fn(self):
+        return self.gen_fn
+
+    def get_retval(self):
+        return _map_any(self._shape, self.inner.get_retval())
+
+    def get_choices(self) -> ChoiceMap:
+        return self.inner.get_choices().map_leaves(self._shape)
+
+    def get_score(self):
+        s = self.inner.get_score()
+        if isinstance(s, torch.Tensor) and s.dim() >= 1:
+            s = s.reshape(self.n, self.m).sum(1)
+            return s if self.batched else s[0]
+        return s * self.m
+
+    def map_leaves(self, fn):
+        return VmapTrace(self.gen_fn, self.inner.map_leaves(fn), _map_any(fn, self.args), self.n, self.m, self.batched)
+
+
+class Vmap(GenerativeFunction):
+    """`gen_fn.vmap(in_axes=(0, None, ...))`: independent copies over a mapped axis of the arguments;
+    element j of particle i uses key split(key_i, m)[j] (vmap.py:186, 201)."""
+
+    def __init__(self, gen_fn: GenerativeFunction, in_axes=0, axis_size: int | None = None):
+        self.gen_fn, self.in_axes, self.axis_size = gen_fn, in_axes, axis_size
+
+    def _axes(self, args):
+        ax = self.in_axes
+        if not isinstance(ax, (tuple, list)):
+            ax = (ax,) * len(args)
+        if len(ax) != len(args):
+            raise ValueError("in_axes must match the arguments")
+        for a in ax:
+            if a not in (0, None):
+                raise NotImplementedError("Vmap supports in_axes entries 0 and None")
+        return ax
+
+    def _length(self, args, axes, n: int, batched: bool) -> int:
+        if self.axis_size is not None:
+            return int(self.axis_size)
+        for a, ax in zip(args, axes):
+            if ax == 0:
+                t = torch.as_tensor(a)
+                # a mapped argument is [m] (shared by all particles) or [n, m] (per particle)
+                return int(t.shape[1] if (batched and t.dim() >= 2 and t.shape[0] == n) else t.shape[0])
+        raise ValueError("Vmap needs a mapped argument or axis_size")
+
+    def _expand_args(self, args, axes, n, m, batched):
+        ops = get_ops()
+        out = []
+        for a, ax in zip(args, axes):
+            if ax == 0:
+                t = torch.as_tensor(a).to(ops.device())
+                if t.dtype == torch.float64:
+                    t = t.to(torch.float32)
+                if batched and t.dim() >= 2 and t.shape[0] == n and t.shape[1] == m:
+                    out.append(t.reshape((n * m,) + tuple(t.shape[2:])).contiguous())
+                else:
+                    out.append(t.repeat((n,) + (1,) * (t.dim() - 1)).contiguous())  # index i*m+j -> a[j]
+            elif isinstance(a, torch.Tensor) and a.dim() >= 1 and a.shape[0] == n and n > 1:
+                out.append(a.repeat_interleave(m, dim=0))  # per-particle value shared by its m elements
+            else:
+                out.append(a)
+        return tuple(out)
+
+    def _inner_keys(self, pk: ParticleKeys, m: int) -> ParticleKeys:
+        t = get_ops().rng_split_each(pk.kb, pk.n, m)
+        return ParticleKeys(KeyBatch(pk.impl, 0, tensor=t), pk.n * m)
+
+    def _expand_constraint(self, constraint: ChoiceMap, n: int, m: int) -> ChoiceMap:
+        """Constraints on a vmapped site are vectors over the mapped axis (`C[:, "x"].set(xs)`,
+        test_choice_maps.py:1033): leaf [m] (all particles) or [n, m]."""
+        ops = get_ops()
+
+        def expand(v):
+            t = torch.as_tensor(v).to(ops.device())
+            if t.dtype == torch.float64:
+                t = t.to(torch.float32)
+            if t.dim() >= 2 and t.shape[0] == n and t.shape[1] == m:
+                return t.reshape((n * m,) + tuple(t.shape[2:])).contiguous()
+            if t.dim() >= 1 and t.shape[0] == m:
+                return t.repeat((n,) + (1,) * (t.dim() - 1)).contiguous()
+            raise NotImplementedError("constraints on a subset of the mapped indices need masked sites (out of scope)")
+
+        for seg in constraint._children:
+            if isinstance(seg, int):
+                raise NotImplementedError("constraints on a subset of the mapped indices need masked sites (out of scope)")
+        return constraint.map_leaves(expand)
+
+    def simulate(self, key, args):
+        pk, batched = as_particle_keys(key)
+        axes = self._axes(args)
+        m = self._length(args, axes, pk.n, batched)
+        inner = self.gen_fn.simulate(self._inner_keys(pk, m), self._expand_args(args, axes, pk.n, m, batched))
+        return VmapTrace(self, inner, args, pk.n, m, batched)
+
+    def generate(self, key, constraint: ChoiceMap, args):
+        pk, batched = as_particle_keys(key)
+        axes = self._axes(args)
+        m = self._length(args, axes, pk.n, batched)
+        inner, w = self.gen_fn.generate(self._inner_keys(pk, m), self._expand_constraint(constraint, pk.n, m),
+                                        self._expand_args(args, axes, pk.n, m, batched))
+        if isinstance(w, torch.Tensor) and w.dim() >= 1:
+            w = w.reshape(pk.n, m).sum(1)
+            w = w if batched else w[0]
+        else:
+            w = w * m
+        return VmapTrace(self, inner, args, pk.n, m, batched), w
+
+    def assess(self, sample: ChoiceMap, args):
+        axes = self._axes(args)
+        m = self._length(args, axes, 1, False)
+        score, ret = self.gen_fn.assess(self._expand_constraint(sample, 1, m), self._expand_args(args, axes, 1, m, False))
+        if isinstance(score, torch.Tensor) and score.dim() >= 1:
+            score = score.sum()
+        return score, ret
+
+    def project(self, key, trace: VmapTrace, selection: Selection):
+        p = trace.inner.project(key, selection)
+        if isinstance(p, torch.Tensor) and p.dim() >= 1:
+            p = p.reshape(trace.n, trace.m).sum(1)
+            return p if trace.batched else p[0]
+        return p
+
+
+def vmap(*, in_axes=0):
+    def decorator(f):
+        from .lang import gen
+
+        return Vmap(gen(f), in_axes=in_axes)
 
     return decorator

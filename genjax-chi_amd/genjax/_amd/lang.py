@@ -378,6 +378,23 @@ class GenerativeFunction:
 
         return Scan(self, length=n)
 
+    def vmap(self, /, *, in_axes=0):
+        from .combinators import Vmap
+
+        return Vmap(self, in_axes=in_axes)
+
+    def repeat(self, /, *, n: int):
+        """`repeat` = vmap over a dummy axis (generative_functions/combinators/repeat.py:28-40)."""
+        from .combinators import Vmap
+
+        inner = self
+
+        class _Repeat(Vmap):
+            def _axes(self, args):
+                return (None,) * len(args)
+
+        return _Repeat(inner, in_axes=None, axis_size=n)
+
     def partial_apply(self, *first_args):
         outer = self
 

@@ -113,6 +113,11 @@ class Ops:
         self.lib.call("gjx_rng_keys", C.byref(self._keys(kb, n)), n, C.c_void_p(out.data_ptr()), self.stream())
         return out
 
+    def rng_split_each(self, kb: KeyBatch, n: int, m: int) -> torch.Tensor:
+        out = self.empty((n * m, 2), torch.int32)
+        self.lib.call("gjx_rng_split_each", C.byref(self._keys(kb, n)), n, m, C.c_void_p(out.data_ptr()), self.stream())
+        return out
+
     def rng_bits(self, kb: KeyBatch, n: int, sub: int = 0) -> torch.Tensor:
         out = self.empty(n, torch.int32)
         self.lib.call("gjx_rng_bits", C.byref(self._keys(kb, n)), sub, n, C.c_void_p(out.data_ptr()), self.stream())

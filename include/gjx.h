@@ -82,6 +82,10 @@ const char* gjx_backend_name(void); /* "hip-gfx950" or "oracle-cpu" */
  * scan.py:213,268) when keys must be materialised. */
 int gjx_rng_keys(const gjx_keys* k, uint64_t n, uint32_t* out, gjx_stream s);
 
+/* out[i*m + j] = split(key_i, m)[j] for the n keys described by k (after the optional fold):
+ * the nested key batch of Vmap.generate / simulate (combinators/vmap.py:186,201).  dev u32[n,m,2]. */
+int gjx_rng_split_each(const gjx_keys* k, uint64_t n, uint32_t m, uint32_t* out, gjx_stream s);
+
 /* out[i] = 32 random bits of key i, sub-stream `sub` (DESIGN.md §3.2 bits32_at).  dev u32[n]. */
 int gjx_rng_bits(const gjx_keys* k, uint32_t sub, uint64_t n, uint32_t* out, gjx_stream s);
 

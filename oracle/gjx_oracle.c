@@ -65,6 +65,19 @@ int gjx_rng_keys(const gjx_keys* k, uint64_t n, uint32_t* out, gjx_stream s) {
   return GJX_OK;
 }
 
+int gjx_rng_split_each(const gjx_keys* k, uint64_t n, uint32_t m, uint32_t* out, gjx_stream s) {
+  (void)s;
+  if (!keys_ok(k) || (!out && n) || m == 0) return GJX_ERR_INVALID;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    uint32_t key[2];
+    key_at(k, (uint64_t)i, key);
+    if (k->has_fold) { uint32_t f[2]; o_fold_in(k->impl, key, k->fold, f); key[0] = f[0]; key[1] = f[1]; }
+    for (uint32_t j = 0; j < m; ++j) o_split_at(k->impl, key, j, &out[2 * ((uint64_t)i * m + j)]);
+  }
+  return GJX_OK;
+}
+
 int gjx_rng_bits(const gjx_keys* k, uint32_t sub, uint64_t n, uint32_t* out, gjx_stream s) {
   (void)s;
   if (!keys_ok(k) || (!out && n)) return GJX_ERR_INVALID;

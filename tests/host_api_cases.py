@@ -317,6 +317,42 @@ def case_scan(impl):
     assert trb.get_score().shape == (64,)
 
 
+# ---- vmap / repeat (tests/generative_functions/test_vmap_combinator.py:60-79) ---------------------------
+def case_vmap(impl):
+    @gen
+    def point(x, s):
+        y = normal(x, s) @ "y"
+        return y
+
+    vm = point.vmap(in_axes=(0, None))
+    key = genjax.random.key(314159, impl)
+    xs = torch.tensor([0.0, 1.0, 2.0])
+    tr = vm.simulate(key, (xs, 0.1))
+    assert tr.get_choices()["y"].shape == (3,) and tr.get_retval().shape == (3,)
+    assert f(tr.get_score()) == pytest.approx(f(vm.assess(tr.get_choices(), (xs, 0.1))[0]), rel=1e-5)
+    obs = torch.tensor([3.0, 2.0, 3.0])
+    tr, w = vm.importance(key, C[:, "y"].set(obs), (xs, 1.0))
+    want = sum(f(normal.logpdf(v, m, 1.0)) for v, m in zip(obs.tolist(), xs.tolist()))
+    assert f(w) == pytest.approx(want, rel=1e-5)  # weight == sum of the three normal log-densities
+    keys = genjax.random.split(key, 7)
+    trb, wb = vm.importance(keys, C[:, "y"].set(obs), (xs, 1.0))
+    assert wb.shape == (7,) and trb.get_choices()["y"].shape == (7, 3)
+    assert torch.allclose(wb, torch.full_like(wb, want), rtol=1e-5)
+    sim = vm.simulate(keys, (xs, 1.0))
+    ys = sim.get_choices()["y"]
+    assert ys.shape == (7, 3) and len(set(ys.flatten().tolist())) == 21  # independent draws per (particle, element)
+    rep = point.repeat(n=4).simulate(keys, (0.0, 1.0))
+    assert rep.get_choices()["y"].shape == (7, 4)
+
+    @gen
+    def model():
+        mu = normal(0.0, 1.0) @ "mu"
+        return point.vmap(in_axes=(0, None))(torch.zeros(3), 1.0) @ "ys"
+
+    tr, w = model.importance(keys, C["ys", :, "y"].set(obs), ())
+    assert w.shape == (7,) and tr.get_choices()["ys", "y"].shape == (7, 3)
+
+
 # ---- fused bootstrap SMC ---------------------------------------------------------------------------------
 def case_bootstrap_smc(impl):
     from genjax._amd import workloads as W
@@ -334,4 +370,4 @@ def case_bootstrap_smc(impl):
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_fused_equals_eager, case_particle_collection, case_scan,
-             case_bootstrap_smc]
+             case_vmap, case_bootstrap_smc]

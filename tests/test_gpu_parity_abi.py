@@ -55,6 +55,10 @@ def test_rng_keys_and_bits(hip_ops, oracle_ops, impl, n):
     same(oracle_ops.rng_bits(ek_o.with_fold(2), n), oracle_ops.rng_bits(kb.with_fold(2), n))
     lit = KeyBatch(impl, 2, parent=(9, 10))
     same(hip_ops.rng_bits(lit, n, 3), oracle_ops.rng_bits(lit, n, 3), "literal key")
+    for m in (1, 3):
+        same(hip_ops.rng_split_each(kb, n, m), oracle_ops.rng_split_each(kb, n, m), "rng_split_each")
+    se = oracle_ops.rng_split_each(kb, n, 3).view(n, 3, 2)
+    assert torch.equal(se[:, 0], oracle_ops.rng_keys(KeyBatch(impl, 0, tensor=mat).with_fold(0), n)) or impl == 1
 
 
 @pytest.mark.parametrize("impl", IMPLS)
