@@ -161,12 +161,29 @@ def smc_key_schedule(root: prng.PRNGKey, T: int):
     return [k.words() for k in ks[0::2]], [k.words() for k in ks[1::2]]
 
 
+class LgssmSMC:
+    """Reusable state of the C3 workload: data, key schedule and exact log Z are prepared once, so
+    `run()` is only the enqueue of the fused filter (2 kernels per step, no host sync)."""
+
+    def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, want_ancestors: bool = False):
+        self.ops, self.impl, self.n, self.T, self.want_ancestors = ops, impl, n, T, want_ancestors
+        self.y = lgssm_data(T)
+        self.sk, self.rk = smc_key_schedule(prng.key(seed, impl), T)
+        self.model = lgssm_model()
+        self.log_z_exact = lgssm_exact_log_z(self.y)
+
+    def run(self):
+        return self.ops.smc_run_lgssm(self.impl, self.n, self.sk, self.rk, self.model, self.y, self.want_ancestors)
+
+    def result(self, out):
+        out_max, out_q, state, logw, anc = out
+        return dict(out_max=out_max, out_q=out_q, state=state, logw=logw, ancestors=anc,
+                    log_z=self.ops.log_z_from_pairs(out_max, out_q, self.n), log_z_exact=self.log_z_exact)
+
+
 def lgssm_smc(ops: Ops, impl: int, seed: int, n: int, T: int, want_ancestors: bool = False):
-    y = lgssm_data(T)
-    sk, rk = smc_key_schedule(prng.key(seed, impl), T)
-    out_max, out_q, state, logw, anc = ops.smc_run_lgssm(impl, n, sk, rk, lgssm_model(), y, want_ancestors)
-    return dict(out_max=out_max, out_q=out_q, state=state, logw=logw, ancestors=anc,
-                log_z=ops.log_z_from_pairs(out_max, out_q, n), log_z_exact=lgssm_exact_log_z(y))
+    w = LgssmSMC(ops, impl, seed, n, T, want_ancestors)
+    return w.result(w.run())
 
 
 # ---------------------------------------------------------------------------------------------
@@ -234,14 +251,31 @@ def hmm_exact_log_z(y, n_states=None, init_state=None) -> float:
     return ll
 
 
+class HmmSMC:
+    """Reusable state of the C5 workload (tables resident on the device, data and keys prepared)."""
+
+    def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, n_states=None, want_ancestors: bool = False):
+        trans, obs = hmm_tables(n_states)
+        self.ops, self.impl, self.n, self.T, self.want_ancestors = ops, impl, n, T, want_ancestors
+        self.k = trans.shape[0]
+        self.init = HMM["init_state"] % self.k
+        self.y = hmm_data(T, n_states)
+        dev = ops.device()
+        self.tl = torch.from_numpy(trans).to(dev).contiguous()
+        self.ol = torch.from_numpy(obs).to(dev).contiguous()
+        self.sk, self.rk = smc_key_schedule(prng.key(seed, impl), T)
+        self.log_z_exact = hmm_exact_log_z(self.y, n_states)
+
+    def run(self):
+        return self.ops.smc_run_hmm(self.impl, self.n, self.sk, self.rk, self.k, self.init, self.tl, self.ol, self.y,
+                                    self.want_ancestors)
+
+    def result(self, out):
+        out_max, out_q, state, logw, anc = out
+        return dict(out_max=out_max, out_q=out_q, state=state, logw=logw, ancestors=anc,
+                    log_z=self.ops.log_z_from_pairs(out_max, out_q, self.n), log_z_exact=self.log_z_exact)
+
+
 def hmm_smc(ops: Ops, impl: int, seed: int, n: int, T: int, n_states=None, want_ancestors: bool = False):
-    trans, obs = hmm_tables(n_states)
-    k = trans.shape[0]
-    init = HMM["init_state"] % k
-    y = hmm_data(T, n_states)
-    dev = ops.device()
-    tl, ol = torch.from_numpy(trans).to(dev).contiguous(), torch.from_numpy(obs).to(dev).contiguous()
-    sk, rk = smc_key_schedule(prng.key(seed, impl), T)
-    out_max, out_q, state, logw, anc = ops.smc_run_hmm(impl, n, sk, rk, k, init, tl, ol, y, want_ancestors)
-    return dict(out_max=out_max, out_q=out_q, state=state, logw=logw, ancestors=anc,
-                log_z=ops.log_z_from_pairs(out_max, out_q, n), log_z_exact=hmm_exact_log_z(y, n_states))
+    w = HmmSMC(ops, impl, seed, n, T, n_states, want_ancestors)
+    return w.result(w.run())
