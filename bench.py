@@ -181,6 +181,20 @@ def bench_importance(args, ops, rank, world):
     else:  # row-anchored pair from the fused partial sums
         log_z = ops.log_z_from_rows(m, q, total_particles)
     achieved = BYTES_IMPORTANCE_KERNEL_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
+    # collected by profiles/collect.sh on this same command); null if none matches this kernel/size.
+    traffic, traffic_src = None, None
+    if n == N_PER_GPU:
+        import glob
+
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+            try:
+                pj = json.load(open(f))
+                if f"gjx_plan_kernel_{args.rng}" in pj.get("kernel", ""):
+                    traffic, traffic_src = pj["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+                    break
+            except Exception:
+                pass
     res = {
         "metric": "particles/sec, ImportanceK log-marginal-likelihood estimate (1e6 particles per GPU)",
         "value": total_particles / (dt / args.steps),
@@ -190,7 +204,7 @@ def bench_importance(args, ops, rank, world):
                    "particles_per_gpu": n, "latent_sites": 10, "observed_sites": 10, "rng": args.rng,
                    "parallelism": f"particle-sharded x{world}"},
         "roofline": {"bound": "hbm", "kernel": f"gjx_plan_kernel_{args.rng}", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel_ms": k_ms, "kernel_ms_raw_event_interval": k_ms_raw,
                      "event_pair_overhead_ms": ev_overhead_ms, "kernel_launches_timed": len(kernel_ms),
                      "algorithmic_bytes_per_launch": BYTES_IMPORTANCE_KERNEL_PER_PARTICLE * n},

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Collect the round's rocprof evidence on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 900 -- 'bash profiles/collect.sh r01'
+# Writes raw output under gpurun_out/profiles_<tag>/; profiles/summarize.py turns it into the
+# committed summaries.  Counters are collected in their own passes (no trace domains with --pmc).
+set -o pipefail
+TAG=${1:-r01}
+OUT=gpurun_out/profiles_$TAG
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+rm -rf "$OUT" && mkdir -p "$OUT"
+BENCH="python3 bench.py --steps 50 --warmup 5"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_under_rocprof.log" 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $BENCH --no-cpu-baseline --no-extra > "$OUT/fetch.log" 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $BENCH --no-cpu-baseline --no-extra > "$OUT/write.log" 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/sq" -- $BENCH --no-cpu-baseline --no-extra > "$OUT/sq.log" 2>&1 || exit 1
+timeout -k 10 300 $BENCH > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err" || exit 1
+tail -c 600 "$OUT/bench_plain.json"
