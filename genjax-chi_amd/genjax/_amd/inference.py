@@ -401,6 +401,12 @@ def _batched_random_weighted(q, sub_keys: ParticleKeys, target: Target):
     """vmap(q.random_weighted, in_axes=(0, None))(sub_keys, target)."""
     if hasattr(q, "batched_random_weighted"):
         return q.batched_random_weighted(sub_keys, target)
+    try:  # proposals built from `@gen` functions (Marginal) run once over the whole key batch
+        w, chm = q.random_weighted(sub_keys, target)
+        if isinstance(w, torch.Tensor) and w.dim() == 1 and w.shape[0] == sub_keys.n:
+            return w, chm
+    except (TypeError, NotImplementedError):
+        pass
     # generic proposals run once per key (the reference vmaps them); their results are stacked
     ws, chms = [], []
     for k in sub_keys:

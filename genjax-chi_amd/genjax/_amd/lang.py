@@ -90,7 +90,11 @@ def split(key, num: int = 2):
     """`jax.random.split`: scalar key -> `num` keys (lazy batch; iterable / indexable)."""
     if isinstance(key, prng.PRNGKey):
         return ParticleKeys(prng.split_lazy(key, num), num)
-    raise TypeError("split() of a key batch is not supported; split the scalar key instead")
+    if isinstance(key, ParticleKeys):
+        # vmap(split): every particle key is split `num` ways (one nested-split kernel)
+        t = get_ops().rng_split_each(key.kb, key.n, num).view(key.n, num, 2)
+        return tuple(ParticleKeys(KeyBatch(key.impl, 0, tensor=t[:, j].contiguous()), key.n) for j in range(num))
+    raise TypeError(f"expected a PRNG key, got {type(key).__name__}")
 
 
 def fold_in(key, data: int):

@@ -291,6 +291,47 @@ def case_particle_collection(impl):
     assert len(one) == 1
 
 
+# ---- custom proposals q (smc.py:256-258, 301-305; sp.py:217-238) ------------------------------------
+def case_custom_proposal(impl):
+    @gen
+    def model():
+        x = normal(0.0, 1.0) @ "x"
+        _ = normal(x, 0.5) @ "y"
+        return x
+
+    @gen
+    def exact_posterior(target):
+        y = target["y"]
+        _ = normal(0.8 * y, math.sqrt(0.2)) @ "x"  # the exact posterior of x | y
+
+    t = Target(model, (), C["y"].set(1.0))
+    q = exact_posterior.marginal()
+    key = genjax.random.key(21, impl)
+    # Mirrored reference behaviour (sp.py:217-230): with the default selection (all) a Marginal's
+    # random_weighted returns weight = tr.project(~all) = 0, so the collection's weights are the
+    # target's importance weights at the PROPOSED choices: log p(x) + log p(y | x).
+    keys = genjax.random.split(key, 64)
+    wq, chm = q.random_weighted(keys, t)
+    assert f(torch.as_tensor(wq).abs().max()) == 0.0 and chm["x"].shape == (64,)
+    assert f(chm["x"].mean()) == pytest.approx(0.8, abs=0.25)
+    coll = ImportanceK(t, q, k_particles=4096).run_smc(key)
+    lw, xs = coll.get_log_weights(), coll.get_particles().get_choices()["x"]
+    assert lw.shape == (4096,)
+    assert torch.allclose(lw, normal.logpdf(xs, 0.0, 1.0) + normal.logpdf(1.0, xs, 0.5), atol=2e-5)
+    assert f(xs.mean()) == pytest.approx(0.8, abs=0.03) and f(xs.std()) == pytest.approx(math.sqrt(0.2), abs=0.02)
+    # the batched proposal run equals the reference's per-key vmap, key by key
+    k1, sub = genjax.random.split(key)
+    pks = genjax.random.split(sub, 4096)
+    for i in (0, 17, 4095):
+        wi, ci = q.random_weighted(pks[i], t)
+        assert f(ci["x"]) == f(xs[i])
+    one = Importance(t, q).run_smc(key)
+    x1 = one.get_particles().get_choices()["x"][0]
+    assert f(one.get_log_weights()[0]) == pytest.approx(f(normal.logpdf(x1, 0.0, 1.0) + normal.logpdf(1.0, x1, 0.5)), abs=2e-5)
+    cs = ImportanceK(t, q, k_particles=8).run_csmc(key, C["x"].set(0.5))
+    assert len(cs) == 8 and f(cs.get_particles().get_choices()["x"][-1]) == pytest.approx(0.5)
+
+
 # ---- scan (tests/generative_functions/test_scan_combinator.py:54-61) ------------------------------------
 def case_scan(impl):
     @genjax.scan(n=10)
@@ -369,5 +410,5 @@ def case_bootstrap_smc(impl):
 
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
-             case_static_gen_fn, case_distributions, case_fused_equals_eager, case_particle_collection, case_scan,
-             case_vmap, case_bootstrap_smc]
+             case_static_gen_fn, case_distributions, case_fused_equals_eager, case_particle_collection, case_custom_proposal,
+             case_scan, case_vmap, case_bootstrap_smc]
