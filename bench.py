@@ -33,8 +33,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 N_PER_GPU = 1_000_000
 # Algorithmic bytes per unit (SURVEY §8d / DESIGN.md §5)
-BYTES_IMPORTANCE_PER_PARTICLE = 52  # 10 latent columns + score + logw written, logw re-read
-BYTES_IMPORTANCE_KERNEL_PER_PARTICLE = 48  # the dominant kernel's share (everything but the re-read)
+# SURVEY §8d counts 52 B/particle for the pass (the last 4 are the log-sum-exp's re-read of logw, which the
+# fused row-anchored partial sums made unnecessary); the dominant kernel's algorithmic share:
+BYTES_IMPORTANCE_KERNEL_PER_PARTICLE = 48  # 10 latent columns + score + logw written
 BYTES_SMC_PER_PARTICLE_STEP = 44
 
 

@@ -526,45 +526,3 @@ class HipEvent:
             _Hip.lib().hipEventDestroy(self.h)
         except Exception:
             pass
-
-
-class ImportancePipeline:
-    """Back-to-back importance passes with their log-sum-exp on a second HIP stream.
-
-    The importance kernel of pass i+1 does not depend on the log-normaliser of pass i, and the two
-    small log-sum-exp kernels are latency-bound (a few workgroups), so running them on a side stream
-    hides them under the next pass's kernel: per-pass time falls from kernel + lse to ~kernel.
-    `depth` prepared buffer sets rotate; events order reuse.  (GPU only.)"""
-
-    def __init__(self, ops: Ops, preps: list["PreparedImportance"]):
-        self.ops, self.preps = ops, preps
-        self.main = torch.cuda.current_stream()
-        self.side = torch.cuda.Stream()
-        self.ev_done = [HipEvent(timing=False) for _ in preps]
-        self.ev_free = [HipEvent(timing=False) for _ in preps]
-        self.used = [False] * len(preps)
-        self.i = 0
-        self._main_h = C.c_void_p(self.main.cuda_stream)
-        self._side_h = C.c_void_p(self.side.cuda_stream)
-        self._wait = _Hip.lib().hipStreamWaitEvent
-
-    def step(self, e0: HipEvent | None = None, e1: HipEvent | None = None) -> "PreparedImportance":
-        k = self.i % len(self.preps)
-        self.i += 1
-        prep = self.preps[k]
-        if self.used[k]:
-            self._wait(self._main_h, self.ev_free[k].h, 0)  # its previous log-sum-exp has consumed the buffers
-        if e0 is not None:
-            e0.record(self._main_h)
-        prep.launch_importance(self._main_h)
-        if e1 is not None:
-            e1.record(self._main_h)
-        self.ev_done[k].record(self._main_h)
-        self._wait(self._side_h, self.ev_done[k].h, 0)
-        prep.launch_lse(self._side_h)
-        self.ev_free[k].record(self._side_h)
-        self.used[k] = True
-        return prep
-
-    def drain(self):
-        self.main.wait_stream(self.side)
