@@ -494,4 +494,164 @@ GJX_DEV uint64_t block_scan_excl(uint64_t v, uint64_t* sh, uint64_t& total) {
   return base + incl - v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Systematic resampling, tile-centric: workgroup b owns SOURCE particles [b*1024, (b+1)*1024).
+// It rebuilds the fixed-point CDF of its tile in LDS (prefix of the preceding tiles comes from the
+// per-tile sums), turns it into "teeth below" counts, and serves the contiguous range of OUTPUT
+// slots whose teeth fall into its mass — so both the source reads (one tile of lw / state) and
+// the output writes are coalesced, and ancestors never round-trip through HBM unless asked for.
+// The per-output work (propagate + weight for the fused SMC models) is the template policy.
+// ------------------------------------------------------------------------------------------------
+struct ResampleArgs {
+  const float* lw;            // [n] source log-weights
+  const float* m_ptr;         // max of lw
+  const uint64_t* tile_sums;  // [ntiles] fixed-point mass of every source tile
+  uint64_t n, ntiles;
+  uint64_t n_out;             // number of comb teeth (global output slots)
+  int64_t out_lo, out_hi;     // slots this launch serves
+  int frac;
+  int lw_vec;                 // lw is 16-byte aligned: tiles may use float4 loads
+  Key rkey;                   // resampling key (its sub-stream 0 gives the comb offset)
+  int rkey_has_fold;
+  uint32_t rkey_fold;
+  uint64_t* q_total_out;      // nullable: block 0 stores the total mass (= sum of tile_sums)
+};
+
+// Kernel argument block of a plan-driven SMC step (the generated policy wraps it).
+struct PlanPolicyArgs {
+  const float* prev_state[4];
+  float* state_out[4];
+  float* logw_out;
+  int32_t* anc_out;
+  Key step_key;
+  float obs[8];
+};
+
+template <int N>
+struct IntC {
+  static constexpr int value = N;
+};
+
+template <int IMPL, class Policy>
+GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials) {
+  __shared__ uint64_t sh64[kBlock / kWave];
+  __shared__ float shf[kBlock / kWave];
+  __shared__ int32_t nb[kTile];  // teeth below the inclusive CDF of each source in the tile
+  const uint64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const uint64_t base = b * kTile;
+
+  // Issue this tile's loads first: their HBM latency overlaps the tile-mass prefix reduction.
+  float lw4[4];
+  if (A.lw_vec && base + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
+    const float4 v = reinterpret_cast<const float4*>(A.lw + base)[tid];
+    lw4[0] = v.x; lw4[1] = v.y; lw4[2] = v.z; lw4[3] = v.w;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint64_t i = base + 4 * (uint64_t)tid + r;
+      lw4[r] = i < A.n ? A.lw[i] : -__builtin_inff();
+    }
+  }
+  P.fetch_source(base, A.n, tid);  // registers now, LDS after the scan
+
+  // prefix / total of tile masses (u64, exact)
+  uint64_t pre = 0, tot = 0;
+  for (uint64_t k = tid; k < A.ntiles; k += kBlock) {
+    const uint64_t v = A.tile_sums[k];
+    tot += v;
+    if (k < b) pre += v;
+  }
+  pre = block_sum(pre, sh64);
+  tot = block_sum(tot, sh64);
+  if (A.q_total_out && b == 0 && tid == 0) A.q_total_out[0] = tot;
+
+  const Stream<IMPL> rs(A.rkey, A.rkey_has_fold != 0, A.rkey_fold);
+  const double u0 = u0_from_bits(rs.bits64(0));
+  const double scale = (double)A.n_out / (double)tot;
+  const float m = A.m_ptr[0];
+
+  // tile CDF: each thread owns 4 CONSECUTIVE sources (base + 4*tid + r) so the scan is a
+  // thread-local prefix plus one block scan.
+  uint64_t q[4];
+  uint64_t local = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t i = base + 4 * (uint64_t)tid + r;
+    q[r] = i < A.n ? fixw(lw4[r], m, A.frac) : 0;
+    local += q[r];
+  }
+  uint64_t tile_total;
+  uint64_t run = pre + block_scan_excl(local, sh64, tile_total);
+  const int64_t n_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t i = base + 4 * (uint64_t)tid + r;
+    run += q[r];
+    // the last real particle (and any padding after it) closes the comb at n_out
+    const int64_t t = (i + 1 >= A.n) ? (int64_t)A.n_out
+                                     : teeth_below(run, scale, u0, (int64_t)A.n_out);
+    nb[4 * tid + r] = (int32_t)t;
+  }
+  P.stage_source(tid);
+  __syncthreads();
+  const int64_t n_hi = nb[kTile - 1];
+  const int64_t j0 = n_lo > A.out_lo ? n_lo : A.out_lo;
+  const int64_t j1 = n_hi < A.out_hi ? n_hi : A.out_hi;
+
+  // Output slots in groups of up to 4 rows (256 slots each) per pass: NU independent ancestor
+  // searches and NU independent propagate chains are in flight per lane (ILP); the group size is
+  // wave-uniform, so rows past the block's range cost nothing.  Stores close the group.
+  float tmax = -__builtin_inff();
+  auto group = [&](auto nu_tag, int64_t jb) {
+    constexpr int NU = decltype(nu_tag)::value;
+    int64_t jj[NU];
+    bool ok[NU];
+    int lo[NU], hi[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int64_t j = jb + tid + (int64_t)u * kBlock;
+      ok[u] = j < j1;
+      jj[u] = ok[u] ? j : j1 - 1;  // surplus lanes of the last row redo its last slot, stores masked
+      lo[u] = 0;
+      hi[u] = kTile - 1;
+    }
+    // first source s in the tile with nb[s] > j: exactly log2(kTile) halvings, branch-free
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int mid = (lo[u] + hi[u]) >> 1;
+        const bool gt = (int64_t)nb[mid] > jj[u];
+        hi[u] = gt ? mid : hi[u];
+        lo[u] = gt ? lo[u] : mid + 1;
+      }
+    }
+    typename Policy::Out out[NU];
+    float w[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) w[u] = P.compute(jj[u], lo[u], out[u]);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (ok[u]) {
+        P.store(jj[u], A.out_lo, base + (uint64_t)lo[u], out[u]);
+        tmax = w[u] > tmax ? w[u] : tmax;
+      }
+    }
+  };
+  for (int64_t jb = j0; jb < j1; jb += 4 * (int64_t)kBlock) {
+    const int64_t rows = (j1 - jb + kBlock - 1) / kBlock;  // wave-uniform
+    if (rows >= 4) group(IntC<4>{}, jb);
+    else if (rows == 3) group(IntC<3>{}, jb);
+    else if (rows == 2) group(IntC<2>{}, jb);
+    else group(IntC<1>{}, jb);
+  }
+  static_assert(kTile == 1024, "the ancestor search assumes 10 halvings");
+  if (max_partials) {
+    const float bm = block_max(tmax, shf);
+    if (tid == 0) max_partials[b] = bm;
+  }
+}
+
+
 }  // namespace gjx

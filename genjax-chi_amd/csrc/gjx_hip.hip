@@ -14,7 +14,6 @@
 #include <math.h>
 #include <new>
 #include <string.h>
-#include <type_traits>
 
 #include "gjx_plan_jit.hpp"
 
@@ -604,29 +603,6 @@ __global__ void k_lse_finish(const float* m_ptr, const uint64_t* q_ptr, int frac
   out[0] = m_ptr[0] + m_log(qf);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Systematic resampling, tile-centric: workgroup b owns SOURCE particles [b*1024, (b+1)*1024).
-// It rebuilds the fixed-point CDF of its tile in LDS (prefix of the preceding tiles comes from the
-// per-tile sums), turns it into "teeth below" counts, and serves the contiguous range of OUTPUT
-// slots whose teeth fall into its mass — so both the source reads (one tile of lw / state) and
-// the output writes are coalesced, and ancestors never round-trip through HBM unless asked for.
-// The per-output work (propagate + weight for the fused SMC models) is the template policy.
-// ------------------------------------------------------------------------------------------------
-struct ResampleArgs {
-  const float* lw;            // [n] source log-weights
-  const float* m_ptr;         // max of lw
-  const uint64_t* tile_sums;  // [ntiles] fixed-point mass of every source tile
-  uint64_t n, ntiles;
-  uint64_t n_out;             // number of comb teeth (global output slots)
-  int64_t out_lo, out_hi;     // slots this launch serves
-  int frac;
-  int lw_vec;                 // lw is 16-byte aligned: tiles may use float4 loads
-  Key rkey;                   // resampling key (its sub-stream 0 gives the comb offset)
-  int rkey_has_fold;
-  uint32_t rkey_fold;
-  uint64_t* q_total_out;      // nullable: block 0 stores the total mass (= sum of tile_sums)
-};
-
 // A policy turns (output slot j, its ancestor) into the new particle.  `compute` is pure so the
 // kernel can run four slots' cipher / transform chains interleaved; `store` writes the results.
 struct AncestorOnly {
@@ -639,125 +615,8 @@ struct AncestorOnly {
 };
 
 template <int IMPL, class Policy>
-__global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P,
-                                                     float* max_partials) {
-  __shared__ uint64_t sh64[kBlock / kWave];
-  __shared__ float shf[kBlock / kWave];
-  __shared__ int32_t nb[kTile];  // teeth below the inclusive CDF of each source in the tile
-  const uint64_t b = blockIdx.x;
-  const int tid = threadIdx.x;
-  const uint64_t base = b * kTile;
-
-  // Issue this tile's loads first: their HBM latency overlaps the tile-mass prefix reduction.
-  float lw4[4];
-  if (A.lw_vec && base + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
-    const float4 v = reinterpret_cast<const float4*>(A.lw + base)[tid];
-    lw4[0] = v.x; lw4[1] = v.y; lw4[2] = v.z; lw4[3] = v.w;
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint64_t i = base + 4 * (uint64_t)tid + r;
-      lw4[r] = i < A.n ? A.lw[i] : -__builtin_inff();
-    }
-  }
-  P.fetch_source(base, A.n, tid);  // registers now, LDS after the scan
-
-  // prefix / total of tile masses (u64, exact)
-  uint64_t pre = 0, tot = 0;
-  for (uint64_t k = tid; k < A.ntiles; k += kBlock) {
-    const uint64_t v = A.tile_sums[k];
-    tot += v;
-    if (k < b) pre += v;
-  }
-  pre = block_sum(pre, sh64);
-  tot = block_sum(tot, sh64);
-  if (A.q_total_out && b == 0 && tid == 0) A.q_total_out[0] = tot;
-
-  const Stream<IMPL> rs(A.rkey, A.rkey_has_fold != 0, A.rkey_fold);
-  const double u0 = u0_from_bits(rs.bits64(0));
-  const double scale = (double)A.n_out / (double)tot;
-  const float m = A.m_ptr[0];
-
-  // tile CDF: each thread owns 4 CONSECUTIVE sources (base + 4*tid + r) so the scan is a
-  // thread-local prefix plus one block scan.
-  uint64_t q[4];
-  uint64_t local = 0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint64_t i = base + 4 * (uint64_t)tid + r;
-    q[r] = i < A.n ? fixw(lw4[r], m, A.frac) : 0;
-    local += q[r];
-  }
-  uint64_t tile_total;
-  uint64_t run = pre + block_scan_excl(local, sh64, tile_total);
-  const int64_t n_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint64_t i = base + 4 * (uint64_t)tid + r;
-    run += q[r];
-    // the last real particle (and any padding after it) closes the comb at n_out
-    const int64_t t = (i + 1 >= A.n) ? (int64_t)A.n_out
-                                     : teeth_below(run, scale, u0, (int64_t)A.n_out);
-    nb[4 * tid + r] = (int32_t)t;
-  }
-  P.stage_source(tid);
-  __syncthreads();
-  const int64_t n_hi = nb[kTile - 1];
-  const int64_t j0 = n_lo > A.out_lo ? n_lo : A.out_lo;
-  const int64_t j1 = n_hi < A.out_hi ? n_hi : A.out_hi;
-
-  // Output slots in groups of up to 4 rows (256 slots each) per pass: NU independent ancestor
-  // searches and NU independent propagate chains are in flight per lane (ILP); the group size is
-  // wave-uniform, so rows past the block's range cost nothing.  Stores close the group.
-  float tmax = -__builtin_inff();
-  auto group = [&](auto nu_tag, int64_t jb) {
-    constexpr int NU = decltype(nu_tag)::value;
-    int64_t jj[NU];
-    bool ok[NU];
-    int lo[NU], hi[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int64_t j = jb + tid + (int64_t)u * kBlock;
-      ok[u] = j < j1;
-      jj[u] = ok[u] ? j : j1 - 1;  // surplus lanes of the last row redo its last slot, stores masked
-      lo[u] = 0;
-      hi[u] = kTile - 1;
-    }
-    // first source s in the tile with nb[s] > j: exactly log2(kTile) halvings, branch-free
-#pragma unroll
-    for (int it = 0; it < 10; ++it) {
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const int mid = (lo[u] + hi[u]) >> 1;
-        const bool gt = (int64_t)nb[mid] > jj[u];
-        hi[u] = gt ? mid : hi[u];
-        lo[u] = gt ? lo[u] : mid + 1;
-      }
-    }
-    typename Policy::Out out[NU];
-    float w[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) w[u] = P.compute(jj[u], lo[u], out[u]);
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      if (ok[u]) {
-        P.store(jj[u], A.out_lo, base + (uint64_t)lo[u], out[u]);
-        tmax = w[u] > tmax ? w[u] : tmax;
-      }
-    }
-  };
-  for (int64_t jb = j0; jb < j1; jb += 4 * (int64_t)kBlock) {
-    const int64_t rows = (j1 - jb + kBlock - 1) / kBlock;  // wave-uniform
-    if (rows >= 4) group(std::integral_constant<int, 4>{}, jb);
-    else if (rows == 3) group(std::integral_constant<int, 3>{}, jb);
-    else if (rows == 2) group(std::integral_constant<int, 2>{}, jb);
-    else group(std::integral_constant<int, 1>{}, jb);
-  }
-  static_assert(kTile == 1024, "the ancestor search assumes 10 halvings");
-  if (max_partials) {
-    const float bm = block_max(tmax, shf);
-    if (tid == 0) max_partials[b] = bm;
-  }
+__global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P, float* max_partials) {
+  resample_body<IMPL>(A, P, max_partials);
 }
 
 // Per-tile fixed-point mass of local log-weights, written at the global tile offset.
@@ -1273,16 +1132,52 @@ struct gjx_plan {
   std::mutex jit_mu;
 };
 
-static bool arg_ok(const gjx_arg& a, int s) {
+// Argument validity.  n_state / n_obs > -1 switch on the SMC-plan kinds (STATE only if allow_state).
+static bool arg_ok(const gjx_arg& a, int s, int n_state = -1, int n_obs = -1, bool allow_state = false) {
   switch (a.kind) {
     case GJX_ARG_CONST: return true;
     case GJX_ARG_SITE: return a.ref >= 0 && a.ref < s;
-    case GJX_ARG_INPUT: return a.ref >= 0 && a.ref < 16;
+    case GJX_ARG_INPUT: return n_state < 0 && a.ref >= 0 && a.ref < 16;
     case GJX_ARG_TABLE: return a.ref >= 0 && a.ref < s && a.table != nullptr;
+    case GJX_ARG_STATE: return allow_state && a.ref >= 0 && a.ref < n_state;
+    case GJX_ARG_OBS: return n_obs >= 0 && a.ref >= 0 && a.ref < n_obs;
     default: return false;
   }
 }
 static CArg carg(const gjx_arg& a) { return CArg{a.kind, a.ref, 0, a.ref, a.scale, a.offset, a.table}; }
+
+// Validate one site and convert it (hoisting per-site constants with the same spec functions).
+static bool convert_site(const gjx_site& st, int s, CSite& c, int n_state = -1, int n_obs = -1,
+                         bool allow_state = false) {
+  bool ok = st.dist >= 0 && st.dist <= GJX_DIST_CATEGORICAL && arg_ok(st.arg[0], s, n_state, n_obs, allow_state);
+  const bool two_args = st.dist != GJX_DIST_BERNOULLI && st.dist != GJX_DIST_CATEGORICAL;
+  if (ok && two_args) ok = arg_ok(st.arg[1], s, n_state, n_obs, allow_state);
+  if (ok && st.observed) {
+    if (n_state < 0) ok = st.obs.kind == GJX_ARG_CONST || (st.obs.kind == GJX_ARG_INPUT && st.obs.ref >= 0 && st.obs.ref < 16);
+    else ok = st.obs.kind == GJX_ARG_CONST || (st.obs.kind == GJX_ARG_OBS && st.obs.ref >= 0 && st.obs.ref < n_obs);
+  }
+  if (ok && st.dist == GJX_DIST_CATEGORICAL)
+    ok = st.logits && st.n_cat > 0 && st.n_rows > 0 && (st.cat_mode == 0 || st.cat_mode == 1);
+  if (!ok) return false;
+  memset(&c, 0, sizeof(c));
+  c.dist = st.dist; c.observed = st.observed; c.out_col = st.out_col;
+  c.n_cat = st.n_cat; c.n_rows = st.n_rows; c.cat_mode = st.cat_mode;
+  c.slot = -1;
+  c.a0 = carg(st.arg[0]); c.a1 = carg(st.arg[1]); c.obs = carg(st.obs);
+  if (!two_args) c.a1.kind = GJX_ARG_CONST;
+  c.logits = st.logits;
+  // Hoist per-site constants: same spec functions, evaluated once on the host (IEEE-exact ops
+  // give the same bits as evaluating them per particle on the device).
+  const bool c0 = st.arg[0].kind == GJX_ARG_CONST, c1 = st.arg[1].kind == GJX_ARG_CONST;
+  if (st.dist == GJX_DIST_NORMAL && c1) {
+    c.pre = 1; c.pre0 = normal_rs(st.arg[1].offset); c.pre1 = normal_lognorm(st.arg[1].offset);
+  } else if (st.dist == GJX_DIST_GAMMA && c0 && c1) {
+    c.pre = 1; c.pre1 = gamma_lognorm(st.arg[0].offset, st.arg[1].offset);
+  } else if (st.dist == GJX_DIST_BETA && c0 && c1) {
+    c.pre = 1; c.pre1 = beta_lbeta(st.arg[0].offset, st.arg[1].offset);
+  }
+  return true;
+}
 
 int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
   if (!sites || !out || n_sites <= 0 || n_sites > GJX_MAX_SITES) return GJX_ERR_INVALID;
@@ -1294,38 +1189,14 @@ int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
   int last_use[GJX_MAX_SITES];
   for (int s = 0; s < n_sites; ++s) last_use[s] = -1;
   for (int s = 0; s < n_sites; ++s) {
-    const gjx_site& st = sites[s];
-    bool ok = st.dist >= 0 && st.dist <= GJX_DIST_CATEGORICAL && arg_ok(st.arg[0], s);
-    const bool two_args = st.dist != GJX_DIST_BERNOULLI && st.dist != GJX_DIST_CATEGORICAL;
-    if (ok && two_args) ok = arg_ok(st.arg[1], s);
-    if (ok && st.observed) ok = st.obs.kind == GJX_ARG_CONST || (st.obs.kind == GJX_ARG_INPUT && st.obs.ref >= 0 && st.obs.ref < 16);
-    if (ok && st.dist == GJX_DIST_CATEGORICAL)
-      ok = st.logits && st.n_cat > 0 && st.n_rows > 0 && (st.cat_mode == 0 || st.cat_mode == 1);
-    if (!ok) {
+    CSite& c = p->host[s];
+    if (!convert_site(sites[s], s, c)) {
       delete p;
       return GJX_ERR_INVALID;
     }
-    p->dist_mask |= 1 << st.dist;
-    CSite& c = p->host[s];
-    memset(&c, 0, sizeof(c));
-    c.dist = st.dist; c.observed = st.observed; c.out_col = st.out_col;
-    c.n_cat = st.n_cat; c.n_rows = st.n_rows; c.cat_mode = st.cat_mode;
-    c.slot = -1;
-    c.a0 = carg(st.arg[0]); c.a1 = carg(st.arg[1]); c.obs = carg(st.obs);
-    if (!two_args) c.a1.kind = GJX_ARG_CONST;
-    c.logits = st.logits;
+    p->dist_mask |= 1 << sites[s].dist;
     for (CArg* a : {&c.a0, &c.a1})
       if (a->kind == GJX_ARG_SITE || a->kind == GJX_ARG_TABLE) last_use[a->ref] = s;
-    // Hoist per-site constants: same spec functions, evaluated once on the host (IEEE-exact ops
-    // give the same bits as evaluating them per particle on the device).
-    const bool c0 = st.arg[0].kind == GJX_ARG_CONST, c1 = st.arg[1].kind == GJX_ARG_CONST;
-    if (st.dist == GJX_DIST_NORMAL && c1) {
-      c.pre = 1; c.pre0 = normal_rs(st.arg[1].offset); c.pre1 = normal_lognorm(st.arg[1].offset);
-    } else if (st.dist == GJX_DIST_GAMMA && c0 && c1) {
-      c.pre = 1; c.pre1 = gamma_lognorm(st.arg[0].offset, st.arg[1].offset);
-    } else if (st.dist == GJX_DIST_BETA && c0 && c1) {
-      c.pre = 1; c.pre1 = beta_lbeta(st.arg[0].offset, st.arg[1].offset);
-    }
   }
   // LDS slots by liveness (linear scan): a value occupies a slot from its site to its last use.
   int slot_free_at[GJX_MAX_SITES];  // slot -> first site index at which it is free again
@@ -1761,6 +1632,113 @@ int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_
   if (!cfg_ok(cfg) || !tile_sums || !q_out) return GJX_ERR_INVALID;
   k_reduce_sum<<<1, kBlock, 0, S(s)>>>(tile_sums, ntiles_of(cfg->n_total), q_out, 0, nullptr, 0, nullptr, nullptr);
   return launch_status();
+}
+
+// ---- bootstrap SMC for a user model: generated policy in the fused resample kernel -----------------
+struct gjx_smc_plan {
+  int n_state, n_obs, n_init, n_step;
+  CSite init[GJX_MAX_SITES], step[GJX_MAX_SITES];
+  CArg init_state[GJX_SMC_MAX_STATE], next_state[GJX_SMC_MAX_STATE];
+  gjx_jit::CompiledSmc jit[2];
+  std::mutex mu;
+};
+
+int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
+  if (!m || !out || m->n_state < 1 || m->n_state > GJX_SMC_MAX_STATE || m->n_obs < 0 || m->n_obs > GJX_SMC_MAX_OBS ||
+      !m->init_sites || !m->step_sites || m->n_init_sites <= 0 || m->n_init_sites > GJX_MAX_SITES ||
+      m->n_step_sites <= 0 || m->n_step_sites > GJX_MAX_SITES)
+    return GJX_ERR_INVALID;
+  gjx_smc_plan* p = new (std::nothrow) gjx_smc_plan;
+  if (!p) return GJX_ERR_LAUNCH;
+  p->n_state = m->n_state; p->n_obs = m->n_obs; p->n_init = m->n_init_sites; p->n_step = m->n_step_sites;
+  bool ok = true;
+  for (int s = 0; ok && s < p->n_init; ++s) ok = convert_site(m->init_sites[s], s, p->init[s], m->n_state, m->n_obs, false);
+  for (int s = 0; ok && s < p->n_step; ++s) ok = convert_site(m->step_sites[s], s, p->step[s], m->n_state, m->n_obs, true);
+  for (int k = 0; ok && k < p->n_state; ++k) {
+    ok = arg_ok(m->init_state[k], p->n_init, m->n_state, m->n_obs, false) && m->init_state[k].kind != GJX_ARG_TABLE &&
+         arg_ok(m->next_state[k], p->n_step, m->n_state, m->n_obs, true) && m->next_state[k].kind != GJX_ARG_TABLE;
+    p->init_state[k] = carg(m->init_state[k]);
+    p->next_state[k] = carg(m->next_state[k]);
+  }
+  if (!ok) {
+    delete p;
+    return GJX_ERR_INVALID;
+  }
+  *out = p;
+  return GJX_OK;
+}
+int gjx_smc_plan_destroy(gjx_smc_plan* p) {
+  delete p;  // compiled modules are owned by the process-wide cache
+  return GJX_OK;
+}
+
+static std::string smc_plan_source(const gjx_smc_plan* plan, int impl) {
+  gjx_jit::GenSmc<CSite, CArg> g;
+  g.impl = impl; g.init_sites = plan->init; g.n_init = plan->n_init; g.step_sites = plan->step;
+  g.n_step = plan->n_step; g.init_state = plan->init_state; g.next_state = plan->next_state; g.n_state = plan->n_state;
+  return g.run();
+}
+int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl) {
+  if (!p || (impl != 0 && impl != 1)) return GJX_ERR_INVALID;
+  if (std::getenv("GJX_PLAN_JIT_DUMP")) fprintf(stderr, "%s\n", smc_plan_source(p, impl).c_str());
+  return gjx_jit::compile_only(smc_plan_source(p, impl)) ? GJX_OK : GJX_ERR_UNSUPPORTED;
+}
+
+int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
+                     uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out,
+                     void* ws, size_t ws_bytes, gjx_stream s) {
+  if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !plan || !out_max || !out_q ||
+      !state_out || !logw_out || (plan->n_obs > 0 && !obs_host))
+    return GJX_ERR_INVALID;
+  if (!gjx_jit::enabled()) return GJX_ERR_UNSUPPORTED;  // SMC plans exist only as specialised kernels
+  gjx_jit::CompiledSmc& c = plan->jit[cfg->impl];
+  if (c.state == 0) {
+    std::lock_guard<std::mutex> lock(plan->mu);
+    if (c.state == 0) {
+      c.state = gjx_jit::compile_smc(smc_plan_source(plan, cfg->impl), &c) ? 1 : -1;
+    }
+  }
+  if (c.state != 1) return GJX_ERR_UNSUPPORTED;
+  const uint64_t N = cfg->n_total, nt = ntiles_of(N);
+  const int D = plan->n_state;
+  Carver cv{(char*)ws, ws ? ws_bytes : 0};
+  float* st_ws[GJX_SMC_MAX_STATE];
+  for (int k = 0; k < D; ++k) st_ws[k] = cv.take<float>(N);
+  float* lw_ws = cv.take<float>(N);
+  float* mp = cv.take<float>(nt);
+  uint64_t* tiles = cv.take<uint64_t>(nt);
+  if (!cv.ok) return GJX_ERR_WORKSPACE;
+  for (int k = 0; k < D; ++k)
+    if (!state_out[k]) return GJX_ERR_INVALID;
+  const int last = (cfg->n_steps - 1) & 1;
+  float* stb[2][GJX_SMC_MAX_STATE];
+  float* lwb[2];
+  for (int k = 0; k < D; ++k) { stb[last][k] = state_out[k]; stb[last ^ 1][k] = st_ws[k]; }
+  lwb[last] = logw_out; lwb[last ^ 1] = lw_ws;
+  for (int t = 0; t < cfg->n_steps; ++t) {
+    const int cur = t & 1, prv = cur ^ 1;
+    PlanPolicyArgs PA;
+    memset(&PA, 0, sizeof(PA));
+    for (int k = 0; k < D; ++k) { PA.prev_state[k] = stb[prv][k]; PA.state_out[k] = stb[cur][k]; }
+    PA.logw_out = lwb[cur];
+    PA.anc_out = ancestors_out ? ancestors_out + (size_t)t * N : nullptr;
+    PA.step_key = Key{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
+    for (int k = 0; k < plan->n_obs; ++k) PA.obs[k] = obs_host[(size_t)t * (size_t)plan->n_obs + k];
+    if (t == 0) {
+      uint64_t first = 0, nl = N;
+      void* args[] = {&PA, &first, &nl, &mp};
+      if (hipModuleLaunchKernel(c.init, (unsigned)nt, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess)
+        return GJX_ERR_LAUNCH;
+    } else {
+      ResampleArgs A = smc_resample_args(cfg, t, lwb[prv], out_max + (t - 1), tiles, out_q + (t - 1));
+      void* args[] = {&A, &PA, &mp};
+      if (hipModuleLaunchKernel(c.step, (unsigned)nt, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess)
+        return GJX_ERR_LAUNCH;
+    }
+    const int rc = gjx_smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s);
+    if (rc) return rc;
+  }
+  return gjx_smc_finish(cfg, tiles, out_q + (cfg->n_steps - 1), s);
 }
 
 }  // extern "C"

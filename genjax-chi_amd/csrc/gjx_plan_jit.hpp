@@ -37,16 +37,19 @@ inline std::string plit(const void* p) {
   return b;
 }
 
+// Emits the walk of one site table as straight-line HIP, in exactly the interpreter's operation
+// order.  mode 0 = importance (particle index `i`, particle key `pkey`, input columns, score and
+// output columns); mode 1 = SMC step / init (slot `j`, `a.step_key`, ancestor state `st_k`,
+// observation constants `a.obs[]`, weight only).
 template <class CSiteT, class CArgT>
-struct Gen {
-  std::ostringstream o;
-  int impl;
+struct SiteEmitter {
+  std::ostringstream& o;
+  int impl, mode;
   const CSiteT* sites;
   int n_sites;
-  int min_waves = 0;  // __launch_bounds__ waves-per-SIMD hint (0 = none)
+  const char* ind;
 
   static bool is_int(const CSiteT& s) { return s.dist >= GJX_DIST_BERNOULLI; }
-
   std::string val_f32(int site) const {
     return is_int(sites[site]) ? "(float)vi" + std::to_string(site) : "vf" + std::to_string(site);
   }
@@ -54,107 +57,110 @@ struct Gen {
     return is_int(sites[site]) ? "vi" + std::to_string(site)
                                : "(int32_t)__builtin_rintf(vf" + std::to_string(site) + ")";
   }
-  // The value of an argument, in exactly the interpreter's operation order.
   std::string arg(const CArgT& a) const {
     switch (a.kind) {
       case GJX_ARG_CONST: return flit(a.offset);
       case GJX_ARG_SITE: return "((" + flit(a.scale) + " * " + val_f32(a.ref_site) + ") + " + flit(a.offset) + ")";
       case GJX_ARG_INPUT:
         return "((" + flit(a.scale) + " * cols.in[" + std::to_string(a.ref) + "][i]) + " + flit(a.offset) + ")";
+      case GJX_ARG_STATE: return "((" + flit(a.scale) + " * st_" + std::to_string(a.ref) + ") + " + flit(a.offset) + ")";
+      case GJX_ARG_OBS: return "((" + flit(a.scale) + " * a.obs[" + std::to_string(a.ref) + "]) + " + flit(a.offset) + ")";
       default: return plit(a.table) + "[" + val_i32(a.ref_site) + "]";
     }
   }
+  // does any latent site need the per-particle key (threefry always; philox only multi-word samplers)?
+  bool needs_pk() const {
+    for (int q = 0; q < n_sites; ++q) {
+      const CSiteT& st = sites[q];
+      if (st.observed) continue;
+      if (impl == 0) return true;
+      if (st.dist == GJX_DIST_GAMMA || st.dist == GJX_DIST_BETA || (st.dist == GJX_DIST_CATEGORICAL && st.cat_mode == 0))
+        return true;
+    }
+    return false;
+  }
 
-  std::string run() {
+  void run() {
     const std::string I = std::to_string(impl);
-    o << "#include \"gjx_device.hpp\"\nusing namespace gjx;\n";
-    o << "__device__ __forceinline__ float jrow_max(const float* l, uint32_t K){ float m=l[0]; for(uint32_t c=1;c<K;++c) m = l[c]>m?l[c]:m; return m; }\n";
-    o << "__device__ __forceinline__ float jrow_lse(const float* l, uint32_t K){ const float m=jrow_max(l,K); float acc=0.0f; for(uint32_t c=0;c<K;++c) acc = acc + m_exp(l[c]-m); return m + m_log(acc); }\n";
-    o << "__device__ __forceinline__ int32_t jcat_invcdf(const float* l, uint32_t K, uint32_t bits){ const float m=jrow_max(l,K); uint64_t Q=0; for(uint32_t c=0;c<K;++c) Q += cat_fix(l[c],m); const uint64_t thr=((uint64_t)bits*Q)>>32; uint64_t C=0; for(uint32_t c=0;c<K;++c){ C += cat_fix(l[c],m); if (C>thr) return (int32_t)c; } return (int32_t)(K-1); }\n";
-    o << "template <int IMPL> __device__ __forceinline__ int32_t jcat_gumbel(const float* l, uint32_t K, const Stream<IMPL>& st){ int32_t best=0; float bv=-__builtin_inff(); for(uint32_t c=0;c<K;++c){ const float v = l[c] + gumbel_from_bits(st.bits32(c)); if (v>bv || c==0){ bv=v; best=(int32_t)c; } } return best; }\n";
-    // One workgroup per 256-particle row (grid-stride): short blocks keep every SIMD's wave slots
-    // full even at 1e6 particles (15 rows per lane), where a 4-row block would serialise its rows.
-    o << "extern \"C\" __global__ __launch_bounds__(256" << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
-      << ") void gjx_plan_kernel_" << (impl == 0 ? "threefry" : "philox") << "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s) {\n";
-    o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
-    o << "  for (uint64_t row = blockIdx.x; row * 256 < n; row += gridDim.x) {\n";
-    o << "    float tmax = -__builtin_inff();\n    bool live = false;\n";
-    o << "    {\n";
-    o << "      const uint64_t i = row * 256 + threadIdx.x;\n";
-    o << "      if (i < n) {\n";
-    o << "        const Key pkey = key_at<" << I << ">(ks, i);\n";
-    o << "        float w = 0.0f, sc = 0.0f;\n";
     int cur_blk = -1;
     for (int q = 0; q < n_sites; ++q) {
       const CSiteT& st = sites[q];
       const std::string Q = std::to_string(q);
       const uint32_t fold = (uint32_t)(q + 1);
-      o << "        // site " << q << " dist " << st.dist << (st.observed ? " observed" : " latent") << "\n";
+      o << ind << "// site " << q << " dist " << st.dist << (st.observed ? " observed" : " latent") << "\n";
       std::string row;
       if (st.dist == GJX_DIST_CATEGORICAL) {
         std::string rr;
         if (st.a0.kind == GJX_ARG_SITE) rr = val_i32(st.a0.ref_site);
         else if (st.a0.kind == GJX_ARG_CONST) rr = "(int32_t)__builtin_rintf(" + flit(st.a0.offset) + ")";
         else rr = "(int32_t)__builtin_rintf(" + arg(st.a0) + ")";
-        o << "        int32_t rr" << Q << " = " << rr << "; rr" << Q << " = rr" << Q << " < 0 ? 0 : (rr" << Q
+        o << ind << "int32_t rr" << Q << " = " << rr << "; rr" << Q << " = rr" << Q << " < 0 ? 0 : (rr" << Q
           << " >= " << st.n_rows << " ? " << st.n_rows - 1 << " : rr" << Q << ");\n";
-        o << "        const float* row" << Q << " = " << plit(st.logits) << " + (size_t)rr" << Q << " * " << st.n_cat << ";\n";
+        o << ind << "const float* row" << Q << " = " << plit(st.logits) << " + (size_t)rr" << Q << " * " << st.n_cat << ";\n";
         row = "row" + Q;
       } else {
-        o << "        const float a0_" << Q << " = " << arg(st.a0) << ";\n";
-        if (st.dist != GJX_DIST_BERNOULLI) o << "        const float a1_" << Q << " = " << arg(st.a1) << ";\n";
+        o << ind << "const float a0_" << Q << " = " << arg(st.a0) << ";\n";
+        if (st.dist != GJX_DIST_BERNOULLI) o << ind << "const float a1_" << Q << " = " << arg(st.a1) << ";\n";
       }
       const bool isint = is_int(st);
       if (st.observed) {
-        const std::string ov = st.obs.kind == GJX_ARG_CONST ? flit(st.obs.offset)
-                                                            : "cols.in[" + std::to_string(st.obs.ref) + "][i]";
-        if (isint) o << "        const int32_t vi" << Q << " = (int32_t)__builtin_rintf(" << ov << ");\n";
-        else o << "        const float vf" << Q << " = " << ov << ";\n";
+        std::string ov;
+        if (st.obs.kind == GJX_ARG_CONST) ov = flit(st.obs.offset);
+        else if (st.obs.kind == GJX_ARG_OBS) ov = "a.obs[" + std::to_string(st.obs.ref) + "]";
+        else ov = "cols.in[" + std::to_string(st.obs.ref) + "][i]";
+        if (isint) o << ind << "const int32_t vi" << Q << " = (int32_t)__builtin_rintf(" << ov << ");\n";
+        else o << ind << "const float vf" << Q << " = " << ov << ";\n";
       } else {
         const bool one_word = st.dist == GJX_DIST_NORMAL || st.dist == GJX_DIST_BERNOULLI ||
                               (st.dist == GJX_DIST_CATEGORICAL && st.cat_mode == 1);
         if (one_word) {
           if (impl == 1) {
-            const int blk = (int)(fold >> 2);
+            // importance: block fold>>2, word fold&3 of ("BITS", key pkey); SMC: block (fold-1)>>2,
+            // word (fold-1)&3 of ("SMCS", step key, slot)
+            const int blk = mode == 0 ? (int)(fold >> 2) : (int)((fold - 1u) >> 2);
+            const uint32_t word = mode == 0 ? (fold & 3u) : ((fold - 1u) & 3u);
             if (blk != cur_blk) {
               cur_blk = blk;
-              o << "        uint32_t pw" << blk << "_0, pw" << blk << "_1, pw" << blk << "_2, pw" << blk << "_3;\n";
-              o << "        philox4x32(pkey.k0, pkey.k1, 0u, " << blk << "u, 2u, kTagBits, pw" << blk << "_0, pw" << blk
-                << "_1, pw" << blk << "_2, pw" << blk << "_3);\n";
+              o << ind << "uint32_t pw" << blk << "_0, pw" << blk << "_1, pw" << blk << "_2, pw" << blk << "_3;\n";
+              if (mode == 0)
+                o << ind << "philox4x32(pkey.k0, pkey.k1, 0u, " << blk << "u, 2u, kTagBits, pw" << blk << "_0, pw" << blk
+                  << "_1, pw" << blk << "_2, pw" << blk << "_3);\n";
+              else
+                o << ind << "philox4x32(a.step_key.k0, a.step_key.k1, (uint32_t)j, (uint32_t)((uint64_t)j >> 32), " << blk
+                  << "u, kTagSmc, pw" << blk << "_0, pw" << blk << "_1, pw" << blk << "_2, pw" << blk << "_3);\n";
             }
-            o << "        const uint32_t bits" << Q << " = pw" << blk << "_" << (fold & 3u) << ";\n";
+            o << ind << "const uint32_t bits" << Q << " = pw" << blk << "_" << word << ";\n";
           } else {
-            o << "        const uint32_t bits" << Q << " = Stream<0>(pkey, true, " << fold << "u).bits32(0);\n";
+            o << ind << "const uint32_t bits" << Q << " = Stream<0>(pkey, true, " << fold << "u).bits32(0);\n";
           }
         }
         switch (st.dist) {
           case GJX_DIST_NORMAL:
-            o << "        const float t" << Q << " = a1_" << Q << " * std_normal(bits" << Q << ");\n";
-            o << "        const float vf" << Q << " = a0_" << Q << " + t" << Q << ";\n";
+            o << ind << "const float t" << Q << " = a1_" << Q << " * std_normal(bits" << Q << ");\n";
+            o << ind << "const float vf" << Q << " = a0_" << Q << " + t" << Q << ";\n";
             break;
           case GJX_DIST_BERNOULLI:
-            o << "        const int32_t vi" << Q << " = uniform01(bits" << Q << ") < a0_" << Q << " ? 1 : 0;\n";
+            o << ind << "const int32_t vi" << Q << " = uniform01(bits" << Q << ") < a0_" << Q << " ? 1 : 0;\n";
             break;
           case GJX_DIST_GAMMA:
-            o << "        const Stream<" << I << "> strm" << Q << "(pkey, true, " << fold << "u);\n";
-            o << "        const float vf" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 0, a0_" << Q << ") / a1_" << Q << ";\n";
+            o << ind << "const Stream<" << I << "> strm" << Q << "(pkey, true, " << fold << "u);\n";
+            o << ind << "const float vf" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 0, a0_" << Q << ") / a1_" << Q << ";\n";
             break;
           case GJX_DIST_BETA:
-            o << "        const Stream<" << I << "> strm" << Q << "(pkey, true, " << fold << "u);\n";
-            o << "        const float g1_" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 0, a0_" << Q << ");\n";
-            o << "        const float g2_" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 1, a1_" << Q << ");\n";
-            o << "        const float vf" << Q << " = g1_" << Q << " / (g1_" << Q << " + g2_" << Q << ");\n";
+            o << ind << "const Stream<" << I << "> strm" << Q << "(pkey, true, " << fold << "u);\n";
+            o << ind << "const float g1_" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 0, a0_" << Q << ");\n";
+            o << ind << "const float g2_" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 1, a1_" << Q << ");\n";
+            o << ind << "const float vf" << Q << " = g1_" << Q << " / (g1_" << Q << " + g2_" << Q << ");\n";
             break;
           default:
             if (st.cat_mode == 0) {
-              o << "        const Stream<" << I << "> strm" << Q << "(pkey, true, " << fold << "u);\n";
-              o << "        const int32_t vi" << Q << " = jcat_gumbel<" << I << ">(" << row << ", " << st.n_cat << "u, strm" << Q << ");\n";
+              o << ind << "const Stream<" << I << "> strm" << Q << "(pkey, true, " << fold << "u);\n";
+              o << ind << "const int32_t vi" << Q << " = jcat_gumbel<" << I << ">(" << row << ", " << st.n_cat << "u, strm" << Q << ");\n";
             } else {
-              o << "        const int32_t vi" << Q << " = jcat_invcdf(" << row << ", " << st.n_cat << "u, bits" << Q << ");\n";
+              o << ind << "const int32_t vi" << Q << " = jcat_invcdf(" << row << ", " << st.n_cat << "u, bits" << Q << ");\n";
             }
         }
       }
-      // log-density
       std::string lp;
       const std::string v = (isint ? "vi" : "vf") + Q;
       switch (st.dist) {
@@ -175,11 +181,48 @@ struct Gen {
           lp = "((" + v + " < 0 || " + v + " >= " + std::to_string(st.n_cat) + ") ? -__builtin_inff() : " + row + "[" + v +
                "] - jrow_lse(" + row + ", " + std::to_string(st.n_cat) + "u))";
       }
-      o << "        { const float lp = " << lp << "; sc = sc + lp;" << (st.observed ? " w = w + lp;" : "") << " }\n";
-      if (st.out_col >= 0)
-        o << "        reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "])[i] = "
+      o << ind << "{ const float lp = " << lp << "; sc = sc + lp;" << (st.observed ? " w = w + lp;" : "") << " }\n";
+      if (mode == 0 && st.out_col >= 0)
+        o << ind << "reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "])[i] = "
           << (isint ? "(uint32_t)" + v : "f2u(" + v + ")") << ";\n";
     }
+  }
+};
+
+inline void emit_prelude(std::ostringstream& o) {
+  o << "#include \"gjx_device.hpp\"\nusing namespace gjx;\n";
+  o << "__device__ __forceinline__ float jrow_max(const float* l, uint32_t K){ float m=l[0]; for(uint32_t c=1;c<K;++c) m = l[c]>m?l[c]:m; return m; }\n";
+  o << "__device__ __forceinline__ float jrow_lse(const float* l, uint32_t K){ const float m=jrow_max(l,K); float acc=0.0f; for(uint32_t c=0;c<K;++c) acc = acc + m_exp(l[c]-m); return m + m_log(acc); }\n";
+  o << "__device__ __forceinline__ int32_t jcat_invcdf(const float* l, uint32_t K, uint32_t bits){ const float m=jrow_max(l,K); uint64_t Q=0; for(uint32_t c=0;c<K;++c) Q += cat_fix(l[c],m); const uint64_t thr=((uint64_t)bits*Q)>>32; uint64_t C=0; for(uint32_t c=0;c<K;++c){ C += cat_fix(l[c],m); if (C>thr) return (int32_t)c; } return (int32_t)(K-1); }\n";
+  o << "template <int IMPL> __device__ __forceinline__ int32_t jcat_gumbel(const float* l, uint32_t K, const Stream<IMPL>& st){ int32_t best=0; float bv=-__builtin_inff(); for(uint32_t c=0;c<K;++c){ const float v = l[c] + gumbel_from_bits(st.bits32(c)); if (v>bv || c==0){ bv=v; best=(int32_t)c; } } return best; }\n";
+}
+
+template <class CSiteT, class CArgT>
+struct Gen {
+  std::ostringstream o;
+  int impl;
+  const CSiteT* sites;
+  int n_sites;
+  int min_waves = 0;  // __launch_bounds__ waves-per-SIMD hint (0 = none)
+
+  std::string run() {
+    const std::string I = std::to_string(impl);
+    emit_prelude(o);
+    // One workgroup per 256-particle row (grid-stride): short blocks keep every SIMD's wave slots
+    // full even at 1e6 particles (15 rows per lane), where a 4-row block would serialise its rows.
+    o << "extern \"C\" __global__ __launch_bounds__(256" << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
+      << ") void gjx_plan_kernel_" << (impl == 0 ? "threefry" : "philox")
+      << "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s) {\n";
+    o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
+    o << "  for (uint64_t row = blockIdx.x; row * 256 < n; row += gridDim.x) {\n";
+    o << "    float tmax = -__builtin_inff();\n    bool live = false;\n";
+    o << "    {\n";
+    o << "      const uint64_t i = row * 256 + threadIdx.x;\n";
+    o << "      if (i < n) {\n";
+    o << "        const Key pkey = key_at<" << I << ">(ks, i);\n";
+    o << "        float w = 0.0f, sc = 0.0f;\n";
+    SiteEmitter<CSiteT, CArgT> em{o, impl, 0, sites, n_sites, "        "};
+    em.run();
     o << "        logw[i] = w;\n        if (score) score[i] = sc;\n        tmax = w;\n        live = true;\n";
     o << "      }\n    }\n";
     o << "    if (max_partials || row_e) {\n";
@@ -191,6 +234,60 @@ struct Gen {
     o << "        if (threadIdx.x == 0) { row_e[row] = eb; row_s[row] = sb; }\n";
     o << "      }\n    }\n";
     o << "  }\n}\n";
+    return o.str();
+  }
+};
+
+// Plan-driven bootstrap SMC: a generated policy inside the fused resample kernel (step) and a plain
+// per-slot kernel (init).  State columns are staged per source tile in LDS like the fixed models.
+template <class CSiteT, class CArgT>
+struct GenSmc {
+  std::ostringstream o;
+  int impl;
+  const CSiteT* init_sites;
+  int n_init;
+  const CSiteT* step_sites;
+  int n_step;
+  const CArgT* init_state;
+  const CArgT* next_state;
+  int n_state;
+
+  std::string run() {
+    const std::string I = std::to_string(impl), D = std::to_string(n_state);
+    emit_prelude(o);
+    SiteEmitter<CSiteT, CArgT> es{o, impl, 1, step_sites, n_step, "    "};
+    SiteEmitter<CSiteT, CArgT> ei{o, impl, 1, init_sites, n_init, "        "};
+    // ---- step policy
+    o << "struct GenPolicy {\n  PlanPolicyArgs a;\n  float* xs[" << D << "];\n  float xr[" << D << "][4];\n";
+    o << "  struct Out { float s[" << D << "]; float lw; };\n";
+    o << "  __device__ __forceinline__ void fetch_source(uint64_t base, uint64_t n, int tid) {\n";
+    o << "    for (int k = 0; k < " << D << "; ++k)\n      for (int r = 0; r < 4; ++r) { const uint64_t i = base + (uint64_t)r * 256 + tid; xr[k][r] = i < n ? a.prev_state[k][i] : 0.0f; }\n  }\n";
+    o << "  __device__ __forceinline__ void stage_source(int tid) {\n    __shared__ float tile[" << D << "][1024];\n";
+    o << "    for (int k = 0; k < " << D << "; ++k) { xs[k] = tile[k]; for (int r = 0; r < 4; ++r) tile[k][r * 256 + tid] = xr[k][r]; }\n  }\n";
+    o << "  __device__ __forceinline__ float compute(int64_t j, int src_local, Out& out) const {\n";
+    for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << " = xs[" << k << "][src_local];\n";
+    if (es.needs_pk()) o << "    const Key pkey = split_at<" << I << ">(a.step_key, (uint64_t)j);\n";
+    o << "    float w = 0.0f, sc = 0.0f;\n";
+    es.run();
+    for (int k = 0; k < n_state; ++k) o << "    out.s[" << k << "] = " << es.arg(next_state[k]) << ";\n";
+    o << "    (void)sc;\n    out.lw = w;\n    return w;\n  }\n";
+    o << "  __device__ __forceinline__ void store(int64_t j, int64_t out_lo, uint64_t src, const Out& out) const {\n";
+    o << "    for (int k = 0; k < " << D << "; ++k) a.state_out[k][j - out_lo] = out.s[k];\n";
+    o << "    a.logw_out[j - out_lo] = out.lw;\n    if (a.anc_out) a.anc_out[j - out_lo] = (int32_t)src;\n  }\n};\n";
+    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_step_kernel(ResampleArgs A, PlanPolicyArgs PA, float* max_partials) {\n";
+    o << "  GenPolicy P;\n  P.a = PA;\n  resample_body<" << I << ">(A, P, max_partials);\n}\n";
+    // ---- init kernel: one workgroup per global tile, like k_lgssm_init
+    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_init_kernel(PlanPolicyArgs a, uint64_t first_slot, uint64_t n_local, float* max_partials) {\n";
+    o << "  __shared__ float shf[4];\n  const uint64_t gbase = (uint64_t)blockIdx.x * 1024;\n  float tmax = -__builtin_inff();\n";
+    o << "  if (gbase >= first_slot && gbase < first_slot + n_local) {\n    for (int r = 0; r < 4; ++r) {\n";
+    o << "      const uint64_t j = gbase + (uint64_t)r * 256 + threadIdx.x;\n      if (j < first_slot + n_local) {\n";
+    if (ei.needs_pk()) o << "        const Key pkey = split_at<" << I << ">(a.step_key, j);\n";
+    o << "        float w = 0.0f, sc = 0.0f;\n";
+    ei.run();
+    for (int k = 0; k < n_state; ++k) o << "        a.state_out[" << k << "][j - first_slot] = " << ei.arg(init_state[k]) << ";\n";
+    o << "        (void)sc;\n        a.logw_out[j - first_slot] = w;\n        if (a.anc_out) a.anc_out[j - first_slot] = (int32_t)j;\n";
+    o << "        tmax = w > tmax ? w : tmax;\n      }\n    }\n  }\n";
+    o << "  const float bm = block_max(tmax, shf);\n  if (threadIdx.x == 0) max_partials[blockIdx.x] = bm;\n}\n";
     return o.str();
   }
 };
@@ -238,28 +335,42 @@ inline bool compile_only(const std::string& src) {
 }
 // ... and load it on the current device.  Identical sources (same model, same constants) share
 // one module process-wide, so re-creating a plan does not recompile.
-inline bool compile(const std::string& src, int impl, Compiled* out) {
+inline bool compile_module(const std::string& src, hipModule_t* mod_out) {
   static std::mutex mu;
-  static std::unordered_map<std::string, std::pair<hipModule_t, hipFunction_t>> cache;
+  static std::unordered_map<std::string, hipModule_t> cache;
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(src);
   if (it != cache.end()) {
-    out->mod = nullptr;  // owned by the cache
-    out->fn = it->second.second;
+    *mod_out = it->second;
     return true;
   }
   std::string code;
   if (!compile_to_code(src, &code)) return false;
   hipModule_t mod = nullptr;
-  hipFunction_t fn = nullptr;
   if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return false;
-  if (hipModuleGetFunction(&fn, mod, impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox") != hipSuccess) {
-    (void)hipModuleUnload(mod);
+  cache.emplace(src, mod);
+  *mod_out = mod;
+  return true;
+}
+inline bool compile(const std::string& src, int impl, Compiled* out) {
+  hipModule_t mod = nullptr;
+  if (!compile_module(src, &mod)) return false;
+  hipFunction_t fn = nullptr;
+  if (hipModuleGetFunction(&fn, mod, impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox") != hipSuccess)
     return false;
-  }
-  cache.emplace(src, std::make_pair(mod, fn));
-  out->mod = nullptr;
+  out->mod = nullptr;  // owned by the cache
   out->fn = fn;
+  return true;
+}
+struct CompiledSmc {
+  hipFunction_t step = nullptr, init = nullptr;
+  int state = 0;  // 0 untried, 1 ready, -1 failed
+};
+inline bool compile_smc(const std::string& src, CompiledSmc* out) {
+  hipModule_t mod = nullptr;
+  if (!compile_module(src, &mod)) return false;
+  if (hipModuleGetFunction(&out->step, mod, "gjx_smc_step_kernel") != hipSuccess) return false;
+  if (hipModuleGetFunction(&out->init, mod, "gjx_smc_init_kernel") != hipSuccess) return false;
   return true;
 }
 

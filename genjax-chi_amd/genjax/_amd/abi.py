@@ -33,7 +33,8 @@ RNG_THREEFRY = 0
 RNG_PHILOX = 1
 
 DIST_NORMAL, DIST_GAMMA, DIST_BETA, DIST_BERNOULLI, DIST_CATEGORICAL = range(5)
-ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE = range(4)
+ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE, ARG_STATE, ARG_OBS = range(6)
+SMC_MAX_STATE, SMC_MAX_OBS = 4, 8
 OP_LOGSUMEXP, OP_CATEGORICAL_INDEX, OP_RESAMPLE, OP_SMC = range(4)
 MAX_SITES = 64
 
@@ -81,6 +82,19 @@ class Site(C.Structure):
         ("arg", Arg * 2),
         ("obs", Arg),
         ("logits", C.c_void_p),
+    ]
+
+
+class SmcModel(C.Structure):
+    _fields_ = [
+        ("init_sites", C.POINTER(Site)),
+        ("n_init_sites", C.c_int32),
+        ("step_sites", C.POINTER(Site)),
+        ("n_step_sites", C.c_int32),
+        ("init_state", Arg * 4),
+        ("next_state", Arg * 4),
+        ("n_state", C.c_int32),
+        ("n_obs", C.c_int32),
     ]
 
 
@@ -178,6 +192,13 @@ PROTOTYPES = {
     "gjx_smc_run_hmm": (
         C.c_int,
         [C.POINTER(SmcConfig), C.POINTER(Hmm), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
+    ),
+    "gjx_smc_plan_create": (C.c_int, [C.POINTER(SmcModel), C.POINTER(_P)]),
+    "gjx_smc_plan_destroy": (C.c_int, [_P]),
+    "gjx_smc_plan_compile_check": (C.c_int, [_P, C.c_int]),
+    "gjx_smc_run_plan": (
+        C.c_int,
+        [C.POINTER(SmcConfig), _P, _P, _P, _P, C.POINTER(_P), _P, _P, _P, C.c_size_t, _P],
     ),
     "gjx_smc_lgssm_step_a": (
         C.c_int,

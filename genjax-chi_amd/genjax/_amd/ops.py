@@ -366,6 +366,38 @@ class Ops:
                       C.c_void_p(ws.data_ptr()), nb, self.stream())
         return out_max, out_q, state, logw, anc
 
+    # ---- bootstrap SMC for a user model (init + step site tables) --------------------------------
+    def smc_plan_create(self, init_sites, step_sites, init_state, next_state, n_obs: int) -> "SmcPlan":
+        m = abi.SmcModel()
+        ia = (abi.Site * len(init_sites))(*init_sites)
+        sa = (abi.Site * len(step_sites))(*step_sites)
+        m.init_sites, m.n_init_sites, m.step_sites, m.n_step_sites = ia, len(init_sites), sa, len(step_sites)
+        for k, a in enumerate(init_state):
+            m.init_state[k] = a
+        for k, a in enumerate(next_state):
+            m.next_state[k] = a
+        m.n_state, m.n_obs = len(next_state), n_obs
+        handle = C.c_void_p()
+        self.lib.call("gjx_smc_plan_create", C.byref(m), C.byref(handle))
+        return SmcPlan(self, handle, len(next_state), n_obs)
+
+    def smc_run_plan(self, plan: "SmcPlan", impl, n, step_keys, resample_keys, obs, want_ancestors=False):
+        import numpy as np
+
+        T = len(step_keys)
+        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys)
+        oh = np.ascontiguousarray(np.asarray(obs, dtype=np.float32).reshape(T, max(plan.n_obs, 1))[:, :plan.n_obs])
+        out_max, out_q = self.empty(T, torch.float32), self.empty(T, torch.int64)
+        states = [self.empty(n, torch.float32) for _ in range(plan.n_state)]
+        sp = (C.c_void_p * plan.n_state)(*[t.data_ptr() for t in states])
+        logw = self.empty(n, torch.float32)
+        anc = self.empty((T, n), torch.int32) if want_ancestors else None
+        ws, nb = self.workspace(abi.OP_SMC, n * (plan.n_state + 1))
+        self.lib.call("gjx_smc_run_plan", C.byref(cfg), plan.handle, C.c_void_p(oh.ctypes.data) if plan.n_obs else None,
+                      self._p(out_max), self._p(out_q), sp, self._p(logw), self._p(anc), C.c_void_p(ws.data_ptr()), nb,
+                      self.stream())
+        return out_max, out_q, states, logw, anc
+
     # ---- step-level SMC pieces (multi-device driver: dist.py) -----------------------------------
     def smc_config(self, impl, n_total, first, n_local, step_keys, resample_keys):
         return self._smc_cfg(impl, n_total, first, n_local, step_keys, resample_keys)
@@ -395,6 +427,19 @@ class Ops:
         m = out_max.detach().cpu().double()
         q = out_q.detach().cpu().double()
         return float((m + torch.log(q) - frac * math.log(2.0) - math.log(n_total)).sum())
+
+
+class SmcPlan:
+    def __init__(self, ops: "Ops", handle, n_state: int, n_obs: int):
+        self.ops, self.handle, self.n_state, self.n_obs = ops, handle, n_state, n_obs
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.ops.lib.call("gjx_smc_plan_destroy", self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 @dataclass

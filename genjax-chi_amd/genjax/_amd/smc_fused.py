@@ -18,7 +18,9 @@ import numpy as np
 import torch
 
 from . import abi, prng
+from .choicemap import ChoiceMap
 from .runtime import get_ops
+from .smc_plan import StateSpaceModel, build_smc_plan, observation_matrix
 
 
 @dataclass(frozen=True)
@@ -42,7 +44,7 @@ class SMCResult:
     log_marginal_likelihood: float  # float64 from the exact per-step (max, fixed-point sum) pairs
     step_max: torch.Tensor  # f32[T]
     step_q: torch.Tensor  # i64[T]
-    particles: torch.Tensor  # final-step particles [n]
+    particles: torch.Tensor  # final-step particles [n] (a tuple of columns for a multi-component carry)
     log_weights: torch.Tensor  # their incremental log-weights [n]
     ancestors: torch.Tensor | None  # int32[T, n] (row 0 = identity)
 
@@ -61,15 +63,23 @@ class BootstrapSMC:
 
     def __init__(self, model, observations, n_particles: int, record_ancestors: bool = False):
         self.model, self.n, self.record_ancestors = model, int(n_particles), record_ancestors
-        self.observations = np.asarray(observations)
+        self._plan = None
+        if isinstance(model, StateSpaceModel):
+            if not isinstance(observations, ChoiceMap):
+                raise TypeError("observations for a StateSpaceModel are a ChoiceMap of length-T sequences")
+            self._obs_chm = observations
+            self.observations = None
+        else:
+            self.observations = np.asarray(observations)
 
     def get_num_particles(self):
         return self.n
 
     def run(self, key: prng.PRNGKey) -> SMCResult:
         ops = get_ops()
-        T = len(self.observations)
-        sk, rk = smc_key_schedule(key, T)
+        if self.observations is not None:
+            T = len(self.observations)
+            sk, rk = smc_key_schedule(key, T)
         if isinstance(self.model, LinearGaussianSSM):
             m = self.model
             out = ops.smc_run_lgssm(key.impl, self.n, sk, rk, abi.Lgssm(m.x0_loc, m.x0_scale, m.a, m.q, m.r),
@@ -81,6 +91,16 @@ class BootstrapSMC:
             ol = torch.as_tensor(m.obs_logits, dtype=torch.float32).to(dev).contiguous()
             out = ops.smc_run_hmm(key.impl, self.n, sk, rk, int(tl.shape[0]), int(m.init_state), tl, ol,
                                   self.observations.astype(np.int32), self.record_ancestors)
+        elif isinstance(self.model, StateSpaceModel):
+            if self._plan is None:
+                self._obs_addrs = [a for a, _ in self._obs_chm.leaves()]
+                self._plan, self._n_state = build_smc_plan(self.model, self._obs_addrs)
+                self._obs = observation_matrix(self._obs_chm, self._obs_addrs)
+            T = self._obs.shape[0]
+            sk, rk = smc_key_schedule(key, T)
+            om, oq, states, logw, anc = ops.smc_run_plan(self._plan, key.impl, self.n, sk, rk, self._obs,
+                                                         self.record_ancestors)
+            out = (om, oq, states[0] if self._n_state == 1 else tuple(states), logw, anc)
         else:
             raise TypeError(f"no fused SMC kernel for {type(self.model).__name__}")
         step_max, step_q, state, logw, anc = out

@@ -4,7 +4,7 @@ Importance, ImportanceK, SMCAlgorithm), plus what the north star adds on top of 
 
 from .._amd.inference import (ChangeTarget, Importance, ImportanceK, ParticleCollection, SMCAlgorithm,
                               stack_to_first_dim)
-from .._amd.smc_fused import BootstrapSMC, DiscreteHMM, LinearGaussianSSM, SMCResult
+from .._amd.smc_fused import BootstrapSMC, DiscreteHMM, LinearGaussianSSM, SMCResult, StateSpaceModel
 
 __all__ = ["ChangeTarget", "Importance", "ImportanceK", "SMCAlgorithm", "ParticleCollection", "BootstrapSMC",
-           "LinearGaussianSSM", "DiscreteHMM", "SMCResult", "stack_to_first_dim"]
+           "LinearGaussianSSM", "DiscreteHMM", "StateSpaceModel", "SMCResult", "stack_to_first_dim"]

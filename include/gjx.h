@@ -144,7 +144,9 @@ typedef enum {
   GJX_ARG_CONST = 0, /* value = offset */
   GJX_ARG_SITE = 1,  /* value = scale * (value of site `ref`, as f32) + offset */
   GJX_ARG_INPUT = 2, /* value = scale * input_cols[ref][i] + offset */
-  GJX_ARG_TABLE = 3  /* value = table[(int) value of site `ref`] (dev f32 table) */
+  GJX_ARG_TABLE = 3, /* value = table[(int) value of site `ref`] (dev f32 table) */
+  GJX_ARG_STATE = 4, /* SMC plans: value = scale * state[ref] of the particle's ANCESTOR + offset */
+  GJX_ARG_OBS = 5    /* SMC plans: value = scale * obs[t][ref] + offset (this step's observation constants) */
 } gjx_arg_kind;
 
 typedef struct {
@@ -336,6 +338,37 @@ int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const flo
                    float* max_out, uint64_t* tile_sums, gjx_stream s);
 int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
                    gjx_stream s);
+/* ---- bootstrap SMC for a user model: init sites + step sites as plans ------------------------ *
+ * The general form of the two fixed models above: x_0 comes from `init_sites`, every later step
+ * walks `step_sites` for each output slot with GJX_ARG_STATE arguments reading the resampled
+ * ancestor's state columns; observed sites contribute their log-density to the step's log-weight.
+ * Site counter f (1-based, table order) draws — threefry: particle key split(step_key)[slot], site
+ * key fold_in(., f); philox: single-word draws are word (f-1)&3 of
+ * PH(ctr = (slot_lo, slot_hi, (f-1)>>2, "SMCS"), step_key), multi-word samplers use the stream of
+ * split(step_key)[slot] folded with f.  libgjx_hip.so lowers the step to a hiprtc-compiled policy
+ * inside the fused resample kernel.  State columns are f32 (integer-valued sites are converted). */
+#define GJX_SMC_MAX_STATE 4
+#define GJX_SMC_MAX_OBS 8
+typedef struct {
+  const gjx_site* init_sites;
+  int32_t n_init_sites;
+  const gjx_site* step_sites;
+  int32_t n_step_sites;
+  gjx_arg init_state[GJX_SMC_MAX_STATE]; /* state k after step 0, over the init sites (CONST/SITE/OBS) */
+  gjx_arg next_state[GJX_SMC_MAX_STATE]; /* state k after a step (CONST/SITE/STATE/OBS) */
+  int32_t n_state;
+  int32_t n_obs;
+} gjx_smc_model;
+typedef struct gjx_smc_plan gjx_smc_plan;
+int gjx_smc_plan_create(const gjx_smc_model* m /*host*/, gjx_smc_plan** out);
+int gjx_smc_plan_destroy(gjx_smc_plan* p);
+int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl); /* offline hiprtc compile, needs no GPU */
+/* obs_host: host f32[T, n_obs].  state_out: host array of n_state dev f32[n] pointers (final-step
+ * particles); other outputs as gjx_smc_run_lgssm.  Single device (first_slot 0, n_local n_total). */
+int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host,
+                     float* out_max, uint64_t* out_q, float* const* state_out, float* logw_out,
+                     int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s);
+
 /* HMM tables: trans_cdf dev u32[K,K] fixed-point inclusive CDF per row,
  * obs_logp dev f32[K,K] = log_softmax rows of obs_logits.  K <= 256. */
 int gjx_hmm_prepare(const gjx_hmm* model, uint32_t* trans_cdf, float* obs_logp, gjx_stream s);

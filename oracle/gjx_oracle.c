@@ -326,14 +326,84 @@ typedef struct { float f; int32_t i; int is_int; } site_val;
 static inline float sv_as_f32(const site_val* v) { return v->is_int ? (float)v->i : v->f; }
 static inline int32_t sv_as_i32(const site_val* v) { return v->is_int ? v->i : (int32_t)rintf(v->f); }
 
-static inline float eval_arg(const gjx_arg* a, const site_val* vals, const float* const* in,
-                             uint64_t i) {
+/* Everything one particle's walk over a site table reads. */
+typedef struct {
+  int impl;
+  int smc;                   /* 0: importance (per-particle key pkey); 1: SMC slot of step_key */
+  uint32_t pkey[2];          /* importance: particle key; smc: split(step_key)[slot] (multi-word streams) */
+  const uint32_t* step_key;  /* smc */
+  uint64_t slot;             /* smc: global slot */
+  const float* const* in;    /* importance: input columns */
+  uint64_t i;                /* importance: particle index into the input columns */
+  const float* state;        /* smc: the ancestor's state columns (NULL at step 0) */
+  const float* obs;          /* smc: this step's observation constants */
+} walk_ctx;
+
+static inline float eval_arg(const gjx_arg* a, const site_val* vals, const walk_ctx* c) {
   switch (a->kind) {
     case GJX_ARG_CONST: return a->offset;
     case GJX_ARG_SITE: { float t = a->scale * sv_as_f32(&vals[a->ref]); return t + a->offset; }
-    case GJX_ARG_INPUT: { float t = a->scale * in[a->ref][i]; return t + a->offset; }
+    case GJX_ARG_INPUT: { float t = a->scale * c->in[a->ref][c->i]; return t + a->offset; }
+    case GJX_ARG_STATE: { float t = a->scale * c->state[a->ref]; return t + a->offset; }
+    case GJX_ARG_OBS: { float t = a->scale * c->obs[a->ref]; return t + a->offset; }
     default: return a->table[sv_as_i32(&vals[a->ref])];
   }
+}
+
+/* The walk of static.py:340-399 for one particle: values into vals[], returns weight / score. */
+static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, site_val* vals, float* w_out,
+                      float* sc_out) {
+  float w = 0.0f, sc = 0.0f;
+  for (int q = 0; q < n_sites; ++q) {
+    const gjx_site* st = &sites[q];
+    site_val v;
+    v.f = 0.0f; v.i = 0;
+    v.is_int = (st->dist == GJX_DIST_BERNOULLI || st->dist == GJX_DIST_CATEGORICAL);
+    float a0 = 0.0f, a1 = 0.0f;
+    const float* row = NULL;
+    if (st->dist == GJX_DIST_CATEGORICAL) {
+      int32_t r = 0;
+      if (st->arg[0].kind == GJX_ARG_SITE) r = sv_as_i32(&vals[st->arg[0].ref]);
+      else if (st->arg[0].kind == GJX_ARG_CONST) r = (int32_t)rintf(st->arg[0].offset);
+      else r = (int32_t)rintf(eval_arg(&st->arg[0], vals, c));
+      if (r < 0) r = 0;
+      if (r >= st->n_rows) r = st->n_rows - 1;
+      row = st->logits + (size_t)r * (size_t)st->n_cat;
+    } else {
+      a0 = eval_arg(&st->arg[0], vals, c);
+      if (st->dist != GJX_DIST_BERNOULLI) a1 = eval_arg(&st->arg[1], vals, c);
+    }
+    float lp;
+    if (st->observed) {
+      float ov = st->obs.kind == GJX_ARG_CONST ? st->obs.offset
+               : st->obs.kind == GJX_ARG_OBS ? c->obs[st->obs.ref] : c->in[st->obs.ref][c->i];
+      if (v.is_int) v.i = (int32_t)rintf(ov); else v.f = ov;
+    } else {
+      const uint32_t f = (uint32_t)(q + 1);
+      o_stream strm = o_stream_make(c->impl, c->pkey, 1, f);
+      const uint32_t bits0 = c->smc ? o_smc_site_bits(c->impl, c->step_key, c->slot, f) : o_bits32_at(&strm, 0);
+      switch (st->dist) {
+        case GJX_DIST_NORMAL: { float t = a1 * o_std_normal(bits0); v.f = a0 + t; break; }
+        case GJX_DIST_GAMMA: v.f = o_std_gamma(&strm, 0, a0) / a1; break;
+        case GJX_DIST_BETA: { float g1 = o_std_gamma(&strm, 0, a0), g2 = o_std_gamma(&strm, 1, a1); v.f = g1 / (g1 + g2); break; }
+        case GJX_DIST_BERNOULLI: v.i = o_uniform01(bits0) < a0; break;
+        default: v.i = st->cat_mode == 0 ? cat_gumbel(row, (uint32_t)st->n_cat, &strm)
+                                         : cat_invcdf(row, (uint32_t)st->n_cat, bits0);
+      }
+    }
+    switch (st->dist) {
+      case GJX_DIST_NORMAL: lp = o_logpdf_normal(v.f, a0, a1); break;
+      case GJX_DIST_GAMMA: lp = o_logpdf_gamma(v.f, a0, a1); break;
+      case GJX_DIST_BETA: lp = o_logpdf_beta(v.f, a0, a1); break;
+      case GJX_DIST_BERNOULLI: lp = o_logpdf_bernoulli(v.i != 0, a0); break;
+      default: lp = (v.i < 0 || v.i >= st->n_cat) ? -INFINITY : row[v.i] - row_lse(row, (uint32_t)st->n_cat);
+    }
+    sc = sc + lp;
+    if (st->observed) w = w + lp;
+    vals[q] = v;
+  }
+  *w_out = w;
+  *sc_out = sc;
 }
 
 int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const* input_cols,
@@ -352,57 +422,20 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
   }
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < (int64_t)n; ++i) {
-    uint32_t key[2];
-    key_at(pk, (uint64_t)i, key);
+    walk_ctx c;
+    memset(&c, 0, sizeof c);
+    c.impl = pk->impl;
+    key_at(pk, (uint64_t)i, c.pkey);
+    c.in = input_cols;
+    c.i = (uint64_t)i;
     site_val vals[GJX_MAX_SITES];
-    float w = 0.0f, sc = 0.0f;
+    float w, sc;
+    site_walk(p->sites, p->n_sites, &c, vals, &w, &sc);
     for (int q = 0; q < p->n_sites; ++q) {
       const gjx_site* st = &p->sites[q];
-      site_val v;
-      v.f = 0.0f; v.i = 0;
-      v.is_int = (st->dist == GJX_DIST_BERNOULLI || st->dist == GJX_DIST_CATEGORICAL);
-      float a0 = 0.0f, a1 = 0.0f;
-      const float* row = NULL;
-      if (st->dist == GJX_DIST_CATEGORICAL) {
-        int32_t r = 0;
-        if (st->arg[0].kind == GJX_ARG_SITE) r = sv_as_i32(&vals[st->arg[0].ref]);
-        else if (st->arg[0].kind == GJX_ARG_CONST) r = (int32_t)rintf(st->arg[0].offset);
-        else r = (int32_t)rintf(eval_arg(&st->arg[0], vals, input_cols, (uint64_t)i));
-        if (r < 0) r = 0;
-        if (r >= st->n_rows) r = st->n_rows - 1;
-        row = st->logits + (size_t)r * (size_t)st->n_cat;
-      } else {
-        a0 = eval_arg(&st->arg[0], vals, input_cols, (uint64_t)i);
-        if (st->dist != GJX_DIST_BERNOULLI) a1 = eval_arg(&st->arg[1], vals, input_cols, (uint64_t)i);
-      }
-      float lp;
-      if (st->observed) {
-        float ov = st->obs.kind == GJX_ARG_CONST ? st->obs.offset : input_cols[st->obs.ref][i];
-        if (v.is_int) v.i = (int32_t)rintf(ov); else v.f = ov;
-      } else {
-        o_stream strm = o_stream_make(pk->impl, key, 1, (uint32_t)(q + 1));
-        switch (st->dist) {
-          case GJX_DIST_NORMAL: { float t = a1 * o_std_normal(o_bits32_at(&strm, 0)); v.f = a0 + t; break; }
-          case GJX_DIST_GAMMA: v.f = o_std_gamma(&strm, 0, a0) / a1; break;
-          case GJX_DIST_BETA: { float g1 = o_std_gamma(&strm, 0, a0), g2 = o_std_gamma(&strm, 1, a1); v.f = g1 / (g1 + g2); break; }
-          case GJX_DIST_BERNOULLI: v.i = o_uniform01(o_bits32_at(&strm, 0)) < a0; break;
-          default: v.i = st->cat_mode == 0 ? cat_gumbel(row, (uint32_t)st->n_cat, &strm)
-                                           : cat_invcdf(row, (uint32_t)st->n_cat, o_bits32_at(&strm, 0));
-        }
-      }
-      switch (st->dist) {
-        case GJX_DIST_NORMAL: lp = o_logpdf_normal(v.f, a0, a1); break;
-        case GJX_DIST_GAMMA: lp = o_logpdf_gamma(v.f, a0, a1); break;
-        case GJX_DIST_BETA: lp = o_logpdf_beta(v.f, a0, a1); break;
-        case GJX_DIST_BERNOULLI: lp = o_logpdf_bernoulli(v.i != 0, a0); break;
-        default: lp = (v.i < 0 || v.i >= st->n_cat) ? -INFINITY : row[v.i] - row_lse(row, (uint32_t)st->n_cat);
-      }
-      sc = sc + lp;
-      if (st->observed) w = w + lp;
-      vals[q] = v;
       if (st->out_col >= 0) {
-        if (v.is_int) ((int32_t*)value_cols[st->out_col])[i] = v.i;
-        else ((float*)value_cols[st->out_col])[i] = v.f;
+        if (vals[q].is_int) ((int32_t*)value_cols[st->out_col])[i] = vals[q].i;
+        else ((float*)value_cols[st->out_col])[i] = vals[q].f;
       }
     }
     logw[i] = w;
@@ -887,4 +920,130 @@ void gjo_math(int fn, const float* x, float* y, uint64_t n) {
       default: y[i] = o_uniform01(o_f2u(x[i])); break;
     }
   }
+}
+
+
+/* ---- bootstrap SMC for a user model (init + step site tables) ------------------------------------ */
+struct gjx_smc_plan {
+  gjx_smc_model m;
+  gjx_site init_sites[GJX_MAX_SITES];
+  gjx_site step_sites[GJX_MAX_SITES];
+};
+
+static int smc_arg_ok(const gjx_arg* a, int s, int n_state, int n_obs, int allow_state) {
+  switch (a->kind) {
+    case GJX_ARG_CONST: return 1;
+    case GJX_ARG_SITE: return a->ref >= 0 && a->ref < s;
+    case GJX_ARG_TABLE: return a->ref >= 0 && a->ref < s && a->table != NULL;
+    case GJX_ARG_STATE: return allow_state && a->ref >= 0 && a->ref < n_state;
+    case GJX_ARG_OBS: return a->ref >= 0 && a->ref < n_obs;
+    default: return 0;
+  }
+}
+static int smc_sites_ok(const gjx_site* sites, int n, int n_state, int n_obs, int allow_state) {
+  if (!sites || n <= 0 || n > GJX_MAX_SITES) return 0;
+  for (int s = 0; s < n; ++s) {
+    const gjx_site* st = &sites[s];
+    if (st->dist < 0 || st->dist > GJX_DIST_CATEGORICAL) return 0;
+    if (!smc_arg_ok(&st->arg[0], s, n_state, n_obs, allow_state)) return 0;
+    if (st->dist != GJX_DIST_BERNOULLI && st->dist != GJX_DIST_CATEGORICAL &&
+        !smc_arg_ok(&st->arg[1], s, n_state, n_obs, allow_state))
+      return 0;
+    if (st->observed && !(st->obs.kind == GJX_ARG_CONST || (st->obs.kind == GJX_ARG_OBS && st->obs.ref >= 0 && st->obs.ref < n_obs)))
+      return 0;
+    if (st->dist == GJX_DIST_CATEGORICAL &&
+        (!st->logits || st->n_cat <= 0 || st->n_rows <= 0 || (st->cat_mode != 0 && st->cat_mode != 1)))
+      return 0;
+  }
+  return 1;
+}
+
+int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
+  if (!m || !out || m->n_state < 1 || m->n_state > GJX_SMC_MAX_STATE || m->n_obs < 0 || m->n_obs > GJX_SMC_MAX_OBS)
+    return GJX_ERR_INVALID;
+  if (!smc_sites_ok(m->init_sites, m->n_init_sites, m->n_state, m->n_obs, 0)) return GJX_ERR_INVALID;
+  if (!smc_sites_ok(m->step_sites, m->n_step_sites, m->n_state, m->n_obs, 1)) return GJX_ERR_INVALID;
+  for (int k = 0; k < m->n_state; ++k) {
+    if (!smc_arg_ok(&m->init_state[k], m->n_init_sites, m->n_state, m->n_obs, 0) || m->init_state[k].kind == GJX_ARG_TABLE)
+      return GJX_ERR_INVALID;
+    if (!smc_arg_ok(&m->next_state[k], m->n_step_sites, m->n_state, m->n_obs, 1) || m->next_state[k].kind == GJX_ARG_TABLE)
+      return GJX_ERR_INVALID;
+  }
+  gjx_smc_plan* p = (gjx_smc_plan*)malloc(sizeof(gjx_smc_plan));
+  if (!p) return GJX_ERR_LAUNCH;
+  p->m = *m;
+  memcpy(p->init_sites, m->init_sites, sizeof(gjx_site) * (size_t)m->n_init_sites);
+  memcpy(p->step_sites, m->step_sites, sizeof(gjx_site) * (size_t)m->n_step_sites);
+  p->m.init_sites = p->init_sites;
+  p->m.step_sites = p->step_sites;
+  *out = p;
+  return GJX_OK;
+}
+int gjx_smc_plan_destroy(gjx_smc_plan* p) { free(p); return GJX_OK; }
+int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl) { (void)p; (void)impl; return GJX_ERR_UNSUPPORTED; }
+
+int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
+                     uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out,
+                     void* ws, size_t ws_bytes, gjx_stream s) {
+  (void)ws; (void)ws_bytes; (void)s;
+  if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !plan || !out_max || !out_q ||
+      !state_out || !logw_out || (plan->m.n_obs > 0 && !obs_host))
+    return GJX_ERR_INVALID;
+  const gjx_smc_model* m = &plan->m;
+  const uint64_t N = cfg->n_total, ntile = gjx_num_tiles(N);
+  const int D = m->n_state;
+  float* st[2] = {(float*)malloc(4 * N * (size_t)D), (float*)malloc(4 * N * (size_t)D)};  /* [D][N] each */
+  float* lw[2] = {(float*)malloc(4 * N), (float*)malloc(4 * N)};
+  uint64_t* tiles = (uint64_t*)malloc(8 * ntile);
+  float* mp = (float*)malloc(4 * ntile);
+  int32_t* anc_tmp = (int32_t*)malloc(4 * N);
+  int rc = GJX_OK;
+  for (int t = 0; t < cfg->n_steps && rc == GJX_OK; ++t) {
+    const int cur = t & 1, prv = cur ^ 1;
+    int32_t* anc = ancestors_out ? ancestors_out + (size_t)t * N : anc_tmp;
+    if (t > 0) {
+      uint64_t Qprev = sum_tiles(cfg, tiles);
+      out_q[t - 1] = Qprev;
+      smc_ancestors(cfg, t, lw[prv], out_max[t - 1], Qprev, anc);
+    } else {
+      for (uint64_t j = 0; j < N; ++j) anc[j] = (int32_t)j;
+    }
+    const uint32_t* skey = &cfg->step_keys[2 * t];
+    const float* obs = obs_host ? obs_host + (size_t)t * (size_t)m->n_obs : NULL;
+    const gjx_site* sites = t == 0 ? m->init_sites : m->step_sites;
+    const int ns = t == 0 ? m->n_init_sites : m->n_step_sites;
+    const gjx_arg* nxt = t == 0 ? m->init_state : m->next_state;
+    float mx = -INFINITY;
+#pragma omp parallel for reduction(max : mx) schedule(static)
+    for (int64_t j = 0; j < (int64_t)N; ++j) {
+      walk_ctx c;
+      memset(&c, 0, sizeof c);
+      c.impl = cfg->impl;
+      c.smc = 1;
+      c.step_key = skey;
+      c.slot = (uint64_t)j;
+      o_split_at(cfg->impl, skey, (uint64_t)j, c.pkey);
+      float prev[GJX_SMC_MAX_STATE];
+      if (t > 0)
+        for (int k = 0; k < D; ++k) prev[k] = st[prv][(size_t)k * N + (uint64_t)anc[j]];
+      c.state = t > 0 ? prev : NULL;
+      c.obs = obs;
+      site_val vals[GJX_MAX_SITES];
+      float w, sc;
+      site_walk(sites, ns, &c, vals, &w, &sc);
+      for (int k = 0; k < D; ++k) st[cur][(size_t)k * N + (uint64_t)j] = eval_arg(&nxt[k], vals, &c);
+      lw[cur][j] = w;
+      mx = w > mx ? w : mx;
+    }
+    put_max_partials(cfg, mx, mp);
+    rc = gjx_smc_step_b(cfg, lw[cur], mp, &out_max[t], tiles, NULL);
+  }
+  if (rc == GJX_OK) rc = gjx_smc_finish(cfg, tiles, &out_q[cfg->n_steps - 1], NULL);
+  if (rc == GJX_OK) {
+    const int last = (cfg->n_steps - 1) & 1;
+    for (int k = 0; k < D; ++k) memcpy(state_out[k], st[last] + (size_t)k * N, 4 * N);
+    memcpy(logw_out, lw[last], 4 * N);
+  }
+  free(st[0]); free(st[1]); free(lw[0]); free(lw[1]); free(tiles); free(mp); free(anc_tmp);
+  return rc;
 }

@@ -155,6 +155,19 @@ static inline uint32_t o_smc_slot_bits(int impl, const uint32_t step_key[2], uin
   return o[0];
 }
 
+/* Single-word draw of site counter f (1-based) of SMC slot j — generalises o_smc_slot_bits (f = 1). */
+static inline uint32_t o_smc_site_bits(int impl, const uint32_t step_key[2], uint64_t j, uint32_t f) {
+  if (impl == 0) {
+    uint32_t pk[2];
+    o_split_at(0, step_key, j, pk);
+    o_stream st = o_stream_make(0, pk, 1, f);
+    return o_bits32_at(&st, 0);
+  }
+  uint32_t c[4] = {(uint32_t)j, (uint32_t)(j >> 32), (f - 1u) >> 2, O_TAG_SMC}, o[4];
+  o_philox4x32(step_key[0], step_key[1], c, o);
+  return o[(f - 1u) & 3u];
+}
+
 /* ---------------- f32 math spec: only IEEE-exact primitives -------------- *
  * (+, -, *, fmaf, /, sqrtf, rintf, integer ops).  Coefficients: Cephes logf/expf
  * (Moshier), Giles' single-precision erfinv (the polynomial XLA's ErfInv32 uses). */

@@ -14,7 +14,8 @@ from genjax import ChoiceMap, ChoiceMapBuilder as C, SelectionBuilder as S, Targ
 from genjax._amd import jaxlike
 from genjax._amd.lang import ParticleKeys, StaticTrace
 from genjax._amd.plan import try_fused_generate
-from genjax.inference.smc import BootstrapSMC, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM
+from genjax.inference.smc import (BootstrapSMC, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM,
+                                  StateSpaceModel)
 
 jax = jaxlike
 jnp = jaxlike.jnp
@@ -409,6 +410,63 @@ def case_bootstrap_smc(impl):
     assert torch.equal(res.step_q, res2.step_q)  # counter-based: runs are replayable
 
 
+def case_general_smc(impl):
+    """A user-written state-space model lowered to the fused SMC kernels (smc_plan.py)."""
+    from genjax._amd import workloads as W
+
+    @gen
+    def init():
+        x = normal(0.0, 1.0) @ "x"
+        normal(x, 0.5) @ "y"
+        return x
+
+    @gen
+    def step(x):
+        x2 = normal(0.9 * x, 1.0) @ "x"
+        normal(x2, 0.5) @ "y"
+        return x2
+
+    y = W.lgssm_data(25)
+    key = genjax.random.key(3, impl)
+    a = BootstrapSMC(StateSpaceModel(init, step), C["y"].set(torch.tensor(y)), 8192, record_ancestors=True).run(key)
+    b = BootstrapSMC(LinearGaussianSSM(), y, 8192, record_ancestors=True).run(key)
+    # the generated kernel and the hand-written LGSSM kernel are the same filter, bit for bit
+    assert torch.equal(a.step_q, b.step_q) and torch.equal(a.step_max, b.step_max)
+    assert torch.equal(a.particles, b.particles) and torch.equal(a.ancestors, b.ancestors)
+    assert a.log_marginal_likelihood == pytest.approx(W.lgssm_exact_log_z(y), abs=0.5)
+
+    @gen
+    def init2():
+        m = normal(0.0, 1.0) @ "m"
+        g = gamma(2.0, 2.0) @ "g"
+        normal(m, 0.7) @ "y"
+        return m, g
+
+    @gen
+    def step2(c):
+        m, g = c
+        m2 = normal(0.8 * m, 0.5) @ "m"
+        g2 = gamma(2.0, g + 1.0) @ "g"
+        normal(m2, 0.7) @ "y"
+        return m2, g2
+
+    r = BootstrapSMC(StateSpaceModel(init2, step2), C["y"].set(torch.tensor(y)), 4096).run(key)
+    assert len(r.particles) == 2 and r.particles[0].shape == (4096,) and bool((r.particles[1] > 0).all())
+    assert math.isfinite(r.log_marginal_likelihood)
+    # the m-chain is linear-Gaussian and independent of g: its exact evidence is a Kalman filter
+    mm, pp, ll = 0.0, 1.0, 0.0
+    for t, yt in enumerate(y.astype("float64")):
+        if t:
+            mm, pp = 0.8 * mm, 0.64 * pp + 0.25
+        sv = pp + 0.49
+        ll += -0.5 * (yt - mm) ** 2 / sv - 0.5 * math.log(2 * math.pi * sv)
+        kk = pp / sv
+        mm, pp = mm + kk * (yt - mm), (1 - kk) * pp
+    assert r.log_marginal_likelihood == pytest.approx(ll, abs=0.6)
+    with pytest.raises(ValueError):
+        BootstrapSMC(StateSpaceModel(init, step), C["nope"].set(torch.tensor(y)), 1024).run(key)
+
+
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_fused_equals_eager, case_particle_collection, case_custom_proposal,
-             case_scan, case_vmap, case_bootstrap_smc]
+             case_scan, case_vmap, case_bootstrap_smc, case_general_smc]

@@ -266,6 +266,66 @@ def test_smc_hmm(hip_ops, oracle_ops, impl, n, T, k):
     same(h["state"], o["state"]); same(h["logw"], o["logw"])
 
 
+def _smc_plans(ops):
+    """(LGSSM as a plan, a 2-state plan with gamma / bernoulli / table arguments)."""
+    A, m = abi.Arg, W.LGSSM
+
+    def site(dist, a0, a1=None, obs=None):
+        s_ = abi.Site()
+        s_.dist, s_.observed, s_.out_col = dist, 0 if obs is None else 1, -1
+        s_.arg[0] = a0
+        if a1 is not None:
+            s_.arg[1] = a1
+        if obs is not None:
+            s_.obs = obs
+        return s_
+
+    c = lambda v: A(abi.ARG_CONST, 0, 0.0, v, None)
+    lg = ops.smc_plan_create(
+        [site(abi.DIST_NORMAL, c(m["x0_loc"]), c(m["x0_scale"])),
+         site(abi.DIST_NORMAL, A(abi.ARG_SITE, 0, 1.0, 0.0, None), c(m["r"]), A(abi.ARG_OBS, 0, 1.0, 0.0, None))],
+        [site(abi.DIST_NORMAL, A(abi.ARG_STATE, 0, m["a"], 0.0, None), c(m["q"])),
+         site(abi.DIST_NORMAL, A(abi.ARG_SITE, 0, 1.0, 0.0, None), c(m["r"]), A(abi.ARG_OBS, 0, 1.0, 0.0, None))],
+        [A(abi.ARG_SITE, 0, 1.0, 0.0, None)], [A(abi.ARG_SITE, 0, 1.0, 0.0, None)], 1)
+    rich = ops.smc_plan_create(
+        [site(abi.DIST_NORMAL, c(0.0), c(1.0)), site(abi.DIST_GAMMA, c(2.0), c(2.0)),
+         site(abi.DIST_NORMAL, A(abi.ARG_SITE, 0, 1.0, 0.0, None), c(0.7), A(abi.ARG_OBS, 0, 1.0, 0.0, None))],
+        [site(abi.DIST_NORMAL, A(abi.ARG_STATE, 0, 0.8, 0.0, None), c(0.5)),
+         site(abi.DIST_GAMMA, c(0.6), A(abi.ARG_STATE, 1, 1.0, 1.0, None)),
+         site(abi.DIST_BERNOULLI, c(0.3)),
+         site(abi.DIST_BETA, c(2.0), A(abi.ARG_SITE, 2, 1.5, 0.5, None)),
+         site(abi.DIST_NORMAL, A(abi.ARG_SITE, 0, 1.0, 0.0, None), A(abi.ARG_SITE, 3, 1.0, 0.2, None),
+              A(abi.ARG_OBS, 0, 1.0, 0.0, None)),
+         site(abi.DIST_BERNOULLI, A(abi.ARG_SITE, 3, 1.0, 0.0, None), None, A(abi.ARG_OBS, 1, 1.0, 0.0, None))],
+        [A(abi.ARG_SITE, 0, 1.0, 0.0, None), A(abi.ARG_SITE, 1, 1.0, 0.0, None)],
+        [A(abi.ARG_SITE, 0, 1.0, 0.0, None), A(abi.ARG_SITE, 1, 0.5, 0.1, None)], 2)
+    return lg, rich
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_smc_plans(hip_ops, oracle_ops, impl):
+    """Plan-driven bootstrap SMC (hiprtc-generated policy in the fused resample kernel) against the
+    oracle's plan interpreter, and against the hand-written LGSSM kernel."""
+    from genjax._amd import prng
+
+    T, n = 14, 30000
+    y = W.lgssm_data(T)
+    obs2 = np.stack([y, (np.arange(T) % 2).astype(np.float32)], axis=1)
+    sk, rk = W.smc_key_schedule(prng.key(13, impl), T)
+    hl, hr = _smc_plans(hip_ops)
+    ol, orr = _smc_plans(oracle_ops)
+    for hp, op_, obs in ((hl, ol, y), (hr, orr, obs2)):
+        h = hip_ops.smc_run_plan(hp, impl, n, sk, rk, obs, True)
+        o = oracle_ops.smc_run_plan(op_, impl, n, sk, rk, obs, True)
+        same(h[0], o[0], "step max"); same(h[1], o[1], "step q"); same(h[3], o[3], "logw"); same(h[4], o[4], "ancestors")
+        for a, b in zip(h[2], o[2]):
+            same(a, b, "state column")
+    fixed = hip_ops.smc_run_lgssm(impl, n, sk, rk, W.lgssm_model(), y, True)
+    gen_ = hip_ops.smc_run_plan(hl, impl, n, sk, rk, y, True)
+    same(gen_[1], fixed[1], "generated vs hand-written LGSSM q"); same(gen_[2][0], fixed[2], "particles")
+    same(gen_[4], fixed[4], "ancestors")
+
+
 def test_full_size_properties(hip_ops):
     """BASELINE sizes (1e6 particles) through size-independent properties: closed-form log Z within
     Monte-Carlo error, weight-sum invariants, monotone ancestors with floor/ceil offspring counts."""

@@ -78,3 +78,35 @@ def test_invalid_plans_are_rejected(hip_lib_nogpu):
         ops.plan_create([bad])
     with pytest.raises(abi.GjxError):
         ops.plan_create([])
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_smc_plan_compiles(hip_lib_nogpu, impl):
+    """The generated step policy + init kernel of a plan-driven bootstrap filter compile offline."""
+    ops = hip_lib_nogpu
+    A = abi.Arg
+    c = lambda v: A(abi.ARG_CONST, 0, 0.0, v, None)
+
+    def site(dist, a0, a1=None, obs=None):
+        s_ = abi.Site()
+        s_.dist, s_.observed, s_.out_col = dist, 0 if obs is None else 1, -1
+        s_.arg[0] = a0
+        if a1 is not None:
+            s_.arg[1] = a1
+        if obs is not None:
+            s_.obs = obs
+        return s_
+
+    plan = ops.smc_plan_create(
+        [site(abi.DIST_NORMAL, c(0.0), c(1.0)), site(abi.DIST_GAMMA, c(2.0), c(2.0)),
+         site(abi.DIST_NORMAL, A(abi.ARG_SITE, 0, 1.0, 0.0, None), c(0.7), A(abi.ARG_OBS, 0, 1.0, 0.0, None))],
+        [site(abi.DIST_NORMAL, A(abi.ARG_STATE, 0, 0.8, 0.0, None), c(0.5)),
+         site(abi.DIST_GAMMA, c(0.6), A(abi.ARG_STATE, 1, 1.0, 1.0, None)),
+         site(abi.DIST_BERNOULLI, c(0.3)),
+         site(abi.DIST_NORMAL, A(abi.ARG_SITE, 0, 1.0, 0.0, None), c(0.7), A(abi.ARG_OBS, 0, 1.0, 0.0, None))],
+        [A(abi.ARG_SITE, 0, 1.0, 0.0, None), A(abi.ARG_SITE, 1, 1.0, 0.0, None)],
+        [A(abi.ARG_SITE, 0, 1.0, 0.0, None), A(abi.ARG_SITE, 1, 0.5, 0.1, None)], 1)
+    ops.lib.call("gjx_smc_plan_compile_check", plan.handle, impl)
+    with pytest.raises(abi.GjxError):  # a STATE reference is not allowed in the init table
+        ops.smc_plan_create([site(abi.DIST_NORMAL, A(abi.ARG_STATE, 0, 1.0, 0.0, None), c(1.0))],
+                            [site(abi.DIST_NORMAL, c(0.0), c(1.0))], [c(0.0)], [c(0.0)], 0)
