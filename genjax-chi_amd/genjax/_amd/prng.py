@@ -112,3 +112,39 @@ def fold_in(k: PRNGKey, data: int) -> PRNGKey:
     else:
         o0, o1, _, _ = philox4x32(k.k0, k.k1, d, 0, 0, TAG_FOLD)
     return PRNGKey(o0, o1, k.impl)
+
+
+# ---- vectorised host derivation (numpy): the 2T step / resample keys of an SMC run ------------------
+def split_words(k: PRNGKey, n: int):
+    """split(k, n) as a uint32 array [n, 2] computed with numpy (same ciphers, vectorised over the index)."""
+    import numpy as np
+
+    idx = np.arange(n, dtype=np.uint64)
+    m = np.uint64(M32)
+
+    def rotl(x, r):
+        return ((x << np.uint64(r)) | (x >> np.uint64(32 - r))) & m
+
+    if k.impl == THREEFRY:
+        ks = (np.uint64(k.k0), np.uint64(k.k1), np.uint64(0x1BD11BDA ^ k.k0 ^ k.k1))
+        x0 = ((idx >> np.uint64(32)) + ks[0]) & m
+        x1 = ((idx & m) + ks[1]) & m
+        rot = ((13, 15, 26, 6), (17, 29, 16, 24))
+        for blk in range(5):
+            for r in rot[blk & 1]:
+                x0 = (x0 + x1) & m
+                x1 = rotl(x1, r) ^ x0
+            x0 = (x0 + ks[(blk + 1) % 3]) & m
+            x1 = (x1 + ks[(blk + 2) % 3] + np.uint64(blk + 1)) & m
+        return np.stack([x0, x1], axis=1).astype(np.uint32)
+    c0, c1 = idx & m, idx >> np.uint64(32)
+    c2 = np.zeros(n, dtype=np.uint64)
+    c3 = np.full(n, TAG_SPLIT, dtype=np.uint64)
+    k0, k1 = np.uint64(k.k0), np.uint64(k.k1)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = (p1 >> np.uint64(32)) ^ c1 ^ k0, p1 & m, (p0 >> np.uint64(32)) ^ c3 ^ k1, p0 & m
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m
+    return np.stack([c0, c1], axis=1).astype(np.uint32)

@@ -54,8 +54,8 @@ class SMCResult:
 
 def smc_key_schedule(key: prng.PRNGKey, T: int):
     """step t propagates with split(key, 2T)[2t] and resamples with split(key, 2T)[2t+1]."""
-    ks = prng.split(key, 2 * T)
-    return [k.words() for k in ks[0::2]], [k.words() for k in ks[1::2]]
+    w = prng.split_words(key, 2 * T)
+    return w[0::2].copy(), w[1::2].copy()
 
 
 class BootstrapSMC:

@@ -157,8 +157,8 @@ def lgssm_exact_log_z(y) -> float:
 
 def smc_key_schedule(root: prng.PRNGKey, T: int):
     """step_keys[t], resample_keys[t] = split(root, 2T)[2t], [2t+1]."""
-    ks = prng.split(root, 2 * T)
-    return [k.words() for k in ks[0::2]], [k.words() for k in ks[1::2]]
+    w = prng.split_words(root, 2 * T)
+    return w[0::2].copy(), w[1::2].copy()
 
 
 class LgssmSMC:
