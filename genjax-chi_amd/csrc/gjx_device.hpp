@@ -312,6 +312,80 @@ GJX_HD float std_normal(uint32_t bits) {
   return 1.41421356237309505f * m_erfinv(u);
 }
 
+// --- two particles per lane: the same operation sequences on 2-vectors, which gfx950 issues as
+// packed f32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of float work per
+// instruction).  IEEE per element, so results are bit-identical to the scalar forms.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+GJX_DEV f32x2 splat2(float v) { return (f32x2){v, v}; }
+GJX_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// m_log restricted to positive NORMAL floats (no zero / subnormal handling needed by callers).
+GJX_DEV f32x2 m_log2n(f32x2 x) {
+  const u32x2 ix = __builtin_bit_cast(u32x2, x);
+  const u32x2 t = ix - 0x3f3504f3u;
+  const i32x2 e = __builtin_bit_cast(i32x2, t) >> 23;
+  const f32x2 m = __builtin_bit_cast(f32x2, (t & 0x007fffffu) + 0x3f3504f3u);
+  const f32x2 f = m - 1.0f;
+  const f32x2 z = f * f;
+  f32x2 p = splat2(7.0376836292E-2f);
+  p = fma2(p, f, splat2(-1.1514610310E-1f));
+  p = fma2(p, f, splat2(1.1676998740E-1f));
+  p = fma2(p, f, splat2(-1.2420140846E-1f));
+  p = fma2(p, f, splat2(1.4249322787E-1f));
+  p = fma2(p, f, splat2(-1.6668057665E-1f));
+  p = fma2(p, f, splat2(2.0000714765E-1f));
+  p = fma2(p, f, splat2(-2.4999993993E-1f));
+  p = fma2(p, f, splat2(3.3333331174E-1f));
+  f32x2 y = (p * f) * z;
+  const f32x2 fe = __builtin_convertvector(e, f32x2);
+  y = fma2(fe, splat2(-2.12194440e-4f), y);
+  y = fma2(splat2(-0.5f), z, y);
+  f32x2 r = f + y;
+  r = fma2(fe, splat2(0.693359375f), r);
+  return r;
+}
+GJX_DEV float erfinv_tail(float w) {  // the w >= 5 branch of m_erfinv
+  w = __builtin_sqrtf(w) - 3.0f;
+  float p = -0.000200214257f;
+  p = __builtin_fmaf(p, w, 0.000100950558f);
+  p = __builtin_fmaf(p, w, 0.00134934322f);
+  p = __builtin_fmaf(p, w, -0.00367342844f);
+  p = __builtin_fmaf(p, w, 0.00573950773f);
+  p = __builtin_fmaf(p, w, -0.0076224613f);
+  p = __builtin_fmaf(p, w, 0.00943887047f);
+  p = __builtin_fmaf(p, w, 1.00167406f);
+  p = __builtin_fmaf(p, w, 2.83297682f);
+  return p;
+}
+// std_normal for two independent 32-bit draws.
+GJX_DEV f32x2 std_normal2(uint32_t b0, uint32_t b1) {
+  const float lo = -0.99999994f;
+  f32x2 u = (f32x2){uniform01(b0), uniform01(b1)} * 2.0f + lo;
+  u.x = u.x > lo ? u.x : lo;
+  u.y = u.y > lo ? u.y : lo;
+  const f32x2 arg = (1.0f - u) * (1.0f + u);  // in (1e-7, 1]: positive normal
+  const f32x2 w = -m_log2n(arg);
+  const f32x2 wc = w - 2.5f;
+  f32x2 p = splat2(2.81022636e-08f);
+  p = fma2(p, wc, splat2(3.43273939e-07f));
+  p = fma2(p, wc, splat2(-3.5233877e-06f));
+  p = fma2(p, wc, splat2(-4.39150654e-06f));
+  p = fma2(p, wc, splat2(0.00021858087f));
+  p = fma2(p, wc, splat2(-0.00125372503f));
+  p = fma2(p, wc, splat2(-0.00417768164f));
+  p = fma2(p, wc, splat2(0.246640727f));
+  p = fma2(p, wc, splat2(1.50140941f));
+  if (!(w.x < 5.0f)) p.x = erfinv_tail(w.x);  // rare (0.3 % of draws)
+  if (!(w.y < 5.0f)) p.y = erfinv_tail(w.y);
+  return 1.41421356237309505f * (p * u);
+}
+GJX_DEV f32x2 logpdf_normal_pre2(f32x2 x, f32x2 loc, float rs, float lognorm) {
+  const f32x2 d = x * rs - loc * rs;
+  return (-0.5f * d) * d - lognorm;
+}
+
 // --- log-densities (TFP formulas).  The *_pre forms take the per-site constants a plan hoists.
 GJX_HD float normal_rs(float scale) { return 1.0f / scale; }
 GJX_HD float normal_lognorm(float scale) { return 0.91893853320467f + m_log(scale); }
@@ -321,6 +395,9 @@ GJX_HD float logpdf_normal_pre(float x, float loc, float rs, float lognorm) {
 }
 GJX_HD float logpdf_normal(float x, float loc, float scale) {
   return logpdf_normal_pre(x, loc, normal_rs(scale), normal_lognorm(scale));
+}
+GJX_DEV f32x2 logpdf_normal2(f32x2 x, f32x2 loc, f32x2 scale) {
+  return (f32x2){logpdf_normal(x.x, loc.x, scale.x), logpdf_normal(x.y, loc.y, scale.y)};
 }
 GJX_HD float xlogy(float a, float y) { return a == 0.0f ? 0.0f : a * m_log(y); }
 GJX_HD float gamma_lognorm(float conc, float rate) { return m_lgamma(conc) - conc * m_log(rate); }

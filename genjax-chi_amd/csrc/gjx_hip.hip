@@ -1301,13 +1301,15 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
         gjx_jit::Gen<CSite, CArg> g;
         g.impl = pk->impl; g.sites = p->host; g.n_sites = p->n_sites;
         if (const char* e = std::getenv("GJX_JIT_MIN_WAVES")) g.min_waves = atoi(e);
-        c.state = gjx_jit::compile(g.run(), pk->impl, &c) ? 1 : -1;
+        const std::string src = g.run();
+        c.rows_per_block = g.rows_per_block;
+        c.state = gjx_jit::compile(src, pk->impl, &c) ? 1 : -1;
       }
     }
     if (c.state == 1) {
       uint64_t nn = n;
       void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials, &row_e, &row_s};
-      const uint64_t rows = nrows_of(n);
+      const uint64_t rows = (nrows_of(n) + c.rows_per_block - 1) / c.rows_per_block;
       if (hipModuleLaunchKernel(c.fn, (unsigned)(rows > 0x7fffffffull ? 0x7fffffffull : rows), 1, 1, kBlock, 1, 1, 0,
                                 S(s), args, nullptr) != hipSuccess)
         return GJX_ERR_LAUNCH;

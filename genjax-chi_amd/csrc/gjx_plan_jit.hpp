@@ -204,9 +204,100 @@ struct Gen {
   const CSiteT* sites;
   int n_sites;
   int min_waves = 0;  // __launch_bounds__ waves-per-SIMD hint (0 = none)
+  int rows_per_block = 1;
+
+  bool all_normal() const {
+    for (int q = 0; q < n_sites; ++q) {
+      if (sites[q].dist != GJX_DIST_NORMAL) return false;
+      for (const CArgT* a : {&sites[q].a0, &sites[q].a1})
+        if (a->kind == GJX_ARG_TABLE) return false;
+    }
+    return true;
+  }
+  std::string arg2(const CArgT& a) const {
+    switch (a.kind) {
+      case GJX_ARG_CONST: return "splat2(" + flit(a.offset) + ")";
+      case GJX_ARG_SITE: return "((" + flit(a.scale) + " * vf" + std::to_string(a.ref_site) + ") + " + flit(a.offset) + ")";
+      default:
+        return "((" + flit(a.scale) + " * (f32x2){cols.in[" + std::to_string(a.ref) + "][i0], cols.in[" + std::to_string(a.ref) +
+               "][i1]}) + " + flit(a.offset) + ")";
+    }
+  }
+  // All-Normal plans: two particles per lane (rows r and r+1 of a 512-particle block) on packed f32.
+  std::string run2() {
+    const std::string I = std::to_string(impl);
+    rows_per_block = 2;
+    emit_prelude(o);
+    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_plan_kernel_" << (impl == 0 ? "threefry" : "philox")
+      << "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s) {\n";
+    o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
+    o << "  for (uint64_t blk = blockIdx.x; blk * 512 < n; blk += gridDim.x) {\n";
+    o << "    const uint64_t j0 = blk * 512 + threadIdx.x, j1 = j0 + 256;\n";
+    o << "    const bool ok0 = j0 < n, ok1 = j1 < n;\n";
+    o << "    const uint64_t i0 = ok0 ? j0 : n - 1, i1 = ok1 ? j1 : n - 1;  // surplus lanes redo the last particle, stores masked\n";
+    o << "    const Key pkA = key_at<" << I << ">(ks, i0), pkB = key_at<" << I << ">(ks, i1);\n";
+    o << "    f32x2 w = splat2(0.0f), sc = splat2(0.0f);\n";
+    int cur_blk = -1;
+    for (int q = 0; q < n_sites; ++q) {
+      const CSiteT& st = sites[q];
+      const std::string Q = std::to_string(q);
+      const uint32_t fold = (uint32_t)(q + 1);
+      o << "    // site " << q << (st.observed ? " observed" : " latent") << "\n";
+      o << "    const f32x2 a0_" << Q << " = " << arg2(st.a0) << ";\n";
+      o << "    const f32x2 a1_" << Q << " = " << arg2(st.a1) << ";\n";
+      if (st.observed) {
+        if (st.obs.kind == GJX_ARG_CONST) o << "    const f32x2 vf" << Q << " = splat2(" << flit(st.obs.offset) << ");\n";
+        else o << "    const f32x2 vf" << Q << " = (f32x2){cols.in[" << st.obs.ref << "][i0], cols.in[" << st.obs.ref << "][i1]};\n";
+      } else {
+        if (impl == 1) {
+          const int b = (int)(fold >> 2);
+          if (b != cur_blk) {
+            cur_blk = b;
+            for (const char* P : {"A", "B"}) {
+              o << "    uint32_t pw" << P << b << "_0, pw" << P << b << "_1, pw" << P << b << "_2, pw" << P << b << "_3;\n";
+              o << "    philox4x32(pk" << P << ".k0, pk" << P << ".k1, 0u, " << b << "u, 2u, kTagBits, pw" << P << b << "_0, pw" << P << b
+                << "_1, pw" << P << b << "_2, pw" << P << b << "_3);\n";
+            }
+          }
+          o << "    const uint32_t bA" << Q << " = pwA" << b << "_" << (fold & 3u) << ", bB" << Q << " = pwB" << b << "_" << (fold & 3u) << ";\n";
+        } else {
+          o << "    const uint32_t bA" << Q << " = Stream<0>(pkA, true, " << fold << "u).bits32(0), bB" << Q
+            << " = Stream<0>(pkB, true, " << fold << "u).bits32(0);\n";
+        }
+        o << "    const f32x2 t" << Q << " = a1_" << Q << " * std_normal2(bA" << Q << ", bB" << Q << ");\n";
+        o << "    const f32x2 vf" << Q << " = a0_" << Q << " + t" << Q << ";\n";
+      }
+      const std::string lp = st.pre ? "logpdf_normal_pre2(vf" + Q + ", a0_" + Q + ", " + flit(st.pre0) + ", " + flit(st.pre1) + ")"
+                                    : "logpdf_normal2(vf" + Q + ", a0_" + Q + ", a1_" + Q + ")";
+      o << "    { const f32x2 lp = " << lp << "; sc = sc + lp;" << (st.observed ? " w = w + lp;" : "") << " }\n";
+      if (st.out_col >= 0) {
+        o << "    if (ok0) reinterpret_cast<float*>(cols.out[" << st.out_col << "])[j0] = vf" << Q << ".x;\n";
+        o << "    if (ok1) reinterpret_cast<float*>(cols.out[" << st.out_col << "])[j1] = vf" << Q << ".y;\n";
+      }
+    }
+    o << "    if (ok0) { logw[j0] = w.x; if (score) score[j0] = sc.x; }\n";
+    o << "    if (ok1) { logw[j1] = w.y; if (score) score[j1] = sc.y; }\n";
+    for (int r = 0; r < 2; ++r) {
+      const std::string R = std::to_string(r), W = r == 0 ? "w.x" : "w.y", OK = r == 0 ? "ok0" : "ok1";
+      o << "    if ((max_partials || row_e) && (blk * 512 + " << (r * 256) << ") < n) {\n";
+      o << "      const float bm = block_max(" << OK << " ? " << W << " : -__builtin_inff(), sh_red);\n";
+      o << "      if (max_partials && threadIdx.x == 0) max_partials[blk * 2 + " << R << "] = bm;\n";
+      o << "      if (row_e) {\n        const int32_t eb = row_anchor(bm);\n";
+      o << "        const uint64_t sb = block_sum(" << OK << " ? rowfix(" << W << ", eb) : 0, sh_sum);\n";
+      o << "        if (threadIdx.x == 0) { row_e[blk * 2 + " << R << "] = eb; row_s[blk * 2 + " << R << "] = sb; }\n";
+      o << "      }\n    }\n";
+    }
+    o << "  }\n}\n";
+    return o.str();
+  }
 
   std::string run() {
     const std::string I = std::to_string(impl);
+    // Packed-f32 form (two particles per lane): bit-identical, but measured SLOWER on MI355X for the
+    // 10-latent model (29.1 vs 26.8 us) — the kernel is bound by the integer cipher and by issue slots,
+    // not by f32 throughput — so it is opt-in (GJX_JIT_PACKED=1) and kept for the parity tests.
+    const char* e2 = std::getenv("GJX_JIT_PACKED");
+    if (all_normal() && e2 && e2[0] == '1') return run2();
     emit_prelude(o);
     // One workgroup per 256-particle row (grid-stride): short blocks keep every SIMD's wave slots
     // full even at 1e6 particles (15 rows per lane), where a 4-row block would serialise its rows.
@@ -296,6 +387,7 @@ struct Compiled {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   int state = 0;  // 0 untried, 1 ready, -1 failed
+  int rows_per_block = 1;  // 256-particle rows one workgroup processes per grid-stride iteration
 };
 
 inline bool enabled() {

@@ -110,11 +110,13 @@ def test_categorical(hip_ops, oracle_ops, impl, mode):
             assert not bool((hv.cpu() == 2).any()), "a -inf logit must never be drawn"
 
 
-@pytest.fixture(params=["specialized", "interpreter"])
+@pytest.fixture(params=["specialized", "specialized-packed", "interpreter"])
 def plan_mode(request, monkeypatch):
-    """Both importance kernels: the hiprtc-specialised straight-line kernel (default) and the
+    """All importance kernels: the hiprtc-specialised straight-line kernel (default), its opt-in
+    two-particles-per-lane packed-f32 form for all-Normal plans (GJX_JIT_PACKED=1) and the
     site-table interpreter (GJX_PLAN_JIT=0)."""
-    monkeypatch.setenv("GJX_PLAN_JIT", "1" if request.param == "specialized" else "0")
+    monkeypatch.setenv("GJX_PLAN_JIT", "0" if request.param == "interpreter" else "1")
+    monkeypatch.setenv("GJX_JIT_PACKED", "1" if request.param == "specialized-packed" else "0")
     return request.param
 
 

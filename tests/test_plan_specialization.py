@@ -34,13 +34,19 @@ def source_of(ops, plan, impl):
 
 
 @pytest.mark.parametrize("impl", [0, 1])
-def test_gaussian10_plan_compiles(hip_lib_nogpu, impl):
+def test_gaussian10_plan_compiles(hip_lib_nogpu, impl, monkeypatch):
     ops = hip_lib_nogpu
     plan = ops.plan_create(W.gaussian10_sites(W.gaussian10_data()))
-    src = source_of(ops, plan, impl)
-    assert src.count("std_normal(") == 10 and src.count("logpdf_normal_pre(") == 20
+    src1 = source_of(ops, plan, impl)
+    assert src1.count("std_normal(") == 10 and src1.count("logpdf_normal_pre(") == 20
     if impl == 1:  # 4 leaf sites share one Philox block: sites 1..20 -> blocks 0..5, only odd sites draw
-        assert src.count("philox4x32(pkey") == 5
+        assert src1.count("philox4x32(pkey") == 5
+    ops.lib.call("gjx_plan_compile_check", plan.handle, impl)
+    monkeypatch.setenv("GJX_JIT_PACKED", "1")  # opt-in: two particles per lane on packed f32
+    src = source_of(ops, plan, impl)
+    assert src.count("std_normal2(") == 10 and src.count("logpdf_normal_pre2(") == 20
+    if impl == 1:
+        assert src.count("philox4x32(pkA") == 5 and src.count("philox4x32(pkB") == 5
     ops.lib.call("gjx_plan_compile_check", plan.handle, impl)
 
 
