@@ -592,6 +592,8 @@ struct ResampleArgs {
   int rkey_has_fold;
   uint32_t rkey_fold;
   uint64_t* q_total_out;      // nullable: block 0 stores the total mass (= sum of tile_sums)
+  const uint64_t* tile_prefix;  // nullable: exclusive prefix [ntiles + 1] of tile_sums, precomputed for
+                                // large populations (otherwise every workgroup reduces tile_sums itself)
 };
 
 // Kernel argument block of a plan-driven SMC step (the generated policy wraps it).
@@ -634,13 +636,18 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
 
   // prefix / total of tile masses (u64, exact)
   uint64_t pre = 0, tot = 0;
-  for (uint64_t k = tid; k < A.ntiles; k += kBlock) {
-    const uint64_t v = A.tile_sums[k];
-    tot += v;
-    if (k < b) pre += v;
+  if (A.tile_prefix) {
+    pre = A.tile_prefix[b];
+    tot = A.tile_prefix[A.ntiles];
+  } else {
+    for (uint64_t k = tid; k < A.ntiles; k += kBlock) {
+      const uint64_t v = A.tile_sums[k];
+      tot += v;
+      if (k < b) pre += v;
+    }
+    pre = block_sum(pre, sh64);
+    tot = block_sum(tot, sh64);
   }
-  pre = block_sum(pre, sh64);
-  tot = block_sum(tot, sh64);
   if (A.q_total_out && b == 0 && tid == 0) A.q_total_out[0] = tot;
 
   const Stream<IMPL> rs(A.rkey, A.rkey_has_fold != 0, A.rkey_fold);

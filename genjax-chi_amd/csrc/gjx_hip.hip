@@ -623,8 +623,8 @@ __global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P, f
 // The max is reduced redundantly by every block from the per-tile maxima (L2-resident).
 __global__ __launch_bounds__(kBlock) void k_tile_sums(const float* lw, uint64_t n_local,
                                                       const float* max_partials, uint64_t n_mp,
-                                                      int frac, uint64_t* tile_sums_at,
-                                                      float* max_out) {
+                                                      const float* m_ptr, int frac,
+                                                      uint64_t* tile_sums_at, float* max_out) {
   __shared__ uint64_t sh64[kBlock / kWave];
   __shared__ float shf[kBlock / kWave];
   const uint64_t tile = blockIdx.x;
@@ -634,13 +634,18 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums(const float* lw, uint64_t 
     const uint64_t i = tile * kTile + (uint64_t)r * kBlock + threadIdx.x;
     lwv[r] = i < n_local ? lw[i] : -__builtin_inff();
   }
-  float m = -__builtin_inff();
-  for (uint64_t k = threadIdx.x; k < n_mp; k += kBlock) {
-    const float v = max_partials[k];
-    m = v > m ? v : m;
+  float m;
+  if (m_ptr) {  // large populations: the max was reduced once by k_reduce_max
+    m = m_ptr[0];
+  } else {
+    m = -__builtin_inff();
+    for (uint64_t k = threadIdx.x; k < n_mp; k += kBlock) {
+      const float v = max_partials[k];
+      m = v > m ? v : m;
+    }
+    m = block_max(m, shf);
+    if (max_out && blockIdx.x == 0 && threadIdx.x == 0) max_out[0] = m;
   }
-  m = block_max(m, shf);
-  if (max_out && blockIdx.x == 0 && threadIdx.x == 0) max_out[0] = m;
   uint64_t acc = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -649,6 +654,26 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums(const float* lw, uint64_t 
   }
   acc = block_sum(acc, sh64);
   if (threadIdx.x == 0) tile_sums_at[tile] = acc;
+}
+
+// Exclusive prefix of the tile masses, [ntiles + 1] (last entry = total): one workgroup, each thread
+// scans a contiguous chunk.  Used when the population is large enough that every resample workgroup
+// re-reducing tile_sums would dominate (ntiles > kPrefixTiles).
+constexpr uint64_t kPrefixTiles = 2048;
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint64_t* tile_sums, uint64_t ntiles,
+                                                       uint64_t* prefix) {
+  __shared__ uint64_t sh64[kBlock / kWave];
+  const uint64_t per = (ntiles + kBlock - 1) / kBlock;
+  const uint64_t lo = threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
+  uint64_t local = 0;
+  for (uint64_t k = lo; k < hi; ++k) local += tile_sums[k];
+  uint64_t total;
+  uint64_t run = block_scan_excl(local, sh64, total);
+  for (uint64_t k = lo; k < hi; ++k) {
+    prefix[k] = run;
+    run += tile_sums[k];
+  }
+  if (threadIdx.x == 0) prefix[ntiles] = total;
 }
 
 // Inclusive fixed-point CDF materialised in HBM (multinomial / single-draw paths).
@@ -1011,7 +1036,7 @@ size_t gjx_workspace_bytes(int op, uint64_t n) {
     case GJX_OP_RESAMPLE:
       return pad256(nt * 4) + 2 * pad256(nt * 8) + pad256(n * 8) + 1024;
     case GJX_OP_SMC:
-      return 2 * pad256(n * 4) + pad256(nt * 4) + pad256(nt * 8) + 2 * pad256(256 * 256 * 4) + 1024;
+      return 2 * pad256(n * 4) + pad256(nt * 4) + 2 * pad256((nt + 1) * 8) + 2 * pad256(256 * 256 * 4) + 1024;
     default: return 0;
   }
 }
@@ -1415,7 +1440,7 @@ static int weights_prepare(const float* logw, uint64_t n, Carver& cv, float** m_
   float* m = cv.take<float>(1);
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   k_max_partials<<<grid_for(n), kBlock, 0, st>>>(logw, n, mp);
-  k_tile_sums<<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, frac_bits(n), tiles, m);
+  k_tile_sums<<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, nullptr, frac_bits(n), tiles, m);
   *m_out = m;
   *tiles_out = tiles;
   return GJX_OK;
@@ -1482,6 +1507,7 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
   A.lw_vec = ((uintptr_t)logw & 15) == 0;
   A.rkey = k; A.rkey_has_fold = key->has_fold; A.rkey_fold = key->fold;
   A.q_total_out = out_q ? out_q : qtot;
+  A.tile_prefix = nullptr;
   AncestorOnly P{ancestors};
   if (key->impl == 0) k_resample<0, AncestorOnly><<<(unsigned)A.ntiles, kBlock, 0, S(s)>>>(A, P, nullptr);
   else k_resample<1, AncestorOnly><<<(unsigned)A.ntiles, kBlock, 0, S(s)>>>(A, P, nullptr);
@@ -1547,10 +1573,14 @@ int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gj
   return launch_status();
 }
 
+// Set by the whole-run drivers around their step launches (large populations only).
+static thread_local const uint64_t* g_tile_prefix = nullptr;
+
 static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const float* prev_logw,
                                       const float* prev_max, const uint64_t* prev_tile_sums,
                                       uint64_t* prev_q_out) {
   ResampleArgs A;
+  A.tile_prefix = g_tile_prefix;
   A.lw = prev_logw; A.m_ptr = prev_max; A.tile_sums = prev_tile_sums;
   A.n = cfg->n_total; A.ntiles = ntiles_of(cfg->n_total); A.n_out = cfg->n_total;
   A.out_lo = (int64_t)cfg->first_slot; A.out_hi = (int64_t)(cfg->first_slot + cfg->n_local);
@@ -1623,7 +1653,12 @@ int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const flo
   if (!cfg_ok(cfg) || !logw_local || !max_partials || !max_out || !tile_sums) return GJX_ERR_INVALID;
   const uint64_t nt_total = ntiles_of(cfg->n_total);
   const uint64_t nt_local = ntiles_of(cfg->n_local);
-  k_tile_sums<<<(unsigned)nt_local, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total,
+  const float* m_ptr = nullptr;
+  if (nt_total > kPrefixTiles) {  // reduce the tile maxima once instead of in every workgroup
+    k_reduce_max<<<1, kBlock, 0, S(s)>>>(max_partials, nt_total, max_out);
+    m_ptr = max_out;
+  }
+  k_tile_sums<<<(unsigned)nt_local, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total, m_ptr,
                                                        frac_bits(cfg->n_total),
                                                        tile_sums + cfg->first_slot / kTile, max_out);
   return launch_status();
@@ -1709,6 +1744,7 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
   float* lw_ws = cv.take<float>(N);
   float* mp = cv.take<float>(nt);
   uint64_t* tiles = cv.take<uint64_t>(nt);
+  uint64_t* prefix = nt > kPrefixTiles ? cv.take<uint64_t>(nt + 1) : nullptr;
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   for (int k = 0; k < D; ++k)
     if (!state_out[k]) return GJX_ERR_INVALID;
@@ -1732,7 +1768,9 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
       if (hipModuleLaunchKernel(c.init, (unsigned)nt, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess)
         return GJX_ERR_LAUNCH;
     } else {
+      if (prefix) k_scan_tiles<<<1, kBlock, 0, S(s)>>>(tiles, nt, prefix);
       ResampleArgs A = smc_resample_args(cfg, t, lwb[prv], out_max + (t - 1), tiles, out_q + (t - 1));
+      A.tile_prefix = prefix;
       void* args[] = {&A, &PA, &mp};
       if (hipModuleLaunchKernel(c.step, (unsigned)nt, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess)
         return GJX_ERR_LAUNCH;
@@ -1758,6 +1796,7 @@ static int smc_run(const gjx_smc_config* cfg, const void* model, float* out_max,
   float* lw_ws = cv.take<float>(N);
   float* mp = cv.take<float>(nt);
   uint64_t* tiles = cv.take<uint64_t>(nt);
+  uint64_t* prefix = nt > kPrefixTiles ? cv.take<uint64_t>(nt + 1) : nullptr;
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   // ping-pong so that the last step lands in the caller's output buffers
   StateT* stb[2];
@@ -1768,8 +1807,11 @@ static int smc_run(const gjx_smc_config* cfg, const void* model, float* out_max,
   for (int t = 0; t < cfg->n_steps; ++t) {
     const int cur = t & 1, prv = cur ^ 1;
     int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * N : nullptr;
+    if (prefix && t) k_scan_tiles<<<1, kBlock, 0, S(s)>>>(tiles, nt, prefix);
+    g_tile_prefix = t ? prefix : nullptr;
     int rc = step_a(t, stb[prv], lwb[prv], t ? out_max + (t - 1) : nullptr, tiles,
                     t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur], mp, anc_t);
+    g_tile_prefix = nullptr;
     if (rc) return rc;
     rc = gjx_smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s);
     if (rc) return rc;

@@ -245,7 +245,7 @@ def test_categorical_index(hip_ops, oracle_ops, impl, mode, n):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-@pytest.mark.parametrize("n,T", [(1024, 5), (5000, 20), (100000, 30)])
+@pytest.mark.parametrize("n,T", [(1024, 5), (5000, 20), (100000, 30), (2_200_000, 3)])  # last: > 2048 tiles
 def test_smc_lgssm(hip_ops, oracle_ops, impl, n, T):
     h = W.lgssm_smc(hip_ops, impl, seed=7, n=n, T=T, want_ancestors=True)
     o = W.lgssm_smc(oracle_ops, impl, seed=7, n=n, T=T, want_ancestors=True)
