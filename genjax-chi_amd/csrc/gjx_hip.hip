@@ -659,7 +659,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums(const float* lw, uint64_t 
 // Exclusive prefix of the tile masses, [ntiles + 1] (last entry = total): one workgroup, each thread
 // scans a contiguous chunk.  Used when the population is large enough that every resample workgroup
 // re-reducing tile_sums would dominate (ntiles > kPrefixTiles).
-constexpr uint64_t kPrefixTiles = 2048;
+static const uint64_t kPrefixTiles = [] {
+  const char* e = std::getenv("GJX_PREFIX_TILES");  // tuning knob; default from measurement
+  return e ? (uint64_t)atoll(e) : (uint64_t)2048;
+}();
 __global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint64_t* tile_sums, uint64_t ntiles,
                                                        uint64_t* prefix) {
   __shared__ uint64_t sh64[kBlock / kWave];
