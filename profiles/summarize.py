@@ -18,7 +18,7 @@ here = os.path.dirname(os.path.abspath(__file__))
 def one(pattern):
     files = glob.glob(os.path.join(src, pattern))
     assert files, pattern
-    return files[0]
+    return max(files, key=os.path.getmtime)  # gpurun merges runs into the same tree: take the latest
 
 
 shutil.copy(one("trace/*/*kernel_stats.csv"), os.path.join(here, f"{tag}_kernel_stats.csv"))
