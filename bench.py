@@ -11,7 +11,7 @@ A "step" is one pass of the hot path over one batch of synthetic input, inputs r
   smc_lgssm (configs[2]): bootstrap SMC, T=100, 1e6 particles per GPU.  value = particle-steps/s.
   smc_hmm   (configs[4]): 256-state HMM, T=500.
 For N>1 (launched by torch.distributed.run, one rank per GPU) the particle population is sharded
-(weak scaling); importance needs one all-reduce(max) + one all-reduce(sum) of the log-normaliser.
+(weak scaling); importance exchanges one 520-byte record per pass (all-gather, bucketed and overlapped).
 Rank 0 prints ONE JSON line.
 """
 
@@ -97,8 +97,17 @@ def bench_importance(args, ops, rank, world):
     from genjax._amd import workloads as W
 
     impl = 1 if args.rng == "philox" else 0
-    n = args.particles
-    wl = W.Gaussian10(ops, impl, seed=0, n_local=n, first=rank * n, n_total=world * n)
+    sharded = world > 1 or FORCE_DIST
+    total_particles = args.particles * world
+    if sharded:
+        from genjax._amd import dist as gdist
+
+        # weak scaling: world x 1e6 particles split at 256-particle row boundaries (per-rank counts differ
+        # by at most one row), which keeps the exact log-normaliser independent of the number of ranks
+        first, n = gdist.shard_rows(total_particles, rank, world)
+    else:
+        first, n = 0, args.particles
+    wl = W.Gaussian10(ops, impl, seed=0, n_local=n, first=first, n_total=total_particles)
     kernel_ms = []
     # HIP events are created (and their pool grown) before the timed region
     from genjax._amd.ops import HipEvent
@@ -106,22 +115,26 @@ def bench_importance(args, ops, rank, world):
     ev_pool = [(HipEvent(), HipEvent()) for _ in range(args.steps + args.warmup)]
 
     prep = wl.prepare()  # persistent output buffers + pre-marshalled C calls: no host allocation per step
-    sharded = world > 1 or FORCE_DIST
     BATCH = 8
     if sharded:
-        from genjax._amd import dist as gdist
-
-        # sharded population: exact global log-normaliser = all-reduce(max) + all-reduce(sum of u64);
-        # the tiny collectives of BATCH independent passes are bucketed (genjax/_amd/dist.py)
-        pipe = gdist.BatchedImportance(
-            ops, lambda: W.Gaussian10(ops, impl, seed=0, n_local=n, first=rank * n, n_total=world * n), batch=BATCH)
+        # each pass leaves a 65-word record of its shard's weights; one asynchronous all-gather per BATCH
+        # passes overlaps with the next batch's kernels (genjax/_amd/dist.py)
+        pipe = gdist.BatchedImportance(ops, wl, batch=BATCH, world=world, always_exchange=True)
+    last_buf = [0]
 
     def run_sharded(count, timed):
-        evs = [ev_pool.pop() for _ in range(count)]
+        evs = {}
         sh = ops.stream()
-        pipe.run(count, on_kernel=lambda b, k: evs[b][k].record(sh))
+
+        def on_kernel(b, k):  # sample the kernel on every 4th pass, as in the single-device loop
+            if b % EVENT_EVERY == EVENT_EVERY - 1:
+                if k == 0:
+                    evs[b] = ev_pool.pop()
+                evs[b][k].record(sh)
+
+        last_buf[0] = pipe.run(count, on_kernel=on_kernel)
         if timed:
-            kernel_ms.extend(evs)
+            kernel_ms.extend(evs.values())
 
     EVENT_EVERY = 4  # an event record is a queue barrier packet (~2-3 us of device time): sample the kernel
     step_no = [0]
@@ -151,7 +164,9 @@ def bench_importance(args, ops, rank, world):
             c = min(BATCH, count - done)
             run_sharded(c, timed)
             done += c
-        return pipe.m_all[:1], pipe.q_all[:1], None
+        pipe.wait()  # every exchange has landed (stream-ordered; the host does not block)
+        _, e_all, q_all = pipe.results(last_buf[0])
+        return e_all[:1], q_all[:1], None
 
     run_steps(args.warmup, False)
     # An event record is a barrier packet in the HIP queue; a back-to-back pair with nothing in
@@ -176,11 +191,7 @@ def bench_importance(args, ops, rank, world):
     k_ms_raw = sum(a.elapsed_ms(b) for a, b in kernel_ms) / len(kernel_ms)
     k_ms = max(k_ms_raw - ev_overhead_ms, 1e-6)
     ms_per_step = dt / args.steps * 1e3
-    total_particles = n * world
-    if sharded:  # max-anchored pair (all-reduced)
-        log_z = float(m.cpu()) + math.log(int(q.cpu())) - wl.frac * math.log(2.0) - math.log(total_particles)
-    else:  # row-anchored pair from the fused partial sums
-        log_z = ops.log_z_from_rows(m, q, total_particles)
+    log_z = ops.log_z_from_rows(m, q, total_particles)  # exact (anchor, fixed-point sum) pair of the last pass
     achieved = BYTES_IMPORTANCE_KERNEL_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
     # collected by profiles/collect.sh on this same command); null if none matches this kernel/size.
@@ -202,8 +213,10 @@ def bench_importance(args, ops, rank, world):
         "unit": "particles/s",
         "ms_per_step": ms_per_step,
         "config": {"workload": "ImportanceK k_particles=1e6/GPU on a 10-latent Gaussian model (BASELINE configs[1])",
-                   "particles_per_gpu": n, "latent_sites": 10, "observed_sites": 10, "rng": args.rng,
-                   "parallelism": f"particle-sharded x{world}"},
+                   "particles_per_gpu": args.particles, "latent_sites": 10, "observed_sites": 10, "rng": args.rng,
+                   "parallelism": (f"particle-sharded x{world}, row-aligned; one 520 B all-gather per pass, "
+                                   f"bucketed x{BATCH} and overlapped with the next batch") if sharded
+                   else "single device"},
         "roofline": {"bound": "hbm", "kernel": f"gjx_plan_kernel_{args.rng}", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel_ms": k_ms, "kernel_ms_raw_event_interval": k_ms_raw,

@@ -462,6 +462,8 @@ GJX_HD uint64_t fixw(float lw, float m, int frac) {
 // global maximum; rows combine by exact right shifts.
 constexpr int kRowFrac = 30;
 constexpr int32_t kRowEmpty = -(1 << 30);
+constexpr int kLseBuckets = 64;                     // shifts 0..63 relative to the anchor
+constexpr int kLseRecordWords = 1 + kLseBuckets;    // [0] = anchor e (sign-extended), [1+d] = bucket d
 GJX_HD int32_t row_anchor(float m) {
   if (!(m > -__builtin_inff())) return kRowEmpty;  // -inf or NaN: the row carries no mass
   float t = m * 1.44269504088896341f;

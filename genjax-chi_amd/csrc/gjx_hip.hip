@@ -533,19 +533,46 @@ __global__ __launch_bounds__(kBlock) void k_row_stats(const float* x, uint64_t n
     }
   }
 }
-// one block: e = max e_b, Q = sum_b S_b >> (e - e_b), lse = e ln2 + log(Q 2^-30).
+// one block: e = max e_b; buckets B_d = sum of S_b over rows with e - e_b == d (d < 64, exact);
+// Q = sum_d B_d >> d; lse = e ln2 + log(Q 2^-30).  The (e, B_0..B_63) record is what ranks exchange:
+// bucket sums are exact integers, so records merge (k_lse_combine) into the same bits for any sharding.
 // Up to 16 rows per thread are held in registers (all loads in flight at once: one memory latency),
 // which covers 4096 rows = 1M particles; larger populations take the two-pass loop.
+GJX_DEV void lse_emit(int32_t e, uint64_t bucket, int32_t* out_e, uint64_t* out_q, float* out_lse,
+                      uint64_t* out_record) {
+  // called by the first wave: lane d holds bucket d
+  const uint64_t q = wave_sum(bucket >> (threadIdx.x & 63));
+  if (out_record) {
+    out_record[1 + threadIdx.x] = bucket;
+    if (threadIdx.x == 0) out_record[0] = (uint64_t)(int64_t)e;
+  }
+  if (threadIdx.x == 0) {
+    if (out_e) out_e[0] = e;
+    if (out_q) out_q[0] = q;
+    if (out_lse) {
+      if (e == kRowEmpty || q == 0) {
+        out_lse[0] = -__builtin_inff();
+      } else {
+        const float t1 = (float)e * 0.69314718055994531f;
+        const float t2 = m_log((float)q * u2f((uint32_t)(127 - kRowFrac) << 23));
+        out_lse[0] = t1 + t2;
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(kBlock) void k_lse_rows(const int32_t* row_e, const uint64_t* row_s,
                                                      uint64_t n_rows, int32_t* out_e,
-                                                     uint64_t* out_q, float* out_lse) {
+                                                     uint64_t* out_q, float* out_lse,
+                                                     uint64_t* out_record) {
   __shared__ int32_t she[kBlock / kWave];
-  __shared__ uint64_t sh64[kBlock / kWave];
+  __shared__ unsigned long long shb[kLseBuckets];
   constexpr int kPer = 16;
+  constexpr int kNear = 4;  // shifts 0..3 (practically every row) accumulate in registers
   const bool in_regs = n_rows <= (uint64_t)kPer * kBlock;
   int32_t ev[kPer];
   uint64_t sv[kPer];
   int32_t e = kRowEmpty;
+  if (threadIdx.x < kLseBuckets) shb[threadIdx.x] = 0;
   if (in_regs) {
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
@@ -568,35 +595,52 @@ __global__ __launch_bounds__(kBlock) void k_lse_rows(const int32_t* row_e, const
   e = she[0];
 #pragma unroll
   for (int i = 1; i < kBlock / kWave; ++i) e = she[i] > e ? she[i] : e;
-  uint64_t acc = 0;
+  uint64_t near[kNear] = {0, 0, 0, 0};
+  auto add_row = [&](int32_t eb, uint64_t sb) {
+    if (eb == kRowEmpty) return;
+    const int64_t d = (int64_t)e - (int64_t)eb;
+#pragma unroll
+    for (int k = 0; k < kNear; ++k) near[k] += d == k ? sb : 0;
+    if (d >= kNear && d < kLseBuckets && sb) atomicAdd(&shb[d], (unsigned long long)sb);
+  };
   if (in_regs) {
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int64_t sh = (int64_t)e - (int64_t)ev[k];
-      acc += (ev[k] == kRowEmpty || sh > 63) ? 0 : (sv[k] >> sh);
-    }
+    for (int k = 0; k < kPer; ++k) add_row(ev[k], sv[k]);
   } else {
-    for (uint64_t b = threadIdx.x; b < n_rows; b += kBlock) {
-      const int32_t eb = row_e[b];
-      if (eb == kRowEmpty) continue;
-      const int64_t sh = (int64_t)e - (int64_t)eb;
-      acc += sh > 63 ? 0 : (row_s[b] >> sh);
-    }
+    for (uint64_t b = threadIdx.x; b < n_rows; b += kBlock) add_row(row_e[b], row_s[b]);
   }
-  acc = block_sum(acc, sh64);
-  if (threadIdx.x == 0) {
-    if (out_e) out_e[0] = e;
-    if (out_q) out_q[0] = acc;
-    if (out_lse) {
-      if (e == kRowEmpty || acc == 0) {
-        out_lse[0] = -__builtin_inff();
-      } else {
-        const float t1 = (float)e * 0.69314718055994531f;
-        const float t2 = m_log((float)acc * u2f((uint32_t)(127 - kRowFrac) << 23));
-        out_lse[0] = t1 + t2;
-      }
-    }
+#pragma unroll
+  for (int k = 0; k < kNear; ++k) {
+    const uint64_t w = wave_sum(near[k]);
+    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&shb[k], (unsigned long long)w);
   }
+  __syncthreads();
+  if (threadIdx.x < kLseBuckets) lse_emit(e, (uint64_t)shb[threadIdx.x], out_e, out_q, out_lse, out_record);
+}
+// Merge `n_records` records (one per rank; consecutive records `record_stride` words apart) for each of
+// gridDim.x independent passes (`batch_stride` words apart): buckets re-indexed to the common anchor.
+__global__ __launch_bounds__(kWave) void k_lse_combine(const uint64_t* records, int n_records,
+                                                       uint64_t record_stride, uint64_t batch_stride,
+                                                       int32_t* out_e, uint64_t* out_q, float* out_lse,
+                                                       uint64_t* out_record) {
+  const uint64_t* base = records + (uint64_t)blockIdx.x * batch_stride;
+  int32_t e = kRowEmpty;
+  for (int r = 0; r < n_records; ++r) {
+    const int32_t er = (int32_t)(int64_t)base[(uint64_t)r * record_stride];
+    e = er > e ? er : e;
+  }
+  uint64_t bucket = 0;
+  const int d = threadIdx.x;
+  for (int r = 0; r < n_records; ++r) {
+    const uint64_t* rec = base + (uint64_t)r * record_stride;
+    const int32_t er = (int32_t)(int64_t)rec[0];
+    if (er == kRowEmpty) continue;
+    const int64_t k = (int64_t)d - ((int64_t)e - (int64_t)er);
+    if (k >= 0) bucket += rec[1 + k];
+  }
+  lse_emit(e, bucket, out_e ? out_e + blockIdx.x : nullptr, out_q ? out_q + blockIdx.x : nullptr,
+           out_lse ? out_lse + blockIdx.x : nullptr,
+           out_record ? out_record + (uint64_t)blockIdx.x * kLseRecordWords : nullptr);
 }
 __global__ void k_lse_finish(const float* m_ptr, const uint64_t* q_ptr, int frac, float* out) {
   const float qf = (float)q_ptr[0] * u2f((uint32_t)(127 - frac) << 23);
@@ -1402,9 +1446,17 @@ int gjx_row_stats(const float* x, uint64_t n, int32_t* row_e, uint64_t* row_s, g
   return launch_status();
 }
 int gjx_lse_rows(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, int32_t* out_e,
-                 uint64_t* out_q, float* out_lse, gjx_stream s) {
+                 uint64_t* out_q, float* out_lse, uint64_t* out_record, gjx_stream s) {
   if (!row_e || !row_s || n_rows == 0) return GJX_ERR_INVALID;
-  k_lse_rows<<<1, kBlock, 0, S(s)>>>(row_e, row_s, n_rows, out_e, out_q, out_lse);
+  k_lse_rows<<<1, kBlock, 0, S(s)>>>(row_e, row_s, n_rows, out_e, out_q, out_lse, out_record);
+  return launch_status();
+}
+int gjx_lse_combine(const uint64_t* records, int32_t n_records, uint64_t record_stride, int32_t n_batch,
+                    uint64_t batch_stride, int32_t* out_e, uint64_t* out_q, float* out_lse,
+                    uint64_t* out_record, gjx_stream s) {
+  if (!records || n_records < 1 || n_batch < 1 || record_stride < GJX_LSE_RECORD_WORDS) return GJX_ERR_INVALID;
+  k_lse_combine<<<(unsigned)n_batch, kWave, 0, S(s)>>>(records, n_records, record_stride, batch_stride, out_e,
+                                                       out_q, out_lse, out_record);
   return launch_status();
 }
 int gjx_lse_finish(const float* max_dev, const uint64_t* q_dev, int frac_bits_, float* out_lse,

@@ -32,6 +32,7 @@ STATUS = {
 RNG_THREEFRY = 0
 RNG_PHILOX = 1
 
+LSE_RECORD_WORDS = 65  # include/gjx.h: GJX_LSE_RECORD_WORDS
 DIST_NORMAL, DIST_GAMMA, DIST_BETA, DIST_BERNOULLI, DIST_CATEGORICAL = range(5)
 ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE, ARG_STATE, ARG_OBS = range(6)
 SMC_MAX_STATE, SMC_MAX_OBS = 4, 8
@@ -169,7 +170,8 @@ PROTOTYPES = {
     "gjx_num_tiles": (C.c_uint64, [C.c_uint64]),
     "gjx_num_max_partials": (C.c_uint64, [C.c_uint64]),
     "gjx_row_stats": (C.c_int, [_P, C.c_uint64, _P, _P, _P]),
-    "gjx_lse_rows": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P]),
+    "gjx_lse_rows": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, _P]),
+    "gjx_lse_combine": (C.c_int, [_P, C.c_int32, C.c_uint64, C.c_int32, C.c_uint64, _P, _P, _P, _P, _P]),
     "gjx_max_f32": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.c_size_t, _P]),
     "gjx_expsum_fix": (C.c_int, [_P, C.c_uint64, _P, C.c_int, _P, _P, C.c_size_t, _P]),
     "gjx_lse_finish": (C.c_int, [_P, _P, C.c_int, _P, _P]),

@@ -8,8 +8,11 @@ this is a new design around two properties of the single-device path:
 so a population sharded over G ranks produces bit-identical particles, ancestors and log-Z for
 every G — the exchange is pure data movement, never a change of arithmetic.
 
-ImportanceK: rank r runs slots [r n, (r+1) n) with no communication; the global log-normaliser needs
-one all-reduce(max) of a float and one all-reduce(sum) of an int64 (exact, order-independent).
+ImportanceK: rank r runs a row-aligned block of slots with no data-path communication.  The importance
+kernel emits row-anchored partial sums of its own log-weights; one tiny kernel folds them into a
+65-word record (anchor exponent + 64 exact integer buckets) and ONE all-gather of that
+record per pass yields the global log-normaliser — no second pass over the log-weights, no all-reduce
+pair, and the merged result is bit-identical for every number of ranks.
 
 Bootstrap SMC: resampling is global.  Per step each rank (1) resamples + propagates + weights its own
 output slots reading the GLOBAL previous population, (2) all-reduce(max) of the per-tile maxima,
@@ -36,63 +39,92 @@ def _dist():
     return dist
 
 
-def importance_log_z(ops: Ops, wl: "W.Gaussian10", prep=None):
-    """Sharded ImportanceK pass -> (log_z float64, local logw).  `wl` was built with first / n_total."""
-    dist = _dist()
-    if prep is None:
-        prep = wl.prepare()
-    prep.launch_importance()
-    m = ops.max_f32(None, wl.n, max_partials=prep.max_partials)
-    dist.all_reduce(m, op=dist.ReduceOp.MAX)
-    q = ops.expsum_fix(prep.logw, m, wl.frac)
-    dist.all_reduce(q, op=dist.ReduceOp.SUM)
-    log_z = float(m.cpu()) + math.log(int(q.cpu())) - wl.frac * math.log(2.0) - math.log(wl.n_total)
-    return log_z, prep.logw, m, q
+ROW = 256  # particles per row of the row-anchored partial sums (gjx_num_max_partials)
+
+
+def shard_rows(n_total: int, rank: int, world: int) -> tuple[int, int]:
+    """(first slot, slot count) of rank's block when the population is split at row boundaries (what
+    keeps the row-anchored log-normaliser independent of the number of ranks)."""
+    rows = -(-n_total // ROW)
+    r0, r1 = rows * rank // world, rows * (rank + 1) // world
+    first = r0 * ROW
+    return first, min(r1 * ROW, n_total) - first
 
 
 class BatchedImportance:
-    """Sharded ImportanceK passes with *bucketed* collectives: B independent passes are issued back to
-    back, their B local maxima are all-reduced as ONE message, then the B fixed-point sums as one more.
-    A small-message RCCL all-reduce costs tens of microseconds of latency (and as much host time to
-    enqueue), more than the 29 us kernel; bucketing B passes amortises it B-fold — the xGMI analogue
-    of gradient bucketing.  Each pass keeps its own output buffers (B x 48 MB at 1e6 particles)."""
+    """Sharded ImportanceK passes with *bucketed, overlapped* collectives.
 
-    def __init__(self, ops: Ops, make_workload, batch: int = 8):
-        self.ops, self.batch = ops, batch
-        dev = ops.device()
-        self.m_all = torch.empty(batch, dtype=torch.float32, device=dev)
-        self.q_all = torch.empty(batch, dtype=torch.int64, device=dev)
-        self.preps = []
-        self.wl = None
-        for _ in range(batch):
-            wl = make_workload()
-            self.wl = self.wl or wl
-            self.preps.append((wl, ops.prepare_importance(wl.plan, wl.keys, wl.n, [], [torch.float32] * W.G10_LATENTS,
-                                                          with_lse=False)))
-        self.m_views = [self.m_all[b:b + 1] for b in range(batch)]
-        self.q_views = [self.q_all[b:b + 1] for b in range(batch)]
+    A pass = importance kernel + `gjx_lse_rows`, which leaves the shard's 65-word record in slot b of a
+    [batch, 65] block.  After `batch` passes the block is all-gathered ONCE, asynchronously (RCCL runs on
+    its own stream), while the next batch already computes into the other block of a double buffer; the
+    wait is deferred until that block is reused or its results are read.  A small-message RCCL collective
+    costs tens of microseconds — more than the 28 us kernel — so this is the xGMI analogue of gradient
+    bucketing with compute/communication overlap: per pass the exchange costs 1/batch of one collective
+    and none of the device's time.  Passes reuse one set of trace buffers (48 MB at 1e6 particles)."""
 
-    def run(self, count: int | None = None, on_kernel=None):
-        """`count` (<= batch) passes; afterwards m_all[:count], q_all[:count] hold the global pairs."""
-        dist, ops = _dist(), self.ops
+    def __init__(self, ops: Ops, wl, batch: int = 8, world: int | None = None, depth: int = 2,
+                 always_exchange: bool = False):
+        import ctypes as C
+
+        dist = _dist()
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        if self.world > 1 and (wl.first % ROW or (wl.n % ROW and wl.first + wl.n != wl.n_total)):
+            raise ValueError("shards must be split at 256-particle row boundaries (dist.shard_rows)")
+        self.ops, self.wl, self.batch, self.depth = ops, wl, batch, depth
+        self.prep = wl.prepare()
+        dev, words = ops.device(), abi.LSE_RECORD_WORDS
+        self.local = [torch.zeros((batch, words), dtype=torch.int64, device=dev) for _ in range(depth)]
+        self.exchange = self.world > 1 or always_exchange  # a one-rank group still goes through the collective
+        self.gathered = [torch.zeros((self.world, batch, words), dtype=torch.int64, device=dev) if self.exchange
+                         else t.view(1, batch, words) for t in self.local]
+        self._rec = [[C.c_void_p(t[b].data_ptr()) for b in range(batch)] for t in self.local]
+        self._work = [None] * depth
+        self._count = [0] * depth
+        self._slot = 0
+
+    def run(self, count: int | None = None, on_kernel=None) -> int:
+        """Enqueue `count` (<= batch) passes and the exchange of their records; returns the buffer
+        index to hand to `results`."""
         count = self.batch if count is None else count
+        d, self._slot = self._slot, (self._slot + 1) % self.depth
+        self.wait(d)  # the block's previous exchange must have read it before it is overwritten
+        st = self.ops.stream()
         for b in range(count):
-            wl, prep = self.preps[b]
             if on_kernel:
                 on_kernel(b, 0)
-            prep.launch_importance()
+            self.prep.launch_importance(st)
             if on_kernel:
                 on_kernel(b, 1)
-            ops.max_f32(None, wl.n, max_partials=prep.max_partials, out=self.m_views[b])
-        dist.all_reduce(self.m_all[:count], op=dist.ReduceOp.MAX)
-        for b in range(count):
-            wl, prep = self.preps[b]
-            ops.expsum_fix(prep.logw, self.m_views[b], wl.frac, out=self.q_views[b])
-        dist.all_reduce(self.q_all[:count], op=dist.ReduceOp.SUM)
+            self.prep.launch_lse_rows(st, self._rec[d][b])
+        if self.exchange:
+            self._work[d] = _dist().all_gather_into_tensor(self.gathered[d].view(-1, self.gathered[d].shape[-1]),
+                                                            self.local[d], async_op=True)
+        self._count[d] = count
+        return d
 
-    def log_z(self, b: int = 0) -> float:
-        return (float(self.m_all[b].cpu()) + math.log(int(self.q_all[b].cpu())) - self.wl.frac * math.log(2.0)
-                - math.log(self.wl.n_total))
+    def wait(self, d: int | None = None):
+        for i in (range(self.depth) if d is None else (d,)):
+            if self._work[i] is not None:
+                self._work[i].wait()
+                self._work[i] = None
+
+    def results(self, d: int):
+        """(lse f32[count], e i32[count], q i64[count]) of buffer d's passes (device tensors)."""
+        self.wait(d)
+        return self.ops.lse_combine(self.gathered[d], self._count[d])
+
+    def log_z(self, d: int, b: int = 0) -> float:
+        _, e, q = self.results(d)
+        return self.ops.log_z_from_rows(e[b], q[b], self.wl.n_total)
+
+
+def importance_log_z(ops: Ops, wl: "W.Gaussian10"):
+    """One sharded ImportanceK pass -> (log_z float64, local logw, e, q).  `wl` was built with the
+    rank's (first, n_local) from `shard_rows` and the global n_total."""
+    pipe = BatchedImportance(ops, wl, batch=1, depth=1)
+    d = pipe.run(1)
+    _, e, q = pipe.results(d)
+    return ops.log_z_from_rows(e[0], q[0], wl.n_total), pipe.prep.logw, e, q
 
 
 class ShardedLgssmSMC:

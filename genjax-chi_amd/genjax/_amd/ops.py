@@ -225,11 +225,26 @@ class Ops:
                       self.stream())
         return rows
 
-    def lse_rows(self, rows: "RowStats"):
-        """-> (lse f32[1], e i32[1], q i64[1]) on device."""
+    def lse_rows(self, rows: "RowStats", record: torch.Tensor | None = None):
+        """-> (lse f32[1], e i32[1], q i64[1]) on device; `record` (int64[65]) also receives the
+        exchangeable (anchor, buckets) summary of these rows (gjx.h: GJX_LSE_RECORD_WORDS)."""
         lse, e, q = self.empty(1, torch.float32), self.empty(1, torch.int32), self.empty(1, torch.int64)
         self.lib.call("gjx_lse_rows", self._p(rows.e), self._p(rows.s), rows.e.numel(), self._p(e), self._p(q),
-                      self._p(lse), self.stream())
+                      self._p(lse), None if record is None else self._chk(record, torch.int64, abi.LSE_RECORD_WORDS, "record"),
+                      self.stream())
+        return lse, e, q
+
+    def lse_combine(self, records: torch.Tensor, n_batch: int | None = None):
+        """records int64[n_records, batch, 65] (the all-gather of per-rank [batch, 65] blocks) ->
+        (lse f32[n_batch], e i32[n_batch], q i64[n_batch]): the merged log-sum-exp of the first
+        n_batch passes, bit-identical to one lse_rows over the whole population."""
+        g, b, w = records.shape
+        if w != abi.LSE_RECORD_WORDS or records.dtype != torch.int64 or not records.is_contiguous():
+            raise ValueError("records must be contiguous int64[n_records, batch, 65]")
+        n_batch = b if n_batch is None else n_batch
+        lse, e, q = self.empty(n_batch, torch.float32), self.empty(n_batch, torch.int32), self.empty(n_batch, torch.int64)
+        self.lib.call("gjx_lse_combine", self._p(records), g, b * w, n_batch, w, self._p(e), self._p(q), self._p(lse),
+                      None, self.stream())
         return lse, e, q
 
     @staticmethod
@@ -494,6 +509,7 @@ class PreparedImportance:
         self._args_lse_rows = (C.c_void_p(self.rows.e.data_ptr()), C.c_void_p(self.rows.s.data_ptr()),
                                self.rows.e.numel(), C.c_void_p(self.row_e_out.data_ptr()),
                                C.c_void_p(self.row_q_out.data_ptr()), C.c_void_p(self.lse.data_ptr()))
+        self._no_record = C.c_void_p(None)
         self._args_lse = (C.c_void_p(self.logw.data_ptr()), n, C.c_void_p(self.max_partials.data_ptr()),
                           C.c_void_p(self.lse.data_ptr()), C.c_void_p(self.max.data_ptr()), C.c_void_p(self.q.data_ptr()),
                           C.c_void_p(self._ws.data_ptr()), self._nb)
@@ -509,10 +525,12 @@ class PreparedImportance:
         if rc:
             raise abi.GjxError("gjx_logsumexp_f32", rc)
 
-    def launch_lse_rows(self, stream=None):
+    def launch_lse_rows(self, stream=None, record_ptr=None):
         """Row-anchored log-sum-exp from the partial sums the importance kernel emitted: one tiny
-        kernel, no pass over logw.  Results in .lse, .row_e_out, .row_q_out."""
-        rc = self._lse_rows(*self._args_lse_rows, stream if stream is not None else self.ops.stream())
+        kernel, no pass over logw.  Results in .lse, .row_e_out, .row_q_out; `record_ptr`
+        (C.c_void_p of a dev int64[65]) also receives the shard's exchangeable record."""
+        rc = self._lse_rows(*self._args_lse_rows, self._no_record if record_ptr is None else record_ptr,
+                            stream if stream is not None else self.ops.stream())
         if rc:
             raise abi.GjxError("gjx_lse_rows", rc)
 

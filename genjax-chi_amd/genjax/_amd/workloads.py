@@ -85,8 +85,7 @@ class Gaussian10:
     def prepare(self):
         """Persistent-buffer form of `step` (no host allocation per pass)."""
         if getattr(self, "_prep", None) is None:
-            self._prep = self.ops.prepare_importance(self.plan, self.keys, self.n, [], [torch.float32] * G10_LATENTS,
-                                                     with_lse=(self.n_total == self.n))
+            self._prep = self.ops.prepare_importance(self.plan, self.keys, self.n, [], [torch.float32] * G10_LATENTS)
         return self._prep
 
     def step(self):
@@ -100,13 +99,10 @@ class Gaussian10:
             rlse, re, rq = self.ops.lse_rows(rows)  # row-anchored form (fused into the kernel, §3.5b)
             return dict(values=vals, score=score, logw=logw, lse=lse, max=m, q=q, rows=rows, row_lse=rlse,
                         row_e=re, row_q=rq)
-        m = self.ops.max_f32(None, self.n, max_partials=mp)
-        return dict(values=vals, score=score, logw=logw, max=m, max_partials=mp)
-
-    def finish_distributed(self, out, global_max: torch.Tensor):
-        """Second half for the sharded run: local fixed-point sum under the all-reduced max."""
-        out["q"] = self.ops.expsum_fix(out["logw"], global_max, self.frac)
-        return out
+        # a shard of a larger population: its exchangeable record (dist.BatchedImportance merges them)
+        record = torch.zeros(abi.LSE_RECORD_WORDS, dtype=torch.int64, device=logw.device)
+        self.ops.lse_rows(rows, record=record)
+        return dict(values=vals, score=score, logw=logw, rows=rows, record=record, max_partials=mp)
 
 
 def gaussian10_importance(ops: Ops, impl: int, seed: int, n: int):

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define GJX_VERSION_MAJOR 0
-#define GJX_VERSION_MINOR 1
+#define GJX_VERSION_MINOR 2
 
 typedef void* gjx_stream; /* hipStream_t; ignored by the oracle build */
 
@@ -217,11 +217,28 @@ uint64_t gjx_num_max_partials(uint64_t n); /* rows: entries of max_partials / ro
  * (row_e[b], row_s[b]): anchor exponent e_b = ceil(max_b * log2 e) and S_b = sum of
  * rint(exp(x_i - e_b ln 2) * 2^30) as exact u64 — computable by the kernel that PRODUCES the
  * log-weights, before any global maximum exists (gjx_importance_run fills them when row_e/row_s
- * are given).  Rows combine exactly: e = max e_b, Q = sum_b (S_b >> (e - e_b)),
- * lse = e ln 2 + log(Q 2^-30).  gjx_row_stats is the one-pass producer for arbitrary x. */
+ * are given).  Rows combine exactly: e = max e_b; bucket B_d = sum of S_b over the rows with
+ * e - e_b == d, d in [0, 64) (exact u64; rows further below carry no mass); Q = sum_d (B_d >> d);
+ * lse = e ln 2 + log(Q 2^-30).  gjx_row_stats is the one-pass producer for arbitrary x.
+ *
+ * out_record (nullable, dev u64[GJX_LSE_RECORD_WORDS]): word 0 = e (int64), word 1+d = B_d — the
+ * exchangeable summary of a population shard.  Bucket sums are exact integers, so records of shards
+ * that split the population at row boundaries merge (gjx_lse_combine) into the SAME (e, Q, lse) as one
+ * gjx_lse_rows over all rows: a sharded ImportanceK pass needs ONE all-gather of 520 bytes per rank and
+ * no pass over logw (replaces logsumexp(lw) at inference/smc.py:97 for a sharded population). */
+#define GJX_LSE_RECORD_WORDS 65
 int gjx_row_stats(const float* x, uint64_t n, int32_t* row_e, uint64_t* row_s, gjx_stream s);
 int gjx_lse_rows(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, int32_t* out_e /*nullable*/,
-                 uint64_t* out_q /*nullable*/, float* out_lse /*nullable*/, gjx_stream s);
+                 uint64_t* out_q /*nullable*/, float* out_lse /*nullable*/, uint64_t* out_record /*nullable*/,
+                 gjx_stream s);
+/* Merge records: for each of n_batch independent passes p (records of pass p start at
+ * records + p*batch_stride words) combine n_records records lying record_stride words apart
+ * (>= GJX_LSE_RECORD_WORDS; the layout of an all-gather of [n_batch, 65] blocks is record_stride =
+ * n_batch*65, batch_stride = 65).  Outputs are arrays of n_batch entries (each nullable);
+ * out_record dev u64[n_batch, 65] receives the merged records. */
+int gjx_lse_combine(const uint64_t* records, int32_t n_records, uint64_t record_stride, int32_t n_batch,
+                    uint64_t batch_stride, int32_t* out_e, uint64_t* out_q, float* out_lse,
+                    uint64_t* out_record, gjx_stream s);
 
 /* out_max[0] = max_i x[i] (dev f32). Pass 1 of logsumexp; multi-GPU callers all-reduce(max) it.
  * max_partials_in: nullable row maxima already produced by gjx_importance_run

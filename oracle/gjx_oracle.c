@@ -470,17 +470,14 @@ int gjx_row_stats(const float* x, uint64_t n, int32_t* row_e, uint64_t* row_s, g
   }
   return GJX_OK;
 }
-int gjx_lse_rows(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, int32_t* out_e,
-                 uint64_t* out_q, float* out_lse, gjx_stream s) {
-  (void)s;
-  if (!row_e || !row_s || n_rows == 0) return GJX_ERR_INVALID;
-  int32_t e = O_ROW_EMPTY;
-  for (uint64_t b = 0; b < n_rows; ++b) e = row_e[b] > e ? row_e[b] : e;
+/* Shared tail: Q = sum_d B_d >> d, optional record, f32 lse. */
+static void lse_emit(int32_t e, const uint64_t* B, int32_t* out_e, uint64_t* out_q, float* out_lse,
+                     uint64_t* out_record) {
   uint64_t Q = 0;
-  for (uint64_t b = 0; b < n_rows; ++b) {
-    if (row_e[b] == O_ROW_EMPTY) continue;
-    int64_t sh = (int64_t)e - (int64_t)row_e[b];
-    Q += sh > 63 ? 0 : (row_s[b] >> sh);
+  for (int d = 0; d < GJX_LSE_RECORD_WORDS - 1; ++d) Q += B[d] >> d;
+  if (out_record) {
+    out_record[0] = (uint64_t)(int64_t)e;
+    memcpy(out_record + 1, B, sizeof(uint64_t) * (GJX_LSE_RECORD_WORDS - 1));
   }
   if (out_e) *out_e = e;
   if (out_q) *out_q = Q;
@@ -491,6 +488,45 @@ int gjx_lse_rows(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, i
       float t2 = o_log((float)Q * o_u2f((uint32_t)(127 - O_ROW_FRAC) << 23));
       *out_lse = t1 + t2;
     }
+  }
+}
+int gjx_lse_rows(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, int32_t* out_e,
+                 uint64_t* out_q, float* out_lse, uint64_t* out_record, gjx_stream s) {
+  (void)s;
+  if (!row_e || !row_s || n_rows == 0) return GJX_ERR_INVALID;
+  int32_t e = O_ROW_EMPTY;
+  for (uint64_t b = 0; b < n_rows; ++b) e = row_e[b] > e ? row_e[b] : e;
+  uint64_t B[GJX_LSE_RECORD_WORDS - 1] = {0};
+  for (uint64_t b = 0; b < n_rows; ++b) {
+    if (row_e[b] == O_ROW_EMPTY) continue;
+    int64_t d = (int64_t)e - (int64_t)row_e[b];
+    if (d < GJX_LSE_RECORD_WORDS - 1) B[d] += row_s[b];
+  }
+  lse_emit(e, B, out_e, out_q, out_lse, out_record);
+  return GJX_OK;
+}
+int gjx_lse_combine(const uint64_t* records, int32_t n_records, uint64_t record_stride, int32_t n_batch,
+                    uint64_t batch_stride, int32_t* out_e, uint64_t* out_q, float* out_lse,
+                    uint64_t* out_record, gjx_stream s) {
+  (void)s;
+  if (!records || n_records < 1 || n_batch < 1 || record_stride < GJX_LSE_RECORD_WORDS) return GJX_ERR_INVALID;
+  for (int32_t p = 0; p < n_batch; ++p) {
+    const uint64_t* base = records + (uint64_t)p * batch_stride;
+    int32_t e = O_ROW_EMPTY;
+    for (int32_t r = 0; r < n_records; ++r) {
+      int32_t er = (int32_t)(int64_t)base[(uint64_t)r * record_stride];
+      e = er > e ? er : e;
+    }
+    uint64_t B[GJX_LSE_RECORD_WORDS - 1] = {0};
+    for (int32_t r = 0; r < n_records; ++r) {
+      const uint64_t* rec = base + (uint64_t)r * record_stride;
+      int32_t er = (int32_t)(int64_t)rec[0];
+      if (er == O_ROW_EMPTY) continue;
+      int64_t off = (int64_t)e - (int64_t)er;
+      for (int64_t k = 0; k + off < GJX_LSE_RECORD_WORDS - 1; ++k) B[k + off] += rec[1 + k];
+    }
+    lse_emit(e, B, out_e ? out_e + p : NULL, out_q ? out_q + p : NULL, out_lse ? out_lse + p : NULL,
+             out_record ? out_record + (uint64_t)p * GJX_LSE_RECORD_WORDS : NULL);
   }
   return GJX_OK;
 }

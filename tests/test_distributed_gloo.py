@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, impl, n_total, T, out_dir):
+def _worker(rank, world, port, impl, n_total, n_imp_total, T, out_dir):
     sys.path.insert(0, os.path.join(ROOT, "genjax-chi_amd"))
     import torch.distributed as dist
 
@@ -34,18 +34,21 @@ def _worker(rank, world, port, impl, n_total, T, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     ops = Ops(GjxLib(ORACLE_LIB, "cpu"))
-    n_local = n_total // world
-    wl = W.Gaussian10(ops, impl, seed=3, n_local=n_local, first=rank * n_local, n_total=n_total)
-    log_z, logw, m, q = gdist.importance_log_z(ops, wl)
-    pipe = gdist.BatchedImportance(
-        ops, lambda: W.Gaussian10(ops, impl, seed=3, n_local=n_local, first=rank * n_local, n_total=n_total), batch=3)
-    pipe.run()
-    pipe.run(2)
-    assert all(torch.equal(pipe.m_all[b:b + 1], m) and torch.equal(pipe.q_all[b:b + 1], q) for b in range(3))
-    assert pipe.log_z(1) == log_z
+    first, n_imp = gdist.shard_rows(n_imp_total, rank, world)  # uneven row-aligned blocks, ragged tail
+    wl = W.Gaussian10(ops, impl, seed=3, n_local=n_imp, first=first, n_total=n_imp_total)
+    log_z, logw, e, q = gdist.importance_log_z(ops, wl)
+    logw = logw.clone()
+    pipe = gdist.BatchedImportance(ops, wl, batch=3)  # 5 passes through a double-buffered batch of 3
+    d0 = pipe.run()
+    d1 = pipe.run(2)
+    for d, cnt in ((d0, 3), (d1, 2)):
+        _, eb, qb = pipe.results(d)
+        assert eb.numel() == cnt and all(torch.equal(eb[b:b + 1], e) and torch.equal(qb[b:b + 1], q) for b in range(cnt))
+    d2 = pipe.run(1)  # reuses the first block after its exchange completed
+    assert pipe.log_z(d2) == log_z
     smc = gdist.ShardedLgssmSMC(ops, impl, seed=5, n_total=n_total, T=T, rank=rank, world=world,
                                 record_ancestors=True).run()
-    torch.save(dict(log_z=log_z, logw=logw.clone(), m=m, q=q, smc_max=smc["out_max"], smc_q=smc["out_q"],
+    torch.save(dict(log_z=log_z, logw=logw, e=e, q=q, smc_max=smc["out_max"], smc_q=smc["out_q"],
                     smc_state=smc["state"].clone(), smc_anc=smc["ancestors"], smc_log_z=smc["log_z"]),
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
@@ -57,14 +60,17 @@ def test_two_ranks_equal_one_rank(tmp_path, oracle_ops, impl):
     from genjax._amd import workloads as W
 
     world, n_total, T = 2, 8192, 7
-    mp.spawn(_worker, args=(world, _free_port(), impl, n_total, T, str(tmp_path)), nprocs=world, join=True)
+    n_imp_total = 256 * 37 + 100  # 38 rows (the last one ragged) split 19 / 19
+    mp.spawn(_worker, args=(world, _free_port(), impl, n_total, n_imp_total, T, str(tmp_path)), nprocs=world,
+             join=True)
     parts = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
     # single-rank references
-    ref_imp = W.Gaussian10(oracle_ops, impl, seed=3, n_local=n_total).step()
+    ref_imp = W.Gaussian10(oracle_ops, impl, seed=3, n_local=n_imp_total).step()
     ref_smc = W.lgssm_smc(oracle_ops, impl, seed=5, n=n_total, T=T, want_ancestors=True)
     assert torch.equal(torch.cat([p["logw"] for p in parts]), ref_imp["logw"])
     for p in parts:
-        assert torch.equal(p["m"], ref_imp["max"]) and torch.equal(p["q"], ref_imp["q"])
+        assert torch.equal(p["e"], ref_imp["row_e"]) and torch.equal(p["q"], ref_imp["row_q"])
+        assert p["log_z"] == oracle_ops.log_z_from_rows(ref_imp["row_e"], ref_imp["row_q"], n_imp_total)
         assert torch.equal(p["smc_max"], ref_smc["out_max"]) and torch.equal(p["smc_q"], ref_smc["out_q"])
         assert p["smc_log_z"] == ref_smc["log_z"]
     assert parts[0]["log_z"] == parts[1]["log_z"]

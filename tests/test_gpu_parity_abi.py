@@ -207,6 +207,16 @@ def test_logsumexp(hip_ops, oracle_ops, n):
     assert abs(float(hip_ops.lse_rows(hr)[0].cpu()) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
 
 
+def test_lse_records(hip_ops, oracle_ops):
+    """gjx_lse_rows records / gjx_lse_combine: shards merge exactly, and HIP == oracle bit for bit."""
+    from test_oracle_pinning import check_lse_records
+
+    got = check_lse_records(hip_ops, lambda t: dev(t, hip_ops))
+    want = check_lse_records(oracle_ops)
+    for (gr, gl), (wr, wl) in zip(got, want):
+        assert torch.equal(gr, wr) and torch.equal(gl, wl)
+
+
 @pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("n,n_out", [(1, 1), (7, 20), (1024, 1024), (1025, 300), (30000, 30000), (200000, 200000)])
 def test_resample_and_gather(hip_ops, oracle_ops, impl, n, n_out):

@@ -197,6 +197,54 @@ def test_logsumexp_edge_cases(oracle_ops):
     assert oracle_ops.log_z_from_rows(e, rq, 1) == pytest.approx(float(torch.logsumexp(x.double(), 0)), abs=1e-7)
 
 
+def lse_record_cases():
+    """Row-stat sets whose anchors spread over 0..70 binades (rows beyond 63 drop out), with empty rows."""
+    from genjax._amd.ops import RowStats
+
+    g = torch.Generator().manual_seed(11)
+    for n_rows, spread in ((1, 0), (9, 3), (700, 70), (5000, 5), (5000, 70)):
+        e = (torch.randint(0, spread + 1, (n_rows,), generator=g) * (torch.rand(n_rows, generator=g) < 0.3) - 40).int()
+        s = torch.randint(1 << 29, 1 << 38, (n_rows,), generator=g)
+        if n_rows > 5:
+            e[2], s[2] = -(1 << 30), 0  # an empty row (all -inf)
+        yield RowStats(e, s, n_rows * 256)
+
+
+def check_lse_records(ops, to_dev=lambda t: t):
+    """Shared with the GPU suite: records of row-aligned shards merge into exactly the unsharded result."""
+    from genjax._amd.ops import RowStats
+
+    out = []
+    for rows in lse_record_cases():
+        n_rows = rows.e.numel()
+        e_all, s_all = to_dev(rows.e), to_dev(rows.s)
+        rec = to_dev(torch.zeros(65, dtype=torch.int64))
+        lse, e, q = ops.lse_rows(RowStats(e_all, s_all, rows.n), record=rec)
+        assert int(rec[0].cpu()) == int(e.cpu())
+        assert sum(int(b) >> d for d, b in enumerate(rec[1:].cpu().tolist())) == int(q.cpu())
+        for cuts in ((0, n_rows), (0, n_rows // 3, n_rows), (0, 1, n_rows // 2, n_rows // 2 + 1, n_rows)):
+            cuts = sorted(set(cuts))
+            recs = to_dev(torch.zeros((len(cuts) - 1, 2, 65), dtype=torch.int64))  # batch of 2: slot 1 used
+            for r, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+                ops.lse_rows(RowStats(e_all[a:b].clone(), s_all[a:b].clone(), (b - a) * 256), record=recs[r, 1])
+            recs[:, 0, 0] = -(1 << 30)  # slot 0: empty records
+            cl, ce, cq = ops.lse_combine(recs)
+            assert float(cl[0].cpu()) == float("-inf") and int(cq[0].cpu()) == 0
+            assert int(ce[1].cpu()) == int(e.cpu()) and int(cq[1].cpu()) == int(q.cpu())
+            assert torch.equal(cl[1:2].cpu(), lse.cpu())
+        # float64 check of the bucket arithmetic itself
+        ed, sd = rows.e.double(), rows.s.double()
+        live = rows.e > -(1 << 30)
+        ref = torch.logsumexp(ed[live] * math.log(2.0) + torch.log(sd[live]) - 30 * math.log(2.0), 0)
+        assert ops.log_z_from_rows(e, q, 1) == pytest.approx(float(ref), abs=1e-6)
+        out.append((rec.cpu().clone(), lse.cpu().clone()))
+    return out
+
+
+def test_lse_records_merge_exactly(oracle_ops):
+    check_lse_records(oracle_ops)
+
+
 def test_regression_vectors(oracle_ops):
     check_regression(oracle_ops)
 
