@@ -81,41 +81,57 @@ GJX_HD void philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint3
   o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
-constexpr uint32_t kTagSplit = 0x53504C54u;  // "SPLT"
-constexpr uint32_t kTagFold = 0x464F4C44u;   // "FOLD"
-constexpr uint32_t kTagBits = 0x42495453u;   // "BITS"
+// Philox domain tags (low byte of counter word 3; the upper 24 bits carry the site fold of a stream).
+constexpr uint32_t kTagSplit = 0x53u;   // 'S'  split of a laned key
+constexpr uint32_t kTagFold = 0x46u;    // 'F'  fold_in
+constexpr uint32_t kTagDraw = 0x44u;    // 'D'  packed single-word draws
+constexpr uint32_t kTagStream = 0x52u;  // 'R'  sub-streams of multi-word samplers
 
+// A key.  THREEFRY (jax semantics) uses k0,k1 only.  PHILOX keys carry a 64-bit LANE next to the
+// 64-bit cipher key: counter words 0,1 of every block are the lane, so the n children of a lane-0
+// key are (same cipher key, lane i+1) — a population's keys cost no cipher block and share one
+// wave-uniform cipher key (the round keys live in scalar registers).
 struct Key {
   uint32_t k0, k1;
+  uint32_t l0, l1;  // PHILOX lane (0 = none)
 };
+GJX_HD Key make_key(uint32_t k0, uint32_t k1) { return Key{k0, k1, 0u, 0u}; }
 
 // split(parent, *)[i]
 template <int IMPL>
 GJX_HD Key split_at(Key parent, uint64_t i) {
   Key out;
+  out.l0 = 0u;
+  out.l1 = 0u;
   if (IMPL == 0) {
     threefry2x32(parent.k0, parent.k1, (uint32_t)(i >> 32), (uint32_t)i, out.k0, out.k1);
+  } else if ((parent.l0 | parent.l1) == 0u) {
+    const uint64_t lane = i + 1u;
+    out = Key{parent.k0, parent.k1, (uint32_t)lane, (uint32_t)(lane >> 32)};
   } else {
     uint32_t o2, o3;
-    philox4x32(parent.k0, parent.k1, (uint32_t)i, (uint32_t)(i >> 32), 0u, kTagSplit, out.k0,
-               out.k1, o2, o3);
+    philox4x32(parent.k0, parent.k1, parent.l0, parent.l1, (uint32_t)i,
+               ((uint32_t)(i >> 32) << 8) | kTagSplit, out.k0, out.k1, o2, o3);
   }
   return out;
 }
 template <int IMPL>
 GJX_HD Key fold_in(Key k, uint32_t d) {
   Key out;
+  out.l0 = 0u;
+  out.l1 = 0u;
   if (IMPL == 0) {
     threefry2x32(k.k0, k.k1, 0u, d, out.k0, out.k1);
   } else {
     uint32_t o2, o3;
-    philox4x32(k.k0, k.k1, d, 0u, 0u, kTagFold, out.k0, out.k1, o2, o3);
+    philox4x32(k.k0, k.k1, k.l0, k.l1, d, kTagFold, out.k0, out.k1, o2, o3);
   }
   return out;
 }
 
-// A draw stream: key plus optional leaf-site counter.  THREEFRY folds the counter into the key
-// (one block, jax semantics); PHILOX carries it in the 128-bit counter (no extra block).
+// A draw stream: key plus optional leaf-site fold.  THREEFRY folds the counter into the key (one
+// block, jax semantics: fold = site counter from 1).  PHILOX carries it in the 128-bit counter (no
+// extra block; fold = 0-based index of the site among the body's randomness-consuming sites).
 template <int IMPL>
 struct Stream {
   Key k;
@@ -131,21 +147,22 @@ struct Stream {
       hf = has_fold ? 1u : 0u;
     }
   }
+  // words 0,1 of sub-stream `sub` (multi-word samplers)
   GJX_HD void words(uint32_t sub, uint32_t& w0, uint32_t& w1) const {
     if (IMPL == 0) {
       threefry2x32(k.k0, k.k1, 0u, sub, w0, w1);
     } else {
       uint32_t o2, o3;
-      philox4x32(k.k0, k.k1, sub, f, hf, kTagBits, w0, w1, o2, o3);
+      philox4x32(k.k0, k.k1, k.l0, k.l1, sub, ((hf ? f + 1u : 0u) << 8) | kTagStream, w0, w1, o2, o3);
     }
   }
-  // 32 bits of sub-stream `sub`.  PHILOX packs the single-word draw (sub 0) of the four leaf
-  // sites f>>2 into one block: word (f & 3) of PH(ctr = (0, f >> 2, 2, TAG_BITS), key).
+  // 32 bits of sub-stream `sub`.  PHILOX packs the single-word draws (sub 0) of four consecutive
+  // folds into one block: word (f & 3) of PH(ctr = (lane, f >> 2, 'D'), key).
   GJX_HD uint32_t bits32(uint32_t sub) const {
     uint32_t w0, w1;
     if (IMPL == 1 && hf && sub == 0u) {
       uint32_t o[4];
-      philox4x32(k.k0, k.k1, 0u, f >> 2, 2u, kTagBits, o[0], o[1], o[2], o[3]);
+      philox4x32(k.k0, k.k1, k.l0, k.l1, f >> 2, kTagDraw, o[0], o[1], o[2], o[3]);
       const uint32_t sel = f & 3u;
       return sel == 0 ? o[0] : (sel == 1 ? o[1] : (sel == 2 ? o[2] : o[3]));
     }
@@ -165,25 +182,26 @@ struct RunCols {
   void* out[64];
 };
 
-// The 32-bit draw of SMC slot j at one step (one latent site per step).  THREEFRY keeps the jax
-// shape: particle key split(step_key)[j], site key fold_in(., 1), bits of block 0 (3 blocks).
-// PHILOX is counter-native: word 0 of PH(ctr = (j_lo, j_hi, 0, "SMCS"), step_key) — one block.
-constexpr uint32_t kTagSmc = 0x534D4353u;  // "SMCS"
+// The 32-bit draw of SMC slot j at one step (one latent site per step): the first single-word draw of
+// the slot's key split(step_key)[j].  THREEFRY keeps the jax shape (split, fold_in(., 1), bits: 3
+// blocks); PHILOX: step_key has lane 0, so the slot key is (step_key, lane j+1) and the draw is word 0
+// of ONE block whose cipher key is uniform over the launch.
+template <int IMPL>
+GJX_HD Key slot_key(Key step_key, uint64_t j) {  // split(step_key, *)[j]; step keys have lane 0
+  if (IMPL == 0) return split_at<0>(step_key, j);
+  const uint64_t lane = j + 1u;
+  return Key{step_key.k0, step_key.k1, (uint32_t)lane, (uint32_t)(lane >> 32)};
+}
 template <int IMPL>
 GJX_HD uint32_t smc_slot_bits(Key step_key, uint64_t j) {
-  if (IMPL == 0) {
-    const Stream<0> st(split_at<0>(step_key, j), true, 1u);
-    return st.bits32(0);
-  }
-  uint32_t o0, o1, o2, o3;
-  philox4x32(step_key.k0, step_key.k1, (uint32_t)j, (uint32_t)(j >> 32), 0u, kTagSmc, o0, o1, o2, o3);
-  return o0;
+  const Stream<IMPL> st(slot_key<IMPL>(step_key, j), true, IMPL == 0 ? 1u : 0u);
+  return st.bits32(0);
 }
 
 // Host-visible description of a key batch (mirrors gjx_keys).
 struct KeySrc {
-  const uint32_t* keys;  // mode 0
-  Key parent;            // mode 1
+  const uint32_t* keys;  // mode 0: [n, 2] (threefry) / [n, 4] (philox)
+  Key parent;            // modes 1, 2 (with its lane)
   uint64_t first;
   int mode;
   int has_fold;
@@ -192,11 +210,20 @@ struct KeySrc {
 template <int IMPL>
 GJX_DEV Key key_at(const KeySrc& s, uint64_t i) {
   if (s.mode == 0) {
-    const uint2 v = reinterpret_cast<const uint2*>(s.keys)[i];
-    return Key{v.x, v.y};
+    if (IMPL == 0) {
+      const uint2 v = reinterpret_cast<const uint2*>(s.keys)[i];
+      return make_key(v.x, v.y);
+    }
+    const uint4 v = reinterpret_cast<const uint4*>(s.keys)[i];
+    return Key{v.x, v.y, v.z, v.w};
   }
   if (s.mode == 2) return s.parent;
   return split_at<IMPL>(s.parent, s.first + i);
+}
+template <int IMPL>
+GJX_DEV void store_key(uint32_t* out, uint64_t i, Key k) {
+  if (IMPL == 0) reinterpret_cast<uint2*>(out)[i] = make_uint2(k.k0, k.k1);
+  else reinterpret_cast<uint4*>(out)[i] = make_uint4(k.k0, k.k1, k.l0, k.l1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -213,6 +240,32 @@ GJX_HD float m_log(float x) {
   }
   const uint32_t t = ix - 0x3f3504f3u;
   e += (int32_t)t >> 23;
+  const float m = u2f((t & 0x007fffffu) + 0x3f3504f3u);
+  const float f = m - 1.0f;
+  const float z = f * f;
+  float p = 7.0376836292E-2f;
+  p = __builtin_fmaf(p, f, -1.1514610310E-1f);
+  p = __builtin_fmaf(p, f, 1.1676998740E-1f);
+  p = __builtin_fmaf(p, f, -1.2420140846E-1f);
+  p = __builtin_fmaf(p, f, 1.4249322787E-1f);
+  p = __builtin_fmaf(p, f, -1.6668057665E-1f);
+  p = __builtin_fmaf(p, f, 2.0000714765E-1f);
+  p = __builtin_fmaf(p, f, -2.4999993993E-1f);
+  p = __builtin_fmaf(p, f, 3.3333331174E-1f);
+  float y = (p * f) * z;
+  const float fe = (float)e;
+  y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+  y = __builtin_fmaf(-0.5f, z, y);
+  float r = f + y;
+  r = __builtin_fmaf(fe, 0.693359375f, r);
+  return r;
+}
+
+// m_log for positive NORMAL floats: the same operations minus the zero / subnormal pre-scaling, hence
+// the same bits.  erfinv's argument (1-x)(1+x) lies in [2^-24, 1].
+GJX_HD float m_log_normal(float x) {
+  const uint32_t t = f2u(x) - 0x3f3504f3u;
+  const int32_t e = (int32_t)t >> 23;
   const float m = u2f((t & 0x007fffffu) + 0x3f3504f3u);
   const float f = m - 1.0f;
   const float z = f * f;
@@ -253,7 +306,7 @@ GJX_HD float m_exp(float x) {
 }
 
 GJX_HD float m_erfinv(float x) {
-  float w = -m_log((1.0f - x) * (1.0f + x));
+  float w = -m_log_normal((1.0f - x) * (1.0f + x));
   float p;
   if (w < 5.0f) {
     w = w - 2.5f;

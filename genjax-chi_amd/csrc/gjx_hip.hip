@@ -34,12 +34,13 @@ bool keys_ok(const gjx_keys* k) {
   if (!k) return false;
   if (k->impl != 0 && k->impl != 1) return false;
   if (k->mode == 0) return k->keys != nullptr;
+  if (k->impl == 0 && k->parent_lane != 0) return false;  // lanes are a PHILOX notion
   return k->mode == 1 || k->mode == 2;
 }
 KeySrc key_src(const gjx_keys* k) {
   KeySrc s;
   s.keys = k->keys;
-  s.parent = Key{k->parent[0], k->parent[1]};
+  s.parent = Key{k->parent[0], k->parent[1], (uint32_t)k->parent_lane, (uint32_t)(k->parent_lane >> 32)};
   s.first = k->first;
   s.mode = k->mode;
   s.has_fold = k->has_fold;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void k_rng_keys(KeySrc ks, uint64_t n, uint
   GJX_TILE_LOOP(i, n) {
     Key k = key_at<IMPL>(ks, i);
     if (ks.has_fold) k = fold_in<IMPL>(k, ks.fold);
-    reinterpret_cast<uint2*>(out)[i] = make_uint2(k.k0, k.k1);
+    store_key<IMPL>(out, i, k);
   }
 }
 template <int IMPL>
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void k_rng_split_each(KeySrc ks, uint64_t n
     Key k = key_at<IMPL>(ks, i);
     if (ks.has_fold) k = fold_in<IMPL>(k, ks.fold);
     k = split_at<IMPL>(k, j);
-    reinterpret_cast<uint2*>(out)[e] = make_uint2(k.k0, k.k1);
+    store_key<IMPL>(out, e, k);
   }
 }
 template <int IMPL>
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
     float w[kPPT], sc[kPPT];
     uint32_t pw[kPPT][4];  // PHILOX: cached packed block (4 single-word draws) per particle
     int pw_blk = -1;
+    uint32_t draws = 0;  // PHILOX: sampled sites so far (their fold)
 #pragma unroll
     for (int r = 0; r < kPPT; ++r) {
       idx[r] = tile * kTile + (uint64_t)r * kBlock + tid;
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
           vi[r] = is_int ? (int32_t)__builtin_rintf(ov) : 0;
         }
       } else {
-        const uint32_t fold = (uint32_t)(q + 1);
+        const uint32_t fold = IMPL == 0 ? (uint32_t)(q + 1) : draws++;
         // single-word draws (normal / bernoulli / inverse-CDF categorical)
         uint32_t bits[kPPT];
         const bool one_word = dist == GJX_DIST_NORMAL || dist == GJX_DIST_BERNOULLI ||
@@ -359,8 +361,8 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
               pw_blk = (int)(fold >> 2);
 #pragma unroll
               for (int r = 0; r < kPPT; ++r)
-                philox4x32(pkey[r].k0, pkey[r].k1, 0u, fold >> 2, 2u, kTagBits, pw[r][0], pw[r][1],
-                           pw[r][2], pw[r][3]);
+                philox4x32(pkey[r].k0, pkey[r].k1, pkey[r].l0, pkey[r].l1, fold >> 2, kTagDraw, pw[r][0],
+                           pw[r][1], pw[r][2], pw[r][3]);
             }
             const uint32_t sel = fold & 3u;
 #pragma unroll
@@ -1200,7 +1202,7 @@ struct gjx_plan {
   int dist_mask;
   CSite host[GJX_MAX_SITES];
   CSite* dev;
-  gjx_jit::Compiled jit[2];  // specialised kernel per RNG scheme, built on first use
+  gjx_jit::Compiled jit[3];  // specialised kernel per RNG scheme (+ PHILOX laned keys), built on first use
   std::mutex jit_mu;
 };
 
@@ -1316,7 +1318,7 @@ static int plan_device_table(gjx_plan* p) {
 int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t buf_len, size_t* needed) {
   if (!p || (impl != 0 && impl != 1)) return GJX_ERR_INVALID;
   gjx_jit::Gen<CSite, CArg> g;
-  g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites;
+  g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites; g.laned = impl == 1;
   const std::string src = g.run();
   if (needed) *needed = src.size() + 1;
   if (buf && buf_len > 0) {
@@ -1329,9 +1331,12 @@ int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t b
 
 int gjx_plan_compile_check(const gjx_plan* p, int impl) {
   if (!p || (impl != 0 && impl != 1)) return GJX_ERR_INVALID;
-  gjx_jit::Gen<CSite, CArg> g;
-  g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites;
-  return gjx_jit::compile_only(g.run()) ? GJX_OK : GJX_ERR_UNSUPPORTED;
+  for (int laned = 0; laned <= impl; ++laned) {  // PHILOX: both key forms
+    gjx_jit::Gen<CSite, CArg> g;
+    g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites; g.laned = laned != 0;
+    if (!gjx_jit::compile_only(g.run())) return GJX_ERR_UNSUPPORTED;
+  }
+  return GJX_OK;
 }
 int gjx_plan_destroy(gjx_plan* p) {
   if (!p) return GJX_OK;
@@ -1366,12 +1371,14 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
   // Specialised straight-line kernel for this site table (compiled once per plan and RNG scheme).
   if (gjx_jit::enabled()) {
     gjx_plan* mp = const_cast<gjx_plan*>(p);
-    gjx_jit::Compiled& c = mp->jit[pk->impl];
+    // PHILOX children of a lane-0 key share one cipher key: a variant keeps it in scalar registers
+    const bool laned = pk->impl == 1 && pk->mode == 1 && pk->parent_lane == 0;
+    gjx_jit::Compiled& c = mp->jit[laned ? 2 : pk->impl];
     if (c.state == 0) {
       std::lock_guard<std::mutex> lock(mp->jit_mu);
       if (c.state == 0) {
         gjx_jit::Gen<CSite, CArg> g;
-        g.impl = pk->impl; g.sites = p->host; g.n_sites = p->n_sites;
+        g.impl = pk->impl; g.sites = p->host; g.n_sites = p->n_sites; g.laned = laned;
         if (const char* e = std::getenv("GJX_JIT_MIN_WAVES")) g.min_waves = atoi(e);
         const std::string src = g.run();
         c.rows_per_block = g.rows_per_block;
@@ -1503,7 +1510,7 @@ static int weights_prepare(const float* logw, uint64_t n, Carver& cv, float** m_
 
 // A scalar key (categorical draw / resampling offset) is resolved on the host side of the call.
 static int scalar_key(const gjx_keys* key, Key* out) {
-  const Key parent{key->parent[0], key->parent[1]};
+  const Key parent{key->parent[0], key->parent[1], (uint32_t)key->parent_lane, (uint32_t)(key->parent_lane >> 32)};
   if (key->mode == 2) { *out = parent; return GJX_OK; }
   if (key->mode != 1) return GJX_ERR_UNSUPPORTED;  // device-resident scalar keys: not needed by the host API
   *out = key->impl == 0 ? split_at<0>(parent, key->first) : split_at<1>(parent, key->first);

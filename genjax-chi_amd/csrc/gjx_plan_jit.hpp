@@ -68,16 +68,18 @@ struct SiteEmitter {
       default: return plit(a.table) + "[" + val_i32(a.ref_site) + "]";
     }
   }
-  // does any latent site need the per-particle key (threefry always; philox only multi-word samplers)?
+  // does any site draw (and so need the per-particle key)?
   bool needs_pk() const {
-    for (int q = 0; q < n_sites; ++q) {
-      const CSiteT& st = sites[q];
-      if (st.observed) continue;
-      if (impl == 0) return true;
-      if (st.dist == GJX_DIST_GAMMA || st.dist == GJX_DIST_BETA || (st.dist == GJX_DIST_CATEGORICAL && st.cat_mode == 0))
-        return true;
-    }
+    for (int q = 0; q < n_sites; ++q)
+      if (!sites[q].observed) return true;
     return false;
+  }
+  // fold of site q: THREEFRY the 1-based site counter; PHILOX the 0-based index among the sampled sites
+  uint32_t fold_of(int q) const {
+    if (impl == 0) return (uint32_t)(q + 1);
+    uint32_t d = 0;
+    for (int p = 0; p < q; ++p) d += sites[p].observed ? 0u : 1u;
+    return d;
   }
 
   void run() {
@@ -86,7 +88,7 @@ struct SiteEmitter {
     for (int q = 0; q < n_sites; ++q) {
       const CSiteT& st = sites[q];
       const std::string Q = std::to_string(q);
-      const uint32_t fold = (uint32_t)(q + 1);
+      const uint32_t fold = fold_of(q);
       o << ind << "// site " << q << " dist " << st.dist << (st.observed ? " observed" : " latent") << "\n";
       std::string row;
       if (st.dist == GJX_DIST_CATEGORICAL) {
@@ -115,19 +117,14 @@ struct SiteEmitter {
                               (st.dist == GJX_DIST_CATEGORICAL && st.cat_mode == 1);
         if (one_word) {
           if (impl == 1) {
-            // importance: block fold>>2, word fold&3 of ("BITS", key pkey); SMC: block (fold-1)>>2,
-            // word (fold-1)&3 of ("SMCS", step key, slot)
-            const int blk = mode == 0 ? (int)(fold >> 2) : (int)((fold - 1u) >> 2);
-            const uint32_t word = mode == 0 ? (fold & 3u) : ((fold - 1u) & 3u);
+            // word fold&3 of the packed draw block fold>>2 of the particle / slot key
+            const int blk = (int)(fold >> 2);
+            const uint32_t word = fold & 3u;
             if (blk != cur_blk) {
               cur_blk = blk;
               o << ind << "uint32_t pw" << blk << "_0, pw" << blk << "_1, pw" << blk << "_2, pw" << blk << "_3;\n";
-              if (mode == 0)
-                o << ind << "philox4x32(pkey.k0, pkey.k1, 0u, " << blk << "u, 2u, kTagBits, pw" << blk << "_0, pw" << blk
-                  << "_1, pw" << blk << "_2, pw" << blk << "_3);\n";
-              else
-                o << ind << "philox4x32(a.step_key.k0, a.step_key.k1, (uint32_t)j, (uint32_t)((uint64_t)j >> 32), " << blk
-                  << "u, kTagSmc, pw" << blk << "_0, pw" << blk << "_1, pw" << blk << "_2, pw" << blk << "_3);\n";
+              o << ind << "philox4x32(pkey.k0, pkey.k1, pkey.l0, pkey.l1, " << blk << "u, kTagDraw, pw" << blk << "_0, pw" << blk
+                << "_1, pw" << blk << "_2, pw" << blk << "_3);\n";
             }
             o << ind << "const uint32_t bits" << Q << " = pw" << blk << "_" << word << ";\n";
           } else {
@@ -205,6 +202,7 @@ struct Gen {
   int n_sites;
   int min_waves = 0;  // __launch_bounds__ waves-per-SIMD hint (0 = none)
   int rows_per_block = 1;
+  bool laned = false;  // specialise for gjx_keys{mode 1, parent_lane 0} (PHILOX only)
 
   bool all_normal() const {
     for (int q = 0; q < n_sites; ++q) {
@@ -235,13 +233,17 @@ struct Gen {
     o << "    const uint64_t j0 = blk * 512 + threadIdx.x, j1 = j0 + 256;\n";
     o << "    const bool ok0 = j0 < n, ok1 = j1 < n;\n";
     o << "    const uint64_t i0 = ok0 ? j0 : n - 1, i1 = ok1 ? j1 : n - 1;  // surplus lanes redo the last particle, stores masked\n";
-    o << "    const Key pkA = key_at<" << I << ">(ks, i0), pkB = key_at<" << I << ">(ks, i1);\n";
+    if (laned)
+      o << "    const uint64_t lnA = ks.first + i0 + 1u, lnB = ks.first + i1 + 1u;\n"
+        << "    const Key pkA{ks.parent.k0, ks.parent.k1, (uint32_t)lnA, (uint32_t)(lnA >> 32)}, pkB{ks.parent.k0, ks.parent.k1, (uint32_t)lnB, (uint32_t)(lnB >> 32)};\n";
+    else
+      o << "    const Key pkA = key_at<" << I << ">(ks, i0), pkB = key_at<" << I << ">(ks, i1);\n";
     o << "    f32x2 w = splat2(0.0f), sc = splat2(0.0f);\n";
     int cur_blk = -1;
     for (int q = 0; q < n_sites; ++q) {
       const CSiteT& st = sites[q];
       const std::string Q = std::to_string(q);
-      const uint32_t fold = (uint32_t)(q + 1);
+      const uint32_t fold = SiteEmitter<CSiteT, CArgT>{o, impl, 0, sites, n_sites, ""}.fold_of(q);
       o << "    // site " << q << (st.observed ? " observed" : " latent") << "\n";
       o << "    const f32x2 a0_" << Q << " = " << arg2(st.a0) << ";\n";
       o << "    const f32x2 a1_" << Q << " = " << arg2(st.a1) << ";\n";
@@ -255,7 +257,7 @@ struct Gen {
             cur_blk = b;
             for (const char* P : {"A", "B"}) {
               o << "    uint32_t pw" << P << b << "_0, pw" << P << b << "_1, pw" << P << b << "_2, pw" << P << b << "_3;\n";
-              o << "    philox4x32(pk" << P << ".k0, pk" << P << ".k1, 0u, " << b << "u, 2u, kTagBits, pw" << P << b << "_0, pw" << P << b
+              o << "    philox4x32(pk" << P << ".k0, pk" << P << ".k1, pk" << P << ".l0, pk" << P << ".l1, " << b << "u, kTagDraw, pw" << P << b << "_0, pw" << P << b
                 << "_1, pw" << P << b << "_2, pw" << P << b << "_3);\n";
             }
           }
@@ -310,7 +312,10 @@ struct Gen {
     o << "    {\n";
     o << "      const uint64_t i = row * 256 + threadIdx.x;\n";
     o << "      if (i < n) {\n";
-    o << "        const Key pkey = key_at<" << I << ">(ks, i);\n";
+    if (laned)  // lazy children of a lane-0 PHILOX key: the cipher key is uniform over the launch
+      o << "        const uint64_t lane = ks.first + i + 1u;\n        const Key pkey{ks.parent.k0, ks.parent.k1, (uint32_t)lane, (uint32_t)(lane >> 32)};\n";
+    else
+      o << "        const Key pkey = key_at<" << I << ">(ks, i);\n";
     o << "        float w = 0.0f, sc = 0.0f;\n";
     SiteEmitter<CSiteT, CArgT> em{o, impl, 0, sites, n_sites, "        "};
     em.run();
@@ -357,7 +362,7 @@ struct GenSmc {
     o << "    for (int k = 0; k < " << D << "; ++k) { xs[k] = tile[k]; for (int r = 0; r < 4; ++r) tile[k][r * 256 + tid] = xr[k][r]; }\n  }\n";
     o << "  __device__ __forceinline__ float compute(int64_t j, int src_local, Out& out) const {\n";
     for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << " = xs[" << k << "][src_local];\n";
-    if (es.needs_pk()) o << "    const Key pkey = split_at<" << I << ">(a.step_key, (uint64_t)j);\n";
+    if (es.needs_pk()) o << "    const Key pkey = slot_key<" << I << ">(a.step_key, (uint64_t)j);\n";
     o << "    float w = 0.0f, sc = 0.0f;\n";
     es.run();
     for (int k = 0; k < n_state; ++k) o << "    out.s[" << k << "] = " << es.arg(next_state[k]) << ";\n";
@@ -372,7 +377,7 @@ struct GenSmc {
     o << "  __shared__ float shf[4];\n  const uint64_t gbase = (uint64_t)blockIdx.x * 1024;\n  float tmax = -__builtin_inff();\n";
     o << "  if (gbase >= first_slot && gbase < first_slot + n_local) {\n    for (int r = 0; r < 4; ++r) {\n";
     o << "      const uint64_t j = gbase + (uint64_t)r * 256 + threadIdx.x;\n      if (j < first_slot + n_local) {\n";
-    if (ei.needs_pk()) o << "        const Key pkey = split_at<" << I << ">(a.step_key, j);\n";
+    if (ei.needs_pk()) o << "        const Key pkey = slot_key<" << I << ">(a.step_key, j);\n";
     o << "        float w = 0.0f, sc = 0.0f;\n";
     ei.run();
     for (int k = 0; k < n_state; ++k) o << "        a.state_out[" << k << "][j - first_slot] = " << ei.arg(init_state[k]) << ";\n";

@@ -55,7 +55,13 @@ class Keys(C.Structure):
         ("first", C.c_uint64),
         ("has_fold", C.c_int32),
         ("fold", C.c_uint32),
+        ("parent_lane", C.c_uint64),
     ]
+
+
+def key_words(impl: int) -> int:
+    """Words per materialised key (gjx.h: GJX_KEY_WORDS): threefry 2, philox 4 (cipher key + lane)."""
+    return 4 if impl == RNG_PHILOX else 2
 
 
 class F32(C.Structure):

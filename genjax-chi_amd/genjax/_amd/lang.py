@@ -54,7 +54,7 @@ class ParticleKeys:
                 raise IndexError("ParticleKeys supports contiguous slices only")
             if self.kb.mode == 1:
                 return ParticleKeys(KeyBatch(self.kb.impl, 1, parent=self.kb.parent, first=self.kb.first + start,
-                                             fold=self.kb.fold), max(0, stop - start))
+                                             fold=self.kb.fold, parent_lane=self.kb.parent_lane), max(0, stop - start))
             if self.kb.mode == 0:
                 return ParticleKeys(KeyBatch(self.kb.impl, 0, tensor=self.kb.tensor[start:stop].contiguous(),
                                              fold=self.kb.fold), max(0, stop - start))
@@ -66,12 +66,14 @@ class ParticleKeys:
             raise IndexError(i)
         if self.kb.fold is not None:
             raise ValueError("cannot index a folded key batch")
+        parent = prng.PRNGKey(*self.kb.parent, self.kb.impl, self.kb.parent_lane)
         if self.kb.mode == 1:
-            return prng.split_at(prng.PRNGKey(*self.kb.parent, self.kb.impl), self.kb.first + i)
+            return prng.split_at(parent, self.kb.first + i)
         if self.kb.mode == 2:
-            return prng.PRNGKey(*self.kb.parent, self.kb.impl)
-        w = self.kb.tensor[i].cpu().tolist()
-        return prng.PRNGKey(w[0] & 0xFFFFFFFF, w[1] & 0xFFFFFFFF, self.kb.impl)
+            return parent
+        w = [x & 0xFFFFFFFF for x in self.kb.tensor[i].cpu().tolist()]
+        lane = (w[2] | (w[3] << 32)) if len(w) == 4 else 0
+        return prng.PRNGKey(w[0], w[1], self.kb.impl, lane)
 
     def __iter__(self):
         return (self[i] for i in range(self.n))
@@ -92,7 +94,7 @@ def split(key, num: int = 2):
         return ParticleKeys(prng.split_lazy(key, num), num)
     if isinstance(key, ParticleKeys):
         # vmap(split): every particle key is split `num` ways (one nested-split kernel)
-        t = get_ops().rng_split_each(key.kb, key.n, num).view(key.n, num, 2)
+        t = get_ops().rng_split_each(key.kb, key.n, num).view(key.n, num, -1)
         return tuple(ParticleKeys(KeyBatch(key.impl, 0, tensor=t[:, j].contiguous()), key.n) for j in range(num))
     raise TypeError(f"expected a PRNG key, got {type(key).__name__}")
 
@@ -107,12 +109,31 @@ def fold_in(key, data: int):
     raise TypeError(type(key))
 
 
-def site_keys(key: ParticleKeys, counter: int, leaf: bool) -> ParticleKeys:
-    """Per-`@`-site key: fold_in(key, counter) (static.py:349-352).  Leaf distributions take the
+def site_keys(key: ParticleKeys, fold: int, leaf: bool) -> ParticleKeys:
+    """Per-`@`-site key: fold_in(key, fold) (static.py:349-352).  Leaf distributions take the
     fold lazily (fused into their kernel); nested generative functions get materialised keys."""
     if leaf:
-        return ParticleKeys(key.kb.with_fold(counter), key.n)
-    return fold_in(key, counter)
+        return ParticleKeys(key.kb.with_fold(fold), key.n)
+    return fold_in(key, fold)
+
+
+class _SiteCounter:
+    """The per-body site numbering.  threefry: the reference's counter, from 1, advanced by every `@`
+    site (static.py:349-352, 374-375).  philox: the 0-based index among the sites that consume
+    randomness (unconstrained leaves and nested calls), so four consecutive single-word draws share
+    one cipher block whatever is observed in between."""
+
+    def __init__(self, impl: int):
+        self.impl, self.counter, self.draws = impl, 1, 0
+
+    def next(self, consumes: bool) -> int:
+        if self.impl == prng.THREEFRY:
+            f = self.counter
+        else:
+            f = self.draws
+            self.draws += 1 if consumes else 0
+        self.counter += 1
+        return f
 
 
 # =================================================================================================
@@ -452,11 +473,10 @@ class _Handler:
 class SimulateHandler(_Handler):
     def __init__(self, key: ParticleKeys):
         super().__init__()
-        self.key, self.counter = key, 1
+        self.key, self.sites = key, _SiteCounter(key.impl)
 
     def handle_trace(self, addr, gen_fn, args):
-        sub_key = site_keys(self.key, self.counter, isinstance(gen_fn, Distribution))
-        self.counter += 1
+        sub_key = site_keys(self.key, self.sites.next(True), isinstance(gen_fn, Distribution))
         tr = gen_fn.simulate(sub_key, args)
         self.record(addr, tr)
         return tr.get_retval()
@@ -465,13 +485,13 @@ class SimulateHandler(_Handler):
 class GenerateHandler(_Handler):
     def __init__(self, key: ParticleKeys, constraint: ChoiceMap):
         super().__init__()
-        self.key, self.constraint, self.counter = key, constraint, 1
+        self.key, self.constraint, self.sites = key, constraint, _SiteCounter(key.impl)
         self.weight = 0.0
 
     def handle_trace(self, addr, gen_fn, args):
         sub = self.constraint.get_submap(*(addr if isinstance(addr, tuple) else (addr,)))
-        sub_key = site_keys(self.key, self.counter, isinstance(gen_fn, Distribution))
-        self.counter += 1  # constrained sites consume a counter too (static.py:374-375)
+        leaf = isinstance(gen_fn, Distribution)
+        sub_key = site_keys(self.key, self.sites.next(not leaf or sub.static_is_empty()), leaf)
         tr, w = gen_fn.generate(sub_key, sub, args)
         self.weight = self.weight + w
         self.record(addr, tr)

@@ -23,16 +23,17 @@ class KeyBatch:
     """Host-side description of `n` per-particle keys (mirrors gjx_keys)."""
 
     impl: int
-    mode: int  # 0 explicit tensor [n,2] (int32 view of u32), 1 lazy split, 2 literal
+    mode: int  # 0 explicit tensor [n, key_words] (int32 view of u32), 1 lazy split, 2 literal
     tensor: torch.Tensor | None = None
     parent: tuple[int, int] = (0, 0)
     first: int = 0
     fold: int | None = None
+    parent_lane: int = 0  # philox: lane of the parent key (modes 1, 2)
 
     def with_fold(self, fold: int) -> "KeyBatch":
         if self.fold is not None:
             raise ValueError("key batch already carries a fold")
-        return KeyBatch(self.impl, self.mode, self.tensor, self.parent, self.first, int(fold))
+        return KeyBatch(self.impl, self.mode, self.tensor, self.parent, self.first, int(fold), self.parent_lane)
 
 
 class Ops:
@@ -82,11 +83,12 @@ class Ops:
         k.mode = kb.mode
         if kb.mode == 0:
             assert kb.tensor is not None
-            k.keys = self._chk(kb.tensor, torch.int32, 2 * n, "keys").value
+            k.keys = self._chk(kb.tensor, torch.int32, abi.key_words(kb.impl) * n, "keys").value
         else:
             k.keys = None
             k.parent[0], k.parent[1] = kb.parent
             k.first = kb.first
+            k.parent_lane = kb.parent_lane
         k.has_fold = 0 if kb.fold is None else 1
         k.fold = 0 if kb.fold is None else kb.fold & 0xFFFFFFFF
         return k
@@ -109,12 +111,12 @@ class Ops:
 
     # ---- RNG --------------------------------------------------------------------------------
     def rng_keys(self, kb: KeyBatch, n: int) -> torch.Tensor:
-        out = self.empty((n, 2), torch.int32)
+        out = self.empty((n, abi.key_words(kb.impl)), torch.int32)
         self.lib.call("gjx_rng_keys", C.byref(self._keys(kb, n)), n, C.c_void_p(out.data_ptr()), self.stream())
         return out
 
     def rng_split_each(self, kb: KeyBatch, n: int, m: int) -> torch.Tensor:
-        out = self.empty((n * m, 2), torch.int32)
+        out = self.empty((n * m, abi.key_words(kb.impl)), torch.int32)
         self.lib.call("gjx_rng_split_each", C.byref(self._keys(kb, n)), n, m, C.c_void_p(out.data_ptr()), self.stream())
         return out
 

@@ -1,13 +1,16 @@
 """Host side of the counter-based PRNG: scalar keys are plain Python integers and are derived on
 the host (a few cipher blocks); batches of per-particle keys stay *lazy* — `split(key, n)` with a
 large n returns a `KeyBatch` describing `split(key, *)[first + i]`, and the kernels derive each
-particle's key in registers instead of reading n×8 bytes of keys from HBM.
+particle's key in registers instead of reading keys from HBM.
 
 Derivation semantics:
   impl="threefry"  jax.random's Threefry2x32 key tree with jax_threefry_partitionable
                    (reference call sites: inference/smc.py:154,171,299-300; static.py:349-352;
-                   scan.py:267-268).
-  impl="philox"    native Philox4x32-10 counter scheme.
+                   scan.py:267-268).  Keys are 2 words.
+  impl="philox"    native Philox4x32-10 counter scheme.  A key is a 64-bit cipher key plus a 64-bit
+                   *lane* that fills counter words 0,1 of every block: the children of a lane-0 key
+                   are (same cipher key, lane i+1) — free, and a whole population shares one cipher
+                   key — while the children of a laned key are hashed to fresh lane-0 keys.
 The scalar ciphers below restate Salmon et al. (SC'11) and are checked against the Random123
 known-answer vectors in tests/test_prng_host.py.
 """
@@ -21,7 +24,7 @@ from .ops import KeyBatch
 M32 = 0xFFFFFFFF
 THREEFRY, PHILOX = 0, 1
 _IMPL = {"threefry": THREEFRY, "philox": PHILOX, THREEFRY: THREEFRY, PHILOX: PHILOX}
-TAG_SPLIT, TAG_FOLD, TAG_BITS = 0x53504C54, 0x464F4C44, 0x42495453
+TAG_SPLIT, TAG_FOLD, TAG_DRAW, TAG_STREAM = 0x53, 0x46, 0x44, 0x52  # low byte of counter word 3
 
 _default_impl = THREEFRY
 
@@ -60,21 +63,23 @@ def philox4x32(k0, k1, c0, c1, c2, c3):
 
 @dataclass(frozen=True)
 class PRNGKey:
-    """A scalar key: two 32-bit words + the derivation scheme."""
+    """A scalar key: two 32-bit cipher-key words, the derivation scheme and (philox) the lane."""
 
     k0: int
     k1: int
     impl: int = THREEFRY
+    lane: int = 0
 
     def words(self) -> tuple[int, int]:
         return (self.k0, self.k1)
 
     def literal(self) -> KeyBatch:
         """This key as a 1-element key batch (by value)."""
-        return KeyBatch(self.impl, 2, parent=(self.k0, self.k1))
+        return KeyBatch(self.impl, 2, parent=(self.k0, self.k1), parent_lane=self.lane)
 
     def __repr__(self):
-        return f"PRNGKey({self.k0:#010x}, {self.k1:#010x}, {'threefry' if self.impl == 0 else 'philox'})"
+        lane = f", lane={self.lane}" if self.lane else ""
+        return f"PRNGKey({self.k0:#010x}, {self.k1:#010x}, {'threefry' if self.impl == 0 else 'philox'}{lane})"
 
 
 def key(seed: int, impl=None) -> PRNGKey:
@@ -87,11 +92,17 @@ def key(seed: int, impl=None) -> PRNGKey:
 PRNGKeyLike = PRNGKey
 
 
+def _philox_lane(k: PRNGKey, b: int, a_tag: int):
+    return philox4x32(k.k0, k.k1, k.lane & M32, (k.lane >> 32) & M32, b & M32, a_tag & M32)
+
+
 def split_at(k: PRNGKey, i: int) -> PRNGKey:
     if k.impl == THREEFRY:
         o0, o1 = threefry2x32(k.k0, k.k1, (i >> 32) & M32, i & M32)
-    else:
-        o0, o1, _, _ = philox4x32(k.k0, k.k1, i & M32, (i >> 32) & M32, 0, TAG_SPLIT)
+        return PRNGKey(o0, o1, k.impl)
+    if k.lane == 0:
+        return PRNGKey(k.k0, k.k1, k.impl, lane=i + 1)
+    o0, o1, _, _ = _philox_lane(k, i & M32, ((i >> 32) << 8) | TAG_SPLIT)
     return PRNGKey(o0, o1, k.impl)
 
 
@@ -102,7 +113,7 @@ def split(k: PRNGKey, num: int = 2):
 
 def split_lazy(k: PRNGKey, n: int, first: int = 0) -> KeyBatch:
     """split(k, n_total)[first : first + n] as a lazy per-particle key batch."""
-    return KeyBatch(k.impl, 1, parent=(k.k0, k.k1), first=first)
+    return KeyBatch(k.impl, 1, parent=(k.k0, k.k1), first=first, parent_lane=k.lane)
 
 
 def fold_in(k: PRNGKey, data: int) -> PRNGKey:
@@ -110,13 +121,14 @@ def fold_in(k: PRNGKey, data: int) -> PRNGKey:
     if k.impl == THREEFRY:
         o0, o1 = threefry2x32(k.k0, k.k1, 0, d)
     else:
-        o0, o1, _, _ = philox4x32(k.k0, k.k1, d, 0, 0, TAG_FOLD)
+        o0, o1, _, _ = _philox_lane(k, d, TAG_FOLD)
     return PRNGKey(o0, o1, k.impl)
 
 
 # ---- vectorised host derivation (numpy): the 2T step / resample keys of an SMC run ------------------
-def split_words(k: PRNGKey, n: int):
-    """split(k, n) as a uint32 array [n, 2] computed with numpy (same ciphers, vectorised over the index)."""
+def fold_words(k: PRNGKey, n: int):
+    """[fold_in(k, d) for d in range(n)] as a uint32 array [n, 2] (fresh lane-0 keys) computed with numpy
+    (same ciphers, vectorised over d).  For threefry this equals split(k, n) (TF(k, (0, d)) either way)."""
     import numpy as np
 
     idx = np.arange(n, dtype=np.uint64)
@@ -127,7 +139,7 @@ def split_words(k: PRNGKey, n: int):
 
     if k.impl == THREEFRY:
         ks = (np.uint64(k.k0), np.uint64(k.k1), np.uint64(0x1BD11BDA ^ k.k0 ^ k.k1))
-        x0 = ((idx >> np.uint64(32)) + ks[0]) & m
+        x0 = np.full(n, ks[0], dtype=np.uint64)
         x1 = ((idx & m) + ks[1]) & m
         rot = ((13, 15, 26, 6), (17, 29, 16, 24))
         for blk in range(5):
@@ -137,9 +149,10 @@ def split_words(k: PRNGKey, n: int):
             x0 = (x0 + ks[(blk + 1) % 3]) & m
             x1 = (x1 + ks[(blk + 2) % 3] + np.uint64(blk + 1)) & m
         return np.stack([x0, x1], axis=1).astype(np.uint32)
-    c0, c1 = idx & m, idx >> np.uint64(32)
-    c2 = np.zeros(n, dtype=np.uint64)
-    c3 = np.full(n, TAG_SPLIT, dtype=np.uint64)
+    c0 = np.full(n, k.lane & M32, dtype=np.uint64)
+    c1 = np.full(n, (k.lane >> 32) & M32, dtype=np.uint64)
+    c2 = idx & m
+    c3 = np.full(n, TAG_FOLD, dtype=np.uint64)
     k0, k1 = np.uint64(k.k0), np.uint64(k.k1)
     for _ in range(10):
         p0 = np.uint64(0xD2511F53) * c0

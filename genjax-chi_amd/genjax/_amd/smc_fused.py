@@ -53,8 +53,9 @@ class SMCResult:
 
 
 def smc_key_schedule(key: prng.PRNGKey, T: int):
-    """step t propagates with split(key, 2T)[2t] and resamples with split(key, 2T)[2t+1]."""
-    w = prng.split_words(key, 2 * T)
+    """step t propagates with fold_in(key, 2t) and resamples with fold_in(key, 2t+1) (fresh lane-0 keys;
+    for threefry the same words as split(key, 2T)[2t], [2t+1])."""
+    w = prng.fold_words(key, 2 * T)
     return w[0::2].copy(), w[1::2].copy()
 
 

@@ -152,8 +152,9 @@ def lgssm_exact_log_z(y) -> float:
 
 
 def smc_key_schedule(root: prng.PRNGKey, T: int):
-    """step_keys[t], resample_keys[t] = split(root, 2T)[2t], [2t+1]."""
-    w = prng.split_words(root, 2 * T)
+    """step_keys[t], resample_keys[t] = fold_in(root, 2t), fold_in(root, 2t+1): fresh lane-0 keys (for
+    threefry the same words as split(root, 2T)[2t], [2t+1])."""
+    w = prng.fold_words(root, 2 * T)
     return w[0::2].copy(), w[1::2].copy()
 
 

@@ -47,16 +47,24 @@ typedef enum {
 /* ---- PRNG ------------------------------------------------------------------------------- */
 
 /* Cipher / derivation scheme.  THREEFRY reproduces jax.random's key tree (SURVEY App. A:
- * threefry2x32, partitionable split/fold_in); PHILOX is the native counter scheme
- * (Philox4x32-10). */
+ * threefry2x32, partitionable split/fold_in): keys are 2 words.  PHILOX is the native counter
+ * scheme (Philox4x32-10): a key is 4 words (k0, k1, lane_lo, lane_hi) — a 64-bit
+ * cipher key plus a 64-bit LANE that occupies counter words 0,1 of every block.  The children of a
+ * lane-0 key are (same cipher key, lane i+1): a population's keys cost no cipher block and share
+ * one cipher key; the children of a laned key are hashed to fresh lane-0 keys. */
 typedef enum { GJX_RNG_THREEFRY = 0, GJX_RNG_PHILOX = 1 } gjx_rng_impl;
+#define GJX_KEY_WORDS(impl) ((impl) == GJX_RNG_PHILOX ? 4 : 2)
 
 /* A batch of n per-particle keys, either materialised or lazily derived in-register.
- *   mode 0: keys[i] = (keys[2i], keys[2i+1])                      (dev u32[n,2])
+ *   mode 0: keys[i] = row i of keys            (dev u32[n, GJX_KEY_WORDS(impl)])
  *   mode 1: keys[i] = split(parent, *)[first + i]                 (nothing read from HBM)
  *   mode 2: keys[i] = parent for every i                          (one literal key, by value)
- * If has_fold, the key actually used is fold_in(keys[i], fold) — the per-`@`-site key of
- * generative_functions/static.py:349-352 (counter from 1).
+ * parent = (parent[0], parent[1]) with lane parent_lane (PHILOX; must be 0 for THREEFRY).
+ * If has_fold, the draws of a leaf site come from the key's stream number `fold`: THREEFRY uses
+ * fold_in(keys[i], fold) with fold = the per-`@`-site counter of generative_functions/
+ * static.py:349-352 (from 1, constrained sites included); PHILOX carries the fold in the block
+ * counter, with fold = the 0-based index of the site among the sites that consume randomness (four
+ * consecutive single-word draws share one cipher block).
  * Replaces: jax.random.split / fold_in call sites inference/smc.py:299-300, static.py:261,350. */
 typedef struct {
   int32_t impl;        /* gjx_rng_impl */
@@ -66,6 +74,7 @@ typedef struct {
   uint64_t first;      /* mode 1: global index of element 0 (shard offset) */
   int32_t has_fold;
   uint32_t fold;
+  uint64_t parent_lane;/* mode 1 / 2, PHILOX: lane of the parent key (0 = none) */
 } gjx_keys;
 
 /* f32 operand: per-particle column (dev, stride 1) or broadcast scalar when ptr == NULL. */
@@ -77,13 +86,15 @@ typedef struct {
 int gjx_version(int* major, int* minor);
 const char* gjx_backend_name(void); /* "hip-gfx950" or "oracle-cpu" */
 
-/* out[i] = the i-th key described by k (after the optional fold).  dev u32[n,2].
+/* out[i] = the i-th key described by k (after the optional fold: fold_in(key, fold), a fresh
+ * lane-0 key).  dev u32[n, GJX_KEY_WORDS(impl)].
  * Replaces jax.random.split (smc.py:300,386; vmap.py:186,201) and fold_in (static.py:350,
  * scan.py:213,268) when keys must be materialised. */
 int gjx_rng_keys(const gjx_keys* k, uint64_t n, uint32_t* out, gjx_stream s);
 
 /* out[i*m + j] = split(key_i, m)[j] for the n keys described by k (after the optional fold):
- * the nested key batch of Vmap.generate / simulate (combinators/vmap.py:186,201).  dev u32[n,m,2]. */
+ * the nested key batch of Vmap.generate / simulate (combinators/vmap.py:186,201).
+ * dev u32[n, m, GJX_KEY_WORDS(impl)]. */
 int gjx_rng_split_each(const gjx_keys* k, uint64_t n, uint32_t m, uint32_t* out, gjx_stream s);
 
 /* out[i] = 32 random bits of key i, sub-stream `sub` (DESIGN.md §3.2 bits32_at).  dev u32[n]. */
@@ -283,7 +294,9 @@ int gjx_gather_cols(const int32_t* ancestors, uint64_t n_out, const void* const*
 
 /* ---- fused bootstrap SMC for the benchmark state-space models ------------------------------ *
  * One call enqueues the whole T-step filter (2 kernels per step) on the stream, no host sync.
- * Particle slot j (global index) of step t uses key split(step_keys[t], *)[j], site counter 1
+ * Particle slot j (global index) of step t uses key split(step_keys[t], *)[j] and its first
+ * single-word draw (THREEFRY: site counter 1; PHILOX: step keys are lane-0 keys, so the slot key
+ * is (step key, lane j+1) and the draw costs ONE block under a launch-uniform cipher key)
  * (the kernel `@gen` body has one latent site; Scan.generate scan.py:237-294 is the reference's
  * T-loop, resampling itself is not in the reference: SURVEY F3/E3).
  * Multi-device: each rank owns slots [first_slot, first_slot+n_local) of n_total and passes
@@ -309,7 +322,7 @@ typedef struct {
   uint64_t first_slot;     /* this rank's first slot (multiple of the tile size) */
   uint64_t n_local;        /* this rank's slot count */
   int32_t n_steps;         /* T */
-  const uint32_t* step_keys;     /* host u32[T,2]: per-step propagate keys */
+  const uint32_t* step_keys;     /* host u32[T,2]: per-step propagate keys (lane 0: fold_in results) */
   const uint32_t* resample_keys; /* host u32[T,2]: per-step resampling keys (entry 0 unused) */
 } gjx_smc_config;
 
@@ -359,10 +372,9 @@ int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_
  * The general form of the two fixed models above: x_0 comes from `init_sites`, every later step
  * walks `step_sites` for each output slot with GJX_ARG_STATE arguments reading the resampled
  * ancestor's state columns; observed sites contribute their log-density to the step's log-weight.
- * Site counter f (1-based, table order) draws — threefry: particle key split(step_key)[slot], site
- * key fold_in(., f); philox: single-word draws are word (f-1)&3 of
- * PH(ctr = (slot_lo, slot_hi, (f-1)>>2, "SMCS"), step_key), multi-word samplers use the stream of
- * split(step_key)[slot] folded with f.  libgjx_hip.so lowers the step to a hiprtc-compiled policy
+ * Slot key = split(step_key)[slot]; sites draw from it exactly as in gjx_importance_run (THREEFRY:
+ * fold_in(., 1-based table position); PHILOX: fold = 0-based index among the sampled sites, four
+ * single-word draws per block).  libgjx_hip.so lowers the step to a hiprtc-compiled policy
  * inside the fused resample kernel.  State columns are f32 (integer-valued sites are converted). */
 #define GJX_SMC_MAX_STATE 4
 #define GJX_SMC_MAX_OBS 8

@@ -34,13 +34,29 @@ uint64_t gjx_num_max_partials(uint64_t n) { return (n + O_ROW - 1) / O_ROW; }
 size_t gjx_workspace_bytes(int op, uint64_t n) { (void)op; (void)n; return 64; }
 
 /* ---- keys ---------------------------------------------------------------------------------- */
-static inline void key_at(const gjx_keys* k, uint64_t i, uint32_t out[2]) {
-  if (k->mode == 0) { out[0] = k->keys[2 * i]; out[1] = k->keys[2 * i + 1]; }
-  else if (k->mode == 1) o_split_at(k->impl, k->parent, k->first + i, out);
-  else { out[0] = k->parent[0]; out[1] = k->parent[1]; }
+static inline int key_words(int impl) { return GJX_KEY_WORDS(impl); }
+static inline void parent_key(const gjx_keys* k, uint32_t out[4]) {
+  out[0] = k->parent[0]; out[1] = k->parent[1];
+  out[2] = (uint32_t)k->parent_lane; out[3] = (uint32_t)(k->parent_lane >> 32);
+}
+static inline void key_at(const gjx_keys* k, uint64_t i, uint32_t out[4]) {
+  if (k->mode == 0) {
+    const int w = key_words(k->impl);
+    out[2] = 0u; out[3] = 0u;
+    for (int c = 0; c < w; ++c) out[c] = k->keys[(uint64_t)w * i + c];
+  } else {
+    uint32_t parent[4];
+    parent_key(k, parent);
+    if (k->mode == 1) o_split_at(k->impl, parent, k->first + i, out);
+    else o_key_copy(out, parent);
+  }
+}
+static inline void key_store(int impl, uint32_t* out, uint64_t i, const uint32_t key[4]) {
+  const int w = key_words(impl);
+  for (int c = 0; c < w; ++c) out[(uint64_t)w * i + c] = key[c];
 }
 static inline o_stream stream_at(const gjx_keys* k, uint64_t i) {
-  uint32_t key[2];
+  uint32_t key[4];
   key_at(k, i, key);
   return o_stream_make(k->impl, key, k->has_fold, k->fold);
 }
@@ -48,6 +64,7 @@ static int keys_ok(const gjx_keys* k) {
   if (!k) return 0;
   if (k->impl != 0 && k->impl != 1) return 0;
   if (k->mode == 0) return k->keys != NULL;
+  if (k->impl == 0 && k->parent_lane != 0) return 0;
   return k->mode == 1 || k->mode == 2;
 }
 
@@ -56,11 +73,10 @@ int gjx_rng_keys(const gjx_keys* k, uint64_t n, uint32_t* out, gjx_stream s) {
   if (!keys_ok(k) || (!out && n)) return GJX_ERR_INVALID;
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < (int64_t)n; ++i) {
-    uint32_t key[2];
+    uint32_t key[4];
     key_at(k, (uint64_t)i, key);
-    if (k->has_fold) { uint32_t f[2]; o_fold_in(k->impl, key, k->fold, f); key[0] = f[0]; key[1] = f[1]; }
-    out[2 * i] = key[0];
-    out[2 * i + 1] = key[1];
+    if (k->has_fold) { uint32_t f[4]; o_fold_in(k->impl, key, k->fold, f); o_key_copy(key, f); }
+    key_store(k->impl, out, (uint64_t)i, key);
   }
   return GJX_OK;
 }
@@ -70,10 +86,13 @@ int gjx_rng_split_each(const gjx_keys* k, uint64_t n, uint32_t m, uint32_t* out,
   if (!keys_ok(k) || (!out && n) || m == 0) return GJX_ERR_INVALID;
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < (int64_t)n; ++i) {
-    uint32_t key[2];
+    uint32_t key[4], child[4];
     key_at(k, (uint64_t)i, key);
-    if (k->has_fold) { uint32_t f[2]; o_fold_in(k->impl, key, k->fold, f); key[0] = f[0]; key[1] = f[1]; }
-    for (uint32_t j = 0; j < m; ++j) o_split_at(k->impl, key, j, &out[2 * ((uint64_t)i * m + j)]);
+    if (k->has_fold) { uint32_t f[4]; o_fold_in(k->impl, key, k->fold, f); o_key_copy(key, f); }
+    for (uint32_t j = 0; j < m; ++j) {
+      o_split_at(k->impl, key, j, child);
+      key_store(k->impl, out, (uint64_t)i * m + j, child);
+    }
   }
   return GJX_OK;
 }
@@ -329,10 +348,7 @@ static inline int32_t sv_as_i32(const site_val* v) { return v->is_int ? v->i : (
 /* Everything one particle's walk over a site table reads. */
 typedef struct {
   int impl;
-  int smc;                   /* 0: importance (per-particle key pkey); 1: SMC slot of step_key */
-  uint32_t pkey[2];          /* importance: particle key; smc: split(step_key)[slot] (multi-word streams) */
-  const uint32_t* step_key;  /* smc */
-  uint64_t slot;             /* smc: global slot */
+  uint32_t pkey[4];          /* importance: particle key; smc: slot key split(step_key)[slot] */
   const float* const* in;    /* importance: input columns */
   uint64_t i;                /* importance: particle index into the input columns */
   const float* state;        /* smc: the ancestor's state columns (NULL at step 0) */
@@ -354,6 +370,7 @@ static inline float eval_arg(const gjx_arg* a, const site_val* vals, const walk_
 static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, site_val* vals, float* w_out,
                       float* sc_out) {
   float w = 0.0f, sc = 0.0f;
+  uint32_t draws = 0;
   for (int q = 0; q < n_sites; ++q) {
     const gjx_site* st = &sites[q];
     site_val v;
@@ -379,9 +396,11 @@ static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, sit
                : st->obs.kind == GJX_ARG_OBS ? c->obs[st->obs.ref] : c->in[st->obs.ref][c->i];
       if (v.is_int) v.i = (int32_t)rintf(ov); else v.f = ov;
     } else {
-      const uint32_t f = (uint32_t)(q + 1);
+      /* THREEFRY: site counter from 1 (static.py:349-352); PHILOX: index among the sampled sites */
+      const uint32_t f = c->impl == 0 ? (uint32_t)(q + 1) : draws;
+      ++draws;
       o_stream strm = o_stream_make(c->impl, c->pkey, 1, f);
-      const uint32_t bits0 = c->smc ? o_smc_site_bits(c->impl, c->step_key, c->slot, f) : o_bits32_at(&strm, 0);
+      const uint32_t bits0 = o_bits32_at(&strm, 0);
       switch (st->dist) {
         case GJX_DIST_NORMAL: { float t = a1 * o_std_normal(bits0); v.f = a0 + t; break; }
         case GJX_DIST_GAMMA: v.f = o_std_gamma(&strm, 0, a0) / a1; break;
@@ -711,7 +730,8 @@ static void smc_ancestors(const gjx_smc_config* cfg, int t, const float* prev_lo
   const uint64_t N = cfg->n_total;
   const int frac = o_frac_bits(N);
   const int64_t lo = (int64_t)cfg->first_slot, hi = lo + (int64_t)cfg->n_local;
-  o_stream st = o_stream_make(cfg->impl, &cfg->resample_keys[2 * t], 0, 0);
+  const uint32_t rkey[4] = {cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1], 0u, 0u};
+  o_stream st = o_stream_make(cfg->impl, rkey, 0, 0);
   double u0 = u0_from_bits(o_bits64_at(&st, 0));
   double scale = (double)N / (double)Q;
   uint64_t C = 0;
@@ -788,7 +808,7 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
   } else if (ancestors_out) {
     for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
   }
-  const uint32_t* skey = &cfg->step_keys[2 * t];
+  const uint32_t skey[4] = {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u};
   float mx = -INFINITY;
 #pragma omp parallel for reduction(max : mx) schedule(static)
   for (int64_t j = 0; j < (int64_t)nl; ++j) {
@@ -853,7 +873,7 @@ int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int
   } else if (ancestors_out) {
     for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
   }
-  const uint32_t* skey = &cfg->step_keys[2 * t];
+  const uint32_t skey[4] = {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u};
   float mx = -INFINITY;
 #pragma omp parallel for reduction(max : mx) schedule(static)
   for (int64_t j = 0; j < (int64_t)nl; ++j) {
@@ -1044,7 +1064,7 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
     } else {
       for (uint64_t j = 0; j < N; ++j) anc[j] = (int32_t)j;
     }
-    const uint32_t* skey = &cfg->step_keys[2 * t];
+    const uint32_t skey[4] = {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u};
     const float* obs = obs_host ? obs_host + (size_t)t * (size_t)m->n_obs : NULL;
     const gjx_site* sites = t == 0 ? m->init_sites : m->step_sites;
     const int ns = t == 0 ? m->n_init_sites : m->n_step_sites;
@@ -1055,9 +1075,6 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
       walk_ctx c;
       memset(&c, 0, sizeof c);
       c.impl = cfg->impl;
-      c.smc = 1;
-      c.step_key = skey;
-      c.slot = (uint64_t)j;
       o_split_at(cfg->impl, skey, (uint64_t)j, c.pkey);
       float prev[GJX_SMC_MAX_STATE];
       if (t > 0)

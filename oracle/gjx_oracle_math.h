@@ -68,41 +68,60 @@ static inline void o_philox4x32(uint32_t k0, uint32_t k1, const uint32_t c[4], u
 }
 
 /* ---------------- key derivation ----------------------------------------- *
+ * A key is 4 words (k0, k1, lane_lo, lane_hi); THREEFRY uses k0,k1 only (lane 0).
  * THREEFRY = jax.random semantics with jax_threefry_partitionable (default from jax 0.5.0,
- * SURVEY App. A): split(k,n)[i] = TF(k,(0,i)); fold_in(k,d) = TF(k,(0,d)).
- * PHILOX (native): derive(k, idx, tag) = words 0,1 of PH(ctr=(idx_lo, idx_hi, 0, tag), key=k). */
-#define O_TAG_SPLIT 0x53504C54u /* "SPLT" */
-#define O_TAG_FOLD 0x464F4C44u  /* "FOLD" */
-#define O_TAG_BITS 0x42495453u  /* "BITS" */
+ * SURVEY App. A): split(k,n)[i] = TF(k,(hi(i),lo(i))); fold_in(k,d) = TF(k,(0,d)).
+ * PHILOX (native): every block is PH(ctr = (lane_lo, lane_hi, b, (a << 8) | tag), key = (k0,k1)).
+ *   split of a lane-0 key: child i = (k0, k1, lane i+1)             — no cipher block
+ *   split of a laned key:  child i = words 0,1 of block (b = i_lo, a = i_hi, 'S'), lane 0
+ *   fold_in(k, d)        = words 0,1 of block (b = d, 'F'), lane 0
+ *   packed single-word draw number f = word f&3 of block (b = f>>2, 'D')
+ *   sub-stream s of a stream with optional fold f = words 0,1 of block (b = s, a = has_fold ? f+1 : 0, 'R') */
+#define O_TAG_SPLIT 0x53u
+#define O_TAG_FOLD 0x46u
+#define O_TAG_DRAW 0x44u
+#define O_TAG_STREAM 0x52u
 
-static inline void o_split_at(int impl, const uint32_t k[2], uint64_t i, uint32_t out[2]) {
-  if (impl == 0) {
-    o_threefry2x32(k[0], k[1], (uint32_t)(i >> 32), (uint32_t)i, &out[0], &out[1]);
-  } else {
-    uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), 0u, O_TAG_SPLIT}, o[4];
-    o_philox4x32(k[0], k[1], c, o);
-    out[0] = o[0]; out[1] = o[1];
-  }
+static inline void o_key_copy(uint32_t dst[4], const uint32_t src[4]) { memcpy(dst, src, 16); }
+static inline void o_philox_lane(const uint32_t k[4], uint32_t b, uint32_t a_tag, uint32_t o[4]) {
+  uint32_t c[4] = {k[2], k[3], b, a_tag};
+  o_philox4x32(k[0], k[1], c, o);
 }
-static inline void o_fold_in(int impl, const uint32_t k[2], uint32_t d, uint32_t out[2]) {
+static inline void o_split_at(int impl, const uint32_t k[4], uint64_t i, uint32_t out[4]) {
+  uint32_t r[4] = {0u, 0u, 0u, 0u};
   if (impl == 0) {
-    o_threefry2x32(k[0], k[1], 0u, d, &out[0], &out[1]);
+    o_threefry2x32(k[0], k[1], (uint32_t)(i >> 32), (uint32_t)i, &r[0], &r[1]);
+  } else if ((k[2] | k[3]) == 0u) {
+    const uint64_t lane = i + 1u;
+    r[0] = k[0]; r[1] = k[1]; r[2] = (uint32_t)lane; r[3] = (uint32_t)(lane >> 32);
   } else {
-    uint32_t c[4] = {d, 0u, 0u, O_TAG_FOLD}, o[4];
-    o_philox4x32(k[0], k[1], c, o);
-    out[0] = o[0]; out[1] = o[1];
+    uint32_t o[4];
+    o_philox_lane(k, (uint32_t)i, ((uint32_t)(i >> 32) << 8) | O_TAG_SPLIT, o);
+    r[0] = o[0]; r[1] = o[1];
   }
+  o_key_copy(out, r);
 }
-/* A draw stream = (key, optional leaf-site counter).  THREEFRY: the stream key is
- * fold_in(key, fold) (static.py:349-352) and sub-stream `sub` is TF(stream key, (0, sub)).
- * PHILOX: the leaf fold is carried in the counter instead of costing a block:
- * words(sub) = PH(ctr = (sub, fold, has_fold, TAG_BITS), key). */
-typedef struct { int impl; uint32_t k[2]; uint32_t f; uint32_t hf; } o_stream;
+static inline void o_fold_in(int impl, const uint32_t k[4], uint32_t d, uint32_t out[4]) {
+  uint32_t r[4] = {0u, 0u, 0u, 0u};
+  if (impl == 0) {
+    o_threefry2x32(k[0], k[1], 0u, d, &r[0], &r[1]);
+  } else {
+    uint32_t o[4];
+    o_philox_lane(k, d, O_TAG_FOLD, o);
+    r[0] = o[0]; r[1] = o[1];
+  }
+  o_key_copy(out, r);
+}
+/* A draw stream = (key, optional leaf-site fold).  THREEFRY: the stream key is
+ * fold_in(key, fold) with fold = the site counter (static.py:349-352) and sub-stream `sub` is
+ * TF(stream key, (0, sub)).  PHILOX: the fold (0-based index among the sampled sites) is carried in
+ * the counter instead of costing a block. */
+typedef struct { int impl; uint32_t k[4]; uint32_t f; uint32_t hf; } o_stream;
 
-static inline o_stream o_stream_make(int impl, const uint32_t key[2], int has_fold, uint32_t fold) {
+static inline o_stream o_stream_make(int impl, const uint32_t key[4], int has_fold, uint32_t fold) {
   o_stream s;
   s.impl = impl; s.f = 0u; s.hf = 0u;
-  s.k[0] = key[0]; s.k[1] = key[1];
+  o_key_copy(s.k, key);
   if (has_fold) {
     if (impl == 0) o_fold_in(0, key, fold, s.k);
     else { s.f = fold; s.hf = 1u; }
@@ -114,20 +133,20 @@ static inline void o_words(const o_stream* s, uint32_t sub, uint32_t* w0, uint32
   if (s->impl == 0) {
     o_threefry2x32(s->k[0], s->k[1], 0u, sub, w0, w1);
   } else {
-    uint32_t c[4] = {sub, s->f, s->hf, O_TAG_BITS}, o[4];
-    o_philox4x32(s->k[0], s->k[1], c, o);
+    uint32_t o[4];
+    o_philox_lane(s->k, sub, ((s->hf ? s->f + 1u : 0u) << 8) | O_TAG_STREAM, o);
     *w0 = o[0]; *w1 = o[1];
   }
 }
 /* 32 random bits of element `sub` — THREEFRY: jax _threefry_random_bits_partitionable, hi ^ lo.
- * PHILOX: word 0 of the sub-stream, except the single-word draw (sub 0) of a leaf site with
- * counter f, which is word (f & 3) of the block shared by the four sites f>>2:
- * PH(ctr = (0, f >> 2, 2, TAG_BITS), key) — one cipher block serves four scalar sites. */
+ * PHILOX: word 0 of the sub-stream, except the single-word draw (sub 0) of a folded stream, which
+ * is word (f & 3) of the block shared by folds 4(f>>2)..4(f>>2)+3 — one cipher block serves four
+ * scalar sites. */
 static inline uint32_t o_bits32_at(const o_stream* s, uint32_t sub) {
   uint32_t w0, w1;
   if (s->impl == 1 && s->hf && sub == 0u) {
-    uint32_t c[4] = {0u, s->f >> 2, 2u, O_TAG_BITS}, o[4];
-    o_philox4x32(s->k[0], s->k[1], c, o);
+    uint32_t o[4];
+    o_philox_lane(s->k, s->f >> 2, O_TAG_DRAW, o);
     return o[s->f & 3u];
   }
   o_words(s, sub, &w0, &w1);
@@ -139,33 +158,13 @@ static inline uint64_t o_bits64_at(const o_stream* s, uint32_t sub) {
   return ((uint64_t)w0 << 32) | w1;
 }
 
-/* The 32-bit draw of SMC slot j at one step.  THREEFRY: particle key
- * split(step_key)[j], site key fold_in(., 1), bits of block 0.  PHILOX: word 0 of
- * PH(ctr = (j_lo, j_hi, 0, "SMCS"), step_key). */
-#define O_TAG_SMC 0x534D4353u
-static inline uint32_t o_smc_slot_bits(int impl, const uint32_t step_key[2], uint64_t j) {
-  if (impl == 0) {
-    uint32_t pk[2];
-    o_split_at(0, step_key, j, pk);
-    o_stream st = o_stream_make(0, pk, 1, 1u);
-    return o_bits32_at(&st, 0);
-  }
-  uint32_t c[4] = {(uint32_t)j, (uint32_t)(j >> 32), 0u, O_TAG_SMC}, o[4];
-  o_philox4x32(step_key[0], step_key[1], c, o);
-  return o[0];
-}
-
-/* Single-word draw of site counter f (1-based) of SMC slot j — generalises o_smc_slot_bits (f = 1). */
-static inline uint32_t o_smc_site_bits(int impl, const uint32_t step_key[2], uint64_t j, uint32_t f) {
-  if (impl == 0) {
-    uint32_t pk[2];
-    o_split_at(0, step_key, j, pk);
-    o_stream st = o_stream_make(0, pk, 1, f);
-    return o_bits32_at(&st, 0);
-  }
-  uint32_t c[4] = {(uint32_t)j, (uint32_t)(j >> 32), (f - 1u) >> 2, O_TAG_SMC}, o[4];
-  o_philox4x32(step_key[0], step_key[1], c, o);
-  return o[(f - 1u) & 3u];
+/* The 32-bit draw of SMC slot j at one step: the first single-word draw of the slot
+ * key split(step_key)[j] (THREEFRY: site counter 1; PHILOX: fold 0). */
+static inline uint32_t o_smc_slot_bits(int impl, const uint32_t step_key[4], uint64_t j) {
+  uint32_t pk[4];
+  o_split_at(impl, step_key, j, pk);
+  o_stream st = o_stream_make(impl, pk, 1, impl == 0 ? 1u : 0u);
+  return o_bits32_at(&st, 0);
 }
 
 /* ---------------- f32 math spec: only IEEE-exact primitives -------------- *

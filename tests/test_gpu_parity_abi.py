@@ -51,8 +51,17 @@ def test_rng_keys_and_bits(hip_ops, oracle_ops, impl, n):
     same(hip_ops.rng_bits(lit, n, 3), oracle_ops.rng_bits(lit, n, 3), "literal key")
     for m in (1, 3):
         same(hip_ops.rng_split_each(kb, n, m), oracle_ops.rng_split_each(kb, n, m), "rng_split_each")
-    se = oracle_ops.rng_split_each(kb, n, 3).view(n, 3, 2)
+        same(hip_ops.rng_split_each(ek_h, n, m), oracle_ops.rng_split_each(kb, n, m), "rng_split_each explicit")
+    se = oracle_ops.rng_split_each(kb, n, 3).view(n, 3, -1)
     assert torch.equal(se[:, 0], oracle_ops.rng_keys(KeyBatch(impl, 0, tensor=mat).with_fold(0), n)) or impl == 1
+    if impl == 1:  # philox keys with a lane: as parent of a lazy batch (children are hashed) and as a literal
+        for lk in (KeyBatch(1, 1, parent=(7, 8), first=3, parent_lane=(1 << 40) + 9),
+                   KeyBatch(1, 2, parent=(7, 8), parent_lane=12345)):
+            for k in (lk, lk.with_fold(6)):
+                same(hip_ops.rng_keys(k, n), oracle_ops.rng_keys(k, n), "laned rng_keys")
+                same(hip_ops.rng_bits(k, n, 0), oracle_ops.rng_bits(k, n, 0), "laned rng_bits")
+                same(hip_ops.rng_bits(k, n, 5), oracle_ops.rng_bits(k, n, 5), "laned rng_bits sub")
+            same(hip_ops.rng_split_each(lk, n, 2), oracle_ops.rng_split_each(lk, n, 2), "laned split_each")
 
 
 @pytest.mark.parametrize("impl", IMPLS)
