@@ -114,8 +114,10 @@ def bench_importance(args, ops, rank, world):
 
     ev_pool = [(HipEvent(), HipEvent()) for _ in range(args.steps + args.warmup)]
 
-    prep = wl.prepare()  # persistent output buffers + pre-marshalled C calls: no host allocation per step
     BATCH = 8
+    # persistent output buffers + pre-marshalled C calls: no host allocation per step; BATCH passes share one
+    # log-sum-exp launch
+    prep = wl.prepare(fold_batch=BATCH)
     if sharded:
         # each pass leaves a 65-word record of its shard's weights; one asynchronous all-gather per BATCH
         # passes overlaps with the next batch's kernels (genjax/_amd/dist.py)
@@ -146,19 +148,25 @@ def bench_importance(args, ops, rank, world):
         if sample:
             e0, e1 = ev_pool.pop()
             e0.record(st)
-        prep.launch_importance(st)  # also emits the row-anchored partial sums of its log-weights
+        # the walk: trace columns, score, log-weights and the row-anchored partial sums of this pass (slot b)
+        b = (step_no[0] - 1) % BATCH
+        prep.launch_importance(st, b)
         if sample:
             e1.record(st)
             if timed:
                 kernel_ms.append((e0, e1))
-        prep.launch_lse_rows(st)  # one tiny kernel: combine 3907 (anchor, sum) pairs
-        return prep.row_e_out, prep.row_q_out, prep.logw
+        if b == BATCH - 1:  # one launch folds the 3907 (anchor, sum) pairs of each of the last BATCH passes
+            prep.launch_fold(BATCH, st)
+        return b
 
     def run_steps(count, timed):
         if not sharded:
+            step_no[0] = 0
             for _ in range(count):
-                out = step(timed)
-            return out
+                b = step(timed)
+            if b != BATCH - 1:
+                prep.launch_fold(b + 1, ops.stream())  # the ragged last batch
+            return prep.e_all[b:b + 1], prep.q_all[b:b + 1], prep.logw
         done = 0
         while done < count:
             c = min(BATCH, count - done)
@@ -174,7 +182,6 @@ def bench_importance(args, ops, rank, world):
     cal = [(HipEvent(), HipEvent()) for _ in range(16)]
     sh_cal = ops.stream()
     for a, b in cal:
-        prep.launch_lse_rows(sh_cal) if not sharded else None
         a.record(sh_cal)
         b.record(sh_cal)
     barrier_sync(world)

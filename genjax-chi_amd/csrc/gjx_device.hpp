@@ -651,6 +651,161 @@ struct ResampleArgs {
                                 // large populations (otherwise every workgroup reduces tile_sums itself)
 };
 
+// ------------------------------------------------------------------------------------------------
+// Row-anchored log-sum-exp of a whole pass: e = max e_b; buckets B_d = sum of S_b over
+// the rows with e - e_b == d (d < 64, exact); Q = sum_d B_d >> d; lse = e ln2 + log(Q 2^-30).  The
+// (e, B_0..B_63) record is what ranks exchange: bucket sums are exact integers, so records merge
+// (k_lse_combine) into the same bits for any sharding.
+// ------------------------------------------------------------------------------------------------
+GJX_DEV void lse_emit(int32_t e, uint64_t bucket, int32_t* out_e, uint64_t* out_q, float* out_lse,
+                      uint64_t* out_record) {
+  // called by the first wave: lane d holds bucket d
+  const uint64_t q = wave_sum(bucket >> (threadIdx.x & 63));
+  if (out_record) {
+    out_record[1 + threadIdx.x] = bucket;
+    if (threadIdx.x == 0) out_record[0] = (uint64_t)(int64_t)e;
+  }
+  if (threadIdx.x == 0) {
+    if (out_e) out_e[0] = e;
+    if (out_q) out_q[0] = q;
+    if (out_lse) {
+      if (e == kRowEmpty || q == 0) {
+        out_lse[0] = -__builtin_inff();
+      } else {
+        const float t1 = (float)e * 0.69314718055994531f;
+        const float t2 = m_log((float)q * u2f((uint32_t)(127 - kRowFrac) << 23));
+        out_lse[0] = t1 + t2;
+      }
+    }
+  }
+}
+// One 256-thread workgroup folds n_rows (e_b, S_b) pairs.  Up to 16 rows per thread are held in
+// registers (all loads in flight at once: one memory latency), which covers 4096 rows = 1M particles;
+// larger populations take the two-pass loop.  DEVICE_SCOPE: the pairs were written by other
+// workgroups of the SAME launch, so they are read with agent-scope (sc1) loads that bypass this CU's L1.
+template <bool DEVICE_SCOPE>
+GJX_DEV int32_t lse_load_e(const int32_t* p) {
+  return DEVICE_SCOPE ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool DEVICE_SCOPE>
+GJX_DEV uint64_t lse_load_s(const uint64_t* p) {
+  return DEVICE_SCOPE ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool DEVICE_SCOPE>
+GJX_DEV void lse_rows_block(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows,
+                            int32_t* out_e, uint64_t* out_q, float* out_lse, uint64_t* out_record) {
+  __shared__ int32_t she[kBlock / kWave];
+  __shared__ unsigned long long shb[kLseBuckets];
+  constexpr int kPer = 16;
+  constexpr int kNear = 4;  // shifts 0..3 (practically every row) accumulate in registers
+  const bool in_regs = n_rows <= (uint64_t)kPer * kBlock;
+  int32_t ev[kPer];
+  uint64_t sv[kPer];
+  int32_t e = kRowEmpty;
+  if (threadIdx.x < kLseBuckets) shb[threadIdx.x] = 0;
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const uint64_t b = threadIdx.x + (uint64_t)k * kBlock;
+      ev[k] = b < n_rows ? lse_load_e<DEVICE_SCOPE>(row_e + b) : kRowEmpty;
+      sv[k] = b < n_rows ? lse_load_s<DEVICE_SCOPE>(row_s + b) : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) e = ev[k] > e ? ev[k] : e;
+  } else {
+    for (uint64_t b = threadIdx.x; b < n_rows; b += kBlock) {
+      const int32_t eb = lse_load_e<DEVICE_SCOPE>(row_e + b);
+      e = eb > e ? eb : e;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int32_t o = __shfl_xor(e, off, kWave);
+    e = o > e ? o : e;
+  }
+  if ((threadIdx.x & 63) == 0) she[threadIdx.x >> 6] = e;
+  __syncthreads();
+  e = she[0];
+#pragma unroll
+  for (int i = 1; i < kBlock / kWave; ++i) e = she[i] > e ? she[i] : e;
+  uint64_t near[kNear] = {0, 0, 0, 0};
+  auto add_row = [&](int32_t eb, uint64_t sb) {
+    if (eb == kRowEmpty) return;
+    const int64_t d = (int64_t)e - (int64_t)eb;
+#pragma unroll
+    for (int k = 0; k < kNear; ++k) near[k] += d == k ? sb : 0;
+    if (d >= kNear && d < kLseBuckets && sb) atomicAdd(&shb[d], (unsigned long long)sb);
+  };
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) add_row(ev[k], sv[k]);
+  } else {
+    for (uint64_t b = threadIdx.x; b < n_rows; b += kBlock)
+      add_row(lse_load_e<DEVICE_SCOPE>(row_e + b), lse_load_s<DEVICE_SCOPE>(row_s + b));
+  }
+#pragma unroll
+  for (int k = 0; k < kNear; ++k) {
+    const uint64_t w = wave_sum(near[k]);
+    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&shb[k], (unsigned long long)w);
+  }
+  __syncthreads();
+  if (threadIdx.x < kLseBuckets) lse_emit(e, (uint64_t)shb[threadIdx.x], out_e, out_q, out_lse, out_record);
+}
+
+// The log-marginal of a pass fused into the kernel that produces the log-weights (mirrors gjx_lse_out):
+// every workgroup publishes its row pairs, takes a ticket, and the workgroup that arrives LAST folds all
+// of them — no second launch.  Hand-off form (MI355X: per-XCD L2s are not coherent, L1 is never
+// refreshed by other CUs' stores): the pairs are written by ONE lane with agent-scope (sc1, write-through)
+// stores, that lane drains them (s_waitcnt vmcnt(0)) and then takes the ticket with an agent-scope atomic
+// add; the last arriver — told by the value its own add returned — reads them with sc1 loads after a
+// workgroup barrier.  Tickets are sharded 16 ways (+1 top word) so 4k arrivals do not queue on one word,
+// and the last workgroup leaves them zero for the next launch on the stream.
+constexpr int kLseTicketShards = 16;
+constexpr int kLseTicketStride = 64;  // words between counters: each on its own 256-byte line (atomics on one
+                                      // line are served one at a time by the memory-side atomic unit)
+struct LseTail {
+  int32_t* e;
+  uint64_t* q;
+  float* lse;
+  uint64_t* record;
+  uint32_t* tickets;  // [(kLseTicketShards + 1) * kLseTicketStride], zero between launches; null = no fused tail
+};
+GJX_DEV void lse_store_row(int32_t* row_e, uint64_t* row_s, uint64_t row, int32_t eb, uint64_t sb, bool device_scope) {
+  if (device_scope) {  // read by the last workgroup of THIS launch: write-through
+    __hip_atomic_store(row_e + row, eb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(row_s + row, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {  // read by a later launch
+    row_e[row] = eb;
+    row_s[row] = sb;
+  }
+}
+// Called by every thread of every workgroup once, after the workgroup's last lse_store_row (thread 0's).
+GJX_DEV void lse_tail(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, const LseTail& t) {
+  if (!t.tickets) return;
+  __shared__ uint32_t sh_last;
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t shard = blockIdx.x % kLseTicketShards;
+    const uint32_t in_shard = (gridDim.x - shard + kLseTicketShards - 1) / kLseTicketShards;
+    uint32_t last = 0;
+    if (__hip_atomic_fetch_add(t.tickets + shard * kLseTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+        in_shard - 1) {
+      const uint32_t n_shards = gridDim.x < (uint32_t)kLseTicketShards ? gridDim.x : (uint32_t)kLseTicketShards;
+      last = __hip_atomic_fetch_add(t.tickets + kLseTicketShards * kLseTicketStride, 1u, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT) ==
+                     n_shards - 1
+                 ? 1u
+                 : 0u;
+    }
+    sh_last = last;
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  lse_rows_block<true>(row_e, row_s, n_rows, t.e, t.q, t.lse, t.record);
+  if (threadIdx.x <= kLseTicketShards)
+    __hip_atomic_store(t.tickets + threadIdx.x * kLseTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Kernel argument block of a plan-driven SMC step (the generated policy wraps it).
 struct PlanPolicyArgs {
   const float* prev_state[4];

@@ -535,89 +535,16 @@ __global__ __launch_bounds__(kBlock) void k_row_stats(const float* x, uint64_t n
     }
   }
 }
-// one block: e = max e_b; buckets B_d = sum of S_b over rows with e - e_b == d (d < 64, exact);
-// Q = sum_d B_d >> d; lse = e ln2 + log(Q 2^-30).  The (e, B_0..B_63) record is what ranks exchange:
-// bucket sums are exact integers, so records merge (k_lse_combine) into the same bits for any sharding.
-// Up to 16 rows per thread are held in registers (all loads in flight at once: one memory latency),
-// which covers 4096 rows = 1M particles; larger populations take the two-pass loop.
-GJX_DEV void lse_emit(int32_t e, uint64_t bucket, int32_t* out_e, uint64_t* out_q, float* out_lse,
-                      uint64_t* out_record) {
-  // called by the first wave: lane d holds bucket d
-  const uint64_t q = wave_sum(bucket >> (threadIdx.x & 63));
-  if (out_record) {
-    out_record[1 + threadIdx.x] = bucket;
-    if (threadIdx.x == 0) out_record[0] = (uint64_t)(int64_t)e;
-  }
-  if (threadIdx.x == 0) {
-    if (out_e) out_e[0] = e;
-    if (out_q) out_q[0] = q;
-    if (out_lse) {
-      if (e == kRowEmpty || q == 0) {
-        out_lse[0] = -__builtin_inff();
-      } else {
-        const float t1 = (float)e * 0.69314718055994531f;
-        const float t2 = m_log((float)q * u2f((uint32_t)(127 - kRowFrac) << 23));
-        out_lse[0] = t1 + t2;
-      }
-    }
-  }
-}
+// gjx_lse_rows / gjx_lse_rows_batch: one workgroup per pass folds that pass's row pairs
+// (lse_rows_block, gjx_device.hpp); passes lie batch_stride rows apart.
 __global__ __launch_bounds__(kBlock) void k_lse_rows(const int32_t* row_e, const uint64_t* row_s,
-                                                     uint64_t n_rows, int32_t* out_e,
+                                                     uint64_t n_rows, uint64_t batch_stride, int32_t* out_e,
                                                      uint64_t* out_q, float* out_lse,
                                                      uint64_t* out_record) {
-  __shared__ int32_t she[kBlock / kWave];
-  __shared__ unsigned long long shb[kLseBuckets];
-  constexpr int kPer = 16;
-  constexpr int kNear = 4;  // shifts 0..3 (practically every row) accumulate in registers
-  const bool in_regs = n_rows <= (uint64_t)kPer * kBlock;
-  int32_t ev[kPer];
-  uint64_t sv[kPer];
-  int32_t e = kRowEmpty;
-  if (threadIdx.x < kLseBuckets) shb[threadIdx.x] = 0;
-  if (in_regs) {
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const uint64_t b = threadIdx.x + (uint64_t)k * kBlock;
-      ev[k] = b < n_rows ? row_e[b] : kRowEmpty;
-      sv[k] = b < n_rows ? row_s[b] : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) e = ev[k] > e ? ev[k] : e;
-  } else {
-    for (uint64_t b = threadIdx.x; b < n_rows; b += kBlock) e = row_e[b] > e ? row_e[b] : e;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const int32_t o = __shfl_xor(e, off, kWave);
-    e = o > e ? o : e;
-  }
-  if ((threadIdx.x & 63) == 0) she[threadIdx.x >> 6] = e;
-  __syncthreads();
-  e = she[0];
-#pragma unroll
-  for (int i = 1; i < kBlock / kWave; ++i) e = she[i] > e ? she[i] : e;
-  uint64_t near[kNear] = {0, 0, 0, 0};
-  auto add_row = [&](int32_t eb, uint64_t sb) {
-    if (eb == kRowEmpty) return;
-    const int64_t d = (int64_t)e - (int64_t)eb;
-#pragma unroll
-    for (int k = 0; k < kNear; ++k) near[k] += d == k ? sb : 0;
-    if (d >= kNear && d < kLseBuckets && sb) atomicAdd(&shb[d], (unsigned long long)sb);
-  };
-  if (in_regs) {
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) add_row(ev[k], sv[k]);
-  } else {
-    for (uint64_t b = threadIdx.x; b < n_rows; b += kBlock) add_row(row_e[b], row_s[b]);
-  }
-#pragma unroll
-  for (int k = 0; k < kNear; ++k) {
-    const uint64_t w = wave_sum(near[k]);
-    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&shb[k], (unsigned long long)w);
-  }
-  __syncthreads();
-  if (threadIdx.x < kLseBuckets) lse_emit(e, (uint64_t)shb[threadIdx.x], out_e, out_q, out_lse, out_record);
+  const uint64_t b = blockIdx.x;
+  lse_rows_block<false>(row_e + b * batch_stride, row_s + b * batch_stride, n_rows, out_e ? out_e + b : nullptr,
+                        out_q ? out_q + b : nullptr, out_lse ? out_lse + b : nullptr,
+                        out_record ? out_record + b * kLseRecordWords : nullptr);
 }
 // Merge `n_records` records (one per rank; consecutive records `record_stride` words apart) for each of
 // gridDim.x independent passes (`batch_stride` words apart): buckets re-indexed to the common anchor.
@@ -1350,9 +1277,10 @@ int gjx_plan_destroy(gjx_plan* p) {
 int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const* input_cols,
                        int n_input_cols, void* const* value_cols, int n_value_cols, float* score,
                        float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s,
-                       gjx_stream s) {
+                       const gjx_lse_out* lse, gjx_stream s) {
   if (!p || !keys_ok(pk) || pk->has_fold || !logw || n_input_cols < 0 || n_input_cols > 16 ||
-      n_value_cols < 0 || n_value_cols > GJX_MAX_SITES || ((row_e == nullptr) != (row_s == nullptr)))
+      n_value_cols < 0 || n_value_cols > GJX_MAX_SITES || ((row_e == nullptr) != (row_s == nullptr)) ||
+      (lse && (!row_e || !lse->tickets)))
     return GJX_ERR_INVALID;
   RunCols cols;
   memset(&cols, 0, sizeof(cols));
@@ -1387,8 +1315,15 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
     }
     if (c.state == 1) {
       uint64_t nn = n;
-      void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials, &row_e, &row_s};
-      const uint64_t rows = (nrows_of(n) + c.rows_per_block - 1) / c.rows_per_block;
+      LseTail tail{nullptr, nullptr, nullptr, nullptr, nullptr};
+      if (lse) tail = LseTail{lse->e, lse->q, lse->lse, lse->record, lse->tickets};
+      void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials, &row_e, &row_s, &tail};
+      uint64_t rows = (nrows_of(n) + c.rows_per_block - 1) / c.rows_per_block;
+      static const uint64_t grid_cap = [] {
+        const char* e = std::getenv("GJX_IMPORTANCE_GRID");
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : 0ull;
+      }();
+      if (grid_cap && rows > grid_cap) rows = grid_cap;  // the kernel strides over rows
       if (hipModuleLaunchKernel(c.fn, (unsigned)(rows > 0x7fffffffull ? 0x7fffffffull : rows), 1, 1, kBlock, 1, 1, 0,
                                 S(s), args, nullptr) != hipSuccess)
         return GJX_ERR_LAUNCH;
@@ -1413,6 +1348,8 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
     else GJX_LAUNCH_IMPORTANCE(1, kMaskAll);
   }
 #undef GJX_LAUNCH_IMPORTANCE
+  // generic route: the fold is a second (one-workgroup) launch
+  if (lse) k_lse_rows<<<1, kBlock, 0, S(s)>>>(row_e, row_s, nrows_of(n), 0, lse->e, lse->q, lse->lse, lse->record);
   return launch_status();
 }
 
@@ -1455,7 +1392,15 @@ int gjx_row_stats(const float* x, uint64_t n, int32_t* row_e, uint64_t* row_s, g
 int gjx_lse_rows(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, int32_t* out_e,
                  uint64_t* out_q, float* out_lse, uint64_t* out_record, gjx_stream s) {
   if (!row_e || !row_s || n_rows == 0) return GJX_ERR_INVALID;
-  k_lse_rows<<<1, kBlock, 0, S(s)>>>(row_e, row_s, n_rows, out_e, out_q, out_lse, out_record);
+  k_lse_rows<<<1, kBlock, 0, S(s)>>>(row_e, row_s, n_rows, 0, out_e, out_q, out_lse, out_record);
+  return launch_status();
+}
+int gjx_lse_rows_batch(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, int32_t n_batch,
+                       uint64_t batch_stride, int32_t* out_e, uint64_t* out_q, float* out_lse,
+                       uint64_t* out_record, gjx_stream s) {
+  if (!row_e || !row_s || n_rows == 0 || n_batch < 1 || batch_stride < n_rows) return GJX_ERR_INVALID;
+  k_lse_rows<<<(unsigned)n_batch, kBlock, 0, S(s)>>>(row_e, row_s, n_rows, batch_stride, out_e, out_q, out_lse,
+                                                     out_record);
   return launch_status();
 }
 int gjx_lse_combine(const uint64_t* records, int32_t n_records, uint64_t record_stride, int32_t n_batch,

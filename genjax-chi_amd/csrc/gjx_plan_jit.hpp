@@ -227,7 +227,7 @@ struct Gen {
     rows_per_block = 2;
     emit_prelude(o);
     o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_plan_kernel_" << (impl == 0 ? "threefry" : "philox")
-      << "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s) {\n";
+      << "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s, LseTail tail) {\n";
     o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
     o << "  for (uint64_t blk = blockIdx.x; blk * 512 < n; blk += gridDim.x) {\n";
     o << "    const uint64_t j0 = blk * 512 + threadIdx.x, j1 = j0 + 256;\n";
@@ -286,10 +286,10 @@ struct Gen {
       o << "      if (max_partials && threadIdx.x == 0) max_partials[blk * 2 + " << R << "] = bm;\n";
       o << "      if (row_e) {\n        const int32_t eb = row_anchor(bm);\n";
       o << "        const uint64_t sb = block_sum(" << OK << " ? rowfix(" << W << ", eb) : 0, sh_sum);\n";
-      o << "        if (threadIdx.x == 0) { row_e[blk * 2 + " << R << "] = eb; row_s[blk * 2 + " << R << "] = sb; }\n";
+      o << "        if (threadIdx.x == 0) lse_store_row(row_e, row_s, blk * 2 + " << R << ", eb, sb, tail.tickets != nullptr);\n";
       o << "      }\n    }\n";
     }
-    o << "  }\n}\n";
+    o << "  }\n  if (row_e) lse_tail(row_e, row_s, (n + 255) / 256, tail);\n}\n";
     return o.str();
   }
 
@@ -305,7 +305,7 @@ struct Gen {
     // full even at 1e6 particles (15 rows per lane), where a 4-row block would serialise its rows.
     o << "extern \"C\" __global__ __launch_bounds__(256" << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
       << ") void gjx_plan_kernel_" << (impl == 0 ? "threefry" : "philox")
-      << "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s) {\n";
+      << "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s, LseTail tail) {\n";
     o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
     o << "  for (uint64_t row = blockIdx.x; row * 256 < n; row += gridDim.x) {\n";
     o << "    float tmax = -__builtin_inff();\n    bool live = false;\n";
@@ -327,9 +327,9 @@ struct Gen {
     o << "      if (row_e) {\n";
     o << "        const int32_t eb = row_anchor(bm);\n";
     o << "        const uint64_t sb = block_sum(live ? rowfix(tmax, eb) : 0, sh_sum);\n";
-    o << "        if (threadIdx.x == 0) { row_e[row] = eb; row_s[row] = sb; }\n";
+    o << "        if (threadIdx.x == 0) lse_store_row(row_e, row_s, row, eb, sb, tail.tickets != nullptr);\n";
     o << "      }\n    }\n";
-    o << "  }\n}\n";
+    o << "  }\n  if (row_e) lse_tail(row_e, row_s, (n + 255) / 256, tail);\n}\n";
     return o.str();
   }
 };

@@ -59,6 +59,16 @@ class Keys(C.Structure):
     ]
 
 
+class LseOut(C.Structure):
+    """gjx_lse_out: where a fused importance launch leaves the pass's log-sum-exp."""
+
+    _fields_ = [("e", C.c_void_p), ("q", C.c_void_p), ("lse", C.c_void_p), ("record", C.c_void_p),
+                ("tickets", C.c_void_p)]
+
+
+LSE_TICKET_WORDS = 17 * 64  # include/gjx.h: GJX_LSE_TICKET_WORDS
+
+
 def key_words(impl: int) -> int:
     """Words per materialised key (gjx.h: GJX_KEY_WORDS): threefry 2, philox 4 (cipher key + lane)."""
     return 4 if impl == RNG_PHILOX else 2
@@ -169,7 +179,7 @@ PROTOTYPES = {
     "gjx_plan_compile_check": (C.c_int, [_P, C.c_int]),
     "gjx_importance_run": (
         C.c_int,
-        [_P, _KP, C.POINTER(_P), C.c_int, C.POINTER(_P), C.c_int, _P, _P, C.c_uint64, _P, _P, _P, _P],
+        [_P, _KP, C.POINTER(_P), C.c_int, C.POINTER(_P), C.c_int, _P, _P, C.c_uint64, _P, _P, _P, _P, _P],
     ),
     "gjx_workspace_bytes": (C.c_size_t, [C.c_int, C.c_uint64]),
     "gjx_frac_bits": (C.c_int, [C.c_uint64]),
@@ -177,6 +187,7 @@ PROTOTYPES = {
     "gjx_num_max_partials": (C.c_uint64, [C.c_uint64]),
     "gjx_row_stats": (C.c_int, [_P, C.c_uint64, _P, _P, _P]),
     "gjx_lse_rows": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, _P]),
+    "gjx_lse_rows_batch": (C.c_int, [_P, _P, C.c_uint64, C.c_int32, C.c_uint64, _P, _P, _P, _P, _P]),
     "gjx_lse_combine": (C.c_int, [_P, C.c_int32, C.c_uint64, C.c_int32, C.c_uint64, _P, _P, _P, _P, _P]),
     "gjx_max_f32": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.c_size_t, _P]),
     "gjx_expsum_fix": (C.c_int, [_P, C.c_uint64, _P, C.c_int, _P, _P, C.c_size_t, _P]),

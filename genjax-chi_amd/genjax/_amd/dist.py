@@ -54,8 +54,8 @@ def shard_rows(n_total: int, rank: int, world: int) -> tuple[int, int]:
 class BatchedImportance:
     """Sharded ImportanceK passes with *bucketed, overlapped* collectives.
 
-    A pass = importance kernel + `gjx_lse_rows`, which leaves the shard's 65-word record in slot b of a
-    [batch, 65] block.  After `batch` passes the block is all-gathered ONCE, asynchronously (RCCL runs on
+    A pass = the importance kernel, which leaves its row sums in slot b; one `gjx_lse_rows_batch` launch
+    per batch folds them into the shard's 65-word records, a [batch, 65] block.  After `batch` passes the block is all-gathered ONCE, asynchronously (RCCL runs on
     its own stream), while the next batch already computes into the other block of a double buffer; the
     wait is deferred until that block is reused or its results are read.  A small-message RCCL collective
     costs tens of microseconds — more than the 28 us kernel — so this is the xGMI analogue of gradient
@@ -64,20 +64,20 @@ class BatchedImportance:
 
     def __init__(self, ops: Ops, wl, batch: int = 8, world: int | None = None, depth: int = 2,
                  always_exchange: bool = False):
-        import ctypes as C
-
         dist = _dist()
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         if self.world > 1 and (wl.first % ROW or (wl.n % ROW and wl.first + wl.n != wl.n_total)):
             raise ValueError("shards must be split at 256-particle row boundaries (dist.shard_rows)")
         self.ops, self.wl, self.batch, self.depth = ops, wl, batch, depth
-        self.prep = wl.prepare()
+        self.prep = wl.prepare(fold_batch=batch)
         dev, words = ops.device(), abi.LSE_RECORD_WORDS
         self.local = [torch.zeros((batch, words), dtype=torch.int64, device=dev) for _ in range(depth)]
         self.exchange = self.world > 1 or always_exchange  # a one-rank group still goes through the collective
         self.gathered = [torch.zeros((self.world, batch, words), dtype=torch.int64, device=dev) if self.exchange
                          else t.view(1, batch, words) for t in self.local]
-        self._rec = [[C.c_void_p(t[b].data_ptr()) for b in range(batch)] for t in self.local]
+        import ctypes as C
+
+        self._rec = [C.c_void_p(t.data_ptr()) for t in self.local]
         self._work = [None] * depth
         self._count = [0] * depth
         self._slot = 0
@@ -92,10 +92,10 @@ class BatchedImportance:
         for b in range(count):
             if on_kernel:
                 on_kernel(b, 0)
-            self.prep.launch_importance(st)
+            self.prep.launch_importance(st, b)  # row sums into slot b
             if on_kernel:
                 on_kernel(b, 1)
-            self.prep.launch_lse_rows(st, self._rec[d][b])
+        self.prep.launch_fold(count, st, self._rec[d])  # one launch folds the batch into its records
         if self.exchange:
             self._work[d] = _dist().all_gather_into_tensor(self.gathered[d].view(-1, self.gathered[d].shape[-1]),
                                                             self.local[d], async_op=True)

@@ -195,8 +195,20 @@ class Ops:
         self.lib.call("gjx_plan_create", arr, len(sites), C.byref(handle))
         return Plan(self, handle, len(sites))
 
+    def tickets(self) -> torch.Tensor:
+        """The zeroed ticket words of fused log-sum-exp launches on the current stream (gjx_lse_out.tickets:
+        every launch leaves them zero, launches sharing them must be stream-ordered)."""
+        key = ("tickets", str(self.device()), self.stream().value)
+        t = self._ws.get(key)
+        if t is None:
+            t = torch.zeros(abi.LSE_TICKET_WORDS, dtype=torch.int32, device=self.device())
+            self._ws[key] = t
+        return t
+
     def importance_run(self, plan: "Plan", kb: KeyBatch, n: int, input_cols: list[torch.Tensor],
                        value_dtypes: list, want_score=True, want_max_partials=True, want_rows=False):
+        """One fused `@gen` walk.  With want_rows the launch also folds its row-anchored partial sums:
+        rows.lse / rows.e_out / rows.q_out hold the pass's log-sum-exp (no further kernel)."""
         if kb.fold is not None:
             raise ValueError("particle keys must not carry a fold")
         ins = (C.c_void_p * max(1, len(input_cols)))()
@@ -209,12 +221,19 @@ class Ops:
         score = self.empty(n, torch.float32) if want_score else None
         logw = self.empty(n, torch.float32)
         mp = self.empty(self.num_max_partials(n), torch.float32) if want_max_partials else None
-        rows = RowStats(self.empty(self.num_max_partials(n), torch.int32),
-                        self.empty(self.num_max_partials(n), torch.int64), n) if want_rows else None
+        rows, lse = None, None
+        if want_rows:
+            rows = RowStats(self.empty(self.num_max_partials(n), torch.int32),
+                            self.empty(self.num_max_partials(n), torch.int64), n,
+                            lse=self.empty(1, torch.float32), e_out=self.empty(1, torch.int32),
+                            q_out=self.empty(1, torch.int64))
+            lse = abi.LseOut(rows.e_out.data_ptr(), rows.q_out.data_ptr(), rows.lse.data_ptr(), None,
+                             self.tickets().data_ptr())
         self.lib.call("gjx_importance_run", plan.handle, C.byref(self._keys(kb, n)), ins, len(input_cols), outs,
                       len(vals), C.c_void_p(score.data_ptr()) if want_score else None,
                       C.c_void_p(logw.data_ptr()), n, C.c_void_p(mp.data_ptr()) if mp is not None else None,
-                      self._p(rows.e) if rows else None, self._p(rows.s) if rows else None, self.stream())
+                      self._p(rows.e) if rows else None, self._p(rows.s) if rows else None,
+                      C.byref(lse) if lse is not None else None, self.stream())
         if want_rows:
             return vals, score, logw, mp, rows
         return vals, score, logw, mp
@@ -230,6 +249,8 @@ class Ops:
     def lse_rows(self, rows: "RowStats", record: torch.Tensor | None = None):
         """-> (lse f32[1], e i32[1], q i64[1]) on device; `record` (int64[65]) also receives the
         exchangeable (anchor, buckets) summary of these rows (gjx.h: GJX_LSE_RECORD_WORDS)."""
+        if record is None and rows.lse is not None:
+            return rows.lse, rows.e_out, rows.q_out  # already folded by the launch that produced the rows
         lse, e, q = self.empty(1, torch.float32), self.empty(1, torch.int32), self.empty(1, torch.int64)
         self.lib.call("gjx_lse_rows", self._p(rows.e), self._p(rows.s), rows.e.numel(), self._p(e), self._p(q),
                       self._p(lse), None if record is None else self._chk(record, torch.int64, abi.LSE_RECORD_WORDS, "record"),
@@ -255,11 +276,11 @@ class Ops:
         return int(e.cpu()) * math.log(2.0) + math.log(int(q.cpu())) - 30 * math.log(2.0) - math.log(n_total)
 
     def prepare_importance(self, plan: "Plan", kb: KeyBatch, n: int, input_cols: list[torch.Tensor],
-                           value_dtypes: list, with_lse: bool = True) -> "PreparedImportance":
+                           value_dtypes: list, with_lse: bool = True, fold_batch: int = 1) -> "PreparedImportance":
         """Pre-bind one importance pass (+ its log-sum-exp) to persistent output buffers: a launch
         is then two C calls with no allocation or marshalling on the host (what a latency-bound
         1e6-particle step needs; it is also what a HIP-graph capture of the step would replay)."""
-        return PreparedImportance(self, plan, kb, n, input_cols, value_dtypes, with_lse)
+        return PreparedImportance(self, plan, kb, n, input_cols, value_dtypes, with_lse, fold_batch)
 
     # ---- weights --------------------------------------------------------------------------------
     def max_f32(self, x: torch.Tensor | None, n: int, max_partials=None, out=None) -> torch.Tensor:
@@ -466,6 +487,9 @@ class RowStats:
     e: torch.Tensor  # int32[rows]
     s: torch.Tensor  # int64[rows]
     n: int
+    lse: torch.Tensor | None = None    # f32[1]: log-sum-exp of the rows when the producing launch folded them
+    e_out: torch.Tensor | None = None  # int32[1] anchor of that fold
+    q_out: torch.Tensor | None = None  # int64[1] fixed-point sum of that fold
 
 
 class Plan:
@@ -482,43 +506,88 @@ class Plan:
 
 
 class PreparedImportance:
-    """A fully marshalled `gjx_importance_run` (+ `gjx_logsumexp_f32`) call on persistent buffers."""
+    """A fully marshalled `gjx_importance_run` (+ its log-sum-exp) on persistent buffers.
 
-    def __init__(self, ops: Ops, plan: Plan, kb: KeyBatch, n: int, input_cols, value_dtypes, with_lse):
+    `fold_batch` B > 1 keeps B slots of row sums: passes write their (anchor, sum) pairs into consecutive
+    slots and ONE `gjx_lse_rows_batch` launch folds them all (`launch_fold`) — the ~5 us latency of a
+    one-workgroup kernel is paid once per B passes.  The trace columns / log-weights are shared by the
+    slots (a pass overwrites the previous one's), only the few-KB row sums and the results are per slot."""
+
+    def __init__(self, ops: Ops, plan: Plan, kb: KeyBatch, n: int, input_cols, value_dtypes, with_lse=True,
+                 fold_batch: int = 1):
         if kb.fold is not None:
             raise ValueError("particle keys must not carry a fold")
-        self.ops, self.plan, self.n = ops, plan, n
+        self.ops, self.plan, self.n, self.fold_batch = ops, plan, n, fold_batch
         self.inputs = [t for t in input_cols]
         self.values = [ops.empty(n, dt) for dt in value_dtypes]
         self.score, self.logw = ops.empty(n, torch.float32), ops.empty(n, torch.float32)
         self.max_partials = ops.empty(ops.num_max_partials(n), torch.float32)
-        self.rows = RowStats(ops.empty(ops.num_max_partials(n), torch.int32), ops.empty(ops.num_max_partials(n), torch.int64), n)
-        self.row_e_out, self.row_q_out = ops.empty(1, torch.int32), ops.empty(1, torch.int64)
-        self.lse, self.max, self.q = ops.empty(1, torch.float32), ops.empty(1, torch.float32), ops.empty(1, torch.int64)
+        R = self.n_rows = ops.num_max_partials(n)
+        self.row_e_all, self.row_s_all = ops.empty((fold_batch, R), torch.int32), ops.empty((fold_batch, R), torch.int64)
+        self.rows = RowStats(self.row_e_all[0], self.row_s_all[0], n)  # slot 0
+        self.lse_all, self.e_all, self.q_all = (ops.empty(fold_batch, torch.float32), ops.empty(fold_batch, torch.int32),
+                                                ops.empty(fold_batch, torch.int64))
+        self.lse, self.row_e_out, self.row_q_out = self.lse_all[:1], self.e_all[:1], self.q_all[:1]
+        self.max, self.q = ops.empty(1, torch.float32), ops.empty(1, torch.int64)
         self._keys = ops._keys(kb, n)
         self._ins = (C.c_void_p * max(1, len(self.inputs)))(*[ops._chk(t, torch.float32, n).value for t in self.inputs])
         self._outs = (C.c_void_p * max(1, len(self.values)))(*[t.data_ptr() for t in self.values])
         self._ws, self._nb = ops.workspace(abi.OP_LOGSUMEXP, n)
         self._ws = self._ws.clone()  # private: the shared workspace may be re-grown by other calls
         lib = ops.lib
-        self._run = lib._gjx_importance_run
-        self._lse = lib._gjx_logsumexp_f32
-        self._args_run = (plan.handle, C.byref(self._keys), self._ins, len(self.inputs), self._outs, len(self.values),
-                          C.c_void_p(self.score.data_ptr()), C.c_void_p(self.logw.data_ptr()), n,
-                          C.c_void_p(self.max_partials.data_ptr()), C.c_void_p(self.rows.e.data_ptr()),
-                          C.c_void_p(self.rows.s.data_ptr()))
-        self._lse_rows = lib._gjx_lse_rows
-        self._args_lse_rows = (C.c_void_p(self.rows.e.data_ptr()), C.c_void_p(self.rows.s.data_ptr()),
-                               self.rows.e.numel(), C.c_void_p(self.row_e_out.data_ptr()),
-                               C.c_void_p(self.row_q_out.data_ptr()), C.c_void_p(self.lse.data_ptr()))
+        self._run, self._lse, self._lse_rows, self._fold = (lib._gjx_importance_run, lib._gjx_logsumexp_f32,
+                                                            lib._gjx_lse_rows, lib._gjx_lse_rows_batch)
+        head = (plan.handle, C.byref(self._keys), self._ins, len(self.inputs), self._outs, len(self.values),
+                C.c_void_p(self.score.data_ptr()), C.c_void_p(self.logw.data_ptr()), n,
+                C.c_void_p(self.max_partials.data_ptr()))
+        self._args_run = [head + (C.c_void_p(self.row_e_all[b].data_ptr()), C.c_void_p(self.row_s_all[b].data_ptr()))
+                          for b in range(fold_batch)]
+        # fused form: the importance launch folds its own row sums (results in .lse / .row_e_out / .row_q_out)
+        self._tickets = torch.zeros(abi.LSE_TICKET_WORDS, dtype=torch.int32, device=ops.device())
+        self._lse_out = abi.LseOut(self.row_e_out.data_ptr(), self.row_q_out.data_ptr(), self.lse.data_ptr(), None,
+                                   self._tickets.data_ptr())
+        self._lse_ref = C.byref(self._lse_out)
+        self._lse_with_record: dict = {}
+        self._args_lse_rows = (C.c_void_p(self.rows.e.data_ptr()), C.c_void_p(self.rows.s.data_ptr()), R,
+                               C.c_void_p(self.row_e_out.data_ptr()), C.c_void_p(self.row_q_out.data_ptr()),
+                               C.c_void_p(self.lse.data_ptr()))
+        self._args_fold = (C.c_void_p(self.row_e_all.data_ptr()), C.c_void_p(self.row_s_all.data_ptr()), R)
+        self._fold_outs = (C.c_void_p(self.e_all.data_ptr()), C.c_void_p(self.q_all.data_ptr()),
+                           C.c_void_p(self.lse_all.data_ptr()))
         self._no_record = C.c_void_p(None)
         self._args_lse = (C.c_void_p(self.logw.data_ptr()), n, C.c_void_p(self.max_partials.data_ptr()),
                           C.c_void_p(self.lse.data_ptr()), C.c_void_p(self.max.data_ptr()), C.c_void_p(self.q.data_ptr()),
                           C.c_void_p(self._ws.data_ptr()), self._nb)
         self.with_lse = with_lse
 
-    def launch_importance(self, stream=None):
-        rc = self._run(*self._args_run, stream if stream is not None else self.ops.stream())
+    def launch_importance(self, stream=None, slot: int = 0):
+        """The walk only; its row sums go to slot `slot` (folded later by launch_lse_rows / launch_fold)."""
+        rc = self._run(*self._args_run[slot], None, stream if stream is not None else self.ops.stream())
+        if rc:
+            raise abi.GjxError("gjx_importance_run", rc)
+
+    def launch_fold(self, count: int, stream=None, records_ptr=None):
+        """Fold the row sums of slots [0, count) in ONE launch: lse_all / e_all / q_all[:count]; `records_ptr`
+        (C.c_void_p of a dev int64[count, 65]) also receives each pass's exchangeable record."""
+        rc = self._fold(*self._args_fold, count, self.n_rows, *self._fold_outs,
+                        self._no_record if records_ptr is None else records_ptr,
+                        stream if stream is not None else self.ops.stream())
+        if rc:
+            raise abi.GjxError("gjx_lse_rows_batch", rc)
+
+    def launch_fused(self, stream=None, record: torch.Tensor | None = None):
+        """Walk + log-sum-exp in ONE launch: .lse, .row_e_out, .row_q_out (and `record`, a dev int64[65]
+        slot, when given) are written by the workgroup that finishes last."""
+        if record is None:
+            ref = self._lse_ref
+        else:
+            ent = self._lse_with_record.get(record.data_ptr())
+            if ent is None:
+                out = abi.LseOut(self.row_e_out.data_ptr(), self.row_q_out.data_ptr(), self.lse.data_ptr(),
+                                 record.data_ptr(), self._tickets.data_ptr())
+                ent = self._lse_with_record[record.data_ptr()] = (out, C.byref(out), record)
+            ref = ent[1]
+        rc = self._run(*self._args_run[0], ref, stream if stream is not None else self.ops.stream())
         if rc:
             raise abi.GjxError("gjx_importance_run", rc)
 
@@ -528,7 +597,7 @@ class PreparedImportance:
             raise abi.GjxError("gjx_logsumexp_f32", rc)
 
     def launch_lse_rows(self, stream=None, record_ptr=None):
-        """Row-anchored log-sum-exp from the partial sums the importance kernel emitted: one tiny
+        """Row-anchored log-sum-exp of slot 0 from the partial sums the importance kernel emitted: one tiny
         kernel, no pass over logw.  Results in .lse, .row_e_out, .row_q_out; `record_ptr`
         (C.c_void_p of a dev int64[65]) also receives the shard's exchangeable record."""
         rc = self._lse_rows(*self._args_lse_rows, self._no_record if record_ptr is None else record_ptr,
@@ -538,9 +607,10 @@ class PreparedImportance:
 
     def launch(self, stream=None):
         st = stream if stream is not None else self.ops.stream()
-        self.launch_importance(st)
         if self.with_lse:
-            self.launch_lse_rows(st)
+            self.launch_fused(st)
+        else:
+            self.launch_importance(st)
 
 
 class _Hip:

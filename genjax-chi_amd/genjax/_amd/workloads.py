@@ -82,10 +82,13 @@ class Gaussian10:
         self.keys = importance_particle_keys(prng.key(seed, impl), n_local, first)
         self.frac = ops.frac_bits(self.n_total)
 
-    def prepare(self):
-        """Persistent-buffer form of `step` (no host allocation per pass)."""
-        if getattr(self, "_prep", None) is None:
-            self._prep = self.ops.prepare_importance(self.plan, self.keys, self.n, [], [torch.float32] * G10_LATENTS)
+    def prepare(self, fold_batch: int = 1):
+        """Persistent-buffer form of `step` (no host allocation per pass); `fold_batch` passes share one
+        log-sum-exp launch (ops.PreparedImportance)."""
+        prep = getattr(self, "_prep", None)
+        if prep is None or prep.fold_batch != fold_batch:
+            self._prep = self.ops.prepare_importance(self.plan, self.keys, self.n, [], [torch.float32] * G10_LATENTS,
+                                                     fold_batch=fold_batch)
         return self._prep
 
     def step(self):

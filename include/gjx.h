@@ -199,11 +199,25 @@ int gjx_plan_compile_check(const gjx_plan* p, int impl);
  * f32[n] (score nullable).  max_partials: nullable dev f32[gjx_num_max_partials(n)]; when given, the
  * kernel also stores the maxima of logw per 256-particle row so the following log-sum-exp skips
  * its max pass.  row_e / row_s: nullable (both or neither) row-anchored partial sums, see
- * gjx_lse_rows: with them the log-marginal needs one further tiny kernel and no pass over logw. */
+ * gjx_lse_rows: with them the log-marginal needs one further tiny kernel and no pass over logw.
+ * lse: nullable; needs row_e/row_s.  The pass's log-sum-exp (the outputs of gjx_lse_rows over these
+ * rows, each nullable) is produced by the SAME launch: the workgroup that finishes last folds the row
+ * pairs (replaces logsumexp(lw) at inference/smc.py:97 with zero extra launches).  tickets: dev
+ * u32[GJX_LSE_TICKET_WORDS] owned by the caller, zero before the first use; every launch leaves it zero,
+ * so launches sharing it must be stream-ordered. */
+#define GJX_LSE_TICKET_WORDS (17 * 64) /* 17 counters, each on its own 256-byte line */
+typedef struct {
+  int32_t* e;       /* dev int32[1] */
+  uint64_t* q;      /* dev u64[1] */
+  float* lse;       /* dev f32[1] */
+  uint64_t* record; /* dev u64[GJX_LSE_RECORD_WORDS] */
+  uint32_t* tickets;
+} gjx_lse_out;
 int gjx_importance_run(const gjx_plan* p, const gjx_keys* particle_keys,
                        const float* const* input_cols, int n_input_cols, void* const* value_cols,
                        int n_value_cols, float* score, float* logw, uint64_t n,
-                       float* max_partials, int32_t* row_e, uint64_t* row_s, gjx_stream s);
+                       float* max_partials, int32_t* row_e, uint64_t* row_s, const gjx_lse_out* lse,
+                       gjx_stream s);
 
 /* ---- weights: log-sum-exp, single draw, resampling ---------------------------------------- */
 
@@ -242,6 +256,13 @@ int gjx_row_stats(const float* x, uint64_t n, int32_t* row_e, uint64_t* row_s, g
 int gjx_lse_rows(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, int32_t* out_e /*nullable*/,
                  uint64_t* out_q /*nullable*/, float* out_lse /*nullable*/, uint64_t* out_record /*nullable*/,
                  gjx_stream s);
+/* The same fold for n_batch independent passes in ONE launch (one workgroup each): pass p's rows
+ * start at row_e / row_s + p*batch_stride (batch_stride >= n_rows); outputs are arrays of n_batch
+ * entries (out_record dev u64[n_batch, 65]).  A one-workgroup launch costs ~5 us of latency, more than a
+ * quarter of the importance kernel at 1e6 particles: folding B passes together divides that by B. */
+int gjx_lse_rows_batch(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, int32_t n_batch,
+                       uint64_t batch_stride, int32_t* out_e, uint64_t* out_q, float* out_lse,
+                       uint64_t* out_record, gjx_stream s);
 /* Merge records: for each of n_batch independent passes p (records of pass p start at
  * records + p*batch_stride words) combine n_records records lying record_stride words apart
  * (>= GJX_LSE_RECORD_WORDS; the layout of an all-gather of [n_batch, 65] blocks is record_stride =

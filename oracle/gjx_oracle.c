@@ -428,9 +428,10 @@ static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, sit
 int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const* input_cols,
                        int n_input_cols, void* const* value_cols, int n_value_cols, float* score,
                        float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s,
-                       gjx_stream s) {
+                       const gjx_lse_out* lse, gjx_stream s) {
   (void)s;
-  if (!p || !keys_ok(pk) || pk->has_fold || !logw) return GJX_ERR_INVALID;
+  if (!p || !keys_ok(pk) || pk->has_fold || !logw || (lse && (!row_e || !row_s || !lse->tickets)))
+    return GJX_ERR_INVALID;
   for (int q = 0; q < p->n_sites; ++q) {
     const gjx_site* st = &p->sites[q];
     if (st->out_col >= n_value_cols) return GJX_ERR_INVALID;
@@ -467,7 +468,11 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
       max_partials[b] = m;
     }
   }
-  if (row_e && row_s) return gjx_row_stats(logw, n, row_e, row_s, s);
+  if (row_e && row_s) {
+    int rc = gjx_row_stats(logw, n, row_e, row_s, s);
+    if (rc || !lse) return rc;
+    return gjx_lse_rows(row_e, row_s, gjx_num_max_partials(n), lse->e, lse->q, lse->lse, lse->record, s);
+  }
   return GJX_OK;
 }
 
@@ -522,6 +527,18 @@ int gjx_lse_rows(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, i
     if (d < GJX_LSE_RECORD_WORDS - 1) B[d] += row_s[b];
   }
   lse_emit(e, B, out_e, out_q, out_lse, out_record);
+  return GJX_OK;
+}
+int gjx_lse_rows_batch(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, int32_t n_batch,
+                       uint64_t batch_stride, int32_t* out_e, uint64_t* out_q, float* out_lse,
+                       uint64_t* out_record, gjx_stream s) {
+  if (!row_e || !row_s || n_rows == 0 || n_batch < 1 || batch_stride < n_rows) return GJX_ERR_INVALID;
+  for (int32_t b = 0; b < n_batch; ++b) {
+    int rc = gjx_lse_rows(row_e + (uint64_t)b * batch_stride, row_s + (uint64_t)b * batch_stride, n_rows,
+                          out_e ? out_e + b : NULL, out_q ? out_q + b : NULL, out_lse ? out_lse + b : NULL,
+                          out_record ? out_record + (uint64_t)b * GJX_LSE_RECORD_WORDS : NULL, s);
+    if (rc) return rc;
+  }
   return GJX_OK;
 }
 int gjx_lse_combine(const uint64_t* records, int32_t n_records, uint64_t record_stride, int32_t n_batch,

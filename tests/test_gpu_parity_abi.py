@@ -216,6 +216,32 @@ def test_logsumexp(hip_ops, oracle_ops, n):
     assert abs(float(hip_ops.lse_rows(hr)[0].cpu()) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 5000, 1_000_000, 1_100_003])
+def test_fused_lse_tail(hip_ops, oracle_ops, impl, n):
+    """The importance launch folds its own row sums (last-workgroup tail): the fused (e, q, lse, record)
+    equal a separate gjx_lse_rows over the rows it wrote, equal the oracle, on every one of many
+    back-to-back launches sharing one ticket buffer (1_100_003 particles: > 4096 rows, the looped fold)."""
+    from genjax._amd import abi
+
+    wl_h = W.Gaussian10(hip_ops, impl, seed=4, n_local=n)
+    prep = wl_h.prepare()
+    reps = 40 if n <= 5000 else 12
+    recs = torch.zeros((reps, abi.LSE_RECORD_WORDS), dtype=torch.int64, device=hip_ops.device())
+    for r in range(reps):
+        prep.launch_fused(record=recs[r])
+    fused = (prep.lse.clone(), prep.row_e_out.clone(), prep.row_q_out.clone())
+    ref_rec = torch.zeros(abi.LSE_RECORD_WORDS, dtype=torch.int64, device=hip_ops.device())
+    prep.rows.lse = None
+    sep = hip_ops.lse_rows(prep.rows, record=ref_rec)
+    for a, b in zip(fused, sep):
+        same(a, b, "fused vs separate fold")
+    assert all(torch.equal(recs[r], ref_rec) for r in range(reps)), "a launch read stale row sums"
+    assert int(prep._tickets.abs().sum().cpu()) == 0  # left zero for the next launch
+    out = W.Gaussian10(oracle_ops, impl, seed=4, n_local=n).step()
+    same(fused[0], out["row_lse"], "lse vs oracle"); same(fused[1], out["row_e"]); same(fused[2], out["row_q"])
+
+
 def test_lse_records(hip_ops, oracle_ops):
     """gjx_lse_rows records / gjx_lse_combine: shards merge exactly, and HIP == oracle bit for bit."""
     from test_oracle_pinning import check_lse_records
