@@ -825,6 +825,18 @@ struct LgssmPolicy {
   }
 };
 
+// Rows of the prepared transition table are kHmmGuideWords apart beyond K: C_0..C_{K-1} (fixed-point
+// inclusive CDF) followed by a 256-byte GUIDE, guide[b] = first c with C_c > ((b << 24) * Q) >> 32.  A draw
+// with top byte b starts its scan there: the index is the one a search of the whole row returns, found
+// after ~1 dependent load instead of 8 (the row loads are L2 latency, the dominant cost of the HMM step).
+constexpr int kHmmGuideWords = 64;
+GJX_DEV uint32_t hmm_row_draw(const uint32_t* row, int32_t K, uint32_t bits) {
+  const uint64_t thr = ((uint64_t)bits * (uint64_t)row[K - 1]) >> 32;
+  uint32_t c = reinterpret_cast<const uint8_t*>(row + K)[bits >> 24];
+  while ((uint64_t)row[c] <= thr) ++c;  // row[K-1] = Q > thr: terminates
+  return c;
+}
+
 template <int IMPL>
 struct HmmPolicy {
   const int32_t* prev_state;
@@ -862,14 +874,7 @@ struct HmmPolicy {
   };
   GJX_DEV float compute(int64_t j, int src_local, Out& o) const {
     const uint32_t bits = smc_slot_bits<IMPL>(step_key, (uint64_t)j);
-    const uint32_t* cdf = trans_cdf + (size_t)zs[src_local] * K;
-    const uint64_t thr = ((uint64_t)bits * (uint64_t)cdf[K - 1]) >> 32;
-    uint32_t lo = 0, hi = (uint32_t)K - 1;
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if ((uint64_t)cdf[mid] > thr) hi = mid;
-      else lo = mid + 1;
-    }
+    const uint32_t lo = hmm_row_draw(trans_cdf + (size_t)zs[src_local] * (K + kHmmGuideWords), K, bits);
     o.z = (int32_t)lo;
     o.lw = ocol[lo];
     return o.lw;
@@ -924,19 +929,13 @@ __global__ __launch_bounds__(kBlock) void k_hmm_init(Key step_key, uint64_t firs
   const uint64_t gbase = (uint64_t)blockIdx.x * kTile;
   float tmax = -__builtin_inff();
   if (gbase >= first_slot && gbase < first_slot + n_local) {
-    const uint32_t* cdf = trans_cdf + (size_t)init_state * K;
+    const uint32_t* cdf = trans_cdf + (size_t)init_state * (K + kHmmGuideWords);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const uint64_t j = gbase + (uint64_t)r * kBlock + threadIdx.x;
       if (j < first_slot + n_local) {
         const uint32_t bits = smc_slot_bits<IMPL>(step_key, j);
-        const uint64_t thr = ((uint64_t)bits * (uint64_t)cdf[K - 1]) >> 32;
-        uint32_t lo = 0, hi = (uint32_t)K - 1;
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if ((uint64_t)cdf[mid] > thr) hi = mid;
-          else lo = mid + 1;
-        }
+        const uint32_t lo = hmm_row_draw(cdf, K, bits);
         const float lw = obs_logp[(size_t)lo * K + y];
         state_out[j - first_slot] = (int32_t)lo;
         logw_out[j - first_slot] = lw;
@@ -959,11 +958,24 @@ __global__ void k_hmm_prepare(const float* trans_logits, const float* obs_logits
   uint32_t C = 0;
   for (int c = 0; c < K; ++c) {
     C += cat_fix(l[c], m);
-    trans_cdf[(size_t)r * K + c] = C;
+    trans_cdf[(size_t)r * (K + kHmmGuideWords) + c] = C;
   }
   const float* o = obs_logits + (size_t)r * K;
   const float lse = row_lse(o, (uint32_t)K);
   for (int c = 0; c < K; ++c) obs_logp[(size_t)r * K + c] = o[c] - lse;
+}
+
+// guide bytes of every row (one workgroup per row, thread b = top byte of the draw)
+__global__ __launch_bounds__(256) void k_hmm_guide(int32_t K, uint32_t* trans_cdf) {
+  uint32_t* row = trans_cdf + (size_t)blockIdx.x * (K + kHmmGuideWords);
+  const uint64_t thr = ((uint64_t)(threadIdx.x << 24) * (uint64_t)row[K - 1]) >> 32;
+  uint32_t lo = 0, hi = (uint32_t)K - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((uint64_t)row[mid] > thr) hi = mid;
+    else lo = mid + 1;
+  }
+  reinterpret_cast<uint8_t*>(row + K)[threadIdx.x] = (uint8_t)lo;
 }
 
 // workspace carving
@@ -1012,7 +1024,8 @@ size_t gjx_workspace_bytes(int op, uint64_t n) {
     case GJX_OP_RESAMPLE:
       return pad256(nt * 4) + 2 * pad256(nt * 8) + pad256(n * 8) + 1024;
     case GJX_OP_SMC:
-      return 2 * pad256(n * 4) + pad256(nt * 4) + 2 * pad256((nt + 1) * 8) + 2 * pad256(256 * 256 * 4) + 1024;
+      return 2 * pad256(n * 4) + pad256(nt * 4) + 2 * pad256((nt + 1) * 8) + pad256(256 * (256 + 64) * 4) +
+             pad256(256 * 256 * 4) + 1024;
     default: return 0;
   }
 }
@@ -1571,12 +1584,16 @@ static bool cfg_ok(const gjx_smc_config* c) {
          c->resample_keys && (c->first_slot % kTile) == 0 && c->n_total <= 0x7fffffffull;
 }
 
+uint64_t gjx_hmm_cdf_words(int32_t n_states) {
+  return n_states > 0 ? (uint64_t)n_states * (uint64_t)(n_states + kHmmGuideWords) : 0;
+}
 int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gjx_stream s) {
   if (!mdl || !trans_cdf || !obs_logp || mdl->n_states <= 0 || mdl->n_states > 256 ||
       !mdl->trans_logits || !mdl->obs_logits)
     return GJX_ERR_INVALID;
   k_hmm_prepare<<<(mdl->n_states + 63) / 64, 64, 0, S(s)>>>(mdl->trans_logits, mdl->obs_logits,
                                                              mdl->n_states, trans_cdf, obs_logp);
+  k_hmm_guide<<<mdl->n_states, 256, 0, S(s)>>>(mdl->n_states, trans_cdf);
   return launch_status();
 }
 
@@ -1846,12 +1863,13 @@ int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32
   if (!y_host || !model || model->n_states <= 0 || model->n_states > 256) return GJX_ERR_INVALID;
   // tables live at the tail of the workspace
   const size_t kk = (size_t)model->n_states * (size_t)model->n_states;
-  const size_t tail = 2 * pad256(kk * 4);
+  const size_t cdf_bytes = pad256((size_t)gjx_hmm_cdf_words(model->n_states) * 4);
+  const size_t tail = cdf_bytes + pad256(kk * 4);
   if (!ws || ws_bytes < tail) return GJX_ERR_WORKSPACE;
   char* tail_p = (char*)ws + (ws_bytes - tail);
   tail_p = (char*)(((uintptr_t)tail_p) & ~(uintptr_t)255);
   uint32_t* tcdf = (uint32_t*)tail_p;
-  float* ologp = (float*)(tail_p + pad256(kk * 4));
+  float* ologp = (float*)(tail_p + cdf_bytes);
   if ((char*)ologp + kk * 4 > (char*)ws + ws_bytes) return GJX_ERR_WORKSPACE;
   int rc = gjx_hmm_prepare(model, tcdf, ologp, s);
   if (rc) return rc;

@@ -404,6 +404,18 @@ class Ops:
                       C.c_void_p(ws.data_ptr()), nb, self.stream())
         return out_max, out_q, state, logw, anc
 
+    def hmm_prepare(self, n_states: int, init_state: int, trans_logits: torch.Tensor, obs_logits: torch.Tensor):
+        """-> (trans_cdf int32[K, K+64] incl. the guide bytes, obs_logp f32[K, K]) — the tables of gjx.h."""
+        mdl = abi.Hmm()
+        mdl.n_states, mdl.init_state = n_states, init_state
+        mdl.trans_logits = self._chk(trans_logits, torch.float32, n_states * n_states).value
+        mdl.obs_logits = self._chk(obs_logits, torch.float32, n_states * n_states).value
+        words = int(self.lib.call("gjx_hmm_cdf_words", n_states))
+        cdf = torch.zeros(words, dtype=torch.int32, device=self.device())
+        logp = self.empty((n_states, n_states), torch.float32)
+        self.lib.call("gjx_hmm_prepare", C.byref(mdl), self._p(cdf), self._p(logp), self.stream())
+        return cdf.view(n_states, -1), logp
+
     # ---- bootstrap SMC for a user model (init + step site tables) --------------------------------
     def smc_plan_create(self, init_sites, step_sites, init_state, next_state, n_obs: int) -> "SmcPlan":
         m = abi.SmcModel()

@@ -849,6 +849,10 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
   return GJX_OK;
 }
 
+#define O_HMM_GUIDE_WORDS 64
+uint64_t gjx_hmm_cdf_words(int32_t n_states) {
+  return n_states > 0 ? (uint64_t)n_states * (uint64_t)(n_states + O_HMM_GUIDE_WORDS) : 0;
+}
 int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gjx_stream s) {
   (void)s;
   if (!mdl || !trans_cdf || !obs_logp || mdl->n_states <= 0 || mdl->n_states > 256 ||
@@ -859,7 +863,14 @@ int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gj
     const float* l = mdl->trans_logits + (size_t)r * K;
     float m = row_max(l, K);
     uint32_t C = 0;
-    for (uint32_t c = 0; c < K; ++c) { C += cat_fix(l[c], m); trans_cdf[(size_t)r * K + c] = C; }
+    uint32_t* row = trans_cdf + (size_t)r * (K + O_HMM_GUIDE_WORDS);
+    for (uint32_t c = 0; c < K; ++c) { C += cat_fix(l[c], m); row[c] = C; }
+    for (uint32_t b = 0; b < 256; ++b) { /* guide: where the scan of a draw with top byte b may start */
+      uint64_t thr = ((uint64_t)(b << 24) * (uint64_t)row[K - 1]) >> 32;
+      uint32_t c = 0;
+      while ((uint64_t)row[c] <= thr) ++c;
+      ((uint8_t*)(row + K))[b] = (uint8_t)c;
+    }
     const float* o = mdl->obs_logits + (size_t)r * K;
     float lse = row_lse(o, K);
     for (uint32_t c = 0; c < K; ++c) obs_logp[(size_t)r * K + c] = o[c] - lse;
@@ -896,7 +907,7 @@ int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int
   for (int64_t j = 0; j < (int64_t)nl; ++j) {
     uint32_t bits = o_smc_slot_bits(cfg->impl, skey, cfg->first_slot + (uint64_t)j);
     int32_t zp = t == 0 ? mdl->init_state : prev_state[anc[j]];
-    const uint32_t* cdf = trans_cdf + (size_t)zp * K;
+    const uint32_t* cdf = trans_cdf + (size_t)zp * (K + O_HMM_GUIDE_WORDS);
     uint64_t thr = ((uint64_t)bits * (uint64_t)cdf[K - 1]) >> 32;
     uint32_t lo = 0, hi = K - 1; /* first c with cdf[c] > thr */
     while (lo < hi) {
@@ -932,7 +943,7 @@ static int smc_run_common(const gjx_smc_config* cfg, int is_hmm, const void* mod
   if (is_hmm) {
     const gjx_hmm* h = (const gjx_hmm*)model;
     size_t kk = (size_t)h->n_states * (size_t)h->n_states;
-    tcdf = (uint32_t*)malloc(4 * kk);
+    tcdf = (uint32_t*)malloc(4 * (size_t)gjx_hmm_cdf_words(h->n_states));
     ologp = (float*)malloc(4 * kk);
     rc = gjx_hmm_prepare(h, tcdf, ologp, NULL);
   }

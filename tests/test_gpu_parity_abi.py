@@ -242,6 +242,25 @@ def test_fused_lse_tail(hip_ops, oracle_ops, impl, n):
     same(fused[0], out["row_lse"], "lse vs oracle"); same(fused[1], out["row_e"]); same(fused[2], out["row_q"])
 
 
+@pytest.mark.parametrize("k", [3, 17, 256])
+def test_hmm_tables(hip_ops, oracle_ops, k):
+    """gjx_hmm_prepare: CDF rows, guide bytes and observation log-probabilities, HIP == oracle; the guide
+    entry of every bucket is where a full search for the bucket's smallest threshold lands."""
+    tl, ol = W.hmm_tables(k)
+    tl, ol = torch.from_numpy(tl).contiguous(), torch.from_numpy(ol).contiguous()
+    hc, hp = hip_ops.hmm_prepare(k, 0, dev(tl, hip_ops), dev(ol, hip_ops))
+    oc, op_ = oracle_ops.hmm_prepare(k, 0, tl, ol)
+    same(hc, oc, "trans_cdf + guide"); same(hp, op_, "obs_logp")
+    cdf = oc[:, :k].numpy().astype(np.int64)
+    guide = oc[:, k:].contiguous().numpy().view(np.uint8)
+    assert guide.shape == (k, 256)
+    b = np.arange(256, dtype=np.int64)
+    for r in range(k):
+        thr = ((b << 24) * cdf[r, -1]) >> 32
+        assert (guide[r] == np.searchsorted(cdf[r], thr, side="right")).all()
+        assert (np.diff(cdf[r]) >= 0).all()
+
+
 def test_lse_records(hip_ops, oracle_ops):
     """gjx_lse_rows records / gjx_lse_combine: shards merge exactly, and HIP == oracle bit for bit."""
     from test_oracle_pinning import check_lse_records
