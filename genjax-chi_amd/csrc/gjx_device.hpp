@@ -31,7 +31,11 @@ namespace gjx {
 
 constexpr int kWave = 64;         // CDNA wavefront
 constexpr int kBlock = 256;       // threads per workgroup (4 waves, one per SIMD)
-constexpr int kTile = 1024;       // particles per workgroup tile (4 per thread)
+#ifndef GJX_TILE
+#define GJX_TILE 1024
+#endif
+constexpr int kTile = GJX_TILE;         // particles per workgroup tile
+constexpr int kPer = kTile / kBlock;    // ... = particles per thread
 constexpr int kCatFrac = 23;      // fixed-point bits of per-row categorical CDFs
 
 GJX_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
@@ -626,6 +630,37 @@ GJX_DEV uint64_t block_scan_excl(uint64_t v, uint64_t* sh, uint64_t& total) {
   return base + incl - v;
 }
 
+// Exclusive block max-scan of one int per thread (identity 0) and a block-wide int sum.  `sh` needs 4 ints.
+GJX_DEV int block_scan_max_excl(int v, int* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int o = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl = o > incl ? o : incl;
+  }
+  int excl = __shfl_up(incl, 1, kWave);
+  if (lane == 0) excl = 0;
+  __syncthreads();
+  if (lane == 63) sh[w] = incl;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kBlock / kWave; ++i)
+    if (i < w) excl = sh[i] > excl ? sh[i] : excl;
+  return excl;
+}
+GJX_DEV int block_sum_int(int v, int* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int r = 0;
+#pragma unroll
+  for (int i = 0; i < kBlock / kWave; ++i) r += sh[i];
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Systematic resampling, tile-centric: workgroup b owns SOURCE particles [b*1024, (b+1)*1024).
 // It rebuilds the fixed-point CDF of its tile in LDS (prefix of the preceding tiles comes from the
@@ -831,14 +866,17 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   const uint64_t base = b * kTile;
 
   // Issue this tile's loads first: their HBM latency overlaps the tile-mass prefix reduction.
-  float lw4[4];
-  if (A.lw_vec && base + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
+  float lw4[kPer];
+  if (kPer == 4 && A.lw_vec && base + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
     const float4 v = reinterpret_cast<const float4*>(A.lw + base)[tid];
-    lw4[0] = v.x; lw4[1] = v.y; lw4[2] = v.z; lw4[3] = v.w;
+    lw4[0] = v.x; lw4[1] = v.y; lw4[kPer > 2 ? 2 : 0] = v.z; lw4[kPer > 3 ? 3 : 0] = v.w;
+  } else if (kPer == 2 && A.lw_vec && base + kTile <= A.n) {
+    const float2 v = reinterpret_cast<const float2*>(A.lw + base)[tid];
+    lw4[0] = v.x; lw4[1] = v.y;
   } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint64_t i = base + 4 * (uint64_t)tid + r;
+    for (int r = 0; r < kPer; ++r) {
+      const uint64_t i = base + kPer * (uint64_t)tid + r;
       lw4[r] = i < A.n ? A.lw[i] : -__builtin_inff();
     }
   }
@@ -867,11 +905,11 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
 
   // tile CDF: each thread owns 4 CONSECUTIVE sources (base + 4*tid + r) so the scan is a
   // thread-local prefix plus one block scan.
-  uint64_t q[4];
+  uint64_t q[kPer];
   uint64_t local = 0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint64_t i = base + 4 * (uint64_t)tid + r;
+  for (int r = 0; r < kPer; ++r) {
+    const uint64_t i = base + kPer * (uint64_t)tid + r;
     q[r] = i < A.n ? fixw(lw4[r], m, A.frac) : 0;
     local += q[r];
   }
@@ -879,13 +917,13 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   uint64_t run = pre + block_scan_excl(local, sh64, tile_total);
   const int64_t n_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint64_t i = base + 4 * (uint64_t)tid + r;
+  for (int r = 0; r < kPer; ++r) {
+    const uint64_t i = base + kPer * (uint64_t)tid + r;
     run += q[r];
     // the last real particle (and any padding after it) closes the comb at n_out
     const int64_t t = (i + 1 >= A.n) ? (int64_t)A.n_out
                                      : teeth_below(run, scale, u0, (int64_t)A.n_out);
-    nb[4 * tid + r] = (int32_t)t;
+    nb[kPer * tid + r] = (int32_t)t;
   }
   P.stage_source(tid);
   __syncthreads();
@@ -893,54 +931,82 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   const int64_t j0 = n_lo > A.out_lo ? n_lo : A.out_lo;
   const int64_t j1 = n_hi < A.out_hi ? n_hi : A.out_hi;
 
-  // Output slots in groups of up to 4 rows (256 slots each) per pass: NU independent ancestor
-  // searches and NU independent propagate chains are in flight per lane (ILP); the group size is
-  // wave-uniform, so rows past the block's range cost nothing.  Stores close the group.
+  // Ancestors of the tile's output slots, 1024 at a time, WITHOUT a search per slot: ancestors are
+  // monotone, so every source that owns at least one slot marks the slot where its run starts and an
+  // inclusive max-scan over the chunk spreads each mark over the run (slots before the first mark
+  // belong to the source whose run straddles the chunk start).  ~4 LDS accesses per slot instead of a
+  // 10-step dependent binary search.  The chunk is then served as up to 4 rows of 256 slots per lane:
+  // NU independent propagate chains in flight per lane (ILP); the row count is wave-uniform, so rows
+  // past the block's range cost nothing.  Stores close the group.
+  __shared__ int32_t anc_s[kTile];
+  __shared__ int shi[kBlock / kWave];
+  int32_t nbr[kPer];  // this thread's consecutive sources
+#pragma unroll
+  for (int r = 0; r < kPer; ++r) nbr[r] = nb[kPer * tid + r];
+  const int32_t nb_prev = tid == 0 ? (int32_t)n_lo : nb[kPer * tid - 1];
   float tmax = -__builtin_inff();
   auto group = [&](auto nu_tag, int64_t jb) {
     constexpr int NU = decltype(nu_tag)::value;
     int64_t jj[NU];
     bool ok[NU];
-    int lo[NU], hi[NU];
+    int src[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int64_t j = jb + tid + (int64_t)u * kBlock;
       ok[u] = j < j1;
       jj[u] = ok[u] ? j : j1 - 1;  // surplus lanes of the last row redo its last slot, stores masked
-      lo[u] = 0;
-      hi[u] = kTile - 1;
-    }
-    // first source s in the tile with nb[s] > j: exactly log2(kTile) halvings, branch-free
-#pragma unroll
-    for (int it = 0; it < 10; ++it) {
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const int mid = (lo[u] + hi[u]) >> 1;
-        const bool gt = (int64_t)nb[mid] > jj[u];
-        hi[u] = gt ? mid : hi[u];
-        lo[u] = gt ? lo[u] : mid + 1;
-      }
+      src[u] = anc_s[jj[u] - jb];
     }
     typename Policy::Out out[NU];
     float w[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) w[u] = P.compute(jj[u], lo[u], out[u]);
+    for (int u = 0; u < NU; ++u) w[u] = P.compute(jj[u], src[u], out[u]);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       if (ok[u]) {
-        P.store(jj[u], A.out_lo, base + (uint64_t)lo[u], out[u]);
+        P.store(jj[u], A.out_lo, base + (uint64_t)src[u], out[u]);
         tmax = w[u] > tmax ? w[u] : tmax;
       }
     }
   };
-  for (int64_t jb = j0; jb < j1; jb += 4 * (int64_t)kBlock) {
+  for (int64_t jb = j0; jb < j1; jb += (int64_t)kTile) {
+    // the source whose run contains slot jb: the first s with nb[s] > jb
+    int below = 0;
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) below += (int64_t)nbr[r] <= jb ? 1 : 0;
+    const int s_first = block_sum_int(below, shi);  // (its barriers also fence the previous chunk's reads)
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) anc_s[tid + r * kBlock] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+      const int64_t start = r == 0 ? nb_prev : nbr[r - 1];  // source 4*tid+r owns slots [start, nbr[r])
+      if ((int64_t)nbr[r] > start && start >= jb && start < jb + (int64_t)kTile)
+        anc_s[start - jb] = kPer * tid + r + 1;
+    }
+    __syncthreads();
+    int v[kPer];
+    int run_max = 0;
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+      const int x = anc_s[kPer * tid + r];
+      run_max = x > run_max ? x : run_max;
+      v[r] = run_max;
+    }
+    const int carry = block_scan_max_excl(run_max, shi);
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+      const int a = v[r] > carry ? v[r] : carry;
+      anc_s[kPer * tid + r] = a ? a - 1 : s_first;
+    }
+    __syncthreads();
     const int64_t rows = (j1 - jb + kBlock - 1) / kBlock;  // wave-uniform
-    if (rows >= 4) group(IntC<4>{}, jb);
-    else if (rows == 3) group(IntC<3>{}, jb);
-    else if (rows == 2) group(IntC<2>{}, jb);
+    if (kPer >= 4 && rows >= 4) group(IntC<(kPer >= 4 ? 4 : 1)>{}, jb);
+    else if (kPer >= 3 && rows == 3) group(IntC<(kPer >= 3 ? 3 : 1)>{}, jb);
+    else if (rows >= 2) group(IntC<2>{}, jb);
     else group(IntC<1>{}, jb);
   }
-  static_assert(kTile == 1024, "the ancestor search assumes 10 halvings");
+  static_assert(kPer == 2 || kPer == 4, "two or four sources / output rows per lane");
   if (max_partials) {
     const float bm = block_max(tmax, shf);
     if (tid == 0) max_partials[b] = bm;

@@ -254,7 +254,8 @@ struct CSite {
 };
 static_assert(GJX_MAX_SITES == 64, "RunCols::out is sized for 64 sites");
 
-constexpr int kPPT = kTile / kBlock;  // particles per thread (4): ILP across independent particles
+constexpr int kPPT = 4;             // particles per thread: ILP across independent particles
+constexpr int kImpTile = kPPT * kBlock;  // the interpreter kernel walks 1024-particle tiles
 constexpr int kMaskNormal = 1 << GJX_DIST_NORMAL;
 constexpr int kMaskReal = kMaskNormal | (1 << GJX_DIST_GAMMA) | (1 << GJX_DIST_BETA) | (1 << GJX_DIST_BERNOULLI);
 constexpr int kMaskAll = kMaskReal | (1 << GJX_DIST_CATEGORICAL);
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
   __shared__ uint64_t sh_sum[kBlock / kWave];
   const int tid = threadIdx.x;
 
-  for (uint64_t tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
+  for (uint64_t tile = blockIdx.x; tile * kImpTile < n; tile += gridDim.x) {
     uint64_t idx[kPPT];
     Key pkey[kPPT];
     float w[kPPT], sc[kPPT];
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
     uint32_t draws = 0;  // PHILOX: sampled sites so far (their fold)
 #pragma unroll
     for (int r = 0; r < kPPT; ++r) {
-      idx[r] = tile * kTile + (uint64_t)r * kBlock + tid;
+      idx[r] = tile * kImpTile + (uint64_t)r * kBlock + tid;
       // out-of-range lanes of the last tile run on the last particle and are masked at the stores
       pkey[r] = key_at<IMPL>(ks, idx[r] < n ? idx[r] : n - 1);
       w[r] = 0.0f;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
         logw[idx[r]] = w[r];
         if (score) score[idx[r]] = sc[r];
       }
-      if ((max_partials || row_e) && (tile * kTile + (uint64_t)r * kBlock) < n) {  // per 256-particle row
+      if ((max_partials || row_e) && (tile * kImpTile + (uint64_t)r * kBlock) < n) {  // per 256-particle row
         const float bm = block_max(idx[r] < n ? w[r] : -__builtin_inff(), sh_red);
         if (max_partials && tid == 0) max_partials[tile * kPPT + r] = bm;
         if (row_e) {  // row-anchored partial sum: no global maximum needed
@@ -601,9 +602,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums(const float* lw, uint64_t 
   __shared__ uint64_t sh64[kBlock / kWave];
   __shared__ float shf[kBlock / kWave];
   const uint64_t tile = blockIdx.x;
-  float lwv[4];
+  float lwv[kPer];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {  // issued before the max reduction so the latencies overlap
+  for (int r = 0; r < kPer; ++r) {  // issued before the max reduction so the latencies overlap
     const uint64_t i = tile * kTile + (uint64_t)r * kBlock + threadIdx.x;
     lwv[r] = i < n_local ? lw[i] : -__builtin_inff();
   }
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums(const float* lw, uint64_t 
   }
   uint64_t acc = 0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < kPer; ++r) {
     const uint64_t i = tile * kTile + (uint64_t)r * kBlock + threadIdx.x;
     if (i < n_local) acc += fixw(lwv[r], m, frac);
   }
@@ -663,18 +664,18 @@ __global__ __launch_bounds__(kBlock) void k_cdf(const float* lw, uint64_t n, con
   pre = block_sum(pre, sh64);
   const float m = m_ptr[0];
   const uint64_t base = b * kTile;
-  uint64_t q[4], local = 0;
+  uint64_t q[kPer], local = 0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint64_t i = base + 4 * (uint64_t)threadIdx.x + r;
+  for (int r = 0; r < kPer; ++r) {
+    const uint64_t i = base + kPer * (uint64_t)threadIdx.x + r;
     q[r] = i < n ? fixw(lw[i], m, frac) : 0;
     local += q[r];
   }
   uint64_t tt;
   uint64_t run = pre + block_scan_excl(local, sh64, tt);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint64_t i = base + 4 * (uint64_t)threadIdx.x + r;
+  for (int r = 0; r < kPer; ++r) {
+    const uint64_t i = base + kPer * (uint64_t)threadIdx.x + r;
     run += q[r];
     if (i < n) cdf[i] = run;
   }
@@ -793,10 +794,10 @@ struct LgssmPolicy {
   Key step_key;
   float a, q, y, rs, lognorm;
   float* xs;                // LDS tile of previous states (set in stage_source)
-  float xr[4];              // the tile row values while in flight
+  float xr[kPer];           // the tile row values while in flight
   GJX_DEV void fetch_source(uint64_t base, uint64_t n, int tid) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < kPer; ++r) {
       const uint64_t i = base + (uint64_t)r * kBlock + tid;
       xr[r] = i < n ? prev_state[i] : 0.0f;
     }
@@ -805,7 +806,7 @@ struct LgssmPolicy {
     __shared__ float xs_tile[kTile];
     xs = xs_tile;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xs_tile[r * kBlock + tid] = xr[r];
+    for (int r = 0; r < kPer; ++r) xs_tile[r * kBlock + tid] = xr[r];
   }
   struct Out {
     float x, lw;
@@ -849,11 +850,11 @@ struct HmmPolicy {
   int32_t K, y;
   int32_t* zs;
   float* ocol;
-  int32_t zr[4];
+  int32_t zr[kPer];
   float oc;
   GJX_DEV void fetch_source(uint64_t base, uint64_t n, int tid) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < kPer; ++r) {
       const uint64_t i = base + (uint64_t)r * kBlock + tid;
       zr[r] = i < n ? prev_state[i] : 0;
     }
@@ -865,7 +866,7 @@ struct HmmPolicy {
     zs = zs_tile;
     ocol = ocol_tile;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) zs_tile[r * kBlock + tid] = zr[r];
+    for (int r = 0; r < kPer; ++r) zs_tile[r * kBlock + tid] = zr[r];
     if (tid < K) ocol_tile[tid] = oc;
   }
   struct Out {
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(kBlock) void k_lgssm_init(Key step_key, uint64_t fi
   float tmax = -__builtin_inff();
   if (gbase >= first_slot && gbase < first_slot + n_local) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < kPer; ++r) {
       const uint64_t j = gbase + (uint64_t)r * kBlock + threadIdx.x;
       if (j < first_slot + n_local) {
         const float eps = std_normal(smc_slot_bits<IMPL>(step_key, j));
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(kBlock) void k_hmm_init(Key step_key, uint64_t firs
   if (gbase >= first_slot && gbase < first_slot + n_local) {
     const uint32_t* cdf = trans_cdf + (size_t)init_state * (K + kHmmGuideWords);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < kPer; ++r) {
       const uint64_t j = gbase + (uint64_t)r * kBlock + threadIdx.x;
       if (j < first_slot + n_local) {
         const uint32_t bits = smc_slot_bits<IMPL>(step_key, j);
@@ -1347,9 +1348,9 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
     const int rc = plan_device_table(const_cast<gjx_plan*>(p));
     if (rc) return rc;
   }
-  const size_t lds = sizeof(uint32_t) * (size_t)(p->n_slots > 0 ? p->n_slots : 1) * kTile;
+  const size_t lds = sizeof(uint32_t) * (size_t)(p->n_slots > 0 ? p->n_slots : 1) * kImpTile;
 #define GJX_LAUNCH_IMPORTANCE(IMPL, MASK) \
-  k_importance<IMPL, MASK><<<grid_for(n), kBlock, lds, S(s)>>>(p->dev, p->n_sites, k, cols, score, logw, n, max_partials, row_e, row_s)
+  k_importance<IMPL, MASK><<<(unsigned)((n + kImpTile - 1) / kImpTile), kBlock, lds, S(s)>>>(p->dev, p->n_sites, k, cols, score, logw, n, max_partials, row_e, row_s)
   const int m = p->dist_mask;
   if (pk->impl == 0) {
     if ((m & ~kMaskNormal) == 0) GJX_LAUNCH_IMPORTANCE(0, kMaskNormal);
@@ -1634,10 +1635,10 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
   ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out);
   if (cfg->impl == 0) {
-    LgssmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {0, 0, 0, 0}};
+    LgssmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {}};
     k_resample<0, LgssmPolicy<0>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   } else {
-    LgssmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {0, 0, 0, 0}};
+    LgssmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {}};
     k_resample<1, LgssmPolicy<1>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   }
   return launch_status();
@@ -1663,10 +1664,10 @@ int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
   ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out);
   if (cfg->impl == 0) {
-    HmmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {0, 0, 0, 0}, 0.0f};
+    HmmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {}, 0.0f};
     k_resample<0, HmmPolicy<0>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   } else {
-    HmmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {0, 0, 0, 0}, 0.0f};
+    HmmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {}, 0.0f};
     k_resample<1, HmmPolicy<1>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   }
   return launch_status();

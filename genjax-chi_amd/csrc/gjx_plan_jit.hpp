@@ -354,12 +354,12 @@ struct GenSmc {
     SiteEmitter<CSiteT, CArgT> es{o, impl, 1, step_sites, n_step, "    "};
     SiteEmitter<CSiteT, CArgT> ei{o, impl, 1, init_sites, n_init, "        "};
     // ---- step policy
-    o << "struct GenPolicy {\n  PlanPolicyArgs a;\n  float* xs[" << D << "];\n  float xr[" << D << "][4];\n";
+    o << "struct GenPolicy {\n  PlanPolicyArgs a;\n  float* xs[" << D << "];\n  float xr[" << D << "][kPer];\n";
     o << "  struct Out { float s[" << D << "]; float lw; };\n";
     o << "  __device__ __forceinline__ void fetch_source(uint64_t base, uint64_t n, int tid) {\n";
-    o << "    for (int k = 0; k < " << D << "; ++k)\n      for (int r = 0; r < 4; ++r) { const uint64_t i = base + (uint64_t)r * 256 + tid; xr[k][r] = i < n ? a.prev_state[k][i] : 0.0f; }\n  }\n";
-    o << "  __device__ __forceinline__ void stage_source(int tid) {\n    __shared__ float tile[" << D << "][1024];\n";
-    o << "    for (int k = 0; k < " << D << "; ++k) { xs[k] = tile[k]; for (int r = 0; r < 4; ++r) tile[k][r * 256 + tid] = xr[k][r]; }\n  }\n";
+    o << "    for (int k = 0; k < " << D << "; ++k)\n      for (int r = 0; r < kPer; ++r) { const uint64_t i = base + (uint64_t)r * 256 + tid; xr[k][r] = i < n ? a.prev_state[k][i] : 0.0f; }\n  }\n";
+    o << "  __device__ __forceinline__ void stage_source(int tid) {\n    __shared__ float tile[" << D << "][kTile];\n";
+    o << "    for (int k = 0; k < " << D << "; ++k) { xs[k] = tile[k]; for (int r = 0; r < kPer; ++r) tile[k][r * 256 + tid] = xr[k][r]; }\n  }\n";
     o << "  __device__ __forceinline__ float compute(int64_t j, int src_local, Out& out) const {\n";
     for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << " = xs[" << k << "][src_local];\n";
     if (es.needs_pk()) o << "    const Key pkey = slot_key<" << I << ">(a.step_key, (uint64_t)j);\n";
@@ -374,8 +374,8 @@ struct GenSmc {
     o << "  GenPolicy P;\n  P.a = PA;\n  resample_body<" << I << ">(A, P, max_partials);\n}\n";
     // ---- init kernel: one workgroup per global tile, like k_lgssm_init
     o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_init_kernel(PlanPolicyArgs a, uint64_t first_slot, uint64_t n_local, float* max_partials) {\n";
-    o << "  __shared__ float shf[4];\n  const uint64_t gbase = (uint64_t)blockIdx.x * 1024;\n  float tmax = -__builtin_inff();\n";
-    o << "  if (gbase >= first_slot && gbase < first_slot + n_local) {\n    for (int r = 0; r < 4; ++r) {\n";
+    o << "  __shared__ float shf[4];\n  const uint64_t gbase = (uint64_t)blockIdx.x * kTile;\n  float tmax = -__builtin_inff();\n";
+    o << "  if (gbase >= first_slot && gbase < first_slot + n_local) {\n    for (int r = 0; r < kPer; ++r) {\n";
     o << "      const uint64_t j = gbase + (uint64_t)r * 256 + threadIdx.x;\n      if (j < first_slot + n_local) {\n";
     if (ei.needs_pk()) o << "        const Key pkey = slot_key<" << I << ">(a.step_key, j);\n";
     o << "        float w = 0.0f, sc = 0.0f;\n";
