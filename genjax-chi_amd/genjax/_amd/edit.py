@@ -1,0 +1,188 @@
+"""Trace edits: `Update` requests, change-tagged values (`Diff`) and the per-site update walk.
+
+Mirror of the reference's edit interface for the part of it an SMC driver uses to move a population of
+particles to a new target:
+  Diff / NoChange / UnknownChange .... core/compiler/interpreters/incremental.py:60-260
+  EditRequest, Update ................ core/generative/concepts.py:95-167, generative_function.py:1688-1700
+  Trace.edit / Trace.update .......... core/generative/generative_function.py:153-183
+  GenerativeFunction.update .......... core/generative/generative_function.py:611-627
+  Distribution edit_update ........... generative_functions/distributions/distribution.py:163-258, 302-340
+  Static UpdateHandler ............... generative_functions/static.py:405-504, 827-865
+
+Semantics (same as the reference): `update(key, trace, constraint, argdiffs)` returns
+`(new_trace, w, retdiff, discard)` with `w = log p'(new choices; new args) − log p(old choices; old args)`
+restricted to what changed (sites that appear for the first time are sampled from their prior and
+contribute nothing), and `discard` the old values the constraint replaced.
+
+Design difference, stated: the reference pushes `Diff` tags through the body with an incremental
+interpreter so that untouched sites can be skipped; here a body runs once over the whole particle
+population and every visited site re-evaluates its log-density column on the GPU (one `gjx_logpdf_*`
+kernel per site) — an unchanged site re-evaluates to exactly its old score, so its weight increment is
+exactly 0.  Inner sites therefore always receive `UnknownChange` arguments; return-value diffs are
+`no_change` only when nothing was constrained and no argument changed.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any
+
+import torch
+
+from .choicemap import ChoiceMap
+
+
+# ---- change tags ----------------------------------------------------------------------------------
+class ChangeTangent:
+    def __repr__(self):
+        return type(self).__name__.lstrip("_")
+
+
+class _UnknownChange(ChangeTangent):
+    pass
+
+
+class _NoChange(ChangeTangent):
+    pass
+
+
+UnknownChange = _UnknownChange()
+NoChange = _NoChange()
+
+
+def _tree_map(fn, tree):
+    if isinstance(tree, Diff):
+        return fn(tree)
+    if isinstance(tree, tuple):
+        return tuple(_tree_map(fn, x) for x in tree)
+    if isinstance(tree, list):
+        return [_tree_map(fn, x) for x in tree]
+    if isinstance(tree, dict):
+        return {k: _tree_map(fn, x) for k, x in tree.items()}
+    return fn(tree)
+
+
+def _tree_leaves(tree, out):
+    if isinstance(tree, (tuple, list)):
+        for x in tree:
+            _tree_leaves(x, out)
+    elif isinstance(tree, dict):
+        for x in tree.values():
+            _tree_leaves(x, out)
+    else:
+        out.append(tree)
+    return out
+
+
+@dataclass(frozen=True)
+class Diff:
+    """A value paired with a change tag (incremental.py:89-260).  Leaves of an argument tuple only."""
+
+    primal: Any
+    tangent: ChangeTangent
+
+    def get_primal(self):
+        return self.primal
+
+    def get_tangent(self):
+        return self.tangent
+
+    @staticmethod
+    def tree_primal(tree):
+        return _tree_map(lambda v: v.primal if isinstance(v, Diff) else v, tree)
+
+    @staticmethod
+    def tree_tangent(tree):
+        return _tree_map(lambda v: v.tangent if isinstance(v, Diff) else NoChange, tree)
+
+    @staticmethod
+    def tree_diff(tree, tangent_tree):
+        flat_t = _tree_leaves(tangent_tree, [])
+        it = iter(flat_t)
+        return _tree_map(lambda p: Diff(p, next(it)), tree)
+
+    @staticmethod
+    def no_change(tree):
+        return _tree_map(lambda p: Diff(p, NoChange), Diff.tree_primal(tree))
+
+    @staticmethod
+    def unknown_change(tree):
+        return _tree_map(lambda p: Diff(p, UnknownChange), Diff.tree_primal(tree))
+
+    @staticmethod
+    def static_check_no_change(tree) -> bool:
+        return all(not isinstance(v, Diff) or v.tangent is NoChange for v in _tree_leaves(tree, []))
+
+    @staticmethod
+    def static_check_tree_diff(tree) -> bool:
+        return all(isinstance(v, Diff) for v in _tree_leaves(tree, []))
+
+
+# ---- requests -------------------------------------------------------------------------------------
+class NotSupportedEditRequest(Exception):
+    """concepts.py:167."""
+
+    def __init__(self, request):
+        super().__init__(f"edit request not supported: {request!r}")
+        self.request = request
+
+
+class EditRequest:
+    """concepts.py:95-140."""
+
+    def edit(self, key, tr, argdiffs):
+        raise NotImplementedError
+
+    def dimap(self, *, pre=lambda v: v, post=lambda v: v):
+        raise NotSupportedEditRequest(self)
+
+
+class PrimitiveEditRequest(EditRequest):
+    """A request a generative function answers itself (concepts.py:143-164)."""
+
+    def edit(self, key, tr, argdiffs):
+        return tr.get_gen_fn().edit(key, tr, self, argdiffs)
+
+
+@dataclass(frozen=True)
+class Update(PrimitiveEditRequest):
+    """Move a trace to new arguments and / or new values at the constrained addresses
+    (generative_function.py:1688-1700)."""
+
+    constraint: ChoiceMap
+
+
+@dataclass(frozen=True)
+class Regenerate(PrimitiveEditRequest):
+    """requests.py:64-66.  Named for API parity; no generative function on this path answers it
+    (`NotSupportedEditRequest`): MCMC rejuvenation is outside the SMC / ImportanceK hot path."""
+
+    selection: Any
+
+
+# ---- the generic answer to Update ------------------------------------------------------------------
+def generic_update(gen_fn, key, trace, constraint: ChoiceMap, argdiffs):
+    """Update by re-generation: every old choice the constraint does not replace is constrained to its
+    old value, so `generate` re-evaluates all log-densities at the new arguments and samples only
+    addresses that did not exist before.  `generate`'s weight is then the log-density of everything but
+    the fresh samples, and `w = that − old score` is the update weight.  Used by the combinators; the
+    static language walks site by site (`UpdateHandler`)."""
+    args = Diff.tree_primal(argdiffs)
+    old = trace.get_choices()
+    merged = constraint | old
+    new_trace, gw = gen_fn.generate(key, merged, args)
+    w = gw - trace.get_score()
+    discard = ChoiceMap.empty()  # address by address: combinator choices are stacked leaves behind an index
+    for addr, _ in constraint.leaves():
+        if addr in old:
+            discard = discard | ChoiceMap.entry(old[addr], *addr)
+    unchanged = constraint.static_is_empty() and Diff.static_check_no_change(argdiffs)
+    retval = new_trace.get_retval()
+    return new_trace, w, (Diff.no_change(retval) if unchanged else Diff.unknown_change(retval)), Update(discard)
+
+
+def as_weight(w, like=None):
+    """Weights may be Python floats (no constrained site touched) or [n] columns."""
+    if isinstance(w, torch.Tensor) or like is None or not isinstance(like, torch.Tensor):
+        return w
+    return torch.zeros_like(like) + w

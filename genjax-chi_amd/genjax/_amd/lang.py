@@ -176,6 +176,19 @@ class Trace:
     def project(self, key, selection: Selection):
         return self.get_gen_fn().project(key, self, selection)
 
+    def edit(self, key, request, argdiffs=None):
+        """generative_function.py:153-166: answer an edit request; arguments unchanged unless given."""
+        from .edit import Diff
+
+        return request.edit(key, self, Diff.no_change(self.get_args()) if argdiffs is None else argdiffs)
+
+    def update(self, key, constraint: ChoiceMap, argdiffs=None):
+        """generative_function.py:168-183 -> (new trace, weight, retdiff, discard)."""
+        from .edit import Diff
+
+        return self.get_gen_fn().update(key, self, constraint,
+                                        Diff.no_change(self.get_args()) if argdiffs is None else argdiffs)
+
     def map_leaves(self, fn) -> "Trace":
         raise NotImplementedError
 
@@ -392,6 +405,23 @@ class GenerativeFunction:
     def project(self, key, trace: Trace, selection: Selection):
         raise NotImplementedError
 
+    def edit(self, key, trace: Trace, edit_request, argdiffs):
+        """generative_function.py:496-610.  `Update` is answered by re-generation unless a subclass
+        walks its own structure; other requests are not supported on this path."""
+        from .edit import NotSupportedEditRequest, Update, generic_update
+
+        if isinstance(edit_request, Update):
+            return generic_update(self, key, trace, edit_request.constraint, argdiffs)
+        raise NotSupportedEditRequest(edit_request)
+
+    def update(self, key, trace: Trace, constraint: ChoiceMap, argdiffs):
+        """generative_function.py:611-627."""
+        from .edit import Update
+
+        tr, w, rd, bwd = Update(constraint).edit(key, trace, argdiffs)
+        assert isinstance(bwd, Update), type(bwd)
+        return tr, w, rd, bwd.constraint
+
     # -- combinator sugar ----------------------------------------------------------------------------
     def marginal(self, /, *, selection: Selection = Selection.all(), algorithm=None):
         from .inference import Marginal
@@ -498,6 +528,36 @@ class GenerateHandler(_Handler):
         return tr.get_retval()
 
 
+class UpdateHandler(_Handler):
+    """static.py:405-461: every visited site edits its previous sub-trace with the sub-constraint;
+    weights add up, the backward constraints are collected per address."""
+
+    def __init__(self, key: ParticleKeys, previous_trace: "StaticTrace", constraint: ChoiceMap):
+        super().__init__()
+        self.key, self.previous_trace, self.constraint = key, previous_trace, constraint
+        self.sites = _SiteCounter(key.impl)
+        self.weight = 0.0
+        self.bwd_constraints: dict = {}
+
+    def handle_trace(self, addr, gen_fn, args):
+        from .edit import Diff, Update
+
+        leaf = isinstance(gen_fn, Distribution)
+        sub = self.constraint.get_submap(*(addr if isinstance(addr, tuple) else (addr,)))
+        try:
+            subtrace = self.previous_trace.get_inner_trace(addr)
+        except KeyError:
+            raise MissingAddress(addr) from None
+        # exact densities draw nothing during an update; nested functions get their folded key
+        sub_key = site_keys(self.key, self.sites.next(not leaf), leaf)
+        tr, w, retdiff, bwd = Update(sub).edit(sub_key, subtrace, Diff.unknown_change(tuple(args)))
+        assert isinstance(bwd, Update) and isinstance(bwd.constraint, ChoiceMap)
+        self.bwd_constraints[addr] = bwd.constraint
+        self.weight = self.weight + w
+        self.record(addr, tr)
+        return Diff.tree_primal(retdiff)
+
+
 class AssessHandler(_Handler):
     def __init__(self, sample: ChoiceMap):
         super().__init__()
@@ -577,6 +637,26 @@ class StaticGenerativeFunction(GenerativeFunction):
         h = AssessHandler(sample)
         retval = h.run(self.source, args)
         return h.score, retval
+
+    def edit(self, key, trace: StaticTrace, edit_request, argdiffs):
+        """static.py:827-865 (`edit_update`): re-run the body at the new arguments, editing each site's
+        previous sub-trace; the backward request restores the discarded values."""
+        from .edit import Diff, NotSupportedEditRequest, Update
+
+        if not isinstance(edit_request, Update):
+            raise NotSupportedEditRequest(edit_request)
+        constraint = edit_request.constraint
+        args = Diff.tree_primal(argdiffs)
+        pk, batched = as_particle_keys(key)
+        if not batched and batch_size_of(trace.get_score()) is not None:
+            raise TypeError("a population trace needs per-particle keys (split(key, n)) for update")
+        h = UpdateHandler(pk, trace, constraint)
+        retval = h.run(self.source, args)
+        new_trace = StaticTrace(self, args, retval, h.traces)
+        discard = ChoiceMap.d({a: c for a, c in h.bwd_constraints.items() if not c.static_is_empty()})
+        unchanged = constraint.static_is_empty() and Diff.static_check_no_change(argdiffs)
+        retdiff = Diff.no_change(retval) if unchanged else Diff.unknown_change(retval)
+        return new_trace, h.weight, retdiff, Update(discard)
 
     def project(self, key, trace: StaticTrace, selection: Selection):
         total = 0.0
@@ -684,6 +764,32 @@ class Distribution(GenerativeFunction):
 
     def project(self, key, trace: DistributionTrace, selection: Selection):
         return trace.get_score() if selection.check() else 0.0
+
+    def edit(self, key, trace: DistributionTrace, edit_request, argdiffs):
+        """distribution.py:302-340 (dispatch) and 179-258 (`Update` with a ChoiceMap constraint):
+        no value -> the old value is kept and re-scored at the new arguments (weight fwd − bwd, retval
+        unchanged, nothing discarded); a value -> it replaces the old one (retval changed, the old choice
+        is the discard).  Masked values (`lax.cond` on a flag) are outside the supported subset."""
+        from .edit import Diff, NotSupportedEditRequest, Update
+
+        if not isinstance(edit_request, Update):
+            raise NotSupportedEditRequest(edit_request)
+        constraint = edit_request.constraint
+        primals = Diff.tree_primal(argdiffs)
+        bwd = trace.get_score()
+        v = constraint.get_value()
+        if v is None:
+            if not constraint.static_is_empty():
+                raise ValueError("constraint for a distribution must be a value (ChoiceMap.choice)")
+            old = trace.get_retval()
+            fwd = self.estimate_logpdf(key, old, *primals)
+            return DistributionTrace(self, primals, old, fwd), fwd - bwd, Diff.no_change(old), Update(ChoiceMap.empty())
+        n = batch_size_of(bwd)
+        fwd = self.estimate_logpdf(key, v, *primals)
+        if n is not None and batch_size_of(fwd) is None:  # scalar value and arguments on a population
+            fwd = torch.zeros_like(bwd) + fwd
+        new_v = self._canonical_value(v, n)
+        return DistributionTrace(self, primals, new_v, fwd), fwd - bwd, Diff.unknown_change(new_v), Update(trace.get_choices())
 
     def _canonical_value(self, v, n):
         return v

@@ -168,6 +168,137 @@ def case_static_gen_fn(impl):
     kw.simulate(key, ())
 
 
+# ---- tests/generative_functions/test_static_gen_fn.py:500-700, test_distributions.py update tests ----
+def case_update(impl):
+    from genjax import Diff, Update
+
+    key = genjax.random.key(314159, impl)
+
+    # distributions (distribution.py:179-258): re-score at new arguments, or replace the value
+    key, sub_key = jax.random.split(key)
+    tr = normal.simulate(sub_key, (0.0, 1.0))
+    v = f(tr.get_retval())
+    new_tr, w, rd, discard = tr.update(key, C.n())
+    assert f(w) == 0.0 and rd.tangent is genjax.NoChange and discard.static_is_empty()
+    new_tr, w, rd, discard = tr.update(key, C.n(), Diff.unknown_change((1.0, 2.0)))
+    assert f(new_tr.get_retval()) == v and rd.tangent is genjax.NoChange
+    assert f(w) == pytest.approx(f(normal.logpdf(v, 1.0, 2.0)) - f(tr.get_score()), abs=1e-6)
+    assert f(new_tr.get_score()) == pytest.approx(f(normal.logpdf(v, 1.0, 2.0)), abs=1e-6)
+    new_tr, w, rd, discard = tr.update(key, C.v(1.5))
+    assert f(new_tr.get_retval()) == 1.5 and rd.tangent is genjax.UnknownChange and f(discard.get_value()) == v
+    assert f(w) == pytest.approx(f(normal.logpdf(1.5, 0.0, 1.0)) - f(tr.get_score()), abs=1e-6)
+
+    # test_simple_normal_update / test_simple_linked_normal_update
+    @gen
+    def simple_linked_normal():
+        y1 = normal(0.0, 1.0) @ "y1"
+        y2 = normal(y1, 1.0) @ "y2"
+        y3 = normal(y1 + y2, 1.0) @ "y3"
+        return y1 + y2 + y3
+
+    key, sub_key = jax.random.split(key)
+    tr = simple_linked_normal.simulate(sub_key, ())
+    original_choice, original_score = tr.get_choices(), f(tr.get_score())
+    new = C["y1"].set(2.0)
+    key, sub_key = jax.random.split(key)
+    updated, w, rd, discard = simple_linked_normal.update(sub_key, tr, new, ())
+    _, w_edit, _, bwd = tr.edit(sub_key, Update(new))  # update_weight_correctness_general_assertions: same move
+    assert f(w_edit) == f(w) and isinstance(bwd, Update)
+    uc = updated.get_choices()
+    y1, y2, y3 = f(uc["y1"]), f(uc["y2"]), f(uc["y3"])
+    assert y1 == 2.0 and y2 == f(original_choice["y2"]) and y3 == f(original_choice["y3"])
+    test_score = f(normal.assess(C.v(y1), (0.0, 1.0))[0]) + f(normal.assess(C.v(y2), (y1, 1.0))[0]) + \
+        f(normal.assess(C.v(y3), (y1 + y2, 1.0))[0])
+    assert f(original_choice["y1"]) == f(discard["y1"]) and "y2" not in discard
+    assert f(updated.get_score()) == pytest.approx(original_score + f(w), rel=1e-5)
+    assert f(updated.get_score()) == pytest.approx(test_score, rel=1e-5)
+    assert f(updated.get_retval()) == pytest.approx(y1 + y2 + y3, rel=1e-6) and rd.tangent is genjax.UnknownChange
+    # weight correctness: w = sum over changed factors of new − old log-density
+    oy1 = f(original_choice["y1"])
+    expect = (f(normal.logpdf(2.0, 0.0, 1.0)) - f(normal.logpdf(oy1, 0.0, 1.0))
+              + f(normal.logpdf(y2, 2.0, 1.0)) - f(normal.logpdf(y2, oy1, 1.0))
+              + f(normal.logpdf(y3, 2.0 + y2, 1.0)) - f(normal.logpdf(y3, oy1 + y2, 1.0)))
+    assert f(w) == pytest.approx(expect, abs=1e-4)
+    # the backward request undoes the move
+    back, w_back, _, _ = bwd.edit(sub_key, updated, ())
+    assert f(back.get_choices()["y1"]) == oy1 and f(w_back) == pytest.approx(-f(w), abs=1e-4)
+    # two addresses at once
+    upd2, w2, _, d2 = simple_linked_normal.update(sub_key, tr, C["y1"].set(2.0).at["y2"].set(3.0), ())
+    assert f(upd2.get_score()) == pytest.approx(original_score + f(w2), rel=1e-5) and "y2" in d2 and "y3" not in d2
+
+    # test_simple_hierarchical_normal: nested generative functions, argument changes flow into them
+    @gen
+    def _inner(x):
+        return normal(x, 1.0) @ "y1"
+
+    @gen
+    def simple_hierarchical_normal():
+        y1 = normal(0.0, 1.0) @ "y1"
+        y2 = _inner(y1) @ "y2"
+        y3 = _inner(y1 + y2) @ "y3"
+        return y1 + y2 + y3
+
+    key, sub_key = jax.random.split(key)
+    tr = simple_hierarchical_normal.simulate(sub_key, ())
+    oc, os_ = tr.get_choices(), f(tr.get_score())
+    updated, w, _, discard = simple_hierarchical_normal.update(sub_key, tr, C["y1"].set(2.0), ())
+    uc = updated.get_choices()
+    assert f(uc["y1"]) == 2.0 and f(uc["y2", "y1"]) == f(oc["y2", "y1"]) and f(uc["y3", "y1"]) == f(oc["y3", "y1"])
+    y2, y3 = f(uc["y2", "y1"]), f(uc["y3", "y1"])
+    test_score = f(normal.logpdf(2.0, 0.0, 1.0)) + f(normal.logpdf(y2, 2.0, 1.0)) + f(normal.logpdf(y3, 2.0 + y2, 1.0))
+    assert f(oc["y1"]) == f(discard["y1"])
+    assert f(updated.get_score()) == pytest.approx(os_ + f(w), rel=1e-5)
+    assert f(updated.get_score()) == pytest.approx(test_score, rel=1e-5)
+
+    # argdiffs: a model argument changes, no constraint (generative_function.py:496-560 docstring example)
+    @gen
+    def model(var):
+        v1 = normal(0.0, 1.0) @ "v1"
+        v2 = normal(v1, var) @ "v2"
+        return v2
+
+    tr = model.simulate(sub_key, (1.0,))
+    new_tr, w, rd, _ = tr.edit(key, Update(C.n()), Diff.unknown_change((3.0,)))
+    ch = tr.get_choices()
+    assert new_tr.get_args() == (3.0,) and f(new_tr.get_choices()["v2"]) == f(ch["v2"])
+    assert f(w) == pytest.approx(f(normal.logpdf(f(ch["v2"]), f(ch["v1"]), 3.0)) - f(normal.logpdf(f(ch["v2"]), f(ch["v1"]), 1.0)), abs=1e-5)
+    same, w0, rd0, _ = tr.update(key, C.n())
+    assert f(w0) == 0.0 and rd0.tangent is genjax.NoChange
+    with pytest.raises(genjax.NotSupportedEditRequest):
+        tr.edit(key, genjax.Regenerate(S["v1"]))
+    with pytest.raises(genjax.MissingAddress):  # a previous trace that never visited "y1" (static.py:432-436)
+        simple_linked_normal.update(sub_key, StaticTrace(simple_linked_normal, (), None, {}), C.n(), ())
+
+    # a whole population at once: per-particle keys, [n] columns, one log-density kernel per site
+    n = 4096
+    keys = jax.random.split(key, n)
+    ptr = simple_linked_normal.simulate(keys, ())
+    pupd, pw, _, pdisc = ptr.update(keys, C["y2"].set(0.25))
+    y1c, y3c = ptr.get_choices()["y1"], ptr.get_choices()["y3"]
+    assert pw.shape == (n,) and torch.equal(pupd.get_choices()["y1"], y1c) and torch.equal(pdisc["y2"], ptr.get_choices()["y2"])
+    y2o = ptr.get_choices()["y2"]
+    expect = (normal.logpdf(torch.full_like(y1c, 0.25), y1c, 1.0) - normal.logpdf(y2o, y1c, 1.0)
+              + normal.logpdf(y3c, y1c + 0.25, 1.0) - normal.logpdf(y3c, y1c + y2o, 1.0))
+    assert torch.allclose(pw, expect, atol=1e-4)
+    assert torch.allclose(pupd.get_score(), ptr.get_score() + pw, atol=1e-4)
+
+    # combinators answer Update by re-generation (scan: test_scan_combinator.py update tests)
+    @gen
+    def step(carry, x):
+        z = normal(carry + x, 1.0) @ "z"
+        return z, z
+
+    scanner = genjax.scan(n=3)(step)
+    xs = torch.tensor([0.5, -0.5, 1.0])
+    str_ = scanner.simulate(sub_key, (0.0, xs))
+    supd, sw, _, sdisc = str_.update(key, C[1, "z"].set(0.75))
+    zs = str_.get_choices()[:, "z"] if False else [f(str_.get_choices()[i, "z"]) for i in range(3)]
+    assert f(supd.get_choices()[1, "z"]) == 0.75 and f(supd.get_choices()[0, "z"]) == zs[0]
+    exp = (f(normal.logpdf(0.75, zs[0] - 0.5, 1.0)) - f(normal.logpdf(zs[1], zs[0] - 0.5, 1.0))
+           + f(normal.logpdf(zs[2], 0.75 + 1.0, 1.0)) - f(normal.logpdf(zs[2], zs[1] + 1.0, 1.0)))
+    assert f(sw) == pytest.approx(exp, abs=1e-4) and f(sdisc[1, "z"]) == zs[1]
+
+
 # ---- tests/generative_functions/test_distributions.py:25-60 ---------------------------------------
 def case_distributions(impl):
     key = genjax.random.key(314159, impl)
@@ -469,4 +600,4 @@ def case_general_smc(impl):
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_fused_equals_eager, case_particle_collection, case_custom_proposal,
-             case_scan, case_vmap, case_bootstrap_smc, case_general_smc]
+             case_scan, case_vmap, case_bootstrap_smc, case_general_smc, case_update]
