@@ -35,7 +35,21 @@ def _as_addr(addr) -> tuple:
     return (addr,)
 
 
+def _index_list(seg):
+    """An array-valued address segment (`C[jnp.array([0, 2]), "x"]`, choice_map.py:1454-1531) as a list of
+    ints, else None."""
+    if isinstance(seg, (str, bool)) or seg is Ellipsis:
+        return None
+    if isinstance(seg, (list, range)):
+        return [int(i) for i in seg]
+    if hasattr(seg, "ndim") and hasattr(seg, "tolist") and getattr(seg, "ndim", 0) == 1:
+        return [int(i) for i in seg.tolist()]
+    return None
+
+
 def _check_segment(seg):
+    if _index_list(seg) is not None:
+        return
     if seg is Ellipsis or isinstance(seg, (str, int)) or seg == _FULL:
         return
     if isinstance(seg, slice):
@@ -263,6 +277,23 @@ SelectionBuilder = _SelectionBuilder()
 # =================================================================================================
 # ChoiceMap
 # =================================================================================================
+class Mask:
+    """A value that is only present where `flag` holds (core/generative/functional_types.py Mask): the
+    constraint a vectorised site receives when only some of its elements are constrained.  `flag` is a
+    Python bool or a bool tensor broadcastable against `value`'s leading axis."""
+
+    __slots__ = ("value", "flag")
+
+    def __init__(self, value, flag):
+        self.value, self.flag = value, flag
+
+    def primal_flag(self):
+        return self.flag
+
+    def __repr__(self):
+        return f"Mask({_short(self.value)}, {_short(self.flag)})"
+
+
 class ChoiceMap:
     """Immutable trie of random choices.  `_value` is the leaf payload (or None); `_children`
     maps one address segment to a sub-map."""
@@ -429,9 +460,10 @@ class ChoiceMap:
         return ChoiceMap(value, kids) if (value is not None or kids) else _EMPTY
 
     def mask(self, flag) -> "ChoiceMap":
+        """choice_map.py `mask`: static flags resolve now, tensor flags wrap every leaf in a `Mask`."""
         if isinstance(flag, bool):
             return self if flag else _EMPTY
-        raise NotImplementedError("dynamic masks are outside the supported static subset")
+        return self.map_leaves(lambda v: Mask(v.value, v.flag & flag) if isinstance(v, Mask) else Mask(v, flag))
 
     # -- builders ----------------------------------------------------------------------------------
     @property
@@ -525,6 +557,16 @@ class ChoiceMapBuilder:
         return ChoiceMapBuilder(self._chm, addr)
 
     def set(self, v) -> ChoiceMap:
+        for k, seg in enumerate(self._addr):
+            idx = _index_list(seg)
+            if idx is not None:  # C[array, ...].set(values): one entry per index, values along their leading axis
+                new = _EMPTY
+                for pos, i in enumerate(idx):
+                    vi = v[pos] if hasattr(v, "__getitem__") and getattr(v, "ndim", 1) >= 1 and not isinstance(v, (str, dict)) else v
+                    new = new | ChoiceMapBuilder(None, self._addr[:k] + (i,) + self._addr[k + 1:]).set(vi)
+                if self._chm is None:
+                    return new
+                return new | self._chm
         new = ChoiceMap.entry(v, *self._addr)
         if self._chm is None:
             return new

@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import torch
 
-from .choicemap import ChoiceMap, Selection
+from .choicemap import ChoiceMap, Mask, Selection
 from .lang import GenerativeFunction, ParticleKeys, Trace, _map_any, as_particle_keys, fold_in, squeeze_leaf
 from .ops import KeyBatch
 from .runtime import get_ops
@@ -227,24 +227,48 @@ class Vmap(GenerativeFunction):
         return ParticleKeys(KeyBatch(pk.impl, 0, tensor=t), pk.n * m)
 
     def _expand_constraint(self, constraint: ChoiceMap, n: int, m: int) -> ChoiceMap:
-        """Constraints on a vmapped site are vectors over the mapped axis (`C[:, "x"].set(xs)`,
-        test_choice_maps.py:1033): leaf [m] (all particles) or [n, m]."""
+        """Constraints on a vmapped site.  Vectors over the whole mapped axis (`C[:, "x"].set(xs)`,
+        test_choice_maps.py:1033): leaf [m] (all particles) or [n, m].  Constraints on SOME indices
+        (`C[0, "x"].set(v)`, `C[jnp.array([0, 2]), "x"].set(vs)`; vmap.py:193-218 `get_submap(idx)` over an
+        indexed choice map, test_vmap_combinator.py:84-106): the site receives a `Mask` — the constrained
+        values scattered into a column plus the flags of the constrained elements — and samples the rest."""
         ops = get_ops()
+        dev = ops.device()
 
         def expand(v):
-            t = torch.as_tensor(v).to(ops.device())
+            if isinstance(v, Mask):  # masked by an enclosing vmap: every element of a masked particle is masked
+                return Mask(expand(v.value), v.flag.reshape(n, 1).expand(n, m).reshape(-1))
+            t = torch.as_tensor(v).to(dev)
             if t.dtype == torch.float64:
                 t = t.to(torch.float32)
             if t.dim() >= 2 and t.shape[0] == n and t.shape[1] == m:
                 return t.reshape((n * m,) + tuple(t.shape[2:])).contiguous()
             if t.dim() >= 1 and t.shape[0] == m:
                 return t.repeat((n,) + (1,) * (t.dim() - 1)).contiguous()
-            raise NotImplementedError("constraints on a subset of the mapped indices need masked sites (out of scope)")
+            raise ValueError(f"a constraint on a vmapped site needs a leading axis of {m} (got shape {tuple(t.shape)})")
 
-        for seg in constraint._children:
-            if isinstance(seg, int):
-                raise NotImplementedError("constraints on a subset of the mapped indices need masked sites (out of scope)")
-        return constraint.map_leaves(expand)
+        whole = ChoiceMap(constraint._value, {s: c for s, c in constraint._children.items() if not isinstance(s, int)})
+        out = whole.map_leaves(expand)
+        by_addr: dict = {}
+        for j, sub in constraint._children.items():
+            if not isinstance(j, int):
+                continue
+            if not 0 <= j < m:
+                raise IndexError(f"constraint index {j} outside the mapped axis of length {m}")
+            for addr, v in sub.leaves():
+                by_addr.setdefault(addr, []).append((j, v))
+        for addr, items in by_addr.items():
+            v0 = items[0][1]
+            first = torch.as_tensor(v0.value if isinstance(v0, Mask) else v0)
+            vals = torch.zeros((n, m), dtype=torch.float32 if first.dtype.is_floating_point else first.dtype, device=dev)
+            flag = torch.zeros((n, m), dtype=torch.bool, device=dev)
+            for j, v in items:
+                outer = v.flag.to(dev).reshape(-1) if isinstance(v, Mask) else None  # set by an enclosing vmap
+                t = torch.as_tensor(v.value if isinstance(v, Mask) else v).to(dev).to(vals.dtype)
+                vals[:, j] = t.reshape(-1) if t.dim() >= 1 and t.numel() == n else t.reshape(())
+                flag[:, j] = True if outer is None else outer
+            out = ChoiceMap.entry(Mask(vals.reshape(-1), flag.reshape(-1)), *addr) | out
+        return out
 
     def simulate(self, key, args):
         pk, batched = as_particle_keys(key)

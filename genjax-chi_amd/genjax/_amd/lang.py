@@ -24,7 +24,7 @@ from typing import Any, Callable
 import torch
 
 from . import prng
-from .choicemap import ChoiceMap, Selection
+from .choicemap import ChoiceMap, Mask, Selection
 from .ops import KeyBatch
 from .runtime import get_ops
 
@@ -521,7 +521,8 @@ class GenerateHandler(_Handler):
     def handle_trace(self, addr, gen_fn, args):
         sub = self.constraint.get_submap(*(addr if isinstance(addr, tuple) else (addr,)))
         leaf = isinstance(gen_fn, Distribution)
-        sub_key = site_keys(self.key, self.sites.next(not leaf or sub.static_is_empty()), leaf)
+        draws = not leaf or sub.static_is_empty() or isinstance(sub.get_value(), Mask)  # masked sites sample too
+        sub_key = site_keys(self.key, self.sites.next(draws), leaf)
         tr, w = gen_fn.generate(sub_key, sub, args)
         self.weight = self.weight + w
         self.record(addr, tr)
@@ -750,6 +751,23 @@ class Distribution(GenerativeFunction):
             return self.simulate(key, args), 0.0
         pk, batched = as_particle_keys(key)
         n = pk.n
+        if isinstance(v, Mask):
+            # distribution.py:129-142: cond(flag, importance, simulate), here over a whole column — every
+            # element is sampled AND scored at the constrained value, the flag selects per element
+            if isinstance(v.flag, bool):
+                return self.generate(key, ChoiceMap.choice(v.value) if v.flag else ChoiceMap.empty(), args)
+            flag = v.flag.to(get_ops().device()).reshape(-1).bool()
+            if flag.numel() != n:
+                raise ValueError(f"mask flag has {flag.numel()} elements for a population of {n}")
+            sim_v, sim_s = self._sample(pk, args)
+            con_v = self._canonical_value(v.value, n)
+            if not isinstance(con_v, torch.Tensor) or con_v.dim() == 0:
+                con_v = torch.zeros_like(sim_v) + con_v
+            con_v = con_v.to(device=sim_v.device, dtype=sim_v.dtype).reshape(-1)
+            con_s = self._logpdf(n, torch.where(flag, con_v, sim_v), args)  # unconstrained elements: any in-support value
+            value, score = torch.where(flag, con_v, sim_v), torch.where(flag, con_s, sim_s)
+            w = torch.where(flag, con_s, torch.zeros_like(con_s))
+            return DistributionTrace(self, args, value, score), w
         w = self._logpdf(n, v, args)
         if not batched:
             w = squeeze_leaf(w)

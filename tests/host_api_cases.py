@@ -527,6 +527,59 @@ def case_vmap(impl):
 
 
 # ---- fused bootstrap SMC ---------------------------------------------------------------------------------
+def case_vmap_indexed_constraints(impl):
+    """test_vmap_combinator.py:61-122: constraints on some / all indices of a vmapped site."""
+    @genjax.vmap(in_axes=(0,))
+    @gen
+    def kernel(x):
+        z = normal(x, 1.0) @ "z"
+        return z
+
+    key = genjax.random.key(314159, impl)
+    map_over = torch.arange(0, 3, dtype=torch.float32)
+    chm = C[jnp.arange(3), "z"].set(jnp.array([3.0, 2.0, 3.0]))  # one entry per index == the whole axis
+    _, w = kernel.importance(key, chm, (map_over,))
+    expect = sum(f(normal.assess(C.v(v), (m, 1.0))[0]) for v, m in ((3.0, 0.0), (2.0, 1.0), (3.0, 2.0)))
+    assert f(w) == pytest.approx(expect, rel=1e-6)
+    _, w_whole = kernel.importance(key, C[:, "z"].set(jnp.array([3.0, 2.0, 3.0])), (map_over,))
+    assert f(w_whole) == pytest.approx(f(w), rel=1e-6)
+    # a single index: only that element is constrained, the others are sampled (weight excludes them)
+    key, sub_key = jax.random.split(key)
+    tr, w = kernel.importance(sub_key, C[0, "z"].set(3.0), (map_over,))
+    assert f(w) == pytest.approx(f(normal.assess(C.v(3.0), (0.0, 1.0))[0]), rel=1e-6)
+    ch = tr.get_choices()
+    assert f(ch[0, "z"]) == 3.0 and f(ch[1, "z"]) != 3.0
+    assert f(tr.get_score()) == pytest.approx(sum(f(normal.logpdf(f(ch[i, "z"]), float(i), 1.0)) for i in range(3)), rel=1e-5)
+    zv = jnp.array([3.0, -1.0, 2.0])
+    tr, _ = kernel.importance(sub_key, C[jnp.arange(3), "z"].set(zv), (map_over,))
+    for i in range(3):
+        assert f(tr.get_choices()[i, "z"]) == f(zv[i])
+    # the unconstrained elements draw what an unconstrained run draws (same keys, same folds)
+    free = kernel.simulate(sub_key, (map_over,)).get_choices()
+    tr, _ = kernel.importance(sub_key, C[1, "z"].set(0.5), (map_over,))
+    assert f(tr.get_choices()[0, "z"]) == f(free[0, "z"]) and f(tr.get_choices()[2, "z"]) == f(free[2, "z"])
+    # nested vmaps (test_vmap_combinator.py:108-122)
+    @genjax.vmap(in_axes=(0,))
+    @gen
+    def higher_model(x):
+        return kernel(x) @ "outer"
+
+    _, w = higher_model.importance(key, C[0, "outer", 1, "z"].set(1.0), (torch.ones(3, 3),))
+    assert f(w) == pytest.approx(f(normal.assess(C.v(1.0), (1.0, 1.0))[0]), rel=1e-6)
+    # a population of particles over the same partially constrained site
+    n = 512
+    ptr, pw = kernel.importance(jax.random.split(key, n), C[2, "z"].set(0.25), (map_over,))
+    assert pw.shape == (n,) and torch.allclose(pw, torch.full_like(pw, f(normal.logpdf(0.25, 2.0, 1.0))), atol=1e-6)
+    pz = ptr.get_choices()[:, "z"] if False else ptr.inner.get_choices()["z"].reshape(n, 3)
+    assert bool((pz[:, 2] == 0.25).all()) and float(pz[:, 0].std()) > 0.5
+    # masks built by hand (choice_map.py mask): a flag column selects which particles are constrained
+    flag = torch.arange(n) % 2 == 0
+    tr, w = normal.importance(jax.random.split(key, n), C.v(torch.full((n,), 1.5)).mask(flag), (0.0, 1.0))
+    lp = f(normal.logpdf(1.5, 0.0, 1.0))
+    assert torch.equal(w != 0, flag.to(w.device)) and torch.allclose(w[::2], torch.full_like(w[::2], lp))
+    assert bool((tr.get_retval()[::2] == 1.5).all()) and float(tr.get_retval()[1::2].std()) > 0.5
+
+
 def case_bootstrap_smc(impl):
     from genjax._amd import workloads as W
 
@@ -600,4 +653,4 @@ def case_general_smc(impl):
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_fused_equals_eager, case_particle_collection, case_custom_proposal,
-             case_scan, case_vmap, case_bootstrap_smc, case_general_smc, case_update]
+             case_scan, case_vmap, case_vmap_indexed_constraints, case_bootstrap_smc, case_general_smc, case_update]
