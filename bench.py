@@ -138,7 +138,9 @@ def bench_importance(args, ops, rank, world):
         if timed:
             kernel_ms.extend(evs.values())
 
-    EVENT_EVERY = 4  # an event record is a queue barrier packet (~2-3 us of device time): sample the kernel
+    # an event record is a queue barrier packet (~2-3 us of device time): sample the kernel on every 8th pass
+    # (every 4th in short runs, so that at least ~6 launches are timed)
+    EVENT_EVERY = 8 if args.steps >= 48 else 4
     step_no = [0]
 
     def step(timed):
