@@ -129,7 +129,7 @@ def bench_importance(args, ops, rank, world):
         sh = ops.stream()
 
         def on_kernel(b, k):  # sample the kernel on every 4th pass, as in the single-device loop
-            if b % EVENT_EVERY == EVENT_EVERY - 1:
+            if b % EVENT_EVERY == 0:
                 if k == 0:
                     evs[b] = ev_pool.pop()
                 evs[b][k].record(sh)
@@ -146,7 +146,7 @@ def bench_importance(args, ops, rank, world):
     def step(timed):
         st = ops.stream()
         step_no[0] += 1
-        sample = step_no[0] % EVENT_EVERY == 0
+        sample = (step_no[0] - 1) % EVENT_EVERY == 0  # the first pass of a run is always timed
         if sample:
             e0, e1 = ev_pool.pop()
             e0.record(st)
@@ -162,6 +162,8 @@ def bench_importance(args, ops, rank, world):
         return b
 
     def run_steps(count, timed):
+        if count <= 0:
+            return None
         if not sharded:
             step_no[0] = 0
             for _ in range(count):

@@ -1288,6 +1288,30 @@ int gjx_plan_destroy(gjx_plan* p) {
   return GJX_OK;
 }
 
+// The hiprtc-specialised kernel of a plan for this key form (compiled and loaded on first use).
+static gjx_jit::Compiled& plan_compiled(gjx_plan* mp, const gjx_keys* pk) {
+  // PHILOX children of a lane-0 key share one cipher key: a variant keeps it in scalar registers
+  const bool laned = pk->impl == 1 && pk->mode == 1 && pk->parent_lane == 0;
+  gjx_jit::Compiled& c = mp->jit[laned ? 2 : pk->impl];
+  if (c.state == 0) {
+    std::lock_guard<std::mutex> lock(mp->jit_mu);
+    if (c.state == 0) {
+      gjx_jit::Gen<CSite, CArg> g;
+      g.impl = pk->impl; g.sites = mp->host; g.n_sites = mp->n_sites; g.laned = laned;
+      if (const char* e = std::getenv("GJX_JIT_MIN_WAVES")) g.min_waves = atoi(e);
+      const std::string src = g.run();
+      c.rows_per_block = g.rows_per_block;
+      c.state = gjx_jit::compile(src, pk->impl, &c) ? 1 : -1;
+    }
+  }
+  return c;
+}
+int gjx_plan_prepare(gjx_plan* p, const gjx_keys* pk) {
+  if (!p || !keys_ok(pk)) return GJX_ERR_INVALID;
+  if (!gjx_jit::enabled()) return plan_device_table(p);
+  return plan_compiled(p, pk).state == 1 ? GJX_OK : plan_device_table(p);
+}
+
 int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const* input_cols,
                        int n_input_cols, void* const* value_cols, int n_value_cols, float* score,
                        float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s,
@@ -1312,21 +1336,7 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
   KeySrc k = key_src(pk);
   // Specialised straight-line kernel for this site table (compiled once per plan and RNG scheme).
   if (gjx_jit::enabled()) {
-    gjx_plan* mp = const_cast<gjx_plan*>(p);
-    // PHILOX children of a lane-0 key share one cipher key: a variant keeps it in scalar registers
-    const bool laned = pk->impl == 1 && pk->mode == 1 && pk->parent_lane == 0;
-    gjx_jit::Compiled& c = mp->jit[laned ? 2 : pk->impl];
-    if (c.state == 0) {
-      std::lock_guard<std::mutex> lock(mp->jit_mu);
-      if (c.state == 0) {
-        gjx_jit::Gen<CSite, CArg> g;
-        g.impl = pk->impl; g.sites = p->host; g.n_sites = p->n_sites; g.laned = laned;
-        if (const char* e = std::getenv("GJX_JIT_MIN_WAVES")) g.min_waves = atoi(e);
-        const std::string src = g.run();
-        c.rows_per_block = g.rows_per_block;
-        c.state = gjx_jit::compile(src, pk->impl, &c) ? 1 : -1;
-      }
-    }
+    gjx_jit::Compiled& c = plan_compiled(const_cast<gjx_plan*>(p), pk);
     if (c.state == 1) {
       uint64_t nn = n;
       LseTail tail{nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -542,6 +542,7 @@ class PreparedImportance:
         self.lse, self.row_e_out, self.row_q_out = self.lse_all[:1], self.e_all[:1], self.q_all[:1]
         self.max, self.q = ops.empty(1, torch.float32), ops.empty(1, torch.int64)
         self._keys = ops._keys(kb, n)
+        ops.lib.call("gjx_plan_prepare", plan.handle, C.byref(self._keys))  # build the specialised kernel now
         self._ins = (C.c_void_p * max(1, len(self.inputs)))(*[ops._chk(t, torch.float32, n).value for t in self.inputs])
         self._outs = (C.c_void_p * max(1, len(self.values)))(*[t.data_ptr() for t in self.values])
         self._ws, self._nb = ops.workspace(abi.OP_LOGSUMEXP, n)

@@ -192,6 +192,10 @@ int gjx_plan_destroy(gjx_plan* p);
  * the generated HIP source (buf nullable; *needed = bytes incl. NUL) and an offline compile check
  * (needs no GPU).  The oracle build returns GJX_ERR_UNSUPPORTED for both. */
 int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t buf_len, size_t* needed);
+/* Build (hiprtc) and load now the kernel gjx_importance_run would build on its first launch with
+ * this key form, so that no launch pays the ~0.2 s compilation.  Optional; the oracle build returns
+ * GJX_OK and does nothing. */
+int gjx_plan_prepare(gjx_plan* p, const gjx_keys* particle_keys);
 int gjx_plan_compile_check(const gjx_plan* p, int impl);
 /* particle_keys: the per-particle keys BEFORE the per-site fold (has_fold must be 0).
  * input_cols / value_cols: host arrays of dev pointers (each column dev [n], 4-byte elements:

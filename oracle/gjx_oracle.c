@@ -425,6 +425,7 @@ static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, sit
   *sc_out = sc;
 }
 
+int gjx_plan_prepare(gjx_plan* p, const gjx_keys* pk) { return (p && keys_ok(pk)) ? GJX_OK : GJX_ERR_INVALID; }
 int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const* input_cols,
                        int n_input_cols, void* const* value_cols, int n_value_cols, float* score,
                        float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s,
