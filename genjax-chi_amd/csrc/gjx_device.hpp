@@ -681,8 +681,8 @@ struct ResampleArgs {
   Key rkey;                   // resampling key (its sub-stream 0 gives the comb offset)
   int rkey_has_fold;
   uint32_t rkey_fold;
-  uint64_t* q_total_out;      // nullable: block 0 stores the total mass (= sum of tile_sums)
-  const uint64_t* tile_prefix;  // nullable: exclusive prefix [ntiles + 1] of tile_sums, precomputed for
+  uint64_t* q_total_out = nullptr;  // nullable: block 0 stores the total mass (= sum of tile_sums)
+  const uint64_t* tile_prefix = nullptr;  // nullable: exclusive prefix [ntiles + 1] of tile_sums, precomputed for
                                 // large populations (otherwise every workgroup reduces tile_sums itself)
 };
 
