@@ -369,78 +369,64 @@ GJX_HD float std_normal(uint32_t bits) {
   return 1.41421356237309505f * m_erfinv(u);
 }
 
-// --- two particles per lane: the same operation sequences on 2-vectors, which gfx950 issues as
-// packed f32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of float work per
-// instruction).  IEEE per element, so results are bit-identical to the scalar forms.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
-GJX_DEV f32x2 splat2(float v) { return (f32x2){v, v}; }
-GJX_DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-// m_log restricted to positive NORMAL floats (no zero / subnormal handling needed by callers).
-GJX_DEV f32x2 m_log2n(f32x2 x) {
-  const u32x2 ix = __builtin_bit_cast(u32x2, x);
-  const u32x2 t = ix - 0x3f3504f3u;
-  const i32x2 e = __builtin_bit_cast(i32x2, t) >> 23;
-  const f32x2 m = __builtin_bit_cast(f32x2, (t & 0x007fffffu) + 0x3f3504f3u);
-  const f32x2 f = m - 1.0f;
-  const f32x2 z = f * f;
-  f32x2 p = splat2(7.0376836292E-2f);
-  p = fma2(p, f, splat2(-1.1514610310E-1f));
-  p = fma2(p, f, splat2(1.1676998740E-1f));
-  p = fma2(p, f, splat2(-1.2420140846E-1f));
-  p = fma2(p, f, splat2(1.4249322787E-1f));
-  p = fma2(p, f, splat2(-1.6668057665E-1f));
-  p = fma2(p, f, splat2(2.0000714765E-1f));
-  p = fma2(p, f, splat2(-2.4999993993E-1f));
-  p = fma2(p, f, splat2(3.3333331174E-1f));
-  f32x2 y = (p * f) * z;
-  const f32x2 fe = __builtin_convertvector(e, f32x2);
-  y = fma2(fe, splat2(-2.12194440e-4f), y);
-  y = fma2(splat2(-0.5f), z, y);
-  f32x2 r = f + y;
-  r = fma2(fe, splat2(0.693359375f), r);
-  return r;
+// --- PHILOX normal sites: Box-Muller over PAIRS OF PARTICLES.  Particles j0 = j & ~1 and j1 = j0 + 1 of a
+// key batch (key lanes j0+1, j0+2) share one transform at every Normal site: the radius comes from j0's
+// draw word, the angle from j1's, j0 takes the cosine and j1 the sine — two independent standard normals
+// for ONE log, one sqrt and one sine/cosine pair, against a log + erfinv polynomial per normal.  A lane
+// that owns both particles (the specialised importance kernel) pays ~35 instructions per normal instead
+// of ~50; each particle still consumes exactly one word per site, so keys, blocks and draw indices are
+// unchanged.  All operations are IEEE-exact (Cephes sinf / cosf kernels on [0, pi/4] after an exact
+// octant reduction of the 24-bit angle), so HIP == oracle bit for bit.  THREEFRY keeps jax's erfinv form.
+GJX_HD void bm_pair(uint32_t w_radius, uint32_t w_angle, float& z_cos, float& z_sin) {
+  // radius: u in (0, 1] with full float resolution near 0 (tails to 6.6 sigma)
+  const float u = ((float)w_radius + 1.0f) * 2.3283064365386963e-10f;
+  const float r = __builtin_sqrtf(-2.0f * m_log_normal(u));
+  // angle = 2 pi a / 2^24: octant (3 bits) + fraction (21 bits)
+  const uint32_t a = w_angle >> 8;
+  const uint32_t oct = a >> 21;
+  const float f = (float)(a & 0x1fffffu) * 4.76837158203125e-07f;
+  const float g = (oct & 1u) ? 1.0f - f : f;
+  const float x = g * 0.78539816339744831f;  // [0, pi/4]
+  const float z = x * x;
+  float ps = -1.9515295891E-4f;
+  ps = __builtin_fmaf(ps, z, 8.3321608736E-3f);
+  ps = __builtin_fmaf(ps, z, -1.6666654611E-1f);
+  const float s = __builtin_fmaf(ps * z, x, x);
+  float pc = 2.443315711809948E-5f;
+  pc = __builtin_fmaf(pc, z, -1.388731625493765E-3f);
+  pc = __builtin_fmaf(pc, z, 4.166664568298827E-2f);
+  const float c = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+  const bool swap = ((oct + 1u) & 2u) != 0u;  // octants 1, 2, 5, 6
+  float cs = swap ? s : c, sn = swap ? c : s;
+  cs = ((oct + 2u) & 4u) ? -cs : cs;  // cosine < 0 in octants 2..5
+  sn = (oct & 4u) ? -sn : sn;         // sine < 0 in octants 4..7
+  z_cos = r * cs;
+  z_sin = r * sn;
 }
-GJX_DEV float erfinv_tail(float w) {  // the w >= 5 branch of m_erfinv
-  w = __builtin_sqrtf(w) - 3.0f;
-  float p = -0.000200214257f;
-  p = __builtin_fmaf(p, w, 0.000100950558f);
-  p = __builtin_fmaf(p, w, 0.00134934322f);
-  p = __builtin_fmaf(p, w, -0.00367342844f);
-  p = __builtin_fmaf(p, w, 0.00573950773f);
-  p = __builtin_fmaf(p, w, -0.0076224613f);
-  p = __builtin_fmaf(p, w, 0.00943887047f);
-  p = __builtin_fmaf(p, w, 1.00167406f);
-  p = __builtin_fmaf(p, w, 2.83297682f);
-  return p;
+// Draw word number f (packed single-word draws) of key k — Stream::bits32(0) of a folded stream.
+constexpr uint32_t kTagTwin = 0x54u;  // 'T': the angle word of a lane-0 key (it has no partner particle)
+GJX_HD uint32_t philox_draw_word(Key k, uint32_t f, uint32_t tag) {
+  uint32_t o[4];
+  philox4x32(k.k0, k.k1, k.l0, k.l1, f >> 2, tag, o[0], o[1], o[2], o[3]);
+  const uint32_t sel = f & 3u;
+  return sel == 0 ? o[0] : (sel == 1 ? o[1] : (sel == 2 ? o[2] : o[3]));
 }
-// std_normal for two independent 32-bit draws.
-GJX_DEV f32x2 std_normal2(uint32_t b0, uint32_t b1) {
-  const float lo = -0.99999994f;
-  f32x2 u = (f32x2){uniform01(b0), uniform01(b1)} * 2.0f + lo;
-  u.x = u.x > lo ? u.x : lo;
-  u.y = u.y > lo ? u.y : lo;
-  const f32x2 arg = (1.0f - u) * (1.0f + u);  // in (1e-7, 1]: positive normal
-  const f32x2 w = -m_log2n(arg);
-  const f32x2 wc = w - 2.5f;
-  f32x2 p = splat2(2.81022636e-08f);
-  p = fma2(p, wc, splat2(3.43273939e-07f));
-  p = fma2(p, wc, splat2(-3.5233877e-06f));
-  p = fma2(p, wc, splat2(-4.39150654e-06f));
-  p = fma2(p, wc, splat2(0.00021858087f));
-  p = fma2(p, wc, splat2(-0.00125372503f));
-  p = fma2(p, wc, splat2(-0.00417768164f));
-  p = fma2(p, wc, splat2(0.246640727f));
-  p = fma2(p, wc, splat2(1.50140941f));
-  if (!(w.x < 5.0f)) p.x = erfinv_tail(w.x);  // rare (0.3 % of draws)
-  if (!(w.y < 5.0f)) p.y = erfinv_tail(w.y);
-  return 1.41421356237309505f * (p * u);
-}
-GJX_DEV f32x2 logpdf_normal_pre2(f32x2 x, f32x2 loc, float rs, float lognorm) {
-  const f32x2 d = x * rs - loc * rs;
-  return (-0.5f * d) * d - lognorm;
+// The standard normal of a Normal SITE (generic, one particle: both words of its pair are derived here;
+// kernels that own the whole pair use bm_pair directly).
+template <int IMPL>
+GJX_HD float site_normal(const Stream<IMPL>& st) {
+  if (IMPL == 0 || !st.hf) return std_normal(st.bits32(0));
+  float zc, zs;
+  if ((st.k.l0 | st.k.l1) == 0u) {  // lane-0 key: radius and angle words from the key itself
+    bm_pair(philox_draw_word(st.k, st.f, kTagDraw), philox_draw_word(st.k, st.f, kTagTwin), zc, zs);
+    return zc;
+  }
+  const uint64_t j = (((uint64_t)st.k.l1 << 32) | st.k.l0) - 1u;
+  const uint64_t la = (j & ~(uint64_t)1) + 1u, lb = la + 1u;
+  const Key ka{st.k.k0, st.k.k1, (uint32_t)la, (uint32_t)(la >> 32)};
+  const Key kb{st.k.k0, st.k.k1, (uint32_t)lb, (uint32_t)(lb >> 32)};
+  bm_pair(philox_draw_word(ka, st.f, kTagDraw), philox_draw_word(kb, st.f, kTagDraw), zc, zs);
+  return (j & 1u) ? zs : zc;
 }
 
 // --- log-densities (TFP formulas).  The *_pre forms take the per-site constants a plan hoists.
@@ -452,9 +438,6 @@ GJX_HD float logpdf_normal_pre(float x, float loc, float rs, float lognorm) {
 }
 GJX_HD float logpdf_normal(float x, float loc, float scale) {
   return logpdf_normal_pre(x, loc, normal_rs(scale), normal_lognorm(scale));
-}
-GJX_DEV f32x2 logpdf_normal2(f32x2 x, f32x2 loc, f32x2 scale) {
-  return (f32x2){logpdf_normal(x.x, loc.x, scale.x), logpdf_normal(x.y, loc.y, scale.y)};
 }
 GJX_HD float xlogy(float a, float y) { return a == 0.0f ? 0.0f : a * m_log(y); }
 GJX_HD float gamma_lognorm(float conc, float rate) { return m_lgamma(conc) - conc * m_log(rate); }
@@ -730,10 +713,11 @@ template <bool DEVICE_SCOPE>
 GJX_DEV void lse_rows_block(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows,
                             int32_t* out_e, uint64_t* out_q, float* out_lse, uint64_t* out_record) {
   __shared__ int32_t she[kBlock / kWave];
+  const int nthr = (int)blockDim.x, nwave = nthr / kWave;  // 256 (k_lse_rows, generic tail) or 128 (paired kernel)
   __shared__ unsigned long long shb[kLseBuckets];
   constexpr int kPer = 16;
   constexpr int kNear = 4;  // shifts 0..3 (practically every row) accumulate in registers
-  const bool in_regs = n_rows <= (uint64_t)kPer * kBlock;
+  const bool in_regs = n_rows <= (uint64_t)kPer * nthr;
   int32_t ev[kPer];
   uint64_t sv[kPer];
   int32_t e = kRowEmpty;
@@ -741,14 +725,14 @@ GJX_DEV void lse_rows_block(const int32_t* row_e, const uint64_t* row_s, uint64_
   if (in_regs) {
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-      const uint64_t b = threadIdx.x + (uint64_t)k * kBlock;
+      const uint64_t b = threadIdx.x + (uint64_t)k * nthr;
       ev[k] = b < n_rows ? lse_load_e<DEVICE_SCOPE>(row_e + b) : kRowEmpty;
       sv[k] = b < n_rows ? lse_load_s<DEVICE_SCOPE>(row_s + b) : 0;
     }
 #pragma unroll
     for (int k = 0; k < kPer; ++k) e = ev[k] > e ? ev[k] : e;
   } else {
-    for (uint64_t b = threadIdx.x; b < n_rows; b += kBlock) {
+    for (uint64_t b = threadIdx.x; b < n_rows; b += nthr) {
       const int32_t eb = lse_load_e<DEVICE_SCOPE>(row_e + b);
       e = eb > e ? eb : e;
     }
@@ -761,8 +745,7 @@ GJX_DEV void lse_rows_block(const int32_t* row_e, const uint64_t* row_s, uint64_
   if ((threadIdx.x & 63) == 0) she[threadIdx.x >> 6] = e;
   __syncthreads();
   e = she[0];
-#pragma unroll
-  for (int i = 1; i < kBlock / kWave; ++i) e = she[i] > e ? she[i] : e;
+  for (int i = 1; i < nwave; ++i) e = she[i] > e ? she[i] : e;
   uint64_t near[kNear] = {0, 0, 0, 0};
   auto add_row = [&](int32_t eb, uint64_t sb) {
     if (eb == kRowEmpty) return;
@@ -775,7 +758,7 @@ GJX_DEV void lse_rows_block(const int32_t* row_e, const uint64_t* row_s, uint64_
 #pragma unroll
     for (int k = 0; k < kPer; ++k) add_row(ev[k], sv[k]);
   } else {
-    for (uint64_t b = threadIdx.x; b < n_rows; b += kBlock)
+    for (uint64_t b = threadIdx.x; b < n_rows; b += nthr)
       add_row(lse_load_e<DEVICE_SCOPE>(row_e + b), lse_load_s<DEVICE_SCOPE>(row_s + b));
   }
 #pragma unroll

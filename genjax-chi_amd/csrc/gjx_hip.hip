@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_sample_normal(KeySrc ks, Opnd loc, O
   GJX_TILE_LOOP(i, n) {
     const Stream<IMPL> st(key_at<IMPL>(ks, i), ks.has_fold != 0, ks.fold);
     const float mu = loc.at(i), sg = scale.at(i);
-    const float eps = std_normal(st.bits32(0));
+    const float eps = site_normal<IMPL>(st);
     const float t = sg * eps;
     const float v = mu + t;
     val[i] = v;
@@ -354,7 +354,8 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
         const uint32_t fold = IMPL == 0 ? (uint32_t)(q + 1) : draws++;
         // single-word draws (normal / bernoulli / inverse-CDF categorical)
         uint32_t bits[kPPT];
-        const bool one_word = dist == GJX_DIST_NORMAL || dist == GJX_DIST_BERNOULLI ||
+        // (PHILOX Normal sites pair particles, site_normal: their words are derived there)
+        const bool one_word = (dist == GJX_DIST_NORMAL && IMPL == 0) || dist == GJX_DIST_BERNOULLI ||
                               (dist == GJX_DIST_CATEGORICAL && st.cat_mode == 1);
         if (one_word) {
           if (IMPL == 1) {
@@ -379,7 +380,8 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
           vf[r] = 0.0f;
           vi[r] = 0;
           if (dist == GJX_DIST_NORMAL) {
-            const float t = a1[r] * std_normal(bits[r]);
+            const float eps = IMPL == 0 ? std_normal(bits[r]) : site_normal<IMPL>(Stream<IMPL>(pkey[r], true, fold));
+            const float t = a1[r] * eps;
             vf[r] = a0[r] + t;
           } else if ((MASK & (1 << GJX_DIST_BERNOULLI)) && dist == GJX_DIST_BERNOULLI) {
             vi[r] = uniform01(bits[r]) < a0[r] ? 1 : 0;
@@ -1289,9 +1291,14 @@ int gjx_plan_destroy(gjx_plan* p) {
 }
 
 // The hiprtc-specialised kernel of a plan for this key form (compiled and loaded on first use).
-static gjx_jit::Compiled& plan_compiled(gjx_plan* mp, const gjx_keys* pk) {
-  // PHILOX children of a lane-0 key share one cipher key: a variant keeps it in scalar registers
-  const bool laned = pk->impl == 1 && pk->mode == 1 && pk->parent_lane == 0;
+static gjx_jit::Compiled& plan_compiled(gjx_plan* mp, const gjx_keys* pk, bool pairable) {
+  // PHILOX children of a lane-0 key share one cipher key, and an even first index keeps particle pairs
+  // (2i, 2i+1) together: the paired kernel form (gjx_plan_jit.hpp)
+  static const bool paired_ok = [] {
+    const char* e = std::getenv("GJX_JIT_PAIRED");  // 0: always the one-particle-per-lane form (test knob)
+    return !(e && e[0] == '0');
+  }();
+  const bool laned = paired_ok && pairable && pk->impl == 1 && pk->mode == 1 && pk->parent_lane == 0 && (pk->first & 1) == 0;
   gjx_jit::Compiled& c = mp->jit[laned ? 2 : pk->impl];
   if (c.state == 0) {
     std::lock_guard<std::mutex> lock(mp->jit_mu);
@@ -1300,6 +1307,7 @@ static gjx_jit::Compiled& plan_compiled(gjx_plan* mp, const gjx_keys* pk) {
       g.impl = pk->impl; g.sites = mp->host; g.n_sites = mp->n_sites; g.laned = laned;
       if (const char* e = std::getenv("GJX_JIT_MIN_WAVES")) g.min_waves = atoi(e);
       const std::string src = g.run();
+      c.block = g.block;
       c.rows_per_block = g.rows_per_block;
       c.state = gjx_jit::compile(src, pk->impl, &c) ? 1 : -1;
     }
@@ -1309,7 +1317,8 @@ static gjx_jit::Compiled& plan_compiled(gjx_plan* mp, const gjx_keys* pk) {
 int gjx_plan_prepare(gjx_plan* p, const gjx_keys* pk) {
   if (!p || !keys_ok(pk)) return GJX_ERR_INVALID;
   if (!gjx_jit::enabled()) return plan_device_table(p);
-  return plan_compiled(p, pk).state == 1 ? GJX_OK : plan_device_table(p);
+  plan_compiled(p, pk, false);  // both forms: which one a launch takes depends on n and on buffer alignment
+  return plan_compiled(p, pk, true).state == 1 ? GJX_OK : plan_device_table(p);
 }
 
 int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const* input_cols,
@@ -1336,7 +1345,10 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
   KeySrc k = key_src(pk);
   // Specialised straight-line kernel for this site table (compiled once per plan and RNG scheme).
   if (gjx_jit::enabled()) {
-    gjx_jit::Compiled& c = plan_compiled(const_cast<gjx_plan*>(p), pk);
+    // the paired form writes both particles of a lane with one 8-byte store: even n, 8-byte aligned columns
+    bool pairable = (n & 1) == 0 && ((uintptr_t)logw & 7) == 0 && ((uintptr_t)score & 7) == 0;
+    for (int c = 0; c < n_value_cols && pairable; ++c) pairable = ((uintptr_t)value_cols[c] & 7) == 0;
+    gjx_jit::Compiled& c = plan_compiled(const_cast<gjx_plan*>(p), pk, pairable);
     if (c.state == 1) {
       uint64_t nn = n;
       LseTail tail{nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1348,7 +1360,7 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
         return e ? (uint64_t)strtoull(e, nullptr, 10) : 0ull;
       }();
       if (grid_cap && rows > grid_cap) rows = grid_cap;  // the kernel strides over rows
-      if (hipModuleLaunchKernel(c.fn, (unsigned)(rows > 0x7fffffffull ? 0x7fffffffull : rows), 1, 1, kBlock, 1, 1, 0,
+      if (hipModuleLaunchKernel(c.fn, (unsigned)(rows > 0x7fffffffull ? 0x7fffffffull : rows), 1, 1, (unsigned)c.block, 1, 1, 0,
                                 S(s), args, nullptr) != hipSuccess)
         return GJX_ERR_LAUNCH;
       return launch_status();

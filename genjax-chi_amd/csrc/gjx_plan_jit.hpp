@@ -40,7 +40,8 @@ inline std::string plit(const void* p) {
 // Emits the walk of one site table as straight-line HIP, in exactly the interpreter's operation
 // order.  mode 0 = importance (particle index `i`, particle key `pkey`, input columns, score and
 // output columns); mode 1 = SMC step / init (slot `j`, `a.step_key`, ancestor state `st_k`,
-// observation constants `a.obs[]`, weight only).
+// observation constants `a.obs[]`, weight only).  `sfx` is appended to every per-particle name, so two
+// emitters ("A", "B") can interleave the walks of the two particles a lane owns.
 template <class CSiteT, class CArgT>
 struct SiteEmitter {
   std::ostringstream& o;
@@ -48,21 +49,22 @@ struct SiteEmitter {
   const CSiteT* sites;
   int n_sites;
   const char* ind;
+  std::string sfx = "";
+  int cur_blk = -1;
+  bool store_values = true;  // false: the caller stores (the paired kernel writes both particles at once)
 
   static bool is_int(const CSiteT& s) { return s.dist >= GJX_DIST_BERNOULLI; }
-  std::string val_f32(int site) const {
-    return is_int(sites[site]) ? "(float)vi" + std::to_string(site) : "vf" + std::to_string(site);
-  }
+  std::string nm(const char* base, int q) const { return std::string(base) + std::to_string(q) + sfx; }
+  std::string val_f32(int site) const { return is_int(sites[site]) ? "(float)" + nm("vi", site) : nm("vf", site); }
   std::string val_i32(int site) const {
-    return is_int(sites[site]) ? "vi" + std::to_string(site)
-                               : "(int32_t)__builtin_rintf(vf" + std::to_string(site) + ")";
+    return is_int(sites[site]) ? nm("vi", site) : "(int32_t)__builtin_rintf(" + nm("vf", site) + ")";
   }
   std::string arg(const CArgT& a) const {
     switch (a.kind) {
       case GJX_ARG_CONST: return flit(a.offset);
       case GJX_ARG_SITE: return "((" + flit(a.scale) + " * " + val_f32(a.ref_site) + ") + " + flit(a.offset) + ")";
       case GJX_ARG_INPUT:
-        return "((" + flit(a.scale) + " * cols.in[" + std::to_string(a.ref) + "][i]) + " + flit(a.offset) + ")";
+        return "((" + flit(a.scale) + " * cols.in[" + std::to_string(a.ref) + "][li" + sfx + "]) + " + flit(a.offset) + ")";
       case GJX_ARG_STATE: return "((" + flit(a.scale) + " * st_" + std::to_string(a.ref) + ") + " + flit(a.offset) + ")";
       case GJX_ARG_OBS: return "((" + flit(a.scale) + " * a.obs[" + std::to_string(a.ref) + "]) + " + flit(a.offset) + ")";
       default: return plit(a.table) + "[" + val_i32(a.ref_site) + "]";
@@ -81,107 +83,131 @@ struct SiteEmitter {
     for (int p = 0; p < q; ++p) d += sites[p].observed ? 0u : 1u;
     return d;
   }
+  bool one_word(const CSiteT& st) const {
+    return st.dist == GJX_DIST_NORMAL || st.dist == GJX_DIST_BERNOULLI ||
+           (st.dist == GJX_DIST_CATEGORICAL && st.cat_mode == 1);
+  }
+  // Importance plans under PHILOX pair particles at Normal sites (gjx_device.hpp bm_pair / site_normal);
+  // SMC steps keep the single-draw inverse-CDF form (one latent per slot-step: a pair would cost two blocks).
+  bool pairs_normals() const { return impl == 1 && mode == 0; }
 
-  void run() {
-    const std::string I = std::to_string(impl);
-    int cur_blk = -1;
-    for (int q = 0; q < n_sites; ++q) {
-      const CSiteT& st = sites[q];
-      const std::string Q = std::to_string(q);
-      const uint32_t fold = fold_of(q);
-      o << ind << "// site " << q << " dist " << st.dist << (st.observed ? " observed" : " latent") << "\n";
-      std::string row;
-      if (st.dist == GJX_DIST_CATEGORICAL) {
-        std::string rr;
-        if (st.a0.kind == GJX_ARG_SITE) rr = val_i32(st.a0.ref_site);
-        else if (st.a0.kind == GJX_ARG_CONST) rr = "(int32_t)__builtin_rintf(" + flit(st.a0.offset) + ")";
-        else rr = "(int32_t)__builtin_rintf(" + arg(st.a0) + ")";
-        o << ind << "int32_t rr" << Q << " = " << rr << "; rr" << Q << " = rr" << Q << " < 0 ? 0 : (rr" << Q
-          << " >= " << st.n_rows << " ? " << st.n_rows - 1 << " : rr" << Q << ");\n";
-        o << ind << "const float* row" << Q << " = " << plit(st.logits) << " + (size_t)rr" << Q << " * " << st.n_cat << ";\n";
-        row = "row" + Q;
-      } else {
-        o << ind << "const float a0_" << Q << " = " << arg(st.a0) << ";\n";
-        if (st.dist != GJX_DIST_BERNOULLI) o << ind << "const float a1_" << Q << " = " << arg(st.a1) << ";\n";
+  // Part 1 of site q: arguments, the observed value, or the draw word(s).
+  void head(int q) {
+    const CSiteT& st = sites[q];
+    const std::string Q = std::to_string(q) + sfx;
+    const uint32_t fold = fold_of(q);
+    o << ind << "// site " << q << sfx << " dist " << st.dist << (st.observed ? " observed" : " latent") << "\n";
+    if (st.dist == GJX_DIST_CATEGORICAL) {
+      std::string rr;
+      if (st.a0.kind == GJX_ARG_SITE) rr = val_i32(st.a0.ref_site);
+      else if (st.a0.kind == GJX_ARG_CONST) rr = "(int32_t)__builtin_rintf(" + flit(st.a0.offset) + ")";
+      else rr = "(int32_t)__builtin_rintf(" + arg(st.a0) + ")";
+      o << ind << "int32_t rr" << Q << " = " << rr << "; rr" << Q << " = rr" << Q << " < 0 ? 0 : (rr" << Q
+        << " >= " << st.n_rows << " ? " << st.n_rows - 1 << " : rr" << Q << ");\n";
+      o << ind << "const float* row" << Q << " = " << plit(st.logits) << " + (size_t)rr" << Q << " * " << st.n_cat << ";\n";
+    } else {
+      o << ind << "const float a0_" << Q << " = " << arg(st.a0) << ";\n";
+      if (st.dist != GJX_DIST_BERNOULLI) o << ind << "const float a1_" << Q << " = " << arg(st.a1) << ";\n";
+    }
+    if (st.observed) {
+      std::string ov;
+      if (st.obs.kind == GJX_ARG_CONST) ov = flit(st.obs.offset);
+      else if (st.obs.kind == GJX_ARG_OBS) ov = "a.obs[" + std::to_string(st.obs.ref) + "]";
+      else ov = "cols.in[" + std::to_string(st.obs.ref) + "][li" + sfx + "]";
+      if (is_int(st)) o << ind << "const int32_t vi" << Q << " = (int32_t)__builtin_rintf(" << ov << ");\n";
+      else o << ind << "const float vf" << Q << " = " << ov << ";\n";
+      return;
+    }
+    if (!one_word(st)) return;
+    if (impl == 1) {
+      // word fold&3 of the packed draw block fold>>2 of the particle / slot key
+      const int blk = (int)(fold >> 2);
+      const uint32_t word = fold & 3u;
+      const std::string B = std::to_string(blk) + sfx;
+      if (blk != cur_blk) {
+        cur_blk = blk;
+        o << ind << "uint32_t pw" << B << "_0, pw" << B << "_1, pw" << B << "_2, pw" << B << "_3;\n";
+        o << ind << "philox4x32(pkey" << sfx << ".k0, pkey" << sfx << ".k1, pkey" << sfx << ".l0, pkey" << sfx << ".l1, " << blk
+          << "u, kTagDraw, pw" << B << "_0, pw" << B << "_1, pw" << B << "_2, pw" << B << "_3);\n";
       }
-      const bool isint = is_int(st);
-      if (st.observed) {
-        std::string ov;
-        if (st.obs.kind == GJX_ARG_CONST) ov = flit(st.obs.offset);
-        else if (st.obs.kind == GJX_ARG_OBS) ov = "a.obs[" + std::to_string(st.obs.ref) + "]";
-        else ov = "cols.in[" + std::to_string(st.obs.ref) + "][i]";
-        if (isint) o << ind << "const int32_t vi" << Q << " = (int32_t)__builtin_rintf(" << ov << ");\n";
-        else o << ind << "const float vf" << Q << " = " << ov << ";\n";
-      } else {
-        const bool one_word = st.dist == GJX_DIST_NORMAL || st.dist == GJX_DIST_BERNOULLI ||
-                              (st.dist == GJX_DIST_CATEGORICAL && st.cat_mode == 1);
-        if (one_word) {
-          if (impl == 1) {
-            // word fold&3 of the packed draw block fold>>2 of the particle / slot key
-            const int blk = (int)(fold >> 2);
-            const uint32_t word = fold & 3u;
-            if (blk != cur_blk) {
-              cur_blk = blk;
-              o << ind << "uint32_t pw" << blk << "_0, pw" << blk << "_1, pw" << blk << "_2, pw" << blk << "_3;\n";
-              o << ind << "philox4x32(pkey.k0, pkey.k1, pkey.l0, pkey.l1, " << blk << "u, kTagDraw, pw" << blk << "_0, pw" << blk
-                << "_1, pw" << blk << "_2, pw" << blk << "_3);\n";
-            }
-            o << ind << "const uint32_t bits" << Q << " = pw" << blk << "_" << word << ";\n";
-          } else {
-            o << ind << "const uint32_t bits" << Q << " = Stream<0>(pkey, true, " << fold << "u).bits32(0);\n";
-          }
-        }
-        switch (st.dist) {
-          case GJX_DIST_NORMAL:
-            o << ind << "const float t" << Q << " = a1_" << Q << " * std_normal(bits" << Q << ");\n";
-            o << ind << "const float vf" << Q << " = a0_" << Q << " + t" << Q << ";\n";
-            break;
-          case GJX_DIST_BERNOULLI:
-            o << ind << "const int32_t vi" << Q << " = uniform01(bits" << Q << ") < a0_" << Q << " ? 1 : 0;\n";
-            break;
-          case GJX_DIST_GAMMA:
-            o << ind << "const Stream<" << I << "> strm" << Q << "(pkey, true, " << fold << "u);\n";
-            o << ind << "const float vf" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 0, a0_" << Q << ") / a1_" << Q << ";\n";
-            break;
-          case GJX_DIST_BETA:
-            o << ind << "const Stream<" << I << "> strm" << Q << "(pkey, true, " << fold << "u);\n";
-            o << ind << "const float g1_" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 0, a0_" << Q << ");\n";
-            o << ind << "const float g2_" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 1, a1_" << Q << ");\n";
-            o << ind << "const float vf" << Q << " = g1_" << Q << " / (g1_" << Q << " + g2_" << Q << ");\n";
-            break;
-          default:
-            if (st.cat_mode == 0) {
-              o << ind << "const Stream<" << I << "> strm" << Q << "(pkey, true, " << fold << "u);\n";
-              o << ind << "const int32_t vi" << Q << " = jcat_gumbel<" << I << ">(" << row << ", " << st.n_cat << "u, strm" << Q << ");\n";
-            } else {
-              o << ind << "const int32_t vi" << Q << " = jcat_invcdf(" << row << ", " << st.n_cat << "u, bits" << Q << ");\n";
-            }
-        }
-      }
-      std::string lp;
-      const std::string v = (isint ? "vi" : "vf") + Q;
+      o << ind << "const uint32_t bits" << Q << " = pw" << B << "_" << word << ";\n";
+    } else {
+      o << ind << "const uint32_t bits" << Q << " = Stream<0>(pkey" << sfx << ", true, " << fold << "u).bits32(0);\n";
+    }
+  }
+
+  // Part 2 of site q: the sampled value (Normal sites take their standard normal from `eps`: an expression
+  // or, empty, this particle's own derivation), the log-density, the accumulators and the stored column.
+  void tail(int q, const std::string& eps = "") {
+    const CSiteT& st = sites[q];
+    const std::string I = std::to_string(impl), Q = std::to_string(q) + sfx, K = "pkey" + sfx;
+    const uint32_t fold = fold_of(q);
+    const std::string row = "row" + Q;
+    const bool isint = is_int(st);
+    if (!st.observed) {
       switch (st.dist) {
-        case GJX_DIST_NORMAL:
-          lp = st.pre ? "logpdf_normal_pre(" + v + ", a0_" + Q + ", " + flit(st.pre0) + ", " + flit(st.pre1) + ")"
-                      : "logpdf_normal(" + v + ", a0_" + Q + ", a1_" + Q + ")";
+        case GJX_DIST_NORMAL: {
+          std::string e = eps;
+          if (e.empty())
+            e = pairs_normals() ? "site_normal<1>(Stream<1>(" + K + ", true, " + std::to_string(fold) + "u))"
+                                : "std_normal(bits" + Q + ")";
+          o << ind << "const float t" << Q << " = a1_" << Q << " * " << e << ";\n";
+          o << ind << "const float vf" << Q << " = a0_" << Q << " + t" << Q << ";\n";
+          break;
+        }
+        case GJX_DIST_BERNOULLI:
+          o << ind << "const int32_t vi" << Q << " = uniform01(bits" << Q << ") < a0_" << Q << " ? 1 : 0;\n";
           break;
         case GJX_DIST_GAMMA:
-          lp = st.pre ? "logpdf_gamma_pre(" + v + ", a0_" + Q + ", a1_" + Q + ", " + flit(st.pre1) + ")"
-                      : "logpdf_gamma(" + v + ", a0_" + Q + ", a1_" + Q + ")";
+          o << ind << "const Stream<" << I << "> strm" << Q << "(" << K << ", true, " << fold << "u);\n";
+          o << ind << "const float vf" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 0, a0_" << Q << ") / a1_" << Q << ";\n";
           break;
         case GJX_DIST_BETA:
-          lp = st.pre ? "logpdf_beta_pre(" + v + ", a0_" + Q + ", a1_" + Q + ", " + flit(st.pre1) + ")"
-                      : "logpdf_beta(" + v + ", a0_" + Q + ", a1_" + Q + ")";
+          o << ind << "const Stream<" << I << "> strm" << Q << "(" << K << ", true, " << fold << "u);\n";
+          o << ind << "const float g1_" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 0, a0_" << Q << ");\n";
+          o << ind << "const float g2_" << Q << " = std_gamma<" << I << ">(strm" << Q << ", 1, a1_" << Q << ");\n";
+          o << ind << "const float vf" << Q << " = g1_" << Q << " / (g1_" << Q << " + g2_" << Q << ");\n";
           break;
-        case GJX_DIST_BERNOULLI: lp = "logpdf_bernoulli(" + v + " != 0, a0_" + Q + ")"; break;
         default:
-          lp = "((" + v + " < 0 || " + v + " >= " + std::to_string(st.n_cat) + ") ? -__builtin_inff() : " + row + "[" + v +
-               "] - jrow_lse(" + row + ", " + std::to_string(st.n_cat) + "u))";
+          if (st.cat_mode == 0) {
+            o << ind << "const Stream<" << I << "> strm" << Q << "(" << K << ", true, " << fold << "u);\n";
+            o << ind << "const int32_t vi" << Q << " = jcat_gumbel<" << I << ">(" << row << ", " << st.n_cat << "u, strm" << Q << ");\n";
+          } else {
+            o << ind << "const int32_t vi" << Q << " = jcat_invcdf(" << row << ", " << st.n_cat << "u, bits" << Q << ");\n";
+          }
       }
-      o << ind << "{ const float lp = " << lp << "; sc = sc + lp;" << (st.observed ? " w = w + lp;" : "") << " }\n";
-      if (mode == 0 && st.out_col >= 0)
-        o << ind << "reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "])[i] = "
-          << (isint ? "(uint32_t)" + v : "f2u(" + v + ")") << ";\n";
+    }
+    std::string lp;
+    const std::string v = (isint ? "vi" : "vf") + Q;
+    switch (st.dist) {
+      case GJX_DIST_NORMAL:
+        lp = st.pre ? "logpdf_normal_pre(" + v + ", a0_" + Q + ", " + flit(st.pre0) + ", " + flit(st.pre1) + ")"
+                    : "logpdf_normal(" + v + ", a0_" + Q + ", a1_" + Q + ")";
+        break;
+      case GJX_DIST_GAMMA:
+        lp = st.pre ? "logpdf_gamma_pre(" + v + ", a0_" + Q + ", a1_" + Q + ", " + flit(st.pre1) + ")"
+                    : "logpdf_gamma(" + v + ", a0_" + Q + ", a1_" + Q + ")";
+        break;
+      case GJX_DIST_BETA:
+        lp = st.pre ? "logpdf_beta_pre(" + v + ", a0_" + Q + ", a1_" + Q + ", " + flit(st.pre1) + ")"
+                    : "logpdf_beta(" + v + ", a0_" + Q + ", a1_" + Q + ")";
+        break;
+      case GJX_DIST_BERNOULLI: lp = "logpdf_bernoulli(" + v + " != 0, a0_" + Q + ")"; break;
+      default:
+        lp = "((" + v + " < 0 || " + v + " >= " + std::to_string(st.n_cat) + ") ? -__builtin_inff() : " + row + "[" + v +
+             "] - jrow_lse(" + row + ", " + std::to_string(st.n_cat) + "u))";
+    }
+    o << ind << "{ const float lp = " << lp << "; sc" << sfx << " = sc" << sfx << " + lp;"
+      << (st.observed ? " w" + sfx + " = w" + sfx + " + lp;" : "") << " }\n";
+    if (mode == 0 && st.out_col >= 0 && store_values)
+      o << ind << "reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "])[i" << sfx << "] = "
+        << (isint ? "(uint32_t)" + v : "f2u(" + v + ")") << ";\n";
+  }
+
+  void run() {
+    for (int q = 0; q < n_sites; ++q) {
+      head(q);
+      tail(q);
     }
   }
 };
@@ -194,6 +220,12 @@ inline void emit_prelude(std::ostringstream& o) {
   o << "template <int IMPL> __device__ __forceinline__ int32_t jcat_gumbel(const float* l, uint32_t K, const Stream<IMPL>& st){ int32_t best=0; float bv=-__builtin_inff(); for(uint32_t c=0;c<K;++c){ const float v = l[c] + gumbel_from_bits(st.bits32(c)); if (v>bv || c==0){ bv=v; best=(int32_t)c; } } return best; }\n";
 }
 
+// The importance kernel of a plan.  Two forms:
+//  * generic: one 256-particle row per 256-thread workgroup, one particle per lane, any key batch;
+//  * paired (PHILOX, lazy children of a lane-0 key, even first index): one row per 128-thread workgroup,
+//    TWO ADJACENT PARTICLES per lane.  The lane derives both particles' words anyway, so every Normal site
+//    costs one shared Box-Muller transform for the pair, and the cipher key (the parent's) is uniform over
+//    the launch: the round keys live in scalar registers.
 template <class CSiteT, class CArgT>
 struct Gen {
   std::ostringstream o;
@@ -201,121 +233,99 @@ struct Gen {
   const CSiteT* sites;
   int n_sites;
   int min_waves = 0;  // __launch_bounds__ waves-per-SIMD hint (0 = none)
+  int block = 256;    // threads per workgroup of the generated kernel
   int rows_per_block = 1;
-  bool laned = false;  // specialise for gjx_keys{mode 1, parent_lane 0} (PHILOX only)
+  bool laned = false; // the paired form (see above)
 
-  bool all_normal() const {
-    for (int q = 0; q < n_sites; ++q) {
-      if (sites[q].dist != GJX_DIST_NORMAL) return false;
-      for (const CArgT* a : {&sites[q].a0, &sites[q].a1})
-        if (a->kind == GJX_ARG_TABLE) return false;
-    }
-    return true;
+  static const char* signature() {
+    return "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, "
+           "uint64_t* row_s, LseTail tail) {\n";
   }
-  std::string arg2(const CArgT& a) const {
-    switch (a.kind) {
-      case GJX_ARG_CONST: return "splat2(" + flit(a.offset) + ")";
-      case GJX_ARG_SITE: return "((" + flit(a.scale) + " * vf" + std::to_string(a.ref_site) + ") + " + flit(a.offset) + ")";
-      default:
-        return "((" + flit(a.scale) + " * (f32x2){cols.in[" + std::to_string(a.ref) + "][i0], cols.in[" + std::to_string(a.ref) +
-               "][i1]}) + " + flit(a.offset) + ")";
-    }
-  }
-  // All-Normal plans: two particles per lane (rows r and r+1 of a 512-particle block) on packed f32.
-  std::string run2() {
-    const std::string I = std::to_string(impl);
-    rows_per_block = 2;
+  const char* kname() const { return impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox"; }
+
+  std::string run_paired() {
+    // R rows (256 particles each) per workgroup of 128*R threads: wave pair r serves row blockIdx*R + r
+    int R = 1;
+    if (const char* e = std::getenv("GJX_JIT_PAIR_ROWS")) R = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 1);
+    block = 128 * R;
+    rows_per_block = R;
     emit_prelude(o);
-    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_plan_kernel_" << (impl == 0 ? "threefry" : "philox")
-      << "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s, LseTail tail) {\n";
-    o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
-    o << "  for (uint64_t blk = blockIdx.x; blk * 512 < n; blk += gridDim.x) {\n";
-    o << "    const uint64_t j0 = blk * 512 + threadIdx.x, j1 = j0 + 256;\n";
-    o << "    const bool ok0 = j0 < n, ok1 = j1 < n;\n";
-    o << "    const uint64_t i0 = ok0 ? j0 : n - 1, i1 = ok1 ? j1 : n - 1;  // surplus lanes redo the last particle, stores masked\n";
-    if (laned)
-      o << "    const uint64_t lnA = ks.first + i0 + 1u, lnB = ks.first + i1 + 1u;\n"
-        << "    const Key pkA{ks.parent.k0, ks.parent.k1, (uint32_t)lnA, (uint32_t)(lnA >> 32)}, pkB{ks.parent.k0, ks.parent.k1, (uint32_t)lnB, (uint32_t)(lnB >> 32)};\n";
-    else
-      o << "    const Key pkA = key_at<" << I << ">(ks, i0), pkB = key_at<" << I << ">(ks, i1);\n";
-    o << "    f32x2 w = splat2(0.0f), sc = splat2(0.0f);\n";
-    int cur_blk = -1;
+    o << "extern \"C\" __global__ __launch_bounds__(" << block << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
+      << ") void " << kname() << signature();
+    o << "  __shared__ float sh_red[" << 2 * R << "];\n  __shared__ uint64_t sh_sum[" << 2 * R << "];\n";
+    o << "  const int wv = threadIdx.x >> 6, pr = wv >> 1, tr = threadIdx.x & 127;\n";
+    o << "  for (uint64_t row0 = (uint64_t)blockIdx.x * " << R << "; row0 * 256 < n; row0 += (uint64_t)gridDim.x * " << R << ") {\n";
+    o << "    const uint64_t row = row0 + pr;\n";
+    o << "    const uint64_t iA = row * 256 + 2 * (uint64_t)tr, iB = iA + 1;\n";
+    o << "    const bool ok = iA < n;  // n is even in this form: both particles of a lane exist or neither\n";
+    o << "    const uint64_t liA = iA, liB = iB;\n";
+    o << "    float wA = 0.0f, scA = 0.0f, wB = 0.0f, scB = 0.0f;\n";
+    o << "    if (ok) {\n";
+    o << "      const uint64_t lnA = ks.first + iA + 1u, lnB = lnA + 1u;\n";
+    o << "      const Key pkeyA{ks.parent.k0, ks.parent.k1, (uint32_t)lnA, (uint32_t)(lnA >> 32)};\n";
+    o << "      const Key pkeyB{ks.parent.k0, ks.parent.k1, (uint32_t)lnB, (uint32_t)(lnB >> 32)};\n";
+    SiteEmitter<CSiteT, CArgT> ea{o, impl, 0, sites, n_sites, "      ", "A"};
+    SiteEmitter<CSiteT, CArgT> eb{o, impl, 0, sites, n_sites, "      ", "B"};
+    ea.store_values = eb.store_values = false;
     for (int q = 0; q < n_sites; ++q) {
       const CSiteT& st = sites[q];
-      const std::string Q = std::to_string(q);
-      const uint32_t fold = SiteEmitter<CSiteT, CArgT>{o, impl, 0, sites, n_sites, ""}.fold_of(q);
-      o << "    // site " << q << (st.observed ? " observed" : " latent") << "\n";
-      o << "    const f32x2 a0_" << Q << " = " << arg2(st.a0) << ";\n";
-      o << "    const f32x2 a1_" << Q << " = " << arg2(st.a1) << ";\n";
-      if (st.observed) {
-        if (st.obs.kind == GJX_ARG_CONST) o << "    const f32x2 vf" << Q << " = splat2(" << flit(st.obs.offset) << ");\n";
-        else o << "    const f32x2 vf" << Q << " = (f32x2){cols.in[" << st.obs.ref << "][i0], cols.in[" << st.obs.ref << "][i1]};\n";
+      ea.head(q);
+      eb.head(q);
+      if (!st.observed && st.dist == GJX_DIST_NORMAL) {
+        const std::string Q = std::to_string(q);
+        o << "      float zc" << Q << ", zs" << Q << ";\n      bm_pair(bits" << Q << "A, bits" << Q << "B, zc" << Q << ", zs" << Q << ");\n";
+        ea.tail(q, "zc" + Q);
+        eb.tail(q, "zs" + Q);
       } else {
-        if (impl == 1) {
-          const int b = (int)(fold >> 2);
-          if (b != cur_blk) {
-            cur_blk = b;
-            for (const char* P : {"A", "B"}) {
-              o << "    uint32_t pw" << P << b << "_0, pw" << P << b << "_1, pw" << P << b << "_2, pw" << P << b << "_3;\n";
-              o << "    philox4x32(pk" << P << ".k0, pk" << P << ".k1, pk" << P << ".l0, pk" << P << ".l1, " << b << "u, kTagDraw, pw" << P << b << "_0, pw" << P << b
-                << "_1, pw" << P << b << "_2, pw" << P << b << "_3);\n";
-            }
-          }
-          o << "    const uint32_t bA" << Q << " = pwA" << b << "_" << (fold & 3u) << ", bB" << Q << " = pwB" << b << "_" << (fold & 3u) << ";\n";
-        } else {
-          o << "    const uint32_t bA" << Q << " = Stream<0>(pkA, true, " << fold << "u).bits32(0), bB" << Q
-            << " = Stream<0>(pkB, true, " << fold << "u).bits32(0);\n";
-        }
-        o << "    const f32x2 t" << Q << " = a1_" << Q << " * std_normal2(bA" << Q << ", bB" << Q << ");\n";
-        o << "    const f32x2 vf" << Q << " = a0_" << Q << " + t" << Q << ";\n";
+        ea.tail(q);
+        eb.tail(q);
       }
-      const std::string lp = st.pre ? "logpdf_normal_pre2(vf" + Q + ", a0_" + Q + ", " + flit(st.pre0) + ", " + flit(st.pre1) + ")"
-                                    : "logpdf_normal2(vf" + Q + ", a0_" + Q + ", a1_" + Q + ")";
-      o << "    { const f32x2 lp = " << lp << "; sc = sc + lp;" << (st.observed ? " w = w + lp;" : "") << " }\n";
-      if (st.out_col >= 0) {
-        o << "    if (ok0) reinterpret_cast<float*>(cols.out[" << st.out_col << "])[j0] = vf" << Q << ".x;\n";
-        o << "    if (ok1) reinterpret_cast<float*>(cols.out[" << st.out_col << "])[j1] = vf" << Q << ".y;\n";
+      if (st.out_col >= 0) {  // the two particles are adjacent in the column: one 8-byte store per lane
+        const bool isint = SiteEmitter<CSiteT, CArgT>::is_int(st);
+        const std::string Q = std::to_string(q);
+        const std::string ra = isint ? "(uint32_t)vi" + Q + "A" : "f2u(vf" + Q + "A)", rb = isint ? "(uint32_t)vi" + Q + "B" : "f2u(vf" + Q + "B)";
+        o << "      *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "]) + iA) = make_uint2(" << ra << ", " << rb << ");\n";
       }
     }
-    o << "    if (ok0) { logw[j0] = w.x; if (score) score[j0] = sc.x; }\n";
-    o << "    if (ok1) { logw[j1] = w.y; if (score) score[j1] = sc.y; }\n";
-    for (int r = 0; r < 2; ++r) {
-      const std::string R = std::to_string(r), W = r == 0 ? "w.x" : "w.y", OK = r == 0 ? "ok0" : "ok1";
-      o << "    if ((max_partials || row_e) && (blk * 512 + " << (r * 256) << ") < n) {\n";
-      o << "      const float bm = block_max(" << OK << " ? " << W << " : -__builtin_inff(), sh_red);\n";
-      o << "      if (max_partials && threadIdx.x == 0) max_partials[blk * 2 + " << R << "] = bm;\n";
-      o << "      if (row_e) {\n        const int32_t eb = row_anchor(bm);\n";
-      o << "        const uint64_t sb = block_sum(" << OK << " ? rowfix(" << W << ", eb) : 0, sh_sum);\n";
-      o << "        if (threadIdx.x == 0) lse_store_row(row_e, row_s, blk * 2 + " << R << ", eb, sb, tail.tickets != nullptr);\n";
-      o << "      }\n    }\n";
-    }
+    o << "      *reinterpret_cast<float2*>(logw + iA) = make_float2(wA, wB);\n";
+    o << "      if (score) *reinterpret_cast<float2*>(score + iA) = make_float2(scA, scB);\n";
+    o << "    }\n";
+    o << "    const bool okA = ok, okB = ok;\n";
+    o << "    if (max_partials || row_e) {\n";
+    o << "      const float ninf = -__builtin_inff();\n";
+    o << "      const float mA = okA ? wA : ninf, mB = okB ? wB : ninf;\n";
+    o << "      float bm = wave_max(mA > mB ? mA : mB);\n";
+    o << "      __syncthreads();\n      if ((threadIdx.x & 63) == 0) sh_red[wv] = bm;\n      __syncthreads();\n";
+    o << "      bm = sh_red[2 * pr] > sh_red[2 * pr + 1] ? sh_red[2 * pr] : sh_red[2 * pr + 1];\n";
+    o << "      const bool live_row = row * 256 < n;\n";
+    o << "      if (max_partials && tr == 0 && live_row) max_partials[row] = bm;\n";
+    o << "      if (row_e) {\n";
+    o << "        const int32_t eb = row_anchor(bm);\n";
+    o << "        uint64_t sb = wave_sum((okA ? rowfix(wA, eb) : 0) + (okB ? rowfix(wB, eb) : 0));\n";
+    o << "        __syncthreads();\n        if ((threadIdx.x & 63) == 0) sh_sum[wv] = sb;\n        __syncthreads();\n";
+    o << "        sb = sh_sum[2 * pr] + sh_sum[2 * pr + 1];\n";
+    o << "        if (tr == 0 && live_row) lse_store_row(row_e, row_s, row, eb, sb, tail.tickets != nullptr);\n";
+    o << "      }\n    }\n";
     o << "  }\n  if (row_e) lse_tail(row_e, row_s, (n + 255) / 256, tail);\n}\n";
     return o.str();
   }
 
   std::string run() {
+    if (laned && impl == 1) return run_paired();
     const std::string I = std::to_string(impl);
-    // Packed-f32 form (two particles per lane): bit-identical, but measured SLOWER on MI355X for the
-    // 10-latent model (29.1 vs 26.8 us) — the kernel is bound by the integer cipher and by issue slots,
-    // not by f32 throughput — so it is opt-in (GJX_JIT_PACKED=1) and kept for the parity tests.
-    const char* e2 = std::getenv("GJX_JIT_PACKED");
-    if (all_normal() && e2 && e2[0] == '1') return run2();
     emit_prelude(o);
     // One workgroup per 256-particle row (grid-stride): short blocks keep every SIMD's wave slots
     // full even at 1e6 particles (15 rows per lane), where a 4-row block would serialise its rows.
     o << "extern \"C\" __global__ __launch_bounds__(256" << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
-      << ") void gjx_plan_kernel_" << (impl == 0 ? "threefry" : "philox")
-      << "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s, LseTail tail) {\n";
+      << ") void " << kname() << signature();
     o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
     o << "  for (uint64_t row = blockIdx.x; row * 256 < n; row += gridDim.x) {\n";
     o << "    float tmax = -__builtin_inff();\n    bool live = false;\n";
     o << "    {\n";
-    o << "      const uint64_t i = row * 256 + threadIdx.x;\n";
-    o << "      if (i < n) {\n";
-    if (laned)  // lazy children of a lane-0 PHILOX key: the cipher key is uniform over the launch
-      o << "        const uint64_t lane = ks.first + i + 1u;\n        const Key pkey{ks.parent.k0, ks.parent.k1, (uint32_t)lane, (uint32_t)(lane >> 32)};\n";
-    else
-      o << "        const Key pkey = key_at<" << I << ">(ks, i);\n";
+    o << "      const uint64_t i = row * 256 + threadIdx.x, li = i;\n";
+    o << "      const bool ok = i < n;\n";
+    o << "      if (ok) {\n";
+    o << "        const Key pkey = key_at<" << I << ">(ks, i);\n";
     o << "        float w = 0.0f, sc = 0.0f;\n";
     SiteEmitter<CSiteT, CArgT> em{o, impl, 0, sites, n_sites, "        "};
     em.run();
@@ -392,7 +402,8 @@ struct Compiled {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   int state = 0;  // 0 untried, 1 ready, -1 failed
-  int rows_per_block = 1;  // 256-particle rows one workgroup processes per grid-stride iteration
+  int block = 256;  // threads per workgroup of the compiled kernel
+  int rows_per_block = 1;  // 256-particle rows per workgroup
 };
 
 inline bool enabled() {

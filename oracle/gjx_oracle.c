@@ -172,7 +172,7 @@ int gjx_sample_logpdf_normal(const gjx_keys* k, gjx_f32 loc, gjx_f32 scale, floa
   for (int64_t i = 0; i < (int64_t)n; ++i) {
     o_stream st = stream_at(k, (uint64_t)i);
     float mu = OPND(loc, i), sg = OPND(scale, i);
-    float eps = o_std_normal(o_bits32_at(&st, 0));
+    float eps = o_site_normal(&st);
     float t = sg * eps;
     float v = mu + t;
     value_out[i] = v;
@@ -349,6 +349,7 @@ static inline int32_t sv_as_i32(const site_val* v) { return v->is_int ? v->i : (
 typedef struct {
   int impl;
   uint32_t pkey[4];          /* importance: particle key; smc: slot key split(step_key)[slot] */
+  int pair_normals;          /* importance: 1 */
   const float* const* in;    /* importance: input columns */
   uint64_t i;                /* importance: particle index into the input columns */
   const float* state;        /* smc: the ancestor's state columns (NULL at step 0) */
@@ -402,7 +403,9 @@ static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, sit
       o_stream strm = o_stream_make(c->impl, c->pkey, 1, f);
       const uint32_t bits0 = o_bits32_at(&strm, 0);
       switch (st->dist) {
-        case GJX_DIST_NORMAL: { float t = a1 * o_std_normal(bits0); v.f = a0 + t; break; }
+        case GJX_DIST_NORMAL: { /* importance walks pair particles (PHILOX); SMC steps keep the single draw */
+          float eps = c->pair_normals ? o_site_normal(&strm) : o_std_normal(bits0);
+          float t = a1 * eps; v.f = a0 + t; break; }
         case GJX_DIST_GAMMA: v.f = o_std_gamma(&strm, 0, a0) / a1; break;
         case GJX_DIST_BETA: { float g1 = o_std_gamma(&strm, 0, a0), g2 = o_std_gamma(&strm, 1, a1); v.f = g1 / (g1 + g2); break; }
         case GJX_DIST_BERNOULLI: v.i = o_uniform01(bits0) < a0; break;
@@ -446,6 +449,7 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
     walk_ctx c;
     memset(&c, 0, sizeof c);
     c.impl = pk->impl;
+    c.pair_normals = 1;
     key_at(pk, (uint64_t)i, c.pkey);
     c.in = input_cols;
     c.i = (uint64_t)i;

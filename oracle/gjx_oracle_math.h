@@ -276,6 +276,61 @@ static inline float o_std_normal(uint32_t bits) {
   return 1.41421356237309505f * o_erfinv(u);
 }
 
+/* ---- PHILOX Normal sites: Box-Muller over pairs of particles ----------------------
+ * Particles j0 = j & ~1 and j1 = j0 + 1 of a key batch (key lanes j0+1, j0+2) share one transform at every
+ * Normal site: radius from j0's draw word, angle from j1's; j0 takes the cosine, j1 the sine.  Every
+ * operation is IEEE-exact: Cephes sinf / cosf kernels on [0, pi/4] after an exact octant reduction of
+ * the 24-bit angle.  A lane-0 key has no partner: its angle word comes from the same key under tag 'T'. */
+#define O_TAG_TWIN 0x54u
+static inline float o_log_normal_range(float x) { return o_log(x); } /* same bits for positive normal x */
+static inline void o_bm_pair(uint32_t w_radius, uint32_t w_angle, float* z_cos, float* z_sin) {
+  float u = ((float)w_radius + 1.0f) * 2.3283064365386963e-10f;
+  float r = sqrtf(-2.0f * o_log_normal_range(u));
+  uint32_t a = w_angle >> 8;
+  uint32_t oct = a >> 21;
+  float f = (float)(a & 0x1fffffu) * 4.76837158203125e-07f;
+  float g = (oct & 1u) ? 1.0f - f : f;
+  float x = g * 0.78539816339744831f;
+  float z = x * x;
+  float ps = -1.9515295891E-4f;
+  ps = fmaf(ps, z, 8.3321608736E-3f);
+  ps = fmaf(ps, z, -1.6666654611E-1f);
+  float t = ps * z;
+  float s = fmaf(t, x, x);
+  float pc = 2.443315711809948E-5f;
+  pc = fmaf(pc, z, -1.388731625493765E-3f);
+  pc = fmaf(pc, z, 4.166664568298827E-2f);
+  float t2 = pc * z;
+  float c = fmaf(t2, z, fmaf(-0.5f, z, 1.0f));
+  int swap = ((oct + 1u) & 2u) != 0u;
+  float cs = swap ? s : c, sn = swap ? c : s;
+  if ((oct + 2u) & 4u) cs = -cs;
+  if (oct & 4u) sn = -sn;
+  *z_cos = r * cs;
+  *z_sin = r * sn;
+}
+static inline uint32_t o_draw_word(const uint32_t k[4], uint32_t f, uint32_t tag) {
+  uint32_t o[4];
+  o_philox_lane(k, f >> 2, tag, o);
+  return o[f & 3u];
+}
+/* The standard normal of a Normal site for stream `s` (folded, PHILOX); THREEFRY / unfolded streams keep
+ * jax's erfinv form. */
+static inline float o_site_normal(const o_stream* s) {
+  if (s->impl == 0 || !s->hf) return o_std_normal(o_bits32_at(s, 0));
+  float zc, zs;
+  if ((s->k[2] | s->k[3]) == 0u) {
+    o_bm_pair(o_draw_word(s->k, s->f, O_TAG_DRAW), o_draw_word(s->k, s->f, O_TAG_TWIN), &zc, &zs);
+    return zc;
+  }
+  uint64_t j = (((uint64_t)s->k[3] << 32) | s->k[2]) - 1u;
+  uint64_t la = (j & ~(uint64_t)1) + 1u, lb = la + 1u;
+  uint32_t ka[4] = {s->k[0], s->k[1], (uint32_t)la, (uint32_t)(la >> 32)};
+  uint32_t kb[4] = {s->k[0], s->k[1], (uint32_t)lb, (uint32_t)(lb >> 32)};
+  o_bm_pair(o_draw_word(ka, s->f, O_TAG_DRAW), o_draw_word(kb, s->f, O_TAG_DRAW), &zc, &zs);
+  return (j & 1u) ? zs : zc;
+}
+
 /* ---------------- log-densities (TFP formulas) ----------------------------- */
 
 static inline float o_logpdf_normal(float x, float loc, float scale) {

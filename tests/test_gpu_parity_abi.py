@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from genjax._amd import abi, workloads as W
+from genjax._amd import abi, prng, workloads as W
 from genjax._amd.ops import KeyBatch
 
 pytestmark = pytest.mark.gpu
@@ -119,13 +119,11 @@ def test_categorical(hip_ops, oracle_ops, impl, mode):
             assert not bool((hv.cpu() == 2).any()), "a -inf logit must never be drawn"
 
 
-@pytest.fixture(params=["specialized", "specialized-packed", "interpreter"])
+@pytest.fixture(params=["specialized", "interpreter"])
 def plan_mode(request, monkeypatch):
-    """All importance kernels: the hiprtc-specialised straight-line kernel (default), its opt-in
-    two-particles-per-lane packed-f32 form for all-Normal plans (GJX_JIT_PACKED=1) and the
-    site-table interpreter (GJX_PLAN_JIT=0)."""
+    """The importance kernels: the hiprtc-specialised straight-line kernel (default; Philox lazy batches
+    take its paired two-particles-per-lane form) and the site-table interpreter (GJX_PLAN_JIT=0)."""
     monkeypatch.setenv("GJX_PLAN_JIT", "0" if request.param == "interpreter" else "1")
-    monkeypatch.setenv("GJX_JIT_PACKED", "1" if request.param == "specialized-packed" else "0")
     return request.param
 
 
@@ -143,6 +141,45 @@ def test_importance_gaussian10(hip_ops, oracle_ops, impl, n, plan_mode):
     same(h["rows"].e, o["rows"].e, "row anchors"); same(h["rows"].s, o["rows"].s, "row sums")
     assert (h["row_e"], h["row_q"], h["row_lse"]) == (o["row_e"], o["row_q"], o["row_lse"])
     assert abs(h["log_z_rows"] - h["log_z"]) < 1e-6, "the two fixed-point forms agree to fixed-point resolution"
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_importance_key_forms_agree(hip_ops, oracle_ops, impl):
+    """One population, every way of handing over its keys: the paired kernel (lazy batch, even first), the
+    one-particle-per-lane kernel (odd first: pairs straddle lanes), explicit key arrays, and the eager
+    per-site kernel all draw the same values — Philox Normal sites pair particles by key lane, wherever the
+    partner's word has to be derived."""
+    import torch as T
+
+    n, first = 3001, 10
+    sites = W.gaussian10_sites(W.gaussian10_data())
+    root = prng.key(77, impl)
+    k2 = prng.split(prng.split(root)[1])[1]
+
+    def run(ops, kb, m):
+        plan = ops.plan_create(sites)
+        vals, score, logw, _ = ops.importance_run(plan, kb, m, [], [T.float32] * W.G10_LATENTS)
+        return T.stack([v.cpu() for v in vals]), score.cpu(), logw.cpu()
+
+    lazy = prng.split_lazy(k2, n, first)
+    ref = run(oracle_ops, lazy, n)
+    got = run(hip_ops, lazy, n)
+    for a, b in zip(got, ref):
+        same(a, b, "lazy, even first (paired kernel)")
+    odd = run(hip_ops, prng.split_lazy(k2, n - 1, first + 1), n - 1)  # the same particles minus the first one
+    for a, b in zip(odd, ref):
+        same(a, b[..., 1:], "lazy, odd first (generic kernel)")
+    mat = hip_ops.rng_keys(lazy, n)
+    exp = run(hip_ops, KeyBatch(impl, 0, tensor=mat), n)
+    for a, b in zip(exp, ref):
+        same(a, b, "explicit key array")
+    # eager per-site kernel, site 0 (fold: threefry counter 1, philox draw index 0)
+    v0, _ = hip_ops.sample_logpdf("normal", lazy.with_fold(1 if impl == 0 else 0), n, 0.0, 1.0)
+    same(v0, ref[0][0], "eager site kernel")
+    # a scalar run with keys[i] draws what element i of the batch draws
+    i = 7
+    one = run(hip_ops, prng.split_at(k2, first + i).literal(), 1)
+    same(one[0][:, 0], ref[0][:, i], "scalar key == batch element")
 
 
 @pytest.mark.parametrize("impl", IMPLS)

@@ -34,20 +34,21 @@ def source_of(ops, plan, impl):
 
 
 @pytest.mark.parametrize("impl", [0, 1])
-def test_gaussian10_plan_compiles(hip_lib_nogpu, impl, monkeypatch):
+def test_gaussian10_plan_compiles(hip_lib_nogpu, impl):
     ops = hip_lib_nogpu
     plan = ops.plan_create(W.gaussian10_sites(W.gaussian10_data()))
     src1 = source_of(ops, plan, impl)
-    assert src1.count("std_normal(") == 10 and src1.count("logpdf_normal_pre(") == 20
-    if impl == 1:  # 4 sampled sites share one Philox block whatever is observed in between: 10 draws -> 3 blocks
-        assert src1.count("philox4x32(pkey") == 3
-        assert "ks.parent.k0" in src1  # laned-key variant: the cipher key is the (uniform) parent key
-    ops.lib.call("gjx_plan_compile_check", plan.handle, impl)
-    monkeypatch.setenv("GJX_JIT_PACKED", "1")  # opt-in: two particles per lane on packed f32
-    src = source_of(ops, plan, impl)
-    assert src.count("std_normal2(") == 10 and src.count("logpdf_normal_pre2(") == 20
-    if impl == 1:
-        assert src.count("philox4x32(pkA") == 3 and src.count("philox4x32(pkB") == 3
+    if impl == 0:  # jax key tree: one particle per lane, erfinv normals, 20 log-densities
+        assert src1.count("std_normal(") == 10 and src1.count("logpdf_normal_pre(") == 20
+        assert "__launch_bounds__(256" in src1
+    else:
+        # the paired form: two adjacent particles per lane (A, B), ONE Box-Muller transform per Normal site for
+        # the pair, 4 sampled sites per Philox block whatever is observed in between (10 draws -> 3 blocks per
+        # particle), the cipher key is the (launch-uniform) parent key
+        assert src1.count("bm_pair(") == 10 and src1.count("std_normal(") == 0
+        assert src1.count("logpdf_normal_pre(") == 40
+        assert src1.count("philox4x32(pkeyA") == 3 and src1.count("philox4x32(pkeyB") == 3
+        assert "ks.parent.k0" in src1 and "__launch_bounds__(128)" in src1
     ops.lib.call("gjx_plan_compile_check", plan.handle, impl)
 
 
