@@ -112,71 +112,62 @@ def bench_importance(args, ops, rank, world):
     # HIP events are created (and their pool grown) before the timed region
     from genjax._amd.ops import HipEvent
 
-    ev_pool = [(HipEvent(), HipEvent()) for _ in range(args.steps + args.warmup)]
+    ev_pool = [(HipEvent(), HipEvent()) for _ in range(args.steps + args.warmup + 8)]
 
-    BATCH = int(os.environ.get("GJX_BENCH_BATCH", "32"))  # passes per log-sum-exp fold / per exchanged record block
-    # persistent output buffers + pre-marshalled C calls: no host allocation per step; BATCH passes share one
-    # log-sum-exp launch (and, sharded, one exchanged block of records): 32 amortises a ~35 us per-batch cost
-    # to ~1 us per pass (measured: 8 -> 28.6, 16 -> 26.7, 32 -> 25.7 us per pass through a one-rank RCCL group)
-    prep = wl.prepare(fold_batch=BATCH)
+    # BATCH passes share one log-sum-exp launch (and, sharded, one exchanged block of records): 32 amortises a
+    # ~35 us per-batch cost to ~1 us per pass.  LAUNCH independent passes (seeds 0, 1, ...) share one importance
+    # launch: a single 1e6-particle pass is under two rounds of the machine (21.5 us), eight keep it full
+    # (17.5 us per pass).  Persistent output buffers + pre-marshalled C calls: no host allocation per step.
+    LAUNCH = int(os.environ.get("GJX_BENCH_LAUNCH", "8"))
+    BATCH = int(os.environ.get("GJX_BENCH_BATCH", "32")) // LAUNCH * LAUNCH or LAUNCH
+    prep = wl.prepare(fold_batch=BATCH, passes=LAUNCH)
     if sharded:
         # each pass leaves a 65-word record of its shard's weights; one asynchronous all-gather per BATCH
         # passes overlaps with the next batch's kernels (genjax/_amd/dist.py)
-        pipe = gdist.BatchedImportance(ops, wl, batch=BATCH, world=world, always_exchange=True)
+        pipe = gdist.BatchedImportance(ops, wl, batch=BATCH, world=world, always_exchange=True, passes=LAUNCH)
     last_buf = [0]
 
-    def run_sharded(count, timed):
-        evs = {}
-        sh = ops.stream()
+    launch_no = [0]
 
-        def on_kernel(b, k):  # sample the kernel on every 4th pass, as in the single-device loop
-            if b % EVENT_EVERY == 0:
-                if k == 0:
-                    evs[b] = ev_pool.pop()
-                evs[b][k].record(sh)
-
-        last_buf[0] = pipe.run(count, on_kernel=on_kernel)
-        if timed:
-            kernel_ms.extend(evs.values())
-
-    # an event record is a queue barrier packet (~2-3 us of device time): sample the kernel on every 8th pass
-    # (every 4th in short runs, so that at least ~6 launches are timed)
-    EVENT_EVERY = 8 if args.steps >= 48 else 4
-    step_no = [0]
-
-    def step(timed):
-        st = ops.stream()
-        step_no[0] += 1
-        sample = (step_no[0] - 1) % EVENT_EVERY == 0  # the first pass of a run is always timed
-        if sample:
-            e0, e1 = ev_pool.pop()
-            e0.record(st)
-        # the walk: trace columns, score, log-weights and the row-anchored partial sums of this pass (slot b)
-        b = (step_no[0] - 1) % BATCH
-        prep.launch_importance(st, b)
-        if sample:
-            e1.record(st)
+    def on_launch(phase, count, evs, timed):
+        """HIP events around every other importance launch (a barrier packet each: ~2.5 us against ~150 us)."""
+        if phase == 0:
+            launch_no[0] += 1
+            if launch_no[0] % 2 == 1:
+                evs.append(ev_pool.pop() + (count,))
+                evs[-1][0].record(ops.stream())
+            else:
+                evs.append(None)
+        elif evs[-1] is not None:
+            evs[-1][1].record(ops.stream())
             if timed:
-                kernel_ms.append((e0, e1))
-        if b == BATCH - 1:  # one launch folds the 3907 (anchor, sum) pairs of each of the last BATCH passes
-            prep.launch_fold(BATCH, st)
-        return b
+                kernel_ms.append(evs[-1])
+
+    def run_batch(count, timed):
+        """`count` (<= BATCH) passes: ceil(count / LAUNCH) importance launches + one fold launch."""
+        evs = []
+        if sharded:
+            last_buf[0] = pipe.run(count, on_launch=lambda ph, c: on_launch(ph, c, evs, timed))
+            return
+        st, done = ops.stream(), 0
+        while done < count:
+            c = min(LAUNCH, count - done)
+            on_launch(0, c, evs, timed)
+            prep.launch_passes(done, c, st)  # trace columns, score, log-weights, row sums of c passes (slots done..)
+            on_launch(1, c, evs, timed)
+            done += c
+        prep.launch_fold(count, st)  # one launch folds the 3907 (anchor, sum) pairs of each pass of the batch
 
     def run_steps(count, timed):
         if count <= 0:
             return None
-        if not sharded:
-            step_no[0] = 0
-            for _ in range(count):
-                b = step(timed)
-            if b != BATCH - 1:
-                prep.launch_fold(b + 1, ops.stream())  # the ragged last batch
-            return prep.e_all[b:b + 1], prep.q_all[b:b + 1], prep.logw
         done = 0
         while done < count:
             c = min(BATCH, count - done)
-            run_sharded(c, timed)
+            run_batch(c, timed)
             done += c
+        if not sharded:
+            return prep.e_all[:1], prep.q_all[:1], prep.logw
         pipe.wait()  # every exchange has landed (stream-ordered; the host does not block)
         _, e_all, q_all = pipe.results(last_buf[0])
         return e_all[:1], q_all[:1], None
@@ -200,11 +191,15 @@ def bench_importance(args, ops, rank, world):
     if os.environ.get("GJX_BENCH_DEBUG"):
         print("host per-step ms:", ["%.3f" % (x * 1e3) for x in host_ts], "loop", t_loop * 1e3, "total", dt * 1e3,
               file=sys.stderr)
-    k_ms_raw = sum(a.elapsed_ms(b) for a, b in kernel_ms) / len(kernel_ms)
+    # the dominant kernel: launches of `c` passes each; full launches (c == LAUNCH) define the quoted duration
+    full = [(a, b, c) for a, b, c in kernel_ms if c == LAUNCH] or kernel_ms
+    k_ms_raw = sum(a.elapsed_ms(b) for a, b, _ in full) / len(full)
     k_ms = max(k_ms_raw - ev_overhead_ms, 1e-6)
+    passes_per_launch = full[0][2]
     ms_per_step = dt / args.steps * 1e3
-    log_z = ops.log_z_from_rows(m, q, total_particles)  # exact (anchor, fixed-point sum) pair of the last pass
-    achieved = BYTES_IMPORTANCE_KERNEL_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9
+    log_z = ops.log_z_from_rows(m, q, total_particles)  # exact (anchor, fixed-point sum) pair of pass 0
+    bytes_per_launch = BYTES_IMPORTANCE_KERNEL_PER_PARTICLE * n * passes_per_launch
+    achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
     # collected by profiles/collect.sh on this same command); null if none matches this kernel/size.
     traffic, traffic_src = None, None
@@ -215,7 +210,9 @@ def bench_importance(args, ops, rank, world):
             try:
                 pj = json.load(open(f))
                 if f"gjx_plan_kernel_{args.rng}" in pj.get("kernel", ""):
-                    traffic, traffic_src = pj["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+                    # the PMC figure is per 1e6-particle pass; a launch of several passes moves that many times it
+                    per_pass = pj.get("hbm_bytes_per_pass", pj["hbm_bytes_per_launch"] / max(1, pj.get("passes_per_launch", 1)))
+                    traffic, traffic_src = per_pass * passes_per_launch, os.path.relpath(f, ROOT)
                     break
             except Exception:
                 pass
@@ -226,14 +223,16 @@ def bench_importance(args, ops, rank, world):
         "ms_per_step": ms_per_step,
         "config": {"workload": "ImportanceK k_particles=1e6/GPU on a 10-latent Gaussian model (BASELINE configs[1])",
                    "particles_per_gpu": args.particles, "latent_sites": 10, "observed_sites": 10, "rng": args.rng,
+                   "passes_per_launch": LAUNCH, "passes_per_fold": BATCH,
                    "parallelism": (f"particle-sharded x{world}, row-aligned; one 520 B all-gather per pass, "
                                    f"bucketed x{BATCH} and overlapped with the next batch") if sharded
                    else "single device"},
         "roofline": {"bound": "hbm", "kernel": f"gjx_plan_kernel_{args.rng}", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel_ms": k_ms, "kernel_ms_raw_event_interval": k_ms_raw,
-                     "event_pair_overhead_ms": ev_overhead_ms, "kernel_launches_timed": len(kernel_ms),
-                     "algorithmic_bytes_per_launch": BYTES_IMPORTANCE_KERNEL_PER_PARTICLE * n},
+                     "event_pair_overhead_ms": ev_overhead_ms, "kernel_launches_timed": len(full),
+                     "passes_per_launch": passes_per_launch, "kernel_ms_per_pass": k_ms / passes_per_launch,
+                     "algorithmic_bytes_per_launch": bytes_per_launch},
         "log_z": log_z,
         "log_z_exact": W.gaussian10_exact_log_z(wl.y),
     }

@@ -180,6 +180,20 @@ struct Stream {
   }
 };
 
+// Several independent passes in one launch (the algorithm vmapped over keys): pass p draws from the lazy
+// children of its own parent key and writes p * pass_stride elements further in every output column
+// (p * row_stride entries further in the per-row arrays).  One 1e6-particle pass is 7.8k waves — less than two
+// rounds of the machine — so a launch of several passes keeps the SIMDs full through what would otherwise
+// be each pass's fill and drain.
+constexpr int kMaxPasses = 32;
+struct PassBatch {
+  uint32_t n_pass;         // >= 1
+  uint32_t rows_per_pass;  // ceil(n / 256)
+  uint64_t pass_stride;
+  uint64_t row_stride;
+  uint32_t parent[kMaxPasses][2];  // used when n_pass > 1 (lazy batches of lane-0 parents)
+};
+
 // Column pointer table of one importance run (kernel argument, by value).
 struct RunCols {
   const float* in[16];

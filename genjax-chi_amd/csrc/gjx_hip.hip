@@ -1321,14 +1321,17 @@ int gjx_plan_prepare(gjx_plan* p, const gjx_keys* pk) {
   return plan_compiled(p, pk, true).state == 1 ? GJX_OK : plan_device_table(p);
 }
 
-int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const* input_cols,
-                       int n_input_cols, void* const* value_cols, int n_value_cols, float* score,
-                       float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s,
-                       const gjx_lse_out* lse, gjx_stream s) {
-  if (!p || !keys_ok(pk) || pk->has_fold || !logw || n_input_cols < 0 || n_input_cols > 16 ||
-      n_value_cols < 0 || n_value_cols > GJX_MAX_SITES || ((row_e == nullptr) != (row_s == nullptr)) ||
-      (lse && (!row_e || !lse->tickets)))
+// One launch of a plan over n_pass independent passes (n_pass == 1: the plain call).
+static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pass, uint64_t pass_stride,
+                             uint64_t row_stride, const float* const* input_cols, int n_input_cols,
+                             void* const* value_cols, int n_value_cols, float* score, float* logw, uint64_t n,
+                             float* max_partials, int32_t* row_e, uint64_t* row_s, const gjx_lse_out* lse,
+                             gjx_stream s) {
+  if (!p || !pk || !logw || n_input_cols < 0 || n_input_cols > 16 || n_value_cols < 0 ||
+      n_value_cols > GJX_MAX_SITES || ((row_e == nullptr) != (row_s == nullptr)) || (lse && (!row_e || !lse->tickets)))
     return GJX_ERR_INVALID;
+  for (int32_t b = 0; b < n_pass; ++b)
+    if (!keys_ok(pk + b) || pk[b].has_fold) return GJX_ERR_INVALID;
   RunCols cols;
   memset(&cols, 0, sizeof(cols));
   for (int c = 0; c < n_input_cols; ++c) cols.in[c] = input_cols[c];
@@ -1346,15 +1349,22 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
   // Specialised straight-line kernel for this site table (compiled once per plan and RNG scheme).
   if (gjx_jit::enabled()) {
     // the paired form writes both particles of a lane with one 8-byte store: even n, 8-byte aligned columns
-    bool pairable = (n & 1) == 0 && ((uintptr_t)logw & 7) == 0 && ((uintptr_t)score & 7) == 0;
+    bool pairable = (n & 1) == 0 && ((uintptr_t)logw & 7) == 0 && ((uintptr_t)score & 7) == 0 && (pass_stride & 1) == 0;
     for (int c = 0; c < n_value_cols && pairable; ++c) pairable = ((uintptr_t)value_cols[c] & 7) == 0;
     gjx_jit::Compiled& c = plan_compiled(const_cast<gjx_plan*>(p), pk, pairable);
     if (c.state == 1) {
       uint64_t nn = n;
       LseTail tail{nullptr, nullptr, nullptr, nullptr, nullptr};
       if (lse) tail = LseTail{lse->e, lse->q, lse->lse, lse->record, lse->tickets};
-      void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials, &row_e, &row_s, &tail};
-      uint64_t rows = (nrows_of(n) + c.rows_per_block - 1) / c.rows_per_block;
+      PassBatch bt;
+      memset(&bt, 0, sizeof bt);
+      bt.n_pass = (uint32_t)n_pass;
+      bt.rows_per_pass = (uint32_t)nrows_of(n);
+      bt.pass_stride = pass_stride;
+      bt.row_stride = row_stride;
+      for (int32_t b = 0; b < n_pass; ++b) { bt.parent[b][0] = pk[b].parent[0]; bt.parent[b][1] = pk[b].parent[1]; }
+      void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials, &row_e, &row_s, &tail, &bt};
+      uint64_t rows = ((uint64_t)n_pass * nrows_of(n) + c.rows_per_block - 1) / c.rows_per_block;
       static const uint64_t grid_cap = [] {
         const char* e = std::getenv("GJX_IMPORTANCE_GRID");
         return e ? (uint64_t)strtoull(e, nullptr, 10) : 0ull;
@@ -1370,23 +1380,69 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
     const int rc = plan_device_table(const_cast<gjx_plan*>(p));
     if (rc) return rc;
   }
+  // generic route (table interpreter): one launch per pass
   const size_t lds = sizeof(uint32_t) * (size_t)(p->n_slots > 0 ? p->n_slots : 1) * kImpTile;
-#define GJX_LAUNCH_IMPORTANCE(IMPL, MASK) \
-  k_importance<IMPL, MASK><<<(unsigned)((n + kImpTile - 1) / kImpTile), kBlock, lds, S(s)>>>(p->dev, p->n_sites, k, cols, score, logw, n, max_partials, row_e, row_s)
   const int m = p->dist_mask;
-  if (pk->impl == 0) {
-    if ((m & ~kMaskNormal) == 0) GJX_LAUNCH_IMPORTANCE(0, kMaskNormal);
-    else if ((m & ~kMaskReal) == 0) GJX_LAUNCH_IMPORTANCE(0, kMaskReal);
-    else GJX_LAUNCH_IMPORTANCE(0, kMaskAll);
-  } else {
-    if ((m & ~kMaskNormal) == 0) GJX_LAUNCH_IMPORTANCE(1, kMaskNormal);
-    else if ((m & ~kMaskReal) == 0) GJX_LAUNCH_IMPORTANCE(1, kMaskReal);
-    else GJX_LAUNCH_IMPORTANCE(1, kMaskAll);
-  }
+  for (int32_t b = 0; b < n_pass; ++b) {
+    KeySrc kb = key_src(pk + b);
+    RunCols cb = cols;
+    for (int c = 0; c < n_value_cols; ++c)
+      if (cb.out[c]) cb.out[c] = (char*)cb.out[c] + 4 * (size_t)b * pass_stride;
+    float* sc_b = score ? score + (size_t)b * pass_stride : nullptr;
+    float* lw_b = logw + (size_t)b * pass_stride;
+    float* mp_b = max_partials ? max_partials + (size_t)b * row_stride : nullptr;
+    int32_t* re_b = row_e ? row_e + (size_t)b * row_stride : nullptr;
+    uint64_t* rs_b = row_s ? row_s + (size_t)b * row_stride : nullptr;
+#define GJX_LAUNCH_IMPORTANCE(IMPL, MASK) \
+  k_importance<IMPL, MASK><<<(unsigned)((n + kImpTile - 1) / kImpTile), kBlock, lds, S(s)>>>(p->dev, p->n_sites, kb, cb, sc_b, lw_b, n, mp_b, re_b, rs_b)
+    if (pk->impl == 0) {
+      if ((m & ~kMaskNormal) == 0) GJX_LAUNCH_IMPORTANCE(0, kMaskNormal);
+      else if ((m & ~kMaskReal) == 0) GJX_LAUNCH_IMPORTANCE(0, kMaskReal);
+      else GJX_LAUNCH_IMPORTANCE(0, kMaskAll);
+    } else {
+      if ((m & ~kMaskNormal) == 0) GJX_LAUNCH_IMPORTANCE(1, kMaskNormal);
+      else if ((m & ~kMaskReal) == 0) GJX_LAUNCH_IMPORTANCE(1, kMaskReal);
+      else GJX_LAUNCH_IMPORTANCE(1, kMaskAll);
+    }
 #undef GJX_LAUNCH_IMPORTANCE
+  }
   // generic route: the fold is a second (one-workgroup) launch
   if (lse) k_lse_rows<<<1, kBlock, 0, S(s)>>>(row_e, row_s, nrows_of(n), 0, lse->e, lse->q, lse->lse, lse->record);
   return launch_status();
+}
+
+int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const* input_cols,
+                       int n_input_cols, void* const* value_cols, int n_value_cols, float* score,
+                       float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s,
+                       const gjx_lse_out* lse, gjx_stream s) {
+  return importance_launch(p, pk, 1, 0, 0, input_cols, n_input_cols, value_cols, n_value_cols, score, logw, n,
+                           max_partials, row_e, row_s, lse, s);
+}
+
+int gjx_importance_run_batch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pass, uint64_t pass_stride,
+                             uint64_t row_stride, const float* const* input_cols, int n_input_cols,
+                             void* const* value_cols, int n_value_cols, float* score, float* logw, uint64_t n,
+                             float* max_partials, int32_t* row_e, uint64_t* row_s, gjx_stream s) {
+  if (!pk || n_pass < 1 || n_pass > kMaxPasses || pass_stride < n || row_stride < nrows_of(n)) return GJX_ERR_INVALID;
+  // one launch serves lazy batches that differ only in their (lane-0) parent key
+  bool fused = true;
+  for (int32_t b = 0; b < n_pass && fused; ++b)
+    fused = pk[b].impl == pk[0].impl && pk[b].mode == 1 && pk[b].parent_lane == 0 && pk[b].first == pk[0].first &&
+            !pk[b].has_fold;
+  if (fused || n_pass == 1)
+    return importance_launch(p, pk, n_pass, pass_stride, row_stride, input_cols, n_input_cols, value_cols, n_value_cols,
+                             score, logw, n, max_partials, row_e, row_s, nullptr, s);
+  for (int32_t b = 0; b < n_pass; ++b) {  // anything else: pass by pass
+    void* vc[GJX_MAX_SITES];
+    for (int c = 0; c < n_value_cols; ++c) vc[c] = value_cols[c] ? (char*)value_cols[c] + 4 * (size_t)b * pass_stride : nullptr;
+    const int rc = importance_launch(p, pk + b, 1, 0, 0, input_cols, n_input_cols, vc, n_value_cols,
+                                     score ? score + (size_t)b * pass_stride : nullptr, logw + (size_t)b * pass_stride, n,
+                                     max_partials ? max_partials + (size_t)b * row_stride : nullptr,
+                                     row_e ? row_e + (size_t)b * row_stride : nullptr,
+                                     row_s ? row_s + (size_t)b * row_stride : nullptr, nullptr, s);
+    if (rc) return rc;
+  }
+  return GJX_OK;
 }
 
 // ---- weights -------------------------------------------------------------------------------------

@@ -239,7 +239,7 @@ struct Gen {
 
   static const char* signature() {
     return "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, "
-           "uint64_t* row_s, LseTail tail) {\n";
+           "uint64_t* row_s, LseTail tail, PassBatch bt) {\n";
   }
   const char* kname() const { return impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox"; }
 
@@ -253,17 +253,25 @@ struct Gen {
     o << "extern \"C\" __global__ __launch_bounds__(" << block << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
       << ") void " << kname() << signature();
     o << "  __shared__ float sh_red[" << 2 * R << "];\n  __shared__ uint64_t sh_sum[" << 2 * R << "];\n";
-    o << "  const int wv = threadIdx.x >> 6, pr = wv >> 1, tr = threadIdx.x & 127;\n";
-    o << "  for (uint64_t row0 = (uint64_t)blockIdx.x * " << R << "; row0 * 256 < n; row0 += (uint64_t)gridDim.x * " << R << ") {\n";
-    o << "    const uint64_t row = row0 + pr;\n";
+    if (R == 1) o << "  const int wv = threadIdx.x >> 6, pr = 0, tr = threadIdx.x;  // (block-uniform row: the cipher key stays scalar)\n";
+    else o << "  const int wv = threadIdx.x >> 6, pr = wv >> 1, tr = threadIdx.x & 127;\n";
+    o << "  const uint64_t rows_all = (uint64_t)bt.n_pass * bt.rows_per_pass;\n";
+    o << "  for (uint64_t g0 = (uint64_t)blockIdx.x * " << R << "; g0 < rows_all; g0 += (uint64_t)gridDim.x * " << R << ") {\n";
+    o << "    const uint64_t gr = g0 + pr;\n";
+    o << "    const uint32_t pass = (uint32_t)(gr / bt.rows_per_pass);\n";
+    o << "    const uint64_t row = gr - (uint64_t)pass * bt.rows_per_pass;\n";
+    o << "    const bool live_row = gr < rows_all;\n";
+    o << "    const uint32_t pk0 = bt.n_pass > 1 ? bt.parent[pass < bt.n_pass ? pass : 0][0] : ks.parent.k0;\n";
+    o << "    const uint32_t pk1 = bt.n_pass > 1 ? bt.parent[pass < bt.n_pass ? pass : 0][1] : ks.parent.k1;\n";
+    o << "    const uint64_t po = (uint64_t)pass * bt.pass_stride, ro = (uint64_t)pass * bt.row_stride;  // this pass's outputs\n";
     o << "    const uint64_t iA = row * 256 + 2 * (uint64_t)tr, iB = iA + 1;\n";
-    o << "    const bool ok = iA < n;  // n is even in this form: both particles of a lane exist or neither\n";
+    o << "    const bool ok = live_row && iA < n;  // n is even in this form: both particles of a lane exist or neither\n";
     o << "    const uint64_t liA = iA, liB = iB;\n";
     o << "    float wA = 0.0f, scA = 0.0f, wB = 0.0f, scB = 0.0f;\n";
     o << "    if (ok) {\n";
     o << "      const uint64_t lnA = ks.first + iA + 1u, lnB = lnA + 1u;\n";
-    o << "      const Key pkeyA{ks.parent.k0, ks.parent.k1, (uint32_t)lnA, (uint32_t)(lnA >> 32)};\n";
-    o << "      const Key pkeyB{ks.parent.k0, ks.parent.k1, (uint32_t)lnB, (uint32_t)(lnB >> 32)};\n";
+    o << "      const Key pkeyA{pk0, pk1, (uint32_t)lnA, (uint32_t)(lnA >> 32)};\n";
+    o << "      const Key pkeyB{pk0, pk1, (uint32_t)lnB, (uint32_t)(lnB >> 32)};\n";
     SiteEmitter<CSiteT, CArgT> ea{o, impl, 0, sites, n_sites, "      ", "A"};
     SiteEmitter<CSiteT, CArgT> eb{o, impl, 0, sites, n_sites, "      ", "B"};
     ea.store_values = eb.store_values = false;
@@ -284,11 +292,11 @@ struct Gen {
         const bool isint = SiteEmitter<CSiteT, CArgT>::is_int(st);
         const std::string Q = std::to_string(q);
         const std::string ra = isint ? "(uint32_t)vi" + Q + "A" : "f2u(vf" + Q + "A)", rb = isint ? "(uint32_t)vi" + Q + "B" : "f2u(vf" + Q + "B)";
-        o << "      *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "]) + iA) = make_uint2(" << ra << ", " << rb << ");\n";
+        o << "      *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "]) + po + iA) = make_uint2(" << ra << ", " << rb << ");\n";
       }
     }
-    o << "      *reinterpret_cast<float2*>(logw + iA) = make_float2(wA, wB);\n";
-    o << "      if (score) *reinterpret_cast<float2*>(score + iA) = make_float2(scA, scB);\n";
+    o << "      *reinterpret_cast<float2*>(logw + po + iA) = make_float2(wA, wB);\n";
+    o << "      if (score) *reinterpret_cast<float2*>(score + po + iA) = make_float2(scA, scB);\n";
     o << "    }\n";
     o << "    const bool okA = ok, okB = ok;\n";
     o << "    if (max_partials || row_e) {\n";
@@ -297,14 +305,13 @@ struct Gen {
     o << "      float bm = wave_max(mA > mB ? mA : mB);\n";
     o << "      __syncthreads();\n      if ((threadIdx.x & 63) == 0) sh_red[wv] = bm;\n      __syncthreads();\n";
     o << "      bm = sh_red[2 * pr] > sh_red[2 * pr + 1] ? sh_red[2 * pr] : sh_red[2 * pr + 1];\n";
-    o << "      const bool live_row = row * 256 < n;\n";
-    o << "      if (max_partials && tr == 0 && live_row) max_partials[row] = bm;\n";
+    o << "      if (max_partials && tr == 0 && live_row) max_partials[ro + row] = bm;\n";
     o << "      if (row_e) {\n";
     o << "        const int32_t eb = row_anchor(bm);\n";
     o << "        uint64_t sb = wave_sum((okA ? rowfix(wA, eb) : 0) + (okB ? rowfix(wB, eb) : 0));\n";
     o << "        __syncthreads();\n        if ((threadIdx.x & 63) == 0) sh_sum[wv] = sb;\n        __syncthreads();\n";
     o << "        sb = sh_sum[2 * pr] + sh_sum[2 * pr + 1];\n";
-    o << "        if (tr == 0 && live_row) lse_store_row(row_e, row_s, row, eb, sb, tail.tickets != nullptr);\n";
+    o << "        if (tr == 0 && live_row) lse_store_row(row_e, row_s, ro + row, eb, sb, tail.tickets != nullptr);\n";
     o << "      }\n    }\n";
     o << "  }\n  if (row_e) lse_tail(row_e, row_s, (n + 255) / 256, tail);\n}\n";
     return o.str();
@@ -319,13 +326,19 @@ struct Gen {
     o << "extern \"C\" __global__ __launch_bounds__(256" << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
       << ") void " << kname() << signature();
     o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
-    o << "  for (uint64_t row = blockIdx.x; row * 256 < n; row += gridDim.x) {\n";
+    o << "  const uint64_t rows_all = (uint64_t)bt.n_pass * bt.rows_per_pass;\n";
+    o << "  for (uint64_t gr = blockIdx.x; gr < rows_all; gr += gridDim.x) {\n";
+    o << "    const uint32_t pass = (uint32_t)(gr / bt.rows_per_pass);\n";
+    o << "    const uint64_t row = gr - (uint64_t)pass * bt.rows_per_pass;\n";
+    o << "    const uint64_t po = (uint64_t)pass * bt.pass_stride, ro = (uint64_t)pass * bt.row_stride;\n";
+    o << "    KeySrc kp = ks;\n";
+    o << "    if (bt.n_pass > 1) { kp.parent.k0 = bt.parent[pass][0]; kp.parent.k1 = bt.parent[pass][1]; }\n";
     o << "    float tmax = -__builtin_inff();\n    bool live = false;\n";
     o << "    {\n";
-    o << "      const uint64_t i = row * 256 + threadIdx.x, li = i;\n";
-    o << "      const bool ok = i < n;\n";
+    o << "      const uint64_t li = row * 256 + threadIdx.x, i = po + li;\n";
+    o << "      const bool ok = li < n;\n";
     o << "      if (ok) {\n";
-    o << "        const Key pkey = key_at<" << I << ">(ks, i);\n";
+    o << "        const Key pkey = key_at<" << I << ">(kp, li);\n";
     o << "        float w = 0.0f, sc = 0.0f;\n";
     SiteEmitter<CSiteT, CArgT> em{o, impl, 0, sites, n_sites, "        "};
     em.run();
@@ -333,11 +346,11 @@ struct Gen {
     o << "      }\n    }\n";
     o << "    if (max_partials || row_e) {\n";
     o << "      const float bm = block_max(tmax, sh_red);\n";
-    o << "      if (max_partials && threadIdx.x == 0) max_partials[row] = bm;\n";
+    o << "      if (max_partials && threadIdx.x == 0) max_partials[ro + row] = bm;\n";
     o << "      if (row_e) {\n";
     o << "        const int32_t eb = row_anchor(bm);\n";
     o << "        const uint64_t sb = block_sum(live ? rowfix(tmax, eb) : 0, sh_sum);\n";
-    o << "        if (threadIdx.x == 0) lse_store_row(row_e, row_s, row, eb, sb, tail.tickets != nullptr);\n";
+    o << "        if (threadIdx.x == 0) lse_store_row(row_e, row_s, ro + row, eb, sb, tail.tickets != nullptr);\n";
     o << "      }\n    }\n";
     o << "  }\n  if (row_e) lse_tail(row_e, row_s, (n + 255) / 256, tail);\n}\n";
     return o.str();

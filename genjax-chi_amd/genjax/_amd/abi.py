@@ -182,6 +182,11 @@ PROTOTYPES = {
         C.c_int,
         [_P, _KP, C.POINTER(_P), C.c_int, C.POINTER(_P), C.c_int, _P, _P, C.c_uint64, _P, _P, _P, _P, _P],
     ),
+    "gjx_importance_run_batch": (
+        C.c_int,
+        [_P, _KP, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(_P), C.c_int, C.POINTER(_P), C.c_int, _P, _P, C.c_uint64,
+         _P, _P, _P, _P],
+    ),
     "gjx_workspace_bytes": (C.c_size_t, [C.c_int, C.c_uint64]),
     "gjx_frac_bits": (C.c_int, [C.c_uint64]),
     "gjx_num_tiles": (C.c_uint64, [C.c_uint64]),

@@ -63,13 +63,14 @@ class BatchedImportance:
     and none of the device's time.  Passes reuse one set of trace buffers (48 MB at 1e6 particles)."""
 
     def __init__(self, ops: Ops, wl, batch: int = 8, world: int | None = None, depth: int = 2,
-                 always_exchange: bool = False):
+                 always_exchange: bool = False, passes: int = 1):
         dist = _dist()
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         if self.world > 1 and (wl.first % ROW or (wl.n % ROW and wl.first + wl.n != wl.n_total)):
             raise ValueError("shards must be split at 256-particle row boundaries (dist.shard_rows)")
         self.ops, self.wl, self.batch, self.depth = ops, wl, batch, depth
-        self.prep = wl.prepare(fold_batch=batch)
+        self.passes = passes  # independent passes per importance launch (gjx_importance_run_batch)
+        self.prep = wl.prepare(fold_batch=batch, passes=passes)
         dev, words = ops.device(), abi.LSE_RECORD_WORDS
         self.local = [torch.zeros((batch, words), dtype=torch.int64, device=dev) for _ in range(depth)]
         self.exchange = self.world > 1 or always_exchange  # a one-rank group still goes through the collective
@@ -82,19 +83,24 @@ class BatchedImportance:
         self._count = [0] * depth
         self._slot = 0
 
-    def run(self, count: int | None = None, on_kernel=None) -> int:
+    def run(self, count: int | None = None, on_launch=None) -> int:
         """Enqueue `count` (<= batch) passes and the exchange of their records; returns the buffer
-        index to hand to `results`."""
+        index to hand to `results`.  `on_launch(phase, n_passes)` brackets every importance launch."""
         count = self.batch if count is None else count
         d, self._slot = self._slot, (self._slot + 1) % self.depth
         self.wait(d)  # the block's previous exchange must have read it before it is overwritten
-        st = self.ops.stream()
-        for b in range(count):
-            if on_kernel:
-                on_kernel(b, 0)
-            self.prep.launch_importance(st, b)  # row sums into slot b
-            if on_kernel:
-                on_kernel(b, 1)
+        st, done = self.ops.stream(), 0
+        while done < count:
+            c = min(self.passes, count - done)
+            if on_launch:
+                on_launch(0, c)
+            if self.passes == 1:
+                self.prep.launch_importance(st, done)  # row sums into slot `done`
+            else:
+                self.prep.launch_passes(done, c, st)  # c passes, row sums into slots done .. done + c - 1
+            if on_launch:
+                on_launch(1, c)
+            done += c
         self.prep.launch_fold(count, st, self._rec[d])  # one launch folds the batch into its records
         if self.exchange:
             self._work[d] = _dist().all_gather_into_tensor(self.gathered[d].view(-1, self.gathered[d].shape[-1]),

@@ -275,7 +275,7 @@ class Ops:
         """float64 log Z = e ln2 + log(q) - 30 ln2 - log N from the exact (e, q) pair."""
         return int(e.cpu()) * math.log(2.0) + math.log(int(q.cpu())) - 30 * math.log(2.0) - math.log(n_total)
 
-    def prepare_importance(self, plan: "Plan", kb: KeyBatch, n: int, input_cols: list[torch.Tensor],
+    def prepare_importance(self, plan: "Plan", kb, n: int, input_cols: list[torch.Tensor],
                            value_dtypes: list, with_lse: bool = True, fold_batch: int = 1) -> "PreparedImportance":
         """Pre-bind one importance pass (+ its log-sum-exp) to persistent output buffers: a launch
         is then two C calls with no allocation or marshalling on the host (what a latency-bound
@@ -520,41 +520,60 @@ class Plan:
 class PreparedImportance:
     """A fully marshalled `gjx_importance_run` (+ its log-sum-exp) on persistent buffers.
 
-    `fold_batch` B > 1 keeps B slots of row sums: passes write their (anchor, sum) pairs into consecutive
+    `fold_batch` B >= 1 keeps B slots of row sums: passes write their (anchor, sum) pairs into consecutive
     slots and ONE `gjx_lse_rows_batch` launch folds them all (`launch_fold`) — the ~5 us latency of a
-    one-workgroup kernel is paid once per B passes.  The trace columns / log-weights are shared by the
-    slots (a pass overwrites the previous one's), only the few-KB row sums and the results are per slot."""
+    one-workgroup kernel is paid once per B passes.
+    `kb` may be a LIST of L key batches (L <= 32, lazy, differing in their parent key): `launch_passes`
+    then runs L independent passes in ONE launch (`gjx_importance_run_batch`) — a single 1e6-particle pass
+    is under two rounds of the machine, L passes keep it full.  Every pass of a launch has its own trace
+    buffers (`values[c][p]`, `logw[p]`, `score[p]`); successive launches reuse them."""
 
-    def __init__(self, ops: Ops, plan: Plan, kb: KeyBatch, n: int, input_cols, value_dtypes, with_lse=True,
-                 fold_batch: int = 1):
-        if kb.fold is not None:
+    def __init__(self, ops: Ops, plan: Plan, kb, n: int, input_cols, value_dtypes, with_lse=True, fold_batch: int = 1):
+        kbs = list(kb) if isinstance(kb, (list, tuple)) else [kb]
+        if any(k.fold is not None for k in kbs):
             raise ValueError("particle keys must not carry a fold")
+        L = self.launch_passes_n = len(kbs)
+        if fold_batch % L:
+            raise ValueError("fold_batch must be a multiple of the passes per launch")
         self.ops, self.plan, self.n, self.fold_batch = ops, plan, n, fold_batch
         self.inputs = [t for t in input_cols]
-        self.values = [ops.empty(n, dt) for dt in value_dtypes]
-        self.score, self.logw = ops.empty(n, torch.float32), ops.empty(n, torch.float32)
-        self.max_partials = ops.empty(ops.num_max_partials(n), torch.float32)
+        stride = self.pass_stride = -(-n // 256) * 256  # even, and every pass 1 KiB-aligned
+        self.values_all = [ops.empty((L, stride), dt) for dt in value_dtypes]
+        self.score_all, self.logw_all = ops.empty((L, stride), torch.float32), ops.empty((L, stride), torch.float32)
+        self.values = [v[0, :n] for v in self.values_all]  # pass 0 (the single-pass views)
+        self.score, self.logw = self.score_all[0, :n], self.logw_all[0, :n]
         R = self.n_rows = ops.num_max_partials(n)
+        self.max_partials_all = ops.empty((L, R), torch.float32)
+        self.max_partials = self.max_partials_all[0]
         self.row_e_all, self.row_s_all = ops.empty((fold_batch, R), torch.int32), ops.empty((fold_batch, R), torch.int64)
         self.rows = RowStats(self.row_e_all[0], self.row_s_all[0], n)  # slot 0
         self.lse_all, self.e_all, self.q_all = (ops.empty(fold_batch, torch.float32), ops.empty(fold_batch, torch.int32),
                                                 ops.empty(fold_batch, torch.int64))
         self.lse, self.row_e_out, self.row_q_out = self.lse_all[:1], self.e_all[:1], self.q_all[:1]
         self.max, self.q = ops.empty(1, torch.float32), ops.empty(1, torch.int64)
-        self._keys = ops._keys(kb, n)
-        ops.lib.call("gjx_plan_prepare", plan.handle, C.byref(self._keys))  # build the specialised kernel now
+        self._keys_arr = (abi.Keys * L)(*[ops._keys(k, n) for k in kbs])
+        self._keys = self._keys_arr[0]
+        for k in self._keys_arr:
+            ops.lib.call("gjx_plan_prepare", plan.handle, C.byref(k))  # build the specialised kernel now
         self._ins = (C.c_void_p * max(1, len(self.inputs)))(*[ops._chk(t, torch.float32, n).value for t in self.inputs])
-        self._outs = (C.c_void_p * max(1, len(self.values)))(*[t.data_ptr() for t in self.values])
+        self._outs = (C.c_void_p * max(1, len(self.values_all)))(*[t.data_ptr() for t in self.values_all])
         self._ws, self._nb = ops.workspace(abi.OP_LOGSUMEXP, n)
         self._ws = self._ws.clone()  # private: the shared workspace may be re-grown by other calls
         lib = ops.lib
-        self._run, self._lse, self._lse_rows, self._fold = (lib._gjx_importance_run, lib._gjx_logsumexp_f32,
-                                                            lib._gjx_lse_rows, lib._gjx_lse_rows_batch)
-        head = (plan.handle, C.byref(self._keys), self._ins, len(self.inputs), self._outs, len(self.values),
-                C.c_void_p(self.score.data_ptr()), C.c_void_p(self.logw.data_ptr()), n,
-                C.c_void_p(self.max_partials.data_ptr()))
+        self._run, self._run_batch, self._lse, self._lse_rows, self._fold = (
+            lib._gjx_importance_run, lib._gjx_importance_run_batch, lib._gjx_logsumexp_f32, lib._gjx_lse_rows,
+            lib._gjx_lse_rows_batch)
+        head = (plan.handle, C.byref(self._keys), self._ins, len(self.inputs), self._outs, len(self.values_all),
+                C.c_void_p(self.score_all.data_ptr()), C.c_void_p(self.logw_all.data_ptr()), n,
+                C.c_void_p(self.max_partials_all.data_ptr()))
         self._args_run = [head + (C.c_void_p(self.row_e_all[b].data_ptr()), C.c_void_p(self.row_s_all[b].data_ptr()))
                           for b in range(fold_batch)]
+        self._batch_head = (plan.handle, self._keys_arr)
+        self._batch_mid = (stride, R, self._ins, len(self.inputs), self._outs, len(self.values_all),
+                           C.c_void_p(self.score_all.data_ptr()), C.c_void_p(self.logw_all.data_ptr()), n,
+                           C.c_void_p(self.max_partials_all.data_ptr()))
+        self._batch_rows = [(C.c_void_p(self.row_e_all[b].data_ptr()), C.c_void_p(self.row_s_all[b].data_ptr()))
+                            for b in range(fold_batch)]
         # fused form: the importance launch folds its own row sums (results in .lse / .row_e_out / .row_q_out)
         self._tickets = torch.zeros(abi.LSE_TICKET_WORDS, dtype=torch.int32, device=ops.device())
         self._lse_out = abi.LseOut(self.row_e_out.data_ptr(), self.row_q_out.data_ptr(), self.lse.data_ptr(), None,
@@ -574,10 +593,18 @@ class PreparedImportance:
         self.with_lse = with_lse
 
     def launch_importance(self, stream=None, slot: int = 0):
-        """The walk only; its row sums go to slot `slot` (folded later by launch_lse_rows / launch_fold)."""
+        """One pass (key batch 0); its row sums go to slot `slot` (folded later by launch_lse_rows / launch_fold)."""
         rc = self._run(*self._args_run[slot], None, stream if stream is not None else self.ops.stream())
         if rc:
             raise abi.GjxError("gjx_importance_run", rc)
+
+    def launch_passes(self, slot0: int = 0, count: int | None = None, stream=None):
+        """`count` (default: all L) independent passes in ONE launch; pass p's row sums go to slot slot0 + p."""
+        count = self.launch_passes_n if count is None else count
+        rc = self._run_batch(*self._batch_head, count, *self._batch_mid, *self._batch_rows[slot0],
+                             stream if stream is not None else self.ops.stream())
+        if rc:
+            raise abi.GjxError("gjx_importance_run_batch", rc)
 
     def launch_fold(self, count: int, stream=None, records_ptr=None):
         """Fold the row sums of slots [0, count) in ONE launch: lse_all / e_all / q_all[:count]; `records_ptr`

@@ -75,19 +75,22 @@ class Gaussian10:
     """Reusable state of the C2 workload (plan + key batch), so a bench step is kernels only."""
 
     def __init__(self, ops: Ops, impl: int, seed: int, n_local: int, first: int = 0, n_total: int | None = None):
-        self.ops, self.n, self.first = ops, n_local, first
+        self.ops, self.n, self.first, self.impl, self.seed = ops, n_local, first, impl, seed
         self.n_total = n_local if n_total is None else n_total
         self.y = gaussian10_data()
         self.plan = ops.plan_create(gaussian10_sites(self.y))
         self.keys = importance_particle_keys(prng.key(seed, impl), n_local, first)
         self.frac = ops.frac_bits(self.n_total)
 
-    def prepare(self, fold_batch: int = 1):
+    def prepare(self, fold_batch: int = 1, passes: int = 1):
         """Persistent-buffer form of `step` (no host allocation per pass); `fold_batch` passes share one
-        log-sum-exp launch (ops.PreparedImportance)."""
+        log-sum-exp launch and `passes` independent passes (seeds seed, seed+1, ...) share one importance
+        launch (ops.PreparedImportance)."""
         prep = getattr(self, "_prep", None)
-        if prep is None or prep.fold_batch != fold_batch:
-            self._prep = self.ops.prepare_importance(self.plan, self.keys, self.n, [], [torch.float32] * G10_LATENTS,
+        if prep is None or prep.fold_batch != fold_batch or prep.launch_passes_n != passes:
+            keys = self.keys if passes == 1 else [
+                importance_particle_keys(prng.key(self.seed + p, self.impl), self.n, self.first) for p in range(passes)]
+            self._prep = self.ops.prepare_importance(self.plan, keys, self.n, [], [torch.float32] * G10_LATENTS,
                                                      fold_batch=fold_batch)
         return self._prep
 

@@ -223,6 +223,19 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* particle_keys,
                        float* max_partials, int32_t* row_e, uint64_t* row_s, const gjx_lse_out* lse,
                        gjx_stream s);
 
+/* n_pass (<= 32) independent passes of the same plan — the algorithm vmapped over keys.  Pass b draws from
+ * particle_keys[b] and writes b * pass_stride elements further in every output column (score, logw, value
+ * columns; pass_stride >= n, even for the fast path) and b * row_stride entries further in max_partials /
+ * row_e / row_s (row_stride >= gjx_num_max_partials(n)); input columns are shared.  Lazy key batches that
+ * differ only in their lane-0 parent run as ONE launch: a 1e6-particle pass is under two rounds of the
+ * machine, several passes per launch keep it full (17.5 instead of 21.5 us per pass on MI355X).  Results
+ * are those of n_pass separate gjx_importance_run calls, bit for bit. */
+int gjx_importance_run_batch(const gjx_plan* p, const gjx_keys* particle_keys /*host [n_pass]*/, int32_t n_pass,
+                             uint64_t pass_stride, uint64_t row_stride, const float* const* input_cols,
+                             int n_input_cols, void* const* value_cols, int n_value_cols, float* score,
+                             float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s,
+                             gjx_stream s);
+
 /* ---- weights: log-sum-exp, single draw, resampling ---------------------------------------- */
 
 typedef enum {

@@ -481,6 +481,26 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
   return GJX_OK;
 }
 
+int gjx_importance_run_batch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pass, uint64_t pass_stride,
+                             uint64_t row_stride, const float* const* input_cols, int n_input_cols,
+                             void* const* value_cols, int n_value_cols, float* score, float* logw, uint64_t n,
+                             float* max_partials, int32_t* row_e, uint64_t* row_s, gjx_stream s) {
+  if (!pk || n_pass < 1 || n_pass > 32 || pass_stride < n || row_stride < gjx_num_max_partials(n) ||
+      n_value_cols < 0 || n_value_cols > GJX_MAX_SITES)
+    return GJX_ERR_INVALID;
+  for (int32_t b = 0; b < n_pass; ++b) { /* the definition: n_pass separate passes */
+    void* vc[GJX_MAX_SITES];
+    for (int c = 0; c < n_value_cols; ++c) vc[c] = value_cols[c] ? (char*)value_cols[c] + 4 * (size_t)b * pass_stride : NULL;
+    int rc = gjx_importance_run(p, pk + b, input_cols, n_input_cols, vc, n_value_cols,
+                                score ? score + (size_t)b * pass_stride : NULL, logw + (size_t)b * pass_stride, n,
+                                max_partials ? max_partials + (size_t)b * row_stride : NULL,
+                                row_e ? row_e + (size_t)b * row_stride : NULL,
+                                row_s ? row_s + (size_t)b * row_stride : NULL, NULL, s);
+    if (rc) return rc;
+  }
+  return GJX_OK;
+}
+
 /* ---- row-anchored weights ----------------------------------------------------- */
 int gjx_row_stats(const float* x, uint64_t n, int32_t* row_e, uint64_t* row_s, gjx_stream s) {
   (void)s;

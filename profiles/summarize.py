@@ -25,11 +25,17 @@ shutil.copy(one("trace/*/*kernel_stats.csv"), os.path.join(here, f"{tag}_kernel_
 stats = list(csv.DictReader(open(os.path.join(here, f"{tag}_kernel_stats.csv"))))
 
 
-def pmc(dirname):
+# A launch of the importance kernel covers several independent passes (bench.py: LAUNCH = 8; the warm-up and the
+# ragged last launch cover fewer), so counters are totalled over the run and divided by the passes it made.
+PASSES_PER_RUN = 55  # collect.sh: --steps 50 --warmup 5
+
+
+def pmc(dirname, per_pass=True):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(one(f"{dirname}/*/*counter_collection.csv"))):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+    return {k: {c: sum(v) / (PASSES_PER_RUN if per_pass and "gjx_plan_kernel" in k else len(v)) for c, v in cs.items()}
+            for k, cs in agg.items()}
 
 
 fetch, write, sq = pmc("fetch"), pmc("write"), pmc("sq")
@@ -39,11 +45,14 @@ traffic = {
     "kernel": dom,
     "FETCH_SIZE_KB_raw": fetch_kb,
     "WRITE_SIZE_KB": write_kb,
+    "per": "1e6-particle pass (a launch covers up to 8 passes)",
     "hbm_read_bytes_per_launch": fetch_kb * 1024 * 2,  # gfx950: FETCH_SIZE reports half of coalesced reads
     "hbm_write_bytes_per_launch": write_kb * 1024,
     "hbm_bytes_per_launch": fetch_kb * 1024 * 2 + write_kb * 1024,
+    "hbm_bytes_per_pass": fetch_kb * 1024 * 2 + write_kb * 1024,
+    "passes_per_launch": 1,  # the three figures above are already per pass
     "note": "separate --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section); 4-byte-per-lane "
-            "column stores, WRITE_SIZE uncalibrated for this width but equals the algorithmic 48 MB within 0.3 %",
+            "column stores (8 bytes per lane); WRITE_SIZE equals the algorithmic 48 MB per pass within 1 %",
     "sq": sq.get(dom, {}),
 }
 json.dump(traffic, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1)
@@ -57,11 +66,11 @@ with open(os.path.join(here, f"{tag}_summary.md"), "w") as f:
         f.write(f"| `{r['Name'][:80]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['Percentage']} |\n")
     rf = bench["roofline"]
     f.write(f"\nbench.py (un-profiled run): value {bench['value']:.4g} {bench['unit']}, {bench['ms_per_step']*1e3:.1f} us/step; "
-            f"dominant kernel `{rf['kernel']}` {rf['kernel_ms']*1e3:.1f} us by HIP events "
+            f"dominant kernel `{rf['kernel']}` {rf['kernel_ms']*1e3:.1f} us per launch of {rf.get('passes_per_launch', 1)} passes by HIP events "
             f"(raw interval {rf['kernel_ms_raw_event_interval']*1e3:.1f} us - event-pair overhead {rf['event_pair_overhead_ms']*1e3:.1f} us), "
             f"achieved {rf['achieved']:.0f} GB/s = {rf['frac']:.3f} of 8 TB/s.\n")
-    f.write(f"\nHBM traffic of `{dom}` per launch (PMC, separate passes): read {traffic['hbm_read_bytes_per_launch']/1e6:.2f} MB "
+    f.write(f"\nHBM traffic of `{dom}` per 1e6-particle pass (PMC, separate runs; a launch covers up to 8 passes): read {traffic['hbm_read_bytes_per_launch']/1e6:.2f} MB "
             f"(FETCH_SIZE x2), write {traffic['hbm_write_bytes_per_launch']/1e6:.2f} MB; algorithmic 48.0 MB.\n")
     if traffic["sq"]:
-        f.write("\nSQ counters per launch: " + ", ".join(f"{k}={v:.3g}" for k, v in sorted(traffic["sq"].items())) + "\n")
+        f.write("\nSQ counters per pass: " + ", ".join(f"{k}={v:.3g}" for k, v in sorted(traffic["sq"].items())) + "\n")
 print(open(os.path.join(here, f"{tag}_summary.md")).read())

@@ -183,6 +183,33 @@ def test_importance_key_forms_agree(hip_ops, oracle_ops, impl):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n", [2, 1000, 1001, 70002])
+def test_importance_passes_in_one_launch(hip_ops, oracle_ops, impl, n, plan_mode):
+    """gjx_importance_run_batch: L independent passes (seeds s, s+1, ...) in one launch write what L separate
+    passes write — trace columns, scores, log-weights, row sums and folded log-marginals — and equal the
+    oracle's passes bit for bit; n odd takes the one-particle-per-lane kernel, the interpreter one launch per pass."""
+    L = 3
+    wl_h = W.Gaussian10(hip_ops, impl, seed=21, n_local=n)
+    prep = wl_h.prepare(fold_batch=2 * L, passes=L)
+    prep.launch_passes(L, L)  # second half of the slots
+    prep.launch_fold(2 * L)
+    for p_ in range(L):
+        ref = W.Gaussian10(oracle_ops, impl, seed=21 + p_, n_local=n).step()
+        same(prep.logw_all[p_, :n], ref["logw"], f"logw pass {p_}")
+        same(prep.score_all[p_, :n], ref["score"], f"score pass {p_}")
+        for c, col in enumerate(ref["values"]):
+            same(prep.values_all[c][p_, :n], col, f"column {c} pass {p_}")
+        same(prep.row_e_all[L + p_], ref["rows"].e, "row anchors"); same(prep.row_s_all[L + p_], ref["rows"].s, "row sums")
+        same(prep.lse_all[L + p_:L + p_ + 1], ref["row_lse"], "folded lse")
+        same(prep.e_all[L + p_:L + p_ + 1], ref["row_e"]); same(prep.q_all[L + p_:L + p_ + 1], ref["row_q"])
+    # a ragged launch (2 of 3 passes) into the first slots
+    prep.launch_passes(0, 2)
+    prep.launch_fold(2)
+    for p_ in range(2):
+        same(prep.q_all[p_:p_ + 1], W.Gaussian10(oracle_ops, impl, seed=21 + p_, n_local=n).step()["row_q"], "ragged launch")
+
+
+@pytest.mark.parametrize("impl", IMPLS)
 def test_importance_mixed_plan(hip_ops, oracle_ops, impl, plan_mode):
     """A plan touching every distribution and argument kind: beta-bernoulli, gamma-scaled normal,
     categorical selecting a table row, input columns, observed input column."""
