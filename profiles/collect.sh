@@ -8,7 +8,9 @@ TAG=${1:-r01}
 OUT=gpurun_out/profiles_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 rm -rf "$OUT" && mkdir -p "$OUT"
-BENCH="python3 bench.py --steps 50 --warmup 5"
+# 48 timed + 8 warm-up passes: every importance launch then covers exactly 8 passes (bench.py LAUNCH), so the
+# per-launch averages of rocprof and of bench.py's HIP events describe the same thing
+BENCH="python3 bench.py --steps 48 --warmup 8"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_under_rocprof.log" 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $BENCH --no-cpu-baseline --no-extra > "$OUT/fetch.log" 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $BENCH --no-cpu-baseline --no-extra > "$OUT/write.log" 2>&1 || exit 1

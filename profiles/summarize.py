@@ -27,7 +27,7 @@ stats = list(csv.DictReader(open(os.path.join(here, f"{tag}_kernel_stats.csv")))
 
 # A launch of the importance kernel covers several independent passes (bench.py: LAUNCH = 8; the warm-up and the
 # ragged last launch cover fewer), so counters are totalled over the run and divided by the passes it made.
-PASSES_PER_RUN = 55  # collect.sh: --steps 50 --warmup 5
+PASSES_PER_RUN = 56  # collect.sh: --steps 48 --warmup 8 (7 launches of 8 passes)
 
 
 def pmc(dirname, per_pass=True):
@@ -60,7 +60,7 @@ bench = json.loads(open(one("bench_plain.json")).read().strip().splitlines()[-1]
 json.dump(bench, open(os.path.join(here, f"{tag}_bench.json"), "w"), indent=1)
 with open(os.path.join(here, f"{tag}_summary.md"), "w") as f:
     f.write(f"# {tag}: rocprofv3 evidence (one MI355X)\n\n")
-    f.write("`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5` (collect.sh)\n\n")
+    f.write("`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 48 --warmup 8` (collect.sh; every importance launch covers 8 passes)\n\n")
     f.write("| kernel | calls | avg ns | % |\n|---|---|---|---|\n")
     for r in stats:
         f.write(f"| `{r['Name'][:80]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['Percentage']} |\n")
