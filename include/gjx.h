@@ -106,7 +106,10 @@ int gjx_rng_bits(const gjx_keys* k, uint32_t sub, uint64_t n, uint32_t* out, gjx
  * (distributions/tensorflow_probability/__init__.py:35-64; instances normal 259, gamma 164,
  * beta 82, flip 155, bernoulli 72, categorical 102-104), batched over the particle axis as
  * ImportanceK's vmap does (inference/smc.py:302-310).
- * value_out / score_out are dev [n]; score_out may be NULL.  */
+ * value_out / score_out are dev [n]; score_out may be NULL.
+ * Normal: THREEFRY draws sqrt(2) erfinv(u) (jax).  PHILOX with a fold (a model site) draws the
+ * Box-Muller pair of particles (2i, 2i+1) of the key batch: each element derives its
+ * partner's word from the key lane, so this call, gjx_importance_run and a scalar run agree bit for bit. */
 int gjx_sample_logpdf_normal(const gjx_keys* k, gjx_f32 loc, gjx_f32 scale, float* value_out,
                              float* score_out, uint64_t n, gjx_stream s);
 int gjx_sample_logpdf_gamma(const gjx_keys* k, gjx_f32 concentration, gjx_f32 rate,
