@@ -372,6 +372,34 @@ class ImportanceK(SMCAlgorithm):
         return ParticleCollection(trs, target_scores, True, max_partials=getattr(trs, "max_partials", None),
                                   row_stats=getattr(trs, "row_stats", None))
 
+    def log_marginal_likelihood_estimates(self, keys):
+        """`vmap(self.log_marginal_likelihood_estimate)(keys)`: one independent estimate per key, as a
+        float32 tensor [len(keys)].  A plan-able target without a custom proposal runs up to 32 estimates per
+        kernel launch (a single 1e6-particle pass does not keep an MI355X full for long enough); anything
+        else runs key by key.  Element b equals `self.log_marginal_likelihood_estimate(keys[b])` bit for bit."""
+        from .lang import StaticGenerativeFunction
+        from .plan import fused_log_weights_batch
+
+        keys = list(keys)
+        k = self.get_num_particles()
+        out = []
+        fusable = self.q is None and isinstance(self.target.p, StaticGenerativeFunction) and len(keys) > 1
+        for lo in range(0, len(keys), 32):
+            chunk, res = keys[lo:lo + 32], None
+            if fusable:
+                pks = []
+                for key in chunk:  # log_marginal_likelihood_estimate: split; run_smc: split, split(sub, K)
+                    _, sub_key = split(key)
+                    _, sub_key = split(sub_key)
+                    pks.append(split(sub_key, k))
+                res = fused_log_weights_batch(self.target.p, pks, self.target.constraint, self.target.args)
+            if res is None:
+                fusable = False
+                out.extend(torch.as_tensor(self.log_marginal_likelihood_estimate(key)).reshape(1) for key in chunk)
+            else:
+                out.append(res[1] - math.log(k))
+        return torch.cat([t.to(out[0].device) for t in out])
+
     def run_csmc(self, key, retained: ChoiceMap):
         k = self.get_num_particles()
         key, sub_key = split(key)

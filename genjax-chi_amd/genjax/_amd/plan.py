@@ -279,5 +279,32 @@ def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
     return tr, logw
 
 
+def fused_log_weights_batch(gen_fn, pks: list, constraint: ChoiceMap, args):
+    """Several independent importance passes of one plan-able body in ONE launch
+    (`gjx_importance_run_batch`) -> (log-weights [B, n], lse f32[B]) or None.  The passes differ only in
+    their particle keys (lazy children of B parent keys); the log-sum-exp of every pass is folded by one
+    `gjx_lse_rows_batch` launch from the row sums the kernel emitted."""
+    n = pks[0].n
+    if any(pk.n != n or pk.kb.fold is not None or pk.kb.mode != 1 for pk in pks) or any(_needs_eager(a) for a in args):
+        return None
+    tracer = PlanTracer(constraint, n)
+    try:
+        tracer.run(gen_fn.source, args)
+    except Exception:
+        return None
+    if not tracer.sites:
+        return None
+    ops = get_ops()
+    plan = ops.plan_create(tracer.sites)
+    dtypes = [torch.float32] * tracer.n_out
+    for m in tracer.meta:
+        if m["out_col"] >= 0 and m["is_int"]:
+            dtypes[m["out_col"]] = torch.int32
+    prep = ops.prepare_importance(plan, [pk.kb for pk in pks], n, tracer.inputs, dtypes, fold_batch=len(pks))
+    prep.launch_passes(0, len(pks))
+    prep.launch_fold(len(pks))
+    return prep.logw_all[:, :n], prep.lse_all
+
+
 def _needs_eager(a) -> bool:
     return isinstance(a, torch.Tensor) and a.dim() >= 1 and a.numel() > 1

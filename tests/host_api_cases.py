@@ -580,6 +580,39 @@ def case_vmap_indexed_constraints(impl):
     assert bool((tr.get_retval()[::2] == 1.5).all()) and float(tr.get_retval()[1::2].std()) > 0.5
 
 
+def case_batched_estimates(impl):
+    """vmap of ImportanceK.log_marginal_likelihood_estimate over keys: several estimates per launch, each
+    equal to the single call bit for bit; non-plan-able targets run key by key with the same results."""
+    @gen
+    def model(s):
+        z = normal(0.0, 1.0) @ "z"
+        p_ = beta(2.0, 2.0) @ "p"
+        _ = flip(p_) @ "v"
+        _ = normal(z, s) @ "y"
+
+    target = Target(model, (0.5,), C["y"].set(0.3).at["v"].set(True))
+    alg = ImportanceK(target, k_particles=4000)
+    root = genjax.random.key(99, impl)
+    keys = list(jax.random.split(root, 5))
+    got = alg.log_marginal_likelihood_estimates(keys)
+    assert got.shape == (5,)
+    for b, key in enumerate(keys):
+        assert f(got[b]) == f(alg.log_marginal_likelihood_estimate(key))
+    exact = math.log(0.5) + f(normal.logpdf(0.3, 0.0, math.sqrt(1.25)))
+    assert f(got.mean()) == pytest.approx(exact, abs=0.05)
+
+    @gen
+    def nested():  # a nested call is not plan-able: the same API, key by key
+        z = normal(0.0, 1.0) @ "z"
+        _ = model(1.0) @ "m"
+        return z
+
+    alg2 = ImportanceK(Target(nested, (), C["m", "y"].set(0.3)), k_particles=500)
+    got2 = alg2.log_marginal_likelihood_estimates(keys[:3])
+    for b in range(3):
+        assert f(got2[b]) == f(alg2.log_marginal_likelihood_estimate(keys[b]))
+
+
 def case_bootstrap_smc(impl):
     from genjax._amd import workloads as W
 
@@ -653,4 +686,4 @@ def case_general_smc(impl):
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_fused_equals_eager, case_particle_collection, case_custom_proposal,
-             case_scan, case_vmap, case_vmap_indexed_constraints, case_bootstrap_smc, case_general_smc, case_update]
+             case_scan, case_vmap, case_vmap_indexed_constraints, case_batched_estimates, case_bootstrap_smc, case_general_smc, case_update]
