@@ -46,9 +46,14 @@ def _worker(rank, world, port, impl, n_total, n_imp_total, T, out_dir):
         assert eb.numel() == cnt and all(torch.equal(eb[b:b + 1], e) and torch.equal(qb[b:b + 1], q) for b in range(cnt))
     d2 = pipe.run(1)  # reuses the first block after its exchange completed
     assert pipe.log_z(d2) == log_z
+    # several passes per launch (seeds 3, 4): pass 0 is the estimate above, pass 1 an independent one
+    pipe2 = gdist.BatchedImportance(ops, wl, batch=4, passes=2)
+    _, e2, q2 = pipe2.results(pipe2.run(3))  # launches of 2 + 1 passes
+    assert torch.equal(e2[0:1], e) and torch.equal(q2[0:1], q) and torch.equal(e2[2:3], e) and torch.equal(q2[2:3], q)
+    logw_seed4 = pipe2.prep.logw_all[1, :n_imp].clone()
     smc = gdist.ShardedLgssmSMC(ops, impl, seed=5, n_total=n_total, T=T, rank=rank, world=world,
                                 record_ancestors=True).run()
-    torch.save(dict(log_z=log_z, logw=logw, e=e, q=q, smc_max=smc["out_max"], smc_q=smc["out_q"],
+    torch.save(dict(log_z=log_z, logw=logw, e=e, q=q, e_seed4=e2[1:2].clone(), q_seed4=q2[1:2].clone(), logw_seed4=logw_seed4, smc_max=smc["out_max"], smc_q=smc["out_q"],
                     smc_state=smc["state"].clone(), smc_anc=smc["ancestors"], smc_log_z=smc["log_z"]),
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
@@ -74,5 +79,9 @@ def test_two_ranks_equal_one_rank(tmp_path, oracle_ops, impl):
         assert torch.equal(p["smc_max"], ref_smc["out_max"]) and torch.equal(p["smc_q"], ref_smc["out_q"])
         assert p["smc_log_z"] == ref_smc["log_z"]
     assert parts[0]["log_z"] == parts[1]["log_z"]
+    ref4 = W.Gaussian10(oracle_ops, impl, seed=4, n_local=n_imp_total).step()  # the second pass of a launch
+    assert torch.equal(torch.cat([p["logw_seed4"] for p in parts]), ref4["logw"])
+    for p in parts:
+        assert torch.equal(p["e_seed4"], ref4["row_e"]) and torch.equal(p["q_seed4"], ref4["row_q"])
     assert torch.equal(torch.cat([p["smc_state"] for p in parts]), ref_smc["state"])
     assert torch.equal(torch.cat([p["smc_anc"] for p in parts], dim=1), ref_smc["ancestors"])
