@@ -666,6 +666,20 @@ GJX_DEV int block_sum_int(int v, int* sh) {
 // the output writes are coalesced, and ancestors never round-trip through HBM unless asked for.
 // The per-output work (propagate + weight for the fused SMC models) is the template policy.
 // ------------------------------------------------------------------------------------------------
+// Several independent filters stepping in ONE launch (the bootstrap filter vmapped over keys): workgroup
+// f * tiles + b serves tile b of filter f.  Filter f's particles, tile sums, (max, q) results and keys lie
+// f * stride / f * tiles / f * mq_stride further.  A 1e6-particle step is ~1000 workgroups — under one round
+// of the machine — so a few filters per launch fill it (the large-population rates: 14 -> 11.5 us per 1e6).
+constexpr int kMaxFilters = 8;
+struct FilterBatch {
+  uint32_t n_filters = 0;  // <= 1: a single filter (nothing below is read)
+  uint32_t tiles = 0;      // tiles per filter
+  uint64_t stride = 0;     // particles between consecutive filters in every per-particle array (tiles * 1024)
+  uint64_t mq_stride = 0;  // entries between the filters' per-step (max, q) results
+  Key step_key[kMaxFilters];
+  Key rkey[kMaxFilters];
+};
+
 struct ResampleArgs {
   const float* lw;            // [n] source log-weights
   const float* m_ptr;         // max of lw
@@ -681,6 +695,7 @@ struct ResampleArgs {
   uint64_t* q_total_out = nullptr;  // nullable: block 0 stores the total mass (= sum of tile_sums)
   const uint64_t* tile_prefix = nullptr;  // nullable: exclusive prefix [ntiles + 1] of tile_sums, precomputed for
                                 // large populations (otherwise every workgroup reduces tile_sums itself)
+  FilterBatch fb;               // several filters per launch (n, ntiles, n_out, out_lo/out_hi are then PER FILTER)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -858,23 +873,40 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   __shared__ uint64_t sh64[kBlock / kWave];
   __shared__ float shf[kBlock / kWave];
   __shared__ int32_t nb[kTile];  // teeth below the inclusive CDF of each source in the tile
-  const uint64_t b = blockIdx.x;
+  uint64_t b = blockIdx.x;
   const int tid = threadIdx.x;
+  // this workgroup's filter: local views of the per-filter arrays, keys and results
+  const float* lw_all = A.lw;
+  const uint64_t* tile_sums = A.tile_sums;
+  const float* m_ptr = A.m_ptr;
+  uint64_t* q_total_out = A.q_total_out;
+  Key rkey = A.rkey;
+  if (A.fb.n_filters > 1) {
+    const uint32_t f = (uint32_t)(b / A.fb.tiles);
+    b -= (uint64_t)f * A.fb.tiles;
+    lw_all += (uint64_t)f * A.fb.stride;
+    tile_sums += (uint64_t)f * A.fb.tiles;
+    m_ptr += (uint64_t)f * A.fb.mq_stride;
+    if (q_total_out) q_total_out += (uint64_t)f * A.fb.mq_stride;
+    if (max_partials) max_partials += (uint64_t)f * A.fb.tiles;
+    rkey = A.fb.rkey[f];
+    P.select_filter((uint64_t)f * A.fb.stride, A.fb.step_key[f]);
+  }
   const uint64_t base = b * kTile;
 
   // Issue this tile's loads first: their HBM latency overlaps the tile-mass prefix reduction.
   float lw4[kPer];
   if (kPer == 4 && A.lw_vec && base + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
-    const float4 v = reinterpret_cast<const float4*>(A.lw + base)[tid];
+    const float4 v = reinterpret_cast<const float4*>(lw_all + base)[tid];
     lw4[0] = v.x; lw4[1] = v.y; lw4[kPer > 2 ? 2 : 0] = v.z; lw4[kPer > 3 ? 3 : 0] = v.w;
   } else if (kPer == 2 && A.lw_vec && base + kTile <= A.n) {
-    const float2 v = reinterpret_cast<const float2*>(A.lw + base)[tid];
+    const float2 v = reinterpret_cast<const float2*>(lw_all + base)[tid];
     lw4[0] = v.x; lw4[1] = v.y;
   } else {
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
       const uint64_t i = base + kPer * (uint64_t)tid + r;
-      lw4[r] = i < A.n ? A.lw[i] : -__builtin_inff();
+      lw4[r] = i < A.n ? lw_all[i] : -__builtin_inff();
     }
   }
   P.fetch_source(base, A.n, tid);  // registers now, LDS after the scan
@@ -886,19 +918,19 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
     tot = A.tile_prefix[A.ntiles];
   } else {
     for (uint64_t k = tid; k < A.ntiles; k += kBlock) {
-      const uint64_t v = A.tile_sums[k];
+      const uint64_t v = tile_sums[k];
       tot += v;
       if (k < b) pre += v;
     }
     pre = block_sum(pre, sh64);
     tot = block_sum(tot, sh64);
   }
-  if (A.q_total_out && b == 0 && tid == 0) A.q_total_out[0] = tot;
+  if (q_total_out && b == 0 && tid == 0) q_total_out[0] = tot;
 
-  const Stream<IMPL> rs(A.rkey, A.rkey_has_fold != 0, A.rkey_fold);
+  const Stream<IMPL> rs(rkey, A.rkey_has_fold != 0, A.rkey_fold);
   const double u0 = u0_from_bits(rs.bits64(0));
   const double scale = (double)A.n_out / (double)tot;
-  const float m = A.m_ptr[0];
+  const float m = m_ptr[0];
 
   // tile CDF: each thread owns 4 CONSECUTIVE sources (base + 4*tid + r) so the scan is a
   // thread-local prefix plus one block scan.

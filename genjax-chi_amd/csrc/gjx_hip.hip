@@ -584,6 +584,7 @@ __global__ void k_lse_finish(const float* m_ptr, const uint64_t* q_ptr, int frac
 struct AncestorOnly {
   int32_t* anc;  // [out_hi - out_lo]
   struct Out {};
+  GJX_DEV void select_filter(uint64_t off, Key) { anc += off; }
   GJX_DEV void fetch_source(uint64_t, uint64_t, int) const {}
   GJX_DEV void stage_source(int) const {}
   GJX_DEV float compute(int64_t, int, Out&) const { return 0.0f; }
@@ -600,10 +601,20 @@ __global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P, f
 __global__ __launch_bounds__(kBlock) void k_tile_sums(const float* lw, uint64_t n_local,
                                                       const float* max_partials, uint64_t n_mp,
                                                       const float* m_ptr, int frac,
-                                                      uint64_t* tile_sums_at, float* max_out) {
+                                                      uint64_t* tile_sums_at, float* max_out,
+                                                      uint32_t filter_tiles, uint64_t filter_stride,
+                                                      uint64_t mq_stride) {
   __shared__ uint64_t sh64[kBlock / kWave];
   __shared__ float shf[kBlock / kWave];
-  const uint64_t tile = blockIdx.x;
+  uint64_t tile = blockIdx.x;
+  if (filter_tiles) {  // several filters per launch: this workgroup's filter
+    const uint64_t f = tile / filter_tiles;
+    tile -= f * filter_tiles;
+    lw += f * filter_stride;
+    max_partials += f * filter_tiles;
+    tile_sums_at += f * filter_tiles;
+    if (max_out) max_out += f * mq_stride;
+  }
   float lwv[kPer];
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {  // issued before the max reduction so the latencies overlap
@@ -620,7 +631,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums(const float* lw, uint64_t 
       m = v > m ? v : m;
     }
     m = block_max(m, shf);
-    if (max_out && blockIdx.x == 0 && threadIdx.x == 0) max_out[0] = m;
+    if (max_out && tile == 0 && threadIdx.x == 0) max_out[0] = m;
   }
   uint64_t acc = 0;
 #pragma unroll
@@ -797,6 +808,11 @@ struct LgssmPolicy {
   float a, q, y, rs, lognorm;
   float* xs;                // LDS tile of previous states (set in stage_source)
   float xr[kPer];           // the tile row values while in flight
+  GJX_DEV void select_filter(uint64_t off, Key k) {
+    prev_state += off; state_out += off; logw_out += off;
+    if (anc_out) anc_out += off;
+    step_key = k;
+  }
   GJX_DEV void fetch_source(uint64_t base, uint64_t n, int tid) {
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
@@ -854,6 +870,11 @@ struct HmmPolicy {
   float* ocol;
   int32_t zr[kPer];
   float oc;
+  GJX_DEV void select_filter(uint64_t off, Key k) {
+    prev_state += off; state_out += off; logw_out += off;
+    if (anc_out) anc_out += off;
+    step_key = k;
+  }
   GJX_DEV void fetch_source(uint64_t base, uint64_t n, int tid) {
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
@@ -892,14 +913,23 @@ struct HmmPolicy {
 // Step 0 (no resampling): one block per GLOBAL tile; tiles outside this rank only clear their
 // max partial so the array can be max-combined across ranks.
 template <int IMPL>
-__global__ __launch_bounds__(kBlock) void k_lgssm_init(Key step_key, uint64_t first_slot,
+__global__ __launch_bounds__(kBlock) void k_lgssm_init(FilterBatch fb, Key step_key, uint64_t first_slot,
                                                        uint64_t n_local, float x0_loc,
                                                        float x0_scale, float y, float rs,
                                                        float lognorm, float* state_out,
                                                        float* logw_out, int32_t* anc_out,
                                                        float* max_partials) {
   __shared__ float shf[kBlock / kWave];
-  const uint64_t gbase = (uint64_t)blockIdx.x * kTile;
+  uint64_t gtile = blockIdx.x;
+  if (fb.n_filters > 1) {  // several filters per launch: tile of filter f, its key, its outputs
+    const uint32_t f = (uint32_t)(gtile / fb.tiles);
+    gtile -= (uint64_t)f * fb.tiles;
+    step_key = fb.step_key[f];
+    state_out += (uint64_t)f * fb.stride;
+    logw_out += (uint64_t)f * fb.stride;
+    if (anc_out) anc_out += (uint64_t)f * fb.stride;
+  }
+  const uint64_t gbase = gtile * kTile;
   float tmax = -__builtin_inff();
   if (gbase >= first_slot && gbase < first_slot + n_local) {
 #pragma unroll
@@ -922,14 +952,23 @@ __global__ __launch_bounds__(kBlock) void k_lgssm_init(Key step_key, uint64_t fi
 }
 
 template <int IMPL>
-__global__ __launch_bounds__(kBlock) void k_hmm_init(Key step_key, uint64_t first_slot,
+__global__ __launch_bounds__(kBlock) void k_hmm_init(FilterBatch fb, Key step_key, uint64_t first_slot,
                                                      uint64_t n_local, const uint32_t* trans_cdf,
                                                      const float* obs_logp, int32_t K,
                                                      int32_t init_state, int32_t y,
                                                      int32_t* state_out, float* logw_out,
                                                      int32_t* anc_out, float* max_partials) {
   __shared__ float shf[kBlock / kWave];
-  const uint64_t gbase = (uint64_t)blockIdx.x * kTile;
+  uint64_t gtile = blockIdx.x;
+  if (fb.n_filters > 1) {  // several filters per launch: tile of filter f, its key, its outputs
+    const uint32_t f = (uint32_t)(gtile / fb.tiles);
+    gtile -= (uint64_t)f * fb.tiles;
+    step_key = fb.step_key[f];
+    state_out += (uint64_t)f * fb.stride;
+    logw_out += (uint64_t)f * fb.stride;
+    if (anc_out) anc_out += (uint64_t)f * fb.stride;
+  }
+  const uint64_t gbase = gtile * kTile;
   float tmax = -__builtin_inff();
   if (gbase >= first_slot && gbase < first_slot + n_local) {
     const uint32_t* cdf = trans_cdf + (size_t)init_state * (K + kHmmGuideWords);
@@ -1539,7 +1578,7 @@ static int weights_prepare(const float* logw, uint64_t n, Carver& cv, float** m_
   float* m = cv.take<float>(1);
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   k_max_partials<<<grid_for(n), kBlock, 0, st>>>(logw, n, mp);
-  k_tile_sums<<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, nullptr, frac_bits(n), tiles, m);
+  k_tile_sums<<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, nullptr, frac_bits(n), tiles, m, 0, 0, 0);
   *m_out = m;
   *tiles_out = tiles;
   return GJX_OK;
@@ -1678,12 +1717,16 @@ int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gj
 
 // Set by the whole-run drivers around their step launches (large populations only).
 static thread_local const uint64_t* g_tile_prefix = nullptr;
+// Set by the whole-run drivers when several filters step in one launch (cfg->n_filters > 1): the keys of
+// this step and the strides of the per-filter arrays.  n_filters <= 1 otherwise.
+static thread_local FilterBatch g_filters;
 
 static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const float* prev_logw,
                                       const float* prev_max, const uint64_t* prev_tile_sums,
                                       uint64_t* prev_q_out) {
   ResampleArgs A;
   A.tile_prefix = g_tile_prefix;
+  A.fb = g_filters;
   A.lw = prev_logw; A.m_ptr = prev_max; A.tile_sums = prev_tile_sums;
   A.n = cfg->n_total; A.ntiles = ntiles_of(cfg->n_total); A.n_out = cfg->n_total;
   A.out_lo = (int64_t)cfg->first_slot; A.out_hi = (int64_t)(cfg->first_slot + cfg->n_local);
@@ -1704,20 +1747,20 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
     return GJX_ERR_INVALID;
   const Key sk{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
   const float rs = normal_rs(mdl->r), lognorm = normal_lognorm(mdl->r);
-  const unsigned nt = (unsigned)ntiles_of(cfg->n_total);
+  const unsigned nt = (unsigned)ntiles_of(cfg->n_total), nf = g_filters.n_filters > 1 ? g_filters.n_filters : 1u;
   if (t == 0) {
     GJX_DISPATCH_IMPL(cfg->impl, k_lgssm_init,
-                      <<<nt, kBlock, 0, S(s)>>>(sk, cfg->first_slot, cfg->n_local, mdl->x0_loc, mdl->x0_scale, y_t, rs, lognorm, state_out, logw_out, ancestors_out, max_partials_out));
+                      <<<nt * nf, kBlock, 0, S(s)>>>(g_filters, sk, cfg->first_slot, cfg->n_local, mdl->x0_loc, mdl->x0_scale, y_t, rs, lognorm, state_out, logw_out, ancestors_out, max_partials_out));
     return launch_status();
   }
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
   ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out);
   if (cfg->impl == 0) {
     LgssmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {}};
-    k_resample<0, LgssmPolicy<0>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    k_resample<0, LgssmPolicy<0>><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   } else {
     LgssmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {}};
-    k_resample<1, LgssmPolicy<1>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    k_resample<1, LgssmPolicy<1>><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   }
   return launch_status();
 }
@@ -1733,20 +1776,20 @@ int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int
       mdl->n_states > 256 || mdl->init_state < 0 || mdl->init_state >= mdl->n_states)
     return GJX_ERR_INVALID;
   const Key sk{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
-  const unsigned nt = (unsigned)ntiles_of(cfg->n_total);
+  const unsigned nt = (unsigned)ntiles_of(cfg->n_total), nf = g_filters.n_filters > 1 ? g_filters.n_filters : 1u;
   if (t == 0) {
     GJX_DISPATCH_IMPL(cfg->impl, k_hmm_init,
-                      <<<nt, kBlock, 0, S(s)>>>(sk, cfg->first_slot, cfg->n_local, trans_cdf, obs_logp, mdl->n_states, mdl->init_state, y_t, state_out, logw_out, ancestors_out, max_partials_out));
+                      <<<nt * nf, kBlock, 0, S(s)>>>(g_filters, sk, cfg->first_slot, cfg->n_local, trans_cdf, obs_logp, mdl->n_states, mdl->init_state, y_t, state_out, logw_out, ancestors_out, max_partials_out));
     return launch_status();
   }
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
   ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out);
   if (cfg->impl == 0) {
     HmmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {}, 0.0f};
-    k_resample<0, HmmPolicy<0>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    k_resample<0, HmmPolicy<0>><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   } else {
     HmmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {}, 0.0f};
-    k_resample<1, HmmPolicy<1>><<<nt, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    k_resample<1, HmmPolicy<1>><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   }
   return launch_status();
 }
@@ -1761,16 +1804,22 @@ int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const flo
     k_reduce_max<<<1, kBlock, 0, S(s)>>>(max_partials, nt_total, max_out);
     m_ptr = max_out;
   }
-  k_tile_sums<<<(unsigned)nt_local, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total, m_ptr,
-                                                       frac_bits(cfg->n_total),
-                                                       tile_sums + cfg->first_slot / kTile, max_out);
+  const FilterBatch& fb = g_filters;
+  const unsigned nf = fb.n_filters > 1 ? fb.n_filters : 1u;
+  k_tile_sums<<<(unsigned)nt_local * nf, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total, m_ptr,
+                                                            frac_bits(cfg->n_total),
+                                                            tile_sums + cfg->first_slot / kTile, max_out,
+                                                            nf > 1 ? fb.tiles : 0u, fb.stride, fb.mq_stride);
   return launch_status();
 }
 
 int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
                    gjx_stream s) {
   if (!cfg_ok(cfg) || !tile_sums || !q_out) return GJX_ERR_INVALID;
-  k_reduce_sum<<<1, kBlock, 0, S(s)>>>(tile_sums, ntiles_of(cfg->n_total), q_out, 0, nullptr, 0, nullptr, nullptr);
+  const unsigned nf = g_filters.n_filters > 1 ? g_filters.n_filters : 1u;
+  const uint64_t nt = ntiles_of(cfg->n_total);
+  for (unsigned f = 0; f < nf; ++f)
+    k_reduce_sum<<<1, kBlock, 0, S(s)>>>(tile_sums + f * nt, nt, q_out + f * g_filters.mq_stride, 0, nullptr, 0, nullptr, nullptr);
   return launch_status();
 }
 
@@ -1894,32 +1943,52 @@ static int smc_run(const gjx_smc_config* cfg, const void* model, float* out_max,
       !out_q || !state_out || !logw_out)
     return GJX_ERR_INVALID;
   const uint64_t N = cfg->n_total, nt = ntiles_of(N);
+  // several filters per launch: filter f's particles lie f * stride further in every per-particle array
+  const unsigned F = cfg->n_filters > 1 ? (unsigned)cfg->n_filters : 1u;
+  const uint64_t stride = F > 1 ? cfg->filter_stride : N;
+  const int T = cfg->n_steps;
+  if (F > kMaxFilters || (F > 1 && (stride != nt * kTile || nt > kPrefixTiles))) return GJX_ERR_UNSUPPORTED;
   Carver cv{(char*)ws, ws ? ws_bytes : 0};
-  StateT* st_ws = cv.take<StateT>(N);
-  float* lw_ws = cv.take<float>(N);
-  float* mp = cv.take<float>(nt);
-  uint64_t* tiles = cv.take<uint64_t>(nt);
+  StateT* st_ws = cv.take<StateT>(F * stride);
+  float* lw_ws = cv.take<float>(F * stride);
+  float* mp = cv.take<float>(F * nt);
+  uint64_t* tiles = cv.take<uint64_t>(F * nt);
   uint64_t* prefix = nt > kPrefixTiles ? cv.take<uint64_t>(nt + 1) : nullptr;
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   // ping-pong so that the last step lands in the caller's output buffers
   StateT* stb[2];
   float* lwb[2];
-  const int last = (cfg->n_steps - 1) & 1;
+  const int last = (T - 1) & 1;
   stb[last] = state_out; stb[last ^ 1] = st_ws;
   lwb[last] = logw_out; lwb[last ^ 1] = lw_ws;
-  for (int t = 0; t < cfg->n_steps; ++t) {
-    const int cur = t & 1, prv = cur ^ 1;
-    int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * N : nullptr;
-    if (prefix && t) k_scan_tiles<<<1, kBlock, 0, S(s)>>>(tiles, nt, prefix);
-    g_tile_prefix = t ? prefix : nullptr;
-    int rc = step_a(t, stb[prv], lwb[prv], t ? out_max + (t - 1) : nullptr, tiles,
-                    t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur], mp, anc_t);
-    g_tile_prefix = nullptr;
-    if (rc) return rc;
-    rc = gjx_smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s);
-    if (rc) return rc;
+  FilterBatch fb;
+  if (F > 1) {
+    fb.n_filters = F; fb.tiles = (uint32_t)nt; fb.stride = stride; fb.mq_stride = (uint64_t)T;
   }
-  return gjx_smc_finish(cfg, tiles, out_q + (cfg->n_steps - 1), s);
+  int rc = GJX_OK;
+  for (int t = 0; t < T && !rc; ++t) {
+    const int cur = t & 1, prv = cur ^ 1;
+    int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * F * stride : nullptr;
+    if (prefix && t) k_scan_tiles<<<1, kBlock, 0, S(s)>>>(tiles, nt, prefix);
+    for (unsigned f = 0; f < F && F > 1; ++f) {  // this step's keys of every filter ([F, T, 2] host arrays)
+      const uint32_t* sk = cfg->step_keys + 2 * ((size_t)f * T + t);
+      const uint32_t* rk = cfg->resample_keys + 2 * ((size_t)f * T + t);
+      fb.step_key[f] = Key{sk[0], sk[1]};
+      fb.rkey[f] = Key{rk[0], rk[1]};
+    }
+    g_tile_prefix = t ? prefix : nullptr;
+    g_filters = fb;
+    rc = step_a(t, stb[prv], lwb[prv], t ? out_max + (t - 1) : nullptr, tiles,
+                t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur], mp, anc_t);
+    g_tile_prefix = nullptr;
+    if (!rc) rc = gjx_smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s);
+    g_filters = FilterBatch{};
+  }
+  if (rc) return rc;
+  g_filters = fb;
+  rc = gjx_smc_finish(cfg, tiles, out_q + (T - 1), s);
+  g_filters = FilterBatch{};
+  return rc;
 }
 
 extern "C" {

@@ -379,6 +379,9 @@ struct GenSmc {
     // ---- step policy
     o << "struct GenPolicy {\n  PlanPolicyArgs a;\n  float* xs[" << D << "];\n  float xr[" << D << "][kPer];\n";
     o << "  struct Out { float s[" << D << "]; float lw; };\n";
+    o << "  __device__ __forceinline__ void select_filter(uint64_t off, Key k) {\n";
+    o << "    for (int c = 0; c < " << D << "; ++c) { a.prev_state[c] += off; a.state_out[c] += off; }\n";
+    o << "    a.logw_out += off; if (a.anc_out) a.anc_out += off; a.step_key = k;\n  }\n";
     o << "  __device__ __forceinline__ void fetch_source(uint64_t base, uint64_t n, int tid) {\n";
     o << "    for (int k = 0; k < " << D << "; ++k)\n      for (int r = 0; r < kPer; ++r) { const uint64_t i = base + (uint64_t)r * 256 + tid; xr[k][r] = i < n ? a.prev_state[k][i] : 0.0f; }\n  }\n";
     o << "  __device__ __forceinline__ void stage_source(int tid) {\n    __shared__ float tile[" << D << "][kTile];\n";

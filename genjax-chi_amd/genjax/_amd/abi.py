@@ -143,6 +143,8 @@ class SmcConfig(C.Structure):
         ("n_steps", C.c_int32),
         ("step_keys", C.c_void_p),
         ("resample_keys", C.c_void_p),
+        ("n_filters", C.c_int32),
+        ("filter_stride", C.c_uint64),
     ]
 
 

@@ -354,28 +354,47 @@ class Ops:
 
     # ---- fused SMC --------------------------------------------------------------------------------
     def _smc_cfg(self, impl, n_total, first, n_local, step_keys, resample_keys):
+        """`step_keys` / `resample_keys`: [T, 2] for one filter, [F, T, 2] for F filters stepping in the same
+        launches (gjx_smc_config.n_filters)."""
         import numpy as np
 
-        T = len(step_keys)
-        sk = np.ascontiguousarray(np.asarray(step_keys, dtype=np.uint32).reshape(T, 2))
-        rk = np.ascontiguousarray(np.asarray(resample_keys, dtype=np.uint32).reshape(T, 2))
+        sk = np.ascontiguousarray(np.asarray(step_keys, dtype=np.uint32))
+        rk = np.ascontiguousarray(np.asarray(resample_keys, dtype=np.uint32))
+        F = sk.shape[0] if sk.ndim == 3 else 1
+        T = sk.shape[-2]
         cfg = abi.SmcConfig()
         cfg.impl, cfg.n_total, cfg.first_slot, cfg.n_local, cfg.n_steps = impl, n_total, first, n_local, T
         cfg.step_keys, cfg.resample_keys = sk.ctypes.data, rk.ctypes.data
+        cfg.n_filters = F if F > 1 else 0
+        cfg.filter_stride = self.num_tiles(n_total) * self.tile if F > 1 else 0
         cfg._keep = (sk, rk)  # keep host arrays alive
+        cfg._filters = F
         return cfg
+
+    def _smc_buffers(self, cfg, n, state_dtype, want_ancestors):
+        """Outputs of a whole-run call: one filter -> [T], [n]; F filters -> [F, T], [F, stride] (views [:, :n])."""
+        F, T = cfg._filters, cfg.n_steps
+        if F == 1:
+            return (self.empty(T, torch.float32), self.empty(T, torch.int64), self.empty(n, state_dtype),
+                    self.empty(n, torch.float32), self.empty((T, n), torch.int32) if want_ancestors else None,
+                    self.workspace(abi.OP_SMC, n))
+        stride = cfg.filter_stride
+        ws_one = int(self.lib.call("gjx_workspace_bytes", abi.OP_SMC, n))
+        key = ("smc_filters", str(self.device()))
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < F * ws_one:
+            ws = self._ws[key] = torch.empty(F * ws_one, dtype=torch.uint8, device=self.device())
+        return (self.empty((F, T), torch.float32), self.empty((F, T), torch.int64), self.empty((F, stride), state_dtype),
+                self.empty((F, stride), torch.float32),
+                self.empty((T, F, stride), torch.int32) if want_ancestors else None, (ws, F * ws_one))
 
     def smc_run_lgssm(self, impl, n, step_keys, resample_keys, model: abi.Lgssm, y, want_ancestors=False):
         import numpy as np
 
-        T = len(step_keys)
         cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys)
         yh = np.ascontiguousarray(np.asarray(y, dtype=np.float32))
-        assert yh.size == T
-        out_max, out_q = self.empty(T, torch.float32), self.empty(T, torch.int64)
-        state, logw = self.empty(n, torch.float32), self.empty(n, torch.float32)
-        anc = self.empty((T, n), torch.int32) if want_ancestors else None
-        ws, nb = self.workspace(abi.OP_SMC, n)
+        assert yh.size == cfg.n_steps
+        out_max, out_q, state, logw, anc, (ws, nb) = self._smc_buffers(cfg, n, torch.float32, want_ancestors)
         self.lib.call("gjx_smc_run_lgssm", C.byref(cfg), C.byref(model), C.c_void_p(yh.ctypes.data),
                       C.c_void_p(out_max.data_ptr()), C.c_void_p(out_q.data_ptr()), C.c_void_p(state.data_ptr()),
                       C.c_void_p(logw.data_ptr()), C.c_void_p(anc.data_ptr()) if anc is not None else None,
@@ -386,18 +405,14 @@ class Ops:
                     want_ancestors=False):
         import numpy as np
 
-        T = len(step_keys)
         cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys)
         yh = np.ascontiguousarray(np.asarray(y, dtype=np.int32))
-        assert yh.size == T
+        assert yh.size == cfg.n_steps
         mdl = abi.Hmm()
         mdl.n_states, mdl.init_state = n_states, init_state
         mdl.trans_logits = self._chk(trans_logits, torch.float32, n_states * n_states).value
         mdl.obs_logits = self._chk(obs_logits, torch.float32, n_states * n_states).value
-        out_max, out_q = self.empty(T, torch.float32), self.empty(T, torch.int64)
-        state, logw = self.empty(n, torch.int32), self.empty(n, torch.float32)
-        anc = self.empty((T, n), torch.int32) if want_ancestors else None
-        ws, nb = self.workspace(abi.OP_SMC, n)
+        out_max, out_q, state, logw, anc, (ws, nb) = self._smc_buffers(cfg, n, torch.int32, want_ancestors)
         self.lib.call("gjx_smc_run_hmm", C.byref(cfg), C.byref(mdl), C.c_void_p(yh.ctypes.data),
                       C.c_void_p(out_max.data_ptr()), C.c_void_p(out_q.data_ptr()), C.c_void_p(state.data_ptr()),
                       C.c_void_p(logw.data_ptr()), C.c_void_p(anc.data_ptr()) if anc is not None else None,

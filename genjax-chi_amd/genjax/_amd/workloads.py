@@ -164,14 +164,33 @@ def smc_key_schedule(root: prng.PRNGKey, T: int):
     return w[0::2].copy(), w[1::2].copy()
 
 
+def filter_key_schedules(seed: int, impl: int, T: int, filters: int):
+    """Key schedule(s): [T, 2] arrays for one filter, [F, T, 2] for F filters with seeds seed .. seed+F-1."""
+    if filters == 1:
+        return smc_key_schedule(prng.key(seed, impl), T)
+    pairs = [smc_key_schedule(prng.key(seed + f, impl), T) for f in range(filters)]
+    return np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+
+
+def smc_result(ops: Ops, out, n: int, filters: int, log_z_exact: float):
+    out_max, out_q, state, logw, anc = out
+    if filters == 1:
+        return dict(out_max=out_max, out_q=out_q, state=state, logw=logw, ancestors=anc,
+                    log_z=ops.log_z_from_pairs(out_max, out_q, n), log_z_exact=log_z_exact)
+    return dict(out_max=out_max, out_q=out_q, state=state[:, :n], logw=logw[:, :n],
+                ancestors=None if anc is None else anc[:, :, :n],
+                log_z=[ops.log_z_from_pairs(out_max[f], out_q[f], n) for f in range(filters)], log_z_exact=log_z_exact)
+
+
 class LgssmSMC:
     """Reusable state of the C3 workload: data, key schedule and exact log Z are prepared once, so
     `run()` is only the enqueue of the fused filter (2 kernels per step, no host sync)."""
 
-    def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, want_ancestors: bool = False):
-        self.ops, self.impl, self.n, self.T, self.want_ancestors = ops, impl, n, T, want_ancestors
+    def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, want_ancestors: bool = False, filters: int = 1):
+        """`filters` > 1: that many independent filters (seeds seed, seed+1, ...) step in the same launches."""
+        self.ops, self.impl, self.n, self.T, self.want_ancestors, self.filters = ops, impl, n, T, want_ancestors, filters
         self.y = lgssm_data(T)
-        self.sk, self.rk = smc_key_schedule(prng.key(seed, impl), T)
+        self.sk, self.rk = filter_key_schedules(seed, impl, T, filters)
         self.model = lgssm_model()
         self.log_z_exact = lgssm_exact_log_z(self.y)
 
@@ -179,9 +198,7 @@ class LgssmSMC:
         return self.ops.smc_run_lgssm(self.impl, self.n, self.sk, self.rk, self.model, self.y, self.want_ancestors)
 
     def result(self, out):
-        out_max, out_q, state, logw, anc = out
-        return dict(out_max=out_max, out_q=out_q, state=state, logw=logw, ancestors=anc,
-                    log_z=self.ops.log_z_from_pairs(out_max, out_q, self.n), log_z_exact=self.log_z_exact)
+        return smc_result(self.ops, out, self.n, self.filters, self.log_z_exact)
 
 
 def lgssm_smc(ops: Ops, impl: int, seed: int, n: int, T: int, want_ancestors: bool = False):
@@ -257,16 +274,17 @@ def hmm_exact_log_z(y, n_states=None, init_state=None) -> float:
 class HmmSMC:
     """Reusable state of the C5 workload (tables resident on the device, data and keys prepared)."""
 
-    def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, n_states=None, want_ancestors: bool = False):
+    def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, n_states=None, want_ancestors: bool = False,
+                 filters: int = 1):
         trans, obs = hmm_tables(n_states)
-        self.ops, self.impl, self.n, self.T, self.want_ancestors = ops, impl, n, T, want_ancestors
+        self.ops, self.impl, self.n, self.T, self.want_ancestors, self.filters = ops, impl, n, T, want_ancestors, filters
         self.k = trans.shape[0]
         self.init = HMM["init_state"] % self.k
         self.y = hmm_data(T, n_states)
         dev = ops.device()
         self.tl = torch.from_numpy(trans).to(dev).contiguous()
         self.ol = torch.from_numpy(obs).to(dev).contiguous()
-        self.sk, self.rk = smc_key_schedule(prng.key(seed, impl), T)
+        self.sk, self.rk = filter_key_schedules(seed, impl, T, filters)
         self.log_z_exact = hmm_exact_log_z(self.y, n_states)
 
     def run(self):
@@ -274,9 +292,7 @@ class HmmSMC:
                                     self.want_ancestors)
 
     def result(self, out):
-        out_max, out_q, state, logw, anc = out
-        return dict(out_max=out_max, out_q=out_q, state=state, logw=logw, ancestors=anc,
-                    log_z=self.ops.log_z_from_pairs(out_max, out_q, self.n), log_z_exact=self.log_z_exact)
+        return smc_result(self.ops, out, self.n, self.filters, self.log_z_exact)
 
 
 def hmm_smc(ops: Ops, impl: int, seed: int, n: int, T: int, n_states=None, want_ancestors: bool = False):

@@ -996,17 +996,42 @@ static int smc_run_common(const gjx_smc_config* cfg, int is_hmm, const void* mod
   return rc;
 }
 
+/* Several filters (gjx_smc_config.n_filters): by definition, each filter's own single run, with its keys
+ * [f, T, 2] and its slice of every output. */
+static int smc_run_filters(const gjx_smc_config* cfg, int kind, const void* model, const void* y, float* out_max,
+                           uint64_t* out_q, void* state_out, float* logw_out, int32_t* ancestors_out) {
+  if (!cfg) return GJX_ERR_INVALID;
+  if (cfg->n_filters <= 1) return smc_run_common(cfg, kind, model, y, out_max, out_q, state_out, logw_out, ancestors_out);
+  const int F = cfg->n_filters, T = cfg->n_steps;
+  const uint64_t N = cfg->n_total, stride = cfg->filter_stride;
+  if (F > 8 || stride < N) return GJX_ERR_INVALID;
+  int32_t* anc1 = ancestors_out ? (int32_t*)malloc(sizeof(int32_t) * (size_t)T * N) : NULL;
+  int rc = GJX_OK;
+  for (int f = 0; f < F && !rc; ++f) {
+    gjx_smc_config c = *cfg;
+    c.n_filters = 0;
+    c.step_keys = cfg->step_keys + 2 * (size_t)f * T;
+    c.resample_keys = cfg->resample_keys + 2 * (size_t)f * T;
+    rc = smc_run_common(&c, kind, model, y, out_max + (size_t)f * T, out_q + (size_t)f * T,
+                        (char*)state_out + 4 * (size_t)f * stride, logw_out + (size_t)f * stride, anc1);
+    if (!rc && anc1)  /* [T, N] -> [T, F, stride] */
+      for (int t = 0; t < T; ++t)
+        memcpy(ancestors_out + ((size_t)t * F + f) * stride, anc1 + (size_t)t * N, sizeof(int32_t) * N);
+  }
+  free(anc1);
+  return rc;
+}
 int gjx_smc_run_lgssm(const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y,
                       float* out_max, uint64_t* out_q, float* state_out, float* logw_out,
                       int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s) {
   (void)ws; (void)ws_bytes; (void)s;
-  return smc_run_common(cfg, 0, model, y, out_max, out_q, state_out, logw_out, ancestors_out);
+  return smc_run_filters(cfg, 0, model, y, out_max, out_q, state_out, logw_out, ancestors_out);
 }
 int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32_t* y,
                     float* out_max, uint64_t* out_q, int32_t* state_out, float* logw_out,
                     int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s) {
   (void)ws; (void)ws_bytes; (void)s;
-  return smc_run_common(cfg, 1, model, y, out_max, out_q, state_out, logw_out, ancestors_out);
+  return smc_run_filters(cfg, 1, model, y, out_max, out_q, state_out, logw_out, ancestors_out);
 }
 
 /* ---- oracle-only probes (not part of include/gjx.h): raw ciphers and math-spec functions, so the

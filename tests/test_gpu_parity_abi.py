@@ -433,6 +433,29 @@ def _smc_plans(ops):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("kind,n,T", [("lgssm", 5000, 12), ("lgssm", 1024, 4), ("hmm", 3000, 9)])
+def test_smc_filters_in_one_launch(hip_ops, oracle_ops, impl, kind, n, T):
+    """gjx_smc_config.n_filters: F independent filters (seeds s, s+1, ...) stepping in the same launches equal
+    F separate runs bit for bit — per-step (max, q), final particles and weights, ancestors — on both backends."""
+    F = 3
+    mk = (lambda ops, f, seed: W.LgssmSMC(ops, impl, seed, n, T, want_ancestors=True, filters=f)) if kind == "lgssm" else (
+        lambda ops, f, seed: W.HmmSMC(ops, impl, seed, n, T, n_states=16, want_ancestors=True, filters=f))
+    hb = mk(hip_ops, F, 7)
+    got = hb.result(hb.run())
+    ob = mk(oracle_ops, F, 7)
+    want = ob.result(ob.run())
+    for key in ("out_max", "out_q", "state", "logw", "ancestors"):
+        same(got[key], want[key], f"{key} (batched, HIP vs oracle)")
+    for f in range(F):
+        one = mk(hip_ops, 1, 7 + f)
+        ref = one.result(one.run())
+        same(got["out_max"][f], ref["out_max"], "out_max"); same(got["out_q"][f], ref["out_q"], "out_q")
+        same(got["state"][f], ref["state"], "state"); same(got["logw"][f], ref["logw"], "logw")
+        same(got["ancestors"][:, f], ref["ancestors"], "ancestors")
+        assert got["log_z"][f] == ref["log_z"]
+
+
+@pytest.mark.parametrize("impl", IMPLS)
 def test_smc_plans(hip_ops, oracle_ops, impl):
     """Plan-driven bootstrap SMC (hiprtc-generated policy in the fused resample kernel) against the
     oracle's plan interpreter, and against the hand-written LGSSM kernel."""
