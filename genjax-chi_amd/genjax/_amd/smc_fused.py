@@ -107,5 +107,37 @@ class BootstrapSMC:
         step_max, step_q, state, logw, anc = out
         return SMCResult(ops.log_z_from_pairs(step_max, step_q, self.n), step_max, step_q, state, logw, anc)
 
+    def run_many(self, keys) -> list:
+        """`vmap(self.run)(keys)`: one independent filter per key.  For the hand-written models up to 8 filters step
+        in the same kernel launches (`gjx_smc_config.n_filters`: a 1e6-particle step alone is under one round
+        of an MI355X); element b equals `self.run(keys[b])` bit for bit.  Other models run key by key."""
+        keys = list(keys)
+        if not isinstance(self.model, (LinearGaussianSSM, DiscreteHMM)) or len(keys) < 2:
+            return [self.run(k) for k in keys]
+        ops, out = get_ops(), []
+        T = len(self.observations)
+        for lo in range(0, len(keys), 8):
+            chunk = keys[lo:lo + 8]
+            if len(chunk) == 1:
+                out.append(self.run(chunk[0]))
+                continue
+            pairs = [smc_key_schedule(k, T) for k in chunk]
+            sk, rk = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+            m, impl = self.model, chunk[0].impl
+            if isinstance(m, LinearGaussianSSM):
+                res = ops.smc_run_lgssm(impl, self.n, sk, rk, abi.Lgssm(m.x0_loc, m.x0_scale, m.a, m.q, m.r),
+                                        self.observations.astype(np.float32), self.record_ancestors)
+            else:
+                dev = ops.device()
+                tl = torch.as_tensor(m.trans_logits, dtype=torch.float32).to(dev).contiguous()
+                ol = torch.as_tensor(m.obs_logits, dtype=torch.float32).to(dev).contiguous()
+                res = ops.smc_run_hmm(impl, self.n, sk, rk, int(tl.shape[0]), int(m.init_state), tl, ol,
+                                      self.observations.astype(np.int32), self.record_ancestors)
+            step_max, step_q, state, logw, anc = res
+            for f in range(len(chunk)):
+                out.append(SMCResult(ops.log_z_from_pairs(step_max[f], step_q[f], self.n), step_max[f], step_q[f],
+                                     state[f, :self.n], logw[f, :self.n], None if anc is None else anc[:, f, :self.n]))
+        return out
+
     def log_marginal_likelihood_estimate(self, key: prng.PRNGKey) -> float:
         return self.run(key).log_marginal_likelihood

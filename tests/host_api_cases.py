@@ -625,6 +625,13 @@ def case_bootstrap_smc(impl):
     assert bool((a[1:] >= a[:-1]).all())
     res2 = smc.run(genjax.random.key(3, impl))
     assert torch.equal(res.step_q, res2.step_q)  # counter-based: runs are replayable
+    # several filters in the same launches == the filters run one by one
+    many = smc.run_many([genjax.random.key(s_, impl) for s_ in (3, 4, 5)])
+    assert torch.equal(many[0].step_q, res.step_q) and torch.equal(many[0].ancestors, res.ancestors)
+    assert torch.equal(many[0].particles, res.particles)
+    one = smc.run(genjax.random.key(5, impl))
+    assert torch.equal(many[2].step_q, one.step_q) and many[2].log_marginal_likelihood == one.log_marginal_likelihood
+    assert torch.equal(many[2].log_weights, one.log_weights)
 
 
 def case_general_smc(impl):
