@@ -881,9 +881,11 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   const float* m_ptr = A.m_ptr;
   uint64_t* q_total_out = A.q_total_out;
   Key rkey = A.rkey;
+  const uint64_t* tile_prefix = A.tile_prefix;
   if (A.fb.n_filters > 1) {
     const uint32_t f = (uint32_t)(b / A.fb.tiles);
     b -= (uint64_t)f * A.fb.tiles;
+    if (tile_prefix) tile_prefix += (uint64_t)f * (A.fb.tiles + 1);
     lw_all += (uint64_t)f * A.fb.stride;
     tile_sums += (uint64_t)f * A.fb.tiles;
     m_ptr += (uint64_t)f * A.fb.mq_stride;
@@ -913,9 +915,9 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
 
   // prefix / total of tile masses (u64, exact)
   uint64_t pre = 0, tot = 0;
-  if (A.tile_prefix) {
-    pre = A.tile_prefix[b];
-    tot = A.tile_prefix[A.ntiles];
+  if (tile_prefix) {
+    pre = tile_prefix[b];
+    tot = tile_prefix[A.ntiles];
   } else {
     for (uint64_t k = tid; k < A.ntiles; k += kBlock) {
       const uint64_t v = tile_sums[k];

@@ -653,6 +653,8 @@ static const uint64_t kPrefixTiles = [] {
 __global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint64_t* tile_sums, uint64_t ntiles,
                                                        uint64_t* prefix) {
   __shared__ uint64_t sh64[kBlock / kWave];
+  tile_sums += (uint64_t)blockIdx.x * ntiles;  // one workgroup per filter
+  prefix += (uint64_t)blockIdx.x * (ntiles + 1);
   const uint64_t per = (ntiles + kBlock - 1) / kBlock;
   const uint64_t lo = threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
   uint64_t local = 0;
@@ -1948,12 +1950,16 @@ static int smc_run(const gjx_smc_config* cfg, const void* model, float* out_max,
   const uint64_t stride = F > 1 ? cfg->filter_stride : N;
   const int T = cfg->n_steps;
   if (F > kMaxFilters || (F > 1 && (stride != nt * kTile || nt > kPrefixTiles))) return GJX_ERR_UNSUPPORTED;
+  // Tile-mass prefixes by a separate (one workgroup per filter) launch: worth it for large populations, and for
+  // several filters per launch, where its ~5 us are shared by all of them while every resample workgroup saves
+  // the block-wide reduction of its filter's tile sums.
+  const bool scan = nt > kPrefixTiles || F >= 4;
   Carver cv{(char*)ws, ws ? ws_bytes : 0};
   StateT* st_ws = cv.take<StateT>(F * stride);
   float* lw_ws = cv.take<float>(F * stride);
   float* mp = cv.take<float>(F * nt);
   uint64_t* tiles = cv.take<uint64_t>(F * nt);
-  uint64_t* prefix = nt > kPrefixTiles ? cv.take<uint64_t>(nt + 1) : nullptr;
+  uint64_t* prefix = scan ? cv.take<uint64_t>(F * (nt + 1)) : nullptr;
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   // ping-pong so that the last step lands in the caller's output buffers
   StateT* stb[2];
@@ -1969,7 +1975,7 @@ static int smc_run(const gjx_smc_config* cfg, const void* model, float* out_max,
   for (int t = 0; t < T && !rc; ++t) {
     const int cur = t & 1, prv = cur ^ 1;
     int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * F * stride : nullptr;
-    if (prefix && t) k_scan_tiles<<<1, kBlock, 0, S(s)>>>(tiles, nt, prefix);
+    if (prefix && t) k_scan_tiles<<<F, kBlock, 0, S(s)>>>(tiles, nt, prefix);
     for (unsigned f = 0; f < F && F > 1; ++f) {  // this step's keys of every filter ([F, T, 2] host arrays)
       const uint32_t* sk = cfg->step_keys + 2 * ((size_t)f * T + t);
       const uint32_t* rk = cfg->resample_keys + 2 * ((size_t)f * T + t);
