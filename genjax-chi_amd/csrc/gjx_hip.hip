@@ -1882,6 +1882,7 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
       !state_out || !logw_out || (plan->n_obs > 0 && !obs_host))
     return GJX_ERR_INVALID;
   if (!gjx_jit::enabled()) return GJX_ERR_UNSUPPORTED;  // SMC plans exist only as specialised kernels
+  if (cfg->n_filters > 1) return GJX_ERR_UNSUPPORTED;   // filter batches: the hand-written models only
   gjx_jit::CompiledSmc& c = plan->jit[cfg->impl];
   if (c.state == 0) {
     std::lock_guard<std::mutex> lock(plan->mu);

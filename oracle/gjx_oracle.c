@@ -1123,6 +1123,7 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
   if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !plan || !out_max || !out_q ||
       !state_out || !logw_out || (plan->m.n_obs > 0 && !obs_host))
     return GJX_ERR_INVALID;
+  if (cfg->n_filters > 1) return GJX_ERR_UNSUPPORTED;
   const gjx_smc_model* m = &plan->m;
   const uint64_t N = cfg->n_total, ntile = gjx_num_tiles(N);
   const int D = m->n_state;
