@@ -206,9 +206,9 @@ class Ops:
         return t
 
     def importance_run(self, plan: "Plan", kb: KeyBatch, n: int, input_cols: list[torch.Tensor],
-                       value_dtypes: list, want_score=True, want_max_partials=True, want_rows=False):
-        """One fused `@gen` walk.  With want_rows the launch also folds its row-anchored partial sums:
-        rows.lse / rows.e_out / rows.q_out hold the pass's log-sum-exp (no further kernel)."""
+                       value_dtypes: list, want_score=True, want_max_partials=True, want_rows=False, fuse_lse=False):
+        """One fused `@gen` walk.  With want_rows the launch also emits the row-anchored partial sums of its
+        log-weights (`lse_rows(rows)` folds them); with fuse_lse it folds them itself (rows.lse / e_out / q_out)."""
         if kb.fold is not None:
             raise ValueError("particle keys must not carry a fold")
         ins = (C.c_void_p * max(1, len(input_cols)))()
@@ -223,12 +223,16 @@ class Ops:
         mp = self.empty(self.num_max_partials(n), torch.float32) if want_max_partials else None
         rows, lse = None, None
         if want_rows:
+            # the fold is a separate one-workgroup launch (`lse_rows`, on demand).  gjx_importance_run can also
+            # fold inside the launch (gjx_lse_out, `fuse_lse=True`): one launch fewer, no faster at 1e6 particles,
+            # and it leans on an in-launch hand-off between workgroups — the eager API keeps the plain form.
             rows = RowStats(self.empty(self.num_max_partials(n), torch.int32),
-                            self.empty(self.num_max_partials(n), torch.int64), n,
-                            lse=self.empty(1, torch.float32), e_out=self.empty(1, torch.int32),
-                            q_out=self.empty(1, torch.int64))
-            lse = abi.LseOut(rows.e_out.data_ptr(), rows.q_out.data_ptr(), rows.lse.data_ptr(), None,
-                             self.tickets().data_ptr())
+                            self.empty(self.num_max_partials(n), torch.int64), n)
+            if fuse_lse:
+                rows.lse, rows.e_out, rows.q_out = (self.empty(1, torch.float32), self.empty(1, torch.int32),
+                                                    self.empty(1, torch.int64))
+                lse = abi.LseOut(rows.e_out.data_ptr(), rows.q_out.data_ptr(), rows.lse.data_ptr(), None,
+                                 self.tickets().data_ptr())
         self.lib.call("gjx_importance_run", plan.handle, C.byref(self._keys(kb, n)), ins, len(input_cols), outs,
                       len(vals), C.c_void_p(score.data_ptr()) if want_score else None,
                       C.c_void_p(logw.data_ptr()), n, C.c_void_p(mp.data_ptr()) if mp is not None else None,
@@ -661,11 +665,11 @@ class PreparedImportance:
             raise abi.GjxError("gjx_lse_rows", rc)
 
     def launch(self, stream=None):
+        """One pass (+ the fold of its row sums, a second one-workgroup launch, when with_lse)."""
         st = stream if stream is not None else self.ops.stream()
+        self.launch_importance(st)
         if self.with_lse:
-            self.launch_fused(st)
-        else:
-            self.launch_importance(st)
+            self.launch_lse_rows(st)
 
 
 class _Hip:
