@@ -497,3 +497,31 @@ def test_full_size_properties(hip_ops):
         cnt = torch.bincount(a.long(), minlength=n).double()
         w = torch.softmax(lw.double().cpu(), 0) * n
         assert float((cnt - w).abs().max()) < 1.0 + 1e-4
+
+
+def test_full_size_batches(hip_ops):
+    """The benchmark's launches at full size: 8 independent 1e6-particle ImportanceK passes in one launch and 8
+    bootstrap filters (T = 20) in the same launches.  Every pass / filter has its own seed: the estimates differ,
+    each agrees with the float64 log-sum-exp of its own log-weights, and their spread around the closed form is
+    the Monte-Carlo error of one estimate."""
+    n, L = 1_000_000, 8
+    wl = W.Gaussian10(hip_ops, 1, seed=100, n_local=n)
+    prep = wl.prepare(fold_batch=L, passes=L)
+    prep.launch_passes(0, L)
+    prep.launch_fold(L)
+    exact = W.gaussian10_exact_log_z(wl.y)
+    zs = [hip_ops.log_z_from_rows(prep.e_all[p], prep.q_all[p], n) for p in range(L)]
+    assert len({round(z, 9) for z in zs}) == L, "independent passes"
+    for p in range(L):
+        ref = float(torch.logsumexp(prep.logw_all[p, :n].double(), 0).cpu()) - np.log(n)
+        assert abs(zs[p] - ref) < 1e-5
+    err = np.array(zs) - exact
+    assert abs(err.mean()) < 0.1 and err.std() < 0.1, (err.mean(), err.std())
+    # the variance of the weights fixes the estimator's standard deviation: sqrt(var(w) / n) / mean(w)
+    w = torch.exp(prep.logw_all[0, :n].double() - zs[0])
+    assert float(w.std() / np.sqrt(n)) == pytest.approx(err.std(), rel=1.5)
+    f = W.LgssmSMC(hip_ops, 1, 200, n, 20, filters=8)
+    r = f.result(f.run())
+    zf = np.array(r["log_z"])
+    assert len({round(z, 9) for z in zf}) == 8
+    assert abs(zf.mean() - W.lgssm_exact_log_z(f.y)) < 0.1 and zf.std() < 0.1, (zf, W.lgssm_exact_log_z(f.y))
