@@ -42,8 +42,8 @@ BYTES_SMC_PER_PARTICLE_STEP = 44
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=50)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=64)  # multiples of the 8 passes per launch: no ragged launch by default
+    p.add_argument("--warmup", type=int, default=8)
     p.add_argument("--workload", default="importance", choices=["importance", "smc_lgssm", "smc_hmm"])
     p.add_argument("--rng", default="philox", choices=["philox", "threefry"])
     p.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
