@@ -14,7 +14,7 @@ from .abi import GjxLib
 from .ops import Ops
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libgjx_hip.so"))
+HIP_LIB_PATH = os.environ.get("GJX_HIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libgjx_hip.so"))
 
 _current: Ops | None = None
 
