@@ -1718,17 +1718,20 @@ int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gj
 }
 
 // Set by the whole-run drivers around their step launches (large populations only).
-static thread_local const uint64_t* g_tile_prefix = nullptr;
-// Set by the whole-run drivers when several filters step in one launch (cfg->n_filters > 1): the keys of
-// this step and the strides of the per-filter arrays.  n_filters <= 1 otherwise.
-static thread_local FilterBatch g_filters;
+// What the whole-run drivers add to a step (the public per-step entry points pass the default): the
+// precomputed tile-mass prefix of large populations / filter batches, and the filter batch itself (this
+// step's keys and the strides of the per-filter arrays; n_filters <= 1 otherwise).
+struct StepCtx {
+  const uint64_t* tile_prefix = nullptr;
+  FilterBatch fb;
+};
 
 static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const float* prev_logw,
                                       const float* prev_max, const uint64_t* prev_tile_sums,
-                                      uint64_t* prev_q_out) {
+                                      uint64_t* prev_q_out, const StepCtx& ctx = StepCtx{}) {
   ResampleArgs A;
-  A.tile_prefix = g_tile_prefix;
-  A.fb = g_filters;
+  A.tile_prefix = ctx.tile_prefix;
+  A.fb = ctx.fb;
   A.lw = prev_logw; A.m_ptr = prev_max; A.tile_sums = prev_tile_sums;
   A.n = cfg->n_total; A.ntiles = ntiles_of(cfg->n_total); A.n_out = cfg->n_total;
   A.out_lo = (int64_t)cfg->first_slot; A.out_hi = (int64_t)(cfg->first_slot + cfg->n_local);
@@ -1740,23 +1743,23 @@ static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const fl
   return A;
 }
 
-int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t,
-                         const float* prev_state, const float* prev_logw, const float* prev_max,
-                         const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* state_out,
-                         float* logw_out, float* max_partials_out, int32_t* ancestors_out,
-                         gjx_stream s) {
+static int lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t,
+                        const float* prev_state, const float* prev_logw, const float* prev_max,
+                        const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* state_out,
+                        float* logw_out, float* max_partials_out, int32_t* ancestors_out,
+                        gjx_stream s, const StepCtx& ctx) {
   if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !state_out || !logw_out || !max_partials_out)
     return GJX_ERR_INVALID;
   const Key sk{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
   const float rs = normal_rs(mdl->r), lognorm = normal_lognorm(mdl->r);
-  const unsigned nt = (unsigned)ntiles_of(cfg->n_total), nf = g_filters.n_filters > 1 ? g_filters.n_filters : 1u;
+  const unsigned nt = (unsigned)ntiles_of(cfg->n_total), nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
   if (t == 0) {
     GJX_DISPATCH_IMPL(cfg->impl, k_lgssm_init,
-                      <<<nt * nf, kBlock, 0, S(s)>>>(g_filters, sk, cfg->first_slot, cfg->n_local, mdl->x0_loc, mdl->x0_scale, y_t, rs, lognorm, state_out, logw_out, ancestors_out, max_partials_out));
+                      <<<nt * nf, kBlock, 0, S(s)>>>(ctx.fb, sk, cfg->first_slot, cfg->n_local, mdl->x0_loc, mdl->x0_scale, y_t, rs, lognorm, state_out, logw_out, ancestors_out, max_partials_out));
     return launch_status();
   }
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
-  ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out);
+  ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out, ctx);
   if (cfg->impl == 0) {
     LgssmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {}};
     k_resample<0, LgssmPolicy<0>><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
@@ -1767,25 +1770,25 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
   return launch_status();
 }
 
-int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_t y_t,
-                       const int32_t* prev_state, const float* prev_logw, const float* prev_max,
-                       const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
-                       const uint32_t* trans_cdf, const float* obs_logp, int32_t* state_out,
-                       float* logw_out, float* max_partials_out, int32_t* ancestors_out,
-                       gjx_stream s) {
+static int hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_t y_t,
+                      const int32_t* prev_state, const float* prev_logw, const float* prev_max,
+                      const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
+                      const uint32_t* trans_cdf, const float* obs_logp, int32_t* state_out,
+                      float* logw_out, float* max_partials_out, int32_t* ancestors_out,
+                      gjx_stream s, const StepCtx& ctx) {
   if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !state_out || !logw_out ||
       !max_partials_out || !trans_cdf || !obs_logp || y_t < 0 || y_t >= mdl->n_states ||
       mdl->n_states > 256 || mdl->init_state < 0 || mdl->init_state >= mdl->n_states)
     return GJX_ERR_INVALID;
   const Key sk{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
-  const unsigned nt = (unsigned)ntiles_of(cfg->n_total), nf = g_filters.n_filters > 1 ? g_filters.n_filters : 1u;
+  const unsigned nt = (unsigned)ntiles_of(cfg->n_total), nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
   if (t == 0) {
     GJX_DISPATCH_IMPL(cfg->impl, k_hmm_init,
-                      <<<nt * nf, kBlock, 0, S(s)>>>(g_filters, sk, cfg->first_slot, cfg->n_local, trans_cdf, obs_logp, mdl->n_states, mdl->init_state, y_t, state_out, logw_out, ancestors_out, max_partials_out));
+                      <<<nt * nf, kBlock, 0, S(s)>>>(ctx.fb, sk, cfg->first_slot, cfg->n_local, trans_cdf, obs_logp, mdl->n_states, mdl->init_state, y_t, state_out, logw_out, ancestors_out, max_partials_out));
     return launch_status();
   }
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
-  ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out);
+  ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out, ctx);
   if (cfg->impl == 0) {
     HmmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {}, 0.0f};
     k_resample<0, HmmPolicy<0>><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
@@ -1796,8 +1799,26 @@ int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int
   return launch_status();
 }
 
-int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const float* max_partials,
-                   float* max_out, uint64_t* tile_sums, gjx_stream s) {
+int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t,
+                         const float* prev_state, const float* prev_logw, const float* prev_max,
+                         const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* state_out,
+                         float* logw_out, float* max_partials_out, int32_t* ancestors_out,
+                         gjx_stream s) {
+  return lgssm_step_a(cfg, mdl, t, y_t, prev_state, prev_logw, prev_max, prev_tile_sums, prev_q_out, state_out,
+                      logw_out, max_partials_out, ancestors_out, s, StepCtx{});
+}
+int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_t y_t,
+                       const int32_t* prev_state, const float* prev_logw, const float* prev_max,
+                       const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
+                       const uint32_t* trans_cdf, const float* obs_logp, int32_t* state_out,
+                       float* logw_out, float* max_partials_out, int32_t* ancestors_out,
+                       gjx_stream s) {
+  return hmm_step_a(cfg, mdl, t, y_t, prev_state, prev_logw, prev_max, prev_tile_sums, prev_q_out, trans_cdf,
+                    obs_logp, state_out, logw_out, max_partials_out, ancestors_out, s, StepCtx{});
+}
+
+static int smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const float* max_partials,
+                      float* max_out, uint64_t* tile_sums, gjx_stream s, const StepCtx& ctx) {
   if (!cfg_ok(cfg) || !logw_local || !max_partials || !max_out || !tile_sums) return GJX_ERR_INVALID;
   const uint64_t nt_total = ntiles_of(cfg->n_total);
   const uint64_t nt_local = ntiles_of(cfg->n_local);
@@ -1806,7 +1827,7 @@ int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const flo
     k_reduce_max<<<1, kBlock, 0, S(s)>>>(max_partials, nt_total, max_out);
     m_ptr = max_out;
   }
-  const FilterBatch& fb = g_filters;
+  const FilterBatch& fb = ctx.fb;
   const unsigned nf = fb.n_filters > 1 ? fb.n_filters : 1u;
   k_tile_sums<<<(unsigned)nt_local * nf, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total, m_ptr,
                                                             frac_bits(cfg->n_total),
@@ -1815,14 +1836,23 @@ int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const flo
   return launch_status();
 }
 
-int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
-                   gjx_stream s) {
+int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const float* max_partials,
+                   float* max_out, uint64_t* tile_sums, gjx_stream s) {
+  return smc_step_b(cfg, logw_local, max_partials, max_out, tile_sums, s, StepCtx{});
+}
+
+static int smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out, gjx_stream s,
+                      const StepCtx& ctx) {
   if (!cfg_ok(cfg) || !tile_sums || !q_out) return GJX_ERR_INVALID;
-  const unsigned nf = g_filters.n_filters > 1 ? g_filters.n_filters : 1u;
+  const unsigned nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
   const uint64_t nt = ntiles_of(cfg->n_total);
   for (unsigned f = 0; f < nf; ++f)
-    k_reduce_sum<<<1, kBlock, 0, S(s)>>>(tile_sums + f * nt, nt, q_out + f * g_filters.mq_stride, 0, nullptr, 0, nullptr, nullptr);
+    k_reduce_sum<<<1, kBlock, 0, S(s)>>>(tile_sums + f * nt, nt, q_out + f * ctx.fb.mq_stride, 0, nullptr, 0, nullptr, nullptr);
   return launch_status();
+}
+int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
+                   gjx_stream s) {
+  return smc_finish(cfg, tile_sums, q_out, s, StepCtx{});
 }
 
 // ---- bootstrap SMC for a user model: generated policy in the fused resample kernel -----------------
@@ -1983,19 +2013,17 @@ static int smc_run(const gjx_smc_config* cfg, const void* model, float* out_max,
       fb.step_key[f] = Key{sk[0], sk[1]};
       fb.rkey[f] = Key{rk[0], rk[1]};
     }
-    g_tile_prefix = t ? prefix : nullptr;
-    g_filters = fb;
+    StepCtx ctx;
+    ctx.tile_prefix = t ? prefix : nullptr;
+    ctx.fb = fb;
     rc = step_a(t, stb[prv], lwb[prv], t ? out_max + (t - 1) : nullptr, tiles,
-                t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur], mp, anc_t);
-    g_tile_prefix = nullptr;
-    if (!rc) rc = gjx_smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s);
-    g_filters = FilterBatch{};
+                t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur], mp, anc_t, ctx);
+    if (!rc) rc = smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s, ctx);
   }
   if (rc) return rc;
-  g_filters = fb;
-  rc = gjx_smc_finish(cfg, tiles, out_q + (T - 1), s);
-  g_filters = FilterBatch{};
-  return rc;
+  StepCtx ctx;
+  ctx.fb = fb;
+  return smc_finish(cfg, tiles, out_q + (T - 1), s, ctx);
 }
 
 extern "C" {
@@ -2005,8 +2033,8 @@ int gjx_smc_run_lgssm(const gjx_smc_config* cfg, const gjx_lgssm* model, const f
                       int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s) {
   if (!y_host) return GJX_ERR_INVALID;
   auto step = [&](int t, const float* ps, const float* pl, const float* pm, const uint64_t* tiles,
-                  uint64_t* pq, float* so, float* lo, float* mp, int32_t* anc) {
-    return gjx_smc_lgssm_step_a(cfg, model, t, y_host[t], ps, pl, pm, tiles, pq, so, lo, mp, anc, s);
+                  uint64_t* pq, float* so, float* lo, float* mp, int32_t* anc, const StepCtx& ctx) {
+    return lgssm_step_a(cfg, model, t, y_host[t], ps, pl, pm, tiles, pq, so, lo, mp, anc, s, ctx);
   };
   return smc_run<float>(cfg, model, out_max, out_q, state_out, logw_out, ancestors_out, ws, ws_bytes,
                         s, step);
@@ -2030,8 +2058,8 @@ int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32
   if (rc) return rc;
   const size_t head_bytes = (size_t)(tail_p - (char*)ws);
   auto step = [&](int t, const int32_t* ps, const float* pl, const float* pm, const uint64_t* tiles,
-                  uint64_t* pq, int32_t* so, float* lo, float* mp, int32_t* anc) {
-    return gjx_smc_hmm_step_a(cfg, model, t, y_host[t], ps, pl, pm, tiles, pq, tcdf, ologp, so, lo, mp, anc, s);
+                  uint64_t* pq, int32_t* so, float* lo, float* mp, int32_t* anc, const StepCtx& ctx) {
+    return hmm_step_a(cfg, model, t, y_host[t], ps, pl, pm, tiles, pq, tcdf, ologp, so, lo, mp, anc, s, ctx);
   };
   return smc_run<int32_t>(cfg, model, out_max, out_q, state_out, logw_out, ancestors_out, ws,
                           head_bytes, s, step);
