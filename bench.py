@@ -19,7 +19,6 @@ from __future__ import annotations
 
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -240,7 +239,7 @@ def bench_importance(args, ops, rank, world):
 
 
 def bench_smc(args, ops, rank, world, kind):
-    from genjax._amd import prng, workloads as W
+    from genjax._amd import workloads as W
 
     impl = 1 if args.rng == "philox" else 0
     n = args.particles

@@ -24,9 +24,6 @@ that replaces step (4) with reads of only the ancestor ranges actually needed.
 
 from __future__ import annotations
 
-import math
-
-import numpy as np
 import torch
 
 from . import abi, prng, workloads as W

@@ -10,15 +10,12 @@ categorical draw of `sample_particle`, resampling and ancestor gathers are C-ABI
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
-from typing import Any
 
 import torch
 
 from . import prng
 from .choicemap import ChoiceMap, Selection
-from .lang import (Distribution, DistributionTrace, GenerativeFunction, ParticleKeys, Trace, _map_any, split,
-                   squeeze_leaf)
+from .lang import Distribution, DistributionTrace, GenerativeFunction, ParticleKeys, Trace, split
 from .ops import KeyBatch
 from .runtime import get_ops
 

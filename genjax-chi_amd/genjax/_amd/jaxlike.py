@@ -12,7 +12,7 @@ import torch
 
 from . import prng
 from .choicemap import ChoiceMap
-from .lang import ParticleKeys, fold_in as _fold_in, split as _split
+from .lang import fold_in as _fold_in, split as _split
 from .runtime import get_ops
 
 # ---- jax.random ---------------------------------------------------------------------------------

@@ -31,7 +31,7 @@ import torch
 from . import abi
 from .choicemap import ChoiceMap
 from .lang import GenerativeFunction, StaticGenerativeFunction
-from .plan import PlanTracer, PlanUnsupported, Sym, _IntSym, _Table
+from .plan import PlanTracer, PlanUnsupported, Sym, _Table
 from .runtime import get_ops
 
 

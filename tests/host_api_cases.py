@@ -12,7 +12,7 @@ import torch
 import genjax
 from genjax import ChoiceMap, ChoiceMapBuilder as C, SelectionBuilder as S, Target, beta, categorical, flip, gamma, gen, normal
 from genjax._amd import jaxlike
-from genjax._amd.lang import ParticleKeys, StaticTrace
+from genjax._amd.lang import StaticTrace
 from genjax._amd.plan import try_fused_generate
 from genjax.inference.smc import (BootstrapSMC, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM,
                                   StateSpaceModel)

@@ -6,7 +6,6 @@ import ctypes as C
 import os
 
 import pytest
-import torch
 
 from genjax._amd import abi, workloads as W
 from genjax._amd.abi import GjxLib
