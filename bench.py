@@ -245,17 +245,18 @@ def bench_smc(args, ops, rank, world, kind):
     n = args.particles
     T = 100 if kind == "smc_lgssm" else 500
     if world > 1 or FORCE_DIST:
-        if kind != "smc_lgssm":
-            raise SystemExit("sharded SMC is implemented for smc_lgssm")
         from genjax._amd import dist as gdist
 
         # the sharded filter exchanges whole 1024-particle tiles: round the per-GPU population up
         n = -(-n // ops.tile) * ops.tile
         n_total = n * world
-        smc = gdist.ShardedLgssmSMC(ops, impl, 1, n_total, T, rank, world)
+        exchange = os.environ.get("GJX_BENCH_SHUFFLE", "ranges")
+        smc = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world,
+                               exchange=exchange)
         smc.run()
         barrier_sync(world)
         steps = max(1, min(args.steps, 5))
+        smc.received = 0
         t0 = time.perf_counter()
         for _ in range(steps):
             r = smc.run()
@@ -263,11 +264,14 @@ def bench_smc(args, ops, rank, world, kind):
         dt = max_over_ranks((time.perf_counter() - t0) / steps, world)
         per_step_ms = dt * 1e3 / T
         achieved = BYTES_SMC_PER_PARTICLE_STEP * n / (per_step_ms * 1e-3) / 1e9
+        shuffle = ("ancestor shuffle = grouped send/recv of each rank's contiguous source range (all-to-all-v, in place)"
+                   if exchange == "ranges" else "all-gather of particles and weights")
         return {
             "metric": "particle-steps/sec, bootstrap SMC (1e6 particles per GPU)",
             "value": n_total * T / dt, "unit": "particle-steps/s", "ms_per_step": dt * 1e3,
             "config": {"workload": f"bootstrap SMC {kind} T={T} N={n_total} sharded x{world}", "rng": args.rng,
-                       "parallelism": f"particle-sharded x{world}: all-reduce(max) + all-gather per step"},
+                       "parallelism": f"particle-sharded x{world}: all-reduce(max) + all-gather of tile masses + {shuffle}",
+                       "particles_received_per_rank_step": r["received"] / steps / max(1, T - 1)},
             "roofline": {"bound": "hbm", "kernel": "one SMC step incl. exchange", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "step_ms": per_step_ms, "algorithmic_bytes_per_launch": BYTES_SMC_PER_PARTICLE_STEP * n},

@@ -896,22 +896,28 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   }
   const uint64_t base = b * kTile;
 
-  // Issue this tile's loads first: their HBM latency overlaps the tile-mass prefix reduction.
+  // Issue this tile's loads first: their HBM latency overlaps the tile-mass prefix reduction.  A rank that owns
+  // only a shard of the output slots decides from the tile masses alone whether this source tile feeds any of its
+  // slots, and touches the tile's particles only then (remote tiles it does not need were never exchanged).
+  const bool part = A.out_lo > 0 || A.out_hi < (int64_t)A.n_out;
   float lw4[kPer];
-  if (kPer == 4 && A.lw_vec && base + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
-    const float4 v = reinterpret_cast<const float4*>(lw_all + base)[tid];
-    lw4[0] = v.x; lw4[1] = v.y; lw4[kPer > 2 ? 2 : 0] = v.z; lw4[kPer > 3 ? 3 : 0] = v.w;
-  } else if (kPer == 2 && A.lw_vec && base + kTile <= A.n) {
-    const float2 v = reinterpret_cast<const float2*>(lw_all + base)[tid];
-    lw4[0] = v.x; lw4[1] = v.y;
-  } else {
+  auto load_tile = [&] {
+    if (kPer == 4 && A.lw_vec && base + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
+      const float4 v = reinterpret_cast<const float4*>(lw_all + base)[tid];
+      lw4[0] = v.x; lw4[1] = v.y; lw4[kPer > 2 ? 2 : 0] = v.z; lw4[kPer > 3 ? 3 : 0] = v.w;
+    } else if (kPer == 2 && A.lw_vec && base + kTile <= A.n) {
+      const float2 v = reinterpret_cast<const float2*>(lw_all + base)[tid];
+      lw4[0] = v.x; lw4[1] = v.y;
+    } else {
 #pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-      const uint64_t i = base + kPer * (uint64_t)tid + r;
-      lw4[r] = i < A.n ? lw_all[i] : -__builtin_inff();
+      for (int r = 0; r < kPer; ++r) {
+        const uint64_t i = base + kPer * (uint64_t)tid + r;
+        lw4[r] = i < A.n ? lw_all[i] : -__builtin_inff();
+      }
     }
-  }
-  P.fetch_source(base, A.n, tid);  // registers now, LDS after the scan
+    P.fetch_source(base, A.n, tid);  // registers now, LDS after the scan
+  };
+  if (!part) load_tile();
 
   // prefix / total of tile masses (u64, exact)
   uint64_t pre = 0, tot = 0;
@@ -933,6 +939,16 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   const double u0 = u0_from_bits(rs.bits64(0));
   const double scale = (double)A.n_out / (double)tot;
   const float m = m_ptr[0];
+  if (part) {
+    const uint64_t pre_next = tile_prefix ? tile_prefix[b + 1] : pre + tile_sums[b];
+    const int64_t t_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
+    const int64_t t_hi = b + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(pre_next, scale, u0, (int64_t)A.n_out);
+    if (t_hi <= A.out_lo || t_lo >= A.out_hi) {  // workgroup-uniform
+      if (max_partials && tid == 0) max_partials[b] = -__builtin_inff();
+      return;
+    }
+    load_tile();
+  }
 
   // tile CDF: each thread owns 4 CONSECUTIVE sources (base + 4*tid + r) so the scan is a
   // thread-local prefix plus one block scan.

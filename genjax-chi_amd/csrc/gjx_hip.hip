@@ -912,6 +912,56 @@ struct HmmPolicy {
   }
 };
 
+// Source-tile ranges of `world` equal blocks of output slots (gjx.h: gjx_smc_source_ranges).  One workgroup:
+// every thread owns a contiguous chunk of tiles; chunk offsets by one block scan; tile b can own slots in
+// [ceil(P_b) - 1, ceil(P_{b+1})) for some comb offset (P = prefix * N / Q in float64, the products
+// teeth_below forms), both bounds monotone in b, so a block's range is [#tiles with upper <= lo, #tiles with
+// lower < hi).
+constexpr int kMaxRangeBlocks = 64;
+__global__ __launch_bounds__(kBlock) void k_source_ranges(const uint64_t* tile_sums, uint64_t ntiles, uint64_t n_total,
+                                                          int world, int64_t ticket, int64_t* out) {
+  __shared__ uint64_t sh64[kBlock / kWave];
+  __shared__ unsigned long long cnt[2 * kMaxRangeBlocks];
+  const int tid = threadIdx.x;
+  if (tid < 2 * kMaxRangeBlocks) cnt[tid] = 0;
+  const uint64_t per = (ntiles + kBlock - 1) / kBlock;
+  const uint64_t b0 = per * (uint64_t)tid < ntiles ? per * (uint64_t)tid : ntiles;
+  const uint64_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
+  uint64_t local = 0;
+  for (uint64_t b = b0; b < b1; ++b) local += tile_sums[b];
+  uint64_t tot;
+  const uint64_t pre0 = block_scan_excl(local, sh64, tot);  // (barriers inside also order the cnt[] clear)
+  const double scale = (double)n_total / (double)tot;
+  const double nd = (double)n_total;
+  const uint64_t n_local = n_total / (uint64_t)world;
+  for (int j = 0; j < world; ++j) {
+    const double lo = (double)((uint64_t)j * n_local), hi = (double)((uint64_t)(j + 1) * n_local);
+    uint64_t pre = pre0;
+    unsigned long long first = 0, end = 0;
+    for (uint64_t b = b0; b < b1; ++b) {
+      double lower = __builtin_ceil((double)pre * scale);
+      lower = lower < nd ? lower : nd;
+      lower = lower - 1.0 > 0.0 ? lower - 1.0 : 0.0;
+      pre += tile_sums[b];
+      double upper = __builtin_ceil((double)pre * scale);
+      upper = (b + 1 == ntiles || !(upper < nd)) ? nd : upper;
+      first += upper <= lo ? 1 : 0;
+      end += lower < hi ? 1 : 0;
+    }
+    if (first) atomicAdd(&cnt[2 * j], first);
+    if (end) atomicAdd(&cnt[2 * j + 1], end);
+  }
+  __syncthreads();
+  if (tid < 2 * world) {
+    out[tid] = (int64_t)cnt[tid];
+    __threadfence_system();
+  }
+  __syncthreads();
+  // the ticket goes last, system scope: a host polling pinned memory may consume the ranges without waiting for
+  // the stream
+  if (tid == 0) __hip_atomic_store(out + 2 * world, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Step 0 (no resampling): one block per GLOBAL tile; tiles outside this rank only clear their
 // max partial so the array can be max-combined across ranks.
 template <int IMPL>
@@ -1853,6 +1903,13 @@ static int smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint
 int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
                    gjx_stream s) {
   return smc_finish(cfg, tile_sums, q_out, s, StepCtx{});
+}
+int gjx_smc_source_ranges(const gjx_smc_config* cfg, const uint64_t* tile_sums, int world, int64_t ticket,
+                          int64_t* out_ranges, gjx_stream s) {
+  if (!cfg_ok(cfg) || !tile_sums || !out_ranges || world < 1 || world > kMaxRangeBlocks || cfg->n_total % (uint64_t)world)
+    return GJX_ERR_INVALID;
+  k_source_ranges<<<1, kBlock, 0, S(s)>>>(tile_sums, ntiles_of(cfg->n_total), cfg->n_total, world, ticket, out_ranges);
+  return launch_status();
 }
 
 // ---- bootstrap SMC for a user model: generated policy in the fused resample kernel -----------------

@@ -237,6 +237,7 @@ PROTOTYPES = {
     ),
     "gjx_smc_step_b": (C.c_int, [C.POINTER(SmcConfig), _P, _P, _P, _P, _P]),
     "gjx_smc_finish": (C.c_int, [C.POINTER(SmcConfig), _P, _P, _P]),
+    "gjx_smc_source_ranges": (C.c_int, [C.POINTER(SmcConfig), _P, C.c_int, C.c_int64, _P, _P]),
     "gjx_hmm_cdf_words": (C.c_uint64, [C.c_int32]),
     "gjx_hmm_prepare": (C.c_int, [C.POINTER(Hmm), _P, _P, _P]),
 }

@@ -15,11 +15,12 @@ record per pass yields the global log-normaliser — no second pass over the log
 pair, and the merged result is bit-identical for every number of ranks.
 
 Bootstrap SMC: resampling is global.  Per step each rank (1) resamples + propagates + weights its own
-output slots reading the GLOBAL previous population, (2) all-reduce(max) of the per-tile maxima,
-(3) computes its tiles' fixed-point masses, (4) all-gathers the new particles, weights and tile masses.
-All-gathers over 7 point-to-point xGMI links use every link at once; their volume (8 B per particle
-per step per rank) is what bounds weak scaling — see DESIGN.md §6 for the direct peer-read design
-that replaces step (4) with reads of only the ancestor ranges actually needed.
+output slots reading the GLOBAL previous population — only the source tiles that feed its slots —
+(2) all-reduce(max) of the per-tile maxima, (3) computes its tiles' fixed-point masses and all-gathers
+them (8 B per 1024 particles), (4) the ancestor shuffle: ancestors are monotone, so each rank needs ONE
+contiguous global source range, which every rank derives from the tile masses; it arrives in place by
+grouped send/recv from the ranks that own it (an all-to-all-v with no packing and no count exchange).
+`exchange="allgather"` keeps the simpler all-gather of the whole population.
 """
 
 from __future__ import annotations
@@ -130,62 +131,245 @@ def importance_log_z(ops: Ops, wl: "W.Gaussian10"):
     return ops.log_z_from_rows(e[0], q[0], wl.n_total), pipe.prep.logw, e, q
 
 
-class ShardedLgssmSMC:
-    """Bootstrap SMC on the linear-Gaussian model with the population sharded over ranks."""
+def needed_tile_ranges(tile_sums, n_total: int, tile: int, world: int):
+    """For every rank of a filter sharded into equal contiguous blocks: the half-open range of SOURCE tiles that
+    can own one of the rank's output slots at the next systematic resampling — int64 [world, 2].  Host (numpy)
+    statement of `gjx_smc_source_ranges`, which the sharded filter runs on the device; kept as its cross-check.
 
-    def __init__(self, ops: Ops, impl: int, seed: int, n_total: int, T: int, rank: int, world: int,
-                 record_ancestors: bool = False):
-        tile = ops.tile
-        if n_total % (world * tile) != 0:
-            raise ValueError(f"n_total must be a multiple of world*{tile}")
-        self.ops, self.impl, self.T, self.rank, self.world = ops, impl, T, rank, world
-        self.n_total, self.n_local = n_total, n_total // world
-        self.first = rank * self.n_local
-        self.y = W.lgssm_data(T)
-        sk, rk = W.smc_key_schedule(prng.key(seed, impl), T)
-        self.cfg = ops.smc_config(impl, n_total, self.first, self.n_local, sk, rk)
-        self.model = W.lgssm_model()
-        dev = ops.device()
-        nt = ops.num_tiles(n_total)
-        self.state = [torch.empty(n_total, dtype=torch.float32, device=dev) for _ in range(2)]
-        self.logw = [torch.empty(n_total, dtype=torch.float32, device=dev) for _ in range(2)]
-        self.tile_sums = torch.zeros(nt, dtype=torch.int64, device=dev)
-        self.max_partials = torch.empty(nt, dtype=torch.float32, device=dev)
-        self.out_max = torch.empty(T, dtype=torch.float32, device=dev)
-        self.out_q = torch.zeros(T, dtype=torch.int64, device=dev)
-        self.ancestors = torch.empty((T, self.n_local), dtype=torch.int32, device=dev) if record_ancestors else None
+    Source tile b owns the comb teeth between `teeth_below(prefix_b)` and `teeth_below(prefix_{b+1})`
+    (gjx_device.hpp), `teeth_below(C) = ceil(C * (N / Q) - u0)` in float64 with the comb offset u0 in [0, 1).
+    The same float64 products are formed here from the exact tile masses; u0 is bounded instead of derived, so
+    the range is the exact one or one tile wider at either end.  Both bounds are monotone in b, hence the tiles a
+    rank needs are contiguous."""
+    import numpy as np
 
-    def _gather(self, full: torch.Tensor, lo: int, hi: int):
+    q = np.ascontiguousarray(np.asarray(tile_sums)).view(np.uint64)
+    nt = q.size
+    prefix = np.zeros(nt + 1, dtype=np.uint64)
+    np.cumsum(q, out=prefix[1:])
+    scale = np.float64(n_total) / np.float64(prefix[-1])
+    teeth = np.minimum(np.ceil(prefix.astype(np.float64) * scale), np.float64(n_total))  # u0 = 0: the upper bound
+    lo_b = np.maximum(teeth[:-1] - 1.0, 0.0)  # u0 -> 1
+    hi_b = teeth[1:].copy()
+    hi_b[-1] = n_total  # the last particle closes the comb
+    n_local = n_total // world
+    out = np.empty((world, 2), dtype=np.int64)
+    for j in range(world):
+        out[j, 0] = np.searchsorted(hi_b, np.float64(j * n_local), side="right")
+        out[j, 1] = np.searchsorted(lo_b, np.float64((j + 1) * n_local), side="left")
+    return out
+
+
+class TorchComm:
+    """The exchanges of a sharded filter over `torch.distributed` (RCCL on the GPU box, gloo in the CPU tests)."""
+
+    def __init__(self, rank: int, world: int):
+        self.rank, self.world = rank, world
+
+    def all_reduce_max(self, t: torch.Tensor):
         dist = _dist()
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+
+    def all_gather(self, full: torch.Tensor, lo: int, hi: int):
         if self.world == 1:
             return
         local = full[lo:hi]
         if full.device.type != "cuda":
             local = local.clone()  # gloo: keep input and output distinct
-        dist.all_gather_into_tensor(full, local)
+        _dist().all_gather_into_tensor(full, local)
+
+    def exchange(self, cols, sends, recvs):
+        """Grouped point-to-point transfers of global slices of `cols`: `sends` / `recvs` = [(peer, a, b)].  A slice
+        keeps its global position on both sides, so nothing is packed or unpacked."""
+        dist = _dist()
+        p2p = [dist.P2POp(dist.isend, c[a:b], peer) for peer, a, b in sends for c in cols]
+        p2p += [dist.P2POp(dist.irecv, c[a:b], peer) for peer, a, b in recvs for c in cols]
+        if p2p:
+            for w in dist.batch_isend_irecv(p2p):
+                w.wait()  # stream-ordered on RCCL; blocking on gloo
+
+
+class ThreadComm:
+    """`world` virtual ranks as threads of ONE process sharing one device and one stream: the same exchange
+    protocol with host barriers in place of collectives.  The enqueue order on the shared stream is the
+    execution order, so a barrier between "everyone enqueued its writes" and "everyone enqueues its reads" is
+    all the synchronisation the copies need.  Used to run the sharded protocol on the HIP kernels of a one-GPU
+    box (tests); not a transport."""
+
+    class Shared:
+        def __init__(self, world: int):
+            import threading
+
+            self.world, self.barrier, self.slots = world, threading.Barrier(world), [None] * world
+
+    def __init__(self, shared: "ThreadComm.Shared", rank: int):
+        self.sh, self.rank, self.world = shared, rank, shared.world
+
+    def _post(self, obj):
+        self.sh.slots[self.rank] = obj
+        self.sh.barrier.wait()
+        got = list(self.sh.slots)
+        return got
+
+    def all_reduce_max(self, t: torch.Tensor):
+        got = self._post(t)
+        red = torch.stack(got).amax(dim=0)
+        self.sh.barrier.wait()  # everyone has read every contribution
+        t.copy_(red)
+        self.sh.barrier.wait()
+
+    def all_gather(self, full: torch.Tensor, lo: int, hi: int):
+        got = self._post((full, lo, hi))
+        for r, (src, a, b) in enumerate(got):
+            if r != self.rank:
+                full[a:b].copy_(src[a:b])
+        self.sh.barrier.wait()
+
+    def exchange(self, cols, sends, recvs):
+        got = self._post(cols)
+        for peer, a, b in recvs:
+            for mine, theirs in zip(cols, got[peer]):
+                mine[a:b].copy_(theirs[a:b])
+        self.sh.barrier.wait()
+
+
+class ShardedSMC:
+    """Bootstrap SMC (`kind` "lgssm": BASELINE configs[2]/[3]; "hmm": configs[4]) with the population sharded
+    over ranks in equal contiguous blocks of whole tiles.
+
+    Per step: (a) resample + propagate + weight the rank's OWN output slots from the global previous
+    population (only the source tiles that feed those slots are read), all-reduce(max) of the tile maxima;
+    (b) exact fixed-point tile masses, all-gather of the masses (8 B per 1024 particles); (c) the ancestor
+    shuffle.  Ancestors are monotone in the output slot, so the sources of a rank's slots are ONE contiguous
+    global range, known to every rank from the tile masses alone (`needed_tile_ranges`):
+      exchange="ranges"    each rank receives exactly that range, in place at its global offset, from the few
+                           ranks that own a piece of it (grouped send/recv = an all-to-all-v over xGMI without
+                           packing or a count exchange); volume ~ the rank's own block, independent of the
+                           number of ranks; costs one device->host read of the tile masses per step;
+      exchange="allgather" every rank receives the whole population (no host sync; volume grows with ranks).
+    Either way particles, ancestors and log Z are bit-identical to the single-device filter."""
+
+    def __init__(self, ops: Ops, kind: str, impl: int, seed: int, n_total: int, T: int, rank: int, world: int,
+                 record_ancestors: bool = False, exchange: str = "ranges", comm=None, poison: bool = False,
+                 n_states=None):
+        tile = ops.tile
+        if n_total % (world * tile) != 0:
+            raise ValueError(f"n_total must be a multiple of world*{tile}")
+        if kind not in ("lgssm", "hmm") or exchange not in ("ranges", "allgather"):
+            raise ValueError("kind: lgssm | hmm; exchange: ranges | allgather")
+        self.ops, self.kind, self.impl, self.T, self.rank, self.world = ops, kind, impl, T, rank, world
+        self.exchange, self.poison = exchange, poison
+        self.comm = comm if comm is not None else TorchComm(rank, world)
+        self.n_total, self.n_local = n_total, n_total // world
+        self.first = rank * self.n_local
+        sk, rk = W.smc_key_schedule(prng.key(seed, impl), T)
+        self.cfg = ops.smc_config(impl, n_total, self.first, self.n_local, sk, rk)
+        dev = ops.device()
+        if kind == "lgssm":
+            self.y = W.lgssm_data(T)
+            self.model = W.lgssm_model()
+            self.log_z_exact = W.lgssm_exact_log_z(self.y)
+            sdt = torch.float32
+        else:
+            trans, obs = W.hmm_tables(n_states)
+            self.k = trans.shape[0]
+            self.init = W.HMM["init_state"] % self.k
+            self.y = W.hmm_data(T, n_states)
+            self.log_z_exact = W.hmm_exact_log_z(self.y, n_states)
+            self.model = ops.hmm_model(self.k, self.init, torch.from_numpy(trans).to(dev).contiguous(),
+                                       torch.from_numpy(obs).to(dev).contiguous())
+            self.trans_cdf, self.obs_logp = ops.hmm_prepare_model(self.model)
+            sdt = torch.int32
+        nt = ops.num_tiles(n_total)
+        # global-size buffers: a rank's own block is always current, remote ranges are filled on demand
+        self.state = [torch.zeros(n_total, dtype=sdt, device=dev) for _ in range(2)]
+        self.logw = [torch.zeros(n_total, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.tile_sums = torch.zeros(nt, dtype=torch.int64, device=dev)
+        self.max_partials = torch.empty(nt, dtype=torch.float32, device=dev)
+        self.out_max = torch.empty(T, dtype=torch.float32, device=dev)
+        self.out_q = torch.zeros(T, dtype=torch.int64, device=dev)
+        self.ancestors = torch.empty((T, self.n_local), dtype=torch.int32, device=dev) if record_ancestors else None
+        self.ranges = torch.zeros(2 * world + 1, dtype=torch.int64)  # host memory the device writes (pinned on a GPU box)
+        if dev.type == "cuda":
+            self.ranges = self.ranges.pin_memory()
+        self.ranges_np, self.ticket = self.ranges.numpy(), 0
+        self.received = 0  # particles received over the run (volume of the shuffle)
+
+    def _step_a(self, t: int, cur: int, prv: int):
+        lo, hi = self.first, self.first + self.n_local
+        prev = (self.state[prv], self.logw[prv], self.out_max[t - 1:t], self.tile_sums, self.out_q[t - 1:t]) if t else (
+            None, None, None, None, None)
+        outs = (self.state[cur][lo:hi], self.logw[cur][lo:hi], self.max_partials,
+                None if self.ancestors is None else self.ancestors[t])
+        if self.kind == "lgssm":
+            self.ops.smc_lgssm_step_a(self.cfg, self.model, t, float(self.y[t]), *prev, *outs)
+        else:
+            self.ops.smc_hmm_step_a(self.cfg, self.model, t, int(self.y[t]), *prev, self.trans_cdf, self.obs_logp, *outs)
+
+    def _shuffle(self, cur: int):
+        """Make the source ranges of the next resampling present on every rank."""
+        ops, tile = self.ops, self.ops.tile
+        lo, hi = self.first, self.first + self.n_local
+        cols = [self.state[cur], self.logw[cur]]
+        if self.poison:  # tests: whatever is not received below must never be read
+            for c in cols:
+                keep = c[lo:hi].clone()
+                c.fill_(float("nan") if c.dtype == torch.float32 else 0)
+                c[lo:hi] = keep
+        if self.exchange == "allgather":
+            for c in cols:
+                self.comm.all_gather(c, lo, hi)
+            self.received += self.n_total - self.n_local
+            return
+        # the ranges of all ranks from the tile masses, computed on the device and stored straight into pinned host
+        # memory with a ticket behind them: the host polls for the ticket instead of synchronising the stream
+        self.ticket += 1
+        ops.smc_source_ranges(self.cfg, self.tile_sums, self.world, self.ranges, self.ticket)
+        rh = self.ranges_np
+        if self.ranges.is_pinned():
+            spins = 0
+            while rh[-1] != self.ticket:
+                spins += 1
+                if spins > 200000:  # ~tens of ms: something else holds the stream; fall back to waiting for it
+                    torch.cuda.current_stream().synchronize()
+                    if rh[-1] != self.ticket:
+                        raise RuntimeError("gjx_smc_source_ranges did not deliver its ticket")
+        ranges = rh[:-1].reshape(self.world, 2) * tile
+        sends, recvs = [], []
+        for j in range(self.world):
+            if j == self.rank:
+                continue
+            a, b = max(int(ranges[j, 0]), lo), min(int(ranges[j, 1]), hi)  # what rank j needs of my block
+            if a < b:
+                sends.append((j, a, b))
+            jl = j * self.n_local
+            a, b = max(int(ranges[self.rank, 0]), jl), min(int(ranges[self.rank, 1]), jl + self.n_local)
+            if a < b:
+                recvs.append((j, a, b))
+                self.received += b - a
+        self.comm.exchange(cols, sends, recvs)
 
     def run(self):
-        ops, dist = self.ops, _dist()
+        ops = self.ops
         lo, hi = self.first, self.first + self.n_local
         tl, th = lo // ops.tile, hi // ops.tile
         for t in range(self.T):
             cur, prv = t & 1, (t & 1) ^ 1
-            ops.smc_lgssm_step_a(
-                self.cfg, self.model, t, float(self.y[t]),
-                self.state[prv] if t else None, self.logw[prv] if t else None,
-                self.out_max[t - 1:t] if t else None, self.tile_sums if t else None,
-                self.out_q[t - 1:t] if t else None,
-                self.state[cur][lo:hi], self.logw[cur][lo:hi], self.max_partials,
-                None if self.ancestors is None else self.ancestors[t])
-            if self.world > 1:
-                dist.all_reduce(self.max_partials, op=dist.ReduceOp.MAX)
+            self._step_a(t, cur, prv)
+            self.comm.all_reduce_max(self.max_partials)
             ops.smc_step_b(self.cfg, self.logw[cur][lo:hi], self.max_partials, self.out_max[t:t + 1], self.tile_sums)
-            self._gather(self.tile_sums, tl, th)
-            self._gather(self.state[cur], lo, hi)
-            self._gather(self.logw[cur], lo, hi)
+            self.comm.all_gather(self.tile_sums, tl, th)
+            if t + 1 < self.T:
+                self._shuffle(cur)
         ops.smc_finish(self.cfg, self.tile_sums, self.out_q[self.T - 1:self.T])
         last = (self.T - 1) & 1
         return dict(out_max=self.out_max, out_q=self.out_q, state=self.state[last][lo:hi],
                     logw=self.logw[last][lo:hi], ancestors=self.ancestors,
                     log_z=ops.log_z_from_pairs(self.out_max, self.out_q, self.n_total),
-                    log_z_exact=W.lgssm_exact_log_z(self.y))
+                    log_z_exact=self.log_z_exact, received=self.received)
+
+
+def ShardedLgssmSMC(ops: Ops, impl: int, seed: int, n_total: int, T: int, rank: int, world: int,
+                    record_ancestors: bool = False, **kw):
+    return ShardedSMC(ops, "lgssm", impl, seed, n_total, T, rank, world, record_ancestors, **kw)

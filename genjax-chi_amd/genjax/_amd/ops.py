@@ -423,12 +423,20 @@ class Ops:
                       C.c_void_p(ws.data_ptr()), nb, self.stream())
         return out_max, out_q, state, logw, anc
 
-    def hmm_prepare(self, n_states: int, init_state: int, trans_logits: torch.Tensor, obs_logits: torch.Tensor):
-        """-> (trans_cdf int32[K, K+64] incl. the guide bytes, obs_logp f32[K, K]) — the tables of gjx.h."""
+    def hmm_model(self, n_states: int, init_state: int, trans_logits: torch.Tensor, obs_logits: torch.Tensor) -> abi.Hmm:
         mdl = abi.Hmm()
         mdl.n_states, mdl.init_state = n_states, init_state
         mdl.trans_logits = self._chk(trans_logits, torch.float32, n_states * n_states).value
         mdl.obs_logits = self._chk(obs_logits, torch.float32, n_states * n_states).value
+        mdl._keep = (trans_logits, obs_logits)
+        return mdl
+
+    def hmm_prepare(self, n_states: int, init_state: int, trans_logits: torch.Tensor, obs_logits: torch.Tensor):
+        """-> (trans_cdf int32[K, K+64] incl. the guide bytes, obs_logp f32[K, K]) — the tables of gjx.h."""
+        return self.hmm_prepare_model(self.hmm_model(n_states, init_state, trans_logits, obs_logits))
+
+    def hmm_prepare_model(self, mdl: abi.Hmm):
+        n_states = mdl.n_states
         words = int(self.lib.call("gjx_hmm_cdf_words", n_states))
         cdf = torch.zeros(words, dtype=torch.int32, device=self.device())
         logp = self.empty((n_states, n_states), torch.float32)
@@ -482,12 +490,25 @@ class Ops:
                       self._p(state_out), self._p(logw_out), self._p(max_partials_out), self._p(ancestors_out),
                       self.stream())
 
+    def smc_hmm_step_a(self, cfg, model: abi.Hmm, t: int, y_t: int, prev_state, prev_logw, prev_max, prev_tile_sums,
+                       prev_q_out, trans_cdf, obs_logp, state_out, logw_out, max_partials_out, ancestors_out=None):
+        self.lib.call("gjx_smc_hmm_step_a", C.byref(cfg), C.byref(model), t, int(y_t), self._p(prev_state),
+                      self._p(prev_logw), self._p(prev_max), self._p(prev_tile_sums), self._p(prev_q_out),
+                      self._p(trans_cdf), self._p(obs_logp), self._p(state_out), self._p(logw_out),
+                      self._p(max_partials_out), self._p(ancestors_out), self.stream())
+
     def smc_step_b(self, cfg, logw_local, max_partials, max_out, tile_sums):
         self.lib.call("gjx_smc_step_b", C.byref(cfg), self._p(logw_local), self._p(max_partials), self._p(max_out),
                       self._p(tile_sums), self.stream())
 
     def smc_finish(self, cfg, tile_sums, q_out):
         self.lib.call("gjx_smc_finish", C.byref(cfg), self._p(tile_sums), self._p(q_out), self.stream())
+
+    def smc_source_ranges(self, cfg, tile_sums, world: int, out_ranges, ticket: int = 0):
+        """out_ranges int64[2 world + 1]: the source tiles each of `world` equal output blocks can draw from, then
+        the ticket (stored last; a pinned host buffer can be polled for it)."""
+        self.lib.call("gjx_smc_source_ranges", C.byref(cfg), self._p(tile_sums), int(world), int(ticket),
+                      self._p(out_ranges), self.stream())
 
     def log_z_from_pairs(self, out_max: torch.Tensor, out_q: torch.Tensor, n_total: int) -> float:
         """log Z = sum_t (max_t + log(q_t 2^-frac) - log N), evaluated in float64 on the host from

@@ -400,6 +400,7 @@ int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32
  *    f32[gjx_num_tiles(n_total)]: max over that array == max of the local new log-weights
  *    (-inf entries for work this rank did not own, so ranks combine it with all-reduce(max)).
  *    prev_q_out (nullable dev u64[1]) receives sum(prev_tile_sums).  t == 0 ignores prev_*.
+ *    Only the source tiles that own one of the rank's slots are read (gjx_smc_source_ranges).
  *  step B: max_out[0] = max(max_partials) and tile_sums[first_slot/tile + b] = fixed-point mass
  *    of local tile b under that max (tile_sums is the GLOBAL array; ranks all-gather it).
  *  finish: q_out[0] = sum(tile_sums) (the last step's total). */
@@ -419,6 +420,18 @@ int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const flo
                    float* max_out, uint64_t* tile_sums, gjx_stream s);
 int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
                    gjx_stream s);
+/* A rank with n_local < n_total reads, in step A, ONLY the source tiles that own one of its slots (which tiles
+ * those are follows from prev_tile_sums and the comb offset alone), so between steps it needs just that part
+ * of the other ranks' particles.  source_ranges: for each of `world` equal contiguous blocks of output slots
+ * (block j = slots [j n_total/world, (j+1) n_total/world)), out_ranges[2j], [2j+1] = the half-open range of
+ * source tiles that can own a slot of the block at the next resampling — the exact range or one tile more at
+ * either end (the comb offset is bounded, not derived, so the ranges of a step are known before its key is
+ * used).  Ancestors are monotone in the slot, hence one contiguous range per block.  out_ranges:
+ * int64[2 world + 1], device memory or device-visible pinned host memory; out_ranges[2 world] = ticket is
+ * stored LAST with a system-scope release, so a host that owns a pinned buffer can poll for its ticket and
+ * read the ranges without synchronising the stream.  world <= 64 and n_total a multiple of world. */
+int gjx_smc_source_ranges(const gjx_smc_config* cfg, const uint64_t* tile_sums, int world, int64_t ticket,
+                          int64_t* out_ranges, gjx_stream s);
 /* ---- bootstrap SMC for a user model: init sites + step sites as plans ------------------------ *
  * The general form of the two fixed models above: x_0 comes from `init_sites`, every later step
  * walks `step_sites` for each output slot with GJX_ARG_STATE arguments reading the resampled

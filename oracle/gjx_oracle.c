@@ -766,9 +766,11 @@ static int cfg_ok(const gjx_smc_config* c) {
          c->resample_keys && (c->first_slot % O_TILE) == 0;
 }
 
-/* Ancestors of slots [lo, hi) by systematic resampling of the GLOBAL previous population. */
+/* Ancestors of slots [lo, hi) by systematic resampling of the GLOBAL previous population.  Source tiles
+   whose slots (known from the exact tile masses alone) all lie outside [lo, hi) are skipped without reading
+   their particles: a rank of a sharded filter holds only the source ranges it needs. */
 static void smc_ancestors(const gjx_smc_config* cfg, int t, const float* prev_logw, float m,
-                          uint64_t Q, int32_t* anc /* [n_local] */) {
+                          const uint64_t* tile_sums, uint64_t Q, int32_t* anc /* [n_local] */) {
   const uint64_t N = cfg->n_total;
   const int frac = o_frac_bits(N);
   const int64_t lo = (int64_t)cfg->first_slot, hi = lo + (int64_t)cfg->n_local;
@@ -776,14 +778,24 @@ static void smc_ancestors(const gjx_smc_config* cfg, int t, const float* prev_lo
   o_stream st = o_stream_make(cfg->impl, rkey, 0, 0);
   double u0 = u0_from_bits(o_bits64_at(&st, 0));
   double scale = (double)N / (double)Q;
+  const uint64_t nt = gjx_num_tiles(N);
   uint64_t C = 0;
-  int64_t prev = 0;
-  for (uint64_t i = 0; i < N && prev < hi; ++i) {
-    C += o_fixw(prev_logw[i], m, frac);
-    int64_t ni = (i == N - 1) ? (int64_t)N : teeth_below(C, scale, u0, (int64_t)N);
-    int64_t a = prev > lo ? prev : lo, b = ni < hi ? ni : hi;
-    for (int64_t j = a; j < b; ++j) anc[j - lo] = (int32_t)i;
-    if (ni > prev) prev = ni;
+  for (uint64_t b = 0; b < nt; ++b) {
+    const int64_t t_lo = teeth_below(C, scale, u0, (int64_t)N);
+    const int64_t t_hi = b + 1 == nt ? (int64_t)N : teeth_below(C + tile_sums[b], scale, u0, (int64_t)N);
+    if (t_hi <= lo || t_lo >= hi) {
+      C += tile_sums[b];
+      continue;
+    }
+    int64_t prev = t_lo;
+    const uint64_t i1 = (b + 1) * O_TILE < N ? (b + 1) * O_TILE : N;
+    for (uint64_t i = b * O_TILE; i < i1; ++i) {
+      C += o_fixw(prev_logw[i], m, frac);
+      int64_t ni = (i == N - 1) ? (int64_t)N : teeth_below(C, scale, u0, (int64_t)N);
+      int64_t a = prev > lo ? prev : lo, e = ni < hi ? ni : hi;
+      for (int64_t j = a; j < e; ++j) anc[j - lo] = (int32_t)i;
+      if (ni > prev) prev = ni;
+    }
   }
 }
 
@@ -818,6 +830,39 @@ int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_
   return GJX_OK;
 }
 
+/* Source-tile ranges of `world` equal blocks of output slots: tile b can own slots in [ceil(P_b) - 1,
+   ceil(P_{b+1})) for some comb offset u0 in [0, 1) (teeth_below above; P = prefix * N / Q in double), the last
+   tile up to N. */
+int gjx_smc_source_ranges(const gjx_smc_config* cfg, const uint64_t* tile_sums, int world, int64_t ticket,
+                          int64_t* out_ranges, gjx_stream s) {
+  (void)s;
+  if (!cfg_ok(cfg) || !tile_sums || !out_ranges || world < 1 || world > 64 || cfg->n_total % (uint64_t)world)
+    return GJX_ERR_INVALID;
+  const uint64_t N = cfg->n_total, nt = gjx_num_tiles(N), nl = N / (uint64_t)world;
+  uint64_t Q = 0;
+  for (uint64_t b = 0; b < nt; ++b) Q += tile_sums[b];
+  const double scale = (double)N / (double)Q, nd = (double)N;
+  for (int j = 0; j < world; ++j) {
+    const double lo = (double)((uint64_t)j * nl), hi = (double)((uint64_t)(j + 1) * nl);
+    int64_t first = 0, end = 0;
+    uint64_t pre = 0;
+    for (uint64_t b = 0; b < nt; ++b) {
+      double lower = ceil((double)pre * scale);
+      if (!(lower < nd)) lower = nd;
+      lower = lower - 1.0 > 0.0 ? lower - 1.0 : 0.0;
+      pre += tile_sums[b];
+      double upper = ceil((double)pre * scale);
+      if (b + 1 == nt || !(upper < nd)) upper = nd;
+      first += upper <= lo;
+      end += lower < hi;
+    }
+    out_ranges[2 * j] = first;
+    out_ranges[2 * j + 1] = end;
+  }
+  out_ranges[2 * world] = ticket;
+  return GJX_OK;
+}
+
 /* max_partials_out: only "max over the array == local max" is specified; the oracle puts the
  * local max in the rank's first tile entry and -inf elsewhere. */
 static void put_max_partials(const gjx_smc_config* cfg, float mx, float* mp) {
@@ -846,7 +891,7 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
     if (!anc) return GJX_ERR_LAUNCH;
     const uint64_t Qprev = sum_tiles(cfg, prev_tile_sums);
     if (prev_q_out) *prev_q_out = Qprev;
-    smc_ancestors(cfg, t, prev_logw, *prev_max, Qprev, anc);
+    smc_ancestors(cfg, t, prev_logw, *prev_max, prev_tile_sums, Qprev, anc);
   } else if (ancestors_out) {
     for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
   }
@@ -922,7 +967,7 @@ int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int
     if (!anc) return GJX_ERR_LAUNCH;
     const uint64_t Qprev = sum_tiles(cfg, prev_tile_sums);
     if (prev_q_out) *prev_q_out = Qprev;
-    smc_ancestors(cfg, t, prev_logw, *prev_max, Qprev, anc);
+    smc_ancestors(cfg, t, prev_logw, *prev_max, prev_tile_sums, Qprev, anc);
   } else if (ancestors_out) {
     for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
   }
@@ -1139,7 +1184,7 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
     if (t > 0) {
       uint64_t Qprev = sum_tiles(cfg, tiles);
       out_q[t - 1] = Qprev;
-      smc_ancestors(cfg, t, lw[prv], out_max[t - 1], Qprev, anc);
+      smc_ancestors(cfg, t, lw[prv], out_max[t - 1], tiles, Qprev, anc);
     } else {
       for (uint64_t j = 0; j < N; ++j) anc[j] = (int32_t)j;
     }

@@ -52,8 +52,15 @@ def _worker(rank, world, port, impl, n_total, n_imp_total, T, out_dir):
     assert torch.equal(e2[0:1], e) and torch.equal(q2[0:1], q) and torch.equal(e2[2:3], e) and torch.equal(q2[2:3], q)
     logw_seed4 = pipe2.prep.logw_all[1, :n_imp].clone()
     smc = gdist.ShardedLgssmSMC(ops, impl, seed=5, n_total=n_total, T=T, rank=rank, world=world,
-                                record_ancestors=True).run()
-    torch.save(dict(log_z=log_z, logw=logw, e=e, q=q, e_seed4=e2[1:2].clone(), q_seed4=q2[1:2].clone(), logw_seed4=logw_seed4, smc_max=smc["out_max"], smc_q=smc["out_q"],
+                                record_ancestors=True, poison=True).run()  # exchange="ranges": grouped send/recv
+    assert 0 < smc["received"] < (T - 1) * (n_total - n_total // world)  # less than the whole population per step
+    hmm = gdist.ShardedSMC(ops, "hmm", impl, 6, n_total, T, rank, world, True, exchange="ranges", poison=True,
+                           n_states=16).run()
+    hmm_ag = gdist.ShardedSMC(ops, "hmm", impl, 6, n_total, T, rank, world, True, exchange="allgather",
+                              n_states=16).run()
+    assert torch.equal(hmm["state"], hmm_ag["state"]) and torch.equal(hmm["ancestors"], hmm_ag["ancestors"])
+    torch.save(dict(hmm_state=hmm["state"].clone(), hmm_anc=hmm["ancestors"], hmm_q=hmm["out_q"], hmm_log_z=hmm["log_z"],
+                    log_z=log_z, logw=logw, e=e, q=q, e_seed4=e2[1:2].clone(), q_seed4=q2[1:2].clone(), logw_seed4=logw_seed4, smc_max=smc["out_max"], smc_q=smc["out_q"],
                     smc_state=smc["state"].clone(), smc_anc=smc["ancestors"], smc_log_z=smc["log_z"]),
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
@@ -85,3 +92,123 @@ def test_two_ranks_equal_one_rank(tmp_path, oracle_ops, impl):
         assert torch.equal(p["e_seed4"], ref4["row_e"]) and torch.equal(p["q_seed4"], ref4["row_q"])
     assert torch.equal(torch.cat([p["smc_state"] for p in parts]), ref_smc["state"])
     assert torch.equal(torch.cat([p["smc_anc"] for p in parts], dim=1), ref_smc["ancestors"])
+    ref_hmm = W.hmm_smc(oracle_ops, impl, seed=6, n=n_total, T=T, n_states=16, want_ancestors=True)
+    assert torch.equal(torch.cat([p["hmm_state"] for p in parts]), ref_hmm["state"])
+    assert torch.equal(torch.cat([p["hmm_anc"] for p in parts], dim=1), ref_hmm["ancestors"])
+    for p in parts:
+        assert torch.equal(p["hmm_q"], ref_hmm["out_q"]) and p["hmm_log_z"] == ref_hmm["log_z"]
+
+
+def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_states=16):
+    """`world` virtual ranks as threads sharing one backend (dist.ThreadComm): the sharded protocol without
+    process groups.  Returns the per-rank results."""
+    import threading
+
+    from genjax._amd import dist as gdist
+
+    sh, res, err = gdist.ThreadComm.Shared(world), [None] * world, []
+
+    def work(r):
+        try:
+            kw = dict(n_states=n_states) if kind == "hmm" else {}
+            res[r] = gdist.ShardedSMC(ops, kind, impl, seed, n_total, T, r, world, True, exchange=exchange,
+                                      comm=gdist.ThreadComm(sh, r), poison=True, **kw).run()
+        except BaseException as e:  # noqa: BLE001 - re-raised below; release the others
+            err.append(e)
+            sh.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if err:
+        raise err[0]
+    return res
+
+
+def check_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ref_ops=None):
+    """`ref_ops`: the backend of the single-rank reference filter (default: the same one)."""
+    from genjax._amd import workloads as W
+
+    res = _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange)
+    ref_ops = ops if ref_ops is None else ref_ops
+    ref = (W.lgssm_smc(ref_ops, impl, 5, n_total, T, True) if kind == "lgssm"
+           else W.hmm_smc(ref_ops, impl, 5, n_total, T, 16, True))
+    res = [{k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in r.items()} for r in res]
+    ref = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in ref.items()}
+    assert torch.equal(torch.cat([r["state"] for r in res]), ref["state"])
+    assert torch.equal(torch.cat([r["logw"] for r in res]), ref["logw"])
+    assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1), ref["ancestors"])
+    for r in res:
+        assert torch.equal(r["out_q"], ref["out_q"]) and torch.equal(r["out_max"], ref["out_max"])
+        assert r["log_z"] == ref["log_z"]
+    return res
+
+
+@pytest.mark.parametrize("kind", ["lgssm", "hmm"])
+@pytest.mark.parametrize("world", [3, 4])
+def test_sharded_filter_on_more_ranks(oracle_ops, kind, world):
+    """3 and 4 ranks (virtual: threads + host barriers), remote regions poisoned before every shuffle: the
+    ranges each rank receives are all it reads, and the filter equals the single-rank one bit for bit."""
+    n_total, T = 1024 * world * 3, 9
+    res = check_virtual_ranks(oracle_ops, kind, 1, world, n_total, T, "ranges")
+    everything = (T - 1) * (n_total - n_total // world)
+    assert all(0 < r["received"] < everything // 2 for r in res)
+    check_virtual_ranks(oracle_ops, kind, 0, world, n_total, T, "allgather")
+
+
+def test_needed_tile_ranges_bounds():
+    """The host-side range rule against a brute-force comb: for random tile masses and every comb offset tried,
+    each rank's true source tiles lie inside its range."""
+    import numpy as np
+
+    from genjax._amd import dist as gdist
+
+    rng = np.random.default_rng(0)
+    for world, nt, tile in ((2, 8, 4), (4, 16, 8), (3, 12, 2)):
+        for trial in range(50):
+            q = rng.integers(0, 1 << 40, size=nt).astype(np.uint64)
+            if trial % 5 == 0:
+                q[rng.integers(0, nt, size=nt // 2)] = 0  # empty tiles
+            if q.sum() == 0:
+                q[0] = 1
+            n_total = nt * tile
+            got = gdist.needed_tile_ranges(q.view(np.int64), n_total, tile, world)
+            prefix = np.concatenate([[0], np.cumsum(q.astype(object))])
+            Q = int(prefix[-1])
+            for u0 in (0.0, 0.3, 0.999999):
+                # tooth j sits at (j + u0) * Q / N; its tile is the one whose mass interval contains it
+                pos = [(j + u0) * Q / n_total for j in range(n_total)]
+                owner = [min(int(np.searchsorted(prefix[1:].astype(np.float64), x, side="right")), nt - 1) for x in pos]
+                for r in range(world):
+                    mine = owner[r * n_total // world:(r + 1) * n_total // world]
+                    assert got[r, 0] <= min(mine) and max(mine) < got[r, 1], (world, trial, u0, r)
+
+
+def check_source_ranges(ops):
+    """gjx_smc_source_ranges == the numpy statement of the same rule, for random tile masses."""
+    import numpy as np
+
+    from genjax._amd import dist as gdist, prng, workloads as W
+
+    rng = np.random.default_rng(1)
+    for world, nt in ((2, 8), (4, 16), (3, 12), (8, 64), (1, 5), (8, 1000)):
+        n_total = nt * ops.tile
+        sk, rk = W.smc_key_schedule(prng.key(0, 1), 2)
+        cfg = ops.smc_config(1, n_total, 0, n_total, sk, rk)
+        for trial in range(12):
+            q = rng.integers(0, 1 << 40, size=nt).astype(np.int64)
+            if trial % 4 == 0:
+                q[rng.integers(0, nt, size=nt // 2)] = 0
+            if q.sum() == 0:
+                q[0] = 1
+            out = torch.zeros(2 * world + 1, dtype=torch.int64, device=ops.device())
+            ops.smc_source_ranges(cfg, torch.from_numpy(q).to(ops.device()), world, out, ticket=trial + 1)
+            got = out.cpu().numpy()
+            assert got[-1] == trial + 1
+            assert np.array_equal(got[:-1].reshape(world, 2), gdist.needed_tile_ranges(q, n_total, ops.tile, world)), (world, trial)
+
+
+def test_source_ranges_oracle(oracle_ops):
+    check_source_ranges(oracle_ops)

@@ -1,0 +1,43 @@
+"""The sharded filter's protocol on the HIP kernels of ONE device: virtual ranks (threads sharing the device
+and its stream, `dist.ThreadComm`) run the same per-step sequence the RCCL ranks run — resample only the
+source tiles that feed the rank's slots, max exchange, tile masses, ancestor shuffle by ranges — with every
+region a rank did not receive poisoned.  Particles, ancestors and log Z must equal the CPU oracle's
+single-rank filter bit for bit, and at full size the HIP single-rank filter."""
+
+import pytest
+import torch
+
+from genjax._amd import workloads as W
+from test_distributed_gloo import _run_virtual_ranks, check_virtual_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("kind", ["lgssm", "hmm"])
+@pytest.mark.parametrize("world,exchange", [(2, "ranges"), (4, "ranges"), (3, "allgather")])
+def test_virtual_ranks_equal_oracle(hip_ops, oracle_ops, impl, kind, world, exchange):
+    n_total, T = 1024 * world * 5, 11
+    res = check_virtual_ranks(hip_ops, kind, impl, world, n_total, T, exchange, ref_ops=oracle_ops)
+    if exchange == "ranges":
+        assert all(0 < r["received"] < (T - 1) * (n_total - n_total // world) // 2 for r in res)
+
+
+def test_virtual_ranks_full_size(hip_ops):
+    """2 x 1e6 particles (rounded to whole tiles), T=20: sharded == single-device on the same kernels, and the
+    shuffle moves a small fraction of what an all-gather would."""
+    world, T = 2, 20
+    n_total = 2 * 977 * 1024
+    res = _run_virtual_ranks(hip_ops, "lgssm", 1, world, n_total, T, "ranges")
+    ref = W.lgssm_smc(hip_ops, 1, 5, n_total, T, True)
+    assert torch.equal(torch.cat([r["state"] for r in res]), ref["state"])
+    assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1), ref["ancestors"])
+    for r in res:
+        assert torch.equal(r["out_q"], ref["out_q"]) and r["log_z"] == ref["log_z"]
+        assert r["received"] < 0.05 * (T - 1) * (n_total // world)
+
+
+def test_source_ranges(hip_ops):
+    from test_distributed_gloo import check_source_ranges
+
+    check_source_ranges(hip_ops)
