@@ -200,20 +200,41 @@ struct RunCols {
   void* out[64];
 };
 
-// The 32-bit draw of SMC slot j at one step (one latent site per step): the first single-word draw of
-// the slot's key split(step_key)[j].  THREEFRY keeps the jax shape (split, fold_in(., 1), bits: 3
-// blocks); PHILOX: step_key has lane 0, so the slot key is (step_key, lane j+1) and the draw is word 0
-// of ONE block whose cipher key is uniform over the launch.
+// The 32-bit draw of SMC slot j at one step of the fixed-model filters (one latent site per step).
+// THREEFRY keeps the jax shape: the first single-word draw of the slot's key split(step_key)[j] (split,
+// fold_in(., 1), bits: 3 blocks per slot).  PHILOX: step keys have lane 0, and output slots 4g .. 4g+3 share
+// ONE block, PH(ctr = (g_lo, g_hi, 0, 'Q'), key = step_key): slot j takes word j & 3 — a quarter of a block per
+// particle-step, the cipher key uniform over the launch.  The resampling kernel gives each lane four
+// consecutive slots, i.e. exactly one block.
 template <int IMPL>
 GJX_HD Key slot_key(Key step_key, uint64_t j) {  // split(step_key, *)[j]; step keys have lane 0
   if (IMPL == 0) return split_at<0>(step_key, j);
   const uint64_t lane = j + 1u;
   return Key{step_key.k0, step_key.k1, (uint32_t)lane, (uint32_t)(lane >> 32)};
 }
+constexpr uint32_t kTagQuad = 0x51u;  // 'Q': the shared block of four SMC slots
 template <int IMPL>
-GJX_HD uint32_t smc_slot_bits(Key step_key, uint64_t j) {
-  const Stream<IMPL> st(slot_key<IMPL>(step_key, j), true, IMPL == 0 ? 1u : 0u);
-  return st.bits32(0);
+GJX_HD void smc_quad_bits(Key step_key, uint64_t g, uint32_t (&w)[4]) {  // the draws of slots 4g .. 4g+3
+  if (IMPL == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const Stream<IMPL> st(slot_key<IMPL>(step_key, 4u * g + (uint64_t)u), true, 1u);
+      w[u] = st.bits32(0);
+    }
+  } else {
+    philox4x32(step_key.k0, step_key.k1, (uint32_t)g, (uint32_t)(g >> 32), 0u, kTagQuad, w[0], w[1], w[2], w[3]);
+  }
+}
+template <int IMPL>
+GJX_HD uint32_t smc_slot_bits(Key step_key, uint64_t j) {  // one slot on its own (init kernels' ragged edges, oracle)
+  if (IMPL == 0) {
+    const Stream<IMPL> st(slot_key<IMPL>(step_key, j), true, 1u);
+    return st.bits32(0);
+  }
+  uint32_t w[4];
+  smc_quad_bits<IMPL>(step_key, j >> 2, w);
+  const uint32_t sel = (uint32_t)j & 3u;
+  return sel == 0 ? w[0] : (sel == 1 ? w[1] : (sel == 2 ? w[2] : w[3]));
 }
 
 // Host-visible description of a key batch (mirrors gjx_keys).
@@ -441,6 +462,29 @@ GJX_HD float site_normal(const Stream<IMPL>& st) {
   const Key kb{st.k.k0, st.k.k1, (uint32_t)lb, (uint32_t)(lb >> 32)};
   bm_pair(philox_draw_word(ka, st.f, kTagDraw), philox_draw_word(kb, st.f, kTagDraw), zc, zs);
   return (j & 1u) ? zs : zc;
+}
+
+// Standard normals of SMC slots 4g .. 4g+3 (the LGSSM filter).  THREEFRY: erfinv of each slot's draw.  PHILOX: two
+// Box-Muller transforms over the quad's words, (w0, w1) -> slots 4g, 4g+1 and (w2, w3) -> slots 4g+2, 4g+3.
+template <int IMPL>
+GJX_HD void smc_quad_normals(Key step_key, uint64_t g, float (&z)[4]) {
+  uint32_t w[4];
+  smc_quad_bits<IMPL>(step_key, g, w);
+  if (IMPL == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) z[u] = std_normal(w[u]);
+  } else {
+    bm_pair(w[0], w[1], z[0], z[1]);
+    bm_pair(w[2], w[3], z[2], z[3]);
+  }
+}
+template <int IMPL>
+GJX_HD float smc_slot_normal(Key step_key, uint64_t j) {  // one slot on its own
+  if (IMPL == 0) return std_normal(smc_slot_bits<IMPL>(step_key, j));
+  float z[4];
+  smc_quad_normals<IMPL>(step_key, j >> 2, z);
+  const uint32_t sel = (uint32_t)j & 3u;
+  return sel == 0 ? z[0] : (sel == 1 ? z[1] : (sel == 2 ? z[2] : z[3]));
 }
 
 // --- log-densities (TFP formulas).  The *_pre forms take the per-site constants a plan hoists.
@@ -868,6 +912,33 @@ struct IntC {
   static constexpr int value = N;
 };
 
+// A resampling policy serves the four consecutive output slots of a lane either at once (compute_quad /
+// store_quad: shared cipher block, vector stores) or slot by slot (compute / store: generated policies).
+template <class Policy>
+GJX_DEV auto policy_compute_quad(Policy& P, int64_t jq, const int (&src)[4], typename Policy::Out (&o)[4], float (&w)[4],
+                                 int) -> decltype(P.compute_quad(jq, src, o, w), void()) {
+  P.compute_quad(jq, src, o, w);
+}
+template <class Policy>
+GJX_DEV void policy_compute_quad(Policy& P, int64_t jq, const int (&src)[4], typename Policy::Out (&o)[4], float (&w)[4],
+                                 long) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) w[u] = P.compute(jq + u, src[u], o[u]);
+}
+template <class Policy>
+GJX_DEV auto policy_store_quad(Policy& P, int64_t jq, int64_t out_lo, uint64_t base, const int (&src)[4],
+                               const typename Policy::Out (&o)[4], const bool (&ok)[4], int)
+    -> decltype(P.store_quad(jq, out_lo, base, src, o, ok), void()) {
+  P.store_quad(jq, out_lo, base, src, o, ok);
+}
+template <class Policy>
+GJX_DEV void policy_store_quad(Policy& P, int64_t jq, int64_t out_lo, uint64_t base, const int (&src)[4],
+                               const typename Policy::Out (&o)[4], const bool (&ok)[4], long) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (ok[u]) P.store(jq + u, out_lo, base + (uint64_t)src[u], o[u]);
+}
+
 template <int IMPL, class Policy>
 GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials) {
   __shared__ uint64_t sh64[kBlock / kWave];
@@ -982,41 +1053,18 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   // monotone, so every source that owns at least one slot marks the slot where its run starts and an
   // inclusive max-scan over the chunk spreads each mark over the run (slots before the first mark
   // belong to the source whose run straddles the chunk start).  ~4 LDS accesses per slot instead of a
-  // 10-step dependent binary search.  The chunk is then served as up to 4 rows of 256 slots per lane:
-  // NU independent propagate chains in flight per lane (ILP); the row count is wave-uniform, so rows
-  // past the block's range cost nothing.  Stores close the group.
-  __shared__ int32_t anc_s[kTile];
+  // 10-step dependent binary search.  Chunks start at a multiple of 4 slots and each lane serves FOUR
+  // CONSECUTIVE slots: one 16-byte LDS read of their ancestors, four independent propagate chains in flight
+  // (ILP), one shared cipher block for their draws (smc_quad_bits), 16-byte stores.  Waves whose 256 slots lie
+  // outside the tile's range skip the chunk.
+  __shared__ __attribute__((aligned(16))) int32_t anc_s[kTile];
   __shared__ int shi[kBlock / kWave];
   int32_t nbr[kPer];  // this thread's consecutive sources
 #pragma unroll
   for (int r = 0; r < kPer; ++r) nbr[r] = nb[kPer * tid + r];
   const int32_t nb_prev = tid == 0 ? (int32_t)n_lo : nb[kPer * tid - 1];
   float tmax = -__builtin_inff();
-  auto group = [&](auto nu_tag, int64_t jb) {
-    constexpr int NU = decltype(nu_tag)::value;
-    int64_t jj[NU];
-    bool ok[NU];
-    int src[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int64_t j = jb + tid + (int64_t)u * kBlock;
-      ok[u] = j < j1;
-      jj[u] = ok[u] ? j : j1 - 1;  // surplus lanes of the last row redo its last slot, stores masked
-      src[u] = anc_s[jj[u] - jb];
-    }
-    typename Policy::Out out[NU];
-    float w[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) w[u] = P.compute(jj[u], src[u], out[u]);
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      if (ok[u]) {
-        P.store(jj[u], A.out_lo, base + (uint64_t)src[u], out[u]);
-        tmax = w[u] > tmax ? w[u] : tmax;
-      }
-    }
-  };
-  for (int64_t jb = j0; jb < j1; jb += (int64_t)kTile) {
+  for (int64_t jb = j0 & ~(int64_t)3; jb < j1; jb += (int64_t)kTile) {
     // the source whose run contains slot jb: the first s with nb[s] > jb
     int below = 0;
 #pragma unroll
@@ -1041,19 +1089,30 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
       v[r] = run_max;
     }
     const int carry = block_scan_max_excl(run_max, shi);
+    // every entry of the chunk ends up a valid local source index (slots outside [j0, j1) included: they are
+    // computed along with their quad and never stored), so no lane needs clamping
+    int src[kPer];
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
       const int a = v[r] > carry ? v[r] : carry;
-      anc_s[kPer * tid + r] = a ? a - 1 : s_first;
+      src[r] = a ? a - 1 : (s_first < kTile ? s_first : kTile - 1);
     }
-    __syncthreads();
-    const int64_t rows = (j1 - jb + kBlock - 1) / kBlock;  // wave-uniform
-    if (kPer >= 4 && rows >= 4) group(IntC<(kPer >= 4 ? 4 : 1)>{}, jb);
-    else if (kPer >= 3 && rows == 3) group(IntC<(kPer >= 3 ? 3 : 1)>{}, jb);
-    else if (rows >= 2) group(IntC<2>{}, jb);
-    else group(IntC<1>{}, jb);
+    // the lane's own four slots are the four entries it just resolved: no LDS round trip
+    const int64_t jq = jb + (int64_t)kPer * tid;
+    const int64_t wave_lo = jb + (int64_t)kPer * (tid & ~(kWave - 1));
+    if (wave_lo < j1 && wave_lo + (int64_t)kPer * kWave > j0) {  // wave-uniform
+      bool ok[kPer];
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) ok[r] = jq + r >= j0 && jq + r < j1;
+      typename Policy::Out out[kPer];
+      float w[kPer];
+      policy_compute_quad(P, jq, src, out, w, 0);
+      policy_store_quad(P, jq, A.out_lo, base, src, out, ok, 0);
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) tmax = ok[r] && w[r] > tmax ? w[r] : tmax;
+    }
   }
-  static_assert(kPer == 2 || kPer == 4, "two or four sources / output rows per lane");
+  static_assert(kPer == 4, "four consecutive sources and four consecutive output slots per lane");
   if (max_partials) {
     const float bm = block_max(tmax, shf);
     if (tid == 0) max_partials[b] = bm;

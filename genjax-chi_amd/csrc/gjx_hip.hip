@@ -831,18 +831,39 @@ struct LgssmPolicy {
   struct Out {
     float x, lw;
   };
-  GJX_DEV float compute(int64_t j, int src_local, Out& o) const {
-    const float eps = std_normal(smc_slot_bits<IMPL>(step_key, (uint64_t)j));
-    const float mean = a * xs[src_local];
-    const float t = q * eps;
-    o.x = mean + t;
-    o.lw = logpdf_normal_pre(y, o.x, rs, lognorm);
-    return o.lw;
+  // the lane's four consecutive slots jq .. jq+3 (jq a multiple of 4): one quad of normals
+  GJX_DEV void compute_quad(int64_t jq, const int (&src)[4], Out (&o)[4], float (&w)[4]) const {
+    float z[4];
+    smc_quad_normals<IMPL>(step_key, (uint64_t)jq >> 2, z);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float mean = a * xs[src[u]];
+      const float t = q * z[u];
+      o[u].x = mean + t;
+      o[u].lw = logpdf_normal_pre(y, o[u].x, rs, lognorm);
+      w[u] = o[u].lw;
+    }
   }
-  GJX_DEV void store(int64_t j, int64_t out_lo, uint64_t src, const Out& o) const {
-    state_out[j - out_lo] = o.x;
-    logw_out[j - out_lo] = o.lw;
-    if (anc_out) anc_out[j - out_lo] = (int32_t)src;
+  GJX_DEV void store_quad(int64_t jq, int64_t out_lo, uint64_t base, const int (&src)[4], const Out (&o)[4],
+                          const bool (&ok)[4]) const {
+    const int64_t k = jq - out_lo;
+    const bool vec = ((((uintptr_t)state_out | (uintptr_t)logw_out | (uintptr_t)anc_out) & 15) == 0);  // uniform
+    if (vec && ok[0] && ok[1] && ok[2] && ok[3]) {
+      *reinterpret_cast<float4*>(state_out + k) = make_float4(o[0].x, o[1].x, o[2].x, o[3].x);
+      *reinterpret_cast<float4*>(logw_out + k) = make_float4(o[0].lw, o[1].lw, o[2].lw, o[3].lw);
+      if (anc_out)
+        *reinterpret_cast<int4*>(anc_out + k) = make_int4((int32_t)(base + (uint64_t)src[0]), (int32_t)(base + (uint64_t)src[1]),
+                                                         (int32_t)(base + (uint64_t)src[2]), (int32_t)(base + (uint64_t)src[3]));
+      return;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ok[u]) {
+        state_out[k + u] = o[u].x;
+        logw_out[k + u] = o[u].lw;
+        if (anc_out) anc_out[k + u] = (int32_t)(base + (uint64_t)src[u]);
+      }
+    }
   }
 };
 
@@ -898,17 +919,68 @@ struct HmmPolicy {
     int32_t z;
     float lw;
   };
-  GJX_DEV float compute(int64_t j, int src_local, Out& o) const {
-    const uint32_t bits = smc_slot_bits<IMPL>(step_key, (uint64_t)j);
-    const uint32_t lo = hmm_row_draw(trans_cdf + (size_t)zs[src_local] * (K + kHmmGuideWords), K, bits);
-    o.z = (int32_t)lo;
-    o.lw = ocol[lo];
-    return o.lw;
+  GJX_DEV void compute_quad(int64_t jq, const int (&src)[4], Out (&o)[4], float (&w)[4]) const {
+    uint32_t bits[4];
+    smc_quad_bits<IMPL>(step_key, (uint64_t)jq >> 2, bits);
+    // hmm_row_draw for the four slots with their table loads issued TOGETHER at every level (row total + guide
+    // byte, first CDF word, then the rare extra steps): the step is bound by the latency of these L2-resident
+    // loads, so four in flight per lane instead of four dependent chains one after the other.
+    const uint32_t* row[4];
+    uint32_t qrow[4], c[4], v[4];
+    uint64_t thr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) row[u] = trans_cdf + (size_t)zs[src[u]] * (K + kHmmGuideWords);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      qrow[u] = row[u][K - 1];
+      c[u] = reinterpret_cast<const uint8_t*>(row[u] + K)[bits[u] >> 24];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      thr[u] = ((uint64_t)bits[u] * (uint64_t)qrow[u]) >> 32;
+      v[u] = row[u][c[u]];
+    }
+    bool more = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) more = more || (uint64_t)v[u] <= thr[u];
+    while (more) {  // row[K-1] = Q > thr: every chain stops at or before K-1
+      more = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if ((uint64_t)v[u] <= thr[u]) {
+          ++c[u];
+          v[u] = row[u][c[u]];
+          more = more || (uint64_t)v[u] <= thr[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      o[u].z = (int32_t)c[u];
+      o[u].lw = ocol[c[u]];
+      w[u] = o[u].lw;
+    }
   }
-  GJX_DEV void store(int64_t j, int64_t out_lo, uint64_t src, const Out& o) const {
-    state_out[j - out_lo] = o.z;
-    logw_out[j - out_lo] = o.lw;
-    if (anc_out) anc_out[j - out_lo] = (int32_t)src;
+  GJX_DEV void store_quad(int64_t jq, int64_t out_lo, uint64_t base, const int (&src)[4], const Out (&o)[4],
+                          const bool (&ok)[4]) const {
+    const int64_t k = jq - out_lo;
+    const bool vec = ((((uintptr_t)state_out | (uintptr_t)logw_out | (uintptr_t)anc_out) & 15) == 0);  // uniform
+    if (vec && ok[0] && ok[1] && ok[2] && ok[3]) {
+      *reinterpret_cast<int4*>(state_out + k) = make_int4(o[0].z, o[1].z, o[2].z, o[3].z);
+      *reinterpret_cast<float4*>(logw_out + k) = make_float4(o[0].lw, o[1].lw, o[2].lw, o[3].lw);
+      if (anc_out)
+        *reinterpret_cast<int4*>(anc_out + k) = make_int4((int32_t)(base + (uint64_t)src[0]), (int32_t)(base + (uint64_t)src[1]),
+                                                         (int32_t)(base + (uint64_t)src[2]), (int32_t)(base + (uint64_t)src[3]));
+      return;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ok[u]) {
+        state_out[k + u] = o[u].z;
+        logw_out[k + u] = o[u].lw;
+        if (anc_out) anc_out[k + u] = (int32_t)(base + (uint64_t)src[u]);
+      }
+    }
   }
 };
 
@@ -984,11 +1056,13 @@ __global__ __launch_bounds__(kBlock) void k_lgssm_init(FilterBatch fb, Key step_
   const uint64_t gbase = gtile * kTile;
   float tmax = -__builtin_inff();
   if (gbase >= first_slot && gbase < first_slot + n_local) {
+    float z[4];  // the lane's four consecutive slots: one quad of normals
+    smc_quad_normals<IMPL>(step_key, (gbase >> 2) + threadIdx.x, z);
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
-      const uint64_t j = gbase + (uint64_t)r * kBlock + threadIdx.x;
+      const uint64_t j = gbase + (uint64_t)kPer * threadIdx.x + r;
       if (j < first_slot + n_local) {
-        const float eps = std_normal(smc_slot_bits<IMPL>(step_key, j));
+        const float eps = z[r];
         const float t = x0_scale * eps;
         const float x = x0_loc + t;
         const float lw = logpdf_normal_pre(y, x, rs, lognorm);
@@ -1024,11 +1098,13 @@ __global__ __launch_bounds__(kBlock) void k_hmm_init(FilterBatch fb, Key step_ke
   float tmax = -__builtin_inff();
   if (gbase >= first_slot && gbase < first_slot + n_local) {
     const uint32_t* cdf = trans_cdf + (size_t)init_state * (K + kHmmGuideWords);
+    uint32_t qb[4];  // the lane's four consecutive slots: one quad of draws
+    smc_quad_bits<IMPL>(step_key, (gbase >> 2) + threadIdx.x, qb);
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
-      const uint64_t j = gbase + (uint64_t)r * kBlock + threadIdx.x;
+      const uint64_t j = gbase + (uint64_t)kPer * threadIdx.x + r;
       if (j < first_slot + n_local) {
-        const uint32_t bits = smc_slot_bits<IMPL>(step_key, j);
+        const uint32_t bits = qb[r];
         const uint32_t lo = hmm_row_draw(cdf, K, bits);
         const float lw = obs_logp[(size_t)lo * K + y];
         state_out[j - first_slot] = (int32_t)lo;

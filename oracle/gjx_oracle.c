@@ -899,7 +899,7 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
   float mx = -INFINITY;
 #pragma omp parallel for reduction(max : mx) schedule(static)
   for (int64_t j = 0; j < (int64_t)nl; ++j) {
-    float eps = o_std_normal(o_smc_slot_bits(cfg->impl, skey, cfg->first_slot + (uint64_t)j));
+    float eps = o_smc_slot_normal(cfg->impl, skey, cfg->first_slot + (uint64_t)j);
     float x;
     if (t == 0) {
       float tt = mdl->x0_scale * eps;

@@ -158,13 +158,22 @@ static inline uint64_t o_bits64_at(const o_stream* s, uint32_t sub) {
   return ((uint64_t)w0 << 32) | w1;
 }
 
-/* The 32-bit draw of SMC slot j at one step: the first single-word draw of the slot
- * key split(step_key)[j] (THREEFRY: site counter 1; PHILOX: fold 0). */
+/* The 32-bit draw of SMC slot j at one step of the fixed-model filters.  THREEFRY: the first
+ * single-word draw of the slot key split(step_key)[j] (site counter 1).  PHILOX: slots 4g .. 4g+3 share the block
+ * PH(ctr = (g_lo, g_hi, 0, 'Q'), key = step_key) and slot j takes word j & 3. */
+#define O_TAG_QUAD 0x51u
 static inline uint32_t o_smc_slot_bits(int impl, const uint32_t step_key[4], uint64_t j) {
-  uint32_t pk[4];
-  o_split_at(impl, step_key, j, pk);
-  o_stream st = o_stream_make(impl, pk, 1, impl == 0 ? 1u : 0u);
-  return o_bits32_at(&st, 0);
+  if (impl == 0) {
+    uint32_t pk[4];
+    o_split_at(impl, step_key, j, pk);
+    o_stream st = o_stream_make(impl, pk, 1, 1u);
+    return o_bits32_at(&st, 0);
+  }
+  const uint64_t g = j >> 2;
+  const uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), 0u, O_TAG_QUAD};
+  uint32_t o[4];
+  o_philox4x32(step_key[0], step_key[1], c, o);
+  return o[j & 3u];
 }
 
 /* ---------------- f32 math spec: only IEEE-exact primitives -------------- *
@@ -328,6 +337,17 @@ static inline float o_site_normal(const o_stream* s) {
   uint32_t ka[4] = {s->k[0], s->k[1], (uint32_t)la, (uint32_t)(la >> 32)};
   uint32_t kb[4] = {s->k[0], s->k[1], (uint32_t)lb, (uint32_t)(lb >> 32)};
   o_bm_pair(o_draw_word(ka, s->f, O_TAG_DRAW), o_draw_word(kb, s->f, O_TAG_DRAW), &zc, &zs);
+  return (j & 1u) ? zs : zc;
+}
+
+/* The standard normal of SMC slot j (LGSSM filter).  THREEFRY: erfinv of the slot's draw.  PHILOX: Box-Muller
+ * over the slot's pair inside its quad — slots (4g, 4g+1) from words (0, 1), slots (4g+2, 4g+3) from words
+ * (2, 3); the even slot takes the cosine branch. */
+static inline float o_smc_slot_normal(int impl, const uint32_t step_key[4], uint64_t j) {
+  if (impl == 0) return o_std_normal(o_smc_slot_bits(impl, step_key, j));
+  const uint64_t even = j & ~(uint64_t)1;
+  float zc, zs;
+  o_bm_pair(o_smc_slot_bits(impl, step_key, even), o_smc_slot_bits(impl, step_key, even + 1u), &zc, &zs);
   return (j & 1u) ? zs : zc;
 }
 
