@@ -867,16 +867,16 @@ struct LgssmPolicy {
   }
 };
 
-// Rows of the prepared transition table are kHmmGuideWords apart beyond K: C_0..C_{K-1} (fixed-point
-// inclusive CDF) followed by a 256-byte GUIDE, guide[b] = first c with C_c > ((b << 24) * Q) >> 32.  A draw
-// with top byte b starts its scan there: the index is the one a search of the whole row returns, found
-// after ~1 dependent load instead of 8 (the row loads are L2 latency, the dominant cost of the HMM step).
-constexpr int kHmmGuideWords = 64;
-GJX_DEV uint32_t hmm_row_draw(const uint32_t* row, int32_t K, uint32_t bits) {
-  const uint64_t thr = ((uint64_t)bits * (uint64_t)row[K - 1]) >> 32;
-  uint32_t c = reinterpret_cast<const uint8_t*>(row + K)[bits >> 24];
-  while ((uint64_t)row[c] <= thr) ++c;  // row[K-1] = Q > thr: terminates
-  return c;
+// The transition table is an ALIAS table (gjx.h): row z holds K packed entries
+// (threshold24 << 8) | alias, and a draw costs ONE 4-byte table load: column = floor(bits K / 2^32), the next
+// 24 bits of the product choose between the column and its alias.  The HMM step is bound by the rate of
+// scattered L2-resident loads (one cache line per lane per load), not by arithmetic: an inverse-CDF walk
+// (row total + guide byte + CDF word: three lines per draw) ran at 0.55 of this form's speed.
+GJX_DEV uint32_t hmm_alias_pick(uint32_t e, uint32_t col, uint32_t f24) { return f24 < (e >> 8) ? col : (e & 255u); }
+GJX_DEV uint32_t hmm_alias_draw(const uint32_t* row, int32_t K, uint32_t bits) {
+  const uint64_t t = (uint64_t)bits * (uint64_t)(uint32_t)K;
+  const uint32_t col = (uint32_t)(t >> 32);
+  return hmm_alias_pick(row[col], col, (uint32_t)t >> 8);
 }
 
 template <int IMPL>
@@ -886,7 +886,7 @@ struct HmmPolicy {
   float* logw_out;
   int32_t* anc_out;
   Key step_key;
-  const uint32_t* trans_cdf;  // [K,K]
+  const uint32_t* trans_cdf;  // alias table [K,K]
   const float* obs_logp;      // [K,K]
   int32_t K, y;
   int32_t* zs;
@@ -922,38 +922,17 @@ struct HmmPolicy {
   GJX_DEV void compute_quad(int64_t jq, const int (&src)[4], Out (&o)[4], float (&w)[4]) const {
     uint32_t bits[4];
     smc_quad_bits<IMPL>(step_key, (uint64_t)jq >> 2, bits);
-    // hmm_row_draw for the four slots with their table loads issued TOGETHER at every level (row total + guide
-    // byte, first CDF word, then the rare extra steps): the step is bound by the latency of these L2-resident
-    // loads, so four in flight per lane instead of four dependent chains one after the other.
-    const uint32_t* row[4];
-    uint32_t qrow[4], c[4], v[4];
-    uint64_t thr[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) row[u] = trans_cdf + (size_t)zs[src[u]] * (K + kHmmGuideWords);
+    // the four table words of the lane's slots are loaded together, then resolved
+    uint32_t col[4], f24[4], e[4], c[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      qrow[u] = row[u][K - 1];
-      c[u] = reinterpret_cast<const uint8_t*>(row[u] + K)[bits[u] >> 24];
+      const uint64_t t = (uint64_t)bits[u] * (uint64_t)(uint32_t)K;
+      col[u] = (uint32_t)(t >> 32);
+      f24[u] = (uint32_t)t >> 8;
+      e[u] = trans_cdf[(size_t)zs[src[u]] * K + col[u]];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      thr[u] = ((uint64_t)bits[u] * (uint64_t)qrow[u]) >> 32;
-      v[u] = row[u][c[u]];
-    }
-    bool more = false;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) more = more || (uint64_t)v[u] <= thr[u];
-    while (more) {  // row[K-1] = Q > thr: every chain stops at or before K-1
-      more = false;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if ((uint64_t)v[u] <= thr[u]) {
-          ++c[u];
-          v[u] = row[u][c[u]];
-          more = more || (uint64_t)v[u] <= thr[u];
-        }
-      }
-    }
+    for (int u = 0; u < 4; ++u) c[u] = hmm_alias_pick(e[u], col[u], f24[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       o[u].z = (int32_t)c[u];
@@ -1097,7 +1076,7 @@ __global__ __launch_bounds__(kBlock) void k_hmm_init(FilterBatch fb, Key step_ke
   const uint64_t gbase = gtile * kTile;
   float tmax = -__builtin_inff();
   if (gbase >= first_slot && gbase < first_slot + n_local) {
-    const uint32_t* cdf = trans_cdf + (size_t)init_state * (K + kHmmGuideWords);
+    const uint32_t* cdf = trans_cdf + (size_t)init_state * K;
     uint32_t qb[4];  // the lane's four consecutive slots: one quad of draws
     smc_quad_bits<IMPL>(step_key, (gbase >> 2) + threadIdx.x, qb);
 #pragma unroll
@@ -1105,7 +1084,7 @@ __global__ __launch_bounds__(kBlock) void k_hmm_init(FilterBatch fb, Key step_ke
       const uint64_t j = gbase + (uint64_t)kPer * threadIdx.x + r;
       if (j < first_slot + n_local) {
         const uint32_t bits = qb[r];
-        const uint32_t lo = hmm_row_draw(cdf, K, bits);
+        const uint32_t lo = hmm_alias_draw(cdf, K, bits);
         const float lw = obs_logp[(size_t)lo * K + y];
         state_out[j - first_slot] = (int32_t)lo;
         logw_out[j - first_slot] = lw;
@@ -1118,34 +1097,43 @@ __global__ __launch_bounds__(kBlock) void k_hmm_init(FilterBatch fb, Key step_ke
   if (threadIdx.x == 0) max_partials[blockIdx.x] = bm;
 }
 
-// HMM tables: one thread per row, sequential in k (exactly the spec's order).
+// HMM tables: one thread per row, sequential (exactly the spec's order).  Alias construction in integers
+// (DESIGN.md 3.6 states it in full): p_c = cat_fix, scaled_c = p_c K against Q = sum p; "small" columns
+// (scaled < Q) in increasing order take their alias from the front "large" column, which gives up the
+// difference and joins the back of the small queue once below Q.
 __global__ void k_hmm_prepare(const float* trans_logits, const float* obs_logits, int32_t K,
-                              uint32_t* trans_cdf, float* obs_logp) {
+                              uint32_t* trans_alias, float* obs_logp) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= K) return;
   const float* l = trans_logits + (size_t)r * K;
+  uint32_t* row = trans_alias + (size_t)r * K;
+  uint64_t scaled[256];  // private (scratch) arrays: K <= 256 threads run this once per model
+  uint16_t small[256], large[256];
   const float m = row_max(l, (uint32_t)K);
-  uint32_t C = 0;
+  uint64_t Q = 0;
   for (int c = 0; c < K; ++c) {
-    C += cat_fix(l[c], m);
-    trans_cdf[(size_t)r * (K + kHmmGuideWords) + c] = C;
+    scaled[c] = (uint64_t)cat_fix(l[c], m);
+    Q += scaled[c];
+  }
+  uint32_t hs = 0, ts = 0, hl = 0, tl = 0;
+  for (int c = 0; c < K; ++c) {
+    scaled[c] *= (uint64_t)K;
+    if (scaled[c] < Q) small[ts++] = (uint16_t)c;
+    else large[tl++] = (uint16_t)c;
+    row[c] = (0xffffffu << 8) | (uint32_t)c;  // accept always
+  }
+  while (hs < ts && hl < tl) {
+    const uint32_t sc = small[hs++], g = large[hl];
+    row[sc] = ((uint32_t)((scaled[sc] << 24) / Q) << 8) | g;
+    scaled[g] -= Q - scaled[sc];
+    if (scaled[g] < Q) {
+      ++hl;
+      small[ts++] = (uint16_t)g;
+    }
   }
   const float* o = obs_logits + (size_t)r * K;
   const float lse = row_lse(o, (uint32_t)K);
   for (int c = 0; c < K; ++c) obs_logp[(size_t)r * K + c] = o[c] - lse;
-}
-
-// guide bytes of every row (one workgroup per row, thread b = top byte of the draw)
-__global__ __launch_bounds__(256) void k_hmm_guide(int32_t K, uint32_t* trans_cdf) {
-  uint32_t* row = trans_cdf + (size_t)blockIdx.x * (K + kHmmGuideWords);
-  const uint64_t thr = ((uint64_t)(threadIdx.x << 24) * (uint64_t)row[K - 1]) >> 32;
-  uint32_t lo = 0, hi = (uint32_t)K - 1;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if ((uint64_t)row[mid] > thr) hi = mid;
-    else lo = mid + 1;
-  }
-  reinterpret_cast<uint8_t*>(row + K)[threadIdx.x] = (uint8_t)lo;
 }
 
 // workspace carving
@@ -1830,8 +1818,8 @@ static bool cfg_ok(const gjx_smc_config* c) {
          c->resample_keys && (c->first_slot % kTile) == 0 && c->n_total <= 0x7fffffffull;
 }
 
-uint64_t gjx_hmm_cdf_words(int32_t n_states) {
-  return n_states > 0 ? (uint64_t)n_states * (uint64_t)(n_states + kHmmGuideWords) : 0;
+uint64_t gjx_hmm_alias_words(int32_t n_states) {
+  return n_states > 0 ? (uint64_t)n_states * (uint64_t)n_states : 0;
 }
 int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gjx_stream s) {
   if (!mdl || !trans_cdf || !obs_logp || mdl->n_states <= 0 || mdl->n_states > 256 ||
@@ -1839,7 +1827,6 @@ int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gj
     return GJX_ERR_INVALID;
   k_hmm_prepare<<<(mdl->n_states + 63) / 64, 64, 0, S(s)>>>(mdl->trans_logits, mdl->obs_logits,
                                                              mdl->n_states, trans_cdf, obs_logp);
-  k_hmm_guide<<<mdl->n_states, 256, 0, S(s)>>>(mdl->n_states, trans_cdf);
   return launch_status();
 }
 
@@ -2179,7 +2166,7 @@ int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32
   if (!y_host || !model || model->n_states <= 0 || model->n_states > 256) return GJX_ERR_INVALID;
   // tables live at the tail of the workspace
   const size_t kk = (size_t)model->n_states * (size_t)model->n_states;
-  const size_t cdf_bytes = pad256((size_t)gjx_hmm_cdf_words(model->n_states) * 4);
+  const size_t cdf_bytes = pad256((size_t)gjx_hmm_alias_words(model->n_states) * 4);
   const size_t tail = cdf_bytes + pad256(kk * 4);
   if (!ws || ws_bytes < tail) return GJX_ERR_WORKSPACE;
   char* tail_p = (char*)ws + (ws_bytes - tail);

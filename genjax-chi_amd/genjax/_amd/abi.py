@@ -238,7 +238,7 @@ PROTOTYPES = {
     "gjx_smc_step_b": (C.c_int, [C.POINTER(SmcConfig), _P, _P, _P, _P, _P]),
     "gjx_smc_finish": (C.c_int, [C.POINTER(SmcConfig), _P, _P, _P]),
     "gjx_smc_source_ranges": (C.c_int, [C.POINTER(SmcConfig), _P, C.c_int, C.c_int64, _P, _P]),
-    "gjx_hmm_cdf_words": (C.c_uint64, [C.c_int32]),
+    "gjx_hmm_alias_words": (C.c_uint64, [C.c_int32]),
     "gjx_hmm_prepare": (C.c_int, [C.POINTER(Hmm), _P, _P, _P]),
 }
 
@@ -249,7 +249,7 @@ _NO_STATUS = {
     "gjx_smc_tile",
     "gjx_num_tiles",
     "gjx_num_max_partials",
-    "gjx_hmm_cdf_words",
+    "gjx_hmm_alias_words",
 }
 
 

@@ -432,12 +432,12 @@ class Ops:
         return mdl
 
     def hmm_prepare(self, n_states: int, init_state: int, trans_logits: torch.Tensor, obs_logits: torch.Tensor):
-        """-> (trans_cdf int32[K, K+64] incl. the guide bytes, obs_logp f32[K, K]) — the tables of gjx.h."""
+        """-> (trans_alias int32[K, K] packed alias-table entries, obs_logp f32[K, K]) — the tables of gjx.h."""
         return self.hmm_prepare_model(self.hmm_model(n_states, init_state, trans_logits, obs_logits))
 
     def hmm_prepare_model(self, mdl: abi.Hmm):
         n_states = mdl.n_states
-        words = int(self.lib.call("gjx_hmm_cdf_words", n_states))
+        words = int(self.lib.call("gjx_hmm_alias_words", n_states))
         cdf = torch.zeros(words, dtype=torch.int32, device=self.device())
         logp = self.empty((n_states, n_states), torch.float32)
         self.lib.call("gjx_hmm_prepare", C.byref(mdl), self._p(cdf), self._p(logp), self.stream())

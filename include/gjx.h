@@ -412,7 +412,7 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* model, int 
 int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* model, int t, int32_t y_t,
                        const int32_t* prev_state, const float* prev_logw, const float* prev_max,
                        const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
-                       const uint32_t* trans_cdf /* dev, from gjx_hmm_prepare */,
+                       const uint32_t* trans_alias /* dev, from gjx_hmm_prepare */,
                        const float* obs_logp /* dev f32[K,K] from gjx_hmm_prepare */,
                        int32_t* state_out, float* logw_out, float* max_partials_out,
                        int32_t* ancestors_out, gjx_stream s);
@@ -462,13 +462,13 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
                      float* out_max, uint64_t* out_q, float* const* state_out, float* logw_out,
                      int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s);
 
-/* HMM tables.  trans_cdf: dev u32[gjx_hmm_cdf_words(K)] = K rows of K+64 words: the fixed-point
- * inclusive CDF C_0..C_{K-1} of the row's softmax followed by a 256-byte guide,
- * guide[b] = first c with C_c > ((b << 24) * C_{K-1}) >> 32 — where the scan of a draw whose top byte
- * is b starts (same index as a search of the whole row, ~1 dependent load instead of 8).
- * obs_logp dev f32[K,K] = log_softmax rows of obs_logits.  K <= 256. */
-uint64_t gjx_hmm_cdf_words(int32_t n_states);
-int gjx_hmm_prepare(const gjx_hmm* model, uint32_t* trans_cdf, float* obs_logp, gjx_stream s);
+/* HMM tables.  trans_alias: dev u32[gjx_hmm_alias_words(K)] = K rows of K packed alias-table entries
+ * (threshold24 << 8) | alias built from the row's fixed-point softmax weights: the next state
+ * from 32 random bits is column = floor(bits K / 2^32) if the next 24 bits of bits*K are below the column's
+ * threshold, else the column's alias — one 4-byte table load per draw (the HMM step is bound by the rate of
+ * scattered table loads).  obs_logp dev f32[K,K] = log_softmax rows of obs_logits.  K <= 256. */
+uint64_t gjx_hmm_alias_words(int32_t n_states);
+int gjx_hmm_prepare(const gjx_hmm* model, uint32_t* trans_alias, float* obs_logp, gjx_stream s);
 uint64_t gjx_smc_tile(void); /* particles per tile */
 
 #ifdef __cplusplus

@@ -919,28 +919,50 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
   return GJX_OK;
 }
 
-#define O_HMM_GUIDE_WORDS 64
-uint64_t gjx_hmm_cdf_words(int32_t n_states) {
-  return n_states > 0 ? (uint64_t)n_states * (uint64_t)(n_states + O_HMM_GUIDE_WORDS) : 0;
+/* HMM transition tables as ALIAS tables: one 4-byte table word per draw.  Row r of the table
+ * holds K packed entries (threshold24 << 8) | alias.  Construction, all in integers: p_c = cat_fix(l_c, max l),
+ * Q = sum p_c, scaled_c = p_c * K; columns with scaled < Q queue up as "small", the others as "large", both in
+ * increasing column order; repeatedly the front small column s is paired with the front large column g
+ * (entry s: accept mass scaled_s, alias g; g gives up Q - scaled_s and moves to the BACK of the small queue
+ * once it falls below Q); columns left over accept always.  threshold24 = floor(accept * 2^24 / Q). */
+uint64_t gjx_hmm_alias_words(int32_t n_states) {
+  return n_states > 0 ? (uint64_t)n_states * (uint64_t)n_states : 0;
 }
-int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gjx_stream s) {
+static void hmm_alias_row(const float* l, uint32_t K, uint32_t* row) {
+  uint64_t scaled[256];
+  uint16_t small[512], large[256]; /* queues: a column enters `small` at most twice (once from `large`) */
+  uint32_t hs = 0, ts = 0, hl = 0, tl = 0;
+  const float m = row_max(l, K);
+  uint64_t Q = 0;
+  for (uint32_t c = 0; c < K; ++c) { scaled[c] = (uint64_t)cat_fix(l[c], m); Q += scaled[c]; }
+  for (uint32_t c = 0; c < K; ++c) {
+    scaled[c] *= K;
+    if (scaled[c] < Q) small[ts++] = (uint16_t)c; else large[tl++] = (uint16_t)c;
+  }
+  for (uint32_t c = 0; c < K; ++c) row[c] = (0xffffffu << 8) | c; /* accept always */
+  while (hs < ts && hl < tl) {
+    const uint32_t sc = small[hs++], g = large[hl];
+    row[sc] = ((uint32_t)((scaled[sc] << 24) / Q) << 8) | g;
+    scaled[g] -= Q - scaled[sc];
+    if (scaled[g] < Q) { ++hl; small[ts++] = (uint16_t)g; }
+  }
+}
+/* The state drawn from row `row` with 32 random bits: column = floor(bits K / 2^32), the next 24 bits of the
+ * product decide between the column and its alias. */
+static inline uint32_t hmm_alias_draw(const uint32_t* row, uint32_t K, uint32_t bits) {
+  const uint64_t t = (uint64_t)bits * (uint64_t)K;
+  const uint32_t col = (uint32_t)(t >> 32), f24 = (uint32_t)t >> 8;
+  const uint32_t e = row[col];
+  return f24 < (e >> 8) ? col : (e & 255u);
+}
+int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_alias, float* obs_logp, gjx_stream s) {
   (void)s;
-  if (!mdl || !trans_cdf || !obs_logp || mdl->n_states <= 0 || mdl->n_states > 256 ||
+  if (!mdl || !trans_alias || !obs_logp || mdl->n_states <= 0 || mdl->n_states > 256 ||
       !mdl->trans_logits || !mdl->obs_logits)
     return GJX_ERR_INVALID;
   const uint32_t K = (uint32_t)mdl->n_states;
   for (uint32_t r = 0; r < K; ++r) {
-    const float* l = mdl->trans_logits + (size_t)r * K;
-    float m = row_max(l, K);
-    uint32_t C = 0;
-    uint32_t* row = trans_cdf + (size_t)r * (K + O_HMM_GUIDE_WORDS);
-    for (uint32_t c = 0; c < K; ++c) { C += cat_fix(l[c], m); row[c] = C; }
-    for (uint32_t b = 0; b < 256; ++b) { /* guide: where the scan of a draw with top byte b may start */
-      uint64_t thr = ((uint64_t)(b << 24) * (uint64_t)row[K - 1]) >> 32;
-      uint32_t c = 0;
-      while ((uint64_t)row[c] <= thr) ++c;
-      ((uint8_t*)(row + K))[b] = (uint8_t)c;
-    }
+    hmm_alias_row(mdl->trans_logits + (size_t)r * K, K, trans_alias + (size_t)r * K);
     const float* o = mdl->obs_logits + (size_t)r * K;
     float lse = row_lse(o, K);
     for (uint32_t c = 0; c < K; ++c) obs_logp[(size_t)r * K + c] = o[c] - lse;
@@ -951,12 +973,12 @@ int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gj
 int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_t y_t,
                        const int32_t* prev_state, const float* prev_logw, const float* prev_max,
                        const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
-                       const uint32_t* trans_cdf, const float* obs_logp, int32_t* state_out,
+                       const uint32_t* trans_alias, const float* obs_logp, int32_t* state_out,
                        float* logw_out, float* max_partials_out, int32_t* ancestors_out,
                        gjx_stream s) {
   (void)s;
   if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !state_out || !logw_out || !max_partials_out ||
-      !trans_cdf || !obs_logp || y_t < 0 || y_t >= mdl->n_states)
+      !trans_alias || !obs_logp || y_t < 0 || y_t >= mdl->n_states)
     return GJX_ERR_INVALID;
   const uint64_t nl = cfg->n_local;
   const uint32_t K = (uint32_t)mdl->n_states;
@@ -977,13 +999,7 @@ int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int
   for (int64_t j = 0; j < (int64_t)nl; ++j) {
     uint32_t bits = o_smc_slot_bits(cfg->impl, skey, cfg->first_slot + (uint64_t)j);
     int32_t zp = t == 0 ? mdl->init_state : prev_state[anc[j]];
-    const uint32_t* cdf = trans_cdf + (size_t)zp * (K + O_HMM_GUIDE_WORDS);
-    uint64_t thr = ((uint64_t)bits * (uint64_t)cdf[K - 1]) >> 32;
-    uint32_t lo = 0, hi = K - 1; /* first c with cdf[c] > thr */
-    while (lo < hi) {
-      uint32_t mid = (lo + hi) >> 1;
-      if ((uint64_t)cdf[mid] > thr) hi = mid; else lo = mid + 1;
-    }
+    const uint32_t lo = hmm_alias_draw(trans_alias + (size_t)zp * K, K, bits);
     float lw = obs_logp[(size_t)lo * K + (uint32_t)y_t];
     state_out[j] = (int32_t)lo;
     logw_out[j] = lw;
@@ -1013,7 +1029,7 @@ static int smc_run_common(const gjx_smc_config* cfg, int is_hmm, const void* mod
   if (is_hmm) {
     const gjx_hmm* h = (const gjx_hmm*)model;
     size_t kk = (size_t)h->n_states * (size_t)h->n_states;
-    tcdf = (uint32_t*)malloc(4 * (size_t)gjx_hmm_cdf_words(h->n_states));
+    tcdf = (uint32_t*)malloc(4 * (size_t)gjx_hmm_alias_words(h->n_states));
     ologp = (float*)malloc(4 * kk);
     rc = gjx_hmm_prepare(h, tcdf, ologp, NULL);
   }

@@ -282,3 +282,35 @@ def check_regression(ops):
         assert s_["ancestors"][5, :16].cpu().tolist() == r["lgssm_anc_t5_head"]
         h = W.hmm_smc(ops, impl, seed=5, n=2048, T=6, n_states=16)
         assert h["out_q"].cpu().tolist() == r["hmm_q"]
+
+
+def check_hmm_alias(ops, k):
+    """The alias table of every transition row encodes the row's softmax: summing, over the K columns, the
+    accept mass of the column and the reject mass handed to its alias reproduces softmax(logits) to the table's
+    24-bit threshold resolution; thresholds are below 2^24 and aliases are valid states."""
+    from genjax._amd import workloads as W
+
+    tl, ol = W.hmm_tables(k)
+    dev = ops.device()
+    tab, logp = ops.hmm_prepare(k, 0, torch.from_numpy(tl).contiguous().to(dev), torch.from_numpy(ol).contiguous().to(dev))
+    tab = tab.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert tab.shape == (k, k)
+    thr, alias = tab >> 8, tab & 255
+    assert (alias < k).all() and (thr <= 0xFFFFFF).all()
+    p = np.exp(tl.astype(np.float64) - tl.max(axis=1, keepdims=True))
+    p /= p.sum(axis=1, keepdims=True)
+    acc = thr / float(1 << 24)
+    acc[(alias == np.arange(k)[None, :])] = 1.0  # a column that is its own alias always yields itself
+    got = np.zeros((k, k))
+    for r in range(k):
+        np.add.at(got[r], np.arange(k), acc[r] / k)
+        np.add.at(got[r], alias[r], (1.0 - acc[r]) / k)
+    assert np.abs(got - p).max() < 4e-7  # cat_fix resolution 2^-23 per weight, threshold resolution 2^-24 / K
+    lp = ol.astype(np.float64) - ol.max(axis=1, keepdims=True)
+    lp = lp - np.log(np.exp(lp).sum(axis=1, keepdims=True))
+    assert np.abs(logp.cpu().numpy() - lp).max() < 1e-5
+
+
+@pytest.mark.parametrize("k", [2, 3, 17, 64, 256])
+def test_hmm_alias_tables(oracle_ops, k):
+    check_hmm_alias(oracle_ops, k)
