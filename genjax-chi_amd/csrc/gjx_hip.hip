@@ -867,7 +867,7 @@ struct LgssmPolicy {
   }
 };
 
-// The transition table is an ALIAS table (gjx.h, DESIGN 3.6): row z holds K packed entries
+// The transition table is an ALIAS table (gjx.h, DESIGN 3.6b): row z holds K packed entries
 // (threshold24 << 8) | alias, and a draw costs ONE 4-byte table load: column = floor(bits K / 2^32), the next
 // 24 bits of the product choose between the column and its alias.  The HMM step is bound by the rate of
 // scattered L2-resident loads (one cache line per lane per load), not by arithmetic: an inverse-CDF walk
@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(kBlock) void k_hmm_init(FilterBatch fb, Key step_ke
 }
 
 // HMM tables: one thread per row, sequential (exactly the spec's order).  Alias construction in integers
-// (DESIGN.md 3.6 states it in full): p_c = cat_fix, scaled_c = p_c K against Q = sum p; "small" columns
+// (DESIGN.md 3.6b states it in full): p_c = cat_fix, scaled_c = p_c K against Q = sum p; "small" columns
 // (scaled < Q) in increasing order take their alias from the front "large" column, which gives up the
 // difference and joins the back of the small queue once below Q.
 __global__ void k_hmm_prepare(const float* trans_logits, const float* obs_logits, int32_t K,

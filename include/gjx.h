@@ -335,9 +335,11 @@ int gjx_gather_cols(const int32_t* ancestors, uint64_t n_out, const void* const*
 
 /* ---- fused bootstrap SMC for the benchmark state-space models ------------------------------ *
  * One call enqueues the whole T-step filter (2 kernels per step) on the stream, no host sync.
- * Particle slot j (global index) of step t uses key split(step_keys[t], *)[j] and its first
- * single-word draw (THREEFRY: site counter 1; PHILOX: step keys are lane-0 keys, so the slot key
- * is (step key, lane j+1) and the draw costs ONE block under a launch-uniform cipher key)
+ * Particle slot j (global index) of step t draws ONE 32-bit word.  THREEFRY: the first
+ * single-word draw of the slot key split(step_keys[t], *)[j] (site counter 1), normals by erfinv.  PHILOX: step
+ * keys are lane-0 keys and slots 4g .. 4g+3 share the block PH(ctr = (g_lo, g_hi, 0, 'Q'), key = step key), slot j
+ * taking word j & 3; the LGSSM's normals are Box-Muller pairs over the quad's words ((w0,w1) -> slots 4g, 4g+1;
+ * (w2,w3) -> 4g+2, 4g+3)
  * (the kernel `@gen` body has one latent site; Scan.generate scan.py:237-294 is the reference's
  * T-loop, resampling itself is not in the reference: SURVEY F3/E3).
  * Multi-device: each rank owns slots [first_slot, first_slot+n_local) of n_total and passes
@@ -463,7 +465,7 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
                      int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s);
 
 /* HMM tables.  trans_alias: dev u32[gjx_hmm_alias_words(K)] = K rows of K packed alias-table entries
- * (threshold24 << 8) | alias built from the row's fixed-point softmax weights (DESIGN.md §3.6): the next state
+ * (threshold24 << 8) | alias built from the row's fixed-point softmax weights (DESIGN.md §3.6b): the next state
  * from 32 random bits is column = floor(bits K / 2^32) if the next 24 bits of bits*K are below the column's
  * threshold, else the column's alias — one 4-byte table load per draw (the HMM step is bound by the rate of
  * scattered table loads).  obs_logp dev f32[K,K] = log_softmax rows of obs_logits.  K <= 256. */

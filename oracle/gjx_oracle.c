@@ -919,7 +919,7 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
   return GJX_OK;
 }
 
-/* HMM transition tables as ALIAS tables (DESIGN.md §3.6): one 4-byte table word per draw.  Row r of the table
+/* HMM transition tables as ALIAS tables (DESIGN.md §3.6b): one 4-byte table word per draw.  Row r of the table
  * holds K packed entries (threshold24 << 8) | alias.  Construction, all in integers: p_c = cat_fix(l_c, max l),
  * Q = sum p_c, scaled_c = p_c * K; columns with scaled < Q queue up as "small", the others as "large", both in
  * increasing column order; repeatedly the front small column s is paired with the front large column g
