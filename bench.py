@@ -238,7 +238,7 @@ def bench_importance(args, ops, rank, world):
     return res, wl
 
 
-def bench_smc(args, ops, rank, world, kind):
+def bench_smc(args, ops, rank, world, kind, filters=0):
     from genjax._amd import workloads as W
 
     impl = 1 if args.rng == "philox" else 0
@@ -279,7 +279,7 @@ def bench_smc(args, ops, rank, world, kind):
         }
     # FILTERS independent filters (seeds s, s+1, ...) step in the same launches: a 1e6-particle step is ~1000
     # workgroups, under one round of the machine
-    FILTERS = int(os.environ.get("GJX_BENCH_FILTERS", "8"))
+    FILTERS = filters if filters else int(os.environ.get("GJX_BENCH_FILTERS", "8"))
     wl = W.LgssmSMC(ops, impl, 1, n, T, filters=FILTERS) if kind == "smc_lgssm" else W.HmmSMC(ops, impl, 2, n, T, filters=FILTERS)
     for _ in range(max(1, min(args.warmup, 2))):
         out = wl.run()
@@ -375,6 +375,10 @@ def main():
                 a2.steps, a2.warmup = (5, 1) if kind == "smc_lgssm" else (2, 1)
                 r = bench_smc(a2, ops, rank, world, kind)
                 extra[kind] = {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "log_z", "log_z_exact")}
+                extra[kind]["filters_per_launch"] = r["config"]["filters_per_launch"]
+                r1 = bench_smc(a2, ops, rank, world, kind, filters=1)  # the literal BASELINE config: ONE filter of 1e6 particles
+                extra[kind]["one_filter"] = {"value": r1["value"], "ms_per_step": r1["ms_per_step"],
+                                             "roofline_frac": r1["roofline"]["frac"], "step_ms": r1["roofline"]["step_ms"]}
             a2 = argparse.Namespace(**vars(args))
             a2.rng = "threefry" if args.rng == "philox" else "philox"
             a2.steps, a2.warmup = 20, 3
