@@ -412,10 +412,26 @@ GJX_HD float std_normal(uint32_t bits) {
 // of ~50; each particle still consumes exactly one word per site, so keys, blocks and draw indices are
 // unchanged.  All operations are IEEE-exact (Cephes sinf / cosf kernels on [0, pi/4] after an exact
 // octant reduction of the 24-bit angle), so HIP == oracle bit for bit.  THREEFRY keeps jax's erfinv form.
+// Correctly rounded sqrtf for arguments that are zero or not tiny (here: -2 log u in {0} U [1e-7, 45]).  Same
+// result as __builtin_sqrtf bit for bit; on the device it is the hardware estimate (<= 1 ulp) stepped to the
+// correctly rounded neighbour by two exact residuals, without the scaling and class handling the general
+// lowering adds for tiny and special arguments (16 -> 9 instructions).
+GJX_HD float sqrt_pos(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GJX_GENERAL_SQRT)
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float dn = u2f(f2u(s) - 1u), up = u2f(f2u(s) + 1u);
+  const float e_dn = __builtin_fmaf(-dn, s, x), e_up = __builtin_fmaf(-up, s, x);
+  float r = e_dn <= 0.0f ? dn : s;
+  r = e_up > 0.0f ? up : r;
+  return r;
+#else
+  return __builtin_sqrtf(x);
+#endif
+}
 GJX_HD void bm_pair(uint32_t w_radius, uint32_t w_angle, float& z_cos, float& z_sin) {
   // radius: u in (0, 1] with full float resolution near 0 (tails to 6.6 sigma)
   const float u = ((float)w_radius + 1.0f) * 2.3283064365386963e-10f;
-  const float r = __builtin_sqrtf(-2.0f * m_log_normal(u));
+  const float r = sqrt_pos(-2.0f * m_log_normal(u));
   // angle = 2 pi a / 2^24: octant (3 bits) + fraction (21 bits)
   const uint32_t a = w_angle >> 8;
   const uint32_t oct = a >> 21;
@@ -608,18 +624,55 @@ GJX_HD double u0_from_bits(uint64_t U) { return (double)(U >> 11) * 0x1.0p-53; }
 // ------------------------------------------------------------------------------------------------
 // 64-wide wavefront / 256-thread workgroup reductions and scans (LDS-staged across the 4 waves).
 // ------------------------------------------------------------------------------------------------
+// Cross-lane steps are DPP modifiers (data-parallel primitives: row_shr / row_bcast), i.e. plain VALU
+// instructions: a 64-lane inclusive scan is 6 combine steps with no LDS round trip and no s_waitcnt (the
+// ds_bpermute form of __shfl_* costs an LDS access and a wait per step; the importance kernel's row statistics
+// were 18 such dependent round trips per row).  Pattern (GCN3+ cross-lane reference): shifts by 1, 2, 3 of the
+// input inside each row of 16, then row_shr:4 / row_shr:8 on the upper banks, then row_bcast:15 / row_bcast:31
+// to carry row totals; lanes without a source keep the identity.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+GJX_DEV uint32_t dpp_u32(uint32_t identity, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+GJX_DEV uint64_t dpp_u64(uint64_t identity, uint64_t v) {
+  const uint32_t lo = dpp_u32<CTRL, ROW_MASK, BANK_MASK>((uint32_t)identity, (uint32_t)v);
+  const uint32_t hi = dpp_u32<CTRL, ROW_MASK, BANK_MASK>((uint32_t)(identity >> 32), (uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr3 = 0x113, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118,
+              kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138;
+// Inclusive scan over the wave; `op` associative and commutative, `id` its identity.  Mov is the per-type DPP move.
+#define GJX_WAVE_SCAN_BODY(T, MOV)                                               \
+  T r = op(v, MOV<kDppRowShr1, 0xf, 0xf>(id, v));                                \
+  r = op(r, MOV<kDppRowShr2, 0xf, 0xf>(id, v));                                  \
+  r = op(r, MOV<kDppRowShr3, 0xf, 0xf>(id, v));                                  \
+  r = op(r, MOV<kDppRowShr4, 0xf, 0xe>(id, r));                                  \
+  r = op(r, MOV<kDppRowShr8, 0xf, 0xc>(id, r));                                  \
+  r = op(r, MOV<kDppRowBcast15, 0xa, 0xf>(id, r));                               \
+  r = op(r, MOV<kDppRowBcast31, 0xc, 0xf>(id, r));                               \
+  return r;
+template <class Op>
+GJX_DEV uint32_t wave_scan_u32(uint32_t v, uint32_t id, Op op) { GJX_WAVE_SCAN_BODY(uint32_t, dpp_u32) }
+template <class Op>
+GJX_DEV uint64_t wave_scan_u64(uint64_t v, uint64_t id, Op op) { GJX_WAVE_SCAN_BODY(uint64_t, dpp_u64) }
+#undef GJX_WAVE_SCAN_BODY
+GJX_DEV uint32_t wave_last_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+GJX_DEV uint64_t wave_last_u64(uint64_t v) {
+  return ((uint64_t)wave_last_u32((uint32_t)(v >> 32)) << 32) | wave_last_u32((uint32_t)v);
+}
+// Wave-wide reductions; result valid in every lane.
 GJX_DEV float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const float o = __shfl_xor(v, off, kWave);
-    v = o > v ? o : v;
-  }
-  return v;
+  // float max through the u32 scan: bit patterns are combined with a float compare (exact, order-free)
+  const uint32_t r = wave_scan_u32(f2u(v), f2u(-__builtin_inff()),
+                                   [](uint32_t a, uint32_t b) { return u2f(b) > u2f(a) ? b : a; });
+  return u2f(wave_last_u32(r));
 }
 GJX_DEV uint64_t wave_sum(uint64_t v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, off, kWave);
-  return v;
+  return wave_last_u64(wave_scan_u64(v, 0, [](uint64_t a, uint64_t b) { return a + b; }));
+}
+GJX_DEV int wave_sum_int(int v) {
+  return (int)wave_last_u32(wave_scan_u32((uint32_t)v, 0u, [](uint32_t a, uint32_t b) { return a + b; }));
 }
 // Block-wide max; result valid in every thread.  `sh` needs 4 floats.
 GJX_DEV float block_max(float v, float* sh) {
@@ -646,13 +699,7 @@ GJX_DEV uint64_t block_sum(uint64_t v, uint64_t* sh) {
 }
 // Inclusive wave scan of u64.
 GJX_DEV uint64_t wave_scan_incl(uint64_t v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const uint64_t o = (uint64_t)__shfl_up((unsigned long long)v, off, kWave);
-    if (lane >= off) v += o;
-  }
-  return v;
+  return wave_scan_u64(v, 0, [](uint64_t a, uint64_t b) { return a + b; });
 }
 // Exclusive block scan of one u64 per thread; returns the exclusive prefix, total in `total`.
 GJX_DEV uint64_t block_scan_excl(uint64_t v, uint64_t* sh, uint64_t& total) {
@@ -674,14 +721,9 @@ GJX_DEV uint64_t block_scan_excl(uint64_t v, uint64_t* sh, uint64_t& total) {
 // Exclusive block max-scan of one int per thread (identity 0) and a block-wide int sum.  `sh` needs 4 ints.
 GJX_DEV int block_scan_max_excl(int v, int* sh) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int incl = v;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const int o = __shfl_up(incl, off, kWave);
-    if (lane >= off) incl = o > incl ? o : incl;
-  }
-  int excl = __shfl_up(incl, 1, kWave);
-  if (lane == 0) excl = 0;
+  // values are >= 0 (identity 0): the unsigned scan orders them like the signed one
+  const int incl = (int)wave_scan_u32((uint32_t)v, 0u, [](uint32_t a, uint32_t b) { return b > a ? b : a; });
+  int excl = (int)dpp_u32<kDppWaveShr1, 0xf, 0xf>(0u, (uint32_t)incl);  // lane i <- lane i-1, lane 0 keeps 0
   __syncthreads();
   if (lane == 63) sh[w] = incl;
   __syncthreads();
@@ -691,8 +733,7 @@ GJX_DEV int block_scan_max_excl(int v, int* sh) {
   return excl;
 }
 GJX_DEV int block_sum_int(int v, int* sh) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  v = wave_sum_int(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();

@@ -1460,11 +1460,29 @@ static gjx_jit::Compiled& plan_compiled(gjx_plan* mp, const gjx_keys* pk, bool p
     if (c.state == 0) {
       gjx_jit::Gen<CSite, CArg> g;
       g.impl = pk->impl; g.sites = mp->host; g.n_sites = mp->n_sites; g.laned = laned;
-      if (const char* e = std::getenv("GJX_JIT_MIN_WAVES")) g.min_waves = atoi(e);
-      const std::string src = g.run();
+      // The kernels are bound by dependency latency, not by issue slots (a wave64 VALU instruction issues in ~2.4
+      // cycles, tools/microbench/valu_rate.hip): a sixth wave per SIMD (<= 80 VGPRs) is worth 2-3 % on the paired
+      // form as long as the allocator gets there with (next to) no spilling; otherwise the unconstrained build is kept.
+      const char* e = std::getenv("GJX_JIT_MIN_WAVES");  // test knob: force the hint (0 = none)
+      g.min_waves = e ? atoi(e) : (laned ? 6 : 0);
+      std::string src = g.run();
       c.block = g.block;
       c.rows_per_block = g.rows_per_block;
-      c.state = gjx_jit::compile(src, pk->impl, &c) ? 1 : -1;
+      bool ok = gjx_jit::compile(src, pk->impl, &c);
+      if (ok && !e && g.min_waves > 0) {
+        int scratch = 0;
+        const hipError_t qe = hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, c.fn);
+        if (qe != hipSuccess) (void)hipGetLastError();  // a failed query must not surface as a launch error later
+        if (std::getenv("GJX_PLAN_JIT_VERBOSE")) fprintf(stderr, "gjx jit: waves-per-SIMD hint %d: query %d, scratch %d B\n", g.min_waves, (int)qe, scratch);
+        if (qe != hipSuccess || scratch > 32) {  // (a couple of spilled words cost less than the lost wave)
+          c.fn = nullptr;  // the hinted module stays in the source-keyed cache
+          gjx_jit::Gen<CSite, CArg> g2;
+          g2.impl = pk->impl; g2.sites = mp->host; g2.n_sites = mp->n_sites; g2.laned = laned;
+          src = g2.run();
+          ok = gjx_jit::compile(src, pk->impl, &c);
+        }
+      }
+      c.state = ok ? 1 : -1;
     }
   }
   return c;

@@ -292,7 +292,9 @@ struct Gen {
         const bool isint = SiteEmitter<CSiteT, CArgT>::is_int(st);
         const std::string Q = std::to_string(q);
         const std::string ra = isint ? "(uint32_t)vi" + Q + "A" : "f2u(vf" + Q + "A)", rb = isint ? "(uint32_t)vi" + Q + "B" : "f2u(vf" + Q + "B)";
+        o << "#ifndef GJX_EXP_NO_VALUE_STORES\n";
         o << "      *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "]) + po + iA) = make_uint2(" << ra << ", " << rb << ");\n";
+        o << "#endif\n";
       }
     }
     o << "      *reinterpret_cast<float2*>(logw + po + iA) = make_float2(wA, wB);\n";
@@ -433,8 +435,11 @@ inline bool compile_to_code(const std::string& src, std::string* code) {
   const char* hn[] = {"gjx_device.hpp"};
   const char* hs[] = {kDeviceHeader};
   if (hiprtcCreateProgram(&prog, src.c_str(), "gjx_plan.hip", 1, hs, hn) != HIPRTC_SUCCESS) return false;
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
-  const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+  // GJX_JIT_DEFINE=NAME[=VALUE]: one extra -D for the generated kernel (A/B knob for device-header variants)
+  std::string extra_def;
+  if (const char* d = std::getenv("GJX_JIT_DEFINE")) extra_def = std::string("-D") + d;
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", extra_def.c_str()};
+  const hiprtcResult r = hiprtcCompileProgram(prog, extra_def.empty() ? 4 : 5, opts);
   if (r != HIPRTC_SUCCESS) {
     if (std::getenv("GJX_PLAN_JIT_VERBOSE")) {
       size_t ls = 0;
