@@ -64,6 +64,16 @@ with open(os.path.join(here, f"{tag}_summary.md"), "w") as f:
     f.write("| kernel | calls | avg ns | % |\n|---|---|---|---|\n")
     for r in stats:
         f.write(f"| `{r['Name'][:80]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['Percentage']} |\n")
+    # the same kernels by launch size (the bench times SMC with 8 filters per launch and with one; an importance
+    # launch covers 8 passes): average duration per (kernel, grid) from the kernel trace of the same run
+    by = collections.defaultdict(list)
+    for r in csv.DictReader(open(one("trace/*/*kernel_trace.csv"))):
+        name = r["Kernel_Name"]
+        if any(k in name for k in ("k_resample", "k_tile_sums", "k_scan_tiles", "gjx_plan_kernel")):
+            by[(name[:80], int(r["Grid_Size_X"]), int(r["VGPR_Count"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    f.write("\n| kernel | grid (threads) | VGPRs | launches | avg ns |\n|---|---|---|---|---|\n")
+    for (name, grid, vg), ts in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+        f.write(f"| `{name}` | {grid} | {vg} | {len(ts)} | {sum(ts) / len(ts):.0f} |\n")
     rf = bench["roofline"]
     f.write(f"\nbench.py (un-profiled run): value {bench['value']:.4g} {bench['unit']}, {bench['ms_per_step']*1e3:.1f} us/step; "
             f"dominant kernel `{rf['kernel']}` {rf['kernel_ms']*1e3:.1f} us per launch of {rf.get('passes_per_launch', 1)} passes by HIP events "
