@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "genjax-chi_amd"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-ORACLE_LIB = os.path.join(ROOT, "oracle", "libgjx_oracle.so")
+ORACLE_LIB = os.environ.get("GJX_ORACLE_LIB") or os.path.join(ROOT, "oracle", "libgjx_oracle.so")  # (override: the sanitizer build)
 
 
 def pytest_configure(config):
