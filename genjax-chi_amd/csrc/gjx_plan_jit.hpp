@@ -18,6 +18,7 @@
 #include <string>
 #include <unordered_map>
 #include <utility>
+#include <vector>
 
 namespace gjx_jit {
 
@@ -52,6 +53,7 @@ struct SiteEmitter {
   std::string sfx = "";
   int cur_blk = -1;
   bool store_values = true;  // false: the caller stores (the paired kernel writes both particles at once)
+  bool ext_bits = false;     // true: the caller defines bits<q><sfx> of one-word draws (SMC quads share a block)
 
   static bool is_int(const CSiteT& s) { return s.dist >= GJX_DIST_BERNOULLI; }
   std::string nm(const char* base, int q) const { return std::string(base) + std::to_string(q) + sfx; }
@@ -65,7 +67,7 @@ struct SiteEmitter {
       case GJX_ARG_SITE: return "((" + flit(a.scale) + " * " + val_f32(a.ref_site) + ") + " + flit(a.offset) + ")";
       case GJX_ARG_INPUT:
         return "((" + flit(a.scale) + " * cols.in[" + std::to_string(a.ref) + "][li" + sfx + "]) + " + flit(a.offset) + ")";
-      case GJX_ARG_STATE: return "((" + flit(a.scale) + " * st_" + std::to_string(a.ref) + ") + " + flit(a.offset) + ")";
+      case GJX_ARG_STATE: return "((" + flit(a.scale) + " * st_" + std::to_string(a.ref) + sfx + ") + " + flit(a.offset) + ")";
       case GJX_ARG_OBS: return "((" + flit(a.scale) + " * a.obs[" + std::to_string(a.ref) + "]) + " + flit(a.offset) + ")";
       default: return plit(a.table) + "[" + val_i32(a.ref_site) + "]";
     }
@@ -74,6 +76,11 @@ struct SiteEmitter {
   bool needs_pk() const {
     for (int q = 0; q < n_sites; ++q)
       if (!sites[q].observed) return true;
+    return false;
+  }
+  bool needs_stream_key() const {
+    for (int q = 0; q < n_sites; ++q)
+      if (!sites[q].observed && !one_word(sites[q])) return true;
     return false;
   }
   // fold of site q: THREEFRY the 1-based site counter; PHILOX the 0-based index among the sampled sites
@@ -118,7 +125,7 @@ struct SiteEmitter {
       else o << ind << "const float vf" << Q << " = " << ov << ";\n";
       return;
     }
-    if (!one_word(st)) return;
+    if (!one_word(st) || ext_bits) return;
     if (impl == 1) {
       // word fold&3 of the packed draw block fold>>2 of the particle / slot key
       const int blk = (int)(fold >> 2);
@@ -373,6 +380,54 @@ struct GenSmc {
   const CArgT* next_state;
   int n_state;
 
+  // PHILOX: the four consecutive slots jq .. jq+3 of a lane (jq a multiple of 4) walked together.  One-word draw
+  // number f of the quad is ONE block, PH(ctr = (g_lo, g_hi, f, 'Q'), key = step key), g = jq / 4, slot u taking
+  // word u (for f = 0 and one Normal site this is the fixed LGSSM filter, bit for bit); Normal sites are two
+  // Box-Muller transforms over the quad's words; multi-word samplers keep their per-slot streams.
+  void emit_quad_body(const CSiteT* sites, int n_sites, const CArgT* state_args, bool step) {
+    const char* sf[4] = {"A", "B", "C", "D"};
+    std::vector<SiteEmitter<CSiteT, CArgT>> em;
+    for (int u = 0; u < 4; ++u) {
+      em.push_back(SiteEmitter<CSiteT, CArgT>{o, impl, 1, sites, n_sites, "    ", sf[u]});
+      em.back().ext_bits = true;
+    }
+    o << "    const uint64_t g = (uint64_t)jq >> 2;\n";
+    for (int u = 0; u < 4; ++u) {
+      if (step)
+        for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << sf[u] << " = xs[" << k << "][src[" << u << "]];\n";
+      if (em[u].needs_stream_key()) o << "    const Key pkey" << sf[u] << " = slot_key<1>(a.step_key, (uint64_t)jq + " << u << "u);\n";
+      o << "    float w" << sf[u] << " = 0.0f, sc" << sf[u] << " = 0.0f;\n";
+    }
+    for (int q = 0; q < n_sites; ++q) {
+      const CSiteT& st = sites[q];
+      const std::string Q = std::to_string(q);
+      for (int u = 0; u < 4; ++u) em[u].head(q);
+      const bool drawn = !st.observed && em[0].one_word(st);
+      if (drawn) {
+        o << "    uint32_t qw" << Q << "_0, qw" << Q << "_1, qw" << Q << "_2, qw" << Q << "_3;\n";
+        o << "    philox4x32(a.step_key.k0, a.step_key.k1, (uint32_t)g, (uint32_t)(g >> 32), " << em[0].fold_of(q)
+          << "u, kTagQuad, qw" << Q << "_0, qw" << Q << "_1, qw" << Q << "_2, qw" << Q << "_3);\n";
+        for (int u = 0; u < 4; ++u) o << "    const uint32_t bits" << Q << sf[u] << " = qw" << Q << "_" << u << ";\n";
+      }
+      const bool normal = drawn && st.dist == GJX_DIST_NORMAL;
+      if (normal) {
+        o << "    float z" << Q << "A, z" << Q << "B, z" << Q << "C, z" << Q << "D;\n";
+        o << "    bm_pair(bits" << Q << "A, bits" << Q << "B, z" << Q << "A, z" << Q << "B);\n";
+        o << "    bm_pair(bits" << Q << "C, bits" << Q << "D, z" << Q << "C, z" << Q << "D);\n";
+      }
+      for (int u = 0; u < 4; ++u) em[u].tail(q, normal ? "z" + Q + sf[u] : std::string());
+    }
+    for (int u = 0; u < 4; ++u) {
+      for (int k = 0; k < n_state; ++k) o << "    out[" << u << "].s[" << k << "] = " << em[u].arg(state_args[k]) << ";\n";
+      o << "    (void)sc" << sf[u] << ";\n    out[" << u << "].lw = w" << sf[u] << ";\n    wq[" << u << "] = w" << sf[u] << ";\n";
+    }
+  }
+  void emit_quad(const CSiteT* sites, int n_sites, const CArgT* state_args, bool step) {
+    o << "  __device__ __forceinline__ void compute_quad(int64_t jq, const int (&src)[4], Out (&out)[4], float (&wq)[4]) const {\n";
+    emit_quad_body(sites, n_sites, state_args, step);
+    o << "  }\n";
+  }
+
   std::string run() {
     const std::string I = std::to_string(impl), D = std::to_string(n_state);
     emit_prelude(o);
@@ -395,14 +450,33 @@ struct GenSmc {
     es.run();
     for (int k = 0; k < n_state; ++k) o << "    out.s[" << k << "] = " << es.arg(next_state[k]) << ";\n";
     o << "    (void)sc;\n    out.lw = w;\n    return w;\n  }\n";
+    if (impl == 1) emit_quad(step_sites, n_step, next_state, true);
     o << "  __device__ __forceinline__ void store(int64_t j, int64_t out_lo, uint64_t src, const Out& out) const {\n";
     o << "    for (int k = 0; k < " << D << "; ++k) a.state_out[k][j - out_lo] = out.s[k];\n";
     o << "    a.logw_out[j - out_lo] = out.lw;\n    if (a.anc_out) a.anc_out[j - out_lo] = (int32_t)src;\n  }\n};\n";
     o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_step_kernel(ResampleArgs A, PlanPolicyArgs PA, float* max_partials) {\n";
     o << "  GenPolicy P;\n  P.a = PA;\n  resample_body<" << I << ">(A, P, max_partials);\n}\n";
     // ---- init kernel: one workgroup per global tile, like k_lgssm_init
+    if (impl == 1) {
+      o << "struct GenInitOut { float s[" << D << "]; float lw; };\n";
+      o << "__device__ __forceinline__ void init_quad(const PlanPolicyArgs& a, int64_t jq, GenInitOut (&out)[4], float (&wq)[4]) {\n";
+      emit_quad_body(init_sites, n_init, init_state, false);
+      o << "}\n";
+    }
     o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_init_kernel(PlanPolicyArgs a, uint64_t first_slot, uint64_t n_local, float* max_partials) {\n";
     o << "  __shared__ float shf[4];\n  const uint64_t gbase = (uint64_t)blockIdx.x * kTile;\n  float tmax = -__builtin_inff();\n";
+    if (impl == 1) {  // four consecutive slots per lane, one cipher block per one-word draw of the quad
+      o << "  if (gbase >= first_slot && gbase < first_slot + n_local) {\n";
+      o << "    const int64_t jq = (int64_t)(gbase + 4 * (uint64_t)threadIdx.x);\n";
+      o << "    GenInitOut out[4];\n    float wq[4];\n";
+      o << "    init_quad(a, jq, out, wq);\n";
+      o << "    for (int u = 0; u < 4; ++u) {\n      const uint64_t j = (uint64_t)jq + u;\n      if (j < first_slot + n_local) {\n";
+      for (int k = 0; k < n_state; ++k) o << "        a.state_out[" << k << "][j - first_slot] = out[u].s[" << k << "];\n";
+      o << "        a.logw_out[j - first_slot] = wq[u];\n        if (a.anc_out) a.anc_out[j - first_slot] = (int32_t)j;\n";
+      o << "        tmax = wq[u] > tmax ? wq[u] : tmax;\n      }\n    }\n  }\n";
+      o << "  const float bm = block_max(tmax, shf);\n  if (threadIdx.x == 0) max_partials[blockIdx.x] = bm;\n}\n";
+      return o.str();
+    }
     o << "  if (gbase >= first_slot && gbase < first_slot + n_local) {\n    for (int r = 0; r < kPer; ++r) {\n";
     o << "      const uint64_t j = gbase + (uint64_t)r * 256 + threadIdx.x;\n      if (j < first_slot + n_local) {\n";
     if (ei.needs_pk()) o << "        const Key pkey = slot_key<" << I << ">(a.step_key, j);\n";

@@ -438,9 +438,12 @@ int gjx_smc_source_ranges(const gjx_smc_config* cfg, const uint64_t* tile_sums, 
  * The general form of the two fixed models above: x_0 comes from `init_sites`, every later step
  * walks `step_sites` for each output slot with GJX_ARG_STATE arguments reading the resampled
  * ancestor's state columns; observed sites contribute their log-density to the step's log-weight.
- * Slot key = split(step_key)[slot]; sites draw from it exactly as in gjx_importance_run (THREEFRY:
- * fold_in(., 1-based table position); PHILOX: fold = 0-based index among the sampled sites, four
- * single-word draws per block).  libgjx_hip.so lowers the step to a hiprtc-compiled policy
+ * Slot key = split(step_key)[slot].  THREEFRY: sites draw from it exactly as in gjx_importance_run
+ * (fold_in(., 1-based table position)).  PHILOX: single-word draw number f (0-based index among the
+ * sampled sites) of slots 4g .. 4g+3 is ONE block, PH(ctr = (g_lo, g_hi, f, 'Q'), key = step key), slot j
+ * taking word j & 3, and Normal sites pair Box-Muller inside the quad ((w0,w1) -> slots 4g, 4g+1; (w2,w3)
+ * -> 4g+2, 4g+3) — the fixed models above are the case of one sampled site; multi-word samplers (gamma,
+ * beta, Gumbel-max categorical) keep the slot key's streams.  libgjx_hip.so lowers the step to a hiprtc-compiled policy
  * inside the fused resample kernel.  State columns are f32 (integer-valued sites are converted). */
 #define GJX_SMC_MAX_STATE 4
 #define GJX_SMC_MAX_OBS 8

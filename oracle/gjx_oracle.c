@@ -352,6 +352,8 @@ typedef struct {
   int pair_normals;          /* importance: 1 */
   const float* const* in;    /* importance: input columns */
   uint64_t i;                /* importance: particle index into the input columns */
+  const uint32_t* quad_key;  /* smc under PHILOX: the step key — one-word draws come from the slot's quad block */
+  uint64_t slot;             /* smc: the output slot */
   const float* state;        /* smc: the ancestor's state columns (NULL at step 0) */
   const float* obs;          /* smc: this step's observation constants */
 } walk_ctx;
@@ -401,10 +403,12 @@ static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, sit
       const uint32_t f = c->impl == 0 ? (uint32_t)(q + 1) : draws;
       ++draws;
       o_stream strm = o_stream_make(c->impl, c->pkey, 1, f);
-      const uint32_t bits0 = o_bits32_at(&strm, 0);
+      /* one-word draws: SMC slots under PHILOX take word (slot & 3) of their quad's block number f */
+      const uint32_t bits0 = c->quad_key ? o_smc_quad_word(c->quad_key, c->slot, f) : o_bits32_at(&strm, 0);
       switch (st->dist) {
-        case GJX_DIST_NORMAL: { /* importance walks pair particles (PHILOX); SMC steps keep the single draw */
-          float eps = c->pair_normals ? o_site_normal(&strm) : o_std_normal(bits0);
+        case GJX_DIST_NORMAL: { /* PHILOX pairs draws: importance over particle pairs, SMC inside the slot's quad */
+          float eps = c->quad_key ? o_smc_quad_normal(c->quad_key, c->slot, f)
+                    : c->pair_normals ? o_site_normal(&strm) : o_std_normal(bits0);
           float t = a1 * eps; v.f = a0 + t; break; }
         case GJX_DIST_GAMMA: v.f = o_std_gamma(&strm, 0, a0) / a1; break;
         case GJX_DIST_BETA: { float g1 = o_std_gamma(&strm, 0, a0), g2 = o_std_gamma(&strm, 1, a1); v.f = g1 / (g1 + g2); break; }
@@ -1216,6 +1220,8 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
       memset(&c, 0, sizeof c);
       c.impl = cfg->impl;
       o_split_at(cfg->impl, skey, (uint64_t)j, c.pkey);
+      c.quad_key = cfg->impl == 1 ? skey : NULL;
+      c.slot = (uint64_t)j;
       float prev[GJX_SMC_MAX_STATE];
       if (t > 0)
         for (int k = 0; k < D; ++k) prev[k] = st[prv][(size_t)k * N + (uint64_t)anc[j]];
