@@ -1084,6 +1084,10 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
                                      : teeth_below(run, scale, u0, (int64_t)A.n_out);
     nb[kPer * tid + r] = (int32_t)t;
   }
+  // run-start marks of the ancestor search below; cleared here so that the barrier that publishes nb covers it
+  __shared__ int32_t anc_s[kTile];
+#pragma unroll
+  for (int r = 0; r < kPer; ++r) anc_s[tid + r * kBlock] = 0;
   P.stage_source(tid);
   __syncthreads();
   const int64_t n_hi = nb[kTile - 1];
@@ -1091,34 +1095,29 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   const int64_t j1 = n_hi < A.out_hi ? n_hi : A.out_hi;
 
   // Ancestors of the tile's output slots, 1024 at a time, WITHOUT a search per slot: ancestors are
-  // monotone, so every source that owns at least one slot marks the slot where its run starts and an
-  // inclusive max-scan over the chunk spreads each mark over the run (slots before the first mark
-  // belong to the source whose run straddles the chunk start).  ~4 LDS accesses per slot instead of a
-  // 10-step dependent binary search.  Chunks start at a multiple of 4 slots and each lane serves FOUR
+  // monotone, so every source that owns at least one slot marks the slot where its run starts (the chunk start
+  // for a run that began earlier) and an inclusive max-scan over the chunk spreads each mark over the run.
+  // ~4 LDS accesses per slot instead of a 10-step dependent binary search; 3 barriers per chunk.  Chunks start at a multiple of 4 slots and each lane serves FOUR
   // CONSECUTIVE slots: one 16-byte LDS read of their ancestors, four independent propagate chains in flight
   // (ILP), one shared cipher block for their draws (smc_quad_bits), 16-byte stores.  Waves whose 256 slots lie
   // outside the tile's range skip the chunk.
-  __shared__ __attribute__((aligned(16))) int32_t anc_s[kTile];
   __shared__ int shi[kBlock / kWave];
   int32_t nbr[kPer];  // this thread's consecutive sources
 #pragma unroll
   for (int r = 0; r < kPer; ++r) nbr[r] = nb[kPer * tid + r];
   const int32_t nb_prev = tid == 0 ? (int32_t)n_lo : nb[kPer * tid - 1];
   float tmax = -__builtin_inff();
-  for (int64_t jb = j0 & ~(int64_t)3; jb < j1; jb += (int64_t)kTile) {
-    // the source whose run contains slot jb: the first s with nb[s] > jb
-    int below = 0;
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) below += (int64_t)nbr[r] <= jb ? 1 : 0;
-    const int s_first = block_sum_int(below, shi);  // (its barriers also fence the previous chunk's reads)
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) anc_s[tid + r * kBlock] = 0;
-    __syncthreads();
+  const int64_t jb0 = j0 & ~(int64_t)3;
+  for (int64_t jb = jb0; jb < j1; jb += (int64_t)kTile) {
+    if (jb != jb0) __syncthreads();  // the marks were cleared after the previous chunk's scan
+    // every source that owns a slot of the chunk marks the first one it owns there — its run start, or the chunk
+    // start for the one source whose run straddles it — so each slot from max(jb, n_lo) on has a mark at or
+    // before it and no separate search for the straddling source is needed
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
       const int64_t start = r == 0 ? nb_prev : nbr[r - 1];  // source 4*tid+r owns slots [start, nbr[r])
-      if ((int64_t)nbr[r] > start && start >= jb && start < jb + (int64_t)kTile)
-        anc_s[start - jb] = kPer * tid + r + 1;
+      if ((int64_t)nbr[r] > start && (int64_t)nbr[r] > jb && start < jb + (int64_t)kTile)
+        anc_s[(start > jb ? start : jb) - jb] = kPer * tid + r + 1;
     }
     __syncthreads();
     int v[kPer];
@@ -1129,14 +1128,18 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
       run_max = x > run_max ? x : run_max;
       v[r] = run_max;
     }
-    const int carry = block_scan_max_excl(run_max, shi);
-    // every entry of the chunk ends up a valid local source index (slots outside [j0, j1) included: they are
-    // computed along with their quad and never stored), so no lane needs clamping
+    const int carry = block_scan_max_excl(run_max, shi);  // (its barriers close this chunk's reads of the marks)
+    if (jb + (int64_t)kTile < j1) {  // another chunk follows (rare): clear the marks for it
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) anc_s[tid + r * kBlock] = 0;
+    }
+    // every entry of the chunk is a valid local source index (slots outside [j0, j1) included — those before the
+    // tile's first slot have no mark and take source 0: they are computed along with their quad, never stored)
     int src[kPer];
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
       const int a = v[r] > carry ? v[r] : carry;
-      src[r] = a ? a - 1 : (s_first < kTile ? s_first : kTile - 1);
+      src[r] = a ? a - 1 : 0;
     }
     // the lane's own four slots are the four entries it just resolved: no LDS round trip
     const int64_t jq = jb + (int64_t)kPer * tid;
