@@ -1097,43 +1097,66 @@ __global__ __launch_bounds__(kBlock) void k_hmm_init(FilterBatch fb, Key step_ke
   if (threadIdx.x == 0) max_partials[blockIdx.x] = bm;
 }
 
-// HMM tables: one thread per row, sequential (exactly the spec's order).  Alias construction in integers
-// (DESIGN.md 3.6b states it in full): p_c = cat_fix, scaled_c = p_c K against Q = sum p; "small" columns
-// (scaled < Q) in increasing order take their alias from the front "large" column, which gives up the
-// difference and joins the back of the small queue once below Q.
-__global__ void k_hmm_prepare(const float* trans_logits, const float* obs_logits, int32_t K,
-                              uint32_t* trans_alias, float* obs_logp) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= K) return;
+// HMM tables.  Alias construction in integers (DESIGN.md 3.6b states it in full): p_c = cat_fix, scaled_c = p_c K
+// against Q = sum p; "small" columns (scaled < Q) in increasing order take their alias from the front "large"
+// column, which gives up the difference and joins the back of the small queue once below Q.
+// One 128-thread workgroup per row.  Parallel parts across the lanes: the fixed-point weights p_c, their sum Q
+// (integers: any order), the thresholds (one 64-bit division per column) and the log-softmax subtraction.
+// Sequential parts exactly in the spec's order: lane 0 of wave 0 runs the small / large pairing over LDS-resident
+// queues; lane 0 of wave 1 meanwhile accumulates the observation row's log-sum-exp column by column.
+__global__ __launch_bounds__(128) void k_hmm_prepare(const float* trans_logits, const float* obs_logits, int32_t K,
+                                                     uint32_t* trans_alias, float* obs_logp) {
+  __shared__ uint64_t scaled[256];  // p_c K, then (paired small columns) their accept mass
+  __shared__ uint16_t small[256], large[256], alias[256];
+  __shared__ float sh_m[2];
+  __shared__ uint64_t sh_q[2];
+  __shared__ float sh_lse;
+  const int r = blockIdx.x, tid = threadIdx.x;
   const float* l = trans_logits + (size_t)r * K;
-  uint32_t* row = trans_alias + (size_t)r * K;
-  uint64_t scaled[256];  // private (scratch) arrays: K <= 256 threads run this once per model
-  uint16_t small[256], large[256];
-  const float m = row_max(l, (uint32_t)K);
-  uint64_t Q = 0;
-  for (int c = 0; c < K; ++c) {
-    scaled[c] = (uint64_t)cat_fix(l[c], m);
-    Q += scaled[c];
+  float m = -__builtin_inff();
+  for (int c = tid; c < K; c += 128) m = l[c] > m ? l[c] : m;
+  m = wave_max(m);
+  if ((tid & 63) == 0) sh_m[tid >> 6] = m;
+  __syncthreads();
+  m = sh_m[0] > sh_m[1] ? sh_m[0] : sh_m[1];
+  uint64_t q = 0;
+  for (int c = tid; c < K; c += 128) {
+    const uint64_t p = (uint64_t)cat_fix(l[c], m);
+    scaled[c] = p * (uint64_t)K;
+    alias[c] = (uint16_t)c;
+    q += p;
   }
-  uint32_t hs = 0, ts = 0, hl = 0, tl = 0;
-  for (int c = 0; c < K; ++c) {
-    scaled[c] *= (uint64_t)K;
-    if (scaled[c] < Q) small[ts++] = (uint16_t)c;
-    else large[tl++] = (uint16_t)c;
-    row[c] = (0xffffffu << 8) | (uint32_t)c;  // accept always
-  }
-  while (hs < ts && hl < tl) {
-    const uint32_t sc = small[hs++], g = large[hl];
-    row[sc] = ((uint32_t)((scaled[sc] << 24) / Q) << 8) | g;
-    scaled[g] -= Q - scaled[sc];
-    if (scaled[g] < Q) {
-      ++hl;
-      small[ts++] = (uint16_t)g;
+  q = wave_sum(q);
+  if ((tid & 63) == 0) sh_q[tid >> 6] = q;
+  __syncthreads();
+  const uint64_t Q = sh_q[0] + sh_q[1];
+  if (tid == 0) {
+    uint32_t hs = 0, ts = 0, hl = 0, tl = 0;
+    for (int c = 0; c < K; ++c) {
+      if (scaled[c] < Q) small[ts++] = (uint16_t)c;
+      else large[tl++] = (uint16_t)c;
     }
+    while (hs < ts && hl < tl) {
+      const uint32_t sc = small[hs++], g = large[hl];
+      alias[sc] = (uint16_t)g;  // scaled[sc] stays: it is the column's accept mass
+      scaled[g] -= Q - scaled[sc];
+      if (scaled[g] < Q) {
+        ++hl;
+        small[ts++] = (uint16_t)g;
+      }
+    }
+  } else if (tid == 64) {
+    const float* o = obs_logits + (size_t)r * K;
+    sh_lse = row_lse(o, (uint32_t)K);
   }
-  const float* o = obs_logits + (size_t)r * K;
-  const float lse = row_lse(o, (uint32_t)K);
-  for (int c = 0; c < K; ++c) obs_logp[(size_t)r * K + c] = o[c] - lse;
+  __syncthreads();
+  uint32_t* row = trans_alias + (size_t)r * K;
+  for (int c = tid; c < K; c += 128) {
+    // a column that kept itself as alias accepts always (its mass ended at exactly Q, or it was never paired)
+    const uint32_t thr = alias[c] == c ? 0xffffffu : (uint32_t)((scaled[c] << 24) / Q);
+    row[c] = (thr << 8) | alias[c];
+    obs_logp[(size_t)r * K + c] = obs_logits[(size_t)r * K + c] - sh_lse;
+  }
 }
 
 // workspace carving
@@ -1843,8 +1866,7 @@ int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gj
   if (!mdl || !trans_cdf || !obs_logp || mdl->n_states <= 0 || mdl->n_states > 256 ||
       !mdl->trans_logits || !mdl->obs_logits)
     return GJX_ERR_INVALID;
-  k_hmm_prepare<<<(mdl->n_states + 63) / 64, 64, 0, S(s)>>>(mdl->trans_logits, mdl->obs_logits,
-                                                             mdl->n_states, trans_cdf, obs_logp);
+  k_hmm_prepare<<<mdl->n_states, 128, 0, S(s)>>>(mdl->trans_logits, mdl->obs_logits, mdl->n_states, trans_cdf, obs_logp);
   return launch_status();
 }
 
