@@ -252,7 +252,8 @@ class ShardedSMC:
 
     def __init__(self, ops: Ops, kind: str, impl: int, seed: int, n_total: int, T: int, rank: int, world: int,
                  record_ancestors: bool = False, exchange: str = "ranges", comm=None, poison: bool = False,
-                 n_states=None):
+                 n_states=None, lgssm=None, y=None):
+        """`lgssm` (abi.Lgssm) / `y`: another linear-Gaussian model and observation sequence than the benchmark's."""
         tile = ops.tile
         if n_total % (world * tile) != 0:
             raise ValueError(f"n_total must be a multiple of world*{tile}")
@@ -267,9 +268,9 @@ class ShardedSMC:
         self.cfg = ops.smc_config(impl, n_total, self.first, self.n_local, sk, rk)
         dev = ops.device()
         if kind == "lgssm":
-            self.y = W.lgssm_data(T)
-            self.model = W.lgssm_model()
-            self.log_z_exact = W.lgssm_exact_log_z(self.y)
+            self.y = W.lgssm_data(T) if y is None else y
+            self.model = W.lgssm_model() if lgssm is None else lgssm
+            self.log_z_exact = W.lgssm_exact_log_z(self.y) if lgssm is None else float("nan")
             sdt = torch.float32
         else:
             trans, obs = W.hmm_tables(n_states)

@@ -99,7 +99,7 @@ def test_two_ranks_equal_one_rank(tmp_path, oracle_ops, impl):
         assert torch.equal(p["hmm_q"], ref_hmm["out_q"]) and p["hmm_log_z"] == ref_hmm["log_z"]
 
 
-def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_states=16):
+def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_states=16, **model_kw):
     """`world` virtual ranks as threads sharing one backend (dist.ThreadComm): the sharded protocol without
     process groups.  Returns the per-rank results."""
     import threading
@@ -110,7 +110,7 @@ def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_s
 
     def work(r):
         try:
-            kw = dict(n_states=n_states) if kind == "hmm" else {}
+            kw = dict(n_states=n_states) if kind == "hmm" else dict(model_kw)
             res[r] = gdist.ShardedSMC(ops, kind, impl, seed, n_total, T, r, world, True, exchange=exchange,
                                       comm=gdist.ThreadComm(sh, r), poison=True, **kw).run()
         except BaseException as e:  # noqa: BLE001 - re-raised below; release the others
@@ -212,3 +212,29 @@ def check_source_ranges(ops):
 
 def test_source_ranges_oracle(oracle_ops):
     check_source_ranges(oracle_ops)
+
+
+def check_degenerate_sharded(ops, impl, world):
+    """Collapsing weights (a few particles of one rank carry all the mass): every rank's source range lies in
+    one remote block, most tiles are empty — sharded == single-rank bit for bit."""
+    import numpy as np
+
+    from genjax._amd import abi, prng, workloads as W
+
+    T, n_total = 8, 1024 * world * 4
+    y = np.array([0.1, 25.0, -40.0, -39.5, 60.0, 60.2, 0.0, 3.0], dtype=np.float32)
+    mdl = abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.05)
+    res = _run_virtual_ranks(ops, "lgssm", impl, world, n_total, T, "ranges", seed=11, lgssm=mdl, y=y)
+    sk, rk = W.smc_key_schedule(prng.key(11, impl), T)
+    ref = ops.smc_run_lgssm(impl, n_total, sk, rk, mdl, y, True)
+    assert torch.equal(torch.cat([r["state"] for r in res]).cpu(), ref[2].cpu())
+    assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1).cpu(), ref[4].cpu())
+    for r in res:
+        assert torch.equal(r["out_q"].cpu(), ref[1].cpu()) and torch.equal(r["out_max"].cpu(), ref[0].cpu())
+    assert int(ref[4][3].unique().numel()) == 1  # total collapse at that step
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_filter_with_collapsing_weights(oracle_ops, world):
+    check_degenerate_sharded(oracle_ops, 1, world)
+    check_degenerate_sharded(oracle_ops, 0, world)

@@ -381,6 +381,27 @@ def test_smc_lgssm(hip_ops, oracle_ops, impl, n, T):
     same(h2["out_q"], o["out_q"]); same(h2["state"], o["state"])
 
 
+def degenerate_lgssm_run(ops, impl, n, T=8):
+    """A filter whose weights collapse: a sharp observation model and observations that jump by tens of
+    standard deviations, so that at some steps a handful of particles (in a few tiles) carry all the mass
+    and most tiles have mass 0 — the resampler's empty-tile and many-copies-of-one-source paths."""
+    from genjax._amd import abi, prng
+
+    y = np.array([0.1, 25.0, -40.0, -39.5, 60.0, 60.2, 0.0, 3.0][:T], dtype=np.float32)
+    sk, rk = W.smc_key_schedule(prng.key(11, impl), T)
+    return ops.smc_run_lgssm(impl, n, sk, rk, abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.05), y, True)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n", [4096, 50000])
+def test_smc_degenerate_weights(hip_ops, oracle_ops, impl, n):
+    h, o = degenerate_lgssm_run(hip_ops, impl, n), degenerate_lgssm_run(oracle_ops, impl, n)
+    for a, b, what in zip(h, o, ("step max", "step q", "state", "logw", "ancestors")):
+        same(a, b, what)
+    anc = o[4]
+    assert int(anc[2].unique().numel()) < n // 100  # the collapse really happens: few distinct ancestors
+
+
 @pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("n,T,k", [(2048, 6, 16), (30000, 25, 256)])
 def test_smc_hmm(hip_ops, oracle_ops, impl, n, T, k):

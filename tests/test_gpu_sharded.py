@@ -41,3 +41,10 @@ def test_source_ranges(hip_ops):
     from test_distributed_gloo import check_source_ranges
 
     check_source_ranges(hip_ops)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_virtual_ranks_with_collapsing_weights(hip_ops, world):
+    from test_distributed_gloo import check_degenerate_sharded
+
+    check_degenerate_sharded(hip_ops, 1, world)
