@@ -886,7 +886,7 @@ struct HmmPolicy {
   float* logw_out;
   int32_t* anc_out;
   Key step_key;
-  const uint32_t* trans_cdf;  // alias table [K,K]
+  const uint32_t* trans_cdf;  // alias table [K,K] (gjx.h: trans_alias)
   const float* obs_logp;      // [K,K]
   int32_t K, y;
   int32_t* zs;
@@ -1004,7 +1004,8 @@ __global__ __launch_bounds__(kBlock) void k_source_ranges(const uint64_t* tile_s
   }
   __syncthreads();
   if (tid < 2 * world) {
-    out[tid] = (int64_t)cnt[tid];
+    // no mass at all (every weight underflowed): the comb degenerates to "the last particle owns every slot"
+    out[tid] = tot == 0 ? (int64_t)ntiles - 1 + (tid & 1) : (int64_t)cnt[tid];
     __threadfence_system();
   }
   __syncthreads();

@@ -147,6 +147,8 @@ def needed_tile_ranges(tile_sums, n_total: int, tile: int, world: int):
     nt = q.size
     prefix = np.zeros(nt + 1, dtype=np.uint64)
     np.cumsum(q, out=prefix[1:])
+    if prefix[-1] == 0:  # no mass at all: the last particle closes the comb and owns every slot
+        return np.tile(np.array([[nt - 1, nt]], dtype=np.int64), (world, 1))
     scale = np.float64(n_total) / np.float64(prefix[-1])
     teeth = np.minimum(np.ceil(prefix.astype(np.float64) * scale), np.float64(n_total))  # u0 = 0: the upper bound
     lo_b = np.maximum(teeth[:-1] - 1.0, 0.0)  # u0 -> 1
@@ -280,7 +282,7 @@ class ShardedSMC:
             self.log_z_exact = W.hmm_exact_log_z(self.y, n_states)
             self.model = ops.hmm_model(self.k, self.init, torch.from_numpy(trans).to(dev).contiguous(),
                                        torch.from_numpy(obs).to(dev).contiguous())
-            self.trans_cdf, self.obs_logp = ops.hmm_prepare_model(self.model)
+            self.trans_alias, self.obs_logp = ops.hmm_prepare_model(self.model)
             sdt = torch.int32
         nt = ops.num_tiles(n_total)
         # global-size buffers: a rank's own block is always current, remote ranges are filled on demand
@@ -306,7 +308,7 @@ class ShardedSMC:
         if self.kind == "lgssm":
             self.ops.smc_lgssm_step_a(self.cfg, self.model, t, float(self.y[t]), *prev, *outs)
         else:
-            self.ops.smc_hmm_step_a(self.cfg, self.model, t, int(self.y[t]), *prev, self.trans_cdf, self.obs_logp, *outs)
+            self.ops.smc_hmm_step_a(self.cfg, self.model, t, int(self.y[t]), *prev, self.trans_alias, self.obs_logp, *outs)
 
     def _shuffle(self, cur: int):
         """Make the source ranges of the next resampling present on every rank."""

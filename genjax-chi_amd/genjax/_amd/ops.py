@@ -491,10 +491,10 @@ class Ops:
                       self.stream())
 
     def smc_hmm_step_a(self, cfg, model: abi.Hmm, t: int, y_t: int, prev_state, prev_logw, prev_max, prev_tile_sums,
-                       prev_q_out, trans_cdf, obs_logp, state_out, logw_out, max_partials_out, ancestors_out=None):
+                       prev_q_out, trans_alias, obs_logp, state_out, logw_out, max_partials_out, ancestors_out=None):
         self.lib.call("gjx_smc_hmm_step_a", C.byref(cfg), C.byref(model), t, int(y_t), self._p(prev_state),
                       self._p(prev_logw), self._p(prev_max), self._p(prev_tile_sums), self._p(prev_q_out),
-                      self._p(trans_cdf), self._p(obs_logp), self._p(state_out), self._p(logw_out),
+                      self._p(trans_alias), self._p(obs_logp), self._p(state_out), self._p(logw_out),
                       self._p(max_partials_out), self._p(ancestors_out), self.stream())
 
     def smc_step_b(self, cfg, logw_local, max_partials, max_out, tile_sums):

@@ -860,8 +860,9 @@ int gjx_smc_source_ranges(const gjx_smc_config* cfg, const uint64_t* tile_sums, 
       first += upper <= lo;
       end += lower < hi;
     }
-    out_ranges[2 * j] = first;
-    out_ranges[2 * j + 1] = end;
+    /* no mass at all: the last particle closes the comb and owns every slot */
+    out_ranges[2 * j] = Q == 0 ? (int64_t)nt - 1 : first;
+    out_ranges[2 * j + 1] = Q == 0 ? (int64_t)nt : end;
   }
   out_ranges[2 * world] = ticket;
   return GJX_OK;

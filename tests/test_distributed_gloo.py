@@ -201,7 +201,9 @@ def check_source_ranges(ops):
             q = rng.integers(0, 1 << 40, size=nt).astype(np.int64)
             if trial % 4 == 0:
                 q[rng.integers(0, nt, size=nt // 2)] = 0
-            if q.sum() == 0:
+            if trial == 11:
+                q[:] = 0  # no mass at all: every block draws from the last tile
+            elif q.sum() == 0:
                 q[0] = 1
             out = torch.zeros(2 * world + 1, dtype=torch.int64, device=ops.device())
             ops.smc_source_ranges(cfg, torch.from_numpy(q).to(ops.device()), world, out, ticket=trial + 1)
