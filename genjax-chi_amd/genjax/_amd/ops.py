@@ -277,7 +277,10 @@ class Ops:
     @staticmethod
     def log_z_from_rows(e: torch.Tensor, q: torch.Tensor, n_total: int) -> float:
         """float64 log Z = e ln2 + log(q) - 30 ln2 - log N from the exact (e, q) pair."""
-        return int(e.cpu()) * math.log(2.0) + math.log(int(q.cpu())) - 30 * math.log(2.0) - math.log(n_total)
+        qi = int(q.cpu())
+        if qi <= 0:
+            return float("-inf")  # no mass: every weight underflowed (or was -inf)
+        return int(e.cpu()) * math.log(2.0) + math.log(qi) - 30 * math.log(2.0) - math.log(n_total)
 
     def prepare_importance(self, plan: "Plan", kb, n: int, input_cols: list[torch.Tensor],
                            value_dtypes: list, with_lse: bool = True, fold_batch: int = 1) -> "PreparedImportance":
