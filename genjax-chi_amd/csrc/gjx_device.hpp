@@ -133,6 +133,31 @@ GJX_HD Key fold_in(Key k, uint32_t d) {
   return out;
 }
 
+// PHILOX single-word draw number f of a key (f = 0-based index of the site among the body's sampled sites).
+//  * lane-0 key (a lone key): four draws per block of its own, word f & 3 of PH(ctr = (0, 0, f >> 2, 'D'), key);
+//  * laned key (lane L >= 1 = particle i = L - 1 among its parent's children): the PAIR (i, i ^ 1) shares its
+//    blocks — PH(ctr = (p_lo, p_hi, f >> 1, 'P'), key), p = i >> 1, holds draws 2 (f >> 1) and 2 (f >> 1) + 1 of
+//    both particles, particle i taking word ((f & 1) << 1) | (i & 1).  A kernel that owns both particles of a
+//    pair computes S / 2 blocks per particle for S draws, and a Normal site's Box-Muller pair (even particle:
+//    radius word, odd: angle word) sits in one block.
+constexpr uint32_t kTagPair = 0x50u;  // 'P'
+GJX_HD void philox_pair_block(Key k, uint32_t blk, uint32_t (&o)[4]) {  // lane >= 1
+  const uint64_t p = ((((uint64_t)k.l1 << 32) | k.l0) - 1u) >> 1;
+  philox4x32(k.k0, k.k1, (uint32_t)p, (uint32_t)(p >> 32), blk, kTagPair, o[0], o[1], o[2], o[3]);
+}
+GJX_HD uint32_t philox_single_draw(Key k, uint32_t f) {
+  uint32_t o[4];
+  uint32_t sel;
+  if ((k.l0 | k.l1) == 0u) {
+    philox4x32(k.k0, k.k1, 0u, 0u, f >> 2, kTagDraw, o[0], o[1], o[2], o[3]);
+    sel = f & 3u;
+  } else {
+    philox_pair_block(k, f >> 1, o);
+    sel = ((f & 1u) << 1) | ((k.l0 - 1u) & 1u);
+  }
+  return sel == 0 ? o[0] : (sel == 1 ? o[1] : (sel == 2 ? o[2] : o[3]));
+}
+
 // A draw stream: key plus optional leaf-site fold.  THREEFRY folds the counter into the key (one
 // block, jax semantics: fold = site counter from 1).  PHILOX carries it in the 128-bit counter (no
 // extra block; fold = 0-based index of the site among the body's randomness-consuming sites).
@@ -160,16 +185,11 @@ struct Stream {
       philox4x32(k.k0, k.k1, k.l0, k.l1, sub, ((hf ? f + 1u : 0u) << 8) | kTagStream, w0, w1, o2, o3);
     }
   }
-  // 32 bits of sub-stream `sub`.  PHILOX packs the single-word draws (sub 0) of four consecutive
-  // folds into one block: word (f & 3) of PH(ctr = (lane, f >> 2, 'D'), key).
+  // 32 bits of sub-stream `sub`.  PHILOX packs the single-word draws (sub 0) of a folded stream several to a
+  // block (philox_single_draw).
   GJX_HD uint32_t bits32(uint32_t sub) const {
     uint32_t w0, w1;
-    if (IMPL == 1 && hf && sub == 0u) {
-      uint32_t o[4];
-      philox4x32(k.k0, k.k1, k.l0, k.l1, f >> 2, kTagDraw, o[0], o[1], o[2], o[3]);
-      const uint32_t sel = f & 3u;
-      return sel == 0 ? o[0] : (sel == 1 ? o[1] : (sel == 2 ? o[2] : o[3]));
-    }
+    if (IMPL == 1 && hf && sub == 0u) return philox_single_draw(k, f);
     words(sub, w0, w1);
     return IMPL == 0 ? (w0 ^ w1) : w0;
   }
@@ -454,30 +474,24 @@ GJX_HD void bm_pair(uint32_t w_radius, uint32_t w_angle, float& z_cos, float& z_
   z_cos = r * cs;
   z_sin = r * sn;
 }
-// Draw word number f (packed single-word draws) of key k — Stream::bits32(0) of a folded stream.
 constexpr uint32_t kTagTwin = 0x54u;  // 'T': the angle word of a lane-0 key (it has no partner particle)
-GJX_HD uint32_t philox_draw_word(Key k, uint32_t f, uint32_t tag) {
-  uint32_t o[4];
-  philox4x32(k.k0, k.k1, k.l0, k.l1, f >> 2, tag, o[0], o[1], o[2], o[3]);
-  const uint32_t sel = f & 3u;
-  return sel == 0 ? o[0] : (sel == 1 ? o[1] : (sel == 2 ? o[2] : o[3]));
-}
 // The standard normal of a Normal SITE (generic, one particle: both words of its pair are derived here;
 // kernels that own the whole pair use bm_pair directly).
 template <int IMPL>
 GJX_HD float site_normal(const Stream<IMPL>& st) {
   if (IMPL == 0 || !st.hf) return std_normal(st.bits32(0));
   float zc, zs;
-  if ((st.k.l0 | st.k.l1) == 0u) {  // lane-0 key: radius and angle words from the key itself
-    bm_pair(philox_draw_word(st.k, st.f, kTagDraw), philox_draw_word(st.k, st.f, kTagTwin), zc, zs);
+  uint32_t o[4];
+  if ((st.k.l0 | st.k.l1) == 0u) {  // lane-0 key: radius word from its draw block, angle word from the twin block
+    philox4x32(st.k.k0, st.k.k1, 0u, 0u, st.f >> 2, kTagTwin, o[0], o[1], o[2], o[3]);
+    const uint32_t sel = st.f & 3u;
+    bm_pair(philox_single_draw(st.k, st.f), sel == 0 ? o[0] : (sel == 1 ? o[1] : (sel == 2 ? o[2] : o[3])), zc, zs);
     return zc;
   }
-  const uint64_t j = (((uint64_t)st.k.l1 << 32) | st.k.l0) - 1u;
-  const uint64_t la = (j & ~(uint64_t)1) + 1u, lb = la + 1u;
-  const Key ka{st.k.k0, st.k.k1, (uint32_t)la, (uint32_t)(la >> 32)};
-  const Key kb{st.k.k0, st.k.k1, (uint32_t)lb, (uint32_t)(lb >> 32)};
-  bm_pair(philox_draw_word(ka, st.f, kTagDraw), philox_draw_word(kb, st.f, kTagDraw), zc, zs);
-  return (j & 1u) ? zs : zc;
+  philox_pair_block(st.k, st.f >> 1, o);  // both words of the pair are in its block
+  if (st.f & 1u) bm_pair(o[2], o[3], zc, zs);
+  else bm_pair(o[0], o[1], zc, zs);
+  return ((st.k.l0 - 1u) & 1u) ? zs : zc;
 }
 
 // Standard normals of SMC slots 4g .. 4g+3 (the LGSSM filter).  THREEFRY: erfinv of each slot's draw.  PHILOX: two

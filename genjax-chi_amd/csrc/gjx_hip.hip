@@ -281,8 +281,6 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
     uint64_t idx[kPPT];
     Key pkey[kPPT];
     float w[kPPT], sc[kPPT];
-    uint32_t pw[kPPT][4];  // PHILOX: cached packed block (4 single-word draws) per particle
-    int pw_blk = -1;
     uint32_t draws = 0;  // PHILOX: sampled sites so far (their fold)
 #pragma unroll
     for (int r = 0; r < kPPT; ++r) {
@@ -358,22 +356,8 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
         const bool one_word = (dist == GJX_DIST_NORMAL && IMPL == 0) || dist == GJX_DIST_BERNOULLI ||
                               (dist == GJX_DIST_CATEGORICAL && st.cat_mode == 1);
         if (one_word) {
-          if (IMPL == 1) {
-            if (pw_blk != (int)(fold >> 2)) {
-              pw_blk = (int)(fold >> 2);
 #pragma unroll
-              for (int r = 0; r < kPPT; ++r)
-                philox4x32(pkey[r].k0, pkey[r].k1, pkey[r].l0, pkey[r].l1, fold >> 2, kTagDraw, pw[r][0],
-                           pw[r][1], pw[r][2], pw[r][3]);
-            }
-            const uint32_t sel = fold & 3u;
-#pragma unroll
-            for (int r = 0; r < kPPT; ++r)
-              bits[r] = sel == 0 ? pw[r][0] : (sel == 1 ? pw[r][1] : (sel == 2 ? pw[r][2] : pw[r][3]));
-          } else {
-#pragma unroll
-            for (int r = 0; r < kPPT; ++r) bits[r] = Stream<IMPL>(pkey[r], true, fold).bits32(0);
-          }
+          for (int r = 0; r < kPPT; ++r) bits[r] = Stream<IMPL>(pkey[r], true, fold).bits32(0);
         }
 #pragma unroll
         for (int r = 0; r < kPPT; ++r) {

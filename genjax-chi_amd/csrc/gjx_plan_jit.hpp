@@ -126,18 +126,8 @@ struct SiteEmitter {
       return;
     }
     if (!one_word(st) || ext_bits) return;
-    if (impl == 1) {
-      // word fold&3 of the packed draw block fold>>2 of the particle / slot key
-      const int blk = (int)(fold >> 2);
-      const uint32_t word = fold & 3u;
-      const std::string B = std::to_string(blk) + sfx;
-      if (blk != cur_blk) {
-        cur_blk = blk;
-        o << ind << "uint32_t pw" << B << "_0, pw" << B << "_1, pw" << B << "_2, pw" << B << "_3;\n";
-        o << ind << "philox4x32(pkey" << sfx << ".k0, pkey" << sfx << ".k1, pkey" << sfx << ".l0, pkey" << sfx << ".l1, " << blk
-          << "u, kTagDraw, pw" << B << "_0, pw" << B << "_1, pw" << B << "_2, pw" << B << "_3);\n";
-      }
-      o << ind << "const uint32_t bits" << Q << " = pw" << B << "_" << word << ";\n";
+    if (impl == 1) {  // (the generic form: kernels that own whole pairs / quads define bits themselves, ext_bits)
+      o << ind << "const uint32_t bits" << Q << " = philox_single_draw(pkey" << sfx << ", " << fold << "u);\n";
     } else {
       o << ind << "const uint32_t bits" << Q << " = Stream<0>(pkey" << sfx << ", true, " << fold << "u).bits32(0);\n";
     }
@@ -282,10 +272,27 @@ struct Gen {
     SiteEmitter<CSiteT, CArgT> ea{o, impl, 0, sites, n_sites, "      ", "A"};
     SiteEmitter<CSiteT, CArgT> eb{o, impl, 0, sites, n_sites, "      ", "B"};
     ea.store_values = eb.store_values = false;
+    ea.ext_bits = eb.ext_bits = true;  // the lane owns the pair: its single-word draws come from the pair's blocks
+    o << "      const uint64_t pairA = (lnA - 1u) >> 1;\n";
+    int cur_pair_blk = -1;
     for (int q = 0; q < n_sites; ++q) {
       const CSiteT& st = sites[q];
       ea.head(q);
       eb.head(q);
+      if (!st.observed && ea.one_word(st)) {
+        // draw f of the pair: block f >> 1 holds words (A, B) of draw 2 (f >> 1) and of draw 2 (f >> 1) + 1
+        const uint32_t f = ea.fold_of(q);
+        const int blk = (int)(f >> 1);
+        const std::string B = std::to_string(blk), Q = std::to_string(q);
+        if (blk != cur_pair_blk) {
+          cur_pair_blk = blk;
+          o << "      uint32_t pp" << B << "_0, pp" << B << "_1, pp" << B << "_2, pp" << B << "_3;\n";
+          o << "      philox4x32(pk0, pk1, (uint32_t)pairA, (uint32_t)(pairA >> 32), " << blk << "u, kTagPair, pp" << B << "_0, pp" << B
+            << "_1, pp" << B << "_2, pp" << B << "_3);\n";
+        }
+        o << "      const uint32_t bits" << Q << "A = pp" << B << "_" << ((f & 1u) << 1) << ", bits" << Q << "B = pp" << B << "_"
+          << (((f & 1u) << 1) | 1u) << ";\n";
+      }
       if (!st.observed && st.dist == GJX_DIST_NORMAL) {
         const std::string Q = std::to_string(q);
         o << "      float zc" << Q << ", zs" << Q << ";\n      bm_pair(bits" << Q << "A, bits" << Q << "B, zc" << Q << ", zs" << Q << ");\n";

@@ -63,8 +63,9 @@ typedef enum { GJX_RNG_THREEFRY = 0, GJX_RNG_PHILOX = 1 } gjx_rng_impl;
  * If has_fold, the draws of a leaf site come from the key's stream number `fold`: THREEFRY uses
  * fold_in(keys[i], fold) with fold = the per-`@`-site counter of generative_functions/
  * static.py:349-352 (from 1, constrained sites included); PHILOX carries the fold in the block
- * counter, with fold = the 0-based index of the site among the sites that consume randomness (four
- * consecutive single-word draws share one cipher block).
+ * counter, with fold = the 0-based index of the site among the sites that consume randomness; the
+ * single-word draws of a lane-0 key go four to a block of its own, those of a laned key two to a block
+ * shared with its pair partner (particles 2i, 2i+1 of the batch: DESIGN.md §3.2).
  * Replaces: jax.random.split / fold_in call sites inference/smc.py:299-300, static.py:261,350. */
 typedef struct {
   int32_t impl;        /* gjx_rng_impl */
@@ -108,8 +109,8 @@ int gjx_rng_bits(const gjx_keys* k, uint32_t sub, uint64_t n, uint32_t* out, gjx
  * ImportanceK's vmap does (inference/smc.py:302-310).
  * value_out / score_out are dev [n]; score_out may be NULL.
  * Normal: THREEFRY draws sqrt(2) erfinv(u) (jax).  PHILOX with a fold (a model site) draws the
- * Box-Muller pair of particles (2i, 2i+1) of the key batch: each element derives its
- * partner's word from the key lane, so this call, gjx_importance_run and a scalar run agree bit for bit. */
+ * Box-Muller pair of particles (2i, 2i+1) of the key batch: each element derives the
+ * pair's block from the key lane, so this call, gjx_importance_run and a scalar run agree bit for bit. */
 int gjx_sample_logpdf_normal(const gjx_keys* k, gjx_f32 loc, gjx_f32 scale, float* value_out,
                              float* score_out, uint64_t n, gjx_stream s);
 int gjx_sample_logpdf_gamma(const gjx_keys* k, gjx_f32 concentration, gjx_f32 rate,

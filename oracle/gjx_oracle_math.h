@@ -142,13 +142,26 @@ static inline void o_words(const o_stream* s, uint32_t sub, uint32_t* w0, uint32
  * PHILOX: word 0 of the sub-stream, except the single-word draw (sub 0) of a folded stream, which
  * is word (f & 3) of the block shared by folds 4(f>>2)..4(f>>2)+3 — one cipher block serves four
  * scalar sites. */
+/* PHILOX single-word draw number f of key k.  A lane-0 key packs four draws per block of its
+ * own: word f & 3 of PH(ctr = (0, 0, f >> 2, 'D')).  A laned key (lane L >= 1: particle i = L - 1 of its parent)
+ * shares blocks with its pair partner i ^ 1: word ((f & 1) << 1) | (i & 1) of PH(ctr = (p_lo, p_hi, f >> 1, 'P')),
+ * p = i >> 1. */
+#define O_TAG_PAIR 0x50u
+static inline uint32_t o_single_draw(const uint32_t k[4], uint32_t f) {
+  uint32_t o[4];
+  if ((k[2] | k[3]) == 0u) {
+    const uint32_t c[4] = {0u, 0u, f >> 2, O_TAG_DRAW};
+    o_philox4x32(k[0], k[1], c, o);
+    return o[f & 3u];
+  }
+  const uint64_t i = (((uint64_t)k[3] << 32) | k[2]) - 1u, p = i >> 1;
+  const uint32_t c[4] = {(uint32_t)p, (uint32_t)(p >> 32), f >> 1, O_TAG_PAIR};
+  o_philox4x32(k[0], k[1], c, o);
+  return o[((f & 1u) << 1) | (uint32_t)(i & 1u)];
+}
 static inline uint32_t o_bits32_at(const o_stream* s, uint32_t sub) {
   uint32_t w0, w1;
-  if (s->impl == 1 && s->hf && sub == 0u) {
-    uint32_t o[4];
-    o_philox_lane(s->k, s->f >> 2, O_TAG_DRAW, o);
-    return o[s->f & 3u];
-  }
+  if (s->impl == 1 && s->hf && sub == 0u) return o_single_draw(s->k, s->f);
   o_words(s, sub, &w0, &w1);
   return s->impl == 0 ? (w0 ^ w1) : w0;
 }
@@ -323,25 +336,24 @@ static inline void o_bm_pair(uint32_t w_radius, uint32_t w_angle, float* z_cos, 
   *z_cos = r * cs;
   *z_sin = r * sn;
 }
-static inline uint32_t o_draw_word(const uint32_t k[4], uint32_t f, uint32_t tag) {
-  uint32_t o[4];
-  o_philox_lane(k, f >> 2, tag, o);
-  return o[f & 3u];
-}
-/* The standard normal of a Normal site for stream `s` (folded, PHILOX); THREEFRY / unfolded streams keep
- * jax's erfinv form. */
+/* The standard normal of a Normal site for stream `s` (folded, PHILOX): Box-Muller over the particle pair — the
+ * even particle's draw is the radius word, the odd one's the angle word, the even particle takes the cosine
+ * branch; a lane-0 key has no partner and takes its angle word from its twin block ('T').  THREEFRY / unfolded
+ * streams keep jax's erfinv form. */
 static inline float o_site_normal(const o_stream* s) {
   if (s->impl == 0 || !s->hf) return o_std_normal(o_bits32_at(s, 0));
   float zc, zs;
   if ((s->k[2] | s->k[3]) == 0u) {
-    o_bm_pair(o_draw_word(s->k, s->f, O_TAG_DRAW), o_draw_word(s->k, s->f, O_TAG_TWIN), &zc, &zs);
+    uint32_t o[4];
+    o_philox_lane(s->k, s->f >> 2, O_TAG_TWIN, o);
+    o_bm_pair(o_single_draw(s->k, s->f), o[s->f & 3u], &zc, &zs);
     return zc;
   }
   uint64_t j = (((uint64_t)s->k[3] << 32) | s->k[2]) - 1u;
   uint64_t la = (j & ~(uint64_t)1) + 1u, lb = la + 1u;
   uint32_t ka[4] = {s->k[0], s->k[1], (uint32_t)la, (uint32_t)(la >> 32)};
   uint32_t kb[4] = {s->k[0], s->k[1], (uint32_t)lb, (uint32_t)(lb >> 32)};
-  o_bm_pair(o_draw_word(ka, s->f, O_TAG_DRAW), o_draw_word(kb, s->f, O_TAG_DRAW), &zc, &zs);
+  o_bm_pair(o_single_draw(ka, s->f), o_single_draw(kb, s->f), &zc, &zs);
   return (j & 1u) ? zs : zc;
 }
 

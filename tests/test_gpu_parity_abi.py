@@ -533,9 +533,10 @@ def test_full_size_batches(hip_ops):
         assert abs(zs[p] - ref) < 1e-5
     err = np.array(zs) - exact
     assert abs(err.mean()) < 0.1 and err.std() < 0.1, (err.mean(), err.std())
-    # the variance of the weights fixes the estimator's standard deviation: sqrt(var(w) / n) / mean(w)
+    # the variance of the weights fixes the estimator's standard deviation: sqrt(var(w) / n) / mean(w).  Both
+    # sides are noisy (8 estimates; heavy-tailed weights in 10 dimensions): same order of magnitude is the claim
     w = torch.exp(prep.logw_all[0, :n].double() - zs[0])
-    assert float(w.std() / np.sqrt(n)) == pytest.approx(err.std(), rel=1.5)
+    assert 0.2 < float(w.std() / np.sqrt(n)) / err.std() < 5.0, (float(w.std() / np.sqrt(n)), err.std())
     f = W.LgssmSMC(hip_ops, 1, 200, n, 20, filters=8)
     r = f.result(f.run())
     zf = np.array(r["log_z"])

@@ -42,12 +42,12 @@ def test_gaussian10_plan_compiles(hip_lib_nogpu, impl):
         assert "__launch_bounds__(256" in src1
     else:
         # the paired form: two adjacent particles per lane (A, B), ONE Box-Muller transform per Normal site for
-        # the pair, 4 sampled sites per Philox block whatever is observed in between (10 draws -> 3 blocks per
-        # particle), the cipher key is the (launch-uniform) parent key
+        # the pair, and the pair's single-word draws two sites to a Philox block whatever is observed in between
+        # (10 draws x 2 particles -> 5 blocks per pair), the cipher key is the (launch-uniform) parent key
         assert src1.count("bm_pair(") == 10 and src1.count("std_normal(") == 0
         assert src1.count("logpdf_normal_pre(") == 40
-        assert src1.count("philox4x32(pkeyA") == 3 and src1.count("philox4x32(pkeyB") == 3
-        assert "ks.parent.k0" in src1 and "__launch_bounds__(128)" in src1
+        assert src1.count("kTagPair") == 5 and src1.count("philox4x32(") == 5
+        assert "ks.parent.k0" in src1 and "__launch_bounds__(128" in src1
     ops.lib.call("gjx_plan_compile_check", plan.handle, impl)
 
 
