@@ -2057,7 +2057,6 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
       !state_out || !logw_out || (plan->n_obs > 0 && !obs_host))
     return GJX_ERR_INVALID;
   if (!gjx_jit::enabled()) return GJX_ERR_UNSUPPORTED;  // SMC plans exist only as specialised kernels
-  if (cfg->n_filters > 1) return GJX_ERR_UNSUPPORTED;   // filter batches: the hand-written models only
   gjx_jit::CompiledSmc& c = plan->jit[cfg->impl];
   if (c.state == 0) {
     std::lock_guard<std::mutex> lock(plan->mu);
@@ -2067,48 +2066,67 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
   }
   if (c.state != 1) return GJX_ERR_UNSUPPORTED;
   const uint64_t N = cfg->n_total, nt = ntiles_of(N);
-  const int D = plan->n_state;
+  const int D = plan->n_state, T = cfg->n_steps;
+  // several filters per launch (as in smc_run): filter f's particles lie f * stride further in every array
+  const unsigned F = cfg->n_filters > 1 ? (unsigned)cfg->n_filters : 1u;
+  const uint64_t stride = F > 1 ? cfg->filter_stride : N;
+  if (F > kMaxFilters || (F > 1 && (stride != nt * kTile || nt > kPrefixTiles))) return GJX_ERR_UNSUPPORTED;
+  const bool scan = nt > kPrefixTiles || F >= 4;
   Carver cv{(char*)ws, ws ? ws_bytes : 0};
   float* st_ws[GJX_SMC_MAX_STATE];
-  for (int k = 0; k < D; ++k) st_ws[k] = cv.take<float>(N);
-  float* lw_ws = cv.take<float>(N);
-  float* mp = cv.take<float>(nt);
-  uint64_t* tiles = cv.take<uint64_t>(nt);
-  uint64_t* prefix = nt > kPrefixTiles ? cv.take<uint64_t>(nt + 1) : nullptr;
+  for (int k = 0; k < D; ++k) st_ws[k] = cv.take<float>(F * stride);
+  float* lw_ws = cv.take<float>(F * stride);
+  float* mp = cv.take<float>(F * nt);
+  uint64_t* tiles = cv.take<uint64_t>(F * nt);
+  uint64_t* prefix = scan ? cv.take<uint64_t>(F * (nt + 1)) : nullptr;
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   for (int k = 0; k < D; ++k)
     if (!state_out[k]) return GJX_ERR_INVALID;
-  const int last = (cfg->n_steps - 1) & 1;
+  const int last = (T - 1) & 1;
   float* stb[2][GJX_SMC_MAX_STATE];
   float* lwb[2];
   for (int k = 0; k < D; ++k) { stb[last][k] = state_out[k]; stb[last ^ 1][k] = st_ws[k]; }
   lwb[last] = logw_out; lwb[last ^ 1] = lw_ws;
-  for (int t = 0; t < cfg->n_steps; ++t) {
+  FilterBatch fb;
+  if (F > 1) {
+    fb.n_filters = F; fb.tiles = (uint32_t)nt; fb.stride = stride; fb.mq_stride = (uint64_t)T;
+  }
+  for (int t = 0; t < T; ++t) {
     const int cur = t & 1, prv = cur ^ 1;
+    for (unsigned f = 0; f < F && F > 1; ++f) {  // this step's keys of every filter ([F, T, 2] host arrays)
+      const uint32_t* sk = cfg->step_keys + 2 * ((size_t)f * T + t);
+      const uint32_t* rk = cfg->resample_keys + 2 * ((size_t)f * T + t);
+      fb.step_key[f] = Key{sk[0], sk[1]};
+      fb.rkey[f] = Key{rk[0], rk[1]};
+    }
+    StepCtx ctx;
+    ctx.fb = fb;
     PlanPolicyArgs PA;
     memset(&PA, 0, sizeof(PA));
     for (int k = 0; k < D; ++k) { PA.prev_state[k] = stb[prv][k]; PA.state_out[k] = stb[cur][k]; }
     PA.logw_out = lwb[cur];
-    PA.anc_out = ancestors_out ? ancestors_out + (size_t)t * N : nullptr;
+    PA.anc_out = ancestors_out ? ancestors_out + (size_t)t * F * stride : nullptr;
     PA.step_key = Key{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
     for (int k = 0; k < plan->n_obs; ++k) PA.obs[k] = obs_host[(size_t)t * (size_t)plan->n_obs + k];
     if (t == 0) {
       uint64_t first = 0, nl = N;
-      void* args[] = {&PA, &first, &nl, &mp};
-      if (hipModuleLaunchKernel(c.init, (unsigned)nt, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess)
+      void* args[] = {&PA, &first, &nl, &mp, &fb};
+      if (hipModuleLaunchKernel(c.init, (unsigned)(nt * F), 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess)
         return GJX_ERR_LAUNCH;
     } else {
-      if (prefix) k_scan_tiles<<<1, kBlock, 0, S(s)>>>(tiles, nt, prefix);
-      ResampleArgs A = smc_resample_args(cfg, t, lwb[prv], out_max + (t - 1), tiles, out_q + (t - 1));
-      A.tile_prefix = prefix;
+      if (prefix) k_scan_tiles<<<F, kBlock, 0, S(s)>>>(tiles, nt, prefix);
+      ctx.tile_prefix = prefix;
+      ResampleArgs A = smc_resample_args(cfg, t, lwb[prv], out_max + (t - 1), tiles, out_q + (t - 1), ctx);
       void* args[] = {&A, &PA, &mp};
-      if (hipModuleLaunchKernel(c.step, (unsigned)nt, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess)
+      if (hipModuleLaunchKernel(c.step, (unsigned)(nt * F), 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess)
         return GJX_ERR_LAUNCH;
     }
-    const int rc = gjx_smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s);
+    const int rc = smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s, ctx);
     if (rc) return rc;
   }
-  return gjx_smc_finish(cfg, tiles, out_q + (cfg->n_steps - 1), s);
+  StepCtx ctx;
+  ctx.fb = fb;
+  return smc_finish(cfg, tiles, out_q + (T - 1), s, ctx);
 }
 
 }  // extern "C"

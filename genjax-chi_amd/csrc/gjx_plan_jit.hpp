@@ -470,8 +470,13 @@ struct GenSmc {
       emit_quad_body(init_sites, n_init, init_state, false);
       o << "}\n";
     }
-    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_init_kernel(PlanPolicyArgs a, uint64_t first_slot, uint64_t n_local, float* max_partials) {\n";
-    o << "  __shared__ float shf[4];\n  const uint64_t gbase = (uint64_t)blockIdx.x * kTile;\n  float tmax = -__builtin_inff();\n";
+    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_init_kernel(PlanPolicyArgs a, uint64_t first_slot, uint64_t n_local, float* max_partials, FilterBatch fb) {\n";
+    o << "  __shared__ float shf[4];\n  uint64_t gtile = blockIdx.x;\n";
+    o << "  if (fb.n_filters > 1) {  // several filters per launch: tile of filter f, its key, its outputs\n";
+    o << "    const uint32_t f = (uint32_t)(gtile / fb.tiles);\n    gtile -= (uint64_t)f * fb.tiles;\n    a.step_key = fb.step_key[f];\n";
+    o << "    for (int k = 0; k < " << D << "; ++k) a.state_out[k] += (uint64_t)f * fb.stride;\n";
+    o << "    a.logw_out += (uint64_t)f * fb.stride;\n    if (a.anc_out) a.anc_out += (uint64_t)f * fb.stride;\n  }\n";
+    o << "  const uint64_t gbase = gtile * kTile;\n  float tmax = -__builtin_inff();\n";
     if (impl == 1) {  // four consecutive slots per lane, one cipher block per one-word draw of the quad
       o << "  if (gbase >= first_slot && gbase < first_slot + n_local) {\n";
       o << "    const int64_t jq = (int64_t)(gbase + 4 * (uint64_t)threadIdx.x);\n";

@@ -462,17 +462,22 @@ class Ops:
         return SmcPlan(self, handle, len(next_state), n_obs)
 
     def smc_run_plan(self, plan: "SmcPlan", impl, n, step_keys, resample_keys, obs, want_ancestors=False):
+        """`step_keys` / `resample_keys` [T, 2]: one filter -> (max [T], q [T], state columns [n], logw [n], ancestors
+        [T, n]); [F, T, 2]: F filters (same observations, own keys) stepping in the same launches -> ([F, T], [F, T],
+        columns [F, stride], [F, stride], [T, F, stride]), filter f equal to its own single run bit for bit."""
         import numpy as np
 
-        T = len(step_keys)
         cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys)
+        T, F = cfg.n_steps, cfg._filters
         oh = np.ascontiguousarray(np.asarray(obs, dtype=np.float32).reshape(T, max(plan.n_obs, 1))[:, :plan.n_obs])
-        out_max, out_q = self.empty(T, torch.float32), self.empty(T, torch.int64)
-        states = [self.empty(n, torch.float32) for _ in range(plan.n_state)]
+        stride = cfg.filter_stride if F > 1 else n
+        shape = (lambda *tail: (F, *tail)) if F > 1 else (lambda *tail: tail)
+        out_max, out_q = self.empty(shape(T), torch.float32), self.empty(shape(T), torch.int64)
+        states = [self.empty(shape(stride), torch.float32) for _ in range(plan.n_state)]
         sp = (C.c_void_p * plan.n_state)(*[t.data_ptr() for t in states])
-        logw = self.empty(n, torch.float32)
-        anc = self.empty((T, n), torch.int32) if want_ancestors else None
-        ws, nb = self.workspace(abi.OP_SMC, n * (plan.n_state + 1))
+        logw = self.empty(shape(stride), torch.float32)
+        anc = self.empty((T, F, stride) if F > 1 else (T, n), torch.int32) if want_ancestors else None
+        ws, nb = self.workspace(abi.OP_SMC, F * stride * (plan.n_state + 1))
         self.lib.call("gjx_smc_run_plan", C.byref(cfg), plan.handle, C.c_void_p(oh.ctypes.data) if plan.n_obs else None,
                       self._p(out_max), self._p(out_q), sp, self._p(logw), self._p(anc), C.c_void_p(ws.data_ptr()), nb,
                       self.stream())

@@ -108,14 +108,16 @@ class BootstrapSMC:
         return SMCResult(ops.log_z_from_pairs(step_max, step_q, self.n), step_max, step_q, state, logw, anc)
 
     def run_many(self, keys) -> list:
-        """`vmap(self.run)(keys)`: one independent filter per key.  For the hand-written models up to 8 filters step
-        in the same kernel launches (`gjx_smc_config.n_filters`: a 1e6-particle step alone is under one round
-        of an MI355X); element b equals `self.run(keys[b])` bit for bit.  Other models run key by key."""
+        """`vmap(self.run)(keys)`: one independent filter per key.  Up to 8 filters step in the same kernel launches
+        (`gjx_smc_config.n_filters`: a 1e6-particle step alone is under one round of an MI355X), for the hand-written
+        models and for generated ones alike; element b equals `self.run(keys[b])` bit for bit."""
         keys = list(keys)
-        if not isinstance(self.model, (LinearGaussianSSM, DiscreteHMM)) or len(keys) < 2:
+        if not isinstance(self.model, (LinearGaussianSSM, DiscreteHMM, StateSpaceModel)) or len(keys) < 2:
             return [self.run(k) for k in keys]
         ops, out = get_ops(), []
-        T = len(self.observations)
+        if isinstance(self.model, StateSpaceModel) and self._plan is None:
+            self.run(keys[0])  # builds the plan and the observation matrix
+        T = len(self.observations) if self.observations is not None else self._obs.shape[0]
         for lo in range(0, len(keys), 8):
             chunk = keys[lo:lo + 8]
             if len(chunk) == 1:
@@ -124,6 +126,14 @@ class BootstrapSMC:
             pairs = [smc_key_schedule(k, T) for k in chunk]
             sk, rk = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
             m, impl = self.model, chunk[0].impl
+            if isinstance(m, StateSpaceModel):
+                om, oq, states, logw, anc = ops.smc_run_plan(self._plan, impl, self.n, sk, rk, self._obs, self.record_ancestors)
+                for f in range(len(chunk)):
+                    cols = [c[f, :self.n] for c in states]
+                    out.append(SMCResult(ops.log_z_from_pairs(om[f], oq[f], self.n), om[f], oq[f],
+                                         cols[0] if self._n_state == 1 else tuple(cols), logw[f, :self.n],
+                                         None if anc is None else anc[:, f, :self.n]))
+                continue
             if isinstance(m, LinearGaussianSSM):
                 res = ops.smc_run_lgssm(impl, self.n, sk, rk, abi.Lgssm(m.x0_loc, m.x0_scale, m.a, m.q, m.r),
                                         self.observations.astype(np.float32), self.record_ancestors)

@@ -463,7 +463,9 @@ int gjx_smc_plan_create(const gjx_smc_model* m /*host*/, gjx_smc_plan** out);
 int gjx_smc_plan_destroy(gjx_smc_plan* p);
 int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl); /* offline hiprtc compile, needs no GPU */
 /* obs_host: host f32[T, n_obs].  state_out: host array of n_state dev f32[n] pointers (final-step
- * particles); other outputs as gjx_smc_run_lgssm.  Single device (first_slot 0, n_local n_total). */
+ * particles); other outputs as gjx_smc_run_lgssm, gjx_smc_config.n_filters included (F filters of the same
+ * model and observations with their own keys step in the same launches: every state column dev f32[F, stride]).
+ * Single device (first_slot 0, n_local n_total). */
 int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host,
                      float* out_max, uint64_t* out_q, float* const* state_out, float* logw_out,
                      int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s);

@@ -1182,14 +1182,41 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
 int gjx_smc_plan_destroy(gjx_smc_plan* p) { free(p); return GJX_OK; }
 int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl) { (void)p; (void)impl; return GJX_ERR_UNSUPPORTED; }
 
+static int smc_run_plan_one(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
+                            uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out);
+/* Several filters: each filter's own single run, with its keys [f, T, 2] and its slice of every output. */
 int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
                      uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out,
                      void* ws, size_t ws_bytes, gjx_stream s) {
   (void)ws; (void)ws_bytes; (void)s;
+  if (!cfg || !plan || !state_out) return GJX_ERR_INVALID;
+  if (cfg->n_filters <= 1) return smc_run_plan_one(cfg, plan, obs_host, out_max, out_q, state_out, logw_out, ancestors_out);
+  const int F = cfg->n_filters, T = cfg->n_steps, D = plan->m.n_state;
+  const uint64_t N = cfg->n_total, stride = cfg->filter_stride;
+  if (F > 8 || stride < N) return GJX_ERR_INVALID;
+  int32_t* anc1 = ancestors_out ? (int32_t*)malloc(sizeof(int32_t) * (size_t)T * N) : NULL;
+  int rc = GJX_OK;
+  for (int f = 0; f < F && !rc; ++f) {
+    gjx_smc_config c = *cfg;
+    c.n_filters = 0;
+    c.step_keys = cfg->step_keys + 2 * (size_t)f * T;
+    c.resample_keys = cfg->resample_keys + 2 * (size_t)f * T;
+    float* cols[GJX_SMC_MAX_STATE];
+    for (int k = 0; k < D; ++k) cols[k] = state_out[k] + (size_t)f * stride;
+    rc = smc_run_plan_one(&c, plan, obs_host, out_max + (size_t)f * T, out_q + (size_t)f * T, cols,
+                          logw_out + (size_t)f * stride, anc1);
+    if (!rc && anc1)  /* [T, N] -> [T, F, stride] */
+      for (int t = 0; t < T; ++t)
+        memcpy(ancestors_out + ((size_t)t * F + f) * stride, anc1 + (size_t)t * N, sizeof(int32_t) * N);
+  }
+  free(anc1);
+  return rc;
+}
+static int smc_run_plan_one(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
+                            uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out) {
   if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !plan || !out_max || !out_q ||
       !state_out || !logw_out || (plan->m.n_obs > 0 && !obs_host))
     return GJX_ERR_INVALID;
-  if (cfg->n_filters > 1) return GJX_ERR_UNSUPPORTED;
   const gjx_smc_model* m = &plan->m;
   const uint64_t N = cfg->n_total, ntile = gjx_num_tiles(N);
   const int D = m->n_state;

@@ -689,6 +689,15 @@ def case_general_smc(impl):
         kk = pp / sv
         mm, pp = mm + kk * (yt - mm), (1 - kk) * pp
     assert r.log_marginal_likelihood == pytest.approx(ll, abs=0.6)
+    # vmap over keys: the filters of a user model step in the same launches, each equal to its own run
+    smc2 = BootstrapSMC(StateSpaceModel(init2, step2), C["y"].set(torch.tensor(y)), 4096, record_ancestors=True)
+    ks = [genjax.random.key(s_, impl) for s_ in (3, 8, 9)]
+    many = smc2.run_many(ks)
+    assert many[0].log_marginal_likelihood == r.log_marginal_likelihood
+    for k_, m_ in zip(ks, many):
+        one = smc2.run(k_)
+        assert torch.equal(m_.step_q, one.step_q) and torch.equal(m_.ancestors, one.ancestors)
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(m_.particles, one.particles))
     with pytest.raises(ValueError):
         BootstrapSMC(StateSpaceModel(init, step), C["nope"].set(torch.tensor(y)), 1024).run(key)
 

@@ -489,6 +489,18 @@ def test_smc_plans(hip_ops, oracle_ops, impl):
         same(h[0], o[0], "step max"); same(h[1], o[1], "step q"); same(h[3], o[3], "logw"); same(h[4], o[4], "ancestors")
         for a, b in zip(h[2], o[2]):
             same(a, b, "state column")
+    # three filters of the two-state model in the same launches == their own runs == the oracle's
+    pairs = [W.smc_key_schedule(prng.key(20 + f, impl), T) for f in range(3)]
+    skf, rkf = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    hb = hip_ops.smc_run_plan(hr, impl, n, skf, rkf, obs2, True)
+    ob = oracle_ops.smc_run_plan(orr, impl, n, skf, rkf, obs2, True)
+    same(hb[0], ob[0], "batched step max"); same(hb[1], ob[1], "batched step q"); same(hb[4][:, :, :n], ob[4][:, :, :n], "batched ancestors")  # (slots n .. stride of a filter are padding)
+    for f in range(3):
+        one = hip_ops.smc_run_plan(hr, impl, n, pairs[f][0], pairs[f][1], obs2, True)
+        same(hb[1][f], one[1], "q of filter"); same(hb[3][f, :n], one[3], "logw of filter")
+        same(hb[4][:, f, :n], one[4], "ancestors of filter")
+        for a, b in zip(hb[2], one[2]):
+            same(a[f, :n], b, "state column of filter")
     fixed = hip_ops.smc_run_lgssm(impl, n, sk, rk, W.lgssm_model(), y, True)
     gen_ = hip_ops.smc_run_plan(hl, impl, n, sk, rk, y, True)
     same(gen_[1], fixed[1], "generated vs hand-written LGSSM q"); same(gen_[2][0], fixed[2], "particles")
