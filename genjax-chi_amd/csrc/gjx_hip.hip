@@ -2050,21 +2050,68 @@ int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl) {
   return gjx_jit::compile_only(smc_plan_source(p, impl)) ? GJX_OK : GJX_ERR_UNSUPPORTED;
 }
 
+static gjx_jit::CompiledSmc* smc_plan_compiled(gjx_smc_plan* plan, int impl) {
+  if (!gjx_jit::enabled()) return nullptr;  // SMC plans exist only as specialised kernels
+  gjx_jit::CompiledSmc& c = plan->jit[impl];
+  if (c.state == 0) {
+    std::lock_guard<std::mutex> lock(plan->mu);
+    if (c.state == 0) c.state = gjx_jit::compile_smc(smc_plan_source(plan, impl), &c) ? 1 : -1;
+  }
+  return c.state == 1 ? &c : nullptr;
+}
+
+// Step A of a plan-driven filter: the generated init kernel (t == 0) or the generated policy inside the fused
+// resample kernel, for the output slots [first_slot, first_slot + n_local) of cfg.
+static int smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, gjx_jit::CompiledSmc& c, int t,
+                           const float* obs_t, const float* const* prev_state, const float* prev_logw,
+                           const float* prev_max, const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
+                           float* const* state_out, float* logw_out, float* max_partials_out, int32_t* ancestors_out,
+                           gjx_stream s, const StepCtx& ctx) {
+  const unsigned nt = (unsigned)ntiles_of(cfg->n_total), nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
+  PlanPolicyArgs PA;
+  memset(&PA, 0, sizeof(PA));
+  for (int k = 0; k < plan->n_state; ++k) { PA.prev_state[k] = prev_state ? prev_state[k] : nullptr; PA.state_out[k] = state_out[k]; }
+  PA.logw_out = logw_out;
+  PA.anc_out = ancestors_out;
+  PA.step_key = Key{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
+  for (int k = 0; k < plan->n_obs; ++k) PA.obs[k] = obs_t[k];
+  if (t == 0) {
+    uint64_t first = cfg->first_slot, nl = cfg->n_local;
+    FilterBatch fb = ctx.fb;
+    void* args[] = {&PA, &first, &nl, &max_partials_out, &fb};
+    if (hipModuleLaunchKernel(c.init, nt * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
+    return launch_status();
+  }
+  if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
+  ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out, ctx);
+  void* args[] = {&A, &PA, &max_partials_out};
+  if (hipModuleLaunchKernel(c.step, nt * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
+  return launch_status();
+}
+
+int gjx_smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, const float* obs_t,
+                        const float* const* prev_state, const float* prev_logw, const float* prev_max,
+                        const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* const* state_out,
+                        float* logw_out, float* max_partials_out, int32_t* ancestors_out, gjx_stream s) {
+  if (!cfg_ok(cfg) || !plan || t < 0 || t >= cfg->n_steps || !state_out || !logw_out || !max_partials_out ||
+      (plan->n_obs > 0 && !obs_t) || cfg->n_filters > 1)
+    return GJX_ERR_INVALID;
+  for (int k = 0; k < plan->n_state; ++k)
+    if (!state_out[k] || (t > 0 && (!prev_state || !prev_state[k]))) return GJX_ERR_INVALID;
+  gjx_jit::CompiledSmc* c = smc_plan_compiled(plan, cfg->impl);
+  if (!c) return GJX_ERR_UNSUPPORTED;
+  return smc_plan_step_a(cfg, plan, *c, t, obs_t, prev_state, prev_logw, prev_max, prev_tile_sums, prev_q_out, state_out,
+                         logw_out, max_partials_out, ancestors_out, s, StepCtx{});
+}
+
 int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
                      uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out,
                      void* ws, size_t ws_bytes, gjx_stream s) {
   if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !plan || !out_max || !out_q ||
       !state_out || !logw_out || (plan->n_obs > 0 && !obs_host))
     return GJX_ERR_INVALID;
-  if (!gjx_jit::enabled()) return GJX_ERR_UNSUPPORTED;  // SMC plans exist only as specialised kernels
-  gjx_jit::CompiledSmc& c = plan->jit[cfg->impl];
-  if (c.state == 0) {
-    std::lock_guard<std::mutex> lock(plan->mu);
-    if (c.state == 0) {
-      c.state = gjx_jit::compile_smc(smc_plan_source(plan, cfg->impl), &c) ? 1 : -1;
-    }
-  }
-  if (c.state != 1) return GJX_ERR_UNSUPPORTED;
+  gjx_jit::CompiledSmc* cp = smc_plan_compiled(plan, cfg->impl);
+  if (!cp) return GJX_ERR_UNSUPPORTED;
   const uint64_t N = cfg->n_total, nt = ntiles_of(N);
   const int D = plan->n_state, T = cfg->n_steps;
   // several filters per launch (as in smc_run): filter f's particles lie f * stride further in every array
@@ -2101,27 +2148,14 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
     }
     StepCtx ctx;
     ctx.fb = fb;
-    PlanPolicyArgs PA;
-    memset(&PA, 0, sizeof(PA));
-    for (int k = 0; k < D; ++k) { PA.prev_state[k] = stb[prv][k]; PA.state_out[k] = stb[cur][k]; }
-    PA.logw_out = lwb[cur];
-    PA.anc_out = ancestors_out ? ancestors_out + (size_t)t * F * stride : nullptr;
-    PA.step_key = Key{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
-    for (int k = 0; k < plan->n_obs; ++k) PA.obs[k] = obs_host[(size_t)t * (size_t)plan->n_obs + k];
-    if (t == 0) {
-      uint64_t first = 0, nl = N;
-      void* args[] = {&PA, &first, &nl, &mp, &fb};
-      if (hipModuleLaunchKernel(c.init, (unsigned)(nt * F), 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess)
-        return GJX_ERR_LAUNCH;
-    } else {
-      if (prefix) k_scan_tiles<<<F, kBlock, 0, S(s)>>>(tiles, nt, prefix);
+    if (prefix && t) {
+      k_scan_tiles<<<F, kBlock, 0, S(s)>>>(tiles, nt, prefix);
       ctx.tile_prefix = prefix;
-      ResampleArgs A = smc_resample_args(cfg, t, lwb[prv], out_max + (t - 1), tiles, out_q + (t - 1), ctx);
-      void* args[] = {&A, &PA, &mp};
-      if (hipModuleLaunchKernel(c.step, (unsigned)(nt * F), 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess)
-        return GJX_ERR_LAUNCH;
     }
-    const int rc = smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s, ctx);
+    int rc = smc_plan_step_a(cfg, plan, *cp, t, plan->n_obs ? obs_host + (size_t)t * (size_t)plan->n_obs : nullptr, stb[prv],
+                             lwb[prv], t ? out_max + (t - 1) : nullptr, tiles, t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur],
+                             mp, ancestors_out ? ancestors_out + (size_t)t * F * stride : nullptr, s, ctx);
+    if (!rc) rc = smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s, ctx);
     if (rc) return rc;
   }
   StepCtx ctx;

@@ -235,6 +235,7 @@ PROTOTYPES = {
         C.c_int,
         [C.POINTER(SmcConfig), C.POINTER(Hmm), C.c_int, C.c_int32] + [_P] * 12,
     ),
+    "gjx_smc_plan_step_a": (C.c_int, [C.POINTER(SmcConfig), _P, C.c_int] + [_P] * 11),
     "gjx_smc_step_b": (C.c_int, [C.POINTER(SmcConfig), _P, _P, _P, _P, _P]),
     "gjx_smc_finish": (C.c_int, [C.POINTER(SmcConfig), _P, _P, _P]),
     "gjx_smc_source_ranges": (C.c_int, [C.POINTER(SmcConfig), _P, C.c_int, C.c_int64, _P, _P]),

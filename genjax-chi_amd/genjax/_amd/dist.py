@@ -254,13 +254,14 @@ class ShardedSMC:
 
     def __init__(self, ops: Ops, kind: str, impl: int, seed: int, n_total: int, T: int, rank: int, world: int,
                  record_ancestors: bool = False, exchange: str = "ranges", comm=None, poison: bool = False,
-                 n_states=None, lgssm=None, y=None):
-        """`lgssm` (abi.Lgssm) / `y`: another linear-Gaussian model and observation sequence than the benchmark's."""
+                 n_states=None, lgssm=None, y=None, plan=None, obs=None):
+        """`lgssm` (abi.Lgssm) / `y`: another linear-Gaussian model and observation sequence than the benchmark's.
+        kind "plan": a generated filter — `plan` from `ops.smc_plan_create`, `obs` [T, n_obs]."""
         tile = ops.tile
         if n_total % (world * tile) != 0:
             raise ValueError(f"n_total must be a multiple of world*{tile}")
-        if kind not in ("lgssm", "hmm") or exchange not in ("ranges", "allgather"):
-            raise ValueError("kind: lgssm | hmm; exchange: ranges | allgather")
+        if kind not in ("lgssm", "hmm", "plan") or exchange not in ("ranges", "allgather"):
+            raise ValueError("kind: lgssm | hmm | plan; exchange: ranges | allgather")
         self.ops, self.kind, self.impl, self.T, self.rank, self.world = ops, kind, impl, T, rank, world
         self.exchange, self.poison = exchange, poison
         self.comm = comm if comm is not None else TorchComm(rank, world)
@@ -274,6 +275,13 @@ class ShardedSMC:
             self.model = W.lgssm_model() if lgssm is None else lgssm
             self.log_z_exact = W.lgssm_exact_log_z(self.y) if lgssm is None else float("nan")
             sdt = torch.float32
+        elif kind == "plan":
+            import numpy as np
+
+            self.plan = plan
+            self.y = np.asarray(obs, dtype=np.float32).reshape(T, -1)
+            self.log_z_exact = float("nan")
+            sdt = torch.float32
         else:
             trans, obs = W.hmm_tables(n_states)
             self.k = trans.shape[0]
@@ -286,7 +294,9 @@ class ShardedSMC:
             sdt = torch.int32
         nt = ops.num_tiles(n_total)
         # global-size buffers: a rank's own block is always current, remote ranges are filled on demand
-        self.state = [torch.zeros(n_total, dtype=sdt, device=dev) for _ in range(2)]
+        self.n_cols = plan.n_state if kind == "plan" else 1
+        # state[buffer][column]: the hand-written models have one state column
+        self.state = [[torch.zeros(n_total, dtype=sdt, device=dev) for _ in range(self.n_cols)] for _ in range(2)]
         self.logw = [torch.zeros(n_total, dtype=torch.float32, device=dev) for _ in range(2)]
         self.tile_sums = torch.zeros(nt, dtype=torch.int64, device=dev)
         self.max_partials = torch.empty(nt, dtype=torch.float32, device=dev)
@@ -301,10 +311,15 @@ class ShardedSMC:
 
     def _step_a(self, t: int, cur: int, prv: int):
         lo, hi = self.first, self.first + self.n_local
-        prev = (self.state[prv], self.logw[prv], self.out_max[t - 1:t], self.tile_sums, self.out_q[t - 1:t]) if t else (
-            None, None, None, None, None)
-        outs = (self.state[cur][lo:hi], self.logw[cur][lo:hi], self.max_partials,
-                None if self.ancestors is None else self.ancestors[t])
+        anc = None if self.ancestors is None else self.ancestors[t]
+        weights = (self.logw[prv], self.out_max[t - 1:t], self.tile_sums, self.out_q[t - 1:t]) if t else (None,) * 4
+        own = [c[lo:hi] for c in self.state[cur]]
+        if self.kind == "plan":
+            self.ops.smc_plan_step_a(self.cfg, self.plan, t, self.y[t], self.state[prv] if t else None, *weights, own,
+                                     self.logw[cur][lo:hi], self.max_partials, anc)
+            return
+        prev = ((self.state[prv][0],) + weights) if t else (None,) * 5
+        outs = (own[0], self.logw[cur][lo:hi], self.max_partials, anc)
         if self.kind == "lgssm":
             self.ops.smc_lgssm_step_a(self.cfg, self.model, t, float(self.y[t]), *prev, *outs)
         else:
@@ -314,7 +329,7 @@ class ShardedSMC:
         """Make the source ranges of the next resampling present on every rank."""
         ops, tile = self.ops, self.ops.tile
         lo, hi = self.first, self.first + self.n_local
-        cols = [self.state[cur], self.logw[cur]]
+        cols = [*self.state[cur], self.logw[cur]]
         if self.poison:  # tests: whatever is not received below must never be read
             for c in cols:
                 keep = c[lo:hi].clone()
@@ -367,7 +382,8 @@ class ShardedSMC:
                 self._shuffle(cur)
         ops.smc_finish(self.cfg, self.tile_sums, self.out_q[self.T - 1:self.T])
         last = (self.T - 1) & 1
-        return dict(out_max=self.out_max, out_q=self.out_q, state=self.state[last][lo:hi],
+        final = [c[lo:hi] for c in self.state[last]]
+        return dict(out_max=self.out_max, out_q=self.out_q, state=final[0] if self.n_cols == 1 else final,
                     logw=self.logw[last][lo:hi], ancestors=self.ancestors,
                     log_z=ops.log_z_from_pairs(self.out_max, self.out_q, self.n_total),
                     log_z_exact=self.log_z_exact, received=self.received)

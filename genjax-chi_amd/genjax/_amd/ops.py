@@ -505,6 +505,19 @@ class Ops:
                       self._p(trans_alias), self._p(obs_logp), self._p(state_out), self._p(logw_out),
                       self._p(max_partials_out), self._p(ancestors_out), self.stream())
 
+    def smc_plan_step_a(self, cfg, plan: "SmcPlan", t: int, obs_t, prev_state, prev_logw, prev_max, prev_tile_sums,
+                        prev_q_out, state_out, logw_out, max_partials_out, ancestors_out=None):
+        """Step A of a plan-driven filter: `prev_state` / `state_out` are lists of the n_state columns (global-size
+        / this rank's slots); `obs_t` the step's observation constants."""
+        import numpy as np
+
+        oh = np.ascontiguousarray(np.asarray(obs_t, dtype=np.float32).reshape(-1)[:plan.n_obs])
+        pp = (C.c_void_p * plan.n_state)(*[c.data_ptr() for c in prev_state]) if prev_state is not None else None
+        sp = (C.c_void_p * plan.n_state)(*[c.data_ptr() for c in state_out])
+        self.lib.call("gjx_smc_plan_step_a", C.byref(cfg), plan.handle, t, C.c_void_p(oh.ctypes.data) if plan.n_obs else None,
+                      pp, self._p(prev_logw), self._p(prev_max), self._p(prev_tile_sums), self._p(prev_q_out), sp,
+                      self._p(logw_out), self._p(max_partials_out), self._p(ancestors_out), self.stream())
+
     def smc_step_b(self, cfg, logw_local, max_partials, max_out, tile_sums):
         self.lib.call("gjx_smc_step_b", C.byref(cfg), self._p(logw_local), self._p(max_partials), self._p(max_out),
                       self._p(tile_sums), self.stream())

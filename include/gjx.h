@@ -466,6 +466,13 @@ int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl); /* offline hipr
  * particles); other outputs as gjx_smc_run_lgssm, gjx_smc_config.n_filters included (F filters of the same
  * model and observations with their own keys step in the same launches: every state column dev f32[F, stride]).
  * Single device (first_slot 0, n_local n_total). */
+/* Step A of a plan-driven filter (the per-step piece for a multi-device driver, like gjx_smc_lgssm_step_a; steps
+ * B / finish / source ranges are the model-independent calls above): obs_t host f32[n_obs]; prev_state host array
+ * of n_state dev f32[n_total] (GLOBAL arrays), state_out host array of n_state dev f32[n_local]. */
+int gjx_smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, const float* obs_t,
+                        const float* const* prev_state, const float* prev_logw, const float* prev_max,
+                        const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* const* state_out,
+                        float* logw_out, float* max_partials_out, int32_t* ancestors_out, gjx_stream s);
 int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host,
                      float* out_max, uint64_t* out_q, float* const* state_out, float* logw_out,
                      int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s);

@@ -1184,6 +1184,60 @@ int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl) { (void)p; (void
 
 static int smc_run_plan_one(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
                             uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out);
+/* Step A of a plan-driven filter for the slots [first_slot, first_slot + n_local) (the sharded driver's piece). */
+int gjx_smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, const float* obs_t,
+                        const float* const* prev_state, const float* prev_logw, const float* prev_max,
+                        const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* const* state_out,
+                        float* logw_out, float* max_partials_out, int32_t* ancestors_out, gjx_stream s) {
+  (void)s;
+  if (!cfg_ok(cfg) || !plan || t < 0 || t >= cfg->n_steps || !state_out || !logw_out || !max_partials_out ||
+      (plan->m.n_obs > 0 && !obs_t) || cfg->n_filters > 1)
+    return GJX_ERR_INVALID;
+  const gjx_smc_model* m = &plan->m;
+  const int D = m->n_state;
+  const uint64_t nl = cfg->n_local;
+  int32_t* anc = NULL;
+  if (t > 0) {
+    if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
+    anc = ancestors_out ? ancestors_out : (int32_t*)malloc(sizeof(int32_t) * nl);
+    if (!anc) return GJX_ERR_LAUNCH;
+    const uint64_t Qprev = sum_tiles(cfg, prev_tile_sums);
+    if (prev_q_out) *prev_q_out = Qprev;
+    smc_ancestors(cfg, t, prev_logw, *prev_max, prev_tile_sums, Qprev, anc);
+  } else if (ancestors_out) {
+    for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
+  }
+  const uint32_t skey[4] = {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u};
+  const gjx_site* sites = t == 0 ? m->init_sites : m->step_sites;
+  const int ns = t == 0 ? m->n_init_sites : m->n_step_sites;
+  const gjx_arg* nxt = t == 0 ? m->init_state : m->next_state;
+  float mx = -INFINITY;
+#pragma omp parallel for reduction(max : mx) schedule(static)
+  for (int64_t j = 0; j < (int64_t)nl; ++j) {
+    const uint64_t slot = cfg->first_slot + (uint64_t)j;
+    walk_ctx c;
+    memset(&c, 0, sizeof c);
+    c.impl = cfg->impl;
+    o_split_at(cfg->impl, skey, slot, c.pkey);
+    c.quad_key = cfg->impl == 1 ? skey : NULL;
+    c.slot = slot;
+    float prev[GJX_SMC_MAX_STATE];
+    if (t > 0)
+      for (int k = 0; k < D; ++k) prev[k] = prev_state[k][anc[j]];
+    c.state = t > 0 ? prev : NULL;
+    c.obs = obs_t;
+    site_val vals[GJX_MAX_SITES];
+    float w, sc;
+    site_walk(sites, ns, &c, vals, &w, &sc);
+    for (int k = 0; k < D; ++k) state_out[k][j] = eval_arg(&nxt[k], vals, &c);
+    logw_out[j] = w;
+    mx = w > mx ? w : mx;
+  }
+  put_max_partials(cfg, mx, max_partials_out);
+  if (anc && anc != ancestors_out) free(anc);
+  return GJX_OK;
+}
+
 /* Several filters: each filter's own single run, with its keys [f, T, 2] and its slice of every output. */
 int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
                      uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out,

@@ -240,3 +240,50 @@ def check_degenerate_sharded(ops, impl, world):
 def test_sharded_filter_with_collapsing_weights(oracle_ops, world):
     check_degenerate_sharded(oracle_ops, 1, world)
     check_degenerate_sharded(oracle_ops, 0, world)
+
+
+def check_sharded_plan(ops, impl, world, build_plans):
+    """A generated filter (two state columns; normal / gamma / bernoulli / beta sites) sharded over virtual ranks,
+    remote regions poisoned: equal to its single-device run bit for bit."""
+    import threading
+
+    import numpy as np
+
+    from genjax._amd import dist as gdist, prng, workloads as W
+
+    T, n_total = 9, 1024 * world * 3
+    y = W.lgssm_data(T)
+    obs = np.stack([y, (np.arange(T) % 2).astype(np.float32)], axis=1)
+    _, plan = build_plans(ops)
+    sh, res, err = gdist.ThreadComm.Shared(world), [None] * world, []
+
+    def work(r):
+        try:
+            res[r] = gdist.ShardedSMC(ops, "plan", impl, 13, n_total, T, r, world, True, comm=gdist.ThreadComm(sh, r),
+                                      poison=True, plan=plan, obs=obs).run()
+        except BaseException as e:  # noqa: BLE001
+            err.append(e)
+            sh.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if err:
+        raise err[0]
+    sk, rk = W.smc_key_schedule(prng.key(13, impl), T)
+    om, oq, states, logw, anc = ops.smc_run_plan(plan, impl, n_total, sk, rk, obs, True)
+    for k in range(2):
+        assert torch.equal(torch.cat([r["state"][k] for r in res]).cpu(), states[k].cpu())
+    assert torch.equal(torch.cat([r["logw"] for r in res]).cpu(), logw.cpu())
+    assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1).cpu(), anc.cpu())
+    for r in res:
+        assert torch.equal(r["out_q"].cpu(), oq.cpu()) and torch.equal(r["out_max"].cpu(), om.cpu())
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_sharded_generated_filter(oracle_ops, impl):
+    from test_gpu_parity_abi import _smc_plans
+
+    check_sharded_plan(oracle_ops, impl, 3, _smc_plans)

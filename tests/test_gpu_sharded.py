@@ -48,3 +48,12 @@ def test_virtual_ranks_with_collapsing_weights(hip_ops, world):
     from test_distributed_gloo import check_degenerate_sharded
 
     check_degenerate_sharded(hip_ops, 1, world)
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_virtual_ranks_generated_filter(hip_ops, impl):
+    from test_distributed_gloo import check_sharded_plan
+    from test_gpu_parity_abi import _smc_plans
+
+    check_sharded_plan(hip_ops, impl, 2, _smc_plans)
+    check_sharded_plan(hip_ops, impl, 4, _smc_plans)
