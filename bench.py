@@ -298,6 +298,20 @@ def bench_smc(args, ops, rank, world, kind, filters=0):
     per_step_ms = dev_ms / T
     achieved = BYTES_SMC_PER_PARTICLE_STEP * n * FILTERS / (per_step_ms * 1e-3) / 1e9
     log_z = r["log_z"][0] if FILTERS > 1 else r["log_z"]
+    # HBM bytes of one step (k_resample + k_tile_sums) from the PMC passes committed under profiles/ (collected at 8
+    # filters x 1e6 particles per launch; FETCH_SIZE x2 + WRITE_SIZE), scaled to this launch's particles
+    traffic, traffic_src = None, None
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_smc_pmc.json")), reverse=True):
+        try:
+            ks = json.load(open(f)).get(kind, {})
+            per = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for k, v in ks.items() if "k_resample" in k or "k_tile_sums" in k) / 8e6
+            if per > 0:
+                traffic, traffic_src = per * n * FILTERS, os.path.relpath(f, ROOT)
+                break
+        except Exception:
+            pass
     return {
         "metric": "particle-steps/sec, bootstrap SMC (1e6 particles per GPU)",
         "value": n * T * FILTERS / dt,
@@ -305,8 +319,8 @@ def bench_smc(args, ops, rank, world, kind, filters=0):
         "ms_per_step": dt * 1e3,
         "config": {"workload": f"bootstrap SMC {kind} T={T} N={n}", "rng": args.rng, "filters_per_launch": FILTERS},
         "roofline": {"bound": "hbm", "kernel": "k_resample+k_tile_sums (one SMC step of every filter)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "step_ms": per_step_ms, "step_ms_per_filter": per_step_ms / FILTERS,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_src, "step_ms": per_step_ms, "step_ms_per_filter": per_step_ms / FILTERS,
                      "algorithmic_bytes_per_launch": BYTES_SMC_PER_PARTICLE_STEP * n * FILTERS},
         "log_z": log_z, "log_z_exact": r["log_z_exact"],
     }

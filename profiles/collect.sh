@@ -15,5 +15,11 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $BENCH --no-cpu-baseline --no-extra > "$OUT/fetch.log" 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $BENCH --no-cpu-baseline --no-extra > "$OUT/write.log" 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/sq" -- $BENCH --no-cpu-baseline --no-extra > "$OUT/sq.log" 2>&1 || exit 1
+# HBM traffic of the SMC step kernels (8 filters of 1e6 particles per launch), one counter per pass
+for w in smc_lgssm smc_hmm; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d "$OUT/smc_${w}_$c" -- python3 bench.py --workload $w --no-cpu-baseline --steps 1 --warmup 1 > "$OUT/smc_${w}_$c.log" 2>&1 || exit 1
+  done
+done
 timeout -k 10 300 $BENCH > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err" || exit 1
 tail -c 600 "$OUT/bench_plain.json"
