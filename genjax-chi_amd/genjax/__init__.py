@@ -6,7 +6,7 @@ Public names mirror the `genjax` package of genjax-dev/genjax-chi for that path
 Compute happens in hand-written HIP kernels behind the C-ABI of include/gjx.h; there is no CPU
 fallback (genjax._amd.runtime)."""
 
-from ._amd.choicemap import (ChoiceMap, ChoiceMapBuilder as _CMB, ChoiceMapNoValueAtAddress, Selection,
+from ._amd.choicemap import (ChoiceMap, ChoiceMapBuilder as _CMB, ChoiceMapNoValueAtAddress, Mask, Selection,
                              SelectionBuilder, C as _C)
 from ._amd.lang import (AddressReuse, Distribution, GenerativeFunction, GenerativeFunctionClosure, MissingAddress,
                         StaticGenerativeFunction, Trace, bernoulli, beta, categorical, exact_density, flip, gamma,
@@ -38,7 +38,7 @@ random = _Random()
 
 __all__ = [
     "AddressReuse", "Algorithm", "ChoiceMap", "ChoiceMapBuilder", "ChoiceMapNoValueAtAddress", "Diff", "Distribution",
-    "EditRequest", "NoChange", "NotSupportedEditRequest", "Regenerate", "UnknownChange", "Update", "GenerativeFunction", "GenerativeFunctionClosure", "Marginal", "MissingAddress", "SampleDistribution", "Scan",
+    "EditRequest", "NoChange", "NotSupportedEditRequest", "Regenerate", "UnknownChange", "Update", "GenerativeFunction", "GenerativeFunctionClosure", "Marginal", "Mask", "MissingAddress", "SampleDistribution", "Scan",
     "Selection", "SelectionBuilder", "StaticGenerativeFunction", "Target", "Trace", "bernoulli", "beta",
     "categorical", "exact_density", "flip", "gamma", "gen", "inference", "jaxlike", "marginal", "normal", "random",
     "scan", "Vmap", "vmap",

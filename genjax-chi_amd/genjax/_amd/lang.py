@@ -787,7 +787,9 @@ class Distribution(GenerativeFunction):
         """distribution.py:302-340 (dispatch) and 179-258 (`Update` with a ChoiceMap constraint):
         no value -> the old value is kept and re-scored at the new arguments (weight fwd − bwd, retval
         unchanged, nothing discarded); a value -> it replaces the old one (retval changed, the old choice
-        is the discard).  Masked values (`lax.cond` on a flag) are outside the supported subset."""
+        is the discard).  A `Mask(value, flag)` constraint (distribution.py:214-243: `cond(flag, ...)`) replaces the
+        value where the flag holds and keeps the old one elsewhere — over a population: one select and ONE
+        log-density kernel on the merged column; the discard is the old value under the same flag."""
         from .edit import Diff, NotSupportedEditRequest, Update
 
         if not isinstance(edit_request, Update):
@@ -796,6 +798,26 @@ class Distribution(GenerativeFunction):
         primals = Diff.tree_primal(argdiffs)
         bwd = trace.get_score()
         v = constraint.get_value()
+        if isinstance(v, Mask):
+            if isinstance(v.flag, bool):
+                sub = ChoiceMap.choice(v.value) if v.flag else ChoiceMap.empty()
+                return self.edit(key, trace, Update(sub), argdiffs)
+            old = trace.get_retval()
+            if not isinstance(old, torch.Tensor) or old.dim() == 0:
+                raise ValueError("a per-element mask needs a population trace")
+            n = old.shape[0]
+            flag = v.flag.to(old.device).reshape(-1).bool()
+            if flag.numel() != n:
+                raise ValueError(f"mask flag has {flag.numel()} elements for a population of {n}")
+            new = self._canonical_value(v.value, n)
+            if not isinstance(new, torch.Tensor) or new.dim() == 0:
+                new = torch.zeros_like(old) + new
+            merged = torch.where(flag, new.to(device=old.device, dtype=old.dtype).reshape(-1), old)
+            fwd = self.estimate_logpdf(key, merged, *primals)
+            if batch_size_of(fwd) is None:
+                fwd = torch.zeros_like(bwd) + fwd
+            return (DistributionTrace(self, primals, merged, fwd), fwd - bwd, Diff.unknown_change(merged),
+                    Update(ChoiceMap.choice(Mask(old, flag))))
         if v is None:
             if not constraint.static_is_empty():
                 raise ValueError("constraint for a distribution must be a value (ChoiceMap.choice)")

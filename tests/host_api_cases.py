@@ -281,6 +281,19 @@ def case_update(impl):
               + normal.logpdf(y3c, y1c + 0.25, 1.0) - normal.logpdf(y3c, y1c + y2o, 1.0))
     assert torch.allclose(pw, expect, atol=1e-4)
     assert torch.allclose(pupd.get_score(), ptr.get_score() + pw, atol=1e-4)
+    # a masked constraint (distribution.py:214-243): the value is replaced on SOME particles only
+    from genjax import Mask
+
+    flag = (torch.arange(n, device=y2o.device) % 3) == 0
+    mupd, mw, _, mdisc = ptr.update(keys, C["y2"].set(Mask(torch.full_like(y2o, 0.25), flag)))
+    y2n = mupd.get_choices()["y2"]
+    assert torch.equal(y2n[flag], torch.full_like(y2o, 0.25)[flag]) and torch.equal(y2n[~flag], y2o[~flag])
+    assert torch.equal(mw[~flag], torch.zeros_like(mw)[~flag])  # untouched particles: weight exactly 0
+    assert torch.allclose(mw[flag], pw[flag], atol=1e-5) and torch.allclose(mupd.get_score(), ptr.get_score() + mw, atol=1e-4)
+    dm = mdisc["y2"]
+    assert isinstance(dm, Mask) and torch.equal(dm.flag, flag) and torch.equal(dm.value, y2o)
+    same_tr, w_none, _, _ = ptr.update(keys, C["y2"].set(Mask(torch.full_like(y2o, 0.25), False)))  # a static False flag: no-op
+    assert torch.equal(same_tr.get_choices()["y2"], y2o) and float(torch.as_tensor(w_none).abs().max()) == 0.0
 
     # combinators answer Update by re-generation (scan: test_scan_combinator.py update tests)
     @gen
