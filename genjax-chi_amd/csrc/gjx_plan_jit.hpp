@@ -524,8 +524,16 @@ inline bool compile_to_code(const std::string& src, std::string* code) {
   // GJX_JIT_DEFINE=NAME[=VALUE]: one extra -D for the generated kernel (A/B knob for device-header variants)
   std::string extra_def;
   if (const char* d = std::getenv("GJX_JIT_DEFINE")) extra_def = std::string("-D") + d;
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", extra_def.c_str()};
-  const hiprtcResult r = hiprtcCompileProgram(prog, extra_def.empty() ? 4 : 5, opts);
+  // GJX_JIT_OPTS="opt opt ...": extra compiler options for the generated kernel (scheduling experiments)
+  std::vector<std::string> extra;
+  if (!extra_def.empty()) extra.push_back(extra_def);
+  if (const char* e = std::getenv("GJX_JIT_OPTS")) {
+    std::istringstream is(e);
+    for (std::string t; is >> t;) extra.push_back(t);
+  }
+  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+  for (const std::string& t : extra) opts.push_back(t.c_str());
+  const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (r != HIPRTC_SUCCESS) {
     if (std::getenv("GJX_PLAN_JIT_VERBOSE")) {
       size_t ls = 0;
