@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+RAMP_PASSES = int(os.environ.get("GJX_BENCH_RAMP", "2048"))  # untimed passes before the warm-up (clock ramp, ~35 ms)
 N_PER_GPU = 1_000_000
 # Algorithmic bytes per unit (SURVEY §8d / DESIGN.md §5)
 # SURVEY §8d counts 52 B/particle for the pass (the last 4 are the log-sum-exp's re-read of logw, which the
@@ -41,8 +42,8 @@ BYTES_SMC_PER_PARTICLE_STEP = 44
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=64)  # multiples of the 8 passes per launch: no ragged launch by default
-    p.add_argument("--warmup", type=int, default=8)
+    p.add_argument("--steps", type=int, default=1024)  # multiples of the 8 passes per launch: no ragged launch by default
+    p.add_argument("--warmup", type=int, default=64)
     p.add_argument("--workload", default="importance", choices=["importance", "smc_lgssm", "smc_hmm"])
     p.add_argument("--rng", default="philox", choices=["philox", "threefry"])
     p.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
@@ -111,7 +112,7 @@ def bench_importance(args, ops, rank, world):
     # HIP events are created (and their pool grown) before the timed region
     from genjax._amd.ops import HipEvent
 
-    ev_pool = [(HipEvent(), HipEvent()) for _ in range(args.steps + args.warmup + 8)]
+    ev_pool = [(HipEvent(), HipEvent()) for _ in range(args.steps + 8)]  # (events bracket timed launches only)
 
     # BATCH passes share one log-sum-exp launch (and, sharded, one exchanged block of records): 32 amortises a
     # ~35 us per-batch cost to ~1 us per pass.  LAUNCH independent passes (seeds 0, 1, ...) share one importance
@@ -131,8 +132,8 @@ def bench_importance(args, ops, rank, world):
     def on_launch(phase, count, evs, timed):
         """HIP events around every other importance launch (a barrier packet each: ~2.5 us against ~150 us)."""
         if phase == 0:
-            launch_no[0] += 1
-            if launch_no[0] % 2 == 1:
+            launch_no[0] += 1 if timed else 0  # (every other TIMED launch, the first one included)
+            if timed and launch_no[0] % 2 == 1:
                 evs.append(ev_pool.pop() + (count,))
                 evs[-1][0].record(ops.stream())
             else:
@@ -171,6 +172,11 @@ def bench_importance(args, ops, rank, world):
         _, e_all, q_all = pipe.results(last_buf[0])
         return e_all[:1], q_all[:1], None
 
+    # Clock ramp: the device reaches its sustained clocks only after tens of milliseconds of load (measured on the box:
+    # 120-128 us per launch in the first milliseconds, a dip to ~140 us between ~4 and ~20 ms, 115-119 us from ~30 ms
+    # on), so a fixed untimed run of the same launches precedes the W warm-up steps and the timed region sees the
+    # steady state whatever W and K are.
+    run_steps(max(0, RAMP_PASSES - args.warmup), False)
     run_steps(args.warmup, False)
     # An event record is a barrier packet in the HIP queue; a back-to-back pair with nothing in
     # between measures that fixed cost, which is subtracted from the kernel intervals.
@@ -223,6 +229,7 @@ def bench_importance(args, ops, rank, world):
         "config": {"workload": "ImportanceK k_particles=1e6/GPU on a 10-latent Gaussian model (BASELINE configs[1])",
                    "particles_per_gpu": args.particles, "latent_sites": 10, "observed_sites": 10, "rng": args.rng,
                    "passes_per_launch": LAUNCH, "passes_per_fold": BATCH,
+                   "clock_ramp_passes_before_warmup": max(0, RAMP_PASSES - args.warmup),
                    "parallelism": (f"particle-sharded x{world}, row-aligned; one 520 B all-gather per pass, "
                                    f"bucketed x{BATCH} and overlapped with the next batch") if sharded
                    else "single device"},
@@ -281,10 +288,11 @@ def bench_smc(args, ops, rank, world, kind, filters=0):
     # workgroups, under one round of the machine
     FILTERS = filters if filters else int(os.environ.get("GJX_BENCH_FILTERS", "8"))
     wl = W.LgssmSMC(ops, impl, 1, n, T, filters=FILTERS) if kind == "smc_lgssm" else W.HmmSMC(ops, impl, 2, n, T, filters=FILTERS)
-    for _ in range(max(1, min(args.warmup, 2))):
+    # warm-up long enough for the clock ramp (see bench_importance): ~50 ms of the same launches
+    for _ in range(8 if kind == "smc_lgssm" else 2):
         out = wl.run()
     barrier_sync(world)
-    steps = max(1, min(args.steps, 10))
+    steps = max(1, min(args.steps, 10 if kind == "smc_lgssm" else 3))
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
     for e0, e1 in evs:
@@ -386,7 +394,7 @@ def main():
             extra = {}
             for kind in ("smc_lgssm", "smc_hmm"):
                 a2 = argparse.Namespace(**vars(args))
-                a2.steps, a2.warmup = (5, 1) if kind == "smc_lgssm" else (2, 1)
+                a2.steps, a2.warmup = (10, 1) if kind == "smc_lgssm" else (3, 1)
                 r = bench_smc(a2, ops, rank, world, kind)
                 extra[kind] = {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "log_z", "log_z_exact")}
                 extra[kind]["filters_per_launch"] = r["config"]["filters_per_launch"]

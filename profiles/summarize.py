@@ -60,7 +60,9 @@ bench = json.loads(open(one("bench_plain.json")).read().strip().splitlines()[-1]
 json.dump(bench, open(os.path.join(here, f"{tag}_bench.json"), "w"), indent=1)
 with open(os.path.join(here, f"{tag}_summary.md"), "w") as f:
     f.write(f"# {tag}: rocprofv3 evidence (one MI355X)\n\n")
-    f.write("`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 48 --warmup 8` (collect.sh; every importance launch covers 8 passes)\n\n")
+    f.write("`rocprofv3 --kernel-trace --stats -- python3 bench.py` (collect.sh; defaults: 2048-pass clock ramp, 64 warm-up, 1024 timed "
+            "passes; every importance launch covers 8 passes, so the timed region is the last 128 launches of `gjx_plan_kernel_philox`; "
+            "the first table averages over ALL launches, ramp included)\n\n")
     f.write("| kernel | calls | avg ns | % |\n|---|---|---|---|\n")
     for r in stats:
         f.write(f"| `{r['Name'][:80]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['Percentage']} |\n")
@@ -70,10 +72,12 @@ with open(os.path.join(here, f"{tag}_summary.md"), "w") as f:
     for r in csv.DictReader(open(one("trace/*/*kernel_trace.csv"))):
         name = r["Kernel_Name"]
         if any(k in name for k in ("k_resample", "k_tile_sums", "k_scan_tiles", "gjx_plan_kernel")):
-            by[(name[:80], int(r["Grid_Size_X"]), int(r["VGPR_Count"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    f.write("\n| kernel | grid (threads) | VGPRs | launches | avg ns |\n|---|---|---|---|---|\n")
+            by[(name[:80], int(r["Grid_Size_X"]), int(r["VGPR_Count"]))].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    by = {k: [d for _, d in sorted(v)] for k, v in by.items()}  # chronological
+    f.write("\n| kernel | grid (threads) | VGPRs | launches | avg ns | avg ns, last 128 launches |\n|---|---|---|---|---|---|\n")
     for (name, grid, vg), ts in sorted(by.items(), key=lambda kv: -sum(kv[1])):
-        f.write(f"| `{name}` | {grid} | {vg} | {len(ts)} | {sum(ts) / len(ts):.0f} |\n")
+        tail = ts[-128:]
+        f.write(f"| `{name}` | {grid} | {vg} | {len(ts)} | {sum(ts) / len(ts):.0f} | {sum(tail) / len(tail):.0f} |\n")
     rf = bench["roofline"]
     f.write(f"\nbench.py (un-profiled run): value {bench['value']:.4g} {bench['unit']}, {bench['ms_per_step']*1e3:.1f} us/step; "
             f"dominant kernel `{rf['kernel']}` {rf['kernel_ms']*1e3:.1f} us per launch of {rf.get('passes_per_launch', 1)} passes by HIP events "
