@@ -286,7 +286,7 @@ def bench_smc(args, ops, rank, world, kind, filters=0):
         }
     # FILTERS independent filters (seeds s, s+1, ...) step in the same launches: a 1e6-particle step is ~1000
     # workgroups, under one round of the machine
-    FILTERS = filters if filters else int(os.environ.get("GJX_BENCH_FILTERS", "8"))
+    FILTERS = filters if filters else int(os.environ.get("GJX_BENCH_FILTERS", "16"))
     wl = W.LgssmSMC(ops, impl, 1, n, T, filters=FILTERS) if kind == "smc_lgssm" else W.HmmSMC(ops, impl, 2, n, T, filters=FILTERS)
     # warm-up long enough for the clock ramp (see bench_importance): ~50 ms of the same launches
     for _ in range(8 if kind == "smc_lgssm" else 2):
@@ -306,15 +306,16 @@ def bench_smc(args, ops, rank, world, kind, filters=0):
     per_step_ms = dev_ms / T
     achieved = BYTES_SMC_PER_PARTICLE_STEP * n * FILTERS / (per_step_ms * 1e-3) / 1e9
     log_z = r["log_z"][0] if FILTERS > 1 else r["log_z"]
-    # HBM bytes of one step (k_resample + k_tile_sums) from the PMC passes committed under profiles/ (collected at 8
-    # filters x 1e6 particles per launch; FETCH_SIZE x2 + WRITE_SIZE), scaled to this launch's particles
+    # HBM bytes of one step (k_resample + k_tile_sums) from the PMC passes committed under profiles/ (bytes per
+    # particle-step of the many-filter launches; FETCH_SIZE x2 + WRITE_SIZE), scaled to this launch's particles
     traffic, traffic_src = None, None
     import glob
 
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_smc_pmc.json")), reverse=True):
         try:
             ks = json.load(open(f)).get(kind, {})
-            per = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for k, v in ks.items() if "k_resample" in k or "k_tile_sums" in k) / 8e6
+            per = sum((v["hbm_read_bytes"] + v["hbm_write_bytes"]) / v.get("particles_per_launch", 8e6) for k, v in ks.items()
+                      if "k_resample" in k or "k_tile_sums" in k)
             if per > 0:
                 traffic, traffic_src = per * n * FILTERS, os.path.relpath(f, ROOT)
                 break

@@ -769,7 +769,7 @@ GJX_DEV int block_sum_int(int v, int* sh) {
 // f * tiles + b serves tile b of filter f.  Filter f's particles, tile sums, (max, q) results and keys lie
 // f * stride / f * tiles / f * mq_stride further.  A 1e6-particle step is ~1000 workgroups — under one round
 // of the machine — so a few filters per launch fill it (the large-population rates: 14 -> 11.5 us per 1e6).
-constexpr int kMaxFilters = 8;
+constexpr int kMaxFilters = 16;
 struct FilterBatch {
   uint32_t n_filters = 0;  // <= 1: a single filter (nothing below is read)
   uint32_t tiles = 0;      // tiles per filter

@@ -108,7 +108,7 @@ class BootstrapSMC:
         return SMCResult(ops.log_z_from_pairs(step_max, step_q, self.n), step_max, step_q, state, logw, anc)
 
     def run_many(self, keys) -> list:
-        """`vmap(self.run)(keys)`: one independent filter per key.  Up to 8 filters step in the same kernel launches
+        """`vmap(self.run)(keys)`: one independent filter per key.  Up to 16 filters step in the same kernel launches
         (`gjx_smc_config.n_filters`: a 1e6-particle step alone is under one round of an MI355X), for the hand-written
         models and for generated ones alike; element b equals `self.run(keys[b])` bit for bit."""
         keys = list(keys)
@@ -118,8 +118,8 @@ class BootstrapSMC:
         if isinstance(self.model, StateSpaceModel) and self._plan is None:
             self.run(keys[0])  # builds the plan and the observation matrix
         T = len(self.observations) if self.observations is not None else self._obs.shape[0]
-        for lo in range(0, len(keys), 8):
-            chunk = keys[lo:lo + 8]
+        for lo in range(0, len(keys), 16):
+            chunk = keys[lo:lo + 16]
             if len(chunk) == 1:
                 out.append(self.run(chunk[0]))
                 continue

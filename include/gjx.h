@@ -369,7 +369,7 @@ typedef struct {
   const uint32_t* step_keys;     /* host u32[T,2]: per-step propagate keys (lane 0: fold_in results) */
   const uint32_t* resample_keys; /* host u32[T,2]: per-step resampling keys (entry 0 unused) */
   /* Several independent filters of n_total particles each, stepping in the same launches (the filter vmapped
-   * over keys; whole-run calls gjx_smc_run_lgssm / gjx_smc_run_hmm on one device only; <= 8).  0 or 1: one
+   * over keys; whole-run calls gjx_smc_run_lgssm / gjx_smc_run_hmm on one device only; <= 16).  0 or 1: one
    * filter.  With F = n_filters > 1: step_keys / resample_keys are host u32[F,T,2]; filter f's particles lie
    * f * filter_stride further in state_out / logw_out (dev [F, filter_stride], filter_stride =
    * gjx_num_tiles(n_total) * gjx_smc_tile()), its results in out_max / out_q dev [F, T], its ancestors in

@@ -1070,7 +1070,7 @@ static int smc_run_filters(const gjx_smc_config* cfg, int kind, const void* mode
   if (cfg->n_filters <= 1) return smc_run_common(cfg, kind, model, y, out_max, out_q, state_out, logw_out, ancestors_out);
   const int F = cfg->n_filters, T = cfg->n_steps;
   const uint64_t N = cfg->n_total, stride = cfg->filter_stride;
-  if (F > 8 || stride < N) return GJX_ERR_INVALID;
+  if (F > 16 || stride < N) return GJX_ERR_INVALID;
   int32_t* anc1 = ancestors_out ? (int32_t*)malloc(sizeof(int32_t) * (size_t)T * N) : NULL;
   int rc = GJX_OK;
   for (int f = 0; f < F && !rc; ++f) {
@@ -1247,7 +1247,7 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
   if (cfg->n_filters <= 1) return smc_run_plan_one(cfg, plan, obs_host, out_max, out_q, state_out, logw_out, ancestors_out);
   const int F = cfg->n_filters, T = cfg->n_steps, D = plan->m.n_state;
   const uint64_t N = cfg->n_total, stride = cfg->filter_stride;
-  if (F > 8 || stride < N) return GJX_ERR_INVALID;
+  if (F > 16 || stride < N) return GJX_ERR_INVALID;
   int32_t* anc1 = ancestors_out ? (int32_t*)malloc(sizeof(int32_t) * (size_t)T * N) : NULL;
   int rc = GJX_OK;
   for (int f = 0; f < F && !rc; ++f) {

@@ -96,22 +96,26 @@ for w in ("smc_lgssm", "smc_hmm"):
         if not files:
             continue
         acc = collections.defaultdict(list)
-        for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
-            if int(r["Grid_Size"]) == 8 * 977 * 256:  # the 8-filter launches
+        rows = list(csv.DictReader(open(max(files, key=os.path.getmtime))))
+        big = max(int(r["Grid_Size"]) for r in rows if "k_resample" in r["Kernel_Name"])  # the many-filter launches
+        for r in rows:
+            if int(r["Grid_Size"]) == big:
                 acc[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             per[k][c] = sum(v) / len(v) * 1024 * (2 if c == "FETCH_SIZE" else 1)
+            per[k]["particles_per_launch"] = big * 4  # 256 threads per 1024-particle tile
     if per:
-        smc[w] = {k: {"hbm_read_bytes": v.get("FETCH_SIZE", 0.0), "hbm_write_bytes": v.get("WRITE_SIZE", 0.0)} for k, v in per.items()}
+        smc[w] = {k: {"hbm_read_bytes": v.get("FETCH_SIZE", 0.0), "hbm_write_bytes": v.get("WRITE_SIZE", 0.0),
+                      "particles_per_launch": v["particles_per_launch"]} for k, v in per.items()}
 if smc:
     json.dump(smc, open(os.path.join(here, f"{tag}_smc_pmc.json"), "w"), indent=1)
     with open(os.path.join(here, f"{tag}_summary.md"), "a") as f:
-        f.write("\nHBM traffic of the SMC step kernels per launch of 8 filters x 1e6 particles (PMC; FETCH_SIZE x2), bytes per particle-step:\n\n")
+        f.write("\nHBM traffic of the SMC step kernels (launches of 16 filters x 1e6 particles; PMC; FETCH_SIZE x2), bytes per particle-step:\n\n")
         f.write("| workload | kernel | read B | write B |\n|---|---|---|---|\n")
         for w, ks in smc.items():
             for k, v in ks.items():
                 if "k_resample" in k or "k_tile_sums" in k:
-                    f.write(f"| {w} | `{k}` | {v['hbm_read_bytes'] / 8e6:.2f} | {v['hbm_write_bytes'] / 8e6:.2f} |\n")
+                    f.write(f"| {w} | `{k}` | {v['hbm_read_bytes'] / v['particles_per_launch']:.2f} | {v['hbm_write_bytes'] / v['particles_per_launch']:.2f} |\n")
         f.write("\n(SURVEY §8d counts 44 algorithmic bytes per particle-step for an unfused step; the fused step moves ~20: "
                 "state + log-weights read and written once, log-weights read once more for the tile masses.)\n")
 print(open(os.path.join(here, f"{tag}_summary.md")).read())

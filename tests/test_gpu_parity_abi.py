@@ -453,7 +453,7 @@ def _smc_plans(ops):
 def test_smc_filters_in_one_launch(hip_ops, oracle_ops, impl, kind, n, T):
     """gjx_smc_config.n_filters: F independent filters (seeds s, s+1, ...) stepping in the same launches equal
     F separate runs bit for bit — per-step (max, q), final particles and weights, ancestors — on both backends."""
-    F = 3
+    F = 3 if n > 2000 else 16  # (16 = the most filters one launch takes)
     mk = (lambda ops, f, seed: W.LgssmSMC(ops, impl, seed, n, T, want_ancestors=True, filters=f)) if kind == "lgssm" else (
         lambda ops, f, seed: W.HmmSMC(ops, impl, seed, n, T, n_states=16, want_ancestors=True, filters=f))
     hb = mk(hip_ops, F, 7)
@@ -528,7 +528,7 @@ def test_full_size_properties(hip_ops):
 
 
 def test_full_size_batches(hip_ops):
-    """The benchmark's launches at full size: 8 independent 1e6-particle ImportanceK passes in one launch and 8
+    """The benchmark's launches at full size: 8 independent 1e6-particle ImportanceK passes in one launch and 16
     bootstrap filters (T = 20) in the same launches.  Every pass / filter has its own seed: the estimates differ,
     each agrees with the float64 log-sum-exp of its own log-weights, and their spread around the closed form is
     the Monte-Carlo error of one estimate."""
@@ -549,8 +549,8 @@ def test_full_size_batches(hip_ops):
     # sides are noisy (8 estimates; heavy-tailed weights in 10 dimensions): same order of magnitude is the claim
     w = torch.exp(prep.logw_all[0, :n].double() - zs[0])
     assert 0.2 < float(w.std() / np.sqrt(n)) / err.std() < 5.0, (float(w.std() / np.sqrt(n)), err.std())
-    f = W.LgssmSMC(hip_ops, 1, 200, n, 20, filters=8)
+    f = W.LgssmSMC(hip_ops, 1, 200, n, 20, filters=16)
     r = f.result(f.run())
     zf = np.array(r["log_z"])
-    assert len({round(z, 9) for z in zf}) == 8
+    assert len({round(z, 9) for z in zf}) == 16
     assert abs(zf.mean() - W.lgssm_exact_log_z(f.y)) < 0.1 and zf.std() < 0.1, (zf, W.lgssm_exact_log_z(f.y))
