@@ -98,8 +98,11 @@ for w in ("smc_lgssm", "smc_hmm"):
         acc = collections.defaultdict(list)
         rows = list(csv.DictReader(open(max(files, key=os.path.getmtime))))
         big = max(int(r["Grid_Size"]) for r in rows if "k_resample" in r["Kernel_Name"])  # the many-filter launches
+        top = {}  # every kernel's own largest grid = its many-filter launches (k_tile_sums_wave runs a wave per tile)
         for r in rows:
-            if int(r["Grid_Size"]) == big:
+            top[r["Kernel_Name"]] = max(top.get(r["Kernel_Name"], 0), int(r["Grid_Size"]))
+        for r in rows:
+            if int(r["Grid_Size"]) == top[r["Kernel_Name"]] and ("k_resample" in r["Kernel_Name"] or "k_tile_sums_wave" in r["Kernel_Name"]):
                 acc[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             per[k][c] = sum(v) / len(v) * 1024 * (2 if c == "FETCH_SIZE" else 1)
