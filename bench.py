@@ -5,14 +5,22 @@
                   [--rng philox|threefry] [--no-cpu-baseline] [--no-extra]
 
 A "step" is one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
-  importance (default, BASELINE configs[1]): ImportanceK on the 10-latent Gaussian model, 1e6
-      particles per GPU: fused `@gen`-body kernel (RNG -> samplers -> SoA trace columns -> score,
-      log-weights, per-tile max) + fixed-point log-sum-exp.  value = particles/s.
-  smc_lgssm (configs[2]): bootstrap SMC, T=100, 1e6 particles per GPU.  value = particle-steps/s.
-  smc_hmm   (configs[4]): 256-state HMM, T=500.
-For N>1 (launched by torch.distributed.run, one rank per GPU) the particle population is sharded
-(weak scaling); importance exchanges one 520-byte record per pass (all-gather, bucketed and overlapped).
-Rank 0 prints ONE JSON line.
+  importance (default, BASELINE configs[1]): ImportanceK on the 10-latent Gaussian model, 1e6 particles per
+      GPU: fused `@gen`-body kernel (RNG -> samplers -> SoA trace columns -> score, log-weights, row sums) +
+      the fold of the row sums into the log-marginal.  value = particles/s.
+  smc_lgssm (configs[2]): bootstrap SMC, T=100, ONE filter of 1e6 particles.  value = particle-steps/s.
+  smc_hmm   (configs[4]): 256-state HMM, T=500, ONE filter of 1e6 particles.
+
+Protocol: W untimed warm-up steps, then a block of EXACTLY K steps bracketed by barrier + synchronize on both
+sides (max over ranks).  A K-step block of a 18 us step is far too short to carry a number, so the block is
+repeated (each repetition bracketed the same way) until at least 50 ms and 5 blocks have been timed; `value`
+and `ms_per_step` are the MEDIAN block, `timed_blocks` / `block_ms_{min,median,max}` report the rest.  The
+dominant kernel is sampled with HIP events on the launch stream over all timed blocks (>= 20 samples; median).
+
+`--gpus N` with N > 1: launched by `torch.distributed.run` (RANK / WORLD_SIZE in the environment) this process
+is one rank; launched plainly it is the PARENT, which starts N rank processes before any GPU call, never touches
+the GPU itself, and exits with their worst status.  Rank 0 prints ONE JSON line.  The N > 1 line carries the
+sharded ImportanceK headline and `extra.smc_lgssm_sharded` (BASELINE configs[3]: 1e6 particles per GPU).
 """
 
 from __future__ import annotations
@@ -20,6 +28,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,22 +37,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "genjax-chi_amd"))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 RAMP_PASSES = int(os.environ.get("GJX_BENCH_RAMP", "2048"))  # untimed passes before the warm-up (clock ramp, ~35 ms)
 N_PER_GPU = 1_000_000
-# Algorithmic bytes per unit (SURVEY §8d / DESIGN.md §5)
-# SURVEY §8d counts 52 B/particle for the pass (the last 4 are the log-sum-exp's re-read of logw, which the
-# fused row-anchored partial sums made unnecessary); the dominant kernel's algorithmic share:
+MIN_TIMED_S = float(os.environ.get("GJX_BENCH_MIN_S", "0.05"))
+# Algorithmic bytes per unit (SURVEY §8d / DESIGN.md §5).  SURVEY counts 52 B/particle for the pass (the last 4 are
+# the log-sum-exp's re-read of logw, which the fused row-anchored partial sums made unnecessary).
 BYTES_IMPORTANCE_KERNEL_PER_PARTICLE = 48  # 10 latent columns + score + logw written
-BYTES_SMC_PER_PARTICLE_STEP = 44
+BYTES_SMC_PER_PARTICLE_STEP = 44  # SURVEY §8d contract figure of the UNFUSED pipeline (the fused step moves ~20)
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=1024)  # multiples of the 8 passes per launch: no ragged launch by default
+    p.add_argument("--steps", type=int, default=1024)
     p.add_argument("--warmup", type=int, default=64)
     p.add_argument("--workload", default="importance", choices=["importance", "smc_lgssm", "smc_hmm"])
     p.add_argument("--rng", default="philox", choices=["philox", "threefry"])
@@ -55,10 +63,44 @@ def parse():
 FORCE_DIST = bool(os.environ.get("GJX_BENCH_FORCE_DIST"))  # exercise the N>1 code path with one rank
 
 
+# ------------------------------------------------------------------------------------------------------------
+# process layout
+# ------------------------------------------------------------------------------------------------------------
+def parent_launch(args) -> int:
+    """`python bench.py --gpus N` started plainly: start N rank processes (one per GPU) and wait.  The parent
+    makes no GPU call (counting devices does not initialise the runtime on this image)."""
+    import socket
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s); refusing to print a "
+              f"line for fewer ranks than asked", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def init_dist(n_gpus):
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n_gpus:
+        print(f"bench.py: --gpus {n_gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     if world > 1 or FORCE_DIST:
         import torch.distributed as dist
 
@@ -67,13 +109,14 @@ def init_dist(n_gpus):
         os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
     else:
         torch.cuda.set_device(0)
     return rank, world
 
 
 def barrier_sync(world):
+    import torch
+
     if world > 1 or FORCE_DIST:
         import torch.distributed as dist
 
@@ -84,6 +127,7 @@ def barrier_sync(world):
 def max_over_ranks(seconds, world):
     if world == 1 and not FORCE_DIST:
         return seconds
+    import torch
     import torch.distributed as dist
 
     t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
@@ -91,12 +135,53 @@ def max_over_ranks(seconds, world):
     return float(t.item())
 
 
-def bench_importance(args, ops, rank, world):
-    import torch.distributed as dist
+def timed_blocks(run_block, world, min_s=MIN_TIMED_S, min_blocks=5, max_blocks=2000):
+    """Repeat `run_block()` (EXACTLY the K steps of the protocol), each repetition bracketed by barrier +
+    synchronize on both sides; the duration of a block is the max over ranks (the same number on every rank, so
+    all ranks stop together).  Returns the list of block durations in seconds and the last block's result."""
+    blocks, out = [], None
+    while True:
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        out = run_block()
+        barrier_sync(world)
+        blocks.append(max_over_ranks(time.perf_counter() - t0, world))
+        if (sum(blocks) >= min_s and len(blocks) >= min_blocks) or len(blocks) >= max_blocks:
+            return blocks, out
 
+
+def block_stats(blocks):
+    return {"timed_blocks": len(blocks), "block_ms_min": min(blocks) * 1e3, "block_ms_median": statistics.median(blocks) * 1e3,
+            "block_ms_max": max(blocks) * 1e3}
+
+
+def pmc_traffic(pattern: str, pick):
+    """HBM bytes from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, collected by
+    profiles/collect.sh on this same command) — newest round first; (None, None) if nothing matches."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            v = pick(json.load(open(f)))
+            if v:
+                return v, os.path.relpath(f, ROOT)
+        except Exception:
+            pass
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------------------
+# ImportanceK (BASELINE configs[1])
+# ------------------------------------------------------------------------------------------------------------
+def bench_importance(args, ops, rank, world, launch_passes=None, rng=None, steps=None, warmup=None, ramp=True,
+                     min_s=MIN_TIMED_S, fast_math=False):
     from genjax._amd import workloads as W
+    from genjax._amd.ops import HipEvent
 
-    impl = 1 if args.rng == "philox" else 0
+    rng = rng or args.rng
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    impl = 1 if rng == "philox" else 0
     sharded = world > 1 or FORCE_DIST
     total_particles = args.particles * world
     if sharded:
@@ -107,18 +192,12 @@ def bench_importance(args, ops, rank, world):
         first, n = gdist.shard_rows(total_particles, rank, world)
     else:
         first, n = 0, args.particles
-    wl = W.Gaussian10(ops, impl, seed=0, n_local=n, first=first, n_total=total_particles)
-    kernel_ms = []
-    # HIP events are created (and their pool grown) before the timed region
-    from genjax._amd.ops import HipEvent
-
-    ev_pool = [(HipEvent(), HipEvent()) for _ in range(args.steps + 8)]  # (events bracket timed launches only)
-
-    # BATCH passes share one log-sum-exp launch (and, sharded, one exchanged block of records): 32 amortises a
-    # ~35 us per-batch cost to ~1 us per pass.  LAUNCH independent passes (seeds 0, 1, ...) share one importance
-    # launch: a single 1e6-particle pass is under two rounds of the machine (21.5 us), eight keep it full
-    # (17.5 us per pass).  Persistent output buffers + pre-marshalled C calls: no host allocation per step.
-    LAUNCH = int(os.environ.get("GJX_BENCH_LAUNCH", "8"))
+    wl = W.Gaussian10(ops, impl, seed=0, n_local=n, first=first, n_total=total_particles, fast_math=fast_math)
+    # BATCH passes share one fold launch (and, sharded, one exchanged block of records): 32 amortises a ~35 us
+    # per-batch cost to ~1 us per pass.  LAUNCH independent passes (seeds 0, 1, ...) share one importance launch: a
+    # single 1e6-particle pass is under two rounds of the machine, eight keep it full.  Persistent output buffers +
+    # pre-marshalled C calls: no host allocation per step.
+    LAUNCH = launch_passes if launch_passes else int(os.environ.get("GJX_BENCH_LAUNCH", "8"))
     BATCH = int(os.environ.get("GJX_BENCH_BATCH", "32")) // LAUNCH * LAUNCH or LAUNCH
     prep = wl.prepare(fold_batch=BATCH, passes=LAUNCH)
     if sharded:
@@ -126,22 +205,23 @@ def bench_importance(args, ops, rank, world):
         # passes overlaps with the next batch's kernels (genjax/_amd/dist.py)
         pipe = gdist.BatchedImportance(ops, wl, batch=BATCH, world=world, always_exchange=True, passes=LAUNCH)
     last_buf = [0]
-
+    # HIP events (created before anything is timed) bracket every SAMPLE_EVERY-th timed launch on the launch stream
+    ev_pool = [(HipEvent(), HipEvent()) for _ in range(256)]
+    samples = []  # (start, stop, passes in the launch)
     launch_no = [0]
+    SAMPLE_EVERY = 3
 
     def on_launch(phase, count, evs, timed):
-        """HIP events around every fourth importance launch (a barrier packet each: ~2.5 us against ~120 us)."""
         if phase == 0:
-            launch_no[0] += 1 if timed else 0  # (every fourth TIMED launch, the first one included)
-            if timed and launch_no[0] % 4 == 1:
+            launch_no[0] += 1 if timed else 0
+            if timed and ev_pool and launch_no[0] % SAMPLE_EVERY == 1:
                 evs.append(ev_pool.pop() + (count,))
                 evs[-1][0].record(ops.stream())
             else:
                 evs.append(None)
         elif evs[-1] is not None:
             evs[-1][1].record(ops.stream())
-            if timed:
-                kernel_ms.append(evs[-1])
+            samples.append(evs[-1])
 
     def run_batch(count, timed):
         """`count` (<= BATCH) passes: ceil(count / LAUNCH) importance launches + one fold launch."""
@@ -167,221 +247,407 @@ def bench_importance(args, ops, rank, world):
             run_batch(c, timed)
             done += c
         if not sharded:
-            return prep.e_all[:1], prep.q_all[:1], prep.logw
+            return prep.e_all[:1], prep.q_all[:1]
         pipe.wait()  # every exchange has landed (stream-ordered; the host does not block)
         _, e_all, q_all = pipe.results(last_buf[0])
-        return e_all[:1], q_all[:1], None
+        return e_all[:1], q_all[:1]
 
-    # Clock ramp: the device reaches its sustained clocks only after tens of milliseconds of load (measured on the box:
-    # 120-128 us per launch in the first milliseconds, a dip to ~140 us between ~4 and ~20 ms, 115-119 us from ~30 ms
-    # on), so a fixed untimed run of the same launches precedes the W warm-up steps and the timed region sees the
-    # steady state whatever W and K are.
-    run_steps(max(0, RAMP_PASSES - args.warmup), False)
-    run_steps(args.warmup, False)
-    # An event record is a barrier packet in the HIP queue; a back-to-back pair with nothing in
-    # between measures that fixed cost, which is subtracted from the kernel intervals.
+    # Clock ramp: the device reaches its sustained clocks only after tens of milliseconds of load, so a fixed untimed
+    # run of the same launches precedes the W warm-up steps (GJX_BENCH_RAMP=0 turns it off).
+    if ramp:
+        run_steps(max(0, RAMP_PASSES - warmup), False)
+    run_steps(warmup, False)
+    # An event record is a barrier packet in the HIP queue; a back-to-back pair with nothing in between measures
+    # that fixed cost, which is subtracted from the kernel intervals.
     cal = [(HipEvent(), HipEvent()) for _ in range(16)]
-    sh_cal = ops.stream()
     for a, b in cal:
-        a.record(sh_cal)
-        b.record(sh_cal)
+        a.record(ops.stream())
+        b.record(ops.stream())
     barrier_sync(world)
-    ev_overhead_ms = sorted(a.elapsed_ms(b) for a, b in cal)[len(cal) // 2]
-    t0 = time.perf_counter()
-    m, q, logw = run_steps(args.steps, True)  # EXACTLY args.steps passes
-    t_loop = time.perf_counter() - t0
-    barrier_sync(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world)
-    host_ts = [t_loop / args.steps]
-    if os.environ.get("GJX_BENCH_DEBUG"):
-        print("host per-step ms:", ["%.3f" % (x * 1e3) for x in host_ts], "loop", t_loop * 1e3, "total", dt * 1e3,
-              file=sys.stderr)
+    ev_overhead_ms = statistics.median(a.elapsed_ms(b) for a, b in cal)
+    blocks, (e, q) = timed_blocks(lambda: run_steps(steps, True), world, min_s=min_s)  # each block: EXACTLY `steps` passes
+    dt = statistics.median(blocks)
     # the dominant kernel: launches of `c` passes each; full launches (c == LAUNCH) define the quoted duration
-    full = [(a, b, c) for a, b, c in kernel_ms if c == LAUNCH] or kernel_ms
-    k_ms_raw = sum(a.elapsed_ms(b) for a, b, _ in full) / len(full)
+    full = [(a, b, c) for a, b, c in samples if c == min(LAUNCH, steps)] or samples
+    raw = sorted(a.elapsed_ms(b) for a, b, _ in full)
+    k_ms_raw = statistics.median(raw)
     k_ms = max(k_ms_raw - ev_overhead_ms, 1e-6)
     passes_per_launch = full[0][2]
-    ms_per_step = dt / args.steps * 1e3
-    log_z = ops.log_z_from_rows(m, q, total_particles)  # exact (anchor, fixed-point sum) pair of pass 0
+    log_z = ops.log_z_from_rows(e, q, total_particles)  # exact (anchor, fixed-point sum) pair of pass 0
     bytes_per_launch = BYTES_IMPORTANCE_KERNEL_PER_PARTICLE * n * passes_per_launch
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
-    # collected by profiles/collect.sh on this same command); null if none matches this kernel/size.
-    traffic, traffic_src = None, None
+    traffic, traffic_src = (None, None)
     if n == N_PER_GPU:
-        import glob
-
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
-            try:
-                pj = json.load(open(f))
-                if f"gjx_plan_kernel_{args.rng}" in pj.get("kernel", ""):
-                    # the PMC figure is per 1e6-particle pass; a launch of several passes moves that many times it
-                    per_pass = pj.get("hbm_bytes_per_pass", pj["hbm_bytes_per_launch"] / max(1, pj.get("passes_per_launch", 1)))
-                    traffic, traffic_src = per_pass * passes_per_launch, os.path.relpath(f, ROOT)
-                    break
-            except Exception:
-                pass
+        per_pass, traffic_src = pmc_traffic(
+            "r*_pmc.json", lambda pj: pj.get("hbm_bytes_per_pass") if f"gjx_plan_kernel_{rng}" in pj.get("kernel", "") else None)
+        traffic = per_pass * passes_per_launch if per_pass else None
     res = {
         "metric": "particles/sec, ImportanceK log-marginal-likelihood estimate (1e6 particles per GPU)",
-        "value": total_particles / (dt / args.steps),
+        "value": total_particles * steps / dt,
         "unit": "particles/s",
-        "ms_per_step": ms_per_step,
+        "ms_per_step": dt / steps * 1e3,
         "config": {"workload": "ImportanceK k_particles=1e6/GPU on a 10-latent Gaussian model (BASELINE configs[1])",
-                   "particles_per_gpu": args.particles, "latent_sites": 10, "observed_sites": 10, "rng": args.rng,
+                   "particles_per_gpu": args.particles, "latent_sites": 10, "observed_sites": 10, "rng": rng,
+                   "math": "fast (hardware log/exp/sqrt/sin/cos, 1e-5 rel)" if fast_math else "bit-exact spec",
                    "passes_per_launch": LAUNCH, "passes_per_fold": BATCH,
-                   "clock_ramp_passes_before_warmup": max(0, RAMP_PASSES - args.warmup),
+                   "clock_ramp_passes_before_warmup": max(0, RAMP_PASSES - warmup) if ramp else 0,
                    "parallelism": (f"particle-sharded x{world}, row-aligned; one 520 B all-gather per pass, "
                                    f"bucketed x{BATCH} and overlapped with the next batch") if sharded
                    else "single device"},
-        "roofline": {"bound": "hbm", "kernel": f"gjx_plan_kernel_{args.rng}", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": f"gjx_plan_kernel_{rng}", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel_ms": k_ms, "kernel_ms_raw_event_interval": k_ms_raw,
-                     "event_pair_overhead_ms": ev_overhead_ms, "kernel_launches_timed": len(full),
+                     "kernel_ms": k_ms, "kernel_ms_raw_event_interval": k_ms_raw, "kernel_ms_min": max(raw[0] - ev_overhead_ms, 0.0),
+                     "event_pair_overhead_ms": ev_overhead_ms, "kernel_launches_timed": len(full), "statistic": "median",
                      "passes_per_launch": passes_per_launch, "kernel_ms_per_pass": k_ms / passes_per_launch,
-                     "algorithmic_bytes_per_launch": bytes_per_launch},
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "limiter": "VALU issue / dependency latency (samplers), not HBM: PMC traffic == algorithmic bytes"},
         "log_z": log_z,
         "log_z_exact": W.gaussian10_exact_log_z(wl.y),
     }
+    res.update(block_stats(blocks))
     return res, wl
 
 
-def bench_smc(args, ops, rank, world, kind, filters=0):
+# ------------------------------------------------------------------------------------------------------------
+# bootstrap SMC (BASELINE configs[2], [4]; sharded: configs[3])
+# ------------------------------------------------------------------------------------------------------------
+def bench_smc_sharded(args, ops, rank, world, kind):
+    from genjax._amd import dist as gdist
+
+    impl = 1 if args.rng == "philox" else 0
+    T = 100 if kind == "smc_lgssm" else 500
+    n = -(-args.particles // ops.tile) * ops.tile  # the sharded filter exchanges whole 1024-particle tiles
+    n_total = n * world
+    exchange = os.environ.get("GJX_BENCH_SHUFFLE", "ranges")
+    smc = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world, exchange=exchange)
+    smc.run()  # warm-up (also builds any generated kernels)
+    smc.received = 0
+    runs = [0]
+
+    def one_run():
+        runs[0] += 1
+        return smc.run()
+
+    blocks, r = timed_blocks(one_run, world, min_s=0.05, min_blocks=3, max_blocks=5)
+    dt = statistics.median(blocks)
+    per_step_ms = dt * 1e3 / T
+    achieved = BYTES_SMC_PER_PARTICLE_STEP * n / (per_step_ms * 1e-3) / 1e9
+    shuffle = ("ancestor shuffle = grouped send/recv of each rank's contiguous source range (all-to-all-v, in place)"
+               if exchange == "ranges" else "all-gather of particles and weights")
+    res = {
+        "metric": "particle-steps/sec, bootstrap SMC (1e6 particles per GPU)",
+        "value": n_total * T / dt, "unit": "particle-steps/s", "ms_per_step": dt * 1e3,
+        "config": {"workload": f"bootstrap SMC {kind} T={T} N={n_total} sharded x{world} (BASELINE configs[3] at world=8)",
+                   "rng": args.rng,
+                   "parallelism": f"particle-sharded x{world}: all-reduce(max) + all-gather of tile masses + {shuffle}",
+                   "particles_received_per_rank_step": r["received"] / runs[0] / max(1, T - 1)},
+        "roofline": {"bound": "hbm", "kernel": "one SMC step incl. exchange", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "step_ms": per_step_ms, "algorithmic_bytes_per_launch": BYTES_SMC_PER_PARTICLE_STEP * n,
+                     "limiter": "host-mediated exchange (3 small collectives per step), not HBM"},
+        "log_z": r["log_z"], "log_z_exact": r["log_z_exact"],
+    }
+    res.update(block_stats(blocks))
+    return res
+
+
+def bench_smc(args, ops, kind, filters=1, min_s=0.08, variant=None):
+    """Single device: `filters` independent filters (seeds s, s+1, ...) step in the same launches; filters=1 is
+    the literal BASELINE config.  A "step" of the protocol here is one whole T-step filter run (one enqueue)."""
+    import torch
+
     from genjax._amd import workloads as W
+    from genjax._amd.ops import HipEvent
 
     impl = 1 if args.rng == "philox" else 0
     n = args.particles
     T = 100 if kind == "smc_lgssm" else 500
-    if world > 1 or FORCE_DIST:
-        from genjax._amd import dist as gdist
-
-        # the sharded filter exchanges whole 1024-particle tiles: round the per-GPU population up
-        n = -(-n // ops.tile) * ops.tile
-        n_total = n * world
-        exchange = os.environ.get("GJX_BENCH_SHUFFLE", "ranges")
-        smc = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world,
-                               exchange=exchange)
-        smc.run()
-        barrier_sync(world)
-        steps = max(1, min(args.steps, 5))
-        smc.received = 0
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            r = smc.run()
-        barrier_sync(world)
-        dt = max_over_ranks((time.perf_counter() - t0) / steps, world)
-        per_step_ms = dt * 1e3 / T
-        achieved = BYTES_SMC_PER_PARTICLE_STEP * n / (per_step_ms * 1e-3) / 1e9
-        shuffle = ("ancestor shuffle = grouped send/recv of each rank's contiguous source range (all-to-all-v, in place)"
-                   if exchange == "ranges" else "all-gather of particles and weights")
-        return {
-            "metric": "particle-steps/sec, bootstrap SMC (1e6 particles per GPU)",
-            "value": n_total * T / dt, "unit": "particle-steps/s", "ms_per_step": dt * 1e3,
-            "config": {"workload": f"bootstrap SMC {kind} T={T} N={n_total} sharded x{world}", "rng": args.rng,
-                       "parallelism": f"particle-sharded x{world}: all-reduce(max) + all-gather of tile masses + {shuffle}",
-                       "particles_received_per_rank_step": r["received"] / steps / max(1, T - 1)},
-            "roofline": {"bound": "hbm", "kernel": "one SMC step incl. exchange", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "step_ms": per_step_ms, "algorithmic_bytes_per_launch": BYTES_SMC_PER_PARTICLE_STEP * n},
-            "log_z": r["log_z"], "log_z_exact": r["log_z_exact"],
-        }
-    # FILTERS independent filters (seeds s, s+1, ...) step in the same launches: a 1e6-particle step is ~1000
-    # workgroups, under one round of the machine
-    FILTERS = filters if filters else int(os.environ.get("GJX_BENCH_FILTERS", "16"))
-    wl = W.LgssmSMC(ops, impl, 1, n, T, filters=FILTERS) if kind == "smc_lgssm" else W.HmmSMC(ops, impl, 2, n, T, filters=FILTERS)
+    kw = dict(filters=filters)
+    if variant:
+        kw.update(variant)
+    wl = W.LgssmSMC(ops, impl, 1, n, T, **kw) if kind == "smc_lgssm" else W.HmmSMC(ops, impl, 2, n, T, **kw)
     # warm-up long enough for the clock ramp (see bench_importance): ~50 ms of the same launches
-    for _ in range(8 if kind == "smc_lgssm" else 2):
-        out = wl.run()
-    barrier_sync(world)
-    steps = max(1, min(args.steps, 10 if kind == "smc_lgssm" else 3))
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record()
-        out = wl.run()  # enqueue only: data, keys and tables were prepared above
-        e1.record()
-    barrier_sync(world)
-    dt = (time.perf_counter() - t0) / steps
+    out = wl.run()
+    torch.cuda.synchronize()
+    while time.perf_counter() - t0 < 0.05:
+        out = wl.run()
+        torch.cuda.synchronize()
+    evs = []
+
+    def one_run():
+        e0, e1 = HipEvent(), HipEvent()
+        e0.record(ops.stream())
+        o = wl.run()  # enqueue only: data, keys and tables were prepared above
+        e1.record(ops.stream())
+        evs.append((e0, e1))
+        return o
+
+    blocks, out = timed_blocks(one_run, 1, min_s=min_s, min_blocks=5, max_blocks=40)
     r = wl.result(out)
-    dev_ms = sum(a.elapsed_time(b) for a, b in evs) / steps
+    dev_ms = statistics.median(a.elapsed_ms(b) for a, b in evs)
+    dt = statistics.median(blocks)
     per_step_ms = dev_ms / T
-    achieved = BYTES_SMC_PER_PARTICLE_STEP * n * FILTERS / (per_step_ms * 1e-3) / 1e9
-    log_z = r["log_z"][0] if FILTERS > 1 else r["log_z"]
-    # HBM bytes of one step (k_resample + k_tile_sums) from the PMC passes committed under profiles/ (bytes per
-    # particle-step of the many-filter launches; FETCH_SIZE x2 + WRITE_SIZE), scaled to this launch's particles
-    traffic, traffic_src = None, None
-    import glob
-
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_smc_pmc.json")), reverse=True):
-        try:
-            ks = json.load(open(f)).get(kind, {})
-            per = sum((v["hbm_read_bytes"] + v["hbm_write_bytes"]) / v.get("particles_per_launch", 8e6) for k, v in ks.items()
-                      if "k_resample" in k or "k_tile_sums" in k)
-            if per > 0:
-                traffic, traffic_src = per * n * FILTERS, os.path.relpath(f, ROOT)
-                break
-        except Exception:
-            pass
-    return {
-        "metric": "particle-steps/sec, bootstrap SMC (1e6 particles per GPU)",
-        "value": n * T * FILTERS / dt,
-        "unit": "particle-steps/s",
-        "ms_per_step": dt * 1e3,
-        "config": {"workload": f"bootstrap SMC {kind} T={T} N={n}", "rng": args.rng, "filters_per_launch": FILTERS},
-        "roofline": {"bound": "hbm", "kernel": "k_resample+k_tile_sums (one SMC step of every filter)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": traffic_src, "step_ms": per_step_ms, "step_ms_per_filter": per_step_ms / FILTERS,
-                     "algorithmic_bytes_per_launch": BYTES_SMC_PER_PARTICLE_STEP * n * FILTERS},
-        "log_z": log_z, "log_z_exact": r["log_z_exact"],
+    achieved = BYTES_SMC_PER_PARTICLE_STEP * n * filters / (per_step_ms * 1e-3) / 1e9
+    log_z = r["log_z"][0] if filters > 1 else r["log_z"]
+    # HBM bytes of one step from the PMC passes committed under profiles/ (bytes per particle-step; FETCH_SIZE x2 + WRITE_SIZE)
+    per, traffic_src = pmc_traffic(
+        "r*_smc_pmc.json",
+        lambda pj: sum((v["hbm_read_bytes"] + v["hbm_write_bytes"]) / v.get("particles_per_launch", 8e6)
+                       for k, v in pj.get(kind, {}).items() if "k_resample" in k or "k_tile_sums" in k))
+    traffic = per * n * filters if per else None
+    res = {
+        "metric": "particle-steps/sec, bootstrap SMC (1e6 particles)",
+        "value": n * T * filters / dt, "unit": "particle-steps/s", "ms_per_step": dt * 1e3,
+        "config": {"workload": f"bootstrap SMC {kind} T={T} N={n}, systematic resampling every step"
+                               + (" (BASELINE configs[2])" if kind == "smc_lgssm" else " (BASELINE configs[4])"),
+                   "rng": args.rng, "filters_per_launch": filters, **({"variant": variant} if variant else {})},
+        "roofline": {"bound": "hbm", "kernel": "k_resample + k_tile_sums (one SMC step" + (" of every filter)" if filters > 1 else ")"),
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "frac_basis": "44 B/particle-step contract figure of the unfused pipeline (SURVEY 8d)",
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "frac_of_peak_on_pmc_traffic": (traffic / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "step_ms": per_step_ms, "step_ms_per_filter": per_step_ms / filters, "runs_timed": len(evs),
+                     "statistic": "median", "algorithmic_bytes_per_launch": BYTES_SMC_PER_PARTICLE_STEP * n * filters,
+                     "limiter": ("two dependent launches per step at ~1000 workgroups each (under one round of the machine): "
+                                 "per-launch latency floor, not HBM") if filters == 1 else "VALU issue"},
+        "log_z": log_z, "log_z_exact": r["log_z_exact"], "log_z_abs_err_vs_exact": abs(log_z - r["log_z_exact"]),
     }
+    res.update(block_stats(blocks))
+    return res, r
 
 
-def cpu_baseline(args):
-    """The CPU oracle (a port: plain C + OpenMP restatement) timed on this box's host cores on a
-    bounded sample of the same workload."""
-    from genjax._amd import workloads as W
+# ------------------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle: a port) — bounded samples of the same workloads, timed on this box's host cores
+# ------------------------------------------------------------------------------------------------------------
+def host_cores() -> int:
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands
+    one GPU's share of a 256-thread host to the job; 256 OpenMP threads on a 16-core share run 5x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    env = os.environ.get("GJX_BENCH_CPU_THREADS")
+    return int(env) if env else n
+
+
+def best_thread_count(run_once, candidates):
+    """Time `run_once()` at a few OpenMP thread counts (the quota may be invisible from inside the box) and return
+    (threads, seconds) of the fastest."""
+    best = None
+    for c in candidates:
+        if not _omp_threads(c):
+            return candidates[0], None
+        t0 = time.perf_counter()
+        run_once()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (c, dt)
+    _omp_threads(best[0])
+    return best
+
+
+def _omp_threads(nthreads: int):
+    import ctypes
+
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(nthreads))
+        return True
+    except OSError:
+        return False
+
+
+def _oracle():
     from genjax._amd.abi import GjxLib
     from genjax._amd.ops import Ops
 
     lib = os.path.join(ROOT, "oracle", "libgjx_oracle.so")
-    if not os.path.exists(lib):
+    return Ops(GjxLib(lib, "cpu")) if os.path.exists(lib) else None
+
+
+def cpu_baseline_importance(args, gpu_log_z=None):
+    from genjax._amd import workloads as W
+
+    ora = _oracle()
+    if ora is None:
         return None
-    ora = Ops(GjxLib(lib, "cpu"))
     impl = 1 if args.rng == "philox" else 0
-    cores = os.cpu_count() or 1
-    if args.workload == "importance":
-        n = args.particles
-        wl = W.Gaussian10(ora, impl, seed=0, n_local=n)
+    n = args.particles
+    wl = W.Gaussian10(ora, impl, seed=0, n_local=n)
+    out = wl.step()
+    hc = host_cores()
+    cores, _ = best_thread_count(wl.step, sorted({hc, max(1, hc // 2), min(hc, 16), min(hc, 32), min(hc, 64)}, reverse=True))
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 8.0:
+        out = wl.step()
+        reps += 1
+    dt = time.perf_counter() - t0
+    log_z = ora.log_z_from_rows(out["row_e"], out["row_q"], n)
+    res = {"value": n * reps / dt, "unit": "particles/s", "cores": cores, "kind": "port",
+           "sample": f"{reps} full passes of the same {n}-particle ImportanceK workload (OpenMP, {cores} threads)",
+           "log_z": log_z}
+    if gpu_log_z is not None:
+        res["log_z_abs_err_gpu_vs_cpu"] = abs(gpu_log_z - log_z)
+    if _omp_threads(1):
+        t0 = time.perf_counter()
         wl.step()
+        res["value_1_thread"] = n / (time.perf_counter() - t0)
+        _omp_threads(cores)
+    res["host_threads_visible"] = os.cpu_count()
+    return res
+
+
+def cpu_baseline_smc(args, kind, gpu_result=None):
+    """The oracle filter on all host cores: LGSSM the full T=100 run (its log Z is compared with the GPU's); HMM
+    the first 100 of 500 steps (compared with the GPU's log Z over the same prefix)."""
+    import math
+
+    from genjax._amd import workloads as W
+
+    ora = _oracle()
+    if ora is None:
+        return None
+    impl = 1 if args.rng == "philox" else 0
+    n = args.particles
+    T_full = 100 if kind == "smc_lgssm" else 500
+    T = 100
+    # the key schedule of a T-step prefix is the prefix of the full schedule (fold_in(key, 2t), fold_in(key, 2t + 1))
+    mk = (lambda t: W.LgssmSMC(ora, impl, 1, n, t)) if kind == "smc_lgssm" else (lambda t: W.HmmSMC(ora, impl, 2, n, t))
+    wl = mk(T_full)
+    if T < T_full:
+        wl.T, wl.y, wl.sk, wl.rk = T, wl.y[:T], wl.sk[:T], wl.rk[:T]
+    probe = mk(T_full)
+    probe.T, probe.y, probe.sk, probe.rk = 4, probe.y[:4], probe.sk[:4], probe.rk[:4]
+    probe.run()
+    hc = host_cores()
+    cores, _ = best_thread_count(probe.run, sorted({hc, max(1, hc // 2), min(hc, 16), min(hc, 32), min(hc, 64)}, reverse=True))
+    t0 = time.perf_counter()
+    out = wl.run()
+    dt = time.perf_counter() - t0
+    out_max, out_q = out[0], out[1]
+    log_z = ora.log_z_from_pairs(out_max, out_q, n)
+    res = {"value": n * T / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{'all' if T == T_full else 'first'} {T} steps of the same {n}-particle filter (OpenMP, {cores} threads)",
+           "log_z_steps": T, "log_z": log_z}
+    if gpu_result is not None:
+        g = ora.log_z_from_pairs(gpu_result["out_max"][:T].cpu(), gpu_result["out_q"][:T].cpu(), n)
+        res["log_z_gpu_same_steps"] = g
+        res["log_z_abs_err_gpu_vs_cpu"] = abs(g - log_z)
+    if _omp_threads(1):
+        w1 = mk(T_full)
+        t1 = 3
+        w1.T, w1.y, w1.sk, w1.rk = t1, w1.y[:t1], w1.sk[:t1], w1.rk[:t1]
+        t0 = time.perf_counter()
+        w1.run()
+        res["value_1_thread"] = n * t1 / (time.perf_counter() - t0)
+        _omp_threads(cores)
+    _ = math
+    res["host_threads_visible"] = os.cpu_count()
+    return res
+
+
+def jax_cpu_plain(args):
+    """BASELINE.md §2 secondary baseline: a plain `jax.jit(jax.vmap(...))` restatement of the 10-latent model on
+    CPU, timed only if jax happens to be importable on this box (it is not part of the image)."""
+    try:
+        import jax  # noqa: F401
+        import jax.numpy as jnp
+    except Exception as e:  # ModuleNotFoundError on the stock image
+        return {"available": False, "note": f"jax not importable on this box ({type(e).__name__})"}
+    import numpy as np
+
+    from genjax._amd import workloads as W
+
+    y = jnp.asarray(W.gaussian10_data())
+    n = args.particles
+
+    def one(key):
+        z = jax.random.normal(key, (10,))
+        lw = jnp.sum(-0.5 * ((y - z) / 0.5) ** 2 - jnp.log(0.5) - 0.5 * jnp.log(2 * jnp.pi))
+        return z, lw
+
+    @jax.jit
+    def run(key):
+        z, lw = jax.vmap(one)(jax.random.split(key, n))
+        return z, lw, jax.scipy.special.logsumexp(lw) - jnp.log(n)
+
+    with jax.default_device(jax.devices("cpu")[0]):
+        k = jax.random.key(0)
+        run(k)[2].block_until_ready()
         reps, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 10.0:
-            wl.step()
+        while time.perf_counter() - t0 < 5.0:
+            run(jax.random.fold_in(k, reps))[2].block_until_ready()
             reps += 1
         dt = time.perf_counter() - t0
-        return {"value": n * reps / dt, "unit": "particles/s", "cores": cores, "kind": "port",
-                "sample": f"{reps} full passes of the same {n}-particle ImportanceK workload (OpenMP, {cores} threads)"}
-    T = 10
-    n = args.particles
-    fn = W.lgssm_smc if args.workload == "smc_lgssm" else W.hmm_smc
-    seed = 1 if args.workload == "smc_lgssm" else 2
-    fn(ora, impl, seed, n, 2)
-    t0 = time.perf_counter()
-    fn(ora, impl, seed, n, T)
-    dt = time.perf_counter() - t0
-    return {"value": n * T / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-            "sample": f"first {T} steps of the same {n}-particle filter (propagate/weight OpenMP over {cores} threads, "
-                      "resampling scan sequential)"}
+    _ = np
+    return {"available": True, "value": n * reps / dt, "unit": "particles/s", "cores": os.cpu_count(),
+            "sample": f"{reps} passes, jax.jit(jax.vmap) on CPU"}
 
 
-def main():
-    args = parse()
+# ------------------------------------------------------------------------------------------------------------
+def entry(r, keys=("value", "unit", "ms_per_step", "config", "roofline", "log_z", "log_z_exact", "timed_blocks",
+                   "block_ms_min", "block_ms_median", "block_ms_max")):
+    e = {k: r[k] for k in keys if k in r}
+    if "log_z" in e and "log_z_exact" in e:
+        e["log_z_abs_err_vs_exact"] = abs(e["log_z"] - e["log_z_exact"])
+    return e
+
+
+def run_rank(args):
     rank, world = init_dist(args.gpus)
     from genjax._amd.runtime import load_hip_ops
 
     ops = load_hip_ops()  # raises without libgjx_hip.so / a GPU: there is no CPU fallback
+    sharded = world > 1 or FORCE_DIST
+    smc_gpu = None
     if args.workload == "importance":
         res, _ = bench_importance(args, ops, rank, world)
+    elif sharded:
+        res = bench_smc_sharded(args, ops, rank, world, args.workload)
     else:
-        res = bench_smc(args, ops, rank, world, args.workload)
+        res, smc_gpu = bench_smc(args, ops, args.workload, filters=int(os.environ.get("GJX_BENCH_FILTERS", "1")))
+    extra = {}
+    if not args.no_extra and args.workload == "importance":
+        if sharded:
+            # BASELINE configs[3]: the LGSSM filter with 1e6 particles per GPU, sharded (every rank takes part)
+            extra["smc_lgssm_sharded"] = entry(bench_smc_sharded(args, ops, rank, world, "smc_lgssm"))
+        elif rank == 0:
+            # the literal single-GPU BASELINE configs, each first-class: roofline, CPU baseline, log Z vs CPU
+            for kind in ("smc_lgssm", "smc_hmm"):
+                r1, g1 = bench_smc(args, ops, kind, filters=1)
+                e = entry(r1)
+                if not args.no_cpu_baseline:
+                    e["cpu_baseline"] = cpu_baseline_smc(args, kind, g1)
+                r16, _ = bench_smc(args, ops, kind, filters=16, min_s=0.05)
+                e["batched_16_filters_per_launch"] = entry(r16, ("value", "unit", "ms_per_step", "roofline", "log_z"))
+                e["batched_16_filters_per_launch"]["note"] = ("16 independent filters x 1e6 particles step in the same launches: "
+                                                              "NOT a BASELINE config; throughput of the kernels once the machine is full")
+                extra[kind] = e
+            # ImportanceK variants: one pass per launch (the literal config), the other generator, fast math
+            r, _ = bench_importance(args, ops, rank, world, launch_passes=1, steps=64, warmup=16, ramp=False, min_s=0.03)
+            extra["importance_1_pass_per_launch"] = entry(r)
+            r, _ = bench_importance(args, ops, rank, world, rng="threefry" if args.rng == "philox" else "philox", steps=24,
+                                    warmup=8, ramp=False, min_s=0.03)
+            extra[f"importance_{r['config']['rng']}"] = entry(r)
+            try:
+                r, _ = bench_importance(args, ops, rank, world, steps=64, warmup=16, min_s=0.05, fast_math=True)
+                extra["importance_fast_math"] = entry(r)
+                r, _ = bench_importance(args, ops, rank, world, launch_passes=1, steps=64, warmup=16, ramp=False, min_s=0.03,
+                                        fast_math=True)
+                extra["importance_fast_math_1_pass_per_launch"] = entry(r)
+            except Exception as ex:  # reported, never silently dropped
+                extra["importance_fast_math"] = {"error": f"{type(ex).__name__}: {ex}"}
     if rank == 0:
         out = {
             "metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"),
@@ -391,31 +657,28 @@ def main():
         }
         out.update(res)
         out["log_z_abs_err_vs_exact"] = abs(out["log_z"] - out["log_z_exact"])
-        if world == 1 and not args.no_extra and args.workload == "importance":
-            extra = {}
-            for kind in ("smc_lgssm", "smc_hmm"):
-                a2 = argparse.Namespace(**vars(args))
-                a2.steps, a2.warmup = (10, 1) if kind == "smc_lgssm" else (3, 1)
-                r = bench_smc(a2, ops, rank, world, kind)
-                extra[kind] = {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "log_z", "log_z_exact")}
-                extra[kind]["filters_per_launch"] = r["config"]["filters_per_launch"]
-                r1 = bench_smc(a2, ops, rank, world, kind, filters=1)  # the literal BASELINE config: ONE filter of 1e6 particles
-                extra[kind]["one_filter"] = {"value": r1["value"], "ms_per_step": r1["ms_per_step"],
-                                             "roofline_frac": r1["roofline"]["frac"], "step_ms": r1["roofline"]["step_ms"]}
-            a2 = argparse.Namespace(**vars(args))
-            a2.rng = "threefry" if args.rng == "philox" else "philox"
-            a2.steps, a2.warmup = 20, 3
-            r, _ = bench_importance(a2, ops, rank, world)
-            extra[f"importance_{a2.rng}"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "log_z")}
+        out["statistic"] = "median over timed_blocks repetitions of the K-step block"
+        if extra:
             out["extra"] = extra
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out))
-    if world > 1 or FORCE_DIST:
+        if world == 1 and not FORCE_DIST and not args.no_cpu_baseline:
+            if args.workload == "importance":
+                out["cpu_baseline"] = cpu_baseline_importance(args, out["log_z"])
+                out["jax_cpu_plain"] = jax_cpu_plain(args)
+            else:
+                out["cpu_baseline"] = cpu_baseline_smc(args, args.workload, smc_gpu)
+        print(json.dumps(out), flush=True)
+    if sharded:
         import torch.distributed as dist
 
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(parent_launch(args))  # the parent never touches the GPU
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -364,6 +364,23 @@ GJX_HD float m_exp(float x) {
   return u2f(f2u(y) + ((uint32_t)n << 23));
 }
 
+// --- opt-in FAST math for importance plans (gjx.h: GJX_PLAN_FAST_MATH).  The north star asks for log-weights within
+// 1e-5 relative of the reference on a path WITHOUT resampling, so an importance plan may trade the bit-exact
+// polynomials for the hardware transcendentals (v_log_f32 / v_exp_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32: ~1 ulp,
+// an 8-cycle issue each against 24-40 dependent fma's) wherever the result is a CONTINUOUS function of its input: the
+// Box-Muller transform of Normal sites, the transcendental terms of log-densities, and the row-anchored weight sums.
+// Everything that DECIDES something (rejection tests of the gamma sampler, categorical CDFs, Bernoulli thresholds,
+// resampling weights) keeps the exact functions, so a fast plan draws the same particles as the exact plan up to
+// rounding.  d_log / d_exp are the density-side functions; the exact build maps them to m_log / m_exp.
+#if defined(GJX_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+#define GJX_FAST_MATH_DEVICE 1
+GJX_HD float d_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+GJX_HD float d_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+#else
+GJX_HD float d_log(float x) { return m_log(x); }
+GJX_HD float d_exp(float x) { return m_exp(x); }
+#endif
+
 GJX_HD float m_erfinv(float x) {
   float w = -m_log_normal((1.0f - x) * (1.0f + x));
   float p;
@@ -451,6 +468,15 @@ GJX_HD float sqrt_pos(float x) {
 GJX_HD void bm_pair(uint32_t w_radius, uint32_t w_angle, float& z_cos, float& z_sin) {
   // radius: u in (0, 1] with full float resolution near 0 (tails to 6.6 sigma)
   const float u = ((float)w_radius + 1.0f) * 2.3283064365386963e-10f;
+#ifdef GJX_FAST_MATH_DEVICE
+  {  // the same map from the same two words through the hardware functions (v_sin / v_cos take revolutions)
+    const float rf = __builtin_amdgcn_sqrtf(-1.38629436111989062f * __builtin_amdgcn_logf(u));
+    const float tf = (float)(w_angle >> 8) * 5.9604644775390625e-08f;
+    z_cos = rf * __builtin_amdgcn_cosf(tf);
+    z_sin = rf * __builtin_amdgcn_sinf(tf);
+    return;
+  }
+#endif
   const float r = sqrt_pos(-2.0f * m_log_normal(u));
   // angle = 2 pi a / 2^24: octant (3 bits) + fraction (21 bits)
   const uint32_t a = w_angle >> 8;
@@ -519,7 +545,7 @@ GJX_HD float smc_slot_normal(Key step_key, uint64_t j) {  // one slot on its own
 
 // --- log-densities (TFP formulas).  The *_pre forms take the per-site constants a plan hoists.
 GJX_HD float normal_rs(float scale) { return 1.0f / scale; }
-GJX_HD float normal_lognorm(float scale) { return 0.91893853320467f + m_log(scale); }
+GJX_HD float normal_lognorm(float scale) { return 0.91893853320467f + d_log(scale); }
 GJX_HD float logpdf_normal_pre(float x, float loc, float rs, float lognorm) {
   const float d = x * rs - loc * rs;
   return (-0.5f * d) * d - lognorm;
@@ -527,7 +553,7 @@ GJX_HD float logpdf_normal_pre(float x, float loc, float rs, float lognorm) {
 GJX_HD float logpdf_normal(float x, float loc, float scale) {
   return logpdf_normal_pre(x, loc, normal_rs(scale), normal_lognorm(scale));
 }
-GJX_HD float xlogy(float a, float y) { return a == 0.0f ? 0.0f : a * m_log(y); }
+GJX_HD float xlogy(float a, float y) { return a == 0.0f ? 0.0f : a * d_log(y); }
 GJX_HD float gamma_lognorm(float conc, float rate) { return m_lgamma(conc) - conc * m_log(rate); }
 GJX_HD float logpdf_gamma_pre(float x, float conc, float rate, float lognorm) {
   return (xlogy(conc - 1.0f, x) - rate * x) - lognorm;
@@ -542,7 +568,7 @@ GJX_HD float logpdf_beta_pre(float x, float a, float b, float lbeta) {
 GJX_HD float logpdf_beta(float x, float a, float b) {
   return logpdf_beta_pre(x, a, b, beta_lbeta(a, b));
 }
-GJX_HD float logpdf_bernoulli(bool e, float p) { return e ? m_log(p) : m_log(1.0f - p); }
+GJX_HD float logpdf_bernoulli(bool e, float p) { return e ? d_log(p) : d_log(1.0f - p); }
 
 // --- Marsaglia-Tsang Gamma(conc, 1).  Attempt a of gamma `which` uses sub-stream 1 + 2a + which
 // (w0 -> normal, w1 -> uniform); the conc<1 boost uniform is word `which` of sub-stream 0.
@@ -603,7 +629,7 @@ GJX_HD uint64_t rowfix(float lw, int32_t e) {
   const float fe = (float)e;
   float d = __builtin_fmaf(-fe, 0.693359375f, lw);
   d = __builtin_fmaf(-fe, -2.12194440e-4f, d);
-  return (uint64_t)__builtin_rintf(m_exp(d) * 1073741824.0f);
+  return (uint64_t)__builtin_rintf(d_exp(d) * 1073741824.0f);
 }
 
 GJX_HD uint32_t cat_fix(float l, float m) {

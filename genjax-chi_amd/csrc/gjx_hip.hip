@@ -1369,9 +1369,12 @@ struct gjx_plan {
   int n_sites;
   int n_slots;
   int dist_mask;
+  uint32_t flags;  // GJX_PLAN_*
   CSite host[GJX_MAX_SITES];
   CSite* dev;
-  gjx_jit::Compiled jit[3];  // specialised kernel per RNG scheme (+ PHILOX laned keys), built on first use
+  // specialised kernels, built on first use: [0] THREEFRY, [1] PHILOX one particle per lane, [2] PHILOX pairs
+  // (two adjacent particles per lane), [3] PHILOX quads (four per lane: one wave per 256-particle row)
+  gjx_jit::Compiled jit[4];
   std::mutex jit_mu;
 };
 
@@ -1422,10 +1425,12 @@ static bool convert_site(const gjx_site& st, int s, CSite& c, int n_state = -1, 
   return true;
 }
 
-int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
-  if (!sites || !out || n_sites <= 0 || n_sites > GJX_MAX_SITES) return GJX_ERR_INVALID;
+int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) { return gjx_plan_create_ex(sites, n_sites, 0u, out); }
+int gjx_plan_create_ex(const gjx_site* sites, int n_sites, uint32_t flags, gjx_plan** out) {
+  if (!sites || !out || n_sites <= 0 || n_sites > GJX_MAX_SITES || (flags & ~(uint32_t)GJX_PLAN_FAST_MATH)) return GJX_ERR_INVALID;
   gjx_plan* p = new (std::nothrow) gjx_plan;
   if (!p) return GJX_ERR_LAUNCH;
+  p->flags = flags;
   p->n_sites = n_sites;
   p->dev = nullptr;
   p->dist_mask = 0;
@@ -1484,10 +1489,21 @@ static int plan_device_table(gjx_plan* p) {
   return GJX_OK;
 }
 
+static int jit_form_pref() {  // GJX_JIT_FORM = one | pair | quad (test / tuning knob, read at every launch); default: the measured best
+  const char* e = std::getenv("GJX_JIT_FORM");
+  if (e && !strcmp(e, "one")) return 1;
+  if (e && !strcmp(e, "pair")) return 2;
+  if (e && !strcmp(e, "quad")) return 4;
+  const char* old = std::getenv("GJX_JIT_PAIRED");  // 0: always the one-particle-per-lane form
+  if (old && old[0] == '0') return 1;
+  return 4;  // measured (tools/ab_importance.py, 1e6 particles): quad 13.1 / pair 13.6 / one 28.3 us per pass at 8 passes per launch
+}
 int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t buf_len, size_t* needed) {
   if (!p || (impl != 0 && impl != 1)) return GJX_ERR_INVALID;
   gjx_jit::Gen<CSite, CArg> g;
-  g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites; g.laned = impl == 1;
+  g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites; g.laned = impl == 1 && jit_form_pref() >= 2;
+  g.pairs_per_lane = jit_form_pref() == 4 ? 2 : 1;  // (GJX_JIT_FORM picks the PHILOX form shown)
+  g.fast_math = (p->flags & GJX_PLAN_FAST_MATH) != 0;
   const std::string src = g.run();
   if (needed) *needed = src.size() + 1;
   if (buf && buf_len > 0) {
@@ -1500,9 +1516,10 @@ int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t b
 
 int gjx_plan_compile_check(const gjx_plan* p, int impl) {
   if (!p || (impl != 0 && impl != 1)) return GJX_ERR_INVALID;
-  for (int laned = 0; laned <= impl; ++laned) {  // PHILOX: both key forms
+  for (int form = 0; form <= 2 * impl; ++form) {  // PHILOX: one particle per lane, pairs, quads
     gjx_jit::Gen<CSite, CArg> g;
-    g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites; g.laned = laned != 0;
+    g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites; g.laned = form != 0; g.pairs_per_lane = form == 2 ? 2 : 1;
+    g.fast_math = (p->flags & GJX_PLAN_FAST_MATH) != 0;
     if (!gjx_jit::compile_only(g.run())) return GJX_ERR_UNSUPPORTED;
   }
   return GJX_OK;
@@ -1517,52 +1534,71 @@ int gjx_plan_destroy(gjx_plan* p) {
 }
 
 // The hiprtc-specialised kernel of a plan for this key form (compiled and loaded on first use).
-static gjx_jit::Compiled& plan_compiled(gjx_plan* mp, const gjx_keys* pk, bool pairable) {
+// `lane_particles`: how many adjacent particles a lane may own given n and the alignment of the output buffers (1, 2, 4).
+static gjx_jit::Compiled& plan_compiled(gjx_plan* mp, const gjx_keys* pk, int lane_particles) {
   // PHILOX children of a lane-0 key share one cipher key, and an even first index keeps particle pairs
-  // (2i, 2i+1) together: the paired kernel form (gjx_plan_jit.hpp)
-  static const bool paired_ok = [] {
-    const char* e = std::getenv("GJX_JIT_PAIRED");  // 0: always the one-particle-per-lane form (test knob)
-    return !(e && e[0] == '0');
-  }();
-  const bool laned = paired_ok && pairable && pk->impl == 1 && pk->mode == 1 && pk->parent_lane == 0 && (pk->first & 1) == 0;
-  gjx_jit::Compiled& c = mp->jit[laned ? 2 : pk->impl];
+  // (2i, 2i+1) together: the paired / quad kernel forms (gjx_plan_jit.hpp)
+  const bool pairable = pk->impl == 1 && pk->mode == 1 && pk->parent_lane == 0 && (pk->first & 1) == 0;
+  int P = pairable ? (lane_particles < jit_form_pref() ? lane_particles : jit_form_pref()) : 1;
+  if (P == 3) P = 2;
+  const bool laned = P >= 2;
+  gjx_jit::Compiled& c = mp->jit[P == 4 ? 3 : (laned ? 2 : pk->impl)];
   if (c.state == 0) {
     std::lock_guard<std::mutex> lock(mp->jit_mu);
     if (c.state == 0) {
-      gjx_jit::Gen<CSite, CArg> g;
-      g.impl = pk->impl; g.sites = mp->host; g.n_sites = mp->n_sites; g.laned = laned;
+      auto make = [&](int min_waves) {
+        gjx_jit::Gen<CSite, CArg> g;
+        g.impl = pk->impl; g.sites = mp->host; g.n_sites = mp->n_sites; g.laned = laned; g.pairs_per_lane = P == 4 ? 2 : 1;
+        g.fast_math = (mp->flags & GJX_PLAN_FAST_MATH) != 0;
+        g.min_waves = min_waves;
+        std::string src = g.run();
+        c.block = g.block;
+        c.rows_per_block = g.rows_per_block;
+        return src;
+      };
       // The kernels are bound by dependency latency, not by issue slots (a wave64 VALU instruction issues in ~2.4
       // cycles, tools/microbench/valu_rate.hip): a sixth wave per SIMD (<= 80 VGPRs) is worth 2-3 % on the paired
       // form as long as the allocator gets there with (next to) no spilling; otherwise the unconstrained build is kept.
       const char* e = std::getenv("GJX_JIT_MIN_WAVES");  // test knob: force the hint (0 = none)
-      g.min_waves = e ? atoi(e) : (laned ? 6 : 0);
-      std::string src = g.run();
-      c.block = g.block;
-      c.rows_per_block = g.rows_per_block;
-      bool ok = gjx_jit::compile(src, pk->impl, &c);
-      if (ok && !e && g.min_waves > 0) {
+      const int hint = e ? atoi(e) : (P == 2 ? 6 : 0);
+      bool ok = gjx_jit::compile(make(hint), pk->impl, &c);
+      if (ok && !e && hint > 0) {
         int scratch = 0;
         const hipError_t qe = hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, c.fn);
         if (qe != hipSuccess) (void)hipGetLastError();  // a failed query must not surface as a launch error later
-        if (std::getenv("GJX_PLAN_JIT_VERBOSE")) fprintf(stderr, "gjx jit: waves-per-SIMD hint %d: query %d, scratch %d B\n", g.min_waves, (int)qe, scratch);
+        if (std::getenv("GJX_PLAN_JIT_VERBOSE")) fprintf(stderr, "gjx jit: waves-per-SIMD hint %d: query %d, scratch %d B\n", hint, (int)qe, scratch);
         if (qe != hipSuccess || scratch > 32) {  // (a couple of spilled words cost less than the lost wave)
           c.fn = nullptr;  // the hinted module stays in the source-keyed cache
-          gjx_jit::Gen<CSite, CArg> g2;
-          g2.impl = pk->impl; g2.sites = mp->host; g2.n_sites = mp->n_sites; g2.laned = laned;
-          src = g2.run();
-          ok = gjx_jit::compile(src, pk->impl, &c);
+          ok = gjx_jit::compile(make(0), pk->impl, &c);
         }
+      }
+      if (!ok) {
+        (void)hipGetLastError();
+        fprintf(stderr, "[gjx] plan specialisation FAILED (hiprtc compile or module load; impl %d, %d particle(s) per lane). "
+                        "gjx_importance_run returns GJX_ERR_JIT; set GJX_PLAN_JIT_VERBOSE=1 for the compiler log, GJX_PLAN_JIT=0 "
+                        "or GJX_PLAN_JIT_FALLBACK=1 to run the (7x slower) table interpreter instead.\n", pk->impl, P);
       }
       c.state = ok ? 1 : -1;
     }
   }
   return c;
 }
+static bool jit_fallback_allowed() {
+  static const bool allow = [] {
+    const char* e = std::getenv("GJX_PLAN_JIT_FALLBACK");
+    return e && e[0] == '1';
+  }();
+  return allow;
+}
 int gjx_plan_prepare(gjx_plan* p, const gjx_keys* pk) {
   if (!p || !keys_ok(pk)) return GJX_ERR_INVALID;
   if (!gjx_jit::enabled()) return plan_device_table(p);
-  plan_compiled(p, pk, false);  // both forms: which one a launch takes depends on n and on buffer alignment
-  return plan_compiled(p, pk, true).state == 1 ? GJX_OK : plan_device_table(p);
+  // every form a launch may take (which one depends on n and on buffer alignment)
+  bool ok = plan_compiled(p, pk, 1).state == 1;
+  ok = plan_compiled(p, pk, 2).state == 1 && ok;
+  ok = plan_compiled(p, pk, 4).state == 1 && ok;
+  if (ok) return GJX_OK;
+  return jit_fallback_allowed() ? plan_device_table(p) : GJX_ERR_JIT;
 }
 
 // One launch of a plan over n_pass independent passes (n_pass == 1: the plain call).
@@ -1592,10 +1628,13 @@ static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pa
   KeySrc k = key_src(pk);
   // Specialised straight-line kernel for this site table (compiled once per plan and RNG scheme).
   if (gjx_jit::enabled()) {
-    // the paired form writes both particles of a lane with one 8-byte store: even n, 8-byte aligned columns
-    bool pairable = (n & 1) == 0 && ((uintptr_t)logw & 7) == 0 && ((uintptr_t)score & 7) == 0 && (pass_stride & 1) == 0;
-    for (int c = 0; c < n_value_cols && pairable; ++c) pairable = ((uintptr_t)value_cols[c] & 7) == 0;
-    gjx_jit::Compiled& c = plan_compiled(const_cast<gjx_plan*>(p), pk, pairable);
+    // the paired / quad forms write the 2 / 4 adjacent particles of a lane with one 8- / 16-byte store: n a multiple
+    // of 2 / 4, columns (and the distance between passes) aligned alike
+    uintptr_t al = (uintptr_t)logw | (uintptr_t)score | (uintptr_t)(4 * pass_stride) | (uintptr_t)(4 * n);
+    for (int c = 0; c < n_value_cols; ++c) al |= (uintptr_t)value_cols[c];
+    const int lane_particles = (al & 15) == 0 ? 4 : ((al & 7) == 0 ? 2 : 1);
+    gjx_jit::Compiled& c = plan_compiled(const_cast<gjx_plan*>(p), pk, lane_particles);
+    if (c.state != 1 && !jit_fallback_allowed()) return GJX_ERR_JIT;  // loud: never a silent 7x slower route
     if (c.state == 1) {
       uint64_t nn = n;
       LseTail tail{nullptr, nullptr, nullptr, nullptr, nullptr};

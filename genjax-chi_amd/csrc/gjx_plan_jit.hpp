@@ -209,7 +209,8 @@ struct SiteEmitter {
   }
 };
 
-inline void emit_prelude(std::ostringstream& o) {
+inline void emit_prelude(std::ostringstream& o, bool fast_math = false) {
+  if (fast_math) o << "#define GJX_FAST_MATH 1\n";  // gjx.h GJX_PLAN_FAST_MATH: hardware transcendentals (gjx_device.hpp d_log / d_exp / bm_pair)
   o << "#include \"gjx_device.hpp\"\nusing namespace gjx;\n";
   o << "__device__ __forceinline__ float jrow_max(const float* l, uint32_t K){ float m=l[0]; for(uint32_t c=1;c<K;++c) m = l[c]>m?l[c]:m; return m; }\n";
   o << "__device__ __forceinline__ float jrow_lse(const float* l, uint32_t K){ const float m=jrow_max(l,K); float acc=0.0f; for(uint32_t c=0;c<K;++c) acc = acc + m_exp(l[c]-m); return m + m_log(acc); }\n";
@@ -233,6 +234,10 @@ struct Gen {
   int block = 256;    // threads per workgroup of the generated kernel
   int rows_per_block = 1;
   bool laned = false; // the paired form (see above)
+  bool fast_math = false;  // GJX_PLAN_FAST_MATH
+  int pairs_per_lane = 1;  // paired form: 1 = two adjacent particles per lane (128-thread workgroup per 256-particle row);
+                           // 2 = FOUR adjacent particles per lane: one WAVE owns the whole row, so the row statistics are
+                           // wave reductions (DPP only: no LDS, no barrier) and every column store is 16 bytes per lane
 
   static const char* signature() {
     return "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, "
@@ -241,17 +246,21 @@ struct Gen {
   const char* kname() const { return impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox"; }
 
   std::string run_paired() {
-    // R rows (256 particles each) per workgroup of 128*R threads: wave pair r serves row blockIdx*R + r
+    // NP pairs of adjacent particles per lane; a 256-particle row is 128 / NP lanes.  R rows per workgroup.
+    const int NP = pairs_per_lane == 2 ? 2 : 1;
+    const int lanes_per_row = 128 / NP;
     int R = 1;
     if (const char* e = std::getenv("GJX_JIT_PAIR_ROWS")) R = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 1);
-    block = 128 * R;
+    block = lanes_per_row * R;
     rows_per_block = R;
-    emit_prelude(o);
+    const int waves_per_row = lanes_per_row / 64;  // 2 (pairs) or 1 (quads)
+    emit_prelude(o, fast_math);
     o << "extern \"C\" __global__ __launch_bounds__(" << block << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
       << ") void " << kname() << signature();
-    o << "  __shared__ float sh_red[" << 2 * R << "];\n  __shared__ uint64_t sh_sum[" << 2 * R << "];\n";
+    if (waves_per_row > 1) o << "  __shared__ float sh_red[" << waves_per_row * R << "];\n  __shared__ uint64_t sh_sum[" << waves_per_row * R << "];\n";
     if (R == 1) o << "  const int wv = threadIdx.x >> 6, pr = 0, tr = threadIdx.x;  // (block-uniform row: the cipher key stays scalar)\n";
-    else o << "  const int wv = threadIdx.x >> 6, pr = wv >> 1, tr = threadIdx.x & 127;\n";
+    else o << "  const int wv = threadIdx.x >> 6, pr = threadIdx.x / " << lanes_per_row << ", tr = threadIdx.x % " << lanes_per_row << ";\n";
+    o << "  (void)wv;\n";
     o << "  const uint64_t rows_all = (uint64_t)bt.n_pass * bt.rows_per_pass;\n";
     o << "  for (uint64_t g0 = (uint64_t)blockIdx.x * " << R << "; g0 < rows_all; g0 += (uint64_t)gridDim.x * " << R << ") {\n";
     o << "    const uint64_t gr = g0 + pr;\n";
@@ -261,72 +270,108 @@ struct Gen {
     o << "    const uint32_t pk0 = bt.n_pass > 1 ? bt.parent[pass < bt.n_pass ? pass : 0][0] : ks.parent.k0;\n";
     o << "    const uint32_t pk1 = bt.n_pass > 1 ? bt.parent[pass < bt.n_pass ? pass : 0][1] : ks.parent.k1;\n";
     o << "    const uint64_t po = (uint64_t)pass * bt.pass_stride, ro = (uint64_t)pass * bt.row_stride;  // this pass's outputs\n";
-    o << "    const uint64_t iA = row * 256 + 2 * (uint64_t)tr, iB = iA + 1;\n";
-    o << "    const bool ok = live_row && iA < n;  // n is even in this form: both particles of a lane exist or neither\n";
-    o << "    const uint64_t liA = iA, liB = iB;\n";
-    o << "    float wA = 0.0f, scA = 0.0f, wB = 0.0f, scB = 0.0f;\n";
+    const char* sfx[4] = {"A", "B", "C", "D"};
+    const int P = 2 * NP;  // particles per lane
+    o << "    const uint64_t iA = row * 256 + " << P << " * (uint64_t)tr;\n";
+    for (int u = 1; u < P; ++u) o << "    const uint64_t i" << sfx[u] << " = iA + " << u << ";\n";
+    // n is a multiple of P in this form (checked by the host): all particles of a lane exist or none
+    o << "    const bool ok = live_row && iA < n;\n";
+    for (int u = 0; u < P; ++u) o << "    const uint64_t li" << sfx[u] << " = i" << sfx[u] << "; (void)li" << sfx[u] << ";\n";
+    for (int u = 0; u < P; ++u) o << "    float w" << sfx[u] << " = 0.0f, sc" << sfx[u] << " = 0.0f;\n";
     o << "    if (ok) {\n";
-    o << "      const uint64_t lnA = ks.first + iA + 1u, lnB = lnA + 1u;\n";
-    o << "      const Key pkeyA{pk0, pk1, (uint32_t)lnA, (uint32_t)(lnA >> 32)};\n";
-    o << "      const Key pkeyB{pk0, pk1, (uint32_t)lnB, (uint32_t)(lnB >> 32)};\n";
-    SiteEmitter<CSiteT, CArgT> ea{o, impl, 0, sites, n_sites, "      ", "A"};
-    SiteEmitter<CSiteT, CArgT> eb{o, impl, 0, sites, n_sites, "      ", "B"};
-    ea.store_values = eb.store_values = false;
-    ea.ext_bits = eb.ext_bits = true;  // the lane owns the pair: its single-word draws come from the pair's blocks
-    o << "      const uint64_t pairA = (lnA - 1u) >> 1;\n";
+    o << "      const uint64_t lnA = ks.first + iA + 1u;\n";
+    for (int u = 0; u < P; ++u) {
+      if (u) o << "      const uint64_t ln" << sfx[u] << " = lnA + " << u << "u;\n";
+      o << "      const Key pkey" << sfx[u] << "{pk0, pk1, (uint32_t)ln" << sfx[u] << ", (uint32_t)(ln" << sfx[u] << " >> 32)}; (void)pkey" << sfx[u] << ";\n";
+    }
+    std::vector<SiteEmitter<CSiteT, CArgT>> em;
+    for (int u = 0; u < P; ++u) {
+      em.push_back(SiteEmitter<CSiteT, CArgT>{o, impl, 0, sites, n_sites, "      ", sfx[u]});
+      em.back().store_values = false;
+      em.back().ext_bits = true;  // the lane owns whole pairs: their single-word draws come from the pairs' blocks
+    }
+    o << "      const uint64_t pair0 = (lnA - 1u) >> 1;\n";
+    if (NP == 2) o << "      const uint64_t pair1 = pair0 + 1u;\n";
     int cur_pair_blk = -1;
     for (int q = 0; q < n_sites; ++q) {
       const CSiteT& st = sites[q];
-      ea.head(q);
-      eb.head(q);
-      if (!st.observed && ea.one_word(st)) {
-        // draw f of the pair: block f >> 1 holds words (A, B) of draw 2 (f >> 1) and of draw 2 (f >> 1) + 1
-        const uint32_t f = ea.fold_of(q);
+      for (int u = 0; u < P; ++u) em[u].head(q);
+      const std::string Q = std::to_string(q);
+      if (!st.observed && em[0].one_word(st)) {
+        // draw f of a pair: block f >> 1 holds words (even, odd particle) of draw 2 (f >> 1) and of draw 2 (f >> 1) + 1
+        const uint32_t f = em[0].fold_of(q);
         const int blk = (int)(f >> 1);
-        const std::string B = std::to_string(blk), Q = std::to_string(q);
+        const std::string B = std::to_string(blk);
         if (blk != cur_pair_blk) {
           cur_pair_blk = blk;
-          o << "      uint32_t pp" << B << "_0, pp" << B << "_1, pp" << B << "_2, pp" << B << "_3;\n";
-          o << "      philox4x32(pk0, pk1, (uint32_t)pairA, (uint32_t)(pairA >> 32), " << blk << "u, kTagPair, pp" << B << "_0, pp" << B
-            << "_1, pp" << B << "_2, pp" << B << "_3);\n";
+          for (int pi = 0; pi < NP; ++pi) {
+            const std::string V = "pp" + std::to_string(pi) + "_" + B;
+            o << "      uint32_t " << V << "_0, " << V << "_1, " << V << "_2, " << V << "_3;\n";
+            o << "      philox4x32(pk0, pk1, (uint32_t)pair" << pi << ", (uint32_t)(pair" << pi << " >> 32), " << blk << "u, kTagPair, " << V
+              << "_0, " << V << "_1, " << V << "_2, " << V << "_3);\n";
+          }
         }
-        o << "      const uint32_t bits" << Q << "A = pp" << B << "_" << ((f & 1u) << 1) << ", bits" << Q << "B = pp" << B << "_"
-          << (((f & 1u) << 1) | 1u) << ";\n";
+        for (int pi = 0; pi < NP; ++pi) {
+          const std::string V = "pp" + std::to_string(pi) + "_" + B;
+          o << "      const uint32_t bits" << Q << sfx[2 * pi] << " = " << V << "_" << ((f & 1u) << 1) << ", bits" << Q << sfx[2 * pi + 1]
+            << " = " << V << "_" << (((f & 1u) << 1) | 1u) << ";\n";
+        }
       }
       if (!st.observed && st.dist == GJX_DIST_NORMAL) {
-        const std::string Q = std::to_string(q);
-        o << "      float zc" << Q << ", zs" << Q << ";\n      bm_pair(bits" << Q << "A, bits" << Q << "B, zc" << Q << ", zs" << Q << ");\n";
-        ea.tail(q, "zc" + Q);
-        eb.tail(q, "zs" + Q);
+        for (int pi = 0; pi < NP; ++pi) {
+          const std::string Z = Q + "_" + std::to_string(pi);
+          o << "      float zc" << Z << ", zs" << Z << ";\n      bm_pair(bits" << Q << sfx[2 * pi] << ", bits" << Q << sfx[2 * pi + 1] << ", zc" << Z
+            << ", zs" << Z << ");\n";
+        }
+        for (int pi = 0; pi < NP; ++pi) {
+          const std::string Z = Q + "_" + std::to_string(pi);
+          em[2 * pi].tail(q, "zc" + Z);
+          em[2 * pi + 1].tail(q, "zs" + Z);
+        }
       } else {
-        ea.tail(q);
-        eb.tail(q);
+        for (int u = 0; u < P; ++u) em[u].tail(q);
       }
-      if (st.out_col >= 0) {  // the two particles are adjacent in the column: one 8-byte store per lane
+      if (st.out_col >= 0) {  // the lane's particles are adjacent in the column: one 8- / 16-byte store per lane
         const bool isint = SiteEmitter<CSiteT, CArgT>::is_int(st);
-        const std::string Q = std::to_string(q);
-        const std::string ra = isint ? "(uint32_t)vi" + Q + "A" : "f2u(vf" + Q + "A)", rb = isint ? "(uint32_t)vi" + Q + "B" : "f2u(vf" + Q + "B)";
+        std::string vals;
+        for (int u = 0; u < P; ++u)
+          vals += (u ? ", " : "") + (isint ? "(uint32_t)vi" + Q + sfx[u] : "f2u(vf" + Q + sfx[u] + ")");
         o << "#ifndef GJX_EXP_NO_VALUE_STORES\n";
-        o << "      *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "]) + po + iA) = make_uint2(" << ra << ", " << rb << ");\n";
+        o << "      *reinterpret_cast<uint" << P << "*>(reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "]) + po + iA) = make_uint" << P
+          << "(" << vals << ");\n";
         o << "#endif\n";
       }
     }
-    o << "      *reinterpret_cast<float2*>(logw + po + iA) = make_float2(wA, wB);\n";
-    o << "      if (score) *reinterpret_cast<float2*>(score + po + iA) = make_float2(scA, scB);\n";
+    {
+      std::string ws, ss;
+      for (int u = 0; u < P; ++u) { ws += (u ? ", w" : "w") + std::string(sfx[u]); ss += (u ? ", sc" : "sc") + std::string(sfx[u]); }
+      o << "      *reinterpret_cast<float" << P << "*>(logw + po + iA) = make_float" << P << "(" << ws << ");\n";
+      o << "      if (score) *reinterpret_cast<float" << P << "*>(score + po + iA) = make_float" << P << "(" << ss << ");\n";
+    }
     o << "    }\n";
-    o << "    const bool okA = ok, okB = ok;\n";
     o << "    if (max_partials || row_e) {\n";
     o << "      const float ninf = -__builtin_inff();\n";
-    o << "      const float mA = okA ? wA : ninf, mB = okB ? wB : ninf;\n";
-    o << "      float bm = wave_max(mA > mB ? mA : mB);\n";
-    o << "      __syncthreads();\n      if ((threadIdx.x & 63) == 0) sh_red[wv] = bm;\n      __syncthreads();\n";
-    o << "      bm = sh_red[2 * pr] > sh_red[2 * pr + 1] ? sh_red[2 * pr] : sh_red[2 * pr + 1];\n";
+    {
+      std::string mx = "wA";
+      for (int u = 1; u < P; ++u) mx = "(" + mx + " > w" + sfx[u] + " ? " + mx + " : w" + sfx[u] + ")";
+      o << "      float bm = wave_max(ok ? " << mx << " : ninf);\n";
+    }
+    if (waves_per_row > 1) {
+      o << "      __syncthreads();\n      if ((threadIdx.x & 63) == 0) sh_red[wv] = bm;\n      __syncthreads();\n";
+      o << "      bm = sh_red[2 * pr] > sh_red[2 * pr + 1] ? sh_red[2 * pr] : sh_red[2 * pr + 1];\n";
+    }
     o << "      if (max_partials && tr == 0 && live_row) max_partials[ro + row] = bm;\n";
     o << "      if (row_e) {\n";
     o << "        const int32_t eb = row_anchor(bm);\n";
-    o << "        uint64_t sb = wave_sum((okA ? rowfix(wA, eb) : 0) + (okB ? rowfix(wB, eb) : 0));\n";
-    o << "        __syncthreads();\n        if ((threadIdx.x & 63) == 0) sh_sum[wv] = sb;\n        __syncthreads();\n";
-    o << "        sb = sh_sum[2 * pr] + sh_sum[2 * pr + 1];\n";
+    {
+      std::string sm;
+      for (int u = 0; u < P; ++u) sm += (u ? " + rowfix(w" : "rowfix(w") + std::string(sfx[u]) + ", eb)";
+      o << "        uint64_t sb = wave_sum(ok ? (" << sm << ") : 0);\n";
+    }
+    if (waves_per_row > 1) {
+      o << "        __syncthreads();\n        if ((threadIdx.x & 63) == 0) sh_sum[wv] = sb;\n        __syncthreads();\n";
+      o << "        sb = sh_sum[2 * pr] + sh_sum[2 * pr + 1];\n";
+    }
     o << "        if (tr == 0 && live_row) lse_store_row(row_e, row_s, ro + row, eb, sb, tail.tickets != nullptr);\n";
     o << "      }\n    }\n";
     o << "  }\n  if (row_e) lse_tail(row_e, row_s, (n + 255) / 256, tail);\n}\n";
@@ -336,7 +381,7 @@ struct Gen {
   std::string run() {
     if (laned && impl == 1) return run_paired();
     const std::string I = std::to_string(impl);
-    emit_prelude(o);
+    emit_prelude(o, fast_math);
     // One workgroup per 256-particle row (grid-stride): short blocks keep every SIMD's wave slots
     // full even at 1e6 particles (15 rows per lane), where a 4-row block would serialise its rows.
     o << "extern \"C\" __global__ __launch_bounds__(256" << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())

@@ -27,6 +27,7 @@ STATUS = {
     -3: "GJX_ERR_WORKSPACE",
     -4: "GJX_ERR_LAUNCH",
     -5: "GJX_ERR_NO_DEVICE",
+    -6: "GJX_ERR_JIT",
 }
 
 RNG_THREEFRY = 0
@@ -38,6 +39,7 @@ ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE, ARG_STATE, ARG_OBS = range(6)
 SMC_MAX_STATE, SMC_MAX_OBS = 4, 8
 OP_LOGSUMEXP, OP_CATEGORICAL_INDEX, OP_RESAMPLE, OP_SMC = range(4)
 MAX_SITES = 64
+PLAN_FAST_MATH = 1  # gjx.h: GJX_PLAN_FAST_MATH
 
 
 class GjxError(RuntimeError):
@@ -176,6 +178,7 @@ PROTOTYPES = {
         [_P, C.c_int, _P, C.c_uint64, C.c_uint32, _P, _P, C.c_uint64, _P],
     ),
     "gjx_plan_create": (C.c_int, [C.POINTER(Site), C.c_int, C.POINTER(_P)]),
+    "gjx_plan_create_ex": (C.c_int, [C.POINTER(Site), C.c_int, C.c_uint32, C.POINTER(_P)]),
     "gjx_plan_destroy": (C.c_int, [_P]),
     "gjx_plan_specialized_source": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gjx_plan_compile_check": (C.c_int, [_P, C.c_int]),

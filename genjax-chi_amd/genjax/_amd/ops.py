@@ -189,10 +189,12 @@ class Ops:
         return score
 
     # ---- plans ----------------------------------------------------------------------------------
-    def plan_create(self, sites: list[abi.Site]) -> "Plan":
+    def plan_create(self, sites: list[abi.Site], fast_math: bool = False) -> "Plan":
+        """`fast_math`: gjx.h GJX_PLAN_FAST_MATH — hardware transcendentals for the continuous parts of the walk
+        (<= 1e-5 relative on values and log-weights; no longer bit-identical to the oracle)."""
         arr = (abi.Site * len(sites))(*sites)
         handle = C.c_void_p()
-        self.lib.call("gjx_plan_create", arr, len(sites), C.byref(handle))
+        self.lib.call("gjx_plan_create_ex", arr, len(sites), abi.PLAN_FAST_MATH if fast_math else 0, C.byref(handle))
         return Plan(self, handle, len(sites))
 
     def tickets(self) -> torch.Tensor:

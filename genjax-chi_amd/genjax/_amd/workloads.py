@@ -74,11 +74,12 @@ def importance_particle_keys(root: prng.PRNGKey, n_local: int, first: int = 0):
 class Gaussian10:
     """Reusable state of the C2 workload (plan + key batch), so a bench step is kernels only."""
 
-    def __init__(self, ops: Ops, impl: int, seed: int, n_local: int, first: int = 0, n_total: int | None = None):
+    def __init__(self, ops: Ops, impl: int, seed: int, n_local: int, first: int = 0, n_total: int | None = None,
+                 fast_math: bool = False):
         self.ops, self.n, self.first, self.impl, self.seed = ops, n_local, first, impl, seed
         self.n_total = n_local if n_total is None else n_total
         self.y = gaussian10_data()
-        self.plan = ops.plan_create(gaussian10_sites(self.y))
+        self.plan = ops.plan_create(gaussian10_sites(self.y), fast_math=fast_math)
         self.keys = importance_particle_keys(prng.key(seed, impl), n_local, first)
         self.frac = ops.frac_bits(self.n_total)
 
@@ -111,8 +112,8 @@ class Gaussian10:
         return dict(values=vals, score=score, logw=logw, rows=rows, record=record, max_partials=mp)
 
 
-def gaussian10_importance(ops: Ops, impl: int, seed: int, n: int):
-    w = Gaussian10(ops, impl, seed, n)
+def gaussian10_importance(ops: Ops, impl: int, seed: int, n: int, fast_math: bool = False):
+    w = Gaussian10(ops, impl, seed, n, fast_math=fast_math)
     out = w.step()
     q, m = int(out["q"].cpu()), float(out["max"].cpu())
     log_z = m + math.log(q) - w.frac * math.log(2.0) - math.log(n)

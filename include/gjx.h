@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define GJX_VERSION_MAJOR 0
-#define GJX_VERSION_MINOR 2
+#define GJX_VERSION_MINOR 3
 
 typedef void* gjx_stream; /* hipStream_t; ignored by the oracle build */
 
@@ -41,7 +41,10 @@ typedef enum {
   GJX_ERR_UNSUPPORTED = -2,  /* valid request this build cannot run */
   GJX_ERR_WORKSPACE = -3,    /* workspace too small */
   GJX_ERR_LAUNCH = -4,       /* HIP launch / runtime failure */
-  GJX_ERR_NO_DEVICE = -5     /* no usable gfx950 device */
+  GJX_ERR_NO_DEVICE = -5,    /* no usable gfx950 device */
+  GJX_ERR_JIT = -6           /* run-time specialisation (hiprtc compile / module load) of a plan failed; the cause is
+                                logged to stderr.  Never a silent fallback: GJX_PLAN_JIT_FALLBACK=1 opts into the
+                                table interpreter instead */
 } gjx_status;
 
 /* ---- PRNG ------------------------------------------------------------------------------- */
@@ -189,6 +192,17 @@ typedef struct gjx_plan gjx_plan;
 #define GJX_MAX_SITES 64
 
 int gjx_plan_create(const gjx_site* sites /*host*/, int n_sites, gjx_plan** out);
+/* Plan options (flags of gjx_plan_create_ex; gjx_plan_create passes 0).
+ *  GJX_PLAN_FAST_MATH: the north star bounds log-weights by 1e-5 relative on the path WITHOUT resampling, so an
+ *    importance plan may opt into the hardware transcendentals (v_log / v_exp / v_sqrt / v_sin / v_cos) for the
+ *    CONTINUOUS parts of the walk: the Box-Muller transform of PHILOX Normal sites, the transcendental terms of
+ *    log-densities and the row-anchored weight sums.  Everything that decides something (gamma rejection tests,
+ *    categorical CDFs, Bernoulli thresholds) stays on the exact functions, so the same particles are drawn from the
+ *    same counters and every value / log-weight agrees with the exact plan to <= 1e-5 relative (tested); results
+ *    are no longer bit-identical to the oracle.  Honoured by the specialised (hiprtc) kernels of libgjx_hip.so; the
+ *    table interpreter and the oracle ignore it (they ARE the exact specification). */
+#define GJX_PLAN_FAST_MATH 1u
+int gjx_plan_create_ex(const gjx_site* sites /*host*/, int n_sites, uint32_t flags, gjx_plan** out);
 int gjx_plan_destroy(gjx_plan* p);
 /* Plan specialisation (libgjx_hip.so): on first use per RNG scheme a plan is lowered to a
  * straight-line gfx950 kernel — the same device functions in the same order, constants folded —

@@ -333,6 +333,10 @@ int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
   *out = p;
   return GJX_OK;
 }
+int gjx_plan_create_ex(const gjx_site* sites, int n_sites, uint32_t flags, gjx_plan** out) {
+  if (flags & ~(uint32_t)GJX_PLAN_FAST_MATH) return GJX_ERR_INVALID;
+  return gjx_plan_create(sites, n_sites, out); /* the oracle is the exact specification: FAST_MATH is not its concern */
+}
 int gjx_plan_destroy(gjx_plan* p) { free(p); return GJX_OK; }
 int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t buf_len, size_t* needed) {
   (void)p; (void)impl; (void)buf; (void)buf_len; (void)needed;
@@ -783,14 +787,18 @@ static void smc_ancestors(const gjx_smc_config* cfg, int t, const float* prev_lo
   double u0 = u0_from_bits(o_bits64_at(&st, 0));
   double scale = (double)N / (double)Q;
   const uint64_t nt = gjx_num_tiles(N);
-  uint64_t C = 0;
-  for (uint64_t b = 0; b < nt; ++b) {
+  /* tiles are independent given the exclusive prefix of their (exact) masses: one tile per loop iteration */
+  uint64_t* prefix = (uint64_t*)malloc(sizeof(uint64_t) * (nt + 1));
+  if (!prefix) return;
+  prefix[0] = 0;
+  for (uint64_t b = 0; b < nt; ++b) prefix[b + 1] = prefix[b] + tile_sums[b];
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int64_t bb = 0; bb < (int64_t)nt; ++bb) {
+    const uint64_t b = (uint64_t)bb;
+    uint64_t C = prefix[b];
     const int64_t t_lo = teeth_below(C, scale, u0, (int64_t)N);
-    const int64_t t_hi = b + 1 == nt ? (int64_t)N : teeth_below(C + tile_sums[b], scale, u0, (int64_t)N);
-    if (t_hi <= lo || t_lo >= hi) {
-      C += tile_sums[b];
-      continue;
-    }
+    const int64_t t_hi = b + 1 == nt ? (int64_t)N : teeth_below(prefix[b + 1], scale, u0, (int64_t)N);
+    if (t_hi <= lo || t_lo >= hi) continue;
     int64_t prev = t_lo;
     const uint64_t i1 = (b + 1) * O_TILE < N ? (b + 1) * O_TILE : N;
     for (uint64_t i = b * O_TILE; i < i1; ++i) {
@@ -801,6 +809,7 @@ static void smc_ancestors(const gjx_smc_config* cfg, int t, const float* prev_lo
       if (ni > prev) prev = ni;
     }
   }
+  free(prefix);
 }
 
 int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const float* max_partials,

@@ -626,6 +626,184 @@ def case_batched_estimates(impl):
         assert f(got2[b]) == f(alg2.log_marginal_likelihood_estimate(keys[b]))
 
 
+# ---- GenSP estimators (smc.py:181-225, 432-465; sp.py:207-252) -----------------------------------------
+def _gaussian_pair():
+    @gen
+    def model():
+        z = normal(0.0, 1.0) @ "z"
+        _ = normal(z, 0.5) @ "y"
+        return z
+
+    return model
+
+
+def _lpdf(x, m, s):  # float64 log N(x; m, s)
+    return -0.5 * ((x - m) / s) ** 2 - math.log(s) - 0.5 * math.log(2 * math.pi)
+
+
+def case_gensp_estimators(impl):
+    """estimate_normalizing_constant / estimate_reciprocal_normalizing_constant / run_csmc_for_normalizing_constant /
+    estimate_logpdf on the conjugate pair z ~ N(0,1), y ~ N(z, 0.5): closed-form Z = N(y; 0, sqrt(1.25)), the
+    unbiasedness identities of the estimators, and an independent float64 restatement of the reference's
+    formulas (key order: split, then split(key, K-1); retained particle LAST) on explicitly derived particles."""
+    model = _gaussian_pair()
+    y0 = 0.7
+    log_z = _lpdf(y0, 0.0, math.sqrt(1.25))
+    target = Target(model, (), C["y"].set(y0))
+    alg = ImportanceK(target, k_particles=50000)
+    key = genjax.random.key(17, impl)
+    # (1) estimate_normalizing_constant == ChangeTarget(alg, target).run_smc(second split).lml  (smc.py:204-212)
+    z1 = f(alg.estimate_normalizing_constant(key, target))
+    assert z1 == pytest.approx(log_z, abs=0.02)
+    assert z1 == f(alg.log_marginal_likelihood_estimate(key, target))  # the same key path (smc.py:145-156)
+    # an EQUAL but distinct target object takes the re-weighting pass: same estimate up to f32 rounding
+    z1b = f(alg.estimate_normalizing_constant(key, Target(model, (), C["y"].set(y0))))
+    assert z1b == pytest.approx(z1, abs=2e-5)
+    # a DIFFERENT target re-weights by the likelihood ratio
+    t2 = Target(model, (), C["y"].set(-0.4))
+    assert f(alg.estimate_normalizing_constant(key, t2)) == pytest.approx(_lpdf(-0.4, 0.0, math.sqrt(1.25)), abs=0.03)
+    # unbiasedness: E[exp(estimate)] = Z for ANY k (here k = 8, 400 keys)
+    small = ImportanceK(target, k_particles=8)
+    ks = genjax.random.split(genjax.random.key(3, impl), 400)
+    ests = torch.stack([torch.as_tensor(small.estimate_normalizing_constant(ks[i], target)).reshape(()).double().cpu()
+                        for i in range(400)])
+    ratio = torch.exp(ests - log_z)
+    assert f(ratio.mean()) == pytest.approx(1.0, abs=5 * f(ratio.std()) / 20.0)
+
+    # (2) run_csmc + the reciprocal estimator.  Explicit derivation of the conditional collection:
+    K = 64
+    alg_k = ImportanceK(target, k_particles=K)
+    z_star = 0.31
+    retained = C["z"].set(z_star)
+    kk = genjax.random.key(23, impl)
+    k_a, k_b = genjax.random.split(kk)            # run_csmc_for_normalizing_constant: key, sub_key = split(key)
+    coll = alg_k.run_csmc(k_b, retained)          # prev.run_csmc(sub_key, latent_choices)
+    zs = coll.get_particles().get_choices()["z"].double().cpu()
+    lw = coll.get_log_weights().double().cpu()
+    assert len(coll) == K and f(zs[-1]) == pytest.approx(z_star, abs=1e-7)  # retained LAST
+    # fresh particles are prior draws weighted by the likelihood; the retained one carries its full score (all
+    # of its choices are constrained: the reference's weight, smc.py:333-346)
+    for i in (0, 5, K - 2):
+        assert f(lw[i]) == pytest.approx(_lpdf(y0, f(zs[i]), 0.5), abs=1e-5)
+    assert f(lw[-1]) == pytest.approx(_lpdf(z_star, 0.0, 1.0) + _lpdf(y0, z_star, 0.5), abs=1e-5)
+    # the first K-1 particles are those of split(second split of k_b, K-1): smc.py:318-319
+    k_b1, k_b2 = genjax.random.split(k_b)
+    fresh = target.importance(genjax.random.split(k_b2, K - 1), ChoiceMap.empty())[0].get_choices()["z"].double().cpu()
+    assert torch.equal(fresh, zs[:-1])
+    # float64 restatement of smc.py:432-465 for the SAME target (rejected weights re-scored against it) and w
+    w_in = _lpdf(y0, z_star, 0.5)                 # properly weighted for the target under the prior proposal
+    rej = torch.tensor([_lpdf(y0, f(zs[i]), 0.5) for i in range(K - 1)], dtype=torch.float64)
+    retained_score = _lpdf(z_star, 0.0, 1.0) + _lpdf(y0, z_star, 0.5)
+    tail = w_in - retained_score + f(lw[-1])
+    want = retained_score - (f(torch.logsumexp(torch.cat([rej, torch.tensor([tail], dtype=torch.float64)]), 0)) - math.log(K))
+    got = f(alg_k.estimate_reciprocal_normalizing_constant(kk, Target(model, (), C["y"].set(y0)), retained, w_in))
+    assert got == pytest.approx(want, abs=3e-5)
+    assert got == pytest.approx(f(ChangeTarget(alg_k, target).run_csmc_for_normalizing_constant(kk, retained, w_in)), abs=3e-5)
+    # conditional-SMC identity: with z* ~ p(z | y) and the proper w, E[exp(estimate - log p(z*, y))] = 1 / Z
+    post_m, post_s = y0 / 1.25, math.sqrt(0.2)
+    g = torch.Generator().manual_seed(7)
+    inv = []
+    small = ImportanceK(target, k_particles=6)
+    ks = genjax.random.split(genjax.random.key(29, impl), 400)
+    for i in range(400):
+        zi = post_m + post_s * float(torch.randn((), generator=g))
+        joint = _lpdf(zi, 0.0, 1.0) + _lpdf(y0, zi, 0.5)
+        e = f(small.estimate_reciprocal_normalizing_constant(ks[i], target, C["z"].set(zi), _lpdf(y0, zi, 0.5)))
+        inv.append(math.exp(e - joint + log_z))   # = Z / Z_hat_csmc
+    inv = torch.tensor(inv, dtype=torch.float64)
+    assert f(inv.mean()) == pytest.approx(1.0, abs=5 * f(inv.std()) / 20.0)
+    # k_particles = 1: the collection is the retained particle alone
+    one = ImportanceK(target, k_particles=1)
+    e1 = f(one.estimate_reciprocal_normalizing_constant(kk, target, retained, w_in))
+    assert e1 == pytest.approx(retained_score - w_in, abs=2e-5)
+    assert f(one.estimate_logpdf(kk, retained, target)) == pytest.approx(0.0, abs=2e-5)  # score - its own weight
+
+    # (3) estimate_logpdf (smc.py:181-198): score of a particle drawn from run_csmc(key, v) minus that collection's
+    # log-marginal estimate; restated on the explicitly built collection
+    k1, k2 = genjax.random.split(kk)
+    cs = ChangeTarget(alg_k, target).run_csmc(k1, retained)
+    part = cs.sample_particle(k2)
+    want_lp = f(part.get_score()) - f(cs.get_log_marginal_likelihood_estimate())
+    assert f(alg_k.estimate_logpdf(kk, retained, target)) == pytest.approx(want_lp, abs=1e-6)
+    zp = f(part.get_choices()["z"])
+    assert f(part.get_score()) == pytest.approx(_lpdf(zp, 0.0, 1.0) + _lpdf(y0, zp, 0.5), abs=2e-5)
+
+
+def case_marginal_with_algorithm(impl):
+    """Marginal(selection, algorithm=ImportanceK(...)) (sp.py:207-252): `estimate_logpdf` is the algorithm's
+    normalising-constant estimate of the target constrained to the value; `random_weighted` simulates the model and
+    scores the selected choices with the reciprocal estimator.  Used as a proposal `q` it plugs into ImportanceK
+    (custom_proposal.ipynb cell 22 shape)."""
+    model = _gaussian_pair()
+    K = 4000
+    template = Target(model, (), C["y"].set(0.0))  # the algorithm's own target: same constrained addresses
+    marg = genjax.marginal(S["y"], algorithm=ImportanceK(template, k_particles=K))(model)
+    key = genjax.random.key(41, impl)
+    # estimate_logpdf(y) ~ log p(y) = log N(y; 0, sqrt(1.25)); and it IS estimate_normalizing_constant on the target
+    for yv in (0.3, -1.1):
+        est = f(marg.estimate_logpdf(key, C["y"].set(yv)))
+        assert est == pytest.approx(_lpdf(yv, 0.0, math.sqrt(1.25)), abs=0.06)
+        again = f(ImportanceK(template, k_particles=K).estimate_normalizing_constant(key, Target(model, (), C["y"].set(yv))))
+        assert est == again
+    # random_weighted: key order of sp.py:222-236 — simulate with the 2nd output of the first split, project with the
+    # 2nd output of the second split, the remaining key goes to the algorithm
+    wgt, chm = marg.random_weighted(key)
+    assert "y" in chm and "z" not in chm
+    k_rest, k_sim = genjax.random.split(key)
+    tr = model.simulate(k_sim, ())
+    assert f(chm["y"]) == f(tr.get_choices()["y"])
+    k_alg, k_proj = genjax.random.split(k_rest)
+    z_sim, y_sim = f(tr.get_choices()["z"]), f(tr.get_choices()["y"])
+    w_proj = f(tr.project(k_proj, ~S["y"]))
+    assert w_proj == pytest.approx(_lpdf(z_sim, 0.0, 1.0), abs=2e-5)  # score of the unselected choice
+    direct = f(ImportanceK(template, k_particles=K).estimate_reciprocal_normalizing_constant(
+        k_alg, Target(model, (), C["y"].set(tr.get_choices()["y"])), C["z"].set(tr.get_choices()["z"]), tr.project(k_proj, ~S["y"])))
+    assert f(wgt) == direct
+    # the formula of smc.py:432-465 in float64 on the explicitly derived conditional collection (reference quirks
+    # kept: the retained score / weight are those under the algorithm's OWN target, y = 0)
+    alg = ImportanceK(template, k_particles=K)
+    ka, kb = genjax.random.split(k_alg)
+    coll = alg.run_csmc(kb, C["z"].set(tr.get_choices()["z"]))
+    zs = coll.get_particles().get_choices()["z"].double().cpu()
+    rej = torch.tensor([_lpdf(y_sim, float(v), 0.5) for v in zs[:-1]], dtype=torch.float64)  # re-scored for y = y_sim
+    ret_score = _lpdf(z_sim, 0.0, 1.0) + _lpdf(0.0, z_sim, 0.5)
+    tail = w_proj - ret_score + f(coll.get_log_weights()[-1])
+    want = ret_score - (f(torch.logsumexp(torch.cat([rej, torch.tensor([tail], dtype=torch.float64)]), 0)) - math.log(K))
+    assert f(wgt) == pytest.approx(want, abs=5e-5)
+    # round trip: the value it proposed has an estimated log-density close to the analytic marginal
+    rt = f(marg.estimate_logpdf(genjax.random.key(43, impl), chm))
+    assert rt == pytest.approx(_lpdf(y_sim, 0.0, math.sqrt(1.25)), abs=0.06)
+    # as a proposal q of ImportanceK over a target whose latent is "y" of the marginal's model
+    @gen
+    def outer():
+        y = normal(0.0, math.sqrt(1.25)) @ "y"
+        _ = normal(y, 1.0) @ "obs"
+
+    @gen
+    def pair_for(target):  # a proposal receives the target it proposes for (sp.py:217-238, notebook cell 20)
+        z = normal(0.0, 1.0) @ "z"
+        _ = normal(z, 0.5) @ "y"
+
+    t_outer = Target(outer, (), C["obs"].set(0.5))
+    template_q = Target(pair_for, (t_outer,), C["y"].set(0.0))
+    small = genjax.marginal(S["y"], algorithm=ImportanceK(template_q, k_particles=32))(pair_for)
+    coll = ImportanceK(t_outer, q=small, k_particles=64).run_smc(genjax.random.key(47, impl))
+    ys, lw = coll.get_particles().get_choices()["y"], coll.get_log_weights()
+    assert ys.shape == (64,) and lw.shape == (64,) and bool(torch.isfinite(lw).all())
+    # weights = target score at the proposed choice - q's own (reciprocal-estimator) score of it, particle i using
+    # the SAME sub-key for q and for the target (smc.py:299-305).  (With the reference's `project(~selection)` weight
+    # the score q reports is not the marginal density — mirrored, not fixed: DESIGN.md §8 — so only the plumbing
+    # is pinned here, not a posterior.)
+    _, sub = genjax.random.split(genjax.random.key(47, impl))
+    pks = genjax.random.split(sub, 64)
+    for i in (0, 9, 63):
+        wi, ci = small.random_weighted(pks[i], t_outer)
+        yi = f(ci["y"])
+        assert yi == f(ys[i])
+        assert f(lw[i]) == pytest.approx(_lpdf(yi, 0.0, math.sqrt(1.25)) + _lpdf(0.5, yi, 1.0) - f(wi), abs=3e-5)
+
+
+
 def case_bootstrap_smc(impl):
     from genjax._amd import workloads as W
 
@@ -717,4 +895,5 @@ def case_general_smc(impl):
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_fused_equals_eager, case_particle_collection, case_custom_proposal,
-             case_scan, case_vmap, case_vmap_indexed_constraints, case_batched_estimates, case_bootstrap_smc, case_general_smc, case_update]
+             case_scan, case_vmap, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
+             case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update]

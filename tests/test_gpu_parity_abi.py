@@ -119,16 +119,22 @@ def test_categorical(hip_ops, oracle_ops, impl, mode):
             assert not bool((hv.cpu() == 2).any()), "a -inf logit must never be drawn"
 
 
-@pytest.fixture(params=["specialized", "interpreter"])
+@pytest.fixture(params=["specialized", "pair", "interpreter"])
 def plan_mode(request, monkeypatch):
-    """The importance kernels: the hiprtc-specialised straight-line kernel (default; Philox lazy batches
-    take its paired two-particles-per-lane form) and the site-table interpreter (GJX_PLAN_JIT=0)."""
+    """The importance kernels: the hiprtc-specialised straight-line kernel (default: Philox lazy batches take the
+    form with FOUR adjacent particles per lane, one wave per 256-particle row, whenever n and the buffers are 16-byte
+    aligned), the same with two particles per lane (GJX_JIT_FORM=pair) and the site-table interpreter
+    (GJX_PLAN_JIT=0).  All three must give the oracle's bits."""
     monkeypatch.setenv("GJX_PLAN_JIT", "0" if request.param == "interpreter" else "1")
+    if request.param == "pair":
+        monkeypatch.setenv("GJX_JIT_FORM", "pair")
+    else:
+        monkeypatch.delenv("GJX_JIT_FORM", raising=False)
     return request.param
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-@pytest.mark.parametrize("n", [1, 1000, 1024, 70001])
+@pytest.mark.parametrize("n", [1, 1000, 1024, 70001, 70004])
 def test_importance_gaussian10(hip_ops, oracle_ops, impl, n, plan_mode):
     h = W.gaussian10_importance(hip_ops, impl, seed=11, n=n)
     o = W.gaussian10_importance(oracle_ops, impl, seed=11, n=n)
@@ -183,7 +189,7 @@ def test_importance_key_forms_agree(hip_ops, oracle_ops, impl):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-@pytest.mark.parametrize("n", [2, 1000, 1001, 70002])
+@pytest.mark.parametrize("n", [2, 1000, 1001, 70002, 70004])
 def test_importance_passes_in_one_launch(hip_ops, oracle_ops, impl, n, plan_mode):
     """gjx_importance_run_batch: L independent passes (seeds s, s+1, ...) in one launch write what L separate
     passes write — trace columns, scores, log-weights, row sums and folded log-marginals — and equal the
@@ -554,3 +560,28 @@ def test_full_size_batches(hip_ops):
     zf = np.array(r["log_z"])
     assert len({round(z, 9) for z in zf}) == 16
     assert abs(zf.mean() - W.lgssm_exact_log_z(f.y)) < 0.1 and zf.std() < 0.1, (zf, W.lgssm_exact_log_z(f.y))
+
+
+@pytest.mark.parametrize("form", ["pair", "quad", "one"])
+@pytest.mark.parametrize("n", [1000, 70004, 1_000_000])
+def test_importance_fast_math_tolerance(hip_ops, oracle_ops, n, form, monkeypatch):
+    """GJX_PLAN_FAST_MATH (hardware log / exp / sqrt / sin / cos for the continuous parts of the walk): the same
+    particles from the same counters, every latent value and log-weight within the north star's 1e-5 relative
+    bound of the exact specification (the oracle), log Z within 1e-4 absolute."""
+    monkeypatch.setenv("GJX_PLAN_JIT", "1")
+    monkeypatch.setenv("GJX_JIT_FORM", form)
+    h = W.gaussian10_importance(hip_ops, 1, seed=5, n=n, fast_math=True)
+    o = W.gaussian10_importance(oracle_ops, 1, seed=5, n=n)
+    lw_h, lw_o = h["logw"].cpu().double(), o["logw"].double()
+    rel = ((lw_h - lw_o).abs() / lw_o.abs().clamp_min(1e-30)).max().item()
+    assert rel <= 1e-5, f"log-weights: max relative deviation {rel:.3g}"
+    sc_h, sc_o = h["score"].cpu().double(), o["score"].double()
+    assert ((sc_h - sc_o).abs() / sc_o.abs().clamp_min(1e-30)).max().item() <= 1e-5
+    for a, b in zip(h["values"], o["values"]):
+        a, b = a.cpu().double(), b.double()
+        # a standard normal near 0 has no meaningful relative error: 1e-5 relative OR 2e-6 absolute (|z| <~ 6)
+        err = (a - b).abs()
+        assert bool(((err <= 1e-5 * b.abs()) | (err <= 2e-6)).all()), f"latent values: max abs deviation {err.max().item():.3g}"
+    assert abs(h["log_z_rows"] - o["log_z_rows"]) <= 1e-4
+    if form == "pair":  # the exact plan on the same device still gives the oracle's bits (the flag is per plan)
+        same(W.gaussian10_importance(hip_ops, 1, seed=5, n=n)["logw"], o["logw"], "exact plan next to a fast one")

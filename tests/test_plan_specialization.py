@@ -33,9 +33,10 @@ def source_of(ops, plan, impl):
 
 
 @pytest.mark.parametrize("impl", [0, 1])
-def test_gaussian10_plan_compiles(hip_lib_nogpu, impl):
+def test_gaussian10_plan_compiles(hip_lib_nogpu, impl, monkeypatch):
     ops = hip_lib_nogpu
     plan = ops.plan_create(W.gaussian10_sites(W.gaussian10_data()))
+    monkeypatch.setenv("GJX_JIT_FORM", "pair")
     src1 = source_of(ops, plan, impl)
     if impl == 0:  # jax key tree: one particle per lane, erfinv normals, 20 log-densities
         assert src1.count("std_normal(") == 10 and src1.count("logpdf_normal_pre(") == 20
@@ -48,6 +49,17 @@ def test_gaussian10_plan_compiles(hip_lib_nogpu, impl):
         assert src1.count("logpdf_normal_pre(") == 40
         assert src1.count("kTagPair") == 5 and src1.count("philox4x32(") == 5
         assert "ks.parent.k0" in src1 and "__launch_bounds__(128" in src1
+        # the default form: FOUR adjacent particles per lane = two pairs, one wave per 256-particle row (no LDS,
+        # no barrier in the row statistics), 16-byte column stores
+        monkeypatch.delenv("GJX_JIT_FORM")
+        src4 = source_of(ops, plan, impl)
+        assert src4.count("bm_pair(") == 20 and src4.count("logpdf_normal_pre(") == 80
+        assert src4.count("kTagPair") == 10 and "__launch_bounds__(64" in src4
+        assert "make_uint4(" in src4 and "__syncthreads" not in src4.split("lse_tail")[0].split("void gjx_plan_kernel_philox")[1]
+        # GJX_PLAN_FAST_MATH switches the device header's continuous functions to the hardware transcendentals
+        fast = ops.plan_create(W.gaussian10_sites(W.gaussian10_data()), fast_math=True)
+        assert source_of(ops, fast, impl).startswith("#define GJX_FAST_MATH 1")
+        ops.lib.call("gjx_plan_compile_check", fast.handle, impl)
     ops.lib.call("gjx_plan_compile_check", plan.handle, impl)
 
 
