@@ -16,6 +16,7 @@
 #include <stdint.h>
 #else  // hiprtc (plan specialisation): HIP built-ins are pre-included, fixed-width types are not
 typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
 typedef int int32_t;
 typedef unsigned int uint32_t;
 typedef long long int64_t;
@@ -805,6 +806,20 @@ struct FilterBatch {
   Key rkey[kMaxFilters];
 };
 
+// Collapse-proof resampling.  The kernel is source-tile-centric: a tile serves the output slots its mass owns, in
+// chunks of 1024.  Under weight collapse ONE tile owns (nearly) every slot; left alone its workgroup would walk a
+// thousand chunks while 255 CUs idle.  So a tile serves at most kCapSlots of its slots itself; the slots beyond
+// belong to the workgroup of the 1024-slot WINDOW they fall into (workgroup h = slots [1024 h, 1024 h + 1024)),
+// which rebuilds the heavy tile's CDF and serves just that window.  Which tiles are heavy follows from the exact
+// tile masses alone (every workgroup reduces them anyway), so owners and helpers agree without communicating; the
+// ancestors, particles and weights are the same bits whoever computes them.
+constexpr int kCapSlots = 4 * kTile;
+constexpr int kMaxHeavy = 256;  // more candidates than this (never seen): owners serve everything, as before
+// Layout of the precomputed tile-mass prefix (k_scan_tiles; large populations and filter batches): [0 .. ntiles] the
+// exclusive prefix (entry ntiles = total), then R1, R2 (ESS sums), the number of heavy candidates and their
+// (tile, prefix) pairs.
+constexpr int kPrefixTail = 3 + 2 * kMaxHeavy;
+
 struct ResampleArgs {
   const float* lw;            // [n] source log-weights
   const float* m_ptr;         // max of lw
@@ -818,10 +833,33 @@ struct ResampleArgs {
   int rkey_has_fold;
   uint32_t rkey_fold;
   uint64_t* q_total_out = nullptr;  // nullable: block 0 stores the total mass (= sum of tile_sums)
-  const uint64_t* tile_prefix = nullptr;  // nullable: exclusive prefix [ntiles + 1] of tile_sums, precomputed for
-                                // large populations (otherwise every workgroup reduces tile_sums itself)
+  const uint64_t* tile_prefix = nullptr;  // nullable: [ntiles + 1 + kPrefixTail] (k_scan_tiles), precomputed for large
+                                // populations and filter batches (otherwise every workgroup scans tile_sums itself)
   FilterBatch fb;               // several filters per launch (n, ntiles, n_out, out_lo/out_hi are then PER FILTER)
+  // ESS-adaptive resampling (gjx_smc_config.ess_threshold): ess_thr = threshold * n_total, 0 = resample always.
+  double ess_thr = 0.0;
+  const uint64_t* tile_ess = nullptr;  // [2 ntiles]: (R1_b, R2_b) of every source tile (needed when ess_thr > 0)
+  int32_t* resampled_out = nullptr;    // nullable: block 0 of each filter stores 1 (resampled) / 0 (kept)
+  float* max_accum = nullptr;          // nullable: running max of the NEW log-weights (float atomic max; -inf before)
+  int allow_help = 1;                  // 0: owners serve all their slots (generic entry points with n_out != n)
 };
+
+// resample iff ESS = R1^2 / R2 < thr (thr in particles); every backend evaluates exactly these double operations
+GJX_HD bool ess_says_resample(uint64_t r1, uint64_t r2, double thr) {
+  if (!(thr > 0.0) || r2 == 0) return true;
+  const double a = (double)r1 * (double)r1;
+  const double b = thr * (double)r2;
+  return a < b;
+}
+// the reduced weight of the ESS sums: the top 16 bits of the fixed-point weight
+GJX_HD uint64_t ess_r(uint64_t q, int frac) { return q >> (frac - 16); }
+// float atomic max through the integer atomics (works from an initial -inf; ignores NaN: callers never pass one)
+GJX_DEV void atomic_max_f32(float* addr, float v) {
+  if (!(v > -__builtin_inff())) return;
+  v = v + 0.0f;  // -0 -> +0
+  if (v >= 0.0f) __hip_atomic_fetch_max(reinterpret_cast<int*>(addr), (int)f2u(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else __hip_atomic_fetch_min(reinterpret_cast<unsigned*>(addr), f2u(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Row-anchored log-sum-exp of a whole pass: e = max e_b; buckets B_d = sum of S_b over
@@ -1020,186 +1058,349 @@ GJX_DEV void policy_store_quad(Policy& P, int64_t jq, int64_t out_lo, uint64_t b
     if (ok[u]) P.store(jq + u, out_lo, base + (uint64_t)src[u], o[u]);
 }
 
+// log-weight carried over a step without resampling: Out types with an `lw` member accumulate it
+template <class Out>
+GJX_DEV auto carry_lw(Out& o, float prev, int) -> decltype(o.lw, void()) { o.lw = o.lw + prev; }
+template <class Out>
+GJX_DEV void carry_lw(Out&, float, long) {}
+template <class Out>
+GJX_DEV auto out_lw(const Out& o, float w, int) -> decltype(o.lw, float()) { return o.lw; }
+template <class Out>
+GJX_DEV float out_lw(const Out&, float w, long) { return w; }
+
 template <int IMPL, class Policy>
 GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials) {
-  __shared__ uint64_t sh64[kBlock / kWave];
-  __shared__ float shf[kBlock / kWave];
-  __shared__ int32_t nb[kTile];  // teeth below the inclusive CDF of each source in the tile
+  constexpr int kW = kBlock / kWave;
+  __shared__ uint64_t sh_scan[kW];      // tile-mass scan
+  __shared__ uint64_t sh_ess[2 * kW];   // ESS sums
+  __shared__ uint64_t sh_cdf[kW];       // CDF scan of a served tile
+  __shared__ uint64_t sh_pre;           // exclusive prefix of this workgroup's own tile
+  __shared__ float shf[kW];
+  __shared__ int shi[kW];
+  __shared__ int32_t nb[kTile];     // teeth below the inclusive CDF of each source in the served tile
+  __shared__ int32_t anc_s[kTile];  // run-start marks of the ancestor search
+  __shared__ uint32_t heavy_n, hit_n;
+  __shared__ uint32_t heavy_tile[kMaxHeavy];
+  __shared__ uint64_t heavy_pre[kMaxHeavy];
+  __shared__ uint16_t hit[kMaxHeavy];
   uint64_t b = blockIdx.x;
   const int tid = threadIdx.x;
   // this workgroup's filter: local views of the per-filter arrays, keys and results
   const float* lw_all = A.lw;
   const uint64_t* tile_sums = A.tile_sums;
+  const uint64_t* tile_ess = A.tile_ess;
   const float* m_ptr = A.m_ptr;
   uint64_t* q_total_out = A.q_total_out;
+  int32_t* resampled_out = A.resampled_out;
+  float* max_accum = A.max_accum;
   Key rkey = A.rkey;
   const uint64_t* tile_prefix = A.tile_prefix;
   if (A.fb.n_filters > 1) {
     const uint32_t f = (uint32_t)(b / A.fb.tiles);
     b -= (uint64_t)f * A.fb.tiles;
-    if (tile_prefix) tile_prefix += (uint64_t)f * (A.fb.tiles + 1);
+    if (tile_prefix) tile_prefix += (uint64_t)f * (A.fb.tiles + 1 + kPrefixTail);
     lw_all += (uint64_t)f * A.fb.stride;
     tile_sums += (uint64_t)f * A.fb.tiles;
+    if (tile_ess) tile_ess += 2 * (uint64_t)f * A.fb.tiles;
     m_ptr += (uint64_t)f * A.fb.mq_stride;
     if (q_total_out) q_total_out += (uint64_t)f * A.fb.mq_stride;
+    if (resampled_out) resampled_out += (uint64_t)f * A.fb.mq_stride;
+    if (max_accum) max_accum += (uint64_t)f * A.fb.mq_stride;
     if (max_partials) max_partials += (uint64_t)f * A.fb.tiles;
     rkey = A.fb.rkey[f];
     P.select_filter((uint64_t)f * A.fb.stride, A.fb.step_key[f]);
   }
   const uint64_t base = b * kTile;
+  const bool adaptive = A.ess_thr > 0.0;
 
-  // Issue this tile's loads first: their HBM latency overlaps the tile-mass prefix reduction.  A rank that owns
-  // only a shard of the output slots decides from the tile masses alone whether this source tile feeds any of its
-  // slots, and touches the tile's particles only then (remote tiles it does not need were never exchanged).
+  // Issue the own tile's loads first: their HBM latency overlaps the tile-mass scan.  A rank that owns only a shard
+  // of the output slots decides from the tile masses alone whether a source tile feeds any of its slots, and touches
+  // the tile's particles only then (remote tiles it does not need were never exchanged).
   const bool part = A.out_lo > 0 || A.out_hi < (int64_t)A.n_out;
   float lw4[kPer];
-  auto load_tile = [&] {
-    if (kPer == 4 && A.lw_vec && base + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
-      const float4 v = reinterpret_cast<const float4*>(lw_all + base)[tid];
+  auto load_tile = [&](uint64_t tbase) {
+    if (kPer == 4 && A.lw_vec && tbase + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
+      const float4 v = reinterpret_cast<const float4*>(lw_all + tbase)[tid];
       lw4[0] = v.x; lw4[1] = v.y; lw4[kPer > 2 ? 2 : 0] = v.z; lw4[kPer > 3 ? 3 : 0] = v.w;
-    } else if (kPer == 2 && A.lw_vec && base + kTile <= A.n) {
-      const float2 v = reinterpret_cast<const float2*>(lw_all + base)[tid];
-      lw4[0] = v.x; lw4[1] = v.y;
     } else {
 #pragma unroll
       for (int r = 0; r < kPer; ++r) {
-        const uint64_t i = base + kPer * (uint64_t)tid + r;
+        const uint64_t i = tbase + kPer * (uint64_t)tid + r;
         lw4[r] = i < A.n ? lw_all[i] : -__builtin_inff();
       }
     }
-    P.fetch_source(base, A.n, tid);  // registers now, LDS after the scan
+    P.fetch_source(tbase, A.n, tid);  // registers now, LDS after the scan
   };
-  if (!part) load_tile();
+  bool own_loaded = false;
+  if (!part) { load_tile(base); own_loaded = true; }
 
-  // prefix / total of tile masses (u64, exact)
-  uint64_t pre = 0, tot = 0;
+  // ---- tile masses: exclusive prefix of the own tile, total, ESS sums, heavy candidates ------------------------
+  if (tid == 0) { heavy_n = 0; hit_n = 0; }
+  uint64_t pre = 0, tot = 0, r1 = 0, r2 = 0;
+  uint32_t n_heavy = 0;
+  const double n_out_d = (double)A.n_out;
   if (tile_prefix) {
     pre = tile_prefix[b];
     tot = tile_prefix[A.ntiles];
+    if (adaptive) { r1 = tile_prefix[A.ntiles + 1]; r2 = tile_prefix[A.ntiles + 2]; }
+    n_heavy = (uint32_t)tile_prefix[A.ntiles + 3];
+    __syncthreads();
   } else {
-    for (uint64_t k = tid; k < A.ntiles; k += kBlock) {
-      const uint64_t v = tile_sums[k];
-      tot += v;
-      if (k < b) pre += v;
+    // thread t owns the c consecutive tiles [t c, t c + c): a thread-local prefix plus ONE block scan gives every
+    // thread the exclusive prefix of each of its tiles (own prefix, heavy candidates) and the total.  Up to kC tiles
+    // per thread stay in registers; beyond that (generic entry points on very large inputs) they are re-read.
+    constexpr int kC = 8;
+    const uint64_t c = (A.ntiles + kBlock - 1) / kBlock;
+    const uint64_t k0 = (uint64_t)tid * c;
+    uint64_t v[kC];
+    uint64_t local = 0, l1 = 0, l2 = 0;
+    if (c <= (uint64_t)kC) {
+#pragma unroll
+      for (int i = 0; i < kC; ++i) {
+        const uint64_t k = k0 + i;
+        const bool in = (uint64_t)i < c && k < A.ntiles;
+        v[i] = in ? tile_sums[k] : 0;
+        local += v[i];
+        if (adaptive && in) { l1 += tile_ess[2 * k]; l2 += tile_ess[2 * k + 1]; }
+      }
+    } else {
+      for (uint64_t i = 0; i < c && k0 + i < A.ntiles; ++i) {
+        local += tile_sums[k0 + i];
+        if (adaptive) { l1 += tile_ess[2 * (k0 + i)]; l2 += tile_ess[2 * (k0 + i) + 1]; }
+      }
     }
-    pre = block_sum(pre, sh64);
-    tot = block_sum(tot, sh64);
-  }
-  if (q_total_out && b == 0 && tid == 0) q_total_out[0] = tot;
-
-  const Stream<IMPL> rs(rkey, A.rkey_has_fold != 0, A.rkey_fold);
-  const double u0 = u0_from_bits(rs.bits64(0));
-  const double scale = (double)A.n_out / (double)tot;
-  const float m = m_ptr[0];
-  if (part) {
-    const uint64_t pre_next = tile_prefix ? tile_prefix[b + 1] : pre + tile_sums[b];
-    const int64_t t_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
-    const int64_t t_hi = b + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(pre_next, scale, u0, (int64_t)A.n_out);
-    if (t_hi <= A.out_lo || t_lo >= A.out_hi) {  // workgroup-uniform
-      if (max_partials && tid == 0) max_partials[b] = -__builtin_inff();
-      return;
-    }
-    load_tile();
-  }
-
-  // tile CDF: each thread owns 4 CONSECUTIVE sources (base + 4*tid + r) so the scan is a
-  // thread-local prefix plus one block scan.
-  uint64_t q[kPer];
-  uint64_t local = 0;
-#pragma unroll
-  for (int r = 0; r < kPer; ++r) {
-    const uint64_t i = base + kPer * (uint64_t)tid + r;
-    q[r] = i < A.n ? fixw(lw4[r], m, A.frac) : 0;
-    local += q[r];
-  }
-  uint64_t tile_total;
-  uint64_t run = pre + block_scan_excl(local, sh64, tile_total);
-  const int64_t n_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
-#pragma unroll
-  for (int r = 0; r < kPer; ++r) {
-    const uint64_t i = base + kPer * (uint64_t)tid + r;
-    run += q[r];
-    // the last real particle (and any padding after it) closes the comb at n_out
-    const int64_t t = (i + 1 >= A.n) ? (int64_t)A.n_out
-                                     : teeth_below(run, scale, u0, (int64_t)A.n_out);
-    nb[kPer * tid + r] = (int32_t)t;
-  }
-  // run-start marks of the ancestor search below; cleared here so that the barrier that publishes nb covers it
-  __shared__ int32_t anc_s[kTile];
-#pragma unroll
-  for (int r = 0; r < kPer; ++r) anc_s[tid + r * kBlock] = 0;
-  P.stage_source(tid);
-  __syncthreads();
-  const int64_t n_hi = nb[kTile - 1];
-  const int64_t j0 = n_lo > A.out_lo ? n_lo : A.out_lo;
-  const int64_t j1 = n_hi < A.out_hi ? n_hi : A.out_hi;
-
-  // Ancestors of the tile's output slots, 1024 at a time, WITHOUT a search per slot: ancestors are
-  // monotone, so every source that owns at least one slot marks the slot where its run starts (the chunk start
-  // for a run that began earlier) and an inclusive max-scan over the chunk spreads each mark over the run.
-  // ~4 LDS accesses per slot instead of a 10-step dependent binary search; 3 barriers per chunk.  Chunks start at a multiple of 4 slots and each lane serves FOUR
-  // CONSECUTIVE slots: one 16-byte LDS read of their ancestors, four independent propagate chains in flight
-  // (ILP), one shared cipher block for their draws (smc_quad_bits), 16-byte stores.  Waves whose 256 slots lie
-  // outside the tile's range skip the chunk.
-  __shared__ int shi[kBlock / kWave];
-  int32_t nbr[kPer];  // this thread's consecutive sources
-#pragma unroll
-  for (int r = 0; r < kPer; ++r) nbr[r] = nb[kPer * tid + r];
-  const int32_t nb_prev = tid == 0 ? (int32_t)n_lo : nb[kPer * tid - 1];
-  float tmax = -__builtin_inff();
-  const int64_t jb0 = j0 & ~(int64_t)3;
-  for (int64_t jb = jb0; jb < j1; jb += (int64_t)kTile) {
-    if (jb != jb0) __syncthreads();  // the marks were cleared after the previous chunk's scan
-    // every source that owns a slot of the chunk marks the first one it owns there — its run start, or the chunk
-    // start for the one source whose run straddles it — so each slot from max(jb, n_lo) on has a mark at or
-    // before it and no separate search for the straddling source is needed
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-      const int64_t start = r == 0 ? nb_prev : nbr[r - 1];  // source 4*tid+r owns slots [start, nbr[r])
-      if ((int64_t)nbr[r] > start && (int64_t)nbr[r] > jb && start < jb + (int64_t)kTile)
-        anc_s[(start > jb ? start : jb) - jb] = kPer * tid + r + 1;
+    const uint64_t incl = wave_scan_incl(local);
+    const int w = tid >> 6, lane = tid & 63;
+    if (adaptive) { l1 = wave_sum(l1); l2 = wave_sum(l2); }
+    if (lane == 63) {
+      sh_scan[w] = incl;
+      if (adaptive) { sh_ess[w] = l1; sh_ess[kW + w] = l2; }
     }
     __syncthreads();
-    int v[kPer];
-    int run_max = 0;
+    uint64_t wbase = 0;
 #pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-      const int x = anc_s[kPer * tid + r];
-      run_max = x > run_max ? x : run_max;
-      v[r] = run_max;
+    for (int i = 0; i < kW; ++i) {
+      if (i < w) wbase += sh_scan[i];
+      tot += sh_scan[i];
+      if (adaptive) { r1 += sh_ess[i]; r2 += sh_ess[kW + i]; }
     }
-    const int carry = block_scan_max_excl(run_max, shi);  // (its barriers close this chunk's reads of the marks)
-    if (jb + (int64_t)kTile < j1) {  // another chunk follows (rare): clear the marks for it
+    uint64_t run = wbase + incl - local;  // exclusive prefix of this thread's first tile
+    const double hscale = n_out_d / (double)tot;
+    auto visit = [&](uint64_t k, uint64_t mass) {
+      if (k == b) sh_pre = run;
+      // may own more than the cap (or, with no mass at all, the last tile: it closes the comb): a candidate
+      if (A.allow_help && ((double)mass * hscale > (double)(kCapSlots - 8) || (tot == 0 && k + 1 == A.ntiles))) {
+        const uint32_t e = atomicAdd(&heavy_n, 1u);
+        if (e < (uint32_t)kMaxHeavy) { heavy_tile[e] = (uint32_t)k; heavy_pre[e] = run; }
+      }
+      run += mass;
+    };
+    if (c <= (uint64_t)kC) {
 #pragma unroll
-      for (int r = 0; r < kPer; ++r) anc_s[tid + r * kBlock] = 0;
+      for (int i = 0; i < kC; ++i)
+        if ((uint64_t)i < c && k0 + i < A.ntiles) visit(k0 + i, v[i]);
+    } else {
+      for (uint64_t i = 0; i < c && k0 + i < A.ntiles; ++i) visit(k0 + i, tile_sums[k0 + i]);
     }
-    // every entry of the chunk is a valid local source index (slots outside [j0, j1) included — those before the
-    // tile's first slot have no mark and take source 0: they are computed along with their quad, never stored)
-    int src[kPer];
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-      const int a = v[r] > carry ? v[r] : carry;
-      src[r] = a ? a - 1 : 0;
-    }
-    // the lane's own four slots are the four entries it just resolved: no LDS round trip
-    const int64_t jq = jb + (int64_t)kPer * tid;
-    const int64_t wave_lo = jb + (int64_t)kPer * (tid & ~(kWave - 1));
-    if (wave_lo < j1 && wave_lo + (int64_t)kPer * kWave > j0) {  // wave-uniform
+    __syncthreads();
+    pre = sh_pre;
+    n_heavy = heavy_n;
+  }
+  if (q_total_out && b == 0 && tid == 0) q_total_out[0] = tot;
+  const bool helping = A.allow_help && n_heavy > 0 && n_heavy <= (uint32_t)kMaxHeavy;
+  const bool resample = !adaptive || ess_says_resample(r1, r2, A.ess_thr);
+  if (resampled_out && b == 0 && tid == 0) resampled_out[0] = resample ? 1 : 0;
+
+  float tmax = -__builtin_inff();
+  static_assert(kPer == 4, "four consecutive sources and four consecutive output slots per lane");
+
+  if (!resample) {
+    // ---- no resampling at this step: slot j keeps particle j, its log-weight accumulates --------------------
+    const int64_t jq = (int64_t)base + (int64_t)kPer * tid;
+    if ((int64_t)base < A.out_hi && (int64_t)(base + kTile) > A.out_lo && base < A.n) {  // workgroup-uniform
+      if (!own_loaded) load_tile(base);
+      P.stage_source(tid);
+      __syncthreads();
+      const int64_t hi = A.out_hi < (int64_t)A.n ? A.out_hi : (int64_t)A.n;
+      int src[kPer];
       bool ok[kPer];
 #pragma unroll
-      for (int r = 0; r < kPer; ++r) ok[r] = jq + r >= j0 && jq + r < j1;
+      for (int r = 0; r < kPer; ++r) {
+        src[r] = kPer * tid + r;
+        ok[r] = jq + r >= A.out_lo && jq + r < hi;
+      }
       typename Policy::Out out[kPer];
       float w[kPer];
       policy_compute_quad(P, jq, src, out, w, 0);
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) {
+        carry_lw(out[r], lw4[r], 0);
+        w[r] = out_lw(out[r], w[r], 0);
+      }
       policy_store_quad(P, jq, A.out_lo, base, src, out, ok, 0);
 #pragma unroll
       for (int r = 0; r < kPer; ++r) tmax = ok[r] && w[r] > tmax ? w[r] : tmax;
     }
+  } else {
+    const Stream<IMPL> rs(rkey, A.rkey_has_fold != 0, A.rkey_fold);
+    const double u0 = u0_from_bits(rs.bits64(0));
+    const double scale = n_out_d / (double)tot;
+    const float m = m_ptr[0];
+    int served = 0;
+    // Serve the output slots [s_lo, s_hi) that source tile `ts` (exclusive mass prefix ts_pre) owns: rebuild the
+    // tile's CDF, turn it into teeth counts, find every slot's ancestor, propagate, store.
+    auto serve = [&](uint64_t ts, uint64_t ts_pre, int64_t s_lo, int64_t s_hi, bool loaded) {
+      const uint64_t tbase = ts * kTile;
+      if (served++) __syncthreads();  // the previous tile's LDS arrays are free again
+      if (!loaded) load_tile(tbase);
+      // tile CDF: each thread owns 4 CONSECUTIVE sources (tbase + 4*tid + r) so the scan is a thread-local prefix
+      // plus one block scan
+      uint64_t q[kPer];
+      uint64_t local = 0;
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) {
+        const uint64_t i = tbase + kPer * (uint64_t)tid + r;
+        q[r] = i < A.n ? fixw(lw4[r], m, A.frac) : 0;
+        local += q[r];
+      }
+      const uint64_t incl = wave_scan_incl(local);
+      const int w_ = tid >> 6;
+      if ((tid & 63) == 63) sh_cdf[w_] = incl;
+      // run-start marks of the ancestor search below; cleared here so that the barrier that publishes nb covers it
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) anc_s[tid + r * kBlock] = 0;
+      P.stage_source(tid);
+      __syncthreads();
+      uint64_t run = ts_pre + incl - local;
+#pragma unroll
+      for (int i = 0; i < kW; ++i)
+        if (i < w_) run += sh_cdf[i];
+      const int64_t n_lo = teeth_below(ts_pre, scale, u0, (int64_t)A.n_out);
+      int32_t nbr[kPer];  // teeth below this thread's consecutive sources
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) {
+        const uint64_t i = tbase + kPer * (uint64_t)tid + r;
+        run += q[r];
+        // the last real particle (and any padding after it) closes the comb at n_out
+        nbr[r] = (int32_t)((i + 1 >= A.n) ? (int64_t)A.n_out : teeth_below(run, scale, u0, (int64_t)A.n_out));
+      }
+      // neighbours' counts through LDS: nb_prev (source 4*tid - 1) and the tile's last count
+      nb[kPer * tid + kPer - 1] = nbr[kPer - 1];
+      __syncthreads();
+      const int64_t n_hi = nb[kTile - 1];
+      const int32_t nb_prev = tid == 0 ? (int32_t)n_lo : nb[kPer * tid - 1];
+      const int64_t j0 = n_lo > s_lo ? n_lo : s_lo;
+      const int64_t j1 = n_hi < s_hi ? n_hi : s_hi;
+      // Ancestors of the slots, 1024 at a time, WITHOUT a search per slot: ancestors are monotone, so every source
+      // that owns at least one slot marks the slot where its run starts (the chunk start for a run that began
+      // earlier) and an inclusive max-scan over the chunk spreads each mark over the run.  Chunks start at a multiple
+      // of 4 slots and each lane serves FOUR CONSECUTIVE slots: four independent propagate chains in flight, one
+      // shared cipher block for their draws (smc_quad_bits), 16-byte stores.  Waves whose 256 slots lie outside the
+      // range skip the chunk.
+      const int64_t jb0 = j0 & ~(int64_t)3;
+      for (int64_t jb = jb0; jb < j1; jb += (int64_t)kTile) {
+        if (jb != jb0) __syncthreads();  // the marks were cleared after the previous chunk's scan
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) {
+          const int64_t start = r == 0 ? nb_prev : nbr[r - 1];  // source 4*tid+r owns slots [start, nbr[r])
+          if ((int64_t)nbr[r] > start && (int64_t)nbr[r] > jb && start < jb + (int64_t)kTile)
+            anc_s[(start > jb ? start : jb) - jb] = kPer * tid + r + 1;
+        }
+        __syncthreads();
+        int v[kPer];
+        int run_max = 0;
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) {
+          const int x = anc_s[kPer * tid + r];
+          run_max = x > run_max ? x : run_max;
+          v[r] = run_max;
+        }
+        const int carry = block_scan_max_excl(run_max, shi);  // (its barriers close this chunk's reads of the marks)
+        if (jb + (int64_t)kTile < j1) {  // another chunk follows: clear the marks for it
+#pragma unroll
+          for (int r = 0; r < kPer; ++r) anc_s[tid + r * kBlock] = 0;
+        }
+        // every entry of the chunk is a valid local source index (slots outside [j0, j1) included — those before the
+        // range's first slot have no mark and take source 0: they are computed along with their quad, never stored)
+        int src[kPer];
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) {
+          const int a = v[r] > carry ? v[r] : carry;
+          src[r] = a ? a - 1 : 0;
+        }
+        const int64_t jq = jb + (int64_t)kPer * tid;
+        const int64_t wave_lo = jb + (int64_t)kPer * (tid & ~(kWave - 1));
+        if (wave_lo < j1 && wave_lo + (int64_t)kPer * kWave > j0) {  // wave-uniform
+          bool ok[kPer];
+#pragma unroll
+          for (int r = 0; r < kPer; ++r) ok[r] = jq + r >= j0 && jq + r < j1;
+          typename Policy::Out out[kPer];
+          float w[kPer];
+          policy_compute_quad(P, jq, src, out, w, 0);
+          policy_store_quad(P, jq, A.out_lo, tbase, src, out, ok, 0);
+#pragma unroll
+          for (int r = 0; r < kPer; ++r) tmax = ok[r] && w[r] > tmax ? w[r] : tmax;
+        }
+      }
+    };
+    // where the slots a tile serves itself end (the same rule for its own workgroup and for the helpers)
+    auto cap_of = [&](int64_t t_lo) {
+      const int64_t first = (t_lo > A.out_lo ? t_lo : A.out_lo) & ~(int64_t)3;
+      return first + (int64_t)kCapSlots;
+    };
+    // ---- the own tile ----------------------------------------------------------------------------------------
+    {
+      const uint64_t own_mass = tile_prefix ? tile_prefix[b + 1] - pre : tile_sums[b];
+      const int64_t t_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
+      const int64_t t_hi = b + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(pre + own_mass, scale, u0, (int64_t)A.n_out);
+      if (!(t_hi <= A.out_lo || t_lo >= A.out_hi)) {  // workgroup-uniform
+        const int64_t s_hi = helping ? (cap_of(t_lo) < A.out_hi ? cap_of(t_lo) : A.out_hi) : A.out_hi;
+        serve(b, pre, A.out_lo, s_hi, own_loaded);
+      }
+    }
+    // ---- helper duty: slots of this workgroup's window that lie beyond a heavy tile's cap ----------------------
+    if (helping) {
+      const int64_t w_lo = (int64_t)base, w_hi = (int64_t)(base + kTile);
+      for (uint32_t e0 = 0; e0 < n_heavy; e0 += kBlock) {
+        const uint32_t e = e0 + (uint32_t)tid;
+        if (e < n_heavy) {
+          uint64_t ts, tp;
+          if (tile_prefix) { ts = tile_prefix[A.ntiles + 4 + 2 * e]; tp = tile_prefix[A.ntiles + 5 + 2 * e]; }
+          else { ts = heavy_tile[e]; tp = heavy_pre[e]; }
+          const uint64_t mass = tile_prefix ? tile_prefix[ts + 1] - tp : tile_sums[ts];
+          const int64_t t_lo = teeth_below(tp, scale, u0, (int64_t)A.n_out);
+          const int64_t t_hi = ts + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(tp + mass, scale, u0, (int64_t)A.n_out);
+          int64_t lo = cap_of(t_lo), hi = t_hi < A.out_hi ? t_hi : A.out_hi;
+          lo = lo > w_lo ? lo : w_lo;
+          hi = hi < w_hi ? hi : w_hi;
+          if (lo < hi) hit[atomicAdd(&hit_n, 1u)] = (uint16_t)e;
+        }
+      }
+      __syncthreads();
+      const uint32_t n_hit = hit_n;
+      for (uint32_t k = 0; k < n_hit; ++k) {
+        // hits are served in list order; the order does not matter (disjoint slots), only that all threads agree
+        const uint32_t e = hit[k];
+        uint64_t ts, tp;
+        if (tile_prefix) { ts = tile_prefix[A.ntiles + 4 + 2 * e]; tp = tile_prefix[A.ntiles + 5 + 2 * e]; }
+        else { ts = heavy_tile[e]; tp = heavy_pre[e]; }
+        const int64_t t_lo = teeth_below(tp, scale, u0, (int64_t)A.n_out);
+        const int64_t lo = cap_of(t_lo) > w_lo ? cap_of(t_lo) : w_lo;
+        serve(ts, tp, lo, w_hi < A.out_hi ? w_hi : A.out_hi, false);
+      }
+    }
   }
-  static_assert(kPer == 4, "four consecutive sources and four consecutive output slots per lane");
-  if (max_partials) {
-    const float bm = block_max(tmax, shf);
-    if (tid == 0) max_partials[b] = bm;
+  {
+    const float wm = wave_max(tmax);
+    if ((tid & 63) == 0) shf[tid >> 6] = wm;
+    __syncthreads();
+    if (tid == 0) {
+      float bm = shf[0];
+#pragma unroll
+      for (int i = 1; i < kW; ++i) bm = shf[i] > bm ? shf[i] : bm;
+      if (max_partials) max_partials[b] = bm;
+      if (max_accum) atomic_max_f32(max_accum, bm);
+    }
   }
 }
 

@@ -590,7 +590,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_wave(const float* lw, uint
                                                       const float* m_ptr, int frac,
                                                       uint64_t* tile_sums_at, float* max_out,
                                                       uint32_t filter_tiles, uint64_t filter_stride,
-                                                      uint64_t mq_stride, uint32_t ntiles_local) {
+                                                      uint64_t mq_stride, uint32_t ntiles_local,
+                                                      uint64_t* tile_ess_at) {
   __shared__ float shf[kBlock / kWave];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t tiles = filter_tiles ? filter_tiles : ntiles_local;
@@ -600,9 +601,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_wave(const float* lw, uint
     const uint64_t f = g / groups;
     g -= f * groups;
     lw += f * filter_stride;
-    max_partials += f * filter_tiles;
+    if (max_partials) max_partials += f * filter_tiles;
     tile_sums_at += f * filter_tiles;
+    if (tile_ess_at) tile_ess_at += 2 * f * filter_tiles;
     if (max_out) max_out += f * mq_stride;
+    if (m_ptr) m_ptr += f * mq_stride;
   }
   const uint64_t tile = g * kTilesPerSumBlock + (uint64_t)wv;
   const bool live = tile < tiles;
@@ -633,14 +636,25 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_wave(const float* lw, uint
     m = block_max(m, shf);
     if (max_out && g == 0 && threadIdx.x == 0) max_out[0] = m;
   }
-  uint64_t acc = 0;
+  uint64_t acc = 0, a1 = 0, a2 = 0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const uint64_t i = base + (uint64_t)(k >> 2) * 256 + 4 * (uint64_t)lane + (k & 3);
-    if (live && i < n_local) acc += fixw(lwv[k], m, frac);
+    if (live && i < n_local) {
+      const uint64_t q = fixw(lwv[k], m, frac);
+      acc += q;
+      const uint64_t r = ess_r(q, frac);  // (the ESS sums of adaptive filters: gjx_smc_config.ess_threshold)
+      a1 += r;
+      a2 += r * r;
+    }
   }
   acc = wave_sum(acc);
   if (live && lane == 0) tile_sums_at[tile] = acc;
+  if (tile_ess_at) {  // launch-uniform
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    if (live && lane == 0) { tile_ess_at[2 * tile] = a1; tile_ess_at[2 * tile + 1] = a2; }
+  }
 }
 
 // The same with one WORKGROUP per tile (4 particles per lane): more workgroups — better while a launch has few
@@ -650,17 +664,19 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_block(const float* lw, uin
                                                       const float* m_ptr, int frac,
                                                       uint64_t* tile_sums_at, float* max_out,
                                                       uint32_t filter_tiles, uint64_t filter_stride,
-                                                      uint64_t mq_stride) {
-  __shared__ uint64_t sh64[kBlock / kWave];
+                                                      uint64_t mq_stride, uint64_t* tile_ess_at) {
+  __shared__ uint64_t sh64[3 * (kBlock / kWave)];
   __shared__ float shf[kBlock / kWave];
   uint64_t tile = blockIdx.x;
   if (filter_tiles) {  // several filters per launch: this workgroup's filter
     const uint64_t f = tile / filter_tiles;
     tile -= f * filter_tiles;
     lw += f * filter_stride;
-    max_partials += f * filter_tiles;
+    if (max_partials) max_partials += f * filter_tiles;
     tile_sums_at += f * filter_tiles;
+    if (tile_ess_at) tile_ess_at += 2 * f * filter_tiles;
     if (max_out) max_out += f * mq_stride;
+    if (m_ptr) m_ptr += f * mq_stride;
   }
   float lwv[kPer];
 #pragma unroll
@@ -680,39 +696,88 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_block(const float* lw, uin
     m = block_max(m, shf);
     if (max_out && tile == 0 && threadIdx.x == 0) max_out[0] = m;
   }
-  uint64_t acc = 0;
+  uint64_t acc = 0, a1 = 0, a2 = 0;
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {
     const uint64_t i = tile * kTile + (uint64_t)r * kBlock + threadIdx.x;
-    if (i < n_local) acc += fixw(lwv[r], m, frac);
+    if (i < n_local) {
+      const uint64_t q = fixw(lwv[r], m, frac);
+      acc += q;
+      const uint64_t rr = ess_r(q, frac);
+      a1 += rr;
+      a2 += rr * rr;
+    }
   }
-  acc = block_sum(acc, sh64);
-  if (threadIdx.x == 0) tile_sums_at[tile] = acc;
+  // one barrier for all three sums (ESS sums only in adaptive filters: launch-uniform)
+  constexpr int kW = kBlock / kWave;
+  acc = wave_sum(acc);
+  if (tile_ess_at) { a1 = wave_sum(a1); a2 = wave_sum(a2); }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh64[wv] = acc;
+    if (tile_ess_at) { sh64[kW + wv] = a1; sh64[2 * kW + wv] = a2; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+    for (int i = 0; i < kW; ++i) {
+      t0 += sh64[i];
+      if (tile_ess_at) { t1 += sh64[kW + i]; t2 += sh64[2 * kW + i]; }
+    }
+    tile_sums_at[tile] = t0;
+    if (tile_ess_at) { tile_ess_at[2 * tile] = t1; tile_ess_at[2 * tile + 1] = t2; }
+  }
 }
 
-// Exclusive prefix of the tile masses, [ntiles + 1] (last entry = total): one workgroup, each thread
-// scans a contiguous chunk.  Used when the population is large enough that every resample workgroup
-// re-reducing tile_sums would dominate (ntiles > kPrefixTiles).
+// Exclusive prefix of the tile masses, [ntiles + 1] (last entry = total), followed by the tail resample_body reads
+// (gjx_device.hpp kPrefixTail: ESS sums R1, R2, the number of heavy candidates and their (tile, prefix) pairs): one
+// workgroup per filter, each thread scans a contiguous chunk.  Used when the population is large enough that every
+// resample workgroup scanning tile_sums itself would dominate (ntiles > kPrefixTiles), and for filter batches.
 static const uint64_t kPrefixTiles = [] {
-  const char* e = std::getenv("GJX_PREFIX_TILES");  // tuning knob; default from measurement
-  return e ? (uint64_t)atoll(e) : (uint64_t)2048;
+  const char* e = std::getenv("GJX_PREFIX_TILES");  // tuning knob; default from measurement (<= 2048: resample_body's register scan)
+  const uint64_t v = e ? (uint64_t)atoll(e) : (uint64_t)2048;
+  return v > 2048 ? (uint64_t)2048 : v;
 }();
-__global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint64_t* tile_sums, uint64_t ntiles,
-                                                       uint64_t* prefix) {
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint64_t* tile_sums, const uint64_t* tile_ess, uint64_t ntiles,
+                                                       uint64_t n_out, uint64_t* prefix) {
   __shared__ uint64_t sh64[kBlock / kWave];
+  __shared__ uint64_t sh_e[2 * (kBlock / kWave)];
+  __shared__ uint32_t heavy_n;
   tile_sums += (uint64_t)blockIdx.x * ntiles;  // one workgroup per filter
-  prefix += (uint64_t)blockIdx.x * (ntiles + 1);
+  if (tile_ess) tile_ess += 2 * (uint64_t)blockIdx.x * ntiles;
+  prefix += (uint64_t)blockIdx.x * (ntiles + 1 + kPrefixTail);
+  if (threadIdx.x == 0) heavy_n = 0;
   const uint64_t per = (ntiles + kBlock - 1) / kBlock;
   const uint64_t lo = threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
-  uint64_t local = 0;
-  for (uint64_t k = lo; k < hi; ++k) local += tile_sums[k];
+  uint64_t local = 0, l1 = 0, l2 = 0;
+  for (uint64_t k = lo; k < hi; ++k) {
+    local += tile_sums[k];
+    if (tile_ess) { l1 += tile_ess[2 * k]; l2 += tile_ess[2 * k + 1]; }
+  }
   uint64_t total;
   uint64_t run = block_scan_excl(local, sh64, total);
-  for (uint64_t k = lo; k < hi; ++k) {
-    prefix[k] = run;
-    run += tile_sums[k];
+  if (tile_ess) {
+    l1 = block_sum(l1, sh_e);
+    l2 = block_sum(l2, sh_e + kBlock / kWave);
   }
-  if (threadIdx.x == 0) prefix[ntiles] = total;
+  const double hscale = (double)n_out / (double)total;
+  for (uint64_t k = lo; k < hi; ++k) {
+    const uint64_t v = tile_sums[k];
+    prefix[k] = run;
+    if ((double)v * hscale > (double)(kCapSlots - 8) || (total == 0 && k + 1 == ntiles)) {  // resample_body: a heavy candidate
+      const uint32_t e = atomicAdd(&heavy_n, 1u);
+      if (e < (uint32_t)kMaxHeavy) { prefix[ntiles + 4 + 2 * e] = k; prefix[ntiles + 5 + 2 * e] = run; }
+    }
+    run += v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    prefix[ntiles] = total;
+    prefix[ntiles + 1] = l1;
+    prefix[ntiles + 2] = l2;
+    prefix[ntiles + 3] = heavy_n;
+  }
 }
 
 // Inclusive fixed-point CDF materialised in HBM (multinomial / single-draw paths).
@@ -1016,17 +1081,36 @@ struct HmmPolicy {
 // teeth_below forms), both bounds monotone in b, so a block's range is [#tiles with upper <= lo, #tiles with
 // lower < hi).
 constexpr int kMaxRangeBlocks = 64;
-__global__ __launch_bounds__(kBlock) void k_source_ranges(const uint64_t* tile_sums, uint64_t ntiles, uint64_t n_total,
-                                                          int world, int64_t ticket, int64_t* out) {
+__global__ __launch_bounds__(kBlock) void k_source_ranges(const uint64_t* tile_sums, const uint64_t* tile_ess, double ess_thr,
+                                                          uint64_t ntiles, uint64_t n_total, int world, int64_t ticket,
+                                                          int64_t* out) {
   __shared__ uint64_t sh64[kBlock / kWave];
+  __shared__ uint64_t sh_e[2 * (kBlock / kWave)];
   __shared__ unsigned long long cnt[2 * kMaxRangeBlocks];
   const int tid = threadIdx.x;
   if (tid < 2 * kMaxRangeBlocks) cnt[tid] = 0;
   const uint64_t per = (ntiles + kBlock - 1) / kBlock;
   const uint64_t b0 = per * (uint64_t)tid < ntiles ? per * (uint64_t)tid : ntiles;
   const uint64_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
-  uint64_t local = 0;
-  for (uint64_t b = b0; b < b1; ++b) local += tile_sums[b];
+  uint64_t local = 0, l1 = 0, l2 = 0;
+  for (uint64_t b = b0; b < b1; ++b) {
+    local += tile_sums[b];
+    if (ess_thr > 0.0) { l1 += tile_ess[2 * b]; l2 += tile_ess[2 * b + 1]; }
+  }
+  if (ess_thr > 0.0) {  // an adaptive filter that keeps its particles at the next step needs no exchange at all:
+    l1 = block_sum(l1, sh_e);                       // every block's sources are its own tiles
+    l2 = block_sum(l2, sh_e + kBlock / kWave);
+    if (!ess_says_resample(l1, l2, ess_thr)) {
+      const uint64_t tiles_per_block = (n_total / (uint64_t)world) / kTile;
+      if (tid < 2 * world) {
+        out[tid] = (int64_t)(((uint64_t)(tid >> 1) + (uint64_t)(tid & 1)) * tiles_per_block);
+        __threadfence_system();
+      }
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(out + 2 * world, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
   uint64_t tot;
   const uint64_t pre0 = block_scan_excl(local, sh64, tot);  // (barriers inside also order the cnt[] clear)
   const double scale = (double)n_total / (double)tot;
@@ -1252,9 +1336,9 @@ size_t gjx_workspace_bytes(int op, uint64_t n) {
     case GJX_OP_CATEGORICAL_INDEX:
     case GJX_OP_RESAMPLE:
       return pad256(nt * 4) + 2 * pad256(nt * 8) + pad256(n * 8) + 1024;
-    case GJX_OP_SMC:
-      return 2 * pad256(n * 4) + pad256(nt * 4) + 2 * pad256((nt + 1) * 8) + pad256(256 * (256 + 64) * 4) +
-             pad256(256 * 256 * 4) + 1024;
+    case GJX_OP_SMC:  // ping-pong state + weights, tile maxima, tile masses, their prefix (+ tail), ESS sums, HMM tables
+      return 2 * pad256(n * 4) + pad256(nt * 4) + pad256(nt * 8) + pad256((nt + 1 + kPrefixTail) * 8) + pad256(2 * nt * 8) +
+             pad256(256 * (256 + 64) * 4) + pad256(256 * 256 * 4) + 1024;
     default: return 0;
   }
 }
@@ -1822,7 +1906,7 @@ static int weights_prepare(const float* logw, uint64_t n, Carver& cv, float** m_
   float* m = cv.take<float>(1);
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   k_max_partials<<<grid_for(n), kBlock, 0, st>>>(logw, n, mp);
-  k_tile_sums_block<<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, nullptr, frac_bits(n), tiles, m, 0, 0, 0);
+  k_tile_sums_block<<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, nullptr, frac_bits(n), tiles, m, 0, 0, 0, nullptr);
   *m_out = m;
   *tiles_out = tiles;
   return GJX_OK;
@@ -1890,6 +1974,7 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
   A.rkey = k; A.rkey_has_fold = key->has_fold; A.rkey_fold = key->fold;
   A.q_total_out = out_q ? out_q : qtot;
   A.tile_prefix = nullptr;
+  A.allow_help = n_out <= A.ntiles * (uint64_t)kTile ? 1 : 0;  // helpers are the workgroups of the output windows
   AncestorOnly P{ancestors};
   if (key->impl == 0) k_resample<0, AncestorOnly><<<(unsigned)A.ntiles, kBlock, 0, S(s)>>>(A, P, nullptr);
   else k_resample<1, AncestorOnly><<<(unsigned)A.ntiles, kBlock, 0, S(s)>>>(A, P, nullptr);
@@ -1940,10 +2025,12 @@ int gjx_gather_cols(const int32_t* ancestors, uint64_t n_out, const void* const*
 }
 
 // ---- fused bootstrap SMC ---------------------------------------------------------------------------
+static bool cfg_adaptive(const gjx_smc_config* c) { return c->ess_threshold > 0.0f && c->ess_threshold < 1.0f; }
 static bool cfg_ok(const gjx_smc_config* c) {
   return c && (c->impl == 0 || c->impl == 1) && c->n_total > 0 && c->n_local > 0 &&
          c->first_slot + c->n_local <= c->n_total && c->n_steps > 0 && c->step_keys &&
-         c->resample_keys && (c->first_slot % kTile) == 0 && c->n_total <= 0x7fffffffull;
+         c->resample_keys && (c->first_slot % kTile) == 0 && c->n_total <= 0x7fffffffull &&
+         !(c->ess_threshold < 0.0f) && c->tile_sums_form >= 0 && c->tile_sums_form <= 2;
 }
 
 uint64_t gjx_hmm_alias_words(int32_t n_states) {
@@ -1964,6 +2051,10 @@ int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gj
 struct StepCtx {
   const uint64_t* tile_prefix = nullptr;
   FilterBatch fb;
+  uint64_t* tile_ess = nullptr;    // whole-run drivers of adaptive filters: their workspace copy (else cfg->tile_ess)
+  int32_t* resampled_out = nullptr;  // this step's entry of cfg->resampled_out
+  float* max_accum = nullptr;      // this step's entry of out_max (-inf before the step): the kernels maintain the
+                                   // running max by float atomics, so step B needs no reduction of the tile maxima
 };
 
 static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const float* prev_logw,
@@ -1980,6 +2071,12 @@ static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const fl
   A.rkey = Key{cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1]};
   A.rkey_has_fold = 0; A.rkey_fold = 0;
   A.q_total_out = prev_q_out;
+  if (cfg_adaptive(cfg)) {
+    A.ess_thr = (double)cfg->ess_threshold * (double)cfg->n_total;
+    A.tile_ess = ctx.tile_ess ? ctx.tile_ess : cfg->tile_ess;
+  }
+  A.resampled_out = ctx.resampled_out ? ctx.resampled_out : (cfg->resampled_out && !(cfg->n_filters > 1) ? cfg->resampled_out + t : nullptr);
+  A.max_accum = ctx.max_accum;
   return A;
 }
 
@@ -2000,6 +2097,7 @@ static int lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, 
   }
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
   ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out, ctx);
+  if (A.ess_thr > 0.0 && !A.tile_ess) return GJX_ERR_INVALID;
   if (cfg->impl == 0) {
     LgssmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {}};
     k_resample<0, LgssmPolicy<0>><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
@@ -2029,6 +2127,7 @@ static int hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int3
   }
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
   ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out, ctx);
+  if (A.ess_thr > 0.0 && !A.tile_ess) return GJX_ERR_INVALID;
   if (cfg->impl == 0) {
     HmmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {}, 0.0f};
     k_resample<0, HmmPolicy<0>><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
@@ -2063,25 +2162,35 @@ static int smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const 
   const uint64_t nt_total = ntiles_of(cfg->n_total);
   const uint64_t nt_local = ntiles_of(cfg->n_local);
   const float* m_ptr = nullptr;
-  if (nt_total > kPrefixTiles) {  // reduce the tile maxima once instead of in every workgroup
+  if (ctx.max_accum) {
+    m_ptr = ctx.max_accum;  // step A kept the running max in max_out (float atomics): nothing to reduce
+  } else if (nt_total > kPrefixTiles) {  // reduce the tile maxima once instead of in every workgroup
     k_reduce_max<<<1, kBlock, 0, S(s)>>>(max_partials, nt_total, max_out);
     m_ptr = max_out;
   }
+  uint64_t* tile_ess = cfg_adaptive(cfg) ? (ctx.tile_ess ? ctx.tile_ess : cfg->tile_ess) : nullptr;
+  if (cfg_adaptive(cfg) && !tile_ess) return GJX_ERR_INVALID;
+  const uint64_t tile0 = cfg->first_slot / kTile;
   const FilterBatch& fb = ctx.fb;
   const unsigned nf = fb.n_filters > 1 ? fb.n_filters : 1u;
   static const uint64_t wave_min = [] {
     const char* e = std::getenv("GJX_TILE_SUMS_WAVE_MIN");  // tuning knob; default from measurement
     return e ? (uint64_t)atoll(e) : (uint64_t)4096;
   }();
-  if (nt_local * nf >= wave_min) {  // enough tiles to fill the machine with a wave each (measured: 16 x 977 tiles +8 %, 977 tiles -13 %)
+  // enough tiles to fill the machine with a wave each (measured: 16 x 977 tiles +8 %, 977 tiles -13 %); cfg->tile_sums_form
+  // forces one form (tests: both give the same bits)
+  const bool wave_form = cfg->tile_sums_form == 2 || (cfg->tile_sums_form == 0 && nt_local * nf >= wave_min);
+  if (wave_form) {
     const unsigned groups = (unsigned)((nt_local + kTilesPerSumBlock - 1) / kTilesPerSumBlock);
     k_tile_sums_wave<<<groups * nf, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total, m_ptr,
-                                                       frac_bits(cfg->n_total), tile_sums + cfg->first_slot / kTile, max_out,
-                                                       nf > 1 ? fb.tiles : 0u, fb.stride, fb.mq_stride, (uint32_t)nt_local);
+                                                       frac_bits(cfg->n_total), tile_sums + tile0, m_ptr ? nullptr : max_out,
+                                                       nf > 1 ? fb.tiles : 0u, fb.stride, fb.mq_stride, (uint32_t)nt_local,
+                                                       tile_ess ? tile_ess + 2 * tile0 : nullptr);
   } else {
     k_tile_sums_block<<<(unsigned)nt_local * nf, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total, m_ptr,
-                                                                    frac_bits(cfg->n_total), tile_sums + cfg->first_slot / kTile,
-                                                                    max_out, nf > 1 ? fb.tiles : 0u, fb.stride, fb.mq_stride);
+                                                                    frac_bits(cfg->n_total), tile_sums + tile0,
+                                                                    m_ptr ? nullptr : max_out, nf > 1 ? fb.tiles : 0u, fb.stride,
+                                                                    fb.mq_stride, tile_ess ? tile_ess + 2 * tile0 : nullptr);
   }
   return launch_status();
 }
@@ -2108,8 +2217,68 @@ int gjx_smc_source_ranges(const gjx_smc_config* cfg, const uint64_t* tile_sums, 
                           int64_t* out_ranges, gjx_stream s) {
   if (!cfg_ok(cfg) || !tile_sums || !out_ranges || world < 1 || world > kMaxRangeBlocks || cfg->n_total % (uint64_t)world)
     return GJX_ERR_INVALID;
-  k_source_ranges<<<1, kBlock, 0, S(s)>>>(tile_sums, ntiles_of(cfg->n_total), cfg->n_total, world, ticket, out_ranges);
+  if (cfg_adaptive(cfg) && !cfg->tile_ess) return GJX_ERR_INVALID;
+  k_source_ranges<<<1, kBlock, 0, S(s)>>>(tile_sums, cfg_adaptive(cfg) ? cfg->tile_ess : nullptr,
+                                          cfg_adaptive(cfg) ? (double)cfg->ess_threshold * (double)cfg->n_total : 0.0,
+                                          ntiles_of(cfg->n_total), cfg->n_total, world, ticket, out_ranges);
   return launch_status();
+}
+
+// What the whole-run drivers (fixed models and plans) share: the per-filter scratch arrays carved from the caller's
+// workspace, and the per-step context (this step's keys of every filter, the tile-mass prefix, where the step's
+// running max / resampling flag go).
+struct RunCommon {
+  unsigned F = 1;
+  uint64_t nt = 0, stride = 0;
+  float* mp = nullptr;
+  uint64_t* tiles = nullptr;
+  uint64_t* prefix = nullptr;
+  uint64_t* tile_ess = nullptr;
+  FilterBatch fb;
+};
+static int run_common_init(const gjx_smc_config* cfg, Carver& cv, RunCommon& rc, float* out_max, gjx_stream s) {
+  const uint64_t N = cfg->n_total;
+  rc.nt = ntiles_of(N);
+  rc.F = cfg->n_filters > 1 ? (unsigned)cfg->n_filters : 1u;
+  rc.stride = rc.F > 1 ? cfg->filter_stride : N;
+  if (rc.F > kMaxFilters || (rc.F > 1 && (rc.stride != rc.nt * kTile || rc.nt > kPrefixTiles))) return GJX_ERR_UNSUPPORTED;
+  if (cfg_adaptive(cfg) && !cfg->resampled_out) return GJX_ERR_INVALID;
+  // Tile-mass prefixes by a separate (one workgroup per filter) launch: worth it for large populations, and for
+  // several filters per launch, where its ~5 us are shared by all of them while every resample workgroup saves
+  // the block-wide scan of its filter's tile sums.
+  const bool scan = rc.nt > kPrefixTiles || rc.F >= 4;
+  rc.mp = cv.take<float>(rc.F * rc.nt);
+  rc.tiles = cv.take<uint64_t>(rc.F * rc.nt);
+  rc.prefix = scan ? cv.take<uint64_t>(rc.F * (rc.nt + 1 + kPrefixTail)) : nullptr;
+  rc.tile_ess = cfg_adaptive(cfg) ? cv.take<uint64_t>(2 * rc.F * rc.nt) : nullptr;
+  if (!cv.ok) return GJX_ERR_WORKSPACE;
+  if (rc.F > 1) {
+    rc.fb.n_filters = rc.F; rc.fb.tiles = (uint32_t)rc.nt; rc.fb.stride = rc.stride; rc.fb.mq_stride = (uint64_t)cfg->n_steps;
+  }
+  // the per-step maxima start at -inf: the step kernels fold their tile maxima into them with float atomics
+  const size_t nmq = (size_t)rc.F * (size_t)cfg->n_steps;
+  if (hipMemsetD32Async((hipDeviceptr_t)out_max, (int)0xff800000u, nmq, S(s)) != hipSuccess) return GJX_ERR_LAUNCH;
+  if (cfg->resampled_out && hipMemsetAsync(cfg->resampled_out, 0, nmq * sizeof(int32_t), S(s)) != hipSuccess) return GJX_ERR_LAUNCH;
+  return GJX_OK;
+}
+static StepCtx run_step_ctx(const gjx_smc_config* cfg, RunCommon& rc, int t, float* out_max, gjx_stream s) {
+  const int T = cfg->n_steps;
+  for (unsigned f = 0; f < rc.F && rc.F > 1; ++f) {  // this step's keys of every filter ([F, T, 2] host arrays)
+    const uint32_t* sk = cfg->step_keys + 2 * ((size_t)f * T + t);
+    const uint32_t* rk = cfg->resample_keys + 2 * ((size_t)f * T + t);
+    rc.fb.step_key[f] = Key{sk[0], sk[1]};
+    rc.fb.rkey[f] = Key{rk[0], rk[1]};
+  }
+  StepCtx ctx;
+  ctx.fb = rc.fb;
+  ctx.tile_ess = rc.tile_ess;
+  if (rc.prefix && t) {
+    k_scan_tiles<<<rc.F, kBlock, 0, S(s)>>>(rc.tiles, rc.tile_ess, rc.nt, cfg->n_total, rc.prefix);
+    ctx.tile_prefix = rc.prefix;
+  }
+  ctx.resampled_out = cfg->resampled_out ? cfg->resampled_out + t : nullptr;
+  ctx.max_accum = t ? out_max + t : nullptr;  // (step 0 has no resample kernel: its maxima are reduced by step B)
+  return ctx;
 }
 
 // ---- bootstrap SMC for a user model: generated policy in the fused resample kernel -----------------
@@ -2196,6 +2365,7 @@ static int smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, gjx_ji
   }
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
   ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out, ctx);
+  if (A.ess_thr > 0.0 && !A.tile_ess) return GJX_ERR_INVALID;
   void* args[] = {&A, &PA, &max_partials_out};
   if (hipModuleLaunchKernel(c.step, nt * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
   return launch_status();
@@ -2224,21 +2394,20 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
     return GJX_ERR_INVALID;
   gjx_jit::CompiledSmc* cp = smc_plan_compiled(plan, cfg->impl);
   if (!cp) return GJX_ERR_UNSUPPORTED;
-  const uint64_t N = cfg->n_total, nt = ntiles_of(N);
+  const uint64_t N = cfg->n_total;
   const int D = plan->n_state, T = cfg->n_steps;
   // several filters per launch (as in smc_run): filter f's particles lie f * stride further in every array
-  const unsigned F = cfg->n_filters > 1 ? (unsigned)cfg->n_filters : 1u;
-  const uint64_t stride = F > 1 ? cfg->filter_stride : N;
-  if (F > kMaxFilters || (F > 1 && (stride != nt * kTile || nt > kPrefixTiles))) return GJX_ERR_UNSUPPORTED;
-  const bool scan = nt > kPrefixTiles || F >= 4;
   Carver cv{(char*)ws, ws ? ws_bytes : 0};
+  RunCommon rc;
+  const unsigned F0 = cfg->n_filters > 1 ? (unsigned)cfg->n_filters : 1u;
+  const uint64_t stride0 = F0 > 1 ? cfg->filter_stride : N;
   float* st_ws[GJX_SMC_MAX_STATE];
-  for (int k = 0; k < D; ++k) st_ws[k] = cv.take<float>(F * stride);
-  float* lw_ws = cv.take<float>(F * stride);
-  float* mp = cv.take<float>(F * nt);
-  uint64_t* tiles = cv.take<uint64_t>(F * nt);
-  uint64_t* prefix = scan ? cv.take<uint64_t>(F * (nt + 1)) : nullptr;
-  if (!cv.ok) return GJX_ERR_WORKSPACE;
+  for (int k = 0; k < D; ++k) st_ws[k] = cv.take<float>(F0 * stride0);
+  float* lw_ws = cv.take<float>(F0 * stride0);
+  int rc0 = run_common_init(cfg, cv, rc, out_max, s);
+  if (rc0) return rc0;
+  const unsigned F = rc.F;
+  const uint64_t stride = rc.stride;
   for (int k = 0; k < D; ++k)
     if (!state_out[k]) return GJX_ERR_INVALID;
   const int last = (T - 1) & 1;
@@ -2246,33 +2415,18 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
   float* lwb[2];
   for (int k = 0; k < D; ++k) { stb[last][k] = state_out[k]; stb[last ^ 1][k] = st_ws[k]; }
   lwb[last] = logw_out; lwb[last ^ 1] = lw_ws;
-  FilterBatch fb;
-  if (F > 1) {
-    fb.n_filters = F; fb.tiles = (uint32_t)nt; fb.stride = stride; fb.mq_stride = (uint64_t)T;
-  }
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1, prv = cur ^ 1;
-    for (unsigned f = 0; f < F && F > 1; ++f) {  // this step's keys of every filter ([F, T, 2] host arrays)
-      const uint32_t* sk = cfg->step_keys + 2 * ((size_t)f * T + t);
-      const uint32_t* rk = cfg->resample_keys + 2 * ((size_t)f * T + t);
-      fb.step_key[f] = Key{sk[0], sk[1]};
-      fb.rkey[f] = Key{rk[0], rk[1]};
-    }
-    StepCtx ctx;
-    ctx.fb = fb;
-    if (prefix && t) {
-      k_scan_tiles<<<F, kBlock, 0, S(s)>>>(tiles, nt, prefix);
-      ctx.tile_prefix = prefix;
-    }
-    int rc = smc_plan_step_a(cfg, plan, *cp, t, plan->n_obs ? obs_host + (size_t)t * (size_t)plan->n_obs : nullptr, stb[prv],
-                             lwb[prv], t ? out_max + (t - 1) : nullptr, tiles, t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur],
-                             mp, ancestors_out ? ancestors_out + (size_t)t * F * stride : nullptr, s, ctx);
-    if (!rc) rc = smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s, ctx);
-    if (rc) return rc;
+    StepCtx ctx = run_step_ctx(cfg, rc, t, out_max, s);
+    int r = smc_plan_step_a(cfg, plan, *cp, t, plan->n_obs ? obs_host + (size_t)t * (size_t)plan->n_obs : nullptr, stb[prv],
+                            lwb[prv], t ? out_max + (t - 1) : nullptr, rc.tiles, t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur],
+                            rc.mp, ancestors_out ? ancestors_out + (size_t)t * F * stride : nullptr, s, ctx);
+    if (!r) r = smc_step_b(cfg, lwb[cur], rc.mp, out_max + t, rc.tiles, s, ctx);
+    if (r) return r;
   }
   StepCtx ctx;
-  ctx.fb = fb;
-  return smc_finish(cfg, tiles, out_q + (T - 1), s, ctx);
+  ctx.fb = rc.fb;
+  return smc_finish(cfg, rc.tiles, out_q + (T - 1), s, ctx);
 }
 
 }  // extern "C"
@@ -2284,55 +2438,37 @@ static int smc_run(const gjx_smc_config* cfg, const void* model, float* out_max,
   if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !model || !out_max ||
       !out_q || !state_out || !logw_out)
     return GJX_ERR_INVALID;
-  const uint64_t N = cfg->n_total, nt = ntiles_of(N);
+  const uint64_t N = cfg->n_total;
   // several filters per launch: filter f's particles lie f * stride further in every per-particle array
-  const unsigned F = cfg->n_filters > 1 ? (unsigned)cfg->n_filters : 1u;
-  const uint64_t stride = F > 1 ? cfg->filter_stride : N;
+  const unsigned F0 = cfg->n_filters > 1 ? (unsigned)cfg->n_filters : 1u;
+  const uint64_t stride0 = F0 > 1 ? cfg->filter_stride : N;
   const int T = cfg->n_steps;
-  if (F > kMaxFilters || (F > 1 && (stride != nt * kTile || nt > kPrefixTiles))) return GJX_ERR_UNSUPPORTED;
-  // Tile-mass prefixes by a separate (one workgroup per filter) launch: worth it for large populations, and for
-  // several filters per launch, where its ~5 us are shared by all of them while every resample workgroup saves
-  // the block-wide reduction of its filter's tile sums.
-  const bool scan = nt > kPrefixTiles || F >= 4;
   Carver cv{(char*)ws, ws ? ws_bytes : 0};
-  StateT* st_ws = cv.take<StateT>(F * stride);
-  float* lw_ws = cv.take<float>(F * stride);
-  float* mp = cv.take<float>(F * nt);
-  uint64_t* tiles = cv.take<uint64_t>(F * nt);
-  uint64_t* prefix = scan ? cv.take<uint64_t>(F * (nt + 1)) : nullptr;
-  if (!cv.ok) return GJX_ERR_WORKSPACE;
+  StateT* st_ws = cv.take<StateT>(F0 * stride0);
+  float* lw_ws = cv.take<float>(F0 * stride0);
+  RunCommon rc;
+  int r = run_common_init(cfg, cv, rc, out_max, s);
+  if (r) return r;
+  const unsigned F = rc.F;
+  const uint64_t stride = rc.stride;
   // ping-pong so that the last step lands in the caller's output buffers
   StateT* stb[2];
   float* lwb[2];
   const int last = (T - 1) & 1;
   stb[last] = state_out; stb[last ^ 1] = st_ws;
   lwb[last] = logw_out; lwb[last ^ 1] = lw_ws;
-  FilterBatch fb;
-  if (F > 1) {
-    fb.n_filters = F; fb.tiles = (uint32_t)nt; fb.stride = stride; fb.mq_stride = (uint64_t)T;
-  }
-  int rc = GJX_OK;
-  for (int t = 0; t < T && !rc; ++t) {
+  for (int t = 0; t < T && !r; ++t) {
     const int cur = t & 1, prv = cur ^ 1;
     int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * F * stride : nullptr;
-    if (prefix && t) k_scan_tiles<<<F, kBlock, 0, S(s)>>>(tiles, nt, prefix);
-    for (unsigned f = 0; f < F && F > 1; ++f) {  // this step's keys of every filter ([F, T, 2] host arrays)
-      const uint32_t* sk = cfg->step_keys + 2 * ((size_t)f * T + t);
-      const uint32_t* rk = cfg->resample_keys + 2 * ((size_t)f * T + t);
-      fb.step_key[f] = Key{sk[0], sk[1]};
-      fb.rkey[f] = Key{rk[0], rk[1]};
-    }
-    StepCtx ctx;
-    ctx.tile_prefix = t ? prefix : nullptr;
-    ctx.fb = fb;
-    rc = step_a(t, stb[prv], lwb[prv], t ? out_max + (t - 1) : nullptr, tiles,
-                t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur], mp, anc_t, ctx);
-    if (!rc) rc = smc_step_b(cfg, lwb[cur], mp, out_max + t, tiles, s, ctx);
+    StepCtx ctx = run_step_ctx(cfg, rc, t, out_max, s);
+    r = step_a(t, stb[prv], lwb[prv], t ? out_max + (t - 1) : nullptr, rc.tiles,
+               t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur], rc.mp, anc_t, ctx);
+    if (!r) r = smc_step_b(cfg, lwb[cur], rc.mp, out_max + t, rc.tiles, s, ctx);
   }
-  if (rc) return rc;
+  if (r) return r;
   StepCtx ctx;
-  ctx.fb = fb;
-  return smc_finish(cfg, tiles, out_q + (T - 1), s, ctx);
+  ctx.fb = rc.fb;
+  return smc_finish(cfg, rc.tiles, out_q + (T - 1), s, ctx);
 }
 
 extern "C" {
@@ -2358,8 +2494,11 @@ int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32
   const size_t cdf_bytes = pad256((size_t)gjx_hmm_alias_words(model->n_states) * 4);
   const size_t tail = cdf_bytes + pad256(kk * 4);
   if (!ws || ws_bytes < tail) return GJX_ERR_WORKSPACE;
-  char* tail_p = (char*)ws + (ws_bytes - tail);
-  tail_p = (char*)(((uintptr_t)tail_p) & ~(uintptr_t)255);
+  // aligned DOWN from the end of the workspace: with an unaligned `ws` within 255 bytes of `tail` that lands below
+  // the workspace — checked as addresses, before anything is carved
+  const uintptr_t w0 = (uintptr_t)ws, tail_a = (w0 + ws_bytes - tail) & ~(uintptr_t)255;
+  if (tail_a < w0) return GJX_ERR_WORKSPACE;
+  char* tail_p = (char*)tail_a;
   uint32_t* tcdf = (uint32_t*)tail_p;
   float* ologp = (float*)(tail_p + cdf_bytes);
   if ((char*)ologp + kk * 4 > (char*)ws + ws_bytes) return GJX_ERR_WORKSPACE;

@@ -147,6 +147,10 @@ class SmcConfig(C.Structure):
         ("resample_keys", C.c_void_p),
         ("n_filters", C.c_int32),
         ("filter_stride", C.c_uint64),
+        ("ess_threshold", C.c_float),     # 0 / >= 1: resample at every step; (0, 1): only when ESS < threshold * N
+        ("resampled_out", C.c_void_p),    # dev int32[T] / [F, T]: 1 where a step began with a resampling
+        ("tile_ess", C.c_void_p),         # step-level API of adaptive filters: global u64[2 * tiles] ESS sums
+        ("tile_sums_form", C.c_int32),    # 0 auto, 1 workgroup per tile, 2 wave per tile
     ]
 
 

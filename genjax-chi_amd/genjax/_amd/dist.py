@@ -254,7 +254,7 @@ class ShardedSMC:
 
     def __init__(self, ops: Ops, kind: str, impl: int, seed: int, n_total: int, T: int, rank: int, world: int,
                  record_ancestors: bool = False, exchange: str = "ranges", comm=None, poison: bool = False,
-                 n_states=None, lgssm=None, y=None, plan=None, obs=None):
+                 n_states=None, lgssm=None, y=None, plan=None, obs=None, ess_threshold: float = 0.0):
         """`lgssm` (abi.Lgssm) / `y`: another linear-Gaussian model and observation sequence than the benchmark's.
         kind "plan": a generated filter — `plan` from `ops.smc_plan_create`, `obs` [T, n_obs]."""
         tile = ops.tile
@@ -268,7 +268,9 @@ class ShardedSMC:
         self.n_total, self.n_local = n_total, n_total // world
         self.first = rank * self.n_local
         sk, rk = W.smc_key_schedule(prng.key(seed, impl), T)
-        self.cfg = ops.smc_config(impl, n_total, self.first, self.n_local, sk, rk)
+        # ess_threshold in (0, 1): resample only when ESS < threshold * n_total; every rank takes the same decision
+        # from the all-gathered exact ESS sums, and a step that keeps its particles exchanges nothing
+        self.cfg = ops.smc_config(impl, n_total, self.first, self.n_local, sk, rk, ess_threshold)
         dev = ops.device()
         if kind == "lgssm":
             self.y = W.lgssm_data(T) if y is None else y
@@ -378,6 +380,8 @@ class ShardedSMC:
             self.comm.all_reduce_max(self.max_partials)
             ops.smc_step_b(self.cfg, self.logw[cur][lo:hi], self.max_partials, self.out_max[t:t + 1], self.tile_sums)
             self.comm.all_gather(self.tile_sums, tl, th)
+            if self.cfg._tile_ess is not None:
+                self.comm.all_gather(self.cfg._tile_ess, 2 * tl, 2 * th)
             if t + 1 < self.T:
                 self._shuffle(cur)
         ops.smc_finish(self.cfg, self.tile_sums, self.out_q[self.T - 1:self.T])
@@ -385,8 +389,8 @@ class ShardedSMC:
         final = [c[lo:hi] for c in self.state[last]]
         return dict(out_max=self.out_max, out_q=self.out_q, state=final[0] if self.n_cols == 1 else final,
                     logw=self.logw[last][lo:hi], ancestors=self.ancestors,
-                    log_z=ops.log_z_from_pairs(self.out_max, self.out_q, self.n_total),
-                    log_z_exact=self.log_z_exact, received=self.received)
+                    log_z=ops.log_z_from_pairs(self.out_max, self.out_q, self.n_total, self.cfg._flags),
+                    resampled=self.cfg._flags, log_z_exact=self.log_z_exact, received=self.received)
 
 
 def ShardedLgssmSMC(ops: Ops, impl: int, seed: int, n_total: int, T: int, rank: int, world: int,

@@ -362,9 +362,11 @@ class Ops:
         return outs
 
     # ---- fused SMC --------------------------------------------------------------------------------
-    def _smc_cfg(self, impl, n_total, first, n_local, step_keys, resample_keys):
+    def _smc_cfg(self, impl, n_total, first, n_local, step_keys, resample_keys, ess_threshold: float = 0.0,
+                 tile_sums_form: int = 0):
         """`step_keys` / `resample_keys`: [T, 2] for one filter, [F, T, 2] for F filters stepping in the same
-        launches (gjx_smc_config.n_filters)."""
+        launches (gjx_smc_config.n_filters).  `ess_threshold` in (0, 1): ESS-adaptive resampling — the config then
+        carries a device int32[T] / [F, T] `cfg._flags` (1 where a step began with a resampling)."""
         import numpy as np
 
         sk = np.ascontiguousarray(np.asarray(step_keys, dtype=np.uint32))
@@ -378,6 +380,13 @@ class Ops:
         cfg.filter_stride = self.num_tiles(n_total) * self.tile if F > 1 else 0
         cfg._keep = (sk, rk)  # keep host arrays alive
         cfg._filters = F
+        cfg.ess_threshold = float(ess_threshold)
+        cfg.tile_sums_form = int(tile_sums_form)
+        cfg._adaptive = 0.0 < float(ess_threshold) < 1.0
+        cfg._flags = None
+        if cfg._adaptive:
+            cfg._flags = torch.zeros((F, T) if F > 1 else (T,), dtype=torch.int32, device=self.device())
+            cfg.resampled_out = cfg._flags.data_ptr()
         return cfg
 
     def _smc_buffers(self, cfg, n, state_dtype, want_ancestors):
@@ -397,10 +406,12 @@ class Ops:
                 self.empty((F, stride), torch.float32),
                 self.empty((T, F, stride), torch.int32) if want_ancestors else None, (ws, F * ws_one))
 
-    def smc_run_lgssm(self, impl, n, step_keys, resample_keys, model: abi.Lgssm, y, want_ancestors=False):
+    def smc_run_lgssm(self, impl, n, step_keys, resample_keys, model: abi.Lgssm, y, want_ancestors=False,
+                      ess_threshold: float = 0.0, tile_sums_form: int = 0, want_flags: bool = False):
+        """-> (out_max, out_q, state, logw, ancestors[, resampled flags or None])."""
         import numpy as np
 
-        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys)
+        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys, ess_threshold, tile_sums_form)
         yh = np.ascontiguousarray(np.asarray(y, dtype=np.float32))
         assert yh.size == cfg.n_steps
         out_max, out_q, state, logw, anc, (ws, nb) = self._smc_buffers(cfg, n, torch.float32, want_ancestors)
@@ -408,13 +419,13 @@ class Ops:
                       C.c_void_p(out_max.data_ptr()), C.c_void_p(out_q.data_ptr()), C.c_void_p(state.data_ptr()),
                       C.c_void_p(logw.data_ptr()), C.c_void_p(anc.data_ptr()) if anc is not None else None,
                       C.c_void_p(ws.data_ptr()), nb, self.stream())
-        return out_max, out_q, state, logw, anc
+        return (out_max, out_q, state, logw, anc, cfg._flags) if want_flags else (out_max, out_q, state, logw, anc)
 
     def smc_run_hmm(self, impl, n, step_keys, resample_keys, n_states, init_state, trans_logits, obs_logits, y,
-                    want_ancestors=False):
+                    want_ancestors=False, ess_threshold: float = 0.0, tile_sums_form: int = 0, want_flags: bool = False):
         import numpy as np
 
-        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys)
+        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys, ess_threshold, tile_sums_form)
         yh = np.ascontiguousarray(np.asarray(y, dtype=np.int32))
         assert yh.size == cfg.n_steps
         mdl = abi.Hmm()
@@ -426,7 +437,7 @@ class Ops:
                       C.c_void_p(out_max.data_ptr()), C.c_void_p(out_q.data_ptr()), C.c_void_p(state.data_ptr()),
                       C.c_void_p(logw.data_ptr()), C.c_void_p(anc.data_ptr()) if anc is not None else None,
                       C.c_void_p(ws.data_ptr()), nb, self.stream())
-        return out_max, out_q, state, logw, anc
+        return (out_max, out_q, state, logw, anc, cfg._flags) if want_flags else (out_max, out_q, state, logw, anc)
 
     def hmm_model(self, n_states: int, init_state: int, trans_logits: torch.Tensor, obs_logits: torch.Tensor) -> abi.Hmm:
         mdl = abi.Hmm()
@@ -463,13 +474,14 @@ class Ops:
         self.lib.call("gjx_smc_plan_create", C.byref(m), C.byref(handle))
         return SmcPlan(self, handle, len(next_state), n_obs)
 
-    def smc_run_plan(self, plan: "SmcPlan", impl, n, step_keys, resample_keys, obs, want_ancestors=False):
+    def smc_run_plan(self, plan: "SmcPlan", impl, n, step_keys, resample_keys, obs, want_ancestors=False,
+                     ess_threshold: float = 0.0, tile_sums_form: int = 0, want_flags: bool = False):
         """`step_keys` / `resample_keys` [T, 2]: one filter -> (max [T], q [T], state columns [n], logw [n], ancestors
         [T, n]); [F, T, 2]: F filters (same observations, own keys) stepping in the same launches -> ([F, T], [F, T],
         columns [F, stride], [F, stride], [T, F, stride]), filter f equal to its own single run bit for bit."""
         import numpy as np
 
-        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys)
+        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys, ess_threshold, tile_sums_form)
         T, F = cfg.n_steps, cfg._filters
         oh = np.ascontiguousarray(np.asarray(obs, dtype=np.float32).reshape(T, max(plan.n_obs, 1))[:, :plan.n_obs])
         stride = cfg.filter_stride if F > 1 else n
@@ -483,11 +495,19 @@ class Ops:
         self.lib.call("gjx_smc_run_plan", C.byref(cfg), plan.handle, C.c_void_p(oh.ctypes.data) if plan.n_obs else None,
                       self._p(out_max), self._p(out_q), sp, self._p(logw), self._p(anc), C.c_void_p(ws.data_ptr()), nb,
                       self.stream())
-        return out_max, out_q, states, logw, anc
+        return (out_max, out_q, states, logw, anc, cfg._flags) if want_flags else (out_max, out_q, states, logw, anc)
 
     # ---- step-level SMC pieces (multi-device driver: dist.py) -----------------------------------
-    def smc_config(self, impl, n_total, first, n_local, step_keys, resample_keys):
-        return self._smc_cfg(impl, n_total, first, n_local, step_keys, resample_keys)
+    def smc_config(self, impl, n_total, first, n_local, step_keys, resample_keys, ess_threshold: float = 0.0,
+                   tile_sums_form: int = 0):
+        """Step-level config.  Adaptive filters (`ess_threshold` in (0, 1)) also get `cfg._tile_ess`, the GLOBAL
+        int64[2 * tiles] array of ESS sums step B fills and step A / source_ranges read (ranks all-gather it)."""
+        cfg = self._smc_cfg(impl, n_total, first, n_local, step_keys, resample_keys, ess_threshold, tile_sums_form)
+        cfg._tile_ess = None
+        if cfg._adaptive:
+            cfg._tile_ess = torch.zeros(2 * self.num_tiles(n_total), dtype=torch.int64, device=self.device())
+            cfg.tile_ess = cfg._tile_ess.data_ptr()
+        return cfg
 
     @staticmethod
     def _p(t):
@@ -533,13 +553,20 @@ class Ops:
         self.lib.call("gjx_smc_source_ranges", C.byref(cfg), self._p(tile_sums), int(world), int(ticket),
                       self._p(out_ranges), self.stream())
 
-    def log_z_from_pairs(self, out_max: torch.Tensor, out_q: torch.Tensor, n_total: int) -> float:
-        """log Z = sum_t (max_t + log(q_t 2^-frac) - log N), evaluated in float64 on the host from
-        the exact per-step (max, fixed-point sum) pairs."""
+    def log_z_from_pairs(self, out_max: torch.Tensor, out_q: torch.Tensor, n_total: int, resampled=None) -> float:
+        """log Z = sum_t (max_t + log(q_t 2^-frac) - log N), evaluated in float64 on the host from the exact
+        per-step (max, fixed-point sum) pairs.  `resampled` (int32[T], ESS-adaptive filters): the sum runs over the
+        steps that END an epoch of accumulated weights — a resampling follows (resampled[t + 1] == 1) or t = T - 1."""
         frac = self.frac_bits(n_total)
         m = out_max.detach().cpu().double()
         q = out_q.detach().cpu().double()
-        return float((m + torch.log(q) - frac * math.log(2.0) - math.log(n_total)).sum())
+        terms = m + torch.log(q) - frac * math.log(2.0) - math.log(n_total)
+        if resampled is not None:
+            r = resampled.detach().cpu().bool()
+            ends = torch.ones_like(r)
+            ends[:-1] = r[1:]
+            terms = terms[ends]
+        return float(terms.sum())
 
 
 class SmcPlan:

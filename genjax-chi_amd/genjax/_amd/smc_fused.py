@@ -47,6 +47,7 @@ class SMCResult:
     particles: torch.Tensor  # final-step particles [n] (a tuple of columns for a multi-component carry)
     log_weights: torch.Tensor  # their incremental log-weights [n]
     ancestors: torch.Tensor | None  # int32[T, n] (row 0 = identity)
+    resampled: torch.Tensor | None = None  # int32[T] (ESS-adaptive filters): 1 where a step began with a resampling
 
     def get_log_marginal_likelihood_estimate(self) -> float:
         return self.log_marginal_likelihood
@@ -60,10 +61,13 @@ def smc_key_schedule(key: prng.PRNGKey, T: int):
 
 
 class BootstrapSMC:
-    """Bootstrap particle filter, systematic resampling at every step."""
+    """Bootstrap particle filter with systematic resampling: at every step (default), or — `ess_threshold` in (0, 1) —
+    only when the effective sample size of the current weights falls below `ess_threshold * n_particles`; between
+    resamplings the log-weights accumulate (gjx.h: gjx_smc_config.ess_threshold)."""
 
-    def __init__(self, model, observations, n_particles: int, record_ancestors: bool = False):
+    def __init__(self, model, observations, n_particles: int, record_ancestors: bool = False, ess_threshold: float = 0.0):
         self.model, self.n, self.record_ancestors = model, int(n_particles), record_ancestors
+        self.ess_threshold = float(ess_threshold)
         self._plan = None
         if isinstance(model, StateSpaceModel):
             if not isinstance(observations, ChoiceMap):
@@ -84,14 +88,16 @@ class BootstrapSMC:
         if isinstance(self.model, LinearGaussianSSM):
             m = self.model
             out = ops.smc_run_lgssm(key.impl, self.n, sk, rk, abi.Lgssm(m.x0_loc, m.x0_scale, m.a, m.q, m.r),
-                                    self.observations.astype(np.float32), self.record_ancestors)
+                                    self.observations.astype(np.float32), self.record_ancestors,
+                                    ess_threshold=self.ess_threshold, want_flags=True)
         elif isinstance(self.model, DiscreteHMM):
             m = self.model
             dev = ops.device()
             tl = torch.as_tensor(m.trans_logits, dtype=torch.float32).to(dev).contiguous()
             ol = torch.as_tensor(m.obs_logits, dtype=torch.float32).to(dev).contiguous()
             out = ops.smc_run_hmm(key.impl, self.n, sk, rk, int(tl.shape[0]), int(m.init_state), tl, ol,
-                                  self.observations.astype(np.int32), self.record_ancestors)
+                                  self.observations.astype(np.int32), self.record_ancestors,
+                                  ess_threshold=self.ess_threshold, want_flags=True)
         elif isinstance(self.model, StateSpaceModel):
             if self._plan is None:
                 self._obs_addrs = [a for a, _ in self._obs_chm.leaves()]
@@ -99,13 +105,14 @@ class BootstrapSMC:
                 self._obs = observation_matrix(self._obs_chm, self._obs_addrs)
             T = self._obs.shape[0]
             sk, rk = smc_key_schedule(key, T)
-            om, oq, states, logw, anc = ops.smc_run_plan(self._plan, key.impl, self.n, sk, rk, self._obs,
-                                                         self.record_ancestors)
-            out = (om, oq, states[0] if self._n_state == 1 else tuple(states), logw, anc)
+            om, oq, states, logw, anc, fl = ops.smc_run_plan(self._plan, key.impl, self.n, sk, rk, self._obs,
+                                                             self.record_ancestors, ess_threshold=self.ess_threshold,
+                                                             want_flags=True)
+            out = (om, oq, states[0] if self._n_state == 1 else tuple(states), logw, anc, fl)
         else:
             raise TypeError(f"no fused SMC kernel for {type(self.model).__name__}")
-        step_max, step_q, state, logw, anc = out
-        return SMCResult(ops.log_z_from_pairs(step_max, step_q, self.n), step_max, step_q, state, logw, anc)
+        step_max, step_q, state, logw, anc, flags = out
+        return SMCResult(ops.log_z_from_pairs(step_max, step_q, self.n, flags), step_max, step_q, state, logw, anc, flags)
 
     def run_many(self, keys) -> list:
         """`vmap(self.run)(keys)`: one independent filter per key.  Up to 16 filters step in the same kernel launches
@@ -118,35 +125,51 @@ class BootstrapSMC:
         if isinstance(self.model, StateSpaceModel) and self._plan is None:
             self.run(keys[0])  # builds the plan and the observation matrix
         T = len(self.observations) if self.observations is not None else self._obs.shape[0]
+        ess = dict(ess_threshold=self.ess_threshold, want_flags=True)
         for lo in range(0, len(keys), 16):
             chunk = keys[lo:lo + 16]
             if len(chunk) == 1:
                 out.append(self.run(chunk[0]))
                 continue
-            pairs = [smc_key_schedule(k, T) for k in chunk]
-            sk, rk = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
-            m, impl = self.model, chunk[0].impl
-            if isinstance(m, StateSpaceModel):
-                om, oq, states, logw, anc = ops.smc_run_plan(self._plan, impl, self.n, sk, rk, self._obs, self.record_ancestors)
-                for f in range(len(chunk)):
-                    cols = [c[f, :self.n] for c in states]
-                    out.append(SMCResult(ops.log_z_from_pairs(om[f], oq[f], self.n), om[f], oq[f],
-                                         cols[0] if self._n_state == 1 else tuple(cols), logw[f, :self.n],
-                                         None if anc is None else anc[:, f, :self.n]))
-                continue
-            if isinstance(m, LinearGaussianSSM):
-                res = ops.smc_run_lgssm(impl, self.n, sk, rk, abi.Lgssm(m.x0_loc, m.x0_scale, m.a, m.q, m.r),
-                                        self.observations.astype(np.float32), self.record_ancestors)
-            else:
-                dev = ops.device()
-                tl = torch.as_tensor(m.trans_logits, dtype=torch.float32).to(dev).contiguous()
-                ol = torch.as_tensor(m.obs_logits, dtype=torch.float32).to(dev).contiguous()
-                res = ops.smc_run_hmm(impl, self.n, sk, rk, int(tl.shape[0]), int(m.init_state), tl, ol,
-                                      self.observations.astype(np.int32), self.record_ancestors)
-            step_max, step_q, state, logw, anc = res
+            try:
+                out.extend(self._run_chunk(ops, chunk, T, ess))
+            except abi.GjxError as e:
+                # populations too large for a filter batch (more than 2048 tiles per filter, or a workspace the
+                # device cannot hold): the documented contract is "element b equals self.run(keys[b])" — run them so
+                if e.code not in (-2, -3):  # GJX_ERR_UNSUPPORTED, GJX_ERR_WORKSPACE
+                    raise
+                out.extend(self.run(k) for k in chunk)
+        return out
+
+    def _run_chunk(self, ops, chunk, T, ess) -> list:
+        out = []
+        pairs = [smc_key_schedule(k, T) for k in chunk]
+        sk, rk = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+        m, impl = self.model, chunk[0].impl
+        if isinstance(m, StateSpaceModel):
+            om, oq, states, logw, anc, fl = ops.smc_run_plan(self._plan, impl, self.n, sk, rk, self._obs,
+                                                             self.record_ancestors, **ess)
             for f in range(len(chunk)):
-                out.append(SMCResult(ops.log_z_from_pairs(step_max[f], step_q[f], self.n), step_max[f], step_q[f],
-                                     state[f, :self.n], logw[f, :self.n], None if anc is None else anc[:, f, :self.n]))
+                cols = [c[f, :self.n] for c in states]
+                ff = None if fl is None else fl[f]
+                out.append(SMCResult(ops.log_z_from_pairs(om[f], oq[f], self.n, ff), om[f], oq[f],
+                                     cols[0] if self._n_state == 1 else tuple(cols), logw[f, :self.n],
+                                     None if anc is None else anc[:, f, :self.n], ff))
+            return out
+        if isinstance(m, LinearGaussianSSM):
+            res = ops.smc_run_lgssm(impl, self.n, sk, rk, abi.Lgssm(m.x0_loc, m.x0_scale, m.a, m.q, m.r),
+                                    self.observations.astype(np.float32), self.record_ancestors, **ess)
+        else:
+            dev = ops.device()
+            tl = torch.as_tensor(m.trans_logits, dtype=torch.float32).to(dev).contiguous()
+            ol = torch.as_tensor(m.obs_logits, dtype=torch.float32).to(dev).contiguous()
+            res = ops.smc_run_hmm(impl, self.n, sk, rk, int(tl.shape[0]), int(m.init_state), tl, ol,
+                                  self.observations.astype(np.int32), self.record_ancestors, **ess)
+        step_max, step_q, state, logw, anc, fl = res
+        for f in range(len(chunk)):
+            ff = None if fl is None else fl[f]
+            out.append(SMCResult(ops.log_z_from_pairs(step_max[f], step_q[f], self.n, ff), step_max[f], step_q[f],
+                                 state[f, :self.n], logw[f, :self.n], None if anc is None else anc[:, f, :self.n], ff))
         return out
 
     def log_marginal_likelihood_estimate(self, key: prng.PRNGKey) -> float:

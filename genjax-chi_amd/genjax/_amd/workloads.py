@@ -174,36 +174,42 @@ def filter_key_schedules(seed: int, impl: int, T: int, filters: int):
 
 
 def smc_result(ops: Ops, out, n: int, filters: int, log_z_exact: float):
-    out_max, out_q, state, logw, anc = out
+    out_max, out_q, state, logw, anc = out[:5]
+    flags = out[5] if len(out) > 5 else None  # ESS-adaptive filters: 1 where a step began with a resampling
     if filters == 1:
-        return dict(out_max=out_max, out_q=out_q, state=state, logw=logw, ancestors=anc,
-                    log_z=ops.log_z_from_pairs(out_max, out_q, n), log_z_exact=log_z_exact)
+        return dict(out_max=out_max, out_q=out_q, state=state, logw=logw, ancestors=anc, resampled=flags,
+                    log_z=ops.log_z_from_pairs(out_max, out_q, n, flags), log_z_exact=log_z_exact)
     return dict(out_max=out_max, out_q=out_q, state=state[:, :n], logw=logw[:, :n],
-                ancestors=None if anc is None else anc[:, :, :n],
-                log_z=[ops.log_z_from_pairs(out_max[f], out_q[f], n) for f in range(filters)], log_z_exact=log_z_exact)
+                ancestors=None if anc is None else anc[:, :, :n], resampled=flags,
+                log_z=[ops.log_z_from_pairs(out_max[f], out_q[f], n, None if flags is None else flags[f]) for f in range(filters)],
+                log_z_exact=log_z_exact)
 
 
 class LgssmSMC:
     """Reusable state of the C3 workload: data, key schedule and exact log Z are prepared once, so
     `run()` is only the enqueue of the fused filter (2 kernels per step, no host sync)."""
 
-    def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, want_ancestors: bool = False, filters: int = 1):
-        """`filters` > 1: that many independent filters (seeds seed, seed+1, ...) step in the same launches."""
+    def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, want_ancestors: bool = False, filters: int = 1,
+                 ess_threshold: float = 0.0, tile_sums_form: int = 0, y=None, model=None):
+        """`filters` > 1: that many independent filters (seeds seed, seed+1, ...) step in the same launches.
+        `ess_threshold` in (0, 1): resample only when ESS < threshold * n (gjx_smc_config)."""
         self.ops, self.impl, self.n, self.T, self.want_ancestors, self.filters = ops, impl, n, T, want_ancestors, filters
-        self.y = lgssm_data(T)
+        self.ess, self.form = ess_threshold, tile_sums_form
+        self.y = lgssm_data(T) if y is None else np.asarray(y, dtype=np.float32)
         self.sk, self.rk = filter_key_schedules(seed, impl, T, filters)
-        self.model = lgssm_model()
-        self.log_z_exact = lgssm_exact_log_z(self.y)
+        self.model = lgssm_model() if model is None else model
+        self.log_z_exact = lgssm_exact_log_z(self.y) if model is None else float("nan")
 
     def run(self):
-        return self.ops.smc_run_lgssm(self.impl, self.n, self.sk, self.rk, self.model, self.y, self.want_ancestors)
+        return self.ops.smc_run_lgssm(self.impl, self.n, self.sk, self.rk, self.model, self.y, self.want_ancestors,
+                                      ess_threshold=self.ess, tile_sums_form=self.form, want_flags=True)
 
     def result(self, out):
         return smc_result(self.ops, out, self.n, self.filters, self.log_z_exact)
 
 
-def lgssm_smc(ops: Ops, impl: int, seed: int, n: int, T: int, want_ancestors: bool = False):
-    w = LgssmSMC(ops, impl, seed, n, T, want_ancestors)
+def lgssm_smc(ops: Ops, impl: int, seed: int, n: int, T: int, want_ancestors: bool = False, **kw):
+    w = LgssmSMC(ops, impl, seed, n, T, want_ancestors, **kw)
     return w.result(w.run())
 
 
@@ -276,9 +282,10 @@ class HmmSMC:
     """Reusable state of the C5 workload (tables resident on the device, data and keys prepared)."""
 
     def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, n_states=None, want_ancestors: bool = False,
-                 filters: int = 1):
+                 filters: int = 1, ess_threshold: float = 0.0, tile_sums_form: int = 0):
         trans, obs = hmm_tables(n_states)
         self.ops, self.impl, self.n, self.T, self.want_ancestors, self.filters = ops, impl, n, T, want_ancestors, filters
+        self.ess, self.form = ess_threshold, tile_sums_form
         self.k = trans.shape[0]
         self.init = HMM["init_state"] % self.k
         self.y = hmm_data(T, n_states)
@@ -290,12 +297,12 @@ class HmmSMC:
 
     def run(self):
         return self.ops.smc_run_hmm(self.impl, self.n, self.sk, self.rk, self.k, self.init, self.tl, self.ol, self.y,
-                                    self.want_ancestors)
+                                    self.want_ancestors, ess_threshold=self.ess, tile_sums_form=self.form, want_flags=True)
 
     def result(self, out):
         return smc_result(self.ops, out, self.n, self.filters, self.log_z_exact)
 
 
-def hmm_smc(ops: Ops, impl: int, seed: int, n: int, T: int, n_states=None, want_ancestors: bool = False):
-    w = HmmSMC(ops, impl, seed, n, T, n_states, want_ancestors)
+def hmm_smc(ops: Ops, impl: int, seed: int, n: int, T: int, n_states=None, want_ancestors: bool = False, **kw):
+    w = HmmSMC(ops, impl, seed, n, T, n_states, want_ancestors, **kw)
     return w.result(w.run())

@@ -392,6 +392,26 @@ typedef struct {
    * MI355X: a few filters per launch fill it.  Each filter equals its own single run bit for bit. */
   int32_t n_filters;
   uint64_t filter_stride;
+  /* ESS-adaptive resampling (not in the reference, which has no resampling step at all).
+   * 0 (unset) or >= 1: systematic resampling before every step t >= 1 (the BASELINE configs).  In (0, 1): the
+   * population of step t-1 is resampled only if its effective sample size is below ess_threshold * n_total;
+   * otherwise every particle keeps its own ancestor (ancestors[t][j] = j), and its log-weight ACCUMULATES:
+   * logw_t[j] = logw_{t-1}[j] + increment.  ESS is evaluated on exact integers so that every backend, tiling and
+   * number of ranks takes the same decision: r_i = q_i >> (frac - 16) (q_i the fixed-point weight),
+   * R1 = sum r_i, R2 = sum r_i^2, resample iff (double)R1 * (double)R1 < (ess_threshold * n_total) * (double)R2.
+   * log Z = sum over the steps t that END an epoch (a resampling follows, or t = T-1) of
+   * (max_t + log(q_t 2^-frac) - log N): the per-step (out_max, out_q) pairs are those of the accumulated weights.
+   * resampled_out: nullable dev int32[T] ([F, T] for F filters): entry t = 1 if step t began with a resampling
+   * (entry 0 is 0).  Required (non-NULL) when ess_threshold is in (0, 1). */
+  float ess_threshold;
+  int32_t* resampled_out;
+  /* Per-step pieces of an adaptive filter (the whole-run calls carve it from their workspace): GLOBAL array dev
+   * u64[2 gjx_num_tiles(n_total)]; step B leaves the sums R1_b, R2_b of its tiles in entries 2 b, 2 b + 1 (ranks
+   * all-gather it like tile_sums) and step A of the next step decides from it. */
+  uint64_t* tile_ess;
+  /* Tuning / test knob: form of the tile-mass kernel.  0 = by launch size (a wave per tile from 4096 tiles per
+   * launch, a workgroup per tile below), 1 = a workgroup per tile, 2 = a wave per tile.  Same bits either way. */
+  int32_t tile_sums_form;
 } gjx_smc_config;
 
 /* Single-device whole run (first_slot = 0, n_local = n_total).  y: HOST array [T] (f32 for lgssm,
@@ -435,6 +455,7 @@ int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* model, int t, i
                        int32_t* ancestors_out, gjx_stream s);
 int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const float* max_partials,
                    float* max_out, uint64_t* tile_sums, gjx_stream s);
+
 int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
                    gjx_stream s);
 /* A rank with n_local < n_total reads, in step A, ONLY the source tiles that own one of its slots (which tiles

@@ -771,7 +771,25 @@ int gjx_gather_cols(const int32_t* ancestors, uint64_t n_out, const void* const*
 static int cfg_ok(const gjx_smc_config* c) {
   return c && (c->impl == 0 || c->impl == 1) && c->n_total > 0 && c->n_local > 0 &&
          c->first_slot + c->n_local <= c->n_total && c->n_steps > 0 && c->step_keys &&
-         c->resample_keys && (c->first_slot % O_TILE) == 0;
+         c->resample_keys && (c->first_slot % O_TILE) == 0 && !(c->ess_threshold < 0.0f) &&
+         c->tile_sums_form >= 0 && c->tile_sums_form <= 2;
+}
+/* ESS-adaptive resampling (gjx.h: gjx_smc_config.ess_threshold).  The decision is a function of exact integer sums
+ * and three double operations, so every backend and every sharding takes the same one. */
+static int cfg_adaptive(const gjx_smc_config* c) { return c->ess_threshold > 0.0f && c->ess_threshold < 1.0f; }
+static inline uint64_t ess_r(uint64_t q, int frac) { return q >> (frac - 16); }
+static int ess_says_resample(uint64_t r1, uint64_t r2, double thr) {
+  if (!(thr > 0.0) || r2 == 0) return 1;
+  const double a = (double)r1 * (double)r1;
+  const double b = thr * (double)r2;
+  return a < b;
+}
+/* Does step t (>= 1) begin with a resampling of the population of step t - 1? */
+static int smc_resamples(const gjx_smc_config* cfg) {
+  if (!cfg_adaptive(cfg)) return 1;
+  uint64_t r1 = 0, r2 = 0;
+  for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) { r1 += cfg->tile_ess[2 * b]; r2 += cfg->tile_ess[2 * b + 1]; }
+  return ess_says_resample(r1, r2, (double)cfg->ess_threshold * (double)cfg->n_total);
 }
 
 /* Ancestors of slots [lo, hi) by systematic resampling of the GLOBAL previous population.  Source tiles
@@ -822,13 +840,21 @@ int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const flo
   *max_out = m;
   const uint64_t tile0 = cfg->first_slot / O_TILE;
   const uint64_t ntile = gjx_num_tiles(cfg->n_local);
+  if (cfg_adaptive(cfg) && !cfg->tile_ess) return GJX_ERR_INVALID;
 #pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < (int64_t)ntile; ++b) {
-    uint64_t acc = 0;
+    uint64_t acc = 0, a1 = 0, a2 = 0;
     uint64_t e = ((uint64_t)b + 1) * O_TILE;
     if (e > cfg->n_local) e = cfg->n_local;
-    for (uint64_t i = (uint64_t)b * O_TILE; i < e; ++i) acc += o_fixw(logw_local[i], m, frac);
+    for (uint64_t i = (uint64_t)b * O_TILE; i < e; ++i) {
+      const uint64_t q = o_fixw(logw_local[i], m, frac);
+      acc += q;
+      const uint64_t r = ess_r(q, frac);
+      a1 += r;
+      a2 += r * r;
+    }
     tile_sums[tile0 + (uint64_t)b] = acc;
+    if (cfg_adaptive(cfg)) { cfg->tile_ess[2 * (tile0 + (uint64_t)b)] = a1; cfg->tile_ess[2 * (tile0 + (uint64_t)b) + 1] = a2; }
   }
   return GJX_OK;
 }
@@ -852,6 +878,17 @@ int gjx_smc_source_ranges(const gjx_smc_config* cfg, const uint64_t* tile_sums, 
   if (!cfg_ok(cfg) || !tile_sums || !out_ranges || world < 1 || world > 64 || cfg->n_total % (uint64_t)world)
     return GJX_ERR_INVALID;
   const uint64_t N = cfg->n_total, nt = gjx_num_tiles(N), nl = N / (uint64_t)world;
+  if (cfg_adaptive(cfg)) {
+    if (!cfg->tile_ess) return GJX_ERR_INVALID;
+    if (!smc_resamples(cfg)) { /* the next step keeps its particles: every block's sources are its own tiles */
+      for (int j = 0; j < world; ++j) {
+        out_ranges[2 * j] = (int64_t)((uint64_t)j * (nl / O_TILE));
+        out_ranges[2 * j + 1] = (int64_t)((uint64_t)(j + 1) * (nl / O_TILE));
+      }
+      out_ranges[2 * world] = ticket;
+      return GJX_OK;
+    }
+  }
   uint64_t Q = 0;
   for (uint64_t b = 0; b < nt; ++b) Q += tile_sums[b];
   const double scale = (double)N / (double)Q, nd = (double)N;
@@ -877,16 +914,27 @@ int gjx_smc_source_ranges(const gjx_smc_config* cfg, const uint64_t* tile_sums, 
   return GJX_OK;
 }
 
+/* Front half of every step A (t >= 1): the ancestors of the rank's slots — by systematic resampling, or the identity
+ * when an adaptive filter keeps its particles — the total mass of the previous weights and the step's flag.
+ * Returns 1 if the step resamples (the new log-weights start from 0), 0 if it accumulates. */
+static int smc_step_front(const gjx_smc_config* cfg, int t, const float* prev_logw, float prev_max,
+                          const uint64_t* prev_tile_sums, uint64_t* prev_q_out, int32_t* anc) {
+  uint64_t Q = 0;
+  for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) Q += prev_tile_sums[b];
+  if (prev_q_out) *prev_q_out = Q;
+  const int res = smc_resamples(cfg);
+  if (cfg->resampled_out && !(cfg->n_filters > 1)) cfg->resampled_out[t] = res;
+  if (res) smc_ancestors(cfg, t, prev_logw, prev_max, prev_tile_sums, Q, anc);
+  else
+    for (uint64_t j = 0; j < cfg->n_local; ++j) anc[j] = (int32_t)(cfg->first_slot + j);
+  return res;
+}
+
 /* max_partials_out: only "max over the array == local max" is specified; the oracle puts the
  * local max in the rank's first tile entry and -inf elsewhere. */
 static void put_max_partials(const gjx_smc_config* cfg, float mx, float* mp) {
   for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) mp[b] = -INFINITY;
   mp[cfg->first_slot / O_TILE] = mx;
-}
-static uint64_t sum_tiles(const gjx_smc_config* cfg, const uint64_t* tiles) {
-  uint64_t Q = 0;
-  for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) Q += tiles[b];
-  return Q;
 }
 
 int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t,
@@ -899,13 +947,13 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
     return GJX_ERR_INVALID;
   const uint64_t nl = cfg->n_local;
   int32_t* anc = NULL;
+  int carry = 0;
   if (t > 0) {
     if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
+    if (cfg_adaptive(cfg) && !cfg->tile_ess) return GJX_ERR_INVALID;
     anc = ancestors_out ? ancestors_out : (int32_t*)malloc(sizeof(int32_t) * nl);
     if (!anc) return GJX_ERR_LAUNCH;
-    const uint64_t Qprev = sum_tiles(cfg, prev_tile_sums);
-    if (prev_q_out) *prev_q_out = Qprev;
-    smc_ancestors(cfg, t, prev_logw, *prev_max, prev_tile_sums, Qprev, anc);
+    carry = !smc_step_front(cfg, t, prev_logw, *prev_max, prev_tile_sums, prev_q_out, anc);
   } else if (ancestors_out) {
     for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
   }
@@ -924,6 +972,7 @@ int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t,
       x = mean + tt;
     }
     float lw = o_logpdf_normal(y_t, x, mdl->r);
+    if (carry) lw = lw + prev_logw[anc[j]]; /* no resampling at this step: the log-weight accumulates */
     state_out[j] = x;
     logw_out[j] = lw;
     mx = lw > mx ? lw : mx;
@@ -997,13 +1046,13 @@ int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int
   const uint64_t nl = cfg->n_local;
   const uint32_t K = (uint32_t)mdl->n_states;
   int32_t* anc = NULL;
+  int carry = 0;
   if (t > 0) {
     if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
+    if (cfg_adaptive(cfg) && !cfg->tile_ess) return GJX_ERR_INVALID;
     anc = ancestors_out ? ancestors_out : (int32_t*)malloc(sizeof(int32_t) * nl);
     if (!anc) return GJX_ERR_LAUNCH;
-    const uint64_t Qprev = sum_tiles(cfg, prev_tile_sums);
-    if (prev_q_out) *prev_q_out = Qprev;
-    smc_ancestors(cfg, t, prev_logw, *prev_max, prev_tile_sums, Qprev, anc);
+    carry = !smc_step_front(cfg, t, prev_logw, *prev_max, prev_tile_sums, prev_q_out, anc);
   } else if (ancestors_out) {
     for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
   }
@@ -1015,6 +1064,7 @@ int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int
     int32_t zp = t == 0 ? mdl->init_state : prev_state[anc[j]];
     const uint32_t lo = hmm_alias_draw(trans_alias + (size_t)zp * K, K, bits);
     float lw = obs_logp[(size_t)lo * K + (uint32_t)y_t];
+    if (carry) lw = lw + prev_logw[anc[j]];
     state_out[j] = (int32_t)lo;
     logw_out[j] = lw;
     mx = lw > mx ? lw : mx;
@@ -1033,6 +1083,13 @@ static int smc_run_common(const gjx_smc_config* cfg, int is_hmm, const void* mod
     return GJX_ERR_INVALID;
   const uint64_t N = cfg->n_total;
   const uint64_t ntile = gjx_num_tiles(N);
+  gjx_smc_config lc = *cfg; /* the run's own ESS sums (an adaptive filter) */
+  if (cfg_adaptive(cfg)) {
+    if (!cfg->resampled_out) return GJX_ERR_INVALID;
+    lc.tile_ess = (uint64_t*)calloc(2 * ntile, sizeof(uint64_t));
+  }
+  if (lc.resampled_out) memset(lc.resampled_out, 0, sizeof(int32_t) * (size_t)cfg->n_steps);
+  cfg = &lc;
   void* st[2] = {malloc(4 * N), malloc(4 * N)};
   float* lw[2] = {(float*)malloc(4 * N), (float*)malloc(4 * N)};
   uint64_t* tiles = (uint64_t*)malloc(8 * ntile);
@@ -1068,6 +1125,7 @@ static int smc_run_common(const gjx_smc_config* cfg, int is_hmm, const void* mod
     memcpy(logw_out, lw[last], 4 * N);
   }
   free(st[0]); free(st[1]); free(lw[0]); free(lw[1]); free(tiles); free(mp); free(tcdf); free(ologp);
+  if (cfg_adaptive(cfg)) free(lc.tile_ess);
   return rc;
 }
 
@@ -1087,6 +1145,7 @@ static int smc_run_filters(const gjx_smc_config* cfg, int kind, const void* mode
     c.n_filters = 0;
     c.step_keys = cfg->step_keys + 2 * (size_t)f * T;
     c.resample_keys = cfg->resample_keys + 2 * (size_t)f * T;
+    c.resampled_out = cfg->resampled_out ? cfg->resampled_out + (size_t)f * T : NULL;
     rc = smc_run_common(&c, kind, model, y, out_max + (size_t)f * T, out_q + (size_t)f * T,
                         (char*)state_out + 4 * (size_t)f * stride, logw_out + (size_t)f * stride, anc1);
     if (!rc && anc1)  /* [T, N] -> [T, F, stride] */
@@ -1206,13 +1265,13 @@ int gjx_smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, co
   const int D = m->n_state;
   const uint64_t nl = cfg->n_local;
   int32_t* anc = NULL;
+  int carry = 0;
   if (t > 0) {
     if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
+    if (cfg_adaptive(cfg) && !cfg->tile_ess) return GJX_ERR_INVALID;
     anc = ancestors_out ? ancestors_out : (int32_t*)malloc(sizeof(int32_t) * nl);
     if (!anc) return GJX_ERR_LAUNCH;
-    const uint64_t Qprev = sum_tiles(cfg, prev_tile_sums);
-    if (prev_q_out) *prev_q_out = Qprev;
-    smc_ancestors(cfg, t, prev_logw, *prev_max, prev_tile_sums, Qprev, anc);
+    carry = !smc_step_front(cfg, t, prev_logw, *prev_max, prev_tile_sums, prev_q_out, anc);
   } else if (ancestors_out) {
     for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
   }
@@ -1239,6 +1298,7 @@ int gjx_smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, co
     float w, sc;
     site_walk(sites, ns, &c, vals, &w, &sc);
     for (int k = 0; k < D; ++k) state_out[k][j] = eval_arg(&nxt[k], vals, &c);
+    if (carry) w = w + prev_logw[anc[j]];
     logw_out[j] = w;
     mx = w > mx ? w : mx;
   }
@@ -1264,6 +1324,7 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
     c.n_filters = 0;
     c.step_keys = cfg->step_keys + 2 * (size_t)f * T;
     c.resample_keys = cfg->resample_keys + 2 * (size_t)f * T;
+    c.resampled_out = cfg->resampled_out ? cfg->resampled_out + (size_t)f * T : NULL;
     float* cols[GJX_SMC_MAX_STATE];
     for (int k = 0; k < D; ++k) cols[k] = state_out[k] + (size_t)f * stride;
     rc = smc_run_plan_one(&c, plan, obs_host, out_max + (size_t)f * T, out_q + (size_t)f * T, cols,
@@ -1283,6 +1344,13 @@ static int smc_run_plan_one(const gjx_smc_config* cfg, gjx_smc_plan* plan, const
   const gjx_smc_model* m = &plan->m;
   const uint64_t N = cfg->n_total, ntile = gjx_num_tiles(N);
   const int D = m->n_state;
+  gjx_smc_config lc = *cfg;
+  if (cfg_adaptive(cfg)) {
+    if (!cfg->resampled_out) return GJX_ERR_INVALID;
+    lc.tile_ess = (uint64_t*)calloc(2 * ntile, sizeof(uint64_t));
+  }
+  if (lc.resampled_out) memset(lc.resampled_out, 0, sizeof(int32_t) * (size_t)cfg->n_steps);
+  cfg = &lc;
   float* st[2] = {(float*)malloc(4 * N * (size_t)D), (float*)malloc(4 * N * (size_t)D)};  /* [D][N] each */
   float* lw[2] = {(float*)malloc(4 * N), (float*)malloc(4 * N)};
   uint64_t* tiles = (uint64_t*)malloc(8 * ntile);
@@ -1292,10 +1360,9 @@ static int smc_run_plan_one(const gjx_smc_config* cfg, gjx_smc_plan* plan, const
   for (int t = 0; t < cfg->n_steps && rc == GJX_OK; ++t) {
     const int cur = t & 1, prv = cur ^ 1;
     int32_t* anc = ancestors_out ? ancestors_out + (size_t)t * N : anc_tmp;
+    int carry = 0;
     if (t > 0) {
-      uint64_t Qprev = sum_tiles(cfg, tiles);
-      out_q[t - 1] = Qprev;
-      smc_ancestors(cfg, t, lw[prv], out_max[t - 1], tiles, Qprev, anc);
+      carry = !smc_step_front(cfg, t, lw[prv], out_max[t - 1], tiles, &out_q[t - 1], anc);
     } else {
       for (uint64_t j = 0; j < N; ++j) anc[j] = (int32_t)j;
     }
@@ -1322,6 +1389,7 @@ static int smc_run_plan_one(const gjx_smc_config* cfg, gjx_smc_plan* plan, const
       float w, sc;
       site_walk(sites, ns, &c, vals, &w, &sc);
       for (int k = 0; k < D; ++k) st[cur][(size_t)k * N + (uint64_t)j] = eval_arg(&nxt[k], vals, &c);
+      if (carry) w = w + lw[prv][anc[j]];
       lw[cur][j] = w;
       mx = w > mx ? w : mx;
     }
@@ -1335,5 +1403,6 @@ static int smc_run_plan_one(const gjx_smc_config* cfg, gjx_smc_plan* plan, const
     memcpy(logw_out, lw[last], 4 * N);
   }
   free(st[0]); free(st[1]); free(lw[0]); free(lw[1]); free(tiles); free(mp); free(anc_tmp);
+  if (cfg_adaptive(cfg)) free(lc.tile_ess);
   return rc;
 }

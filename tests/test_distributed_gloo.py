@@ -110,7 +110,7 @@ def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_s
 
     def work(r):
         try:
-            kw = dict(n_states=n_states) if kind == "hmm" else dict(model_kw)
+            kw = dict(model_kw, n_states=n_states) if kind == "hmm" else dict(model_kw)
             res[r] = gdist.ShardedSMC(ops, kind, impl, seed, n_total, T, r, world, True, exchange=exchange,
                                       comm=gdist.ThreadComm(sh, r), poison=True, **kw).run()
         except BaseException as e:  # noqa: BLE001 - re-raised below; release the others
@@ -127,14 +127,14 @@ def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_s
     return res
 
 
-def check_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ref_ops=None):
+def check_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ref_ops=None, ess_threshold=0.0):
     """`ref_ops`: the backend of the single-rank reference filter (default: the same one)."""
     from genjax._amd import workloads as W
 
-    res = _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange)
+    res = _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ess_threshold=ess_threshold)
     ref_ops = ops if ref_ops is None else ref_ops
-    ref = (W.lgssm_smc(ref_ops, impl, 5, n_total, T, True) if kind == "lgssm"
-           else W.hmm_smc(ref_ops, impl, 5, n_total, T, 16, True))
+    ref = (W.lgssm_smc(ref_ops, impl, 5, n_total, T, True, ess_threshold=ess_threshold) if kind == "lgssm"
+           else W.hmm_smc(ref_ops, impl, 5, n_total, T, 16, True, ess_threshold=ess_threshold))
     res = [{k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in r.items()} for r in res]
     ref = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in ref.items()}
     assert torch.equal(torch.cat([r["state"] for r in res]), ref["state"])
@@ -143,7 +143,67 @@ def check_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ref_ops=No
     for r in res:
         assert torch.equal(r["out_q"], ref["out_q"]) and torch.equal(r["out_max"], ref["out_max"])
         assert r["log_z"] == ref["log_z"]
+        if ess_threshold:
+            assert torch.equal(r["resampled"], ref["resampled"])
     return res
+
+
+@pytest.mark.parametrize("kind", ["lgssm", "hmm"])
+def test_sharded_adaptive_filter(oracle_ops, kind):
+    """ESS-adaptive resampling sharded over 3 virtual ranks: every rank takes the single-rank decision at every step
+    (exact integer ESS sums, all-gathered), a step that keeps its particles exchanges nothing (the device reports
+    each rank's own block as its source range), and the filter equals the single-rank one bit for bit."""
+    world, T = 3, 14
+    n_total = 1024 * world * 2
+    res = check_virtual_ranks(oracle_ops, kind, 1, world, n_total, T, "ranges", ess_threshold=0.5)
+    flags = res[0]["resampled"]
+    kept = int((flags[1:] == 0).sum())
+    assert 0 < kept < T - 1
+    # only the resampling steps moved particles between ranks
+    always = check_virtual_ranks(oracle_ops, kind, 1, world, n_total, T, "ranges")
+    assert all(a["received"] < b["received"] for a, b in zip(res, always))
+    check_virtual_ranks(oracle_ops, kind, 0, world, n_total, T, "allgather", ess_threshold=0.5)
+
+
+def test_ess_adaptive_properties(oracle_ops):
+    """The adaptive schedule on the oracle: a threshold above every ESS is the always-resampling filter; kept steps
+    have identity ancestors and ACCUMULATE log-weights (recomputed here from the particles); log Z stays an estimate of
+    the evidence; the decision rule is the documented integer / double expression."""
+    import math
+
+    import numpy as np
+
+    from genjax._amd import workloads as W
+
+    n, T = 6000, 24
+    always = W.lgssm_smc(oracle_ops, 1, 5, n, T, True)
+    hi = W.lgssm_smc(oracle_ops, 1, 5, n, T, True, ess_threshold=0.999)
+    assert torch.equal(hi["ancestors"], always["ancestors"]) and hi["log_z"] == always["log_z"]
+    assert int(hi["resampled"][1:].sum()) == T - 1
+    ad = W.lgssm_smc(oracle_ops, 1, 5, n, T, True, ess_threshold=0.5)
+    fl = ad["resampled"]
+    kept = [t for t in range(1, T) if int(fl[t]) == 0]
+    assert 0 < len(kept) < T - 1
+    assert abs(ad["log_z"] - ad["log_z_exact"]) < 0.6
+    for t in kept:
+        assert torch.equal(ad["ancestors"][t], torch.arange(n, dtype=torch.int32))
+    # final weights of a run ending on a kept step accumulate the previous step's: check the last kept step by
+    # rerunning to t and t - 1 (prefix property of the key schedule) and recomputing the increment from the particles
+    t = kept[-1]
+    a = W.LgssmSMC(oracle_ops, 1, 5, n, T, ess_threshold=0.5)
+    b = W.LgssmSMC(oracle_ops, 1, 5, n, T, ess_threshold=0.5)
+    a.y, a.sk, a.rk = a.y[:t + 1], a.sk[:t + 1], a.rk[:t + 1]
+    b.y, b.sk, b.rk = b.y[:t], b.sk[:t], b.rk[:t]
+    ra, rb = a.result(a.run()), b.result(b.run())
+    inc = -0.5 * ((float(a.y[t]) - ra["state"].double()) / 0.5) ** 2 - math.log(0.5) - 0.5 * math.log(2 * math.pi)
+    assert torch.allclose(ra["logw"].double(), rb["logw"].double() + inc, atol=1e-4)
+    # the decision rule on the last step's weights: r = q >> (frac - 16), resample iff R1^2 < thr * N * R2
+    frac = oracle_ops.frac_bits(n)
+    lw = rb["logw"].double().numpy()
+    q = np.rint(np.exp(lw - lw.max()) * 2.0 ** frac).astype(np.uint64)
+    r = q >> np.uint64(frac - 16)
+    want = float(r.sum()) ** 2 < 0.5 * n * float((r.astype(object) ** 2).sum())
+    assert bool(ra["resampled"][t]) == want  # (float64 exp vs the spec's f32 exp: never close to the threshold here)
 
 
 @pytest.mark.parametrize("kind", ["lgssm", "hmm"])
@@ -287,3 +347,50 @@ def test_sharded_generated_filter(oracle_ops, impl):
     from test_gpu_parity_abi import _smc_plans
 
     check_sharded_plan(oracle_ops, impl, 3, _smc_plans)
+
+
+def _worker4(rank, world, port, n_imp_total, n_total, T, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "genjax-chi_amd"))
+    import torch.distributed as dist
+
+    from genjax._amd import dist as gdist, workloads as W
+    from genjax._amd.abi import GjxLib
+    from genjax._amd.ops import Ops
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    ops = Ops(GjxLib(ORACLE_LIB, "cpu"))
+    first, n_imp = gdist.shard_rows(n_imp_total, rank, world)
+    wl = W.Gaussian10(ops, 1, seed=3, n_local=n_imp, first=first, n_total=n_imp_total)
+    log_z, logw, e, q = gdist.importance_log_z(ops, wl)
+    smc = gdist.ShardedLgssmSMC(ops, 1, seed=5, n_total=n_total, T=T, rank=rank, world=world, record_ancestors=True,
+                                poison=True, ess_threshold=0.5).run()
+    torch.save(dict(n_imp=n_imp, log_z=log_z, logw=logw.clone(), e=e, q=q, smc_state=smc["state"].clone(), smc_anc=smc["ancestors"],
+                    smc_q=smc["out_q"], smc_flags=smc["resampled"], smc_log_z=smc["log_z"]), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_uneven_rows(tmp_path, oracle_ops):
+    """Four gloo processes: an ImportanceK population whose 256-particle rows do not divide by 4 (uneven, row-aligned
+    shards with a ragged tail) and an ESS-adaptive LGSSM filter — equal to the single-rank results bit for bit."""
+    from genjax._amd import workloads as W
+
+    world, T = 4, 8
+    n_imp_total = 256 * 37 + 100  # 38 rows -> 9 / 10 / 9 / 10
+    n_total = 1024 * world * 2
+    mp.spawn(_worker4, args=(world, _free_port(), n_imp_total, n_total, T, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    assert len({p["n_imp"] for p in parts}) > 1  # uneven shards
+    ref = W.Gaussian10(oracle_ops, 1, seed=3, n_local=n_imp_total).step()
+    assert torch.equal(torch.cat([p["logw"] for p in parts]), ref["logw"])
+    for p in parts:
+        assert torch.equal(p["e"], ref["row_e"]) and torch.equal(p["q"], ref["row_q"])
+        assert p["log_z"] == oracle_ops.log_z_from_rows(ref["row_e"], ref["row_q"], n_imp_total)
+    ref_smc = W.lgssm_smc(oracle_ops, 1, 5, n_total, T, True, ess_threshold=0.5)
+    assert torch.equal(torch.cat([p["smc_state"] for p in parts]), ref_smc["state"])
+    assert torch.equal(torch.cat([p["smc_anc"] for p in parts], dim=1), ref_smc["ancestors"])
+    for p in parts:
+        assert torch.equal(p["smc_q"], ref_smc["out_q"]) and torch.equal(p["smc_flags"], ref_smc["resampled"])
+        assert p["smc_log_z"] == ref_smc["log_z"]

@@ -387,7 +387,7 @@ def test_smc_lgssm(hip_ops, oracle_ops, impl, n, T):
     same(h2["out_q"], o["out_q"]); same(h2["state"], o["state"])
 
 
-def degenerate_lgssm_run(ops, impl, n, T=8):
+def degenerate_lgssm_run(ops, impl, n, T=8, **kw):
     """A filter whose weights collapse: a sharp observation model and observations that jump by tens of
     standard deviations, so that at some steps a handful of particles (in a few tiles) carry all the mass
     and most tiles have mass 0 — the resampler's empty-tile and many-copies-of-one-source paths."""
@@ -395,7 +395,7 @@ def degenerate_lgssm_run(ops, impl, n, T=8):
 
     y = np.array([0.1, 25.0, -40.0, -39.5, 60.0, 60.2, 0.0, 3.0][:T], dtype=np.float32)
     sk, rk = W.smc_key_schedule(prng.key(11, impl), T)
-    return ops.smc_run_lgssm(impl, n, sk, rk, abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.05), y, True)
+    return ops.smc_run_lgssm(impl, n, sk, rk, abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.05), y, True, **kw)
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -406,6 +406,78 @@ def test_smc_degenerate_weights(hip_ops, oracle_ops, impl, n):
         same(a, b, what)
     anc = o[4]
     assert int(anc[2].unique().numel()) < n // 100  # the collapse really happens: few distinct ancestors
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n", [20000, 300000, 2_200_000])  # 300000: a heavy tile owns > 4096 slots -> helper workgroups;
+def test_smc_collapse_helpers(hip_ops, oracle_ops, impl, n):  # 2.2e6: the same through the precomputed tile prefix
+    """Weight collapse at sizes where ONE source tile owns far more than kCapSlots = 4096 output slots: its own
+    workgroup serves the first 4096, the workgroups of the 1024-slot windows beyond serve the rest from the same
+    CDF — ancestors, particles and weights are the oracle's bits whoever computes them."""
+    T = 6 if n > 1_000_000 else 8
+    h, o = degenerate_lgssm_run(hip_ops, impl, n, T), degenerate_lgssm_run(oracle_ops, impl, n, T)
+    for a, b, what in zip(h, o, ("step max", "step q", "state", "logw", "ancestors")):
+        same(a, b, what)
+    anc = o[4]
+    counts = torch.bincount(anc[2].long() // 1024, minlength=(n + 1023) // 1024)
+    assert int(counts.max()) > 4096  # some tile really is heavy: the helper path ran
+    # a filter batch takes the same path per filter
+    if n == 20000:
+        from genjax._amd import abi, prng
+        y = np.array([0.1, 25.0, -40.0, -39.5, 60.0, 60.2], dtype=np.float32)
+        pairs = [W.smc_key_schedule(prng.key(11 + f, impl), 6) for f in range(5)]
+        sk, rk = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+        mdl = abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.05)
+        hb = hip_ops.smc_run_lgssm(impl, n, sk, rk, mdl, y, True)
+        ob = oracle_ops.smc_run_lgssm(impl, n, sk, rk, mdl, y, True)
+        for a, b, what in zip(hb, ob, ("step max", "step q", "state", "logw", "ancestors")):
+            same(a, b, what + " (batch of 5)")
+
+
+ESS_CASES = [("lgssm", 5000, 30, 0.5, 1), ("lgssm", 1024, 12, 0.9, 1), ("lgssm", 70000, 25, 0.3, 1), ("lgssm", 3000, 20, 0.5, 5),
+             ("hmm", 6000, 30, 0.5, 1), ("hmm", 2048, 16, 0.25, 3), ("lgssm", 2_200_000, 5, 0.5, 1), ("lgssm", 4096, 10, 1e-6, 1)]
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("kind,n,T,thr,F", ESS_CASES)
+def test_smc_ess_adaptive(hip_ops, oracle_ops, impl, kind, n, T, thr, F):
+    """gjx_smc_config.ess_threshold: resample only when ESS < thr * N.  The decision is a function of exact integer
+    sums, so HIP and oracle take the same one at every step: flags, ancestors (identity on kept steps), accumulated
+    log-weights, per-step (max, q) and log Z are equal bit for bit — single filters, filter batches, > 2048 tiles."""
+    mk = (lambda ops: W.LgssmSMC(ops, impl, 5, n, T, want_ancestors=True, filters=F, ess_threshold=thr)) if kind == "lgssm" else (
+        lambda ops: W.HmmSMC(ops, impl, 5, n, T, n_states=16, want_ancestors=True, filters=F, ess_threshold=thr))
+    hw, ow = mk(hip_ops), mk(oracle_ops)
+    h, o = hw.result(hw.run()), ow.result(ow.run())
+    for key in ("resampled", "out_max", "out_q", "state", "logw", "ancestors"):
+        same(h[key], o[key], key)
+    assert h["log_z"] == o["log_z"]
+    fl = o["resampled"] if F == 1 else o["resampled"][0]
+    anc = o["ancestors"] if F == 1 else o["ancestors"][:, 0]
+    assert int(fl[0]) == 0
+    kept = [t for t in range(1, T) if int(fl[t]) == 0]
+    if thr < 1e-3:
+        assert len(kept) == T - 1  # never resamples
+    elif thr < 0.9:
+        assert 0 < len(kept) < T - 1  # a genuinely adaptive schedule
+    for t in kept[:3]:
+        assert torch.equal(anc[t], torch.arange(n, dtype=torch.int32))
+    if kind == "lgssm" and F == 1 and 0.2 < thr < 0.9 and n >= 5000:
+        assert abs(o["log_z"] - o["log_z_exact"]) < 0.8  # still an estimate of the evidence
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n,F,ess", [(5000, 1, 0.0), (5000, 3, 0.0), (1500, 16, 0.0), (2_200_000, 1, 0.0), (9000, 2, 0.5)])
+def test_tile_sums_forms_agree(hip_ops, oracle_ops, impl, n, F, ess):
+    """The two forms of the tile-mass kernel (gjx_smc_config.tile_sums_form: 1 = a workgroup per tile, 2 = a wave per
+    tile) — ragged last tile, filter batches, more than 2048 tiles, adaptive filters — give the oracle's bits."""
+    T = 4 if n > 1_000_000 else 7
+    ow = W.LgssmSMC(oracle_ops, impl, 3, n, T, want_ancestors=True, filters=F, ess_threshold=ess)
+    o = ow.result(ow.run())
+    for form in (1, 2):
+        hw = W.LgssmSMC(hip_ops, impl, 3, n, T, want_ancestors=True, filters=F, ess_threshold=ess, tile_sums_form=form)
+        h = hw.result(hw.run())
+        for key in ("out_max", "out_q", "state", "logw", "ancestors"):
+            same(h[key], o[key], f"{key} (form {form})")
 
 
 @pytest.mark.parametrize("impl", IMPLS)
