@@ -351,9 +351,10 @@ def bench_smc_sharded(args, ops, rank, world, kind):
     return res
 
 
-def bench_smc(args, ops, kind, filters=1, min_s=0.08, variant=None):
+def bench_smc(args, ops, kind, filters=1, min_s=0.08, variant=None, T=None):
     """Single device: `filters` independent filters (seeds s, s+1, ...) step in the same launches; filters=1 is
-    the literal BASELINE config.  A "step" of the protocol here is one whole T-step filter run (one enqueue)."""
+    the literal BASELINE config.  A "step" of the protocol here is one whole T-step filter run (one enqueue).
+    `variant`: extra keywords of the workload (ess_threshold, another model / observation sequence)."""
     import torch
 
     from genjax._amd import workloads as W
@@ -361,7 +362,7 @@ def bench_smc(args, ops, kind, filters=1, min_s=0.08, variant=None):
 
     impl = 1 if args.rng == "philox" else 0
     n = args.particles
-    T = 100 if kind == "smc_lgssm" else 500
+    T = T if T else (100 if kind == "smc_lgssm" else 500)
     kw = dict(filters=filters)
     if variant:
         kw.update(variant)
@@ -413,6 +414,10 @@ def bench_smc(args, ops, kind, filters=1, min_s=0.08, variant=None):
                                  "per-launch latency floor, not HBM") if filters == 1 else "VALU issue"},
         "log_z": log_z, "log_z_exact": r["log_z_exact"], "log_z_abs_err_vs_exact": abs(log_z - r["log_z_exact"]),
     }
+    if r.get("resampled") is not None:
+        fl = r["resampled"] if filters == 1 else r["resampled"][0]
+        res["resampling_steps"] = int(fl.sum())
+        res["steps"] = T
     res.update(block_stats(blocks))
     return res, r
 
@@ -629,11 +634,34 @@ def run_rank(args):
                 e = entry(r1)
                 if not args.no_cpu_baseline:
                     e["cpu_baseline"] = cpu_baseline_smc(args, kind, g1)
+                # ESS-adaptive variant: resample only when ESS < N / 2
+                ra, _ = bench_smc(args, ops, kind, filters=1, min_s=0.05, variant=dict(ess_threshold=0.5))
+                e["ess_adaptive_0.5"] = entry(ra, ("value", "unit", "ms_per_step", "log_z", "log_z_exact", "resampling_steps", "steps"))
+                e["ess_adaptive_0.5"]["step_ms"] = ra["roofline"]["step_ms"]
                 r16, _ = bench_smc(args, ops, kind, filters=16, min_s=0.05)
                 e["batched_16_filters_per_launch"] = entry(r16, ("value", "unit", "ms_per_step", "roofline", "log_z"))
                 e["batched_16_filters_per_launch"]["note"] = ("16 independent filters x 1e6 particles step in the same launches: "
                                                               "NOT a BASELINE config; throughput of the kernels once the machine is full")
                 extra[kind] = e
+            # worst case of the resampler: collapsing weights (a sharp observation model, observations jumping by tens of
+            # standard deviations: at most steps ONE tile owns every output slot), against the normal LGSSM step
+            try:
+                import numpy as np
+
+                from genjax._amd import abi as _abi
+
+                yc = np.tile(np.array([0.1, 25.0, -40.0, -39.5, 60.0, 60.2, 0.0, 3.0], dtype=np.float32), 5)
+                rc_, gc_ = bench_smc(args, ops, "smc_lgssm", filters=1, min_s=0.03, T=len(yc),
+                                     variant=dict(y=yc, model=_abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.05), want_ancestors=True))
+                anc = gc_["ancestors"]
+                extra["smc_lgssm_collapsing_weights"] = {
+                    "step_ms": rc_["roofline"]["step_ms"], "normal_step_ms": extra["smc_lgssm"]["roofline"]["step_ms"],
+                    "ratio_to_normal_step": rc_["roofline"]["step_ms"] / extra["smc_lgssm"]["roofline"]["step_ms"],
+                    "distinct_ancestors_at_step_2": int(anc[2].unique().numel()), "steps": len(yc),
+                    "note": "heavy tiles serve 4096 slots themselves; the 1024-slot windows beyond are served by the window's "
+                            "workgroup from the same CDF (bit-identical ancestors): no workgroup walks the whole population"}
+            except Exception as ex:
+                extra["smc_lgssm_collapsing_weights"] = {"error": f"{type(ex).__name__}: {ex}"}
             # ImportanceK variants: one pass per launch (the literal config), the other generator, fast math
             r, _ = bench_importance(args, ops, rank, world, launch_passes=1, steps=64, warmup=16, ramp=False, min_s=0.03)
             extra["importance_1_pass_per_launch"] = entry(r)

@@ -215,6 +215,15 @@ struct PassBatch {
   uint32_t parent[kMaxPasses][2];  // used when n_pass > 1 (lazy batches of lane-0 parents)
 };
 
+// Launch-uniform parameters of an importance plan (GJX_ARG_PARAM; kernel argument, by value: they live in scalar
+// registers): p[] the caller's values (gjx_plan_set_params), d[2 q], d[2 q + 1] the per-site constants derived from them
+// on the host by the spec functions (normal: 1 / scale, log normaliser; gamma / beta: -, log normaliser).
+constexpr int kMaxParams = 64;
+struct PlanParams {
+  float p[kMaxParams];
+  float d[2 * 64];
+};
+
 // Column pointer table of one importance run (kernel argument, by value).
 struct RunCols {
   const float* in[16];
@@ -808,17 +817,23 @@ struct FilterBatch {
 
 // Collapse-proof resampling.  The kernel is source-tile-centric: a tile serves the output slots its mass owns, in
 // chunks of 1024.  Under weight collapse ONE tile owns (nearly) every slot; left alone its workgroup would walk a
-// thousand chunks while 255 CUs idle.  So a tile serves at most kCapSlots of its slots itself; the slots beyond
-// belong to the workgroup of the 1024-slot WINDOW they fall into (workgroup h = slots [1024 h, 1024 h + 1024)),
-// which rebuilds the heavy tile's CDF and serves just that window.  Which tiles are heavy follows from the exact
-// tile masses alone (every workgroup reduces them anyway), so owners and helpers agree without communicating; the
-// ancestors, particles and weights are the same bits whoever computes them.
-constexpr int kCapSlots = 4 * kTile;
+// thousand chunks while 255 CUs idle — and almost every other tile has no mass at all, so its workgroup has nothing to
+// do.  So: a tile that owns more than kOwnChunks chunks ("heavy") keeps the first kOwnChunks and DELEGATES the
+// following ones, chunk by chunk, to the idle workgroups (tiles of mass exactly 0), in index order: chunk c of the
+// i-th heavy tile goes to idle workgroup number cum_i + (c - kOwnChunks) while idle workgroups last; what is left stays
+// with the owner.  Who is heavy, who is idle and who gets which chunk follows from the exact tile masses (every
+// workgroup reduces them anyway) and the comb offset, so all workgroups agree without communicating, every workgroup
+// still serves ONE (tile, slot range) item with ONE copy of the serving code, and ancestors, particles and weights are
+// the same bits whoever computes them.
+constexpr int kOwnChunks = 4;
+constexpr int kCapSlots = kOwnChunks * kTile;
 constexpr int kMaxHeavy = 256;  // more candidates than this (never seen): owners serve everything, as before
 // Layout of the precomputed tile-mass prefix (k_scan_tiles; large populations and filter batches): [0 .. ntiles] the
-// exclusive prefix (entry ntiles = total), then R1, R2 (ESS sums), the number of heavy candidates and their
-// (tile, prefix) pairs.
-constexpr int kPrefixTail = 3 + 2 * kMaxHeavy;
+// exclusive prefix (entry ntiles = total); then R1, R2 (ESS sums), the number of heavy candidates, their (tile,
+// prefix) pairs, the number of idle tiles; then — only meaningful when there are heavy candidates — every tile's
+// rank among the idle tiles, two u32 per word.
+constexpr int kPrefixTail = 4 + 2 * kMaxHeavy;  // words between the prefix [ntiles + 1] and the idle ranks
+GJX_HD uint64_t prefix_words(uint64_t ntiles) { return ntiles + 1 + kPrefixTail + (ntiles + 1) / 2; }
 
 struct ResampleArgs {
   const float* lw;            // [n] source log-weights
@@ -833,17 +848,23 @@ struct ResampleArgs {
   int rkey_has_fold;
   uint32_t rkey_fold;
   uint64_t* q_total_out = nullptr;  // nullable: block 0 stores the total mass (= sum of tile_sums)
-  const uint64_t* tile_prefix = nullptr;  // nullable: [ntiles + 1 + kPrefixTail] (k_scan_tiles), precomputed for large
+  const uint64_t* tile_prefix = nullptr;  // nullable: [prefix_words(ntiles)] (k_scan_tiles), precomputed for large
                                 // populations and filter batches (otherwise every workgroup scans tile_sums itself)
   FilterBatch fb;               // several filters per launch (n, ntiles, n_out, out_lo/out_hi are then PER FILTER)
   // ESS-adaptive resampling (gjx_smc_config.ess_threshold): ess_thr = threshold * n_total, 0 = resample always.
   double ess_thr = 0.0;
   const uint64_t* tile_ess = nullptr;  // [2 ntiles]: (R1_b, R2_b) of every source tile (needed when ess_thr > 0)
   int32_t* resampled_out = nullptr;    // nullable: block 0 of each filter stores 1 (resampled) / 0 (kept)
-  float* max_accum = nullptr;          // nullable: running max of the NEW log-weights (float atomic max; -inf before)
-  int allow_help = 1;                  // 0: owners serve all their slots (generic entry points with n_out != n)
+  int allow_help = 1;                  // 0: heavy tiles serve all their slots themselves
+  double heavy_frac = 0.0;             // (kCapSlots - 8) / n_out: the share of the total mass above which a tile may be heavy
 };
 
+// The tile mass above which a tile MAY own more than kCapSlots output slots (slots <= mass * n_out / total + 1)
+// with heavy_frac = (kCapSlots - 8) / n_out formed once on the host (ResampleArgs::heavy_frac)
+GJX_HD uint64_t heavy_threshold(uint64_t total, double heavy_frac) {
+  const double t = (double)total * heavy_frac;
+  return t >= 18446744073709549568.0 ? ~(uint64_t)0 : (uint64_t)t;
+}
 // resample iff ESS = R1^2 / R2 < thr (thr in particles); every backend evaluates exactly these double operations
 GJX_HD bool ess_says_resample(uint64_t r1, uint64_t r2, double thr) {
   if (!(thr > 0.0) || r2 == 0) return true;
@@ -853,14 +874,6 @@ GJX_HD bool ess_says_resample(uint64_t r1, uint64_t r2, double thr) {
 }
 // the reduced weight of the ESS sums: the top 16 bits of the fixed-point weight
 GJX_HD uint64_t ess_r(uint64_t q, int frac) { return q >> (frac - 16); }
-// float atomic max through the integer atomics (works from an initial -inf; ignores NaN: callers never pass one)
-GJX_DEV void atomic_max_f32(float* addr, float v) {
-  if (!(v > -__builtin_inff())) return;
-  v = v + 0.0f;  // -0 -> +0
-  if (v >= 0.0f) __hip_atomic_fetch_max(reinterpret_cast<int*>(addr), (int)f2u(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else __hip_atomic_fetch_min(reinterpret_cast<unsigned*>(addr), f2u(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Row-anchored log-sum-exp of a whole pass: e = max e_b; buckets B_d = sum of S_b over
 // the rows with e - e_b == d (d < 64, exact); Q = sum_d B_d >> d; lse = e ln2 + log(Q 2^-30).  The
@@ -1068,21 +1081,155 @@ GJX_DEV auto out_lw(const Out& o, float w, int) -> decltype(o.lw, float()) { ret
 template <class Out>
 GJX_DEV float out_lw(const Out&, float w, long) { return w; }
 
+// What serving a source tile needs besides the tile itself: the launch's arguments, the comb, the workgroup's LDS arrays.
+struct ServeEnv {
+  const ResampleArgs* A;
+  const float* lw_all;  // this filter's source log-weights
+  float m;              // their maximum
+  double scale, u0;     // comb: teeth per unit of mass, offset
+  int32_t* nb;          // LDS [kTile]
+  int32_t* anc_s;       // LDS [kTile]
+  uint64_t* sh_cdf;     // LDS [kBlock / kWave]
+  int* shi;             // LDS [kBlock / kWave]
+  int tid;
+};
+// a source tile's log-weights (four consecutive sources per lane) and the policy's source state, into registers
+template <class Policy>
+GJX_DEV void load_tile_regs(const ServeEnv& E, Policy& P, float (&lw4)[kPer], uint64_t tbase) {
+  const ResampleArgs& A = *E.A;
+  if (kPer == 4 && A.lw_vec && tbase + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
+    const float4 v = reinterpret_cast<const float4*>(E.lw_all + tbase)[E.tid];
+    lw4[0] = v.x; lw4[1] = v.y; lw4[kPer > 2 ? 2 : 0] = v.z; lw4[kPer > 3 ? 3 : 0] = v.w;
+  } else {
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+      const uint64_t i = tbase + kPer * (uint64_t)E.tid + r;
+      lw4[r] = i < A.n ? E.lw_all[i] : -__builtin_inff();
+    }
+  }
+  P.fetch_source(tbase, A.n, E.tid);  // registers now, LDS after the scan
+}
+// Serve the output slots [s_lo, s_hi) that source tile `ts` (exclusive mass prefix ts_pre) owns: rebuild the tile's
+// CDF, turn it into teeth counts, find every slot's ancestor, propagate, store.  Chunks [skip_from, skip_from + skip_n)
+// of the range (counted from its first chunk) are delegated to other workgroups and skipped here.
 template <int IMPL, class Policy>
+GJX_DEV void serve_tile(const ServeEnv& E, Policy& P, float (&lw4)[kPer], uint64_t ts, uint64_t ts_pre, int64_t s_lo,
+                        int64_t s_hi, bool loaded, float& tmax, uint32_t skip_from, uint32_t skip_n) {
+  constexpr int kW = kBlock / kWave;
+  const ResampleArgs& A = *E.A;
+  const int tid = E.tid;
+  const uint64_t tbase = ts * kTile;
+  if (!loaded) load_tile_regs(E, P, lw4, tbase);
+  // tile CDF: each thread owns 4 CONSECUTIVE sources (tbase + 4*tid + r) so the scan is a thread-local prefix plus
+  // one block scan
+  uint64_t q[kPer];
+  uint64_t local = 0;
+#pragma unroll
+  for (int r = 0; r < kPer; ++r) {
+    const uint64_t i = tbase + kPer * (uint64_t)tid + r;
+    q[r] = i < A.n ? fixw(lw4[r], E.m, A.frac) : 0;
+    local += q[r];
+  }
+  const uint64_t incl = wave_scan_incl(local);
+  const int w_ = tid >> 6;
+  if ((tid & 63) == 63) E.sh_cdf[w_] = incl;
+  // run-start marks of the ancestor search below; cleared here so that the barrier that publishes the scan covers it
+#pragma unroll
+  for (int r = 0; r < kPer; ++r) E.anc_s[tid + r * kBlock] = 0;
+  P.stage_source(tid);
+  __syncthreads();
+  uint64_t run = ts_pre + incl - local;
+#pragma unroll
+  for (int i = 0; i < kW; ++i)
+    if (i < w_) run += E.sh_cdf[i];
+  const int64_t n_lo = teeth_below(ts_pre, E.scale, E.u0, (int64_t)A.n_out);
+  int32_t nbr[kPer];  // teeth below this thread's consecutive sources
+#pragma unroll
+  for (int r = 0; r < kPer; ++r) {
+    const uint64_t i = tbase + kPer * (uint64_t)tid + r;
+    run += q[r];
+    // the last real particle (and any padding after it) closes the comb at n_out
+    nbr[r] = (int32_t)((i + 1 >= A.n) ? (int64_t)A.n_out : teeth_below(run, E.scale, E.u0, (int64_t)A.n_out));
+  }
+  // neighbours' counts through LDS: nb_prev (source 4*tid - 1) and the tile's last count
+  E.nb[kPer * tid + kPer - 1] = nbr[kPer - 1];
+  __syncthreads();
+  const int64_t n_hi = E.nb[kTile - 1];
+  const int32_t nb_prev = tid == 0 ? (int32_t)n_lo : E.nb[kPer * tid - 1];
+  const int64_t j0 = n_lo > s_lo ? n_lo : s_lo;
+  const int64_t j1 = n_hi < s_hi ? n_hi : s_hi;
+  // Ancestors of the slots, 1024 at a time, WITHOUT a search per slot: ancestors are monotone, so every source that
+  // owns at least one slot marks the slot where its run starts (the chunk start for a run that began earlier) and an
+  // inclusive max-scan over the chunk spreads each mark over the run.  Chunks start at a multiple of 4 slots and each
+  // lane serves FOUR CONSECUTIVE slots: four independent propagate chains in flight, one shared cipher block for their
+  // draws (smc_quad_bits), 16-byte stores.  Waves whose 256 slots lie outside the range skip the chunk.
+  const int64_t jb0 = j0 & ~(int64_t)3;
+  for (int64_t jb = jb0; jb < j1; jb += (int64_t)kTile) {
+    if (skip_n) {  // (workgroup-uniform) a delegated chunk: its marks were never set, nothing to clear
+      const uint32_t ci = (uint32_t)((jb - jb0) / (int64_t)kTile);
+      if (ci >= skip_from && ci - skip_from < skip_n) continue;
+    }
+    if (jb != jb0) __syncthreads();  // the marks were cleared after the previous chunk's scan
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+      const int64_t start = r == 0 ? nb_prev : nbr[r - 1];  // source 4*tid+r owns slots [start, nbr[r])
+      if ((int64_t)nbr[r] > start && (int64_t)nbr[r] > jb && start < jb + (int64_t)kTile)
+        E.anc_s[(start > jb ? start : jb) - jb] = kPer * tid + r + 1;
+    }
+    __syncthreads();
+    int v[kPer];
+    int run_max = 0;
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+      const int x = E.anc_s[kPer * tid + r];
+      run_max = x > run_max ? x : run_max;
+      v[r] = run_max;
+    }
+    const int carry = block_scan_max_excl(run_max, E.shi);  // (its barriers close this chunk's reads of the marks)
+    if (jb + (int64_t)kTile < j1) {  // another chunk follows: clear the marks for it
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) E.anc_s[tid + r * kBlock] = 0;
+    }
+    // every entry of the chunk is a valid local source index (slots outside [j0, j1) included — those before the
+    // range's first slot have no mark and take source 0: they are computed along with their quad, never stored)
+    int src[kPer];
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+      const int a = v[r] > carry ? v[r] : carry;
+      src[r] = a ? a - 1 : 0;
+    }
+    const int64_t jq = jb + (int64_t)kPer * tid;
+    const int64_t wave_lo = jb + (int64_t)kPer * (tid & ~(kWave - 1));
+    if (wave_lo < j1 && wave_lo + (int64_t)kPer * kWave > j0) {  // wave-uniform
+      bool ok[kPer];
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) ok[r] = jq + r >= j0 && jq + r < j1;
+      typename Policy::Out out[kPer];
+      float w[kPer];
+      policy_compute_quad(P, jq, src, out, w, 0);
+      policy_store_quad(P, jq, A.out_lo, tbase, src, out, ok, 0);
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) tmax = ok[r] && w[r] > tmax ? w[r] : tmax;
+    }
+  }
+}
+
+// ADAPTIVE: the launch may be a step of an ESS-adaptive filter (A.ess_thr > 0): only then does the kernel carry the
+// decision and the keep-your-particle path (the fixed models' every-step filters are compiled without them).
+template <int IMPL, class Policy, bool ADAPTIVE = true>
 GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials) {
   constexpr int kW = kBlock / kWave;
   __shared__ uint64_t sh_scan[kW];      // tile-mass scan
   __shared__ uint64_t sh_ess[2 * kW];   // ESS sums
-  __shared__ uint64_t sh_cdf[kW];       // CDF scan of a served tile
+  __shared__ uint64_t sh_cdf[kW];       // CDF scan of the served tile
   __shared__ uint64_t sh_pre;           // exclusive prefix of this workgroup's own tile
   __shared__ float shf[kW];
   __shared__ int shi[kW];
-  __shared__ int32_t nb[kTile];     // teeth below the inclusive CDF of each source in the served tile
+  __shared__ int32_t nb[kTile];     // teeth below the inclusive CDF of the sources (their last-of-four counts)
   __shared__ int32_t anc_s[kTile];  // run-start marks of the ancestor search
-  __shared__ uint32_t heavy_n, hit_n;
+  __shared__ uint32_t heavy_n;
   __shared__ uint32_t heavy_tile[kMaxHeavy];
-  __shared__ uint64_t heavy_pre[kMaxHeavy];
-  __shared__ uint16_t hit[kMaxHeavy];
+  __shared__ uint32_t sh_u32[kW + 4];   // rare path: idle-count scan, own idle rank, item selection
   uint64_t b = blockIdx.x;
   const int tid = threadIdx.x;
   // this workgroup's filter: local views of the per-filter arrays, keys and results
@@ -1092,67 +1239,55 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   const float* m_ptr = A.m_ptr;
   uint64_t* q_total_out = A.q_total_out;
   int32_t* resampled_out = A.resampled_out;
-  float* max_accum = A.max_accum;
   Key rkey = A.rkey;
   const uint64_t* tile_prefix = A.tile_prefix;
   if (A.fb.n_filters > 1) {
     const uint32_t f = (uint32_t)(b / A.fb.tiles);
     b -= (uint64_t)f * A.fb.tiles;
-    if (tile_prefix) tile_prefix += (uint64_t)f * (A.fb.tiles + 1 + kPrefixTail);
+    if (tile_prefix) tile_prefix += (uint64_t)f * prefix_words(A.fb.tiles);
     lw_all += (uint64_t)f * A.fb.stride;
     tile_sums += (uint64_t)f * A.fb.tiles;
     if (tile_ess) tile_ess += 2 * (uint64_t)f * A.fb.tiles;
     m_ptr += (uint64_t)f * A.fb.mq_stride;
     if (q_total_out) q_total_out += (uint64_t)f * A.fb.mq_stride;
     if (resampled_out) resampled_out += (uint64_t)f * A.fb.mq_stride;
-    if (max_accum) max_accum += (uint64_t)f * A.fb.mq_stride;
     if (max_partials) max_partials += (uint64_t)f * A.fb.tiles;
     rkey = A.fb.rkey[f];
     P.select_filter((uint64_t)f * A.fb.stride, A.fb.step_key[f]);
   }
   const uint64_t base = b * kTile;
-  const bool adaptive = A.ess_thr > 0.0;
+  const bool adaptive = ADAPTIVE && A.ess_thr > 0.0;
 
   // Issue the own tile's loads first: their HBM latency overlaps the tile-mass scan.  A rank that owns only a shard
   // of the output slots decides from the tile masses alone whether a source tile feeds any of its slots, and touches
   // the tile's particles only then (remote tiles it does not need were never exchanged).
   const bool part = A.out_lo > 0 || A.out_hi < (int64_t)A.n_out;
   float lw4[kPer];
-  auto load_tile = [&](uint64_t tbase) {
-    if (kPer == 4 && A.lw_vec && tbase + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
-      const float4 v = reinterpret_cast<const float4*>(lw_all + tbase)[tid];
-      lw4[0] = v.x; lw4[1] = v.y; lw4[kPer > 2 ? 2 : 0] = v.z; lw4[kPer > 3 ? 3 : 0] = v.w;
-    } else {
-#pragma unroll
-      for (int r = 0; r < kPer; ++r) {
-        const uint64_t i = tbase + kPer * (uint64_t)tid + r;
-        lw4[r] = i < A.n ? lw_all[i] : -__builtin_inff();
-      }
-    }
-    P.fetch_source(tbase, A.n, tid);  // registers now, LDS after the scan
-  };
+  ServeEnv E;
+  E.A = &A; E.lw_all = lw_all; E.nb = nb; E.anc_s = anc_s; E.sh_cdf = sh_cdf; E.shi = shi; E.tid = tid;
+  E.m = 0.0f; E.scale = 0.0; E.u0 = 0.0;
   bool own_loaded = false;
-  if (!part) { load_tile(base); own_loaded = true; }
+  if (!part) { load_tile_regs(E, P, lw4, base); own_loaded = true; }
 
   // ---- tile masses: exclusive prefix of the own tile, total, ESS sums, heavy candidates ------------------------
-  if (tid == 0) { heavy_n = 0; hit_n = 0; }
-  uint64_t pre = 0, tot = 0, r1 = 0, r2 = 0;
+  if (tid == 0) heavy_n = 0;
+  uint64_t pre = 0, tot = 0, r1 = 0, r2 = 0, own_mass = 0;
   uint32_t n_heavy = 0;
-  const double n_out_d = (double)A.n_out;
+  // thread t owns the c consecutive tiles [t c, t c + c): a thread-local prefix plus ONE block scan gives every thread
+  // the exclusive prefix of each of its tiles (own prefix, heavy candidates) and the total.  Up to kC tiles per thread
+  // stay in registers; beyond that (generic entry points on very large inputs) they are re-read.
+  constexpr int kC = 4;  // 1e6 particles: 977 tiles, 4 per thread
+  const uint64_t c = (A.ntiles + kBlock - 1) / kBlock;
+  const uint64_t k0 = (uint64_t)tid * c;
+  uint64_t v[kC];
+  uint64_t chunk_pre = 0;  // exclusive prefix of this thread's first tile (no tile_prefix)
   if (tile_prefix) {
     pre = tile_prefix[b];
+    own_mass = tile_prefix[b + 1] - pre;
     tot = tile_prefix[A.ntiles];
     if (adaptive) { r1 = tile_prefix[A.ntiles + 1]; r2 = tile_prefix[A.ntiles + 2]; }
     n_heavy = (uint32_t)tile_prefix[A.ntiles + 3];
-    __syncthreads();
   } else {
-    // thread t owns the c consecutive tiles [t c, t c + c): a thread-local prefix plus ONE block scan gives every
-    // thread the exclusive prefix of each of its tiles (own prefix, heavy candidates) and the total.  Up to kC tiles
-    // per thread stay in registers; beyond that (generic entry points on very large inputs) they are re-read.
-    constexpr int kC = 8;
-    const uint64_t c = (A.ntiles + kBlock - 1) / kBlock;
-    const uint64_t k0 = (uint64_t)tid * c;
-    uint64_t v[kC];
     uint64_t local = 0, l1 = 0, l2 = 0;
     if (c <= (uint64_t)kC) {
 #pragma unroll
@@ -1184,23 +1319,30 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
       tot += sh_scan[i];
       if (adaptive) { r1 += sh_ess[i]; r2 += sh_ess[kW + i]; }
     }
-    uint64_t run = wbase + incl - local;  // exclusive prefix of this thread's first tile
-    const double hscale = n_out_d / (double)tot;
-    auto visit = [&](uint64_t k, uint64_t mass) {
-      if (k == b) sh_pre = run;
-      // may own more than the cap (or, with no mass at all, the last tile: it closes the comb): a candidate
-      if (A.allow_help && ((double)mass * hscale > (double)(kCapSlots - 8) || (tot == 0 && k + 1 == A.ntiles))) {
-        const uint32_t e = atomicAdd(&heavy_n, 1u);
-        if (e < (uint32_t)kMaxHeavy) { heavy_tile[e] = (uint32_t)k; heavy_pre[e] = run; }
-      }
-      run += mass;
-    };
-    if (c <= (uint64_t)kC) {
+    chunk_pre = wbase + incl - local;
+    // a tile may own more than kCapSlots slots only if its mass exceeds (kCapSlots - 8) / n_out of the total: ONE
+    // threshold (every workgroup derives the same one from the same total), tested first on the thread's whole chunk
+    const uint64_t heavy_mass = heavy_threshold(tot, A.heavy_frac);
+    const bool owns_b = k0 <= b && b < k0 + c;  // (no division: b / c on 64-bit scalars is a long sequence)
+    const bool maybe_heavy = A.allow_help && (local > heavy_mass || (tot == 0 && k0 + c >= A.ntiles));
+    if (owns_b || maybe_heavy) {  // (one thread per workgroup in the common case)
+      uint64_t run = chunk_pre;
+      auto visit = [&](uint64_t k, uint64_t mass) {
+        if (k == b) sh_pre = run;
+        // (with no mass at all the last tile closes the comb and owns every slot: a candidate too)
+        if (A.allow_help && (mass > heavy_mass || (tot == 0 && k + 1 == A.ntiles))) {
+          const uint32_t e = atomicAdd(&heavy_n, 1u);
+          if (e < (uint32_t)kMaxHeavy) heavy_tile[e] = (uint32_t)k;
+        }
+        run += mass;
+      };
+      if (c <= (uint64_t)kC) {
 #pragma unroll
-      for (int i = 0; i < kC; ++i)
-        if ((uint64_t)i < c && k0 + i < A.ntiles) visit(k0 + i, v[i]);
-    } else {
-      for (uint64_t i = 0; i < c && k0 + i < A.ntiles; ++i) visit(k0 + i, tile_sums[k0 + i]);
+        for (int i = 0; i < kC; ++i)
+          if ((uint64_t)i < c && k0 + i < A.ntiles) visit(k0 + i, v[i]);
+      } else {
+        for (uint64_t i = 0; i < c && k0 + i < A.ntiles; ++i) visit(k0 + i, tile_sums[k0 + i]);
+      }
     }
     __syncthreads();
     pre = sh_pre;
@@ -1214,11 +1356,11 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   float tmax = -__builtin_inff();
   static_assert(kPer == 4, "four consecutive sources and four consecutive output slots per lane");
 
-  if (!resample) {
+  if (ADAPTIVE && !resample) {
     // ---- no resampling at this step: slot j keeps particle j, its log-weight accumulates --------------------
     const int64_t jq = (int64_t)base + (int64_t)kPer * tid;
     if ((int64_t)base < A.out_hi && (int64_t)(base + kTile) > A.out_lo && base < A.n) {  // workgroup-uniform
-      if (!own_loaded) load_tile(base);
+      if (!own_loaded) load_tile_regs(E, P, lw4, base);
       P.stage_source(tid);
       __syncthreads();
       const int64_t hi = A.out_hi < (int64_t)A.n ? A.out_hi : (int64_t)A.n;
@@ -1244,151 +1386,147 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   } else {
     const Stream<IMPL> rs(rkey, A.rkey_has_fold != 0, A.rkey_fold);
     const double u0 = u0_from_bits(rs.bits64(0));
-    const double scale = n_out_d / (double)tot;
-    const float m = m_ptr[0];
-    int served = 0;
-    // Serve the output slots [s_lo, s_hi) that source tile `ts` (exclusive mass prefix ts_pre) owns: rebuild the
-    // tile's CDF, turn it into teeth counts, find every slot's ancestor, propagate, store.
-    auto serve = [&](uint64_t ts, uint64_t ts_pre, int64_t s_lo, int64_t s_hi, bool loaded) {
-      const uint64_t tbase = ts * kTile;
-      if (served++) __syncthreads();  // the previous tile's LDS arrays are free again
-      if (!loaded) load_tile(tbase);
-      // tile CDF: each thread owns 4 CONSECUTIVE sources (tbase + 4*tid + r) so the scan is a thread-local prefix
-      // plus one block scan
-      uint64_t q[kPer];
-      uint64_t local = 0;
-#pragma unroll
-      for (int r = 0; r < kPer; ++r) {
-        const uint64_t i = tbase + kPer * (uint64_t)tid + r;
-        q[r] = i < A.n ? fixw(lw4[r], m, A.frac) : 0;
-        local += q[r];
-      }
-      const uint64_t incl = wave_scan_incl(local);
-      const int w_ = tid >> 6;
-      if ((tid & 63) == 63) sh_cdf[w_] = incl;
-      // run-start marks of the ancestor search below; cleared here so that the barrier that publishes nb covers it
-#pragma unroll
-      for (int r = 0; r < kPer; ++r) anc_s[tid + r * kBlock] = 0;
-      P.stage_source(tid);
-      __syncthreads();
-      uint64_t run = ts_pre + incl - local;
-#pragma unroll
-      for (int i = 0; i < kW; ++i)
-        if (i < w_) run += sh_cdf[i];
-      const int64_t n_lo = teeth_below(ts_pre, scale, u0, (int64_t)A.n_out);
-      int32_t nbr[kPer];  // teeth below this thread's consecutive sources
-#pragma unroll
-      for (int r = 0; r < kPer; ++r) {
-        const uint64_t i = tbase + kPer * (uint64_t)tid + r;
-        run += q[r];
-        // the last real particle (and any padding after it) closes the comb at n_out
-        nbr[r] = (int32_t)((i + 1 >= A.n) ? (int64_t)A.n_out : teeth_below(run, scale, u0, (int64_t)A.n_out));
-      }
-      // neighbours' counts through LDS: nb_prev (source 4*tid - 1) and the tile's last count
-      nb[kPer * tid + kPer - 1] = nbr[kPer - 1];
-      __syncthreads();
-      const int64_t n_hi = nb[kTile - 1];
-      const int32_t nb_prev = tid == 0 ? (int32_t)n_lo : nb[kPer * tid - 1];
-      const int64_t j0 = n_lo > s_lo ? n_lo : s_lo;
-      const int64_t j1 = n_hi < s_hi ? n_hi : s_hi;
-      // Ancestors of the slots, 1024 at a time, WITHOUT a search per slot: ancestors are monotone, so every source
-      // that owns at least one slot marks the slot where its run starts (the chunk start for a run that began
-      // earlier) and an inclusive max-scan over the chunk spreads each mark over the run.  Chunks start at a multiple
-      // of 4 slots and each lane serves FOUR CONSECUTIVE slots: four independent propagate chains in flight, one
-      // shared cipher block for their draws (smc_quad_bits), 16-byte stores.  Waves whose 256 slots lie outside the
-      // range skip the chunk.
-      const int64_t jb0 = j0 & ~(int64_t)3;
-      for (int64_t jb = jb0; jb < j1; jb += (int64_t)kTile) {
-        if (jb != jb0) __syncthreads();  // the marks were cleared after the previous chunk's scan
-#pragma unroll
-        for (int r = 0; r < kPer; ++r) {
-          const int64_t start = r == 0 ? nb_prev : nbr[r - 1];  // source 4*tid+r owns slots [start, nbr[r])
-          if ((int64_t)nbr[r] > start && (int64_t)nbr[r] > jb && start < jb + (int64_t)kTile)
-            anc_s[(start > jb ? start : jb) - jb] = kPer * tid + r + 1;
-        }
-        __syncthreads();
-        int v[kPer];
-        int run_max = 0;
-#pragma unroll
-        for (int r = 0; r < kPer; ++r) {
-          const int x = anc_s[kPer * tid + r];
-          run_max = x > run_max ? x : run_max;
-          v[r] = run_max;
-        }
-        const int carry = block_scan_max_excl(run_max, shi);  // (its barriers close this chunk's reads of the marks)
-        if (jb + (int64_t)kTile < j1) {  // another chunk follows: clear the marks for it
-#pragma unroll
-          for (int r = 0; r < kPer; ++r) anc_s[tid + r * kBlock] = 0;
-        }
-        // every entry of the chunk is a valid local source index (slots outside [j0, j1) included — those before the
-        // range's first slot have no mark and take source 0: they are computed along with their quad, never stored)
-        int src[kPer];
-#pragma unroll
-        for (int r = 0; r < kPer; ++r) {
-          const int a = v[r] > carry ? v[r] : carry;
-          src[r] = a ? a - 1 : 0;
-        }
-        const int64_t jq = jb + (int64_t)kPer * tid;
-        const int64_t wave_lo = jb + (int64_t)kPer * (tid & ~(kWave - 1));
-        if (wave_lo < j1 && wave_lo + (int64_t)kPer * kWave > j0) {  // wave-uniform
-          bool ok[kPer];
-#pragma unroll
-          for (int r = 0; r < kPer; ++r) ok[r] = jq + r >= j0 && jq + r < j1;
-          typename Policy::Out out[kPer];
-          float w[kPer];
-          policy_compute_quad(P, jq, src, out, w, 0);
-          policy_store_quad(P, jq, A.out_lo, tbase, src, out, ok, 0);
-#pragma unroll
-          for (int r = 0; r < kPer; ++r) tmax = ok[r] && w[r] > tmax ? w[r] : tmax;
-        }
-      }
-    };
-    // where the slots a tile serves itself end (the same rule for its own workgroup and for the helpers)
-    auto cap_of = [&](int64_t t_lo) {
-      const int64_t first = (t_lo > A.out_lo ? t_lo : A.out_lo) & ~(int64_t)3;
-      return first + (int64_t)kCapSlots;
-    };
-    // ---- the own tile ----------------------------------------------------------------------------------------
-    {
-      const uint64_t own_mass = tile_prefix ? tile_prefix[b + 1] - pre : tile_sums[b];
+    const double scale = (double)A.n_out / (double)tot;
+    E.m = m_ptr[0];
+    E.scale = scale;
+    E.u0 = u0;
+    // the ONE item this workgroup serves: by default its own tile, all of its slots
+    uint64_t it_tile = b, it_pre = pre;
+    int64_t it_lo = A.out_lo, it_hi = A.out_hi;
+    uint32_t skip_from = 0, skip_n = 0;
+    bool go = true, it_loaded = own_loaded;
+    if (part && !helping) {  // does the own tile serve anything here?
+      if (!tile_prefix) own_mass = tile_sums[b];
       const int64_t t_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
       const int64_t t_hi = b + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(pre + own_mass, scale, u0, (int64_t)A.n_out);
-      if (!(t_hi <= A.out_lo || t_lo >= A.out_hi)) {  // workgroup-uniform
-        const int64_t s_hi = helping ? (cap_of(t_lo) < A.out_hi ? cap_of(t_lo) : A.out_hi) : A.out_hi;
-        serve(b, pre, A.out_lo, s_hi, own_loaded);
-      }
+      go = !(t_hi <= A.out_lo || t_lo >= A.out_hi);  // workgroup-uniform
     }
-    // ---- helper duty: slots of this workgroup's window that lie beyond a heavy tile's cap ----------------------
     if (helping) {
-      const int64_t w_lo = (int64_t)base, w_hi = (int64_t)(base + kTile);
-      for (uint32_t e0 = 0; e0 < n_heavy; e0 += kBlock) {
-        const uint32_t e = e0 + (uint32_t)tid;
-        if (e < n_heavy) {
-          uint64_t ts, tp;
-          if (tile_prefix) { ts = tile_prefix[A.ntiles + 4 + 2 * e]; tp = tile_prefix[A.ntiles + 5 + 2 * e]; }
-          else { ts = heavy_tile[e]; tp = heavy_pre[e]; }
-          const uint64_t mass = tile_prefix ? tile_prefix[ts + 1] - tp : tile_sums[ts];
-          const int64_t t_lo = teeth_below(tp, scale, u0, (int64_t)A.n_out);
-          const int64_t t_hi = ts + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(tp + mass, scale, u0, (int64_t)A.n_out);
-          int64_t lo = cap_of(t_lo), hi = t_hi < A.out_hi ? t_hi : A.out_hi;
-          lo = lo > w_lo ? lo : w_lo;
-          hi = hi < w_hi ? hi : w_hi;
-          if (lo < hi) hit[atomicAdd(&hit_n, 1u)] = (uint16_t)e;
+      // ---- rare: some tile is heavy.  Everything below is workgroup-uniform bookkeeping in LDS scratch (the nb / anc_s
+      // arrays are free until a tile is served): order the heavy tiles, count their delegable chunks, rank the idle
+      // tiles, pick this workgroup's item. -----------------------------------------------------------------------
+      int64_t* hv_first = reinterpret_cast<int64_t*>(nb);            // [kMaxHeavy] first slot of the tile's chunk grid
+      int64_t* hv_hi = hv_first + kMaxHeavy;                          // [kMaxHeavy] end of its slots here
+      uint64_t* hv_pre = reinterpret_cast<uint64_t*>(anc_s);          // [kMaxHeavy] exclusive mass prefix
+      uint32_t* hv_tile = reinterpret_cast<uint32_t*>(hv_pre + kMaxHeavy);  // [kMaxHeavy] ordered by tile index
+      uint32_t* hv_win = hv_tile + kMaxHeavy;                         // [kMaxHeavy] delegable chunks
+      uint32_t* hv_cum = heavy_tile;                                  // [kMaxHeavy] ... before this tile (written once the
+                                                                      // unordered list has been consumed, behind a barrier)
+      static_assert(2 * kMaxHeavy * 8 <= kTile * 4 && kMaxHeavy * (8 + 8) <= kTile * 4, "rare-path scratch fits nb / anc_s");
+      uint32_t idle_rank = ~0u, n_idle = 0;
+      if (tile_prefix) {
+        n_idle = (uint32_t)tile_prefix[A.ntiles + 4 + 2 * kMaxHeavy];
+        if (own_mass == 0 && b + 1 < A.ntiles) {
+          const uint64_t wd = tile_prefix[A.ntiles + 1 + kPrefixTail + (b >> 1)];
+          idle_rank = (uint32_t)(wd >> (32 * (b & 1)));
+        }
+      } else {
+        // idle tiles (mass 0, not the last one: it closes the comb) before this thread's chunk: a second block scan
+        uint32_t cnt = 0;
+        auto is_idle = [&](uint64_t k, uint64_t mass) { return mass == 0 && k + 1 < A.ntiles; };
+        if (c <= (uint64_t)kC) {
+#pragma unroll
+          for (int i = 0; i < kC; ++i)
+            if ((uint64_t)i < c && k0 + i < A.ntiles && is_idle(k0 + i, v[i])) ++cnt;
+        } else {
+          for (uint64_t i = 0; i < c && k0 + i < A.ntiles; ++i)
+            if (is_idle(k0 + i, tile_sums[k0 + i])) ++cnt;
+        }
+        const uint32_t incl = wave_scan_u32(cnt, 0u, [](uint32_t a, uint32_t x) { return a + x; });
+        const int w = tid >> 6;
+        if ((tid & 63) == 63) sh_u32[w] = incl;
+        if (tid == 0) sh_u32[kW] = ~0u;
+        __syncthreads();
+        uint32_t before = incl - cnt;
+#pragma unroll
+        for (int i = 0; i < kW; ++i) {
+          if (i < w) before += sh_u32[i];
+          n_idle += sh_u32[i];
+        }
+        if (k0 <= b && b < k0 + c) {  // the thread whose chunk holds the own tile: rank = idle tiles before it
+          uint32_t r = before;
+          uint64_t bm = 0;
+          for (uint64_t k = k0; k <= b; ++k) {
+            const uint64_t mass = tile_sums[k];
+            if (k == b) bm = mass;
+            else if (is_idle(k, mass)) ++r;
+          }
+          sh_u32[kW] = is_idle(b, bm) ? r : ~0u;
+          sh_scan[0] = bm;
+        }
+        __syncthreads();
+        idle_rank = sh_u32[kW];
+        own_mass = sh_scan[0];
+      }
+      // heavy entries in tile order, with their chunk grids
+      if ((uint32_t)tid < n_heavy) {
+        uint64_t ts, tp;
+        if (tile_prefix) { ts = tile_prefix[A.ntiles + 4 + 2 * tid]; tp = tile_prefix[A.ntiles + 5 + 2 * tid]; }
+        else { ts = heavy_tile[tid]; tp = 0; }
+        uint32_t pos = 0;
+        for (uint32_t e = 0; e < n_heavy; ++e) {
+          const uint64_t te = tile_prefix ? tile_prefix[A.ntiles + 4 + 2 * e] : (uint64_t)heavy_tile[e];
+          pos += te < ts ? 1u : 0u;
+        }
+        if (!tile_prefix) {  // the tile's exclusive prefix: masses before it (rare path: a plain loop)
+          for (uint64_t k = 0; k < ts; ++k) tp += tile_sums[k];
+        }
+        const uint64_t mass = tile_prefix ? tile_prefix[ts + 1] - tp : tile_sums[ts];
+        const int64_t t_lo = teeth_below(tp, scale, u0, (int64_t)A.n_out);
+        const int64_t t_hi = ts + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(tp + mass, scale, u0, (int64_t)A.n_out);
+        const int64_t lo = t_lo > A.out_lo ? t_lo : A.out_lo, hi = t_hi < A.out_hi ? t_hi : A.out_hi;
+        const int64_t first = lo & ~(int64_t)3;
+        const int64_t nchunk = hi > first ? (hi - first + (int64_t)kTile - 1) / (int64_t)kTile : 0;
+        hv_tile[pos] = (uint32_t)ts;
+        hv_pre[pos] = tp;
+        hv_first[pos] = first;
+        hv_hi[pos] = hi;
+        hv_win[pos] = nchunk > kOwnChunks ? (uint32_t)(nchunk - kOwnChunks) : 0u;
+      }
+      __syncthreads();
+      if ((uint32_t)tid < n_heavy) {
+        uint32_t cum = 0;
+        for (uint32_t e = 0; e < (uint32_t)tid; ++e) cum += hv_win[e];
+        hv_cum[tid] = cum;
+      }
+      if (tid == 0) { sh_u32[kW + 1] = ~0u; sh_u32[kW + 2] = 0; }
+      __syncthreads();
+      // this workgroup's item: thread p speaks for heavy entry p
+      if ((uint32_t)tid < n_heavy) {
+        const uint32_t p = (uint32_t)tid, cum = hv_cum[p], win = hv_win[p];
+        if (hv_tile[p] == (uint32_t)b) {  // the own tile is heavy: it keeps its first kOwnChunks and what no idle workgroup takes
+          sh_u32[kW + 1] = p;
+          sh_u32[kW + 2] = n_idle > cum ? (n_idle - cum < win ? n_idle - cum : win) : 0u;  // delegated chunks
+        } else if (idle_rank != ~0u && idle_rank >= cum && idle_rank - cum < win) {
+          sh_u32[kW + 1] = p | 0x80000000u;  // an idle workgroup: chunk kOwnChunks + (rank - cum) of heavy tile p
         }
       }
       __syncthreads();
-      const uint32_t n_hit = hit_n;
-      for (uint32_t k = 0; k < n_hit; ++k) {
-        // hits are served in list order; the order does not matter (disjoint slots), only that all threads agree
-        const uint32_t e = hit[k];
-        uint64_t ts, tp;
-        if (tile_prefix) { ts = tile_prefix[A.ntiles + 4 + 2 * e]; tp = tile_prefix[A.ntiles + 5 + 2 * e]; }
-        else { ts = heavy_tile[e]; tp = heavy_pre[e]; }
-        const int64_t t_lo = teeth_below(tp, scale, u0, (int64_t)A.n_out);
-        const int64_t lo = cap_of(t_lo) > w_lo ? cap_of(t_lo) : w_lo;
-        serve(ts, tp, lo, w_hi < A.out_hi ? w_hi : A.out_hi, false);
+      const uint32_t sel = sh_u32[kW + 1];
+      if (sel == ~0u) {
+        if (part) {  // an ordinary tile of a sharded launch: does it serve anything here?
+          const int64_t t_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
+          const int64_t t_hi = b + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(pre + own_mass, scale, u0, (int64_t)A.n_out);
+          go = !(t_hi <= A.out_lo || t_lo >= A.out_hi);
+        }
+        if (idle_rank != ~0u) go = false;  // an idle tile nobody needs: it owns no slot
+      } else if (sel & 0x80000000u) {
+        const uint32_t p = sel & 0x7fffffffu;
+        const int64_t ci = (int64_t)kOwnChunks + (int64_t)(idle_rank - hv_cum[p]);
+        it_tile = hv_tile[p];
+        it_pre = hv_pre[p];
+        it_lo = hv_first[p] + ci * (int64_t)kTile;
+        it_hi = it_lo + (int64_t)kTile < hv_hi[p] ? it_lo + (int64_t)kTile : hv_hi[p];
+        it_loaded = false;
+        go = it_lo < it_hi;
+      } else {
+        skip_from = (uint32_t)kOwnChunks;
+        skip_n = sh_u32[kW + 2];
+        go = hv_hi[sel] > hv_first[sel];
       }
+      __syncthreads();  // the scratch in nb / anc_s has been read: serving may overwrite it
     }
+    if (go) serve_tile<IMPL>(E, P, lw4, it_tile, it_pre, it_lo, it_hi, it_loaded, tmax, skip_from, skip_n);
   }
   {
     const float wm = wave_max(tmax);
@@ -1399,7 +1537,6 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
 #pragma unroll
       for (int i = 1; i < kW; ++i) bm = shf[i] > bm ? shf[i] : bm;
       if (max_partials) max_partials[b] = bm;
-      if (max_accum) atomic_max_f32(max_accum, bm);
     }
   }
 }

@@ -249,7 +249,8 @@ struct CSite {
   int32_t slot;  // LDS slot this site's value is kept in for later sites, -1 if never referenced
   CArg a0, a1, obs;
   const float* logits;
-  int32_t pre;       // 1: pre0/pre1 hold the hoisted per-site constants
+  int32_t pre;       // 1: pre0/pre1 hold the hoisted per-site constants; 2: they depend on launch parameters
+                     // (GJX_ARG_PARAM) and are re-derived by gjx_plan_set_params into PlanParams::d[2 site], [2 site + 1]
   float pre0, pre1;  // normal: rs, lognorm; gamma: -, lognorm; beta: -, lbeta
 };
 static_assert(GJX_MAX_SITES == 64, "RunCols::out is sized for 64 sites");
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
                                                        int n_sites, KeySrc ks, RunCols cols,
                                                        float* score, float* logw, uint64_t n,
                                                        float* max_partials, int32_t* row_e,
-                                                       uint64_t* row_s) {
+                                                       uint64_t* row_s, PlanParams prm) {
   extern __shared__ uint32_t vals[];  // [n_slots][kPPT][kBlock]
   __shared__ float sh_red[kBlock / kWave];
   __shared__ uint64_t sh_sum[kBlock / kWave];
@@ -305,6 +306,10 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
           }
           case GJX_ARG_INPUT: {
             const float t = a.scale * cols.in[a.ref][idx[r] < n ? idx[r] : n - 1];
+            return t + a.offset;
+          }
+          case GJX_ARG_PARAM: {
+            const float t = a.scale * prm.p[a.ref];
             return t + a.offset;
           }
           default: {
@@ -344,7 +349,8 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
 #pragma unroll
         for (int r = 0; r < kPPT; ++r) {
           const float ov = st.obs.kind == GJX_ARG_CONST ? st.obs.offset
-                                                        : cols.in[st.obs.ref][idx[r] < n ? idx[r] : n - 1];
+                           : st.obs.kind == GJX_ARG_PARAM ? eval(st.obs, r)
+                                                          : cols.in[st.obs.ref][idx[r] < n ? idx[r] : n - 1];
           vf[r] = ov;
           vi[r] = is_int ? (int32_t)__builtin_rintf(ov) : 0;
         }
@@ -390,12 +396,13 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
 #pragma unroll
       for (int r = 0; r < kPPT; ++r) {
         float lp = 0.0f;
+        const float pre0 = st.pre == 2 ? prm.d[2 * q] : st.pre0, pre1 = st.pre == 2 ? prm.d[2 * q + 1] : st.pre1;
         if (dist == GJX_DIST_NORMAL) {
-          lp = st.pre ? logpdf_normal_pre(vf[r], a0[r], st.pre0, st.pre1) : logpdf_normal(vf[r], a0[r], a1[r]);
+          lp = st.pre ? logpdf_normal_pre(vf[r], a0[r], pre0, pre1) : logpdf_normal(vf[r], a0[r], a1[r]);
         } else if ((MASK & (1 << GJX_DIST_GAMMA)) && dist == GJX_DIST_GAMMA) {
-          lp = st.pre ? logpdf_gamma_pre(vf[r], a0[r], a1[r], st.pre1) : logpdf_gamma(vf[r], a0[r], a1[r]);
+          lp = st.pre ? logpdf_gamma_pre(vf[r], a0[r], a1[r], pre1) : logpdf_gamma(vf[r], a0[r], a1[r]);
         } else if ((MASK & (1 << GJX_DIST_BETA)) && dist == GJX_DIST_BETA) {
-          lp = st.pre ? logpdf_beta_pre(vf[r], a0[r], a1[r], st.pre1) : logpdf_beta(vf[r], a0[r], a1[r]);
+          lp = st.pre ? logpdf_beta_pre(vf[r], a0[r], a1[r], pre1) : logpdf_beta(vf[r], a0[r], a1[r]);
         } else if ((MASK & (1 << GJX_DIST_BERNOULLI)) && dist == GJX_DIST_BERNOULLI) {
           lp = logpdf_bernoulli(vi[r] != 0, a0[r]);
         } else if ((MASK & (1 << GJX_DIST_CATEGORICAL)) && dist == GJX_DIST_CATEGORICAL) {
@@ -575,9 +582,11 @@ struct AncestorOnly {
   GJX_DEV void store(int64_t j, int64_t out_lo, uint64_t src, const Out&) const { anc[j - out_lo] = (int32_t)src; }
 };
 
-template <int IMPL, class Policy>
-__global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P, float* max_partials) {
-  resample_body<IMPL>(A, P, max_partials);
+// (amdgpu_num_sgpr(96): 256-thread workgroups are admitted per CU by their SGPR allocation — 97+ cost a seventh
+// workgroup per CU, MI355X_MICROARCH.md "Residency" — and the allocator settles at 100 without the cap; no spill at 96)
+template <int IMPL, class Policy, bool ADAPTIVE = false>
+__global__ __attribute__((amdgpu_num_sgpr(96))) __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P, float* max_partials) {
+  resample_body<IMPL, Policy, ADAPTIVE>(A, P, max_partials);
 }
 
 // Per-tile fixed-point mass of local log-weights, written at the global tile offset.
@@ -585,6 +594,7 @@ __global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P, f
 // workgroup = 4 tiles): 16 particles per lane as four 16-byte loads, the tile's mass is a wave reduction (DPP, no
 // LDS, no barrier) — the only workgroup-wide step left is the max of the tile maxima, once per 4 tiles.
 constexpr int kTilesPerSumBlock = kBlock / kWave;
+template <bool ESS>
 __global__ __launch_bounds__(kBlock) void k_tile_sums_wave(const float* lw, uint64_t n_local,
                                                       const float* max_partials, uint64_t n_mp,
                                                       const float* m_ptr, int frac,
@@ -643,14 +653,16 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_wave(const float* lw, uint
     if (live && i < n_local) {
       const uint64_t q = fixw(lwv[k], m, frac);
       acc += q;
-      const uint64_t r = ess_r(q, frac);  // (the ESS sums of adaptive filters: gjx_smc_config.ess_threshold)
-      a1 += r;
-      a2 += r * r;
+      if (ESS) {  // the ESS sums of adaptive filters: gjx_smc_config.ess_threshold
+        const uint64_t r = ess_r(q, frac);
+        a1 += r;
+        a2 += r * r;
+      }
     }
   }
   acc = wave_sum(acc);
   if (live && lane == 0) tile_sums_at[tile] = acc;
-  if (tile_ess_at) {  // launch-uniform
+  if (ESS && tile_ess_at) {  // launch-uniform
     a1 = wave_sum(a1);
     a2 = wave_sum(a2);
     if (live && lane == 0) { tile_ess_at[2 * tile] = a1; tile_ess_at[2 * tile + 1] = a2; }
@@ -659,6 +671,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_wave(const float* lw, uint
 
 // The same with one WORKGROUP per tile (4 particles per lane): more workgroups — better while a launch has few
 // tiles (one filter of 1e6 particles: 977), where the wave-per-tile form leaves most of the machine idle.
+template <bool ESS>
 __global__ __launch_bounds__(kBlock) void k_tile_sums_block(const float* lw, uint64_t n_local,
                                                       const float* max_partials, uint64_t n_mp,
                                                       const float* m_ptr, int frac,
@@ -703,19 +716,21 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_block(const float* lw, uin
     if (i < n_local) {
       const uint64_t q = fixw(lwv[r], m, frac);
       acc += q;
-      const uint64_t rr = ess_r(q, frac);
-      a1 += rr;
-      a2 += rr * rr;
+      if (ESS) {
+        const uint64_t rr = ess_r(q, frac);
+        a1 += rr;
+        a2 += rr * rr;
+      }
     }
   }
-  // one barrier for all three sums (ESS sums only in adaptive filters: launch-uniform)
+  // one barrier for all three sums (ESS sums only in adaptive filters)
   constexpr int kW = kBlock / kWave;
   acc = wave_sum(acc);
-  if (tile_ess_at) { a1 = wave_sum(a1); a2 = wave_sum(a2); }
+  if (ESS) { a1 = wave_sum(a1); a2 = wave_sum(a2); }
   const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
     sh64[wv] = acc;
-    if (tile_ess_at) { sh64[kW + wv] = a1; sh64[2 * kW + wv] = a2; }
+    if (ESS) { sh64[kW + wv] = a1; sh64[2 * kW + wv] = a2; }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -723,10 +738,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_block(const float* lw, uin
 #pragma unroll
     for (int i = 0; i < kW; ++i) {
       t0 += sh64[i];
-      if (tile_ess_at) { t1 += sh64[kW + i]; t2 += sh64[2 * kW + i]; }
+      if (ESS) { t1 += sh64[kW + i]; t2 += sh64[2 * kW + i]; }
     }
     tile_sums_at[tile] = t0;
-    if (tile_ess_at) { tile_ess_at[2 * tile] = t1; tile_ess_at[2 * tile + 1] = t2; }
+    if (ESS && tile_ess_at) { tile_ess_at[2 * tile] = t1; tile_ess_at[2 * tile + 1] = t2; }
   }
 }
 
@@ -746,7 +761,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint64_t* tile_sums
   __shared__ uint32_t heavy_n;
   tile_sums += (uint64_t)blockIdx.x * ntiles;  // one workgroup per filter
   if (tile_ess) tile_ess += 2 * (uint64_t)blockIdx.x * ntiles;
-  prefix += (uint64_t)blockIdx.x * (ntiles + 1 + kPrefixTail);
+  prefix += (uint64_t)blockIdx.x * prefix_words(ntiles);
   if (threadIdx.x == 0) heavy_n = 0;
   const uint64_t per = (ntiles + kBlock - 1) / kBlock;
   const uint64_t lo = threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
@@ -761,23 +776,36 @@ __global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint64_t* tile_sums
     l1 = block_sum(l1, sh_e);
     l2 = block_sum(l2, sh_e + kBlock / kWave);
   }
-  const double hscale = (double)n_out / (double)total;
+  const uint64_t heavy_mass = heavy_threshold(total, (double)(kCapSlots - 8) / (double)n_out);
   for (uint64_t k = lo; k < hi; ++k) {
     const uint64_t v = tile_sums[k];
     prefix[k] = run;
-    if ((double)v * hscale > (double)(kCapSlots - 8) || (total == 0 && k + 1 == ntiles)) {  // resample_body: a heavy candidate
+    if (v > heavy_mass || (total == 0 && k + 1 == ntiles)) {  // resample_body: a heavy candidate
       const uint32_t e = atomicAdd(&heavy_n, 1u);
       if (e < (uint32_t)kMaxHeavy) { prefix[ntiles + 4 + 2 * e] = k; prefix[ntiles + 5 + 2 * e] = run; }
     }
     run += v;
   }
   __syncthreads();
+  const uint32_t nh = heavy_n;
   if (threadIdx.x == 0) {
     prefix[ntiles] = total;
     prefix[ntiles + 1] = l1;
     prefix[ntiles + 2] = l2;
-    prefix[ntiles + 3] = heavy_n;
+    prefix[ntiles + 3] = nh;
   }
+  if (nh == 0) return;  // (uniform) the idle ranks are read only when some tile is heavy
+  // every tile's rank among the idle tiles (mass 0, not the last tile: it closes the comb), and their number
+  uint32_t cnt = 0;
+  for (uint64_t k = lo; k < hi; ++k) cnt += (tile_sums[k] == 0 && k + 1 < ntiles) ? 1u : 0u;
+  uint64_t tot_idle;
+  uint32_t r = (uint32_t)block_scan_excl((uint64_t)cnt, sh64, tot_idle);
+  uint32_t* ranks = reinterpret_cast<uint32_t*>(prefix + ntiles + 1 + kPrefixTail);
+  for (uint64_t k = lo; k < hi; ++k) {
+    ranks[k] = r;
+    r += (tile_sums[k] == 0 && k + 1 < ntiles) ? 1u : 0u;
+  }
+  if (threadIdx.x == 0) prefix[ntiles + 4 + 2 * kMaxHeavy] = tot_idle;
 }
 
 // Inclusive fixed-point CDF materialised in HBM (multinomial / single-draw paths).
@@ -1337,7 +1365,7 @@ size_t gjx_workspace_bytes(int op, uint64_t n) {
     case GJX_OP_RESAMPLE:
       return pad256(nt * 4) + 2 * pad256(nt * 8) + pad256(n * 8) + 1024;
     case GJX_OP_SMC:  // ping-pong state + weights, tile maxima, tile masses, their prefix (+ tail), ESS sums, HMM tables
-      return 2 * pad256(n * 4) + pad256(nt * 4) + pad256(nt * 8) + pad256((nt + 1 + kPrefixTail) * 8) + pad256(2 * nt * 8) +
+      return 2 * pad256(n * 4) + pad256(nt * 4) + pad256(nt * 8) + pad256(prefix_words(nt) * 8) + pad256(2 * nt * 8) +
              pad256(256 * (256 + 64) * 4) + pad256(256 * 256 * 4) + 1024;
     default: return 0;
   }
@@ -1454,6 +1482,9 @@ struct gjx_plan {
   int n_slots;
   int dist_mask;
   uint32_t flags;  // GJX_PLAN_*
+  int n_params;    // values set by gjx_plan_set_params
+  int max_param;   // highest GJX_ARG_PARAM index referenced (-1: none)
+  PlanParams prm;
   CSite host[GJX_MAX_SITES];
   CSite* dev;
   // specialised kernels, built on first use: [0] THREEFRY, [1] PHILOX one particle per lane, [2] PHILOX pairs
@@ -1471,6 +1502,7 @@ static bool arg_ok(const gjx_arg& a, int s, int n_state = -1, int n_obs = -1, bo
     case GJX_ARG_TABLE: return a.ref >= 0 && a.ref < s && a.table != nullptr;
     case GJX_ARG_STATE: return allow_state && a.ref >= 0 && a.ref < n_state;
     case GJX_ARG_OBS: return n_obs >= 0 && a.ref >= 0 && a.ref < n_obs;
+    case GJX_ARG_PARAM: return n_state < 0 && a.ref >= 0 && a.ref < GJX_MAX_PARAMS;
     default: return false;
   }
 }
@@ -1483,7 +1515,8 @@ static bool convert_site(const gjx_site& st, int s, CSite& c, int n_state = -1, 
   const bool two_args = st.dist != GJX_DIST_BERNOULLI && st.dist != GJX_DIST_CATEGORICAL;
   if (ok && two_args) ok = arg_ok(st.arg[1], s, n_state, n_obs, allow_state);
   if (ok && st.observed) {
-    if (n_state < 0) ok = st.obs.kind == GJX_ARG_CONST || (st.obs.kind == GJX_ARG_INPUT && st.obs.ref >= 0 && st.obs.ref < 16);
+    if (n_state < 0) ok = st.obs.kind == GJX_ARG_CONST || (st.obs.kind == GJX_ARG_INPUT && st.obs.ref >= 0 && st.obs.ref < 16) ||
+                          (st.obs.kind == GJX_ARG_PARAM && st.obs.ref >= 0 && st.obs.ref < GJX_MAX_PARAMS);
     else ok = st.obs.kind == GJX_ARG_CONST || (st.obs.kind == GJX_ARG_OBS && st.obs.ref >= 0 && st.obs.ref < n_obs);
   }
   if (ok && st.dist == GJX_DIST_CATEGORICAL)
@@ -1499,12 +1532,15 @@ static bool convert_site(const gjx_site& st, int s, CSite& c, int n_state = -1, 
   // Hoist per-site constants: same spec functions, evaluated once on the host (IEEE-exact ops
   // give the same bits as evaluating them per particle on the device).
   const bool c0 = st.arg[0].kind == GJX_ARG_CONST, c1 = st.arg[1].kind == GJX_ARG_CONST;
+  const bool u0 = c0 || st.arg[0].kind == GJX_ARG_PARAM, u1 = c1 || st.arg[1].kind == GJX_ARG_PARAM;  // launch-uniform
   if (st.dist == GJX_DIST_NORMAL && c1) {
     c.pre = 1; c.pre0 = normal_rs(st.arg[1].offset); c.pre1 = normal_lognorm(st.arg[1].offset);
   } else if (st.dist == GJX_DIST_GAMMA && c0 && c1) {
     c.pre = 1; c.pre1 = gamma_lognorm(st.arg[0].offset, st.arg[1].offset);
   } else if (st.dist == GJX_DIST_BETA && c0 && c1) {
     c.pre = 1; c.pre1 = beta_lbeta(st.arg[0].offset, st.arg[1].offset);
+  } else if ((st.dist == GJX_DIST_NORMAL && u1) || ((st.dist == GJX_DIST_GAMMA || st.dist == GJX_DIST_BETA) && u0 && u1)) {
+    c.pre = 2;  // the same constants, derived from the launch's parameters (plan_derive_params)
   }
   return true;
 }
@@ -1515,6 +1551,9 @@ int gjx_plan_create_ex(const gjx_site* sites, int n_sites, uint32_t flags, gjx_p
   gjx_plan* p = new (std::nothrow) gjx_plan;
   if (!p) return GJX_ERR_LAUNCH;
   p->flags = flags;
+  p->n_params = 0;
+  p->max_param = -1;
+  memset(&p->prm, 0, sizeof p->prm);
   p->n_sites = n_sites;
   p->dev = nullptr;
   p->dist_mask = 0;
@@ -1527,6 +1566,8 @@ int gjx_plan_create_ex(const gjx_site* sites, int n_sites, uint32_t flags, gjx_p
       return GJX_ERR_INVALID;
     }
     p->dist_mask |= 1 << sites[s].dist;
+    for (CArg* a : {&c.a0, &c.a1, &c.obs})
+      if (a->kind == GJX_ARG_PARAM && a->ref > p->max_param && (a != &c.obs || c.observed)) p->max_param = a->ref;
     for (CArg* a : {&c.a0, &c.a1})
       if (a->kind == GJX_ARG_SITE || a->kind == GJX_ARG_TABLE) last_use[a->ref] = s;
   }
@@ -1554,6 +1595,32 @@ int gjx_plan_create_ex(const gjx_site* sites, int n_sites, uint32_t flags, gjx_p
   }
   p->n_slots = n_slots;
   *out = p;  // the interpreter's device copy of the table is made on first use (plan_device_table)
+  return GJX_OK;
+}
+
+// Launch parameters: the caller's values and the per-site constants that depend on them (the spec functions on the
+// host: IEEE-exact ops give the bits the device would compute per particle).
+int gjx_plan_set_params(gjx_plan* p, const float* params, int n_params) {
+  if (!p || n_params < 0 || n_params > GJX_MAX_PARAMS || (n_params && !params) || n_params <= p->max_param) return GJX_ERR_INVALID;
+  for (int k = 0; k < n_params; ++k) p->prm.p[k] = params[k];
+  p->n_params = n_params;
+  auto val = [&](const CArg& a) {  // CONST or PARAM
+    if (a.kind == GJX_ARG_CONST) return a.offset;
+    const float t = a.scale * p->prm.p[a.ref];
+    return t + a.offset;
+  };
+  for (int q = 0; q < p->n_sites; ++q) {
+    const CSite& c = p->host[q];
+    if (c.pre != 2) continue;
+    if (c.dist == GJX_DIST_NORMAL) {
+      p->prm.d[2 * q] = normal_rs(val(c.a1));
+      p->prm.d[2 * q + 1] = normal_lognorm(val(c.a1));
+    } else if (c.dist == GJX_DIST_GAMMA) {
+      p->prm.d[2 * q + 1] = gamma_lognorm(val(c.a0), val(c.a1));
+    } else {
+      p->prm.d[2 * q + 1] = beta_lbeta(val(c.a0), val(c.a1));
+    }
+  }
   return GJX_OK;
 }
 
@@ -1708,6 +1775,7 @@ static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pa
     if (st.a1.kind == GJX_ARG_INPUT && st.a1.ref >= n_input_cols) return GJX_ERR_INVALID;
     if (st.observed && st.obs.kind == GJX_ARG_INPUT && st.obs.ref >= n_input_cols) return GJX_ERR_INVALID;
   }
+  if (p->max_param >= p->n_params) return GJX_ERR_INVALID;  // parameters referenced but never set
   if (n == 0) return GJX_OK;
   KeySrc k = key_src(pk);
   // Specialised straight-line kernel for this site table (compiled once per plan and RNG scheme).
@@ -1730,7 +1798,8 @@ static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pa
       bt.pass_stride = pass_stride;
       bt.row_stride = row_stride;
       for (int32_t b = 0; b < n_pass; ++b) { bt.parent[b][0] = pk[b].parent[0]; bt.parent[b][1] = pk[b].parent[1]; }
-      void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials, &row_e, &row_s, &tail, &bt};
+      PlanParams prm = p->prm;
+      void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials, &row_e, &row_s, &tail, &bt, &prm};
       uint64_t rows = ((uint64_t)n_pass * nrows_of(n) + c.rows_per_block - 1) / c.rows_per_block;
       static const uint64_t grid_cap = [] {
         const char* e = std::getenv("GJX_IMPORTANCE_GRID");
@@ -1761,7 +1830,7 @@ static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pa
     int32_t* re_b = row_e ? row_e + (size_t)b * row_stride : nullptr;
     uint64_t* rs_b = row_s ? row_s + (size_t)b * row_stride : nullptr;
 #define GJX_LAUNCH_IMPORTANCE(IMPL, MASK) \
-  k_importance<IMPL, MASK><<<(unsigned)((n + kImpTile - 1) / kImpTile), kBlock, lds, S(s)>>>(p->dev, p->n_sites, kb, cb, sc_b, lw_b, n, mp_b, re_b, rs_b)
+  k_importance<IMPL, MASK><<<(unsigned)((n + kImpTile - 1) / kImpTile), kBlock, lds, S(s)>>>(p->dev, p->n_sites, kb, cb, sc_b, lw_b, n, mp_b, re_b, rs_b, p->prm)
     if (pk->impl == 0) {
       if ((m & ~kMaskNormal) == 0) GJX_LAUNCH_IMPORTANCE(0, kMaskNormal);
       else if ((m & ~kMaskReal) == 0) GJX_LAUNCH_IMPORTANCE(0, kMaskReal);
@@ -1906,7 +1975,7 @@ static int weights_prepare(const float* logw, uint64_t n, Carver& cv, float** m_
   float* m = cv.take<float>(1);
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   k_max_partials<<<grid_for(n), kBlock, 0, st>>>(logw, n, mp);
-  k_tile_sums_block<<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, nullptr, frac_bits(n), tiles, m, 0, 0, 0, nullptr);
+  k_tile_sums_block<false><<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, nullptr, frac_bits(n), tiles, m, 0, 0, 0, nullptr);
   *m_out = m;
   *tiles_out = tiles;
   return GJX_OK;
@@ -1975,6 +2044,7 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
   A.q_total_out = out_q ? out_q : qtot;
   A.tile_prefix = nullptr;
   A.allow_help = n_out <= A.ntiles * (uint64_t)kTile ? 1 : 0;  // helpers are the workgroups of the output windows
+  A.heavy_frac = (double)(kCapSlots - 8) / (double)n_out;
   AncestorOnly P{ancestors};
   if (key->impl == 0) k_resample<0, AncestorOnly><<<(unsigned)A.ntiles, kBlock, 0, S(s)>>>(A, P, nullptr);
   else k_resample<1, AncestorOnly><<<(unsigned)A.ntiles, kBlock, 0, S(s)>>>(A, P, nullptr);
@@ -2053,8 +2123,6 @@ struct StepCtx {
   FilterBatch fb;
   uint64_t* tile_ess = nullptr;    // whole-run drivers of adaptive filters: their workspace copy (else cfg->tile_ess)
   int32_t* resampled_out = nullptr;  // this step's entry of cfg->resampled_out
-  float* max_accum = nullptr;      // this step's entry of out_max (-inf before the step): the kernels maintain the
-                                   // running max by float atomics, so step B needs no reduction of the tile maxima
 };
 
 static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const float* prev_logw,
@@ -2067,6 +2135,7 @@ static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const fl
   A.n = cfg->n_total; A.ntiles = ntiles_of(cfg->n_total); A.n_out = cfg->n_total;
   A.out_lo = (int64_t)cfg->first_slot; A.out_hi = (int64_t)(cfg->first_slot + cfg->n_local);
   A.frac = frac_bits(cfg->n_total);
+  A.heavy_frac = (double)(kCapSlots - 8) / (double)cfg->n_total;
   A.lw_vec = ((uintptr_t)prev_logw & 15) == 0;
   A.rkey = Key{cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1]};
   A.rkey_has_fold = 0; A.rkey_fold = 0;
@@ -2076,7 +2145,6 @@ static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const fl
     A.tile_ess = ctx.tile_ess ? ctx.tile_ess : cfg->tile_ess;
   }
   A.resampled_out = ctx.resampled_out ? ctx.resampled_out : (cfg->resampled_out && !(cfg->n_filters > 1) ? cfg->resampled_out + t : nullptr);
-  A.max_accum = ctx.max_accum;
   return A;
 }
 
@@ -2098,12 +2166,15 @@ static int lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, 
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
   ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out, ctx);
   if (A.ess_thr > 0.0 && !A.tile_ess) return GJX_ERR_INVALID;
+  const bool ad = A.ess_thr > 0.0;
   if (cfg->impl == 0) {
     LgssmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {}};
-    k_resample<0, LgssmPolicy<0>><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    if (ad) k_resample<0, LgssmPolicy<0>, true><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    else k_resample<0, LgssmPolicy<0>, false><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   } else {
     LgssmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {}};
-    k_resample<1, LgssmPolicy<1>><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    if (ad) k_resample<1, LgssmPolicy<1>, true><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    else k_resample<1, LgssmPolicy<1>, false><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   }
   return launch_status();
 }
@@ -2128,12 +2199,15 @@ static int hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int3
   if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
   ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out, ctx);
   if (A.ess_thr > 0.0 && !A.tile_ess) return GJX_ERR_INVALID;
+  const bool ad = A.ess_thr > 0.0;
   if (cfg->impl == 0) {
     HmmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {}, 0.0f};
-    k_resample<0, HmmPolicy<0>><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    if (ad) k_resample<0, HmmPolicy<0>, true><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    else k_resample<0, HmmPolicy<0>, false><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   } else {
     HmmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {}, 0.0f};
-    k_resample<1, HmmPolicy<1>><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    if (ad) k_resample<1, HmmPolicy<1>, true><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    else k_resample<1, HmmPolicy<1>, false><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   }
   return launch_status();
 }
@@ -2162,9 +2236,7 @@ static int smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const 
   const uint64_t nt_total = ntiles_of(cfg->n_total);
   const uint64_t nt_local = ntiles_of(cfg->n_local);
   const float* m_ptr = nullptr;
-  if (ctx.max_accum) {
-    m_ptr = ctx.max_accum;  // step A kept the running max in max_out (float atomics): nothing to reduce
-  } else if (nt_total > kPrefixTiles) {  // reduce the tile maxima once instead of in every workgroup
+  if (nt_total > kPrefixTiles) {  // reduce the tile maxima once instead of in every workgroup
     k_reduce_max<<<1, kBlock, 0, S(s)>>>(max_partials, nt_total, max_out);
     m_ptr = max_out;
   }
@@ -2182,15 +2254,19 @@ static int smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const 
   const bool wave_form = cfg->tile_sums_form == 2 || (cfg->tile_sums_form == 0 && nt_local * nf >= wave_min);
   if (wave_form) {
     const unsigned groups = (unsigned)((nt_local + kTilesPerSumBlock - 1) / kTilesPerSumBlock);
-    k_tile_sums_wave<<<groups * nf, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total, m_ptr,
-                                                       frac_bits(cfg->n_total), tile_sums + tile0, m_ptr ? nullptr : max_out,
-                                                       nf > 1 ? fb.tiles : 0u, fb.stride, fb.mq_stride, (uint32_t)nt_local,
-                                                       tile_ess ? tile_ess + 2 * tile0 : nullptr);
+#define GJX_TS_WAVE(E) k_tile_sums_wave<E><<<groups * nf, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total, m_ptr, \
+    frac_bits(cfg->n_total), tile_sums + tile0, m_ptr ? nullptr : max_out, nf > 1 ? fb.tiles : 0u, fb.stride, fb.mq_stride,           \
+    (uint32_t)nt_local, tile_ess ? tile_ess + 2 * tile0 : nullptr)
+    if (tile_ess) GJX_TS_WAVE(true);
+    else GJX_TS_WAVE(false);
+#undef GJX_TS_WAVE
   } else {
-    k_tile_sums_block<<<(unsigned)nt_local * nf, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total, m_ptr,
-                                                                    frac_bits(cfg->n_total), tile_sums + tile0,
-                                                                    m_ptr ? nullptr : max_out, nf > 1 ? fb.tiles : 0u, fb.stride,
-                                                                    fb.mq_stride, tile_ess ? tile_ess + 2 * tile0 : nullptr);
+#define GJX_TS_BLOCK(E) k_tile_sums_block<E><<<(unsigned)nt_local * nf, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials,      \
+    nt_total, m_ptr, frac_bits(cfg->n_total), tile_sums + tile0, m_ptr ? nullptr : max_out, nf > 1 ? fb.tiles : 0u, fb.stride,           \
+    fb.mq_stride, tile_ess ? tile_ess + 2 * tile0 : nullptr)
+    if (tile_ess) GJX_TS_BLOCK(true);
+    else GJX_TS_BLOCK(false);
+#undef GJX_TS_BLOCK
   }
   return launch_status();
 }
@@ -2249,15 +2325,14 @@ static int run_common_init(const gjx_smc_config* cfg, Carver& cv, RunCommon& rc,
   const bool scan = rc.nt > kPrefixTiles || rc.F >= 4;
   rc.mp = cv.take<float>(rc.F * rc.nt);
   rc.tiles = cv.take<uint64_t>(rc.F * rc.nt);
-  rc.prefix = scan ? cv.take<uint64_t>(rc.F * (rc.nt + 1 + kPrefixTail)) : nullptr;
+  rc.prefix = scan ? cv.take<uint64_t>(rc.F * prefix_words(rc.nt)) : nullptr;
   rc.tile_ess = cfg_adaptive(cfg) ? cv.take<uint64_t>(2 * rc.F * rc.nt) : nullptr;
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   if (rc.F > 1) {
     rc.fb.n_filters = rc.F; rc.fb.tiles = (uint32_t)rc.nt; rc.fb.stride = rc.stride; rc.fb.mq_stride = (uint64_t)cfg->n_steps;
   }
-  // the per-step maxima start at -inf: the step kernels fold their tile maxima into them with float atomics
   const size_t nmq = (size_t)rc.F * (size_t)cfg->n_steps;
-  if (hipMemsetD32Async((hipDeviceptr_t)out_max, (int)0xff800000u, nmq, S(s)) != hipSuccess) return GJX_ERR_LAUNCH;
+  (void)out_max;
   if (cfg->resampled_out && hipMemsetAsync(cfg->resampled_out, 0, nmq * sizeof(int32_t), S(s)) != hipSuccess) return GJX_ERR_LAUNCH;
   return GJX_OK;
 }
@@ -2277,7 +2352,7 @@ static StepCtx run_step_ctx(const gjx_smc_config* cfg, RunCommon& rc, int t, flo
     ctx.tile_prefix = rc.prefix;
   }
   ctx.resampled_out = cfg->resampled_out ? cfg->resampled_out + t : nullptr;
-  ctx.max_accum = t ? out_max + t : nullptr;  // (step 0 has no resample kernel: its maxima are reduced by step B)
+  (void)out_max;
   return ctx;
 }
 

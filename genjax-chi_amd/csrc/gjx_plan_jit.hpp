@@ -69,6 +69,7 @@ struct SiteEmitter {
         return "((" + flit(a.scale) + " * cols.in[" + std::to_string(a.ref) + "][li" + sfx + "]) + " + flit(a.offset) + ")";
       case GJX_ARG_STATE: return "((" + flit(a.scale) + " * st_" + std::to_string(a.ref) + sfx + ") + " + flit(a.offset) + ")";
       case GJX_ARG_OBS: return "((" + flit(a.scale) + " * a.obs[" + std::to_string(a.ref) + "]) + " + flit(a.offset) + ")";
+      case GJX_ARG_PARAM: return "((" + flit(a.scale) + " * prm.p[" + std::to_string(a.ref) + "]) + " + flit(a.offset) + ")";
       default: return plit(a.table) + "[" + val_i32(a.ref_site) + "]";
     }
   }
@@ -120,6 +121,7 @@ struct SiteEmitter {
       std::string ov;
       if (st.obs.kind == GJX_ARG_CONST) ov = flit(st.obs.offset);
       else if (st.obs.kind == GJX_ARG_OBS) ov = "a.obs[" + std::to_string(st.obs.ref) + "]";
+      else if (st.obs.kind == GJX_ARG_PARAM) ov = arg(st.obs);
       else ov = "cols.in[" + std::to_string(st.obs.ref) + "][li" + sfx + "]";
       if (is_int(st)) o << ind << "const int32_t vi" << Q << " = (int32_t)__builtin_rintf(" << ov << ");\n";
       else o << ind << "const float vf" << Q << " = " << ov << ";\n";
@@ -176,17 +178,20 @@ struct SiteEmitter {
     }
     std::string lp;
     const std::string v = (isint ? "vi" : "vf") + Q;
+    // hoisted per-site constants: literals (pre == 1) or derived from the launch's parameters (pre == 2)
+    const std::string p0 = st.pre == 2 ? "prm.d[" + std::to_string(2 * q) + "]" : flit(st.pre0);
+    const std::string p1 = st.pre == 2 ? "prm.d[" + std::to_string(2 * q + 1) + "]" : flit(st.pre1);
     switch (st.dist) {
       case GJX_DIST_NORMAL:
-        lp = st.pre ? "logpdf_normal_pre(" + v + ", a0_" + Q + ", " + flit(st.pre0) + ", " + flit(st.pre1) + ")"
+        lp = st.pre ? "logpdf_normal_pre(" + v + ", a0_" + Q + ", " + p0 + ", " + p1 + ")"
                     : "logpdf_normal(" + v + ", a0_" + Q + ", a1_" + Q + ")";
         break;
       case GJX_DIST_GAMMA:
-        lp = st.pre ? "logpdf_gamma_pre(" + v + ", a0_" + Q + ", a1_" + Q + ", " + flit(st.pre1) + ")"
+        lp = st.pre ? "logpdf_gamma_pre(" + v + ", a0_" + Q + ", a1_" + Q + ", " + p1 + ")"
                     : "logpdf_gamma(" + v + ", a0_" + Q + ", a1_" + Q + ")";
         break;
       case GJX_DIST_BETA:
-        lp = st.pre ? "logpdf_beta_pre(" + v + ", a0_" + Q + ", a1_" + Q + ", " + flit(st.pre1) + ")"
+        lp = st.pre ? "logpdf_beta_pre(" + v + ", a0_" + Q + ", a1_" + Q + ", " + p1 + ")"
                     : "logpdf_beta(" + v + ", a0_" + Q + ", a1_" + Q + ")";
         break;
       case GJX_DIST_BERNOULLI: lp = "logpdf_bernoulli(" + v + " != 0, a0_" + Q + ")"; break;
@@ -241,7 +246,7 @@ struct Gen {
 
   static const char* signature() {
     return "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, "
-           "uint64_t* row_s, LseTail tail, PassBatch bt) {\n";
+           "uint64_t* row_s, LseTail tail, PassBatch bt, PlanParams prm) {\n";
   }
   const char* kname() const { return impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox"; }
 
@@ -506,7 +511,7 @@ struct GenSmc {
     o << "  __device__ __forceinline__ void store(int64_t j, int64_t out_lo, uint64_t src, const Out& out) const {\n";
     o << "    for (int k = 0; k < " << D << "; ++k) a.state_out[k][j - out_lo] = out.s[k];\n";
     o << "    a.logw_out[j - out_lo] = out.lw;\n    if (a.anc_out) a.anc_out[j - out_lo] = (int32_t)src;\n  }\n};\n";
-    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_step_kernel(ResampleArgs A, PlanPolicyArgs PA, float* max_partials) {\n";
+    o << "extern \"C\" __global__ __attribute__((amdgpu_num_sgpr(96))) __launch_bounds__(256) void gjx_smc_step_kernel(ResampleArgs A, PlanPolicyArgs PA, float* max_partials) {\n";
     o << "  GenPolicy P;\n  P.a = PA;\n  resample_body<" << I << ">(A, P, max_partials);\n}\n";
     // ---- init kernel: one workgroup per global tile, like k_lgssm_init
     if (impl == 1) {

@@ -35,7 +35,8 @@ RNG_PHILOX = 1
 
 LSE_RECORD_WORDS = 65  # include/gjx.h: GJX_LSE_RECORD_WORDS
 DIST_NORMAL, DIST_GAMMA, DIST_BETA, DIST_BERNOULLI, DIST_CATEGORICAL = range(5)
-ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE, ARG_STATE, ARG_OBS = range(6)
+ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE, ARG_STATE, ARG_OBS, ARG_PARAM = range(7)
+MAX_PARAMS = 64
 SMC_MAX_STATE, SMC_MAX_OBS = 4, 8
 OP_LOGSUMEXP, OP_CATEGORICAL_INDEX, OP_RESAMPLE, OP_SMC = range(4)
 MAX_SITES = 64
@@ -184,6 +185,7 @@ PROTOTYPES = {
     "gjx_plan_create": (C.c_int, [C.POINTER(Site), C.c_int, C.POINTER(_P)]),
     "gjx_plan_create_ex": (C.c_int, [C.POINTER(Site), C.c_int, C.c_uint32, C.POINTER(_P)]),
     "gjx_plan_destroy": (C.c_int, [_P]),
+    "gjx_plan_set_params": (C.c_int, [_P, _P, C.c_int]),
     "gjx_plan_specialized_source": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gjx_plan_compile_check": (C.c_int, [_P, C.c_int]),
     "gjx_plan_prepare": (C.c_int, [_P, _KP]),

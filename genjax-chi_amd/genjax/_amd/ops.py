@@ -598,6 +598,15 @@ class Plan:
     def __init__(self, ops: Ops, handle, n_sites: int):
         self.ops, self.handle, self.n_sites = ops, handle, n_sites
 
+    def set_params(self, values) -> "Plan":
+        """Values of the plan's GJX_ARG_PARAM references for the launches that follow (observations, model arguments:
+        one specialised kernel serves every dataset)."""
+        import numpy as np
+
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
+        self.ops.lib.call("gjx_plan_set_params", self.handle, C.c_void_p(v.ctypes.data) if v.size else None, int(v.size))
+        return self
+
     def __del__(self):
         try:
             if self.handle:

@@ -164,8 +164,13 @@ typedef enum {
   GJX_ARG_INPUT = 2, /* value = scale * input_cols[ref][i] + offset */
   GJX_ARG_TABLE = 3, /* value = table[(int) value of site `ref`] (dev f32 table) */
   GJX_ARG_STATE = 4, /* SMC plans: value = scale * state[ref] of the particle's ANCESTOR + offset */
-  GJX_ARG_OBS = 5    /* SMC plans: value = scale * obs[t][ref] + offset (this step's observation constants) */
+  GJX_ARG_OBS = 5,   /* SMC plans: value = scale * obs[t][ref] + offset (this step's observation constants) */
+  GJX_ARG_PARAM = 6  /* importance plans: value = scale * params[ref] + offset — a LAUNCH-UNIFORM parameter
+                        (gjx_plan_set_params): observations and model arguments that change from dataset to dataset
+                        without changing the model's structure.  libgjx_hip.so passes them as kernel arguments
+                        (scalar registers), so one specialised kernel serves every dataset: no recompilation. */
 } gjx_arg_kind;
+#define GJX_MAX_PARAMS 64
 
 typedef struct {
   int32_t kind;
@@ -183,7 +188,7 @@ typedef struct {
   int32_t n_rows;     /* categorical: rows in `logits` */
   int32_t cat_mode;   /* categorical: 0 Gumbel-max, 1 inverse-CDF */
   gjx_arg arg[2];
-  gjx_arg obs;        /* observed value: CONST or INPUT (int-valued dists: rounded to nearest) */
+  gjx_arg obs;        /* observed value: CONST, INPUT or PARAM (int-valued dists: rounded to nearest) */
   const float* logits;/* dev f32 [n_rows,n_cat], categorical only (borrowed until plan destroy) */
 } gjx_site;
 
@@ -204,6 +209,11 @@ int gjx_plan_create(const gjx_site* sites /*host*/, int n_sites, gjx_plan** out)
 #define GJX_PLAN_FAST_MATH 1u
 int gjx_plan_create_ex(const gjx_site* sites /*host*/, int n_sites, uint32_t flags, gjx_plan** out);
 int gjx_plan_destroy(gjx_plan* p);
+/* The values of the plan's GJX_ARG_PARAM references for the launches that follow (host f32[n_params], copied; n_params
+ * <= GJX_MAX_PARAMS and > every referenced index).  Per-site constants that depend on them (1/scale, the log
+ * normaliser, lgamma terms) are re-derived on the host by the spec functions, exactly as plan creation does for
+ * constants.  Set-then-run of one plan must be ordered by the caller (a plan is not a concurrent object). */
+int gjx_plan_set_params(gjx_plan* p, const float* params /*host*/, int n_params);
 /* Plan specialisation (libgjx_hip.so): on first use per RNG scheme a plan is lowered to a
  * straight-line gfx950 kernel — the same device functions in the same order, constants folded —
  * and compiled with hiprtc; GJX_PLAN_JIT=0 keeps the table-interpreter kernel.  Diagnostics:

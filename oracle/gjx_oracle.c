@@ -299,6 +299,8 @@ int gjx_logpdf_categorical(const int32_t* value, int value_scalar, const float* 
 struct gjx_plan {
   int n_sites;
   gjx_site sites[GJX_MAX_SITES];
+  int n_params;
+  float params[GJX_MAX_PARAMS]; /* GJX_ARG_PARAM values (gjx_plan_set_params) */
 };
 
 static int arg_ok(const gjx_arg* a, int s, int allow_site) {
@@ -307,6 +309,7 @@ static int arg_ok(const gjx_arg* a, int s, int allow_site) {
     case GJX_ARG_SITE: return allow_site && a->ref >= 0 && a->ref < s;
     case GJX_ARG_INPUT: return a->ref >= 0;
     case GJX_ARG_TABLE: return allow_site && a->ref >= 0 && a->ref < s && a->table != NULL;
+    case GJX_ARG_PARAM: return a->ref >= 0 && a->ref < GJX_MAX_PARAMS;
     default: return 0;
   }
 }
@@ -320,13 +323,14 @@ int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
     if (st->dist != GJX_DIST_BERNOULLI && st->dist != GJX_DIST_CATEGORICAL &&
         !arg_ok(&st->arg[1], s, 1))
       return GJX_ERR_INVALID;
-    if (st->observed && !(st->obs.kind == GJX_ARG_CONST || st->obs.kind == GJX_ARG_INPUT))
+    if (st->observed && !(st->obs.kind == GJX_ARG_CONST || st->obs.kind == GJX_ARG_INPUT ||
+                          (st->obs.kind == GJX_ARG_PARAM && st->obs.ref >= 0 && st->obs.ref < GJX_MAX_PARAMS)))
       return GJX_ERR_INVALID;
     if (st->dist == GJX_DIST_CATEGORICAL &&
         (!st->logits || st->n_cat <= 0 || st->n_rows <= 0 || (st->cat_mode != 0 && st->cat_mode != 1)))
       return GJX_ERR_INVALID;
   }
-  gjx_plan* p = (gjx_plan*)malloc(sizeof(gjx_plan));
+  gjx_plan* p = (gjx_plan*)calloc(1, sizeof(gjx_plan));
   if (!p) return GJX_ERR_LAUNCH;
   p->n_sites = n_sites;
   memcpy(p->sites, sites, sizeof(gjx_site) * (size_t)n_sites);
@@ -338,6 +342,23 @@ int gjx_plan_create_ex(const gjx_site* sites, int n_sites, uint32_t flags, gjx_p
   return gjx_plan_create(sites, n_sites, out); /* the oracle is the exact specification: FAST_MATH is not its concern */
 }
 int gjx_plan_destroy(gjx_plan* p) { free(p); return GJX_OK; }
+static int plan_max_param(const gjx_plan* p) {
+  int mx = -1;
+  for (int q = 0; q < p->n_sites; ++q) {
+    const gjx_site* st = &p->sites[q];
+    for (int a = 0; a < 2; ++a)
+      if (st->arg[a].kind == GJX_ARG_PARAM && st->arg[a].ref > mx) mx = st->arg[a].ref;
+    if (st->observed && st->obs.kind == GJX_ARG_PARAM && st->obs.ref > mx) mx = st->obs.ref;
+  }
+  return mx;
+}
+int gjx_plan_set_params(gjx_plan* p, const float* params, int n_params) {
+  if (!p || n_params < 0 || n_params > GJX_MAX_PARAMS || (n_params && !params) || n_params <= plan_max_param(p))
+    return GJX_ERR_INVALID;
+  memcpy(p->params, params, sizeof(float) * (size_t)n_params);
+  p->n_params = n_params;
+  return GJX_OK;
+}
 int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t buf_len, size_t* needed) {
   (void)p; (void)impl; (void)buf; (void)buf_len; (void)needed;
   return GJX_ERR_UNSUPPORTED;
@@ -360,6 +381,7 @@ typedef struct {
   uint64_t slot;             /* smc: the output slot */
   const float* state;        /* smc: the ancestor's state columns (NULL at step 0) */
   const float* obs;          /* smc: this step's observation constants */
+  const float* params;       /* importance: the plan's GJX_ARG_PARAM values */
 } walk_ctx;
 
 static inline float eval_arg(const gjx_arg* a, const site_val* vals, const walk_ctx* c) {
@@ -369,6 +391,7 @@ static inline float eval_arg(const gjx_arg* a, const site_val* vals, const walk_
     case GJX_ARG_INPUT: { float t = a->scale * c->in[a->ref][c->i]; return t + a->offset; }
     case GJX_ARG_STATE: { float t = a->scale * c->state[a->ref]; return t + a->offset; }
     case GJX_ARG_OBS: { float t = a->scale * c->obs[a->ref]; return t + a->offset; }
+    case GJX_ARG_PARAM: { float t = a->scale * c->params[a->ref]; return t + a->offset; }
     default: return a->table[sv_as_i32(&vals[a->ref])];
   }
 }
@@ -400,7 +423,8 @@ static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, sit
     float lp;
     if (st->observed) {
       float ov = st->obs.kind == GJX_ARG_CONST ? st->obs.offset
-               : st->obs.kind == GJX_ARG_OBS ? c->obs[st->obs.ref] : c->in[st->obs.ref][c->i];
+               : st->obs.kind == GJX_ARG_OBS ? c->obs[st->obs.ref]
+               : st->obs.kind == GJX_ARG_PARAM ? eval_arg(&st->obs, vals, c) : c->in[st->obs.ref][c->i];
       if (v.is_int) v.i = (int32_t)rintf(ov); else v.f = ov;
     } else {
       /* THREEFRY: site counter from 1 (static.py:349-352); PHILOX: index among the sampled sites */
@@ -452,11 +476,13 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
     if (st->observed && st->obs.kind == GJX_ARG_INPUT && st->obs.ref >= n_input_cols)
       return GJX_ERR_INVALID;
   }
+  if (plan_max_param(p) >= p->n_params) return GJX_ERR_INVALID; /* parameters referenced but never set */
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < (int64_t)n; ++i) {
     walk_ctx c;
     memset(&c, 0, sizeof c);
     c.impl = pk->impl;
+    c.params = p->params;
     c.pair_normals = 1;
     key_at(pk, (uint64_t)i, c.pkey);
     c.in = input_cols;

@@ -431,6 +431,10 @@ def test_smc_collapse_helpers(hip_ops, oracle_ops, impl, n):  # 2.2e6: the same 
         hb = hip_ops.smc_run_lgssm(impl, n, sk, rk, mdl, y, True)
         ob = oracle_ops.smc_run_lgssm(impl, n, sk, rk, mdl, y, True)
         for a, b, what in zip(hb, ob, ("step max", "step q", "state", "logw", "ancestors")):
+            if what in ("state", "logw"):  # [F, stride]: the padding behind each filter's n particles is never written
+                a, b = a[:, :n], b[:, :n]
+            elif what == "ancestors":
+                a, b = a[:, :, :n], b[:, :, :n]
             same(a, b, what + " (batch of 5)")
 
 

@@ -63,5 +63,5 @@ def test_virtual_ranks_generated_filter(hip_ops, impl):
 def test_sharded_adaptive_on_device(hip_ops, oracle_ops, kind):
     """ESS-adaptive resampling sharded over 3 virtual ranks on the HIP kernels: the per-rank decisions, the identity
     source ranges of kept steps and the accumulated weights equal the single-rank ORACLE filter bit for bit."""
-    res = G.check_virtual_ranks(hip_ops, kind, 1, 3, 1024 * 6, 14, "ranges", ref_ops=oracle_ops, ess_threshold=0.5)
+    res = check_virtual_ranks(hip_ops, kind, 1, 3, 1024 * 6, 14, "ranges", ref_ops=oracle_ops, ess_threshold=0.5)
     assert 0 < int((res[0]["resampled"][1:] == 0).sum()) < 13
