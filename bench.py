@@ -422,6 +422,88 @@ def bench_smc(args, ops, kind, filters=1, min_s=0.08, variant=None, T=None):
     return res, r
 
 
+def bench_scan(args, ops, min_s=0.08, T=100, fast_math=False, with_host_loop=True):
+    """ImportanceK over `step.scan(n=T)` — the reference's literal semantics for a state-space model without
+    resampling (scan.py:237-294, [N, T] leaves): N = 1e6 particles x T steps in ONE launch (gjx_scan_run).  Reported
+    in particle-steps/s; the HBM floor is the 4-byte store of x_t per particle-step (+ 8 B / T for logw and score)."""
+    import torch
+
+    from genjax._amd import workloads as W
+    from genjax._amd.ops import HipEvent
+
+    impl = 1 if args.rng == "philox" else 0
+    n = args.particles
+    wl = W.LgssmScan(ops, impl, 3, n, T, fast_math=fast_math)
+    t0 = time.perf_counter()
+    wl.run()
+    torch.cuda.synchronize()
+    while time.perf_counter() - t0 < 0.05:
+        wl.run()
+        torch.cuda.synchronize()
+    evs = []
+
+    def one_run():
+        e0, e1 = HipEvent(), HipEvent()
+        e0.record(ops.stream())
+        o = wl.run()
+        e1.record(ops.stream())
+        evs.append((e0, e1))
+        return o
+
+    blocks, _ = timed_blocks(one_run, 1, min_s=min_s, min_blocks=5, max_blocks=40)
+    r = wl.result()
+    dev_ms = statistics.median(a.elapsed_ms(b) for a, b in evs)
+    dt = statistics.median(blocks)
+    bytes_per_launch = (4.0 * T + 8.0) * n
+    achieved = bytes_per_launch / (dev_ms * 1e-3) / 1e9
+    res = {
+        "value": n * T / dt, "unit": "particle-steps/s", "ms_per_run": dt * 1e3, "kernel_ms": dev_ms, "runs_timed": len(evs),
+        "config": {"workload": f"ImportanceK over step.scan(n={T}), LGSSM, N={n}, no resampling, [T, N] trajectories stored",
+                   "rng": args.rng, "math": "fast" if fast_math else "exact"},
+        "roofline": {"bound": "hbm", "kernel": "gjx_scan_kernel (one launch per pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "traffic": None,
+                     "limiter": "VALU issue: three cipher blocks (key chain, draw, Box-Muller twin) + two log-densities per particle-step"},
+        "log_z": r["log_z"],
+    }
+    if with_host_loop:
+        # the general route (host loop of per-site launches, combinators.py) on the same model, once, for scale
+        import genjax
+        from genjax import ChoiceMapBuilder as C, gen, normal
+        from genjax._amd import combinators as CB
+        from genjax._amd.runtime import use_ops
+
+        m = W.LGSSM
+
+        @gen
+        def step(x, _):
+            x2 = normal(m["a"] * x, m["q"]) @ "x"
+            _ = normal(x2, m["r"]) @ "y"
+            return x2, x2
+
+        with use_ops(ops):
+            keys = genjax.random.split(genjax.random.key(3, args.rng), n)
+            chm = C["y"].set(torch.from_numpy(W.lgssm_data(T)))
+            times = {}
+            for fused in (True, False):
+                CB.FUSED_SCAN = fused
+                try:
+                    step.scan(n=T).generate(keys, chm, (0.0, None))  # warm (hiprtc, allocator)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    tr, w = step.scan(n=T).generate(keys, chm, (0.0, None))
+                    torch.cuda.synchronize()
+                    times[fused] = time.perf_counter() - t0
+                finally:
+                    CB.FUSED_SCAN = True
+                del tr, w
+        res["host_api"] = {"scan_generate_fused_ms": times[True] * 1e3, "scan_generate_host_loop_ms": times[False] * 1e3,
+                           "speedup": times[False] / times[True],
+                           "note": "Scan.generate through the host API (tracing, lowering, launch, trace assembly) vs the "
+                                   "T x per-site-launch host loop it replaces"}
+    return res
+
+
 # ------------------------------------------------------------------------------------------------------------
 # CPU baselines (the oracle: a port) — bounded samples of the same workloads, timed on this box's host cores
 # ------------------------------------------------------------------------------------------------------------
@@ -562,6 +644,33 @@ def cpu_baseline_smc(args, kind, gpu_result=None):
     return res
 
 
+def cpu_baseline_scan(args, T=100):
+    """The oracle's gjx_scan_run (all host cores) on a bounded sample: the first 1/8 of the particles, all T steps."""
+    from genjax._amd import workloads as W
+
+    ora = _oracle()
+    if ora is None:
+        return None
+    impl = 1 if args.rng == "philox" else 0
+    n = max(1024, args.particles // 8)
+    wl = W.LgssmScan(ora, impl, 3, n, T)
+    probe = W.LgssmScan(ora, impl, 3, max(1024, n // 16), T)
+    probe.run()
+    hc = host_cores()
+    cores, _ = best_thread_count(probe.run, sorted({hc, max(1, hc // 2), min(hc, 16), min(hc, 32)}, reverse=True))
+    t0 = time.perf_counter()
+    wl.run()
+    dt = time.perf_counter() - t0
+    res = {"value": n * T / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{n} of {args.particles} particles x {T} steps (OpenMP, {cores} threads)"}
+    if _omp_threads(1):
+        t0 = time.perf_counter()
+        probe.run()
+        res["value_1_thread"] = probe.n * T / (time.perf_counter() - t0)
+        _omp_threads(cores)
+    return res
+
+
 def jax_cpu_plain(args):
     """BASELINE.md §2 secondary baseline: a plain `jax.jit(jax.vmap(...))` restatement of the 10-latent model on
     CPU, timed only if jax happens to be importable on this box (it is not part of the image)."""
@@ -658,10 +767,20 @@ def run_rank(args):
                     "step_ms": rc_["roofline"]["step_ms"], "normal_step_ms": extra["smc_lgssm"]["roofline"]["step_ms"],
                     "ratio_to_normal_step": rc_["roofline"]["step_ms"] / extra["smc_lgssm"]["roofline"]["step_ms"],
                     "distinct_ancestors_at_step_2": int(anc[2].unique().numel()), "steps": len(yc),
-                    "note": "heavy tiles serve 4096 slots themselves; the 1024-slot windows beyond are served by the window's "
-                            "workgroup from the same CDF (bit-identical ancestors): no workgroup walks the whole population"}
+                    "note": "a heavy tile's workgroup serves its first 4 chunks of 1024 slots; the chunks beyond are delegated to idle "
+                            "(zero-mass) workgroups, which stage the same source tile and serve them from the same CDF "
+                            "(bit-identical ancestors): no workgroup walks the whole population"}
             except Exception as ex:
                 extra["smc_lgssm_collapsing_weights"] = {"error": f"{type(ex).__name__}: {ex}"}
+            # ImportanceK over a Scan model: the reference's literal semantics of the state-space configs (no resampling)
+            try:
+                extra["importance_scan_lgssm"] = bench_scan(args, ops)
+                extra["importance_scan_lgssm"]["fast_math"] = entry(bench_scan(args, ops, min_s=0.04, fast_math=True, with_host_loop=False),
+                                                                    ("value", "unit", "kernel_ms", "roofline", "log_z"))
+                if not args.no_cpu_baseline:
+                    extra["importance_scan_lgssm"]["cpu_baseline"] = cpu_baseline_scan(args)
+            except Exception as ex:
+                extra["importance_scan_lgssm"] = {"error": f"{type(ex).__name__}: {ex}"}
             # ImportanceK variants: one pass per launch (the literal config), the other generator, fast math
             r, _ = bench_importance(args, ops, rank, world, launch_passes=1, steps=64, warmup=16, ramp=False, min_s=0.03)
             extra["importance_1_pass_per_launch"] = entry(r)

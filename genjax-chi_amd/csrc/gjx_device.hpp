@@ -224,6 +224,17 @@ struct PlanParams {
   float d[2 * 64];
 };
 
+// Launch arguments of an importance run over a Scan model (gjx_scan_run; kernel argument, by value).
+struct ScanArgs {
+  const float* obs;  // [T, n_obs]
+  uint64_t n;
+  uint64_t col_stride;
+  int32_t n_steps;
+  float carry0[4];
+  const float* carry0_cols[4];
+  float* carry_out[4];
+};
+
 // Column pointer table of one importance run (kernel argument, by value).
 struct RunCols {
   const float* in[16];

@@ -1678,8 +1678,7 @@ int gjx_plan_compile_check(const gjx_plan* p, int impl) {
 int gjx_plan_destroy(gjx_plan* p) {
   if (!p) return GJX_OK;
   if (p->dev) (void)hipFree(p->dev);
-  for (auto& c : p->jit)
-    if (c.mod) (void)hipModuleUnload(c.mod);
+  for (auto& c : p->jit) gjx_jit::release(&c);  // the modules stay cached (bounded, LRU) for plans of the same structure
   delete p;
   return GJX_OK;
 }
@@ -1719,8 +1718,7 @@ static gjx_jit::Compiled& plan_compiled(gjx_plan* mp, const gjx_keys* pk, int la
         if (qe != hipSuccess) (void)hipGetLastError();  // a failed query must not surface as a launch error later
         if (std::getenv("GJX_PLAN_JIT_VERBOSE")) fprintf(stderr, "gjx jit: waves-per-SIMD hint %d: query %d, scratch %d B\n", hint, (int)qe, scratch);
         if (qe != hipSuccess || scratch > 32) {  // (a couple of spilled words cost less than the lost wave)
-          c.fn = nullptr;  // the hinted module stays in the source-keyed cache
-          ok = gjx_jit::compile(make(0), pk->impl, &c);
+          ok = gjx_jit::compile(make(0), pk->impl, &c);  // (releases the hinted module: it stays cached, unreferenced)
         }
       }
       if (!ok) {
@@ -2356,6 +2354,102 @@ static StepCtx run_step_ctx(const gjx_smc_config* cfg, RunCommon& rc, int t, flo
   return ctx;
 }
 
+// ---- importance over a Scan model: the T-step walk of every particle in one launch ------------------
+struct gjx_scan_plan {
+  int n_state, n_obs, n_step;
+  uint32_t flags;
+  CSite step[GJX_MAX_SITES];
+  CArg next_state[GJX_SMC_MAX_STATE];
+  gjx_jit::Compiled jit[2];
+  std::mutex mu;
+};
+int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan** out) {
+  if (!m || !out || (flags & ~(uint32_t)GJX_PLAN_FAST_MATH) || m->n_state < 1 || m->n_state > GJX_SMC_MAX_STATE ||
+      m->n_obs < 0 || m->n_obs > GJX_SMC_MAX_OBS || !m->step_sites || m->n_step_sites <= 0 || m->n_step_sites > GJX_MAX_SITES)
+    return GJX_ERR_INVALID;
+  gjx_scan_plan* p = new (std::nothrow) gjx_scan_plan;
+  if (!p) return GJX_ERR_LAUNCH;
+  p->n_state = m->n_state; p->n_obs = m->n_obs; p->n_step = m->n_step_sites; p->flags = flags;
+  bool ok = true;
+  for (int s = 0; ok && s < p->n_step; ++s) ok = convert_site(m->step_sites[s], s, p->step[s], m->n_state, m->n_obs, true);
+  for (int k = 0; ok && k < p->n_state; ++k) {
+    ok = arg_ok(m->next_state[k], p->n_step, m->n_state, m->n_obs, true) && m->next_state[k].kind != GJX_ARG_TABLE;
+    p->next_state[k] = carg(m->next_state[k]);
+  }
+  if (!ok) {
+    delete p;
+    return GJX_ERR_INVALID;
+  }
+  *out = p;
+  return GJX_OK;
+}
+int gjx_scan_plan_destroy(gjx_scan_plan* p) {
+  if (!p) return GJX_OK;
+  for (auto& c : p->jit) gjx_jit::release(&c);
+  delete p;
+  return GJX_OK;
+}
+static std::string scan_plan_source(const gjx_scan_plan* plan, int impl, const char** kname = nullptr) {
+  gjx_jit::GenScan<CSite, CArg> g;
+  g.impl = impl; g.sites = plan->step; g.n_sites = plan->n_step; g.next_state = plan->next_state;
+  g.n_state = plan->n_state; g.n_obs = plan->n_obs; g.fast_math = (plan->flags & GJX_PLAN_FAST_MATH) != 0;
+  if (kname) *kname = g.kname();
+  return g.run();
+}
+int gjx_scan_plan_compile_check(const gjx_scan_plan* p, int impl) {
+  if (!p || (impl != 0 && impl != 1)) return GJX_ERR_INVALID;
+  if (std::getenv("GJX_PLAN_JIT_DUMP")) fprintf(stderr, "%s\n", scan_plan_source(p, impl).c_str());
+  return gjx_jit::compile_only(scan_plan_source(p, impl)) ? GJX_OK : GJX_ERR_UNSUPPORTED;
+}
+int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
+  if (!p || !io || !keys_ok(io->particle_keys) || io->particle_keys->has_fold || !io->logw || io->n_steps < 1 ||
+      io->col_stride < io->n || (p->n_obs > 0 && !io->obs) || !io->carry0 || io->n_value_cols < 0 ||
+      io->n_value_cols > GJX_MAX_SITES || ((io->row_e == nullptr) != (io->row_s == nullptr)) ||
+      (io->lse && (!io->row_e || !io->lse->tickets)))
+    return GJX_ERR_INVALID;
+  RunCols cols;
+  memset(&cols, 0, sizeof(cols));
+  for (int c = 0; c < io->n_value_cols; ++c) cols.out[c] = io->value_cols[c];
+  for (int q = 0; q < p->n_step; ++q) {
+    const CSite& st = p->step[q];
+    if (st.out_col >= io->n_value_cols || (st.out_col >= 0 && !cols.out[st.out_col])) return GJX_ERR_INVALID;
+  }
+  if (io->n == 0) return GJX_OK;
+  const int impl = io->particle_keys->impl;
+  // Scan plans exist only as specialised kernels: a failed compilation is an error, never a slower route.
+  if (!gjx_jit::enabled()) return GJX_ERR_UNSUPPORTED;
+  gjx_jit::Compiled& c = p->jit[impl];
+  if (c.state == 0) {
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (c.state == 0) {
+      const char* kname = nullptr;
+      const std::string src = scan_plan_source(p, impl, &kname);
+      if (std::getenv("GJX_PLAN_JIT_DUMP")) fprintf(stderr, "%s\n", src.c_str());
+      c.state = gjx_jit::compile(src, impl, &c, kname) ? 1 : -1;
+    }
+  }
+  if (c.state != 1) return GJX_ERR_JIT;
+  KeySrc k = key_src(io->particle_keys);
+  ScanArgs sa;
+  memset(&sa, 0, sizeof sa);
+  sa.obs = io->obs; sa.n = io->n; sa.col_stride = io->col_stride; sa.n_steps = io->n_steps;
+  for (int d = 0; d < p->n_state; ++d) {
+    sa.carry0[d] = io->carry0[d];
+    sa.carry0_cols[d] = io->carry0_cols ? io->carry0_cols[d] : nullptr;
+    sa.carry_out[d] = io->carry_out ? io->carry_out[d] : nullptr;
+  }
+  LseTail tail{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (io->lse) tail = LseTail{io->lse->e, io->lse->q, io->lse->lse, io->lse->record, io->lse->tickets};
+  float* score = io->score; float* logw = io->logw; float* mp = io->max_partials;
+  int32_t* row_e = io->row_e; uint64_t* row_s = io->row_s;
+  void* args[] = {&k, &cols, &sa, &score, &logw, &mp, &row_e, &row_s, &tail};
+  const uint64_t rows = nrows_of(io->n);
+  if (hipModuleLaunchKernel(c.fn, (unsigned)(rows > 0x7fffffffull ? 0x7fffffffull : rows), 1, 1, 256, 1, 1, 0, S(s), args,
+                            nullptr) != hipSuccess)
+    return GJX_ERR_LAUNCH;
+  return launch_status();
+}
+
 // ---- bootstrap SMC for a user model: generated policy in the fused resample kernel -----------------
 struct gjx_smc_plan {
   int n_state, n_obs, n_init, n_step;
@@ -2390,7 +2484,17 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
   return GJX_OK;
 }
 int gjx_smc_plan_destroy(gjx_smc_plan* p) {
-  delete p;  // compiled modules are owned by the process-wide cache
+  if (!p) return GJX_OK;
+  for (auto& c : p->jit) gjx_jit::release_smc(&c);  // compiled modules are owned by the process-wide (bounded) cache
+  delete p;
+  return GJX_OK;
+}
+int gjx_jit_stats(uint64_t* compiles, uint64_t* cached_modules, uint64_t* evictions) {
+  gjx_jit::ModuleCache& mc = gjx_jit::ModuleCache::get();
+  std::lock_guard<std::mutex> lock(mc.mu);
+  if (compiles) *compiles = mc.compiles;
+  if (cached_modules) *cached_modules = mc.map.size();
+  if (evictions) *evictions = mc.evictions;
   return GJX_OK;
 }
 

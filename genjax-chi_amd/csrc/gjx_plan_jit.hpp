@@ -97,7 +97,8 @@ struct SiteEmitter {
   }
   // Importance plans under PHILOX pair particles at Normal sites (gjx_device.hpp bm_pair / site_normal);
   // SMC steps keep the single-draw inverse-CDF form (one latent per slot-step: a pair would cost two blocks).
-  bool pairs_normals() const { return impl == 1 && mode == 0; }
+  // Scan steps (mode 2) are importance walks under the step's chained key: same draws as mode 0.
+  bool pairs_normals() const { return impl == 1 && mode != 1; }
 
   // Part 1 of site q: arguments, the observed value, or the draw word(s).
   void head(int q) {
@@ -201,8 +202,8 @@ struct SiteEmitter {
     }
     o << ind << "{ const float lp = " << lp << "; sc" << sfx << " = sc" << sfx << " + lp;"
       << (st.observed ? " w" + sfx + " = w" + sfx + " + lp;" : "") << " }\n";
-    if (mode == 0 && st.out_col >= 0 && store_values)
-      o << ind << "reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "])[i" << sfx << "] = "
+    if ((mode == 0 || mode == 2) && st.out_col >= 0 && store_values)
+      o << ind << "reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "])[" << (mode == 2 ? "oi" : "i") << sfx << "] = "
         << (isint ? "(uint32_t)" + v : "f2u(" + v + ")") << ";\n";
   }
 
@@ -423,6 +424,60 @@ struct Gen {
   }
 };
 
+// Importance over a Scan model (gjx_scan_run): one lane per particle walks all T steps — the key chain, the carry and
+// the running weight / score stay in registers, every step stores its sampled values as one coalesced row of the
+// time-major columns, and the epilogue is the importance kernel's (row maxima, row-anchored sums, in-launch fold).
+template <class CSiteT, class CArgT>
+struct GenScan {
+  std::ostringstream o;
+  int impl;
+  const CSiteT* sites;
+  int n_sites;
+  const CArgT* next_state;
+  int n_state, n_obs;
+  bool fast_math = false;
+  const char* kname() const { return impl == 0 ? "gjx_scan_kernel_threefry" : "gjx_scan_kernel_philox"; }
+  std::string run() {
+    const std::string I = std::to_string(impl);
+    emit_prelude(o, fast_math);
+    o << "struct StepObs { const float* obs; };\n";
+    o << "extern \"C\" __global__ __launch_bounds__(256) void " << kname()
+      << "(KeySrc ks, RunCols cols, ScanArgs sa, float* score, float* logw, float* max_partials, int32_t* row_e, uint64_t* row_s, LseTail tail) {\n";
+    o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
+    o << "  const uint64_t n = sa.n, rows_all = (n + 255) / 256;\n";
+    o << "  for (uint64_t row = blockIdx.x; row < rows_all; row += gridDim.x) {\n";
+    o << "    float tmax = -__builtin_inff();\n    bool live = false;\n";
+    o << "    const uint64_t i = row * 256 + threadIdx.x;\n";
+    o << "    if (i < n) {\n";
+    o << "      Key pkey = key_at<" << I << ">(ks, i);\n";
+    for (int k = 0; k < n_state; ++k)
+      o << "      float st_" << k << " = sa.carry0_cols[" << k << "] ? sa.carry0_cols[" << k << "][i] : sa.carry0[" << k << "];\n";
+    o << "      float wt = 0.0f, sct = 0.0f;\n";
+    o << "      for (int32_t t = 0; t < sa.n_steps; ++t) {\n";
+    o << "        pkey = fold_in<" << I << ">(pkey, (uint32_t)t);  // chained: the folded key is carried\n";
+    o << "        StepObs a; a.obs = sa.obs + (size_t)t * " << n_obs << "; (void)a;\n";
+    o << "        const uint64_t oi = (uint64_t)t * sa.col_stride + i; (void)oi;\n";
+    o << "        float w = 0.0f, sc = 0.0f;\n";
+    SiteEmitter<CSiteT, CArgT> em{o, impl, 2, sites, n_sites, "        "};
+    em.run();
+    for (int k = 0; k < n_state; ++k) o << "        const float nx_" << k << " = " << em.arg(next_state[k]) << ";\n";
+    for (int k = 0; k < n_state; ++k) o << "        st_" << k << " = nx_" << k << ";\n";
+    o << "        wt = wt + w;\n        sct = sct + sc;\n      }\n";
+    for (int k = 0; k < n_state; ++k) o << "      if (sa.carry_out[" << k << "]) sa.carry_out[" << k << "][i] = st_" << k << ";\n";
+    o << "      logw[i] = wt;\n      if (score) score[i] = sct;\n      tmax = wt;\n      live = true;\n    }\n";
+    o << "    if (max_partials || row_e) {\n";
+    o << "      const float bm = block_max(tmax, sh_red);\n";
+    o << "      if (max_partials && threadIdx.x == 0) max_partials[row] = bm;\n";
+    o << "      if (row_e) {\n";
+    o << "        const int32_t eb = row_anchor(bm);\n";
+    o << "        const uint64_t sb = block_sum(live ? rowfix(tmax, eb) : 0, sh_sum);\n";
+    o << "        if (threadIdx.x == 0) lse_store_row(row_e, row_s, row, eb, sb, tail.tickets != nullptr);\n";
+    o << "      }\n    }\n";
+    o << "  }\n  if (row_e) lse_tail(row_e, row_s, (n + 255) / 256, tail);\n}\n";
+    return o.str();
+  }
+};
+
 // Plan-driven bootstrap SMC: a generated policy inside the fused resample kernel (step) and a plain
 // per-slot kernel (init).  State columns are staged per source tile in LDS like the fixed models.
 template <class CSiteT, class CArgT>
@@ -558,6 +613,7 @@ struct Compiled {
   int state = 0;  // 0 untried, 1 ready, -1 failed
   int block = 256;  // threads per workgroup of the compiled kernel
   int rows_per_block = 1;  // 256-particle rows per workgroup
+  std::string key;  // the source this slot holds a reference on (module cache)
 };
 
 inline bool enabled() {
@@ -585,13 +641,14 @@ inline bool compile_to_code(const std::string& src, std::string* code) {
   for (const std::string& t : extra) opts.push_back(t.c_str());
   const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (r != HIPRTC_SUCCESS) {
-    if (std::getenv("GJX_PLAN_JIT_VERBOSE")) {
-      size_t ls = 0;
-      hiprtcGetProgramLogSize(prog, &ls);
-      std::string log(ls, 0);
-      hiprtcGetProgramLog(prog, &log[0]);
-      std::fprintf(stderr, "[gjx] plan specialisation failed to compile:\n%s\n", log.c_str());
-    }
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    std::string log(ls, 0);
+    if (ls) hiprtcGetProgramLog(prog, &log[0]);
+    // always say THAT it failed; the full compiler log on request
+    std::fprintf(stderr, "[gjx] hiprtc: plan specialisation failed to compile (%s)%s\n", hiprtcGetErrorString(r),
+                 std::getenv("GJX_PLAN_JIT_VERBOSE") ? ":" : "; GJX_PLAN_JIT_VERBOSE=1 prints the compiler log");
+    if (std::getenv("GJX_PLAN_JIT_VERBOSE")) std::fprintf(stderr, "%s\n", log.c_str());
     hiprtcDestroyProgram(&prog);
     return false;
   }
@@ -606,31 +663,91 @@ inline bool compile_only(const std::string& src) {
   std::string code;
   return compile_to_code(src, &code) && !code.empty();
 }
-// ... and load it on the current device.  Identical sources (same model, same constants) share
-// one module process-wide, so re-creating a plan does not recompile.
-inline bool compile_module(const std::string& src, hipModule_t* mod_out) {
-  static std::mutex mu;
-  static std::unordered_map<std::string, hipModule_t> cache;
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = cache.find(src);
-  if (it != cache.end()) {
-    *mod_out = it->second;
-    return true;
+
+// The module cache.  Identical sources (same model structure) share one loaded module process-wide, so re-creating a
+// plan — or running the same model on another dataset, whose values are launch parameters, not source — does not
+// recompile.  Entries are reference-counted by the plans that use them; unreferenced modules stay cached for reuse up to
+// GJX_JIT_CACHE_MAX entries (default 64) and are then unloaded least-recently-used first, so a long-lived process that
+// keeps generating NEW model structures holds a bounded number of code objects.
+struct ModuleCache {
+  struct Entry {
+    hipModule_t mod = nullptr;
+    int refs = 0;
+    uint64_t tick = 0;
+  };
+  std::mutex mu;
+  std::unordered_map<std::string, Entry> map;
+  uint64_t clock = 0, compiles = 0, evictions = 0;
+  size_t cap = [] {
+    const char* e = std::getenv("GJX_JIT_CACHE_MAX");
+    const long v = e ? atol(e) : 64;
+    return (size_t)(v < 1 ? 1 : v);
+  }();
+  static ModuleCache& get() {
+    static ModuleCache c;
+    return c;
   }
-  std::string code;
-  if (!compile_to_code(src, &code)) return false;
-  hipModule_t mod = nullptr;
-  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return false;
-  cache.emplace(src, mod);
-  *mod_out = mod;
-  return true;
+  // -> the loaded module of `src` with one more reference, or nullptr (compile / load failure, logged)
+  hipModule_t acquire(const std::string& src) {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = map.find(src);
+    if (it == map.end()) {
+      std::string code;
+      if (!compile_to_code(src, &code)) return nullptr;
+      hipModule_t mod = nullptr;
+      const hipError_t le = hipModuleLoadData(&mod, code.data());
+      if (le != hipSuccess) {
+        (void)hipGetLastError();
+        std::fprintf(stderr, "[gjx] hipModuleLoadData failed for a specialised plan kernel: %s\n", hipGetErrorString(le));
+        return nullptr;
+      }
+      ++compiles;
+      it = map.emplace(src, Entry{mod, 0, 0}).first;
+      evict_locked();
+    }
+    it->second.refs++;
+    it->second.tick = ++clock;
+    return it->second.mod;
+  }
+  void release(const std::string& src) {
+    if (src.empty()) return;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = map.find(src);
+    if (it != map.end() && it->second.refs > 0) it->second.refs--;
+    evict_locked();
+  }
+  void evict_locked() {
+    while (map.size() > cap) {
+      auto victim = map.end();
+      for (auto it = map.begin(); it != map.end(); ++it)
+        if (it->second.refs == 0 && (victim == map.end() || it->second.tick < victim->second.tick)) victim = it;
+      if (victim == map.end()) return;  // everything is in use
+      (void)hipModuleUnload(victim->second.mod);
+      map.erase(victim);
+      ++evictions;
+    }
+  }
+};
+inline void release(Compiled* c) {
+  ModuleCache::get().release(c->key);
+  c->key.clear();
+  c->fn = nullptr;
+  c->mod = nullptr;
 }
-inline bool compile(const std::string& src, int impl, Compiled* out) {
-  hipModule_t mod = nullptr;
-  if (!compile_module(src, &mod)) return false;
+inline bool compile(const std::string& src, int impl, Compiled* out, const char* kernel = nullptr) {
+  release(out);  // (a slot that is being rebuilt, e.g. without the occupancy hint)
+  hipModule_t mod = ModuleCache::get().acquire(src);
+  if (!mod) return false;
+  out->key = src;
   hipFunction_t fn = nullptr;
-  if (hipModuleGetFunction(&fn, mod, impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox") != hipSuccess)
+  const hipError_t ge =
+      hipModuleGetFunction(&fn, mod, kernel ? kernel : (impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox"));
+  if (ge != hipSuccess) {
+    (void)hipGetLastError();
+    std::fprintf(stderr, "[gjx] hipModuleGetFunction failed for a specialised plan kernel: %s\n", hipGetErrorString(ge));
+    release(out);
     return false;
+  }
   out->mod = nullptr;  // owned by the cache
   out->fn = fn;
   return true;
@@ -638,12 +755,24 @@ inline bool compile(const std::string& src, int impl, Compiled* out) {
 struct CompiledSmc {
   hipFunction_t step = nullptr, init = nullptr;
   int state = 0;  // 0 untried, 1 ready, -1 failed
+  std::string key;
 };
+inline void release_smc(CompiledSmc* c) {
+  ModuleCache::get().release(c->key);
+  c->key.clear();
+  c->step = c->init = nullptr;
+}
 inline bool compile_smc(const std::string& src, CompiledSmc* out) {
-  hipModule_t mod = nullptr;
-  if (!compile_module(src, &mod)) return false;
-  if (hipModuleGetFunction(&out->step, mod, "gjx_smc_step_kernel") != hipSuccess) return false;
-  if (hipModuleGetFunction(&out->init, mod, "gjx_smc_init_kernel") != hipSuccess) return false;
+  hipModule_t mod = ModuleCache::get().acquire(src);
+  if (!mod) return false;
+  out->key = src;
+  if (hipModuleGetFunction(&out->step, mod, "gjx_smc_step_kernel") != hipSuccess ||
+      hipModuleGetFunction(&out->init, mod, "gjx_smc_init_kernel") != hipSuccess) {
+    (void)hipGetLastError();
+    std::fprintf(stderr, "[gjx] hipModuleGetFunction failed for a generated SMC kernel\n");
+    release_smc(out);
+    return false;
+  }
   return true;
 }
 

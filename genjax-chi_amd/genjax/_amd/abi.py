@@ -118,6 +118,37 @@ class SmcModel(C.Structure):
     ]
 
 
+class ScanModel(C.Structure):
+    _fields_ = [
+        ("step_sites", C.POINTER(Site)),
+        ("n_step_sites", C.c_int32),
+        ("next_state", Arg * 4),
+        ("n_state", C.c_int32),
+        ("n_obs", C.c_int32),
+    ]
+
+
+class ScanIO(C.Structure):
+    _fields_ = [
+        ("particle_keys", C.c_void_p),
+        ("n", C.c_uint64),
+        ("n_steps", C.c_int32),
+        ("obs", C.c_void_p),
+        ("carry0", C.c_void_p),
+        ("carry0_cols", C.c_void_p),
+        ("value_cols", C.c_void_p),
+        ("n_value_cols", C.c_int32),
+        ("col_stride", C.c_uint64),
+        ("carry_out", C.c_void_p),
+        ("score", C.c_void_p),
+        ("logw", C.c_void_p),
+        ("max_partials", C.c_void_p),
+        ("row_e", C.c_void_p),
+        ("row_s", C.c_void_p),
+        ("lse", C.c_void_p),
+    ]
+
+
 class Lgssm(C.Structure):
     _fields_ = [
         ("x0_loc", C.c_float),
@@ -189,6 +220,7 @@ PROTOTYPES = {
     "gjx_plan_specialized_source": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gjx_plan_compile_check": (C.c_int, [_P, C.c_int]),
     "gjx_plan_prepare": (C.c_int, [_P, _KP]),
+    "gjx_jit_stats": (C.c_int, [_P, _P, _P]),
     "gjx_importance_run": (
         C.c_int,
         [_P, _KP, C.POINTER(_P), C.c_int, C.POINTER(_P), C.c_int, _P, _P, C.c_uint64, _P, _P, _P, _P, _P],
@@ -232,6 +264,10 @@ PROTOTYPES = {
     "gjx_smc_plan_create": (C.c_int, [C.POINTER(SmcModel), C.POINTER(_P)]),
     "gjx_smc_plan_destroy": (C.c_int, [_P]),
     "gjx_smc_plan_compile_check": (C.c_int, [_P, C.c_int]),
+    "gjx_scan_plan_create": (C.c_int, [C.POINTER(ScanModel), C.c_uint32, C.POINTER(_P)]),
+    "gjx_scan_plan_destroy": (C.c_int, [_P]),
+    "gjx_scan_plan_compile_check": (C.c_int, [_P, C.c_int]),
+    "gjx_scan_run": (C.c_int, [_P, C.POINTER(ScanIO), _P]),
     "gjx_smc_run_plan": (
         C.c_int,
         [C.POINTER(SmcConfig), _P, _P, _P, _P, C.POINTER(_P), _P, _P, _P, C.c_size_t, _P],

@@ -1,12 +1,15 @@
 """`Scan` — the state-space combinator (reference: generative_functions/combinators/scan.py:55-96
 ScanTrace, 200-294 simulate/generate, 638-664 assess).
 
-General (any kernel) path: a host loop over the T steps; step t runs the kernel generative
-function once over the whole particle population with the chained key
-`key_t = fold_in(key_{t-1}, t)` (scan.py:212-213, 267-268: the folded key is carried).  Every
+Two routes, the same numbers.  A plan-able kernel (scan_plan.py: supported distributions, affine arguments,
+the same scalar constraints at every step) runs the WHOLE scan of a particle population as one launch
+(`gjx_scan_run`): key chain, carry and running weight in registers, every sampled value streamed into a
+time-major `[T, n]` column.  Anything else takes the general path: a host loop over the T steps; step t runs
+the kernel generative function once over the whole population with the chained key
+`key_t = fold_in(key_{t-1}, t)` (scan.py:212-213, 267-268: the folded key is carried).  Either way every
 choice is stored time-major `[T, n]` (particle axis contiguous) and presented particle-major
 `[n, T]` like the reference's vmapped ScanTrace.  Bootstrap SMC on the benchmark state-space
-models does not go through this loop: it uses the fused `gjx_smc_run_*` kernels (smc_fused.py).
+models does not go through either: it uses the fused `gjx_smc_run_*` kernels (smc_fused.py).
 """
 
 from __future__ import annotations
@@ -69,6 +72,43 @@ class ScanTrace(Trace):
                          _map_any(fn, self.retval), _map_any(fn, self.score), self.batched)
 
 
+FUSED_SCAN = True  # tests switch the one-launch route off to compare it with the host loop
+
+
+class FusedScanTrace(ScanTrace):
+    """Trace of a one-launch scan: the `[T, n]` columns the kernel wrote.  The per-step traces the general
+    `ScanTrace` methods walk (project, per-step scores) are rebuilt on demand by re-running the kernel generative
+    function with every choice constrained — deterministic, nothing is sampled."""
+
+    def __init__(self, gen_fn, args, retval, score, leaves: list, pk, constraint_free_choices=None):
+        self.gen_fn, self.args, self.retval, self.score = gen_fn, args, retval, score
+        self.batched = True
+        self.leaves = leaves  # [(addr, [n, T] tensor | [T] observed vector)]
+        self._pk = pk
+        self._steps = None
+
+    @property
+    def step_traces(self):
+        if self._steps is None:
+            carry, xs = self.args
+            steps = []
+            for t in range(self.gen_fn._length(xs)):
+                chm_t = ChoiceMap.from_mapping([(a, v[:, t] if v.dim() == 2 else v[t]) for a, v in self.leaves])
+                tr, _ = self.gen_fn.kernel_gen_fn.generate(self._pk, chm_t, (carry, _index_xs(xs, t)))
+                carry = tr.get_retval()[0]
+                steps.append(tr)
+            self._steps = steps
+        return self._steps
+
+    def get_choices(self) -> ChoiceMap:
+        return ChoiceMap.from_mapping(self.leaves)
+
+    def map_leaves(self, fn):
+        out = FusedScanTrace(self.gen_fn, _map_any(fn, self.args), _map_any(fn, self.retval), _map_any(fn, self.score),
+                             [(a, _map_any(fn, v)) for a, v in self.leaves], self._pk)
+        return out
+
+
 class Scan(GenerativeFunction):
     """`kernel.scan(n=T)`: kernel(carry, x_t) -> (carry', y_t)."""
 
@@ -100,11 +140,59 @@ class Scan(GenerativeFunction):
         retval = (carry, _stack_time(ys, True) if ys and ys[0] is not None else None)
         return ScanTrace(self, traces, args, retval, score, True), weight, batched
 
+    def _fused(self, key, constraint: ChoiceMap, args):
+        """-> (FusedScanTrace, weight) through one `gjx_scan_run` launch, or None (not a population / not plan-able)."""
+        if not FUSED_SCAN or not isinstance(key, ParticleKeys) or key.n < 2 or key.kb.fold is not None:
+            return None
+        from . import scan_plan as SP
+        from .plan import PlanUnsupported
+
+        carry0, xs = args
+        try:  # lowering: the kernel body is traced again on every call (it may close over values that changed)
+            T = self._length(xs)
+            if T < 1:
+                return None
+            obs_addrs, obs_values = SP.step_constraints(constraint, T)
+            low = SP.lower_scan(self.kernel_gen_fn, carry0, xs, obs_addrs)
+            table = SP.observation_table(obs_values, xs, T)
+        except Exception:
+            # PlanUnsupported, or symbolic values fed to code that needs tensors: the host loop runs the model and
+            # raises genuine model errors itself
+            return None
+        try:
+            out = SP.run_scan(low, key, T, carry0, table)  # launch / hiprtc failures propagate: no silent slow route
+        except PlanUnsupported:
+            return None
+        dev = out["logw"].device
+        values_nt = []
+        for m, v in zip(low.value_meta, out["values"]):
+            v = v.t()  # [n, T] view of the time-major column
+            values_nt.append(v != 0 if m["dtype"] == torch.bool else v)
+        leaves = []
+        k_obs = {a: i for i, a in enumerate(obs_addrs)}
+        for m in low.tracer.meta:
+            a = m["addr"] if isinstance(m["addr"], tuple) else (m["addr"],)
+            if m["out_col"] >= 0:
+                leaves.append((m["addr"], values_nt[m["out_col"]]))
+            else:
+                leaves.append((m["addr"], _stack_time(obs_values[k_obs[a]], True)))
+        final = [c[0] if u else c for c, u in zip(out["carry"], low.uniform_carry)]
+        retval = (low.rebuild_carry(final), SP.resolve(low, low.ret_y, values_nt, table, dev))
+        tr = FusedScanTrace(self, args, retval, out["score"], leaves, key)
+        tr.max_partials, tr.row_stats = out["max_partials"], out["rows"]
+        return tr, out["logw"]
+
     def simulate(self, key, args):
+        fused = self._fused(key, ChoiceMap.empty(), args)
+        if fused is not None:
+            return fused[0]
         tr, _, batched = self._run(key, args, lambda pk, t, a: (self.kernel_gen_fn.simulate(pk, a), 0.0))
         return tr if batched else tr.map_leaves(squeeze_leaf)
 
     def generate(self, key, constraint: ChoiceMap, args):
+        fused = self._fused(key, constraint, args)
+        if fused is not None:
+            return fused
         tr, w, batched = self._run(
             key, args, lambda pk, t, a: self.kernel_gen_fn.generate(pk, constraint.get_submap(t), a))
         if batched:

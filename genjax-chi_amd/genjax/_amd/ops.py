@@ -197,6 +197,12 @@ class Ops:
         self.lib.call("gjx_plan_create_ex", arr, len(sites), abi.PLAN_FAST_MATH if fast_math else 0, C.byref(handle))
         return Plan(self, handle, len(sites))
 
+    def jit_stats(self) -> dict:
+        """gjx_jit_stats: hiprtc compilations so far, code objects loaded now, code objects evicted."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.lib.call("gjx_jit_stats", C.byref(a), C.byref(b), C.byref(c))
+        return dict(compiles=a.value, cached_modules=b.value, evictions=c.value)
+
     def tickets(self) -> torch.Tensor:
         """The zeroed ticket words of fused log-sum-exp launches on the current stream (gjx_lse_out.tickets:
         every launch leaves them zero, launches sharing them must be stream-ordered)."""
@@ -474,6 +480,71 @@ class Ops:
         self.lib.call("gjx_smc_plan_create", C.byref(m), C.byref(handle))
         return SmcPlan(self, handle, len(next_state), n_obs)
 
+    # ---- importance over a Scan model: T steps per particle in one launch ------------------------
+    def scan_plan_create(self, step_sites, next_state, n_obs: int, fast_math: bool = False) -> "ScanPlan":
+        m = abi.ScanModel()
+        sa = (abi.Site * len(step_sites))(*step_sites)
+        m.step_sites, m.n_step_sites = sa, len(step_sites)
+        for k, a in enumerate(next_state):
+            m.next_state[k] = a
+        m.n_state, m.n_obs = len(next_state), n_obs
+        handle = C.c_void_p()
+        self.lib.call("gjx_scan_plan_create", C.byref(m), abi.PLAN_FAST_MATH if fast_math else 0, C.byref(handle))
+        return ScanPlan(self, handle, len(next_state), n_obs)
+
+    def scan_run(self, plan: "ScanPlan", kb: KeyBatch, n: int, T: int, obs, carry0, value_dtypes: list,
+                 want_score=True, want_rows=True, out=None):
+        """One launch for the whole scan: -> dict(values [T, n] each, score, logw, carry [n] each, max_partials, rows).
+        `obs` [T, n_obs] (host array or device tensor); `carry0`: per component a float or a device f32[n] column.
+        `out`: a dict from an earlier call whose buffers are reused (benchmarks)."""
+        import numpy as np
+
+        if kb.fold is not None:
+            raise ValueError("particle keys must not carry a fold")
+        D = plan.n_state
+        if len(carry0) != D:
+            raise ValueError(f"carry0 must have {D} components")
+        if plan.n_obs:
+            obs_d = obs if isinstance(obs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(obs, dtype=np.float32)))
+            obs_d = obs_d.to(device=self.device(), dtype=torch.float32).reshape(T, plan.n_obs).contiguous()
+        else:
+            obs_d = None
+        c0 = np.zeros(D, dtype=np.float32)
+        c0cols = (C.c_void_p * D)()
+        keep = []
+        for k, v in enumerate(carry0):
+            if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.numel() > 1:
+                keep.append(v.to(device=self.device(), dtype=torch.float32).contiguous())
+                c0cols[k] = self._chk(keep[-1], torch.float32, n, f"carry0[{k}]").value
+            else:
+                c0[k] = float(v)
+        if out is None:
+            out = dict(values=[self.empty((T, n), dt) for dt in value_dtypes],
+                       score=self.empty(n, torch.float32) if want_score else None, logw=self.empty(n, torch.float32),
+                       carry=[self.empty(n, torch.float32) for _ in range(D)],
+                       max_partials=self.empty(self.num_max_partials(n), torch.float32),
+                       rows=RowStats(self.empty(self.num_max_partials(n), torch.int32),
+                                     self.empty(self.num_max_partials(n), torch.int64), n) if want_rows else None)
+        outs = (C.c_void_p * max(1, len(out["values"])))(*[t.data_ptr() for t in out["values"]])
+        couts = (C.c_void_p * D)(*[t.data_ptr() for t in out["carry"]])
+        keys = self._keys(kb, n)
+        io = abi.ScanIO()
+        io.particle_keys = C.cast(C.pointer(keys), C.c_void_p)
+        io.n, io.n_steps = n, T
+        io.obs = obs_d.data_ptr() if obs_d is not None else None
+        io.carry0 = c0.ctypes.data
+        io.carry0_cols = C.cast(c0cols, C.c_void_p)
+        io.value_cols, io.n_value_cols, io.col_stride = C.cast(outs, C.c_void_p), len(out["values"]), n
+        io.carry_out = C.cast(couts, C.c_void_p)
+        io.score = out["score"].data_ptr() if out["score"] is not None else None
+        io.logw = out["logw"].data_ptr()
+        io.max_partials = out["max_partials"].data_ptr()
+        if out["rows"] is not None:
+            io.row_e, io.row_s = out["rows"].e.data_ptr(), out["rows"].s.data_ptr()
+        self.lib.call("gjx_scan_run", plan.handle, C.byref(io), self.stream())
+        out["_keep"] = (obs_d, keep)
+        return out
+
     def smc_run_plan(self, plan: "SmcPlan", impl, n, step_keys, resample_keys, obs, want_ancestors=False,
                      ess_threshold: float = 0.0, tile_sums_form: int = 0, want_flags: bool = False):
         """`step_keys` / `resample_keys` [T, 2]: one filter -> (max [T], q [T], state columns [n], logw [n], ancestors
@@ -577,6 +648,22 @@ class SmcPlan:
         try:
             if self.handle:
                 self.ops.lib.call("gjx_smc_plan_destroy", self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class ScanPlan:
+    def __init__(self, ops: "Ops", handle, n_state: int, n_obs: int):
+        self.ops, self.handle, self.n_state, self.n_obs = ops, handle, n_state, n_obs
+
+    def compile_check(self, impl: int) -> int:
+        return self.ops.lib._gjx_scan_plan_compile_check(self.handle, impl)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.ops.lib.call("gjx_scan_plan_destroy", self.handle)
                 self.handle = None
         except Exception:
             pass

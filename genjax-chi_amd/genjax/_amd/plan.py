@@ -11,6 +11,13 @@ the same numbers bit for bit, only with one launch per site.
 Restricting the affine forms to at most one multiply and one add is deliberate: that is exactly
 the f32 operation sequence the column path would execute for the same expression, so both routes
 round identically.
+
+Structure versus data.  Scalar observations and scalar floating-point model arguments are lowered to
+LAUNCH-UNIFORM PARAMETERS (`GJX_ARG_PARAM`, `gjx_plan_set_params`), not to constants: the specialised kernel
+of a model is keyed by its structure alone, so the same model on another dataset (other observed values,
+other hyper-parameters) reuses the compiled kernel instead of paying a hiprtc compilation.  A body that does
+more with an argument than the affine forms above (`sigma ** 2`, `if mu > 0`) is traced a second time with
+its arguments as plain constants — same numbers, one compilation per distinct value.
 """
 
 from __future__ import annotations
@@ -42,6 +49,8 @@ class Sym:
     # -- affine algebra (one multiply, then one add — in that order) -------------------------------
     @staticmethod
     def _const(c):
+        if isinstance(c, ParamVal):
+            raise PlanUnsupported("a launch parameter combined with a traced site value")
         if isinstance(c, (bool, int, float)):
             return float(c)
         if isinstance(c, torch.Tensor) and c.dim() == 0:
@@ -82,6 +91,65 @@ class Sym:
         raise PlanUnsupported(f"torch.{getattr(func, '__name__', func)} on a traced site value")
 
 
+class ParamVal:
+    """A launch-uniform scalar (an observation, a scalar model argument, or host arithmetic on those): it carries the
+    concrete value and does its arithmetic on the host with the operands' own types — exactly what the per-site column
+    path would compute — but reaches the kernel as a PARAMETER, so its value is not part of the kernel's source.
+    Anything that would turn it into structure (a comparison, `float()`, an index, mixing with a traced site value)
+    raises `PlanUnsupported`; the body is then traced again with plain constants."""
+
+    __slots__ = ("value", "slot")
+
+    def __init__(self, value):
+        self.value, self.slot = value, None
+
+    @staticmethod
+    def _v(x):
+        if isinstance(x, ParamVal):
+            return x.value
+        if isinstance(x, (bool, int, float)) or (isinstance(x, torch.Tensor) and x.dim() == 0):
+            return x
+        return None
+
+    def _bin(op, swap=False):  # noqa: N805
+        def f(self, other):
+            o = ParamVal._v(other)
+            if o is None:
+                if isinstance(other, Sym):
+                    raise PlanUnsupported("a launch parameter combined with a traced site value")
+                return NotImplemented
+            return ParamVal(op(o, self.value) if swap else op(self.value, o))
+
+        return f
+
+    __add__, __radd__ = _bin(lambda a, b: a + b), _bin(lambda a, b: a + b, True)
+    __sub__, __rsub__ = _bin(lambda a, b: a - b), _bin(lambda a, b: a - b, True)
+    __mul__, __rmul__ = _bin(lambda a, b: a * b), _bin(lambda a, b: a * b, True)
+    __truediv__, __rtruediv__ = _bin(lambda a, b: a / b), _bin(lambda a, b: a / b, True)
+    __pow__, __rpow__ = _bin(lambda a, b: a ** b), _bin(lambda a, b: a ** b, True)
+    del _bin
+
+    def __neg__(self):
+        return ParamVal(-self.value)
+
+    def __abs__(self):
+        return ParamVal(abs(self.value))
+
+    def _no(self, *a, **k):
+        raise PlanUnsupported("a launch parameter used as structure")
+
+    __bool__ = __float__ = __int__ = __index__ = __lt__ = __le__ = __gt__ = __ge__ = __len__ = __iter__ = _no
+    __array__ = __floordiv__ = __rfloordiv__ = __mod__ = __rmod__ = _no
+    __hash__ = object.__hash__
+
+    def __eq__(self, other):
+        raise PlanUnsupported("a launch parameter used as structure")
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        raise PlanUnsupported(f"torch.{getattr(func, '__name__', func)} on a launch parameter")
+
+
 class _Table:
     """`table[sym]` with a 1-D constant table and an integer-valued site."""
 
@@ -94,9 +162,10 @@ _DIST_IDS = {id(normal): abi.DIST_NORMAL, id(gamma): abi.DIST_GAMMA, id(beta): a
 
 
 class PlanTracer(_Handler):
-    def __init__(self, constraint: ChoiceMap, n: int):
+    def __init__(self, constraint: ChoiceMap, n: int, use_params: bool = True):
         super().__init__()
-        self.constraint, self.n = constraint, n
+        self.constraint, self.n, self.use_params = constraint, n, use_params
+        self.params: list[float] = []  # launch-uniform parameter values (observations, model arguments)
         self.sites: list[abi.Site] = []
         self.meta: list[dict] = []  # per site: addr, gen_fn, args (symbolic), out_col, observed
         self.inputs: list[torch.Tensor] = []
@@ -104,10 +173,31 @@ class PlanTracer(_Handler):
         self.n_out = 0
 
     # -- argument encoding ---------------------------------------------------------------------------
+    def param_slot(self, pv: ParamVal) -> int:
+        """The parameter slot of `pv` (allocated on first use as a distribution argument / observed value)."""
+        if pv.slot is None:
+            if len(self.params) >= abi.MAX_PARAMS:
+                raise PlanUnsupported("too many launch parameters")
+            v = pv.value
+            self.params.append(float(torch.as_tensor(float(v) if not isinstance(v, torch.Tensor) else v,
+                                                     dtype=torch.float32)))
+            pv.slot = len(self.params) - 1
+        return pv.slot
+
+    def wrap_args(self, args):
+        """Top-level scalar floating-point model arguments become parameters (ints and bools stay Python values: they
+        are structure — loop bounds, switches)."""
+        if not self.use_params:
+            return tuple(args)
+        return tuple(ParamVal(a) if isinstance(a, float) or (isinstance(a, torch.Tensor) and a.dim() == 0
+                                                               and a.is_floating_point()) else a for a in args)
+
     def _arg(self, v) -> abi.Arg:
         if isinstance(v, Sym):
             kind = abi.ARG_SITE if v.src[0] == "site" else abi.ARG_INPUT
             return abi.Arg(kind, v.src[1], v.scale, v.offset, None)
+        if isinstance(v, ParamVal):
+            return abi.Arg(abi.ARG_PARAM, self.param_slot(v), 1.0, 0.0, None)
         if isinstance(v, _Table):
             return abi.Arg(abi.ARG_TABLE, v.idx.src[1], 0.0, 0.0, v.table.data_ptr())
         if isinstance(v, torch.Tensor) and v.dim() == 1 and v.shape[0] == self.n and self.n > 1:
@@ -150,7 +240,7 @@ class PlanTracer(_Handler):
             is_int = True
         elif isinstance(gen_fn, Categorical):
             kind, v = args[0] if isinstance(args[0], tuple) else ("logits", args[0])
-            if isinstance(v, (Sym, _Table)):
+            if isinstance(v, (Sym, _Table, ParamVal)):
                 raise PlanUnsupported("data-dependent categorical parameters")
             logits = Categorical._logits((kind, v), self.n)
             if logits.shape[0] != 1:
@@ -165,11 +255,17 @@ class PlanTracer(_Handler):
         else:
             raise PlanUnsupported(f"distribution {gen_fn!r} has no fused sampler")
         idx = len(self.sites)
+        obs_sym = None
         if obs is not None:
             if isinstance(obs, torch.Tensor) and obs.dim() == 1 and obs.shape[0] == self.n and self.n > 1:
                 site.obs = abi.Arg(abi.ARG_INPUT, self._input(obs.to(torch.float32)), 1.0, 0.0, None)
             else:
-                site.obs = abi.Arg(abi.ARG_CONST, 0, 0.0, Sym._const(obs) if not isinstance(obs, bool) else float(obs), None)
+                if self.use_params and not isinstance(obs, ParamVal):
+                    Sym._const(obs)  # (rejects non-scalars)
+                    obs_sym = ParamVal(obs)
+                    site.obs = abi.Arg(abi.ARG_PARAM, self.param_slot(obs_sym), 1.0, 0.0, None)
+                else:
+                    site.obs = abi.Arg(abi.ARG_CONST, 0, 0.0, float(Sym._const(obs)), None)
         else:
             site.out_col = self.n_out
             self.n_out += 1
@@ -181,7 +277,7 @@ class PlanTracer(_Handler):
             # a constrained value may feed later sites: constants stay constants, columns become inputs
             if isinstance(obs, torch.Tensor) and obs.dim() == 1 and obs.shape[0] == self.n and self.n > 1:
                 return Sym(self, ("input", site.obs.ref), is_int=is_int)
-            return obs
+            return obs if obs_sym is None else obs_sym
         return _IntSym(self, ("site", idx)) if is_int else Sym(self, ("site", idx))
 
 
@@ -212,7 +308,7 @@ class TableProxy:
 
 
 def _contains_sym(v) -> bool:
-    if isinstance(v, (Sym, _Table)):
+    if isinstance(v, (Sym, _Table, ParamVal)):
         return True
     if isinstance(v, (tuple, list)):
         return any(_contains_sym(x) for x in v)
@@ -221,21 +317,40 @@ def _contains_sym(v) -> bool:
     return False
 
 
+def _trace(gen_fn, constraint: ChoiceMap, n: int, args):
+    """-> (tracer, retval) of the body, observations and scalar arguments as launch parameters when the body only
+    uses them affinely, as constants otherwise; None when the body is not plan-able at all."""
+    for use_params in (True, False):
+        tracer = PlanTracer(constraint, n, use_params)
+        try:
+            retval = tracer.run(gen_fn.source, tracer.wrap_args(args))
+        except Exception:
+            # PlanUnsupported, or any error provoked by feeding symbolic values to code that expects
+            # tensors: the column path re-runs the body and raises genuine model errors itself.
+            continue
+        if not tracer.sites:
+            return None
+        return tracer, retval
+    return None
+
+
+def _make_plan(tracer):
+    plan = get_ops().plan_create(tracer.sites)
+    if tracer.params:
+        plan.set_params(tracer.params)
+    return plan
+
+
 def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
     """-> (trace, weight) through the fused kernel, or None when the body is not plan-able."""
     if pk.kb.fold is not None or any(_needs_eager(a) for a in args):
         return None
-    tracer = PlanTracer(constraint, pk.n)
-    try:
-        retval = tracer.run(gen_fn.source, args)
-    except Exception:
-        # PlanUnsupported, or any error provoked by feeding symbolic values to code that expects
-        # tensors: the column path re-runs the body and raises genuine model errors itself.
+    traced = _trace(gen_fn, constraint, pk.n, args)
+    if traced is None:
         return None
-    if not tracer.sites:
-        return None
+    tracer, retval = traced
     ops = get_ops()
-    plan = ops.plan_create(tracer.sites)
+    plan = _make_plan(tracer)
     dtypes = [torch.float32] * tracer.n_out
     for m in tracer.meta:
         if m["out_col"] >= 0 and m["is_int"]:
@@ -255,6 +370,8 @@ def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
     def resolve(x):
         if isinstance(x, Sym):
             base = site_vals[x.src[1]] if x.src[0] == "site" else tracer.inputs[x.src[1]]
+            if not (x.has_mul or x.has_add):
+                return base  # the value itself, in its presented dtype (bool for flip, int32 for categorical)
             base = base.to(torch.float32) if isinstance(base, torch.Tensor) else float(base)
             out = base
             if x.has_mul:
@@ -264,6 +381,8 @@ def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
             return out
         if isinstance(x, _Table):
             return x.table[site_vals[x.idx.src[1]].long()]
+        if isinstance(x, ParamVal):
+            return x.value
         if isinstance(x, tuple):
             return tuple(resolve(y) for y in x)
         if isinstance(x, list):
@@ -287,15 +406,12 @@ def fused_log_weights_batch(gen_fn, pks: list, constraint: ChoiceMap, args):
     n = pks[0].n
     if any(pk.n != n or pk.kb.fold is not None or pk.kb.mode != 1 for pk in pks) or any(_needs_eager(a) for a in args):
         return None
-    tracer = PlanTracer(constraint, n)
-    try:
-        tracer.run(gen_fn.source, args)
-    except Exception:
+    traced = _trace(gen_fn, constraint, n, args)
+    if traced is None:
         return None
-    if not tracer.sites:
-        return None
+    tracer = traced[0]
     ops = get_ops()
-    plan = ops.plan_create(tracer.sites)
+    plan = _make_plan(tracer)
     dtypes = [torch.float32] * tracer.n_out
     for m in tracer.meta:
         if m["out_col"] >= 0 and m["is_int"]:

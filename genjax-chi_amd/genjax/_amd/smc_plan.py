@@ -48,7 +48,7 @@ class _SmcTracer(PlanTracer):
     """PlanTracer whose observed sites read per-step observation constants."""
 
     def __init__(self, obs_index: dict):
-        super().__init__(ChoiceMap.empty(), 1)
+        super().__init__(ChoiceMap.empty(), 1, use_params=False)
         self.obs_index = obs_index
 
     def _arg(self, v) -> abi.Arg:

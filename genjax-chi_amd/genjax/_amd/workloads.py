@@ -216,6 +216,60 @@ def lgssm_smc(ops: Ops, impl: int, seed: int, n: int, T: int, want_ancestors: bo
 # ---------------------------------------------------------------------------------------------
 # C5: HMM with circulant logits (construction of distributions/custom/discrete_hmm.py:42-86)
 # ---------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------
+# C3 as the reference literally runs it when given ImportanceK over `step.scan(n=T)` (no resampling,
+# [N, T] leaves; scan.py:237-294): the whole scan of every particle in one launch (gjx_scan_run)
+# ---------------------------------------------------------------------------------------------
+def lgssm_scan_sites():
+    """Site table of the scan kernel
+        @gen
+        def step(x, _):
+            x2 = normal(a * x, q) @ "x"
+            normal(x2, r) @ "y"            # constrained to y[t]
+            return x2, x2
+    -> (sites, next_state)."""
+    m = LGSSM
+    x = abi.Site()
+    x.dist, x.observed, x.out_col = abi.DIST_NORMAL, 0, 0
+    x.arg[0] = abi.Arg(abi.ARG_STATE, 0, m["a"], 0.0, None)
+    x.arg[1] = abi.Arg(abi.ARG_CONST, 0, 0.0, m["q"], None)
+    y = abi.Site()
+    y.dist, y.observed, y.out_col = abi.DIST_NORMAL, 1, -1
+    y.arg[0] = abi.Arg(abi.ARG_SITE, 0, 1.0, 0.0, None)
+    y.arg[1] = abi.Arg(abi.ARG_CONST, 0, 0.0, m["r"], None)
+    y.obs = abi.Arg(abi.ARG_OBS, 0, 1.0, 0.0, None)
+    return [x, y], [abi.Arg(abi.ARG_SITE, 0, 1.0, 0.0, None)]
+
+
+class LgssmScan:
+    """Reusable state of the scan-importance workload (plan, keys, observation table, output buffers)."""
+
+    def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, fast_math: bool = False, x0: float = 0.0):
+        self.ops, self.impl, self.n, self.T, self.x0 = ops, impl, n, T, x0
+        sites, nxt = lgssm_scan_sites()
+        self.plan = ops.scan_plan_create(sites, nxt, 1, fast_math=fast_math)
+        self.y = lgssm_data(T)
+        self.obs = torch.from_numpy(self.y.reshape(T, 1).copy()).to(ops.device())
+        self.kb = importance_particle_keys(prng.key(seed, impl), n)
+        self.out = None
+
+    def run(self):
+        self.out = self.ops.scan_run(self.plan, self.kb, self.n, self.T, self.obs, [self.x0], [torch.float32], out=self.out)
+        return self.out
+
+    def result(self):
+        o = self.out
+        lse, e, q = self.ops.lse_rows(o["rows"])
+        return dict(x=o["values"][0], logw=o["logw"], score=o["score"], carry=o["carry"][0], max_partials=o["max_partials"],
+                    row_e=o["rows"].e, row_s=o["rows"].s, log_z=Ops.log_z_from_rows(e, q, self.n))
+
+
+def lgssm_scan(ops: Ops, impl: int, seed: int, n: int, T: int, **kw):
+    wl = LgssmScan(ops, impl, seed, n, T, **kw)
+    wl.run()
+    return wl.result()
+
+
 def scaled_circulant(n: int, k: int, epsilon: float, delta: float) -> np.ndarray:
     """Row-circulant matrix whose first column is eps^|i| within distance k of the diagonal
     (wrapping) and -delta elsewhere — restated from the reference's description, float32."""

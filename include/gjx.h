@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define GJX_VERSION_MAJOR 0
-#define GJX_VERSION_MINOR 3
+#define GJX_VERSION_MINOR 4
 
 typedef void* gjx_stream; /* hipStream_t; ignored by the oracle build */
 
@@ -225,6 +225,12 @@ int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t b
  * GJX_OK and does nothing. */
 int gjx_plan_prepare(gjx_plan* p, const gjx_keys* particle_keys);
 int gjx_plan_compile_check(const gjx_plan* p, int impl);
+/* Counters of the run-time specialisation cache (libgjx_hip.so; the oracle reports zeros): hiprtc compilations so far,
+ * code objects currently loaded, code objects unloaded.  Modules are keyed by their generated source — the model's
+ * STRUCTURE (values that arrive as GJX_ARG_PARAM are kernel arguments, not source) — reference-counted by the plans
+ * using them, and unreferenced ones are kept for reuse up to GJX_JIT_CACHE_MAX (default 64) entries, then unloaded
+ * least-recently-used first.  Each output nullable. */
+int gjx_jit_stats(uint64_t* compiles, uint64_t* cached_modules, uint64_t* evictions);
 /* particle_keys: the per-particle keys BEFORE the per-site fold (has_fold must be 0).
  * input_cols / value_cols: host arrays of dev pointers (each column dev [n], 4-byte elements:
  * f32, or int32 for Bernoulli/Categorical values; at most 16 input columns).  score, logw: dev
@@ -521,6 +527,46 @@ int gjx_smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, co
 int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host,
                      float* out_max, uint64_t* out_q, float* const* state_out, float* logw_out,
                      int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s);
+
+/* ---- importance over a `Scan` (state-space) model: the whole T-step walk in ONE launch --------- *
+ * Replaces Scan.generate (generative_functions/combinators/scan.py:237-294) under ImportanceK (no resampling): particle
+ * i runs `kernel(carry, x_t) -> (carry', y_t)` for t = 0 .. T-1 with the CHAINED key key_t = fold_in(key_{t-1}, t),
+ * key_{-1} = its particle key (scan.py:267-268, 276: the folded key is carried), and step t walks `step_sites` with
+ * key_t exactly as gjx_importance_run walks a plan with that particle key.  GJX_ARG_STATE reads the carry, GJX_ARG_OBS
+ * this step's row of `obs` (observed values and scanned inputs x_t alike), `next_state` gives the new carry.
+ * weight = ((0 + w_0) + w_1) + ..., score likewise — the f32 sums of scan.py:290, 293 in time order.  The carry and
+ * the key chain live in registers; every sampled value is stored TIME-MAJOR, value_cols[c][t * col_stride + i] (each
+ * step's store is one coalesced row), the layout the reference's vmapped ScanTrace presents transposed as [N, T]. */
+typedef struct {
+  const gjx_site* step_sites;
+  int32_t n_step_sites;
+  gjx_arg next_state[GJX_SMC_MAX_STATE]; /* carry k after a step (CONST/SITE/STATE/OBS) */
+  int32_t n_state;
+  int32_t n_obs;
+} gjx_scan_model;
+typedef struct gjx_scan_plan gjx_scan_plan;
+int gjx_scan_plan_create(const gjx_scan_model* m /*host*/, uint32_t flags /* GJX_PLAN_* */, gjx_scan_plan** out);
+int gjx_scan_plan_destroy(gjx_scan_plan* p);
+int gjx_scan_plan_compile_check(const gjx_scan_plan* p, int impl); /* offline hiprtc compile, needs no GPU */
+typedef struct {
+  const gjx_keys* particle_keys;   /* before the chain; has_fold must be 0 */
+  uint64_t n;                      /* particles */
+  int32_t n_steps;                 /* T >= 1 */
+  const float* obs;                /* dev f32[T, n_obs] (nullable iff n_obs == 0) */
+  const float* carry0;             /* host f32[n_state]: the initial carry where carry0_cols[k] is null */
+  const float* const* carry0_cols; /* nullable; host array of n_state nullable dev f32[n] (per-particle initial carry) */
+  void* const* value_cols;         /* host array of dev [T, col_stride] 4-byte columns (f32 / int32), as gjx_importance_run */
+  int32_t n_value_cols;
+  uint64_t col_stride;             /* >= n */
+  float* const* carry_out;         /* nullable; host array of n_state nullable dev f32[n]: the final carry */
+  float* score;                    /* nullable dev f32[n] */
+  float* logw;                     /* dev f32[n] */
+  float* max_partials;             /* nullable, as gjx_importance_run */
+  int32_t* row_e;                  /* nullable (with row_s), as gjx_importance_run */
+  uint64_t* row_s;
+  const gjx_lse_out* lse;          /* nullable; needs row_e / row_s */
+} gjx_scan_io;
+int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s);
 
 /* HMM tables.  trans_alias: dev u32[gjx_hmm_alias_words(K)] = K rows of K packed alias-table entries
  * (threshold24 << 8) | alias built from the row's fixed-point softmax weights: the next state

@@ -364,6 +364,12 @@ int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t b
   return GJX_ERR_UNSUPPORTED;
 }
 int gjx_plan_compile_check(const gjx_plan* p, int impl) { (void)p; (void)impl; return GJX_ERR_UNSUPPORTED; }
+int gjx_jit_stats(uint64_t* compiles, uint64_t* cached_modules, uint64_t* evictions) {
+  if (compiles) *compiles = 0;
+  if (cached_modules) *cached_modules = 0;
+  if (evictions) *evictions = 0;
+  return GJX_OK;
+}
 
 typedef struct { float f; int32_t i; int is_int; } site_val;
 
@@ -1275,6 +1281,98 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
 }
 int gjx_smc_plan_destroy(gjx_smc_plan* p) { free(p); return GJX_OK; }
 int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl) { (void)p; (void)impl; return GJX_ERR_UNSUPPORTED; }
+
+/* ---- importance over a Scan model (scan.py:237-294): per particle, T steps with the chained key ---- */
+struct gjx_scan_plan {
+  gjx_scan_model m;
+  gjx_site step_sites[GJX_MAX_SITES];
+};
+int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan** out) {
+  if (!m || !out || (flags & ~(uint32_t)GJX_PLAN_FAST_MATH) || m->n_state < 1 || m->n_state > GJX_SMC_MAX_STATE ||
+      m->n_obs < 0 || m->n_obs > GJX_SMC_MAX_OBS)
+    return GJX_ERR_INVALID;
+  if (!smc_sites_ok(m->step_sites, m->n_step_sites, m->n_state, m->n_obs, 1)) return GJX_ERR_INVALID;
+  for (int k = 0; k < m->n_state; ++k)
+    if (!smc_arg_ok(&m->next_state[k], m->n_step_sites, m->n_state, m->n_obs, 1) || m->next_state[k].kind == GJX_ARG_TABLE)
+      return GJX_ERR_INVALID;
+  gjx_scan_plan* p = (gjx_scan_plan*)malloc(sizeof(gjx_scan_plan));
+  if (!p) return GJX_ERR_LAUNCH;
+  p->m = *m;
+  memcpy(p->step_sites, m->step_sites, sizeof(gjx_site) * (size_t)m->n_step_sites);
+  p->m.step_sites = p->step_sites;
+  *out = p;
+  return GJX_OK;
+}
+int gjx_scan_plan_destroy(gjx_scan_plan* p) { free(p); return GJX_OK; }
+int gjx_scan_plan_compile_check(const gjx_scan_plan* p, int impl) { (void)p; (void)impl; return GJX_ERR_UNSUPPORTED; }
+int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
+  if (!p || !io || !keys_ok(io->particle_keys) || io->particle_keys->has_fold || !io->logw || io->n_steps < 1 ||
+      io->col_stride < io->n || (p->m.n_obs > 0 && !io->obs) || !io->carry0 || io->n_value_cols < 0 ||
+      io->n_value_cols > GJX_MAX_SITES || ((io->row_e == NULL) != (io->row_s == NULL)) ||
+      (io->lse && (!io->row_e || !io->lse->tickets)))
+    return GJX_ERR_INVALID;
+  const gjx_scan_model* m = &p->m;
+  for (int q = 0; q < m->n_step_sites; ++q) {
+    const gjx_site* st = &m->step_sites[q];
+    if (st->out_col >= io->n_value_cols || (st->out_col >= 0 && !io->value_cols[st->out_col])) return GJX_ERR_INVALID;
+  }
+  const int D = m->n_state, impl = io->particle_keys->impl;
+  const uint64_t n = io->n;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    walk_ctx c;
+    memset(&c, 0, sizeof c);
+    c.impl = impl;
+    c.pair_normals = 1;
+    c.i = (uint64_t)i;
+    uint32_t key[4];
+    key_at(io->particle_keys, (uint64_t)i, key);
+    float st[GJX_SMC_MAX_STATE], wt = 0.0f, sct = 0.0f;
+    for (int k = 0; k < D; ++k)
+      st[k] = (io->carry0_cols && io->carry0_cols[k]) ? io->carry0_cols[k][i] : io->carry0[k];
+    for (int t = 0; t < io->n_steps; ++t) {
+      uint32_t kt[4];
+      o_fold_in(impl, key, (uint32_t)t, kt); /* chained: the folded key is carried (scan.py:267-268, 276) */
+      memcpy(key, kt, sizeof key);
+      memcpy(c.pkey, key, sizeof key);
+      c.state = st;
+      c.obs = m->n_obs ? io->obs + (size_t)t * (size_t)m->n_obs : NULL;
+      site_val vals[GJX_MAX_SITES];
+      float w, sc;
+      site_walk(m->step_sites, m->n_step_sites, &c, vals, &w, &sc);
+      for (int q = 0; q < m->n_step_sites; ++q) {
+        const gjx_site* sq = &m->step_sites[q];
+        if (sq->out_col < 0) continue;
+        const size_t at = (size_t)t * io->col_stride + (size_t)i;
+        if (vals[q].is_int) ((int32_t*)io->value_cols[sq->out_col])[at] = vals[q].i;
+        else ((float*)io->value_cols[sq->out_col])[at] = vals[q].f;
+      }
+      float nx[GJX_SMC_MAX_STATE];
+      for (int k = 0; k < D; ++k) nx[k] = eval_arg(&m->next_state[k], vals, &c);
+      for (int k = 0; k < D; ++k) st[k] = nx[k];
+      wt = wt + w;   /* scan.py:293 */
+      sct = sct + sc; /* scan.py:290 */
+    }
+    for (int k = 0; k < D; ++k)
+      if (io->carry_out && io->carry_out[k]) io->carry_out[k][i] = st[k];
+    io->logw[i] = wt;
+    if (io->score) io->score[i] = sct;
+  }
+  if (io->max_partials) {
+    for (uint64_t b = 0; b * O_ROW < n; ++b) {
+      float mx = -INFINITY;
+      for (uint64_t i = b * O_ROW; i < n && i < (b + 1) * O_ROW; ++i) mx = io->logw[i] > mx ? io->logw[i] : mx;
+      io->max_partials[b] = mx;
+    }
+  }
+  if (io->row_e && io->row_s) {
+    int rc = gjx_row_stats(io->logw, n, io->row_e, io->row_s, s);
+    if (rc || !io->lse) return rc;
+    return gjx_lse_rows(io->row_e, io->row_s, gjx_num_max_partials(n), io->lse->e, io->lse->q, io->lse->lse,
+                        io->lse->record, s);
+  }
+  return GJX_OK;
+}
 
 static int smc_run_plan_one(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
                             uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out);

@@ -380,6 +380,80 @@ def _dev():
     return get_ops().device()
 
 
+# ---- structure vs data: observations and scalar arguments are launch parameters -----------------------
+def case_params_equal_constants(impl):
+    """The same model on several datasets: (a) lowering observations / scalar arguments to GJX_ARG_PARAM gives the very
+    bits the constant-folded plan gives, (b) a body that uses an argument non-affinely is traced with constants
+    instead (and still fuses), (c) on the HIP build, a new dataset costs no compilation."""
+    from genjax._amd import plan as P
+    from genjax._amd.runtime import get_ops
+
+    @gen
+    def model(a, s):
+        p = beta(2.0, a) @ "p"
+        v = flip(p) @ "v"
+        g = gamma(a * 0.5 + 0.2, p * 2.0 + 0.5) @ "g"
+        x = normal(g * 0.5, s) @ "x"
+        y = normal(x - 1.0, 0.5) @ "y"
+        z = normal(y * 2.0, s * 3.0) @ "z"  # an observed value feeding a later site
+        return y
+
+    @gen
+    def curved(s):
+        x = normal(0.0, s ** 2) @ "x"
+        y = normal(x, 1.0) @ "y"
+        return x
+
+    n = 3000
+    keys = genjax.random.split(genjax.random.key(11, impl), n)
+    ops = get_ops()
+
+    def run(args, chm, use_params):
+        orig = P.PlanTracer.__init__
+
+        def init(self, constraint, n_, use_params_=True):
+            orig(self, constraint, n_, use_params_ and use_params)
+
+        P.PlanTracer.__init__ = init
+        try:
+            out = try_fused_generate(model, keys, chm, args)
+        finally:
+            P.PlanTracer.__init__ = orig
+        assert out is not None
+        tr, w = out
+        ch = tr.get_choices()
+        return w, tr.get_score(), ch["p"], ch["g"], ch["x"], tr.get_retval()
+
+    datasets = [((3.0, 1.5), C["y"].set(0.25) | C["z"].set(-0.5) | C["v"].set(True)),
+                ((2.25, 0.75), C["y"].set(-1.5) | C["z"].set(2.0) | C["v"].set(False)),
+                ((7.0, 0.3), C["y"].set(3.25) | C["z"].set(0.125) | C["v"].set(True))]
+    run(*datasets[0], True)  # (compiles the structure's kernel on the HIP build)
+    before = ops.jit_stats()
+    for args, chm in datasets:
+        a, b = run(args, chm, True), run(args, chm, False)
+        for u, v in zip(a, b):
+            if isinstance(u, torch.Tensor):
+                assert torch.equal(u, v)
+            else:
+                assert u == v
+    after = ops.jit_stats()
+    if ops.lib.device_type == "cuda":
+        # the three constant-folded plans compile (at most) three kernels; the parameterised plan none
+        assert after["compiles"] - before["compiles"] <= 3
+        c0 = ops.jit_stats()["compiles"]
+        run((1.125, 2.5), C["y"].set(0.7) | C["z"].set(0.9) | C["v"].set(True), True)
+        assert ops.jit_stats()["compiles"] == c0, "a new dataset must not recompile the model's kernel"
+    # non-affine use of an argument: second trace, with constants
+    out = try_fused_generate(curved, keys, C["y"].set(0.5), (1.5,))
+    assert out is not None
+    tr, w = out
+    from genjax._amd.lang import GenerateHandler
+
+    h = GenerateHandler(keys, C["y"].set(0.5))
+    h.run(curved.source, (1.5,))
+    assert torch.equal(w, h.weight)
+
+
 # ---- ParticleCollection / ChangeTarget / CSMC ---------------------------------------------------------
 def case_particle_collection(impl):
     @gen
@@ -504,6 +578,94 @@ def case_scan(impl):
 
 
 # ---- vmap / repeat (tests/generative_functions/test_vmap_combinator.py:60-79) ---------------------------
+def case_scan_fused_equals_loop(impl):
+    """The one-launch scan (`gjx_scan_run`) against the host loop of per-site launches (scan.py:237-294): same key
+    chain, same arithmetic -> the same trace, weights, score and return value, bit for bit; plus ImportanceK over a
+    `.scan(n=T)` target end to end."""
+    from genjax._amd import combinators as CB
+
+    @gen
+    def lg_step(x, _):
+        x2 = normal(0.9 * x, 1.0) @ "x"
+        _ = normal(x2, 0.5) @ "y"
+        return x2, x2
+
+    @gen
+    def rich_step(carry, u):  # tuple carry, a scanned input, discrete and positive sites, an output built from a site
+        x, s = carry
+        b = flip(0.3) @ "b"
+        g = gamma(2.0, 1.5) @ "g"
+        x2 = normal(0.5 * x, u) @ "x"  # (an argument is affine in ONE traced value: plan.py)
+        p = beta(2.0, 3.0) @ "p"
+        _ = normal(x2 * 2.0, 1.25) @ "y"
+        _ = flip(p) @ "z"
+        return (x2, s - 1.0), (g * 0.5 + 1.0, b)
+
+    n, T = 3000, 9
+    keys = genjax.random.split(genjax.random.key(21, impl), n)
+    ys = torch.linspace(-1.0, 1.5, T)
+    us = torch.linspace(0.5, 1.25, T).to(_dev())
+    zs = torch.tensor([True, False, True, True, False, False, True, False, True])
+    x0 = torch.linspace(-2.0, 2.0, n).to(_dev())
+    runs = [(lg_step.scan(n=T), C["y"].set(ys), (0.0, None)),
+            (lg_step.scan(n=T), C[torch.arange(T), "y"].set(ys), (x0, None)),  # per-particle initial carry
+            (lg_step.scan(n=T), C.n(), (0.25, None)),
+            (rich_step.scan(), C["y"].set(ys) | C["z"].set(zs), ((0.5, 3.0), us)),
+            (rich_step.scan(), C["y"].set(ys), ((x0, 1.0), us))]
+
+    def same(a, b):
+        if isinstance(a, (tuple, list)):
+            return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+            a, b = torch.as_tensor(a), torch.as_tensor(b)
+            return a.shape == b.shape and a.dtype == b.dtype and torch.equal(a.cpu(), b.cpu())
+        return a == b
+
+    for model, chm, args in runs:
+        out = {}
+        for fused in (True, False):
+            CB.FUSED_SCAN = fused
+            try:
+                tr, w = model.generate(keys, chm, args)
+                sim = model.simulate(keys, args)
+            finally:
+                CB.FUSED_SCAN = True
+            assert isinstance(tr, CB.FusedScanTrace) == fused and isinstance(sim, CB.FusedScanTrace) == fused
+            out[fused] = (tr, w, sim)
+        (ta, wa, sa), (tb, wb, sb) = out[True], out[False]
+        wb = wb if isinstance(wb, torch.Tensor) else torch.zeros(n, device=_dev()) + wb
+        assert same(wa, wb) and same(ta.get_score(), tb.get_score()) and same(ta.get_retval(), tb.get_retval())
+        ca, cb = dict(ta.get_choices().leaves()), dict(tb.get_choices().leaves())
+        assert ca.keys() == cb.keys()
+        for k in ca:
+            assert same(ca[k], cb[k]), k
+        assert same(sa.get_score(), sb.get_score()) and same(sa.get_retval(), sb.get_retval())
+        for k, v in dict(sa.get_choices().leaves()).items():
+            assert same(v, dict(sb.get_choices().leaves())[k]), k
+        # the general ScanTrace methods work on the fused trace (per-step traces rebuilt on demand)
+        pa, pb = ta.project(keys, S["x"]), tb.project(keys, S["x"])
+        assert torch.allclose(torch.as_tensor(pa), torch.as_tensor(pb), atol=1e-4)
+        idx = torch.arange(0, n, 7, device=_dev())
+        sub = ta.map_leaves(lambda v: v[idx] if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == n else v)
+        assert same(sub.get_choices()["x"], ta.get_choices()["x"][idx]) and same(sub.get_score(), ta.get_score()[idx])
+    # ImportanceK over a scan target: exact log-marginal of the linear-Gaussian chain (Kalman filter, float64)
+    T = 5
+    ys = torch.tensor([0.3, -0.2, 0.5, 0.1, -0.4])
+    target = Target(lg_step.scan(n=T), (0.0, None), C["y"].set(ys))
+    coll = ImportanceK(target, k_particles=200_000).run_smc(genjax.random.key(4, impl))
+    m, p, logz = 0.0, 0.0, 0.0
+    for y in ys.tolist():
+        m, p = 0.9 * m, 0.81 * p + 1.0
+        s = p + 0.25
+        logz += _lpdf(y, m, math.sqrt(s))
+        k = p / s
+        m, p = m + k * (y - m), (1 - k) * p
+    assert f(coll.get_log_marginal_likelihood_estimate()) == pytest.approx(logz, abs=0.02)
+    assert isinstance(coll.get_particles(), CB.FusedScanTrace)
+    part = coll.sample_particle(genjax.random.key(5, impl))
+    assert tuple(part.get_choices()["x"].shape) == (T,)
+
+
 def case_vmap(impl):
     @gen
     def point(x, s):
@@ -894,6 +1056,6 @@ def case_general_smc(impl):
 
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
-             case_static_gen_fn, case_distributions, case_fused_equals_eager, case_particle_collection, case_custom_proposal,
-             case_scan, case_vmap, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
+             case_static_gen_fn, case_distributions, case_fused_equals_eager, case_params_equal_constants, case_particle_collection, case_custom_proposal,
+             case_scan, case_scan_fused_equals_loop, case_vmap, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
              case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update]

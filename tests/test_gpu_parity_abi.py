@@ -3,6 +3,8 @@ seeded inputs.  Integer / index outputs and — because the math spec fixes ever
 outputs are compared BIT-EXACTLY (tolerance 0), which is stronger than the north star's 1e-5
 relative bound on log-weights."""
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -587,6 +589,87 @@ def test_smc_plans(hip_ops, oracle_ops, impl):
     gen_ = hip_ops.smc_run_plan(hl, impl, n, sk, rk, y, True)
     same(gen_[1], fixed[1], "generated vs hand-written LGSSM q"); same(gen_[2][0], fixed[2], "particles")
     same(gen_[4], fixed[4], "ancestors")
+
+
+def _scan_plans(ops):
+    """(the LGSSM scan kernel, a two-component carry with gamma / beta / bernoulli sites, an input and two observations)."""
+    A = abi.Arg
+    c = lambda v: A(abi.ARG_CONST, 0, 0.0, v, None)
+
+    def site(dist, out_col, a0, a1=None, obs=None):
+        s_ = abi.Site()
+        s_.dist, s_.observed, s_.out_col = dist, 0 if obs is None else 1, out_col
+        s_.arg[0] = a0
+        if a1 is not None:
+            s_.arg[1] = a1
+        if obs is not None:
+            s_.obs = obs
+        return s_
+
+    sites, nxt = W.lgssm_scan_sites()
+    lg = ops.scan_plan_create(sites, nxt, 1)
+    rich = ops.scan_plan_create(
+        [site(abi.DIST_NORMAL, 0, A(abi.ARG_STATE, 0, 0.8, 0.0, None), A(abi.ARG_OBS, 2, 1.0, 0.0, None)),
+         site(abi.DIST_GAMMA, 1, c(0.6), A(abi.ARG_STATE, 1, 1.0, 1.0, None)),
+         site(abi.DIST_BERNOULLI, 2, c(0.3)),
+         site(abi.DIST_BETA, 3, c(2.0), A(abi.ARG_SITE, 2, 1.5, 0.5, None)),
+         site(abi.DIST_NORMAL, -1, A(abi.ARG_SITE, 0, 1.0, 0.0, None), A(abi.ARG_SITE, 3, 1.0, 0.2, None), A(abi.ARG_OBS, 0, 1.0, 0.0, None)),
+         site(abi.DIST_BERNOULLI, -1, A(abi.ARG_SITE, 3, 1.0, 0.0, None), None, A(abi.ARG_OBS, 1, 1.0, 0.0, None))],
+        [A(abi.ARG_SITE, 0, 1.0, 0.0, None), A(abi.ARG_SITE, 1, 0.5, 0.1, None)], 3)
+    return lg, rich
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n,T", [(70004, 13), (5000, 40), (257, 1)])
+def test_scan_run(hip_ops, oracle_ops, impl, n, T):
+    """gjx_scan_run (Scan.generate under ImportanceK, scan.py:237-294) — the whole T-step walk of every particle in one
+    launch — against the oracle: time-major value columns, weights, scores, final carry, row maxima and row-anchored
+    sums, with lazy and materialised particle keys and a per-particle initial carry."""
+    from genjax._amd import prng
+
+    y = W.lgssm_data(T)
+    obs3 = np.stack([y, (np.arange(T) % 2).astype(np.float32), np.linspace(0.5, 1.5, T).astype(np.float32)], axis=1)
+    kb = W.importance_particle_keys(prng.key(3, impl), n)
+    x0 = torch.linspace(-1.0, 1.0, n)
+    hl, hr = _scan_plans(hip_ops)
+    ol, orr = _scan_plans(oracle_ops)
+    runs = [(hl, ol, y.reshape(T, 1), [0.25], [torch.float32]),
+            (hl, ol, y.reshape(T, 1), [x0], [torch.float32]),
+            (hr, orr, obs3, [x0, 0.5], [torch.float32, torch.float32, torch.int32, torch.float32])]
+    for hp, op_, obs, c0, dts in runs:
+        for keys in (kb, "explicit"):
+            got, want = [], []
+            for ops, plan, dst in ((hip_ops, hp, got), (oracle_ops, op_, want)):
+                k = keys
+                if keys == "explicit":
+                    k = KeyBatch(impl, 0, tensor=ops.rng_keys(kb, n))
+                c0d = [v.to(ops.device()) if isinstance(v, torch.Tensor) else v for v in c0]
+                o = ops.scan_run(plan, k, n, T, obs, c0d, dts)
+                dst.extend(o["values"] + o["carry"] + [o["score"], o["logw"], o["max_partials"], o["rows"].e, o["rows"].s])
+            for i, (a, b) in enumerate(zip(got, want)):
+                same(a, b, f"scan output {i}")
+
+
+def test_scan_full_size(hip_ops):
+    """N = 1e6, T = 100 (the reference's literal config-3 semantics under ImportanceK): weights and scores of the
+    one-launch scan agree with a float64 recomputation from the stored [T, N] trajectories."""
+    n, T = 1_000_000, 100
+    m = W.LGSSM
+    for impl in IMPLS:
+        r = W.lgssm_scan(hip_ops, impl, seed=2, n=n, T=T)
+        x = r["x"].double()  # [T, n]
+        y = torch.from_numpy(W.lgssm_data(T)).to(x.device).double()[:, None]
+        prev = torch.cat([torch.zeros(1, n, device=x.device, dtype=torch.float64), x[:-1]], 0)
+        lp = lambda v, mu, s: -0.5 * ((v - mu) / s) ** 2 - math.log(s) - 0.5 * math.log(2 * math.pi)
+        w = lp(y, x, m["r"]).sum(0)
+        sc = w + lp(x, m["a"] * prev, m["q"]).sum(0)
+        assert float((r["logw"].double() - w).abs().max()) < 2e-3 * T ** 0.5
+        assert float((r["score"].double() - sc).abs().max()) < 4e-3 * T ** 0.5
+        assert torch.equal(r["carry"], r["x"][-1])
+        ref = float(torch.logsumexp(r["logw"].double(), 0).cpu()) - np.log(n)
+        assert abs(r["log_z"] - ref) < 1e-5
+        std = x.std(1)  # the prior's stationary spread: 1 / sqrt(1 - a^2)
+        assert abs(float(std[-1]) - 1.0 / math.sqrt(1.0 - m["a"] ** 2)) < 0.02
 
 
 def test_full_size_properties(hip_ops):

@@ -129,3 +129,15 @@ def test_smc_plan_compiles(hip_lib_nogpu, impl):
     with pytest.raises(abi.GjxError):  # a STATE reference is not allowed in the init table
         ops.smc_plan_create([site(abi.DIST_NORMAL, A(abi.ARG_STATE, 0, 1.0, 0.0, None), c(1.0))],
                             [site(abi.DIST_NORMAL, c(0.0), c(1.0))], [c(0.0)], [c(0.0)], 0)
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_scan_plans_compile(hip_lib_nogpu, impl):
+    """The one-launch scan kernels (gjx_scan_run) generate and compile for gfx950 offline."""
+    from test_gpu_parity_abi import _scan_plans
+
+    for plan in _scan_plans(hip_lib_nogpu):
+        assert plan.compile_check(impl) == 0
+    sites, nxt = W.lgssm_scan_sites()
+    fast = hip_lib_nogpu.scan_plan_create(sites, nxt, 1, fast_math=True)
+    assert fast.compile_check(impl) == 0

@@ -47,7 +47,7 @@ for r in range(rounds):
         b.record(ops.stream())
         times[name].append(a.elapsed_ms(b) * 1e3 / (reps * L))
 for name, ts in times.items():
-    print(f"{name}: median {statistics.median(ts):7.2f} us/pass   min {min(ts):7.2f}   ({48e6 / statistics.median(ts) / 1e6 / 8e3:.3f} of 8 TB/s)")
+    print(f"{name}: median {statistics.median(ts):7.2f} us/pass   min {min(ts):7.2f}   ({48e6 / (statistics.median(ts) * 1e-6) / 8e12:.3f} of 8 TB/s)")
 # deviations of the fast plans
 os.environ["GJX_JIT_FORM"] = "pair"
 ex = W.gaussian10_importance(ops, 1, seed=5, n=N)
