@@ -702,8 +702,9 @@ struct ModuleCache {
         return nullptr;
       }
       ++compiles;
-      it = map.emplace(src, Entry{mod, 0, 0}).first;
+      it = map.emplace(src, Entry{mod, 1, ++clock}).first;  // referenced before anything is evicted
       evict_locked();
+      return mod;
     }
     it->second.refs++;
     it->second.tick = ++clock;
