@@ -52,7 +52,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=1024)
     p.add_argument("--warmup", type=int, default=64)
-    p.add_argument("--workload", default="importance", choices=["importance", "smc_lgssm", "smc_hmm"])
+    p.add_argument("--workload", default="importance", choices=["importance", "smc_lgssm", "smc_hmm", "scan_lgssm"])
+    p.add_argument("--fast-math", action="store_true", help="importance / scan: the opt-in hardware-transcendental plan (profiling passes)")
     p.add_argument("--rng", default="philox", choices=["philox", "threefry"])
     p.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -276,11 +277,15 @@ def bench_importance(args, ops, rank, world, launch_passes=None, rng=None, steps
     log_z = ops.log_z_from_rows(e, q, total_particles)  # exact (anchor, fixed-point sum) pair of pass 0
     bytes_per_launch = BYTES_IMPORTANCE_KERNEL_PER_PARTICLE * n * passes_per_launch
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-    traffic, traffic_src = (None, None)
+    traffic, traffic_src, pmc_insts = (None, None, None)
     if n == N_PER_GPU:
+        sel = (lambda pj: pj.get("fast_math", {})) if fast_math else (lambda pj: pj)
         per_pass, traffic_src = pmc_traffic(
-            "r*_pmc.json", lambda pj: pj.get("hbm_bytes_per_pass") if f"gjx_plan_kernel_{rng}" in pj.get("kernel", "") else None)
+            "r*_pmc.json", lambda pj: sel(pj).get("hbm_bytes_per_pass") if f"gjx_plan_kernel_{rng}" in sel(pj).get("kernel", "") else None)
         traffic = per_pass * passes_per_launch if per_pass else None
+        # instruction counts of the same kernel from the committed SQ passes (per 1e6-particle pass)
+        pmc_insts, _ = pmc_traffic(
+            "r*_pmc.json", lambda pj: sel(pj).get("sq_per_pass") if f"gjx_plan_kernel_{rng}" in sel(pj).get("kernel", "") else None)
     res = {
         "metric": "particles/sec, ImportanceK log-marginal-likelihood estimate (1e6 particles per GPU)",
         "value": total_particles * steps / dt,
@@ -304,6 +309,9 @@ def bench_importance(args, ops, rank, world, launch_passes=None, rng=None, steps
         "log_z": log_z,
         "log_z_exact": W.gaussian10_exact_log_z(wl.y),
     }
+    if pmc_insts:
+        res["roofline"]["pmc_instructions_per_pass"] = {
+            k: pmc_insts[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_SALU", "SQ_INSTS_VMEM", "SQ_WAVES") if k in pmc_insts}
     res.update(block_stats(blocks))
     return res, wl
 
@@ -725,8 +733,12 @@ def run_rank(args):
     ops = load_hip_ops()  # raises without libgjx_hip.so / a GPU: there is no CPU fallback
     sharded = world > 1 or FORCE_DIST
     smc_gpu = None
+    if args.workload == "scan_lgssm":  # profiling passes of the one-launch scan (an `extra` entry of the default run)
+        if rank == 0:
+            print(json.dumps(bench_scan(args, ops, fast_math=args.fast_math, with_host_loop=False)), flush=True)
+        return
     if args.workload == "importance":
-        res, _ = bench_importance(args, ops, rank, world)
+        res, _ = bench_importance(args, ops, rank, world, fast_math=args.fast_math)
     elif sharded:
         res = bench_smc_sharded(args, ops, rank, world, args.workload)
     else:

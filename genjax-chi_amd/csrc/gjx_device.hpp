@@ -1175,10 +1175,12 @@ GJX_DEV void serve_tile(const ServeEnv& E, Policy& P, float (&lw4)[kPer], uint64
   // lane serves FOUR CONSECUTIVE slots: four independent propagate chains in flight, one shared cipher block for their
   // draws (smc_quad_bits), 16-byte stores.  Waves whose 256 slots lie outside the range skip the chunk.
   const int64_t jb0 = j0 & ~(int64_t)3;
+  // (workgroup-uniform) the delegated chunks are jumped over in one step: their marks were never set, nothing to clear
+  const int64_t skip_lo = jb0 + (int64_t)skip_from * (int64_t)kTile;
   for (int64_t jb = jb0; jb < j1; jb += (int64_t)kTile) {
-    if (skip_n) {  // (workgroup-uniform) a delegated chunk: its marks were never set, nothing to clear
-      const uint32_t ci = (uint32_t)((jb - jb0) / (int64_t)kTile);
-      if (ci >= skip_from && ci - skip_from < skip_n) continue;
+    if (skip_n && jb == skip_lo) {
+      jb += (int64_t)skip_n * (int64_t)kTile;
+      if (jb >= j1) break;
     }
     if (jb != jb0) __syncthreads();  // the marks were cleared after the previous chunk's scan
 #pragma unroll
@@ -1197,7 +1199,7 @@ GJX_DEV void serve_tile(const ServeEnv& E, Policy& P, float (&lw4)[kPer], uint64
       v[r] = run_max;
     }
     const int carry = block_scan_max_excl(run_max, E.shi);  // (its barriers close this chunk's reads of the marks)
-    if (jb + (int64_t)kTile < j1) {  // another chunk follows: clear the marks for it
+    if (jb + (int64_t)kTile < j1) {  // another chunk may follow: clear the marks for it
 #pragma unroll
       for (int r = 0; r < kPer; ++r) E.anc_s[tid + r * kBlock] = 0;
     }
@@ -1343,7 +1345,10 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
         // (with no mass at all the last tile closes the comb and owns every slot: a candidate too)
         if (A.allow_help && (mass > heavy_mass || (tot == 0 && k + 1 == A.ntiles))) {
           const uint32_t e = atomicAdd(&heavy_n, 1u);
-          if (e < (uint32_t)kMaxHeavy) heavy_tile[e] = (uint32_t)k;
+          if (e < (uint32_t)kMaxHeavy) {
+            heavy_tile[e] = (uint32_t)k;
+            reinterpret_cast<uint64_t*>(nb)[e] = run;  // its exclusive mass prefix (nb is free until a tile is served)
+          }
         }
         run += mass;
       };
@@ -1470,18 +1475,18 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
         own_mass = sh_scan[0];
       }
       // heavy entries in tile order, with their chunk grids
+      uint64_t ts = 0, tp = 0;
+      uint32_t pos = 0;
       if ((uint32_t)tid < n_heavy) {
-        uint64_t ts, tp;
         if (tile_prefix) { ts = tile_prefix[A.ntiles + 4 + 2 * tid]; tp = tile_prefix[A.ntiles + 5 + 2 * tid]; }
-        else { ts = heavy_tile[tid]; tp = 0; }
-        uint32_t pos = 0;
+        else { ts = heavy_tile[tid]; tp = reinterpret_cast<const uint64_t*>(nb)[tid]; }  // (unordered list of the mass scan)
         for (uint32_t e = 0; e < n_heavy; ++e) {
           const uint64_t te = tile_prefix ? tile_prefix[A.ntiles + 4 + 2 * e] : (uint64_t)heavy_tile[e];
           pos += te < ts ? 1u : 0u;
         }
-        if (!tile_prefix) {  // the tile's exclusive prefix: masses before it (rare path: a plain loop)
-          for (uint64_t k = 0; k < ts; ++k) tp += tile_sums[k];
-        }
+      }
+      __syncthreads();  // the unordered list has been read: the ordered arrays may overwrite its scratch
+      if ((uint32_t)tid < n_heavy) {
         const uint64_t mass = tile_prefix ? tile_prefix[ts + 1] - tp : tile_sums[ts];
         const int64_t t_lo = teeth_below(tp, scale, u0, (int64_t)A.n_out);
         const int64_t t_hi = ts + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(tp + mass, scale, u0, (int64_t)A.n_out);
