@@ -2693,3 +2693,229 @@ int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Multi-GPU: the native communicator and the sharded filter driver (gjx.h "multi-GPU"; driver in gjx_sharded.hpp)
+// =====================================================================================================================
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: the library itself is loaded on first use (dlopen)
+
+#include <atomic>
+
+#include "gjx_sharded.hpp"
+
+namespace {
+
+__global__ void k_max_across(float* dst, gjx::RunCols srcs, int world, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float m = reinterpret_cast<const float*>(srcs.in[0])[i];
+  for (int r = 1; r < world; ++r) {
+    const float v = reinterpret_cast<const float*>(srcs.in[r & 15])[i];
+    m = v > m ? v : m;
+  }
+  dst[i] = m;
+}
+
+// device memory primitives of the virtual-rank transport
+struct HipMem {
+  void* buf = nullptr;
+  size_t cap = 0;
+  ~HipMem() {
+    if (buf) (void)hipFree(buf);
+  }
+  int copy(void* dst, const void* src, size_t bytes, gjx_stream s) {
+    if (!bytes) return GJX_OK;
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(s)) == hipSuccess ? GJX_OK : GJX_ERR_LAUNCH;
+  }
+  int max_f32(float* dst, const float* const* srcs, int world, size_t n, gjx_stream s) {
+    if (world > 16) return GJX_ERR_UNSUPPORTED;  // (virtual ranks are a test transport)
+    gjx::RunCols rc;
+    memset(&rc, 0, sizeof rc);
+    for (int r = 0; r < world; ++r) rc.in[r] = srcs[r];
+    k_max_across<<<(unsigned)((n + 255) / 256), 256, 0, S(s)>>>(dst, rc, world, n);
+    return launch_status();
+  }
+  void* scratch(size_t bytes) {
+    if (bytes > cap) {
+      if (buf) (void)hipFree(buf);
+      buf = nullptr;
+      cap = 0;
+      if (hipMalloc(&buf, bytes) != hipSuccess) return nullptr;
+      cap = bytes;
+    }
+    return buf;
+  }
+  int sync(gjx_stream s) { return hipStreamSynchronize(S(s)) == hipSuccess ? GJX_OK : GJX_ERR_LAUNCH; }
+};
+
+// RCCL, loaded on first use (a process that never shards does not need the library)
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  bool ok = false;
+  static Rccl& get() {
+    static Rccl r = [] {
+      Rccl x;
+      // an RCCL already in the process (torch's) first: two copies of the library must not talk to each other
+      const char* names[] = {"librccl.so", "librccl.so.1"};
+      for (const char* nm : names)
+        if (!x.lib) x.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+      for (const char* nm : names)
+        if (!x.lib) x.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (!x.lib) {
+        fprintf(stderr, "[gjx] RCCL not found (dlopen librccl.so): %s\n", dlerror());
+        return x;
+      }
+#define GJX_NCCL_SYM(field, name) x.field = reinterpret_cast<decltype(x.field)>(dlsym(x.lib, name))
+      GJX_NCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+      GJX_NCCL_SYM(CommInitRank, "ncclCommInitRank");
+      GJX_NCCL_SYM(CommDestroy, "ncclCommDestroy");
+      GJX_NCCL_SYM(AllReduce, "ncclAllReduce");
+      GJX_NCCL_SYM(AllGather, "ncclAllGather");
+      GJX_NCCL_SYM(Send, "ncclSend");
+      GJX_NCCL_SYM(Recv, "ncclRecv");
+      GJX_NCCL_SYM(GroupStart, "ncclGroupStart");
+      GJX_NCCL_SYM(GroupEnd, "ncclGroupEnd");
+#undef GJX_NCCL_SYM
+      x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllReduce && x.AllGather && x.Send && x.Recv &&
+             x.GroupStart && x.GroupEnd;
+      if (!x.ok) fprintf(stderr, "[gjx] RCCL library lacks a required symbol\n");
+      return x;
+    }();
+    return r;
+  }
+};
+static_assert(sizeof(ncclUniqueId) == GJX_COMM_ID_BYTES, "gjx.h GJX_COMM_ID_BYTES");
+
+struct RcclTransport : gjx_sharded::Transport {
+  ncclComm_t comm = nullptr;
+  ~RcclTransport() override {
+    if (comm) (void)Rccl::get().CommDestroy(comm);
+  }
+  static int st(ncclResult_t r) {
+    if (r == ncclSuccess) return GJX_OK;
+    fprintf(stderr, "[gjx] RCCL call failed (ncclResult %d)\n", (int)r);
+    return GJX_ERR_LAUNCH;
+  }
+  int allreduce_max_f32(float* buf, size_t n, gjx_stream s) override {
+    return st(Rccl::get().AllReduce(buf, buf, n, ncclFloat32, ncclMax, comm, S(s)));
+  }
+  int allgather(void* full, size_t bytes, gjx_stream s) override {  // in place: the send buffer is this rank's block
+    return st(Rccl::get().AllGather((const char*)full + (size_t)rank * bytes, full, bytes, ncclUint8, comm, S(s)));
+  }
+  int exchange(void* const* cols, int n_cols, size_t elem, const gjx_sharded::Seg* sends, int ns, const gjx_sharded::Seg* recvs,
+               int nr, gjx_stream s) override {
+    if (!ns && !nr) return GJX_OK;
+    Rccl& R = Rccl::get();
+    ncclResult_t r = R.GroupStart();
+    for (int i = 0; i < ns && r == ncclSuccess; ++i)
+      for (int c = 0; c < n_cols && r == ncclSuccess; ++c)
+        r = R.Send((const char*)cols[c] + sends[i].a * elem, (size_t)(sends[i].b - sends[i].a) * elem, ncclUint8, sends[i].peer, comm, S(s));
+    for (int i = 0; i < nr && r == ncclSuccess; ++i)
+      for (int c = 0; c < n_cols && r == ncclSuccess; ++c)
+        r = R.Recv((char*)cols[c] + recvs[i].a * elem, (size_t)(recvs[i].b - recvs[i].a) * elem, ncclUint8, recvs[i].peer, comm, S(s));
+    const ncclResult_t e = R.GroupEnd();
+    return st(r != ncclSuccess ? r : e);
+  }
+  int stream_sync(gjx_stream s) override { return hipStreamSynchronize(S(s)) == hipSuccess ? GJX_OK : GJX_ERR_LAUNCH; }
+};
+
+int dev_copy(void* dst, const void* src, size_t bytes, gjx_stream s) {
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(s)) == hipSuccess ? GJX_OK : GJX_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gjx_comm_unique_id(void* id_out) {
+  if (!id_out) return GJX_ERR_INVALID;
+  Rccl& R = Rccl::get();
+  if (!R.ok) return GJX_ERR_UNSUPPORTED;
+  ncclUniqueId id;
+  if (R.GetUniqueId(&id) != ncclSuccess) return GJX_ERR_LAUNCH;
+  memcpy(id_out, &id, sizeof id);
+  return GJX_OK;
+}
+int gjx_comm_init_rccl(const void* id, int rank, int world, gjx_comm** out) {
+  if (!id || !out || world < 1 || world > 64 || rank < 0 || rank >= world) return GJX_ERR_INVALID;
+  Rccl& R = Rccl::get();
+  if (!R.ok) return GJX_ERR_UNSUPPORTED;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  RcclTransport* t = new (std::nothrow) RcclTransport;
+  if (!t) return GJX_ERR_LAUNCH;
+  t->rank = rank;
+  t->world = world;
+  if (R.CommInitRank(&t->comm, world, uid, rank) != ncclSuccess) {
+    t->comm = nullptr;
+    delete t;
+    return GJX_ERR_LAUNCH;
+  }
+  gjx_comm* c = new (std::nothrow) gjx_comm;
+  if (!c) {
+    delete t;
+    return GJX_ERR_LAUNCH;
+  }
+  c->t = t;
+  *out = c;
+  return GJX_OK;
+}
+int gjx_comm_group_create(int world, gjx_comm_group** out) {
+  if (!out || world < 1 || world > 16) return GJX_ERR_INVALID;
+  *out = new (std::nothrow) gjx_comm_group(world);
+  return *out ? GJX_OK : GJX_ERR_LAUNCH;
+}
+int gjx_comm_group_destroy(gjx_comm_group* g) {
+  delete g;
+  return GJX_OK;
+}
+int gjx_comm_init_local(gjx_comm_group* g, int rank, gjx_comm** out) {
+  if (!g || !out || rank < 0 || rank >= g->g.world) return GJX_ERR_INVALID;
+  gjx_comm* c = new (std::nothrow) gjx_comm;
+  if (!c) return GJX_ERR_LAUNCH;
+  c->t = new (std::nothrow) gjx_sharded::LocalTransport<HipMem>(&g->g, rank);
+  if (!c->t) {
+    delete c;
+    return GJX_ERR_LAUNCH;
+  }
+  *out = c;
+  return GJX_OK;
+}
+int gjx_comm_destroy(gjx_comm* c) {
+  delete c;
+  return GJX_OK;
+}
+int gjx_comm_rank(const gjx_comm* c) { return c && c->t ? c->t->rank : -1; }
+int gjx_comm_world(const gjx_comm* c) { return c && c->t ? c->t->world : -1; }
+int gjx_comm_lse_combine(gjx_comm* c, const uint64_t* records, int32_t n_batch, uint64_t* gathered, int32_t* out_e,
+                         uint64_t* out_q, float* out_lse, gjx_stream s) {
+  if (!c || !c->t) return GJX_ERR_INVALID;
+  return gjx_sharded::lse_combine(*c->t, records, n_batch, gathered, out_e, out_q, out_lse, s, dev_copy);
+}
+int gjx_smc_sharded_run_lgssm(gjx_comm* c, const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y_host,
+                              const gjx_sharded_io* io, gjx_stream s) {
+  if (!c || !c->t) return GJX_ERR_INVALID;
+  return gjx_sharded::run_lgssm(*c->t, cfg, model, y_host, io, s);
+}
+int gjx_smc_sharded_run_hmm(gjx_comm* c, const gjx_smc_config* cfg, const gjx_hmm* model, const int32_t* y_host,
+                            const uint32_t* trans_alias, const float* obs_logp, const gjx_sharded_io* io, gjx_stream s) {
+  if (!c || !c->t) return GJX_ERR_INVALID;
+  return gjx_sharded::run_hmm(*c->t, cfg, model, y_host, trans_alias, obs_logp, io, s);
+}
+int gjx_smc_sharded_run_plan(gjx_comm* c, const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host,
+                             const gjx_sharded_io* io, gjx_stream s) {
+  if (!c || !c->t || !plan) return GJX_ERR_INVALID;
+  return gjx_sharded::run_plan(*c->t, cfg, plan, plan->n_state, plan->n_obs, obs_host, io, s);
+}
+
+}  // extern "C"

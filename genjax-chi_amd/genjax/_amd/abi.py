@@ -149,6 +149,24 @@ class ScanIO(C.Structure):
     ]
 
 
+class ShardedIO(C.Structure):
+    _fields_ = [
+        ("state", (C.c_void_p * 4) * 2),
+        ("logw", C.c_void_p * 2),
+        ("tile_sums", C.c_void_p),
+        ("max_partials", C.c_void_p),
+        ("out_max", C.c_void_p),
+        ("out_q", C.c_void_p),
+        ("ancestors", C.c_void_p),
+        ("ranges", C.c_void_p),
+        ("shuffle", C.c_int32),
+        ("received", C.POINTER(C.c_uint64)),
+    ]
+
+
+COMM_ID_BYTES = 128
+
+
 class Lgssm(C.Structure):
     _fields_ = [
         ("x0_loc", C.c_float),
@@ -268,6 +286,18 @@ PROTOTYPES = {
     "gjx_scan_plan_destroy": (C.c_int, [_P]),
     "gjx_scan_plan_compile_check": (C.c_int, [_P, C.c_int]),
     "gjx_scan_run": (C.c_int, [_P, C.POINTER(ScanIO), _P]),
+    "gjx_comm_unique_id": (C.c_int, [_P]),
+    "gjx_comm_init_rccl": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "gjx_comm_group_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "gjx_comm_group_destroy": (C.c_int, [_P]),
+    "gjx_comm_init_local": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "gjx_comm_destroy": (C.c_int, [_P]),
+    "gjx_comm_rank": (C.c_int, [_P]),
+    "gjx_comm_world": (C.c_int, [_P]),
+    "gjx_comm_lse_combine": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P]),
+    "gjx_smc_sharded_run_lgssm": (C.c_int, [_P, C.POINTER(SmcConfig), C.POINTER(Lgssm), _P, C.POINTER(ShardedIO), _P]),
+    "gjx_smc_sharded_run_hmm": (C.c_int, [_P, C.POINTER(SmcConfig), C.POINTER(Hmm), _P, _P, _P, C.POINTER(ShardedIO), _P]),
+    "gjx_smc_sharded_run_plan": (C.c_int, [_P, C.POINTER(SmcConfig), _P, _P, C.POINTER(ShardedIO), _P]),
     "gjx_smc_run_plan": (
         C.c_int,
         [C.POINTER(SmcConfig), _P, _P, _P, _P, C.POINTER(_P), _P, _P, _P, C.c_size_t, _P],
@@ -296,6 +326,8 @@ _NO_STATUS = {
     "gjx_num_tiles",
     "gjx_num_max_partials",
     "gjx_hmm_alias_words",
+    "gjx_comm_rank",
+    "gjx_comm_world",
 }
 
 

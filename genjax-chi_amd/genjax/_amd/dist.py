@@ -236,6 +236,81 @@ class ThreadComm:
         self.sh.barrier.wait()
 
 
+class NativeComm:
+    """`gjx_comm` (include/gjx.h): the library's own communicator.  `NativeComm.rccl(ops, rank, world)` builds an RCCL
+    communicator (the 128-byte id travels through the torch.distributed store / broadcast); `NativeComm.local_group(ops,
+    world)` gives `world` virtual ranks for threads of this process (tests)."""
+
+    def __init__(self, ops: Ops, handle, group=None):
+        self.ops, self.handle, self._group = ops, handle, group
+        self.rank = int(ops.lib.call("gjx_comm_rank", handle))
+        self.world = int(ops.lib.call("gjx_comm_world", handle))
+
+    @staticmethod
+    def rccl(ops: Ops, rank: int, world: int) -> "NativeComm":
+        import ctypes as C
+
+        from . import abi
+
+        buf = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            ops.lib.call("gjx_comm_unique_id", C.c_void_p(buf.data_ptr()))
+        if world > 1:
+            dist = _dist()
+            dev_buf = buf.to(ops.device()) if dist.get_backend() == "nccl" else buf
+            dist.broadcast(dev_buf, 0)
+            buf = dev_buf.cpu()
+        h = C.c_void_p()
+        ops.lib.call("gjx_comm_init_rccl", C.c_void_p(buf.data_ptr()), rank, world, C.byref(h))
+        return NativeComm(ops, h)
+
+    @staticmethod
+    def local_group(ops: Ops, world: int) -> list:
+        import ctypes as C
+
+        g = C.c_void_p()
+        ops.lib.call("gjx_comm_group_create", world, C.byref(g))
+        owner = _GroupOwner(ops, g)
+        out = []
+        for r in range(world):
+            h = C.c_void_p()
+            ops.lib.call("gjx_comm_init_local", g, r, C.byref(h))
+            out.append(NativeComm(ops, h, owner))
+        return out
+
+    def lse_combine(self, records: torch.Tensor):
+        """records int64[n_batch, 65] of this rank's shard -> (lse f32[n_batch], e i32[n_batch], q i64[n_batch]) of the
+        whole population, the same on every rank (`gjx_comm_lse_combine`)."""
+        from . import abi
+
+        nb = records.shape[0]
+        gathered = self.ops.empty((self.world, nb, abi.LSE_RECORD_WORDS), torch.int64)
+        lse, e, q = self.ops.empty(nb, torch.float32), self.ops.empty(nb, torch.int32), self.ops.empty(nb, torch.int64)
+        self.ops.lib.call("gjx_comm_lse_combine", self.handle, self.ops._p(records), nb, self.ops._p(gathered), self.ops._p(e),
+                          self.ops._p(q), self.ops._p(lse), self.ops.stream())
+        self._keep = gathered
+        return lse, e, q
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.ops.lib.call("gjx_comm_destroy", self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class _GroupOwner:
+    def __init__(self, ops, handle):
+        self.ops, self.handle = ops, handle
+
+    def __del__(self):
+        try:
+            self.ops.lib.call("gjx_comm_group_destroy", self.handle)
+        except Exception:
+            pass
+
+
 class ShardedSMC:
     """Bootstrap SMC (`kind` "lgssm": BASELINE configs[2]/[3]; "hmm": configs[4]) with the population sharded
     over ranks in equal contiguous blocks of whole tiles.
@@ -369,6 +444,57 @@ class ShardedSMC:
                 recvs.append((j, a, b))
                 self.received += b - a
         self.comm.exchange(cols, sends, recvs)
+
+    def run_native(self, comm: "NativeComm"):
+        """The same filter driven from C (`gjx_smc_sharded_run_*`): the per-step launches, the two small collectives and
+        the ancestor shuffle without the interpreter in between.  Same results as `run()` bit for bit."""
+        import ctypes as C
+
+        from . import abi
+
+        ops = self.ops
+        if self.poison:  # tests: whatever a rank never receives must never be read
+            for b in range(2):
+                for c in [*self.state[b], self.logw[b]]:
+                    c.fill_(float("nan") if c.dtype == torch.float32 else -1)
+        io = abi.ShardedIO()
+        for b in range(2):
+            for k, c in enumerate(self.state[b]):
+                io.state[b][k] = c.data_ptr()
+            io.logw[b] = self.logw[b].data_ptr()
+        io.tile_sums, io.max_partials = self.tile_sums.data_ptr(), self.max_partials.data_ptr()
+        io.out_max, io.out_q = self.out_max.data_ptr(), self.out_q.data_ptr()
+        io.ancestors = self.ancestors.data_ptr() if self.ancestors is not None else None
+        io.ranges = self.ranges.data_ptr()
+        io.shuffle = 0 if self.exchange == "ranges" else 1
+        recv = C.c_uint64(0)
+        io.received = C.pointer(recv)
+        if self.kind == "lgssm":
+            import numpy as np
+
+            y = np.ascontiguousarray(np.asarray(self.y, dtype=np.float32))
+            ops.lib.call("gjx_smc_sharded_run_lgssm", comm.handle, C.byref(self.cfg), C.byref(self.model), C.c_void_p(y.ctypes.data),
+                         C.byref(io), ops.stream())
+        elif self.kind == "hmm":
+            import numpy as np
+
+            y = np.ascontiguousarray(np.asarray(self.y, dtype=np.int32))
+            ops.lib.call("gjx_smc_sharded_run_hmm", comm.handle, C.byref(self.cfg), C.byref(self.model), C.c_void_p(y.ctypes.data),
+                         ops._p(self.trans_alias), ops._p(self.obs_logp), C.byref(io), ops.stream())
+        else:
+            import numpy as np
+
+            y = np.ascontiguousarray(np.asarray(self.y, dtype=np.float32))
+            ops.lib.call("gjx_smc_sharded_run_plan", comm.handle, C.byref(self.cfg), self.plan.handle,
+                         C.c_void_p(y.ctypes.data) if y.size else None, C.byref(io), ops.stream())
+        self.received = int(recv.value)
+        lo, hi = self.first, self.first + self.n_local
+        last = (self.T - 1) & 1
+        final = [c[lo:hi] for c in self.state[last]]
+        return dict(out_max=self.out_max, out_q=self.out_q, state=final[0] if self.n_cols == 1 else final,
+                    logw=self.logw[last][lo:hi], ancestors=self.ancestors,
+                    log_z=ops.log_z_from_pairs(self.out_max, self.out_q, self.n_total, self.cfg._flags),
+                    resampled=self.cfg._flags, log_z_exact=self.log_z_exact, received=self.received)
 
     def run(self):
         ops = self.ops

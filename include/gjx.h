@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define GJX_VERSION_MAJOR 0
-#define GJX_VERSION_MINOR 4
+#define GJX_VERSION_MINOR 5
 
 typedef void* gjx_stream; /* hipStream_t; ignored by the oracle build */
 
@@ -567,6 +567,62 @@ typedef struct {
   const gjx_lse_out* lse;          /* nullable; needs row_e / row_s */
 } gjx_scan_io;
 int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s);
+
+/* ---- multi-GPU: a native communicator, the log-Z combine and the whole sharded filter ---------- *
+ * One process per GPU.  gjx_comm wraps the transport the sharded calls below use:
+ *   RCCL  (libgjx_hip.so): gjx_comm_unique_id on rank 0, broadcast the 128 bytes out of band, gjx_comm_init_rccl on
+ *         every rank (the RCCL library is loaded on first use: processes that never shard do not need it);
+ *   local (both builds): `world` VIRTUAL ranks — threads of ONE process sharing one device and one stream — through a
+ *         gjx_comm_group; collectives are host barriers + device copies on the shared stream.  Test transport: it runs
+ *         the sharded protocol on the HIP kernels of a one-GPU box and on the CPU oracle.
+ * The collectives are not exposed one by one: what a caller of this path needs are the two operations built on them. */
+typedef struct gjx_comm gjx_comm;
+typedef struct gjx_comm_group gjx_comm_group;
+#define GJX_COMM_ID_BYTES 128
+int gjx_comm_unique_id(void* id_out /*host, GJX_COMM_ID_BYTES*/);
+int gjx_comm_init_rccl(const void* id /*host*/, int rank, int world, gjx_comm** out);
+int gjx_comm_group_create(int world, gjx_comm_group** out);
+int gjx_comm_group_destroy(gjx_comm_group* g);
+int gjx_comm_init_local(gjx_comm_group* g, int rank, gjx_comm** out);
+int gjx_comm_destroy(gjx_comm* c);
+int gjx_comm_rank(const gjx_comm* c);
+int gjx_comm_world(const gjx_comm* c);
+/* Global log-marginal of n_batch importance passes sharded over the ranks (replaces logsumexp(lw) - log K of
+ * inference/smc.py:97 across devices): every rank passes the 65-word records of ITS shard (gjx_lse_rows out_record,
+ * dev u64[n_batch, GJX_LSE_RECORD_WORDS]); one all-gather into `gathered` (dev u64[world, n_batch, 65], caller-owned)
+ * and gjx_lse_combine give every rank the same (e, q, lse) per pass — the bits of ONE fold over all rows. */
+int gjx_comm_lse_combine(gjx_comm* c, const uint64_t* records, int32_t n_batch, uint64_t* gathered, int32_t* out_e,
+                         uint64_t* out_q, float* out_lse, gjx_stream s);
+/* The whole bootstrap filter sharded over the communicator's ranks (BASELINE configs[3]): the per-step sequence
+ * step A (own slots) -> all-reduce(max) of the tile maxima -> step B -> all-gather of the tile masses (and ESS sums) ->
+ * ancestor shuffle, driven from C: no interpreter between the launches.  cfg: first_slot / n_local = this rank's block
+ * (n_total a multiple of world * gjx_smc_tile()), one filter.  All arrays are GLOBAL-size device buffers the caller
+ * owns (a rank's own block is always current; remote ranges are filled by the shuffle):
+ *   state[2][n_state] dev 4-byte [n_total] (double-buffered), logw[2] dev f32[n_total], tile_sums dev u64[tiles],
+ *   max_partials dev f32[tiles], out_max dev f32[T], out_q dev u64[T], ancestors nullable dev int32[T, n_local],
+ *   ranges int64[2 world + 1] device-visible PINNED host memory (plain host memory in the oracle build).
+ * shuffle 0 = by source ranges (each rank receives exactly the contiguous range its slots draw from, in place, by
+ * grouped send/recv; the host polls the range kernel's ticket in `ranges`), 1 = all-gather of the population.
+ * *received (nullable): particles this rank received over the run.  Results equal the single-device filter bit for
+ * bit for every world size. */
+typedef struct {
+  void* state[2][GJX_SMC_MAX_STATE];
+  float* logw[2];
+  uint64_t* tile_sums;
+  float* max_partials;
+  float* out_max;
+  uint64_t* out_q;
+  int32_t* ancestors;
+  int64_t* ranges;
+  int32_t shuffle;
+  uint64_t* received;
+} gjx_sharded_io;
+int gjx_smc_sharded_run_lgssm(gjx_comm* c, const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y_host,
+                              const gjx_sharded_io* io, gjx_stream s);
+int gjx_smc_sharded_run_hmm(gjx_comm* c, const gjx_smc_config* cfg, const gjx_hmm* model, const int32_t* y_host,
+                            const uint32_t* trans_alias, const float* obs_logp, const gjx_sharded_io* io, gjx_stream s);
+int gjx_smc_sharded_run_plan(gjx_comm* c, const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host,
+                             const gjx_sharded_io* io, gjx_stream s);
 
 /* HMM tables.  trans_alias: dev u32[gjx_hmm_alias_words(K)] = K rows of K packed alias-table entries
  * (threshold24 << 8) | alias built from the row's fixed-point softmax weights: the next state

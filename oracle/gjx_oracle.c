@@ -1280,6 +1280,11 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
   return GJX_OK;
 }
 int gjx_smc_plan_destroy(gjx_smc_plan* p) { free(p); return GJX_OK; }
+int gjo_smc_plan_dims(const gjx_smc_plan* p, int* n_state, int* n_obs) { /* for gjx_oracle_comm.cpp (the plan is opaque there) */
+  if (!p) return GJX_ERR_INVALID;
+  *n_state = p->m.n_state; *n_obs = p->m.n_obs;
+  return GJX_OK;
+}
 int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl) { (void)p; (void)impl; return GJX_ERR_UNSUPPORTED; }
 
 /* ---- importance over a Scan model (scan.py:237-294): per particle, T steps with the chained key ---- */

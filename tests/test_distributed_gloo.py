@@ -99,20 +99,23 @@ def test_two_ranks_equal_one_rank(tmp_path, oracle_ops, impl):
         assert torch.equal(p["hmm_q"], ref_hmm["out_q"]) and p["hmm_log_z"] == ref_hmm["log_z"]
 
 
-def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_states=16, **model_kw):
+def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_states=16, native=False, **model_kw):
     """`world` virtual ranks as threads sharing one backend (dist.ThreadComm): the sharded protocol without
-    process groups.  Returns the per-rank results."""
+    process groups.  Returns the per-rank results.  native: the whole filter driven from C through the library's own
+    communicator (`gjx_comm` local group + `gjx_smc_sharded_run_*`) instead of the Python loop."""
     import threading
 
     from genjax._amd import dist as gdist
 
     sh, res, err = gdist.ThreadComm.Shared(world), [None] * world, []
+    comms = gdist.NativeComm.local_group(ops, world) if native else None
 
     def work(r):
         try:
             kw = dict(model_kw, n_states=n_states) if kind == "hmm" else dict(model_kw)
-            res[r] = gdist.ShardedSMC(ops, kind, impl, seed, n_total, T, r, world, True, exchange=exchange,
-                                      comm=gdist.ThreadComm(sh, r), poison=True, **kw).run()
+            smc = gdist.ShardedSMC(ops, kind, impl, seed, n_total, T, r, world, True, exchange=exchange,
+                                   comm=gdist.ThreadComm(sh, r), poison=True, **kw)
+            res[r] = smc.run_native(comms[r]) if native else smc.run()
         except BaseException as e:  # noqa: BLE001 - re-raised below; release the others
             err.append(e)
             sh.barrier.abort()
@@ -127,11 +130,11 @@ def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_s
     return res
 
 
-def check_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ref_ops=None, ess_threshold=0.0):
+def check_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ref_ops=None, ess_threshold=0.0, native=False):
     """`ref_ops`: the backend of the single-rank reference filter (default: the same one)."""
     from genjax._amd import workloads as W
 
-    res = _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ess_threshold=ess_threshold)
+    res = _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ess_threshold=ess_threshold, native=native)
     ref_ops = ops if ref_ops is None else ref_ops
     ref = (W.lgssm_smc(ref_ops, impl, 5, n_total, T, True, ess_threshold=ess_threshold) if kind == "lgssm"
            else W.hmm_smc(ref_ops, impl, 5, n_total, T, 16, True, ess_threshold=ess_threshold))
@@ -302,7 +305,7 @@ def test_sharded_filter_with_collapsing_weights(oracle_ops, world):
     check_degenerate_sharded(oracle_ops, 0, world)
 
 
-def check_sharded_plan(ops, impl, world, build_plans):
+def check_sharded_plan(ops, impl, world, build_plans, native=False):
     """A generated filter (two state columns; normal / gamma / bernoulli / beta sites) sharded over virtual ranks,
     remote regions poisoned: equal to its single-device run bit for bit."""
     import threading
@@ -316,11 +319,13 @@ def check_sharded_plan(ops, impl, world, build_plans):
     obs = np.stack([y, (np.arange(T) % 2).astype(np.float32)], axis=1)
     _, plan = build_plans(ops)
     sh, res, err = gdist.ThreadComm.Shared(world), [None] * world, []
+    comms = gdist.NativeComm.local_group(ops, world) if native else None
 
     def work(r):
         try:
-            res[r] = gdist.ShardedSMC(ops, "plan", impl, 13, n_total, T, r, world, True, comm=gdist.ThreadComm(sh, r),
-                                      poison=True, plan=plan, obs=obs).run()
+            smc = gdist.ShardedSMC(ops, "plan", impl, 13, n_total, T, r, world, True, comm=gdist.ThreadComm(sh, r),
+                                   poison=True, plan=plan, obs=obs)
+            res[r] = smc.run_native(comms[r]) if native else smc.run()
         except BaseException as e:  # noqa: BLE001
             err.append(e)
             sh.barrier.abort()
@@ -394,3 +399,58 @@ def test_four_ranks_uneven_rows(tmp_path, oracle_ops):
     for p in parts:
         assert torch.equal(p["smc_q"], ref_smc["out_q"]) and torch.equal(p["smc_flags"], ref_smc["resampled"])
         assert p["smc_log_z"] == ref_smc["log_z"]
+
+
+# ---- the library's own communicator and C driver (gjx.h "multi-GPU") under virtual ranks ---------------------------
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("kind", ["lgssm", "hmm"])
+@pytest.mark.parametrize("world,exchange", [(2, "ranges"), (4, "ranges"), (3, "allgather")])
+def test_native_sharded_run(oracle_ops, impl, kind, world, exchange):
+    """`gjx_smc_sharded_run_*` (per-step launches, collectives and the ancestor shuffle driven from C through a
+    `gjx_comm` of virtual ranks) equals the single-rank filter bit for bit, and moves what the Python driver moves."""
+    n_total, T = 1024 * world * 3, 10
+    nat = check_virtual_ranks(oracle_ops, kind, impl, world, n_total, T, exchange, native=True)
+    py = check_virtual_ranks(oracle_ops, kind, impl, world, n_total, T, exchange)
+    assert [r["received"] for r in nat] == [r["received"] for r in py]
+
+
+def test_native_sharded_adaptive_and_plan(oracle_ops):
+    check_virtual_ranks(oracle_ops, "lgssm", 1, 3, 1024 * 6, 14, "ranges", ess_threshold=0.5, native=True)
+    from test_gpu_parity_abi import _smc_plans
+
+    check_sharded_plan(oracle_ops, 1, 2, _smc_plans, native=True)
+
+
+def check_native_lse_combine(ops, world=3):
+    """`gjx_comm_lse_combine`: the log-marginal of an ImportanceK pass sharded over `world` virtual ranks == one fold over
+    the whole population (inference/smc.py:97 across devices)."""
+    import threading
+
+    from genjax._amd import dist as gdist, workloads as W
+
+    n = 256 * 37
+    whole = W.gaussian10_importance(ops, 1, seed=4, n=n)
+    comms = gdist.NativeComm.local_group(ops, world)
+    out, err = [None] * world, []
+
+    def work(r):
+        try:
+            first, cnt = gdist.shard_rows(n, r, world)
+            shard = W.Gaussian10(ops, 1, seed=4, n_local=cnt, first=first, n_total=n).step()
+            lse, e, q = comms[r].lse_combine(shard["record"].reshape(1, -1).contiguous())
+            out[r] = (int(e.cpu()[0]), int(q.cpu()[0]))
+        except BaseException as ex:  # noqa: BLE001
+            err.append(ex)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if err:
+        raise err[0]
+    assert all(o == (whole["row_e"], whole["row_q"]) for o in out), (out, whole["row_e"], whole["row_q"])
+
+
+def test_native_lse_combine(oracle_ops):
+    check_native_lse_combine(oracle_ops)

@@ -65,3 +65,43 @@ def test_sharded_adaptive_on_device(hip_ops, oracle_ops, kind):
     source ranges of kept steps and the accumulated weights equal the single-rank ORACLE filter bit for bit."""
     res = check_virtual_ranks(hip_ops, kind, 1, 3, 1024 * 6, 14, "ranges", ref_ops=oracle_ops, ess_threshold=0.5)
     assert 0 < int((res[0]["resampled"][1:] == 0).sum()) < 13
+
+
+# ---- the library's own communicator and C driver (gjx.h "multi-GPU") -------------------------------------------------
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("kind", ["lgssm", "hmm"])
+@pytest.mark.parametrize("world,exchange", [(2, "ranges"), (4, "ranges"), (3, "allgather")])
+def test_native_sharded_run_on_device(hip_ops, oracle_ops, impl, kind, world, exchange):
+    """`gjx_smc_sharded_run_*` on the HIP kernels: virtual ranks of a `gjx_comm` local group share the device and its
+    stream; the C driver polls the range kernel's ticket in pinned memory.  Equal to the single-rank ORACLE filter."""
+    check_virtual_ranks(hip_ops, kind, impl, world, 1024 * world * 5, 11, exchange, ref_ops=oracle_ops, native=True)
+
+
+def test_native_sharded_adaptive_plan_and_lse_on_device(hip_ops, oracle_ops):
+    from test_distributed_gloo import check_native_lse_combine, check_sharded_plan
+    from test_gpu_parity_abi import _smc_plans
+
+    check_virtual_ranks(hip_ops, "lgssm", 1, 3, 1024 * 6, 14, "ranges", ref_ops=oracle_ops, ess_threshold=0.5, native=True)
+    check_sharded_plan(hip_ops, 1, 2, _smc_plans, native=True)
+    check_native_lse_combine(hip_ops)
+
+
+def test_rccl_communicator_one_rank(hip_ops):
+    """The RCCL transport on the one GPU of the box (world = 1): the library loads RCCL, builds a communicator from a
+    unique id, and the sharded entry points run through it — a one-rank run equals the single-device filter, and the
+    log-Z combine of one record is the record's own fold.  (More ranks need more GPUs: the protocol itself is covered
+    by the virtual-rank tests above.)"""
+    from genjax._amd import dist as gdist
+
+    comm = gdist.NativeComm.rccl(hip_ops, 0, 1)
+    assert (comm.rank, comm.world) == (0, 1)
+    n, T = 1024 * 9, 12
+    smc = gdist.ShardedSMC(hip_ops, "lgssm", 1, 5, n, T, 0, 1, True)
+    got = smc.run_native(comm)
+    ref = W.lgssm_smc(hip_ops, 1, 5, n, T, True)
+    assert torch.equal(got["state"], ref["state"]) and torch.equal(got["ancestors"], ref["ancestors"])
+    assert torch.equal(got["out_q"], ref["out_q"]) and got["log_z"] == ref["log_z"]
+    whole = W.gaussian10_importance(hip_ops, 1, seed=4, n=256 * 11)
+    shard = W.Gaussian10(hip_ops, 1, seed=4, n_local=256 * 11, first=0, n_total=256 * 11 + 1).step()  # (record form)
+    lse, e, q = comm.lse_combine(shard["record"].reshape(1, -1).contiguous())
+    assert (int(e.cpu()[0]), int(q.cpu()[0])) == (whole["row_e"], whole["row_q"])
