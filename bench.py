@@ -328,13 +328,18 @@ def bench_smc_sharded(args, ops, rank, world, kind):
     n_total = n * world
     exchange = os.environ.get("GJX_BENCH_SHUFFLE", "ranges")
     smc = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world, exchange=exchange)
-    smc.run()  # warm-up (also builds any generated kernels)
+    # GJX_BENCH_NATIVE_COMM=1: the library's own RCCL communicator and C driver (gjx_smc_sharded_run_*) instead of the
+    # torch.distributed loop.  Opt-in: it is covered by virtual-rank tests and a one-rank RCCL test only (no multi-GPU box here).
+    native = os.environ.get("GJX_BENCH_NATIVE_COMM") == "1"
+    comm = gdist.NativeComm.rccl(ops, rank, world) if native else None
+    run = (lambda: smc.run_native(comm)) if native else smc.run
+    run()  # warm-up (also builds any generated kernels)
     smc.received = 0
     runs = [0]
 
     def one_run():
         runs[0] += 1
-        return smc.run()
+        return run()
 
     blocks, r = timed_blocks(one_run, world, min_s=0.05, min_blocks=3, max_blocks=5)
     dt = statistics.median(blocks)
@@ -348,7 +353,8 @@ def bench_smc_sharded(args, ops, rank, world, kind):
         "config": {"workload": f"bootstrap SMC {kind} T={T} N={n_total} sharded x{world} (BASELINE configs[3] at world=8)",
                    "rng": args.rng,
                    "parallelism": f"particle-sharded x{world}: all-reduce(max) + all-gather of tile masses + {shuffle}",
-                   "particles_received_per_rank_step": r["received"] / runs[0] / max(1, T - 1)},
+                   "driver": "native (gjx_comm over RCCL, gjx_smc_sharded_run_*)" if native else "python (torch.distributed)",
+                   "particles_received_per_rank_step": r["received"] / (1 if native else runs[0]) / max(1, T - 1)},
         "roofline": {"bound": "hbm", "kernel": "one SMC step incl. exchange", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "step_ms": per_step_ms, "algorithmic_bytes_per_launch": BYTES_SMC_PER_PARTICLE_STEP * n,
