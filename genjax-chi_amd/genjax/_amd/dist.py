@@ -329,7 +329,8 @@ class ShardedSMC:
 
     def __init__(self, ops: Ops, kind: str, impl: int, seed: int, n_total: int, T: int, rank: int, world: int,
                  record_ancestors: bool = False, exchange: str = "ranges", comm=None, poison: bool = False,
-                 n_states=None, lgssm=None, y=None, plan=None, obs=None, ess_threshold: float = 0.0):
+                 n_states=None, lgssm=None, y=None, plan=None, obs=None, ess_threshold: float = 0.0,
+                 tile_sums_form: int = 0):
         """`lgssm` (abi.Lgssm) / `y`: another linear-Gaussian model and observation sequence than the benchmark's.
         kind "plan": a generated filter — `plan` from `ops.smc_plan_create`, `obs` [T, n_obs]."""
         tile = ops.tile
@@ -345,7 +346,7 @@ class ShardedSMC:
         sk, rk = W.smc_key_schedule(prng.key(seed, impl), T)
         # ess_threshold in (0, 1): resample only when ESS < threshold * n_total; every rank takes the same decision
         # from the all-gathered exact ESS sums, and a step that keeps its particles exchanges nothing
-        self.cfg = ops.smc_config(impl, n_total, self.first, self.n_local, sk, rk, ess_threshold)
+        self.cfg = ops.smc_config(impl, n_total, self.first, self.n_local, sk, rk, ess_threshold, tile_sums_form)
         dev = ops.device()
         if kind == "lgssm":
             self.y = W.lgssm_data(T) if y is None else y

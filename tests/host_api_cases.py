@@ -1053,6 +1053,35 @@ def case_general_smc(impl):
         assert all(torch.equal(a_, b_) for a_, b_ in zip(m_.particles, one.particles))
     with pytest.raises(ValueError):
         BootstrapSMC(StateSpaceModel(init, step), C["nope"].set(torch.tensor(y)), 1024).run(key)
+    # run_many's contract when the library refuses a filter batch (population too large for one: GJX_ERR_UNSUPPORTED,
+    # or a workspace the device cannot hold): element b is still self.run(keys[b])
+    from genjax._amd import abi as _abi
+
+    calls = []
+
+    def refuse(ops_, chunk, T_, ess_):
+        calls.append(len(chunk))
+        raise _abi.GjxError("gjx_smc_run_plan", -2)
+
+    orig = smc2._run_chunk
+    smc2._run_chunk = refuse
+    try:
+        fb = smc2.run_many(ks)
+    finally:
+        smc2._run_chunk = orig
+    assert calls == [3]
+    for a_, b_ in zip(fb, many):
+        assert a_.log_marginal_likelihood == b_.log_marginal_likelihood and torch.equal(a_.ancestors, b_.ancestors)
+
+    def broken(ops_, chunk, T_, ess_):
+        raise _abi.GjxError("gjx_smc_run_plan", -4)  # anything else is an error, not a reason to fall back
+
+    smc2._run_chunk = broken
+    try:
+        with pytest.raises(_abi.GjxError):
+            smc2.run_many(ks)
+    finally:
+        smc2._run_chunk = orig
 
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,

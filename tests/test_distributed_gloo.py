@@ -130,11 +130,13 @@ def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_s
     return res
 
 
-def check_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ref_ops=None, ess_threshold=0.0, native=False):
+def check_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ref_ops=None, ess_threshold=0.0, native=False,
+                        tile_sums_form=0):
     """`ref_ops`: the backend of the single-rank reference filter (default: the same one)."""
     from genjax._amd import workloads as W
 
-    res = _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ess_threshold=ess_threshold, native=native)
+    res = _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ess_threshold=ess_threshold, native=native,
+                             tile_sums_form=tile_sums_form)
     ref_ops = ops if ref_ops is None else ref_ops
     ref = (W.lgssm_smc(ref_ops, impl, 5, n_total, T, True, ess_threshold=ess_threshold) if kind == "lgssm"
            else W.hmm_smc(ref_ops, impl, 5, n_total, T, 16, True, ess_threshold=ess_threshold))

@@ -105,3 +105,12 @@ def test_rccl_communicator_one_rank(hip_ops):
     shard = W.Gaussian10(hip_ops, 1, seed=4, n_local=256 * 11, first=0, n_total=256 * 11 + 1).step()  # (record form)
     lse, e, q = comm.lse_combine(shard["record"].reshape(1, -1).contiguous())
     assert (int(e.cpu()[0]), int(q.cpu()[0])) == (whole["row_e"], whole["row_q"])
+
+
+@pytest.mark.parametrize("form", [1, 2])
+def test_sharded_tile_sums_forms(hip_ops, oracle_ops, form):
+    """Both forms of the tile-mass kernel under sharding (first_slot offsets into the global tile arrays): a wave per
+    tile and a workgroup per tile give the single-rank oracle filter's bits, adaptive filter included."""
+    check_virtual_ranks(hip_ops, "lgssm", 1, 3, 1024 * 3 * 5, 9, "ranges", ref_ops=oracle_ops, tile_sums_form=form)
+    check_virtual_ranks(hip_ops, "hmm", 0, 2, 1024 * 2 * 7, 9, "ranges", ref_ops=oracle_ops, ess_threshold=0.5,
+                        tile_sums_form=form)
