@@ -868,6 +868,12 @@ struct ResampleArgs {
   int32_t* resampled_out = nullptr;    // nullable: block 0 of each filter stores 1 (resampled) / 0 (kept)
   int allow_help = 1;                  // 0: heavy tiles serve all their slots themselves
   double heavy_frac = 0.0;             // (kCapSlots - 8) / n_out: the share of the total mass above which a tile may be heavy
+  // Extra workgroups (per filter) behind the `ntiles` tile workgroups: they own no source tile, exit at once in ordinary
+  // steps, and rank behind the idle tiles as takers of a heavy tile's delegated chunks — so a heavy tile can always
+  // delegate, also when no tile is idle (one particle with 60 % of the mass, the rest spread evenly).
+  uint32_t n_extra = 0;
+  float* extra_max = nullptr;          // nullable [n_extra] (per filter): the maxima of what the extra workgroups served
+  int extra_first = 0;                 // test knob (GJX_SMC_EXTRA_FIRST=1): the extra workgroups rank BEFORE the idle tiles
 };
 
 // The tile mass above which a tile MAY own more than kCapSlots output slots (slots <= mass * n_out / total + 1)
@@ -1254,9 +1260,12 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   int32_t* resampled_out = A.resampled_out;
   Key rkey = A.rkey;
   const uint64_t* tile_prefix = A.tile_prefix;
+  float* extra_max = A.extra_max;
   if (A.fb.n_filters > 1) {
-    const uint32_t f = (uint32_t)(b / A.fb.tiles);
-    b -= (uint64_t)f * A.fb.tiles;
+    const uint32_t per = A.fb.tiles + A.n_extra;  // workgroups per filter: its tiles, then its extras
+    const uint32_t f = (uint32_t)(b / per);
+    b -= (uint64_t)f * per;
+    if (extra_max) extra_max += (uint64_t)f * A.n_extra;
     if (tile_prefix) tile_prefix += (uint64_t)f * prefix_words(A.fb.tiles);
     lw_all += (uint64_t)f * A.fb.stride;
     tile_sums += (uint64_t)f * A.fb.tiles;
@@ -1269,6 +1278,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
     P.select_filter((uint64_t)f * A.fb.stride, A.fb.step_key[f]);
   }
   const uint64_t base = b * kTile;
+  const bool extra = b >= A.ntiles;  // (workgroup-uniform) no tile of its own: a taker of delegated chunks only
   const bool adaptive = ADAPTIVE && A.ess_thr > 0.0;
 
   // Issue the own tile's loads first: their HBM latency overlaps the tile-mass scan.  A rank that owns only a shard
@@ -1280,7 +1290,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   E.A = &A; E.lw_all = lw_all; E.nb = nb; E.anc_s = anc_s; E.sh_cdf = sh_cdf; E.shi = shi; E.tid = tid;
   E.m = 0.0f; E.scale = 0.0; E.u0 = 0.0;
   bool own_loaded = false;
-  if (!part) { load_tile_regs(E, P, lw4, base); own_loaded = true; }
+  if (!part && !extra) { load_tile_regs(E, P, lw4, base); own_loaded = true; }
 
   // ---- tile masses: exclusive prefix of the own tile, total, ESS sums, heavy candidates ------------------------
   if (tid == 0) heavy_n = 0;
@@ -1295,8 +1305,10 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
   uint64_t v[kC];
   uint64_t chunk_pre = 0;  // exclusive prefix of this thread's first tile (no tile_prefix)
   if (tile_prefix) {
-    pre = tile_prefix[b];
-    own_mass = tile_prefix[b + 1] - pre;
+    if (!extra) {
+      pre = tile_prefix[b];
+      own_mass = tile_prefix[b + 1] - pre;
+    }
     tot = tile_prefix[A.ntiles];
     if (adaptive) { r1 = tile_prefix[A.ntiles + 1]; r2 = tile_prefix[A.ntiles + 2]; }
     n_heavy = (uint32_t)tile_prefix[A.ntiles + 3];
@@ -1410,8 +1422,8 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
     uint64_t it_tile = b, it_pre = pre;
     int64_t it_lo = A.out_lo, it_hi = A.out_hi;
     uint32_t skip_from = 0, skip_n = 0;
-    bool go = true, it_loaded = own_loaded;
-    if (part && !helping) {  // does the own tile serve anything here?
+    bool go = !extra, it_loaded = own_loaded;
+    if (part && !helping && !extra) {  // does the own tile serve anything here?
       if (!tile_prefix) own_mass = tile_sums[b];
       const int64_t t_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
       const int64_t t_hi = b + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(pre + own_mass, scale, u0, (int64_t)A.n_out);
@@ -1432,7 +1444,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
       uint32_t idle_rank = ~0u, n_idle = 0;
       if (tile_prefix) {
         n_idle = (uint32_t)tile_prefix[A.ntiles + 4 + 2 * kMaxHeavy];
-        if (own_mass == 0 && b + 1 < A.ntiles) {
+        if (!extra && own_mass == 0 && b + 1 < A.ntiles) {
           const uint64_t wd = tile_prefix[A.ntiles + 1 + kPrefixTail + (b >> 1)];
           idle_rank = (uint32_t)(wd >> (32 * (b & 1)));
         }
@@ -1459,7 +1471,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
           if (i < w) before += sh_u32[i];
           n_idle += sh_u32[i];
         }
-        if (k0 <= b && b < k0 + c) {  // the thread whose chunk holds the own tile: rank = idle tiles before it
+        if (!extra && k0 <= b && b < k0 + c) {  // the thread whose chunk holds the own tile: rank = idle tiles before it
           uint32_t r = before;
           uint64_t bm = 0;
           for (uint64_t k = k0; k <= b; ++k) {
@@ -1472,8 +1484,16 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
         }
         __syncthreads();
         idle_rank = sh_u32[kW];
-        own_mass = sh_scan[0];
+        if (!extra) own_mass = sh_scan[0];
       }
+      // the extra workgroups rank behind the idle tiles
+      if (A.extra_first) {
+        if (extra) idle_rank = (uint32_t)(b - A.ntiles);
+        else if (idle_rank != ~0u) idle_rank += A.n_extra;
+      } else if (extra) {
+        idle_rank = n_idle + (uint32_t)(b - A.ntiles);
+      }
+      n_idle += A.n_extra;
       // heavy entries in tile order, with their chunk grids
       uint64_t ts = 0, tp = 0;
       uint32_t pos = 0;
@@ -1500,27 +1520,38 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
         hv_win[pos] = nchunk > kOwnChunks ? (uint32_t)(nchunk - kOwnChunks) : 0u;
       }
       __syncthreads();
+      // Takers (idle tiles, then the launch's extra workgroups) take GROUPS of g consecutive delegable chunks of one heavy
+      // tile: g = 1 while there are at least as many takers as chunks, more when the launch has fewer extras than chunks
+      // (the extras are a fraction of the tiles: they cost a little in every ordinary step).  hv_cum counts groups.
+      uint32_t grp = 1;
       if ((uint32_t)tid < n_heavy) {
+        uint32_t total = 0;
+        for (uint32_t e = 0; e < n_heavy; ++e) total += hv_win[e];
+        const uint32_t takers = n_idle > n_heavy ? n_idle - n_heavy : 1u;  // (each heavy tile may round one group up)
+        grp = (total + takers - 1) / takers;
+        grp = grp < 1u ? 1u : grp;
         uint32_t cum = 0;
-        for (uint32_t e = 0; e < (uint32_t)tid; ++e) cum += hv_win[e];
+        for (uint32_t e = 0; e < (uint32_t)tid; ++e) cum += (hv_win[e] + grp - 1) / grp;
         hv_cum[tid] = cum;
       }
-      if (tid == 0) { sh_u32[kW + 1] = ~0u; sh_u32[kW + 2] = 0; }
+      if (tid == 0) { sh_u32[kW + 1] = ~0u; sh_u32[kW + 2] = 0; sh_u32[kW + 3] = 1; }
       __syncthreads();
       // this workgroup's item: thread p speaks for heavy entry p
       if ((uint32_t)tid < n_heavy) {
-        const uint32_t p = (uint32_t)tid, cum = hv_cum[p], win = hv_win[p];
-        if (hv_tile[p] == (uint32_t)b) {  // the own tile is heavy: it keeps its first kOwnChunks and what no idle workgroup takes
+        const uint32_t p = (uint32_t)tid, cum = hv_cum[p], win = hv_win[p], groups = (win + grp - 1) / grp;
+        if (hv_tile[p] == (uint32_t)b) {  // the own tile is heavy: it keeps its first kOwnChunks and what no taker takes
+          const uint32_t taken = n_idle > cum ? (n_idle - cum < groups ? n_idle - cum : groups) : 0u;
           sh_u32[kW + 1] = p;
-          sh_u32[kW + 2] = n_idle > cum ? (n_idle - cum < win ? n_idle - cum : win) : 0u;  // delegated chunks
-        } else if (idle_rank != ~0u && idle_rank >= cum && idle_rank - cum < win) {
-          sh_u32[kW + 1] = p | 0x80000000u;  // an idle workgroup: chunk kOwnChunks + (rank - cum) of heavy tile p
+          sh_u32[kW + 2] = taken * grp < win ? taken * grp : win;  // delegated chunks
+        } else if (idle_rank != ~0u && idle_rank >= cum && idle_rank - cum < groups) {
+          sh_u32[kW + 1] = p | 0x80000000u;  // a taker: group (rank - cum) of heavy tile p
+          sh_u32[kW + 3] = grp;
         }
       }
       __syncthreads();
       const uint32_t sel = sh_u32[kW + 1];
       if (sel == ~0u) {
-        if (part) {  // an ordinary tile of a sharded launch: does it serve anything here?
+        if (part && !extra) {  // an ordinary tile of a sharded launch: does it serve anything here?
           const int64_t t_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
           const int64_t t_hi = b + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(pre + own_mass, scale, u0, (int64_t)A.n_out);
           go = !(t_hi <= A.out_lo || t_lo >= A.out_hi);
@@ -1528,11 +1559,12 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
         if (idle_rank != ~0u) go = false;  // an idle tile nobody needs: it owns no slot
       } else if (sel & 0x80000000u) {
         const uint32_t p = sel & 0x7fffffffu;
-        const int64_t ci = (int64_t)kOwnChunks + (int64_t)(idle_rank - hv_cum[p]);
+        const int64_t g = (int64_t)sh_u32[kW + 3];
+        const int64_t ci = (int64_t)kOwnChunks + (int64_t)(idle_rank - hv_cum[p]) * g;  // its first chunk
         it_tile = hv_tile[p];
         it_pre = hv_pre[p];
         it_lo = hv_first[p] + ci * (int64_t)kTile;
-        it_hi = it_lo + (int64_t)kTile < hv_hi[p] ? it_lo + (int64_t)kTile : hv_hi[p];
+        it_hi = it_lo + g * (int64_t)kTile < hv_hi[p] ? it_lo + g * (int64_t)kTile : hv_hi[p];
         it_loaded = false;
         go = it_lo < it_hi;
       } else {
@@ -1552,7 +1584,11 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
       float bm = shf[0];
 #pragma unroll
       for (int i = 1; i < kW; ++i) bm = shf[i] > bm ? shf[i] : bm;
-      if (max_partials) max_partials[b] = bm;
+      if (extra) {
+        if (extra_max) extra_max[b - A.ntiles] = bm;  // (-inf when nothing was served: every launch refreshes it)
+      } else if (max_partials) {
+        max_partials[b] = bm;
+      }
     }
   }
 }

@@ -601,7 +601,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_wave(const float* lw, uint
                                                       uint64_t* tile_sums_at, float* max_out,
                                                       uint32_t filter_tiles, uint64_t filter_stride,
                                                       uint64_t mq_stride, uint32_t ntiles_local,
-                                                      uint64_t* tile_ess_at) {
+                                                      uint64_t* tile_ess_at,
+                                                      const float* extra_partials, uint32_t n_extra) {
   __shared__ float shf[kBlock / kWave];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t tiles = filter_tiles ? filter_tiles : ntiles_local;
@@ -612,6 +613,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_wave(const float* lw, uint
     g -= f * groups;
     lw += f * filter_stride;
     if (max_partials) max_partials += f * filter_tiles;
+    if (extra_partials) extra_partials += f * n_extra;
     tile_sums_at += f * filter_tiles;
     if (tile_ess_at) tile_ess_at += 2 * f * filter_tiles;
     if (max_out) max_out += f * mq_stride;
@@ -643,6 +645,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_wave(const float* lw, uint
       const float v = max_partials[k];
       m = v > m ? v : m;
     }
+    if (extra_partials)  // (launch-uniform) what the extra workgroups of the resample kernel served
+      for (uint32_t k = threadIdx.x; k < n_extra; k += kBlock) {
+        const float v = extra_partials[k];
+        m = v > m ? v : m;
+      }
     m = block_max(m, shf);
     if (max_out && g == 0 && threadIdx.x == 0) max_out[0] = m;
   }
@@ -677,7 +684,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_block(const float* lw, uin
                                                       const float* m_ptr, int frac,
                                                       uint64_t* tile_sums_at, float* max_out,
                                                       uint32_t filter_tiles, uint64_t filter_stride,
-                                                      uint64_t mq_stride, uint64_t* tile_ess_at) {
+                                                      uint64_t mq_stride, uint64_t* tile_ess_at,
+                                                      const float* extra_partials, uint32_t n_extra) {
   __shared__ uint64_t sh64[3 * (kBlock / kWave)];
   __shared__ float shf[kBlock / kWave];
   uint64_t tile = blockIdx.x;
@@ -686,6 +694,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_block(const float* lw, uin
     tile -= f * filter_tiles;
     lw += f * filter_stride;
     if (max_partials) max_partials += f * filter_tiles;
+    if (extra_partials) extra_partials += f * n_extra;
     tile_sums_at += f * filter_tiles;
     if (tile_ess_at) tile_ess_at += 2 * f * filter_tiles;
     if (max_out) max_out += f * mq_stride;
@@ -706,6 +715,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_block(const float* lw, uin
       const float v = max_partials[k];
       m = v > m ? v : m;
     }
+    if (extra_partials)  // (launch-uniform) what the extra workgroups of the resample kernel served
+      for (uint32_t k = threadIdx.x; k < n_extra; k += kBlock) {
+        const float v = extra_partials[k];
+        m = v > m ? v : m;
+      }
     m = block_max(m, shf);
     if (max_out && tile == 0 && threadIdx.x == 0) max_out[0] = m;
   }
@@ -1973,7 +1987,7 @@ static int weights_prepare(const float* logw, uint64_t n, Carver& cv, float** m_
   float* m = cv.take<float>(1);
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   k_max_partials<<<grid_for(n), kBlock, 0, st>>>(logw, n, mp);
-  k_tile_sums_block<false><<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, nullptr, frac_bits(n), tiles, m, 0, 0, 0, nullptr);
+  k_tile_sums_block<false><<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, nullptr, frac_bits(n), tiles, m, 0, 0, 0, nullptr, nullptr, 0u);
   *m_out = m;
   *tiles_out = tiles;
   return GJX_OK;
@@ -2041,11 +2055,15 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
   A.rkey = k; A.rkey_has_fold = key->has_fold; A.rkey_fold = key->fold;
   A.q_total_out = out_q ? out_q : qtot;
   A.tile_prefix = nullptr;
-  A.allow_help = n_out <= A.ntiles * (uint64_t)kTile ? 1 : 0;  // helpers are the workgroups of the output windows
+  A.allow_help = 1;
   A.heavy_frac = (double)(kCapSlots - 8) / (double)n_out;
+  // one extra (tile-less) workgroup per chunk of output slots: a heavy tile can always delegate (no maxima to keep here)
+  const uint64_t chunks = (n_out + kTile - 1) / kTile;
+  A.n_extra = (uint32_t)(chunks < 1024 ? (chunks + 3) / 4 : 256 + (chunks < 32768 ? chunks / 32 : 1024));  // takers take groups of chunks
   AncestorOnly P{ancestors};
-  if (key->impl == 0) k_resample<0, AncestorOnly><<<(unsigned)A.ntiles, kBlock, 0, S(s)>>>(A, P, nullptr);
-  else k_resample<1, AncestorOnly><<<(unsigned)A.ntiles, kBlock, 0, S(s)>>>(A, P, nullptr);
+  const unsigned grid = (unsigned)A.ntiles + A.n_extra;
+  if (key->impl == 0) k_resample<0, AncestorOnly><<<grid, kBlock, 0, S(s)>>>(A, P, nullptr);
+  else k_resample<1, AncestorOnly><<<grid, kBlock, 0, S(s)>>>(A, P, nullptr);
   if (out_max) (void)hipMemcpyAsync(out_max, m, sizeof(float), hipMemcpyDeviceToDevice, S(s));
   return launch_status();
 }
@@ -2121,6 +2139,9 @@ struct StepCtx {
   FilterBatch fb;
   uint64_t* tile_ess = nullptr;    // whole-run drivers of adaptive filters: their workspace copy (else cfg->tile_ess)
   int32_t* resampled_out = nullptr;  // this step's entry of cfg->resampled_out
+  // whole-run drivers: extra (tile-less) workgroups per filter and where their maxima go (ResampleArgs::n_extra)
+  uint32_t n_extra = 0;
+  float* extra_max = nullptr;
 };
 
 static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const float* prev_logw,
@@ -2143,6 +2164,13 @@ static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const fl
     A.tile_ess = ctx.tile_ess ? ctx.tile_ess : cfg->tile_ess;
   }
   A.resampled_out = ctx.resampled_out ? ctx.resampled_out : (cfg->resampled_out && !(cfg->n_filters > 1) ? cfg->resampled_out + t : nullptr);
+  A.n_extra = ctx.n_extra;
+  A.extra_max = ctx.extra_max;
+  static const int extra_first = [] {
+    const char* e = std::getenv("GJX_SMC_EXTRA_FIRST");
+    return e && e[0] == '1' ? 1 : 0;
+  }();
+  A.extra_first = extra_first;
   return A;
 }
 
@@ -2167,12 +2195,12 @@ static int lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, 
   const bool ad = A.ess_thr > 0.0;
   if (cfg->impl == 0) {
     LgssmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {}};
-    if (ad) k_resample<0, LgssmPolicy<0>, true><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
-    else k_resample<0, LgssmPolicy<0>, false><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    if (ad) k_resample<0, LgssmPolicy<0>, true><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    else k_resample<0, LgssmPolicy<0>, false><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   } else {
     LgssmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {}};
-    if (ad) k_resample<1, LgssmPolicy<1>, true><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
-    else k_resample<1, LgssmPolicy<1>, false><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    if (ad) k_resample<1, LgssmPolicy<1>, true><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    else k_resample<1, LgssmPolicy<1>, false><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   }
   return launch_status();
 }
@@ -2200,12 +2228,12 @@ static int hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int3
   const bool ad = A.ess_thr > 0.0;
   if (cfg->impl == 0) {
     HmmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {}, 0.0f};
-    if (ad) k_resample<0, HmmPolicy<0>, true><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
-    else k_resample<0, HmmPolicy<0>, false><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    if (ad) k_resample<0, HmmPolicy<0>, true><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    else k_resample<0, HmmPolicy<0>, false><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   } else {
     HmmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {}, 0.0f};
-    if (ad) k_resample<1, HmmPolicy<1>, true><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
-    else k_resample<1, HmmPolicy<1>, false><<<nt * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    if (ad) k_resample<1, HmmPolicy<1>, true><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    else k_resample<1, HmmPolicy<1>, false><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
   }
   return launch_status();
 }
@@ -2254,14 +2282,14 @@ static int smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const 
     const unsigned groups = (unsigned)((nt_local + kTilesPerSumBlock - 1) / kTilesPerSumBlock);
 #define GJX_TS_WAVE(E) k_tile_sums_wave<E><<<groups * nf, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total, m_ptr, \
     frac_bits(cfg->n_total), tile_sums + tile0, m_ptr ? nullptr : max_out, nf > 1 ? fb.tiles : 0u, fb.stride, fb.mq_stride,           \
-    (uint32_t)nt_local, tile_ess ? tile_ess + 2 * tile0 : nullptr)
+    (uint32_t)nt_local, tile_ess ? tile_ess + 2 * tile0 : nullptr, ctx.extra_max, ctx.n_extra)
     if (tile_ess) GJX_TS_WAVE(true);
     else GJX_TS_WAVE(false);
 #undef GJX_TS_WAVE
   } else {
 #define GJX_TS_BLOCK(E) k_tile_sums_block<E><<<(unsigned)nt_local * nf, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials,      \
     nt_total, m_ptr, frac_bits(cfg->n_total), tile_sums + tile0, m_ptr ? nullptr : max_out, nf > 1 ? fb.tiles : 0u, fb.stride,           \
-    fb.mq_stride, tile_ess ? tile_ess + 2 * tile0 : nullptr)
+    fb.mq_stride, tile_ess ? tile_ess + 2 * tile0 : nullptr, ctx.extra_max, ctx.n_extra)
     if (tile_ess) GJX_TS_BLOCK(true);
     else GJX_TS_BLOCK(false);
 #undef GJX_TS_BLOCK
@@ -2308,6 +2336,8 @@ struct RunCommon {
   uint64_t* tiles = nullptr;
   uint64_t* prefix = nullptr;
   uint64_t* tile_ess = nullptr;
+  uint32_t n_extra = 0;       // extra (tile-less) workgroups per filter in the resample launches
+  float* extra_max = nullptr;  // [F, n_extra]
   FilterBatch fb;
 };
 static int run_common_init(const gjx_smc_config* cfg, Carver& cv, RunCommon& rc, float* out_max, gjx_stream s) {
@@ -2325,7 +2355,21 @@ static int run_common_init(const gjx_smc_config* cfg, Carver& cv, RunCommon& rc,
   rc.tiles = cv.take<uint64_t>(rc.F * rc.nt);
   rc.prefix = scan ? cv.take<uint64_t>(rc.F * prefix_words(rc.nt)) : nullptr;
   rc.tile_ess = cfg_adaptive(cfg) ? cv.take<uint64_t>(2 * rc.F * rc.nt) : nullptr;
+  // Takers for a heavy tile's delegated chunks when no tile is idle (gjx_device.hpp ResampleArgs::n_extra): one extra
+  // workgroup per 8 tiles (per 16 in a filter batch).  A taker serves a GROUP of consecutive chunks, so an eighth is
+  // enough to spread a tile that owns everything over ~120 workgroups; in ordinary steps they exit after the mass scan
+  // (measured: +1.3 % on a one-filter step, +1.5 % on 16 filters).  Not with a separate max reduction (> kPrefixTiles tiles).
+  static const int extra_div = [] {
+    const char* e = std::getenv("GJX_SMC_EXTRA_DIV");  // tuning / test knob: 0 = no extra workgroups
+    return e ? atoi(e) : -1;
+  }();
+  const uint64_t div = extra_div >= 0 ? (uint64_t)extra_div : (rc.F > 1 ? 16u : 8u);
+  rc.n_extra = (div == 0 || rc.nt > kPrefixTiles) ? 0u : (uint32_t)((rc.nt + div - 1) / div);
+  rc.extra_max = rc.n_extra ? cv.take<float>((size_t)rc.F * rc.n_extra) : nullptr;
   if (!cv.ok) return GJX_ERR_WORKSPACE;
+  // (-inf until a resample launch has run: step 0 has no extra workgroups)
+  if (rc.extra_max && hipMemsetD32Async((hipDeviceptr_t)rc.extra_max, (int)0xFF800000u, (size_t)rc.F * rc.n_extra, S(s)) != hipSuccess)
+    return GJX_ERR_LAUNCH;
   if (rc.F > 1) {
     rc.fb.n_filters = rc.F; rc.fb.tiles = (uint32_t)rc.nt; rc.fb.stride = rc.stride; rc.fb.mq_stride = (uint64_t)cfg->n_steps;
   }
@@ -2345,6 +2389,8 @@ static StepCtx run_step_ctx(const gjx_smc_config* cfg, RunCommon& rc, int t, flo
   StepCtx ctx;
   ctx.fb = rc.fb;
   ctx.tile_ess = rc.tile_ess;
+  ctx.n_extra = rc.n_extra;
+  ctx.extra_max = rc.extra_max;
   if (rc.prefix && t) {
     k_scan_tiles<<<rc.F, kBlock, 0, S(s)>>>(rc.tiles, rc.tile_ess, rc.nt, cfg->n_total, rc.prefix);
     ctx.tile_prefix = rc.prefix;
@@ -2546,7 +2592,7 @@ static int smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, gjx_ji
   ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out, ctx);
   if (A.ess_thr > 0.0 && !A.tile_ess) return GJX_ERR_INVALID;
   void* args[] = {&A, &PA, &max_partials_out};
-  if (hipModuleLaunchKernel(c.step, nt * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
+  if (hipModuleLaunchKernel(c.step, (nt + A.n_extra) * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
   return launch_status();
 }
 

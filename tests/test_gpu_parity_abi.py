@@ -4,6 +4,7 @@ outputs are compared BIT-EXACTLY (tolerance 0), which is stronger than the north
 relative bound on log-weights."""
 
 import math
+import os
 
 import numpy as np
 import pytest
@@ -438,6 +439,56 @@ def test_smc_collapse_helpers(hip_ops, oracle_ops, impl, n):  # 2.2e6: the same 
             elif what == "ancestors":
                 a, b = a[:, :, :n], b[:, :, :n]
             same(a, b, what + " (batch of 5)")
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n,n_out", [(300_000, 300_000), (70_004, 70_004), (50_000, 200_000)])
+def test_resample_heavy_tile_without_idle_tiles(hip_ops, oracle_ops, impl, n, n_out):
+    """One particle holds most of the mass and EVERY other particle has some: no tile is idle, so the heavy tile's
+    delegated chunks go to the extra (tile-less) workgroups of the launch.  Ancestors are the oracle's; also with two
+    heavy tiles and with more output slots than particles."""
+    kb = KeyBatch(impl, 2, parent=(5, 6))
+    for heavy in ([n // 3], [7, n - 5]):
+        lw = torch.zeros(n)
+        for i in heavy:
+            lw[i] = math.log(1.5 * n / len(heavy))
+        a, m, q = hip_ops.resample("systematic", kb, lw.to(hip_ops.device()), n_out)
+        b, mo, qo = oracle_ops.resample("systematic", kb, lw, n_out)
+        same(a, b, "ancestors")
+        same(q, qo, "total mass")
+        cnt = torch.bincount(b.long(), minlength=n)
+        assert int(cnt.max()) > 0.25 * n_out and int((cnt > 0).sum()) > 0.2 * min(n, n_out)
+
+
+def test_smc_extra_workgroups_serve(hip_ops):
+    """The extra workgroups' side of a filter run — their served maxima reach the step's global maximum through
+    `extra_max` — exercised by ranking them BEFORE the idle tiles (GJX_SMC_EXTRA_FIRST=1, read when the library loads:
+    a child process): the collapsing-weights filter equals the oracle's bit for bit with them doing the serving."""
+    import subprocess
+    import sys
+
+    child = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import torch
+from genjax._amd.abi import GjxLib
+from genjax._amd.ops import Ops
+from genjax._amd.runtime import load_hip_ops
+from test_gpu_parity_abi import degenerate_lgssm_run
+hip, ora = load_hip_ops(), Ops(GjxLib(sys.argv[3], "cpu"))
+for impl in (0, 1):
+    for n, T in ((300_000, 8), (20_000, 8)):
+        h, o = degenerate_lgssm_run(hip, impl, n, T), degenerate_lgssm_run(ora, impl, n, T)
+        for a, b in zip(h, o):
+            assert torch.equal(a.cpu(), b.cpu())
+print("ok")
+"""
+    from conftest import ORACLE_LIB, ROOT
+
+    env = dict(os.environ, GJX_SMC_EXTRA_FIRST="1")
+    r = subprocess.run([sys.executable, "-c", child, os.path.join(ROOT, "genjax-chi_amd"), os.path.join(ROOT, "tests"), ORACLE_LIB],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 ESS_CASES = [("lgssm", 5000, 30, 0.5, 1), ("lgssm", 1024, 12, 0.9, 1), ("lgssm", 70000, 25, 0.3, 1), ("lgssm", 3000, 20, 0.5, 5),
