@@ -723,6 +723,9 @@ struct ModuleCache {
       for (auto it = map.begin(); it != map.end(); ++it)
         if (it->second.refs == 0 && (victim == map.end() || it->second.tick < victim->second.tick)) victim = it;
       if (victim == map.end()) return;  // everything is in use
+      // no plan references the module, but launches of its kernels may still be in flight on some stream: an eviction
+      // is rare (a process that keeps generating new model structures), so wait for the device before unloading
+      (void)hipDeviceSynchronize();
       (void)hipModuleUnload(victim->second.mod);
       map.erase(victim);
       ++evictions;

@@ -133,6 +133,10 @@ struct LocalTransport : Transport {
   int stream_sync(gjx_stream s) override { return mem.sync(s); }
 };
 
+// Tickets of the range kernel (gjx_smc_source_ranges): process-wide and never reused, so a ticket left in a caller's
+// `ranges` buffer by an earlier run — of any model — cannot be mistaken for the current one.
+inline std::atomic<int64_t> g_ticket_source{0};
+
 // ---- the sharded filter -----------------------------------------------------------------------------------------------
 // StepA: int(int t, int cur, int prv) -> status: step A of step t for the rank's own slots (buffers by parity).
 template <class StepA>
@@ -148,7 +152,6 @@ int sharded_run(Transport& T, const gjx_smc_config* cfg, int n_state, size_t sta
   const bool adaptive = cfg->ess_threshold > 0.0f && cfg->ess_threshold < 1.0f;
   if (adaptive && !cfg->tile_ess) return GJX_ERR_INVALID;
   uint64_t received = 0;
-  static std::atomic<int64_t> ticket_source{0};  // process-wide: a ticket left in `ranges` by an earlier run never matches
   int64_t ticket = 0;
   int rc = GJX_OK;
   for (int t = 0; t < cfg->n_steps && rc == GJX_OK; ++t) {
@@ -171,7 +174,7 @@ int sharded_run(Transport& T, const gjx_smc_config* cfg, int n_state, size_t sta
       received += N - nl;
       continue;
     }
-    ticket = ++ticket_source;
+    ticket = ++g_ticket_source;
     if ((rc = gjx_smc_source_ranges(cfg, io->tile_sums, world, ticket, io->ranges, s))) break;
     // the range kernel stores its words straight into pinned host memory, the ticket last with a system-scope release:
     // poll the ticket instead of synchronising the stream; if it does not show up soon, wait for the stream
