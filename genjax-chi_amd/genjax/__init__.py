@@ -12,7 +12,8 @@ from ._amd.lang import (AddressReuse, Distribution, GenerativeFunction, Generati
                         StaticGenerativeFunction, Trace, bernoulli, beta, categorical, exact_density, flip, gamma,
                         gen, normal)
 from ._amd.combinators import Scan, Vmap, scan, vmap
-from ._amd.edit import Diff, EditRequest, NoChange, NotSupportedEditRequest, Regenerate, UnknownChange, Update
+from ._amd.edit import (Diff, EditRequest, EmptyRequest, NoChange, NotSupportedEditRequest, Regenerate, Rejuvenate, StaticRequest,
+                        UnknownChange, Update)
 from ._amd.inference import Algorithm, Marginal, SampleDistribution, Target, marginal
 from ._amd import prng as _prng
 from ._amd.lang import split as _split, fold_in as _fold_in
@@ -38,7 +39,7 @@ random = _Random()
 
 __all__ = [
     "AddressReuse", "Algorithm", "ChoiceMap", "ChoiceMapBuilder", "ChoiceMapNoValueAtAddress", "Diff", "Distribution",
-    "EditRequest", "NoChange", "NotSupportedEditRequest", "Regenerate", "UnknownChange", "Update", "GenerativeFunction", "GenerativeFunctionClosure", "Marginal", "Mask", "MissingAddress", "SampleDistribution", "Scan",
+    "EditRequest", "EmptyRequest", "NoChange", "NotSupportedEditRequest", "Regenerate", "Rejuvenate", "StaticRequest", "UnknownChange", "Update", "GenerativeFunction", "GenerativeFunctionClosure", "Marginal", "Mask", "MissingAddress", "SampleDistribution", "Scan",
     "Selection", "SelectionBuilder", "StaticGenerativeFunction", "Target", "Trace", "bernoulli", "beta",
     "categorical", "exact_density", "flip", "gamma", "gen", "inference", "jaxlike", "marginal", "normal", "random",
     "scan", "Vmap", "vmap",

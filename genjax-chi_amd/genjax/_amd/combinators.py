@@ -190,6 +190,12 @@ class Scan(GenerativeFunction):
         return tr if batched else tr.map_leaves(squeeze_leaf)
 
     def generate(self, key, constraint: ChoiceMap, args):
+        if isinstance(key, ParticleKeys):
+            # per-particle constraints arrive particle-major, [n, T], like the trace's own choices (the reference's vmap
+            # batches the leading axis): make them time-major so that `get_submap(t)` takes step t's column
+            n, T = key.n, self._length(args[1])
+            constraint = constraint.map_leaves(
+                lambda v: v.t() if isinstance(v, torch.Tensor) and v.dim() == 2 and tuple(v.shape) == (n, T) else v)
         fused = self._fused(key, constraint, args)
         if fused is not None:
             return fused

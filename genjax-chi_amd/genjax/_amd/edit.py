@@ -154,10 +154,60 @@ class Update(PrimitiveEditRequest):
 
 @dataclass(frozen=True)
 class Regenerate(PrimitiveEditRequest):
-    """requests.py:64-66.  Named for API parity; no generative function on this path answers it
-    (`NotSupportedEditRequest`): MCMC rejuvenation is outside the SMC / ImportanceK hot path."""
+    """requests.py:64-66: re-draw the selected choices from their distributions at the (new) arguments, keep and
+    re-score the others.  Answered by distributions (distribution.py:258-300: a selected site takes a fresh value, its
+    weight is `new score − old score`, the old value is the backward `Update`), by the static language site by site
+    (static.py:616-715: site keys `fold_in(key, counter)`, counter from 1) and by `Scan` / `Vmap` element-wise."""
 
     selection: Any
+
+
+@dataclass(frozen=True)
+class StaticRequest(PrimitiveEditRequest):
+    """static.py:130-131: one edit request per address of a static generative function (addresses without an entry get
+    `EmptyRequest`).  It is what a static `Regenerate` hands back as its backward request."""
+
+    addressed: dict
+
+    def __hash__(self):
+        return id(self)
+
+
+@dataclass(frozen=True)
+class EmptyRequest(EditRequest):
+    """requests.py:46-60: nothing changes unless the arguments did (then an `Update` with an empty constraint)."""
+
+    def edit(self, key, tr, argdiffs):
+        if Diff.static_check_no_change(argdiffs):
+            return tr, 0.0, Diff.no_change(tr.get_retval()), EmptyRequest()
+        return Update(ChoiceMap.empty()).edit(key, tr, argdiffs)
+
+
+@dataclass(frozen=True)
+class Rejuvenate(EditRequest):
+    """inference/requests/rejuvenate.py:45-94: a Metropolis-Hastings move with a custom proposal, without the
+    accept / reject step — the ratio is returned as the (SMCP3) weight.  `proposal.propose(key, argument_mapping(choices))`
+    proposes new values, the trace is `Update`d to them, and the proposal is assessed at the discarded values:
+    `w = update weight + log q(old | new) − log q(new | old)`.  Over a population every step is one kernel per site."""
+
+    proposal: Any
+    argument_mapping: Any
+
+    def edit(self, key, tr, argdiffs):
+        from .lang import split
+
+        chm = tr.get_choices()
+        fwd_args = self.argument_mapping(chm)
+        key, sub_key = split(key)
+        proposed, fwd_score, _ = self.proposal.propose(sub_key, fwd_args)
+        new_tr, w, retdiff, bwd = Update(proposed).edit(key, tr, argdiffs)
+        assert isinstance(bwd, Update)
+        bwd_chm = bwd.constraint
+        bwd_score, _ = self.proposal.assess(bwd_chm, self.argument_mapping(bwd_chm))
+        return new_tr, w + bwd_score - fwd_score, retdiff, Rejuvenate(self.proposal, self.argument_mapping)
+
+    def __hash__(self):
+        return id(self)
 
 
 # ---- the generic answer to Update ------------------------------------------------------------------
@@ -179,6 +229,21 @@ def generic_update(gen_fn, key, trace, constraint: ChoiceMap, argdiffs):
     unchanged = constraint.static_is_empty() and Diff.static_check_no_change(argdiffs)
     retval = new_trace.get_retval()
     return new_trace, w, (Diff.no_change(retval) if unchanged else Diff.unknown_change(retval)), Update(discard)
+
+
+def generic_regenerate(gen_fn, key, trace, selection, argdiffs):
+    """`Regenerate` by re-generation, for the combinators (scan.py:430-470, 613: the request is handed down to every
+    element's kernel trace): the choices outside the selection are constrained to their old values, the selected ones
+    are drawn afresh.  Under the reference's rule every site contributes `its new score − its old score` (a selected
+    site's weight is the score of its fresh value minus the old one, distribution.py:268-280), so the weight of any
+    structure is `new total score − old total score`; the backward request restores the discarded values."""
+    args = Diff.tree_primal(argdiffs)
+    old = trace.get_choices()
+    kept = old.filter(~selection)
+    new_trace, _ = gen_fn.generate(key, kept, args)
+    w = new_trace.get_score() - trace.get_score()
+    retval = new_trace.get_retval()
+    return new_trace, w, Diff.unknown_change(retval), Update(old.filter(selection))
 
 
 def as_weight(w, like=None):

@@ -408,10 +408,12 @@ class GenerativeFunction:
     def edit(self, key, trace: Trace, edit_request, argdiffs):
         """generative_function.py:496-610.  `Update` is answered by re-generation unless a subclass
         walks its own structure; other requests are not supported on this path."""
-        from .edit import NotSupportedEditRequest, Update, generic_update
+        from .edit import NotSupportedEditRequest, Regenerate, Update, generic_regenerate, generic_update
 
         if isinstance(edit_request, Update):
             return generic_update(self, key, trace, edit_request.constraint, argdiffs)
+        if isinstance(edit_request, Regenerate):
+            return generic_regenerate(self, key, trace, edit_request.selection, argdiffs)
         raise NotSupportedEditRequest(edit_request)
 
     def update(self, key, trace: Trace, constraint: ChoiceMap, argdiffs):
@@ -559,6 +561,38 @@ class UpdateHandler(_Handler):
         return Diff.tree_primal(retdiff)
 
 
+class RequestHandler(_Handler):
+    """static.py:510-566 (StaticEditRequestHandler) and 616-676 (RegenerateRequestHandler): each visited site edits its
+    previous sub-trace with its own request; the site key is `fold_in(key, counter)`, counter from 1 over ALL sites."""
+
+    def __init__(self, key, previous_trace: "StaticTrace", request):
+        super().__init__()
+        self.key, self.previous_trace, self.request = key, previous_trace, request
+        self.counter = 1
+        self.weight = 0.0
+        self.bwd_requests: list = []
+
+    def handle_trace(self, addr, gen_fn, args):
+        from .edit import Diff, EmptyRequest, Regenerate
+
+        try:
+            subtrace = self.previous_trace.get_inner_trace(addr)
+        except KeyError:
+            raise MissingAddress(addr) from None
+        a = addr if isinstance(addr, tuple) else (addr,)
+        if isinstance(self.request, Regenerate):
+            sub = Regenerate(self.request.selection(*a))
+        else:
+            sub = self.request.addressed.get(addr, EmptyRequest())
+        sub_key = fold_in(self.key, self.counter)
+        self.counter += 1
+        tr, w, retdiff, bwd = sub.edit(sub_key, subtrace, Diff.unknown_change(tuple(args)))
+        self.bwd_requests.append((addr, bwd))
+        self.weight = self.weight + w
+        self.record(addr, tr)
+        return Diff.tree_primal(retdiff)
+
+
 class AssessHandler(_Handler):
     def __init__(self, sample: ChoiceMap):
         super().__init__()
@@ -642,8 +676,19 @@ class StaticGenerativeFunction(GenerativeFunction):
     def edit(self, key, trace: StaticTrace, edit_request, argdiffs):
         """static.py:827-865 (`edit_update`): re-run the body at the new arguments, editing each site's
         previous sub-trace; the backward request restores the discarded values."""
-        from .edit import Diff, NotSupportedEditRequest, Update
+        from .edit import Diff, NotSupportedEditRequest, Regenerate, StaticRequest, Update
 
+        if isinstance(edit_request, (Regenerate, StaticRequest)):
+            # static.py:505-715, 867-960: every visited site edits its previous sub-trace with its sub-request
+            # (`Regenerate(selection(addr))`, or the addressed request / `EmptyRequest`), site keys fold_in(key, counter)
+            args = Diff.tree_primal(argdiffs)
+            pk, batched = as_particle_keys(key)
+            if not batched and batch_size_of(trace.get_score()) is not None:
+                raise TypeError("a population trace needs per-particle keys (split(key, n)) for an edit")
+            h = RequestHandler(key, trace, edit_request)  # (a scalar key stays scalar: its sites draw scalars)
+            retval = h.run(self.source, args)
+            new_trace = StaticTrace(self, args, retval, h.traces)
+            return new_trace, h.weight, Diff.unknown_change(retval), StaticRequest(dict(h.bwd_requests))
         if not isinstance(edit_request, Update):
             raise NotSupportedEditRequest(edit_request)
         constraint = edit_request.constraint
@@ -790,8 +835,21 @@ class Distribution(GenerativeFunction):
         is the discard).  A `Mask(value, flag)` constraint (distribution.py:214-243: `cond(flag, ...)`) replaces the
         value where the flag holds and keeps the old one elsewhere — over a population: one select and ONE
         log-density kernel on the merged column; the discard is the old value under the same flag."""
-        from .edit import Diff, NotSupportedEditRequest, Update
+        from .edit import Diff, NotSupportedEditRequest, Regenerate, Update
 
+        if isinstance(edit_request, Regenerate):
+            # distribution.py:258-300: selected -> a fresh draw at the new arguments, weight = its score − the old score,
+            # the old value is the backward Update; not selected -> keep the value (re-score it if the arguments moved)
+            primals = Diff.tree_primal(argdiffs)
+            if edit_request.selection.check():
+                w, new_v = self.random_weighted(key, *primals)
+                return (DistributionTrace(self, primals, new_v, w), w - trace.get_score(), Diff.unknown_change(new_v),
+                        Update(ChoiceMap.choice(trace.get_retval())))
+            if Diff.static_check_no_change(argdiffs):
+                return trace, 0.0, Diff.no_change(trace.get_retval()), Update(ChoiceMap.empty())
+            old = trace.get_retval()
+            fwd = self.estimate_logpdf(key, old, *primals)
+            return DistributionTrace(self, primals, old, fwd), fwd - trace.get_score(), Diff.no_change(old), Update(ChoiceMap.empty())
         if not isinstance(edit_request, Update):
             raise NotSupportedEditRequest(edit_request)
         constraint = edit_request.constraint

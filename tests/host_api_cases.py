@@ -265,7 +265,7 @@ def case_update(impl):
     same, w0, rd0, _ = tr.update(key, C.n())
     assert f(w0) == 0.0 and rd0.tangent is genjax.NoChange
     with pytest.raises(genjax.NotSupportedEditRequest):
-        tr.edit(key, genjax.Regenerate(S["v1"]))
+        tr.edit(key, genjax._amd.edit.PrimitiveEditRequest())  # (an unknown primitive request; Regenerate & co. are answered)
     with pytest.raises(genjax.MissingAddress):  # a previous trace that never visited "y1" (static.py:432-436)
         simple_linked_normal.update(sub_key, StaticTrace(simple_linked_normal, (), None, {}), C.n(), ())
 
@@ -1084,7 +1084,98 @@ def case_general_smc(impl):
         smc2._run_chunk = orig
 
 
+# ---- Regenerate / StaticRequest / Rejuvenate (requests.py:46-66; static.py:505-715; rejuvenate.py:45-94) -----------------
+def case_regenerate_and_rejuvenate(impl):
+    """Mirrors tests/inference/test_requests.py:37-196: a selected site takes a fresh draw and the weight is the change of
+    the target density; the backward request restores the old trace with the opposite weight; Metropolis-Hastings with
+    either request converges on a sharply observed value — run here over a population of independent chains."""
+    from genjax import Regenerate, StaticRequest
+    from genjax.inference.requests import Rejuvenate
+
+    @gen
+    def simple_normal():
+        y1 = normal(0.0, 1.0) @ "y1"
+        y2 = normal(0.0, 1.0) @ "y2"
+        return y1 + y2
+
+    key = genjax.random.key(314159, impl)
+    key, sub_key = genjax.random.split(key)
+    tr = simple_normal.simulate(sub_key, ())
+    for addr, sel in (("y1", S["y1"]), ("y2", S["y2"])):
+        old_v = tr.get_choices()[addr]
+        new_tr, fwd_w, _, bwd = Regenerate(sel).edit(key, tr, ())
+        new_v = new_tr.get_choices()[addr]
+        assert f(old_v) != f(new_v) and f(fwd_w) != 0.0
+        assert f(fwd_w) == pytest.approx(f(normal.logpdf(new_v, 0.0, 1.0)) - f(normal.logpdf(old_v, 0.0, 1.0)), abs=1e-6)
+        other = "y2" if addr == "y1" else "y1"
+        assert f(new_tr.get_choices()[other]) == f(tr.get_choices()[other])
+        old_tr, bwd_w, _, _ = bwd.edit(sub_key, new_tr, ())
+        assert f(fwd_w) + f(bwd_w) == pytest.approx(0.0, abs=1e-6)
+        assert f(old_tr.get_choices()[addr]) == f(old_v)
+    new_tr, fwd_w, _, bwd = Regenerate(S["y1"] | S["y2"]).edit(key, tr, ())
+    assert f(new_tr.get_choices()["y2"]) != f(tr.get_choices()["y2"])
+    old_tr, bwd_w, _, _ = bwd.edit(key, new_tr, ())
+    assert f(fwd_w) + f(bwd_w) == pytest.approx(0.0, abs=1e-6) and f(old_tr.get_choices()["y2"]) == f(tr.get_choices()["y2"])
+
+    @gen
+    def linked_normal(s):
+        y1 = normal(0.0, 3.0) @ "y1"
+        _ = normal(y1, s) @ "y2"
+
+    tr = linked_normal.simulate(sub_key, (1.0,))
+    dens = lambda t: f(normal.logpdf(t.get_choices()["y1"], 0.0, 3.0)) + f(normal.logpdf(t.get_choices()["y2"], t.get_choices()["y1"], 1.0))
+    new_tr, fwd_w, _, _ = Regenerate(S["y1"]).edit(key, tr, (1.0,))
+    assert f(fwd_w) == pytest.approx(dens(new_tr) - dens(tr), abs=1e-5) and f(fwd_w) != 0.0
+
+    # Metropolis-Hastings over a population of chains: y2 observed at 3.0 with a sharp likelihood
+    n = 128
+
+    def mh(request, sd, steps, k0):
+        keys = genjax.random.split(genjax.random.key(k0, impl), n)
+        t, _ = linked_normal.importance(keys, C.kw(y2=3.0), (sd,))
+        for i in range(steps):
+            ka = genjax.random.split(genjax.random.key(1000 * k0 + 2 * i, impl), n)
+            kb = genjax.random.split(genjax.random.key(1000 * k0 + 2 * i + 1, impl), n)
+            new_t, w, _, _ = request.edit(ka, t, (sd,))
+            accept = torch.log(beta.sample(kb, 1.0, 1.0)) < w
+            # accepted chains move (the per-particle masked update of 8f-3), the others keep their trace
+            t, _, _, _ = t.update(ka, C["y1"].set(new_t.get_choices()["y1"]).mask(accept))
+        return t.get_choices()["y1"]
+
+    y1 = mh(Regenerate(S["y1"]), 0.01, 120, 7)
+    assert f((y1 - 3.0).abs().median()) < 0.05
+    # Rejuvenate with the prior as the proposal: the move is symmetric, its weight vanishes
+    @gen
+    def one_normal():
+        _ = normal(0.0, 1.0) @ "y1"
+
+    tr1 = one_normal.simulate(sub_key, ())
+    req = StaticRequest({"y1": Rejuvenate(normal, lambda chm: (0.0, 1.0))})
+    new_tr, w, _, _ = req.edit(sub_key, tr1, ())
+    assert f(new_tr.get_choices()["y1"]) != f(tr1.get_choices()["y1"]) and abs(f(w)) < 1e-6
+    # ... and a random-walk proposal around the current value converges
+    walk = StaticRequest({"y1": Rejuvenate(normal, lambda chm: (chm.get_value(), 0.3))})
+    y1 = mh(walk, 0.001, 60, 9)
+    assert f((y1 - 3.0).abs().median()) < 0.02
+    # a combinator answers Regenerate element-wise: weight = change of the total score, unselected choices stay
+    @gen
+    def kstep(x, _):
+        z = normal(x, 1.0) @ "z"
+        u = normal(z, 0.5) @ "u"
+        return z, u
+
+    keys = genjax.random.split(genjax.random.key(12, impl), 500)
+    st = kstep.scan(n=4).simulate(keys, (0.0, None))
+    keys2 = genjax.random.split(genjax.random.key(13, impl), 500)  # (the same keys would redraw the same values)
+    new_st, w, _, bwd = Regenerate(S["u"]).edit(keys2, st, (0.0, None))
+    assert torch.equal(new_st.get_choices()["z"], st.get_choices()["z"])
+    assert not torch.equal(new_st.get_choices()["u"], st.get_choices()["u"])
+    assert torch.allclose(w, new_st.get_score() - st.get_score(), atol=1e-5)
+    back, wb, _, _ = bwd.edit(keys, new_st, (0.0, None))
+    assert torch.equal(back.get_choices()["u"], st.get_choices()["u"]) and torch.allclose(w + wb, torch.zeros_like(w), atol=1e-4)
+
+
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_fused_equals_eager, case_params_equal_constants, case_particle_collection, case_custom_proposal,
              case_scan, case_scan_fused_equals_loop, case_vmap, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
-             case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update]
+             case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update, case_regenerate_and_rejuvenate]

@@ -129,6 +129,18 @@ def test_host_level_flows_match_oracle(hip_ops, oracle_ops, impl):
             out["scan_lw"] = sc.get_log_weights()
             out["scan_z"] = sc.get_particles().get_choices()["z"]
             out["scan_logz"] = float(sc.get_log_marginal_likelihood_estimate().cpu())
+            # Regenerate and a Rejuvenate random walk over a population (rejuvenation moves)
+            from genjax import Regenerate, StaticRequest
+            from genjax.inference.requests import Rejuvenate
+
+            k2 = gj.random.split(gj.random.key(77, impl), 700)
+            rg, rw, _, bwd = Regenerate(S["z"]).edit(k2, tr, ())
+            out["regen_w"], out["regen_z"] = rw, rg.get_choices()["z"]
+            back, bw, _, _ = bwd.edit(k2, rg, ())
+            out["regen_back_w"], out["regen_back_z"] = bw, back.get_choices()["z"]
+            walk = StaticRequest({"z": Rejuvenate(normal, lambda chm: (chm.get_value(), 0.25))})
+            rj, jw, _, _ = walk.edit(k2, tr, ())
+            out["rejuv_w"], out["rejuv_z"] = jw, rj.get_choices()["z"]
         return out
 
     g, o = run(hip_ops), run(oracle_ops)
