@@ -743,6 +743,18 @@ def test_full_size_properties(hip_ops):
         assert float((cnt - w).abs().max()) < 1.0 + 1e-4
 
 
+def test_full_size_hmm(hip_ops):
+    """BASELINE configs[4] at full size as a test (not only in bench.py): 1e6 particles, 256 states, T = 500 —
+    log Z against the forward algorithm (float64), ancestors monotone at a late step, states within range."""
+    n, T = 1_000_000, 500
+    for impl in IMPLS:
+        r = W.hmm_smc(hip_ops, impl, seed=2, n=n, T=T, want_ancestors=False)
+        assert abs(r["log_z"] - r["log_z_exact"]) < 0.35, (r["log_z"], r["log_z_exact"])
+        st = r["state"]
+        assert int(st.min()) >= 0 and int(st.max()) < 256
+        assert bool(torch.isfinite(r["out_max"]).all()) and bool((r["out_q"] > 0).all())
+
+
 def test_full_size_batches(hip_ops):
     """The benchmark's launches at full size: 8 independent 1e6-particle ImportanceK passes in one launch and 16
     bootstrap filters (T = 20) in the same launches.  Every pass / filter has its own seed: the estimates differ,
