@@ -18,6 +18,7 @@ from ._amd.inference import Algorithm, Marginal, SampleDistribution, Target, mar
 from ._amd import prng as _prng
 from ._amd.lang import split as _split, fold_in as _fold_in
 from ._amd import jaxlike
+from ._amd.runtime import fast_math
 from . import inference
 
 ChoiceMapBuilder = _C  # `from genjax import ChoiceMapBuilder as C`; C["x"].set(v)
@@ -41,7 +42,7 @@ __all__ = [
     "AddressReuse", "Algorithm", "ChoiceMap", "ChoiceMapBuilder", "ChoiceMapNoValueAtAddress", "Diff", "Distribution",
     "EditRequest", "EmptyRequest", "NoChange", "NotSupportedEditRequest", "Regenerate", "Rejuvenate", "StaticRequest", "UnknownChange", "Update", "GenerativeFunction", "GenerativeFunctionClosure", "Marginal", "Mask", "MissingAddress", "SampleDistribution", "Scan",
     "Selection", "SelectionBuilder", "StaticGenerativeFunction", "Target", "Trace", "bernoulli", "beta",
-    "categorical", "exact_density", "flip", "gamma", "gen", "inference", "jaxlike", "marginal", "normal", "random",
+    "categorical", "exact_density", "fast_math", "flip", "gamma", "gen", "inference", "jaxlike", "marginal", "normal", "random",
     "scan", "Vmap", "vmap",
 ]
 __version__ = "0.1.0"

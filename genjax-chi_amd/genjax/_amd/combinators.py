@@ -153,7 +153,9 @@ class Scan(GenerativeFunction):
             if T < 1:
                 return None
             obs_addrs, obs_values = SP.step_constraints(constraint, T)
-            low = SP.lower_scan(self.kernel_gen_fn, carry0, xs, obs_addrs)
+            from .runtime import fast_math_enabled
+
+            low = SP.lower_scan(self.kernel_gen_fn, carry0, xs, obs_addrs, fast_math=fast_math_enabled())
             table = SP.observation_table(obs_values, xs, T)
         except Exception:
             # PlanUnsupported, or symbolic values fed to code that needs tensors: the host loop runs the model and

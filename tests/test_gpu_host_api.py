@@ -153,3 +153,46 @@ def test_regression_vectors_on_gpu(hip_ops):
     from test_oracle_pinning import check_regression
 
     check_regression(hip_ops)
+
+
+@pytest.mark.parametrize("impl", ["threefry", "philox"])
+def test_fast_math_context(hip_ops, impl):
+    """`with genjax.fast_math():` — the opt-in hardware-transcendental mode of fused `@gen` and `Scan` plans at the host
+    API: log-weights within 1e-5 relative (north star tolerance for paths without resampling), values within 1e-5
+    absolute of the bit-exact mode; outside the context nothing changes."""
+    @gen
+    def model(a):
+        z = normal(0.0, a) @ "z"
+        w = normal(z * 0.5, 1.5) @ "w"
+        _ = normal(w - 1.0, 0.5) @ "y"
+        return w
+
+    @genjax.scan(n=12)
+    @gen
+    def chain(x, _):
+        z = normal(0.8 * x, 1.0) @ "z"
+        _ = normal(z, 0.7) @ "obs"
+        return z, z
+
+    with use_ops(hip_ops):
+        keys = genjax.random.split(genjax.random.key(3, impl), 50_000)
+        obs = torch.linspace(-0.5, 0.5, 12)
+
+        def run():
+            tr, w = model.importance(keys, C["y"].set(0.3), (2.0,))
+            st, sw = chain.importance(keys, C["obs"].set(obs), (0.0, None))
+            return w, tr.get_choices()["w"], sw, st.get_choices()["z"]
+
+        exact = run()
+        with genjax.fast_math():
+            fast = run()
+        again = run()
+    for a, b in zip(exact, again):
+        assert torch.equal(a, b)
+    for k, (a, b) in enumerate(zip(exact, fast)):
+        if k % 2 == 0:  # log-weights
+            assert float(((a - b).abs() / a.abs().clamp_min(1e-3)).max()) < 1e-5
+        else:
+            assert float((a - b).abs().max()) < 2e-5
+    if impl == "philox":
+        assert not torch.equal(exact[0], fast[0])  # the fast plan really ran
