@@ -64,6 +64,8 @@ class ScanTrace(Trace):
 
     def get_choices(self) -> ChoiceMap:
         per_step = [dict(tr.get_choices().leaves()) for tr in self.step_traces]
+        if not per_step:  # a zero-length scan has no choices (test_scan_combinator.py:402-420)
+            return ChoiceMap.empty()
         pairs = [(addr, _stack_time([d[addr] for d in per_step], self.batched)) for addr in per_step[0]]
         return ChoiceMap.from_mapping(pairs)
 
@@ -116,13 +118,18 @@ class Scan(GenerativeFunction):
         self.kernel_gen_fn, self.length = kernel_gen_fn, length
 
     def _length(self, xs):
-        if self.length is not None:
-            return int(self.length)
         leaves = []
         _map_any(lambda v: (leaves.append(v), v)[1], xs)
-        if not leaves:
+        sizes = [int(v.shape[0]) for v in leaves if hasattr(v, "shape") and len(v.shape) >= 1]
+        if len(set(sizes)) > 1:  # scan.py:178-196
+            raise ValueError("scan got values with different leading axis sizes: " + ", ".join(str(z) for z in sizes) + ".")
+        if self.length is not None:
+            if sizes and sizes[0] != int(self.length):
+                raise ValueError(f"scan got `length` argument of {int(self.length)} which disagrees with leading axis sizes {sizes[0]}.")
+            return int(self.length)
+        if not sizes:
             raise ValueError("scan needs either n= or scanned inputs")
-        return int(leaves[0].shape[0])
+        return sizes[0]
 
     def _run(self, key, args, step):
         carry, xs = args

@@ -577,7 +577,45 @@ def case_scan(impl):
     assert trb.get_score().shape == (64,)
 
 
-# ---- vmap / repeat (tests/generative_functions/test_vmap_combinator.py:60-79) ---------------------------
+def case_scan_edge_cases(impl):
+    """tests/generative_functions/test_scan_combinator.py:380-461: the length inferred from the scanned inputs, a zero-length
+    scan (no choices, importance with them is a no-op), inputs of different leading sizes, a population of keys."""
+    key = genjax.random.key(314159, impl)
+
+    @gen
+    def walk_step(x, std):
+        new_x = normal(x, std) @ "x"
+        return new_x, new_x
+
+    args = (0.0, torch.tensor([2.0, 4.0, 3.0, 5.0, 1.0]))
+    for sc in (walk_step.scan(n=5), walk_step.scan()):
+        tr = sc.simulate(key, args)
+        assert torch.allclose(tr.get_choices()[:, "x"], tr.get_retval()[1]) and tuple(tr.get_choices()[:, "x"].shape) == (5,)
+    with pytest.raises(ValueError, match="disagrees with leading axis sizes"):
+        walk_step.scan(n=4).simulate(key, args)
+    keys = genjax.random.split(key, 10)
+    many = walk_step.scan().simulate(keys, args)
+    assert tuple(many.get_score().shape) == (10,) and tuple(many.get_choices()[:, "x"].shape) == (10, 5)
+
+    @gen
+    def step(state, sigma):
+        new_x = normal(state, sigma) @ "x"
+        return (new_x, new_x + 1)
+
+    empty = step.scan(n=0).simulate(key, (2.0, torch.arange(0, dtype=torch.float32)))
+    assert empty.get_choices().static_is_empty() and f(empty.get_score()) == 0.0
+    _, w = step.scan().importance(genjax.random.split(key)[1], empty.get_choices(), (2.0, 2.0 + torch.arange(0, dtype=torch.float32)))
+    assert f(w) == 0.0
+
+    @gen
+    def foo(shift, d):
+        x = normal(d["loc"], d["scale"]) @ "x"
+        return x + shift, None
+
+    with pytest.raises(ValueError, match="scan got values with different leading axis sizes: 2, 1."):
+        foo.scan().simulate(key, (torch.tensor([1.0]), {"loc": torch.tensor([10.0, 12.0]), "scale": torch.tensor([1.0])}))
+
+
 def case_scan_fused_equals_loop(impl):
     """The one-launch scan (`gjx_scan_run`) against the host loop of per-site launches (scan.py:237-294): same key
     chain, same arithmetic -> the same trace, weights, score and return value, bit for bit; plus ImportanceK over a
@@ -666,6 +704,7 @@ def case_scan_fused_equals_loop(impl):
     assert tuple(part.get_choices()["x"].shape) == (T,)
 
 
+# ---- vmap / repeat (tests/generative_functions/test_vmap_combinator.py:60-79) ---------------------------
 def case_vmap(impl):
     @gen
     def point(x, s):
@@ -1177,5 +1216,5 @@ def case_regenerate_and_rejuvenate(impl):
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_fused_equals_eager, case_params_equal_constants, case_particle_collection, case_custom_proposal,
-             case_scan, case_scan_fused_equals_loop, case_vmap, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
+             case_scan, case_scan_edge_cases, case_scan_fused_equals_loop, case_vmap, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
              case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update, case_regenerate_and_rejuvenate]
