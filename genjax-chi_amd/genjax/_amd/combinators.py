@@ -279,6 +279,31 @@ class VmapTrace(Trace):
         return VmapTrace(self.gen_fn, self.inner.map_leaves(fn), _map_any(fn, self.args), self.n, self.m, self.batched)
 
 
+class EmptyVmapTrace(Trace):
+    """A vmap over a zero-length axis: no choices, score 0 (test_vmap_combinator.py:230-243)."""
+
+    def __init__(self, gen_fn, args, n: int, batched: bool):
+        self.gen_fn, self.args, self.n, self.batched = gen_fn, args, n, batched
+
+    def get_args(self):
+        return self.args
+
+    def get_gen_fn(self):
+        return self.gen_fn
+
+    def get_retval(self):
+        return None
+
+    def get_choices(self) -> ChoiceMap:
+        return ChoiceMap.empty()
+
+    def get_score(self):
+        return torch.zeros(self.n, device=get_ops().device()) if self.batched else 0.0
+
+    def map_leaves(self, fn):
+        return self
+
+
 class Vmap(GenerativeFunction):
     """`gen_fn.vmap(in_axes=(0, None, ...))`: independent copies over a mapped axis of the arguments;
     element j of particle i uses key split(key_i, m)[j] (vmap.py:186, 201)."""
@@ -298,14 +323,22 @@ class Vmap(GenerativeFunction):
         return ax
 
     def _length(self, args, axes, n: int, batched: bool) -> int:
-        if self.axis_size is not None:
-            return int(self.axis_size)
+        sizes = []
         for a, ax in zip(args, axes):
             if ax == 0:
                 t = torch.as_tensor(a)
+                if t.dim() == 0:  # (jax.vmap's message, test_vmap_combinator.py:180-184)
+                    raise ValueError("vmap was requested to map its argument along axis 0, which implies that its rank "
+                                     "should be at least 1, but is only 0 (its shape is ())")
                 # a mapped argument is [m] (shared by all particles) or [n, m] (per particle)
-                return int(t.shape[1] if (batched and t.dim() >= 2 and t.shape[0] == n) else t.shape[0])
-        raise ValueError("Vmap needs a mapped argument or axis_size")
+                sizes.append(int(t.shape[1] if (batched and t.dim() >= 2 and t.shape[0] == n) else t.shape[0]))
+        if len(set(sizes)) > 1:
+            raise IndexError("vmap got inconsistent sizes for the mapped axis: " + ", ".join(str(z) for z in sizes))
+        if self.axis_size is not None:
+            return int(self.axis_size)
+        if not sizes:
+            raise ValueError("Vmap needs a mapped argument or axis_size")
+        return sizes[0]
 
     def _expand_args(self, args, axes, n, m, batched):
         ops = get_ops()
@@ -377,6 +410,8 @@ class Vmap(GenerativeFunction):
         pk, batched = as_particle_keys(key)
         axes = self._axes(args)
         m = self._length(args, axes, pk.n, batched)
+        if m == 0:
+            return EmptyVmapTrace(self, args, pk.n, batched)
         inner = self.gen_fn.simulate(self._inner_keys(pk, m), self._expand_args(args, axes, pk.n, m, batched))
         return VmapTrace(self, inner, args, pk.n, m, batched)
 
@@ -384,6 +419,9 @@ class Vmap(GenerativeFunction):
         pk, batched = as_particle_keys(key)
         axes = self._axes(args)
         m = self._length(args, axes, pk.n, batched)
+        if m == 0:
+            tr = EmptyVmapTrace(self, args, pk.n, batched)
+            return tr, tr.get_score()
         inner, w = self.gen_fn.generate(self._inner_keys(pk, m), self._expand_constraint(constraint, pk.n, m),
                                         self._expand_args(args, axes, pk.n, m, batched))
         if isinstance(w, torch.Tensor) and w.dim() >= 1:

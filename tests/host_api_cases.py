@@ -741,6 +741,43 @@ def case_vmap(impl):
 
 
 # ---- fused bootstrap SMC ---------------------------------------------------------------------------------
+def case_vmap_edge_cases(impl):
+    """tests/generative_functions/test_vmap_combinator.py:158-243: assess == the simulated score, argument validation,
+    a population of keys over a vmapped model, a zero-length mapped axis."""
+    key = genjax.random.key(314159, impl)
+
+    @genjax.vmap(in_axes=(0,))
+    @gen
+    def model(x):
+        z = normal(x, 1.0) @ "z"
+        return z
+
+    xs = torch.arange(0, 50, dtype=torch.float32)
+    tr = model.simulate(key, (xs,))
+    assert f(model.assess(tr.get_choices(), (xs,))[0]) == pytest.approx(f(tr.get_score()), rel=1e-6)
+
+    @gen
+    def foo(loc, scale):
+        return normal(loc, scale) @ "x"
+
+    with pytest.raises(ValueError, match="vmap was requested to map its argument along axis 0, which implies that its rank "
+                                         "should be at least 1, but is only 0"):
+        foo.vmap(in_axes=(0, None)).simulate(key, (10.0, torch.arange(3.0)))
+    with pytest.raises(IndexError):
+        foo.vmap(in_axes=0).simulate(key, (torch.arange(2.0), torch.arange(3.0)))
+    keys = genjax.random.split(key, 10)
+    res = model.simulate(keys, (torch.arange(5, dtype=torch.float32),))
+    assert tuple(res.get_score().shape) == (10,) and tuple(res.get_choices()[:, "z"].shape) == (10, 5)
+
+    @gen
+    def step(state, sigma):
+        new_x = normal(state, sigma) @ "x"
+        return (new_x, new_x + 1)
+
+    empty = step.vmap(in_axes=(None, 0)).simulate(genjax.random.key(20, impl), (2.0, torch.arange(0, dtype=torch.float32)))
+    assert empty.get_choices().static_is_empty() and f(empty.get_score()) == 0.0
+
+
 def case_vmap_indexed_constraints(impl):
     """test_vmap_combinator.py:61-122: constraints on some / all indices of a vmapped site."""
     @genjax.vmap(in_axes=(0,))
@@ -1216,5 +1253,5 @@ def case_regenerate_and_rejuvenate(impl):
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_fused_equals_eager, case_params_equal_constants, case_particle_collection, case_custom_proposal,
-             case_scan, case_scan_edge_cases, case_scan_fused_equals_loop, case_vmap, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
+             case_scan, case_scan_edge_cases, case_scan_fused_equals_loop, case_vmap, case_vmap_edge_cases, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
              case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update, case_regenerate_and_rejuvenate]
