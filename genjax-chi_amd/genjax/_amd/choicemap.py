@@ -265,7 +265,19 @@ _ALL, _NONE = _AllSel(), _NoneSel()
 
 
 class _SelectionBuilder:
-    """`S["x"]`, `S["x", "y"]`, `S[...]`."""
+    """`S["x"]`, `S["x", "y"]`, `S[...]`; `S.all`, `S.none`, `S.leaf` (choice_map.py:78-114: properties of the builder)."""
+
+    @property
+    def all(self) -> Selection:
+        return Selection.all()
+
+    @property
+    def none(self) -> Selection:
+        return Selection.none()
+
+    @property
+    def leaf(self) -> Selection:
+        return Selection.leaf()
 
     def __getitem__(self, addr) -> Selection:
         return _ALL.extend(*_as_addr(addr))

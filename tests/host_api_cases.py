@@ -1193,6 +1193,28 @@ def case_regenerate_and_rejuvenate(impl):
     old_tr, bwd_w, _, _ = bwd.edit(key, new_tr, ())
     assert f(fwd_w) + f(bwd_w) == pytest.approx(0.0, abs=1e-6) and f(old_tr.get_choices()["y2"]) == f(tr.get_choices()["y2"])
 
+    # StaticRequest composition, tuple addresses and nested functions (test_static_gen_fn.py:889-961)
+    @gen
+    def submodel():
+        return normal(0.0, 1.0) @ "y2"
+
+    @gen
+    def nested():
+        y1 = normal(0.0, 1.0) @ ("y1", "y3")
+        y2 = submodel() @ "y2"
+        return y1 + y2
+
+    for mdl, req, addr in ((simple_normal, StaticRequest({"y1": Regenerate(genjax.Selection.all()), "y2": genjax.Update(C.v(3.0))}), "y2"),
+                           (nested, StaticRequest({("y1", "y3"): Regenerate(S.all),
+                                                   "y2": StaticRequest({"y2": genjax.Update(C.v(3.0))})}), ("y2", "y2"))):
+        t0 = mdl.simulate(genjax.random.key(0, impl), ())
+        k_a, k_b = genjax.random.split(genjax.random.key(0, impl))
+        new_t, w, _, bwd_req = req.edit(k_a, t0, ())
+        assert f(new_t.get_choices()[addr]) == 3.0 and f(w) != 0.0
+        old_t, w_, _, _ = bwd_req.edit(k_b, new_t, ())
+        assert f(old_t.get_choices()[addr]) == f(t0.get_choices()[addr]) and f(w_) != 0.0
+        assert f(w) + f(w_) == pytest.approx(0.0, abs=1e-6)
+
     @gen
     def linked_normal(s):
         y1 = normal(0.0, 3.0) @ "y1"
