@@ -12,7 +12,7 @@ from ._amd.lang import (AddressReuse, Distribution, GenerativeFunction, Generati
                         StaticGenerativeFunction, Trace, bernoulli, beta, categorical, exact_density, flip, gamma,
                         gen, normal)
 from ._amd.combinators import Scan, Vmap, scan, vmap
-from ._amd.edit import (Diff, EditRequest, EmptyRequest, NoChange, NotSupportedEditRequest, Regenerate, Rejuvenate, StaticRequest,
+from ._amd.edit import (Diff, EditRequest, EmptyRequest, IndexRequest, NoChange, NotSupportedEditRequest, Regenerate, Rejuvenate, StaticRequest,
                         UnknownChange, Update)
 from ._amd.inference import Algorithm, Marginal, SampleDistribution, Target, marginal
 from ._amd import prng as _prng
@@ -40,7 +40,7 @@ random = _Random()
 
 __all__ = [
     "AddressReuse", "Algorithm", "ChoiceMap", "ChoiceMapBuilder", "ChoiceMapNoValueAtAddress", "Diff", "Distribution",
-    "EditRequest", "EmptyRequest", "NoChange", "NotSupportedEditRequest", "Regenerate", "Rejuvenate", "StaticRequest", "UnknownChange", "Update", "GenerativeFunction", "GenerativeFunctionClosure", "Marginal", "Mask", "MissingAddress", "SampleDistribution", "Scan",
+    "EditRequest", "EmptyRequest", "IndexRequest", "NoChange", "NotSupportedEditRequest", "Regenerate", "Rejuvenate", "StaticRequest", "UnknownChange", "Update", "GenerativeFunction", "GenerativeFunctionClosure", "Marginal", "Mask", "MissingAddress", "SampleDistribution", "Scan",
     "Selection", "SelectionBuilder", "StaticGenerativeFunction", "Target", "Trace", "bernoulli", "beta",
     "categorical", "exact_density", "fast_math", "flip", "gamma", "gen", "inference", "jaxlike", "marginal", "normal", "random",
     "scan", "Vmap", "vmap",

@@ -230,6 +230,14 @@ class Scan(GenerativeFunction):
             total = total + tr.project(key, selection)
         return total
 
+    def edit(self, key, trace, edit_request, argdiffs):
+        from .edit import Diff, IndexRequest, generic_index_request
+
+        if isinstance(edit_request, IndexRequest):
+            T = self._length(Diff.tree_primal(argdiffs)[1])
+            return generic_index_request(self, key, trace, edit_request.idx, edit_request.request, argdiffs, T)
+        return super().edit(key, trace, edit_request, argdiffs)
+
 
 def scan(*, n: int | None = None):
     def decorator(f) -> Scan:
@@ -276,7 +284,10 @@ class VmapTrace(Trace):
         return s * self.m
 
     def map_leaves(self, fn):
-        return VmapTrace(self.gen_fn, self.inner.map_leaves(fn), _map_any(fn, self.args), self.n, self.m, self.batched)
+        # a population of one being squeezed (a scalar key's run inside a static function): present [m] leaves and a
+        # scalar score from now on (the inner [1 * m] columns themselves have nothing to squeeze)
+        batched = self.batched and not (fn is squeeze_leaf and self.n == 1)
+        return VmapTrace(self.gen_fn, self.inner.map_leaves(fn), _map_any(fn, self.args), self.n, self.m, batched)
 
 
 class EmptyVmapTrace(Trace):
@@ -445,6 +456,13 @@ class Vmap(GenerativeFunction):
             p = p.reshape(trace.n, trace.m).sum(1)
             return p if trace.batched else p[0]
         return p
+
+    def edit(self, key, trace, edit_request, argdiffs):
+        from .edit import IndexRequest, generic_index_request
+
+        if isinstance(edit_request, IndexRequest):
+            return generic_index_request(self, key, trace, edit_request.idx, edit_request.request, argdiffs, trace.m)
+        return super().edit(key, trace, edit_request, argdiffs)
 
 
 def vmap(*, in_axes=0):

@@ -174,6 +174,19 @@ class StaticRequest(PrimitiveEditRequest):
 
 
 @dataclass(frozen=True)
+class IndexRequest(PrimitiveEditRequest):
+    """concepts.py:154-165: apply `request` to ONE element (`idx`) of a vector combinator's trace (`Scan` step,
+    `Vmap` element); the other elements keep their choices (a later `Scan` step is re-scored where its carry moved).
+    `request`: `Update(constraint)` or `Regenerate(selection)`.  Answered by re-generation (`generic_index_request`)."""
+
+    idx: Any
+    request: Any
+
+    def __hash__(self):
+        return id(self)
+
+
+@dataclass(frozen=True)
 class EmptyRequest(EditRequest):
     """requests.py:46-60: nothing changes unless the arguments did (then an `Update` with an empty constraint)."""
 
@@ -244,6 +257,42 @@ def generic_regenerate(gen_fn, key, trace, selection, argdiffs):
     w = new_trace.get_score() - trace.get_score()
     retval = new_trace.get_retval()
     return new_trace, w, Diff.unknown_change(retval), Update(old.filter(selection))
+
+
+def generic_index_request(gen_fn, key, trace, idx, request, argdiffs, length: int):
+    """`IndexRequest(idx, Update | Regenerate)` on a `Scan` / `Vmap` trace (scan.py:340-420, 627; vmap.py:260-332): every
+    element is constrained to its old choices except element `idx`, whose selected addresses are drawn afresh
+    (`Regenerate`) or take the given values (`Update`).  Weight = new total score − old total score — the reference's
+    per-site rule (`new site score − old site score`, summed; sites after `idx` in a `Scan` are re-scored at the moved
+    carry); the backward request puts the old values of element `idx` back."""
+    idx = int(idx)
+    if not 0 <= idx < length:
+        raise IndexError(f"IndexRequest index {idx} outside the combinator's axis of length {length}")
+    args = Diff.tree_primal(argdiffs)
+    old = trace.get_choices()
+    if isinstance(request, Regenerate):
+        replaced = {a for a, _ in old.leaves() if request.selection[a]}
+        new_vals = {}
+    elif isinstance(request, Update):
+        new_vals = dict(request.constraint.leaves())
+        replaced = set(new_vals)
+    else:
+        raise NotSupportedEditRequest(request)
+    # one explicit entry per element and address: old[..., j] for every element, except (idx, replaced addresses)
+    constraint, discard = ChoiceMap.empty(), ChoiceMap.empty()
+    for addr, v in old.leaves():
+        for j in range(length):
+            elem = v[..., j] if isinstance(v, torch.Tensor) and v.dim() >= 1 else v
+            if j == idx and addr in replaced:
+                discard = discard | ChoiceMap.entry(elem, *addr)
+                if addr in new_vals:
+                    constraint = constraint | ChoiceMap.entry(new_vals[addr], j, *addr)
+                continue
+            constraint = constraint | ChoiceMap.entry(elem, j, *addr)
+    new_trace, _ = gen_fn.generate(key, constraint, args)
+    w = new_trace.get_score() - trace.get_score()
+    retval = new_trace.get_retval()
+    return new_trace, w, Diff.unknown_change(retval), IndexRequest(idx, Update(discard))
 
 
 def as_weight(w, like=None):

@@ -1273,7 +1273,62 @@ def case_regenerate_and_rejuvenate(impl):
     assert torch.equal(back.get_choices()["u"], st.get_choices()["u"]) and torch.allclose(w + wb, torch.zeros_like(w), atol=1e-4)
 
 
+def case_index_request(impl):
+    """`IndexRequest(idx, request)` on `Scan` and `Vmap` traces inside a static model (test_scan_combinator.py:463-534,
+    test_vmap_combinator.py:273-330): the weight is the change of density of the touched element; the others keep their
+    values; out-of-range indices are refused; the backward request restores the trace."""
+    from genjax import IndexRequest, Regenerate, StaticRequest, Update
+
+    @gen
+    def kernel(carry, _):
+        z = normal(0.0, 1.0) @ "z"
+        return z, None
+
+    @gen
+    def scanned_normal():
+        y1 = normal(0.0, 1.0) @ "y1"
+        _ = normal(0.0, 1.0) @ "y2"
+        return kernel.scan(n=10)(y1, None) @ "kernel"
+
+    key = genjax.random.key(314159, impl)
+    key, sub_key = genjax.random.split(key)
+    tr = scanned_normal.simulate(sub_key, ())
+    new_tr, w, _, _ = Regenerate(S["y1"]).edit(key, tr, ())
+    assert f(w) == pytest.approx(f(normal.logpdf(new_tr.get_choices()["y1"], 0.0, 1.0)) - f(normal.logpdf(tr.get_choices()["y1"], 0.0, 1.0)), abs=1e-5)
+    for idx in range(10):
+        old_z = tr.get_choices()["kernel", idx, "z"]
+        req = StaticRequest({"kernel": IndexRequest(torch.tensor(idx), Regenerate(S["z"]))})
+        new_tr, w, _, bwd = req.edit(key, tr, ())
+        new_z = new_tr.get_choices()["kernel", idx, "z"]
+        assert f(new_z) != f(old_z)
+        assert f(w) == pytest.approx(f(normal.logpdf(new_z, 0.0, 1.0)) - f(normal.logpdf(old_z, 0.0, 1.0)), abs=2e-5)
+        other = (idx + 1) % 10
+        assert f(new_tr.get_choices()["kernel", other, "z"]) == f(tr.get_choices()["kernel", other, "z"])
+        back, wb, _, _ = bwd.edit(key, new_tr, ())
+        assert f(back.get_choices()["kernel", idx, "z"]) == f(old_z) and f(w) + f(wb) == pytest.approx(0.0, abs=2e-5)
+    with pytest.raises(IndexError):
+        StaticRequest({"kernel": IndexRequest(11, Regenerate(S["z"]))}).edit(key, tr, ())
+
+    @gen
+    def model():
+        x = normal(0.0, 1.0) @ "x"
+        _ = normal.vmap()(torch.zeros(100), torch.ones(100)) @ "a"
+        return x
+
+    tr = model.simulate(sub_key, ())
+    for idx in range(0, 100, 13):
+        old_a = tr.get_choices()["a", idx]
+        new_tr, w, _, _ = StaticRequest({"a": IndexRequest(idx, Regenerate(S.all))}).edit(key, tr, ())
+        new_a = new_tr.get_choices()["a", idx]
+        assert f(w) == pytest.approx(f(normal.logpdf(new_a, 0.0, 1.0)) - f(normal.logpdf(old_a, 0.0, 1.0)), abs=5e-5)
+        new_tr, w, _, _ = StaticRequest({"a": IndexRequest(idx, Update(C.v(idx + 7.0)))}).edit(key, tr, ())
+        assert f(new_tr.get_choices()["a", idx]) == idx + 7.0
+        assert f(w) == pytest.approx(f(normal.logpdf(idx + 7.0, 0.0, 1.0)) - f(normal.logpdf(old_a, 0.0, 1.0)), rel=1e-5, abs=5e-5)
+        keep = (idx + 1) % 100
+        assert f(new_tr.get_choices()["a", keep]) == f(tr.get_choices()["a", keep])
+
+
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_fused_equals_eager, case_params_equal_constants, case_particle_collection, case_custom_proposal,
              case_scan, case_scan_edge_cases, case_scan_fused_equals_loop, case_vmap, case_vmap_edge_cases, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
-             case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update, case_regenerate_and_rejuvenate]
+             case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update, case_regenerate_and_rejuvenate, case_index_request]
