@@ -445,7 +445,13 @@ class Vmap(GenerativeFunction):
     def assess(self, sample: ChoiceMap, args):
         axes = self._axes(args)
         m = self._length(args, axes, 1, False)
-        score, ret = self.gen_fn.assess(self._expand_constraint(sample, 1, m), self._expand_args(args, axes, 1, m, False))
+        from . import lang as _lang
+
+        _lang._ASSESS_BATCH.append(m)
+        try:
+            score, ret = self.gen_fn.assess(self._expand_constraint(sample, 1, m), self._expand_args(args, axes, 1, m, False))
+        finally:
+            _lang._ASSESS_BATCH.pop()
         if isinstance(score, torch.Tensor) and score.dim() >= 1:
             score = score.sum()
         return score, ret

@@ -593,6 +593,9 @@ class RequestHandler(_Handler):
         return Diff.tree_primal(retdiff)
 
 
+_ASSESS_BATCH: list = [None]  # stack: the column length of an enclosing Vmap.assess (assess carries no key to tell)
+
+
 class AssessHandler(_Handler):
     def __init__(self, sample: ChoiceMap):
         super().__init__()
@@ -701,8 +704,12 @@ class StaticGenerativeFunction(GenerativeFunction):
         new_trace = StaticTrace(self, args, retval, h.traces)
         discard = ChoiceMap.d({a: c for a, c in h.bwd_constraints.items() if not c.static_is_empty()})
         unchanged = constraint.static_is_empty() and Diff.static_check_no_change(argdiffs)
+        weight = h.weight
+        if not batched:  # nested combinators ran as a population of one
+            new_trace, weight, discard = new_trace.map_leaves(squeeze_leaf), squeeze_leaf(weight), discard.map_leaves(squeeze_leaf)
+            retval = new_trace.get_retval()
         retdiff = Diff.no_change(retval) if unchanged else Diff.unknown_change(retval)
-        return new_trace, h.weight, retdiff, Update(discard)
+        return new_trace, weight, retdiff, Update(discard)
 
     def project(self, key, trace: StaticTrace, selection: Selection):
         total = 0.0
@@ -781,8 +788,45 @@ class Distribution(GenerativeFunction):
         score = self._logpdf(n or 1, v, args)
         return score if batched else squeeze_leaf(score)
 
+    # -- vector-valued sites ---------------------------------------------------------------------------
+    def _event_vmap(self, key, args, value=None):
+        """A site whose arguments (or constrained value) carry an EVENT axis — `normal(mu_vec, 1.0) @ "x"` — is the
+        distribution mapped over that axis: values `[d]` (`[n, d]` over a population), score summed over it
+        (distribution.py:392-396 `jnp.sum(w)`).  -> the `Vmap` answering it, or None for a scalar event.  Element e draws
+        from `split(site_key, d)[e]` (the mapped-site rule of `Vmap`), not from counter e of the site key as jax does:
+        the same distribution, another stream (the samplers are not bit-pinned against jax either way)."""
+        if not isinstance(self, (_RealDist, Flip)):
+            return None
+        n = key.n if isinstance(key, ParticleKeys) else 1
+        batched = isinstance(key, ParticleKeys)
+
+        def axis(a):
+            if isinstance(a, Mask):
+                a = a.value
+            if not isinstance(a, torch.Tensor):
+                return None
+            if a.dim() >= 2:
+                return 0
+            if a.dim() == 1 and a.shape[0] > 1 and not (batched and a.shape[0] == n and n > 1):
+                return 0
+            return None
+
+        axes = tuple(axis(a) for a in args)
+        if all(x is None for x in axes) and (value is None or axis(value) is None):
+            return None
+        from .combinators import Vmap
+
+        size = None
+        if all(x is None for x in axes):  # only the constrained value is a vector: its length is the mapped axis
+            v = value.value if isinstance(value, Mask) else value
+            size = int(v.shape[-1] if v.dim() >= 2 else v.shape[0])
+        return Vmap(self, in_axes=axes, axis_size=size)
+
     # -- GFI -----------------------------------------------------------------------------------------
     def simulate(self, key, args):
+        ev = self._event_vmap(key, args) if key is not None else None
+        if ev is not None:
+            return ev.simulate(key, args)
         w, v = self.random_weighted(key, *args)
         return DistributionTrace(self, args, v, w)
 
@@ -790,6 +834,9 @@ class Distribution(GenerativeFunction):
         """distribution.py:117-147: unconstrained -> simulate, weight 0; constrained -> weight =
         score = logpdf(value)."""
         v = constraint.get_value()
+        ev = self._event_vmap(key, args, v)
+        if ev is not None:
+            return ev.generate(key, constraint, args)
         if v is None:
             if not constraint.static_is_empty():
                 raise ValueError("constraint for a distribution must be a value (ChoiceMap.choice)")
@@ -822,6 +869,10 @@ class Distribution(GenerativeFunction):
         v = sample.get_value()
         if v is None:
             raise MissingAddress(())
+        if _ASSESS_BATCH[-1] is None:  # (inside a Vmap's assess the columns are its mapped axis, not an event axis)
+            ev = self._event_vmap(None, args, v)
+            if ev is not None:  # a vector-valued site: the sum of its elements' log-densities
+                return ev.assess(sample, args)
         w = self.estimate_logpdf(None, v, *args)
         return w, v
 

@@ -1273,6 +1273,47 @@ def case_regenerate_and_rejuvenate(impl):
     assert torch.equal(back.get_choices()["u"], st.get_choices()["u"]) and torch.allclose(w + wb, torch.zeros_like(w), atol=1e-4)
 
 
+def case_vector_valued_sites(impl):
+    """A distribution site whose arguments carry an event axis (`normal(mu_vec, 1.0) @ "x"`): values `[d]` (`[n, d]` over a
+    population), the score summed over the axis (distribution.py:392-396).  simulate / importance / assess / update, a scalar
+    key and a population; means of the draws; flip over a probability vector."""
+    @gen
+    def model(mu):
+        x = normal(mu, 1.0) @ "x"
+        _ = normal(x.sum(-1), 0.5) @ "y"
+        return x
+
+    mu = torch.tensor([0.0, 1.0, -2.0]).to(_dev())
+    key = genjax.random.key(3, impl)
+    tr = model.simulate(key, (mu,))
+    x = tr.get_choices()["x"]
+    assert tuple(x.shape) == (3,) and tuple(tr.get_retval().shape) == (3,)
+    want = sum(_lpdf(f(x[i]), f(mu[i]), 1.0) for i in range(3)) + _lpdf(f(tr.get_choices()["y"]), f(x.sum()), 0.5)
+    assert f(tr.get_score()) == pytest.approx(want, abs=1e-5)
+    s, _ = model.assess(tr.get_choices(), (mu,))
+    assert f(s) == pytest.approx(want, abs=1e-5)
+    cx = torch.tensor([0.5, 0.5, 0.5])
+    tr2, w = model.importance(key, C["x"].set(cx) | C["y"].set(1.0), (mu,))
+    assert torch.equal(tr2.get_choices()["x"].cpu(), cx)
+    assert f(w) == pytest.approx(sum(_lpdf(0.5, f(mu[i]), 1.0) for i in range(3)) + _lpdf(1.0, 1.5, 0.5), abs=1e-5)
+    tr3, wu, _, disc = tr.update(key, C["x"].set(torch.tensor([1.0, 1.0, 1.0])))
+    assert tuple(tr3.get_choices()["x"].shape) == (3,) and f(wu) == pytest.approx(f(tr3.get_score()) - f(tr.get_score()), abs=1e-4)
+    keys = genjax.random.split(key, 4000)
+    trp, wp = model.importance(keys, C["y"].set(-1.0), (mu,))
+    xs = trp.get_choices()["x"]
+    assert tuple(xs.shape) == (4000, 3) and tuple(wp.shape) == (4000,) and tuple(trp.get_score().shape) == (4000,)
+    assert torch.allclose(xs.mean(0).cpu(), mu.cpu(), atol=0.08)
+    assert torch.allclose(wp.cpu(), normal.logpdf(-1.0, xs.sum(-1), 0.5).cpu(), atol=1e-5)
+
+    @gen
+    def coins():
+        b = flip(torch.tensor([0.1, 0.9, 0.5, 0.5])) @ "b"
+        return b
+
+    t = coins.simulate(keys, ())
+    assert torch.allclose(t.get_choices()["b"].float().mean(0).cpu(), torch.tensor([0.1, 0.9, 0.5, 0.5]), atol=0.04)
+
+
 def case_index_request(impl):
     """`IndexRequest(idx, request)` on `Scan` and `Vmap` traces inside a static model (test_scan_combinator.py:463-534,
     test_vmap_combinator.py:273-330): the weight is the change of density of the touched element; the others keep their
@@ -1331,4 +1372,4 @@ def case_index_request(impl):
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_fused_equals_eager, case_params_equal_constants, case_particle_collection, case_custom_proposal,
              case_scan, case_scan_edge_cases, case_scan_fused_equals_loop, case_vmap, case_vmap_edge_cases, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
-             case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update, case_regenerate_and_rejuvenate, case_index_request]
+             case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update, case_regenerate_and_rejuvenate, case_vector_valued_sites, case_index_request]
