@@ -520,6 +520,48 @@ def bench_scan(args, ops, min_s=0.08, T=100, fast_math=False, with_host_loop=Tru
     return res
 
 
+def bench_scan_hmm(args, ops, min_s=0.08, T=500):
+    """ImportanceK over the 256-state HMM written as a scan (the reference's literal configs[4] semantics without
+    resampling): `z' ~ categorical(trans[z]); y ~ categorical(obs[z'])`, N = 1e6, T = 500, one launch per pass.  The
+    categorical rows are chosen by the carried state: the specialised kernel draws by binary search on the row's prepared
+    fixed-point CDF and scores with the row's prepared log-sum-exp (same bits as the two-pass walk of the row)."""
+    import torch
+
+    from genjax._amd import workloads as W
+    from genjax._amd.ops import HipEvent
+
+    impl = 1 if args.rng == "philox" else 0
+    n = args.particles
+    wl = W.HmmScan(ops, impl, 4, n, T, cat_mode=1)
+    wl.run()
+    torch.cuda.synchronize()
+    evs = []
+
+    def one_run():
+        e0, e1 = HipEvent(), HipEvent()
+        e0.record(ops.stream())
+        o = wl.run()
+        e1.record(ops.stream())
+        evs.append((e0, e1))
+        return o
+
+    blocks, _ = timed_blocks(one_run, 1, min_s=min_s, min_blocks=3, max_blocks=12)
+    r = wl.result()
+    dev_ms = statistics.median(a.elapsed_ms(b) for a, b in evs)
+    dt = statistics.median(blocks)
+    bytes_per_launch = (4.0 * T + 8.0) * n
+    achieved = bytes_per_launch / (dev_ms * 1e-3) / 1e9
+    return {
+        "value": n * T / dt, "unit": "particle-steps/s", "ms_per_run": dt * 1e3, "kernel_ms": dev_ms, "runs_timed": len(evs),
+        "config": {"workload": f"ImportanceK over hmm_step.scan(n={T}), {wl.k} states, N={n}, no resampling, [T, N] state trajectories stored",
+                   "rng": args.rng, "categorical": "inverse CDF (one uniform per draw)"},
+        "roofline": {"bound": "hbm", "kernel": "gjx_scan_kernel (one launch per pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": None,
+                     "limiter": "scattered table loads (8 binary-search steps + 2 log-density loads per particle-step) and the cipher"},
+        "log_z": r["log_z"],
+    }
+
+
 # ------------------------------------------------------------------------------------------------------------
 # CPU baselines (the oracle: a port) — bounded samples of the same workloads, timed on this box's host cores
 # ------------------------------------------------------------------------------------------------------------
@@ -801,6 +843,10 @@ def run_rank(args):
                     extra["importance_scan_lgssm"]["cpu_baseline"] = cpu_baseline_scan(args)
             except Exception as ex:
                 extra["importance_scan_lgssm"] = {"error": f"{type(ex).__name__}: {ex}"}
+            try:
+                extra["importance_scan_hmm"] = bench_scan_hmm(args, ops)
+            except Exception as ex:
+                extra["importance_scan_hmm"] = {"error": f"{type(ex).__name__}: {ex}"}
             # ImportanceK variants: one pass per launch (the literal config), the other generator, fast math
             r, _ = bench_importance(args, ops, rank, world, launch_passes=1, steps=64, warmup=16, ramp=False, min_s=0.03)
             extra["importance_1_pass_per_launch"] = entry(r)

@@ -249,6 +249,12 @@ struct CSite {
   int32_t slot;  // LDS slot this site's value is kept in for later sites, -1 if never referenced
   CArg a0, a1, obs;
   const float* logits;
+  // categorical sites of specialised kernels: per-row tables built once on the device (cat_tables_prepare) — the row's
+  // inclusive fixed-point CDF (inverse-CDF sampling by binary search instead of two passes over the row) and its
+  // log-sum-exp (log-density = row[v] - lse[row]); null = evaluate the row on the fly.  Same integers / same f32 ops:
+  // the same bits.
+  const uint32_t* cat_cdf;
+  const float* cat_lse;
   int32_t pre;       // 1: pre0/pre1 hold the hoisted per-site constants; 2: they depend on launch parameters
                      // (GJX_ARG_PARAM) and are re-derived by gjx_plan_set_params into PlanParams::d[2 site], [2 site + 1]
   float pre0, pre1;  // normal: rs, lognorm; gamma: -, lognorm; beta: -, lbeta
@@ -1491,6 +1497,47 @@ int gjx_logpdf_categorical(const int32_t* value, int value_scalar, const float* 
 }
 
 // ---- plans ---------------------------------------------------------------------------------------
+// ---- per-row tables of categorical sites (specialised kernels) ------------------------------------------------------
+__global__ void k_cat_prepare(const float* logits, uint32_t n_rows, uint32_t K, uint32_t* cdf, float* lse) {
+  // one thread per row, sequential in the category exactly as cat_invcdf / row_lse state it
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const float* l = logits + (size_t)r * K;
+  const float m = row_max(l, K);
+  uint32_t C = 0;
+  for (uint32_t c = 0; c < K; ++c) {
+    C += cat_fix(l[c], m);
+    cdf[(size_t)r * K + c] = C;
+  }
+  lse[r] = row_lse(l, K);
+}
+// Build the tables of every categorical site of a table (first compilation of a plan: a GPU is present by then).
+// K <= 511 keeps the inclusive CDF inside 32 bits (cat_fix <= 2^23).  Failure to allocate leaves the on-the-fly path.
+static void cat_tables_prepare(CSite* sites, int n, std::vector<void*>* owned) {
+  bool any = false;
+  for (int q = 0; q < n; ++q) {
+    CSite& st = sites[q];
+    if (st.dist != GJX_DIST_CATEGORICAL || st.cat_lse || !st.logits || st.n_cat > 511 || st.n_rows < 1) continue;
+    uint32_t* cdf = nullptr;
+    float* lse = nullptr;
+    if (hipMalloc(&cdf, sizeof(uint32_t) * (size_t)st.n_rows * (size_t)st.n_cat) != hipSuccess) { (void)hipGetLastError(); continue; }
+    if (hipMalloc(&lse, sizeof(float) * (size_t)st.n_rows) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(cdf); continue; }
+    // (one thread per row: rows are few — a transition / emission matrix — and this runs once per plan)
+    const unsigned rows = (unsigned)st.n_rows;
+    k_cat_prepare<<<(rows + 63) / 64, 64>>>(st.logits, rows, (uint32_t)st.n_cat, cdf, lse);
+    owned->push_back(cdf);
+    owned->push_back(lse);
+    st.cat_cdf = cdf;
+    st.cat_lse = lse;
+    any = true;
+  }
+  if (any && hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+}
+static void free_owned(std::vector<void*>& owned) {
+  for (void* p : owned) (void)hipFree(p);
+  owned.clear();
+}
+
 struct gjx_plan {
   int n_sites;
   int n_slots;
@@ -1504,6 +1551,7 @@ struct gjx_plan {
   // specialised kernels, built on first use: [0] THREEFRY, [1] PHILOX one particle per lane, [2] PHILOX pairs
   // (two adjacent particles per lane), [3] PHILOX quads (four per lane: one wave per 256-particle row)
   gjx_jit::Compiled jit[4];
+  std::vector<void*> dev_owned;  // per-row tables of categorical sites (specialised kernels)
   std::mutex jit_mu;
 };
 
@@ -1693,6 +1741,7 @@ int gjx_plan_destroy(gjx_plan* p) {
   if (!p) return GJX_OK;
   if (p->dev) (void)hipFree(p->dev);
   for (auto& c : p->jit) gjx_jit::release(&c);  // the modules stay cached (bounded, LRU) for plans of the same structure
+  free_owned(p->dev_owned);
   delete p;
   return GJX_OK;
 }
@@ -1710,6 +1759,7 @@ static gjx_jit::Compiled& plan_compiled(gjx_plan* mp, const gjx_keys* pk, int la
   if (c.state == 0) {
     std::lock_guard<std::mutex> lock(mp->jit_mu);
     if (c.state == 0) {
+      cat_tables_prepare(mp->host, mp->n_sites, &mp->dev_owned);
       auto make = [&](int min_waves) {
         gjx_jit::Gen<CSite, CArg> g;
         g.impl = pk->impl; g.sites = mp->host; g.n_sites = mp->n_sites; g.laned = laned; g.pairs_per_lane = P == 4 ? 2 : 1;
@@ -2407,6 +2457,7 @@ struct gjx_scan_plan {
   CSite step[GJX_MAX_SITES];
   CArg next_state[GJX_SMC_MAX_STATE];
   gjx_jit::Compiled jit[2];
+  std::vector<void*> dev_owned;  // per-row tables of categorical sites
   std::mutex mu;
 };
 int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan** out) {
@@ -2432,6 +2483,7 @@ int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan*
 int gjx_scan_plan_destroy(gjx_scan_plan* p) {
   if (!p) return GJX_OK;
   for (auto& c : p->jit) gjx_jit::release(&c);
+  free_owned(p->dev_owned);
   delete p;
   return GJX_OK;
 }
@@ -2468,6 +2520,7 @@ int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
   if (c.state == 0) {
     std::lock_guard<std::mutex> lock(p->mu);
     if (c.state == 0) {
+      cat_tables_prepare(p->step, p->n_step, &p->dev_owned);
       const char* kname = nullptr;
       const std::string src = scan_plan_source(p, impl, &kname);
       if (std::getenv("GJX_PLAN_JIT_DUMP")) fprintf(stderr, "%s\n", src.c_str());
@@ -2502,6 +2555,7 @@ struct gjx_smc_plan {
   CSite init[GJX_MAX_SITES], step[GJX_MAX_SITES];
   CArg init_state[GJX_SMC_MAX_STATE], next_state[GJX_SMC_MAX_STATE];
   gjx_jit::CompiledSmc jit[2];
+  std::vector<void*> dev_owned;  // per-row tables of categorical sites
   std::mutex mu;
 };
 
@@ -2532,6 +2586,7 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
 int gjx_smc_plan_destroy(gjx_smc_plan* p) {
   if (!p) return GJX_OK;
   for (auto& c : p->jit) gjx_jit::release_smc(&c);  // compiled modules are owned by the process-wide (bounded) cache
+  free_owned(p->dev_owned);
   delete p;
   return GJX_OK;
 }
@@ -2561,7 +2616,11 @@ static gjx_jit::CompiledSmc* smc_plan_compiled(gjx_smc_plan* plan, int impl) {
   gjx_jit::CompiledSmc& c = plan->jit[impl];
   if (c.state == 0) {
     std::lock_guard<std::mutex> lock(plan->mu);
-    if (c.state == 0) c.state = gjx_jit::compile_smc(smc_plan_source(plan, impl), &c) ? 1 : -1;
+    if (c.state == 0) {
+      cat_tables_prepare(plan->init, plan->n_init, &plan->dev_owned);
+      cat_tables_prepare(plan->step, plan->n_step, &plan->dev_owned);
+      c.state = gjx_jit::compile_smc(smc_plan_source(plan, impl), &c) ? 1 : -1;
+    }
   }
   return c.state == 1 ? &c : nullptr;
 }

@@ -32,6 +32,11 @@ inline std::string flit(float f) {
   std::snprintf(b, sizeof b, "u2f(0x%08xu)", gjx::f2u(f));
   return b;
 }
+inline std::string plit_u32(const void* p) {
+  char b[64];
+  std::snprintf(b, sizeof b, "((const uint32_t*)0x%llxull)", (unsigned long long)(uintptr_t)p);
+  return b;
+}
 inline std::string plit(const void* p) {
   char b[64];
   std::snprintf(b, sizeof b, "((const float*)0x%llxull)", (unsigned long long)(uintptr_t)p);
@@ -172,6 +177,9 @@ struct SiteEmitter {
           if (st.cat_mode == 0) {
             o << ind << "const Stream<" << I << "> strm" << Q << "(" << K << ", true, " << fold << "u);\n";
             o << ind << "const int32_t vi" << Q << " = jcat_gumbel<" << I << ">(" << row << ", " << st.n_cat << "u, strm" << Q << ");\n";
+          } else if (st.cat_cdf) {  // the row's prepared inclusive CDF: binary search (same integers as the two-pass walk)
+            o << ind << "const int32_t vi" << Q << " = jcat_invcdf_tab(" << plit_u32(st.cat_cdf) << " + (size_t)rr" << Q << " * " << st.n_cat
+              << ", " << st.n_cat << "u, bits" << Q << ");\n";
           } else {
             o << ind << "const int32_t vi" << Q << " = jcat_invcdf(" << row << ", " << st.n_cat << "u, bits" << Q << ");\n";
           }
@@ -197,8 +205,8 @@ struct SiteEmitter {
         break;
       case GJX_DIST_BERNOULLI: lp = "logpdf_bernoulli(" + v + " != 0, a0_" + Q + ")"; break;
       default:
-        lp = "((" + v + " < 0 || " + v + " >= " + std::to_string(st.n_cat) + ") ? -__builtin_inff() : " + row + "[" + v +
-             "] - jrow_lse(" + row + ", " + std::to_string(st.n_cat) + "u))";
+        lp = "((" + v + " < 0 || " + v + " >= " + std::to_string(st.n_cat) + ") ? -__builtin_inff() : " + row + "[" + v + "] - " +
+             (st.cat_lse ? plit(st.cat_lse) + "[rr" + Q + "]" : "jrow_lse(" + row + ", " + std::to_string(st.n_cat) + "u)") + ")";
     }
     o << ind << "{ const float lp = " << lp << "; sc" << sfx << " = sc" << sfx << " + lp;"
       << (st.observed ? " w" + sfx + " = w" + sfx + " + lp;" : "") << " }\n";
@@ -221,6 +229,7 @@ inline void emit_prelude(std::ostringstream& o, bool fast_math = false) {
   o << "__device__ __forceinline__ float jrow_max(const float* l, uint32_t K){ float m=l[0]; for(uint32_t c=1;c<K;++c) m = l[c]>m?l[c]:m; return m; }\n";
   o << "__device__ __forceinline__ float jrow_lse(const float* l, uint32_t K){ const float m=jrow_max(l,K); float acc=0.0f; for(uint32_t c=0;c<K;++c) acc = acc + m_exp(l[c]-m); return m + m_log(acc); }\n";
   o << "__device__ __forceinline__ int32_t jcat_invcdf(const float* l, uint32_t K, uint32_t bits){ const float m=jrow_max(l,K); uint64_t Q=0; for(uint32_t c=0;c<K;++c) Q += cat_fix(l[c],m); const uint64_t thr=((uint64_t)bits*Q)>>32; uint64_t C=0; for(uint32_t c=0;c<K;++c){ C += cat_fix(l[c],m); if (C>thr) return (int32_t)c; } return (int32_t)(K-1); }\n";
+  o << "__device__ __forceinline__ int32_t jcat_invcdf_tab(const uint32_t* cdf, uint32_t K, uint32_t bits){ const uint64_t thr=((uint64_t)bits*(uint64_t)cdf[K-1])>>32; uint32_t lo=0, hi=K-1; while (lo<hi){ const uint32_t mid=(lo+hi)>>1; if ((uint64_t)cdf[mid]>thr) hi=mid; else lo=mid+1; } return (int32_t)lo; }\n";
   o << "template <int IMPL> __device__ __forceinline__ int32_t jcat_gumbel(const float* l, uint32_t K, const Stream<IMPL>& st){ int32_t best=0; float bv=-__builtin_inff(); for(uint32_t c=0;c<K;++c){ const float v = l[c] + gumbel_from_bits(st.bits32(c)); if (v>bv || c==0){ bv=v; best=(int32_t)c; } } return best; }\n";
 }
 

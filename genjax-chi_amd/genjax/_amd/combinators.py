@@ -186,6 +186,7 @@ class Scan(GenerativeFunction):
             else:
                 leaves.append((m["addr"], _stack_time(obs_values[k_obs[a]], True)))
         final = [c[0] if u else c for c, u in zip(out["carry"], low.uniform_carry)]
+        final = [(c != 0 if dt == torch.bool else c.to(dt)) if dt is not None else c for c, dt in zip(final, low.carry_dtypes)]
         retval = (low.rebuild_carry(final), SP.resolve(low, low.ret_y, values_nt, table, dev))
         tr = FusedScanTrace(self, args, retval, out["score"], leaves, key)
         tr.max_partials, tr.row_stats = out["max_partials"], out["rows"]

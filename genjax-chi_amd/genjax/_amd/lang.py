@@ -869,9 +869,12 @@ class Distribution(GenerativeFunction):
         v = sample.get_value()
         if v is None:
             raise MissingAddress(())
-        if _ASSESS_BATCH[-1] is None:  # (inside a Vmap's assess the columns are its mapped axis, not an event axis)
+        # `assess` carries no key: a 1-D column is a POPULATION (one value per particle, as everywhere on this path), so a
+        # vector-valued site is recognised here only by a 2-D value / argument ([n, d]); for a single trace write the
+        # site as `dist.vmap()(...)`, which carries its structure
+        if _ASSESS_BATCH[-1] is None and any(isinstance(a, torch.Tensor) and a.dim() >= 2 for a in (v, *args)):
             ev = self._event_vmap(None, args, v)
-            if ev is not None:  # a vector-valued site: the sum of its elements' log-densities
+            if ev is not None:  # the sum of the elements' log-densities
                 return ev.assess(sample, args)
         w = self.estimate_logpdf(None, v, *args)
         return w, v

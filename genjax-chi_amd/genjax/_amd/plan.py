@@ -88,7 +88,25 @@ class Sym:
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
+        # `table[sym]`: a constant tensor indexed by a traced integer-valued value — a 1-D table gives a distribution
+        # argument (`means[idx]`), a 2-D one the logits / probs ROW of a categorical site (`trans[z]`)
+        if func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[0], torch.Tensor) \
+                and not isinstance(args[0], Sym) and isinstance(args[1], Sym):
+            table, idx = args
+            if idx.has_mul or idx.has_add:
+                raise PlanUnsupported("table index must be a plain traced value")
+            if table.dim() == 1:
+                return TableProxy(table)[idx]
+            if table.dim() == 2:
+                return _Rows(idx.tracer, table, idx)
         raise PlanUnsupported(f"torch.{getattr(func, '__name__', func)} on a traced site value")
+
+
+class _Rows:
+    """`table2d[sym]`: row `sym` of a constant [rows, K] tensor — the parameters of a categorical site."""
+
+    def __init__(self, tracer, table: torch.Tensor, idx: Sym):
+        self.tracer, self.table, self.idx = tracer, table, idx
 
 
 class ParamVal:
@@ -169,6 +187,7 @@ class PlanTracer(_Handler):
         self.sites: list[abi.Site] = []
         self.meta: list[dict] = []  # per site: addr, gen_fn, args (symbolic), out_col, observed
         self.inputs: list[torch.Tensor] = []
+        self.input_orig: dict = {}  # input column -> the constrained value it was made from (its own dtype)
         self.keep: list = []  # device tensors the site table points into
         self.n_out = 0
 
@@ -242,14 +261,23 @@ class PlanTracer(_Handler):
             kind, v = args[0] if isinstance(args[0], tuple) else ("logits", args[0])
             if isinstance(v, (Sym, _Table, ParamVal)):
                 raise PlanUnsupported("data-dependent categorical parameters")
-            logits = Categorical._logits((kind, v), self.n)
-            if logits.shape[0] != 1:
-                raise PlanUnsupported("per-particle categorical parameters")
-            self.keep.append(logits)
             site.dist = abi.DIST_CATEGORICAL
-            site.n_cat, site.n_rows = int(logits.shape[1]), 1
             site.cat_mode = 0 if gen_fn.sampling == "gumbel" else 1
-            site.arg[0] = abi.Arg(abi.ARG_CONST, 0, 0.0, 0.0, None)
+            if isinstance(v, _Rows):  # `categorical(logits=trans[z])`: the row is chosen by an earlier value
+                ops = get_ops()
+                logits = torch.as_tensor(v.table, dtype=torch.float32).to(ops.device())
+                if kind == "probs":
+                    logits = torch.log(logits)
+                logits = logits.contiguous()
+                site.n_cat, site.n_rows = int(logits.shape[1]), int(logits.shape[0])
+                site.arg[0] = self._arg(v.idx)
+            else:
+                logits = Categorical._logits((kind, v), self.n)
+                if logits.shape[0] != 1:
+                    raise PlanUnsupported("per-particle categorical parameters")
+                site.n_cat, site.n_rows = int(logits.shape[1]), 1
+                site.arg[0] = abi.Arg(abi.ARG_CONST, 0, 0.0, 0.0, None)
+            self.keep.append(logits)
             site.logits = logits.data_ptr()
             is_int = True
         else:
@@ -276,6 +304,7 @@ class PlanTracer(_Handler):
         if obs is not None:
             # a constrained value may feed later sites: constants stay constants, columns become inputs
             if isinstance(obs, torch.Tensor) and obs.dim() == 1 and obs.shape[0] == self.n and self.n > 1:
+                self.input_orig[site.obs.ref] = obs
                 return Sym(self, ("input", site.obs.ref), is_int=is_int)
             return obs if obs_sym is None else obs_sym
         return _IntSym(self, ("site", idx)) if is_int else Sym(self, ("site", idx))
@@ -296,7 +325,7 @@ class TableProxy:
 
     def __getitem__(self, idx):
         if isinstance(idx, Sym):
-            if not idx.is_int:
+            if not idx.is_int and idx.src[0] not in ("state", "obs"):  # (a carry / observation is rounded to nearest)
                 raise PlanUnsupported("table index must be an integer-valued site")
             ops = get_ops()
             t = self.table.to(ops.device()).contiguous()
@@ -308,7 +337,7 @@ class TableProxy:
 
 
 def _contains_sym(v) -> bool:
-    if isinstance(v, (Sym, _Table, ParamVal)):
+    if isinstance(v, (Sym, _Table, _Rows, ParamVal)):
         return True
     if isinstance(v, (tuple, list)):
         return any(_contains_sym(x) for x in v)
@@ -373,7 +402,9 @@ def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
         if isinstance(x, Sym):
             base = site_vals[x.src[1]] if x.src[0] == "site" else tracer.inputs[x.src[1]]
             if not (x.has_mul or x.has_add):
-                return base  # the value itself, in its presented dtype (bool for flip, int32 for categorical)
+                # the value itself, in its presented dtype (bool for flip, int32 for categorical; a constrained column
+                # as it was given)
+                return tracer.input_orig.get(x.src[1], base) if x.src[0] == "input" else base
             base = base.to(torch.float32) if isinstance(base, torch.Tensor) else float(base)
             out = base
             if x.has_mul:
@@ -383,6 +414,9 @@ def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
             return out
         if isinstance(x, _Table):
             return x.table[site_vals[x.idx.src[1]].long()]
+        if isinstance(x, _Rows):
+            base = site_vals[x.idx.src[1]] if x.idx.src[0] == "site" else tracer.inputs[x.idx.src[1]]
+            return x.table.to(base.device)[base.long()]
         if isinstance(x, ParamVal):
             return x.value
         if isinstance(x, tuple):

@@ -135,6 +135,12 @@ def lower_scan(kernel_gen_fn, carry0, xs, obs_addrs: list[tuple], fast_math: boo
             if a.kind == abi.ARG_SITE or a.kind == abi.ARG_TABLE or (a.kind == abi.ARG_STATE and not uniform[a.ref]):
                 uniform[k] = False
     low.uniform_carry = uniform
+    # a carry component that IS an integer-valued site (an HMM's state) is presented in the site's dtype (the kernel's
+    # state columns are f32)
+    low.carry_dtypes = []
+    for v in nc_leaves:
+        m = tr.meta[v.src[1]] if isinstance(v, Sym) and v.src[0] == "site" and not (v.has_mul or v.has_add) else None
+        low.carry_dtypes.append(m["dtype"] if m is not None and m["is_int"] else None)
     return low
 
 

@@ -270,6 +270,46 @@ def lgssm_scan(ops: Ops, impl: int, seed: int, n: int, T: int, **kw):
     return wl.result()
 
 
+class HmmScan:
+    """ImportanceK over the HMM as a scan (the reference's literal configs[4] semantics: no resampling, `[T, N]` state
+    trajectories): kernel `z' ~ categorical(trans[z]); y ~ categorical(obs[z'])` in one launch."""
+
+    def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, n_states=None, cat_mode: int = 1):
+        self.ops, self.impl, self.n, self.T = ops, impl, n, T
+        trans, obs = hmm_tables(n_states)
+        self.k = trans.shape[0]
+        dev = ops.device()
+        self.trans = torch.from_numpy(trans).to(dev).contiguous()
+        self.obs_l = torch.from_numpy(obs).to(dev).contiguous()
+        z = abi.Site()
+        z.dist, z.observed, z.out_col = abi.DIST_CATEGORICAL, 0, 0
+        z.n_cat, z.n_rows, z.cat_mode = self.k, self.k, cat_mode
+        z.arg[0] = abi.Arg(abi.ARG_STATE, 0, 1.0, 0.0, None)
+        z.logits = self.trans.data_ptr()
+        y = abi.Site()
+        y.dist, y.observed, y.out_col = abi.DIST_CATEGORICAL, 1, -1
+        y.n_cat, y.n_rows, y.cat_mode = self.k, self.k, cat_mode
+        y.arg[0] = abi.Arg(abi.ARG_SITE, 0, 1.0, 0.0, None)
+        y.obs = abi.Arg(abi.ARG_OBS, 0, 1.0, 0.0, None)
+        y.logits = self.obs_l.data_ptr()
+        self.plan = ops.scan_plan_create([z, y], [abi.Arg(abi.ARG_SITE, 0, 1.0, 0.0, None)], 1)
+        self.y = hmm_data(T, n_states)
+        self.obs = torch.from_numpy(self.y.astype(np.float32).reshape(T, 1)).to(dev)
+        self.z0 = float(HMM["init_state"] % self.k)
+        self.kb = importance_particle_keys(prng.key(seed, impl), n)
+        self.out = None
+
+    def run(self):
+        self.out = self.ops.scan_run(self.plan, self.kb, self.n, self.T, self.obs, [self.z0], [torch.int32], out=self.out)
+        return self.out
+
+    def result(self):
+        o = self.out
+        lse, e, q = self.ops.lse_rows(o["rows"])
+        return dict(z=o["values"][0], logw=o["logw"], score=o["score"], carry=o["carry"][0],
+                    log_z=Ops.log_z_from_rows(e, q, self.n))
+
+
 def scaled_circulant(n: int, k: int, epsilon: float, delta: float) -> np.ndarray:
     """Row-circulant matrix whose first column is eps^|i| within distance k of the diagonal
     (wrapping) and -delta elsewhere — restated from the reference's description, float32."""

@@ -639,6 +639,15 @@ def case_scan_fused_equals_loop(impl):
         _ = flip(p) @ "z"
         return (x2, s - 1.0), (g * 0.5 + 1.0, b)
 
+    torch.manual_seed(0)
+    trans, emit = torch.randn(6, 6).to(_dev()), torch.randn(6, 6).to(_dev())
+
+    @gen
+    def hmm_step(z, _):  # the shape of BASELINE configs[4]: categorical rows chosen by the carried state / the new state
+        z2 = categorical(logits=trans[z]) @ "z"
+        _ = categorical(logits=emit[z2]) @ "y"
+        return z2, z2
+
     n, T = 3000, 9
     keys = genjax.random.split(genjax.random.key(21, impl), n)
     ys = torch.linspace(-1.0, 1.5, T)
@@ -649,7 +658,9 @@ def case_scan_fused_equals_loop(impl):
             (lg_step.scan(n=T), C[torch.arange(T), "y"].set(ys), (x0, None)),  # per-particle initial carry
             (lg_step.scan(n=T), C.n(), (0.25, None)),
             (rich_step.scan(), C["y"].set(ys) | C["z"].set(zs), ((0.5, 3.0), us)),
-            (rich_step.scan(), C["y"].set(ys), ((x0, 1.0), us))]
+            (rich_step.scan(), C["y"].set(ys), ((x0, 1.0), us)),
+            (hmm_step.scan(n=T), C["y"].set(torch.tensor([1, 0, 3, 5, 2, 2, 4, 0, 1])), (0, None)),
+            (hmm_step.scan(n=T), C.n(), (2, None))]
 
     def same(a, b):
         if isinstance(a, (tuple, list)):
@@ -681,11 +692,12 @@ def case_scan_fused_equals_loop(impl):
         for k, v in dict(sa.get_choices().leaves()).items():
             assert same(v, dict(sb.get_choices().leaves())[k]), k
         # the general ScanTrace methods work on the fused trace (per-step traces rebuilt on demand)
-        pa, pb = ta.project(keys, S["x"]), tb.project(keys, S["x"])
+        lat = "x" if "x" in ta.get_choices() else "z"
+        pa, pb = ta.project(keys, S[lat]), tb.project(keys, S[lat])
         assert torch.allclose(torch.as_tensor(pa), torch.as_tensor(pb), atol=1e-4)
         idx = torch.arange(0, n, 7, device=_dev())
         sub = ta.map_leaves(lambda v: v[idx] if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == n else v)
-        assert same(sub.get_choices()["x"], ta.get_choices()["x"][idx]) and same(sub.get_score(), ta.get_score()[idx])
+        assert same(sub.get_choices()[lat], ta.get_choices()[lat][idx]) and same(sub.get_score(), ta.get_score()[idx])
     # ImportanceK over a scan target: exact log-marginal of the linear-Gaussian chain (Kalman filter, float64)
     T = 5
     ys = torch.tensor([0.3, -0.2, 0.5, 0.1, -0.4])
@@ -1290,7 +1302,14 @@ def case_vector_valued_sites(impl):
     assert tuple(x.shape) == (3,) and tuple(tr.get_retval().shape) == (3,)
     want = sum(_lpdf(f(x[i]), f(mu[i]), 1.0) for i in range(3)) + _lpdf(f(tr.get_choices()["y"]), f(x.sum()), 0.5)
     assert f(tr.get_score()) == pytest.approx(want, abs=1e-5)
-    s, _ = model.assess(tr.get_choices(), (mu,))
+    # (keyless `assess` reads 1-D columns as a population; the explicit `vmap` form carries the event structure)
+    @gen
+    def model_v(mu):
+        x = normal.vmap(in_axes=(0, None))(mu, 1.0) @ "x"
+        _ = normal(x.sum(-1), 0.5) @ "y"
+        return x
+
+    s, _ = model_v.assess(tr.get_choices(), (mu,))
     assert f(s) == pytest.approx(want, abs=1e-5)
     cx = torch.tensor([0.5, 0.5, 0.5])
     tr2, w = model.importance(key, C["x"].set(cx) | C["y"].set(1.0), (mu,))

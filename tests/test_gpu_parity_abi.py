@@ -701,6 +701,22 @@ def test_scan_run(hip_ops, oracle_ops, impl, n, T):
                 same(a, b, f"scan output {i}")
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("cat_mode", [0, 1])
+def test_scan_run_hmm(hip_ops, oracle_ops, impl, cat_mode):
+    """The HMM as a scan kernel (categorical rows chosen by the carried state and by the new state; the reference's
+    configs[4] semantics under ImportanceK): one launch == the oracle, Gumbel-max and inverse-CDF categoricals."""
+    n, T = 6000, 12
+    h, o = W.HmmScan(hip_ops, impl, 4, n, T, n_states=16, cat_mode=cat_mode), W.HmmScan(oracle_ops, impl, 4, n, T, n_states=16, cat_mode=cat_mode)
+    h.run(); o.run()
+    rh, ro = h.result(), o.result()
+    for key in ("z", "logw", "score", "carry"):
+        same(rh[key], ro[key], key)
+    assert rh["log_z"] == ro["log_z"]
+    z = ro["z"]
+    assert int(z.min()) >= 0 and int(z.max()) < 16
+
+
 def test_scan_full_size(hip_ops):
     """N = 1e6, T = 100 (the reference's literal config-3 semantics under ImportanceK): weights and scores of the
     one-launch scan agree with a float64 recomputation from the stored [T, N] trajectories."""

@@ -141,3 +141,18 @@ def test_scan_plans_compile(hip_lib_nogpu, impl):
     sites, nxt = W.lgssm_scan_sites()
     fast = hip_lib_nogpu.scan_plan_create(sites, nxt, 1, fast_math=True)
     assert fast.compile_check(impl) == 0
+
+
+def test_hmm_scan_plan_compiles(hip_lib_nogpu):
+    """categorical sites whose logits row is chosen by the carried state / an earlier site (the HMM as a scan kernel)"""
+    for mode in (0, 1):
+        A = abi.Arg
+        z = abi.Site(); z.dist, z.observed, z.out_col = abi.DIST_CATEGORICAL, 0, 0
+        z.n_cat, z.n_rows, z.cat_mode = 16, 16, mode
+        z.arg[0] = A(abi.ARG_STATE, 0, 1.0, 0.0, None); z.logits = 0x7F0000001000
+        y = abi.Site(); y.dist, y.observed, y.out_col = abi.DIST_CATEGORICAL, 1, -1
+        y.n_cat, y.n_rows, y.cat_mode = 16, 16, mode
+        y.arg[0] = A(abi.ARG_SITE, 0, 1.0, 0.0, None); y.obs = A(abi.ARG_OBS, 0, 1.0, 0.0, None); y.logits = 0x7F0000002000
+        plan = hip_lib_nogpu.scan_plan_create([z, y], [A(abi.ARG_SITE, 0, 1.0, 0.0, None)], 1)
+        for impl in (0, 1):
+            assert plan.compile_check(impl) == 0
