@@ -739,6 +739,32 @@ def test_scan_full_size(hip_ops):
         assert abs(float(std[-1]) - 1.0 / math.sqrt(1.0 - m["a"] ** 2)) < 0.02
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+def test_smc_plans_ess_adaptive(hip_ops, oracle_ops, impl):
+    """ESS-adaptive resampling in GENERATED filters (user models): flags, per-step pairs, particles, accumulated weights
+    and ancestors equal the oracle's, for one filter and for a batch of three."""
+    from genjax._amd import prng
+
+    T, n = 16, 20000
+    y = W.lgssm_data(T)
+    obs2 = np.stack([y, (np.arange(T) % 2).astype(np.float32)], axis=1)
+    _, hr = _smc_plans(hip_ops)
+    _, orr = _smc_plans(oracle_ops)
+    sk, rk = W.smc_key_schedule(prng.key(13, impl), T)
+    h = hip_ops.smc_run_plan(hr, impl, n, sk, rk, obs2, True, ess_threshold=0.5, want_flags=True)
+    o = oracle_ops.smc_run_plan(orr, impl, n, sk, rk, obs2, True, ess_threshold=0.5, want_flags=True)
+    same(h[5], o[5], "resampled flags")
+    assert 0 < int((o[5][1:] == 0).sum()) < T - 1
+    same(h[0], o[0], "step max"); same(h[1], o[1], "step q"); same(h[3], o[3], "logw"); same(h[4], o[4], "ancestors")
+    for a, b in zip(h[2], o[2]):
+        same(a, b, "state column")
+    pairs = [W.smc_key_schedule(prng.key(20 + f, impl), T) for f in range(3)]
+    skf, rkf = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    hb = hip_ops.smc_run_plan(hr, impl, n, skf, rkf, obs2, True, ess_threshold=0.5, want_flags=True)
+    ob = oracle_ops.smc_run_plan(orr, impl, n, skf, rkf, obs2, True, ess_threshold=0.5, want_flags=True)
+    same(hb[5], ob[5], "batched flags"); same(hb[1], ob[1], "batched step q"); same(hb[4][:, :, :n], ob[4][:, :, :n], "batched ancestors")
+
+
 def test_full_size_properties(hip_ops):
     """BASELINE sizes (1e6 particles) through size-independent properties: closed-form log Z within
     Monte-Carlo error, weight-sum invariants, monotone ancestors with floor/ceil offspring counts."""
