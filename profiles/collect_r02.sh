@@ -21,7 +21,8 @@ CMD[smc_hmm]="python3 bench.py --workload smc_hmm --no-cpu-baseline --steps 2 --
 CMD[scan_lgssm]="python3 bench.py --workload scan_lgssm --no-cpu-baseline"
 SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM"
 SQ2="SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32"
-export GJX_BENCH_FILTERS=1 GJX_BENCH_MIN_S=0.01
+# (counter passes: 8 importance passes per launch, so that every launch of these runs covers the same work)
+export GJX_BENCH_FILTERS=1 GJX_BENCH_MIN_S=0.01 GJX_BENCH_LAUNCH=8
 for w in importance importance_fast smc_lgssm smc_hmm scan_lgssm; do
   timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${w}_fetch" -- ${CMD[$w]} > "$OUT/${w}_fetch.log" 2>&1 || exit 1
   timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${w}_write" -- ${CMD[$w]} > "$OUT/${w}_write.log" 2>&1 || exit 1
@@ -29,7 +30,7 @@ for w in importance importance_fast smc_lgssm smc_hmm scan_lgssm; do
   timeout -k 10 200 rocprofv3 --pmc $SQ2 --output-format csv -d "$OUT/${w}_sq2" -- ${CMD[$w]} > "$OUT/${w}_sq2.log" 2>&1 || exit 1
   echo "$w counters done"
 done
-unset GJX_BENCH_RAMP GJX_BENCH_MIN_S
+unset GJX_BENCH_RAMP GJX_BENCH_MIN_S GJX_BENCH_LAUNCH
 # 3. the plain bench line of the same build
 timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err" || exit 1
 python3 profiles/summarize_r02.py "$TAG" "$OUT" > "$OUT/summarize.log" 2>&1 || { tail -20 "$OUT/summarize.log"; exit 1; }

@@ -68,7 +68,7 @@ for r in csv.DictReader(open(newest("trace/**/*kernel_trace.csv"))):
         int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 with open(os.path.join(here, f"{tag}_summary.md"), "w") as f:
     f.write(f"# {tag}: rocprofv3 evidence (one MI355X)\n\n`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 "
-            "--no-cpu-baseline` (profiles/collect_r02.sh) — the driver's command: headline ImportanceK (8 passes per launch), every "
+            "--no-cpu-baseline` (profiles/collect_r02.sh) — the driver's command: headline ImportanceK (20 passes per launch at --steps 20), every "
             "`extra` entry (one-filter SMC LGSSM / HMM, ESS-adaptive, 16 filters per launch, collapsing weights, the one-launch Scan, "
             "1 pass per launch, threefry, fast math).\n\n## --stats (all launches of the run, warm-up and clock ramp included)\n\n")
     f.write("| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|\n")
@@ -91,7 +91,7 @@ for w, label in (("importance", "exact"), ("importance_fast", "fast_math")):
     imp[label] = e
 pmc = dict(imp["exact"])
 pmc["fast_math"] = imp["fast_math"]
-pmc["note"] = ("separate --pmc passes of `bench.py --steps 48 --warmup 8 --no-extra` (every launch: 8 passes of 1e6 particles); FETCH_SIZE "
+pmc["note"] = ("separate --pmc passes of `GJX_BENCH_LAUNCH=8 bench.py --steps 48 --warmup 8 --no-extra` (every launch: 8 passes of 1e6 particles); FETCH_SIZE "
                "doubled per MI355X_MICROARCH.md; algorithmic bytes per pass = 48 MB (10 value columns + score + logw, 4 B each)")
 json.dump(pmc, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1)
 
