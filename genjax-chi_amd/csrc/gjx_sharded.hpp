@@ -47,9 +47,8 @@ struct Group {
   int arrived = 0;
   uint64_t generation = 0;
   bool broken = false;
-  std::vector<const void*> slot;   // one posted pointer per rank
-  std::vector<const void*> slot2;  // a second one (exchange: the recv list)
-  explicit Group(int w) : world(w), slot((size_t)w, nullptr), slot2((size_t)w, nullptr) {}
+  std::vector<const void*> slot;  // one posted pointer per rank
+  explicit Group(int w) : world(w), slot((size_t)w, nullptr) {}
   // -> false if a rank did not arrive within the timeout (another rank failed): the group is broken for good
   bool barrier() {
     std::unique_lock<std::mutex> lk(mu);
@@ -112,7 +111,6 @@ struct LocalTransport : Transport {
   int exchange(void* const* cols, int n_cols, size_t elem, const Seg* sends, int ns, const Seg* recvs, int nr,
                gjx_stream s) override {
     if (world == 1) return GJX_OK;
-    (void)sends; (void)ns;
     post = ExPost{cols, sends, ns};
     g->slot[(size_t)rank] = &post;
     if (!g->barrier()) return GJX_ERR_LAUNCH;
@@ -148,7 +146,7 @@ int sharded_run(Transport& T, const gjx_smc_config* cfg, int n_state, size_t sta
       cfg->n_filters > 1 || N % ((uint64_t)world * tile) != 0 || nl != N / (uint64_t)world || lo != (uint64_t)rank * nl ||
       (io->shuffle == 0 && world > 1 && !io->ranges) || world > 64)
     return GJX_ERR_INVALID;
-  const uint64_t nt = gjx_num_tiles(N), tl = lo / tile, tiles_local = nl / tile;
+  const uint64_t nt = gjx_num_tiles(N), tiles_local = nl / tile;
   const bool adaptive = cfg->ess_threshold > 0.0f && cfg->ess_threshold < 1.0f;
   if (adaptive && !cfg->tile_ess) return GJX_ERR_INVALID;
   uint64_t received = 0;
@@ -160,7 +158,6 @@ int sharded_run(Transport& T, const gjx_smc_config* cfg, int n_state, size_t sta
     if (rc) break;
     if ((rc = T.allreduce_max_f32(io->max_partials, (size_t)nt, s))) break;
     if ((rc = gjx_smc_step_b(cfg, io->logw[cur] + lo, io->max_partials, io->out_max + t, io->tile_sums, s))) break;
-    (void)tl;
     if ((rc = T.allgather(io->tile_sums, (size_t)tiles_local * sizeof(uint64_t), s))) break;
     if (adaptive && (rc = T.allgather(cfg->tile_ess, (size_t)tiles_local * 2 * sizeof(uint64_t), s))) break;
     if (t + 1 >= cfg->n_steps || world == 1) continue;
@@ -212,9 +209,6 @@ int sharded_run(Transport& T, const gjx_smc_config* cfg, int n_state, size_t sta
   if (io->received) *io->received = received;
   return rc;
 }
-
-template <class PrevQ>
-inline void unused(PrevQ) {}
 
 inline int run_lgssm(Transport& T, const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y, const gjx_sharded_io* io,
                      gjx_stream s) {

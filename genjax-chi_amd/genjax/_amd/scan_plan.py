@@ -20,7 +20,7 @@ import torch
 
 from . import abi
 from .choicemap import ChoiceMap
-from .lang import StaticGenerativeFunction, ParticleKeys, _map_any
+from .lang import StaticGenerativeFunction, ParticleKeys
 from .plan import PlanTracer, PlanUnsupported, Sym, _Table
 from .runtime import get_ops
 
