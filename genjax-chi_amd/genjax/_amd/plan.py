@@ -22,6 +22,8 @@ its arguments as plain constants — same numbers, one compilation per distinct 
 
 from __future__ import annotations
 
+import threading
+
 import torch
 
 from . import abi
@@ -363,10 +365,34 @@ def _trace(gen_fn, constraint: ChoiceMap, n: int, args):
     return None
 
 
+_PLANS = threading.local()  # per thread: a plan's parameters are set-then-run, not a concurrent object
+_PLAN_CACHE_MAX = 32
+
+
 def _make_plan(tracer):
+    """The plan of a traced body.  Plans are cached by their site table (the model's STRUCTURE — observations and scalar
+    arguments are parameters, set per call): a repeated call skips plan creation and, in the library, regenerating and
+    looking up the specialised kernel's source."""
+    import ctypes as C
+    from collections import OrderedDict
+
     from .runtime import fast_math_enabled
 
-    plan = get_ops().plan_create(tracer.sites, fast_math=fast_math_enabled())
+    ops, fast = get_ops(), fast_math_enabled()
+    cache = getattr(_PLANS, "cache", None)
+    if cache is None:
+        cache = _PLANS.cache = OrderedDict()
+    arr = (abi.Site * len(tracer.sites))(*tracer.sites)
+    key = (id(ops), fast, bytes(memoryview(arr)))
+    hit = cache.get(key)
+    if hit is not None:
+        cache.move_to_end(key)
+        plan = hit[0]
+    else:
+        plan = ops.plan_create(tracer.sites, fast_math=fast)
+        cache[key] = (plan, tracer.keep)  # (the tables the site table points into stay alive with the plan)
+        while len(cache) > _PLAN_CACHE_MAX:
+            cache.popitem(last=False)
     if tracer.params:
         plan.set_params(tracer.params)
     return plan
