@@ -11,6 +11,8 @@ SURVEY F6, and its tests hold no random golden vectors):
                       test_static_gen_fn.py:317-318, README.md:121-123 analytic means).
   oracle_regression.json  outputs of the in-repo oracle for fixed counters — regression pins of
                       the arithmetic spec (both the oracle and the HIP library must reproduce them).
+  oracle_regression_r02.json  the same for what round 2 added: the one-launch scan (LGSSM and HMM kernels), the
+                      ESS-adaptive schedule, launch parameters, the collapsing-weights filter.
 """
 import json
 import math
@@ -111,3 +113,31 @@ for impl, nm in ((0, "threefry"), (1, "philox")):
     r["hmm_q"] = h["out_q"].tolist()
     reg[nm] = r
 dump("oracle_regression.json", reg)
+
+# ---- round 2 additions (a separate file: the round-1 pins above must keep reproducing unchanged) ------------------------
+reg2 = {}
+for impl, nm in ((0, "threefry"), (1, "philox")):
+    r = {}
+    sc = W.lgssm_scan(ora, impl, seed=6, n=1500, T=9)
+    r["scan_lgssm_logw_head_bits"] = sc["logw"][:6].view(torch.int32).tolist()
+    r["scan_lgssm_x_t8_head_bits"] = sc["x"][8, :6].view(torch.int32).tolist()
+    hs = W.HmmScan(ora, impl, 7, 1200, 8, n_states=16, cat_mode=1)
+    hs.run()
+    hr = hs.result()
+    r["scan_hmm_z_t7_head"] = hr["z"][7, :12].tolist()
+    r["scan_hmm_logw_head_bits"] = hr["logw"][:4].view(torch.int32).tolist()
+    ad = W.lgssm_smc(ora, impl, seed=8, n=3000, T=16, want_ancestors=True, ess_threshold=0.5)
+    r["ess_flags"] = ad["resampled"].tolist()
+    r["ess_q"] = ad["out_q"].tolist()
+    r["ess_logw_head_bits"] = ad["logw"][:4].view(torch.int32).tolist()
+    from genjax._amd import abi, prng  # noqa: E402
+    import numpy as np  # noqa: E402,F811
+
+    y = np.array([0.1, 25.0, -40.0, -39.5, 60.0, 60.2], dtype=np.float32)
+    sk, rk = W.smc_key_schedule(prng.key(11, impl), 6)
+    col = ora.smc_run_lgssm(impl, 20000, sk, rk, abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.05), y, True)
+    r["collapse_q"] = col[1].tolist()
+    r["collapse_anc_t2_distinct"] = int(col[4][2].unique().numel())
+    r["collapse_anc_t5_head"] = col[4][5, :8].tolist()
+    reg2[nm] = r
+dump("oracle_regression_r02.json", reg2)

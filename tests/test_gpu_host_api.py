@@ -150,9 +150,10 @@ def test_host_level_flows_match_oracle(hip_ops, oracle_ops, impl):
 
 
 def test_regression_vectors_on_gpu(hip_ops):
-    from test_oracle_pinning import check_regression
+    from test_oracle_pinning import check_regression, check_regression_r02
 
     check_regression(hip_ops)
+    check_regression_r02(hip_ops)
 
 
 @pytest.mark.parametrize("impl", ["threefry", "philox"])

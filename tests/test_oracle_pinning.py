@@ -247,6 +247,7 @@ def test_lse_records_merge_exactly(oracle_ops):
 
 def test_regression_vectors(oracle_ops):
     check_regression(oracle_ops)
+    check_regression_r02(oracle_ops)
 
 
 def check_regression(ops):
@@ -282,6 +283,34 @@ def check_regression(ops):
         assert s_["ancestors"][5, :16].cpu().tolist() == r["lgssm_anc_t5_head"]
         h = W.hmm_smc(ops, impl, seed=5, n=2048, T=6, n_states=16)
         assert h["out_q"].cpu().tolist() == r["hmm_q"]
+
+
+def check_regression_r02(ops):
+    """Round-2 pins (tests/golden/oracle_regression_r02.json): the one-launch scan, ESS-adaptive schedule, collapse."""
+    import numpy as np
+
+    from genjax._amd import abi, prng
+
+    reg = gold("oracle_regression_r02.json")
+    for impl, nm in ((0, "threefry"), (1, "philox")):
+        r = reg[nm]
+        sc = W.lgssm_scan(ops, impl, seed=6, n=1500, T=9)
+        assert sc["logw"][:6].cpu().view(torch.int32).tolist() == r["scan_lgssm_logw_head_bits"]
+        assert sc["x"][8, :6].cpu().view(torch.int32).tolist() == r["scan_lgssm_x_t8_head_bits"]
+        hs = W.HmmScan(ops, impl, 7, 1200, 8, n_states=16, cat_mode=1)
+        hs.run()
+        hr = hs.result()
+        assert hr["z"][7, :12].cpu().tolist() == r["scan_hmm_z_t7_head"]
+        assert hr["logw"][:4].cpu().view(torch.int32).tolist() == r["scan_hmm_logw_head_bits"]
+        ad = W.lgssm_smc(ops, impl, seed=8, n=3000, T=16, want_ancestors=True, ess_threshold=0.5)
+        assert ad["resampled"].cpu().tolist() == r["ess_flags"] and ad["out_q"].cpu().tolist() == r["ess_q"]
+        assert ad["logw"][:4].cpu().view(torch.int32).tolist() == r["ess_logw_head_bits"]
+        y = np.array([0.1, 25.0, -40.0, -39.5, 60.0, 60.2], dtype=np.float32)
+        sk, rk = W.smc_key_schedule(prng.key(11, impl), 6)
+        col = ops.smc_run_lgssm(impl, 20000, sk, rk, abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.05), y, True)
+        assert col[1].cpu().tolist() == r["collapse_q"]
+        assert int(col[4][2].unique().numel()) == r["collapse_anc_t2_distinct"]
+        assert col[4][5, :8].cpu().tolist() == r["collapse_anc_t5_head"]
 
 
 def check_hmm_alias(ops, k):
