@@ -200,9 +200,8 @@ def bench_importance(args, ops, rank, world, launch_passes=None, rng=None, steps
     # per-batch cost to ~1 us per pass.  LAUNCH independent passes (seeds 0, 1, ...) share one importance launch: a
     # single 1e6-particle pass is under two rounds of the machine, eight keep it full.  Persistent output buffers +
     # pre-marshalled C calls: no host allocation per step.
-    # (single device: as many passes per launch as the timed block has, up to the 32 a launch takes — fewer gaps between
-    # launches; the sharded pipeline keeps 8, the configuration its tests cover)
-    default_launch = 8 if sharded else max(1, min(32, steps))
+    # (as many passes per launch as the timed block has, up to the 32 a launch takes: fewer gaps between launches)
+    default_launch = max(1, min(32, steps))
     LAUNCH = launch_passes if launch_passes else int(os.environ.get("GJX_BENCH_LAUNCH", str(default_launch)))
     BATCH = int(os.environ.get("GJX_BENCH_BATCH", "32")) // LAUNCH * LAUNCH or LAUNCH
     prep = wl.prepare(fold_batch=BATCH, passes=LAUNCH)
