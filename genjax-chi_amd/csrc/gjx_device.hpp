@@ -867,7 +867,7 @@ struct ResampleArgs {
   const uint64_t* tile_ess = nullptr;  // [2 ntiles]: (R1_b, R2_b) of every source tile (needed when ess_thr > 0)
   int32_t* resampled_out = nullptr;    // nullable: block 0 of each filter stores 1 (resampled) / 0 (kept)
   int allow_help = 1;                  // 0: heavy tiles serve all their slots themselves
-  double heavy_frac = 0.0;             // (kCapSlots - 8) / n_out: the share of the total mass above which a tile may be heavy
+  int heavy_shift = 64;                // a tile may be heavy if its mass exceeds total >> heavy_shift (heavy_shift_for(n_out))
   // Extra workgroups (per filter) behind the `ntiles` tile workgroups: they own no source tile, exit at once in ordinary
   // steps, and rank behind the idle tiles as takers of a heavy tile's delegated chunks — so a heavy tile can always
   // delegate, also when no tile is idle (one particle with 60 % of the mass, the rest spread evenly).
@@ -876,11 +876,19 @@ struct ResampleArgs {
   int extra_first = 0;                 // test knob (GJX_SMC_EXTRA_FIRST=1): the extra workgroups rank BEFORE the idle tiles
 };
 
-// The tile mass above which a tile MAY own more than kCapSlots output slots (slots <= mass * n_out / total + 1)
-// with heavy_frac = (kCapSlots - 8) / n_out formed once on the host (ResampleArgs::heavy_frac)
-GJX_HD uint64_t heavy_threshold(uint64_t total, double heavy_frac) {
-  const double t = (double)total * heavy_frac;
-  return t >= 18446744073709549568.0 ? ~(uint64_t)0 : (uint64_t)t;
+// The tile mass above which a tile MAY own more than kCapSlots output slots (slots <= mass * n_out / total + 1): a power-
+// of-two fraction of the total at or below (kCapSlots - 8) / n_out, so the test is one shift in every workgroup.  The
+// threshold only decides WHO serves a tile's slots (every workgroup of a launch derives the same one): results do not
+// depend on it.
+GJX_HD uint64_t heavy_threshold(uint64_t total, int heavy_shift) {
+  return heavy_shift >= 64 ? ~(uint64_t)0 : total >> heavy_shift;
+}
+GJX_HD int heavy_shift_for(uint64_t n_out) {  // host: smallest s with 2^s >= n_out / (kCapSlots - 8); 64 = no tile can be heavy
+  const uint64_t cap = (uint64_t)kCapSlots - 8;
+  if (n_out <= cap) return 64;
+  int sh = 0;
+  while (sh < 63 && (cap << sh) < n_out) ++sh;
+  return sh;
 }
 // resample iff ESS = R1^2 / R2 < thr (thr in particles); every backend evaluates exactly these double operations
 GJX_HD bool ess_says_resample(uint64_t r1, uint64_t r2, double thr) {
@@ -1347,7 +1355,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
     chunk_pre = wbase + incl - local;
     // a tile may own more than kCapSlots slots only if its mass exceeds (kCapSlots - 8) / n_out of the total: ONE
     // threshold (every workgroup derives the same one from the same total), tested first on the thread's whole chunk
-    const uint64_t heavy_mass = heavy_threshold(tot, A.heavy_frac);
+    const uint64_t heavy_mass = heavy_threshold(tot, A.heavy_shift);
     const bool owns_b = k0 <= b && b < k0 + c;  // (no division: b / c on 64-bit scalars is a long sequence)
     const bool maybe_heavy = A.allow_help && (local > heavy_mass || (tot == 0 && k0 + c >= A.ntiles));
     if (owns_b || maybe_heavy) {  // (one thread per workgroup in the common case)
@@ -1521,24 +1529,25 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials
       }
       __syncthreads();
       // Takers (idle tiles, then the launch's extra workgroups) take GROUPS of g consecutive delegable chunks of one heavy
-      // tile: g = 1 while there are at least as many takers as chunks, more when the launch has fewer extras than chunks
+      // tile: g = 1 while there are at least as many takers as chunks, 2, 4, ... when the launch has fewer extras than chunks
       // (the extras are a fraction of the tiles: they cost a little in every ordinary step).  hv_cum counts groups.
-      uint32_t grp = 1;
+      // (g is a power of two found by doubling: an integer division here costs ~30 registers while the own tile's
+      // particles are live in registers — 95 instead of 67 VGPRs, a wave less per SIMD for every launch)
+      uint32_t grp = 1, grp_sh = 0;
       if ((uint32_t)tid < n_heavy) {
         uint32_t total = 0;
         for (uint32_t e = 0; e < n_heavy; ++e) total += hv_win[e];
         const uint32_t takers = n_idle > n_heavy ? n_idle - n_heavy : 1u;  // (each heavy tile may round one group up)
-        grp = (total + takers - 1) / takers;
-        grp = grp < 1u ? 1u : grp;
+        while ((uint64_t)grp * takers < (uint64_t)total && grp_sh < 20u) { grp <<= 1; ++grp_sh; }
         uint32_t cum = 0;
-        for (uint32_t e = 0; e < (uint32_t)tid; ++e) cum += (hv_win[e] + grp - 1) / grp;
+        for (uint32_t e = 0; e < (uint32_t)tid; ++e) cum += (hv_win[e] + grp - 1u) >> grp_sh;
         hv_cum[tid] = cum;
       }
       if (tid == 0) { sh_u32[kW + 1] = ~0u; sh_u32[kW + 2] = 0; sh_u32[kW + 3] = 1; }
       __syncthreads();
       // this workgroup's item: thread p speaks for heavy entry p
       if ((uint32_t)tid < n_heavy) {
-        const uint32_t p = (uint32_t)tid, cum = hv_cum[p], win = hv_win[p], groups = (win + grp - 1) / grp;
+        const uint32_t p = (uint32_t)tid, cum = hv_cum[p], win = hv_win[p], groups = (win + grp - 1u) >> grp_sh;
         if (hv_tile[p] == (uint32_t)b) {  // the own tile is heavy: it keeps its first kOwnChunks and what no taker takes
           const uint32_t taken = n_idle > cum ? (n_idle - cum < groups ? n_idle - cum : groups) : 0u;
           sh_u32[kW + 1] = p;

@@ -796,7 +796,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint64_t* tile_sums
     l1 = block_sum(l1, sh_e);
     l2 = block_sum(l2, sh_e + kBlock / kWave);
   }
-  const uint64_t heavy_mass = heavy_threshold(total, (double)(kCapSlots - 8) / (double)n_out);
+  const uint64_t heavy_mass = heavy_threshold(total, heavy_shift_for(n_out));
   for (uint64_t k = lo; k < hi; ++k) {
     const uint64_t v = tile_sums[k];
     prefix[k] = run;
@@ -2106,7 +2106,7 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
   A.q_total_out = out_q ? out_q : qtot;
   A.tile_prefix = nullptr;
   A.allow_help = 1;
-  A.heavy_frac = (double)(kCapSlots - 8) / (double)n_out;
+  A.heavy_shift = heavy_shift_for(n_out);
   // one extra (tile-less) workgroup per chunk of output slots: a heavy tile can always delegate (no maxima to keep here)
   const uint64_t chunks = (n_out + kTile - 1) / kTile;
   A.n_extra = (uint32_t)(chunks < 1024 ? (chunks + 3) / 4 : 256 + (chunks < 32768 ? chunks / 32 : 1024));  // takers take groups of chunks
@@ -2204,7 +2204,7 @@ static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const fl
   A.n = cfg->n_total; A.ntiles = ntiles_of(cfg->n_total); A.n_out = cfg->n_total;
   A.out_lo = (int64_t)cfg->first_slot; A.out_hi = (int64_t)(cfg->first_slot + cfg->n_local);
   A.frac = frac_bits(cfg->n_total);
-  A.heavy_frac = (double)(kCapSlots - 8) / (double)cfg->n_total;
+  A.heavy_shift = heavy_shift_for(cfg->n_total);
   A.lw_vec = ((uintptr_t)prev_logw & 15) == 0;
   A.rkey = Key{cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1]};
   A.rkey_has_fold = 0; A.rkey_fold = 0;
@@ -2406,14 +2406,14 @@ static int run_common_init(const gjx_smc_config* cfg, Carver& cv, RunCommon& rc,
   rc.prefix = scan ? cv.take<uint64_t>(rc.F * prefix_words(rc.nt)) : nullptr;
   rc.tile_ess = cfg_adaptive(cfg) ? cv.take<uint64_t>(2 * rc.F * rc.nt) : nullptr;
   // Takers for a heavy tile's delegated chunks when no tile is idle (gjx_device.hpp ResampleArgs::n_extra): one extra
-  // workgroup per 8 tiles (per 16 in a filter batch).  A taker serves a GROUP of consecutive chunks, so an eighth is
-  // enough to spread a tile that owns everything over ~120 workgroups; in ordinary steps they exit after the mass scan
-  // (measured: +1.3 % on a one-filter step, +1.5 % on 16 filters).  Not with a separate max reduction (> kPrefixTiles tiles).
+  // workgroup per 16 tiles.  A taker serves a GROUP of consecutive chunks, so a sixteenth is enough to spread a tile
+  // that owns everything over ~60 workgroups; in ordinary steps they exit after the mass scan (measured: under 1 % of a
+  // step).  Not with a separate max reduction (> kPrefixTiles tiles).
   static const int extra_div = [] {
     const char* e = std::getenv("GJX_SMC_EXTRA_DIV");  // tuning / test knob: 0 = no extra workgroups
     return e ? atoi(e) : -1;
   }();
-  const uint64_t div = extra_div >= 0 ? (uint64_t)extra_div : (rc.F > 1 ? 16u : 8u);
+  const uint64_t div = extra_div >= 0 ? (uint64_t)extra_div : 16u;
   rc.n_extra = (div == 0 || rc.nt > kPrefixTiles) ? 0u : (uint32_t)((rc.nt + div - 1) / div);
   rc.extra_max = rc.n_extra ? cv.take<float>((size_t)rc.F * rc.n_extra) : nullptr;
   if (!cv.ok) return GJX_ERR_WORKSPACE;
