@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs the round-1 tree next to this one:  git worktree add -f build/r01_tree 6312f20 && (cd build/r01_tree && python __graft_entry__.py)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 export GJX_BENCH_FILTERS=16
 for tree in build/r01_tree .; do
