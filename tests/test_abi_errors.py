@@ -1,0 +1,115 @@
+"""Error behaviour at the C-ABI (include/gjx.h: every entry point returns a status, never crashes on a bad argument):
+invalid arguments are refused with GJX_ERR_INVALID by the oracle build and — validation happens on the host, before
+any launch — by libgjx_hip.so without a GPU."""
+
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from genjax._amd import abi, prng, workloads as W
+from genjax._amd.abi import GjxError, GjxLib
+from genjax._amd.ops import Ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP_LIB = os.path.join(ROOT, "genjax-chi_amd", "lib", "libgjx_hip.so")
+
+
+@pytest.fixture(scope="module", params=["oracle", "hip-nogpu"])
+def lib_ops(request, oracle_ops):
+    if request.param == "oracle":
+        return oracle_ops
+    if not os.path.exists(HIP_LIB):
+        import __graft_entry__ as g
+
+        g.build()
+    return Ops(GjxLib(HIP_LIB, "cuda"))  # host-side validation only: nothing below reaches a launch
+
+
+def _site(dist, a0, a1=None, obs=None, out_col=-1):
+    s = abi.Site()
+    s.dist, s.observed, s.out_col = dist, 0 if obs is None else 1, out_col
+    s.arg[0] = a0
+    if a1 is not None:
+        s.arg[1] = a1
+    if obs is not None:
+        s.obs = obs
+    return s
+
+
+A = abi.Arg
+c = lambda v: A(abi.ARG_CONST, 0, 0.0, v, None)
+
+
+def test_plan_creation_refuses_bad_tables(lib_ops):
+    ops = lib_ops
+    with pytest.raises(GjxError):  # a site that refers to a LATER site
+        ops.plan_create([_site(abi.DIST_NORMAL, A(abi.ARG_SITE, 1, 1.0, 0.0, None), c(1.0)), _site(abi.DIST_NORMAL, c(0.0), c(1.0))])
+    with pytest.raises(GjxError):  # unknown distribution
+        ops.plan_create([_site(17, c(0.0), c(1.0))])
+    with pytest.raises(GjxError):  # parameter index out of range
+        ops.plan_create([_site(abi.DIST_NORMAL, A(abi.ARG_PARAM, abi.MAX_PARAMS, 1.0, 0.0, None), c(1.0))])
+    with pytest.raises(GjxError):  # STATE arguments belong to SMC / scan plans
+        ops.plan_create([_site(abi.DIST_NORMAL, A(abi.ARG_STATE, 0, 1.0, 0.0, None), c(1.0))])
+    plan = ops.plan_create([_site(abi.DIST_NORMAL, A(abi.ARG_PARAM, 2, 1.0, 0.0, None), c(1.0), out_col=0)])
+    with pytest.raises(GjxError):  # fewer values than the highest referenced parameter
+        plan.set_params([0.5, 0.25])
+    plan.set_params([0.5, 0.25, 0.125])
+
+
+def test_scan_plan_creation_refuses_bad_models(lib_ops):
+    ops = lib_ops
+    step = [_site(abi.DIST_NORMAL, A(abi.ARG_STATE, 0, 0.9, 0.0, None), c(1.0), out_col=0)]
+    nxt = [A(abi.ARG_SITE, 0, 1.0, 0.0, None)]
+    ops.scan_plan_create(step, nxt, 0)
+    with pytest.raises(GjxError):  # the carry refers to a state component that does not exist
+        ops.scan_plan_create([_site(abi.DIST_NORMAL, A(abi.ARG_STATE, 1, 1.0, 0.0, None), c(1.0), out_col=0)], nxt, 0)
+    with pytest.raises(GjxError):  # an observation index beyond n_obs
+        ops.scan_plan_create(step + [_site(abi.DIST_NORMAL, A(abi.ARG_SITE, 0, 1.0, 0.0, None), c(0.5), obs=A(abi.ARG_OBS, 2, 1.0, 0.0, None))], nxt, 1)
+    with pytest.raises(GjxError):  # more observation columns than GJX_SMC_MAX_OBS
+        ops.scan_plan_create(step, nxt, abi.SMC_MAX_OBS + 1)
+    with pytest.raises(GjxError):  # a table lookup cannot be a carry component
+        ops.scan_plan_create(step, [A(abi.ARG_TABLE, 0, 0.0, 0.0, 0x1000)], 0)
+
+
+def test_scan_run_refuses_bad_io(oracle_ops):
+    """(run-time validation, on the oracle: the same checks head gjx_scan_run in libgjx_hip.so)"""
+    ops = oracle_ops
+    sites, nxt = W.lgssm_scan_sites()
+    plan = ops.scan_plan_create(sites, nxt, 1)
+    kb = W.importance_particle_keys(prng.key(1, 1), 64)
+    y = np.zeros((3, 1), dtype=np.float32)
+    ops.scan_run(plan, kb, 64, 3, y, [0.0], [torch.float32])
+    with pytest.raises(GjxError):  # T < 1
+        ops.scan_run(plan, kb, 64, 0, np.zeros((0, 1), dtype=np.float32), [0.0], [torch.float32])
+    with pytest.raises(GjxError):  # the latent site's value column is missing
+        ops.scan_run(plan, kb, 64, 3, y, [0.0], [])
+    with pytest.raises(ValueError):  # a folded key batch
+        ops.scan_run(plan, kb.with_fold(1), 64, 3, y, [0.0], [torch.float32])
+    with pytest.raises(ValueError):
+        ops.scan_run(plan, kb, 64, 3, y, [0.0, 1.0], [torch.float32])
+
+
+def test_comm_entry_points_validate(lib_ops):
+    ops = lib_ops
+    g = C.c_void_p()
+    with pytest.raises(GjxError):
+        ops.lib.call("gjx_comm_group_create", 0, C.byref(g))
+    with pytest.raises(GjxError):
+        ops.lib.call("gjx_comm_group_create", 1000, C.byref(g))
+    ops.lib.call("gjx_comm_group_create", 2, C.byref(g))
+    h = C.c_void_p()
+    with pytest.raises(GjxError):
+        ops.lib.call("gjx_comm_init_local", g, 2, C.byref(h))  # rank outside the group
+    ops.lib.call("gjx_comm_init_local", g, 1, C.byref(h))
+    assert ops.lib.call("gjx_comm_rank", h) == 1 and ops.lib.call("gjx_comm_world", h) == 2
+    assert ops.lib.call("gjx_comm_rank", None) == -1
+    with pytest.raises(GjxError):  # no communicator
+        ops.lib.call("gjx_smc_sharded_run_lgssm", None, None, None, None, None, None)
+    ops.lib.call("gjx_comm_destroy", h)
+    ops.lib.call("gjx_comm_group_destroy", g)
+    if ops.lib.device_type == "cpu":  # the oracle has no RCCL side
+        with pytest.raises(GjxError):
+            ops.lib.call("gjx_comm_unique_id", C.c_void_p(0))
