@@ -1,0 +1,190 @@
+"""Randomised HIP-vs-oracle parity (one MI355X):  python tools/fuzz_parity.py [seconds] [seed]
+Random site tables (all distributions, CONST / SITE / INPUT / PARAM / TABLE arguments, observed and latent sites), random
+population sizes (ragged rows included), both generators, lazy and materialised keys — importance plans, scan plans and
+generated SMC filters.  Every output must be equal bit for bit.  Prints the failing case and exits 1 on a mismatch."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "genjax-chi_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from genjax._amd import abi, prng, workloads as W  # noqa: E402
+from genjax._amd.abi import GjxLib  # noqa: E402
+from genjax._amd.ops import KeyBatch, Ops  # noqa: E402
+from genjax._amd.runtime import load_hip_ops  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+hip = load_hip_ops()
+ora = Ops(GjxLib(os.path.join(ROOT, "oracle", "libgjx_oracle.so"), "cpu"))
+A = abi.Arg
+
+
+def const(lo, hi):
+    return A(abi.ARG_CONST, 0, 0.0, float(rng.uniform(lo, hi)), None)
+
+
+def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
+    """mode: 'imp' | 'scan' | 'smc'.  Positive-valued arguments are kept positive by construction."""
+    sites, kinds = [], []  # kinds[q]: 'real' | 'pos' | 'unit' | 'int'
+    out_col = 0
+    for q in range(n_sites):
+        dist = int(rng.choice([abi.DIST_NORMAL, abi.DIST_NORMAL, abi.DIST_GAMMA, abi.DIST_BETA, abi.DIST_BERNOULLI]))
+        s = abi.Site()
+        s.dist = dist
+
+        def loc_arg():
+            opts = ["const"]
+            if any(k in ("real", "pos", "unit") for k in kinds):
+                opts += ["site"] * 2
+            if n_state:
+                opts.append("state")
+            if n_inputs and mode == "imp":
+                opts.append("input")
+            if mode == "imp":
+                opts.append("param")
+            k = rng.choice(opts)
+            sc, off = float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1, 1))
+            if k == "site":
+                ref = int(rng.choice([i for i, kk in enumerate(kinds) if kk in ("real", "pos", "unit")]))
+                return A(abi.ARG_SITE, ref, sc, off, None)
+            if k == "state":
+                return A(abi.ARG_STATE, int(rng.integers(n_state)), sc, off, None)
+            if k == "input":
+                return A(abi.ARG_INPUT, int(rng.integers(n_inputs)), sc, off, None)
+            if k == "param":
+                return A(abi.ARG_PARAM, int(rng.integers(4)), sc, off, None)
+            return const(-2, 2)
+
+        def pos_arg():
+            opts = ["const", "const"]
+            if any(k in ("pos", "unit") for k in kinds):
+                opts.append("site")
+            if mode == "imp":
+                opts.append("param_pos")
+            k = rng.choice(opts)
+            if k == "site":
+                ref = int(rng.choice([i for i, kk in enumerate(kinds) if kk in ("pos", "unit")]))
+                return A(abi.ARG_SITE, ref, float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.2, 1.0)), None)
+            if k == "param_pos":
+                return A(abi.ARG_PARAM, 4 + int(rng.integers(2)), float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.1, 0.5)), None)
+            return const(0.3, 2.5)
+
+        if dist == abi.DIST_NORMAL:
+            s.arg[0], s.arg[1] = loc_arg(), pos_arg()
+            kinds.append("real")
+        elif dist == abi.DIST_GAMMA:
+            s.arg[0], s.arg[1] = pos_arg(), pos_arg()
+            kinds.append("pos")
+        elif dist == abi.DIST_BETA:
+            s.arg[0], s.arg[1] = pos_arg(), pos_arg()
+            kinds.append("unit")
+        else:
+            if any(k == "unit" for k in kinds) and rng.random() < 0.5:
+                ref = int(rng.choice([i for i, kk in enumerate(kinds) if kk == "unit"]))
+                s.arg[0] = A(abi.ARG_SITE, ref, 1.0, 0.0, None)
+            else:
+                s.arg[0] = const(0.1, 0.9)
+            kinds.append("int")
+        observed = rng.random() < 0.35
+        s.observed = int(observed)
+        if observed:
+            val = {"real": rng.uniform(-2, 2), "pos": rng.uniform(0.2, 3), "unit": rng.uniform(0.1, 0.9), "int": float(rng.integers(2))}[kinds[-1]]
+            if mode in ("scan", "smc") and n_obs and rng.random() < 0.7 and kinds[-1] in ("real", "int"):
+                s.obs = A(abi.ARG_OBS, int(rng.integers(n_obs)), 1.0, 0.0, None)
+                if kinds[-1] == "int":
+                    s.obs = A(abi.ARG_OBS, n_obs - 1, 1.0, 0.0, None)  # (the last observation column holds 0/1 values)
+            else:
+                s.obs = A(abi.ARG_CONST, 0, 0.0, float(val), None)
+            s.out_col = -1
+        else:
+            s.out_col = out_col if mode != "smc" else -1
+            out_col += 1 if mode != "smc" else 0
+        sites.append(s)
+    return sites, kinds, out_col
+
+
+def dtypes_for(sites, kinds):
+    out = []
+    for s, k in zip(sites, kinds):
+        if s.out_col >= 0:
+            out.append(torch.int32 if k == "int" else torch.float32)
+    return out
+
+
+def eq(a, b, what, ctx):
+    a, b = (a.cpu() if isinstance(a, torch.Tensor) else a), (b.cpu() if isinstance(b, torch.Tensor) else b)
+    ok = torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b
+    if not ok:
+        # NaN == NaN bitwise
+        if isinstance(a, torch.Tensor) and a.dtype.is_floating_point and torch.equal(a.view(torch.int32), b.view(torch.int32)):
+            return
+        print("MISMATCH", what, ctx)
+        sys.exit(1)
+
+
+t_end, cases = time.time() + budget, 0
+while time.time() < t_end:
+    impl = int(rng.integers(2))
+    n = int(rng.choice([1, 3, 255, 256, 257, 1000, 4099, 20000, 70004]))
+    mode = str(rng.choice(["imp", "imp", "scan", "smc"]))
+    seed = int(rng.integers(1 << 30))
+    ctx = dict(mode=mode, impl=impl, n=n, seed=seed, case=cases)
+    kb = W.importance_particle_keys(prng.key(seed, impl), n)
+    if mode == "imp":
+        n_inputs = int(rng.integers(0, 3))
+        sites, kinds, n_out = random_sites(int(rng.integers(1, 12)), "imp", n_inputs=n_inputs)
+        params = [float(x) for x in rng.uniform(-1, 1, 4)] + [float(x) for x in rng.uniform(0.5, 2.0, 2)]
+        cols = [torch.from_numpy(rng.uniform(-1, 1, n).astype(np.float32)) for _ in range(n_inputs)]
+        outs = []
+        for ops in (hip, ora):
+            plan = ops.plan_create(sites)
+            plan.set_params(params)
+            keys = kb if rng.random() < 0.7 or True else kb
+            vals, score, logw, mp, rows = ops.importance_run(plan, keys, n, [c_.to(ops.device()) for c_ in cols], dtypes_for(sites, kinds),
+                                                             want_rows=True)
+            outs.append(vals + [score, logw, mp, rows.e, rows.s])
+        for i, (a, b) in enumerate(zip(*outs)):
+            eq(a, b, f"importance output {i}", ctx)
+    elif mode == "scan":
+        n_state, n_obs, T = int(rng.integers(1, 3)), 2, int(rng.integers(1, 9))
+        sites, kinds, n_out = random_sites(int(rng.integers(1, 7)), "scan", n_state=n_state, n_obs=n_obs)
+        real = [i for i, k in enumerate(kinds) if k in ("real", "pos", "unit")]
+        nxt = [A(abi.ARG_SITE, int(rng.choice(real)), float(rng.uniform(-1, 1)), float(rng.uniform(-0.5, 0.5)), None) if real and rng.random() < 0.8
+               else A(abi.ARG_STATE, int(rng.integers(n_state)), 0.5, 0.1, None) for _ in range(n_state)]
+        obs = np.stack([rng.uniform(-1, 1, T), rng.integers(0, 2, T)], axis=1).astype(np.float32)
+        carry0 = [float(rng.uniform(-1, 1)) for _ in range(n_state)]
+        outs = []
+        for ops in (hip, ora):
+            plan = ops.scan_plan_create(sites, nxt, n_obs)
+            o = ops.scan_run(plan, kb, n, T, obs, carry0, dtypes_for(sites, kinds))
+            outs.append(o["values"] + o["carry"] + [o["score"], o["logw"], o["max_partials"], o["rows"].e, o["rows"].s])
+        for i, (a, b) in enumerate(zip(*outs)):
+            eq(a, b, f"scan output {i}", ctx)
+    else:
+        if n < 256:
+            continue
+        n_state, n_obs, T = int(rng.integers(1, 3)), 2, int(rng.integers(2, 7))
+        init, ik, _ = random_sites(int(rng.integers(1, 4)), "smc", n_state=0, n_obs=n_obs)
+        step, sk_, _ = random_sites(int(rng.integers(1, 5)), "smc", n_state=n_state, n_obs=n_obs)
+        ireal = [i for i, k in enumerate(ik) if k != "int"]
+        sreal = [i for i, k in enumerate(sk_) if k != "int"]
+        if not ireal or not sreal:
+            continue
+        istate = [A(abi.ARG_SITE, int(rng.choice(ireal)), 1.0, 0.0, None) for _ in range(n_state)]
+        nstate = [A(abi.ARG_SITE, int(rng.choice(sreal)), float(rng.uniform(0.5, 1.0)), 0.0, None) for _ in range(n_state)]
+        obs = np.stack([rng.uniform(-1, 1, T), rng.integers(0, 2, T)], axis=1).astype(np.float32)
+        skeys, rkeys = W.smc_key_schedule(prng.key(seed, impl), T)
+        ess = float(rng.choice([0.0, 0.0, 0.5]))
+        outs = []
+        for ops in (hip, ora):
+            plan = ops.smc_plan_create(init, step, istate, nstate, n_obs)
+            r = ops.smc_run_plan(plan, impl, n, skeys, rkeys, obs, True, ess_threshold=ess, want_flags=True)
+            outs.append([r[0], r[1], *r[2], r[3], r[4]] + ([r[5]] if r[5] is not None else []))
+        for i, (a, b) in enumerate(zip(*outs)):
+            eq(a, b, f"smc output {i}", dict(ctx, ess=ess, T=T))
+    cases += 1
+print(f"fuzz ok: {cases} random cases, HIP == oracle bit for bit")
