@@ -32,9 +32,30 @@ def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
     sites, kinds = [], []  # kinds[q]: 'real' | 'pos' | 'unit' | 'int'
     out_col = 0
     for q in range(n_sites):
-        dist = int(rng.choice([abi.DIST_NORMAL, abi.DIST_NORMAL, abi.DIST_GAMMA, abi.DIST_BETA, abi.DIST_BERNOULLI]))
+        dist = int(rng.choice([abi.DIST_NORMAL, abi.DIST_NORMAL, abi.DIST_GAMMA, abi.DIST_BETA, abi.DIST_BERNOULLI] +
+                              ([abi.DIST_CATEGORICAL] if tables is not None else [])))
         s = abi.Site()
         s.dist = dist
+        if dist == abi.DIST_CATEGORICAL:  # a logits table; the row is constant or chosen by an earlier 0/1 site
+            K = int(rng.choice([3, 17, 64]))
+            ints = [i for i, kk in enumerate(kinds) if kk == "int01"]
+            rows = 2 if ints and rng.random() < 0.6 else 1
+            tab = rng.normal(0, 1.5, (rows, K)).astype(np.float32)
+            tables.append(tab)
+            s.n_cat, s.n_rows, s.cat_mode = K, rows, int(rng.integers(2))
+            s.arg[0] = A(abi.ARG_SITE, int(rng.choice(ints)), 1.0, 0.0, None) if rows == 2 else A(abi.ARG_CONST, 0, 0.0, 0.0, None)
+            s.logits = len(tables) - 1  # (index; replaced by the device pointer of each backend)
+            observed = rng.random() < 0.35
+            s.observed = int(observed)
+            if observed:
+                s.obs = A(abi.ARG_CONST, 0, 0.0, float(rng.integers(K)), None)
+                s.out_col = -1
+            else:
+                s.out_col = out_col if mode != "smc" else -1
+                out_col += 1 if mode != "smc" else 0
+            kinds.append("cat")
+            sites.append(s)
+            continue
 
         def loc_arg():
             opts = ["const"]
@@ -88,14 +109,14 @@ def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
                 s.arg[0] = A(abi.ARG_SITE, ref, 1.0, 0.0, None)
             else:
                 s.arg[0] = const(0.1, 0.9)
-            kinds.append("int")
+            kinds.append("int01")
         observed = rng.random() < 0.35
         s.observed = int(observed)
         if observed:
-            val = {"real": rng.uniform(-2, 2), "pos": rng.uniform(0.2, 3), "unit": rng.uniform(0.1, 0.9), "int": float(rng.integers(2))}[kinds[-1]]
-            if mode in ("scan", "smc") and n_obs and rng.random() < 0.7 and kinds[-1] in ("real", "int"):
+            val = {"real": rng.uniform(-2, 2), "pos": rng.uniform(0.2, 3), "unit": rng.uniform(0.1, 0.9), "int01": float(rng.integers(2))}[kinds[-1]]
+            if mode in ("scan", "smc") and n_obs and rng.random() < 0.7 and kinds[-1] in ("real", "int01"):
                 s.obs = A(abi.ARG_OBS, int(rng.integers(n_obs)), 1.0, 0.0, None)
-                if kinds[-1] == "int":
+                if kinds[-1] == "int01":
                     s.obs = A(abi.ARG_OBS, n_obs - 1, 1.0, 0.0, None)  # (the last observation column holds 0/1 values)
             else:
                 s.obs = A(abi.ARG_CONST, 0, 0.0, float(val), None)
@@ -107,11 +128,26 @@ def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
     return sites, kinds, out_col
 
 
+def bind_tables(ops, sites, tables):
+    """Copies of the site table with every categorical site's logits pointing at this backend's copy of its table."""
+    keep, out = [], []
+    for s_ in sites:
+        t = abi.Site()
+        C_ = __import__("ctypes")
+        C_.memmove(C_.byref(t), C_.byref(s_), C_.sizeof(abi.Site))
+        if s_.dist == abi.DIST_CATEGORICAL:
+            dev = torch.from_numpy(tables[int(s_.logits or 0)]).to(ops.device()).contiguous()
+            keep.append(dev)
+            t.logits = dev.data_ptr()
+        out.append(t)
+    return out, keep
+
+
 def dtypes_for(sites, kinds):
     out = []
     for s, k in zip(sites, kinds):
         if s.out_col >= 0:
-            out.append(torch.int32 if k == "int" else torch.float32)
+            out.append(torch.int32 if k in ("int01", "cat") else torch.float32)
     return out
 
 
@@ -136,12 +172,14 @@ while time.time() < t_end:
     kb = W.importance_particle_keys(prng.key(seed, impl), n)
     if mode == "imp":
         n_inputs = int(rng.integers(0, 3))
-        sites, kinds, n_out = random_sites(int(rng.integers(1, 12)), "imp", n_inputs=n_inputs)
+        tables = []
+        sites, kinds, n_out = random_sites(int(rng.integers(1, 12)), "imp", n_inputs=n_inputs, tables=tables)
         params = [float(x) for x in rng.uniform(-1, 1, 4)] + [float(x) for x in rng.uniform(0.5, 2.0, 2)]
         cols = [torch.from_numpy(rng.uniform(-1, 1, n).astype(np.float32)) for _ in range(n_inputs)]
         outs = []
         for ops in (hip, ora):
-            plan = ops.plan_create(sites)
+            bound, keep = bind_tables(ops, sites, tables)
+            plan = ops.plan_create(bound)
             plan.set_params(params)
             keys = kb if rng.random() < 0.7 or True else kb
             vals, score, logw, mp, rows = ops.importance_run(plan, keys, n, [c_.to(ops.device()) for c_ in cols], dtypes_for(sites, kinds),
@@ -151,7 +189,8 @@ while time.time() < t_end:
             eq(a, b, f"importance output {i}", ctx)
     elif mode == "scan":
         n_state, n_obs, T = int(rng.integers(1, 3)), 2, int(rng.integers(1, 9))
-        sites, kinds, n_out = random_sites(int(rng.integers(1, 7)), "scan", n_state=n_state, n_obs=n_obs)
+        tables = []
+        sites, kinds, n_out = random_sites(int(rng.integers(1, 7)), "scan", n_state=n_state, n_obs=n_obs, tables=tables)
         real = [i for i, k in enumerate(kinds) if k in ("real", "pos", "unit")]
         nxt = [A(abi.ARG_SITE, int(rng.choice(real)), float(rng.uniform(-1, 1)), float(rng.uniform(-0.5, 0.5)), None) if real and rng.random() < 0.8
                else A(abi.ARG_STATE, int(rng.integers(n_state)), 0.5, 0.1, None) for _ in range(n_state)]
@@ -159,7 +198,8 @@ while time.time() < t_end:
         carry0 = [float(rng.uniform(-1, 1)) for _ in range(n_state)]
         outs = []
         for ops in (hip, ora):
-            plan = ops.scan_plan_create(sites, nxt, n_obs)
+            bound, keep = bind_tables(ops, sites, tables)
+            plan = ops.scan_plan_create(bound, nxt, n_obs)
             o = ops.scan_run(plan, kb, n, T, obs, carry0, dtypes_for(sites, kinds))
             outs.append(o["values"] + o["carry"] + [o["score"], o["logw"], o["max_partials"], o["rows"].e, o["rows"].s])
         for i, (a, b) in enumerate(zip(*outs)):
@@ -170,8 +210,8 @@ while time.time() < t_end:
         n_state, n_obs, T = int(rng.integers(1, 3)), 2, int(rng.integers(2, 7))
         init, ik, _ = random_sites(int(rng.integers(1, 4)), "smc", n_state=0, n_obs=n_obs)
         step, sk_, _ = random_sites(int(rng.integers(1, 5)), "smc", n_state=n_state, n_obs=n_obs)
-        ireal = [i for i, k in enumerate(ik) if k != "int"]
-        sreal = [i for i, k in enumerate(sk_) if k != "int"]
+        ireal = [i for i, k in enumerate(ik) if k not in ("int01", "cat")]
+        sreal = [i for i, k in enumerate(sk_) if k not in ("int01", "cat")]
         if not ireal or not sreal:
             continue
         istate = [A(abi.ARG_SITE, int(rng.choice(ireal)), 1.0, 0.0, None) for _ in range(n_state)]
