@@ -398,11 +398,55 @@ def _make_plan(tracer):
     return plan
 
 
+TRACE_CACHE = True  # reuse the traced form of a body when it is called again with the SAME target (see _traced)
+_TRACE_CACHE_MAX = 16
+
+
+def _leaf_key(v):
+    if isinstance(v, torch.Tensor):
+        return ("t", id(v), v._version)  # (an in-place change of a tensor invalidates what was traced from it)
+    if isinstance(v, (bool, int, float, str, type(None))):
+        return ("v", type(v).__name__, v)
+    return ("o", id(v))
+
+
+def _traced(gen_fn, constraint: ChoiceMap, n: int, args):
+    """`_trace` with a small per-thread cache for the repeated-call pattern `alg.log_marginal_likelihood_estimate(key)`
+    in a loop: the SAME generative function, constraint object and argument values.  Only an exact repetition hits (the
+    key holds the identities and versions of every tensor involved and strong references to the objects, so an identity is
+    never recycled while cached); like a jitted function, a body that reads a mutable global sees the value it had when it
+    was first traced — `plan.TRACE_CACHE = False` turns the cache off."""
+    if not TRACE_CACHE:
+        return _trace(gen_fn, constraint, n, args)
+    from collections import OrderedDict
+
+    from .runtime import fast_math_enabled
+
+    cache = getattr(_PLANS, "traces", None)
+    if cache is None:
+        cache = _PLANS.traces = OrderedDict()
+    try:
+        key = (id(gen_fn), id(constraint), n, fast_math_enabled(), id(get_ops()), tuple(_leaf_key(a) for a in args),
+               tuple(_leaf_key(v) for _, v in constraint.leaves()))
+        hash(key)
+    except TypeError:
+        return _trace(gen_fn, constraint, n, args)
+    hit = cache.get(key)
+    if hit is not None:
+        cache.move_to_end(key)
+        return hit[0]
+    traced = _trace(gen_fn, constraint, n, args)
+    cache[key] = (traced, gen_fn, constraint, args)  # (strong references: the identities in the key stay taken)
+    while len(cache) > _TRACE_CACHE_MAX:
+        cache.popitem(last=False)
+    return traced
+
+
 def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
     """-> (trace, weight) through the fused kernel, or None when the body is not plan-able."""
     if pk.kb.fold is not None or any(_needs_eager(a) for a in args):
         return None
-    traced = _trace(gen_fn, constraint, pk.n, args)
+    traced = _traced(gen_fn, constraint, pk.n, args)
     if traced is None:
         return None
     tracer, retval = traced

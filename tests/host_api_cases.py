@@ -455,6 +455,50 @@ def case_params_equal_constants(impl):
 
 
 # ---- ParticleCollection / ChangeTarget / CSMC ---------------------------------------------------------
+def case_trace_cache(impl):
+    """The traced form of a body is reused only for an exact repetition of the call (same function, constraint object and
+    argument values): repeated calls equal uncached ones bit for bit, another constraint / argument or an in-place change
+    of a constraint tensor is traced afresh."""
+    from genjax._amd import plan as P
+
+    @gen
+    def model(a):
+        z = normal(0.0, a) @ "z"
+        _ = normal(z * 0.5, 0.7) @ "y"
+        _ = normal(z, 1.5) @ "w"
+        return z
+
+    n = 2000
+    keys = genjax.random.split(genjax.random.key(17, impl), n)
+    wcol = torch.linspace(-1.0, 1.0, n).to(_dev())
+    chm = C["y"].set(0.3) | C["w"].set(wcol)
+
+    def run(c, a):
+        tr, w = model.importance(keys, c, (a,))
+        return w.clone(), tr.get_choices()["z"].clone()
+
+    P.TRACE_CACHE = False
+    try:
+        ref1, ref2 = run(chm, 2.0), run(chm, 3.0)
+    finally:
+        P.TRACE_CACHE = True
+    for _ in range(3):  # the second and third calls hit the cache
+        got = run(chm, 2.0)
+        assert torch.equal(got[0], ref1[0]) and torch.equal(got[1], ref1[1])
+    got = run(chm, 3.0)  # another argument value
+    assert torch.equal(got[0], ref2[0]) and torch.equal(got[1], ref2[1])
+    chm2 = C["y"].set(-0.4) | C["w"].set(wcol)  # another constraint
+    assert not torch.equal(run(chm2, 2.0)[0], ref1[0])
+    wcol.add_(0.5)  # the SAME objects, a tensor changed in place: must not reuse the column traced before
+    P.TRACE_CACHE = False
+    try:
+        ref3 = run(chm, 2.0)
+    finally:
+        P.TRACE_CACHE = True
+    got = run(chm, 2.0)
+    assert torch.equal(got[0], ref3[0]) and not torch.equal(got[0], ref1[0])
+
+
 def case_particle_collection(impl):
     @gen
     def model():
@@ -1389,6 +1433,6 @@ def case_index_request(impl):
 
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
-             case_static_gen_fn, case_distributions, case_fused_equals_eager, case_params_equal_constants, case_particle_collection, case_custom_proposal,
+             case_static_gen_fn, case_distributions, case_fused_equals_eager, case_params_equal_constants, case_trace_cache, case_particle_collection, case_custom_proposal,
              case_scan, case_scan_edge_cases, case_scan_fused_equals_loop, case_vmap, case_vmap_edge_cases, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
              case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update, case_regenerate_and_rejuvenate, case_vector_valued_sites, case_index_request]
