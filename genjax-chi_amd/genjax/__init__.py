@@ -10,7 +10,7 @@ from ._amd.choicemap import (ChoiceMap, ChoiceMapBuilder as _CMB, ChoiceMapNoVal
                              SelectionBuilder, C as _C)
 from ._amd.lang import (AddressReuse, Distribution, GenerativeFunction, GenerativeFunctionClosure, MissingAddress,
                         StaticGenerativeFunction, Trace, bernoulli, beta, categorical, exact_density, flip, gamma,
-                        gen, normal)
+                        gen, normal, uniform)
 from ._amd.combinators import Scan, Vmap, scan, vmap
 from ._amd.edit import (Diff, EditRequest, EmptyRequest, IndexRequest, NoChange, NotSupportedEditRequest, Regenerate, Rejuvenate, StaticRequest,
                         UnknownChange, Update)
@@ -43,6 +43,6 @@ __all__ = [
     "EditRequest", "EmptyRequest", "IndexRequest", "NoChange", "NotSupportedEditRequest", "Regenerate", "Rejuvenate", "StaticRequest", "UnknownChange", "Update", "GenerativeFunction", "GenerativeFunctionClosure", "Marginal", "Mask", "MissingAddress", "SampleDistribution", "Scan",
     "Selection", "SelectionBuilder", "StaticGenerativeFunction", "Target", "Trace", "bernoulli", "beta",
     "categorical", "exact_density", "fast_math", "flip", "gamma", "gen", "inference", "jaxlike", "marginal", "normal", "random",
-    "scan", "Vmap", "vmap",
+    "scan", "uniform", "Vmap", "vmap",
 ]
 __version__ = "0.1.0"

@@ -1092,7 +1092,32 @@ class Categorical(Distribution):
         return ops.logpdf_categorical(n, v, self._logits(args[0], n))
 
 
+class Uniform(_RealDist):
+    """tfd.Uniform(low, high) — tensorflow_probability/__init__.py (`uniform`): `low + (high − low)·u`, u the 24-bit uniform
+    of the site's one-word draw (the bits every one-word sampler takes); log-density `−log(high − low)` inside `[low, high]`.
+    Not a plan site (no `gjx_dist` entry): it runs as a bits kernel plus element-wise torch ops — enough for what the
+    reference uses it for on this path (Metropolis–Hastings acceptance draws)."""
+    name, abi_name, arg_names = "uniform", "", ("low", "high")
+
+    def _sample(self, pk: ParticleKeys, args):
+        ops = get_ops()
+        bits = ops.rng_bits(pk.kb, pk.n)
+        u = ((bits >> 9) & 0x7FFFFF | 0x3F800000).view(torch.float32) - 1.0
+        lo, hi = (_to_device_col(x, pk.n) for x in args)
+        v = lo + (hi - lo) * u
+        return v, self._logpdf(pk.n, v, args)
+
+    def _logpdf(self, n, v, args):
+        ops = get_ops()
+        lo, hi = (torch.as_tensor(_to_device_col(x, n), dtype=torch.float32, device=ops.device()) for x in args)
+        v = torch.as_tensor(_to_device_col(v, n), dtype=torch.float32, device=ops.device())
+        inside = (v >= lo) & (v <= hi)
+        out = torch.where(inside, -torch.log(hi - lo), torch.full_like(v + lo, float("-inf")))
+        return out if out.dim() else out.reshape(1).expand(n).clone()
+
+
 normal = Normal()
+uniform = Uniform()
 gamma = Gamma()
 beta = Beta()
 flip = Flip()

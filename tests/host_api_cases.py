@@ -335,6 +335,30 @@ def case_distributions(impl):
 
 
 # ---- batched execution: fused kernel == per-site column kernels, bit for bit -------------------------
+def case_uniform(impl):
+    """`genjax.uniform(low, high)` (tensorflow_probability/__init__.py:294): range, moments, log-density, inside a model."""
+    from genjax import uniform
+
+    key = genjax.random.key(1, impl)
+    assert 0.0 <= f(uniform.sample(key, 0.0, 1.0)) < 1.0
+    assert f(uniform.logpdf(0.3, 0.0, 2.0)) == pytest.approx(-math.log(2.0)) and f(uniform.logpdf(3.0, 0.0, 2.0)) == -math.inf
+    keys = genjax.random.split(key, 40000)
+    u = uniform.sample(keys, -1.0, 3.0)
+    assert f(u.min()) >= -1.0 and f(u.max()) < 3.0
+    assert f(u.mean()) == pytest.approx(1.0, abs=0.03) and f(u.var()) == pytest.approx(16.0 / 12.0, abs=0.03)
+
+    @gen
+    def m():
+        a = uniform(0.0, 2.0) @ "a"
+        _ = normal(a, 0.5) @ "y"
+        return a
+
+    tr, w = m.importance(keys, C["y"].set(1.0), ())
+    a = tr.get_choices()["a"]
+    assert torch.allclose(w, normal.logpdf(1.0, a, 0.5), atol=1e-5)
+    assert torch.allclose(tr.get_score(), w - math.log(2.0), atol=1e-5)
+
+
 def case_fused_equals_eager(impl):
     @gen
     def model(a):
@@ -1433,6 +1457,6 @@ def case_index_request(impl):
 
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
-             case_static_gen_fn, case_distributions, case_fused_equals_eager, case_params_equal_constants, case_trace_cache, case_particle_collection, case_custom_proposal,
+             case_static_gen_fn, case_distributions, case_uniform, case_fused_equals_eager, case_params_equal_constants, case_trace_cache, case_particle_collection, case_custom_proposal,
              case_scan, case_scan_edge_cases, case_scan_fused_equals_loop, case_vmap, case_vmap_edge_cases, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
              case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update, case_regenerate_and_rejuvenate, case_vector_valued_sites, case_index_request]
