@@ -1,4 +1,5 @@
-"""Randomised HIP-vs-oracle parity (one MI355X):  python tools/fuzz_parity.py [seconds] [seed]
+"""Randomised HIP-vs-oracle parity (one MI355X):  python tests/fuzz_parity.py [seconds] [seed]
+(test infrastructure: it loads the oracle; `test_random_plans_fuzz` runs it for 25 s)
 Random site tables (all distributions, CONST / SITE / INPUT / PARAM / TABLE arguments, observed and latent sites), random
 population sizes (ragged rows included), both generators, lazy and materialised keys — importance plans, scan plans and
 generated SMC filters.  Every output must be equal bit for bit.  Prints the failing case and exits 1 on a mismatch."""

@@ -852,13 +852,13 @@ def test_importance_fast_math_tolerance(hip_ops, oracle_ops, n, form, monkeypatc
 
 
 def test_random_plans_fuzz(hip_ops):
-    """A short run of tools/fuzz_parity.py (random site tables, sizes, generators; importance, scan and generated-SMC
+    """A short run of tests/fuzz_parity.py (random site tables, sizes, generators; importance, scan and generated-SMC
     plans): every output of the HIP library equals the oracle's bit for bit.  (A child process: the tool owns its backends.)"""
     import subprocess
     import sys
 
     from conftest import ROOT
 
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "25", "7"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "25", "7"], capture_output=True, text=True,
                        timeout=400)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
