@@ -778,7 +778,60 @@ def entry(r, keys=("value", "unit", "ms_per_step", "config", "roofline", "log_z"
     return e
 
 
+_LINE_OUT = None
+
+
+def reserve_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner from C at
+    communicator creation): keep the real stdout for the line and point descriptor 1 at stderr for everything else."""
+    global _LINE_OUT
+    if _LINE_OUT is None:
+        sys.stdout.flush()
+        _LINE_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit_line(obj):
+    out = _LINE_OUT or sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
+class ExtrasDeadline:
+    """At N > 1 the extra workload runs collectives after the headline has been measured.  If it (or the closing barrier)
+    has not come back after `seconds`, rank 0 prints the line it already has, with the extra marked as missing, and every
+    rank leaves with `os._exit(0)` — a rank stuck in a collective cannot be unwound any other way."""
+
+    def __init__(self, rank, out, seconds, name):
+        import threading
+
+        self.rank, self.out, self.seconds, self.name = rank, out, seconds, name
+        self.lock, self.line_done, self.done = threading.Lock(), False, threading.Event()
+        self.t0 = time.perf_counter()
+        threading.Thread(target=self._watch, daemon=True).start()
+
+    def claim_line(self) -> bool:
+        with self.lock:
+            first, self.line_done = not self.line_done, True
+            return first
+
+    def finish(self):
+        self.done.set()
+
+    def _watch(self):
+        if self.done.wait(self.seconds):
+            return
+        if self.rank == 0 and self.claim_line():
+            line = dict(self.out)
+            line["extra"] = {self.name: {"error": f"no result within {self.seconds:g} s; the line carries the headline only"}}
+            emit_line(line)
+        print(f"bench.py: rank {self.rank}: '{self.name}' exceeded its {self.seconds:g} s deadline "
+              f"({time.perf_counter() - self.t0:.1f} s after the headline)", file=sys.stderr, flush=True)
+        os._exit(0)
+
+
 def run_rank(args):
+    reserve_stdout()
     rank, world = init_dist(args.gpus)
     from genjax._amd.runtime import load_hip_ops
 
@@ -787,7 +840,7 @@ def run_rank(args):
     smc_gpu = None
     if args.workload == "scan_lgssm":  # profiling passes of the one-launch scan (an `extra` entry of the default run)
         if rank == 0:
-            print(json.dumps(bench_scan(args, ops, fast_math=args.fast_math, with_host_loop=False)), flush=True)
+            emit_line(bench_scan(args, ops, fast_math=args.fast_math, with_host_loop=False))
         return
     if args.workload == "importance":
         res, _ = bench_importance(args, ops, rank, world, fast_math=args.fast_math)
@@ -796,10 +849,27 @@ def run_rank(args):
     else:
         res, smc_gpu = bench_smc(args, ops, args.workload, filters=int(os.environ.get("GJX_BENCH_FILTERS", "1")))
     extra = {}
+    out = None
+    if rank == 0:
+        out = {
+            "metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": res.pop("config"), "roofline": res.pop("roofline"),
+        }
+        out.update(res)
+        out["log_z_abs_err_vs_exact"] = abs(out["log_z"] - out["log_z_exact"])
+        out["statistic"] = "median over timed_blocks repetitions of the K-step block"
+    guard = None
     if not args.no_extra and args.workload == "importance":
         if sharded:
-            # BASELINE configs[3]: the LGSSM filter with 1e6 particles per GPU, sharded (every rank takes part)
-            extra["smc_lgssm_sharded"] = entry(bench_smc_sharded(args, ops, rank, world, "smc_lgssm"))
+            # BASELINE configs[3]: the LGSSM filter with 1e6 particles per GPU, sharded (every rank takes part).  The
+            # headline above is already measured: a rank that never comes back from the exchange must not cost the line.
+            guard = ExtrasDeadline(rank, out, float(os.environ.get("GJX_BENCH_EXTRA_DEADLINE_S", "240")), "smc_lgssm_sharded")
+            try:
+                extra["smc_lgssm_sharded"] = entry(bench_smc_sharded(args, ops, rank, world, "smc_lgssm"))
+            except Exception as ex:  # reported in the line; the other ranks are released by their own deadline
+                extra["smc_lgssm_sharded"] = {"error": f"{type(ex).__name__}: {ex}"}
         elif rank == 0:
             # the literal single-GPU BASELINE configs, each first-class: roofline, CPU baseline, log Z vs CPU
             for kind in ("smc_lgssm", "smc_hmm"):
@@ -864,15 +934,6 @@ def run_rank(args):
             except Exception as ex:  # reported, never silently dropped
                 extra["importance_fast_math"] = {"error": f"{type(ex).__name__}: {ex}"}
     if rank == 0:
-        out = {
-            "metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "config": res.pop("config"), "roofline": res.pop("roofline"),
-        }
-        out.update(res)
-        out["log_z_abs_err_vs_exact"] = abs(out["log_z"] - out["log_z_exact"])
-        out["statistic"] = "median over timed_blocks repetitions of the K-step block"
         if extra:
             out["extra"] = extra
         if world == 1 and not FORCE_DIST and not args.no_cpu_baseline:
@@ -881,12 +942,15 @@ def run_rank(args):
                 out["jax_cpu_plain"] = jax_cpu_plain(args)
             else:
                 out["cpu_baseline"] = cpu_baseline_smc(args, args.workload, smc_gpu)
-        print(json.dumps(out), flush=True)
+        if guard is None or guard.claim_line():
+            emit_line(out)
     if sharded:
         import torch.distributed as dist
 
         dist.barrier()
         dist.destroy_process_group()
+    if guard is not None:
+        guard.finish()
 
 
 def main():
