@@ -250,11 +250,15 @@ struct CSite {
   CArg a0, a1, obs;
   const float* logits;
   // categorical sites of specialised kernels: per-row tables built once on the device (cat_tables_prepare) — the row's
-  // inclusive fixed-point CDF (inverse-CDF sampling by binary search instead of two passes over the row) and its
-  // log-sum-exp (log-density = row[v] - lse[row]); null = evaluate the row on the fly.  Same integers / same f32 ops:
-  // the same bits.
-  const uint32_t* cat_cdf;
-  const float* cat_lse;
+  // inclusive fixed-point CDF (inverse-CDF sampling by a guided walk instead of two passes over the row) packed with the
+  // normalised log-probabilities (log-density = row[v] - lse(row), the same f32 subtraction done once per entry); null =
+  // evaluate the row on the fly.  Same integers / same f32 ops: the same bits.
+  const uint2* cat_ent;       // [n_rows, n_cat]: {inclusive CDF, bits of row[c] - lse(row)} — the draw's walk ends on the entry
+                              // that also holds the drawn category's log-density
+  const uint32_t* cat_tot;    // [n_rows]: the row's total (its last CDF entry), dense
+  const uint16_t* cat_guide;  // [n_rows, 256]: where the walk of a draw whose top byte is g starts (k_cat_prepare)
+  const float* cat_logp_t;    // observed sites whose value is the same for every particle: [n_cat, n_rows], row[c] - lse(row)
+                              // TRANSPOSED — the launch reads one contiguous n_rows-float column, whatever rows the particles hold
   int32_t pre;       // 1: pre0/pre1 hold the hoisted per-site constants; 2: they depend on launch parameters
                      // (GJX_ARG_PARAM) and are re-derived by gjx_plan_set_params into PlanParams::d[2 site], [2 site + 1]
   float pre0, pre1;  // normal: rs, lognorm; gamma: -, lognorm; beta: -, lbeta
@@ -1498,18 +1502,34 @@ int gjx_logpdf_categorical(const int32_t* value, int value_scalar, const float* 
 
 // ---- plans ---------------------------------------------------------------------------------------
 // ---- per-row tables of categorical sites (specialised kernels) ------------------------------------------------------
-__global__ void k_cat_prepare(const float* logits, uint32_t n_rows, uint32_t K, uint32_t* cdf, float* lse) {
+__global__ void k_cat_prepare(const float* logits, uint32_t n_rows, uint32_t K, uint2* ent, uint32_t* tot, uint16_t* guide,
+                              float* logp_t) {
   // one thread per row, sequential in the category exactly as cat_invcdf / row_lse state it
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rows) return;
   const float* l = logits + (size_t)r * K;
+  const float lse = row_lse(l, K);
+  if (logp_t) {
+    for (uint32_t c = 0; c < K; ++c) logp_t[(size_t)c * n_rows + r] = l[c] - lse;
+    return;
+  }
   const float m = row_max(l, K);
+  uint2* row = ent + (size_t)r * K;
   uint32_t C = 0;
   for (uint32_t c = 0; c < K; ++c) {
     C += cat_fix(l[c], m);
-    cdf[(size_t)r * K + c] = C;
+    row[c] = make_uint2(C, f2u(l[c] - lse));
   }
-  lse[r] = row_lse(l, K);
+  tot[r] = C;
+  // guide[g] = the category drawn by the SMALLEST draw whose top byte is g (bits = g << 24).  The threshold is monotone
+  // in the draw, so every draw of that bucket lands at or after guide[g]: a walk from there finds the same category as a
+  // search of the whole row.
+  uint32_t c = 0;
+  for (uint32_t g = 0; g < 256; ++g) {
+    const uint64_t thr = ((uint64_t)(g << 24) * (uint64_t)C) >> 32;
+    while (c < K - 1 && (uint64_t)row[c].x <= thr) ++c;
+    guide[(size_t)r * 256 + g] = (uint16_t)c;
+  }
 }
 // Build the tables of every categorical site of a table (first compilation of a plan: a GPU is present by then).
 // K <= 511 keeps the inclusive CDF inside 32 bits (cat_fix <= 2^23).  Failure to allocate leaves the on-the-fly path.
@@ -1517,18 +1537,36 @@ static void cat_tables_prepare(CSite* sites, int n, std::vector<void*>* owned) {
   bool any = false;
   for (int q = 0; q < n; ++q) {
     CSite& st = sites[q];
-    if (st.dist != GJX_DIST_CATEGORICAL || st.cat_lse || !st.logits || st.n_cat > 511 || st.n_rows < 1) continue;
-    uint32_t* cdf = nullptr;
-    float* lse = nullptr;
-    if (hipMalloc(&cdf, sizeof(uint32_t) * (size_t)st.n_rows * (size_t)st.n_cat) != hipSuccess) { (void)hipGetLastError(); continue; }
-    if (hipMalloc(&lse, sizeof(float) * (size_t)st.n_rows) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(cdf); continue; }
+    if (st.dist != GJX_DIST_CATEGORICAL || st.cat_ent || st.cat_logp_t || !st.logits || st.n_cat > 511 || st.n_rows < 1) continue;
+    const size_t rows = (size_t)st.n_rows;
+    const unsigned grid = ((unsigned)rows + 63) / 64;
     // (one thread per row: rows are few — a transition / emission matrix — and this runs once per plan)
-    const unsigned rows = (unsigned)st.n_rows;
-    k_cat_prepare<<<(rows + 63) / 64, 64>>>(st.logits, rows, (uint32_t)st.n_cat, cdf, lse);
-    owned->push_back(cdf);
-    owned->push_back(lse);
-    st.cat_cdf = cdf;
-    st.cat_lse = lse;
+    if (st.observed && st.obs.kind != GJX_ARG_INPUT) {  // the value is launch-uniform: the transposed log-probabilities only
+      float* lt = nullptr;
+      if (hipMalloc(&lt, sizeof(float) * rows * (size_t)st.n_cat) != hipSuccess) { (void)hipGetLastError(); continue; }
+      k_cat_prepare<<<grid, 64>>>(st.logits, (uint32_t)rows, (uint32_t)st.n_cat, nullptr, nullptr, nullptr, lt);
+      owned->push_back(lt);
+      st.cat_logp_t = lt;
+      any = true;
+      continue;
+    }
+    uint2* ent = nullptr;
+    uint32_t* tot = nullptr;
+    uint16_t* guide = nullptr;
+    if (hipMalloc(&ent, sizeof(uint2) * rows * (size_t)st.n_cat) != hipSuccess || hipMalloc(&tot, sizeof(uint32_t) * rows) != hipSuccess ||
+        hipMalloc(&guide, sizeof(uint16_t) * 256 * rows) != hipSuccess) {
+      (void)hipGetLastError();
+      if (ent) (void)hipFree(ent);
+      if (tot) (void)hipFree(tot);
+      continue;
+    }
+    k_cat_prepare<<<grid, 64>>>(st.logits, (uint32_t)rows, (uint32_t)st.n_cat, ent, tot, guide, nullptr);
+    owned->push_back(ent);
+    owned->push_back(tot);
+    owned->push_back(guide);
+    st.cat_ent = ent;
+    st.cat_tot = tot;
+    st.cat_guide = guide;
     any = true;
   }
   if (any && hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();

@@ -32,9 +32,9 @@ inline std::string flit(float f) {
   std::snprintf(b, sizeof b, "u2f(0x%08xu)", gjx::f2u(f));
   return b;
 }
-inline std::string plit_u32(const void* p) {
-  char b[64];
-  std::snprintf(b, sizeof b, "((const uint32_t*)0x%llxull)", (unsigned long long)(uintptr_t)p);
+inline std::string plit_as(const char* type, const void* p) {
+  char b[96];
+  std::snprintf(b, sizeof b, "((const %s*)0x%llxull)", type, (unsigned long long)(uintptr_t)p);
   return b;
 }
 inline std::string plit(const void* p) {
@@ -177,9 +177,13 @@ struct SiteEmitter {
           if (st.cat_mode == 0) {
             o << ind << "const Stream<" << I << "> strm" << Q << "(" << K << ", true, " << fold << "u);\n";
             o << ind << "const int32_t vi" << Q << " = jcat_gumbel<" << I << ">(" << row << ", " << st.n_cat << "u, strm" << Q << ");\n";
-          } else if (st.cat_cdf) {  // the row's prepared inclusive CDF: binary search (same integers as the two-pass walk)
-            o << ind << "const int32_t vi" << Q << " = jcat_invcdf_tab(" << plit_u32(st.cat_cdf) << " + (size_t)rr" << Q << " * " << st.n_cat
-              << ", " << st.n_cat << "u, bits" << Q << ");\n";
+          } else if (st.cat_ent) {  // the row's prepared {CDF, log-probability} entries, entered at the guide of the draw's
+                                    // top byte (same integers as the two-pass walk: the same category); the entry the walk
+                                    // ends on carries the log-density
+            o << ind << "uint32_t lpb" << Q << ";\n";
+            o << ind << "const int32_t vi" << Q << " = jcat_invcdf_ent(" << plit_as("uint2", st.cat_ent) << " + (size_t)rr" << Q << " * " << st.n_cat
+              << ", " << plit_as("uint16_t", st.cat_guide) << " + (size_t)rr" << Q << " * 256, " << plit_as("uint32_t", st.cat_tot) << "[rr" << Q
+              << "], " << st.n_cat << "u, bits" << Q << ", lpb" << Q << ");\n";
           } else {
             o << ind << "const int32_t vi" << Q << " = jcat_invcdf(" << row << ", " << st.n_cat << "u, bits" << Q << ");\n";
           }
@@ -205,8 +209,13 @@ struct SiteEmitter {
         break;
       case GJX_DIST_BERNOULLI: lp = "logpdf_bernoulli(" + v + " != 0, a0_" + Q + ")"; break;
       default:
-        lp = "((" + v + " < 0 || " + v + " >= " + std::to_string(st.n_cat) + ") ? -__builtin_inff() : " + row + "[" + v + "] - " +
-             (st.cat_lse ? plit(st.cat_lse) + "[rr" + Q + "]" : "jrow_lse(" + row + ", " + std::to_string(st.n_cat) + "u)") + ")";
+        if (st.cat_ent && !st.observed && st.cat_mode != 0)
+          lp = "u2f(lpb" + Q + ")";  // a drawn category is in range
+        else
+          lp = "((" + v + " < 0 || " + v + " >= " + std::to_string(st.n_cat) + ") ? -__builtin_inff() : " +
+               (st.cat_logp_t ? plit(st.cat_logp_t) + "[(size_t)" + v + " * " + std::to_string(st.n_rows) + " + rr" + Q + "]"
+                : st.cat_ent ? "u2f(" + plit_as("uint2", st.cat_ent) + "[(size_t)rr" + Q + " * " + std::to_string(st.n_cat) + " + " + v + "].y)"
+                             : row + "[" + v + "] - jrow_lse(" + row + ", " + std::to_string(st.n_cat) + "u)") + ")";
     }
     o << ind << "{ const float lp = " << lp << "; sc" << sfx << " = sc" << sfx << " + lp;"
       << (st.observed ? " w" + sfx + " = w" + sfx + " + lp;" : "") << " }\n";
@@ -229,7 +238,7 @@ inline void emit_prelude(std::ostringstream& o, bool fast_math = false) {
   o << "__device__ __forceinline__ float jrow_max(const float* l, uint32_t K){ float m=l[0]; for(uint32_t c=1;c<K;++c) m = l[c]>m?l[c]:m; return m; }\n";
   o << "__device__ __forceinline__ float jrow_lse(const float* l, uint32_t K){ const float m=jrow_max(l,K); float acc=0.0f; for(uint32_t c=0;c<K;++c) acc = acc + m_exp(l[c]-m); return m + m_log(acc); }\n";
   o << "__device__ __forceinline__ int32_t jcat_invcdf(const float* l, uint32_t K, uint32_t bits){ const float m=jrow_max(l,K); uint64_t Q=0; for(uint32_t c=0;c<K;++c) Q += cat_fix(l[c],m); const uint64_t thr=((uint64_t)bits*Q)>>32; uint64_t C=0; for(uint32_t c=0;c<K;++c){ C += cat_fix(l[c],m); if (C>thr) return (int32_t)c; } return (int32_t)(K-1); }\n";
-  o << "__device__ __forceinline__ int32_t jcat_invcdf_tab(const uint32_t* cdf, uint32_t K, uint32_t bits){ const uint64_t thr=((uint64_t)bits*(uint64_t)cdf[K-1])>>32; uint32_t lo=0, hi=K-1; while (lo<hi){ const uint32_t mid=(lo+hi)>>1; if ((uint64_t)cdf[mid]>thr) hi=mid; else lo=mid+1; } return (int32_t)lo; }\n";
+  o << "__device__ __forceinline__ int32_t jcat_invcdf_ent(const uint2* ent, const uint16_t* guide, uint32_t tot, uint32_t K, uint32_t bits, uint32_t& lpb){ const uint64_t thr=((uint64_t)bits*(uint64_t)tot)>>32; uint32_t c=guide[bits>>24]; uint2 e=ent[c]; while (c<K-1 && (uint64_t)e.x<=thr){ ++c; e=ent[c]; } lpb=e.y; return (int32_t)c; }\n";
   o << "template <int IMPL> __device__ __forceinline__ int32_t jcat_gumbel(const float* l, uint32_t K, const Stream<IMPL>& st){ int32_t best=0; float bv=-__builtin_inff(); for(uint32_t c=0;c<K;++c){ const float v = l[c] + gumbel_from_bits(st.bits32(c)); if (v>bv || c==0){ bv=v; best=(int32_t)c; } } return best; }\n";
 }
 
