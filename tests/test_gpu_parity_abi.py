@@ -364,6 +364,57 @@ def test_resample_and_gather(hip_ops, oracle_ops, impl, n, n_out):
         same(o, c[a.long()], "gather")
 
 
+def pathological_weights(n):
+    g = torch.Generator().manual_seed(n)
+    lw = torch.randn(n, generator=g) * 2
+    cases = {}
+    cases["all -inf"] = torch.full((n,), float("-inf"))
+    a = lw.clone(); a[::7] = float("nan"); cases["some nan"] = a
+    cases["all nan"] = torch.full((n,), float("nan"))
+    a = lw.clone(); a[n // 3] = float("inf"); cases["one +inf"] = a
+    a = lw.clone(); a[n // 3] = float("inf"); a[n - 2] = float("inf"); a[9] = float("nan"); cases["two +inf and a nan"] = a
+    cases["all -3e38"] = torch.full((n,), -3e38)
+    return cases
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n", [5000, 300000])
+def test_pathological_weights(hip_ops, oracle_ops, impl, n):
+    """Weights no filter should produce but a caller can pass: all -inf (uniform), NaNs (weight 0), +inf (all the mass),
+    all NaN (zero total: every slot takes the last particle).  Defined by the spec's comparisons (fixw, teeth_below), the
+    same on both sides, indices always in range."""
+    for name, lw in pathological_weights(n).items():
+        key = KeyBatch(impl, 2, parent=(5, n))
+        for kind in ("systematic", "multinomial"):
+            ha, hm, hq = hip_ops.resample(kind, key, dev(lw, hip_ops), n)
+            oa, om, oq = oracle_ops.resample(kind, key, lw, n)
+            same(ha, oa, f"{name}: {kind} ancestors"); same(hq, oq, f"{name}: q")
+            assert torch.equal(hm.cpu().isnan(), om.isnan()) and torch.equal(hm.cpu().nan_to_num(), om.nan_to_num()), name
+            assert 0 <= int(oa.min()) and int(oa.max()) < n
+        for mode in (0, 1):
+            same(hip_ops.categorical_index(key, dev(lw, hip_ops), mode), oracle_ops.categorical_index(key, lw, mode), name)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), 1e30])
+def test_smc_with_an_impossible_observation(hip_ops, oracle_ops, impl, bad):
+    """One observation is NaN / inf / absurd: that step's weights are all NaN or -inf.  The filter goes on (zero total:
+    every slot takes the last particle; all -inf: uniform) and HIP equals the oracle at every step."""
+    n, T = 70000, 5
+    y = np.array([0.1, bad, 0.3, 0.2, -0.4], dtype=np.float32)
+    sk, rk = W.smc_key_schedule(prng.key(11, impl), T)
+    mdl = abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.5)
+    h = hip_ops.smc_run_lgssm(impl, n, sk, rk, mdl, y, True)
+    o = oracle_ops.smc_run_lgssm(impl, n, sk, rk, mdl, y, True)
+    for a, b, what in zip(h, o, ("step max", "step q", "state", "logw", "ancestors")):
+        a, b = a.cpu(), b.cpu()
+        if a.is_floating_point():
+            assert torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(), b.nan_to_num()), what
+        else:
+            same(a, b, what)
+    assert 0 <= int(o[4].min()) and int(o[4].max()) < n
+
+
 @pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("n", [1, 100, 5000, 100000])
