@@ -650,6 +650,7 @@ GJX_HD uint64_t rowfix(float lw, int32_t e) {
   const float fe = (float)e;
   float d = __builtin_fmaf(-fe, 0.693359375f, lw);
   d = __builtin_fmaf(-fe, -2.12194440e-4f, d);
+  d = d > 1.0f ? 1.0f : d;  // only a weight beyond the clamped anchor (+inf, > 1.1e7): keeps the conversion defined
   return (uint64_t)__builtin_rintf(d_exp(d) * 1073741824.0f);
 }
 
@@ -724,7 +725,9 @@ GJX_DEV uint64_t wave_last_u64(uint64_t v) {
 }
 // Wave-wide reductions; result valid in every lane.
 GJX_DEV float wave_max(float v) {
-  // float max through the u32 scan: bit patterns are combined with a float compare (exact, order-free)
+  // float max through the u32 scan: bit patterns are combined with a float compare (exact; order-free once a NaN — which
+  // every sequential `x > m ? x : m` maximum of the specification skips — has been replaced by the identity)
+  v = v == v ? v : -__builtin_inff();
   const uint32_t r = wave_scan_u32(f2u(v), f2u(-__builtin_inff()),
                                    [](uint32_t a, uint32_t b) { return u2f(b) > u2f(a) ? b : a; });
   return u2f(wave_last_u32(r));

@@ -456,6 +456,7 @@ static inline uint64_t o_rowfix(float lw, int32_t e) {
   float fe = (float)e;
   float d = fmaf(-fe, 0.693359375f, lw);
   d = fmaf(-fe, -2.12194440e-4f, d);
+  if (d > 1.0f) d = 1.0f; /* only a weight beyond the clamped anchor (+inf, > 1.1e7): keeps the conversion defined */
   return (uint64_t)rintf(o_exp(d) * 1073741824.0f);
 }
 

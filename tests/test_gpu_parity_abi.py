@@ -393,6 +393,11 @@ def test_pathological_weights(hip_ops, oracle_ops, impl, n):
             assert 0 <= int(oa.min()) and int(oa.max()) < n
         for mode in (0, 1):
             same(hip_ops.categorical_index(key, dev(lw, hip_ops), mode), oracle_ops.categorical_index(key, lw, mode), name)
+        # the log-normalisers: max-anchored (logsumexp) and row-anchored (row_stats + lse_rows)
+        for a, b in zip(hip_ops.logsumexp(dev(lw, hip_ops)), oracle_ops.logsumexp(lw)):
+            same(a, b, f"{name}: logsumexp")
+        for a, b in zip(hip_ops.lse_rows(hip_ops.row_stats(dev(lw, hip_ops))), oracle_ops.lse_rows(oracle_ops.row_stats(lw))):
+            same(a, b, f"{name}: lse_rows")
 
 
 @pytest.mark.parametrize("impl", IMPLS)
