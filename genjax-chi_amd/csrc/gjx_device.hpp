@@ -312,7 +312,10 @@ GJX_DEV void store_key(uint32_t* out, uint64_t i, Key k) {
 GJX_HD float m_log(float x) {
   uint32_t ix = f2u(x);
   int32_t e = 0;
-  if (ix == 0u) return -__builtin_inff();
+  if (ix - 1u >= 0x7f7fffffu) {  // +-0, +inf, NaN, every negative: log's own values (one compare on the common path)
+    if ((ix << 1) == 0u) return -__builtin_inff();
+    return ix == 0x7f800000u ? x : u2f(0x7fc00000u);
+  }
   if (ix < 0x00800000u) {
     x = x * 8388608.0f;
     ix = f2u(x);

@@ -201,7 +201,10 @@ static inline uint32_t o_smc_slot_bits(int impl, const uint32_t step_key[4], uin
 static inline float o_log(float x) {
   uint32_t ix = o_f2u(x);
   int32_t e = 0;
-  if (ix == 0u) return -INFINITY;
+  if (ix - 1u >= 0x7f7fffffu) { /* +-0, +inf, NaN, every negative: log's own values */
+    if ((ix << 1) == 0u) return -INFINITY;
+    return ix == 0x7f800000u ? x : o_u2f(0x7fc00000u);
+  }
   if (ix < 0x00800000u) { x = x * 8388608.0f; ix = o_f2u(x); e = -23; }
   uint32_t t = ix - 0x3f3504f3u;
   e += (int32_t)t >> 23;

@@ -400,6 +400,110 @@ def test_pathological_weights(hip_ops, oracle_ops, impl, n):
             same(a, b, f"{name}: lse_rows")
 
 
+def same_or_both_nan(a, b, what=""):
+    """Bit-equal where a number comes out; where the arithmetic gives NaN, a NaN on both sides (its sign / payload is
+    the platform's)."""
+    a, b = a.cpu(), b.cpu()
+    if a.dtype.is_floating_point:
+        assert torch.equal(a.isnan(), b.isnan()), f"{what}: NaN in different places ({int(a.isnan().sum())} vs {int(b.isnan().sum())})"
+        same(a.nan_to_num(nan=0.0), b.nan_to_num(nan=0.0), what)
+    else:
+        same(a, b, what)
+
+
+BAD_ARGS = [float("nan"), float("inf"), float("-inf"), 0.0, -1.0, 1e-45, 3e38]
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("dist", ["normal", "gamma", "beta", "bernoulli"])
+def test_sites_with_invalid_parameters(hip_ops, oracle_ops, impl, dist):
+    """Parameters outside a distribution's domain (zero / negative / infinite / NaN scale, rate, concentration,
+    probability): the reference's TFP arithmetic returns NaN or inf there and raises nothing; here too the result is
+    whatever the spec's f32 operations give — the same on both sides, samplers bounded (64 rejection rounds)."""
+    n = 3000
+    key = KeyBatch(impl, 2, parent=(8, 1))
+    for a in BAD_ARGS + [1.5]:
+        for b in ([None] if dist == "bernoulli" else BAD_ARGS + [0.7]):
+            hv, hs = hip_ops.sample_logpdf(dist, key, n, a, b)
+            ov, os_ = oracle_ops.sample_logpdf(dist, key, n, a, b)
+            same_or_both_nan(hv, ov, f"{dist}({a}, {b}) value")
+            same_or_both_nan(hs, os_, f"{dist}({a}, {b}) score")
+            if dist != "bernoulli":
+                for v in (0.3, -2.0, float("nan"), float("inf"), 0.0, 1.0):
+                    same_or_both_nan(hip_ops.logpdf(dist, n, v, a, b), oracle_ops.logpdf(dist, n, v, a, b), f"{dist}.logpdf({v}; {a}, {b})")
+            else:
+                for v in (0, 1):
+                    same_or_both_nan(hip_ops.logpdf(dist, n, v, a), oracle_ops.logpdf(dist, n, v, a), f"bernoulli.logpdf({v}; {a})")
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_importance_plan_with_invalid_parameters(hip_ops, oracle_ops, impl, plan_mode):
+    """The specialised importance kernels on a model whose parameters / observations are invalid here and there: a NaN
+    observation, a zero and a negative scale, an infinite mean, a gamma with a negative concentration feeding a scale.
+    Values, scores, weights and the row-anchored log-normaliser records equal the oracle's (NaN where it has NaN)."""
+    n = 20000
+    kb = W.importance_particle_keys(prng.key(5, impl), n)
+    for variant in range(6):
+        sites = W.gaussian10_sites(W.gaussian10_data())[:8]
+        if variant == 0:
+            sites[1].obs = abi.Arg(abi.ARG_CONST, 0, 0.0, float("nan"), None)
+        elif variant == 1:
+            sites[3].arg[1] = abi.Arg(abi.ARG_CONST, 0, 0.0, 0.0, None)       # observation scale 0
+        elif variant == 2:
+            sites[2].arg[1] = abi.Arg(abi.ARG_CONST, 0, 0.0, -1.0, None)      # a latent's scale negative
+        elif variant == 3:
+            sites[4].arg[0] = abi.Arg(abi.ARG_CONST, 0, 0.0, float("inf"), None)
+        elif variant == 4:
+            g = abi.Site()
+            g.dist, g.observed, g.out_col = abi.DIST_GAMMA, 0, 4
+            g.arg[0] = abi.Arg(abi.ARG_CONST, 0, 0.0, -2.0, None)
+            g.arg[1] = abi.Arg(abi.ARG_CONST, 0, 0.0, 1.0, None)
+            sites.append(g)
+            o = abi.Site()
+            o.dist, o.observed, o.out_col = abi.DIST_NORMAL, 1, -1
+            o.arg[0] = abi.Arg(abi.ARG_CONST, 0, 0.0, 0.0, None)
+            o.arg[1] = abi.Arg(abi.ARG_SITE, 8, 1.0, 0.0, None)
+            o.obs = abi.Arg(abi.ARG_CONST, 0, 0.0, 0.3, None)
+            sites.append(o)
+        else:
+            sites[5].obs = abi.Arg(abi.ARG_CONST, 0, 0.0, 3e38, None)          # log-weights near -inf
+        nlat = sum(1 for st in sites if not st.observed)
+        out = []
+        for ops in (hip_ops, oracle_ops):
+            plan = ops.plan_create(sites)
+            vals, score, logw, mp = ops.importance_run(plan, kb, n, [], [torch.float32] * nlat)
+            rows = ops.row_stats(logw)
+            out.append((vals, score, logw, mp, rows.e, rows.s, ops.lse_rows(rows), ops.logsumexp(logw)))
+        h, o = out
+        for a, b in zip(h[0], o[0]):
+            same_or_both_nan(a, b, f"variant {variant}: values")
+        for k, what in ((1, "score"), (2, "logw"), (3, "max partials"), (4, "row anchors"), (5, "row sums")):
+            same_or_both_nan(h[k], o[k], f"variant {variant}: {what}")
+        for a, b in zip(h[6] + h[7], o[6] + o[7]):
+            same_or_both_nan(a, b, f"variant {variant}: log-normaliser")
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_categorical_with_invalid_logits(hip_ops, oracle_ops, impl, mode):
+    n, K = 2000, 7
+    key = KeyBatch(impl, 2, parent=(8, 2))
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(1, K, generator=g)
+    rows = {"all -inf": torch.full((1, K), float("-inf")), "all nan": torch.full((1, K), float("nan")),
+            "one nan": base.clone().index_fill_(1, torch.tensor([2]), float("nan")),
+            "one +inf": base.clone().index_fill_(1, torch.tensor([4]), float("inf")),
+            "huge": base * 1e38}
+    for name, logits in rows.items():
+        hv, hs = hip_ops.sample_logpdf_categorical(key, n, dev(logits, hip_ops), mode=mode)
+        ov, os_ = oracle_ops.sample_logpdf_categorical(key, n, logits, mode=mode)
+        same(hv, ov, f"{name}: value")
+        same_or_both_nan(hs, os_, f"{name}: score")
+        assert 0 <= int(ov.min()) and int(ov.max()) < K
+        for v in (0, 4, -1, K):
+            same_or_both_nan(hip_ops.logpdf_categorical(n, v, dev(logits, hip_ops)), oracle_ops.logpdf_categorical(n, v, logits), f"{name}: logpdf({v})")
+
+
 @pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("bad", [float("nan"), float("inf"), 1e30])
 def test_smc_with_an_impossible_observation(hip_ops, oracle_ops, impl, bad):
