@@ -505,6 +505,33 @@ def test_categorical_with_invalid_logits(hip_ops, oracle_ops, impl, mode):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
+def test_hmm_with_invalid_tables(hip_ops, oracle_ops, impl):
+    """HMM tables with forbidden transitions (-inf), an unreachable-and-unleavable state (a row of -inf), NaN entries and
+    an observation no state can emit: the prepared alias / log-probability tables and the whole filter equal the oracle's."""
+    K, n, T = 12, 30000, 6
+    g = torch.Generator().manual_seed(4)
+    base_t, base_o = torch.randn(K, K, generator=g), torch.randn(K, K, generator=g)
+    variants = []
+    t = base_t.clone(); t[:, ::3] = float("-inf"); variants.append(("forbidden transitions", t, base_o))
+    t = base_t.clone(); t[5, :] = float("-inf"); variants.append(("a row of -inf", t, base_o))
+    t = base_t.clone(); t[2, 7] = float("nan"); t[4, :] = float("nan"); variants.append(("NaN transitions", t, base_o))
+    o = base_o.clone(); o[:, 3] = float("-inf"); variants.append(("an observation no state emits", base_t, o))
+    o = base_o.clone(); o[1, :] = float("nan"); o[:, 8] = float("inf"); variants.append(("NaN / +inf emissions", base_t, o))
+    y = np.array([3, 1, 8, 3, 0, 11], dtype=np.int32)
+    sk, rk = W.smc_key_schedule(prng.key(13, impl), T)
+    for name, tl, ol in variants:
+        for init in (0, 5):
+            ha, hl = hip_ops.hmm_prepare(K, init, dev(tl, hip_ops), dev(ol, hip_ops))
+            oa, ol_ = oracle_ops.hmm_prepare(K, init, tl, ol)
+            same(ha, oa, f"{name}: alias table"); same_or_both_nan(hl, ol_, f"{name}: emission log-probabilities")
+            h = hip_ops.smc_run_hmm(impl, n, sk, rk, K, init, dev(tl, hip_ops), dev(ol, hip_ops), y, True)
+            o_ = oracle_ops.smc_run_hmm(impl, n, sk, rk, K, init, tl, ol, y, True)
+            for a, b, what in zip(h, o_, ("step max", "step q", "state", "logw", "ancestors")):
+                same_or_both_nan(a, b, f"{name} (init {init}): {what}")
+            assert 0 <= int(o_[2].min()) and int(o_[2].max()) < K and 0 <= int(o_[4].min()) and int(o_[4].max()) < n
+
+
+@pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("bad", [float("nan"), float("inf"), 1e30])
 def test_smc_with_an_impossible_observation(hip_ops, oracle_ops, impl, bad):
     """One observation is NaN / inf / absurd: that step's weights are all NaN or -inf.  The filter goes on (zero total:
