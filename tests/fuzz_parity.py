@@ -1,5 +1,7 @@
-"""Randomised HIP-vs-oracle parity (one MI355X):  python tests/fuzz_parity.py [seconds] [seed]
-(test infrastructure: it loads the oracle; `test_random_plans_fuzz` runs it for 25 s)
+"""Randomised HIP-vs-oracle parity (one MI355X):  python tests/fuzz_parity.py [seconds] [seed] [p_invalid]
+(test infrastructure: it loads the oracle; `test_random_plans_fuzz` runs it for 25 s, and again with p_invalid = 0.12:
+constants, observations, launch parameters and carries are then replaced, with that probability each, by NaN / +-inf / 0 /
+negative / denormal / huge values — DESIGN 3.11; where the arithmetic gives NaN, a NaN is required on both sides)
 Random site tables (all distributions, CONST / SITE / INPUT / PARAM / TABLE arguments, observed and latent sites), random
 population sizes (ragged rows included), both generators, lazy and materialised keys — importance plans, scan plans and
 generated SMC filters.  Every output must be equal bit for bit.  Prints the failing case and exits 1 on a mismatch."""
@@ -19,13 +21,19 @@ from genjax._amd.runtime import load_hip_ops  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+P_BAD = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+BAD = [float("nan"), float("inf"), float("-inf"), 0.0, -1.0, 1e-45, 3e38, -3e38]
+
+
+def maybe_bad(x):
+    return float(rng.choice(BAD)) if P_BAD and rng.random() < P_BAD else x
 hip = load_hip_ops()
 ora = Ops(GjxLib(os.path.join(ROOT, "oracle", "libgjx_oracle.so"), "cpu"))
 A = abi.Arg
 
 
 def const(lo, hi):
-    return A(abi.ARG_CONST, 0, 0.0, float(rng.uniform(lo, hi)), None)
+    return A(abi.ARG_CONST, 0, 0.0, maybe_bad(float(rng.uniform(lo, hi))), None)
 
 
 def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
@@ -120,7 +128,7 @@ def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
                 if kinds[-1] == "int01":
                     s.obs = A(abi.ARG_OBS, n_obs - 1, 1.0, 0.0, None)  # (the last observation column holds 0/1 values)
             else:
-                s.obs = A(abi.ARG_CONST, 0, 0.0, float(val), None)
+                s.obs = A(abi.ARG_CONST, 0, 0.0, maybe_bad(float(val)) if kinds[-1] != "int01" else float(val), None)
             s.out_col = -1
         else:
             s.out_col = out_col if mode != "smc" else -1
@@ -159,7 +167,15 @@ def eq(a, b, what, ctx):
         # NaN == NaN bitwise
         if isinstance(a, torch.Tensor) and a.dtype.is_floating_point and torch.equal(a.view(torch.int32), b.view(torch.int32)):
             return
+        # invalid-value runs: a NaN on both sides, whatever its sign / payload
+        if P_BAD and isinstance(a, torch.Tensor) and a.dtype.is_floating_point and torch.equal(a.isnan(), b.isnan()) and \
+                torch.equal(a.nan_to_num(nan=0.0).view(torch.int32), b.nan_to_num(nan=0.0).view(torch.int32)):
+            return
         print("MISMATCH", what, ctx)
+        if isinstance(a, torch.Tensor):
+            d = (a != b) & ~(a.isnan() & b.isnan()) if a.dtype.is_floating_point else a != b
+            idx = d.flatten().nonzero().flatten()[:6]
+            print(f"  {int(d.sum())} of {a.numel()} differ; first at {idx.tolist()}: {a.flatten()[idx].tolist()} vs {b.flatten()[idx].tolist()}")
         sys.exit(1)
 
 
@@ -175,7 +191,7 @@ while time.time() < t_end:
         n_inputs = int(rng.integers(0, 3))
         tables = []
         sites, kinds, n_out = random_sites(int(rng.integers(1, 12)), "imp", n_inputs=n_inputs, tables=tables)
-        params = [float(x) for x in rng.uniform(-1, 1, 4)] + [float(x) for x in rng.uniform(0.5, 2.0, 2)]
+        params = [maybe_bad(float(x)) for x in rng.uniform(-1, 1, 4)] + [maybe_bad(float(x)) for x in rng.uniform(0.5, 2.0, 2)]
         cols = [torch.from_numpy(rng.uniform(-1, 1, n).astype(np.float32)) for _ in range(n_inputs)]
         outs = []
         for ops in (hip, ora):
@@ -195,8 +211,8 @@ while time.time() < t_end:
         real = [i for i, k in enumerate(kinds) if k in ("real", "pos", "unit")]
         nxt = [A(abi.ARG_SITE, int(rng.choice(real)), float(rng.uniform(-1, 1)), float(rng.uniform(-0.5, 0.5)), None) if real and rng.random() < 0.8
                else A(abi.ARG_STATE, int(rng.integers(n_state)), 0.5, 0.1, None) for _ in range(n_state)]
-        obs = np.stack([rng.uniform(-1, 1, T), rng.integers(0, 2, T)], axis=1).astype(np.float32)
-        carry0 = [float(rng.uniform(-1, 1)) for _ in range(n_state)]
+        obs = np.stack([[maybe_bad(float(x)) for x in rng.uniform(-1, 1, T)], rng.integers(0, 2, T)], axis=1).astype(np.float32)
+        carry0 = [maybe_bad(float(rng.uniform(-1, 1))) for _ in range(n_state)]
         outs = []
         for ops in (hip, ora):
             bound, keep = bind_tables(ops, sites, tables)
@@ -217,7 +233,7 @@ while time.time() < t_end:
             continue
         istate = [A(abi.ARG_SITE, int(rng.choice(ireal)), 1.0, 0.0, None) for _ in range(n_state)]
         nstate = [A(abi.ARG_SITE, int(rng.choice(sreal)), float(rng.uniform(0.5, 1.0)), 0.0, None) for _ in range(n_state)]
-        obs = np.stack([rng.uniform(-1, 1, T), rng.integers(0, 2, T)], axis=1).astype(np.float32)
+        obs = np.stack([[maybe_bad(float(x)) for x in rng.uniform(-1, 1, T)], rng.integers(0, 2, T)], axis=1).astype(np.float32)
         skeys, rkeys = W.smc_key_schedule(prng.key(seed, impl), T)
         ess = float(rng.choice([0.0, 0.0, 0.5]))
         outs = []
@@ -228,4 +244,4 @@ while time.time() < t_end:
         for i, (a, b) in enumerate(zip(*outs)):
             eq(a, b, f"smc output {i}", dict(ctx, ess=ess, T=T))
     cases += 1
-print(f"fuzz ok: {cases} random cases, HIP == oracle bit for bit")
+print(f"fuzz ok: {cases} random cases (p_invalid {P_BAD}), HIP == oracle bit for bit")

@@ -1038,14 +1038,17 @@ def test_importance_fast_math_tolerance(hip_ops, oracle_ops, n, form, monkeypatc
         same(W.gaussian10_importance(hip_ops, 1, seed=5, n=n)["logw"], o["logw"], "exact plan next to a fast one")
 
 
-def test_random_plans_fuzz(hip_ops):
+@pytest.mark.parametrize("seconds,seed,p_invalid", [("25", "7", "0"), ("15", "3", "0.2")])
+def test_random_plans_fuzz(hip_ops, seconds, seed, p_invalid):
     """A short run of tests/fuzz_parity.py (random site tables, sizes, generators; importance, scan and generated-SMC
-    plans): every output of the HIP library equals the oracle's bit for bit.  (A child process: the tool owns its backends.)"""
+    plans): every output of the HIP library equals the oracle's bit for bit — also when a fifth of the constants,
+    observations, parameters and carries are NaN / infinite / out of the domain.  (A child process: the tool
+    owns its backends.)"""
     import subprocess
     import sys
 
     from conftest import ROOT
 
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "25", "7"], capture_output=True, text=True,
-                       timeout=400)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), seconds, seed, p_invalid], capture_output=True,
+                       text=True, timeout=400)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
