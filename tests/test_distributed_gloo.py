@@ -301,6 +301,39 @@ def check_degenerate_sharded(ops, impl, world):
     assert int(ref[4][3].unique().numel()) == 1  # total collapse at that step
 
 
+def check_impossible_observation_sharded(ops, impl, world, native):
+    """One observation is NaN (that step's weights are all NaN: zero total mass, every slot takes the LAST particle of
+    the last rank) and one is +inf (all -inf: uniform): the sharded filter goes on like the single-rank one, bit for bit."""
+    import numpy as np
+
+    from genjax._amd import abi, prng, workloads as W
+
+    T, n_total = 6, 1024 * world * 3
+    y = np.array([0.1, float("nan"), 0.3, float("inf"), -0.2, 0.4], dtype=np.float32)
+    mdl = abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.5)
+    res = _run_virtual_ranks(ops, "lgssm", impl, world, n_total, T, "ranges", seed=11, native=native, lgssm=mdl, y=y)
+    sk, rk = W.smc_key_schedule(prng.key(11, impl), T)
+    ref = ops.smc_run_lgssm(impl, n_total, sk, rk, mdl, y, True)
+
+    def eq(a, b):
+        a, b = a.cpu(), b.cpu()
+        if a.dtype.is_floating_point:
+            return torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(), b.nan_to_num())
+        return torch.equal(a, b)
+
+    assert eq(torch.cat([r["state"] for r in res]), ref[2])
+    assert eq(torch.cat([r["ancestors"] for r in res], dim=1), ref[4])
+    assert int(ref[4][2].unique().numel()) == 1 and int(ref[4][2][0]) == n_total - 1
+    for r in res:
+        assert eq(r["out_q"], ref[1]) and eq(r["out_max"], ref[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("native", [False, True])
+def test_sharded_filter_with_an_impossible_observation(oracle_ops, world, native):
+    check_impossible_observation_sharded(oracle_ops, 1, world, native)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_filter_with_collapsing_weights(oracle_ops, world):
     check_degenerate_sharded(oracle_ops, 1, world)

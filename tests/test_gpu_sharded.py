@@ -50,6 +50,13 @@ def test_virtual_ranks_with_collapsing_weights(hip_ops, world):
     check_degenerate_sharded(hip_ops, 1, world)
 
 
+@pytest.mark.parametrize("native", [False, True])
+def test_virtual_ranks_with_an_impossible_observation(hip_ops, native):
+    from test_distributed_gloo import check_impossible_observation_sharded
+
+    check_impossible_observation_sharded(hip_ops, 1, 3, native)
+
+
 @pytest.mark.parametrize("impl", [0, 1])
 def test_virtual_ranks_generated_filter(hip_ops, impl):
     from test_distributed_gloo import check_sharded_plan
