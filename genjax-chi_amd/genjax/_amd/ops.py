@@ -42,6 +42,9 @@ class Ops:
         self.device_type = lib.device_type
         self.tile = int(lib.call("gjx_smc_tile"))
         self._ws: dict = {}
+        # allocations name the device TYPE: torch resolves "the current device" itself (a Python-level
+        # torch.cuda.current_device() per allocation was a tenth of an eager call's host time)
+        self._alloc_device = torch.device(self.device_type)
 
     # ---- plumbing ---------------------------------------------------------------------------
     def device(self) -> torch.device:
@@ -66,7 +69,16 @@ class Ops:
         return C.c_void_p(t.data_ptr())
 
     def empty(self, n, dtype):
-        return torch.empty(n, dtype=dtype, device=self.device())
+        return torch.empty(n, dtype=dtype, device=self._alloc_device)
+
+    def empty_columns(self, n: int, dtypes: list) -> list[torch.Tensor]:
+        """len(dtypes) columns of n 4-byte elements carved from ONE allocation (rows of a [k, n] block)."""
+        if not dtypes:
+            return []
+        if any(dt not in (torch.float32, torch.int32) for dt in dtypes):
+            return [self.empty(n, dt) for dt in dtypes]
+        cols = torch.empty((len(dtypes), n), dtype=torch.float32, device=self._alloc_device).unbind(0)
+        return [c if dt == torch.float32 else c.view(torch.int32) for c, dt in zip(cols, dtypes)]
 
     def workspace(self, op: int, n: int) -> tuple[torch.Tensor, int]:
         nbytes = int(self.lib.call("gjx_workspace_bytes", op, n))
@@ -222,12 +234,15 @@ class Ops:
         ins = (C.c_void_p * max(1, len(input_cols)))()
         for i, t in enumerate(input_cols):
             ins[i] = self._chk(t, torch.float32, n, f"input_cols[{i}]").value
-        vals = [self.empty(n, dt) for dt in value_dtypes]
+        # value columns, score and log-weights: rows of one block (n a multiple of 4 keeps every row 16-byte aligned,
+        # which the four-particles-per-lane kernel form asks for)
+        block = self.empty_columns(n, list(value_dtypes) + [torch.float32] * (2 if want_score else 1))
+        vals = block[:len(value_dtypes)]
         outs = (C.c_void_p * max(1, len(vals)))()
         for i, t in enumerate(vals):
             outs[i] = t.data_ptr()
-        score = self.empty(n, torch.float32) if want_score else None
-        logw = self.empty(n, torch.float32)
+        score = block[-2] if want_score else None
+        logw = block[-1]
         mp = self.empty(self.num_max_partials(n), torch.float32) if want_max_partials else None
         rows, lse = None, None
         if want_rows:

@@ -38,17 +38,25 @@ def _rotl(x, r):
     return ((x << r) | (x >> (32 - r))) & M32
 
 
-def threefry2x32(k0, k1, c0, c1):
+def _threefry_source() -> str:
+    """The 20 rounds written out (no loop, no call): the host derives a handful of keys per inference call."""
     rot = ((13, 15, 26, 6), (17, 29, 16, 24))
-    ks = (k0, k1, 0x1BD11BDA ^ k0 ^ k1)
-    x0, x1 = (c0 + ks[0]) & M32, (c1 + ks[1]) & M32
+    lines = ["def threefry2x32(k0, k1, c0, c1):", "    k2 = 0x1BD11BDA ^ k0 ^ k1", "    x0 = (c0 + k0) & 0xFFFFFFFF",
+             "    x1 = (c1 + k1) & 0xFFFFFFFF"]
+    ks = ("k0", "k1", "k2")
     for blk in range(5):
         for r in rot[blk & 1]:
-            x0 = (x0 + x1) & M32
-            x1 = _rotl(x1, r) ^ x0
-        x0 = (x0 + ks[(blk + 1) % 3]) & M32
-        x1 = (x1 + ks[(blk + 2) % 3] + blk + 1) & M32
-    return x0, x1
+            lines.append("    x0 = (x0 + x1) & 0xFFFFFFFF")
+            lines.append(f"    x1 = (((x1 << {r}) | (x1 >> {32 - r})) & 0xFFFFFFFF) ^ x0")
+        lines.append(f"    x0 = (x0 + {ks[(blk + 1) % 3]}) & 0xFFFFFFFF")
+        lines.append(f"    x1 = (x1 + {ks[(blk + 2) % 3]} + {blk + 1}) & 0xFFFFFFFF")
+    lines.append("    return x0, x1")
+    return "\n".join(lines)
+
+
+_ns: dict = {}
+exec(_threefry_source(), _ns)  # noqa: S102 - generated from the constants above
+threefry2x32 = _ns["threefry2x32"]
 
 
 def philox4x32(k0, k1, c0, c1, c2, c3):

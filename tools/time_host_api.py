@@ -37,6 +37,7 @@ for rep in range(40):
     z = alg.log_marginal_likelihood_estimate(genjax.random.key(100 + rep))
     float(z)
     ts.append(time.perf_counter() - t0)
+print("per call (us):", " ".join(f"{t * 1e6:.0f}" for t in ts))
 print(f"ImportanceK.log_marginal_likelihood_estimate (1e6 particles, 20 sites): median {statistics.median(ts) * 1e6:.0f} us per call, min {min(ts) * 1e6:.0f} us")
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
