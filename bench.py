@@ -567,6 +567,45 @@ def bench_scan_hmm(args, ops, min_s=0.08, T=500):
 # ------------------------------------------------------------------------------------------------------------
 # CPU baselines (the oracle: a port) — bounded samples of the same workloads, timed on this box's host cores
 # ------------------------------------------------------------------------------------------------------------
+def bench_host_api_call(args, calls=60):
+    """`ImportanceK(Target(model, (), obs), k_particles=N).log_marginal_likelihood_estimate(key)` through the host API that
+    mirrors the reference's (genjax.inference.smc), a fresh key per call, the scalar brought back to the host: what one
+    literal call of BASELINE configs[1] costs end to end."""
+    import torch
+
+    import genjax
+    from genjax import ChoiceMapBuilder as C, Target, gen, normal
+    from genjax._amd import workloads as W
+    from genjax.inference.smc import ImportanceK
+
+    y = W.gaussian10_data()
+
+    @gen
+    def model():
+        for i in range(10):
+            z = normal(0.0, 1.0) @ f"z{i}"
+            _ = normal(z, 0.5) @ f"y{i}"
+
+    chm = C.n()
+    for i in range(10):
+        chm = chm | C[f"y{i}"].set(float(y[i]))
+    alg = ImportanceK(Target(model, (), chm), k_particles=args.particles)
+    for rep in range(10):
+        float(alg.log_marginal_likelihood_estimate(genjax.random.key(rep, args.rng)))
+    torch.cuda.synchronize()
+    ts, zs = [], []
+    for rep in range(calls):
+        t0 = time.perf_counter()
+        z = float(alg.log_marginal_likelihood_estimate(genjax.random.key(1000 + rep, args.rng)))
+        ts.append(time.perf_counter() - t0)
+        zs.append(z)
+    med = statistics.median(ts)
+    return {"value": args.particles / med, "unit": "particles/s", "us_per_call": med * 1e6, "us_per_call_min": min(ts) * 1e6,
+            "calls": calls, "rng": args.rng, "log_z_mean": statistics.fmean(zs), "log_z_exact": W.gaussian10_exact_log_z(y),
+            "note": "host-inclusive latency of ONE eager call (one pass per launch, ~19 us of kernel): Python tracing-cache "
+                    "lookup, key derivation, output allocation, launch, fold, device-to-host scalar"}
+
+
 def host_cores() -> int:
     """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands
     one GPU's share of a 256-thread host to the job; 256 OpenMP threads on a 16-core share run 5x slower than 16)."""
@@ -919,6 +958,11 @@ def run_rank(args):
                 extra["importance_scan_hmm"] = bench_scan_hmm(args, ops)
             except Exception as ex:
                 extra["importance_scan_hmm"] = {"error": f"{type(ex).__name__}: {ex}"}
+            # the reference-API call a user makes (tracing cache hit, plan lookup, one launch, fold, one scalar back)
+            try:
+                extra["importance_host_api_call"] = bench_host_api_call(args)
+            except Exception as ex:
+                extra["importance_host_api_call"] = {"error": f"{type(ex).__name__}: {ex}"}
             # ImportanceK variants: one pass per launch (the literal config), the other generator, fast math
             r, _ = bench_importance(args, ops, rank, world, launch_passes=1, steps=64, warmup=16, ramp=False, min_s=0.03)
             extra["importance_1_pass_per_launch"] = entry(r)
