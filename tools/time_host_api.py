@@ -29,12 +29,12 @@ for i in range(10):
     chm = chm | C[f"y{i}"].set(float(y[i]))
 alg = ImportanceK(Target(model, (), chm), k_particles=1_000_000)
 for rep in range(3):
-    alg.log_marginal_likelihood_estimate(genjax.random.key(rep))
+    alg.log_marginal_likelihood_estimate(genjax.random.key(rep, "philox"))
 torch.cuda.synchronize()
 ts = []
 for rep in range(40):
     t0 = time.perf_counter()
-    z = alg.log_marginal_likelihood_estimate(genjax.random.key(100 + rep))
+    z = alg.log_marginal_likelihood_estimate(genjax.random.key(100 + rep, "philox"))
     float(z)
     ts.append(time.perf_counter() - t0)
 print("per call (us):", " ".join(f"{t * 1e6:.0f}" for t in ts))
