@@ -144,7 +144,7 @@ int sharded_run(Transport& T, const gjx_smc_config* cfg, int n_state, size_t sta
   const uint64_t tile = gjx_smc_tile(), N = cfg->n_total, nl = cfg->n_local, lo = cfg->first_slot;
   if (!io || !io->tile_sums || !io->max_partials || !io->out_max || !io->out_q || !io->logw[0] || !io->logw[1] ||
       cfg->n_filters > 1 || N % ((uint64_t)world * tile) != 0 || nl != N / (uint64_t)world || lo != (uint64_t)rank * nl ||
-      (io->shuffle == 0 && world > 1 && !io->ranges) || world > 64)
+      (io->shuffle == 0 && world > 1 && !io->ranges) || world > 64 || state_elem != 4 /* every state column is 4-byte */)
     return GJX_ERR_INVALID;
   const uint64_t nt = gjx_num_tiles(N), tiles_local = nl / tile;
   const bool adaptive = cfg->ess_threshold > 0.0f && cfg->ess_threshold < 1.0f;
@@ -165,7 +165,6 @@ int sharded_run(Transport& T, const gjx_smc_config* cfg, int n_state, size_t sta
     void* cols[GJX_SMC_MAX_STATE + 1];
     for (int k = 0; k < n_state; ++k) cols[k] = io->state[cur][k];
     cols[n_state] = io->logw[cur];
-    if (state_elem != sizeof(float)) return GJX_ERR_INVALID;  // (all state columns are 4-byte)
     if (io->shuffle == 1) {
       for (int c = 0; c <= n_state && rc == GJX_OK; ++c) rc = T.allgather(cols[c], (size_t)nl * 4, s);
       received += N - nl;
