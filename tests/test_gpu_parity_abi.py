@@ -1038,6 +1038,27 @@ def test_importance_fast_math_tolerance(hip_ops, oracle_ops, n, form, monkeypatc
         same(W.gaussian10_importance(hip_ops, 1, seed=5, n=n)["logw"], o["logw"], "exact plan next to a fast one")
 
 
+def test_population_near_the_index_limit(hip_ops, oracle_ops):
+    """2 000 000 001 particles (ancestors are int32: the cap is 2^31 - 1): two steps of the LGSSM filter — byte offsets
+    beyond 2^32, 1.95 million tiles, the precomputed tile prefix — equal the oracle bit for bit.  32 GB on the device and
+    as much on the host; skipped where that does not fit."""
+    import psutil
+
+    n, T = 2_000_000_001, 2
+    free, _ = torch.cuda.mem_get_info()
+    if free < 48 * 2**30 or psutil.virtual_memory().available < 96 * 2**30:
+        pytest.skip("needs 48 GiB of device memory and 96 GiB of host memory")
+    h = W.lgssm_smc(hip_ops, 1, seed=3, n=n, T=T)
+    got = {k: h[k].cpu() for k in ("out_max", "out_q", "state", "logw")}
+    log_z = h["log_z"]
+    del h
+    torch.cuda.empty_cache()
+    o = W.lgssm_smc(oracle_ops, 1, seed=3, n=n, T=T)
+    for k, v in got.items():
+        assert torch.equal(v, o[k]), k
+    assert log_z == o["log_z"] and abs(log_z - o["log_z_exact"]) < 1e-3
+
+
 @pytest.mark.parametrize("seconds,seed,p_invalid", [("25", "7", "0"), ("15", "3", "0.2")])
 def test_random_plans_fuzz(hip_ops, seconds, seed, p_invalid):
     """A short run of tests/fuzz_parity.py (random site tables, sizes, generators; importance, scan and generated-SMC
