@@ -1059,6 +1059,31 @@ def test_population_near_the_index_limit(hip_ops, oracle_ops):
     assert log_z == o["log_z"] and abs(log_z - o["log_z_exact"]) < 1e-3
 
 
+def test_importance_beyond_4g_bytes_per_column(hip_ops, oracle_ops):
+    """1 200 000 004 particles of a two-site model: every output column is 4.8 GB, so the specialised kernel's 16-byte
+    stores land beyond byte offset 2^32.  Values, scores, weights and the row records equal the oracle's."""
+    import psutil
+
+    n = 1_200_000_004
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2**30 or psutil.virtual_memory().available < 96 * 2**30:
+        pytest.skip("needs 40 GiB of device memory and 96 GiB of host memory")
+    sites = W.gaussian10_sites(W.gaussian10_data())[:2]
+    kb = W.importance_particle_keys(prng.key(9, 1), n)
+
+    def run(ops):
+        plan = ops.plan_create(sites)
+        vals, score, logw, mp, rows = ops.importance_run(plan, kb, n, [], [torch.float32], want_rows=True)
+        lse = ops.lse_rows(rows)
+        return [vals[0].cpu(), score.cpu(), logw.cpu(), mp.cpu(), rows.e.cpu(), rows.s.cpu()] + [x.cpu() for x in lse]
+
+    got = run(hip_ops)
+    torch.cuda.empty_cache()
+    want = run(oracle_ops)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), f"output {i}"
+
+
 @pytest.mark.parametrize("seconds,seed,p_invalid", [("25", "7", "0"), ("15", "3", "0.2")])
 def test_random_plans_fuzz(hip_ops, seconds, seed, p_invalid):
     """A short run of tests/fuzz_parity.py (random site tables, sizes, generators; importance, scan and generated-SMC
