@@ -81,13 +81,11 @@ class Ops:
         return [c if dt == torch.float32 else c.view(torch.int32) for c, dt in zip(cols, dtypes)]
 
     def workspace(self, op: int, n: int) -> tuple[torch.Tensor, int]:
+        """Scratch for one call, from torch's caching allocator: a block is handed out again only to work ordered after
+        this call on the same stream, so calls on different streams / threads never share scratch (a cache of our own,
+        keyed by operation, let two concurrent filters of different streams write the same tile sums)."""
         nbytes = int(self.lib.call("gjx_workspace_bytes", op, n))
-        key = (op, str(self.device()))
-        ws = self._ws.get(key)
-        if ws is None or ws.numel() < nbytes:
-            ws = torch.empty(max(nbytes, 1024), dtype=torch.uint8, device=self.device())
-            self._ws[key] = ws
-        return ws, nbytes
+        return torch.empty(max(nbytes, 1024), dtype=torch.uint8, device=self._alloc_device), nbytes
 
     def _keys(self, kb: KeyBatch, n: int) -> Keys:
         k = Keys()
@@ -419,10 +417,7 @@ class Ops:
                     self.workspace(abi.OP_SMC, n))
         stride = cfg.filter_stride
         ws_one = int(self.lib.call("gjx_workspace_bytes", abi.OP_SMC, n))
-        key = ("smc_filters", str(self.device()))
-        ws = self._ws.get(key)
-        if ws is None or ws.numel() < F * ws_one:
-            ws = self._ws[key] = torch.empty(F * ws_one, dtype=torch.uint8, device=self.device())
+        ws = torch.empty(F * ws_one, dtype=torch.uint8, device=self._alloc_device)  # (per call: see workspace())
         return (self.empty((F, T), torch.float32), self.empty((F, T), torch.int64), self.empty((F, stride), state_dtype),
                 self.empty((F, stride), torch.float32),
                 self.empty((T, F, stride), torch.int32) if want_ancestors else None, (ws, F * ws_one))
@@ -758,8 +753,7 @@ class PreparedImportance:
             ops.lib.call("gjx_plan_prepare", plan.handle, C.byref(k))  # build the specialised kernel now
         self._ins = (C.c_void_p * max(1, len(self.inputs)))(*[ops._chk(t, torch.float32, n).value for t in self.inputs])
         self._outs = (C.c_void_p * max(1, len(self.values_all)))(*[t.data_ptr() for t in self.values_all])
-        self._ws, self._nb = ops.workspace(abi.OP_LOGSUMEXP, n)
-        self._ws = self._ws.clone()  # private: the shared workspace may be re-grown by other calls
+        self._ws, self._nb = ops.workspace(abi.OP_LOGSUMEXP, n)  # this object's own (persistent) scratch
         lib = ops.lib
         self._run, self._run_batch, self._lse, self._lse_rows, self._fold = (
             lib._gjx_importance_run, lib._gjx_importance_run_batch, lib._gjx_logsumexp_f32, lib._gjx_lse_rows,
