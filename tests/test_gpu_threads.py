@@ -17,6 +17,7 @@ import sys, threading
 sys.path.insert(0, sys.argv[1])
 import torch
 from genjax._amd import abi, prng, workloads as W
+from genjax._amd.ops import KeyBatch
 from genjax._amd.runtime import load_hip_ops
 
 ops = load_hip_ops()
@@ -34,8 +35,18 @@ def job(k):
         out.append((torch.stack(vals).clone(), score.clone(), logw.clone()))
     smc = W.lgssm_smc(ops, 1, seed=k, n=20_000 + 1000 * k, T=12, want_ancestors=True)
     hmm = W.hmm_smc(ops, 1, seed=k, n=10_000, T=6, n_states=32)
+    # the generic weight operations: the SAME sizes in every thread (whatever scratch they use must not be shared)
+    g = torch.Generator().manual_seed(k)
+    lw = (torch.randn(300_000, generator=g) * 3).cuda()
+    gen = []
+    for rep in range(4):
+        key = KeyBatch(1, 2, parent=(k, rep))
+        a, m, q = ops.resample("systematic", key, lw, 300_000)
+        a2, _, _ = ops.resample("multinomial", key, lw, 50_000)
+        gen.append((a.clone(), m.clone(), q.clone(), a2.clone(), ops.categorical_index(key, lw, 1).clone(),
+                    *[x.clone() for x in ops.logsumexp(lw)]))
     torch.cuda.current_stream().synchronize()
-    return out, smc, hmm
+    return out, smc, hmm, gen
 
 results, errors = {}, []
 def work(k):
@@ -51,8 +62,11 @@ threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
 assert not errors, errors
 torch.cuda.synchronize()
 for k in range(4):
-    out, smc, hmm = job(k)           # one thread, default stream
-    tout, tsmc, thmm = results[k]
+    out, smc, hmm, gen = job(k)      # one thread, default stream
+    tout, tsmc, thmm, tgen = results[k]
+    for a, b in zip(gen, tgen):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), (k, "generic weight operations")
     for (a, b, c), (ta, tb, tc) in zip(out, tout):
         assert torch.equal(a, ta) and torch.equal(b, tb) and torch.equal(c, tc), k
     for name in ("out_max", "out_q", "state", "logw", "ancestors"):
