@@ -331,7 +331,9 @@ def bench_smc_sharded(args, ops, rank, world, kind):
     n = -(-args.particles // ops.tile) * ops.tile  # the sharded filter exchanges whole 1024-particle tiles
     n_total = n * world
     exchange = os.environ.get("GJX_BENCH_SHUFFLE", "ranges")
-    smc = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world, exchange=exchange)
+    # (a forced one-rank group still issues every collective: the RCCL calls of the N > 1 path run on a one-GPU box)
+    smc = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world, exchange=exchange,
+                           comm=gdist.TorchComm(rank, world, always=FORCE_DIST))
     # GJX_BENCH_NATIVE_COMM=1: the library's own RCCL communicator and C driver (gjx_smc_sharded_run_*) instead of the
     # torch.distributed loop.  Opt-in: it is covered by virtual-rank tests and a one-rank RCCL test only (no multi-GPU box here).
     native = os.environ.get("GJX_BENCH_NATIVE_COMM") == "1"

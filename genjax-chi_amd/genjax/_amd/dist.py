@@ -165,16 +165,17 @@ def needed_tile_ranges(tile_sums, n_total: int, tile: int, world: int):
 class TorchComm:
     """The exchanges of a sharded filter over `torch.distributed` (RCCL on the GPU box, gloo in the CPU tests)."""
 
-    def __init__(self, rank: int, world: int):
-        self.rank, self.world = rank, world
+    def __init__(self, rank: int, world: int, always: bool = False):
+        """`always`: issue the collectives even in a one-rank group (rehearsal of the N > 1 calls on a one-GPU box)."""
+        self.rank, self.world, self.always = rank, world, always
 
     def all_reduce_max(self, t: torch.Tensor):
         dist = _dist()
-        if self.world > 1:
+        if self.world > 1 or self.always:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
 
     def all_gather(self, full: torch.Tensor, lo: int, hi: int):
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         local = full[lo:hi]
         if full.device.type != "cuda":
