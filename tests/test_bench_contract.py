@@ -64,3 +64,18 @@ print("alive", file=sys.stderr)
 """)
     assert rc == 0 and "alive" in err
     assert [json.loads(l) for l in out.splitlines()] == [{"value": 3.0, "extra": {"x": 1}}]
+
+
+def test_gpus_n_without_n_gpus_fails_loudly():
+    """`python bench.py --gpus 2` on a box with fewer than 2 GPUs: exit status 2 and a message, never a line that says
+    n_gpus 1 (the parent process counts devices without initialising the GPU runtime and starts nothing)."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        import pytest
+
+        pytest.skip("this box has the GPUs: the command would run")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 2 and p.stdout.strip() == "" and "refusing" in p.stderr
