@@ -1576,6 +1576,12 @@ static void free_owned(std::vector<void*>& owned) {
   owned.clear();
 }
 
+// A plan's own copy of the programs of one site table (the caller's arrays need not outlive plan creation; only the
+// host-side code generator reads them: plans with programs run as specialised kernels only).
+struct ExprStore {
+  gjx_expr_op ops[GJX_MAX_SITES][2][GJX_MAX_EXPR_OPS];
+};
+
 struct gjx_plan {
   int n_sites;
   int n_slots;
@@ -1591,11 +1597,39 @@ struct gjx_plan {
   gjx_jit::Compiled jit[4];
   std::vector<void*> dev_owned;  // per-row tables of categorical sites (specialised kernels)
   std::mutex jit_mu;
+  ExprStore expr;      // GJX_ARG_EXPR programs (host; read by the code generator)
+  bool has_expr;       // ... any?  Then the plan runs as a specialised kernel only
+  int expr_max_input;  // highest input column a program reads (-1: none)
 };
+
+// GJX_ARG_EXPR (gjx.h): a postfix program as a distribution argument.  Well-formed: at most GJX_MAX_EXPR_OPS entries,
+// operands in range for the plan kind, the stack never deeper than 8, exactly one value left.
+static bool expr_ok(const gjx_arg& a, int s, int n_state, int n_obs, bool allow_state) {
+  const gjx_expr_op* ops = reinterpret_cast<const gjx_expr_op*>(a.table);
+  if (!ops || a.ref < 1 || a.ref > GJX_MAX_EXPR_OPS) return false;
+  int depth = 0;
+  for (int k = 0; k < a.ref; ++k) {
+    const int r = ops[k].ref;
+    switch (ops[k].op) {
+      case GJX_EXPR_CONST: ++depth; break;
+      case GJX_EXPR_SITE: if (r < 0 || r >= s) return false; ++depth; break;
+      case GJX_EXPR_INPUT: if (n_state >= 0 || r < 0 || r >= 16) return false; ++depth; break;
+      case GJX_EXPR_PARAM: if (n_state >= 0 || r < 0 || r >= GJX_MAX_PARAMS) return false; ++depth; break;
+      case GJX_EXPR_STATE: if (n_state < 0 || !allow_state || r < 0 || r >= n_state) return false; ++depth; break;
+      case GJX_EXPR_OBS: if (n_state < 0 || r < 0 || r >= n_obs) return false; ++depth; break;
+      case GJX_EXPR_ADD: case GJX_EXPR_SUB: case GJX_EXPR_MUL: if (depth < 2) return false; --depth; break;
+      case GJX_EXPR_NEG: if (depth < 1) return false; break;
+      default: return false;
+    }
+    if (depth > 8) return false;
+  }
+  return depth == 1;
+}
 
 // Argument validity.  n_state / n_obs > -1 switch on the SMC-plan kinds (STATE only if allow_state).
 static bool arg_ok(const gjx_arg& a, int s, int n_state = -1, int n_obs = -1, bool allow_state = false) {
   switch (a.kind) {
+    case GJX_ARG_EXPR: return expr_ok(a, s, n_state, n_obs, allow_state);
     case GJX_ARG_CONST: return true;
     case GJX_ARG_SITE: return a.ref >= 0 && a.ref < s;
     case GJX_ARG_INPUT: return n_state < 0 && a.ref >= 0 && a.ref < 16;
@@ -1620,7 +1654,7 @@ static bool convert_site(const gjx_site& st, int s, CSite& c, int n_state = -1, 
     else ok = st.obs.kind == GJX_ARG_CONST || (st.obs.kind == GJX_ARG_OBS && st.obs.ref >= 0 && st.obs.ref < n_obs);
   }
   if (ok && st.dist == GJX_DIST_CATEGORICAL)
-    ok = st.logits && st.n_cat > 0 && st.n_rows > 0 && (st.cat_mode == 0 || st.cat_mode == 1);
+    ok = st.logits && st.n_cat > 0 && st.n_rows > 0 && (st.cat_mode == 0 || st.cat_mode == 1) && st.arg[0].kind != GJX_ARG_EXPR;
   if (!ok) return false;
   memset(&c, 0, sizeof(c));
   c.dist = st.dist; c.observed = st.observed; c.out_col = st.out_col;
@@ -1643,6 +1677,34 @@ static bool convert_site(const gjx_site& st, int s, CSite& c, int n_state = -1, 
     c.pre = 2;  // the same constants, derived from the launch's parameters (plan_derive_params)
   }
   return true;
+}
+
+static bool expr_adopt(CSite* sites, int n, ExprStore* store) {  // -> does the table hold any program?
+  bool any = false;
+  for (int q = 0; q < n; ++q) {
+    CArg* as[2] = {&sites[q].a0, &sites[q].a1};
+    for (int k = 0; k < 2; ++k)
+      if (as[k]->kind == GJX_ARG_EXPR) {
+        memcpy(store->ops[q][k], as[k]->table, sizeof(gjx_expr_op) * (size_t)as[k]->ref);
+        as[k]->table = reinterpret_cast<const float*>(store->ops[q][k]);
+        any = true;
+      }
+  }
+  return any;
+}
+// highest operand index of `opcode` in a site table's programs (-1: none)
+static int expr_max_ref(const CSite* sites, int n, int opcode) {
+  int mx = -1;
+  for (int q = 0; q < n; ++q) {
+    const CArg* as[2] = {&sites[q].a0, &sites[q].a1};
+    for (int k = 0; k < 2; ++k)
+      if (as[k]->kind == GJX_ARG_EXPR) {
+        const gjx_expr_op* ops = reinterpret_cast<const gjx_expr_op*>(as[k]->table);
+        for (int i = 0; i < as[k]->ref; ++i)
+          if (ops[i].op == opcode && ops[i].ref > mx) mx = ops[i].ref;
+      }
+  }
+  return mx;
 }
 
 int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) { return gjx_plan_create_ex(sites, n_sites, 0u, out); }
@@ -1694,6 +1756,10 @@ int gjx_plan_create_ex(const gjx_site* sites, int n_sites, uint32_t flags, gjx_p
     c.slot = slot;
   }
   p->n_slots = n_slots;
+  p->has_expr = expr_adopt(p->host, n_sites, &p->expr);
+  p->expr_max_input = expr_max_ref(p->host, n_sites, GJX_EXPR_INPUT);
+  const int mp = expr_max_ref(p->host, n_sites, GJX_EXPR_PARAM);
+  if (mp > p->max_param) p->max_param = mp;
   *out = p;  // the interpreter's device copy of the table is made on first use (plan_device_table)
   return GJX_OK;
 }
@@ -1843,13 +1909,13 @@ static bool jit_fallback_allowed() {
 }
 int gjx_plan_prepare(gjx_plan* p, const gjx_keys* pk) {
   if (!p || !keys_ok(pk)) return GJX_ERR_INVALID;
-  if (!gjx_jit::enabled()) return plan_device_table(p);
+  if (!gjx_jit::enabled()) return p->has_expr ? GJX_ERR_UNSUPPORTED : plan_device_table(p);
   // every form a launch may take (which one depends on n and on buffer alignment)
   bool ok = plan_compiled(p, pk, 1).state == 1;
   ok = plan_compiled(p, pk, 2).state == 1 && ok;
   ok = plan_compiled(p, pk, 4).state == 1 && ok;
   if (ok) return GJX_OK;
-  return jit_fallback_allowed() ? plan_device_table(p) : GJX_ERR_JIT;
+  return jit_fallback_allowed() && !p->has_expr ? plan_device_table(p) : GJX_ERR_JIT;
 }
 
 // One launch of a plan over n_pass independent passes (n_pass == 1: the plain call).
@@ -1876,6 +1942,7 @@ static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pa
     if (st.observed && st.obs.kind == GJX_ARG_INPUT && st.obs.ref >= n_input_cols) return GJX_ERR_INVALID;
   }
   if (p->max_param >= p->n_params) return GJX_ERR_INVALID;  // parameters referenced but never set
+  if (p->expr_max_input >= n_input_cols) return GJX_ERR_INVALID;
   if (n == 0) return GJX_OK;
   KeySrc k = key_src(pk);
   // Specialised straight-line kernel for this site table (compiled once per plan and RNG scheme).
@@ -1886,7 +1953,7 @@ static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pa
     for (int c = 0; c < n_value_cols; ++c) al |= (uintptr_t)value_cols[c];
     const int lane_particles = (al & 15) == 0 ? 4 : ((al & 7) == 0 ? 2 : 1);
     gjx_jit::Compiled& c = plan_compiled(const_cast<gjx_plan*>(p), pk, lane_particles);
-    if (c.state != 1 && !jit_fallback_allowed()) return GJX_ERR_JIT;  // loud: never a silent 7x slower route
+    if (c.state != 1 && (!jit_fallback_allowed() || p->has_expr)) return GJX_ERR_JIT;  // loud: never a silent 7x slower route
     if (c.state == 1) {
       uint64_t nn = n;
       LseTail tail{nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1912,6 +1979,7 @@ static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pa
       return launch_status();
     }
   }
+  if (p->has_expr) return GJX_ERR_UNSUPPORTED;  // programs are compiled, never interpreted (gjx.h: GJX_ARG_EXPR)
   {
     const int rc = plan_device_table(const_cast<gjx_plan*>(p));
     if (rc) return rc;
@@ -2497,6 +2565,7 @@ struct gjx_scan_plan {
   gjx_jit::Compiled jit[2];
   std::vector<void*> dev_owned;  // per-row tables of categorical sites
   std::mutex mu;
+  ExprStore step_expr;  // GJX_ARG_EXPR programs
 };
 int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan** out) {
   if (!m || !out || (flags & ~(uint32_t)GJX_PLAN_FAST_MATH) || m->n_state < 1 || m->n_state > GJX_SMC_MAX_STATE ||
@@ -2508,13 +2577,15 @@ int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan*
   bool ok = true;
   for (int s = 0; ok && s < p->n_step; ++s) ok = convert_site(m->step_sites[s], s, p->step[s], m->n_state, m->n_obs, true);
   for (int k = 0; ok && k < p->n_state; ++k) {
-    ok = arg_ok(m->next_state[k], p->n_step, m->n_state, m->n_obs, true) && m->next_state[k].kind != GJX_ARG_TABLE;
+    ok = arg_ok(m->next_state[k], p->n_step, m->n_state, m->n_obs, true) && m->next_state[k].kind != GJX_ARG_TABLE &&
+         m->next_state[k].kind != GJX_ARG_EXPR;
     p->next_state[k] = carg(m->next_state[k]);
   }
   if (!ok) {
     delete p;
     return GJX_ERR_INVALID;
   }
+  (void)expr_adopt(p->step, p->n_step, &p->step_expr);
   *out = p;
   return GJX_OK;
 }
@@ -2595,6 +2666,7 @@ struct gjx_smc_plan {
   gjx_jit::CompiledSmc jit[2];
   std::vector<void*> dev_owned;  // per-row tables of categorical sites
   std::mutex mu;
+  ExprStore init_expr, step_expr;  // GJX_ARG_EXPR programs of the two tables
 };
 
 int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
@@ -2610,7 +2682,9 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
   for (int s = 0; ok && s < p->n_step; ++s) ok = convert_site(m->step_sites[s], s, p->step[s], m->n_state, m->n_obs, true);
   for (int k = 0; ok && k < p->n_state; ++k) {
     ok = arg_ok(m->init_state[k], p->n_init, m->n_state, m->n_obs, false) && m->init_state[k].kind != GJX_ARG_TABLE &&
-         arg_ok(m->next_state[k], p->n_step, m->n_state, m->n_obs, true) && m->next_state[k].kind != GJX_ARG_TABLE;
+         m->init_state[k].kind != GJX_ARG_EXPR &&
+         arg_ok(m->next_state[k], p->n_step, m->n_state, m->n_obs, true) && m->next_state[k].kind != GJX_ARG_TABLE &&
+         m->next_state[k].kind != GJX_ARG_EXPR;
     p->init_state[k] = carg(m->init_state[k]);
     p->next_state[k] = carg(m->next_state[k]);
   }
@@ -2618,6 +2692,8 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
     delete p;
     return GJX_ERR_INVALID;
   }
+  (void)expr_adopt(p->init, p->n_init, &p->init_expr);
+  (void)expr_adopt(p->step, p->n_step, &p->step_expr);
   *out = p;
   return GJX_OK;
 }

@@ -75,6 +75,31 @@ struct SiteEmitter {
       case GJX_ARG_STATE: return "((" + flit(a.scale) + " * st_" + std::to_string(a.ref) + sfx + ") + " + flit(a.offset) + ")";
       case GJX_ARG_OBS: return "((" + flit(a.scale) + " * a.obs[" + std::to_string(a.ref) + "]) + " + flit(a.offset) + ")";
       case GJX_ARG_PARAM: return "((" + flit(a.scale) + " * prm.p[" + std::to_string(a.ref) + "]) + " + flit(a.offset) + ")";
+      case GJX_ARG_EXPR: {
+        // the postfix program as ONE parenthesised f32 expression: every operator rounds once, in program order (the
+        // translation unit is compiled with -ffp-contract=off: no fusion, no re-association)
+        const gjx_expr_op* ops = reinterpret_cast<const gjx_expr_op*>(a.table);
+        std::vector<std::string> st;
+        for (int k = 0; k < a.ref; ++k) {
+          const std::string r = std::to_string(ops[k].ref);
+          switch (ops[k].op) {
+            case GJX_EXPR_CONST: st.push_back(flit(ops[k].value)); break;
+            case GJX_EXPR_SITE: st.push_back(val_f32(ops[k].ref)); break;
+            case GJX_EXPR_INPUT: st.push_back("cols.in[" + r + "][li" + sfx + "]"); break;
+            case GJX_EXPR_PARAM: st.push_back("prm.p[" + r + "]"); break;
+            case GJX_EXPR_STATE: st.push_back("st_" + r + sfx); break;
+            case GJX_EXPR_OBS: st.push_back("a.obs[" + r + "]"); break;
+            case GJX_EXPR_NEG: st.back() = "(-" + st.back() + ")"; break;
+            default: {
+              const std::string b = st.back();
+              st.pop_back();
+              const char* op = ops[k].op == GJX_EXPR_ADD ? " + " : (ops[k].op == GJX_EXPR_SUB ? " - " : " * ");
+              st.back() = "(" + st.back() + op + b + ")";
+            }
+          }
+        }
+        return st.back();
+      }
       default: return plit(a.table) + "[" + val_i32(a.ref_site) + "]";
     }
   }

@@ -35,7 +35,10 @@ RNG_PHILOX = 1
 
 LSE_RECORD_WORDS = 65  # include/gjx.h: GJX_LSE_RECORD_WORDS
 DIST_NORMAL, DIST_GAMMA, DIST_BETA, DIST_BERNOULLI, DIST_CATEGORICAL = range(5)
-ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE, ARG_STATE, ARG_OBS, ARG_PARAM = range(7)
+ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE, ARG_STATE, ARG_OBS, ARG_PARAM, ARG_EXPR = range(8)
+# postfix programs as distribution arguments (gjx.h: GJX_ARG_EXPR / gjx_expr_op)
+EXPR_CONST, EXPR_SITE, EXPR_INPUT, EXPR_PARAM, EXPR_STATE, EXPR_OBS, EXPR_ADD, EXPR_SUB, EXPR_MUL, EXPR_NEG = range(10)
+MAX_EXPR_OPS, MAX_EXPR_DEPTH = 16, 8
 MAX_PARAMS = 64
 SMC_MAX_STATE, SMC_MAX_OBS = 4, 8
 OP_LOGSUMEXP, OP_CATEGORICAL_INDEX, OP_RESAMPLE, OP_SMC = range(4)
@@ -89,6 +92,18 @@ class Arg(C.Structure):
         ("offset", C.c_float),
         ("table", C.c_void_p),
     ]
+
+
+class ExprOp(C.Structure):
+    _fields_ = [("op", C.c_int32), ("ref", C.c_int32), ("value", C.c_float)]
+
+
+def expr_arg(prog, keep: list) -> Arg:
+    """`prog`: [(opcode, ref, value)] -> a GJX_ARG_EXPR argument.  The ctypes array goes into `keep` (the library copies
+    the program at plan creation; until then the caller keeps it alive)."""
+    arr = (ExprOp * len(prog))(*[ExprOp(int(o), int(r), float(v)) for o, r, v in prog])
+    keep.append(arr)
+    return Arg(ARG_EXPR, len(prog), 0.0, 0.0, C.addressof(arr))
 
 
 class Site(C.Structure):

@@ -51,41 +51,56 @@ class Sym:
     # -- affine algebra (one multiply, then one add — in that order) -------------------------------
     @staticmethod
     def _const(c):
-        if isinstance(c, ParamVal):
-            raise PlanUnsupported("a launch parameter combined with a traced site value")
         if isinstance(c, (bool, int, float)):
             return float(c)
         if isinstance(c, torch.Tensor) and c.dim() == 0:
             return float(c)
         raise PlanUnsupported("non-constant operand")
 
+    @staticmethod
+    def _is_const(c) -> bool:
+        return isinstance(c, (bool, int, float)) or (isinstance(c, torch.Tensor) and c.dim() == 0)
+
     def __mul__(self, c):
+        if not self._is_const(c) or self.has_mul or self.has_add:  # beyond one affine step: a postfix program
+            return SymExpr.binop(abi.EXPR_MUL, self, c)
         c = self._const(c)
-        if self.has_mul or self.has_add:
-            raise PlanUnsupported("more than one multiply / multiply after add")
         return Sym(self.tracer, self.src, float(torch.tensor(c, dtype=torch.float32)), 0.0, True, False, False)
 
-    __rmul__ = __mul__
+    def __rmul__(self, c):
+        if not self._is_const(c) or self.has_mul or self.has_add:
+            return SymExpr.binop(abi.EXPR_MUL, c, self)
+        return self.__mul__(c)
 
     def __add__(self, c):
+        if not self._is_const(c) or self.has_add:
+            return SymExpr.binop(abi.EXPR_ADD, self, c)
         c = self._const(c)
-        if self.has_add:
-            raise PlanUnsupported("more than one add")
         return Sym(self.tracer, self.src, self.scale, float(torch.tensor(c, dtype=torch.float32)), self.has_mul,
                    True, False)
 
-    __radd__ = __add__
+    def __radd__(self, c):
+        if not self._is_const(c) or self.has_add:
+            return SymExpr.binop(abi.EXPR_ADD, c, self)
+        return self.__add__(c)
 
     def __sub__(self, c):
+        if not self._is_const(c) or self.has_add:
+            return SymExpr.binop(abi.EXPR_SUB, self, c)
         return self.__add__(-self._const(c))
 
+    def __rsub__(self, c):
+        return SymExpr.binop(abi.EXPR_SUB, c, self)
+
     def __neg__(self):
+        if self.has_mul or self.has_add:
+            return SymExpr.unop(abi.EXPR_NEG, self)
         return self.__mul__(-1.0)
 
     def _no(self, *a, **k):
         raise PlanUnsupported("unsupported operation on a traced site value")
 
-    __truediv__ = __rtruediv__ = __rsub__ = __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
+    __truediv__ = __rtruediv__ = __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
     __lt__ = __le__ = __gt__ = __ge__ = __abs__ = __index__ = __array__ = __len__ = __iter__ = _no
 
     @classmethod
@@ -109,6 +124,102 @@ class _Rows:
 
     def __init__(self, tracer, table: torch.Tensor, idx: Sym):
         self.tracer, self.table, self.idx = tracer, table, idx
+
+
+class SymExpr:
+    """A traced f32 value beyond one affine step — `w * x + b` over two sites, `(z - m) * (z - m)`, ... — as the postfix
+    program of `abi.ARG_EXPR`: operands push a value, `+ - *` pop two, unary minus one; every operator is one f32 rounding,
+    in the order the model body wrote it (what the per-site column path computes with torch's f32 tensor arithmetic)."""
+
+    __slots__ = ("tracer", "prog")
+
+    def __init__(self, tracer, prog):
+        self.tracer, self.prog = tracer, prog
+        if len(prog) > abi.MAX_EXPR_OPS:
+            raise PlanUnsupported("expression too long for a plan argument")
+        depth = deepest = 0
+        for op, _, _ in prog:
+            depth += 1 if op <= abi.EXPR_OBS else (-1 if op != abi.EXPR_NEG else 0)
+            deepest = max(deepest, depth)
+        if deepest > abi.MAX_EXPR_DEPTH:
+            raise PlanUnsupported("expression too deep for a plan argument")
+
+    _LEAF = {"site": abi.EXPR_SITE, "input": abi.EXPR_INPUT, "state": abi.EXPR_STATE, "obs": abi.EXPR_OBS}
+
+    @staticmethod
+    def _f32(c) -> float:
+        return float(torch.tensor(float(c), dtype=torch.float32))
+
+    @classmethod
+    def program_of(cls, x, tracer):
+        """Operand -> (tracer, program).  Traced values keep their own rounding steps (a `Sym` is its source, then its
+        multiply, then its add); numbers become f32 literals; launch parameters stay parameters."""
+        if isinstance(x, SymExpr):
+            return x.tracer, list(x.prog)
+        if isinstance(x, Sym):
+            prog = [(cls._LEAF[x.src[0]], x.src[1], 0.0)]
+            if x.has_mul:
+                prog += [(abi.EXPR_CONST, 0, x.scale), (abi.EXPR_MUL, 0, 0.0)]
+            if x.has_add:
+                prog += [(abi.EXPR_CONST, 0, x.offset), (abi.EXPR_ADD, 0, 0.0)]
+            return x.tracer, prog
+        if isinstance(x, ParamVal):
+            if tracer is None or not getattr(tracer, "use_params", False):
+                raise PlanUnsupported("a launch parameter outside an importance plan")
+            return tracer, [(abi.EXPR_PARAM, tracer.param_slot(x), 0.0)]
+        if Sym._is_const(x):
+            return tracer, [(abi.EXPR_CONST, 0, cls._f32(x))]
+        raise PlanUnsupported("unsupported operand in an expression over traced site values")
+
+    @classmethod
+    def binop(cls, op, a, b):
+        tr = next((v.tracer for v in (a, b) if isinstance(v, (Sym, SymExpr))), None)
+        _, pa = cls.program_of(a, tr)
+        _, pb = cls.program_of(b, tr)
+        return cls(tr, pa + pb + [(op, 0, 0.0)])
+
+    @classmethod
+    def unop(cls, op, a):
+        tr, pa = cls.program_of(a, getattr(a, "tracer", None))
+        return cls(tr, pa + [(op, 0, 0.0)])
+
+    def __add__(self, o): return SymExpr.binop(abi.EXPR_ADD, self, o)  # noqa: E704
+    def __radd__(self, o): return SymExpr.binop(abi.EXPR_ADD, o, self)  # noqa: E704
+    def __sub__(self, o): return SymExpr.binop(abi.EXPR_SUB, self, o)  # noqa: E704
+    def __rsub__(self, o): return SymExpr.binop(abi.EXPR_SUB, o, self)  # noqa: E704
+    def __mul__(self, o): return SymExpr.binop(abi.EXPR_MUL, self, o)  # noqa: E704
+    def __rmul__(self, o): return SymExpr.binop(abi.EXPR_MUL, o, self)  # noqa: E704
+    def __neg__(self): return SymExpr.unop(abi.EXPR_NEG, self)  # noqa: E704
+
+    def _no(self, *a, **k):
+        raise PlanUnsupported("unsupported operation on a traced expression")
+
+    __truediv__ = __rtruediv__ = __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
+    __lt__ = __le__ = __gt__ = __ge__ = __abs__ = __index__ = __array__ = __len__ = __iter__ = _no
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        raise PlanUnsupported(f"torch.{getattr(func, '__name__', func)} on a traced expression")
+
+    def evaluate(self, leaf):
+        """The program over concrete operands: `leaf(kind, ref)` -> tensor / number.  Same f32 steps as the kernel."""
+        st = []
+        for op, ref, val in self.prog:
+            if op == abi.EXPR_CONST:
+                st.append(torch.tensor(val, dtype=torch.float32))
+            elif op <= abi.EXPR_OBS:
+                v = leaf(op, ref)
+                v = v.to(torch.float32) if isinstance(v, torch.Tensor) else torch.tensor(float(v), dtype=torch.float32)
+                st.append(v)
+            elif op == abi.EXPR_NEG:
+                st[-1] = -st[-1]
+            else:
+                b = st.pop()
+                a = st.pop()
+                if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.device != b.device:
+                    a, b = (a.to(b.device), b) if a.dim() == 0 else (a, b.to(a.device))
+                st.append(a + b if op == abi.EXPR_ADD else (a - b if op == abi.EXPR_SUB else a * b))
+        return st[0]
 
 
 class ParamVal:
@@ -135,9 +246,7 @@ class ParamVal:
         def f(self, other):
             o = ParamVal._v(other)
             if o is None:
-                if isinstance(other, Sym):
-                    raise PlanUnsupported("a launch parameter combined with a traced site value")
-                return NotImplemented
+                return NotImplemented  # (a traced value: its reflected method builds the expression)
             return ParamVal(op(o, self.value) if swap else op(self.value, o))
 
         return f
@@ -190,7 +299,8 @@ class PlanTracer(_Handler):
         self.meta: list[dict] = []  # per site: addr, gen_fn, args (symbolic), out_col, observed
         self.inputs: list[torch.Tensor] = []
         self.input_orig: dict = {}  # input column -> the constrained value it was made from (its own dtype)
-        self.keep: list = []  # device tensors the site table points into
+        self.keep: list = []  # device tensors (and expression programs) the site table points into
+        self.expr_progs: dict = {}  # address of a program's ctypes array -> the program
         self.n_out = 0
 
     # -- argument encoding ---------------------------------------------------------------------------
@@ -214,6 +324,10 @@ class PlanTracer(_Handler):
                                                                and a.is_floating_point()) else a for a in args)
 
     def _arg(self, v) -> abi.Arg:
+        if isinstance(v, SymExpr):
+            a = abi.expr_arg(v.prog, self.keep)
+            self.expr_progs[a.table] = tuple(v.prog)  # (by address: the plan cache keys on the program, not on where it lies)
+            return a
         if isinstance(v, Sym):
             kind = abi.ARG_SITE if v.src[0] == "site" else abi.ARG_INPUT
             return abi.Arg(kind, v.src[1], v.scale, v.offset, None)
@@ -383,7 +497,17 @@ def _make_plan(tracer):
     if cache is None:
         cache = _PLANS.cache = OrderedDict()
     arr = (abi.Site * len(tracer.sites))(*tracer.sites)
-    key = (id(ops), fast, bytes(memoryview(arr)))
+    raw = bytes(memoryview(arr))
+    if tracer.expr_progs:  # programs enter the key by content: their addresses differ from trace to trace
+        tmp = (abi.Site * len(tracer.sites)).from_buffer_copy(raw)
+        progs = []
+        for q in range(len(tracer.sites)):
+            for k in range(2):
+                if tmp[q].arg[k].kind == abi.ARG_EXPR:
+                    progs.append((q, k, tracer.expr_progs[tmp[q].arg[k].table]))
+                    tmp[q].arg[k].table = None
+        raw = bytes(memoryview(tmp)) + repr(progs).encode()
+    key = (id(ops), fast, raw)
     hit = cache.get(key)
     if hit is not None:
         cache.move_to_end(key)
@@ -482,6 +606,14 @@ def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
             if x.has_add:
                 out = out + x.offset
             return out
+        if isinstance(x, SymExpr):
+            def leaf(kind, ref):
+                if kind == abi.EXPR_SITE:
+                    return site_vals[ref]
+                if kind == abi.EXPR_INPUT:
+                    return tracer.inputs[ref]
+                return tracer.params[ref]
+            return x.evaluate(leaf)
         if isinstance(x, _Table):
             return x.table[site_vals[x.idx.src[1]].long()]
         if isinstance(x, _Rows):

@@ -21,7 +21,7 @@ import torch
 from . import abi
 from .choicemap import ChoiceMap
 from .lang import StaticGenerativeFunction, ParticleKeys
-from .plan import PlanTracer, PlanUnsupported, Sym, _Table
+from .plan import PlanTracer, PlanUnsupported, Sym, SymExpr, _Table
 from .runtime import get_ops
 
 
@@ -108,6 +108,8 @@ def lower_scan(kernel_gen_fn, carry0, xs, obs_addrs: list[tuple], fast_math: boo
     for v in nc_leaves:
         if isinstance(v, _Table):
             raise PlanUnsupported("a table lookup cannot be a carry component")
+        if isinstance(v, SymExpr):
+            raise PlanUnsupported("the next carry must be a site value (or one affine step of a site / carry / input)")
         next_state.append(tr._arg(v))
     y_leaves: list = []
     _flatten(y, y_leaves)
@@ -118,6 +120,10 @@ def lower_scan(kernel_gen_fn, carry0, xs, obs_addrs: list[tuple], fast_math: boo
             raise PlanUnsupported("y_t is a table lookup")
         if isinstance(v, Sym) and v.src[0] == "site" and tr.meta[v.src[1]]["out_col"] < 0:
             raise PlanUnsupported("y_t reads a site that is not stored")
+        if isinstance(v, SymExpr):
+            for op, ref, _ in v.prog:
+                if op == abi.EXPR_STATE or (op == abi.EXPR_SITE and tr.meta[ref]["out_col"] < 0):
+                    raise PlanUnsupported("y_t reads the previous carry or a site that is not stored")
     seen = {(m["addr"] if isinstance(m["addr"], tuple) else (m["addr"],)) for m in tr.meta}
     if any(a not in seen for a in obs_addrs):
         raise PlanUnsupported("a constrained address is not visited by the kernel")
@@ -194,6 +200,14 @@ def run_scan(low: ScanLowering, pk: ParticleKeys, T: int, carry0, table: np.ndar
 
 def resolve(low: ScanLowering, x, values_nt: list, table: np.ndarray, device):
     """A symbolic per-step output -> its [n, T] (or [T]) tensor, with the f32 operation order of the kernel."""
+    if isinstance(x, SymExpr):
+        def leaf(kind, ref):
+            if kind == abi.EXPR_SITE:
+                return values_nt[low.tracer.meta[ref]["out_col"]]
+            if kind == abi.EXPR_OBS:
+                return torch.from_numpy(table[:, ref].copy()).to(device)
+            raise PlanUnsupported("unresolvable output")
+        return x.evaluate(leaf)
     if isinstance(x, Sym):
         if x.src[0] == "site":
             m = low.tracer.meta[x.src[1]]

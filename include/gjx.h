@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define GJX_VERSION_MAJOR 0
-#define GJX_VERSION_MINOR 5
+#define GJX_VERSION_MINOR 6
 
 typedef void* gjx_stream; /* hipStream_t; ignored by the oracle build */
 
@@ -165,19 +165,45 @@ typedef enum {
   GJX_ARG_TABLE = 3, /* value = table[(int) value of site `ref`] (dev f32 table) */
   GJX_ARG_STATE = 4, /* SMC plans: value = scale * state[ref] of the particle's ANCESTOR + offset */
   GJX_ARG_OBS = 5,   /* SMC plans: value = scale * obs[t][ref] + offset (this step's observation constants) */
-  GJX_ARG_PARAM = 6  /* importance plans: value = scale * params[ref] + offset — a LAUNCH-UNIFORM parameter
+  GJX_ARG_PARAM = 6, /* importance plans: value = scale * params[ref] + offset — a LAUNCH-UNIFORM parameter
                         (gjx_plan_set_params): observations and model arguments that change from dataset to dataset
                         without changing the model's structure.  libgjx_hip.so passes them as kernel arguments
                         (scalar registers), so one specialised kernel serves every dataset: no recompilation. */
+  GJX_ARG_EXPR = 7   /* value = a small POSTFIX PROGRAM over earlier sites, input columns, parameters / state / observation
+                        constants and literals: `table` points at `ref` gjx_expr_op entries in HOST memory (copied at plan
+                        creation).  What a model body writes between its `@` sites — `normal(w * x + b, s)`
+                        (static.py:340-380 runs that arithmetic as traced jnp ops) — evaluated per particle in f32, one
+                        rounding per operation, in program order (no fusion).  Distribution arguments of sites only (not
+                        observed values, not the row of a categorical site, not the next state).  libgjx_hip.so runs such
+                        plans as specialised kernels only (GJX_ERR_UNSUPPORTED if specialisation is turned off). */
 } gjx_arg_kind;
 #define GJX_MAX_PARAMS 64
+
+typedef enum {
+  GJX_EXPR_CONST = 0, /* push `value` */
+  GJX_EXPR_SITE = 1,  /* push the value of site `ref` (an integer-valued site converts to f32) */
+  GJX_EXPR_INPUT = 2, /* push input_cols[ref][i] */
+  GJX_EXPR_PARAM = 3, /* push params[ref]            (importance plans) */
+  GJX_EXPR_STATE = 4, /* push state[ref] of the ancestor (scan / SMC plans) */
+  GJX_EXPR_OBS = 5,   /* push obs[t][ref]            (scan / SMC plans) */
+  GJX_EXPR_ADD = 6,   /* pop b, pop a, push a + b */
+  GJX_EXPR_SUB = 7,   /* ... a - b */
+  GJX_EXPR_MUL = 8,   /* ... a * b */
+  GJX_EXPR_NEG = 9    /* pop a, push -a */
+} gjx_expr_opcode;
+typedef struct {
+  int32_t op;   /* gjx_expr_opcode */
+  int32_t ref;
+  float value;
+} gjx_expr_op;
+#define GJX_MAX_EXPR_OPS 16 /* per argument; the evaluation stack is at most 8 deep */
 
 typedef struct {
   int32_t kind;
   int32_t ref;
   float scale;
   float offset;
-  const float* table; /* dev, GJX_ARG_TABLE only */
+  const float* table; /* GJX_ARG_TABLE: dev f32 table; GJX_ARG_EXPR: (const gjx_expr_op*) host program of `ref` entries */
 } gjx_arg;
 
 typedef struct {

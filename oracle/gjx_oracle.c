@@ -295,12 +295,47 @@ int gjx_logpdf_categorical(const int32_t* value, int value_scalar, const float* 
   return GJX_OK;
 }
 
+/* ---- GJX_ARG_EXPR: postfix programs as distribution arguments (gjx.h) ----------------------------- */
+/* Well-formed: at most GJX_MAX_EXPR_OPS entries, operands in range for the plan kind (n_state < 0: importance plan — INPUT /
+ * PARAM; otherwise STATE (if allowed) / OBS), the stack never deeper than 8 and exactly one value left at the end. */
+static int expr_ok(const gjx_arg* a, int s, int n_state, int n_obs, int allow_state) {
+  const gjx_expr_op* ops = (const gjx_expr_op*)(const void*)a->table;
+  if (!ops || a->ref < 1 || a->ref > GJX_MAX_EXPR_OPS) return 0;
+  int depth = 0;
+  for (int k = 0; k < a->ref; ++k) {
+    switch (ops[k].op) {
+      case GJX_EXPR_CONST: ++depth; break;
+      case GJX_EXPR_SITE: if (ops[k].ref < 0 || ops[k].ref >= s) return 0; ++depth; break;
+      case GJX_EXPR_INPUT: if (n_state >= 0 || ops[k].ref < 0 || ops[k].ref >= 16) return 0; ++depth; break;
+      case GJX_EXPR_PARAM: if (n_state >= 0 || ops[k].ref < 0 || ops[k].ref >= GJX_MAX_PARAMS) return 0; ++depth; break;
+      case GJX_EXPR_STATE: if (n_state < 0 || !allow_state || ops[k].ref < 0 || ops[k].ref >= n_state) return 0; ++depth; break;
+      case GJX_EXPR_OBS: if (n_state < 0 || ops[k].ref < 0 || ops[k].ref >= n_obs) return 0; ++depth; break;
+      case GJX_EXPR_ADD: case GJX_EXPR_SUB: case GJX_EXPR_MUL: if (depth < 2) return 0; --depth; break;
+      case GJX_EXPR_NEG: if (depth < 1) return 0; break;
+      default: return 0;
+    }
+    if (depth > 8) return 0;
+  }
+  return depth == 1;
+}
+/* The plan's own copy of every program of a site table (the caller's arrays need not outlive plan creation). */
+typedef struct { gjx_expr_op ops[GJX_MAX_SITES][2][GJX_MAX_EXPR_OPS]; } expr_store;
+static void expr_adopt(gjx_site* sites, int n, expr_store* st) {
+  for (int q = 0; q < n; ++q)
+    for (int a = 0; a < 2; ++a)
+      if (sites[q].arg[a].kind == GJX_ARG_EXPR) {
+        memcpy(st->ops[q][a], (const void*)sites[q].arg[a].table, sizeof(gjx_expr_op) * (size_t)sites[q].arg[a].ref);
+        sites[q].arg[a].table = (const float*)(const void*)st->ops[q][a];
+      }
+}
+
 /* ---- fused static-model importance ------------------------------------------------------------ */
 struct gjx_plan {
   int n_sites;
   gjx_site sites[GJX_MAX_SITES];
   int n_params;
   float params[GJX_MAX_PARAMS]; /* GJX_ARG_PARAM values (gjx_plan_set_params) */
+  expr_store expr;
 };
 
 static int arg_ok(const gjx_arg* a, int s, int allow_site) {
@@ -310,6 +345,7 @@ static int arg_ok(const gjx_arg* a, int s, int allow_site) {
     case GJX_ARG_INPUT: return a->ref >= 0;
     case GJX_ARG_TABLE: return allow_site && a->ref >= 0 && a->ref < s && a->table != NULL;
     case GJX_ARG_PARAM: return a->ref >= 0 && a->ref < GJX_MAX_PARAMS;
+    case GJX_ARG_EXPR: return allow_site && expr_ok(a, s, -1, -1, 0);
     default: return 0;
   }
 }
@@ -327,13 +363,15 @@ int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
                           (st->obs.kind == GJX_ARG_PARAM && st->obs.ref >= 0 && st->obs.ref < GJX_MAX_PARAMS)))
       return GJX_ERR_INVALID;
     if (st->dist == GJX_DIST_CATEGORICAL &&
-        (!st->logits || st->n_cat <= 0 || st->n_rows <= 0 || (st->cat_mode != 0 && st->cat_mode != 1)))
+        (!st->logits || st->n_cat <= 0 || st->n_rows <= 0 || (st->cat_mode != 0 && st->cat_mode != 1) ||
+         st->arg[0].kind == GJX_ARG_EXPR))
       return GJX_ERR_INVALID;
   }
   gjx_plan* p = (gjx_plan*)calloc(1, sizeof(gjx_plan));
   if (!p) return GJX_ERR_LAUNCH;
   p->n_sites = n_sites;
   memcpy(p->sites, sites, sizeof(gjx_site) * (size_t)n_sites);
+  expr_adopt(p->sites, n_sites, &p->expr);
   *out = p;
   return GJX_OK;
 }
@@ -346,8 +384,14 @@ static int plan_max_param(const gjx_plan* p) {
   int mx = -1;
   for (int q = 0; q < p->n_sites; ++q) {
     const gjx_site* st = &p->sites[q];
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) {
       if (st->arg[a].kind == GJX_ARG_PARAM && st->arg[a].ref > mx) mx = st->arg[a].ref;
+      if (st->arg[a].kind == GJX_ARG_EXPR) {
+        const gjx_expr_op* ops = (const gjx_expr_op*)(const void*)st->arg[a].table;
+        for (int k = 0; k < st->arg[a].ref; ++k)
+          if (ops[k].op == GJX_EXPR_PARAM && ops[k].ref > mx) mx = ops[k].ref;
+      }
+    }
     if (st->observed && st->obs.kind == GJX_ARG_PARAM && st->obs.ref > mx) mx = st->obs.ref;
   }
   return mx;
@@ -398,6 +442,26 @@ static inline float eval_arg(const gjx_arg* a, const site_val* vals, const walk_
     case GJX_ARG_STATE: { float t = a->scale * c->state[a->ref]; return t + a->offset; }
     case GJX_ARG_OBS: { float t = a->scale * c->obs[a->ref]; return t + a->offset; }
     case GJX_ARG_PARAM: { float t = a->scale * c->params[a->ref]; return t + a->offset; }
+    case GJX_ARG_EXPR: {
+      const gjx_expr_op* ops = (const gjx_expr_op*)(const void*)a->table;
+      float st[8];
+      int d = 0;
+      for (int k = 0; k < a->ref; ++k) {
+        switch (ops[k].op) {
+          case GJX_EXPR_CONST: st[d++] = ops[k].value; break;
+          case GJX_EXPR_SITE: st[d++] = sv_as_f32(&vals[ops[k].ref]); break;
+          case GJX_EXPR_INPUT: st[d++] = c->in[ops[k].ref][c->i]; break;
+          case GJX_EXPR_PARAM: st[d++] = c->params[ops[k].ref]; break;
+          case GJX_EXPR_STATE: st[d++] = c->state[ops[k].ref]; break;
+          case GJX_EXPR_OBS: st[d++] = c->obs[ops[k].ref]; break;
+          case GJX_EXPR_ADD: { const float r = st[d - 2] + st[d - 1]; st[--d - 1] = r; break; }
+          case GJX_EXPR_SUB: { const float r = st[d - 2] - st[d - 1]; st[--d - 1] = r; break; }
+          case GJX_EXPR_MUL: { const float r = st[d - 2] * st[d - 1]; st[--d - 1] = r; break; }
+          default: st[d - 1] = -st[d - 1]; break; /* GJX_EXPR_NEG */
+        }
+      }
+      return st[0];
+    }
     default: return a->table[sv_as_i32(&vals[a->ref])];
   }
 }
@@ -1228,6 +1292,7 @@ struct gjx_smc_plan {
   gjx_smc_model m;
   gjx_site init_sites[GJX_MAX_SITES];
   gjx_site step_sites[GJX_MAX_SITES];
+  expr_store init_expr, step_expr;
 };
 
 static int smc_arg_ok(const gjx_arg* a, int s, int n_state, int n_obs, int allow_state) {
@@ -1237,6 +1302,7 @@ static int smc_arg_ok(const gjx_arg* a, int s, int n_state, int n_obs, int allow
     case GJX_ARG_TABLE: return a->ref >= 0 && a->ref < s && a->table != NULL;
     case GJX_ARG_STATE: return allow_state && a->ref >= 0 && a->ref < n_state;
     case GJX_ARG_OBS: return a->ref >= 0 && a->ref < n_obs;
+    case GJX_ARG_EXPR: return expr_ok(a, s, n_state, n_obs, allow_state);
     default: return 0;
   }
 }
@@ -1252,7 +1318,8 @@ static int smc_sites_ok(const gjx_site* sites, int n, int n_state, int n_obs, in
     if (st->observed && !(st->obs.kind == GJX_ARG_CONST || (st->obs.kind == GJX_ARG_OBS && st->obs.ref >= 0 && st->obs.ref < n_obs)))
       return 0;
     if (st->dist == GJX_DIST_CATEGORICAL &&
-        (!st->logits || st->n_cat <= 0 || st->n_rows <= 0 || (st->cat_mode != 0 && st->cat_mode != 1)))
+        (!st->logits || st->n_cat <= 0 || st->n_rows <= 0 || (st->cat_mode != 0 && st->cat_mode != 1) ||
+         st->arg[0].kind == GJX_ARG_EXPR))
       return 0;
   }
   return 1;
@@ -1264,9 +1331,9 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
   if (!smc_sites_ok(m->init_sites, m->n_init_sites, m->n_state, m->n_obs, 0)) return GJX_ERR_INVALID;
   if (!smc_sites_ok(m->step_sites, m->n_step_sites, m->n_state, m->n_obs, 1)) return GJX_ERR_INVALID;
   for (int k = 0; k < m->n_state; ++k) {
-    if (!smc_arg_ok(&m->init_state[k], m->n_init_sites, m->n_state, m->n_obs, 0) || m->init_state[k].kind == GJX_ARG_TABLE)
+    if (!smc_arg_ok(&m->init_state[k], m->n_init_sites, m->n_state, m->n_obs, 0) || m->init_state[k].kind == GJX_ARG_TABLE || m->init_state[k].kind == GJX_ARG_EXPR)
       return GJX_ERR_INVALID;
-    if (!smc_arg_ok(&m->next_state[k], m->n_step_sites, m->n_state, m->n_obs, 1) || m->next_state[k].kind == GJX_ARG_TABLE)
+    if (!smc_arg_ok(&m->next_state[k], m->n_step_sites, m->n_state, m->n_obs, 1) || m->next_state[k].kind == GJX_ARG_TABLE || m->next_state[k].kind == GJX_ARG_EXPR)
       return GJX_ERR_INVALID;
   }
   gjx_smc_plan* p = (gjx_smc_plan*)malloc(sizeof(gjx_smc_plan));
@@ -1274,6 +1341,8 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
   p->m = *m;
   memcpy(p->init_sites, m->init_sites, sizeof(gjx_site) * (size_t)m->n_init_sites);
   memcpy(p->step_sites, m->step_sites, sizeof(gjx_site) * (size_t)m->n_step_sites);
+  expr_adopt(p->init_sites, m->n_init_sites, &p->init_expr);
+  expr_adopt(p->step_sites, m->n_step_sites, &p->step_expr);
   p->m.init_sites = p->init_sites;
   p->m.step_sites = p->step_sites;
   *out = p;
@@ -1291,6 +1360,7 @@ int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl) { (void)p; (void
 struct gjx_scan_plan {
   gjx_scan_model m;
   gjx_site step_sites[GJX_MAX_SITES];
+  expr_store step_expr;
 };
 int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan** out) {
   if (!m || !out || (flags & ~(uint32_t)GJX_PLAN_FAST_MATH) || m->n_state < 1 || m->n_state > GJX_SMC_MAX_STATE ||
@@ -1298,12 +1368,13 @@ int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan*
     return GJX_ERR_INVALID;
   if (!smc_sites_ok(m->step_sites, m->n_step_sites, m->n_state, m->n_obs, 1)) return GJX_ERR_INVALID;
   for (int k = 0; k < m->n_state; ++k)
-    if (!smc_arg_ok(&m->next_state[k], m->n_step_sites, m->n_state, m->n_obs, 1) || m->next_state[k].kind == GJX_ARG_TABLE)
+    if (!smc_arg_ok(&m->next_state[k], m->n_step_sites, m->n_state, m->n_obs, 1) || m->next_state[k].kind == GJX_ARG_TABLE || m->next_state[k].kind == GJX_ARG_EXPR)
       return GJX_ERR_INVALID;
   gjx_scan_plan* p = (gjx_scan_plan*)malloc(sizeof(gjx_scan_plan));
   if (!p) return GJX_ERR_LAUNCH;
   p->m = *m;
   memcpy(p->step_sites, m->step_sites, sizeof(gjx_site) * (size_t)m->n_step_sites);
+  expr_adopt(p->step_sites, m->n_step_sites, &p->step_expr);
   p->m.step_sites = p->step_sites;
   *out = p;
   return GJX_OK;

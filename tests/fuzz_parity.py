@@ -2,7 +2,7 @@
 (test infrastructure: it loads the oracle; `test_random_plans_fuzz` runs it for 25 s, and again with p_invalid = 0.12:
 constants, observations, launch parameters and carries are then replaced, with that probability each, by NaN / +-inf / 0 /
 negative / denormal / huge values — DESIGN 3.11; where the arithmetic gives NaN, a NaN is required on both sides)
-Random site tables (all distributions, CONST / SITE / INPUT / PARAM / TABLE arguments, observed and latent sites), random
+Random site tables (all distributions, CONST / SITE / INPUT / PARAM / TABLE / EXPR arguments, observed and latent sites), random
 population sizes (ragged rows included), both generators, lazy and materialised keys — importance plans, scan plans and
 generated SMC filters.  Every output must be equal bit for bit.  Prints the failing case and exits 1 on a mismatch."""
 import os
@@ -30,6 +30,9 @@ def maybe_bad(x):
 hip = load_hip_ops()
 ora = Ops(GjxLib(os.path.join(ROOT, "oracle", "libgjx_oracle.so"), "cpu"))
 A = abi.Arg
+
+
+EXPR_KEEP: list = []  # the programs' ctypes arrays (the libraries copy them at plan creation)
 
 
 def const(lo, hi):
@@ -103,8 +106,51 @@ def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
                 return A(abi.ARG_PARAM, 4 + int(rng.integers(2)), float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.1, 0.5)), None)
             return const(0.3, 2.5)
 
+        def expr_loc():
+            """A postfix program over earlier real-valued sites / state / inputs / parameters / constants (GJX_ARG_EXPR)."""
+            prog, depth = [], 0
+
+            def operand():
+                opts = ["const"]
+                reals = [i for i, kk in enumerate(kinds) if kk in ("real", "pos", "unit", "int01")]
+                if reals:
+                    opts += ["site"] * 3
+                if n_state:
+                    opts.append("state")
+                if mode in ("scan", "smc") and n_obs:
+                    opts.append("obs")
+                if n_inputs and mode == "imp":
+                    opts.append("input")
+                if mode == "imp":
+                    opts.append("param")
+                k = rng.choice(opts)
+                if k == "site":
+                    return (abi.EXPR_SITE, int(rng.choice(reals)), 0.0)
+                if k == "state":
+                    return (abi.EXPR_STATE, int(rng.integers(n_state)), 0.0)
+                if k == "obs":
+                    return (abi.EXPR_OBS, 0, 0.0)
+                if k == "input":
+                    return (abi.EXPR_INPUT, int(rng.integers(n_inputs)), 0.0)
+                if k == "param":
+                    return (abi.EXPR_PARAM, int(rng.integers(4)), 0.0)
+                return (abi.EXPR_CONST, 0, maybe_bad(float(rng.uniform(-2, 2))))
+
+            for _ in range(int(rng.integers(2, 5))):
+                prog.append(operand())
+                depth += 1
+                while depth >= 2 and rng.random() < 0.7:
+                    prog.append((int(rng.choice([abi.EXPR_ADD, abi.EXPR_SUB, abi.EXPR_MUL])), 0, 0.0))
+                    depth -= 1
+                if rng.random() < 0.15:
+                    prog.append((abi.EXPR_NEG, 0, 0.0))
+            while depth >= 2:
+                prog.append((int(rng.choice([abi.EXPR_ADD, abi.EXPR_SUB, abi.EXPR_MUL])), 0, 0.0))
+                depth -= 1
+            return abi.expr_arg(prog, EXPR_KEEP)
+
         if dist == abi.DIST_NORMAL:
-            s.arg[0], s.arg[1] = loc_arg(), pos_arg()
+            s.arg[0], s.arg[1] = (expr_loc() if rng.random() < 0.3 else loc_arg()), pos_arg()
             kinds.append("real")
         elif dist == abi.DIST_GAMMA:
             s.arg[0], s.arg[1] = pos_arg(), pos_arg()
@@ -244,4 +290,5 @@ while time.time() < t_end:
         for i, (a, b) in enumerate(zip(*outs)):
             eq(a, b, f"smc output {i}", dict(ctx, ess=ess, T=T))
     cases += 1
+    del EXPR_KEEP[:]
 print(f"fuzz ok: {cases} random cases (p_invalid {P_BAD}), HIP == oracle bit for bit")

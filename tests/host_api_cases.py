@@ -398,6 +398,72 @@ def case_fused_equals_eager(impl):
         assert torch.equal(ftr.get_subtrace("x").get_score(), eager.get_subtrace("x").get_score())
 
 
+def case_expression_arguments(impl):
+    """Site arguments that are arithmetic over SEVERAL earlier sites / inputs / arguments — `normal(w * x + b, s)`, a
+    product of two traced values, a parameter times a site — lower to postfix programs (gjx.h GJX_ARG_EXPR) and run as ONE
+    fused kernel; weights, scores, values, recomputed site scores and the returned expression equal the per-site column
+    path bit for bit (every operator is one f32 rounding, in the order the body wrote it)."""
+    from genjax._amd import plan as P
+    from genjax._amd.lang import GenerateHandler
+
+    xs = [0.5, -1.25, 2.0, 0.1]
+
+    @gen
+    def regression(s, slope_scale):
+        w = normal(0.0, 1.0) @ "w"
+        b = normal(0.0, 2.0) @ "b"
+        k = flip(0.3) @ "k"
+        for i, x in enumerate(xs):
+            normal(w * x + b, s) @ ("y", i)                       # two sites in one argument
+        q = normal((w - b) * (w - b) - 1.0, 0.7) @ "q"          # a product of traced values
+        r = normal(slope_scale * w + 0.25 - q * 3.0, s * 2.0) @ "r"   # a launch parameter times a site, three terms
+        u = gamma(w * w + 0.5, b * b + 1.0) @ "u"
+        t = normal(k * 2.0 - u, 1.0) @ "t"                       # an integer-valued site in arithmetic
+        return w * 2.0 + b * b - 1.0, -(q * r)
+
+    n = 4000
+    keys = genjax.random.split(genjax.random.key(21, impl), n)
+    col = torch.linspace(-2, 2, n).to(_dev())
+    for chm in (C.n(),
+                C["y", 0].set(0.3) | C["y", 1].set(-0.2) | C["y", 2].set(1.1) | C["y", 3].set(0.05) | C["t"].set(0.4),
+                C["q"].set(col) | C["u"].set(1.5) | C["y", 2].set(0.0)):
+        fused = try_fused_generate(regression, keys, chm, (0.5, 1.75))
+        assert fused is not None, "expression arguments must lower to the fused kernel"
+        ftr, fw = fused
+        h = GenerateHandler(keys, chm)
+        retval = h.run(regression.source, (0.5, 1.75))
+        eager = StaticTrace(regression, (0.5, 1.75), retval, h.traces)
+        ew = h.weight
+        if isinstance(ew, torch.Tensor):
+            assert torch.equal(fw, ew)
+        assert torch.equal(ftr.get_score(), eager.get_score())
+        fc, ec = dict(ftr.get_choices().leaves()), dict(eager.get_choices().leaves())
+        assert fc.keys() == ec.keys()
+        for key_ in fc:
+            a_, b_ = fc[key_], ec[key_]
+            if isinstance(a_, torch.Tensor) and a_.dim():
+                assert torch.equal(a_, b_.to(a_.dtype) if isinstance(b_, torch.Tensor) else torch.full_like(a_, b_)), key_
+        for fr, er in zip(ftr.get_retval(), eager.get_retval()):
+            assert torch.equal(fr, er)
+        for addr in ("q", "r", "u", "t", ("y", 1)):
+            assert torch.equal(torch.as_tensor(ftr.get_subtrace(addr).get_score()).to(torch.float32).expand(n),
+                               torch.as_tensor(eager.get_subtrace(addr).get_score()).to(torch.float32).expand(n)), addr
+    # the same structure on another dataset: parameters, not a new kernel (the plan cache keys on the programs' CONTENT)
+    tr1 = P._traced(regression, C["y", 0].set(0.3), n, (0.5, 1.75))
+    tr2 = P._traced(regression, C["y", 0].set(-0.9), n, (0.8, -0.3))
+    assert tr1 is not None and tr2 is not None and P._make_plan(tr1[0]) is P._make_plan(tr2[0])
+    # what does NOT lower still runs (division by a traced value): the per-site path
+    @gen
+    def ratio():
+        a = normal(0.0, 1.0) @ "a"
+        c = gamma(2.0, 1.0) @ "c"
+        return normal(a / c, 1.0) @ "d"
+
+    assert try_fused_generate(ratio, keys, C.n(), ()) is None
+    tr, w = ratio.importance(keys, C["d"].set(0.1), ())
+    assert w.shape == (n,) and bool(torch.isfinite(w).all())
+
+
 def _dev():
     from genjax._amd.runtime import get_ops
 
@@ -707,6 +773,14 @@ def case_scan_fused_equals_loop(impl):
         _ = flip(p) @ "z"
         return (x2, s - 1.0), (g * 0.5 + 1.0, b)
 
+    @gen
+    def controlled_step(carry, u):  # arguments over SEVERAL traced values (postfix programs, gjx.h GJX_ARG_EXPR): a
+        x, v = carry                # controlled, two-component state-space kernel
+        v2 = normal(0.8 * v + 0.3 * u, 0.5) @ "v"
+        x2 = normal(x + 0.1 * v2 - 0.05 * u * u, 0.25) @ "x"
+        _ = normal(x2 * x2 - v2, 1.0) @ "y"
+        return (x2, v2), (x2 - v2 * 2.0, v2)
+
     torch.manual_seed(0)
     trans, emit = torch.randn(6, 6).to(_dev()), torch.randn(6, 6).to(_dev())
 
@@ -727,6 +801,8 @@ def case_scan_fused_equals_loop(impl):
             (lg_step.scan(n=T), C.n(), (0.25, None)),
             (rich_step.scan(), C["y"].set(ys) | C["z"].set(zs), ((0.5, 3.0), us)),
             (rich_step.scan(), C["y"].set(ys), ((x0, 1.0), us)),
+            (controlled_step.scan(), C["y"].set(ys), ((0.0, 1.0), us)),
+            (controlled_step.scan(), C.n(), ((x0, -0.5), us)),
             (hmm_step.scan(n=T), C["y"].set(torch.tensor([1, 0, 3, 5, 2, 2, 4, 0, 1])), (0, None)),
             (hmm_step.scan(n=T), C.n(), (2, None))]
 
@@ -1198,6 +1274,41 @@ def case_general_smc(impl):
         kk = pp / sv
         mm, pp = mm + kk * (yt - mm), (1 - kk) * pp
     assert r.log_marginal_likelihood == pytest.approx(ll, abs=0.6)
+    # a COUPLED two-component kernel: arguments over several traced values (postfix programs, gjx.h GJX_ARG_EXPR) —
+    # position / velocity, the observation sees the position; exact evidence by a 2-d Kalman filter (float64)
+    @gen
+    def init3():
+        p = normal(0.0, 1.0) @ "p"
+        v = normal(0.0, 0.5) @ "v"
+        normal(p, 0.6) @ "y"
+        return p, v
+
+    @gen
+    def step3(c):
+        p, v = c
+        v2 = normal(0.9 * v - 0.1 * p, 0.3) @ "v"
+        p2 = normal(p + 0.5 * v2, 0.2) @ "p"
+        normal(p2, 0.6) @ "y"
+        return p2, v2
+
+    import numpy as np
+
+    r3 = BootstrapSMC(StateSpaceModel(init3, step3), C["y"].set(torch.tensor(y)), 65536).run(key)
+    mu, P_ = np.zeros(2), np.diag([1.0, 0.25])
+    # x = (p, v);  v' = 0.9 v - 0.1 p + e_v (0.3);  p' = p + 0.5 v' + e_p (0.2)
+    A_ = np.array([[1.0 - 0.05, 0.45], [-0.1, 0.9]])
+    G_ = np.array([[0.2, 0.5 * 0.3], [0.0, 0.3]])  # noise loading of (e_p, e_v)
+    Q_ = G_ @ G_.T
+    H_, R_ = np.array([[1.0, 0.0]]), 0.36
+    ll3 = 0.0
+    for t, yt in enumerate(y.astype("float64")):
+        if t:
+            mu, P_ = A_ @ mu, A_ @ P_ @ A_.T + Q_
+        sv = (H_ @ P_ @ H_.T).item() + R_
+        ll3 += -0.5 * (yt - mu[0]) ** 2 / sv - 0.5 * math.log(2 * math.pi * sv)
+        kk = (P_ @ H_.T) / sv
+        mu, P_ = mu + kk[:, 0] * (yt - mu[0]), P_ - kk @ H_ @ P_
+    assert r3.log_marginal_likelihood == pytest.approx(ll3, abs=0.25)
     # vmap over keys: the filters of a user model step in the same launches, each equal to its own run
     smc2 = BootstrapSMC(StateSpaceModel(init2, step2), C["y"].set(torch.tensor(y)), 4096, record_ancestors=True)
     ks = [genjax.random.key(s_, impl) for s_ in (3, 8, 9)]
@@ -1457,6 +1568,6 @@ def case_index_request(impl):
 
 
 ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
-             case_static_gen_fn, case_distributions, case_uniform, case_fused_equals_eager, case_params_equal_constants, case_trace_cache, case_particle_collection, case_custom_proposal,
+             case_static_gen_fn, case_distributions, case_uniform, case_fused_equals_eager, case_expression_arguments, case_params_equal_constants, case_trace_cache, case_particle_collection, case_custom_proposal,
              case_scan, case_scan_edge_cases, case_scan_fused_equals_loop, case_vmap, case_vmap_edge_cases, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
              case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update, case_regenerate_and_rejuvenate, case_vector_valued_sites, case_index_request]

@@ -113,3 +113,37 @@ def test_comm_entry_points_validate(lib_ops):
     if ops.lib.device_type == "cpu":  # the oracle has no RCCL side
         with pytest.raises(GjxError):
             ops.lib.call("gjx_comm_unique_id", C.c_void_p(0))
+
+
+def test_expression_programs_are_validated(lib_ops):
+    """GJX_ARG_EXPR (gjx.h): malformed postfix programs are refused at plan creation by both builds."""
+    ops = lib_ops
+    keep = []
+    E = lambda prog: abi.expr_arg(prog, keep)
+    z = _site(abi.DIST_NORMAL, c(0.0), c(1.0), out_col=0)
+    ok = [(abi.EXPR_SITE, 0, 0.0), (abi.EXPR_CONST, 0, 2.0), (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_PARAM, 1, 0.0), (abi.EXPR_ADD, 0, 0.0)]
+    plan = ops.plan_create([z, _site(abi.DIST_NORMAL, E(ok), c(1.0), out_col=1)])
+    with pytest.raises(GjxError):  # the program reads parameter 1: two values are needed
+        plan.set_params([0.5])
+    plan.set_params([0.5, 0.25])
+    bad = {
+        "a value left on the stack": [(abi.EXPR_SITE, 0, 0.0), (abi.EXPR_CONST, 0, 2.0)],
+        "an operator without operands": [(abi.EXPR_SITE, 0, 0.0), (abi.EXPR_ADD, 0, 0.0)],
+        "a later site": [(abi.EXPR_SITE, 1, 0.0)],
+        "an unknown opcode": [(abi.EXPR_SITE, 0, 0.0), (99, 0, 0.0)],
+        "a state operand in an importance plan": [(abi.EXPR_STATE, 0, 0.0)],
+        "too long": [(abi.EXPR_CONST, 0, 1.0)] + [(abi.EXPR_CONST, 0, 1.0), (abi.EXPR_ADD, 0, 0.0)] * 8,
+        "too deep": [(abi.EXPR_CONST, 0, 1.0)] * 9 + [(abi.EXPR_ADD, 0, 0.0)] * 8,
+    }
+    for what, prog in bad.items():
+        with pytest.raises(GjxError):
+            ops.plan_create([z, _site(abi.DIST_NORMAL, E(prog), c(1.0), out_col=1)])
+    with pytest.raises(GjxError):  # an empty program
+        ops.plan_create([z, _site(abi.DIST_NORMAL, A(abi.ARG_EXPR, 0, 0.0, 0.0, None), c(1.0), out_col=1)])
+    with pytest.raises(GjxError):  # not as an observed value
+        ops.plan_create([z, _site(abi.DIST_NORMAL, c(0.0), c(1.0), obs=E(ok))])
+    cat = _site(abi.DIST_CATEGORICAL, E([(abi.EXPR_SITE, 0, 0.0)]), out_col=1)
+    logits = torch.zeros(2, 3)
+    cat.n_cat, cat.n_rows, cat.cat_mode, cat.logits = 3, 2, 1, logits.data_ptr()
+    with pytest.raises(GjxError):  # not as the row of a categorical site
+        ops.plan_create([z, cat])

@@ -484,6 +484,57 @@ def test_importance_plan_with_invalid_parameters(hip_ops, oracle_ops, impl, plan
 
 
 @pytest.mark.parametrize("impl", IMPLS)
+def test_expression_arguments(hip_ops, oracle_ops, impl, monkeypatch):
+    """GJX_ARG_EXPR at the ABI: postfix programs over sites, an input column, parameters and literals as distribution
+    arguments (`w * x + b`, a product of two sites, a negation); every kernel form (n aligned for four particles per lane,
+    n odd) equals the oracle; the table interpreter refuses such a plan (GJX_ERR_UNSUPPORTED) instead of guessing."""
+    from genjax._amd.abi import GjxError
+
+    keep = []
+    E = lambda prog: abi.expr_arg(prog, keep)  # noqa: E731
+    c = lambda v: abi.Arg(abi.ARG_CONST, 0, 0.0, v, None)  # noqa: E731
+
+    def site(dist, a0, a1, out_col=-1, obs=None):
+        st = abi.Site()
+        st.dist, st.observed, st.out_col = dist, 0 if obs is None else 1, out_col
+        st.arg[0], st.arg[1] = a0, a1
+        if obs is not None:
+            st.obs = obs
+        return st
+
+    S, K, P_, I = abi.EXPR_SITE, abi.EXPR_CONST, abi.EXPR_PARAM, abi.EXPR_INPUT
+    ADD, SUB, MUL, NEG = abi.EXPR_ADD, abi.EXPR_SUB, abi.EXPR_MUL, abi.EXPR_NEG
+    sites = [
+        site(abi.DIST_NORMAL, c(0.0), c(1.0), 0),                                                    # w
+        site(abi.DIST_NORMAL, c(0.5), c(2.0), 1),                                                    # b
+        site(abi.DIST_BERNOULLI, c(0.3), c(0.0), 2),                                                 # k
+        site(abi.DIST_NORMAL, E([(S, 0, 0), (P_, 0, 0), (MUL, 0, 0), (S, 1, 0), (ADD, 0, 0)]), c(0.5), obs=abi.Arg(abi.ARG_PARAM, 1, 1.0, 0.0, None)),
+        site(abi.DIST_NORMAL, E([(S, 0, 0), (S, 1, 0), (SUB, 0, 0), (S, 0, 0), (S, 1, 0), (SUB, 0, 0), (MUL, 0, 0), (K, 0, 1.0), (SUB, 0, 0)]), c(0.7), 3),
+        site(abi.DIST_GAMMA, E([(S, 0, 0), (S, 0, 0), (MUL, 0, 0), (K, 0, 0.5), (ADD, 0, 0)]), E([(I, 0, 0), (I, 0, 0), (MUL, 0, 0), (K, 0, 1.0), (ADD, 0, 0)]), 4),
+        site(abi.DIST_NORMAL, E([(S, 2, 0), (K, 0, 2.0), (MUL, 0, 0), (S, 5, 0), (SUB, 0, 0), (NEG, 0, 0)]), c(1.0), obs=c(0.4)),
+    ]
+    dtypes = [torch.float32, torch.float32, torch.int32, torch.float32, torch.float32]
+    for n in (20000, 20001, 3):
+        g = torch.Generator().manual_seed(n)
+        col = torch.randn(n, generator=g)
+        kb = W.importance_particle_keys(prng.key(31, impl), n)
+        outs = []
+        for ops in (hip_ops, oracle_ops):
+            plan = ops.plan_create(sites)
+            plan.set_params([1.25, -0.3])
+            vals, score, logw, mp, rows = ops.importance_run(plan, kb, n, [dev(col, ops)], dtypes, want_rows=True)
+            outs.append(vals + [score, logw, mp, rows.e, rows.s])
+        for i, (a, b) in enumerate(zip(*outs)):
+            same(a, b, f"n {n}: output {i}")
+    monkeypatch.setenv("GJX_PLAN_JIT", "0")
+    plan = hip_ops.plan_create(sites)
+    plan.set_params([1.25, -0.3])
+    with pytest.raises(GjxError) as ei:
+        hip_ops.importance_run(plan, W.importance_particle_keys(prng.key(31, impl), 64), 64, [dev(torch.zeros(64), hip_ops)], dtypes)
+    assert ei.value.code == -2  # GJX_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("mode", [0, 1])
 def test_categorical_with_invalid_logits(hip_ops, oracle_ops, impl, mode):
     n, K = 2000, 7
