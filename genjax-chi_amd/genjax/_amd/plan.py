@@ -496,9 +496,12 @@ def _make_plan(tracer):
     cache = getattr(_PLANS, "cache", None)
     if cache is None:
         cache = _PLANS.cache = OrderedDict()
-    arr = (abi.Site * len(tracer.sites))(*tracer.sites)
-    raw = bytes(memoryview(arr))
-    if tracer.expr_progs:  # programs enter the key by content: their addresses differ from trace to trace
+    raw = getattr(tracer, "_table_key", None)  # (a tracer that the trace cache hands back has been keyed before)
+    arr = None
+    if raw is None:
+        arr = (abi.Site * len(tracer.sites))(*tracer.sites)
+        raw = bytes(memoryview(arr))
+    if arr is not None and tracer.expr_progs:  # programs enter the key by content: their addresses differ from trace to trace
         tmp = (abi.Site * len(tracer.sites)).from_buffer_copy(raw)
         progs = []
         for q in range(len(tracer.sites)):
@@ -507,6 +510,7 @@ def _make_plan(tracer):
                     progs.append((q, k, tracer.expr_progs[tmp[q].arg[k].table]))
                     tmp[q].arg[k].table = None
         raw = bytes(memoryview(tmp)) + repr(progs).encode()
+    tracer._table_key = raw
     key = (id(ops), fast, raw)
     hit = cache.get(key)
     if hit is not None:
