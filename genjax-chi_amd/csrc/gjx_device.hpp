@@ -306,6 +306,19 @@ GJX_DEV void store_key(uint32_t* out, uint64_t i, Key k) {
   else reinterpret_cast<uint4*>(out)[i] = make_uint4(k.k0, k.k1, k.l0, k.l1);
 }
 
+// A value the optimiser must treat as unknown (generated kernels: constants whose folding would put a NaN / +inf
+// CONSTANT log-weight into the kernel — invalid parameters, observations outside the support — are kept out of constant
+// propagation: this toolchain's backend dies on such kernels, "SmallVector unable to grow", taking the process with it
+// when the compiler runs in-process).  No instruction: an empty asm with a register constraint.
+#if defined(__HIP_DEVICE_COMPILE__)
+GJX_DEV float opq(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+#else
+GJX_HD float opq(float x) { return x; }
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // f32 math spec.  Cephes logf/expf coefficients; Giles' single-precision erfinv.
 // ------------------------------------------------------------------------------------------------

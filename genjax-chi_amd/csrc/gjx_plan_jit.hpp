@@ -28,10 +28,13 @@ static const char kDeviceHeader[] =
     ;
 
 inline std::string flit(float f) {
-  char b[48];
-  std::snprintf(b, sizeof b, "u2f(0x%08xu)", gjx::f2u(f));
+  char b[64];
+  // (a NaN / infinite literal is kept out of constant propagation: gjx_device.hpp opq)
+  std::snprintf(b, sizeof b, (f - f == 0.0f) ? "u2f(0x%08xu)" : "opq(u2f(0x%08xu))", gjx::f2u(f));
   return b;
 }
+// a finite literal that must still stay opaque (a parameter outside its domain, an observation outside the support)
+inline std::string flit_opaque(float f) { return (f - f == 0.0f) ? "opq(" + flit(f) + ")" : flit(f); }
 inline std::string plit_as(const char* type, const void* p) {
   char b[96];
   std::snprintf(b, sizeof b, "((const %s*)0x%llxull)", type, (unsigned long long)(uintptr_t)p);
@@ -145,12 +148,27 @@ struct SiteEmitter {
         << " >= " << st.n_rows << " ? " << st.n_rows - 1 << " : rr" << Q << ");\n";
       o << ind << "const float* row" << Q << " = " << plit(st.logits) << " + (size_t)rr" << Q << " * " << st.n_cat << ";\n";
     } else {
-      o << ind << "const float a0_" << Q << " = " << arg(st.a0) << ";\n";
-      if (st.dist != GJX_DIST_BERNOULLI) o << ind << "const float a1_" << Q << " = " << arg(st.a1) << ";\n";
+      // a CONSTANT argument outside its domain (scale / rate / concentration <= 0, a probability outside [0, 1]) or an
+      // observed constant outside the support would fold into a NaN / +inf constant log-density: kept opaque (opq)
+      auto carg = [&](const CArgT& a, int which) {
+        if (a.kind != GJX_ARG_CONST) return arg(a);
+        const float v = a.offset;
+        bool ok = v - v == 0.0f;
+        if (st.dist == GJX_DIST_NORMAL) ok = ok && (which == 0 || v > 0.0f);
+        else if (st.dist == GJX_DIST_BERNOULLI) ok = ok && v >= 0.0f && v <= 1.0f;
+        else ok = ok && v > 0.0f;
+        return ok ? flit(v) : flit_opaque(v);
+      };
+      o << ind << "const float a0_" << Q << " = " << carg(st.a0, 0) << ";\n";
+      if (st.dist != GJX_DIST_BERNOULLI) o << ind << "const float a1_" << Q << " = " << carg(st.a1, 1) << ";\n";
     }
     if (st.observed) {
       std::string ov;
-      if (st.obs.kind == GJX_ARG_CONST) ov = flit(st.obs.offset);
+      if (st.obs.kind == GJX_ARG_CONST) {
+        const float v = st.obs.offset;
+        const bool in_support = st.dist == GJX_DIST_GAMMA ? v > 0.0f : (st.dist == GJX_DIST_BETA ? (v > 0.0f && v < 1.0f) : true);
+        ov = in_support ? flit(v) : flit_opaque(v);
+      }
       else if (st.obs.kind == GJX_ARG_OBS) ov = "a.obs[" + std::to_string(st.obs.ref) + "]";
       else if (st.obs.kind == GJX_ARG_PARAM) ov = arg(st.obs);
       else ov = "cols.in[" + std::to_string(st.obs.ref) + "][li" + sfx + "]";
@@ -242,6 +260,11 @@ struct SiteEmitter {
                 : st.cat_ent ? "u2f(" + plit_as("uint2", st.cat_ent) + "[(size_t)rr" + Q + " * " + std::to_string(st.n_cat) + " + " + v + "].y)"
                              : row + "[" + v + "] - jrow_lse(" + row + ", " + std::to_string(st.n_cat) + "u)") + ")";
     }
+    // an observed site whose arguments and value are ALL compile-time constants has a compile-time log-density: opaque, so
+    // that no overflow of valid constants (-inf, +inf) becomes a constant log-weight either
+    const bool all_const = st.observed && st.obs.kind == GJX_ARG_CONST && st.a0.kind == GJX_ARG_CONST &&
+                           (st.dist == GJX_DIST_BERNOULLI || st.dist == GJX_DIST_CATEGORICAL || st.a1.kind == GJX_ARG_CONST);
+    if (all_const) lp = "opq(" + lp + ")";
     o << ind << "{ const float lp = " << lp << "; sc" << sfx << " = sc" << sfx << " + lp;"
       << (st.observed ? " w" + sfx + " = w" + sfx + " + lp;" : "") << " }\n";
     if ((mode == 0 || mode == 2) && st.out_col >= 0 && store_values)
@@ -666,6 +689,14 @@ inline bool enabled() {
 
 // Compile `src` for gfx950; on success `code` holds the code object.
 inline bool compile_to_code(const std::string& src, std::string* code) {
+  // GJX_PLAN_JIT_DUMP_FILE=path: the source about to be compiled (overwritten per compilation: after a compiler crash the
+  // file holds the offending kernel)
+  if (const char* f = std::getenv("GJX_PLAN_JIT_DUMP_FILE")) {
+    if (FILE* fp = fopen(f, "w")) {
+      fwrite(src.data(), 1, src.size(), fp);
+      fclose(fp);
+    }
+  }
   hiprtcProgram prog;
   const char* hn[] = {"gjx_device.hpp"};
   const char* hs[] = {kDeviceHeader};

@@ -156,3 +156,46 @@ def test_hmm_scan_plan_compiles(hip_lib_nogpu):
         plan = hip_lib_nogpu.scan_plan_create([z, y], [A(abi.ARG_SITE, 0, 1.0, 0.0, None)], 1)
         for impl in (0, 1):
             assert plan.compile_check(impl) == 0
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_plans_with_invalid_constants_compile(hip_lib_nogpu, impl):
+    """Compile-time constants that make a log-density NaN / infinite (a negative rate, a gamma observation below zero, NaN
+    and infinite literals, a scale of zero) once put a CONSTANT NaN / +inf log-weight into the generated kernel, and this
+    toolchain's backend died on it ("SmallVector unable to grow") — in-process, taking the caller with it.  Such constants
+    are kept out of constant propagation now (gjx_device.hpp `opq`): the kernels compile, and DESIGN 3.11's GPU tests
+    check what they compute."""
+    ops = hip_lib_nogpu
+    A = abi.Arg
+    c = lambda v: A(abi.ARG_CONST, 0, 0.0, v, None)  # noqa: E731
+
+    def site(dist, a0, a1=None, obs=None, out_col=-1):
+        s_ = abi.Site()
+        s_.dist, s_.observed, s_.out_col = dist, 0 if obs is None else 1, out_col
+        s_.arg[0] = a0
+        if a1 is not None:
+            s_.arg[1] = a1
+        if obs is not None:
+            s_.obs = obs
+        return s_
+
+    nan, inf = float("nan"), float("inf")
+    # the filter the fuzzer found: an observed gamma with rate -1 (its hoisted log-normaliser is NaN) feeding later sites
+    init = [site(abi.DIST_GAMMA, c(1.746), c(-1.0), obs=c(1.827)),
+            site(abi.DIST_BETA, A(abi.ARG_SITE, 0, 1.076, 0.759, None), A(abi.ARG_SITE, 0, 1.468, 0.706, None)),
+            site(abi.DIST_GAMMA, A(abi.ARG_SITE, 1, 0.56, 0.82, None), c(3.0e38))]
+    step = [site(abi.DIST_NORMAL, A(abi.ARG_STATE, 0, 0.8, 0.0, None), c(0.5)),
+            site(abi.DIST_NORMAL, A(abi.ARG_SITE, 0, 1.0, 0.0, None), c(0.0), obs=A(abi.ARG_OBS, 0, 1.0, 0.0, None))]
+    plan = ops.smc_plan_create(init, step, [A(abi.ARG_SITE, 0, 1.0, 0.0, None)], [A(abi.ARG_SITE, 0, 1.0, 0.0, None)], 1)
+    ops.lib.call("gjx_smc_plan_compile_check", plan.handle, impl)
+    tables = [
+        [site(abi.DIST_NORMAL, c(0.0), c(1.0), out_col=0), site(abi.DIST_NORMAL, c(0.0), c(1.0), obs=c(inf))],      # +inf observation, all constant
+        [site(abi.DIST_NORMAL, c(0.0), c(1.0), out_col=0), site(abi.DIST_GAMMA, c(2.0), c(1.5), obs=c(-0.5))],       # below the support
+        [site(abi.DIST_NORMAL, c(0.0), c(1.0), out_col=0), site(abi.DIST_NORMAL, A(abi.ARG_SITE, 0, 1.0, 0.0, None), c(0.0), obs=c(0.3))],  # scale 0
+        [site(abi.DIST_NORMAL, c(nan), c(-1.0), out_col=0), site(abi.DIST_BETA, c(-2.0), c(inf), out_col=1),
+         site(abi.DIST_BERNOULLI, c(1.5), out_col=2), site(abi.DIST_NORMAL, A(abi.ARG_SITE, 1, 1.0, 0.0, None), c(1.0), obs=c(nan))],
+        [site(abi.DIST_GAMMA, c(0.0), c(0.0), out_col=0), site(abi.DIST_NORMAL, c(1.0e38), c(1.0e-38), obs=c(-3.0e38))],
+    ]
+    for sites in tables:
+        plan = ops.plan_create(sites)
+        ops.lib.call("gjx_plan_compile_check", plan.handle, impl)
