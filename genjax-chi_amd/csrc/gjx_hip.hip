@@ -1617,7 +1617,7 @@ static bool expr_ok(const gjx_arg& a, int s, int n_state, int n_obs, bool allow_
       case GJX_EXPR_PARAM: if (n_state >= 0 || r < 0 || r >= GJX_MAX_PARAMS) return false; ++depth; break;
       case GJX_EXPR_STATE: if (n_state < 0 || !allow_state || r < 0 || r >= n_state) return false; ++depth; break;
       case GJX_EXPR_OBS: if (n_state < 0 || r < 0 || r >= n_obs) return false; ++depth; break;
-      case GJX_EXPR_ADD: case GJX_EXPR_SUB: case GJX_EXPR_MUL: if (depth < 2) return false; --depth; break;
+      case GJX_EXPR_ADD: case GJX_EXPR_SUB: case GJX_EXPR_MUL: case GJX_EXPR_DIV: if (depth < 2) return false; --depth; break;
       case GJX_EXPR_NEG: if (depth < 1) return false; break;
       default: return false;
     }

@@ -96,7 +96,7 @@ struct SiteEmitter {
             default: {
               const std::string b = st.back();
               st.pop_back();
-              const char* op = ops[k].op == GJX_EXPR_ADD ? " + " : (ops[k].op == GJX_EXPR_SUB ? " - " : " * ");
+              const char* op = ops[k].op == GJX_EXPR_ADD ? " + " : (ops[k].op == GJX_EXPR_SUB ? " - " : (ops[k].op == GJX_EXPR_MUL ? " * " : " / "));
               st.back() = "(" + st.back() + op + b + ")";
             }
           }

@@ -37,7 +37,7 @@ LSE_RECORD_WORDS = 65  # include/gjx.h: GJX_LSE_RECORD_WORDS
 DIST_NORMAL, DIST_GAMMA, DIST_BETA, DIST_BERNOULLI, DIST_CATEGORICAL = range(5)
 ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE, ARG_STATE, ARG_OBS, ARG_PARAM, ARG_EXPR = range(8)
 # postfix programs as distribution arguments (gjx.h: GJX_ARG_EXPR / gjx_expr_op)
-EXPR_CONST, EXPR_SITE, EXPR_INPUT, EXPR_PARAM, EXPR_STATE, EXPR_OBS, EXPR_ADD, EXPR_SUB, EXPR_MUL, EXPR_NEG = range(10)
+EXPR_CONST, EXPR_SITE, EXPR_INPUT, EXPR_PARAM, EXPR_STATE, EXPR_OBS, EXPR_ADD, EXPR_SUB, EXPR_MUL, EXPR_NEG, EXPR_DIV = range(11)
 MAX_EXPR_OPS, MAX_EXPR_DEPTH = 16, 8
 MAX_PARAMS = 64
 SMC_MAX_STATE, SMC_MAX_OBS = 4, 8

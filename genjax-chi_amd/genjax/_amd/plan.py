@@ -100,7 +100,13 @@ class Sym:
     def _no(self, *a, **k):
         raise PlanUnsupported("unsupported operation on a traced site value")
 
-    __truediv__ = __rtruediv__ = __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
+    def __truediv__(self, c):  # (x / c is NOT x * (1 / c): a true division, as torch computes it)
+        return SymExpr.binop(abi.EXPR_DIV, self, c)
+
+    def __rtruediv__(self, c):
+        return SymExpr.binop(abi.EXPR_DIV, c, self)
+
+    __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
     __lt__ = __le__ = __gt__ = __ge__ = __abs__ = __index__ = __array__ = __len__ = __iter__ = _no
 
     @classmethod
@@ -128,7 +134,7 @@ class _Rows:
 
 class SymExpr:
     """A traced f32 value beyond one affine step — `w * x + b` over two sites, `(z - m) * (z - m)`, ... — as the postfix
-    program of `abi.ARG_EXPR`: operands push a value, `+ - *` pop two, unary minus one; every operator is one f32 rounding,
+    program of `abi.ARG_EXPR`: operands push a value, `+ - * /` pop two, unary minus one; every operator is one f32 rounding,
     in the order the model body wrote it (what the per-site column path computes with torch's f32 tensor arithmetic)."""
 
     __slots__ = ("tracer", "prog")
@@ -173,6 +179,11 @@ class SymExpr:
 
     @classmethod
     def binop(cls, op, a, b):
+        if op == abi.EXPR_DIV and not (isinstance(a, (Sym, SymExpr)) and isinstance(b, (Sym, SymExpr))):
+            # torch divides a device tensor by a NUMBER as a multiplication by the number's reciprocal, and a number by a
+            # tensor through a reciprocal kernel: neither is the IEEE division the program's `/` is.  Only a quotient of two
+            # traced values (tensor / tensor: a true division on every backend) lowers; the rest takes the per-site path.
+            raise PlanUnsupported("division by / of a constant")
         tr = next((v.tracer for v in (a, b) if isinstance(v, (Sym, SymExpr))), None)
         _, pa = cls.program_of(a, tr)
         _, pb = cls.program_of(b, tr)
@@ -190,11 +201,13 @@ class SymExpr:
     def __mul__(self, o): return SymExpr.binop(abi.EXPR_MUL, self, o)  # noqa: E704
     def __rmul__(self, o): return SymExpr.binop(abi.EXPR_MUL, o, self)  # noqa: E704
     def __neg__(self): return SymExpr.unop(abi.EXPR_NEG, self)  # noqa: E704
+    def __truediv__(self, o): return SymExpr.binop(abi.EXPR_DIV, self, o)  # noqa: E704
+    def __rtruediv__(self, o): return SymExpr.binop(abi.EXPR_DIV, o, self)  # noqa: E704
 
     def _no(self, *a, **k):
         raise PlanUnsupported("unsupported operation on a traced expression")
 
-    __truediv__ = __rtruediv__ = __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
+    __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
     __lt__ = __le__ = __gt__ = __ge__ = __abs__ = __index__ = __array__ = __len__ = __iter__ = _no
 
     @classmethod
@@ -218,7 +231,7 @@ class SymExpr:
                 a = st.pop()
                 if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.device != b.device:
                     a, b = (a.to(b.device), b) if a.dim() == 0 else (a, b.to(a.device))
-                st.append(a + b if op == abi.EXPR_ADD else (a - b if op == abi.EXPR_SUB else a * b))
+                st.append(a + b if op == abi.EXPR_ADD else (a - b if op == abi.EXPR_SUB else (a * b if op == abi.EXPR_MUL else a / b)))
         return st[0]
 
 

@@ -170,7 +170,7 @@ typedef enum {
                         without changing the model's structure.  libgjx_hip.so passes them as kernel arguments
                         (scalar registers), so one specialised kernel serves every dataset: no recompilation. */
   GJX_ARG_EXPR = 7   /* value = a small POSTFIX PROGRAM over earlier sites, input columns, parameters / state / observation
-                        constants and literals: `table` points at `ref` gjx_expr_op entries in HOST memory (copied at plan
+                        constants and literals (+ - * / and negation): `table` points at `ref` gjx_expr_op entries in HOST memory (copied at plan
                         creation).  What a model body writes between its `@` sites — `normal(w * x + b, s)`
                         (static.py:340-380 runs that arithmetic as traced jnp ops) — evaluated per particle in f32, one
                         rounding per operation, in program order (no fusion).  Distribution arguments of sites only (not
@@ -189,7 +189,8 @@ typedef enum {
   GJX_EXPR_ADD = 6,   /* pop b, pop a, push a + b */
   GJX_EXPR_SUB = 7,   /* ... a - b */
   GJX_EXPR_MUL = 8,   /* ... a * b */
-  GJX_EXPR_NEG = 9    /* pop a, push -a */
+  GJX_EXPR_NEG = 9,   /* pop a, push -a */
+  GJX_EXPR_DIV = 10   /* pop b, pop a, push a / b (IEEE, correctly rounded) */
 } gjx_expr_opcode;
 typedef struct {
   int32_t op;   /* gjx_expr_opcode */

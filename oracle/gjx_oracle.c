@@ -310,7 +310,7 @@ static int expr_ok(const gjx_arg* a, int s, int n_state, int n_obs, int allow_st
       case GJX_EXPR_PARAM: if (n_state >= 0 || ops[k].ref < 0 || ops[k].ref >= GJX_MAX_PARAMS) return 0; ++depth; break;
       case GJX_EXPR_STATE: if (n_state < 0 || !allow_state || ops[k].ref < 0 || ops[k].ref >= n_state) return 0; ++depth; break;
       case GJX_EXPR_OBS: if (n_state < 0 || ops[k].ref < 0 || ops[k].ref >= n_obs) return 0; ++depth; break;
-      case GJX_EXPR_ADD: case GJX_EXPR_SUB: case GJX_EXPR_MUL: if (depth < 2) return 0; --depth; break;
+      case GJX_EXPR_ADD: case GJX_EXPR_SUB: case GJX_EXPR_MUL: case GJX_EXPR_DIV: if (depth < 2) return 0; --depth; break;
       case GJX_EXPR_NEG: if (depth < 1) return 0; break;
       default: return 0;
     }
@@ -457,6 +457,7 @@ static inline float eval_arg(const gjx_arg* a, const site_val* vals, const walk_
           case GJX_EXPR_ADD: { const float r = st[d - 2] + st[d - 1]; st[--d - 1] = r; break; }
           case GJX_EXPR_SUB: { const float r = st[d - 2] - st[d - 1]; st[--d - 1] = r; break; }
           case GJX_EXPR_MUL: { const float r = st[d - 2] * st[d - 1]; st[--d - 1] = r; break; }
+          case GJX_EXPR_DIV: { const float r = st[d - 2] / st[d - 1]; st[--d - 1] = r; break; }
           default: st[d - 1] = -st[d - 1]; break; /* GJX_EXPR_NEG */
         }
       }

@@ -144,6 +144,8 @@ def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
                     depth -= 1
                 if rng.random() < 0.15:
                     prog.append((abi.EXPR_NEG, 0, 0.0))
+                if rng.random() < 0.2 and len(prog) < 12:  # a division by a constant away from zero
+                    prog += [(abi.EXPR_CONST, 0, maybe_bad(float(rng.choice([-1, 1]) * rng.uniform(0.5, 3.0)))), (abi.EXPR_DIV, 0, 0.0)]
             while depth >= 2:
                 prog.append((int(rng.choice([abi.EXPR_ADD, abi.EXPR_SUB, abi.EXPR_MUL])), 0, 0.0))
                 depth -= 1

@@ -419,14 +419,15 @@ def case_expression_arguments(impl):
         r = normal(slope_scale * w + 0.25 - q * 3.0, s * 2.0) @ "r"   # a launch parameter times a site, three terms
         u = gamma(w * w + 0.5, b * b + 1.0) @ "u"
         t = normal(k * 2.0 - u, 1.0) @ "t"                       # an integer-valued site in arithmetic
-        return w * 2.0 + b * b - 1.0, -(q * r)
+        d = normal(w / u - b / (u + 2.0), q * q + 0.1) @ "d"      # quotients of traced values: IEEE divisions
+        return w * 2.0 + b * b - 1.0, -(q * r) / (d * d + 1.0)
 
     n = 4000
     keys = genjax.random.split(genjax.random.key(21, impl), n)
     col = torch.linspace(-2, 2, n).to(_dev())
     for chm in (C.n(),
                 C["y", 0].set(0.3) | C["y", 1].set(-0.2) | C["y", 2].set(1.1) | C["y", 3].set(0.05) | C["t"].set(0.4),
-                C["q"].set(col) | C["u"].set(1.5) | C["y", 2].set(0.0)):
+                C["q"].set(col) | C["r"].set(-0.75) | C["y", 2].set(0.0)):
         fused = try_fused_generate(regression, keys, chm, (0.5, 1.75))
         assert fused is not None, "expression arguments must lower to the fused kernel"
         ftr, fw = fused
@@ -445,19 +446,27 @@ def case_expression_arguments(impl):
                 assert torch.equal(a_, b_.to(a_.dtype) if isinstance(b_, torch.Tensor) else torch.full_like(a_, b_)), key_
         for fr, er in zip(ftr.get_retval(), eager.get_retval()):
             assert torch.equal(fr, er)
-        for addr in ("q", "r", "u", "t", ("y", 1)):
+        for addr in ("q", "r", "u", "t", "d", ("y", 1)):
             assert torch.equal(torch.as_tensor(ftr.get_subtrace(addr).get_score()).to(torch.float32).expand(n),
                                torch.as_tensor(eager.get_subtrace(addr).get_score()).to(torch.float32).expand(n)), addr
     # the same structure on another dataset: parameters, not a new kernel (the plan cache keys on the programs' CONTENT)
     tr1 = P._traced(regression, C["y", 0].set(0.3), n, (0.5, 1.75))
     tr2 = P._traced(regression, C["y", 0].set(-0.9), n, (0.8, -0.3))
     assert tr1 is not None and tr2 is not None and P._make_plan(tr1[0]) is P._make_plan(tr2[0])
-    # what does NOT lower still runs (division by a traced value): the per-site path
+    # what does NOT lower still runs on the per-site path: a transcendental function of a traced value (torch's device exp
+    # is not the spec's), a division by a NUMBER (torch multiplies a device tensor by the reciprocal instead)
     @gen
     def ratio():
         a = normal(0.0, 1.0) @ "a"
         c = gamma(2.0, 1.0) @ "c"
-        return normal(a / c, 1.0) @ "d"
+        return normal(a, torch.exp(c * 0.1)) @ "d"
+
+    @gen
+    def halves():
+        a = normal(0.0, 1.0) @ "a"
+        return normal(a / 3.0, 1.0) @ "d"
+
+    assert try_fused_generate(halves, keys, C.n(), ()) is None
 
     assert try_fused_generate(ratio, keys, C.n(), ()) is None
     tr, w = ratio.importance(keys, C["d"].set(0.1), ())

@@ -121,7 +121,8 @@ def test_expression_programs_are_validated(lib_ops):
     keep = []
     E = lambda prog: abi.expr_arg(prog, keep)
     z = _site(abi.DIST_NORMAL, c(0.0), c(1.0), out_col=0)
-    ok = [(abi.EXPR_SITE, 0, 0.0), (abi.EXPR_CONST, 0, 2.0), (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_PARAM, 1, 0.0), (abi.EXPR_ADD, 0, 0.0)]
+    ok = [(abi.EXPR_SITE, 0, 0.0), (abi.EXPR_CONST, 0, 2.0), (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_PARAM, 1, 0.0), (abi.EXPR_ADD, 0, 0.0),
+          (abi.EXPR_CONST, 0, 3.0), (abi.EXPR_DIV, 0, 0.0)]
     plan = ops.plan_create([z, _site(abi.DIST_NORMAL, E(ok), c(1.0), out_col=1)])
     with pytest.raises(GjxError):  # the program reads parameter 1: two values are needed
         plan.set_params([0.5])
