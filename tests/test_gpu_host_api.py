@@ -197,3 +197,14 @@ def test_fast_math_context(hip_ops, impl):
             assert float((a - b).abs().max()) < 2e-5
     if impl == "philox":
         assert not torch.equal(exact[0], fast[0])  # the fast plan really ran
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_random_models_fused_equals_per_site(hip_ops, impl):
+    """tests/fuzz_models.py on the device: random `@gen` bodies — the specialised kernel a body lowers to equals the per-site
+    column path (the library's per-site kernels + torch's device arithmetic between the sites) bit for bit."""
+    import fuzz_models
+
+    with use_ops(hip_ops):
+        compared, skipped = fuzz_models.run(12.0, 31 + impl, impl, n=3000)
+    assert compared > 5 and skipped < compared

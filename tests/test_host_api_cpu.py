@@ -12,3 +12,13 @@ from genjax._amd.runtime import use_ops
 def test_host_api(oracle_ops, case, impl):
     with use_ops(oracle_ops):
         case(impl)
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_random_models_fused_equals_per_site(oracle_ops, impl):
+    """tests/fuzz_models.py: random `@gen` bodies — the fused kernel a body lowers to equals the per-site column path."""
+    import fuzz_models
+
+    with use_ops(oracle_ops):
+        compared, skipped = fuzz_models.run(6.0, 11 + impl, impl)
+    assert compared > 200 and skipped < compared
