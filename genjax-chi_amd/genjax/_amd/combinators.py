@@ -45,6 +45,18 @@ def _stack_time(items: list, batched: bool):
     return None
 
 
+def _float_leaves_to_f32(v):
+    if isinstance(v, float):
+        return torch.tensor(v, dtype=torch.float32)
+    if isinstance(v, tuple):
+        return tuple(_float_leaves_to_f32(x) for x in v)
+    if isinstance(v, list):
+        return [_float_leaves_to_f32(x) for x in v]
+    if isinstance(v, dict):
+        return {k: _float_leaves_to_f32(x) for k, x in v.items()}
+    return v
+
+
 class ScanTrace(Trace):
     def __init__(self, gen_fn, step_traces: list, args, retval, score, batched: bool):
         self.gen_fn, self.step_traces, self.args, self.retval, self.score = gen_fn, step_traces, args, retval, score
@@ -133,6 +145,10 @@ class Scan(GenerativeFunction):
 
     def _run(self, key, args, step):
         carry, xs = args
+        # `lax.scan` makes every carry leaf an array: a Python float enters as float32, so the arithmetic a kernel does on a
+        # carried scalar (`v * 1.45`, step after step) is f32 arithmetic — as in the one-launch scan, where it is a state
+        # column — not Python's float64
+        carry = _float_leaves_to_f32(carry)
         pk, batched = as_particle_keys(key)
         T = self._length(xs)
         traces, ys, score, weight = [], [], 0.0, 0.0

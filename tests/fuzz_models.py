@@ -127,3 +127,76 @@ def run(seconds: float, seed: int, impl: int = 1, n: int = 1500):
         assert _same(ftr.get_retval(), eager.get_retval()), "return values differ" + ctx
         compared += 1
     return compared, skipped
+
+
+# ---- random scan kernels: the one-launch scan (gjx_scan_run) against the host loop of per-site launches ------------------
+def random_step(rng):
+    lines, reals, poss, units, sites = [], ["x", "v"], [], [], []
+    params = ["u"]
+    for q in range(int(rng.integers(2, 6))):
+        name = f"s{q}"
+        kind = rng.choice(["normal", "normal", "gamma", "beta"])
+        pool = reals + poss + units
+        if kind == "normal":
+            lines.append(f"    {name} = normal({_expr(rng, pool, params)}, {_pos(rng, pool, poss, [])}) @ '{name}'")
+            reals.append(name)
+        elif kind == "gamma":
+            lines.append(f"    {name} = gamma({_pos(rng, pool, poss, [])}, {_pos(rng, pool, poss, [])}) @ '{name}'")
+            poss.append(name)
+        else:
+            lines.append(f"    {name} = beta({_pos(rng, pool, poss, [])}, {_pos(rng, pool, poss, [])}) @ '{name}'")
+            units.append(name)
+        sites.append((name, kind))
+    new = [n for n, _ in sites]
+    cx, cv = str(rng.choice(new)), str(rng.choice(new + ["v"]))
+    if rng.random() < 0.4:
+        cv = f"({cv} * {round(float(rng.uniform(0.5, 1.5)), 2)})"
+    y = _expr(rng, new, params)
+    src = ("def step(carry, u):\n    x, v = carry\n" + "\n".join(lines) + f"\n    return ({cx}, {cv}), ({y}, {new[0]})\n")
+    return src, sites
+
+
+def run_scans(seconds: float, seed: int, impl: int = 1, n: int = 800):
+    from genjax._amd import combinators as CB
+
+    rng = np.random.default_rng(seed)
+    dev = get_ops().device()
+    t_end, compared, skipped = time.time() + seconds, 0, 0
+    while time.time() < t_end:
+        src, sites = random_step(rng)
+        ns = {"normal": normal, "gamma": gamma, "beta": beta, "flip": flip}
+        exec(src, ns)  # noqa: S102 - generated by random_step above
+        T = int(rng.integers(1, 7))
+        model = gen(ns["step"]).scan()
+        us = torch.linspace(0.2, 1.4, T).to(dev)
+        keys = genjax.random.split(genjax.random.key(int(rng.integers(1 << 30)), impl), n)
+        chm = C.n()
+        for name, kind in sites:
+            if rng.random() < 0.4:
+                lo, hi = {"normal": (-2, 2), "gamma": (0.2, 3), "beta": (0.1, 0.9)}[kind]
+                chm = chm | C[name].set(torch.linspace(lo, hi, T))
+        x0 = torch.linspace(-1, 1, n).to(dev) if rng.random() < 0.5 else 0.25
+        args = ((x0, -0.5), us)
+        out = {}
+        for fused in (True, False):
+            CB.FUSED_SCAN = fused
+            try:
+                tr, w = model.generate(keys, chm, args)
+            finally:
+                CB.FUSED_SCAN = True
+            out[fused] = (tr, w)
+        if not isinstance(out[True][0], CB.FusedScanTrace):
+            skipped += 1
+            continue
+        (ta, wa), (tb, wb) = out[True], out[False]
+        ctx = f"\n{src}\nT {T} constraint {list(dict(chm.leaves()).keys())} seed {seed}"
+        wb = wb if isinstance(wb, torch.Tensor) else torch.zeros(n) + wb
+        assert _same(wa, wb), "weights differ" + ctx
+        assert _same(ta.get_score(), tb.get_score()), "scores differ" + ctx
+        ca, cb = dict(ta.get_choices().leaves()), dict(tb.get_choices().leaves())
+        assert ca.keys() == cb.keys(), "addresses differ" + ctx
+        for k in ca:
+            assert _same(ca[k], cb[k]), f"choice {k} differs" + ctx
+        assert _same(ta.get_retval(), tb.get_retval()), "return values differ" + ctx
+        compared += 1
+    return compared, skipped

@@ -208,3 +208,12 @@ def test_random_models_fused_equals_per_site(hip_ops, impl):
     with use_ops(hip_ops):
         compared, skipped = fuzz_models.run(12.0, 31 + impl, impl, n=3000)
     assert compared > 5 and skipped < compared
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_random_scan_kernels_fused_equals_loop(hip_ops, impl):
+    import fuzz_models
+
+    with use_ops(hip_ops):
+        compared, skipped = fuzz_models.run_scans(12.0, 41 + impl, impl, n=2000)
+    assert compared > 3 and skipped < compared

@@ -22,3 +22,14 @@ def test_random_models_fused_equals_per_site(oracle_ops, impl):
     with use_ops(oracle_ops):
         compared, skipped = fuzz_models.run(6.0, 11 + impl, impl)
     assert compared > 200 and skipped < compared
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_random_scan_kernels_fused_equals_loop(oracle_ops, impl):
+    """tests/fuzz_models.py: random scan kernels (tuple carry, a scanned input, expressions over carry / sites / input) — the
+    one-launch scan equals the host loop of per-site launches."""
+    import fuzz_models
+
+    with use_ops(oracle_ops):
+        compared, skipped = fuzz_models.run_scans(6.0, 17 + impl, impl)
+    assert compared > 100 and skipped < compared
