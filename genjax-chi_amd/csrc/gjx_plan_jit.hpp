@@ -151,12 +151,27 @@ struct SiteEmitter {
       // a CONSTANT argument outside its domain (scale / rate / concentration <= 0, a probability outside [0, 1]) or an
       // observed constant outside the support would fold into a NaN / +inf constant log-density: kept opaque (opq)
       auto carg = [&](const CArgT& a, int which) {
-        if (a.kind != GJX_ARG_CONST) return arg(a);
-        const float v = a.offset;
+        float v = a.offset;
+        if (a.kind == GJX_ARG_EXPR) {  // a program over literals only is a constant too: its value, by the program's own steps
+          const gjx_expr_op* ops = reinterpret_cast<const gjx_expr_op*>(a.table);
+          float stk[8];
+          int d = 0;
+          for (int k = 0; k < a.ref; ++k) {
+            if (ops[k].op >= GJX_EXPR_SITE && ops[k].op <= GJX_EXPR_OBS) return arg(a);  // (not a constant)
+            if (ops[k].op == GJX_EXPR_CONST) { stk[d++] = ops[k].value; continue; }
+            if (ops[k].op == GJX_EXPR_NEG) { stk[d - 1] = -stk[d - 1]; continue; }
+            const float y = stk[--d], x = stk[d - 1];
+            stk[d - 1] = ops[k].op == GJX_EXPR_ADD ? x + y : (ops[k].op == GJX_EXPR_SUB ? x - y : (ops[k].op == GJX_EXPR_MUL ? x * y : x / y));
+          }
+          v = stk[0];
+        } else if (a.kind != GJX_ARG_CONST) {
+          return arg(a);
+        }
         bool ok = v - v == 0.0f;
         if (st.dist == GJX_DIST_NORMAL) ok = ok && (which == 0 || v > 0.0f);
         else if (st.dist == GJX_DIST_BERNOULLI) ok = ok && v >= 0.0f && v <= 1.0f;
         else ok = ok && v > 0.0f;
+        if (a.kind == GJX_ARG_EXPR) return ok ? arg(a) : "opq(" + arg(a) + ")";
         return ok ? flit(v) : flit_opaque(v);
       };
       o << ind << "const float a0_" << Q << " = " << carg(st.a0, 0) << ";\n";
@@ -262,8 +277,16 @@ struct SiteEmitter {
     }
     // an observed site whose arguments and value are ALL compile-time constants has a compile-time log-density: opaque, so
     // that no overflow of valid constants (-inf, +inf) becomes a constant log-weight either
-    const bool all_const = st.observed && st.obs.kind == GJX_ARG_CONST && st.a0.kind == GJX_ARG_CONST &&
-                           (st.dist == GJX_DIST_BERNOULLI || st.dist == GJX_DIST_CATEGORICAL || st.a1.kind == GJX_ARG_CONST);
+    auto is_const = [](const CArgT& a) {  // a literal, or a program over literals only
+      if (a.kind == GJX_ARG_CONST) return true;
+      if (a.kind != GJX_ARG_EXPR) return false;
+      const gjx_expr_op* ops = reinterpret_cast<const gjx_expr_op*>(a.table);
+      for (int k = 0; k < a.ref; ++k)
+        if (ops[k].op >= GJX_EXPR_SITE && ops[k].op <= GJX_EXPR_OBS) return false;
+      return true;
+    };
+    const bool all_const = st.observed && st.obs.kind == GJX_ARG_CONST && is_const(st.a0) &&
+                           (st.dist == GJX_DIST_BERNOULLI || st.dist == GJX_DIST_CATEGORICAL || is_const(st.a1));
     if (all_const) lp = "opq(" + lp + ")";
     o << ind << "{ const float lp = " << lp << "; sc" << sfx << " = sc" << sfx << " + lp;"
       << (st.observed ? " w" + sfx + " = w" + sfx + " + lp;" : "") << " }\n";

@@ -196,6 +196,12 @@ def test_plans_with_invalid_constants_compile(hip_lib_nogpu, impl):
          site(abi.DIST_BERNOULLI, c(1.5), out_col=2), site(abi.DIST_NORMAL, A(abi.ARG_SITE, 1, 1.0, 0.0, None), c(1.0), obs=c(nan))],
         [site(abi.DIST_GAMMA, c(0.0), c(0.0), out_col=0), site(abi.DIST_NORMAL, c(1.0e38), c(1.0e-38), obs=c(-3.0e38))],
     ]
+    keep = []
+    neg = abi.expr_arg([(abi.EXPR_CONST, 0, 1.0), (abi.EXPR_CONST, 0, 3.0), (abi.EXPR_SUB, 0, 0.0)], keep)       # 1 - 3: a negative scale
+    zero_by_zero = abi.expr_arg([(abi.EXPR_CONST, 0, 0.0), (abi.EXPR_CONST, 0, 0.0), (abi.EXPR_DIV, 0, 0.0)], keep)
+    tables.append([site(abi.DIST_NORMAL, c(0.0), c(1.0), out_col=0),                                             # programs over literals only
+                   site(abi.DIST_NORMAL, A(abi.ARG_SITE, 0, 1.0, 0.0, None), neg, obs=A(abi.ARG_INPUT, 0, 1.0, 0.0, None)),
+                   site(abi.DIST_NORMAL, zero_by_zero, c(1.0), obs=c(0.2)), site(abi.DIST_GAMMA, neg, neg, out_col=1)])
     for sites in tables:
         plan = ops.plan_create(sites)
         ops.lib.call("gjx_plan_compile_check", plan.handle, impl)
