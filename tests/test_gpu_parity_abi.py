@@ -1135,6 +1135,19 @@ def test_importance_beyond_4g_bytes_per_column(hip_ops, oracle_ops):
         assert torch.equal(a, b), f"output {i}"
 
 
+def test_random_resampling_fuzz(hip_ops):
+    """tests/fuzz_resample.py: random sizes and weight patterns through the generic resamplers, the log-sum-exp and short
+    collapsing filters — the heavy-tile / idle-tile / extra-workgroup paths of the resampling kernel against the oracle."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_resample.py"), "20", "5"], capture_output=True, text=True,
+                       timeout=400)
+    assert r.returncode == 0 and "resample fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("seconds,seed,p_invalid", [("25", "7", "0"), ("15", "3", "0.2")])
 def test_random_plans_fuzz(hip_ops, seconds, seed, p_invalid):
     """A short run of tests/fuzz_parity.py (random site tables, sizes, generators; importance, scan and generated-SMC
