@@ -489,3 +489,26 @@ def check_native_lse_combine(ops, world=3):
 
 def test_native_lse_combine(oracle_ops):
     check_native_lse_combine(oracle_ops)
+
+
+def random_sharded_configs(ops, seed, count, ref_ops=None):
+    """`count` random sharded filters over virtual ranks — world 2..6, 1..3 tiles per rank, both models, both generators, both
+    shuffles, every-step or ESS-adaptive, the Python and the native C driver — each equal to its single-rank run."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    for _ in range(count):
+        world = int(rng.integers(2, 7))
+        n_total = 1024 * world * int(rng.integers(1, 4))
+        kind = str(rng.choice(["lgssm", "hmm"]))
+        cfg = dict(impl=int(rng.integers(2)), T=int(rng.integers(2, 9)), exchange=str(rng.choice(["ranges", "allgather"])),
+                   ess_threshold=float(rng.choice([0.0, 0.0, 0.5])), native=bool(rng.integers(2)))
+        try:
+            check_virtual_ranks(ops, kind, cfg["impl"], world, n_total, cfg["T"], cfg["exchange"], ref_ops=ref_ops,
+                                ess_threshold=cfg["ess_threshold"], native=cfg["native"])
+        except AssertionError as e:
+            raise AssertionError(f"sharded != single-rank for {kind} world {world} n {n_total} {cfg}") from e
+
+
+def test_random_sharded_configurations(oracle_ops):
+    random_sharded_configs(oracle_ops, 3, 14)

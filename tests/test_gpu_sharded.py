@@ -121,3 +121,11 @@ def test_sharded_tile_sums_forms(hip_ops, oracle_ops, form):
     check_virtual_ranks(hip_ops, "lgssm", 1, 3, 1024 * 3 * 5, 9, "ranges", ref_ops=oracle_ops, tile_sums_form=form)
     check_virtual_ranks(hip_ops, "hmm", 0, 2, 1024 * 2 * 7, 9, "ranges", ref_ops=oracle_ops, ess_threshold=0.5,
                         tile_sums_form=form)
+
+
+def test_random_sharded_configurations_on_device(hip_ops, oracle_ops):
+    """Random sharded filters over virtual ranks on the HIP kernels (Python and native drivers), each against the ORACLE's
+    single-rank run."""
+    from test_distributed_gloo import random_sharded_configs
+
+    random_sharded_configs(hip_ops, 9, 10, ref_ops=oracle_ops)
