@@ -1679,6 +1679,17 @@ static bool convert_site(const gjx_site& st, int s, CSite& c, int n_state = -1, 
   return true;
 }
 
+// programs of state arguments (init_state / next_state of SMC and scan plans)
+struct StateExprStore {
+  gjx_expr_op ops[GJX_SMC_MAX_STATE][GJX_MAX_EXPR_OPS];
+};
+static void state_expr_adopt(CArg* args, int n, StateExprStore* store) {
+  for (int k = 0; k < n; ++k)
+    if (args[k].kind == GJX_ARG_EXPR) {
+      memcpy(store->ops[k], args[k].table, sizeof(gjx_expr_op) * (size_t)args[k].ref);
+      args[k].table = reinterpret_cast<const float*>(store->ops[k]);
+    }
+}
 static bool expr_adopt(CSite* sites, int n, ExprStore* store) {  // -> does the table hold any program?
   bool any = false;
   for (int q = 0; q < n; ++q) {
@@ -2566,6 +2577,7 @@ struct gjx_scan_plan {
   std::vector<void*> dev_owned;  // per-row tables of categorical sites
   std::mutex mu;
   ExprStore step_expr;  // GJX_ARG_EXPR programs
+  StateExprStore next_state_expr;
 };
 int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan** out) {
   if (!m || !out || (flags & ~(uint32_t)GJX_PLAN_FAST_MATH) || m->n_state < 1 || m->n_state > GJX_SMC_MAX_STATE ||
@@ -2577,8 +2589,7 @@ int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan*
   bool ok = true;
   for (int s = 0; ok && s < p->n_step; ++s) ok = convert_site(m->step_sites[s], s, p->step[s], m->n_state, m->n_obs, true);
   for (int k = 0; ok && k < p->n_state; ++k) {
-    ok = arg_ok(m->next_state[k], p->n_step, m->n_state, m->n_obs, true) && m->next_state[k].kind != GJX_ARG_TABLE &&
-         m->next_state[k].kind != GJX_ARG_EXPR;
+    ok = arg_ok(m->next_state[k], p->n_step, m->n_state, m->n_obs, true) && m->next_state[k].kind != GJX_ARG_TABLE;
     p->next_state[k] = carg(m->next_state[k]);
   }
   if (!ok) {
@@ -2586,6 +2597,7 @@ int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan*
     return GJX_ERR_INVALID;
   }
   (void)expr_adopt(p->step, p->n_step, &p->step_expr);
+  state_expr_adopt(p->next_state, p->n_state, &p->next_state_expr);
   *out = p;
   return GJX_OK;
 }
@@ -2667,6 +2679,7 @@ struct gjx_smc_plan {
   std::vector<void*> dev_owned;  // per-row tables of categorical sites
   std::mutex mu;
   ExprStore init_expr, step_expr;  // GJX_ARG_EXPR programs of the two tables
+  StateExprStore init_state_expr, next_state_expr;
 };
 
 int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
@@ -2682,9 +2695,7 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
   for (int s = 0; ok && s < p->n_step; ++s) ok = convert_site(m->step_sites[s], s, p->step[s], m->n_state, m->n_obs, true);
   for (int k = 0; ok && k < p->n_state; ++k) {
     ok = arg_ok(m->init_state[k], p->n_init, m->n_state, m->n_obs, false) && m->init_state[k].kind != GJX_ARG_TABLE &&
-         m->init_state[k].kind != GJX_ARG_EXPR &&
-         arg_ok(m->next_state[k], p->n_step, m->n_state, m->n_obs, true) && m->next_state[k].kind != GJX_ARG_TABLE &&
-         m->next_state[k].kind != GJX_ARG_EXPR;
+         arg_ok(m->next_state[k], p->n_step, m->n_state, m->n_obs, true) && m->next_state[k].kind != GJX_ARG_TABLE;
     p->init_state[k] = carg(m->init_state[k]);
     p->next_state[k] = carg(m->next_state[k]);
   }
@@ -2694,6 +2705,8 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
   }
   (void)expr_adopt(p->init, p->n_init, &p->init_expr);
   (void)expr_adopt(p->step, p->n_step, &p->step_expr);
+  state_expr_adopt(p->init_state, p->n_state, &p->init_state_expr);
+  state_expr_adopt(p->next_state, p->n_state, &p->next_state_expr);
   *out = p;
   return GJX_OK;
 }

@@ -108,9 +108,7 @@ def lower_scan(kernel_gen_fn, carry0, xs, obs_addrs: list[tuple], fast_math: boo
     for v in nc_leaves:
         if isinstance(v, _Table):
             raise PlanUnsupported("a table lookup cannot be a carry component")
-        if isinstance(v, SymExpr):
-            raise PlanUnsupported("the next carry must be a site value (or one affine step of a site / carry / input)")
-        next_state.append(tr._arg(v))
+        next_state.append(tr._arg(v))  # (an expression over sites / the carry / the input is a postfix program)
     y_leaves: list = []
     _flatten(y, y_leaves)
     for v in y_leaves:  # y_t must be recoverable from what the launch stores
@@ -139,6 +137,9 @@ def lower_scan(kernel_gen_fn, carry0, xs, obs_addrs: list[tuple], fast_math: boo
     for _ in range(len(uniform)):
         for k, a in enumerate(next_state):
             if a.kind == abi.ARG_SITE or a.kind == abi.ARG_TABLE or (a.kind == abi.ARG_STATE and not uniform[a.ref]):
+                uniform[k] = False
+            if a.kind == abi.ARG_EXPR and any(op == abi.EXPR_SITE or (op == abi.EXPR_STATE and not uniform[ref])
+                                              for op, ref, _ in tr.expr_progs[a.table]):
                 uniform[k] = False
     low.uniform_carry = uniform
     # a carry component that IS an integer-valued site (an HMM's state) is presented in the site's dtype (the kernel's

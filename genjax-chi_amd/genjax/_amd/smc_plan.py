@@ -31,7 +31,7 @@ import torch
 from . import abi
 from .choicemap import ChoiceMap
 from .lang import GenerativeFunction, StaticGenerativeFunction
-from .plan import PlanTracer, PlanUnsupported, Sym, SymExpr, _Table
+from .plan import PlanTracer, PlanUnsupported, Sym, _Table
 from .runtime import get_ops
 
 
@@ -87,9 +87,7 @@ def _state_args(tracer: _SmcTracer, ret, n_expected: int | None):
     for v in vals:
         if isinstance(v, _Table):
             raise PlanUnsupported("a table lookup cannot be a carry component")
-        if isinstance(v, SymExpr):
-            raise PlanUnsupported("a carry component must be a site value (or one affine step of a site / carry / observation)")
-        out.append(tracer._arg(v))
+        out.append(tracer._arg(v))  # (an expression over sites / the carry / observations is a postfix program)
     return out
 
 

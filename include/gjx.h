@@ -173,8 +173,9 @@ typedef enum {
                         constants and literals (+ - * / and negation): `table` points at `ref` gjx_expr_op entries in HOST memory (copied at plan
                         creation).  What a model body writes between its `@` sites — `normal(w * x + b, s)`
                         (static.py:340-380 runs that arithmetic as traced jnp ops) — evaluated per particle in f32, one
-                        rounding per operation, in program order (no fusion).  Distribution arguments of sites only (not
-                        observed values, not the row of a categorical site, not the next state).  libgjx_hip.so runs such
+                        rounding per operation, in program order (no fusion).  Distribution arguments of sites and the
+                        state arguments of SMC / scan plans (`x + 0.1 * v`: a deterministic update of a carried component);
+                        not observed values, not the row of a categorical site.  libgjx_hip.so runs such
                         plans as specialised kernels only (GJX_ERR_UNSUPPORTED if specialisation is turned off). */
 } gjx_arg_kind;
 #define GJX_MAX_PARAMS 64

@@ -1289,11 +1289,21 @@ void gjo_math(int fn, const float* x, float* y, uint64_t n) {
 
 
 /* ---- bootstrap SMC for a user model (init + step site tables) ------------------------------------ */
+/* programs of the state arguments (init_state / next_state): the plan's own copies */
+typedef struct { gjx_expr_op ops[GJX_SMC_MAX_STATE][GJX_MAX_EXPR_OPS]; } state_expr_store;
+static void state_expr_adopt(gjx_arg* args, int n, state_expr_store* st) {
+  for (int k = 0; k < n; ++k)
+    if (args[k].kind == GJX_ARG_EXPR) {
+      memcpy(st->ops[k], (const void*)args[k].table, sizeof(gjx_expr_op) * (size_t)args[k].ref);
+      args[k].table = (const float*)(const void*)st->ops[k];
+    }
+}
 struct gjx_smc_plan {
   gjx_smc_model m;
   gjx_site init_sites[GJX_MAX_SITES];
   gjx_site step_sites[GJX_MAX_SITES];
   expr_store init_expr, step_expr;
+  state_expr_store init_state_expr, next_state_expr;
 };
 
 static int smc_arg_ok(const gjx_arg* a, int s, int n_state, int n_obs, int allow_state) {
@@ -1332,9 +1342,9 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
   if (!smc_sites_ok(m->init_sites, m->n_init_sites, m->n_state, m->n_obs, 0)) return GJX_ERR_INVALID;
   if (!smc_sites_ok(m->step_sites, m->n_step_sites, m->n_state, m->n_obs, 1)) return GJX_ERR_INVALID;
   for (int k = 0; k < m->n_state; ++k) {
-    if (!smc_arg_ok(&m->init_state[k], m->n_init_sites, m->n_state, m->n_obs, 0) || m->init_state[k].kind == GJX_ARG_TABLE || m->init_state[k].kind == GJX_ARG_EXPR)
+    if (!smc_arg_ok(&m->init_state[k], m->n_init_sites, m->n_state, m->n_obs, 0) || m->init_state[k].kind == GJX_ARG_TABLE)
       return GJX_ERR_INVALID;
-    if (!smc_arg_ok(&m->next_state[k], m->n_step_sites, m->n_state, m->n_obs, 1) || m->next_state[k].kind == GJX_ARG_TABLE || m->next_state[k].kind == GJX_ARG_EXPR)
+    if (!smc_arg_ok(&m->next_state[k], m->n_step_sites, m->n_state, m->n_obs, 1) || m->next_state[k].kind == GJX_ARG_TABLE)
       return GJX_ERR_INVALID;
   }
   gjx_smc_plan* p = (gjx_smc_plan*)malloc(sizeof(gjx_smc_plan));
@@ -1344,6 +1354,8 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
   memcpy(p->step_sites, m->step_sites, sizeof(gjx_site) * (size_t)m->n_step_sites);
   expr_adopt(p->init_sites, m->n_init_sites, &p->init_expr);
   expr_adopt(p->step_sites, m->n_step_sites, &p->step_expr);
+  state_expr_adopt(p->m.init_state, m->n_state, &p->init_state_expr);
+  state_expr_adopt(p->m.next_state, m->n_state, &p->next_state_expr);
   p->m.init_sites = p->init_sites;
   p->m.step_sites = p->step_sites;
   *out = p;
@@ -1362,6 +1374,7 @@ struct gjx_scan_plan {
   gjx_scan_model m;
   gjx_site step_sites[GJX_MAX_SITES];
   expr_store step_expr;
+  state_expr_store next_state_expr;
 };
 int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan** out) {
   if (!m || !out || (flags & ~(uint32_t)GJX_PLAN_FAST_MATH) || m->n_state < 1 || m->n_state > GJX_SMC_MAX_STATE ||
@@ -1369,13 +1382,14 @@ int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan*
     return GJX_ERR_INVALID;
   if (!smc_sites_ok(m->step_sites, m->n_step_sites, m->n_state, m->n_obs, 1)) return GJX_ERR_INVALID;
   for (int k = 0; k < m->n_state; ++k)
-    if (!smc_arg_ok(&m->next_state[k], m->n_step_sites, m->n_state, m->n_obs, 1) || m->next_state[k].kind == GJX_ARG_TABLE || m->next_state[k].kind == GJX_ARG_EXPR)
+    if (!smc_arg_ok(&m->next_state[k], m->n_step_sites, m->n_state, m->n_obs, 1) || m->next_state[k].kind == GJX_ARG_TABLE)
       return GJX_ERR_INVALID;
   gjx_scan_plan* p = (gjx_scan_plan*)malloc(sizeof(gjx_scan_plan));
   if (!p) return GJX_ERR_LAUNCH;
   p->m = *m;
   memcpy(p->step_sites, m->step_sites, sizeof(gjx_site) * (size_t)m->n_step_sites);
   expr_adopt(p->step_sites, m->n_step_sites, &p->step_expr);
+  state_expr_adopt(p->m.next_state, m->n_state, &p->next_state_expr);
   p->m.step_sites = p->step_sites;
   *out = p;
   return GJX_OK;

@@ -259,6 +259,9 @@ while time.time() < t_end:
         real = [i for i, k in enumerate(kinds) if k in ("real", "pos", "unit")]
         nxt = [A(abi.ARG_SITE, int(rng.choice(real)), float(rng.uniform(-1, 1)), float(rng.uniform(-0.5, 0.5)), None) if real and rng.random() < 0.8
                else A(abi.ARG_STATE, int(rng.integers(n_state)), 0.5, 0.1, None) for _ in range(n_state)]
+        if real and rng.random() < 0.4:  # a carry component that is an expression over a site, the carry and the input
+            nxt[0] = abi.expr_arg([(abi.EXPR_STATE, 0, 0.0), (abi.EXPR_SITE, int(rng.choice(real)), 0.0), (abi.EXPR_CONST, 0, float(rng.uniform(-0.5, 0.5))),
+                                   (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_ADD, 0, 0.0), (abi.EXPR_OBS, 0, 0.0), (abi.EXPR_SUB, 0, 0.0)], EXPR_KEEP)
         obs = np.stack([[maybe_bad(float(x)) for x in rng.uniform(-1, 1, T)], rng.integers(0, 2, T)], axis=1).astype(np.float32)
         carry0 = [maybe_bad(float(rng.uniform(-1, 1))) for _ in range(n_state)]
         outs = []
@@ -281,6 +284,11 @@ while time.time() < t_end:
             continue
         istate = [A(abi.ARG_SITE, int(rng.choice(ireal)), 1.0, 0.0, None) for _ in range(n_state)]
         nstate = [A(abi.ARG_SITE, int(rng.choice(sreal)), float(rng.uniform(0.5, 1.0)), 0.0, None) for _ in range(n_state)]
+        if rng.random() < 0.4:
+            nstate[0] = abi.expr_arg([(abi.EXPR_STATE, 0, 0.0), (abi.EXPR_CONST, 0, 0.9), (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_SITE, int(rng.choice(sreal)), 0.0),
+                                      (abi.EXPR_CONST, 0, float(rng.uniform(0.1, 0.6))), (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_ADD, 0, 0.0)], EXPR_KEEP)
+            istate[0] = abi.expr_arg([(abi.EXPR_SITE, int(rng.choice(ireal)), 0.0), (abi.EXPR_OBS, 0, 0.0), (abi.EXPR_CONST, 0, 0.25), (abi.EXPR_MUL, 0, 0.0),
+                                      (abi.EXPR_ADD, 0, 0.0)], EXPR_KEEP)
         obs = np.stack([[maybe_bad(float(x)) for x in rng.uniform(-1, 1, T)], rng.integers(0, 2, T)], axis=1).astype(np.float32)
         skeys, rkeys = W.smc_key_schedule(prng.key(seed, impl), T)
         ess = float(rng.choice([0.0, 0.0, 0.5]))

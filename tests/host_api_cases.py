@@ -790,6 +790,13 @@ def case_scan_fused_equals_loop(impl):
         _ = normal(x2 * x2 - v2, 1.0) @ "y"
         return (x2, v2), (x2 - v2 * 2.0, v2)
 
+    @gen
+    def kinematic_step(carry, u):  # a DETERMINISTIC update of a carried component: the next carry is an expression
+        x, v = carry
+        v2 = normal(0.9 * v + 0.2 * u, 0.4) @ "x"
+        _ = normal(x + 0.5 * v2, 0.6) @ "y"
+        return (x + 0.5 * v2 - 0.01 * x * x, v2), v2 * 2.0 - u
+
     torch.manual_seed(0)
     trans, emit = torch.randn(6, 6).to(_dev()), torch.randn(6, 6).to(_dev())
 
@@ -812,6 +819,8 @@ def case_scan_fused_equals_loop(impl):
             (rich_step.scan(), C["y"].set(ys), ((x0, 1.0), us)),
             (controlled_step.scan(), C["y"].set(ys), ((0.0, 1.0), us)),
             (controlled_step.scan(), C.n(), ((x0, -0.5), us)),
+            (kinematic_step.scan(), C["y"].set(ys), ((0.0, 1.0), us)),
+            (kinematic_step.scan(), C.n(), ((x0, 0.25), us)),
             (hmm_step.scan(n=T), C["y"].set(torch.tensor([1, 0, 3, 5, 2, 2, 4, 0, 1])), (0, None)),
             (hmm_step.scan(n=T), C.n(), (2, None))]
 
@@ -1318,6 +1327,37 @@ def case_general_smc(impl):
         kk = (P_ @ H_.T) / sv
         mu, P_ = mu + kk[:, 0] * (yt - mu[0]), P_ - kk @ H_ @ P_
     assert r3.log_marginal_likelihood == pytest.approx(ll3, abs=0.25)
+
+    # constant-velocity tracking: the position is a DETERMINISTIC function of the carried state and the sampled velocity (the
+    # carry component is an expression); exact evidence by the same Kalman filter with a singular process noise
+    @gen
+    def init4():
+        p = normal(0.0, 1.0) @ "p"
+        v = normal(0.0, 0.5) @ "v"
+        normal(p, 0.6) @ "y"
+        return p, v
+
+    @gen
+    def step4(c):
+        p, v = c
+        v2 = normal(0.95 * v, 0.3) @ "v"
+        normal(p + 0.5 * v2, 0.6) @ "y"
+        return p + 0.5 * v2, v2
+
+    r4 = BootstrapSMC(StateSpaceModel(init4, step4), C["y"].set(torch.tensor(y)), 65536).run(key)
+    mu, P_ = np.zeros(2), np.diag([1.0, 0.25])
+    A4 = np.array([[1.0, 0.5 * 0.95], [0.0, 0.95]])
+    G4 = np.array([[0.5 * 0.3], [0.3]])
+    Q4 = G4 @ G4.T
+    ll4 = 0.0
+    for t, yt in enumerate(y.astype("float64")):
+        if t:
+            mu, P_ = A4 @ mu, A4 @ P_ @ A4.T + Q4
+        sv = (H_ @ P_ @ H_.T).item() + R_
+        ll4 += -0.5 * (yt - mu[0]) ** 2 / sv - 0.5 * math.log(2 * math.pi * sv)
+        kk = (P_ @ H_.T) / sv
+        mu, P_ = mu + kk[:, 0] * (yt - mu[0]), P_ - kk @ H_ @ P_
+    assert r4.log_marginal_likelihood == pytest.approx(ll4, abs=0.3)
     # vmap over keys: the filters of a user model step in the same launches, each equal to its own run
     smc2 = BootstrapSMC(StateSpaceModel(init2, step2), C["y"].set(torch.tensor(y)), 4096, record_ancestors=True)
     ks = [genjax.random.key(s_, impl) for s_ in (3, 8, 9)]
