@@ -30,12 +30,13 @@ def _stack_time(items: list, batched: bool):
     """list over t of pytrees with [n] leaves -> pytree with [n, T] leaves (views of [T, n]).
     Constrained steps contribute Python scalars; they are broadcast to the column shape."""
     first = items[0]
-    ref = next((it for it in items if isinstance(it, torch.Tensor)), None)
+    tens = [it for it in items if isinstance(it, torch.Tensor)]
+    ref = max(tens, key=lambda t: t.dim()) if tens else None  # (a step may contribute a 0-d value: the carried scalar)
     if ref is not None or isinstance(first, (bool, int, float)):
         if ref is None:
             return torch.as_tensor(items)
-        cols = [it if isinstance(it, torch.Tensor) else torch.as_tensor(it, dtype=ref.dtype, device=ref.device).expand(ref.shape)
-                for it in items]
+        cols = [(it if it.dim() == ref.dim() else it.to(device=ref.device, dtype=ref.dtype).expand(ref.shape)) if isinstance(it, torch.Tensor)
+                else torch.as_tensor(it, dtype=ref.dtype, device=ref.device).expand(ref.shape) for it in items]
         st = torch.stack(cols, 0)
         return st.movedim(0, 1) if (batched and st.dim() >= 2) else st
     if isinstance(first, (tuple, list)):
@@ -203,7 +204,7 @@ class Scan(GenerativeFunction):
                 leaves.append((m["addr"], _stack_time(obs_values[k_obs[a]], True)))
         final = [c[0] if u else c for c, u in zip(out["carry"], low.uniform_carry)]
         final = [(c != 0 if dt == torch.bool else c.to(dt)) if dt is not None else c for c, dt in zip(final, low.carry_dtypes)]
-        retval = (low.rebuild_carry(final), SP.resolve(low, low.ret_y, values_nt, table, dev))
+        retval = (low.rebuild_carry(final), SP.resolve(low, low.ret_y, values_nt, table, dev, carry0))
         tr = FusedScanTrace(self, args, retval, out["score"], leaves, key)
         tr.max_partials, tr.row_stats = out["max_partials"], out["rows"]
         return tr, out["logw"]

@@ -10,7 +10,8 @@ chain, same device functions in the same order: the trace, the weights and the s
 bit (tests/host_api_cases.py::case_scan_fused_equals_loop).
 
 Not lowered (the host loop runs instead): constraints that differ in shape between steps or are per-particle, nested
-generative functions in the kernel, a `y_t` output that needs the carry of a past step, non-affine arithmetic.
+generative functions in the kernel, a `y_t` output that reads a carry component which is not itself a stored float site
+value, division by numbers and transcendental functions of traced values (plan.py).
 """
 
 from __future__ import annotations
@@ -109,19 +110,25 @@ def lower_scan(kernel_gen_fn, carry0, xs, obs_addrs: list[tuple], fast_math: boo
         if isinstance(v, _Table):
             raise PlanUnsupported("a table lookup cannot be a carry component")
         next_state.append(tr._arg(v))  # (an expression over sites / the carry / the input is a postfix program)
+    # a carry component that IS a stored float site value can be read back step by step (the carry before step t is the
+    # site's value at step t - 1, the initial carry at t = 0): y_t may then read the previous carry
+    state_col = []
+    for v in nc_leaves:
+        m = tr.meta[v.src[1]] if isinstance(v, Sym) and v.src[0] == "site" and not (v.has_mul or v.has_add) else None
+        state_col.append(m["out_col"] if m is not None and m["out_col"] >= 0 and not m["is_int"] else None)
     y_leaves: list = []
     _flatten(y, y_leaves)
     for v in y_leaves:  # y_t must be recoverable from what the launch stores
-        if isinstance(v, Sym) and v.src[0] == "state":
-            raise PlanUnsupported("y_t reads the previous carry")
+        if isinstance(v, Sym) and v.src[0] == "state" and state_col[v.src[1]] is None:
+            raise PlanUnsupported("y_t reads a carry component that is not a stored site value")
         if isinstance(v, _Table):
             raise PlanUnsupported("y_t is a table lookup")
         if isinstance(v, Sym) and v.src[0] == "site" and tr.meta[v.src[1]]["out_col"] < 0:
             raise PlanUnsupported("y_t reads a site that is not stored")
         if isinstance(v, SymExpr):
             for op, ref, _ in v.prog:
-                if op == abi.EXPR_STATE or (op == abi.EXPR_SITE and tr.meta[ref]["out_col"] < 0):
-                    raise PlanUnsupported("y_t reads the previous carry or a site that is not stored")
+                if (op == abi.EXPR_STATE and state_col[ref] is None) or (op == abi.EXPR_SITE and tr.meta[ref]["out_col"] < 0):
+                    raise PlanUnsupported("y_t reads a carry component / a site that is not stored")
     seen = {(m["addr"] if isinstance(m["addr"], tuple) else (m["addr"],)) for m in tr.meta}
     if any(a not in seen for a in obs_addrs):
         raise PlanUnsupported("a constrained address is not visited by the kernel")
@@ -131,6 +138,7 @@ def lower_scan(kernel_gen_fn, carry0, xs, obs_addrs: list[tuple], fast_math: boo
     plan._keep = tr.keep
     value_meta = [m for m in tr.meta if m["out_col"] >= 0]
     low = ScanLowering(tr, plan, obs_addrs, len(xs_leaves), rebuild_carry, new_carry, y, value_meta)
+    low.state_col = state_col
     # carry components that no particle-dependent value ever reaches (a step counter, a schedule): presented as
     # scalars, like the host loop's Python values
     uniform = [_is_scalar(v) for v in carry_leaves]
@@ -199,17 +207,35 @@ def run_scan(low: ScanLowering, pk: ParticleKeys, T: int, carry0, table: np.ndar
     return get_ops().scan_run(low.plan, pk.kb, pk.n, T, table, leaves, dtypes, want_score=want_score, out=out)
 
 
-def resolve(low: ScanLowering, x, values_nt: list, table: np.ndarray, device):
-    """A symbolic per-step output -> its [n, T] (or [T]) tensor, with the f32 operation order of the kernel."""
+def resolve(low: ScanLowering, x, values_nt: list, table: np.ndarray, device, carry0=None):
+    """A symbolic per-step output -> its [n, T] (or [T]) tensor, with the f32 operation order of the kernel.
+    `carry0`: the initial carry (outputs that read the previous carry, `state_col` of lower_scan)."""
+    def previous_carry(k):  # [n, T]: the carry before every step
+        col = values_nt[low.state_col[k]]
+        leaves: list = []
+        _flatten(carry0, leaves)
+        c0 = torch.as_tensor(leaves[k], dtype=torch.float32).to(col.device)
+        c0 = c0.reshape(-1, 1).expand(col.shape[0], 1)
+        return torch.cat([c0, col[:, :-1]], dim=1)
+
     if isinstance(x, SymExpr):
         def leaf(kind, ref):
             if kind == abi.EXPR_SITE:
                 return values_nt[low.tracer.meta[ref]["out_col"]]
             if kind == abi.EXPR_OBS:
                 return torch.from_numpy(table[:, ref].copy()).to(device)
+            if kind == abi.EXPR_STATE and carry0 is not None:
+                return previous_carry(ref)
             raise PlanUnsupported("unresolvable output")
         return x.evaluate(leaf)
     if isinstance(x, Sym):
+        if x.src[0] == "state" and carry0 is not None:
+            base = previous_carry(x.src[1])
+            if x.has_mul:
+                base = base * x.scale
+            if x.has_add:
+                base = base + x.offset
+            return base
         if x.src[0] == "site":
             m = low.tracer.meta[x.src[1]]
             if not (x.has_mul or x.has_add):
@@ -226,9 +252,9 @@ def resolve(low: ScanLowering, x, values_nt: list, table: np.ndarray, device):
             out = out + x.offset
         return out
     if isinstance(x, (tuple, list)):
-        return type(x)(resolve(low, y, values_nt, table, device) for y in x)
+        return type(x)(resolve(low, y, values_nt, table, device, carry0) for y in x)
     if isinstance(x, dict):
-        return {k: resolve(low, y, values_nt, table, device) for k, y in x.items()}
+        return {k: resolve(low, y, values_nt, table, device, carry0) for k, y in x.items()}
     if x is None:
         return None
     if _is_scalar(x):

@@ -153,7 +153,7 @@ def random_step(rng):
         cv = f"({cv} * {round(float(rng.uniform(0.5, 1.5)), 2)})"
     if rng.random() < 0.4:  # a deterministic update: the next carry is an expression over the carry, a site and the input
         cx = f"(x + {round(float(rng.uniform(0.1, 0.9)), 2)} * {cx} - u * {round(float(rng.uniform(0.0, 0.3)), 2)})"
-    y = _expr(rng, new, params)
+    y = _expr(rng, new + (["x"] if rng.random() < 0.4 else []), params)  # (sometimes y_t reads the carry it was given)
     src = ("def step(carry, u):\n    x, v = carry\n" + "\n".join(lines) + f"\n    return ({cx}, {cv}), ({y}, {new[0]})\n")
     return src, sites
 
