@@ -31,12 +31,14 @@ def _stack_time(items: list, batched: bool):
     Constrained steps contribute Python scalars; they are broadcast to the column shape."""
     first = items[0]
     tens = [it for it in items if isinstance(it, torch.Tensor)]
-    ref = max(tens, key=lambda t: t.dim()) if tens else None  # (a step may contribute a 0-d value: the carried scalar)
+    # (a step may contribute a 0-d value — the carried scalar, which starts on the host: the widest tensor, on the device if
+    # any step's value lives there, sets shape, dtype and device of the stack)
+    ref = max(tens, key=lambda t: (t.dim(), t.device.type != "cpu")) if tens else None
     if ref is not None or isinstance(first, (bool, int, float)):
         if ref is None:
             return torch.as_tensor(items)
-        cols = [(it if it.dim() == ref.dim() else it.to(device=ref.device, dtype=ref.dtype).expand(ref.shape)) if isinstance(it, torch.Tensor)
-                else torch.as_tensor(it, dtype=ref.dtype, device=ref.device).expand(ref.shape) for it in items]
+        cols = [(it.to(ref.device) if it.dim() == ref.dim() else it.to(device=ref.device, dtype=ref.dtype).expand(ref.shape))
+                if isinstance(it, torch.Tensor) else torch.as_tensor(it, dtype=ref.dtype, device=ref.device).expand(ref.shape) for it in items]
         st = torch.stack(cols, 0)
         return st.movedim(0, 1) if (batched and st.dim() >= 2) else st
     if isinstance(first, (tuple, list)):
