@@ -729,7 +729,7 @@ def cpu_baseline_smc(args, kind, gpu_result=None):
            "sample": f"{'all' if T == T_full else 'first'} {T} steps of the same {n}-particle filter (OpenMP, {cores} threads)",
            "log_z_steps": T, "log_z": log_z}
     if gpu_result is not None:
-        g = ora.log_z_from_pairs(gpu_result["out_max"][:T].cpu(), gpu_result["out_q"][:T].cpu(), n)
+        g = ora.log_z_from_pairs(gpu_result["out_e"][:T].cpu(), gpu_result["out_q"][:T].cpu(), n)
         res["log_z_gpu_same_steps"] = g
         res["log_z_abs_err_gpu_vs_cpu"] = abs(g - log_z)
     if _omp_threads(1):

@@ -824,91 +824,83 @@ GJX_DEV int block_sum_int(int v, int* sh) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Systematic resampling, tile-centric: workgroup b owns SOURCE particles [b*1024, (b+1)*1024).
-// It rebuilds the fixed-point CDF of its tile in LDS (prefix of the preceding tiles comes from the
-// per-tile sums), turns it into "teeth below" counts, and serves the contiguous range of OUTPUT
-// slots whose teeth fall into its mass — so both the source reads (one tile of lw / state) and
-// the output writes are coalesced, and ancestors never round-trip through HBM unless asked for.
-// The per-output work (propagate + weight for the fused SMC models) is the template policy.
+// Systematic resampling, OUTPUT-tile-centric, one launch per SMC step.
+//
+// Weights are TILE-ANCHORED fixed point: tile t (1024 consecutive particles) is anchored at the power of two just
+// above its own maximum, e_t = row_anchor(max_t lw); q_i = rowfix(lw_i, e_t) (30 fractional bits); c_i = the
+// INCLUSIVE prefix of q inside the tile (u64, stored per particle: the "in-tile CDF"); the tile's record is
+// (e_t, S_t = c_last).  All of that is known to the workgroup that PRODUCES the tile's log-weights — no grid-wide
+// maximum is needed, so the kernel that propagates a population also emits what the next resampling reads, and a
+// bootstrap step is ONE launch.  The consumer merges the records: e = max e_t, d_t = e - e_t, M_t = S_t >> d_t,
+// P_t = sum_{t' < t} M_t', total Q = P_ntiles, and the GLOBAL fixed-point CDF is C_i = P_t + (c_i >> d_t): exact
+// integers, the same bits for every tiling of the work, every number of ranks and the oracle.
+//
+// Workgroup b owns OUTPUT slots [b*1024, (b+1)*1024): from the merged records it finds the source tiles whose teeth
+// fall into its slots (ancestors are monotone: a contiguous range, typically 2-3 tiles), turns their stored CDFs into
+// teeth counts, marks where every source's run of slots starts, spreads the marks with a max-scan, gathers the
+// ancestors' state, propagates, weights, and emits its own tile's CDF and record.  Collapse-proof by construction:
+// under weight collapse every output tile reads the same heavy source tile; when an output tile has MANY light
+// sources (more than kScanMax tiles with a tooth in it) every slot finds its ancestor by binary search of the tile
+// prefix and of one stored in-tile CDF instead — the cost of a step is bounded whatever the weights are.
 // ------------------------------------------------------------------------------------------------
 // Several independent filters stepping in ONE launch (the bootstrap filter vmapped over keys): workgroup
-// f * tiles + b serves tile b of filter f.  Filter f's particles, tile sums, (max, q) results and keys lie
-// f * stride / f * tiles / f * mq_stride further.  A 1e6-particle step is ~1000 workgroups — under one round
-// of the machine — so a few filters per launch fill it (the large-population rates: 14 -> 11.5 us per 1e6).
+// f * tiles + b serves output tile b of filter f.  Filter f's particles, records, (e, q) results and keys lie
+// f * stride / f * tiles / f * mq_stride further.
 constexpr int kMaxFilters = 16;
 struct FilterBatch {
   uint32_t n_filters = 0;  // <= 1: a single filter (nothing below is read)
   uint32_t tiles = 0;      // tiles per filter
   uint64_t stride = 0;     // particles between consecutive filters in every per-particle array (tiles * 1024)
-  uint64_t mq_stride = 0;  // entries between the filters' per-step (max, q) results
+  uint64_t mq_stride = 0;  // entries between the filters' per-step (e, q) results
   Key step_key[kMaxFilters];
   Key rkey[kMaxFilters];
 };
 
-// Collapse-proof resampling.  The kernel is source-tile-centric: a tile serves the output slots its mass owns, in
-// chunks of 1024.  Under weight collapse ONE tile owns (nearly) every slot; left alone its workgroup would walk a
-// thousand chunks while 255 CUs idle — and almost every other tile has no mass at all, so its workgroup has nothing to
-// do.  So: a tile that owns more than kOwnChunks chunks ("heavy") keeps the first kOwnChunks and DELEGATES the
-// following ones, chunk by chunk, to the idle workgroups (tiles of mass exactly 0), in index order: chunk c of the
-// i-th heavy tile goes to idle workgroup number cum_i + (c - kOwnChunks) while idle workgroups last; what is left stays
-// with the owner.  Who is heavy, who is idle and who gets which chunk follows from the exact tile masses (every
-// workgroup reduces them anyway) and the comb offset, so all workgroups agree without communicating, every workgroup
-// still serves ONE (tile, slot range) item with ONE copy of the serving code, and ancestors, particles and weights are
-// the same bits whoever computes them.
-constexpr int kOwnChunks = 4;
-constexpr int kCapSlots = kOwnChunks * kTile;
-constexpr int kMaxHeavy = 256;  // more candidates than this (never seen): owners serve everything, as before
-// Layout of the precomputed tile-mass prefix (k_scan_tiles; large populations and filter batches): [0 .. ntiles] the
-// exclusive prefix (entry ntiles = total); then R1, R2 (ESS sums), the number of heavy candidates, their (tile,
-// prefix) pairs, the number of idle tiles; then — only meaningful when there are heavy candidates — every tile's
-// rank among the idle tiles, two u32 per word.
-constexpr int kPrefixTail = 4 + 2 * kMaxHeavy;  // words between the prefix [ntiles + 1] and the idle ranks
-GJX_HD uint64_t prefix_words(uint64_t ntiles) { return ntiles + 1 + kPrefixTail + (ntiles + 1) / 2; }
+constexpr int kTileFrac = kRowFrac;   // fractional bits of the tile-anchored weights (rowfix)
+constexpr int kEssShift = kTileFrac - 16;
+constexpr int kMaxLdsTiles = 1024;    // populations up to 2^20 particles keep the merged tile prefix in LDS
+constexpr int kScanMax = 16;          // an output tile with more source tiles than this searches per slot
+struct alignas(16) TileRec {
+  uint64_t s;   // S_t: the tile's mass relative to its own anchor (= the last entry of its in-tile CDF)
+  int32_t e;    // e_t (kRowEmpty: no mass)
+  int32_t pad;
+};
+// shift of a tile's fixed point relative to the merged anchor e (>= every e_t): 64 = the tile carries no mass
+GJX_HD int tile_shift(int32_t e, int32_t et) {
+  if (et == kRowEmpty) return 64;
+  const int64_t d = (int64_t)e - (int64_t)et;
+  return d > 63 ? 64 : (int)d;
+}
+GJX_HD uint64_t shr64(uint64_t v, int d) { return d >= 64 ? 0 : v >> d; }
+// layout of the precomputed prefix of large populations (k_scan_records): [0 .. ntiles] exclusive prefix (entry
+// ntiles = total), then e (sign-extended), R1, R2
+GJX_HD uint64_t prefix_words(uint64_t ntiles) { return ntiles + 4; }
 
 struct ResampleArgs {
-  const float* lw;            // [n] source log-weights
-  const float* m_ptr;         // max of lw
-  const uint64_t* tile_sums;  // [ntiles] fixed-point mass of every source tile
-  uint64_t n, ntiles;
-  uint64_t n_out;             // number of comb teeth (global output slots)
-  int64_t out_lo, out_hi;     // slots this launch serves
-  int frac;
-  int lw_vec;                 // lw is 16-byte aligned: tiles may use float4 loads
-  Key rkey;                   // resampling key (its sub-stream 0 gives the comb offset)
-  int rkey_has_fold;
-  uint32_t rkey_fold;
-  uint64_t* q_total_out = nullptr;  // nullable: block 0 stores the total mass (= sum of tile_sums)
-  const uint64_t* tile_prefix = nullptr;  // nullable: [prefix_words(ntiles)] (k_scan_tiles), precomputed for large
-                                // populations and filter batches (otherwise every workgroup scans tile_sums itself)
-  FilterBatch fb;               // several filters per launch (n, ntiles, n_out, out_lo/out_hi are then PER FILTER)
-  // ESS-adaptive resampling (gjx_smc_config.ess_threshold): ess_thr = threshold * n_total, 0 = resample always.
-  double ess_thr = 0.0;
-  const uint64_t* tile_ess = nullptr;  // [2 ntiles]: (R1_b, R2_b) of every source tile (needed when ess_thr > 0)
-  int32_t* resampled_out = nullptr;    // nullable: block 0 of each filter stores 1 (resampled) / 0 (kept)
-  int allow_help = 1;                  // 0: heavy tiles serve all their slots themselves
-  int heavy_shift = 64;                // a tile may be heavy if its mass exceeds total >> heavy_shift (heavy_shift_for(n_out))
-  // Extra workgroups (per filter) behind the `ntiles` tile workgroups: they own no source tile, exit at once in ordinary
-  // steps, and rank behind the idle tiles as takers of a heavy tile's delegated chunks — so a heavy tile can always
-  // delegate, also when no tile is idle (one particle with 60 % of the mass, the rest spread evenly).
-  uint32_t n_extra = 0;
-  float* extra_max = nullptr;          // nullable [n_extra] (per filter): the maxima of what the extra workgroups served
-  int extra_first = 0;                 // test knob (GJX_SMC_EXTRA_FIRST=1): the extra workgroups rank BEFORE the idle tiles
+  const uint64_t* cdf = nullptr;        // [n] in-tile inclusive CDF of the SOURCE weights
+  const float* lw = nullptr;            // [n] source log-weights (adaptive filters: a kept step accumulates them)
+  const TileRec* recs = nullptr;        // [ntiles] source records
+  const uint64_t* tile_ess = nullptr;   // [2 ntiles] (R1_t, R2_t), tile-anchored (adaptive filters)
+  uint64_t n = 0, ntiles = 0;
+  uint64_t n_out = 0;                   // number of comb teeth (global output slots)
+  int64_t out_lo = 0, out_hi = 0;       // slots this launch serves (out_lo a multiple of the tile size)
+  Key rkey;                             // resampling key (its sub-stream 0 gives the comb offset)
+  int rkey_has_fold = 0;
+  uint32_t rkey_fold = 0;
+  int32_t* e_out = nullptr;             // nullable: workgroup 0 stores the merged anchor of the source weights
+  uint64_t* q_out = nullptr;            // nullable: ... and their total mass
+  int32_t* resampled_out = nullptr;     // nullable: workgroup 0 of each filter stores 1 (resampled) / 0 (kept)
+  const uint64_t* prefix = nullptr;     // nullable: [prefix_words(ntiles)] (k_scan_records); required beyond kMaxLdsTiles
+  FilterBatch fb;                       // several filters per launch (n, ntiles, n_out, out_lo/out_hi are then PER FILTER)
+  double ess_thr = 0.0;                 // threshold * n_total, 0 = resample always
+  // what the step emits for the NEXT resampling (policies with weights)
+  uint64_t* cdf_out = nullptr;          // [n_local] (slot - out_lo)
+  float* logw_out = nullptr;            // nullable [n_local]
+  TileRec* recs_out = nullptr;          // GLOBAL [tiles of n_out]: entry of every output tile served
+  uint64_t* ess_out = nullptr;          // nullable GLOBAL [2 tiles]
+  int scan_max = kScanMax;              // test knob: 0 = every output tile takes the per-slot search
 };
 
-// The tile mass above which a tile MAY own more than kCapSlots output slots (slots <= mass * n_out / total + 1): a power-
-// of-two fraction of the total at or below (kCapSlots - 8) / n_out, so the test is one shift in every workgroup.  The
-// threshold only decides WHO serves a tile's slots (every workgroup of a launch derives the same one): results do not
-// depend on it.
-GJX_HD uint64_t heavy_threshold(uint64_t total, int heavy_shift) {
-  return heavy_shift >= 64 ? ~(uint64_t)0 : total >> heavy_shift;
-}
-GJX_HD int heavy_shift_for(uint64_t n_out) {  // host: smallest s with 2^s >= n_out / (kCapSlots - 8); 64 = no tile can be heavy
-  const uint64_t cap = (uint64_t)kCapSlots - 8;
-  if (n_out <= cap) return 64;
-  int sh = 0;
-  while (sh < 63 && (cap << sh) < n_out) ++sh;
-  return sh;
-}
 // resample iff ESS = R1^2 / R2 < thr (thr in particles); every backend evaluates exactly these double operations
 GJX_HD bool ess_says_resample(uint64_t r1, uint64_t r2, double thr) {
   if (!(thr > 0.0) || r2 == 0) return true;
@@ -916,8 +908,8 @@ GJX_HD bool ess_says_resample(uint64_t r1, uint64_t r2, double thr) {
   const double b = thr * (double)r2;
   return a < b;
 }
-// the reduced weight of the ESS sums: the top 16 bits of the fixed-point weight
-GJX_HD uint64_t ess_r(uint64_t q, int frac) { return q >> (frac - 16); }
+// the reduced weight of the ESS sums: the top 16 bits of the tile-anchored fixed-point weight
+GJX_HD uint64_t ess_r(uint64_t q) { return q >> kEssShift; }
 // ------------------------------------------------------------------------------------------------
 // Row-anchored log-sum-exp of a whole pass: e = max e_b; buckets B_d = sum of S_b over
 // the rows with e - e_b == d (d < 64, exact); Q = sum_d B_d >> d; lse = e ln2 + log(Q 2^-30).  The
@@ -1077,7 +1069,6 @@ GJX_DEV void lse_tail(const int32_t* row_e, const uint64_t* row_s, uint64_t n_ro
 struct PlanPolicyArgs {
   const float* prev_state[4];
   float* state_out[4];
-  float* logw_out;
   int32_t* anc_out;
   Key step_key;
   float obs[8];
@@ -1089,537 +1080,543 @@ struct IntC {
 };
 
 // A resampling policy serves the four consecutive output slots of a lane either at once (compute_quad /
-// store_quad: shared cipher block, vector stores) or slot by slot (compute / store: generated policies).
+// store_quad: shared cipher block, vector stores) or slot by slot (compute / store: generated policies).  `anc` are
+// GLOBAL source indices: the policy gathers its ancestors' state itself.  prefetch (optional) is called before the
+// kernel's first wait on memory: whatever does not depend on the ancestors (cipher blocks, Box-Muller) goes there.
 template <class Policy>
-GJX_DEV auto policy_compute_quad(Policy& P, int64_t jq, const int (&src)[4], typename Policy::Out (&o)[4], float (&w)[4],
-                                 int) -> decltype(P.compute_quad(jq, src, o, w), void()) {
-  P.compute_quad(jq, src, o, w);
+GJX_DEV auto policy_prefetch(Policy& P, int64_t jq, int) -> decltype(P.prefetch(jq), void()) { P.prefetch(jq); }
+template <class Policy>
+GJX_DEV void policy_prefetch(Policy&, int64_t, long) {}
+// stage (optional): what prefetch loaded goes to LDS; called once by every thread, a workgroup barrier before compute
+template <class Policy>
+GJX_DEV auto policy_stage(Policy& P, int) -> decltype(P.stage(), void()) { P.stage(); }
+template <class Policy>
+GJX_DEV void policy_stage(Policy&, long) {}
+template <class Policy>
+GJX_DEV auto policy_compute_quad(Policy& P, int64_t jq, const uint32_t (&anc)[4], typename Policy::Out (&o)[4], float (&w)[4],
+                                 int) -> decltype(P.compute_quad(jq, anc, o, w), void()) {
+  P.compute_quad(jq, anc, o, w);
 }
 template <class Policy>
-GJX_DEV void policy_compute_quad(Policy& P, int64_t jq, const int (&src)[4], typename Policy::Out (&o)[4], float (&w)[4],
+GJX_DEV void policy_compute_quad(Policy& P, int64_t jq, const uint32_t (&anc)[4], typename Policy::Out (&o)[4], float (&w)[4],
                                  long) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) w[u] = P.compute(jq + u, src[u], o[u]);
+  for (int u = 0; u < 4; ++u) w[u] = P.compute(jq + u, anc[u], o[u]);
 }
 template <class Policy>
-GJX_DEV auto policy_store_quad(Policy& P, int64_t jq, int64_t out_lo, uint64_t base, const int (&src)[4],
+GJX_DEV auto policy_store_quad(Policy& P, int64_t jq, int64_t out_lo, const uint32_t (&anc)[4],
                                const typename Policy::Out (&o)[4], const bool (&ok)[4], int)
-    -> decltype(P.store_quad(jq, out_lo, base, src, o, ok), void()) {
-  P.store_quad(jq, out_lo, base, src, o, ok);
+    -> decltype(P.store_quad(jq, out_lo, anc, o, ok), void()) {
+  P.store_quad(jq, out_lo, anc, o, ok);
 }
 template <class Policy>
-GJX_DEV void policy_store_quad(Policy& P, int64_t jq, int64_t out_lo, uint64_t base, const int (&src)[4],
+GJX_DEV void policy_store_quad(Policy& P, int64_t jq, int64_t out_lo, const uint32_t (&anc)[4],
                                const typename Policy::Out (&o)[4], const bool (&ok)[4], long) {
 #pragma unroll
   for (int u = 0; u < 4; ++u)
-    if (ok[u]) P.store(jq + u, out_lo, base + (uint64_t)src[u], o[u]);
+    if (ok[u]) P.store(jq + u, out_lo, anc[u], o[u]);
 }
 
-// log-weight carried over a step without resampling: Out types with an `lw` member accumulate it
-template <class Out>
-GJX_DEV auto carry_lw(Out& o, float prev, int) -> decltype(o.lw, void()) { o.lw = o.lw + prev; }
-template <class Out>
-GJX_DEV void carry_lw(Out&, float, long) {}
-template <class Out>
-GJX_DEV auto out_lw(const Out& o, float w, int) -> decltype(o.lw, float()) { return o.lw; }
-template <class Out>
-GJX_DEV float out_lw(const Out&, float w, long) { return w; }
-
-// What serving a source tile needs besides the tile itself: the launch's arguments, the comb, the workgroup's LDS arrays.
-struct ServeEnv {
-  const ResampleArgs* A;
-  const float* lw_all;  // this filter's source log-weights
-  float m;              // their maximum
-  double scale, u0;     // comb: teeth per unit of mass, offset
-  int32_t* nb;          // LDS [kTile]
-  int32_t* anc_s;       // LDS [kTile]
-  uint64_t* sh_cdf;     // LDS [kBlock / kWave]
-  int* shi;             // LDS [kBlock / kWave]
-  int tid;
-};
-// a source tile's log-weights (four consecutive sources per lane) and the policy's source state, into registers
-template <class Policy>
-GJX_DEV void load_tile_regs(const ServeEnv& E, Policy& P, float (&lw4)[kPer], uint64_t tbase) {
-  const ResampleArgs& A = *E.A;
-  if (kPer == 4 && A.lw_vec && tbase + kTile <= A.n) {  // one 16-B load per lane, 1 KiB per wave-instruction
-    const float4 v = reinterpret_cast<const float4*>(E.lw_all + tbase)[E.tid];
-    lw4[0] = v.x; lw4[1] = v.y; lw4[kPer > 2 ? 2 : 0] = v.z; lw4[kPer > 3 ? 3 : 0] = v.w;
-  } else {
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-      const uint64_t i = tbase + kPer * (uint64_t)E.tid + r;
-      lw4[r] = i < A.n ? E.lw_all[i] : -__builtin_inff();
-    }
-  }
-  P.fetch_source(tbase, A.n, E.tid);  // registers now, LDS after the scan
-}
-// Serve the output slots [s_lo, s_hi) that source tile `ts` (exclusive mass prefix ts_pre) owns: rebuild the tile's
-// CDF, turn it into teeth counts, find every slot's ancestor, propagate, store.  Chunks [skip_from, skip_from + skip_n)
-// of the range (counted from its first chunk) are delegated to other workgroups and skipped here.
-template <int IMPL, class Policy>
-GJX_DEV void serve_tile(const ServeEnv& E, Policy& P, float (&lw4)[kPer], uint64_t ts, uint64_t ts_pre, int64_t s_lo,
-                        int64_t s_hi, bool loaded, float& tmax, uint32_t skip_from, uint32_t skip_n) {
+// ---- emission: the in-tile CDF and the record of the tile a workgroup has just produced ---------------------------
+// w[r], ok[r]: the log-weights of the thread's four consecutive slots (tile offset 4 tid + r) and whether the slot
+// exists.  cdf_at / logw_at: where the thread's first slot goes (logw_at nullable); rec_at / ess_at: the tile's record.
+// Called by every thread of the workgroup (two barriers inside).
+template <bool ESS>
+GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint64_t* cdf_at, float* logw_at, TileRec* rec_at,
+                       uint64_t* ess_at) {
   constexpr int kW = kBlock / kWave;
-  const ResampleArgs& A = *E.A;
-  const int tid = E.tid;
-  const uint64_t tbase = ts * kTile;
-  if (!loaded) load_tile_regs(E, P, lw4, tbase);
-  // tile CDF: each thread owns 4 CONSECUTIVE sources (tbase + 4*tid + r) so the scan is a thread-local prefix plus
-  // one block scan
-  uint64_t q[kPer];
-  uint64_t local = 0;
+  __shared__ float em_f[kW];
+  __shared__ uint64_t em_q[3 * kW];
+  static_assert(kPer == 4, "four consecutive slots per lane");
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  float tm = -__builtin_inff();
+#pragma unroll
+  for (int r = 0; r < kPer; ++r) tm = ok[r] && w[r] > tm ? w[r] : tm;
+  tm = wave_max(tm);
+  if (lane == 0) em_f[wv] = tm;
+  __syncthreads();
+  float m = em_f[0];
+#pragma unroll
+  for (int i = 1; i < kW; ++i) m = em_f[i] > m ? em_f[i] : m;
+  const int32_t e = row_anchor(m);
+  uint64_t c[kPer];
+  uint64_t run = 0, a1 = 0, a2 = 0;
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {
-    const uint64_t i = tbase + kPer * (uint64_t)tid + r;
-    q[r] = i < A.n ? fixw(lw4[r], E.m, A.frac) : 0;
-    local += q[r];
+    const uint64_t q = ok[r] ? rowfix(w[r], e) : 0;
+    run += q;
+    c[r] = run;
+    if (ESS) {
+      const uint64_t rr = ess_r(q);
+      a1 += rr;
+      a2 += rr * rr;
+    }
   }
-  const uint64_t incl = wave_scan_incl(local);
-  const int w_ = tid >> 6;
-  if ((tid & 63) == 63) E.sh_cdf[w_] = incl;
-  // run-start marks of the ancestor search below; cleared here so that the barrier that publishes the scan covers it
-#pragma unroll
-  for (int r = 0; r < kPer; ++r) E.anc_s[tid + r * kBlock] = 0;
-  P.stage_source(tid);
+  const uint64_t incl = wave_scan_incl(run);
+  if (ESS) { a1 = wave_sum(a1); a2 = wave_sum(a2); }
+  if (lane == 63) {
+    em_q[wv] = incl;
+    if (ESS) { em_q[kW + wv] = a1; em_q[2 * kW + wv] = a2; }
+  }
   __syncthreads();
-  uint64_t run = ts_pre + incl - local;
+  uint64_t base = incl - run;
 #pragma unroll
   for (int i = 0; i < kW; ++i)
-    if (i < w_) run += E.sh_cdf[i];
-  const int64_t n_lo = teeth_below(ts_pre, E.scale, E.u0, (int64_t)A.n_out);
-  int32_t nbr[kPer];  // teeth below this thread's consecutive sources
+    if (i < wv) base += em_q[i];
+  const bool all = ok[0] && ok[1] && ok[2] && ok[3];
+  if (all && (((uintptr_t)cdf_at & 15) == 0)) {
+    reinterpret_cast<ulonglong2*>(cdf_at)[0] = make_ulonglong2(base + c[0], base + c[1]);
+    reinterpret_cast<ulonglong2*>(cdf_at)[1] = make_ulonglong2(base + c[2], base + c[3]);
+  } else {
 #pragma unroll
-  for (int r = 0; r < kPer; ++r) {
-    const uint64_t i = tbase + kPer * (uint64_t)tid + r;
-    run += q[r];
-    // the last real particle (and any padding after it) closes the comb at n_out
-    nbr[r] = (int32_t)((i + 1 >= A.n) ? (int64_t)A.n_out : teeth_below(run, E.scale, E.u0, (int64_t)A.n_out));
+    for (int r = 0; r < kPer; ++r)
+      if (ok[r]) cdf_at[r] = base + c[r];
   }
-  // neighbours' counts through LDS: nb_prev (source 4*tid - 1) and the tile's last count
-  E.nb[kPer * tid + kPer - 1] = nbr[kPer - 1];
+  if (logw_at) {
+    if (all && (((uintptr_t)logw_at & 15) == 0)) {
+      *reinterpret_cast<float4*>(logw_at) = make_float4(w[0], w[1], w[2], w[3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < kPer; ++r)
+        if (ok[r]) logw_at[r] = w[r];
+    }
+  }
+  if (tid == kBlock - 1) {
+    TileRec rec;
+    rec.s = base + c[kPer - 1];
+    rec.e = e;
+    rec.pad = 0;
+    *rec_at = rec;
+  }
+  if (ESS && ess_at && tid == 0) {
+    uint64_t t1 = 0, t2 = 0;
+#pragma unroll
+    for (int i = 0; i < kW; ++i) { t1 += em_q[kW + i]; t2 += em_q[2 * kW + i]; }
+    ess_at[0] = t1;
+    ess_at[1] = t2;
+  }
+}
+
+// Where a step's weights go for the NEXT resampling (kernel argument of the init kernels; the resample kernel carries
+// the same fields in ResampleArgs): local CDF / log-weight columns, the GLOBAL record and ESS arrays.
+struct EmitOut {
+  uint64_t* cdf;   // [n_local]
+  float* logw;     // nullable [n_local]
+  TileRec* recs;   // GLOBAL [tiles]
+  uint64_t* ess;   // nullable GLOBAL [2 tiles] (adaptive filters)
+};
+GJX_DEV void emit_init_tile(const float (&w)[kPer], const bool (&ok)[kPer], const EmitOut& em, uint64_t loc, uint64_t gtile) {
+  if (em.ess) emit_tile<true>(w, ok, em.cdf + loc, em.logw ? em.logw + loc : nullptr, em.recs + gtile, em.ess + 2 * gtile);
+  else emit_tile<false>(w, ok, em.cdf + loc, em.logw ? em.logw + loc : nullptr, em.recs + gtile, nullptr);
+}
+GJX_DEV void select_filter_emit(EmitOut& em, const FilterBatch& fb, uint32_t f) {
+  em.cdf += (uint64_t)f * fb.stride;
+  if (em.logw) em.logw += (uint64_t)f * fb.stride;
+  em.recs += (uint64_t)f * fb.tiles;
+  if (em.ess) em.ess += 2 * (uint64_t)f * fb.tiles;
+}
+
+// teeth below source i whose global CDF value is C: the last real particle (and any padding after it) closes the comb
+GJX_DEV int64_t teeth_at(uint64_t i, uint64_t n, uint64_t C, double scale, double u0, int64_t n_out) {
+  return i + 1 >= n ? n_out : teeth_below(C, scale, u0, n_out);
+}
+
+// Exclusive block max-scan of one u32 per thread (identity 0).  `sh` needs 4 words.
+GJX_DEV uint32_t block_scan_umax_excl(uint32_t v, uint32_t* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t incl = wave_scan_u32(v, 0u, [](uint32_t a, uint32_t b) { return b > a ? b : a; });
+  uint32_t excl = dpp_u32<kDppWaveShr1, 0xf, 0xf>(0u, incl);  // lane i <- lane i-1, lane 0 keeps 0
   __syncthreads();
-  const int64_t n_hi = E.nb[kTile - 1];
-  const int32_t nb_prev = tid == 0 ? (int32_t)n_lo : E.nb[kPer * tid - 1];
-  const int64_t j0 = n_lo > s_lo ? n_lo : s_lo;
-  const int64_t j1 = n_hi < s_hi ? n_hi : s_hi;
-  // Ancestors of the slots, 1024 at a time, WITHOUT a search per slot: ancestors are monotone, so every source that
-  // owns at least one slot marks the slot where its run starts (the chunk start for a run that began earlier) and an
-  // inclusive max-scan over the chunk spreads each mark over the run.  Chunks start at a multiple of 4 slots and each
-  // lane serves FOUR CONSECUTIVE slots: four independent propagate chains in flight, one shared cipher block for their
-  // draws (smc_quad_bits), 16-byte stores.  Waves whose 256 slots lie outside the range skip the chunk.
-  const int64_t jb0 = j0 & ~(int64_t)3;
-  // (workgroup-uniform) the delegated chunks are jumped over in one step: their marks were never set, nothing to clear
-  const int64_t skip_lo = jb0 + (int64_t)skip_from * (int64_t)kTile;
-  for (int64_t jb = jb0; jb < j1; jb += (int64_t)kTile) {
-    if (skip_n && jb == skip_lo) {
-      jb += (int64_t)skip_n * (int64_t)kTile;
-      if (jb >= j1) break;
-    }
-    if (jb != jb0) __syncthreads();  // the marks were cleared after the previous chunk's scan
+  if (lane == 63) sh[w] = incl;
+  __syncthreads();
 #pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-      const int64_t start = r == 0 ? nb_prev : nbr[r - 1];  // source 4*tid+r owns slots [start, nbr[r])
-      if ((int64_t)nbr[r] > start && (int64_t)nbr[r] > jb && start < jb + (int64_t)kTile)
-        E.anc_s[(start > jb ? start : jb) - jb] = kPer * tid + r + 1;
-    }
-    __syncthreads();
-    int v[kPer];
-    int run_max = 0;
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-      const int x = E.anc_s[kPer * tid + r];
-      run_max = x > run_max ? x : run_max;
-      v[r] = run_max;
-    }
-    const int carry = block_scan_max_excl(run_max, E.shi);  // (its barriers close this chunk's reads of the marks)
-    if (jb + (int64_t)kTile < j1) {  // another chunk may follow: clear the marks for it
-#pragma unroll
-      for (int r = 0; r < kPer; ++r) E.anc_s[tid + r * kBlock] = 0;
-    }
-    // every entry of the chunk is a valid local source index (slots outside [j0, j1) included — those before the
-    // range's first slot have no mark and take source 0: they are computed along with their quad, never stored)
-    int src[kPer];
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-      const int a = v[r] > carry ? v[r] : carry;
-      src[r] = a ? a - 1 : 0;
-    }
-    const int64_t jq = jb + (int64_t)kPer * tid;
-    const int64_t wave_lo = jb + (int64_t)kPer * (tid & ~(kWave - 1));
-    if (wave_lo < j1 && wave_lo + (int64_t)kPer * kWave > j0) {  // wave-uniform
-      bool ok[kPer];
-#pragma unroll
-      for (int r = 0; r < kPer; ++r) ok[r] = jq + r >= j0 && jq + r < j1;
-      typename Policy::Out out[kPer];
-      float w[kPer];
-      policy_compute_quad(P, jq, src, out, w, 0);
-      policy_store_quad(P, jq, A.out_lo, tbase, src, out, ok, 0);
-#pragma unroll
-      for (int r = 0; r < kPer; ++r) tmax = ok[r] && w[r] > tmax ? w[r] : tmax;
-    }
-  }
+  for (int i = 0; i < kBlock / kWave; ++i)
+    if (i < w) excl = sh[i] > excl ? sh[i] : excl;
+  return excl;
 }
 
 // ADAPTIVE: the launch may be a step of an ESS-adaptive filter (A.ess_thr > 0): only then does the kernel carry the
-// decision and the keep-your-particle path (the fixed models' every-step filters are compiled without them).
+// decision and the keep-your-particle path (the every-step filters are compiled without them).
 template <int IMPL, class Policy, bool ADAPTIVE = true>
-GJX_DEV void resample_body(const ResampleArgs& A, Policy& P, float* max_partials) {
+GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   constexpr int kW = kBlock / kWave;
-  __shared__ uint64_t sh_scan[kW];      // tile-mass scan
-  __shared__ uint64_t sh_ess[2 * kW];   // ESS sums
-  __shared__ uint64_t sh_cdf[kW];       // CDF scan of the served tile
-  __shared__ uint64_t sh_pre;           // exclusive prefix of this workgroup's own tile
-  __shared__ float shf[kW];
-  __shared__ int shi[kW];
-  __shared__ int32_t nb[kTile];     // teeth below the inclusive CDF of the sources (their last-of-four counts)
-  __shared__ int32_t anc_s[kTile];  // run-start marks of the ancestor search
-  __shared__ uint32_t heavy_n;
-  __shared__ uint32_t heavy_tile[kMaxHeavy];
-  __shared__ uint32_t sh_u32[kW + 4];   // rare path: idle-count scan, own idle rank, item selection
+  __shared__ uint64_t sh_pre[kMaxLdsTiles + 1];  // merged exclusive tile prefix (populations up to kMaxLdsTiles tiles)
+  __shared__ uint8_t sh_d[kMaxLdsTiles];         // every tile's shift to the merged anchor
+  __shared__ uint32_t marks[kTile];              // run-start marks of the ancestor search
+  __shared__ uint64_t sh_scan[3 * kW];
+  __shared__ int32_t sh_e[kW];
+  __shared__ uint32_t sh_u[kW];
+  __shared__ uint32_t sh_klo, sh_khi, sh_cnt;
+  __shared__ uint32_t sh_list[kScanMax];
+  static_assert(kPer == 4, "four consecutive sources and four consecutive output slots per lane");
   uint64_t b = blockIdx.x;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   // this workgroup's filter: local views of the per-filter arrays, keys and results
+  const uint64_t* cdf_all = A.cdf;
   const float* lw_all = A.lw;
-  const uint64_t* tile_sums = A.tile_sums;
+  const TileRec* recs = A.recs;
   const uint64_t* tile_ess = A.tile_ess;
-  const float* m_ptr = A.m_ptr;
-  uint64_t* q_total_out = A.q_total_out;
+  int32_t* e_out = A.e_out;
+  uint64_t* q_out = A.q_out;
   int32_t* resampled_out = A.resampled_out;
+  uint64_t* cdf_out = A.cdf_out;
+  float* logw_out = A.logw_out;
+  TileRec* recs_out = A.recs_out;
+  uint64_t* ess_out = A.ess_out;
   Key rkey = A.rkey;
-  const uint64_t* tile_prefix = A.tile_prefix;
-  float* extra_max = A.extra_max;
   if (A.fb.n_filters > 1) {
-    const uint32_t per = A.fb.tiles + A.n_extra;  // workgroups per filter: its tiles, then its extras
-    const uint32_t f = (uint32_t)(b / per);
-    b -= (uint64_t)f * per;
-    if (extra_max) extra_max += (uint64_t)f * A.n_extra;
-    if (tile_prefix) tile_prefix += (uint64_t)f * prefix_words(A.fb.tiles);
-    lw_all += (uint64_t)f * A.fb.stride;
-    tile_sums += (uint64_t)f * A.fb.tiles;
+    const uint32_t f = (uint32_t)(b / A.fb.tiles);
+    b -= (uint64_t)f * A.fb.tiles;
+    cdf_all += (uint64_t)f * A.fb.stride;
+    if (lw_all) lw_all += (uint64_t)f * A.fb.stride;
+    recs += (uint64_t)f * A.fb.tiles;
     if (tile_ess) tile_ess += 2 * (uint64_t)f * A.fb.tiles;
-    m_ptr += (uint64_t)f * A.fb.mq_stride;
-    if (q_total_out) q_total_out += (uint64_t)f * A.fb.mq_stride;
+    if (e_out) e_out += (uint64_t)f * A.fb.mq_stride;
+    if (q_out) q_out += (uint64_t)f * A.fb.mq_stride;
     if (resampled_out) resampled_out += (uint64_t)f * A.fb.mq_stride;
-    if (max_partials) max_partials += (uint64_t)f * A.fb.tiles;
+    if (cdf_out) cdf_out += (uint64_t)f * A.fb.stride;
+    if (logw_out) logw_out += (uint64_t)f * A.fb.stride;
+    if (recs_out) recs_out += (uint64_t)f * A.fb.tiles;
+    if (ess_out) ess_out += 2 * (uint64_t)f * A.fb.tiles;
     rkey = A.fb.rkey[f];
     P.select_filter((uint64_t)f * A.fb.stride, A.fb.step_key[f]);
   }
-  const uint64_t base = b * kTile;
-  const bool extra = b >= A.ntiles;  // (workgroup-uniform) no tile of its own: a taker of delegated chunks only
   const bool adaptive = ADAPTIVE && A.ess_thr > 0.0;
+  const uint64_t ot = (uint64_t)A.out_lo / kTile + b;  // this workgroup's output tile (global index)
+  const int64_t j0 = (int64_t)(ot * kTile);
+  const int64_t j1 = j0 + (int64_t)kTile < A.out_hi ? j0 + (int64_t)kTile : A.out_hi;
+  const int64_t jq = j0 + (int64_t)kPer * tid;
 
-  // Issue the own tile's loads first: their HBM latency overlaps the tile-mass scan.  A rank that owns only a shard
-  // of the output slots decides from the tile masses alone whether a source tile feeds any of its slots, and touches
-  // the tile's particles only then (remote tiles it does not need were never exchanged).
-  const bool part = A.out_lo > 0 || A.out_hi < (int64_t)A.n_out;
-  float lw4[kPer];
-  ServeEnv E;
-  E.A = &A; E.lw_all = lw_all; E.nb = nb; E.anc_s = anc_s; E.sh_cdf = sh_cdf; E.shi = shi; E.tid = tid;
-  E.m = 0.0f; E.scale = 0.0; E.u0 = 0.0;
-  bool own_loaded = false;
-  if (!part && !extra) { load_tile_regs(E, P, lw4, base); own_loaded = true; }
-
-  // ---- tile masses: exclusive prefix of the own tile, total, ESS sums, heavy candidates ------------------------
-  if (tid == 0) heavy_n = 0;
-  uint64_t pre = 0, tot = 0, r1 = 0, r2 = 0, own_mass = 0;
-  uint32_t n_heavy = 0;
-  // thread t owns the c consecutive tiles [t c, t c + c): a thread-local prefix plus ONE block scan gives every thread
-  // the exclusive prefix of each of its tiles (own prefix, heavy candidates) and the total.  Up to kC tiles per thread
-  // stay in registers; beyond that (generic entry points on very large inputs) they are re-read.
-  constexpr int kC = 4;  // 1e6 particles: 977 tiles, 4 per thread
-  const uint64_t c = (A.ntiles + kBlock - 1) / kBlock;
-  const uint64_t k0 = (uint64_t)tid * c;
-  uint64_t v[kC];
-  uint64_t chunk_pre = 0;  // exclusive prefix of this thread's first tile (no tile_prefix)
-  if (tile_prefix) {
-    if (!extra) {
-      pre = tile_prefix[b];
-      own_mass = tile_prefix[b + 1] - pre;
-    }
-    tot = tile_prefix[A.ntiles];
-    if (adaptive) { r1 = tile_prefix[A.ntiles + 1]; r2 = tile_prefix[A.ntiles + 2]; }
-    n_heavy = (uint32_t)tile_prefix[A.ntiles + 3];
-  } else {
-    uint64_t local = 0, l1 = 0, l2 = 0;
-    if (c <= (uint64_t)kC) {
+  // ---- the source records (issued first; the policy's ancestor-independent work runs under their latency) --------
+  constexpr int kC = kMaxLdsTiles / kBlock;  // tiles per thread of the in-kernel merge
+  const bool lds_prefix = A.prefix == nullptr;  // (launch-uniform)
+  const uint64_t c_per = (A.ntiles + kBlock - 1) / kBlock;
+  const uint64_t k0 = (uint64_t)tid * c_per;
+  TileRec rv[kC];
+  uint64_t ev1[kC], ev2[kC];
+  if (lds_prefix) {
 #pragma unroll
-      for (int i = 0; i < kC; ++i) {
-        const uint64_t k = k0 + i;
-        const bool in = (uint64_t)i < c && k < A.ntiles;
-        v[i] = in ? tile_sums[k] : 0;
-        local += v[i];
-        if (adaptive && in) { l1 += tile_ess[2 * k]; l2 += tile_ess[2 * k + 1]; }
+    for (int i = 0; i < kC; ++i) {
+      const uint64_t k = k0 + i;
+      const bool in = (uint64_t)i < c_per && k < A.ntiles;
+      if (in) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(recs + k);
+        rv[i].s = ((uint64_t)raw.y << 32) | raw.x;
+        rv[i].e = (int32_t)raw.z;
+      } else {
+        rv[i].s = 0;
+        rv[i].e = kRowEmpty;
       }
-    } else {
-      for (uint64_t i = 0; i < c && k0 + i < A.ntiles; ++i) {
-        local += tile_sums[k0 + i];
-        if (adaptive) { l1 += tile_ess[2 * (k0 + i)]; l2 += tile_ess[2 * (k0 + i) + 1]; }
-      }
+      ev1[i] = adaptive && in ? tile_ess[2 * k] : 0;
+      ev2[i] = adaptive && in ? tile_ess[2 * k + 1] : 0;
     }
-    const uint64_t incl = wave_scan_incl(local);
-    const int w = tid >> 6, lane = tid & 63;
+  }
+#pragma unroll
+  for (int r = 0; r < kPer; ++r) marks[tid + r * kBlock] = 0;
+  if (tid == 0) { sh_klo = ~0u; sh_khi = 0; sh_cnt = 0; }
+  policy_prefetch(P, jq, 0);
+
+  // ---- merge: anchor, shifted masses, exclusive prefix, total, ESS sums ------------------------------------------
+  int32_t e = kRowEmpty;
+  uint64_t tot = 0, r1 = 0, r2 = 0;
+  uint64_t mass[kC];
+  uint64_t chunk_pre = 0, chunk_mass = 0;
+  if (lds_prefix) {
+#pragma unroll
+    for (int i = 0; i < kC; ++i) e = rv[i].e > e ? rv[i].e : e;
+    e = (int32_t)wave_last_u32(wave_scan_u32((uint32_t)e ^ 0x80000000u, 0u, [](uint32_t a, uint32_t x) { return x > a ? x : a; })) ^ (int32_t)0x80000000u;
+    if (lane == 0) sh_e[wv] = e;
+    __syncthreads();
+    e = sh_e[0];
+#pragma unroll
+    for (int i = 1; i < kW; ++i) e = sh_e[i] > e ? sh_e[i] : e;
+    uint64_t l1 = 0, l2 = 0;
+    int dsh[kC];
+#pragma unroll
+    for (int i = 0; i < kC; ++i) {
+      dsh[i] = tile_shift(e, rv[i].e);
+      mass[i] = shr64(rv[i].s, dsh[i]);
+      chunk_mass += mass[i];
+      if (adaptive) { l1 += shr64(ev1[i], dsh[i]); l2 += shr64(ev2[i], 2 * dsh[i]); }
+    }
+    const uint64_t incl = wave_scan_incl(chunk_mass);
     if (adaptive) { l1 = wave_sum(l1); l2 = wave_sum(l2); }
     if (lane == 63) {
-      sh_scan[w] = incl;
-      if (adaptive) { sh_ess[w] = l1; sh_ess[kW + w] = l2; }
+      sh_scan[wv] = incl;
+      if (adaptive) { sh_scan[kW + wv] = l1; sh_scan[2 * kW + wv] = l2; }
     }
     __syncthreads();
     uint64_t wbase = 0;
 #pragma unroll
     for (int i = 0; i < kW; ++i) {
-      if (i < w) wbase += sh_scan[i];
+      if (i < wv) wbase += sh_scan[i];
       tot += sh_scan[i];
-      if (adaptive) { r1 += sh_ess[i]; r2 += sh_ess[kW + i]; }
+      if (adaptive) { r1 += sh_scan[kW + i]; r2 += sh_scan[2 * kW + i]; }
     }
-    chunk_pre = wbase + incl - local;
-    // a tile may own more than kCapSlots slots only if its mass exceeds (kCapSlots - 8) / n_out of the total: ONE
-    // threshold (every workgroup derives the same one from the same total), tested first on the thread's whole chunk
-    const uint64_t heavy_mass = heavy_threshold(tot, A.heavy_shift);
-    const bool owns_b = k0 <= b && b < k0 + c;  // (no division: b / c on 64-bit scalars is a long sequence)
-    const bool maybe_heavy = A.allow_help && (local > heavy_mass || (tot == 0 && k0 + c >= A.ntiles));
-    if (owns_b || maybe_heavy) {  // (one thread per workgroup in the common case)
-      uint64_t run = chunk_pre;
-      auto visit = [&](uint64_t k, uint64_t mass) {
-        if (k == b) sh_pre = run;
-        // (with no mass at all the last tile closes the comb and owns every slot: a candidate too)
-        if (A.allow_help && (mass > heavy_mass || (tot == 0 && k + 1 == A.ntiles))) {
-          const uint32_t e = atomicAdd(&heavy_n, 1u);
-          if (e < (uint32_t)kMaxHeavy) {
-            heavy_tile[e] = (uint32_t)k;
-            reinterpret_cast<uint64_t*>(nb)[e] = run;  // its exclusive mass prefix (nb is free until a tile is served)
-          }
-        }
-        run += mass;
-      };
-      if (c <= (uint64_t)kC) {
+    chunk_pre = wbase + incl - chunk_mass;
+    uint64_t run = chunk_pre;
 #pragma unroll
-        for (int i = 0; i < kC; ++i)
-          if ((uint64_t)i < c && k0 + i < A.ntiles) visit(k0 + i, v[i]);
-      } else {
-        for (uint64_t i = 0; i < c && k0 + i < A.ntiles; ++i) visit(k0 + i, tile_sums[k0 + i]);
+    for (int i = 0; i < kC; ++i) {
+      const uint64_t k = k0 + i;
+      if ((uint64_t)i < c_per && k < A.ntiles) {
+        sh_pre[k] = run;
+        sh_d[k] = (uint8_t)dsh[i];
+        run += mass[i];
       }
     }
-    __syncthreads();
-    pre = sh_pre;
-    n_heavy = heavy_n;
+    if (tid == 0) sh_pre[A.ntiles] = tot;
+  } else {
+    tot = A.prefix[A.ntiles];
+    e = (int32_t)(int64_t)A.prefix[A.ntiles + 1];
+    if (adaptive) { r1 = A.prefix[A.ntiles + 2]; r2 = A.prefix[A.ntiles + 3]; }
   }
-  if (q_total_out && b == 0 && tid == 0) q_total_out[0] = tot;
-  const bool helping = A.allow_help && n_heavy > 0 && n_heavy <= (uint32_t)kMaxHeavy;
+  if (b == 0 && tid == 0) {
+    if (e_out) e_out[0] = e;
+    if (q_out) q_out[0] = tot;
+  }
   const bool resample = !adaptive || ess_says_resample(r1, r2, A.ess_thr);
   if (resampled_out && b == 0 && tid == 0) resampled_out[0] = resample ? 1 : 0;
+  policy_stage(P, 0);  // (every path below passes a barrier before the policy computes)
 
-  float tmax = -__builtin_inff();
-  static_assert(kPer == 4, "four consecutive sources and four consecutive output slots per lane");
+  auto pre_at = [&](uint64_t k) -> uint64_t { return lds_prefix ? sh_pre[k] : A.prefix[k]; };
+  auto shift_at = [&](uint64_t k) -> int { return lds_prefix ? (int)sh_d[k] : tile_shift(e, recs[k].e); };
+
+  uint32_t anc[kPer];
+  bool ok[kPer];
+#pragma unroll
+  for (int r = 0; r < kPer; ++r) ok[r] = jq + r < j1;
+  float lw_prev[kPer] = {0.0f, 0.0f, 0.0f, 0.0f};
 
   if (ADAPTIVE && !resample) {
-    // ---- no resampling at this step: slot j keeps particle j, its log-weight accumulates --------------------
-    const int64_t jq = (int64_t)base + (int64_t)kPer * tid;
-    if ((int64_t)base < A.out_hi && (int64_t)(base + kTile) > A.out_lo && base < A.n) {  // workgroup-uniform
-      if (!own_loaded) load_tile_regs(E, P, lw4, base);
-      P.stage_source(tid);
-      __syncthreads();
-      const int64_t hi = A.out_hi < (int64_t)A.n ? A.out_hi : (int64_t)A.n;
-      int src[kPer];
-      bool ok[kPer];
+    // ---- no resampling at this step: slot j keeps particle j, its log-weight accumulates -------------------------
 #pragma unroll
-      for (int r = 0; r < kPer; ++r) {
-        src[r] = kPer * tid + r;
-        ok[r] = jq + r >= A.out_lo && jq + r < hi;
-      }
-      typename Policy::Out out[kPer];
-      float w[kPer];
-      policy_compute_quad(P, jq, src, out, w, 0);
-#pragma unroll
-      for (int r = 0; r < kPer; ++r) {
-        carry_lw(out[r], lw4[r], 0);
-        w[r] = out_lw(out[r], w[r], 0);
-      }
-      policy_store_quad(P, jq, A.out_lo, base, src, out, ok, 0);
-#pragma unroll
-      for (int r = 0; r < kPer; ++r) tmax = ok[r] && w[r] > tmax ? w[r] : tmax;
+    for (int r = 0; r < kPer; ++r) {
+      const uint64_t j = (uint64_t)jq + r;
+      anc[r] = (uint32_t)(j < A.n ? j : A.n - 1);
+      lw_prev[r] = ok[r] ? lw_all[anc[r]] : 0.0f;
     }
+    __syncthreads();  // (the policy's staged data: a barrier before it computes)
+  } else if (tot == 0) {
+    // ---- no mass at all (every weight -inf / NaN / underflowed): the population is kept as it is — slot j takes
+    // particle floor(j n / n_out) (the identity when n_out == n), the weights start afresh ---------------------------
+    const double ratio = (double)A.n / (double)A.n_out;
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+      const uint64_t g = (uint64_t)__builtin_floor((double)(jq + r) * ratio);
+      anc[r] = (uint32_t)(g < A.n ? g : A.n - 1);
+    }
+    __syncthreads();
   } else {
     const Stream<IMPL> rs(rkey, A.rkey_has_fold != 0, A.rkey_fold);
     const double u0 = u0_from_bits(rs.bits64(0));
     const double scale = (double)A.n_out / (double)tot;
-    E.m = m_ptr[0];
-    E.scale = scale;
-    E.u0 = u0;
-    // the ONE item this workgroup serves: by default its own tile, all of its slots
-    uint64_t it_tile = b, it_pre = pre;
-    int64_t it_lo = A.out_lo, it_hi = A.out_hi;
-    uint32_t skip_from = 0, skip_n = 0;
-    bool go = !extra, it_loaded = own_loaded;
-    if (part && !helping && !extra) {  // does the own tile serve anything here?
-      if (!tile_prefix) own_mass = tile_sums[b];
-      const int64_t t_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
-      const int64_t t_hi = b + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(pre + own_mass, scale, u0, (int64_t)A.n_out);
-      go = !(t_hi <= A.out_lo || t_lo >= A.out_hi);  // workgroup-uniform
-    }
-    if (helping) {
-      // ---- rare: some tile is heavy.  Everything below is workgroup-uniform bookkeeping in LDS scratch (the nb / anc_s
-      // arrays are free until a tile is served): order the heavy tiles, count their delegable chunks, rank the idle
-      // tiles, pick this workgroup's item. -----------------------------------------------------------------------
-      int64_t* hv_first = reinterpret_cast<int64_t*>(nb);            // [kMaxHeavy] first slot of the tile's chunk grid
-      int64_t* hv_hi = hv_first + kMaxHeavy;                          // [kMaxHeavy] end of its slots here
-      uint64_t* hv_pre = reinterpret_cast<uint64_t*>(anc_s);          // [kMaxHeavy] exclusive mass prefix
-      uint32_t* hv_tile = reinterpret_cast<uint32_t*>(hv_pre + kMaxHeavy);  // [kMaxHeavy] ordered by tile index
-      uint32_t* hv_win = hv_tile + kMaxHeavy;                         // [kMaxHeavy] delegable chunks
-      uint32_t* hv_cum = heavy_tile;                                  // [kMaxHeavy] ... before this tile (written once the
-                                                                      // unordered list has been consumed, behind a barrier)
-      static_assert(2 * kMaxHeavy * 8 <= kTile * 4 && kMaxHeavy * (8 + 8) <= kTile * 4, "rare-path scratch fits nb / anc_s");
-      uint32_t idle_rank = ~0u, n_idle = 0;
-      if (tile_prefix) {
-        n_idle = (uint32_t)tile_prefix[A.ntiles + 4 + 2 * kMaxHeavy];
-        if (!extra && own_mass == 0 && b + 1 < A.ntiles) {
-          const uint64_t wd = tile_prefix[A.ntiles + 1 + kPrefixTail + (b >> 1)];
-          idle_rank = (uint32_t)(wd >> (32 * (b & 1)));
-        }
-      } else {
-        // idle tiles (mass 0, not the last one: it closes the comb) before this thread's chunk: a second block scan
-        uint32_t cnt = 0;
-        auto is_idle = [&](uint64_t k, uint64_t mass) { return mass == 0 && k + 1 < A.ntiles; };
-        if (c <= (uint64_t)kC) {
+    const int64_t n_out = (int64_t)A.n_out;
+    auto nhi_of = [&](uint64_t k) -> int64_t {  // teeth below the END of tile k
+      return k + 1 >= A.ntiles ? n_out : teeth_below(pre_at(k + 1), scale, u0, n_out);
+    };
+    // ---- which source tiles own a tooth in [j0, j1)? -------------------------------------------------------------
+    uint64_t k_lo = 0, k_hi = 0;
+    if (lds_prefix) {
+      __syncthreads();  // sh_pre / sh_d complete
+      const int64_t c_lo = teeth_below(chunk_pre, scale, u0, n_out);
+      const int64_t c_hi = k0 + c_per >= A.ntiles ? n_out : teeth_below(chunk_pre + chunk_mass, scale, u0, n_out);
+      if (k0 < A.ntiles && c_hi > j0 && c_lo < j1 && c_hi > c_lo) {
+        int64_t lo_t = c_lo;
+        uint64_t run = chunk_pre;
 #pragma unroll
-          for (int i = 0; i < kC; ++i)
-            if ((uint64_t)i < c && k0 + i < A.ntiles && is_idle(k0 + i, v[i])) ++cnt;
-        } else {
-          for (uint64_t i = 0; i < c && k0 + i < A.ntiles; ++i)
-            if (is_idle(k0 + i, tile_sums[k0 + i])) ++cnt;
-        }
-        const uint32_t incl = wave_scan_u32(cnt, 0u, [](uint32_t a, uint32_t x) { return a + x; });
-        const int w = tid >> 6;
-        if ((tid & 63) == 63) sh_u32[w] = incl;
-        if (tid == 0) sh_u32[kW] = ~0u;
-        __syncthreads();
-        uint32_t before = incl - cnt;
-#pragma unroll
-        for (int i = 0; i < kW; ++i) {
-          if (i < w) before += sh_u32[i];
-          n_idle += sh_u32[i];
-        }
-        if (!extra && k0 <= b && b < k0 + c) {  // the thread whose chunk holds the own tile: rank = idle tiles before it
-          uint32_t r = before;
-          uint64_t bm = 0;
-          for (uint64_t k = k0; k <= b; ++k) {
-            const uint64_t mass = tile_sums[k];
-            if (k == b) bm = mass;
-            else if (is_idle(k, mass)) ++r;
+        for (int i = 0; i < kC; ++i) {
+          const uint64_t k = k0 + i;
+          if ((uint64_t)i < c_per && k < A.ntiles) {
+            run += mass[i];
+            const int64_t hi_t = k + 1 >= A.ntiles ? n_out : teeth_below(run, scale, u0, n_out);
+            if (hi_t > lo_t && hi_t > j0 && lo_t < j1) {
+              atomicMin(&sh_klo, (uint32_t)k);
+              atomicMax(&sh_khi, (uint32_t)k);
+              const uint32_t pos = atomicAdd(&sh_cnt, 1u);
+              if (pos < (uint32_t)kScanMax) sh_list[pos] = (uint32_t)k;
+            }
+            lo_t = hi_t;
           }
-          sh_u32[kW] = is_idle(b, bm) ? r : ~0u;
-          sh_scan[0] = bm;
         }
+      }
+      __syncthreads();
+      k_lo = sh_klo;
+      k_hi = sh_khi;
+    } else {
+      // large populations: 256-ary searches of the precomputed prefix.  k_lo = min{k : teeth below the end of tile k
+      // > j0}; k_hi = max{k : teeth below the start of tile k < j1}.
+      uint64_t lo = 0, hi = A.ntiles - 1;
+      while (hi - lo >= (uint64_t)kBlock) {  // (workgroup-uniform)
+        const uint64_t stride = (hi - lo + kBlock) / kBlock;
+        uint64_t kk = lo + (uint64_t)tid * stride + (stride - 1);
+        kk = kk > hi ? hi : kk;
+        if (lo + (uint64_t)tid * stride <= hi && nhi_of(kk) > j0) atomicMin(&sh_klo, (uint32_t)tid);
         __syncthreads();
-        idle_rank = sh_u32[kW];
-        if (!extra) own_mass = sh_scan[0];
+        const uint64_t i = sh_klo;
+        __syncthreads();
+        if (tid == 0) sh_klo = ~0u;
+        const uint64_t nlo = lo + i * stride;
+        uint64_t nhi = nlo + (stride - 1);
+        hi = nhi > hi ? hi : nhi;
+        lo = nlo;
+        __syncthreads();
       }
-      // the extra workgroups rank behind the idle tiles
-      if (A.extra_first) {
-        if (extra) idle_rank = (uint32_t)(b - A.ntiles);
-        else if (idle_rank != ~0u) idle_rank += A.n_extra;
-      } else if (extra) {
-        idle_rank = n_idle + (uint32_t)(b - A.ntiles);
-      }
-      n_idle += A.n_extra;
-      // heavy entries in tile order, with their chunk grids
-      uint64_t ts = 0, tp = 0;
-      uint32_t pos = 0;
-      if ((uint32_t)tid < n_heavy) {
-        if (tile_prefix) { ts = tile_prefix[A.ntiles + 4 + 2 * tid]; tp = tile_prefix[A.ntiles + 5 + 2 * tid]; }
-        else { ts = heavy_tile[tid]; tp = reinterpret_cast<const uint64_t*>(nb)[tid]; }  // (unordered list of the mass scan)
-        for (uint32_t e = 0; e < n_heavy; ++e) {
-          const uint64_t te = tile_prefix ? tile_prefix[A.ntiles + 4 + 2 * e] : (uint64_t)heavy_tile[e];
-          pos += te < ts ? 1u : 0u;
-        }
-      }
-      __syncthreads();  // the unordered list has been read: the ordered arrays may overwrite its scratch
-      if ((uint32_t)tid < n_heavy) {
-        const uint64_t mass = tile_prefix ? tile_prefix[ts + 1] - tp : tile_sums[ts];
-        const int64_t t_lo = teeth_below(tp, scale, u0, (int64_t)A.n_out);
-        const int64_t t_hi = ts + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(tp + mass, scale, u0, (int64_t)A.n_out);
-        const int64_t lo = t_lo > A.out_lo ? t_lo : A.out_lo, hi = t_hi < A.out_hi ? t_hi : A.out_hi;
-        const int64_t first = lo & ~(int64_t)3;
-        const int64_t nchunk = hi > first ? (hi - first + (int64_t)kTile - 1) / (int64_t)kTile : 0;
-        hv_tile[pos] = (uint32_t)ts;
-        hv_pre[pos] = tp;
-        hv_first[pos] = first;
-        hv_hi[pos] = hi;
-        hv_win[pos] = nchunk > kOwnChunks ? (uint32_t)(nchunk - kOwnChunks) : 0u;
-      }
+      if (lo + (uint64_t)tid <= hi && nhi_of(lo + (uint64_t)tid) > j0) atomicMin(&sh_klo, (uint32_t)tid);
       __syncthreads();
-      // Takers (idle tiles, then the launch's extra workgroups) take GROUPS of g consecutive delegable chunks of one heavy
-      // tile: g = 1 while there are at least as many takers as chunks, 2, 4, ... when the launch has fewer extras than chunks
-      // (the extras are a fraction of the tiles: they cost a little in every ordinary step).  hv_cum counts groups.
-      // (g is a power of two found by doubling: an integer division here costs ~30 registers while the own tile's
-      // particles are live in registers — 95 instead of 67 VGPRs, a wave less per SIMD for every launch)
-      uint32_t grp = 1, grp_sh = 0;
-      if ((uint32_t)tid < n_heavy) {
-        uint32_t total = 0;
-        for (uint32_t e = 0; e < n_heavy; ++e) total += hv_win[e];
-        const uint32_t takers = n_idle > n_heavy ? n_idle - n_heavy : 1u;  // (each heavy tile may round one group up)
-        while ((uint64_t)grp * takers < (uint64_t)total && grp_sh < 20u) { grp <<= 1; ++grp_sh; }
-        uint32_t cum = 0;
-        for (uint32_t e = 0; e < (uint32_t)tid; ++e) cum += (hv_win[e] + grp - 1u) >> grp_sh;
-        hv_cum[tid] = cum;
+      k_lo = lo + sh_klo;
+      lo = k_lo;
+      hi = A.ntiles - 1;
+      while (hi - lo >= (uint64_t)kBlock) {
+        const uint64_t stride = (hi - lo + kBlock) / kBlock;
+        const uint64_t kk = lo + (uint64_t)tid * stride;  // the START of sub-block tid
+        if (kk <= hi && teeth_below(pre_at(kk), scale, u0, n_out) < j1) atomicMax(&sh_khi, (uint32_t)tid);
+        __syncthreads();
+        const uint64_t i = sh_khi;
+        __syncthreads();
+        if (tid == 0) sh_khi = 0;
+        const uint64_t nlo = lo + i * stride;
+        uint64_t nhi = nlo + (stride - 1);
+        hi = nhi > hi ? hi : nhi;
+        lo = nlo;
+        __syncthreads();
       }
-      if (tid == 0) { sh_u32[kW + 1] = ~0u; sh_u32[kW + 2] = 0; sh_u32[kW + 3] = 1; }
+      if (lo + (uint64_t)tid <= hi && teeth_below(pre_at(lo + (uint64_t)tid), scale, u0, n_out) < j1) atomicMax(&sh_khi, (uint32_t)tid);
       __syncthreads();
-      // this workgroup's item: thread p speaks for heavy entry p
-      if ((uint32_t)tid < n_heavy) {
-        const uint32_t p = (uint32_t)tid, cum = hv_cum[p], win = hv_win[p], groups = (win + grp - 1u) >> grp_sh;
-        if (hv_tile[p] == (uint32_t)b) {  // the own tile is heavy: it keeps its first kOwnChunks and what no taker takes
-          const uint32_t taken = n_idle > cum ? (n_idle - cum < groups ? n_idle - cum : groups) : 0u;
-          sh_u32[kW + 1] = p;
-          sh_u32[kW + 2] = taken * grp < win ? taken * grp : win;  // delegated chunks
-        } else if (idle_rank != ~0u && idle_rank >= cum && idle_rank - cum < groups) {
-          sh_u32[kW + 1] = p | 0x80000000u;  // a taker: group (rank - cum) of heavy tile p
-          sh_u32[kW + 3] = grp;
-        }
-      }
-      __syncthreads();
-      const uint32_t sel = sh_u32[kW + 1];
-      if (sel == ~0u) {
-        if (part && !extra) {  // an ordinary tile of a sharded launch: does it serve anything here?
-          const int64_t t_lo = teeth_below(pre, scale, u0, (int64_t)A.n_out);
-          const int64_t t_hi = b + 1 >= A.ntiles ? (int64_t)A.n_out : teeth_below(pre + own_mass, scale, u0, (int64_t)A.n_out);
-          go = !(t_hi <= A.out_lo || t_lo >= A.out_hi);
-        }
-        if (idle_rank != ~0u) go = false;  // an idle tile nobody needs: it owns no slot
-      } else if (sel & 0x80000000u) {
-        const uint32_t p = sel & 0x7fffffffu;
-        const int64_t g = (int64_t)sh_u32[kW + 3];
-        const int64_t ci = (int64_t)kOwnChunks + (int64_t)(idle_rank - hv_cum[p]) * g;  // its first chunk
-        it_tile = hv_tile[p];
-        it_pre = hv_pre[p];
-        it_lo = hv_first[p] + ci * (int64_t)kTile;
-        it_hi = it_lo + g * (int64_t)kTile < hv_hi[p] ? it_lo + g * (int64_t)kTile : hv_hi[p];
-        it_loaded = false;
-        go = it_lo < it_hi;
-      } else {
-        skip_from = (uint32_t)kOwnChunks;
-        skip_n = sh_u32[kW + 2];
-        go = hv_hi[sel] > hv_first[sel];
-      }
-      __syncthreads();  // the scratch in nb / anc_s has been read: serving may overwrite it
-    }
-    if (go) serve_tile<IMPL>(E, P, lw4, it_tile, it_pre, it_lo, it_hi, it_loaded, tmax, skip_from, skip_n);
-  }
-  {
-    const float wm = wave_max(tmax);
-    if ((tid & 63) == 0) shf[tid >> 6] = wm;
-    __syncthreads();
-    if (tid == 0) {
-      float bm = shf[0];
+      k_hi = lo + sh_khi;
+      // the tiles of [k_lo, k_hi] that do own a tooth here (up to 4 per thread; a wider range searches per slot)
+      if (k_hi - k_lo < (uint64_t)(4 * kBlock)) {
 #pragma unroll
-      for (int i = 1; i < kW; ++i) bm = shf[i] > bm ? shf[i] : bm;
-      if (extra) {
-        if (extra_max) extra_max[b - A.ntiles] = bm;  // (-inf when nothing was served: every launch refreshes it)
-      } else if (max_partials) {
-        max_partials[b] = bm;
+        for (int i = 0; i < 4; ++i) {
+          const uint64_t k = k_lo + (uint64_t)tid + (uint64_t)i * kBlock;
+          if (k <= k_hi) {
+            const int64_t lo_t = teeth_below(pre_at(k), scale, u0, n_out), hi_t = nhi_of(k);
+            if (hi_t > lo_t && hi_t > j0 && lo_t < j1) {
+              const uint32_t pos = atomicAdd(&sh_cnt, 1u);
+              if (pos < (uint32_t)kScanMax) sh_list[pos] = (uint32_t)k;
+            }
+          }
+        }
+      } else if (tid == 0) {
+        sh_cnt = ~0u;
       }
+      __syncthreads();
     }
+    const uint32_t n_src = sh_cnt;
+    if (n_src <= (uint32_t)A.scan_max) {
+      // ---- few source tiles: every source marks the slot where its run starts; a max-scan spreads the marks -------
+      for (uint32_t li = 0; li < n_src; li += 2) {  // two tiles per round: their loads are in flight together
+        uint64_t kk[2], pre[2];
+        int dd[2];
+        bool live[2];
+        uint64_t c[2][kPer + 1];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          live[h] = li + h < n_src;
+          kk[h] = live[h] ? sh_list[li + h] : 0;
+          pre[h] = live[h] ? pre_at(kk[h]) : 0;
+          dd[h] = live[h] ? shift_at(kk[h]) : 64;
+          const uint64_t sbase = kk[h] * kTile + (uint64_t)kPer * tid;
+          if (live[h] && sbase + kPer <= A.n) {
+            const ulonglong2 v0 = reinterpret_cast<const ulonglong2*>(cdf_all + sbase)[0];
+            const ulonglong2 v1 = reinterpret_cast<const ulonglong2*>(cdf_all + sbase)[1];
+            c[h][1] = v0.x; c[h][2] = v0.y; c[h][3] = v1.x; c[h][4] = v1.y;
+          } else {
+#pragma unroll
+            for (int r = 0; r < kPer; ++r) c[h][r + 1] = live[h] && sbase + r < A.n ? cdf_all[sbase + r] : 0;
+          }
+          c[h][0] = live[h] && tid > 0 && sbase - 1 < A.n ? cdf_all[sbase - 1] : 0;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (!live[h]) continue;
+          const uint64_t sbase = kk[h] * kTile + (uint64_t)kPer * tid;
+          const uint32_t id_base = ((uint32_t)(kk[h] - k_lo) << 10) + (uint32_t)(kPer * tid) + 1u;
+          // teeth below the source before this thread's first (the tile's start for thread 0)
+          int64_t start = tid == 0 ? teeth_below(pre[h], scale, u0, n_out)
+                                   : teeth_at(sbase - 1, A.n, pre[h] + shr64(c[h][0], dd[h]), scale, u0, n_out);
+#pragma unroll
+          for (int r = 0; r < kPer; ++r) {
+            const int64_t nr = teeth_at(sbase + r, A.n, pre[h] + shr64(c[h][r + 1], dd[h]), scale, u0, n_out);
+            if (nr > start && nr > j0 && start < j1) marks[(start > j0 ? start : j0) - j0] = id_base + (uint32_t)r;
+            start = nr;
+          }
+        }
+      }
+      __syncthreads();
+      uint32_t v[kPer];
+      uint32_t run_max = 0;
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) {
+        const uint32_t x = marks[kPer * tid + r];
+        run_max = x > run_max ? x : run_max;
+        v[r] = run_max;
+      }
+      const uint32_t carry = block_scan_umax_excl(run_max, sh_u);
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) {
+        const uint32_t a = v[r] > carry ? v[r] : carry;
+        const uint64_t g = k_lo * kTile + (uint64_t)(a ? a - 1u : 0u);
+        anc[r] = (uint32_t)(g < A.n ? g : A.n - 1);
+      }
+    } else {
+      // ---- many light source tiles (or a very wide range): every slot searches the tile prefix, then the stored
+      // in-tile CDF of its tile.  Four independent searches per lane. ------------------------------------------------
+      uint64_t tl[kPer], th[kPer];
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) { tl[r] = k_lo; th[r] = k_hi; }
+      for (uint64_t span = k_hi - k_lo; span > 0; span >>= 1) {  // (uniform trip count: ceil(log2(span + 1)))
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) {
+          if (tl[r] < th[r]) {
+            const uint64_t mid = (tl[r] + th[r]) >> 1;
+            if (nhi_of(mid) > jq + r) th[r] = mid;
+            else tl[r] = mid + 1;
+          }
+        }
+      }
+      uint64_t pl[kPer], ph[kPer], pre[kPer], tb[kPer];
+      int dd[kPer];
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) {
+        const uint64_t k = tl[r];
+        pre[r] = pre_at(k);
+        dd[r] = shift_at(k);
+        tb[r] = k * kTile;
+        pl[r] = 0;
+        const uint64_t cnt = tb[r] + kTile <= A.n ? (uint64_t)kTile : A.n - tb[r];
+        ph[r] = cnt - 1;
+      }
+#pragma unroll 1
+      for (int it = 0; it < 10; ++it) {  // log2(kTile)
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) {
+          if (pl[r] < ph[r]) {
+            const uint64_t mid = (pl[r] + ph[r]) >> 1;
+            const int64_t nm = teeth_at(tb[r] + mid, A.n, pre[r] + shr64(cdf_all[tb[r] + mid], dd[r]), scale, u0, n_out);
+            if (nm > jq + r) ph[r] = mid;
+            else pl[r] = mid + 1;
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kPer; ++r) anc[r] = (uint32_t)(tb[r] + pl[r]);
+      __syncthreads();  // (barrier count as on the marks path)
+    }
+  }
+
+  typename Policy::Out out[kPer];
+  float w[kPer];
+  policy_compute_quad(P, jq, anc, out, w, 0);
+  if (ADAPTIVE && !resample) {
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) w[r] = w[r] + lw_prev[r];
+  }
+  policy_store_quad(P, jq, A.out_lo, anc, out, ok, 0);
+  if (Policy::kEmit) {
+    const uint64_t loc = (uint64_t)(jq - A.out_lo);
+    emit_tile<ADAPTIVE>(w, ok, cdf_out + loc, logw_out ? logw_out + loc : nullptr, recs_out + ot,
+                        adaptive && ess_out ? ess_out + 2 * ot : nullptr);
   }
 }
-
 
 }  // namespace gjx

@@ -580,219 +580,93 @@ __global__ void k_lse_finish(const float* m_ptr, const uint64_t* q_ptr, int frac
   out[0] = m_ptr[0] + m_log(qf);
 }
 
-// A policy turns (output slot j, its ancestor) into the new particle.  `compute` is pure so the
+// A policy turns (output slot j, its ancestor's GLOBAL index) into the new particle.  `compute` is pure so the
 // kernel can run four slots' cipher / transform chains interleaved; `store` writes the results.
 struct AncestorOnly {
+  static constexpr bool kEmit = false;  // no weights: nothing to emit for a next resampling
   int32_t* anc;  // [out_hi - out_lo]
   struct Out {};
   GJX_DEV void select_filter(uint64_t off, Key) { anc += off; }
-  GJX_DEV void fetch_source(uint64_t, uint64_t, int) const {}
-  GJX_DEV void stage_source(int) const {}
-  GJX_DEV float compute(int64_t, int, Out&) const { return 0.0f; }
-  GJX_DEV void store(int64_t j, int64_t out_lo, uint64_t src, const Out&) const { anc[j - out_lo] = (int32_t)src; }
+  GJX_DEV float compute(int64_t, uint32_t, Out&) const { return 0.0f; }
+  GJX_DEV void store(int64_t j, int64_t out_lo, uint32_t src, const Out&) const { anc[j - out_lo] = (int32_t)src; }
 };
 
-// (amdgpu_num_sgpr(96): 256-thread workgroups are admitted per CU by their SGPR allocation — 97+ cost a seventh
-// workgroup per CU, MI355X_MICROARCH.md "Residency" — and the allocator settles at 100 without the cap; no spill at 96)
+// ONE launch per SMC step: resample (from the previous step's records and in-tile CDFs) + gather + propagate + weight
+// + this step's CDFs and records (resample_body, gjx_device.hpp).
 template <int IMPL, class Policy, bool ADAPTIVE = false>
-__global__ __attribute__((amdgpu_num_sgpr(96))) __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P, float* max_partials) {
-  resample_body<IMPL, Policy, ADAPTIVE>(A, P, max_partials);
+__global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P) {
+  resample_body<IMPL, Policy, ADAPTIVE>(A, P);
 }
 
-// Per-tile fixed-point mass of local log-weights, written at the global tile offset.
-// The max is reduced redundantly by every block from the per-tile maxima (L2-resident).  One WAVE per tile (a
-// workgroup = 4 tiles): 16 particles per lane as four 16-byte loads, the tile's mass is a wave reduction (DPP, no
-// LDS, no barrier) — the only workgroup-wide step left is the max of the tile maxima, once per 4 tiles.
-constexpr int kTilesPerSumBlock = kBlock / kWave;
-template <bool ESS>
-__global__ __launch_bounds__(kBlock) void k_tile_sums_wave(const float* lw, uint64_t n_local,
-                                                      const float* max_partials, uint64_t n_mp,
-                                                      const float* m_ptr, int frac,
-                                                      uint64_t* tile_sums_at, float* max_out,
-                                                      uint32_t filter_tiles, uint64_t filter_stride,
-                                                      uint64_t mq_stride, uint32_t ntiles_local,
-                                                      uint64_t* tile_ess_at,
-                                                      const float* extra_partials, uint32_t n_extra) {
+// Per-tile fixed-point mass of log-weights under their GLOBAL maximum (the multinomial / single-draw
+// paths, which materialise a global CDF).  The max is reduced redundantly by every block from the per-tile maxima.
+__global__ __launch_bounds__(kBlock) void k_tile_sums_block(const float* lw, uint64_t n_local, const float* max_partials,
+                                                            uint64_t n_mp, int frac, uint64_t* tile_sums_at, float* max_out) {
+  __shared__ uint64_t sh64[kBlock / kWave];
   __shared__ float shf[kBlock / kWave];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t tiles = filter_tiles ? filter_tiles : ntiles_local;
-  const uint32_t groups = (tiles + kTilesPerSumBlock - 1) / kTilesPerSumBlock;
-  uint64_t g = blockIdx.x;
-  if (filter_tiles) {  // several filters per launch: this workgroup's filter
-    const uint64_t f = g / groups;
-    g -= f * groups;
-    lw += f * filter_stride;
-    if (max_partials) max_partials += f * filter_tiles;
-    if (extra_partials) extra_partials += f * n_extra;
-    tile_sums_at += f * filter_tiles;
-    if (tile_ess_at) tile_ess_at += 2 * f * filter_tiles;
-    if (max_out) max_out += f * mq_stride;
-    if (m_ptr) m_ptr += f * mq_stride;
-  }
-  const uint64_t tile = g * kTilesPerSumBlock + (uint64_t)wv;
-  const bool live = tile < tiles;
-  const uint64_t base = tile * kTile;
-  float lwv[16];  // issued before the max reduction so the latencies overlap
-  if (live && base + kTile <= n_local && ((uintptr_t)lw & 15) == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float4 v = reinterpret_cast<const float4*>(lw + base + (uint64_t)k * 256)[lane];
-      lwv[4 * k] = v.x; lwv[4 * k + 1] = v.y; lwv[4 * k + 2] = v.z; lwv[4 * k + 3] = v.w;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint64_t i = base + (uint64_t)(k >> 2) * 256 + 4 * (uint64_t)lane + (k & 3);
-      lwv[k] = live && i < n_local ? lw[i] : -__builtin_inff();
-    }
-  }
-  float m;
-  if (m_ptr) {  // large populations: the max was reduced once by k_reduce_max
-    m = m_ptr[0];
-  } else {
-    m = -__builtin_inff();
-    for (uint64_t k = threadIdx.x; k < n_mp; k += kBlock) {
-      const float v = max_partials[k];
-      m = v > m ? v : m;
-    }
-    if (extra_partials)  // (launch-uniform) what the extra workgroups of the resample kernel served
-      for (uint32_t k = threadIdx.x; k < n_extra; k += kBlock) {
-        const float v = extra_partials[k];
-        m = v > m ? v : m;
-      }
-    m = block_max(m, shf);
-    if (max_out && g == 0 && threadIdx.x == 0) max_out[0] = m;
-  }
-  uint64_t acc = 0, a1 = 0, a2 = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const uint64_t i = base + (uint64_t)(k >> 2) * 256 + 4 * (uint64_t)lane + (k & 3);
-    if (live && i < n_local) {
-      const uint64_t q = fixw(lwv[k], m, frac);
-      acc += q;
-      if (ESS) {  // the ESS sums of adaptive filters: gjx_smc_config.ess_threshold
-        const uint64_t r = ess_r(q, frac);
-        a1 += r;
-        a2 += r * r;
-      }
-    }
-  }
-  acc = wave_sum(acc);
-  if (live && lane == 0) tile_sums_at[tile] = acc;
-  if (ESS && tile_ess_at) {  // launch-uniform
-    a1 = wave_sum(a1);
-    a2 = wave_sum(a2);
-    if (live && lane == 0) { tile_ess_at[2 * tile] = a1; tile_ess_at[2 * tile + 1] = a2; }
-  }
-}
-
-// The same with one WORKGROUP per tile (4 particles per lane): more workgroups — better while a launch has few
-// tiles (one filter of 1e6 particles: 977), where the wave-per-tile form leaves most of the machine idle.
-template <bool ESS>
-__global__ __launch_bounds__(kBlock) void k_tile_sums_block(const float* lw, uint64_t n_local,
-                                                      const float* max_partials, uint64_t n_mp,
-                                                      const float* m_ptr, int frac,
-                                                      uint64_t* tile_sums_at, float* max_out,
-                                                      uint32_t filter_tiles, uint64_t filter_stride,
-                                                      uint64_t mq_stride, uint64_t* tile_ess_at,
-                                                      const float* extra_partials, uint32_t n_extra) {
-  __shared__ uint64_t sh64[3 * (kBlock / kWave)];
-  __shared__ float shf[kBlock / kWave];
-  uint64_t tile = blockIdx.x;
-  if (filter_tiles) {  // several filters per launch: this workgroup's filter
-    const uint64_t f = tile / filter_tiles;
-    tile -= f * filter_tiles;
-    lw += f * filter_stride;
-    if (max_partials) max_partials += f * filter_tiles;
-    if (extra_partials) extra_partials += f * n_extra;
-    tile_sums_at += f * filter_tiles;
-    if (tile_ess_at) tile_ess_at += 2 * f * filter_tiles;
-    if (max_out) max_out += f * mq_stride;
-    if (m_ptr) m_ptr += f * mq_stride;
-  }
+  const uint64_t tile = blockIdx.x;
   float lwv[kPer];
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {  // issued before the max reduction so the latencies overlap
     const uint64_t i = tile * kTile + (uint64_t)r * kBlock + threadIdx.x;
     lwv[r] = i < n_local ? lw[i] : -__builtin_inff();
   }
-  float m;
-  if (m_ptr) {  // large populations: the max was reduced once by k_reduce_max
-    m = m_ptr[0];
-  } else {
-    m = -__builtin_inff();
-    for (uint64_t k = threadIdx.x; k < n_mp; k += kBlock) {
-      const float v = max_partials[k];
-      m = v > m ? v : m;
-    }
-    if (extra_partials)  // (launch-uniform) what the extra workgroups of the resample kernel served
-      for (uint32_t k = threadIdx.x; k < n_extra; k += kBlock) {
-        const float v = extra_partials[k];
-        m = v > m ? v : m;
-      }
-    m = block_max(m, shf);
-    if (max_out && tile == 0 && threadIdx.x == 0) max_out[0] = m;
+  float m = -__builtin_inff();
+  for (uint64_t k = threadIdx.x; k < n_mp; k += kBlock) {
+    const float v = max_partials[k];
+    m = v > m ? v : m;
   }
-  uint64_t acc = 0, a1 = 0, a2 = 0;
+  m = block_max(m, shf);
+  if (max_out && tile == 0 && threadIdx.x == 0) max_out[0] = m;
+  uint64_t acc = 0;
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {
     const uint64_t i = tile * kTile + (uint64_t)r * kBlock + threadIdx.x;
-    if (i < n_local) {
-      const uint64_t q = fixw(lwv[r], m, frac);
-      acc += q;
-      if (ESS) {
-        const uint64_t rr = ess_r(q, frac);
-        a1 += rr;
-        a2 += rr * rr;
-      }
-    }
+    if (i < n_local) acc += fixw(lwv[r], m, frac);
   }
-  // one barrier for all three sums (ESS sums only in adaptive filters)
-  constexpr int kW = kBlock / kWave;
-  acc = wave_sum(acc);
-  if (ESS) { a1 = wave_sum(a1); a2 = wave_sum(a2); }
-  const int wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    sh64[wv] = acc;
-    if (ESS) { sh64[kW + wv] = a1; sh64[2 * kW + wv] = a2; }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint64_t t0 = 0, t1 = 0, t2 = 0;
-#pragma unroll
-    for (int i = 0; i < kW; ++i) {
-      t0 += sh64[i];
-      if (ESS) { t1 += sh64[kW + i]; t2 += sh64[2 * kW + i]; }
-    }
-    tile_sums_at[tile] = t0;
-    if (ESS && tile_ess_at) { tile_ess_at[2 * tile] = t1; tile_ess_at[2 * tile + 1] = t2; }
-  }
+  acc = block_sum(acc, sh64);
+  if (threadIdx.x == 0) tile_sums_at[tile] = acc;
 }
 
-// Exclusive prefix of the tile masses, [ntiles + 1] (last entry = total), followed by the tail resample_body reads
-// (gjx_device.hpp kPrefixTail: ESS sums R1, R2, the number of heavy candidates and their (tile, prefix) pairs): one
-// workgroup per filter, each thread scans a contiguous chunk.  Used when the population is large enough that every
-// resample workgroup scanning tile_sums itself would dominate (ntiles > kPrefixTiles), and for filter batches.
-static const uint64_t kPrefixTiles = [] {
-  const char* e = std::getenv("GJX_PREFIX_TILES");  // tuning knob; default from measurement (<= 2048: resample_body's register scan)
-  const uint64_t v = e ? (uint64_t)atoll(e) : (uint64_t)2048;
-  return v > 2048 ? (uint64_t)2048 : v;
-}();
-__global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint64_t* tile_sums, const uint64_t* tile_ess, uint64_t ntiles,
-                                                       uint64_t n_out, uint64_t* prefix) {
+// Tile-anchored CDFs and records of ARBITRARY log-weights (the generic resampler's front half; the SMC kernels emit
+// theirs themselves): one workgroup per tile.
+__global__ __launch_bounds__(kBlock) void k_tile_cdf(const float* lw, uint64_t n, uint64_t* cdf, TileRec* recs) {
+  const uint64_t base = (uint64_t)blockIdx.x * kTile + (uint64_t)kPer * threadIdx.x;
+  float w[kPer];
+  bool ok[kPer];
+#pragma unroll
+  for (int r = 0; r < kPer; ++r) {
+    ok[r] = base + r < n;
+    w[r] = ok[r] ? lw[base + r] : -__builtin_inff();
+  }
+  emit_tile<false>(w, ok, cdf + base, nullptr, recs + blockIdx.x, nullptr);
+}
+
+// The merge of a population's tile records by ONE workgroup per filter: anchor e, total mass Q, ESS sums, and — for
+// populations beyond kMaxLdsTiles, where every resample workgroup merging all records itself would dominate — the
+// exclusive prefix of the shifted tile masses (layout: gjx_device.hpp prefix_words).  Also the closing (e, Q) of a run.
+__global__ __launch_bounds__(kBlock) void k_scan_records(const TileRec* recs, const uint64_t* tile_ess, uint64_t ntiles,
+                                                         uint64_t* prefix, int32_t* e_out, uint64_t* q_out, uint64_t mq_stride) {
   __shared__ uint64_t sh64[kBlock / kWave];
   __shared__ uint64_t sh_e[2 * (kBlock / kWave)];
-  __shared__ uint32_t heavy_n;
-  tile_sums += (uint64_t)blockIdx.x * ntiles;  // one workgroup per filter
+  __shared__ float shf[kBlock / kWave];
+  recs += (uint64_t)blockIdx.x * ntiles;  // one workgroup per filter
   if (tile_ess) tile_ess += 2 * (uint64_t)blockIdx.x * ntiles;
-  prefix += (uint64_t)blockIdx.x * prefix_words(ntiles);
-  if (threadIdx.x == 0) heavy_n = 0;
+  if (prefix) prefix += (uint64_t)blockIdx.x * prefix_words(ntiles);
   const uint64_t per = (ntiles + kBlock - 1) / kBlock;
-  const uint64_t lo = threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
+  const uint64_t lo = threadIdx.x * per < ntiles ? threadIdx.x * per : ntiles, hi = lo + per < ntiles ? lo + per : ntiles;
+  // anchors are integers of magnitude <= 2^24 (row_anchor): exact as floats, so the float block max serves
+  float ef = (float)kRowEmpty;
+  for (uint64_t k = lo; k < hi; ++k) {
+    const float v = (float)recs[k].e;
+    ef = v > ef ? v : ef;
+  }
+  const int32_t e = (int32_t)block_max(ef, shf);
   uint64_t local = 0, l1 = 0, l2 = 0;
   for (uint64_t k = lo; k < hi; ++k) {
-    local += tile_sums[k];
-    if (tile_ess) { l1 += tile_ess[2 * k]; l2 += tile_ess[2 * k + 1]; }
+    const int d = tile_shift(e, recs[k].e);
+    local += shr64(recs[k].s, d);
+    if (tile_ess) { l1 += shr64(tile_ess[2 * k], d); l2 += shr64(tile_ess[2 * k + 1], 2 * d); }
   }
   uint64_t total;
   uint64_t run = block_scan_excl(local, sh64, total);
@@ -800,36 +674,22 @@ __global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint64_t* tile_sums
     l1 = block_sum(l1, sh_e);
     l2 = block_sum(l2, sh_e + kBlock / kWave);
   }
-  const uint64_t heavy_mass = heavy_threshold(total, heavy_shift_for(n_out));
-  for (uint64_t k = lo; k < hi; ++k) {
-    const uint64_t v = tile_sums[k];
-    prefix[k] = run;
-    if (v > heavy_mass || (total == 0 && k + 1 == ntiles)) {  // resample_body: a heavy candidate
-      const uint32_t e = atomicAdd(&heavy_n, 1u);
-      if (e < (uint32_t)kMaxHeavy) { prefix[ntiles + 4 + 2 * e] = k; prefix[ntiles + 5 + 2 * e] = run; }
+  if (prefix) {
+    for (uint64_t k = lo; k < hi; ++k) {
+      prefix[k] = run;
+      run += shr64(recs[k].s, tile_shift(e, recs[k].e));
     }
-    run += v;
   }
-  __syncthreads();
-  const uint32_t nh = heavy_n;
   if (threadIdx.x == 0) {
-    prefix[ntiles] = total;
-    prefix[ntiles + 1] = l1;
-    prefix[ntiles + 2] = l2;
-    prefix[ntiles + 3] = nh;
+    if (prefix) {
+      prefix[ntiles] = total;
+      prefix[ntiles + 1] = (uint64_t)(int64_t)e;
+      prefix[ntiles + 2] = l1;
+      prefix[ntiles + 3] = l2;
+    }
+    if (e_out) e_out[(uint64_t)blockIdx.x * mq_stride] = e;
+    if (q_out) q_out[(uint64_t)blockIdx.x * mq_stride] = total;
   }
-  if (nh == 0) return;  // (uniform) the idle ranks are read only when some tile is heavy
-  // every tile's rank among the idle tiles (mass 0, not the last tile: it closes the comb), and their number
-  uint32_t cnt = 0;
-  for (uint64_t k = lo; k < hi; ++k) cnt += (tile_sums[k] == 0 && k + 1 < ntiles) ? 1u : 0u;
-  uint64_t tot_idle;
-  uint32_t r = (uint32_t)block_scan_excl((uint64_t)cnt, sh64, tot_idle);
-  uint32_t* ranks = reinterpret_cast<uint32_t*>(prefix + ntiles + 1 + kPrefixTail);
-  for (uint64_t k = lo; k < hi; ++k) {
-    ranks[k] = r;
-    r += (tile_sums[k] == 0 && k + 1 < ntiles) ? 1u : 0u;
-  }
-  if (threadIdx.x == 0) prefix[ntiles + 4 + 2 * kMaxHeavy] = tot_idle;
 }
 
 // Inclusive fixed-point CDF materialised in HBM (multinomial / single-draw paths).
@@ -962,70 +822,52 @@ __global__ __launch_bounds__(kBlock) void k_gather(const int32_t* anc, uint64_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused bootstrap-SMC policies: propagate + weight one output slot.
+// Fused bootstrap-SMC policies: propagate + weight the four consecutive output slots of a lane.
 // ------------------------------------------------------------------------------------------------
 template <int IMPL>
 struct LgssmPolicy {
+  static constexpr bool kEmit = true;
   const float* prev_state;  // [n] (global) previous-step particles
   float* state_out;         // [n_local]
-  float* logw_out;          // [n_local]
   int32_t* anc_out;         // nullable [n_local]
   Key step_key;
   float a, q, y, rs, lognorm;
-  float* xs;                // LDS tile of previous states (set in stage_source)
-  float xr[kPer];           // the tile row values while in flight
+  float z[kPer];            // the quad's standard normals (prefetch: they do not depend on the ancestors)
   GJX_DEV void select_filter(uint64_t off, Key k) {
-    prev_state += off; state_out += off; logw_out += off;
+    prev_state += off; state_out += off;
     if (anc_out) anc_out += off;
     step_key = k;
   }
-  GJX_DEV void fetch_source(uint64_t base, uint64_t n, int tid) {
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-      const uint64_t i = base + (uint64_t)r * kBlock + tid;
-      xr[r] = i < n ? prev_state[i] : 0.0f;
-    }
-  }
-  GJX_DEV void stage_source(int tid) {
-    __shared__ float xs_tile[kTile];
-    xs = xs_tile;
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) xs_tile[r * kBlock + tid] = xr[r];
-  }
+  GJX_DEV void prefetch(int64_t jq) { smc_quad_normals<IMPL>(step_key, (uint64_t)jq >> 2, z); }
   struct Out {
-    float x, lw;
+    float x;
   };
   // the lane's four consecutive slots jq .. jq+3 (jq a multiple of 4): one quad of normals
-  GJX_DEV void compute_quad(int64_t jq, const int (&src)[4], Out (&o)[4], float (&w)[4]) const {
-    float z[4];
-    smc_quad_normals<IMPL>(step_key, (uint64_t)jq >> 2, z);
+  GJX_DEV void compute_quad(int64_t, const uint32_t (&anc)[4], Out (&o)[4], float (&w)[4]) const {
+    float xs[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xs[u] = prev_state[anc[u]];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float mean = a * xs[src[u]];
+      const float mean = a * xs[u];
       const float t = q * z[u];
       o[u].x = mean + t;
-      o[u].lw = logpdf_normal_pre(y, o[u].x, rs, lognorm);
-      w[u] = o[u].lw;
+      w[u] = logpdf_normal_pre(y, o[u].x, rs, lognorm);
     }
   }
-  GJX_DEV void store_quad(int64_t jq, int64_t out_lo, uint64_t base, const int (&src)[4], const Out (&o)[4],
-                          const bool (&ok)[4]) const {
+  GJX_DEV void store_quad(int64_t jq, int64_t out_lo, const uint32_t (&anc)[4], const Out (&o)[4], const bool (&ok)[4]) const {
     const int64_t k = jq - out_lo;
-    const bool vec = ((((uintptr_t)state_out | (uintptr_t)logw_out | (uintptr_t)anc_out) & 15) == 0);  // uniform
+    const bool vec = ((((uintptr_t)state_out | (uintptr_t)anc_out) & 15) == 0);  // uniform
     if (vec && ok[0] && ok[1] && ok[2] && ok[3]) {
       *reinterpret_cast<float4*>(state_out + k) = make_float4(o[0].x, o[1].x, o[2].x, o[3].x);
-      *reinterpret_cast<float4*>(logw_out + k) = make_float4(o[0].lw, o[1].lw, o[2].lw, o[3].lw);
-      if (anc_out)
-        *reinterpret_cast<int4*>(anc_out + k) = make_int4((int32_t)(base + (uint64_t)src[0]), (int32_t)(base + (uint64_t)src[1]),
-                                                         (int32_t)(base + (uint64_t)src[2]), (int32_t)(base + (uint64_t)src[3]));
+      if (anc_out) *reinterpret_cast<int4*>(anc_out + k) = make_int4((int32_t)anc[0], (int32_t)anc[1], (int32_t)anc[2], (int32_t)anc[3]);
       return;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (ok[u]) {
         state_out[k + u] = o[u].x;
-        logw_out[k + u] = o[u].lw;
-        if (anc_out) anc_out[k + u] = (int32_t)(base + (uint64_t)src[u]);
+        if (anc_out) anc_out[k + u] = (int32_t)anc[u];
       }
     }
   }
@@ -1045,109 +887,108 @@ GJX_DEV uint32_t hmm_alias_draw(const uint32_t* row, int32_t K, uint32_t bits) {
 
 template <int IMPL>
 struct HmmPolicy {
+  static constexpr bool kEmit = true;
   const int32_t* prev_state;
   int32_t* state_out;
-  float* logw_out;
   int32_t* anc_out;
   Key step_key;
   const uint32_t* trans_cdf;  // alias table [K,K] (gjx.h: trans_alias)
   const float* obs_logp;      // [K,K]
   int32_t K, y;
-  int32_t* zs;
-  float* ocol;
-  int32_t zr[kPer];
-  float oc;
+  uint32_t col[kPer], f24[kPer];  // the quad's draws, split into column and fraction (prefetch)
+  float oc;                       // obs_logp[tid, y] on its way to LDS
+  float* ocol;                    // LDS: column y of the observation table (one entry per state)
   GJX_DEV void select_filter(uint64_t off, Key k) {
-    prev_state += off; state_out += off; logw_out += off;
+    prev_state += off; state_out += off;
     if (anc_out) anc_out += off;
     step_key = k;
   }
-  GJX_DEV void fetch_source(uint64_t base, uint64_t n, int tid) {
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-      const uint64_t i = base + (uint64_t)r * kBlock + tid;
-      zr[r] = i < n ? prev_state[i] : 0;
-    }
-    oc = tid < K ? obs_logp[(size_t)tid * K + y] : 0.0f;
-  }
-  GJX_DEV void stage_source(int tid) {
-    __shared__ int32_t zs_tile[kTile];
-    __shared__ float ocol_tile[256];
-    zs = zs_tile;
-    ocol = ocol_tile;
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) zs_tile[r * kBlock + tid] = zr[r];
-    if (tid < K) ocol_tile[tid] = oc;
-  }
-  struct Out {
-    int32_t z;
-    float lw;
-  };
-  GJX_DEV void compute_quad(int64_t jq, const int (&src)[4], Out (&o)[4], float (&w)[4]) const {
+  GJX_DEV void prefetch(int64_t jq) {
     uint32_t bits[4];
     smc_quad_bits<IMPL>(step_key, (uint64_t)jq >> 2, bits);
-    // the four table words of the lane's slots are loaded together, then resolved
-    uint32_t col[4], f24[4], e[4], c[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint64_t t = (uint64_t)bits[u] * (uint64_t)(uint32_t)K;
       col[u] = (uint32_t)(t >> 32);
       f24[u] = (uint32_t)t >> 8;
-      e[u] = trans_cdf[(size_t)zs[src[u]] * K + col[u]];
     }
+    oc = (int)threadIdx.x < K ? obs_logp[(size_t)threadIdx.x * K + y] : 0.0f;
+  }
+  GJX_DEV void stage() {
+    __shared__ float ocol_tile[256];
+    ocol = ocol_tile;
+    if ((int)threadIdx.x < K) ocol_tile[threadIdx.x] = oc;
+  }
+  struct Out {
+    int32_t z;
+  };
+  GJX_DEV void compute_quad(int64_t, const uint32_t (&anc)[4], Out (&o)[4], float (&w)[4]) const {
+    // the four states, then the four table words, are loaded together
+    int32_t zs[4];
+    uint32_t e[4], c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) zs[u] = prev_state[anc[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e[u] = trans_cdf[(size_t)zs[u] * K + col[u]];
 #pragma unroll
     for (int u = 0; u < 4; ++u) c[u] = hmm_alias_pick(e[u], col[u], f24[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       o[u].z = (int32_t)c[u];
-      o[u].lw = ocol[c[u]];
-      w[u] = o[u].lw;
+      w[u] = ocol[c[u]];
     }
   }
-  GJX_DEV void store_quad(int64_t jq, int64_t out_lo, uint64_t base, const int (&src)[4], const Out (&o)[4],
-                          const bool (&ok)[4]) const {
+  GJX_DEV void store_quad(int64_t jq, int64_t out_lo, const uint32_t (&anc)[4], const Out (&o)[4], const bool (&ok)[4]) const {
     const int64_t k = jq - out_lo;
-    const bool vec = ((((uintptr_t)state_out | (uintptr_t)logw_out | (uintptr_t)anc_out) & 15) == 0);  // uniform
+    const bool vec = ((((uintptr_t)state_out | (uintptr_t)anc_out) & 15) == 0);  // uniform
     if (vec && ok[0] && ok[1] && ok[2] && ok[3]) {
       *reinterpret_cast<int4*>(state_out + k) = make_int4(o[0].z, o[1].z, o[2].z, o[3].z);
-      *reinterpret_cast<float4*>(logw_out + k) = make_float4(o[0].lw, o[1].lw, o[2].lw, o[3].lw);
-      if (anc_out)
-        *reinterpret_cast<int4*>(anc_out + k) = make_int4((int32_t)(base + (uint64_t)src[0]), (int32_t)(base + (uint64_t)src[1]),
-                                                         (int32_t)(base + (uint64_t)src[2]), (int32_t)(base + (uint64_t)src[3]));
+      if (anc_out) *reinterpret_cast<int4*>(anc_out + k) = make_int4((int32_t)anc[0], (int32_t)anc[1], (int32_t)anc[2], (int32_t)anc[3]);
       return;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (ok[u]) {
         state_out[k + u] = o[u].z;
-        logw_out[k + u] = o[u].lw;
-        if (anc_out) anc_out[k + u] = (int32_t)(base + (uint64_t)src[u]);
+        if (anc_out) anc_out[k + u] = (int32_t)anc[u];
       }
     }
   }
 };
 
 // Source-tile ranges of `world` equal blocks of output slots (gjx.h: gjx_smc_source_ranges).  One workgroup:
-// every thread owns a contiguous chunk of tiles; chunk offsets by one block scan; tile b can own slots in
-// [ceil(P_b) - 1, ceil(P_{b+1})) for some comb offset (P = prefix * N / Q in float64, the products
-// teeth_below forms), both bounds monotone in b, so a block's range is [#tiles with upper <= lo, #tiles with
-// lower < hi).
+// every thread owns a contiguous chunk of tiles; the records are merged like in the resample kernel (anchor, shifted
+// masses, chunk offsets by one block scan); tile b can own slots in [ceil(P_b) - 1, ceil(P_{b+1})) for some comb offset
+// (P = prefix * N / Q in float64, the products teeth_below forms), both bounds monotone in b, so a block's range is
+// [#tiles with upper <= lo, #tiles with lower < hi).
 constexpr int kMaxRangeBlocks = 64;
-__global__ __launch_bounds__(kBlock) void k_source_ranges(const uint64_t* tile_sums, const uint64_t* tile_ess, double ess_thr,
+__global__ __launch_bounds__(kBlock) void k_source_ranges(const TileRec* recs, const uint64_t* tile_ess, double ess_thr,
                                                           uint64_t ntiles, uint64_t n_total, int world, int64_t ticket,
                                                           int64_t* out) {
   __shared__ uint64_t sh64[kBlock / kWave];
   __shared__ uint64_t sh_e[2 * (kBlock / kWave)];
+  __shared__ float shf[kBlock / kWave];
   __shared__ unsigned long long cnt[2 * kMaxRangeBlocks];
   const int tid = threadIdx.x;
   if (tid < 2 * kMaxRangeBlocks) cnt[tid] = 0;
   const uint64_t per = (ntiles + kBlock - 1) / kBlock;
   const uint64_t b0 = per * (uint64_t)tid < ntiles ? per * (uint64_t)tid : ntiles;
   const uint64_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
+  float ef = (float)kRowEmpty;  // (anchors are exact as floats: |e| <= 2^24)
+  for (uint64_t b = b0; b < b1; ++b) {
+    const float v = (float)recs[b].e;
+    ef = v > ef ? v : ef;
+  }
+  const int32_t e = (int32_t)block_max(ef, shf);
+  auto mass = [&](uint64_t b) { return shr64(recs[b].s, tile_shift(e, recs[b].e)); };
   uint64_t local = 0, l1 = 0, l2 = 0;
   for (uint64_t b = b0; b < b1; ++b) {
-    local += tile_sums[b];
-    if (ess_thr > 0.0) { l1 += tile_ess[2 * b]; l2 += tile_ess[2 * b + 1]; }
+    local += mass(b);
+    if (ess_thr > 0.0) {
+      const int d = tile_shift(e, recs[b].e);
+      l1 += shr64(tile_ess[2 * b], d);
+      l2 += shr64(tile_ess[2 * b + 1], 2 * d);
+    }
   }
   if (ess_thr > 0.0) {  // an adaptive filter that keeps its particles at the next step needs no exchange at all:
     l1 = block_sum(l1, sh_e);                       // every block's sources are its own tiles
@@ -1176,7 +1017,7 @@ __global__ __launch_bounds__(kBlock) void k_source_ranges(const uint64_t* tile_s
       double lower = __builtin_ceil((double)pre * scale);
       lower = lower < nd ? lower : nd;
       lower = lower - 1.0 > 0.0 ? lower - 1.0 : 0.0;
-      pre += tile_sums[b];
+      pre += mass(b);
       double upper = __builtin_ceil((double)pre * scale);
       upper = (b + 1 == ntiles || !(upper < nd)) ? nd : upper;
       first += upper <= lo ? 1 : 0;
@@ -1187,8 +1028,9 @@ __global__ __launch_bounds__(kBlock) void k_source_ranges(const uint64_t* tile_s
   }
   __syncthreads();
   if (tid < 2 * world) {
-    // no mass at all (every weight underflowed): the comb degenerates to "the last particle owns every slot"
-    out[tid] = tot == 0 ? (int64_t)ntiles - 1 + (tid & 1) : (int64_t)cnt[tid];
+    // no mass at all (every weight underflowed): the population is kept, every block's sources are its own tiles
+    const uint64_t tiles_per_block = (n_total / (uint64_t)world) / kTile;
+    out[tid] = tot == 0 ? (int64_t)(((uint64_t)(tid >> 1) + (uint64_t)(tid & 1)) * tiles_per_block) : (int64_t)cnt[tid];
     __threadfence_system();
   }
   __syncthreads();
@@ -1197,47 +1039,39 @@ __global__ __launch_bounds__(kBlock) void k_source_ranges(const uint64_t* tile_s
   if (tid == 0) __hip_atomic_store(out + 2 * world, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Step 0 (no resampling): one block per GLOBAL tile; tiles outside this rank only clear their
-// max partial so the array can be max-combined across ranks.
+// Step 0 (no resampling): one block per LOCAL tile of the rank.
 template <int IMPL>
 __global__ __launch_bounds__(kBlock) void k_lgssm_init(FilterBatch fb, Key step_key, uint64_t first_slot,
                                                        uint64_t n_local, float x0_loc,
                                                        float x0_scale, float y, float rs,
-                                                       float lognorm, float* state_out,
-                                                       float* logw_out, int32_t* anc_out,
-                                                       float* max_partials) {
-  __shared__ float shf[kBlock / kWave];
-  uint64_t gtile = blockIdx.x;
+                                                       float lognorm, float* state_out, int32_t* anc_out, EmitOut em) {
+  uint64_t ltile = blockIdx.x;
   if (fb.n_filters > 1) {  // several filters per launch: tile of filter f, its key, its outputs
-    const uint32_t f = (uint32_t)(gtile / fb.tiles);
-    gtile -= (uint64_t)f * fb.tiles;
+    const uint32_t f = (uint32_t)(ltile / fb.tiles);
+    ltile -= (uint64_t)f * fb.tiles;
     step_key = fb.step_key[f];
     state_out += (uint64_t)f * fb.stride;
-    logw_out += (uint64_t)f * fb.stride;
     if (anc_out) anc_out += (uint64_t)f * fb.stride;
+    select_filter_emit(em, fb, f);
   }
-  const uint64_t gbase = gtile * kTile;
-  float tmax = -__builtin_inff();
-  if (gbase >= first_slot && gbase < first_slot + n_local) {
-    float z[4];  // the lane's four consecutive slots: one quad of normals
-    smc_quad_normals<IMPL>(step_key, (gbase >> 2) + threadIdx.x, z);
+  const uint64_t loc = ltile * kTile + (uint64_t)kPer * threadIdx.x;  // the lane's four consecutive slots, local
+  const uint64_t gq = first_slot + loc;
+  float z[4];  // one quad of normals
+  smc_quad_normals<IMPL>(step_key, gq >> 2, z);
+  float w[kPer];
+  bool ok[kPer];
 #pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-      const uint64_t j = gbase + (uint64_t)kPer * threadIdx.x + r;
-      if (j < first_slot + n_local) {
-        const float eps = z[r];
-        const float t = x0_scale * eps;
-        const float x = x0_loc + t;
-        const float lw = logpdf_normal_pre(y, x, rs, lognorm);
-        state_out[j - first_slot] = x;
-        logw_out[j - first_slot] = lw;
-        if (anc_out) anc_out[j - first_slot] = (int32_t)j;
-        tmax = lw > tmax ? lw : tmax;
-      }
+  for (int r = 0; r < kPer; ++r) {
+    ok[r] = loc + r < n_local;
+    const float t = x0_scale * z[r];
+    const float x = x0_loc + t;
+    w[r] = logpdf_normal_pre(y, x, rs, lognorm);
+    if (ok[r]) {
+      state_out[loc + r] = x;
+      if (anc_out) anc_out[loc + r] = (int32_t)(gq + r);
     }
   }
-  const float bm = block_max(tmax, shf);
-  if (threadIdx.x == 0) max_partials[blockIdx.x] = bm;
+  emit_init_tile(w, ok, em, loc, first_slot / kTile + ltile);
 }
 
 template <int IMPL>
@@ -1245,40 +1079,34 @@ __global__ __launch_bounds__(kBlock) void k_hmm_init(FilterBatch fb, Key step_ke
                                                      uint64_t n_local, const uint32_t* trans_cdf,
                                                      const float* obs_logp, int32_t K,
                                                      int32_t init_state, int32_t y,
-                                                     int32_t* state_out, float* logw_out,
-                                                     int32_t* anc_out, float* max_partials) {
-  __shared__ float shf[kBlock / kWave];
-  uint64_t gtile = blockIdx.x;
+                                                     int32_t* state_out, int32_t* anc_out, EmitOut em) {
+  uint64_t ltile = blockIdx.x;
   if (fb.n_filters > 1) {  // several filters per launch: tile of filter f, its key, its outputs
-    const uint32_t f = (uint32_t)(gtile / fb.tiles);
-    gtile -= (uint64_t)f * fb.tiles;
+    const uint32_t f = (uint32_t)(ltile / fb.tiles);
+    ltile -= (uint64_t)f * fb.tiles;
     step_key = fb.step_key[f];
     state_out += (uint64_t)f * fb.stride;
-    logw_out += (uint64_t)f * fb.stride;
     if (anc_out) anc_out += (uint64_t)f * fb.stride;
+    select_filter_emit(em, fb, f);
   }
-  const uint64_t gbase = gtile * kTile;
-  float tmax = -__builtin_inff();
-  if (gbase >= first_slot && gbase < first_slot + n_local) {
-    const uint32_t* cdf = trans_cdf + (size_t)init_state * K;
-    uint32_t qb[4];  // the lane's four consecutive slots: one quad of draws
-    smc_quad_bits<IMPL>(step_key, (gbase >> 2) + threadIdx.x, qb);
+  const uint64_t loc = ltile * kTile + (uint64_t)kPer * threadIdx.x;
+  const uint64_t gq = first_slot + loc;
+  const uint32_t* cdf = trans_cdf + (size_t)init_state * K;
+  uint32_t qb[4];  // one quad of draws
+  smc_quad_bits<IMPL>(step_key, gq >> 2, qb);
+  float w[kPer];
+  bool ok[kPer];
 #pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-      const uint64_t j = gbase + (uint64_t)kPer * threadIdx.x + r;
-      if (j < first_slot + n_local) {
-        const uint32_t bits = qb[r];
-        const uint32_t lo = hmm_alias_draw(cdf, K, bits);
-        const float lw = obs_logp[(size_t)lo * K + y];
-        state_out[j - first_slot] = (int32_t)lo;
-        logw_out[j - first_slot] = lw;
-        if (anc_out) anc_out[j - first_slot] = (int32_t)j;
-        tmax = lw > tmax ? lw : tmax;
-      }
+  for (int r = 0; r < kPer; ++r) {
+    ok[r] = loc + r < n_local;
+    const uint32_t lo = hmm_alias_draw(cdf, K, qb[r]);
+    w[r] = obs_logp[(size_t)lo * K + y];
+    if (ok[r]) {
+      state_out[loc + r] = (int32_t)lo;
+      if (anc_out) anc_out[loc + r] = (int32_t)(gq + r);
     }
   }
-  const float bm = block_max(tmax, shf);
-  if (threadIdx.x == 0) max_partials[blockIdx.x] = bm;
+  emit_init_tile(w, ok, em, loc, first_slot / kTile + ltile);
 }
 
 // HMM tables.  Alias construction in integers (DESIGN.md 3.6b states it in full): p_c = cat_fix, scaled_c = p_c K
@@ -1386,11 +1214,12 @@ size_t gjx_workspace_bytes(int op, uint64_t n) {
   switch (op) {
     case GJX_OP_LOGSUMEXP: return pad256(nrows_of(n) * 4) + pad256(nt * 8) + 1024;
     case GJX_OP_CATEGORICAL_INDEX:
-    case GJX_OP_RESAMPLE:
-      return pad256(nt * 4) + 2 * pad256(nt * 8) + pad256(n * 8) + 1024;
-    case GJX_OP_SMC:  // ping-pong state + weights, tile maxima, tile masses, their prefix (+ tail), ESS sums, HMM tables
-      return 2 * pad256(n * 4) + pad256(nt * 4) + pad256(nt * 8) + pad256(prefix_words(nt) * 8) + pad256(2 * nt * 8) +
-             pad256(256 * (256 + 64) * 4) + pad256(256 * 256 * 4) + 1024;
+    case GJX_OP_RESAMPLE:  // (multinomial: tile maxima, masses, global CDF; systematic: in-tile CDF, records, prefix)
+      return pad256(nt * 4) + 2 * pad256(nt * 8) + pad256(n * 8) + pad256(nt * 16) + pad256(prefix_words(nt) * 8) + 1024;
+    case GJX_OP_SMC:  // the second copy of up to 4 state columns and the log-weights, two in-tile CDFs, two sets of records,
+                      // ESS sums and merged prefixes, HMM tables
+      return (GJX_SMC_MAX_STATE + 1) * pad256(n * 4) + 2 * pad256(n * 8) + 2 * pad256(nt * 16) + 2 * pad256(2 * nt * 8) +
+             2 * pad256(prefix_words(nt) * 8) + pad256(256 * (256 + 64) * 4) + pad256(256 * 256 * 4) + 1024;
     default: return 0;
   }
 }
@@ -2154,7 +1983,7 @@ static int weights_prepare(const float* logw, uint64_t n, Carver& cv, float** m_
   float* m = cv.take<float>(1);
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   k_max_partials<<<grid_for(n), kBlock, 0, st>>>(logw, n, mp);
-  k_tile_sums_block<false><<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, nullptr, frac_bits(n), tiles, m, 0, 0, 0, nullptr, nullptr, 0u);
+  k_tile_sums_block<<<(unsigned)nt, kBlock, 0, st>>>(logw, n, mp, nt, frac_bits(n), tiles, m);
   *m_out = m;
   *tiles_out = tiles;
   return GJX_OK;
@@ -2199,8 +2028,29 @@ int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, 
   return launch_status();
 }
 
+int gjx_tile_cdf(const float* x, uint64_t n, uint64_t* cdf, gjx_tile_rec* recs, gjx_stream s) {
+  if (!x || !cdf || !recs || n == 0 || n > 0x7fffffffull) return GJX_ERR_INVALID;
+  k_tile_cdf<<<(unsigned)ntiles_of(n), kBlock, 0, S(s)>>>(x, n, cdf, reinterpret_cast<TileRec*>(recs));
+  return launch_status();
+}
+int gjx_tile_merge(const gjx_tile_rec* recs, uint64_t n_tiles, int32_t* out_e, uint64_t* out_q, gjx_stream s) {
+  if (!recs || n_tiles == 0) return GJX_ERR_INVALID;
+  k_scan_records<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), nullptr, n_tiles, nullptr, out_e, out_q, 0);
+  return launch_status();
+}
+
+// test knob: GJX_SMC_SCAN_MAX=0 sends every output tile through the per-slot search (same ancestors either way)
+static int scan_max_knob() {
+  static const int v = [] {
+    const char* e = std::getenv("GJX_SMC_SCAN_MAX");
+    const int x = e ? atoi(e) : kScanMax;
+    return x < 0 ? 0 : (x > kScanMax ? kScanMax : x);
+  }();
+  return v;
+}
+
 int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, uint64_t n_out,
-                            int32_t* ancestors, float* out_max, uint64_t* out_q, void* ws,
+                            int32_t* ancestors, int32_t* out_e, uint64_t* out_q, void* ws,
                             size_t ws_bytes, gjx_stream s) {
   if (!keys_ok(key) || !logw || !ancestors || n == 0 || n_out == 0 || n > 0x7fffffffull ||
       n_out > 0x7fffffffull)
@@ -2208,30 +2058,25 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
   Key k;
   int rc = scalar_key(key, &k);
   if (rc) return rc;
+  const uint64_t nt = ntiles_of(n);
   Carver cv{(char*)ws, ws ? ws_bytes : 0};
-  float* m;
-  uint64_t* tiles;
-  rc = weights_prepare(logw, n, cv, &m, &tiles, S(s));
-  if (rc) return rc;
-  uint64_t* qtot = cv.take<uint64_t>(1);
+  uint64_t* cdf = cv.take<uint64_t>(n);
+  TileRec* recs = cv.take<TileRec>(nt);
+  uint64_t* prefix = nt > (uint64_t)kMaxLdsTiles ? cv.take<uint64_t>(prefix_words(nt)) : nullptr;
   if (!cv.ok) return GJX_ERR_WORKSPACE;
+  k_tile_cdf<<<(unsigned)nt, kBlock, 0, S(s)>>>(logw, n, cdf, recs);
+  if (prefix) k_scan_records<<<1, kBlock, 0, S(s)>>>(recs, nullptr, nt, prefix, nullptr, nullptr, 0);
   ResampleArgs A;
-  A.lw = logw; A.m_ptr = m; A.tile_sums = tiles; A.n = n; A.ntiles = ntiles_of(n);
-  A.n_out = n_out; A.out_lo = 0; A.out_hi = (int64_t)n_out; A.frac = frac_bits(n);
-  A.lw_vec = ((uintptr_t)logw & 15) == 0;
+  A.cdf = cdf; A.recs = recs; A.n = n; A.ntiles = nt;
+  A.n_out = n_out; A.out_lo = 0; A.out_hi = (int64_t)n_out;
   A.rkey = k; A.rkey_has_fold = key->has_fold; A.rkey_fold = key->fold;
-  A.q_total_out = out_q ? out_q : qtot;
-  A.tile_prefix = nullptr;
-  A.allow_help = 1;
-  A.heavy_shift = heavy_shift_for(n_out);
-  // one extra (tile-less) workgroup per chunk of output slots: a heavy tile can always delegate (no maxima to keep here)
-  const uint64_t chunks = (n_out + kTile - 1) / kTile;
-  A.n_extra = (uint32_t)(chunks < 1024 ? (chunks + 3) / 4 : 256 + (chunks < 32768 ? chunks / 32 : 1024));  // takers take groups of chunks
+  A.e_out = out_e; A.q_out = out_q;
+  A.prefix = prefix;
+  A.scan_max = scan_max_knob();
   AncestorOnly P{ancestors};
-  const unsigned grid = (unsigned)A.ntiles + A.n_extra;
-  if (key->impl == 0) k_resample<0, AncestorOnly><<<grid, kBlock, 0, S(s)>>>(A, P, nullptr);
-  else k_resample<1, AncestorOnly><<<grid, kBlock, 0, S(s)>>>(A, P, nullptr);
-  if (out_max) (void)hipMemcpyAsync(out_max, m, sizeof(float), hipMemcpyDeviceToDevice, S(s));
+  const unsigned grid = (unsigned)ntiles_of(n_out);
+  if (key->impl == 0) k_resample<0, AncestorOnly><<<grid, kBlock, 0, S(s)>>>(A, P);
+  else k_resample<1, AncestorOnly><<<grid, kBlock, 0, S(s)>>>(A, P);
   return launch_status();
 }
 
@@ -2283,8 +2128,9 @@ static bool cfg_ok(const gjx_smc_config* c) {
   return c && (c->impl == 0 || c->impl == 1) && c->n_total > 0 && c->n_local > 0 &&
          c->first_slot + c->n_local <= c->n_total && c->n_steps > 0 && c->step_keys &&
          c->resample_keys && (c->first_slot % kTile) == 0 && c->n_total <= 0x7fffffffull &&
-         !(c->ess_threshold < 0.0f) && c->tile_sums_form >= 0 && c->tile_sums_form <= 2;
+         !(c->ess_threshold < 0.0f);
 }
+static_assert(sizeof(gjx_tile_rec) == sizeof(TileRec) && alignof(TileRec) == 16, "gjx.h gjx_tile_rec");
 
 uint64_t gjx_hmm_alias_words(int32_t n_states) {
   return n_states > 0 ? (uint64_t)n_states * (uint64_t)n_states : 0;
@@ -2297,255 +2143,199 @@ int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gj
   return launch_status();
 }
 
-// Set by the whole-run drivers around their step launches (large populations only).
-// What the whole-run drivers add to a step (the public per-step entry points pass the default): the
-// precomputed tile-mass prefix of large populations / filter batches, and the filter batch itself (this
-// step's keys and the strides of the per-filter arrays; n_filters <= 1 otherwise).
+// What the whole-run drivers add to a step (the public per-step entry points pass the default): the filter batch
+// (this step's keys and the strides of the per-filter arrays; n_filters <= 1 otherwise) and where the step's
+// resampling flag goes.
 struct StepCtx {
-  const uint64_t* tile_prefix = nullptr;
   FilterBatch fb;
-  uint64_t* tile_ess = nullptr;    // whole-run drivers of adaptive filters: their workspace copy (else cfg->tile_ess)
   int32_t* resampled_out = nullptr;  // this step's entry of cfg->resampled_out
-  // whole-run drivers: extra (tile-less) workgroups per filter and where their maxima go (ResampleArgs::n_extra)
-  uint32_t n_extra = 0;
-  float* extra_max = nullptr;
 };
 
-static ResampleArgs smc_resample_args(const gjx_smc_config* cfg, int t, const float* prev_logw,
-                                      const float* prev_max, const uint64_t* prev_tile_sums,
-                                      uint64_t* prev_q_out, const StepCtx& ctx = StepCtx{}) {
-  ResampleArgs A;
-  A.tile_prefix = ctx.tile_prefix;
+// a population a step READS (t >= 1) / WRITES: the pointers its configuration needs
+static bool pop_ok(const gjx_smc_pop* p, int n_state, bool adaptive, bool reading, uint64_t nt) {
+  if (!p || !p->cdf || !p->recs) return false;
+  for (int k = 0; k < n_state; ++k)
+    if (!p->state[k]) return false;
+  if (adaptive && (!p->logw || !p->ess)) return false;
+  if (reading && nt > (uint64_t)kMaxLdsTiles && !p->prefix) return false;
+  if (((uintptr_t)p->recs & 15) != 0) return false;
+  return true;
+}
+
+// The arguments of a step's resample launch; for populations beyond kMaxLdsTiles the records of `prev` are merged
+// into prev->prefix first (one small launch).
+static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop* prev, const gjx_smc_pop* out,
+                             int32_t* prev_e_out, uint64_t* prev_q_out, const StepCtx& ctx, gjx_stream s, ResampleArgs* Ap) {
+  ResampleArgs& A = *Ap;
+  const bool ad = cfg_adaptive(cfg);
   A.fb = ctx.fb;
-  A.lw = prev_logw; A.m_ptr = prev_max; A.tile_sums = prev_tile_sums;
+  A.cdf = prev->cdf;
+  A.lw = ad ? prev->logw : nullptr;
+  A.recs = reinterpret_cast<const TileRec*>(prev->recs);
+  A.tile_ess = ad ? prev->ess : nullptr;
   A.n = cfg->n_total; A.ntiles = ntiles_of(cfg->n_total); A.n_out = cfg->n_total;
   A.out_lo = (int64_t)cfg->first_slot; A.out_hi = (int64_t)(cfg->first_slot + cfg->n_local);
-  A.frac = frac_bits(cfg->n_total);
-  A.heavy_shift = heavy_shift_for(cfg->n_total);
-  A.lw_vec = ((uintptr_t)prev_logw & 15) == 0;
   A.rkey = Key{cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1]};
   A.rkey_has_fold = 0; A.rkey_fold = 0;
-  A.q_total_out = prev_q_out;
-  if (cfg_adaptive(cfg)) {
-    A.ess_thr = (double)cfg->ess_threshold * (double)cfg->n_total;
-    A.tile_ess = ctx.tile_ess ? ctx.tile_ess : cfg->tile_ess;
-  }
+  A.e_out = prev_e_out; A.q_out = prev_q_out;
+  if (ad) A.ess_thr = (double)cfg->ess_threshold * (double)cfg->n_total;
   A.resampled_out = ctx.resampled_out ? ctx.resampled_out : (cfg->resampled_out && !(cfg->n_filters > 1) ? cfg->resampled_out + t : nullptr);
-  A.n_extra = ctx.n_extra;
-  A.extra_max = ctx.extra_max;
-  static const int extra_first = [] {
-    const char* e = std::getenv("GJX_SMC_EXTRA_FIRST");
-    return e && e[0] == '1' ? 1 : 0;
-  }();
-  A.extra_first = extra_first;
-  return A;
+  A.cdf_out = out->cdf; A.logw_out = out->logw;
+  A.recs_out = reinterpret_cast<TileRec*>(out->recs);
+  A.ess_out = ad ? out->ess : nullptr;
+  A.scan_max = scan_max_knob();
+  if (A.ntiles > (uint64_t)kMaxLdsTiles) {
+    if (ctx.fb.n_filters > 1) return GJX_ERR_UNSUPPORTED;
+    k_scan_records<<<1, kBlock, 0, S(s)>>>(A.recs, A.tile_ess, A.ntiles, prev->prefix, nullptr, nullptr, 0);
+    A.prefix = prev->prefix;
+  }
+  return GJX_OK;
+}
+static EmitOut emit_out_of(const gjx_smc_config* cfg, const gjx_smc_pop* out) {
+  return EmitOut{out->cdf, out->logw, reinterpret_cast<TileRec*>(out->recs), cfg_adaptive(cfg) ? out->ess : nullptr};
 }
 
-static int lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t,
-                        const float* prev_state, const float* prev_logw, const float* prev_max,
-                        const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* state_out,
-                        float* logw_out, float* max_partials_out, int32_t* ancestors_out,
-                        gjx_stream s, const StepCtx& ctx) {
-  if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !state_out || !logw_out || !max_partials_out)
-    return GJX_ERR_INVALID;
+static int lgssm_step(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t, const gjx_smc_pop* prev,
+                      const gjx_smc_pop* out, int32_t* prev_e_out, uint64_t* prev_q_out, int32_t* ancestors_out,
+                      gjx_stream s, const StepCtx& ctx) {
+  if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps) return GJX_ERR_INVALID;
+  const bool ad = cfg_adaptive(cfg);
+  const uint64_t nt = ntiles_of(cfg->n_total);
+  if (!pop_ok(out, 1, ad, false, nt) || (t > 0 && (!pop_ok(prev, 1, ad, true, nt) || prev->recs == out->recs))) return GJX_ERR_INVALID;
   const Key sk{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
   const float rs = normal_rs(mdl->r), lognorm = normal_lognorm(mdl->r);
-  const unsigned nt = (unsigned)ntiles_of(cfg->n_total), nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
+  const unsigned ntl = (unsigned)ntiles_of(cfg->n_local), nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
   if (t == 0) {
     GJX_DISPATCH_IMPL(cfg->impl, k_lgssm_init,
-                      <<<nt * nf, kBlock, 0, S(s)>>>(ctx.fb, sk, cfg->first_slot, cfg->n_local, mdl->x0_loc, mdl->x0_scale, y_t, rs, lognorm, state_out, logw_out, ancestors_out, max_partials_out));
+                      <<<ntl * nf, kBlock, 0, S(s)>>>(ctx.fb, sk, cfg->first_slot, cfg->n_local, mdl->x0_loc, mdl->x0_scale, y_t, rs, lognorm, (float*)out->state[0], ancestors_out, emit_out_of(cfg, out)));
     return launch_status();
   }
-  if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
-  ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out, ctx);
-  if (A.ess_thr > 0.0 && !A.tile_ess) return GJX_ERR_INVALID;
-  const bool ad = A.ess_thr > 0.0;
+  ResampleArgs A;
+  int rc = smc_resample_args(cfg, t, prev, out, prev_e_out, prev_q_out, ctx, s, &A);
+  if (rc) return rc;
   if (cfg->impl == 0) {
-    LgssmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {}};
-    if (ad) k_resample<0, LgssmPolicy<0>, true><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
-    else k_resample<0, LgssmPolicy<0>, false><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    LgssmPolicy<0> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}};
+    if (ad) k_resample<0, LgssmPolicy<0>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
+    else k_resample<0, LgssmPolicy<0>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   } else {
-    LgssmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, nullptr, {}};
-    if (ad) k_resample<1, LgssmPolicy<1>, true><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
-    else k_resample<1, LgssmPolicy<1>, false><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    LgssmPolicy<1> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}};
+    if (ad) k_resample<1, LgssmPolicy<1>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
+    else k_resample<1, LgssmPolicy<1>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   }
   return launch_status();
 }
 
-static int hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_t y_t,
-                      const int32_t* prev_state, const float* prev_logw, const float* prev_max,
-                      const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
-                      const uint32_t* trans_cdf, const float* obs_logp, int32_t* state_out,
-                      float* logw_out, float* max_partials_out, int32_t* ancestors_out,
-                      gjx_stream s, const StepCtx& ctx) {
-  if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !state_out || !logw_out ||
-      !max_partials_out || !trans_cdf || !obs_logp || y_t < 0 || y_t >= mdl->n_states ||
+static int hmm_step(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_t y_t, const gjx_smc_pop* prev,
+                    const gjx_smc_pop* out, int32_t* prev_e_out, uint64_t* prev_q_out, const uint32_t* trans_cdf,
+                    const float* obs_logp, int32_t* ancestors_out, gjx_stream s, const StepCtx& ctx) {
+  if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !trans_cdf || !obs_logp || y_t < 0 || y_t >= mdl->n_states ||
       mdl->n_states > 256 || mdl->init_state < 0 || mdl->init_state >= mdl->n_states)
     return GJX_ERR_INVALID;
+  const bool ad = cfg_adaptive(cfg);
+  const uint64_t nt = ntiles_of(cfg->n_total);
+  if (!pop_ok(out, 1, ad, false, nt) || (t > 0 && (!pop_ok(prev, 1, ad, true, nt) || prev->recs == out->recs))) return GJX_ERR_INVALID;
   const Key sk{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
-  const unsigned nt = (unsigned)ntiles_of(cfg->n_total), nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
+  const unsigned ntl = (unsigned)ntiles_of(cfg->n_local), nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
   if (t == 0) {
     GJX_DISPATCH_IMPL(cfg->impl, k_hmm_init,
-                      <<<nt * nf, kBlock, 0, S(s)>>>(ctx.fb, sk, cfg->first_slot, cfg->n_local, trans_cdf, obs_logp, mdl->n_states, mdl->init_state, y_t, state_out, logw_out, ancestors_out, max_partials_out));
+                      <<<ntl * nf, kBlock, 0, S(s)>>>(ctx.fb, sk, cfg->first_slot, cfg->n_local, trans_cdf, obs_logp, mdl->n_states, mdl->init_state, y_t, (int32_t*)out->state[0], ancestors_out, emit_out_of(cfg, out)));
     return launch_status();
   }
-  if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
-  ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out, ctx);
-  if (A.ess_thr > 0.0 && !A.tile_ess) return GJX_ERR_INVALID;
-  const bool ad = A.ess_thr > 0.0;
+  ResampleArgs A;
+  int rc = smc_resample_args(cfg, t, prev, out, prev_e_out, prev_q_out, ctx, s, &A);
+  if (rc) return rc;
   if (cfg->impl == 0) {
-    HmmPolicy<0> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {}, 0.0f};
-    if (ad) k_resample<0, HmmPolicy<0>, true><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
-    else k_resample<0, HmmPolicy<0>, false><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    HmmPolicy<0> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr};
+    if (ad) k_resample<0, HmmPolicy<0>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
+    else k_resample<0, HmmPolicy<0>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   } else {
-    HmmPolicy<1> P{prev_state, state_out, logw_out, ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, nullptr, nullptr, {}, 0.0f};
-    if (ad) k_resample<1, HmmPolicy<1>, true><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
-    else k_resample<1, HmmPolicy<1>, false><<<(nt + A.n_extra) * nf, kBlock, 0, S(s)>>>(A, P, max_partials_out);
+    HmmPolicy<1> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr};
+    if (ad) k_resample<1, HmmPolicy<1>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
+    else k_resample<1, HmmPolicy<1>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   }
   return launch_status();
 }
 
-int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t,
-                         const float* prev_state, const float* prev_logw, const float* prev_max,
-                         const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* state_out,
-                         float* logw_out, float* max_partials_out, int32_t* ancestors_out,
-                         gjx_stream s) {
-  return lgssm_step_a(cfg, mdl, t, y_t, prev_state, prev_logw, prev_max, prev_tile_sums, prev_q_out, state_out,
-                      logw_out, max_partials_out, ancestors_out, s, StepCtx{});
-}
-int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_t y_t,
-                       const int32_t* prev_state, const float* prev_logw, const float* prev_max,
-                       const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
-                       const uint32_t* trans_cdf, const float* obs_logp, int32_t* state_out,
-                       float* logw_out, float* max_partials_out, int32_t* ancestors_out,
+int gjx_smc_lgssm_step(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t, const gjx_smc_pop* prev,
+                       const gjx_smc_pop* out, int32_t* prev_e_out, uint64_t* prev_q_out, int32_t* ancestors_out,
                        gjx_stream s) {
-  return hmm_step_a(cfg, mdl, t, y_t, prev_state, prev_logw, prev_max, prev_tile_sums, prev_q_out, trans_cdf,
-                    obs_logp, state_out, logw_out, max_partials_out, ancestors_out, s, StepCtx{});
+  if (cfg && cfg->n_filters > 1) return GJX_ERR_INVALID;
+  return lgssm_step(cfg, mdl, t, y_t, prev, out, prev_e_out, prev_q_out, ancestors_out, s, StepCtx{});
+}
+int gjx_smc_hmm_step(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_t y_t, const gjx_smc_pop* prev,
+                     const gjx_smc_pop* out, int32_t* prev_e_out, uint64_t* prev_q_out, const uint32_t* trans_cdf,
+                     const float* obs_logp, int32_t* ancestors_out, gjx_stream s) {
+  if (cfg && cfg->n_filters > 1) return GJX_ERR_INVALID;
+  return hmm_step(cfg, mdl, t, y_t, prev, out, prev_e_out, prev_q_out, trans_cdf, obs_logp, ancestors_out, s, StepCtx{});
 }
 
-static int smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const float* max_partials,
-                      float* max_out, uint64_t* tile_sums, gjx_stream s, const StepCtx& ctx) {
-  if (!cfg_ok(cfg) || !logw_local || !max_partials || !max_out || !tile_sums) return GJX_ERR_INVALID;
-  const uint64_t nt_total = ntiles_of(cfg->n_total);
-  const uint64_t nt_local = ntiles_of(cfg->n_local);
-  const float* m_ptr = nullptr;
-  if (nt_total > kPrefixTiles) {  // reduce the tile maxima once instead of in every workgroup
-    k_reduce_max<<<1, kBlock, 0, S(s)>>>(max_partials, nt_total, max_out);
-    m_ptr = max_out;
-  }
-  uint64_t* tile_ess = cfg_adaptive(cfg) ? (ctx.tile_ess ? ctx.tile_ess : cfg->tile_ess) : nullptr;
-  if (cfg_adaptive(cfg) && !tile_ess) return GJX_ERR_INVALID;
-  const uint64_t tile0 = cfg->first_slot / kTile;
-  const FilterBatch& fb = ctx.fb;
-  const unsigned nf = fb.n_filters > 1 ? fb.n_filters : 1u;
-  static const uint64_t wave_min = [] {
-    const char* e = std::getenv("GJX_TILE_SUMS_WAVE_MIN");  // tuning knob; default from measurement
-    return e ? (uint64_t)atoll(e) : (uint64_t)4096;
-  }();
-  // enough tiles to fill the machine with a wave each (measured: 16 x 977 tiles +8 %, 977 tiles -13 %); cfg->tile_sums_form
-  // forces one form (tests: both give the same bits)
-  const bool wave_form = cfg->tile_sums_form == 2 || (cfg->tile_sums_form == 0 && nt_local * nf >= wave_min);
-  if (wave_form) {
-    const unsigned groups = (unsigned)((nt_local + kTilesPerSumBlock - 1) / kTilesPerSumBlock);
-#define GJX_TS_WAVE(E) k_tile_sums_wave<E><<<groups * nf, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials, nt_total, m_ptr, \
-    frac_bits(cfg->n_total), tile_sums + tile0, m_ptr ? nullptr : max_out, nf > 1 ? fb.tiles : 0u, fb.stride, fb.mq_stride,           \
-    (uint32_t)nt_local, tile_ess ? tile_ess + 2 * tile0 : nullptr, ctx.extra_max, ctx.n_extra)
-    if (tile_ess) GJX_TS_WAVE(true);
-    else GJX_TS_WAVE(false);
-#undef GJX_TS_WAVE
-  } else {
-#define GJX_TS_BLOCK(E) k_tile_sums_block<E><<<(unsigned)nt_local * nf, kBlock, 0, S(s)>>>(logw_local, cfg->n_local, max_partials,      \
-    nt_total, m_ptr, frac_bits(cfg->n_total), tile_sums + tile0, m_ptr ? nullptr : max_out, nf > 1 ? fb.tiles : 0u, fb.stride,           \
-    fb.mq_stride, tile_ess ? tile_ess + 2 * tile0 : nullptr, ctx.extra_max, ctx.n_extra)
-    if (tile_ess) GJX_TS_BLOCK(true);
-    else GJX_TS_BLOCK(false);
-#undef GJX_TS_BLOCK
-  }
+int gjx_smc_finish(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int32_t* e_out, uint64_t* q_out, gjx_stream s) {
+  if (!cfg_ok(cfg) || !recs || cfg->n_filters > 1) return GJX_ERR_INVALID;
+  k_scan_records<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), nullptr, ntiles_of(cfg->n_total), nullptr, e_out, q_out, 0);
   return launch_status();
 }
-
-int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const float* max_partials,
-                   float* max_out, uint64_t* tile_sums, gjx_stream s) {
-  return smc_step_b(cfg, logw_local, max_partials, max_out, tile_sums, s, StepCtx{});
-}
-
-static int smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out, gjx_stream s,
-                      const StepCtx& ctx) {
-  if (!cfg_ok(cfg) || !tile_sums || !q_out) return GJX_ERR_INVALID;
-  const unsigned nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
-  const uint64_t nt = ntiles_of(cfg->n_total);
-  for (unsigned f = 0; f < nf; ++f)
-    k_reduce_sum<<<1, kBlock, 0, S(s)>>>(tile_sums + f * nt, nt, q_out + f * ctx.fb.mq_stride, 0, nullptr, 0, nullptr, nullptr);
-  return launch_status();
-}
-int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
-                   gjx_stream s) {
-  return smc_finish(cfg, tile_sums, q_out, s, StepCtx{});
-}
-int gjx_smc_source_ranges(const gjx_smc_config* cfg, const uint64_t* tile_sums, int world, int64_t ticket,
-                          int64_t* out_ranges, gjx_stream s) {
-  if (!cfg_ok(cfg) || !tile_sums || !out_ranges || world < 1 || world > kMaxRangeBlocks || cfg->n_total % (uint64_t)world)
+int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, const uint64_t* ess, int world,
+                          int64_t ticket, int64_t* out_ranges, gjx_stream s) {
+  if (!cfg_ok(cfg) || !recs || !out_ranges || world < 1 || world > kMaxRangeBlocks || cfg->n_total % (uint64_t)world)
     return GJX_ERR_INVALID;
-  if (cfg_adaptive(cfg) && !cfg->tile_ess) return GJX_ERR_INVALID;
-  k_source_ranges<<<1, kBlock, 0, S(s)>>>(tile_sums, cfg_adaptive(cfg) ? cfg->tile_ess : nullptr,
+  if (cfg_adaptive(cfg) && !ess) return GJX_ERR_INVALID;
+  k_source_ranges<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), cfg_adaptive(cfg) ? ess : nullptr,
                                           cfg_adaptive(cfg) ? (double)cfg->ess_threshold * (double)cfg->n_total : 0.0,
                                           ntiles_of(cfg->n_total), cfg->n_total, world, ticket, out_ranges);
   return launch_status();
 }
 
-// What the whole-run drivers (fixed models and plans) share: the per-filter scratch arrays carved from the caller's
-// workspace, and the per-step context (this step's keys of every filter, the tile-mass prefix, where the step's
-// running max / resampling flag go).
+// What the whole-run drivers (fixed models and plans) share: the ping-pong populations carved from the caller's
+// workspace — the LAST step lands in the caller's state / log-weight buffers — and the per-step context (this step's
+// keys of every filter, where the step's resampling flag goes).
 struct RunCommon {
   unsigned F = 1;
   uint64_t nt = 0, stride = 0;
-  float* mp = nullptr;
-  uint64_t* tiles = nullptr;
-  uint64_t* prefix = nullptr;
-  uint64_t* tile_ess = nullptr;
-  uint32_t n_extra = 0;       // extra (tile-less) workgroups per filter in the resample launches
-  float* extra_max = nullptr;  // [F, n_extra]
+  bool adaptive = false;
+  gjx_smc_pop pop[2];
+  float* logw_final = nullptr;  // the caller's log-weight buffer (written by the last step)
+  int last = 0;
   FilterBatch fb;
 };
-static int run_common_init(const gjx_smc_config* cfg, Carver& cv, RunCommon& rc, float* out_max, gjx_stream s) {
+static int run_common_init(const gjx_smc_config* cfg, Carver& cv, RunCommon& rc, int n_state, void* const* state_out,
+                           float* logw_out, gjx_stream s) {
   const uint64_t N = cfg->n_total;
   rc.nt = ntiles_of(N);
   rc.F = cfg->n_filters > 1 ? (unsigned)cfg->n_filters : 1u;
   rc.stride = rc.F > 1 ? cfg->filter_stride : N;
-  if (rc.F > kMaxFilters || (rc.F > 1 && (rc.stride != rc.nt * kTile || rc.nt > kPrefixTiles))) return GJX_ERR_UNSUPPORTED;
-  if (cfg_adaptive(cfg) && !cfg->resampled_out) return GJX_ERR_INVALID;
-  // Tile-mass prefixes by a separate (one workgroup per filter) launch: worth it for large populations, and for
-  // several filters per launch, where its ~5 us are shared by all of them while every resample workgroup saves
-  // the block-wide scan of its filter's tile sums.
-  const bool scan = rc.nt > kPrefixTiles || rc.F >= 4;
-  rc.mp = cv.take<float>(rc.F * rc.nt);
-  rc.tiles = cv.take<uint64_t>(rc.F * rc.nt);
-  rc.prefix = scan ? cv.take<uint64_t>(rc.F * prefix_words(rc.nt)) : nullptr;
-  rc.tile_ess = cfg_adaptive(cfg) ? cv.take<uint64_t>(2 * rc.F * rc.nt) : nullptr;
-  // Takers for a heavy tile's delegated chunks when no tile is idle (gjx_device.hpp ResampleArgs::n_extra): one extra
-  // workgroup per 16 tiles.  A taker serves a GROUP of consecutive chunks, so a sixteenth is enough to spread a tile
-  // that owns everything over ~60 workgroups; in ordinary steps they exit after the mass scan (measured: under 1 % of a
-  // step).  Not with a separate max reduction (> kPrefixTiles tiles).
-  static const int extra_div = [] {
-    const char* e = std::getenv("GJX_SMC_EXTRA_DIV");  // tuning / test knob: 0 = no extra workgroups
-    return e ? atoi(e) : -1;
-  }();
-  const uint64_t div = extra_div >= 0 ? (uint64_t)extra_div : 16u;
-  rc.n_extra = (div == 0 || rc.nt > kPrefixTiles) ? 0u : (uint32_t)((rc.nt + div - 1) / div);
-  rc.extra_max = rc.n_extra ? cv.take<float>((size_t)rc.F * rc.n_extra) : nullptr;
-  if (!cv.ok) return GJX_ERR_WORKSPACE;
-  // (-inf until a resample launch has run: step 0 has no extra workgroups)
-  if (rc.extra_max && hipMemsetD32Async((hipDeviceptr_t)rc.extra_max, (int)0xFF800000u, (size_t)rc.F * rc.n_extra, S(s)) != hipSuccess)
-    return GJX_ERR_LAUNCH;
-  if (rc.F > 1) {
-    rc.fb.n_filters = rc.F; rc.fb.tiles = (uint32_t)rc.nt; rc.fb.stride = rc.stride; rc.fb.mq_stride = (uint64_t)cfg->n_steps;
+  rc.adaptive = cfg_adaptive(cfg);
+  if (rc.F > kMaxFilters || (rc.F > 1 && (rc.stride != rc.nt * kTile || rc.nt > (uint64_t)kMaxLdsTiles))) return GJX_ERR_UNSUPPORTED;
+  if (rc.adaptive && !cfg->resampled_out) return GJX_ERR_INVALID;
+  const int T = cfg->n_steps;
+  rc.last = (T - 1) & 1;
+  memset(rc.pop, 0, sizeof rc.pop);
+  const size_t cells = (size_t)rc.F * rc.stride;
+  for (int k = 0; k < n_state; ++k) {
+    rc.pop[rc.last].state[k] = state_out[k];
+    rc.pop[rc.last ^ 1].state[k] = cv.take<uint32_t>(cells);
   }
-  const size_t nmq = (size_t)rc.F * (size_t)cfg->n_steps;
-  (void)out_max;
+  for (int i = 0; i < 2; ++i) {
+    rc.pop[i].cdf = cv.take<uint64_t>(cells);
+    rc.pop[i].recs = reinterpret_cast<gjx_tile_rec*>(cv.take<TileRec>((size_t)rc.F * rc.nt));
+    rc.pop[i].ess = rc.adaptive ? cv.take<uint64_t>(2 * (size_t)rc.F * rc.nt) : nullptr;
+    rc.pop[i].prefix = rc.nt > (uint64_t)kMaxLdsTiles ? cv.take<uint64_t>(prefix_words(rc.nt)) : nullptr;
+  }
+  // log-weights: an adaptive filter carries them from step to step; otherwise only the last step's are stored
+  rc.logw_final = logw_out;
+  if (rc.adaptive) {
+    rc.pop[rc.last].logw = logw_out;
+    rc.pop[rc.last ^ 1].logw = cv.take<float>(cells);
+  }
+  if (!cv.ok) return GJX_ERR_WORKSPACE;
+  if (rc.F > 1) {
+    rc.fb.n_filters = rc.F; rc.fb.tiles = (uint32_t)rc.nt; rc.fb.stride = rc.stride; rc.fb.mq_stride = (uint64_t)T;
+  }
+  const size_t nmq = (size_t)rc.F * (size_t)T;
   if (cfg->resampled_out && hipMemsetAsync(cfg->resampled_out, 0, nmq * sizeof(int32_t), S(s)) != hipSuccess) return GJX_ERR_LAUNCH;
   return GJX_OK;
 }
-static StepCtx run_step_ctx(const gjx_smc_config* cfg, RunCommon& rc, int t, float* out_max, gjx_stream s) {
+// the populations of step t: written (`out`) and read (`prev`), and the step's context
+static StepCtx run_step_ctx(const gjx_smc_config* cfg, RunCommon& rc, int t, gjx_smc_pop* out) {
   const int T = cfg->n_steps;
   for (unsigned f = 0; f < rc.F && rc.F > 1; ++f) {  // this step's keys of every filter ([F, T, 2] host arrays)
     const uint32_t* sk = cfg->step_keys + 2 * ((size_t)f * T + t);
@@ -2553,18 +2343,19 @@ static StepCtx run_step_ctx(const gjx_smc_config* cfg, RunCommon& rc, int t, flo
     rc.fb.step_key[f] = Key{sk[0], sk[1]};
     rc.fb.rkey[f] = Key{rk[0], rk[1]};
   }
+  *out = rc.pop[t & 1];
+  if (!rc.adaptive) out->logw = t == T - 1 ? rc.logw_final : nullptr;
   StepCtx ctx;
   ctx.fb = rc.fb;
-  ctx.tile_ess = rc.tile_ess;
-  ctx.n_extra = rc.n_extra;
-  ctx.extra_max = rc.extra_max;
-  if (rc.prefix && t) {
-    k_scan_tiles<<<rc.F, kBlock, 0, S(s)>>>(rc.tiles, rc.tile_ess, rc.nt, cfg->n_total, rc.prefix);
-    ctx.tile_prefix = rc.prefix;
-  }
   ctx.resampled_out = cfg->resampled_out ? cfg->resampled_out + t : nullptr;
-  (void)out_max;
   return ctx;
+}
+// the closing (e, Q) pairs of a run: the merge of the last step's records, one workgroup per filter
+static int run_finish(const gjx_smc_config* cfg, RunCommon& rc, int32_t* out_e, uint64_t* out_q, gjx_stream s) {
+  const int T = cfg->n_steps;
+  k_scan_records<<<rc.F, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(rc.pop[rc.last].recs), nullptr, rc.nt, nullptr,
+                                            out_e + (T - 1), out_q + (T - 1), (uint64_t)T);
+  return launch_status();
 }
 
 // ---- importance over a Scan model: the T-step walk of every particle in one launch ------------------
@@ -2752,152 +2543,120 @@ static gjx_jit::CompiledSmc* smc_plan_compiled(gjx_smc_plan* plan, int impl) {
   return c.state == 1 ? &c : nullptr;
 }
 
-// Step A of a plan-driven filter: the generated init kernel (t == 0) or the generated policy inside the fused
+// One step of a plan-driven filter: the generated init kernel (t == 0) or the generated policy inside the fused
 // resample kernel, for the output slots [first_slot, first_slot + n_local) of cfg.
-static int smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, gjx_jit::CompiledSmc& c, int t,
-                           const float* obs_t, const float* const* prev_state, const float* prev_logw,
-                           const float* prev_max, const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
-                           float* const* state_out, float* logw_out, float* max_partials_out, int32_t* ancestors_out,
-                           gjx_stream s, const StepCtx& ctx) {
-  const unsigned nt = (unsigned)ntiles_of(cfg->n_total), nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
+static int smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, gjx_jit::CompiledSmc& c, int t,
+                         const float* obs_t, const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* prev_e_out,
+                         uint64_t* prev_q_out, int32_t* ancestors_out, gjx_stream s, const StepCtx& ctx) {
+  const bool ad = cfg_adaptive(cfg);
+  const uint64_t nt = ntiles_of(cfg->n_total);
+  if (!pop_ok(out, plan->n_state, ad, false, nt) ||
+      (t > 0 && (!pop_ok(prev, plan->n_state, ad, true, nt) || prev->recs == out->recs)))
+    return GJX_ERR_INVALID;
+  const unsigned ntl = (unsigned)ntiles_of(cfg->n_local), nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
   PlanPolicyArgs PA;
   memset(&PA, 0, sizeof(PA));
-  for (int k = 0; k < plan->n_state; ++k) { PA.prev_state[k] = prev_state ? prev_state[k] : nullptr; PA.state_out[k] = state_out[k]; }
-  PA.logw_out = logw_out;
+  for (int k = 0; k < plan->n_state; ++k) {
+    PA.prev_state[k] = t > 0 ? (const float*)prev->state[k] : nullptr;
+    PA.state_out[k] = (float*)out->state[k];
+  }
   PA.anc_out = ancestors_out;
   PA.step_key = Key{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
   for (int k = 0; k < plan->n_obs; ++k) PA.obs[k] = obs_t[k];
   if (t == 0) {
     uint64_t first = cfg->first_slot, nl = cfg->n_local;
     FilterBatch fb = ctx.fb;
-    void* args[] = {&PA, &first, &nl, &max_partials_out, &fb};
-    if (hipModuleLaunchKernel(c.init, nt * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
+    EmitOut em = emit_out_of(cfg, out);
+    void* args[] = {&PA, &first, &nl, &em, &fb};
+    if (hipModuleLaunchKernel(c.init, ntl * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
     return launch_status();
   }
-  if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
-  ResampleArgs A = smc_resample_args(cfg, t, prev_logw, prev_max, prev_tile_sums, prev_q_out, ctx);
-  if (A.ess_thr > 0.0 && !A.tile_ess) return GJX_ERR_INVALID;
-  void* args[] = {&A, &PA, &max_partials_out};
-  if (hipModuleLaunchKernel(c.step, (nt + A.n_extra) * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
+  ResampleArgs A;
+  int rc = smc_resample_args(cfg, t, prev, out, prev_e_out, prev_q_out, ctx, s, &A);
+  if (rc) return rc;
+  void* args[] = {&A, &PA};
+  if (hipModuleLaunchKernel(c.step, ntl * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
   return launch_status();
 }
 
-int gjx_smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, const float* obs_t,
-                        const float* const* prev_state, const float* prev_logw, const float* prev_max,
-                        const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* const* state_out,
-                        float* logw_out, float* max_partials_out, int32_t* ancestors_out, gjx_stream s) {
-  if (!cfg_ok(cfg) || !plan || t < 0 || t >= cfg->n_steps || !state_out || !logw_out || !max_partials_out ||
-      (plan->n_obs > 0 && !obs_t) || cfg->n_filters > 1)
+int gjx_smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, const float* obs_t, const gjx_smc_pop* prev,
+                      const gjx_smc_pop* out, int32_t* prev_e_out, uint64_t* prev_q_out, int32_t* ancestors_out,
+                      gjx_stream s) {
+  if (!cfg_ok(cfg) || !plan || t < 0 || t >= cfg->n_steps || !out || (t > 0 && !prev) || (plan->n_obs > 0 && !obs_t) ||
+      cfg->n_filters > 1)
     return GJX_ERR_INVALID;
-  for (int k = 0; k < plan->n_state; ++k)
-    if (!state_out[k] || (t > 0 && (!prev_state || !prev_state[k]))) return GJX_ERR_INVALID;
   gjx_jit::CompiledSmc* c = smc_plan_compiled(plan, cfg->impl);
   if (!c) return GJX_ERR_UNSUPPORTED;
-  return smc_plan_step_a(cfg, plan, *c, t, obs_t, prev_state, prev_logw, prev_max, prev_tile_sums, prev_q_out, state_out,
-                         logw_out, max_partials_out, ancestors_out, s, StepCtx{});
+  return smc_plan_step(cfg, plan, *c, t, obs_t, prev, out, prev_e_out, prev_q_out, ancestors_out, s, StepCtx{});
 }
 
-int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
+int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, int32_t* out_e,
                      uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out,
                      void* ws, size_t ws_bytes, gjx_stream s) {
-  if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !plan || !out_max || !out_q ||
+  if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !plan || !out_e || !out_q ||
       !state_out || !logw_out || (plan->n_obs > 0 && !obs_host))
     return GJX_ERR_INVALID;
   gjx_jit::CompiledSmc* cp = smc_plan_compiled(plan, cfg->impl);
   if (!cp) return GJX_ERR_UNSUPPORTED;
-  const uint64_t N = cfg->n_total;
   const int D = plan->n_state, T = cfg->n_steps;
+  void* st[GJX_SMC_MAX_STATE];
+  for (int k = 0; k < D; ++k) {
+    if (!state_out[k]) return GJX_ERR_INVALID;
+    st[k] = state_out[k];
+  }
   // several filters per launch (as in smc_run): filter f's particles lie f * stride further in every array
   Carver cv{(char*)ws, ws ? ws_bytes : 0};
   RunCommon rc;
-  const unsigned F0 = cfg->n_filters > 1 ? (unsigned)cfg->n_filters : 1u;
-  const uint64_t stride0 = F0 > 1 ? cfg->filter_stride : N;
-  float* st_ws[GJX_SMC_MAX_STATE];
-  for (int k = 0; k < D; ++k) st_ws[k] = cv.take<float>(F0 * stride0);
-  float* lw_ws = cv.take<float>(F0 * stride0);
-  int rc0 = run_common_init(cfg, cv, rc, out_max, s);
-  if (rc0) return rc0;
-  const unsigned F = rc.F;
-  const uint64_t stride = rc.stride;
-  for (int k = 0; k < D; ++k)
-    if (!state_out[k]) return GJX_ERR_INVALID;
-  const int last = (T - 1) & 1;
-  float* stb[2][GJX_SMC_MAX_STATE];
-  float* lwb[2];
-  for (int k = 0; k < D; ++k) { stb[last][k] = state_out[k]; stb[last ^ 1][k] = st_ws[k]; }
-  lwb[last] = logw_out; lwb[last ^ 1] = lw_ws;
+  int r = run_common_init(cfg, cv, rc, D, st, logw_out, s);
+  if (r) return r;
   for (int t = 0; t < T; ++t) {
-    const int cur = t & 1, prv = cur ^ 1;
-    StepCtx ctx = run_step_ctx(cfg, rc, t, out_max, s);
-    int r = smc_plan_step_a(cfg, plan, *cp, t, plan->n_obs ? obs_host + (size_t)t * (size_t)plan->n_obs : nullptr, stb[prv],
-                            lwb[prv], t ? out_max + (t - 1) : nullptr, rc.tiles, t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur],
-                            rc.mp, ancestors_out ? ancestors_out + (size_t)t * F * stride : nullptr, s, ctx);
-    if (!r) r = smc_step_b(cfg, lwb[cur], rc.mp, out_max + t, rc.tiles, s, ctx);
+    gjx_smc_pop out;
+    StepCtx ctx = run_step_ctx(cfg, rc, t, &out);
+    r = smc_plan_step(cfg, plan, *cp, t, plan->n_obs ? obs_host + (size_t)t * (size_t)plan->n_obs : nullptr,
+                      &rc.pop[(t & 1) ^ 1], &out, t ? out_e + (t - 1) : nullptr, t ? out_q + (t - 1) : nullptr,
+                      ancestors_out ? ancestors_out + (size_t)t * rc.F * rc.stride : nullptr, s, ctx);
     if (r) return r;
   }
-  StepCtx ctx;
-  ctx.fb = rc.fb;
-  return smc_finish(cfg, rc.tiles, out_q + (T - 1), s, ctx);
+  return run_finish(cfg, rc, out_e, out_q, s);
 }
 
 }  // extern "C"
 
-template <class StateT, class StepA>
-static int smc_run(const gjx_smc_config* cfg, const void* model, float* out_max, uint64_t* out_q,
-                   StateT* state_out, float* logw_out, int32_t* ancestors_out, void* ws,
-                   size_t ws_bytes, gjx_stream s, StepA step_a) {
-  if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !model || !out_max ||
+template <class Step>
+static int smc_run(const gjx_smc_config* cfg, const void* model, int32_t* out_e, uint64_t* out_q,
+                   void* state_out, float* logw_out, int32_t* ancestors_out, void* ws,
+                   size_t ws_bytes, gjx_stream s, Step step) {
+  if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !model || !out_e ||
       !out_q || !state_out || !logw_out)
     return GJX_ERR_INVALID;
-  const uint64_t N = cfg->n_total;
-  // several filters per launch: filter f's particles lie f * stride further in every per-particle array
-  const unsigned F0 = cfg->n_filters > 1 ? (unsigned)cfg->n_filters : 1u;
-  const uint64_t stride0 = F0 > 1 ? cfg->filter_stride : N;
   const int T = cfg->n_steps;
   Carver cv{(char*)ws, ws ? ws_bytes : 0};
-  StateT* st_ws = cv.take<StateT>(F0 * stride0);
-  float* lw_ws = cv.take<float>(F0 * stride0);
   RunCommon rc;
-  int r = run_common_init(cfg, cv, rc, out_max, s);
-  if (r) return r;
-  const unsigned F = rc.F;
-  const uint64_t stride = rc.stride;
-  // ping-pong so that the last step lands in the caller's output buffers
-  StateT* stb[2];
-  float* lwb[2];
-  const int last = (T - 1) & 1;
-  stb[last] = state_out; stb[last ^ 1] = st_ws;
-  lwb[last] = logw_out; lwb[last ^ 1] = lw_ws;
+  void* st[1] = {state_out};
+  int r = run_common_init(cfg, cv, rc, 1, st, logw_out, s);
   for (int t = 0; t < T && !r; ++t) {
-    const int cur = t & 1, prv = cur ^ 1;
-    int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * F * stride : nullptr;
-    StepCtx ctx = run_step_ctx(cfg, rc, t, out_max, s);
-    r = step_a(t, stb[prv], lwb[prv], t ? out_max + (t - 1) : nullptr, rc.tiles,
-               t ? out_q + (t - 1) : nullptr, stb[cur], lwb[cur], rc.mp, anc_t, ctx);
-    if (!r) r = smc_step_b(cfg, lwb[cur], rc.mp, out_max + t, rc.tiles, s, ctx);
+    int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * rc.F * rc.stride : nullptr;
+    gjx_smc_pop out;
+    StepCtx ctx = run_step_ctx(cfg, rc, t, &out);
+    r = step(t, &rc.pop[(t & 1) ^ 1], &out, t ? out_e + (t - 1) : nullptr, t ? out_q + (t - 1) : nullptr, anc_t, ctx);
   }
   if (r) return r;
-  StepCtx ctx;
-  ctx.fb = rc.fb;
-  return smc_finish(cfg, rc.tiles, out_q + (T - 1), s, ctx);
+  return run_finish(cfg, rc, out_e, out_q, s);
 }
 
 extern "C" {
 
 int gjx_smc_run_lgssm(const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y_host,
-                      float* out_max, uint64_t* out_q, float* state_out, float* logw_out,
+                      int32_t* out_e, uint64_t* out_q, float* state_out, float* logw_out,
                       int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s) {
   if (!y_host) return GJX_ERR_INVALID;
-  auto step = [&](int t, const float* ps, const float* pl, const float* pm, const uint64_t* tiles,
-                  uint64_t* pq, float* so, float* lo, float* mp, int32_t* anc, const StepCtx& ctx) {
-    return lgssm_step_a(cfg, model, t, y_host[t], ps, pl, pm, tiles, pq, so, lo, mp, anc, s, ctx);
-  };
-  return smc_run<float>(cfg, model, out_max, out_q, state_out, logw_out, ancestors_out, ws, ws_bytes,
-                        s, step);
+  auto step = [&](int t, const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* pe, uint64_t* pq, int32_t* anc,
+                  const StepCtx& ctx) { return lgssm_step(cfg, model, t, y_host[t], prev, out, pe, pq, anc, s, ctx); };
+  return smc_run(cfg, model, out_e, out_q, state_out, logw_out, ancestors_out, ws, ws_bytes, s, step);
 }
 
 int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32_t* y_host,
-                    float* out_max, uint64_t* out_q, int32_t* state_out, float* logw_out,
+                    int32_t* out_e, uint64_t* out_q, int32_t* state_out, float* logw_out,
                     int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s) {
   if (!y_host || !model || model->n_states <= 0 || model->n_states > 256) return GJX_ERR_INVALID;
   // tables live at the tail of the workspace
@@ -2916,12 +2675,9 @@ int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32
   int rc = gjx_hmm_prepare(model, tcdf, ologp, s);
   if (rc) return rc;
   const size_t head_bytes = (size_t)(tail_p - (char*)ws);
-  auto step = [&](int t, const int32_t* ps, const float* pl, const float* pm, const uint64_t* tiles,
-                  uint64_t* pq, int32_t* so, float* lo, float* mp, int32_t* anc, const StepCtx& ctx) {
-    return hmm_step_a(cfg, model, t, y_host[t], ps, pl, pm, tiles, pq, tcdf, ologp, so, lo, mp, anc, s, ctx);
-  };
-  return smc_run<int32_t>(cfg, model, out_max, out_q, state_out, logw_out, ancestors_out, ws,
-                          head_bytes, s, step);
+  auto step = [&](int t, const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* pe, uint64_t* pq, int32_t* anc,
+                  const StepCtx& ctx) { return hmm_step(cfg, model, t, y_host[t], prev, out, pe, pq, tcdf, ologp, anc, s, ctx); };
+  return smc_run(cfg, model, out_e, out_q, state_out, logw_out, ancestors_out, ws, head_bytes, s, step);
 }
 
 }  // extern "C"
@@ -2938,17 +2694,6 @@ int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32
 
 namespace {
 
-__global__ void k_max_across(float* dst, gjx::RunCols srcs, int world, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float m = reinterpret_cast<const float*>(srcs.in[0])[i];
-  for (int r = 1; r < world; ++r) {
-    const float v = reinterpret_cast<const float*>(srcs.in[r & 15])[i];
-    m = v > m ? v : m;
-  }
-  dst[i] = m;
-}
-
 // device memory primitives of the virtual-rank transport
 struct HipMem {
   void* buf = nullptr;
@@ -2960,24 +2705,6 @@ struct HipMem {
     if (!bytes) return GJX_OK;
     return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(s)) == hipSuccess ? GJX_OK : GJX_ERR_LAUNCH;
   }
-  int max_f32(float* dst, const float* const* srcs, int world, size_t n, gjx_stream s) {
-    if (world > 16) return GJX_ERR_UNSUPPORTED;  // (virtual ranks are a test transport)
-    gjx::RunCols rc;
-    memset(&rc, 0, sizeof rc);
-    for (int r = 0; r < world; ++r) rc.in[r] = srcs[r];
-    k_max_across<<<(unsigned)((n + 255) / 256), 256, 0, S(s)>>>(dst, rc, world, n);
-    return launch_status();
-  }
-  void* scratch(size_t bytes) {
-    if (bytes > cap) {
-      if (buf) (void)hipFree(buf);
-      buf = nullptr;
-      cap = 0;
-      if (hipMalloc(&buf, bytes) != hipSuccess) return nullptr;
-      cap = bytes;
-    }
-    return buf;
-  }
   int sync(gjx_stream s) { return hipStreamSynchronize(S(s)) == hipSuccess ? GJX_OK : GJX_ERR_LAUNCH; }
 };
 
@@ -2987,6 +2714,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -3011,6 +2739,7 @@ struct Rccl {
       GJX_NCCL_SYM(GetUniqueId, "ncclGetUniqueId");
       GJX_NCCL_SYM(CommInitRank, "ncclCommInitRank");
       GJX_NCCL_SYM(CommDestroy, "ncclCommDestroy");
+      GJX_NCCL_SYM(CommAbort, "ncclCommAbort");
       GJX_NCCL_SYM(AllReduce, "ncclAllReduce");
       GJX_NCCL_SYM(AllGather, "ncclAllGather");
       GJX_NCCL_SYM(Send, "ncclSend");
@@ -3033,28 +2762,34 @@ struct RcclTransport : gjx_sharded::Transport {
   ~RcclTransport() override {
     if (comm) (void)Rccl::get().CommDestroy(comm);
   }
+  // a rank that failed mid-run: abort the communicator so that peers blocked in a collective return with an error
+  // instead of waiting for this rank forever
+  void abort() override {
+    Rccl& R = Rccl::get();
+    if (comm && R.CommAbort) {
+      (void)R.CommAbort(comm);
+      comm = nullptr;
+    }
+  }
   static int st(ncclResult_t r) {
     if (r == ncclSuccess) return GJX_OK;
     fprintf(stderr, "[gjx] RCCL call failed (ncclResult %d)\n", (int)r);
     return GJX_ERR_LAUNCH;
   }
-  int allreduce_max_f32(float* buf, size_t n, gjx_stream s) override {
-    return st(Rccl::get().AllReduce(buf, buf, n, ncclFloat32, ncclMax, comm, S(s)));
-  }
   int allgather(void* full, size_t bytes, gjx_stream s) override {  // in place: the send buffer is this rank's block
     return st(Rccl::get().AllGather((const char*)full + (size_t)rank * bytes, full, bytes, ncclUint8, comm, S(s)));
   }
-  int exchange(void* const* cols, int n_cols, size_t elem, const gjx_sharded::Seg* sends, int ns, const gjx_sharded::Seg* recvs,
-               int nr, gjx_stream s) override {
+  int exchange(void* const* cols, const size_t* elems, int n_cols, const gjx_sharded::Seg* sends, int ns,
+               const gjx_sharded::Seg* recvs, int nr, gjx_stream s) override {
     if (!ns && !nr) return GJX_OK;
     Rccl& R = Rccl::get();
     ncclResult_t r = R.GroupStart();
     for (int i = 0; i < ns && r == ncclSuccess; ++i)
       for (int c = 0; c < n_cols && r == ncclSuccess; ++c)
-        r = R.Send((const char*)cols[c] + sends[i].a * elem, (size_t)(sends[i].b - sends[i].a) * elem, ncclUint8, sends[i].peer, comm, S(s));
+        r = R.Send((const char*)cols[c] + sends[i].a * elems[c], (size_t)(sends[i].b - sends[i].a) * elems[c], ncclUint8, sends[i].peer, comm, S(s));
     for (int i = 0; i < nr && r == ncclSuccess; ++i)
       for (int c = 0; c < n_cols && r == ncclSuccess; ++c)
-        r = R.Recv((char*)cols[c] + recvs[i].a * elem, (size_t)(recvs[i].b - recvs[i].a) * elem, ncclUint8, recvs[i].peer, comm, S(s));
+        r = R.Recv((char*)cols[c] + recvs[i].a * elems[c], (size_t)(recvs[i].b - recvs[i].a) * elems[c], ncclUint8, recvs[i].peer, comm, S(s));
     const ncclResult_t e = R.GroupEnd();
     return st(r != ncclSuccess ? r : e);
   }
@@ -3119,6 +2854,19 @@ int gjx_comm_init_local(gjx_comm_group* g, int rank, gjx_comm** out) {
   if (!c->t) {
     delete c;
     return GJX_ERR_LAUNCH;
+  }
+  *out = c;
+  return GJX_OK;
+}
+int gjx_comm_init_callbacks(int rank, int world, gjx_allgather_fn allgather, gjx_exchange_fn exchange,
+                            gjx_stream_sync_fn stream_sync, void* user, gjx_comm** out) {
+  if (!out) return GJX_ERR_INVALID;
+  gjx_comm* c = new (std::nothrow) gjx_comm;
+  if (!c) return GJX_ERR_LAUNCH;
+  const int rc = gjx_sharded::comm_init_callbacks(rank, world, allgather, exchange, stream_sync, user, &c->t);
+  if (rc) {
+    delete c;
+    return rc;
   }
   *out = c;
   return GJX_OK;

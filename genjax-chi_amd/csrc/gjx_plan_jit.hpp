@@ -568,7 +568,7 @@ struct GenScan {
 };
 
 // Plan-driven bootstrap SMC: a generated policy inside the fused resample kernel (step) and a plain
-// per-slot kernel (init).  State columns are staged per source tile in LDS like the fixed models.
+// per-slot kernel (init).  State columns are gathered from global memory by ancestor index like the fixed models.
 template <class CSiteT, class CArgT>
 struct GenSmc {
   std::ostringstream o;
@@ -595,7 +595,7 @@ struct GenSmc {
     o << "    const uint64_t g = (uint64_t)jq >> 2;\n";
     for (int u = 0; u < 4; ++u) {
       if (step)
-        for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << sf[u] << " = xs[" << k << "][src[" << u << "]];\n";
+        for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << sf[u] << " = a.prev_state[" << k << "][src[" << u << "]];\n";
       if (em[u].needs_stream_key()) o << "    const Key pkey" << sf[u] << " = slot_key<1>(a.step_key, (uint64_t)jq + " << u << "u);\n";
       o << "    float w" << sf[u] << " = 0.0f, sc" << sf[u] << " = 0.0f;\n";
     }
@@ -620,11 +620,11 @@ struct GenSmc {
     }
     for (int u = 0; u < 4; ++u) {
       for (int k = 0; k < n_state; ++k) o << "    out[" << u << "].s[" << k << "] = " << em[u].arg(state_args[k]) << ";\n";
-      o << "    (void)sc" << sf[u] << ";\n    out[" << u << "].lw = w" << sf[u] << ";\n    wq[" << u << "] = w" << sf[u] << ";\n";
+      o << "    (void)sc" << sf[u] << ";\n    wq[" << u << "] = w" << sf[u] << ";\n";
     }
   }
   void emit_quad(const CSiteT* sites, int n_sites, const CArgT* state_args, bool step) {
-    o << "  __device__ __forceinline__ void compute_quad(int64_t jq, const int (&src)[4], Out (&out)[4], float (&wq)[4]) const {\n";
+    o << "  __device__ __forceinline__ void compute_quad(int64_t jq, const uint32_t (&src)[4], Out (&out)[4], float (&wq)[4]) const {\n";
     emit_quad_body(sites, n_sites, state_args, step);
     o << "  }\n";
   }
@@ -635,63 +635,56 @@ struct GenSmc {
     SiteEmitter<CSiteT, CArgT> es{o, impl, 1, step_sites, n_step, "    "};
     SiteEmitter<CSiteT, CArgT> ei{o, impl, 1, init_sites, n_init, "        "};
     // ---- step policy
-    o << "struct GenPolicy {\n  PlanPolicyArgs a;\n  float* xs[" << D << "];\n  float xr[" << D << "][kPer];\n";
-    o << "  struct Out { float s[" << D << "]; float lw; };\n";
+    o << "struct GenPolicy {\n  static constexpr bool kEmit = true;\n  PlanPolicyArgs a;\n";
+    o << "  struct Out { float s[" << D << "]; };\n";
     o << "  __device__ __forceinline__ void select_filter(uint64_t off, Key k) {\n";
     o << "    for (int c = 0; c < " << D << "; ++c) { a.prev_state[c] += off; a.state_out[c] += off; }\n";
-    o << "    a.logw_out += off; if (a.anc_out) a.anc_out += off; a.step_key = k;\n  }\n";
-    o << "  __device__ __forceinline__ void fetch_source(uint64_t base, uint64_t n, int tid) {\n";
-    o << "    for (int k = 0; k < " << D << "; ++k)\n      for (int r = 0; r < kPer; ++r) { const uint64_t i = base + (uint64_t)r * 256 + tid; xr[k][r] = i < n ? a.prev_state[k][i] : 0.0f; }\n  }\n";
-    o << "  __device__ __forceinline__ void stage_source(int tid) {\n    __shared__ float tile[" << D << "][kTile];\n";
-    o << "    for (int k = 0; k < " << D << "; ++k) { xs[k] = tile[k]; for (int r = 0; r < kPer; ++r) tile[k][r * 256 + tid] = xr[k][r]; }\n  }\n";
-    o << "  __device__ __forceinline__ float compute(int64_t j, int src_local, Out& out) const {\n";
-    for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << " = xs[" << k << "][src_local];\n";
+    o << "    if (a.anc_out) a.anc_out += off; a.step_key = k;\n  }\n";
+    o << "  __device__ __forceinline__ float compute(int64_t j, uint32_t src_global, Out& out) const {\n";
+    for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << " = a.prev_state[" << k << "][src_global];\n";
     if (es.needs_pk()) o << "    const Key pkey = slot_key<" << I << ">(a.step_key, (uint64_t)j);\n";
     o << "    float w = 0.0f, sc = 0.0f;\n";
     es.run();
     for (int k = 0; k < n_state; ++k) o << "    out.s[" << k << "] = " << es.arg(next_state[k]) << ";\n";
-    o << "    (void)sc;\n    out.lw = w;\n    return w;\n  }\n";
+    o << "    (void)sc;\n    return w;\n  }\n";
     if (impl == 1) emit_quad(step_sites, n_step, next_state, true);
-    o << "  __device__ __forceinline__ void store(int64_t j, int64_t out_lo, uint64_t src, const Out& out) const {\n";
+    o << "  __device__ __forceinline__ void store(int64_t j, int64_t out_lo, uint32_t src, const Out& out) const {\n";
     o << "    for (int k = 0; k < " << D << "; ++k) a.state_out[k][j - out_lo] = out.s[k];\n";
-    o << "    a.logw_out[j - out_lo] = out.lw;\n    if (a.anc_out) a.anc_out[j - out_lo] = (int32_t)src;\n  }\n};\n";
-    o << "extern \"C\" __global__ __attribute__((amdgpu_num_sgpr(96))) __launch_bounds__(256) void gjx_smc_step_kernel(ResampleArgs A, PlanPolicyArgs PA, float* max_partials) {\n";
-    o << "  GenPolicy P;\n  P.a = PA;\n  resample_body<" << I << ">(A, P, max_partials);\n}\n";
-    // ---- init kernel: one workgroup per global tile, like k_lgssm_init
+    o << "    if (a.anc_out) a.anc_out[j - out_lo] = (int32_t)src;\n  }\n};\n";
+    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_step_kernel(ResampleArgs A, PlanPolicyArgs PA) {\n";
+    o << "  GenPolicy P;\n  P.a = PA;\n  resample_body<" << I << ">(A, P);\n}\n";
+    // ---- init kernel: one workgroup per LOCAL tile, like k_lgssm_init
     if (impl == 1) {
-      o << "struct GenInitOut { float s[" << D << "]; float lw; };\n";
+      o << "struct GenInitOut { float s[" << D << "]; };\n";
       o << "__device__ __forceinline__ void init_quad(const PlanPolicyArgs& a, int64_t jq, GenInitOut (&out)[4], float (&wq)[4]) {\n";
       emit_quad_body(init_sites, n_init, init_state, false);
       o << "}\n";
     }
-    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_init_kernel(PlanPolicyArgs a, uint64_t first_slot, uint64_t n_local, float* max_partials, FilterBatch fb) {\n";
-    o << "  __shared__ float shf[4];\n  uint64_t gtile = blockIdx.x;\n";
+    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_init_kernel(PlanPolicyArgs a, uint64_t first_slot, uint64_t n_local, EmitOut em, FilterBatch fb) {\n";
+    o << "  uint64_t ltile = blockIdx.x;\n";
     o << "  if (fb.n_filters > 1) {  // several filters per launch: tile of filter f, its key, its outputs\n";
-    o << "    const uint32_t f = (uint32_t)(gtile / fb.tiles);\n    gtile -= (uint64_t)f * fb.tiles;\n    a.step_key = fb.step_key[f];\n";
+    o << "    const uint32_t f = (uint32_t)(ltile / fb.tiles);\n    ltile -= (uint64_t)f * fb.tiles;\n    a.step_key = fb.step_key[f];\n";
     o << "    for (int k = 0; k < " << D << "; ++k) a.state_out[k] += (uint64_t)f * fb.stride;\n";
-    o << "    a.logw_out += (uint64_t)f * fb.stride;\n    if (a.anc_out) a.anc_out += (uint64_t)f * fb.stride;\n  }\n";
-    o << "  const uint64_t gbase = gtile * kTile;\n  float tmax = -__builtin_inff();\n";
+    o << "    if (a.anc_out) a.anc_out += (uint64_t)f * fb.stride;\n    select_filter_emit(em, fb, f);\n  }\n";
+    o << "  const uint64_t loc = ltile * kTile + 4 * (uint64_t)threadIdx.x;\n  const uint64_t gq = first_slot + loc;\n";
+    o << "  float wq[4];\n  bool okq[4];\n  for (int u = 0; u < 4; ++u) okq[u] = loc + u < n_local;\n";
     if (impl == 1) {  // four consecutive slots per lane, one cipher block per one-word draw of the quad
-      o << "  if (gbase >= first_slot && gbase < first_slot + n_local) {\n";
-      o << "    const int64_t jq = (int64_t)(gbase + 4 * (uint64_t)threadIdx.x);\n";
-      o << "    GenInitOut out[4];\n    float wq[4];\n";
+      o << "  {\n    const int64_t jq = (int64_t)gq;\n    GenInitOut out[4];\n";
       o << "    init_quad(a, jq, out, wq);\n";
-      o << "    for (int u = 0; u < 4; ++u) {\n      const uint64_t j = (uint64_t)jq + u;\n      if (j < first_slot + n_local) {\n";
-      for (int k = 0; k < n_state; ++k) o << "        a.state_out[" << k << "][j - first_slot] = out[u].s[" << k << "];\n";
-      o << "        a.logw_out[j - first_slot] = wq[u];\n        if (a.anc_out) a.anc_out[j - first_slot] = (int32_t)j;\n";
-      o << "        tmax = wq[u] > tmax ? wq[u] : tmax;\n      }\n    }\n  }\n";
-      o << "  const float bm = block_max(tmax, shf);\n  if (threadIdx.x == 0) max_partials[blockIdx.x] = bm;\n}\n";
-      return o.str();
+      o << "    for (int u = 0; u < 4; ++u) {\n      if (okq[u]) {\n";
+      for (int k = 0; k < n_state; ++k) o << "        a.state_out[" << k << "][loc + u] = out[u].s[" << k << "];\n";
+      o << "        if (a.anc_out) a.anc_out[loc + u] = (int32_t)(gq + u);\n      }\n    }\n  }\n";
+    } else {
+      o << "  for (int u = 0; u < 4; ++u) {\n    const uint64_t j = gq + u;\n    wq[u] = 0.0f;\n    {\n";
+      if (ei.needs_pk()) o << "        const Key pkey = slot_key<" << I << ">(a.step_key, j);\n";
+      o << "        float w = 0.0f, sc = 0.0f;\n";
+      ei.run();
+      for (int k = 0; k < n_state; ++k) o << "        const float ns_" << k << " = " << ei.arg(init_state[k]) << ";\n";
+      o << "        (void)sc;\n        wq[u] = w;\n        if (okq[u]) {\n";
+      for (int k = 0; k < n_state; ++k) o << "          a.state_out[" << k << "][loc + u] = ns_" << k << ";\n";
+      o << "          if (a.anc_out) a.anc_out[loc + u] = (int32_t)j;\n        }\n    }\n  }\n";
     }
-    o << "  if (gbase >= first_slot && gbase < first_slot + n_local) {\n    for (int r = 0; r < kPer; ++r) {\n";
-    o << "      const uint64_t j = gbase + (uint64_t)r * 256 + threadIdx.x;\n      if (j < first_slot + n_local) {\n";
-    if (ei.needs_pk()) o << "        const Key pkey = slot_key<" << I << ">(a.step_key, j);\n";
-    o << "        float w = 0.0f, sc = 0.0f;\n";
-    ei.run();
-    for (int k = 0; k < n_state; ++k) o << "        a.state_out[" << k << "][j - first_slot] = " << ei.arg(init_state[k]) << ";\n";
-    o << "        (void)sc;\n        a.logw_out[j - first_slot] = w;\n        if (a.anc_out) a.anc_out[j - first_slot] = (int32_t)j;\n";
-    o << "        tmax = w > tmax ? w : tmax;\n      }\n    }\n  }\n";
-    o << "  const float bm = block_max(tmax, shf);\n  if (threadIdx.x == 0) max_partials[blockIdx.x] = bm;\n}\n";
+    o << "  emit_init_tile(wq, okq, em, loc, first_slot / kTile + ltile);\n}\n";
     return o.str();
   }
 };

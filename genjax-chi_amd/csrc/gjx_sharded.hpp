@@ -1,7 +1,7 @@
 // gjx_sharded.hpp — the native multi-rank driver of the sharded bootstrap filter (include/gjx.h: gjx_comm,
 // gjx_smc_sharded_run_*, gjx_comm_lse_combine).
 //
-// Orchestration only: every arithmetic step is one of the public per-step entry points (gjx_smc_*_step_a, gjx_smc_step_b,
+// Orchestration only: every arithmetic step is one of the public per-step entry points (gjx_smc_*_step,
 // gjx_smc_source_ranges, gjx_smc_finish, gjx_lse_combine) and every exchange goes through the abstract Transport below, so
 // the same driver serves libgjx_hip.so (RCCL ranks; virtual ranks on one device) and the CPU oracle build (virtual ranks),
 // which is how the protocol is tested without a multi-GPU box.  A build provides `Mem` — copy / max on ITS memory.
@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -19,22 +20,20 @@
 
 namespace gjx_sharded {
 
-struct Seg {  // elements [a, b) of a global column travel to / from `peer`
-  int peer;
-  uint64_t a, b;
-};
+using Seg = gjx_seg;  // elements [a, b) of a global column travel to / from `peer`
+static_assert(sizeof(size_t) == sizeof(uint64_t), "gjx_exchange_fn passes element sizes as uint64_t");
 
 struct Transport {
   int rank = 0, world = 1;
   virtual ~Transport() {}
-  // element-wise max over the ranks' buffers, result in every rank's buffer
-  virtual int allreduce_max_f32(float* buf, size_t n, gjx_stream s) = 0;
   // in place: rank r's block is full + r * bytes_per_rank
   virtual int allgather(void* full, size_t bytes_per_rank, gjx_stream s) = 0;
-  // slices keep their global position on both sides: cols[c] + a * elem .. cols[c] + b * elem
-  virtual int exchange(void* const* cols, int n_cols, size_t elem, const Seg* sends, int ns, const Seg* recvs, int nr,
+  // slices keep their global position on both sides: cols[c] + a * elems[c] .. cols[c] + b * elems[c]
+  virtual int exchange(void* const* cols, const size_t* elems, int n_cols, const Seg* sends, int ns, const Seg* recvs, int nr,
                        gjx_stream s) = 0;
   virtual int stream_sync(gjx_stream s) = 0;
+  // this rank has failed and will not take part in further collectives: release the peers (best effort)
+  virtual void abort() {}
 };
 
 // ---- virtual ranks: threads of one process ------------------------------------------------------------------------
@@ -69,8 +68,7 @@ struct Group {
   }
 };
 
-// Mem: int copy(void* dst, const void* src, size_t bytes, gjx_stream); int max_f32(float* dst, const float* const* srcs,
-// int world, size_t n, gjx_stream) (dst may be one of srcs? no: dst is scratch); void* scratch(size_t bytes); int sync(gjx_stream)
+// Mem: int copy(void* dst, const void* src, size_t bytes, gjx_stream); int sync(gjx_stream)
 template <class Mem>
 struct LocalTransport : Transport {
   Group* g;
@@ -85,19 +83,6 @@ struct LocalTransport : Transport {
     rank = r;
     world = grp->world;
   }
-  int allreduce_max_f32(float* buf, size_t n, gjx_stream s) override {
-    if (world == 1) return GJX_OK;
-    g->slot[(size_t)rank] = buf;
-    if (!g->barrier()) return GJX_ERR_LAUNCH;  // every rank's values are enqueued
-    float* tmp = (float*)mem.scratch(n * sizeof(float));
-    if (!tmp) return GJX_ERR_WORKSPACE;
-    std::vector<const float*> srcs((size_t)world);
-    for (int r = 0; r < world; ++r) srcs[(size_t)r] = (const float*)g->slot[(size_t)r];
-    int rc = mem.max_f32(tmp, srcs.data(), world, n, s);
-    if (!g->barrier()) return GJX_ERR_LAUNCH;  // every rank has read every buffer
-    if (rc == GJX_OK) rc = mem.copy(buf, tmp, n * sizeof(float), s);
-    return rc;
-  }
   int allgather(void* full, size_t bytes, gjx_stream s) override {
     if (world == 1) return GJX_OK;
     g->slot[(size_t)rank] = full;
@@ -108,7 +93,7 @@ struct LocalTransport : Transport {
     if (!g->barrier()) return GJX_ERR_LAUNCH;
     return rc;
   }
-  int exchange(void* const* cols, int n_cols, size_t elem, const Seg* sends, int ns, const Seg* recvs, int nr,
+  int exchange(void* const* cols, const size_t* elems, int n_cols, const Seg* sends, int ns, const Seg* recvs, int nr,
                gjx_stream s) override {
     if (world == 1) return GJX_OK;
     post = ExPost{cols, sends, ns};
@@ -122,68 +107,101 @@ struct LocalTransport : Transport {
         matched = matched || (peer->sends[k].peer == rank && peer->sends[k].a == recvs[i].a && peer->sends[k].b == recvs[i].b);
       if (!matched) rc = GJX_ERR_INVALID;
       for (int c = 0; c < n_cols && rc == GJX_OK; ++c)
-        rc = mem.copy((char*)cols[c] + recvs[i].a * elem, (const char*)peer->cols[c] + recvs[i].a * elem,
-                      (size_t)(recvs[i].b - recvs[i].a) * elem, s);
+        rc = mem.copy((char*)cols[c] + recvs[i].a * elems[c], (const char*)peer->cols[c] + recvs[i].a * elems[c],
+                      (size_t)(recvs[i].b - recvs[i].a) * elems[c], s);
     }
     if (!g->barrier()) return GJX_ERR_LAUNCH;
     return rc;
   }
   int stream_sync(gjx_stream s) override { return mem.sync(s); }
+  void abort() override {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->broken = true;
+    g->cv.notify_all();
+  }
 };
+
+// ---- the caller's collectives (gjx_comm_init_callbacks) ---------------------------------------------------------------
+struct CallbackTransport : Transport {
+  gjx_allgather_fn ag;
+  gjx_exchange_fn ex;
+  gjx_stream_sync_fn sy;
+  void* user;
+  int allgather(void* full, size_t bytes, gjx_stream s) override { return world == 1 ? GJX_OK : ag(user, full, (uint64_t)bytes, s); }
+  int exchange(void* const* cols, const size_t* elems, int n_cols, const Seg* sends, int ns, const Seg* recvs, int nr,
+               gjx_stream s) override {
+    if (world == 1 || (!ns && !nr)) return GJX_OK;
+    return ex(user, cols, reinterpret_cast<const uint64_t*>(elems), n_cols, sends, ns, recvs, nr, s);
+  }
+  int stream_sync(gjx_stream s) override { return sy ? sy(user, s) : GJX_OK; }
+};
+inline int comm_init_callbacks(int rank, int world, gjx_allgather_fn ag, gjx_exchange_fn ex, gjx_stream_sync_fn sy, void* user,
+                               Transport** out) {
+  if (!out || world < 1 || world > 64 || rank < 0 || rank >= world || (world > 1 && (!ag || !ex))) return GJX_ERR_INVALID;
+  CallbackTransport* t = new (std::nothrow) CallbackTransport;
+  if (!t) return GJX_ERR_LAUNCH;
+  t->rank = rank; t->world = world; t->ag = ag; t->ex = ex; t->sy = sy; t->user = user;
+  *out = t;
+  return GJX_OK;
+}
 
 // Tickets of the range kernel (gjx_smc_source_ranges): process-wide and never reused, so a ticket left in a caller's
 // `ranges` buffer by an earlier run — of any model — cannot be mistaken for the current one.
 inline std::atomic<int64_t> g_ticket_source{0};
 
 // ---- the sharded filter -----------------------------------------------------------------------------------------------
-// StepA: int(int t, int cur, int prv) -> status: step A of step t for the rank's own slots (buffers by parity).
-template <class StepA>
-int sharded_run(Transport& T, const gjx_smc_config* cfg, int n_state, size_t state_elem, const gjx_sharded_io* io,
-                StepA step_a, gjx_stream s) {
+// Step: int(int t, const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* prev_e, uint64_t* prev_q, int32_t* anc) ->
+// status: ONE launch for the rank's own slots.  Per step: that launch, ONE all-gather of the tile records (16 bytes per
+// tile; + the ESS sums of an adaptive filter), then the ancestor shuffle of the state columns and the in-tile CDF.
+template <class Step>
+int sharded_steps(Transport& T, const gjx_smc_config* cfg, int n_state, const gjx_sharded_io* io, Step step, gjx_stream s,
+                  uint64_t* received_out) {
   const int world = T.world, rank = T.rank;
   const uint64_t tile = gjx_smc_tile(), N = cfg->n_total, nl = cfg->n_local, lo = cfg->first_slot;
-  if (!io || !io->tile_sums || !io->max_partials || !io->out_max || !io->out_q || !io->logw[0] || !io->logw[1] ||
-      cfg->n_filters > 1 || N % ((uint64_t)world * tile) != 0 || nl != N / (uint64_t)world || lo != (uint64_t)rank * nl ||
-      (io->shuffle == 0 && world > 1 && !io->ranges) || world > 64 || state_elem != 4 /* every state column is 4-byte */)
-    return GJX_ERR_INVALID;
-  const uint64_t nt = gjx_num_tiles(N), tiles_local = nl / tile;
+  const uint64_t tiles_local = nl / tile;
   const bool adaptive = cfg->ess_threshold > 0.0f && cfg->ess_threshold < 1.0f;
-  if (adaptive && !cfg->tile_ess) return GJX_ERR_INVALID;
-  uint64_t received = 0;
-  int64_t ticket = 0;
+  const int n_steps = cfg->n_steps;
+  uint64_t& received = *received_out;
   int rc = GJX_OK;
-  for (int t = 0; t < cfg->n_steps && rc == GJX_OK; ++t) {
+  for (int t = 0; t < n_steps && rc == GJX_OK; ++t) {
     const int cur = t & 1, prv = cur ^ 1;
-    rc = step_a(t, cur, prv);
-    if (rc) break;
-    if ((rc = T.allreduce_max_f32(io->max_partials, (size_t)nt, s))) break;
-    if ((rc = gjx_smc_step_b(cfg, io->logw[cur] + lo, io->max_partials, io->out_max + t, io->tile_sums, s))) break;
-    if ((rc = T.allgather(io->tile_sums, (size_t)tiles_local * sizeof(uint64_t), s))) break;
-    if (adaptive && (rc = T.allgather(cfg->tile_ess, (size_t)tiles_local * 2 * sizeof(uint64_t), s))) break;
-    if (t + 1 >= cfg->n_steps || world == 1) continue;
+    const gjx_smc_pop& full = io->pop[cur];
+    gjx_smc_pop out = full;  // the rank's own block of the local arrays; records / ESS sums stay global
+    for (int k = 0; k < n_state; ++k) out.state[k] = (char*)full.state[k] + lo * 4;
+    out.cdf = full.cdf + lo;
+    out.logw = (adaptive || t == n_steps - 1) && full.logw ? full.logw + lo : nullptr;
+    if ((rc = step(t, &io->pop[prv], &out, t ? io->out_e + (t - 1) : nullptr, t ? io->out_q + (t - 1) : nullptr,
+                   io->ancestors ? io->ancestors + (size_t)t * nl : nullptr)))
+      break;
+    if ((rc = T.allgather(full.recs, (size_t)tiles_local * sizeof(gjx_tile_rec), s))) break;
+    if (adaptive && (rc = T.allgather(full.ess, (size_t)tiles_local * 2 * sizeof(uint64_t), s))) break;
+    if (t + 1 >= n_steps || world == 1) continue;
     // ---- the ancestor shuffle: make the source ranges of the next resampling present on every rank
-    void* cols[GJX_SMC_MAX_STATE + 1];
-    for (int k = 0; k < n_state; ++k) cols[k] = io->state[cur][k];
-    cols[n_state] = io->logw[cur];
+    void* cols[GJX_SMC_MAX_STATE + 2];
+    size_t elems[GJX_SMC_MAX_STATE + 2];
+    int nc = 0;
+    for (int k = 0; k < n_state; ++k) { cols[nc] = full.state[k]; elems[nc++] = 4; }
+    cols[nc] = full.cdf; elems[nc++] = 8;
+    if (adaptive) { cols[nc] = full.logw; elems[nc++] = 4; }
     if (io->shuffle == 1) {
-      for (int c = 0; c <= n_state && rc == GJX_OK; ++c) rc = T.allgather(cols[c], (size_t)nl * 4, s);
+      for (int c = 0; c < nc && rc == GJX_OK; ++c) rc = T.allgather(cols[c], (size_t)nl * elems[c], s);
       received += N - nl;
       continue;
     }
-    ticket = ++g_ticket_source;
-    if ((rc = gjx_smc_source_ranges(cfg, io->tile_sums, world, ticket, io->ranges, s))) break;
+    const int64_t ticket = ++g_ticket_source;
+    if ((rc = gjx_smc_source_ranges(cfg, full.recs, full.ess, world, ticket, io->ranges, s))) break;
     // the range kernel stores its words straight into pinned host memory, the ticket last with a system-scope release:
     // poll the ticket instead of synchronising the stream; if it does not show up soon, wait for the stream
     volatile int64_t* rh = io->ranges;
     const auto t0 = std::chrono::steady_clock::now();
     bool synced = false;
-    while (rh[2 * world] != ticket) {
+    while (rh[2 * world] != ticket && rc == GJX_OK) {
       if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(synced ? 5000 : 50)) {
-        if (synced) return GJX_ERR_LAUNCH;
-        if ((rc = T.stream_sync(s))) return rc;
-        synced = true;
+        if (synced) rc = GJX_ERR_LAUNCH;
+        else if ((rc = T.stream_sync(s)) == GJX_OK) synced = true;
       }
     }
+    if (rc) break;
     std::atomic_thread_fence(std::memory_order_acquire);
     Seg sends[64], recvs[64];
     int ns = 0, nr = 0;
@@ -202,56 +220,59 @@ int sharded_run(Transport& T, const gjx_smc_config* cfg, int n_state, size_t sta
         received += b - a;
       }
     }
-    rc = T.exchange(cols, n_state + 1, 4, sends, ns, recvs, nr, s);
+    rc = T.exchange(cols, elems, nc, sends, ns, recvs, nr, s);
   }
-  if (rc == GJX_OK) rc = gjx_smc_finish(cfg, io->tile_sums, io->out_q + (cfg->n_steps - 1), s);
+  if (rc == GJX_OK)
+    rc = gjx_smc_finish(cfg, io->pop[(n_steps - 1) & 1].recs, io->out_e + (n_steps - 1), io->out_q + (n_steps - 1), s);
+  return rc;
+}
+template <class Step>
+int sharded_run(Transport& T, const gjx_smc_config* cfg, int n_state, const gjx_sharded_io* io, Step step, gjx_stream s) {
+  if (!io) return GJX_ERR_INVALID;
+  uint64_t received = 0;
+  int rc = GJX_ERR_INVALID;
+  const int world = T.world, rank = T.rank;
+  const uint64_t tile = gjx_smc_tile();
+  const bool adaptive = cfg && cfg->ess_threshold > 0.0f && cfg->ess_threshold < 1.0f;
+  bool ok = cfg && io->out_e && io->out_q && cfg->n_filters <= 1 && cfg->n_steps > 0 && world >= 1 && world <= 64 &&
+            cfg->n_total % ((uint64_t)world * tile) == 0 && cfg->n_local == cfg->n_total / (uint64_t)world &&
+            cfg->first_slot == (uint64_t)rank * cfg->n_local && !(io->shuffle == 0 && world > 1 && !io->ranges);
+  for (int i = 0; i < 2 && ok; ++i) {
+    ok = io->pop[i].cdf && io->pop[i].recs && (!adaptive || (io->pop[i].logw && io->pop[i].ess));
+    for (int k = 0; k < n_state && ok; ++k) ok = io->pop[i].state[k] != nullptr;
+  }
+  if (ok) {
+    rc = sharded_steps(T, cfg, n_state, io, step, s, &received);
+    // a rank that leaves the loop early would leave its peers waiting in the next collective: tell the transport
+    if (rc != GJX_OK) T.abort();
+  }
   if (io->received) *io->received = received;
   return rc;
 }
 
 inline int run_lgssm(Transport& T, const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y, const gjx_sharded_io* io,
                      gjx_stream s) {
-  if (!cfg || !model || !y || !io || !io->state[0][0] || !io->state[1][0]) return GJX_ERR_INVALID;
-  const uint64_t lo = cfg->first_slot, nl = cfg->n_local;
-  auto step_a = [&](int t, int cur, int prv) {
-    return gjx_smc_lgssm_step_a(cfg, model, t, y[t], t ? (const float*)io->state[prv][0] : nullptr, t ? io->logw[prv] : nullptr,
-                                t ? io->out_max + (t - 1) : nullptr, t ? io->tile_sums : nullptr, t ? io->out_q + (t - 1) : nullptr,
-                                (float*)io->state[cur][0] + lo, io->logw[cur] + lo, io->max_partials,
-                                io->ancestors ? io->ancestors + (size_t)t * nl : nullptr, s);
+  if (!cfg || !model || !y || !io) return GJX_ERR_INVALID;
+  auto step = [&](int t, const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* pe, uint64_t* pq, int32_t* anc) {
+    return gjx_smc_lgssm_step(cfg, model, t, y[t], prev, out, pe, pq, anc, s);
   };
-  return sharded_run(T, cfg, 1, sizeof(float), io, step_a, s);
+  return sharded_run(T, cfg, 1, io, step, s);
 }
 inline int run_hmm(Transport& T, const gjx_smc_config* cfg, const gjx_hmm* model, const int32_t* y, const uint32_t* trans_alias,
                    const float* obs_logp, const gjx_sharded_io* io, gjx_stream s) {
-  if (!cfg || !model || !y || !io || !trans_alias || !obs_logp || !io->state[0][0] || !io->state[1][0]) return GJX_ERR_INVALID;
-  const uint64_t lo = cfg->first_slot, nl = cfg->n_local;
-  auto step_a = [&](int t, int cur, int prv) {
-    return gjx_smc_hmm_step_a(cfg, model, t, y[t], t ? (const int32_t*)io->state[prv][0] : nullptr, t ? io->logw[prv] : nullptr,
-                              t ? io->out_max + (t - 1) : nullptr, t ? io->tile_sums : nullptr, t ? io->out_q + (t - 1) : nullptr,
-                              trans_alias, obs_logp, (int32_t*)io->state[cur][0] + lo, io->logw[cur] + lo, io->max_partials,
-                              io->ancestors ? io->ancestors + (size_t)t * nl : nullptr, s);
+  if (!cfg || !model || !y || !io || !trans_alias || !obs_logp) return GJX_ERR_INVALID;
+  auto step = [&](int t, const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* pe, uint64_t* pq, int32_t* anc) {
+    return gjx_smc_hmm_step(cfg, model, t, y[t], prev, out, pe, pq, trans_alias, obs_logp, anc, s);
   };
-  return sharded_run(T, cfg, 1, sizeof(int32_t), io, step_a, s);
+  return sharded_run(T, cfg, 1, io, step, s);
 }
 inline int run_plan(Transport& T, const gjx_smc_config* cfg, gjx_smc_plan* plan, int n_state, int n_obs, const float* obs,
                     const gjx_sharded_io* io, gjx_stream s) {
   if (!cfg || !plan || !io || (n_obs > 0 && !obs) || n_state < 1 || n_state > GJX_SMC_MAX_STATE) return GJX_ERR_INVALID;
-  for (int k = 0; k < n_state; ++k)
-    if (!io->state[0][k] || !io->state[1][k]) return GJX_ERR_INVALID;
-  const uint64_t lo = cfg->first_slot, nl = cfg->n_local;
-  auto step_a = [&](int t, int cur, int prv) {
-    const float* prev[GJX_SMC_MAX_STATE];
-    float* own[GJX_SMC_MAX_STATE];
-    for (int k = 0; k < n_state; ++k) {
-      prev[k] = (const float*)io->state[prv][k];
-      own[k] = (float*)io->state[cur][k] + lo;
-    }
-    return gjx_smc_plan_step_a(cfg, plan, t, n_obs ? obs + (size_t)t * (size_t)n_obs : nullptr, t ? prev : nullptr,
-                               t ? io->logw[prv] : nullptr, t ? io->out_max + (t - 1) : nullptr, t ? io->tile_sums : nullptr,
-                               t ? io->out_q + (t - 1) : nullptr, own, io->logw[cur] + lo, io->max_partials,
-                               io->ancestors ? io->ancestors + (size_t)t * nl : nullptr, s);
+  auto step = [&](int t, const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* pe, uint64_t* pq, int32_t* anc) {
+    return gjx_smc_plan_step(cfg, plan, t, n_obs ? obs + (size_t)t * (size_t)n_obs : nullptr, prev, out, pe, pq, anc, s);
   };
-  return sharded_run(T, cfg, n_state, sizeof(float), io, step_a, s);
+  return sharded_run(T, cfg, n_state, io, step, s);
 }
 
 // log-marginal of sharded importance passes: all-gather of the shards' records, then the exact merge

@@ -164,19 +164,49 @@ class ScanIO(C.Structure):
     ]
 
 
+class TileRec(C.Structure):
+    """gjx_tile_rec: a tile's mass relative to its own power-of-two anchor."""
+    _fields_ = [("s", C.c_uint64), ("e", C.c_int32), ("pad", C.c_int32)]
+
+
+TILE_REC_BYTES = 16
+TILE_FRAC = 30  # gjx.h: GJX_TILE_FRAC
+TILE_EMPTY = -(1 << 30)
+
+
+class SmcPop(C.Structure):
+    """gjx_smc_pop: a population between two steps."""
+    _fields_ = [
+        ("state", C.c_void_p * 4),
+        ("cdf", C.c_void_p),
+        ("logw", C.c_void_p),
+        ("recs", C.c_void_p),
+        ("ess", C.c_void_p),
+        ("prefix", C.c_void_p),
+    ]
+
+
 class ShardedIO(C.Structure):
     _fields_ = [
-        ("state", (C.c_void_p * 4) * 2),
-        ("logw", C.c_void_p * 2),
-        ("tile_sums", C.c_void_p),
-        ("max_partials", C.c_void_p),
-        ("out_max", C.c_void_p),
+        ("pop", SmcPop * 2),
+        ("out_e", C.c_void_p),
         ("out_q", C.c_void_p),
         ("ancestors", C.c_void_p),
         ("ranges", C.c_void_p),
         ("shuffle", C.c_int32),
         ("received", C.POINTER(C.c_uint64)),
     ]
+
+
+class Seg(C.Structure):
+    """gjx_seg: elements [a, b) of a global column travel to / from `peer`."""
+    _fields_ = [("peer", C.c_int32), ("a", C.c_uint64), ("b", C.c_uint64)]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int32, C.POINTER(Seg),
+                          C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p)
+STREAM_SYNC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 
 COMM_ID_BYTES = 128
@@ -214,8 +244,6 @@ class SmcConfig(C.Structure):
         ("filter_stride", C.c_uint64),
         ("ess_threshold", C.c_float),     # 0 / >= 1: resample at every step; (0, 1): only when ESS < threshold * N
         ("resampled_out", C.c_void_p),    # dev int32[T] / [F, T]: 1 where a step began with a resampling
-        ("tile_ess", C.c_void_p),         # step-level API of adaptive filters: global u64[2 * tiles] ESS sums
-        ("tile_sums_form", C.c_int32),    # 0 auto, 1 workgroup per tile, 2 wave per tile
     ]
 
 
@@ -317,18 +345,20 @@ PROTOTYPES = {
         C.c_int,
         [C.POINTER(SmcConfig), _P, _P, _P, _P, C.POINTER(_P), _P, _P, _P, C.c_size_t, _P],
     ),
-    "gjx_smc_lgssm_step_a": (
+    "gjx_smc_lgssm_step": (
         C.c_int,
-        [C.POINTER(SmcConfig), C.POINTER(Lgssm), C.c_int, C.c_float] + [_P] * 10,
+        [C.POINTER(SmcConfig), C.POINTER(Lgssm), C.c_int, C.c_float, C.POINTER(SmcPop), C.POINTER(SmcPop), _P, _P, _P, _P],
     ),
-    "gjx_smc_hmm_step_a": (
+    "gjx_smc_hmm_step": (
         C.c_int,
-        [C.POINTER(SmcConfig), C.POINTER(Hmm), C.c_int, C.c_int32] + [_P] * 12,
+        [C.POINTER(SmcConfig), C.POINTER(Hmm), C.c_int, C.c_int32, C.POINTER(SmcPop), C.POINTER(SmcPop), _P, _P, _P, _P, _P, _P],
     ),
-    "gjx_smc_plan_step_a": (C.c_int, [C.POINTER(SmcConfig), _P, C.c_int] + [_P] * 11),
-    "gjx_smc_step_b": (C.c_int, [C.POINTER(SmcConfig), _P, _P, _P, _P, _P]),
-    "gjx_smc_finish": (C.c_int, [C.POINTER(SmcConfig), _P, _P, _P]),
-    "gjx_smc_source_ranges": (C.c_int, [C.POINTER(SmcConfig), _P, C.c_int, C.c_int64, _P, _P]),
+    "gjx_smc_plan_step": (C.c_int, [C.POINTER(SmcConfig), _P, C.c_int, _P, C.POINTER(SmcPop), C.POINTER(SmcPop), _P, _P, _P, _P]),
+    "gjx_smc_finish": (C.c_int, [C.POINTER(SmcConfig), _P, _P, _P, _P]),
+    "gjx_smc_source_ranges": (C.c_int, [C.POINTER(SmcConfig), _P, _P, C.c_int, C.c_int64, _P, _P]),
+    "gjx_tile_cdf": (C.c_int, [_P, C.c_uint64, _P, _P, _P]),
+    "gjx_tile_merge": (C.c_int, [_P, C.c_uint64, _P, _P, _P]),
+    "gjx_comm_init_callbacks": (C.c_int, [C.c_int, C.c_int, ALLGATHER_FN, EXCHANGE_FN, STREAM_SYNC_FN, _P, C.POINTER(_P)]),
     "gjx_hmm_alias_words": (C.c_uint64, [C.c_int32]),
     "gjx_hmm_prepare": (C.c_int, [C.POINTER(Hmm), _P, _P, _P]),
 }

@@ -131,6 +131,23 @@ def importance_log_z(ops: Ops, wl: "W.Gaussian10"):
     return ops.log_z_from_rows(e[0], q[0], wl.n_total), pipe.prep.logw, e, q
 
 
+def merged_tile_masses(recs):
+    """Tile records (int64 [tiles, 2]: word 0 = S_t, low half of word 1 = e_t; gjx_tile_rec) -> (e, masses uint64
+    [tiles]): the merge every consumer of the records performs: e = max e_t, M_t = S_t >> (e - e_t)."""
+    import numpy as np
+
+    from . import abi
+
+    r = np.ascontiguousarray(np.asarray(recs.cpu() if hasattr(recs, "cpu") else recs)).view(np.uint64).reshape(-1, 2)
+    s = r[:, 0].copy()
+    et = (r[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32).astype(np.int64)
+    live = et != abi.TILE_EMPTY
+    e = int(et[live].max()) if live.any() else abi.TILE_EMPTY
+    d = np.where(live, e - et, 64)
+    m = np.where(d < 64, s >> np.minimum(d, 63).astype(np.uint64), np.uint64(0)).astype(np.uint64)
+    return e, m
+
+
 def needed_tile_ranges(tile_sums, n_total: int, tile: int, world: int):
     """For every rank of a filter sharded into equal contiguous blocks: the half-open range of SOURCE tiles that
     can own one of the rank's output slots at the next systematic resampling — int64 [world, 2].  Host (numpy)
@@ -147,8 +164,9 @@ def needed_tile_ranges(tile_sums, n_total: int, tile: int, world: int):
     nt = q.size
     prefix = np.zeros(nt + 1, dtype=np.uint64)
     np.cumsum(q, out=prefix[1:])
-    if prefix[-1] == 0:  # no mass at all: the last particle closes the comb and owns every slot
-        return np.tile(np.array([[nt - 1, nt]], dtype=np.int64), (world, 1))
+    if prefix[-1] == 0:  # no mass at all: the population is kept, every block's sources are its own tiles
+        per = (n_total // world) // tile
+        return np.array([[j * per, (j + 1) * per] for j in range(world)], dtype=np.int64)
     scale = np.float64(n_total) / np.float64(prefix[-1])
     teeth = np.minimum(np.ceil(prefix.astype(np.float64) * scale), np.float64(n_total))  # u0 = 0: the upper bound
     lo_b = np.maximum(teeth[:-1] - 1.0, 0.0)  # u0 -> 1
@@ -168,11 +186,6 @@ class TorchComm:
     def __init__(self, rank: int, world: int, always: bool = False):
         """`always`: issue the collectives even in a one-rank group (rehearsal of the N > 1 calls on a one-GPU box)."""
         self.rank, self.world, self.always = rank, world, always
-
-    def all_reduce_max(self, t: torch.Tensor):
-        dist = _dist()
-        if self.world > 1 or self.always:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
 
     def all_gather(self, full: torch.Tensor, lo: int, hi: int):
         if self.world == 1 and not self.always:
@@ -214,13 +227,6 @@ class ThreadComm:
         self.sh.barrier.wait()
         got = list(self.sh.slots)
         return got
-
-    def all_reduce_max(self, t: torch.Tensor):
-        got = self._post(t)
-        red = torch.stack(got).amax(dim=0)
-        self.sh.barrier.wait()  # everyone has read every contribution
-        t.copy_(red)
-        self.sh.barrier.wait()
 
     def all_gather(self, full: torch.Tensor, lo: int, hi: int):
         got = self._post((full, lo, hi))
@@ -264,6 +270,66 @@ class NativeComm:
         h = C.c_void_p()
         ops.lib.call("gjx_comm_init_rccl", C.c_void_p(buf.data_ptr()), rank, world, C.byref(h))
         return NativeComm(ops, h)
+
+    @staticmethod
+    def over_torch(ops: Ops, rank: int, world: int, always: bool = False) -> "NativeComm":
+        """`gjx_comm_init_callbacks`: the native driver with `torch.distributed` as its transport — the all-gather and the
+        grouped send/recv of the process group the program already has (gloo on CPU: how `gjx_smc_sharded_run_*` is
+        tested across REAL processes; nccl = RCCL on GPUs).  The callbacks wrap the raw buffers as byte tensors."""
+        import ctypes as C
+
+        from . import abi
+
+        cuda = ops.device().type == "cuda"
+
+        def view(ptr: int, nbytes: int) -> torch.Tensor:
+            if cuda:
+                class _Dev:  # a device buffer as an array the tensor constructor understands
+                    __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+                return torch.as_tensor(_Dev(), device=ops.device())
+            return torch.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=torch.uint8)
+
+        def allgather(_user, full, nbytes, _s):
+            try:
+                dist = _dist()
+                t = view(full, world * nbytes)
+                local = t[rank * nbytes:(rank + 1) * nbytes]
+                dist.all_gather_into_tensor(t, local if cuda else local.clone())
+                return 0
+            except Exception as ex:  # an exception must not unwind through the C driver
+                print(f"[gjx] all-gather callback failed: {ex!r}", flush=True)
+                return -4
+
+        def exchange(_user, cols, elems, n_cols, sends, ns, recvs, nr, _s):
+            try:
+                dist = _dist()
+                ops_ = []
+                for segs, n, fn in ((sends, ns, dist.isend), (recvs, nr, dist.irecv)):
+                    for i in range(n):
+                        sg = segs[i]
+                        for c in range(n_cols):
+                            el = int(elems[c])
+                            ops_.append(dist.P2POp(fn, view(int(cols[c]) + int(sg.a) * el, (int(sg.b) - int(sg.a)) * el), int(sg.peer)))
+                if ops_:
+                    for w in dist.batch_isend_irecv(ops_):
+                        w.wait()
+                return 0
+            except Exception as ex:
+                print(f"[gjx] exchange callback failed: {ex!r}", flush=True)
+                return -4
+
+        def sync(_user, _s):
+            if cuda:
+                torch.cuda.current_stream().synchronize()
+            return 0
+
+        cbs = (abi.ALLGATHER_FN(allgather), abi.EXCHANGE_FN(exchange), abi.STREAM_SYNC_FN(sync))
+        h = C.c_void_p()
+        ops.lib.call("gjx_comm_init_callbacks", rank, world, cbs[0], cbs[1], cbs[2], None, C.byref(h))
+        nc = NativeComm(ops, h)
+        nc._callbacks = cbs  # the C side keeps the function pointers: keep the Python objects alive as long
+        return nc
 
     @staticmethod
     def local_group(ops: Ops, world: int) -> list:
@@ -316,22 +382,22 @@ class ShardedSMC:
     """Bootstrap SMC (`kind` "lgssm": BASELINE configs[2]/[3]; "hmm": configs[4]) with the population sharded
     over ranks in equal contiguous blocks of whole tiles.
 
-    Per step: (a) resample + propagate + weight the rank's OWN output slots from the global previous
-    population (only the source tiles that feed those slots are read), all-reduce(max) of the tile maxima;
-    (b) exact fixed-point tile masses, all-gather of the masses (8 B per 1024 particles); (c) the ancestor
-    shuffle.  Ancestors are monotone in the output slot, so the sources of a rank's slots are ONE contiguous
-    global range, known to every rank from the tile masses alone (`needed_tile_ranges`):
+    Per step: (a) ONE launch: resample + propagate + weight the rank's OWN output slots from the global previous
+    population (only the source tiles that feed those slots are read), emitting the in-tile CDFs and tile records
+    of the new weights; (b) ONE all-gather of the records (16 B per 1024 particles; no all-reduce: the records are
+    anchored per tile); (c) the ancestor shuffle.  Ancestors are monotone in the output slot, so the
+    sources of a rank's slots are ONE contiguous global range, known to every rank from the records alone
+    (`needed_tile_ranges`):
       exchange="ranges"    each rank receives exactly that range, in place at its global offset, from the few
                            ranks that own a piece of it (grouped send/recv = an all-to-all-v over xGMI without
                            packing or a count exchange); volume ~ the rank's own block, independent of the
-                           number of ranks; costs one device->host read of the tile masses per step;
+                           number of ranks; costs one device->host read of the ranges per step;
       exchange="allgather" every rank receives the whole population (no host sync; volume grows with ranks).
     Either way particles, ancestors and log Z are bit-identical to the single-device filter."""
 
     def __init__(self, ops: Ops, kind: str, impl: int, seed: int, n_total: int, T: int, rank: int, world: int,
                  record_ancestors: bool = False, exchange: str = "ranges", comm=None, poison: bool = False,
-                 n_states=None, lgssm=None, y=None, plan=None, obs=None, ess_threshold: float = 0.0,
-                 tile_sums_form: int = 0):
+                 n_states=None, lgssm=None, y=None, plan=None, obs=None, ess_threshold: float = 0.0):
         """`lgssm` (abi.Lgssm) / `y`: another linear-Gaussian model and observation sequence than the benchmark's.
         kind "plan": a generated filter — `plan` from `ops.smc_plan_create`, `obs` [T, n_obs]."""
         tile = ops.tile
@@ -347,7 +413,7 @@ class ShardedSMC:
         sk, rk = W.smc_key_schedule(prng.key(seed, impl), T)
         # ess_threshold in (0, 1): resample only when ESS < threshold * n_total; every rank takes the same decision
         # from the all-gathered exact ESS sums, and a step that keeps its particles exchanges nothing
-        self.cfg = ops.smc_config(impl, n_total, self.first, self.n_local, sk, rk, ess_threshold, tile_sums_form)
+        self.cfg = ops.smc_config(impl, n_total, self.first, self.n_local, sk, rk, ess_threshold)
         dev = ops.device()
         if kind == "lgssm":
             self.y = W.lgssm_data(T) if y is None else y
@@ -371,15 +437,14 @@ class ShardedSMC:
                                        torch.from_numpy(obs).to(dev).contiguous())
             self.trans_alias, self.obs_logp = ops.hmm_prepare_model(self.model)
             sdt = torch.int32
-        nt = ops.num_tiles(n_total)
         # global-size buffers: a rank's own block is always current, remote ranges are filled on demand
         self.n_cols = plan.n_state if kind == "plan" else 1
-        # state[buffer][column]: the hand-written models have one state column
-        self.state = [[torch.zeros(n_total, dtype=sdt, device=dev) for _ in range(self.n_cols)] for _ in range(2)]
-        self.logw = [torch.zeros(n_total, dtype=torch.float32, device=dev) for _ in range(2)]
-        self.tile_sums = torch.zeros(nt, dtype=torch.int64, device=dev)
-        self.max_partials = torch.empty(nt, dtype=torch.float32, device=dev)
-        self.out_max = torch.empty(T, dtype=torch.float32, device=dev)
+        self.adaptive = bool(self.cfg._adaptive)
+        self.pop = [ops.smc_pop(n_total, [sdt] * self.n_cols, self.adaptive) for _ in range(2)]
+        for p_ in self.pop:
+            for c in [*p_.state, p_.cdf, p_.logw]:
+                c.zero_()
+        self.out_e = torch.empty(T, dtype=torch.int32, device=dev)
         self.out_q = torch.zeros(T, dtype=torch.int64, device=dev)
         self.ancestors = torch.empty((T, self.n_local), dtype=torch.int32, device=dev) if record_ancestors else None
         self.ranges = torch.zeros(2 * world + 1, dtype=torch.int64)  # host memory the device writes (pinned on a GPU box)
@@ -388,41 +453,39 @@ class ShardedSMC:
         self.ranges_np, self.ticket = self.ranges.numpy(), 0
         self.received = 0  # particles received over the run (volume of the shuffle)
 
-    def _step_a(self, t: int, cur: int, prv: int):
-        lo, hi = self.first, self.first + self.n_local
+    def _step(self, t: int, cur: int, prv: int):
         anc = None if self.ancestors is None else self.ancestors[t]
-        weights = (self.logw[prv], self.out_max[t - 1:t], self.tile_sums, self.out_q[t - 1:t]) if t else (None,) * 4
-        own = [c[lo:hi] for c in self.state[cur]]
+        keep_logw = self.adaptive or t == self.T - 1
+        out = self.pop[cur].struct(self.first, with_logw=keep_logw)
+        prev = self.pop[prv].struct() if t else None
+        pe, pq = (self.out_e[t - 1:t], self.out_q[t - 1:t]) if t else (None, None)
         if self.kind == "plan":
-            self.ops.smc_plan_step_a(self.cfg, self.plan, t, self.y[t], self.state[prv] if t else None, *weights, own,
-                                     self.logw[cur][lo:hi], self.max_partials, anc)
-            return
-        prev = ((self.state[prv][0],) + weights) if t else (None,) * 5
-        outs = (own[0], self.logw[cur][lo:hi], self.max_partials, anc)
-        if self.kind == "lgssm":
-            self.ops.smc_lgssm_step_a(self.cfg, self.model, t, float(self.y[t]), *prev, *outs)
+            self.ops.smc_plan_step(self.cfg, self.plan, t, self.y[t], prev, out, pe, pq, anc)
+        elif self.kind == "lgssm":
+            self.ops.smc_lgssm_step(self.cfg, self.model, t, float(self.y[t]), prev, out, pe, pq, anc)
         else:
-            self.ops.smc_hmm_step_a(self.cfg, self.model, t, int(self.y[t]), *prev, self.trans_alias, self.obs_logp, *outs)
+            self.ops.smc_hmm_step(self.cfg, self.model, t, int(self.y[t]), prev, out, self.trans_alias, self.obs_logp, pe, pq, anc)
 
     def _shuffle(self, cur: int):
         """Make the source ranges of the next resampling present on every rank."""
         ops, tile = self.ops, self.ops.tile
         lo, hi = self.first, self.first + self.n_local
-        cols = [*self.state[cur], self.logw[cur]]
+        pop = self.pop[cur]
+        cols = pop.columns()
         if self.poison:  # tests: whatever is not received below must never be read
             for c in cols:
                 keep = c[lo:hi].clone()
-                c.fill_(float("nan") if c.dtype == torch.float32 else 0)
+                c.fill_(float("nan") if c.dtype == torch.float32 else (-1 if c.dtype == torch.int64 else 0))
                 c[lo:hi] = keep
         if self.exchange == "allgather":
             for c in cols:
                 self.comm.all_gather(c, lo, hi)
             self.received += self.n_total - self.n_local
             return
-        # the ranges of all ranks from the tile masses, computed on the device and stored straight into pinned host
+        # the ranges of all ranks from the records, computed on the device and stored straight into pinned host
         # memory with a ticket behind them: the host polls for the ticket instead of synchronising the stream
         self.ticket += 1
-        ops.smc_source_ranges(self.cfg, self.tile_sums, self.world, self.ranges, self.ticket)
+        ops.smc_source_ranges(self.cfg, pop.recs, pop.ess, self.world, self.ranges, self.ticket)
         rh = self.ranges_np
         if self.ranges.is_pinned():
             spins = 0
@@ -447,56 +510,56 @@ class ShardedSMC:
                 self.received += b - a
         self.comm.exchange(cols, sends, recvs)
 
+    def _result(self):
+        ops = self.ops
+        lo, hi = self.first, self.first + self.n_local
+        last = self.pop[(self.T - 1) & 1]
+        final = [c[lo:hi] for c in last.state]
+        return dict(out_e=self.out_e, out_q=self.out_q, state=final[0] if self.n_cols == 1 else final,
+                    logw=last.logw[lo:hi], ancestors=self.ancestors,
+                    log_z=ops.log_z_from_pairs(self.out_e, self.out_q, self.n_total, self.cfg._flags),
+                    resampled=self.cfg._flags, log_z_exact=self.log_z_exact, received=self.received)
+
     def run_native(self, comm: "NativeComm"):
-        """The same filter driven from C (`gjx_smc_sharded_run_*`): the per-step launches, the two small collectives and
-        the ancestor shuffle without the interpreter in between.  Same results as `run()` bit for bit."""
+        """The same filter driven from C (`gjx_smc_sharded_run_*`): the per-step launch, the all-gather of the records
+        and the ancestor shuffle without the interpreter in between.  Same results as `run()` bit for bit."""
         import ctypes as C
+
+        import numpy as np
 
         from . import abi
 
         ops = self.ops
         if self.poison:  # tests: whatever a rank never receives must never be read
-            for b in range(2):
-                for c in [*self.state[b], self.logw[b]]:
+            for p_ in self.pop:
+                for c in p_.columns(with_logw=True):
                     c.fill_(float("nan") if c.dtype == torch.float32 else -1)
         io = abi.ShardedIO()
+        structs = [p_.struct() for p_ in self.pop]
         for b in range(2):
-            for k, c in enumerate(self.state[b]):
-                io.state[b][k] = c.data_ptr()
-            io.logw[b] = self.logw[b].data_ptr()
-        io.tile_sums, io.max_partials = self.tile_sums.data_ptr(), self.max_partials.data_ptr()
-        io.out_max, io.out_q = self.out_max.data_ptr(), self.out_q.data_ptr()
+            io.pop[b] = structs[b]
+        io.out_e, io.out_q = self.out_e.data_ptr(), self.out_q.data_ptr()
         io.ancestors = self.ancestors.data_ptr() if self.ancestors is not None else None
         io.ranges = self.ranges.data_ptr()
         io.shuffle = 0 if self.exchange == "ranges" else 1
         recv = C.c_uint64(0)
         io.received = C.pointer(recv)
-        if self.kind == "lgssm":
-            import numpy as np
-
-            y = np.ascontiguousarray(np.asarray(self.y, dtype=np.float32))
-            ops.lib.call("gjx_smc_sharded_run_lgssm", comm.handle, C.byref(self.cfg), C.byref(self.model), C.c_void_p(y.ctypes.data),
-                         C.byref(io), ops.stream())
-        elif self.kind == "hmm":
-            import numpy as np
-
-            y = np.ascontiguousarray(np.asarray(self.y, dtype=np.int32))
-            ops.lib.call("gjx_smc_sharded_run_hmm", comm.handle, C.byref(self.cfg), C.byref(self.model), C.c_void_p(y.ctypes.data),
-                         ops._p(self.trans_alias), ops._p(self.obs_logp), C.byref(io), ops.stream())
-        else:
-            import numpy as np
-
-            y = np.ascontiguousarray(np.asarray(self.y, dtype=np.float32))
-            ops.lib.call("gjx_smc_sharded_run_plan", comm.handle, C.byref(self.cfg), self.plan.handle,
-                         C.c_void_p(y.ctypes.data) if y.size else None, C.byref(io), ops.stream())
-        self.received = int(recv.value)
-        lo, hi = self.first, self.first + self.n_local
-        last = (self.T - 1) & 1
-        final = [c[lo:hi] for c in self.state[last]]
-        return dict(out_max=self.out_max, out_q=self.out_q, state=final[0] if self.n_cols == 1 else final,
-                    logw=self.logw[last][lo:hi], ancestors=self.ancestors,
-                    log_z=ops.log_z_from_pairs(self.out_max, self.out_q, self.n_total, self.cfg._flags),
-                    resampled=self.cfg._flags, log_z_exact=self.log_z_exact, received=self.received)
+        try:
+            if self.kind == "lgssm":
+                y = np.ascontiguousarray(np.asarray(self.y, dtype=np.float32))
+                ops.lib.call("gjx_smc_sharded_run_lgssm", comm.handle, C.byref(self.cfg), C.byref(self.model),
+                             C.c_void_p(y.ctypes.data), C.byref(io), ops.stream())
+            elif self.kind == "hmm":
+                y = np.ascontiguousarray(np.asarray(self.y, dtype=np.int32))
+                ops.lib.call("gjx_smc_sharded_run_hmm", comm.handle, C.byref(self.cfg), C.byref(self.model),
+                             C.c_void_p(y.ctypes.data), ops._p(self.trans_alias), ops._p(self.obs_logp), C.byref(io), ops.stream())
+            else:
+                y = np.ascontiguousarray(np.asarray(self.y, dtype=np.float32))
+                ops.lib.call("gjx_smc_sharded_run_plan", comm.handle, C.byref(self.cfg), self.plan.handle,
+                             C.c_void_p(y.ctypes.data) if y.size else None, C.byref(io), ops.stream())
+        finally:
+            self.received = int(recv.value)
+        return self._result()
 
     def run(self):
         ops = self.ops
@@ -504,21 +567,15 @@ class ShardedSMC:
         tl, th = lo // ops.tile, hi // ops.tile
         for t in range(self.T):
             cur, prv = t & 1, (t & 1) ^ 1
-            self._step_a(t, cur, prv)
-            self.comm.all_reduce_max(self.max_partials)
-            ops.smc_step_b(self.cfg, self.logw[cur][lo:hi], self.max_partials, self.out_max[t:t + 1], self.tile_sums)
-            self.comm.all_gather(self.tile_sums, tl, th)
-            if self.cfg._tile_ess is not None:
-                self.comm.all_gather(self.cfg._tile_ess, 2 * tl, 2 * th)
+            self._step(t, cur, prv)
+            pop = self.pop[cur]
+            self.comm.all_gather(pop.recs, tl, th)
+            if pop.ess is not None:
+                self.comm.all_gather(pop.ess, 2 * tl, 2 * th)
             if t + 1 < self.T:
                 self._shuffle(cur)
-        ops.smc_finish(self.cfg, self.tile_sums, self.out_q[self.T - 1:self.T])
-        last = (self.T - 1) & 1
-        final = [c[lo:hi] for c in self.state[last]]
-        return dict(out_max=self.out_max, out_q=self.out_q, state=final[0] if self.n_cols == 1 else final,
-                    logw=self.logw[last][lo:hi], ancestors=self.ancestors,
-                    log_z=ops.log_z_from_pairs(self.out_max, self.out_q, self.n_total, self.cfg._flags),
-                    resampled=self.cfg._flags, log_z_exact=self.log_z_exact, received=self.received)
+        ops.smc_finish(self.cfg, self.pop[(self.T - 1) & 1].recs, self.out_e[self.T - 1:self.T], self.out_q[self.T - 1:self.T])
+        return self._result()
 
 
 def ShardedLgssmSMC(ops: Ops, impl: int, seed: int, n_total: int, T: int, rank: int, world: int,

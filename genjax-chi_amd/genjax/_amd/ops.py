@@ -354,16 +354,32 @@ class Ops:
         return out
 
     def resample(self, kind: str, kb: KeyBatch, logw: torch.Tensor, n_out: int | None = None):
-        """-> (ancestors int32[n_out], max f32[1], q i64[1])."""
+        """-> (ancestors int32[n_out], anchor, q i64[1]): systematic — tile-anchored weights, anchor = the merged
+        power-of-two exponent e int32[1] (lse = e ln 2 + log(q 2^-30)); multinomial — anchor = max f32[1]
+        (lse = max + log(q 2^-frac_bits(n)))."""
         n = logw.numel()
         n_out = n if n_out is None else n_out
         anc = self.empty(n_out, torch.int32)
-        m, q = self.empty(1, torch.float32), self.empty(1, torch.int64)
+        m, q = self.empty(1, torch.int32 if kind == "systematic" else torch.float32), self.empty(1, torch.int64)
         ws, nb = self.workspace(abi.OP_RESAMPLE, max(n, n_out))
         self.lib.call(f"gjx_resample_{kind}", C.byref(self._keys(kb, 1)), self._chk(logw, torch.float32, n), n,
                       n_out, C.c_void_p(anc.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(q.data_ptr()),
                       C.c_void_p(ws.data_ptr()), nb, self.stream())
         return anc, m, q
+
+    def tile_cdf(self, x: torch.Tensor):
+        """-> (cdf int64[n], recs int64[tiles, 2]): the in-tile CDFs and tile records (gjx_tile_rec: word 0 = S_t,
+        low half of word 1 = e_t) of arbitrary log-weights."""
+        n = x.numel()
+        cdf, recs = self.empty(n, torch.int64), self.empty((self.num_tiles(n), 2), torch.int64)
+        self.lib.call("gjx_tile_cdf", self._chk(x, torch.float32, n), n, self._p(cdf), self._p(recs), self.stream())
+        return cdf, recs
+
+    def tile_merge(self, recs: torch.Tensor):
+        """-> (e int32[1], q int64[1]): merged anchor and total mass of tile records."""
+        e, q = self.empty(1, torch.int32), self.empty(1, torch.int64)
+        self.lib.call("gjx_tile_merge", self._p(recs), recs.shape[0], self._p(e), self._p(q), self.stream())
+        return e, q
 
     def gather_cols(self, ancestors: torch.Tensor, cols: list[torch.Tensor]) -> list[torch.Tensor]:
         n_out = ancestors.numel()
@@ -381,8 +397,7 @@ class Ops:
         return outs
 
     # ---- fused SMC --------------------------------------------------------------------------------
-    def _smc_cfg(self, impl, n_total, first, n_local, step_keys, resample_keys, ess_threshold: float = 0.0,
-                 tile_sums_form: int = 0):
+    def _smc_cfg(self, impl, n_total, first, n_local, step_keys, resample_keys, ess_threshold: float = 0.0):
         """`step_keys` / `resample_keys`: [T, 2] for one filter, [F, T, 2] for F filters stepping in the same
         launches (gjx_smc_config.n_filters).  `ess_threshold` in (0, 1): ESS-adaptive resampling — the config then
         carries a device int32[T] / [F, T] `cfg._flags` (1 where a step began with a resampling)."""
@@ -400,7 +415,6 @@ class Ops:
         cfg._keep = (sk, rk)  # keep host arrays alive
         cfg._filters = F
         cfg.ess_threshold = float(ess_threshold)
-        cfg.tile_sums_form = int(tile_sums_form)
         cfg._adaptive = 0.0 < float(ess_threshold) < 1.0
         cfg._flags = None
         if cfg._adaptive:
@@ -412,48 +426,48 @@ class Ops:
         """Outputs of a whole-run call: one filter -> [T], [n]; F filters -> [F, T], [F, stride] (views [:, :n])."""
         F, T = cfg._filters, cfg.n_steps
         if F == 1:
-            return (self.empty(T, torch.float32), self.empty(T, torch.int64), self.empty(n, state_dtype),
+            return (self.empty(T, torch.int32), self.empty(T, torch.int64), self.empty(n, state_dtype),
                     self.empty(n, torch.float32), self.empty((T, n), torch.int32) if want_ancestors else None,
                     self.workspace(abi.OP_SMC, n))
         stride = cfg.filter_stride
         ws_one = int(self.lib.call("gjx_workspace_bytes", abi.OP_SMC, n))
         ws = torch.empty(F * ws_one, dtype=torch.uint8, device=self._alloc_device)  # (per call: see workspace())
-        return (self.empty((F, T), torch.float32), self.empty((F, T), torch.int64), self.empty((F, stride), state_dtype),
+        return (self.empty((F, T), torch.int32), self.empty((F, T), torch.int64), self.empty((F, stride), state_dtype),
                 self.empty((F, stride), torch.float32),
                 self.empty((T, F, stride), torch.int32) if want_ancestors else None, (ws, F * ws_one))
 
     def smc_run_lgssm(self, impl, n, step_keys, resample_keys, model: abi.Lgssm, y, want_ancestors=False,
-                      ess_threshold: float = 0.0, tile_sums_form: int = 0, want_flags: bool = False):
-        """-> (out_max, out_q, state, logw, ancestors[, resampled flags or None])."""
+                      ess_threshold: float = 0.0, want_flags: bool = False):
+        """-> (out_e, out_q, state, logw, ancestors[, resampled flags or None])."""
         import numpy as np
 
-        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys, ess_threshold, tile_sums_form)
+        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys, ess_threshold)
         yh = np.ascontiguousarray(np.asarray(y, dtype=np.float32))
         assert yh.size == cfg.n_steps
-        out_max, out_q, state, logw, anc, (ws, nb) = self._smc_buffers(cfg, n, torch.float32, want_ancestors)
+        out_e, out_q, state, logw, anc, (ws, nb) = self._smc_buffers(cfg, n, torch.float32, want_ancestors)
         self.lib.call("gjx_smc_run_lgssm", C.byref(cfg), C.byref(model), C.c_void_p(yh.ctypes.data),
-                      C.c_void_p(out_max.data_ptr()), C.c_void_p(out_q.data_ptr()), C.c_void_p(state.data_ptr()),
+                      C.c_void_p(out_e.data_ptr()), C.c_void_p(out_q.data_ptr()), C.c_void_p(state.data_ptr()),
                       C.c_void_p(logw.data_ptr()), C.c_void_p(anc.data_ptr()) if anc is not None else None,
                       C.c_void_p(ws.data_ptr()), nb, self.stream())
-        return (out_max, out_q, state, logw, anc, cfg._flags) if want_flags else (out_max, out_q, state, logw, anc)
+        return (out_e, out_q, state, logw, anc, cfg._flags) if want_flags else (out_e, out_q, state, logw, anc)
 
     def smc_run_hmm(self, impl, n, step_keys, resample_keys, n_states, init_state, trans_logits, obs_logits, y,
-                    want_ancestors=False, ess_threshold: float = 0.0, tile_sums_form: int = 0, want_flags: bool = False):
+                    want_ancestors=False, ess_threshold: float = 0.0, want_flags: bool = False):
         import numpy as np
 
-        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys, ess_threshold, tile_sums_form)
+        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys, ess_threshold)
         yh = np.ascontiguousarray(np.asarray(y, dtype=np.int32))
         assert yh.size == cfg.n_steps
         mdl = abi.Hmm()
         mdl.n_states, mdl.init_state = n_states, init_state
         mdl.trans_logits = self._chk(trans_logits, torch.float32, n_states * n_states).value
         mdl.obs_logits = self._chk(obs_logits, torch.float32, n_states * n_states).value
-        out_max, out_q, state, logw, anc, (ws, nb) = self._smc_buffers(cfg, n, torch.int32, want_ancestors)
+        out_e, out_q, state, logw, anc, (ws, nb) = self._smc_buffers(cfg, n, torch.int32, want_ancestors)
         self.lib.call("gjx_smc_run_hmm", C.byref(cfg), C.byref(mdl), C.c_void_p(yh.ctypes.data),
-                      C.c_void_p(out_max.data_ptr()), C.c_void_p(out_q.data_ptr()), C.c_void_p(state.data_ptr()),
+                      C.c_void_p(out_e.data_ptr()), C.c_void_p(out_q.data_ptr()), C.c_void_p(state.data_ptr()),
                       C.c_void_p(logw.data_ptr()), C.c_void_p(anc.data_ptr()) if anc is not None else None,
                       C.c_void_p(ws.data_ptr()), nb, self.stream())
-        return (out_max, out_q, state, logw, anc, cfg._flags) if want_flags else (out_max, out_q, state, logw, anc)
+        return (out_e, out_q, state, logw, anc, cfg._flags) if want_flags else (out_e, out_q, state, logw, anc)
 
     def hmm_model(self, n_states: int, init_state: int, trans_logits: torch.Tensor, obs_logits: torch.Tensor) -> abi.Hmm:
         mdl = abi.Hmm()
@@ -556,98 +570,122 @@ class Ops:
         return out
 
     def smc_run_plan(self, plan: "SmcPlan", impl, n, step_keys, resample_keys, obs, want_ancestors=False,
-                     ess_threshold: float = 0.0, tile_sums_form: int = 0, want_flags: bool = False):
-        """`step_keys` / `resample_keys` [T, 2]: one filter -> (max [T], q [T], state columns [n], logw [n], ancestors
+                     ess_threshold: float = 0.0, want_flags: bool = False):
+        """`step_keys` / `resample_keys` [T, 2]: one filter -> (e [T], q [T], state columns [n], logw [n], ancestors
         [T, n]); [F, T, 2]: F filters (same observations, own keys) stepping in the same launches -> ([F, T], [F, T],
         columns [F, stride], [F, stride], [T, F, stride]), filter f equal to its own single run bit for bit."""
         import numpy as np
 
-        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys, ess_threshold, tile_sums_form)
+        cfg = self._smc_cfg(impl, n, 0, n, step_keys, resample_keys, ess_threshold)
         T, F = cfg.n_steps, cfg._filters
         oh = np.ascontiguousarray(np.asarray(obs, dtype=np.float32).reshape(T, max(plan.n_obs, 1))[:, :plan.n_obs])
         stride = cfg.filter_stride if F > 1 else n
         shape = (lambda *tail: (F, *tail)) if F > 1 else (lambda *tail: tail)
-        out_max, out_q = self.empty(shape(T), torch.float32), self.empty(shape(T), torch.int64)
+        out_e, out_q = self.empty(shape(T), torch.int32), self.empty(shape(T), torch.int64)
         states = [self.empty(shape(stride), torch.float32) for _ in range(plan.n_state)]
         sp = (C.c_void_p * plan.n_state)(*[t.data_ptr() for t in states])
         logw = self.empty(shape(stride), torch.float32)
         anc = self.empty((T, F, stride) if F > 1 else (T, n), torch.int32) if want_ancestors else None
-        ws, nb = self.workspace(abi.OP_SMC, F * stride * (plan.n_state + 1))
+        ws, nb = self.workspace(abi.OP_SMC, F * stride)
         self.lib.call("gjx_smc_run_plan", C.byref(cfg), plan.handle, C.c_void_p(oh.ctypes.data) if plan.n_obs else None,
-                      self._p(out_max), self._p(out_q), sp, self._p(logw), self._p(anc), C.c_void_p(ws.data_ptr()), nb,
+                      self._p(out_e), self._p(out_q), sp, self._p(logw), self._p(anc), C.c_void_p(ws.data_ptr()), nb,
                       self.stream())
-        return (out_max, out_q, states, logw, anc, cfg._flags) if want_flags else (out_max, out_q, states, logw, anc)
+        return (out_e, out_q, states, logw, anc, cfg._flags) if want_flags else (out_e, out_q, states, logw, anc)
 
     # ---- step-level SMC pieces (multi-device driver: dist.py) -----------------------------------
-    def smc_config(self, impl, n_total, first, n_local, step_keys, resample_keys, ess_threshold: float = 0.0,
-                   tile_sums_form: int = 0):
-        """Step-level config.  Adaptive filters (`ess_threshold` in (0, 1)) also get `cfg._tile_ess`, the GLOBAL
-        int64[2 * tiles] array of ESS sums step B fills and step A / source_ranges read (ranks all-gather it)."""
-        cfg = self._smc_cfg(impl, n_total, first, n_local, step_keys, resample_keys, ess_threshold, tile_sums_form)
-        cfg._tile_ess = None
-        if cfg._adaptive:
-            cfg._tile_ess = torch.zeros(2 * self.num_tiles(n_total), dtype=torch.int64, device=self.device())
-            cfg.tile_ess = cfg._tile_ess.data_ptr()
-        return cfg
+    def smc_config(self, impl, n_total, first, n_local, step_keys, resample_keys, ess_threshold: float = 0.0):
+        """Step-level config (one filter)."""
+        return self._smc_cfg(impl, n_total, first, n_local, step_keys, resample_keys, ess_threshold)
 
     @staticmethod
     def _p(t):
         return None if t is None else C.c_void_p(t.data_ptr())
 
-    def smc_lgssm_step_a(self, cfg, model: abi.Lgssm, t: int, y_t: float, prev_state, prev_logw, prev_max,
-                         prev_tile_sums, prev_q_out, state_out, logw_out, max_partials_out, ancestors_out=None):
-        self.lib.call("gjx_smc_lgssm_step_a", C.byref(cfg), C.byref(model), t, float(y_t), self._p(prev_state),
-                      self._p(prev_logw), self._p(prev_max), self._p(prev_tile_sums), self._p(prev_q_out),
-                      self._p(state_out), self._p(logw_out), self._p(max_partials_out), self._p(ancestors_out),
-                      self.stream())
+    def smc_pop(self, n_total: int, state_dtypes: list, adaptive: bool, want_logw: bool = True) -> "SmcPopulation":
+        """A GLOBAL-size population (gjx_smc_pop): state columns, in-tile CDF, log-weights, tile records, ESS sums."""
+        return SmcPopulation(self, n_total, state_dtypes, adaptive, want_logw)
 
-    def smc_hmm_step_a(self, cfg, model: abi.Hmm, t: int, y_t: int, prev_state, prev_logw, prev_max, prev_tile_sums,
-                       prev_q_out, trans_alias, obs_logp, state_out, logw_out, max_partials_out, ancestors_out=None):
-        self.lib.call("gjx_smc_hmm_step_a", C.byref(cfg), C.byref(model), t, int(y_t), self._p(prev_state),
-                      self._p(prev_logw), self._p(prev_max), self._p(prev_tile_sums), self._p(prev_q_out),
-                      self._p(trans_alias), self._p(obs_logp), self._p(state_out), self._p(logw_out),
-                      self._p(max_partials_out), self._p(ancestors_out), self.stream())
+    def smc_lgssm_step(self, cfg, model: abi.Lgssm, t: int, y_t: float, prev, out, prev_e_out=None, prev_q_out=None,
+                       ancestors_out=None):
+        """`prev` / `out`: abi.SmcPop structs (SmcPopulation.struct(): `out` offset to the rank's own block)."""
+        self.lib.call("gjx_smc_lgssm_step", C.byref(cfg), C.byref(model), t, float(y_t),
+                      C.byref(prev) if prev is not None else None, C.byref(out), self._p(prev_e_out), self._p(prev_q_out),
+                      self._p(ancestors_out), self.stream())
 
-    def smc_plan_step_a(self, cfg, plan: "SmcPlan", t: int, obs_t, prev_state, prev_logw, prev_max, prev_tile_sums,
-                        prev_q_out, state_out, logw_out, max_partials_out, ancestors_out=None):
-        """Step A of a plan-driven filter: `prev_state` / `state_out` are lists of the n_state columns (global-size
-        / this rank's slots); `obs_t` the step's observation constants."""
+    def smc_hmm_step(self, cfg, model: abi.Hmm, t: int, y_t: int, prev, out, trans_alias, obs_logp, prev_e_out=None,
+                     prev_q_out=None, ancestors_out=None):
+        self.lib.call("gjx_smc_hmm_step", C.byref(cfg), C.byref(model), t, int(y_t),
+                      C.byref(prev) if prev is not None else None, C.byref(out), self._p(prev_e_out), self._p(prev_q_out),
+                      self._p(trans_alias), self._p(obs_logp), self._p(ancestors_out), self.stream())
+
+    def smc_plan_step(self, cfg, plan: "SmcPlan", t: int, obs_t, prev, out, prev_e_out=None, prev_q_out=None,
+                      ancestors_out=None):
+        """One step of a plan-driven filter; `obs_t` the step's observation constants."""
         import numpy as np
 
         oh = np.ascontiguousarray(np.asarray(obs_t, dtype=np.float32).reshape(-1)[:plan.n_obs])
-        pp = (C.c_void_p * plan.n_state)(*[c.data_ptr() for c in prev_state]) if prev_state is not None else None
-        sp = (C.c_void_p * plan.n_state)(*[c.data_ptr() for c in state_out])
-        self.lib.call("gjx_smc_plan_step_a", C.byref(cfg), plan.handle, t, C.c_void_p(oh.ctypes.data) if plan.n_obs else None,
-                      pp, self._p(prev_logw), self._p(prev_max), self._p(prev_tile_sums), self._p(prev_q_out), sp,
-                      self._p(logw_out), self._p(max_partials_out), self._p(ancestors_out), self.stream())
+        self.lib.call("gjx_smc_plan_step", C.byref(cfg), plan.handle, t, C.c_void_p(oh.ctypes.data) if plan.n_obs else None,
+                      C.byref(prev) if prev is not None else None, C.byref(out), self._p(prev_e_out), self._p(prev_q_out),
+                      self._p(ancestors_out), self.stream())
 
-    def smc_step_b(self, cfg, logw_local, max_partials, max_out, tile_sums):
-        self.lib.call("gjx_smc_step_b", C.byref(cfg), self._p(logw_local), self._p(max_partials), self._p(max_out),
-                      self._p(tile_sums), self.stream())
+    def smc_finish(self, cfg, recs, e_out, q_out):
+        self.lib.call("gjx_smc_finish", C.byref(cfg), self._p(recs), self._p(e_out), self._p(q_out), self.stream())
 
-    def smc_finish(self, cfg, tile_sums, q_out):
-        self.lib.call("gjx_smc_finish", C.byref(cfg), self._p(tile_sums), self._p(q_out), self.stream())
-
-    def smc_source_ranges(self, cfg, tile_sums, world: int, out_ranges, ticket: int = 0):
+    def smc_source_ranges(self, cfg, recs, ess, world: int, out_ranges, ticket: int = 0):
         """out_ranges int64[2 world + 1]: the source tiles each of `world` equal output blocks can draw from, then
         the ticket (stored last; a pinned host buffer can be polled for it)."""
-        self.lib.call("gjx_smc_source_ranges", C.byref(cfg), self._p(tile_sums), int(world), int(ticket),
+        self.lib.call("gjx_smc_source_ranges", C.byref(cfg), self._p(recs), self._p(ess), int(world), int(ticket),
                       self._p(out_ranges), self.stream())
 
-    def log_z_from_pairs(self, out_max: torch.Tensor, out_q: torch.Tensor, n_total: int, resampled=None) -> float:
-        """log Z = sum_t (max_t + log(q_t 2^-frac) - log N), evaluated in float64 on the host from the exact
-        per-step (max, fixed-point sum) pairs.  `resampled` (int32[T], ESS-adaptive filters): the sum runs over the
-        steps that END an epoch of accumulated weights — a resampling follows (resampled[t + 1] == 1) or t = T - 1."""
-        frac = self.frac_bits(n_total)
-        m = out_max.detach().cpu().double()
+    def log_z_from_pairs(self, out_e: torch.Tensor, out_q: torch.Tensor, n_total: int, resampled=None) -> float:
+        """log Z = sum_t (e_t ln 2 + log(q_t 2^-30) - log N), evaluated in float64 on the host from the exact
+        per-step (merged anchor, fixed-point sum) pairs.  `resampled` (int32[T], ESS-adaptive filters):
+        the sum runs over the steps that END an epoch of accumulated weights — a resampling follows (resampled[t + 1]
+        == 1) or t = T - 1."""
+        e = out_e.detach().cpu().double()
         q = out_q.detach().cpu().double()
-        terms = m + torch.log(q) - frac * math.log(2.0) - math.log(n_total)
+        terms = (e - abi.TILE_FRAC) * math.log(2.0) + torch.log(q) - math.log(n_total)
         if resampled is not None:
             r = resampled.detach().cpu().bool()
             ends = torch.ones_like(r)
             ends[:-1] = r[1:]
             terms = terms[ends]
         return float(terms.sum())
+
+
+class SmcPopulation:
+    """Device buffers of one population of a step-level (sharded) filter, all GLOBAL size (gjx.h gjx_smc_pop)."""
+
+    def __init__(self, ops: "Ops", n_total: int, state_dtypes: list, adaptive: bool, want_logw: bool = True):
+        self.ops, self.n, self.adaptive = ops, n_total, adaptive
+        nt = ops.num_tiles(n_total)
+        self.state = [ops.empty(n_total, dt) for dt in state_dtypes]
+        self.cdf = ops.empty(n_total, torch.int64)
+        self.logw = ops.empty(n_total, torch.float32) if (want_logw or adaptive) else None
+        self.recs = torch.zeros((nt, 2), dtype=torch.int64, device=ops.device())
+        self.ess = torch.zeros(2 * nt, dtype=torch.int64, device=ops.device()) if adaptive else None
+        self.prefix = ops.empty(nt + 4, torch.int64) if nt > 1024 else None
+
+    def columns(self, with_logw: bool | None = None) -> list[torch.Tensor]:
+        """The per-particle columns an ancestor shuffle moves: state, in-tile CDF (and log-weights when adaptive)."""
+        cols = list(self.state) + [self.cdf]
+        if self.adaptive if with_logw is None else with_logw:
+            cols.append(self.logw)
+        return cols
+
+    def struct(self, first: int = 0, with_logw: bool = True) -> abi.SmcPop:
+        """abi.SmcPop: per-particle arrays start at slot `first` (a rank's own block for the population a step WRITES;
+        0 for the one it READS); records / ESS sums are always the global arrays."""
+        p = abi.SmcPop()
+        for k, c in enumerate(self.state):
+            p.state[k] = c.data_ptr() + first * 4
+        p.cdf = self.cdf.data_ptr() + first * 8
+        p.logw = (self.logw.data_ptr() + first * 4) if (self.logw is not None and with_logw) else None
+        p.recs = self.recs.data_ptr()
+        p.ess = self.ess.data_ptr() if self.ess is not None else None
+        p.prefix = self.prefix.data_ptr() if self.prefix is not None else None
+        p._keep = self
+        return p
 
 
 class SmcPlan:

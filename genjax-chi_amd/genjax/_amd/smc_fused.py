@@ -42,7 +42,7 @@ class DiscreteHMM:
 @dataclass
 class SMCResult:
     log_marginal_likelihood: float  # float64 from the exact per-step (max, fixed-point sum) pairs
-    step_max: torch.Tensor  # f32[T]
+    step_e: torch.Tensor  # int32[T]: per-step merged anchor e_t (lse_t = e_t ln 2 + log(q_t 2^-30))
     step_q: torch.Tensor  # i64[T]
     particles: torch.Tensor  # final-step particles [n] (a tuple of columns for a multi-component carry)
     log_weights: torch.Tensor  # their incremental log-weights [n]
@@ -111,8 +111,8 @@ class BootstrapSMC:
             out = (om, oq, states[0] if self._n_state == 1 else tuple(states), logw, anc, fl)
         else:
             raise TypeError(f"no fused SMC kernel for {type(self.model).__name__}")
-        step_max, step_q, state, logw, anc, flags = out
-        return SMCResult(ops.log_z_from_pairs(step_max, step_q, self.n, flags), step_max, step_q, state, logw, anc, flags)
+        step_e, step_q, state, logw, anc, flags = out
+        return SMCResult(ops.log_z_from_pairs(step_e, step_q, self.n, flags), step_e, step_q, state, logw, anc, flags)
 
     def run_many(self, keys) -> list:
         """`vmap(self.run)(keys)`: one independent filter per key.  Up to 16 filters step in the same kernel launches
@@ -165,10 +165,10 @@ class BootstrapSMC:
             ol = torch.as_tensor(m.obs_logits, dtype=torch.float32).to(dev).contiguous()
             res = ops.smc_run_hmm(impl, self.n, sk, rk, int(tl.shape[0]), int(m.init_state), tl, ol,
                                   self.observations.astype(np.int32), self.record_ancestors, **ess)
-        step_max, step_q, state, logw, anc, fl = res
+        step_e, step_q, state, logw, anc, fl = res
         for f in range(len(chunk)):
             ff = None if fl is None else fl[f]
-            out.append(SMCResult(ops.log_z_from_pairs(step_max[f], step_q[f], self.n, ff), step_max[f], step_q[f],
+            out.append(SMCResult(ops.log_z_from_pairs(step_e[f], step_q[f], self.n, ff), step_e[f], step_q[f],
                                  state[f, :self.n], logw[f, :self.n], None if anc is None else anc[:, f, :self.n], ff))
         return out
 

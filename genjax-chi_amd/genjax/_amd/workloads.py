@@ -174,14 +174,14 @@ def filter_key_schedules(seed: int, impl: int, T: int, filters: int):
 
 
 def smc_result(ops: Ops, out, n: int, filters: int, log_z_exact: float):
-    out_max, out_q, state, logw, anc = out[:5]
+    out_e, out_q, state, logw, anc = out[:5]
     flags = out[5] if len(out) > 5 else None  # ESS-adaptive filters: 1 where a step began with a resampling
     if filters == 1:
-        return dict(out_max=out_max, out_q=out_q, state=state, logw=logw, ancestors=anc, resampled=flags,
-                    log_z=ops.log_z_from_pairs(out_max, out_q, n, flags), log_z_exact=log_z_exact)
-    return dict(out_max=out_max, out_q=out_q, state=state[:, :n], logw=logw[:, :n],
+        return dict(out_e=out_e, out_q=out_q, state=state, logw=logw, ancestors=anc, resampled=flags,
+                    log_z=ops.log_z_from_pairs(out_e, out_q, n, flags), log_z_exact=log_z_exact)
+    return dict(out_e=out_e, out_q=out_q, state=state[:, :n], logw=logw[:, :n],
                 ancestors=None if anc is None else anc[:, :, :n], resampled=flags,
-                log_z=[ops.log_z_from_pairs(out_max[f], out_q[f], n, None if flags is None else flags[f]) for f in range(filters)],
+                log_z=[ops.log_z_from_pairs(out_e[f], out_q[f], n, None if flags is None else flags[f]) for f in range(filters)],
                 log_z_exact=log_z_exact)
 
 
@@ -190,11 +190,11 @@ class LgssmSMC:
     `run()` is only the enqueue of the fused filter (2 kernels per step, no host sync)."""
 
     def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, want_ancestors: bool = False, filters: int = 1,
-                 ess_threshold: float = 0.0, tile_sums_form: int = 0, y=None, model=None):
+                 ess_threshold: float = 0.0, y=None, model=None):
         """`filters` > 1: that many independent filters (seeds seed, seed+1, ...) step in the same launches.
         `ess_threshold` in (0, 1): resample only when ESS < threshold * n (gjx_smc_config)."""
         self.ops, self.impl, self.n, self.T, self.want_ancestors, self.filters = ops, impl, n, T, want_ancestors, filters
-        self.ess, self.form = ess_threshold, tile_sums_form
+        self.ess = ess_threshold
         self.y = lgssm_data(T) if y is None else np.asarray(y, dtype=np.float32)
         self.sk, self.rk = filter_key_schedules(seed, impl, T, filters)
         self.model = lgssm_model() if model is None else model
@@ -202,7 +202,7 @@ class LgssmSMC:
 
     def run(self):
         return self.ops.smc_run_lgssm(self.impl, self.n, self.sk, self.rk, self.model, self.y, self.want_ancestors,
-                                      ess_threshold=self.ess, tile_sums_form=self.form, want_flags=True)
+                                      ess_threshold=self.ess, want_flags=True)
 
     def result(self, out):
         return smc_result(self.ops, out, self.n, self.filters, self.log_z_exact)
@@ -376,10 +376,10 @@ class HmmSMC:
     """Reusable state of the C5 workload (tables resident on the device, data and keys prepared)."""
 
     def __init__(self, ops: Ops, impl: int, seed: int, n: int, T: int, n_states=None, want_ancestors: bool = False,
-                 filters: int = 1, ess_threshold: float = 0.0, tile_sums_form: int = 0):
+                 filters: int = 1, ess_threshold: float = 0.0):
         trans, obs = hmm_tables(n_states)
         self.ops, self.impl, self.n, self.T, self.want_ancestors, self.filters = ops, impl, n, T, want_ancestors, filters
-        self.ess, self.form = ess_threshold, tile_sums_form
+        self.ess = ess_threshold
         self.k = trans.shape[0]
         self.init = HMM["init_state"] % self.k
         self.y = hmm_data(T, n_states)
@@ -391,7 +391,7 @@ class HmmSMC:
 
     def run(self):
         return self.ops.smc_run_hmm(self.impl, self.n, self.sk, self.rk, self.k, self.init, self.tl, self.ol, self.y,
-                                    self.want_ancestors, ess_threshold=self.ess, tile_sums_form=self.form, want_flags=True)
+                                    self.want_ancestors, ess_threshold=self.ess, want_flags=True)
 
     def result(self, out):
         return smc_result(self.ops, out, self.n, self.filters, self.log_z_exact)

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define GJX_VERSION_MAJOR 0
-#define GJX_VERSION_MINOR 6
+#define GJX_VERSION_MINOR 7
 
 typedef void* gjx_stream; /* hipStream_t; ignored by the oracle build */
 
@@ -375,12 +375,35 @@ int gjx_logsumexp_f32(const float* x, uint64_t n, const float* max_partials_in, 
 int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, int64_t* out_idx,
                           int mode, void* ws, size_t ws_bytes, gjx_stream s);
 
+/* Tile-anchored weights: what a resampling reads.  Tile t = particles [1024 t, 1024 t + 1024):
+ * e_t = ceil(max_t x * log2 e) (the row anchor of 3.5b on a tile), q_i = rint(exp(x_i - e_t ln 2) * 2^30), the
+ * IN-TILE CDF c_i = sum of q over the tile's particles up to and including i (u64 per particle), and the tile's
+ * record (e_t, S_t = c_last).  Everything is known to the workgroup that produces the tile's log-weights — no
+ * grid-wide maximum — so the kernel that propagates a population emits it, and a bootstrap step is ONE launch.
+ * Records merge exactly: e = max e_t, d_t = e - e_t, M_t = S_t >> d_t (0 from d_t = 64), P_t = sum_{t' < t} M_t',
+ * Q = sum_t M_t; the GLOBAL fixed-point CDF is C_i = P_t + (c_i >> d_t); lse = e ln 2 + log(Q 2^-30). */
+typedef struct {
+  uint64_t s; /* S_t */
+  int32_t e;  /* e_t; GJX_TILE_EMPTY: the tile carries no mass */
+  int32_t pad;
+} gjx_tile_rec;
+#define GJX_TILE_EMPTY (-(1 << 30))
+#define GJX_TILE_FRAC 30
+/* cdf dev u64[n], recs dev gjx_tile_rec[gjx_num_tiles(n)] of arbitrary log-weights x (one pass). */
+int gjx_tile_cdf(const float* x, uint64_t n, uint64_t* cdf, gjx_tile_rec* recs, gjx_stream s);
+/* out_e[0], out_q[0] = the merged anchor and total mass of `recs` (each nullable). */
+int gjx_tile_merge(const gjx_tile_rec* recs, uint64_t n_tiles, int32_t* out_e, uint64_t* out_q, gjx_stream s);
+
 /* ancestors[j], j < n_out: systematic (one 64-bit uniform, monotone ancestors) or multinomial
- * (n_out iid draws) resampling from softmax(logw).  out_max/out_q receive the (max, fixed-point
- * sum) pair of logw.  NOT in the reference library (docs idiom
+ * (n_out iid draws) resampling from softmax(logw).
+ * Systematic: tile-anchored weights (above): u0 = top 53 bits of the key's 64-bit draw; teeth below particle i:
+ * n_i = clamp(ceil(f64(C_i) * (n_out / f64(Q)) - u0), 0, n_out), the last particle closes at n_out;
+ * ancestors[j] = min{i : n_i > j}.  out_e / out_q (nullable): merged anchor and total mass of logw.
+ * Multinomial: max-anchored weights (§3.5); out_max / out_q: the (max, fixed-point sum) pair of logw.
+ * NOT in the reference library (docs idiom
  * docs/cookbook/inactive/inference/importance_sampling.ipynb cell 16). */
 int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, uint64_t n_out,
-                            int32_t* ancestors, float* out_max, uint64_t* out_q, void* ws,
+                            int32_t* ancestors, int32_t* out_e, uint64_t* out_q, void* ws,
                             size_t ws_bytes, gjx_stream s);
 int gjx_resample_multinomial(const gjx_keys* key, const float* logw, uint64_t n, uint64_t n_out,
                              int32_t* ancestors, float* out_max, uint64_t* out_q, void* ws,
@@ -393,7 +416,7 @@ int gjx_gather_cols(const int32_t* ancestors, uint64_t n_out, const void* const*
                     void* const* dst_cols, int n_cols, gjx_stream s);
 
 /* ---- fused bootstrap SMC for the benchmark state-space models ------------------------------ *
- * One call enqueues the whole T-step filter (2 kernels per step) on the stream, no host sync.
+ * One call enqueues the whole T-step filter — ONE kernel per step — on the stream, no host sync.
  * Particle slot j (global index) of step t draws ONE 32-bit word.  THREEFRY: the first
  * single-word draw of the slot key split(step_keys[t], *)[j] (site counter 1), normals by erfinv.  PHILOX: step
  * keys are lane-0 keys and slots 4g .. 4g+3 share the block PH(ctr = (g_lo, g_hi, 0, 'Q'), key = step key), slot j
@@ -430,7 +453,7 @@ typedef struct {
    * over keys; whole-run calls gjx_smc_run_lgssm / gjx_smc_run_hmm on one device only; <= 16).  0 or 1: one
    * filter.  With F = n_filters > 1: step_keys / resample_keys are host u32[F,T,2]; filter f's particles lie
    * f * filter_stride further in state_out / logw_out (dev [F, filter_stride], filter_stride =
-   * gjx_num_tiles(n_total) * gjx_smc_tile()), its results in out_max / out_q dev [F, T], its ancestors in
+   * gjx_num_tiles(n_total) * gjx_smc_tile()), its results in out_e / out_q dev [F, T], its ancestors in
    * ancestors_out dev int32[T, F, filter_stride] (indices within the filter); the workspace is F times
    * gjx_workspace_bytes(GJX_OP_SMC, n).  A 1e6-particle step is ~1000 workgroups, under one round of an
    * MI355X: a few filters per launch fill it.  Each filter equals its own single run bit for bit. */
@@ -441,79 +464,76 @@ typedef struct {
    * population of step t-1 is resampled only if its effective sample size is below ess_threshold * n_total;
    * otherwise every particle keeps its own ancestor (ancestors[t][j] = j), and its log-weight ACCUMULATES:
    * logw_t[j] = logw_{t-1}[j] + increment.  ESS is evaluated on exact integers so that every backend, tiling and
-   * number of ranks takes the same decision: r_i = q_i >> (frac - 16) (q_i the fixed-point weight),
-   * R1 = sum r_i, R2 = sum r_i^2, resample iff (double)R1 * (double)R1 < (ess_threshold * n_total) * (double)R2.
+   * number of ranks takes the same decision: per tile r_i = q_i >> 14 (the top 16 bits of the tile-anchored weight),
+   * R1_t = sum r_i, R2_t = sum r_i^2; merged R1 = sum_t R1_t >> d_t, R2 = sum_t R2_t >> 2 d_t;
+   * resample iff (double)R1 * (double)R1 < (ess_threshold * n_total) * (double)R2.
    * log Z = sum over the steps t that END an epoch (a resampling follows, or t = T-1) of
-   * (max_t + log(q_t 2^-frac) - log N): the per-step (out_max, out_q) pairs are those of the accumulated weights.
+   * (e_t ln 2 + log(q_t 2^-30) - log N): the per-step (out_e, out_q) pairs are those of the accumulated weights.
    * resampled_out: nullable dev int32[T] ([F, T] for F filters): entry t = 1 if step t began with a resampling
    * (entry 0 is 0).  Required (non-NULL) when ess_threshold is in (0, 1). */
   float ess_threshold;
   int32_t* resampled_out;
-  /* Per-step pieces of an adaptive filter (the whole-run calls carve it from their workspace): GLOBAL array dev
-   * u64[2 gjx_num_tiles(n_total)]; step B leaves the sums R1_b, R2_b of its tiles in entries 2 b, 2 b + 1 (ranks
-   * all-gather it like tile_sums) and step A of the next step decides from it. */
-  uint64_t* tile_ess;
-  /* Tuning / test knob: form of the tile-mass kernel.  0 = by launch size (a wave per tile from 4096 tiles per
-   * launch, a workgroup per tile below), 1 = a workgroup per tile, 2 = a wave per tile.  Same bits either way. */
-  int32_t tile_sums_form;
 } gjx_smc_config;
+
+/* A population between two steps: what a step reads of the previous one and writes for the next. */
+#define GJX_SMC_MAX_STATE 4
+#define GJX_SMC_MAX_OBS 8
+typedef struct {
+  void* state[GJX_SMC_MAX_STATE]; /* 4-byte columns (f32 x / int32 z) */
+  uint64_t* cdf;                  /* in-tile CDF of the weights (gjx_tile_rec above) */
+  float* logw;                    /* log-weights: nullable unless the filter is ESS-adaptive */
+  gjx_tile_rec* recs;             /* GLOBAL dev [gjx_num_tiles(n_total)]: the tiles' records */
+  uint64_t* ess;                  /* GLOBAL dev u64[2 gjx_num_tiles(n_total)] (R1_t, R2_t): adaptive filters only */
+  uint64_t* prefix;               /* scratch dev u64[gjx_num_tiles(n_total) + 4]: required only when the population READ by a
+                                     step has more than 1024 tiles (n_total > 2^20) — the step then merges its records
+                                     into this array with one extra small launch instead of in every workgroup */
+} gjx_smc_pop;
 
 /* Single-device whole run (first_slot = 0, n_local = n_total).  y: HOST array [T] (f32 for lgssm,
  * int32 for hmm) — observations are baked into the launches.
- * Outputs: out_max dev f32[T], out_q dev u64[T] (per-step (max, fixed-point sum) of the
- * incremental log-weights => log Z = sum_t (max_t + log(q_t 2^-frac) - log N), frac =
- * gjx_frac_bits(n_total)); state_out dev [n] final-step particles (f32 x / int32 z) and logw_out
- * dev f32[n] their weights (before the final resampling); ancestors_out dev int32[T,n] or NULL
- * (row 0 is the identity). */
+ * Outputs: out_e dev int32[T], out_q dev u64[T] (per-step merged anchor and total mass of the
+ * incremental log-weights => log Z = sum_t (e_t ln 2 + log(q_t 2^-30) - log N)); state_out dev [n] final-step
+ * particles (f32 x / int32 z) and logw_out dev f32[n] their weights (before the final resampling);
+ * ancestors_out dev int32[T,n] or NULL (row 0 is the identity). */
 int gjx_smc_run_lgssm(const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y_host,
-                      float* out_max, uint64_t* out_q, float* state_out, float* logw_out,
+                      int32_t* out_e, uint64_t* out_q, float* state_out, float* logw_out,
                       int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s);
 int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32_t* y_host,
-                    float* out_max, uint64_t* out_q, int32_t* state_out, float* logw_out,
+                    int32_t* out_e, uint64_t* out_q, int32_t* state_out, float* logw_out,
                     int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s);
 
-/* Per-step pieces (the whole-run calls are loops over these; the multi-device driver runs the
- * RCCL exchange between them).  All "global" arrays are indexed by global slot / global tile.
- *  step A (t): for every slot j in [first_slot, first_slot+n_local): systematic-resampling
- *    ancestor from the GLOBAL previous population (prev_state / prev_logw dev [n_total], prev_max
- *    dev f32[1], prev_tile_sums dev u64[gjx_num_tiles(n_total)]), propagate, weight.  Writes
- *    state_out / logw_out / ancestors_out (nullable) dev [n_local] and max_partials_out dev
- *    f32[gjx_num_tiles(n_total)]: max over that array == max of the local new log-weights
- *    (-inf entries for work this rank did not own, so ranks combine it with all-reduce(max)).
- *    prev_q_out (nullable dev u64[1]) receives sum(prev_tile_sums).  t == 0 ignores prev_*.
- *    Only the source tiles that own one of the rank's slots are read (gjx_smc_source_ranges).
- *  step B: max_out[0] = max(max_partials) and tile_sums[first_slot/tile + b] = fixed-point mass
- *    of local tile b under that max (tile_sums is the GLOBAL array; ranks all-gather it).
- *  finish: q_out[0] = sum(tile_sums) (the last step's total). */
-int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* model, int t, float y_t,
-                         const float* prev_state, const float* prev_logw, const float* prev_max,
-                         const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* state_out,
-                         float* logw_out, float* max_partials_out, int32_t* ancestors_out,
-                         gjx_stream s);
-int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* model, int t, int32_t y_t,
-                       const int32_t* prev_state, const float* prev_logw, const float* prev_max,
-                       const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
-                       const uint32_t* trans_alias /* dev, from gjx_hmm_prepare */,
-                       const float* obs_logp /* dev f32[K,K] from gjx_hmm_prepare */,
-                       int32_t* state_out, float* logw_out, float* max_partials_out,
+/* One step as ONE launch (the whole-run calls are loops over these; the multi-device driver runs the
+ * exchange between them).  step (t): for every slot j in [first_slot, first_slot+n_local): systematic-resampling
+ * ancestor from the GLOBAL previous population `prev` (state / cdf / logw dev [n_total], recs / ess GLOBAL), propagate,
+ * weight; writes `out`: state / cdf / logw (nullable) dev [n_local] — LOCAL arrays, slot j at j - first_slot — and the
+ * records (and ESS sums) of the rank's own tiles into the GLOBAL arrays out->recs / out->ess (at the global tile
+ * index; out->recs must not alias prev->recs: ranks all-gather it).  prev_e_out / prev_q_out (nullable dev [1]):
+ * the merged anchor and total mass of prev's weights.  ancestors_out nullable dev int32[n_local].  t == 0 ignores
+ * prev.  Only the source tiles that own one of the rank's slots are read (gjx_smc_source_ranges).
+ *  finish: e_out[0], q_out[0] = merged anchor / total mass of the last step's records. */
+int gjx_smc_lgssm_step(const gjx_smc_config* cfg, const gjx_lgssm* model, int t, float y_t,
+                       const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* prev_e_out, uint64_t* prev_q_out,
                        int32_t* ancestors_out, gjx_stream s);
-int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const float* max_partials,
-                   float* max_out, uint64_t* tile_sums, gjx_stream s);
-
-int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
+int gjx_smc_hmm_step(const gjx_smc_config* cfg, const gjx_hmm* model, int t, int32_t y_t,
+                     const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* prev_e_out, uint64_t* prev_q_out,
+                     const uint32_t* trans_alias /* dev, from gjx_hmm_prepare */,
+                     const float* obs_logp /* dev f32[K,K] from gjx_hmm_prepare */,
+                     int32_t* ancestors_out, gjx_stream s);
+int gjx_smc_finish(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int32_t* e_out, uint64_t* q_out,
                    gjx_stream s);
-/* A rank with n_local < n_total reads, in step A, ONLY the source tiles that own one of its slots (which tiles
- * those are follows from prev_tile_sums and the comb offset alone), so between steps it needs just that part
+/* A rank with n_local < n_total reads, in a step, ONLY the source tiles that own one of its slots (which tiles
+ * those are follows from the records and the comb offset alone), so between steps it needs just that part
  * of the other ranks' particles.  source_ranges: for each of `world` equal contiguous blocks of output slots
  * (block j = slots [j n_total/world, (j+1) n_total/world)), out_ranges[2j], [2j+1] = the half-open range of
  * source tiles that can own a slot of the block at the next resampling — the exact range or one tile more at
  * either end (the comb offset is bounded, not derived, so the ranges of a step are known before its key is
- * used).  Ancestors are monotone in the slot, hence one contiguous range per block.  out_ranges:
+ * used).  Ancestors are monotone in the slot, hence one contiguous range per block.  ess: the population's ESS sums
+ * (adaptive filters; a kept step needs no exchange: identity ranges).  out_ranges:
  * int64[2 world + 1], device memory or device-visible pinned host memory; out_ranges[2 world] = ticket is
  * stored LAST with a system-scope release, so a host that owns a pinned buffer can poll for its ticket and
  * read the ranges without synchronising the stream.  world <= 64 and n_total a multiple of world. */
-int gjx_smc_source_ranges(const gjx_smc_config* cfg, const uint64_t* tile_sums, int world, int64_t ticket,
-                          int64_t* out_ranges, gjx_stream s);
+int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, const uint64_t* ess, int world,
+                          int64_t ticket, int64_t* out_ranges, gjx_stream s);
 /* ---- bootstrap SMC for a user model: init sites + step sites as plans ------------------------ *
  * The general form of the two fixed models above: x_0 comes from `init_sites`, every later step
  * walks `step_sites` for each output slot with GJX_ARG_STATE arguments reading the resampled
@@ -525,8 +545,6 @@ int gjx_smc_source_ranges(const gjx_smc_config* cfg, const uint64_t* tile_sums, 
  * -> 4g+2, 4g+3) — the fixed models above are the case of one sampled site; multi-word samplers (gamma,
  * beta, Gumbel-max categorical) keep the slot key's streams.  libgjx_hip.so lowers the step to a hiprtc-compiled policy
  * inside the fused resample kernel.  State columns are f32 (integer-valued sites are converted). */
-#define GJX_SMC_MAX_STATE 4
-#define GJX_SMC_MAX_OBS 8
 typedef struct {
   const gjx_site* init_sites;
   int32_t n_init_sites;
@@ -545,15 +563,14 @@ int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl); /* offline hipr
  * particles); other outputs as gjx_smc_run_lgssm, gjx_smc_config.n_filters included (F filters of the same
  * model and observations with their own keys step in the same launches: every state column dev f32[F, stride]).
  * Single device (first_slot 0, n_local n_total). */
-/* Step A of a plan-driven filter (the per-step piece for a multi-device driver, like gjx_smc_lgssm_step_a; steps
- * B / finish / source ranges are the model-independent calls above): obs_t host f32[n_obs]; prev_state host array
- * of n_state dev f32[n_total] (GLOBAL arrays), state_out host array of n_state dev f32[n_local]. */
-int gjx_smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, const float* obs_t,
-                        const float* const* prev_state, const float* prev_logw, const float* prev_max,
-                        const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* const* state_out,
-                        float* logw_out, float* max_partials_out, int32_t* ancestors_out, gjx_stream s);
+/* One step of a plan-driven filter as ONE launch (the per-step piece for a multi-device driver, like
+ * gjx_smc_lgssm_step; finish / source ranges are the model-independent calls above): obs_t host f32[n_obs]; the
+ * populations' state columns are the plan's n_state f32 columns. */
+int gjx_smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, const float* obs_t,
+                      const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* prev_e_out, uint64_t* prev_q_out,
+                      int32_t* ancestors_out, gjx_stream s);
 int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host,
-                     float* out_max, uint64_t* out_q, float* const* state_out, float* logw_out,
+                     int32_t* out_e, uint64_t* out_q, float* const* state_out, float* logw_out,
                      int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s);
 
 /* ---- importance over a `Scan` (state-space) model: the whole T-step walk in ONE launch --------- *
@@ -612,6 +629,22 @@ int gjx_comm_init_rccl(const void* id /*host*/, int rank, int world, gjx_comm** 
 int gjx_comm_group_create(int world, gjx_comm_group** out);
 int gjx_comm_group_destroy(gjx_comm_group* g);
 int gjx_comm_init_local(gjx_comm_group* g, int rank, gjx_comm** out);
+/*   callbacks (both builds): the collectives are the CALLER's — the all-gather and the grouped send/recv of whatever
+ *         process group the host program already has (torch.distributed over gloo or RCCL, MPI, ...), so the native driver
+ *         runs across REAL processes on any transport; this is how gjx_smc_sharded_run_* is tested with world_size-2/4
+ *         gloo process groups on CPU.  allgather: in place, rank r's block is full + r * bytes_per_rank.  exchange: element
+ *         ranges [a, b) of every column keep their global position on both sides (column c at cols[c] + a * elem_bytes[c]);
+ *         both sides list the same ranges.  Callbacks return 0 or a negative gjx status. */
+typedef struct {
+  int32_t peer;
+  uint64_t a, b;
+} gjx_seg;
+typedef int (*gjx_allgather_fn)(void* user, void* full, uint64_t bytes_per_rank, gjx_stream s);
+typedef int (*gjx_exchange_fn)(void* user, void* const* cols, const uint64_t* elem_bytes, int32_t n_cols, const gjx_seg* sends,
+                               int32_t n_sends, const gjx_seg* recvs, int32_t n_recvs, gjx_stream s);
+typedef int (*gjx_stream_sync_fn)(void* user, gjx_stream s);
+int gjx_comm_init_callbacks(int rank, int world, gjx_allgather_fn allgather, gjx_exchange_fn exchange,
+                            gjx_stream_sync_fn stream_sync, void* user, gjx_comm** out);
 int gjx_comm_destroy(gjx_comm* c);
 int gjx_comm_rank(const gjx_comm* c);
 int gjx_comm_world(const gjx_comm* c);
@@ -621,24 +654,21 @@ int gjx_comm_world(const gjx_comm* c);
  * and gjx_lse_combine give every rank the same (e, q, lse) per pass — the bits of ONE fold over all rows. */
 int gjx_comm_lse_combine(gjx_comm* c, const uint64_t* records, int32_t n_batch, uint64_t* gathered, int32_t* out_e,
                          uint64_t* out_q, float* out_lse, gjx_stream s);
-/* The whole bootstrap filter sharded over the communicator's ranks (BASELINE configs[3]): the per-step sequence
- * step A (own slots) -> all-reduce(max) of the tile maxima -> step B -> all-gather of the tile masses (and ESS sums) ->
- * ancestor shuffle, driven from C: no interpreter between the launches.  cfg: first_slot / n_local = this rank's block
- * (n_total a multiple of world * gjx_smc_tile()), one filter.  All arrays are GLOBAL-size device buffers the caller
- * owns (a rank's own block is always current; remote ranges are filled by the shuffle):
- *   state[2][n_state] dev 4-byte [n_total] (double-buffered), logw[2] dev f32[n_total], tile_sums dev u64[tiles],
- *   max_partials dev f32[tiles], out_max dev f32[T], out_q dev u64[T], ancestors nullable dev int32[T, n_local],
+/* The whole bootstrap filter sharded over the communicator's ranks (BASELINE configs[3]): per step ONE launch (own
+ * slots) -> ONE all-gather of the tile records (and ESS sums) -> ancestor shuffle, driven from C: no interpreter
+ * between the launches.  cfg: first_slot / n_local = this rank's block (n_total a multiple of world * gjx_smc_tile()),
+ * one filter.  All arrays are GLOBAL-size device buffers the caller owns (a rank's own block is always current; remote
+ * ranges are filled by the shuffle): pop[2] (double-buffered: state columns dev 4-byte [n_total], cdf dev u64[n_total],
+ * logw dev f32[n_total], recs dev gjx_tile_rec[tiles], ess dev u64[2 tiles] for adaptive filters),
+ * out_e dev int32[T], out_q dev u64[T], ancestors nullable dev int32[T, n_local],
  *   ranges int64[2 world + 1] device-visible PINNED host memory (plain host memory in the oracle build).
  * shuffle 0 = by source ranges (each rank receives exactly the contiguous range its slots draw from, in place, by
  * grouped send/recv; the host polls the range kernel's ticket in `ranges`), 1 = all-gather of the population.
- * *received (nullable): particles this rank received over the run.  Results equal the single-device filter bit for
- * bit for every world size. */
+ * *received (nullable): particles this rank received over the run (written on every exit path).  Results equal the
+ * single-device filter bit for bit for every world size. */
 typedef struct {
-  void* state[2][GJX_SMC_MAX_STATE];
-  float* logw[2];
-  uint64_t* tile_sums;
-  float* max_partials;
-  float* out_max;
+  gjx_smc_pop pop[2];
+  int32_t* out_e;
   uint64_t* out_q;
   int32_t* ancestors;
   int64_t* ranges;

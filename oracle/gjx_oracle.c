@@ -786,6 +786,82 @@ int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, 
   return GJX_OK;
 }
 
+/* ---- tile-anchored weights (gjx.h gjx_tile_rec) ---------------------------------- *
+ * Sequential restatement: per tile of 1024 particles the maximum (the sequential `x > m ? x : m`, a NaN is skipped),
+ * its power-of-two anchor, the fixed-point weights, their running sum (the in-tile CDF), the ESS sums. */
+#define O_ESS_SHIFT (O_ROW_FRAC - 16)
+static void tile_emit(const float* lw, uint64_t cnt, uint64_t* cdf, gjx_tile_rec* rec, uint64_t* ess2) {
+  float m = -INFINITY;
+  for (uint64_t i = 0; i < cnt; ++i) m = lw[i] > m ? lw[i] : m;
+  const int32_t e = o_row_anchor(m);
+  uint64_t run = 0, r1 = 0, r2 = 0;
+  for (uint64_t i = 0; i < cnt; ++i) {
+    const uint64_t q = o_rowfix(lw[i], e);
+    run += q;
+    cdf[i] = run;
+    const uint64_t r = q >> O_ESS_SHIFT;
+    r1 += r;
+    r2 += r * r;
+  }
+  rec->s = run;
+  rec->e = e;
+  rec->pad = 0;
+  if (ess2) { ess2[0] = r1; ess2[1] = r2; }
+}
+int gjx_tile_cdf(const float* x, uint64_t n, uint64_t* cdf, gjx_tile_rec* recs, gjx_stream s) {
+  (void)s;
+  if (!x || !cdf || !recs || n == 0) return GJX_ERR_INVALID;
+  const uint64_t nt = gjx_num_tiles(n);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < (int64_t)nt; ++b) {
+    const uint64_t lo = (uint64_t)b * O_TILE, cnt = lo + O_TILE <= n ? O_TILE : n - lo;
+    tile_emit(x + lo, cnt, cdf + lo, &recs[b], NULL);
+  }
+  return GJX_OK;
+}
+/* The merge of a population's records: anchor, every tile's shift, the exclusive prefix of the shifted masses. */
+typedef struct {
+  int32_t e;
+  uint64_t Q, R1, R2;
+  uint64_t* pre; /* [nt + 1] */
+  uint8_t* d;    /* [nt]: 64 = the tile carries no mass */
+} merged;
+static inline uint64_t shr64(uint64_t v, int d) { return d >= 64 ? 0 : v >> d; }
+static int merge_records(const gjx_tile_rec* recs, const uint64_t* ess, uint64_t nt, merged* m) {
+  m->pre = (uint64_t*)malloc(sizeof(uint64_t) * (nt + 1));
+  m->d = (uint8_t*)malloc(nt ? nt : 1);
+  if (!m->pre || !m->d) { free(m->pre); free(m->d); return GJX_ERR_LAUNCH; }
+  int32_t e = O_ROW_EMPTY;
+  for (uint64_t b = 0; b < nt; ++b) e = recs[b].e > e ? recs[b].e : e;
+  uint64_t run = 0, r1 = 0, r2 = 0;
+  for (uint64_t b = 0; b < nt; ++b) {
+    int d = 64;
+    if (recs[b].e != O_ROW_EMPTY) {
+      const int64_t dd = (int64_t)e - (int64_t)recs[b].e;
+      d = dd > 63 ? 64 : (int)dd;
+    }
+    m->d[b] = (uint8_t)d;
+    m->pre[b] = run;
+    run += shr64(recs[b].s, d);
+    if (ess) { r1 += shr64(ess[2 * b], d); r2 += shr64(ess[2 * b + 1], 2 * d); }
+  }
+  m->pre[nt] = run;
+  m->e = e; m->Q = run; m->R1 = r1; m->R2 = r2;
+  return GJX_OK;
+}
+static void merged_free(merged* m) { free(m->pre); free(m->d); }
+int gjx_tile_merge(const gjx_tile_rec* recs, uint64_t n_tiles, int32_t* out_e, uint64_t* out_q, gjx_stream s) {
+  (void)s;
+  if (!recs || n_tiles == 0) return GJX_ERR_INVALID;
+  merged m;
+  int rc = merge_records(recs, NULL, n_tiles, &m);
+  if (rc) return rc;
+  if (out_e) *out_e = m.e;
+  if (out_q) *out_q = m.Q;
+  merged_free(&m);
+  return GJX_OK;
+}
+
 /* Number of comb teeth (j + u0), j in [0, n_out), strictly below normalised mass P = C*scale. */
 static inline int64_t teeth_below(uint64_t C, double scale, double u0, int64_t n_out) {
   double P = (double)C * scale;
@@ -796,30 +872,62 @@ static inline int64_t teeth_below(uint64_t C, double scale, double u0, int64_t n
 }
 static inline double u0_from_bits(uint64_t U) { return (double)(U >> 11) * 0x1.0p-53; }
 
+/* Ancestors of the slots [lo, hi) of an n_out-tooth comb over n particles: particle i of tile b has the global CDF
+ * value C_i = pre[b] + (cdf[i] >> d[b]); teeth below it n_i = teeth_below(C_i), the last particle closes at n_out;
+ * slot j takes the first particle with n_i > j.  Tiles whose slots (known from the merged records alone) all lie
+ * outside [lo, hi) are skipped without reading their CDF: a rank of a sharded filter holds only the source ranges it
+ * needs. */
+static void systematic_ancestors(const uint64_t* cdf, uint64_t n, const merged* m, uint64_t nt, uint64_t n_out_u,
+                                 double u0, int64_t lo, int64_t hi, int32_t* anc /* [hi - lo] */) {
+  const int64_t n_out = (int64_t)n_out_u;
+  if (m->Q == 0) { /* no mass at all: the population is kept — slot j takes particle floor(j n / n_out) */
+    const double ratio = (double)n / (double)n_out_u;
+    for (int64_t j = lo; j < hi; ++j) {
+      const uint64_t g = (uint64_t)floor((double)j * ratio);
+      anc[j - lo] = (int32_t)(g < n ? g : n - 1);
+    }
+    return;
+  }
+  const double scale = (double)n_out_u / (double)m->Q;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int64_t bb = 0; bb < (int64_t)nt; ++bb) {
+    const uint64_t b = (uint64_t)bb;
+    const int64_t t_lo = teeth_below(m->pre[b], scale, u0, n_out);
+    const int64_t t_hi = b + 1 == nt ? n_out : teeth_below(m->pre[b + 1], scale, u0, n_out);
+    if (t_hi <= lo || t_lo >= hi) continue;
+    int64_t prev = t_lo;
+    const uint64_t i1 = (b + 1) * O_TILE < n ? (b + 1) * O_TILE : n;
+    for (uint64_t i = b * O_TILE; i < i1; ++i) {
+      const uint64_t C = m->pre[b] + shr64(cdf[i], m->d[b]);
+      const int64_t ni = (i == n - 1) ? n_out : teeth_below(C, scale, u0, n_out);
+      const int64_t a = prev > lo ? prev : lo, e = ni < hi ? ni : hi;
+      for (int64_t j = a; j < e; ++j) anc[j - lo] = (int32_t)i;
+      if (ni > prev) prev = ni;
+    }
+  }
+}
+
 int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, uint64_t n_out,
-                            int32_t* ancestors, float* out_max, uint64_t* out_q, void* ws,
+                            int32_t* ancestors, int32_t* out_e, uint64_t* out_q, void* ws,
                             size_t ws_bytes, gjx_stream s) {
   (void)ws; (void)ws_bytes; (void)s;
   if (!keys_ok(key) || !logw || !ancestors || n == 0 || n_out == 0) return GJX_ERR_INVALID;
-  float m = -INFINITY;
-  for (uint64_t i = 0; i < n; ++i) m = logw[i] > m ? logw[i] : m;
-  int frac = o_frac_bits(n);
-  uint64_t Q = 0;
-  for (uint64_t i = 0; i < n; ++i) Q += o_fixw(logw[i], m, frac);
-  o_stream st = stream_at(key, 0);
-  double u0 = u0_from_bits(o_bits64_at(&st, 0));
-  double scale = (double)n_out / (double)Q;
-  uint64_t C = 0;
-  int64_t prev = 0;
-  for (uint64_t i = 0; i < n; ++i) {
-    C += o_fixw(logw[i], m, frac);
-    int64_t ni = (i == n - 1) ? (int64_t)n_out : teeth_below(C, scale, u0, (int64_t)n_out);
-    for (int64_t j = prev; j < ni; ++j) ancestors[j] = (int32_t)i;
-    if (ni > prev) prev = ni;
+  const uint64_t nt = gjx_num_tiles(n);
+  uint64_t* cdf = (uint64_t*)malloc(sizeof(uint64_t) * n);
+  gjx_tile_rec* recs = (gjx_tile_rec*)malloc(sizeof(gjx_tile_rec) * nt);
+  merged m;
+  int rc = (cdf && recs) ? gjx_tile_cdf(logw, n, cdf, recs, NULL) : GJX_ERR_LAUNCH;
+  if (!rc) rc = merge_records(recs, NULL, nt, &m);
+  if (!rc) {
+    o_stream st = stream_at(key, 0);
+    const double u0 = u0_from_bits(o_bits64_at(&st, 0));
+    systematic_ancestors(cdf, n, &m, nt, n_out, u0, 0, (int64_t)n_out, ancestors);
+    if (out_e) *out_e = m.e;
+    if (out_q) *out_q = m.Q;
+    merged_free(&m);
   }
-  if (out_max) *out_max = m;
-  if (out_q) *out_q = Q;
-  return GJX_OK;
+  free(cdf); free(recs);
+  return rc;
 }
 
 int gjx_resample_multinomial(const gjx_keys* key, const float* logw, uint64_t n, uint64_t n_out,
@@ -868,215 +976,183 @@ int gjx_gather_cols(const int32_t* ancestors, uint64_t n_out, const void* const*
 static int cfg_ok(const gjx_smc_config* c) {
   return c && (c->impl == 0 || c->impl == 1) && c->n_total > 0 && c->n_local > 0 &&
          c->first_slot + c->n_local <= c->n_total && c->n_steps > 0 && c->step_keys &&
-         c->resample_keys && (c->first_slot % O_TILE) == 0 && !(c->ess_threshold < 0.0f) &&
-         c->tile_sums_form >= 0 && c->tile_sums_form <= 2;
+         c->resample_keys && (c->first_slot % O_TILE) == 0 && !(c->ess_threshold < 0.0f);
 }
 /* ESS-adaptive resampling (gjx.h: gjx_smc_config.ess_threshold).  The decision is a function of exact integer sums
  * and three double operations, so every backend and every sharding takes the same one. */
 static int cfg_adaptive(const gjx_smc_config* c) { return c->ess_threshold > 0.0f && c->ess_threshold < 1.0f; }
-static inline uint64_t ess_r(uint64_t q, int frac) { return q >> (frac - 16); }
 static int ess_says_resample(uint64_t r1, uint64_t r2, double thr) {
   if (!(thr > 0.0) || r2 == 0) return 1;
   const double a = (double)r1 * (double)r1;
   const double b = thr * (double)r2;
   return a < b;
 }
-/* Does step t (>= 1) begin with a resampling of the population of step t - 1? */
-static int smc_resamples(const gjx_smc_config* cfg) {
-  if (!cfg_adaptive(cfg)) return 1;
-  uint64_t r1 = 0, r2 = 0;
-  for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) { r1 += cfg->tile_ess[2 * b]; r2 += cfg->tile_ess[2 * b + 1]; }
-  return ess_says_resample(r1, r2, (double)cfg->ess_threshold * (double)cfg->n_total);
+static int pop_ok(const gjx_smc_pop* p, int n_state, int adaptive) {
+  if (!p || !p->cdf || !p->recs) return 0;
+  for (int k = 0; k < n_state; ++k)
+    if (!p->state[k]) return 0;
+  return !adaptive || (p->logw && p->ess);
 }
 
-/* Ancestors of slots [lo, hi) by systematic resampling of the GLOBAL previous population.  Source tiles
-   whose slots (known from the exact tile masses alone) all lie outside [lo, hi) are skipped without reading
-   their particles: a rank of a sharded filter holds only the source ranges it needs. */
-static void smc_ancestors(const gjx_smc_config* cfg, int t, const float* prev_logw, float m,
-                          const uint64_t* tile_sums, uint64_t Q, int32_t* anc /* [n_local] */) {
-  const uint64_t N = cfg->n_total;
-  const int frac = o_frac_bits(N);
-  const int64_t lo = (int64_t)cfg->first_slot, hi = lo + (int64_t)cfg->n_local;
-  const uint32_t rkey[4] = {cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1], 0u, 0u};
-  o_stream st = o_stream_make(cfg->impl, rkey, 0, 0);
-  double u0 = u0_from_bits(o_bits64_at(&st, 0));
-  double scale = (double)N / (double)Q;
-  const uint64_t nt = gjx_num_tiles(N);
-  /* tiles are independent given the exclusive prefix of their (exact) masses: one tile per loop iteration */
-  uint64_t* prefix = (uint64_t*)malloc(sizeof(uint64_t) * (nt + 1));
-  if (!prefix) return;
-  prefix[0] = 0;
-  for (uint64_t b = 0; b < nt; ++b) prefix[b + 1] = prefix[b] + tile_sums[b];
-#pragma omp parallel for schedule(dynamic, 8)
-  for (int64_t bb = 0; bb < (int64_t)nt; ++bb) {
-    const uint64_t b = (uint64_t)bb;
-    uint64_t C = prefix[b];
-    const int64_t t_lo = teeth_below(C, scale, u0, (int64_t)N);
-    const int64_t t_hi = b + 1 == nt ? (int64_t)N : teeth_below(prefix[b + 1], scale, u0, (int64_t)N);
-    if (t_hi <= lo || t_lo >= hi) continue;
-    int64_t prev = t_lo;
-    const uint64_t i1 = (b + 1) * O_TILE < N ? (b + 1) * O_TILE : N;
-    for (uint64_t i = b * O_TILE; i < i1; ++i) {
-      C += o_fixw(prev_logw[i], m, frac);
-      int64_t ni = (i == N - 1) ? (int64_t)N : teeth_below(C, scale, u0, (int64_t)N);
-      int64_t a = prev > lo ? prev : lo, e = ni < hi ? ni : hi;
-      for (int64_t j = a; j < e; ++j) anc[j - lo] = (int32_t)i;
-      if (ni > prev) prev = ni;
-    }
-  }
-  free(prefix);
-}
-
-int gjx_smc_step_b(const gjx_smc_config* cfg, const float* logw_local, const float* max_partials,
-                   float* max_out, uint64_t* tile_sums, gjx_stream s) {
-  (void)s;
-  if (!cfg_ok(cfg) || !logw_local || !max_partials || !max_out || !tile_sums) return GJX_ERR_INVALID;
-  const int frac = o_frac_bits(cfg->n_total);
-  float m = -INFINITY;
-  for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) m = max_partials[b] > m ? max_partials[b] : m;
-  *max_out = m;
-  const uint64_t tile0 = cfg->first_slot / O_TILE;
-  const uint64_t ntile = gjx_num_tiles(cfg->n_local);
-  if (cfg_adaptive(cfg) && !cfg->tile_ess) return GJX_ERR_INVALID;
-#pragma omp parallel for schedule(static)
-  for (int64_t b = 0; b < (int64_t)ntile; ++b) {
-    uint64_t acc = 0, a1 = 0, a2 = 0;
-    uint64_t e = ((uint64_t)b + 1) * O_TILE;
-    if (e > cfg->n_local) e = cfg->n_local;
-    for (uint64_t i = (uint64_t)b * O_TILE; i < e; ++i) {
-      const uint64_t q = o_fixw(logw_local[i], m, frac);
-      acc += q;
-      const uint64_t r = ess_r(q, frac);
-      a1 += r;
-      a2 += r * r;
-    }
-    tile_sums[tile0 + (uint64_t)b] = acc;
-    if (cfg_adaptive(cfg)) { cfg->tile_ess[2 * (tile0 + (uint64_t)b)] = a1; cfg->tile_ess[2 * (tile0 + (uint64_t)b) + 1] = a2; }
-  }
-  return GJX_OK;
-}
-
-int gjx_smc_finish(const gjx_smc_config* cfg, const uint64_t* tile_sums, uint64_t* q_out,
-                   gjx_stream s) {
-  (void)s;
-  if (!cfg_ok(cfg) || !tile_sums || !q_out) return GJX_ERR_INVALID;
-  uint64_t Q = 0;
-  for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) Q += tile_sums[b];
-  *q_out = Q;
-  return GJX_OK;
+int gjx_smc_finish(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int32_t* e_out, uint64_t* q_out, gjx_stream s) {
+  if (!cfg_ok(cfg) || !recs || cfg->n_filters > 1) return GJX_ERR_INVALID;
+  return gjx_tile_merge(recs, gjx_num_tiles(cfg->n_total), e_out, q_out, s);
 }
 
 /* Source-tile ranges of `world` equal blocks of output slots: tile b can own slots in [ceil(P_b) - 1,
    ceil(P_{b+1})) for some comb offset u0 in [0, 1) (teeth_below above; P = prefix * N / Q in double), the last
    tile up to N. */
-int gjx_smc_source_ranges(const gjx_smc_config* cfg, const uint64_t* tile_sums, int world, int64_t ticket,
-                          int64_t* out_ranges, gjx_stream s) {
+int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, const uint64_t* ess, int world,
+                          int64_t ticket, int64_t* out_ranges, gjx_stream s) {
   (void)s;
-  if (!cfg_ok(cfg) || !tile_sums || !out_ranges || world < 1 || world > 64 || cfg->n_total % (uint64_t)world)
+  if (!cfg_ok(cfg) || !recs || !out_ranges || world < 1 || world > 64 || cfg->n_total % (uint64_t)world)
     return GJX_ERR_INVALID;
+  if (cfg_adaptive(cfg) && !ess) return GJX_ERR_INVALID;
   const uint64_t N = cfg->n_total, nt = gjx_num_tiles(N), nl = N / (uint64_t)world;
-  if (cfg_adaptive(cfg)) {
-    if (!cfg->tile_ess) return GJX_ERR_INVALID;
-    if (!smc_resamples(cfg)) { /* the next step keeps its particles: every block's sources are its own tiles */
-      for (int j = 0; j < world; ++j) {
-        out_ranges[2 * j] = (int64_t)((uint64_t)j * (nl / O_TILE));
-        out_ranges[2 * j + 1] = (int64_t)((uint64_t)(j + 1) * (nl / O_TILE));
-      }
-      out_ranges[2 * world] = ticket;
-      return GJX_OK;
+  merged m;
+  int rc = merge_records(recs, cfg_adaptive(cfg) ? ess : NULL, nt, &m);
+  if (rc) return rc;
+  if (cfg_adaptive(cfg) && !ess_says_resample(m.R1, m.R2, (double)cfg->ess_threshold * (double)N)) {
+    /* the next step keeps its particles: every block's sources are its own tiles */
+    for (int j = 0; j < world; ++j) {
+      out_ranges[2 * j] = (int64_t)((uint64_t)j * (nl / O_TILE));
+      out_ranges[2 * j + 1] = (int64_t)((uint64_t)(j + 1) * (nl / O_TILE));
     }
+    out_ranges[2 * world] = ticket;
+    merged_free(&m);
+    return GJX_OK;
   }
-  uint64_t Q = 0;
-  for (uint64_t b = 0; b < nt; ++b) Q += tile_sums[b];
+  const uint64_t Q = m.Q;
   const double scale = (double)N / (double)Q, nd = (double)N;
   for (int j = 0; j < world; ++j) {
     const double lo = (double)((uint64_t)j * nl), hi = (double)((uint64_t)(j + 1) * nl);
     int64_t first = 0, end = 0;
-    uint64_t pre = 0;
     for (uint64_t b = 0; b < nt; ++b) {
-      double lower = ceil((double)pre * scale);
+      double lower = ceil((double)m.pre[b] * scale);
       if (!(lower < nd)) lower = nd;
       lower = lower - 1.0 > 0.0 ? lower - 1.0 : 0.0;
-      pre += tile_sums[b];
-      double upper = ceil((double)pre * scale);
+      double upper = ceil((double)m.pre[b + 1] * scale);
       if (b + 1 == nt || !(upper < nd)) upper = nd;
       first += upper <= lo;
       end += lower < hi;
     }
-    /* no mass at all: the last particle closes the comb and owns every slot */
-    out_ranges[2 * j] = Q == 0 ? (int64_t)nt - 1 : first;
-    out_ranges[2 * j + 1] = Q == 0 ? (int64_t)nt : end;
+    /* no mass at all: the population is kept, every block's sources are its own tiles */
+    out_ranges[2 * j] = Q == 0 ? (int64_t)((uint64_t)j * (nl / O_TILE)) : first;
+    out_ranges[2 * j + 1] = Q == 0 ? (int64_t)((uint64_t)(j + 1) * (nl / O_TILE)) : end;
   }
   out_ranges[2 * world] = ticket;
+  merged_free(&m);
   return GJX_OK;
 }
 
-/* Front half of every step A (t >= 1): the ancestors of the rank's slots — by systematic resampling, or the identity
- * when an adaptive filter keeps its particles — the total mass of the previous weights and the step's flag.
- * Returns 1 if the step resamples (the new log-weights start from 0), 0 if it accumulates. */
-static int smc_step_front(const gjx_smc_config* cfg, int t, const float* prev_logw, float prev_max,
-                          const uint64_t* prev_tile_sums, uint64_t* prev_q_out, int32_t* anc) {
-  uint64_t Q = 0;
-  for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) Q += prev_tile_sums[b];
-  if (prev_q_out) *prev_q_out = Q;
-  const int res = smc_resamples(cfg);
+/* Front half of every step (t >= 1): the merge of the previous population's records (its anchor and total mass go to
+ * prev_e_out / prev_q_out), the step's flag, and the ancestors of the rank's slots — by systematic resampling, or the
+ * identity when an adaptive filter keeps its particles.
+ * Returns 1 if the step resamples (the new log-weights start from 0), 0 if it accumulates, < 0 on error. */
+static int smc_step_front(const gjx_smc_config* cfg, int t, const gjx_smc_pop* prev, int32_t* prev_e_out,
+                          uint64_t* prev_q_out, int32_t* anc) {
+  const uint64_t N = cfg->n_total, nt = gjx_num_tiles(N);
+  const int ad = cfg_adaptive(cfg);
+  merged m;
+  int rc = merge_records(prev->recs, ad ? prev->ess : NULL, nt, &m);
+  if (rc) return rc;
+  if (prev_e_out) *prev_e_out = m.e;
+  if (prev_q_out) *prev_q_out = m.Q;
+  const int res = !ad || ess_says_resample(m.R1, m.R2, (double)cfg->ess_threshold * (double)N);
   if (cfg->resampled_out && !(cfg->n_filters > 1)) cfg->resampled_out[t] = res;
-  if (res) smc_ancestors(cfg, t, prev_logw, prev_max, prev_tile_sums, Q, anc);
-  else
+  if (res) {
+    const uint32_t rkey[4] = {cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1], 0u, 0u};
+    o_stream st = o_stream_make(cfg->impl, rkey, 0, 0);
+    const double u0 = u0_from_bits(o_bits64_at(&st, 0));
+    systematic_ancestors(prev->cdf, N, &m, nt, N, u0, (int64_t)cfg->first_slot, (int64_t)(cfg->first_slot + cfg->n_local), anc);
+  } else {
     for (uint64_t j = 0; j < cfg->n_local; ++j) anc[j] = (int32_t)(cfg->first_slot + j);
+  }
+  merged_free(&m);
   return res;
 }
-
-/* max_partials_out: only "max over the array == local max" is specified; the oracle puts the
- * local max in the rank's first tile entry and -inf elsewhere. */
-static void put_max_partials(const gjx_smc_config* cfg, float mx, float* mp) {
-  for (uint64_t b = 0; b < gjx_num_tiles(cfg->n_total); ++b) mp[b] = -INFINITY;
-  mp[cfg->first_slot / O_TILE] = mx;
+/* Back half of every step: the in-tile CDFs, records and ESS sums of the rank's new log-weights lw[n_local]. */
+static void smc_step_back(const gjx_smc_config* cfg, const gjx_smc_pop* out, const float* lw) {
+  const uint64_t nl = cfg->n_local, tile0 = cfg->first_slot / O_TILE, ntl = gjx_num_tiles(nl);
+  const int ad = cfg_adaptive(cfg);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < (int64_t)ntl; ++b) {
+    const uint64_t lo = (uint64_t)b * O_TILE, cnt = lo + O_TILE <= nl ? O_TILE : nl - lo;
+    tile_emit(lw + lo, cnt, out->cdf + lo, &out->recs[tile0 + (uint64_t)b], ad ? out->ess + 2 * (tile0 + (uint64_t)b) : NULL);
+  }
+  if (out->logw) memcpy(out->logw, lw, sizeof(float) * nl);
 }
 
-int gjx_smc_lgssm_step_a(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t,
-                         const float* prev_state, const float* prev_logw, const float* prev_max,
-                         const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* state_out,
-                         float* logw_out, float* max_partials_out, int32_t* ancestors_out,
-                         gjx_stream s) {
-  (void)s;
-  if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !state_out || !logw_out || !max_partials_out)
-    return GJX_ERR_INVALID;
+/* One step of a filter.  propagate(ctx, j, anc or -1, &w): writes slot j's new state, returns its log-weight increment. */
+typedef float (*propagate_fn)(void* ctx, uint64_t j_local, int64_t ancestor);
+static int smc_step_generic(const gjx_smc_config* cfg, int t, int n_state, const gjx_smc_pop* prev, const gjx_smc_pop* out,
+                            int32_t* prev_e_out, uint64_t* prev_q_out, int32_t* ancestors_out, propagate_fn fn, void* ctx) {
+  const int ad = cfg_adaptive(cfg);
+  if (!pop_ok(out, n_state, ad) || (t > 0 && (!pop_ok(prev, n_state, ad) || prev->recs == out->recs))) return GJX_ERR_INVALID;
   const uint64_t nl = cfg->n_local;
   int32_t* anc = NULL;
   int carry = 0;
   if (t > 0) {
-    if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
-    if (cfg_adaptive(cfg) && !cfg->tile_ess) return GJX_ERR_INVALID;
     anc = ancestors_out ? ancestors_out : (int32_t*)malloc(sizeof(int32_t) * nl);
     if (!anc) return GJX_ERR_LAUNCH;
-    carry = !smc_step_front(cfg, t, prev_logw, *prev_max, prev_tile_sums, prev_q_out, anc);
+    const int res = smc_step_front(cfg, t, prev, prev_e_out, prev_q_out, anc);
+    if (res < 0) {
+      if (anc != ancestors_out) free(anc);
+      return res;
+    }
+    carry = !res;
   } else if (ancestors_out) {
     for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
   }
-  const uint32_t skey[4] = {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u};
-  float mx = -INFINITY;
-#pragma omp parallel for reduction(max : mx) schedule(static)
-  for (int64_t j = 0; j < (int64_t)nl; ++j) {
-    float eps = o_smc_slot_normal(cfg->impl, skey, cfg->first_slot + (uint64_t)j);
-    float x;
-    if (t == 0) {
-      float tt = mdl->x0_scale * eps;
-      x = mdl->x0_loc + tt;
-    } else {
-      float mean = mdl->a * prev_state[anc[j]];
-      float tt = mdl->q * eps;
-      x = mean + tt;
-    }
-    float lw = o_logpdf_normal(y_t, x, mdl->r);
-    if (carry) lw = lw + prev_logw[anc[j]]; /* no resampling at this step: the log-weight accumulates */
-    state_out[j] = x;
-    logw_out[j] = lw;
-    mx = lw > mx ? lw : mx;
+  float* lw = (float*)malloc(sizeof(float) * nl);
+  if (!lw) {
+    if (anc && anc != ancestors_out) free(anc);
+    return GJX_ERR_LAUNCH;
   }
-  put_max_partials(cfg, mx, max_partials_out);
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < (int64_t)nl; ++j) {
+    float w = fn(ctx, (uint64_t)j, t > 0 ? (int64_t)anc[j] : -1);
+    if (carry) w = w + prev->logw[anc[j]]; /* no resampling at this step: the log-weight accumulates */
+    lw[j] = w;
+  }
+  smc_step_back(cfg, out, lw);
+  free(lw);
   if (anc && anc != ancestors_out) free(anc);
   return GJX_OK;
+}
+
+typedef struct {
+  const gjx_smc_config* cfg;
+  const gjx_lgssm* mdl;
+  int t;
+  float y;
+  const float* prev_x;
+  float* x_out;
+  uint32_t skey[4];
+} lgssm_ctx;
+static float lgssm_propagate(void* vc, uint64_t j, int64_t a) {
+  lgssm_ctx* c = (lgssm_ctx*)vc;
+  const float eps = o_smc_slot_normal(c->cfg->impl, c->skey, c->cfg->first_slot + j);
+  float x;
+  if (a < 0) {
+    const float tt = c->mdl->x0_scale * eps;
+    x = c->mdl->x0_loc + tt;
+  } else {
+    const float mean = c->mdl->a * c->prev_x[a];
+    const float tt = c->mdl->q * eps;
+    x = mean + tt;
+  }
+  c->x_out[j] = x;
+  return o_logpdf_normal(c->y, x, c->mdl->r);
+}
+int gjx_smc_lgssm_step(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t, const gjx_smc_pop* prev,
+                       const gjx_smc_pop* out, int32_t* prev_e_out, uint64_t* prev_q_out, int32_t* ancestors_out,
+                       gjx_stream s) {
+  (void)s;
+  if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !out || (t > 0 && !prev) || cfg->n_filters > 1) return GJX_ERR_INVALID;
+  lgssm_ctx c = {cfg, mdl, t, y_t, t > 0 ? (const float*)prev->state[0] : NULL, (float*)out->state[0],
+                 {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u}};
+  return smc_step_generic(cfg, t, 1, prev, out, prev_e_out, prev_q_out, ancestors_out, lgssm_propagate, &c);
 }
 
 /* HMM transition tables as ALIAS tables: one 4-byte table word per draw.  Row r of the table
@@ -1130,108 +1206,88 @@ int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_alias, float* obs_logp, 
   return GJX_OK;
 }
 
-int gjx_smc_hmm_step_a(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_t y_t,
-                       const int32_t* prev_state, const float* prev_logw, const float* prev_max,
-                       const uint64_t* prev_tile_sums, uint64_t* prev_q_out,
-                       const uint32_t* trans_alias, const float* obs_logp, int32_t* state_out,
-                       float* logw_out, float* max_partials_out, int32_t* ancestors_out,
-                       gjx_stream s) {
+typedef struct {
+  const gjx_smc_config* cfg;
+  const gjx_hmm* mdl;
+  int32_t y;
+  const int32_t* prev_z;
+  int32_t* z_out;
+  const uint32_t* trans_alias;
+  const float* obs_logp;
+  uint32_t skey[4];
+} hmm_ctx;
+static float hmm_propagate(void* vc, uint64_t j, int64_t a) {
+  hmm_ctx* c = (hmm_ctx*)vc;
+  const uint32_t K = (uint32_t)c->mdl->n_states;
+  const uint32_t bits = o_smc_slot_bits(c->cfg->impl, c->skey, c->cfg->first_slot + j);
+  const int32_t zp = a < 0 ? c->mdl->init_state : c->prev_z[a];
+  const uint32_t z = hmm_alias_draw(c->trans_alias + (size_t)zp * K, K, bits);
+  c->z_out[j] = (int32_t)z;
+  return c->obs_logp[(size_t)z * K + (uint32_t)c->y];
+}
+int gjx_smc_hmm_step(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_t y_t, const gjx_smc_pop* prev,
+                     const gjx_smc_pop* out, int32_t* prev_e_out, uint64_t* prev_q_out, const uint32_t* trans_alias,
+                     const float* obs_logp, int32_t* ancestors_out, gjx_stream s) {
   (void)s;
-  if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !state_out || !logw_out || !max_partials_out ||
-      !trans_alias || !obs_logp || y_t < 0 || y_t >= mdl->n_states)
+  if (!cfg_ok(cfg) || !mdl || t < 0 || t >= cfg->n_steps || !out || (t > 0 && !prev) || !trans_alias || !obs_logp ||
+      y_t < 0 || y_t >= mdl->n_states || cfg->n_filters > 1)
     return GJX_ERR_INVALID;
-  const uint64_t nl = cfg->n_local;
-  const uint32_t K = (uint32_t)mdl->n_states;
-  int32_t* anc = NULL;
-  int carry = 0;
-  if (t > 0) {
-    if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
-    if (cfg_adaptive(cfg) && !cfg->tile_ess) return GJX_ERR_INVALID;
-    anc = ancestors_out ? ancestors_out : (int32_t*)malloc(sizeof(int32_t) * nl);
-    if (!anc) return GJX_ERR_LAUNCH;
-    carry = !smc_step_front(cfg, t, prev_logw, *prev_max, prev_tile_sums, prev_q_out, anc);
-  } else if (ancestors_out) {
-    for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
-  }
-  const uint32_t skey[4] = {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u};
-  float mx = -INFINITY;
-#pragma omp parallel for reduction(max : mx) schedule(static)
-  for (int64_t j = 0; j < (int64_t)nl; ++j) {
-    uint32_t bits = o_smc_slot_bits(cfg->impl, skey, cfg->first_slot + (uint64_t)j);
-    int32_t zp = t == 0 ? mdl->init_state : prev_state[anc[j]];
-    const uint32_t lo = hmm_alias_draw(trans_alias + (size_t)zp * K, K, bits);
-    float lw = obs_logp[(size_t)lo * K + (uint32_t)y_t];
-    if (carry) lw = lw + prev_logw[anc[j]];
-    state_out[j] = (int32_t)lo;
-    logw_out[j] = lw;
-    mx = lw > mx ? lw : mx;
-  }
-  put_max_partials(cfg, mx, max_partials_out);
-  if (anc && anc != ancestors_out) free(anc);
-  return GJX_OK;
+  hmm_ctx c = {cfg, mdl, y_t, t > 0 ? (const int32_t*)prev->state[0] : NULL, (int32_t*)out->state[0], trans_alias, obs_logp,
+               {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u}};
+  return smc_step_generic(cfg, t, 1, prev, out, prev_e_out, prev_q_out, ancestors_out, hmm_propagate, &c);
 }
 
-/* Whole single-device runs: the straightforward T-loop over the step pieces. */
-static int smc_run_common(const gjx_smc_config* cfg, int is_hmm, const void* model, const void* y,
-                          float* out_max, uint64_t* out_q, void* state_out, float* logw_out,
-                          int32_t* ancestors_out) {
-  if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !model || !y ||
-      !out_max || !out_q || !state_out || !logw_out)
+/* Whole single-device runs: the straightforward T-loop over the steps, on two populations of the run's own. */
+typedef int (*step_fn)(void* ctx, const gjx_smc_config* cfg, int t, const gjx_smc_pop* prev, const gjx_smc_pop* out,
+                       int32_t* pe, uint64_t* pq, int32_t* anc);
+static int pop_alloc(gjx_smc_pop* p, uint64_t N, int n_state, int adaptive) {
+  memset(p, 0, sizeof *p);
+  const uint64_t nt = gjx_num_tiles(N);
+  int ok = 1;
+  for (int k = 0; k < n_state; ++k) ok = ok && (p->state[k] = malloc(4 * N)) != NULL;
+  ok = ok && (p->cdf = (uint64_t*)malloc(8 * N)) != NULL;
+  ok = ok && (p->logw = (float*)malloc(4 * N)) != NULL;
+  ok = ok && (p->recs = (gjx_tile_rec*)malloc(sizeof(gjx_tile_rec) * nt)) != NULL;
+  if (adaptive) ok = ok && (p->ess = (uint64_t*)calloc(2 * nt, sizeof(uint64_t))) != NULL;
+  return ok ? GJX_OK : GJX_ERR_LAUNCH;
+}
+static void pop_free(gjx_smc_pop* p) {
+  for (int k = 0; k < GJX_SMC_MAX_STATE; ++k) free(p->state[k]);
+  free(p->cdf); free(p->logw); free(p->recs); free(p->ess);
+}
+static int smc_run_one(const gjx_smc_config* cfg, int n_state, step_fn step, void* ctx, int32_t* out_e, uint64_t* out_q,
+                       void* const* state_out, float* logw_out, int32_t* ancestors_out) {
+  if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !out_e || !out_q || !state_out || !logw_out)
     return GJX_ERR_INVALID;
   const uint64_t N = cfg->n_total;
-  const uint64_t ntile = gjx_num_tiles(N);
-  gjx_smc_config lc = *cfg; /* the run's own ESS sums (an adaptive filter) */
-  if (cfg_adaptive(cfg)) {
-    if (!cfg->resampled_out) return GJX_ERR_INVALID;
-    lc.tile_ess = (uint64_t*)calloc(2 * ntile, sizeof(uint64_t));
+  const int ad = cfg_adaptive(cfg), T = cfg->n_steps;
+  if (ad && !cfg->resampled_out) return GJX_ERR_INVALID;
+  if (cfg->resampled_out) memset(cfg->resampled_out, 0, sizeof(int32_t) * (size_t)T);
+  gjx_smc_pop pop[2];
+  int rc = pop_alloc(&pop[0], N, n_state, ad);
+  if (!rc) rc = pop_alloc(&pop[1], N, n_state, ad);
+  for (int t = 0; t < T && rc == GJX_OK; ++t) {
+    const int cur = t & 1, prv = cur ^ 1;
+    rc = step(ctx, cfg, t, &pop[prv], &pop[cur], t ? &out_e[t - 1] : NULL, t ? &out_q[t - 1] : NULL,
+              ancestors_out ? ancestors_out + (size_t)t * N : NULL);
   }
-  if (lc.resampled_out) memset(lc.resampled_out, 0, sizeof(int32_t) * (size_t)cfg->n_steps);
-  cfg = &lc;
-  void* st[2] = {malloc(4 * N), malloc(4 * N)};
-  float* lw[2] = {(float*)malloc(4 * N), (float*)malloc(4 * N)};
-  uint64_t* tiles = (uint64_t*)malloc(8 * ntile);
-  float* mp = (float*)malloc(4 * ntile);
-  uint32_t* tcdf = NULL;
-  float* ologp = NULL;
-  int rc = GJX_OK;
-  if (is_hmm) {
-    const gjx_hmm* h = (const gjx_hmm*)model;
-    size_t kk = (size_t)h->n_states * (size_t)h->n_states;
-    tcdf = (uint32_t*)malloc(4 * (size_t)gjx_hmm_alias_words(h->n_states));
-    ologp = (float*)malloc(4 * kk);
-    rc = gjx_hmm_prepare(h, tcdf, ologp, NULL);
-  }
-  for (int t = 0; t < cfg->n_steps && rc == GJX_OK; ++t) {
-    int cur = t & 1, prv = cur ^ 1;
-    int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * N : NULL;
-    if (is_hmm)
-      rc = gjx_smc_hmm_step_a(cfg, (const gjx_hmm*)model, t, ((const int32_t*)y)[t],
-                              (const int32_t*)st[prv], lw[prv], t ? &out_max[t - 1] : NULL, tiles,
-                              t ? &out_q[t - 1] : NULL, tcdf, ologp, (int32_t*)st[cur], lw[cur], mp,
-                              anc_t, NULL);
-    else
-      rc = gjx_smc_lgssm_step_a(cfg, (const gjx_lgssm*)model, t, ((const float*)y)[t],
-                                (const float*)st[prv], lw[prv], t ? &out_max[t - 1] : NULL, tiles,
-                                t ? &out_q[t - 1] : NULL, (float*)st[cur], lw[cur], mp, anc_t, NULL);
-    if (rc == GJX_OK) rc = gjx_smc_step_b(cfg, lw[cur], mp, &out_max[t], tiles, NULL);
-  }
-  if (rc == GJX_OK) rc = gjx_smc_finish(cfg, tiles, &out_q[cfg->n_steps - 1], NULL);
+  const int last = (T - 1) & 1;
+  if (rc == GJX_OK) rc = gjx_smc_finish(cfg, pop[last].recs, &out_e[T - 1], &out_q[T - 1], NULL);
   if (rc == GJX_OK) {
-    int last = (cfg->n_steps - 1) & 1;
-    memcpy(state_out, st[last], 4 * N);
-    memcpy(logw_out, lw[last], 4 * N);
+    for (int k = 0; k < n_state; ++k) memcpy(state_out[k], pop[last].state[k], 4 * N);
+    memcpy(logw_out, pop[last].logw, 4 * N);
   }
-  free(st[0]); free(st[1]); free(lw[0]); free(lw[1]); free(tiles); free(mp); free(tcdf); free(ologp);
-  if (cfg_adaptive(cfg)) free(lc.tile_ess);
+  pop_free(&pop[0]);
+  pop_free(&pop[1]);
   return rc;
 }
-
 /* Several filters (gjx_smc_config.n_filters): by definition, each filter's own single run, with its keys
  * [f, T, 2] and its slice of every output. */
-static int smc_run_filters(const gjx_smc_config* cfg, int kind, const void* model, const void* y, float* out_max,
-                           uint64_t* out_q, void* state_out, float* logw_out, int32_t* ancestors_out) {
-  if (!cfg) return GJX_ERR_INVALID;
-  if (cfg->n_filters <= 1) return smc_run_common(cfg, kind, model, y, out_max, out_q, state_out, logw_out, ancestors_out);
+static int smc_run_filters(const gjx_smc_config* cfg, int n_state, step_fn step, void* ctx, int32_t* out_e, uint64_t* out_q,
+                           void* const* state_out, float* logw_out, int32_t* ancestors_out) {
+  if (!cfg || !state_out) return GJX_ERR_INVALID;
+  if (cfg->n_filters <= 1) return smc_run_one(cfg, n_state, step, ctx, out_e, out_q, state_out, logw_out, ancestors_out);
+  if (!cfg_ok(cfg) || !out_e || !out_q || !logw_out) return GJX_ERR_INVALID;
   const int F = cfg->n_filters, T = cfg->n_steps;
   const uint64_t N = cfg->n_total, stride = cfg->filter_stride;
   if (F > 16 || stride < N) return GJX_ERR_INVALID;
@@ -1243,8 +1299,10 @@ static int smc_run_filters(const gjx_smc_config* cfg, int kind, const void* mode
     c.step_keys = cfg->step_keys + 2 * (size_t)f * T;
     c.resample_keys = cfg->resample_keys + 2 * (size_t)f * T;
     c.resampled_out = cfg->resampled_out ? cfg->resampled_out + (size_t)f * T : NULL;
-    rc = smc_run_common(&c, kind, model, y, out_max + (size_t)f * T, out_q + (size_t)f * T,
-                        (char*)state_out + 4 * (size_t)f * stride, logw_out + (size_t)f * stride, anc1);
+    void* cols[GJX_SMC_MAX_STATE];
+    for (int k = 0; k < n_state; ++k) cols[k] = (char*)state_out[k] + 4 * (size_t)f * stride;
+    rc = smc_run_one(&c, n_state, step, ctx, out_e + (size_t)f * T, out_q + (size_t)f * T, cols,
+                     logw_out + (size_t)f * stride, anc1);
     if (!rc && anc1)  /* [T, N] -> [T, F, stride] */
       for (int t = 0; t < T; ++t)
         memcpy(ancestors_out + ((size_t)t * F + f) * stride, anc1 + (size_t)t * N, sizeof(int32_t) * N);
@@ -1252,17 +1310,39 @@ static int smc_run_filters(const gjx_smc_config* cfg, int kind, const void* mode
   free(anc1);
   return rc;
 }
+typedef struct { const gjx_lgssm* mdl; const float* y; } lgssm_run;
+static int lgssm_run_step(void* vc, const gjx_smc_config* cfg, int t, const gjx_smc_pop* prev, const gjx_smc_pop* out,
+                          int32_t* pe, uint64_t* pq, int32_t* anc) {
+  lgssm_run* r = (lgssm_run*)vc;
+  return gjx_smc_lgssm_step(cfg, r->mdl, t, r->y[t], prev, out, pe, pq, anc, NULL);
+}
 int gjx_smc_run_lgssm(const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y,
-                      float* out_max, uint64_t* out_q, float* state_out, float* logw_out,
+                      int32_t* out_e, uint64_t* out_q, float* state_out, float* logw_out,
                       int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s) {
   (void)ws; (void)ws_bytes; (void)s;
-  return smc_run_filters(cfg, 0, model, y, out_max, out_q, state_out, logw_out, ancestors_out);
+  if (!model || !y || !state_out) return GJX_ERR_INVALID;
+  lgssm_run r = {model, y};
+  void* st[1] = {state_out};
+  return smc_run_filters(cfg, 1, lgssm_run_step, &r, out_e, out_q, st, logw_out, ancestors_out);
+}
+typedef struct { const gjx_hmm* mdl; const int32_t* y; uint32_t* tcdf; float* ologp; } hmm_run;
+static int hmm_run_step(void* vc, const gjx_smc_config* cfg, int t, const gjx_smc_pop* prev, const gjx_smc_pop* out,
+                        int32_t* pe, uint64_t* pq, int32_t* anc) {
+  hmm_run* r = (hmm_run*)vc;
+  return gjx_smc_hmm_step(cfg, r->mdl, t, r->y[t], prev, out, pe, pq, r->tcdf, r->ologp, anc, NULL);
 }
 int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32_t* y,
-                    float* out_max, uint64_t* out_q, int32_t* state_out, float* logw_out,
+                    int32_t* out_e, uint64_t* out_q, int32_t* state_out, float* logw_out,
                     int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s) {
   (void)ws; (void)ws_bytes; (void)s;
-  return smc_run_filters(cfg, 1, model, y, out_max, out_q, state_out, logw_out, ancestors_out);
+  if (!model || !y || !state_out || model->n_states <= 0 || model->n_states > 256) return GJX_ERR_INVALID;
+  const size_t kk = (size_t)model->n_states * (size_t)model->n_states;
+  hmm_run r = {model, y, (uint32_t*)malloc(4 * (size_t)gjx_hmm_alias_words(model->n_states)), (float*)malloc(4 * kk)};
+  int rc = (r.tcdf && r.ologp) ? gjx_hmm_prepare(model, r.tcdf, r.ologp, NULL) : GJX_ERR_LAUNCH;
+  void* st[1] = {state_out};
+  if (!rc) rc = smc_run_filters(cfg, 1, hmm_run_step, &r, out_e, out_q, st, logw_out, ancestors_out);
+  free(r.tcdf); free(r.ologp);
+  return rc;
 }
 
 /* ---- oracle-only probes (not part of include/gjx.h): raw ciphers and math-spec functions, so the
@@ -1465,159 +1545,70 @@ int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
   return GJX_OK;
 }
 
-static int smc_run_plan_one(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
-                            uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out);
-/* Step A of a plan-driven filter for the slots [first_slot, first_slot + n_local) (the sharded driver's piece). */
-int gjx_smc_plan_step_a(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, const float* obs_t,
-                        const float* const* prev_state, const float* prev_logw, const float* prev_max,
-                        const uint64_t* prev_tile_sums, uint64_t* prev_q_out, float* const* state_out,
-                        float* logw_out, float* max_partials_out, int32_t* ancestors_out, gjx_stream s) {
-  (void)s;
-  if (!cfg_ok(cfg) || !plan || t < 0 || t >= cfg->n_steps || !state_out || !logw_out || !max_partials_out ||
-      (plan->m.n_obs > 0 && !obs_t) || cfg->n_filters > 1)
-    return GJX_ERR_INVALID;
-  const gjx_smc_model* m = &plan->m;
+/* One step of a plan-driven filter for the slots [first_slot, first_slot + n_local) (the sharded driver's piece). */
+typedef struct {
+  const gjx_smc_config* cfg;
+  const gjx_smc_model* m;
+  int t;
+  const float* obs;
+  const gjx_smc_pop* prev;
+  const gjx_smc_pop* out;
+  uint32_t skey[4];
+} plan_ctx;
+static float plan_propagate(void* vc, uint64_t j, int64_t a) {
+  plan_ctx* p = (plan_ctx*)vc;
+  const gjx_smc_model* m = p->m;
   const int D = m->n_state;
-  const uint64_t nl = cfg->n_local;
-  int32_t* anc = NULL;
-  int carry = 0;
-  if (t > 0) {
-    if (!prev_state || !prev_logw || !prev_max || !prev_tile_sums) return GJX_ERR_INVALID;
-    if (cfg_adaptive(cfg) && !cfg->tile_ess) return GJX_ERR_INVALID;
-    anc = ancestors_out ? ancestors_out : (int32_t*)malloc(sizeof(int32_t) * nl);
-    if (!anc) return GJX_ERR_LAUNCH;
-    carry = !smc_step_front(cfg, t, prev_logw, *prev_max, prev_tile_sums, prev_q_out, anc);
-  } else if (ancestors_out) {
-    for (uint64_t j = 0; j < nl; ++j) ancestors_out[j] = (int32_t)(cfg->first_slot + j);
-  }
-  const uint32_t skey[4] = {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u};
-  const gjx_site* sites = t == 0 ? m->init_sites : m->step_sites;
-  const int ns = t == 0 ? m->n_init_sites : m->n_step_sites;
-  const gjx_arg* nxt = t == 0 ? m->init_state : m->next_state;
-  float mx = -INFINITY;
-#pragma omp parallel for reduction(max : mx) schedule(static)
-  for (int64_t j = 0; j < (int64_t)nl; ++j) {
-    const uint64_t slot = cfg->first_slot + (uint64_t)j;
-    walk_ctx c;
-    memset(&c, 0, sizeof c);
-    c.impl = cfg->impl;
-    o_split_at(cfg->impl, skey, slot, c.pkey);
-    c.quad_key = cfg->impl == 1 ? skey : NULL;
-    c.slot = slot;
-    float prev[GJX_SMC_MAX_STATE];
-    if (t > 0)
-      for (int k = 0; k < D; ++k) prev[k] = prev_state[k][anc[j]];
-    c.state = t > 0 ? prev : NULL;
-    c.obs = obs_t;
-    site_val vals[GJX_MAX_SITES];
-    float w, sc;
-    site_walk(sites, ns, &c, vals, &w, &sc);
-    for (int k = 0; k < D; ++k) state_out[k][j] = eval_arg(&nxt[k], vals, &c);
-    if (carry) w = w + prev_logw[anc[j]];
-    logw_out[j] = w;
-    mx = w > mx ? w : mx;
-  }
-  put_max_partials(cfg, mx, max_partials_out);
-  if (anc && anc != ancestors_out) free(anc);
-  return GJX_OK;
+  const uint64_t slot = p->cfg->first_slot + j;
+  walk_ctx c;
+  memset(&c, 0, sizeof c);
+  c.impl = p->cfg->impl;
+  o_split_at(p->cfg->impl, p->skey, slot, c.pkey);
+  c.quad_key = p->cfg->impl == 1 ? p->skey : NULL;
+  c.slot = slot;
+  float prev[GJX_SMC_MAX_STATE];
+  if (a >= 0)
+    for (int k = 0; k < D; ++k) prev[k] = ((const float*)p->prev->state[k])[a];
+  c.state = a >= 0 ? prev : NULL;
+  c.obs = p->obs;
+  const gjx_site* sites = p->t == 0 ? m->init_sites : m->step_sites;
+  const int ns = p->t == 0 ? m->n_init_sites : m->n_step_sites;
+  const gjx_arg* nxt = p->t == 0 ? m->init_state : m->next_state;
+  site_val vals[GJX_MAX_SITES];
+  float w, sc;
+  site_walk(sites, ns, &c, vals, &w, &sc);
+  for (int k = 0; k < D; ++k) ((float*)p->out->state[k])[j] = eval_arg(&nxt[k], vals, &c);
+  return w;
+}
+int gjx_smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, const float* obs_t, const gjx_smc_pop* prev,
+                      const gjx_smc_pop* out, int32_t* prev_e_out, uint64_t* prev_q_out, int32_t* ancestors_out,
+                      gjx_stream s) {
+  (void)s;
+  if (!cfg_ok(cfg) || !plan || t < 0 || t >= cfg->n_steps || !out || (t > 0 && !prev) || (plan->m.n_obs > 0 && !obs_t) ||
+      cfg->n_filters > 1)
+    return GJX_ERR_INVALID;
+  plan_ctx c = {cfg, &plan->m, t, obs_t, prev, out, {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u}};
+  return smc_step_generic(cfg, t, plan->m.n_state, prev, out, prev_e_out, prev_q_out, ancestors_out, plan_propagate, &c);
 }
 
+typedef struct { gjx_smc_plan* plan; const float* obs; } plan_run;
+static int plan_run_step(void* vc, const gjx_smc_config* cfg, int t, const gjx_smc_pop* prev, const gjx_smc_pop* out,
+                         int32_t* pe, uint64_t* pq, int32_t* anc) {
+  plan_run* r = (plan_run*)vc;
+  const int no = r->plan->m.n_obs;
+  return gjx_smc_plan_step(cfg, r->plan, t, no ? r->obs + (size_t)t * (size_t)no : NULL, prev, out, pe, pq, anc, NULL);
+}
 /* Several filters: each filter's own single run, with its keys [f, T, 2] and its slice of every output. */
-int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
+int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, int32_t* out_e,
                      uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out,
                      void* ws, size_t ws_bytes, gjx_stream s) {
   (void)ws; (void)ws_bytes; (void)s;
-  if (!cfg || !plan || !state_out) return GJX_ERR_INVALID;
-  if (cfg->n_filters <= 1) return smc_run_plan_one(cfg, plan, obs_host, out_max, out_q, state_out, logw_out, ancestors_out);
-  const int F = cfg->n_filters, T = cfg->n_steps, D = plan->m.n_state;
-  const uint64_t N = cfg->n_total, stride = cfg->filter_stride;
-  if (F > 16 || stride < N) return GJX_ERR_INVALID;
-  int32_t* anc1 = ancestors_out ? (int32_t*)malloc(sizeof(int32_t) * (size_t)T * N) : NULL;
-  int rc = GJX_OK;
-  for (int f = 0; f < F && !rc; ++f) {
-    gjx_smc_config c = *cfg;
-    c.n_filters = 0;
-    c.step_keys = cfg->step_keys + 2 * (size_t)f * T;
-    c.resample_keys = cfg->resample_keys + 2 * (size_t)f * T;
-    c.resampled_out = cfg->resampled_out ? cfg->resampled_out + (size_t)f * T : NULL;
-    float* cols[GJX_SMC_MAX_STATE];
-    for (int k = 0; k < D; ++k) cols[k] = state_out[k] + (size_t)f * stride;
-    rc = smc_run_plan_one(&c, plan, obs_host, out_max + (size_t)f * T, out_q + (size_t)f * T, cols,
-                          logw_out + (size_t)f * stride, anc1);
-    if (!rc && anc1)  /* [T, N] -> [T, F, stride] */
-      for (int t = 0; t < T; ++t)
-        memcpy(ancestors_out + ((size_t)t * F + f) * stride, anc1 + (size_t)t * N, sizeof(int32_t) * N);
+  if (!cfg || !plan || !state_out || (plan->m.n_obs > 0 && !obs_host)) return GJX_ERR_INVALID;
+  plan_run r = {plan, obs_host};
+  void* st[GJX_SMC_MAX_STATE];
+  for (int k = 0; k < plan->m.n_state; ++k) {
+    if (!state_out[k]) return GJX_ERR_INVALID;
+    st[k] = state_out[k];
   }
-  free(anc1);
-  return rc;
-}
-static int smc_run_plan_one(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, float* out_max,
-                            uint64_t* out_q, float* const* state_out, float* logw_out, int32_t* ancestors_out) {
-  if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !plan || !out_max || !out_q ||
-      !state_out || !logw_out || (plan->m.n_obs > 0 && !obs_host))
-    return GJX_ERR_INVALID;
-  const gjx_smc_model* m = &plan->m;
-  const uint64_t N = cfg->n_total, ntile = gjx_num_tiles(N);
-  const int D = m->n_state;
-  gjx_smc_config lc = *cfg;
-  if (cfg_adaptive(cfg)) {
-    if (!cfg->resampled_out) return GJX_ERR_INVALID;
-    lc.tile_ess = (uint64_t*)calloc(2 * ntile, sizeof(uint64_t));
-  }
-  if (lc.resampled_out) memset(lc.resampled_out, 0, sizeof(int32_t) * (size_t)cfg->n_steps);
-  cfg = &lc;
-  float* st[2] = {(float*)malloc(4 * N * (size_t)D), (float*)malloc(4 * N * (size_t)D)};  /* [D][N] each */
-  float* lw[2] = {(float*)malloc(4 * N), (float*)malloc(4 * N)};
-  uint64_t* tiles = (uint64_t*)malloc(8 * ntile);
-  float* mp = (float*)malloc(4 * ntile);
-  int32_t* anc_tmp = (int32_t*)malloc(4 * N);
-  int rc = GJX_OK;
-  for (int t = 0; t < cfg->n_steps && rc == GJX_OK; ++t) {
-    const int cur = t & 1, prv = cur ^ 1;
-    int32_t* anc = ancestors_out ? ancestors_out + (size_t)t * N : anc_tmp;
-    int carry = 0;
-    if (t > 0) {
-      carry = !smc_step_front(cfg, t, lw[prv], out_max[t - 1], tiles, &out_q[t - 1], anc);
-    } else {
-      for (uint64_t j = 0; j < N; ++j) anc[j] = (int32_t)j;
-    }
-    const uint32_t skey[4] = {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u};
-    const float* obs = obs_host ? obs_host + (size_t)t * (size_t)m->n_obs : NULL;
-    const gjx_site* sites = t == 0 ? m->init_sites : m->step_sites;
-    const int ns = t == 0 ? m->n_init_sites : m->n_step_sites;
-    const gjx_arg* nxt = t == 0 ? m->init_state : m->next_state;
-    float mx = -INFINITY;
-#pragma omp parallel for reduction(max : mx) schedule(static)
-    for (int64_t j = 0; j < (int64_t)N; ++j) {
-      walk_ctx c;
-      memset(&c, 0, sizeof c);
-      c.impl = cfg->impl;
-      o_split_at(cfg->impl, skey, (uint64_t)j, c.pkey);
-      c.quad_key = cfg->impl == 1 ? skey : NULL;
-      c.slot = (uint64_t)j;
-      float prev[GJX_SMC_MAX_STATE];
-      if (t > 0)
-        for (int k = 0; k < D; ++k) prev[k] = st[prv][(size_t)k * N + (uint64_t)anc[j]];
-      c.state = t > 0 ? prev : NULL;
-      c.obs = obs;
-      site_val vals[GJX_MAX_SITES];
-      float w, sc;
-      site_walk(sites, ns, &c, vals, &w, &sc);
-      for (int k = 0; k < D; ++k) st[cur][(size_t)k * N + (uint64_t)j] = eval_arg(&nxt[k], vals, &c);
-      if (carry) w = w + lw[prv][anc[j]];
-      lw[cur][j] = w;
-      mx = w > mx ? w : mx;
-    }
-    put_max_partials(cfg, mx, mp);
-    rc = gjx_smc_step_b(cfg, lw[cur], mp, &out_max[t], tiles, NULL);
-  }
-  if (rc == GJX_OK) rc = gjx_smc_finish(cfg, tiles, &out_q[cfg->n_steps - 1], NULL);
-  if (rc == GJX_OK) {
-    const int last = (cfg->n_steps - 1) & 1;
-    for (int k = 0; k < D; ++k) memcpy(state_out[k], st[last] + (size_t)k * N, 4 * N);
-    memcpy(logw_out, lw[last], 4 * N);
-  }
-  free(st[0]); free(st[1]); free(lw[0]); free(lw[1]); free(tiles); free(mp); free(anc_tmp);
-  if (cfg_adaptive(cfg)) free(lc.tile_ess);
-  return rc;
+  return smc_run_filters(cfg, plan->m.n_state, plan_run_step, &r, out_e, out_q, st, logw_out, ancestors_out);
 }

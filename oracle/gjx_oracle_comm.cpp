@@ -11,28 +11,9 @@ extern "C" int gjo_smc_plan_dims(const gjx_smc_plan* p, int* n_state, int* n_obs
 
 namespace {
 struct HostMem {
-  void* buf = nullptr;
-  size_t cap = 0;
-  ~HostMem() { free(buf); }
   int copy(void* dst, const void* src, size_t bytes, gjx_stream) {
     if (bytes) memmove(dst, src, bytes);
     return GJX_OK;
-  }
-  int max_f32(float* dst, const float* const* srcs, int world, size_t n, gjx_stream) {
-    for (size_t i = 0; i < n; ++i) {
-      float m = srcs[0][i];
-      for (int r = 1; r < world; ++r) m = srcs[r][i] > m ? srcs[r][i] : m;
-      dst[i] = m;
-    }
-    return GJX_OK;
-  }
-  void* scratch(size_t bytes) {
-    if (bytes > cap) {
-      free(buf);
-      buf = malloc(bytes);
-      cap = buf ? bytes : 0;
-    }
-    return buf;
   }
   int sync(gjx_stream) { return GJX_OK; }
 };
@@ -60,6 +41,19 @@ int gjx_comm_init_local(gjx_comm_group* g, int rank, gjx_comm** out) {
   if (!c) return GJX_ERR_LAUNCH;
   c->t = new (std::nothrow) gjx_sharded::LocalTransport<HostMem>(&g->g, rank);
   if (!c->t) { delete c; return GJX_ERR_LAUNCH; }
+  *out = c;
+  return GJX_OK;
+}
+int gjx_comm_init_callbacks(int rank, int world, gjx_allgather_fn allgather, gjx_exchange_fn exchange,
+                            gjx_stream_sync_fn stream_sync, void* user, gjx_comm** out) {
+  if (!out) return GJX_ERR_INVALID;
+  gjx_comm* c = new (std::nothrow) gjx_comm;
+  if (!c) return GJX_ERR_LAUNCH;
+  const int rc = gjx_sharded::comm_init_callbacks(rank, world, allgather, exchange, stream_sync, user, &c->t);
+  if (rc) {
+    delete c;
+    return rc;
+  }
   *out = c;
   return GJX_OK;
 }

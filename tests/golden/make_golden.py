@@ -98,7 +98,7 @@ for impl, nm in ((0, "threefry"), (1, "philox")):
     lw = torch.linspace(-3, 2, 37)
     a, m, q = ora.resample("systematic", KeyBatch(impl, 2, parent=(5, 6)), lw)
     r["systematic_ancestors"] = a.tolist()
-    r["systematic_q"] = int(q)
+    r["systematic_q"], r["systematic_e"] = int(q), int(m)
     a, _, _ = ora.resample("multinomial", KeyBatch(impl, 2, parent=(5, 6)), lw, 12)
     r["multinomial_ancestors"] = a.tolist()
     r["categorical_index_gumbel"] = int(ora.categorical_index(KeyBatch(impl, 2, parent=(5, 6)), lw, 0))
@@ -107,14 +107,16 @@ for impl, nm in ((0, "threefry"), (1, "philox")):
     r["gaussian10_q"], r["gaussian10_max_bits"] = g["q"], int(torch.tensor(g["max"], dtype=torch.float32).view(torch.int32))
     r["gaussian10_logw_head_bits"] = g["logw"][:4].view(torch.int32).tolist()
     s_ = W.lgssm_smc(ora, impl, seed=4, n=2048, T=6, want_ancestors=True)
-    r["lgssm_q"] = s_["out_q"].tolist()
+    r["lgssm_q"], r["lgssm_e"] = s_["out_q"].tolist(), s_["out_e"].tolist()
     r["lgssm_anc_t5_head"] = s_["ancestors"][5, :16].tolist()
     h = W.hmm_smc(ora, impl, seed=5, n=2048, T=6, n_states=16)
-    r["hmm_q"] = h["out_q"].tolist()
+    r["hmm_q"], r["hmm_e"] = h["out_q"].tolist(), h["out_e"].tolist()
     reg[nm] = r
 dump("oracle_regression.json", reg)
 
-# ---- round 2 additions (a separate file: the round-1 pins above must keep reproducing unchanged) ------------------------
+# ---- round 2 additions (a separate file).  Round 3 revised the resampling weight spec (tile-anchored
+# records, one launch per SMC step), so the resampling / SMC entries of BOTH files were regenerated then; everything else
+# reproduced unchanged. ----
 reg2 = {}
 for impl, nm in ((0, "threefry"), (1, "philox")):
     r = {}
@@ -128,7 +130,7 @@ for impl, nm in ((0, "threefry"), (1, "philox")):
     r["scan_hmm_logw_head_bits"] = hr["logw"][:4].view(torch.int32).tolist()
     ad = W.lgssm_smc(ora, impl, seed=8, n=3000, T=16, want_ancestors=True, ess_threshold=0.5)
     r["ess_flags"] = ad["resampled"].tolist()
-    r["ess_q"] = ad["out_q"].tolist()
+    r["ess_q"], r["ess_e"] = ad["out_q"].tolist(), ad["out_e"].tolist()
     r["ess_logw_head_bits"] = ad["logw"][:4].view(torch.int32).tolist()
     from genjax._amd import abi, prng  # noqa: E402
     import numpy as np  # noqa: E402,F811
@@ -136,7 +138,7 @@ for impl, nm in ((0, "threefry"), (1, "philox")):
     y = np.array([0.1, 25.0, -40.0, -39.5, 60.0, 60.2], dtype=np.float32)
     sk, rk = W.smc_key_schedule(prng.key(11, impl), 6)
     col = ora.smc_run_lgssm(impl, 20000, sk, rk, abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.05), y, True)
-    r["collapse_q"] = col[1].tolist()
+    r["collapse_q"], r["collapse_e"] = col[1].tolist(), col[0].tolist()
     r["collapse_anc_t2_distinct"] = int(col[4][2].unique().numel())
     r["collapse_anc_t5_head"] = col[4][5, :8].tolist()
     reg2[nm] = r

@@ -1259,7 +1259,7 @@ def case_general_smc(impl):
     b = BootstrapSMC(LinearGaussianSSM(), y, 8192, record_ancestors=True).run(key)
     # the generated kernel and the hand-written LGSSM kernel are the same filter, bit for bit (threefry: per-slot
     # keys; philox: both draw word (slot & 3) of the quad's block 0 and pair Box-Muller inside the quad)
-    assert torch.equal(a.step_q, b.step_q) and torch.equal(a.step_max, b.step_max)
+    assert torch.equal(a.step_q, b.step_q) and torch.equal(a.step_e, b.step_e)
     assert torch.equal(a.particles, b.particles) and torch.equal(a.ancestors, b.ancestors)
     assert a.log_marginal_likelihood == pytest.approx(W.lgssm_exact_log_z(y), abs=0.5)
     assert b.log_marginal_likelihood == pytest.approx(W.lgssm_exact_log_z(y), abs=0.5)

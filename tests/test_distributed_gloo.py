@@ -60,7 +60,7 @@ def _worker(rank, world, port, impl, n_total, n_imp_total, T, out_dir):
                               n_states=16).run()
     assert torch.equal(hmm["state"], hmm_ag["state"]) and torch.equal(hmm["ancestors"], hmm_ag["ancestors"])
     torch.save(dict(hmm_state=hmm["state"].clone(), hmm_anc=hmm["ancestors"], hmm_q=hmm["out_q"], hmm_log_z=hmm["log_z"],
-                    log_z=log_z, logw=logw, e=e, q=q, e_seed4=e2[1:2].clone(), q_seed4=q2[1:2].clone(), logw_seed4=logw_seed4, smc_max=smc["out_max"], smc_q=smc["out_q"],
+                    log_z=log_z, logw=logw, e=e, q=q, e_seed4=e2[1:2].clone(), q_seed4=q2[1:2].clone(), logw_seed4=logw_seed4, smc_max=smc["out_e"], smc_q=smc["out_q"],
                     smc_state=smc["state"].clone(), smc_anc=smc["ancestors"], smc_log_z=smc["log_z"]),
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
@@ -83,7 +83,7 @@ def test_two_ranks_equal_one_rank(tmp_path, oracle_ops, impl):
     for p in parts:
         assert torch.equal(p["e"], ref_imp["row_e"]) and torch.equal(p["q"], ref_imp["row_q"])
         assert p["log_z"] == oracle_ops.log_z_from_rows(ref_imp["row_e"], ref_imp["row_q"], n_imp_total)
-        assert torch.equal(p["smc_max"], ref_smc["out_max"]) and torch.equal(p["smc_q"], ref_smc["out_q"])
+        assert torch.equal(p["smc_max"], ref_smc["out_e"]) and torch.equal(p["smc_q"], ref_smc["out_q"])
         assert p["smc_log_z"] == ref_smc["log_z"]
     assert parts[0]["log_z"] == parts[1]["log_z"]
     ref4 = W.Gaussian10(oracle_ops, impl, seed=4, n_local=n_imp_total).step()  # the second pass of a launch
@@ -130,13 +130,11 @@ def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_s
     return res
 
 
-def check_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ref_ops=None, ess_threshold=0.0, native=False,
-                        tile_sums_form=0):
+def check_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ref_ops=None, ess_threshold=0.0, native=False):
     """`ref_ops`: the backend of the single-rank reference filter (default: the same one)."""
     from genjax._amd import workloads as W
 
-    res = _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ess_threshold=ess_threshold, native=native,
-                             tile_sums_form=tile_sums_form)
+    res = _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ess_threshold=ess_threshold, native=native)
     ref_ops = ops if ref_ops is None else ref_ops
     ref = (W.lgssm_smc(ref_ops, impl, 5, n_total, T, True, ess_threshold=ess_threshold) if kind == "lgssm"
            else W.hmm_smc(ref_ops, impl, 5, n_total, T, 16, True, ess_threshold=ess_threshold))
@@ -146,7 +144,7 @@ def check_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, ref_ops=No
     assert torch.equal(torch.cat([r["logw"] for r in res]), ref["logw"])
     assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1), ref["ancestors"])
     for r in res:
-        assert torch.equal(r["out_q"], ref["out_q"]) and torch.equal(r["out_max"], ref["out_max"])
+        assert torch.equal(r["out_q"], ref["out_q"]) and torch.equal(r["out_e"], ref["out_e"])
         assert r["log_z"] == ref["log_z"]
         if ess_threshold:
             assert torch.equal(r["resampled"], ref["resampled"])
@@ -252,10 +250,11 @@ def test_needed_tile_ranges_bounds():
 
 
 def check_source_ranges(ops):
-    """gjx_smc_source_ranges == the numpy statement of the same rule, for random tile masses."""
+    """gjx_smc_source_ranges == the numpy statement of the same rule, for random tile records (masses under tile
+    anchors that differ by a few powers of two, empty tiles, no mass at all)."""
     import numpy as np
 
-    from genjax._amd import dist as gdist, prng, workloads as W
+    from genjax._amd import abi, dist as gdist, prng, workloads as W
 
     rng = np.random.default_rng(1)
     for world, nt in ((2, 8), (4, 16), (3, 12), (8, 64), (1, 5), (8, 1000)):
@@ -263,18 +262,27 @@ def check_source_ranges(ops):
         sk, rk = W.smc_key_schedule(prng.key(0, 1), 2)
         cfg = ops.smc_config(1, n_total, 0, n_total, sk, rk)
         for trial in range(12):
-            q = rng.integers(0, 1 << 40, size=nt).astype(np.int64)
+            s_ = rng.integers(1, 1 << 40, size=nt).astype(np.uint64)
+            e_ = rng.integers(-3, 4, size=nt).astype(np.int32)
             if trial % 4 == 0:
-                q[rng.integers(0, nt, size=nt // 2)] = 0
+                dead = rng.integers(0, nt, size=nt // 2)
+                s_[dead] = 0
+                e_[dead] = abi.TILE_EMPTY
+            if trial % 3 == 0:
+                e_[rng.integers(0, nt)] += 70  # one tile far above the others: they carry no mass at all
             if trial == 11:
-                q[:] = 0  # no mass at all: every block draws from the last tile
-            elif q.sum() == 0:
-                q[0] = 1
+                s_[:] = 0  # no mass at all: every block keeps its own tiles
+                e_[:] = abi.TILE_EMPTY
+            recs = np.zeros((nt, 2), dtype=np.uint64)
+            recs[:, 0] = s_
+            recs[:, 1] = e_.view(np.uint32).astype(np.uint64)
+            recs_t = torch.from_numpy(recs.view(np.int64)).to(ops.device())
             out = torch.zeros(2 * world + 1, dtype=torch.int64, device=ops.device())
-            ops.smc_source_ranges(cfg, torch.from_numpy(q).to(ops.device()), world, out, ticket=trial + 1)
+            ops.smc_source_ranges(cfg, recs_t, None, world, out, ticket=trial + 1)
             got = out.cpu().numpy()
             assert got[-1] == trial + 1
-            assert np.array_equal(got[:-1].reshape(world, 2), gdist.needed_tile_ranges(q, n_total, ops.tile, world)), (world, trial)
+            _, masses = gdist.merged_tile_masses(recs_t)
+            assert np.array_equal(got[:-1].reshape(world, 2), gdist.needed_tile_ranges(masses, n_total, ops.tile, world)), (world, trial)
 
 
 def test_source_ranges_oracle(oracle_ops):
@@ -297,13 +305,14 @@ def check_degenerate_sharded(ops, impl, world):
     assert torch.equal(torch.cat([r["state"] for r in res]).cpu(), ref[2].cpu())
     assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1).cpu(), ref[4].cpu())
     for r in res:
-        assert torch.equal(r["out_q"].cpu(), ref[1].cpu()) and torch.equal(r["out_max"].cpu(), ref[0].cpu())
+        assert torch.equal(r["out_q"].cpu(), ref[1].cpu()) and torch.equal(r["out_e"].cpu(), ref[0].cpu())
     assert int(ref[4][3].unique().numel()) == 1  # total collapse at that step
 
 
 def check_impossible_observation_sharded(ops, impl, world, native):
-    """One observation is NaN (that step's weights are all NaN: zero total mass, every slot takes the LAST particle of
-    the last rank) and one is +inf (all -inf: uniform): the sharded filter goes on like the single-rank one, bit for bit."""
+    """One observation is NaN (that step's weights are all NaN) and one is +inf (all -inf): zero total mass both times —
+    the population is kept as it is (identity ancestors, no exchange) and the sharded filter goes on like the
+    single-rank one, bit for bit."""
     import numpy as np
 
     from genjax._amd import abi, prng, workloads as W
@@ -323,9 +332,10 @@ def check_impossible_observation_sharded(ops, impl, world, native):
 
     assert eq(torch.cat([r["state"] for r in res]), ref[2])
     assert eq(torch.cat([r["ancestors"] for r in res], dim=1), ref[4])
-    assert int(ref[4][2].unique().numel()) == 1 and int(ref[4][2][0]) == n_total - 1
+    ident = torch.arange(n_total, dtype=ref[4].dtype)
+    assert torch.equal(ref[4][2].cpu(), ident) and torch.equal(ref[4][4].cpu(), ident)
     for r in res:
-        assert eq(r["out_q"], ref[1]) and eq(r["out_max"], ref[0])
+        assert eq(r["out_q"], ref[1]) and eq(r["out_e"], ref[0])
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -379,7 +389,7 @@ def check_sharded_plan(ops, impl, world, build_plans, native=False):
     assert torch.equal(torch.cat([r["logw"] for r in res]).cpu(), logw.cpu())
     assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1).cpu(), anc.cpu())
     for r in res:
-        assert torch.equal(r["out_q"].cpu(), oq.cpu()) and torch.equal(r["out_max"].cpu(), om.cpu())
+        assert torch.equal(r["out_q"].cpu(), oq.cpu()) and torch.equal(r["out_e"].cpu(), om.cpu())
 
 
 @pytest.mark.parametrize("impl", [0, 1])

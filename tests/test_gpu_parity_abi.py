@@ -620,7 +620,7 @@ def test_smc_lgssm(hip_ops, oracle_ops, impl, n, T):
     h = W.lgssm_smc(hip_ops, impl, seed=7, n=n, T=T, want_ancestors=True)
     o = W.lgssm_smc(oracle_ops, impl, seed=7, n=n, T=T, want_ancestors=True)
     same(h["ancestors"], o["ancestors"], "ancestors")
-    same(h["out_max"], o["out_max"], "per-step max"); same(h["out_q"], o["out_q"], "per-step q")
+    same(h["out_e"], o["out_e"], "per-step max"); same(h["out_q"], o["out_q"], "per-step q")
     same(h["state"], o["state"], "final particles"); same(h["logw"], o["logw"], "final log-weights")
     assert h["log_z"] == o["log_z"]
     # without ancestor output the run must not change
@@ -650,18 +650,18 @@ def test_smc_degenerate_weights(hip_ops, oracle_ops, impl, n):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-@pytest.mark.parametrize("n", [20000, 300000, 2_200_000])  # 300000: a heavy tile owns > 4096 slots -> helper workgroups;
-def test_smc_collapse_helpers(hip_ops, oracle_ops, impl, n):  # 2.2e6: the same through the precomputed tile prefix
-    """Weight collapse at sizes where ONE source tile owns far more than kCapSlots = 4096 output slots: its own
-    workgroup serves the first 4096, the workgroups of the 1024-slot windows beyond serve the rest from the same
-    CDF — ancestors, particles and weights are the oracle's bits whoever computes them."""
+@pytest.mark.parametrize("n", [20000, 300000, 2_200_000])  # 2.2e6: through the precomputed tile prefix (> 1024 tiles)
+def test_smc_collapse_helpers(hip_ops, oracle_ops, impl, n):
+    """Weight collapse at sizes where ONE source tile owns thousands of output slots: every output tile inside its run
+    reads that one tile's stored CDF (the output-centric step is collapse-proof by construction) — ancestors, particles
+    and weights are the oracle's bits."""
     T = 6 if n > 1_000_000 else 8
     h, o = degenerate_lgssm_run(hip_ops, impl, n, T), degenerate_lgssm_run(oracle_ops, impl, n, T)
     for a, b, what in zip(h, o, ("step max", "step q", "state", "logw", "ancestors")):
         same(a, b, what)
     anc = o[4]
     counts = torch.bincount(anc[2].long() // 1024, minlength=(n + 1023) // 1024)
-    assert int(counts.max()) > 4096  # some tile really is heavy: the helper path ran
+    assert int(counts.max()) > 4096  # some tile really is heavy
     # a filter batch takes the same path per filter
     if n == 20000:
         from genjax._amd import abi, prng
@@ -682,9 +682,9 @@ def test_smc_collapse_helpers(hip_ops, oracle_ops, impl, n):  # 2.2e6: the same 
 @pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("n,n_out", [(300_000, 300_000), (70_004, 70_004), (50_000, 200_000)])
 def test_resample_heavy_tile_without_idle_tiles(hip_ops, oracle_ops, impl, n, n_out):
-    """One particle holds most of the mass and EVERY other particle has some: no tile is idle, so the heavy tile's
-    delegated chunks go to the extra (tile-less) workgroups of the launch.  Ancestors are the oracle's; also with two
-    heavy tiles and with more output slots than particles."""
+    """One particle holds most of the mass and EVERY other particle has some (the pattern that left the source-centric
+    kernels of rounds 1-2 without idle workgroups to delegate to).  Ancestors are the oracle's; also with two heavy
+    tiles and with more output slots than particles."""
     kb = KeyBatch(impl, 2, parent=(5, 6))
     for heavy in ([n // 3], [7, n - 5]):
         lw = torch.zeros(n)
@@ -698,10 +698,11 @@ def test_resample_heavy_tile_without_idle_tiles(hip_ops, oracle_ops, impl, n, n_
         assert int(cnt.max()) > 0.25 * n_out and int((cnt > 0).sum()) > 0.2 * min(n, n_out)
 
 
-def test_smc_extra_workgroups_serve(hip_ops):
-    """The extra workgroups' side of a filter run — their served maxima reach the step's global maximum through
-    `extra_max` — exercised by ranking them BEFORE the idle tiles (GJX_SMC_EXTRA_FIRST=1, read when the library loads:
-    a child process): the collapsing-weights filter equals the oracle's bit for bit with them doing the serving."""
+def test_smc_per_slot_search_path(hip_ops):
+    """The other way an output tile finds its ancestors — every slot searching the merged tile prefix and one stored
+    in-tile CDF, taken when a tile has more than 16 source tiles — forced for EVERY tile (GJX_SMC_SCAN_MAX=0, read when
+    the library loads: a child process): collapsing and ordinary filters, the generic resampler with n_out != n, and a
+    population beyond 1024 tiles (precomputed prefix) equal the oracle bit for bit."""
     import subprocess
     import sys
 
@@ -710,23 +711,52 @@ import sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
 import torch
 from genjax._amd.abi import GjxLib
-from genjax._amd.ops import Ops
+from genjax._amd.ops import KeyBatch, Ops
 from genjax._amd.runtime import load_hip_ops
+from genjax._amd import workloads as W
 from test_gpu_parity_abi import degenerate_lgssm_run
 hip, ora = load_hip_ops(), Ops(GjxLib(sys.argv[3], "cpu"))
 for impl in (0, 1):
-    for n, T in ((300_000, 8), (20_000, 8)):
+    for n, T in ((300_000, 8), (20_000, 8), (1_200_000, 4)):
         h, o = degenerate_lgssm_run(hip, impl, n, T), degenerate_lgssm_run(ora, impl, n, T)
         for a, b in zip(h, o):
             assert torch.equal(a.cpu(), b.cpu())
+    h = W.lgssm_smc(hip, impl, seed=7, n=70_001, T=12, want_ancestors=True)
+    o = W.lgssm_smc(ora, impl, seed=7, n=70_001, T=12, want_ancestors=True)
+    for k in ("ancestors", "out_e", "out_q", "state", "logw"):
+        assert torch.equal(h[k].cpu(), o[k].cpu()), k
+    g = torch.Generator().manual_seed(3)
+    lw = torch.randn(50_000, generator=g) * 4
+    for n_out in (50_000, 7, 130_001):
+        a, e, q = hip.resample("systematic", KeyBatch(impl, 2, parent=(5, 6)), lw.cuda(), n_out)
+        b, eo, qo = ora.resample("systematic", KeyBatch(impl, 2, parent=(5, 6)), lw, n_out)
+        assert torch.equal(a.cpu(), b) and int(e) == int(eo) and int(q) == int(qo)
 print("ok")
 """
     from conftest import ORACLE_LIB, ROOT
 
-    env = dict(os.environ, GJX_SMC_EXTRA_FIRST="1")
+    env = dict(os.environ, GJX_SMC_SCAN_MAX="0")
     r = subprocess.run([sys.executable, "-c", child, os.path.join(ROOT, "genjax-chi_amd"), os.path.join(ROOT, "tests"), ORACLE_LIB],
-                       env=env, capture_output=True, text=True, timeout=600)
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n,n_out", [(1_000_000, 1_000_000), (300_000, 300_000), (70_004, 20_000)])
+def test_resample_many_light_source_tiles(hip_ops, oracle_ops, impl, n, n_out):
+    """One particle holds 99.9 % of the mass and the rest is spread evenly: the thousand slots of the light particles
+    fall into one or two OUTPUT tiles whose sources are hundreds of tiles with a tooth each — those tiles take the
+    per-slot search, every other one the marks; a step's cost is bounded either way.  Ancestors are the oracle's."""
+    kb = KeyBatch(impl, 2, parent=(5, 6))
+    for frac_light in (1e-3, 5e-2):
+        lw = torch.zeros(n)
+        lw[n // 2 + 3] = math.log((1.0 - frac_light) / frac_light * n)
+        a, e, q = hip_ops.resample("systematic", kb, lw.to(hip_ops.device()), n_out)
+        b, eo, qo = oracle_ops.resample("systematic", kb, lw, n_out)
+        same(a, b, "ancestors")
+        same(q, qo, "total mass"); same(e, eo, "anchor")
+        cnt = torch.bincount(b.long(), minlength=n)
+        assert int(cnt.max()) > 0.9 * n_out and int((cnt > 0).sum()) > 0.5 * frac_light * n_out
 
 
 ESS_CASES = [("lgssm", 5000, 30, 0.5, 1), ("lgssm", 1024, 12, 0.9, 1), ("lgssm", 70000, 25, 0.3, 1), ("lgssm", 3000, 20, 0.5, 5),
@@ -738,12 +768,12 @@ ESS_CASES = [("lgssm", 5000, 30, 0.5, 1), ("lgssm", 1024, 12, 0.9, 1), ("lgssm",
 def test_smc_ess_adaptive(hip_ops, oracle_ops, impl, kind, n, T, thr, F):
     """gjx_smc_config.ess_threshold: resample only when ESS < thr * N.  The decision is a function of exact integer
     sums, so HIP and oracle take the same one at every step: flags, ancestors (identity on kept steps), accumulated
-    log-weights, per-step (max, q) and log Z are equal bit for bit — single filters, filter batches, > 2048 tiles."""
+    log-weights, per-step (e, q) and log Z are equal bit for bit — single filters, filter batches, > 1024 tiles."""
     mk = (lambda ops: W.LgssmSMC(ops, impl, 5, n, T, want_ancestors=True, filters=F, ess_threshold=thr)) if kind == "lgssm" else (
         lambda ops: W.HmmSMC(ops, impl, 5, n, T, n_states=16, want_ancestors=True, filters=F, ess_threshold=thr))
     hw, ow = mk(hip_ops), mk(oracle_ops)
     h, o = hw.result(hw.run()), ow.result(ow.run())
-    for key in ("resampled", "out_max", "out_q", "state", "logw", "ancestors"):
+    for key in ("resampled", "out_e", "out_q", "state", "logw", "ancestors"):
         same(h[key], o[key], key)
     assert h["log_z"] == o["log_z"]
     fl = o["resampled"] if F == 1 else o["resampled"][0]
@@ -760,19 +790,23 @@ def test_smc_ess_adaptive(hip_ops, oracle_ops, impl, kind, n, T, thr, F):
         assert abs(o["log_z"] - o["log_z_exact"]) < 0.8  # still an estimate of the evidence
 
 
-@pytest.mark.parametrize("impl", IMPLS)
-@pytest.mark.parametrize("n,F,ess", [(5000, 1, 0.0), (5000, 3, 0.0), (1500, 16, 0.0), (2_200_000, 1, 0.0), (9000, 2, 0.5)])
-def test_tile_sums_forms_agree(hip_ops, oracle_ops, impl, n, F, ess):
-    """The two forms of the tile-mass kernel (gjx_smc_config.tile_sums_form: 1 = a workgroup per tile, 2 = a wave per
-    tile) — ragged last tile, filter batches, more than 2048 tiles, adaptive filters — give the oracle's bits."""
-    T = 4 if n > 1_000_000 else 7
-    ow = W.LgssmSMC(oracle_ops, impl, 3, n, T, want_ancestors=True, filters=F, ess_threshold=ess)
-    o = ow.result(ow.run())
-    for form in (1, 2):
-        hw = W.LgssmSMC(hip_ops, impl, 3, n, T, want_ancestors=True, filters=F, ess_threshold=ess, tile_sums_form=form)
-        h = hw.result(hw.run())
-        for key in ("out_max", "out_q", "state", "logw", "ancestors"):
-            same(h[key], o[key], f"{key} (form {form})")
+@pytest.mark.parametrize("n", [1, 1023, 1024, 1025, 5000, 1_500_000])
+def test_tile_records(hip_ops, oracle_ops, n):
+    """gjx_tile_cdf / gjx_tile_merge: in-tile CDFs, tile records and their merge of arbitrary
+    log-weights — wide dynamic range, -inf / NaN / +inf entries, a ragged last tile — are the oracle's bits, and the
+    merged (e, Q) pair reproduces logsumexp."""
+    g = torch.Generator().manual_seed(n)
+    lw = torch.randn(n, generator=g) * 30
+    if n > 10:
+        lw[3] = float("-inf"); lw[7] = float("nan")
+    hc, hr = hip_ops.tile_cdf(lw.to(hip_ops.device()))
+    oc, orr = oracle_ops.tile_cdf(lw)
+    same(hc, oc, "in-tile cdf"); same(hr, orr, "records")
+    he, hq = hip_ops.tile_merge(hr)
+    oe, oq = oracle_ops.tile_merge(orr)
+    same(he, oe, "merged anchor"); same(hq, oq, "merged mass")
+    ref = float(torch.logsumexp(torch.nan_to_num(lw.double(), nan=float("-inf")), 0))
+    assert (int(oe) - 30) * math.log(2) + math.log(int(oq)) == pytest.approx(ref, abs=1e-5)
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -781,7 +815,7 @@ def test_smc_hmm(hip_ops, oracle_ops, impl, n, T, k):
     h = W.hmm_smc(hip_ops, impl, seed=9, n=n, T=T, n_states=k, want_ancestors=True)
     o = W.hmm_smc(oracle_ops, impl, seed=9, n=n, T=T, n_states=k, want_ancestors=True)
     same(h["ancestors"], o["ancestors"], "ancestors")
-    same(h["out_max"], o["out_max"]); same(h["out_q"], o["out_q"])
+    same(h["out_e"], o["out_e"]); same(h["out_q"], o["out_q"])
     same(h["state"], o["state"]); same(h["logw"], o["logw"])
 
 
@@ -833,12 +867,12 @@ def test_smc_filters_in_one_launch(hip_ops, oracle_ops, impl, kind, n, T):
     got = hb.result(hb.run())
     ob = mk(oracle_ops, F, 7)
     want = ob.result(ob.run())
-    for key in ("out_max", "out_q", "state", "logw", "ancestors"):
+    for key in ("out_e", "out_q", "state", "logw", "ancestors"):
         same(got[key], want[key], f"{key} (batched, HIP vs oracle)")
     for f in range(F):
         one = mk(hip_ops, 1, 7 + f)
         ref = one.result(one.run())
-        same(got["out_max"][f], ref["out_max"], "out_max"); same(got["out_q"][f], ref["out_q"], "out_q")
+        same(got["out_e"][f], ref["out_e"], "out_e"); same(got["out_q"][f], ref["out_q"], "out_q")
         same(got["state"][f], ref["state"], "state"); same(got["logw"][f], ref["logw"], "logw")
         same(got["ancestors"][:, f], ref["ancestors"], "ancestors")
         assert got["log_z"][f] == ref["log_z"]
@@ -1032,7 +1066,7 @@ def test_full_size_hmm(hip_ops):
         assert abs(r["log_z"] - r["log_z_exact"]) < 0.35, (r["log_z"], r["log_z_exact"])
         st = r["state"]
         assert int(st.min()) >= 0 and int(st.max()) < 256
-        assert bool(torch.isfinite(r["out_max"]).all()) and bool((r["out_q"] > 0).all())
+        assert bool(torch.isfinite(r["out_e"]).all()) and bool((r["out_q"] > 0).all())
 
 
 def test_full_size_batches(hip_ops):
@@ -1100,7 +1134,7 @@ def test_population_near_the_index_limit(hip_ops, oracle_ops):
     if free < 48 * 2**30 or psutil.virtual_memory().available < 96 * 2**30:
         pytest.skip("needs 48 GiB of device memory and 96 GiB of host memory")
     h = W.lgssm_smc(hip_ops, 1, seed=3, n=n, T=T)
-    got = {k: h[k].cpu() for k in ("out_max", "out_q", "state", "logw")}
+    got = {k: h[k].cpu() for k in ("out_e", "out_q", "state", "logw")}
     log_z = h["log_z"]
     del h
     torch.cuda.empty_cache()

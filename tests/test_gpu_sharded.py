@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from genjax._amd import workloads as W
-from test_distributed_gloo import _run_virtual_ranks, check_virtual_ranks
+from test_distributed_gloo import _run_virtual_ranks, check_degenerate_sharded, check_virtual_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -114,13 +114,13 @@ def test_rccl_communicator_one_rank(hip_ops):
     assert (int(e.cpu()[0]), int(q.cpu()[0])) == (whole["row_e"], whole["row_q"])
 
 
-@pytest.mark.parametrize("form", [1, 2])
-def test_sharded_tile_sums_forms(hip_ops, oracle_ops, form):
-    """Both forms of the tile-mass kernel under sharding (first_slot offsets into the global tile arrays): a wave per
-    tile and a workgroup per tile give the single-rank oracle filter's bits, adaptive filter included."""
-    check_virtual_ranks(hip_ops, "lgssm", 1, 3, 1024 * 3 * 5, 9, "ranges", ref_ops=oracle_ops, tile_sums_form=form)
-    check_virtual_ranks(hip_ops, "hmm", 0, 2, 1024 * 2 * 7, 9, "ranges", ref_ops=oracle_ops, ess_threshold=0.5,
-                        tile_sums_form=form)
+def test_sharded_collapse_without_idle_tiles(hip_ops, oracle_ops):
+    """a sharded filter whose weights collapse onto one tile while EVERY other tile keeps some
+    mass.  The output-centric step needs no idle workgroups: every rank's output tiles inside the heavy run read the
+    one heavy source tile (received through the shuffle) — equal to the single-rank oracle filter bit for bit."""
+    check_degenerate_sharded(hip_ops, 1, 4)
+    check_virtual_ranks(hip_ops, "lgssm", 1, 3, 1024 * 3 * 5, 9, "ranges", ref_ops=oracle_ops)
+    check_virtual_ranks(hip_ops, "hmm", 0, 2, 1024 * 2 * 7, 9, "ranges", ref_ops=oracle_ops, ess_threshold=0.5)
 
 
 def test_random_sharded_configurations_on_device(hip_ops, oracle_ops):

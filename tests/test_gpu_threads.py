@@ -69,10 +69,10 @@ for k in range(4):
             assert torch.equal(x, y), (k, "generic weight operations")
     for (a, b, c), (ta, tb, tc) in zip(out, tout):
         assert torch.equal(a, ta) and torch.equal(b, tb) and torch.equal(c, tc), k
-    for name in ("out_max", "out_q", "state", "logw", "ancestors"):
+    for name in ("out_e", "out_q", "state", "logw", "ancestors"):
         assert torch.equal(smc[name], tsmc[name]), (k, name)
     if hmm is not None:
-        for name in ("out_max", "out_q", "state", "logw"):
+        for name in ("out_e", "out_q", "state", "logw"):
             assert torch.equal(hmm[name], thmm[name]), (k, name)
 print("ok", ops.jit_stats())
 """

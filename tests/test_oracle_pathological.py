@@ -37,9 +37,11 @@ def test_weights(oracle_ops, impl):
         oracle_ops.logsumexp(w)
         oracle_ops.lse_rows(oracle_ops.row_stats(w))
     anc, _, _ = oracle_ops.resample("systematic", KeyBatch(impl, 2, parent=(5, 1)), weights(n)["all nan"], n)
-    assert int(anc.min()) == n - 1  # zero total mass: every slot takes the last particle
+    assert torch.equal(anc, torch.arange(n, dtype=anc.dtype))  # zero total mass: the population is kept
     anc, _, _ = oracle_ops.resample("systematic", KeyBatch(impl, 2, parent=(5, 1)), weights(n)["all -inf"], n)
-    assert torch.equal(anc, torch.arange(n, dtype=anc.dtype))  # uniform weights: the identity
+    assert torch.equal(anc, torch.arange(n, dtype=anc.dtype))  # likewise
+    anc, _, _ = oracle_ops.resample("systematic", KeyBatch(impl, 2, parent=(5, 1)), weights(n)["all -inf"], 3 * n)
+    assert torch.equal(anc, torch.arange(3 * n, dtype=anc.dtype) // 3)  # ... floor(j n / n_out) when n_out != n
     anc, _, _ = oracle_ops.resample("systematic", KeyBatch(impl, 2, parent=(5, 1)), weights(n)["one +inf"], n)
     assert int(anc.min()) == int(anc.max()) == 123
 

@@ -168,9 +168,9 @@ def test_resampling_invariants(oracle_ops, impl):
         assert float((cnt - w).abs().max()) < 1 + 1e-6  # counts in {floor, ceil}
         if n > 5:
             assert cnt[2] == 0
-        assert float(m) == float(lw.max())
-        # the (max, q) pair reproduces logsumexp
-        lse = float(m) + math.log(int(q)) - oracle_ops.frac_bits(n) * math.log(2)
+        # the merged anchor is the power of two just above the maximum; the (e, q) pair reproduces logsumexp
+        assert int(m) == math.ceil(float(lw.max() * torch.tensor(1.44269504088896341, dtype=torch.float32)))
+        lse = (int(m) - 30) * math.log(2) + math.log(int(q))
         assert lse == pytest.approx(float(torch.logsumexp(lw.double(), 0)), abs=1e-6)
         a2, _, _ = oracle_ops.resample("multinomial", key, lw, n_out)
         assert int(a2.min()) >= 0 and int(a2.max()) < n
@@ -270,7 +270,7 @@ def check_regression(ops):
         assert v.cpu().tolist() == r["bernoulli"]
         lw = torch.linspace(-3, 2, 37).to(dev)
         a, m, q = ops.resample("systematic", KeyBatch(impl, 2, parent=(5, 6)), lw)
-        assert a.cpu().tolist() == r["systematic_ancestors"] and int(q.cpu()) == r["systematic_q"]
+        assert a.cpu().tolist() == r["systematic_ancestors"] and int(q.cpu()) == r["systematic_q"] and int(m.cpu()) == r["systematic_e"]
         a, _, _ = ops.resample("multinomial", KeyBatch(impl, 2, parent=(5, 6)), lw, 12)
         assert a.cpu().tolist() == r["multinomial_ancestors"]
         assert int(ops.categorical_index(KeyBatch(impl, 2, parent=(5, 6)), lw, 0).cpu()) == r["categorical_index_gumbel"]
@@ -279,10 +279,10 @@ def check_regression(ops):
         assert g["q"] == r["gaussian10_q"]
         assert g["logw"][:4].cpu().view(torch.int32).tolist() == r["gaussian10_logw_head_bits"]
         s_ = W.lgssm_smc(ops, impl, seed=4, n=2048, T=6, want_ancestors=True)
-        assert s_["out_q"].cpu().tolist() == r["lgssm_q"]
+        assert s_["out_q"].cpu().tolist() == r["lgssm_q"] and s_["out_e"].cpu().tolist() == r["lgssm_e"]
         assert s_["ancestors"][5, :16].cpu().tolist() == r["lgssm_anc_t5_head"]
         h = W.hmm_smc(ops, impl, seed=5, n=2048, T=6, n_states=16)
-        assert h["out_q"].cpu().tolist() == r["hmm_q"]
+        assert h["out_q"].cpu().tolist() == r["hmm_q"] and h["out_e"].cpu().tolist() == r["hmm_e"]
 
 
 def check_regression_r02(ops):
@@ -304,11 +304,12 @@ def check_regression_r02(ops):
         assert hr["logw"][:4].cpu().view(torch.int32).tolist() == r["scan_hmm_logw_head_bits"]
         ad = W.lgssm_smc(ops, impl, seed=8, n=3000, T=16, want_ancestors=True, ess_threshold=0.5)
         assert ad["resampled"].cpu().tolist() == r["ess_flags"] and ad["out_q"].cpu().tolist() == r["ess_q"]
+        assert ad["out_e"].cpu().tolist() == r["ess_e"]
         assert ad["logw"][:4].cpu().view(torch.int32).tolist() == r["ess_logw_head_bits"]
         y = np.array([0.1, 25.0, -40.0, -39.5, 60.0, 60.2], dtype=np.float32)
         sk, rk = W.smc_key_schedule(prng.key(11, impl), 6)
         col = ops.smc_run_lgssm(impl, 20000, sk, rk, abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.05), y, True)
-        assert col[1].cpu().tolist() == r["collapse_q"]
+        assert col[1].cpu().tolist() == r["collapse_q"] and col[0].cpu().tolist() == r["collapse_e"]
         assert int(col[4][2].unique().numel()) == r["collapse_anc_t2_distinct"]
         assert col[4][5, :8].cpu().tolist() == r["collapse_anc_t5_head"]
 
