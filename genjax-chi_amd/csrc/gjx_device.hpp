@@ -695,7 +695,7 @@ GJX_HD int64_t teeth_below(uint64_t C, double scale, double u0, int64_t n_out) {
   const double c = __builtin_ceil(P - u0);
   if (!(c > 0.0)) return 0;
   if (c >= (double)n_out) return n_out;
-  return (int64_t)c;
+  return (int64_t)(int32_t)c;  // (n_out < 2^31: one v_cvt_i32_f64 instead of the 64-bit conversion sequence)
 }
 GJX_HD double u0_from_bits(uint64_t U) { return (double)(U >> 11) * 0x1.0p-53; }
 
@@ -827,21 +827,24 @@ GJX_DEV int block_sum_int(int v, int* sh) {
 // Systematic resampling, OUTPUT-tile-centric, one launch per SMC step.
 //
 // Weights are TILE-ANCHORED fixed point: tile t (1024 consecutive particles) is anchored at the power of two just
-// above its own maximum, e_t = row_anchor(max_t lw); q_i = rowfix(lw_i, e_t) (30 fractional bits); c_i = the
-// INCLUSIVE prefix of q inside the tile (u64, stored per particle: the "in-tile CDF"); the tile's record is
-// (e_t, S_t = c_last).  All of that is known to the workgroup that PRODUCES the tile's log-weights — no grid-wide
-// maximum is needed, so the kernel that propagates a population also emits what the next resampling reads, and a
-// bootstrap step is ONE launch.  The consumer merges the records: e = max e_t, d_t = e - e_t, M_t = S_t >> d_t,
-// P_t = sum_{t' < t} M_t', total Q = P_ntiles, and the GLOBAL fixed-point CDF is C_i = P_t + (c_i >> d_t): exact
-// integers, the same bits for every tiling of the work, every number of ranks and the oracle.
+// above its own maximum, e_t = row_anchor(max_t lw); q_i = rowfix(lw_i, e_t) (30 fractional bits, one u32 per particle:
+// what a step stores instead of the log-weight); the tile's record holds S_t = sum q, e_t, the running sum of q at
+// every 64th particle (16 sub-prefixes) and the ESS sums.  All of that is known to the workgroup that PRODUCES the
+// tile's log-weights — no grid-wide maximum is needed, so the kernel that propagates a population also emits what the
+// next resampling reads, and a bootstrap step is ONE launch.  The consumer merges the records: e = max e_t, d_t = e - e_t,
+// M_t = S_t >> d_t, P_t = sum_{t' < t} M_t', total Q = P_ntiles: exact integers, the same bits for every tiling of the
+// work, every number of ranks and the oracle.  Teeth of the comb below particle i of tile t (c_i = the running sum of q
+// inside the tile, exact in float64): n_i = min(clamp(ceil(fma(c_i, scale 2^-d_t, P_t scale - u0))), nhi_t), the tile
+// itself ending at nhi_t = clamp(ceil(P_{t+1} scale - u0)) (comb_* below): monotone, and consistent across tiles.
 //
 // Workgroup b owns OUTPUT slots [b*1024, (b+1)*1024): from the merged records it finds the source tiles whose teeth
-// fall into its slots (ancestors are monotone: a contiguous range, typically 2-3 tiles), turns their stored CDFs into
-// teeth counts, marks where every source's run of slots starts, spreads the marks with a max-scan, gathers the
-// ancestors' state, propagates, weights, and emits its own tile's CDF and record.  Collapse-proof by construction:
-// under weight collapse every output tile reads the same heavy source tile; when an output tile has MANY light
-// sources (more than kScanMax tiles with a tooth in it) every slot finds its ancestor by binary search of the tile
-// prefix and of one stored in-tile CDF instead — the cost of a step is bounded whatever the weights are.
+// fall into its slots (ancestors are monotone: a contiguous range, typically 2-3 tiles), re-scans their stored weights
+// (integer adds: no exponential), turns the running sums into teeth counts, marks where every source's run of slots
+// starts, spreads the marks with a max-scan, gathers the ancestors' state, propagates, weights, and emits its own tile's
+// weights and record.  Collapse-proof by construction: under weight collapse every output tile reads the same heavy
+// source tile; when an output tile has MANY light sources (more than kScanMax tiles with a tooth in it) every slot finds
+// its ancestor by binary search of the tile prefix, then of the tile's 16 sub-prefixes, then a walk over at most 64
+// stored weights — the cost of a step is bounded whatever the weights are.
 // ------------------------------------------------------------------------------------------------
 // Several independent filters stepping in ONE launch (the bootstrap filter vmapped over keys): workgroup
 // f * tiles + b serves output tile b of filter f.  Filter f's particles, records, (e, q) results and keys lie
@@ -860,11 +863,16 @@ constexpr int kTileFrac = kRowFrac;   // fractional bits of the tile-anchored we
 constexpr int kEssShift = kTileFrac - 16;
 constexpr int kMaxLdsTiles = 1024;    // populations up to 2^20 particles keep the merged tile prefix in LDS
 constexpr int kScanMax = 16;          // an output tile with more source tiles than this searches per slot
+constexpr int kSubs = 16;             // sub-prefixes per tile: the running sum of q after every 64th particle
+constexpr int kSubLen = kTile / kSubs;
 struct alignas(16) TileRec {
-  uint64_t s;   // S_t: the tile's mass relative to its own anchor (= the last entry of its in-tile CDF)
+  uint64_t s;   // S_t: the tile's mass relative to its own anchor
   int32_t e;    // e_t (kRowEmpty: no mass)
   int32_t pad;
+  uint64_t r1, r2;        // ESS sums of the tile (tile-anchored): sum r_i, sum r_i^2, r_i = q_i >> 14
+  uint64_t sub[kSubs];    // sub[b] = sum of q over the tile's particles [0, 64 (b + 1))  (sub[15] = S_t)
 };
+static_assert(sizeof(TileRec) == 160, "gjx.h gjx_tile_rec");
 // shift of a tile's fixed point relative to the merged anchor e (>= every e_t): 64 = the tile carries no mass
 GJX_HD int tile_shift(int32_t e, int32_t et) {
   if (et == kRowEmpty) return 64;
@@ -877,10 +885,9 @@ GJX_HD uint64_t shr64(uint64_t v, int d) { return d >= 64 ? 0 : v >> d; }
 GJX_HD uint64_t prefix_words(uint64_t ntiles) { return ntiles + 4; }
 
 struct ResampleArgs {
-  const uint64_t* cdf = nullptr;        // [n] in-tile inclusive CDF of the SOURCE weights
+  const uint32_t* qw = nullptr;         // [n] tile-anchored fixed-point weights of the SOURCE population
   const float* lw = nullptr;            // [n] source log-weights (adaptive filters: a kept step accumulates them)
   const TileRec* recs = nullptr;        // [ntiles] source records
-  const uint64_t* tile_ess = nullptr;   // [2 ntiles] (R1_t, R2_t), tile-anchored (adaptive filters)
   uint64_t n = 0, ntiles = 0;
   uint64_t n_out = 0;                   // number of comb teeth (global output slots)
   int64_t out_lo = 0, out_hi = 0;       // slots this launch serves (out_lo a multiple of the tile size)
@@ -894,11 +901,11 @@ struct ResampleArgs {
   FilterBatch fb;                       // several filters per launch (n, ntiles, n_out, out_lo/out_hi are then PER FILTER)
   double ess_thr = 0.0;                 // threshold * n_total, 0 = resample always
   // what the step emits for the NEXT resampling (policies with weights)
-  uint64_t* cdf_out = nullptr;          // [n_local] (slot - out_lo)
+  uint32_t* qw_out = nullptr;           // [n_local] (slot - out_lo)
   float* logw_out = nullptr;            // nullable [n_local]
   TileRec* recs_out = nullptr;          // GLOBAL [tiles of n_out]: entry of every output tile served
-  uint64_t* ess_out = nullptr;          // nullable GLOBAL [2 tiles]
   int scan_max = kScanMax;              // test knob: 0 = every output tile takes the per-slot search
+  int debug_stop = 0;                   // profiling knob (GJX_SMC_DEBUG_STOP): leave the kernel after phase k
 };
 
 // resample iff ESS = R1^2 / R2 < thr (thr in particles); every backend evaluates exactly these double operations
@@ -910,6 +917,27 @@ GJX_HD bool ess_says_resample(uint64_t r1, uint64_t r2, double thr) {
 }
 // the reduced weight of the ESS sums: the top 16 bits of the tile-anchored fixed-point weight
 GJX_HD uint64_t ess_r(uint64_t q) { return q >> kEssShift; }
+
+GJX_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
+// ---- the comb: every backend evaluates exactly these float64 operations ------------------------------
+// teeth (j + u0), j in [0, n_out), strictly below a position: ceil, clamped to [0, n_out] (a NaN counts as 0)
+GJX_HD int32_t comb_clamp(double t, int32_t n_out) {
+  const double c = __builtin_ceil(t);
+  if (!(c > 0.0)) return 0;
+  if (c >= (double)n_out) return n_out;
+  return (int32_t)c;
+}
+// the position of a tile's start: P_t scale - u0 (two roundings)
+GJX_HD double comb_base(uint64_t P, double scale, double u0) { return (double)P * scale - u0; }
+// teeth below the start of the tile whose exclusive mass prefix is P
+GJX_HD int32_t comb_tile(uint64_t P, double scale, double u0, int32_t n_out) { return comb_clamp(comb_base(P, scale, u0), n_out); }
+// teeth below a particle inside a tile: c = running sum of q up to and including it (exact in float64), scale_t =
+// scale 2^-d_t, base = comb_base of the tile, nhi = teeth below the tile's end (the cap keeps tiles consistent)
+GJX_HD int32_t comb_in_tile(double c, double scale_t, double base, int32_t nhi, int32_t n_out) {
+  const int32_t t = comb_clamp(__builtin_fma(c, scale_t, base), n_out);
+  return t < nhi ? t : nhi;
+}
+GJX_HD double comb_tile_scale(double scale, int d) { return d >= 64 ? 0.0 : scale * u2d((uint64_t)(1023 - d) << 52); }
 // ------------------------------------------------------------------------------------------------
 // Row-anchored log-sum-exp of a whole pass: e = max e_b; buckets B_d = sum of S_b over
 // the rows with e - e_b == d (d < 64, exact); Q = sum_d B_d >> d; lse = e ln2 + log(Q 2^-30).  The
@@ -1117,17 +1145,15 @@ GJX_DEV void policy_store_quad(Policy& P, int64_t jq, int64_t out_lo, const uint
     if (ok[u]) P.store(jq + u, out_lo, anc[u], o[u]);
 }
 
-// ---- emission: the in-tile CDF and the record of the tile a workgroup has just produced ---------------------------
+// ---- emission: the fixed-point weights and the record of the tile a workgroup has just produced -------------------
 // w[r], ok[r]: the log-weights of the thread's four consecutive slots (tile offset 4 tid + r) and whether the slot
-// exists.  cdf_at / logw_at: where the thread's first slot goes (logw_at nullable); rec_at / ess_at: the tile's record.
+// exists.  qw_at / logw_at: where the thread's first slot goes (logw_at nullable); rec_at: the tile's record.
 // Called by every thread of the workgroup (two barriers inside).
-template <bool ESS>
-GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint64_t* cdf_at, float* logw_at, TileRec* rec_at,
-                       uint64_t* ess_at) {
+GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint32_t* qw_at, float* logw_at, TileRec* rec_at) {
   constexpr int kW = kBlock / kWave;
   __shared__ float em_f[kW];
   __shared__ uint64_t em_q[3 * kW];
-  static_assert(kPer == 4, "four consecutive slots per lane");
+  static_assert(kPer == 4 && kSubLen == 64, "four consecutive slots per lane: a 64-particle block is one DPP row of 16 lanes");
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   float tm = -__builtin_inff();
 #pragma unroll
@@ -1139,38 +1165,32 @@ GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint64_t*
 #pragma unroll
   for (int i = 1; i < kW; ++i) m = em_f[i] > m ? em_f[i] : m;
   const int32_t e = row_anchor(m);
-  uint64_t c[kPer];
+  uint32_t q[kPer];
   uint64_t run = 0, a1 = 0, a2 = 0;
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {
-    const uint64_t q = ok[r] ? rowfix(w[r], e) : 0;
-    run += q;
-    c[r] = run;
-    if (ESS) {
-      const uint64_t rr = ess_r(q);
-      a1 += rr;
-      a2 += rr * rr;
-    }
+    q[r] = ok[r] ? (uint32_t)rowfix(w[r], e) : 0u;
+    run += q[r];
+    const uint64_t rr = ess_r(q[r]);
+    a1 += rr;
+    a2 += rr * rr;
   }
   const uint64_t incl = wave_scan_incl(run);
-  if (ESS) { a1 = wave_sum(a1); a2 = wave_sum(a2); }
-  if (lane == 63) {
-    em_q[wv] = incl;
-    if (ESS) { em_q[kW + wv] = a1; em_q[2 * kW + wv] = a2; }
-  }
+  a1 = wave_sum(a1);
+  a2 = wave_sum(a2);
+  if (lane == 63) { em_q[wv] = incl; em_q[kW + wv] = a1; em_q[2 * kW + wv] = a2; }
   __syncthreads();
-  uint64_t base = incl - run;
+  uint64_t base = 0;
 #pragma unroll
   for (int i = 0; i < kW; ++i)
     if (i < wv) base += em_q[i];
   const bool all = ok[0] && ok[1] && ok[2] && ok[3];
-  if (all && (((uintptr_t)cdf_at & 15) == 0)) {
-    reinterpret_cast<ulonglong2*>(cdf_at)[0] = make_ulonglong2(base + c[0], base + c[1]);
-    reinterpret_cast<ulonglong2*>(cdf_at)[1] = make_ulonglong2(base + c[2], base + c[3]);
+  if (all && (((uintptr_t)qw_at & 15) == 0)) {
+    *reinterpret_cast<uint4*>(qw_at) = make_uint4(q[0], q[1], q[2], q[3]);
   } else {
 #pragma unroll
     for (int r = 0; r < kPer; ++r)
-      if (ok[r]) cdf_at[r] = base + c[r];
+      if (ok[r]) qw_at[r] = q[r];
   }
   if (logw_at) {
     if (all && (((uintptr_t)logw_at & 15) == 0)) {
@@ -1181,44 +1201,34 @@ GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint64_t*
         if (ok[r]) logw_at[r] = w[r];
     }
   }
+  // the record: the last lane of every row of 16 lanes holds the running sum after its 64-particle block
+  if ((lane & 15) == 15) rec_at->sub[tid >> 4] = base + incl;
   if (tid == kBlock - 1) {
-    TileRec rec;
-    rec.s = base + c[kPer - 1];
-    rec.e = e;
-    rec.pad = 0;
-    *rec_at = rec;
-  }
-  if (ESS && ess_at && tid == 0) {
     uint64_t t1 = 0, t2 = 0;
 #pragma unroll
     for (int i = 0; i < kW; ++i) { t1 += em_q[kW + i]; t2 += em_q[2 * kW + i]; }
-    ess_at[0] = t1;
-    ess_at[1] = t2;
+    rec_at->s = base + incl;
+    rec_at->e = e;
+    rec_at->pad = 0;
+    rec_at->r1 = t1;
+    rec_at->r2 = t2;
   }
 }
 
 // Where a step's weights go for the NEXT resampling (kernel argument of the init kernels; the resample kernel carries
-// the same fields in ResampleArgs): local CDF / log-weight columns, the GLOBAL record and ESS arrays.
+// the same fields in ResampleArgs): local weight / log-weight columns, the GLOBAL record array.
 struct EmitOut {
-  uint64_t* cdf;   // [n_local]
+  uint32_t* qw;    // [n_local]
   float* logw;     // nullable [n_local]
   TileRec* recs;   // GLOBAL [tiles]
-  uint64_t* ess;   // nullable GLOBAL [2 tiles] (adaptive filters)
 };
 GJX_DEV void emit_init_tile(const float (&w)[kPer], const bool (&ok)[kPer], const EmitOut& em, uint64_t loc, uint64_t gtile) {
-  if (em.ess) emit_tile<true>(w, ok, em.cdf + loc, em.logw ? em.logw + loc : nullptr, em.recs + gtile, em.ess + 2 * gtile);
-  else emit_tile<false>(w, ok, em.cdf + loc, em.logw ? em.logw + loc : nullptr, em.recs + gtile, nullptr);
+  emit_tile(w, ok, em.qw + loc, em.logw ? em.logw + loc : nullptr, em.recs + gtile);
 }
 GJX_DEV void select_filter_emit(EmitOut& em, const FilterBatch& fb, uint32_t f) {
-  em.cdf += (uint64_t)f * fb.stride;
+  em.qw += (uint64_t)f * fb.stride;
   if (em.logw) em.logw += (uint64_t)f * fb.stride;
   em.recs += (uint64_t)f * fb.tiles;
-  if (em.ess) em.ess += 2 * (uint64_t)f * fb.tiles;
-}
-
-// teeth below source i whose global CDF value is C: the last real particle (and any padding after it) closes the comb
-GJX_DEV int64_t teeth_at(uint64_t i, uint64_t n, uint64_t C, double scale, double u0, int64_t n_out) {
-  return i + 1 >= n ? n_out : teeth_below(C, scale, u0, n_out);
 }
 
 // Exclusive block max-scan of one u32 per thread (identity 0).  `sh` needs 4 words.
@@ -1240,10 +1250,12 @@ GJX_DEV uint32_t block_scan_umax_excl(uint32_t v, uint32_t* sh) {
 template <int IMPL, class Policy, bool ADAPTIVE = true>
 GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   constexpr int kW = kBlock / kWave;
+  constexpr int kBatch = 2;                      // source tiles scanned per round (their loads are in flight together)
   __shared__ uint64_t sh_pre[kMaxLdsTiles + 1];  // merged exclusive tile prefix (populations up to kMaxLdsTiles tiles)
   __shared__ uint8_t sh_d[kMaxLdsTiles];         // every tile's shift to the merged anchor
   __shared__ uint32_t marks[kTile];              // run-start marks of the ancestor search
   __shared__ uint64_t sh_scan[3 * kW];
+  __shared__ uint64_t sh_src[kBatch][kW];        // wave totals of the source tiles being scanned
   __shared__ int32_t sh_e[kW];
   __shared__ uint32_t sh_u[kW];
   __shared__ uint32_t sh_klo, sh_khi, sh_cnt;
@@ -1252,32 +1264,28 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   uint64_t b = blockIdx.x;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   // this workgroup's filter: local views of the per-filter arrays, keys and results
-  const uint64_t* cdf_all = A.cdf;
+  const uint32_t* qw_all = A.qw;
   const float* lw_all = A.lw;
   const TileRec* recs = A.recs;
-  const uint64_t* tile_ess = A.tile_ess;
   int32_t* e_out = A.e_out;
   uint64_t* q_out = A.q_out;
   int32_t* resampled_out = A.resampled_out;
-  uint64_t* cdf_out = A.cdf_out;
+  uint32_t* qw_out = A.qw_out;
   float* logw_out = A.logw_out;
   TileRec* recs_out = A.recs_out;
-  uint64_t* ess_out = A.ess_out;
   Key rkey = A.rkey;
   if (A.fb.n_filters > 1) {
     const uint32_t f = (uint32_t)(b / A.fb.tiles);
     b -= (uint64_t)f * A.fb.tiles;
-    cdf_all += (uint64_t)f * A.fb.stride;
+    qw_all += (uint64_t)f * A.fb.stride;
     if (lw_all) lw_all += (uint64_t)f * A.fb.stride;
     recs += (uint64_t)f * A.fb.tiles;
-    if (tile_ess) tile_ess += 2 * (uint64_t)f * A.fb.tiles;
     if (e_out) e_out += (uint64_t)f * A.fb.mq_stride;
     if (q_out) q_out += (uint64_t)f * A.fb.mq_stride;
     if (resampled_out) resampled_out += (uint64_t)f * A.fb.mq_stride;
-    if (cdf_out) cdf_out += (uint64_t)f * A.fb.stride;
+    if (qw_out) qw_out += (uint64_t)f * A.fb.stride;
     if (logw_out) logw_out += (uint64_t)f * A.fb.stride;
     if (recs_out) recs_out += (uint64_t)f * A.fb.tiles;
-    if (ess_out) ess_out += 2 * (uint64_t)f * A.fb.tiles;
     rkey = A.fb.rkey[f];
     P.select_filter((uint64_t)f * A.fb.stride, A.fb.step_key[f]);
   }
@@ -1286,14 +1294,15 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   const int64_t j0 = (int64_t)(ot * kTile);
   const int64_t j1 = j0 + (int64_t)kTile < A.out_hi ? j0 + (int64_t)kTile : A.out_hi;
   const int64_t jq = j0 + (int64_t)kPer * tid;
+  const int32_t n_out = (int32_t)A.n_out;
 
   // ---- the source records (issued first; the policy's ancestor-independent work runs under their latency) --------
   constexpr int kC = kMaxLdsTiles / kBlock;  // tiles per thread of the in-kernel merge
   const bool lds_prefix = A.prefix == nullptr;  // (launch-uniform)
   const uint64_t c_per = (A.ntiles + kBlock - 1) / kBlock;
   const uint64_t k0 = (uint64_t)tid * c_per;
-  TileRec rv[kC];
-  uint64_t ev1[kC], ev2[kC];
+  uint64_t rs_[kC], ev1[kC], ev2[kC];
+  int32_t re_[kC];
   if (lds_prefix) {
 #pragma unroll
     for (int i = 0; i < kC; ++i) {
@@ -1301,19 +1310,22 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
       const bool in = (uint64_t)i < c_per && k < A.ntiles;
       if (in) {
         const uint4 raw = *reinterpret_cast<const uint4*>(recs + k);
-        rv[i].s = ((uint64_t)raw.y << 32) | raw.x;
-        rv[i].e = (int32_t)raw.z;
+        rs_[i] = ((uint64_t)raw.y << 32) | raw.x;
+        re_[i] = (int32_t)raw.z;
       } else {
-        rv[i].s = 0;
-        rv[i].e = kRowEmpty;
+        rs_[i] = 0;
+        re_[i] = kRowEmpty;
       }
-      ev1[i] = adaptive && in ? tile_ess[2 * k] : 0;
-      ev2[i] = adaptive && in ? tile_ess[2 * k + 1] : 0;
+      ev1[i] = adaptive && in ? recs[k].r1 : 0;
+      ev2[i] = adaptive && in ? recs[k].r2 : 0;
     }
   }
 #pragma unroll
   for (int r = 0; r < kPer; ++r) marks[tid + r * kBlock] = 0;
   if (tid == 0) { sh_klo = ~0u; sh_khi = 0; sh_cnt = 0; }
+  // (under the latency of the record loads) the comb offset and whatever the policy can do without its ancestors
+  const Stream<IMPL> rstream(rkey, A.rkey_has_fold != 0, A.rkey_fold);
+  const double u0 = u0_from_bits(rstream.bits64(0));
   policy_prefetch(P, jq, 0);
 
   // ---- merge: anchor, shifted masses, exclusive prefix, total, ESS sums ------------------------------------------
@@ -1323,8 +1335,8 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   uint64_t chunk_pre = 0, chunk_mass = 0;
   if (lds_prefix) {
 #pragma unroll
-    for (int i = 0; i < kC; ++i) e = rv[i].e > e ? rv[i].e : e;
-    e = (int32_t)wave_last_u32(wave_scan_u32((uint32_t)e ^ 0x80000000u, 0u, [](uint32_t a, uint32_t x) { return x > a ? x : a; })) ^ (int32_t)0x80000000u;
+    for (int i = 0; i < kC; ++i) e = re_[i] > e ? re_[i] : e;
+    e = (int32_t)(wave_last_u32(wave_scan_u32((uint32_t)e ^ 0x80000000u, 0u, [](uint32_t a, uint32_t x) { return x > a ? x : a; })) ^ 0x80000000u);
     if (lane == 0) sh_e[wv] = e;
     __syncthreads();
     e = sh_e[0];
@@ -1334,8 +1346,8 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     int dsh[kC];
 #pragma unroll
     for (int i = 0; i < kC; ++i) {
-      dsh[i] = tile_shift(e, rv[i].e);
-      mass[i] = shr64(rv[i].s, dsh[i]);
+      dsh[i] = tile_shift(e, re_[i]);
+      mass[i] = shr64(rs_[i], dsh[i]);
       chunk_mass += mass[i];
       if (adaptive) { l1 += shr64(ev1[i], dsh[i]); l2 += shr64(ev2[i], 2 * dsh[i]); }
     }
@@ -1377,6 +1389,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   const bool resample = !adaptive || ess_says_resample(r1, r2, A.ess_thr);
   if (resampled_out && b == 0 && tid == 0) resampled_out[0] = resample ? 1 : 0;
   policy_stage(P, 0);  // (every path below passes a barrier before the policy computes)
+  if (A.debug_stop == 1) return;
 
   auto pre_at = [&](uint64_t k) -> uint64_t { return lds_prefix ? sh_pre[k] : A.prefix[k]; };
   auto shift_at = [&](uint64_t k) -> int { return lds_prefix ? (int)sh_d[k] : tile_shift(e, recs[k].e); };
@@ -1407,28 +1420,24 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     }
     __syncthreads();
   } else {
-    const Stream<IMPL> rs(rkey, A.rkey_has_fold != 0, A.rkey_fold);
-    const double u0 = u0_from_bits(rs.bits64(0));
     const double scale = (double)A.n_out / (double)tot;
-    const int64_t n_out = (int64_t)A.n_out;
-    auto nhi_of = [&](uint64_t k) -> int64_t {  // teeth below the END of tile k
-      return k + 1 >= A.ntiles ? n_out : teeth_below(pre_at(k + 1), scale, u0, n_out);
-    };
+    auto nlo_of = [&](uint64_t k) -> int32_t { return comb_tile(pre_at(k), scale, u0, n_out); };  // teeth below the START of tile k
+    auto nhi_of = [&](uint64_t k) -> int32_t { return k + 1 >= A.ntiles ? n_out : nlo_of(k + 1); };  // ... below its END
     // ---- which source tiles own a tooth in [j0, j1)? -------------------------------------------------------------
     uint64_t k_lo = 0, k_hi = 0;
     if (lds_prefix) {
       __syncthreads();  // sh_pre / sh_d complete
-      const int64_t c_lo = teeth_below(chunk_pre, scale, u0, n_out);
-      const int64_t c_hi = k0 + c_per >= A.ntiles ? n_out : teeth_below(chunk_pre + chunk_mass, scale, u0, n_out);
+      const int32_t c_lo = comb_tile(chunk_pre, scale, u0, n_out);
+      const int32_t c_hi = k0 + c_per >= A.ntiles ? n_out : comb_tile(chunk_pre + chunk_mass, scale, u0, n_out);
       if (k0 < A.ntiles && c_hi > j0 && c_lo < j1 && c_hi > c_lo) {
-        int64_t lo_t = c_lo;
+        int32_t lo_t = c_lo;
         uint64_t run = chunk_pre;
 #pragma unroll
         for (int i = 0; i < kC; ++i) {
           const uint64_t k = k0 + i;
           if ((uint64_t)i < c_per && k < A.ntiles) {
             run += mass[i];
-            const int64_t hi_t = k + 1 >= A.ntiles ? n_out : teeth_below(run, scale, u0, n_out);
+            const int32_t hi_t = k + 1 >= A.ntiles ? n_out : comb_tile(run, scale, u0, n_out);
             if (hi_t > lo_t && hi_t > j0 && lo_t < j1) {
               atomicMin(&sh_klo, (uint32_t)k);
               atomicMax(&sh_khi, (uint32_t)k);
@@ -1469,7 +1478,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
       while (hi - lo >= (uint64_t)kBlock) {
         const uint64_t stride = (hi - lo + kBlock) / kBlock;
         const uint64_t kk = lo + (uint64_t)tid * stride;  // the START of sub-block tid
-        if (kk <= hi && teeth_below(pre_at(kk), scale, u0, n_out) < j1) atomicMax(&sh_khi, (uint32_t)tid);
+        if (kk <= hi && nlo_of(kk) < j1) atomicMax(&sh_khi, (uint32_t)tid);
         __syncthreads();
         const uint64_t i = sh_khi;
         __syncthreads();
@@ -1480,7 +1489,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         lo = nlo;
         __syncthreads();
       }
-      if (lo + (uint64_t)tid <= hi && teeth_below(pre_at(lo + (uint64_t)tid), scale, u0, n_out) < j1) atomicMax(&sh_khi, (uint32_t)tid);
+      if (lo + (uint64_t)tid <= hi && nlo_of(lo + (uint64_t)tid) < j1) atomicMax(&sh_khi, (uint32_t)tid);
       __syncthreads();
       k_hi = lo + sh_khi;
       // the tiles of [k_lo, k_hi] that do own a tooth here (up to 4 per thread; a wider range searches per slot)
@@ -1489,7 +1498,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         for (int i = 0; i < 4; ++i) {
           const uint64_t k = k_lo + (uint64_t)tid + (uint64_t)i * kBlock;
           if (k <= k_hi) {
-            const int64_t lo_t = teeth_below(pre_at(k), scale, u0, n_out), hi_t = nhi_of(k);
+            const int32_t lo_t = nlo_of(k), hi_t = nhi_of(k);
             if (hi_t > lo_t && hi_t > j0 && lo_t < j1) {
               const uint32_t pos = atomicAdd(&sh_cnt, 1u);
               if (pos < (uint32_t)kScanMax) sh_list[pos] = (uint32_t)k;
@@ -1502,47 +1511,66 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
       __syncthreads();
     }
     const uint32_t n_src = sh_cnt;
+    if (A.debug_stop == 2) return;
     if (n_src <= (uint32_t)A.scan_max) {
-      // ---- few source tiles: every source marks the slot where its run starts; a max-scan spreads the marks -------
-      for (uint32_t li = 0; li < n_src; li += 2) {  // two tiles per round: their loads are in flight together
-        uint64_t kk[2], pre[2];
-        int dd[2];
-        bool live[2];
-        uint64_t c[2][kPer + 1];
+      // ---- few source tiles: re-scan their stored weights (integer adds), every source marks the slot where its run
+      // starts; a max-scan spreads the marks ---------------------------------------------------------------------------
+      for (uint32_t li = 0; li < n_src; li += kBatch) {
+        uint64_t kk[kBatch];
+        bool live[kBatch];
+        uint32_t q[kBatch][kPer];
+        uint64_t run[kBatch], incl[kBatch];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < kBatch; ++h) {
           live[h] = li + h < n_src;
           kk[h] = live[h] ? sh_list[li + h] : 0;
-          pre[h] = live[h] ? pre_at(kk[h]) : 0;
-          dd[h] = live[h] ? shift_at(kk[h]) : 64;
           const uint64_t sbase = kk[h] * kTile + (uint64_t)kPer * tid;
           if (live[h] && sbase + kPer <= A.n) {
-            const ulonglong2 v0 = reinterpret_cast<const ulonglong2*>(cdf_all + sbase)[0];
-            const ulonglong2 v1 = reinterpret_cast<const ulonglong2*>(cdf_all + sbase)[1];
-            c[h][1] = v0.x; c[h][2] = v0.y; c[h][3] = v1.x; c[h][4] = v1.y;
+            const uint4 v = *reinterpret_cast<const uint4*>(qw_all + sbase);
+            q[h][0] = v.x; q[h][1] = v.y; q[h][2] = v.z; q[h][3] = v.w;
           } else {
 #pragma unroll
-            for (int r = 0; r < kPer; ++r) c[h][r + 1] = live[h] && sbase + r < A.n ? cdf_all[sbase + r] : 0;
+            for (int r = 0; r < kPer; ++r) q[h][r] = live[h] && sbase + r < A.n ? qw_all[sbase + r] : 0u;
           }
-          c[h][0] = live[h] && tid > 0 && sbase - 1 < A.n ? cdf_all[sbase - 1] : 0;
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < kBatch; ++h) {
+          run[h] = (uint64_t)q[h][0] + q[h][1] + q[h][2] + q[h][3];
+          incl[h] = wave_scan_incl(run[h]);
+          if (lane == 63) sh_src[h][wv] = incl[h];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < kBatch; ++h) {
           if (!live[h]) continue;
-          const uint64_t sbase = kk[h] * kTile + (uint64_t)kPer * tid;
-          const uint32_t id_base = ((uint32_t)(kk[h] - k_lo) << 10) + (uint32_t)(kPer * tid) + 1u;
-          // teeth below the source before this thread's first (the tile's start for thread 0)
-          int64_t start = tid == 0 ? teeth_below(pre[h], scale, u0, n_out)
-                                   : teeth_at(sbase - 1, A.n, pre[h] + shr64(c[h][0], dd[h]), scale, u0, n_out);
+          uint64_t base_c = incl[h] - run[h];  // running sum before this thread's first source
+#pragma unroll
+          for (int i = 0; i < kW; ++i)
+            if (i < wv) base_c += sh_src[h][i];
+          const uint64_t k = kk[h];
+          const uint64_t sbase = k * kTile + (uint64_t)kPer * tid;
+          const uint64_t pre = pre_at(k);
+          const int d = shift_at(k);
+          const double scale_t = comb_tile_scale(scale, d), tb = comb_base(pre, scale, u0);
+          const int32_t nhi = nhi_of(k);
+          const uint32_t id_base = ((uint32_t)(k - k_lo) << 10) + (uint32_t)(kPer * tid) + 1u;
+          double c = (double)base_c;
+          // teeth below the source before this thread's first (the tile's start for thread 0: c == 0)
+          int32_t start = comb_in_tile(c, scale_t, tb, nhi, n_out);
 #pragma unroll
           for (int r = 0; r < kPer; ++r) {
-            const int64_t nr = teeth_at(sbase + r, A.n, pre[h] + shr64(c[h][r + 1], dd[h]), scale, u0, n_out);
-            if (nr > start && nr > j0 && start < j1) marks[(start > j0 ? start : j0) - j0] = id_base + (uint32_t)r;
+            c += (double)q[h][r];
+            // the tile's last particle (and any padding after the population's last) ends at the tile's end
+            const bool last = kPer * tid + r == kTile - 1 || sbase + r + 1 >= A.n;
+            const int32_t nr = last ? nhi : comb_in_tile(c, scale_t, tb, nhi, n_out);
+            if (nr > start && nr > j0 && start < j1) marks[(start > j0 ? start : (int32_t)j0) - (int32_t)j0] = id_base + (uint32_t)r;
             start = nr;
           }
         }
+        if (li + kBatch < n_src) __syncthreads();  // sh_src is rewritten by the next round
       }
       __syncthreads();
+      if (A.debug_stop == 3) return;
       uint32_t v[kPer];
       uint32_t run_max = 0;
 #pragma unroll
@@ -1559,8 +1587,8 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         anc[r] = (uint32_t)(g < A.n ? g : A.n - 1);
       }
     } else {
-      // ---- many light source tiles (or a very wide range): every slot searches the tile prefix, then the stored
-      // in-tile CDF of its tile.  Four independent searches per lane. ------------------------------------------------
+      // ---- many light source tiles (or a very wide range): every slot searches the tile prefix, then its tile's 16
+      // sub-prefixes, then walks at most 64 stored weights.  Four independent searches per lane. ------------------------
       uint64_t tl[kPer], th[kPer];
 #pragma unroll
       for (int r = 0; r < kPer; ++r) { tl[r] = k_lo; th[r] = k_hi; }
@@ -1569,41 +1597,53 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         for (int r = 0; r < kPer; ++r) {
           if (tl[r] < th[r]) {
             const uint64_t mid = (tl[r] + th[r]) >> 1;
-            if (nhi_of(mid) > jq + r) th[r] = mid;
+            if ((int64_t)nhi_of(mid) > jq + r) th[r] = mid;
             else tl[r] = mid + 1;
           }
         }
       }
-      uint64_t pl[kPer], ph[kPer], pre[kPer], tb[kPer];
-      int dd[kPer];
-#pragma unroll
+#pragma unroll 1
       for (int r = 0; r < kPer; ++r) {
         const uint64_t k = tl[r];
-        pre[r] = pre_at(k);
-        dd[r] = shift_at(k);
-        tb[r] = k * kTile;
-        pl[r] = 0;
-        const uint64_t cnt = tb[r] + kTile <= A.n ? (uint64_t)kTile : A.n - tb[r];
-        ph[r] = cnt - 1;
-      }
-#pragma unroll 1
-      for (int it = 0; it < 10; ++it) {  // log2(kTile)
-#pragma unroll
-        for (int r = 0; r < kPer; ++r) {
-          if (pl[r] < ph[r]) {
-            const uint64_t mid = (pl[r] + ph[r]) >> 1;
-            const int64_t nm = teeth_at(tb[r] + mid, A.n, pre[r] + shr64(cdf_all[tb[r] + mid], dd[r]), scale, u0, n_out);
-            if (nm > jq + r) ph[r] = mid;
-            else pl[r] = mid + 1;
-          }
+        const int64_t j = jq + r;
+        const double scale_t = comb_tile_scale(scale, shift_at(k)), tb = comb_base(pre_at(k), scale, u0);
+        const int32_t nhi = nhi_of(k);
+        const uint64_t tbase = k * kTile;
+        const uint64_t cnt = tbase + kTile <= A.n ? (uint64_t)kTile : A.n - tbase;  // real particles of the tile
+        // block: the first 64-particle block whose END has more than j teeth below it (the tile's last block at the latest)
+        uint32_t blk = kSubs - 1;
+        bool have = false;
+        uint64_t cbase = 0;  // running sum before the block
+        for (int sb = 0; sb < kSubs; ++sb) {
+          const uint64_t cs = recs[k].sub[sb];
+          const bool ends_tile = (uint64_t)(sb + 1) * kSubLen >= cnt;
+          const int32_t ns = ends_tile ? nhi : comb_in_tile((double)cs, scale_t, tb, nhi, n_out);
+          if (!have && (int64_t)ns > j) { blk = (uint32_t)sb; have = true; }
+          if (!have) cbase = cs;
         }
+        // walk the block: the first particle with more than j teeth below it
+        double c = (double)cbase;
+        uint32_t found = kSubLen - 1;
+        bool done = false;
+        for (uint32_t i = 0; i < (uint32_t)kSubLen; ++i) {
+          const uint64_t li_ = (uint64_t)blk * kSubLen + i;
+          const uint32_t qv = li_ < cnt ? qw_all[tbase + li_] : 0u;
+          c += (double)qv;
+          const bool last = li_ + 1 >= cnt;
+          const int32_t ni = last ? nhi : comb_in_tile(c, scale_t, tb, nhi, n_out);
+          if (!done && (int64_t)ni > j) { found = i; done = true; }
+        }
+        const uint64_t g = tbase + (uint64_t)blk * kSubLen + found;
+        anc[r] = (uint32_t)(g < A.n ? g : A.n - 1);
       }
-#pragma unroll
-      for (int r = 0; r < kPer; ++r) anc[r] = (uint32_t)(tb[r] + pl[r]);
       __syncthreads();  // (barrier count as on the marks path)
     }
   }
 
+  if (A.debug_stop == 4) {
+    if (anc[0] == 0xffffffffu) marks[0] = anc[1] + anc[2] + anc[3];
+    return;
+  }
   typename Policy::Out out[kPer];
   float w[kPer];
   policy_compute_quad(P, jq, anc, out, w, 0);
@@ -1612,10 +1652,10 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     for (int r = 0; r < kPer; ++r) w[r] = w[r] + lw_prev[r];
   }
   policy_store_quad(P, jq, A.out_lo, anc, out, ok, 0);
+  if (A.debug_stop == 5) return;
   if (Policy::kEmit) {
     const uint64_t loc = (uint64_t)(jq - A.out_lo);
-    emit_tile<ADAPTIVE>(w, ok, cdf_out + loc, logw_out ? logw_out + loc : nullptr, recs_out + ot,
-                        adaptive && ess_out ? ess_out + 2 * ot : nullptr);
+    emit_tile(w, ok, qw_out + loc, logw_out ? logw_out + loc : nullptr, recs_out + ot);
   }
 }
 

@@ -628,9 +628,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_block(const float* lw, uin
   if (threadIdx.x == 0) tile_sums_at[tile] = acc;
 }
 
-// Tile-anchored CDFs and records of ARBITRARY log-weights (the generic resampler's front half; the SMC kernels emit
-// theirs themselves): one workgroup per tile.
-__global__ __launch_bounds__(kBlock) void k_tile_cdf(const float* lw, uint64_t n, uint64_t* cdf, TileRec* recs) {
+// Tile-anchored fixed-point weights and records of ARBITRARY log-weights (the generic resampler's front half; the SMC
+// kernels emit theirs themselves): one workgroup per tile.
+__global__ __launch_bounds__(kBlock) void k_tile_weights(const float* lw, uint64_t n, uint32_t* qw, TileRec* recs) {
   const uint64_t base = (uint64_t)blockIdx.x * kTile + (uint64_t)kPer * threadIdx.x;
   float w[kPer];
   bool ok[kPer];
@@ -639,19 +639,18 @@ __global__ __launch_bounds__(kBlock) void k_tile_cdf(const float* lw, uint64_t n
     ok[r] = base + r < n;
     w[r] = ok[r] ? lw[base + r] : -__builtin_inff();
   }
-  emit_tile<false>(w, ok, cdf + base, nullptr, recs + blockIdx.x, nullptr);
+  emit_tile(w, ok, qw + base, nullptr, recs + blockIdx.x);
 }
 
 // The merge of a population's tile records by ONE workgroup per filter: anchor e, total mass Q, ESS sums, and — for
 // populations beyond kMaxLdsTiles, where every resample workgroup merging all records itself would dominate — the
 // exclusive prefix of the shifted tile masses (layout: gjx_device.hpp prefix_words).  Also the closing (e, Q) of a run.
-__global__ __launch_bounds__(kBlock) void k_scan_records(const TileRec* recs, const uint64_t* tile_ess, uint64_t ntiles,
+__global__ __launch_bounds__(kBlock) void k_scan_records(const TileRec* recs, int with_ess, uint64_t ntiles,
                                                          uint64_t* prefix, int32_t* e_out, uint64_t* q_out, uint64_t mq_stride) {
   __shared__ uint64_t sh64[kBlock / kWave];
   __shared__ uint64_t sh_e[2 * (kBlock / kWave)];
   __shared__ float shf[kBlock / kWave];
   recs += (uint64_t)blockIdx.x * ntiles;  // one workgroup per filter
-  if (tile_ess) tile_ess += 2 * (uint64_t)blockIdx.x * ntiles;
   if (prefix) prefix += (uint64_t)blockIdx.x * prefix_words(ntiles);
   const uint64_t per = (ntiles + kBlock - 1) / kBlock;
   const uint64_t lo = threadIdx.x * per < ntiles ? threadIdx.x * per : ntiles, hi = lo + per < ntiles ? lo + per : ntiles;
@@ -666,11 +665,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_records(const TileRec* recs, co
   for (uint64_t k = lo; k < hi; ++k) {
     const int d = tile_shift(e, recs[k].e);
     local += shr64(recs[k].s, d);
-    if (tile_ess) { l1 += shr64(tile_ess[2 * k], d); l2 += shr64(tile_ess[2 * k + 1], 2 * d); }
+    if (with_ess) { l1 += shr64(recs[k].r1, d); l2 += shr64(recs[k].r2, 2 * d); }
   }
   uint64_t total;
   uint64_t run = block_scan_excl(local, sh64, total);
-  if (tile_ess) {
+  if (with_ess) {
     l1 = block_sum(l1, sh_e);
     l2 = block_sum(l2, sh_e + kBlock / kWave);
   }
@@ -962,7 +961,7 @@ struct HmmPolicy {
 // (P = prefix * N / Q in float64, the products teeth_below forms), both bounds monotone in b, so a block's range is
 // [#tiles with upper <= lo, #tiles with lower < hi).
 constexpr int kMaxRangeBlocks = 64;
-__global__ __launch_bounds__(kBlock) void k_source_ranges(const TileRec* recs, const uint64_t* tile_ess, double ess_thr,
+__global__ __launch_bounds__(kBlock) void k_source_ranges(const TileRec* recs, double ess_thr,
                                                           uint64_t ntiles, uint64_t n_total, int world, int64_t ticket,
                                                           int64_t* out) {
   __shared__ uint64_t sh64[kBlock / kWave];
@@ -986,8 +985,8 @@ __global__ __launch_bounds__(kBlock) void k_source_ranges(const TileRec* recs, c
     local += mass(b);
     if (ess_thr > 0.0) {
       const int d = tile_shift(e, recs[b].e);
-      l1 += shr64(tile_ess[2 * b], d);
-      l2 += shr64(tile_ess[2 * b + 1], 2 * d);
+      l1 += shr64(recs[b].r1, d);
+      l2 += shr64(recs[b].r2, 2 * d);
     }
   }
   if (ess_thr > 0.0) {  // an adaptive filter that keeps its particles at the next step needs no exchange at all:
@@ -1215,11 +1214,11 @@ size_t gjx_workspace_bytes(int op, uint64_t n) {
     case GJX_OP_LOGSUMEXP: return pad256(nrows_of(n) * 4) + pad256(nt * 8) + 1024;
     case GJX_OP_CATEGORICAL_INDEX:
     case GJX_OP_RESAMPLE:  // (multinomial: tile maxima, masses, global CDF; systematic: in-tile CDF, records, prefix)
-      return pad256(nt * 4) + 2 * pad256(nt * 8) + pad256(n * 8) + pad256(nt * 16) + pad256(prefix_words(nt) * 8) + 1024;
-    case GJX_OP_SMC:  // the second copy of up to 4 state columns and the log-weights, two in-tile CDFs, two sets of records,
-                      // ESS sums and merged prefixes, HMM tables
-      return (GJX_SMC_MAX_STATE + 1) * pad256(n * 4) + 2 * pad256(n * 8) + 2 * pad256(nt * 16) + 2 * pad256(2 * nt * 8) +
-             2 * pad256(prefix_words(nt) * 8) + pad256(256 * (256 + 64) * 4) + pad256(256 * 256 * 4) + 1024;
+      return pad256(nt * 4) + 2 * pad256(nt * 8) + pad256(n * 8) + pad256(nt * sizeof(TileRec)) + pad256(prefix_words(nt) * 8) + 1024;
+    case GJX_OP_SMC:  // the second copy of up to 4 state columns and the log-weights, two columns of fixed-point weights,
+                      // two sets of records and merged prefixes, HMM tables
+      return (GJX_SMC_MAX_STATE + 3) * pad256(n * 4) + 2 * pad256(nt * sizeof(TileRec)) + 2 * pad256(prefix_words(nt) * 8) +
+             pad256(256 * (256 + 64) * 4) + pad256(256 * 256 * 4) + 1024;
     default: return 0;
   }
 }
@@ -2028,14 +2027,14 @@ int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, 
   return launch_status();
 }
 
-int gjx_tile_cdf(const float* x, uint64_t n, uint64_t* cdf, gjx_tile_rec* recs, gjx_stream s) {
-  if (!x || !cdf || !recs || n == 0 || n > 0x7fffffffull) return GJX_ERR_INVALID;
-  k_tile_cdf<<<(unsigned)ntiles_of(n), kBlock, 0, S(s)>>>(x, n, cdf, reinterpret_cast<TileRec*>(recs));
+int gjx_tile_weights(const float* x, uint64_t n, uint32_t* qw, gjx_tile_rec* recs, gjx_stream s) {
+  if (!x || !qw || !recs || n == 0 || n > 0x7fffffffull) return GJX_ERR_INVALID;
+  k_tile_weights<<<(unsigned)ntiles_of(n), kBlock, 0, S(s)>>>(x, n, qw, reinterpret_cast<TileRec*>(recs));
   return launch_status();
 }
 int gjx_tile_merge(const gjx_tile_rec* recs, uint64_t n_tiles, int32_t* out_e, uint64_t* out_q, gjx_stream s) {
   if (!recs || n_tiles == 0) return GJX_ERR_INVALID;
-  k_scan_records<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), nullptr, n_tiles, nullptr, out_e, out_q, 0);
+  k_scan_records<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), 0, n_tiles, nullptr, out_e, out_q, 0);
   return launch_status();
 }
 
@@ -2060,14 +2059,14 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
   if (rc) return rc;
   const uint64_t nt = ntiles_of(n);
   Carver cv{(char*)ws, ws ? ws_bytes : 0};
-  uint64_t* cdf = cv.take<uint64_t>(n);
+  uint32_t* qw = cv.take<uint32_t>(n);
   TileRec* recs = cv.take<TileRec>(nt);
   uint64_t* prefix = nt > (uint64_t)kMaxLdsTiles ? cv.take<uint64_t>(prefix_words(nt)) : nullptr;
   if (!cv.ok) return GJX_ERR_WORKSPACE;
-  k_tile_cdf<<<(unsigned)nt, kBlock, 0, S(s)>>>(logw, n, cdf, recs);
-  if (prefix) k_scan_records<<<1, kBlock, 0, S(s)>>>(recs, nullptr, nt, prefix, nullptr, nullptr, 0);
+  k_tile_weights<<<(unsigned)nt, kBlock, 0, S(s)>>>(logw, n, qw, recs);
+  if (prefix) k_scan_records<<<1, kBlock, 0, S(s)>>>(recs, 0, nt, prefix, nullptr, nullptr, 0);
   ResampleArgs A;
-  A.cdf = cdf; A.recs = recs; A.n = n; A.ntiles = nt;
+  A.qw = qw; A.recs = recs; A.n = n; A.ntiles = nt;
   A.n_out = n_out; A.out_lo = 0; A.out_hi = (int64_t)n_out;
   A.rkey = k; A.rkey_has_fold = key->has_fold; A.rkey_fold = key->fold;
   A.e_out = out_e; A.q_out = out_q;
@@ -2130,7 +2129,7 @@ static bool cfg_ok(const gjx_smc_config* c) {
          c->resample_keys && (c->first_slot % kTile) == 0 && c->n_total <= 0x7fffffffull &&
          !(c->ess_threshold < 0.0f);
 }
-static_assert(sizeof(gjx_tile_rec) == sizeof(TileRec) && alignof(TileRec) == 16, "gjx.h gjx_tile_rec");
+static_assert(sizeof(gjx_tile_rec) == sizeof(TileRec) && alignof(TileRec) == 16 && offsetof(gjx_tile_rec, sub) == offsetof(TileRec, sub), "gjx.h gjx_tile_rec");
 
 uint64_t gjx_hmm_alias_words(int32_t n_states) {
   return n_states > 0 ? (uint64_t)n_states * (uint64_t)n_states : 0;
@@ -2153,10 +2152,10 @@ struct StepCtx {
 
 // a population a step READS (t >= 1) / WRITES: the pointers its configuration needs
 static bool pop_ok(const gjx_smc_pop* p, int n_state, bool adaptive, bool reading, uint64_t nt) {
-  if (!p || !p->cdf || !p->recs) return false;
+  if (!p || !p->qw || !p->recs) return false;
   for (int k = 0; k < n_state; ++k)
     if (!p->state[k]) return false;
-  if (adaptive && (!p->logw || !p->ess)) return false;
+  if (adaptive && !p->logw) return false;
   if (reading && nt > (uint64_t)kMaxLdsTiles && !p->prefix) return false;
   if (((uintptr_t)p->recs & 15) != 0) return false;
   return true;
@@ -2169,10 +2168,9 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
   ResampleArgs& A = *Ap;
   const bool ad = cfg_adaptive(cfg);
   A.fb = ctx.fb;
-  A.cdf = prev->cdf;
+  A.qw = prev->qw;
   A.lw = ad ? prev->logw : nullptr;
   A.recs = reinterpret_cast<const TileRec*>(prev->recs);
-  A.tile_ess = ad ? prev->ess : nullptr;
   A.n = cfg->n_total; A.ntiles = ntiles_of(cfg->n_total); A.n_out = cfg->n_total;
   A.out_lo = (int64_t)cfg->first_slot; A.out_hi = (int64_t)(cfg->first_slot + cfg->n_local);
   A.rkey = Key{cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1]};
@@ -2180,19 +2178,21 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
   A.e_out = prev_e_out; A.q_out = prev_q_out;
   if (ad) A.ess_thr = (double)cfg->ess_threshold * (double)cfg->n_total;
   A.resampled_out = ctx.resampled_out ? ctx.resampled_out : (cfg->resampled_out && !(cfg->n_filters > 1) ? cfg->resampled_out + t : nullptr);
-  A.cdf_out = out->cdf; A.logw_out = out->logw;
+  A.qw_out = out->qw; A.logw_out = out->logw;
   A.recs_out = reinterpret_cast<TileRec*>(out->recs);
-  A.ess_out = ad ? out->ess : nullptr;
   A.scan_max = scan_max_knob();
+  static const int dbg_stop = [] { const char* e = std::getenv("GJX_SMC_DEBUG_STOP"); return e ? atoi(e) : 0; }();
+  A.debug_stop = dbg_stop;
   if (A.ntiles > (uint64_t)kMaxLdsTiles) {
     if (ctx.fb.n_filters > 1) return GJX_ERR_UNSUPPORTED;
-    k_scan_records<<<1, kBlock, 0, S(s)>>>(A.recs, A.tile_ess, A.ntiles, prev->prefix, nullptr, nullptr, 0);
+    k_scan_records<<<1, kBlock, 0, S(s)>>>(A.recs, ad ? 1 : 0, A.ntiles, prev->prefix, nullptr, nullptr, 0);
     A.prefix = prev->prefix;
   }
   return GJX_OK;
 }
 static EmitOut emit_out_of(const gjx_smc_config* cfg, const gjx_smc_pop* out) {
-  return EmitOut{out->cdf, out->logw, reinterpret_cast<TileRec*>(out->recs), cfg_adaptive(cfg) ? out->ess : nullptr};
+  (void)cfg;
+  return EmitOut{out->qw, out->logw, reinterpret_cast<TileRec*>(out->recs)};
 }
 
 static int lgssm_step(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t, const gjx_smc_pop* prev,
@@ -2271,15 +2271,14 @@ int gjx_smc_hmm_step(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32
 
 int gjx_smc_finish(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int32_t* e_out, uint64_t* q_out, gjx_stream s) {
   if (!cfg_ok(cfg) || !recs || cfg->n_filters > 1) return GJX_ERR_INVALID;
-  k_scan_records<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), nullptr, ntiles_of(cfg->n_total), nullptr, e_out, q_out, 0);
+  k_scan_records<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), 0, ntiles_of(cfg->n_total), nullptr, e_out, q_out, 0);
   return launch_status();
 }
-int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, const uint64_t* ess, int world,
-                          int64_t ticket, int64_t* out_ranges, gjx_stream s) {
+int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int world, int64_t ticket, int64_t* out_ranges,
+                          gjx_stream s) {
   if (!cfg_ok(cfg) || !recs || !out_ranges || world < 1 || world > kMaxRangeBlocks || cfg->n_total % (uint64_t)world)
     return GJX_ERR_INVALID;
-  if (cfg_adaptive(cfg) && !ess) return GJX_ERR_INVALID;
-  k_source_ranges<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), cfg_adaptive(cfg) ? ess : nullptr,
+  k_source_ranges<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs),
                                           cfg_adaptive(cfg) ? (double)cfg->ess_threshold * (double)cfg->n_total : 0.0,
                                           ntiles_of(cfg->n_total), cfg->n_total, world, ticket, out_ranges);
   return launch_status();
@@ -2315,9 +2314,8 @@ static int run_common_init(const gjx_smc_config* cfg, Carver& cv, RunCommon& rc,
     rc.pop[rc.last ^ 1].state[k] = cv.take<uint32_t>(cells);
   }
   for (int i = 0; i < 2; ++i) {
-    rc.pop[i].cdf = cv.take<uint64_t>(cells);
+    rc.pop[i].qw = cv.take<uint32_t>(cells);
     rc.pop[i].recs = reinterpret_cast<gjx_tile_rec*>(cv.take<TileRec>((size_t)rc.F * rc.nt));
-    rc.pop[i].ess = rc.adaptive ? cv.take<uint64_t>(2 * (size_t)rc.F * rc.nt) : nullptr;
     rc.pop[i].prefix = rc.nt > (uint64_t)kMaxLdsTiles ? cv.take<uint64_t>(prefix_words(rc.nt)) : nullptr;
   }
   // log-weights: an adaptive filter carries them from step to step; otherwise only the last step's are stored
@@ -2353,7 +2351,7 @@ static StepCtx run_step_ctx(const gjx_smc_config* cfg, RunCommon& rc, int t, gjx
 // the closing (e, Q) pairs of a run: the merge of the last step's records, one workgroup per filter
 static int run_finish(const gjx_smc_config* cfg, RunCommon& rc, int32_t* out_e, uint64_t* out_q, gjx_stream s) {
   const int T = cfg->n_steps;
-  k_scan_records<<<rc.F, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(rc.pop[rc.last].recs), nullptr, rc.nt, nullptr,
+  k_scan_records<<<rc.F, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(rc.pop[rc.last].recs), 0, rc.nt, nullptr,
                                             out_e + (T - 1), out_q + (T - 1), (uint64_t)T);
   return launch_status();
 }
@@ -2638,6 +2636,13 @@ static int smc_run(const gjx_smc_config* cfg, const void* model, int32_t* out_e,
     int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * rc.F * rc.stride : nullptr;
     gjx_smc_pop out;
     StepCtx ctx = run_step_ctx(cfg, rc, t, &out);
+    static const bool dbg_fixed = std::getenv("GJX_SMC_DEBUG_FIXED") != nullptr;  // profiling: every step reads step 0's population
+    if (dbg_fixed && t > 0) {
+      out = rc.pop[1];
+      if (!rc.adaptive) out.logw = nullptr;
+      r = step(t, &rc.pop[0], &out, out_e + (t - 1), out_q + (t - 1), anc_t, ctx);
+      continue;
+    }
     r = step(t, &rc.pop[(t & 1) ^ 1], &out, t ? out_e + (t - 1) : nullptr, t ? out_q + (t - 1) : nullptr, anc_t, ctx);
   }
   if (r) return r;

@@ -132,13 +132,14 @@ def importance_log_z(ops: Ops, wl: "W.Gaussian10"):
 
 
 def merged_tile_masses(recs):
-    """Tile records (int64 [tiles, 2]: word 0 = S_t, low half of word 1 = e_t; gjx_tile_rec) -> (e, masses uint64
+    """Tile records (int64 [tiles, 20]: word 0 = S_t, low half of word 1 = e_t, ...; gjx_tile_rec) -> (e, masses uint64
     [tiles]): the merge every consumer of the records performs: e = max e_t, M_t = S_t >> (e - e_t)."""
     import numpy as np
 
     from . import abi
 
-    r = np.ascontiguousarray(np.asarray(recs.cpu() if hasattr(recs, "cpu") else recs)).view(np.uint64).reshape(-1, 2)
+    r = np.ascontiguousarray(np.asarray(recs.cpu() if hasattr(recs, "cpu") else recs)).view(np.uint64)
+    r = r.reshape(r.shape[0], -1)
     s = r[:, 0].copy()
     et = (r[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32).astype(np.int64)
     live = et != abi.TILE_EMPTY
@@ -383,8 +384,8 @@ class ShardedSMC:
     over ranks in equal contiguous blocks of whole tiles.
 
     Per step: (a) ONE launch: resample + propagate + weight the rank's OWN output slots from the global previous
-    population (only the source tiles that feed those slots are read), emitting the in-tile CDFs and tile records
-    of the new weights; (b) ONE all-gather of the records (16 B per 1024 particles; no all-reduce: the records are
+    population (only the source tiles that feed those slots are read), emitting the fixed-point weights and tile records
+    of the new weights; (b) ONE all-gather of the records (160 B per 1024 particles; no all-reduce: the records are
     anchored per tile); (c) the ancestor shuffle.  Ancestors are monotone in the output slot, so the
     sources of a rank's slots are ONE contiguous global range, known to every rank from the records alone
     (`needed_tile_ranges`):
@@ -442,7 +443,7 @@ class ShardedSMC:
         self.adaptive = bool(self.cfg._adaptive)
         self.pop = [ops.smc_pop(n_total, [sdt] * self.n_cols, self.adaptive) for _ in range(2)]
         for p_ in self.pop:
-            for c in [*p_.state, p_.cdf, p_.logw]:
+            for c in [*p_.state, p_.qw, p_.logw]:
                 c.zero_()
         self.out_e = torch.empty(T, dtype=torch.int32, device=dev)
         self.out_q = torch.zeros(T, dtype=torch.int64, device=dev)
@@ -475,7 +476,7 @@ class ShardedSMC:
         if self.poison:  # tests: whatever is not received below must never be read
             for c in cols:
                 keep = c[lo:hi].clone()
-                c.fill_(float("nan") if c.dtype == torch.float32 else (-1 if c.dtype == torch.int64 else 0))
+                c.fill_(float("nan") if c.dtype == torch.float32 else 0)
                 c[lo:hi] = keep
         if self.exchange == "allgather":
             for c in cols:
@@ -485,7 +486,7 @@ class ShardedSMC:
         # the ranges of all ranks from the records, computed on the device and stored straight into pinned host
         # memory with a ticket behind them: the host polls for the ticket instead of synchronising the stream
         self.ticket += 1
-        ops.smc_source_ranges(self.cfg, pop.recs, pop.ess, self.world, self.ranges, self.ticket)
+        ops.smc_source_ranges(self.cfg, pop.recs, self.world, self.ranges, self.ticket)
         rh = self.ranges_np
         if self.ranges.is_pinned():
             spins = 0
@@ -570,8 +571,6 @@ class ShardedSMC:
             self._step(t, cur, prv)
             pop = self.pop[cur]
             self.comm.all_gather(pop.recs, tl, th)
-            if pop.ess is not None:
-                self.comm.all_gather(pop.ess, 2 * tl, 2 * th)
             if t + 1 < self.T:
                 self._shuffle(cur)
         ops.smc_finish(self.cfg, self.pop[(self.T - 1) & 1].recs, self.out_e[self.T - 1:self.T], self.out_q[self.T - 1:self.T])

@@ -367,13 +367,14 @@ class Ops:
                       C.c_void_p(ws.data_ptr()), nb, self.stream())
         return anc, m, q
 
-    def tile_cdf(self, x: torch.Tensor):
-        """-> (cdf int64[n], recs int64[tiles, 2]): the in-tile CDFs and tile records (gjx_tile_rec: word 0 = S_t,
-        low half of word 1 = e_t) of arbitrary log-weights."""
+    def tile_weights(self, x: torch.Tensor):
+        """-> (qw int32[n], recs int64[tiles, 20]): the tile-anchored fixed-point weights (u32 bit patterns) and tile
+        records (gjx_tile_rec as 20 words: S_t, e_t in the low half of word 1, ESS sums, 16 sub-prefixes) of arbitrary
+        log-weights."""
         n = x.numel()
-        cdf, recs = self.empty(n, torch.int64), self.empty((self.num_tiles(n), 2), torch.int64)
-        self.lib.call("gjx_tile_cdf", self._chk(x, torch.float32, n), n, self._p(cdf), self._p(recs), self.stream())
-        return cdf, recs
+        qw, recs = self.empty(n, torch.int32), self.empty((self.num_tiles(n), abi.TILE_REC_WORDS), torch.int64)
+        self.lib.call("gjx_tile_weights", self._chk(x, torch.float32, n), n, self._p(qw), self._p(recs), self.stream())
+        return qw, recs
 
     def tile_merge(self, recs: torch.Tensor):
         """-> (e int32[1], q int64[1]): merged anchor and total mass of tile records."""
@@ -602,7 +603,7 @@ class Ops:
         return None if t is None else C.c_void_p(t.data_ptr())
 
     def smc_pop(self, n_total: int, state_dtypes: list, adaptive: bool, want_logw: bool = True) -> "SmcPopulation":
-        """A GLOBAL-size population (gjx_smc_pop): state columns, in-tile CDF, log-weights, tile records, ESS sums."""
+        """A GLOBAL-size population (gjx_smc_pop): state columns, fixed-point weights, log-weights, tile records."""
         return SmcPopulation(self, n_total, state_dtypes, adaptive, want_logw)
 
     def smc_lgssm_step(self, cfg, model: abi.Lgssm, t: int, y_t: float, prev, out, prev_e_out=None, prev_q_out=None,
@@ -631,10 +632,10 @@ class Ops:
     def smc_finish(self, cfg, recs, e_out, q_out):
         self.lib.call("gjx_smc_finish", C.byref(cfg), self._p(recs), self._p(e_out), self._p(q_out), self.stream())
 
-    def smc_source_ranges(self, cfg, recs, ess, world: int, out_ranges, ticket: int = 0):
+    def smc_source_ranges(self, cfg, recs, world: int, out_ranges, ticket: int = 0):
         """out_ranges int64[2 world + 1]: the source tiles each of `world` equal output blocks can draw from, then
         the ticket (stored last; a pinned host buffer can be polled for it)."""
-        self.lib.call("gjx_smc_source_ranges", C.byref(cfg), self._p(recs), self._p(ess), int(world), int(ticket),
+        self.lib.call("gjx_smc_source_ranges", C.byref(cfg), self._p(recs), int(world), int(ticket),
                       self._p(out_ranges), self.stream())
 
     def log_z_from_pairs(self, out_e: torch.Tensor, out_q: torch.Tensor, n_total: int, resampled=None) -> float:
@@ -660,29 +661,27 @@ class SmcPopulation:
         self.ops, self.n, self.adaptive = ops, n_total, adaptive
         nt = ops.num_tiles(n_total)
         self.state = [ops.empty(n_total, dt) for dt in state_dtypes]
-        self.cdf = ops.empty(n_total, torch.int64)
+        self.qw = ops.empty(n_total, torch.int32)
         self.logw = ops.empty(n_total, torch.float32) if (want_logw or adaptive) else None
-        self.recs = torch.zeros((nt, 2), dtype=torch.int64, device=ops.device())
-        self.ess = torch.zeros(2 * nt, dtype=torch.int64, device=ops.device()) if adaptive else None
+        self.recs = torch.zeros((nt, abi.TILE_REC_WORDS), dtype=torch.int64, device=ops.device())
         self.prefix = ops.empty(nt + 4, torch.int64) if nt > 1024 else None
 
     def columns(self, with_logw: bool | None = None) -> list[torch.Tensor]:
-        """The per-particle columns an ancestor shuffle moves: state, in-tile CDF (and log-weights when adaptive)."""
-        cols = list(self.state) + [self.cdf]
+        """The per-particle columns an ancestor shuffle moves: state, fixed-point weights (and log-weights when adaptive)."""
+        cols = list(self.state) + [self.qw]
         if self.adaptive if with_logw is None else with_logw:
             cols.append(self.logw)
         return cols
 
     def struct(self, first: int = 0, with_logw: bool = True) -> abi.SmcPop:
         """abi.SmcPop: per-particle arrays start at slot `first` (a rank's own block for the population a step WRITES;
-        0 for the one it READS); records / ESS sums are always the global arrays."""
+        0 for the one it READS); the records are always the global array."""
         p = abi.SmcPop()
         for k, c in enumerate(self.state):
             p.state[k] = c.data_ptr() + first * 4
-        p.cdf = self.cdf.data_ptr() + first * 8
+        p.qw = self.qw.data_ptr() + first * 4
         p.logw = (self.logw.data_ptr() + first * 4) if (self.logw is not None and with_logw) else None
         p.recs = self.recs.data_ptr()
-        p.ess = self.ess.data_ptr() if self.ess is not None else None
         p.prefix = self.prefix.data_ptr() if self.prefix is not None else None
         p._keep = self
         return p

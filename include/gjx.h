@@ -376,29 +376,35 @@ int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, 
                           int mode, void* ws, size_t ws_bytes, gjx_stream s);
 
 /* Tile-anchored weights: what a resampling reads.  Tile t = particles [1024 t, 1024 t + 1024):
- * e_t = ceil(max_t x * log2 e) (the row anchor of 3.5b on a tile), q_i = rint(exp(x_i - e_t ln 2) * 2^30), the
- * IN-TILE CDF c_i = sum of q over the tile's particles up to and including i (u64 per particle), and the tile's
- * record (e_t, S_t = c_last).  Everything is known to the workgroup that produces the tile's log-weights — no
- * grid-wide maximum — so the kernel that propagates a population emits it, and a bootstrap step is ONE launch.
- * Records merge exactly: e = max e_t, d_t = e - e_t, M_t = S_t >> d_t (0 from d_t = 64), P_t = sum_{t' < t} M_t',
- * Q = sum_t M_t; the GLOBAL fixed-point CDF is C_i = P_t + (c_i >> d_t); lse = e ln 2 + log(Q 2^-30). */
+ * e_t = ceil(max_t x * log2 e) (the row anchor of 3.5b on a tile); q_i = rint(exp(x_i - e_t ln 2) * 2^30), ONE u32 PER
+ * PARTICLE (what a step stores instead of the log-weight); the tile's record: S_t = sum q_i, e_t, the ESS sums
+ * r1 = sum (q_i >> 14), r2 = sum (q_i >> 14)^2, and the running sum of q after every 64th particle (sub[b] = sum over the
+ * tile's particles [0, 64 (b + 1)); sub[15] = S_t).  Everything is known to the workgroup that produces the tile's
+ * log-weights — no grid-wide maximum — so the kernel that propagates a population emits it, and a bootstrap step is ONE
+ * launch.  Records merge exactly: e = max e_t, d_t = e - e_t, M_t = S_t >> d_t (0 from d_t = 64), P_t = sum_{t' < t}
+ * M_t', Q = sum_t M_t; lse = e ln 2 + log(Q 2^-30). */
 typedef struct {
   uint64_t s; /* S_t */
   int32_t e;  /* e_t; GJX_TILE_EMPTY: the tile carries no mass */
   int32_t pad;
+  uint64_t r1, r2;
+  uint64_t sub[16];
 } gjx_tile_rec;
 #define GJX_TILE_EMPTY (-(1 << 30))
 #define GJX_TILE_FRAC 30
-/* cdf dev u64[n], recs dev gjx_tile_rec[gjx_num_tiles(n)] of arbitrary log-weights x (one pass). */
-int gjx_tile_cdf(const float* x, uint64_t n, uint64_t* cdf, gjx_tile_rec* recs, gjx_stream s);
+/* qw dev u32[n], recs dev gjx_tile_rec[gjx_num_tiles(n)] of arbitrary log-weights x (one pass). */
+int gjx_tile_weights(const float* x, uint64_t n, uint32_t* qw, gjx_tile_rec* recs, gjx_stream s);
 /* out_e[0], out_q[0] = the merged anchor and total mass of `recs` (each nullable). */
 int gjx_tile_merge(const gjx_tile_rec* recs, uint64_t n_tiles, int32_t* out_e, uint64_t* out_q, gjx_stream s);
 
 /* ancestors[j], j < n_out: systematic (one 64-bit uniform, monotone ancestors) or multinomial
  * (n_out iid draws) resampling from softmax(logw).
- * Systematic: tile-anchored weights (above): u0 = top 53 bits of the key's 64-bit draw; teeth below particle i:
- * n_i = clamp(ceil(f64(C_i) * (n_out / f64(Q)) - u0), 0, n_out), the last particle closes at n_out;
- * ancestors[j] = min{i : n_i > j}.  out_e / out_q (nullable): merged anchor and total mass of logw.
+ * Systematic: tile-anchored weights (above): u0 = top 53 bits of the key's 64-bit draw, scale = n_out / f64(Q); teeth
+ * below the START of tile t: nlo_t = clamp(ceil(f64(P_t) scale - u0), 0, n_out); below particle i of tile t, with c_i the
+ * running sum of q inside the tile (exact in float64): n_i = min(clamp(ceil(fma(c_i, scale 2^-d_t, f64(P_t) scale - u0)),
+ * 0, n_out), nlo_{t+1}), a tile's last particle ending at nlo_{t+1} and the population's last at n_out;
+ * ancestors[j] = min{i : n_i > j}.  No mass at all (Q = 0): ancestors[j] = floor(j n / n_out).
+ * out_e / out_q (nullable): merged anchor and total mass of logw.
  * Multinomial: max-anchored weights (§3.5); out_max / out_q: the (max, fixed-point sum) pair of logw.
  * NOT in the reference library (docs idiom
  * docs/cookbook/inactive/inference/importance_sampling.ipynb cell 16). */
@@ -465,7 +471,7 @@ typedef struct {
    * otherwise every particle keeps its own ancestor (ancestors[t][j] = j), and its log-weight ACCUMULATES:
    * logw_t[j] = logw_{t-1}[j] + increment.  ESS is evaluated on exact integers so that every backend, tiling and
    * number of ranks takes the same decision: per tile r_i = q_i >> 14 (the top 16 bits of the tile-anchored weight),
-   * R1_t = sum r_i, R2_t = sum r_i^2; merged R1 = sum_t R1_t >> d_t, R2 = sum_t R2_t >> 2 d_t;
+   * R1_t = sum r_i, R2_t = sum r_i^2 (gjx_tile_rec.r1 / r2); merged R1 = sum_t R1_t >> d_t, R2 = sum_t R2_t >> 2 d_t;
    * resample iff (double)R1 * (double)R1 < (ess_threshold * n_total) * (double)R2.
    * log Z = sum over the steps t that END an epoch (a resampling follows, or t = T-1) of
    * (e_t ln 2 + log(q_t 2^-30) - log N): the per-step (out_e, out_q) pairs are those of the accumulated weights.
@@ -480,10 +486,9 @@ typedef struct {
 #define GJX_SMC_MAX_OBS 8
 typedef struct {
   void* state[GJX_SMC_MAX_STATE]; /* 4-byte columns (f32 x / int32 z) */
-  uint64_t* cdf;                  /* in-tile CDF of the weights (gjx_tile_rec above) */
+  uint32_t* qw;                   /* tile-anchored fixed-point weights (gjx_tile_rec above) */
   float* logw;                    /* log-weights: nullable unless the filter is ESS-adaptive */
   gjx_tile_rec* recs;             /* GLOBAL dev [gjx_num_tiles(n_total)]: the tiles' records */
-  uint64_t* ess;                  /* GLOBAL dev u64[2 gjx_num_tiles(n_total)] (R1_t, R2_t): adaptive filters only */
   uint64_t* prefix;               /* scratch dev u64[gjx_num_tiles(n_total) + 4]: required only when the population READ by a
                                      step has more than 1024 tiles (n_total > 2^20) — the step then merges its records
                                      into this array with one extra small launch instead of in every workgroup */
@@ -504,10 +509,10 @@ int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32
 
 /* One step as ONE launch (the whole-run calls are loops over these; the multi-device driver runs the
  * exchange between them).  step (t): for every slot j in [first_slot, first_slot+n_local): systematic-resampling
- * ancestor from the GLOBAL previous population `prev` (state / cdf / logw dev [n_total], recs / ess GLOBAL), propagate,
- * weight; writes `out`: state / cdf / logw (nullable) dev [n_local] — LOCAL arrays, slot j at j - first_slot — and the
- * records (and ESS sums) of the rank's own tiles into the GLOBAL arrays out->recs / out->ess (at the global tile
- * index; out->recs must not alias prev->recs: ranks all-gather it).  prev_e_out / prev_q_out (nullable dev [1]):
+ * ancestor from the GLOBAL previous population `prev` (state / qw / logw dev [n_total], recs GLOBAL), propagate,
+ * weight; writes `out`: state / qw / logw (nullable) dev [n_local] — LOCAL arrays, slot j at j - first_slot — and the
+ * records of the rank's own tiles into the GLOBAL array out->recs (at the global tile index; out->recs must not alias
+ * prev->recs: ranks all-gather it).  prev_e_out / prev_q_out (nullable dev [1]):
  * the merged anchor and total mass of prev's weights.  ancestors_out nullable dev int32[n_local].  t == 0 ignores
  * prev.  Only the source tiles that own one of the rank's slots are read (gjx_smc_source_ranges).
  *  finish: e_out[0], q_out[0] = merged anchor / total mass of the last step's records. */
@@ -527,13 +532,13 @@ int gjx_smc_finish(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int32_t*
  * (block j = slots [j n_total/world, (j+1) n_total/world)), out_ranges[2j], [2j+1] = the half-open range of
  * source tiles that can own a slot of the block at the next resampling — the exact range or one tile more at
  * either end (the comb offset is bounded, not derived, so the ranges of a step are known before its key is
- * used).  Ancestors are monotone in the slot, hence one contiguous range per block.  ess: the population's ESS sums
- * (adaptive filters; a kept step needs no exchange: identity ranges).  out_ranges:
+ * used).  Ancestors are monotone in the slot, hence one contiguous range per block.  An adaptive filter that keeps its
+ * particles at the next step (the records carry the ESS sums) needs no exchange: identity ranges.  out_ranges:
  * int64[2 world + 1], device memory or device-visible pinned host memory; out_ranges[2 world] = ticket is
  * stored LAST with a system-scope release, so a host that owns a pinned buffer can poll for its ticket and
  * read the ranges without synchronising the stream.  world <= 64 and n_total a multiple of world. */
-int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, const uint64_t* ess, int world,
-                          int64_t ticket, int64_t* out_ranges, gjx_stream s);
+int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int world, int64_t ticket,
+                          int64_t* out_ranges, gjx_stream s);
 /* ---- bootstrap SMC for a user model: init sites + step sites as plans ------------------------ *
  * The general form of the two fixed models above: x_0 comes from `init_sites`, every later step
  * walks `step_sites` for each output slot with GJX_ARG_STATE arguments reading the resampled
@@ -655,11 +660,11 @@ int gjx_comm_world(const gjx_comm* c);
 int gjx_comm_lse_combine(gjx_comm* c, const uint64_t* records, int32_t n_batch, uint64_t* gathered, int32_t* out_e,
                          uint64_t* out_q, float* out_lse, gjx_stream s);
 /* The whole bootstrap filter sharded over the communicator's ranks (BASELINE configs[3]): per step ONE launch (own
- * slots) -> ONE all-gather of the tile records (and ESS sums) -> ancestor shuffle, driven from C: no interpreter
+ * slots) -> ONE all-gather of the tile records (160 bytes per 1024 particles) -> ancestor shuffle, driven from C: no interpreter
  * between the launches.  cfg: first_slot / n_local = this rank's block (n_total a multiple of world * gjx_smc_tile()),
  * one filter.  All arrays are GLOBAL-size device buffers the caller owns (a rank's own block is always current; remote
- * ranges are filled by the shuffle): pop[2] (double-buffered: state columns dev 4-byte [n_total], cdf dev u64[n_total],
- * logw dev f32[n_total], recs dev gjx_tile_rec[tiles], ess dev u64[2 tiles] for adaptive filters),
+ * ranges are filled by the shuffle): pop[2] (double-buffered: state columns dev 4-byte [n_total], qw dev u32[n_total],
+ * logw dev f32[n_total] (adaptive filters; else only the final population's, nullable), recs dev gjx_tile_rec[tiles]),
  * out_e dev int32[T], out_q dev u64[T], ancestors nullable dev int32[T, n_local],
  *   ranges int64[2 world + 1] device-visible PINNED host memory (plain host memory in the oracle build).
  * shuffle 0 = by source ranges (each rank receives exactly the contiguous range its slots draw from, in place, by

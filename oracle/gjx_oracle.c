@@ -788,34 +788,41 @@ int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, 
 
 /* ---- tile-anchored weights (gjx.h gjx_tile_rec) ---------------------------------- *
  * Sequential restatement: per tile of 1024 particles the maximum (the sequential `x > m ? x : m`, a NaN is skipped),
- * its power-of-two anchor, the fixed-point weights, their running sum (the in-tile CDF), the ESS sums. */
+ * its power-of-two anchor, the fixed-point weights (one u32 per particle), their running sum after every 64th
+ * particle, the ESS sums. */
 #define O_ESS_SHIFT (O_ROW_FRAC - 16)
-static void tile_emit(const float* lw, uint64_t cnt, uint64_t* cdf, gjx_tile_rec* rec, uint64_t* ess2) {
+#define O_SUBS 16
+#define O_SUBLEN (O_TILE / O_SUBS)
+static void tile_emit(const float* lw, uint64_t cnt, uint32_t* qw, gjx_tile_rec* rec) {
   float m = -INFINITY;
   for (uint64_t i = 0; i < cnt; ++i) m = lw[i] > m ? lw[i] : m;
   const int32_t e = o_row_anchor(m);
   uint64_t run = 0, r1 = 0, r2 = 0;
-  for (uint64_t i = 0; i < cnt; ++i) {
-    const uint64_t q = o_rowfix(lw[i], e);
-    run += q;
-    cdf[i] = run;
-    const uint64_t r = q >> O_ESS_SHIFT;
-    r1 += r;
-    r2 += r * r;
+  for (uint64_t i = 0; i < O_TILE; ++i) {
+    if (i < cnt) {
+      const uint64_t q = o_rowfix(lw[i], e);
+      qw[i] = (uint32_t)q;
+      run += q;
+      const uint64_t r = q >> O_ESS_SHIFT;
+      r1 += r;
+      r2 += r * r;
+    }
+    if ((i + 1) % O_SUBLEN == 0) rec->sub[i / O_SUBLEN] = run;
   }
   rec->s = run;
   rec->e = e;
   rec->pad = 0;
-  if (ess2) { ess2[0] = r1; ess2[1] = r2; }
+  rec->r1 = r1;
+  rec->r2 = r2;
 }
-int gjx_tile_cdf(const float* x, uint64_t n, uint64_t* cdf, gjx_tile_rec* recs, gjx_stream s) {
+int gjx_tile_weights(const float* x, uint64_t n, uint32_t* qw, gjx_tile_rec* recs, gjx_stream s) {
   (void)s;
-  if (!x || !cdf || !recs || n == 0) return GJX_ERR_INVALID;
+  if (!x || !qw || !recs || n == 0) return GJX_ERR_INVALID;
   const uint64_t nt = gjx_num_tiles(n);
 #pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < (int64_t)nt; ++b) {
     const uint64_t lo = (uint64_t)b * O_TILE, cnt = lo + O_TILE <= n ? O_TILE : n - lo;
-    tile_emit(x + lo, cnt, cdf + lo, &recs[b], NULL);
+    tile_emit(x + lo, cnt, qw + lo, &recs[b]);
   }
   return GJX_OK;
 }
@@ -827,7 +834,7 @@ typedef struct {
   uint8_t* d;    /* [nt]: 64 = the tile carries no mass */
 } merged;
 static inline uint64_t shr64(uint64_t v, int d) { return d >= 64 ? 0 : v >> d; }
-static int merge_records(const gjx_tile_rec* recs, const uint64_t* ess, uint64_t nt, merged* m) {
+static int merge_records(const gjx_tile_rec* recs, uint64_t nt, merged* m) {
   m->pre = (uint64_t*)malloc(sizeof(uint64_t) * (nt + 1));
   m->d = (uint8_t*)malloc(nt ? nt : 1);
   if (!m->pre || !m->d) { free(m->pre); free(m->d); return GJX_ERR_LAUNCH; }
@@ -843,7 +850,8 @@ static int merge_records(const gjx_tile_rec* recs, const uint64_t* ess, uint64_t
     m->d[b] = (uint8_t)d;
     m->pre[b] = run;
     run += shr64(recs[b].s, d);
-    if (ess) { r1 += shr64(ess[2 * b], d); r2 += shr64(ess[2 * b + 1], 2 * d); }
+    r1 += shr64(recs[b].r1, d);
+    r2 += shr64(recs[b].r2, 2 * d);
   }
   m->pre[nt] = run;
   m->e = e; m->Q = run; m->R1 = r1; m->R2 = r2;
@@ -854,7 +862,7 @@ int gjx_tile_merge(const gjx_tile_rec* recs, uint64_t n_tiles, int32_t* out_e, u
   (void)s;
   if (!recs || n_tiles == 0) return GJX_ERR_INVALID;
   merged m;
-  int rc = merge_records(recs, NULL, n_tiles, &m);
+  int rc = merge_records(recs, n_tiles, &m);
   if (rc) return rc;
   if (out_e) *out_e = m.e;
   if (out_q) *out_q = m.Q;
@@ -862,24 +870,32 @@ int gjx_tile_merge(const gjx_tile_rec* recs, uint64_t n_tiles, int32_t* out_e, u
   return GJX_OK;
 }
 
-/* Number of comb teeth (j + u0), j in [0, n_out), strictly below normalised mass P = C*scale. */
-static inline int64_t teeth_below(uint64_t C, double scale, double u0, int64_t n_out) {
-  double P = (double)C * scale;
-  double c = ceil(P - u0);
+/* ---- the comb: the float64 operations every backend evaluates ------------------------------------ */
+/* teeth (j + u0), j in [0, n_out), strictly below a position: ceil, clamped to [0, n_out] (a NaN counts as 0) */
+static inline int32_t comb_clamp(double t, int32_t n_out) {
+  const double c = ceil(t);
   if (!(c > 0.0)) return 0;
   if (c >= (double)n_out) return n_out;
-  return (int64_t)c;
+  return (int32_t)c;
 }
+static inline double comb_base(uint64_t P, double scale, double u0) { return (double)P * scale - u0; }
+static inline int32_t comb_tile(uint64_t P, double scale, double u0, int32_t n_out) { return comb_clamp(comb_base(P, scale, u0), n_out); }
+static inline int32_t comb_in_tile(double c, double scale_t, double base, int32_t nhi, int32_t n_out) {
+  const int32_t t = comb_clamp(fma(c, scale_t, base), n_out);
+  return t < nhi ? t : nhi;
+}
+static inline double comb_tile_scale(double scale, int d) { return d >= 64 ? 0.0 : ldexp(scale, -d); }
 static inline double u0_from_bits(uint64_t U) { return (double)(U >> 11) * 0x1.0p-53; }
 
-/* Ancestors of the slots [lo, hi) of an n_out-tooth comb over n particles: particle i of tile b has the global CDF
- * value C_i = pre[b] + (cdf[i] >> d[b]); teeth below it n_i = teeth_below(C_i), the last particle closes at n_out;
- * slot j takes the first particle with n_i > j.  Tiles whose slots (known from the merged records alone) all lie
- * outside [lo, hi) are skipped without reading their CDF: a rank of a sharded filter holds only the source ranges it
- * needs. */
-static void systematic_ancestors(const uint64_t* cdf, uint64_t n, const merged* m, uint64_t nt, uint64_t n_out_u,
+/* Ancestors of the slots [lo, hi) of an n_out-tooth comb over n particles with stored weights qw and merged records:
+ * teeth below the start of tile b: nlo_b = comb_tile(pre[b]); below particle i of tile b (c = running sum of q inside
+ * the tile): n_i = min(comb_clamp(fma(c, scale 2^-d_b, base_b)), nlo_{b+1}), a tile's last particle ending at nlo_{b+1},
+ * the population's last at n_out; slot j takes the first particle with n_i > j.  Tiles whose slots (known from the
+ * merged records alone) all lie outside [lo, hi) are skipped without reading their weights: a rank of a sharded filter
+ * holds only the source ranges it needs. */
+static void systematic_ancestors(const uint32_t* qw, uint64_t n, const merged* m, uint64_t nt, uint64_t n_out_u,
                                  double u0, int64_t lo, int64_t hi, int32_t* anc /* [hi - lo] */) {
-  const int64_t n_out = (int64_t)n_out_u;
+  const int32_t n_out = (int32_t)n_out_u;
   if (m->Q == 0) { /* no mass at all: the population is kept — slot j takes particle floor(j n / n_out) */
     const double ratio = (double)n / (double)n_out_u;
     for (int64_t j = lo; j < hi; ++j) {
@@ -892,14 +908,16 @@ static void systematic_ancestors(const uint64_t* cdf, uint64_t n, const merged* 
 #pragma omp parallel for schedule(dynamic, 8)
   for (int64_t bb = 0; bb < (int64_t)nt; ++bb) {
     const uint64_t b = (uint64_t)bb;
-    const int64_t t_lo = teeth_below(m->pre[b], scale, u0, n_out);
-    const int64_t t_hi = b + 1 == nt ? n_out : teeth_below(m->pre[b + 1], scale, u0, n_out);
+    const int32_t t_lo = comb_tile(m->pre[b], scale, u0, n_out);
+    const int32_t t_hi = b + 1 == nt ? n_out : comb_tile(m->pre[b + 1], scale, u0, n_out);
     if (t_hi <= lo || t_lo >= hi) continue;
+    const double scale_t = comb_tile_scale(scale, m->d[b]), base = comb_base(m->pre[b], scale, u0);
     int64_t prev = t_lo;
-    const uint64_t i1 = (b + 1) * O_TILE < n ? (b + 1) * O_TILE : n;
-    for (uint64_t i = b * O_TILE; i < i1; ++i) {
-      const uint64_t C = m->pre[b] + shr64(cdf[i], m->d[b]);
-      const int64_t ni = (i == n - 1) ? n_out : teeth_below(C, scale, u0, n_out);
+    const uint64_t i0 = b * O_TILE, i1 = (b + 1) * O_TILE < n ? (b + 1) * O_TILE : n;
+    double c = 0.0;
+    for (uint64_t i = i0; i < i1; ++i) {
+      c += (double)qw[i];
+      const int64_t ni = (i + 1 == i1) ? t_hi : comb_in_tile(c, scale_t, base, t_hi, n_out);
       const int64_t a = prev > lo ? prev : lo, e = ni < hi ? ni : hi;
       for (int64_t j = a; j < e; ++j) anc[j - lo] = (int32_t)i;
       if (ni > prev) prev = ni;
@@ -911,22 +929,22 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
                             int32_t* ancestors, int32_t* out_e, uint64_t* out_q, void* ws,
                             size_t ws_bytes, gjx_stream s) {
   (void)ws; (void)ws_bytes; (void)s;
-  if (!keys_ok(key) || !logw || !ancestors || n == 0 || n_out == 0) return GJX_ERR_INVALID;
+  if (!keys_ok(key) || !logw || !ancestors || n == 0 || n_out == 0 || n > 0x7fffffffull || n_out > 0x7fffffffull) return GJX_ERR_INVALID;
   const uint64_t nt = gjx_num_tiles(n);
-  uint64_t* cdf = (uint64_t*)malloc(sizeof(uint64_t) * n);
+  uint32_t* qw = (uint32_t*)malloc(sizeof(uint32_t) * n);
   gjx_tile_rec* recs = (gjx_tile_rec*)malloc(sizeof(gjx_tile_rec) * nt);
   merged m;
-  int rc = (cdf && recs) ? gjx_tile_cdf(logw, n, cdf, recs, NULL) : GJX_ERR_LAUNCH;
-  if (!rc) rc = merge_records(recs, NULL, nt, &m);
+  int rc = (qw && recs) ? gjx_tile_weights(logw, n, qw, recs, NULL) : GJX_ERR_LAUNCH;
+  if (!rc) rc = merge_records(recs, nt, &m);
   if (!rc) {
     o_stream st = stream_at(key, 0);
     const double u0 = u0_from_bits(o_bits64_at(&st, 0));
-    systematic_ancestors(cdf, n, &m, nt, n_out, u0, 0, (int64_t)n_out, ancestors);
+    systematic_ancestors(qw, n, &m, nt, n_out, u0, 0, (int64_t)n_out, ancestors);
     if (out_e) *out_e = m.e;
     if (out_q) *out_q = m.Q;
     merged_free(&m);
   }
-  free(cdf); free(recs);
+  free(qw); free(recs);
   return rc;
 }
 
@@ -988,10 +1006,10 @@ static int ess_says_resample(uint64_t r1, uint64_t r2, double thr) {
   return a < b;
 }
 static int pop_ok(const gjx_smc_pop* p, int n_state, int adaptive) {
-  if (!p || !p->cdf || !p->recs) return 0;
+  if (!p || !p->qw || !p->recs) return 0;
   for (int k = 0; k < n_state; ++k)
     if (!p->state[k]) return 0;
-  return !adaptive || (p->logw && p->ess);
+  return !adaptive || p->logw != NULL;
 }
 
 int gjx_smc_finish(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int32_t* e_out, uint64_t* q_out, gjx_stream s) {
@@ -1002,15 +1020,14 @@ int gjx_smc_finish(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int32_t*
 /* Source-tile ranges of `world` equal blocks of output slots: tile b can own slots in [ceil(P_b) - 1,
    ceil(P_{b+1})) for some comb offset u0 in [0, 1) (teeth_below above; P = prefix * N / Q in double), the last
    tile up to N. */
-int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, const uint64_t* ess, int world,
-                          int64_t ticket, int64_t* out_ranges, gjx_stream s) {
+int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int world, int64_t ticket,
+                          int64_t* out_ranges, gjx_stream s) {
   (void)s;
   if (!cfg_ok(cfg) || !recs || !out_ranges || world < 1 || world > 64 || cfg->n_total % (uint64_t)world)
     return GJX_ERR_INVALID;
-  if (cfg_adaptive(cfg) && !ess) return GJX_ERR_INVALID;
   const uint64_t N = cfg->n_total, nt = gjx_num_tiles(N), nl = N / (uint64_t)world;
   merged m;
-  int rc = merge_records(recs, cfg_adaptive(cfg) ? ess : NULL, nt, &m);
+  int rc = merge_records(recs, nt, &m);
   if (rc) return rc;
   if (cfg_adaptive(cfg) && !ess_says_resample(m.R1, m.R2, (double)cfg->ess_threshold * (double)N)) {
     /* the next step keeps its particles: every block's sources are its own tiles */
@@ -1054,7 +1071,7 @@ static int smc_step_front(const gjx_smc_config* cfg, int t, const gjx_smc_pop* p
   const uint64_t N = cfg->n_total, nt = gjx_num_tiles(N);
   const int ad = cfg_adaptive(cfg);
   merged m;
-  int rc = merge_records(prev->recs, ad ? prev->ess : NULL, nt, &m);
+  int rc = merge_records(prev->recs, nt, &m);
   if (rc) return rc;
   if (prev_e_out) *prev_e_out = m.e;
   if (prev_q_out) *prev_q_out = m.Q;
@@ -1064,21 +1081,20 @@ static int smc_step_front(const gjx_smc_config* cfg, int t, const gjx_smc_pop* p
     const uint32_t rkey[4] = {cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1], 0u, 0u};
     o_stream st = o_stream_make(cfg->impl, rkey, 0, 0);
     const double u0 = u0_from_bits(o_bits64_at(&st, 0));
-    systematic_ancestors(prev->cdf, N, &m, nt, N, u0, (int64_t)cfg->first_slot, (int64_t)(cfg->first_slot + cfg->n_local), anc);
+    systematic_ancestors(prev->qw, N, &m, nt, N, u0, (int64_t)cfg->first_slot, (int64_t)(cfg->first_slot + cfg->n_local), anc);
   } else {
     for (uint64_t j = 0; j < cfg->n_local; ++j) anc[j] = (int32_t)(cfg->first_slot + j);
   }
   merged_free(&m);
   return res;
 }
-/* Back half of every step: the in-tile CDFs, records and ESS sums of the rank's new log-weights lw[n_local]. */
+/* Back half of every step: the fixed-point weights and records of the rank's new log-weights lw[n_local]. */
 static void smc_step_back(const gjx_smc_config* cfg, const gjx_smc_pop* out, const float* lw) {
   const uint64_t nl = cfg->n_local, tile0 = cfg->first_slot / O_TILE, ntl = gjx_num_tiles(nl);
-  const int ad = cfg_adaptive(cfg);
 #pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < (int64_t)ntl; ++b) {
     const uint64_t lo = (uint64_t)b * O_TILE, cnt = lo + O_TILE <= nl ? O_TILE : nl - lo;
-    tile_emit(lw + lo, cnt, out->cdf + lo, &out->recs[tile0 + (uint64_t)b], ad ? out->ess + 2 * (tile0 + (uint64_t)b) : NULL);
+    tile_emit(lw + lo, cnt, out->qw + lo, &out->recs[tile0 + (uint64_t)b]);
   }
   if (out->logw) memcpy(out->logw, lw, sizeof(float) * nl);
 }
@@ -1245,15 +1261,15 @@ static int pop_alloc(gjx_smc_pop* p, uint64_t N, int n_state, int adaptive) {
   const uint64_t nt = gjx_num_tiles(N);
   int ok = 1;
   for (int k = 0; k < n_state; ++k) ok = ok && (p->state[k] = malloc(4 * N)) != NULL;
-  ok = ok && (p->cdf = (uint64_t*)malloc(8 * N)) != NULL;
+  ok = ok && (p->qw = (uint32_t*)malloc(4 * N)) != NULL;
   ok = ok && (p->logw = (float*)malloc(4 * N)) != NULL;
   ok = ok && (p->recs = (gjx_tile_rec*)malloc(sizeof(gjx_tile_rec) * nt)) != NULL;
-  if (adaptive) ok = ok && (p->ess = (uint64_t*)calloc(2 * nt, sizeof(uint64_t))) != NULL;
+  (void)adaptive;
   return ok ? GJX_OK : GJX_ERR_LAUNCH;
 }
 static void pop_free(gjx_smc_pop* p) {
   for (int k = 0; k < GJX_SMC_MAX_STATE; ++k) free(p->state[k]);
-  free(p->cdf); free(p->logw); free(p->recs); free(p->ess);
+  free(p->qw); free(p->logw); free(p->recs);
 }
 static int smc_run_one(const gjx_smc_config* cfg, int n_state, step_fn step, void* ctx, int32_t* out_e, uint64_t* out_q,
                        void* const* state_out, float* logw_out, int32_t* ancestors_out) {

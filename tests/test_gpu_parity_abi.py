@@ -792,16 +792,16 @@ def test_smc_ess_adaptive(hip_ops, oracle_ops, impl, kind, n, T, thr, F):
 
 @pytest.mark.parametrize("n", [1, 1023, 1024, 1025, 5000, 1_500_000])
 def test_tile_records(hip_ops, oracle_ops, n):
-    """gjx_tile_cdf / gjx_tile_merge: in-tile CDFs, tile records and their merge of arbitrary
+    """gjx_tile_weights / gjx_tile_merge: fixed-point weights, tile records and their merge of arbitrary
     log-weights — wide dynamic range, -inf / NaN / +inf entries, a ragged last tile — are the oracle's bits, and the
     merged (e, Q) pair reproduces logsumexp."""
     g = torch.Generator().manual_seed(n)
     lw = torch.randn(n, generator=g) * 30
     if n > 10:
         lw[3] = float("-inf"); lw[7] = float("nan")
-    hc, hr = hip_ops.tile_cdf(lw.to(hip_ops.device()))
-    oc, orr = oracle_ops.tile_cdf(lw)
-    same(hc, oc, "in-tile cdf"); same(hr, orr, "records")
+    hc, hr = hip_ops.tile_weights(lw.to(hip_ops.device()))
+    oc, orr = oracle_ops.tile_weights(lw)
+    same(hc, oc, "fixed-point weights"); same(hr, orr, "records")
     he, hq = hip_ops.tile_merge(hr)
     oe, oq = oracle_ops.tile_merge(orr)
     same(he, oe, "merged anchor"); same(hq, oq, "merged mass")
