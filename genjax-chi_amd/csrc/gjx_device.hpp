@@ -856,13 +856,14 @@ struct FilterBatch {
   uint64_t stride = 0;     // particles between consecutive filters in every per-particle array (tiles * 1024)
   uint64_t mq_stride = 0;  // entries between the filters' per-step (e, q) results
   Key step_key[kMaxFilters];
-  Key rkey[kMaxFilters];
+  double u0[kMaxFilters];  // comb offsets (from the filters' resampling keys)
 };
 
 constexpr int kTileFrac = kRowFrac;   // fractional bits of the tile-anchored weights (rowfix)
 constexpr int kEssShift = kTileFrac - 16;
 constexpr int kMaxLdsTiles = 1024;    // populations up to 2^20 particles keep the merged tile prefix in LDS
-constexpr int kScanMax = 16;          // an output tile with more source tiles than this searches per slot
+constexpr int kWindow = 2 * kTile;     // sources one round of the window scan covers (8 consecutive sources per lane)
+constexpr int kScanMax = 4;           // rounds of the window scan before an output tile searches per slot
 constexpr int kSubs = 16;             // sub-prefixes per tile: the running sum of q after every 64th particle
 constexpr int kSubLen = kTile / kSubs;
 struct alignas(16) TileRec {
@@ -891,9 +892,7 @@ struct ResampleArgs {
   uint64_t n = 0, ntiles = 0;
   uint64_t n_out = 0;                   // number of comb teeth (global output slots)
   int64_t out_lo = 0, out_hi = 0;       // slots this launch serves (out_lo a multiple of the tile size)
-  Key rkey;                             // resampling key (its sub-stream 0 gives the comb offset)
-  int rkey_has_fold = 0;
-  uint32_t rkey_fold = 0;
+  double u0 = 0.0;                      // the comb offset: u0_from_bits(64-bit draw of the resampling key), from the host
   int32_t* e_out = nullptr;             // nullable: workgroup 0 stores the merged anchor of the source weights
   uint64_t* q_out = nullptr;            // nullable: ... and their total mass
   int32_t* resampled_out = nullptr;     // nullable: workgroup 0 of each filter stores 1 (resampled) / 0 (kept)
@@ -904,7 +903,7 @@ struct ResampleArgs {
   uint32_t* qw_out = nullptr;           // [n_local] (slot - out_lo)
   float* logw_out = nullptr;            // nullable [n_local]
   TileRec* recs_out = nullptr;          // GLOBAL [tiles of n_out]: entry of every output tile served
-  int scan_max = kScanMax;              // test knob: 0 = every output tile takes the per-slot search
+  int scan_max = kScanMax;              // rounds of the window scan (test knob: 0 = every output tile takes the per-slot search)
   int debug_stop = 0;                   // profiling knob (GJX_SMC_DEBUG_STOP): leave the kernel after phase k
 };
 
@@ -1149,6 +1148,7 @@ GJX_DEV void policy_store_quad(Policy& P, int64_t jq, int64_t out_lo, const uint
 // w[r], ok[r]: the log-weights of the thread's four consecutive slots (tile offset 4 tid + r) and whether the slot
 // exists.  qw_at / logw_at: where the thread's first slot goes (logw_at nullable); rec_at: the tile's record.
 // Called by every thread of the workgroup (two barriers inside).
+template <bool ESS>
 GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint32_t* qw_at, float* logw_at, TileRec* rec_at) {
   constexpr int kW = kBlock / kWave;
   __shared__ float em_f[kW];
@@ -1171,14 +1171,18 @@ GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint32_t*
   for (int r = 0; r < kPer; ++r) {
     q[r] = ok[r] ? (uint32_t)rowfix(w[r], e) : 0u;
     run += q[r];
-    const uint64_t rr = ess_r(q[r]);
-    a1 += rr;
-    a2 += rr * rr;
+    if (ESS) {
+      const uint64_t rr = ess_r(q[r]);
+      a1 += rr;
+      a2 += rr * rr;
+    }
   }
   const uint64_t incl = wave_scan_incl(run);
-  a1 = wave_sum(a1);
-  a2 = wave_sum(a2);
-  if (lane == 63) { em_q[wv] = incl; em_q[kW + wv] = a1; em_q[2 * kW + wv] = a2; }
+  if (ESS) { a1 = wave_sum(a1); a2 = wave_sum(a2); }
+  if (lane == 63) {
+    em_q[wv] = incl;
+    if (ESS) { em_q[kW + wv] = a1; em_q[2 * kW + wv] = a2; }
+  }
   __syncthreads();
   uint64_t base = 0;
 #pragma unroll
@@ -1205,8 +1209,10 @@ GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint32_t*
   if ((lane & 15) == 15) rec_at->sub[tid >> 4] = base + incl;
   if (tid == kBlock - 1) {
     uint64_t t1 = 0, t2 = 0;
+    if (ESS) {
 #pragma unroll
-    for (int i = 0; i < kW; ++i) { t1 += em_q[kW + i]; t2 += em_q[2 * kW + i]; }
+      for (int i = 0; i < kW; ++i) { t1 += em_q[kW + i]; t2 += em_q[2 * kW + i]; }
+    }
     rec_at->s = base + incl;
     rec_at->e = e;
     rec_at->pad = 0;
@@ -1221,9 +1227,11 @@ struct EmitOut {
   uint32_t* qw;    // [n_local]
   float* logw;     // nullable [n_local]
   TileRec* recs;   // GLOBAL [tiles]
+  int ess;         // the filter is ESS-adaptive: the records carry the ESS sums
 };
 GJX_DEV void emit_init_tile(const float (&w)[kPer], const bool (&ok)[kPer], const EmitOut& em, uint64_t loc, uint64_t gtile) {
-  emit_tile(w, ok, em.qw + loc, em.logw ? em.logw + loc : nullptr, em.recs + gtile);
+  if (em.ess) emit_tile<true>(w, ok, em.qw + loc, em.logw ? em.logw + loc : nullptr, em.recs + gtile);
+  else emit_tile<false>(w, ok, em.qw + loc, em.logw ? em.logw + loc : nullptr, em.recs + gtile);
 }
 GJX_DEV void select_filter_emit(EmitOut& em, const FilterBatch& fb, uint32_t f) {
   em.qw += (uint64_t)f * fb.stride;
@@ -1245,22 +1253,42 @@ GJX_DEV uint32_t block_scan_umax_excl(uint32_t v, uint32_t* sh) {
   return excl;
 }
 
+// Inclusive scan of one u64 per lane inside groups of 8 consecutive lanes (one 64-particle block: 8 sources per lane).
+GJX_DEV uint64_t scan8_incl(uint64_t v) {
+  const int l8 = threadIdx.x & 7;
+  uint64_t t = dpp_u64<kDppRowShr1, 0xf, 0xf>(0, v);
+  v += l8 >= 1 ? t : 0;
+  t = dpp_u64<kDppRowShr2, 0xf, 0xf>(0, v);
+  v += l8 >= 2 ? t : 0;
+  t = dpp_u64<kDppRowShr4, 0xf, 0xf>(0, v);
+  v += l8 >= 4 ? t : 0;
+  return v;
+}
+
+// the policy's source state for the window scan's first round (optional): loads the lane's 8 consecutive sources and
+// stages them in LDS, so that compute() finds its ancestors without another trip to memory
+template <class Policy>
+GJX_DEV auto policy_stage_window(Policy& P, uint64_t i0, uint64_t i_base, uint64_t n, int) -> decltype(P.stage_window(i0, i_base, n), void()) {
+  P.stage_window(i0, i_base, n);
+}
+template <class Policy>
+GJX_DEV void policy_stage_window(Policy&, uint64_t, uint64_t, uint64_t, long) {}
+
 // ADAPTIVE: the launch may be a step of an ESS-adaptive filter (A.ess_thr > 0): only then does the kernel carry the
-// decision and the keep-your-particle path (the every-step filters are compiled without them).
+// decision, the ESS sums and the keep-your-particle path (the every-step filters are compiled without them).
 template <int IMPL, class Policy, bool ADAPTIVE = true>
 GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   constexpr int kW = kBlock / kWave;
-  constexpr int kBatch = 2;                      // source tiles scanned per round (their loads are in flight together)
+  constexpr int kSrc = kWindow / kBlock;         // sources per lane and round of the window scan
+  static_assert(kSrc == 8 && kSubLen == 64, "8 consecutive sources per lane: a 64-particle block is 8 lanes");
   __shared__ uint64_t sh_pre[kMaxLdsTiles + 1];  // merged exclusive tile prefix (populations up to kMaxLdsTiles tiles)
   __shared__ uint8_t sh_d[kMaxLdsTiles];         // every tile's shift to the merged anchor
   __shared__ uint32_t marks[kTile];              // run-start marks of the ancestor search
   __shared__ uint64_t sh_scan[3 * kW];
-  __shared__ uint64_t sh_src[kBatch][kW];        // wave totals of the source tiles being scanned
   __shared__ int32_t sh_e[kW];
   __shared__ uint32_t sh_u[kW];
-  __shared__ uint32_t sh_klo, sh_khi, sh_cnt;
-  __shared__ uint32_t sh_list[kScanMax];
-  static_assert(kPer == 4, "four consecutive sources and four consecutive output slots per lane");
+  __shared__ uint32_t sh_klo, sh_cov[2];
+  static_assert(kPer == 4, "four consecutive output slots per lane");
   uint64_t b = blockIdx.x;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   // this workgroup's filter: local views of the per-filter arrays, keys and results
@@ -1273,7 +1301,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   uint32_t* qw_out = A.qw_out;
   float* logw_out = A.logw_out;
   TileRec* recs_out = A.recs_out;
-  Key rkey = A.rkey;
+  double u0 = A.u0;
   if (A.fb.n_filters > 1) {
     const uint32_t f = (uint32_t)(b / A.fb.tiles);
     b -= (uint64_t)f * A.fb.tiles;
@@ -1286,7 +1314,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     if (qw_out) qw_out += (uint64_t)f * A.fb.stride;
     if (logw_out) logw_out += (uint64_t)f * A.fb.stride;
     if (recs_out) recs_out += (uint64_t)f * A.fb.tiles;
-    rkey = A.fb.rkey[f];
+    u0 = A.fb.u0[f];
     P.select_filter((uint64_t)f * A.fb.stride, A.fb.step_key[f]);
   }
   const bool adaptive = ADAPTIVE && A.ess_thr > 0.0;
@@ -1322,11 +1350,8 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   }
 #pragma unroll
   for (int r = 0; r < kPer; ++r) marks[tid + r * kBlock] = 0;
-  if (tid == 0) { sh_klo = ~0u; sh_khi = 0; sh_cnt = 0; }
-  // (under the latency of the record loads) the comb offset and whatever the policy can do without its ancestors
-  const Stream<IMPL> rstream(rkey, A.rkey_has_fold != 0, A.rkey_fold);
-  const double u0 = u0_from_bits(rstream.bits64(0));
-  policy_prefetch(P, jq, 0);
+  if (tid == 0) sh_klo = ~0u;
+  policy_prefetch(P, jq, 0);  // (under the latency of the record loads)
 
   // ---- merge: anchor, shifted masses, exclusive prefix, total, ESS sums ------------------------------------------
   int32_t e = kRowEmpty;
@@ -1423,14 +1448,15 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     const double scale = (double)A.n_out / (double)tot;
     auto nlo_of = [&](uint64_t k) -> int32_t { return comb_tile(pre_at(k), scale, u0, n_out); };  // teeth below the START of tile k
     auto nhi_of = [&](uint64_t k) -> int32_t { return k + 1 >= A.ntiles ? n_out : nlo_of(k + 1); };  // ... below its END
-    // ---- which source tiles own a tooth in [j0, j1)? -------------------------------------------------------------
-    uint64_t k_lo = 0, k_hi = 0;
+    // ---- the first source tile with a tooth in [j0, j1): k_lo = min{k : teeth below the END of tile k > j0} ----------
+    uint64_t k_lo = 0;
     if (lds_prefix) {
       __syncthreads();  // sh_pre / sh_d complete
+      // (monotone: the chunk that holds k_lo is the one whose start lies at or below j0 and whose end beyond it; only that
+      // thread walks its tiles)
       const int32_t c_lo = comb_tile(chunk_pre, scale, u0, n_out);
       const int32_t c_hi = k0 + c_per >= A.ntiles ? n_out : comb_tile(chunk_pre + chunk_mass, scale, u0, n_out);
-      if (k0 < A.ntiles && c_hi > j0 && c_lo < j1 && c_hi > c_lo) {
-        int32_t lo_t = c_lo;
+      if (k0 < A.ntiles && c_lo <= j0 && c_hi > j0) {
         uint64_t run = chunk_pre;
 #pragma unroll
         for (int i = 0; i < kC; ++i) {
@@ -1438,22 +1464,14 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
           if ((uint64_t)i < c_per && k < A.ntiles) {
             run += mass[i];
             const int32_t hi_t = k + 1 >= A.ntiles ? n_out : comb_tile(run, scale, u0, n_out);
-            if (hi_t > lo_t && hi_t > j0 && lo_t < j1) {
-              atomicMin(&sh_klo, (uint32_t)k);
-              atomicMax(&sh_khi, (uint32_t)k);
-              const uint32_t pos = atomicAdd(&sh_cnt, 1u);
-              if (pos < (uint32_t)kScanMax) sh_list[pos] = (uint32_t)k;
-            }
-            lo_t = hi_t;
+            if (hi_t > j0) atomicMin(&sh_klo, (uint32_t)k);
           }
         }
       }
       __syncthreads();
       k_lo = sh_klo;
-      k_hi = sh_khi;
     } else {
-      // large populations: 256-ary searches of the precomputed prefix.  k_lo = min{k : teeth below the end of tile k
-      // > j0}; k_hi = max{k : teeth below the start of tile k < j1}.
+      // large populations: a 256-ary search of the precomputed prefix
       uint64_t lo = 0, hi = A.ntiles - 1;
       while (hi - lo >= (uint64_t)kBlock) {  // (workgroup-uniform)
         const uint64_t stride = (hi - lo + kBlock) / kBlock;
@@ -1473,104 +1491,74 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
       if (lo + (uint64_t)tid <= hi && nhi_of(lo + (uint64_t)tid) > j0) atomicMin(&sh_klo, (uint32_t)tid);
       __syncthreads();
       k_lo = lo + sh_klo;
-      lo = k_lo;
-      hi = A.ntiles - 1;
-      while (hi - lo >= (uint64_t)kBlock) {
-        const uint64_t stride = (hi - lo + kBlock) / kBlock;
-        const uint64_t kk = lo + (uint64_t)tid * stride;  // the START of sub-block tid
-        if (kk <= hi && nlo_of(kk) < j1) atomicMax(&sh_khi, (uint32_t)tid);
-        __syncthreads();
-        const uint64_t i = sh_khi;
-        __syncthreads();
-        if (tid == 0) sh_khi = 0;
-        const uint64_t nlo = lo + i * stride;
-        uint64_t nhi = nlo + (stride - 1);
-        hi = nhi > hi ? hi : nhi;
-        lo = nlo;
-        __syncthreads();
-      }
-      if (lo + (uint64_t)tid <= hi && nlo_of(lo + (uint64_t)tid) < j1) atomicMax(&sh_khi, (uint32_t)tid);
-      __syncthreads();
-      k_hi = lo + sh_khi;
-      // the tiles of [k_lo, k_hi] that do own a tooth here (up to 4 per thread; a wider range searches per slot)
-      if (k_hi - k_lo < (uint64_t)(4 * kBlock)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint64_t k = k_lo + (uint64_t)tid + (uint64_t)i * kBlock;
-          if (k <= k_hi) {
-            const int32_t lo_t = nlo_of(k), hi_t = nhi_of(k);
-            if (hi_t > lo_t && hi_t > j0 && lo_t < j1) {
-              const uint32_t pos = atomicAdd(&sh_cnt, 1u);
-              if (pos < (uint32_t)kScanMax) sh_list[pos] = (uint32_t)k;
-            }
-          }
-        }
-      } else if (tid == 0) {
-        sh_cnt = ~0u;
-      }
-      __syncthreads();
     }
-    const uint32_t n_src = sh_cnt;
     if (A.debug_stop == 2) return;
-    if (n_src <= (uint32_t)A.scan_max) {
-      // ---- few source tiles: re-scan their stored weights (integer adds), every source marks the slot where its run
-      // starts; a max-scan spreads the marks ---------------------------------------------------------------------------
-      for (uint32_t li = 0; li < n_src; li += kBatch) {
-        uint64_t kk[kBatch];
-        bool live[kBatch];
-        uint32_t q[kBatch][kPer];
-        uint64_t run[kBatch], incl[kBatch];
+    // ---- the window: it starts at the 64-particle block of tile k_lo that holds the first tooth of [j0, j1) ----------
+    uint64_t i_base;
+    {
+      const uint64_t tbase = k_lo * kTile;
+      const uint64_t cnt = tbase + kTile <= A.n ? (uint64_t)kTile : A.n - tbase;
+      const int sb = lane & (kSubs - 1);  // (every 16 lanes evaluate the tile's 16 sub-prefixes: no exchange needed)
+      const uint64_t cs = recs[k_lo].sub[sb];
+      const double scale_t = comb_tile_scale(scale, shift_at(k_lo)), tb = comb_base(pre_at(k_lo), scale, u0);
+      const int32_t nhi = nhi_of(k_lo);
+      const bool ends_tile = (uint64_t)(sb + 1) * kSubLen >= cnt;
+      const int32_t ns = ends_tile ? nhi : comb_in_tile((double)cs, scale_t, tb, nhi, n_out);
+      const uint64_t hit = __ballot(ns > j0) & 0xffffull;  // (non-empty: the tile's end lies beyond j0)
+      const int blk0 = hit ? __builtin_ctzll(hit) : kSubs - 1;
+      i_base = tbase + (uint64_t)blk0 * kSubLen;
+    }
+    bool covered = false;
+    int rounds = 0;
+    for (; rounds < A.scan_max && !covered; ++rounds) {
+      // ---- one round: the lane's 8 consecutive sources, their running sums from the block's sub-prefix and an 8-lane
+      // scan (integer adds: no exponential, no workgroup-wide scan), teeth below each, marks where runs start -----------
+      const uint64_t i0 = i_base + (uint64_t)rounds * kWindow + (uint64_t)kSrc * tid;
+      const uint64_t k = i0 >> 10;
+      const bool live = i0 < A.n;
+      uint32_t q[kSrc];
+      if (live && i0 + kSrc <= A.n) {
+        const uint4 v0 = reinterpret_cast<const uint4*>(qw_all + i0)[0];
+        const uint4 v1 = reinterpret_cast<const uint4*>(qw_all + i0)[1];
+        q[0] = v0.x; q[1] = v0.y; q[2] = v0.z; q[3] = v0.w; q[4] = v1.x; q[5] = v1.y; q[6] = v1.z; q[7] = v1.w;
+      } else {
 #pragma unroll
-        for (int h = 0; h < kBatch; ++h) {
-          live[h] = li + h < n_src;
-          kk[h] = live[h] ? sh_list[li + h] : 0;
-          const uint64_t sbase = kk[h] * kTile + (uint64_t)kPer * tid;
-          if (live[h] && sbase + kPer <= A.n) {
-            const uint4 v = *reinterpret_cast<const uint4*>(qw_all + sbase);
-            q[h][0] = v.x; q[h][1] = v.y; q[h][2] = v.z; q[h][3] = v.w;
-          } else {
+        for (int r = 0; r < kSrc; ++r) q[r] = live && i0 + r < A.n ? qw_all[i0 + r] : 0u;
+      }
+      const uint32_t sbk = (uint32_t)(i0 >> 6) & (kSubs - 1);
+      const uint64_t subpre = live && sbk ? recs[k].sub[sbk - 1] : 0;
+      if (rounds == 0) policy_stage_window(P, i0, i_base, A.n, 0);
+      uint64_t own = 0;
 #pragma unroll
-            for (int r = 0; r < kPer; ++r) q[h][r] = live[h] && sbase + r < A.n ? qw_all[sbase + r] : 0u;
-          }
-        }
+      for (int r = 0; r < kSrc; ++r) own += q[r];
+      const uint64_t c_start = subpre + scan8_incl(own) - own;
+      int32_t n_end = n_out;  // a lane beyond the population ends the comb
+      if (live) {
+        const double scale_t = comb_tile_scale(scale, shift_at(k)), tb = comb_base(pre_at(k), scale, u0);
+        const int32_t nhi = nhi_of(k);
+        const uint64_t tend = (k + 1) * kTile < A.n ? (k + 1) * kTile : A.n;  // the tile's (real) end
+        double c = (double)c_start;
+        int32_t start = comb_in_tile(c, scale_t, tb, nhi, n_out);  // (the tile's start for its first source: c == 0)
+        n_end = i0 + kSrc >= tend ? nhi : comb_in_tile((double)(c_start + own), scale_t, tb, nhi, n_out);
+        if (n_end > start && n_end > j0 && start < j1) {  // the lane's sources own a tooth of this tile's slots
+          const uint32_t id_base = (uint32_t)(i0 - i_base) + 1u;
 #pragma unroll
-        for (int h = 0; h < kBatch; ++h) {
-          run[h] = (uint64_t)q[h][0] + q[h][1] + q[h][2] + q[h][3];
-          incl[h] = wave_scan_incl(run[h]);
-          if (lane == 63) sh_src[h][wv] = incl[h];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < kBatch; ++h) {
-          if (!live[h]) continue;
-          uint64_t base_c = incl[h] - run[h];  // running sum before this thread's first source
-#pragma unroll
-          for (int i = 0; i < kW; ++i)
-            if (i < wv) base_c += sh_src[h][i];
-          const uint64_t k = kk[h];
-          const uint64_t sbase = k * kTile + (uint64_t)kPer * tid;
-          const uint64_t pre = pre_at(k);
-          const int d = shift_at(k);
-          const double scale_t = comb_tile_scale(scale, d), tb = comb_base(pre, scale, u0);
-          const int32_t nhi = nhi_of(k);
-          const uint32_t id_base = ((uint32_t)(k - k_lo) << 10) + (uint32_t)(kPer * tid) + 1u;
-          double c = (double)base_c;
-          // teeth below the source before this thread's first (the tile's start for thread 0: c == 0)
-          int32_t start = comb_in_tile(c, scale_t, tb, nhi, n_out);
-#pragma unroll
-          for (int r = 0; r < kPer; ++r) {
-            c += (double)q[h][r];
-            // the tile's last particle (and any padding after the population's last) ends at the tile's end
-            const bool last = kPer * tid + r == kTile - 1 || sbase + r + 1 >= A.n;
-            const int32_t nr = last ? nhi : comb_in_tile(c, scale_t, tb, nhi, n_out);
+          for (int r = 0; r < kSrc; ++r) {
+            c += (double)q[r];
+            const int32_t nr = r == kSrc - 1 ? n_end : (i0 + r + 1 >= tend ? nhi : comb_in_tile(c, scale_t, tb, nhi, n_out));
             if (nr > start && nr > j0 && start < j1) marks[(start > j0 ? start : (int32_t)j0) - (int32_t)j0] = id_base + (uint32_t)r;
             start = nr;
           }
         }
-        if (li + kBatch < n_src) __syncthreads();  // sh_src is rewritten by the next round
       }
+      // the window reaches the end of the workgroup's slots?  (two flags by round parity: a wave may be one barrier ahead)
+      if (tid == kBlock - 1) sh_cov[rounds & 1] = n_end >= j1 ? 1u : 0u;
       __syncthreads();
-      if (A.debug_stop == 3) return;
+      covered = sh_cov[rounds & 1] != 0;
+    }
+    if (A.debug_stop == 3) return;
+    if (covered) {
+      // ---- a max-scan spreads the marks over the runs ----------------------------------------------------------------
       uint32_t v[kPer];
       uint32_t run_max = 0;
 #pragma unroll
@@ -1583,29 +1571,22 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
 #pragma unroll
       for (int r = 0; r < kPer; ++r) {
         const uint32_t a = v[r] > carry ? v[r] : carry;
-        const uint64_t g = k_lo * kTile + (uint64_t)(a ? a - 1u : 0u);
+        const uint64_t g = i_base + (uint64_t)(a ? a - 1u : 0u);
         anc[r] = (uint32_t)(g < A.n ? g : A.n - 1);
       }
     } else {
-      // ---- many light source tiles (or a very wide range): every slot searches the tile prefix, then its tile's 16
-      // sub-prefixes, then walks at most 64 stored weights.  Four independent searches per lane. ------------------------
-      uint64_t tl[kPer], th[kPer];
-#pragma unroll
-      for (int r = 0; r < kPer; ++r) { tl[r] = k_lo; th[r] = k_hi; }
-      for (uint64_t span = k_hi - k_lo; span > 0; span >>= 1) {  // (uniform trip count: ceil(log2(span + 1)))
-#pragma unroll
-        for (int r = 0; r < kPer; ++r) {
-          if (tl[r] < th[r]) {
-            const uint64_t mid = (tl[r] + th[r]) >> 1;
-            if ((int64_t)nhi_of(mid) > jq + r) th[r] = mid;
-            else tl[r] = mid + 1;
-          }
-        }
-      }
+      // ---- many light sources (the slots' sources spread over more than scan_max windows): every slot searches the
+      // tile prefix, then its tile's 16 sub-prefixes, then walks at most 64 stored weights ------------------------------
 #pragma unroll 1
       for (int r = 0; r < kPer; ++r) {
-        const uint64_t k = tl[r];
         const int64_t j = jq + r;
+        uint64_t tl = k_lo, th = A.ntiles - 1;
+        while (tl < th) {
+          const uint64_t mid = (tl + th) >> 1;
+          if ((int64_t)nhi_of(mid) > j) th = mid;
+          else tl = mid + 1;
+        }
+        const uint64_t k = tl;
         const double scale_t = comb_tile_scale(scale, shift_at(k)), tb = comb_base(pre_at(k), scale, u0);
         const int32_t nhi = nhi_of(k);
         const uint64_t tbase = k * kTile;
@@ -1636,7 +1617,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         const uint64_t g = tbase + (uint64_t)blk * kSubLen + found;
         anc[r] = (uint32_t)(g < A.n ? g : A.n - 1);
       }
-      __syncthreads();  // (barrier count as on the marks path)
+      __syncthreads();
     }
   }
 
@@ -1655,7 +1636,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   if (A.debug_stop == 5) return;
   if (Policy::kEmit) {
     const uint64_t loc = (uint64_t)(jq - A.out_lo);
-    emit_tile(w, ok, qw_out + loc, logw_out ? logw_out + loc : nullptr, recs_out + ot);
+    emit_tile<ADAPTIVE>(w, ok, qw_out + loc, logw_out ? logw_out + loc : nullptr, recs_out + ot);
   }
 }
 

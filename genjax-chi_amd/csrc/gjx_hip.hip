@@ -639,7 +639,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_weights(const float* lw, uint64
     ok[r] = base + r < n;
     w[r] = ok[r] ? lw[base + r] : -__builtin_inff();
   }
-  emit_tile(w, ok, qw + base, nullptr, recs + blockIdx.x);
+  emit_tile<true>(w, ok, qw + base, nullptr, recs + blockIdx.x);
 }
 
 // The merge of a population's tile records by ONE workgroup per filter: anchor e, total mass Q, ESS sums, and — for
@@ -823,6 +823,8 @@ __global__ __launch_bounds__(kBlock) void k_gather(const int32_t* anc, uint64_t 
 // ------------------------------------------------------------------------------------------------
 // Fused bootstrap-SMC policies: propagate + weight the four consecutive output slots of a lane.
 // ------------------------------------------------------------------------------------------------
+// "no window staged": larger than any source index, so that (anc - win_base) wraps to a value beyond the window
+constexpr uint64_t kNoWindow = (uint64_t)1 << 62;
 template <int IMPL>
 struct LgssmPolicy {
   static constexpr bool kEmit = true;
@@ -832,23 +834,45 @@ struct LgssmPolicy {
   Key step_key;
   float a, q, y, rs, lognorm;
   float z[kPer];            // the quad's standard normals (prefetch: they do not depend on the ancestors)
+  uint64_t win_base;        // first source of the staged window (kNoWindow: nothing staged)
+  float* xs;                // LDS: the window's states
   GJX_DEV void select_filter(uint64_t off, Key k) {
     prev_state += off; state_out += off;
     if (anc_out) anc_out += off;
     step_key = k;
   }
   GJX_DEV void prefetch(int64_t jq) { smc_quad_normals<IMPL>(step_key, (uint64_t)jq >> 2, z); }
+  // the lane's 8 consecutive sources of the window scan's first round, into LDS
+  GJX_DEV void stage_window(uint64_t i0, uint64_t i_base, uint64_t n) {
+    __shared__ float xs_win[kWindow];
+    xs = xs_win;
+    win_base = i_base;
+    const uint32_t o = (uint32_t)(i0 - i_base);
+    if (i0 + 8 <= n) {
+      const float4 v0 = reinterpret_cast<const float4*>(prev_state + i0)[0];
+      const float4 v1 = reinterpret_cast<const float4*>(prev_state + i0)[1];
+      reinterpret_cast<float4*>(xs_win + o)[0] = v0;
+      reinterpret_cast<float4*>(xs_win + o)[1] = v1;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) xs_win[o + r] = i0 + r < n ? prev_state[i0 + r] : 0.0f;
+    }
+  }
+  GJX_DEV float source(uint32_t anc) const {
+    const uint64_t o = (uint64_t)anc - win_base;  // (wraps to a huge value below the window or when nothing is staged)
+    return o < (uint64_t)kWindow ? xs[o] : prev_state[anc];
+  }
   struct Out {
     float x;
   };
   // the lane's four consecutive slots jq .. jq+3 (jq a multiple of 4): one quad of normals
   GJX_DEV void compute_quad(int64_t, const uint32_t (&anc)[4], Out (&o)[4], float (&w)[4]) const {
-    float xs[4];
+    float xv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xs[u] = prev_state[anc[u]];
+    for (int u = 0; u < 4; ++u) xv[u] = source(anc[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float mean = a * xs[u];
+      const float mean = a * xv[u];
       const float t = q * z[u];
       o[u].x = mean + t;
       w[u] = logpdf_normal_pre(y, o[u].x, rs, lognorm);
@@ -897,6 +921,8 @@ struct HmmPolicy {
   uint32_t col[kPer], f24[kPer];  // the quad's draws, split into column and fraction (prefetch)
   float oc;                       // obs_logp[tid, y] on its way to LDS
   float* ocol;                    // LDS: column y of the observation table (one entry per state)
+  uint64_t win_base;              // first source of the staged window (kNoWindow: nothing staged)
+  int32_t* zs_;                   // LDS: the window's states
   GJX_DEV void select_filter(uint64_t off, Key k) {
     prev_state += off; state_out += off;
     if (anc_out) anc_out += off;
@@ -918,6 +944,25 @@ struct HmmPolicy {
     ocol = ocol_tile;
     if ((int)threadIdx.x < K) ocol_tile[threadIdx.x] = oc;
   }
+  GJX_DEV void stage_window(uint64_t i0, uint64_t i_base, uint64_t n) {
+    __shared__ int32_t zs_win[kWindow];
+    zs_ = zs_win;
+    win_base = i_base;
+    const uint32_t o = (uint32_t)(i0 - i_base);
+    if (i0 + 8 <= n) {
+      const int4 v0 = reinterpret_cast<const int4*>(prev_state + i0)[0];
+      const int4 v1 = reinterpret_cast<const int4*>(prev_state + i0)[1];
+      reinterpret_cast<int4*>(zs_win + o)[0] = v0;
+      reinterpret_cast<int4*>(zs_win + o)[1] = v1;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) zs_win[o + r] = i0 + r < n ? prev_state[i0 + r] : 0;
+    }
+  }
+  GJX_DEV int32_t source(uint32_t anc) const {
+    const uint64_t o = (uint64_t)anc - win_base;
+    return o < (uint64_t)kWindow ? zs_[o] : prev_state[anc];
+  }
   struct Out {
     int32_t z;
   };
@@ -926,7 +971,7 @@ struct HmmPolicy {
     int32_t zs[4];
     uint32_t e[4], c[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) zs[u] = prev_state[anc[u]];
+    for (int u = 0; u < 4; ++u) zs[u] = source(anc[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) e[u] = trans_cdf[(size_t)zs[u] * K + col[u]];
 #pragma unroll
@@ -2038,12 +2083,18 @@ int gjx_tile_merge(const gjx_tile_rec* recs, uint64_t n_tiles, int32_t* out_e, u
   return launch_status();
 }
 
+// the comb offset of a resampling key: the top 53 bits of its 64-bit draw (sub-stream 0), evaluated on the host — it is
+// launch-uniform, and in the kernel it cost every wave a cipher block
+static double comb_offset(int impl, Key k, int has_fold, uint32_t fold) {
+  if (impl == 0) return u0_from_bits(Stream<0>(k, has_fold != 0, fold).bits64(0));
+  return u0_from_bits(Stream<1>(k, has_fold != 0, fold).bits64(0));
+}
 // test knob: GJX_SMC_SCAN_MAX=0 sends every output tile through the per-slot search (same ancestors either way)
 static int scan_max_knob() {
   static const int v = [] {
     const char* e = std::getenv("GJX_SMC_SCAN_MAX");
     const int x = e ? atoi(e) : kScanMax;
-    return x < 0 ? 0 : (x > kScanMax ? kScanMax : x);
+    return x < 0 ? 0 : (x > 64 ? 64 : x);
   }();
   return v;
 }
@@ -2068,7 +2119,7 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
   ResampleArgs A;
   A.qw = qw; A.recs = recs; A.n = n; A.ntiles = nt;
   A.n_out = n_out; A.out_lo = 0; A.out_hi = (int64_t)n_out;
-  A.rkey = k; A.rkey_has_fold = key->has_fold; A.rkey_fold = key->fold;
+  A.u0 = comb_offset(key->impl, k, key->has_fold, key->fold);
   A.e_out = out_e; A.q_out = out_q;
   A.prefix = prefix;
   A.scan_max = scan_max_knob();
@@ -2173,8 +2224,7 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
   A.recs = reinterpret_cast<const TileRec*>(prev->recs);
   A.n = cfg->n_total; A.ntiles = ntiles_of(cfg->n_total); A.n_out = cfg->n_total;
   A.out_lo = (int64_t)cfg->first_slot; A.out_hi = (int64_t)(cfg->first_slot + cfg->n_local);
-  A.rkey = Key{cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1]};
-  A.rkey_has_fold = 0; A.rkey_fold = 0;
+  A.u0 = comb_offset(cfg->impl, Key{cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1]}, 0, 0);
   A.e_out = prev_e_out; A.q_out = prev_q_out;
   if (ad) A.ess_thr = (double)cfg->ess_threshold * (double)cfg->n_total;
   A.resampled_out = ctx.resampled_out ? ctx.resampled_out : (cfg->resampled_out && !(cfg->n_filters > 1) ? cfg->resampled_out + t : nullptr);
@@ -2191,8 +2241,7 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
   return GJX_OK;
 }
 static EmitOut emit_out_of(const gjx_smc_config* cfg, const gjx_smc_pop* out) {
-  (void)cfg;
-  return EmitOut{out->qw, out->logw, reinterpret_cast<TileRec*>(out->recs)};
+  return EmitOut{out->qw, out->logw, reinterpret_cast<TileRec*>(out->recs), cfg_adaptive(cfg) ? 1 : 0};
 }
 
 static int lgssm_step(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t, const gjx_smc_pop* prev,
@@ -2214,11 +2263,11 @@ static int lgssm_step(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, fl
   int rc = smc_resample_args(cfg, t, prev, out, prev_e_out, prev_q_out, ctx, s, &A);
   if (rc) return rc;
   if (cfg->impl == 0) {
-    LgssmPolicy<0> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}};
+    LgssmPolicy<0> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}, kNoWindow, nullptr};
     if (ad) k_resample<0, LgssmPolicy<0>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
     else k_resample<0, LgssmPolicy<0>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   } else {
-    LgssmPolicy<1> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}};
+    LgssmPolicy<1> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}, kNoWindow, nullptr};
     if (ad) k_resample<1, LgssmPolicy<1>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
     else k_resample<1, LgssmPolicy<1>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   }
@@ -2245,11 +2294,11 @@ static int hmm_step(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_
   int rc = smc_resample_args(cfg, t, prev, out, prev_e_out, prev_q_out, ctx, s, &A);
   if (rc) return rc;
   if (cfg->impl == 0) {
-    HmmPolicy<0> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr};
+    HmmPolicy<0> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr, kNoWindow, nullptr};
     if (ad) k_resample<0, HmmPolicy<0>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
     else k_resample<0, HmmPolicy<0>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   } else {
-    HmmPolicy<1> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr};
+    HmmPolicy<1> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr, kNoWindow, nullptr};
     if (ad) k_resample<1, HmmPolicy<1>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
     else k_resample<1, HmmPolicy<1>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   }
@@ -2339,7 +2388,7 @@ static StepCtx run_step_ctx(const gjx_smc_config* cfg, RunCommon& rc, int t, gjx
     const uint32_t* sk = cfg->step_keys + 2 * ((size_t)f * T + t);
     const uint32_t* rk = cfg->resample_keys + 2 * ((size_t)f * T + t);
     rc.fb.step_key[f] = Key{sk[0], sk[1]};
-    rc.fb.rkey[f] = Key{rk[0], rk[1]};
+    rc.fb.u0[f] = comb_offset(cfg->impl, Key{rk[0], rk[1]}, 0, 0);
   }
   *out = rc.pop[t & 1];
   if (!rc.adaptive) out->logw = t == T - 1 ? rc.logw_final : nullptr;
