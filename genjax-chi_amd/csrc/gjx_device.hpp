@@ -862,18 +862,30 @@ struct FilterBatch {
 constexpr int kTileFrac = kRowFrac;   // fractional bits of the tile-anchored weights (rowfix)
 constexpr int kEssShift = kTileFrac - 16;
 constexpr int kMaxLdsTiles = 1024;    // populations up to 2^20 particles keep the merged tile prefix in LDS
-constexpr int kWindow = 2 * kTile;     // sources one round of the window scan covers (8 consecutive sources per lane)
+#ifndef GJX_SCAN_LANES
+#define GJX_SCAN_LANES 192
+#endif
+constexpr int kScanLanes = GJX_SCAN_LANES;  // lanes of the workgroup that scan sources (8 consecutive sources each)
+constexpr int kWindow = 8 * kScanLanes;      // sources one round of the window scan covers: 1.5 tiles (the slots of an
+                                             // output tile draw from ~1024 + 64 sources; a wider window only reads more)
 constexpr int kScanMax = 4;           // rounds of the window scan before an output tile searches per slot
 constexpr int kSubs = 16;             // sub-prefixes per tile: the running sum of q after every 64th particle
 constexpr int kSubLen = kTile / kSubs;
+// A tile's record is kept as three DENSE arrays indexed by tile — the 16-byte header every workgroup merges (a strided
+// header inside a 160-byte record cost every workgroup of a 1e6-particle step 156 KB of cache lines for 15 KB of
+// payload), the 16 sub-prefixes only the window scan's few lanes read, the ESS sums only adaptive filters read.
 struct alignas(16) TileRec {
   uint64_t s;   // S_t: the tile's mass relative to its own anchor
   int32_t e;    // e_t (kRowEmpty: no mass)
   int32_t pad;
-  uint64_t r1, r2;        // ESS sums of the tile (tile-anchored): sum r_i, sum r_i^2, r_i = q_i >> 14
+};
+struct alignas(16) TileSub {
   uint64_t sub[kSubs];    // sub[b] = sum of q over the tile's particles [0, 64 (b + 1))  (sub[15] = S_t)
 };
-static_assert(sizeof(TileRec) == 160, "gjx.h gjx_tile_rec");
+struct alignas(16) TileEss {
+  uint64_t r1, r2;        // ESS sums of the tile (tile-anchored): sum r_i, sum r_i^2, r_i = q_i >> 14
+};
+static_assert(sizeof(TileRec) == 16 && sizeof(TileSub) == 128 && sizeof(TileEss) == 16, "gjx.h gjx_tile_rec / gjx_tile_sub / gjx_tile_ess");
 // shift of a tile's fixed point relative to the merged anchor e (>= every e_t): 64 = the tile carries no mass
 GJX_HD int tile_shift(int32_t e, int32_t et) {
   if (et == kRowEmpty) return 64;
@@ -889,6 +901,8 @@ struct ResampleArgs {
   const uint32_t* qw = nullptr;         // [n] tile-anchored fixed-point weights of the SOURCE population
   const float* lw = nullptr;            // [n] source log-weights (adaptive filters: a kept step accumulates them)
   const TileRec* recs = nullptr;        // [ntiles] source records
+  const TileSub* subs = nullptr;        // [ntiles] their sub-prefixes
+  const TileEss* ess = nullptr;         // [ntiles] their ESS sums (adaptive filters)
   uint64_t n = 0, ntiles = 0;
   uint64_t n_out = 0;                   // number of comb teeth (global output slots)
   int64_t out_lo = 0, out_hi = 0;       // slots this launch serves (out_lo a multiple of the tile size)
@@ -903,6 +917,8 @@ struct ResampleArgs {
   uint32_t* qw_out = nullptr;           // [n_local] (slot - out_lo)
   float* logw_out = nullptr;            // nullable [n_local]
   TileRec* recs_out = nullptr;          // GLOBAL [tiles of n_out]: entry of every output tile served
+  TileSub* subs_out = nullptr;          // GLOBAL, likewise
+  TileEss* ess_out = nullptr;           // GLOBAL, likewise (adaptive filters)
   int scan_max = kScanMax;              // rounds of the window scan (test knob: 0 = every output tile takes the per-slot search)
   int debug_stop = 0;                   // profiling knob (GJX_SMC_DEBUG_STOP): leave the kernel after phase k
 };
@@ -1149,7 +1165,8 @@ GJX_DEV void policy_store_quad(Policy& P, int64_t jq, int64_t out_lo, const uint
 // exists.  qw_at / logw_at: where the thread's first slot goes (logw_at nullable); rec_at: the tile's record.
 // Called by every thread of the workgroup (two barriers inside).
 template <bool ESS>
-GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint32_t* qw_at, float* logw_at, TileRec* rec_at) {
+GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint32_t* qw_at, float* logw_at, TileRec* rec_at,
+                       TileSub* sub_at, TileEss* ess_at) {
   constexpr int kW = kBlock / kWave;
   __shared__ float em_f[kW];
   __shared__ uint64_t em_q[3 * kW];
@@ -1206,18 +1223,20 @@ GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint32_t*
     }
   }
   // the record: the last lane of every row of 16 lanes holds the running sum after its 64-particle block
-  if ((lane & 15) == 15) rec_at->sub[tid >> 4] = base + incl;
+  if ((lane & 15) == 15) sub_at->sub[tid >> 4] = base + incl;
   if (tid == kBlock - 1) {
-    uint64_t t1 = 0, t2 = 0;
-    if (ESS) {
+    TileRec rec;
+    rec.s = base + incl;
+    rec.e = e;
+    rec.pad = 0;
+    *rec_at = rec;
+    if (ESS && ess_at) {
+      uint64_t t1 = 0, t2 = 0;
 #pragma unroll
       for (int i = 0; i < kW; ++i) { t1 += em_q[kW + i]; t2 += em_q[2 * kW + i]; }
+      ess_at->r1 = t1;
+      ess_at->r2 = t2;
     }
-    rec_at->s = base + incl;
-    rec_at->e = e;
-    rec_at->pad = 0;
-    rec_at->r1 = t1;
-    rec_at->r2 = t2;
   }
 }
 
@@ -1227,16 +1246,19 @@ struct EmitOut {
   uint32_t* qw;    // [n_local]
   float* logw;     // nullable [n_local]
   TileRec* recs;   // GLOBAL [tiles]
-  int ess;         // the filter is ESS-adaptive: the records carry the ESS sums
+  TileSub* subs;   // GLOBAL [tiles]
+  TileEss* ess;    // nullable GLOBAL [tiles]: the filter is ESS-adaptive
 };
 GJX_DEV void emit_init_tile(const float (&w)[kPer], const bool (&ok)[kPer], const EmitOut& em, uint64_t loc, uint64_t gtile) {
-  if (em.ess) emit_tile<true>(w, ok, em.qw + loc, em.logw ? em.logw + loc : nullptr, em.recs + gtile);
-  else emit_tile<false>(w, ok, em.qw + loc, em.logw ? em.logw + loc : nullptr, em.recs + gtile);
+  if (em.ess) emit_tile<true>(w, ok, em.qw + loc, em.logw ? em.logw + loc : nullptr, em.recs + gtile, em.subs + gtile, em.ess + gtile);
+  else emit_tile<false>(w, ok, em.qw + loc, em.logw ? em.logw + loc : nullptr, em.recs + gtile, em.subs + gtile, nullptr);
 }
 GJX_DEV void select_filter_emit(EmitOut& em, const FilterBatch& fb, uint32_t f) {
   em.qw += (uint64_t)f * fb.stride;
   if (em.logw) em.logw += (uint64_t)f * fb.stride;
   em.recs += (uint64_t)f * fb.tiles;
+  em.subs += (uint64_t)f * fb.tiles;
+  if (em.ess) em.ess += (uint64_t)f * fb.tiles;
 }
 
 // Exclusive block max-scan of one u32 per thread (identity 0).  `sh` needs 4 words.
@@ -1265,21 +1287,12 @@ GJX_DEV uint64_t scan8_incl(uint64_t v) {
   return v;
 }
 
-// the policy's source state for the window scan's first round (optional): loads the lane's 8 consecutive sources and
-// stages them in LDS, so that compute() finds its ancestors without another trip to memory
-template <class Policy>
-GJX_DEV auto policy_stage_window(Policy& P, uint64_t i0, uint64_t i_base, uint64_t n, int) -> decltype(P.stage_window(i0, i_base, n), void()) {
-  P.stage_window(i0, i_base, n);
-}
-template <class Policy>
-GJX_DEV void policy_stage_window(Policy&, uint64_t, uint64_t, uint64_t, long) {}
-
 // ADAPTIVE: the launch may be a step of an ESS-adaptive filter (A.ess_thr > 0): only then does the kernel carry the
 // decision, the ESS sums and the keep-your-particle path (the every-step filters are compiled without them).
 template <int IMPL, class Policy, bool ADAPTIVE = true>
 GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   constexpr int kW = kBlock / kWave;
-  constexpr int kSrc = kWindow / kBlock;         // sources per lane and round of the window scan
+  constexpr int kSrc = 8;                        // sources per lane and round of the window scan
   static_assert(kSrc == 8 && kSubLen == 64, "8 consecutive sources per lane: a 64-particle block is 8 lanes");
   __shared__ uint64_t sh_pre[kMaxLdsTiles + 1];  // merged exclusive tile prefix (populations up to kMaxLdsTiles tiles)
   __shared__ uint8_t sh_d[kMaxLdsTiles];         // every tile's shift to the merged anchor
@@ -1295,12 +1308,17 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   const uint32_t* qw_all = A.qw;
   const float* lw_all = A.lw;
   const TileRec* recs = A.recs;
+  const TileSub* subs = A.subs;
+  const TileEss* ess = A.ess;
   int32_t* e_out = A.e_out;
   uint64_t* q_out = A.q_out;
   int32_t* resampled_out = A.resampled_out;
   uint32_t* qw_out = A.qw_out;
   float* logw_out = A.logw_out;
   TileRec* recs_out = A.recs_out;
+  TileSub* subs_out = A.subs_out;
+  TileEss* ess_out = A.ess_out;
+  const uint64_t* prefix = A.prefix;
   double u0 = A.u0;
   if (A.fb.n_filters > 1) {
     const uint32_t f = (uint32_t)(b / A.fb.tiles);
@@ -1308,12 +1326,17 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     qw_all += (uint64_t)f * A.fb.stride;
     if (lw_all) lw_all += (uint64_t)f * A.fb.stride;
     recs += (uint64_t)f * A.fb.tiles;
+    subs += (uint64_t)f * A.fb.tiles;
+    if (ess) ess += (uint64_t)f * A.fb.tiles;
     if (e_out) e_out += (uint64_t)f * A.fb.mq_stride;
     if (q_out) q_out += (uint64_t)f * A.fb.mq_stride;
     if (resampled_out) resampled_out += (uint64_t)f * A.fb.mq_stride;
     if (qw_out) qw_out += (uint64_t)f * A.fb.stride;
     if (logw_out) logw_out += (uint64_t)f * A.fb.stride;
     if (recs_out) recs_out += (uint64_t)f * A.fb.tiles;
+    if (subs_out) subs_out += (uint64_t)f * A.fb.tiles;
+    if (ess_out) ess_out += (uint64_t)f * A.fb.tiles;
+    if (prefix) prefix += (uint64_t)f * prefix_words(A.fb.tiles);
     u0 = A.fb.u0[f];
     P.select_filter((uint64_t)f * A.fb.stride, A.fb.step_key[f]);
   }
@@ -1326,7 +1349,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
 
   // ---- the source records (issued first; the policy's ancestor-independent work runs under their latency) --------
   constexpr int kC = kMaxLdsTiles / kBlock;  // tiles per thread of the in-kernel merge
-  const bool lds_prefix = A.prefix == nullptr;  // (launch-uniform)
+  const bool lds_prefix = prefix == nullptr;  // (launch-uniform)
   const uint64_t c_per = (A.ntiles + kBlock - 1) / kBlock;
   const uint64_t k0 = (uint64_t)tid * c_per;
   uint64_t rs_[kC], ev1[kC], ev2[kC];
@@ -1344,8 +1367,8 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         rs_[i] = 0;
         re_[i] = kRowEmpty;
       }
-      ev1[i] = adaptive && in ? recs[k].r1 : 0;
-      ev2[i] = adaptive && in ? recs[k].r2 : 0;
+      ev1[i] = adaptive && in ? ess[k].r1 : 0;
+      ev2[i] = adaptive && in ? ess[k].r2 : 0;
     }
   }
 #pragma unroll
@@ -1403,9 +1426,9 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     }
     if (tid == 0) sh_pre[A.ntiles] = tot;
   } else {
-    tot = A.prefix[A.ntiles];
-    e = (int32_t)(int64_t)A.prefix[A.ntiles + 1];
-    if (adaptive) { r1 = A.prefix[A.ntiles + 2]; r2 = A.prefix[A.ntiles + 3]; }
+    tot = prefix[A.ntiles];
+    e = (int32_t)(int64_t)prefix[A.ntiles + 1];
+    if (adaptive) { r1 = prefix[A.ntiles + 2]; r2 = prefix[A.ntiles + 3]; }
   }
   if (b == 0 && tid == 0) {
     if (e_out) e_out[0] = e;
@@ -1414,9 +1437,9 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   const bool resample = !adaptive || ess_says_resample(r1, r2, A.ess_thr);
   if (resampled_out && b == 0 && tid == 0) resampled_out[0] = resample ? 1 : 0;
   policy_stage(P, 0);  // (every path below passes a barrier before the policy computes)
-  if (A.debug_stop == 1) return;
+  if ((A.debug_stop & 15) == 1) return;
 
-  auto pre_at = [&](uint64_t k) -> uint64_t { return lds_prefix ? sh_pre[k] : A.prefix[k]; };
+  auto pre_at = [&](uint64_t k) -> uint64_t { return lds_prefix ? sh_pre[k] : prefix[k]; };
   auto shift_at = [&](uint64_t k) -> int { return lds_prefix ? (int)sh_d[k] : tile_shift(e, recs[k].e); };
 
   uint32_t anc[kPer];
@@ -1452,21 +1475,33 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     uint64_t k_lo = 0;
     if (lds_prefix) {
       __syncthreads();  // sh_pre / sh_d complete
-      // (monotone: the chunk that holds k_lo is the one whose start lies at or below j0 and whose end beyond it; only that
-      // thread walks its tiles)
+      // (monotone: the chunk of tiles that holds k_lo is the one whose start lies at or below j0 and whose end beyond it;
+      // only that thread walks its tiles)
+      const uint64_t k1 = k0 + c_per < A.ntiles ? k0 + c_per : A.ntiles;
       const int32_t c_lo = comb_tile(chunk_pre, scale, u0, n_out);
-      const int32_t c_hi = k0 + c_per >= A.ntiles ? n_out : comb_tile(chunk_pre + chunk_mass, scale, u0, n_out);
+      const int32_t c_hi = k1 >= A.ntiles ? n_out : comb_tile(chunk_pre + chunk_mass, scale, u0, n_out);
       if (k0 < A.ntiles && c_lo <= j0 && c_hi > j0) {
-        uint64_t run = chunk_pre;
-#pragma unroll
-        for (int i = 0; i < kC; ++i) {
-          const uint64_t k = k0 + i;
-          if ((uint64_t)i < c_per && k < A.ntiles) {
-            run += mass[i];
-            const int32_t hi_t = k + 1 >= A.ntiles ? n_out : comb_tile(run, scale, u0, n_out);
-            if (hi_t > j0) atomicMin(&sh_klo, (uint32_t)k);
+        for (uint64_t k = k0; k < k1; ++k) {
+          const int32_t hi_t = k + 1 >= A.ntiles ? n_out : comb_tile(sh_pre[k + 1], scale, u0, n_out);
+          if (hi_t > j0) {
+            atomicMin(&sh_klo, (uint32_t)k);
+            break;
           }
         }
+      }
+      __syncthreads();
+      k_lo = sh_klo;
+    } else if (A.ntiles <= (uint64_t)(kWave * 16)) {
+      // a precomputed prefix of up to 1024 tiles (filter batches): ONE wave samples every 16th entry, then the 16 entries
+      // of the bracket — two small loads instead of every thread reading its share of the whole prefix
+      if (wv == 0) {
+        const uint64_t ks = (uint64_t)lane * 16 + 15 < A.ntiles ? (uint64_t)lane * 16 + 15 : A.ntiles - 1;  // the END tile of group `lane`
+        const bool in = (uint64_t)lane * 16 < A.ntiles;
+        const uint64_t hit = __ballot(in && nhi_of(ks) > j0);  // (non-empty: the last tile's end lies beyond every slot)
+        const uint64_t g = hit ? (uint64_t)__builtin_ctzll(hit) : 0;
+        const uint64_t kk = g * 16 + (uint64_t)(lane & 15);
+        const uint64_t hit2 = __ballot(lane < 16 && kk < A.ntiles && nhi_of(kk) > j0);
+        if (lane == 0) sh_klo = (uint32_t)(g * 16 + (hit2 ? (uint64_t)__builtin_ctzll(hit2) : 0));
       }
       __syncthreads();
       k_lo = sh_klo;
@@ -1492,14 +1527,14 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
       __syncthreads();
       k_lo = lo + sh_klo;
     }
-    if (A.debug_stop == 2) return;
+    if ((A.debug_stop & 15) == 2) return;
     // ---- the window: it starts at the 64-particle block of tile k_lo that holds the first tooth of [j0, j1) ----------
     uint64_t i_base;
     {
       const uint64_t tbase = k_lo * kTile;
       const uint64_t cnt = tbase + kTile <= A.n ? (uint64_t)kTile : A.n - tbase;
       const int sb = lane & (kSubs - 1);  // (every 16 lanes evaluate the tile's 16 sub-prefixes: no exchange needed)
-      const uint64_t cs = recs[k_lo].sub[sb];
+      const uint64_t cs = subs[k_lo].sub[sb];
       const double scale_t = comb_tile_scale(scale, shift_at(k_lo)), tb = comb_base(pre_at(k_lo), scale, u0);
       const int32_t nhi = nhi_of(k_lo);
       const bool ends_tile = (uint64_t)(sb + 1) * kSubLen >= cnt;
@@ -1515,7 +1550,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
       // scan (integer adds: no exponential, no workgroup-wide scan), teeth below each, marks where runs start -----------
       const uint64_t i0 = i_base + (uint64_t)rounds * kWindow + (uint64_t)kSrc * tid;
       const uint64_t k = i0 >> 10;
-      const bool live = i0 < A.n;
+      const bool live = i0 < A.n && tid < kScanLanes;
       uint32_t q[kSrc];
       if (live && i0 + kSrc <= A.n) {
         const uint4 v0 = reinterpret_cast<const uint4*>(qw_all + i0)[0];
@@ -1526,8 +1561,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         for (int r = 0; r < kSrc; ++r) q[r] = live && i0 + r < A.n ? qw_all[i0 + r] : 0u;
       }
       const uint32_t sbk = (uint32_t)(i0 >> 6) & (kSubs - 1);
-      const uint64_t subpre = live && sbk ? recs[k].sub[sbk - 1] : 0;
-      if (rounds == 0) policy_stage_window(P, i0, i_base, A.n, 0);
+      const uint64_t subpre = live && sbk ? subs[k].sub[sbk - 1] : 0;
       uint64_t own = 0;
 #pragma unroll
       for (int r = 0; r < kSrc; ++r) own += q[r];
@@ -1552,11 +1586,11 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         }
       }
       // the window reaches the end of the workgroup's slots?  (two flags by round parity: a wave may be one barrier ahead)
-      if (tid == kBlock - 1) sh_cov[rounds & 1] = n_end >= j1 ? 1u : 0u;
+      if (tid == kScanLanes - 1) sh_cov[rounds & 1] = n_end >= j1 ? 1u : 0u;
       __syncthreads();
       covered = sh_cov[rounds & 1] != 0;
     }
-    if (A.debug_stop == 3) return;
+    if ((A.debug_stop & 15) == 3) return;
     if (covered) {
       // ---- a max-scan spreads the marks over the runs ----------------------------------------------------------------
       uint32_t v[kPer];
@@ -1596,7 +1630,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         bool have = false;
         uint64_t cbase = 0;  // running sum before the block
         for (int sb = 0; sb < kSubs; ++sb) {
-          const uint64_t cs = recs[k].sub[sb];
+          const uint64_t cs = subs[k].sub[sb];
           const bool ends_tile = (uint64_t)(sb + 1) * kSubLen >= cnt;
           const int32_t ns = ends_tile ? nhi : comb_in_tile((double)cs, scale_t, tb, nhi, n_out);
           if (!have && (int64_t)ns > j) { blk = (uint32_t)sb; have = true; }
@@ -1621,7 +1655,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     }
   }
 
-  if (A.debug_stop == 4) {
+  if ((A.debug_stop & 15) == 4) {
     if (anc[0] == 0xffffffffu) marks[0] = anc[1] + anc[2] + anc[3];
     return;
   }
@@ -1633,10 +1667,11 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     for (int r = 0; r < kPer; ++r) w[r] = w[r] + lw_prev[r];
   }
   policy_store_quad(P, jq, A.out_lo, anc, out, ok, 0);
-  if (A.debug_stop == 5) return;
+  if ((A.debug_stop & 15) == 5) return;
   if (Policy::kEmit) {
     const uint64_t loc = (uint64_t)(jq - A.out_lo);
-    emit_tile<ADAPTIVE>(w, ok, qw_out + loc, logw_out ? logw_out + loc : nullptr, recs_out + ot);
+    emit_tile<ADAPTIVE>(w, ok, qw_out + loc, logw_out ? logw_out + loc : nullptr, recs_out + ot, subs_out + ot,
+                        adaptive && ess_out ? ess_out + ot : nullptr);
   }
 }
 

@@ -630,7 +630,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_sums_block(const float* lw, uin
 
 // Tile-anchored fixed-point weights and records of ARBITRARY log-weights (the generic resampler's front half; the SMC
 // kernels emit theirs themselves): one workgroup per tile.
-__global__ __launch_bounds__(kBlock) void k_tile_weights(const float* lw, uint64_t n, uint32_t* qw, TileRec* recs) {
+__global__ __launch_bounds__(kBlock) void k_tile_weights(const float* lw, uint64_t n, uint32_t* qw, TileRec* recs, TileSub* subs,
+                                                         TileEss* ess) {
   const uint64_t base = (uint64_t)blockIdx.x * kTile + (uint64_t)kPer * threadIdx.x;
   float w[kPer];
   bool ok[kPer];
@@ -639,18 +640,20 @@ __global__ __launch_bounds__(kBlock) void k_tile_weights(const float* lw, uint64
     ok[r] = base + r < n;
     w[r] = ok[r] ? lw[base + r] : -__builtin_inff();
   }
-  emit_tile<true>(w, ok, qw + base, nullptr, recs + blockIdx.x);
+  if (ess) emit_tile<true>(w, ok, qw + base, nullptr, recs + blockIdx.x, subs + blockIdx.x, ess + blockIdx.x);
+  else emit_tile<false>(w, ok, qw + base, nullptr, recs + blockIdx.x, subs + blockIdx.x, nullptr);
 }
 
 // The merge of a population's tile records by ONE workgroup per filter: anchor e, total mass Q, ESS sums, and — for
 // populations beyond kMaxLdsTiles, where every resample workgroup merging all records itself would dominate — the
 // exclusive prefix of the shifted tile masses (layout: gjx_device.hpp prefix_words).  Also the closing (e, Q) of a run.
-__global__ __launch_bounds__(kBlock) void k_scan_records(const TileRec* recs, int with_ess, uint64_t ntiles,
+__global__ __launch_bounds__(kBlock) void k_scan_records(const TileRec* recs, const TileEss* ess, uint64_t ntiles,
                                                          uint64_t* prefix, int32_t* e_out, uint64_t* q_out, uint64_t mq_stride) {
   __shared__ uint64_t sh64[kBlock / kWave];
   __shared__ uint64_t sh_e[2 * (kBlock / kWave)];
   __shared__ float shf[kBlock / kWave];
   recs += (uint64_t)blockIdx.x * ntiles;  // one workgroup per filter
+  if (ess) ess += (uint64_t)blockIdx.x * ntiles;
   if (prefix) prefix += (uint64_t)blockIdx.x * prefix_words(ntiles);
   const uint64_t per = (ntiles + kBlock - 1) / kBlock;
   const uint64_t lo = threadIdx.x * per < ntiles ? threadIdx.x * per : ntiles, hi = lo + per < ntiles ? lo + per : ntiles;
@@ -665,11 +668,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_records(const TileRec* recs, in
   for (uint64_t k = lo; k < hi; ++k) {
     const int d = tile_shift(e, recs[k].e);
     local += shr64(recs[k].s, d);
-    if (with_ess) { l1 += shr64(recs[k].r1, d); l2 += shr64(recs[k].r2, 2 * d); }
+    if (ess) { l1 += shr64(ess[k].r1, d); l2 += shr64(ess[k].r2, 2 * d); }
   }
   uint64_t total;
   uint64_t run = block_scan_excl(local, sh64, total);
-  if (with_ess) {
+  if (ess) {
     l1 = block_sum(l1, sh_e);
     l2 = block_sum(l2, sh_e + kBlock / kWave);
   }
@@ -823,8 +826,6 @@ __global__ __launch_bounds__(kBlock) void k_gather(const int32_t* anc, uint64_t 
 // ------------------------------------------------------------------------------------------------
 // Fused bootstrap-SMC policies: propagate + weight the four consecutive output slots of a lane.
 // ------------------------------------------------------------------------------------------------
-// "no window staged": larger than any source index, so that (anc - win_base) wraps to a value beyond the window
-constexpr uint64_t kNoWindow = (uint64_t)1 << 62;
 template <int IMPL>
 struct LgssmPolicy {
   static constexpr bool kEmit = true;
@@ -834,34 +835,13 @@ struct LgssmPolicy {
   Key step_key;
   float a, q, y, rs, lognorm;
   float z[kPer];            // the quad's standard normals (prefetch: they do not depend on the ancestors)
-  uint64_t win_base;        // first source of the staged window (kNoWindow: nothing staged)
-  float* xs;                // LDS: the window's states
   GJX_DEV void select_filter(uint64_t off, Key k) {
     prev_state += off; state_out += off;
     if (anc_out) anc_out += off;
     step_key = k;
   }
   GJX_DEV void prefetch(int64_t jq) { smc_quad_normals<IMPL>(step_key, (uint64_t)jq >> 2, z); }
-  // the lane's 8 consecutive sources of the window scan's first round, into LDS
-  GJX_DEV void stage_window(uint64_t i0, uint64_t i_base, uint64_t n) {
-    __shared__ float xs_win[kWindow];
-    xs = xs_win;
-    win_base = i_base;
-    const uint32_t o = (uint32_t)(i0 - i_base);
-    if (i0 + 8 <= n) {
-      const float4 v0 = reinterpret_cast<const float4*>(prev_state + i0)[0];
-      const float4 v1 = reinterpret_cast<const float4*>(prev_state + i0)[1];
-      reinterpret_cast<float4*>(xs_win + o)[0] = v0;
-      reinterpret_cast<float4*>(xs_win + o)[1] = v1;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) xs_win[o + r] = i0 + r < n ? prev_state[i0 + r] : 0.0f;
-    }
-  }
-  GJX_DEV float source(uint32_t anc) const {
-    const uint64_t o = (uint64_t)anc - win_base;  // (wraps to a huge value below the window or when nothing is staged)
-    return o < (uint64_t)kWindow ? xs[o] : prev_state[anc];
-  }
+  GJX_DEV float source(uint32_t anc) const { return prev_state[anc]; }
   struct Out {
     float x;
   };
@@ -921,8 +901,6 @@ struct HmmPolicy {
   uint32_t col[kPer], f24[kPer];  // the quad's draws, split into column and fraction (prefetch)
   float oc;                       // obs_logp[tid, y] on its way to LDS
   float* ocol;                    // LDS: column y of the observation table (one entry per state)
-  uint64_t win_base;              // first source of the staged window (kNoWindow: nothing staged)
-  int32_t* zs_;                   // LDS: the window's states
   GJX_DEV void select_filter(uint64_t off, Key k) {
     prev_state += off; state_out += off;
     if (anc_out) anc_out += off;
@@ -944,25 +922,7 @@ struct HmmPolicy {
     ocol = ocol_tile;
     if ((int)threadIdx.x < K) ocol_tile[threadIdx.x] = oc;
   }
-  GJX_DEV void stage_window(uint64_t i0, uint64_t i_base, uint64_t n) {
-    __shared__ int32_t zs_win[kWindow];
-    zs_ = zs_win;
-    win_base = i_base;
-    const uint32_t o = (uint32_t)(i0 - i_base);
-    if (i0 + 8 <= n) {
-      const int4 v0 = reinterpret_cast<const int4*>(prev_state + i0)[0];
-      const int4 v1 = reinterpret_cast<const int4*>(prev_state + i0)[1];
-      reinterpret_cast<int4*>(zs_win + o)[0] = v0;
-      reinterpret_cast<int4*>(zs_win + o)[1] = v1;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) zs_win[o + r] = i0 + r < n ? prev_state[i0 + r] : 0;
-    }
-  }
-  GJX_DEV int32_t source(uint32_t anc) const {
-    const uint64_t o = (uint64_t)anc - win_base;
-    return o < (uint64_t)kWindow ? zs_[o] : prev_state[anc];
-  }
+  GJX_DEV int32_t source(uint32_t anc) const { return prev_state[anc]; }
   struct Out {
     int32_t z;
   };
@@ -1006,7 +966,7 @@ struct HmmPolicy {
 // (P = prefix * N / Q in float64, the products teeth_below forms), both bounds monotone in b, so a block's range is
 // [#tiles with upper <= lo, #tiles with lower < hi).
 constexpr int kMaxRangeBlocks = 64;
-__global__ __launch_bounds__(kBlock) void k_source_ranges(const TileRec* recs, double ess_thr,
+__global__ __launch_bounds__(kBlock) void k_source_ranges(const TileRec* recs, const TileEss* ess, double ess_thr,
                                                           uint64_t ntiles, uint64_t n_total, int world, int64_t ticket,
                                                           int64_t* out) {
   __shared__ uint64_t sh64[kBlock / kWave];
@@ -1030,8 +990,8 @@ __global__ __launch_bounds__(kBlock) void k_source_ranges(const TileRec* recs, d
     local += mass(b);
     if (ess_thr > 0.0) {
       const int d = tile_shift(e, recs[b].e);
-      l1 += shr64(recs[b].r1, d);
-      l2 += shr64(recs[b].r2, 2 * d);
+      l1 += shr64(ess[b].r1, d);
+      l2 += shr64(ess[b].r2, 2 * d);
     }
   }
   if (ess_thr > 0.0) {  // an adaptive filter that keeps its particles at the next step needs no exchange at all:
@@ -1259,10 +1219,10 @@ size_t gjx_workspace_bytes(int op, uint64_t n) {
     case GJX_OP_LOGSUMEXP: return pad256(nrows_of(n) * 4) + pad256(nt * 8) + 1024;
     case GJX_OP_CATEGORICAL_INDEX:
     case GJX_OP_RESAMPLE:  // (multinomial: tile maxima, masses, global CDF; systematic: in-tile CDF, records, prefix)
-      return pad256(nt * 4) + 2 * pad256(nt * 8) + pad256(n * 8) + pad256(nt * sizeof(TileRec)) + pad256(prefix_words(nt) * 8) + 1024;
+      return pad256(nt * 4) + 2 * pad256(nt * 8) + pad256(n * 8) + pad256(nt * 160) + pad256(prefix_words(nt) * 8) + 2048;
     case GJX_OP_SMC:  // the second copy of up to 4 state columns and the log-weights, two columns of fixed-point weights,
                       // two sets of records and merged prefixes, HMM tables
-      return (GJX_SMC_MAX_STATE + 3) * pad256(n * 4) + 2 * pad256(nt * sizeof(TileRec)) + 2 * pad256(prefix_words(nt) * 8) +
+      return (GJX_SMC_MAX_STATE + 3) * pad256(n * 4) + 2 * (pad256(nt * 16) + pad256(nt * 128) + pad256(nt * 16)) + 2 * pad256(prefix_words(nt) * 8) + 4096 +
              pad256(256 * (256 + 64) * 4) + pad256(256 * 256 * 4) + 1024;
     default: return 0;
   }
@@ -2072,14 +2032,16 @@ int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, 
   return launch_status();
 }
 
-int gjx_tile_weights(const float* x, uint64_t n, uint32_t* qw, gjx_tile_rec* recs, gjx_stream s) {
-  if (!x || !qw || !recs || n == 0 || n > 0x7fffffffull) return GJX_ERR_INVALID;
-  k_tile_weights<<<(unsigned)ntiles_of(n), kBlock, 0, S(s)>>>(x, n, qw, reinterpret_cast<TileRec*>(recs));
+int gjx_tile_weights(const float* x, uint64_t n, uint32_t* qw, gjx_tile_rec* recs, gjx_tile_sub* subs, gjx_tile_ess* ess,
+                     gjx_stream s) {
+  if (!x || !qw || !recs || !subs || n == 0 || n > 0x7fffffffull) return GJX_ERR_INVALID;
+  k_tile_weights<<<(unsigned)ntiles_of(n), kBlock, 0, S(s)>>>(x, n, qw, reinterpret_cast<TileRec*>(recs), reinterpret_cast<TileSub*>(subs),
+                                                              reinterpret_cast<TileEss*>(ess));
   return launch_status();
 }
 int gjx_tile_merge(const gjx_tile_rec* recs, uint64_t n_tiles, int32_t* out_e, uint64_t* out_q, gjx_stream s) {
   if (!recs || n_tiles == 0) return GJX_ERR_INVALID;
-  k_scan_records<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), 0, n_tiles, nullptr, out_e, out_q, 0);
+  k_scan_records<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), nullptr, n_tiles, nullptr, out_e, out_q, 0);
   return launch_status();
 }
 
@@ -2112,12 +2074,13 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
   Carver cv{(char*)ws, ws ? ws_bytes : 0};
   uint32_t* qw = cv.take<uint32_t>(n);
   TileRec* recs = cv.take<TileRec>(nt);
+  TileSub* subs = cv.take<TileSub>(nt);
   uint64_t* prefix = nt > (uint64_t)kMaxLdsTiles ? cv.take<uint64_t>(prefix_words(nt)) : nullptr;
   if (!cv.ok) return GJX_ERR_WORKSPACE;
-  k_tile_weights<<<(unsigned)nt, kBlock, 0, S(s)>>>(logw, n, qw, recs);
-  if (prefix) k_scan_records<<<1, kBlock, 0, S(s)>>>(recs, 0, nt, prefix, nullptr, nullptr, 0);
+  k_tile_weights<<<(unsigned)nt, kBlock, 0, S(s)>>>(logw, n, qw, recs, subs, nullptr);
+  if (prefix) k_scan_records<<<1, kBlock, 0, S(s)>>>(recs, nullptr, nt, prefix, nullptr, nullptr, 0);
   ResampleArgs A;
-  A.qw = qw; A.recs = recs; A.n = n; A.ntiles = nt;
+  A.qw = qw; A.recs = recs; A.subs = subs; A.n = n; A.ntiles = nt;
   A.n_out = n_out; A.out_lo = 0; A.out_hi = (int64_t)n_out;
   A.u0 = comb_offset(key->impl, k, key->has_fold, key->fold);
   A.e_out = out_e; A.q_out = out_q;
@@ -2180,7 +2143,7 @@ static bool cfg_ok(const gjx_smc_config* c) {
          c->resample_keys && (c->first_slot % kTile) == 0 && c->n_total <= 0x7fffffffull &&
          !(c->ess_threshold < 0.0f);
 }
-static_assert(sizeof(gjx_tile_rec) == sizeof(TileRec) && alignof(TileRec) == 16 && offsetof(gjx_tile_rec, sub) == offsetof(TileRec, sub), "gjx.h gjx_tile_rec");
+static_assert(sizeof(gjx_tile_rec) == sizeof(TileRec) && sizeof(gjx_tile_sub) == sizeof(TileSub) && sizeof(gjx_tile_ess) == sizeof(TileEss), "gjx.h tile records");
 
 uint64_t gjx_hmm_alias_words(int32_t n_states) {
   return n_states > 0 ? (uint64_t)n_states * (uint64_t)n_states : 0;
@@ -2203,12 +2166,12 @@ struct StepCtx {
 
 // a population a step READS (t >= 1) / WRITES: the pointers its configuration needs
 static bool pop_ok(const gjx_smc_pop* p, int n_state, bool adaptive, bool reading, uint64_t nt) {
-  if (!p || !p->qw || !p->recs) return false;
+  if (!p || !p->qw || !p->recs || !p->subs) return false;
   for (int k = 0; k < n_state; ++k)
     if (!p->state[k]) return false;
-  if (adaptive && !p->logw) return false;
+  if (adaptive && (!p->logw || !p->ess)) return false;
   if (reading && nt > (uint64_t)kMaxLdsTiles && !p->prefix) return false;
-  if (((uintptr_t)p->recs & 15) != 0) return false;
+  if ((((uintptr_t)p->recs | (uintptr_t)p->subs | (uintptr_t)p->ess) & 15) != 0) return false;
   return true;
 }
 
@@ -2222,6 +2185,8 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
   A.qw = prev->qw;
   A.lw = ad ? prev->logw : nullptr;
   A.recs = reinterpret_cast<const TileRec*>(prev->recs);
+  A.subs = reinterpret_cast<const TileSub*>(prev->subs);
+  A.ess = ad ? reinterpret_cast<const TileEss*>(prev->ess) : nullptr;
   A.n = cfg->n_total; A.ntiles = ntiles_of(cfg->n_total); A.n_out = cfg->n_total;
   A.out_lo = (int64_t)cfg->first_slot; A.out_hi = (int64_t)(cfg->first_slot + cfg->n_local);
   A.u0 = comb_offset(cfg->impl, Key{cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1]}, 0, 0);
@@ -2230,18 +2195,25 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
   A.resampled_out = ctx.resampled_out ? ctx.resampled_out : (cfg->resampled_out && !(cfg->n_filters > 1) ? cfg->resampled_out + t : nullptr);
   A.qw_out = out->qw; A.logw_out = out->logw;
   A.recs_out = reinterpret_cast<TileRec*>(out->recs);
+  A.subs_out = reinterpret_cast<TileSub*>(out->subs);
+  A.ess_out = ad ? reinterpret_cast<TileEss*>(out->ess) : nullptr;
   A.scan_max = scan_max_knob();
   static const int dbg_stop = [] { const char* e = std::getenv("GJX_SMC_DEBUG_STOP"); return e ? atoi(e) : 0; }();
   A.debug_stop = dbg_stop;
-  if (A.ntiles > (uint64_t)kMaxLdsTiles) {
-    if (ctx.fb.n_filters > 1) return GJX_ERR_UNSUPPORTED;
-    k_scan_records<<<1, kBlock, 0, S(s)>>>(A.recs, ad ? 1 : 0, A.ntiles, prev->prefix, nullptr, nullptr, 0);
+  // The merged prefix by ONE small launch (a workgroup per filter) instead of in every workgroup: required beyond
+  // kMaxLdsTiles, and worth it from a few filters per launch (the whole-run drivers provide prev->prefix then), where its
+  // ~4 us are shared by all filters while every one of the F x tiles workgroups saves the merge of its filter's records.
+  if (A.ntiles > (uint64_t)kMaxLdsTiles || (ctx.fb.n_filters > 1 && prev->prefix)) {
+    if (ctx.fb.n_filters > 1 && A.ntiles > (uint64_t)kMaxLdsTiles) return GJX_ERR_UNSUPPORTED;
+    const unsigned nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
+    k_scan_records<<<nf, kBlock, 0, S(s)>>>(A.recs, A.ess, A.ntiles, prev->prefix, nullptr, nullptr, 0);
     A.prefix = prev->prefix;
   }
   return GJX_OK;
 }
 static EmitOut emit_out_of(const gjx_smc_config* cfg, const gjx_smc_pop* out) {
-  return EmitOut{out->qw, out->logw, reinterpret_cast<TileRec*>(out->recs), cfg_adaptive(cfg) ? 1 : 0};
+  return EmitOut{out->qw, out->logw, reinterpret_cast<TileRec*>(out->recs), reinterpret_cast<TileSub*>(out->subs),
+                 cfg_adaptive(cfg) ? reinterpret_cast<TileEss*>(out->ess) : nullptr};
 }
 
 static int lgssm_step(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, float y_t, const gjx_smc_pop* prev,
@@ -2263,11 +2235,11 @@ static int lgssm_step(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, fl
   int rc = smc_resample_args(cfg, t, prev, out, prev_e_out, prev_q_out, ctx, s, &A);
   if (rc) return rc;
   if (cfg->impl == 0) {
-    LgssmPolicy<0> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}, kNoWindow, nullptr};
+    LgssmPolicy<0> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}};
     if (ad) k_resample<0, LgssmPolicy<0>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
     else k_resample<0, LgssmPolicy<0>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   } else {
-    LgssmPolicy<1> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}, kNoWindow, nullptr};
+    LgssmPolicy<1> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}};
     if (ad) k_resample<1, LgssmPolicy<1>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
     else k_resample<1, LgssmPolicy<1>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   }
@@ -2294,11 +2266,11 @@ static int hmm_step(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_
   int rc = smc_resample_args(cfg, t, prev, out, prev_e_out, prev_q_out, ctx, s, &A);
   if (rc) return rc;
   if (cfg->impl == 0) {
-    HmmPolicy<0> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr, kNoWindow, nullptr};
+    HmmPolicy<0> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr};
     if (ad) k_resample<0, HmmPolicy<0>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
     else k_resample<0, HmmPolicy<0>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   } else {
-    HmmPolicy<1> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr, kNoWindow, nullptr};
+    HmmPolicy<1> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr};
     if (ad) k_resample<1, HmmPolicy<1>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
     else k_resample<1, HmmPolicy<1>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   }
@@ -2320,14 +2292,15 @@ int gjx_smc_hmm_step(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32
 
 int gjx_smc_finish(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int32_t* e_out, uint64_t* q_out, gjx_stream s) {
   if (!cfg_ok(cfg) || !recs || cfg->n_filters > 1) return GJX_ERR_INVALID;
-  k_scan_records<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), 0, ntiles_of(cfg->n_total), nullptr, e_out, q_out, 0);
+  k_scan_records<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), nullptr, ntiles_of(cfg->n_total), nullptr, e_out, q_out, 0);
   return launch_status();
 }
-int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int world, int64_t ticket, int64_t* out_ranges,
-                          gjx_stream s) {
+int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, const gjx_tile_ess* ess, int world, int64_t ticket,
+                          int64_t* out_ranges, gjx_stream s) {
   if (!cfg_ok(cfg) || !recs || !out_ranges || world < 1 || world > kMaxRangeBlocks || cfg->n_total % (uint64_t)world)
     return GJX_ERR_INVALID;
-  k_source_ranges<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs),
+  if (cfg_adaptive(cfg) && !ess) return GJX_ERR_INVALID;
+  k_source_ranges<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), reinterpret_cast<const TileEss*>(ess),
                                           cfg_adaptive(cfg) ? (double)cfg->ess_threshold * (double)cfg->n_total : 0.0,
                                           ntiles_of(cfg->n_total), cfg->n_total, world, ticket, out_ranges);
   return launch_status();
@@ -2365,7 +2338,13 @@ static int run_common_init(const gjx_smc_config* cfg, Carver& cv, RunCommon& rc,
   for (int i = 0; i < 2; ++i) {
     rc.pop[i].qw = cv.take<uint32_t>(cells);
     rc.pop[i].recs = reinterpret_cast<gjx_tile_rec*>(cv.take<TileRec>((size_t)rc.F * rc.nt));
-    rc.pop[i].prefix = rc.nt > (uint64_t)kMaxLdsTiles ? cv.take<uint64_t>(prefix_words(rc.nt)) : nullptr;
+    rc.pop[i].subs = reinterpret_cast<gjx_tile_sub*>(cv.take<TileSub>((size_t)rc.F * rc.nt));
+    rc.pop[i].ess = rc.adaptive ? reinterpret_cast<gjx_tile_ess*>(cv.take<TileEss>((size_t)rc.F * rc.nt)) : nullptr;
+    static const unsigned prefix_filters = [] {
+      const char* e = std::getenv("GJX_SMC_PREFIX_FILTERS");  // tuning knob: filters per launch from which the merge is a launch of its own
+      return e ? (unsigned)atoi(e) : 4u;
+    }();
+    rc.pop[i].prefix = (rc.nt > (uint64_t)kMaxLdsTiles || rc.F >= prefix_filters) ? cv.take<uint64_t>((size_t)rc.F * prefix_words(rc.nt)) : nullptr;
   }
   // log-weights: an adaptive filter carries them from step to step; otherwise only the last step's are stored
   rc.logw_final = logw_out;
@@ -2400,7 +2379,7 @@ static StepCtx run_step_ctx(const gjx_smc_config* cfg, RunCommon& rc, int t, gjx
 // the closing (e, Q) pairs of a run: the merge of the last step's records, one workgroup per filter
 static int run_finish(const gjx_smc_config* cfg, RunCommon& rc, int32_t* out_e, uint64_t* out_q, gjx_stream s) {
   const int T = cfg->n_steps;
-  k_scan_records<<<rc.F, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(rc.pop[rc.last].recs), 0, rc.nt, nullptr,
+  k_scan_records<<<rc.F, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(rc.pop[rc.last].recs), nullptr, rc.nt, nullptr,
                                             out_e + (T - 1), out_q + (T - 1), (uint64_t)T);
   return launch_status();
 }

@@ -151,8 +151,9 @@ inline std::atomic<int64_t> g_ticket_source{0};
 
 // ---- the sharded filter -----------------------------------------------------------------------------------------------
 // Step: int(int t, const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* prev_e, uint64_t* prev_q, int32_t* anc) ->
-// status: ONE launch for the rank's own slots.  Per step: that launch, ONE all-gather of the tile records (160 bytes per
-// tile, ESS sums included), then the ancestor shuffle of the state columns and the fixed-point weights.
+// status: ONE launch for the rank's own slots.  Per step: that launch, the all-gather of the tile records (three dense
+// arrays: headers, sub-prefixes, ESS sums of adaptive filters: 144-160 bytes per tile, no all-reduce), then the ancestor
+// shuffle of the state columns and the fixed-point weights.
 template <class Step>
 int sharded_steps(Transport& T, const gjx_smc_config* cfg, int n_state, const gjx_sharded_io* io, Step step, gjx_stream s,
                   uint64_t* received_out) {
@@ -174,6 +175,8 @@ int sharded_steps(Transport& T, const gjx_smc_config* cfg, int n_state, const gj
                    io->ancestors ? io->ancestors + (size_t)t * nl : nullptr)))
       break;
     if ((rc = T.allgather(full.recs, (size_t)tiles_local * sizeof(gjx_tile_rec), s))) break;
+    if ((rc = T.allgather(full.subs, (size_t)tiles_local * sizeof(gjx_tile_sub), s))) break;
+    if (adaptive && (rc = T.allgather(full.ess, (size_t)tiles_local * sizeof(gjx_tile_ess), s))) break;
     if (t + 1 >= n_steps || world == 1) continue;
     // ---- the ancestor shuffle: make the source ranges of the next resampling present on every rank
     void* cols[GJX_SMC_MAX_STATE + 2];
@@ -188,7 +191,7 @@ int sharded_steps(Transport& T, const gjx_smc_config* cfg, int n_state, const gj
       continue;
     }
     const int64_t ticket = ++g_ticket_source;
-    if ((rc = gjx_smc_source_ranges(cfg, full.recs, world, ticket, io->ranges, s))) break;
+    if ((rc = gjx_smc_source_ranges(cfg, full.recs, full.ess, world, ticket, io->ranges, s))) break;
     // the range kernel stores its words straight into pinned host memory, the ticket last with a system-scope release:
     // poll the ticket instead of synchronising the stream; if it does not show up soon, wait for the stream
     volatile int64_t* rh = io->ranges;
@@ -237,7 +240,7 @@ int sharded_run(Transport& T, const gjx_smc_config* cfg, int n_state, const gjx_
             cfg->n_total % ((uint64_t)world * tile) == 0 && cfg->n_local == cfg->n_total / (uint64_t)world &&
             cfg->first_slot == (uint64_t)rank * cfg->n_local && !(io->shuffle == 0 && world > 1 && !io->ranges);
   for (int i = 0; i < 2 && ok; ++i) {
-    ok = io->pop[i].qw && io->pop[i].recs && (!adaptive || io->pop[i].logw);
+    ok = io->pop[i].qw && io->pop[i].recs && io->pop[i].subs && (!adaptive || (io->pop[i].logw && io->pop[i].ess));
     for (int k = 0; k < n_state && ok; ++k) ok = io->pop[i].state[k] != nullptr;
   }
   if (ok) {

@@ -165,13 +165,11 @@ class ScanIO(C.Structure):
 
 
 class TileRec(C.Structure):
-    """gjx_tile_rec: a tile's mass relative to its own power-of-two anchor, ESS sums, 16 sub-prefixes."""
-    _fields_ = [("s", C.c_uint64), ("e", C.c_int32), ("pad", C.c_int32), ("r1", C.c_uint64), ("r2", C.c_uint64),
-                ("sub", C.c_uint64 * 16)]
+    """gjx_tile_rec: a tile's mass relative to its own power-of-two anchor."""
+    _fields_ = [("s", C.c_uint64), ("e", C.c_int32), ("pad", C.c_int32)]
 
 
-TILE_REC_BYTES = 160
-TILE_REC_WORDS = 20  # as int64 words: [0] = S_t, low half of [1] = e_t, [2], [3] = ESS sums, [4:20] = sub-prefixes
+TILE_REC_WORDS, TILE_SUB_WORDS, TILE_ESS_WORDS = 2, 16, 2  # gjx_tile_rec / gjx_tile_sub / gjx_tile_ess as int64 words
 TILE_FRAC = 30  # gjx.h: GJX_TILE_FRAC
 TILE_EMPTY = -(1 << 30)
 
@@ -183,6 +181,8 @@ class SmcPop(C.Structure):
         ("qw", C.c_void_p),
         ("logw", C.c_void_p),
         ("recs", C.c_void_p),
+        ("subs", C.c_void_p),
+        ("ess", C.c_void_p),
         ("prefix", C.c_void_p),
     ]
 
@@ -356,8 +356,8 @@ PROTOTYPES = {
     ),
     "gjx_smc_plan_step": (C.c_int, [C.POINTER(SmcConfig), _P, C.c_int, _P, C.POINTER(SmcPop), C.POINTER(SmcPop), _P, _P, _P, _P]),
     "gjx_smc_finish": (C.c_int, [C.POINTER(SmcConfig), _P, _P, _P, _P]),
-    "gjx_smc_source_ranges": (C.c_int, [C.POINTER(SmcConfig), _P, C.c_int, C.c_int64, _P, _P]),
-    "gjx_tile_weights": (C.c_int, [_P, C.c_uint64, _P, _P, _P]),
+    "gjx_smc_source_ranges": (C.c_int, [C.POINTER(SmcConfig), _P, _P, C.c_int, C.c_int64, _P, _P]),
+    "gjx_tile_weights": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P]),
     "gjx_tile_merge": (C.c_int, [_P, C.c_uint64, _P, _P, _P]),
     "gjx_comm_init_callbacks": (C.c_int, [C.c_int, C.c_int, ALLGATHER_FN, EXCHANGE_FN, STREAM_SYNC_FN, _P, C.POINTER(_P)]),
     "gjx_hmm_alias_words": (C.c_uint64, [C.c_int32]),

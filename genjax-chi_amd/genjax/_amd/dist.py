@@ -132,7 +132,7 @@ def importance_log_z(ops: Ops, wl: "W.Gaussian10"):
 
 
 def merged_tile_masses(recs):
-    """Tile records (int64 [tiles, 20]: word 0 = S_t, low half of word 1 = e_t, ...; gjx_tile_rec) -> (e, masses uint64
+    """Tile records (int64 [tiles, 2]: word 0 = S_t, low half of word 1 = e_t; gjx_tile_rec) -> (e, masses uint64
     [tiles]): the merge every consumer of the records performs: e = max e_t, M_t = S_t >> (e - e_t)."""
     import numpy as np
 
@@ -385,7 +385,7 @@ class ShardedSMC:
 
     Per step: (a) ONE launch: resample + propagate + weight the rank's OWN output slots from the global previous
     population (only the source tiles that feed those slots are read), emitting the fixed-point weights and tile records
-    of the new weights; (b) ONE all-gather of the records (160 B per 1024 particles; no all-reduce: the records are
+    of the new weights; (b) the all-gather of the records (three dense arrays, 144-160 B per 1024 particles; no all-reduce: they are
     anchored per tile); (c) the ancestor shuffle.  Ancestors are monotone in the output slot, so the
     sources of a rank's slots are ONE contiguous global range, known to every rank from the records alone
     (`needed_tile_ranges`):
@@ -486,7 +486,7 @@ class ShardedSMC:
         # the ranges of all ranks from the records, computed on the device and stored straight into pinned host
         # memory with a ticket behind them: the host polls for the ticket instead of synchronising the stream
         self.ticket += 1
-        ops.smc_source_ranges(self.cfg, pop.recs, self.world, self.ranges, self.ticket)
+        ops.smc_source_ranges(self.cfg, pop.recs, pop.ess, self.world, self.ranges, self.ticket)
         rh = self.ranges_np
         if self.ranges.is_pinned():
             spins = 0
@@ -571,6 +571,9 @@ class ShardedSMC:
             self._step(t, cur, prv)
             pop = self.pop[cur]
             self.comm.all_gather(pop.recs, tl, th)
+            self.comm.all_gather(pop.subs, tl, th)
+            if pop.ess is not None:
+                self.comm.all_gather(pop.ess, tl, th)
             if t + 1 < self.T:
                 self._shuffle(cur)
         ops.smc_finish(self.cfg, self.pop[(self.T - 1) & 1].recs, self.out_e[self.T - 1:self.T], self.out_q[self.T - 1:self.T])

@@ -368,13 +368,15 @@ class Ops:
         return anc, m, q
 
     def tile_weights(self, x: torch.Tensor):
-        """-> (qw int32[n], recs int64[tiles, 20]): the tile-anchored fixed-point weights (u32 bit patterns) and tile
-        records (gjx_tile_rec as 20 words: S_t, e_t in the low half of word 1, ESS sums, 16 sub-prefixes) of arbitrary
-        log-weights."""
-        n = x.numel()
-        qw, recs = self.empty(n, torch.int32), self.empty((self.num_tiles(n), abi.TILE_REC_WORDS), torch.int64)
-        self.lib.call("gjx_tile_weights", self._chk(x, torch.float32, n), n, self._p(qw), self._p(recs), self.stream())
-        return qw, recs
+        """-> (qw int32[n], recs int64[tiles, 2], subs int64[tiles, 16], ess int64[tiles, 2]): the tile-anchored
+        fixed-point weights (u32 bit patterns) and the three dense record arrays (gjx_tile_rec: S_t, e_t in the low half
+        of word 1; gjx_tile_sub: 16 sub-prefixes; gjx_tile_ess: ESS sums) of arbitrary log-weights."""
+        n, nt = x.numel(), self.num_tiles(x.numel())
+        qw, recs = self.empty(n, torch.int32), self.empty((nt, abi.TILE_REC_WORDS), torch.int64)
+        subs, ess = self.empty((nt, abi.TILE_SUB_WORDS), torch.int64), self.empty((nt, abi.TILE_ESS_WORDS), torch.int64)
+        self.lib.call("gjx_tile_weights", self._chk(x, torch.float32, n), n, self._p(qw), self._p(recs), self._p(subs),
+                      self._p(ess), self.stream())
+        return qw, recs, subs, ess
 
     def tile_merge(self, recs: torch.Tensor):
         """-> (e int32[1], q int64[1]): merged anchor and total mass of tile records."""
@@ -632,10 +634,10 @@ class Ops:
     def smc_finish(self, cfg, recs, e_out, q_out):
         self.lib.call("gjx_smc_finish", C.byref(cfg), self._p(recs), self._p(e_out), self._p(q_out), self.stream())
 
-    def smc_source_ranges(self, cfg, recs, world: int, out_ranges, ticket: int = 0):
+    def smc_source_ranges(self, cfg, recs, ess, world: int, out_ranges, ticket: int = 0):
         """out_ranges int64[2 world + 1]: the source tiles each of `world` equal output blocks can draw from, then
         the ticket (stored last; a pinned host buffer can be polled for it)."""
-        self.lib.call("gjx_smc_source_ranges", C.byref(cfg), self._p(recs), int(world), int(ticket),
+        self.lib.call("gjx_smc_source_ranges", C.byref(cfg), self._p(recs), self._p(ess), int(world), int(ticket),
                       self._p(out_ranges), self.stream())
 
     def log_z_from_pairs(self, out_e: torch.Tensor, out_q: torch.Tensor, n_total: int, resampled=None) -> float:
@@ -664,6 +666,8 @@ class SmcPopulation:
         self.qw = ops.empty(n_total, torch.int32)
         self.logw = ops.empty(n_total, torch.float32) if (want_logw or adaptive) else None
         self.recs = torch.zeros((nt, abi.TILE_REC_WORDS), dtype=torch.int64, device=ops.device())
+        self.subs = torch.zeros((nt, abi.TILE_SUB_WORDS), dtype=torch.int64, device=ops.device())
+        self.ess = torch.zeros((nt, abi.TILE_ESS_WORDS), dtype=torch.int64, device=ops.device()) if adaptive else None
         self.prefix = ops.empty(nt + 4, torch.int64) if nt > 1024 else None
 
     def columns(self, with_logw: bool | None = None) -> list[torch.Tensor]:
@@ -675,13 +679,15 @@ class SmcPopulation:
 
     def struct(self, first: int = 0, with_logw: bool = True) -> abi.SmcPop:
         """abi.SmcPop: per-particle arrays start at slot `first` (a rank's own block for the population a step WRITES;
-        0 for the one it READS); the records are always the global array."""
+        0 for the one it READS); the record arrays are always the global ones."""
         p = abi.SmcPop()
         for k, c in enumerate(self.state):
             p.state[k] = c.data_ptr() + first * 4
         p.qw = self.qw.data_ptr() + first * 4
         p.logw = (self.logw.data_ptr() + first * 4) if (self.logw is not None and with_logw) else None
         p.recs = self.recs.data_ptr()
+        p.subs = self.subs.data_ptr()
+        p.ess = self.ess.data_ptr() if self.ess is not None else None
         p.prefix = self.prefix.data_ptr() if self.prefix is not None else None
         p._keep = self
         return p

@@ -377,9 +377,9 @@ int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, 
 
 /* Tile-anchored weights: what a resampling reads.  Tile t = particles [1024 t, 1024 t + 1024):
  * e_t = ceil(max_t x * log2 e) (the row anchor of 3.5b on a tile); q_i = rint(exp(x_i - e_t ln 2) * 2^30), ONE u32 PER
- * PARTICLE (what a step stores instead of the log-weight); the tile's record: S_t = sum q_i, e_t, the ESS sums
- * r1 = sum (q_i >> 14), r2 = sum (q_i >> 14)^2, and the running sum of q after every 64th particle (sub[b] = sum over the
- * tile's particles [0, 64 (b + 1)); sub[15] = S_t).  Everything is known to the workgroup that produces the tile's
+ * PARTICLE (what a step stores instead of the log-weight); the tile's record: S_t = sum q_i and e_t (gjx_tile_rec), the
+ * running sum of q after every 64th particle (gjx_tile_sub: sub[b] = sum over the tile's particles [0, 64 (b + 1));
+ * sub[15] = S_t), the ESS sums r1 = sum (q_i >> 14), r2 = sum (q_i >> 14)^2 (gjx_tile_ess).  Everything is known to the workgroup that produces the tile's
  * log-weights — no grid-wide maximum — so the kernel that propagates a population emits it, and a bootstrap step is ONE
  * launch.  Records merge exactly: e = max e_t, d_t = e - e_t, M_t = S_t >> d_t (0 from d_t = 64), P_t = sum_{t' < t}
  * M_t', Q = sum_t M_t; lse = e ln 2 + log(Q 2^-30). */
@@ -387,13 +387,20 @@ typedef struct {
   uint64_t s; /* S_t */
   int32_t e;  /* e_t; GJX_TILE_EMPTY: the tile carries no mass */
   int32_t pad;
-  uint64_t r1, r2;
-  uint64_t sub[16];
 } gjx_tile_rec;
+typedef struct {
+  uint64_t sub[16]; /* running sum of q after every 64th particle of the tile */
+} gjx_tile_sub;
+typedef struct {
+  uint64_t r1, r2; /* ESS sums */
+} gjx_tile_ess;
 #define GJX_TILE_EMPTY (-(1 << 30))
 #define GJX_TILE_FRAC 30
-/* qw dev u32[n], recs dev gjx_tile_rec[gjx_num_tiles(n)] of arbitrary log-weights x (one pass). */
-int gjx_tile_weights(const float* x, uint64_t n, uint32_t* qw, gjx_tile_rec* recs, gjx_stream s);
+/* The record of a tile lives in three DENSE arrays indexed by tile: recs (16 bytes: what every workgroup merges), subs
+ * (128 bytes: what the few lanes that scan the tile read), ess (16 bytes: adaptive filters only).
+ * qw dev u32[n], recs / subs / ess (nullable) dev [gjx_num_tiles(n)] of arbitrary log-weights x (one pass). */
+int gjx_tile_weights(const float* x, uint64_t n, uint32_t* qw, gjx_tile_rec* recs, gjx_tile_sub* subs, gjx_tile_ess* ess,
+                     gjx_stream s);
 /* out_e[0], out_q[0] = the merged anchor and total mass of `recs` (each nullable). */
 int gjx_tile_merge(const gjx_tile_rec* recs, uint64_t n_tiles, int32_t* out_e, uint64_t* out_q, gjx_stream s);
 
@@ -471,7 +478,7 @@ typedef struct {
    * otherwise every particle keeps its own ancestor (ancestors[t][j] = j), and its log-weight ACCUMULATES:
    * logw_t[j] = logw_{t-1}[j] + increment.  ESS is evaluated on exact integers so that every backend, tiling and
    * number of ranks takes the same decision: per tile r_i = q_i >> 14 (the top 16 bits of the tile-anchored weight),
-   * R1_t = sum r_i, R2_t = sum r_i^2 (gjx_tile_rec.r1 / r2); merged R1 = sum_t R1_t >> d_t, R2 = sum_t R2_t >> 2 d_t;
+   * R1_t = sum r_i, R2_t = sum r_i^2 (gjx_tile_ess); merged R1 = sum_t R1_t >> d_t, R2 = sum_t R2_t >> 2 d_t;
    * resample iff (double)R1 * (double)R1 < (ess_threshold * n_total) * (double)R2.
    * log Z = sum over the steps t that END an epoch (a resampling follows, or t = T-1) of
    * (e_t ln 2 + log(q_t 2^-30) - log N): the per-step (out_e, out_q) pairs are those of the accumulated weights.
@@ -489,6 +496,8 @@ typedef struct {
   uint32_t* qw;                   /* tile-anchored fixed-point weights (gjx_tile_rec above) */
   float* logw;                    /* log-weights: nullable unless the filter is ESS-adaptive */
   gjx_tile_rec* recs;             /* GLOBAL dev [gjx_num_tiles(n_total)]: the tiles' records */
+  gjx_tile_sub* subs;             /* GLOBAL dev [gjx_num_tiles(n_total)]: their sub-prefixes */
+  gjx_tile_ess* ess;              /* GLOBAL dev [gjx_num_tiles(n_total)]: their ESS sums (adaptive filters only) */
   uint64_t* prefix;               /* scratch dev u64[gjx_num_tiles(n_total) + 4]: required only when the population READ by a
                                      step has more than 1024 tiles (n_total > 2^20) — the step then merges its records
                                      into this array with one extra small launch instead of in every workgroup */
@@ -509,10 +518,10 @@ int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32
 
 /* One step as ONE launch (the whole-run calls are loops over these; the multi-device driver runs the
  * exchange between them).  step (t): for every slot j in [first_slot, first_slot+n_local): systematic-resampling
- * ancestor from the GLOBAL previous population `prev` (state / qw / logw dev [n_total], recs GLOBAL), propagate,
- * weight; writes `out`: state / qw / logw (nullable) dev [n_local] — LOCAL arrays, slot j at j - first_slot — and the
- * records of the rank's own tiles into the GLOBAL array out->recs (at the global tile index; out->recs must not alias
- * prev->recs: ranks all-gather it).  prev_e_out / prev_q_out (nullable dev [1]):
+ * ancestor from the GLOBAL previous population `prev` (state / qw / logw dev [n_total], recs / subs / ess GLOBAL),
+ * propagate, weight; writes `out`: state / qw / logw (nullable) dev [n_local] — LOCAL arrays, slot j at j - first_slot —
+ * and the records of the rank's own tiles into the GLOBAL arrays out->recs / subs / ess (at the global tile index; they
+ * must not alias prev's: ranks all-gather them).  prev_e_out / prev_q_out (nullable dev [1]):
  * the merged anchor and total mass of prev's weights.  ancestors_out nullable dev int32[n_local].  t == 0 ignores
  * prev.  Only the source tiles that own one of the rank's slots are read (gjx_smc_source_ranges).
  *  finish: e_out[0], q_out[0] = merged anchor / total mass of the last step's records. */
@@ -532,13 +541,13 @@ int gjx_smc_finish(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int32_t*
  * (block j = slots [j n_total/world, (j+1) n_total/world)), out_ranges[2j], [2j+1] = the half-open range of
  * source tiles that can own a slot of the block at the next resampling — the exact range or one tile more at
  * either end (the comb offset is bounded, not derived, so the ranges of a step are known before its key is
- * used).  Ancestors are monotone in the slot, hence one contiguous range per block.  An adaptive filter that keeps its
- * particles at the next step (the records carry the ESS sums) needs no exchange: identity ranges.  out_ranges:
+ * used).  Ancestors are monotone in the slot, hence one contiguous range per block.  ess: the population's ESS sums
+ * (adaptive filters: a step that keeps its particles needs no exchange: identity ranges).  out_ranges:
  * int64[2 world + 1], device memory or device-visible pinned host memory; out_ranges[2 world] = ticket is
  * stored LAST with a system-scope release, so a host that owns a pinned buffer can poll for its ticket and
  * read the ranges without synchronising the stream.  world <= 64 and n_total a multiple of world. */
-int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int world, int64_t ticket,
-                          int64_t* out_ranges, gjx_stream s);
+int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, const gjx_tile_ess* ess, int world,
+                          int64_t ticket, int64_t* out_ranges, gjx_stream s);
 /* ---- bootstrap SMC for a user model: init sites + step sites as plans ------------------------ *
  * The general form of the two fixed models above: x_0 comes from `init_sites`, every later step
  * walks `step_sites` for each output slot with GJX_ARG_STATE arguments reading the resampled
@@ -660,11 +669,12 @@ int gjx_comm_world(const gjx_comm* c);
 int gjx_comm_lse_combine(gjx_comm* c, const uint64_t* records, int32_t n_batch, uint64_t* gathered, int32_t* out_e,
                          uint64_t* out_q, float* out_lse, gjx_stream s);
 /* The whole bootstrap filter sharded over the communicator's ranks (BASELINE configs[3]): per step ONE launch (own
- * slots) -> ONE all-gather of the tile records (160 bytes per 1024 particles) -> ancestor shuffle, driven from C: no interpreter
+ * slots) -> the all-gather of the tile records (recs, subs and — adaptive filters — ess: 144-160 bytes per 1024 particles,
+ * no all-reduce) -> ancestor shuffle, driven from C: no interpreter
  * between the launches.  cfg: first_slot / n_local = this rank's block (n_total a multiple of world * gjx_smc_tile()),
  * one filter.  All arrays are GLOBAL-size device buffers the caller owns (a rank's own block is always current; remote
  * ranges are filled by the shuffle): pop[2] (double-buffered: state columns dev 4-byte [n_total], qw dev u32[n_total],
- * logw dev f32[n_total] (adaptive filters; else only the final population's, nullable), recs dev gjx_tile_rec[tiles]),
+ * logw dev f32[n_total] (adaptive filters; else only the final population's, nullable), recs / subs / ess dev [tiles]),
  * out_e dev int32[T], out_q dev u64[T], ancestors nullable dev int32[T, n_local],
  *   ranges int64[2 world + 1] device-visible PINNED host memory (plain host memory in the oracle build).
  * shuffle 0 = by source ranges (each rank receives exactly the contiguous range its slots draw from, in place, by

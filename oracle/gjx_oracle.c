@@ -793,7 +793,7 @@ int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, 
 #define O_ESS_SHIFT (O_ROW_FRAC - 16)
 #define O_SUBS 16
 #define O_SUBLEN (O_TILE / O_SUBS)
-static void tile_emit(const float* lw, uint64_t cnt, uint32_t* qw, gjx_tile_rec* rec) {
+static void tile_emit(const float* lw, uint64_t cnt, uint32_t* qw, gjx_tile_rec* rec, gjx_tile_sub* sub, gjx_tile_ess* ess) {
   float m = -INFINITY;
   for (uint64_t i = 0; i < cnt; ++i) m = lw[i] > m ? lw[i] : m;
   const int32_t e = o_row_anchor(m);
@@ -807,22 +807,22 @@ static void tile_emit(const float* lw, uint64_t cnt, uint32_t* qw, gjx_tile_rec*
       r1 += r;
       r2 += r * r;
     }
-    if ((i + 1) % O_SUBLEN == 0) rec->sub[i / O_SUBLEN] = run;
+    if ((i + 1) % O_SUBLEN == 0) sub->sub[i / O_SUBLEN] = run;
   }
   rec->s = run;
   rec->e = e;
   rec->pad = 0;
-  rec->r1 = r1;
-  rec->r2 = r2;
+  if (ess) { ess->r1 = r1; ess->r2 = r2; }
 }
-int gjx_tile_weights(const float* x, uint64_t n, uint32_t* qw, gjx_tile_rec* recs, gjx_stream s) {
+int gjx_tile_weights(const float* x, uint64_t n, uint32_t* qw, gjx_tile_rec* recs, gjx_tile_sub* subs, gjx_tile_ess* ess,
+                     gjx_stream s) {
   (void)s;
-  if (!x || !qw || !recs || n == 0) return GJX_ERR_INVALID;
+  if (!x || !qw || !recs || !subs || n == 0) return GJX_ERR_INVALID;
   const uint64_t nt = gjx_num_tiles(n);
 #pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < (int64_t)nt; ++b) {
     const uint64_t lo = (uint64_t)b * O_TILE, cnt = lo + O_TILE <= n ? O_TILE : n - lo;
-    tile_emit(x + lo, cnt, qw + lo, &recs[b]);
+    tile_emit(x + lo, cnt, qw + lo, &recs[b], &subs[b], ess ? &ess[b] : NULL);
   }
   return GJX_OK;
 }
@@ -834,7 +834,7 @@ typedef struct {
   uint8_t* d;    /* [nt]: 64 = the tile carries no mass */
 } merged;
 static inline uint64_t shr64(uint64_t v, int d) { return d >= 64 ? 0 : v >> d; }
-static int merge_records(const gjx_tile_rec* recs, uint64_t nt, merged* m) {
+static int merge_records(const gjx_tile_rec* recs, const gjx_tile_ess* ess, uint64_t nt, merged* m) {
   m->pre = (uint64_t*)malloc(sizeof(uint64_t) * (nt + 1));
   m->d = (uint8_t*)malloc(nt ? nt : 1);
   if (!m->pre || !m->d) { free(m->pre); free(m->d); return GJX_ERR_LAUNCH; }
@@ -850,8 +850,7 @@ static int merge_records(const gjx_tile_rec* recs, uint64_t nt, merged* m) {
     m->d[b] = (uint8_t)d;
     m->pre[b] = run;
     run += shr64(recs[b].s, d);
-    r1 += shr64(recs[b].r1, d);
-    r2 += shr64(recs[b].r2, 2 * d);
+    if (ess) { r1 += shr64(ess[b].r1, d); r2 += shr64(ess[b].r2, 2 * d); }
   }
   m->pre[nt] = run;
   m->e = e; m->Q = run; m->R1 = r1; m->R2 = r2;
@@ -862,7 +861,7 @@ int gjx_tile_merge(const gjx_tile_rec* recs, uint64_t n_tiles, int32_t* out_e, u
   (void)s;
   if (!recs || n_tiles == 0) return GJX_ERR_INVALID;
   merged m;
-  int rc = merge_records(recs, n_tiles, &m);
+  int rc = merge_records(recs, NULL, n_tiles, &m);
   if (rc) return rc;
   if (out_e) *out_e = m.e;
   if (out_q) *out_q = m.Q;
@@ -933,9 +932,10 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
   const uint64_t nt = gjx_num_tiles(n);
   uint32_t* qw = (uint32_t*)malloc(sizeof(uint32_t) * n);
   gjx_tile_rec* recs = (gjx_tile_rec*)malloc(sizeof(gjx_tile_rec) * nt);
+  gjx_tile_sub* subs = (gjx_tile_sub*)malloc(sizeof(gjx_tile_sub) * nt);
   merged m;
-  int rc = (qw && recs) ? gjx_tile_weights(logw, n, qw, recs, NULL) : GJX_ERR_LAUNCH;
-  if (!rc) rc = merge_records(recs, nt, &m);
+  int rc = (qw && recs && subs) ? gjx_tile_weights(logw, n, qw, recs, subs, NULL, NULL) : GJX_ERR_LAUNCH;
+  if (!rc) rc = merge_records(recs, NULL, nt, &m);
   if (!rc) {
     o_stream st = stream_at(key, 0);
     const double u0 = u0_from_bits(o_bits64_at(&st, 0));
@@ -944,7 +944,7 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
     if (out_q) *out_q = m.Q;
     merged_free(&m);
   }
-  free(qw); free(recs);
+  free(qw); free(recs); free(subs);
   return rc;
 }
 
@@ -1006,10 +1006,10 @@ static int ess_says_resample(uint64_t r1, uint64_t r2, double thr) {
   return a < b;
 }
 static int pop_ok(const gjx_smc_pop* p, int n_state, int adaptive) {
-  if (!p || !p->qw || !p->recs) return 0;
+  if (!p || !p->qw || !p->recs || !p->subs) return 0;
   for (int k = 0; k < n_state; ++k)
     if (!p->state[k]) return 0;
-  return !adaptive || p->logw != NULL;
+  return !adaptive || (p->logw && p->ess);
 }
 
 int gjx_smc_finish(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int32_t* e_out, uint64_t* q_out, gjx_stream s) {
@@ -1020,14 +1020,15 @@ int gjx_smc_finish(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int32_t*
 /* Source-tile ranges of `world` equal blocks of output slots: tile b can own slots in [ceil(P_b) - 1,
    ceil(P_{b+1})) for some comb offset u0 in [0, 1) (teeth_below above; P = prefix * N / Q in double), the last
    tile up to N. */
-int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int world, int64_t ticket,
-                          int64_t* out_ranges, gjx_stream s) {
+int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, const gjx_tile_ess* ess, int world,
+                          int64_t ticket, int64_t* out_ranges, gjx_stream s) {
   (void)s;
   if (!cfg_ok(cfg) || !recs || !out_ranges || world < 1 || world > 64 || cfg->n_total % (uint64_t)world)
     return GJX_ERR_INVALID;
+  if (cfg_adaptive(cfg) && !ess) return GJX_ERR_INVALID;
   const uint64_t N = cfg->n_total, nt = gjx_num_tiles(N), nl = N / (uint64_t)world;
   merged m;
-  int rc = merge_records(recs, nt, &m);
+  int rc = merge_records(recs, cfg_adaptive(cfg) ? ess : NULL, nt, &m);
   if (rc) return rc;
   if (cfg_adaptive(cfg) && !ess_says_resample(m.R1, m.R2, (double)cfg->ess_threshold * (double)N)) {
     /* the next step keeps its particles: every block's sources are its own tiles */
@@ -1071,7 +1072,7 @@ static int smc_step_front(const gjx_smc_config* cfg, int t, const gjx_smc_pop* p
   const uint64_t N = cfg->n_total, nt = gjx_num_tiles(N);
   const int ad = cfg_adaptive(cfg);
   merged m;
-  int rc = merge_records(prev->recs, nt, &m);
+  int rc = merge_records(prev->recs, ad ? prev->ess : NULL, nt, &m);
   if (rc) return rc;
   if (prev_e_out) *prev_e_out = m.e;
   if (prev_q_out) *prev_q_out = m.Q;
@@ -1094,7 +1095,8 @@ static void smc_step_back(const gjx_smc_config* cfg, const gjx_smc_pop* out, con
 #pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < (int64_t)ntl; ++b) {
     const uint64_t lo = (uint64_t)b * O_TILE, cnt = lo + O_TILE <= nl ? O_TILE : nl - lo;
-    tile_emit(lw + lo, cnt, out->qw + lo, &out->recs[tile0 + (uint64_t)b]);
+    tile_emit(lw + lo, cnt, out->qw + lo, &out->recs[tile0 + (uint64_t)b], &out->subs[tile0 + (uint64_t)b],
+              cfg_adaptive(cfg) ? &out->ess[tile0 + (uint64_t)b] : NULL);
   }
   if (out->logw) memcpy(out->logw, lw, sizeof(float) * nl);
 }
@@ -1264,12 +1266,13 @@ static int pop_alloc(gjx_smc_pop* p, uint64_t N, int n_state, int adaptive) {
   ok = ok && (p->qw = (uint32_t*)malloc(4 * N)) != NULL;
   ok = ok && (p->logw = (float*)malloc(4 * N)) != NULL;
   ok = ok && (p->recs = (gjx_tile_rec*)malloc(sizeof(gjx_tile_rec) * nt)) != NULL;
-  (void)adaptive;
+  ok = ok && (p->subs = (gjx_tile_sub*)malloc(sizeof(gjx_tile_sub) * nt)) != NULL;
+  if (adaptive) ok = ok && (p->ess = (gjx_tile_ess*)calloc(nt, sizeof(gjx_tile_ess))) != NULL;
   return ok ? GJX_OK : GJX_ERR_LAUNCH;
 }
 static void pop_free(gjx_smc_pop* p) {
   for (int k = 0; k < GJX_SMC_MAX_STATE; ++k) free(p->state[k]);
-  free(p->qw); free(p->logw); free(p->recs);
+  free(p->qw); free(p->logw); free(p->recs); free(p->subs); free(p->ess);
 }
 static int smc_run_one(const gjx_smc_config* cfg, int n_state, step_fn step, void* ctx, int32_t* out_e, uint64_t* out_q,
                        void* const* state_out, float* logw_out, int32_t* ancestors_out) {

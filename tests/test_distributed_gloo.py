@@ -278,7 +278,7 @@ def check_source_ranges(ops):
             recs[:, 1] = e_.view(np.uint32).astype(np.uint64)
             recs_t = torch.from_numpy(recs.view(np.int64)).to(ops.device())
             out = torch.zeros(2 * world + 1, dtype=torch.int64, device=ops.device())
-            ops.smc_source_ranges(cfg, recs_t, world, out, ticket=trial + 1)
+            ops.smc_source_ranges(cfg, recs_t, None, world, out, ticket=trial + 1)
             got = out.cpu().numpy()
             assert got[-1] == trial + 1
             _, masses = gdist.merged_tile_masses(recs_t)

@@ -799,9 +799,9 @@ def test_tile_records(hip_ops, oracle_ops, n):
     lw = torch.randn(n, generator=g) * 30
     if n > 10:
         lw[3] = float("-inf"); lw[7] = float("nan")
-    hc, hr = hip_ops.tile_weights(lw.to(hip_ops.device()))
-    oc, orr = oracle_ops.tile_weights(lw)
-    same(hc, oc, "fixed-point weights"); same(hr, orr, "records")
+    hc, hr, hs, he_ = hip_ops.tile_weights(lw.to(hip_ops.device()))
+    oc, orr, os_, oe_ = oracle_ops.tile_weights(lw)
+    same(hc, oc, "fixed-point weights"); same(hr, orr, "records"); same(hs, os_, "sub-prefixes"); same(he_, oe_, "ESS sums")
     he, hq = hip_ops.tile_merge(hr)
     oe, oq = oracle_ops.tile_merge(orr)
     same(he, oe, "merged anchor"); same(hq, oq, "merged mass")
