@@ -921,6 +921,7 @@ struct ResampleArgs {
   TileEss* ess_out = nullptr;           // GLOBAL, likewise (adaptive filters)
   int scan_max = kScanMax;              // rounds of the window scan (test knob: 0 = every output tile takes the per-slot search)
   int debug_stop = 0;                   // profiling knob (GJX_SMC_DEBUG_STOP): leave the kernel after phase k
+  int xcd_map = 1;                      // contiguous output tiles per XCD (GJX_SMC_XCD_MAP=0: plain order)
 };
 
 // resample iff ESS = R1^2 / R2 < thr (thr in particles); every backend evaluates exactly these double operations
@@ -1341,6 +1342,14 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     P.select_filter((uint64_t)f * A.fb.stride, A.fb.step_key[f]);
   }
   const bool adaptive = ADAPTIVE && A.ess_thr > 0.0;
+  if (A.xcd_map) {
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin, and neighbouring output tiles read
+    // overlapping source windows — give every XCD a CONTIGUOUS range of output tiles so that the overlap is served by its
+    // own L2 instead of a second trip to memory (a bijection on the launch's tiles: same results)
+    const uint64_t nwg = ((uint64_t)(A.out_hi - A.out_lo) + kTile - 1) / kTile;
+    const uint64_t x = b & 7, c = nwg >> 3, r = nwg & 7;
+    b = x * c + (x < r ? x : r) + (b >> 3);
+  }
   const uint64_t ot = (uint64_t)A.out_lo / kTile + b;  // this workgroup's output tile (global index)
   const int64_t j0 = (int64_t)(ot * kTile);
   const int64_t j1 = j0 + (int64_t)kTile < A.out_hi ? j0 + (int64_t)kTile : A.out_hi;

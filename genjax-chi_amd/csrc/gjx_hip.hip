@@ -2200,6 +2200,8 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
   A.scan_max = scan_max_knob();
   static const int dbg_stop = [] { const char* e = std::getenv("GJX_SMC_DEBUG_STOP"); return e ? atoi(e) : 0; }();
   A.debug_stop = dbg_stop;
+  static const int xcd_map = [] { const char* e = std::getenv("GJX_SMC_XCD_MAP"); return e ? atoi(e) : 1; }();
+  A.xcd_map = xcd_map;
   // The merged prefix by ONE small launch (a workgroup per filter) instead of in every workgroup: required beyond
   // kMaxLdsTiles, and worth it from a few filters per launch (the whole-run drivers provide prev->prefix then), where its
   // ~4 us are shared by all filters while every one of the F x tiles workgroups saves the merge of its filter's records.
