@@ -138,24 +138,57 @@ def max_over_ranks(seconds, world):
     return float(t.item())
 
 
+BRACKET_MIN_S = float(os.environ.get("GJX_BENCH_BRACKET_MIN_S", "0.005"))
+_EMPTY_BRACKET = {}
+
+
+def empty_bracket_s(world):
+    """The cost of the bracket itself (barrier + synchronize on both sides + the max-over-ranks all-reduce) with NOTHING
+    inside: median of 20.  Reported in the line (`bracket.empty_ms`) so that a reader can see how much of a short block
+    it would be; at N > 1 the blocks are made long enough (BRACKET_MIN_S) for it not to matter."""
+    if world not in _EMPTY_BRACKET:
+        ts = []
+        for _ in range(20):
+            barrier_sync(world)
+            t0 = time.perf_counter()
+            barrier_sync(world)
+            ts.append(max_over_ranks(time.perf_counter() - t0, world))
+        _EMPTY_BRACKET[world] = statistics.median(ts)
+    return _EMPTY_BRACKET[world]
+
+
 def timed_blocks(run_block, world, min_s=MIN_TIMED_S, min_blocks=5, max_blocks=2000):
-    """Repeat `run_block()` (EXACTLY the K steps of the protocol), each repetition bracketed by barrier +
-    synchronize on both sides; the duration of a block is the max over ranks (the same number on every rank, so
-    all ranks stop together).  Returns the list of block durations in seconds and the last block's result."""
+    """Repeat `run_block()` (EXACTLY the K steps of the protocol), bracketed by barrier + synchronize on both sides; the
+    duration of a bracket is the max over ranks (the same number on every rank, so all ranks stop together).  One rank:
+    one K-step block per bracket.  Several ranks (or a forced one-rank group): a barrier costs tens of microseconds over
+    RCCL — more than a short block — so a bracket holds M back-to-back K-step blocks, M chosen once (from the first
+    bracket, agreed through the max over ranks) such that a bracket lasts at least BRACKET_MIN_S; the block time reported
+    is bracket / M.  Returns the list of per-block durations in seconds and the last block's result."""
     blocks, out = [], None
+    reps = 1
+    multi = world > 1 or FORCE_DIST
     while True:
         barrier_sync(world)
         t0 = time.perf_counter()
-        out = run_block()
+        for _ in range(reps):
+            out = run_block()
         barrier_sync(world)
-        blocks.append(max_over_ranks(time.perf_counter() - t0, world))
-        if (sum(blocks) >= min_s and len(blocks) >= min_blocks) or len(blocks) >= max_blocks:
+        dt = max_over_ranks(time.perf_counter() - t0, world)
+        if multi and reps == 1 and dt < BRACKET_MIN_S and not blocks:
+            reps = max(2, min(4096, int(BRACKET_MIN_S / max(dt, 1e-6)) + 1))  # (the first, short bracket is dropped)
+            continue
+        blocks.append(dt / reps)
+        if (sum(blocks) * reps >= min_s and len(blocks) >= min_blocks) or len(blocks) >= max_blocks:
+            timed_blocks.last_reps = reps
             return blocks, out
+
+
+timed_blocks.last_reps = 1
 
 
 def block_stats(blocks):
     return {"timed_blocks": len(blocks), "block_ms_min": min(blocks) * 1e3, "block_ms_median": statistics.median(blocks) * 1e3,
-            "block_ms_max": max(blocks) * 1e3}
+            "block_ms_max": max(blocks) * 1e3, "blocks_per_bracket": timed_blocks.last_reps}
 
 
 def pmc_traffic(pattern: str, pick):
@@ -324,6 +357,10 @@ def bench_importance(args, ops, rank, world, launch_passes=None, rng=None, steps
 # bootstrap SMC (BASELINE configs[2], [4]; sharded: configs[3])
 # ------------------------------------------------------------------------------------------------------------
 def bench_smc_sharded(args, ops, rank, world, kind):
+    """BASELINE configs[3] (and its HMM sibling): the filter sharded over the ranks, 1e6 particles per GPU.  Driver: the
+    library's own (`gjx_smc_sharded_run_*` over a `gjx_comm` RCCL communicator: per step ONE launch, the all-gather of
+    the tile records, the grouped send/recv of the ancestor shuffle — no interpreter between the launches);
+    GJX_BENCH_PY_COMM=1 selects the Python `torch.distributed` loop instead (the same protocol, 2-3x the host time)."""
     from genjax._amd import dist as gdist
 
     impl = 1 if args.rng == "philox" else 0
@@ -334,9 +371,7 @@ def bench_smc_sharded(args, ops, rank, world, kind):
     # (a forced one-rank group still issues every collective: the RCCL calls of the N > 1 path run on a one-GPU box)
     smc = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world, exchange=exchange,
                            comm=gdist.TorchComm(rank, world, always=FORCE_DIST))
-    # GJX_BENCH_NATIVE_COMM=1: the library's own RCCL communicator and C driver (gjx_smc_sharded_run_*) instead of the
-    # torch.distributed loop.  Opt-in: it is covered by virtual-rank tests and a one-rank RCCL test only (no multi-GPU box here).
-    native = os.environ.get("GJX_BENCH_NATIVE_COMM") == "1"
+    native = os.environ.get("GJX_BENCH_PY_COMM") != "1"
     comm = gdist.NativeComm.rccl(ops, rank, world) if native else None
     run = (lambda: smc.run_native(comm)) if native else smc.run
     run()  # warm-up (also builds any generated kernels)
@@ -347,25 +382,23 @@ def bench_smc_sharded(args, ops, rank, world, kind):
         runs[0] += 1
         return run()
 
-    blocks, r = timed_blocks(one_run, world, min_s=0.05, min_blocks=3, max_blocks=5)
+    blocks, r = timed_blocks(one_run, world, min_s=0.08, min_blocks=20, max_blocks=60)
     dt = statistics.median(blocks)
     per_step_ms = dt * 1e3 / T
     achieved = BYTES_SMC_PER_PARTICLE_STEP * n / (per_step_ms * 1e-3) / 1e9
-    shuffle = ("ancestor shuffle = grouped send/recv of each rank's contiguous source range (all-to-all-v, in place)"
-               if exchange == "ranges" else "all-gather of particles and weights")
     res = {
         "metric": "particle-steps/sec, bootstrap SMC (1e6 particles per GPU)",
-        "value": n_total * T / dt, "unit": "particle-steps/s", "ms_per_step": dt * 1e3,
+        "value": n_total * T / dt, "unit": "particle-steps/s", "ms_per_step": per_step_ms,
         "config": {"workload": f"bootstrap SMC {kind} T={T} N={n_total} sharded x{world} (BASELINE configs[3] at world=8)",
-                   "rng": args.rng,
-                   "parallelism": f"particle-sharded x{world}: all-reduce(max) + all-gather of tile masses + {shuffle}",
-                   "driver": "native (gjx_comm over RCCL, gjx_smc_sharded_run_*)" if native else "python (torch.distributed)",
+                   "rng": args.rng, "shuffle": exchange,
+                   "parallelism": f"particle-sharded x{world}: 1 launch + all-gather(tile records) + ancestor shuffle per step",
+                   "driver": "native" if native else "python",
                    "particles_received_per_rank_step": r["received"] / (1 if native else runs[0]) / max(1, T - 1)},
-        "roofline": {"bound": "hbm", "kernel": "one SMC step incl. exchange", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "one sharded SMC step incl. exchange (per GPU)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "step_ms": per_step_ms, "algorithmic_bytes_per_launch": BYTES_SMC_PER_PARTICLE_STEP * n,
-                     "limiter": "host-mediated exchange (3 small collectives per step), not HBM"},
+                     "step_ms": per_step_ms, "algorithmic_bytes_per_launch": BYTES_SMC_PER_PARTICLE_STEP * n},
         "log_z": r["log_z"], "log_z_exact": r["log_z_exact"],
+        "bracket": {"empty_ms": empty_bracket_s(world) * 1e3, "min_ms": BRACKET_MIN_S * 1e3},
     }
     res.update(block_stats(blocks))
     return res
@@ -404,7 +437,7 @@ def bench_smc(args, ops, kind, filters=1, min_s=0.08, variant=None, T=None):
         evs.append((e0, e1))
         return o
 
-    blocks, out = timed_blocks(one_run, 1, min_s=min_s, min_blocks=5, max_blocks=40)
+    blocks, out = timed_blocks(one_run, 1, min_s=min_s, min_blocks=20, max_blocks=60)
     r = wl.result(out)
     dev_ms = statistics.median(a.elapsed_ms(b) for a, b in evs)
     dt = statistics.median(blocks)
@@ -414,8 +447,8 @@ def bench_smc(args, ops, kind, filters=1, min_s=0.08, variant=None, T=None):
     # HBM bytes of one step from the PMC passes committed under profiles/ (bytes per particle-step; FETCH_SIZE x2 + WRITE_SIZE)
     per, traffic_src = pmc_traffic(
         "r*_smc_pmc.json",
-        lambda pj: sum((v["hbm_read_bytes"] + v["hbm_write_bytes"]) / v.get("particles_per_launch", 8e6)
-                       for k, v in pj.get(kind, {}).items() if "k_resample" in k or "k_tile_sums" in k))
+        lambda pj: sum((v["hbm_read_bytes"] + v["hbm_write_bytes"]) / v.get("particles_per_launch", 1e6)
+                       for k, v in pj.get(kind, {}).items() if "k_resample" in k))
     traffic = per * n * filters if per else None
     res = {
         "metric": "particle-steps/sec, bootstrap SMC (1e6 particles)",
@@ -423,15 +456,14 @@ def bench_smc(args, ops, kind, filters=1, min_s=0.08, variant=None, T=None):
         "config": {"workload": f"bootstrap SMC {kind} T={T} N={n}, systematic resampling every step"
                                + (" (BASELINE configs[2])" if kind == "smc_lgssm" else " (BASELINE configs[4])"),
                    "rng": args.rng, "filters_per_launch": filters, **({"variant": variant} if variant else {})},
-        "roofline": {"bound": "hbm", "kernel": "k_resample + k_tile_sums (one SMC step" + (" of every filter)" if filters > 1 else ")"),
+        "roofline": {"bound": "hbm", "kernel": "k_resample (ONE launch per SMC step" + (" of every filter)" if filters > 1 else ")"),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "frac_basis": "44 B/particle-step contract figure of the unfused pipeline (SURVEY 8d)",
                      "traffic": traffic, "traffic_source": traffic_src,
                      "frac_of_peak_on_pmc_traffic": (traffic / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "step_ms": per_step_ms, "step_ms_per_filter": per_step_ms / filters, "runs_timed": len(evs),
                      "statistic": "median", "algorithmic_bytes_per_launch": BYTES_SMC_PER_PARTICLE_STEP * n * filters,
-                     "limiter": ("two dependent launches per step at ~1000 workgroups each (under one round of the machine): "
-                                 "per-launch latency floor, not HBM") if filters == 1 else "VALU issue"},
+                     },
         "log_z": log_z, "log_z_exact": r["log_z_exact"], "log_z_abs_err_vs_exact": abs(log_z - r["log_z_exact"]),
     }
     if r.get("resampled") is not None:
@@ -843,10 +875,10 @@ class ExtrasDeadline:
     has not come back after `seconds`, rank 0 prints the line it already has, with the extra marked as missing, and every
     rank leaves with `os._exit(0)` — a rank stuck in a collective cannot be unwound any other way."""
 
-    def __init__(self, rank, out, seconds, name):
+    def __init__(self, rank, out, seconds, name, args=None):
         import threading
 
-        self.rank, self.out, self.seconds, self.name = rank, out, seconds, name
+        self.rank, self.out, self.seconds, self.name, self.args = rank, out, seconds, name, args
         self.lock, self.line_done, self.done = threading.Lock(), False, threading.Event()
         self.t0 = time.perf_counter()
         threading.Thread(target=self._watch, daemon=True).start()
@@ -863,12 +895,123 @@ class ExtrasDeadline:
         if self.done.wait(self.seconds):
             return
         if self.rank == 0 and self.claim_line():
-            line = dict(self.out)
-            line["extra"] = {self.name: {"error": f"no result within {self.seconds:g} s; the line carries the headline only"}}
-            emit_line(line)
+            emit_line(compact_line(self.out, {self.name: {"error": f"no result within {self.seconds:g} s; the line carries the headline only"}}, self.args))
         print(f"bench.py: rank {self.rank}: '{self.name}' exceeded its {self.seconds:g} s deadline "
               f"({time.perf_counter() - self.t0:.1f} s after the headline)", file=sys.stderr, flush=True)
-        os._exit(0)
+        os._exit(3)  # a hang is a FAILURE of the run (the headline line, already measured, has been printed)
+
+
+def _rf(r):
+    """The roofline object of the line: the fields the contract names plus the kernel's name and measured duration."""
+    if not r:
+        return None
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "step_ms", "algorithmic_bytes_per_launch")
+    return {k: r[k] for k in keep if k in r and r[k] is not None or k == "traffic"}
+
+
+def _cb(c):
+    if not c:
+        return None
+    keep = ("value", "unit", "cores", "kind", "sample", "value_1_thread", "log_z_abs_err_gpu_vs_cpu")
+    return {k: c[k] for k in keep if k in c}
+
+
+def _short(e, per="step_ms"):
+    """One `extra` entry of the line: value, time per unit, roofline fraction — the full entry goes to the detail file."""
+    if not isinstance(e, dict):
+        return e
+    if "error" in e:
+        return {"error": str(e["error"])[:120]}
+    o = {}
+    for k in ("value", "unit", "us_per_call", "kernel_ms", "resampling_steps", "ratio_to_normal_step", "step_ms", "normal_step_ms"):
+        if k in e:
+            o[k] = e[k]
+    rf = e.get("roofline") or {}
+    if "step_ms" in rf:
+        o["step_us"] = rf["step_ms"] * 1e3
+    if "kernel_ms" in rf:
+        o["kernel_us"] = rf["kernel_ms"] * 1e3
+    if "frac" in rf:
+        o["roofline_frac"] = rf["frac"]
+    return o
+
+
+def config_entry(e):
+    """A BASELINE config in the line's closing `configs` object: throughput, time per unit, roofline, CPU baseline, log Z
+    against the CPU on the same steps — short enough that the driver's record (the TAIL of stdout) keeps all of them."""
+    rf, cb = e.get("roofline") or {}, e.get("cpu_baseline") or {}
+    o = {"value": e.get("value"), "unit": e.get("unit")}
+    if "step_ms" in rf:
+        o["us_per_step"] = rf["step_ms"] * 1e3
+    elif "kernel_ms" in rf:
+        o["kernel_us"] = rf["kernel_ms"] * 1e3
+    o["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    if cb:
+        o["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "value_1_thread")}
+        o["log_z_abs_err_gpu_vs_cpu"] = cb.get("log_z_abs_err_gpu_vs_cpu")
+    for k in ("log_z", "log_z_exact", "timed_blocks"):
+        if k in e:
+            o[k] = e[k]
+    return o
+
+
+def write_detail(out, extra):
+    """Everything measured, unabridged, beside the line: $GJX_BENCH_DETAIL or gpurun_out/bench_detail.json."""
+    path = os.environ.get("GJX_BENCH_DETAIL") or (os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+                                                  if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
+    if not path:
+        return
+    try:
+        with open(path, "w") as f:
+            json.dump(dict(out, extra=extra), f, indent=1, default=str)
+    except OSError:
+        pass
+
+
+def compact_line(out, extra, args):
+    """The ONE JSON line: the contract's fields, `roofline`, `cpu_baseline`, short `extra` entries, and LAST a `configs`
+    object with every BASELINE config measured in this run (the driver keeps the tail of stdout)."""
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    cfg = dict(out.get("config") or {})
+    for k in list(cfg):
+        if isinstance(cfg[k], str) and len(cfg[k]) > 160:
+            cfg[k] = cfg[k][:157] + "..."
+    line["config"] = cfg
+    line["roofline"] = _rf(out.get("roofline"))
+    line["cpu_baseline"] = _cb(out.get("cpu_baseline"))
+    for k in ("log_z", "log_z_exact", "log_z_abs_err_vs_exact", "timed_blocks", "blocks_per_bracket", "block_ms_median", "bracket"):
+        if k in out:
+            line[k] = out[k]
+    if out.get("cpu_baseline") and "log_z_abs_err_gpu_vs_cpu" in out["cpu_baseline"]:
+        line["log_z_abs_err_gpu_vs_cpu"] = out["cpu_baseline"]["log_z_abs_err_gpu_vs_cpu"]
+    jp = out.get("jax_cpu_plain")
+    if jp is not None:
+        line["jax_cpu_plain"] = {"available": bool(jp.get("available"))} if isinstance(jp, dict) else jp
+    configs = {}
+    head = dict(out)
+    if args.workload == "importance" and out.get("n_gpus", 1) == 1:
+        configs["configs[1] ImportanceK 1e6 (10-latent Gaussian)"] = config_entry(head)
+    elif args.workload == "importance":
+        configs[f"ImportanceK 1e6 per GPU x{out['n_gpus']}"] = config_entry(head)
+    else:
+        nm = {"smc_lgssm": "configs[2] SMC LGSSM T=100 1e6", "smc_hmm": "configs[4] SMC HMM-256 T=500 1e6"}[args.workload]
+        configs[nm + (f" per GPU x{out['n_gpus']} (configs[3])" if out.get("n_gpus", 1) > 1 or FORCE_DIST else "")] = config_entry(head)
+    small = {}
+    for name, e in (extra or {}).items():
+        if name == "smc_lgssm" and isinstance(e, dict) and "value" in e:
+            configs["configs[2] SMC LGSSM T=100 1e6 (one filter)"] = config_entry(e)
+        elif name == "smc_hmm" and isinstance(e, dict) and "value" in e:
+            configs["configs[4] SMC HMM-256 T=500 1e6 (one filter)"] = config_entry(e)
+        elif name == "smc_lgssm_sharded" and isinstance(e, dict) and "value" in e:
+            configs[f"configs[3] SMC LGSSM T=100 1e6 per GPU x{out['n_gpus']}"] = config_entry(e)
+        if isinstance(e, dict):
+            sub = {k: _short(v) for k, v in e.items() if isinstance(v, dict) and ("value" in v or "error" in v) and k not in ("roofline", "cpu_baseline", "config")}
+            small[name] = dict(_short(e), **sub)
+    if small:
+        line["extra"] = small
+    line["configs"] = configs
+    return line
 
 
 def run_rank(args):
@@ -906,7 +1049,7 @@ def run_rank(args):
         if sharded:
             # BASELINE configs[3]: the LGSSM filter with 1e6 particles per GPU, sharded (every rank takes part).  The
             # headline above is already measured: a rank that never comes back from the exchange must not cost the line.
-            guard = ExtrasDeadline(rank, out, float(os.environ.get("GJX_BENCH_EXTRA_DEADLINE_S", "240")), "smc_lgssm_sharded")
+            guard = ExtrasDeadline(rank, out, float(os.environ.get("GJX_BENCH_EXTRA_DEADLINE_S", "240")), "smc_lgssm_sharded", args)
             try:
                 extra["smc_lgssm_sharded"] = entry(bench_smc_sharded(args, ops, rank, world, "smc_lgssm"))
             except Exception as ex:  # reported in the line; the other ranks are released by their own deadline
@@ -924,8 +1067,6 @@ def run_rank(args):
                 e["ess_adaptive_0.5"]["step_ms"] = ra["roofline"]["step_ms"]
                 r16, _ = bench_smc(args, ops, kind, filters=16, min_s=0.05)
                 e["batched_16_filters_per_launch"] = entry(r16, ("value", "unit", "ms_per_step", "roofline", "log_z"))
-                e["batched_16_filters_per_launch"]["note"] = ("16 independent filters x 1e6 particles step in the same launches: "
-                                                              "NOT a BASELINE config; throughput of the kernels once the machine is full")
                 extra[kind] = e
             # worst case of the resampler: collapsing weights (a sharp observation model, observations jumping by tens of
             # standard deviations: at most steps ONE tile owns every output slot), against the normal LGSSM step
@@ -941,10 +1082,7 @@ def run_rank(args):
                 extra["smc_lgssm_collapsing_weights"] = {
                     "step_ms": rc_["roofline"]["step_ms"], "normal_step_ms": extra["smc_lgssm"]["roofline"]["step_ms"],
                     "ratio_to_normal_step": rc_["roofline"]["step_ms"] / extra["smc_lgssm"]["roofline"]["step_ms"],
-                    "distinct_ancestors_at_step_2": int(anc[2].unique().numel()), "steps": len(yc),
-                    "note": "a heavy tile's workgroup serves its first 4 chunks of 1024 slots; the chunks beyond are delegated to idle "
-                            "(zero-mass) workgroups, which stage the same source tile and serve them from the same CDF "
-                            "(bit-identical ancestors): no workgroup walks the whole population"}
+                    "distinct_ancestors_at_step_2": int(anc[2].unique().numel()), "steps": len(yc)}
             except Exception as ex:
                 extra["smc_lgssm_collapsing_weights"] = {"error": f"{type(ex).__name__}: {ex}"}
             # ImportanceK over a Scan model: the reference's literal semantics of the state-space configs (no resampling)
@@ -980,8 +1118,6 @@ def run_rank(args):
             except Exception as ex:  # reported, never silently dropped
                 extra["importance_fast_math"] = {"error": f"{type(ex).__name__}: {ex}"}
     if rank == 0:
-        if extra:
-            out["extra"] = extra
         if world == 1 and not FORCE_DIST and not args.no_cpu_baseline:
             if args.workload == "importance":
                 out["cpu_baseline"] = cpu_baseline_importance(args, out["log_z"])
@@ -989,7 +1125,8 @@ def run_rank(args):
             else:
                 out["cpu_baseline"] = cpu_baseline_smc(args, args.workload, smc_gpu)
         if guard is None or guard.claim_line():
-            emit_line(out)
+            write_detail(out, extra)
+            emit_line(compact_line(out, extra, args))
     if sharded:
         import torch.distributed as dist
 
