@@ -522,3 +522,93 @@ def random_sharded_configs(ops, seed, count, ref_ops=None):
 
 def test_random_sharded_configurations(oracle_ops):
     random_sharded_configs(oracle_ops, 3, 14)
+
+
+# ---- the NATIVE driver across REAL processes: gjx_smc_sharded_run_* with the process group's own
+# collectives as its transport (gjx_comm_init_callbacks -> torch.distributed over gloo) -------------------------------------
+def _worker_native(rank, world, port, n_total, T, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "genjax-chi_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from genjax._amd import dist as gdist
+    from genjax._amd.abi import GjxLib
+    from genjax._amd.ops import Ops
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    ops = Ops(GjxLib(ORACLE_LIB, "cpu"))
+    comm = gdist.NativeComm.over_torch(ops, rank, world)
+    assert comm.rank == rank and comm.world == world
+    out = {}
+    for name, mk in (
+        ("lgssm", lambda: gdist.ShardedSMC(ops, "lgssm", 1, 5, n_total, T, rank, world, True, exchange="ranges", poison=True)),
+        ("hmm", lambda: gdist.ShardedSMC(ops, "hmm", 0, 6, n_total, T, rank, world, True, exchange="ranges", poison=True, n_states=16)),
+        ("lgssm_allgather", lambda: gdist.ShardedSMC(ops, "lgssm", 0, 5, n_total, T, rank, world, True, exchange="allgather", poison=True)),
+        ("lgssm_adaptive", lambda: gdist.ShardedSMC(ops, "lgssm", 1, 5, n_total, T, rank, world, True, exchange="ranges", poison=True,
+                                                    ess_threshold=0.5)),
+    ):
+        r = mk().run_native(comm)
+        out[name] = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in r.items() if k != "log_z_exact"}
+    # a generated filter (the two-column plan of the GPU parity tests)
+    from test_gpu_parity_abi import _smc_plans
+
+    plan, obs, _ = _plan_case(ops, _smc_plans, T)
+    r = gdist.ShardedSMC(ops, "plan", 1, 9, n_total, T, rank, world, True, exchange="ranges", poison=True, plan=plan, obs=obs).run_native(comm)
+    out["plan"] = {k: ([c.clone() for c in v] if isinstance(v, list) else (v.clone() if isinstance(v, torch.Tensor) else v))
+                   for k, v in r.items() if k != "log_z_exact"}
+    torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _plan_case(ops, plans_fn, T):
+    """(plan, observations) of the generated two-column filter (as in check_sharded_plan)."""
+    import numpy as np
+
+    from genjax._amd import workloads as W
+
+    _, plan = plans_fn(ops)
+    obs = np.stack([W.lgssm_data(T), (np.arange(T) % 2).astype(np.float32)], axis=1)
+    return plan, obs, None
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_native_driver_in_real_processes(tmp_path, oracle_ops, world):
+    """`gjx_smc_sharded_run_{lgssm,hmm,plan}` — the C driver that runs on the 8-GPU node — in 2 and 4 REAL processes, its
+    all-gather and grouped send/recv carried by the gloo process group through `gjx_comm_init_callbacks`: particles,
+    ancestors, per-step (e, q), resampling flags and log Z equal the single-rank filter bit for bit; ranks receive only
+    their source ranges (less than an all-gather would move)."""
+    from genjax._amd import prng, workloads as W
+    from test_gpu_parity_abi import _smc_plans
+
+    n_total, T = 1024 * world * 3, 9
+    mp.spawn(_worker_native, args=(world, _free_port(), n_total, T, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(world)]
+    refs = {
+        "lgssm": W.lgssm_smc(oracle_ops, 1, 5, n_total, T, True),
+        "hmm": W.hmm_smc(oracle_ops, 0, 6, n_total, T, 16, True),
+        "lgssm_allgather": W.lgssm_smc(oracle_ops, 0, 5, n_total, T, True),
+        "lgssm_adaptive": W.lgssm_smc(oracle_ops, 1, 5, n_total, T, True, ess_threshold=0.5),
+    }
+    for name, ref in refs.items():
+        assert torch.equal(torch.cat([p[name]["state"] for p in parts]), ref["state"]), name
+        assert torch.equal(torch.cat([p[name]["logw"] for p in parts]), ref["logw"]), name
+        assert torch.equal(torch.cat([p[name]["ancestors"] for p in parts], dim=1), ref["ancestors"]), name
+        for p in parts:
+            assert torch.equal(p[name]["out_e"], ref["out_e"]) and torch.equal(p[name]["out_q"], ref["out_q"]), name
+            assert p[name]["log_z"] == ref["log_z"], name
+            if name == "lgssm_adaptive":
+                assert torch.equal(p[name]["resampled"], ref["resampled"])
+        if name in ("lgssm", "hmm"):
+            assert all(0 < p[name]["received"] < (T - 1) * (n_total - n_total // world) for p in parts), name
+    plan, obs, _ = _plan_case(oracle_ops, _smc_plans, T)
+    sk, rk = W.smc_key_schedule(prng.key(9, 1), T)
+    ref = oracle_ops.smc_run_plan(plan, 1, n_total, sk, rk, obs, True)
+    for c in range(plan.n_state):
+        assert torch.equal(torch.cat([p["plan"]["state"][c] if isinstance(p["plan"]["state"], list) else p["plan"]["state"] for p in parts]),
+                           ref[2][c])
+    assert torch.equal(torch.cat([p["plan"]["ancestors"] for p in parts], dim=1), ref[4])
+    for p in parts:
+        assert torch.equal(p["plan"]["out_e"], ref[0]) and torch.equal(p["plan"]["out_q"], ref[1])
