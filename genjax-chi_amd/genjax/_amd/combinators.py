@@ -171,6 +171,7 @@ class Scan(GenerativeFunction):
         if not FUSED_SCAN or not isinstance(key, ParticleKeys) or key.n < 2 or key.kb.fold is not None:
             return None
         from . import scan_plan as SP
+        from .abi import GjxError
         from .plan import PlanUnsupported
 
         carry0, xs = args
@@ -183,6 +184,8 @@ class Scan(GenerativeFunction):
 
             low = SP.lower_scan(self.kernel_gen_fn, carry0, xs, obs_addrs, fast_math=fast_math_enabled())
             table = SP.observation_table(obs_values, xs, T)
+        except GjxError:
+            raise  # the library refused or failed to create the plan (ABI mismatch, allocation, ...): no silent slow route
         except Exception:
             # PlanUnsupported, or symbolic values fed to code that needs tensors: the host loop runs the model and
             # raises genuine model errors itself

@@ -524,7 +524,11 @@ def _make_plan(tracer):
                     tmp[q].arg[k].table = None
         raw = bytes(memoryview(tmp)) + repr(progs).encode()
     tracer._table_key = raw
-    key = (id(ops), fast, raw)
+    # Tables the site table points into (categorical logits, transition rows) enter the key by identity AND version: the
+    # library derives per-plan tables from them at the plan's first compilation (CDFs, guides, log-probabilities), so an
+    # in-place update of such a tensor (an EM / optimiser step) must not find the plan built from its old contents.
+    tables = tuple((id(t), t._version) for t in tracer.keep if isinstance(t, torch.Tensor))
+    key = (id(ops), fast, raw, tables)
     hit = cache.get(key)
     if hit is not None:
         cache.move_to_end(key)
@@ -548,7 +552,11 @@ def _leaf_key(v):
         return ("t", id(v), v._version)  # (an in-place change of a tensor invalidates what was traced from it)
     if isinstance(v, (bool, int, float, str, type(None))):
         return ("v", type(v).__name__, v)
-    return ("o", id(v))
+    if isinstance(v, (tuple, list)):  # containers by CONTENT: a list mutated in place must not hit its old trace
+        return ("c", type(v).__name__, tuple(_leaf_key(x) for x in v))
+    if isinstance(v, dict):
+        return ("d", tuple((k, _leaf_key(x)) for k, x in v.items()))
+    raise TypeError("an argument of a type the trace cache cannot key by value")  # (-> the call is traced afresh)
 
 
 def _traced(gen_fn, constraint: ChoiceMap, n: int, args):

@@ -36,11 +36,12 @@ bench.emit_line({"metric": "m", "value": 1.0})
 def test_deadline_prints_the_headline_and_leaves():
     rc, out, err = run("""
 bench.reserve_stdout()
-g = bench.ExtrasDeadline(0, {"metric": "m", "value": 2.0}, 0.2, "smc_lgssm_sharded")
+args = type("A", (), {"workload": "importance"})()
+g = bench.ExtrasDeadline(0, {"metric": "m", "value": 2.0, "n_gpus": 2}, 0.2, "smc_lgssm_sharded", args)
 time.sleep(30)          # a rank stuck in a collective
 bench.emit_line({"never": "reached"})
 """)
-    assert rc == 0
+    assert rc == 3  # a hang is a failed run (ADVICE r02): the headline is printed, the status is non-zero
     lines = out.splitlines()
     assert len(lines) == 1
     o = json.loads(lines[0])
@@ -53,7 +54,7 @@ def test_deadline_not_rank0_prints_nothing_and_finish_disarms():
 g = bench.ExtrasDeadline(1, None, 0.2, "x")
 time.sleep(30)
 """)
-    assert rc == 0 and out == ""
+    assert rc == 3 and out == ""
     rc, out, err = run("""
 g = bench.ExtrasDeadline(0, {"value": 3.0}, 0.3, "x")
 assert g.claim_line() and not g.claim_line()

@@ -217,3 +217,41 @@ def test_random_scan_kernels_fused_equals_loop(hip_ops, impl):
     with use_ops(hip_ops):
         compared, skipped = fuzz_models.run_scans(12.0, 41 + impl, impl, n=2000)
     assert compared > 3 and skipped < compared
+
+
+@pytest.mark.parametrize("impl", ["threefry", "philox"])
+def test_tables_updated_in_place_between_calls(hip_ops, oracle_ops, impl):
+    """`categorical(logits=trans[z])` passes the user's own device tensor to the plan, and the library
+    derives per-plan tables (CDFs, guides, log-probabilities) from it at the plan's first compilation.  An in-place update
+    of the tensor (an EM step) keeps its address: the plan cache must not hand back the plan built from the old contents —
+    the second estimate equals the oracle's on the NEW table (and differs from the first)."""
+    from genjax import categorical
+
+    def run(ops):
+        with use_ops(ops):
+            dev = ops.device()
+            g = torch.Generator().manual_seed(3)
+            trans = (torch.randn(6, 6, generator=g) * 1.5).to(dev)
+            emit = (torch.randn(6, 6, generator=g) * 1.5).to(dev)
+
+            @gen
+            def model():
+                z0 = categorical(logits=trans[0]) @ "z0"
+                z1 = categorical(logits=trans[z0]) @ "z1"
+                _ = categorical(logits=emit[z1]) @ "y"
+                return z1
+
+            t = Target(model, (), C["y"].set(2))
+            out = []
+            for step in range(2):
+                alg = ImportanceK(t, k_particles=20000)
+                out.append(float(alg.log_marginal_likelihood_estimate(genjax.random.key(11, impl))))
+                coll = alg.run_smc(genjax.random.key(12, impl))
+                out.append(coll.get_particles().get_choices()["z1"].cpu())
+                trans.mul_(-0.7).add_(0.1)  # in place: same address, new contents
+            return out
+
+    h, o = run(hip_ops), run(oracle_ops)
+    for a, b in zip(h, o):
+        _eq(a, b, "estimate / particles before and after the in-place update")
+    assert h[0] != h[2]
