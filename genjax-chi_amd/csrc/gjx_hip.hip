@@ -2536,6 +2536,10 @@ int gjx_smc_plan_destroy(gjx_smc_plan* p) {
   delete p;
   return GJX_OK;
 }
+int gjx_jit_compile_source(const char* source) {
+  if (!source) return GJX_ERR_INVALID;
+  return gjx_jit::compile_only(source) ? GJX_OK : GJX_ERR_JIT;
+}
 int gjx_jit_stats(uint64_t* compiles, uint64_t* cached_modules, uint64_t* evictions) {
   gjx_jit::ModuleCache& mc = gjx_jit::ModuleCache::get();
   std::lock_guard<std::mutex> lock(mc.mu);

@@ -20,6 +20,14 @@
 #include <utility>
 #include <vector>
 
+#include <dlfcn.h>
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+#include <cerrno>
+
+extern "C" char** environ;
+
 namespace gjx_jit {
 
 // The device header, embedded at build time (see __graft_entry__.build()).
@@ -703,6 +711,97 @@ inline bool enabled() {
   return !(e && e[0] == '0');
 }
 
+// ---- the compiler runs in a CHILD process (gjx_jitc.cpp) ---------------------------------------------------------------
+// hiprtc is the whole AMDGPU backend in-process: a backend crash on generated source would be an abort() of the caller
+// (it happened once: a constant-folded NaN log-weight; the generator now keeps such constants opaque, but ANY other
+// backend bug would do the same).  So generated kernels are compiled by `gjx_jitc`, a helper next to this library: a fresh
+// process that never touches the GPU, started with posix_spawn (a child process — the caller is not replaced), source /
+// header / code object / log in files of a private temporary directory.  A child that dies => false + a log line
+// (callers return GJX_ERR_JIT).  GJX_JIT_INPROC=1 compiles in-process (the round-1/2 behaviour); so does a missing helper,
+// with a warning.
+inline std::string jitc_path() {
+  static const std::string path = [] {
+    if (const char* e = std::getenv("GJX_JITC")) return std::string(e);
+    Dl_info info;
+    if (dladdr((const void*)&kDeviceHeader, &info) && info.dli_fname) {
+      std::string p(info.dli_fname);
+      const size_t k = p.rfind('/');
+      p = (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/gjx_jitc";
+      if (access(p.c_str(), X_OK) == 0) return p;
+    }
+    return std::string();
+  }();
+  return path;
+}
+inline bool write_file(const std::string& path, const char* data, size_t n) {
+  FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) return false;
+  const bool ok = std::fwrite(data, 1, n, f) == n;
+  return std::fclose(f) == 0 && ok;
+}
+inline bool read_file(const std::string& path, std::string* out) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  char buf[1 << 16];
+  size_t n;
+  out->clear();
+  while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
+  std::fclose(f);
+  return true;
+}
+inline std::vector<std::string> compile_options() {
+  std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+  // GJX_JIT_DEFINE=NAME[=VALUE]: one extra -D for the generated kernel (A/B knob for device-header variants)
+  if (const char* d = std::getenv("GJX_JIT_DEFINE")) opts.push_back(std::string("-D") + d);
+  // GJX_JIT_OPTS="opt opt ...": extra compiler options for the generated kernel (scheduling experiments)
+  if (const char* e = std::getenv("GJX_JIT_OPTS")) {
+    std::istringstream is(e);
+    for (std::string t; is >> t;) opts.push_back(t);
+  }
+  return opts;
+}
+// -> 1 compiled, 0 compilation failed or the child died (logged), -1 the child could not be started
+inline int compile_in_child(const std::string& src, std::string* code) {
+  const std::string helper = jitc_path();
+  if (helper.empty()) return -1;
+  static std::mutex mu;  // one directory per process; compilations are serialised by the module cache's lock anyway
+  std::lock_guard<std::mutex> lock(mu);
+  static const std::string dir = [] {
+    const char* t = std::getenv("TMPDIR");
+    std::string d = std::string(t && *t ? t : "/tmp") + "/gjx_jit_XXXXXX";
+    return mkdtemp(&d[0]) ? d : std::string();
+  }();
+  if (dir.empty()) return -1;
+  const std::string fsrc = dir + "/k.hip", fhdr = dir + "/gjx_device.hpp", fout = dir + "/k.co", flog = dir + "/k.log";
+  static const bool hdr_ok = write_file(fhdr, kDeviceHeader, sizeof(kDeviceHeader) - 1);
+  if (!hdr_ok || !write_file(fsrc, src.data(), src.size())) return -1;
+  unlink(fout.c_str());
+  unlink(flog.c_str());
+  const std::vector<std::string> opts = compile_options();
+  std::vector<char*> argv = {const_cast<char*>(helper.c_str()), const_cast<char*>(fsrc.c_str()), const_cast<char*>(fhdr.c_str()),
+                             const_cast<char*>(fout.c_str()), const_cast<char*>(flog.c_str())};
+  for (const std::string& o : opts) argv.push_back(const_cast<char*>(o.c_str()));
+  argv.push_back(nullptr);
+  pid_t pid = 0;
+  if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), environ) != 0) return -1;
+  int status = 0;
+  while (waitpid(pid, &status, 0) < 0) {
+    if (errno != EINTR) return -1;
+  }
+  if (WIFEXITED(status) && WEXITSTATUS(status) == 0 && read_file(fout, code) && !code->empty()) return 1;
+  if (WIFSIGNALED(status)) {
+    std::fprintf(stderr, "[gjx] the plan compiler (gjx_jitc, pid %d) died with signal %d on a generated kernel; source kept in %s\n",
+                 (int)pid, WTERMSIG(status), fsrc.c_str());
+  } else {
+    std::string log;
+    (void)read_file(flog, &log);
+    std::fprintf(stderr, "[gjx] hiprtc: plan specialisation failed to compile (child status %d)%s\n", WIFEXITED(status) ? WEXITSTATUS(status) : -1,
+                 std::getenv("GJX_PLAN_JIT_VERBOSE") ? ":" : "; GJX_PLAN_JIT_VERBOSE=1 prints the compiler log");
+    if (std::getenv("GJX_PLAN_JIT_VERBOSE")) std::fprintf(stderr, "%s\n", log.c_str());
+  }
+  return 0;
+}
+
 // Compile `src` for gfx950; on success `code` holds the code object.
 inline bool compile_to_code(const std::string& src, std::string* code) {
   // GJX_PLAN_JIT_DUMP_FILE=path: the source about to be compiled (overwritten per compilation: after a compiler crash the
@@ -713,21 +812,22 @@ inline bool compile_to_code(const std::string& src, std::string* code) {
       fclose(fp);
     }
   }
+  const char* inproc = std::getenv("GJX_JIT_INPROC");
+  if (!(inproc && inproc[0] == '1')) {
+    const int r = compile_in_child(src, code);
+    if (r >= 0) return r == 1;
+    static bool warned = false;
+    if (!warned) {
+      warned = true;
+      std::fprintf(stderr, "[gjx] gjx_jitc (the plan compiler's child process) is not available next to the library: compiling in-process\n");
+    }
+  }
   hiprtcProgram prog;
   const char* hn[] = {"gjx_device.hpp"};
   const char* hs[] = {kDeviceHeader};
   if (hiprtcCreateProgram(&prog, src.c_str(), "gjx_plan.hip", 1, hs, hn) != HIPRTC_SUCCESS) return false;
-  // GJX_JIT_DEFINE=NAME[=VALUE]: one extra -D for the generated kernel (A/B knob for device-header variants)
-  std::string extra_def;
-  if (const char* d = std::getenv("GJX_JIT_DEFINE")) extra_def = std::string("-D") + d;
-  // GJX_JIT_OPTS="opt opt ...": extra compiler options for the generated kernel (scheduling experiments)
-  std::vector<std::string> extra;
-  if (!extra_def.empty()) extra.push_back(extra_def);
-  if (const char* e = std::getenv("GJX_JIT_OPTS")) {
-    std::istringstream is(e);
-    for (std::string t; is >> t;) extra.push_back(t);
-  }
-  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+  const std::vector<std::string> extra = compile_options();
+  std::vector<const char*> opts;
   for (const std::string& t : extra) opts.push_back(t.c_str());
   const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (r != HIPRTC_SUCCESS) {

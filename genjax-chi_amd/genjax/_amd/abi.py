@@ -283,6 +283,7 @@ PROTOTYPES = {
     "gjx_plan_compile_check": (C.c_int, [_P, C.c_int]),
     "gjx_plan_prepare": (C.c_int, [_P, _KP]),
     "gjx_jit_stats": (C.c_int, [_P, _P, _P]),
+    "gjx_jit_compile_source": (C.c_int, [C.c_char_p]),
     "gjx_importance_run": (
         C.c_int,
         [_P, _KP, C.POINTER(_P), C.c_int, C.POINTER(_P), C.c_int, _P, _P, C.c_uint64, _P, _P, _P, _P, _P],

@@ -259,6 +259,11 @@ int gjx_plan_compile_check(const gjx_plan* p, int impl);
  * using them, and unreferenced ones are kept for reuse up to GJX_JIT_CACHE_MAX (default 64) entries, then unloaded
  * least-recently-used first.  Each output nullable. */
 int gjx_jit_stats(uint64_t* compiles, uint64_t* cached_modules, uint64_t* evictions);
+/* Compile a kernel source the way generated plan kernels are compiled (gfx950, the device header available as
+ * "gjx_device.hpp"), needs no GPU: GJX_OK, or GJX_ERR_JIT if the compiler rejects the source OR DIES on it.  The
+ * compiler runs in a child process (csrc/gjx_jitc.cpp): an AMDGPU-backend crash on generated source — it happened once —
+ * is an error code and a log line for the caller, never an abort.  (GJX_ERR_UNSUPPORTED in the oracle build.) */
+int gjx_jit_compile_source(const char* source);
 /* particle_keys: the per-particle keys BEFORE the per-site fold (has_fold must be 0).
  * input_cols / value_cols: host arrays of dev pointers (each column dev [n], 4-byte elements:
  * f32, or int32 for Bernoulli/Categorical values; at most 16 input columns).  score, logw: dev

@@ -408,6 +408,7 @@ int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t b
   return GJX_ERR_UNSUPPORTED;
 }
 int gjx_plan_compile_check(const gjx_plan* p, int impl) { (void)p; (void)impl; return GJX_ERR_UNSUPPORTED; }
+int gjx_jit_compile_source(const char* source) { (void)source; return GJX_ERR_UNSUPPORTED; }
 int gjx_jit_stats(uint64_t* compiles, uint64_t* cached_modules, uint64_t* evictions) {
   if (compiles) *compiles = 0;
   if (cached_modules) *cached_modules = 0;

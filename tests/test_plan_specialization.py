@@ -205,3 +205,23 @@ def test_plans_with_invalid_constants_compile(hip_lib_nogpu, impl):
     for sites in tables:
         plan = ops.plan_create(sites)
         ops.lib.call("gjx_plan_compile_check", plan.handle, impl)
+
+
+def test_a_compiler_crash_is_an_error_code_not_an_abort():
+    """hiprtc runs the AMDGPU backend in the caller's process, so a backend crash on generated source
+    used to be an abort of the caller.  The library now compiles in a child process (csrc/gjx_jitc.cpp, next to the
+    library): a source that makes the compiler DIE (`#pragma clang __debug crash`), or fail, comes back as GJX_ERR_JIT —
+    and this process is still here to assert it; a valid kernel compiles."""
+    import ctypes as C
+
+    from genjax._amd import abi
+
+    lib = abi.GjxLib(HIP_LIB, "cuda")
+    good = b'#include "gjx_device.hpp"\nextern "C" __global__ void k(float* x) { x[threadIdx.x] = gjx::u2f(0x3f800000u); }\n'
+    assert lib._gjx_jit_compile_source(good) == 0
+    crash = b'#include "gjx_device.hpp"\n#pragma clang __debug crash\nextern "C" __global__ void k(float* x) { x[0] = 1.0f; }\n'
+    assert lib._gjx_jit_compile_source(crash) == -6  # GJX_ERR_JIT
+    bad = b'extern "C" __global__ void k(float* x) { this is not C++ }\n'
+    assert lib._gjx_jit_compile_source(bad) == -6
+    assert lib._gjx_jit_compile_source(good) == 0  # and the compiler is still usable
+    _ = C
