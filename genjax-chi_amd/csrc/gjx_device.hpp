@@ -215,6 +215,14 @@ struct PassBatch {
   uint32_t parent[kMaxPasses][2];  // used when n_pass > 1 (lazy batches of lane-0 parents)
 };
 
+// Device tables a generated kernel reads (categorical logits, the per-row tables derived from them, ARG_TABLE columns):
+// a kernel argument, not literals in the source — the source of a plan is keyed by its STRUCTURE, so another tensor of the
+// same shape (a new transition matrix) costs no compilation (gjx_plan_jit.hpp: TableReg).
+constexpr int kMaxPlanTables = 48;
+struct PlanTables {
+  const void* p[kMaxPlanTables];
+};
+
 // Launch-uniform parameters of an importance plan (GJX_ARG_PARAM; kernel argument, by value: they live in scalar
 // registers): p[] the caller's values (gjx_plan_set_params), d[2 q], d[2 q + 1] the per-site constants derived from them
 // on the host by the spec functions (normal: 1 / scale, log normaliser; gamma / beta: -, log normaliser).

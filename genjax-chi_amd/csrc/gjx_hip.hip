@@ -1665,6 +1665,7 @@ int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t b
   g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites; g.laned = impl == 1 && jit_form_pref() >= 2;
   g.pairs_per_lane = jit_form_pref() == 4 ? 2 : 1;  // (GJX_JIT_FORM picks the PHILOX form shown)
   g.fast_math = (p->flags & GJX_PLAN_FAST_MATH) != 0;
+  gjx_jit::TableScope ts;
   const std::string src = g.run();
   if (needed) *needed = src.size() + 1;
   if (buf && buf_len > 0) {
@@ -1681,6 +1682,7 @@ int gjx_plan_compile_check(const gjx_plan* p, int impl) {
     gjx_jit::Gen<CSite, CArg> g;
     g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites; g.laned = form != 0; g.pairs_per_lane = form == 2 ? 2 : 1;
     g.fast_math = (p->flags & GJX_PLAN_FAST_MATH) != 0;
+    gjx_jit::TableScope ts;
     if (!gjx_jit::compile_only(g.run())) return GJX_ERR_UNSUPPORTED;
   }
   return GJX_OK;
@@ -1713,9 +1715,11 @@ static gjx_jit::Compiled& plan_compiled(gjx_plan* mp, const gjx_keys* pk, int la
         g.impl = pk->impl; g.sites = mp->host; g.n_sites = mp->n_sites; g.laned = laned; g.pairs_per_lane = P == 4 ? 2 : 1;
         g.fast_math = (mp->flags & GJX_PLAN_FAST_MATH) != 0;
         g.min_waves = min_waves;
+        gjx_jit::TableScope ts;  // the source numbers the plan's device tables; the addresses travel as a kernel argument
         std::string src = g.run();
         c.block = g.block;
         c.rows_per_block = g.rows_per_block;
+        c.tabs = ts.reg.tables();
         return src;
       };
       // The kernels are bound by dependency latency, not by issue slots (a wave64 VALU instruction issues in ~2.4
@@ -1810,7 +1814,8 @@ static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pa
       bt.row_stride = row_stride;
       for (int32_t b = 0; b < n_pass; ++b) { bt.parent[b][0] = pk[b].parent[0]; bt.parent[b][1] = pk[b].parent[1]; }
       PlanParams prm = p->prm;
-      void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials, &row_e, &row_s, &tail, &bt, &prm};
+      PlanTables tabs = c.tabs;
+      void* args[] = {&k, &cols, &score, &logw, &nn, &max_partials, &row_e, &row_s, &tail, &bt, &prm, &tabs};
       uint64_t rows = ((uint64_t)n_pass * nrows_of(n) + c.rows_per_block - 1) / c.rows_per_block;
       static const uint64_t grid_cap = [] {
         const char* e = std::getenv("GJX_IMPORTANCE_GRID");
@@ -2427,12 +2432,15 @@ int gjx_scan_plan_destroy(gjx_scan_plan* p) {
   delete p;
   return GJX_OK;
 }
-static std::string scan_plan_source(const gjx_scan_plan* plan, int impl, const char** kname = nullptr) {
+static std::string scan_plan_source(const gjx_scan_plan* plan, int impl, const char** kname = nullptr, PlanTables* tabs = nullptr) {
+  gjx_jit::TableScope ts;
   gjx_jit::GenScan<CSite, CArg> g;
   g.impl = impl; g.sites = plan->step; g.n_sites = plan->n_step; g.next_state = plan->next_state;
   g.n_state = plan->n_state; g.n_obs = plan->n_obs; g.fast_math = (plan->flags & GJX_PLAN_FAST_MATH) != 0;
   if (kname) *kname = g.kname();
-  return g.run();
+  std::string src = g.run();
+  if (tabs) *tabs = ts.reg.tables();
+  return src;
 }
 int gjx_scan_plan_compile_check(const gjx_scan_plan* p, int impl) {
   if (!p || (impl != 0 && impl != 1)) return GJX_ERR_INVALID;
@@ -2462,7 +2470,7 @@ int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
     if (c.state == 0) {
       cat_tables_prepare(p->step, p->n_step, &p->dev_owned);
       const char* kname = nullptr;
-      const std::string src = scan_plan_source(p, impl, &kname);
+      const std::string src = scan_plan_source(p, impl, &kname, &c.tabs);
       if (std::getenv("GJX_PLAN_JIT_DUMP")) fprintf(stderr, "%s\n", src.c_str());
       c.state = gjx_jit::compile(src, impl, &c, kname) ? 1 : -1;
     }
@@ -2481,7 +2489,8 @@ int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
   if (io->lse) tail = LseTail{io->lse->e, io->lse->q, io->lse->lse, io->lse->record, io->lse->tickets};
   float* score = io->score; float* logw = io->logw; float* mp = io->max_partials;
   int32_t* row_e = io->row_e; uint64_t* row_s = io->row_s;
-  void* args[] = {&k, &cols, &sa, &score, &logw, &mp, &row_e, &row_s, &tail};
+  PlanTables tabs = c.tabs;
+  void* args[] = {&k, &cols, &sa, &score, &logw, &mp, &row_e, &row_s, &tail, &tabs};
   const uint64_t rows = nrows_of(io->n);
   if (hipModuleLaunchKernel(c.fn, (unsigned)(rows > 0x7fffffffull ? 0x7fffffffull : rows), 1, 1, 256, 1, 1, 0, S(s), args,
                             nullptr) != hipSuccess)
@@ -2549,11 +2558,14 @@ int gjx_jit_stats(uint64_t* compiles, uint64_t* cached_modules, uint64_t* evicti
   return GJX_OK;
 }
 
-static std::string smc_plan_source(const gjx_smc_plan* plan, int impl) {
+static std::string smc_plan_source(const gjx_smc_plan* plan, int impl, PlanTables* tabs = nullptr) {
+  gjx_jit::TableScope ts;
   gjx_jit::GenSmc<CSite, CArg> g;
   g.impl = impl; g.init_sites = plan->init; g.n_init = plan->n_init; g.step_sites = plan->step;
   g.n_step = plan->n_step; g.init_state = plan->init_state; g.next_state = plan->next_state; g.n_state = plan->n_state;
-  return g.run();
+  std::string src = g.run();
+  if (tabs) *tabs = ts.reg.tables();
+  return src;
 }
 int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl) {
   if (!p || (impl != 0 && impl != 1)) return GJX_ERR_INVALID;
@@ -2569,7 +2581,7 @@ static gjx_jit::CompiledSmc* smc_plan_compiled(gjx_smc_plan* plan, int impl) {
     if (c.state == 0) {
       cat_tables_prepare(plan->init, plan->n_init, &plan->dev_owned);
       cat_tables_prepare(plan->step, plan->n_step, &plan->dev_owned);
-      c.state = gjx_jit::compile_smc(smc_plan_source(plan, impl), &c) ? 1 : -1;
+      c.state = gjx_jit::compile_smc(smc_plan_source(plan, impl, &c.tabs), &c) ? 1 : -1;
     }
   }
   return c.state == 1 ? &c : nullptr;
@@ -2599,14 +2611,16 @@ static int smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, gjx_jit:
     uint64_t first = cfg->first_slot, nl = cfg->n_local;
     FilterBatch fb = ctx.fb;
     EmitOut em = emit_out_of(cfg, out);
-    void* args[] = {&PA, &first, &nl, &em, &fb};
+    PlanTables tabs = c.tabs;
+    void* args[] = {&PA, &first, &nl, &em, &fb, &tabs};
     if (hipModuleLaunchKernel(c.init, ntl * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
     return launch_status();
   }
   ResampleArgs A;
   int rc = smc_resample_args(cfg, t, prev, out, prev_e_out, prev_q_out, ctx, s, &A);
   if (rc) return rc;
-  void* args[] = {&A, &PA};
+  PlanTables tabs = c.tabs;
+  void* args[] = {&A, &PA, &tabs};
   if (hipModuleLaunchKernel(c.step, ntl * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
   return launch_status();
 }

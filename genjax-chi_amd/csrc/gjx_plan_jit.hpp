@@ -17,6 +17,7 @@
 #include <sstream>
 #include <string>
 #include <unordered_map>
+#include <cstring>
 #include <utility>
 #include <vector>
 
@@ -43,16 +44,44 @@ inline std::string flit(float f) {
 }
 // a finite literal that must still stay opaque (a parameter outside its domain, an observation outside the support)
 inline std::string flit_opaque(float f) { return (f - f == 0.0f) ? "opq(" + flit(f) + ")" : flit(f); }
+// Device pointers of a generated kernel: entry k of the `tabs` kernel argument (gjx_device.hpp PlanTables), numbered in
+// order of first use while the source is generated — the SOURCE holds indices, never addresses, so it is the same for
+// every plan of the same structure; the plan keeps the addresses and passes them at launch.  (Beyond kMaxPlanTables
+// distinct tables — 48: never seen — the address is written into the source as before.)
+struct TableReg {
+  std::vector<const void*> ptrs;
+  int index_of(const void* p) {
+    for (size_t i = 0; i < ptrs.size(); ++i)
+      if (ptrs[i] == p) return (int)i;
+    if ((int)ptrs.size() >= gjx::kMaxPlanTables) return -1;
+    ptrs.push_back(p);
+    return (int)ptrs.size() - 1;
+  }
+  gjx::PlanTables tables() const {
+    gjx::PlanTables t;
+    std::memset(&t, 0, sizeof t);
+    for (size_t i = 0; i < ptrs.size(); ++i) t.p[i] = ptrs[i];
+    return t;
+  }
+};
+inline TableReg*& active_tables() {
+  static thread_local TableReg* reg = nullptr;
+  return reg;
+}
+struct TableScope {  // the registry of one source generation
+  TableReg reg;
+  TableReg* prev;
+  TableScope() : prev(active_tables()) { active_tables() = &reg; }
+  ~TableScope() { active_tables() = prev; }
+};
 inline std::string plit_as(const char* type, const void* p) {
   char b[96];
-  std::snprintf(b, sizeof b, "((const %s*)0x%llxull)", type, (unsigned long long)(uintptr_t)p);
+  const int k = active_tables() ? active_tables()->index_of(p) : -1;
+  if (k >= 0) std::snprintf(b, sizeof b, "((const %s*)tabs.p[%d])", type, k);
+  else std::snprintf(b, sizeof b, "((const %s*)0x%llxull)", type, (unsigned long long)(uintptr_t)p);
   return b;
 }
-inline std::string plit(const void* p) {
-  char b[64];
-  std::snprintf(b, sizeof b, "((const float*)0x%llxull)", (unsigned long long)(uintptr_t)p);
-  return b;
-}
+inline std::string plit(const void* p) { return plit_as("float", p); }
 
 // Emits the walk of one site table as straight-line HIP, in exactly the interpreter's operation
 // order.  mode 0 = importance (particle index `i`, particle key `pkey`, input columns, score and
@@ -344,7 +373,7 @@ struct Gen {
 
   static const char* signature() {
     return "(KeySrc ks, RunCols cols, float* score, float* logw, uint64_t n, float* max_partials, int32_t* row_e, "
-           "uint64_t* row_s, LseTail tail, PassBatch bt, PlanParams prm) {\n";
+           "uint64_t* row_s, LseTail tail, PassBatch bt, PlanParams prm, PlanTables tabs) {\n";
   }
   const char* kname() const { return impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox"; }
 
@@ -539,7 +568,7 @@ struct GenScan {
     emit_prelude(o, fast_math);
     o << "struct StepObs { const float* obs; };\n";
     o << "extern \"C\" __global__ __launch_bounds__(256) void " << kname()
-      << "(KeySrc ks, RunCols cols, ScanArgs sa, float* score, float* logw, float* max_partials, int32_t* row_e, uint64_t* row_s, LseTail tail) {\n";
+      << "(KeySrc ks, RunCols cols, ScanArgs sa, float* score, float* logw, float* max_partials, int32_t* row_e, uint64_t* row_s, LseTail tail, PlanTables tabs) {\n";
     o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
     o << "  const uint64_t n = sa.n, rows_all = (n + 255) / 256;\n";
     o << "  for (uint64_t row = blockIdx.x; row < rows_all; row += gridDim.x) {\n";
@@ -643,7 +672,7 @@ struct GenSmc {
     SiteEmitter<CSiteT, CArgT> es{o, impl, 1, step_sites, n_step, "    "};
     SiteEmitter<CSiteT, CArgT> ei{o, impl, 1, init_sites, n_init, "        "};
     // ---- step policy
-    o << "struct GenPolicy {\n  static constexpr bool kEmit = true;\n  PlanPolicyArgs a;\n";
+    o << "struct GenPolicy {\n  static constexpr bool kEmit = true;\n  PlanPolicyArgs a;\n  PlanTables tabs;\n";
     o << "  struct Out { float s[" << D << "]; };\n";
     o << "  __device__ __forceinline__ void select_filter(uint64_t off, Key k) {\n";
     o << "    for (int c = 0; c < " << D << "; ++c) { a.prev_state[c] += off; a.state_out[c] += off; }\n";
@@ -659,16 +688,16 @@ struct GenSmc {
     o << "  __device__ __forceinline__ void store(int64_t j, int64_t out_lo, uint32_t src, const Out& out) const {\n";
     o << "    for (int k = 0; k < " << D << "; ++k) a.state_out[k][j - out_lo] = out.s[k];\n";
     o << "    if (a.anc_out) a.anc_out[j - out_lo] = (int32_t)src;\n  }\n};\n";
-    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_step_kernel(ResampleArgs A, PlanPolicyArgs PA) {\n";
-    o << "  GenPolicy P;\n  P.a = PA;\n  resample_body<" << I << ">(A, P);\n}\n";
+    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_step_kernel(ResampleArgs A, PlanPolicyArgs PA, PlanTables T) {\n";
+    o << "  GenPolicy P;\n  P.a = PA;\n  P.tabs = T;\n  resample_body<" << I << ">(A, P);\n}\n";
     // ---- init kernel: one workgroup per LOCAL tile, like k_lgssm_init
     if (impl == 1) {
       o << "struct GenInitOut { float s[" << D << "]; };\n";
-      o << "__device__ __forceinline__ void init_quad(const PlanPolicyArgs& a, int64_t jq, GenInitOut (&out)[4], float (&wq)[4]) {\n";
+      o << "__device__ __forceinline__ void init_quad(const PlanPolicyArgs& a, const PlanTables& tabs, int64_t jq, GenInitOut (&out)[4], float (&wq)[4]) {\n";
       emit_quad_body(init_sites, n_init, init_state, false);
       o << "}\n";
     }
-    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_init_kernel(PlanPolicyArgs a, uint64_t first_slot, uint64_t n_local, EmitOut em, FilterBatch fb) {\n";
+    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_init_kernel(PlanPolicyArgs a, uint64_t first_slot, uint64_t n_local, EmitOut em, FilterBatch fb, PlanTables tabs) {\n";
     o << "  uint64_t ltile = blockIdx.x;\n";
     o << "  if (fb.n_filters > 1) {  // several filters per launch: tile of filter f, its key, its outputs\n";
     o << "    const uint32_t f = (uint32_t)(ltile / fb.tiles);\n    ltile -= (uint64_t)f * fb.tiles;\n    a.step_key = fb.step_key[f];\n";
@@ -678,7 +707,7 @@ struct GenSmc {
     o << "  float wq[4];\n  bool okq[4];\n  for (int u = 0; u < 4; ++u) okq[u] = loc + u < n_local;\n";
     if (impl == 1) {  // four consecutive slots per lane, one cipher block per one-word draw of the quad
       o << "  {\n    const int64_t jq = (int64_t)gq;\n    GenInitOut out[4];\n";
-      o << "    init_quad(a, jq, out, wq);\n";
+      o << "    init_quad(a, tabs, jq, out, wq);\n";
       o << "    for (int u = 0; u < 4; ++u) {\n      if (okq[u]) {\n";
       for (int k = 0; k < n_state; ++k) o << "        a.state_out[" << k << "][loc + u] = out[u].s[" << k << "];\n";
       o << "        if (a.anc_out) a.anc_out[loc + u] = (int32_t)(gq + u);\n      }\n    }\n  }\n";
@@ -704,6 +733,7 @@ struct Compiled {
   int block = 256;  // threads per workgroup of the compiled kernel
   int rows_per_block = 1;  // 256-particle rows per workgroup
   std::string key;  // the source this slot holds a reference on (module cache)
+  gjx::PlanTables tabs;  // the device tables of THIS plan, in the order the source numbers them (kernel argument)
 };
 
 inline bool enabled() {
@@ -950,6 +980,7 @@ struct CompiledSmc {
   hipFunction_t step = nullptr, init = nullptr;
   int state = 0;  // 0 untried, 1 ready, -1 failed
   std::string key;
+  gjx::PlanTables tabs;  // the device tables of THIS plan (kernel argument of both kernels)
 };
 inline void release_smc(CompiledSmc* c) {
   ModuleCache::get().release(c->key);
