@@ -969,7 +969,7 @@ GJX_HD double comb_tile_scale(double scale, int d) { return d >= 64 ? 0.0 : scal
 // (k_lse_combine) into the same bits for any sharding.
 // ------------------------------------------------------------------------------------------------
 GJX_DEV void lse_emit(int32_t e, uint64_t bucket, int32_t* out_e, uint64_t* out_q, float* out_lse,
-                      uint64_t* out_record) {
+                      uint64_t* out_record, float* out_shifted = nullptr, float shift = 0.0f) {
   // called by the first wave: lane d holds bucket d
   const uint64_t q = wave_sum(bucket >> (threadIdx.x & 63));
   if (out_record) {
@@ -979,14 +979,15 @@ GJX_DEV void lse_emit(int32_t e, uint64_t bucket, int32_t* out_e, uint64_t* out_
   if (threadIdx.x == 0) {
     if (out_e) out_e[0] = e;
     if (out_q) out_q[0] = q;
-    if (out_lse) {
-      if (e == kRowEmpty || q == 0) {
-        out_lse[0] = -__builtin_inff();
-      } else {
+    if (out_lse || out_shifted) {
+      float lse = -__builtin_inff();
+      if (!(e == kRowEmpty || q == 0)) {
         const float t1 = (float)e * 0.69314718055994531f;
         const float t2 = m_log((float)q * u2f((uint32_t)(127 - kRowFrac) << 23));
-        out_lse[0] = t1 + t2;
+        lse = t1 + t2;
       }
+      if (out_lse) out_lse[0] = lse;
+      if (out_shifted) out_shifted[0] = lse - shift;
     }
   }
 }
@@ -1004,7 +1005,8 @@ GJX_DEV uint64_t lse_load_s(const uint64_t* p) {
 }
 template <bool DEVICE_SCOPE>
 GJX_DEV void lse_rows_block(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows,
-                            int32_t* out_e, uint64_t* out_q, float* out_lse, uint64_t* out_record) {
+                            int32_t* out_e, uint64_t* out_q, float* out_lse, uint64_t* out_record,
+                            float* out_shifted = nullptr, float shift = 0.0f) {
   __shared__ int32_t she[kBlock / kWave];
   const int nthr = (int)blockDim.x, nwave = nthr / kWave;  // 256 (k_lse_rows, generic tail) or 128 (paired kernel)
   __shared__ unsigned long long shb[kLseBuckets];
@@ -1060,7 +1062,7 @@ GJX_DEV void lse_rows_block(const int32_t* row_e, const uint64_t* row_s, uint64_
     if ((threadIdx.x & 63) == 0 && w) atomicAdd(&shb[k], (unsigned long long)w);
   }
   __syncthreads();
-  if (threadIdx.x < kLseBuckets) lse_emit(e, (uint64_t)shb[threadIdx.x], out_e, out_q, out_lse, out_record);
+  if (threadIdx.x < kLseBuckets) lse_emit(e, (uint64_t)shb[threadIdx.x], out_e, out_q, out_lse, out_record, out_shifted, shift);
 }
 
 // The log-marginal of a pass fused into the kernel that produces the log-weights (mirrors gjx_lse_out):
@@ -1080,6 +1082,8 @@ struct LseTail {
   float* lse;
   uint64_t* record;
   uint32_t* tickets;  // [(kLseTicketShards + 1) * kLseTicketStride], zero between launches; null = no fused tail
+  float* lse_shifted; // nullable: lse - shift
+  float shift;
 };
 GJX_DEV void lse_store_row(int32_t* row_e, uint64_t* row_s, uint64_t row, int32_t eb, uint64_t sb, bool device_scope) {
   if (device_scope) {  // read by the last workgroup of THIS launch: write-through
@@ -1112,7 +1116,7 @@ GJX_DEV void lse_tail(const int32_t* row_e, const uint64_t* row_s, uint64_t n_ro
   }
   __syncthreads();
   if (!sh_last) return;
-  lse_rows_block<true>(row_e, row_s, n_rows, t.e, t.q, t.lse, t.record);
+  lse_rows_block<true>(row_e, row_s, n_rows, t.e, t.q, t.lse, t.record, t.lse_shifted, t.shift);
   if (threadIdx.x <= kLseTicketShards)
     __hip_atomic_store(t.tickets + threadIdx.x * kLseTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -1804,8 +1804,8 @@ static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pa
     if (c.state != 1 && (!jit_fallback_allowed() || p->has_expr)) return GJX_ERR_JIT;  // loud: never a silent 7x slower route
     if (c.state == 1) {
       uint64_t nn = n;
-      LseTail tail{nullptr, nullptr, nullptr, nullptr, nullptr};
-      if (lse) tail = LseTail{lse->e, lse->q, lse->lse, lse->record, lse->tickets};
+      LseTail tail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f};
+      if (lse) tail = LseTail{lse->e, lse->q, lse->lse, lse->record, lse->tickets, lse->lse_shifted, lse->shift};
       PassBatch bt;
       memset(&bt, 0, sizeof bt);
       bt.n_pass = (uint32_t)n_pass;
@@ -2485,8 +2485,8 @@ int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
     sa.carry0_cols[d] = io->carry0_cols ? io->carry0_cols[d] : nullptr;
     sa.carry_out[d] = io->carry_out ? io->carry_out[d] : nullptr;
   }
-  LseTail tail{nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (io->lse) tail = LseTail{io->lse->e, io->lse->q, io->lse->lse, io->lse->record, io->lse->tickets};
+  LseTail tail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f};
+  if (io->lse) tail = LseTail{io->lse->e, io->lse->q, io->lse->lse, io->lse->record, io->lse->tickets, io->lse->lse_shifted, io->lse->shift};
   float* score = io->score; float* logw = io->logw; float* mp = io->max_partials;
   int32_t* row_e = io->row_e; uint64_t* row_s = io->row_s;
   PlanTables tabs = c.tabs;

@@ -69,7 +69,7 @@ class LseOut(C.Structure):
     """gjx_lse_out: where a fused importance launch leaves the pass's log-sum-exp."""
 
     _fields_ = [("e", C.c_void_p), ("q", C.c_void_p), ("lse", C.c_void_p), ("record", C.c_void_p),
-                ("tickets", C.c_void_p)]
+                ("tickets", C.c_void_p), ("lse_shifted", C.c_void_p), ("shift", C.c_float)]
 
 
 LSE_TICKET_WORDS = 17 * 64  # include/gjx.h: GJX_LSE_TICKET_WORDS

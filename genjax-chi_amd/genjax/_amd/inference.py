@@ -10,6 +10,7 @@ categorical draw of `sample_particle`, resampling and ancestor gathers are C-ABI
 from __future__ import annotations
 
 import math
+import threading
 
 import torch
 
@@ -368,6 +369,79 @@ class ImportanceK(SMCAlgorithm):
         trs, target_scores = self.target.importance(sub_keys, ChoiceMap.empty())
         return ParticleCollection(trs, target_scores, True, max_partials=getattr(trs, "max_partials", None),
                                   row_stats=getattr(trs, "row_stats", None))
+
+    # -- the literal call `ImportanceK(target, k_particles=K).log_marginal_likelihood_estimate(key)` (smc.py:145-156, the
+    # README's and tests/inference/test_smc.py's form) on a plan-able target without a proposal.  The general route builds
+    # the whole `ParticleCollection` first (trace objects per site, freshly allocated columns, plan and trace cache
+    # look-ups): ~85 us of host work around a 19 us kernel.  This route keeps, on the algorithm object, the traced body,
+    # its plan and ONE set of persistent buffers with pre-marshalled launches, and per call only derives the key, points
+    # the launch at it, enqueues the importance kernel and the fold of its row sums, and subtracts log K — the same
+    # kernels on the same keys, so the same bits.
+    def _fast_state(self):
+        from .lang import StaticGenerativeFunction
+        from .plan import _make_plan, _traced
+        from .runtime import fast_math_enabled
+
+        ops = get_ops()
+        st = self.__dict__.get("_fast")
+        if st is not None and st["ops"] is ops and st["fast_math"] == fast_math_enabled() and all(
+                t._version == v for t, v in st["tensors"]):
+            return st
+        self.__dict__["_fast"] = None
+        p_, n = self.target.p, self.get_num_particles()
+        if self.q is not None or not isinstance(p_, StaticGenerativeFunction) or n < 2:
+            return None
+        from .plan import _needs_eager
+
+        if any(_needs_eager(a) for a in self.target.args):
+            return None
+        merged = self.target.constraint.merge(ChoiceMap.empty())
+        traced = _traced(p_, merged, n, self.target.args)
+        if traced is None:
+            return None
+        tracer = traced[0]
+        plan = _make_plan(tracer)  # (sets the launch parameters: observations and scalar arguments of THIS target)
+        dtypes = [torch.float32] * tracer.n_out
+        for m in tracer.meta:
+            if m["out_col"] >= 0 and m["is_int"]:
+                dtypes[m["out_col"]] = torch.int32
+        tensors = [t for t in list(self.target.args) + [v for _, v in merged.leaves()] if isinstance(t, torch.Tensor)]
+        st = dict(ops=ops, fast_math=fast_math_enabled(), tensors=[(t, t._version) for t in tensors], plan=plan,
+                  tracer=tracer, params=list(tracer.params), log_k=math.log(n), preps={}, dtypes=dtypes, n=n)
+        self.__dict__["_fast"] = st
+        return st
+
+    def _fast_estimate(self, key):
+        from . import prng
+
+        if not isinstance(key, prng.PRNGKey):
+            return None
+        st = self._fast_state()
+        if st is None:
+            return None
+        # key, sub_key = split(key) [here]; key, sub_key = split(sub_key); sub_keys = split(sub_key, K) [run_smc]
+        k2 = prng.split_at(prng.split_at(key, 1), 1)
+        slot = (key.impl, threading.get_ident())  # (persistent buffers: one set per generator and host thread)
+        prep = st["preps"].get(slot)
+        if prep is None:
+            kb = prng.split_lazy(k2, st["n"])
+            prep = st["preps"][slot] = st["ops"].prepare_importance(st["plan"], kb, st["n"], st["tracer"].inputs, st["dtypes"])
+        ks = prep._keys
+        ks.parent[0], ks.parent[1], ks.parent_lane = k2.k0, k2.k1, k2.lane
+        if st["params"]:
+            st["plan"].set_params(st["params"])  # (another algorithm object may share the cached plan)
+        # ONE launch: the importance walk, the fold of its row sums by the workgroup that finishes last, and
+        # lse - log K (one f32 subtraction: what `lse[0] - math.log(K)` computes on the general route) into a fresh scalar
+        out = st["ops"].empty(1, torch.float32)
+        prep.launch_fused_shifted(out, st["log_k"])
+        return out[0]
+
+    def log_marginal_likelihood_estimate(self, key, target: Target | None = None):
+        if target is None:
+            fast = self._fast_estimate(key)
+            if fast is not None:
+                return fast
+        return super().log_marginal_likelihood_estimate(key, target)
 
     def log_marginal_likelihood_estimates(self, keys):
         """`vmap(self.log_marginal_likelihood_estimate)(keys)`: one independent estimate per key, as a

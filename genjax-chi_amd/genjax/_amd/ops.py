@@ -815,7 +815,7 @@ class PreparedImportance:
         # fused form: the importance launch folds its own row sums (results in .lse / .row_e_out / .row_q_out)
         self._tickets = torch.zeros(abi.LSE_TICKET_WORDS, dtype=torch.int32, device=ops.device())
         self._lse_out = abi.LseOut(self.row_e_out.data_ptr(), self.row_q_out.data_ptr(), self.lse.data_ptr(), None,
-                                   self._tickets.data_ptr())
+                                   self._tickets.data_ptr(), None, 0.0)
         self._lse_ref = C.byref(self._lse_out)
         self._lse_with_record: dict = {}
         self._args_lse_rows = (C.c_void_p(self.rows.e.data_ptr()), C.c_void_p(self.rows.s.data_ptr()), R,
@@ -862,10 +862,23 @@ class PreparedImportance:
             ent = self._lse_with_record.get(record.data_ptr())
             if ent is None:
                 out = abi.LseOut(self.row_e_out.data_ptr(), self.row_q_out.data_ptr(), self.lse.data_ptr(),
-                                 record.data_ptr(), self._tickets.data_ptr())
+                                 record.data_ptr(), self._tickets.data_ptr(), None, 0.0)
                 ent = self._lse_with_record[record.data_ptr()] = (out, C.byref(out), record)
             ref = ent[1]
         rc = self._run(*self._args_run[0], ref, stream if stream is not None else self.ops.stream())
+        if rc:
+            raise abi.GjxError("gjx_importance_run", rc)
+
+    def launch_fused_shifted(self, out: torch.Tensor, shift: float, stream=None):
+        """Walk + log-sum-exp in ONE launch, `out[0] = lse - shift` (f32): with shift = log K the log-marginal estimate
+        logsumexp(lw) - log K of inference/smc.py:96-97 lands in a tensor of the caller's, no further kernel."""
+        lo = self.__dict__.get("_lse_shifted")
+        if lo is None:
+            lo = self._lse_shifted = abi.LseOut(self.row_e_out.data_ptr(), self.row_q_out.data_ptr(), self.lse.data_ptr(), None,
+                                                self._tickets.data_ptr(), None, 0.0)
+            self._lse_shifted_ref = C.byref(lo)
+        lo.lse_shifted, lo.shift = out.data_ptr(), shift
+        rc = self._run(*self._args_run[0], self._lse_shifted_ref, stream if stream is not None else self.ops.stream())
         if rc:
             raise abi.GjxError("gjx_importance_run", rc)
 

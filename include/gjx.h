@@ -275,7 +275,7 @@ int gjx_jit_compile_source(const char* source);
  * rows, each nullable) is produced by the SAME launch: the workgroup that finishes last folds the row
  * pairs (replaces logsumexp(lw) at inference/smc.py:97 with zero extra launches).  tickets: dev
  * u32[GJX_LSE_TICKET_WORDS] owned by the caller, zero before the first use; every launch leaves it zero,
- * so launches sharing it must be stream-ordered. */
+ * so launches sharing it must be stream-ordered.  (r03: the struct grew by lse_shifted / shift: zero-initialise it.) */
 #define GJX_LSE_TICKET_WORDS (17 * 64) /* 17 counters, each on its own 256-byte line */
 typedef struct {
   int32_t* e;       /* dev int32[1] */
@@ -283,6 +283,9 @@ typedef struct {
   float* lse;       /* dev f32[1] */
   uint64_t* record; /* dev u64[GJX_LSE_RECORD_WORDS] */
   uint32_t* tickets;
+  float* lse_shifted; /* nullable dev f32[1]: lse - shift (ONE f32 subtraction), e.g. shift = log K gives the log-marginal
+                         estimate logsumexp(lw) - log K (inference/smc.py:96-97) out of the same launch */
+  float shift;
 } gjx_lse_out;
 int gjx_importance_run(const gjx_plan* p, const gjx_keys* particle_keys,
                        const float* const* input_cols, int n_input_cols, void* const* value_cols,

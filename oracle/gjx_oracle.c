@@ -582,7 +582,11 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
   if (row_e && row_s) {
     int rc = gjx_row_stats(logw, n, row_e, row_s, s);
     if (rc || !lse) return rc;
-    return gjx_lse_rows(row_e, row_s, gjx_num_max_partials(n), lse->e, lse->q, lse->lse, lse->record, s);
+    float l = 0.0f;
+    rc = gjx_lse_rows(row_e, row_s, gjx_num_max_partials(n), lse->e, lse->q, &l, lse->record, s);
+    if (lse->lse) *lse->lse = l;
+    if (lse->lse_shifted) *lse->lse_shifted = l - lse->shift;
+    return rc;
   }
   return GJX_OK;
 }
@@ -1559,8 +1563,11 @@ int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
   if (io->row_e && io->row_s) {
     int rc = gjx_row_stats(io->logw, n, io->row_e, io->row_s, s);
     if (rc || !io->lse) return rc;
-    return gjx_lse_rows(io->row_e, io->row_s, gjx_num_max_partials(n), io->lse->e, io->lse->q, io->lse->lse,
-                        io->lse->record, s);
+    float l = 0.0f;
+    rc = gjx_lse_rows(io->row_e, io->row_s, gjx_num_max_partials(n), io->lse->e, io->lse->q, &l, io->lse->record, s);
+    if (io->lse->lse) *io->lse->lse = l;
+    if (io->lse->lse_shifted) *io->lse->lse_shifted = l - io->lse->shift;
+    return rc;
   }
   return GJX_OK;
 }

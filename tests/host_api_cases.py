@@ -1616,7 +1616,67 @@ def case_index_request(impl):
         assert f(new_tr.get_choices()["a", keep]) == f(tr.get_choices()["a", keep])
 
 
-ALL_CASES = [case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
+def case_fast_estimate_path(impl):
+    """`ImportanceK(...).log_marginal_likelihood_estimate(key)` on a plan-able target keeps its traced body, plan and one
+    set of persistent buffers on the algorithm object (inference.py: _fast_estimate): the same kernels on the same keys as
+    the general route through `run_smc` — equal bit for bit, call after call, for several models and both generators; an
+    in-place change of a tensor argument is seen; targets that are not plan-able, proposals and `target=` take the
+    general route."""
+    import torch
+
+    from genjax._amd import inference as I
+
+    @gen
+    def gauss(mu0):
+        zs = []
+        for i in range(4):
+            z = normal(mu0, 1.0) @ f"z{i}"
+            _ = normal(z * 0.5 + 0.1, 0.5) @ f"y{i}"
+            zs.append(z)
+        return zs[0]
+
+    @gen
+    def mixed(a):
+        p = beta(2.0, a) @ "p"
+        v = flip(p) @ "v"
+        g = gamma(2.0, 1.5) @ "g"
+        _ = normal(p * 2.0 + g, 1.5) @ "x"
+
+    t1 = Target(gauss, (0.3,), C["y0"].set(0.2) | C["y1"].set(-0.4) | C["y2"].set(1.1) | C["y3"].set(0.0))
+    t2 = Target(mixed, (3.0,), C["x"].set(0.3) | C["v"].set(True))
+    for t, k in ((t1, 3000), (t2, 2500), (t1, 2)):
+        alg = ImportanceK(t, k_particles=k)
+        for rep in range(3):
+            key = genjax.random.key(50 + rep, impl)
+            a = alg.log_marginal_likelihood_estimate(key)
+            b = I.SMCAlgorithm.log_marginal_likelihood_estimate(alg, key)
+            assert torch.equal(a, b), (k, rep)
+            if rep == 0:
+                first = a.clone()
+        assert alg.__dict__.get("_fast") is not None
+        assert torch.equal(first, I.SMCAlgorithm.log_marginal_likelihood_estimate(alg, genjax.random.key(50, impl)))  # results are not views of the buffers
+    # a tensor argument changed in place is seen (the cached trace is keyed by its version)
+    mu = torch.tensor(0.3, device=first.device)
+    alg = ImportanceK(Target(gauss, (mu,), t1.constraint), k_particles=2000)
+    key = genjax.random.key(7, impl)
+    a0 = alg.log_marginal_likelihood_estimate(key)
+    mu.add_(1.5)
+    a1 = alg.log_marginal_likelihood_estimate(key)
+    assert not torch.equal(a0, a1) and torch.equal(a1, I.SMCAlgorithm.log_marginal_likelihood_estimate(alg, key))
+    # the general route: a proposal, another target
+    @gen
+    def prop(target):
+        for i in range(4):
+            _ = normal(0.0, 1.5) @ f"z{i}"
+
+    alg = ImportanceK(t1, q=prop.marginal() if hasattr(prop, "marginal") else None, k_particles=500)
+    z = alg.log_marginal_likelihood_estimate(genjax.random.key(9, impl))
+    assert alg.__dict__.get("_fast") is None and math.isfinite(f(z))
+    z = ImportanceK(t1, k_particles=500).log_marginal_likelihood_estimate(genjax.random.key(9, impl), t1)
+    assert math.isfinite(f(z))
+
+
+ALL_CASES = [case_fast_estimate_path, case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_uniform, case_fused_equals_eager, case_expression_arguments, case_params_equal_constants, case_trace_cache, case_particle_collection, case_custom_proposal,
              case_scan, case_scan_edge_cases, case_scan_fused_equals_loop, case_vmap, case_vmap_edge_cases, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
              case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update, case_regenerate_and_rejuvenate, case_vector_valued_sites, case_index_request]

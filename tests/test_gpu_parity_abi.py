@@ -313,6 +313,14 @@ def test_fused_lse_tail(hip_ops, oracle_ops, impl, n):
     assert int(prep._tickets.abs().sum().cpu()) == 0  # left zero for the next launch
     out = W.Gaussian10(oracle_ops, impl, seed=4, n_local=n).step()
     same(fused[0], out["row_lse"], "lse vs oracle"); same(fused[1], out["row_e"]); same(fused[2], out["row_q"])
+    # the shifted output of the same launch (gjx_lse_out.lse_shifted): lse - shift as ONE f32 subtraction
+    shifted = torch.empty(1, dtype=torch.float32, device=hip_ops.device())
+    prep.launch_fused_shifted(shifted, 2.5)
+    same(shifted, fused[0] - 2.5, "lse - shift"); same(prep.lse, fused[0], "lse beside the shifted output")
+    o_prep = W.Gaussian10(oracle_ops, impl, seed=4, n_local=n).prepare()
+    o_shift = torch.empty(1, dtype=torch.float32)
+    o_prep.launch_fused_shifted(o_shift, 2.5)
+    same(shifted, o_shift, "shifted lse vs oracle")
 
 
 @pytest.mark.parametrize("k", [3, 17, 256])
