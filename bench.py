@@ -636,8 +636,9 @@ def bench_host_api_call(args, calls=60):
     med = statistics.median(ts)
     return {"value": args.particles / med, "unit": "particles/s", "us_per_call": med * 1e6, "us_per_call_min": min(ts) * 1e6,
             "calls": calls, "rng": args.rng, "log_z_mean": statistics.fmean(zs), "log_z_exact": W.gaussian10_exact_log_z(y),
-            "note": "host-inclusive latency of ONE eager call (one pass per launch, ~19 us of kernel): Python tracing-cache "
-                    "lookup, key derivation, output allocation, launch, fold, device-to-host scalar"}
+            "note": "host-inclusive latency of ONE eager call = ONE launch (~18 us of kernel: the walk without value "
+                    "columns, its row sums folded by the last workgroup, lse - log K): key derivation on the host, output "
+                    "allocation, launch, device-to-host scalar"}
 
 
 def host_cores() -> int:

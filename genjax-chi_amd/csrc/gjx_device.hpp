@@ -1026,10 +1026,16 @@ GJX_DEV void lse_rows_block(const int32_t* row_e, const uint64_t* row_s, uint64_
     }
 #pragma unroll
     for (int k = 0; k < kPer; ++k) e = ev[k] > e ? ev[k] : e;
-  } else {
-    for (uint64_t b = threadIdx.x; b < n_rows; b += nthr) {
-      const int32_t eb = lse_load_e<DEVICE_SCOPE>(row_e + b);
-      e = eb > e ? eb : e;
+  } else {  // kPer independent loads in flight per lane and trip (a one-wave workgroup folding 4k rows one dependent load at
+            // a time, each a miss behind the acquire, was +34 us on a 21 us launch)
+    for (uint64_t base = 0; base < n_rows; base += (uint64_t)kPer * nthr) {
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const uint64_t b = base + threadIdx.x + (uint64_t)k * nthr;
+        ev[k] = b < n_rows ? lse_load_e<DEVICE_SCOPE>(row_e + b) : kRowEmpty;
+      }
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) e = ev[k] > e ? ev[k] : e;
     }
   }
 #pragma unroll
@@ -1053,8 +1059,16 @@ GJX_DEV void lse_rows_block(const int32_t* row_e, const uint64_t* row_s, uint64_
 #pragma unroll
     for (int k = 0; k < kPer; ++k) add_row(ev[k], sv[k]);
   } else {
-    for (uint64_t b = threadIdx.x; b < n_rows; b += nthr)
-      add_row(lse_load_e<DEVICE_SCOPE>(row_e + b), lse_load_s<DEVICE_SCOPE>(row_s + b));
+    for (uint64_t base = 0; base < n_rows; base += (uint64_t)kPer * nthr) {
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const uint64_t b = base + threadIdx.x + (uint64_t)k * nthr;
+        ev[k] = b < n_rows ? lse_load_e<DEVICE_SCOPE>(row_e + b) : kRowEmpty;
+        sv[k] = b < n_rows ? lse_load_s<DEVICE_SCOPE>(row_s + b) : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) add_row(ev[k], sv[k]);
+    }
   }
 #pragma unroll
   for (int k = 0; k < kNear; ++k) {
@@ -1094,12 +1108,15 @@ GJX_DEV void lse_store_row(int32_t* row_e, uint64_t* row_s, uint64_t row, int32_
     row_s[row] = sb;
   }
 }
-// Called by every thread of every workgroup once, after the workgroup's last lse_store_row (thread 0's).
+// Called by every thread of every workgroup once, after its last lse_store_row.
 GJX_DEV void lse_tail(const int32_t* row_e, const uint64_t* row_s, uint64_t n_rows, const LseTail& t) {
   if (!t.tickets) return;
   __shared__ uint32_t sh_last;
+  // every wave drains its own stores (a workgroup of several one-wave rows has a storing lane in each wave), then the
+  // workgroup's barrier, then ONE ticket
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t shard = blockIdx.x % kLseTicketShards;
     const uint32_t in_shard = (gridDim.x - shard + kLseTicketShards - 1) / kLseTicketShards;
     uint32_t last = 0;
@@ -1116,7 +1133,11 @@ GJX_DEV void lse_tail(const int32_t* row_e, const uint64_t* row_s, uint64_t n_ro
   }
   __syncthreads();
   if (!sh_last) return;
-  lse_rows_block<true>(row_e, row_s, n_rows, t.e, t.q, t.lse, t.record, t.lse_shifted, t.shift);
+  // every pair was written through (sc1) and drained before its writer's ticket: ONE agent-scope acquire (invalidates this
+  // CU's L1 and the XCD's non-local L2 lines) and the fold reads them with ordinary, pipelined loads — sixteen agent-scope
+  // atomic loads per lane, one after the other, were +34 us on the 21 us kernel
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  lse_rows_block<false>(row_e, row_s, n_rows, t.e, t.q, t.lse, t.record, t.lse_shifted, t.shift);
   if (threadIdx.x <= kLseTicketShards)
     __hip_atomic_store(t.tickets + threadIdx.x * kLseTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void k_importance(const CSite* __restrict__
 #pragma unroll
     for (int r = 0; r < kPPT; ++r) {
       if (idx[r] < n) {
-        logw[idx[r]] = w[r];
+        if (logw) logw[idx[r]] = w[r];
         if (score) score[idx[r]] = sc[r];
       }
       if ((max_partials || row_e) && (tile * kImpTile + (uint64_t)r * kBlock) < n) {  // per 256-particle row
@@ -1772,7 +1772,8 @@ static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pa
                              void* const* value_cols, int n_value_cols, float* score, float* logw, uint64_t n,
                              float* max_partials, int32_t* row_e, uint64_t* row_s, const gjx_lse_out* lse,
                              gjx_stream s) {
-  if (!p || !pk || !logw || n_input_cols < 0 || n_input_cols > 16 || n_value_cols < 0 ||
+  // logw may be null when the row sums are asked for: an estimate that needs only logsumexp(lw) writes no column at all
+  if (!p || !pk || (!logw && !row_e) || n_input_cols < 0 || n_input_cols > 16 || n_value_cols < 0 ||
       n_value_cols > GJX_MAX_SITES || ((row_e == nullptr) != (row_s == nullptr)) || (lse && (!row_e || !lse->tickets)))
     return GJX_ERR_INVALID;
   for (int32_t b = 0; b < n_pass; ++b)

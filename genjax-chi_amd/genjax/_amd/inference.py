@@ -18,7 +18,7 @@ from . import prng
 from .choicemap import ChoiceMap, Selection
 from .lang import Distribution, DistributionTrace, GenerativeFunction, ParticleKeys, Trace, split
 from .ops import KeyBatch
-from .runtime import get_ops
+from .runtime import fast_math_enabled, get_ops
 
 
 # =================================================================================================
@@ -346,6 +346,16 @@ class Importance(SMCAlgorithm):
         return ParticleCollection(_expand0(tr), _as_col(target_score - q_score), True)
 
 
+class _FastEstimate:
+    """What ImportanceK.log_marginal_likelihood_estimate keeps between calls (see _fast_state)."""
+
+    __slots__ = ("ops", "fast_math", "tensors", "plan", "tracer", "params", "log_k", "n", "preps")
+
+    def __init__(self, ops, fast_math, tensors, plan, tracer, params, log_k, n):
+        self.ops, self.fast_math, self.tensors, self.plan, self.tracer = ops, fast_math, tensors, plan, tracer
+        self.params, self.log_k, self.n, self.preps = params, log_k, n, {}
+
+
 class ImportanceK(SMCAlgorithm):
     """K-particle importance sampling (smc.py:282-351): `k_particles` keys, ONE batched run."""
 
@@ -378,21 +388,21 @@ class ImportanceK(SMCAlgorithm):
     # the launch at it, enqueues the importance kernel and the fold of its row sums, and subtracts log K — the same
     # kernels on the same keys, so the same bits.
     def _fast_state(self):
-        from .lang import StaticGenerativeFunction
-        from .plan import _make_plan, _traced
-        from .runtime import fast_math_enabled
-
         ops = get_ops()
         st = self.__dict__.get("_fast")
-        if st is not None and st["ops"] is ops and st["fast_math"] == fast_math_enabled() and all(
-                t._version == v for t, v in st["tensors"]):
-            return st
+        if st is not None and st.ops is ops and st.fast_math == fast_math_enabled():
+            for t, v in st.tensors:
+                if t._version != v:
+                    break
+            else:
+                return st
         self.__dict__["_fast"] = None
+        from .lang import StaticGenerativeFunction
+        from .plan import _make_plan, _needs_eager, _traced
+
         p_, n = self.target.p, self.get_num_particles()
         if self.q is not None or not isinstance(p_, StaticGenerativeFunction) or n < 2:
             return None
-        from .plan import _needs_eager
-
         if any(_needs_eager(a) for a in self.target.args):
             return None
         merged = self.target.constraint.merge(ChoiceMap.empty())
@@ -400,41 +410,41 @@ class ImportanceK(SMCAlgorithm):
         if traced is None:
             return None
         tracer = traced[0]
-        plan = _make_plan(tracer)  # (sets the launch parameters: observations and scalar arguments of THIS target)
-        dtypes = [torch.float32] * tracer.n_out
-        for m in tracer.meta:
-            if m["out_col"] >= 0 and m["is_int"]:
-                dtypes[m["out_col"]] = torch.int32
+        # the estimate needs logsumexp(lw) alone: the walk without value columns, score or log-weights — its kernel stores
+        # one (anchor, sum) pair per 256 particles and the fold of them; same draws, same weights, same fixed-point sums
+        plan = _make_plan(tracer, estimate_only=True)  # (sets the launch parameters: observations and scalar arguments)
         tensors = [t for t in list(self.target.args) + [v for _, v in merged.leaves()] if isinstance(t, torch.Tensor)]
-        st = dict(ops=ops, fast_math=fast_math_enabled(), tensors=[(t, t._version) for t in tensors], plan=plan,
-                  tracer=tracer, params=list(tracer.params), log_k=math.log(n), preps={}, dtypes=dtypes, n=n)
+        st = _FastEstimate(ops, fast_math_enabled(), tuple((t, t._version) for t in tensors), plan, tracer, list(tracer.params),
+                           math.log(n), n)
         self.__dict__["_fast"] = st
         return st
 
     def _fast_estimate(self, key):
-        from . import prng
-
-        if not isinstance(key, prng.PRNGKey):
+        if type(key) is not prng.PRNGKey:
             return None
         st = self._fast_state()
         if st is None:
             return None
         # key, sub_key = split(key) [here]; key, sub_key = split(sub_key); sub_keys = split(sub_key, K) [run_smc]
-        k2 = prng.split_at(prng.split_at(key, 1), 1)
-        slot = (key.impl, threading.get_ident())  # (persistent buffers: one set per generator and host thread)
-        prep = st["preps"].get(slot)
+        impl = key.impl
+        k0, k1, lane = prng.split_at_words(key.k0, key.k1, impl, key.lane, 1)
+        k0, k1, lane = prng.split_at_words(k0, k1, impl, lane, 1)
+        slot = (impl, threading.get_ident())  # (persistent buffers: one set per generator and host thread)
+        prep = st.preps.get(slot)
         if prep is None:
-            kb = prng.split_lazy(k2, st["n"])
-            prep = st["preps"][slot] = st["ops"].prepare_importance(st["plan"], kb, st["n"], st["tracer"].inputs, st["dtypes"])
+            kb = prng.split_lazy(prng.PRNGKey(k0, k1, impl, lane), st.n)
+            prep = st.preps[slot] = st.ops.prepare_importance(st.plan, kb, st.n, st.tracer.inputs, [], estimate_only=True)
         ks = prep._keys
-        ks.parent[0], ks.parent[1], ks.parent_lane = k2.k0, k2.k1, k2.lane
-        if st["params"]:
-            st["plan"].set_params(st["params"])  # (another algorithm object may share the cached plan)
+        ks.parent[0], ks.parent[1], ks.parent_lane = k0, k1, lane
+        plan = st.plan
+        if st.params and plan.params_owner is not st:  # (another algorithm object may share the cached plan)
+            plan.set_params(st.params)
+            plan.params_owner = st
         # ONE launch: the importance walk, the fold of its row sums by the workgroup that finishes last, and
         # lse - log K (one f32 subtraction: what `lse[0] - math.log(K)` computes on the general route) into a fresh scalar
-        out = st["ops"].empty(1, torch.float32)
-        prep.launch_fused_shifted(out, st["log_k"])
-        return out[0]
+        out = torch.empty((), dtype=torch.float32, device=st.ops._alloc_device)
+        prep.launch_fused_shifted(out, st.log_k)
+        return out
 
     def log_marginal_likelihood_estimate(self, key, target: Target | None = None):
         if target is None:

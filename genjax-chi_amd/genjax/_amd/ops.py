@@ -304,11 +304,12 @@ class Ops:
         return int(e.cpu()) * math.log(2.0) + math.log(qi) - 30 * math.log(2.0) - math.log(n_total)
 
     def prepare_importance(self, plan: "Plan", kb, n: int, input_cols: list[torch.Tensor],
-                           value_dtypes: list, with_lse: bool = True, fold_batch: int = 1) -> "PreparedImportance":
+                           value_dtypes: list, with_lse: bool = True, fold_batch: int = 1,
+                           estimate_only: bool = False) -> "PreparedImportance":
         """Pre-bind one importance pass (+ its log-sum-exp) to persistent output buffers: a launch
         is then two C calls with no allocation or marshalling on the host (what a latency-bound
         1e6-particle step needs; it is also what a HIP-graph capture of the step would replay)."""
-        return PreparedImportance(self, plan, kb, n, input_cols, value_dtypes, with_lse, fold_batch)
+        return PreparedImportance(self, plan, kb, n, input_cols, value_dtypes, with_lse, fold_batch, estimate_only)
 
     # ---- weights --------------------------------------------------------------------------------
     def max_f32(self, x: torch.Tensor | None, n: int, max_partials=None, out=None) -> torch.Tensor:
@@ -737,6 +738,7 @@ class RowStats:
 class Plan:
     def __init__(self, ops: Ops, handle, n_sites: int):
         self.ops, self.handle, self.n_sites = ops, handle, n_sites
+        self.params_owner = None
 
     def set_params(self, values) -> "Plan":
         """Values of the plan's GJX_ARG_PARAM references for the launches that follow (observations, model arguments:
@@ -745,6 +747,7 @@ class Plan:
 
         v = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
         self.ops.lib.call("gjx_plan_set_params", self.handle, C.c_void_p(v.ctypes.data) if v.size else None, int(v.size))
+        self.params_owner = None  # (whoever set them may claim them afterwards: see ImportanceK._fast_estimate)
         return self
 
     def __del__(self):
@@ -767,7 +770,8 @@ class PreparedImportance:
     is under two rounds of the machine, L passes keep it full.  Every pass of a launch has its own trace
     buffers (`values[c][p]`, `logw[p]`, `score[p]`); successive launches reuse them."""
 
-    def __init__(self, ops: Ops, plan: Plan, kb, n: int, input_cols, value_dtypes, with_lse=True, fold_batch: int = 1):
+    def __init__(self, ops: Ops, plan: Plan, kb, n: int, input_cols, value_dtypes, with_lse=True, fold_batch: int = 1,
+                 estimate_only: bool = False):
         kbs = list(kb) if isinstance(kb, (list, tuple)) else [kb]
         if any(k.fold is not None for k in kbs):
             raise ValueError("particle keys must not carry a fold")
@@ -778,11 +782,12 @@ class PreparedImportance:
         self.inputs = [t for t in input_cols]
         stride = self.pass_stride = -(-n // 256) * 256  # even, and every pass 1 KiB-aligned
         self.values_all = [ops.empty((L, stride), dt) for dt in value_dtypes]
-        self.score_all, self.logw_all = ops.empty((L, stride), torch.float32), ops.empty((L, stride), torch.float32)
+        cols_n = 0 if estimate_only else stride  # (an estimate-only pass writes no per-particle column)
+        self.score_all, self.logw_all = ops.empty((L, cols_n), torch.float32), ops.empty((L, cols_n), torch.float32)
         self.values = [v[0, :n] for v in self.values_all]  # pass 0 (the single-pass views)
         self.score, self.logw = self.score_all[0, :n], self.logw_all[0, :n]
         R = self.n_rows = ops.num_max_partials(n)
-        self.max_partials_all = ops.empty((L, R), torch.float32)
+        self.max_partials_all = ops.empty((L, R if not estimate_only else 0), torch.float32)
         self.max_partials = self.max_partials_all[0]
         self.row_e_all, self.row_s_all = ops.empty((fold_batch, R), torch.int32), ops.empty((fold_batch, R), torch.int64)
         self.rows = RowStats(self.row_e_all[0], self.row_s_all[0], n)  # slot 0
@@ -804,6 +809,10 @@ class PreparedImportance:
         head = (plan.handle, C.byref(self._keys), self._ins, len(self.inputs), self._outs, len(self.values_all),
                 C.c_void_p(self.score_all.data_ptr()), C.c_void_p(self.logw_all.data_ptr()), n,
                 C.c_void_p(self.max_partials_all.data_ptr()))
+        if estimate_only:  # only the row sums leave the kernel (a plan without value columns): no score / logw / maxima
+            if value_dtypes:
+                raise ValueError("an estimate-only pass has no value columns")
+            head = head[:6] + (None, None, n, None)
         self._args_run = [head + (C.c_void_p(self.row_e_all[b].data_ptr()), C.c_void_p(self.row_s_all[b].data_ptr()))
                           for b in range(fold_batch)]
         self._batch_head = (plan.handle, self._keys_arr)

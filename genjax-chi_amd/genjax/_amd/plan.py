@@ -496,10 +496,11 @@ _PLANS = threading.local()  # per thread: a plan's parameters are set-then-run, 
 _PLAN_CACHE_MAX = 32
 
 
-def _make_plan(tracer):
+def _make_plan(tracer, estimate_only: bool = False):
     """The plan of a traced body.  Plans are cached by their site table (the model's STRUCTURE — observations and scalar
     arguments are parameters, set per call): a repeated call skips plan creation and, in the library, regenerating and
-    looking up the specialised kernel's source."""
+    looking up the specialised kernel's source.  `estimate_only`: the same walk with no value column (every site's
+    out_col = -1) — what an estimate of the log-marginal alone needs: its kernel stores row sums and nothing else."""
     import ctypes as C
     from collections import OrderedDict
 
@@ -509,10 +510,17 @@ def _make_plan(tracer):
     cache = getattr(_PLANS, "cache", None)
     if cache is None:
         cache = _PLANS.cache = OrderedDict()
-    raw = getattr(tracer, "_table_key", None)  # (a tracer that the trace cache hands back has been keyed before)
+    key_attr = "_table_key_est" if estimate_only else "_table_key"
+    raw = getattr(tracer, key_attr, None)  # (a tracer that the trace cache hands back has been keyed before)
     arr = None
+    sites = tracer.sites
+    if estimate_only:
+        sites = (abi.Site * len(tracer.sites))(*tracer.sites)  # (array construction copies the structures)
+        for st in sites:
+            st.out_col = -1
+        sites = list(sites)
     if raw is None:
-        arr = (abi.Site * len(tracer.sites))(*tracer.sites)
+        arr = (abi.Site * len(sites))(*sites)
         raw = bytes(memoryview(arr))
     if arr is not None and tracer.expr_progs:  # programs enter the key by content: their addresses differ from trace to trace
         tmp = (abi.Site * len(tracer.sites)).from_buffer_copy(raw)
@@ -523,7 +531,7 @@ def _make_plan(tracer):
                     progs.append((q, k, tracer.expr_progs[tmp[q].arg[k].table]))
                     tmp[q].arg[k].table = None
         raw = bytes(memoryview(tmp)) + repr(progs).encode()
-    tracer._table_key = raw
+    setattr(tracer, key_attr, raw)
     # Tables the site table points into (categorical logits, transition rows) enter the key by identity AND version: the
     # library derives per-plan tables from them at the plan's first compilation (CDFs, guides, log-probabilities), so an
     # in-place update of such a tensor (an EM / optimiser step) must not find the plan built from its old contents.
@@ -534,7 +542,7 @@ def _make_plan(tracer):
         cache.move_to_end(key)
         plan = hit[0]
     else:
-        plan = ops.plan_create(tracer.sites, fast_math=fast)
+        plan = ops.plan_create(sites, fast_math=fast)
         cache[key] = (plan, tracer.keep)  # (the tables the site table points into stay alive with the plan)
         while len(cache) > _PLAN_CACHE_MAX:
             cache.popitem(last=False)

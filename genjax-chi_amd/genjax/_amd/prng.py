@@ -104,6 +104,17 @@ def _philox_lane(k: PRNGKey, b: int, a_tag: int):
     return philox4x32(k.k0, k.k1, k.lane & M32, (k.lane >> 32) & M32, b & M32, a_tag & M32)
 
 
+def split_at_words(k0: int, k1: int, impl: int, lane: int, i: int):
+    """split_at on bare words: (k0, k1, lane) of split(key)[i] (what split_at wraps in a PRNGKey)."""
+    if impl == THREEFRY:
+        o0, o1 = threefry2x32(k0, k1, (i >> 32) & M32, i & M32)
+        return o0, o1, 0
+    if lane == 0:
+        return k0, k1, i + 1
+    o0, o1, _, _ = philox4x32(k0, k1, lane & M32, (lane >> 32) & M32, i & M32, (((i >> 32) << 8) | TAG_SPLIT) & M32)
+    return o0, o1, 0
+
+
 def split_at(k: PRNGKey, i: int) -> PRNGKey:
     if k.impl == THREEFRY:
         o0, o1 = threefry2x32(k.k0, k.k1, (i >> 32) & M32, i & M32)

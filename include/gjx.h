@@ -267,7 +267,8 @@ int gjx_jit_compile_source(const char* source);
 /* particle_keys: the per-particle keys BEFORE the per-site fold (has_fold must be 0).
  * input_cols / value_cols: host arrays of dev pointers (each column dev [n], 4-byte elements:
  * f32, or int32 for Bernoulli/Categorical values; at most 16 input columns).  score, logw: dev
- * f32[n] (score nullable).  max_partials: nullable dev f32[gjx_num_max_partials(n)]; when given, the
+ * f32[n] (score nullable; logw nullable when row_e / row_s are given: an estimate that needs only logsumexp(lw) — a plan
+ * whose sites all have out_col = -1, score and logw null — writes no per-particle column at all).  max_partials: nullable dev f32[gjx_num_max_partials(n)]; when given, the
  * kernel also stores the maxima of logw per 256-particle row so the following log-sum-exp skips
  * its max pass.  row_e / row_s: nullable (both or neither) row-anchored partial sums, see
  * gjx_lse_rows: with them the log-marginal needs one further tiny kernel and no pass over logw.

@@ -538,8 +538,17 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
                        float* logw, uint64_t n, float* max_partials, int32_t* row_e, uint64_t* row_s,
                        const gjx_lse_out* lse, gjx_stream s) {
   (void)s;
-  if (!p || !keys_ok(pk) || pk->has_fold || !logw || (lse && (!row_e || !row_s || !lse->tickets)))
+  if (!p || !keys_ok(pk) || pk->has_fold || (!logw && !row_e) || ((row_e == NULL) != (row_s == NULL)) ||
+      (lse && (!row_e || !row_s || !lse->tickets)))
     return GJX_ERR_INVALID;
+  if (!logw) { /* only the row sums are asked for: the weights live in a scratch column */
+    float* tmp = (float*)malloc(sizeof(float) * (n ? n : 1));
+    if (!tmp) return GJX_ERR_LAUNCH;
+    int rc = gjx_importance_run(p, pk, input_cols, n_input_cols, value_cols, n_value_cols, score, tmp, n, max_partials, row_e,
+                                row_s, lse, s);
+    free(tmp);
+    return rc;
+  }
   for (int q = 0; q < p->n_sites; ++q) {
     const gjx_site* st = &p->sites[q];
     if (st->out_col >= n_value_cols) return GJX_ERR_INVALID;

@@ -1644,7 +1644,7 @@ def case_fast_estimate_path(impl):
 
     t1 = Target(gauss, (0.3,), C["y0"].set(0.2) | C["y1"].set(-0.4) | C["y2"].set(1.1) | C["y3"].set(0.0))
     t2 = Target(mixed, (3.0,), C["x"].set(0.3) | C["v"].set(True))
-    for t, k in ((t1, 3000), (t2, 2500), (t1, 2)):
+    for t, k in ((t1, 3000), (t2, 2500), (t1, 2), (t1, 66_000)):  # (66_000: 258 rows, a fold over several workgroups)
         alg = ImportanceK(t, k_particles=k)
         for rep in range(3):
             key = genjax.random.key(50 + rep, impl)
