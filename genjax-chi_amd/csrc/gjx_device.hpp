@@ -409,6 +409,17 @@ GJX_HD float m_exp(float x) {
   return u2f(f2u(y) + ((uint32_t)n << 23));
 }
 
+// exp as a model body writes it (GJX_EXPR_EXP, gjx_map_f32): m_exp over its whole domain — NaN stays NaN, the top of the
+// range (m_exp clamps at 88, flushes below -86) goes through exp(x / 2)^2: +inf / subnormals / 0 where exp has them.
+GJX_HD float e_exp(float x) {
+  if (x != x) return x;
+  if (x > 88.0f || x < -86.0f) {  // (below -86 m_exp flushes to 0: the square reaches the subnormals and then 0 as exp does)
+    const float h = m_exp(x * 0.5f);
+    return h * h;
+  }
+  return m_exp(x);
+}
+
 // --- opt-in FAST math for importance plans (gjx.h: GJX_PLAN_FAST_MATH).  The north star asks for log-weights within
 // 1e-5 relative of the reference on a path WITHOUT resampling, so an importance plan may trade the bit-exact
 // polynomials for the hardware transcendentals (v_log_f32 / v_exp_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32: ~1 ulp,

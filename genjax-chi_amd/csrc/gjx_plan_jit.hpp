@@ -130,6 +130,8 @@ struct SiteEmitter {
             case GJX_EXPR_STATE: st.push_back("st_" + r + sfx); break;
             case GJX_EXPR_OBS: st.push_back("a.obs[" + r + "]"); break;
             case GJX_EXPR_NEG: st.back() = "(-" + st.back() + ")"; break;
+            case GJX_EXPR_EXP: st.back() = "e_exp(" + st.back() + ")"; break;
+            case GJX_EXPR_LOG: st.back() = "m_log(" + st.back() + ")"; break;
             default: {
               const std::string b = st.back();
               st.pop_back();
@@ -197,6 +199,8 @@ struct SiteEmitter {
             if (ops[k].op >= GJX_EXPR_SITE && ops[k].op <= GJX_EXPR_OBS) return arg(a);  // (not a constant)
             if (ops[k].op == GJX_EXPR_CONST) { stk[d++] = ops[k].value; continue; }
             if (ops[k].op == GJX_EXPR_NEG) { stk[d - 1] = -stk[d - 1]; continue; }
+            if (ops[k].op == GJX_EXPR_EXP) { stk[d - 1] = gjx::e_exp(stk[d - 1]); continue; }
+            if (ops[k].op == GJX_EXPR_LOG) { stk[d - 1] = gjx::m_log(stk[d - 1]); continue; }
             const float y = stk[--d], x = stk[d - 1];
             stk[d - 1] = ops[k].op == GJX_EXPR_ADD ? x + y : (ops[k].op == GJX_EXPR_SUB ? x - y : (ops[k].op == GJX_EXPR_MUL ? x * y : x / y));
           }

@@ -37,7 +37,10 @@ LSE_RECORD_WORDS = 65  # include/gjx.h: GJX_LSE_RECORD_WORDS
 DIST_NORMAL, DIST_GAMMA, DIST_BETA, DIST_BERNOULLI, DIST_CATEGORICAL = range(5)
 ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE, ARG_STATE, ARG_OBS, ARG_PARAM, ARG_EXPR = range(8)
 # postfix programs as distribution arguments (gjx.h: GJX_ARG_EXPR / gjx_expr_op)
-EXPR_CONST, EXPR_SITE, EXPR_INPUT, EXPR_PARAM, EXPR_STATE, EXPR_OBS, EXPR_ADD, EXPR_SUB, EXPR_MUL, EXPR_NEG, EXPR_DIV = range(11)
+(EXPR_CONST, EXPR_SITE, EXPR_INPUT, EXPR_PARAM, EXPR_STATE, EXPR_OBS, EXPR_ADD, EXPR_SUB, EXPR_MUL, EXPR_NEG, EXPR_DIV, EXPR_EXP,
+ EXPR_LOG) = range(13)
+EXPR_UNARY = (EXPR_NEG, EXPR_EXP, EXPR_LOG)
+MAP_EXP, MAP_LOG, MAP_DIV, MAP_RDIV = range(4)
 MAX_EXPR_OPS, MAX_EXPR_DEPTH = 16, 8
 MAX_PARAMS = 64
 SMC_MAX_STATE, SMC_MAX_OBS = 4, 8
@@ -267,6 +270,7 @@ PROTOTYPES = {
         C.c_int,
         [_KP, _P, C.c_uint64, C.c_uint32, _P, C.c_int, _P, _P, C.c_uint64, _P],
     ),
+    "gjx_map_f32": (C.c_int, [C.c_int, _P, C.c_float, _P, C.c_uint64, _P]),
     "gjx_logpdf_normal": (C.c_int, [F32, F32, F32, _P, C.c_uint64, _P]),
     "gjx_logpdf_gamma": (C.c_int, [F32, F32, F32, _P, C.c_uint64, _P]),
     "gjx_logpdf_beta": (C.c_int, [F32, F32, F32, _P, C.c_uint64, _P]),

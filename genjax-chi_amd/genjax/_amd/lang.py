@@ -23,7 +23,7 @@ from typing import Any, Callable
 
 import torch
 
-from . import prng
+from . import abi, prng
 from .choicemap import ChoiceMap, Mask, Selection
 from .ops import KeyBatch
 from .runtime import get_ops
@@ -473,6 +473,95 @@ def _stack() -> list:
     return _tls.stack
 
 
+class SpecTensor(torch.Tensor):
+    """A site value on the per-site (column) path.  A model body may put `exp`, `log` or a division by a number between
+    its sites (the reference's bodies use `jnp` freely, e.g. tests/inference/test_smc.py:63); inside a fused plan those are
+    GJX_EXPR_EXP / _LOG / _DIV — the spec's f32 functions and an IEEE division.  torch's own kernels compute other bits
+    (`x / c` multiplies by a reciprocal, `exp` / `log` are the device library's), so on this path the same three
+    operations go through `gjx_map_f32`: a body gives the same trace whichever route runs it.  Everything else is
+    torch's, and results stay `SpecTensor`s."""
+
+    @staticmethod
+    def __new__(cls, x):
+        return x.as_subclass(cls)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        h = _SPEC_FUNCS.get(func)
+        if h is not None:
+            r = h(*args, **(kwargs or {}))
+            if r is not NotImplemented:
+                return r
+        return super().__torch_function__(func, types, args, kwargs or {})
+
+
+def _spec_plain(x):
+    return x.as_subclass(torch.Tensor) if isinstance(x, SpecTensor) else x
+
+
+def _spec_unary(op):
+    def f(x, *a, **k):
+        if a or k or not isinstance(x, torch.Tensor):
+            return NotImplemented
+        return get_ops().map_f32(op, _spec_plain(x)).as_subclass(SpecTensor)
+
+    return f
+
+
+def _spec_scalar(c):
+    if isinstance(c, (bool, int, float)):
+        return float(c)
+    if isinstance(c, torch.Tensor) and c.dim() == 0 and not isinstance(c, SpecTensor):
+        return float(c)
+    return None
+
+
+def _spec_div(a, b, *extra, rounding_mode=None, **k):
+    if extra or k or rounding_mode is not None:
+        return NotImplemented
+    cb, ca = _spec_scalar(b), _spec_scalar(a)
+    if cb is not None and isinstance(a, torch.Tensor):  # tensor / number: an IEEE division, not a reciprocal multiply
+        return get_ops().map_f32(abi.MAP_DIV, _spec_plain(a), cb).as_subclass(SpecTensor)
+    if ca is not None and isinstance(b, torch.Tensor):
+        return get_ops().map_f32(abi.MAP_RDIV, _spec_plain(b), ca).as_subclass(SpecTensor)
+    return NotImplemented  # (tensor / tensor is a true division on every backend)
+
+
+def _spec_rdiv(b, a):
+    return _spec_div(a, b)
+
+
+_SPEC_FUNCS = {
+    torch.exp: _spec_unary(abi.MAP_EXP), torch.Tensor.exp: _spec_unary(abi.MAP_EXP),
+    torch.log: _spec_unary(abi.MAP_LOG), torch.Tensor.log: _spec_unary(abi.MAP_LOG),
+    torch.div: _spec_div, torch.true_divide: _spec_div, torch.Tensor.div: _spec_div, torch.Tensor.true_divide: _spec_div,
+    torch.Tensor.__truediv__: _spec_div, torch.Tensor.__rtruediv__: _spec_rdiv,
+}
+
+
+def _spec_wrap(v):
+    """Site values handed to a model body on the per-site path (see SpecTensor); containers of them (a callee's retval)."""
+    if isinstance(v, torch.Tensor):
+        return v if isinstance(v, SpecTensor) or v.is_complex() else v.as_subclass(SpecTensor)
+    if isinstance(v, tuple):
+        return tuple(_spec_wrap(x) for x in v)
+    if isinstance(v, list):
+        return [_spec_wrap(x) for x in v]
+    return v
+
+
+def _spec_unwrap(v):
+    if isinstance(v, SpecTensor):
+        return v.as_subclass(torch.Tensor)
+    if isinstance(v, tuple):
+        return tuple(_spec_unwrap(x) for x in v)
+    if isinstance(v, list):
+        return [_spec_unwrap(x) for x in v]
+    if isinstance(v, dict):
+        return {k: _spec_unwrap(x) for k, x in v.items()}
+    return v
+
+
 def trace(addr, gen_fn: GenerativeFunction, args: tuple):
     st = _stack()
     if not st:
@@ -481,7 +570,7 @@ def trace(addr, gen_fn: GenerativeFunction, args: tuple):
     for seg in addr:
         if not isinstance(seg, (str, int)):
             raise TypeError(f"static addresses must be strings (or ints), got {seg!r}")
-    return st[-1].handle_trace(addr if len(addr) > 1 else addr[0], gen_fn, args)
+    return _spec_wrap(st[-1].handle_trace(addr if len(addr) > 1 else addr[0], gen_fn, args))
 
 
 class _Handler:
@@ -497,7 +586,8 @@ class _Handler:
         st = _stack()
         st.append(self)
         try:
-            return source(*args)
+            # (tensor arguments — a scan's carry — enter as site values do: SpecTensor; what the body returns leaves plain)
+            return _spec_unwrap(source(*_spec_wrap(tuple(args))))
         finally:
             st.pop()
 

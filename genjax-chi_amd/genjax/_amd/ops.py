@@ -184,6 +184,19 @@ class Ops:
             raise ValueError(dist)
         return score
 
+    def map_f32(self, op: int, x: torch.Tensor, c: float = 0.0) -> torch.Tensor:
+        """gjx_map_f32 over a tensor of any shape: the spec's exp / log, x / c, c / x (abi.MAP_*) — the bits the same
+        operation computes inside a fused plan (GJX_EXPR_EXP / _LOG / _DIV)."""
+        x = x.to(torch.float32)
+        if x.device.type != self.device_type:
+            x = x.to(self.device())
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        n = x.numel()
+        if n:
+            self.lib.call("gjx_map_f32", int(op), C.c_void_p(x.data_ptr()), float(c), C.c_void_p(out.data_ptr()), n, self.stream())
+        return out
+
     def logpdf_categorical(self, n: int, value, logits: torch.Tensor, row_index=None) -> torch.Tensor:
         n_rows, n_cat = logits.shape
         if row_index is None and n_rows not in (1, n):

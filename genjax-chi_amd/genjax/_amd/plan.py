@@ -28,7 +28,7 @@ import torch
 
 from . import abi
 from .choicemap import ChoiceMap
-from .lang import (Distribution, ParticleKeys, StaticTrace, ValueTrace, _Handler, normal, gamma, beta, flip,
+from .lang import (_spec_wrap, Distribution, ParticleKeys, StaticTrace, ValueTrace, _Handler, normal, gamma, beta, flip,
                    bernoulli, categorical, Categorical)
 from .runtime import get_ops
 
@@ -100,17 +100,27 @@ class Sym:
     def _no(self, *a, **k):
         raise PlanUnsupported("unsupported operation on a traced site value")
 
-    def __truediv__(self, c):  # (x / c is NOT x * (1 / c): a true division, as torch computes it)
+    def __truediv__(self, c):  # (x / c is NOT x * (1 / c): an IEEE division — lang.SpecTensor does the same per site)
         return SymExpr.binop(abi.EXPR_DIV, self, c)
 
     def __rtruediv__(self, c):
         return SymExpr.binop(abi.EXPR_DIV, c, self)
+
+    def exp(self):
+        return SymExpr.unop(abi.EXPR_EXP, self)
+
+    def log(self):
+        return SymExpr.unop(abi.EXPR_LOG, self)
 
     __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
     __lt__ = __le__ = __gt__ = __ge__ = __abs__ = __index__ = __array__ = __len__ = __iter__ = _no
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if func in _UNARY_FUNCS and len(args) == 1 and not kwargs:
+            return SymExpr.unop(_UNARY_FUNCS[func], args[0])
+        if func in _DIV_FUNCS and len(args) == 2 and not kwargs:
+            return SymExpr.binop(abi.EXPR_DIV, args[0], args[1])
         # `table[sym]`: a constant tensor indexed by a traced integer-valued value — a 1-D table gives a distribution
         # argument (`means[idx]`), a 2-D one the logits / probs ROW of a categorical site (`trans[z]`)
         if func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[0], torch.Tensor) \
@@ -145,7 +155,7 @@ class SymExpr:
             raise PlanUnsupported("expression too long for a plan argument")
         depth = deepest = 0
         for op, _, _ in prog:
-            depth += 1 if op <= abi.EXPR_OBS else (-1 if op != abi.EXPR_NEG else 0)
+            depth += 1 if op <= abi.EXPR_OBS else (0 if op in abi.EXPR_UNARY else -1)
             deepest = max(deepest, depth)
         if deepest > abi.MAX_EXPR_DEPTH:
             raise PlanUnsupported("expression too deep for a plan argument")
@@ -179,11 +189,8 @@ class SymExpr:
 
     @classmethod
     def binop(cls, op, a, b):
-        if op == abi.EXPR_DIV and not (isinstance(a, (Sym, SymExpr)) and isinstance(b, (Sym, SymExpr))):
-            # torch divides a device tensor by a NUMBER as a multiplication by the number's reciprocal, and a number by a
-            # tensor through a reciprocal kernel: neither is the IEEE division the program's `/` is.  Only a quotient of two
-            # traced values (tensor / tensor: a true division on every backend) lowers; the rest takes the per-site path.
-            raise PlanUnsupported("division by / of a constant")
+        # (`/` is an IEEE division whatever its operands: torch divides a device tensor by a NUMBER as a multiplication by
+        # the number's reciprocal, so the per-site path routes that case through gjx_map_f32 — lang.SpecTensor)
         tr = next((v.tracer for v in (a, b) if isinstance(v, (Sym, SymExpr))), None)
         _, pa = cls.program_of(a, tr)
         _, pb = cls.program_of(b, tr)
@@ -203,6 +210,8 @@ class SymExpr:
     def __neg__(self): return SymExpr.unop(abi.EXPR_NEG, self)  # noqa: E704
     def __truediv__(self, o): return SymExpr.binop(abi.EXPR_DIV, self, o)  # noqa: E704
     def __rtruediv__(self, o): return SymExpr.binop(abi.EXPR_DIV, o, self)  # noqa: E704
+    def exp(self): return SymExpr.unop(abi.EXPR_EXP, self)  # noqa: E704
+    def log(self): return SymExpr.unop(abi.EXPR_LOG, self)  # noqa: E704
 
     def _no(self, *a, **k):
         raise PlanUnsupported("unsupported operation on a traced expression")
@@ -212,6 +221,10 @@ class SymExpr:
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if func in _UNARY_FUNCS and len(args) == 1 and not kwargs:
+            return SymExpr.unop(_UNARY_FUNCS[func], args[0])
+        if func in _DIV_FUNCS and len(args) == 2 and not kwargs:
+            return SymExpr.binop(abi.EXPR_DIV, args[0], args[1])
         raise PlanUnsupported(f"torch.{getattr(func, '__name__', func)} on a traced expression")
 
     def evaluate(self, leaf):
@@ -226,13 +239,25 @@ class SymExpr:
                 st.append(v)
             elif op == abi.EXPR_NEG:
                 st[-1] = -st[-1]
+            elif op in (abi.EXPR_EXP, abi.EXPR_LOG):
+                st[-1] = get_ops().map_f32(abi.MAP_EXP if op == abi.EXPR_EXP else abi.MAP_LOG, st[-1])
             else:
                 b = st.pop()
                 a = st.pop()
+                if op == abi.EXPR_DIV and (a.dim() == 0 or b.dim() == 0):  # a NUMBER on either side: the IEEE division
+                    if b.dim() == 0:
+                        st.append(get_ops().map_f32(abi.MAP_DIV, a, float(b)))
+                    else:
+                        st.append(get_ops().map_f32(abi.MAP_RDIV, b, float(a)))
+                    continue
                 if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.device != b.device:
                     a, b = (a.to(b.device), b) if a.dim() == 0 else (a, b.to(a.device))
                 st.append(a + b if op == abi.EXPR_ADD else (a - b if op == abi.EXPR_SUB else (a * b if op == abi.EXPR_MUL else a / b)))
         return st[0]
+
+
+_UNARY_FUNCS = {torch.exp: abi.EXPR_EXP, torch.Tensor.exp: abi.EXPR_EXP, torch.log: abi.EXPR_LOG, torch.Tensor.log: abi.EXPR_LOG}
+_DIV_FUNCS = (torch.div, torch.true_divide, torch.Tensor.div, torch.Tensor.true_divide)
 
 
 class ParamVal:
@@ -245,7 +270,8 @@ class ParamVal:
     __slots__ = ("value", "slot")
 
     def __init__(self, value):
-        self.value, self.slot = value, None
+        # (a tensor does its host arithmetic as a site value does on the per-site path: lang.SpecTensor)
+        self.value, self.slot = _spec_wrap(value), None
 
     @staticmethod
     def _v(x):

@@ -247,6 +247,16 @@ static inline float o_exp(float x) {
   return o_u2f(o_f2u(y) + ((uint32_t)n << 23));
 }
 
+/* exp as a model body writes it (GJX_EXPR_EXP, gjx_map_f32) */
+static inline float o_e_exp(float x) {
+  if (x != x) return x;
+  if (x > 88.0f || x < -86.0f) {
+    const float h = o_exp(x * 0.5f);
+    return h * h;
+  }
+  return o_exp(x);
+}
+
 static inline float o_erfinv(float x) {
   float w = -o_log((1.0f - x) * (1.0f + x));
   float p;

@@ -27,6 +27,12 @@ def _expr(rng, reals, params, depth=0):
         return repr(round(float(rng.uniform(-2, 2)), 3))
     if r < 0.4:
         return f"(-{_expr(rng, reals, params, depth + 1)})"
+    if r < 0.52:  # what reference bodies write between sites: exp / log of a traced value, a division by (of) a number
+        x = str(rng.choice(reals))
+        lit = round(float(rng.uniform(0.3, 3.0)), 3)
+        return str(rng.choice([f"torch.exp({x} * {round(float(rng.uniform(-0.5, 0.5)), 3)})", f"torch.log({x} * {x} + {lit})",
+                               f"({x} * {x} + {lit}).log()", f"({_expr(rng, reals, params, depth + 1)} / {lit})",
+                               f"({lit} / ({x} * {x} + {lit}))", f"torch.div({x}, {lit})"]))
     op = rng.choice(["+", "-", "*", "*", "+"])
     return f"({_expr(rng, reals, params, depth + 1)} {op} {_expr(rng, reals, params, depth + 1)})"
 
@@ -102,7 +108,7 @@ def run(seconds: float, seed: int, impl: int = 1, n: int = 1500):
     t_end, compared, skipped = time.time() + seconds, 0, 0
     while time.time() < t_end:
         src, sites = random_model(rng)
-        ns = {"normal": normal, "gamma": gamma, "beta": beta, "flip": flip}
+        ns = {"normal": normal, "gamma": gamma, "beta": beta, "flip": flip, "torch": torch}
         exec(src, ns)  # noqa: S102 - generated by random_model above
         model = gen(ns["model"])
         keys = genjax.random.split(genjax.random.key(int(rng.integers(1 << 30)), impl), n)
@@ -166,7 +172,7 @@ def run_scans(seconds: float, seed: int, impl: int = 1, n: int = 800):
     t_end, compared, skipped = time.time() + seconds, 0, 0
     while time.time() < t_end:
         src, sites = random_step(rng)
-        ns = {"normal": normal, "gamma": gamma, "beta": beta, "flip": flip}
+        ns = {"normal": normal, "gamma": gamma, "beta": beta, "flip": flip, "torch": torch}
         exec(src, ns)  # noqa: S102 - generated by random_step above
         T = int(rng.integers(1, 7))
         model = gen(ns["step"]).scan()

@@ -453,8 +453,9 @@ def case_expression_arguments(impl):
     tr1 = P._traced(regression, C["y", 0].set(0.3), n, (0.5, 1.75))
     tr2 = P._traced(regression, C["y", 0].set(-0.9), n, (0.8, -0.3))
     assert tr1 is not None and tr2 is not None and P._make_plan(tr1[0]) is P._make_plan(tr2[0])
-    # what does NOT lower still runs on the per-site path: a transcendental function of a traced value (torch's device exp
-    # is not the spec's), a division by a NUMBER (torch multiplies a device tensor by the reciprocal instead)
+    # r03: what reference bodies write between sites — exp / log of a traced value, a division by (or of) a NUMBER — lowers
+    # too (GJX_EXPR_EXP / _LOG / _DIV), and the per-site path computes the same bits (lang.SpecTensor -> gjx_map_f32:
+    # torch's device exp is not the spec's, and torch multiplies a device tensor by the reciprocal instead of dividing)
     @gen
     def ratio():
         a = normal(0.0, 1.0) @ "a"
@@ -464,11 +465,41 @@ def case_expression_arguments(impl):
     @gen
     def halves():
         a = normal(0.0, 1.0) @ "a"
-        return normal(a / 3.0, 1.0) @ "d"
+        b = normal(a / 3.0, 1.0) @ "b"
+        return normal(2.0 / (b * b + 1.5), (a * a + 0.5).log().exp()) @ "d"
 
-    assert try_fused_generate(halves, keys, C.n(), ()) is None
+    @gen
+    def logscale(s0):
+        ls = normal(s0, 0.3) @ "log_sigma"
+        x = normal(0.0, torch.exp(ls)) @ "x"
+        _ = normal(x / 2, torch.log(torch.exp(ls) + 1.0)) @ "y"
+        return torch.div(x, 4.0)
 
-    assert try_fused_generate(ratio, keys, C.n(), ()) is None
+    def same_trace(fn, args, chm):
+        fused = try_fused_generate(fn, keys, chm, args)
+        assert fused is not None, f"{fn.source.__name__}: exp / log / division by a number must lower to the fused kernel"
+        ftr, fw = fused
+        h = GenerateHandler(keys, chm)
+        retval = h.run(fn.source, args)
+        eager = StaticTrace(fn, args, retval, h.traces)
+        if isinstance(h.weight, torch.Tensor):
+            assert torch.equal(fw, h.weight), fn.source.__name__
+        assert torch.equal(ftr.get_score(), eager.get_score()), fn.source.__name__
+        fc, ec = dict(ftr.get_choices().leaves()), dict(eager.get_choices().leaves())
+        assert fc.keys() == ec.keys()
+        for key_ in fc:
+            a_, b_ = fc[key_], ec[key_]
+            if isinstance(a_, torch.Tensor) and a_.dim():
+                assert torch.equal(a_, b_.to(a_.dtype) if isinstance(b_, torch.Tensor) else torch.full_like(a_, b_)), key_
+        assert torch.equal(torch.as_tensor(ftr.get_retval()), torch.as_tensor(eager.get_retval())), fn.source.__name__
+        for addr in fc:
+            a = addr if not (isinstance(addr, tuple) and len(addr) == 1) else addr[0]
+            assert torch.equal(torch.as_tensor(ftr.get_subtrace(a).get_score()).to(torch.float32).expand(n),
+                               torch.as_tensor(eager.get_subtrace(a).get_score()).to(torch.float32).expand(n)), addr
+
+    for fn, args, chm in ((ratio, (), C["d"].set(0.1)), (halves, (), C.n()), (halves, (), C["d"].set(-0.3)),
+                          (logscale, (0.2,), C["y"].set(0.7)), (logscale, (0.2,), C.n())):
+        same_trace(fn, args, chm)
     tr, w = ratio.importance(keys, C["d"].set(0.1), ())
     assert w.shape == (n,) and bool(torch.isfinite(w).all())
 

@@ -265,6 +265,21 @@ def test_importance_mixed_plan(hip_ops, oracle_ops, impl, plan_mode):
     same(hmp, omp, "max partials")
 
 
+def test_map_f32(hip_ops, oracle_ops):
+    """gjx_map_f32: the spec's exp / log and the IEEE division by (of) a number over a column, HIP == oracle bit for bit
+    (edge cases included: zeros, infinities, NaN, subnormals, both ends of exp's range)."""
+    from genjax._amd import abi
+    from test_oracle_pinning import map_inputs
+
+    x = torch.cat([map_inputs(), torch.randn(1 << 20) * 30])
+    xd = dev(x, hip_ops)
+    for op in (abi.MAP_EXP, abi.MAP_LOG):
+        same(hip_ops.map_f32(op, xd), oracle_ops.map_f32(op, x), f"map {op}")
+    for c in (3.0, 0.1, -7.25, 1e-30, 2.263):
+        same(hip_ops.map_f32(abi.MAP_DIV, xd, c), oracle_ops.map_f32(abi.MAP_DIV, x, c), "x / c")
+        same(hip_ops.map_f32(abi.MAP_RDIV, xd, c), oracle_ops.map_f32(abi.MAP_RDIV, x, c), "c / x")
+
+
 @pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 50000, 1 << 20])
 def test_logsumexp(hip_ops, oracle_ops, n):
     g = torch.Generator().manual_seed(n)

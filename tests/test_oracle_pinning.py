@@ -87,6 +87,43 @@ def test_math_spec_accuracy(raw):
     assert _math(raw, 0, [0.0])[0] == -np.inf and _math(raw, 1, [-200.0])[0] == 0.0
 
 
+def map_inputs():
+    import torch
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.randn(5000, generator=g) * 20, torch.rand(3000, generator=g) * 1e-3, torch.randn(2000, generator=g) * 90,
+                   torch.tensor([0.0, -0.0, 1.0, -1.0, float("inf"), float("-inf"), float("nan"), 1e-45, 1e-39, 3.4e38, 88.0,
+                                 88.5, 88.72, 88.73, 89.0, -86.0, -87.5, -104.0, 0.5, 2.0, 3.0])]).to(torch.float32)
+    return x
+
+
+def test_map_f32_against_numpy(oracle_ops):
+    """gjx_map_f32 (what `exp` / `log` / a division by a number between the sites of a model body compute, on the per-site
+    path and — as GJX_EXPR_EXP / _LOG / _DIV — inside fused plans): exp and log within 2 ulp of float64, the IEEE edge cases
+    (log 0 = -inf, log of a negative = NaN, exp overflow = +inf, NaN stays NaN), divisions equal to numpy's f32 bit for bit."""
+    import torch
+
+    from genjax._amd import abi
+
+    x = map_inputs()
+    xn = x.numpy()
+    with np.errstate(all="ignore"):
+        for op, ref in ((abi.MAP_EXP, np.exp(xn.astype(np.float64))), (abi.MAP_LOG, np.log(xn.astype(np.float64)))):
+            got = oracle_ops.map_f32(op, x).numpy()
+            r32 = ref.astype(np.float32)
+            fin = np.isfinite(r32) & (np.abs(r32) > 1.2e-38)
+            assert np.array_equal(np.isnan(got), np.isnan(r32))
+            big = ~np.isnan(r32) & ~fin & (np.abs(r32) > 1.0)  # overflow to +-inf
+            assert np.array_equal(got[big], r32[big])
+            ulp = np.spacing(np.abs(r32[fin]))
+            tol = np.where((xn[fin] > 88.0) | (xn[fin] < -86.0), 4.0, 2.0) if op == abi.MAP_EXP else 2.0  # (the tails square exp(x / 2))
+            assert np.all(np.abs(got[fin].astype(np.float64) - ref[fin]) <= tol * ulp), op
+        for c in (3.0, 0.1, -7.25, 1e-30):
+            assert np.array_equal(oracle_ops.map_f32(abi.MAP_DIV, x, c).numpy(), xn / np.float32(c), equal_nan=True)
+            assert np.array_equal(oracle_ops.map_f32(abi.MAP_RDIV, x, c).numpy(), np.float32(c) / xn, equal_nan=True)
+    assert oracle_ops.map_f32(abi.MAP_EXP, torch.zeros(3, 4)).shape == (3, 4)
+
+
 def test_logpdfs_against_scipy(oracle_ops):
     g = gold("logpdf_scipy.json")
     for r in g["normal"]:
