@@ -1446,6 +1446,7 @@ struct gjx_plan {
   ExprStore expr;      // GJX_ARG_EXPR programs (host; read by the code generator)
   bool has_expr;       // ... any?  Then the plan runs as a specialised kernel only
   int expr_max_input;  // highest input column a program reads (-1: none)
+  gjx_jit::ScopeInfo scopes;  // nested calls (gjx_plan_create_scoped); n_scopes > 0: a specialised kernel only, like programs
 };
 
 // GJX_ARG_EXPR (gjx.h): a postfix program as a distribution argument.  Well-formed: at most GJX_MAX_EXPR_OPS entries,
@@ -1621,6 +1622,19 @@ int gjx_plan_create_ex(const gjx_site* sites, int n_sites, uint32_t flags, gjx_p
   return GJX_OK;
 }
 
+int gjx_plan_create_scoped(const gjx_site* sites, int n_sites, const gjx_scope* scopes, int n_scopes, uint32_t flags,
+                           gjx_plan** out) {
+  gjx_plan* p = nullptr;
+  const int rc = gjx_plan_create_ex(sites, n_sites, flags, &p);
+  if (rc) return rc;
+  if (!gjx_jit::derive_scopes(sites, n_sites, scopes, n_scopes, p->scopes)) {
+    gjx_plan_destroy(p);
+    return GJX_ERR_INVALID;
+  }
+  *out = p;
+  return GJX_OK;
+}
+
 // Launch parameters: the caller's values and the per-site constants that depend on them (the spec functions on the
 // host: IEEE-exact ops give the bits the device would compute per particle).
 int gjx_plan_set_params(gjx_plan* p, const float* params, int n_params) {
@@ -1676,6 +1690,7 @@ int gjx_plan_specialized_source(const gjx_plan* p, int impl, char* buf, size_t b
   if (!p || (impl != 0 && impl != 1)) return GJX_ERR_INVALID;
   gjx_jit::Gen<CSite, CArg> g;
   g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites; g.laned = impl == 1 && jit_form_pref() >= 2;
+  g.sc = p->scopes.n_scopes > 0 ? &p->scopes : nullptr;
   g.pairs_per_lane = jit_form_pref() == 4 ? 2 : 1;  // (GJX_JIT_FORM picks the PHILOX form shown)
   g.fast_math = (p->flags & GJX_PLAN_FAST_MATH) != 0;
   gjx_jit::TableScope ts;
@@ -1694,6 +1709,7 @@ int gjx_plan_compile_check(const gjx_plan* p, int impl) {
   for (int form = 0; form <= 2 * impl; ++form) {  // PHILOX: one particle per lane, pairs, quads
     gjx_jit::Gen<CSite, CArg> g;
     g.impl = impl; g.sites = p->host; g.n_sites = p->n_sites; g.laned = form != 0; g.pairs_per_lane = form == 2 ? 2 : 1;
+    g.sc = p->scopes.n_scopes > 0 ? &p->scopes : nullptr;
     g.fast_math = (p->flags & GJX_PLAN_FAST_MATH) != 0;
     gjx_jit::TableScope ts;
     if (!gjx_jit::compile_only(g.run())) return GJX_ERR_UNSUPPORTED;
@@ -1726,6 +1742,7 @@ static gjx_jit::Compiled& plan_compiled(gjx_plan* mp, const gjx_keys* pk, int la
       auto make = [&](int min_waves) {
         gjx_jit::Gen<CSite, CArg> g;
         g.impl = pk->impl; g.sites = mp->host; g.n_sites = mp->n_sites; g.laned = laned; g.pairs_per_lane = P == 4 ? 2 : 1;
+        g.sc = mp->scopes.n_scopes > 0 ? &mp->scopes : nullptr;
         g.fast_math = (mp->flags & GJX_PLAN_FAST_MATH) != 0;
         g.min_waves = min_waves;
         gjx_jit::TableScope ts;  // the source numbers the plan's device tables; the addresses travel as a kernel argument
@@ -1828,7 +1845,7 @@ static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pa
     for (int c = 0; c < n_value_cols; ++c) al |= (uintptr_t)value_cols[c];
     const int lane_particles = (al & 15) == 0 ? 4 : ((al & 7) == 0 ? 2 : 1);
     gjx_jit::Compiled& c = plan_compiled(const_cast<gjx_plan*>(p), pk, lane_particles);
-    if (c.state != 1 && (!jit_fallback_allowed() || p->has_expr)) return GJX_ERR_JIT;  // loud: never a silent 7x slower route
+    if (c.state != 1 && (!jit_fallback_allowed() || p->has_expr || p->scopes.n_scopes > 0)) return GJX_ERR_JIT;  // loud: never a silent 7x slower route
     if (c.state == 1) {
       uint64_t nn = n;
       LseTail tail{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f};
@@ -1855,7 +1872,7 @@ static int importance_launch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pa
       return launch_status();
     }
   }
-  if (p->has_expr) return GJX_ERR_UNSUPPORTED;  // programs are compiled, never interpreted (gjx.h: GJX_ARG_EXPR)
+  if (p->has_expr || p->scopes.n_scopes > 0) return GJX_ERR_UNSUPPORTED;  // programs and nested calls are compiled, never interpreted
   {
     const int rc = plan_device_table(const_cast<gjx_plan*>(p));
     if (rc) return rc;

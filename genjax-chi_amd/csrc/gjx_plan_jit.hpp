@@ -88,6 +88,53 @@ inline std::string plit(const void* p) { return plit_as("float", p); }
 // output columns); mode 1 = SMC step / init (slot `j`, `a.step_key`, ancestor state `st_k`,
 // observation constants `a.obs[]`, weight only).  `sfx` is appended to every per-particle name, so two
 // emitters ("A", "B") can interleave the walks of the two particles a lane owns.
+// Nested `@gen` calls (gjx.h gjx_scope): which key every site draws under and with which fold.  Derived once per plan
+// from the scopes' ranges: every `@` site and every call takes the next counter of the scope it sits in (THREEFRY: the
+// 1-based counter over all of them; PHILOX: the 0-based index among those that consume randomness — unobserved sites and
+// calls), a callee numbers its own sites afresh under fold_in(caller's key, the call's counter).
+struct ScopeInfo {
+  int n_scopes = 0;
+  int site_scope[GJX_MAX_SITES];
+  uint32_t fold_t[GJX_MAX_SITES], fold_p[GJX_MAX_SITES];
+  int parent[GJX_MAX_SCOPES + 1], begin[GJX_MAX_SCOPES + 1], end[GJX_MAX_SCOPES + 1];
+  uint32_t s_fold_t[GJX_MAX_SCOPES + 1], s_fold_p[GJX_MAX_SCOPES + 1];
+};
+inline bool derive_scopes(const gjx_site* sites, int n_sites, const gjx_scope* sc, int n_sc, ScopeInfo& out) {
+  if (n_sc < 0 || n_sc > GJX_MAX_SCOPES || (n_sc && !sc)) return false;
+  struct Frame { int id, end; uint32_t ct, dr; };
+  Frame fr[8];
+  int depth = 0, next = 0;
+  fr[depth++] = Frame{0, n_sites, 1u, 0u};
+  out.n_scopes = n_sc;
+  out.parent[0] = -1;
+  for (int q = 0; q <= n_sites; ++q) {
+    while (next < n_sc && sc[next].begin == q) {  // the calls made at this position, in call order
+      const gjx_scope& k = sc[next];
+      if (k.parent < 0 || k.parent > next || k.end < k.begin || k.end > n_sites) return false;
+      while (depth > 0 && fr[depth - 1].id != k.parent) {
+        if (fr[depth - 1].end > q) return false;  // the caller is not the innermost open scope
+        --depth;
+      }
+      if (depth == 0 || k.end > fr[depth - 1].end || depth >= 5) return false;
+      out.parent[next + 1] = k.parent;
+      out.begin[next + 1] = k.begin;
+      out.end[next + 1] = k.end;
+      out.s_fold_t[next + 1] = fr[depth - 1].ct++;
+      out.s_fold_p[next + 1] = fr[depth - 1].dr++;
+      fr[depth++] = Frame{next + 1, k.end, 1u, 0u};
+      ++next;
+    }
+    if (next < n_sc && sc[next].begin < q) return false;  // not in call order
+    while (depth > 1 && fr[depth - 1].end <= q) --depth;
+    if (q == n_sites) break;
+    out.site_scope[q] = fr[depth - 1].id;
+    out.fold_t[q] = fr[depth - 1].ct++;
+    out.fold_p[q] = fr[depth - 1].dr;
+    if (!sites[q].observed) fr[depth - 1].dr++;
+  }
+  return next == n_sc;
+}
+
 template <class CSiteT, class CArgT>
 struct SiteEmitter {
   std::ostringstream& o;
@@ -99,6 +146,19 @@ struct SiteEmitter {
   int cur_blk = -1;
   bool store_values = true;  // false: the caller stores (the paired kernel writes both particles at once)
   bool ext_bits = false;     // true: the caller defines bits<q><sfx> of one-word draws (SMC quads share a block)
+  const ScopeInfo* sc = nullptr;  // nested calls: per-site key scope and fold (null: a flat body, the implicit numbering)
+
+  int scope_of(int q) const { return sc ? sc->site_scope[q] : 0; }
+  std::string key_of_scope(int k) const { return k == 0 ? "pkey" + sfx : "skey" + std::to_string(k) + sfx; }
+  std::string key_of(int q) const { return key_of_scope(scope_of(q)); }
+  // the keys of the nested scopes, each fold_in(caller's key, the counter its call took); after pkey<sfx> is defined
+  void emit_scope_keys() {
+    if (!sc) return;
+    for (int k = 1; k <= sc->n_scopes; ++k)
+      o << ind << "const Key " << key_of_scope(k) << " = fold_in<" << impl << ">(" << key_of_scope(sc->parent[k]) << ", "
+        << (impl == 0 ? sc->s_fold_t[k] : sc->s_fold_p[k]) << "u); (void)" << key_of_scope(k) << ";\n";
+    for (int k = 1; k <= sc->n_scopes; ++k) o << ind << "float " << acc("w", k) << " = 0.0f, " << acc("sc", k) << " = 0.0f;\n";
+  }
 
   static bool is_int(const CSiteT& s) { return s.dist >= GJX_DIST_BERNOULLI; }
   std::string nm(const char* base, int q) const { return std::string(base) + std::to_string(q) + sfx; }
@@ -158,6 +218,7 @@ struct SiteEmitter {
   }
   // fold of site q: THREEFRY the 1-based site counter; PHILOX the 0-based index among the sampled sites
   uint32_t fold_of(int q) const {
+    if (sc) return impl == 0 ? sc->fold_t[q] : sc->fold_p[q];
     if (impl == 0) return (uint32_t)(q + 1);
     uint32_t d = 0;
     for (int p = 0; p < q; ++p) d += sites[p].observed ? 0u : 1u;
@@ -232,11 +293,11 @@ struct SiteEmitter {
       else o << ind << "const float vf" << Q << " = " << ov << ";\n";
       return;
     }
-    if (!one_word(st) || ext_bits) return;
+    if (!one_word(st) || (ext_bits && scope_of(q) == 0)) return;  // (a callee's sites draw under their own lone keys)
     if (impl == 1) {  // (the generic form: kernels that own whole pairs / quads define bits themselves, ext_bits)
-      o << ind << "const uint32_t bits" << Q << " = philox_single_draw(pkey" << sfx << ", " << fold << "u);\n";
+      o << ind << "const uint32_t bits" << Q << " = philox_single_draw(" << key_of(q) << ", " << fold << "u);\n";
     } else {
-      o << ind << "const uint32_t bits" << Q << " = Stream<0>(pkey" << sfx << ", true, " << fold << "u).bits32(0);\n";
+      o << ind << "const uint32_t bits" << Q << " = Stream<0>(" << key_of(q) << ", true, " << fold << "u).bits32(0);\n";
     }
   }
 
@@ -244,7 +305,7 @@ struct SiteEmitter {
   // or, empty, this particle's own derivation), the log-density, the accumulators and the stored column.
   void tail(int q, const std::string& eps = "") {
     const CSiteT& st = sites[q];
-    const std::string I = std::to_string(impl), Q = std::to_string(q) + sfx, K = "pkey" + sfx;
+    const std::string I = std::to_string(impl), Q = std::to_string(q) + sfx, K = key_of(q);
     const uint32_t fold = fold_of(q);
     const std::string row = "row" + Q;
     const bool isint = is_int(st);
@@ -329,17 +390,30 @@ struct SiteEmitter {
     const bool all_const = st.observed && st.obs.kind == GJX_ARG_CONST && is_const(st.a0) &&
                            (st.dist == GJX_DIST_BERNOULLI || st.dist == GJX_DIST_CATEGORICAL || is_const(st.a1));
     if (all_const) lp = "opq(" + lp + ")";
-    o << ind << "{ const float lp = " << lp << "; sc" << sfx << " = sc" << sfx << " + lp;"
-      << (st.observed ? " w" + sfx + " = w" + sfx + " + lp;" : "") << " }\n";
+    const std::string aw = acc("w", scope_of(q)), as = acc("sc", scope_of(q));
+    o << ind << "{ const float lp = " << lp << "; " << as << " = " << as << " + lp;"
+      << (st.observed ? " " + aw + " = " + aw + " + lp;" : "") << " }\n";
     if ((mode == 0 || mode == 2) && st.out_col >= 0 && store_values)
       o << ind << "reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "])[" << (mode == 2 ? "oi" : "i") << sfx << "] = "
         << (isint ? "(uint32_t)" + v : "f2u(" + v + ")") << ";\n";
   }
 
+  // a callee's weight and score are ITS totals, added to the caller's when the call returns (static.py:374-380: the
+  // caller adds `w`; StaticTrace.get_score sums the sub-traces' scores): one accumulator pair per scope
+  std::string acc(const char* base, int k) const { return k == 0 ? std::string(base) + sfx : std::string(base) + "_s" + std::to_string(k) + sfx; }
+  void close_scopes(int pos) {  // the calls that have returned once the sites before `pos` are done (inner ones first)
+    if (!sc) return;
+    for (int k = sc->n_scopes; k >= 1; --k)
+      if (sc->end[k] == pos && sc->begin[k] < pos)
+        o << ind << acc("w", sc->parent[k]) << " = " << acc("w", sc->parent[k]) << " + " << acc("w", k) << "; "
+          << acc("sc", sc->parent[k]) << " = " << acc("sc", sc->parent[k]) << " + " << acc("sc", k) << ";\n";
+  }
   void run() {
+    emit_scope_keys();
     for (int q = 0; q < n_sites; ++q) {
       head(q);
       tail(q);
+      close_scopes(q + 1);
     }
   }
 };
@@ -371,6 +445,7 @@ struct Gen {
   int rows_per_block = 1;
   bool laned = false; // the paired form (see above)
   bool fast_math = false;  // GJX_PLAN_FAST_MATH
+  const ScopeInfo* sc = nullptr;  // nested calls (null: a flat body)
   int pairs_per_lane = 1;  // paired form: 1 = two adjacent particles per lane (128-thread workgroup per 256-particle row);
                            // 2 = FOUR adjacent particles per lane: one WAVE owns the whole row, so the row statistics are
                            // wave reductions (DPP only: no LDS, no barrier) and every column store is 16 bytes per lane
@@ -430,7 +505,9 @@ struct Gen {
       em.push_back(SiteEmitter<CSiteT, CArgT>{o, impl, 0, sites, n_sites, "      ", sfx[u]});
       em.back().store_values = false;
       em.back().ext_bits = true;  // the lane owns whole pairs: their single-word draws come from the pairs' blocks
+      em.back().sc = sc;
     }
+    for (int u = 0; u < P; ++u) em[u].emit_scope_keys();
     o << "      const uint64_t pair0 = (lnA - 1u) >> 1;\n";
     if (NP == 2) o << "      const uint64_t pair1 = pair0 + 1u;\n";
     int cur_pair_blk = -1;
@@ -438,7 +515,7 @@ struct Gen {
       const CSiteT& st = sites[q];
       for (int u = 0; u < P; ++u) em[u].head(q);
       const std::string Q = std::to_string(q);
-      if (!st.observed && em[0].one_word(st)) {
+      if (!st.observed && em[0].one_word(st) && em[0].scope_of(q) == 0) {  // (a callee's sites: every particle's own lone key)
         // draw f of a pair: block f >> 1 holds words (even, odd particle) of draw 2 (f >> 1) and of draw 2 (f >> 1) + 1
         const uint32_t f = em[0].fold_of(q);
         const int blk = (int)(f >> 1);
@@ -458,7 +535,7 @@ struct Gen {
             << " = " << V << "_" << (((f & 1u) << 1) | 1u) << ";\n";
         }
       }
-      if (!st.observed && st.dist == GJX_DIST_NORMAL) {
+      if (!st.observed && st.dist == GJX_DIST_NORMAL && em[0].scope_of(q) == 0) {
         for (int pi = 0; pi < NP; ++pi) {
           const std::string Z = Q + "_" + std::to_string(pi);
           o << "      float zc" << Z << ", zs" << Z << ";\n      bm_pair(bits" << Q << sfx[2 * pi] << ", bits" << Q << sfx[2 * pi + 1] << ", zc" << Z
@@ -472,6 +549,7 @@ struct Gen {
       } else {
         for (int u = 0; u < P; ++u) em[u].tail(q);
       }
+      for (int u = 0; u < P; ++u) em[u].close_scopes(q + 1);
       if (st.out_col >= 0) {  // the lane's particles are adjacent in the column: one 8- / 16-byte store per lane
         const bool isint = SiteEmitter<CSiteT, CArgT>::is_int(st);
         std::string vals;
@@ -543,6 +621,7 @@ struct Gen {
     o << "        const Key pkey = key_at<" << I << ">(kp, li);\n";
     o << "        float w = 0.0f, sc = 0.0f;\n";
     SiteEmitter<CSiteT, CArgT> em{o, impl, 0, sites, n_sites, "        "};
+    em.sc = sc;
     em.run();
     o << "        if (logw) logw[i] = w;\n        if (score) score[i] = sc;\n        tmax = w;\n        live = true;\n";
     o << "      }\n    }\n";

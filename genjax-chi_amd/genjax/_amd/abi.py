@@ -68,6 +68,15 @@ class Keys(C.Structure):
     ]
 
 
+class Scope(C.Structure):
+    """include/gjx.h gjx_scope: one nested `@gen` call of a plan (the range of the flat site table it produced)."""
+
+    _fields_ = [("parent", C.c_int32), ("begin", C.c_int32), ("end", C.c_int32)]
+
+
+MAX_SCOPES = 16
+
+
 class LseOut(C.Structure):
     """gjx_lse_out: where a fused importance launch leaves the pass's log-sum-exp."""
 
@@ -281,6 +290,7 @@ PROTOTYPES = {
     ),
     "gjx_plan_create": (C.c_int, [C.POINTER(Site), C.c_int, C.POINTER(_P)]),
     "gjx_plan_create_ex": (C.c_int, [C.POINTER(Site), C.c_int, C.c_uint32, C.POINTER(_P)]),
+    "gjx_plan_create_scoped": (C.c_int, [C.POINTER(Site), C.c_int, C.POINTER(Scope), C.c_int, C.c_uint32, C.POINTER(_P)]),
     "gjx_plan_destroy": (C.c_int, [_P]),
     "gjx_plan_set_params": (C.c_int, [_P, _P, C.c_int]),
     "gjx_plan_specialized_source": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -212,12 +212,18 @@ class Ops:
         return score
 
     # ---- plans ----------------------------------------------------------------------------------
-    def plan_create(self, sites: list[abi.Site], fast_math: bool = False) -> "Plan":
+    def plan_create(self, sites: list[abi.Site], fast_math: bool = False, scopes=()) -> "Plan":
         """`fast_math`: gjx.h GJX_PLAN_FAST_MATH — hardware transcendentals for the continuous parts of the walk
-        (<= 1e-5 relative on values and log-weights; no longer bit-identical to the oracle)."""
+        (<= 1e-5 relative on values and log-weights; no longer bit-identical to the oracle).
+        `scopes`: (parent, begin, end) of every nested `@gen` call, in call order (gjx.h gjx_scope)."""
         arr = (abi.Site * len(sites))(*sites)
         handle = C.c_void_p()
-        self.lib.call("gjx_plan_create_ex", arr, len(sites), abi.PLAN_FAST_MATH if fast_math else 0, C.byref(handle))
+        flags = abi.PLAN_FAST_MATH if fast_math else 0
+        if scopes:
+            sc = (abi.Scope * len(scopes))(*[abi.Scope(*k) for k in scopes])
+            self.lib.call("gjx_plan_create_scoped", arr, len(sites), sc, len(scopes), flags, C.byref(handle))
+        else:
+            self.lib.call("gjx_plan_create_ex", arr, len(sites), flags, C.byref(handle))
         return Plan(self, handle, len(sites))
 
     def jit_stats(self) -> dict:

@@ -341,6 +341,11 @@ class PlanTracer(_Handler):
         self.keep: list = []  # device tensors (and expression programs) the site table points into
         self.expr_progs: dict = {}  # address of a program's ctypes array -> the program
         self.n_out = 0
+        # nested `@gen` calls (static.py:175-193): the callee's body is traced in line; the site table stays flat and
+        # `scopes` says which range of it each call produced (gjx.h gjx_scope)
+        self.scopes: list[list] = []  # [parent scope, begin, end]
+        self.items: list = []         # this body's `@` sites in program order: ("site", index) | ("call", record)
+        self.cur_scope, self.depth, self.allow_scopes = 0, 0, True
 
     # -- argument encoding ---------------------------------------------------------------------------
     def param_slot(self, pv: ParamVal) -> int:
@@ -385,9 +390,35 @@ class PlanTracer(_Handler):
         self.inputs.append(col.to(device=ops.device(), dtype=torch.float32).contiguous())
         return len(self.inputs) - 1
 
+    def _call(self, addr, gen_fn, args):
+        """`callee(*args) @ addr`: the callee takes one counter of this body and numbers its own sites afresh under
+        fold_in(key, counter) — the kernel derives that key per particle (gjx_plan_create_scoped)."""
+        from .lang import StaticGenerativeFunction
+
+        if not self.allow_scopes or not isinstance(gen_fn, StaticGenerativeFunction):
+            raise PlanUnsupported("nested generative function")
+        if len(self.scopes) >= abi.MAX_SCOPES or self.depth >= 3:
+            raise PlanUnsupported("too many / too deep nested calls")
+        a = addr if isinstance(addr, tuple) else (addr,)
+        self.record(addr, None)
+        k = len(self.scopes)
+        self.scopes.append([self.cur_scope, len(self.sites), None])
+        rec = dict(addr=addr, gen_fn=gen_fn, args=args, items=[], retval=None)
+        self.items.append(("call", rec))
+        saved = (self.constraint, self.traces, self.cur_scope, self.items)
+        self.constraint, self.traces, self.cur_scope, self.items = self.constraint.get_submap(*a), {}, k + 1, rec["items"]
+        self.depth += 1
+        try:
+            rec["retval"] = gen_fn.source(*_spec_wrap(tuple(args)))  # (`@` inside reaches this tracer: it is the stack's top)
+        finally:
+            self.constraint, self.traces, self.cur_scope, self.items = saved
+            self.depth -= 1
+        self.scopes[k][2] = len(self.sites)
+        return rec["retval"]
+
     def handle_trace(self, addr, gen_fn, args):
         if not isinstance(gen_fn, Distribution):
-            raise PlanUnsupported("nested generative function")
+            return self._call(addr, gen_fn, args)
         if len(self.sites) >= abi.MAX_SITES:
             raise PlanUnsupported("too many sites")
         a = addr if isinstance(addr, tuple) else (addr,)
@@ -453,6 +484,7 @@ class PlanTracer(_Handler):
             site.out_col = self.n_out
             self.n_out += 1
         self.sites.append(site)
+        self.items.append(("site", idx))
         self.meta.append(dict(addr=addr, gen_fn=gen_fn, args=args, obs=obs, out_col=site.out_col, is_int=is_int,
                               dtype=gen_fn.value_dtype))
         self.record(addr, None)
@@ -562,13 +594,13 @@ def _make_plan(tracer, estimate_only: bool = False):
     # library derives per-plan tables from them at the plan's first compilation (CDFs, guides, log-probabilities), so an
     # in-place update of such a tensor (an EM / optimiser step) must not find the plan built from its old contents.
     tables = tuple((id(t), t._version) for t in tracer.keep if isinstance(t, torch.Tensor))
-    key = (id(ops), fast, raw, tables)
+    key = (id(ops), fast, raw, tables, tuple(tuple(k) for k in tracer.scopes))
     hit = cache.get(key)
     if hit is not None:
         cache.move_to_end(key)
         plan = hit[0]
     else:
-        plan = ops.plan_create(sites, fast_math=fast)
+        plan = ops.plan_create(sites, fast_math=fast, scopes=[tuple(k) for k in tracer.scopes])
         cache[key] = (plan, tracer.keep)  # (the tables the site table points into stay alive with the plan)
         while len(cache) > _PLAN_CACHE_MAX:
             cache.popitem(last=False)
@@ -686,10 +718,17 @@ def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
             return [resolve(y) for y in x]
         return x
 
-    subtraces = {}
-    for m, v in zip(tracer.meta, site_vals):
-        subtraces[m["addr"]] = ValueTrace(m["gen_fn"], (lambda a=m["args"]: tuple(resolve(y) for y in a)), v)
-    tr = StaticTrace(gen_fn, args, resolve(retval), subtraces, score=score)
+    def build(items):  # a body's sub-traces in program order; a nested call's trace sums its sites' scores on demand
+        sub = {}
+        for kind, x in items:
+            if kind == "site":
+                m = tracer.meta[x]
+                sub[m["addr"]] = ValueTrace(m["gen_fn"], (lambda a=m["args"]: tuple(resolve(y) for y in a)), site_vals[x])
+            else:
+                sub[x["addr"]] = StaticTrace(x["gen_fn"], tuple(resolve(y) for y in x["args"]), resolve(x["retval"]), build(x["items"]))
+        return sub
+
+    tr = StaticTrace(gen_fn, args, resolve(retval), build(tracer.items), score=score)
     tr.max_partials = mp  # lets a max-anchored log-sum-exp skip its max pass
     tr.row_stats = rows  # row-anchored partial sums: the log-marginal needs one tiny kernel more
     return tr, logw

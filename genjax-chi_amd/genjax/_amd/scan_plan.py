@@ -32,6 +32,7 @@ class _ScanTracer(PlanTracer):
     def __init__(self, obs_index: dict):
         super().__init__(ChoiceMap.empty(), 1, use_params=False)
         self.obs_index = obs_index
+        self.allow_scopes = False  # (nested calls: importance plans only)
 
     def _arg(self, v) -> abi.Arg:
         if isinstance(v, Sym) and v.src[0] == "state":

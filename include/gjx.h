@@ -245,6 +245,21 @@ int gjx_plan_create(const gjx_site* sites /*host*/, int n_sites, gjx_plan** out)
  *    table interpreter and the oracle ignore it (they ARE the exact specification). */
 #define GJX_PLAN_FAST_MATH 1u
 int gjx_plan_create_ex(const gjx_site* sites /*host*/, int n_sites, uint32_t flags, gjx_plan** out);
+/* Nested `@gen` calls inside a plan (static.py:175-193, 349-352, 374-375; generative_function.py:1568-1583): the body
+ * `callee(args) @ "addr"` takes ONE counter of its caller like any other `@` site, runs under
+ * sub_key = fold_in(key, counter), and numbers its own sites from 1 (THREEFRY; PHILOX: from draw 0 of the lone key
+ * sub_key).  The site table stays FLAT, in program order; scope k (1-based; 0 is the plan's own body) says which
+ * contiguous range [begin, end) of it — deeper calls included — one call produced and which scope made the call.  Scopes
+ * are listed in call order (begin non-decreasing, a caller before its callees); a call that visits no site has
+ * begin == end (it still takes its counter, at that position).  Depth <= 4, at most GJX_MAX_SCOPES calls.
+ * Plans with scopes run as specialised kernels only (like GJX_ARG_EXPR programs); the oracle walks them as written. */
+typedef struct {
+  int32_t parent; /* the calling scope: 0 = the plan's body, k = scopes[k - 1] */
+  int32_t begin, end;
+} gjx_scope;
+#define GJX_MAX_SCOPES 16
+int gjx_plan_create_scoped(const gjx_site* sites /*host*/, int n_sites, const gjx_scope* scopes /*host*/, int n_scopes,
+                           uint32_t flags, gjx_plan** out);
 int gjx_plan_destroy(gjx_plan* p);
 /* The values of the plan's GJX_ARG_PARAM references for the launches that follow (host f32[n_params], copied; n_params
  * <= GJX_MAX_PARAMS and > every referenced index).  Per-site constants that depend on them (1/scale, the log

@@ -330,12 +330,58 @@ static void expr_adopt(gjx_site* sites, int n, expr_store* st) {
 }
 
 /* ---- fused static-model importance ------------------------------------------------------------ */
+/* Nested calls (gjx.h gjx_scope): which key every site draws under and with which fold, derived once per plan. */
+typedef struct {
+  int n_scopes;                         /* calls; 0 = a flat body (the implicit numbering) */
+  int site_scope[GJX_MAX_SITES];        /* 0 = the body's own key */
+  uint32_t fold_t[GJX_MAX_SITES];       /* THREEFRY: the site's 1-based `@` counter within its scope */
+  uint32_t fold_p[GJX_MAX_SITES];       /* PHILOX: its 0-based index among the scope's randomness-consuming sites / calls */
+  int parent[GJX_MAX_SCOPES + 1], begin[GJX_MAX_SCOPES + 1], end[GJX_MAX_SCOPES + 1];
+  uint32_t s_fold_t[GJX_MAX_SCOPES + 1], s_fold_p[GJX_MAX_SCOPES + 1]; /* the counter the CALL took in its caller */
+} scope_info;
+
+static int derive_scopes(const gjx_site* sites, int n_sites, const gjx_scope* sc, int n_sc, scope_info* out) {
+  if (n_sc < 0 || n_sc > GJX_MAX_SCOPES || (n_sc && !sc)) return 0;
+  struct { int id, end; uint32_t ct, dr; } fr[8];
+  int depth = 0, next = 0;
+  fr[depth].id = 0; fr[depth].end = n_sites; fr[depth].ct = 1; fr[depth].dr = 0; ++depth;
+  out->n_scopes = n_sc;
+  out->parent[0] = -1;
+  for (int q = 0; q <= n_sites; ++q) {
+    while (next < n_sc && sc[next].begin == q) { /* calls made at this position, in call order */
+      const gjx_scope* k = &sc[next];
+      if (k->parent < 0 || k->parent > next || k->end < k->begin || k->end > n_sites) return 0;
+      while (depth > 0 && fr[depth - 1].id != k->parent) {
+        if (fr[depth - 1].end > q) return 0; /* the caller is not the innermost open scope */
+        --depth;
+      }
+      if (depth == 0 || k->end > fr[depth - 1].end || depth >= 5) return 0;
+      out->parent[next + 1] = k->parent;
+      out->begin[next + 1] = k->begin;
+      out->end[next + 1] = k->end;
+      out->s_fold_t[next + 1] = fr[depth - 1].ct++;
+      out->s_fold_p[next + 1] = fr[depth - 1].dr++;
+      fr[depth].id = next + 1; fr[depth].end = k->end; fr[depth].ct = 1; fr[depth].dr = 0; ++depth;
+      ++next;
+    }
+    if (next < n_sc && sc[next].begin < q) return 0; /* not in call order */
+    while (depth > 1 && fr[depth - 1].end <= q) --depth;
+    if (q == n_sites) break;
+    out->site_scope[q] = fr[depth - 1].id;
+    out->fold_t[q] = fr[depth - 1].ct++;
+    out->fold_p[q] = fr[depth - 1].dr;
+    if (!sites[q].observed) fr[depth - 1].dr++;
+  }
+  return next == n_sc;
+}
+
 struct gjx_plan {
   int n_sites;
   gjx_site sites[GJX_MAX_SITES];
   int n_params;
   float params[GJX_MAX_PARAMS]; /* GJX_ARG_PARAM values (gjx_plan_set_params) */
   expr_store expr;
+  scope_info scopes;
 };
 
 static int arg_ok(const gjx_arg* a, int s, int allow_site) {
@@ -378,6 +424,18 @@ int gjx_plan_create(const gjx_site* sites, int n_sites, gjx_plan** out) {
 int gjx_plan_create_ex(const gjx_site* sites, int n_sites, uint32_t flags, gjx_plan** out) {
   if (flags & ~(uint32_t)GJX_PLAN_FAST_MATH) return GJX_ERR_INVALID;
   return gjx_plan_create(sites, n_sites, out); /* the oracle is the exact specification: FAST_MATH is not its concern */
+}
+int gjx_plan_create_scoped(const gjx_site* sites, int n_sites, const gjx_scope* scopes, int n_scopes, uint32_t flags,
+                           gjx_plan** out) {
+  gjx_plan* p = NULL;
+  int rc = gjx_plan_create_ex(sites, n_sites, flags, &p);
+  if (rc) return rc;
+  if (!derive_scopes(p->sites, p->n_sites, scopes, n_scopes, &p->scopes)) {
+    gjx_plan_destroy(p);
+    return GJX_ERR_INVALID;
+  }
+  *out = p;
+  return GJX_OK;
 }
 int gjx_plan_destroy(gjx_plan* p) { free(p); return GJX_OK; }
 static int plan_max_param(const gjx_plan* p) {
@@ -433,6 +491,7 @@ typedef struct {
   const float* state;        /* smc: the ancestor's state columns (NULL at step 0) */
   const float* obs;          /* smc: this step's observation constants */
   const float* params;       /* importance: the plan's GJX_ARG_PARAM values */
+  const scope_info* scopes;  /* importance plans with nested calls (NULL / n_scopes 0: a flat body) */
 } walk_ctx;
 
 static inline float eval_arg(const gjx_arg* a, const site_val* vals, const walk_ctx* c) {
@@ -475,6 +534,16 @@ static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, sit
                       float* sc_out) {
   float w = 0.0f, sc = 0.0f;
   uint32_t draws = 0;
+  /* nested calls: scope k draws under fold_in(key of its caller, the counter the call took) */
+  const scope_info* si = (c->scopes && c->scopes->n_scopes > 0) ? c->scopes : NULL;
+  uint32_t skey[GJX_MAX_SCOPES + 1][4];
+  float sw[GJX_MAX_SCOPES + 1], ssc[GJX_MAX_SCOPES + 1];
+  for (int k = 0; k <= GJX_MAX_SCOPES; ++k) sw[k] = ssc[k] = 0.0f;
+  if (si) {
+    memcpy(skey[0], c->pkey, sizeof skey[0]);
+    for (int k = 1; k <= si->n_scopes; ++k)
+      o_fold_in(c->impl, skey[si->parent[k]], c->impl == 0 ? si->s_fold_t[k] : si->s_fold_p[k], skey[k]);
+  }
   for (int q = 0; q < n_sites; ++q) {
     const gjx_site* st = &sites[q];
     site_val v;
@@ -502,9 +571,9 @@ static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, sit
       if (v.is_int) v.i = (int32_t)rintf(ov); else v.f = ov;
     } else {
       /* THREEFRY: site counter from 1 (static.py:349-352); PHILOX: index among the sampled sites */
-      const uint32_t f = c->impl == 0 ? (uint32_t)(q + 1) : draws;
+      const uint32_t f = si ? (c->impl == 0 ? si->fold_t[q] : si->fold_p[q]) : (c->impl == 0 ? (uint32_t)(q + 1) : draws);
       ++draws;
-      o_stream strm = o_stream_make(c->impl, c->pkey, 1, f);
+      o_stream strm = o_stream_make(c->impl, si ? skey[si->site_scope[q]] : c->pkey, 1, f);
       /* one-word draws: SMC slots under PHILOX take word (slot & 3) of their quad's block number f */
       const uint32_t bits0 = c->quad_key ? o_smc_quad_word(c->quad_key, c->slot, f) : o_bits32_at(&strm, 0);
       switch (st->dist) {
@@ -526,9 +595,22 @@ static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, sit
       case GJX_DIST_BERNOULLI: lp = o_logpdf_bernoulli(v.i != 0, a0); break;
       default: lp = (v.i < 0 || v.i >= st->n_cat) ? -INFINITY : row[v.i] - row_lse(row, (uint32_t)st->n_cat);
     }
-    sc = sc + lp;
-    if (st->observed) w = w + lp;
+    if (si && si->site_scope[q] != 0) { /* a callee's weight and score are ITS totals (static.py:374-380) */
+      const int k = si->site_scope[q];
+      ssc[k] = ssc[k] + lp;
+      if (st->observed) sw[k] = sw[k] + lp;
+    } else {
+      sc = sc + lp;
+      if (st->observed) w = w + lp;
+    }
     vals[q] = v;
+    if (si)
+      for (int k = si->n_scopes; k >= 1; --k) /* the calls that return here, inner ones first */
+        if (si->end[k] == q + 1 && si->begin[k] < q + 1) {
+          const int pa = si->parent[k];
+          if (pa == 0) { w = w + sw[k]; sc = sc + ssc[k]; }
+          else { sw[pa] = sw[pa] + sw[k]; ssc[pa] = ssc[pa] + ssc[k]; }
+        }
   }
   *w_out = w;
   *sc_out = sc;
@@ -577,6 +659,7 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
     memset(&c, 0, sizeof c);
     c.impl = pk->impl;
     c.params = p->params;
+    c.scopes = &p->scopes;
     c.pair_normals = 1;
     key_at(pk, (uint64_t)i, c.pkey);
     c.in = input_cols;

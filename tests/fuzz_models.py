@@ -53,9 +53,30 @@ def random_model(rng):
     """-> (source of `def model(s, t): ...`, site names with kinds)."""
     lines, reals, poss, units, ints, sites = [], [], [], [], [], []
     params = ["t"]  # `s` is a positive argument (scales), `t` any real
+    helpers = []
     for q in range(int(rng.integers(2, 9))):
         name = f"v{q}"
         kind = rng.choice(["normal", "normal", "normal", "gamma", "beta", "flip"])
+        if rng.random() < 0.2 and len(helpers) < 3:  # a nested `@gen` call: its own sites, maybe a call of its own
+            hname, inner = f"h{len(helpers)}", []
+            if helpers and rng.random() < 0.4:
+                inner.append(f"    c = {helpers[-1]}(a * 0.5) @ 'c'")
+            hs = round(float(rng.uniform(0.3, 1.5)), 3)
+            inner.append(f"    p = normal(a{' + c' if inner else ''}, {hs}) @ 'p'")
+            if rng.random() < 0.5:
+                inner.append(f"    g = gamma(p * p + {hs}, 1.5) @ 'g'")
+                inner.append("    return p * g")
+            else:
+                inner.append("    return p + a")
+            lines_h = f"@gen\ndef {hname}(a):\n" + "\n".join(inner) + "\n"
+            helpers.append(hname)
+            pool0 = reals + poss + units
+            lines.append(f"    {name} = {hname}({_expr(rng, pool0, params)}) @ '{name}'")
+            reals.append(name)
+            sites.append((name, "call"))
+            globals().setdefault("_HELPER_SRC", {})[hname] = lines_h
+            lines.append(f"    #helper {hname}")
+            continue
         # (a flip value enters arithmetic times a literal: torch has no bool - bool, and neither has numpy)
         pool = reals + poss + units + ([f"({i} * {round(float(rng.uniform(0.5, 2.0)), 2)})" for i in ints] if rng.random() < 0.3 else [])
         if kind == "normal":
@@ -73,13 +94,18 @@ def random_model(rng):
             ints.append(name)
         sites.append((name, kind))
     ret = _expr(rng, reals + poss + units, params) if (reals + poss + units) else "0.0"
-    src = "def model(s, t):\n" + "\n".join(lines) + f"\n    return {ret}, {sites[-1][0]}\n"
+    pre = "".join(globals().get("_HELPER_SRC", {})[h] for h in helpers)
+    src = pre + "def model(s, t):\n" + "\n".join(lines) + f"\n    return {ret}, {sites[-1][0]}\n"
     return src, sites
 
 
 def random_constraint(rng, sites, n, dev):
     chm = C.n()
     for name, kind in sites:
+        if kind == "call":  # (a nested call: sometimes constrain its first site)
+            if rng.random() < 0.3:
+                chm = chm | C[name, "p"].set(float(rng.uniform(-1, 1)))
+            continue
         if rng.random() < 0.35:
             if kind == "flip":
                 v = bool(rng.integers(2))
@@ -108,7 +134,7 @@ def run(seconds: float, seed: int, impl: int = 1, n: int = 1500):
     t_end, compared, skipped = time.time() + seconds, 0, 0
     while time.time() < t_end:
         src, sites = random_model(rng)
-        ns = {"normal": normal, "gamma": gamma, "beta": beta, "flip": flip, "torch": torch}
+        ns = {"normal": normal, "gamma": gamma, "beta": beta, "flip": flip, "torch": torch, "gen": gen}
         exec(src, ns)  # noqa: S102 - generated by random_model above
         model = gen(ns["model"])
         keys = genjax.random.split(genjax.random.key(int(rng.integers(1 << 30)), impl), n)

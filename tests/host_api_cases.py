@@ -1707,7 +1707,99 @@ def case_fast_estimate_path(impl):
     assert math.isfinite(f(z))
 
 
-ALL_CASES = [case_fast_estimate_path, case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
+def case_nested_calls(impl):
+    """Nested `@gen` calls inside a fused plan (static.py:175-193, 349-352, 374-380): `callee(args) @ "addr"` takes ONE counter
+    of its caller, runs under fold_in(key, counter) and numbers its own sites afresh; its weight and score are ITS totals,
+    added to the caller's when it returns.  The body — callees in line, two levels deep, one of them without sites, one
+    called three times — is ONE kernel (gjx_plan_create_scoped), and the trace it gives (hierarchical choices, nested
+    scores and return values, the weight) equals the per-site path's bit for bit; the estimator built on it likewise."""
+    import torch
+
+    from genjax._amd import plan as P
+    from genjax._amd.lang import GenerateHandler
+
+    @gen
+    def noise(scale):
+        a = normal(0.0, scale) @ "a"
+        b = gamma(2.0, 1.5) @ "b"
+        return a * b
+
+    @gen
+    def inner(mu):
+        e = noise(0.5) @ "n"
+        x = normal(mu + e, 1.0) @ "x"
+        y = normal(x * 0.5, 0.8) @ "y"
+        return x + y
+
+    @gen
+    def empty(v):
+        return v * 2.0
+
+    @gen
+    def model(t):
+        z = normal(t, 1.0) @ "z"
+        y1 = inner(z) @ "i1"
+        k = flip(0.4) @ "k"
+        w = empty(y1) @ "e"
+        y2 = inner(w + 1.0) @ "i2"
+        u = noise(2.0) @ "u"
+        _ = normal(y1 + y2 + u, 0.7) @ "obs"
+        return y2, k
+
+    n = 3000
+    keys = genjax.random.split(genjax.random.key(3, impl), n)
+    col = torch.linspace(-1, 1, n).to(_dev())
+    for chm in (C.n(),
+                C["obs"].set(0.3) | C["i1", "x"].set(0.2) | C["i1", "y"].set(-0.1) | C["i1", "n", "a"].set(0.05) | C["i2", "n", "b"].set(1.1),
+                C["z"].set(0.1) | C["u", "a"].set(-0.4) | C["i2", "y"].set(col)):
+        fused = try_fused_generate(model, keys, chm, (0.25,))
+        assert fused is not None, "nested @gen calls must lower to the fused kernel"
+        ftr, fw = fused
+        h = GenerateHandler(keys, chm)
+        retval = h.run(model.source, (0.25,))
+        eager = StaticTrace(model, (0.25,), retval, h.traces)
+        if isinstance(h.weight, torch.Tensor):
+            assert torch.equal(fw, h.weight)
+        assert torch.equal(ftr.get_score(), eager.get_score())
+        fc, ec = dict(ftr.get_choices().leaves()), dict(eager.get_choices().leaves())
+        assert fc.keys() == ec.keys() and ("i2", "n", "b") in fc
+        for key_ in fc:
+            a_, b_ = torch.as_tensor(fc[key_]), torch.as_tensor(ec[key_])
+            if a_.dim():
+                assert torch.equal(a_, b_.to(a_.dtype).expand_as(a_)), key_
+        assert torch.equal(ftr.get_retval()[0], eager.get_retval()[0]) and torch.equal(ftr.get_retval()[1], eager.get_retval()[1])
+        for addr in ("i1", "i2", "u", "e"):
+            fs, es = ftr.get_subtrace(addr), eager.get_subtrace(addr)
+            assert torch.equal(torch.as_tensor(fs.get_score()).to(torch.float32).expand(n), torch.as_tensor(es.get_score()).to(torch.float32).expand(n)), addr
+            assert torch.equal(torch.as_tensor(fs.get_retval()), torch.as_tensor(es.get_retval())), addr
+        assert torch.equal(ftr.get_subtrace("i2").get_subtrace("n").get_score(), eager.get_subtrace("i2").get_subtrace("n").get_score())
+    # the estimator on a target with nested calls takes the one-launch route and equals the general one
+    alg = ImportanceK(Target(model, (0.25,), C["obs"].set(0.3) | C["i1", "y"].set(-0.1)), k_particles=2048)
+    key = genjax.random.key(9, impl)
+    from genjax._amd import inference as I
+    assert torch.equal(alg.log_marginal_likelihood_estimate(key), I.SMCAlgorithm.log_marginal_likelihood_estimate(alg, key))
+    assert alg.__dict__.get("_fast") is not None
+    # an address used twice inside ONE callee body is still an error; the same address in two different calls is not
+    @gen
+    def twice():
+        normal(0.0, 1.0) @ "a"
+        return normal(0.0, 1.0) @ "a"
+
+    @gen
+    def outer():
+        return twice() @ "t"
+
+    try:
+        outer.importance(keys, C.n(), ())
+        raise AssertionError("address reuse inside a callee went unnoticed")
+    except Exception as e:  # noqa: BLE001
+        assert "a" in str(e) or type(e).__name__ == "AddressReuse"
+    # scans and generated SMC filters keep nested calls on the per-site path (importance plans only)
+    tr = P._traced(model, C.n(), n, (0.25,))
+    assert tr is not None and len(tr[0].scopes) == 6
+
+
+ALL_CASES = [case_nested_calls, case_fast_estimate_path, case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
              case_static_gen_fn, case_distributions, case_uniform, case_fused_equals_eager, case_expression_arguments, case_params_equal_constants, case_trace_cache, case_particle_collection, case_custom_proposal,
              case_scan, case_scan_edge_cases, case_scan_fused_equals_loop, case_vmap, case_vmap_edge_cases, case_vmap_indexed_constraints, case_batched_estimates, case_gensp_estimators,
              case_marginal_with_algorithm, case_bootstrap_smc, case_general_smc, case_update, case_regenerate_and_rejuvenate, case_vector_valued_sites, case_index_request]

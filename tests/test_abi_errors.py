@@ -148,3 +148,22 @@ def test_expression_programs_are_validated(lib_ops):
     cat.n_cat, cat.n_rows, cat.cat_mode, cat.logits = 3, 2, 1, logits.data_ptr()
     with pytest.raises(GjxError):  # not as the row of a categorical site
         ops.plan_create([z, cat])
+
+
+def test_scoped_plans_are_validated(lib_ops):
+    """gjx_plan_create_scoped (nested `@gen` calls): scopes must be ranges of the site table in call order, each inside its
+    caller, at most four deep; anything else is GJX_ERR_INVALID from both builds."""
+    c = abi.Arg(abi.ARG_CONST, 0, 0.0, 1.0, None)
+    sites = [_site(abi.DIST_NORMAL, c, c, out_col=k) for k in range(6)]
+    good = [[(0, 1, 3)], [(0, 0, 6)], [(0, 1, 5), (1, 2, 4), (2, 2, 3)], [(0, 2, 2), (0, 2, 4)], [(0, 1, 3), (1, 3, 3), (0, 3, 5)],
+            [(0, 6, 6)]]
+    for sc in good:
+        lib_ops.plan_create(sites, scopes=sc)
+    bad = [[(0, 3, 1)], [(0, 0, 7)], [(1, 0, 2)], [(0, 2, 4), (0, 1, 3)], [(0, 1, 3), (1, 2, 4)], [(0, 1, 3), (0, 2, 5)],
+           [(0, 0, 6), (1, 0, 6), (2, 0, 6), (3, 0, 6), (4, 0, 6)], [(-1, 0, 2)], [(0, 1, 3), (1, 4, 5)]]
+    for sc in bad:
+        with pytest.raises(GjxError) as e:
+            lib_ops.plan_create(sites, scopes=sc)
+        assert e.value.code == -1, sc  # GJX_ERR_INVALID
+    with pytest.raises(GjxError):
+        lib_ops.plan_create(sites, scopes=[(0, 0, 0)] * (abi.MAX_SCOPES + 1))
