@@ -134,6 +134,12 @@ GJX_HD Key fold_in(Key k, uint32_t d) {
   return out;
 }
 
+// The key of step t of a Scan (gjx_scan_run; combinators.py Scan._run).  THREEFRY keeps jax's chain, key_t =
+// fold_in(key_{t-1}, t) (scan.py:267-268, 276).  PHILOX needs no cipher block for a key: step t of particle lane L draws
+// under (the same cipher key, lane L + (t + 1) 2^40) — lanes below 2^40, fewer than 2^24 - 1 steps — so a step's keys
+// are laned keys like a population's: particle pairs share their blocks and the Box-Muller transform of a Normal site.
+GJX_HD Key scan_step_key_philox(Key k, uint32_t t) { return Key{k.k0, k.k1, k.l0, k.l1 + ((t + 1u) << 8)}; }
+
 // PHILOX single-word draw number f of a key (f = 0-based index of the site among the body's sampled sites).
 //  * lane-0 key (a lone key): four draws per block of its own, word f & 3 of PH(ctr = (0, 0, f >> 2, 'D'), key);
 //  * laned key (lane L >= 1 = particle i = L - 1 among its parent's children): the PAIR (i, i ^ 1) shares its

@@ -2497,6 +2497,10 @@ int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
       io->n_value_cols > GJX_MAX_SITES || ((io->row_e == nullptr) != (io->row_s == nullptr)) ||
       (io->lse && (!io->row_e || !io->lse->tickets)))
     return GJX_ERR_INVALID;
+  /* PHILOX step keys put t + 1 above bit 40 of the lane */
+  if (io->particle_keys->impl == 1 &&
+      (io->n_steps >= (1 << 24) - 1 || (io->particle_keys->mode == 1 && io->particle_keys->first + io->n >= (1ull << 40))))
+    return GJX_ERR_INVALID;
   RunCols cols;
   memset(&cols, 0, sizeof(cols));
   for (int c = 0; c < io->n_value_cols; ++c) cols.out[c] = io->value_cols[c];

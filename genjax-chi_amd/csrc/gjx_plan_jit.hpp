@@ -663,12 +663,13 @@ struct GenScan {
     o << "    float tmax = -__builtin_inff();\n    bool live = false;\n";
     o << "    const uint64_t i = row * 256 + threadIdx.x;\n";
     o << "    if (i < n) {\n";
-    o << "      Key pkey = key_at<" << I << ">(ks, i);\n";
+    o << "      Key " << (impl == 0 ? "pkey" : "pkey0") << " = key_at<" << I << ">(ks, i);\n";
     for (int k = 0; k < n_state; ++k)
       o << "      float st_" << k << " = sa.carry0_cols[" << k << "] ? sa.carry0_cols[" << k << "][i] : sa.carry0[" << k << "];\n";
     o << "      float wt = 0.0f, sct = 0.0f;\n";
     o << "      for (int32_t t = 0; t < sa.n_steps; ++t) {\n";
-    o << "        pkey = fold_in<" << I << ">(pkey, (uint32_t)t);  // chained: the folded key is carried\n";
+    if (impl == 0) o << "        pkey = fold_in<0>(pkey, (uint32_t)t);  // chained: the folded key is carried (scan.py:267-268)\n";
+    else o << "        const Key pkey = scan_step_key_philox(pkey0, (uint32_t)t);  // a lane per (particle, step): no cipher block\n";
     o << "        StepObs a; a.obs = sa.obs + (size_t)t * " << n_obs << "; (void)a;\n";
     o << "        const uint64_t oi = (uint64_t)t * sa.col_stride + i; (void)oi;\n";
     o << "        float w = 0.0f, sc = 0.0f;\n";

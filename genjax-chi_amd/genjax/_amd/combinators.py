@@ -17,7 +17,8 @@ from __future__ import annotations
 import torch
 
 from .choicemap import ChoiceMap, Mask, Selection
-from .lang import GenerativeFunction, ParticleKeys, Trace, _map_any, as_particle_keys, fold_in, squeeze_leaf
+from . import prng
+from .lang import GenerativeFunction, ParticleKeys, Trace, _map_any, as_particle_keys, fold_in, scan_step_keys, squeeze_leaf
 from .ops import KeyBatch
 from .runtime import get_ops
 
@@ -155,8 +156,11 @@ class Scan(GenerativeFunction):
         pk, batched = as_particle_keys(key)
         T = self._length(xs)
         traces, ys, score, weight = [], [], 0.0, 0.0
+        pk0 = pk
         for t in range(T):
-            pk = fold_in(pk, t)  # chained: the folded key becomes the carry (scan.py:267-268,276)
+            # THREEFRY, chained: the folded key becomes the carry (scan.py:267-268, 276).  PHILOX: no cipher block for a
+            # key — step t draws under (the particle's cipher key, its lane + (t + 1) 2^40), as gjx_scan_run does
+            pk = fold_in(pk, t) if pk0.impl == prng.THREEFRY else scan_step_keys(pk0, t)
             tr, w = step(pk, t, (carry, _index_xs(xs, t)))
             carry, y = tr.get_retval()
             traces.append(tr)

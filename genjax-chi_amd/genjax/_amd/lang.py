@@ -109,6 +109,28 @@ def fold_in(key, data: int):
     raise TypeError(type(key))
 
 
+def scan_step_keys(key: ParticleKeys, t: int) -> ParticleKeys:
+    """PHILOX keys of step t of a Scan (gjx.h gjx_scan_run; gjx_device.hpp scan_step_key_philox): every particle keeps its
+    cipher key and moves to lane L + (t + 1) 2^40 — no cipher block, and for the lazy children of a lane-0 key no kernel
+    either (the batch's first lane moves)."""
+    kb, bump = key.kb, (t + 1) << 40
+    if kb.fold is not None:
+        raise ValueError("cannot step a folded key batch")
+    if t + 1 >= (1 << 24) - 1:
+        raise ValueError("a PHILOX scan has fewer than 2^24 - 1 steps")
+    if kb.mode == 1 and kb.parent_lane == 0:
+        if kb.first + key.n >= 1 << 40:
+            raise ValueError("PHILOX scan keys need lanes below 2^40")
+        return ParticleKeys(KeyBatch(kb.impl, 1, parent=kb.parent, first=kb.first + bump), key.n)
+    if kb.mode == 2:
+        return ParticleKeys(KeyBatch(kb.impl, 2, parent=kb.parent, parent_lane=kb.parent_lane + bump), key.n)
+    # explicit keys, or the hashed children of a laned parent: materialise, then move every key's lane (word 3 += (t+1) << 8)
+    keys = (kb.tensor if kb.mode == 0 else get_ops().rng_keys(kb, key.n)).clone()
+    w3 = keys[:, 3].to(torch.int64) + ((t + 1) << 8)
+    keys[:, 3] = (((w3 + (1 << 31)) % (1 << 32)) - (1 << 31)).to(keys.dtype)
+    return ParticleKeys(KeyBatch(kb.impl, 0, tensor=keys), key.n)
+
+
 def site_keys(key: ParticleKeys, fold: int, leaf: bool) -> ParticleKeys:
     """Per-`@`-site key: fold_in(key, fold) (static.py:349-352).  Leaf distributions take the
     fold lazily (fused into their kernel); nested generative functions get materialised keys."""

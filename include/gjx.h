@@ -622,9 +622,11 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
 
 /* ---- importance over a `Scan` (state-space) model: the whole T-step walk in ONE launch --------- *
  * Replaces Scan.generate (generative_functions/combinators/scan.py:237-294) under ImportanceK (no resampling): particle
- * i runs `kernel(carry, x_t) -> (carry', y_t)` for t = 0 .. T-1 with the CHAINED key key_t = fold_in(key_{t-1}, t),
- * key_{-1} = its particle key (scan.py:267-268, 276: the folded key is carried), and step t walks `step_sites` with
- * key_t exactly as gjx_importance_run walks a plan with that particle key.  GJX_ARG_STATE reads the carry, GJX_ARG_OBS
+ * i runs `kernel(carry, x_t) -> (carry', y_t)` for t = 0 .. T-1; step t walks `step_sites` with key_t exactly as
+ * gjx_importance_run walks a plan with that particle key.  THREEFRY: the CHAINED key key_t = fold_in(key_{t-1}, t),
+ * key_{-1} = the particle key (scan.py:267-268, 276: the folded key is carried).  PHILOX (r03): no cipher block for a
+ * key — key_t = (the particle's cipher key, its lane + (t + 1) 2^40); lanes < 2^40, T < 2^24 - 1 (GJX_ERR_INVALID
+ * otherwise): a step's keys are laned keys like a population's, so particle pairs share blocks and Box-Muller.  GJX_ARG_STATE reads the carry, GJX_ARG_OBS
  * this step's row of `obs` (observed values and scanned inputs x_t alike), `next_state` gives the new carry.
  * weight = ((0 + w_0) + w_1) + ..., score likewise — the f32 sums of scan.py:290, 293 in time order.  The carry and
  * the key chain live in registers; every sampled value is stored TIME-MAJOR, value_cols[c][t * col_stride + i] (each

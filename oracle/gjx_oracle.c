@@ -1611,6 +1611,10 @@ int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
       io->n_value_cols > GJX_MAX_SITES || ((io->row_e == NULL) != (io->row_s == NULL)) ||
       (io->lse && (!io->row_e || !io->lse->tickets)))
     return GJX_ERR_INVALID;
+  /* PHILOX step keys put t + 1 above bit 40 of the lane */
+  if (io->particle_keys->impl == 1 &&
+      (io->n_steps >= (1 << 24) - 1 || (io->particle_keys->mode == 1 && io->particle_keys->first + io->n >= (1ull << 40))))
+    return GJX_ERR_INVALID;
   const gjx_scan_model* m = &p->m;
   for (int q = 0; q < m->n_step_sites; ++q) {
     const gjx_site* st = &m->step_sites[q];
@@ -1631,10 +1635,15 @@ int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
     for (int k = 0; k < D; ++k)
       st[k] = (io->carry0_cols && io->carry0_cols[k]) ? io->carry0_cols[k][i] : io->carry0[k];
     for (int t = 0; t < io->n_steps; ++t) {
-      uint32_t kt[4];
-      o_fold_in(impl, key, (uint32_t)t, kt); /* chained: the folded key is carried (scan.py:267-268, 276) */
-      memcpy(key, kt, sizeof key);
-      memcpy(c.pkey, key, sizeof key);
+      if (impl == 0) {
+        uint32_t kt[4];
+        o_fold_in(impl, key, (uint32_t)t, kt); /* THREEFRY, chained: the folded key is carried (scan.py:267-268, 276) */
+        memcpy(key, kt, sizeof key);
+        memcpy(c.pkey, key, sizeof key);
+      } else { /* PHILOX: the particle's key on lane L + (t + 1) 2^40 — no cipher block for a key (gjx.h gjx_scan_run) */
+        memcpy(c.pkey, key, sizeof key);
+        c.pkey[3] = key[3] + (((uint32_t)t + 1u) << 8);
+      }
       c.state = st;
       c.obs = m->n_obs ? io->obs + (size_t)t * (size_t)m->n_obs : NULL;
       site_val vals[GJX_MAX_SITES];
