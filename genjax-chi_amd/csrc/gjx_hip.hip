@@ -2441,7 +2441,7 @@ struct gjx_scan_plan {
   uint32_t flags;
   CSite step[GJX_MAX_SITES];
   CArg next_state[GJX_SMC_MAX_STATE];
-  gjx_jit::Compiled jit[2];
+  gjx_jit::Compiled jit[3];  // THREEFRY, PHILOX one particle per lane, PHILOX four per lane (GenScan::quad)
   std::vector<void*> dev_owned;  // per-row tables of categorical sites
   std::mutex mu;
   ExprStore step_expr;  // GJX_ARG_EXPR programs
@@ -2476,19 +2476,23 @@ int gjx_scan_plan_destroy(gjx_scan_plan* p) {
   delete p;
   return GJX_OK;
 }
-static std::string scan_plan_source(const gjx_scan_plan* plan, int impl, const char** kname = nullptr, PlanTables* tabs = nullptr) {
+static std::string scan_plan_source(const gjx_scan_plan* plan, int impl, const char** kname = nullptr, PlanTables* tabs = nullptr,
+                                    bool quad = false, int* block = nullptr) {
   gjx_jit::TableScope ts;
   gjx_jit::GenScan<CSite, CArg> g;
   g.impl = impl; g.sites = plan->step; g.n_sites = plan->n_step; g.next_state = plan->next_state;
   g.n_state = plan->n_state; g.n_obs = plan->n_obs; g.fast_math = (plan->flags & GJX_PLAN_FAST_MATH) != 0;
+  g.quad = quad;
   if (kname) *kname = g.kname();
   std::string src = g.run();
   if (tabs) *tabs = ts.reg.tables();
+  if (block) *block = g.block;
   return src;
 }
 int gjx_scan_plan_compile_check(const gjx_scan_plan* p, int impl) {
   if (!p || (impl != 0 && impl != 1)) return GJX_ERR_INVALID;
   if (std::getenv("GJX_PLAN_JIT_DUMP")) fprintf(stderr, "%s\n", scan_plan_source(p, impl).c_str());
+  if (impl == 1 && !gjx_jit::compile_only(scan_plan_source(p, impl, nullptr, nullptr, true))) return GJX_ERR_UNSUPPORTED;
   return gjx_jit::compile_only(scan_plan_source(p, impl)) ? GJX_OK : GJX_ERR_UNSUPPORTED;
 }
 int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
@@ -2512,13 +2516,26 @@ int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
   const int impl = io->particle_keys->impl;
   // Scan plans exist only as specialised kernels: a failed compilation is an error, never a slower route.
   if (!gjx_jit::enabled()) return GJX_ERR_UNSUPPORTED;
-  gjx_jit::Compiled& c = p->jit[impl];
+  // PHILOX children of a lane-0 key from an even first index, n and every column a multiple of four elements: the quad form
+  // (four adjacent particles per lane share two pair blocks and two Box-Muller transforms per site and step)
+  bool quad = false;
+  {
+    const gjx_keys* pk = io->particle_keys;
+    uintptr_t al = (uintptr_t)io->logw | (uintptr_t)io->score | (uintptr_t)(4 * io->col_stride) | (uintptr_t)(4 * io->n);
+    for (int c = 0; c < io->n_value_cols; ++c) al |= (uintptr_t)io->value_cols[c];
+    for (int d = 0; d < p->n_state; ++d) al |= io->carry_out ? (uintptr_t)io->carry_out[d] : 0;
+    static const bool allow = [] { const char* e = std::getenv("GJX_SCAN_QUAD"); return !(e && e[0] == '0'); }();
+    quad = allow && impl == 1 && pk->mode == 1 && pk->parent_lane == 0 && (pk->first & 1) == 0 && (al & 15) == 0;
+  }
+  gjx_jit::Compiled& c = p->jit[quad ? 2 : impl];
   if (c.state == 0) {
     std::lock_guard<std::mutex> lock(p->mu);
     if (c.state == 0) {
       cat_tables_prepare(p->step, p->n_step, &p->dev_owned);
       const char* kname = nullptr;
-      const std::string src = scan_plan_source(p, impl, &kname, &c.tabs);
+      int block = 256;
+      const std::string src = scan_plan_source(p, impl, &kname, &c.tabs, quad, &block);
+      c.block = block;
       if (std::getenv("GJX_PLAN_JIT_DUMP")) fprintf(stderr, "%s\n", src.c_str());
       c.state = gjx_jit::compile(src, impl, &c, kname) ? 1 : -1;
     }
@@ -2540,7 +2557,7 @@ int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
   PlanTables tabs = c.tabs;
   void* args[] = {&k, &cols, &sa, &score, &logw, &mp, &row_e, &row_s, &tail, &tabs};
   const uint64_t rows = nrows_of(io->n);
-  if (hipModuleLaunchKernel(c.fn, (unsigned)(rows > 0x7fffffffull ? 0x7fffffffull : rows), 1, 1, 256, 1, 1, 0, S(s), args,
+  if (hipModuleLaunchKernel(c.fn, (unsigned)(rows > 0x7fffffffull ? 0x7fffffffull : rows), 1, 1, (unsigned)c.block, 1, 1, 0, S(s), args,
                             nullptr) != hipSuccess)
     return GJX_ERR_LAUNCH;
   return launch_status();

@@ -428,6 +428,67 @@ inline void emit_prelude(std::ostringstream& o, bool fast_math = false) {
   o << "template <int IMPL> __device__ __forceinline__ int32_t jcat_gumbel(const float* l, uint32_t K, const Stream<IMPL>& st){ int32_t best=0; float bv=-__builtin_inff(); for(uint32_t c=0;c<K;++c){ const float v = l[c] + gumbel_from_bits(st.bits32(c)); if (v>bv || c==0){ bv=v; best=(int32_t)c; } } return best; }\n";
 }
 
+// The sites of a lane that owns NP whole PAIRS of adjacent particles (suffixes A, B [, C, D]) under PHILOX: one cipher
+// block per pair and two draws (pk0 / pk1: the cipher key; pair0 [, pair1]: the pairs' counter words — defined by the
+// caller), one Box-Muller transform per pair and Normal site, every stored column one vector store at `store_at`.
+template <class CSiteT, class CArgT>
+inline void emit_pair_lane_sites(std::ostringstream& o, std::vector<SiteEmitter<CSiteT, CArgT>>& em, const CSiteT* sites, int n_sites,
+                                 int NP, const std::string& ind, const std::string& store_at) {
+  const char* sfx[4] = {"A", "B", "C", "D"};
+  const int P = 2 * NP;
+int cur_pair_blk = -1;
+  for (int q = 0; q < n_sites; ++q) {
+    const CSiteT& st = sites[q];
+    for (int u = 0; u < P; ++u) em[u].head(q);
+    const std::string Q = std::to_string(q);
+    if (!st.observed && em[0].one_word(st) && em[0].scope_of(q) == 0) {  // (a callee's sites: every particle's own lone key)
+      // draw f of a pair: block f >> 1 holds words (even, odd particle) of draw 2 (f >> 1) and of draw 2 (f >> 1) + 1
+      const uint32_t f = em[0].fold_of(q);
+      const int blk = (int)(f >> 1);
+      const std::string B = std::to_string(blk);
+      if (blk != cur_pair_blk) {
+        cur_pair_blk = blk;
+        for (int pi = 0; pi < NP; ++pi) {
+          const std::string V = "pp" + std::to_string(pi) + "_" + B;
+          o << ind << "uint32_t " << V << "_0, " << V << "_1, " << V << "_2, " << V << "_3;\n";
+          o << ind << "philox4x32(pk0, pk1, (uint32_t)pair" << pi << ", (uint32_t)(pair" << pi << " >> 32), " << blk << "u, kTagPair, " << V
+            << "_0, " << V << "_1, " << V << "_2, " << V << "_3);\n";
+        }
+      }
+      for (int pi = 0; pi < NP; ++pi) {
+        const std::string V = "pp" + std::to_string(pi) + "_" + B;
+        o << ind << "const uint32_t bits" << Q << sfx[2 * pi] << " = " << V << "_" << ((f & 1u) << 1) << ", bits" << Q << sfx[2 * pi + 1]
+          << " = " << V << "_" << (((f & 1u) << 1) | 1u) << ";\n";
+      }
+    }
+    if (!st.observed && st.dist == GJX_DIST_NORMAL && em[0].scope_of(q) == 0) {
+      for (int pi = 0; pi < NP; ++pi) {
+        const std::string Z = Q + "_" + std::to_string(pi);
+        o << ind << "float zc" << Z << ", zs" << Z << ";\n      bm_pair(bits" << Q << sfx[2 * pi] << ", bits" << Q << sfx[2 * pi + 1] << ", zc" << Z
+          << ", zs" << Z << ");\n";
+      }
+      for (int pi = 0; pi < NP; ++pi) {
+        const std::string Z = Q + "_" + std::to_string(pi);
+        em[2 * pi].tail(q, "zc" + Z);
+        em[2 * pi + 1].tail(q, "zs" + Z);
+      }
+    } else {
+      for (int u = 0; u < P; ++u) em[u].tail(q);
+    }
+    for (int u = 0; u < P; ++u) em[u].close_scopes(q + 1);
+    if (st.out_col >= 0) {  // the lane's particles are adjacent in the column: one 8- / 16-byte store per lane
+      const bool isint = SiteEmitter<CSiteT, CArgT>::is_int(st);
+      std::string vals;
+      for (int u = 0; u < P; ++u)
+        vals += (u ? ", " : "") + (isint ? "(uint32_t)vi" + Q + sfx[u] : "f2u(vf" + Q + sfx[u] + ")");
+      o << "#ifndef GJX_EXP_NO_VALUE_STORES\n";
+      o << ind << "*reinterpret_cast<uint" << P << "*>(reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "]) + " << store_at << ") = make_uint" << P
+        << "(" << vals << ");\n";
+      o << "#endif\n";
+    }
+  }
+}
+
 // The importance kernel of a plan.  Two forms:
 //  * generic: one 256-particle row per 256-thread workgroup, one particle per lane, any key batch;
 //  * paired (PHILOX, lazy children of a lane-0 key, even first index): one row per 128-thread workgroup,
@@ -510,57 +571,7 @@ struct Gen {
     for (int u = 0; u < P; ++u) em[u].emit_scope_keys();
     o << "      const uint64_t pair0 = (lnA - 1u) >> 1;\n";
     if (NP == 2) o << "      const uint64_t pair1 = pair0 + 1u;\n";
-    int cur_pair_blk = -1;
-    for (int q = 0; q < n_sites; ++q) {
-      const CSiteT& st = sites[q];
-      for (int u = 0; u < P; ++u) em[u].head(q);
-      const std::string Q = std::to_string(q);
-      if (!st.observed && em[0].one_word(st) && em[0].scope_of(q) == 0) {  // (a callee's sites: every particle's own lone key)
-        // draw f of a pair: block f >> 1 holds words (even, odd particle) of draw 2 (f >> 1) and of draw 2 (f >> 1) + 1
-        const uint32_t f = em[0].fold_of(q);
-        const int blk = (int)(f >> 1);
-        const std::string B = std::to_string(blk);
-        if (blk != cur_pair_blk) {
-          cur_pair_blk = blk;
-          for (int pi = 0; pi < NP; ++pi) {
-            const std::string V = "pp" + std::to_string(pi) + "_" + B;
-            o << "      uint32_t " << V << "_0, " << V << "_1, " << V << "_2, " << V << "_3;\n";
-            o << "      philox4x32(pk0, pk1, (uint32_t)pair" << pi << ", (uint32_t)(pair" << pi << " >> 32), " << blk << "u, kTagPair, " << V
-              << "_0, " << V << "_1, " << V << "_2, " << V << "_3);\n";
-          }
-        }
-        for (int pi = 0; pi < NP; ++pi) {
-          const std::string V = "pp" + std::to_string(pi) + "_" + B;
-          o << "      const uint32_t bits" << Q << sfx[2 * pi] << " = " << V << "_" << ((f & 1u) << 1) << ", bits" << Q << sfx[2 * pi + 1]
-            << " = " << V << "_" << (((f & 1u) << 1) | 1u) << ";\n";
-        }
-      }
-      if (!st.observed && st.dist == GJX_DIST_NORMAL && em[0].scope_of(q) == 0) {
-        for (int pi = 0; pi < NP; ++pi) {
-          const std::string Z = Q + "_" + std::to_string(pi);
-          o << "      float zc" << Z << ", zs" << Z << ";\n      bm_pair(bits" << Q << sfx[2 * pi] << ", bits" << Q << sfx[2 * pi + 1] << ", zc" << Z
-            << ", zs" << Z << ");\n";
-        }
-        for (int pi = 0; pi < NP; ++pi) {
-          const std::string Z = Q + "_" + std::to_string(pi);
-          em[2 * pi].tail(q, "zc" + Z);
-          em[2 * pi + 1].tail(q, "zs" + Z);
-        }
-      } else {
-        for (int u = 0; u < P; ++u) em[u].tail(q);
-      }
-      for (int u = 0; u < P; ++u) em[u].close_scopes(q + 1);
-      if (st.out_col >= 0) {  // the lane's particles are adjacent in the column: one 8- / 16-byte store per lane
-        const bool isint = SiteEmitter<CSiteT, CArgT>::is_int(st);
-        std::string vals;
-        for (int u = 0; u < P; ++u)
-          vals += (u ? ", " : "") + (isint ? "(uint32_t)vi" + Q + sfx[u] : "f2u(vf" + Q + sfx[u] + ")");
-        o << "#ifndef GJX_EXP_NO_VALUE_STORES\n";
-        o << "      *reinterpret_cast<uint" << P << "*>(reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "]) + po + iA) = make_uint" << P
-          << "(" << vals << ");\n";
-        o << "#endif\n";
-      }
-    }
+    emit_pair_lane_sites<CSiteT, CArgT>(o, em, sites, n_sites, NP, "      ", "po + iA");
     {
       std::string ws, ss;
       for (int u = 0; u < P; ++u) { ws += (u ? ", w" : "w") + std::string(sfx[u]); ss += (u ? ", sc" : "sc") + std::string(sfx[u]); }
@@ -650,8 +661,73 @@ struct GenScan {
   const CArgT* next_state;
   int n_state, n_obs;
   bool fast_math = false;
+  bool quad = false;  // PHILOX, the lazy children of a lane-0 key, n and the columns multiples of four: FOUR adjacent particles
+                      // per lane (one wave per 256-particle row).  A step's keys are lanes (scan_step_key_philox), so the
+                      // lane's two pairs share their cipher blocks and Box-Muller transforms exactly as in the importance
+                      // kernel's quad form; row statistics are wave reductions, every store is 16 bytes per lane.
+  int block = 256;
   const char* kname() const { return impl == 0 ? "gjx_scan_kernel_threefry" : "gjx_scan_kernel_philox"; }
+  std::string run_quad() {
+    block = 64;
+    const char* sfx[4] = {"A", "B", "C", "D"};
+    const int P = 4;
+    emit_prelude(o, fast_math);
+    o << "struct StepObs { const float* obs; };\n";
+    o << "extern \"C\" __global__ __launch_bounds__(64) void " << kname()
+      << "(KeySrc ks, RunCols cols, ScanArgs sa, float* score, float* logw, float* max_partials, int32_t* row_e, uint64_t* row_s, LseTail tail, PlanTables tabs) {\n";
+    o << "  const uint64_t n = sa.n, rows_all = (n + 255) / 256;\n";
+    o << "  const uint32_t pk0 = ks.parent.k0, pk1 = ks.parent.k1;\n";
+    o << "  for (uint64_t row = blockIdx.x; row < rows_all; row += gridDim.x) {\n";
+    o << "    const uint64_t iA = row * 256 + 4 * (uint64_t)threadIdx.x;\n";
+    o << "    const bool ok = iA < n;  // (n is a multiple of four in this form: all particles of a lane exist or none)\n";
+    for (int u = 0; u < P; ++u) o << "    float wt" << sfx[u] << " = 0.0f, sct" << sfx[u] << " = 0.0f;\n";
+    o << "    if (ok) {\n";
+    o << "      const uint64_t lnA = ks.first + iA + 1u;\n";
+    for (int u = 0; u < P; ++u)
+      for (int k = 0; k < n_state; ++k)
+        o << "      float st_" << k << sfx[u] << " = sa.carry0_cols[" << k << "] ? sa.carry0_cols[" << k << "][iA + " << u << "] : sa.carry0[" << k << "];\n";
+    o << "      for (int32_t t = 0; t < sa.n_steps; ++t) {\n";
+    o << "        const uint64_t lt = lnA + (((uint64_t)(uint32_t)t + 1u) << 40);  // the lanes of step t (scan_step_key_philox)\n";
+    for (int u = 0; u < P; ++u)
+      o << "        const Key pkey" << sfx[u] << "{pk0, pk1, (uint32_t)(lt + " << u << "u), (uint32_t)((lt + " << u << "u) >> 32)}; (void)pkey" << sfx[u] << ";\n";
+    o << "        const uint64_t pair0 = (lt - 1u) >> 1, pair1 = pair0 + 1u;\n";
+    o << "        StepObs a; a.obs = sa.obs + (size_t)t * " << n_obs << "; (void)a;\n";
+    o << "        const uint64_t oiA = (uint64_t)t * sa.col_stride + iA; (void)oiA;\n";
+    for (int u = 0; u < P; ++u) o << "        float w" << sfx[u] << " = 0.0f, sc" << sfx[u] << " = 0.0f;\n";
+    std::vector<SiteEmitter<CSiteT, CArgT>> em;
+    for (int u = 0; u < P; ++u) {
+      em.push_back(SiteEmitter<CSiteT, CArgT>{o, impl, 2, sites, n_sites, "        ", sfx[u]});
+      em.back().store_values = false;
+      em.back().ext_bits = true;
+    }
+    emit_pair_lane_sites<CSiteT, CArgT>(o, em, sites, n_sites, 2, "        ", "oiA");
+    for (int u = 0; u < P; ++u)
+      for (int k = 0; k < n_state; ++k) o << "        const float nx_" << k << sfx[u] << " = " << em[u].arg(next_state[k]) << ";\n";
+    for (int u = 0; u < P; ++u)
+      for (int k = 0; k < n_state; ++k) o << "        st_" << k << sfx[u] << " = nx_" << k << sfx[u] << ";\n";
+    for (int u = 0; u < P; ++u) o << "        wt" << sfx[u] << " = wt" << sfx[u] << " + w" << sfx[u] << "; sct" << sfx[u] << " = sct" << sfx[u] << " + sc" << sfx[u] << ";\n";
+    o << "      }\n";
+    for (int k = 0; k < n_state; ++k)
+      o << "      if (sa.carry_out[" << k << "]) *reinterpret_cast<float4*>(sa.carry_out[" << k << "] + iA) = make_float4(st_" << k << "A, st_" << k
+        << "B, st_" << k << "C, st_" << k << "D);\n";
+    o << "      if (logw) *reinterpret_cast<float4*>(logw + iA) = make_float4(wtA, wtB, wtC, wtD);\n";
+    o << "      if (score) *reinterpret_cast<float4*>(score + iA) = make_float4(sctA, sctB, sctC, sctD);\n";
+    o << "    }\n";
+    o << "    if (max_partials || row_e) {\n";
+    o << "      const float ninf = -__builtin_inff();\n";
+    o << "      const float m4 = ((wtA > wtB ? wtA : wtB) > wtC ? (wtA > wtB ? wtA : wtB) : wtC);\n";
+    o << "      const float bm = wave_max(ok ? (m4 > wtD ? m4 : wtD) : ninf);\n";
+    o << "      if (max_partials && threadIdx.x == 0) max_partials[row] = bm;\n";
+    o << "      if (row_e) {\n";
+    o << "        const int32_t eb = row_anchor(bm);\n";
+    o << "        const uint64_t sb = wave_sum(ok ? (rowfix(wtA, eb) + rowfix(wtB, eb) + rowfix(wtC, eb) + rowfix(wtD, eb)) : 0);\n";
+    o << "        if (threadIdx.x == 0) lse_store_row(row_e, row_s, row, eb, sb, tail.tickets != nullptr);\n";
+    o << "      }\n    }\n";
+    o << "  }\n  if (row_e) lse_tail(row_e, row_s, (n + 255) / 256, tail);\n}\n";
+    return o.str();
+  }
   std::string run() {
+    if (quad && impl == 1) return run_quad();
     const std::string I = std::to_string(impl);
     emit_prelude(o, fast_math);
     o << "struct StepObs { const float* obs; };\n";
