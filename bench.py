@@ -54,7 +54,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=1024)
     p.add_argument("--warmup", type=int, default=64)
-    p.add_argument("--workload", default="importance", choices=["importance", "smc_lgssm", "smc_hmm", "scan_lgssm"])
+    p.add_argument("--workload", default="importance", choices=["importance", "smc_lgssm", "smc_hmm", "scan_lgssm", "scan_hmm"])
     p.add_argument("--fast-math", action="store_true", help="importance / scan: the opt-in hardware-transcendental plan (profiling passes)")
     p.add_argument("--rng", default="philox", choices=["philox", "threefry"])
     p.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
@@ -1023,9 +1023,10 @@ def run_rank(args):
     ops = load_hip_ops()  # raises without libgjx_hip.so / a GPU: there is no CPU fallback
     sharded = world > 1 or FORCE_DIST
     smc_gpu = None
-    if args.workload == "scan_lgssm":  # profiling passes of the one-launch scan (an `extra` entry of the default run)
+    if args.workload in ("scan_lgssm", "scan_hmm"):  # profiling passes of the one-launch scans (`extra` entries of the default run)
         if rank == 0:
-            emit_line(bench_scan(args, ops, fast_math=args.fast_math, with_host_loop=False))
+            emit_line(bench_scan(args, ops, fast_math=args.fast_math, with_host_loop=False) if args.workload == "scan_lgssm"
+                      else bench_scan_hmm(args, ops))
         return
     if args.workload == "importance":
         res, _ = bench_importance(args, ops, rank, world, fast_math=args.fast_math)

@@ -19,17 +19,23 @@ CMD[importance_fast]="python3 bench.py --steps 48 --warmup 8 --no-cpu-baseline -
 CMD[smc_lgssm]="python3 bench.py --workload smc_lgssm --no-cpu-baseline --steps 2 --warmup 1"
 CMD[smc_hmm]="python3 bench.py --workload smc_hmm --no-cpu-baseline --steps 2 --warmup 1"
 CMD[scan_lgssm]="python3 bench.py --workload scan_lgssm --no-cpu-baseline"
+CMD[scan_hmm]="python3 bench.py --workload scan_hmm --no-cpu-baseline"
 CMD[importance_threefry]="python3 bench.py --steps 24 --warmup 8 --no-cpu-baseline --no-extra --rng threefry"
 SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM"
 SQ2="SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32"
 # (counter passes: 8 importance passes per launch, so that every launch of these runs covers the same work)
 export GJX_BENCH_FILTERS=1 GJX_BENCH_MIN_S=0.01 GJX_BENCH_LAUNCH=8
-for w in importance importance_fast importance_threefry smc_lgssm smc_hmm scan_lgssm; do
+for w in importance importance_fast importance_threefry smc_lgssm smc_hmm scan_lgssm scan_hmm; do
   timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${w}_fetch" -- ${CMD[$w]} > "$OUT/${w}_fetch.log" 2>&1 || exit 1
   timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${w}_write" -- ${CMD[$w]} > "$OUT/${w}_write.log" 2>&1 || exit 1
   timeout -k 10 200 rocprofv3 --pmc $SQ1 --output-format csv -d "$OUT/${w}_sq1" -- ${CMD[$w]} > "$OUT/${w}_sq1.log" 2>&1 || exit 1
   timeout -k 10 200 rocprofv3 --pmc $SQ2 --output-format csv -d "$OUT/${w}_sq2" -- ${CMD[$w]} > "$OUT/${w}_sq2.log" 2>&1 || exit 1
   echo "$w counters done"
+done
+# L2 behaviour of the scans (the HMM scan reads scattered table lines): hits, misses, requests per launch
+L2="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
+for w in scan_lgssm scan_hmm; do
+  timeout -k 10 200 rocprofv3 --pmc $L2 --output-format csv -d "$OUT/${w}_l2" -- ${CMD[$w]} > "$OUT/${w}_l2.log" 2>&1 || echo "$w: no L2 counters (see ${w}_l2.log)"
 done
 unset GJX_BENCH_RAMP GJX_BENCH_MIN_S GJX_BENCH_LAUNCH
 # 3. the plain bench line of the same build

@@ -111,7 +111,27 @@ for w in ("smc_lgssm", "smc_hmm"):
 smc["note"] = "one filter of 1e6 particles (the literal BASELINE configs): per launch = per SMC step; FETCH_SIZE doubled (gfx950)"
 json.dump(smc, open(os.path.join(here, f"{tag}_smc_pmc.json"), "w"), indent=1)
 
-scan = kernel_block("scan_lgssm", ("gjx_scan_kernel",), 100_000_000, "particle_steps_per_launch")
+scan = {}
+for w, units in (("scan_lgssm", 100_000_000), ("scan_hmm", 500_000_000)):
+    try:
+        blk = kernel_block(w, ("gjx_scan_kernel",), units, "particle_steps_per_launch")
+        try:  # L2 hits / misses / requests per launch (their own pass)
+            for (name, grid), cs in counters(f"{w}_l2").items():
+                for k, e in blk.items():
+                    if k.startswith(name[:90]) and e["grid_threads"] == grid:
+                        e["l2_per_launch"] = {c: sum(v) / len(v) for c, v in cs.items()}
+        except Exception as ex:  # reported, not fatal
+            for e in blk.values():
+                e["l2_per_launch"] = {"error": repr(ex)}
+        for e in blk.values():
+            sq = e.get("sq_per_launch", {})
+            if "SQ_INSTS_VALU" in sq:
+                e["valu_wave_instructions_per_particle_step"] = sq["SQ_INSTS_VALU"] * 64 / e["particle_steps_per_launch"]
+        scan[w] = blk
+    except Exception as ex:
+        scan[w] = {"error": repr(ex)}
+scan["note"] = ("one launch = the whole scan of the population (LGSSM: 1e6 particles x 100 steps; HMM-256: 1e6 x 500); FETCH_SIZE doubled "
+                "(gfx950); valu_wave_instructions_per_particle_step = SQ_INSTS_VALU x 64 lanes / particle-steps")
 json.dump(scan, open(os.path.join(here, f"{tag}_scan_pmc.json"), "w"), indent=1)
 
 bench = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
