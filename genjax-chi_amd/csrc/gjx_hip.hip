@@ -1113,6 +1113,179 @@ __global__ __launch_bounds__(kBlock) void k_hmm_init(FilterBatch fb, Key step_ke
   emit_init_tile(w, ok, em, loc, first_slot / kTile + ltile);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Generated SMC filters WITHOUT the compiler: a table-walking policy (GJX_PLAN_JIT=0, or a failed compilation with
+// GJX_PLAN_JIT_FALLBACK=1).  One slot at a time, the site table read from device memory, the values of earlier sites in a
+// per-thread array — the same device functions in the same order as the generated policy (gjx_plan_jit.hpp GenSmc), so the
+// same bits; several times slower (PHILOX: every slot derives its quad's block itself).  Programs (GJX_ARG_EXPR) are
+// compiled, never interpreted: such filters have no route here.
+struct InterpTable {
+  const CSite* sites;  // device copy of the plan's init / step table
+  int32_t n_sites, n_state;
+  CArg state_args[GJX_SMC_MAX_STATE];
+};
+GJX_DEV float interp_site_f32(const CSite* sites, const uint32_t* vals, int q) {
+  return sites[q].dist >= GJX_DIST_BERNOULLI ? (float)(int32_t)vals[q] : u2f(vals[q]);
+}
+GJX_DEV int32_t interp_site_i32(const CSite* sites, const uint32_t* vals, int q) {
+  return sites[q].dist >= GJX_DIST_BERNOULLI ? (int32_t)vals[q] : (int32_t)__builtin_rintf(u2f(vals[q]));
+}
+GJX_DEV float interp_arg(const CArg& a, const CSite* sites, const uint32_t* vals, const float* st, const float* obs) {
+  switch (a.kind) {
+    case GJX_ARG_CONST: return a.offset;
+    case GJX_ARG_SITE: return (a.scale * interp_site_f32(sites, vals, a.ref_site)) + a.offset;
+    case GJX_ARG_STATE: return (a.scale * st[a.ref]) + a.offset;
+    case GJX_ARG_OBS: return (a.scale * obs[a.ref]) + a.offset;
+    default: return a.table[interp_site_i32(sites, vals, a.ref_site)];  // GJX_ARG_TABLE
+  }
+}
+template <int IMPL>
+GJX_DEV float interp_walk(const InterpTable& T, const float* obs, Key step_key, int64_t j, const float* st, float* st_out) {
+  uint32_t vals[GJX_MAX_SITES];
+  float w = 0.0f;
+  const Key pkey = slot_key<IMPL>(step_key, (uint64_t)j);
+  uint32_t draws = 0;
+  for (int q = 0; q < T.n_sites; ++q) {
+    const CSite& s = T.sites[q];
+    const bool isint = s.dist >= GJX_DIST_BERNOULLI;
+    float a0 = 0.0f, a1 = 0.0f;
+    const float* row = nullptr;
+    if (s.dist == GJX_DIST_CATEGORICAL) {
+      int32_t rr = s.a0.kind == GJX_ARG_SITE ? interp_site_i32(T.sites, vals, s.a0.ref_site)
+                   : (int32_t)__builtin_rintf(s.a0.kind == GJX_ARG_CONST ? s.a0.offset : interp_arg(s.a0, T.sites, vals, st, obs));
+      rr = rr < 0 ? 0 : (rr >= s.n_rows ? s.n_rows - 1 : rr);
+      row = s.logits + (size_t)rr * s.n_cat;
+    } else {
+      a0 = interp_arg(s.a0, T.sites, vals, st, obs);
+      if (s.dist != GJX_DIST_BERNOULLI) a1 = interp_arg(s.a1, T.sites, vals, st, obs);
+    }
+    float vf = 0.0f;
+    int32_t vi = 0;
+    if (s.observed) {
+      const float ov = s.obs.kind == GJX_ARG_CONST ? s.obs.offset : obs[s.obs.ref];
+      if (isint) vi = (int32_t)__builtin_rintf(ov);
+      else vf = ov;
+    } else {
+      const uint32_t fold = IMPL == 0 ? (uint32_t)(q + 1) : draws;  // THREEFRY: the `@` counter; PHILOX: index among the draws
+      ++draws;
+      uint32_t qw[4] = {0u, 0u, 0u, 0u};
+      uint32_t bits = 0u;
+      const bool one_word = s.dist == GJX_DIST_NORMAL || s.dist == GJX_DIST_BERNOULLI || (s.dist == GJX_DIST_CATEGORICAL && s.cat_mode == 1);
+      if (one_word) {
+        if (IMPL == 0) {
+          bits = Stream<IMPL>(pkey, true, fold).bits32(0);
+        } else {  // one block per quad of slots and draw: slot u takes word u
+          const uint64_t g = (uint64_t)j >> 2;
+          philox4x32(step_key.k0, step_key.k1, (uint32_t)g, (uint32_t)(g >> 32), fold, kTagQuad, qw[0], qw[1], qw[2], qw[3]);
+          const uint32_t u = (uint32_t)j & 3u;
+          bits = u == 0 ? qw[0] : (u == 1 ? qw[1] : (u == 2 ? qw[2] : qw[3]));
+        }
+      }
+      switch (s.dist) {
+        case GJX_DIST_NORMAL: {
+          float eps;
+          if (IMPL == 0) {
+            eps = std_normal(bits);
+          } else {  // two Box-Muller transforms over the quad's words: (w0, w1) -> slots 0, 1; (w2, w3) -> slots 2, 3
+            float zc, zs;
+            if ((uint32_t)j & 2u) bm_pair(qw[2], qw[3], zc, zs);
+            else bm_pair(qw[0], qw[1], zc, zs);
+            eps = ((uint32_t)j & 1u) ? zs : zc;
+          }
+          const float t = a1 * eps;
+          vf = a0 + t;
+          break;
+        }
+        case GJX_DIST_BERNOULLI: vi = uniform01(bits) < a0 ? 1 : 0; break;
+        case GJX_DIST_GAMMA: {
+          const Stream<IMPL> strm(pkey, true, fold);
+          vf = std_gamma<IMPL>(strm, 0, a0) / a1;
+          break;
+        }
+        case GJX_DIST_BETA: {
+          const Stream<IMPL> strm(pkey, true, fold);
+          const float g1 = std_gamma<IMPL>(strm, 0, a0);
+          const float g2 = std_gamma<IMPL>(strm, 1, a1);
+          vf = g1 / (g1 + g2);
+          break;
+        }
+        default:
+          if (s.cat_mode == 0) vi = cat_gumbel<IMPL>(row, (uint32_t)s.n_cat, Stream<IMPL>(pkey, true, fold));
+          else vi = cat_invcdf(row, (uint32_t)s.n_cat, bits);
+      }
+    }
+    float lp;
+    switch (s.dist) {
+      case GJX_DIST_NORMAL: lp = logpdf_normal(vf, a0, a1); break;
+      case GJX_DIST_GAMMA: lp = logpdf_gamma(vf, a0, a1); break;
+      case GJX_DIST_BETA: lp = logpdf_beta(vf, a0, a1); break;
+      case GJX_DIST_BERNOULLI: lp = logpdf_bernoulli(vi != 0, a0); break;
+      default: lp = (vi < 0 || vi >= s.n_cat) ? -__builtin_inff() : row[vi] - row_lse(row, (uint32_t)s.n_cat);
+    }
+    if (s.observed) w = w + lp;
+    vals[q] = isint ? (uint32_t)vi : f2u(vf);
+  }
+  float nx[GJX_SMC_MAX_STATE];
+  for (int k = 0; k < T.n_state; ++k) nx[k] = interp_arg(T.state_args[k], T.sites, vals, st, obs);
+  for (int k = 0; k < T.n_state; ++k) st_out[k] = nx[k];
+  return w;
+}
+template <int IMPL>
+struct InterpPolicy {
+  static constexpr bool kEmit = true;
+  PlanPolicyArgs a;
+  InterpTable T;
+  struct Out { float s[GJX_SMC_MAX_STATE]; };
+  GJX_DEV void select_filter(uint64_t off, Key k) {
+    for (int c = 0; c < T.n_state; ++c) { a.prev_state[c] += off; a.state_out[c] += off; }
+    if (a.anc_out) a.anc_out += off;
+    a.step_key = k;
+  }
+  GJX_DEV float compute(int64_t j, uint32_t src_global, Out& out) const {
+    float st[GJX_SMC_MAX_STATE];
+    for (int k = 0; k < T.n_state; ++k) st[k] = a.prev_state[k][src_global];
+    return interp_walk<IMPL>(T, a.obs, a.step_key, j, st, out.s);
+  }
+  GJX_DEV void store(int64_t j, int64_t out_lo, uint32_t src, const Out& out) const {
+    for (int k = 0; k < T.n_state; ++k) a.state_out[k][j - out_lo] = out.s[k];
+    if (a.anc_out) a.anc_out[j - out_lo] = (int32_t)src;
+  }
+};
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_smc_interp_step(ResampleArgs A, PlanPolicyArgs PA, InterpTable T) {
+  InterpPolicy<IMPL> P;
+  P.a = PA;
+  P.T = T;
+  resample_body<IMPL>(A, P);
+}
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_smc_interp_init(PlanPolicyArgs a, uint64_t first_slot, uint64_t n_local, EmitOut em,
+                                                            FilterBatch fb, InterpTable T) {
+  uint64_t ltile = blockIdx.x;
+  if (fb.n_filters > 1) {  // several filters per launch: tile of filter f, its key, its outputs
+    const uint32_t f = (uint32_t)(ltile / fb.tiles);
+    ltile -= (uint64_t)f * fb.tiles;
+    a.step_key = fb.step_key[f];
+    for (int k = 0; k < T.n_state; ++k) a.state_out[k] += (uint64_t)f * fb.stride;
+    if (a.anc_out) a.anc_out += (uint64_t)f * fb.stride;
+    select_filter_emit(em, fb, f);
+  }
+  const uint64_t loc = ltile * kTile + 4 * (uint64_t)threadIdx.x;
+  const uint64_t gq = first_slot + loc;
+  float wq[4];
+  bool okq[4];
+  for (int u = 0; u < 4; ++u) {
+    okq[u] = loc + u < n_local;
+    float ns[GJX_SMC_MAX_STATE];
+    wq[u] = interp_walk<IMPL>(T, a.obs, a.step_key, (int64_t)(gq + u), nullptr, ns);
+    if (okq[u]) {
+      for (int k = 0; k < T.n_state; ++k) a.state_out[k][loc + u] = ns[k];
+      if (a.anc_out) a.anc_out[loc + u] = (int32_t)(gq + u);
+    }
+  }
+  emit_init_tile(wq, okq, em, loc, first_slot / kTile + ltile);
+}
+
 // HMM tables.  Alias construction in integers (DESIGN.md 3.6b states it in full): p_c = cat_fix, scaled_c = p_c K
 // against Q = sum p; "small" columns (scaled < Q) in increasing order take their alias from the front "large"
 // column, which gives up the difference and joins the back of the small queue once below Q.
@@ -2573,6 +2746,8 @@ struct gjx_smc_plan {
   std::mutex mu;
   ExprStore init_expr, step_expr;  // GJX_ARG_EXPR programs of the two tables
   StateExprStore init_state_expr, next_state_expr;
+  bool has_expr = false;                              // any program?  Then the filter runs as generated kernels only
+  CSite* dev_init = nullptr; CSite* dev_step = nullptr;  // the interpreter's device copies of the tables (made on first use)
 };
 
 int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
@@ -2596,10 +2771,12 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
     delete p;
     return GJX_ERR_INVALID;
   }
-  (void)expr_adopt(p->init, p->n_init, &p->init_expr);
-  (void)expr_adopt(p->step, p->n_step, &p->step_expr);
+  p->has_expr = expr_adopt(p->init, p->n_init, &p->init_expr);
+  p->has_expr = expr_adopt(p->step, p->n_step, &p->step_expr) || p->has_expr;
   state_expr_adopt(p->init_state, p->n_state, &p->init_state_expr);
   state_expr_adopt(p->next_state, p->n_state, &p->next_state_expr);
+  for (int k = 0; k < p->n_state; ++k)
+    p->has_expr = p->has_expr || p->init_state[k].kind == GJX_ARG_EXPR || p->next_state[k].kind == GJX_ARG_EXPR;
   *out = p;
   return GJX_OK;
 }
@@ -2607,6 +2784,8 @@ int gjx_smc_plan_destroy(gjx_smc_plan* p) {
   if (!p) return GJX_OK;
   for (auto& c : p->jit) gjx_jit::release_smc(&c);  // compiled modules are owned by the process-wide (bounded) cache
   free_owned(p->dev_owned);
+  if (p->dev_init) (void)hipFree(p->dev_init);
+  if (p->dev_step) (void)hipFree(p->dev_step);
   delete p;
   return GJX_OK;
 }
@@ -2638,8 +2817,23 @@ int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl) {
   return gjx_jit::compile_only(smc_plan_source(p, impl)) ? GJX_OK : GJX_ERR_UNSUPPORTED;
 }
 
+// The interpreter's device copies of the site tables (GJX_PLAN_JIT=0 / a failed compilation with the fallback allowed).
+static int smc_plan_interp_tables(gjx_smc_plan* plan) {
+  std::lock_guard<std::mutex> lock(plan->mu);
+  if (plan->dev_init && plan->dev_step) return GJX_OK;
+  CSite* di = nullptr; CSite* ds = nullptr;
+  if (hipMalloc((void**)&di, sizeof(CSite) * (size_t)plan->n_init) != hipSuccess) return GJX_ERR_LAUNCH;
+  if (hipMalloc((void**)&ds, sizeof(CSite) * (size_t)plan->n_step) != hipSuccess) { (void)hipFree(di); return GJX_ERR_LAUNCH; }
+  if (hipMemcpy(di, plan->init, sizeof(CSite) * (size_t)plan->n_init, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(ds, plan->step, sizeof(CSite) * (size_t)plan->n_step, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(di); (void)hipFree(ds);
+    return GJX_ERR_LAUNCH;
+  }
+  plan->dev_init = di; plan->dev_step = ds;
+  return GJX_OK;
+}
 static gjx_jit::CompiledSmc* smc_plan_compiled(gjx_smc_plan* plan, int impl) {
-  if (!gjx_jit::enabled()) return nullptr;  // SMC plans exist only as specialised kernels
+  if (!gjx_jit::enabled()) return nullptr;  // (GJX_PLAN_JIT=0: the table-walking policy, smc_plan_route)
   gjx_jit::CompiledSmc& c = plan->jit[impl];
   if (c.state == 0) {
     std::lock_guard<std::mutex> lock(plan->mu);
@@ -2654,7 +2848,18 @@ static gjx_jit::CompiledSmc* smc_plan_compiled(gjx_smc_plan* plan, int impl) {
 
 // One step of a plan-driven filter: the generated init kernel (t == 0) or the generated policy inside the fused
 // resample kernel, for the output slots [first_slot, first_slot + n_local) of cfg.
-static int smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, gjx_jit::CompiledSmc& c, int t,
+// Which route a generated filter takes: its compiled kernels; or, with the compiler switched off (GJX_PLAN_JIT=0) or failed
+// and GJX_PLAN_JIT_FALLBACK=1, the table-walking policy (k_smc_interp_*: same bits, several times slower) — unless the
+// model holds programs (compiled, never interpreted).  *c_out = nullptr means the interpreter.
+static int smc_plan_route(gjx_smc_plan* plan, int impl, gjx_jit::CompiledSmc** c_out) {
+  *c_out = smc_plan_compiled(plan, impl);
+  if (*c_out) return GJX_OK;
+  const bool off = !gjx_jit::enabled();
+  if (!off && !jit_fallback_allowed()) return GJX_ERR_JIT;  // loud: never a silent slower route
+  if (plan->has_expr) return off ? GJX_ERR_UNSUPPORTED : GJX_ERR_JIT;
+  return smc_plan_interp_tables(plan);
+}
+static int smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, gjx_jit::CompiledSmc* cp, int t,
                          const float* obs_t, const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* prev_e_out,
                          uint64_t* prev_q_out, int32_t* ancestors_out, gjx_stream s, const StepCtx& ctx) {
   const bool ad = cfg_adaptive(cfg);
@@ -2672,21 +2877,39 @@ static int smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, gjx_jit:
   PA.anc_out = ancestors_out;
   PA.step_key = Key{cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1]};
   for (int k = 0; k < plan->n_obs; ++k) PA.obs[k] = obs_t[k];
+  InterpTable IT;
+  if (!cp) {  // the table-walking policy
+    memset(&IT, 0, sizeof IT);
+    IT.sites = t == 0 ? plan->dev_init : plan->dev_step;
+    IT.n_sites = t == 0 ? plan->n_init : plan->n_step;
+    IT.n_state = plan->n_state;
+    for (int k = 0; k < plan->n_state; ++k) IT.state_args[k] = t == 0 ? plan->init_state[k] : plan->next_state[k];
+  }
   if (t == 0) {
     uint64_t first = cfg->first_slot, nl = cfg->n_local;
     FilterBatch fb = ctx.fb;
     EmitOut em = emit_out_of(cfg, out);
-    PlanTables tabs = c.tabs;
+    if (!cp) {
+      if (cfg->impl == 0) k_smc_interp_init<0><<<ntl * nf, kBlock, 0, S(s)>>>(PA, first, nl, em, fb, IT);
+      else k_smc_interp_init<1><<<ntl * nf, kBlock, 0, S(s)>>>(PA, first, nl, em, fb, IT);
+      return launch_status();
+    }
+    PlanTables tabs = cp->tabs;
     void* args[] = {&PA, &first, &nl, &em, &fb, &tabs};
-    if (hipModuleLaunchKernel(c.init, ntl * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
+    if (hipModuleLaunchKernel(cp->init, ntl * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
     return launch_status();
   }
   ResampleArgs A;
   int rc = smc_resample_args(cfg, t, prev, out, prev_e_out, prev_q_out, ctx, s, &A);
   if (rc) return rc;
-  PlanTables tabs = c.tabs;
+  if (!cp) {
+    if (cfg->impl == 0) k_smc_interp_step<0><<<ntl * nf, kBlock, 0, S(s)>>>(A, PA, IT);
+    else k_smc_interp_step<1><<<ntl * nf, kBlock, 0, S(s)>>>(A, PA, IT);
+    return launch_status();
+  }
+  PlanTables tabs = cp->tabs;
   void* args[] = {&A, &PA, &tabs};
-  if (hipModuleLaunchKernel(c.step, ntl * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
+  if (hipModuleLaunchKernel(cp->step, ntl * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
   return launch_status();
 }
 
@@ -2696,9 +2919,10 @@ int gjx_smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, cons
   if (!cfg_ok(cfg) || !plan || t < 0 || t >= cfg->n_steps || !out || (t > 0 && !prev) || (plan->n_obs > 0 && !obs_t) ||
       cfg->n_filters > 1)
     return GJX_ERR_INVALID;
-  gjx_jit::CompiledSmc* c = smc_plan_compiled(plan, cfg->impl);
-  if (!c) return GJX_ERR_UNSUPPORTED;
-  return smc_plan_step(cfg, plan, *c, t, obs_t, prev, out, prev_e_out, prev_q_out, ancestors_out, s, StepCtx{});
+  gjx_jit::CompiledSmc* c = nullptr;
+  const int route = smc_plan_route(plan, cfg->impl, &c);
+  if (route) return route;
+  return smc_plan_step(cfg, plan, c, t, obs_t, prev, out, prev_e_out, prev_q_out, ancestors_out, s, StepCtx{});
 }
 
 int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float* obs_host, int32_t* out_e,
@@ -2707,8 +2931,9 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
   if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !plan || !out_e || !out_q ||
       !state_out || !logw_out || (plan->n_obs > 0 && !obs_host))
     return GJX_ERR_INVALID;
-  gjx_jit::CompiledSmc* cp = smc_plan_compiled(plan, cfg->impl);
-  if (!cp) return GJX_ERR_UNSUPPORTED;
+  gjx_jit::CompiledSmc* cp = nullptr;
+  const int route = smc_plan_route(plan, cfg->impl, &cp);
+  if (route) return route;
   const int D = plan->n_state, T = cfg->n_steps;
   void* st[GJX_SMC_MAX_STATE];
   for (int k = 0; k < D; ++k) {
@@ -2723,7 +2948,7 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
   for (int t = 0; t < T; ++t) {
     gjx_smc_pop out;
     StepCtx ctx = run_step_ctx(cfg, rc, t, &out);
-    r = smc_plan_step(cfg, plan, *cp, t, plan->n_obs ? obs_host + (size_t)t * (size_t)plan->n_obs : nullptr,
+    r = smc_plan_step(cfg, plan, cp, t, plan->n_obs ? obs_host + (size_t)t * (size_t)plan->n_obs : nullptr,
                       &rc.pop[(t & 1) ^ 1], &out, t ? out_e + (t - 1) : nullptr, t ? out_q + (t - 1) : nullptr,
                       ancestors_out ? ancestors_out + (size_t)t * rc.F * rc.stride : nullptr, s, ctx);
     if (r) return r;

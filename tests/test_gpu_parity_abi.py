@@ -937,6 +937,55 @@ def test_smc_plans(hip_ops, oracle_ops, impl):
     same(gen_[4], fixed[4], "ancestors")
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+def test_smc_plans_without_the_compiler(hip_ops, oracle_ops, impl):
+    """GJX_PLAN_JIT=0: generated filters run through the table-walking policy (k_smc_interp_*: the site table read at run time
+    inside the same fused resample kernel) — the same bits as the oracle (hence as the compiled policy), every-step and
+    ESS-adaptive, one filter and three per launch; a filter whose model holds a program (GJX_ARG_EXPR) has no such route
+    and says so."""
+    import os
+
+    from genjax._amd import prng
+    from genjax._amd.abi import GjxError
+
+    T, n = 9, 6000
+    y = W.lgssm_data(T)
+    obs2 = np.stack([y, (np.arange(T) % 2).astype(np.float32)], axis=1)
+    sk, rk = W.smc_key_schedule(prng.key(13, impl), T)
+    ol, orr = _smc_plans(oracle_ops)
+    before = hip_ops.jit_stats()["compiles"]
+    os.environ["GJX_PLAN_JIT"] = "0"
+    try:
+        hl, hr = _smc_plans(hip_ops)
+        for hp, op_, obs in ((hl, ol, y), (hr, orr, obs2)):
+            for thr in (0.0, 0.5):
+                h = hip_ops.smc_run_plan(hp, impl, n, sk, rk, obs, True, ess_threshold=thr)
+                o = oracle_ops.smc_run_plan(op_, impl, n, sk, rk, obs, True, ess_threshold=thr)
+                same(h[0], o[0], "step max"); same(h[1], o[1], "step q"); same(h[3], o[3], "logw"); same(h[4], o[4], "ancestors")
+                for a, b in zip(h[2], o[2]):
+                    same(a, b, "state column")
+        pairs = [W.smc_key_schedule(prng.key(20 + f, impl), T) for f in range(3)]
+        skf, rkf = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+        hb = hip_ops.smc_run_plan(hr, impl, n, skf, rkf, obs2, True)
+        ob = oracle_ops.smc_run_plan(orr, impl, n, skf, rkf, obs2, True)
+        same(hb[1], ob[1], "batched step q"); same(hb[4][:, :, :n], ob[4][:, :, :n], "batched ancestors")
+        # a program in the model: compiled, never interpreted
+        A = abi.Arg
+        keep = []
+        prog = abi.expr_arg([(abi.EXPR_STATE, 0, 0.0), (abi.EXPR_STATE, 0, 0.0), (abi.EXPR_MUL, 0, 0.0)], keep)
+        s0, s1 = abi.Site(), abi.Site()
+        s0.dist, s0.out_col = abi.DIST_NORMAL, -1
+        s0.arg[0], s0.arg[1] = A(abi.ARG_CONST, 0, 0.0, 0.0, None), A(abi.ARG_CONST, 0, 0.0, 1.0, None)
+        s1.dist, s1.out_col = abi.DIST_NORMAL, -1
+        s1.arg[0], s1.arg[1] = prog, A(abi.ARG_CONST, 0, 0.0, 1.0, None)
+        pe = hip_ops.smc_plan_create([s0], [s1], [A(abi.ARG_SITE, 0, 1.0, 0.0, None)], [A(abi.ARG_SITE, 0, 1.0, 0.0, None)], 0)
+        with pytest.raises(GjxError):
+            hip_ops.smc_run_plan(pe, impl, n, sk, rk, np.zeros((T, 0), np.float32), False)
+    finally:
+        del os.environ["GJX_PLAN_JIT"]
+    assert hip_ops.jit_stats()["compiles"] == before  # nothing was compiled on the way
+
+
 def _scan_plans(ops):
     """(the LGSSM scan kernel, a two-component carry with gamma / beta / bernoulli sites, an input and two observations)."""
     A = abi.Arg
