@@ -980,7 +980,7 @@ def test_smc_plans_without_the_compiler(hip_ops, oracle_ops, impl):
         s1.arg[0], s1.arg[1] = prog, A(abi.ARG_CONST, 0, 0.0, 1.0, None)
         pe = hip_ops.smc_plan_create([s0], [s1], [A(abi.ARG_SITE, 0, 1.0, 0.0, None)], [A(abi.ARG_SITE, 0, 1.0, 0.0, None)], 0)
         with pytest.raises(GjxError):
-            hip_ops.smc_run_plan(pe, impl, n, sk, rk, np.zeros((T, 0), np.float32), False)
+            hip_ops.smc_run_plan(pe, impl, n, sk, rk, np.zeros((T, 1), np.float32), False)
     finally:
         del os.environ["GJX_PLAN_JIT"]
     assert hip_ops.jit_stats()["compiles"] == before  # nothing was compiled on the way
