@@ -591,7 +591,10 @@ int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, c
  * taking word j & 3, and Normal sites pair Box-Muller inside the quad ((w0,w1) -> slots 4g, 4g+1; (w2,w3)
  * -> 4g+2, 4g+3) — the fixed models above are the case of one sampled site; multi-word samplers (gamma,
  * beta, Gumbel-max categorical) keep the slot key's streams.  libgjx_hip.so lowers the step to a hiprtc-compiled policy
- * inside the fused resample kernel.  State columns are f32 (integer-valued sites are converted). */
+ * inside the fused resample kernel.  State columns are f32 (integer-valued sites are converted).
+ * r03: with the compiler switched off (GJX_PLAN_JIT=0), or failed and GJX_PLAN_JIT_FALLBACK=1, a filter runs through a
+ * table-walking policy inside the same kernel (the site tables read at run time: the same bits, several times slower);
+ * a model that holds programs (GJX_ARG_EXPR) has no such route (GJX_ERR_UNSUPPORTED / GJX_ERR_JIT). */
 typedef struct {
   const gjx_site* init_sites;
   int32_t n_init_sites;
