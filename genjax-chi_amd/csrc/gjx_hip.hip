@@ -2615,6 +2615,7 @@ struct gjx_scan_plan {
   CSite step[GJX_MAX_SITES];
   CArg next_state[GJX_SMC_MAX_STATE];
   gjx_jit::Compiled jit[3];  // THREEFRY, PHILOX one particle per lane, PHILOX four per lane (GenScan::quad)
+  gjx_jit::ScopeInfo scopes;  // nested calls inside the step kernel (gjx_scan_plan_create_scoped)
   std::vector<void*> dev_owned;  // per-row tables of categorical sites
   std::mutex mu;
   ExprStore step_expr;  // GJX_ARG_EXPR programs
@@ -2642,6 +2643,18 @@ int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan*
   *out = p;
   return GJX_OK;
 }
+int gjx_scan_plan_create_scoped(const gjx_scan_model* m, const gjx_scope* scopes, int n_scopes, uint32_t flags,
+                                gjx_scan_plan** out) {
+  gjx_scan_plan* p = nullptr;
+  const int rc = gjx_scan_plan_create(m, flags, &p);
+  if (rc) return rc;
+  if (!gjx_jit::derive_scopes(m->step_sites, m->n_step_sites, scopes, n_scopes, p->scopes)) {
+    gjx_scan_plan_destroy(p);
+    return GJX_ERR_INVALID;
+  }
+  *out = p;
+  return GJX_OK;
+}
 int gjx_scan_plan_destroy(gjx_scan_plan* p) {
   if (!p) return GJX_OK;
   for (auto& c : p->jit) gjx_jit::release(&c);
@@ -2656,6 +2669,7 @@ static std::string scan_plan_source(const gjx_scan_plan* plan, int impl, const c
   g.impl = impl; g.sites = plan->step; g.n_sites = plan->n_step; g.next_state = plan->next_state;
   g.n_state = plan->n_state; g.n_obs = plan->n_obs; g.fast_math = (plan->flags & GJX_PLAN_FAST_MATH) != 0;
   g.quad = quad;
+  g.sc = plan->scopes.n_scopes > 0 ? &plan->scopes : nullptr;
   if (kname) *kname = g.kname();
   std::string src = g.run();
   if (tabs) *tabs = ts.reg.tables();

@@ -661,6 +661,7 @@ struct GenScan {
   const CArgT* next_state;
   int n_state, n_obs;
   bool fast_math = false;
+  const ScopeInfo* sc = nullptr;  // nested calls inside the step kernel (null: a flat body)
   bool quad = false;  // PHILOX, the lazy children of a lane-0 key, n and the columns multiples of four: FOUR adjacent particles
                       // per lane (one wave per 256-particle row).  A step's keys are lanes (scan_step_key_philox), so the
                       // lane's two pairs share their cipher blocks and Box-Muller transforms exactly as in the importance
@@ -699,7 +700,9 @@ struct GenScan {
       em.push_back(SiteEmitter<CSiteT, CArgT>{o, impl, 2, sites, n_sites, "        ", sfx[u]});
       em.back().store_values = false;
       em.back().ext_bits = true;
+      em.back().sc = sc;
     }
+    for (int u = 0; u < P; ++u) em[u].emit_scope_keys();
     emit_pair_lane_sites<CSiteT, CArgT>(o, em, sites, n_sites, 2, "        ", "oiA");
     for (int u = 0; u < P; ++u)
       for (int k = 0; k < n_state; ++k) o << "        const float nx_" << k << sfx[u] << " = " << em[u].arg(next_state[k]) << ";\n";
@@ -750,6 +753,7 @@ struct GenScan {
     o << "        const uint64_t oi = (uint64_t)t * sa.col_stride + i; (void)oi;\n";
     o << "        float w = 0.0f, sc = 0.0f;\n";
     SiteEmitter<CSiteT, CArgT> em{o, impl, 2, sites, n_sites, "        "};
+    em.sc = sc;
     em.run();
     for (int k = 0; k < n_state; ++k) o << "        const float nx_" << k << " = " << em.arg(next_state[k]) << ";\n";
     for (int k = 0; k < n_state; ++k) o << "        st_" << k << " = nx_" << k << ";\n";

@@ -342,6 +342,7 @@ PROTOTYPES = {
     "gjx_smc_plan_destroy": (C.c_int, [_P]),
     "gjx_smc_plan_compile_check": (C.c_int, [_P, C.c_int]),
     "gjx_scan_plan_create": (C.c_int, [C.POINTER(ScanModel), C.c_uint32, C.POINTER(_P)]),
+    "gjx_scan_plan_create_scoped": (C.c_int, [C.POINTER(ScanModel), C.POINTER(Scope), C.c_int, C.c_uint32, C.POINTER(_P)]),
     "gjx_scan_plan_destroy": (C.c_int, [_P]),
     "gjx_scan_plan_compile_check": (C.c_int, [_P, C.c_int]),
     "gjx_scan_run": (C.c_int, [_P, C.POINTER(ScanIO), _P]),

@@ -206,11 +206,12 @@ class Scan(GenerativeFunction):
         leaves = []
         k_obs = {a: i for i, a in enumerate(obs_addrs)}
         for m in low.tracer.meta:
-            a = m["addr"] if isinstance(m["addr"], tuple) else (m["addr"],)
+            a = m["path"]  # (the full address: the enclosing calls' addresses, then the site's)
+            addr = a[0] if len(a) == 1 else a
             if m["out_col"] >= 0:
-                leaves.append((m["addr"], values_nt[m["out_col"]]))
+                leaves.append((addr, values_nt[m["out_col"]]))
             else:
-                leaves.append((m["addr"], _stack_time(obs_values[k_obs[a]], True)))
+                leaves.append((addr, _stack_time(obs_values[k_obs[a]], True)))
         final = [c[0] if u else c for c, u in zip(out["carry"], low.uniform_carry)]
         final = [(c != 0 if dt == torch.bool else c.to(dt)) if dt is not None else c for c, dt in zip(final, low.carry_dtypes)]
         retval = (low.rebuild_carry(final), SP.resolve(low, low.ret_y, values_nt, table, dev, carry0))

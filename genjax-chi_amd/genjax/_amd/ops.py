@@ -528,7 +528,7 @@ class Ops:
         return SmcPlan(self, handle, len(next_state), n_obs)
 
     # ---- importance over a Scan model: T steps per particle in one launch ------------------------
-    def scan_plan_create(self, step_sites, next_state, n_obs: int, fast_math: bool = False) -> "ScanPlan":
+    def scan_plan_create(self, step_sites, next_state, n_obs: int, fast_math: bool = False, scopes=()) -> "ScanPlan":
         m = abi.ScanModel()
         sa = (abi.Site * len(step_sites))(*step_sites)
         m.step_sites, m.n_step_sites = sa, len(step_sites)
@@ -536,7 +536,12 @@ class Ops:
             m.next_state[k] = a
         m.n_state, m.n_obs = len(next_state), n_obs
         handle = C.c_void_p()
-        self.lib.call("gjx_scan_plan_create", C.byref(m), abi.PLAN_FAST_MATH if fast_math else 0, C.byref(handle))
+        flags = abi.PLAN_FAST_MATH if fast_math else 0
+        if scopes:  # nested `@gen` calls inside the step kernel
+            sc = (abi.Scope * len(scopes))(*[abi.Scope(*k) for k in scopes])
+            self.lib.call("gjx_scan_plan_create_scoped", C.byref(m), sc, len(scopes), flags, C.byref(handle))
+        else:
+            self.lib.call("gjx_scan_plan_create", C.byref(m), flags, C.byref(handle))
         return ScanPlan(self, handle, len(next_state), n_obs)
 
     def scan_run(self, plan: "ScanPlan", kb: KeyBatch, n: int, T: int, obs, carry0, value_dtypes: list,

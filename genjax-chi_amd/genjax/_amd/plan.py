@@ -346,6 +346,7 @@ class PlanTracer(_Handler):
         self.scopes: list[list] = []  # [parent scope, begin, end]
         self.items: list = []         # this body's `@` sites in program order: ("site", index) | ("call", record)
         self.cur_scope, self.depth, self.allow_scopes = 0, 0, True
+        self.prefix: tuple = ()  # the addresses of the calls the body being traced sits in
 
     # -- argument encoding ---------------------------------------------------------------------------
     def param_slot(self, pv: ParamVal) -> int:
@@ -405,16 +406,20 @@ class PlanTracer(_Handler):
         self.scopes.append([self.cur_scope, len(self.sites), None])
         rec = dict(addr=addr, gen_fn=gen_fn, args=args, items=[], retval=None)
         self.items.append(("call", rec))
-        saved = (self.constraint, self.traces, self.cur_scope, self.items)
-        self.constraint, self.traces, self.cur_scope, self.items = self.constraint.get_submap(*a), {}, k + 1, rec["items"]
+        saved = (self.constraint, self.traces, self.cur_scope, self.items, self.prefix)
+        self.constraint, self.traces, self.cur_scope, self.items = self._callee_constraint(a), {}, k + 1, rec["items"]
+        self.prefix = self.prefix + a
         self.depth += 1
         try:
             rec["retval"] = gen_fn.source(*_spec_wrap(tuple(args)))  # (`@` inside reaches this tracer: it is the stack's top)
         finally:
-            self.constraint, self.traces, self.cur_scope, self.items = saved
+            self.constraint, self.traces, self.cur_scope, self.items, self.prefix = saved
             self.depth -= 1
         self.scopes[k][2] = len(self.sites)
         return rec["retval"]
+
+    def _callee_constraint(self, a: tuple) -> ChoiceMap:
+        return self.constraint.get_submap(*a)
 
     def handle_trace(self, addr, gen_fn, args):
         if not isinstance(gen_fn, Distribution):
@@ -486,7 +491,7 @@ class PlanTracer(_Handler):
         self.sites.append(site)
         self.items.append(("site", idx))
         self.meta.append(dict(addr=addr, gen_fn=gen_fn, args=args, obs=obs, out_col=site.out_col, is_int=is_int,
-                              dtype=gen_fn.value_dtype))
+                              dtype=gen_fn.value_dtype, path=self.prefix + a))
         self.record(addr, None)
         if obs is not None:
             # a constrained value may feed later sites: constants stay constants, columns become inputs

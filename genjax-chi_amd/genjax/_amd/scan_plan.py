@@ -31,8 +31,7 @@ class _ScanTracer(PlanTracer):
 
     def __init__(self, obs_index: dict):
         super().__init__(ChoiceMap.empty(), 1, use_params=False)
-        self.obs_index = obs_index
-        self.allow_scopes = False  # (nested calls: importance plans only)
+        self.obs_index = obs_index  # full address (the calls' addresses, then the site's) -> column of the observation table
 
     def _arg(self, v) -> abi.Arg:
         if isinstance(v, Sym) and v.src[0] == "state":
@@ -43,10 +42,16 @@ class _ScanTracer(PlanTracer):
             raise PlanUnsupported("per-particle tensors cannot enter a scan plan")
         return super()._arg(v)
 
+    def _callee_constraint(self, a: tuple) -> ChoiceMap:
+        return ChoiceMap.empty()  # (observed sites are recognised by their full address, see handle_trace)
+
     def handle_trace(self, addr, gen_fn, args):
-        key = addr if isinstance(addr, tuple) else (addr,)
-        if key in self.obs_index:
-            self.constraint = ChoiceMap.entry(0.0, *key)  # a placeholder; the value is this step's table entry
+        from .lang import Distribution
+
+        local = addr if isinstance(addr, tuple) else (addr,)
+        key = self.prefix + local
+        if isinstance(gen_fn, Distribution) and key in self.obs_index:
+            self.constraint = ChoiceMap.entry(0.0, *local)  # a placeholder; the value is this step's table entry
             super().handle_trace(addr, gen_fn, args)
             k = self.obs_index[key]
             self.sites[-1].obs = abi.Arg(abi.ARG_OBS, k, 1.0, 0.0, None)
@@ -130,12 +135,12 @@ def lower_scan(kernel_gen_fn, carry0, xs, obs_addrs: list[tuple], fast_math: boo
             for op, ref, _ in v.prog:
                 if (op == abi.EXPR_STATE and state_col[ref] is None) or (op == abi.EXPR_SITE and tr.meta[ref]["out_col"] < 0):
                     raise PlanUnsupported("y_t reads a carry component / a site that is not stored")
-    seen = {(m["addr"] if isinstance(m["addr"], tuple) else (m["addr"],)) for m in tr.meta}
+    seen = {m["path"] for m in tr.meta}
     if any(a not in seen for a in obs_addrs):
         raise PlanUnsupported("a constrained address is not visited by the kernel")
     if not tr.sites:
         raise PlanUnsupported("no sites")
-    plan = get_ops().scan_plan_create(tr.sites, next_state, n_obs_total, fast_math=fast_math)
+    plan = get_ops().scan_plan_create(tr.sites, next_state, n_obs_total, fast_math=fast_math, scopes=[tuple(k) for k in tr.scopes])
     plan._keep = tr.keep
     value_meta = [m for m in tr.meta if m["out_col"] >= 0]
     low = ScanLowering(tr, plan, obs_addrs, len(xs_leaves), rebuild_carry, new_carry, y, value_meta)

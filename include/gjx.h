@@ -643,6 +643,10 @@ typedef struct {
 } gjx_scan_model;
 typedef struct gjx_scan_plan gjx_scan_plan;
 int gjx_scan_plan_create(const gjx_scan_model* m /*host*/, uint32_t flags /* GJX_PLAN_* */, gjx_scan_plan** out);
+/* The same with nested `@gen` calls inside the step kernel (scopes over `step_sites`, as gjx_plan_create_scoped): a callee
+ * of step t runs under fold_in(key_t, the counter its call took). */
+int gjx_scan_plan_create_scoped(const gjx_scan_model* m /*host*/, const gjx_scope* scopes /*host*/, int n_scopes, uint32_t flags,
+                                gjx_scan_plan** out);
 int gjx_scan_plan_destroy(gjx_scan_plan* p);
 int gjx_scan_plan_compile_check(const gjx_scan_plan* p, int impl); /* offline hiprtc compile, needs no GPU */
 typedef struct {

@@ -1584,6 +1584,7 @@ struct gjx_scan_plan {
   gjx_site step_sites[GJX_MAX_SITES];
   expr_store step_expr;
   state_expr_store next_state_expr;
+  scope_info scopes;
 };
 int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan** out) {
   if (!m || !out || (flags & ~(uint32_t)GJX_PLAN_FAST_MATH) || m->n_state < 1 || m->n_state > GJX_SMC_MAX_STATE ||
@@ -1600,10 +1601,23 @@ int gjx_scan_plan_create(const gjx_scan_model* m, uint32_t flags, gjx_scan_plan*
   expr_adopt(p->step_sites, m->n_step_sites, &p->step_expr);
   state_expr_adopt(p->m.next_state, m->n_state, &p->next_state_expr);
   p->m.step_sites = p->step_sites;
+  p->scopes.n_scopes = 0;
   *out = p;
   return GJX_OK;
 }
 int gjx_scan_plan_destroy(gjx_scan_plan* p) { free(p); return GJX_OK; }
+int gjx_scan_plan_create_scoped(const gjx_scan_model* m, const gjx_scope* scopes, int n_scopes, uint32_t flags,
+                                gjx_scan_plan** out) {
+  gjx_scan_plan* p = NULL;
+  int rc = gjx_scan_plan_create(m, flags, &p);
+  if (rc) return rc;
+  if (!derive_scopes(p->step_sites, p->m.n_step_sites, scopes, n_scopes, &p->scopes)) {
+    gjx_scan_plan_destroy(p);
+    return GJX_ERR_INVALID;
+  }
+  *out = p;
+  return GJX_OK;
+}
 int gjx_scan_plan_compile_check(const gjx_scan_plan* p, int impl) { (void)p; (void)impl; return GJX_ERR_UNSUPPORTED; }
 int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
   if (!p || !io || !keys_ok(io->particle_keys) || io->particle_keys->has_fold || !io->logw || io->n_steps < 1 ||
@@ -1629,6 +1643,7 @@ int gjx_scan_run(gjx_scan_plan* p, const gjx_scan_io* io, gjx_stream s) {
     c.impl = impl;
     c.pair_normals = 1;
     c.i = (uint64_t)i;
+    c.scopes = &p->scopes;
     uint32_t key[4];
     key_at(io->particle_keys, (uint64_t)i, key);
     float st[GJX_SMC_MAX_STATE], wt = 0.0f, sct = 0.0f;

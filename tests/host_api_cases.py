@@ -1794,9 +1794,54 @@ def case_nested_calls(impl):
         raise AssertionError("address reuse inside a callee went unnoticed")
     except Exception as e:  # noqa: BLE001
         assert "a" in str(e) or type(e).__name__ == "AddressReuse"
-    # scans and generated SMC filters keep nested calls on the per-site path (importance plans only)
     tr = P._traced(model, C.n(), n, (0.25,))
     assert tr is not None and len(tr[0].scopes) == 6
+    # a scan whose step kernel is composed of sub-models (a transition and an emission `@gen` function): ONE launch for all T
+    # steps, equal to the host loop of per-site launches; constraints inside the callees; per-step traces rebuilt on demand
+    from genjax._amd import combinators as CB
+
+    @gen
+    def transition(x, u):
+        e = normal(0.0, 0.3) @ "eps"
+        g = gamma(2.0, 2.0) @ "g"
+        return x * 0.9 + u + e * g
+
+    @gen
+    def emission(x):
+        return normal(x, 0.5) @ "y"
+
+    @gen
+    def step(carry, u):
+        x, v = carry
+        x2 = transition(x, u) @ "tr"
+        k = flip(0.3) @ "k"
+        y = emission(x2 / 2.0) @ "em"
+        return (x2, v * 0.5 + torch.exp(x2 * 0.1)), (y, k)
+
+    T, ns = 5, 1200
+    us = torch.linspace(0.2, 1.4, T).to(_dev())
+    skeys = genjax.random.split(genjax.random.key(5, impl), ns)
+    for chm in (C.n(), C["em", "y"].set(torch.linspace(-1, 1, T)) | C["tr", "g"].set(torch.linspace(0.5, 1.5, T))):
+        out = {}
+        for fused in (True, False):
+            CB.FUSED_SCAN = fused
+            try:
+                out[fused] = step.scan().generate(skeys, chm, ((0.25, -0.5), us))
+            finally:
+                CB.FUSED_SCAN = True
+        (ta, wa), (tb, wb) = out[True], out[False]
+        assert isinstance(ta, CB.FusedScanTrace), "a step kernel with nested calls must lower to the one-launch scan"
+        if isinstance(wb, torch.Tensor):
+            assert torch.equal(wa, wb)
+        assert torch.equal(ta.get_score(), tb.get_score())
+        ca, cb = dict(ta.get_choices().leaves()), dict(tb.get_choices().leaves())
+        assert ca.keys() == cb.keys() and ("tr", "eps") in ca
+        for key_ in ca:
+            a_, b_ = torch.as_tensor(ca[key_]), torch.as_tensor(cb[key_])
+            assert torch.equal(a_.float().cpu(), b_.float().cpu().expand_as(a_)), key_
+        assert torch.equal(ta.get_retval()[0][0], tb.get_retval()[0][0]) and torch.equal(ta.get_retval()[1][0], tb.get_retval()[1][0])
+        assert torch.equal(ta.step_traces[2].get_score(), tb.step_traces[2].get_score())
+    # generated SMC filters keep nested calls on the per-site path
 
 
 ALL_CASES = [case_nested_calls, case_fast_estimate_path, case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,
