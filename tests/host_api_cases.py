@@ -1839,8 +1839,9 @@ def case_nested_calls(impl):
         for key_ in ca:
             a_, b_ = torch.as_tensor(ca[key_]), torch.as_tensor(cb[key_])
             assert torch.equal(a_.float().cpu(), b_.float().cpu().expand_as(a_)), key_
-        assert torch.equal(ta.get_retval()[0][0], tb.get_retval()[0][0]) and torch.equal(ta.get_retval()[1][0], tb.get_retval()[1][0])
-        assert torch.equal(ta.step_traces[2].get_score(), tb.step_traces[2].get_score())
+        assert torch.equal(ta.get_retval()[0][0].cpu(), tb.get_retval()[0][0].cpu())
+        assert torch.equal(torch.as_tensor(ta.get_retval()[1][0]).cpu().expand(ns, T), torch.as_tensor(tb.get_retval()[1][0]).cpu().expand(ns, T))
+        assert torch.equal(ta.step_traces[2].get_score().cpu(), tb.step_traces[2].get_score().cpu())
     # generated SMC filters keep nested calls on the per-site path
 
 
