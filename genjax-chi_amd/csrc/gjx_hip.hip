@@ -2089,6 +2089,29 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
                            max_partials, row_e, row_s, lse, s);
 }
 
+int gjx_importance_estimate(const gjx_estimate_io* io, uint32_t k0, uint32_t k1, uint64_t lane, float* out, float shift,
+                            gjx_stream s) {
+  if (!io || !io->plan || !io->row_e || !io->row_s || !io->lse.tickets || !out || (io->impl != 0 && io->impl != 1) ||
+      (io->impl == 0 && lane != 0))
+    return GJX_ERR_INVALID;
+  for (int q = 0; q < io->plan->n_sites; ++q)
+    if (io->plan->host[q].out_col >= 0) return GJX_ERR_INVALID;  // an estimate-only plan stores no value column
+  // key, sub = split(key); key, sub = split(sub): the second child twice (on the host: two cipher blocks at most)
+  Key k{k0, k1, (uint32_t)lane, (uint32_t)(lane >> 32)};
+  k = io->impl == 0 ? split_at<0>(split_at<0>(k, 1), 1) : split_at<1>(split_at<1>(k, 1), 1);
+  gjx_keys pk;
+  memset(&pk, 0, sizeof pk);
+  pk.impl = io->impl;
+  pk.mode = 1;  // the particle keys: split(sub, K), lazily
+  pk.parent[0] = k.k0; pk.parent[1] = k.k1;
+  pk.parent_lane = ((uint64_t)k.l1 << 32) | k.l0;
+  gjx_lse_out lse = io->lse;
+  lse.lse_shifted = out;
+  lse.shift = shift;
+  return importance_launch(io->plan, &pk, 1, 0, 0, io->input_cols, io->n_input_cols, nullptr, 0, nullptr, nullptr, io->n, nullptr,
+                           io->row_e, io->row_s, &lse, s);
+}
+
 int gjx_importance_run_batch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pass, uint64_t pass_stride,
                              uint64_t row_stride, const float* const* input_cols, int n_input_cols,
                              void* const* value_cols, int n_value_cols, float* score, float* logw, uint64_t n,

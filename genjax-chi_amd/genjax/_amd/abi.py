@@ -87,6 +87,13 @@ class LseOut(C.Structure):
 LSE_TICKET_WORDS = 17 * 64  # include/gjx.h: GJX_LSE_TICKET_WORDS
 
 
+class EstimateIO(C.Structure):
+    """include/gjx.h gjx_estimate_io: what one gjx_importance_estimate call reads besides the key."""
+
+    _fields_ = [("plan", C.c_void_p), ("n", C.c_uint64), ("input_cols", C.c_void_p), ("n_input_cols", C.c_int32), ("impl", C.c_int32),
+                ("row_e", C.c_void_p), ("row_s", C.c_void_p), ("lse", LseOut)]
+
+
 def key_words(impl: int) -> int:
     """Words per materialised key (gjx.h: GJX_KEY_WORDS): threefry 2, philox 4 (cipher key + lane)."""
     return 4 if impl == RNG_PHILOX else 2
@@ -302,6 +309,7 @@ PROTOTYPES = {
         C.c_int,
         [_P, _KP, C.POINTER(_P), C.c_int, C.POINTER(_P), C.c_int, _P, _P, C.c_uint64, _P, _P, _P, _P, _P],
     ),
+    "gjx_importance_estimate": (C.c_int, [C.POINTER(EstimateIO), C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_float, C.c_void_p]),
     "gjx_importance_run_batch": (
         C.c_int,
         [_P, _KP, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(_P), C.c_int, C.POINTER(_P), C.c_int, _P, _P, C.c_uint64,

@@ -425,25 +425,21 @@ class ImportanceK(SMCAlgorithm):
         st = self._fast_state()
         if st is None:
             return None
-        # key, sub_key = split(key) [here]; key, sub_key = split(sub_key); sub_keys = split(sub_key, K) [run_smc]
         impl = key.impl
-        k0, k1, lane = prng.split_at_words(key.k0, key.k1, impl, key.lane, 1)
-        k0, k1, lane = prng.split_at_words(k0, k1, impl, lane, 1)
         slot = (impl, threading.get_ident())  # (persistent buffers: one set per generator and host thread)
         prep = st.preps.get(slot)
         if prep is None:
-            kb = prng.split_lazy(prng.PRNGKey(k0, k1, impl, lane), st.n)
+            kb = prng.split_lazy(prng.split_at(prng.split_at(key, 1), 1), st.n)
             prep = st.preps[slot] = st.ops.prepare_importance(st.plan, kb, st.n, st.tracer.inputs, [], estimate_only=True)
-        ks = prep._keys
-        ks.parent[0], ks.parent[1], ks.parent_lane = k0, k1, lane
         plan = st.plan
         if st.params and plan.params_owner is not st:  # (another algorithm object may share the cached plan)
             plan.set_params(st.params)
             plan.params_owner = st
-        # ONE launch: the importance walk, the fold of its row sums by the workgroup that finishes last, and
-        # lse - log K (one f32 subtraction: what `lse[0] - math.log(K)` computes on the general route) into a fresh scalar
+        # ONE library call = ONE launch (gjx_importance_estimate): key, sub_key = split(key) [the estimate]; key, sub_key =
+        # split(sub_key); sub_keys = split(sub_key, K), lazily [run_smc]; the walk, the fold of its row sums by the workgroup
+        # that finishes last, and lse - log K (one f32 subtraction, as `lse[0] - math.log(K)` on the general route)
         out = torch.empty((), dtype=torch.float32, device=st.ops._alloc_device)
-        prep.launch_fused_shifted(out, st.log_k)
+        prep.launch_estimate(key.k0, key.k1, key.lane, out, st.log_k)
         return out
 
     def log_marginal_likelihood_estimate(self, key, target: Target | None = None):

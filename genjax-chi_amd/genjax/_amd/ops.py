@@ -915,6 +915,22 @@ class PreparedImportance:
         if rc:
             raise abi.GjxError("gjx_importance_run", rc)
 
+    def launch_estimate(self, k0: int, k1: int, lane: int, out: torch.Tensor, shift: float):
+        """gjx_importance_estimate: the reference's key derivation from the caller's scalar key, the estimate-only walk, the fold
+        and `out[()] = lse - shift` as ONE library call (one launch) on the current stream."""
+        io = self.__dict__.get("_est_io")
+        if io is None:
+            io = self._est_io = abi.EstimateIO(self.plan.handle.value, self.n, C.addressof(self._ins), len(self.inputs), self._keys.impl,
+                                               self.rows.e.data_ptr(), self.rows.s.data_ptr(),
+                                               abi.LseOut(self.row_e_out.data_ptr(), self.row_q_out.data_ptr(), self.lse.data_ptr(), None,
+                                                          self._tickets.data_ptr(), None, 0.0))
+            self._est_ref, self._est_fn = C.byref(io), self.ops.lib._gjx_importance_estimate
+            self._est_cuda = self.ops.device_type == "cuda"
+        stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()) if self._est_cuda else 0
+        rc = self._est_fn(self._est_ref, k0, k1, lane, out.data_ptr(), shift, stream)
+        if rc:
+            raise abi.GjxError("gjx_importance_estimate", rc)
+
     def launch_lse(self, stream=None):
         rc = self._lse(*self._args_lse, stream if stream is not None else self.ops.stream())
         if rc:

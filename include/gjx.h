@@ -318,6 +318,26 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* particle_keys,
                        float* max_partials, int32_t* row_e, uint64_t* row_s, const gjx_lse_out* lse,
                        gjx_stream s);
 
+/* ONE library call for `ImportanceK(target, K).log_marginal_likelihood_estimate(key)` (inference/smc.py:83-97, 296-318): the
+ * reference's key derivation — key, sub = split(key) in the estimate, key, sub = split(sub) in run_smc, particle keys =
+ * split(sub, K) (lazy: nothing is materialised) — then the walk of an ESTIMATE-ONLY plan (every site's out_col = -1: no
+ * value column, no score, no log-weight column), the fold of its row sums by the workgroup that finishes last, and
+ * out[0] = logsumexp(lw) - shift (shift = log K).  The caller's scalar key arrives by value (k0, k1, lane; lane 0 for
+ * THREEFRY).  row_e / row_s / lse: the scratch of gjx_importance_run's fused form (lse.lse_shifted / lse.shift are ignored:
+ * `out` and `shift` take their place).  One launch, no allocation, no synchronisation. */
+typedef struct {
+  const gjx_plan* plan;
+  uint64_t n;
+  const float* const* input_cols;
+  int32_t n_input_cols;
+  int32_t impl;
+  int32_t* row_e;
+  uint64_t* row_s;
+  gjx_lse_out lse;
+} gjx_estimate_io;
+int gjx_importance_estimate(const gjx_estimate_io* io, uint32_t k0, uint32_t k1, uint64_t lane, float* out /*dev f32[1]*/,
+                            float shift, gjx_stream s);
+
 /* n_pass (<= 32) independent passes of the same plan — the algorithm vmapped over keys.  Pass b draws from
  * particle_keys[b] and writes b * pass_stride elements further in every output column (score, logw, value
  * columns; pass_stride >= n, even for the fast path) and b * row_stride entries further in max_partials /

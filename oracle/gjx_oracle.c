@@ -696,6 +696,31 @@ int gjx_importance_run(const gjx_plan* p, const gjx_keys* pk, const float* const
   return GJX_OK;
 }
 
+int gjx_importance_estimate(const gjx_estimate_io* io, uint32_t k0, uint32_t k1, uint64_t lane, float* out, float shift,
+                            gjx_stream s) {
+  if (!io || !io->plan || !io->row_e || !io->row_s || !io->lse.tickets || !out || (io->impl != 0 && io->impl != 1) ||
+      (io->impl == 0 && lane != 0))
+    return GJX_ERR_INVALID;
+  for (int q = 0; q < io->plan->n_sites; ++q)
+    if (io->plan->sites[q].out_col >= 0) return GJX_ERR_INVALID;
+  /* key, sub = split(key); key, sub = split(sub); particle keys = split(sub, K) (inference/smc.py:86, 299-300) */
+  gjx_keys k;
+  memset(&k, 0, sizeof k);
+  k.impl = io->impl; k.mode = 1;
+  k.parent[0] = k0; k.parent[1] = k1; k.parent_lane = lane;
+  uint32_t c[4];
+  for (int rep = 0; rep < 2; ++rep) {
+    key_at(&k, 1, c);
+    k.parent[0] = c[0]; k.parent[1] = c[1];
+    k.parent_lane = io->impl == 1 ? (((uint64_t)c[3] << 32) | c[2]) : 0;
+  }
+  gjx_lse_out lse = io->lse;
+  lse.lse_shifted = out;
+  lse.shift = shift;
+  return gjx_importance_run(io->plan, &k, io->input_cols, io->n_input_cols, NULL, 0, NULL, NULL, io->n, NULL, io->row_e, io->row_s,
+                            &lse, s);
+}
+
 int gjx_importance_run_batch(const gjx_plan* p, const gjx_keys* pk, int32_t n_pass, uint64_t pass_stride,
                              uint64_t row_stride, const float* const* input_cols, int n_input_cols,
                              void* const* value_cols, int n_value_cols, float* score, float* logw, uint64_t n,

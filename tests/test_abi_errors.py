@@ -167,3 +167,25 @@ def test_scoped_plans_are_validated(lib_ops):
         assert e.value.code == -1, sc  # GJX_ERR_INVALID
     with pytest.raises(GjxError):
         lib_ops.plan_create(sites, scopes=[(0, 0, 0)] * (abi.MAX_SCOPES + 1))
+
+
+def test_importance_estimate_validates(lib_ops):
+    """gjx_importance_estimate: an estimate-only plan (no value columns), scratch and tickets present, a lane only under
+    PHILOX — anything else is GJX_ERR_INVALID before any launch."""
+    c = abi.Arg(abi.ARG_CONST, 0, 0.0, 1.0, None)
+    plan_cols = lib_ops.plan_create([_site(abi.DIST_NORMAL, c, c, out_col=0)])
+    plan_est = lib_ops.plan_create([_site(abi.DIST_NORMAL, c, c, out_col=-1)])
+    fn = lib_ops.lib._gjx_importance_estimate
+    tick = (C.c_uint32 * abi.LSE_TICKET_WORDS)()
+    buf = (C.c_uint64 * 64)()
+    out = (C.c_float * 1)()
+
+    def io(plan, impl=1, tickets=True, rows=True):
+        lse = abi.LseOut(None, None, None, None, C.addressof(tick) if tickets else None, None, 0.0)
+        return abi.EstimateIO(plan.handle.value, 256, None, 0, impl, C.addressof(buf) if rows else None, C.addressof(buf) if rows else None, lse)
+
+    for bad, lane in ((io(plan_cols), 0), (io(plan_est, tickets=False), 0), (io(plan_est, rows=False), 0), (io(plan_est, impl=0), 5),
+                      (io(plan_est, impl=7), 0)):
+        assert fn(C.byref(bad), 1, 2, lane, C.addressof(out), 0.0, None) == -1
+    assert fn(None, 1, 2, 0, C.addressof(out), 0.0, None) == -1
+    assert fn(C.byref(io(plan_est)), 1, 2, 0, None, 0.0, None) == -1
