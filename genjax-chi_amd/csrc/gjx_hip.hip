@@ -835,6 +835,7 @@ struct LgssmPolicy {
   Key step_key;
   float a, q, y, rs, lognorm;
   float z[kPer];            // the quad's standard normals (prefetch: they do not depend on the ancestors)
+  int wt = 0;               // write-through stores of the state / ancestor columns (store16_out)
   GJX_DEV void select_filter(uint64_t off, Key k) {
     prev_state += off; state_out += off;
     if (anc_out) anc_out += off;
@@ -862,8 +863,8 @@ struct LgssmPolicy {
     const int64_t k = jq - out_lo;
     const bool vec = ((((uintptr_t)state_out | (uintptr_t)anc_out) & 15) == 0);  // uniform
     if (vec && ok[0] && ok[1] && ok[2] && ok[3]) {
-      *reinterpret_cast<float4*>(state_out + k) = make_float4(o[0].x, o[1].x, o[2].x, o[3].x);
-      if (anc_out) *reinterpret_cast<int4*>(anc_out + k) = make_int4((int32_t)anc[0], (int32_t)anc[1], (int32_t)anc[2], (int32_t)anc[3]);
+      store16_out(state_out + k, make_uint4(f2u(o[0].x), f2u(o[1].x), f2u(o[2].x), f2u(o[3].x)), wt != 0);
+      if (anc_out) store16_out(anc_out + k, make_uint4(anc[0], anc[1], anc[2], anc[3]), wt != 0);
       return;
     }
 #pragma unroll
@@ -901,6 +902,7 @@ struct HmmPolicy {
   uint32_t col[kPer], f24[kPer];  // the quad's draws, split into column and fraction (prefetch)
   float oc;                       // obs_logp[tid, y] on its way to LDS
   float* ocol;                    // LDS: column y of the observation table (one entry per state)
+  int wt = 0;                     // write-through stores of the state / ancestor columns (store16_out)
   GJX_DEV void select_filter(uint64_t off, Key k) {
     prev_state += off; state_out += off;
     if (anc_out) anc_out += off;
@@ -946,8 +948,8 @@ struct HmmPolicy {
     const int64_t k = jq - out_lo;
     const bool vec = ((((uintptr_t)state_out | (uintptr_t)anc_out) & 15) == 0);  // uniform
     if (vec && ok[0] && ok[1] && ok[2] && ok[3]) {
-      *reinterpret_cast<int4*>(state_out + k) = make_int4(o[0].z, o[1].z, o[2].z, o[3].z);
-      if (anc_out) *reinterpret_cast<int4*>(anc_out + k) = make_int4((int32_t)anc[0], (int32_t)anc[1], (int32_t)anc[2], (int32_t)anc[3]);
+      store16_out(state_out + k, make_uint4((uint32_t)o[0].z, (uint32_t)o[1].z, (uint32_t)o[2].z, (uint32_t)o[3].z), wt != 0);
+      if (anc_out) store16_out(anc_out + k, make_uint4(anc[0], anc[1], anc[2], anc[3]), wt != 0);
       return;
     }
 #pragma unroll
@@ -2447,6 +2449,8 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
   A.debug_stop = dbg_stop;
   static const int xcd_map = [] { const char* e = std::getenv("GJX_SMC_XCD_MAP"); return e ? atoi(e) : 1; }();
   A.xcd_map = xcd_map;
+  static const int wt_knob = [] { const char* e = std::getenv("GJX_SMC_WT"); return e ? atoi(e) : -1; }();
+  A.wt_stores = wt_knob >= 0 ? wt_knob : (ctx.fb.n_filters > 1 ? 0 : 1);  // (measured: store16_out, gjx_device.hpp)
   // The merged prefix by ONE small launch (a workgroup per filter) instead of in every workgroup: required beyond
   // kMaxLdsTiles, and worth it from a few filters per launch (the whole-run drivers provide prev->prefix then), where its
   // ~4 us are shared by all filters while every one of the F x tiles workgroups saves the merge of its filter's records.
@@ -2483,10 +2487,12 @@ static int lgssm_step(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, fl
   if (rc) return rc;
   if (cfg->impl == 0) {
     LgssmPolicy<0> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}};
+    P.wt = A.wt_stores;
     if (ad) k_resample<0, LgssmPolicy<0>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
     else k_resample<0, LgssmPolicy<0>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   } else {
     LgssmPolicy<1> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}};
+    P.wt = A.wt_stores;
     if (ad) k_resample<1, LgssmPolicy<1>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
     else k_resample<1, LgssmPolicy<1>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   }
@@ -2514,10 +2520,12 @@ static int hmm_step(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_
   if (rc) return rc;
   if (cfg->impl == 0) {
     HmmPolicy<0> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr};
+    P.wt = A.wt_stores;
     if (ad) k_resample<0, HmmPolicy<0>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
     else k_resample<0, HmmPolicy<0>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   } else {
     HmmPolicy<1> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr};
+    P.wt = A.wt_stores;
     if (ad) k_resample<1, HmmPolicy<1>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
     else k_resample<1, HmmPolicy<1>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
   }
