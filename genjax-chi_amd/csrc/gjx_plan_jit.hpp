@@ -428,6 +428,14 @@ inline void emit_prelude(std::ostringstream& o, bool fast_math = false) {
   o << "template <int IMPL> __device__ __forceinline__ int32_t jcat_gumbel(const float* l, uint32_t K, const Stream<IMPL>& st){ int32_t best=0; float bv=-__builtin_inff(); for(uint32_t c=0;c<K;++c){ const float v = l[c] + gumbel_from_bits(st.bits32(c)); if (v>bv || c==0){ bv=v; best=(int32_t)c; } } return best; }\n";
 }
 
+// Write-through (sc1) column stores in the quad kernels when a launch holds ONE pass (store16_out, gjx_device.hpp): the
+// kernel's end no longer waits for the write-back of its 48 MB — 4.94e10 -> 5.47e10 particles/s at one pass per launch;
+// with many passes per launch the write-back overlaps the following passes and plain stores are 1 % faster, hence the
+// run-time flag.  GJX_JIT_WT=0: plain stores always.
+inline bool wt_stores_knob() {
+  const char* e = std::getenv("GJX_JIT_WT");
+  return !(e && e[0] == '0');
+}
 // The sites of a lane that owns NP whole PAIRS of adjacent particles (suffixes A, B [, C, D]) under PHILOX: one cipher
 // block per pair and two draws (pk0 / pk1: the cipher key; pair0 [, pair1]: the pairs' counter words — defined by the
 // caller), one Box-Muller transform per pair and Normal site, every stored column one vector store at `store_at`.
@@ -482,6 +490,9 @@ int cur_pair_blk = -1;
       for (int u = 0; u < P; ++u)
         vals += (u ? ", " : "") + (isint ? "(uint32_t)vi" + Q + sfx[u] : "f2u(vf" + Q + sfx[u] + ")");
       o << "#ifndef GJX_EXP_NO_VALUE_STORES\n";
+      if (P == 4 && wt_stores_knob())
+        o << ind << "store16_out(reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "]) + " << store_at << ", make_uint4(" << vals << "), wt_one_pass);\n";
+      else
       o << ind << "*reinterpret_cast<uint" << P << "*>(reinterpret_cast<uint32_t*>(cols.out[" << st.out_col << "]) + " << store_at << ") = make_uint" << P
         << "(" << vals << ");\n";
       o << "#endif\n";
@@ -539,6 +550,7 @@ struct Gen {
     else o << "  const int wv = threadIdx.x >> 6, pr = threadIdx.x / " << lanes_per_row << ", tr = threadIdx.x % " << lanes_per_row << ";\n";
     o << "  (void)wv;\n";
     o << "  const uint64_t rows_all = (uint64_t)bt.n_pass * bt.rows_per_pass;\n";
+    o << "  const bool wt_one_pass = bt.n_pass <= 1u; (void)wt_one_pass;\n";
     o << "  for (uint64_t g0 = (uint64_t)blockIdx.x * " << R << "; g0 < rows_all; g0 += (uint64_t)gridDim.x * " << R << ") {\n";
     o << "    const uint64_t gr = g0 + pr;\n";
     o << "    const uint32_t pass = (uint32_t)(gr / bt.rows_per_pass);\n";
@@ -575,8 +587,15 @@ struct Gen {
     {
       std::string ws, ss;
       for (int u = 0; u < P; ++u) { ws += (u ? ", w" : "w") + std::string(sfx[u]); ss += (u ? ", sc" : "sc") + std::string(sfx[u]); }
+      if (P == 4 && wt_stores_knob()) {
+        std::string wb, sb;
+        for (int u = 0; u < P; ++u) { wb += (u ? ", f2u(w" : "f2u(w") + std::string(sfx[u]) + ")"; sb += (u ? ", f2u(sc" : "f2u(sc") + std::string(sfx[u]) + ")"; }
+        o << "      if (logw) store16_out(logw + po + iA, make_uint4(" << wb << "), wt_one_pass);\n";
+        o << "      if (score) store16_out(score + po + iA, make_uint4(" << sb << "), wt_one_pass);\n";
+      } else {
       o << "      if (logw) *reinterpret_cast<float" << P << "*>(logw + po + iA) = make_float" << P << "(" << ws << ");\n";
       o << "      if (score) *reinterpret_cast<float" << P << "*>(score + po + iA) = make_float" << P << "(" << ss << ");\n";
+      }
     }
     o << "    }\n";
     o << "    if (max_partials || row_e) {\n";
@@ -677,6 +696,7 @@ struct GenScan {
     o << "extern \"C\" __global__ __launch_bounds__(64) void " << kname()
       << "(KeySrc ks, RunCols cols, ScanArgs sa, float* score, float* logw, float* max_partials, int32_t* row_e, uint64_t* row_s, LseTail tail, PlanTables tabs) {\n";
     o << "  const uint64_t n = sa.n, rows_all = (n + 255) / 256;\n";
+    o << "  const bool wt_one_pass = false; (void)wt_one_pass;  // (a scan's stores spread over its T steps)\n";
     o << "  const uint32_t pk0 = ks.parent.k0, pk1 = ks.parent.k1;\n";
     o << "  for (uint64_t row = blockIdx.x; row < rows_all; row += gridDim.x) {\n";
     o << "    const uint64_t iA = row * 256 + 4 * (uint64_t)threadIdx.x;\n";
