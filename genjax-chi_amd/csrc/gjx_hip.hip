@@ -2791,6 +2791,7 @@ struct gjx_smc_plan {
   std::mutex mu;
   ExprStore init_expr, step_expr;  // GJX_ARG_EXPR programs of the two tables
   StateExprStore init_state_expr, next_state_expr;
+  gjx_jit::ScopeInfo init_scopes, step_scopes;        // nested calls (gjx_smc_plan_create_scoped): generated kernels only
   bool has_expr = false;                              // any program?  Then the filter runs as generated kernels only
   CSite* dev_init = nullptr; CSite* dev_step = nullptr;  // the interpreter's device copies of the tables (made on first use)
 };
@@ -2825,6 +2826,19 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
   *out = p;
   return GJX_OK;
 }
+int gjx_smc_plan_create_scoped(const gjx_smc_model* m, const gjx_scope* init_scopes, int n_init_scopes,
+                               const gjx_scope* step_scopes, int n_step_scopes, gjx_smc_plan** out) {
+  gjx_smc_plan* p = nullptr;
+  const int rc = gjx_smc_plan_create(m, &p);
+  if (rc) return rc;
+  if (!gjx_jit::derive_scopes(m->init_sites, m->n_init_sites, init_scopes, n_init_scopes, p->init_scopes) ||
+      !gjx_jit::derive_scopes(m->step_sites, m->n_step_sites, step_scopes, n_step_scopes, p->step_scopes)) {
+    gjx_smc_plan_destroy(p);
+    return GJX_ERR_INVALID;
+  }
+  *out = p;
+  return GJX_OK;
+}
 int gjx_smc_plan_destroy(gjx_smc_plan* p) {
   if (!p) return GJX_OK;
   for (auto& c : p->jit) gjx_jit::release_smc(&c);  // compiled modules are owned by the process-wide (bounded) cache
@@ -2852,6 +2866,8 @@ static std::string smc_plan_source(const gjx_smc_plan* plan, int impl, PlanTable
   gjx_jit::GenSmc<CSite, CArg> g;
   g.impl = impl; g.init_sites = plan->init; g.n_init = plan->n_init; g.step_sites = plan->step;
   g.n_step = plan->n_step; g.init_state = plan->init_state; g.next_state = plan->next_state; g.n_state = plan->n_state;
+  g.sc_init = plan->init_scopes.n_scopes > 0 ? &plan->init_scopes : nullptr;
+  g.sc_step = plan->step_scopes.n_scopes > 0 ? &plan->step_scopes : nullptr;
   std::string src = g.run();
   if (tabs) *tabs = ts.reg.tables();
   return src;
@@ -2901,7 +2917,7 @@ static int smc_plan_route(gjx_smc_plan* plan, int impl, gjx_jit::CompiledSmc** c
   if (*c_out) return GJX_OK;
   const bool off = !gjx_jit::enabled();
   if (!off && !jit_fallback_allowed()) return GJX_ERR_JIT;  // loud: never a silent slower route
-  if (plan->has_expr) return off ? GJX_ERR_UNSUPPORTED : GJX_ERR_JIT;
+  if (plan->has_expr || plan->init_scopes.n_scopes > 0 || plan->step_scopes.n_scopes > 0) return off ? GJX_ERR_UNSUPPORTED : GJX_ERR_JIT;
   return smc_plan_interp_tables(plan);
 }
 static int smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, gjx_jit::CompiledSmc* cp, int t,

@@ -806,6 +806,8 @@ struct GenSmc {
   const CArgT* init_state;
   const CArgT* next_state;
   int n_state;
+  const ScopeInfo* sc_init = nullptr;  // nested calls inside init / step (null: flat bodies)
+  const ScopeInfo* sc_step = nullptr;
 
   // PHILOX: the four consecutive slots jq .. jq+3 of a lane (jq a multiple of 4) walked together.  One-word draw
   // number f of the quad is ONE block, PH(ctr = (g_lo, g_hi, f, 'Q'), key = step key), g = jq / 4, slot u taking
@@ -814,22 +816,25 @@ struct GenSmc {
   void emit_quad_body(const CSiteT* sites, int n_sites, const CArgT* state_args, bool step) {
     const char* sf[4] = {"A", "B", "C", "D"};
     std::vector<SiteEmitter<CSiteT, CArgT>> em;
+    const ScopeInfo* sc = step ? sc_step : sc_init;
     for (int u = 0; u < 4; ++u) {
       em.push_back(SiteEmitter<CSiteT, CArgT>{o, impl, 1, sites, n_sites, "    ", sf[u]});
       em.back().ext_bits = true;
+      em.back().sc = sc;
     }
     o << "    const uint64_t g = (uint64_t)jq >> 2;\n";
     for (int u = 0; u < 4; ++u) {
       if (step)
         for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << sf[u] << " = a.prev_state[" << k << "][src[" << u << "]];\n";
-      if (em[u].needs_stream_key()) o << "    const Key pkey" << sf[u] << " = slot_key<1>(a.step_key, (uint64_t)jq + " << u << "u);\n";
+      if (em[u].needs_stream_key() || sc) o << "    const Key pkey" << sf[u] << " = slot_key<1>(a.step_key, (uint64_t)jq + " << u << "u);\n";
       o << "    float w" << sf[u] << " = 0.0f, sc" << sf[u] << " = 0.0f;\n";
+      em[u].emit_scope_keys();
     }
     for (int q = 0; q < n_sites; ++q) {
       const CSiteT& st = sites[q];
       const std::string Q = std::to_string(q);
       for (int u = 0; u < 4; ++u) em[u].head(q);
-      const bool drawn = !st.observed && em[0].one_word(st);
+      const bool drawn = !st.observed && em[0].one_word(st) && em[0].scope_of(q) == 0;  // (a callee's sites: their own lone keys)
       if (drawn) {
         o << "    uint32_t qw" << Q << "_0, qw" << Q << "_1, qw" << Q << "_2, qw" << Q << "_3;\n";
         o << "    philox4x32(a.step_key.k0, a.step_key.k1, (uint32_t)g, (uint32_t)(g >> 32), " << em[0].fold_of(q)
@@ -843,6 +848,7 @@ struct GenSmc {
         o << "    bm_pair(bits" << Q << "C, bits" << Q << "D, z" << Q << "C, z" << Q << "D);\n";
       }
       for (int u = 0; u < 4; ++u) em[u].tail(q, normal ? "z" + Q + sf[u] : std::string());
+      for (int u = 0; u < 4; ++u) em[u].close_scopes(q + 1);
     }
     for (int u = 0; u < 4; ++u) {
       for (int k = 0; k < n_state; ++k) o << "    out[" << u << "].s[" << k << "] = " << em[u].arg(state_args[k]) << ";\n";
@@ -860,6 +866,8 @@ struct GenSmc {
     emit_prelude(o);
     SiteEmitter<CSiteT, CArgT> es{o, impl, 1, step_sites, n_step, "    "};
     SiteEmitter<CSiteT, CArgT> ei{o, impl, 1, init_sites, n_init, "        "};
+    es.sc = sc_step;
+    ei.sc = sc_init;
     // ---- step policy
     o << "struct GenPolicy {\n  static constexpr bool kEmit = true;\n  PlanPolicyArgs a;\n  PlanTables tabs;\n";
     o << "  struct Out { float s[" << D << "]; };\n";
@@ -868,7 +876,7 @@ struct GenSmc {
     o << "    if (a.anc_out) a.anc_out += off; a.step_key = k;\n  }\n";
     o << "  __device__ __forceinline__ float compute(int64_t j, uint32_t src_global, Out& out) const {\n";
     for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << " = a.prev_state[" << k << "][src_global];\n";
-    if (es.needs_pk()) o << "    const Key pkey = slot_key<" << I << ">(a.step_key, (uint64_t)j);\n";
+    if (es.needs_pk() || sc_step) o << "    const Key pkey = slot_key<" << I << ">(a.step_key, (uint64_t)j);\n";
     o << "    float w = 0.0f, sc = 0.0f;\n";
     es.run();
     for (int k = 0; k < n_state; ++k) o << "    out.s[" << k << "] = " << es.arg(next_state[k]) << ";\n";
@@ -902,7 +910,7 @@ struct GenSmc {
       o << "        if (a.anc_out) a.anc_out[loc + u] = (int32_t)(gq + u);\n      }\n    }\n  }\n";
     } else {
       o << "  for (int u = 0; u < 4; ++u) {\n    const uint64_t j = gq + u;\n    wq[u] = 0.0f;\n    {\n";
-      if (ei.needs_pk()) o << "        const Key pkey = slot_key<" << I << ">(a.step_key, j);\n";
+      if (ei.needs_pk() || sc_init) o << "        const Key pkey = slot_key<" << I << ">(a.step_key, j);\n";
       o << "        float w = 0.0f, sc = 0.0f;\n";
       ei.run();
       for (int k = 0; k < n_state; ++k) o << "        const float ns_" << k << " = " << ei.arg(init_state[k]) << ";\n";

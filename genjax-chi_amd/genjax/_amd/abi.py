@@ -347,6 +347,7 @@ PROTOTYPES = {
         [C.POINTER(SmcConfig), C.POINTER(Hmm), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
     ),
     "gjx_smc_plan_create": (C.c_int, [C.POINTER(SmcModel), C.POINTER(_P)]),
+    "gjx_smc_plan_create_scoped": (C.c_int, [C.POINTER(SmcModel), C.POINTER(Scope), C.c_int, C.POINTER(Scope), C.c_int, C.POINTER(_P)]),
     "gjx_smc_plan_destroy": (C.c_int, [_P]),
     "gjx_smc_plan_compile_check": (C.c_int, [_P, C.c_int]),
     "gjx_scan_plan_create": (C.c_int, [C.POINTER(ScanModel), C.c_uint32, C.POINTER(_P)]),

@@ -513,7 +513,7 @@ class Ops:
         return cdf.view(n_states, -1), logp
 
     # ---- bootstrap SMC for a user model (init + step site tables) --------------------------------
-    def smc_plan_create(self, init_sites, step_sites, init_state, next_state, n_obs: int) -> "SmcPlan":
+    def smc_plan_create(self, init_sites, step_sites, init_state, next_state, n_obs: int, init_scopes=(), step_scopes=()) -> "SmcPlan":
         m = abi.SmcModel()
         ia = (abi.Site * len(init_sites))(*init_sites)
         sa = (abi.Site * len(step_sites))(*step_sites)
@@ -524,7 +524,12 @@ class Ops:
             m.next_state[k] = a
         m.n_state, m.n_obs = len(next_state), n_obs
         handle = C.c_void_p()
-        self.lib.call("gjx_smc_plan_create", C.byref(m), C.byref(handle))
+        if init_scopes or step_scopes:  # nested `@gen` calls inside init / step
+            si = (abi.Scope * max(1, len(init_scopes)))(*[abi.Scope(*k) for k in init_scopes])
+            ss = (abi.Scope * max(1, len(step_scopes)))(*[abi.Scope(*k) for k in step_scopes])
+            self.lib.call("gjx_smc_plan_create_scoped", C.byref(m), si, len(init_scopes), ss, len(step_scopes), C.byref(handle))
+        else:
+            self.lib.call("gjx_smc_plan_create", C.byref(m), C.byref(handle))
         return SmcPlan(self, handle, len(next_state), n_obs)
 
     # ---- importance over a Scan model: T steps per particle in one launch ------------------------

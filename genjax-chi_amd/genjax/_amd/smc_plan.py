@@ -49,8 +49,7 @@ class _SmcTracer(PlanTracer):
 
     def __init__(self, obs_index: dict):
         super().__init__(ChoiceMap.empty(), 1, use_params=False)
-        self.obs_index = obs_index
-        self.allow_scopes = False  # (nested calls: importance plans only)
+        self.obs_index = obs_index  # full address (the calls' addresses, then the site's) -> observation column
 
     def _arg(self, v) -> abi.Arg:
         if isinstance(v, Sym) and v.src[0] == "state":
@@ -61,11 +60,17 @@ class _SmcTracer(PlanTracer):
             raise PlanUnsupported("per-particle tensors cannot enter an SMC plan")
         return super()._arg(v)
 
+    def _callee_constraint(self, a: tuple) -> ChoiceMap:
+        return ChoiceMap.empty()  # (observed sites are recognised by their full address, see handle_trace)
+
     def handle_trace(self, addr, gen_fn, args):
-        key = addr if isinstance(addr, tuple) else (addr,)
-        if key in self.obs_index:
+        from .lang import Distribution
+
+        local = addr if isinstance(addr, tuple) else (addr,)
+        key = self.prefix + local
+        if isinstance(gen_fn, Distribution) and key in self.obs_index:
             # constrain with a placeholder, then point the site's observed value at the obs vector
-            self.constraint = ChoiceMap.entry(0.0, *key)
+            self.constraint = ChoiceMap.entry(0.0, *local)
             out = super().handle_trace(addr, gen_fn, args)
             k = self.obs_index[key]
             self.sites[-1].obs = abi.Arg(abi.ARG_OBS, k, 1.0, 0.0, None)
@@ -74,7 +79,8 @@ class _SmcTracer(PlanTracer):
             return Sym(self, ("obs", k), is_int=is_int)
         self.constraint = ChoiceMap.empty()
         out = super().handle_trace(addr, gen_fn, args)
-        self.sites[-1].out_col = -1  # SMC plans keep state columns, not per-site columns
+        if isinstance(gen_fn, Distribution):  # (a nested call's own sites have passed through here already)
+            self.sites[-1].out_col = -1  # SMC plans keep state columns, not per-site columns
         return out
 
 
@@ -107,11 +113,12 @@ def build_smc_plan(model: StateSpaceModel, obs_addrs: list[tuple]):
     carry = tuple(Sym(ts, ("state", k)) for k in range(len(init_state)))
     step_ret = ts.run(model.step.source, (carry[0],) if len(carry) == 1 else (carry,))
     next_state = _state_args(ts, step_ret, len(init_state))
-    seen = {(m["addr"] if isinstance(m["addr"], tuple) else (m["addr"],)) for m in ti.meta + ts.meta}
+    seen = {m["path"] for m in ti.meta + ts.meta}
     missing = [a for a in obs_addrs if a not in seen]
     if missing:
         raise ValueError(f"observed addresses not visited by the model: {missing}")
-    plan = get_ops().smc_plan_create(ti.sites, ts.sites, init_state, next_state, len(obs_addrs))
+    plan = get_ops().smc_plan_create(ti.sites, ts.sites, init_state, next_state, len(obs_addrs),
+                                     init_scopes=[tuple(k) for k in ti.scopes], step_scopes=[tuple(k) for k in ts.scopes])
     plan._keep = (ti.keep, ts.keep)  # constant tables the site tables point into
     return plan, len(init_state)
 

@@ -627,6 +627,11 @@ typedef struct {
 } gjx_smc_model;
 typedef struct gjx_smc_plan gjx_smc_plan;
 int gjx_smc_plan_create(const gjx_smc_model* m /*host*/, gjx_smc_plan** out);
+/* The same with nested `@gen` calls inside `init` / `step` (scopes over the two site tables, as gjx_plan_create_scoped): a
+ * callee of slot j runs under fold_in(slot key, the counter its call took) — a lone key, so its draws are its own blocks
+ * (the quad blocks serve the body's own sites only).  Compiled kernels only: the table-walking policy refuses such filters. */
+int gjx_smc_plan_create_scoped(const gjx_smc_model* m /*host*/, const gjx_scope* init_scopes /*host*/, int n_init_scopes,
+                               const gjx_scope* step_scopes /*host*/, int n_step_scopes, gjx_smc_plan** out);
 int gjx_smc_plan_destroy(gjx_smc_plan* p);
 int gjx_smc_plan_compile_check(const gjx_smc_plan* p, int impl); /* offline hiprtc compile, needs no GPU */
 /* obs_host: host f32[T, n_obs].  state_out: host array of n_state dev f32[n] pointers (final-step

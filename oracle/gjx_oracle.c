@@ -575,10 +575,12 @@ static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, sit
       ++draws;
       o_stream strm = o_stream_make(c->impl, si ? skey[si->site_scope[q]] : c->pkey, 1, f);
       /* one-word draws: SMC slots under PHILOX take word (slot & 3) of their quad's block number f */
-      const uint32_t bits0 = c->quad_key ? o_smc_quad_word(c->quad_key, c->slot, f) : o_bits32_at(&strm, 0);
+      /* (a callee's sites draw under their own lone key: the quad's blocks serve the body's own sites only) */
+      const uint32_t* quad_key = (si && si->site_scope[q] != 0) ? NULL : c->quad_key;
+      const uint32_t bits0 = quad_key ? o_smc_quad_word(quad_key, c->slot, f) : o_bits32_at(&strm, 0);
       switch (st->dist) {
         case GJX_DIST_NORMAL: { /* PHILOX pairs draws: importance over particle pairs, SMC inside the slot's quad */
-          float eps = c->quad_key ? o_smc_quad_normal(c->quad_key, c->slot, f)
+          float eps = quad_key ? o_smc_quad_normal(quad_key, c->slot, f)
                     : c->pair_normals ? o_site_normal(&strm) : o_std_normal(bits0);
           float t = a1 * eps; v.f = a0 + t; break; }
         case GJX_DIST_GAMMA: v.f = o_std_gamma(&strm, 0, a0) / a1; break;
@@ -1538,6 +1540,7 @@ struct gjx_smc_plan {
   gjx_site step_sites[GJX_MAX_SITES];
   expr_store init_expr, step_expr;
   state_expr_store init_state_expr, next_state_expr;
+  scope_info init_scopes, step_scopes;
 };
 
 static int smc_arg_ok(const gjx_arg* a, int s, int n_state, int n_obs, int allow_state) {
@@ -1592,10 +1595,25 @@ int gjx_smc_plan_create(const gjx_smc_model* m, gjx_smc_plan** out) {
   state_expr_adopt(p->m.next_state, m->n_state, &p->next_state_expr);
   p->m.init_sites = p->init_sites;
   p->m.step_sites = p->step_sites;
+  p->init_scopes.n_scopes = 0;
+  p->step_scopes.n_scopes = 0;
   *out = p;
   return GJX_OK;
 }
 int gjx_smc_plan_destroy(gjx_smc_plan* p) { free(p); return GJX_OK; }
+int gjx_smc_plan_create_scoped(const gjx_smc_model* m, const gjx_scope* init_scopes, int n_init_scopes,
+                               const gjx_scope* step_scopes, int n_step_scopes, gjx_smc_plan** out) {
+  gjx_smc_plan* p = NULL;
+  int rc = gjx_smc_plan_create(m, &p);
+  if (rc) return rc;
+  if (!derive_scopes(p->init_sites, p->m.n_init_sites, init_scopes, n_init_scopes, &p->init_scopes) ||
+      !derive_scopes(p->step_sites, p->m.n_step_sites, step_scopes, n_step_scopes, &p->step_scopes)) {
+    gjx_smc_plan_destroy(p);
+    return GJX_ERR_INVALID;
+  }
+  *out = p;
+  return GJX_OK;
+}
 int gjo_smc_plan_dims(const gjx_smc_plan* p, int* n_state, int* n_obs) { /* for gjx_oracle_comm.cpp (the plan is opaque there) */
   if (!p) return GJX_ERR_INVALID;
   *n_state = p->m.n_state; *n_obs = p->m.n_obs;
@@ -1735,6 +1753,8 @@ typedef struct {
   const gjx_smc_pop* prev;
   const gjx_smc_pop* out;
   uint32_t skey[4];
+  const scope_info* init_scopes; /* nested calls inside init / step (NULL: flat bodies) */
+  const scope_info* step_scopes;
 } plan_ctx;
 static float plan_propagate(void* vc, uint64_t j, int64_t a) {
   plan_ctx* p = (plan_ctx*)vc;
@@ -1752,6 +1772,7 @@ static float plan_propagate(void* vc, uint64_t j, int64_t a) {
     for (int k = 0; k < D; ++k) prev[k] = ((const float*)p->prev->state[k])[a];
   c.state = a >= 0 ? prev : NULL;
   c.obs = p->obs;
+  c.scopes = p->t == 0 ? p->init_scopes : p->step_scopes;
   const gjx_site* sites = p->t == 0 ? m->init_sites : m->step_sites;
   const int ns = p->t == 0 ? m->n_init_sites : m->n_step_sites;
   const gjx_arg* nxt = p->t == 0 ? m->init_state : m->next_state;
@@ -1768,7 +1789,8 @@ int gjx_smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, cons
   if (!cfg_ok(cfg) || !plan || t < 0 || t >= cfg->n_steps || !out || (t > 0 && !prev) || (plan->m.n_obs > 0 && !obs_t) ||
       cfg->n_filters > 1)
     return GJX_ERR_INVALID;
-  plan_ctx c = {cfg, &plan->m, t, obs_t, prev, out, {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u}};
+  plan_ctx c = {cfg, &plan->m, t, obs_t, prev, out, {cfg->step_keys[2 * t], cfg->step_keys[2 * t + 1], 0u, 0u},
+                &plan->init_scopes, &plan->step_scopes};
   return smc_step_generic(cfg, t, plan->m.n_state, prev, out, prev_e_out, prev_q_out, ancestors_out, plan_propagate, &c);
 }
 
