@@ -1842,7 +1842,37 @@ def case_nested_calls(impl):
         assert torch.equal(ta.get_retval()[0][0].cpu(), tb.get_retval()[0][0].cpu())
         assert torch.equal(torch.as_tensor(ta.get_retval()[1][0]).cpu().expand(ns, T), torch.as_tensor(tb.get_retval()[1][0]).cpu().expand(ns, T))
         assert torch.equal(ta.step_traces[2].get_score().cpu(), tb.step_traces[2].get_score().cpu())
-    # generated SMC filters keep nested calls on the per-site path
+    # a bootstrap filter whose init / step are composed of sub-models: generated kernels with per-scope keys
+    # (gjx_smc_plan_create_scoped); the same LGSSM as the hand-written filter, so the evidence is Kalman's
+    from genjax._amd import workloads as W
+
+    @gen
+    def prior():
+        return normal(0.0, 1.0) @ "x"
+
+    @gen
+    def emit(x):
+        return normal(x, 0.5) @ "y"
+
+    @gen
+    def trans(x):
+        return normal(0.9 * x, 1.0) @ "x"
+
+    @gen
+    def f_init():
+        x = prior() @ "p"
+        emit(x) @ "e"
+        return x
+
+    @gen
+    def f_step(x):
+        x2 = trans(x) @ "t"
+        emit(x2) @ "e"
+        return x2
+
+    yy = W.lgssm_data(25)
+    res = BootstrapSMC(StateSpaceModel(f_init, f_step), C["e", "y"].set(torch.tensor(yy)), 16384).run(genjax.random.key(3, impl))
+    assert res.log_marginal_likelihood == pytest.approx(W.lgssm_exact_log_z(yy), abs=0.5)
 
 
 ALL_CASES = [case_nested_calls, case_fast_estimate_path, case_exact_flip_flip_trivial, case_exact_flip_flip, case_non_marginal_target, case_readme_beta_bernoulli,

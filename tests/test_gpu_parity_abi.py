@@ -937,6 +937,70 @@ def test_smc_plans(hip_ops, oracle_ops, impl):
     same(gen_[4], fixed[4], "ancestors")
 
 
+def _smc_plan_scoped(ops):
+    """A filter whose step is composed of sub-models: transition(x) = {eps ~ normal, g ~ gamma} (scope 1), the body's own
+    x ~ normal(0.8 x_prev + 0.3 eps, 0.4 + 0.1 g) and k ~ flip, emission = {y ~ normal(x, 0.6) observed} (scope 2); init has a
+    nested prior {x0 ~ normal} (scope 1) and an observed y."""
+    A = abi.Arg
+    c = lambda v: A(abi.ARG_CONST, 0, 0.0, v, None)
+
+    def site(dist, a0, a1=None, obs=None):
+        s_ = abi.Site()
+        s_.dist, s_.observed, s_.out_col = dist, 0 if obs is None else 1, -1
+        s_.arg[0] = a0
+        if a1 is not None:
+            s_.arg[1] = a1
+        if obs is not None:
+            s_.obs = obs
+        return s_
+
+    keep = []
+    mean = abi.expr_arg([(abi.EXPR_STATE, 0, 0.0), (abi.EXPR_CONST, 0, 0.8), (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_SITE, 0, 0.0),
+                         (abi.EXPR_CONST, 0, 0.3), (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_ADD, 0, 0.0)], keep)
+    init = [site(abi.DIST_NORMAL, c(0.0), c(1.0)),
+            site(abi.DIST_NORMAL, A(abi.ARG_SITE, 0, 1.0, 0.0, None), c(0.6), A(abi.ARG_OBS, 0, 1.0, 0.0, None))]
+    step = [site(abi.DIST_NORMAL, c(0.0), c(1.0)), site(abi.DIST_GAMMA, c(2.0), c(2.0)),
+            site(abi.DIST_NORMAL, mean, A(abi.ARG_SITE, 1, 0.1, 0.4, None)), site(abi.DIST_BERNOULLI, c(0.3)),
+            site(abi.DIST_NORMAL, A(abi.ARG_SITE, 2, 1.0, 0.0, None), c(0.6), A(abi.ARG_OBS, 0, 1.0, 0.0, None))]
+    plan = ops.smc_plan_create(init, step, [A(abi.ARG_SITE, 0, 1.0, 0.0, None)], [A(abi.ARG_SITE, 2, 1.0, 0.0, None)], 1,
+                               init_scopes=[(0, 0, 1)], step_scopes=[(0, 0, 2), (0, 4, 5)])
+    plan._keep_progs = keep
+    return plan
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_smc_plans_with_nested_calls(hip_ops, oracle_ops, impl):
+    """gjx_smc_plan_create_scoped: a generated filter whose init / step bodies call sub-models — per-scope keys under the
+    slot key, the quad blocks for the body's own sites only — equals the oracle's walk bit for bit (every-step and
+    ESS-adaptive, one filter and three per launch); without the compiler such a filter is refused."""
+    import os
+
+    from genjax._amd import prng
+    from genjax._amd.abi import GjxError
+
+    T, n = 11, 9000
+    y = W.lgssm_data(T)
+    sk, rk = W.smc_key_schedule(prng.key(17, impl), T)
+    hp, op_ = _smc_plan_scoped(hip_ops), _smc_plan_scoped(oracle_ops)
+    for thr in (0.0, 0.5):
+        h = hip_ops.smc_run_plan(hp, impl, n, sk, rk, y, True, ess_threshold=thr)
+        o = oracle_ops.smc_run_plan(op_, impl, n, sk, rk, y, True, ess_threshold=thr)
+        same(h[0], o[0], "step max"); same(h[1], o[1], "step q"); same(h[3], o[3], "logw"); same(h[4], o[4], "ancestors")
+        for a, b in zip(h[2], o[2]):
+            same(a, b, "state column")
+    pairs = [W.smc_key_schedule(prng.key(30 + f, impl), T) for f in range(3)]
+    skf, rkf = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    hb = hip_ops.smc_run_plan(hp, impl, n, skf, rkf, y, True)
+    ob = oracle_ops.smc_run_plan(op_, impl, n, skf, rkf, y, True)
+    same(hb[1], ob[1], "batched step q"); same(hb[4][:, :, :n], ob[4][:, :, :n], "batched ancestors")
+    os.environ["GJX_PLAN_JIT"] = "0"
+    try:
+        with pytest.raises(GjxError):
+            hip_ops.smc_run_plan(_smc_plan_scoped(hip_ops), impl, n, sk, rk, y, False)
+    finally:
+        del os.environ["GJX_PLAN_JIT"]
+
+
 @pytest.mark.parametrize("impl", IMPLS)
 def test_smc_plans_without_the_compiler(hip_ops, oracle_ops, impl):
     """GJX_PLAN_JIT=0: generated filters run through the table-walking policy (k_smc_interp_*: the site table read at run time
