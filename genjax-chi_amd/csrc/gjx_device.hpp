@@ -1223,7 +1223,9 @@ GJX_DEV void store16_out(void* p, uint4 v, bool wt) {
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     v4u_t x;
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    // (s_nop: the compiler's hazard recogniser does not see inside the asm — a 16-byte store must not be followed at once by
+    // a write of its data registers)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
     return;
   }
 #endif
