@@ -1412,6 +1412,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     u0 = A.fb.u0[f];
     P.select_filter((uint64_t)f * A.fb.stride, A.fb.step_key[f]);
   }
+  if ((A.debug_stop & 15) == 15) return;  // (profiling: the launch / dispatch floor)
   const bool adaptive = ADAPTIVE && A.ess_thr > 0.0;
   if (A.xcd_map) {
     // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin, and neighbouring output tiles read
@@ -1455,6 +1456,10 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   for (int r = 0; r < kPer; ++r) marks[tid + r * kBlock] = 0;
   if (tid == 0) sh_klo = ~0u;
   policy_prefetch(P, jq, 0);  // (under the latency of the record loads)
+  if ((A.debug_stop & 15) == 14) {  // (profiling: records loaded, the policy's prefetch done, nothing merged)
+    if (lds_prefix && rs_[0] == 0x123456789abcdefull && re_[0] == 77) marks[0] = 1;
+    return;
+  }
 
   // ---- merge: anchor, shifted masses, exclusive prefix, total, ESS sums ------------------------------------------
   int32_t e = kRowEmpty;

@@ -1,3 +1,7 @@
-for st in 1 2 3 4 5 0; do
+# cumulative per-step time of the one-filter LGSSM step by phase (early exits on a fixed input population):
+#   gpurun -- 'bash tools/phases_smc.sh'
+# 15: launch + dispatch only; 14: + record loads and the policy's prefetch; 1: + merge; 2: + locate; 3: + window scan;
+# 4: + max-scan; 5: + gather and compute; 0: the whole step
+for st in 15 14 1 2 3 4 5 0; do
   echo "stop $st: $(GJX_SMC_DEBUG_FIXED=1 GJX_SMC_DEBUG_STOP=$st python tools/time_lgssm1.py 2>&1 | grep lgssm)"
 done
