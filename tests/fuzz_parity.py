@@ -144,6 +144,11 @@ def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
                     depth -= 1
                 if rng.random() < 0.15:
                     prog.append((abi.EXPR_NEG, 0, 0.0))
+                if rng.random() < 0.12 and len(prog) < 12:  # exp / log of what is on the stack (r03: GJX_EXPR_EXP / _LOG)
+                    if rng.random() < 0.5:
+                        prog += [(abi.EXPR_CONST, 0, float(rng.uniform(-0.4, 0.4))), (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_EXP, 0, 0.0)]
+                    else:
+                        prog.append((abi.EXPR_LOG, 0, 0.0))  # (negative arguments give NaN on both sides)
                 if rng.random() < 0.2 and len(prog) < 12:  # a division by a constant away from zero
                     prog += [(abi.EXPR_CONST, 0, maybe_bad(float(rng.choice([-1, 1]) * rng.uniform(0.5, 3.0)))), (abi.EXPR_DIV, 0, 0.0)]
             while depth >= 2:
@@ -227,6 +232,27 @@ def eq(a, b, what, ctx):
         sys.exit(1)
 
 
+def random_scopes(n_sites):
+    """Random nested calls over a flat table of n_sites sites (gjx_scope, in call order): up to three top-level calls, each
+    maybe with one callee of its own, some without any site."""
+    if rng.random() < 0.5 or n_sites < 1:
+        return []
+    out, pos = [], 0
+    for _ in range(int(rng.integers(1, 4))):
+        if pos > n_sites:
+            break
+        b = int(rng.integers(pos, n_sites + 1))
+        e = int(rng.integers(b, n_sites + 1))
+        out.append((0, b, e))
+        me = len(out)
+        if e > b and rng.random() < 0.5:  # a callee of this call
+            ib = int(rng.integers(b, e + 1))
+            ie = int(rng.integers(ib, e + 1))
+            out.append((me, ib, ie))
+        pos = e
+    return out
+
+
 t_end, cases = time.time() + budget, 0
 while time.time() < t_end:
     impl = int(rng.integers(2))
@@ -242,9 +268,11 @@ while time.time() < t_end:
         params = [maybe_bad(float(x)) for x in rng.uniform(-1, 1, 4)] + [maybe_bad(float(x)) for x in rng.uniform(0.5, 2.0, 2)]
         cols = [torch.from_numpy(rng.uniform(-1, 1, n).astype(np.float32)) for _ in range(n_inputs)]
         outs = []
+        scopes = random_scopes(len(sites))
+        ctx["scopes"] = scopes
         for ops in (hip, ora):
             bound, keep = bind_tables(ops, sites, tables)
-            plan = ops.plan_create(bound)
+            plan = ops.plan_create(bound, scopes=scopes)
             plan.set_params(params)
             keys = kb if rng.random() < 0.7 or True else kb
             vals, score, logw, mp, rows = ops.importance_run(plan, keys, n, [c_.to(ops.device()) for c_ in cols], dtypes_for(sites, kinds),
@@ -265,9 +293,11 @@ while time.time() < t_end:
         obs = np.stack([[maybe_bad(float(x)) for x in rng.uniform(-1, 1, T)], rng.integers(0, 2, T)], axis=1).astype(np.float32)
         carry0 = [maybe_bad(float(rng.uniform(-1, 1))) for _ in range(n_state)]
         outs = []
+        scopes = random_scopes(len(sites))
+        ctx["scopes"] = scopes
         for ops in (hip, ora):
             bound, keep = bind_tables(ops, sites, tables)
-            plan = ops.scan_plan_create(bound, nxt, n_obs)
+            plan = ops.scan_plan_create(bound, nxt, n_obs, scopes=scopes)
             o = ops.scan_run(plan, kb, n, T, obs, carry0, dtypes_for(sites, kinds))
             outs.append(o["values"] + o["carry"] + [o["score"], o["logw"], o["max_partials"], o["rows"].e, o["rows"].s])
         for i, (a, b) in enumerate(zip(*outs)):
@@ -293,8 +323,10 @@ while time.time() < t_end:
         skeys, rkeys = W.smc_key_schedule(prng.key(seed, impl), T)
         ess = float(rng.choice([0.0, 0.0, 0.5]))
         outs = []
+        isc, ssc = random_scopes(len(init)), random_scopes(len(step))
+        ctx["scopes"] = (isc, ssc)
         for ops in (hip, ora):
-            plan = ops.smc_plan_create(init, step, istate, nstate, n_obs)
+            plan = ops.smc_plan_create(init, step, istate, nstate, n_obs, init_scopes=isc, step_scopes=ssc)
             r = ops.smc_run_plan(plan, impl, n, skeys, rkeys, obs, True, ess_threshold=ess, want_flags=True)
             outs.append([r[0], r[1], *r[2], r[3], r[4]] + ([r[5]] if r[5] is not None else []))
         for i, (a, b) in enumerate(zip(*outs)):
