@@ -144,11 +144,10 @@ def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
                     depth -= 1
                 if rng.random() < 0.15:
                     prog.append((abi.EXPR_NEG, 0, 0.0))
-                if rng.random() < 0.12 and len(prog) < 12:  # exp / log of what is on the stack (r03: GJX_EXPR_EXP / _LOG)
-                    if rng.random() < 0.5:
-                        prog += [(abi.EXPR_CONST, 0, float(rng.uniform(-0.4, 0.4))), (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_EXP, 0, 0.0)]
-                    else:
-                        prog.append((abi.EXPR_LOG, 0, 0.0))  # (negative arguments give NaN on both sides)
+                if rng.random() < 0.12 and len(prog) < 9:  # exp / log of what is on the stack (r03: GJX_EXPR_EXP / _LOG)
+                    prog += [(abi.EXPR_CONST, 0, float(rng.uniform(-0.4, 0.4))), (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_EXP, 0, 0.0)]
+                    if rng.random() < 0.5:  # log(exp(c x) + k), k > 0: a positive argument (p_invalid runs reach the others)
+                        prog += [(abi.EXPR_CONST, 0, maybe_bad(float(rng.uniform(0.1, 2.0)))), (abi.EXPR_ADD, 0, 0.0), (abi.EXPR_LOG, 0, 0.0)]
                 if rng.random() < 0.2 and len(prog) < 12:  # a division by a constant away from zero
                     prog += [(abi.EXPR_CONST, 0, maybe_bad(float(rng.choice([-1, 1]) * rng.uniform(0.5, 3.0)))), (abi.EXPR_DIV, 0, 0.0)]
             while depth >= 2:
