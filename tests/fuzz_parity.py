@@ -153,6 +153,8 @@ def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
             while depth >= 2:
                 prog.append((int(rng.choice([abi.EXPR_ADD, abi.EXPR_SUB, abi.EXPR_MUL])), 0, 0.0))
                 depth -= 1
+            if len(prog) > abi.MAX_EXPR_OPS:  # (too long for one argument: draw another)
+                return expr_loc()
             return abi.expr_arg(prog, EXPR_KEEP)
 
         if dist == abi.DIST_NORMAL:
