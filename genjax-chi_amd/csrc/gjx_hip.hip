@@ -1379,7 +1379,8 @@ __global__ __launch_bounds__(kBlock) void k_map_f32(const float* x, float c, flo
     const uint64_t i = i0 + r;
     if (i < n) {
       const float v = x[i];
-      out[i] = OP == GJX_MAP_EXP ? e_exp(v) : (OP == GJX_MAP_LOG ? m_log(v) : (OP == GJX_MAP_DIV ? v / c : c / v));
+      out[i] = OP == GJX_MAP_EXP ? e_exp(v) : OP == GJX_MAP_LOG ? m_log(v) : OP == GJX_MAP_DIV ? v / c : OP == GJX_MAP_RDIV ? c / v
+               : OP == GJX_MAP_SQRT ? __builtin_sqrtf(v) : __builtin_fabsf(v);
     }
   }
 }
@@ -1640,7 +1641,7 @@ static bool expr_ok(const gjx_arg& a, int s, int n_state, int n_obs, bool allow_
       case GJX_EXPR_STATE: if (n_state < 0 || !allow_state || r < 0 || r >= n_state) return false; ++depth; break;
       case GJX_EXPR_OBS: if (n_state < 0 || r < 0 || r >= n_obs) return false; ++depth; break;
       case GJX_EXPR_ADD: case GJX_EXPR_SUB: case GJX_EXPR_MUL: case GJX_EXPR_DIV: if (depth < 2) return false; --depth; break;
-      case GJX_EXPR_NEG: case GJX_EXPR_EXP: case GJX_EXPR_LOG: if (depth < 1) return false; break;
+      case GJX_EXPR_NEG: case GJX_EXPR_EXP: case GJX_EXPR_LOG: case GJX_EXPR_SQRT: case GJX_EXPR_ABS: if (depth < 1) return false; break;
       default: return false;
     }
     if (depth > 8) return false;
@@ -1973,13 +1974,15 @@ int gjx_plan_prepare(gjx_plan* p, const gjx_keys* pk) {
 
 // One launch of a plan over n_pass independent passes (n_pass == 1: the plain call).
 int gjx_map_f32(int op, const float* x, float c, float* out, uint64_t n, gjx_stream s) {
-  if (!x || !out || op < GJX_MAP_EXP || op > GJX_MAP_RDIV) return GJX_ERR_INVALID;
+  if (!x || !out || op < GJX_MAP_EXP || op > GJX_MAP_ABS) return GJX_ERR_INVALID;
   if (n == 0) return GJX_OK;
   const unsigned grid = (unsigned)((n + 4ull * kBlock - 1) / (4ull * kBlock));
   switch (op) {
     case GJX_MAP_EXP: k_map_f32<GJX_MAP_EXP><<<grid, kBlock, 0, S(s)>>>(x, c, out, n); break;
     case GJX_MAP_LOG: k_map_f32<GJX_MAP_LOG><<<grid, kBlock, 0, S(s)>>>(x, c, out, n); break;
     case GJX_MAP_DIV: k_map_f32<GJX_MAP_DIV><<<grid, kBlock, 0, S(s)>>>(x, c, out, n); break;
+    case GJX_MAP_SQRT: k_map_f32<GJX_MAP_SQRT><<<grid, kBlock, 0, S(s)>>>(x, c, out, n); break;
+    case GJX_MAP_ABS: k_map_f32<GJX_MAP_ABS><<<grid, kBlock, 0, S(s)>>>(x, c, out, n); break;
     default: k_map_f32<GJX_MAP_RDIV><<<grid, kBlock, 0, S(s)>>>(x, c, out, n); break;
   }
   return launch_status();

@@ -192,6 +192,8 @@ struct SiteEmitter {
             case GJX_EXPR_NEG: st.back() = "(-" + st.back() + ")"; break;
             case GJX_EXPR_EXP: st.back() = "e_exp(" + st.back() + ")"; break;
             case GJX_EXPR_LOG: st.back() = "m_log(" + st.back() + ")"; break;
+            case GJX_EXPR_SQRT: st.back() = "__builtin_sqrtf(" + st.back() + ")"; break;
+            case GJX_EXPR_ABS: st.back() = "__builtin_fabsf(" + st.back() + ")"; break;
             default: {
               const std::string b = st.back();
               st.pop_back();
@@ -262,6 +264,8 @@ struct SiteEmitter {
             if (ops[k].op == GJX_EXPR_NEG) { stk[d - 1] = -stk[d - 1]; continue; }
             if (ops[k].op == GJX_EXPR_EXP) { stk[d - 1] = gjx::e_exp(stk[d - 1]); continue; }
             if (ops[k].op == GJX_EXPR_LOG) { stk[d - 1] = gjx::m_log(stk[d - 1]); continue; }
+            if (ops[k].op == GJX_EXPR_SQRT) { stk[d - 1] = __builtin_sqrtf(stk[d - 1]); continue; }
+            if (ops[k].op == GJX_EXPR_ABS) { stk[d - 1] = __builtin_fabsf(stk[d - 1]); continue; }
             const float y = stk[--d], x = stk[d - 1];
             stk[d - 1] = ops[k].op == GJX_EXPR_ADD ? x + y : (ops[k].op == GJX_EXPR_SUB ? x - y : (ops[k].op == GJX_EXPR_MUL ? x * y : x / y));
           }

@@ -553,12 +553,30 @@ def _spec_rdiv(b, a):
     return _spec_div(a, b)
 
 
+def _spec_sigmoid(x, *a, **k):
+    """1 / (1 + exp(-x)): the steps the fused program takes (plan._sym_sigmoid), each through the spec's function."""
+    if a or k or not isinstance(x, torch.Tensor):
+        return NotImplemented
+    ops = get_ops()
+    e = ops.map_f32(abi.MAP_EXP, -_spec_plain(x).to(torch.float32))
+    return ops.map_f32(abi.MAP_RDIV, e + 1.0, 1.0).as_subclass(SpecTensor)
+
+
+def _spec_reciprocal(x, *a, **k):
+    if a or k or not isinstance(x, torch.Tensor):
+        return NotImplemented
+    return get_ops().map_f32(abi.MAP_RDIV, _spec_plain(x), 1.0).as_subclass(SpecTensor)
+
+
 _SPEC_FUNCS = {
     torch.exp: _spec_unary(abi.MAP_EXP), torch.Tensor.exp: _spec_unary(abi.MAP_EXP),
     torch.log: _spec_unary(abi.MAP_LOG), torch.Tensor.log: _spec_unary(abi.MAP_LOG),
+    torch.sqrt: _spec_unary(abi.MAP_SQRT), torch.Tensor.sqrt: _spec_unary(abi.MAP_SQRT),
     torch.div: _spec_div, torch.true_divide: _spec_div, torch.Tensor.div: _spec_div, torch.Tensor.true_divide: _spec_div,
     torch.Tensor.__truediv__: _spec_div, torch.Tensor.__rtruediv__: _spec_rdiv,
-}
+    torch.sigmoid: _spec_sigmoid, torch.Tensor.sigmoid: _spec_sigmoid, torch.nn.functional.sigmoid: _spec_sigmoid,
+    torch.reciprocal: _spec_reciprocal, torch.Tensor.reciprocal: _spec_reciprocal,
+}  # (abs, square, negation: torch's own results are exact; sqrt: the device's may not be correctly rounded)
 
 
 def _spec_wrap(v):

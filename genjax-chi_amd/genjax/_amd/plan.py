@@ -112,15 +112,31 @@ class Sym:
     def log(self):
         return SymExpr.unop(abi.EXPR_LOG, self)
 
+    def sqrt(self):
+        return SymExpr.unop(abi.EXPR_SQRT, self)
+
+    def abs(self):
+        return SymExpr.unop(abi.EXPR_ABS, self)
+
+    __abs__ = abs
+
+    def sigmoid(self):
+        return _sym_sigmoid(self)
+
+    def reciprocal(self):
+        return SymExpr.binop(abi.EXPR_DIV, 1.0, self)
+
+    def square(self):
+        return SymExpr.binop(abi.EXPR_MUL, self, self)
+
     __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
-    __lt__ = __le__ = __gt__ = __ge__ = __abs__ = __index__ = __array__ = __len__ = __iter__ = _no
+    __lt__ = __le__ = __gt__ = __ge__ = __index__ = __array__ = __len__ = __iter__ = _no
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
-        if func in _UNARY_FUNCS and len(args) == 1 and not kwargs:
-            return SymExpr.unop(_UNARY_FUNCS[func], args[0])
-        if func in _DIV_FUNCS and len(args) == 2 and not kwargs:
-            return SymExpr.binop(abi.EXPR_DIV, args[0], args[1])
+        r = _sym_torch_function(func, args, kwargs)
+        if r is not NotImplemented:
+            return r
         # `table[sym]`: a constant tensor indexed by a traced integer-valued value — a 1-D table gives a distribution
         # argument (`means[idx]`), a 2-D one the logits / probs ROW of a categorical site (`trans[z]`)
         if func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[0], torch.Tensor) \
@@ -212,19 +228,24 @@ class SymExpr:
     def __rtruediv__(self, o): return SymExpr.binop(abi.EXPR_DIV, o, self)  # noqa: E704
     def exp(self): return SymExpr.unop(abi.EXPR_EXP, self)  # noqa: E704
     def log(self): return SymExpr.unop(abi.EXPR_LOG, self)  # noqa: E704
+    def sqrt(self): return SymExpr.unop(abi.EXPR_SQRT, self)  # noqa: E704
+    def abs(self): return SymExpr.unop(abi.EXPR_ABS, self)  # noqa: E704
+    __abs__ = abs
+    def sigmoid(self): return _sym_sigmoid(self)  # noqa: E704
+    def reciprocal(self): return SymExpr.binop(abi.EXPR_DIV, 1.0, self)  # noqa: E704
+    def square(self): return SymExpr.binop(abi.EXPR_MUL, self, self)  # noqa: E704
 
     def _no(self, *a, **k):
         raise PlanUnsupported("unsupported operation on a traced expression")
 
     __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
-    __lt__ = __le__ = __gt__ = __ge__ = __abs__ = __index__ = __array__ = __len__ = __iter__ = _no
+    __lt__ = __le__ = __gt__ = __ge__ = __index__ = __array__ = __len__ = __iter__ = _no
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
-        if func in _UNARY_FUNCS and len(args) == 1 and not kwargs:
-            return SymExpr.unop(_UNARY_FUNCS[func], args[0])
-        if func in _DIV_FUNCS and len(args) == 2 and not kwargs:
-            return SymExpr.binop(abi.EXPR_DIV, args[0], args[1])
+        r = _sym_torch_function(func, args, kwargs)
+        if r is not NotImplemented:
+            return r
         raise PlanUnsupported(f"torch.{getattr(func, '__name__', func)} on a traced expression")
 
     def evaluate(self, leaf):
@@ -239,8 +260,8 @@ class SymExpr:
                 st.append(v)
             elif op == abi.EXPR_NEG:
                 st[-1] = -st[-1]
-            elif op in (abi.EXPR_EXP, abi.EXPR_LOG):
-                st[-1] = get_ops().map_f32(abi.MAP_EXP if op == abi.EXPR_EXP else abi.MAP_LOG, st[-1])
+            elif op in _UNARY_MAP:
+                st[-1] = get_ops().map_f32(_UNARY_MAP[op], st[-1])
             else:
                 b = st.pop()
                 a = st.pop()
@@ -256,8 +277,33 @@ class SymExpr:
         return st[0]
 
 
-_UNARY_FUNCS = {torch.exp: abi.EXPR_EXP, torch.Tensor.exp: abi.EXPR_EXP, torch.log: abi.EXPR_LOG, torch.Tensor.log: abi.EXPR_LOG}
+_UNARY_MAP = {abi.EXPR_EXP: abi.MAP_EXP, abi.EXPR_LOG: abi.MAP_LOG, abi.EXPR_SQRT: abi.MAP_SQRT, abi.EXPR_ABS: abi.MAP_ABS}
+_UNARY_FUNCS = {torch.exp: abi.EXPR_EXP, torch.Tensor.exp: abi.EXPR_EXP, torch.log: abi.EXPR_LOG, torch.Tensor.log: abi.EXPR_LOG,
+                torch.sqrt: abi.EXPR_SQRT, torch.Tensor.sqrt: abi.EXPR_SQRT, torch.abs: abi.EXPR_ABS, torch.Tensor.abs: abi.EXPR_ABS,
+                torch.absolute: abi.EXPR_ABS}
 _DIV_FUNCS = (torch.div, torch.true_divide, torch.Tensor.div, torch.Tensor.true_divide)
+
+
+def _sym_sigmoid(x):
+    """sigmoid(x) = 1 / (1 + exp(-x)) in the spec's steps (one rounding each): what lang.SpecTensor computes per site."""
+    return SymExpr.binop(abi.EXPR_DIV, 1.0, SymExpr.binop(abi.EXPR_ADD, SymExpr.unop(abi.EXPR_EXP, SymExpr.unop(abi.EXPR_NEG, x)), 1.0))
+
+
+def _sym_torch_function(func, args, kwargs):
+    """torch functions of traced values that lower to the expression program (NotImplemented: not one of them)."""
+    if kwargs:
+        return NotImplemented
+    if func in _UNARY_FUNCS and len(args) == 1:
+        return SymExpr.unop(_UNARY_FUNCS[func], args[0])
+    if func in _DIV_FUNCS and len(args) == 2:
+        return SymExpr.binop(abi.EXPR_DIV, args[0], args[1])
+    if func in (torch.sigmoid, torch.Tensor.sigmoid, torch.nn.functional.sigmoid) and len(args) == 1:
+        return _sym_sigmoid(args[0])
+    if func in (torch.reciprocal, torch.Tensor.reciprocal) and len(args) == 1:
+        return SymExpr.binop(abi.EXPR_DIV, 1.0, args[0])
+    if func in (torch.square, torch.Tensor.square) and len(args) == 1:
+        return SymExpr.binop(abi.EXPR_MUL, args[0], args[0])
+    return NotImplemented
 
 
 class ParamVal:

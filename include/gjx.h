@@ -133,8 +133,9 @@ int gjx_sample_logpdf_categorical(const gjx_keys* k, const float* logits, uint64
 /* Elementwise f32 functions of the spec over a column: what `exp` / `log` / a division by a number between the sites
  * of a model body (jnp.exp, jnp.log, x / c in the reference's bodies, e.g. tests/inference/test_smc.py:63) compute on
  * the per-site path — the same bits GJX_EXPR_EXP / _LOG / _DIV compute inside a fused plan, so a body gives the same
- * trace whichever route it takes.  out[i] = exp(x[i]) | log(x[i]) | x[i] / c | c / x[i]; x, out dev f32[n] (may alias). */
-enum { GJX_MAP_EXP = 0, GJX_MAP_LOG = 1, GJX_MAP_DIV = 2, GJX_MAP_RDIV = 3 };
+ * trace whichever route it takes.  out[i] = exp(x[i]) | log(x[i]) | x[i] / c | c / x[i] | sqrt(x[i]) | |x[i]|; x, out dev f32[n]
+ * (may alias).  (sigmoid(x) = 1 / (1 + exp(-x)) is these steps, on both routes: the host API expands it.) */
+enum { GJX_MAP_EXP = 0, GJX_MAP_LOG = 1, GJX_MAP_DIV = 2, GJX_MAP_RDIV = 3, GJX_MAP_SQRT = 4, GJX_MAP_ABS = 5 };
 int gjx_map_f32(int op, const float* x, float c, float* out, uint64_t n, gjx_stream s);
 
 /* log-density of given values (constrained sites: distribution.py:144-147, 383-396). */
@@ -200,7 +201,9 @@ typedef enum {
   GJX_EXPR_NEG = 9,   /* pop a, push -a */
   GJX_EXPR_DIV = 10,  /* pop b, pop a, push a / b (IEEE, correctly rounded) */
   GJX_EXPR_EXP = 11,  /* pop a, push exp(a): the spec's f32 exp (gjx_map_f32 GJX_MAP_EXP computes the same bits) */
-  GJX_EXPR_LOG = 12   /* pop a, push log(a): the spec's f32 log (0 -> -inf, negative -> NaN) */
+  GJX_EXPR_LOG = 12,  /* pop a, push log(a): the spec's f32 log (0 -> -inf, negative -> NaN) */
+  GJX_EXPR_SQRT = 13, /* pop a, push sqrt(a) (IEEE, correctly rounded; negative -> NaN) */
+  GJX_EXPR_ABS = 14   /* pop a, push |a| */
 } gjx_expr_opcode;
 typedef struct {
   int32_t op;   /* gjx_expr_opcode */

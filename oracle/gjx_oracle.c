@@ -311,7 +311,7 @@ static int expr_ok(const gjx_arg* a, int s, int n_state, int n_obs, int allow_st
       case GJX_EXPR_STATE: if (n_state < 0 || !allow_state || ops[k].ref < 0 || ops[k].ref >= n_state) return 0; ++depth; break;
       case GJX_EXPR_OBS: if (n_state < 0 || ops[k].ref < 0 || ops[k].ref >= n_obs) return 0; ++depth; break;
       case GJX_EXPR_ADD: case GJX_EXPR_SUB: case GJX_EXPR_MUL: case GJX_EXPR_DIV: if (depth < 2) return 0; --depth; break;
-      case GJX_EXPR_NEG: case GJX_EXPR_EXP: case GJX_EXPR_LOG: if (depth < 1) return 0; break;
+      case GJX_EXPR_NEG: case GJX_EXPR_EXP: case GJX_EXPR_LOG: case GJX_EXPR_SQRT: case GJX_EXPR_ABS: if (depth < 1) return 0; break;
       default: return 0;
     }
     if (depth > 8) return 0;
@@ -520,6 +520,8 @@ static inline float eval_arg(const gjx_arg* a, const site_val* vals, const walk_
           case GJX_EXPR_DIV: { const float r = st[d - 2] / st[d - 1]; st[--d - 1] = r; break; }
           case GJX_EXPR_EXP: st[d - 1] = o_e_exp(st[d - 1]); break;
           case GJX_EXPR_LOG: st[d - 1] = o_log(st[d - 1]); break;
+          case GJX_EXPR_SQRT: st[d - 1] = sqrtf(st[d - 1]); break;
+          case GJX_EXPR_ABS: st[d - 1] = fabsf(st[d - 1]); break;
           default: st[d - 1] = -st[d - 1]; break; /* GJX_EXPR_NEG */
         }
       }
@@ -621,11 +623,12 @@ static void site_walk(const gjx_site* sites, int n_sites, const walk_ctx* c, sit
 int gjx_plan_prepare(gjx_plan* p, const gjx_keys* pk) { return (p && keys_ok(pk)) ? GJX_OK : GJX_ERR_INVALID; }
 int gjx_map_f32(int op, const float* x, float c, float* out, uint64_t n, gjx_stream s) {
   (void)s;
-  if (!x || !out || op < GJX_MAP_EXP || op > GJX_MAP_RDIV) return GJX_ERR_INVALID;
+  if (!x || !out || op < GJX_MAP_EXP || op > GJX_MAP_ABS) return GJX_ERR_INVALID;
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < (int64_t)n; ++i) {
     const float v = x[i];
-    out[i] = op == GJX_MAP_EXP ? o_e_exp(v) : (op == GJX_MAP_LOG ? o_log(v) : (op == GJX_MAP_DIV ? v / c : c / v));
+    out[i] = op == GJX_MAP_EXP ? o_e_exp(v) : op == GJX_MAP_LOG ? o_log(v) : op == GJX_MAP_DIV ? v / c : op == GJX_MAP_RDIV ? c / v
+             : op == GJX_MAP_SQRT ? sqrtf(v) : fabsf(v);
   }
   return GJX_OK;
 }

@@ -143,7 +143,9 @@ def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
                     prog.append((int(rng.choice([abi.EXPR_ADD, abi.EXPR_SUB, abi.EXPR_MUL])), 0, 0.0))
                     depth -= 1
                 if rng.random() < 0.15:
-                    prog.append((abi.EXPR_NEG, 0, 0.0))
+                    prog.append((int(rng.choice([abi.EXPR_NEG, abi.EXPR_NEG, abi.EXPR_ABS])), 0, 0.0))
+                if rng.random() < 0.06:
+                    prog += [(abi.EXPR_ABS, 0, 0.0), (abi.EXPR_SQRT, 0, 0.0)]
                 if rng.random() < 0.12 and len(prog) < 9:  # exp / log of what is on the stack (r03: GJX_EXPR_EXP / _LOG)
                     prog += [(abi.EXPR_CONST, 0, float(rng.uniform(-0.4, 0.4))), (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_EXP, 0, 0.0)]
                     if rng.random() < 0.5:  # log(exp(c x) + k), k > 0: a positive argument (p_invalid runs reach the others)

@@ -497,8 +497,21 @@ def case_expression_arguments(impl):
             assert torch.equal(torch.as_tensor(ftr.get_subtrace(a).get_score()).to(torch.float32).expand(n),
                                torch.as_tensor(eager.get_subtrace(a).get_score()).to(torch.float32).expand(n)), addr
 
+    xs_l = [-1.5, -0.3, 0.4, 1.2, 2.0]
+
+    @gen
+    def logistic(scale):  # Bayesian logistic regression: flip(sigmoid(w x + b)) per datum; sqrt / abs / reciprocal / square too
+        w = normal(0.0, scale) @ "w"
+        b = normal(0.0, 1.0) @ "b"
+        for i, x in enumerate(xs_l):
+            flip(torch.sigmoid(w * x + b)) @ ("y", i)
+        r = gamma(torch.sqrt(w * w + 1.0), torch.abs(b) + 0.5) @ "r"
+        return normal(torch.reciprocal(r + 1.0), torch.square(w).sqrt() + 0.1) @ "t"
+
+    ys = C["y", 0].set(False) | C["y", 1].set(False) | C["y", 2].set(True) | C["y", 3].set(True) | C["y", 4].set(True)
     for fn, args, chm in ((ratio, (), C["d"].set(0.1)), (halves, (), C.n()), (halves, (), C["d"].set(-0.3)),
-                          (logscale, (0.2,), C["y"].set(0.7)), (logscale, (0.2,), C.n())):
+                          (logscale, (0.2,), C["y"].set(0.7)), (logscale, (0.2,), C.n()), (logistic, (1.5,), ys),
+                          (logistic, (1.5,), C.n()), (logistic, (1.5,), ys | C["t"].set(0.3))):
         same_trace(fn, args, chm)
     tr, w = ratio.importance(keys, C["d"].set(0.1), ())
     assert w.shape == (n,) and bool(torch.isfinite(w).all())

@@ -273,8 +273,9 @@ def test_map_f32(hip_ops, oracle_ops):
 
     x = torch.cat([map_inputs(), torch.randn(1 << 20) * 30])
     xd = dev(x, hip_ops)
-    for op in (abi.MAP_EXP, abi.MAP_LOG):
+    for op in (abi.MAP_EXP, abi.MAP_LOG, abi.MAP_ABS):
         same(hip_ops.map_f32(op, xd), oracle_ops.map_f32(op, x), f"map {op}")
+    same_or_both_nan(hip_ops.map_f32(abi.MAP_SQRT, xd), oracle_ops.map_f32(abi.MAP_SQRT, x), "sqrt")  # (the NaN of a negative argument: its sign is the platform's)
     for c in (3.0, 0.1, -7.25, 1e-30, 2.263):
         same(hip_ops.map_f32(abi.MAP_DIV, xd, c), oracle_ops.map_f32(abi.MAP_DIV, x, c), "x / c")
         same(hip_ops.map_f32(abi.MAP_RDIV, xd, c), oracle_ops.map_f32(abi.MAP_RDIV, x, c), "c / x")

@@ -121,6 +121,8 @@ def test_map_f32_against_numpy(oracle_ops):
         for c in (3.0, 0.1, -7.25, 1e-30):
             assert np.array_equal(oracle_ops.map_f32(abi.MAP_DIV, x, c).numpy(), xn / np.float32(c), equal_nan=True)
             assert np.array_equal(oracle_ops.map_f32(abi.MAP_RDIV, x, c).numpy(), np.float32(c) / xn, equal_nan=True)
+        assert np.array_equal(oracle_ops.map_f32(abi.MAP_SQRT, x).numpy(), np.sqrt(xn), equal_nan=True)  # correctly rounded
+        assert np.array_equal(oracle_ops.map_f32(abi.MAP_ABS, x).numpy(), np.abs(xn), equal_nan=True)
     assert oracle_ops.map_f32(abi.MAP_EXP, torch.zeros(3, 4)).shape == (3, 4)
 
 
