@@ -426,6 +426,10 @@ GJX_HD float e_exp(float x) {
   return m_exp(x);
 }
 
+// max / min as a model body writes them (GJX_EXPR_MAX / _MIN; torch.maximum / jnp.maximum): a NaN if either argument is one.
+GJX_HD float e_max(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+GJX_HD float e_min(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+
 // --- opt-in FAST math for importance plans (gjx.h: GJX_PLAN_FAST_MATH).  The north star asks for log-weights within
 // 1e-5 relative of the reference on a path WITHOUT resampling, so an importance plan may trade the bit-exact
 // polynomials for the hardware transcendentals (v_log_f32 / v_exp_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32: ~1 ulp,

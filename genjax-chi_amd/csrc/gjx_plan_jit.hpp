@@ -194,6 +194,12 @@ struct SiteEmitter {
             case GJX_EXPR_LOG: st.back() = "m_log(" + st.back() + ")"; break;
             case GJX_EXPR_SQRT: st.back() = "__builtin_sqrtf(" + st.back() + ")"; break;
             case GJX_EXPR_ABS: st.back() = "__builtin_fabsf(" + st.back() + ")"; break;
+            case GJX_EXPR_MAX: case GJX_EXPR_MIN: {
+              const std::string b = st.back();
+              st.pop_back();
+              st.back() = std::string(ops[k].op == GJX_EXPR_MAX ? "e_max(" : "e_min(") + st.back() + ", " + b + ")";
+              break;
+            }
             default: {
               const std::string b = st.back();
               st.pop_back();
@@ -267,7 +273,8 @@ struct SiteEmitter {
             if (ops[k].op == GJX_EXPR_SQRT) { stk[d - 1] = __builtin_sqrtf(stk[d - 1]); continue; }
             if (ops[k].op == GJX_EXPR_ABS) { stk[d - 1] = __builtin_fabsf(stk[d - 1]); continue; }
             const float y = stk[--d], x = stk[d - 1];
-            stk[d - 1] = ops[k].op == GJX_EXPR_ADD ? x + y : (ops[k].op == GJX_EXPR_SUB ? x - y : (ops[k].op == GJX_EXPR_MUL ? x * y : x / y));
+            stk[d - 1] = ops[k].op == GJX_EXPR_ADD ? x + y : ops[k].op == GJX_EXPR_SUB ? x - y : ops[k].op == GJX_EXPR_MUL ? x * y
+                         : ops[k].op == GJX_EXPR_MAX ? gjx::e_max(x, y) : ops[k].op == GJX_EXPR_MIN ? gjx::e_min(x, y) : x / y;
           }
           v = stk[0];
         } else if (a.kind != GJX_ARG_CONST) {

@@ -568,7 +568,18 @@ def _spec_reciprocal(x, *a, **k):
     return get_ops().map_f32(abi.MAP_RDIV, _spec_plain(x), 1.0).as_subclass(SpecTensor)
 
 
+def _spec_softplus(x, *a, **k):
+    """max(x, 0) + log(1 + exp(-|x|)) in the fused program's steps (plan._sym_torch_function)."""
+    if a or k or not isinstance(x, torch.Tensor):
+        return NotImplemented
+    ops = get_ops()
+    xp = _spec_plain(x).to(torch.float32)
+    t = ops.map_f32(abi.MAP_LOG, ops.map_f32(abi.MAP_EXP, -xp.abs()) + 1.0)
+    return (torch.maximum(xp, torch.zeros((), dtype=torch.float32, device=xp.device)) + t.to(xp.device)).as_subclass(SpecTensor)
+
+
 _SPEC_FUNCS = {
+    torch.nn.functional.softplus: _spec_softplus,
     torch.exp: _spec_unary(abi.MAP_EXP), torch.Tensor.exp: _spec_unary(abi.MAP_EXP),
     torch.log: _spec_unary(abi.MAP_LOG), torch.Tensor.log: _spec_unary(abi.MAP_LOG),
     torch.sqrt: _spec_unary(abi.MAP_SQRT), torch.Tensor.sqrt: _spec_unary(abi.MAP_SQRT),

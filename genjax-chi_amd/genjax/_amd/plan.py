@@ -273,6 +273,10 @@ class SymExpr:
                     continue
                 if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.device != b.device:
                     a, b = (a.to(b.device), b) if a.dim() == 0 else (a, b.to(a.device))
+                if op in (abi.EXPR_MAX, abi.EXPR_MIN):  # (torch's own maximum / minimum: exact, a NaN if either is one)
+                    a, b = torch.broadcast_tensors(a, b)
+                    st.append(torch.maximum(a, b) if op == abi.EXPR_MAX else torch.minimum(a, b))
+                    continue
                 st.append(a + b if op == abi.EXPR_ADD else (a - b if op == abi.EXPR_SUB else (a * b if op == abi.EXPR_MUL else a / b)))
         return st[0]
 
@@ -292,6 +296,8 @@ def _sym_sigmoid(x):
 def _sym_torch_function(func, args, kwargs):
     """torch functions of traced values that lower to the expression program (NotImplemented: not one of them)."""
     if kwargs:
+        if func in (torch.clamp, torch.Tensor.clamp, torch.clip, torch.Tensor.clip) and len(args) == 1 and set(kwargs) <= {"min", "max"}:
+            return _sym_torch_function(func, (args[0], kwargs.get("min"), kwargs.get("max")), None)
         return NotImplemented
     if func in _UNARY_FUNCS and len(args) == 1:
         return SymExpr.unop(_UNARY_FUNCS[func], args[0])
@@ -303,6 +309,22 @@ def _sym_torch_function(func, args, kwargs):
         return SymExpr.binop(abi.EXPR_DIV, 1.0, args[0])
     if func in (torch.square, torch.Tensor.square) and len(args) == 1:
         return SymExpr.binop(abi.EXPR_MUL, args[0], args[0])
+    if func in (torch.maximum, torch.Tensor.maximum, torch.minimum, torch.Tensor.minimum) and len(args) == 2:
+        return SymExpr.binop(abi.EXPR_MAX if func in (torch.maximum, torch.Tensor.maximum) else abi.EXPR_MIN, args[0], args[1])
+    if func in (torch.clamp, torch.Tensor.clamp, torch.clip, torch.Tensor.clip) and 1 <= len(args) <= 3:
+        x = args[0]
+        lo = args[1] if len(args) > 1 else None
+        hi = args[2] if len(args) > 2 else None
+        if lo is not None:
+            x = SymExpr.binop(abi.EXPR_MAX, x, lo)
+        if hi is not None:
+            x = SymExpr.binop(abi.EXPR_MIN, x, hi)
+        return x
+    if func is torch.nn.functional.softplus and len(args) == 1:
+        # max(x, 0) + log(1 + exp(-|x|)): no overflow for large x (what lang._spec_softplus computes per site)
+        x = args[0]
+        t = SymExpr.unop(abi.EXPR_LOG, SymExpr.binop(abi.EXPR_ADD, SymExpr.unop(abi.EXPR_EXP, SymExpr.unop(abi.EXPR_NEG, SymExpr.unop(abi.EXPR_ABS, x))), 1.0))
+        return SymExpr.binop(abi.EXPR_ADD, SymExpr.binop(abi.EXPR_MAX, x, 0.0), t)
     return NotImplemented
 
 

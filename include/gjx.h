@@ -203,7 +203,9 @@ typedef enum {
   GJX_EXPR_EXP = 11,  /* pop a, push exp(a): the spec's f32 exp (gjx_map_f32 GJX_MAP_EXP computes the same bits) */
   GJX_EXPR_LOG = 12,  /* pop a, push log(a): the spec's f32 log (0 -> -inf, negative -> NaN) */
   GJX_EXPR_SQRT = 13, /* pop a, push sqrt(a) (IEEE, correctly rounded; negative -> NaN) */
-  GJX_EXPR_ABS = 14   /* pop a, push |a| */
+  GJX_EXPR_ABS = 14,  /* pop a, push |a| */
+  GJX_EXPR_MAX = 15,  /* pop b, pop a, push max(a, b): a NaN if either is one (torch.maximum / jnp.maximum) */
+  GJX_EXPR_MIN = 16   /* ... min(a, b) */
 } gjx_expr_opcode;
 typedef struct {
   int32_t op;   /* gjx_expr_opcode */

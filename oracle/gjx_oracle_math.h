@@ -257,6 +257,10 @@ static inline float o_e_exp(float x) {
   return o_exp(x);
 }
 
+/* max / min as a model body writes them (GJX_EXPR_MAX / _MIN): a NaN if either argument is one */
+static inline float o_e_max(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+static inline float o_e_min(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+
 static inline float o_erfinv(float x) {
   float w = -o_log((1.0f - x) * (1.0f + x));
   float p;

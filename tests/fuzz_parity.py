@@ -140,7 +140,7 @@ def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
                 prog.append(operand())
                 depth += 1
                 while depth >= 2 and rng.random() < 0.7:
-                    prog.append((int(rng.choice([abi.EXPR_ADD, abi.EXPR_SUB, abi.EXPR_MUL])), 0, 0.0))
+                    prog.append((int(rng.choice([abi.EXPR_ADD, abi.EXPR_SUB, abi.EXPR_MUL, abi.EXPR_ADD, abi.EXPR_MAX, abi.EXPR_MIN])), 0, 0.0))
                     depth -= 1
                 if rng.random() < 0.15:
                     prog.append((int(rng.choice([abi.EXPR_NEG, abi.EXPR_NEG, abi.EXPR_ABS])), 0, 0.0))

@@ -506,6 +506,8 @@ def case_expression_arguments(impl):
         for i, x in enumerate(xs_l):
             flip(torch.sigmoid(w * x + b)) @ ("y", i)
         r = gamma(torch.sqrt(w * w + 1.0), torch.abs(b) + 0.5) @ "r"
+        s2 = normal(torch.clamp(w, min=-0.5, max=0.7), torch.nn.functional.softplus(b)) @ "s2"
+        _ = normal(torch.maximum(s2, torch.tensor(0.1)), torch.minimum(r, torch.tensor(1.5)) + 0.2) @ "s3"
         return normal(torch.reciprocal(r + 1.0), torch.square(w).sqrt() + 0.1) @ "t"
 
     ys = C["y", 0].set(False) | C["y", 1].set(False) | C["y", 2].set(True) | C["y", 3].set(True) | C["y", 4].set(True)
