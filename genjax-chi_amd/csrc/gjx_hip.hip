@@ -1641,8 +1641,13 @@ static bool expr_ok(const gjx_arg& a, int s, int n_state, int n_obs, bool allow_
       case GJX_EXPR_STATE: if (n_state < 0 || !allow_state || r < 0 || r >= n_state) return false; ++depth; break;
       case GJX_EXPR_OBS: if (n_state < 0 || r < 0 || r >= n_obs) return false; ++depth; break;
       case GJX_EXPR_ADD: case GJX_EXPR_SUB: case GJX_EXPR_MUL: case GJX_EXPR_DIV: case GJX_EXPR_MAX: case GJX_EXPR_MIN:
+      case GJX_EXPR_LT: case GJX_EXPR_LE: case GJX_EXPR_EQ:
         if (depth < 2) return false;
         --depth;
+        break;
+      case GJX_EXPR_SELECT:
+        if (depth < 3) return false;
+        depth -= 2;
         break;
       case GJX_EXPR_NEG: case GJX_EXPR_EXP: case GJX_EXPR_LOG: case GJX_EXPR_SQRT: case GJX_EXPR_ABS: if (depth < 1) return false; break;
       default: return false;

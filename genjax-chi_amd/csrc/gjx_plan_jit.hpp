@@ -194,6 +194,21 @@ struct SiteEmitter {
             case GJX_EXPR_LOG: st.back() = "m_log(" + st.back() + ")"; break;
             case GJX_EXPR_SQRT: st.back() = "__builtin_sqrtf(" + st.back() + ")"; break;
             case GJX_EXPR_ABS: st.back() = "__builtin_fabsf(" + st.back() + ")"; break;
+            case GJX_EXPR_LT: case GJX_EXPR_LE: case GJX_EXPR_EQ: {
+              const std::string b = st.back();
+              st.pop_back();
+              const char* op = ops[k].op == GJX_EXPR_LT ? " < " : (ops[k].op == GJX_EXPR_LE ? " <= " : " == ");
+              st.back() = "((" + st.back() + op + b + ") ? 1.0f : 0.0f)";
+              break;
+            }
+            case GJX_EXPR_SELECT: {
+              const std::string f = st.back();
+              st.pop_back();
+              const std::string t = st.back();
+              st.pop_back();
+              st.back() = "((" + st.back() + " != 0.0f) ? " + t + " : " + f + ")";
+              break;
+            }
             case GJX_EXPR_MAX: case GJX_EXPR_MIN: {
               const std::string b = st.back();
               st.pop_back();
@@ -272,6 +287,12 @@ struct SiteEmitter {
             if (ops[k].op == GJX_EXPR_LOG) { stk[d - 1] = gjx::m_log(stk[d - 1]); continue; }
             if (ops[k].op == GJX_EXPR_SQRT) { stk[d - 1] = __builtin_sqrtf(stk[d - 1]); continue; }
             if (ops[k].op == GJX_EXPR_ABS) { stk[d - 1] = __builtin_fabsf(stk[d - 1]); continue; }
+            if (ops[k].op == GJX_EXPR_SELECT) { const float r = stk[d - 3] != 0.0f ? stk[d - 2] : stk[d - 1]; d -= 2; stk[d - 1] = r; continue; }
+            if (ops[k].op == GJX_EXPR_LT || ops[k].op == GJX_EXPR_LE || ops[k].op == GJX_EXPR_EQ) {
+              const float y = stk[--d], x = stk[d - 1];
+              stk[d - 1] = (ops[k].op == GJX_EXPR_LT ? x < y : (ops[k].op == GJX_EXPR_LE ? x <= y : x == y)) ? 1.0f : 0.0f;
+              continue;
+            }
             const float y = stk[--d], x = stk[d - 1];
             stk[d - 1] = ops[k].op == GJX_EXPR_ADD ? x + y : ops[k].op == GJX_EXPR_SUB ? x - y : ops[k].op == GJX_EXPR_MUL ? x * y
                          : ops[k].op == GJX_EXPR_MAX ? gjx::e_max(x, y) : ops[k].op == GJX_EXPR_MIN ? gjx::e_min(x, y) : x / y;

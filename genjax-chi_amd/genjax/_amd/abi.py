@@ -38,7 +38,7 @@ DIST_NORMAL, DIST_GAMMA, DIST_BETA, DIST_BERNOULLI, DIST_CATEGORICAL = range(5)
 ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE, ARG_STATE, ARG_OBS, ARG_PARAM, ARG_EXPR = range(8)
 # postfix programs as distribution arguments (gjx.h: GJX_ARG_EXPR / gjx_expr_op)
 (EXPR_CONST, EXPR_SITE, EXPR_INPUT, EXPR_PARAM, EXPR_STATE, EXPR_OBS, EXPR_ADD, EXPR_SUB, EXPR_MUL, EXPR_NEG, EXPR_DIV, EXPR_EXP,
- EXPR_LOG, EXPR_SQRT, EXPR_ABS, EXPR_MAX, EXPR_MIN) = range(17)
+ EXPR_LOG, EXPR_SQRT, EXPR_ABS, EXPR_MAX, EXPR_MIN, EXPR_LT, EXPR_LE, EXPR_EQ, EXPR_SELECT) = range(21)
 EXPR_UNARY = (EXPR_NEG, EXPR_EXP, EXPR_LOG, EXPR_SQRT, EXPR_ABS)
 MAP_EXP, MAP_LOG, MAP_DIV, MAP_RDIV, MAP_SQRT, MAP_ABS = range(6)
 MAX_EXPR_OPS, MAX_EXPR_DEPTH = 16, 8

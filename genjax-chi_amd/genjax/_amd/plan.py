@@ -130,7 +130,17 @@ class Sym:
         return SymExpr.binop(abi.EXPR_MUL, self, self)
 
     __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
-    __lt__ = __le__ = __gt__ = __ge__ = __index__ = __array__ = __len__ = __iter__ = _no
+    __index__ = __array__ = __len__ = __iter__ = _no
+
+    # comparisons give conditions (0 / 1 values of the program: `torch.where(x > 0.5, a, b)`); `==` stays Python's identity
+    def __lt__(self, o): return SymExpr.binop(abi.EXPR_LT, self, o)  # noqa: E704
+    def __le__(self, o): return SymExpr.binop(abi.EXPR_LE, self, o)  # noqa: E704
+    def __gt__(self, o): return SymExpr.binop(abi.EXPR_LT, o, self)  # noqa: E704
+    def __ge__(self, o): return SymExpr.binop(abi.EXPR_LE, o, self)  # noqa: E704
+    def __and__(self, o): return _logical(abi.EXPR_MUL, self, o)  # noqa: E704
+    def __or__(self, o): return _logical(abi.EXPR_MAX, self, o)  # noqa: E704
+    def __invert__(self): return _logical(abi.EXPR_SUB, 1.0, self)  # noqa: E704
+    __rand__, __ror__ = __and__, __or__
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -163,15 +173,16 @@ class SymExpr:
     program of `abi.ARG_EXPR`: operands push a value, `+ - * /` pop two, unary minus one; every operator is one f32 rounding,
     in the order the model body wrote it (what the per-site column path computes with torch's f32 tensor arithmetic)."""
 
-    __slots__ = ("tracer", "prog")
+    __slots__ = ("tracer", "prog", "cond")
 
     def __init__(self, tracer, prog):
         self.tracer, self.prog = tracer, prog
+        self.cond = bool(prog) and prog[-1][0] in (abi.EXPR_LT, abi.EXPR_LE, abi.EXPR_EQ)  # a 0 / 1 value (see _logical)
         if len(prog) > abi.MAX_EXPR_OPS:
             raise PlanUnsupported("expression too long for a plan argument")
         depth = deepest = 0
         for op, _, _ in prog:
-            depth += 1 if op <= abi.EXPR_OBS else (0 if op in abi.EXPR_UNARY else -1)
+            depth += 1 if op <= abi.EXPR_OBS else (0 if op in abi.EXPR_UNARY else (-2 if op == abi.EXPR_SELECT else -1))
             deepest = max(deepest, depth)
         if deepest > abi.MAX_EXPR_DEPTH:
             raise PlanUnsupported("expression too deep for a plan argument")
@@ -217,6 +228,19 @@ class SymExpr:
         tr, pa = cls.program_of(a, getattr(a, "tracer", None))
         return cls(tr, pa + [(op, 0, 0.0)])
 
+    @classmethod
+    def select(cls, c, t, f):
+        """`where(c, t, f)`: c a traced condition (a comparison, a flip value); a constant condition selects on the host."""
+        if not isinstance(c, (Sym, SymExpr)):
+            if isinstance(c, (bool, int)) or (isinstance(c, torch.Tensor) and c.dim() == 0):
+                return t if bool(c) else f
+            raise PlanUnsupported("where() with a condition that is neither traced nor a scalar")
+        tr = c.tracer
+        _, pc = cls.program_of(c, tr)
+        _, pt = cls.program_of(t, tr)
+        _, pf = cls.program_of(f, tr)
+        return cls(tr, pc + pt + pf + [(abi.EXPR_SELECT, 0, 0.0)])
+
     def __add__(self, o): return SymExpr.binop(abi.EXPR_ADD, self, o)  # noqa: E704
     def __radd__(self, o): return SymExpr.binop(abi.EXPR_ADD, o, self)  # noqa: E704
     def __sub__(self, o): return SymExpr.binop(abi.EXPR_SUB, self, o)  # noqa: E704
@@ -239,7 +263,16 @@ class SymExpr:
         raise PlanUnsupported("unsupported operation on a traced expression")
 
     __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
-    __lt__ = __le__ = __gt__ = __ge__ = __index__ = __array__ = __len__ = __iter__ = _no
+    __index__ = __array__ = __len__ = __iter__ = _no
+
+    def __lt__(self, o): return SymExpr.binop(abi.EXPR_LT, self, o)  # noqa: E704
+    def __le__(self, o): return SymExpr.binop(abi.EXPR_LE, self, o)  # noqa: E704
+    def __gt__(self, o): return SymExpr.binop(abi.EXPR_LT, o, self)  # noqa: E704
+    def __ge__(self, o): return SymExpr.binop(abi.EXPR_LE, o, self)  # noqa: E704
+    def __and__(self, o): return _logical(abi.EXPR_MUL, self, o)  # noqa: E704
+    def __or__(self, o): return _logical(abi.EXPR_MAX, self, o)  # noqa: E704
+    def __invert__(self): return _logical(abi.EXPR_SUB, 1.0, self)  # noqa: E704
+    __rand__, __ror__ = __and__, __or__
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -273,6 +306,17 @@ class SymExpr:
                     continue
                 if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.device != b.device:
                     a, b = (a.to(b.device), b) if a.dim() == 0 else (a, b.to(a.device))
+                if op == abi.EXPR_SELECT:  # (b is f, a is t: the condition lies below them)
+                    c = st.pop()
+                    dev = next((v.device for v in (c, a, b) if v.dim()), c.device)  # (0-dim constants follow the columns)
+                    c, a, b = torch.broadcast_tensors(c.to(dev), a.to(dev), b.to(dev))
+                    st.append(torch.where(c != 0, a, b))
+                    continue
+                if op in (abi.EXPR_LT, abi.EXPR_LE, abi.EXPR_EQ):
+                    if a.device != b.device:
+                        a, b = (a.to(b.device), b) if a.dim() == 0 else (a, b.to(a.device))
+                    st.append((a < b if op == abi.EXPR_LT else (a <= b if op == abi.EXPR_LE else a == b)).to(torch.float32))
+                    continue
                 if op in (abi.EXPR_MAX, abi.EXPR_MIN):  # (torch's own maximum / minimum: exact, a NaN if either is one)
                     a, b = torch.broadcast_tensors(a, b)
                     st.append(torch.maximum(a, b) if op == abi.EXPR_MAX else torch.minimum(a, b))
@@ -286,6 +330,38 @@ _UNARY_FUNCS = {torch.exp: abi.EXPR_EXP, torch.Tensor.exp: abi.EXPR_EXP, torch.l
                 torch.sqrt: abi.EXPR_SQRT, torch.Tensor.sqrt: abi.EXPR_SQRT, torch.abs: abi.EXPR_ABS, torch.Tensor.abs: abi.EXPR_ABS,
                 torch.absolute: abi.EXPR_ABS}
 _DIV_FUNCS = (torch.div, torch.true_divide, torch.Tensor.div, torch.Tensor.true_divide)
+
+
+_T = torch.Tensor
+_ARITH_FUNCS = {torch.add: (abi.EXPR_ADD, False), _T.add: (abi.EXPR_ADD, False), _T.__add__: (abi.EXPR_ADD, False),
+                _T.__radd__: (abi.EXPR_ADD, True), torch.sub: (abi.EXPR_SUB, False), _T.sub: (abi.EXPR_SUB, False),
+                _T.__sub__: (abi.EXPR_SUB, False), _T.__rsub__: (abi.EXPR_SUB, True), torch.mul: (abi.EXPR_MUL, False),
+                _T.mul: (abi.EXPR_MUL, False), _T.__mul__: (abi.EXPR_MUL, False), _T.__rmul__: (abi.EXPR_MUL, True),
+                torch.multiply: (abi.EXPR_MUL, False), torch.subtract: (abi.EXPR_SUB, False),
+                _T.__truediv__: (abi.EXPR_DIV, False), _T.__rtruediv__: (abi.EXPR_DIV, True)}
+_CMP_FUNCS = {torch.lt: (abi.EXPR_LT, False), torch.Tensor.lt: (abi.EXPR_LT, False), torch.le: (abi.EXPR_LE, False),
+              torch.Tensor.le: (abi.EXPR_LE, False), torch.gt: (abi.EXPR_LT, True), torch.Tensor.gt: (abi.EXPR_LT, True),
+              torch.ge: (abi.EXPR_LE, True), torch.Tensor.ge: (abi.EXPR_LE, True), torch.eq: (abi.EXPR_EQ, False),
+              torch.Tensor.eq: (abi.EXPR_EQ, False)}
+
+
+def _is_condition(v) -> bool:
+    """A 0 / 1 value: a comparison (or a combination of conditions), a flip site, a boolean constant."""
+    if isinstance(v, SymExpr):
+        return v.cond
+    if isinstance(v, Sym):
+        m = v.tracer.meta[v.src[1]] if v.src[0] == "site" and not (v.has_mul or v.has_add) else None
+        return m is not None and m["dtype"] == torch.bool
+    return isinstance(v, bool) or (isinstance(v, torch.Tensor) and v.dim() == 0 and v.dtype == torch.bool)
+
+
+def _logical(op, a, b):
+    """and = product, or = maximum, not = 1 - c — of CONDITIONS only (`&` on other integers is bitwise: not lowered)."""
+    if not all(_is_condition(v) for v in (a, b) if not (isinstance(v, float) and op == abi.EXPR_SUB)):
+        raise PlanUnsupported("& | ~ on values that are not conditions")
+    r = SymExpr.binop(op, a, b)
+    r.cond = True
+    return r
 
 
 def _sym_sigmoid(x):
@@ -303,6 +379,11 @@ def _sym_torch_function(func, args, kwargs):
         return SymExpr.unop(_UNARY_FUNCS[func], args[0])
     if func in _DIV_FUNCS and len(args) == 2:
         return SymExpr.binop(abi.EXPR_DIV, args[0], args[1])
+    if func in _ARITH_FUNCS and len(args) == 2:  # (a constant TENSOR on the left: `tensor + traced` arrives here)
+        op, swap = _ARITH_FUNCS[func]
+        return SymExpr.binop(op, args[1], args[0]) if swap else SymExpr.binop(op, args[0], args[1])
+    if func in (torch.neg, torch.Tensor.neg, torch.negative, torch.Tensor.__neg__) and len(args) == 1:
+        return -args[0]
     if func in (torch.sigmoid, torch.Tensor.sigmoid, torch.nn.functional.sigmoid) and len(args) == 1:
         return _sym_sigmoid(args[0])
     if func in (torch.reciprocal, torch.Tensor.reciprocal) and len(args) == 1:
@@ -320,6 +401,19 @@ def _sym_torch_function(func, args, kwargs):
         if hi is not None:
             x = SymExpr.binop(abi.EXPR_MIN, x, hi)
         return x
+    if func in _CMP_FUNCS and len(args) == 2:
+        op, swap = _CMP_FUNCS[func]
+        return SymExpr.binop(op, args[1], args[0]) if swap else SymExpr.binop(op, args[0], args[1])
+    if func in (torch.ne, torch.Tensor.ne) and len(args) == 2:
+        return _logical(abi.EXPR_SUB, 1.0, SymExpr.binop(abi.EXPR_EQ, args[0], args[1]))
+    if func in (torch.where, torch.Tensor.where) and len(args) == 3:  # jnp.where(cond, t, f)
+        return SymExpr.select(args[0], args[1], args[2])
+    if func in (torch.logical_and, _T.logical_and, torch.bitwise_and, _T.bitwise_and, _T.__and__, _T.__rand__) and len(args) == 2:
+        return _logical(abi.EXPR_MUL, args[0], args[1])
+    if func in (torch.logical_or, _T.logical_or, torch.bitwise_or, _T.bitwise_or, _T.__or__, _T.__ror__) and len(args) == 2:
+        return _logical(abi.EXPR_MAX, args[0], args[1])
+    if func in (torch.logical_not, _T.logical_not, torch.bitwise_not, _T.bitwise_not, _T.__invert__) and len(args) == 1:
+        return _logical(abi.EXPR_SUB, 1.0, args[0])
     if func is torch.nn.functional.softplus and len(args) == 1:
         # max(x, 0) + log(1 + exp(-|x|)): no overflow for large x (what lang._spec_softplus computes per site)
         x = args[0]

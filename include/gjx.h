@@ -205,7 +205,11 @@ typedef enum {
   GJX_EXPR_SQRT = 13, /* pop a, push sqrt(a) (IEEE, correctly rounded; negative -> NaN) */
   GJX_EXPR_ABS = 14,  /* pop a, push |a| */
   GJX_EXPR_MAX = 15,  /* pop b, pop a, push max(a, b): a NaN if either is one (torch.maximum / jnp.maximum) */
-  GJX_EXPR_MIN = 16   /* ... min(a, b) */
+  GJX_EXPR_MIN = 16,  /* ... min(a, b) */
+  GJX_EXPR_LT = 17,   /* pop b, pop a, push a < b ? 1 : 0 (IEEE: false with a NaN) */
+  GJX_EXPR_LE = 18,   /* ... a <= b */
+  GJX_EXPR_EQ = 19,   /* ... a == b */
+  GJX_EXPR_SELECT = 20 /* pop f, pop t, pop c, push c != 0 ? t : f (jnp.where(c, t, f)) */
 } gjx_expr_opcode;
 typedef struct {
   int32_t op;   /* gjx_expr_opcode */

@@ -311,8 +311,13 @@ static int expr_ok(const gjx_arg* a, int s, int n_state, int n_obs, int allow_st
       case GJX_EXPR_STATE: if (n_state < 0 || !allow_state || ops[k].ref < 0 || ops[k].ref >= n_state) return 0; ++depth; break;
       case GJX_EXPR_OBS: if (n_state < 0 || ops[k].ref < 0 || ops[k].ref >= n_obs) return 0; ++depth; break;
       case GJX_EXPR_ADD: case GJX_EXPR_SUB: case GJX_EXPR_MUL: case GJX_EXPR_DIV: case GJX_EXPR_MAX: case GJX_EXPR_MIN:
+      case GJX_EXPR_LT: case GJX_EXPR_LE: case GJX_EXPR_EQ:
         if (depth < 2) return 0;
         --depth;
+        break;
+      case GJX_EXPR_SELECT:
+        if (depth < 3) return 0;
+        depth -= 2;
         break;
       case GJX_EXPR_NEG: case GJX_EXPR_EXP: case GJX_EXPR_LOG: case GJX_EXPR_SQRT: case GJX_EXPR_ABS: if (depth < 1) return 0; break;
       default: return 0;
@@ -523,6 +528,10 @@ static inline float eval_arg(const gjx_arg* a, const site_val* vals, const walk_
           case GJX_EXPR_DIV: { const float r = st[d - 2] / st[d - 1]; st[--d - 1] = r; break; }
           case GJX_EXPR_MAX: { const float r = o_e_max(st[d - 2], st[d - 1]); st[--d - 1] = r; break; }
           case GJX_EXPR_MIN: { const float r = o_e_min(st[d - 2], st[d - 1]); st[--d - 1] = r; break; }
+          case GJX_EXPR_LT: { const float r = st[d - 2] < st[d - 1] ? 1.0f : 0.0f; st[--d - 1] = r; break; }
+          case GJX_EXPR_LE: { const float r = st[d - 2] <= st[d - 1] ? 1.0f : 0.0f; st[--d - 1] = r; break; }
+          case GJX_EXPR_EQ: { const float r = st[d - 2] == st[d - 1] ? 1.0f : 0.0f; st[--d - 1] = r; break; }
+          case GJX_EXPR_SELECT: { const float r = st[d - 3] != 0.0f ? st[d - 2] : st[d - 1]; d -= 2; st[d - 1] = r; break; }
           case GJX_EXPR_EXP: st[d - 1] = o_e_exp(st[d - 1]); break;
           case GJX_EXPR_LOG: st[d - 1] = o_log(st[d - 1]); break;
           case GJX_EXPR_SQRT: st[d - 1] = sqrtf(st[d - 1]); break;

@@ -30,7 +30,9 @@ def _expr(rng, reals, params, depth=0):
     if r < 0.52:  # what reference bodies write between sites: exp / log of a traced value, a division by (of) a number
         x = str(rng.choice(reals))
         lit = round(float(rng.uniform(0.3, 3.0)), 3)
-        return str(rng.choice([f"torch.clamp({x}, min={-lit}, max={lit})", f"torch.nn.functional.softplus({x})",
+        y = str(rng.choice(reals))
+        return str(rng.choice([f"torch.where({x} > {round(lit - 1.5, 3)}, {x}, {y} * 0.5)", f"torch.where(({x} < {y}) | ({y} >= {lit}), {lit}, {x})",
+                               f"torch.clamp({x}, min={-lit}, max={lit})", f"torch.nn.functional.softplus({x})",
                                f"torch.maximum({x}, torch.tensor({round(lit - 1.5, 3)}))", f"torch.sigmoid({x} * {lit})", f"torch.sqrt({x} * {x} + {lit})", f"torch.abs({x})", f"({x} + {lit}).abs().sqrt()",
                                f"torch.reciprocal({x} * {x} + {lit})",
                                f"torch.exp({x} * {round(float(rng.uniform(-0.5, 0.5)), 3)})", f"torch.log({x} * {x} + {lit})",

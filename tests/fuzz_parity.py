@@ -146,6 +146,9 @@ def random_sites(n_sites, mode, n_state=0, n_obs=0, n_inputs=0, tables=None):
                     prog.append((int(rng.choice([abi.EXPR_NEG, abi.EXPR_NEG, abi.EXPR_ABS])), 0, 0.0))
                 if rng.random() < 0.06:
                     prog += [(abi.EXPR_ABS, 0, 0.0), (abi.EXPR_SQRT, 0, 0.0)]
+                if rng.random() < 0.08 and len(prog) < 9:  # where(top < c, t, f) with the stack's top as the compared value
+                    prog += [(abi.EXPR_CONST, 0, float(rng.uniform(-1, 1))), (int(rng.choice([abi.EXPR_LT, abi.EXPR_LE, abi.EXPR_EQ])), 0, 0.0), operand(),
+                             (abi.EXPR_CONST, 0, float(rng.uniform(-1, 1))), (abi.EXPR_SELECT, 0, 0.0)]
                 if rng.random() < 0.12 and len(prog) < 9:  # exp / log of what is on the stack (r03: GJX_EXPR_EXP / _LOG)
                     prog += [(abi.EXPR_CONST, 0, float(rng.uniform(-0.4, 0.4))), (abi.EXPR_MUL, 0, 0.0), (abi.EXPR_EXP, 0, 0.0)]
                     if rng.random() < 0.5:  # log(exp(c x) + k), k > 0: a positive argument (p_invalid runs reach the others)

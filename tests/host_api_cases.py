@@ -510,7 +510,20 @@ def case_expression_arguments(impl):
         _ = normal(torch.maximum(s2, torch.tensor(0.1)), torch.minimum(r, torch.tensor(1.5)) + 0.2) @ "s3"
         return normal(torch.reciprocal(r + 1.0), torch.square(w).sqrt() + 0.1) @ "t"
 
+    @gen
+    def mixture(sep):  # jnp.where on a flip value and on comparisons of traced values; conditions combined with & | ~
+        k = flip(0.3) @ "k"
+        u = normal(0.0, 1.0) @ "u"
+        m = torch.where(k, sep, -sep)
+        x = normal(m + torch.where(u > 0.5, u, u * 0.25), 0.6) @ "x"
+        c = (x > -1.0) & (x < 1.0) | ~(u <= 0.0)
+        s_ = torch.where(c, torch.tensor(0.4), torch.tensor(1.3))
+        _ = normal(torch.where(torch.eq(k, 1), x, u), s_) @ "y"
+        return torch.where(torch.ne(k, 0) & (x >= u), x, torch.minimum(x, u))
+
     ys = C["y", 0].set(False) | C["y", 1].set(False) | C["y", 2].set(True) | C["y", 3].set(True) | C["y", 4].set(True)
+    for chm_m in (C.n(), C["y"].set(0.3), C["k"].set(torch.tensor(True)) | C["y"].set(-0.2)):
+        same_trace(mixture, (1.2,), chm_m)
     for fn, args, chm in ((ratio, (), C["d"].set(0.1)), (halves, (), C.n()), (halves, (), C["d"].set(-0.3)),
                           (logscale, (0.2,), C["y"].set(0.7)), (logscale, (0.2,), C.n()), (logistic, (1.5,), ys),
                           (logistic, (1.5,), C.n()), (logistic, (1.5,), ys | C["t"].set(0.3))):
