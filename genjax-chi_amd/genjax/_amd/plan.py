@@ -129,7 +129,10 @@ class Sym:
     def square(self):
         return SymExpr.binop(abi.EXPR_MUL, self, self)
 
-    __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
+    def __pow__(self, e):
+        return _sym_pow(self, e)
+
+    __rpow__ = __bool__ = __float__ = __int__ = _no
     __index__ = __array__ = __len__ = __iter__ = _no
 
     # comparisons give conditions (0 / 1 values of the program: `torch.where(x > 0.5, a, b)`); `==` stays Python's identity
@@ -262,7 +265,10 @@ class SymExpr:
     def _no(self, *a, **k):
         raise PlanUnsupported("unsupported operation on a traced expression")
 
-    __pow__ = __rpow__ = __bool__ = __float__ = __int__ = _no
+    def __pow__(self, e):
+        return _sym_pow(self, e)
+
+    __rpow__ = __bool__ = __float__ = __int__ = _no
     __index__ = __array__ = __len__ = __iter__ = _no
 
     def __lt__(self, o): return SymExpr.binop(abi.EXPR_LT, self, o)  # noqa: E704
@@ -345,6 +351,15 @@ _CMP_FUNCS = {torch.lt: (abi.EXPR_LT, False), torch.Tensor.lt: (abi.EXPR_LT, Fal
               torch.Tensor.eq: (abi.EXPR_EQ, False)}
 
 
+def _sym_pow(x, e):
+    """x ** 2 and x ** 3 are products (what torch's pow computes for these exponents, on every backend); other exponents go
+    through the device library's pow on the per-site path: not lowered."""
+    if isinstance(e, (int, float)) and not isinstance(e, bool) and float(e) in (2.0, 3.0):
+        sq = SymExpr.binop(abi.EXPR_MUL, x, x)
+        return sq if float(e) == 2.0 else SymExpr.binop(abi.EXPR_MUL, sq, x)
+    raise PlanUnsupported("a power other than 2 or 3 of a traced value")
+
+
 def _is_condition(v) -> bool:
     """A 0 / 1 value: a comparison (or a combination of conditions), a flip site, a boolean constant."""
     if isinstance(v, SymExpr):
@@ -390,6 +405,8 @@ def _sym_torch_function(func, args, kwargs):
         return SymExpr.binop(abi.EXPR_DIV, 1.0, args[0])
     if func in (torch.square, torch.Tensor.square) and len(args) == 1:
         return SymExpr.binop(abi.EXPR_MUL, args[0], args[0])
+    if func in (torch.pow, torch.Tensor.pow, torch.Tensor.__pow__) and len(args) == 2 and isinstance(args[0], (Sym, SymExpr)):
+        return _sym_pow(args[0], args[1])
     if func in (torch.maximum, torch.Tensor.maximum, torch.minimum, torch.Tensor.minimum) and len(args) == 2:
         return SymExpr.binop(abi.EXPR_MAX if func in (torch.maximum, torch.Tensor.maximum) else abi.EXPR_MIN, args[0], args[1])
     if func in (torch.clamp, torch.Tensor.clamp, torch.clip, torch.Tensor.clip) and 1 <= len(args) <= 3:

@@ -505,7 +505,7 @@ def case_expression_arguments(impl):
         b = normal(0.0, 1.0) @ "b"
         for i, x in enumerate(xs_l):
             flip(torch.sigmoid(w * x + b)) @ ("y", i)
-        r = gamma(torch.sqrt(w * w + 1.0), torch.abs(b) + 0.5) @ "r"
+        r = gamma(torch.sqrt(w ** 2 + 1.0), torch.abs(b) + 0.5 + (b * 0.1) ** 3) @ "r"
         s2 = normal(torch.clamp(w, min=-0.5, max=0.7), torch.nn.functional.softplus(b)) @ "s2"
         _ = normal(torch.maximum(s2, torch.tensor(0.1)), torch.minimum(r, torch.tensor(1.5)) + 0.2) @ "s3"
         return normal(torch.reciprocal(r + 1.0), torch.square(w).sqrt() + 0.1) @ "t"
