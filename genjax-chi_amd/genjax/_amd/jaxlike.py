@@ -25,9 +25,16 @@ random = types.SimpleNamespace(
 
 
 # ---- jax.lax --------------------------------------------------------------------------------------
+def _traced(x) -> bool:
+    """A symbolic value of the plan tracer (plan.Sym / SymExpr): torch functions of it lower to the fused kernel's program."""
+    return hasattr(x, "tracer") and not isinstance(x, torch.Tensor)
+
+
 def _cond(pred, true_fun, false_fun, *operands):
     """`jax.lax.cond` on a column: both branches are evaluated, `where` selects."""
     t, f = true_fun(*operands), false_fun(*operands)
+    if _traced(pred) or _traced(t) or _traced(f):
+        return torch.where(pred, t, f)  # (GJX_EXPR_SELECT in the fused kernel: the same selection)
     if isinstance(pred, torch.Tensor):
         tt = torch.as_tensor(t, device=pred.device)
         ff = torch.as_tensor(f, device=pred.device)
@@ -54,11 +61,16 @@ def _array(x, dtype=None):
 jnp = types.SimpleNamespace(
     array=_array,
     asarray=_array,
-    where=lambda c, a, b: torch.where(torch.as_tensor(c).bool(), torch.as_tensor(a), torch.as_tensor(b)),
-    log=lambda x: torch.log(torch.as_tensor(x, dtype=torch.float32)),
-    exp=lambda x: torch.exp(torch.as_tensor(x, dtype=torch.float32)),
-    sqrt=lambda x: torch.sqrt(torch.as_tensor(x, dtype=torch.float32)),
+    where=lambda c, a, b: torch.where(c, a, b) if (_traced(c) or _traced(a) or _traced(b))
+    else torch.where(torch.as_tensor(c).bool(), torch.as_tensor(a), torch.as_tensor(b)),
+    log=lambda x: torch.log(x if (_traced(x) or isinstance(x, torch.Tensor)) else torch.as_tensor(x, dtype=torch.float32)),
+    exp=lambda x: torch.exp(x if (_traced(x) or isinstance(x, torch.Tensor)) else torch.as_tensor(x, dtype=torch.float32)),
+    sqrt=lambda x: torch.sqrt(x if (_traced(x) or isinstance(x, torch.Tensor)) else torch.as_tensor(x, dtype=torch.float32)),
     abs=torch.abs,
+    maximum=lambda a, b: torch.maximum(a, b) if (_traced(a) or _traced(b)) else torch.maximum(torch.as_tensor(a), torch.as_tensor(b)),
+    minimum=lambda a, b: torch.minimum(a, b) if (_traced(a) or _traced(b)) else torch.minimum(torch.as_tensor(a), torch.as_tensor(b)),
+    clip=lambda x, lo=None, hi=None: torch.clamp(x, min=lo, max=hi),
+    square=torch.square,
     mean=lambda x, axis=None: torch.mean(x.float()) if axis is None else torch.mean(x.float(), dim=axis),
     sum=lambda x, axis=None: torch.sum(x) if axis is None else torch.sum(x, dim=axis),
     ones=lambda *s: torch.ones(*s),

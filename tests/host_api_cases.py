@@ -56,6 +56,18 @@ def case_exact_flip_flip(impl):
     assert f(z) == pytest.approx(math.log(0.6), rel=1e-1)
     z = ImportanceK(problem, k_particles=200000).log_marginal_likelihood_estimate(key)
     assert f(z) == pytest.approx(math.log(0.6), abs=1e-2)
+    # r03: the reference's own body (tests/inference/test_smc.py:59-66: `jax.lax.cond` on a flip value) is ONE fused kernel
+    # (the selection is GJX_EXPR_SELECT), equal to the per-site path bit for bit
+    import torch
+
+    from genjax._amd.lang import GenerateHandler
+
+    keys = genjax.random.split(genjax.random.key(7, impl), 5000)
+    fused = try_fused_generate(flip_flip, keys, C["y"].set(True), ())
+    assert fused is not None, "lax.cond on a traced flip value must lower to the fused kernel"
+    h = GenerateHandler(keys, C["y"].set(True))
+    h.run(flip_flip.source, ())
+    assert torch.equal(fused[1], h.weight) and torch.equal(fused[0].get_choices()["x"], h.traces["x"].get_choices().get_value())
 
 
 def case_non_marginal_target(impl):
