@@ -41,7 +41,7 @@ ARG_CONST, ARG_SITE, ARG_INPUT, ARG_TABLE, ARG_STATE, ARG_OBS, ARG_PARAM, ARG_EX
  EXPR_LOG, EXPR_SQRT, EXPR_ABS, EXPR_MAX, EXPR_MIN, EXPR_LT, EXPR_LE, EXPR_EQ, EXPR_SELECT) = range(21)
 EXPR_UNARY = (EXPR_NEG, EXPR_EXP, EXPR_LOG, EXPR_SQRT, EXPR_ABS)
 MAP_EXP, MAP_LOG, MAP_DIV, MAP_RDIV, MAP_SQRT, MAP_ABS = range(6)
-MAX_EXPR_OPS, MAX_EXPR_DEPTH = 16, 8
+MAX_EXPR_OPS, MAX_EXPR_DEPTH = 32, 8
 MAX_PARAMS = 64
 SMC_MAX_STATE, SMC_MAX_OBS = 4, 8
 OP_LOGSUMEXP, OP_CATEGORICAL_INDEX, OP_RESAMPLE, OP_SMC = range(4)

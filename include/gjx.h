@@ -216,7 +216,7 @@ typedef struct {
   int32_t ref;
   float value;
 } gjx_expr_op;
-#define GJX_MAX_EXPR_OPS 16 /* per argument; the evaluation stack is at most 8 deep */
+#define GJX_MAX_EXPR_OPS 32 /* per argument (r03: 16 -> 32: sigmoid / softplus / where expand to several entries); the evaluation stack is at most 8 deep */
 
 typedef struct {
   int32_t kind;

@@ -533,6 +533,17 @@ def case_expression_arguments(impl):
         _ = normal(torch.where(torch.eq(k, 1), x, u), s_) @ "y"
         return torch.where(torch.ne(k, 0) & (x >= u), x, torch.minimum(x, u))
 
+    @gen
+    def long_args(a):  # arguments of 17-32 program entries (r02's limit was 16): softplus / sigmoid / where of affine forms
+        w = normal(0.0, 1.0) @ "w"
+        b = normal(0.0, 1.0) @ "b"
+        s_ = gamma(2.0, 2.0) @ "s"
+        y = normal(torch.nn.functional.softplus(w * a + b), torch.sigmoid(w * 0.5 - b) + torch.where(s_ > 1.0, s_, 1.0 / (s_ + 0.5))) @ "y"
+        return torch.nn.functional.softplus(y * w + b * s_)
+
+    for chm_m in (C.n(), C["y"].set(0.7)):
+        same_trace(long_args, (0.8,), chm_m)
+
     ys = C["y", 0].set(False) | C["y", 1].set(False) | C["y", 2].set(True) | C["y", 3].set(True) | C["y", 4].set(True)
     for chm_m in (C.n(), C["y"].set(0.3), C["k"].set(torch.tensor(True)) | C["y"].set(-0.2)):
         same_trace(mixture, (1.2,), chm_m)

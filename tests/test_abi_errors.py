@@ -133,7 +133,7 @@ def test_expression_programs_are_validated(lib_ops):
         "a later site": [(abi.EXPR_SITE, 1, 0.0)],
         "an unknown opcode": [(abi.EXPR_SITE, 0, 0.0), (99, 0, 0.0)],
         "a state operand in an importance plan": [(abi.EXPR_STATE, 0, 0.0)],
-        "too long": [(abi.EXPR_CONST, 0, 1.0)] + [(abi.EXPR_CONST, 0, 1.0), (abi.EXPR_ADD, 0, 0.0)] * 8,
+        "too long": [(abi.EXPR_CONST, 0, 1.0)] + [(abi.EXPR_CONST, 0, 1.0), (abi.EXPR_ADD, 0, 0.0)] * 16,
         "too deep": [(abi.EXPR_CONST, 0, 1.0)] * 9 + [(abi.EXPR_ADD, 0, 0.0)] * 8,
     }
     for what, prog in bad.items():
