@@ -1171,6 +1171,7 @@ struct PlanPolicyArgs {
   int32_t* anc_out;
   Key step_key;
   float obs[8];
+  int32_t wt;  // write-through stores of the state / ancestor columns (store16_out; the host sets it for one-filter launches)
 };
 
 template <int N>

@@ -2974,6 +2974,7 @@ static int smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, gjx_jit:
   ResampleArgs A;
   int rc = smc_resample_args(cfg, t, prev, out, prev_e_out, prev_q_out, ctx, s, &A);
   if (rc) return rc;
+  PA.wt = A.wt_stores;
   if (!cp) {
     if (cfg->impl == 0) k_smc_interp_step<0><<<ntl * nf, kBlock, 0, S(s)>>>(A, PA, IT);
     else k_smc_interp_step<1><<<ntl * nf, kBlock, 0, S(s)>>>(A, PA, IT);
@@ -2981,7 +2982,7 @@ static int smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, gjx_jit:
   }
   PlanTables tabs = cp->tabs;
   void* args[] = {&A, &PA, &tabs};
-  if (hipModuleLaunchKernel(cp->step, ntl * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
+  if (hipModuleLaunchKernel(ad ? cp->step_adaptive : cp->step, ntl * nf, 1, 1, kBlock, 1, 1, 0, S(s), args, nullptr) != hipSuccess) return GJX_ERR_LAUNCH;
   return launch_status();
 }
 

@@ -845,8 +845,38 @@ struct GenSmc {
   // number f of the quad is ONE block, PH(ctr = (g_lo, g_hi, f, 'Q'), key = step key), g = jq / 4, slot u taking
   // word u (for f = 0 and one Normal site this is the fixed LGSSM filter, bit for bit); Normal sites are two
   // Box-Muller transforms over the quad's words; multi-word samplers keep their per-slot streams.
-  void emit_quad_body(const CSiteT* sites, int n_sites, const CArgT* state_args, bool step) {
+  // The draws of the quad that do not depend on the ancestors — the cipher block of every one-word draw of the body's own
+  // sites and the Box-Muller transforms of its Normal sites — can run under the latency of the step's first loads: the
+  // policy's prefetch() (as the hand-written LgssmPolicy has it) keeps them in members (registers).
+  int quad_draws(const CSiteT* sites, int n_sites, const ScopeInfo* sc) const {
+    int n = 0;
+    SiteEmitter<CSiteT, CArgT> e{const_cast<std::ostringstream&>(o), impl, 1, sites, n_sites, "", ""};
+    e.sc = sc;
+    for (int q = 0; q < n_sites; ++q)
+      if (!sites[q].observed && e.one_word(sites[q]) && e.scope_of(q) == 0) ++n;
+    return n;
+  }
+  void emit_prefetch(const CSiteT* sites, int n_sites, const ScopeInfo* sc) {
+    SiteEmitter<CSiteT, CArgT> e{o, impl, 1, sites, n_sites, "    ", ""};
+    e.sc = sc;
+    o << "  __device__ __forceinline__ void prefetch(int64_t jq) {\n    const uint64_t g = (uint64_t)jq >> 2;\n";
+    int i = 0;
+    for (int q = 0; q < n_sites; ++q) {
+      const CSiteT& st = sites[q];
+      if (st.observed || !e.one_word(st) || e.scope_of(q) != 0) continue;
+      o << "    philox4x32(a.step_key.k0, a.step_key.k1, (uint32_t)g, (uint32_t)(g >> 32), " << e.fold_of(q) << "u, kTagQuad, pf_w[" << i
+        << "][0], pf_w[" << i << "][1], pf_w[" << i << "][2], pf_w[" << i << "][3]);\n";
+      if (st.dist == GJX_DIST_NORMAL) {
+        o << "    bm_pair(pf_w[" << i << "][0], pf_w[" << i << "][1], pf_z[" << i << "][0], pf_z[" << i << "][1]);\n";
+        o << "    bm_pair(pf_w[" << i << "][2], pf_w[" << i << "][3], pf_z[" << i << "][2], pf_z[" << i << "][3]);\n";
+      }
+      ++i;
+    }
+    o << "  }\n";
+  }
+  void emit_quad_body(const CSiteT* sites, int n_sites, const CArgT* state_args, bool step, bool prefetched = false) {
     const char* sf[4] = {"A", "B", "C", "D"};
+    int pf_i = 0;
     std::vector<SiteEmitter<CSiteT, CArgT>> em;
     const ScopeInfo* sc = step ? sc_step : sc_init;
     for (int u = 0; u < 4; ++u) {
@@ -867,17 +897,22 @@ struct GenSmc {
       const std::string Q = std::to_string(q);
       for (int u = 0; u < 4; ++u) em[u].head(q);
       const bool drawn = !st.observed && em[0].one_word(st) && em[0].scope_of(q) == 0;  // (a callee's sites: their own lone keys)
-      if (drawn) {
+      const bool normal = drawn && st.dist == GJX_DIST_NORMAL;
+      if (drawn && prefetched) {  // (computed by prefetch(): the same block, the same transforms)
+        for (int u = 0; u < 4; ++u) o << "    const uint32_t bits" << Q << sf[u] << " = pf_w[" << pf_i << "][" << u << "]; (void)bits" << Q << sf[u] << ";\n";
+        if (normal)
+          for (int u = 0; u < 4; ++u) o << "    const float z" << Q << sf[u] << " = pf_z[" << pf_i << "][" << u << "];\n";
+        ++pf_i;
+      } else if (drawn) {
         o << "    uint32_t qw" << Q << "_0, qw" << Q << "_1, qw" << Q << "_2, qw" << Q << "_3;\n";
         o << "    philox4x32(a.step_key.k0, a.step_key.k1, (uint32_t)g, (uint32_t)(g >> 32), " << em[0].fold_of(q)
           << "u, kTagQuad, qw" << Q << "_0, qw" << Q << "_1, qw" << Q << "_2, qw" << Q << "_3);\n";
         for (int u = 0; u < 4; ++u) o << "    const uint32_t bits" << Q << sf[u] << " = qw" << Q << "_" << u << ";\n";
-      }
-      const bool normal = drawn && st.dist == GJX_DIST_NORMAL;
-      if (normal) {
-        o << "    float z" << Q << "A, z" << Q << "B, z" << Q << "C, z" << Q << "D;\n";
-        o << "    bm_pair(bits" << Q << "A, bits" << Q << "B, z" << Q << "A, z" << Q << "B);\n";
-        o << "    bm_pair(bits" << Q << "C, bits" << Q << "D, z" << Q << "C, z" << Q << "D);\n";
+        if (normal) {
+          o << "    float z" << Q << "A, z" << Q << "B, z" << Q << "C, z" << Q << "D;\n";
+          o << "    bm_pair(bits" << Q << "A, bits" << Q << "B, z" << Q << "A, z" << Q << "B);\n";
+          o << "    bm_pair(bits" << Q << "C, bits" << Q << "D, z" << Q << "C, z" << Q << "D);\n";
+        }
       }
       for (int u = 0; u < 4; ++u) em[u].tail(q, normal ? "z" + Q + sf[u] : std::string());
       for (int u = 0; u < 4; ++u) em[u].close_scopes(q + 1);
@@ -888,8 +923,13 @@ struct GenSmc {
     }
   }
   void emit_quad(const CSiteT* sites, int n_sites, const CArgT* state_args, bool step) {
+    const int nq = quad_draws(sites, n_sites, step ? sc_step : sc_init);
+    if (nq > 0) {
+      o << "  uint32_t pf_w[" << nq << "][4];\n  float pf_z[" << nq << "][4];\n";
+      emit_prefetch(sites, n_sites, step ? sc_step : sc_init);
+    }
     o << "  __device__ __forceinline__ void compute_quad(int64_t jq, const uint32_t (&src)[4], Out (&out)[4], float (&wq)[4]) const {\n";
-    emit_quad_body(sites, n_sites, state_args, step);
+    emit_quad_body(sites, n_sites, state_args, step, nq > 0);
     o << "  }\n";
   }
 
@@ -916,9 +956,22 @@ struct GenSmc {
     if (impl == 1) emit_quad(step_sites, n_step, next_state, true);
     o << "  __device__ __forceinline__ void store(int64_t j, int64_t out_lo, uint32_t src, const Out& out) const {\n";
     o << "    for (int k = 0; k < " << D << "; ++k) a.state_out[k][j - out_lo] = out.s[k];\n";
-    o << "    if (a.anc_out) a.anc_out[j - out_lo] = (int32_t)src;\n  }\n};\n";
+    o << "    if (a.anc_out) a.anc_out[j - out_lo] = (int32_t)src;\n  }\n";
+    // the lane's four consecutive slots at once: one 16-byte (write-through, for one-filter launches) store per column
+    o << "  __device__ __forceinline__ void store_quad(int64_t jq, int64_t out_lo, const uint32_t (&anc)[4], const Out (&o)[4], const bool (&ok)[4]) const {\n";
+    o << "    const int64_t k = jq - out_lo;\n";
+    o << "    uintptr_t al = (uintptr_t)a.anc_out;\n";
+    o << "    for (int c = 0; c < " << D << "; ++c) al |= (uintptr_t)a.state_out[c];\n";
+    o << "    if ((al & 15) == 0 && ok[0] && ok[1] && ok[2] && ok[3]) {\n";
+    o << "      for (int c = 0; c < " << D << "; ++c) store16_out(a.state_out[c] + k, make_uint4(f2u(o[0].s[c]), f2u(o[1].s[c]), f2u(o[2].s[c]), f2u(o[3].s[c])), a.wt != 0);\n";
+    o << "      if (a.anc_out) store16_out(a.anc_out + k, make_uint4(anc[0], anc[1], anc[2], anc[3]), a.wt != 0);\n";
+    o << "      return;\n    }\n";
+    o << "    for (int u = 0; u < 4; ++u) if (ok[u]) store(jq + u, out_lo, anc[u], o[u]);\n  }\n};\n";
+    // two instantiations, as for the hand-written filters: the every-step form carries no ESS decision / keep-your-particle path
     o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_step_kernel(ResampleArgs A, PlanPolicyArgs PA, PlanTables T) {\n";
-    o << "  GenPolicy P;\n  P.a = PA;\n  P.tabs = T;\n  resample_body<" << I << ">(A, P);\n}\n";
+    o << "  GenPolicy P;\n  P.a = PA;\n  P.tabs = T;\n  resample_body<" << I << ", GenPolicy, false>(A, P);\n}\n";
+    o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_step_kernel_adaptive(ResampleArgs A, PlanPolicyArgs PA, PlanTables T) {\n";
+    o << "  GenPolicy P;\n  P.a = PA;\n  P.tabs = T;\n  resample_body<" << I << ", GenPolicy, true>(A, P);\n}\n";
     // ---- init kernel: one workgroup per LOCAL tile, like k_lgssm_init
     if (impl == 1) {
       o << "struct GenInitOut { float s[" << D << "]; };\n";
@@ -1206,7 +1259,7 @@ inline bool compile(const std::string& src, int impl, Compiled* out, const char*
   return true;
 }
 struct CompiledSmc {
-  hipFunction_t step = nullptr, init = nullptr;
+  hipFunction_t step = nullptr, step_adaptive = nullptr, init = nullptr;
   int state = 0;  // 0 untried, 1 ready, -1 failed
   std::string key;
   gjx::PlanTables tabs;  // the device tables of THIS plan (kernel argument of both kernels)
@@ -1214,13 +1267,14 @@ struct CompiledSmc {
 inline void release_smc(CompiledSmc* c) {
   ModuleCache::get().release(c->key);
   c->key.clear();
-  c->step = c->init = nullptr;
+  c->step = c->step_adaptive = c->init = nullptr;
 }
 inline bool compile_smc(const std::string& src, CompiledSmc* out) {
   hipModule_t mod = ModuleCache::get().acquire(src);
   if (!mod) return false;
   out->key = src;
   if (hipModuleGetFunction(&out->step, mod, "gjx_smc_step_kernel") != hipSuccess ||
+      hipModuleGetFunction(&out->step_adaptive, mod, "gjx_smc_step_kernel_adaptive") != hipSuccess ||
       hipModuleGetFunction(&out->init, mod, "gjx_smc_init_kernel") != hipSuccess) {
     (void)hipGetLastError();
     std::fprintf(stderr, "[gjx] hipModuleGetFunction failed for a generated SMC kernel\n");
