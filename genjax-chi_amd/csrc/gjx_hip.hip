@@ -255,8 +255,10 @@ struct CSite {
   // evaluate the row on the fly.  Same integers / same f32 ops: the same bits.
   const uint2* cat_ent;       // [n_rows, n_cat]: {inclusive CDF, bits of row[c] - lse(row)} — the draw's walk ends on the entry
                               // that also holds the drawn category's log-density
-  const uint32_t* cat_tot;    // [n_rows]: the row's total (its last CDF entry), dense
-  const uint16_t* cat_guide;  // [n_rows, 256]: where the walk of a draw whose top byte is g starts (k_cat_prepare)
+  const uint4* cat_guide4;    // [n_rows, 256]: bucket g = top byte of the draw -> {c, CDF_c, log-density bits of c, the row's total},
+                              // c = where the walk of every draw of the bucket starts (k_cat_prepare): ONE 16-byte load gives
+                              // the threshold's scale, the first candidate and, if it is the answer, its log-density
+                              // (r02: three scattered loads — total, guide byte pair, entry)
   const float* cat_logp_t;    // observed sites whose value is the same for every particle: [n_cat, n_rows], row[c] - lse(row)
                               // TRANSPOSED — the launch reads one contiguous n_rows-float column, whatever rows the particles hold
   int32_t pre;       // 1: pre0/pre1 hold the hoisted per-site constants; 2: they depend on launch parameters
@@ -1524,8 +1526,7 @@ int gjx_logpdf_categorical(const int32_t* value, int value_scalar, const float* 
 
 // ---- plans ---------------------------------------------------------------------------------------
 // ---- per-row tables of categorical sites (specialised kernels) ------------------------------------------------------
-__global__ void k_cat_prepare(const float* logits, uint32_t n_rows, uint32_t K, uint2* ent, uint32_t* tot, uint16_t* guide,
-                              float* logp_t) {
+__global__ void k_cat_prepare(const float* logits, uint32_t n_rows, uint32_t K, uint2* ent, uint4* guide4, float* logp_t) {
   // one thread per row, sequential in the category exactly as cat_invcdf / row_lse state it
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rows) return;
@@ -1542,15 +1543,14 @@ __global__ void k_cat_prepare(const float* logits, uint32_t n_rows, uint32_t K, 
     C += cat_fix(l[c], m);
     row[c] = make_uint2(C, f2u(l[c] - lse));
   }
-  tot[r] = C;
   // guide[g] = the category drawn by the SMALLEST draw whose top byte is g (bits = g << 24).  The threshold is monotone
   // in the draw, so every draw of that bucket lands at or after guide[g]: a walk from there finds the same category as a
-  // search of the whole row.
+  // search of the whole row.  The bucket carries that category's entry and the row's total.
   uint32_t c = 0;
   for (uint32_t g = 0; g < 256; ++g) {
     const uint64_t thr = ((uint64_t)(g << 24) * (uint64_t)C) >> 32;
     while (c < K - 1 && (uint64_t)row[c].x <= thr) ++c;
-    guide[(size_t)r * 256 + g] = (uint16_t)c;
+    guide4[(size_t)r * 256 + g] = make_uint4(c, row[c].x, row[c].y, C);
   }
 }
 // Build the tables of every categorical site of a table (first compilation of a plan: a GPU is present by then).
@@ -1566,29 +1566,24 @@ static void cat_tables_prepare(CSite* sites, int n, std::vector<void*>* owned) {
     if (st.observed && st.obs.kind != GJX_ARG_INPUT) {  // the value is launch-uniform: the transposed log-probabilities only
       float* lt = nullptr;
       if (hipMalloc(&lt, sizeof(float) * rows * (size_t)st.n_cat) != hipSuccess) { (void)hipGetLastError(); continue; }
-      k_cat_prepare<<<grid, 64>>>(st.logits, (uint32_t)rows, (uint32_t)st.n_cat, nullptr, nullptr, nullptr, lt);
+      k_cat_prepare<<<grid, 64>>>(st.logits, (uint32_t)rows, (uint32_t)st.n_cat, nullptr, nullptr, lt);
       owned->push_back(lt);
       st.cat_logp_t = lt;
       any = true;
       continue;
     }
     uint2* ent = nullptr;
-    uint32_t* tot = nullptr;
-    uint16_t* guide = nullptr;
-    if (hipMalloc(&ent, sizeof(uint2) * rows * (size_t)st.n_cat) != hipSuccess || hipMalloc(&tot, sizeof(uint32_t) * rows) != hipSuccess ||
-        hipMalloc(&guide, sizeof(uint16_t) * 256 * rows) != hipSuccess) {
+    uint4* guide4 = nullptr;
+    if (hipMalloc(&ent, sizeof(uint2) * rows * (size_t)st.n_cat) != hipSuccess || hipMalloc(&guide4, sizeof(uint4) * 256 * rows) != hipSuccess) {
       (void)hipGetLastError();
       if (ent) (void)hipFree(ent);
-      if (tot) (void)hipFree(tot);
       continue;
     }
-    k_cat_prepare<<<grid, 64>>>(st.logits, (uint32_t)rows, (uint32_t)st.n_cat, ent, tot, guide, nullptr);
+    k_cat_prepare<<<grid, 64>>>(st.logits, (uint32_t)rows, (uint32_t)st.n_cat, ent, guide4, nullptr);
     owned->push_back(ent);
-    owned->push_back(tot);
-    owned->push_back(guide);
+    owned->push_back(guide4);
     st.cat_ent = ent;
-    st.cat_tot = tot;
-    st.cat_guide = guide;
+    st.cat_guide4 = guide4;
     any = true;
   }
   if (any && hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
