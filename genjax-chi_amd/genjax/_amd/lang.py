@@ -621,6 +621,8 @@ def trace(addr, gen_fn: GenerativeFunction, args: tuple):
     for seg in addr:
         if not isinstance(seg, (str, int)):
             raise TypeError(f"static addresses must be strings (or ints), got {seg!r}")
+    if isinstance(gen_fn, Distribution):
+        args = _spec_unwrap(args)  # (the sampler / log-density wrappers get plain tensors: no subclass dispatch inside them)
     return _spec_wrap(st[-1].handle_trace(addr if len(addr) > 1 else addr[0], gen_fn, args))
 
 

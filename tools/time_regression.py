@@ -35,24 +35,29 @@ for i, y in enumerate(ys):
 alg = ImportanceK(Target(regression, (), chm), k_particles=1_000_000)
 
 
-def timed(label, reps):
+def timed(label, reps, estimate=None):
+    estimate = estimate or alg.log_marginal_likelihood_estimate
     for r in range(3):
-        float(alg.log_marginal_likelihood_estimate(genjax.random.key(r, "philox")))
+        float(estimate(genjax.random.key(r, "philox")))
     ts = []
     for r in range(reps):
         t0 = time.perf_counter()
-        z = float(alg.log_marginal_likelihood_estimate(genjax.random.key(10 + r, "philox")))
+        z = float(estimate(genjax.random.key(10 + r, "philox")))
         ts.append(time.perf_counter() - t0)
-    z = float(alg.log_marginal_likelihood_estimate(genjax.random.key(777, "philox")))
+    z = float(estimate(genjax.random.key(777, "philox")))
     print(f"{label}: median {statistics.median(ts) * 1e3:.3f} ms per estimate (log Z at key 777: {z:.6f})")
     return z
 
 
-zf = timed("fused (one kernel, 52 sites)", 30)
+from genjax._amd import inference as I  # noqa: E402
+
+general = lambda key: I.SMCAlgorithm.log_marginal_likelihood_estimate(alg, key)  # (run_smc: the trace is materialised)
+zf = timed("estimate-only fused kernel, one library call (52 sites)", 30)
+zg = timed("general route (fused kernel with its trace columns)", 30, general)
 orig = P.try_fused_generate
 P.try_fused_generate = lambda *a, **k: None  # the per-site column path
 try:
-    ze = timed("per-site launches", 5)
+    ze = timed("per-site launches", 5, general)
 finally:
     P.try_fused_generate = orig
-print("same estimate:", zf == ze)
+print("same estimate:", zf == ze == zg)
