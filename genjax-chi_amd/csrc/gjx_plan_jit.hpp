@@ -449,7 +449,9 @@ struct SiteEmitter {
   }
 };
 
-inline void emit_prelude(std::ostringstream& o, bool fast_math = false) {
+// bm_lds: the kernels of this source stage the Box-Muller tables in LDS (each calls bm_stage() at entry; gjx_device.hpp)
+inline void emit_prelude(std::ostringstream& o, bool fast_math = false, bool bm_lds = false) {
+  if (bm_lds) o << "#define GJX_BM_LDS 1\n";
   if (fast_math) o << "#define GJX_FAST_MATH 1\n";  // gjx.h GJX_PLAN_FAST_MATH: hardware transcendentals (gjx_device.hpp d_log / d_exp / bm_pair)
   o << "#include \"gjx_device.hpp\"\nusing namespace gjx;\n";
   o << "__device__ __forceinline__ float jrow_max(const float* l, uint32_t K){ float m=l[0]; for(uint32_t c=1;c<K;++c) m = l[c]>m?l[c]:m; return m; }\n";
@@ -558,6 +560,13 @@ struct Gen {
            "uint64_t* row_s, LseTail tail, PassBatch bt, PlanParams prm, PlanTables tabs) {\n";
   }
   const char* kname() const { return impl == 0 ? "gjx_plan_kernel_threefry" : "gjx_plan_kernel_philox"; }
+  // PHILOX Normal sites draw through the Box-Muller tables: this source's kernels stage them in LDS (gjx_device.hpp bm_stage)
+  bool bm_lds() const {
+    if (impl != 1 || fast_math) return false;
+    for (int q = 0; q < n_sites; ++q)
+      if (!sites[q].observed && sites[q].dist == GJX_DIST_NORMAL) return true;
+    return false;
+  }
 
   std::string run_paired() {
     // NP pairs of adjacent particles per lane; a 256-particle row is 128 / NP lanes.  R rows per workgroup.
@@ -573,13 +582,14 @@ struct Gen {
     block = lanes_per_row * R;
     rows_per_block = R;
     const int waves_per_row = lanes_per_row / 64;  // 2 (pairs) or 1 (quads)
-    emit_prelude(o, fast_math);
+    emit_prelude(o, fast_math, bm_lds());
     o << "extern \"C\" __global__ __launch_bounds__(" << block << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
       << ") void " << kname() << signature();
     if (waves_per_row > 1) o << "  __shared__ float sh_red[" << waves_per_row * R << "];\n  __shared__ uint64_t sh_sum[" << waves_per_row * R << "];\n";
     if (R == 1) o << "  const int wv = threadIdx.x >> 6, pr = 0, tr = threadIdx.x;  // (block-uniform row: the cipher key stays scalar)\n";
     else o << "  const int wv = threadIdx.x >> 6, pr = threadIdx.x / " << lanes_per_row << ", tr = threadIdx.x % " << lanes_per_row << ";\n";
     o << "  (void)wv;\n";
+    if (bm_lds()) o << "  bm_stage();\n";
     o << "  const uint64_t rows_all = (uint64_t)bt.n_pass * bt.rows_per_pass;\n";
     o << "  const bool wt_one_pass = bt.n_pass <= 1u; (void)wt_one_pass;\n";
     o << "  for (uint64_t g0 = (uint64_t)blockIdx.x * " << R << "; g0 < rows_all; g0 += (uint64_t)gridDim.x * " << R << ") {\n";
@@ -661,12 +671,13 @@ struct Gen {
   std::string run() {
     if (laned && impl == 1) return run_paired();
     const std::string I = std::to_string(impl);
-    emit_prelude(o, fast_math);
+    emit_prelude(o, fast_math, bm_lds());
     // One workgroup per 256-particle row (grid-stride): short blocks keep every SIMD's wave slots
     // full even at 1e6 particles (15 rows per lane), where a 4-row block would serialise its rows.
     o << "extern \"C\" __global__ __launch_bounds__(256" << (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string())
       << ") void " << kname() << signature();
     o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
+    if (bm_lds()) o << "  bm_stage();\n";
     o << "  const uint64_t rows_all = (uint64_t)bt.n_pass * bt.rows_per_pass;\n";
     o << "  for (uint64_t gr = blockIdx.x; gr < rows_all; gr += gridDim.x) {\n";
     o << "    const uint32_t pass = (uint32_t)(gr / bt.rows_per_pass);\n";
@@ -718,14 +729,22 @@ struct GenScan {
                       // kernel's quad form; row statistics are wave reductions, every store is 16 bytes per lane.
   int block = 256;
   const char* kname() const { return impl == 0 ? "gjx_scan_kernel_threefry" : "gjx_scan_kernel_philox"; }
+  // PHILOX Normal sites draw through the Box-Muller tables: this source's kernels stage them in LDS (gjx_device.hpp bm_stage)
+  bool bm_lds() const {
+    if (impl != 1 || fast_math) return false;
+    for (int q = 0; q < n_sites; ++q)
+      if (!sites[q].observed && sites[q].dist == GJX_DIST_NORMAL) return true;
+    return false;
+  }
   std::string run_quad() {
     block = 64;
     const char* sfx[4] = {"A", "B", "C", "D"};
     const int P = 4;
-    emit_prelude(o, fast_math);
+    emit_prelude(o, fast_math, bm_lds());
     o << "struct StepObs { const float* obs; };\n";
     o << "extern \"C\" __global__ __launch_bounds__(64) void " << kname()
       << "(KeySrc ks, RunCols cols, ScanArgs sa, float* score, float* logw, float* max_partials, int32_t* row_e, uint64_t* row_s, LseTail tail, PlanTables tabs) {\n";
+    if (bm_lds()) o << "  bm_stage();\n";
     o << "  const uint64_t n = sa.n, rows_all = (n + 255) / 256;\n";
     o << "  const bool wt_one_pass = false; (void)wt_one_pass;  // (a scan's stores spread over its T steps)\n";
     o << "  const uint32_t pk0 = ks.parent.k0, pk1 = ks.parent.k1;\n";
@@ -783,11 +802,12 @@ struct GenScan {
   std::string run() {
     if (quad && impl == 1) return run_quad();
     const std::string I = std::to_string(impl);
-    emit_prelude(o, fast_math);
+    emit_prelude(o, fast_math, bm_lds());
     o << "struct StepObs { const float* obs; };\n";
     o << "extern \"C\" __global__ __launch_bounds__(256) void " << kname()
       << "(KeySrc ks, RunCols cols, ScanArgs sa, float* score, float* logw, float* max_partials, int32_t* row_e, uint64_t* row_s, LseTail tail, PlanTables tabs) {\n";
     o << "  __shared__ float sh_red[4];\n  __shared__ uint64_t sh_sum[4];\n";
+    if (bm_lds()) o << "  bm_stage();\n";
     o << "  const uint64_t n = sa.n, rows_all = (n + 255) / 256;\n";
     o << "  for (uint64_t row = blockIdx.x; row < rows_all; row += gridDim.x) {\n";
     o << "    float tmax = -__builtin_inff();\n    bool live = false;\n";

@@ -1540,6 +1540,10 @@ void gjo_math(int fn, const float* x, float* y, uint64_t n) {
   }
 }
 
+/* the Box-Muller transform of two draw words (tests: accuracy against float64) */
+void gjo_bm_pair(const uint32_t* w_radius, const uint32_t* w_angle, float* z_cos, float* z_sin, uint64_t n) {
+  for (uint64_t i = 0; i < n; ++i) o_bm_pair(w_radius[i], w_angle[i], &z_cos[i], &z_sin[i]);
+}
 
 /* ---- bootstrap SMC for a user model (init + step site tables) ------------------------------------ */
 /* programs of the state arguments (init_state / next_state): the plan's own copies */

@@ -323,35 +323,124 @@ static inline float o_std_normal(uint32_t bits) {
 /* ---- PHILOX Normal sites: Box-Muller over pairs of particles ----------------------
  * Particles j0 = j & ~1 and j1 = j0 + 1 of a key batch (key lanes j0+1, j0+2) share one transform at every
  * Normal site: radius from j0's draw word, angle from j1's; j0 takes the cosine, j1 the sine.  Every
- * operation is IEEE-exact: Cephes sinf / cosf kernels on [0, pi/4] after an exact octant reduction of
- * the 24-bit angle.  A lane-0 key has no partner: its angle word comes from the same key under tag 'T'. */
+ * operation is IEEE-exact.  A lane-0 key has no partner: its angle word comes from the same key under tag 'T'. */
 #define O_TAG_TWIN 0x54u
-static inline float o_log_normal_range(float x) { return o_log(x); } /* same bits for positive normal x */
+/* The transform is table-driven (gjx_device.hpp bm_pair is the statement of the spec; tools/gen_bm_tables.py writes the
+ * same constants into both files): log u through Cephes' mantissa reduction, a 64-entry (1/c, log c) table and the
+ * log1p series to the 4th power; the angle through a 256-entry (cos, sin) table and the angle-sum formulas with
+ * short series in the remainder.  Only fmaf / * / + on floats and one correctly rounded sqrtf. */
+typedef struct { uint32_t a, b; } o_bm_ent;
+/* BEGIN BM TABLES (generated: tools/gen_bm_tables.py) */
+#define GJX_BM_LG_INIT { \
+  {0x3fb4065bu, 0xbeaea002u}, {0x3fb21179u, 0xbea907acu}, {0x3fb0275bu, 0xbea37eceu}, {0x3fae47abu, 0xbe9e051au}, \
+  {0x3fac7214u, 0xbe989a3au}, {0x3faaa645u, 0xbe933ddfu}, {0x3fa8e3f0u, 0xbe8defbau}, {0x3fa72acdu, 0xbe88af88u}, \
+  {0x3fa57a92u, 0xbe837cf7u}, {0x3fa3d2fcu, 0xbe7caf8au}, {0x3fa233cau, 0xbe727f63u}, {0x3fa09cbbu, 0xbe6868e7u}, \
+  {0x3f9f0d94u, 0xbe5e6ba2u}, {0x3f9d8619u, 0xbe54870cu}, {0x3f9c0613u, 0xbe4abab3u}, {0x3f9a8d4cu, 0xbe410622u}, \
+  {0x3f991b90u, 0xbe3768e7u}, {0x3f97b0acu, 0xbe2de28cu}, {0x3f964c71u, 0xbe2472aeu}, {0x3f94eeb0u, 0xbe1b18dfu}, \
+  {0x3f93973bu, 0xbe11d4b2u}, {0x3f9245e9u, 0xbe08a5d3u}, {0x3f90fa8fu, 0xbdff17adu}, {0x3f8fb505u, 0xbded0cc2u}, \
+  {0x3f8e7525u, 0xbddb2a38u}, {0x3f8d3ac8u, 0xbdc96f46u}, {0x3f8c05cau, 0xbdb7db42u}, {0x3f8ad60au, 0xbda66d9eu}, \
+  {0x3f89ab64u, 0xbd952594u}, {0x3f8885b8u, 0xbd84028du}, {0x3f8764e7u, 0xbd6607e9u}, {0x3f8648d1u, 0xbd445236u}, \
+  {0x3f85315au, 0xbd22e305u}, {0x3f841e65u, 0xbd01b926u}, {0x3f830fd6u, 0xbcc1a6e7u}, {0x3f820593u, 0xbc8061deu}, \
+  {0x3f80ff81u, 0xbbfe834fu}, {0x3f800000u, 0x80000000u}, {0x3f7c0629u, 0x3c803a74u}, {0x3f7834c1u, 0x3cfd47fdu}, \
+  {0x3f748086u, 0x3d3c3a06u}, {0x3f70e82du, 0x3d78e68cu}, {0x3f6d6a80u, 0x3d9a582eu}, {0x3f6a065bu, 0x3db7cef9u}, \
+  {0x3f66baaau, 0x3dd4dac6u}, {0x3f638667u, 0x3df17e9eu}, {0x3f60689du, 0x3e06dea8u}, {0x3f5d6061u, 0x3e14ccd8u}, \
+  {0x3f5a6cd9u, 0x3e228b23u}, {0x3f578d31u, 0x3e301adbu}, {0x3f54c0a5u, 0x3e3d7d2fu}, {0x3f520677u, 0x3e4ab351u}, \
+  {0x3f4f5df6u, 0x3e57be5cu}, {0x3f4cc677u, 0x3e649f6cu}, {0x3f4a3f5au, 0x3e715784u}, {0x3f47c805u, 0x3e7de7aau}, \
+  {0x3f455fe6u, 0x3e85286bu}, {0x3f430672u, 0x3e8b49fau}, {0x3f40bb24u, 0x3e9158f8u}, {0x3f3e7d7fu, 0x3e9755d1u}, \
+  {0x3f3c4d09u, 0x3e9d40f2u}, {0x3f3a294fu, 0x3ea31ac5u}, {0x3f3811e5u, 0x3ea8e3a8u}, {0x3f36065fu, 0x3eae9c03u}, \
+}
+#define GJX_BM_CS_INIT { \
+  {0x3f7ffb11u, 0x3c490e90u}, {0x3f7fd397u, 0x3d16c32cu}, {0x3f7f84abu, 0x3d7b2b74u}, {0x3f7f0e58u, 0x3dafb680u}, \
+  {0x3f7e70b0u, 0x3de1bc2eu}, {0x3f7dabccu, 0x3e09cf86u}, {0x3f7cbfc9u, 0x3e22abb6u}, {0x3f7baccdu, 0x3e3b6ecfu}, \
+  {0x3f7a7302u, 0x3e541501u}, {0x3f791298u, 0x3e6c9a7fu}, {0x3f778bc5u, 0x3e827dc0u}, {0x3f75dec6u, 0x3e8e9a22u}, \
+  {0x3f740bddu, 0x3e9aa086u}, {0x3f721352u, 0x3ea68f12u}, {0x3f6ff573u, 0x3eb263efu}, {0x3f6db293u, 0x3ebe1d4au}, \
+  {0x3f6b4b0cu, 0x3ec9b953u}, {0x3f68bf3cu, 0x3ed53641u}, {0x3f660f88u, 0x3ee0924fu}, {0x3f633c5au, 0x3eebcbbbu}, \
+  {0x3f604621u, 0x3ef6e0cbu}, {0x3f5d2d53u, 0x3f00e7e4u}, {0x3f59f26au, 0x3f064b82u}, {0x3f5695e5u, 0x3f0b9a6bu}, \
+  {0x3f531849u, 0x3f10d3cdu}, {0x3f4f7a1fu, 0x3f15f6d9u}, {0x3f4bbbf8u, 0x3f1b02c6u}, {0x3f47de65u, 0x3f1ff6cbu}, \
+  {0x3f43e200u, 0x3f24d225u}, {0x3f3fc767u, 0x3f299415u}, {0x3f3b8f3bu, 0x3f2e3bdeu}, {0x3f373a23u, 0x3f32c8c9u}, \
+  {0x3f32c8c9u, 0x3f373a23u}, {0x3f2e3bdeu, 0x3f3b8f3bu}, {0x3f299415u, 0x3f3fc767u}, {0x3f24d225u, 0x3f43e200u}, \
+  {0x3f1ff6cbu, 0x3f47de65u}, {0x3f1b02c6u, 0x3f4bbbf8u}, {0x3f15f6d9u, 0x3f4f7a1fu}, {0x3f10d3cdu, 0x3f531849u}, \
+  {0x3f0b9a6bu, 0x3f5695e5u}, {0x3f064b82u, 0x3f59f26au}, {0x3f00e7e4u, 0x3f5d2d53u}, {0x3ef6e0cbu, 0x3f604621u}, \
+  {0x3eebcbbbu, 0x3f633c5au}, {0x3ee0924fu, 0x3f660f88u}, {0x3ed53641u, 0x3f68bf3cu}, {0x3ec9b953u, 0x3f6b4b0cu}, \
+  {0x3ebe1d4au, 0x3f6db293u}, {0x3eb263efu, 0x3f6ff573u}, {0x3ea68f12u, 0x3f721352u}, {0x3e9aa086u, 0x3f740bddu}, \
+  {0x3e8e9a22u, 0x3f75dec6u}, {0x3e827dc0u, 0x3f778bc5u}, {0x3e6c9a7fu, 0x3f791298u}, {0x3e541501u, 0x3f7a7302u}, \
+  {0x3e3b6ecfu, 0x3f7baccdu}, {0x3e22abb6u, 0x3f7cbfc9u}, {0x3e09cf86u, 0x3f7dabccu}, {0x3de1bc2eu, 0x3f7e70b0u}, \
+  {0x3dafb680u, 0x3f7f0e58u}, {0x3d7b2b74u, 0x3f7f84abu}, {0x3d16c32cu, 0x3f7fd397u}, {0x3c490e90u, 0x3f7ffb11u}, \
+  {0xbc490e90u, 0x3f7ffb11u}, {0xbd16c32cu, 0x3f7fd397u}, {0xbd7b2b74u, 0x3f7f84abu}, {0xbdafb680u, 0x3f7f0e58u}, \
+  {0xbde1bc2eu, 0x3f7e70b0u}, {0xbe09cf86u, 0x3f7dabccu}, {0xbe22abb6u, 0x3f7cbfc9u}, {0xbe3b6ecfu, 0x3f7baccdu}, \
+  {0xbe541501u, 0x3f7a7302u}, {0xbe6c9a7fu, 0x3f791298u}, {0xbe827dc0u, 0x3f778bc5u}, {0xbe8e9a22u, 0x3f75dec6u}, \
+  {0xbe9aa086u, 0x3f740bddu}, {0xbea68f12u, 0x3f721352u}, {0xbeb263efu, 0x3f6ff573u}, {0xbebe1d4au, 0x3f6db293u}, \
+  {0xbec9b953u, 0x3f6b4b0cu}, {0xbed53641u, 0x3f68bf3cu}, {0xbee0924fu, 0x3f660f88u}, {0xbeebcbbbu, 0x3f633c5au}, \
+  {0xbef6e0cbu, 0x3f604621u}, {0xbf00e7e4u, 0x3f5d2d53u}, {0xbf064b82u, 0x3f59f26au}, {0xbf0b9a6bu, 0x3f5695e5u}, \
+  {0xbf10d3cdu, 0x3f531849u}, {0xbf15f6d9u, 0x3f4f7a1fu}, {0xbf1b02c6u, 0x3f4bbbf8u}, {0xbf1ff6cbu, 0x3f47de65u}, \
+  {0xbf24d225u, 0x3f43e200u}, {0xbf299415u, 0x3f3fc767u}, {0xbf2e3bdeu, 0x3f3b8f3bu}, {0xbf32c8c9u, 0x3f373a23u}, \
+  {0xbf373a23u, 0x3f32c8c9u}, {0xbf3b8f3bu, 0x3f2e3bdeu}, {0xbf3fc767u, 0x3f299415u}, {0xbf43e200u, 0x3f24d225u}, \
+  {0xbf47de65u, 0x3f1ff6cbu}, {0xbf4bbbf8u, 0x3f1b02c6u}, {0xbf4f7a1fu, 0x3f15f6d9u}, {0xbf531849u, 0x3f10d3cdu}, \
+  {0xbf5695e5u, 0x3f0b9a6bu}, {0xbf59f26au, 0x3f064b82u}, {0xbf5d2d53u, 0x3f00e7e4u}, {0xbf604621u, 0x3ef6e0cbu}, \
+  {0xbf633c5au, 0x3eebcbbbu}, {0xbf660f88u, 0x3ee0924fu}, {0xbf68bf3cu, 0x3ed53641u}, {0xbf6b4b0cu, 0x3ec9b953u}, \
+  {0xbf6db293u, 0x3ebe1d4au}, {0xbf6ff573u, 0x3eb263efu}, {0xbf721352u, 0x3ea68f12u}, {0xbf740bddu, 0x3e9aa086u}, \
+  {0xbf75dec6u, 0x3e8e9a22u}, {0xbf778bc5u, 0x3e827dc0u}, {0xbf791298u, 0x3e6c9a7fu}, {0xbf7a7302u, 0x3e541501u}, \
+  {0xbf7baccdu, 0x3e3b6ecfu}, {0xbf7cbfc9u, 0x3e22abb6u}, {0xbf7dabccu, 0x3e09cf86u}, {0xbf7e70b0u, 0x3de1bc2eu}, \
+  {0xbf7f0e58u, 0x3dafb680u}, {0xbf7f84abu, 0x3d7b2b74u}, {0xbf7fd397u, 0x3d16c32cu}, {0xbf7ffb11u, 0x3c490e90u}, \
+  {0xbf7ffb11u, 0xbc490e90u}, {0xbf7fd397u, 0xbd16c32cu}, {0xbf7f84abu, 0xbd7b2b74u}, {0xbf7f0e58u, 0xbdafb680u}, \
+  {0xbf7e70b0u, 0xbde1bc2eu}, {0xbf7dabccu, 0xbe09cf86u}, {0xbf7cbfc9u, 0xbe22abb6u}, {0xbf7baccdu, 0xbe3b6ecfu}, \
+  {0xbf7a7302u, 0xbe541501u}, {0xbf791298u, 0xbe6c9a7fu}, {0xbf778bc5u, 0xbe827dc0u}, {0xbf75dec6u, 0xbe8e9a22u}, \
+  {0xbf740bddu, 0xbe9aa086u}, {0xbf721352u, 0xbea68f12u}, {0xbf6ff573u, 0xbeb263efu}, {0xbf6db293u, 0xbebe1d4au}, \
+  {0xbf6b4b0cu, 0xbec9b953u}, {0xbf68bf3cu, 0xbed53641u}, {0xbf660f88u, 0xbee0924fu}, {0xbf633c5au, 0xbeebcbbbu}, \
+  {0xbf604621u, 0xbef6e0cbu}, {0xbf5d2d53u, 0xbf00e7e4u}, {0xbf59f26au, 0xbf064b82u}, {0xbf5695e5u, 0xbf0b9a6bu}, \
+  {0xbf531849u, 0xbf10d3cdu}, {0xbf4f7a1fu, 0xbf15f6d9u}, {0xbf4bbbf8u, 0xbf1b02c6u}, {0xbf47de65u, 0xbf1ff6cbu}, \
+  {0xbf43e200u, 0xbf24d225u}, {0xbf3fc767u, 0xbf299415u}, {0xbf3b8f3bu, 0xbf2e3bdeu}, {0xbf373a23u, 0xbf32c8c9u}, \
+  {0xbf32c8c9u, 0xbf373a23u}, {0xbf2e3bdeu, 0xbf3b8f3bu}, {0xbf299415u, 0xbf3fc767u}, {0xbf24d225u, 0xbf43e200u}, \
+  {0xbf1ff6cbu, 0xbf47de65u}, {0xbf1b02c6u, 0xbf4bbbf8u}, {0xbf15f6d9u, 0xbf4f7a1fu}, {0xbf10d3cdu, 0xbf531849u}, \
+  {0xbf0b9a6bu, 0xbf5695e5u}, {0xbf064b82u, 0xbf59f26au}, {0xbf00e7e4u, 0xbf5d2d53u}, {0xbef6e0cbu, 0xbf604621u}, \
+  {0xbeebcbbbu, 0xbf633c5au}, {0xbee0924fu, 0xbf660f88u}, {0xbed53641u, 0xbf68bf3cu}, {0xbec9b953u, 0xbf6b4b0cu}, \
+  {0xbebe1d4au, 0xbf6db293u}, {0xbeb263efu, 0xbf6ff573u}, {0xbea68f12u, 0xbf721352u}, {0xbe9aa086u, 0xbf740bddu}, \
+  {0xbe8e9a22u, 0xbf75dec6u}, {0xbe827dc0u, 0xbf778bc5u}, {0xbe6c9a7fu, 0xbf791298u}, {0xbe541501u, 0xbf7a7302u}, \
+  {0xbe3b6ecfu, 0xbf7baccdu}, {0xbe22abb6u, 0xbf7cbfc9u}, {0xbe09cf86u, 0xbf7dabccu}, {0xbde1bc2eu, 0xbf7e70b0u}, \
+  {0xbdafb680u, 0xbf7f0e58u}, {0xbd7b2b74u, 0xbf7f84abu}, {0xbd16c32cu, 0xbf7fd397u}, {0xbc490e90u, 0xbf7ffb11u}, \
+  {0x3c490e90u, 0xbf7ffb11u}, {0x3d16c32cu, 0xbf7fd397u}, {0x3d7b2b74u, 0xbf7f84abu}, {0x3dafb680u, 0xbf7f0e58u}, \
+  {0x3de1bc2eu, 0xbf7e70b0u}, {0x3e09cf86u, 0xbf7dabccu}, {0x3e22abb6u, 0xbf7cbfc9u}, {0x3e3b6ecfu, 0xbf7baccdu}, \
+  {0x3e541501u, 0xbf7a7302u}, {0x3e6c9a7fu, 0xbf791298u}, {0x3e827dc0u, 0xbf778bc5u}, {0x3e8e9a22u, 0xbf75dec6u}, \
+  {0x3e9aa086u, 0xbf740bddu}, {0x3ea68f12u, 0xbf721352u}, {0x3eb263efu, 0xbf6ff573u}, {0x3ebe1d4au, 0xbf6db293u}, \
+  {0x3ec9b953u, 0xbf6b4b0cu}, {0x3ed53641u, 0xbf68bf3cu}, {0x3ee0924fu, 0xbf660f88u}, {0x3eebcbbbu, 0xbf633c5au}, \
+  {0x3ef6e0cbu, 0xbf604621u}, {0x3f00e7e4u, 0xbf5d2d53u}, {0x3f064b82u, 0xbf59f26au}, {0x3f0b9a6bu, 0xbf5695e5u}, \
+  {0x3f10d3cdu, 0xbf531849u}, {0x3f15f6d9u, 0xbf4f7a1fu}, {0x3f1b02c6u, 0xbf4bbbf8u}, {0x3f1ff6cbu, 0xbf47de65u}, \
+  {0x3f24d225u, 0xbf43e200u}, {0x3f299415u, 0xbf3fc767u}, {0x3f2e3bdeu, 0xbf3b8f3bu}, {0x3f32c8c9u, 0xbf373a23u}, \
+  {0x3f373a23u, 0xbf32c8c9u}, {0x3f3b8f3bu, 0xbf2e3bdeu}, {0x3f3fc767u, 0xbf299415u}, {0x3f43e200u, 0xbf24d225u}, \
+  {0x3f47de65u, 0xbf1ff6cbu}, {0x3f4bbbf8u, 0xbf1b02c6u}, {0x3f4f7a1fu, 0xbf15f6d9u}, {0x3f531849u, 0xbf10d3cdu}, \
+  {0x3f5695e5u, 0xbf0b9a6bu}, {0x3f59f26au, 0xbf064b82u}, {0x3f5d2d53u, 0xbf00e7e4u}, {0x3f604621u, 0xbef6e0cbu}, \
+  {0x3f633c5au, 0xbeebcbbbu}, {0x3f660f88u, 0xbee0924fu}, {0x3f68bf3cu, 0xbed53641u}, {0x3f6b4b0cu, 0xbec9b953u}, \
+  {0x3f6db293u, 0xbebe1d4au}, {0x3f6ff573u, 0xbeb263efu}, {0x3f721352u, 0xbea68f12u}, {0x3f740bddu, 0xbe9aa086u}, \
+  {0x3f75dec6u, 0xbe8e9a22u}, {0x3f778bc5u, 0xbe827dc0u}, {0x3f791298u, 0xbe6c9a7fu}, {0x3f7a7302u, 0xbe541501u}, \
+  {0x3f7baccdu, 0xbe3b6ecfu}, {0x3f7cbfc9u, 0xbe22abb6u}, {0x3f7dabccu, 0xbe09cf86u}, {0x3f7e70b0u, 0xbde1bc2eu}, \
+  {0x3f7f0e58u, 0xbdafb680u}, {0x3f7f84abu, 0xbd7b2b74u}, {0x3f7fd397u, 0xbd16c32cu}, {0x3f7ffb11u, 0xbc490e90u}, \
+}
+/* END BM TABLES */
+static const o_bm_ent o_bm_lg[64] = GJX_BM_LG_INIT;
+static const o_bm_ent o_bm_cs[256] = GJX_BM_CS_INIT;
 static inline void o_bm_pair(uint32_t w_radius, uint32_t w_angle, float* z_cos, float* z_sin) {
   float u = ((float)w_radius + 1.0f) * 2.3283064365386963e-10f;
-  float r = sqrtf(-2.0f * o_log_normal_range(u));
-  uint32_t a = w_angle >> 8;
-  uint32_t oct = a >> 21;
-  float f = (float)(a & 0x1fffffu) * 4.76837158203125e-07f;
-  float g = (oct & 1u) ? 1.0f - f : f;
-  float x = g * 0.78539816339744831f;
-  float z = x * x;
-  float ps = -1.9515295891E-4f;
-  ps = fmaf(ps, z, 8.3321608736E-3f);
-  ps = fmaf(ps, z, -1.6666654611E-1f);
-  float t = ps * z;
-  float s = fmaf(t, x, x);
-  float pc = 2.443315711809948E-5f;
-  pc = fmaf(pc, z, -1.388731625493765E-3f);
-  pc = fmaf(pc, z, 4.166664568298827E-2f);
-  float t2 = pc * z;
-  float c = fmaf(t2, z, fmaf(-0.5f, z, 1.0f));
-  int swap = ((oct + 1u) & 2u) != 0u;
-  float cs = swap ? s : c, sn = swap ? c : s;
-  if ((oct + 2u) & 4u) cs = -cs;
-  if (oct & 4u) sn = -sn;
-  *z_cos = r * cs;
-  *z_sin = r * sn;
+  uint32_t t = o_f2u(u) - 0x3f3504f3u;
+  o_bm_ent lg = o_bm_lg[(t >> 17) & 63u];
+  float m = o_u2f((t & 0x007fffffu) + 0x3f3504f3u);
+  float fe = (float)((int32_t)t >> 23);
+  float q = fmaf(m, o_u2f(lg.a), -1.0f);
+  float p = fmaf(q, -0.25f, 0.333333343f);
+  p = fmaf(p, q, -0.5f);
+  float qq = q * q;
+  float l1 = fmaf(p, qq, q);
+  float lu = fmaf(fe, 0.693147182f, o_u2f(lg.b)) + l1;
+  float r = sqrtf(-2.0f * lu);
+  o_bm_ent cs = o_bm_cs[w_angle >> 24];
+  float d = fmaf((float)((w_angle >> 8) & 0xffffu), 3.74507035e-07f, -0.0122718466f);
+  float d2 = d * d;
+  float d3 = d2 * d;
+  float sd = fmaf(d3, -0.166666672f, d);
+  float cd = fmaf(d2, fmaf(d2, 0.0416666679f, -0.5f), 1.0f);
+  float ca = o_u2f(cs.a), sa = o_u2f(cs.b);
+  float t1 = sa * sd, t2 = ca * sd;
+  *z_cos = r * fmaf(ca, cd, -t1);
+  *z_sin = r * fmaf(sa, cd, t2);
 }
 /* The standard normal of a Normal site for stream `s` (folded, PHILOX): Box-Muller over the particle pair — the
  * even particle's draw is the radius word, the odd one's the angle word, the even particle takes the cosine

@@ -72,6 +72,41 @@ def _math(raw, fn, x):
     return y
 
 
+def test_box_muller_against_float64(raw):
+    """The table-driven Box-Muller transform of the PHILOX Normal sites (gjx_device.hpp bm_pair): against float64 on the
+    same two words the normals are within 2.5e-7 of the radius (edge words, every table boundary, u -> 1, 2e6 random
+    pairs); u = 1 gives radius 0; and the constants in both headers are the generator's (tools/gen_bm_tables.py)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(HERE)
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_bm_tables.py"), "--check"]).returncode == 0
+    rng = np.random.default_rng(0)
+    n = 2_000_000
+    wr = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    wa = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    edge = np.array([0, 1, 2, 0xFFFFFFFF, 0xFFFFFFFE, 0xFFFFFF00, 0xFFFFFE00, 0xFFFF0000, 0x80000000, 0x7FFFFFFF,
+                     0xB504F333, 0xB504F334], dtype=np.uint32)
+    wr[:edge.size] = edge
+    k = np.arange(256, dtype=np.uint64)
+    wa[100:356] = (k << 24).astype(np.uint32)
+    wa[400:656] = ((k << 24) | 0xFFFFFF).astype(np.uint32)
+    wa[700:956] = ((k << 24) | 0x800000).astype(np.uint32)
+    wr[1000:200000] = (2**32 - 1 - rng.integers(0, 2**26, 199000)).astype(np.uint32)  # u close to 1
+    zc, zs = np.empty(n, np.float32), np.empty(n, np.float32)
+    raw.gjo_bm_pair(wr.ctypes.data_as(C.c_void_p), wa.ctypes.data_as(C.c_void_p), zc.ctypes.data_as(C.c_void_p),
+                    zs.ctypes.data_as(C.c_void_p), C.c_uint64(n))
+    u = ((wr.astype(np.float32) + np.float32(1.0)) * np.float32(2.3283064365386963e-10)).astype(np.float64)
+    r = np.sqrt(-2.0 * np.log(u))
+    th = 2.0 * np.pi * (wa >> 8).astype(np.float64) / 2.0**24
+    assert np.isfinite(zc).all() and np.isfinite(zs).all()
+    assert zc[3] == 0.0 and zs[3] == 0.0  # u == 1
+    for got, ref in ((zc, r * np.cos(th)), (zs, r * np.sin(th))):
+        assert np.max(np.abs(got - ref) - 2.5e-7 * r) <= 0.0
+    assert stats.kstest(zc[200000:].astype(np.float64), "norm").pvalue > 1e-3
+    assert stats.kstest(zs[200000:].astype(np.float64), "norm").pvalue > 1e-3
+
+
 def test_math_spec_accuracy(raw):
     rng = np.random.default_rng(0)
     x = np.exp(rng.uniform(-80, 80, 100000)).astype(np.float32)
