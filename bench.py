@@ -515,7 +515,7 @@ def bench_scan(args, ops, min_s=0.08, T=100, fast_math=False, with_host_loop=Tru
         "roofline": {"bound": "hbm", "kernel": "gjx_scan_kernel (one launch per pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch,
                      "traffic": None,
-                     "limiter": "VALU issue: half a pair block + half a Box-Muller transform + two log-densities per particle-step (quad form; r02: three blocks and a transform)"},
+                     "limiter": "VALU issue: half a pair block + half a table-driven Box-Muller transform + two log-densities per particle-step (quad form; r02: three blocks and a polynomial transform)"},
         "log_z": r["log_z"],
     }
     if with_host_loop:
