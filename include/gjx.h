@@ -30,8 +30,10 @@
 extern "C" {
 #endif
 
+/* 0.8: the arithmetic spec of PHILOX Normal sites changed (table-driven Box-Muller): same words, same
+ * pairing, normals that differ from 0.7's in the last bits.  Library and oracle of one version agree bit for bit. */
 #define GJX_VERSION_MAJOR 0
-#define GJX_VERSION_MINOR 7
+#define GJX_VERSION_MINOR 8
 
 typedef void* gjx_stream; /* hipStream_t; ignored by the oracle build */
 

@@ -40,7 +40,7 @@ def test_gaussian10_plan_compiles(hip_lib_nogpu, impl, monkeypatch):
     src1 = source_of(ops, plan, impl)
     if impl == 0:  # jax key tree: one particle per lane, erfinv normals, 20 log-densities
         assert src1.count("std_normal(") == 10 and src1.count("logpdf_normal_pre(") == 20
-        assert "__launch_bounds__(256" in src1
+        assert "__launch_bounds__(256" in src1 and "GJX_BM_LDS" not in src1 and "bm_stage" not in src1
     else:
         # the paired form: two adjacent particles per lane (A, B), ONE Box-Muller transform per Normal site for
         # the pair, and the pair's single-word draws two sites to a Philox block whatever is observed in between
@@ -48,6 +48,9 @@ def test_gaussian10_plan_compiles(hip_lib_nogpu, impl, monkeypatch):
         assert src1.count("bm_pair(") == 10 and src1.count("std_normal(") == 0
         assert src1.count("logpdf_normal_pre(") == 40
         assert src1.count("kTagPair") == 5 and src1.count("philox4x32(") == 5
+        # the Box-Muller tables are staged in LDS once per workgroup, before the grid-stride loop over rows
+        assert src1.startswith("#define GJX_BM_LDS 1") and src1.count("bm_stage();") == 1
+        assert src1.index("bm_stage();") < src1.index("for (uint64_t g0")
         assert "ks.parent.k0" in src1 and "__launch_bounds__(128" in src1
         # the default form: FOUR adjacent particles per lane = two pairs, one wave per 256-particle row (no LDS,
         # no barrier in the row statistics), 16-byte column stores
@@ -58,7 +61,9 @@ def test_gaussian10_plan_compiles(hip_lib_nogpu, impl, monkeypatch):
         assert "make_uint4(" in src4 and "__syncthreads" not in src4.split("lse_tail")[0].split("void gjx_plan_kernel_philox")[1]
         # GJX_PLAN_FAST_MATH switches the device header's continuous functions to the hardware transcendentals
         fast = ops.plan_create(W.gaussian10_sites(W.gaussian10_data()), fast_math=True)
-        assert source_of(ops, fast, impl).startswith("#define GJX_FAST_MATH 1")
+        fsrc = source_of(ops, fast, impl)
+        assert fsrc.startswith("#define GJX_FAST_MATH 1") and "GJX_BM_LDS" not in fsrc and "bm_stage" not in fsrc
+        assert src4.startswith("#define GJX_BM_LDS 1") and src4.count("bm_stage();") == 1
         ops.lib.call("gjx_plan_compile_check", fast.handle, impl)
     ops.lib.call("gjx_plan_compile_check", plan.handle, impl)
 
