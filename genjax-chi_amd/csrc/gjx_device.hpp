@@ -514,7 +514,7 @@ GJX_HD float std_normal(uint32_t bits) {
 // still consumes exactly one word per site, so keys, blocks and draw indices are unchanged.
 // The transform is TABLE-DRIVEN (tools/gen_bm_tables.py writes the constants; the oracle holds the same bits):
 //   log u:  Cephes' mantissa reduction to [sqrt(1/2), sqrt(2)), then the 64-entry table over the offset mantissa:
-//           log m = log c_k + log1p(q), q = fma(m, 1/c_k, -1) (|q| <= 2^-7 + ), log1p by its series to q^4; the entry
+//           log m = log c_k + log1p(q), q = fma(m, 1/c_k, -1) (|q| <= 2^-6), log1p by its series to q^4; the entry
 //           holds fl(1/c_k) and -log of THAT float, and the interval around 1 has c = 1, so u -> 1 keeps full
 //           relative accuracy;
 //   angle 2 pi a / 2^24:  the top 8 bits pick (cos A_k, sin A_k), A_k = 2 pi (k + 1/2) / 256; the low 16 bits are
@@ -524,7 +524,7 @@ GJX_HD float std_normal(uint32_t bits) {
 // sinf / cosf kernels) it replaces; two 8-byte table reads, from LDS in the kernels that stage the tables
 // (GJX_BM_LDS: bm_stage() at kernel entry — the compiled importance and scan kernels), from the constant arrays
 // elsewhere.  Every operation is an IEEE fma / mul / add on f32, so HIP == oracle bit for bit; against float64 the
-// normals are within 2.5e-7 * (1 + |z|) (tests/test_oracle_pinning.py).  THREEFRY keeps jax's erfinv form.
+// normals are within 2.5e-7 of the radius (tests/test_oracle_pinning.py: test_box_muller_against_float64).  THREEFRY keeps jax's erfinv form.
 struct BmEnt {
   uint32_t a, b;
 };
