@@ -1042,6 +1042,15 @@ GJX_HD uint64_t shr64(uint64_t v, int d) { return d >= 64 ? 0 : v >> d; }
 // ntiles = total), then e (sign-extended), R1, R2
 GJX_HD uint64_t prefix_words(uint64_t ntiles) { return ntiles + 4; }
 
+// Profiling hooks of the SMC step (early exits by phase, tools/phases_smc.sh): compiled in only with -DGJX_PROFILE_HOOKS — a
+// separate build of the library; the shipped kernels carry none of them, and GJX_SMC_DEBUG_STOP / GJX_SMC_DEBUG_FIXED do
+// nothing there (a run that stops early returns GJX_OK with truncated state: not something an environment variable of a
+// production library may cause).
+#ifdef GJX_PROFILE_HOOKS
+#define GJX_DBG_STOP(A, k, ...) if (((A).debug_stop & 15) == (k)) { __VA_ARGS__; return; }
+#else
+#define GJX_DBG_STOP(A, k, ...)
+#endif
 struct ResampleArgs {
   const uint32_t* qw = nullptr;         // [n] tile-anchored fixed-point weights of the SOURCE population
   const float* lw = nullptr;            // [n] source log-weights (adaptive filters: a kept step accumulates them)
@@ -1065,7 +1074,7 @@ struct ResampleArgs {
   TileSub* subs_out = nullptr;          // GLOBAL, likewise
   TileEss* ess_out = nullptr;           // GLOBAL, likewise (adaptive filters)
   int scan_max = kScanMax;              // rounds of the window scan (test knob: 0 = every output tile takes the per-slot search)
-  int debug_stop = 0;                   // profiling knob (GJX_SMC_DEBUG_STOP): leave the kernel after phase k
+  int debug_stop = 0;                   // profiling builds only (-DGJX_PROFILE_HOOKS, GJX_SMC_DEBUG_STOP): leave the kernel after phase k
   int xcd_map = 1;                      // contiguous output tiles per XCD (GJX_SMC_XCD_MAP=0: plain order)
   int wt_stores = 0;                    // write-through stores of the step's output columns (store16_out)
 };
@@ -1335,18 +1344,27 @@ GJX_DEV void policy_store_quad(Policy& P, int64_t jq, int64_t out_lo, const uint
 
 // 16-byte store of a step's output column; `wt`: WRITE-THROUGH (sc1) — the bytes leave the L2 as they are produced instead of
 // in the write-back at the kernel's end (the next step's workgroups, on any XCD, read them from memory either way).
-// Measured, one filter of 1e6 particles: LGSSM step 13.17 -> 12.59 us, HMM 13.73 -> 13.22; with 16 filters per launch
+// Measured (r03), one filter of 1e6 particles: LGSSM step 13.17 -> 12.59 us, HMM 13.73 -> 13.22; with 16 filters per launch
 // the write-back wins (127 vs 132 us: the next step finds part of its input in the L2s), so the host sets `wt` for
 // one-filter launches only (ResampleArgs::wt_stores; GJX_SMC_WT=0|1 forces it).
 GJX_DEV void store16_out(void* p, uint4 v, bool wt) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (wt) {
+    // r04: a compiler BUILTIN carries the cache policy (rounds 1-3: inline asm `global_store_dwordx4 ... sc1` + a hand-placed
+    // `s_nop`, because the hazard recogniser does not look inside asm — a correctness hazard owned by a comment).  The raw
+    // buffer store takes a wave-uniform base (descriptor in SGPRs) and a per-lane byte offset: the base is the first active
+    // lane's address minus 2^30, so lanes up to 1 GiB either side of it are addressable (the callers' lanes lie within a tile);
+    // aux bit 4 = sc1 on gfx94x/gfx950 (`buffer_store_dwordx4 ... offen sc1`), the instruction the asm spelled.
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     v4u_t x;
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-    // (s_nop: the compiler's hazard recogniser does not see inside the asm — a 16-byte store must not be followed at once by
-    // a write of its data registers)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    const uint64_t first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
+                           (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint64_t base = first - (1ull << 30);
+    const uint32_t off = (uint32_t)(a - base);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(x, rs, (int)off, 0, 16 /* sc1 */);
     return;
   }
 #endif
@@ -1533,7 +1551,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     u0 = A.fb.u0[f];
     P.select_filter((uint64_t)f * A.fb.stride, A.fb.step_key[f]);
   }
-  if ((A.debug_stop & 15) == 15) return;  // (profiling: the launch / dispatch floor)
+  GJX_DBG_STOP(A, 15);  // (profiling: the launch / dispatch floor)
   const bool adaptive = ADAPTIVE && A.ess_thr > 0.0;
   if (A.xcd_map) {
     // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin, and neighbouring output tiles read
@@ -1577,10 +1595,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   for (int r = 0; r < kPer; ++r) marks[tid + r * kBlock] = 0;
   if (tid == 0) sh_klo = ~0u;
   policy_prefetch(P, jq, 0);  // (under the latency of the record loads)
-  if ((A.debug_stop & 15) == 14) {  // (profiling: records loaded, the policy's prefetch done, nothing merged)
-    if (lds_prefix && rs_[0] == 0x123456789abcdefull && re_[0] == 77) marks[0] = 1;
-    return;
-  }
+  GJX_DBG_STOP(A, 14, if (lds_prefix && rs_[0] == 0x123456789abcdefull && re_[0] == 77) marks[0] = 1);  // (records loaded, prefetch done, nothing merged)
 
   // ---- merge: anchor, shifted masses, exclusive prefix, total, ESS sums ------------------------------------------
   int32_t e = kRowEmpty;
@@ -1643,7 +1658,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   const bool resample = !adaptive || ess_says_resample(r1, r2, A.ess_thr);
   if (resampled_out && b == 0 && tid == 0) resampled_out[0] = resample ? 1 : 0;
   policy_stage(P, 0);  // (every path below passes a barrier before the policy computes)
-  if ((A.debug_stop & 15) == 1) return;
+  GJX_DBG_STOP(A, 1);
 
   auto pre_at = [&](uint64_t k) -> uint64_t { return lds_prefix ? sh_pre[k] : prefix[k]; };
   auto shift_at = [&](uint64_t k) -> int { return lds_prefix ? (int)sh_d[k] : tile_shift(e, recs[k].e); };
@@ -1733,7 +1748,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
       __syncthreads();
       k_lo = lo + sh_klo;
     }
-    if ((A.debug_stop & 15) == 2) return;
+    GJX_DBG_STOP(A, 2);
     // ---- the window: it starts at the 64-particle block of tile k_lo that holds the first tooth of [j0, j1) ----------
     uint64_t i_base;
     {
@@ -1796,7 +1811,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
       __syncthreads();
       covered = sh_cov[rounds & 1] != 0;
     }
-    if ((A.debug_stop & 15) == 3) return;
+    GJX_DBG_STOP(A, 3);
     if (covered) {
       // ---- a max-scan spreads the marks over the runs ----------------------------------------------------------------
       uint32_t v[kPer];
@@ -1861,10 +1876,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     }
   }
 
-  if ((A.debug_stop & 15) == 4) {
-    if (anc[0] == 0xffffffffu) marks[0] = anc[1] + anc[2] + anc[3];
-    return;
-  }
+  GJX_DBG_STOP(A, 4, if (anc[0] == 0xffffffffu) marks[0] = anc[1] + anc[2] + anc[3]);
   typename Policy::Out out[kPer];
   float w[kPer];
   policy_compute_quad(P, jq, anc, out, w, 0);
@@ -1873,7 +1885,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     for (int r = 0; r < kPer; ++r) w[r] = w[r] + lw_prev[r];
   }
   policy_store_quad(P, jq, A.out_lo, anc, out, ok, 0);
-  if ((A.debug_stop & 15) == 5) return;
+  GJX_DBG_STOP(A, 5);
   if (Policy::kEmit) {
     const uint64_t loc = (uint64_t)(jq - A.out_lo);
     emit_tile<ADAPTIVE>(w, ok, qw_out + loc, logw_out ? logw_out + loc : nullptr, recs_out + ot, subs_out + ot,

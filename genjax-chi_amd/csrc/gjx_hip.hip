@@ -2451,8 +2451,10 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
   A.subs_out = reinterpret_cast<TileSub*>(out->subs);
   A.ess_out = ad ? reinterpret_cast<TileEss*>(out->ess) : nullptr;
   A.scan_max = scan_max_knob();
+#ifdef GJX_PROFILE_HOOKS
   static const int dbg_stop = [] { const char* e = std::getenv("GJX_SMC_DEBUG_STOP"); return e ? atoi(e) : 0; }();
   A.debug_stop = dbg_stop;
+#endif
   static const int xcd_map = [] { const char* e = std::getenv("GJX_SMC_XCD_MAP"); return e ? atoi(e) : 1; }();
   A.xcd_map = xcd_map;
   static const int wt_knob = [] { const char* e = std::getenv("GJX_SMC_WT"); return e ? atoi(e) : -1; }();
@@ -2867,6 +2869,15 @@ int gjx_jit_stats(uint64_t* compiles, uint64_t* cached_modules, uint64_t* evicti
   return GJX_OK;
 }
 
+int gjx_jit_routes(uint64_t* child_compiles, uint64_t* inproc_compiles, uint64_t* child_failures, uint64_t* spawn_failures) {
+  gjx_jit::RouteCounters& r = gjx_jit::routes();
+  if (child_compiles) *child_compiles = r.child.load();
+  if (inproc_compiles) *inproc_compiles = r.inproc.load();
+  if (child_failures) *child_failures = r.child_failures.load();
+  if (spawn_failures) *spawn_failures = r.spawn_failures.load();
+  return GJX_OK;
+}
+
 static std::string smc_plan_source(const gjx_smc_plan* plan, int impl, PlanTables* tabs = nullptr) {
   gjx_jit::TableScope ts;
   gjx_jit::GenSmc<CSite, CArg> g;
@@ -3042,6 +3053,7 @@ static int smc_run(const gjx_smc_config* cfg, const void* model, int32_t* out_e,
     int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * rc.F * rc.stride : nullptr;
     gjx_smc_pop out;
     StepCtx ctx = run_step_ctx(cfg, rc, t, &out);
+#ifdef GJX_PROFILE_HOOKS
     static const bool dbg_fixed = std::getenv("GJX_SMC_DEBUG_FIXED") != nullptr;  // profiling: every step reads step 0's population
     if (dbg_fixed && t > 0) {
       out = rc.pop[1];
@@ -3049,6 +3061,7 @@ static int smc_run(const gjx_smc_config* cfg, const void* model, int32_t* out_e,
       r = step(t, &rc.pop[0], &out, out_e + (t - 1), out_q + (t - 1), anc_t, ctx);
       continue;
     }
+#endif
     r = step(t, &rc.pop[(t & 1) ^ 1], &out, t ? out_e + (t - 1) : nullptr, t ? out_q + (t - 1) : nullptr, anc_t, ctx);
   }
   if (r) return r;

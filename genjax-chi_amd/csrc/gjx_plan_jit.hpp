@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hiprtc.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -21,6 +22,7 @@
 #include <utility>
 #include <vector>
 
+#include <dirent.h>
 #include <dlfcn.h>
 #include <spawn.h>
 #include <sys/wait.h>
@@ -1048,8 +1050,9 @@ inline bool enabled() {
 // backend bug would do the same).  So generated kernels are compiled by `gjx_jitc`, a helper next to this library: a fresh
 // process that never touches the GPU, started with posix_spawn (a child process — the caller is not replaced), source /
 // header / code object / log in files of a private temporary directory.  A child that dies => false + a log line
-// (callers return GJX_ERR_JIT).  GJX_JIT_INPROC=1 compiles in-process (the round-1/2 behaviour); so does a missing helper,
-// with a warning.
+// (callers return GJX_ERR_JIT).  GJX_JIT_INPROC=1 compiles in-process (the round-1/2 behaviour).  A helper that cannot be
+// started is GJX_ERR_JIT too (r04: the silent in-process fallback is opt-in, GJX_JIT_INPROC_FALLBACK=1); gjx_jit_routes
+// says which route produced the code objects of this process.
 inline std::string jitc_path() {
   static const std::string path = [] {
     if (const char* e = std::getenv("GJX_JITC")) return std::string(e);
@@ -1091,46 +1094,114 @@ inline std::vector<std::string> compile_options() {
   }
   return opts;
 }
+// Which route compiled what (gjx_jit_routes): child = code objects produced by gjx_jitc, inproc = by hiprtc inside this
+// process (GJX_JIT_INPROC=1 / GJX_JIT_INPROC_FALLBACK=1 only), child_failures = children that died or rejected a source,
+// spawn_failures = helpers that could not be started at all.
+struct RouteCounters {
+  std::atomic<uint64_t> child{0}, inproc{0}, child_failures{0}, spawn_failures{0};
+};
+inline RouteCounters& routes() {
+  static RouteCounters r;
+  return r;
+}
+// The private directory of THIS process (re-created after a fork: a child of the host program must not share its parent's
+// files), removed at exit.  Files inside are named per compilation.
+struct JitDir {
+  std::string path;
+  pid_t owner = 0;
+  bool hdr_ok = false;
+  void remove_all() {
+    if (path.empty() || owner != getpid()) return;  // (a forked child never deletes its parent's directory)
+    if (DIR* d = opendir(path.c_str())) {
+      while (dirent* e = readdir(d)) {
+        if (!std::strcmp(e->d_name, ".") || !std::strcmp(e->d_name, "..")) continue;
+        unlink((path + "/" + e->d_name).c_str());
+      }
+      closedir(d);
+    }
+    rmdir(path.c_str());
+    path.clear();
+  }
+  ~JitDir() {
+    if (!std::getenv("GJX_JIT_KEEP_FILES")) remove_all();
+  }
+  // -> the directory of the calling process ("" on failure); called under the compile lock
+  const std::string& get() {
+    if (!path.empty() && owner == getpid()) return path;
+    const char* t = std::getenv("TMPDIR");
+    std::string d = std::string(t && *t ? t : "/tmp") + "/gjx_jit_XXXXXX";
+    path = mkdtemp(&d[0]) ? d : std::string();
+    owner = getpid();
+    hdr_ok = !path.empty() && write_file(path + "/gjx_device.hpp", kDeviceHeader, sizeof(kDeviceHeader) - 1);
+    return path;
+  }
+};
+// The child's environment: the caller's without what would make the helper more than a compiler — a profiler's or
+// sanitizer's preloaded library (under rocprofv3 LD_PRELOAD would initialise the GPU inside gjx_jitc and add its output),
+// and the ROCm tool variables that go with it.
+inline std::vector<char*> child_environ() {
+  static const char* const drop[] = {"LD_PRELOAD=", "ROCP_", "ROCPROFILER_", "ROCPROF_", "HSA_TOOLS_", "ROCTX_", "ROCTRACER_"};
+  std::vector<char*> env;
+  for (char** e = environ; e && *e; ++e) {
+    bool skip = false;
+    for (const char* d : drop) skip = skip || std::strncmp(*e, d, std::strlen(d)) == 0;
+    if (!skip) env.push_back(*e);
+  }
+  env.push_back(nullptr);
+  return env;
+}
 // -> 1 compiled, 0 compilation failed or the child died (logged), -1 the child could not be started
 inline int compile_in_child(const std::string& src, std::string* code) {
   const std::string helper = jitc_path();
   if (helper.empty()) return -1;
-  static std::mutex mu;  // one directory per process; compilations are serialised by the module cache's lock anyway
+  static std::mutex mu;  // compilations are serialised by the module cache's lock anyway
   std::lock_guard<std::mutex> lock(mu);
-  static const std::string dir = [] {
-    const char* t = std::getenv("TMPDIR");
-    std::string d = std::string(t && *t ? t : "/tmp") + "/gjx_jit_XXXXXX";
-    return mkdtemp(&d[0]) ? d : std::string();
-  }();
-  if (dir.empty()) return -1;
-  const std::string fsrc = dir + "/k.hip", fhdr = dir + "/gjx_device.hpp", fout = dir + "/k.co", flog = dir + "/k.log";
-  static const bool hdr_ok = write_file(fhdr, kDeviceHeader, sizeof(kDeviceHeader) - 1);
-  if (!hdr_ok || !write_file(fsrc, src.data(), src.size())) return -1;
-  unlink(fout.c_str());
-  unlink(flog.c_str());
+  static JitDir jd;
+  static uint64_t serial = 0;
+  const std::string dir = jd.get();
+  if (dir.empty() || !jd.hdr_ok) return -1;
+  const std::string stem = dir + "/k" + std::to_string(++serial);
+  const std::string fsrc = stem + ".hip", fhdr = dir + "/gjx_device.hpp", fout = stem + ".co", flog = stem + ".log";
+  if (!write_file(fsrc, src.data(), src.size())) return -1;
   const std::vector<std::string> opts = compile_options();
   std::vector<char*> argv = {const_cast<char*>(helper.c_str()), const_cast<char*>(fsrc.c_str()), const_cast<char*>(fhdr.c_str()),
                              const_cast<char*>(fout.c_str()), const_cast<char*>(flog.c_str())};
   for (const std::string& o : opts) argv.push_back(const_cast<char*>(o.c_str()));
   argv.push_back(nullptr);
+  std::vector<char*> env = child_environ();
   pid_t pid = 0;
-  if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), environ) != 0) return -1;
+  // a CHILD process (fork + exec inside posix_spawn): the caller itself is never replaced
+  if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), env.data()) != 0) {
+    unlink(fsrc.c_str());
+    return -1;
+  }
   int status = 0;
   while (waitpid(pid, &status, 0) < 0) {
     if (errno != EINTR) return -1;
   }
-  if (WIFEXITED(status) && WEXITSTATUS(status) == 0 && read_file(fout, code) && !code->empty()) return 1;
-  if (WIFSIGNALED(status)) {
+  const bool ok = WIFEXITED(status) && WEXITSTATUS(status) == 0 && read_file(fout, code) && !code->empty();
+  if (ok) {
+    routes().child++;
+  } else if (WIFEXITED(status) && WEXITSTATUS(status) == 127) {
+    // posix_spawn reports an exec failure of the child as exit status 127: the helper did not start
+    unlink(fsrc.c_str());
+    return -1;
+  } else if (WIFSIGNALED(status)) {
+    routes().child_failures++;
     std::fprintf(stderr, "[gjx] the plan compiler (gjx_jitc, pid %d) died with signal %d on a generated kernel; source kept in %s\n",
                  (int)pid, WTERMSIG(status), fsrc.c_str());
   } else {
+    routes().child_failures++;
     std::string log;
     (void)read_file(flog, &log);
     std::fprintf(stderr, "[gjx] hiprtc: plan specialisation failed to compile (child status %d)%s\n", WIFEXITED(status) ? WEXITSTATUS(status) : -1,
                  std::getenv("GJX_PLAN_JIT_VERBOSE") ? ":" : "; GJX_PLAN_JIT_VERBOSE=1 prints the compiler log");
     if (std::getenv("GJX_PLAN_JIT_VERBOSE")) std::fprintf(stderr, "%s\n", log.c_str());
   }
-  return 0;
+  unlink(fout.c_str());
+  unlink(flog.c_str());
+  if (ok || !WIFSIGNALED(status)) unlink(fsrc.c_str());  // (the source of a crashed compilation is kept for the report)
+  return ok ? 1 : 0;
 }
 
 // Compile `src` for gfx950; on success `code` holds the code object.
@@ -1147,10 +1218,19 @@ inline bool compile_to_code(const std::string& src, std::string* code) {
   if (!(inproc && inproc[0] == '1')) {
     const int r = compile_in_child(src, code);
     if (r >= 0) return r == 1;
+    routes().spawn_failures++;
+    // no silent change of route: a caller that accepts the compiler inside its own address space says so
+    const char* fb = std::getenv("GJX_JIT_INPROC_FALLBACK");
+    if (!(fb && fb[0] == '1')) {
+      std::fprintf(stderr, "[gjx] gjx_jitc (the plan compiler's child process) could not be started%s: GJX_ERR_JIT.  "
+                           "GJX_JIT_INPROC_FALLBACK=1 (or GJX_JIT_INPROC=1) compiles inside the calling process instead\n",
+                   jitc_path().empty() ? " (no executable gjx_jitc next to the library; GJX_JITC=path overrides)" : "");
+      return false;
+    }
     static bool warned = false;
     if (!warned) {
       warned = true;
-      std::fprintf(stderr, "[gjx] gjx_jitc (the plan compiler's child process) is not available next to the library: compiling in-process\n");
+      std::fprintf(stderr, "[gjx] gjx_jitc could not be started: compiling in-process (GJX_JIT_INPROC_FALLBACK=1)\n");
     }
   }
   hiprtcProgram prog;
@@ -1178,6 +1258,7 @@ inline bool compile_to_code(const std::string& src, std::string* code) {
   code->assign(cs, 0);
   hiprtcGetCode(prog, &(*code)[0]);
   hiprtcDestroyProgram(&prog);
+  routes().inproc++;
   return true;
 }
 inline bool compile_only(const std::string& src) {

@@ -304,6 +304,7 @@ PROTOTYPES = {
     "gjx_plan_compile_check": (C.c_int, [_P, C.c_int]),
     "gjx_plan_prepare": (C.c_int, [_P, _KP]),
     "gjx_jit_stats": (C.c_int, [_P, _P, _P]),
+    "gjx_jit_routes": (C.c_int, [_P, _P, _P, _P]),
     "gjx_jit_compile_source": (C.c_int, [C.c_char_p]),
     "gjx_importance_run": (
         C.c_int,
@@ -402,6 +403,17 @@ _NO_STATUS = {
 }
 
 
+# The (major, minor) of include/gjx.h these bindings were written for.  Struct layouts and the sampling spec change behind
+# unchanged entry points from minor to minor (0.7 -> 0.8: LseOut / SmcConfig / ShardedIO layouts, the Philox Normal spec), so a
+# library of another version is refused at load: with mismatched layouts it would read garbage pointers (silent corruption,
+# or a GPU fault on a shared box).
+ABI_VERSION = (0, 9)
+
+
+class AbiVersionMismatch(RuntimeError):
+    pass
+
+
 class GjxLib:
     """A loaded implementation of include/gjx.h.  `device_type` is the torch device type whose
     memory the library's "dev" pointers refer to ("cuda" for libgjx_hip.so)."""
@@ -412,6 +424,17 @@ class GjxLib:
         self.path = path
         self.device_type = device_type
         self._dll = C.CDLL(path)
+        # the version FIRST (gjx_version exists in every build): a library of another minor may lack newer symbols, and the
+        # useful error is "wrong version", not "missing symbol"
+        vfn = self._dll.gjx_version
+        vfn.restype, vfn.argtypes = PROTOTYPES["gjx_version"]
+        major, minor = C.c_int(-1), C.c_int(-1)
+        vfn(C.byref(major), C.byref(minor))
+        if (major.value, minor.value) != ABI_VERSION:
+            raise AbiVersionMismatch(
+                f"{path} implements gjx.h {major.value}.{minor.value}; these bindings are written for "
+                f"{ABI_VERSION[0]}.{ABI_VERSION[1]} (struct layouts and the sampling spec differ between minors): rebuild the "
+                "library from this tree, or run the other library with its own tree's bindings")
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(self._dll, name)  # AttributeError => ABI symbol missing: fail loudly
             fn.restype = res

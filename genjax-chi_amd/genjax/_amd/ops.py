@@ -232,6 +232,13 @@ class Ops:
         self.lib.call("gjx_jit_stats", C.byref(a), C.byref(b), C.byref(c))
         return dict(compiles=a.value, cached_modules=b.value, evictions=c.value)
 
+    def jit_routes(self) -> dict:
+        """gjx_jit_routes: which route compiled this process's generated kernels (the helper process / in-process hiprtc),
+        and how many helpers failed or could not be started."""
+        v = [C.c_uint64() for _ in range(4)]
+        self.lib.call("gjx_jit_routes", *[C.byref(x) for x in v])
+        return dict(child_compiles=v[0].value, inproc_compiles=v[1].value, child_failures=v[2].value, spawn_failures=v[3].value)
+
     def tickets(self) -> torch.Tensor:
         """The zeroed ticket words of fused log-sum-exp launches on the current stream (gjx_lse_out.tickets:
         every launch leaves them zero, launches sharing them must be stream-ordered)."""

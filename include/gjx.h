@@ -33,7 +33,7 @@ extern "C" {
 /* 0.8: the arithmetic spec of PHILOX Normal sites changed (table-driven Box-Muller): same words, same
  * pairing, normals that differ from 0.7's in the last bits.  Library and oracle of one version agree bit for bit. */
 #define GJX_VERSION_MAJOR 0
-#define GJX_VERSION_MINOR 8
+#define GJX_VERSION_MINOR 9
 
 typedef void* gjx_stream; /* hipStream_t; ignored by the oracle build */
 
@@ -294,6 +294,13 @@ int gjx_plan_compile_check(const gjx_plan* p, int impl);
  * using them, and unreferenced ones are kept for reuse up to GJX_JIT_CACHE_MAX (default 64) entries, then unloaded
  * least-recently-used first.  Each output nullable. */
 int gjx_jit_stats(uint64_t* compiles, uint64_t* cached_modules, uint64_t* evictions);
+/* Which ROUTE compiled the generated kernels of this process (r04; each output nullable): child_compiles = code objects
+ * produced by the helper process gjx_jitc (the default and only route unless the caller opts out), inproc_compiles = by
+ * hiprtc inside the calling process (GJX_JIT_INPROC=1, or GJX_JIT_INPROC_FALLBACK=1 after a helper that could not be
+ * started), child_failures = helpers that rejected a source or died on it (each a GJX_ERR_JIT for the caller),
+ * spawn_failures = helpers that could not be started.  Without the opt-in a spawn failure is GJX_ERR_JIT: the compiler
+ * never moves into the caller's address space silently.  (The oracle reports zeros.) */
+int gjx_jit_routes(uint64_t* child_compiles, uint64_t* inproc_compiles, uint64_t* child_failures, uint64_t* spawn_failures);
 /* Compile a kernel source the way generated plan kernels are compiled (gfx950, the device header available as
  * "gjx_device.hpp"), needs no GPU: GJX_OK, or GJX_ERR_JIT if the compiler rejects the source OR DIES on it.  The
  * compiler runs in a child process (csrc/gjx_jitc.cpp): an AMDGPU-backend crash on generated source — it happened once —

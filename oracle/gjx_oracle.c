@@ -482,6 +482,14 @@ int gjx_jit_stats(uint64_t* compiles, uint64_t* cached_modules, uint64_t* evicti
   return GJX_OK;
 }
 
+int gjx_jit_routes(uint64_t* child_compiles, uint64_t* inproc_compiles, uint64_t* child_failures, uint64_t* spawn_failures) {
+  if (child_compiles) *child_compiles = 0;
+  if (inproc_compiles) *inproc_compiles = 0;
+  if (child_failures) *child_failures = 0;
+  if (spawn_failures) *spawn_failures = 0;
+  return GJX_OK;
+}
+
 typedef struct { float f; int32_t i; int is_int; } site_val;
 
 static inline float sv_as_f32(const site_val* v) { return v->is_int ? (float)v->i : v->f; }

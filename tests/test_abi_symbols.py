@@ -11,6 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, "include", "gjx.h")
 HIP_LIB = os.path.join(ROOT, "genjax-chi_amd", "lib", "libgjx_hip.so")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "libgjx_oracle.so")
 
 
 def header_symbols():
@@ -71,3 +72,23 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "libgjx_oracle" not in src and "oracle/" not in src.replace("oracle/libgjx", "X"), f
+
+
+def test_a_library_of_another_version_is_refused(monkeypatch):
+    """struct layouts and the sampling spec change from minor to minor behind unchanged entry points, so
+    the bindings refuse a library whose gjx_version differs from the one they were written for — the product library and
+    the oracle alike (tools/ab_lib.sh loads other builds through GJX_HIP_LIB)."""
+    import re
+
+    from genjax._amd import abi
+
+    hdr = open(os.path.join(ROOT, "include", "gjx.h")).read()
+    major = int(re.search(r"#define GJX_VERSION_MAJOR (\d+)", hdr).group(1))
+    minor = int(re.search(r"#define GJX_VERSION_MINOR (\d+)", hdr).group(1))
+    assert abi.ABI_VERSION == (major, minor)
+    for path in (HIP_LIB, ORACLE_LIB):
+        assert abi.GjxLib(path, "cpu").version == abi.ABI_VERSION
+    monkeypatch.setattr(abi, "ABI_VERSION", (major, minor - 1))
+    for path in (HIP_LIB, ORACLE_LIB):
+        with pytest.raises(abi.AbiVersionMismatch):
+            abi.GjxLib(path, "cpu")

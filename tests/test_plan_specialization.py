@@ -230,3 +230,78 @@ def test_a_compiler_crash_is_an_error_code_not_an_abort():
     assert lib._gjx_jit_compile_source(bad) == -6
     assert lib._gjx_jit_compile_source(good) == 0  # and the compiler is still usable
     _ = C
+
+
+def test_compiler_routes_are_counted_and_a_missing_helper_is_an_error():
+    """VERDICT r03 item 3 / `gjx_jit_routes`: every code object says which route produced it.  By default that is the helper
+    process (child_compiles grows, inproc_compiles stays 0); a helper that cannot be started is GJX_ERR_JIT — never a
+    silent move of the compiler into the caller — unless the caller opts in (GJX_JIT_INPROC_FALLBACK=1).  Each case in a
+    process of its own: the helper's path is resolved once per process."""
+    import subprocess
+    import sys
+
+    child = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+from genjax._amd import abi
+from genjax._amd.ops import Ops
+ops = Ops(abi.GjxLib(sys.argv[2], "cuda"))
+good = b'#include "gjx_device.hpp"\nextern "C" __global__ void k(float* x) { x[threadIdx.x] = gjx::u2f(0x3f800000u); }\n'
+bad = b'extern "C" __global__ void k(float* x) { this is not C++ }\n'
+r0 = ops.jit_routes()
+rc = [ops.lib._gjx_jit_compile_source(good), ops.lib._gjx_jit_compile_source(bad)]
+r1 = ops.jit_routes()
+print("RESULT", rc, {k: r1[k] - r0[k] for k in r1})
+"""
+    pkg = os.path.join(ROOT, "genjax-chi_amd")
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("GJX_JIT")}
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", child, pkg, HIP_LIB], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        line = [x for x in r.stdout.splitlines() if x.startswith("RESULT")][0]
+        return eval(line[len("RESULT"):].strip().replace("] {", "], {")), r.stderr
+
+    (rc, d), _ = run()
+    assert rc == [0, -6] and d == dict(child_compiles=1, inproc_compiles=0, child_failures=1, spawn_failures=0)
+    (rc, d), err = run(GJX_JITC="/nonexistent/gjx_jitc")
+    assert rc == [-6, -6] and d == dict(child_compiles=0, inproc_compiles=0, child_failures=0, spawn_failures=2)
+    assert "could not be started" in err
+    (rc, d), err = run(GJX_JITC="/nonexistent/gjx_jitc", GJX_JIT_INPROC_FALLBACK="1")
+    assert rc == [0, -6] and d == dict(child_compiles=0, inproc_compiles=1, child_failures=0, spawn_failures=2)
+    (rc, d), _ = run(GJX_JIT_INPROC="1")
+    assert rc == [0, -6] and d == dict(child_compiles=0, inproc_compiles=1, child_failures=0, spawn_failures=0)
+
+
+def test_the_helper_leaves_no_files_behind(tmp_path):
+    """the compiler's scratch directory is private to the PROCESS (re-created after a fork), its files are named
+    per compilation and everything is removed at exit; the helper's environment carries no LD_PRELOAD / profiler variables."""
+    import subprocess
+    import sys
+
+    child = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+from genjax._amd import abi
+lib = abi.GjxLib(sys.argv[2], "cuda")
+good = b'#include "gjx_device.hpp"\nextern "C" __global__ void k(float* x) { x[threadIdx.x] = 1.0f; }\n'
+assert lib._gjx_jit_compile_source(good) == 0
+mine = sorted(os.listdir(os.environ["TMPDIR"]))
+pid = os.fork()
+if pid == 0:
+    ok = lib._gjx_jit_compile_source(good) == 0 and len(os.listdir(os.environ["TMPDIR"])) == len(mine) + 1
+    os._exit(0 if ok else 1)
+assert os.waitpid(pid, 0)[1] == 0
+assert lib._gjx_jit_compile_source(good) == 0
+print("DIRS", len(mine))
+"""
+    e = dict(os.environ, TMPDIR=str(tmp_path), LD_PRELOAD="/nonexistent/libprofiler.so")
+    r = subprocess.run([sys.executable, "-c", child, os.path.join(ROOT, "genjax-chi_amd"), HIP_LIB], env=e, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "DIRS 1" in r.stdout, r.stdout + r.stderr
+    # the parent's directory is gone at exit; the forked child left through _exit (no destructors): at most its directory stays
+    left = [d for d in os.listdir(tmp_path) if d.startswith("gjx_jit_")]
+    assert len(left) <= 1, left
+    # a preloaded library in the CALLER's environment is not handed to the helper (ld.so would complain on its stderr)
+    assert "libprofiler.so" not in r.stderr.split("DIRS")[0] or "gjx_jitc" not in r.stderr
