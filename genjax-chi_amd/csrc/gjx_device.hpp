@@ -1359,8 +1359,9 @@ GJX_DEV void store16_out(void* p, uint4 v, bool wt) {
     v4u_t x;
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
     const uint64_t a = (uint64_t)(uintptr_t)p;
-    const uint64_t first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
-                           (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
+    // (the builtin returns int: through uint32_t, or the low word's bit 31 would sign-extend into the high word)
+    const uint64_t first = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) |
+                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
     const uint64_t base = first - (1ull << 30);
     const uint32_t off = (uint32_t)(a - base);
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)base, 0, 0x7fffffff, 0x00020000);
