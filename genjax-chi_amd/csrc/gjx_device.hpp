@@ -1042,6 +1042,54 @@ GJX_HD uint64_t shr64(uint64_t v, int d) { return d >= 64 ? 0 : v >> d; }
 // ntiles = total), then e (sign-extended), R1, R2
 GJX_HD uint64_t prefix_words(uint64_t ntiles) { return ntiles + 4; }
 
+// ---- r04: the peer transport (gjx.h: gjx_smc_peers) ----------------------------------------------------------------
+// The SOURCE population of a step is distributed over `world` ranks: tile k (and its particles) lives in the arena of rank
+// k / tiles_per_rank, at the address it has in this rank's arena plus delta[owner] bytes.  The tile RECORDS (and ESS sums)
+// are read from this rank's own arena, where every rank deposited them (k_peer_signal); sub-prefixes, weights and state
+// columns are read where they live.  flags / wait_value: the step reads nothing of the source before every peer has
+// arrived (peer_wait_wave).
+constexpr int kMaxPeers = 8;
+struct PeerMap {
+  int32_t world = 0;             // 0: the source population is local (nothing below is read)
+  uint32_t tiles_per_rank = 0;
+  int64_t delta[kMaxPeers] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const uint64_t* flags = nullptr;  // this rank's arrival words [world]
+  uint32_t* error = nullptr;        // set to 1 by a wait that timed out
+  uint64_t wait_value = 0;
+  uint64_t timeout_ticks = 0;       // of s_memrealtime (100 MHz)
+};
+template <class T>
+GJX_DEV const T* peer_ptr(const T* p, int64_t delta) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + delta);
+}
+// Called by ONE whole wave: lanes q < world poll flags[q] (system-scope relaxed loads, a sleep between polls) until every
+// one is >= wait_value; then ONE system-scope acquire, so that whatever the peers published before raising their words is
+// what this CU loads from now on (the caller's workgroup barrier hands that to the other waves).  BOUNDED: after
+// timeout_ticks the wave gives up, sets *error and returns false — every wave of every workgroup reaches an exit.
+GJX_DEV bool peer_wait_wave(const PeerMap& pm) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int lane = threadIdx.x & 63;
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  bool ready = false;
+  for (;;) {
+    const uint64_t v = lane < pm.world ? __hip_atomic_load(pm.flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ~0ull;
+    ready = __ballot(v < pm.wait_value) == 0;
+    if (ready) break;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > pm.timeout_ticks) break;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  if (ready) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  } else if (lane == 0) {
+    __hip_atomic_store(pm.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  return ready;
+#else
+  (void)pm;
+  return false;
+#endif
+}
+
 // Profiling hooks of the SMC step (early exits by phase, tools/phases_smc.sh): compiled in only with -DGJX_PROFILE_HOOKS — a
 // separate build of the library; the shipped kernels carry none of them, and GJX_SMC_DEBUG_STOP / GJX_SMC_DEBUG_FIXED do
 // nothing there (a run that stops early returns GJX_OK with truncated state: not something an environment variable of a
@@ -1077,6 +1125,7 @@ struct ResampleArgs {
   int debug_stop = 0;                   // profiling builds only (-DGJX_PROFILE_HOOKS, GJX_SMC_DEBUG_STOP): leave the kernel after phase k
   int xcd_map = 1;                      // contiguous output tiles per XCD (GJX_SMC_XCD_MAP=0: plain order)
   int wt_stores = 0;                    // write-through stores of the step's output columns (store16_out)
+  PeerMap pm;                           // r04: the source population is distributed over peers (PEERS instantiations only)
 };
 
 // resample iff ESS = R1^2 / R2 < thr (thr in particles); every backend evaluates exactly these double operations
@@ -1317,6 +1366,18 @@ template <class Policy>
 GJX_DEV auto policy_stage(Policy& P, int) -> decltype(P.stage(), void()) { P.stage(); }
 template <class Policy>
 GJX_DEV void policy_stage(Policy&, long) {}
+// set_peers (policies of PEERS instantiations): where the byte offsets of the peers' arenas are (LDS) and how many tiles a
+// rank owns — the policy gathers its ancestors' state where it lives
+template <class Policy>
+GJX_DEV auto policy_set_peers(Policy& P, const int64_t* pd, uint32_t tpr, int) -> decltype(P.set_peers(pd, tpr), void()) { P.set_peers(pd, tpr); }
+template <class Policy>
+GJX_DEV void policy_set_peers(Policy&, const int64_t*, uint32_t, long) {}
+// a 4-byte element of a source column: index i of the GLOBAL population, read from its owner's arena
+template <bool PEERS, class T>
+GJX_DEV T src_load(const T* base, uint32_t i, const int64_t* pd, uint32_t tpr) {
+  if (PEERS) return *peer_ptr(base + i, pd[(i >> 10) / tpr]);
+  return base[i];
+}
 template <class Policy>
 GJX_DEV auto policy_compute_quad(Policy& P, int64_t jq, const uint32_t (&anc)[4], typename Policy::Out (&o)[4], float (&w)[4],
                                  int) -> decltype(P.compute_quad(jq, anc, o, w), void()) {
@@ -1501,7 +1562,9 @@ GJX_DEV uint64_t scan8_incl(uint64_t v) {
 
 // ADAPTIVE: the launch may be a step of an ESS-adaptive filter (A.ess_thr > 0): only then does the kernel carry the
 // decision, the ESS sums and the keep-your-particle path (the every-step filters are compiled without them).
-template <int IMPL, class Policy, bool ADAPTIVE = true>
+// PEERS (r04): the source population is distributed (A.pm): the kernel first waits for its peers, then reads remote tiles
+// where they live.  Everything it does with what it read is the code of the single-device step.
+template <int IMPL, class Policy, bool ADAPTIVE = true, bool PEERS = false>
 GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   constexpr int kW = kBlock / kWave;
   constexpr int kSrc = 8;                        // sources per lane and round of the window scan
@@ -1513,9 +1576,25 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   __shared__ int32_t sh_e[kW];
   __shared__ uint32_t sh_u[kW];
   __shared__ uint32_t sh_klo, sh_cov[2];
+  __shared__ int64_t sh_delta[PEERS ? kMaxPeers : 1];
+  __shared__ uint32_t sh_peer_ok;
   static_assert(kPer == 4, "four consecutive output slots per lane");
   uint64_t b = blockIdx.x;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  if (PEERS) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // nothing of the source population is read before every peer has arrived (bounded; a timeout ends the launch)
+    if (tid < kMaxPeers) sh_delta[tid] = tid < A.pm.world ? A.pm.delta[tid] : 0;
+    if (wv == 0) {
+      const bool ready = peer_wait_wave(A.pm);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the acquire's invalidate has completed before the barrier releases the others)
+      if (lane == 0) sh_peer_ok = ready ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!sh_peer_ok) return;
+    policy_set_peers(P, sh_delta, A.pm.tiles_per_rank, 0);
+#endif
+  }
   // this workgroup's filter: local views of the per-filter arrays, keys and results
   const uint32_t* qw_all = A.qw;
   const float* lw_all = A.lw;
@@ -1552,6 +1631,10 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     u0 = A.fb.u0[f];
     P.select_filter((uint64_t)f * A.fb.stride, A.fb.step_key[f]);
   }
+  const uint32_t tpr = PEERS ? A.pm.tiles_per_rank : 1u;
+  // where tile k of the source population lives (its owner's arena when the population is distributed)
+  auto src_subs = [&](uint64_t k) -> const TileSub* { return PEERS ? peer_ptr(subs + k, sh_delta[(uint32_t)k / tpr]) : subs + k; };
+  auto src_qw = [&](uint64_t i) -> const uint32_t* { return PEERS ? peer_ptr(qw_all + i, sh_delta[(uint32_t)(i >> 10) / tpr]) : qw_all + i; };
   GJX_DBG_STOP(A, 15);  // (profiling: the launch / dispatch floor)
   const bool adaptive = ADAPTIVE && A.ess_thr > 0.0;
   if (A.xcd_map) {
@@ -1756,7 +1839,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
       const uint64_t tbase = k_lo * kTile;
       const uint64_t cnt = tbase + kTile <= A.n ? (uint64_t)kTile : A.n - tbase;
       const int sb = lane & (kSubs - 1);  // (every 16 lanes evaluate the tile's 16 sub-prefixes: no exchange needed)
-      const uint64_t cs = subs[k_lo].sub[sb];
+      const uint64_t cs = src_subs(k_lo)->sub[sb];
       const double scale_t = comb_tile_scale(scale, shift_at(k_lo)), tb = comb_base(pre_at(k_lo), scale, u0);
       const int32_t nhi = nhi_of(k_lo);
       const bool ends_tile = (uint64_t)(sb + 1) * kSubLen >= cnt;
@@ -1775,15 +1858,16 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
       const bool live = i0 < A.n && tid < kScanLanes;
       uint32_t q[kSrc];
       if (live && i0 + kSrc <= A.n) {
-        const uint4 v0 = reinterpret_cast<const uint4*>(qw_all + i0)[0];
-        const uint4 v1 = reinterpret_cast<const uint4*>(qw_all + i0)[1];
+        const uint4* qv4 = reinterpret_cast<const uint4*>(src_qw(i0));  // (8 consecutive sources: one tile, one owner)
+        const uint4 v0 = qv4[0];
+        const uint4 v1 = qv4[1];
         q[0] = v0.x; q[1] = v0.y; q[2] = v0.z; q[3] = v0.w; q[4] = v1.x; q[5] = v1.y; q[6] = v1.z; q[7] = v1.w;
       } else {
 #pragma unroll
-        for (int r = 0; r < kSrc; ++r) q[r] = live && i0 + r < A.n ? qw_all[i0 + r] : 0u;
+        for (int r = 0; r < kSrc; ++r) q[r] = live && i0 + r < A.n ? *src_qw(i0 + r) : 0u;
       }
       const uint32_t sbk = (uint32_t)(i0 >> 6) & (kSubs - 1);
-      const uint64_t subpre = live && sbk ? subs[k].sub[sbk - 1] : 0;
+      const uint64_t subpre = live && sbk ? src_subs(k)->sub[sbk - 1] : 0;
       uint64_t own = 0;
 #pragma unroll
       for (int r = 0; r < kSrc; ++r) own += q[r];
@@ -1852,7 +1936,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         bool have = false;
         uint64_t cbase = 0;  // running sum before the block
         for (int sb = 0; sb < kSubs; ++sb) {
-          const uint64_t cs = subs[k].sub[sb];
+          const uint64_t cs = src_subs(k)->sub[sb];
           const bool ends_tile = (uint64_t)(sb + 1) * kSubLen >= cnt;
           const int32_t ns = ends_tile ? nhi : comb_in_tile((double)cs, scale_t, tb, nhi, n_out);
           if (!have && (int64_t)ns > j) { blk = (uint32_t)sb; have = true; }
@@ -1864,7 +1948,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         bool done = false;
         for (uint32_t i = 0; i < (uint32_t)kSubLen; ++i) {
           const uint64_t li_ = (uint64_t)blk * kSubLen + i;
-          const uint32_t qv = li_ < cnt ? qw_all[tbase + li_] : 0u;
+          const uint32_t qv = li_ < cnt ? *src_qw(tbase + li_) : 0u;
           c += (double)qv;
           const bool last = li_ + 1 >= cnt;
           const int32_t ni = last ? nhi : comb_in_tile(c, scale_t, tb, nhi, n_out);

@@ -595,10 +595,46 @@ struct AncestorOnly {
 
 // ONE launch per SMC step: resample (from the previous step's records and in-tile CDFs) + gather + propagate + weight
 // + this step's CDFs and records (resample_body, gjx_device.hpp).
+template <class Policy>
+constexpr auto policy_peers(int) -> decltype(Policy::kPeers) { return Policy::kPeers; }
+template <class Policy>
+constexpr bool policy_peers(long) { return false; }
 template <int IMPL, class Policy, bool ADAPTIVE = false>
 __global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P) {
-  resample_body<IMPL, Policy, ADAPTIVE>(A, P);
+  resample_body<IMPL, Policy, ADAPTIVE, policy_peers<Policy>(0)>(A, P);
 }
+
+// ---- r04: the two small launches of the peer transport (gjx.h: gjx_smc_peer_signal / gjx_smc_peer_wait) ------------------
+// Workgroup o serves rank o: it copies this rank's tile records (and ESS sums) into rank o's arena, every copying thread
+// makes its stores visible at system scope, and then one thread raises this rank's arrival word in rank o's flags.  The
+// launch runs after the step's launch on the same stream, so what the step wrote to this rank's own arena (weights, state,
+// sub-prefixes) is complete in memory when a peer sees the word.
+__global__ __launch_bounds__(kBlock) void k_peer_signal(PeerMap pm, int32_t rank, const TileRec* recs, const TileEss* ess,
+                                                        uint64_t first_tile, uint64_t n_tiles, uint64_t value) {
+  const int o = (int)blockIdx.x;
+  if (o != rank && recs) {
+    TileRec* dst = const_cast<TileRec*>(peer_ptr(recs, pm.delta[o]));
+    for (uint64_t k = threadIdx.x; k < n_tiles; k += kBlock) {
+      const uint4 v = *reinterpret_cast<const uint4*>(recs + first_tile + k);
+      *reinterpret_cast<uint4*>(dst + first_tile + k) = v;
+    }
+    if (ess) {
+      TileEss* de = const_cast<TileEss*>(peer_ptr(ess, pm.delta[o]));
+      for (uint64_t k = threadIdx.x; k < n_tiles; k += kBlock) {
+        const uint4 v = *reinterpret_cast<const uint4*>(ess + first_tile + k);
+        *reinterpret_cast<uint4*>(de + first_tile + k) = v;
+      }
+    }
+  }
+  __threadfence_system();  // release: this thread's copies, and everything earlier launches left in this XCD's L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t* word = const_cast<uint64_t*>(peer_ptr(pm.flags, pm.delta[o])) + rank;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the flag must not overtake the write-back: MI355X guide, compiler hazard)
+    __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__global__ __launch_bounds__(kWave) void k_peer_wait(PeerMap pm) { (void)peer_wait_wave(pm); }
 
 // Per-tile fixed-point mass of log-weights under their GLOBAL maximum (the multinomial / single-draw
 // paths, which materialise a global CDF).  The max is reduced redundantly by every block from the per-tile maxima.
@@ -828,9 +864,10 @@ __global__ __launch_bounds__(kBlock) void k_gather(const int32_t* anc, uint64_t 
 // ------------------------------------------------------------------------------------------------
 // Fused bootstrap-SMC policies: propagate + weight the four consecutive output slots of a lane.
 // ------------------------------------------------------------------------------------------------
-template <int IMPL>
+template <int IMPL, bool PEERS = false>
 struct LgssmPolicy {
   static constexpr bool kEmit = true;
+  static constexpr bool kPeers = PEERS;
   const float* prev_state;  // [n] (global) previous-step particles
   float* state_out;         // [n_local]
   int32_t* anc_out;         // nullable [n_local]
@@ -838,13 +875,16 @@ struct LgssmPolicy {
   float a, q, y, rs, lognorm;
   float z[kPer];            // the quad's standard normals (prefetch: they do not depend on the ancestors)
   int wt = 0;               // write-through stores of the state / ancestor columns (store16_out)
+  const int64_t* pd = nullptr;  // PEERS: byte offsets of the peers' arenas (LDS), tiles per rank (set_peers)
+  uint32_t tpr = 1;
+  GJX_DEV void set_peers(const int64_t* d, uint32_t t) { pd = d; tpr = t; }
   GJX_DEV void select_filter(uint64_t off, Key k) {
     prev_state += off; state_out += off;
     if (anc_out) anc_out += off;
     step_key = k;
   }
   GJX_DEV void prefetch(int64_t jq) { smc_quad_normals<IMPL>(step_key, (uint64_t)jq >> 2, z); }
-  GJX_DEV float source(uint32_t anc) const { return prev_state[anc]; }
+  GJX_DEV float source(uint32_t anc) const { return src_load<PEERS>(prev_state, anc, pd, tpr); }
   struct Out {
     float x;
   };
@@ -891,9 +931,10 @@ GJX_DEV uint32_t hmm_alias_draw(const uint32_t* row, int32_t K, uint32_t bits) {
   return hmm_alias_pick(row[col], col, (uint32_t)t >> 8);
 }
 
-template <int IMPL>
+template <int IMPL, bool PEERS = false>
 struct HmmPolicy {
   static constexpr bool kEmit = true;
+  static constexpr bool kPeers = PEERS;
   const int32_t* prev_state;
   int32_t* state_out;
   int32_t* anc_out;
@@ -905,6 +946,9 @@ struct HmmPolicy {
   float oc;                       // obs_logp[tid, y] on its way to LDS
   float* ocol;                    // LDS: column y of the observation table (one entry per state)
   int wt = 0;                     // write-through stores of the state / ancestor columns (store16_out)
+  const int64_t* pd = nullptr;    // PEERS: byte offsets of the peers' arenas (LDS), tiles per rank (set_peers)
+  uint32_t tpr = 1;
+  GJX_DEV void set_peers(const int64_t* d, uint32_t t) { pd = d; tpr = t; }
   GJX_DEV void select_filter(uint64_t off, Key k) {
     prev_state += off; state_out += off;
     if (anc_out) anc_out += off;
@@ -926,7 +970,7 @@ struct HmmPolicy {
     ocol = ocol_tile;
     if ((int)threadIdx.x < K) ocol_tile[threadIdx.x] = oc;
   }
-  GJX_DEV int32_t source(uint32_t anc) const { return prev_state[anc]; }
+  GJX_DEV int32_t source(uint32_t anc) const { return src_load<PEERS>(prev_state, anc, pd, tpr); }
   struct Out {
     int32_t z;
   };
@@ -2428,6 +2472,28 @@ static bool pop_ok(const gjx_smc_pop* p, int n_state, bool adaptive, bool readin
   return true;
 }
 
+// ---- the peer transport (gjx.h: gjx_smc_peers) ---------------------------------------------------------------------------
+static bool peers_desc_ok(const gjx_smc_peers* p) {
+  return p && p->world >= 2 && p->world <= GJX_MAX_PEERS && p->rank >= 0 && p->rank < p->world && p->flags && p->error &&
+         p->delta[p->rank] == 0;
+}
+static bool peers_ok(const gjx_smc_config* c) {
+  const gjx_smc_peers* p = c->peers;
+  if (!peers_desc_ok(p) || c->n_filters > 1) return false;
+  const uint64_t w = (uint64_t)p->world;
+  return c->n_total % (w * kTile) == 0 && c->n_local == c->n_total / w && c->first_slot == (uint64_t)p->rank * c->n_local;
+}
+static PeerMap peer_map_of(const gjx_smc_peers* p, uint64_t n_total) {
+  PeerMap pm;
+  pm.world = p->world;
+  pm.tiles_per_rank = n_total ? (uint32_t)(n_total / (uint64_t)p->world / kTile) : 1u;
+  for (int o = 0; o < p->world; ++o) pm.delta[o] = p->delta[o];
+  pm.flags = p->flags;
+  pm.error = p->error;
+  pm.wait_value = p->wait_value;
+  pm.timeout_ticks = (uint64_t)(p->timeout_ms ? p->timeout_ms : 10000u) * 100000ull;  // s_memrealtime: 100 MHz
+  return pm;
+}
 // The arguments of a step's resample launch; for populations beyond kMaxLdsTiles the records of `prev` are merged
 // into prev->prefix first (one small launch).
 static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop* prev, const gjx_smc_pop* out,
@@ -2462,9 +2528,16 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
   // The merged prefix by ONE small launch (a workgroup per filter) instead of in every workgroup: required beyond
   // kMaxLdsTiles, and worth it from a few filters per launch (the whole-run drivers provide prev->prefix then), where its
   // ~4 us are shared by all filters while every one of the F x tiles workgroups saves the merge of its filter's records.
+  if (cfg->peers) {
+    if (!peers_ok(cfg) || ctx.fb.n_filters > 1) return GJX_ERR_INVALID;
+    A.pm = peer_map_of(cfg->peers, cfg->n_total);
+  }
   if (A.ntiles > (uint64_t)kMaxLdsTiles || (ctx.fb.n_filters > 1 && prev->prefix)) {
     if (ctx.fb.n_filters > 1 && A.ntiles > (uint64_t)kMaxLdsTiles) return GJX_ERR_UNSUPPORTED;
     const unsigned nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
+    // (peers: the records in this rank's arena are complete only once every peer has arrived — the merge launch reads them
+    // before the step's own wait, so a one-workgroup wait launch goes first)
+    if (cfg->peers) k_peer_wait<<<1, kWave, 0, S(s)>>>(A.pm);
     k_scan_records<<<nf, kBlock, 0, S(s)>>>(A.recs, A.ess, A.ntiles, prev->prefix, nullptr, nullptr, 0);
     A.prefix = prev->prefix;
   }
@@ -2493,17 +2566,22 @@ static int lgssm_step(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, fl
   ResampleArgs A;
   int rc = smc_resample_args(cfg, t, prev, out, prev_e_out, prev_q_out, ctx, s, &A);
   if (rc) return rc;
-  if (cfg->impl == 0) {
-    LgssmPolicy<0> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}};
-    P.wt = A.wt_stores;
-    if (ad) k_resample<0, LgssmPolicy<0>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
-    else k_resample<0, LgssmPolicy<0>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
+  const unsigned grid = ntl * nf;
+#define GJX_LAUNCH_LGSSM(I, PEERS_)                                                                                                        \
+  do {                                                                                                                                     \
+    LgssmPolicy<I, PEERS_> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}}; \
+    P.wt = A.wt_stores;                                                                                                                    \
+    if (ad) k_resample<I, LgssmPolicy<I, PEERS_>, true><<<grid, kBlock, 0, S(s)>>>(A, P);                                                  \
+    else k_resample<I, LgssmPolicy<I, PEERS_>, false><<<grid, kBlock, 0, S(s)>>>(A, P);                                                    \
+  } while (0)
+  if (cfg->peers) {
+    if (cfg->impl == 0) GJX_LAUNCH_LGSSM(0, true);
+    else GJX_LAUNCH_LGSSM(1, true);
   } else {
-    LgssmPolicy<1> P{(const float*)prev->state[0], (float*)out->state[0], ancestors_out, sk, mdl->a, mdl->q, y_t, rs, lognorm, {}};
-    P.wt = A.wt_stores;
-    if (ad) k_resample<1, LgssmPolicy<1>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
-    else k_resample<1, LgssmPolicy<1>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
+    if (cfg->impl == 0) GJX_LAUNCH_LGSSM(0, false);
+    else GJX_LAUNCH_LGSSM(1, false);
   }
+#undef GJX_LAUNCH_LGSSM
   return launch_status();
 }
 
@@ -2526,17 +2604,22 @@ static int hmm_step(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_
   ResampleArgs A;
   int rc = smc_resample_args(cfg, t, prev, out, prev_e_out, prev_q_out, ctx, s, &A);
   if (rc) return rc;
-  if (cfg->impl == 0) {
-    HmmPolicy<0> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr};
-    P.wt = A.wt_stores;
-    if (ad) k_resample<0, HmmPolicy<0>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
-    else k_resample<0, HmmPolicy<0>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
+  const unsigned grid = ntl * nf;
+#define GJX_LAUNCH_HMM(I, PEERS_)                                                                                                          \
+  do {                                                                                                                                     \
+    HmmPolicy<I, PEERS_> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr}; \
+    P.wt = A.wt_stores;                                                                                                                    \
+    if (ad) k_resample<I, HmmPolicy<I, PEERS_>, true><<<grid, kBlock, 0, S(s)>>>(A, P);                                                    \
+    else k_resample<I, HmmPolicy<I, PEERS_>, false><<<grid, kBlock, 0, S(s)>>>(A, P);                                                      \
+  } while (0)
+  if (cfg->peers) {
+    if (cfg->impl == 0) GJX_LAUNCH_HMM(0, true);
+    else GJX_LAUNCH_HMM(1, true);
   } else {
-    HmmPolicy<1> P{(const int32_t*)prev->state[0], (int32_t*)out->state[0], ancestors_out, sk, trans_cdf, obs_logp, mdl->n_states, y_t, {}, {}, 0.0f, nullptr};
-    P.wt = A.wt_stores;
-    if (ad) k_resample<1, HmmPolicy<1>, true><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
-    else k_resample<1, HmmPolicy<1>, false><<<ntl * nf, kBlock, 0, S(s)>>>(A, P);
+    if (cfg->impl == 0) GJX_LAUNCH_HMM(0, false);
+    else GJX_LAUNCH_HMM(1, false);
   }
+#undef GJX_LAUNCH_HMM
   return launch_status();
 }
 
@@ -2556,6 +2639,46 @@ int gjx_smc_hmm_step(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32
 int gjx_smc_finish(const gjx_smc_config* cfg, const gjx_tile_rec* recs, int32_t* e_out, uint64_t* q_out, gjx_stream s) {
   if (!cfg_ok(cfg) || !recs || cfg->n_filters > 1) return GJX_ERR_INVALID;
   k_scan_records<<<1, kBlock, 0, S(s)>>>(reinterpret_cast<const TileRec*>(recs), nullptr, ntiles_of(cfg->n_total), nullptr, e_out, q_out, 0);
+  return launch_status();
+}
+// One message per rank and step for ESS-adaptive filters on a collective transport: [records of the rank's tiles | their ESS
+// sums].  pack: this rank's block -> its slot; unpack: every other rank's slot -> the dense arrays.
+__global__ __launch_bounds__(kBlock) void k_records_pack(TileRec* recs, TileEss* ess, uint4* stage, uint64_t tl, int world, int rank,
+                                                         int unpack) {
+  const uint64_t per = 2 * tl;  // 16-byte words per slot
+  for (uint64_t i = blockIdx.x * (uint64_t)kBlock + threadIdx.x; i < per * (uint64_t)world; i += (uint64_t)gridDim.x * kBlock) {
+    const int r = (int)(i / per);
+    const uint64_t w = i - (uint64_t)r * per;
+    if ((r == rank) == (unpack != 0)) continue;  // pack: own slot only; unpack: the others
+    uint4* arr = w < tl ? reinterpret_cast<uint4*>(recs) + (uint64_t)r * tl + w : reinterpret_cast<uint4*>(ess) + (uint64_t)r * tl + (w - tl);
+    if (unpack) *arr = stage[i];
+    else stage[i] = *arr;
+  }
+}
+int gjx_smc_records_pack(const gjx_smc_config* cfg, int world, int unpack, gjx_tile_rec* recs, gjx_tile_ess* ess, void* stage,
+                         gjx_stream s) {
+  if (!cfg_ok(cfg) || !recs || !ess || !stage || world < 1 || world > 64 || cfg->n_local == 0 || cfg->n_local % kTile ||
+      cfg->n_total != cfg->n_local * (uint64_t)world || cfg->first_slot % cfg->n_local)
+    return GJX_ERR_INVALID;
+  const uint64_t tl = cfg->n_local / kTile;
+  const uint64_t words = 2 * tl * (uint64_t)world;
+  const unsigned grid = (unsigned)((words + kBlock - 1) / kBlock < 64 ? (words + kBlock - 1) / kBlock : 64);
+  k_records_pack<<<grid, kBlock, 0, S(s)>>>(reinterpret_cast<TileRec*>(recs), reinterpret_cast<TileEss*>(ess), reinterpret_cast<uint4*>(stage), tl,
+                                            world, (int)(cfg->first_slot / cfg->n_local), unpack);
+  return launch_status();
+}
+int gjx_smc_peer_signal(const gjx_smc_peers* peers, const gjx_tile_rec* recs, const gjx_tile_ess* ess, uint64_t first_tile,
+                        uint64_t n_tiles, uint64_t value, gjx_stream s) {
+  if (!peers_desc_ok(peers) || (n_tiles > 0 && !recs) || ((((uintptr_t)recs | (uintptr_t)ess) & 15) != 0)) return GJX_ERR_INVALID;
+  k_peer_signal<<<(unsigned)peers->world, kBlock, 0, S(s)>>>(peer_map_of(peers, 0), peers->rank, reinterpret_cast<const TileRec*>(recs),
+                                                             reinterpret_cast<const TileEss*>(ess), first_tile, n_tiles, value);
+  return launch_status();
+}
+int gjx_smc_peer_wait(const gjx_smc_peers* peers, uint64_t value, gjx_stream s) {
+  if (!peers_desc_ok(peers)) return GJX_ERR_INVALID;
+  PeerMap pm = peer_map_of(peers, 0);
+  pm.wait_value = value;
+  k_peer_wait<<<1, kWave, 0, S(s)>>>(pm);
   return launch_status();
 }
 int gjx_smc_source_ranges(const gjx_smc_config* cfg, const gjx_tile_rec* recs, const gjx_tile_ess* ess, int world, int64_t ticket,
@@ -2795,6 +2918,7 @@ struct gjx_smc_plan {
   CSite init[GJX_MAX_SITES], step[GJX_MAX_SITES];
   CArg init_state[GJX_SMC_MAX_STATE], next_state[GJX_SMC_MAX_STATE];
   gjx_jit::CompiledSmc jit[2];
+  gjx_jit::CompiledSmc jit_peers[2];  // r04: the step kernels of the peer transport (compiled on first use)
   std::vector<void*> dev_owned;  // per-row tables of categorical sites
   std::mutex mu;
   ExprStore init_expr, step_expr;  // GJX_ARG_EXPR programs of the two tables
@@ -2850,6 +2974,7 @@ int gjx_smc_plan_create_scoped(const gjx_smc_model* m, const gjx_scope* init_sco
 int gjx_smc_plan_destroy(gjx_smc_plan* p) {
   if (!p) return GJX_OK;
   for (auto& c : p->jit) gjx_jit::release_smc(&c);  // compiled modules are owned by the process-wide (bounded) cache
+  for (auto& c : p->jit_peers) gjx_jit::release_smc(&c);
   free_owned(p->dev_owned);
   if (p->dev_init) (void)hipFree(p->dev_init);
   if (p->dev_step) (void)hipFree(p->dev_step);
@@ -2878,9 +3003,10 @@ int gjx_jit_routes(uint64_t* child_compiles, uint64_t* inproc_compiles, uint64_t
   return GJX_OK;
 }
 
-static std::string smc_plan_source(const gjx_smc_plan* plan, int impl, PlanTables* tabs = nullptr) {
+static std::string smc_plan_source(const gjx_smc_plan* plan, int impl, PlanTables* tabs = nullptr, bool peers = false) {
   gjx_jit::TableScope ts;
   gjx_jit::GenSmc<CSite, CArg> g;
+  g.peers = peers;
   g.impl = impl; g.init_sites = plan->init; g.n_init = plan->n_init; g.step_sites = plan->step;
   g.n_step = plan->n_step; g.init_state = plan->init_state; g.next_state = plan->next_state; g.n_state = plan->n_state;
   g.sc_init = plan->init_scopes.n_scopes > 0 ? &plan->init_scopes : nullptr;
@@ -2910,15 +3036,17 @@ static int smc_plan_interp_tables(gjx_smc_plan* plan) {
   plan->dev_init = di; plan->dev_step = ds;
   return GJX_OK;
 }
-static gjx_jit::CompiledSmc* smc_plan_compiled(gjx_smc_plan* plan, int impl) {
+static gjx_jit::CompiledSmc* smc_plan_compiled(gjx_smc_plan* plan, int impl, bool peers = false) {
   if (!gjx_jit::enabled()) return nullptr;  // (GJX_PLAN_JIT=0: the table-walking policy, smc_plan_route)
-  gjx_jit::CompiledSmc& c = plan->jit[impl];
+  gjx_jit::CompiledSmc& c = peers ? plan->jit_peers[impl] : plan->jit[impl];
   if (c.state == 0) {
     std::lock_guard<std::mutex> lock(plan->mu);
     if (c.state == 0) {
-      cat_tables_prepare(plan->init, plan->n_init, &plan->dev_owned);
-      cat_tables_prepare(plan->step, plan->n_step, &plan->dev_owned);
-      c.state = gjx_jit::compile_smc(smc_plan_source(plan, impl, &c.tabs), &c) ? 1 : -1;
+      if (plan->jit[impl].state == 0 && plan->jit_peers[impl].state == 0) {  // (the derived tables: once per plan)
+        cat_tables_prepare(plan->init, plan->n_init, &plan->dev_owned);
+        cat_tables_prepare(plan->step, plan->n_step, &plan->dev_owned);
+      }
+      c.state = gjx_jit::compile_smc(smc_plan_source(plan, impl, &c.tabs, peers), &c) ? 1 : -1;
     }
   }
   return c.state == 1 ? &c : nullptr;
@@ -2929,9 +3057,10 @@ static gjx_jit::CompiledSmc* smc_plan_compiled(gjx_smc_plan* plan, int impl) {
 // Which route a generated filter takes: its compiled kernels; or, with the compiler switched off (GJX_PLAN_JIT=0) or failed
 // and GJX_PLAN_JIT_FALLBACK=1, the table-walking policy (k_smc_interp_*: same bits, several times slower) — unless the
 // model holds programs (compiled, never interpreted).  *c_out = nullptr means the interpreter.
-static int smc_plan_route(gjx_smc_plan* plan, int impl, gjx_jit::CompiledSmc** c_out) {
-  *c_out = smc_plan_compiled(plan, impl);
+static int smc_plan_route(gjx_smc_plan* plan, int impl, gjx_jit::CompiledSmc** c_out, bool peers = false) {
+  *c_out = smc_plan_compiled(plan, impl, peers);
   if (*c_out) return GJX_OK;
+  if (peers) return gjx_jit::enabled() ? GJX_ERR_JIT : GJX_ERR_UNSUPPORTED;  // (the table-walking policy has no peer form)
   const bool off = !gjx_jit::enabled();
   if (!off && !jit_fallback_allowed()) return GJX_ERR_JIT;  // loud: never a silent slower route
   if (plan->has_expr || plan->init_scopes.n_scopes > 0 || plan->step_scopes.n_scopes > 0) return off ? GJX_ERR_UNSUPPORTED : GJX_ERR_JIT;
@@ -2999,7 +3128,8 @@ int gjx_smc_plan_step(const gjx_smc_config* cfg, gjx_smc_plan* plan, int t, cons
       cfg->n_filters > 1)
     return GJX_ERR_INVALID;
   gjx_jit::CompiledSmc* c = nullptr;
-  const int route = smc_plan_route(plan, cfg->impl, &c);
+  // (the peer transport: steps t >= 1 run the peer form of the generated kernels; step 0 reads no source population)
+  const int route = smc_plan_route(plan, cfg->impl, &c, cfg->peers != nullptr && t > 0);
   if (route) return route;
   return smc_plan_step(cfg, plan, c, t, obs_t, prev, out, prev_e_out, prev_q_out, ancestors_out, s, StepCtx{});
 }
@@ -3203,17 +3333,22 @@ struct RcclTransport : gjx_sharded::Transport {
   int allgather(void* full, size_t bytes, gjx_stream s) override {  // in place: the send buffer is this rank's block
     return st(Rccl::get().AllGather((const char*)full + (size_t)rank * bytes, full, bytes, ncclUint8, comm, S(s)));
   }
-  int exchange(void* const* cols, const size_t* elems, int n_cols, const gjx_sharded::Seg* sends, int ns,
+  int exchange(void* const* cols, const size_t* elems, const size_t* units, int n_cols, const gjx_sharded::Seg* sends, int ns,
                const gjx_sharded::Seg* recvs, int nr, gjx_stream s) override {
     if (!ns && !nr) return GJX_OK;
     Rccl& R = Rccl::get();
+    using gjx_sharded::seg_off;
     ncclResult_t r = R.GroupStart();
     for (int i = 0; i < ns && r == ncclSuccess; ++i)
-      for (int c = 0; c < n_cols && r == ncclSuccess; ++c)
-        r = R.Send((const char*)cols[c] + sends[i].a * elems[c], (size_t)(sends[i].b - sends[i].a) * elems[c], ncclUint8, sends[i].peer, comm, S(s));
+      for (int c = 0; c < n_cols && r == ncclSuccess; ++c) {
+        const size_t a = seg_off(sends[i].a, elems[c], units[c]), b = seg_off(sends[i].b, elems[c], units[c]);
+        r = R.Send((const char*)cols[c] + a, b - a, ncclUint8, sends[i].peer, comm, S(s));
+      }
     for (int i = 0; i < nr && r == ncclSuccess; ++i)
-      for (int c = 0; c < n_cols && r == ncclSuccess; ++c)
-        r = R.Recv((char*)cols[c] + recvs[i].a * elems[c], (size_t)(recvs[i].b - recvs[i].a) * elems[c], ncclUint8, recvs[i].peer, comm, S(s));
+      for (int c = 0; c < n_cols && r == ncclSuccess; ++c) {
+        const size_t a = seg_off(recvs[i].a, elems[c], units[c]), b = seg_off(recvs[i].b, elems[c], units[c]);
+        r = R.Recv((char*)cols[c] + a, b - a, ncclUint8, recvs[i].peer, comm, S(s));
+      }
     const ncclResult_t e = R.GroupEnd();
     return st(r != ncclSuccess ? r : e);
   }
@@ -3288,6 +3423,18 @@ int gjx_comm_init_callbacks(int rank, int world, gjx_allgather_fn allgather, gjx
   gjx_comm* c = new (std::nothrow) gjx_comm;
   if (!c) return GJX_ERR_LAUNCH;
   const int rc = gjx_sharded::comm_init_callbacks(rank, world, allgather, exchange, stream_sync, user, &c->t);
+  if (rc) {
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return GJX_OK;
+}
+int gjx_comm_init_peers(const gjx_smc_peers* peers, gjx_comm_group* group, int wait_launch, gjx_comm** out) {
+  if (!out) return GJX_ERR_INVALID;
+  gjx_comm* c = new (std::nothrow) gjx_comm;
+  if (!c) return GJX_ERR_LAUNCH;
+  const int rc = gjx_sharded::comm_init_peers(peers, group ? &group->g : nullptr, wait_launch, &c->t);
   if (rc) {
     delete c;
     return rc;

@@ -861,6 +861,7 @@ struct GenSmc {
   int n_state;
   const ScopeInfo* sc_init = nullptr;  // nested calls inside init / step (null: flat bodies)
   const ScopeInfo* sc_step = nullptr;
+  bool peers = false;  // r04: the step kernels of the peer transport (the source population lives in the peers' arenas)
 
   // PHILOX: the four consecutive slots jq .. jq+3 of a lane (jq a multiple of 4) walked together.  One-word draw
   // number f of the quad is ONE block, PH(ctr = (g_lo, g_hi, f, 'Q'), key = step key), g = jq / 4, slot u taking
@@ -908,7 +909,7 @@ struct GenSmc {
     o << "    const uint64_t g = (uint64_t)jq >> 2;\n";
     for (int u = 0; u < 4; ++u) {
       if (step)
-        for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << sf[u] << " = a.prev_state[" << k << "][src[" << u << "]];\n";
+        for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << sf[u] << " = src_load<kPeers>(a.prev_state[" << k << "], src[" << u << "], pd, tpr);\n";
       if (em[u].needs_stream_key() || sc) o << "    const Key pkey" << sf[u] << " = slot_key<1>(a.step_key, (uint64_t)jq + " << u << "u);\n";
       o << "    float w" << sf[u] << " = 0.0f, sc" << sf[u] << " = 0.0f;\n";
       em[u].emit_scope_keys();
@@ -962,13 +963,15 @@ struct GenSmc {
     es.sc = sc_step;
     ei.sc = sc_init;
     // ---- step policy
-    o << "struct GenPolicy {\n  static constexpr bool kEmit = true;\n  PlanPolicyArgs a;\n  PlanTables tabs;\n";
+    o << "struct GenPolicy {\n  static constexpr bool kEmit = true;\n  static constexpr bool kPeers = " << (peers ? "true" : "false") << ";\n  PlanPolicyArgs a;\n  PlanTables tabs;\n";
+    o << "  const int64_t* pd = nullptr;\n  uint32_t tpr = 1;\n";
+    o << "  __device__ __forceinline__ void set_peers(const int64_t* d, uint32_t t) { pd = d; tpr = t; }\n";
     o << "  struct Out { float s[" << D << "]; };\n";
     o << "  __device__ __forceinline__ void select_filter(uint64_t off, Key k) {\n";
     o << "    for (int c = 0; c < " << D << "; ++c) { a.prev_state[c] += off; a.state_out[c] += off; }\n";
     o << "    if (a.anc_out) a.anc_out += off; a.step_key = k;\n  }\n";
     o << "  __device__ __forceinline__ float compute(int64_t j, uint32_t src_global, Out& out) const {\n";
-    for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << " = a.prev_state[" << k << "][src_global];\n";
+    for (int k = 0; k < n_state; ++k) o << "    const float st_" << k << " = src_load<kPeers>(a.prev_state[" << k << "], src_global, pd, tpr);\n";
     if (es.needs_pk() || sc_step) o << "    const Key pkey = slot_key<" << I << ">(a.step_key, (uint64_t)j);\n";
     o << "    float w = 0.0f, sc = 0.0f;\n";
     es.run();
@@ -990,9 +993,9 @@ struct GenSmc {
     o << "    for (int u = 0; u < 4; ++u) if (ok[u]) store(jq + u, out_lo, anc[u], o[u]);\n  }\n};\n";
     // two instantiations, as for the hand-written filters: the every-step form carries no ESS decision / keep-your-particle path
     o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_step_kernel(ResampleArgs A, PlanPolicyArgs PA, PlanTables T) {\n";
-    o << "  GenPolicy P;\n  P.a = PA;\n  P.tabs = T;\n  resample_body<" << I << ", GenPolicy, false>(A, P);\n}\n";
+    o << "  GenPolicy P;\n  P.a = PA;\n  P.tabs = T;\n  resample_body<" << I << ", GenPolicy, false, GenPolicy::kPeers>(A, P);\n}\n";
     o << "extern \"C\" __global__ __launch_bounds__(256) void gjx_smc_step_kernel_adaptive(ResampleArgs A, PlanPolicyArgs PA, PlanTables T) {\n";
-    o << "  GenPolicy P;\n  P.a = PA;\n  P.tabs = T;\n  resample_body<" << I << ", GenPolicy, true>(A, P);\n}\n";
+    o << "  GenPolicy P;\n  P.a = PA;\n  P.tabs = T;\n  resample_body<" << I << ", GenPolicy, true, GenPolicy::kPeers>(A, P);\n}\n";
     // ---- init kernel: one workgroup per LOCAL tile, like k_lgssm_init
     if (impl == 1) {
       o << "struct GenInitOut { float s[" << D << "]; };\n";

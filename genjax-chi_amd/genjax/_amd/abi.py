@@ -215,6 +215,7 @@ class ShardedIO(C.Structure):
         ("ranges", C.c_void_p),
         ("shuffle", C.c_int32),
         ("received", C.POINTER(C.c_uint64)),
+        ("stage", C.c_void_p),            # r04: dev [world, tiles_local, 32 B]: adaptive filters on a collective transport
     ]
 
 
@@ -224,8 +225,8 @@ class Seg(C.Structure):
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
-EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int32, C.POINTER(Seg),
-                          C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32,
+                          C.POINTER(Seg), C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p)
 STREAM_SYNC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 
@@ -251,6 +252,24 @@ class Hmm(C.Structure):
     ]
 
 
+MAX_PEERS = 8
+
+
+class SmcPeers(C.Structure):
+    """gjx_smc_peers: the peer transport of a sharded filter (arenas of identical layout; delta[o] = byte distance from this
+    rank's arena to rank o's as mapped in this process; flags / error inside the arena)."""
+    _fields_ = [
+        ("world", C.c_int32),
+        ("rank", C.c_int32),
+        ("delta", C.c_int64 * MAX_PEERS),
+        ("flags", C.c_void_p),
+        ("error", C.c_void_p),
+        ("wait_value", C.c_uint64),
+        ("timeout_ms", C.c_uint32),
+        ("pad", C.c_int32),
+    ]
+
+
 class SmcConfig(C.Structure):
     _fields_ = [
         ("impl", C.c_int32),
@@ -264,6 +283,7 @@ class SmcConfig(C.Structure):
         ("filter_stride", C.c_uint64),
         ("ess_threshold", C.c_float),     # 0 / >= 1: resample at every step; (0, 1): only when ESS < threshold * N
         ("resampled_out", C.c_void_p),    # dev int32[T] / [F, T]: 1 where a step began with a resampling
+        ("peers", C.POINTER(SmcPeers)),   # r04, nullable: the source population lives in the peers' arenas
     ]
 
 
@@ -386,6 +406,10 @@ PROTOTYPES = {
     "gjx_tile_weights": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P]),
     "gjx_tile_merge": (C.c_int, [_P, C.c_uint64, _P, _P, _P]),
     "gjx_comm_init_callbacks": (C.c_int, [C.c_int, C.c_int, ALLGATHER_FN, EXCHANGE_FN, STREAM_SYNC_FN, _P, C.POINTER(_P)]),
+    "gjx_comm_init_peers": (C.c_int, [C.POINTER(SmcPeers), _P, C.c_int, C.POINTER(_P)]),
+    "gjx_smc_peer_signal": (C.c_int, [C.POINTER(SmcPeers), _P, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
+    "gjx_smc_peer_wait": (C.c_int, [C.POINTER(SmcPeers), C.c_uint64, _P]),
+    "gjx_smc_records_pack": (C.c_int, [C.POINTER(SmcConfig), C.c_int, C.c_int, _P, _P, _P, _P]),
     "gjx_hmm_alias_words": (C.c_uint64, [C.c_int32]),
     "gjx_hmm_prepare": (C.c_int, [C.POINTER(Hmm), _P, _P, _P]),
 }

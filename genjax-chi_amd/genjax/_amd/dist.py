@@ -196,12 +196,14 @@ class TorchComm:
             local = local.clone()  # gloo: keep input and output distinct
         _dist().all_gather_into_tensor(full, local)
 
-    def exchange(self, cols, sends, recvs):
-        """Grouped point-to-point transfers of global slices of `cols`: `sends` / `recvs` = [(peer, a, b)].  A slice
+    def exchange(self, cols, sends, recvs, units=None):
+        """Grouped point-to-point transfers of global slices of `cols`: `sends` / `recvs` = [(peer, a, b)] in PARTICLES; column
+        c holds one row per units[c] particles (1: per-particle columns; the tile size: the per-tile sub-prefixes).  A slice
         keeps its global position on both sides, so nothing is packed or unpacked."""
         dist = _dist()
-        p2p = [dist.P2POp(dist.isend, c[a:b], peer) for peer, a, b in sends for c in cols]
-        p2p += [dist.P2POp(dist.irecv, c[a:b], peer) for peer, a, b in recvs for c in cols]
+        units = units or [1] * len(cols)
+        p2p = [dist.P2POp(dist.isend, c[a // u:b // u], peer) for peer, a, b in sends for c, u in zip(cols, units)]
+        p2p += [dist.P2POp(dist.irecv, c[a // u:b // u], peer) for peer, a, b in recvs for c, u in zip(cols, units)]
         if p2p:
             for w in dist.batch_isend_irecv(p2p):
                 w.wait()  # stream-ordered on RCCL; blocking on gloo
@@ -236,11 +238,12 @@ class ThreadComm:
                 full[a:b].copy_(src[a:b])
         self.sh.barrier.wait()
 
-    def exchange(self, cols, sends, recvs):
+    def exchange(self, cols, sends, recvs, units=None):
+        units = units or [1] * len(cols)
         got = self._post(cols)
         for peer, a, b in recvs:
-            for mine, theirs in zip(cols, got[peer]):
-                mine[a:b].copy_(theirs[a:b])
+            for mine, theirs, u in zip(cols, got[peer], units):
+                mine[a // u:b // u].copy_(theirs[a // u:b // u])
         self.sh.barrier.wait()
 
 
@@ -302,7 +305,7 @@ class NativeComm:
                 print(f"[gjx] all-gather callback failed: {ex!r}", flush=True)
                 return -4
 
-        def exchange(_user, cols, elems, n_cols, sends, ns, recvs, nr, _s):
+        def exchange(_user, cols, elems, units, n_cols, sends, ns, recvs, nr, _s):
             try:
                 dist = _dist()
                 ops_ = []
@@ -310,8 +313,9 @@ class NativeComm:
                     for i in range(n):
                         sg = segs[i]
                         for c in range(n_cols):
-                            el = int(elems[c])
-                            ops_.append(dist.P2POp(fn, view(int(cols[c]) + int(sg.a) * el, (int(sg.b) - int(sg.a)) * el), int(sg.peer)))
+                            el, un = int(elems[c]), int(units[c])
+                            a, b = int(sg.a) // un * el, int(sg.b) // un * el
+                            ops_.append(dist.P2POp(fn, view(int(cols[c]) + a, b - a), int(sg.peer)))
                 if ops_:
                     for w in dist.batch_isend_irecv(ops_):
                         w.wait()
@@ -346,6 +350,31 @@ class NativeComm:
             out.append(NativeComm(ops, h, owner))
         return out
 
+    @staticmethod
+    def peers(ops: Ops, arena: "PeerArena", group=None, wait_launch: bool = False, timeout_ms: int = 0) -> "NativeComm":
+        """`gjx_comm_init_peers`: the peer transport over `arena`.  `group`: the handle owner of a `gjx_comm_group` when the
+        ranks are virtual ranks (threads) of this process sharing one stream; `wait_launch`: ranks that share a device as
+        separate processes."""
+        import ctypes as C
+
+        st = arena.peers_struct(timeout_ms)
+        h = C.c_void_p()
+        ops.lib.call("gjx_comm_init_peers", C.byref(st), group.handle if group is not None else None, 1 if wait_launch else 0,
+                     C.byref(h))
+        nc = NativeComm(ops, h, group)
+        nc._arena = arena
+        return nc
+
+    @staticmethod
+    def peers_virtual(ops: Ops, arenas: list, timeout_ms: int = 0) -> list:
+        """One peer-transport communicator per virtual rank of this process (threads sharing one stream)."""
+        import ctypes as C
+
+        g = C.c_void_p()
+        ops.lib.call("gjx_comm_group_create", len(arenas), C.byref(g))
+        owner = _GroupOwner(ops, g)
+        return [NativeComm.peers(ops, a, owner, False, timeout_ms) for a in arenas]
+
     def lse_combine(self, records: torch.Tensor):
         """records int64[n_batch, 65] of this rank's shard -> (lse f32[n_batch], e i32[n_batch], q i64[n_batch]) of the
         whole population, the same on every rank (`gjx_comm_lse_combine`)."""
@@ -366,6 +395,66 @@ class NativeComm:
                 self.handle = None
         except Exception:
             pass
+
+
+class PeerArena:
+    """One rank's ARENA of the peer transport (gjx.h gjx_smc_peers): both populations of a sharded filter, the rank's arrival
+    words and its error word, carved from ONE block of device memory at offsets that depend only on the filter's shape — so
+    the same array sits at the same offset in every rank's arena and `address on rank o = address here + delta[o]`.
+
+    `block`: a uint8 tensor of `PeerArena.nbytes(...)` bytes that the peers can address (a slice of one allocation for virtual
+    ranks of one process; an allocation shared through hipIpc for ranks that are processes).  The arrival words must be zero
+    when the arena is first used and are never reset afterwards (they only grow)."""
+
+    HEAD = 256  # flags: int64[8] at offset 0; error: int32 at offset 128
+
+    def __init__(self, block: torch.Tensor, delta: list[int], rank: int, world: int):
+        self.block, self.delta, self.rank, self.world = block, list(delta), rank, world
+        self.flags = block[0:64].view(torch.int64)
+        self.error = block[128:132].view(torch.int32)
+        self._pops = None
+
+    @staticmethod
+    def nbytes(ops: Ops, n_total: int, state_dtypes: list, adaptive: bool) -> int:
+        from .ops import BlockCarver, SmcPopulation
+
+        cv = BlockCarver(None)
+        cv.off = PeerArena.HEAD
+        for _ in range(2):
+            SmcPopulation(ops, n_total, state_dtypes, adaptive, True, cv)
+        return (cv.off + 4095) // 4096 * 4096
+
+    def pops(self, ops: Ops, n_total: int, state_dtypes: list, adaptive: bool):
+        from .ops import BlockCarver, SmcPopulation
+
+        cv = BlockCarver(self.block)
+        cv.off = PeerArena.HEAD
+        self._pops = [SmcPopulation(ops, n_total, state_dtypes, adaptive, True, cv) for _ in range(2)]
+        return self._pops
+
+    def peers_struct(self, timeout_ms: int = 0):
+        from . import abi
+
+        p = abi.SmcPeers()
+        p.world, p.rank = self.world, self.rank
+        for o in range(self.world):
+            p.delta[o] = int(self.delta[o])
+        p.flags, p.error = self.flags.data_ptr(), self.error.data_ptr()
+        p.timeout_ms = int(timeout_ms)
+        return p
+
+    def check(self, ops: Ops):
+        if ops.device().type == "cuda":
+            torch.cuda.current_stream().synchronize()
+        if int(self.error.cpu()[0]) != 0:
+            raise RuntimeError("peer transport: a step's wait for its peers timed out (gjx_smc_peers.error)")
+
+    @staticmethod
+    def virtual(ops: Ops, world: int, n_total: int, state_dtypes: list, adaptive: bool) -> list:
+        """`world` arenas for virtual ranks of THIS process: slices of one zeroed allocation."""
+        nb = PeerArena.nbytes(ops, n_total, state_dtypes, adaptive)
+        whole = torch.zeros(world * nb, dtype=torch.uint8, device=ops.device())
+        return [PeerArena(whole[r * nb:(r + 1) * nb], [(o - r) * nb for o in range(world)], r, world) for r in range(world)]
 
 
 class _GroupOwner:
@@ -398,7 +487,7 @@ class ShardedSMC:
 
     def __init__(self, ops: Ops, kind: str, impl: int, seed: int, n_total: int, T: int, rank: int, world: int,
                  record_ancestors: bool = False, exchange: str = "ranges", comm=None, poison: bool = False,
-                 n_states=None, lgssm=None, y=None, plan=None, obs=None, ess_threshold: float = 0.0):
+                 n_states=None, lgssm=None, y=None, plan=None, obs=None, ess_threshold: float = 0.0, arena=None):
         """`lgssm` (abi.Lgssm) / `y`: another linear-Gaussian model and observation sequence than the benchmark's.
         kind "plan": a generated filter — `plan` from `ops.smc_plan_create`, `obs` [T, n_obs]."""
         tile = ops.tile
@@ -441,10 +530,18 @@ class ShardedSMC:
         # global-size buffers: a rank's own block is always current, remote ranges are filled on demand
         self.n_cols = plan.n_state if kind == "plan" else 1
         self.adaptive = bool(self.cfg._adaptive)
-        self.pop = [ops.smc_pop(n_total, [sdt] * self.n_cols, self.adaptive) for _ in range(2)]
+        # `arena` (PeerArena): the peer transport — the populations live in the rank's arena, at the same offsets on every rank
+        self.arena = arena
+        if arena is not None:
+            self.pop = arena.pops(ops, n_total, [sdt] * self.n_cols, self.adaptive)
+        else:
+            self.pop = [ops.smc_pop(n_total, [sdt] * self.n_cols, self.adaptive) for _ in range(2)]
         for p_ in self.pop:
             for c in [*p_.state, p_.qw, p_.logw]:
                 c.zero_()
+        # one message per step for adaptive filters on a collective transport: [world, tiles_local, 4] int64 (records | ESS sums)
+        self.stage = (torch.zeros((world, 4 * (self.n_local // tile)), dtype=torch.int64, device=dev)
+                      if self.adaptive and world > 1 and arena is None else None)
         self.out_e = torch.empty(T, dtype=torch.int32, device=dev)
         self.out_q = torch.zeros(T, dtype=torch.int64, device=dev)
         self.ancestors = torch.empty((T, self.n_local), dtype=torch.int32, device=dev) if record_ancestors else None
@@ -481,6 +578,7 @@ class ShardedSMC:
         if self.exchange == "allgather":
             for c in cols:
                 self.comm.all_gather(c, lo, hi)
+            self.comm.all_gather(pop.subs, lo // tile, hi // tile)
             self.received += self.n_total - self.n_local
             return
         # the ranges of all ranks from the records, computed on the device and stored straight into pinned host
@@ -509,7 +607,8 @@ class ShardedSMC:
             if a < b:
                 recvs.append((j, a, b))
                 self.received += b - a
-        self.comm.exchange(cols, sends, recvs)
+        # r04: the sub-prefixes of the requested tiles travel with the shuffle (128 B per tile) instead of an all-gather of all
+        self.comm.exchange(cols + [pop.subs], sends, recvs, [1] * len(cols) + [tile])
 
     def _result(self):
         ops = self.ops
@@ -531,7 +630,7 @@ class ShardedSMC:
         from . import abi
 
         ops = self.ops
-        if self.poison:  # tests: whatever a rank never receives must never be read
+        if self.poison and self.arena is None:  # tests: whatever a rank never receives must never be read
             for p_ in self.pop:
                 for c in p_.columns(with_logw=True):
                     c.fill_(float("nan") if c.dtype == torch.float32 else -1)
@@ -543,6 +642,7 @@ class ShardedSMC:
         io.ancestors = self.ancestors.data_ptr() if self.ancestors is not None else None
         io.ranges = self.ranges.data_ptr()
         io.shuffle = 0 if self.exchange == "ranges" else 1
+        io.stage = self.stage.data_ptr() if self.stage is not None else None
         recv = C.c_uint64(0)
         io.received = C.pointer(recv)
         try:
@@ -560,6 +660,8 @@ class ShardedSMC:
                              C.c_void_p(y.ctypes.data) if y.size else None, C.byref(io), ops.stream())
         finally:
             self.received = int(recv.value)
+        if self.arena is not None:
+            self.arena.check(ops)  # a wait that timed out set the arena's error word: raise instead of returning garbage
         return self._result()
 
     def run(self):
@@ -570,10 +672,13 @@ class ShardedSMC:
             cur, prv = t & 1, (t & 1) ^ 1
             self._step(t, cur, prv)
             pop = self.pop[cur]
-            self.comm.all_gather(pop.recs, tl, th)
-            self.comm.all_gather(pop.subs, tl, th)
-            if pop.ess is not None:
-                self.comm.all_gather(pop.ess, tl, th)
+            # r04: ONE all-gather per step — the records; adaptive filters pack records + ESS sums into one message
+            if pop.ess is not None and self.world > 1:
+                ops.smc_records_pack(self.cfg, self.world, False, pop.recs, pop.ess, self.stage)
+                self.comm.all_gather(self.stage, self.rank, self.rank + 1)
+                ops.smc_records_pack(self.cfg, self.world, True, pop.recs, pop.ess, self.stage)
+            else:
+                self.comm.all_gather(pop.recs, tl, th)
             if t + 1 < self.T:
                 self._shuffle(cur)
         ops.smc_finish(self.cfg, self.pop[(self.T - 1) & 1].recs, self.out_e[self.T - 1:self.T], self.out_q[self.T - 1:self.T])

@@ -668,6 +668,11 @@ class Ops:
                       C.byref(prev) if prev is not None else None, C.byref(out), self._p(prev_e_out), self._p(prev_q_out),
                       self._p(ancestors_out), self.stream())
 
+    def smc_records_pack(self, cfg, world: int, unpack: bool, recs, ess, stage):
+        """gjx_smc_records_pack: a rank's records + ESS sums <-> its slot of the one-message staging buffer."""
+        self.lib.call("gjx_smc_records_pack", C.byref(cfg), int(world), 1 if unpack else 0, self._p(recs), self._p(ess),
+                      self._p(stage), self.stream())
+
     def smc_finish(self, cfg, recs, e_out, q_out):
         self.lib.call("gjx_smc_finish", C.byref(cfg), self._p(recs), self._p(e_out), self._p(q_out), self.stream())
 
@@ -693,19 +698,50 @@ class Ops:
         return float(terms.sum())
 
 
-class SmcPopulation:
-    """Device buffers of one population of a step-level (sharded) filter, all GLOBAL size (gjx.h gjx_smc_pop)."""
+class BlockCarver:
+    """Carves arrays out of ONE block of memory at 256-byte aligned offsets — the same offsets for the same sequence of
+    requests, which is what makes the arenas of the peer transport (gjx_smc_peers) identical in layout on every rank.
+    `block` None: a dry run that only counts bytes."""
 
-    def __init__(self, ops: "Ops", n_total: int, state_dtypes: list, adaptive: bool, want_logw: bool = True):
+    def __init__(self, block: "torch.Tensor | None"):
+        self.block, self.off = block, 0
+
+    def take(self, shape, dtype) -> "torch.Tensor | None":
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        nbytes = int(math.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        off = (self.off + 255) // 256 * 256
+        self.off = off + nbytes
+        if self.block is None:
+            return None
+        if self.off > self.block.numel():
+            raise ValueError("arena block too small")
+        return self.block[off:off + nbytes].view(dtype).view(shape)
+
+
+class SmcPopulation:
+    """Device buffers of one population of a step-level (sharded) filter, all GLOBAL size (gjx.h gjx_smc_pop).  `carver`:
+    carve them from a caller's block (an arena of the peer transport) instead of allocating."""
+
+    def __init__(self, ops: "Ops", n_total: int, state_dtypes: list, adaptive: bool, want_logw: bool = True,
+                 carver: "BlockCarver | None" = None):
         self.ops, self.n, self.adaptive = ops, n_total, adaptive
         nt = ops.num_tiles(n_total)
-        self.state = [ops.empty(n_total, dt) for dt in state_dtypes]
-        self.qw = ops.empty(n_total, torch.int32)
-        self.logw = ops.empty(n_total, torch.float32) if (want_logw or adaptive) else None
-        self.recs = torch.zeros((nt, abi.TILE_REC_WORDS), dtype=torch.int64, device=ops.device())
-        self.subs = torch.zeros((nt, abi.TILE_SUB_WORDS), dtype=torch.int64, device=ops.device())
-        self.ess = torch.zeros((nt, abi.TILE_ESS_WORDS), dtype=torch.int64, device=ops.device()) if adaptive else None
-        self.prefix = ops.empty(nt + 4, torch.int64) if nt > 1024 else None
+        if carver is None:
+            self.state = [ops.empty(n_total, dt) for dt in state_dtypes]
+            self.qw = ops.empty(n_total, torch.int32)
+            self.logw = ops.empty(n_total, torch.float32) if (want_logw or adaptive) else None
+            self.recs = torch.zeros((nt, abi.TILE_REC_WORDS), dtype=torch.int64, device=ops.device())
+            self.subs = torch.zeros((nt, abi.TILE_SUB_WORDS), dtype=torch.int64, device=ops.device())
+            self.ess = torch.zeros((nt, abi.TILE_ESS_WORDS), dtype=torch.int64, device=ops.device()) if adaptive else None
+            self.prefix = ops.empty(nt + 4, torch.int64) if nt > 1024 else None
+        else:
+            self.state = [carver.take(n_total, dt) for dt in state_dtypes]
+            self.qw = carver.take(n_total, torch.int32)
+            self.logw = carver.take(n_total, torch.float32) if (want_logw or adaptive) else None
+            self.recs = carver.take((nt, abi.TILE_REC_WORDS), torch.int64)
+            self.subs = carver.take((nt, abi.TILE_SUB_WORDS), torch.int64)
+            self.ess = carver.take((nt, abi.TILE_ESS_WORDS), torch.int64) if adaptive else None
+            self.prefix = carver.take(nt + 4, torch.int64) if nt > 1024 else None
 
     def columns(self, with_logw: bool | None = None) -> list[torch.Tensor]:
         """The per-particle columns an ancestor shuffle moves: state, fixed-point weights (and log-weights when adaptive)."""

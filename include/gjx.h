@@ -524,6 +524,30 @@ typedef struct {
   const float* obs_logits;   /* dev f32 [K,K]: row = state, column = observation */
 } gjx_hmm;
 
+/* r04: the PEER transport of a sharded filter (below: "multi-GPU").  A population sharded over `world` ranks lives in
+ * `world` ARENAS of identical layout, one per rank: the address of any element of any array on rank o is the address of the
+ * same element on this rank plus delta[o] bytes (both as mapped in THIS process: the rank's own device memory, a peer's
+ * through hipIpcOpenMemHandle / peer access, or another block of the same allocation for virtual ranks).  A step with
+ * cfg->peers set reads the source population WHERE IT LIVES — tile k's weights, sub-prefixes and state columns from the
+ * arena of its owner, rank k / (tiles / world) — and the tile records from its own arena, where every rank has deposited
+ * them (gjx_smc_peer_signal): no collective, no exchange, nothing decided on the host between two steps.
+ * Ordering: flags is this rank's row of arrival words (dev u64[GJX_MAX_PEERS] inside the arena, zero when allocated and
+ * monotone afterwards; flags[q] is written by rank q only).  A step's kernel reads nothing of the source population before
+ * every flags[q], q < world, is >= wait_value — a BOUNDED poll by one wave per workgroup (timeout_ms; 0 = 10 s), followed
+ * by a system-scope acquire; a wait that times out sets *error (dev u32[1] in the arena) and the kernel returns without
+ * writing anything, so a lost peer is an error the caller reads after the run, never a hang. */
+#define GJX_MAX_PEERS 8
+typedef struct gjx_smc_peers {
+  int32_t world;                /* 2 .. GJX_MAX_PEERS */
+  int32_t rank;
+  int64_t delta[GJX_MAX_PEERS]; /* delta[rank] = 0 */
+  uint64_t* flags;              /* this rank's arrival words, inside the arena */
+  uint32_t* error;              /* inside the arena */
+  uint64_t wait_value;          /* what the step waits for (the sharded drivers set it per step) */
+  uint32_t timeout_ms;
+  int32_t pad;
+} gjx_smc_peers;
+
 /* Layout-independent description of one SMC run. */
 typedef struct {
   int32_t impl;            /* gjx_rng_impl */
@@ -557,6 +581,9 @@ typedef struct {
    * (entry 0 is 0).  Required (non-NULL) when ess_threshold is in (0, 1). */
   float ess_threshold;
   int32_t* resampled_out;
+  /* r04 (nullable; host): the source population of the steps t >= 1 is distributed over the arenas of peers (above).  One
+   * filter, n_local = n_total / world, first_slot = rank * n_local, n_total a multiple of world * gjx_smc_tile(). */
+  const gjx_smc_peers* peers;
 } gjx_smc_config;
 
 /* A population between two steps: what a step reads of the previous one and writes for the next. */
@@ -732,18 +759,41 @@ int gjx_comm_init_local(gjx_comm_group* g, int rank, gjx_comm** out);
  *         process group the host program already has (torch.distributed over gloo or RCCL, MPI, ...), so the native driver
  *         runs across REAL processes on any transport; this is how gjx_smc_sharded_run_* is tested with world_size-2/4
  *         gloo process groups on CPU.  allgather: in place, rank r's block is full + r * bytes_per_rank.  exchange: element
- *         ranges [a, b) of every column keep their global position on both sides (column c at cols[c] + a * elem_bytes[c]);
- *         both sides list the same ranges.  Callbacks return 0 or a negative gjx status. */
+ *         ranges [a, b) of PARTICLES (multiples of the tile) keep their global position on both sides; column c holds one
+ *         element of elem_bytes[c] bytes per units[c] particles (1: a per-particle column, the tile size: the per-tile
+ *         sub-prefixes, which travel with the shuffle since r04), so its slice is the bytes [(a / units[c]) elem_bytes[c],
+ *         (b / units[c]) elem_bytes[c]) of cols[c]; both sides list the same ranges.  Callbacks return 0 or a negative gjx
+ *         status. */
 typedef struct {
   int32_t peer;
   uint64_t a, b;
 } gjx_seg;
 typedef int (*gjx_allgather_fn)(void* user, void* full, uint64_t bytes_per_rank, gjx_stream s);
-typedef int (*gjx_exchange_fn)(void* user, void* const* cols, const uint64_t* elem_bytes, int32_t n_cols, const gjx_seg* sends,
+typedef int (*gjx_exchange_fn)(void* user, void* const* cols, const uint64_t* elem_bytes, const uint64_t* units, int32_t n_cols, const gjx_seg* sends,
                                int32_t n_sends, const gjx_seg* recvs, int32_t n_recvs, gjx_stream s);
 typedef int (*gjx_stream_sync_fn)(void* user, gjx_stream s);
 int gjx_comm_init_callbacks(int rank, int world, gjx_allgather_fn allgather, gjx_exchange_fn exchange,
                             gjx_stream_sync_fn stream_sync, void* user, gjx_comm** out);
+/*   peers (both builds; r04): no collective at all.  Every rank's populations live in an arena of identical layout that its
+ *         peers can address (gjx_smc_peers above); per step a rank issues its ONE step launch (which waits, bounded, for
+ *         its peers' arrival words and reads remote source windows where they live) and ONE small launch that deposits the
+ *         records of its tiles in every peer's arena and then raises its arrival word there (gjx_smc_peer_signal): no
+ *         RCCL call, no range kernel, no host poll — the host enqueues all T steps without waiting for anything.
+ *         `group` (nullable): the ranks are VIRTUAL ranks of one process sharing one stream (tests; gjx_comm_group_create):
+ *         launches of one stream execute in enqueue order, so the driver holds a host barrier between "every rank has
+ *         enqueued its signal" and "any rank enqueues the launch that waits for it".  wait_launch != 0: a one-workgroup
+ *         wait launch in front of every step launch — for ranks that SHARE a device as separate processes (tests), so that
+ *         a step's workgroups never occupy the device while the signal they wait for still needs it. */
+int gjx_comm_init_peers(const gjx_smc_peers* peers /*host; copied*/, gjx_comm_group* group, int wait_launch, gjx_comm** out);
+/* The two launches the peer transport is made of (the sharded drivers call them; exposed for drivers written elsewhere).
+ *  signal: deposit the records (and ESS sums when `ess` is given) of this rank's tiles [first_tile, first_tile + n_tiles) —
+ *          read from recs / ess in this rank's arena — at the same place in every peer's arena, make them and everything
+ *          earlier launches of the stream wrote visible at system scope, then store `value` into word `rank` of every
+ *          rank's flags.  recs may be NULL (n_tiles 0): only the arrival word is raised.
+ *  wait:   a one-workgroup launch that returns when every flags[q] >= value (or sets *error after the timeout). */
+int gjx_smc_peer_signal(const gjx_smc_peers* peers, const gjx_tile_rec* recs, const gjx_tile_ess* ess, uint64_t first_tile,
+                        uint64_t n_tiles, uint64_t value, gjx_stream s);
+int gjx_smc_peer_wait(const gjx_smc_peers* peers, uint64_t value, gjx_stream s);
 int gjx_comm_destroy(gjx_comm* c);
 int gjx_comm_rank(const gjx_comm* c);
 int gjx_comm_world(const gjx_comm* c);
@@ -754,8 +804,9 @@ int gjx_comm_world(const gjx_comm* c);
 int gjx_comm_lse_combine(gjx_comm* c, const uint64_t* records, int32_t n_batch, uint64_t* gathered, int32_t* out_e,
                          uint64_t* out_q, float* out_lse, gjx_stream s);
 /* The whole bootstrap filter sharded over the communicator's ranks (BASELINE configs[3]): per step ONE launch (own
- * slots) -> the all-gather of the tile records (recs, subs and — adaptive filters — ess: 144-160 bytes per 1024 particles,
- * no all-reduce) -> ancestor shuffle, driven from C: no interpreter
+ * slots) -> ONE all-gather of the tile records (r04: recs and — adaptive filters — ess packed into one message, 16-32 bytes
+ * per 1024 particles; the sub-prefixes travel with the shuffle, for the requested range only; no all-reduce) -> ancestor
+ * shuffle, driven from C: no interpreter
  * between the launches.  cfg: first_slot / n_local = this rank's block (n_total a multiple of world * gjx_smc_tile()),
  * one filter.  All arrays are GLOBAL-size device buffers the caller owns (a rank's own block is always current; remote
  * ranges are filled by the shuffle): pop[2] (double-buffered: state columns dev 4-byte [n_total], qw dev u32[n_total],
@@ -774,7 +825,13 @@ typedef struct {
   int64_t* ranges;
   int32_t shuffle;
   uint64_t* received;
+  void* stage;       /* r04: dev [world, tiles_local, 32 bytes] — ESS-adaptive filters on a collective transport (world > 1): a
+                        rank's records and ESS sums are packed into ONE message per step; NULL otherwise / for the peer transport */
 } gjx_sharded_io;
+/* pack (unpack = 0): this rank's block of recs / ess -> its slot of `stage`; unpack (1): every OTHER rank's slot of `stage` ->
+ * recs / ess.  world equal blocks of cfg->n_local / gjx_smc_tile() tiles; the rank is cfg->first_slot / cfg->n_local. */
+int gjx_smc_records_pack(const gjx_smc_config* cfg, int world, int unpack, gjx_tile_rec* recs, gjx_tile_ess* ess, void* stage,
+                         gjx_stream s);
 int gjx_smc_sharded_run_lgssm(gjx_comm* c, const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y_host,
                               const gjx_sharded_io* io, gjx_stream s);
 int gjx_smc_sharded_run_hmm(gjx_comm* c, const gjx_smc_config* cfg, const gjx_hmm* model, const int32_t* y_host,

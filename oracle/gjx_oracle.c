@@ -12,10 +12,13 @@
  * OpenMP only parallelises loops whose iterations are independent or whose reduction is an
  * exact integer sum / max, so results do not depend on the thread count.
  */
+#define _POSIX_C_SOURCE 200809L /* clock_gettime, sched_yield (the peer transport's bounded wait) */
 #include "../include/gjx.h"
 #include "gjx_oracle_math.h"
 
 #include <stdlib.h>
+#include <time.h>
+#include <sched.h>
 
 #define O_TILE 1024u
 #define O_CAT_FRAC 23
@@ -1048,6 +1051,98 @@ static inline int32_t comb_in_tile(double c, double scale_t, double base, int32_
 static inline double comb_tile_scale(double scale, int d) { return d >= 64 ? 0.0 : ldexp(scale, -d); }
 static inline double u0_from_bits(uint64_t U) { return (double)(U >> 11) * 0x1.0p-53; }
 
+/* ---- r04: the peer transport (gjx.h: gjx_smc_peers).  The source population is distributed: element i of a per-particle
+ * array (tile k of a per-tile array) lives in the arena of rank (i / 1024) / tiles_per_rank (k / tiles_per_rank), at the address
+ * it has in this rank's arena plus delta[owner] bytes.  Here the arenas are host memory of one process and the ranks are
+ * threads: the wait is a bounded spin on the arrival words, the signal a release store. */
+typedef struct {
+  const gjx_smc_peers* p; /* NULL: everything is local */
+  uint64_t tiles_per_rank;
+} peer_view;
+static peer_view peer_view_of(const gjx_smc_config* cfg) {
+  peer_view v = {cfg->peers, 1};
+  if (cfg->peers) v.tiles_per_rank = cfg->n_total / (uint64_t)cfg->peers->world / O_TILE;
+  return v;
+}
+static inline const void* peer_at(const peer_view* v, const void* p, uint64_t particle) {
+  if (!v->p) return p;
+  return (const char*)p + v->p->delta[(particle / O_TILE) / v->tiles_per_rank];
+}
+static int peers_ok(const gjx_smc_config* c) {
+  const gjx_smc_peers* p = c->peers;
+  if (!p || p->world < 2 || p->world > GJX_MAX_PEERS || p->rank < 0 || p->rank >= p->world || !p->flags || !p->error ||
+      p->delta[p->rank] != 0 || c->n_filters > 1)
+    return 0;
+  const uint64_t w = (uint64_t)p->world;
+  return c->n_total % (w * O_TILE) == 0 && c->n_local == c->n_total / w && c->first_slot == (uint64_t)p->rank * c->n_local;
+}
+static double now_ms(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+/* -> 1 when every arrival word is >= value (then an acquire fence), 0 after the timeout (*error set) */
+static int peer_wait_host(const gjx_smc_peers* p, uint64_t value) {
+  const double t0 = now_ms(), limit = p->timeout_ms ? (double)p->timeout_ms : 10000.0;
+  for (;;) {
+    int ready = 1;
+    for (int q = 0; q < p->world; ++q) ready = ready && __atomic_load_n(&p->flags[q], __ATOMIC_RELAXED) >= value;
+    if (ready) break;
+    if (now_ms() - t0 > limit) {
+      __atomic_store_n(p->error, 1u, __ATOMIC_RELAXED);
+      return 0;
+    }
+    sched_yield();
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return 1;
+}
+int gjx_smc_peer_wait(const gjx_smc_peers* peers, uint64_t value, gjx_stream s) {
+  (void)s;
+  if (!peers || peers->world < 2 || peers->world > GJX_MAX_PEERS || !peers->flags || !peers->error) return GJX_ERR_INVALID;
+  (void)peer_wait_host(peers, value); /* (a timeout is reported through *error, like the device's) */
+  return GJX_OK;
+}
+int gjx_smc_peer_signal(const gjx_smc_peers* peers, const gjx_tile_rec* recs, const gjx_tile_ess* ess, uint64_t first_tile,
+                        uint64_t n_tiles, uint64_t value, gjx_stream s) {
+  (void)s;
+  if (!peers || peers->world < 2 || peers->world > GJX_MAX_PEERS || peers->rank < 0 || peers->rank >= peers->world ||
+      !peers->flags || !peers->error || (n_tiles > 0 && !recs))
+    return GJX_ERR_INVALID;
+  for (int o = 0; o < peers->world; ++o) {
+    if (o != peers->rank && recs && n_tiles) {
+      memcpy((char*)(uintptr_t)(recs + first_tile) + peers->delta[o], recs + first_tile, sizeof(gjx_tile_rec) * n_tiles);
+      if (ess) memcpy((char*)(uintptr_t)(ess + first_tile) + peers->delta[o], ess + first_tile, sizeof(gjx_tile_ess) * n_tiles);
+    }
+  }
+  for (int o = 0; o < peers->world; ++o) {
+    uint64_t* word = (uint64_t*)((char*)peers->flags + peers->delta[o]) + peers->rank;
+    __atomic_store_n(word, value, __ATOMIC_RELEASE);
+  }
+  return GJX_OK;
+}
+int gjx_smc_records_pack(const gjx_smc_config* cfg, int world, int unpack, gjx_tile_rec* recs, gjx_tile_ess* ess, void* stage,
+                         gjx_stream s) {
+  (void)s;
+  if (!cfg || !recs || !ess || !stage || world < 1 || world > 64 || cfg->n_local == 0 || cfg->n_local % O_TILE ||
+      cfg->n_total != cfg->n_local * (uint64_t)world || cfg->first_slot % cfg->n_local)
+    return GJX_ERR_INVALID;
+  const uint64_t tl = cfg->n_local / O_TILE;
+  const int rank = (int)(cfg->first_slot / cfg->n_local);
+  for (int r = 0; r < world; ++r) {
+    if ((r == rank) == (unpack != 0)) continue;
+    char* slot = (char*)stage + (size_t)r * tl * 32;
+    if (unpack) {
+      memcpy(recs + (size_t)r * tl, slot, tl * 16);
+      memcpy(ess + (size_t)r * tl, slot + tl * 16, tl * 16);
+    } else {
+      memcpy(slot, recs + (size_t)r * tl, tl * 16);
+      memcpy(slot + tl * 16, ess + (size_t)r * tl, tl * 16);
+    }
+  }
+  return GJX_OK;
+}
+
 /* Ancestors of the slots [lo, hi) of an n_out-tooth comb over n particles with stored weights qw and merged records:
  * teeth below the start of tile b: nlo_b = comb_tile(pre[b]); below particle i of tile b (c = running sum of q inside
  * the tile): n_i = min(comb_clamp(fma(c, scale 2^-d_b, base_b)), nlo_{b+1}), a tile's last particle ending at nlo_{b+1},
@@ -1055,7 +1150,7 @@ static inline double u0_from_bits(uint64_t U) { return (double)(U >> 11) * 0x1.0
  * merged records alone) all lie outside [lo, hi) are skipped without reading their weights: a rank of a sharded filter
  * holds only the source ranges it needs. */
 static void systematic_ancestors(const uint32_t* qw, uint64_t n, const merged* m, uint64_t nt, uint64_t n_out_u,
-                                 double u0, int64_t lo, int64_t hi, int32_t* anc /* [hi - lo] */) {
+                                 double u0, int64_t lo, int64_t hi, int32_t* anc /* [hi - lo] */, const peer_view* pv) {
   const int32_t n_out = (int32_t)n_out_u;
   if (m->Q == 0) { /* no mass at all: the population is kept — slot j takes particle floor(j n / n_out) */
     const double ratio = (double)n / (double)n_out_u;
@@ -1076,8 +1171,9 @@ static void systematic_ancestors(const uint32_t* qw, uint64_t n, const merged* m
     int64_t prev = t_lo;
     const uint64_t i0 = b * O_TILE, i1 = (b + 1) * O_TILE < n ? (b + 1) * O_TILE : n;
     double c = 0.0;
+    const uint32_t* qt = pv ? (const uint32_t*)peer_at(pv, qw, i0) : qw; /* (the tile's weights, where they live) */
     for (uint64_t i = i0; i < i1; ++i) {
-      c += (double)qw[i];
+      c += (double)qt[i];
       const int64_t ni = (i + 1 == i1) ? t_hi : comb_in_tile(c, scale_t, base, t_hi, n_out);
       const int64_t a = prev > lo ? prev : lo, e = ni < hi ? ni : hi;
       for (int64_t j = a; j < e; ++j) anc[j - lo] = (int32_t)i;
@@ -1101,7 +1197,7 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
   if (!rc) {
     o_stream st = stream_at(key, 0);
     const double u0 = u0_from_bits(o_bits64_at(&st, 0));
-    systematic_ancestors(qw, n, &m, nt, n_out, u0, 0, (int64_t)n_out, ancestors);
+    systematic_ancestors(qw, n, &m, nt, n_out, u0, 0, (int64_t)n_out, ancestors, NULL);
     if (out_e) *out_e = m.e;
     if (out_q) *out_q = m.Q;
     merged_free(&m);
@@ -1244,7 +1340,8 @@ static int smc_step_front(const gjx_smc_config* cfg, int t, const gjx_smc_pop* p
     const uint32_t rkey[4] = {cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1], 0u, 0u};
     o_stream st = o_stream_make(cfg->impl, rkey, 0, 0);
     const double u0 = u0_from_bits(o_bits64_at(&st, 0));
-    systematic_ancestors(prev->qw, N, &m, nt, N, u0, (int64_t)cfg->first_slot, (int64_t)(cfg->first_slot + cfg->n_local), anc);
+    const peer_view pv = peer_view_of(cfg);
+    systematic_ancestors(prev->qw, N, &m, nt, N, u0, (int64_t)cfg->first_slot, (int64_t)(cfg->first_slot + cfg->n_local), anc, &pv);
   } else {
     for (uint64_t j = 0; j < cfg->n_local; ++j) anc[j] = (int32_t)(cfg->first_slot + j);
   }
@@ -1269,6 +1366,10 @@ static int smc_step_generic(const gjx_smc_config* cfg, int t, int n_state, const
                             int32_t* prev_e_out, uint64_t* prev_q_out, int32_t* ancestors_out, propagate_fn fn, void* ctx) {
   const int ad = cfg_adaptive(cfg);
   if (!pop_ok(out, n_state, ad) || (t > 0 && (!pop_ok(prev, n_state, ad) || prev->recs == out->recs))) return GJX_ERR_INVALID;
+  if (cfg->peers) { /* the peer transport: nothing of the source population is read before every peer has arrived */
+    if (!peers_ok(cfg)) return GJX_ERR_INVALID;
+    if (t > 0 && !peer_wait_host(cfg->peers, cfg->peers->wait_value)) return GJX_ERR_LAUNCH;
+  }
   const uint64_t nl = cfg->n_local;
   int32_t* anc = NULL;
   int carry = 0;
@@ -1318,7 +1419,8 @@ static float lgssm_propagate(void* vc, uint64_t j, int64_t a) {
     const float tt = c->mdl->x0_scale * eps;
     x = c->mdl->x0_loc + tt;
   } else {
-    const float mean = c->mdl->a * c->prev_x[a];
+    const peer_view pv = peer_view_of(c->cfg);
+    const float mean = c->mdl->a * *(const float*)peer_at(&pv, c->prev_x + a, (uint64_t)a);
     const float tt = c->mdl->q * eps;
     x = mean + tt;
   }
@@ -1400,7 +1502,8 @@ static float hmm_propagate(void* vc, uint64_t j, int64_t a) {
   hmm_ctx* c = (hmm_ctx*)vc;
   const uint32_t K = (uint32_t)c->mdl->n_states;
   const uint32_t bits = o_smc_slot_bits(c->cfg->impl, c->skey, c->cfg->first_slot + j);
-  const int32_t zp = a < 0 ? c->mdl->init_state : c->prev_z[a];
+  const peer_view pv = peer_view_of(c->cfg);
+  const int32_t zp = a < 0 ? c->mdl->init_state : *(const int32_t*)peer_at(&pv, c->prev_z + a, (uint64_t)a);
   const uint32_t z = hmm_alias_draw(c->trans_alias + (size_t)zp * K, K, bits);
   c->z_out[j] = (int32_t)z;
   return c->obs_logp[(size_t)z * K + (uint32_t)c->y];
@@ -1797,8 +1900,10 @@ static float plan_propagate(void* vc, uint64_t j, int64_t a) {
   c.quad_key = p->cfg->impl == 1 ? p->skey : NULL;
   c.slot = slot;
   float prev[GJX_SMC_MAX_STATE];
-  if (a >= 0)
-    for (int k = 0; k < D; ++k) prev[k] = ((const float*)p->prev->state[k])[a];
+  if (a >= 0) {
+    const peer_view pv = peer_view_of(p->cfg);
+    for (int k = 0; k < D; ++k) prev[k] = *(const float*)peer_at(&pv, (const float*)p->prev->state[k] + a, (uint64_t)a);
+  }
   c.state = a >= 0 ? prev : NULL;
   c.obs = p->obs;
   c.scopes = p->t == 0 ? p->init_scopes : p->step_scopes;

@@ -57,6 +57,18 @@ int gjx_comm_init_callbacks(int rank, int world, gjx_allgather_fn allgather, gjx
   *out = c;
   return GJX_OK;
 }
+int gjx_comm_init_peers(const gjx_smc_peers* peers, gjx_comm_group* group, int wait_launch, gjx_comm** out) {
+  if (!out) return GJX_ERR_INVALID;
+  gjx_comm* c = new (std::nothrow) gjx_comm;
+  if (!c) return GJX_ERR_LAUNCH;
+  const int rc = gjx_sharded::comm_init_peers(peers, group ? &group->g : nullptr, wait_launch, &c->t);
+  if (rc) {
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return GJX_OK;
+}
 int gjx_comm_destroy(gjx_comm* c) { delete c; return GJX_OK; }
 int gjx_comm_rank(const gjx_comm* c) { return c && c->t ? c->t->rank : -1; }
 int gjx_comm_world(const gjx_comm* c) { return c && c->t ? c->t->world : -1; }

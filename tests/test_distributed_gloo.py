@@ -99,7 +99,8 @@ def test_two_ranks_equal_one_rank(tmp_path, oracle_ops, impl):
         assert torch.equal(p["hmm_q"], ref_hmm["out_q"]) and p["hmm_log_z"] == ref_hmm["log_z"]
 
 
-def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_states=16, native=False, **model_kw):
+def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_states=16, native=False, peer_arenas=None,
+                       peer_comms=None, **model_kw):
     """`world` virtual ranks as threads sharing one backend (dist.ThreadComm): the sharded protocol without
     process groups.  Returns the per-rank results.  native: the whole filter driven from C through the library's own
     communicator (`gjx_comm` local group + `gjx_smc_sharded_run_*`) instead of the Python loop."""
@@ -108,13 +109,20 @@ def _run_virtual_ranks(ops, kind, impl, world, n_total, T, exchange, seed=5, n_s
     from genjax._amd import dist as gdist
 
     sh, res, err = gdist.ThreadComm.Shared(world), [None] * world, []
-    comms = gdist.NativeComm.local_group(ops, world) if native else None
+    arenas = [None] * world
+    if native == "peers":  # r04: the peer transport — arenas of one allocation, no collective, no exchange
+        adaptive = 0.0 < float(model_kw.get("ess_threshold", 0.0)) < 1.0
+        arenas = peer_arenas if peer_arenas is not None else gdist.PeerArena.virtual(
+            ops, world, n_total, [torch.int32 if kind == "hmm" else torch.float32], adaptive)
+        comms = peer_comms if peer_comms is not None else gdist.NativeComm.peers_virtual(ops, arenas, timeout_ms=20000)
+    else:
+        comms = gdist.NativeComm.local_group(ops, world) if native else None
 
     def work(r):
         try:
             kw = dict(model_kw, n_states=n_states) if kind == "hmm" else dict(model_kw)
             smc = gdist.ShardedSMC(ops, kind, impl, seed, n_total, T, r, world, True, exchange=exchange,
-                                   comm=gdist.ThreadComm(sh, r), poison=True, **kw)
+                                   comm=gdist.ThreadComm(sh, r), poison=True, arena=arenas[r], **kw)
             res[r] = smc.run_native(comms[r]) if native else smc.run()
         except BaseException as e:  # noqa: BLE001 - re-raised below; release the others
             err.append(e)
@@ -289,7 +297,7 @@ def test_source_ranges_oracle(oracle_ops):
     check_source_ranges(oracle_ops)
 
 
-def check_degenerate_sharded(ops, impl, world):
+def check_degenerate_sharded(ops, impl, world, native=False):
     """Collapsing weights (a few particles of one rank carry all the mass): every rank's source range lies in
     one remote block, most tiles are empty — sharded == single-rank bit for bit."""
     import numpy as np
@@ -299,7 +307,7 @@ def check_degenerate_sharded(ops, impl, world):
     T, n_total = 8, 1024 * world * 4
     y = np.array([0.1, 25.0, -40.0, -39.5, 60.0, 60.2, 0.0, 3.0], dtype=np.float32)
     mdl = abi.Lgssm(0.0, 1.0, 0.9, 1.0, 0.05)
-    res = _run_virtual_ranks(ops, "lgssm", impl, world, n_total, T, "ranges", seed=11, lgssm=mdl, y=y)
+    res = _run_virtual_ranks(ops, "lgssm", impl, world, n_total, T, "ranges", seed=11, native=native, lgssm=mdl, y=y)
     sk, rk = W.smc_key_schedule(prng.key(11, impl), T)
     ref = ops.smc_run_lgssm(impl, n_total, sk, rk, mdl, y, True)
     assert torch.equal(torch.cat([r["state"] for r in res]).cpu(), ref[2].cpu())
@@ -364,12 +372,17 @@ def check_sharded_plan(ops, impl, world, build_plans, native=False):
     obs = np.stack([y, (np.arange(T) % 2).astype(np.float32)], axis=1)
     _, plan = build_plans(ops)
     sh, res, err = gdist.ThreadComm.Shared(world), [None] * world, []
-    comms = gdist.NativeComm.local_group(ops, world) if native else None
+    arenas = [None] * world
+    if native == "peers":
+        arenas = gdist.PeerArena.virtual(ops, world, n_total, [torch.float32] * plan.n_state, False)
+        comms = gdist.NativeComm.peers_virtual(ops, arenas, timeout_ms=20000)
+    else:
+        comms = gdist.NativeComm.local_group(ops, world) if native else None
 
     def work(r):
         try:
             smc = gdist.ShardedSMC(ops, "plan", impl, 13, n_total, T, r, world, True, comm=gdist.ThreadComm(sh, r),
-                                   poison=True, plan=plan, obs=obs)
+                                   poison=True, plan=plan, obs=obs, arena=arenas[r])
             res[r] = smc.run_native(comms[r]) if native else smc.run()
         except BaseException as e:  # noqa: BLE001
             err.append(e)
@@ -464,6 +477,66 @@ def test_native_sharded_adaptive_and_plan(oracle_ops):
     from test_gpu_parity_abi import _smc_plans
 
     check_sharded_plan(oracle_ops, 1, 2, _smc_plans, native=True)
+
+
+# ---- r04: the peer transport (gjx_comm_init_peers) under virtual ranks on the oracle ---------------------------------------
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("kind", ["lgssm", "hmm"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_peer_transport_virtual_ranks(oracle_ops, impl, kind, world):
+    """no all-gather, no range kernel, no host decision — every rank reads remote source windows where
+    they live and deposits its tile records in its peers' arenas; the ranks are THREADS that really run concurrently here
+    (the oracle's steps are synchronous: a rank's step blocks in its bounded wait until its peers have signalled).
+    Particles, ancestors, (e, q) and log Z equal the single-rank filter bit for bit."""
+    check_virtual_ranks(oracle_ops, kind, impl, world, 1024 * world * 3, 9, "ranges", native="peers")
+
+
+def test_peer_transport_adaptive_plan_and_reuse(oracle_ops):
+    from genjax._amd import dist as gdist
+    from test_gpu_parity_abi import _smc_plans as plans
+
+    # ESS-adaptive: kept steps read their own block only, the decision comes from the deposited ESS sums
+    res = check_virtual_ranks(oracle_ops, "lgssm", 1, 3, 1024 * 6, 14, "ranges", ess_threshold=0.5, native="peers")
+    assert 0 < int((res[0]["resampled"][1:] == 0).sum()) < 13
+    check_virtual_ranks(oracle_ops, "hmm", 0, 2, 1024 * 4, 10, "ranges", ess_threshold=0.5, native="peers")
+    # a generated two-column filter
+    check_sharded_plan(oracle_ops, 1, 2, plans, native="peers")
+    # the same arenas and communicators serve one run after the other: the arrival words only grow (epochs)
+    world, n_total = 3, 1024 * 3 * 2
+    arenas = gdist.PeerArena.virtual(oracle_ops, world, n_total, [torch.float32], False)
+    comms = gdist.NativeComm.peers_virtual(oracle_ops, arenas, timeout_ms=20000)
+    a = _run_virtual_ranks(oracle_ops, "lgssm", 1, world, n_total, 6, "ranges", native="peers", peer_arenas=arenas, peer_comms=comms)
+    a = [dict(r, state=r["state"].clone()) for r in a]  # (results are views of the arenas the next run writes)
+    b = _run_virtual_ranks(oracle_ops, "lgssm", 1, world, n_total, 7, "ranges", seed=6, native="peers", peer_arenas=arenas, peer_comms=comms)
+    from genjax._amd import workloads as W
+
+    for got, (seed, T) in ((a, (5, 6)), (b, (6, 7))):
+        ref = W.lgssm_smc(oracle_ops, 1, seed, n_total, T, True)
+        assert torch.equal(torch.cat([r["state"] for r in got]), ref["state"])
+        assert all(r["log_z"] == ref["log_z"] for r in got)
+    assert [int(x) for x in arenas[0].flags[:world]] == [6 + 1 + 7 + 1] * world
+
+
+def test_peer_transport_worst_case_weights(oracle_ops):
+    check_degenerate_sharded(oracle_ops, 1, 4, native="peers")
+    check_impossible_observation_sharded(oracle_ops, 1, 3, "peers")
+
+
+def test_peer_transport_lost_peer_is_an_error_not_a_hang(oracle_ops):
+    """A rank whose peer never arrives: the bounded wait gives up, the call returns an error and the arena's error word is
+    set — nothing waits forever."""
+    import ctypes as C
+
+    from genjax._amd import dist as gdist
+
+    world, n_total, T = 2, 1024 * 2, 4
+    arenas = gdist.PeerArena.virtual(oracle_ops, world, n_total, [torch.float32], False)
+    comm = gdist.NativeComm.peers(oracle_ops, arenas[0], None, False, timeout_ms=200)  # rank 1 never runs
+    smc = gdist.ShardedSMC(oracle_ops, "lgssm", 1, 5, n_total, T, 0, world, False, arena=arenas[0])
+    with pytest.raises(Exception):
+        smc.run_native(comm)
+    assert int(arenas[0].error[0]) == 1
+    _ = C
 
 
 def check_native_lse_combine(ops, world=3):

@@ -129,3 +129,167 @@ def test_random_sharded_configurations_on_device(hip_ops, oracle_ops):
     from test_distributed_gloo import random_sharded_configs
 
     random_sharded_configs(hip_ops, 9, 10, ref_ops=oracle_ops)
+
+
+# ---- r04: the peer transport on the device ----------------------------------------------------------
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("kind", ["lgssm", "hmm"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_peer_transport_on_device(hip_ops, oracle_ops, impl, kind, world):
+    """`gjx_comm_init_peers` on the HIP kernels: `world` virtual ranks whose arenas are slices of one allocation.  Per step and
+    rank ONE step launch (bounded wait for the peers' arrival words, then resampling that reads remote source windows where
+    they live) and ONE signal launch (records into every arena, system-scope release, arrival word) — no collective, no
+    exchange, nothing decided on the host.  Equal to the single-rank ORACLE filter bit for bit."""
+    check_virtual_ranks(hip_ops, kind, impl, world, 1024 * world * 3, 9, "ranges", ref_ops=oracle_ops, native="peers")
+
+
+def test_peer_transport_adaptive_plan_collapse_and_reuse_on_device(hip_ops, oracle_ops):
+    from genjax._amd import dist as gdist
+    from test_distributed_gloo import check_sharded_plan
+    from test_gpu_parity_abi import _smc_plans
+
+    res = check_virtual_ranks(hip_ops, "lgssm", 1, 3, 1024 * 6, 14, "ranges", ref_ops=oracle_ops, ess_threshold=0.5, native="peers")
+    assert 0 < int((res[0]["resampled"][1:] == 0).sum()) < 13
+    check_virtual_ranks(hip_ops, "hmm", 0, 2, 1024 * 2 * 7, 9, "ranges", ref_ops=oracle_ops, ess_threshold=0.5, native="peers")
+    check_sharded_plan(hip_ops, 0, 2, _smc_plans, native="peers")
+    check_sharded_plan(hip_ops, 1, 4, _smc_plans, native="peers")
+    # one communicator, run after run: the arrival words only grow
+    world, n_total = 3, 1024 * 3 * 4
+    arenas = gdist.PeerArena.virtual(hip_ops, world, n_total, [torch.float32], False)
+    comms = gdist.NativeComm.peers_virtual(hip_ops, arenas, timeout_ms=20000)
+    for seed, T in ((5, 6), (6, 7), (7, 3)):
+        got = _run_virtual_ranks(hip_ops, "lgssm", 1, world, n_total, T, "ranges", seed=seed, native="peers", peer_arenas=arenas,
+                                 peer_comms=comms)
+        ref = W.lgssm_smc(oracle_ops, 1, seed, n_total, T, True)
+        assert torch.equal(torch.cat([r["state"] for r in got]).cpu(), ref["state"])
+        assert torch.equal(torch.cat([r["ancestors"] for r in got], dim=1).cpu(), ref["ancestors"])
+        assert all(r["log_z"] == ref["log_z"] for r in got)
+    assert [int(x) for x in arenas[1].flags[:world].cpu()] == [6 + 1 + 7 + 1 + 3 + 1] * world
+
+
+def test_peer_transport_collapsing_and_impossible_weights_on_device(hip_ops):
+    """The worst cases of the single-device step through the peer transport: weights collapsing onto one tile (every rank's
+    output tiles read ONE remote heavy tile) and an impossible observation (zero total mass: the population is kept)."""
+    from test_distributed_gloo import check_degenerate_sharded, check_impossible_observation_sharded
+
+    check_degenerate_sharded(hip_ops, 1, 4, native="peers")
+    check_impossible_observation_sharded(hip_ops, 1, 3, "peers")
+
+
+def test_peer_transport_full_size(hip_ops):
+    """2 x 1e6 particles over two virtual ranks (1954 tiles: the precomputed-prefix route with its wait launch), T = 12: the
+    peer transport equals the single-device filter on the same kernels."""
+    world, T = 2, 12
+    n_total = 2 * 977 * 1024
+    res = _run_virtual_ranks(hip_ops, "lgssm", 1, world, n_total, T, "ranges", native="peers")
+    ref = W.lgssm_smc(hip_ops, 1, 5, n_total, T, True)
+    assert torch.equal(torch.cat([r["state"] for r in res]), ref["state"])
+    assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1), ref["ancestors"])
+    for r in res:
+        assert torch.equal(r["out_q"], ref["out_q"]) and r["log_z"] == ref["log_z"]
+
+
+def test_peer_transport_lost_peer_on_device(hip_ops):
+    """A peer that never arrives: every workgroup's bounded wait gives up, the launches end, the error word is set and the
+    Python layer raises — the device is not left spinning."""
+    from genjax._amd import dist as gdist
+
+    world, n_total, T = 2, 1024 * 2 * 3, 3
+    arenas = gdist.PeerArena.virtual(hip_ops, world, n_total, [torch.float32], False)
+    comm = gdist.NativeComm.peers(hip_ops, arenas[0], None, False, timeout_ms=50)  # rank 1 never runs
+    smc = gdist.ShardedSMC(hip_ops, "lgssm", 1, 5, n_total, T, 0, world, False, arena=arenas[0])
+    with pytest.raises(RuntimeError, match="timed out"):
+        smc.run_native(comm)
+    assert float(torch.ones(100, device="cuda").sum().item()) == 100.0
+
+
+IPC_CHILD = r"""
+import ctypes as C, os, sys, time
+root, rank, world, outdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+sys.path.insert(0, os.path.join(root, "genjax-chi_amd"))
+import torch
+from genjax._amd import dist as gdist
+from genjax._amd.runtime import load_hip_ops
+
+ops = load_hip_ops()
+hip = C.CDLL("libamdhip64.so")
+kind, impl, seed, n_total, T = "lgssm", 1, 5, 1024 * world * 6, 8
+nbytes = gdist.PeerArena.nbytes(ops, n_total, [torch.float32], False)
+mine = C.c_void_p()
+assert hip.hipMalloc(C.byref(mine), C.c_size_t(nbytes)) == 0
+assert hip.hipMemset(mine, 0, C.c_size_t(nbytes)) == 0 and hip.hipDeviceSynchronize() == 0
+handle = (C.c_char * 64)()
+assert hip.hipIpcGetMemHandle(handle, mine) == 0, "hipIpcGetMemHandle"
+with open(os.path.join(outdir, f"h{rank}.tmp"), "wb") as f:
+    f.write(bytes(handle))
+os.rename(os.path.join(outdir, f"h{rank}.tmp"), os.path.join(outdir, f"h{rank}.bin"))
+
+def wait_for(name):
+    t0 = time.time()
+    while not os.path.exists(os.path.join(outdir, name)):
+        assert time.time() - t0 < 120, "peer did not show up: " + name
+        time.sleep(0.01)
+
+ptrs = [None] * world
+for o in range(world):
+    if o == rank:
+        ptrs[o] = mine.value
+        continue
+    wait_for(f"h{o}.bin")
+    hb = (C.c_char * 64).from_buffer_copy(open(os.path.join(outdir, f"h{o}.bin"), "rb").read())
+    p = C.c_void_p()
+    hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), C.c_char * 64, C.c_uint]
+    assert hip.hipIpcOpenMemHandle(C.byref(p), hb, 1) == 0, "hipIpcOpenMemHandle"
+    ptrs[o] = p.value
+
+class _Dev:
+    __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (mine.value, False), "version": 2}
+
+block = torch.as_tensor(_Dev(), device="cuda")
+arena = gdist.PeerArena(block, [ptrs[o] - mine.value for o in range(world)], rank, world)
+comm = gdist.NativeComm.peers(ops, arena, None, True, timeout_ms=60000)  # ranks share the device: a wait launch per step
+open(os.path.join(outdir, f"ready{rank}"), "w").close()
+for o in range(world):
+    wait_for(f"ready{o}")       # every arena is zeroed and mapped before anybody signals into it
+smc = gdist.ShardedSMC(ops, kind, impl, seed, n_total, T, rank, world, True, arena=arena)
+res = smc.run_native(comm)
+torch.cuda.synchronize()
+torch.save({k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in res.items() if k in ("state", "logw", "ancestors", "out_e", "out_q", "log_z")},
+           os.path.join(outdir, f"res{rank}.pt"))
+open(os.path.join(outdir, f"done{rank}"), "w").close()
+for o in range(world):
+    wait_for(f"done{o}")        # nobody unmaps / frees while a peer may still read
+print("ok", rank)
+"""
+
+
+def test_peer_transport_two_processes_one_gpu_ipc(tmp_path, oracle_ops):
+    """two REAL processes share the one GPU; each allocates its arena with hipMalloc, hands it to the
+    other through hipIpcGetMemHandle / hipIpcOpenMemHandle, and runs `gjx_smc_sharded_run_lgssm` over the peer transport
+    (wait launches in front of the steps, as the ranks compete for one device).  Particles, ancestors, (e, q) and log Z equal
+    the single-rank oracle filter bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    world = 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", IPC_CHILD, root, str(r), str(world), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = [torch.load(os.path.join(tmp_path, f"res{r}.pt")) for r in range(world)]
+    ref = W.lgssm_smc(oracle_ops, 1, 5, 1024 * world * 6, 8, True)
+    assert torch.equal(torch.cat([r["state"] for r in res]), ref["state"])
+    assert torch.equal(torch.cat([r["logw"] for r in res]), ref["logw"])
+    assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1), ref["ancestors"])
+    for r in res:
+        assert torch.equal(r["out_q"], ref["out_q"]) and torch.equal(r["out_e"], ref["out_e"]) and r["log_z"] == ref["log_z"]
