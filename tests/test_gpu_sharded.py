@@ -218,8 +218,14 @@ nbytes = gdist.PeerArena.nbytes(ops, n_total, [torch.float32], False)
 mine = C.c_void_p()
 assert hip.hipMalloc(C.byref(mine), C.c_size_t(nbytes)) == 0
 assert hip.hipMemset(mine, 0, C.c_size_t(nbytes)) == 0 and hip.hipDeviceSynchronize() == 0
-handle = (C.c_char * 64)()
-assert hip.hipIpcGetMemHandle(handle, mine) == 0, "hipIpcGetMemHandle"
+class IpcHandle(C.Structure):  # hipIpcMemHandle_t: 64 opaque bytes, passed BY VALUE to hipIpcOpenMemHandle
+    _fields_ = [("reserved", C.c_char * 64)]
+
+hip.hipIpcGetMemHandle.argtypes = [C.POINTER(IpcHandle), C.c_void_p]
+hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), IpcHandle, C.c_uint]
+handle = IpcHandle()
+rc = hip.hipIpcGetMemHandle(C.byref(handle), mine)
+assert rc == 0, f"hipIpcGetMemHandle -> {rc}"
 with open(os.path.join(outdir, f"h{rank}.tmp"), "wb") as f:
     f.write(bytes(handle))
 os.rename(os.path.join(outdir, f"h{rank}.tmp"), os.path.join(outdir, f"h{rank}.bin"))
@@ -236,10 +242,10 @@ for o in range(world):
         ptrs[o] = mine.value
         continue
     wait_for(f"h{o}.bin")
-    hb = (C.c_char * 64).from_buffer_copy(open(os.path.join(outdir, f"h{o}.bin"), "rb").read())
+    hb = IpcHandle.from_buffer_copy(open(os.path.join(outdir, f"h{o}.bin"), "rb").read())
     p = C.c_void_p()
-    hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), C.c_char * 64, C.c_uint]
-    assert hip.hipIpcOpenMemHandle(C.byref(p), hb, 1) == 0, "hipIpcOpenMemHandle"
+    rc = hip.hipIpcOpenMemHandle(C.byref(p), hb, 1)  # hipIpcMemLazyEnablePeerAccess
+    assert rc == 0, f"hipIpcOpenMemHandle -> {rc}"
     ptrs[o] = p.value
 
 class _Dev:
