@@ -404,6 +404,127 @@ def bench_smc_sharded(args, ops, rank, world, kind):
     return res
 
 
+def bench_sharded_rank0_virtual(args, ops, world=8, steps=40):
+    """what ONE rank of BASELINE configs[3] costs per step, measured on the one GPU.  A world-8 filter of
+    8 x 1e6 particles (7 816 tile records: beyond the 1024 a workgroup merges itself) is stepped by 8 VIRTUAL ranks — threads
+    of this process whose launches share the device and one stream, so they execute back to back and the device time of the
+    whole run divided by (8 x steps) is what one rank's launches of one step take on a GPU of its own, less the xGMI latency
+    of its remote windows (one device cannot show that).  Two transports: the peer transport (per step and rank: group-record
+    launch that first waits for the peers + step launch reading remote windows where they live + signal launch writing the
+    records into all 8 arenas; no collective) and the collective protocol over the virtual-rank copy transport (the kernels an
+    RCCL rank launches: group records + step + range kernel, with device copies standing in for the all-gather and the
+    send/recv).  Host time per step: rank 0's enqueue loop run alone (what the CPU spends per step and rank)."""
+    import ctypes as C
+    import threading
+
+    import torch
+
+    from genjax._amd import dist as gdist, prng, workloads as W
+    from genjax._amd.ops import HipEvent
+
+    impl = 1 if args.rng == "philox" else 0
+    n = -(-args.particles // ops.tile) * ops.tile
+    n_total = n * world
+    out = {}
+
+    def run_ranks(make, T):
+        res, err = [None] * world, []
+
+        def work(r):
+            try:
+                res[r] = make(r, T)()
+            except BaseException as e:  # noqa: BLE001
+                err.append(e)
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        if err:
+            raise err[0]
+        return res
+
+    arenas = gdist.PeerArena.virtual(ops, world, n_total, [torch.float32], False)
+    pcomms = gdist.NativeComm.peers_virtual(ops, arenas, timeout_ms=20000)
+    lcomms = gdist.NativeComm.local_group(ops, world)
+    sh = gdist.ThreadComm.Shared(world)
+
+    def make_peers(r, T):
+        smc = gdist.ShardedSMC(ops, "lgssm", impl, 1, n_total, T, r, world, arena=arenas[r])
+        return lambda: smc.run_native(pcomms[r])
+
+    lsmc = {}
+
+    def make_local(r, T):
+        if (r, T) not in lsmc:
+            lsmc[(r, T)] = gdist.ShardedSMC(ops, "lgssm", impl, 1, n_total, T, r, world, comm=gdist.ThreadComm(sh, r))
+        return lambda: lsmc[(r, T)].run_native(lcomms[r])
+
+    # both transports step the same filter: equal results
+    log_z = {}
+    for name, make in (("peers", make_peers), ("collective_protocol_virtual", make_local)):
+        log_z[name] = run_ranks(make, 3)[0]["log_z"]
+    torch.cuda.synchronize()
+    # ---- device and host time of ONE rank's launches: rank 0 alone repeats step t = 3 of the peer run above (it reads
+    # population 0 — step 2's, complete and consistent in every arena — and writes its own block of population 1), its
+    # peers' arrival words raised once so that nothing waits; the same loop without the peer descriptor runs the kernels of
+    # a collective rank on the local arrays (the tiles a shuffle would have delivered copied in first)
+    for a in arenas:
+        a.flags.fill_(1 << 62)
+    T0 = 3
+    sk, rk = W.smc_key_schedule(prng.key(1, impl), T0 + 1)
+    y = W.lgssm_data(T0 + 1)
+    model = W.lgssm_model()
+    tl = n // ops.tile
+    pops = arenas[0]._pops
+    for col0, col1 in zip(pops[0].columns() + [pops[0].subs], arenas[1]._pops[0].columns() + [arenas[1]._pops[0].subs]):
+        k = 16 * (ops.tile if col0.shape[0] == n_total else 1)  # rank 1's first 16 tiles: what rank 0's last windows read
+        a0 = n if col0.shape[0] == n_total else tl
+        col0[a0:a0 + k].copy_(col1[a0:a0 + k])
+    pst = arenas[0].peers_struct(20000)
+    pst.wait_value = 1
+    ranges = torch.zeros(2 * world + 1, dtype=torch.int64).pin_memory()
+    for name in ("peers", "collective_kernels"):
+        cfg = ops.smc_config(impl, n_total, 0, n, sk, rk)
+        if name == "peers":
+            cfg.peers = C.pointer(pst)
+
+        def block(kk):
+            for _ in range(kk):
+                ops.smc_lgssm_step(cfg, model, T0, float(y[T0]), pops[0].struct(), pops[1].struct(0, with_logw=False), None, None, None)
+                if name == "peers":
+                    ops.lib.call("gjx_smc_peer_signal", C.byref(pst), ops._p(pops[1].recs), None, 0, tl, 1 << 62, ops.stream())
+                else:
+                    ops.smc_source_ranges(cfg, pops[1].recs, None, world, ranges, 1)
+
+        block(4)
+        torch.cuda.synchronize()
+        dev, host = [], []
+        for _ in range(12):
+            e0, e1 = HipEvent(), HipEvent()
+            e0.record(ops.stream())
+            t0 = time.perf_counter()
+            block(steps)
+            host.append((time.perf_counter() - t0) / steps)
+            e1.record(ops.stream())
+            torch.cuda.synchronize()
+            dev.append(e0.elapsed_ms(e1) / steps)
+        out[name] = {"step_us_device": statistics.median(dev) * 1e3, "host_us_per_step": statistics.median(host) * 1e6}
+    arenas[0].check(ops)
+    out["peers"].update(launches_per_step=3, collectives_per_step=0, host_decisions_per_step=0,
+                        what="group-record launch (waits for the peers; 31 workgroups) + step launch (remote windows read in place) + signal launch (records into 8 arenas)")
+    out["collective_kernels"].update(
+        launches_per_step=3, collectives_per_step=2, host_decisions_per_step=1,
+        what="group records + step + range kernel: what an RCCL rank launches; on top come 1 all-gather + 1 grouped send/recv (20-50 us each on xGMI) and the host's poll of the range ticket")
+    out["rccl_collectives_per_step"] = {"all_gather": 1, "grouped_send_recv": 1, "host_polls": 1,
+                                        "r03": {"all_gather": 2, "grouped_send_recv": 1, "host_polls": 1}}
+    out["log_z_equal_across_transports"] = log_z["peers"] == log_z["collective_protocol_virtual"]
+    out["config"] = {"world": world, "n_total": n_total, "particles_per_rank": n, "tiles": n_total // ops.tile, "steps_timed": steps,
+                     "virtual_ranks": "threads of this process on ONE device, one stream", "log_z_3_steps": log_z["peers"]}
+    out["value"] = n / (out["peers"]["step_us_device"] * 1e-6)
+    out["unit"] = "particle-steps/s per rank (peer transport; one device, no xGMI latency)"
+    return out
+
+
 def bench_smc(args, ops, kind, filters=1, min_s=0.08, variant=None, T=None):
     """Single device: `filters` independent filters (seeds s, s+1, ...) step in the same launches; filters=1 is
     the literal BASELINE config.  A "step" of the protocol here is one whole T-step filter run (one enqueue).
@@ -924,7 +1045,9 @@ def _short(e, per="step_ms"):
     if "error" in e:
         return {"error": str(e["error"])[:120]}
     o = {}
-    for k in ("value", "unit", "us_per_call", "kernel_ms", "resampling_steps", "ratio_to_normal_step", "step_ms", "normal_step_ms"):
+    for k in ("value", "unit", "us_per_call", "kernel_ms", "resampling_steps", "ratio_to_normal_step", "step_ms", "normal_step_ms",
+              "step_us_device", "host_us_per_step", "launches_per_step", "collectives_per_step", "host_decisions_per_step",
+              "transport", "log_z_equal_across_transports"):
         if k in e:
             o[k] = e[k]
     rf = e.get("roofline") or {}
@@ -1007,7 +1130,8 @@ def compact_line(out, extra, args):
         elif name == "smc_lgssm_sharded" and isinstance(e, dict) and "value" in e:
             configs[f"configs[3] SMC LGSSM T=100 1e6 per GPU x{out['n_gpus']}"] = config_entry(e)
         if isinstance(e, dict):
-            sub = {k: _short(v) for k, v in e.items() if isinstance(v, dict) and ("value" in v or "error" in v) and k not in ("roofline", "cpu_baseline", "config")}
+            sub = {k: _short(v) for k, v in e.items() if isinstance(v, dict) and ("value" in v or "error" in v or "step_us_device" in v)
+                   and k not in ("roofline", "cpu_baseline", "config")}
             small[name] = dict(_short(e), **sub)
     if small:
         line["extra"] = small
@@ -1087,6 +1211,12 @@ def run_rank(args):
                     "distinct_ancestors_at_step_2": int(anc[2].unique().numel()), "steps": len(yc)}
             except Exception as ex:
                 extra["smc_lgssm_collapsing_weights"] = {"error": f"{type(ex).__name__}: {ex}"}
+            # one rank of BASELINE configs[3] on this device: the world-8 step through the peer transport and through the kernels
+            # a collective transport launches
+            try:
+                extra["smc_sharded_rank0_of_8_virtual"] = bench_sharded_rank0_virtual(args, ops)
+            except Exception as ex:
+                extra["smc_sharded_rank0_of_8_virtual"] = {"error": f"{type(ex).__name__}: {ex}"}
             # ImportanceK over a Scan model: the reference's literal semantics of the state-space configs (no resampling)
             try:
                 extra["importance_scan_lgssm"] = bench_scan(args, ops)

@@ -1014,6 +1014,8 @@ constexpr int kScanLanes = GJX_SCAN_LANES;  // lanes of the workgroup that scan 
 constexpr int kWindow = 8 * kScanLanes;      // sources one round of the window scan covers: 1.5 tiles (the slots of an
                                              // output tile draw from ~1024 + 64 sources; a wider window only reads more)
 constexpr int kScanMax = 4;           // rounds of the window scan before an output tile searches per slot
+constexpr int kGroupTiles = 256;      // r04, populations beyond kMaxLdsTiles: tiles per GROUP record (k_group_records)
+constexpr int kMaxGroups = 256;       // groups a workgroup merges (one per thread): up to 65 536 tiles (67M particles)
 constexpr int kSubs = 16;             // sub-prefixes per tile: the running sum of q after every 64th particle
 constexpr int kSubLen = kTile / kSubs;
 // A tile's record is kept as three DENSE arrays indexed by tile — the 16-byte header every workgroup merges (a strided
@@ -1029,6 +1031,17 @@ struct alignas(16) TileSub {
 };
 struct alignas(16) TileEss {
   uint64_t r1, r2;        // ESS sums of the tile (tile-anchored): sum r_i, sum r_i^2, r_i = q_i >> 14
+};
+// r04: the record of a GROUP of kGroupTiles consecutive tiles, anchored at the group's own maximum e: for EVERY shift D of
+// that anchor (the merged anchor of a population is e + D for some D >= 0) the group's merged mass, sum over its tiles of
+// S_t >> (e - e_t + D) — the per-tile floors summed, so a consumer that picks entry D gets exactly the sum of the masses it
+// would have computed tile by tile — and likewise the ESS sums (r1: shift by d, r2: by 2 d).  D >= 64: nothing is left.
+struct alignas(16) GroupRec {
+  uint64_t mass[64];
+  uint64_t r1[64];
+  uint64_t r2[64];
+  int32_t e;              // kRowEmpty: no mass in the group
+  int32_t pad[3];
 };
 static_assert(sizeof(TileRec) == 16 && sizeof(TileSub) == 128 && sizeof(TileEss) == 16, "gjx.h gjx_tile_rec / gjx_tile_sub / gjx_tile_ess");
 // shift of a tile's fixed point relative to the merged anchor e (>= every e_t): 64 = the tile carries no mass
@@ -1077,6 +1090,9 @@ GJX_DEV bool peer_wait_wave(const PeerMap& pm) {
     if (ready) break;
     if (__builtin_amdgcn_s_memrealtime() - t0 > pm.timeout_ticks) break;
     __builtin_amdgcn_s_sleep(16);
+    // a peer's store reaches this device's memory without passing through its caches: the next poll must not be served by a
+    // line cached before it (whatever the memory type of the arena)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
   if (ready) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -1112,7 +1128,8 @@ struct ResampleArgs {
   int32_t* e_out = nullptr;             // nullable: workgroup 0 stores the merged anchor of the source weights
   uint64_t* q_out = nullptr;            // nullable: ... and their total mass
   int32_t* resampled_out = nullptr;     // nullable: workgroup 0 of each filter stores 1 (resampled) / 0 (kept)
-  const uint64_t* prefix = nullptr;     // nullable: [prefix_words(ntiles)] (k_scan_records); required beyond kMaxLdsTiles
+  const uint64_t* prefix = nullptr;     // nullable: [prefix_words(ntiles)] (k_scan_records): filter batches, populations beyond kMaxGroups groups
+  const GroupRec* groups = nullptr;     // nullable (r04): [ceil(ntiles / kGroupTiles)] group records: the route of populations beyond kMaxLdsTiles
   FilterBatch fb;                       // several filters per launch (n, ntiles, n_out, out_lo/out_hi are then PER FILTER)
   double ess_thr = 0.0;                 // threshold * n_total, 0 = resample always
   // what the step emits for the NEXT resampling (policies with weights)
@@ -1576,6 +1593,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   __shared__ int32_t sh_e[kW];
   __shared__ uint32_t sh_u[kW];
   __shared__ uint32_t sh_klo, sh_cov[2];
+  __shared__ uint64_t sh_gpre[kMaxGroups + 1];   // grouped route: merged exclusive prefix of the GROUP masses
   __shared__ int64_t sh_delta[PEERS ? kMaxPeers : 1];
   __shared__ uint32_t sh_peer_ok;
   static_assert(kPer == 4, "four consecutive output slots per lane");
@@ -1585,8 +1603,10 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // nothing of the source population is read before every peer has arrived (bounded; a timeout ends the launch)
     if (tid < kMaxPeers) sh_delta[tid] = tid < A.pm.world ? A.pm.delta[tid] : 0;
+    // (wait_value 0: a launch in front of this one on the stream has already waited and acquired — the group-record launch
+    // of a large population, or the transport's wait launch — and the kernel boundary hands that to this launch)
     if (wv == 0) {
-      const bool ready = peer_wait_wave(A.pm);
+      const bool ready = A.pm.wait_value == 0 || peer_wait_wave(A.pm);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the acquire's invalidate has completed before the barrier releases the others)
       if (lane == 0) sh_peer_ok = ready ? 1u : 0u;
     }
@@ -1652,17 +1672,37 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   const int32_t n_out = (int32_t)A.n_out;
 
   // ---- the source records (issued first; the policy's ancestor-independent work runs under their latency) --------
+  // Three routes to the merged prefix of the source tiles' masses (launch-uniform):
+  //   LDS      (ntiles <= kMaxLdsTiles): every workgroup merges ALL tile records itself;
+  //   grouped  (r04, A.groups: larger populations — one rank of BASELINE configs[3] merges 7 816 records): the workgroup
+  //            merges the GROUP records (k_group_records: one per 256 tiles, the group's mass for every shift of its
+  //            anchor), finds the group that holds its first tooth, and then merges only the 1024 tile records from that
+  //            group on, exactly as the LDS route does — same integers, no serial whole-population scan, no search of a
+  //            prefix array in memory;
+  //   prefix   (A.prefix: batches of >= 4 filters, and populations beyond kMaxGroups groups): a precomputed global prefix.
   constexpr int kC = kMaxLdsTiles / kBlock;  // tiles per thread of the in-kernel merge
-  const bool lds_prefix = prefix == nullptr;  // (launch-uniform)
-  const uint64_t c_per = (A.ntiles + kBlock - 1) / kBlock;
-  const uint64_t k0 = (uint64_t)tid * c_per;
+  const bool grouped = A.groups != nullptr;       // (launch-uniform)
+  const bool lds_prefix = prefix == nullptr;      // (launch-uniform; true for the LDS and the grouped route)
+  const uint64_t ngroups = grouped ? (A.ntiles + kGroupTiles - 1) / kGroupTiles : 0;  // <= kMaxGroups = kBlock: one per thread
+  // the tiles whose prefix will live in LDS: [k_base, k_base + nrange).  Grouped route: SPECULATIVELY the four groups around
+  // the output tile's own position (ancestors stay near their slots unless the weights are very uneven), so that the tile
+  // records are in flight together with the group records; the group merge then says whether the guess holds
+  uint64_t k_base = 0, nrange = A.ntiles;
+  if (grouped) {
+    const uint64_t g_own = ot / kGroupTiles;
+    k_base = (g_own > 0 ? g_own - 1 : 0) * kGroupTiles;
+    if (k_base >= A.ntiles) k_base = (ngroups - 1) * kGroupTiles;
+    nrange = A.ntiles - k_base < (uint64_t)kMaxLdsTiles ? A.ntiles - k_base : (uint64_t)kMaxLdsTiles;
+  }
+  uint64_t c_per = (nrange + kBlock - 1) / kBlock;
+  uint64_t k0 = (uint64_t)tid * c_per;
   uint64_t rs_[kC], ev1[kC], ev2[kC];
   int32_t re_[kC];
-  if (lds_prefix) {
+  auto load_range = [&]() {  // the tile records of the range, contiguous per thread
 #pragma unroll
     for (int i = 0; i < kC; ++i) {
-      const uint64_t k = k0 + i;
-      const bool in = (uint64_t)i < c_per && k < A.ntiles;
+      const uint64_t k = k_base + k0 + i;
+      const bool in = (uint64_t)i < c_per && k0 + i < nrange;
       if (in) {
         const uint4 raw = *reinterpret_cast<const uint4*>(recs + k);
         rs_[i] = ((uint64_t)raw.y << 32) | raw.x;
@@ -1671,10 +1711,21 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         rs_[i] = 0;
         re_[i] = kRowEmpty;
       }
-      ev1[i] = adaptive && in ? ess[k].r1 : 0;
-      ev2[i] = adaptive && in ? ess[k].r2 : 0;
+      ev1[i] = adaptive && !grouped && in ? ess[k].r1 : 0;
+      ev2[i] = adaptive && !grouped && in ? ess[k].r2 : 0;
     }
+  };
+  // grouped route: thread g < ngroups holds group g's anchor and — speculatively — its masses for the shifts 0 and 1 of that
+  // anchor (practically every group's anchor is the population's or one below; other shifts cost a second trip)
+  int32_t ge = kRowEmpty;
+  uint64_t gm0 = 0, gm1 = 0, g10 = 0, g11 = 0, g20 = 0, g21 = 0;
+  if (grouped && (uint64_t)tid < ngroups) {
+    const GroupRec* gr = A.groups + tid;
+    ge = gr->e;
+    gm0 = gr->mass[0]; gm1 = gr->mass[1];
+    if (adaptive) { g10 = gr->r1[0]; g11 = gr->r1[1]; g20 = gr->r2[0]; g21 = gr->r2[1]; }
   }
+  if (lds_prefix) load_range();
 #pragma unroll
   for (int r = 0; r < kPer; ++r) marks[tid + r * kBlock] = 0;
   if (tid == 0) sh_klo = ~0u;
@@ -1686,25 +1737,31 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   uint64_t tot = 0, r1 = 0, r2 = 0;
   uint64_t mass[kC];
   uint64_t chunk_pre = 0, chunk_mass = 0;
-  if (lds_prefix) {
-#pragma unroll
-    for (int i = 0; i < kC; ++i) e = re_[i] > e ? re_[i] : e;
-    e = (int32_t)(wave_last_u32(wave_scan_u32((uint32_t)e ^ 0x80000000u, 0u, [](uint32_t a, uint32_t x) { return x > a ? x : a; })) ^ 0x80000000u);
-    if (lane == 0) sh_e[wv] = e;
+  uint64_t p_base = 0;  // mass before tile k_base (grouped route)
+  // the workgroup's anchor: max of one int32 per thread
+  auto block_anchor = [&](int32_t mine) -> int32_t {
+    int32_t m = (int32_t)(wave_last_u32(wave_scan_u32((uint32_t)mine ^ 0x80000000u, 0u, [](uint32_t a, uint32_t x) { return x > a ? x : a; })) ^ 0x80000000u);
+    if (lane == 0) sh_e[wv] = m;
     __syncthreads();
-    e = sh_e[0];
+    m = sh_e[0];
 #pragma unroll
-    for (int i = 1; i < kW; ++i) e = sh_e[i] > e ? sh_e[i] : e;
-    uint64_t l1 = 0, l2 = 0;
-    int dsh[kC];
-#pragma unroll
-    for (int i = 0; i < kC; ++i) {
-      dsh[i] = tile_shift(e, re_[i]);
-      mass[i] = shr64(rs_[i], dsh[i]);
-      chunk_mass += mass[i];
-      if (adaptive) { l1 += shr64(ev1[i], dsh[i]); l2 += shr64(ev2[i], 2 * dsh[i]); }
+    for (int i = 1; i < kW; ++i) m = sh_e[i] > m ? sh_e[i] : m;
+    return m;
+  };
+  if (grouped) {
+    // ---- group level: the anchor is the maximum of the groups' anchors; a group's mass under it is entry (e - e_g) of the
+    // group's table (exact: the table holds the sum of the group's per-tile shifted masses for every shift)
+    e = block_anchor(ge);
+    const int dg = tile_shift(e, ge);
+    uint64_t gm = dg == 0 ? gm0 : gm1, l1 = dg == 0 ? g10 : g11, l2 = dg == 0 ? g20 : g21;
+    if (dg >= 64 || (uint64_t)tid >= ngroups) {
+      gm = 0; l1 = 0; l2 = 0;
+    } else if (dg > 1) {  // (rare: a group whose best weight is 4x or more below the population's)
+      const GroupRec* gr = A.groups + tid;
+      gm = gr->mass[dg];
+      if (adaptive) { l1 = gr->r1[dg]; l2 = gr->r2[dg]; }
     }
-    const uint64_t incl = wave_scan_incl(chunk_mass);
+    const uint64_t incl = wave_scan_incl(gm);
     if (adaptive) { l1 = wave_sum(l1); l2 = wave_sum(l2); }
     if (lane == 63) {
       sh_scan[wv] = incl;
@@ -1718,18 +1775,77 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
       tot += sh_scan[i];
       if (adaptive) { r1 += sh_scan[kW + i]; r2 += sh_scan[2 * kW + i]; }
     }
-    chunk_pre = wbase + incl - chunk_mass;
+    if ((uint64_t)tid < ngroups) sh_gpre[tid] = wbase + incl - gm;
+    if (tid == 0) sh_gpre[ngroups] = tot;
+    __syncthreads();
+    // ---- the group that holds the first tooth of [j0, j1): the first group whose END has more than j0 teeth below it
+    if (tot != 0 && (!adaptive || ess_says_resample(r1, r2, A.ess_thr))) {
+      const double gscale = (double)A.n_out / (double)tot;
+      if ((uint64_t)tid < ngroups) {
+        const uint64_t g = tid;
+        const int32_t hi_g = g + 1 >= ngroups ? n_out : comb_tile(sh_gpre[g + 1], gscale, u0, n_out);
+        const int32_t lo_g = comb_tile(sh_gpre[g], gscale, u0, n_out);
+        if (hi_g > j0 && (g == 0 || lo_g <= j0)) atomicMin(&sh_klo, (uint32_t)g);
+      }
+      __syncthreads();
+      const uint64_t g_lo = sh_klo < ngroups ? sh_klo : ngroups - 1;
+      __syncthreads();
+      if (tid == 0) sh_klo = ~0u;
+      // the guess holds when the range starts at or before g_lo and keeps >= two groups (512 tiles; a window is < 8) behind its
+      // start — or reaches the population's end; otherwise the range is re-loaded from g_lo on (a dependent trip, rare)
+      const uint64_t kb = g_lo * kGroupTiles;
+      if (!(k_base <= kb && (kb + 2 * kGroupTiles <= k_base + nrange || k_base + nrange >= A.ntiles))) {
+        k_base = kb;
+        nrange = A.ntiles - k_base < (uint64_t)kMaxLdsTiles ? A.ntiles - k_base : (uint64_t)kMaxLdsTiles;
+        c_per = (nrange + kBlock - 1) / kBlock;
+        k0 = (uint64_t)tid * c_per;
+        load_range();
+      }
+    }
+    p_base = sh_gpre[k_base / kGroupTiles];
+  }
+  if (lds_prefix) {
+    if (!grouped) {
+#pragma unroll
+      for (int i = 0; i < kC; ++i) e = re_[i] > e ? re_[i] : e;
+      e = block_anchor(e);
+    }
+    uint64_t l1 = 0, l2 = 0;
+    int dsh[kC];
+#pragma unroll
+    for (int i = 0; i < kC; ++i) {
+      dsh[i] = tile_shift(e, re_[i]);
+      mass[i] = shr64(rs_[i], dsh[i]);
+      chunk_mass += mass[i];
+      if (adaptive && !grouped) { l1 += shr64(ev1[i], dsh[i]); l2 += shr64(ev2[i], 2 * dsh[i]); }
+    }
+    const uint64_t incl = wave_scan_incl(chunk_mass);
+    if (adaptive && !grouped) { l1 = wave_sum(l1); l2 = wave_sum(l2); }
+    if (grouped) __syncthreads();  // (sh_scan was read by the group level)
+    if (lane == 63) {
+      sh_scan[wv] = incl;
+      if (adaptive && !grouped) { sh_scan[kW + wv] = l1; sh_scan[2 * kW + wv] = l2; }
+    }
+    __syncthreads();
+    uint64_t wbase = 0, range_tot = 0;
+#pragma unroll
+    for (int i = 0; i < kW; ++i) {
+      if (i < wv) wbase += sh_scan[i];
+      range_tot += sh_scan[i];
+      if (adaptive && !grouped) { r1 += sh_scan[kW + i]; r2 += sh_scan[2 * kW + i]; }
+    }
+    if (!grouped) tot = range_tot;
+    chunk_pre = p_base + wbase + incl - chunk_mass;
     uint64_t run = chunk_pre;
 #pragma unroll
     for (int i = 0; i < kC; ++i) {
-      const uint64_t k = k0 + i;
-      if ((uint64_t)i < c_per && k < A.ntiles) {
-        sh_pre[k] = run;
-        sh_d[k] = (uint8_t)dsh[i];
+      if ((uint64_t)i < c_per && k0 + i < nrange) {
+        sh_pre[k0 + i] = run;
+        sh_d[k0 + i] = (uint8_t)dsh[i];
         run += mass[i];
       }
     }
-    if (tid == 0) sh_pre[A.ntiles] = tot;
+    if (tid == 0) sh_pre[nrange] = p_base + range_tot;
   } else {
     tot = prefix[A.ntiles];
     e = (int32_t)(int64_t)prefix[A.ntiles + 1];
@@ -1744,8 +1860,10 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   policy_stage(P, 0);  // (every path below passes a barrier before the policy computes)
   GJX_DBG_STOP(A, 1);
 
-  auto pre_at = [&](uint64_t k) -> uint64_t { return lds_prefix ? sh_pre[k] : prefix[k]; };
-  auto shift_at = [&](uint64_t k) -> int { return lds_prefix ? (int)sh_d[k] : tile_shift(e, recs[k].e); };
+  // the merged prefix / shift of tile k: LDS for the tiles of the range (every tile on the LDS route), memory on the prefix route
+  const uint64_t k_end = k_base + nrange;  // (LDS routes) one past the last tile whose prefix is in LDS
+  auto pre_at = [&](uint64_t k) -> uint64_t { return lds_prefix ? sh_pre[k - k_base] : prefix[k]; };
+  auto shift_at = [&](uint64_t k) -> int { return lds_prefix ? (int)sh_d[k - k_base] : tile_shift(e, recs[k].e); };
 
   uint32_t anc[kPer];
   bool ok[kPer];
@@ -1781,13 +1899,13 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     if (lds_prefix) {
       __syncthreads();  // sh_pre / sh_d complete
       // (monotone: the chunk of tiles that holds k_lo is the one whose start lies at or below j0 and whose end beyond it;
-      // only that thread walks its tiles)
-      const uint64_t k1 = k0 + c_per < A.ntiles ? k0 + c_per : A.ntiles;
+      // only that thread walks its tiles.  Grouped route: k_lo lies in the range's first group.)
+      const uint64_t r0 = k0, r1_ = k0 + c_per < nrange ? k0 + c_per : nrange;  // the thread's tiles, relative to k_base
       const int32_t c_lo = comb_tile(chunk_pre, scale, u0, n_out);
-      const int32_t c_hi = k1 >= A.ntiles ? n_out : comb_tile(chunk_pre + chunk_mass, scale, u0, n_out);
-      if (k0 < A.ntiles && c_lo <= j0 && c_hi > j0) {
-        for (uint64_t k = k0; k < k1; ++k) {
-          const int32_t hi_t = k + 1 >= A.ntiles ? n_out : comb_tile(sh_pre[k + 1], scale, u0, n_out);
+      const int32_t c_hi = k_base + r1_ >= A.ntiles ? n_out : comb_tile(chunk_pre + chunk_mass, scale, u0, n_out);
+      if (r0 < nrange && (c_lo <= j0 || (grouped && r0 == 0 && k_base == 0)) && c_hi > j0) {
+        for (uint64_t k = r0; k < r1_; ++k) {
+          const int32_t hi_t = k_base + k + 1 >= A.ntiles ? n_out : comb_tile(sh_pre[k + 1], scale, u0, n_out);
           if (hi_t > j0) {
             atomicMin(&sh_klo, (uint32_t)k);
             break;
@@ -1795,7 +1913,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
         }
       }
       __syncthreads();
-      k_lo = sh_klo;
+      k_lo = k_base + (sh_klo < nrange ? sh_klo : nrange - 1);
     } else if (A.ntiles <= (uint64_t)(kWave * 16)) {
       // a precomputed prefix of up to 1024 tiles (filter batches): ONE wave samples every 16th entry, then the 16 entries
       // of the bracket — two small loads instead of every thread reading its share of the whole prefix
@@ -1920,15 +2038,42 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
 #pragma unroll 1
       for (int r = 0; r < kPer; ++r) {
         const int64_t j = jq + r;
-        uint64_t tl = k_lo, th = A.ntiles - 1;
-        while (tl < th) {
-          const uint64_t mid = (tl + th) >> 1;
-          if ((int64_t)nhi_of(mid) > j) th = mid;
-          else tl = mid + 1;
+        uint64_t k, pk;   // the slot's source tile, the mass before it
+        int dk;           // ... its shift
+        int32_t nhi;      // ... teeth below its end
+        if (grouped && k_end < A.ntiles && (int64_t)nhi_of(k_end - 1) <= j) {
+          // (grouped route, rarer still: the slot's tooth lies beyond the 1024 tiles whose prefix is in LDS — the first
+          // group whose end has more than j teeth below it, by binary search of the group prefix; then a walk over that
+          // group's tile records: at most kGroupTiles loads, the same shifted masses)
+          uint64_t gl = k_end / kGroupTiles, gh = ngroups - 1;
+          while (gl < gh) {
+            const uint64_t mid = (gl + gh) >> 1;
+            const int32_t hi_g = mid + 1 >= ngroups ? n_out : comb_tile(sh_gpre[mid + 1], scale, u0, n_out);
+            if ((int64_t)hi_g > j) gh = mid;
+            else gl = mid + 1;
+          }
+          uint64_t t = gl * kGroupTiles;
+          const uint64_t t_end = t + kGroupTiles < A.ntiles ? t + kGroupTiles : A.ntiles;
+          uint64_t run = sh_gpre[gl];
+          k = t_end - 1; pk = run; dk = 64; nhi = n_out;
+          bool hit = false;
+          for (; t < t_end; ++t) {
+            const int d = tile_shift(e, recs[t].e);
+            const uint64_t m = shr64(recs[t].s, d);
+            const int32_t hi_t = t + 1 >= A.ntiles ? n_out : comb_tile(run + m, scale, u0, n_out);
+            if (!hit && ((int64_t)hi_t > j || t + 1 == t_end)) { k = t; pk = run; dk = d; nhi = hi_t; hit = true; }
+            run += m;
+          }
+        } else {
+          uint64_t tl = k_lo, th = (lds_prefix ? k_end : A.ntiles) - 1;
+          while (tl < th) {
+            const uint64_t mid = (tl + th) >> 1;
+            if ((int64_t)nhi_of(mid) > j) th = mid;
+            else tl = mid + 1;
+          }
+          k = tl; pk = pre_at(k); dk = shift_at(k); nhi = nhi_of(k);
         }
-        const uint64_t k = tl;
-        const double scale_t = comb_tile_scale(scale, shift_at(k)), tb = comb_base(pre_at(k), scale, u0);
-        const int32_t nhi = nhi_of(k);
+        const double scale_t = comb_tile_scale(scale, dk), tb = comb_base(pk, scale, u0);
         const uint64_t tbase = k * kTile;
         const uint64_t cnt = tbase + kTile <= A.n ? (uint64_t)kTile : A.n - tbase;  // real particles of the tile
         // block: the first 64-particle block whose END has more than j teeth below it (the tile's last block at the latest)

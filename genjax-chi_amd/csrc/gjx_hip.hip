@@ -732,6 +732,196 @@ __global__ __launch_bounds__(kBlock) void k_scan_records(const TileRec* recs, co
   }
 }
 
+// r04: the same merge for LARGE populations (beyond kMaxLdsTiles: the precomputed-prefix route of every step of such a filter,
+// e.g. one rank of BASELINE configs[3], 7 816 records).  k_scan_records walks a strided chunk per thread three times, one
+// dependent 16-byte load at a time: 29 us at 7 816 records — more than two step kernels.  Here 1024 threads hold a CONTIGUOUS
+// chunk of up to kBigPer records each in registers (every load issued before the first use: one memory latency), the
+// anchor, the scan and the stores work on registers.  Same integers, same layout.  `pm` (peer transport): the records in
+// this rank's arena are complete only once every peer has arrived, so wave 0 first waits (bounded) — the wait launch and the
+// merge launch of a peer step are ONE launch.
+constexpr int kBigBlock = 1024;
+constexpr int kBigPer = 16;  // -> up to 16 384 tiles (16.7M particles) per filter; beyond that k_scan_records serves
+template <bool ESS>
+__global__ __launch_bounds__(kBigBlock) void k_scan_records_big(const TileRec* recs, const TileEss* ess, uint64_t ntiles, uint64_t* prefix,
+                                                                PeerMap pm) {
+  constexpr int kW = kBigBlock / kWave;
+  __shared__ uint64_t sh_s[3 * kW];
+  __shared__ int32_t sh_e[kW];
+  __shared__ uint32_t sh_ok;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  if (pm.world > 0) {
+    if (wv == 0) {
+      const bool ready = peer_wait_wave(pm);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) sh_ok = ready ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!sh_ok) return;
+  }
+  const uint64_t per = (ntiles + kBigBlock - 1) / kBigBlock;  // <= kBigPer (checked by the host)
+  const uint64_t lo = (uint64_t)tid * per;
+  uint64_t sv[kBigPer], r1v[ESS ? kBigPer : 1], r2v[ESS ? kBigPer : 1];
+  int32_t ev[kBigPer];
+#pragma unroll
+  for (int i = 0; i < kBigPer; ++i) {
+    const uint64_t k = lo + i;
+    const bool in = (uint64_t)i < per && k < ntiles;
+    if (in) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(recs + k);
+      sv[i] = ((uint64_t)raw.y << 32) | raw.x;
+      ev[i] = (int32_t)raw.z;
+    } else {
+      sv[i] = 0;
+      ev[i] = kRowEmpty;
+    }
+    if (ESS) {
+      r1v[i] = in ? ess[k].r1 : 0;
+      r2v[i] = in ? ess[k].r2 : 0;
+    }
+  }
+  int32_t e = kRowEmpty;
+#pragma unroll
+  for (int i = 0; i < kBigPer; ++i) e = ev[i] > e ? ev[i] : e;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int32_t o = __shfl_xor(e, off, kWave);
+    e = o > e ? o : e;
+  }
+  if (lane == 0) sh_e[wv] = e;
+  __syncthreads();
+  e = sh_e[0];
+#pragma unroll
+  for (int i = 1; i < kW; ++i) e = sh_e[i] > e ? sh_e[i] : e;
+  uint64_t local = 0, l1 = 0, l2 = 0;
+#pragma unroll
+  for (int i = 0; i < kBigPer; ++i) {
+    const int d = tile_shift(e, ev[i]);
+    sv[i] = shr64(sv[i], d);  // the tile's shifted mass
+    local += sv[i];
+    if (ESS) {
+      l1 += shr64(r1v[i], d);
+      l2 += shr64(r2v[i], 2 * d);
+    }
+  }
+  const uint64_t incl = wave_scan_incl(local);
+  if (ESS) {
+    l1 = wave_sum(l1);
+    l2 = wave_sum(l2);
+  }
+  if (lane == 63) { sh_s[wv] = incl; sh_s[kW + wv] = l1; sh_s[2 * kW + wv] = l2; }
+  __syncthreads();
+  uint64_t base = 0, total = 0, t1 = 0, t2 = 0;
+#pragma unroll
+  for (int i = 0; i < kW; ++i) {
+    if (i < wv) base += sh_s[i];
+    total += sh_s[i];
+    t1 += sh_s[kW + i];
+    t2 += sh_s[2 * kW + i];
+  }
+  uint64_t run = base + incl - local;
+#pragma unroll
+  for (int i = 0; i < kBigPer; ++i) {
+    const uint64_t k = lo + i;
+    if ((uint64_t)i < per && k < ntiles) prefix[k] = run;
+    run += sv[i];
+  }
+  if (tid == 0) {
+    prefix[ntiles] = total;
+    prefix[ntiles + 1] = (uint64_t)(int64_t)e;
+    prefix[ntiles + 2] = t1;
+    prefix[ntiles + 3] = t2;
+  }
+}
+
+// r04: the GROUP records of a large population (gjx_device.hpp GroupRec; the grouped route of resample_body).  One workgroup
+// per group of kGroupTiles = 256 tiles, thread t <-> tile t of the group: the group's anchor, then — lane L of every wave —
+// the sum over the wave's 64 tiles of their masses shifted by (e_G - e_t) + L (a readlane loop: no cross-lane reduction), the
+// four waves' partial tables added through LDS.  Parallel over the groups (31 workgroups for one rank of configs[3]) where
+// k_scan_records_big is one workgroup's serial scan; `pm` (peer transport): every workgroup first waits, bounded, for the peers.
+template <bool ESS>
+__global__ __launch_bounds__(kBlock) void k_group_records(const TileRec* recs, const TileEss* ess, uint64_t ntiles, GroupRec* groups,
+                                                          PeerMap pm) {
+  static_assert(kGroupTiles == kBlock, "one thread per tile of the group");
+  constexpr int kW = kBlock / kWave;
+  __shared__ uint64_t sh_t[3][kW][64];
+  __shared__ int32_t sh_e[kW];
+  __shared__ uint32_t sh_ok;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  if (pm.world > 0) {
+    if (wv == 0) {
+      const bool ready = peer_wait_wave(pm);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) sh_ok = ready ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!sh_ok) return;
+  }
+  const uint64_t g = blockIdx.x, k = g * kGroupTiles + (uint64_t)tid;
+  const bool in = k < ntiles;
+  uint64_t S = 0, R1 = 0, R2 = 0;
+  int32_t et = kRowEmpty;
+  if (in) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(recs + k);
+    S = ((uint64_t)raw.y << 32) | raw.x;
+    et = (int32_t)raw.z;
+    if (ESS) { R1 = ess[k].r1; R2 = ess[k].r2; }
+  }
+  int32_t e = et;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int32_t o = __shfl_xor(e, off, kWave);
+    e = o > e ? o : e;
+  }
+  if (lane == 0) sh_e[wv] = e;
+  __syncthreads();
+  e = sh_e[0];
+#pragma unroll
+  for (int i = 1; i < kW; ++i) e = sh_e[i] > e ? sh_e[i] : e;
+  const int d = tile_shift(e, et);  // 64: the tile carries nothing under this anchor
+  uint64_t tm = 0, t1 = 0, t2 = 0;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const uint64_t Si = __shfl(S, i, kWave);
+    const int di = __shfl(d, i, kWave);
+    tm += shr64(Si, di + lane);
+    if (ESS) {
+      t1 += shr64(__shfl(R1, i, kWave), di + lane);
+      t2 += shr64(__shfl(R2, i, kWave), 2 * (di + lane));
+    }
+  }
+  sh_t[0][wv][lane] = tm;
+  if (ESS) { sh_t[1][wv][lane] = t1; sh_t[2][wv][lane] = t2; }
+  __syncthreads();
+  if (tid < 64) {
+    uint64_t a = 0, b1 = 0, b2 = 0;
+#pragma unroll
+    for (int i = 0; i < kW; ++i) {
+      a += sh_t[0][i][tid];
+      if (ESS) { b1 += sh_t[1][i][tid]; b2 += sh_t[2][i][tid]; }
+    }
+    groups[g].mass[tid] = a;
+    groups[g].r1[tid] = b1;
+    groups[g].r2[tid] = b2;
+    if (tid == 0) groups[g].e = e;
+  }
+}
+// Which route a population beyond kMaxLdsTiles takes (resample_body): group records (default) or the precomputed global
+// prefix (GJX_SMC_BIG_ROUTE=prefix: the r03 route, kept for A/B and for populations beyond kMaxGroups groups).  `scratch`:
+// the caller's u64[prefix_words(ntiles)].  -> true: A.groups is set and the group launch is enqueued.
+static bool launch_group_records(ResampleArgs& A, uint64_t* scratch, hipStream_t st) {
+  static const bool allow = [] { const char* e = std::getenv("GJX_SMC_BIG_ROUTE"); return !(e && e[0] == 'p'); }();
+  const uint64_t ng = (A.ntiles + kGroupTiles - 1) / kGroupTiles;
+  if (!allow || !scratch || ng > (uint64_t)kMaxGroups || (((uintptr_t)scratch) & 15) != 0 ||
+      ng * sizeof(GroupRec) > prefix_words(A.ntiles) * sizeof(uint64_t))
+    return false;
+  GroupRec* groups = reinterpret_cast<GroupRec*>(scratch);
+  if (A.ess) k_group_records<true><<<(unsigned)ng, kBlock, 0, st>>>(A.recs, A.ess, A.ntiles, groups, A.pm);
+  else k_group_records<false><<<(unsigned)ng, kBlock, 0, st>>>(A.recs, A.ess, A.ntiles, groups, A.pm);
+  A.groups = groups;
+  A.prefix = nullptr;
+  return true;
+}
+
 // Inclusive fixed-point CDF materialised in HBM (multinomial / single-draw paths).
 __global__ __launch_bounds__(kBlock) void k_cdf(const float* lw, uint64_t n, const float* m_ptr,
                                                 const uint64_t* tile_sums, uint64_t ntiles,
@@ -1026,16 +1216,48 @@ __global__ __launch_bounds__(kBlock) void k_source_ranges(const TileRec* recs, c
   const uint64_t per = (ntiles + kBlock - 1) / kBlock;
   const uint64_t b0 = per * (uint64_t)tid < ntiles ? per * (uint64_t)tid : ntiles;
   const uint64_t b1 = b0 + per < ntiles ? b0 + per : ntiles;
+  // r04: the thread's records are loaded ONCE, all loads in flight together (the loops below used to re-read every record
+  // `world` + 2 times, one dependent strided load after the other: 98 us at the 7 816 records of BASELINE configs[3]);
+  // chunks beyond kMassCache tiles per thread fall back to the loads
+  constexpr int kMassCache = 32;
+  uint64_t mcache[kMassCache];
+  int32_t ecache[kMassCache];
+  const bool cached = per <= (uint64_t)kMassCache;
   float ef = (float)kRowEmpty;  // (anchors are exact as floats: |e| <= 2^24)
-  for (uint64_t b = b0; b < b1; ++b) {
-    const float v = (float)recs[b].e;
-    ef = v > ef ? v : ef;
+  if (cached) {
+#pragma unroll
+    for (int i = 0; i < kMassCache; ++i) {
+      // (unconditional loads from a clamped address, masked afterwards: a load inside `if (b < b1)` ends its basic block with
+      // a wait, and 32 such loads are 32 memory round trips one after the other — 50 us of this kernel)
+      const uint64_t b = b0 + i;
+      const uint4 raw = *reinterpret_cast<const uint4*>(recs + (b < ntiles ? b : ntiles - 1));
+      mcache[i] = b < b1 ? (((uint64_t)raw.y << 32) | raw.x) : 0;
+      ecache[i] = b < b1 ? (int32_t)raw.z : kRowEmpty;
+    }
+#pragma unroll
+    for (int i = 0; i < kMassCache; ++i) {
+      const float v = (float)ecache[i];
+      ef = v > ef ? v : ef;
+    }
+  } else {
+    for (uint64_t b = b0; b < b1; ++b) {
+      const float v = (float)recs[b].e;
+      ef = v > ef ? v : ef;
+    }
   }
   const int32_t e = (int32_t)block_max(ef, shf);
+  if (cached) {
+#pragma unroll
+    for (int i = 0; i < kMassCache; ++i) mcache[i] = shr64(mcache[i], tile_shift(e, ecache[i]));
+  }
   auto mass = [&](uint64_t b) { return shr64(recs[b].s, tile_shift(e, recs[b].e)); };
   uint64_t local = 0, l1 = 0, l2 = 0;
+  if (cached) {
+#pragma unroll
+    for (int i = 0; i < kMassCache; ++i) local += mcache[i];
+  }
   for (uint64_t b = b0; b < b1; ++b) {
-    local += mass(b);
+    if (!cached) local += mass(b);
     if (ess_thr > 0.0) {
       const int d = tile_shift(e, recs[b].e);
       l1 += shr64(ess[b].r1, d);
@@ -1061,29 +1283,61 @@ __global__ __launch_bounds__(kBlock) void k_source_ranges(const TileRec* recs, c
   const double scale = (double)n_total / (double)tot;
   const double nd = (double)n_total;
   const uint64_t n_local = n_total / (uint64_t)world;
-  for (int j = 0; j < world; ++j) {
-    const double lo = (double)((uint64_t)j * n_local), hi = (double)((uint64_t)(j + 1) * n_local);
+  // a tile's bounds do not depend on the block: computed once per tile (they were recomputed for every block: two u64 ->
+  // f64 conversions, two products and two ceilings per tile and block), compared per block
+  double lwv[kMassCache], upv[kMassCache];
+  if (cached) {
     uint64_t pre = pre0;
-    unsigned long long first = 0, end = 0;
-    for (uint64_t b = b0; b < b1; ++b) {
+#pragma unroll
+    for (int i = 0; i < kMassCache; ++i) {
+      const uint64_t b = b0 + i;
       double lower = __builtin_ceil((double)pre * scale);
       lower = lower < nd ? lower : nd;
-      lower = lower - 1.0 > 0.0 ? lower - 1.0 : 0.0;
-      pre += mass(b);
-      double upper = __builtin_ceil((double)pre * scale);
-      upper = (b + 1 == ntiles || !(upper < nd)) ? nd : upper;
-      first += upper <= lo ? 1 : 0;
-      end += lower < hi ? 1 : 0;
+      lwv[i] = lower - 1.0 > 0.0 ? lower - 1.0 : 0.0;
+      pre += mcache[i];
+      const double upper = __builtin_ceil((double)pre * scale);
+      upv[i] = (b + 1 == ntiles || !(upper < nd)) ? nd : upper;
     }
-    if (first) atomicAdd(&cnt[2 * j], first);
-    if (end) atomicAdd(&cnt[2 * j + 1], end);
+  }
+  for (int j = 0; j < world; ++j) {
+    const double lo = (double)((uint64_t)j * n_local), hi = (double)((uint64_t)(j + 1) * n_local);
+    unsigned long long first = 0, end = 0;
+    if (cached) {
+#pragma unroll
+      for (int i = 0; i < kMassCache; ++i) {
+        if (b0 + i < b1) {
+          first += upv[i] <= lo ? 1 : 0;
+          end += lwv[i] < hi ? 1 : 0;
+        }
+      }
+    } else {
+      uint64_t pre = pre0;
+      for (uint64_t b = b0; b < b1; ++b) {
+        double lower = __builtin_ceil((double)pre * scale);
+        lower = lower < nd ? lower : nd;
+        lower = lower - 1.0 > 0.0 ? lower - 1.0 : 0.0;
+        pre += mass(b);
+        double upper = __builtin_ceil((double)pre * scale);
+        upper = (b + 1 == ntiles || !(upper < nd)) ? nd : upper;
+        first += upper <= lo ? 1 : 0;
+        end += lower < hi ? 1 : 0;
+      }
+    }
+    // (one LDS atomic per wave and counter: 256 same-address atomics per counter serialise)
+    const uint64_t wf = wave_sum((uint64_t)first), we = wave_sum((uint64_t)end);
+    if ((tid & 63) == 0) {
+      if (wf) atomicAdd(&cnt[2 * j], (unsigned long long)wf);
+      if (we) atomicAdd(&cnt[2 * j + 1], (unsigned long long)we);
+    }
   }
   __syncthreads();
   if (tid < 2 * world) {
     // no mass at all (every weight underflowed): the population is kept, every block's sources are its own tiles
     const uint64_t tiles_per_block = (n_total / (uint64_t)world) / kTile;
-    out[tid] = tot == 0 ? (int64_t)(((uint64_t)(tid >> 1) + (uint64_t)(tid & 1)) * tiles_per_block) : (int64_t)cnt[tid];
-    __threadfence_system();
+    // (system-scope stores: the words go straight to the host-visible buffer; the ticket's release below, behind the
+    // workgroup barrier, orders them — one fence, not one per word)
+    __hip_atomic_store(out + tid, tot == 0 ? (int64_t)(((uint64_t)(tid >> 1) + (uint64_t)(tid & 1)) * tiles_per_block) : (int64_t)cnt[tid],
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   // the ticket goes last, system scope: a host polling pinned memory may consume the ranges without waiting for
@@ -2375,13 +2629,15 @@ int gjx_resample_systematic(const gjx_keys* key, const float* logw, uint64_t n, 
   uint64_t* prefix = nt > (uint64_t)kMaxLdsTiles ? cv.take<uint64_t>(prefix_words(nt)) : nullptr;
   if (!cv.ok) return GJX_ERR_WORKSPACE;
   k_tile_weights<<<(unsigned)nt, kBlock, 0, S(s)>>>(logw, n, qw, recs, subs, nullptr);
-  if (prefix) k_scan_records<<<1, kBlock, 0, S(s)>>>(recs, nullptr, nt, prefix, nullptr, nullptr, 0);
   ResampleArgs A;
   A.qw = qw; A.recs = recs; A.subs = subs; A.n = n; A.ntiles = nt;
   A.n_out = n_out; A.out_lo = 0; A.out_hi = (int64_t)n_out;
   A.u0 = comb_offset(key->impl, k, key->has_fold, key->fold);
   A.e_out = out_e; A.q_out = out_q;
-  A.prefix = prefix;
+  if (prefix && !launch_group_records(A, prefix, S(s))) {
+    k_scan_records<<<1, kBlock, 0, S(s)>>>(recs, nullptr, nt, prefix, nullptr, nullptr, 0);
+    A.prefix = prefix;
+  }
   A.scan_max = scan_max_knob();
   AncestorOnly P{ancestors};
   const unsigned grid = (unsigned)ntiles_of(n_out);
@@ -2535,10 +2791,19 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
   if (A.ntiles > (uint64_t)kMaxLdsTiles || (ctx.fb.n_filters > 1 && prev->prefix)) {
     if (ctx.fb.n_filters > 1 && A.ntiles > (uint64_t)kMaxLdsTiles) return GJX_ERR_UNSUPPORTED;
     const unsigned nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
-    // (peers: the records in this rank's arena are complete only once every peer has arrived — the merge launch reads them
-    // before the step's own wait, so a one-workgroup wait launch goes first)
-    if (cfg->peers) k_peer_wait<<<1, kWave, 0, S(s)>>>(A.pm);
-    k_scan_records<<<nf, kBlock, 0, S(s)>>>(A.recs, A.ess, A.ntiles, prev->prefix, nullptr, nullptr, 0);
+    if (nf == 1 && A.ntiles > (uint64_t)kMaxLdsTiles && launch_group_records(A, prev->prefix, S(s))) {
+      A.pm.wait_value = 0;  // (peers: the group launch has waited for them; the step launch behind it need not)
+      return GJX_OK;        // (r04: the grouped route — no whole-population scan, no prefix array)
+    }
+    if (nf == 1 && A.ntiles <= (uint64_t)kBigBlock * kBigPer) {
+      // (peers: the records in this rank's arena are complete only once every peer has arrived — the merge launch reads them
+      // before the step's own wait, so it waits itself first)
+      if (A.ess) k_scan_records_big<true><<<1, kBigBlock, 0, S(s)>>>(A.recs, A.ess, A.ntiles, prev->prefix, A.pm);
+      else k_scan_records_big<false><<<1, kBigBlock, 0, S(s)>>>(A.recs, A.ess, A.ntiles, prev->prefix, A.pm);
+    } else {
+      if (cfg->peers) k_peer_wait<<<1, kWave, 0, S(s)>>>(A.pm);
+      k_scan_records<<<nf, kBlock, 0, S(s)>>>(A.recs, A.ess, A.ntiles, prev->prefix, nullptr, nullptr, 0);
+    }
     A.prefix = prev->prefix;
   }
   return GJX_OK;

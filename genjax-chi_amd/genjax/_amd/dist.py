@@ -450,6 +450,50 @@ class PeerArena:
             raise RuntimeError("peer transport: a step's wait for its peers timed out (gjx_smc_peers.error)")
 
     @staticmethod
+    def ipc(ops: Ops, rank: int, world: int, n_total: int, state_dtypes: list, adaptive: bool) -> "PeerArena":
+        """The arena of one rank per PROCESS (one process per GPU, or processes sharing a device): allocated with hipMalloc,
+        zeroed, handed to the peers through hipIpcGetMemHandle — the 64-byte handles travel over the `torch.distributed`
+        process group the program already has — and every peer's arena mapped with hipIpcOpenMemHandle (peer access over xGMI
+        when it lives on another device).  Collective over the group: every rank calls it with the same shape."""
+        import ctypes as C
+
+        dist = _dist()
+
+        class IpcHandle(C.Structure):  # hipIpcMemHandle_t: 64 opaque bytes, passed by value
+            _fields_ = [("reserved", C.c_char * 64)]
+
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipIpcGetMemHandle.argtypes = [C.POINTER(IpcHandle), C.c_void_p]
+        hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), IpcHandle, C.c_uint]
+        nb = PeerArena.nbytes(ops, n_total, state_dtypes, adaptive)
+        mine = C.c_void_p()
+        if hip.hipMalloc(C.byref(mine), C.c_size_t(nb)) != 0 or hip.hipMemset(mine, 0, C.c_size_t(nb)) != 0 or hip.hipDeviceSynchronize() != 0:
+            raise RuntimeError("peer arena: hipMalloc / hipMemset failed")
+        h = IpcHandle()
+        if hip.hipIpcGetMemHandle(C.byref(h), mine) != 0:
+            raise RuntimeError("peer arena: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 is required on this driver)")
+        handles = [None] * world
+        dist.all_gather_object(handles, bytes(h))
+        ptrs = []
+        for o in range(world):
+            if o == rank:
+                ptrs.append(mine.value)
+                continue
+            p_ = C.c_void_p()
+            if hip.hipIpcOpenMemHandle(C.byref(p_), IpcHandle.from_buffer_copy(handles[o]), 1) != 0:  # hipIpcMemLazyEnablePeerAccess
+                raise RuntimeError(f"peer arena: hipIpcOpenMemHandle failed for rank {o}")
+            ptrs.append(p_.value)
+
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (nb,), "typestr": "|u1", "data": (mine.value, False), "version": 2}
+
+        block = torch.as_tensor(_Dev(), device=ops.device())
+        arena = PeerArena(block, [ptrs[o] - mine.value for o in range(world)], rank, world)
+        arena._ipc = (hip, mine, ptrs)  # (kept mapped for the life of the process: a peer may read until it exits)
+        dist.barrier()  # every arena is zeroed and mapped before anybody signals into it
+        return arena
+
+    @staticmethod
     def virtual(ops: Ops, world: int, n_total: int, state_dtypes: list, adaptive: bool) -> list:
         """`world` arenas for virtual ranks of THIS process: slices of one zeroed allocation."""
         nb = PeerArena.nbytes(ops, n_total, state_dtypes, adaptive)
