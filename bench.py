@@ -374,7 +374,37 @@ def bench_smc_sharded(args, ops, rank, world, kind):
     native = os.environ.get("GJX_BENCH_PY_COMM") != "1"
     comm = gdist.NativeComm.rccl(ops, rank, world) if native else None
     run = (lambda: smc.run_native(comm)) if native else smc.run
-    run()  # warm-up (also builds any generated kernels)
+    ref = run()  # warm-up (also builds any generated kernels)
+    # r04: the PEER transport (no collective, nothing decided on the host: DESIGN.md 6) is the N > 1 default when it proves
+    # itself HERE: every rank maps its peers' arenas through hipIpc, runs the same filter through it, and every rank's log Z
+    # must equal the RCCL run's bit for bit (the transports only move data).  Anything else — a mapping that fails, a wait
+    # that times out, a different bit — and the line is measured through RCCL and says why.  GJX_BENCH_TRANSPORT=rccl|peers.
+    transport, why = "rccl", None
+    want = os.environ.get("GJX_BENCH_TRANSPORT", "auto")
+    if native and world > 1 and want in ("auto", "peers"):
+        import torch
+        import torch.distributed as dist
+
+        ok, smc_p = 1, None
+        try:
+            sdt = torch.float32 if kind == "smc_lgssm" else torch.int32
+            arena = gdist.PeerArena.ipc(ops, rank, world, n_total, [sdt], False)
+            pcomm = gdist.NativeComm.peers(ops, arena, None, False, timeout_ms=30000)
+            smc_p = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world, arena=arena)
+            got = smc_p.run_native(pcomm)
+            if got["log_z"] != ref["log_z"]:
+                ok, why = 0, f"peer transport log Z {got['log_z']!r} != RCCL {ref['log_z']!r} on rank {rank}"
+        except Exception as ex:  # noqa: BLE001 - reported in the line
+            ok, why = 0, f"{type(ex).__name__}: {ex}"[:200]
+        votes = [None] * world
+        dist.all_gather_object(votes, (ok, why))
+        if all(v[0] for v in votes):
+            transport = "peers"
+            run = lambda: smc_p.run_native(pcomm)  # noqa: E731
+        else:
+            why = "; ".join(f"rank {r}: {v[1]}" for r, v in enumerate(votes) if not v[0])
+            if want == "peers":
+                raise RuntimeError("GJX_BENCH_TRANSPORT=peers: " + why)
     smc.received = 0
     runs = [0]
 
@@ -391,8 +421,11 @@ def bench_smc_sharded(args, ops, rank, world, kind):
         "value": n_total * T / dt, "unit": "particle-steps/s", "ms_per_step": per_step_ms,
         "config": {"workload": f"bootstrap SMC {kind} T={T} N={n_total} sharded x{world} (BASELINE configs[3] at world=8)",
                    "rng": args.rng, "shuffle": exchange,
-                   "parallelism": f"particle-sharded x{world}: 1 launch + all-gather(tile records) + ancestor shuffle per step",
-                   "driver": "native" if native else "python",
+                   "parallelism": (f"particle-sharded x{world}, peer transport: per step 1 step launch reading remote windows in place + 1 signal launch; no collective"
+                                   if transport == "peers" else
+                                   f"particle-sharded x{world}: 1 launch + ONE all-gather(tile records) + ancestor shuffle per step"),
+                   "driver": "native" if native else "python", "transport": transport,
+                   **({"peer_transport_not_used_because": why} if why else {}),
                    "particles_received_per_rank_step": r["received"] / (1 if native else runs[0]) / max(1, T - 1)},
         "roofline": {"bound": "hbm", "kernel": "one sharded SMC step incl. exchange (per GPU)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -1250,7 +1283,7 @@ def run_rank(args):
             except Exception as ex:  # reported, never silently dropped
                 extra["importance_fast_math"] = {"error": f"{type(ex).__name__}: {ex}"}
     if rank == 0:
-        if world == 1 and not FORCE_DIST and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:  # (r04: N > 1 lines carry it too — rank 0's host cores, the same bounded sample)
             if args.workload == "importance":
                 out["cpu_baseline"] = cpu_baseline_importance(args, out["log_z"])
                 out["jax_cpu_plain"] = jax_cpu_plain(args)

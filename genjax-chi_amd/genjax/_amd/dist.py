@@ -466,23 +466,33 @@ class PeerArena:
         hip.hipIpcGetMemHandle.argtypes = [C.POINTER(IpcHandle), C.c_void_p]
         hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), IpcHandle, C.c_uint]
         nb = PeerArena.nbytes(ops, n_total, state_dtypes, adaptive)
-        mine = C.c_void_p()
+        # every rank reaches every collective below whatever fails locally: failures are VOTED on, so that no rank is left
+        # waiting in a collective its peer never enters
+        mine, err, h = C.c_void_p(), None, IpcHandle()
         if hip.hipMalloc(C.byref(mine), C.c_size_t(nb)) != 0 or hip.hipMemset(mine, 0, C.c_size_t(nb)) != 0 or hip.hipDeviceSynchronize() != 0:
-            raise RuntimeError("peer arena: hipMalloc / hipMemset failed")
-        h = IpcHandle()
-        if hip.hipIpcGetMemHandle(C.byref(h), mine) != 0:
-            raise RuntimeError("peer arena: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 is required on this driver)")
+            err = "hipMalloc / hipMemset failed"
+        elif hip.hipIpcGetMemHandle(C.byref(h), mine) != 0:
+            err = "hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 is required on this driver)"
         handles = [None] * world
-        dist.all_gather_object(handles, bytes(h))
+        dist.all_gather_object(handles, None if err else bytes(h))
         ptrs = []
+        if err is None and any(x is None for x in handles):
+            err = "a peer could not export its arena"
         for o in range(world):
+            if err is not None:
+                break
             if o == rank:
                 ptrs.append(mine.value)
                 continue
             p_ = C.c_void_p()
             if hip.hipIpcOpenMemHandle(C.byref(p_), IpcHandle.from_buffer_copy(handles[o]), 1) != 0:  # hipIpcMemLazyEnablePeerAccess
-                raise RuntimeError(f"peer arena: hipIpcOpenMemHandle failed for rank {o}")
+                err = f"hipIpcOpenMemHandle failed for rank {o}"
             ptrs.append(p_.value)
+        votes = [None] * world
+        dist.all_gather_object(votes, err)  # (also the barrier: every arena is zeroed and mapped before anybody signals into it)
+        bad = [f"rank {r}: {v}" for r, v in enumerate(votes) if v is not None]
+        if bad:
+            raise RuntimeError("peer arena: " + "; ".join(bad))
 
         class _Dev:
             __cuda_array_interface__ = {"shape": (nb,), "typestr": "|u1", "data": (mine.value, False), "version": 2}
@@ -490,7 +500,6 @@ class PeerArena:
         block = torch.as_tensor(_Dev(), device=ops.device())
         arena = PeerArena(block, [ptrs[o] - mine.value for o in range(world)], rank, world)
         arena._ipc = (hip, mine, ptrs)  # (kept mapped for the life of the process: a peer may read until it exits)
-        dist.barrier()  # every arena is zeroed and mapped before anybody signals into it
         return arena
 
     @staticmethod
