@@ -437,6 +437,80 @@ def bench_smc_sharded(args, ops, rank, world, kind):
     return res
 
 
+def bench_site_model(args, ops, name, passes=8, min_s=0.05):
+    """the rejection samplers under ImportanceK at 1e6 particles — `beta_bernoulli` (the README model:
+    p ~ Beta(2, 2), flip(p) observed: two Marsaglia-Tsang gammas per particle) and `gamma_normal` (s ~ Gamma(3, 2) as the scale
+    of five observed normals).  `passes` independent passes per launch; kernel time by HIP events; 12 algorithmic bytes per
+    particle (the latent, score, log-weight) — these kernels are bound by the samplers' vector instructions, the roofline
+    fraction says how far.  CPU baseline: the oracle on the host cores, a bounded sample; log Z: GPU == oracle bit for bit."""
+    import torch
+
+    from genjax._amd import workloads as W
+    from genjax._amd.ops import HipEvent
+
+    impl = 1 if args.rng == "philox" else 0
+    n = args.particles
+    mk = W.beta_bernoulli_model if name == "beta_bernoulli" else W.gamma_normal_model
+    wl = mk(ops, impl, 0, n)
+    out = {}
+    for L in (passes, 1):
+        prep = wl.prepare(fold_batch=L, passes=L)
+        st = ops.stream()
+
+        def run():
+            prep.launch_passes(0, L, st)
+            prep.launch_fold(L, st)
+
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.03:
+            run()
+            torch.cuda.synchronize()
+        evs = []
+
+        def one():
+            e0, e1 = HipEvent(), HipEvent()
+            e0.record(st)
+            prep.launch_passes(0, L, st)
+            e1.record(st)
+            prep.launch_fold(L, st)
+            evs.append((e0, e1))
+            return None
+
+        blocks, _ = timed_blocks(one, 1, min_s=min_s, min_blocks=20, max_blocks=200)
+        k_ms = statistics.median(a.elapsed_ms(b) for a, b in evs)
+        dt = statistics.median(blocks)
+        bytes_per_launch = 12.0 * n * L
+        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        log_z = ops.log_z_from_rows(prep.e_all[:1], prep.q_all[:1], n)
+        e = {"value": n * L / dt, "unit": "particles/s", "kernel_ms": k_ms, "kernel_us_per_pass": k_ms * 1e3 / L, "passes_per_launch": L,
+             "roofline": {"bound": "hbm", "kernel": f"gjx_plan_kernel_{args.rng}", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                          "limiter": "vector instructions of the rejection sampler (cipher block + normal + two logs per attempt), not HBM"},
+             "log_z": log_z, "log_z_exact": wl.log_z_exact}
+        if L == passes:
+            out.update(e)
+        else:
+            out["one_pass_per_launch"] = {k: e[k] for k in ("value", "unit", "kernel_ms", "kernel_us_per_pass")}
+    out["config"] = {"workload": f"ImportanceK k_particles={n} on {name}", "rng": args.rng}
+    if not args.no_cpu_baseline:
+        ora = _oracle()
+        if ora is not None:
+            ow = mk(ora, impl, 0, n)
+            o = ow.step()
+            hc = host_cores()
+            cores, _ = best_thread_count(ow.step, sorted({hc, max(1, hc // 2), min(hc, 16)}, reverse=True))
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 3.0:
+                o = ow.step()
+                reps += 1
+            cdt = time.perf_counter() - t0
+            clz = ora.log_z_from_rows(o["row_e"], o["row_q"], n)
+            out["cpu_baseline"] = {"value": n * reps / cdt, "unit": "particles/s", "cores": cores, "kind": "port",
+                                   "sample": f"{reps} full passes of the same {n}-particle workload (OpenMP, {cores} threads)",
+                                   "log_z_abs_err_gpu_vs_cpu": abs(clz - out["log_z"])}
+    return out
+
+
 def bench_sharded_rank0_virtual(args, ops, world=8, steps=40):
     """what ONE rank of BASELINE configs[3] costs per step, measured on the one GPU.  A world-8 filter of
     8 x 1e6 particles (7 816 tile records: beyond the 1024 a workgroup merges itself) is stepped by 8 VIRTUAL ranks — threads
@@ -1263,6 +1337,12 @@ def run_rank(args):
                 extra["importance_scan_hmm"] = bench_scan_hmm(args, ops)
             except Exception as ex:
                 extra["importance_scan_hmm"] = {"error": f"{type(ex).__name__}: {ex}"}
+            # the rejection samplers (Beta = two gammas, Gamma) under ImportanceK
+            for nm in ("beta_bernoulli", "gamma_normal"):
+                try:
+                    extra[f"importance_{nm}"] = bench_site_model(args, ops, nm)
+                except Exception as ex:
+                    extra[f"importance_{nm}"] = {"error": f"{type(ex).__name__}: {ex}"}
             # the reference-API call a user makes (tracing cache hit, plan lookup, one launch, fold, one scalar back)
             try:
                 extra["importance_host_api_call"] = bench_host_api_call(args)

@@ -784,6 +784,79 @@ GJX_DEV float std_gamma(const Stream<IMPL>& st, int which, float conc) {
   return g;
 }
 
+// r04: the same draws for the P particles of a lane (the pair / quad forms of the generated kernels), scheduled for the
+// wavefront.  std_gamma's loop runs as long as ANY lane of the wave still rejects: with ~96 % acceptance nearly every wave
+// runs a second trip for ~3 lanes, for every one of a lane's draws in turn (measured on the README's beta-bernoulli model, 8
+// gammas per lane: 0.68 of the VALU lane-cycles active).  Here the first attempt of all P particles is straight-line code —
+// independent chains the compiler interleaves — and the retries share ONE loop: each trip a lane advances its first
+// unfinished particle by one attempt.  Attempt a of particle u draws from the same sub-stream 1 + 2a + which of u's own
+// stream and the same comparisons decide: the same values as P calls of std_gamma, bit for bit, in fewer wave-trips.
+template <int IMPL>
+GJX_DEV bool gamma_attempt(const Stream<IMPL>& st, int which, int att, float d, float c, float& v) {
+  uint32_t w0, w1;
+  st.words((uint32_t)(1 + 2 * att + which), w0, w1);
+  const float x = std_normal(w0);
+  const float t = 1.0f + c * x;
+  if (t <= 0.0f) return false;
+  v = (t * t) * t;
+  const float u = uniform01(w1);
+  float rhs = (0.5f * x) * x + d;
+  rhs = rhs - d * v;
+  rhs = rhs + d * m_log(v);
+  return m_log(u) < rhs;
+}
+template <int IMPL, int P>
+GJX_DEV void std_gamma_multi(const Stream<IMPL> (&st)[P], int which, const float (&conc)[P], float (&out)[P]) {
+  float d[P], c[P], v[P];
+  int att[P];
+  bool done[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const float a = conc[u] < 1.0f ? conc[u] + 1.0f : conc[u];
+    d[u] = a - 0.33333334f;
+    c[u] = 1.0f / __builtin_sqrtf(9.0f * d[u]);
+    v[u] = 1.0f;
+  }
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    done[u] = gamma_attempt<IMPL>(st[u], which, 0, d[u], c[u], v[u]);
+    att[u] = 1;
+  }
+  for (;;) {
+    int pick = -1;
+#pragma unroll
+    for (int u = P - 1; u >= 0; --u) pick = (!done[u] && att[u] < 64) ? u : pick;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__ballot(pick >= 0) == 0) break;  // (wave-uniform: no lane has an unfinished particle)
+#else
+    if (pick < 0) break;
+#endif
+    if (pick >= 0) {
+      Stream<IMPL> s = st[0];
+      float dd = d[0], cc = c[0], vv = v[0];
+      int aa = att[0];
+#pragma unroll
+      for (int u = 1; u < P; ++u)
+        if (pick == u) { s = st[u]; dd = d[u]; cc = c[u]; vv = v[u]; aa = att[u]; }
+      const bool ok = gamma_attempt<IMPL>(s, which, aa, dd, cc, vv);
+#pragma unroll
+      for (int u = 0; u < P; ++u)
+        if (pick == u) { v[u] = vv; att[u] = aa + 1; done[u] = ok; }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    float g = d[u] * v[u];
+    if (conc[u] < 1.0f) {
+      uint32_t w0, w1;
+      st[u].words(0u, w0, w1);
+      const float ub = uniform01(which ? w1 : w0);
+      g = g * m_exp(m_log(ub) / conc[u]);
+    }
+    out[u] = g;
+  }
+}
+
 // --- fixed-point weights: q = rint(exp(lw - m) * 2^frac) as u64 (exact, order-independent sums).
 GJX_HD uint64_t fixw(float lw, float m, int frac) {
   if (lw == m) return (uint64_t)1 << frac;

@@ -337,13 +337,15 @@ struct SiteEmitter {
 
   // Part 2 of site q: the sampled value (Normal sites take their standard normal from `eps`: an expression
   // or, empty, this particle's own derivation), the log-density, the accumulators and the stored column.
+  bool presampled = false;  // tail(): a Gamma / Beta site's value vf<q> has been defined by the caller
   void tail(int q, const std::string& eps = "") {
     const CSiteT& st = sites[q];
     const std::string I = std::to_string(impl), Q = std::to_string(q) + sfx, K = key_of(q);
     const uint32_t fold = fold_of(q);
     const std::string row = "row" + Q;
     const bool isint = is_int(st);
-    if (!st.observed) {
+    // (presampled: the pair / quad forms draw the gammas of a lane's particles together — std_gamma_multi — and define vf<q> themselves)
+    if (!st.observed && !(presampled && (st.dist == GJX_DIST_GAMMA || st.dist == GJX_DIST_BETA))) {
       switch (st.dist) {
         case GJX_DIST_NORMAL: {
           std::string e = eps;
@@ -474,6 +476,11 @@ inline bool wt_stores_knob() {
 // The sites of a lane that owns NP whole PAIRS of adjacent particles (suffixes A, B [, C, D]) under PHILOX: one cipher
 // block per pair and two draws (pk0 / pk1: the cipher key; pair0 [, pair1]: the pairs' counter words — defined by the
 // caller), one Box-Muller transform per pair and Normal site, every stored column one vector store at `store_at`.
+// GJX_JIT_GAMMA_MULTI=0: every particle of a lane loops over its own rejection attempts (the r01-r03 form; A/B knob)
+inline bool gamma_multi_knob() {
+  const char* e = std::getenv("GJX_JIT_GAMMA_MULTI");
+  return !(e && e[0] == '0');
+}
 template <class CSiteT, class CArgT>
 inline void emit_pair_lane_sites(std::ostringstream& o, std::vector<SiteEmitter<CSiteT, CArgT>>& em, const CSiteT* sites, int n_sites,
                                  int NP, const std::string& ind, const std::string& store_at) {
@@ -514,6 +521,33 @@ int cur_pair_blk = -1;
         const std::string Z = Q + "_" + std::to_string(pi);
         em[2 * pi].tail(q, "zc" + Z);
         em[2 * pi + 1].tail(q, "zs" + Z);
+      }
+    } else if (!st.observed && (st.dist == GJX_DIST_GAMMA || st.dist == GJX_DIST_BETA) && gamma_multi_knob()) {
+      // the lane's P particles draw their gammas TOGETHER (gjx_device.hpp std_gamma_multi: the first attempts straight-line,
+      // the retries in one shared loop): the same values as P std_gamma calls, fewer divergent wave-trips
+      const std::string I = std::to_string(em[0].impl), PS = std::to_string(P);
+      const uint32_t fold = em[0].fold_of(q);
+      o << ind << "float vg0_" << Q << "[" << PS << "]" << (st.dist == GJX_DIST_BETA ? ", vg1_" + Q + "[" + PS + "]" : std::string()) << ";\n";
+      o << ind << "{\n" << ind << "  const Stream<" << I << "> gs[" << PS << "] = {";
+      for (int u = 0; u < P; ++u) o << (u ? ", " : "") << "Stream<" << I << ">(" << em[u].key_of(q) << ", true, " << fold << "u)";
+      o << "};\n";
+      o << ind << "  const float gc0[" << PS << "] = {";
+      for (int u = 0; u < P; ++u) o << (u ? ", " : "") << "a0_" << Q << sfx[u];
+      o << "};\n" << ind << "  std_gamma_multi<" << I << ", " << PS << ">(gs, 0, gc0, vg0_" << Q << ");\n";
+      if (st.dist == GJX_DIST_BETA) {
+        o << ind << "  const float gc1[" << PS << "] = {";
+        for (int u = 0; u < P; ++u) o << (u ? ", " : "") << "a1_" << Q << sfx[u];
+        o << "};\n" << ind << "  std_gamma_multi<" << I << ", " << PS << ">(gs, 1, gc1, vg1_" << Q << ");\n";
+      }
+      o << ind << "}\n";
+      for (int u = 0; u < P; ++u) {
+        if (st.dist == GJX_DIST_GAMMA)
+          o << ind << "const float vf" << Q << sfx[u] << " = vg0_" << Q << "[" << u << "] / a1_" << Q << sfx[u] << ";\n";
+        else
+          o << ind << "const float vf" << Q << sfx[u] << " = vg0_" << Q << "[" << u << "] / (vg0_" << Q << "[" << u << "] + vg1_" << Q << "[" << u << "]);\n";
+        em[u].presampled = true;
+        em[u].tail(q);
+        em[u].presampled = false;
       }
     } else {
       for (int u = 0; u < P; ++u) em[u].tail(q);

@@ -124,6 +124,88 @@ def gaussian10_importance(ops: Ops, impl: int, seed: int, n: int, fast_math: boo
 
 
 # ---------------------------------------------------------------------------------------------
+# The rejection samplers under ImportanceK (north star: "fused Beta/Gamma/Normal/Categorical samplers"): the README's
+# beta-bernoulli model (/root/reference/README.md:89-93) and a Gamma-Normal model, as site tables
+# ---------------------------------------------------------------------------------------------
+def beta_bernoulli_sites(obs: bool = True, alpha: float = 2.0, beta: float = 2.0) -> list[abi.Site]:
+    """@gen def beta_bernoulli(a, b): p = beta(a, b) @ "p"; v = flip(p) @ "v"; return v     (v constrained to `obs`)"""
+    p = abi.Site()
+    p.dist, p.observed, p.out_col = abi.DIST_BETA, 0, 0
+    p.arg[0] = abi.Arg(abi.ARG_CONST, 0, 0.0, alpha, None)
+    p.arg[1] = abi.Arg(abi.ARG_CONST, 0, 0.0, beta, None)
+    v = abi.Site()
+    v.dist, v.observed, v.out_col = abi.DIST_BERNOULLI, 1, -1
+    v.arg[0] = abi.Arg(abi.ARG_SITE, 0, 1.0, 0.0, None)
+    v.obs = abi.Arg(abi.ARG_CONST, 0, 0.0, 1.0 if obs else 0.0, None)
+    return [p, v]
+
+
+def beta_bernoulli_exact_log_z(obs: bool = True, alpha: float = 2.0, beta: float = 2.0) -> float:
+    return math.log((alpha if obs else beta) / (alpha + beta))
+
+
+GN_Y = np.array([0.8, -1.9, 0.35, 2.6, -0.7], dtype=np.float32)
+
+
+def gamma_normal_sites(y=GN_Y, conc: float = 3.0, rate: float = 2.0) -> list[abi.Site]:
+    """@gen def model(): s = gamma(3, 2) @ "s"; for i: normal(0, s) @ f"y{i}"      (a Gamma prior on the scale; y observed)"""
+    s_ = abi.Site()
+    s_.dist, s_.observed, s_.out_col = abi.DIST_GAMMA, 0, 0
+    s_.arg[0] = abi.Arg(abi.ARG_CONST, 0, 0.0, conc, None)
+    s_.arg[1] = abi.Arg(abi.ARG_CONST, 0, 0.0, rate, None)
+    sites = [s_]
+    for v in y:
+        o = abi.Site()
+        o.dist, o.observed, o.out_col = abi.DIST_NORMAL, 1, -1
+        o.arg[0] = abi.Arg(abi.ARG_CONST, 0, 0.0, 0.0, None)
+        o.arg[1] = abi.Arg(abi.ARG_SITE, 0, 1.0, 0.0, None)
+        o.obs = abi.Arg(abi.ARG_CONST, 0, 0.0, float(v), None)
+        sites.append(o)
+    return sites
+
+
+def gamma_normal_exact_log_z(y=GN_Y, conc: float = 3.0, rate: float = 2.0) -> float:
+    from scipy import integrate, stats
+
+    yd = np.asarray(y, dtype=np.float64)
+    f = lambda s: stats.gamma.pdf(s, conc, scale=1.0 / rate) * np.prod(stats.norm.pdf(yd, 0.0, s))  # noqa: E731
+    return float(math.log(integrate.quad(f, 0.0, np.inf, limit=200)[0]))
+
+
+class SiteModel:
+    """An ImportanceK workload given by a site table (plan + key batch + persistent buffers), like Gaussian10."""
+
+    def __init__(self, ops: Ops, impl: int, seed: int, n: int, sites: list, value_dtypes: list, log_z_exact: float):
+        self.ops, self.n, self.impl, self.seed = ops, n, impl, seed
+        self.first, self.n_total = 0, n
+        self.plan = ops.plan_create(sites)
+        self.value_dtypes = value_dtypes
+        self.keys = importance_particle_keys(prng.key(seed, impl), n)
+        self.log_z_exact = log_z_exact
+
+    def prepare(self, fold_batch: int = 1, passes: int = 1):
+        prep = getattr(self, "_prep", None)
+        if prep is None or prep.fold_batch != fold_batch or prep.launch_passes_n != passes:
+            keys = self.keys if passes == 1 else [importance_particle_keys(prng.key(self.seed + p, self.impl), self.n) for p in range(passes)]
+            self._prep = self.ops.prepare_importance(self.plan, keys, self.n, [], self.value_dtypes, fold_batch=fold_batch)
+        return self._prep
+
+    def step(self):
+        vals, score, logw, mp, rows = self.ops.importance_run(self.plan, self.keys, self.n, [], self.value_dtypes, want_score=True,
+                                                            want_max_partials=True, want_rows=True)
+        rlse, re, rq = self.ops.lse_rows(rows)
+        return dict(values=vals, score=score, logw=logw, row_e=re, row_q=rq)
+
+
+def beta_bernoulli_model(ops: Ops, impl: int, seed: int, n: int) -> SiteModel:
+    return SiteModel(ops, impl, seed, n, beta_bernoulli_sites(), [torch.float32], beta_bernoulli_exact_log_z())
+
+
+def gamma_normal_model(ops: Ops, impl: int, seed: int, n: int) -> SiteModel:
+    return SiteModel(ops, impl, seed, n, gamma_normal_sites(), [torch.float32], gamma_normal_exact_log_z())
+
+
+# ---------------------------------------------------------------------------------------------
 # C3: bootstrap SMC on x_0~N(0,1), x_t~N(0.9 x_{t-1}, 1), y_t~N(x_t, 0.5)
 # ---------------------------------------------------------------------------------------------
 LGSSM = dict(x0_loc=0.0, x0_scale=1.0, a=0.9, q=1.0, r=0.5)
