@@ -255,10 +255,13 @@ struct CSite {
   // evaluate the row on the fly.  Same integers / same f32 ops: the same bits.
   const uint2* cat_ent;       // [n_rows, n_cat]: {inclusive CDF, bits of row[c] - lse(row)} — the draw's walk ends on the entry
                               // that also holds the drawn category's log-density
-  const uint4* cat_guide4;    // [n_rows, 256]: bucket g = top byte of the draw -> {c, CDF_c, log-density bits of c, the row's total},
-                              // c = where the walk of every draw of the bucket starts (k_cat_prepare): ONE 16-byte load gives
-                              // the threshold's scale, the first candidate and, if it is the answer, its log-density
-                              // (r02: three scattered loads — total, guide byte pair, entry)
+  const uint4* cat_guide4;    // [n_rows, 1 << cat_gbits]: bucket g = the draw's top cat_gbits bits -> r04: {the LAST draw that maps to
+                              // the bucket's first category c, c | next category with mass << 9 | (more than two categories
+                              // share the bucket) << 18, log-density bits of c, log-density bits of the next}: ONE 16-byte
+                              // load answers a draw unless more than two categories share its bucket (k_cat_prepare).  r03's
+                              // 256 buckets held {c, CDF_c, log-density, total} and the walk read 1.4 further entries per draw
+                              // of the 256-state HMM: 2.4 scattered L2 requests per draw, the bound of that scan
+  int32_t cat_gbits;          // log2 of the buckets per row
   const float* cat_logp_t;    // observed sites whose value is the same for every particle: [n_cat, n_rows], row[c] - lse(row)
                               // TRANSPOSED — the launch reads one contiguous n_rows-float column, whatever rows the particles hold
   int32_t pre;       // 1: pre0/pre1 hold the hoisted per-site constants; 2: they depend on launch parameters
@@ -1824,7 +1827,7 @@ int gjx_logpdf_categorical(const int32_t* value, int value_scalar, const float* 
 
 // ---- plans ---------------------------------------------------------------------------------------
 // ---- per-row tables of categorical sites (specialised kernels) ------------------------------------------------------
-__global__ void k_cat_prepare(const float* logits, uint32_t n_rows, uint32_t K, uint2* ent, uint4* guide4, float* logp_t) {
+__global__ void k_cat_prepare(const float* logits, uint32_t n_rows, uint32_t K, uint2* ent, uint4* guide4, float* logp_t, int gbits) {
   // one thread per row, sequential in the category exactly as cat_invcdf / row_lse state it
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rows) return;
@@ -1841,14 +1844,25 @@ __global__ void k_cat_prepare(const float* logits, uint32_t n_rows, uint32_t K, 
     C += cat_fix(l[c], m);
     row[c] = make_uint2(C, f2u(l[c] - lse));
   }
-  // guide[g] = the category drawn by the SMALLEST draw whose top byte is g (bits = g << 24).  The threshold is monotone
-  // in the draw, so every draw of that bucket lands at or after guide[g]: a walk from there finds the same category as a
-  // search of the whole row.  The bucket carries that category's entry and the row's total.
+  // guide[g] (r04): the draws of bucket g are bits in [g << sh, (g + 1) << sh).  c = the category of the bucket's SMALLEST draw
+  // (the threshold is monotone in the draw, so every draw of the bucket lands at or after c).  A draw maps to c exactly while
+  // floor(bits C_tot / 2^32) < CDF_c, i.e. bits <= (CDF_c 2^32 - 1) / C_tot (integers): that bound, c, the next category
+  // with mass and both log-densities ARE the bucket — one load decides the draw unless the bucket's LAST draw lands beyond
+  // the next category (flag: the walk of the spec goes on from there, rare once buckets are finer than categories).
+  const int sh = 32 - gbits;
+  const uint32_t nb = 1u << gbits;
   uint32_t c = 0;
-  for (uint32_t g = 0; g < 256; ++g) {
-    const uint64_t thr = ((uint64_t)(g << 24) * (uint64_t)C) >> 32;
+  for (uint32_t g = 0; g < nb; ++g) {
+    const uint64_t thr = ((uint64_t)(g << sh) * (uint64_t)C) >> 32;
     while (c < K - 1 && (uint64_t)row[c].x <= thr) ++c;
-    guide4[(size_t)r * 256 + g] = make_uint4(c, row[c].x, row[c].y, C);
+    uint32_t cn = c;  // the next category with mass (c itself if there is none: never taken then)
+    for (uint32_t k = c + 1; k < K; ++k)
+      if (row[k].x > row[c].x) { cn = k; break; }
+    const uint32_t last_bits = (uint32_t)((((uint64_t)g + 1) << sh) - 1);
+    const uint64_t thr_last = ((uint64_t)last_bits * (uint64_t)C) >> 32;
+    const bool multi = cn != c && (uint64_t)row[cn].x <= thr_last;  // the bucket's last draw lies beyond cn
+    const uint32_t bm1 = C == 0 ? 0xffffffffu : (uint32_t)(((((uint64_t)row[c].x) << 32) - 1) / (uint64_t)C);
+    guide4[((size_t)r << gbits) + g] = make_uint4(row[c].x == 0 ? 0xffffffffu : bm1, c | (cn << 9) | ((multi ? 1u : 0u) << 18), row[c].y, row[cn].y);
   }
 }
 // Build the tables of every categorical site of a table (first compilation of a plan: a GPU is present by then).
@@ -1864,7 +1878,7 @@ static void cat_tables_prepare(CSite* sites, int n, std::vector<void*>* owned) {
     if (st.observed && st.obs.kind != GJX_ARG_INPUT) {  // the value is launch-uniform: the transposed log-probabilities only
       float* lt = nullptr;
       if (hipMalloc(&lt, sizeof(float) * rows * (size_t)st.n_cat) != hipSuccess) { (void)hipGetLastError(); continue; }
-      k_cat_prepare<<<grid, 64>>>(st.logits, (uint32_t)rows, (uint32_t)st.n_cat, nullptr, nullptr, lt);
+      k_cat_prepare<<<grid, 64>>>(st.logits, (uint32_t)rows, (uint32_t)st.n_cat, nullptr, nullptr, lt, 0);
       owned->push_back(lt);
       st.cat_logp_t = lt;
       any = true;
@@ -1872,16 +1886,24 @@ static void cat_tables_prepare(CSite* sites, int n, std::vector<void*>* owned) {
     }
     uint2* ent = nullptr;
     uint4* guide4 = nullptr;
-    if (hipMalloc(&ent, sizeof(uint2) * rows * (size_t)st.n_cat) != hipSuccess || hipMalloc(&guide4, sizeof(uint4) * 256 * rows) != hipSuccess) {
+    // buckets per row: finer than the categories (so that a bucket rarely holds more than two), within a table of a few MB
+    // that the L2s keep (GJX_CAT_GUIDE_BITS: tuning knob)
+    static const int gknob = [] { const char* e = std::getenv("GJX_CAT_GUIDE_BITS"); return e ? atoi(e) : 0; }();
+    int gbits = 8;
+    while ((1 << gbits) < 4 * st.n_cat && gbits < 11) ++gbits;
+    while (gbits > 8 && (sizeof(uint4) << gbits) * rows > ((size_t)2 << 20)) --gbits;
+    if (gknob >= 4 && gknob <= 16) gbits = gknob;
+    if (hipMalloc(&ent, sizeof(uint2) * rows * (size_t)st.n_cat) != hipSuccess || hipMalloc(&guide4, (sizeof(uint4) << gbits) * rows) != hipSuccess) {
       (void)hipGetLastError();
       if (ent) (void)hipFree(ent);
       continue;
     }
-    k_cat_prepare<<<grid, 64>>>(st.logits, (uint32_t)rows, (uint32_t)st.n_cat, ent, guide4, nullptr);
+    k_cat_prepare<<<grid, 64>>>(st.logits, (uint32_t)rows, (uint32_t)st.n_cat, ent, guide4, nullptr, gbits);
     owned->push_back(ent);
     owned->push_back(guide4);
     st.cat_ent = ent;
     st.cat_guide4 = guide4;
+    st.cat_gbits = gbits;
     any = true;
   }
   if (any && hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();

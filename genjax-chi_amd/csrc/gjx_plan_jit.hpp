@@ -377,8 +377,8 @@ struct SiteEmitter {
                                     // top byte (same integers as the two-pass walk: the same category); the entry the walk
                                     // ends on carries the log-density
             o << ind << "uint32_t lpb" << Q << ";\n";
-            o << ind << "const int32_t vi" << Q << " = jcat_invcdf_g4(" << plit_as("uint4", st.cat_guide4) << " + (size_t)rr" << Q << " * 256, "
-              << plit_as("uint2", st.cat_ent) << " + (size_t)rr" << Q << " * " << st.n_cat << ", " << st.n_cat << "u, bits" << Q << ", lpb" << Q << ");\n";
+            o << ind << "const int32_t vi" << Q << " = jcat_invcdf_gb(" << plit_as("uint4", st.cat_guide4) << " + ((size_t)rr" << Q << " << " << st.cat_gbits << "), "
+              << plit_as("uint2", st.cat_ent) << " + (size_t)rr" << Q << " * " << st.n_cat << ", " << st.n_cat << "u, bits" << Q << ", " << (32 - st.cat_gbits) << ", lpb" << Q << ");\n";
           } else {
             o << ind << "const int32_t vi" << Q << " = jcat_invcdf(" << row << ", " << st.n_cat << "u, bits" << Q << ");\n";
           }
@@ -461,7 +461,7 @@ inline void emit_prelude(std::ostringstream& o, bool fast_math = false, bool bm_
   o << "__device__ __forceinline__ float jrow_max(const float* l, uint32_t K){ float m=l[0]; for(uint32_t c=1;c<K;++c) m = l[c]>m?l[c]:m; return m; }\n";
   o << "__device__ __forceinline__ float jrow_lse(const float* l, uint32_t K){ const float m=jrow_max(l,K); float acc=0.0f; for(uint32_t c=0;c<K;++c) acc = acc + m_exp(l[c]-m); return m + m_log(acc); }\n";
   o << "__device__ __forceinline__ int32_t jcat_invcdf(const float* l, uint32_t K, uint32_t bits){ const float m=jrow_max(l,K); uint64_t Q=0; for(uint32_t c=0;c<K;++c) Q += cat_fix(l[c],m); const uint64_t thr=((uint64_t)bits*Q)>>32; uint64_t C=0; for(uint32_t c=0;c<K;++c){ C += cat_fix(l[c],m); if (C>thr) return (int32_t)c; } return (int32_t)(K-1); }\n";
-  o << "__device__ __forceinline__ int32_t jcat_invcdf_g4(const uint4* guide4, const uint2* ent, uint32_t K, uint32_t bits, uint32_t& lpb){ const uint4 g=guide4[bits>>24]; const uint64_t thr=((uint64_t)bits*(uint64_t)g.w)>>32; uint32_t c=g.x; uint32_t cdf=g.y; lpb=g.z; while (c<K-1 && (uint64_t)cdf<=thr){ ++c; const uint2 e=ent[c]; cdf=e.x; lpb=e.y; } return (int32_t)c; }\n";
+  o << "__device__ __forceinline__ int32_t jcat_invcdf_gb(const uint4* guide, const uint2* ent, uint32_t K, uint32_t bits, int sh, uint32_t& lpb){ const uint4 g=guide[bits>>sh]; const uint32_t c0=g.y&511u, c1=(g.y>>9)&511u; if (bits<=g.x){ lpb=g.z; return (int32_t)c0; } if (!(g.y>>18)){ lpb=g.w; return (int32_t)c1; } const uint64_t thr=((uint64_t)bits*(uint64_t)ent[K-1].x)>>32; uint32_t c=c1; uint2 e=ent[c]; while (c<K-1 && (uint64_t)e.x<=thr){ ++c; e=ent[c]; } lpb=e.y; return (int32_t)c; }\n";
   o << "template <int IMPL> __device__ __forceinline__ int32_t jcat_gumbel(const float* l, uint32_t K, const Stream<IMPL>& st){ int32_t best=0; float bv=-__builtin_inff(); for(uint32_t c=0;c<K;++c){ const float v = l[c] + gumbel_from_bits(st.bits32(c)); if (v>bv || c==0){ bv=v; best=(int32_t)c; } } return best; }\n";
 }
 

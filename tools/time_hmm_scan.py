@@ -4,7 +4,7 @@ import torch
 from genjax._amd import workloads as W
 from genjax._amd.runtime import load_hip_ops
 ops=load_hip_ops()
-for n,T,mode in ((100_000,100,1),(1_000_000,50,1),(100_000,20,0)):
+for n,T,mode in ((100_000,100,1),(1_000_000,50,1),(100_000,20,0))[:int(sys.argv[1]) if len(sys.argv) > 1 else 3]:
     w=W.HmmScan(ops,1,4,n,T,cat_mode=mode)
     w.run(); torch.cuda.synchronize()
     t0=time.perf_counter(); w.run(); torch.cuda.synchronize(); dt=time.perf_counter()-t0
