@@ -977,6 +977,34 @@ __global__ __launch_bounds__(kBlock) void k_multinomial(Key rkey, int has_fold, 
 }
 
 // Gumbel-max single draw over n logits (jax.random.categorical semantics): tile argmax partials.
+// One 1024-logit tile of a Gumbel-max draw: the workgroup's argmax of logits[i] + gumbel(bits32(i)), first index attaining the
+// maximum (sequential-scan semantics).  Result in shv[0] / shi[0]; every thread calls it (barriers inside).
+template <int IMPL>
+GJX_DEV void gumbel_tile_argmax(const Stream<IMPL>& st, const float* logits, uint64_t n, uint64_t tile, float* shv, int64_t* shi) {
+  float bv = -__builtin_inff();
+  int64_t bi = INT64_MAX;
+  for (uint64_t i = tile * kTile + threadIdx.x; i < n && i < (tile + 1) * kTile; i += kBlock) {
+    const float v = logits[i] + gumbel_from_bits(st.bits32((uint32_t)i));
+    if (v > bv || bi == INT64_MAX) { bv = v; bi = (int64_t)i; }
+  }
+  shv[threadIdx.x] = bv;
+  shi[threadIdx.x] = bi;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const float ov = shv[threadIdx.x + off];
+      const int64_t oi = shi[threadIdx.x + off];
+      const float mv = shv[threadIdx.x];
+      const int64_t mi = shi[threadIdx.x];
+      // sequential-scan semantics: first index attaining the maximum wins
+      if (oi != INT64_MAX && (mi == INT64_MAX || ov > mv || (ov == mv && oi < mi))) {
+        shv[threadIdx.x] = ov;
+        shi[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+}
 template <int IMPL>
 __global__ __launch_bounds__(kBlock) void k_gumbel_partials(Key key, int has_fold, uint32_t fold,
                                                             const float* logits, uint64_t n,
@@ -985,33 +1013,30 @@ __global__ __launch_bounds__(kBlock) void k_gumbel_partials(Key key, int has_fol
   __shared__ int64_t shi[kBlock];
   const Stream<IMPL> st(key, has_fold != 0, fold);
   for (uint64_t tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
-    float bv = -__builtin_inff();
-    int64_t bi = INT64_MAX;
-    for (uint64_t i = tile * kTile + threadIdx.x; i < n && i < (tile + 1) * kTile; i += kBlock) {
-      const float v = logits[i] + gumbel_from_bits(st.bits32((uint32_t)i));
-      if (v > bv || bi == INT64_MAX) { bv = v; bi = (int64_t)i; }
-    }
-    shv[threadIdx.x] = bv;
-    shi[threadIdx.x] = bi;
-    __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-      if ((int)threadIdx.x < off) {
-        const float ov = shv[threadIdx.x + off];
-        const int64_t oi = shi[threadIdx.x + off];
-        const float mv = shv[threadIdx.x];
-        const int64_t mi = shi[threadIdx.x];
-        // sequential-scan semantics: first index attaining the maximum wins
-        if (oi != INT64_MAX && (mi == INT64_MAX || ov > mv || (ov == mv && oi < mi))) {
-          shv[threadIdx.x] = ov;
-          shi[threadIdx.x] = oi;
-        }
-      }
-      __syncthreads();
-    }
+    gumbel_tile_argmax<IMPL>(st, logits, n, tile, shv, shi);
     if (threadIdx.x == 0) { pv[tile] = shv[0]; pi[tile] = shi[0]; }
     __syncthreads();
   }
 }
+// r04: B independent draws in ONE launch (gjx_categorical_index_batch: `vmap(alg.random_weighted)` over keys draws one
+// particle per trial): workgroup b draws from logits[b * stride .. + n) under key b; n <= one tile, so the workgroup's
+// result is the single call's (k_gumbel_partials of the one tile, then k_argmax_final of one partial) bit for bit.
+constexpr int kMaxDrawBatch = 64;
+struct DrawKeys {
+  Key key[kMaxDrawBatch];
+  uint32_t fold[kMaxDrawBatch];
+  uint32_t has_fold[kMaxDrawBatch];
+};
+template <int IMPL>
+__global__ __launch_bounds__(kBlock) void k_gumbel_batch(DrawKeys dk, const float* logits, uint64_t n, uint64_t stride, int64_t* out) {
+  __shared__ float shv[kBlock];
+  __shared__ int64_t shi[kBlock];
+  const uint32_t b = blockIdx.x;
+  const Stream<IMPL> st(dk.key[b], dk.has_fold[b] != 0, dk.fold[b]);
+  gumbel_tile_argmax<IMPL>(st, logits + (uint64_t)b * stride, n, 0, shv, shi);
+  if (threadIdx.x == 0) out[b] = shi[0];
+}
+
 __global__ __launch_bounds__(kBlock) void k_argmax_final(const float* pv, const int64_t* pi,
                                                          uint64_t np, int64_t* out) {
   __shared__ float shv[kBlock];
@@ -2602,6 +2627,23 @@ int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, 
   k_cdf<<<(unsigned)nt, kBlock, 0, S(s)>>>(logits, n, m, tiles, nt, frac_bits(n), cdf);
   GJX_DISPATCH_IMPL(key->impl, k_multinomial,
                     <<<1, kBlock, 0, S(s)>>>(k, key->has_fold, key->fold, cdf, n, 1, nullptr, out_idx));
+  return launch_status();
+}
+
+int gjx_categorical_index_batch(const gjx_keys* keys, int32_t n_batch, const float* logits, uint64_t n, uint64_t stride,
+                                int64_t* out_idx, gjx_stream s) {
+  if (!keys || !logits || !out_idx || n_batch < 1 || n_batch > kMaxDrawBatch || n == 0 || n > (uint64_t)kTile || stride < n)
+    return GJX_ERR_INVALID;
+  DrawKeys dk;
+  memset(&dk, 0, sizeof dk);
+  for (int b = 0; b < n_batch; ++b) {
+    if (!keys_ok(&keys[b]) || keys[b].impl != keys[0].impl) return GJX_ERR_INVALID;
+    const int rc = scalar_key(&keys[b], &dk.key[b]);
+    if (rc) return rc;
+    dk.fold[b] = keys[b].fold;
+    dk.has_fold[b] = keys[b].has_fold ? 1u : 0u;
+  }
+  GJX_DISPATCH_IMPL(keys[0].impl, k_gumbel_batch, <<<(unsigned)n_batch, kBlock, 0, S(s)>>>(dk, logits, n, stride, out_idx));
   return launch_status();
 }
 

@@ -406,6 +406,7 @@ PROTOTYPES = {
     "gjx_tile_weights": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P]),
     "gjx_tile_merge": (C.c_int, [_P, C.c_uint64, _P, _P, _P]),
     "gjx_comm_init_callbacks": (C.c_int, [C.c_int, C.c_int, ALLGATHER_FN, EXCHANGE_FN, STREAM_SYNC_FN, _P, C.POINTER(_P)]),
+    "gjx_categorical_index_batch": (C.c_int, [_KP, C.c_int32, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "gjx_comm_init_peers": (C.c_int, [C.POINTER(SmcPeers), _P, C.c_int, C.POINTER(_P)]),
     "gjx_smc_peer_signal": (C.c_int, [C.POINTER(SmcPeers), _P, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
     "gjx_smc_peer_wait": (C.c_int, [C.POINTER(SmcPeers), C.c_uint64, _P]),

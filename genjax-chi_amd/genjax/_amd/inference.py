@@ -297,6 +297,12 @@ class SMCAlgorithm(Algorithm):
         chm = target.filter_to_unconstrained(particle.get_choices())
         return log_density_estimate, chm
 
+    def random_weighted_batch(self, keys, *args):
+        """`vmap(self.random_weighted, in_axes=(0, None))(keys, target)` in a bounded number of launches, or None when this
+        algorithm has no batched form (jaxlike.vmap then runs key by key).  Element b of every result equals
+        `self.random_weighted(keys[b], target)` bit for bit."""
+        return None
+
     def estimate_logpdf(self, key, v: ChoiceMap, *args):
         assert isinstance(args[0], Target)
         target = args[0]
@@ -448,6 +454,41 @@ class ImportanceK(SMCAlgorithm):
             if fast is not None:
                 return fast
         return super().log_marginal_likelihood_estimate(key, target)
+
+    def random_weighted_batch(self, keys, *args):
+        """The README's call (/root/reference/README.md:111-113: `jax.vmap(alg.random_weighted, in_axes=(0, None))(sub_keys,
+        posterior_target)`, 50 trials of K = 50 particles) as TWO launches per 32 trials instead of a run per trial: the
+        trials' importance passes share one `gjx_importance_run_batch` launch (+ one fold of their row sums), their particle
+        draws one `gjx_categorical_index_batch` launch.  Same key derivation as the scalar path (smc.py:162-179: key, sub_key =
+        split(key); run_smc(key) -> split, split(sub, K); sample_particle(sub_key)); the target must be THIS algorithm's target
+        (ChangeTarget's identity shortcut), no custom proposal, a flat plan-able body, K <= 1024."""
+        from .lang import StaticGenerativeFunction
+        from .plan import fused_generate_batch
+
+        keys = list(keys)
+        k = self.get_num_particles()
+        if (len(args) != 1 or args[0] is not self.target or self.q is not None or k > 1024 or len(keys) < 2
+                or not isinstance(self.target.p, StaticGenerativeFunction) or any(type(key) is not prng.PRNGKey for key in keys)):
+            return None
+        ops = get_ops()
+        ests, cols = [], None
+        for lo in range(0, len(keys), 32):
+            chunk = keys[lo:lo + 32]
+            pks, draw_keys = [], []
+            for key in chunk:
+                key_run, sub_key = split(key)        # random_weighted
+                _, sub2 = split(key_run)             # run_smc
+                pks.append(split(sub2, k))
+                draw_keys.append(_literal_key(sub_key))
+            res = fused_generate_batch(self.target.p, pks, self.target.constraint, self.target.args)
+            if res is None:
+                return None
+            idx = ops.categorical_index_batch(draw_keys, res["logw"], k).reshape(-1, 1)
+            score = res["score"].gather(1, idx).reshape(-1)
+            ests.append(score - (res["lse"] - math.log(k)))
+            picked = [(addr, v.gather(1, idx).reshape(-1)) for addr, v in res["values"]]
+            cols = picked if cols is None else [(a, torch.cat([c0, c1])) for (a, c0), (_, c1) in zip(cols, picked)]
+        return torch.cat(ests), ChoiceMap.from_mapping(cols)
 
     def log_marginal_likelihood_estimates(self, keys):
         """`vmap(self.log_marginal_likelihood_estimate)(keys)`: one independent estimate per key, as a

@@ -108,6 +108,16 @@ def vmap(fn, in_axes=0):
         for a, ax in zip(args, axes):
             if ax is not None:
                 n = len(a)
+        # r04: a trial axis over `alg.random_weighted` / `alg.log_marginal_likelihood_estimate` runs BATCHED when the algorithm
+        # can (a bounded number of launches instead of a run per key); element b equals the scalar call bit for bit
+        owner, name = getattr(fn, "__self__", None), getattr(fn, "__name__", "")
+        if owner is not None and axes and axes[0] is not None and all(ax is None for ax in axes[1:]):
+            if name == "random_weighted" and hasattr(owner, "random_weighted_batch"):
+                got = owner.random_weighted_batch(args[0], *args[1:])
+                if got is not None:
+                    return got
+            if name == "log_marginal_likelihood_estimate" and len(args) == 1 and hasattr(owner, "log_marginal_likelihood_estimates"):
+                return owner.log_marginal_likelihood_estimates(args[0])
         outs = []
         for i in range(n):
             call = [a[i] if ax is not None else a for a, ax in zip(args, axes)]

@@ -380,6 +380,16 @@ class Ops:
                       C.c_void_p(out.data_ptr()), mode, C.c_void_p(ws.data_ptr()), nb, self.stream())
         return out
 
+    def categorical_index_batch(self, kbs: list, logits: torch.Tensor, n: int) -> torch.Tensor:
+        """gjx_categorical_index_batch: one Gumbel-max draw per row of `logits` [B, stride] (the first n entries of each
+        row) under the scalar keys `kbs` — ONE launch; entry b equals categorical_index(kbs[b], logits[b, :n])."""
+        B = len(kbs)
+        arr = (abi.Keys * B)(*[self._keys(k, 1) for k in kbs])
+        out = self.empty(B, torch.int64)
+        self.lib.call("gjx_categorical_index_batch", arr, B, C.c_void_p(logits.data_ptr()), int(n), int(logits.stride(0)),
+                      C.c_void_p(out.data_ptr()), self.stream())
+        return out
+
     def resample(self, kind: str, kb: KeyBatch, logw: torch.Tensor, n_out: int | None = None):
         """-> (ancestors int32[n_out], anchor, q i64[1]): systematic — tile-anchored weights, anchor = the merged
         power-of-two exponent e int32[1] (lse = e ln 2 + log(q 2^-30)); multinomial — anchor = max f32[1]

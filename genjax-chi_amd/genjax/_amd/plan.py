@@ -942,5 +942,35 @@ def fused_log_weights_batch(gen_fn, pks: list, constraint: ChoiceMap, args):
     return prep.logw_all[:, :n], prep.lse_all
 
 
+def fused_generate_batch(gen_fn, pks: list, constraint: ChoiceMap, args):
+    """B independent importance passes of one plan-able FLAT body in ONE launch, with everything a particle draw per pass
+    needs: -> dict(values=[per latent site: (addr, tensor [B, n] in its presented dtype)], score [B, n], logw [B, stride] (the
+    first n of each row), lse f32[B]) or None (not plan-able this way: nested calls, eager arguments, explicit keys)."""
+    n = pks[0].n
+    if any(pk.n != n or pk.kb.fold is not None or pk.kb.mode != 1 for pk in pks) or any(_needs_eager(a) for a in args):
+        return None
+    traced = _trace(gen_fn, constraint, n, args)
+    if traced is None:
+        return None
+    tracer = traced[0]
+    if any(kind != "site" for kind, _ in tracer.items):
+        return None
+    ops = get_ops()
+    plan = _make_plan(tracer)
+    dtypes = [torch.float32] * tracer.n_out
+    for m in tracer.meta:
+        if m["out_col"] >= 0 and m["is_int"]:
+            dtypes[m["out_col"]] = torch.int32
+    prep = ops.prepare_importance(plan, [pk.kb for pk in pks], n, tracer.inputs, dtypes, fold_batch=len(pks))
+    prep.launch_passes(0, len(pks))
+    prep.launch_fold(len(pks))
+    values = []
+    for m in tracer.meta:
+        if m["out_col"] >= 0:
+            v = prep.values_all[m["out_col"]][:, :n]
+            values.append((m["addr"], (v != 0) if m["dtype"] == torch.bool else v))
+    return dict(values=values, score=prep.score_all[:, :n], logw=prep.logw_all, lse=prep.lse_all, _keep=prep)
+
+
 def _needs_eager(a) -> bool:
     return isinstance(a, torch.Tensor) and a.dim() >= 1 and a.numel() > 1

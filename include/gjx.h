@@ -446,6 +446,13 @@ int gjx_logsumexp_f32(const float* x, uint64_t n, const float* max_partials_in, 
 int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, int64_t* out_idx,
                           int mode, void* ws, size_t ws_bytes, gjx_stream s);
 
+/* r04: n_batch (<= 64) independent Gumbel-max draws in ONE launch — the draw of `sample_particle` (inference/smc.py:102-109)
+ * under `vmap(alg.random_weighted)` over keys (README.md:111-113: 50 trials, one particle each).  Draw b takes its index among
+ * the n logits at logits + b * stride under the scalar key keys[b] (host array; one generator); n <= gjx_smc_tile().  out_idx
+ * dev int64[n_batch]; entry b equals gjx_categorical_index(&keys[b], logits + b * stride, n, mode 0) bit for bit. */
+int gjx_categorical_index_batch(const gjx_keys* keys /*host [n_batch]*/, int32_t n_batch, const float* logits, uint64_t n,
+                                uint64_t stride, int64_t* out_idx, gjx_stream s);
+
 /* Tile-anchored weights: what a resampling reads.  Tile t = particles [1024 t, 1024 t + 1024):
  * e_t = ceil(max_t x * log2 e) (the row anchor of 3.5b on a tile); q_i = rint(exp(x_i - e_t ln 2) * 2^30), ONE u32 PER
  * PARTICLE (what a step stores instead of the log-weight); the tile's record: S_t = sum q_i and e_t (gjx_tile_rec), the

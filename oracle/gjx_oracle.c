@@ -951,6 +951,16 @@ int gjx_categorical_index(const gjx_keys* key, const float* logits, uint64_t n, 
   return GJX_OK;
 }
 
+int gjx_categorical_index_batch(const gjx_keys* keys, int32_t n_batch, const float* logits, uint64_t n, uint64_t stride,
+                                int64_t* out_idx, gjx_stream s) {
+  if (!keys || !logits || !out_idx || n_batch < 1 || n_batch > 64 || n == 0 || n > O_TILE || stride < n) return GJX_ERR_INVALID;
+  for (int b = 0; b < n_batch; ++b) { /* by definition: the single draws */
+    const int rc = gjx_categorical_index(&keys[b], logits + (size_t)b * stride, n, out_idx + b, 0, NULL, 0, s);
+    if (rc) return rc;
+  }
+  return GJX_OK;
+}
+
 /* ---- tile-anchored weights (gjx.h gjx_tile_rec) ---------------------------------- *
  * Sequential restatement: per tile of 1024 particles the maximum (the sequential `x > m ? x : m`, a NaN is skipped),
  * its power-of-two anchor, the fixed-point weights (one u32 per particle), their running sum after every 64th

@@ -107,8 +107,13 @@ def case_readme_beta_bernoulli(impl):
         alg = ImportanceK(posterior_target, k_particles=50)
         key = jax.random.key(314159, impl)
         sub_keys = jax.random.split(key, 50)
-        _, p_chm = jax.vmap(alg.random_weighted, in_axes=(0, None))(sub_keys, posterior_target)
-        assert p_chm["p"].shape == (50,)
+        est, p_chm = jax.vmap(alg.random_weighted, in_axes=(0, None))(sub_keys, posterior_target)
+        assert p_chm["p"].shape == (50,) and est.shape == (50,)
+        # r04: the trial axis runs batched (two launches per 32 trials); element b equals the scalar call bit for bit
+        assert alg.random_weighted_batch(sub_keys, posterior_target) is not None
+        for b in (0, 1, 17, 31, 32, 49):
+            e_b, c_b = alg.random_weighted(sub_keys[b], posterior_target)
+            assert torch.equal(torch.as_tensor(e_b).reshape(()).cpu(), est[b].cpu()) and torch.equal(c_b["p"].reshape(()).cpu(), p_chm["p"][b].cpu())
         return f(jnp.mean(p_chm["p"]))
 
     assert run_inference(True) == pytest.approx(0.6, abs=0.07)  # README prints 0.6039314
