@@ -198,6 +198,12 @@ class Scan(GenerativeFunction):
             out = SP.run_scan(low, key, T, carry0, table)  # launch / hiprtc failures propagate: no silent slow route
         except PlanUnsupported:
             return None
+        except GjxError as e:
+            from .runtime import compiler_switched_off
+
+            if compiler_switched_off(e):  # GJX_PLAN_JIT=0: one-launch scans are generated kernels; the host loop runs the scan
+                return None
+            raise
         dev = out["logw"].device
         values_nt = []
         for m, v in zip(low.value_meta, out["values"]):

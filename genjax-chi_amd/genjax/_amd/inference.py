@@ -14,7 +14,7 @@ import threading
 
 import torch
 
-from . import prng
+from . import abi, prng
 from .choicemap import ChoiceMap, Selection
 from .lang import Distribution, DistributionTrace, GenerativeFunction, ParticleKeys, Trace, split
 from .ops import KeyBatch
@@ -395,14 +395,18 @@ class ImportanceK(SMCAlgorithm):
     # kernels on the same keys, so the same bits.
     def _fast_state(self):
         ops = get_ops()
-        st = self.__dict__.get("_fast")
+        # one state PER HOST THREAD: the plan takes its parameters set-then-run, and the plan cache behind
+        # _make_plan is thread-local for that reason — a second thread must not reuse (or re-parameterise) the first one's plan
+        states = self.__dict__.setdefault("_fast", {})
+        tid = threading.get_ident()
+        st = states.get(tid)
         if st is not None and st.ops is ops and st.fast_math == fast_math_enabled():
             for t, v in st.tensors:
                 if t._version != v:
                     break
             else:
                 return st
-        self.__dict__["_fast"] = None
+        states[tid] = None
         from .lang import StaticGenerativeFunction
         from .plan import _make_plan, _needs_eager, _traced
 
@@ -422,7 +426,7 @@ class ImportanceK(SMCAlgorithm):
         tensors = [t for t in list(self.target.args) + [v for _, v in merged.leaves()] if isinstance(t, torch.Tensor)]
         st = _FastEstimate(ops, fast_math_enabled(), tuple((t, t._version) for t in tensors), plan, tracer, list(tracer.params),
                            math.log(n), n)
-        self.__dict__["_fast"] = st
+        states[tid] = st
         return st
 
     def _fast_estimate(self, key):
@@ -436,7 +440,14 @@ class ImportanceK(SMCAlgorithm):
         prep = st.preps.get(slot)
         if prep is None:
             kb = prng.split_lazy(prng.split_at(prng.split_at(key, 1), 1), st.n)
-            prep = st.preps[slot] = st.ops.prepare_importance(st.plan, kb, st.n, st.tracer.inputs, [], estimate_only=True)
+            try:
+                prep = st.preps[slot] = st.ops.prepare_importance(st.plan, kb, st.n, st.tracer.inputs, [], estimate_only=True)
+            except abi.GjxError as e:
+                from .runtime import compiler_switched_off
+
+                if compiler_switched_off(e):
+                    return None
+                raise
         plan = st.plan
         if st.params and plan.params_owner is not st:  # (another algorithm object may share the cached plan)
             plan.set_params(st.params)
@@ -445,7 +456,14 @@ class ImportanceK(SMCAlgorithm):
         # split(sub_key); sub_keys = split(sub_key, K), lazily [run_smc]; the walk, the fold of its row sums by the workgroup
         # that finishes last, and lse - log K (one f32 subtraction, as `lse[0] - math.log(K)` on the general route)
         out = torch.empty((), dtype=torch.float32, device=st.ops._alloc_device)
-        prep.launch_estimate(key.k0, key.k1, key.lane, out, st.log_k)
+        try:
+            prep.launch_estimate(key.k0, key.k1, key.lane, out, st.log_k)
+        except abi.GjxError as e:
+            from .runtime import compiler_switched_off
+
+            if compiler_switched_off(e):  # GJX_PLAN_JIT=0 and a body with programs / nested calls: the general route
+                return None
+            raise
         return out
 
     def log_marginal_likelihood_estimate(self, key, target: Target | None = None):

@@ -841,7 +841,7 @@ def _traced(gen_fn, constraint: ChoiceMap, n: int, args):
     return traced
 
 
-def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
+def _try_fused_generate_impl(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
     """-> (trace, weight) through the fused kernel, or None when the body is not plan-able."""
     if pk.kb.fold is not None or any(_needs_eager(a) for a in args):
         return None
@@ -918,7 +918,7 @@ def try_fused_generate(gen_fn, pk: ParticleKeys, constraint: ChoiceMap, args):
     return tr, logw
 
 
-def fused_log_weights_batch(gen_fn, pks: list, constraint: ChoiceMap, args):
+def _fused_log_weights_batch_impl(gen_fn, pks: list, constraint: ChoiceMap, args):
     """Several independent importance passes of one plan-able body in ONE launch
     (`gjx_importance_run_batch`) -> (log-weights [B, n], lse f32[B]) or None.  The passes differ only in
     their particle keys (lazy children of B parent keys); the log-sum-exp of every pass is folded by one
@@ -942,7 +942,7 @@ def fused_log_weights_batch(gen_fn, pks: list, constraint: ChoiceMap, args):
     return prep.logw_all[:, :n], prep.lse_all
 
 
-def fused_generate_batch(gen_fn, pks: list, constraint: ChoiceMap, args):
+def _fused_generate_batch_impl(gen_fn, pks: list, constraint: ChoiceMap, args):
     """B independent importance passes of one plan-able FLAT body in ONE launch, with everything a particle draw per pass
     needs: -> dict(values=[per latent site: (addr, tensor [B, n] in its presented dtype)], score [B, n], logw [B, stride] (the
     first n of each row), lse f32[B]) or None (not plan-able this way: nested calls, eager arguments, explicit keys)."""
@@ -970,6 +970,30 @@ def fused_generate_batch(gen_fn, pks: list, constraint: ChoiceMap, args):
             v = prep.values_all[m["out_col"]][:, :n]
             values.append((m["addr"], (v != 0) if m["dtype"] == torch.bool else v))
     return dict(values=values, score=prep.score_all[:, :n], logw=prep.logw_all, lse=prep.lse_all, _keep=prep)
+
+
+def _or_per_site(impl):
+    """The fused route, or None (= the per-site path) when the library refuses the plan because the compiler is switched off
+    (runtime.compiler_switched_off)."""
+    import functools
+
+    @functools.wraps(impl)
+    def run(*a, **kw):
+        from .runtime import compiler_switched_off
+
+        try:
+            return impl(*a, **kw)
+        except abi.GjxError as e:
+            if compiler_switched_off(e):
+                return None
+            raise
+
+    return run
+
+
+try_fused_generate = _or_per_site(_try_fused_generate_impl)
+fused_log_weights_batch = _or_per_site(_fused_log_weights_batch_impl)
+fused_generate_batch = _or_per_site(_fused_generate_batch_impl)
 
 
 def _needs_eager(a) -> bool:

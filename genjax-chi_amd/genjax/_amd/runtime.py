@@ -54,6 +54,15 @@ def use_ops(ops: Ops):
         _current = prev
 
 
+def compiler_switched_off(err) -> bool:
+    """A fused plan that the library refuses with GJX_ERR_UNSUPPORTED while the plan compiler is switched off (GJX_PLAN_JIT=0):
+    bodies with arithmetic between their sites (GJX_ARG_EXPR programs) or nested `@gen` calls run as generated kernels only —
+    the table interpreters do not evaluate programs or keep a key stack — so with the compiler off such a body takes the
+    PER-SITE path (one kernel per `@` site: the same bits, several launches), the documented route without a compiler.  A
+    compiler that is ON and fails (GJX_ERR_JIT) stays an error: never a silent slower route."""
+    return getattr(err, "code", None) == -2 and os.environ.get("GJX_PLAN_JIT") == "0"
+
+
 # ---- opt-in fast math for fused importance / scan plans (gjx.h GJX_PLAN_FAST_MATH) -------------------------------------
 _fast_math = False
 

@@ -1740,7 +1740,7 @@ def case_fast_estimate_path(impl):
             assert torch.equal(a, b), (k, rep)
             if rep == 0:
                 first = a.clone()
-        assert alg.__dict__.get("_fast") is not None
+        assert any(v is not None for v in alg.__dict__.get("_fast", {}).values())
         assert torch.equal(first, I.SMCAlgorithm.log_marginal_likelihood_estimate(alg, genjax.random.key(50, impl)))  # results are not views of the buffers
     # a tensor argument changed in place is seen (the cached trace is keyed by its version)
     mu = torch.tensor(0.3, device=first.device)
@@ -1758,7 +1758,7 @@ def case_fast_estimate_path(impl):
 
     alg = ImportanceK(t1, q=prop.marginal() if hasattr(prop, "marginal") else None, k_particles=500)
     z = alg.log_marginal_likelihood_estimate(genjax.random.key(9, impl))
-    assert alg.__dict__.get("_fast") is None and math.isfinite(f(z))
+    assert not any(v is not None for v in (alg.__dict__.get("_fast") or {}).values()) and math.isfinite(f(z))
     z = ImportanceK(t1, k_particles=500).log_marginal_likelihood_estimate(genjax.random.key(9, impl), t1)
     assert math.isfinite(f(z))
 
@@ -1834,7 +1834,7 @@ def case_nested_calls(impl):
     key = genjax.random.key(9, impl)
     from genjax._amd import inference as I
     assert torch.equal(alg.log_marginal_likelihood_estimate(key), I.SMCAlgorithm.log_marginal_likelihood_estimate(alg, key))
-    assert alg.__dict__.get("_fast") is not None
+    assert any(v is not None for v in alg.__dict__.get("_fast", {}).values())
     # an address used twice inside ONE callee body is still an error; the same address in two different calls is not
     @gen
     def twice():

@@ -345,3 +345,83 @@ def test_another_table_of_the_same_shape_costs_no_compilation(hip_ops, oracle_op
     second = run(hip_ops, 2.5)  # new tensors: new addresses, new contents, the same structure
     assert hip_ops.jit_stats()["compiles"] == c0
     assert first == run(oracle_ops, 1.0) and second == run(oracle_ops, 2.5) and first != second
+
+
+NOJIT_CHILD = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import torch
+import genjax
+from genjax import ChoiceMapBuilder as C, Target, gen, normal, flip
+from genjax._amd.abi import GjxLib
+from genjax._amd.ops import Ops
+from genjax._amd.runtime import load_hip_ops, use_ops
+from genjax.inference.smc import ImportanceK
+
+hip, ora = load_hip_ops(), Ops(GjxLib(sys.argv[3], "cpu"))
+
+@gen
+def inner(m):
+    a = normal(m, 0.5) @ "a"
+    b = normal(a * 0.5 + m, torch.exp(a * 0.1)) @ "b"       # a program between two sites
+    return a + b
+
+@gen
+def model(s):
+    z = normal(0.0, 1.0) @ "z"
+    u = inner(z * s + 0.25) @ "u"                                  # a nested call: its own scope of site keys
+    k = flip(torch.sigmoid(u * 0.5)) @ "k"
+    normal(torch.where(k, z, u), 0.7) @ "obs"
+    return z
+
+@gen
+def step(carry, x):
+    v = normal(carry * 0.9 + x, 1.0) @ "v"
+    normal(v * v * 0.1, 0.5) @ "y"
+    return v, v
+
+def run(ops, impl):
+    out = {}
+    with use_ops(ops):
+        dev = ops.device()
+        n = 3000
+        keys = genjax.random.split(genjax.random.key(3, impl), n)
+        chm = C["obs"].set(0.3) | C["u", "a"].set(torch.linspace(-1, 1, n).to(dev))
+        tr, w = model.importance(keys, chm, (0.25,))
+        ch = tr.get_choices()
+        out["w"], out["score"], out["z"], out["b"], out["k"] = w, tr.get_score(), ch["z"], ch["u", "b"], ch["k"]
+        out["lz"] = ImportanceK(Target(model, (0.25,), C["obs"].set(0.3)), k_particles=5000).log_marginal_likelihood_estimate(genjax.random.key(5, impl))
+        T = 7
+        xs = torch.linspace(0.0, 1.0, T).to(dev)
+        skeys = genjax.random.split(genjax.random.key(9, impl), 2000)
+        schm = C[2, "y"].set(0.4) | C[5, "y"].set(-0.2)
+        str_, sw = step.scan().importance(skeys, schm, (0.5, xs))
+        out["sw"], out["sscore"] = sw, str_.get_score()
+    return {k: torch.as_tensor(v).detach().cpu() for k, v in out.items()}
+
+c0 = hip.jit_stats()["compiles"]
+for impl in (0, 1):
+    a, b = run(hip, impl), run(ora, impl)
+    for k in a:
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), (impl, k, a[k].reshape(-1)[:4], b[k].reshape(-1)[:4])
+assert hip.jit_stats()["compiles"] == c0, "GJX_PLAN_JIT=0 must not compile anything"
+print("ok")
+"""
+
+
+def test_bodies_with_programs_and_nested_calls_run_without_the_compiler():
+    """with the plan compiler switched off (GJX_PLAN_JIT=0) the table interpreters refuse plans that hold
+    programs (arithmetic between sites) or nested `@gen` calls — such bodies, importance plans and one-launch scans alike,
+    then take the PER-SITE path on the device (the documented route without a compiler: runtime.compiler_switched_off).  A
+    body with a nested call, programs (`exp`, `sigmoid`, `where`) and a flip, an `ImportanceK` estimate over it, and a scan
+    kernel with a program: choices, scores, weights and the estimate equal the ORACLE's (which walks the fused plan itself)
+    bit for bit under both generators, and nothing is compiled."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GJX_PLAN_JIT="0")
+    r = subprocess.run([sys.executable, "-c", NOJIT_CHILD, os.path.join(root, "genjax-chi_amd"), os.path.join(root, "tests"),
+                        os.path.join(root, "oracle", "libgjx_oracle.so")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

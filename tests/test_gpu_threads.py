@@ -84,3 +84,60 @@ def test_four_threads_four_streams():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ok" in r.stdout
+
+
+SHARED_ALG_CHILD = r"""
+import sys, threading
+sys.path.insert(0, sys.argv[1])
+import torch
+import genjax
+from genjax import ChoiceMapBuilder as C, Target, gen, normal
+from genjax.inference.smc import ImportanceK
+from genjax._amd.runtime import load_hip_ops, use_ops
+
+ops = load_hip_ops()
+
+@gen
+def model():
+    z = normal(0.0, 1.0) @ "z"
+    normal(z, 0.5) @ "y0"
+    normal(z * 0.5, 0.7) @ "y1"
+
+# two algorithm objects with the SAME structure and DIFFERENT observations (launch parameters of one specialised kernel),
+# both used by both threads at once: the estimate-only plan takes its parameters set-then-run
+algs = [ImportanceK(Target(model, (), C["y0"].set(a) | C["y1"].set(b)), k_particles=20000) for a, b in ((0.3, -0.2), (1.7, 0.9))]
+keys = [genjax.random.key(40 + i, 1) for i in range(24)]
+with use_ops(ops):
+    ref = [[float(alg.log_marginal_likelihood_estimate(k)) for k in keys] for alg in algs]
+    assert ref[0] != ref[1]
+    got, errors = {}, []
+    def work(t):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()), use_ops(ops):
+                out = [[], []]
+                for rep in range(6):
+                    for i, k in enumerate(keys):
+                        a = (i + t + rep) & 1            # the two threads alternate between the two objects, out of phase
+                        out[a].append((i, float(algs[a].log_marginal_likelihood_estimate(k))))
+                got[t] = out
+        except BaseException as ex:
+            errors.append((t, repr(ex)))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for t in range(2):
+        for a in range(2):
+            for i, v in got[t][a]:
+                assert v == ref[a][i], (t, a, i, v, ref[a][i])
+print("ok")
+"""
+
+
+def test_two_threads_share_two_algorithm_objects():
+    """`_fast_estimate` keeps its plan per algorithm object AND per host thread — a second thread must neither
+    reuse the first one's plan nor see its parameters change between `set_params` and the launch.  Two objects of one
+    structure with different observations, two threads alternating between them out of phase: every estimate equals the
+    single-thread one."""
+    r = subprocess.run([sys.executable, "-c", SHARED_ALG_CHILD, os.path.join(ROOT, "genjax-chi_amd")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
