@@ -385,26 +385,29 @@ def bench_smc_sharded(args, ops, rank, world, kind):
         import torch
         import torch.distributed as dist
 
-        ok, smc_p = 1, None
-        try:
-            sdt = torch.float32 if kind == "smc_lgssm" else torch.int32
-            arena = gdist.PeerArena.ipc(ops, rank, world, n_total, [sdt], False)
-            pcomm = gdist.NativeComm.peers(ops, arena, None, False, timeout_ms=30000)
-            smc_p = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world, arena=arena)
-            got = smc_p.run_native(pcomm)
-            if got["log_z"] != ref["log_z"]:
-                ok, why = 0, f"peer transport log Z {got['log_z']!r} != RCCL {ref['log_z']!r} on rank {rank}"
-        except Exception as ex:  # noqa: BLE001 - reported in the line
-            ok, why = 0, f"{type(ex).__name__}: {ex}"[:200]
-        votes = [None] * world
-        dist.all_gather_object(votes, (ok, why))
-        if all(v[0] for v in votes):
-            transport = "peers"
-            run = lambda: smc_p.run_native(pcomm)  # noqa: E731
-        else:
-            why = "; ".join(f"rank {r}: {v[1]}" for r, v in enumerate(votes) if not v[0])
-            if want == "peers":
-                raise RuntimeError("GJX_BENCH_TRANSPORT=peers: " + why)
+        sdt = torch.float32 if kind == "smc_lgssm" else torch.int32
+        reasons = []
+        for fine in (False, True):  # ordinary device memory first; fine-grained arenas as the second chance
+            ok, smc_p, why1 = 1, None, None
+            try:
+                arena = gdist.PeerArena.ipc(ops, rank, world, n_total, [sdt], False, fine_grained=fine)
+                pcomm = gdist.NativeComm.peers(ops, arena, None, False, timeout_ms=30000)
+                smc_p = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world, arena=arena)
+                got = smc_p.run_native(pcomm)
+                if got["log_z"] != ref["log_z"]:
+                    ok, why1 = 0, f"peer transport log Z {got['log_z']!r} != RCCL {ref['log_z']!r}"
+            except Exception as ex:  # noqa: BLE001 - reported in the line
+                ok, why1 = 0, f"{type(ex).__name__}: {ex}"[:160]
+            votes = [None] * world
+            dist.all_gather_object(votes, (ok, why1))
+            if all(v[0] for v in votes):
+                transport = "peers" + ("(fine-grained arenas)" if fine else "")
+                run = (lambda sp=smc_p, pc=pcomm: sp.run_native(pc))
+                break
+            reasons.append(("fine-grained: " if fine else "") + "; ".join(f"rank {r}: {v[1]}" for r, v in enumerate(votes) if not v[0]))
+        why = " | ".join(reasons) if transport == "rccl" else None
+        if transport == "rccl" and want == "peers":
+            raise RuntimeError("GJX_BENCH_TRANSPORT=peers: " + str(why))
     smc.received = 0
     runs = [0]
 
@@ -422,7 +425,7 @@ def bench_smc_sharded(args, ops, rank, world, kind):
         "config": {"workload": f"bootstrap SMC {kind} T={T} N={n_total} sharded x{world} (BASELINE configs[3] at world=8)",
                    "rng": args.rng, "shuffle": exchange,
                    "parallelism": (f"particle-sharded x{world}, peer transport: per step 1 step launch reading remote windows in place + 1 signal launch; no collective"
-                                   if transport == "peers" else
+                                   if transport.startswith("peers") else
                                    f"particle-sharded x{world}: 1 launch + ONE all-gather(tile records) + ancestor shuffle per step"),
                    "driver": "native" if native else "python", "transport": transport,
                    **({"peer_transport_not_used_because": why} if why else {}),

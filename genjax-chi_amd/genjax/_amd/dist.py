@@ -450,11 +450,13 @@ class PeerArena:
             raise RuntimeError("peer transport: a step's wait for its peers timed out (gjx_smc_peers.error)")
 
     @staticmethod
-    def ipc(ops: Ops, rank: int, world: int, n_total: int, state_dtypes: list, adaptive: bool) -> "PeerArena":
+    def ipc(ops: Ops, rank: int, world: int, n_total: int, state_dtypes: list, adaptive: bool, fine_grained: bool = False) -> "PeerArena":
         """The arena of one rank per PROCESS (one process per GPU, or processes sharing a device): allocated with hipMalloc,
         zeroed, handed to the peers through hipIpcGetMemHandle — the 64-byte handles travel over the `torch.distributed`
         process group the program already has — and every peer's arena mapped with hipIpcOpenMemHandle (peer access over xGMI
         when it lives on another device).  Collective over the group: every rank calls it with the same shape."""
+        # (the arrival words are polled with system-scope loads behind system-scope acquires and written with system-scope
+        # release stores: correct by the memory model for any device memory a peer can map)
         import ctypes as C
 
         dist = _dist()
@@ -469,7 +471,15 @@ class PeerArena:
         # every rank reaches every collective below whatever fails locally: failures are VOTED on, so that no rank is left
         # waiting in a collective its peer never enters
         mine, err, h = C.c_void_p(), None, IpcHandle()
-        if hip.hipMalloc(C.byref(mine), C.c_size_t(nb)) != 0 or hip.hipMemset(mine, 0, C.c_size_t(nb)) != 0 or hip.hipDeviceSynchronize() != 0:
+        # fine_grained: hipExtMallocWithFlags(hipDeviceMallocFinegrained) — device memory that stays coherent with peers' accesses
+        # without cache maintenance (slower for the bulk columns; the fallback when a peer's arrival words written into ordinary
+        # device memory do not become visible to a polling kernel on some platform)
+        if fine_grained:
+            hip.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+            rc_alloc = hip.hipExtMallocWithFlags(C.byref(mine), C.c_size_t(nb), 0x1)
+        else:
+            rc_alloc = hip.hipMalloc(C.byref(mine), C.c_size_t(nb))
+        if rc_alloc != 0 or hip.hipMemset(mine, 0, C.c_size_t(nb)) != 0 or hip.hipDeviceSynchronize() != 0:
             err = "hipMalloc / hipMemset failed"
         elif hip.hipIpcGetMemHandle(C.byref(h), mine) != 0:
             err = "hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 is required on this driver)"
