@@ -204,84 +204,53 @@ def test_peer_transport_lost_peer_on_device(hip_ops):
 
 
 IPC_CHILD = r"""
-import ctypes as C, os, sys, time
-root, rank, world, outdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+import os, sys
+root, rank, world, outdir, port, fine = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], int(sys.argv[6])
 sys.path.insert(0, os.path.join(root, "genjax-chi_amd"))
 import torch
+import torch.distributed as tdist
 from genjax._amd import dist as gdist
 from genjax._amd.runtime import load_hip_ops
 
 ops = load_hip_ops()
-hip = C.CDLL("libamdhip64.so")
+tdist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
 kind, impl, seed, n_total, T = "lgssm", 1, 5, 1024 * world * 6, 8
-nbytes = gdist.PeerArena.nbytes(ops, n_total, [torch.float32], False)
-mine = C.c_void_p()
-assert hip.hipMalloc(C.byref(mine), C.c_size_t(nbytes)) == 0
-assert hip.hipMemset(mine, 0, C.c_size_t(nbytes)) == 0 and hip.hipDeviceSynchronize() == 0
-class IpcHandle(C.Structure):  # hipIpcMemHandle_t: 64 opaque bytes, passed BY VALUE to hipIpcOpenMemHandle
-    _fields_ = [("reserved", C.c_char * 64)]
-
-hip.hipIpcGetMemHandle.argtypes = [C.POINTER(IpcHandle), C.c_void_p]
-hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), IpcHandle, C.c_uint]
-handle = IpcHandle()
-rc = hip.hipIpcGetMemHandle(C.byref(handle), mine)
-assert rc == 0, f"hipIpcGetMemHandle -> {rc}"
-with open(os.path.join(outdir, f"h{rank}.tmp"), "wb") as f:
-    f.write(bytes(handle))
-os.rename(os.path.join(outdir, f"h{rank}.tmp"), os.path.join(outdir, f"h{rank}.bin"))
-
-def wait_for(name):
-    t0 = time.time()
-    while not os.path.exists(os.path.join(outdir, name)):
-        assert time.time() - t0 < 120, "peer did not show up: " + name
-        time.sleep(0.01)
-
-ptrs = [None] * world
-for o in range(world):
-    if o == rank:
-        ptrs[o] = mine.value
-        continue
-    wait_for(f"h{o}.bin")
-    hb = IpcHandle.from_buffer_copy(open(os.path.join(outdir, f"h{o}.bin"), "rb").read())
-    p = C.c_void_p()
-    rc = hip.hipIpcOpenMemHandle(C.byref(p), hb, 1)  # hipIpcMemLazyEnablePeerAccess
-    assert rc == 0, f"hipIpcOpenMemHandle -> {rc}"
-    ptrs[o] = p.value
-
-class _Dev:
-    __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (mine.value, False), "version": 2}
-
-block = torch.as_tensor(_Dev(), device="cuda")
-arena = gdist.PeerArena(block, [ptrs[o] - mine.value for o in range(world)], rank, world)
+# the product's own arena set-up (dist.PeerArena.ipc: hipMalloc or fine-grained hipExtMallocWithFlags, hipIpcGetMemHandle, the
+# handles over the process group, hipIpcOpenMemHandle, a vote on failures) — what bench.py runs at N > 1
+arena = gdist.PeerArena.ipc(ops, rank, world, n_total, [torch.float32], False, fine_grained=bool(fine))
 comm = gdist.NativeComm.peers(ops, arena, None, True, timeout_ms=60000)  # ranks share the device: a wait launch per step
-open(os.path.join(outdir, f"ready{rank}"), "w").close()
-for o in range(world):
-    wait_for(f"ready{o}")       # every arena is zeroed and mapped before anybody signals into it
-smc = gdist.ShardedSMC(ops, kind, impl, seed, n_total, T, rank, world, True, arena=arena)
-res = smc.run_native(comm)
-torch.cuda.synchronize()
-torch.save({k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in res.items() if k in ("state", "logw", "ancestors", "out_e", "out_q", "log_z")},
-           os.path.join(outdir, f"res{rank}.pt"))
-open(os.path.join(outdir, f"done{rank}"), "w").close()
-for o in range(world):
-    wait_for(f"done{o}")        # nobody unmaps / frees while a peer may still read
+for run in range(2):  # two runs on one communicator: the arrival words keep growing
+    smc = gdist.ShardedSMC(ops, kind, impl, seed + run, n_total, T, rank, world, True, arena=arena)
+    res = smc.run_native(comm)
+    torch.cuda.synchronize()
+    torch.save({k: (v.cpu().clone() if isinstance(v, torch.Tensor) else v) for k, v in res.items()
+                if k in ("state", "logw", "ancestors", "out_e", "out_q", "log_z")}, os.path.join(outdir, f"res{run}_{rank}.pt"))
+    tdist.barrier()
+tdist.barrier()   # nobody unmaps / frees while a peer may still read
+tdist.destroy_process_group()
 print("ok", rank)
 """
 
 
-def test_peer_transport_two_processes_one_gpu_ipc(tmp_path, oracle_ops):
-    """two REAL processes share the one GPU; each allocates its arena with hipMalloc, hands it to the
-    other through hipIpcGetMemHandle / hipIpcOpenMemHandle, and runs `gjx_smc_sharded_run_lgssm` over the peer transport
-    (wait launches in front of the steps, as the ranks compete for one device).  Particles, ancestors, (e, q) and log Z equal
-    the single-rank oracle filter bit for bit."""
+@pytest.mark.parametrize("fine", [0, 1])
+def test_peer_transport_two_processes_one_gpu_ipc(tmp_path, oracle_ops, fine):
+    """two REAL processes share the one GPU; each allocates its arena (ordinary device memory, or
+    fine-grained: bench.py's second chance), hands it to the other through hipIpcGetMemHandle / hipIpcOpenMemHandle
+    (`dist.PeerArena.ipc`, the handles over a gloo process group), and runs `gjx_smc_sharded_run_lgssm` over the peer
+    transport, twice on one communicator (wait launches in front of the steps, as the ranks compete for one device).
+    Particles, ancestors, (e, q) and log Z equal the single-rank oracle filter bit for bit."""
     import os
+    import socket
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     world = 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, "-c", IPC_CHILD, root, str(r), str(world), str(tmp_path)], env=env,
+    procs = [subprocess.Popen([sys.executable, "-c", IPC_CHILD, root, str(r), str(world), str(tmp_path), str(port), str(fine)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
@@ -292,10 +261,11 @@ def test_peer_transport_two_processes_one_gpu_ipc(tmp_path, oracle_ops):
             out, _ = p.communicate()
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    res = [torch.load(os.path.join(tmp_path, f"res{r}.pt")) for r in range(world)]
-    ref = W.lgssm_smc(oracle_ops, 1, 5, 1024 * world * 6, 8, True)
-    assert torch.equal(torch.cat([r["state"] for r in res]), ref["state"])
-    assert torch.equal(torch.cat([r["logw"] for r in res]), ref["logw"])
-    assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1), ref["ancestors"])
-    for r in res:
-        assert torch.equal(r["out_q"], ref["out_q"]) and torch.equal(r["out_e"], ref["out_e"]) and r["log_z"] == ref["log_z"]
+    for run in range(2):
+        res = [torch.load(os.path.join(tmp_path, f"res{run}_{r}.pt")) for r in range(world)]
+        ref = W.lgssm_smc(oracle_ops, 1, 5 + run, 1024 * world * 6, 8, True)
+        assert torch.equal(torch.cat([r["state"] for r in res]), ref["state"])
+        assert torch.equal(torch.cat([r["logw"] for r in res]), ref["logw"])
+        assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1), ref["ancestors"])
+        for r in res:
+            assert torch.equal(r["out_q"], ref["out_q"]) and torch.equal(r["out_e"], ref["out_e"]) and r["log_z"] == ref["log_z"]
