@@ -1143,6 +1143,11 @@ struct PeerMap {
   uint32_t* error = nullptr;        // set to 1 by a wait that timed out
   uint64_t wait_value = 0;
   uint64_t timeout_ticks = 0;       // of s_memrealtime (100 MHz)
+  // a deferred signal (gjx.h gjx_smc_peers.signal_*): what the group-record launch deposits and raises before it waits
+  int32_t rank = 0;
+  const TileRec* sig_recs = nullptr;
+  const TileEss* sig_ess = nullptr;
+  uint64_t sig_first = 0, sig_n = 0, sig_value = 0;
 };
 template <class T>
 GJX_DEV const T* peer_ptr(const T* p, int64_t delta) {

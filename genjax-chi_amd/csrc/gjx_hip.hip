@@ -612,9 +612,8 @@ __global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P) {
 // makes its stores visible at system scope, and then one thread raises this rank's arrival word in rank o's flags.  The
 // launch runs after the step's launch on the same stream, so what the step wrote to this rank's own arena (weights, state,
 // sub-prefixes) is complete in memory when a peer sees the word.
-__global__ __launch_bounds__(kBlock) void k_peer_signal(PeerMap pm, int32_t rank, const TileRec* recs, const TileEss* ess,
-                                                        uint64_t first_tile, uint64_t n_tiles, uint64_t value) {
-  const int o = (int)blockIdx.x;
+GJX_DEV void peer_deposit_and_raise(const PeerMap& pm, int o, int32_t rank, const TileRec* recs, const TileEss* ess, uint64_t first_tile,
+                                    uint64_t n_tiles, uint64_t value) {
   if (o != rank && recs) {
     TileRec* dst = const_cast<TileRec*>(peer_ptr(recs, pm.delta[o]));
     for (uint64_t k = threadIdx.x; k < n_tiles; k += kBlock) {
@@ -636,6 +635,10 @@ __global__ __launch_bounds__(kBlock) void k_peer_signal(PeerMap pm, int32_t rank
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the flag must not overtake the write-back: MI355X guide, compiler hazard)
     __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+__global__ __launch_bounds__(kBlock) void k_peer_signal(PeerMap pm, int32_t rank, const TileRec* recs, const TileEss* ess,
+                                                        uint64_t first_tile, uint64_t n_tiles, uint64_t value) {
+  peer_deposit_and_raise(pm, (int)blockIdx.x, rank, recs, ess, first_tile, n_tiles, value);
 }
 __global__ __launch_bounds__(kWave) void k_peer_wait(PeerMap pm) { (void)peer_wait_wave(pm); }
 
@@ -851,6 +854,11 @@ __global__ __launch_bounds__(kBlock) void k_group_records(const TileRec* recs, c
   __shared__ uint32_t sh_ok;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   if (pm.world > 0) {
+    // a deferred signal of the previous step (gjx_smc_peers.signal_*): workgroup o serves rank o before anybody waits — the
+    // signal launch of step t and this waiting launch of step t + 1 are one launch
+    if (pm.sig_value != 0 && (int)blockIdx.x < pm.world)
+      peer_deposit_and_raise(pm, (int)blockIdx.x, pm.rank, pm.sig_recs, pm.sig_ess, pm.sig_first, pm.sig_n, pm.sig_value);
+    if ((uint64_t)blockIdx.x * kGroupTiles >= ntiles) return;  // (workgroups launched for the signal alone)
     if (wv == 0) {
       const bool ready = peer_wait_wave(pm);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -918,8 +926,9 @@ static bool launch_group_records(ResampleArgs& A, uint64_t* scratch, hipStream_t
       ng * sizeof(GroupRec) > prefix_words(A.ntiles) * sizeof(uint64_t))
     return false;
   GroupRec* groups = reinterpret_cast<GroupRec*>(scratch);
-  if (A.ess) k_group_records<true><<<(unsigned)ng, kBlock, 0, st>>>(A.recs, A.ess, A.ntiles, groups, A.pm);
-  else k_group_records<false><<<(unsigned)ng, kBlock, 0, st>>>(A.recs, A.ess, A.ntiles, groups, A.pm);
+  const unsigned grid = (unsigned)(A.pm.world > 0 && A.pm.sig_value != 0 && (uint64_t)A.pm.world > ng ? (uint64_t)A.pm.world : ng);
+  if (A.ess) k_group_records<true><<<grid, kBlock, 0, st>>>(A.recs, A.ess, A.ntiles, groups, A.pm);
+  else k_group_records<false><<<grid, kBlock, 0, st>>>(A.recs, A.ess, A.ntiles, groups, A.pm);
   A.groups = groups;
   A.prefix = nullptr;
   return true;
@@ -2812,6 +2821,10 @@ static PeerMap peer_map_of(const gjx_smc_peers* p, uint64_t n_total) {
   pm.error = p->error;
   pm.wait_value = p->wait_value;
   pm.timeout_ticks = (uint64_t)(p->timeout_ms ? p->timeout_ms : 10000u) * 100000ull;  // s_memrealtime: 100 MHz
+  pm.rank = p->rank;
+  pm.sig_recs = reinterpret_cast<const TileRec*>(p->signal_recs);
+  pm.sig_ess = reinterpret_cast<const TileEss*>(p->signal_ess);
+  pm.sig_first = p->signal_first_tile; pm.sig_n = p->signal_n_tiles; pm.sig_value = p->signal_value;
   return pm;
 }
 // The arguments of a step's resample launch; for populations beyond kMaxLdsTiles the records of `prev` are merged
@@ -2857,7 +2870,12 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
     const unsigned nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
     if (nf == 1 && A.ntiles > (uint64_t)kMaxLdsTiles && launch_group_records(A, prev->prefix, S(s))) {
       A.pm.wait_value = 0;  // (peers: the group launch has waited for them; the step launch behind it need not)
+      A.pm.sig_value = 0;   // (... and has delivered the deferred signal)
       return GJX_OK;        // (r04: the grouped route — no whole-population scan, no prefix array)
+    }
+    if (cfg->peers && A.pm.sig_value != 0) {  // (a deferred signal and no group launch to carry it: its own launch after all)
+      k_peer_signal<<<(unsigned)A.pm.world, kBlock, 0, S(s)>>>(A.pm, A.pm.rank, A.pm.sig_recs, A.pm.sig_ess, A.pm.sig_first, A.pm.sig_n, A.pm.sig_value);
+      A.pm.sig_value = 0;
     }
     if (nf == 1 && A.ntiles <= (uint64_t)kBigBlock * kBigPer) {
       // (peers: the records in this rank's arena are complete only once every peer has arrived — the merge launch reads them
@@ -2869,6 +2887,10 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
       k_scan_records<<<nf, kBlock, 0, S(s)>>>(A.recs, A.ess, A.ntiles, prev->prefix, nullptr, nullptr, 0);
     }
     A.prefix = prev->prefix;
+  }
+  if (cfg->peers && A.pm.sig_value != 0) {  // (a deferred signal on a route without a waiting launch in front: its own launch)
+    k_peer_signal<<<(unsigned)A.pm.world, kBlock, 0, S(s)>>>(A.pm, A.pm.rank, A.pm.sig_recs, A.pm.sig_ess, A.pm.sig_first, A.pm.sig_n, A.pm.sig_value);
+    A.pm.sig_value = 0;
   }
   return GJX_OK;
 }
@@ -3002,6 +3024,13 @@ int gjx_smc_peer_signal(const gjx_smc_peers* peers, const gjx_tile_rec* recs, co
   k_peer_signal<<<(unsigned)peers->world, kBlock, 0, S(s)>>>(peer_map_of(peers, 0), peers->rank, reinterpret_cast<const TileRec*>(recs),
                                                              reinterpret_cast<const TileEss*>(ess), first_tile, n_tiles, value);
   return launch_status();
+}
+int gjx_smc_peer_signal_fused(const gjx_smc_config* cfg) {
+  // (the group-record route: one filter beyond kMaxLdsTiles tiles, within kMaxGroups groups, not switched off)
+  if (!cfg || !cfg->peers || cfg->n_filters > 1) return 0;
+  static const bool allow = [] { const char* e = std::getenv("GJX_SMC_BIG_ROUTE"); return !(e && e[0] == 'p'); }();
+  const uint64_t nt = ntiles_of(cfg->n_total);
+  return allow && nt > (uint64_t)kMaxLdsTiles && (nt + kGroupTiles - 1) / kGroupTiles <= (uint64_t)kMaxGroups ? 1 : 0;
 }
 int gjx_smc_peer_wait(const gjx_smc_peers* peers, uint64_t value, gjx_stream s) {
   if (!peers_desc_ok(peers)) return GJX_ERR_INVALID;
@@ -3763,7 +3792,8 @@ int gjx_comm_init_peers(const gjx_smc_peers* peers, gjx_comm_group* group, int w
   if (!out) return GJX_ERR_INVALID;
   gjx_comm* c = new (std::nothrow) gjx_comm;
   if (!c) return GJX_ERR_LAUNCH;
-  const int rc = gjx_sharded::comm_init_peers(peers, group ? &group->g : nullptr, wait_launch, &c->t);
+  // (virtual ranks of one process share a device stream: their launches execute in enqueue order)
+  const int rc = gjx_sharded::comm_init_peers(peers, group ? &group->g : nullptr, wait_launch, group != nullptr, &c->t);
   if (rc) {
     delete c;
     return rc;

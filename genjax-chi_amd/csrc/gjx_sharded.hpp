@@ -41,6 +41,8 @@ struct Transport {
   // ... virtual ranks sharing one stream: every rank's signal is ENQUEUED before any rank enqueues the launch that waits for it
   virtual bool enqueue_barrier() { return true; }
   int wait_launch = 0;  // a one-workgroup wait launch in front of every step (ranks that share a device as processes)
+  bool serial_stream = false;  // the ranks' launches execute in ENQUEUE order on one stream (virtual ranks on a device): a
+                               // launch that waits for a peer must not also carry this rank's signal
   uint64_t epoch = 0;   // every rank's arrival words are >= epoch once its previous run is complete (0: freshly allocated)
 };
 inline size_t seg_off(uint64_t a, size_t elem, size_t unit) { return (size_t)(a / unit) * elem; }
@@ -172,13 +174,15 @@ struct PeerTransport : Transport {
     g->cv.notify_all();
   }
 };
-inline int comm_init_peers(const gjx_smc_peers* peers, Group* g, int wait_launch, Transport** out) {
+inline int comm_init_peers(const gjx_smc_peers* peers, Group* g, int wait_launch, bool serial_stream, Transport** out) {
   if (!out || !peers || peers->world < 2 || peers->world > GJX_MAX_PEERS || peers->rank < 0 || peers->rank >= peers->world ||
       !peers->flags || !peers->error || peers->delta[peers->rank] != 0 || (g && g->world != peers->world))
     return GJX_ERR_INVALID;
   PeerTransport* t = new (std::nothrow) PeerTransport;
   if (!t) return GJX_ERR_LAUNCH;
   t->rank = peers->rank; t->world = peers->world; t->p = *peers; t->g = g; t->wait_launch = wait_launch;
+  t->serial_stream = serial_stream;
+  t->p.signal_value = 0;
   *out = t;
   return GJX_OK;
 }
@@ -299,6 +303,10 @@ int sharded_steps_peers(Transport& T, const gjx_smc_config* cfg0, int n_state, c
   const int n_steps = cfg.n_steps;
   const uint64_t base = T.epoch;
   T.epoch = base + (uint64_t)n_steps + 1;  // (whatever happens below: the next run must not wait for words of this one)
+  // a step's first launch can carry the previous step's signal (large populations: the group-record launch waits anyway) —
+  // unless a wait launch goes in front of it, or all ranks' launches share one stream (a launch that both signals and waits
+  // would wait for signals queued behind it)
+  const bool defer = gjx_smc_peer_signal_fused(&cfg) != 0 && !T.wait_launch && !T.serial_stream;
   int rc = GJX_OK;
   for (int t = 0; t < n_steps && rc == GJX_OK; ++t) {
     const int cur = t & 1, prv = cur ^ 1;
@@ -310,10 +318,19 @@ int sharded_steps_peers(Transport& T, const gjx_smc_config* cfg0, int n_state, c
     P.wait_value = base + (uint64_t)t;
     if (!T.enqueue_barrier()) return GJX_ERR_LAUNCH;
     if ((t == 0 || T.wait_launch) && (rc = gjx_smc_peer_wait(&P, P.wait_value, s))) break;
-    if ((rc = step(&cfg, t, &io->pop[prv], &out, t ? io->out_e + (t - 1) : nullptr, t ? io->out_q + (t - 1) : nullptr,
-                   io->ancestors ? io->ancestors + (size_t)t * nl : nullptr)))
-      break;
-    rc = gjx_smc_peer_signal(&P, full.recs, adaptive ? full.ess : nullptr, tile0, tiles_local, base + (uint64_t)t + 1, s);
+    rc = step(&cfg, t, &io->pop[prv], &out, t ? io->out_e + (t - 1) : nullptr, t ? io->out_q + (t - 1) : nullptr,
+              io->ancestors ? io->ancestors + (size_t)t * nl : nullptr);
+    P.signal_value = 0;  // (a deferred signal has gone out with that step's first launch)
+    if (rc) break;
+    if (defer && t >= 0 && t + 1 < n_steps) {  // step t + 1's first launch deposits step t's records and raises the word
+      P.signal_recs = full.recs;
+      P.signal_ess = adaptive ? full.ess : nullptr;
+      P.signal_first_tile = tile0;
+      P.signal_n_tiles = tiles_local;
+      P.signal_value = base + (uint64_t)t + 1;
+    } else {
+      rc = gjx_smc_peer_signal(&P, full.recs, adaptive ? full.ess : nullptr, tile0, tiles_local, base + (uint64_t)t + 1, s);
+    }
   }
   if (rc) return rc;
   if (!T.enqueue_barrier()) return GJX_ERR_LAUNCH;

@@ -267,6 +267,11 @@ class SmcPeers(C.Structure):
         ("wait_value", C.c_uint64),
         ("timeout_ms", C.c_uint32),
         ("pad", C.c_int32),
+        ("signal_recs", C.c_void_p),      # a deferred signal (gjx.h): set by the sharded drivers
+        ("signal_ess", C.c_void_p),
+        ("signal_first_tile", C.c_uint64),
+        ("signal_n_tiles", C.c_uint64),
+        ("signal_value", C.c_uint64),
     ]
 
 
@@ -410,6 +415,7 @@ PROTOTYPES = {
     "gjx_comm_init_peers": (C.c_int, [C.POINTER(SmcPeers), _P, C.c_int, C.POINTER(_P)]),
     "gjx_smc_peer_signal": (C.c_int, [C.POINTER(SmcPeers), _P, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
     "gjx_smc_peer_wait": (C.c_int, [C.POINTER(SmcPeers), C.c_uint64, _P]),
+    "gjx_smc_peer_signal_fused": (C.c_int, [C.POINTER(SmcConfig)]),
     "gjx_smc_records_pack": (C.c_int, [C.POINTER(SmcConfig), C.c_int, C.c_int, _P, _P, _P, _P]),
     "gjx_hmm_alias_words": (C.c_uint64, [C.c_int32]),
     "gjx_hmm_prepare": (C.c_int, [C.POINTER(Hmm), _P, _P, _P]),
@@ -425,6 +431,7 @@ _NO_STATUS = {
     "gjx_hmm_alias_words",
     "gjx_comm_rank",
     "gjx_comm_world",
+    "gjx_smc_peer_signal_fused",
 }
 
 

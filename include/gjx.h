@@ -553,6 +553,13 @@ typedef struct gjx_smc_peers {
   uint64_t wait_value;          /* what the step waits for (the sharded drivers set it per step) */
   uint32_t timeout_ms;
   int32_t pad;
+  /* A DEFERRED signal (signal_value != 0; the sharded drivers set it when gjx_smc_peer_signal_fused() says so): the step's
+   * first launch — the group-record launch of a population beyond 1024 tiles, which waits for the peers anyway — first
+   * deposits these records of the PREVIOUS step and raises signal_value, exactly as gjx_smc_peer_signal would have: the
+   * signal launch of step t and the waiting launch of step t + 1 are ONE launch. */
+  const gjx_tile_rec* signal_recs;
+  const gjx_tile_ess* signal_ess;
+  uint64_t signal_first_tile, signal_n_tiles, signal_value;
 } gjx_smc_peers;
 
 /* Layout-independent description of one SMC run. */
@@ -801,6 +808,8 @@ int gjx_comm_init_peers(const gjx_smc_peers* peers /*host; copied*/, gjx_comm_gr
 int gjx_smc_peer_signal(const gjx_smc_peers* peers, const gjx_tile_rec* recs, const gjx_tile_ess* ess, uint64_t first_tile,
                         uint64_t n_tiles, uint64_t value, gjx_stream s);
 int gjx_smc_peer_wait(const gjx_smc_peers* peers, uint64_t value, gjx_stream s);
+/* 1 if a step t >= 1 of this configuration absorbs a deferred signal (gjx_smc_peers.signal_*) into its first launch. */
+int gjx_smc_peer_signal_fused(const gjx_smc_config* cfg);
 int gjx_comm_destroy(gjx_comm* c);
 int gjx_comm_rank(const gjx_comm* c);
 int gjx_comm_world(const gjx_comm* c);

@@ -1107,6 +1107,10 @@ static int peer_wait_host(const gjx_smc_peers* p, uint64_t value) {
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return 1;
 }
+int gjx_smc_peer_signal_fused(const gjx_smc_config* cfg) {
+  /* (as the device library: populations beyond 1024 tiles — there the step's first launch waits for the peers anyway) */
+  return cfg && cfg->peers && cfg->n_filters <= 1 && gjx_num_tiles(cfg->n_total) > 1024 ? 1 : 0;
+}
 int gjx_smc_peer_wait(const gjx_smc_peers* peers, uint64_t value, gjx_stream s) {
   (void)s;
   if (!peers || peers->world < 2 || peers->world > GJX_MAX_PEERS || !peers->flags || !peers->error) return GJX_ERR_INVALID;
@@ -1378,6 +1382,11 @@ static int smc_step_generic(const gjx_smc_config* cfg, int t, int n_state, const
   if (!pop_ok(out, n_state, ad) || (t > 0 && (!pop_ok(prev, n_state, ad) || prev->recs == out->recs))) return GJX_ERR_INVALID;
   if (cfg->peers) { /* the peer transport: nothing of the source population is read before every peer has arrived */
     if (!peers_ok(cfg)) return GJX_ERR_INVALID;
+    if (cfg->peers->signal_value != 0) { /* a deferred signal of the previous step goes out first (gjx.h) */
+      const int rc = gjx_smc_peer_signal(cfg->peers, cfg->peers->signal_recs, cfg->peers->signal_ess, cfg->peers->signal_first_tile,
+                                         cfg->peers->signal_n_tiles, cfg->peers->signal_value, NULL);
+      if (rc) return rc;
+    }
     if (t > 0 && !peer_wait_host(cfg->peers, cfg->peers->wait_value)) return GJX_ERR_LAUNCH;
   }
   const uint64_t nl = cfg->n_local;

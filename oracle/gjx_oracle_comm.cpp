@@ -61,7 +61,8 @@ int gjx_comm_init_peers(const gjx_smc_peers* peers, gjx_comm_group* group, int w
   if (!out) return GJX_ERR_INVALID;
   gjx_comm* c = new (std::nothrow) gjx_comm;
   if (!c) return GJX_ERR_LAUNCH;
-  const int rc = gjx_sharded::comm_init_peers(peers, group ? &group->g : nullptr, wait_launch, &c->t);
+  // (the oracle's virtual ranks are threads whose steps run synchronously and concurrently: nothing queues behind anything)
+  const int rc = gjx_sharded::comm_init_peers(peers, group ? &group->g : nullptr, wait_launch, false, &c->t);
   if (rc) {
     delete c;
     return rc;

@@ -517,6 +517,21 @@ def test_peer_transport_adaptive_plan_and_reuse(oracle_ops):
     assert [int(x) for x in arenas[0].flags[:world]] == [6 + 1 + 7 + 1] * world
 
 
+def test_peer_transport_deferred_signal(oracle_ops):
+    """Populations beyond 1024 tiles: a step's first launch waits for the peers anyway, so the sharded driver hands it the
+    PREVIOUS step's signal (gjx_smc_peers.signal_*: records into the peers' arenas, arrival word) instead of a launch of its
+    own — two ranks as concurrent threads, 1040 tiles, every-step and ESS-adaptive: equal to the single-rank filter."""
+    import ctypes as C
+
+    from genjax._amd import abi
+
+    cfg = abi.SmcConfig()
+    cfg.n_total, cfg.peers = 1040 * 1024, C.pointer(abi.SmcPeers())
+    assert oracle_ops.lib.call("gjx_smc_peer_signal_fused", C.byref(cfg)) == 1
+    check_virtual_ranks(oracle_ops, "lgssm", 1, 2, 1024 * 2 * 520, 5, "ranges", native="peers")
+    check_virtual_ranks(oracle_ops, "hmm", 0, 2, 1024 * 2 * 520, 4, "ranges", ess_threshold=0.5, native="peers")
+
+
 def test_peer_transport_worst_case_weights(oracle_ops):
     check_degenerate_sharded(oracle_ops, 1, 4, native="peers")
     check_impossible_observation_sharded(oracle_ops, 1, 3, "peers")

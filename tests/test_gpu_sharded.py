@@ -205,7 +205,7 @@ def test_peer_transport_lost_peer_on_device(hip_ops):
 
 IPC_CHILD = r"""
 import os, sys
-root, rank, world, outdir, port, fine = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], int(sys.argv[6])
+root, rank, world, outdir, port, fine, big = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7])
 sys.path.insert(0, os.path.join(root, "genjax-chi_amd"))
 import torch
 import torch.distributed as tdist
@@ -214,11 +214,14 @@ from genjax._amd.runtime import load_hip_ops
 
 ops = load_hip_ops()
 tdist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-kind, impl, seed, n_total, T = "lgssm", 1, 5, 1024 * world * 6, 8
+kind, impl, seed, n_total, T = "lgssm", 1, 5, 1024 * world * (576 if big else 6), (6 if big else 8)
 # the product's own arena set-up (dist.PeerArena.ipc: hipMalloc or fine-grained hipExtMallocWithFlags, hipIpcGetMemHandle, the
 # handles over the process group, hipIpcOpenMemHandle, a vote on failures) — what bench.py runs at N > 1
 arena = gdist.PeerArena.ipc(ops, rank, world, n_total, [torch.float32], False, fine_grained=bool(fine))
-comm = gdist.NativeComm.peers(ops, arena, None, True, timeout_ms=60000)  # ranks share the device: a wait launch per step
+# small: a wait launch per step (the ranks share the device, and a step's 12 workgroups would wait inside the step launch);
+# big (1152 tiles): the step's first launch is the group-record launch — it carries the previous step's DEFERRED signal and
+# waits for the peer itself (a handful of workgroups: the peer's launches run beside it), so no wait launch and no signal launch
+comm = gdist.NativeComm.peers(ops, arena, None, not big, timeout_ms=60000)
 for run in range(2):  # two runs on one communicator: the arrival words keep growing
     smc = gdist.ShardedSMC(ops, kind, impl, seed + run, n_total, T, rank, world, True, arena=arena)
     res = smc.run_native(comm)
@@ -232,8 +235,8 @@ print("ok", rank)
 """
 
 
-@pytest.mark.parametrize("fine", [0, 1])
-def test_peer_transport_two_processes_one_gpu_ipc(tmp_path, oracle_ops, fine):
+@pytest.mark.parametrize("fine,big", [(0, 0), (1, 0), (0, 1)])
+def test_peer_transport_two_processes_one_gpu_ipc(tmp_path, oracle_ops, fine, big):
     """two REAL processes share the one GPU; each allocates its arena (ordinary device memory, or
     fine-grained: bench.py's second chance), hands it to the other through hipIpcGetMemHandle / hipIpcOpenMemHandle
     (`dist.PeerArena.ipc`, the handles over a gloo process group), and runs `gjx_smc_sharded_run_lgssm` over the peer
@@ -250,7 +253,7 @@ def test_peer_transport_two_processes_one_gpu_ipc(tmp_path, oracle_ops, fine):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, "-c", IPC_CHILD, root, str(r), str(world), str(tmp_path), str(port), str(fine)], env=env,
+    procs = [subprocess.Popen([sys.executable, "-c", IPC_CHILD, root, str(r), str(world), str(tmp_path), str(port), str(fine), str(big)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
@@ -263,7 +266,7 @@ def test_peer_transport_two_processes_one_gpu_ipc(tmp_path, oracle_ops, fine):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     for run in range(2):
         res = [torch.load(os.path.join(tmp_path, f"res{run}_{r}.pt")) for r in range(world)]
-        ref = W.lgssm_smc(oracle_ops, 1, 5 + run, 1024 * world * 6, 8, True)
+        ref = W.lgssm_smc(oracle_ops, 1, 5 + run, 1024 * world * (576 if big else 6), 6 if big else 8, True)
         assert torch.equal(torch.cat([r["state"] for r in res]), ref["state"])
         assert torch.equal(torch.cat([r["logw"] for r in res]), ref["logw"])
         assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1), ref["ancestors"])
