@@ -600,10 +600,11 @@ def bench_sharded_rank0_virtual(args, ops, world=8, steps=40):
 
         def block(kk):
             for _ in range(kk):
+                if name == "peers":  # the step's group-record launch carries the previous step's (deferred) signal, as the driver has it
+                    pst.signal_recs, pst.signal_ess = pops[1].recs.data_ptr(), None
+                    pst.signal_first_tile, pst.signal_n_tiles, pst.signal_value = 0, tl, 1 << 62
                 ops.smc_lgssm_step(cfg, model, T0, float(y[T0]), pops[0].struct(), pops[1].struct(0, with_logw=False), None, None, None)
-                if name == "peers":
-                    ops.lib.call("gjx_smc_peer_signal", C.byref(pst), ops._p(pops[1].recs), None, 0, tl, 1 << 62, ops.stream())
-                else:
+                if name != "peers":
                     ops.smc_source_ranges(cfg, pops[1].recs, None, world, ranges, 1)
 
         block(4)
@@ -620,8 +621,8 @@ def bench_sharded_rank0_virtual(args, ops, world=8, steps=40):
             dev.append(e0.elapsed_ms(e1) / steps)
         out[name] = {"step_us_device": statistics.median(dev) * 1e3, "host_us_per_step": statistics.median(host) * 1e6}
     arenas[0].check(ops)
-    out["peers"].update(launches_per_step=3, collectives_per_step=0, host_decisions_per_step=0,
-                        what="group-record launch (waits for the peers; 31 workgroups) + step launch (remote windows read in place) + signal launch (records into 8 arenas)")
+    out["peers"].update(launches_per_step=2, collectives_per_step=0, host_decisions_per_step=0,
+                        what="group-record launch (first the previous step's records into the 8 arenas + arrival word, then the wait for the peers, then 31 workgroups of group records) + step launch (remote windows read in place)")
     out["collective_kernels"].update(
         launches_per_step=3, collectives_per_step=2, host_decisions_per_step=1,
         what="group records + step + range kernel: what an RCCL rank launches; on top come 1 all-gather + 1 grouped send/recv (20-50 us each on xGMI) and the host's poll of the range ticket")
