@@ -461,7 +461,19 @@ inline void emit_prelude(std::ostringstream& o, bool fast_math = false, bool bm_
   o << "__device__ __forceinline__ float jrow_max(const float* l, uint32_t K){ float m=l[0]; for(uint32_t c=1;c<K;++c) m = l[c]>m?l[c]:m; return m; }\n";
   o << "__device__ __forceinline__ float jrow_lse(const float* l, uint32_t K){ const float m=jrow_max(l,K); float acc=0.0f; for(uint32_t c=0;c<K;++c) acc = acc + m_exp(l[c]-m); return m + m_log(acc); }\n";
   o << "__device__ __forceinline__ int32_t jcat_invcdf(const float* l, uint32_t K, uint32_t bits){ const float m=jrow_max(l,K); uint64_t Q=0; for(uint32_t c=0;c<K;++c) Q += cat_fix(l[c],m); const uint64_t thr=((uint64_t)bits*Q)>>32; uint64_t C=0; for(uint32_t c=0;c<K;++c){ C += cat_fix(l[c],m); if (C>thr) return (int32_t)c; } return (int32_t)(K-1); }\n";
-  o << "__device__ __forceinline__ int32_t jcat_invcdf_gb(const uint4* guide, const uint2* ent, uint32_t K, uint32_t bits, int sh, uint32_t& lpb){ const uint4 g=guide[bits>>sh]; const uint32_t c0=g.y&511u, c1=(g.y>>9)&511u; if (bits<=g.x){ lpb=g.z; return (int32_t)c0; } if (!(g.y>>18)){ lpb=g.w; return (int32_t)c1; } const uint64_t thr=((uint64_t)bits*(uint64_t)ent[K-1].x)>>32; uint32_t c=c1; uint2 e=ent[c]; while (c<K-1 && (uint64_t)e.x<=thr){ ++c; e=ent[c]; } lpb=e.y; return (int32_t)c; }\n";
+  // the guide bucket: one scattered 16-byte load per draw from a table of up to 2 MB (L2-resident).  As a BUFFER load
+  // (resource anchored 1 GiB below the first lane's address; every lane of the wave reads the same table, so all offsets
+  // are in range) the scan of the 256-state HMM runs 4.02 -> 2.39 ms per 5e8 particle-steps against the same load as
+  // global_load_dwordx4; the sc0 / sc1 bits make no further difference, a non-temporal global load is 2x slower and an
+  // agent-scope pair of 8-byte loads is even (profiles/r04_ab/README.md).  GJX_GUIDE_LOAD=global keeps the old form for A/B.
+  {
+    const char* gl = std::getenv("GJX_GUIDE_LOAD");
+    if (gl && !strcmp(gl, "global"))
+      o << "__device__ __forceinline__ uint4 jguide_load(const uint4* p){ return *p; }\n";
+    else
+      o << "typedef unsigned jv4u_t __attribute__((ext_vector_type(4)));\n__device__ __forceinline__ uint4 jguide_load(const uint4* p){ const uint64_t a=(uint64_t)(uintptr_t)p; const uint64_t first=((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a>>32))<<32)|(uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a); const uint64_t base=first-(1ull<<30); __amdgpu_buffer_rsrc_t rs=__builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)base,0,0x7fffffff,0x00020000); const jv4u_t v=__builtin_amdgcn_raw_buffer_load_b128(rs,(int)(uint32_t)(a-base),0,0); return make_uint4(v[0],v[1],v[2],v[3]); }\n";
+  }
+  o << "__device__ __forceinline__ int32_t jcat_invcdf_gb(const uint4* guide, const uint2* ent, uint32_t K, uint32_t bits, int sh, uint32_t& lpb){ const uint4 g=jguide_load(guide+(bits>>sh)); const uint32_t c0=g.y&511u, c1=(g.y>>9)&511u; if (bits<=g.x){ lpb=g.z; return (int32_t)c0; } if (!(g.y>>18)){ lpb=g.w; return (int32_t)c1; } const uint64_t thr=((uint64_t)bits*(uint64_t)ent[K-1].x)>>32; uint32_t c=c1; uint2 e=ent[c]; while (c<K-1 && (uint64_t)e.x<=thr){ ++c; e=ent[c]; } lpb=e.y; return (int32_t)c; }\n";
   o << "template <int IMPL> __device__ __forceinline__ int32_t jcat_gumbel(const float* l, uint32_t K, const Stream<IMPL>& st){ int32_t best=0; float bv=-__builtin_inff(); for(uint32_t c=0;c<K;++c){ const float v = l[c] + gumbel_from_bits(st.bits32(c)); if (v>bv || c==0){ bv=v; best=(int32_t)c; } } return best; }\n";
 }
 
