@@ -397,9 +397,14 @@ GJX_HD float m_log_normal(float x) {
   return r;
 }
 
+GJX_HD float m_exp_core(float x);
 GJX_HD float m_exp(float x) {
   if (!(x >= -86.0f)) return 0.0f;
   if (x > 88.0f) x = 88.0f;
+  return m_exp_core(x);
+}
+// (the arithmetic of m_exp for -86 <= x <= 88: callers that have already clamped select around it without a branch)
+GJX_HD float m_exp_core(float x) {
   const float fx = __builtin_rintf(x * 1.44269504088896341f);
   x = __builtin_fmaf(fx, -0.693359375f, x);
   x = __builtin_fmaf(fx, 2.12194440e-4f, x);
@@ -442,9 +447,11 @@ GJX_HD float e_min(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a 
 #define GJX_FAST_MATH_DEVICE 1
 GJX_HD float d_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
 GJX_HD float d_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+GJX_HD float d_exp_core(float x) { return d_exp(x); }
 #else
 GJX_HD float d_log(float x) { return m_log(x); }
 GJX_HD float d_exp(float x) { return m_exp(x); }
+GJX_HD float d_exp_core(float x) { return m_exp_core(x); }
 #endif
 
 GJX_HD float m_erfinv(float x) {
@@ -880,12 +887,26 @@ GJX_HD int32_t row_anchor(float m) {
   return (int32_t)__builtin_ceilf(t);
 }
 GJX_HD uint64_t rowfix(float lw, int32_t e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    // the same function as selects (r04: four calls per lane in the step's emission, each with two divergent branches): a
+    // dead weight (empty row, -inf / NaN, below m_exp's flush at -86) runs the polynomial on 0 and is zeroed at the end
+    const float fe = (float)e;
+    float d = __builtin_fmaf(-fe, 0.693359375f, lw);
+    d = __builtin_fmaf(-fe, -2.12194440e-4f, d);
+    d = d > 1.0f ? 1.0f : d;
+    const bool live = e != kRowEmpty && lw > -__builtin_inff() && d >= -86.0f;
+    const uint32_t q = (uint32_t)__builtin_rintf(d_exp_core(live ? d : 0.0f) * 1073741824.0f);
+    return live ? q : 0u;
+  }
+#endif
   if (e == kRowEmpty || !(lw > -__builtin_inff())) return 0;
   const float fe = (float)e;
   float d = __builtin_fmaf(-fe, 0.693359375f, lw);
   d = __builtin_fmaf(-fe, -2.12194440e-4f, d);
   d = d > 1.0f ? 1.0f : d;  // only a weight beyond the clamped anchor (+inf, > 1.1e7): keeps the conversion defined
-  return (uint64_t)__builtin_rintf(d_exp(d) * 1073741824.0f);
+  // (d <= 1: the product is below e 2^30 < 2^32 — one 32-bit conversion instead of the 64-bit sequence)
+  return (uint64_t)(uint32_t)__builtin_rintf(d_exp(d) * 1073741824.0f);
 }
 
 GJX_HD uint32_t cat_fix(float l, float m) {
@@ -998,6 +1019,14 @@ GJX_DEV uint64_t block_sum(uint64_t v, uint64_t* sh) {
 // Inclusive wave scan of u64.
 GJX_DEV uint64_t wave_scan_incl(uint64_t v) {
   return wave_scan_u64(v, 0, [](uint64_t a, uint64_t b) { return a + b; });
+}
+// ... of values below 2^52 (tile masses: a tile sums 1024 weights below 2^31.5, a thread at most 16 tiles): two 26-bit halves
+// scanned as u32 — a u32 add takes its DPP operand directly (8 instructions per scan), the 64-bit add does not (45) — and
+// the halves' lane sums stay below 2^32
+GJX_DEV uint64_t wave_scan_incl_52(uint64_t v) {
+  const uint32_t lo = wave_scan_u32((uint32_t)v & 0x3ffffffu, 0u, [](uint32_t a, uint32_t b) { return a + b; });
+  const uint32_t hi = wave_scan_u32((uint32_t)(v >> 26), 0u, [](uint32_t a, uint32_t b) { return a + b; });
+  return ((uint64_t)hi << 26) + lo;
 }
 // Exclusive block scan of one u64 per thread; returns the exclusive prefix, total in `total`.
 GJX_DEV uint64_t block_scan_excl(uint64_t v, uint64_t* sh, uint64_t& total) {
@@ -1220,6 +1249,7 @@ struct ResampleArgs {
   int debug_stop = 0;                   // profiling builds only (-DGJX_PROFILE_HOOKS, GJX_SMC_DEBUG_STOP): leave the kernel after phase k
   int xcd_map = 1;                      // contiguous output tiles per XCD (GJX_SMC_XCD_MAP=0: plain order)
   int wt_stores = 0;                    // write-through stores of the step's output columns (store16_out)
+  int wave_route = 1;                   // populations of up to kWave * 4 tiles: every WAVE merges the records itself (GJX_SMC_WAVE_ROUTE=0: LDS route)
   PeerMap pm;                           // r04: the source population is distributed over peers (PEERS instantiations only)
 };
 
@@ -1238,9 +1268,16 @@ GJX_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 // teeth (j + u0), j in [0, n_out), strictly below a position: ceil, clamped to [0, n_out] (a NaN counts as 0)
 GJX_HD int32_t comb_clamp(double t, int32_t n_out) {
   const double c = __builtin_ceil(t);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the same function without branches (r04: the step kernel evaluates it a dozen times per lane; as two early returns it
+  // compiled to two divergent branches each): fmax drops a NaN and anything <= 0 to 0, fmin caps at n_out, the conversion
+  // of an integral double in [0, n_out] is exact
+  return (int32_t)__builtin_fmin(__builtin_fmax(c, 0.0), (double)n_out);
+#else
   if (!(c > 0.0)) return 0;
   if (c >= (double)n_out) return n_out;
   return (int32_t)c;
+#endif
 }
 // the position of a tile's start: P_t scale - u0 (two roundings)
 GJX_HD double comb_base(uint64_t P, double scale, double u0) { return (double)P * scale - u0; }
@@ -1249,8 +1286,13 @@ GJX_HD int32_t comb_tile(uint64_t P, double scale, double u0, int32_t n_out) { r
 // teeth below a particle inside a tile: c = running sum of q up to and including it (exact in float64), scale_t =
 // scale 2^-d_t, base = comb_base of the tile, nhi = teeth below the tile's end (the cap keeps tiles consistent)
 GJX_HD int32_t comb_in_tile(double c, double scale_t, double base, int32_t nhi, int32_t n_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (0 <= nhi <= n_out: the cap at nhi is the only upper clamp needed)
+  return (int32_t)__builtin_fmin(__builtin_fmax(__builtin_ceil(__builtin_fma(c, scale_t, base)), 0.0), (double)nhi);
+#else
   const int32_t t = comb_clamp(__builtin_fma(c, scale_t, base), n_out);
   return t < nhi ? t : nhi;
+#endif
 }
 GJX_HD double comb_tile_scale(double scale, int d) { return d >= 64 ? 0.0 : scale * u2d((uint64_t)(1023 - d) << 52); }
 // ------------------------------------------------------------------------------------------------
@@ -1536,20 +1578,22 @@ template <bool ESS>
 GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint32_t* qw_at, float* logw_at, TileRec* rec_at,
                        TileSub* sub_at, TileEss* ess_at, bool wt = false) {
   constexpr int kW = kBlock / kWave;
-  __shared__ float em_f[kW];
   __shared__ uint64_t em_q[3 * kW];
+  __shared__ int32_t em_e[kW];
   static_assert(kPer == 4 && kSubLen == 64, "four consecutive slots per lane: a 64-particle block is one DPP row of 16 lanes");
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   float tm = -__builtin_inff();
 #pragma unroll
   for (int r = 0; r < kPer; ++r) tm = ok[r] && w[r] > tm ? w[r] : tm;
-  tm = wave_max(tm);
-  if (lane == 0) em_f[wv] = tm;
+  // the tile's anchor row_anchor(max w): row_anchor is monotone, so the maximum is taken over the lanes' ANCHORS (int32: one
+  // v_max_i32 with a DPP operand per step, where the float maximum took a compare and a select)
+  int32_t te = row_anchor(tm);
+  te = (int32_t)(wave_last_u32(wave_scan_u32((uint32_t)te ^ 0x80000000u, 0u, [](uint32_t a, uint32_t x) { return x > a ? x : a; })) ^ 0x80000000u);
+  if (lane == 0) em_e[wv] = te;
   __syncthreads();
-  float m = em_f[0];
+  int32_t e = em_e[0];
 #pragma unroll
-  for (int i = 1; i < kW; ++i) m = em_f[i] > m ? em_f[i] : m;
-  const int32_t e = row_anchor(m);
+  for (int i = 1; i < kW; ++i) e = em_e[i] > e ? em_e[i] : e;
   uint32_t q[kPer];
   uint64_t run = 0, a1 = 0, a2 = 0;
 #pragma unroll
@@ -1562,7 +1606,7 @@ GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint32_t*
       a2 += rr * rr;
     }
   }
-  const uint64_t incl = wave_scan_incl(run);
+  const uint64_t incl = wave_scan_incl_52(run);  // (four weights: below 2^34)
   if (ESS) { a1 = wave_sum(a1); a2 = wave_sum(a2); }
   if (lane == 63) {
     em_q[wv] = incl;
@@ -1653,6 +1697,25 @@ GJX_DEV uint64_t scan8_incl(uint64_t v) {
   t = dpp_u64<kDppRowShr4, 0xf, 0xf>(0, v);
   v += l8 >= 4 ? t : 0;
   return v;
+}
+
+// A workgroup barrier that orders LDS only: the global loads a wave has in flight stay in flight (__syncthreads waits for
+// them too: on gfx9 loads and stores share vmcnt and the workgroup-scope fence covers both).
+GJX_DEV void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
+}
+// ... and the wave-level form: LDS written by one lane is read by another lane of the SAME wave (in order on the hardware;
+// this keeps the compiler from moving the accesses)
+GJX_DEV void wave_lds_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+#endif
 }
 
 // ADAPTIVE: the launch may be a step of an ESS-adaptive filter (A.ess_thr > 0): only then does the kernel carry the
@@ -1758,9 +1821,15 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   //            group on, exactly as the LDS route does — same integers, no serial whole-population scan, no search of a
   //            prefix array in memory;
   //   prefix   (A.prefix: batches of >= 4 filters, and populations beyond kMaxGroups groups): a precomputed global prefix.
+  //   wave     (r04, ntiles <= 64 * kC = 256 — BASELINE configs[2] and [4] have 64 tiles): the LDS route without its
+  //            barriers.  Every WAVE merges all records itself (kC per lane: anchor, masses and prefix by DPP scans inside
+  //            the wave) and finds the first source tile by one ballot; the four waves write the SAME prefix values to LDS
+  //            and each reads only what it wrote itself.  Four workgroup barriers and the per-thread walk of the LDS route
+  //            leave the step's dependent chain: same integers, same float64 comb.
   constexpr int kC = kMaxLdsTiles / kBlock;  // tiles per thread of the in-kernel merge
   const bool grouped = A.groups != nullptr;       // (launch-uniform)
-  const bool lds_prefix = prefix == nullptr;      // (launch-uniform; true for the LDS and the grouped route)
+  const bool lds_prefix = prefix == nullptr;      // (launch-uniform; true for the LDS, the wave and the grouped route)
+  const bool wave_route = lds_prefix && !grouped && A.wave_route != 0 && A.ntiles <= (uint64_t)(kWave * kC);  // (launch-uniform)
   const uint64_t ngroups = grouped ? (A.ntiles + kGroupTiles - 1) / kGroupTiles : 0;  // <= kMaxGroups = kBlock: one per thread
   // the tiles whose prefix will live in LDS: [k_base, k_base + nrange).  Grouped route: SPECULATIVELY the four groups around
   // the output tile's own position (ancestors stay near their slots unless the weights are very uneven), so that the tile
@@ -1772,8 +1841,8 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     if (k_base >= A.ntiles) k_base = (ngroups - 1) * kGroupTiles;
     nrange = A.ntiles - k_base < (uint64_t)kMaxLdsTiles ? A.ntiles - k_base : (uint64_t)kMaxLdsTiles;
   }
-  uint64_t c_per = (nrange + kBlock - 1) / kBlock;
-  uint64_t k0 = (uint64_t)tid * c_per;
+  uint64_t c_per = wave_route ? (nrange + kWave - 1) / kWave : (nrange + kBlock - 1) / kBlock;
+  uint64_t k0 = (uint64_t)(wave_route ? lane : tid) * c_per;
   uint64_t rs_[kC], ev1[kC], ev2[kC];
   int32_t re_[kC];
   auto load_range = [&]() {  // the tile records of the range, contiguous per thread
@@ -1807,6 +1876,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
 #pragma unroll
   for (int r = 0; r < kPer; ++r) marks[tid + r * kBlock] = 0;
   if (tid == 0) sh_klo = ~0u;
+  if (wave_route) lds_barrier();  // (the marks are clear before any wave's scan sets one; the record loads stay in flight)
   policy_prefetch(P, jq, 0);  // (under the latency of the record loads)
   GJX_DBG_STOP(A, 14, if (lds_prefix && rs_[0] == 0x123456789abcdefull && re_[0] == 77) marks[0] = 1);  // (records loaded, prefetch done, nothing merged)
 
@@ -1882,7 +1952,35 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     }
     p_base = sh_gpre[k_base / kGroupTiles];
   }
-  if (lds_prefix) {
+  if (wave_route) {
+#pragma unroll
+    for (int i = 0; i < kC; ++i) e = re_[i] > e ? re_[i] : e;
+    e = (int32_t)(wave_last_u32(wave_scan_u32((uint32_t)e ^ 0x80000000u, 0u, [](uint32_t a, uint32_t x) { return x > a ? x : a; })) ^ 0x80000000u);
+    uint64_t l1 = 0, l2 = 0;
+    int dsh[kC];
+#pragma unroll
+    for (int i = 0; i < kC; ++i) {
+      dsh[i] = tile_shift(e, re_[i]);
+      mass[i] = shr64(rs_[i], dsh[i]);
+      chunk_mass += mass[i];
+      if (adaptive) { l1 += shr64(ev1[i], dsh[i]); l2 += shr64(ev2[i], 2 * dsh[i]); }
+    }
+    const uint64_t incl = wave_scan_incl_52(chunk_mass);  // (at most 4 tile masses: below 2^44)
+    tot = wave_last_u64(incl);
+    if (adaptive) { r1 = wave_sum(l1); r2 = wave_sum(l2); }
+    chunk_pre = incl - chunk_mass;
+    uint64_t run = chunk_pre;
+#pragma unroll
+    for (int i = 0; i < kC; ++i) {
+      if ((uint64_t)i < c_per && k0 + i < nrange) {
+        sh_pre[k0 + i] = run;
+        sh_d[k0 + i] = (uint8_t)dsh[i];
+        run += mass[i];
+      }
+    }
+    if (lane == 0) sh_pre[nrange] = tot;
+    wave_lds_fence();
+  } else if (lds_prefix) {
     if (!grouped) {
 #pragma unroll
       for (int i = 0; i < kC; ++i) e = re_[i] > e ? re_[i] : e;
@@ -1897,7 +1995,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
       chunk_mass += mass[i];
       if (adaptive && !grouped) { l1 += shr64(ev1[i], dsh[i]); l2 += shr64(ev2[i], 2 * dsh[i]); }
     }
-    const uint64_t incl = wave_scan_incl(chunk_mass);
+    const uint64_t incl = wave_scan_incl_52(chunk_mass);  // (at most 4 tile masses: below 2^44)
     if (adaptive && !grouped) { l1 = wave_sum(l1); l2 = wave_sum(l2); }
     if (grouped) __syncthreads();  // (sh_scan was read by the group level)
     if (lane == 63) {
@@ -1974,7 +2072,19 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     auto nhi_of = [&](uint64_t k) -> int32_t { return k + 1 >= A.ntiles ? n_out : nlo_of(k + 1); };  // ... below its END
     // ---- the first source tile with a tooth in [j0, j1): k_lo = min{k : teeth below the END of tile k > j0} ----------
     uint64_t k_lo = 0;
-    if (lds_prefix) {
+    if (wave_route) {
+      // (monotone: the first lane whose chunk of tiles ends beyond j0 holds k_lo — the last tile's end lies beyond every slot)
+      const uint64_t r1_ = k0 + c_per < nrange ? k0 + c_per : nrange;
+      const int32_t c_hi = r1_ >= A.ntiles ? n_out : comb_tile(chunk_pre + chunk_mass, scale, u0, n_out);
+      const uint64_t hit = __ballot(k0 < nrange && c_hi > j0);
+      const uint64_t first = (uint64_t)(hit ? __builtin_ctzll(hit) : 0) * c_per;
+      k_lo = first;
+      if (c_per > 1) {  // (wave-uniform walk of that lane's tiles: their prefix is in LDS)
+        const uint64_t last = first + c_per < nrange ? first + c_per : nrange;
+        for (k_lo = first; k_lo + 1 < last; ++k_lo)
+          if (comb_tile(sh_pre[k_lo + 1], scale, u0, n_out) > j0) break;
+      }
+    } else if (lds_prefix) {
       __syncthreads();  // sh_pre / sh_d complete
       // (monotone: the chunk of tiles that holds k_lo is the one whose start lies at or below j0 and whose end beyond it;
       // only that thread walks its tiles.  Grouped route: k_lo lies in the range's first group.)

@@ -2865,7 +2865,11 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
     if (!peers_ok(cfg) || ctx.fb.n_filters > 1) return GJX_ERR_INVALID;
     A.pm = peer_map_of(cfg->peers, cfg->n_total);
   }
-  if (A.ntiles > (uint64_t)kMaxLdsTiles || (ctx.fb.n_filters > 1 && prev->prefix)) {
+  static const int wave_route = [] { const char* e = std::getenv("GJX_SMC_WAVE_ROUTE"); return e ? atoi(e) : 1; }();
+  A.wave_route = wave_route;
+  // (r04: filters of up to 256 tiles merge their records inside every wave — no prefix launch even for a batch of filters)
+  const bool in_wave = wave_route != 0 && A.ntiles <= (uint64_t)(kWave * (kMaxLdsTiles / kBlock));
+  if (A.ntiles > (uint64_t)kMaxLdsTiles || (ctx.fb.n_filters > 1 && prev->prefix && !in_wave)) {
     if (ctx.fb.n_filters > 1 && A.ntiles > (uint64_t)kMaxLdsTiles) return GJX_ERR_UNSUPPORTED;
     const unsigned nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
     if (nf == 1 && A.ntiles > (uint64_t)kMaxLdsTiles && launch_group_records(A, prev->prefix, S(s))) {
