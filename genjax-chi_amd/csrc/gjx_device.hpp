@@ -1028,6 +1028,7 @@ GJX_DEV uint64_t wave_scan_incl_52(uint64_t v) {
   const uint32_t hi = wave_scan_u32((uint32_t)(v >> 26), 0u, [](uint32_t a, uint32_t b) { return a + b; });
   return ((uint64_t)hi << 26) + lo;
 }
+GJX_DEV uint64_t wave_sum_52(uint64_t v) { return wave_last_u64(wave_scan_incl_52(v)); }
 // Exclusive block scan of one u64 per thread; returns the exclusive prefix, total in `total`.
 GJX_DEV uint64_t block_scan_excl(uint64_t v, uint64_t* sh, uint64_t& total) {
   const uint64_t incl = wave_scan_incl(v);
@@ -1722,8 +1723,11 @@ GJX_DEV void wave_lds_fence() {
 // decision, the ESS sums and the keep-your-particle path (the every-step filters are compiled without them).
 // PEERS (r04): the source population is distributed (A.pm): the kernel first waits for its peers, then reads remote tiles
 // where they live.  Everything it does with what it read is the code of the single-device step.
-template <int IMPL, class Policy, bool ADAPTIVE = true, bool PEERS = false>
-GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
+// LDSP: the merged prefix of the source tiles lives in LDS (the LDS, wave and grouped routes: A.prefix == nullptr) — a
+// compile-time fact inside the body, so that every read of it is an LDS read (as a run-time choice between LDS and the prefix
+// array in memory the reads were flat loads through a selected pointer).
+template <int IMPL, class Policy, bool ADAPTIVE, bool PEERS, bool LDSP>
+GJX_DEV void resample_body_impl(const ResampleArgs& A, Policy& P) {
   constexpr int kW = kBlock / kWave;
   constexpr int kSrc = 8;                        // sources per lane and round of the window scan
   static_assert(kSrc == 8 && kSubLen == 64, "8 consecutive sources per lane: a 64-particle block is 8 lanes");
@@ -1770,7 +1774,7 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   TileRec* recs_out = A.recs_out;
   TileSub* subs_out = A.subs_out;
   TileEss* ess_out = A.ess_out;
-  const uint64_t* prefix = A.prefix;
+  const uint64_t* prefix = LDSP ? nullptr : A.prefix;
   double u0 = A.u0;
   if (A.fb.n_filters > 1) {
     const uint32_t f = (uint32_t)(b / A.fb.tiles);
@@ -1827,8 +1831,8 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
   //            and each reads only what it wrote itself.  Four workgroup barriers and the per-thread walk of the LDS route
   //            leave the step's dependent chain: same integers, same float64 comb.
   constexpr int kC = kMaxLdsTiles / kBlock;  // tiles per thread of the in-kernel merge
-  const bool grouped = A.groups != nullptr;       // (launch-uniform)
-  const bool lds_prefix = prefix == nullptr;      // (launch-uniform; true for the LDS, the wave and the grouped route)
+  const bool grouped = LDSP && A.groups != nullptr;  // (launch-uniform)
+  constexpr bool lds_prefix = LDSP;               // (true for the LDS, the wave and the grouped route)
   const bool wave_route = lds_prefix && !grouped && A.wave_route != 0 && A.ntiles <= (uint64_t)(kWave * kC);  // (launch-uniform)
   const uint64_t ngroups = grouped ? (A.ntiles + kGroupTiles - 1) / kGroupTiles : 0;  // <= kMaxGroups = kBlock: one per thread
   // the tiles whose prefix will live in LDS: [k_base, k_base + nrange).  Grouped route: SPECULATIVELY the four groups around
@@ -2309,6 +2313,11 @@ GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
     emit_tile<ADAPTIVE>(w, ok, qw_out + loc, logw_out ? logw_out + loc : nullptr, recs_out + ot, subs_out + ot,
                         adaptive && ess_out ? ess_out + ot : nullptr, A.wt_stores != 0);
   }
+}
+template <int IMPL, class Policy, bool ADAPTIVE = true, bool PEERS = false>
+GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
+  if (A.prefix == nullptr) resample_body_impl<IMPL, Policy, ADAPTIVE, PEERS, true>(A, P);  // (launch-uniform)
+  else resample_body_impl<IMPL, Policy, ADAPTIVE, PEERS, false>(A, P);
 }
 
 }  // namespace gjx

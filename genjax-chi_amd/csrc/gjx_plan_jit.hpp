@@ -704,7 +704,7 @@ struct Gen {
     {
       std::string sm;
       for (int u = 0; u < P; ++u) sm += (u ? " + rowfix(w" : "rowfix(w") + std::string(sfx[u]) + ", eb)";
-      o << "        uint64_t sb = wave_sum(ok ? (" << sm << ") : 0);\n";
+      o << "        uint64_t sb = wave_sum_52(ok ? (" << sm << ") : 0);  // (at most four weights below 2^32)\n";
     }
     if (waves_per_row > 1) {
       o << "        __syncthreads();\n        if ((threadIdx.x & 63) == 0) sh_sum[wv] = sb;\n        __syncthreads();\n";
