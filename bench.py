@@ -825,7 +825,7 @@ def bench_scan_hmm(args, ops, min_s=0.08, T=500):
                    "rng": args.rng, "categorical": "inverse CDF (one uniform per draw)"},
         "roofline": {"bound": "hbm", "kernel": "gjx_scan_kernel (one launch per pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": None,
-                     "limiter": "scattered table loads (8 binary-search steps + 2 log-density loads per particle-step) and the cipher"},
+                     "limiter": "L2 request rate: one scattered 16-byte guide bucket per categorical draw (a buffer load: 1.08 L2 requests per particle-step, profiles/r04_scan_pmc.json) from a 2 MB table, and the cipher"},
         "log_z": r["log_z"],
     }
 

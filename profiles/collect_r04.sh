@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 rocprof evidence on the GPU box (through gpurun from the repo root):
+# Round-4 rocprof evidence on the GPU box (through gpurun from the repo root):
 #   gpurun --timeout 1100 -- 'bash profiles/collect_r04.sh r04'
 # Raw output under gpurun_out/profiles_<tag>/; profiles/summarize_r04.py turns it into the committed summaries.
 # Counters are collected in their own passes (--pmc never together with a trace domain), the program directly after `--`.
@@ -50,11 +50,15 @@ done
 # r04: the rejection samplers (lane utilisation) and the phase times of the FINAL step kernel (profiling build)
 bash tools/pmc_samplers.sh > "$OUT/pmc_samplers.txt" 2>&1 || echo "pmc_samplers failed"
 [ -f genjax-chi_amd/lib/libgjx_hip_prof.so ] && bash tools/phases_smc.sh > "$OUT/phases_smc.txt" 2>&1
+# ... and the instructions per wave behind those phase times (VALU / SALU / LDS / VMEM, cumulative by phase)
+[ -f genjax-chi_amd/lib/libgjx_hip_prof.so ] && bash tools/pmc_phases.sh lgssm > "$OUT/pmc_phases.txt" 2>&1
 unset GJX_BENCH_RAMP GJX_BENCH_MIN_S GJX_BENCH_LAUNCH
 # 3. the plain bench line of the same build
 GJX_BENCH_DETAIL="$OUT/bench_detail.json" timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err" || exit 1
 python3 profiles/summarize_r04.py "$TAG" "$OUT" > "$OUT/summarize.log" 2>&1 || { tail -20 "$OUT/summarize.log"; exit 1; }
 # keep the summaries; drop the raw per-dispatch CSVs (large)
 mkdir -p "$OUT/summary" && cp profiles/${TAG}_* "$OUT/summary/" 2>/dev/null
+[ -f "$OUT/pmc_phases.txt" ] && cp "$OUT/pmc_phases.txt" "$OUT/summary/${TAG}_phase_counters.txt"
+[ -f "$OUT/phases_smc.txt" ] && cp "$OUT/phases_smc.txt" "$OUT/summary/${TAG}_phase_times.txt"
 find "$OUT" -name "*.csv" -size +1M -delete
 tail -5 "$OUT/summarize.log"

@@ -133,11 +133,14 @@ def _same(a, b):
     return torch.equal(a, b) or (a.dtype.is_floating_point and torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(), b.nan_to_num()))
 
 
-def run(seconds: float, seed: int, impl: int = 1, n: int = 1500):
+def run(seconds: float, seed: int, impl: int = 1, n: int = 1500, min_compared: int = 0):
     rng = np.random.default_rng(seed)
     dev = get_ops().device()
+    # (`min_compared`: on a loaded machine the budget of seconds alone may cover only a handful of bodies — keep going, up to
+    # ten budgets, until that many have been compared)
     t_end, compared, skipped = time.time() + seconds, 0, 0
-    while time.time() < t_end:
+    t_cap = time.time() + 10.0 * seconds
+    while time.time() < t_end or (compared < min_compared and time.time() < t_cap):
         src, sites = random_model(rng)
         ns = {"normal": normal, "gamma": gamma, "beta": beta, "flip": flip, "torch": torch, "gen": gen}
         exec(src, ns)  # noqa: S102 - generated by random_model above
@@ -195,13 +198,16 @@ def random_step(rng):
     return src, sites
 
 
-def run_scans(seconds: float, seed: int, impl: int = 1, n: int = 800):
+def run_scans(seconds: float, seed: int, impl: int = 1, n: int = 800, min_compared: int = 0):
     from genjax._amd import combinators as CB
 
     rng = np.random.default_rng(seed)
     dev = get_ops().device()
+    # (`min_compared`: on a loaded machine the budget of seconds alone may cover only a handful of bodies — keep going, up to
+    # ten budgets, until that many have been compared)
     t_end, compared, skipped = time.time() + seconds, 0, 0
-    while time.time() < t_end:
+    t_cap = time.time() + 10.0 * seconds
+    while time.time() < t_end or (compared < min_compared and time.time() < t_cap):
         src, sites = random_step(rng)
         ns = {"normal": normal, "gamma": gamma, "beta": beta, "flip": flip, "torch": torch}
         exec(src, ns)  # noqa: S102 - generated by random_step above
