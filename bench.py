@@ -391,7 +391,7 @@ def bench_smc_sharded(args, ops, rank, world, kind):
             ok, smc_p, why1 = 1, None, None
             try:
                 arena = gdist.PeerArena.ipc(ops, rank, world, n_total, [sdt], False, fine_grained=fine)
-                pcomm = gdist.NativeComm.peers(ops, arena, None, False, timeout_ms=30000)
+                pcomm = gdist.NativeComm.peers(ops, arena, None, False, timeout_ms=5000)  # (an arrival word takes microseconds)
                 smc_p = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world, arena=arena)
                 got = smc_p.run_native(pcomm)
                 if got["log_z"] != ref["log_z"]:

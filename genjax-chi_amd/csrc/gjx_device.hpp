@@ -1192,6 +1192,9 @@ GJX_DEV bool peer_wait_wave(const PeerMap& pm) {
   const int lane = threadIdx.x & 63;
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
   bool ready = false;
+  // (a wait that has already timed out on this rank is not waited for again: every later wait of the run fails at once, so a
+  // peer that never arrives costs ONE timeout, not one per launch)
+  if (__hip_atomic_load(pm.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return false;
   for (;;) {
     const uint64_t v = lane < pm.world ? __hip_atomic_load(pm.flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ~0ull;
     ready = __ballot(v < pm.wait_value) == 0;

@@ -1094,6 +1094,8 @@ static double now_ms(void) {
 /* -> 1 when every arrival word is >= value (then an acquire fence), 0 after the timeout (*error set) */
 static int peer_wait_host(const gjx_smc_peers* p, uint64_t value) {
   const double t0 = now_ms(), limit = p->timeout_ms ? (double)p->timeout_ms : 10000.0;
+  /* (a wait that has already timed out on this rank is not waited for again: every later wait of the run fails at once) */
+  if (__atomic_load_n(p->error, __ATOMIC_RELAXED) != 0u) return 0;
   for (;;) {
     int ready = 1;
     for (int q = 0; q < p->world; ++q) ready = ready && __atomic_load_n(&p->flags[q], __ATOMIC_RELAXED) >= value;
