@@ -64,6 +64,11 @@ def parse():
 
 
 FORCE_DIST = bool(os.environ.get("GJX_BENCH_FORCE_DIST"))  # exercise the N>1 code path with one rank
+# REHEARSE: `--gpus N --workload smc_lgssm` with all N rank processes on the box's ONE device and a gloo process group — the
+# N > 1 line (brackets, max over ranks, the peer transport through hipIpc, its validation) end to end where RCCL cannot run
+# (it refuses two ranks on one GPU).  The reference log Z is then the single-rank filter of the same n_total.  Not a
+# measurement: the ranks share the device.  tests/test_gpu_sharded.py runs it.
+REHEARSE = bool(os.environ.get("GJX_BENCH_REHEARSE"))
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -77,7 +82,7 @@ def parent_launch(args) -> int:
     import torch
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (REHEARSE and have >= 1):
         print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s); refusing to print a "
               f"line for fewer ranks than asked", file=sys.stderr)
         return 2
@@ -86,7 +91,7 @@ def parent_launch(args) -> int:
         port = s.getsockname()[1]
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % have if REHEARSE else r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
     rc = 0
@@ -111,7 +116,10 @@ def init_dist(n_gpus):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if REHEARSE:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     return rank, world
@@ -133,7 +141,7 @@ def max_over_ranks(seconds, world):
     import torch
     import torch.distributed as dist
 
-    t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if REHEARSE else "cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -369,12 +377,17 @@ def bench_smc_sharded(args, ops, rank, world, kind):
     n_total = n * world
     exchange = os.environ.get("GJX_BENCH_SHUFFLE", "ranges")
     # (a forced one-rank group still issues every collective: the RCCL calls of the N > 1 path run on a one-GPU box)
-    smc = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world, exchange=exchange,
-                           comm=gdist.TorchComm(rank, world, always=FORCE_DIST))
-    native = os.environ.get("GJX_BENCH_PY_COMM") != "1"
-    comm = gdist.NativeComm.rccl(ops, rank, world) if native else None
-    run = (lambda: smc.run_native(comm)) if native else smc.run
-    ref = run()  # warm-up (also builds any generated kernels)
+    if REHEARSE:  # (no RCCL with several ranks on one device: the reference is the single-rank filter of the same population)
+        native, smc, run = True, None, None
+        ref = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, 0, 1, exchange=exchange,
+                               comm=gdist.TorchComm(0, 1)).run()
+    else:
+        smc = gdist.ShardedSMC(ops, kind[4:], impl, 1 if kind == "smc_lgssm" else 2, n_total, T, rank, world, exchange=exchange,
+                               comm=gdist.TorchComm(rank, world, always=FORCE_DIST))
+        native = os.environ.get("GJX_BENCH_PY_COMM") != "1"
+        comm = gdist.NativeComm.rccl(ops, rank, world) if native else None
+        run = (lambda: smc.run_native(comm)) if native else smc.run
+        ref = run()  # warm-up (also builds any generated kernels)
     # r04: the PEER transport (no collective, nothing decided on the host: DESIGN.md 6) is the N > 1 default when it proves
     # itself HERE: every rank maps its peers' arenas through hipIpc, runs the same filter through it, and every rank's log Z
     # must equal the RCCL run's bit for bit (the transports only move data).  Anything else — a mapping that fails, a wait
@@ -406,9 +419,10 @@ def bench_smc_sharded(args, ops, rank, world, kind):
                 break
             reasons.append(("fine-grained: " if fine else "") + "; ".join(f"rank {r}: {v[1]}" for r, v in enumerate(votes) if not v[0]))
         why = " | ".join(reasons) if transport == "rccl" else None
-        if transport == "rccl" and want == "peers":
-            raise RuntimeError("GJX_BENCH_TRANSPORT=peers: " + str(why))
-    smc.received = 0
+        if transport == "rccl" and (want == "peers" or REHEARSE):
+            raise RuntimeError("the peer transport did not validate: " + str(why))
+    if smc is not None:
+        smc.received = 0
     runs = [0]
 
     def one_run():
@@ -1257,6 +1271,9 @@ def run_rank(args):
 
     ops = load_hip_ops()  # raises without libgjx_hip.so / a GPU: there is no CPU fallback
     sharded = world > 1 or FORCE_DIST
+    if REHEARSE and (world < 2 or args.workload not in ("smc_lgssm", "smc_hmm")):
+        print("bench.py: GJX_BENCH_REHEARSE rehearses `--gpus N --workload smc_lgssm|smc_hmm` (N >= 2) only", file=sys.stderr)
+        sys.exit(2)
     smc_gpu = None
     if args.workload in ("scan_lgssm", "scan_hmm"):  # profiling passes of the one-launch scans (`extra` entries of the default run)
         if rank == 0:
@@ -1369,7 +1386,8 @@ def run_rank(args):
     if rank == 0:
         if not args.no_cpu_baseline:  # (r04: N > 1 lines carry it too — rank 0's host cores, the same bounded sample)
             if args.workload == "importance":
-                out["cpu_baseline"] = cpu_baseline_importance(args, out["log_z"])
+                # (N > 1: the CPU sample is ONE GPU's share, 1e6 particles — its log Z is not the job's, so nothing is compared)
+                out["cpu_baseline"] = cpu_baseline_importance(args, out["log_z"] if world == 1 else None)
                 out["jax_cpu_plain"] = jax_cpu_plain(args)
             else:
                 out["cpu_baseline"] = cpu_baseline_smc(args, args.workload, smc_gpu)

@@ -272,3 +272,29 @@ def test_peer_transport_two_processes_one_gpu_ipc(tmp_path, oracle_ops, fine, bi
         assert torch.equal(torch.cat([r["ancestors"] for r in res], dim=1), ref["ancestors"])
         for r in res:
             assert torch.equal(r["out_q"], ref["out_q"]) and torch.equal(r["out_e"], ref["out_e"]) and r["log_z"] == ref["log_z"]
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_line_rehearsal():
+    """`python bench.py --gpus 2 --workload smc_lgssm` end to end with both rank processes on the one device
+    (GJX_BENCH_REHEARSE: gloo process group, the reference log Z from the single-rank filter): the N > 1 line's own code —
+    rank processes started by the parent, brackets with the max over ranks, the peer transport mapped through hipIpc and
+    validated bit for bit before it is used, one JSON line from rank 0 with `cpu_baseline` — runs before an 8-GPU node sees it."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GJX_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GJX_BENCH_BRACKET_MIN_S="0.002")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "smc_lgssm", "--steps", "2",
+                        "--warmup", "1", "--particles", "200000"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["transport"].startswith("peers"), d["config"]
+    assert "roofline" in d and d.get("cpu_baseline") and d["cpu_baseline"]["value"] > 0
+    assert abs(d["log_z"] - d["log_z_exact"]) < 1.0
