@@ -2317,8 +2317,29 @@ GJX_DEV void resample_body_impl(const ResampleArgs& A, Policy& P) {
                         adaptive && ess_out ? ess_out + ot : nullptr, A.wt_stores != 0);
   }
 }
+// The step's scalar arguments, fetched in ONE round.  Left to itself the compiler loads a kernel argument right before its
+// first use, behind whatever branch decides that it is needed: the one-filter step went through five dependent rounds of
+// scalar loads (~0.2 us each) before its first record load was issued, and another one in front of every later phase.
+// Naming the values as inputs of an empty asm statement at the kernel's entry makes them live there, so their loads are issued
+// together (no instruction is emitted; the values stay in scalar registers).
+GJX_DEV void resample_args_anchor(const ResampleArgs& A) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::"s"(A.qw), "s"(A.recs), "s"(A.subs), "s"(A.n), "s"(A.ntiles), "s"(A.n_out), "s"(A.out_lo), "s"(A.out_hi));
+  asm volatile("" ::"s"(A.u0), "s"(A.e_out), "s"(A.q_out), "s"(A.prefix), "s"(A.groups), "s"(A.fb.n_filters), "s"(A.ess_thr));
+  asm volatile("" ::"s"(A.qw_out), "s"(A.logw_out), "s"(A.recs_out), "s"(A.subs_out), "s"(A.scan_max), "s"(A.xcd_map),
+               "s"(A.wt_stores), "s"(A.wave_route), "s"(A.resampled_out));
+#endif
+}
 template <int IMPL, class Policy, bool ADAPTIVE = true, bool PEERS = false>
 GJX_DEV void resample_body(const ResampleArgs& A, Policy& P) {
+#ifndef GJX_NO_ARGS_ANCHOR   // (A/B builds: profiles/r04_ab/README.md; anchoring the policy's members as well measured even)
+  resample_args_anchor(A);
+#endif
+  if (ADAPTIVE) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"s"(A.lw), "s"(A.ess), "s"(A.ess_out));
+#endif
+  }
   if (A.prefix == nullptr) resample_body_impl<IMPL, Policy, ADAPTIVE, PEERS, true>(A, P);  // (launch-uniform)
   else resample_body_impl<IMPL, Policy, ADAPTIVE, PEERS, false>(A, P);
 }
