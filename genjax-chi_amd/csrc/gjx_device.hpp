@@ -632,8 +632,18 @@ static const BmEnt g_bm_cs[256] = GJX_BM_CS_INIT;
 __shared__ BmEnt s_bm_lg[64];
 __shared__ BmEnt s_bm_cs[256];
 GJX_DEV void bm_stage() {  // every thread of the workgroup, before its first Normal site
-  for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) s_bm_cs[i] = g_bm_cs[i];
-  for (uint32_t i = threadIdx.x; i < 64u; i += blockDim.x) s_bm_lg[i] = g_bm_lg[i];
+  // (r04: every load of the thread issued before the first is waited for — as two copy loops a 64-thread workgroup went
+  // through FIVE dependent memory trips at kernel entry, load / wait / write each; workgroups have 64, 128 or 256 threads)
+  const uint32_t t = threadIdx.x, bd = blockDim.x;
+  BmEnt c[4], l{0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c[k] = t + (uint32_t)k * bd < 256u ? g_bm_cs[t + (uint32_t)k * bd] : BmEnt{0u, 0u};
+  if (t < 64u) l = g_bm_lg[t];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (t + (uint32_t)k * bd < 256u) s_bm_cs[t + (uint32_t)k * bd] = c[k];
+  if (t < 64u) s_bm_lg[t] = l;
+  for (uint32_t i = t + 4u * bd; i < 256u; i += bd) s_bm_cs[i] = g_bm_cs[i];  // (workgroups below 64 threads: not generated)
   __syncthreads();
 }
 #define GJX_BM_LG s_bm_lg

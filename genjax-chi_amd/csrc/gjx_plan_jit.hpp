@@ -637,6 +637,16 @@ struct Gen {
     if (R == 1) o << "  const int wv = threadIdx.x >> 6, pr = 0, tr = threadIdx.x;  // (block-uniform row: the cipher key stays scalar)\n";
     else o << "  const int wv = threadIdx.x >> 6, pr = threadIdx.x / " << lanes_per_row << ", tr = threadIdx.x % " << lanes_per_row << ";\n";
     o << "  (void)wv;\n";
+    // the kernel's scalar arguments in ONE round of loads (gjx_device.hpp: resample_args_anchor has the measurement)
+    o << "  asm volatile(\"\" :: \"s\"(n), \"s\"(score), \"s\"(logw), \"s\"(max_partials), \"s\"(row_e), \"s\"(row_s), \"s\"(bt.n_pass), \"s\"(bt.rows_per_pass), \"s\"(bt.pass_stride), \"s\"(bt.row_stride), \"s\"(ks.first), \"s\"(ks.parent.k0), \"s\"(ks.parent.k1), \"s\"(tail.tickets));\n";
+    {
+      bool seen[64] = {};  // ... and the value columns this plan stores (RunCols::out has 64)
+      for (int q = 0; q < n_sites; ++q)
+        if (sites[q].out_col >= 0 && sites[q].out_col < 64 && !seen[sites[q].out_col]) {
+          seen[sites[q].out_col] = true;
+          o << "  asm volatile(\"\" :: \"s\"(cols.out[" << sites[q].out_col << "]));\n";
+        }
+    }
     if (bm_lds()) o << "  bm_stage();\n";
     o << "  const uint64_t rows_all = (uint64_t)bt.n_pass * bt.rows_per_pass;\n";
     o << "  const bool wt_one_pass = bt.n_pass <= 1u; (void)wt_one_pass;\n";
