@@ -2103,22 +2103,23 @@ GJX_DEV void resample_body_impl(const ResampleArgs& A, Policy& P) {
       }
     } else if (lds_prefix) {
       __syncthreads();  // sh_pre / sh_d complete
-      // (monotone: the chunk of tiles that holds k_lo is the one whose start lies at or below j0 and whose end beyond it;
-      // only that thread walks its tiles.  Grouped route: k_lo lies in the range's first group.)
-      const uint64_t r0 = k0, r1_ = k0 + c_per < nrange ? k0 + c_per : nrange;  // the thread's tiles, relative to k_base
-      const int32_t c_lo = comb_tile(chunk_pre, scale, u0, n_out);
-      const int32_t c_hi = k_base + r1_ >= A.ntiles ? n_out : comb_tile(chunk_pre + chunk_mass, scale, u0, n_out);
-      if (r0 < nrange && (c_lo <= j0 || (grouped && r0 == 0 && k_base == 0)) && c_hi > j0) {
-        for (uint64_t k = r0; k < r1_; ++k) {
-          const int32_t hi_t = k_base + k + 1 >= A.ntiles ? n_out : comb_tile(sh_pre[k + 1], scale, u0, n_out);
-          if (hi_t > j0) {
-            atomicMin(&sh_klo, (uint32_t)k);
-            break;
-          }
-        }
-      }
-      __syncthreads();
-      k_lo = k_base + (sh_klo < nrange ? sh_klo : nrange - 1);
+      // r04: every WAVE finds k_lo on its own from the prefix in LDS — lane g looks at the END of the g-th group of 16 tiles
+      // (at most 64 groups), a ballot names the first group whose end lies beyond j0, 16 lanes look at that group's tiles,
+      // a second ballot names the tile.  Two LDS reads, two comb evaluations, no atomic and no barrier (r03: the one thread
+      // whose 4-tile chunk brackets j0 walked it, an LDS atomic and a barrier handed the result round: 1.1 us of the step).
+      // Monotone, so this is min{k in the range : teeth below the END of tile k > j0}, as before.
+      const uint32_t nr = (uint32_t)nrange;
+      const uint32_t ge = ((uint32_t)lane + 1u) * 16u < nr ? ((uint32_t)lane + 1u) * 16u : nr;  // one past group `lane`'s last tile
+      const bool in_g = (uint32_t)lane * 16u < nr;
+      const int32_t hi_g = !in_g ? 0 : (k_base + ge >= A.ntiles ? n_out : comb_tile(sh_pre[ge], scale, u0, n_out));
+      const uint64_t hit = __ballot(in_g && hi_g > j0);
+      const uint32_t g = hit ? (uint32_t)__builtin_ctzll(hit) : (nr - 1u) / 16u;
+      const uint32_t kk = g * 16u + ((uint32_t)lane & 15u);
+      const bool in_t = lane < 16 && kk < nr;
+      const int32_t hi_t = !in_t ? 0 : (k_base + kk + 1 >= A.ntiles ? n_out : comb_tile(sh_pre[kk + 1], scale, u0, n_out));
+      const uint64_t hit2 = __ballot(in_t && hi_t > j0);
+      const uint32_t last = g * 16u + 15u < nr ? g * 16u + 15u : nr - 1u;
+      k_lo = k_base + (hit2 ? g * 16u + (uint32_t)__builtin_ctzll(hit2) : last);
     } else if (A.ntiles <= (uint64_t)(kWave * 16)) {
       // a precomputed prefix of up to 1024 tiles (filter batches): ONE wave samples every 16th entry, then the 16 entries
       // of the bracket — two small loads instead of every thread reading its share of the whole prefix
