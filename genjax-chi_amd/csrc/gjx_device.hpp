@@ -1687,12 +1687,13 @@ GJX_DEV void select_filter_emit(EmitOut& em, const FilterBatch& fb, uint32_t f) 
   if (em.ess) em.ess += (uint64_t)f * fb.tiles;
 }
 
-// Exclusive block max-scan of one u32 per thread (identity 0).  `sh` needs 4 words.
-GJX_DEV uint32_t block_scan_umax_excl(uint32_t v, uint32_t* sh) {
+// Exclusive block max-scan of one u32 per thread (identity 0).  `sh` needs 4 words.  `sh_free`: the caller vouches that no
+// thread can still be reading `sh` from an earlier use (a barrier has passed since), so the guarding barrier is left out.
+GJX_DEV uint32_t block_scan_umax_excl(uint32_t v, uint32_t* sh, bool sh_free = false) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t incl = wave_scan_u32(v, 0u, [](uint32_t a, uint32_t b) { return b > a ? b : a; });
   uint32_t excl = dpp_u32<kDppWaveShr1, 0xf, 0xf>(0u, incl);  // lane i <- lane i-1, lane 0 keeps 0
-  __syncthreads();
+  if (!sh_free) __syncthreads();
   if (lane == 63) sh[w] = incl;
   __syncthreads();
 #pragma unroll
@@ -2231,7 +2232,7 @@ GJX_DEV void resample_body_impl(const ResampleArgs& A, Policy& P) {
         run_max = x > run_max ? x : run_max;
         v[r] = run_max;
       }
-      const uint32_t carry = block_scan_umax_excl(run_max, sh_u);
+      const uint32_t carry = block_scan_umax_excl(run_max, sh_u, true);  // (sh_u is used here only, once per launch)
 #pragma unroll
       for (int r = 0; r < kPer; ++r) {
         const uint32_t a = v[r] > carry ? v[r] : carry;
