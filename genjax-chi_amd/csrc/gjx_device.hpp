@@ -1621,7 +1621,7 @@ GJX_DEV void emit_tile(const float (&w)[kPer], const bool (&ok)[kPer], uint32_t*
     }
   }
   const uint64_t incl = wave_scan_incl_52(run);  // (four weights: below 2^34)
-  if (ESS) { a1 = wave_sum(a1); a2 = wave_sum(a2); }
+  if (ESS) { a1 = wave_sum_52(a1); a2 = wave_sum_52(a2); }  // (four reduced weights below 2^17.5: sums below 2^20 / 2^37 per lane)
   if (lane == 63) {
     em_q[wv] = incl;
     if (ESS) { em_q[kW + wv] = a1; em_q[2 * kW + wv] = a2; }
@@ -1985,7 +1985,7 @@ GJX_DEV void resample_body_impl(const ResampleArgs& A, Policy& P) {
     }
     const uint64_t incl = wave_scan_incl_52(chunk_mass);  // (at most 4 tile masses: below 2^44)
     tot = wave_last_u64(incl);
-    if (adaptive) { r1 = wave_sum(l1); r2 = wave_sum(l2); }
+    if (adaptive) { r1 = wave_sum_52(l1); r2 = wave_sum_52(l2); }  // (per lane: 4 tiles of r1 < 2^28, r2 < 2^45)
     chunk_pre = incl - chunk_mass;
     uint64_t run = chunk_pre;
 #pragma unroll
@@ -2014,7 +2014,7 @@ GJX_DEV void resample_body_impl(const ResampleArgs& A, Policy& P) {
       if (adaptive && !grouped) { l1 += shr64(ev1[i], dsh[i]); l2 += shr64(ev2[i], 2 * dsh[i]); }
     }
     const uint64_t incl = wave_scan_incl_52(chunk_mass);  // (at most 4 tile masses: below 2^44)
-    if (adaptive && !grouped) { l1 = wave_sum(l1); l2 = wave_sum(l2); }
+    if (adaptive && !grouped) { l1 = wave_sum_52(l1); l2 = wave_sum_52(l2); }  // (per lane: 4 tiles of r1 < 2^28, r2 < 2^45)
     if (grouped) __syncthreads();  // (sh_scan was read by the group level)
     if (lane == 63) {
       sh_scan[wv] = incl;
