@@ -1236,7 +1236,18 @@ GJX_DEV bool peer_wait_wave(const PeerMap& pm) {
 #else
 #define GJX_DBG_STOP(A, k, ...)
 #endif
+// r04: what differs between two runs of the same filter over the same buffers — a step's keys, its observation, the comb
+// offset, the model's scalar parameters — read from DEVICE memory instead of from the kernel's arguments, so that the T
+// launches of a whole run are one hipGraph that any later run replays after one small copy (gjx_hip.hip: RunGraphs).
+struct StepParams {
+  uint32_t k0, k1;   // the step's key
+  uint32_t y_bits;   // the step's observation (f32 bits / category)
+  uint32_t pad;
+  double u0;         // comb offset of the step's resampling
+};
 struct ResampleArgs {
+  const StepParams* sp = nullptr;       // nullable: this step's entry (then u0 and the policy's key / observation come from it)
+  const float* rp = nullptr;            // nullable: the run's model parameters (policy-defined layout)
   const uint32_t* qw = nullptr;         // [n] tile-anchored fixed-point weights of the SOURCE population
   const float* lw = nullptr;            // [n] source log-weights (adaptive filters: a kept step accumulates them)
   const TileRec* recs = nullptr;        // [ntiles] source records
@@ -1789,7 +1800,7 @@ GJX_DEV void resample_body_impl(const ResampleArgs& A, Policy& P) {
   TileSub* subs_out = A.subs_out;
   TileEss* ess_out = A.ess_out;
   const uint64_t* prefix = LDSP ? nullptr : A.prefix;
-  double u0 = A.u0;
+  double u0 = A.sp ? A.sp->u0 : A.u0;
   if (A.fb.n_filters > 1) {
     const uint32_t f = (uint32_t)(b / A.fb.tiles);
     b -= (uint64_t)f * A.fb.tiles;

@@ -602,8 +602,18 @@ template <class Policy>
 constexpr auto policy_peers(int) -> decltype(Policy::kPeers) { return Policy::kPeers; }
 template <class Policy>
 constexpr bool policy_peers(long) { return false; }
+template <class Policy>
+GJX_DEV auto policy_bind(Policy& P, const StepParams* sp, const float* rp, int) -> decltype(P.bind(sp, rp), void()) { P.bind(sp, rp); }
+template <class Policy>
+GJX_DEV void policy_bind(Policy&, const StepParams*, const float*, long) {}
 template <int IMPL, class Policy, bool ADAPTIVE = false>
 __global__ __launch_bounds__(kBlock) void k_resample(ResampleArgs A, Policy P) {
+  if (A.sp) {  // (a replayed run: the step's key / observation / parameters from device memory)
+    policy_bind(P, A.sp, A.rp, 0);
+    // the NEXT step's entry is pulled into this XCD's L2 now (every workgroup: all eight L2s): the next launch reads its key
+    // from cache instead of from memory in front of its first cipher round (the block has one entry to spare)
+    if (threadIdx.x == 0) (void)*reinterpret_cast<const volatile uint32_t*>(A.sp + 1);
+  }
   resample_body<IMPL, Policy, ADAPTIVE, policy_peers<Policy>(0)>(A, P);
 }
 
@@ -1111,6 +1121,12 @@ struct LgssmPolicy {
     step_key = k;
   }
   GJX_DEV void prefetch(int64_t jq) { smc_quad_normals<IMPL>(step_key, (uint64_t)jq >> 2, z); }
+  // (rp: kLgssmRunParams floats — x0_loc, x0_scale, a, q, rs, lognorm)
+  GJX_DEV void bind(const StepParams* sp, const float* rp) {
+    step_key.k0 = sp->k0; step_key.k1 = sp->k1;
+    y = u2f(sp->y_bits);
+    if (rp) { a = rp[2]; q = rp[3]; rs = rp[4]; lognorm = rp[5]; }
+  }
   GJX_DEV float source(uint32_t anc) const { return src_load<PEERS>(prev_state, anc, pd, tpr); }
   struct Out {
     float x;
@@ -1191,6 +1207,10 @@ struct HmmPolicy {
       f24[u] = (uint32_t)t >> 8;
     }
     oc = (int)threadIdx.x < K ? obs_logp[(size_t)threadIdx.x * K + y] : 0.0f;
+  }
+  GJX_DEV void bind(const StepParams* sp, const float*) {
+    step_key.k0 = sp->k0; step_key.k1 = sp->k1;
+    y = (int32_t)sp->y_bits;
   }
   GJX_DEV void stage() {
     __shared__ float ocol_tile[256];
@@ -1387,7 +1407,13 @@ template <int IMPL>
 __global__ __launch_bounds__(kBlock) void k_lgssm_init(FilterBatch fb, Key step_key, uint64_t first_slot,
                                                        uint64_t n_local, float x0_loc,
                                                        float x0_scale, float y, float rs,
-                                                       float lognorm, float* state_out, int32_t* anc_out, EmitOut em) {
+                                                       float lognorm, float* state_out, int32_t* anc_out, EmitOut em,
+                                                       const StepParams* sp, const float* rp) {
+  if (sp) {  // (a replayed run: RunGraphs)
+    step_key.k0 = sp->k0; step_key.k1 = sp->k1;
+    y = u2f(sp->y_bits);
+    if (rp) { x0_loc = rp[0]; x0_scale = rp[1]; rs = rp[4]; lognorm = rp[5]; }
+  }
   uint64_t ltile = blockIdx.x;
   if (fb.n_filters > 1) {  // several filters per launch: tile of filter f, its key, its outputs
     const uint32_t f = (uint32_t)(ltile / fb.tiles);
@@ -1422,7 +1448,11 @@ __global__ __launch_bounds__(kBlock) void k_hmm_init(FilterBatch fb, Key step_ke
                                                      uint64_t n_local, const uint32_t* trans_cdf,
                                                      const float* obs_logp, int32_t K,
                                                      int32_t init_state, int32_t y,
-                                                     int32_t* state_out, int32_t* anc_out, EmitOut em) {
+                                                     int32_t* state_out, int32_t* anc_out, EmitOut em, const StepParams* sp) {
+  if (sp) {  // (a replayed run: RunGraphs)
+    step_key.k0 = sp->k0; step_key.k1 = sp->k1;
+    y = (int32_t)sp->y_bits;
+  }
   uint64_t ltile = blockIdx.x;
   if (fb.n_filters > 1) {  // several filters per launch: tile of filter f, its key, its outputs
     const uint32_t f = (uint32_t)(ltile / fb.tiles);
@@ -2788,6 +2818,8 @@ int gjx_hmm_prepare(const gjx_hmm* mdl, uint32_t* trans_cdf, float* obs_logp, gj
 struct StepCtx {
   FilterBatch fb;
   int32_t* resampled_out = nullptr;  // this step's entry of cfg->resampled_out
+  const StepParams* sp = nullptr;    // a replayed run (RunGraphs): this step's entry of the device parameter block
+  const float* rp = nullptr;         // ... and the run's model parameters
 };
 
 // a population a step READS (t >= 1) / WRITES: the pointers its configuration needs
@@ -2834,6 +2866,7 @@ static int smc_resample_args(const gjx_smc_config* cfg, int t, const gjx_smc_pop
   ResampleArgs& A = *Ap;
   const bool ad = cfg_adaptive(cfg);
   A.fb = ctx.fb;
+  A.sp = ctx.sp; A.rp = ctx.rp;
   A.qw = prev->qw;
   A.lw = ad ? prev->logw : nullptr;
   A.recs = reinterpret_cast<const TileRec*>(prev->recs);
@@ -2915,7 +2948,7 @@ static int lgssm_step(const gjx_smc_config* cfg, const gjx_lgssm* mdl, int t, fl
   const unsigned ntl = (unsigned)ntiles_of(cfg->n_local), nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
   if (t == 0) {
     GJX_DISPATCH_IMPL(cfg->impl, k_lgssm_init,
-                      <<<ntl * nf, kBlock, 0, S(s)>>>(ctx.fb, sk, cfg->first_slot, cfg->n_local, mdl->x0_loc, mdl->x0_scale, y_t, rs, lognorm, (float*)out->state[0], ancestors_out, emit_out_of(cfg, out)));
+                      <<<ntl * nf, kBlock, 0, S(s)>>>(ctx.fb, sk, cfg->first_slot, cfg->n_local, mdl->x0_loc, mdl->x0_scale, y_t, rs, lognorm, (float*)out->state[0], ancestors_out, emit_out_of(cfg, out), ctx.sp, ctx.rp));
     return launch_status();
   }
   ResampleArgs A;
@@ -2953,7 +2986,7 @@ static int hmm_step(const gjx_smc_config* cfg, const gjx_hmm* mdl, int t, int32_
   const unsigned ntl = (unsigned)ntiles_of(cfg->n_local), nf = ctx.fb.n_filters > 1 ? ctx.fb.n_filters : 1u;
   if (t == 0) {
     GJX_DISPATCH_IMPL(cfg->impl, k_hmm_init,
-                      <<<ntl * nf, kBlock, 0, S(s)>>>(ctx.fb, sk, cfg->first_slot, cfg->n_local, trans_cdf, obs_logp, mdl->n_states, mdl->init_state, y_t, (int32_t*)out->state[0], ancestors_out, emit_out_of(cfg, out)));
+                      <<<ntl * nf, kBlock, 0, S(s)>>>(ctx.fb, sk, cfg->first_slot, cfg->n_local, trans_cdf, obs_logp, mdl->n_states, mdl->init_state, y_t, (int32_t*)out->state[0], ancestors_out, emit_out_of(cfg, out), ctx.sp));
     return launch_status();
   }
   ResampleArgs A;
@@ -3067,7 +3100,7 @@ struct RunCommon {
   FilterBatch fb;
 };
 static int run_common_init(const gjx_smc_config* cfg, Carver& cv, RunCommon& rc, int n_state, void* const* state_out,
-                           float* logw_out, gjx_stream s) {
+                           float* logw_out, gjx_stream s, bool clear_flags = true) {
   const uint64_t N = cfg->n_total;
   rc.nt = ntiles_of(N);
   rc.F = cfg->n_filters > 1 ? (unsigned)cfg->n_filters : 1u;
@@ -3105,7 +3138,7 @@ static int run_common_init(const gjx_smc_config* cfg, Carver& cv, RunCommon& rc,
     rc.fb.n_filters = rc.F; rc.fb.tiles = (uint32_t)rc.nt; rc.fb.stride = rc.stride; rc.fb.mq_stride = (uint64_t)T;
   }
   const size_t nmq = (size_t)rc.F * (size_t)T;
-  if (cfg->resampled_out && hipMemsetAsync(cfg->resampled_out, 0, nmq * sizeof(int32_t), S(s)) != hipSuccess) return GJX_ERR_LAUNCH;
+  if (clear_flags && cfg->resampled_out && hipMemsetAsync(cfg->resampled_out, 0, nmq * sizeof(int32_t), S(s)) != hipSuccess) return GJX_ERR_LAUNCH;
   return GJX_OK;
 }
 // the populations of step t: written (`out`) and read (`prev`), and the step's context
@@ -3529,46 +3562,203 @@ int gjx_smc_run_plan(const gjx_smc_config* cfg, gjx_smc_plan* plan, const float*
 
 }  // extern "C"
 
+// ---- r04: a whole run as ONE hipGraph, replayed -------------------------------------------------------------------------------
+// A one-filter run is T dependent launches of ~11 us: the ~0.6 us the command processor spends between two launches of a
+// stream are 5 % of it, and a graph's launches follow each other closer (tools/graph_smc.py: 11.5 -> 10.8 us per step).  What
+// differs between two runs over the same buffers — keys, observations, comb offsets, the model's scalars — is read from a
+// device block (StepParams), so ONE instantiated graph serves every later run of the shape: a run copies its parameters (a few
+// KB) and launches the graph.  The first run of a shape takes the plain stream of launches; the second captures (about a
+// millisecond, once); GJX_SMC_GRAPH=0 switches the whole thing off.  The CAPTURE runs on a stream of the entry's own (the
+// legacy default stream cannot be captured); the graph is LAUNCHED on the caller's stream — launched on a second stream and
+// ordered by events it ran a microsecond per step slower than the plain launches (measured: profiles/r04_ab/README.md).
+// Results: the same kernels with the same values.
+struct RunGraphInfo {
+  int kind = 0;              // 0 LGSSM, 1 HMM
+  uint64_t extra[4] = {};    // model facts that are baked into the launches
+  float rp[8] = {};          // the model's scalar parameters (device copy: ResampleArgs::rp)
+  int n_rp = 0;
+  const void* y_host = nullptr;  // T observations (f32 or i32: the bits travel)
+};
+struct RunGraphEntry {
+  uint64_t key[20] = {};
+  hipGraphExec_t exec = nullptr;
+  hipStream_t stream = nullptr;
+  void* dev = nullptr;
+  void* pin[2] = {nullptr, nullptr};       // pinned staging of the parameter block, used alternately
+  hipEvent_t pin_ev[2] = {nullptr, nullptr};  // ... recorded behind the copy that read it
+  int flip = 0;
+  size_t bytes = 0;
+  int seen = 0;
+  bool bad = false;
+  uint64_t stamp = 0;
+  void destroy() {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    for (int i = 0; i < 2; ++i) {
+      if (pin_ev[i]) (void)hipEventDestroy(pin_ev[i]);
+      if (pin[i]) (void)hipHostFree(pin[i]);
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+    if (dev) (void)hipFree(dev);
+    *this = RunGraphEntry{};
+  }
+};
+struct RunGraphs {
+  std::mutex mu;
+  std::vector<RunGraphEntry> entries;
+  uint64_t clock = 0;
+  uint64_t replays = 0, captures = 0;
+  static RunGraphs& get() {
+    static RunGraphs* g = new RunGraphs;  // (never destroyed: HIP objects must not be torn down after the runtime)
+    return *g;
+  }
+  static bool enabled() {
+    static const bool on = [] { const char* e = std::getenv("GJX_SMC_GRAPH"); return !(e && e[0] == '0'); }();
+    return on;
+  }
+};
+
 template <class Step>
 static int smc_run(const gjx_smc_config* cfg, const void* model, int32_t* out_e, uint64_t* out_q,
                    void* state_out, float* logw_out, int32_t* ancestors_out, void* ws,
-                   size_t ws_bytes, gjx_stream s, Step step) {
+                   size_t ws_bytes, gjx_stream s, Step step, const RunGraphInfo* gi = nullptr) {
   if (!cfg_ok(cfg) || cfg->first_slot != 0 || cfg->n_local != cfg->n_total || !model || !out_e ||
       !out_q || !state_out || !logw_out)
     return GJX_ERR_INVALID;
   const int T = cfg->n_steps;
-  Carver cv{(char*)ws, ws ? ws_bytes : 0};
-  RunCommon rc;
-  void* st[1] = {state_out};
-  int r = run_common_init(cfg, cv, rc, 1, st, logw_out, s);
-  for (int t = 0; t < T && !r; ++t) {
-    int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * rc.F * rc.stride : nullptr;
-    gjx_smc_pop out;
-    StepCtx ctx = run_step_ctx(cfg, rc, t, &out);
+  // the T launches of the run on stream `st`; sp / rp: the device parameter block of a replayed run (or null)
+  auto run_loop = [&](gjx_stream st, const StepParams* sp, const float* rp) -> int {
+    Carver cv{(char*)ws, ws ? ws_bytes : 0};
+    RunCommon rc;
+    void* stt[1] = {state_out};
+    int r = run_common_init(cfg, cv, rc, 1, stt, logw_out, st, sp == nullptr);  // (a replayed run clears the flags in front of the graph)
+    for (int t = 0; t < T && !r; ++t) {
+      int32_t* anc_t = ancestors_out ? ancestors_out + (size_t)t * rc.F * rc.stride : nullptr;
+      gjx_smc_pop out;
+      StepCtx ctx = run_step_ctx(cfg, rc, t, &out);
+      if (sp) { ctx.sp = sp + t; ctx.rp = rp; }
 #ifdef GJX_PROFILE_HOOKS
-    static const bool dbg_fixed = std::getenv("GJX_SMC_DEBUG_FIXED") != nullptr;  // profiling: every step reads step 0's population
-    if (dbg_fixed && t > 0) {
-      out = rc.pop[1];
-      if (!rc.adaptive) out.logw = nullptr;
-      r = step(t, &rc.pop[0], &out, out_e + (t - 1), out_q + (t - 1), anc_t, ctx);
-      continue;
-    }
+      static const bool dbg_fixed = std::getenv("GJX_SMC_DEBUG_FIXED") != nullptr;  // profiling: every step reads step 0's population
+      if (dbg_fixed && t > 0) {
+        out = rc.pop[1];
+        if (!rc.adaptive) out.logw = nullptr;
+        r = step(t, &rc.pop[0], &out, out_e + (t - 1), out_q + (t - 1), anc_t, ctx, st);
+        continue;
+      }
 #endif
-    r = step(t, &rc.pop[(t & 1) ^ 1], &out, t ? out_e + (t - 1) : nullptr, t ? out_q + (t - 1) : nullptr, anc_t, ctx);
+      r = step(t, &rc.pop[(t & 1) ^ 1], &out, t ? out_e + (t - 1) : nullptr, t ? out_q + (t - 1) : nullptr, anc_t, ctx, st);
+    }
+    if (r) return r;
+    return run_finish(cfg, rc, out_e, out_q, st);
+  };
+#ifndef GJX_PROFILE_HOOKS
+  if (gi && RunGraphs::enabled() && cfg->n_filters <= 1 && !cfg->peers && T >= 2) {
+    RunGraphs& G = RunGraphs::get();
+    std::lock_guard<std::mutex> lock(G.mu);
+    uint64_t key[20] = {(uint64_t)gi->kind, cfg->n_total, (uint64_t)T, (uint64_t)cfg->impl, (uint64_t)f2u(cfg->ess_threshold),
+                        (uint64_t)(uintptr_t)cfg->resampled_out, (uint64_t)(uintptr_t)out_e, (uint64_t)(uintptr_t)out_q,
+                        (uint64_t)(uintptr_t)state_out, (uint64_t)(uintptr_t)logw_out, (uint64_t)(uintptr_t)ancestors_out,
+                        (uint64_t)(uintptr_t)ws, (uint64_t)ws_bytes, gi->extra[0], gi->extra[1], gi->extra[2], gi->extra[3], 0, 0, 0};
+    RunGraphEntry* e = nullptr;
+    for (auto& x : G.entries)
+      if (memcmp(x.key, key, sizeof key) == 0) { e = &x; break; }
+    if (!e) {
+      if (G.entries.size() >= 16) {  // (evict the entry used longest ago)
+        size_t old = 0;
+        for (size_t i = 1; i < G.entries.size(); ++i)
+          if (G.entries[i].stamp < G.entries[old].stamp) old = i;
+        G.entries[old].destroy();
+        G.entries.erase(G.entries.begin() + (long)old);
+      }
+      G.entries.emplace_back();
+      e = &G.entries.back();
+      memcpy(e->key, key, sizeof key);
+    }
+    e->stamp = ++G.clock;
+    e->seen++;
+    if (!e->bad && (e->exec || e->seen >= 2)) {
+      // this run's parameters
+      const size_t n_rp = 8;
+      const size_t bytes = sizeof(StepParams) * ((size_t)T + 1) + sizeof(float) * n_rp;  // (one spare entry: the last step's prefetch)
+      bool ok = true;
+      if (!e->stream) {
+        ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess && hipMalloc(&e->dev, bytes) == hipSuccess;
+        for (int i = 0; ok && i < 2; ++i)
+          ok = hipHostMalloc(&e->pin[i], bytes, hipHostMallocDefault) == hipSuccess &&
+               hipEventCreateWithFlags(&e->pin_ev[i], hipEventDisableTiming) == hipSuccess &&
+               hipEventRecord(e->pin_ev[i], e->stream) == hipSuccess;
+        e->bytes = bytes;
+      }
+      // (the staging buffer of two runs ago: its copy has long run — the wait returns at once in steady state)
+      const int fl = e->flip;
+      e->flip ^= 1;
+      if (ok) ok = hipEventSynchronize(e->pin_ev[fl]) == hipSuccess;
+      if (!ok) { (void)hipGetLastError(); e->bad = true; return run_loop(s, nullptr, nullptr); }
+      char* host = reinterpret_cast<char*>(e->pin[fl]);
+      StepParams* hp = reinterpret_cast<StepParams*>(host);
+      for (int t = 0; t < T; ++t) {
+        hp[t].k0 = cfg->step_keys[2 * t]; hp[t].k1 = cfg->step_keys[2 * t + 1];
+        hp[t].y_bits = reinterpret_cast<const uint32_t*>(gi->y_host)[t];
+        hp[t].pad = 0;
+        hp[t].u0 = t ? comb_offset(cfg->impl, Key{cfg->resample_keys[2 * t], cfg->resample_keys[2 * t + 1]}, 0, 0) : 0.0;
+      }
+      memset(&hp[T], 0, sizeof(StepParams));
+      memcpy(host + sizeof(StepParams) * ((size_t)T + 1), gi->rp, sizeof(float) * n_rp);
+      const StepParams* dsp = reinterpret_cast<const StepParams*>(e->dev);
+      const float* drp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(e->dev) + sizeof(StepParams) * ((size_t)T + 1));
+      if (ok && !e->exec) {  // capture the run's launches once
+        hipGraph_t graph = nullptr;
+        ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        int r = ok ? run_loop(reinterpret_cast<gjx_stream>(e->stream), dsp, drp) : GJX_ERR_LAUNCH;
+        if (ok) ok = hipStreamEndCapture(e->stream, &graph) == hipSuccess && r == GJX_OK && graph;
+        if (ok) ok = hipGraphInstantiate(&e->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ok) G.captures++;
+      }
+      if (ok && e->exec) {
+        // the graph is LAUNCHED on the caller's stream (only its capture needed a stream of its own): the parameter copy, the
+        // flags' clearing and the graph are stream-ordered there like the launches they replace; nothing waits on the host
+        ok = hipMemcpyAsync(e->dev, host, bytes, hipMemcpyHostToDevice, S(s)) == hipSuccess &&
+             hipEventRecord(e->pin_ev[fl], S(s)) == hipSuccess &&
+             (!cfg->resampled_out || hipMemsetAsync(cfg->resampled_out, 0, (size_t)T * sizeof(int32_t), S(s)) == hipSuccess);
+        if (ok) ok = hipGraphLaunch(e->exec, S(s)) == hipSuccess;
+        if (ok) {
+          G.replays++;
+          return GJX_OK;
+        }
+      }
+      (void)hipGetLastError();
+      e->bad = true;  // (anything that went wrong: this shape takes the plain stream of launches from now on)
+    }
   }
-  if (r) return r;
-  return run_finish(cfg, rc, out_e, out_q, s);
+#endif
+  return run_loop(s, nullptr, nullptr);
 }
 
 extern "C" {
+
+int gjx_smc_run_graph_stats(uint64_t* captures, uint64_t* replays) {
+  RunGraphs& G = RunGraphs::get();
+  std::lock_guard<std::mutex> lock(G.mu);
+  if (captures) *captures = G.captures;
+  if (replays) *replays = G.replays;
+  return GJX_OK;
+}
 
 int gjx_smc_run_lgssm(const gjx_smc_config* cfg, const gjx_lgssm* model, const float* y_host,
                       int32_t* out_e, uint64_t* out_q, float* state_out, float* logw_out,
                       int32_t* ancestors_out, void* ws, size_t ws_bytes, gjx_stream s) {
   if (!y_host) return GJX_ERR_INVALID;
   auto step = [&](int t, const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* pe, uint64_t* pq, int32_t* anc,
-                  const StepCtx& ctx) { return lgssm_step(cfg, model, t, y_host[t], prev, out, pe, pq, anc, s, ctx); };
-  return smc_run(cfg, model, out_e, out_q, state_out, logw_out, ancestors_out, ws, ws_bytes, s, step);
+                  const StepCtx& ctx, gjx_stream st) { return lgssm_step(cfg, model, t, y_host[t], prev, out, pe, pq, anc, st, ctx); };
+  RunGraphInfo gi;
+  gi.kind = 0;
+  gi.y_host = y_host;
+  if (model) {
+    const float rp[6] = {model->x0_loc, model->x0_scale, model->a, model->q, normal_rs(model->r), normal_lognorm(model->r)};
+    memcpy(gi.rp, rp, sizeof rp);
+    gi.n_rp = 6;
+  }
+  return smc_run(cfg, model, out_e, out_q, state_out, logw_out, ancestors_out, ws, ws_bytes, s, step, model ? &gi : nullptr);
 }
 
 int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32_t* y_host,
@@ -3592,8 +3782,16 @@ int gjx_smc_run_hmm(const gjx_smc_config* cfg, const gjx_hmm* model, const int32
   if (rc) return rc;
   const size_t head_bytes = (size_t)(tail_p - (char*)ws);
   auto step = [&](int t, const gjx_smc_pop* prev, const gjx_smc_pop* out, int32_t* pe, uint64_t* pq, int32_t* anc,
-                  const StepCtx& ctx) { return hmm_step(cfg, model, t, y_host[t], prev, out, pe, pq, tcdf, ologp, anc, s, ctx); };
-  return smc_run(cfg, model, out_e, out_q, state_out, logw_out, ancestors_out, ws, head_bytes, s, step);
+                  const StepCtx& ctx, gjx_stream st) { return hmm_step(cfg, model, t, y_host[t], prev, out, pe, pq, tcdf, ologp, anc, st, ctx); };
+  // (a replayed run does not pass through hmm_step's per-step checks: every observation is checked here first; the tables
+  // were prepared above on the caller's stream, in front of the graph)
+  RunGraphInfo gi;
+  gi.kind = 1;
+  gi.y_host = y_host;
+  gi.extra[0] = (uint64_t)model->n_states; gi.extra[1] = (uint64_t)(uint32_t)model->init_state;
+  bool ys_ok = cfg && cfg->n_steps > 0;
+  for (int t = 0; ys_ok && t < cfg->n_steps; ++t) ys_ok = y_host[t] >= 0 && y_host[t] < model->n_states;
+  return smc_run(cfg, model, out_e, out_q, state_out, logw_out, ancestors_out, ws, head_bytes, s, step, ys_ok ? &gi : nullptr);
 }
 
 }  // extern "C"

@@ -330,6 +330,7 @@ PROTOTYPES = {
     "gjx_plan_prepare": (C.c_int, [_P, _KP]),
     "gjx_jit_stats": (C.c_int, [_P, _P, _P]),
     "gjx_jit_routes": (C.c_int, [_P, _P, _P, _P]),
+    "gjx_smc_run_graph_stats": (C.c_int, [_P, _P]),
     "gjx_jit_compile_source": (C.c_int, [C.c_char_p]),
     "gjx_importance_run": (
         C.c_int,
@@ -439,7 +440,7 @@ _NO_STATUS = {
 # unchanged entry points from minor to minor (0.7 -> 0.8: LseOut / SmcConfig / ShardedIO layouts, the Philox Normal spec), so a
 # library of another version is refused at load: with mismatched layouts it would read garbage pointers (silent corruption,
 # or a GPU fault on a shared box).
-ABI_VERSION = (0, 9)
+ABI_VERSION = (0, 10)
 
 
 class AbiVersionMismatch(RuntimeError):

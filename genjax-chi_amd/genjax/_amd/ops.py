@@ -239,6 +239,13 @@ class Ops:
         self.lib.call("gjx_jit_routes", *[C.byref(x) for x in v])
         return dict(child_compiles=v[0].value, inproc_compiles=v[1].value, child_failures=v[2].value, spawn_failures=v[3].value)
 
+    def smc_run_graph_stats(self) -> dict:
+        """gjx_smc_run_graph_stats: whole runs replayed as one hipGraph (captures = graphs instantiated, replays = runs that were
+        one graph launch)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.lib.call("gjx_smc_run_graph_stats", C.byref(a), C.byref(b))
+        return dict(captures=a.value, replays=b.value)
+
     def tickets(self) -> torch.Tensor:
         """The zeroed ticket words of fused log-sum-exp launches on the current stream (gjx_lse_out.tickets:
         every launch leaves them zero, launches sharing them must be stream-ordered)."""

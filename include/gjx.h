@@ -33,7 +33,7 @@ extern "C" {
 /* 0.8: the arithmetic spec of PHILOX Normal sites changed (table-driven Box-Muller): same words, same
  * pairing, normals that differ from 0.7's in the last bits.  Library and oracle of one version agree bit for bit. */
 #define GJX_VERSION_MAJOR 0
-#define GJX_VERSION_MINOR 9
+#define GJX_VERSION_MINOR 10
 
 typedef void* gjx_stream; /* hipStream_t; ignored by the oracle build */
 
@@ -301,6 +301,11 @@ int gjx_jit_stats(uint64_t* compiles, uint64_t* cached_modules, uint64_t* evicti
  * spawn_failures = helpers that could not be started.  Without the opt-in a spawn failure is GJX_ERR_JIT: the compiler
  * never moves into the caller's address space silently.  (The oracle reports zeros.) */
 int gjx_jit_routes(uint64_t* child_compiles, uint64_t* inproc_compiles, uint64_t* child_failures, uint64_t* spawn_failures);
+/* r04 (0.10): whole one-filter runs (gjx_smc_run_lgssm / gjx_smc_run_hmm) are REPLAYED as one hipGraph from the second run of a
+ * shape on (same sizes, generator, threshold and buffers; keys, observations and the model's scalar parameters are free: they
+ * travel in a device block).  captures = graphs instantiated, replays = runs that were one graph launch; each nullable.  The
+ * results are the plain run's bit for bit.  GJX_SMC_GRAPH=0 keeps every run a stream of launches.  (The oracle reports zeros.) */
+int gjx_smc_run_graph_stats(uint64_t* captures, uint64_t* replays);
 /* Compile a kernel source the way generated plan kernels are compiled (gfx950, the device header available as
  * "gjx_device.hpp"), needs no GPU: GJX_OK, or GJX_ERR_JIT if the compiler rejects the source OR DIES on it.  The
  * compiler runs in a child process (csrc/gjx_jitc.cpp): an AMDGPU-backend crash on generated source — it happened once —

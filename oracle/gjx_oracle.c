@@ -493,6 +493,12 @@ int gjx_jit_routes(uint64_t* child_compiles, uint64_t* inproc_compiles, uint64_t
   return GJX_OK;
 }
 
+int gjx_smc_run_graph_stats(uint64_t* captures, uint64_t* replays) {
+  if (captures) *captures = 0;
+  if (replays) *replays = 0;
+  return GJX_OK;
+}
+
 typedef struct { float f; int32_t i; int is_int; } site_val;
 
 static inline float sv_as_f32(const site_val* v) { return v->is_int ? (float)v->i : v->f; }

@@ -1333,3 +1333,40 @@ def test_random_plans_fuzz(hip_ops, seconds, seed, p_invalid):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), seconds, seed, p_invalid], capture_output=True,
                        text=True, timeout=400)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("kind", ["lgssm", "hmm"])
+@pytest.mark.parametrize("ess", [0.0, 0.5])
+def test_smc_runs_replayed_as_one_graph(hip_ops, oracle_ops, impl, kind, ess):
+    """r04: from the second run of a shape on, a whole one-filter run is ONE hipGraph launch whose keys, observations and
+    model scalars come from a device block (gjx_smc_run_graph_stats).  Five runs over the SAME buffers (the caching allocator
+    hands a released output back), each with another seed — and, for the LGSSM, another model and other observations: every
+    run equals the oracle's bit for bit, and at least three of them were replays."""
+    import gc
+
+    n, T = 50_000, 12
+    before = hip_ops.smc_run_graph_stats()
+    for rep in range(5):
+        seed = 31 + rep
+        if kind == "lgssm":
+            y = (W.lgssm_data(T) + np.float32(0.25 * rep)).astype(np.float32)
+            mdl = abi.Lgssm(0.1 * rep, 1.0 + 0.1 * rep, 0.9 - 0.05 * rep, 1.0, 0.8 + 0.1 * rep)
+            h = W.LgssmSMC(hip_ops, impl, seed, n, T, True, ess_threshold=ess, y=y, model=mdl)
+            o = W.LgssmSMC(oracle_ops, impl, seed, n, T, True, ess_threshold=ess, y=y, model=mdl)
+        else:
+            h = W.HmmSMC(hip_ops, impl, seed, n, T, n_states=16, want_ancestors=True, ess_threshold=ess)
+            o = W.HmmSMC(oracle_ops, impl, seed, n, T, n_states=16, want_ancestors=True, ess_threshold=ess)
+        hr, orr = h.result(h.run()), o.result(o.run())
+        torch.cuda.synchronize()
+        same(hr["ancestors"], orr["ancestors"], f"ancestors, run {rep}")
+        same(hr["out_e"], orr["out_e"]); same(hr["out_q"], orr["out_q"])
+        same(hr["state"], orr["state"]); same(hr["logw"], orr["logw"])
+        if ess > 0:
+            same(hr["resampled"], orr["resampled"], "resampling flags")
+        assert hr["log_z"] == orr["log_z"]
+        del hr, h
+        gc.collect()
+    after = hip_ops.smc_run_graph_stats()
+    if os.environ.get("GJX_SMC_GRAPH") != "0":
+        assert after["replays"] - before["replays"] >= 3, (before, after)
