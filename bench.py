@@ -666,6 +666,7 @@ def bench_smc(args, ops, kind, filters=1, min_s=0.08, variant=None, T=None):
     if variant:
         kw.update(variant)
     wl = W.LgssmSMC(ops, impl, 1, n, T, **kw) if kind == "smc_lgssm" else W.HmmSMC(ops, impl, 2, n, T, **kw)
+    g0 = ops.smc_run_graph_stats()  # (r04: from the second run of a shape on, a one-filter run is one replayed hipGraph)
     # warm-up long enough for the clock ramp (see bench_importance): ~50 ms of the same launches
     t0 = time.perf_counter()
     out = wl.run()
@@ -717,6 +718,11 @@ def bench_smc(args, ops, kind, filters=1, min_s=0.08, variant=None, T=None):
         res["resampling_steps"] = int(fl.sum())
         res["steps"] = T
     res.update(block_stats(blocks))
+    g1 = ops.smc_run_graph_stats()
+    res["config"]["launch_form"] = (
+        f"whole run replayed as ONE hipGraph ({g1['replays'] - g0['replays']} of this entry's runs; keys, observations and model "
+        "scalars from a device block; GJX_SMC_GRAPH=0: a stream of T launches)" if g1["replays"] > g0["replays"]
+        else "a stream of T launches per run")
     return res, r
 
 
