@@ -1887,8 +1887,14 @@ GJX_DEV void resample_body_impl(const ResampleArgs& A, Policy& P) {
         rs_[i] = 0;
         re_[i] = kRowEmpty;
       }
-      ev1[i] = adaptive && !grouped && in ? ess[k].r1 : 0;
-      ev2[i] = adaptive && !grouped && in ? ess[k].r2 : 0;
+      if (adaptive && !grouped && in) {  // (one 16-byte load per tile, like the record)
+        const uint4 er = *reinterpret_cast<const uint4*>(ess + k);
+        ev1[i] = ((uint64_t)er.y << 32) | er.x;
+        ev2[i] = ((uint64_t)er.w << 32) | er.z;
+      } else {
+        ev1[i] = 0;
+        ev2[i] = 0;
+      }
     }
   };
   // grouped route: thread g < ngroups holds group g's anchor and — speculatively — its masses for the shifts 0 and 1 of that
