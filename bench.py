@@ -1207,6 +1207,9 @@ def config_entry(e):
     for k in ("log_z", "log_z_exact", "timed_blocks"):
         if k in e:
             o[k] = e[k]
+    lf = (e.get("config") or {}).get("launch_form")
+    if lf:
+        o["launch_form"] = "replayed hipGraph" if lf.startswith("whole run replayed") else "stream of launches"
     return o
 
 
