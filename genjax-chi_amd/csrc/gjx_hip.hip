@@ -3592,6 +3592,8 @@ struct RunGraphEntry {
   bool bad = false;
   uint64_t stamp = 0;
   void destroy() {
+    // (eviction only — the 17th shape of a process: a replay of this graph may still be running on some stream)
+    if (exec) (void)hipDeviceSynchronize();
     if (exec) (void)hipGraphExecDestroy(exec);
     for (int i = 0; i < 2; ++i) {
       if (pin_ev[i]) (void)hipEventDestroy(pin_ev[i]);

@@ -1370,3 +1370,25 @@ def test_smc_runs_replayed_as_one_graph(hip_ops, oracle_ops, impl, kind, ess):
     after = hip_ops.smc_run_graph_stats()
     if os.environ.get("GJX_SMC_GRAPH") != "0":
         assert after["replays"] - before["replays"] >= 3, (before, after)
+
+
+def test_smc_run_graphs_are_evicted_and_rebuilt(hip_ops, oracle_ops):
+    """More shapes than the library keeps graphs for (16): every shape runs three times (plain, capture, replay), old graphs are
+    destroyed as new ones come, and a shape that comes back is captured again — each result equal to the oracle's."""
+    import gc
+
+    if os.environ.get("GJX_SMC_GRAPH") == "0":
+        pytest.skip("run graphs switched off")
+    before = hip_ops.smc_run_graph_stats()
+    shapes = [4096 + 1024 * i for i in range(20)] + [4096, 5120]
+    for n in shapes:
+        o = W.lgssm_smc(oracle_ops, 1, seed=3, n=n, T=4)
+        for _ in range(3):
+            h = W.lgssm_smc(hip_ops, 1, seed=3, n=n, T=4)
+            torch.cuda.synchronize()
+            same(h["state"], o["state"]); same(h["out_q"], o["out_q"])
+            assert h["log_z"] == o["log_z"]
+            del h
+            gc.collect()
+    after = hip_ops.smc_run_graph_stats()
+    assert after["captures"] - before["captures"] >= 20 and after["replays"] - before["replays"] >= 20, (before, after)
