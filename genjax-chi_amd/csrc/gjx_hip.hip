@@ -711,6 +711,60 @@ __global__ __launch_bounds__(kBlock) void k_scan_records(const TileRec* recs, co
   if (prefix) prefix += (uint64_t)blockIdx.x * prefix_words(ntiles);
   const uint64_t per = (ntiles + kBlock - 1) / kBlock;
   const uint64_t lo = threadIdx.x * per < ntiles ? threadIdx.x * per : ntiles, hi = lo + per < ntiles ? lo + per : ntiles;
+  if (per <= 4) {
+    // r04: up to 1024 tiles (every batch of filters: this launch stands between two step launches) — the thread's records
+    // are loaded ONCE, all loads in flight together; the three passes below then run on registers.  Same integers.
+    uint64_t sv[4], a1[4], a2[4];
+    int32_t ev[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint64_t k = lo + (uint64_t)i;
+      const bool in = k < hi;
+      const uint4 raw = in ? *reinterpret_cast<const uint4*>(recs + k) : make_uint4(0u, 0u, (uint32_t)kRowEmpty, 0u);
+      sv[i] = ((uint64_t)raw.y << 32) | raw.x;
+      ev[i] = (int32_t)raw.z;
+      const uint4 er = in && ess ? *reinterpret_cast<const uint4*>(ess + k) : make_uint4(0u, 0u, 0u, 0u);
+      a1[i] = ((uint64_t)er.y << 32) | er.x;
+      a2[i] = ((uint64_t)er.w << 32) | er.z;
+    }
+    float ef4 = (float)kRowEmpty;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ef4 = (float)ev[i] > ef4 ? (float)ev[i] : ef4;
+    const int32_t e4 = (int32_t)block_max(ef4, shf);
+    uint64_t m[4], local4 = 0, l14 = 0, l24 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = tile_shift(e4, ev[i]);
+      m[i] = shr64(sv[i], d);
+      local4 += m[i];
+      l14 += shr64(a1[i], d);
+      l24 += shr64(a2[i], 2 * d);
+    }
+    uint64_t total4;
+    uint64_t run4 = block_scan_excl(local4, sh64, total4);
+    if (ess) {
+      l14 = block_sum(l14, sh_e);
+      l24 = block_sum(l24, sh_e + kBlock / kWave);
+    }
+    if (prefix) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (lo + (uint64_t)i < hi) prefix[lo + i] = run4;
+        run4 += m[i];
+      }
+    }
+    if (threadIdx.x == 0) {
+      if (prefix) {
+        prefix[ntiles] = total4;
+        prefix[ntiles + 1] = (uint64_t)(int64_t)e4;
+        prefix[ntiles + 2] = l14;
+        prefix[ntiles + 3] = l24;
+      }
+      if (e_out) e_out[(uint64_t)blockIdx.x * mq_stride] = e4;
+      if (q_out) q_out[(uint64_t)blockIdx.x * mq_stride] = total4;
+    }
+    return;
+  }
   // anchors are integers of magnitude <= 2^24 (row_anchor): exact as floats, so the float block max serves
   float ef = (float)kRowEmpty;
   for (uint64_t k = lo; k < hi; ++k) {
